@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- M particle-updates/s of the WCSPH timestep hot path on MI355X.
+
+A "step" is one full predictor-corrector time step (forces x2, Euler x2, dt reduction, and the
+neighbour-list rebuild every 10th step) over the synthetic DamBreak3D box with
+all inputs resident in HBM.  Metric = 1e-6 * sum over timed steps of internal particles / wall
+seconds = GPUSPH's MIPPS (src/timing.h:136-164).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P]
+
+For N > 1 the driver launches one rank per GPU (torch.distributed.run); the domain is slab-split
+(strong scaling: the total particle count is fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+DEFAULT_PARTICLES = 32_000_000     # BASELINE.json configs[3]: DamBreak3D 32M (fits one MI355X)
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(target_particles=400_000, steps=2):
+    """Oracle (OpenMP port of the reference algorithm) on a bounded sample of the same workload."""
+    import oracle_lib as ol
+    from gpusph_amd.problem import DamBreak3D
+    dp = DamBreak3D.deltap_for(target_particles)
+    prob = DamBreak3D(dp, obstacle=True)
+    sim = ol.OracleSim(prob)
+    sim.step()                       # includes the neighbour build (iteration 0)
+    t0 = time.perf_counter()
+    done = 0
+    for _ in range(steps):
+        sim.step()
+        done += sim.n
+    t1 = time.perf_counter()
+    # amortise the rebuild like the GPU run does (1 rebuild per 10 steps)
+    t_r0 = time.perf_counter()
+    sim.iterations = 10
+    sim.build_neibs()
+    t_rebuild = time.perf_counter() - t_r0
+    per_step = (t1 - t0) / steps + t_rebuild / 10.0
+    return {
+        "value": round(1e-6 * sim.n / per_step, 4), "unit": "M particle-updates/s",
+        "cores": int(ol.lib().orc_num_threads()), "kind": "port",
+        "sample": "DamBreak3D %d particles (dp=%.5f), %d steps + 1 rebuild amortised over 10 steps, "
+                  "oracle/sph_oracle.c -O2 -fopenmp" % (sim.n, dp, steps),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--particles", type=float, default=DEFAULT_PARTICLES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-obstacle", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from gpusph_amd.problem import DamBreak3D
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    dp = DamBreak3D.deltap_for(args.particles, obstacle=not args.no_obstacle)
+    lin = "xzy" if world > 1 else "yzx"   # multi-GPU: split along Y like DamBreak3D::fillDeviceMap, COORD3 = y
+    prob = DamBreak3D(dp, obstacle=not args.no_obstacle, linearization=lin)
+    n_total = prob.num_particles
+
+    if world > 1:
+        from gpusph_amd.multigpu import MultiGpuEngine
+        eng = MultiGpuEngine(prob, device=device, rank=rank, world=world, track_particle_count=True)
+    else:
+        from gpusph_amd.engine import TimestepEngine
+        eng = TimestepEngine(prob, device=device, track_particle_count=False)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step()
+    info = eng.neibs_info()                 # also checks for neighbour-list overflow
+    eng.profile_forces = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ev = eng.profile_forces
+    eng.profile_forces = None
+    forces_ms = [a.elapsed_time(b) for a, b in ev]
+    n_internal = eng.internal_particles() if hasattr(eng, "internal_particles") else eng.n
+    interactions = info.numInteractions
+    if dist is not None:
+        c = torch.tensor([n_internal, interactions], dtype=torch.float64, device=device)
+        dist.all_reduce(c)
+        n_sum, interactions_sum = int(c[0].item()), int(c[1].item())
+    else:
+        n_sum, interactions_sum = n_internal, interactions
+
+    if rank == 0:
+        updates = n_sum * args.steps
+        value = 1e-6 * updates / elapsed
+        nbar = interactions / max(n_internal, 1)
+        # algorithmic bytes of one forces launch on this rank: (64 + 2*Nbar) B per particle
+        # (own pos+vel+info+hash 44, list 2(Nbar+2), forces write 16) -- BASELINE.md section 3
+        bytes_per_launch = n_internal * (64.0 + 2.0 * nbar)
+        avg_ms = float(np.mean(forces_ms)) if forces_ms else float("nan")
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if forces_ms else float("nan")
+        out = {
+            "metric": "M particle-updates/sec, DamBreak3D", "value": round(value, 2),
+            "unit": "M particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DamBreak3D %d particles (dp=%.6f), Wendland, WCSPH + artificial viscosity, "
+                                   "Colagrossi diffusion, DYN boundary, neib rebuild every 10 steps" % (n_total, dp),
+                       "particles": n_total, "parallelism": "slab%d" % world if world > 1 else "single",
+                       "mean_neibs": round(nbar, 2)},
+            "roofline": {"bound": "hbm", "kernel": "forces_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "launch_ms": round(avg_ms, 4), "bytes_per_launch": int(bytes_per_launch)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

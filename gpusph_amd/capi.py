@@ -1,0 +1,137 @@
+"""ctypes binding of the C ABI in include/sphx.h (libsphx.so).
+
+There is NO fallback: if the HIP library is missing or a call fails, this raises.  The oracle
+under oracle/ is test infrastructure and is never imported from here.
+"""
+import ctypes as C
+import os
+from .params import SphxParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsphx.so")
+
+SPHX_OK, SPHX_ERR_INVALID, SPHX_ERR_RUNTIME, SPHX_ERR_UNSUPPORTED = 0, -1, -2, -3
+
+
+class SphxError(RuntimeError):
+    """std::runtime_error of CUDA_SAFE_CALL / KERNEL_CHECK_ERROR (src/cuda/cuda_call.h:57-85)."""
+
+
+class SphxInvalidArgument(ValueError):
+    """std::invalid_argument of the reference engines (e.g. src/cuda/buildneibs.cu:444-455)."""
+
+
+class SphxUnsupported(NotImplementedError):
+    """option combination not built into libsphx."""
+
+
+class NeibsInfo(C.Structure):
+    _fields_ = [("numInteractions", C.c_int32), ("maxFluidBoundaryNeibs", C.c_int32),
+                ("maxVertexNeibs", C.c_int32), ("hasTooManyNeibs", C.c_int32),
+                ("hasMaxNeibs", C.c_int32 * 3)]
+
+
+_vp, _u32, _f, _i = C.c_void_p, C.c_uint32, C.c_float, C.c_int
+
+# name -> (restype, argtypes); every symbol declared in include/sphx.h
+SIGNATURES = {
+    "sphx_last_error": (C.c_char_p, []),
+    "sphx_version": (C.c_char_p, []),
+    "sphx_create": (_i, [C.POINTER(_vp), _i]),
+    "sphx_destroy": (None, [_vp]),
+    "sphx_reserve": (_i, [_vp, _u32]),
+    "sphx_set_constants": (_i, [_vp, C.POINTER(SphxParams)]),
+    "sphx_get_params": (_i, [_vp, C.POINTER(SphxParams)]),
+    "sphx_set_gravity": (_i, [_vp, C.POINTER(_f)]),
+    "sphx_set_rb_cg": (_i, [_vp, _vp, _vp, _i]),
+    "sphx_set_rb_start": (_i, [_vp, _vp, _i]),
+    "sphx_set_rb_motion": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
+    "sphx_calc_hash": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "sphx_fix_hash": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
+    "sphx_sort": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
+    "sphx_reorder": (_i, [_vp] + [_vp] * 10 + [_u32, _vp, _vp]),
+    "sphx_build_neibs": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _u32, _f, _f, _vp]),
+    "sphx_neibs_resetinfo": (_i, [_vp, _vp]),
+    "sphx_neibs_getinfo": (_i, [_vp, C.POINTER(NeibsInfo), _vp]),
+    "sphx_forces_fmax_elements": (_u32, [_u32]),
+    "sphx_forces_fmax_temp_elements": (_u32, [_u32]),
+    "sphx_forces_round_particles": (_u32, [_u32]),
+    "sphx_forces_basicstep": (_i, [_vp] + [_vp] * 13 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _i,
+                                                       C.POINTER(_u32), _vp]),
+    "sphx_forces_dtreduce": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _u32, C.POINTER(_f), _vp]),
+    "sphx_forces_dtreduce_device": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _u32, _vp, _i, _vp]),
+    "sphx_reduce_rb_forces": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "sphx_calc_visc": (_i, [_vp] + [_vp] * 10 + [_u32, _u32, _f, _f, _f, _vp]),
+    "sphx_euler_basicstep": (_i, [_vp] + [_vp] * 8 + [_u32, _u32, _f, _vp, _f, _i, _f, _f, _f, _i, _vp]),
+    "sphx_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """dlopen libsphx.so and type every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise SphxError("libsphx.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(there is no CPU fallback for the product path)" % p)
+    lib = C.CDLL(p)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == SPHX_OK:
+        return
+    msg = load().sphx_last_error().decode("utf-8", "replace")
+    if rc == SPHX_ERR_INVALID:
+        raise SphxInvalidArgument(msg)
+    if rc == SPHX_ERR_UNSUPPORTED:
+        raise SphxUnsupported(msg)
+    raise SphxError(msg)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None / int passthrough)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+class Context:
+    """One per device: the per-device constant state of the reference engines."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        check(self.lib.sphx_create(C.byref(h), int(device)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sphx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_constants(self, params: SphxParams):
+        check(self.lib.sphx_set_constants(self.handle, C.byref(params)))
+        self.params = params
+
+    def reserve(self, max_particles):
+        check(self.lib.sphx_reserve(self.handle, int(max_particles)))

@@ -1,0 +1,110 @@
+// euler.hip -- predictor/corrector Euler update for gfx950.
+// Replaces CUDAPredCorrEngine::basicstep (GPUSPH src/cuda/euler.cu:329-366) and eulerDevice
+// (src/cuda/euler_kernel.def:396-538).  Pure streaming: 60 B read + 32 B written per particle.
+// The adaptive dt can be read from a device scalar (written by dt_final_kernel) so the
+// corrector never waits for a host round trip.
+// Numerics: -ffp-contract=off, the a + b*c updates are explicit fmaf (DESIGN.md "Numerics");
+// bit-identical to oracle/sph_oracle.c.
+#include "sphx_internal.h"
+
+#define BLOCK_EULER 256
+
+struct EulerArgs {
+	float4 *newPos, *newVel;
+	const float4 *oldPos, *oldVel, *forces;
+	const particleinfo *info;
+	const uint32_t *hash;
+	const RbParams *rb;
+	const float *d_dt;
+	float dt, dt_scale;
+	uint32_t numParticles;
+};
+
+template<int STEP>
+__global__ void __launch_bounds__(BLOCK_EULER)
+euler_kernel(DevParams p, EulerArgs a)
+{
+	const uint32_t index = blockIdx.x*BLOCK_EULER + threadIdx.x;
+	if (index >= a.numParticles) return;
+
+	const float dt = a.d_dt ? a.d_dt[0]*a.dt_scale : a.dt;
+
+	const particleinfo info = a.info[index];
+	const uint32_t ptype = PART_TYPE(info);
+	const float4 force = a.forces[index];
+	float4 pos = a.oldPos[index];
+	float4 vel = a.oldVel[index];
+
+	const bool integrateBoundary = (p.boundarytype == SPHX_DYN_BOUNDARY || p.boundarytype == SPHX_SA_BOUNDARY);
+	if (is_active_w(pos.w) && !(ptype == PT_BOUNDARY && !integrateBoundary && !IS_MOVING(info))) {
+		// standard_corrected_velocity (euler_kernel.def:147-169)
+		float vcx = vel.x, vcy = vel.y, vcz = vel.z;
+		if (STEP == 2) {
+			const float hdt = dt/2;
+			vcx = fmaf(force.x, hdt, vcx);
+			vcy = fmaf(force.y, hdt, vcy);
+			vcz = fmaf(force.z, hdt, vcz);
+		}
+		if (ptype == PT_FLUID) {
+			pos.x = fmaf(vcx, dt, pos.x);
+			pos.y = fmaf(vcy, dt, pos.y);
+			pos.z = fmaf(vcz, dt, pos.z);
+			vel.w = fmaf(dt, force.w, vel.w);   // continuity_integration :203-209
+			vel.x = fmaf(dt, force.x, vel.x);
+			vel.y = fmaf(dt, force.y, vel.y);
+			vel.z = fmaf(dt, force.z, vel.z);
+		} else if (ptype == PT_BOUNDARY || ptype == PT_VERTEX) {
+			if (IS_MOVING(info)) { // rigid motion, euler_kernel.def:470-497, applyrot euler_kernel.cu:67-74
+				const uint32_t obj = OBJECT_NUM(info);
+				const int3 gp = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+				const float rx = (gp.x - a.rb->cgGridPos[obj][0])*p.cs[0] + (pos.x - a.rb->cgPos[obj][0]);
+				const float ry = (gp.y - a.rb->cgGridPos[obj][1])*p.cs[1] + (pos.y - a.rb->cgPos[obj][1]);
+				const float rz = (gp.z - a.rb->cgGridPos[obj][2])*p.cs[2] + (pos.z - a.rb->cgPos[obj][2]);
+				const float *rot = a.rb->steprot[obj];
+				pos.x += (rot[0] - 1.0f)*rx + rot[1]*ry + rot[2]*rz;
+				pos.y += rot[3]*rx + (rot[4] - 1.0f)*ry + rot[5]*rz;
+				pos.z += rot[6]*rx + rot[7]*ry + (rot[8] - 1.0f)*rz;
+				pos.x += a.rb->trans[obj][0];
+				pos.y += a.rb->trans[obj][1];
+				pos.z += a.rb->trans[obj][2];
+				const float *w = a.rb->angularvel[obj];
+				vel.x = a.rb->linearvel[obj][0] + (w[1]*rz - w[2]*ry);
+				vel.y = a.rb->linearvel[obj][1] + (w[2]*rx - w[0]*rz);
+				vel.z = a.rb->linearvel[obj][2] + (w[0]*ry - w[1]*rx);
+			}
+			if (p.boundarytype == SPHX_DYN_BOUNDARY)
+				vel.w = fmaf(dt, force.w, vel.w);
+		}
+	}
+	a.newPos[index] = pos;
+	a.newVel[index] = vel;
+}
+
+extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
+	const void *oldPos, const void *oldVel, const void *info, const uint32_t *hash,
+	const void *forces, const void *xsph,
+	uint32_t numParticles, uint32_t particleRangeEnd,
+	float dt, const float *d_dt, float dt_scale, int step, float t,
+	float slength, float influenceradius, int run_mode, void *stream)
+{
+	(void)t; (void)slength; (void)influenceradius; (void)xsph; (void)numParticles;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_euler_basicstep: constants not set");
+	SPHX_REQUIRE(newPos && newVel && oldPos && oldVel && info && hash && forces, "sphx_euler_basicstep: missing buffer");
+	if (run_mode != SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_euler_basicstep: REPACK run mode is not built");
+	if (step != 1 && step != 2)
+		return sphx_set_error(SPHX_ERR_INVALID, "unsupported predcorr timestep"); // src/cuda/euler.cu:361
+	if (!particleRangeEnd) return SPHX_OK;
+	EulerArgs a;
+	a.newPos = (float4*)newPos; a.newVel = (float4*)newVel;
+	a.oldPos = (const float4*)oldPos; a.oldVel = (const float4*)oldVel; a.forces = (const float4*)forces;
+	a.info = (const particleinfo*)info; a.hash = hash; a.rb = ctx->rb_dev;
+	a.d_dt = d_dt; a.dt = dt; a.dt_scale = dt_scale; a.numParticles = particleRangeEnd;
+	const dim3 grid(div_up_u(particleRangeEnd, BLOCK_EULER));
+	if (step == 1)
+		euler_kernel<1><<<grid, BLOCK_EULER, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	else
+		euler_kernel<2><<<grid, BLOCK_EULER, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("euler_kernel");
+	return SPHX_OK;
+}

@@ -1,0 +1,619 @@
+// forces.hip -- forces engine for gfx950: fused pair summation (fluid<-fluid, fluid<-boundary,
+// boundary<-fluid) + finalize + CFL block maxima in ONE launch, CFL reduction -> dt on the
+// device, rigid-body force totals, SPS stress tensor.
+// Replaces CUDAForcesEngine / CUDAViscEngine (GPUSPH src/cuda/forces.cu:252-1006,
+// src/cuda/forces_kernel.def:3914-4150, src/cuda/visc_kernel.cu:759-811).
+//
+// Why one launch: the reference launches forcesDevice 3x + finalizeforcesDevice, each doing a
+// read-modify-write of forces[] (16 B x 2 x 4 per particle) and re-reading pos/vel/info/hash.
+// The neighbour list is typed (fluid slots grow up from 0, boundary slots down from
+// neibboundpos), so a single thread can walk both sections in the reference's order and keep the
+// accumulator in registers: forces[] is written once, own data is read once.
+//
+// Numerics: accumulation order per particle is the reference's (list order, fluid section then
+// boundary section), so results differ from oracle/sph_oracle.c only through the fast
+// transcendental path (v_log_f32/v_exp_f32 for the Tait EOS instead of powf, v_rcp_f32,
+// v_sqrt_f32), the same class of deviation the reference's own __powf has.
+#include "sphx_internal.h"
+
+struct ForcesArgs {
+	float4 *forces;
+	float  *cfl;
+	float4 *rbforces;
+	float4 *rbtorques;
+	const float4 *pos;
+	const float4 *vel;
+	const particleinfo *info;
+	const uint32_t *hash;
+	const uint32_t *cellStart;
+	const neibdata *neibsList;
+	const float2 *tau0, *tau1, *tau2;
+	const RbParams *rb;
+	uint32_t fromParticle, toParticle, cflOffset;
+	int compute_object_forces;
+};
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// Tait EOS pieces sharing one log2 (P: src/cuda/phys_core.cu:99-104, soundSpeed :130-135)
+struct Eos { float P, sspeed, rho, p_precalc; };
+__device__ __forceinline__ Eos eos(const DevParams &p, float rho_tilde, uint32_t fl)
+{
+	Eos e;
+	const float ratio = rho_tilde + 1.0f;
+	const float L = fast_log2(ratio);
+	e.P = p.bcoeff[fl]*(fast_exp2(p.gammacoeff[fl]*L) - 1.0f);
+	e.sspeed = p.sscoeff[fl]*fast_exp2(p.sspowercoeff[fl]*L);
+	e.rho = ratio*p.rho0[fl];
+	e.p_precalc = e.P*fast_rcp(e.rho*e.rho); // precalc_pressure SPH_F1: P/rho^2 (forces_kernel.def:419-429)
+	return e;
+}
+
+// F<kerneltype>(r, h): src/cuda/sph_core.cu:146-191
+template<int KERNEL>
+__device__ __forceinline__ float kernel_F(const DevParams &p, float r, float inv_h)
+{
+	if (KERNEL == SPHX_WENDLAND) {
+		const float qm2 = r*inv_h - 2.0f;
+		return qm2*qm2*qm2*p.fcoeff;
+	} else if (KERNEL == SPHX_CUBICSPLINE) {
+		const float R = r*inv_h;
+		const float val = (R < 1.0f) ? (-4.0f + 3.0f*R)*inv_h : -(-2.0f + R)*(-2.0f + R)*fast_rcp(r);
+		return val*p.fcoeff;
+	} else if (KERNEL == SPHX_QUADRATIC) {
+		const float R = r*inv_h;
+		return (-2.0f + R)*fast_rcp(r)*p.fcoeff;
+	} else {
+		const float R = r*inv_h;
+		return -fast_exp2(-R*R*1.44269504088896340736f)*p.fcoeff;
+	}
+}
+
+struct Self {
+	float4 pos, vel;
+	int3 gridPos;
+	Eos e;
+	uint32_t fl;
+	float tau[6];
+};
+
+// walk one typed section of the neighbour list (neiblist_iterator_simple,
+// src/cuda/neibs_iteration.cuh:165-205; getNeibIndex src/cuda/cellgrid.cuh:200-228)
+template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID, int NPTYPE, bool MOMENTUM, bool DIFFUSE>
+__device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArgs &a, uint32_t index,
+	const Self &s, float inv_h, float4 &force)
+{
+	const size_t stride = p.stride;
+	size_t loc = (NPTYPE == PT_FLUID) ? (size_t)index : (size_t)p.neibboundpos*stride + index;
+	float pcx = 0.0f, pcy = 0.0f, pcz = 0.0f;
+	uint32_t cell_base = 0;
+
+	for (;;) {
+		uint32_t nd = a.neibsList[loc];
+		if (nd == NEIBS_END) break;
+		loc = (NPTYPE == PT_FLUID) ? loc + stride : loc - stride;
+
+		if (nd >= CELLNUM_ENCODED) {
+			const int c = (int)(nd >> CELLNUM_SHIFT) - 1;
+			nd &= NEIBINDEX_MASK;
+			const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
+			const int ox = cx - 1, oy = cy - 1, oz = cz - 1;
+			pcx = fmaf(-(float)ox, p.cs[0], s.pos.x);
+			pcy = fmaf(-(float)oy, p.cs[1], s.pos.y);
+			pcz = fmaf(-(float)oz, p.cs[2], s.pos.z);
+			cell_base = a.cellStart[grid_hash_periodic(p, s.gridPos.x + ox, s.gridPos.y + oy, s.gridPos.z + oz)];
+		}
+		const uint32_t j = cell_base + nd;
+
+		const float4 npos = a.pos[j];
+		const float4 nvel = a.vel[j];
+		const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
+		const float nmass = npos.w;
+		if (!is_active_w(nmass)) continue;
+		const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
+		const float r = fast_sqrt(r2);
+		if (r >= p.influenceradius) continue;
+
+		uint32_t nfl = 0;
+		if (MULTIFLUID) nfl = FLUID_NUM(a.info[j]);
+
+		const float vx = s.vel.x - nvel.x, vy = s.vel.y - nvel.y, vz = s.vel.z - nvel.z;
+		const float vel_dot_pos = fmaf(vz, rz, fmaf(vy, ry, vx*rx));
+		const float f = kernel_F<KERNEL>(p, r, inv_h);
+		const Eos ne = eos(p, nvel.w, nfl);
+		const float mf = nmass*f;
+
+		// mass_continuity_div_vel_term (forces_kernel.def:2140-2151)
+		float DrDt = mf*vel_dot_pos;
+		if (COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
+			if (!MULTIFLUID || nfl == s.fl) {
+				const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
+				if (!(fabsf(s.e.P - ne.P) < fabsf(gdotr*s.e.rho)))
+					DrDt -= p.densityDiffCoeff*p.sscoeff[s.fl]*(ne.rho*fast_rcp(s.e.rho) - 1.0f)*mf;
+			}
+		}
+		force.w += DrDt;
+
+		if (MOMENTUM) {
+			// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
+			float k = -(s.e.p_precalc + ne.p_precalc)*mf;
+			if (TURB == SPHX_ARTIFICIAL) {
+				// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764)
+				if (vel_dot_pos < 0.0f) {
+					const float visc = vel_dot_pos*p.slength*p.artvisccoeff*(s.e.sspeed + ne.sspeed)*
+						fast_rcp((r2 + p.epsartvisc)*(s.e.rho + ne.rho));
+					k = fmaf(visc, mf, k);
+				}
+			}
+			float ax = k*rx, ay = k*ry, az = k*rz;
+			if (TURB == SPHX_SPS) { // forces_kernel.def:2777-2798
+				const float2 t0 = a.tau0[j], t1 = a.tau1[j], t2 = a.tau2[j];
+				const float xx = s.tau[0] + t0.x, xy = s.tau[1] + t0.y, xz = s.tau[2] + t1.x;
+				const float yy = s.tau[3] + t1.y, yz = s.tau[4] + t2.x, zz = s.tau[5] + t2.y;
+				ax = fmaf(mf, fmaf(xz, rz, fmaf(xy, ry, xx*rx)), ax);
+				ay = fmaf(mf, fmaf(yz, rz, fmaf(yy, ry, xy*rx)), ay);
+				az = fmaf(mf, fmaf(zz, rz, fmaf(yz, ry, xz*rx)), az);
+			}
+			force.x += ax; force.y += ay; force.z += az;
+		}
+	}
+}
+
+template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID>
+__global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
+forces_kernel(DevParams p, ForcesArgs a)
+{
+	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
+	float cfl_term = 0.0f;
+
+	do {
+		if (index >= a.toParticle) break;
+		const particleinfo info = a.info[index];
+		const uint32_t ptype = PART_TYPE(info);
+		const float4 pos = a.pos[index];
+		if (!is_active_w(pos.w)) break;
+
+		Self s;
+		s.pos = pos;
+		s.vel = a.vel[index];
+		s.gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		s.fl = MULTIFLUID ? FLUID_NUM(info) : 0u;
+		s.e = eos(p, s.vel.w, s.fl);
+		if (TURB == SPHX_SPS) {
+			const float2 t0 = a.tau0[index], t1 = a.tau1[index], t2 = a.tau2[index];
+			s.tau[0] = t0.x; s.tau[1] = t0.y; s.tau[2] = t1.x; s.tau[3] = t1.y; s.tau[4] = t2.x; s.tau[5] = t2.y;
+		}
+		const float inv_h = fast_rcp(p.slength);
+		const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
+
+		// the caller clobbers FORCES to 0 before basicstep (src/GPUWorker.cc:1949): the accumulator
+		// starts from that value without re-reading it
+		float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+		if (ptype == PT_FLUID) {
+			// fluid <- fluid : compute_all_pp_interaction (forces_kernel.def:3565-3610)
+			walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, true, true>(p, a, index, s, inv_h, force);
+			// fluid <- boundary : same interaction for DYN_BOUNDARY (forces_kernel.def:3717-3726),
+			// no density diffusion from boundary neighbours (:1596-1606)
+			if (dyn)
+				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_BOUNDARY, true, false>(p, a, index, s, inv_h, force);
+		} else if (ptype == PT_BOUNDARY && (dyn || a.compute_object_forces)) {
+			// boundary <- fluid (forces_kernel.def:3650-3679): DYN always evolves density; momentum
+			// only for particles of bodies with force feedback
+			if (dyn) {
+				if (HAS_COMPUTE_FORCE(info))
+					walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, true, true>(p, a, index, s, inv_h, force);
+				else
+					walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, false, true>(p, a, index, s, inv_h, force);
+			}
+		}
+
+		// ---- finalizeforcesDevice (forces_kernel.def:4032-4150) ----
+		force.w /= p.rho0[s.fl]; // forces_fixup :3212-3218
+		if (ptype == PT_FLUID) {
+			force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
+			// dyndt_forces_shared_data::store (:3436-3457)
+			const float amag = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
+			cfl_term = fmaxf(amag, s.e.sspeed*s.e.sspeed/p.slength);
+		}
+		if (HAS_COMPUTE_FORCE(info) && ptype != PT_VERTEX && a.rbforces) { // :4121-4142
+			force.x *= pos.w; force.y *= pos.w; force.z *= pos.w;
+			const uint32_t obj = OBJECT_NUM(info);
+			const uint32_t rbindex = (uint32_t)((int)info_id(info) + a.rb->rbstart[obj]);
+			a.rbforces[rbindex] = force;
+			const float armx = (s.gridPos.x - a.rb->cgGridPos[obj][0])*p.cs[0] + (pos.x - a.rb->cgPos[obj][0]);
+			const float army = (s.gridPos.y - a.rb->cgGridPos[obj][1])*p.cs[1] + (pos.y - a.rb->cgPos[obj][1]);
+			const float armz = (s.gridPos.z - a.rb->cgGridPos[obj][2])*p.cs[2] + (pos.z - a.rb->cgPos[obj][2]);
+			a.rbtorques[rbindex] = make_float4(army*force.z - armz*force.y,
+				armz*force.x - armx*force.z, armx*force.y - army*force.x, 0.0f);
+		}
+		a.forces[index] = force;
+	} while (0);
+
+	// maxBlockReduce (src/cuda/device_core.cu:40-59) as wave shuffles + one LDS word per wave
+	if (a.cfl) {
+		__shared__ float wave_max[SPHX_BLOCK_FORCES/64];
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1)
+			cfl_term = fmaxf(cfl_term, __shfl_down(cfl_term, d));
+		if ((threadIdx.x & 63u) == 0) wave_max[threadIdx.x >> 6] = cfl_term;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			float m = wave_max[0];
+			for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) m = fmaxf(m, wave_max[w]);
+			a.cfl[a.cflOffset + blockIdx.x] = m;
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// CFL reduction -> dt.  fmaxDevice (src/cuda/forces_kernel.cu:734-793) + dtreduce
+// (src/cuda/forces.cu:556-606), finished on the device so that the adaptive dt never has to
+// visit the host inside a step.
+// ------------------------------------------------------------------------------------------
+#define BLOCK_FMAX 256
+
+__device__ __forceinline__ float block_max_256(float v)
+{
+	__shared__ float wm[4];
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_down(v, d));
+	if ((threadIdx.x & 63u) == 0) wm[threadIdx.x >> 6] = v;
+	__syncthreads();
+	v = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+	__syncthreads();
+	return v;
+}
+
+__global__ void __launch_bounds__(BLOCK_FMAX)
+fmax_kernel(float *__restrict__ output, const float4 *__restrict__ input, uint32_t numquarts)
+{
+	float m = 0.0f;
+	for (uint32_t i = blockIdx.x*BLOCK_FMAX + threadIdx.x; i < numquarts; i += BLOCK_FMAX*gridDim.x) {
+		const float4 v = input[i];
+		m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+	}
+	m = block_max_256(m);
+	if (threadIdx.x == 0) output[blockIdx.x] = m;
+}
+
+__global__ void __launch_bounds__(BLOCK_FMAX)
+dt_final_kernel(float *__restrict__ d_dt, const float *__restrict__ partial, uint32_t numPartials,
+	float slength, float dtadaptfactor, float sspeed_cfl, float max_kinematic, int viscous, int combine_min)
+{
+	float m = 0.0f;
+	for (uint32_t i = threadIdx.x; i < numPartials; i += BLOCK_FMAX) m = fmaxf(m, partial[i]);
+	m = block_max_256(m);
+	if (threadIdx.x == 0) {
+		float dt = dtadaptfactor*fminf(sqrtf(slength/m), slength/sspeed_cfl);
+		if (viscous) {
+			float dt_visc = slength*slength/max_kinematic;
+			dt_visc = (float)((double)dt_visc*0.125);
+			if (dt_visc < dt) dt = dt_visc;
+		}
+		d_dt[0] = combine_min ? fminf(d_dt[0], dt) : dt;
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// rigid-body totals: the reference does two thrust::inclusive_scan_by_key and reads the last
+// element of each segment (src/cuda/forces.cu:966-1004); only those totals are consumed
+// (src/GPUWorker.cc REDUCE_BODIES_FORCES), so they are produced directly: one block per body.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rb_reduce_kernel(const float4 *__restrict__ rbforces, const float4 *__restrict__ rbtorques,
+	const uint32_t *__restrict__ rbnum, const uint32_t *__restrict__ lastindex,
+	float *__restrict__ totals /* 6 per body */, uint32_t numParts)
+{
+	const uint32_t body = blockIdx.x;
+	const uint32_t last = lastindex[body];
+	const uint32_t key = rbnum[last];
+	float fx = 0, fy = 0, fz = 0, tx = 0, ty = 0, tz = 0;
+	for (uint32_t i = threadIdx.x; i < numParts && i <= last; i += 256) {
+		if (rbnum[i] == key) {
+			const float4 f = rbforces[i], t = rbtorques[i];
+			fx += f.x; fy += f.y; fz += f.z; tx += t.x; ty += t.y; tz += t.z;
+		}
+	}
+	__shared__ float red[6][4];
+	float v[6] = { fx, fy, fz, tx, ty, tz };
+#pragma unroll
+	for (int c = 0; c < 6; ++c) {
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1) v[c] += __shfl_down(v[c], d);
+		if ((threadIdx.x & 63u) == 0) red[c][threadIdx.x >> 6] = v[c];
+	}
+	__syncthreads();
+	if (threadIdx.x < 6)
+		totals[6*body + threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// ------------------------------------------------------------------------------------------
+// SPS stress tensor: SPSstressMatrixDevice (src/cuda/visc_kernel.cu:759-811), shearRate :307-367
+// ------------------------------------------------------------------------------------------
+struct SpsArgs {
+	float2 *tau0, *tau1, *tau2;
+	float *turbvisc;
+	const float4 *pos, *vel;
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+};
+
+template<int KERNEL, int NPTYPE>
+__device__ __forceinline__ void sps_section(const DevParams &p, const SpsArgs &a, uint32_t index,
+	const float4 &pos, const float4 &vel, const int3 &gridPos, float inv_h, float dv[9])
+{
+	const size_t stride = p.stride;
+	size_t loc = (NPTYPE == PT_FLUID) ? (size_t)index : (size_t)p.neibboundpos*stride + index;
+	float pcx = 0.0f, pcy = 0.0f, pcz = 0.0f;
+	uint32_t cell_base = 0;
+	for (;;) {
+		uint32_t nd = a.neibsList[loc];
+		if (nd == NEIBS_END) break;
+		loc = (NPTYPE == PT_FLUID) ? loc + stride : loc - stride;
+		if (nd >= CELLNUM_ENCODED) {
+			const int c = (int)(nd >> CELLNUM_SHIFT) - 1;
+			nd &= NEIBINDEX_MASK;
+			const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
+			pcx = fmaf(-(float)(cx - 1), p.cs[0], pos.x);
+			pcy = fmaf(-(float)(cy - 1), p.cs[1], pos.y);
+			pcz = fmaf(-(float)(cz - 1), p.cs[2], pos.z);
+			cell_base = a.cellStart[grid_hash_periodic(p, gridPos.x + cx - 1, gridPos.y + cy - 1, gridPos.z + cz - 1)];
+		}
+		const uint32_t j = cell_base + nd;
+		const float4 npos = a.pos[j];
+		const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
+		const float r = fast_sqrt(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+		if (!is_active_w(npos.w) || r >= p.influenceradius) continue;
+		const float4 nvel = a.vel[j];
+		const uint32_t nfl = FLUID_NUM(a.info[j]);
+		const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+		const float weight = kernel_F<KERNEL>(p, r, inv_h)*npos.w*fast_rcp(n_rho);
+		const float mx = rx*weight, my = ry*weight, mz = rz*weight;
+		const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+		dv[0] -= vx*mx; dv[1] -= vx*my; dv[2] -= vx*mz;
+		dv[3] -= vy*mx; dv[4] -= vy*my; dv[5] -= vy*mz;
+		dv[6] -= vz*mx; dv[7] -= vz*my; dv[8] -= vz*mz;
+	}
+}
+
+template<int KERNEL>
+__global__ void __launch_bounds__(128)
+sps_kernel(DevParams p, SpsArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const float4 pos = a.pos[index];
+	if (!is_active_w(pos.w)) return;
+	const float4 vel = a.vel[index];
+	const particleinfo info = a.info[index];
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	const float inv_h = fast_rcp(p.slength);
+	float dv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+	sps_section<KERNEL, PT_FLUID>(p, a, index, pos, vel, gridPos, inv_h, dv);
+	sps_section<KERNEL, PT_BOUNDARY>(p, a, index, pos, vel, gridPos, inv_h, dv);
+
+	float txx = dv[0], txy = dv[1] + dv[3], txz = dv[2] + dv[6];
+	float tyy = dv[4], tyz = dv[5] + dv[7], tzz = dv[8];
+	const float SijSij_bytwo = 2.0f*(txx*txx + tyy*tyy + tzz*tzz) + (txy*txy + txz*txz + tyz*tyz);
+	const float S = sqrtf(SijSij_bytwo);
+	const float nu_SPS = p.smagfactor*S;
+	const float divu_SPS = 0.6666666666f*nu_SPS*(txx + tyy + tzz);
+	const float Blinetal_SPS = p.kspsfactor*SijSij_bytwo;
+	if (a.turbvisc) a.turbvisc[index] = nu_SPS;
+	if (a.tau0) {
+		const float rho = (vel.w + 1.0f)*p.rho0[FLUID_NUM(info)];
+		txx = (nu_SPS*(txx + txx) - divu_SPS - Blinetal_SPS)/rho;
+		txy *= nu_SPS/rho;
+		txz *= nu_SPS/rho;
+		tyy = (nu_SPS*(tyy + tyy) - divu_SPS - Blinetal_SPS)/rho;
+		tyz *= nu_SPS/rho;
+		tzz = (nu_SPS*(tzz + tzz) - divu_SPS - Blinetal_SPS)/rho;
+		a.tau0[index] = make_float2(txx, txy);
+		a.tau1[index] = make_float2(txz, tyy);
+		a.tau2[index] = make_float2(tyz, tzz);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" uint32_t sphx_forces_fmax_elements(uint32_t n) { return round_up_u(div_up_u(n, SPHX_BLOCK_FORCES), 4u); }
+extern "C" uint32_t sphx_forces_fmax_temp_elements(uint32_t nels)
+{
+	const uint32_t numquarts = nels/4;
+	uint32_t numBlocks = div_up_u(numquarts, BLOCK_FMAX);
+	if (numBlocks > 1) {
+		numBlocks = round_up_u(numBlocks, 4u);
+		if (numBlocks > BLOCK_FMAX*4) numBlocks = BLOCK_FMAX*4;
+	}
+	return numBlocks;
+}
+extern "C" uint32_t sphx_forces_round_particles(uint32_t n) { return (n/SPHX_BLOCK_FORCES)*SPHX_BLOCK_FORCES; }
+
+template<int KERNEL, int TURB, bool COLA>
+static void launch_forces_mf(bool multifluid, dim3 grid, hipStream_t stream, const DevParams &p, const ForcesArgs &a)
+{
+	if (multifluid)
+		forces_kernel<KERNEL, TURB, COLA, true><<<grid, SPHX_BLOCK_FORCES, 0, stream>>>(p, a);
+	else
+		forces_kernel<KERNEL, TURB, COLA, false><<<grid, SPHX_BLOCK_FORCES, 0, stream>>>(p, a);
+}
+
+template<int KERNEL>
+static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const ForcesArgs &a)
+{
+	const DevParams &p = ctx->dev;
+	const bool mf = p.numfluids > 1;
+	const bool cola = p.densitydiff == SPHX_COLAGROSSI;
+	switch (p.turbmodel) {
+	case SPHX_ARTIFICIAL:
+		if (cola) launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, true>(mf, grid, stream, p, a);
+		else launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, false>(mf, grid, stream, p, a);
+		break;
+	case SPHX_SPS:
+		if (cola) launch_forces_mf<KERNEL, SPHX_SPS, true>(mf, grid, stream, p, a);
+		else launch_forces_mf<KERNEL, SPHX_SPS, false>(mf, grid, stream, p, a);
+		break;
+	case SPHX_LAMINAR_FLOW:
+		if (cola) launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, true>(mf, grid, stream, p, a);
+		else launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, false>(mf, grid, stream, p, a);
+		break;
+	default:
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: turbulence model not built");
+	}
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
+	void *forces, float *cfl, void *rbforces, void *rbtorques,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *tau0, const void *tau1, const void *tau2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius,
+	uint32_t cflOffset, int run_mode, int step, float dt, int compute_object_forces,
+	uint32_t *h_numBlocks, void *stream)
+{
+	(void)deltap; (void)dtadaptfactor; (void)step; (void)dt;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_forces_basicstep: constants not set");
+	SPHX_REQUIRE(forces && pos && vel && info && hash && cellStart && neibsList, "sphx_forces_basicstep: missing buffer");
+	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_forces_basicstep: invalid particle range");
+	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
+		"sphx_forces_basicstep: slength/influenceradius differ from set_constants");
+	if (run_mode != SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: REPACK run mode is not built");
+	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: only DYN_BOUNDARY pair interactions are built");
+	if (ctx->dev.turbmodel == SPHX_SPS)
+		SPHX_REQUIRE(tau0 && tau1 && tau2, "sphx_forces_basicstep: SPS needs the three TAU arrays");
+	if ((ctx->dev.simflags & SPHX_ENABLE_DTADAPT))
+		SPHX_REQUIRE(cfl != nullptr, "sphx_forces_basicstep: ENABLE_DTADAPT needs the CFL buffer");
+	SPHX_REQUIRE((rbforces == nullptr) == (rbtorques == nullptr), "sphx_forces_basicstep: RB_FORCES and RB_TORQUES must come together");
+
+	const uint32_t nrange = toParticle - fromParticle;
+	const uint32_t numBlocks = round_up_u(div_up_u(nrange, SPHX_BLOCK_FORCES), 4u);
+	if (h_numBlocks) *h_numBlocks = numBlocks;
+	if (!numBlocks) return SPHX_OK;
+
+	ForcesArgs a;
+	a.forces = (float4*)forces; a.cfl = (ctx->dev.simflags & SPHX_ENABLE_DTADAPT) ? cfl : nullptr;
+	a.rbforces = (float4*)rbforces; a.rbtorques = (float4*)rbtorques;
+	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.info = (const particleinfo*)info;
+	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.tau0 = (const float2*)tau0; a.tau1 = (const float2*)tau1; a.tau2 = (const float2*)tau2;
+	a.rb = ctx->rb_dev;
+	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
+	a.compute_object_forces = compute_object_forces;
+
+	int rc;
+	switch (ctx->dev.kerneltype) {
+	case SPHX_CUBICSPLINE: rc = launch_forces_k<SPHX_CUBICSPLINE>(ctx, dim3(numBlocks), (hipStream_t)stream, a); break;
+	case SPHX_QUADRATIC:   rc = launch_forces_k<SPHX_QUADRATIC>(ctx, dim3(numBlocks), (hipStream_t)stream, a); break;
+	case SPHX_WENDLAND:    rc = launch_forces_k<SPHX_WENDLAND>(ctx, dim3(numBlocks), (hipStream_t)stream, a); break;
+	case SPHX_GAUSSIAN:    rc = launch_forces_k<SPHX_GAUSSIAN>(ctx, dim3(numBlocks), (hipStream_t)stream, a); break;
+	default: return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid kernel type");
+	}
+	if (rc != SPHX_OK) return rc;
+	SPHX_LAUNCH_CHECK("forces_kernel");
+	return SPHX_OK;
+}
+
+static int dtreduce_launch(sphx_ctx *ctx, float slength, float dtadaptfactor, float sspeed_cfl,
+	float max_kinematic, const float *cfl, float *cflTemp, uint32_t numBlocks,
+	float *d_dt, int combine_min, hipStream_t stream)
+{
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_forces_dtreduce: constants not set");
+	SPHX_REQUIRE(cfl && cflTemp && d_dt, "sphx_forces_dtreduce: missing buffer (CFL, CFL_TEMP)");
+	SPHX_REQUIRE((numBlocks & 3u) == 0 && numBlocks > 0, "sphx_forces_dtreduce: number of elements to reduce is not a multiple of 4");
+	const uint32_t nPartials = sphx_forces_fmax_temp_elements(numBlocks);
+	fmax_kernel<<<nPartials, BLOCK_FMAX, 0, stream>>>(cflTemp, (const float4*)cfl, numBlocks/4);
+	const int viscous = (ctx->dev.rheology != SPHX_INVISCID || ctx->dev.turbmodel > SPHX_ARTIFICIAL) ? 1 : 0;
+	dt_final_kernel<<<1, BLOCK_FMAX, 0, stream>>>(d_dt, cflTemp, nPartials, slength, dtadaptfactor, sspeed_cfl,
+		max_kinematic, viscous, combine_min);
+	SPHX_LAUNCH_CHECK("fmax_kernel/dt_final_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_dtreduce_device(sphx_ctx *ctx, float slength, float dtadaptfactor, float sspeed_cfl,
+	float max_kinematic, const float *cfl, float *cflTemp, uint32_t numBlocks,
+	float *d_dt, int combine_min, void *stream)
+{
+	return dtreduce_launch(ctx, slength, dtadaptfactor, sspeed_cfl, max_kinematic, cfl, cflTemp, numBlocks,
+		d_dt, combine_min, (hipStream_t)stream);
+}
+
+extern "C" int sphx_forces_dtreduce(sphx_ctx *ctx, float slength, float dtadaptfactor, float sspeed_cfl,
+	float max_kinematic, const float *cfl, float *cflTemp, uint32_t numBlocks,
+	float *h_dt, void *stream)
+{
+	SPHX_REQUIRE(h_dt != nullptr, "sphx_forces_dtreduce: h_dt is NULL");
+	int rc = dtreduce_launch(ctx, slength, dtadaptfactor, sspeed_cfl, max_kinematic, cfl, cflTemp, numBlocks,
+		ctx ? ctx->dt_scratch : nullptr, 0, (hipStream_t)stream);
+	if (rc != SPHX_OK) return rc;
+	SPHX_HIP(hipMemcpyAsync(h_dt, ctx->dt_scratch, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+	SPHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+	return SPHX_OK;
+}
+
+extern "C" int sphx_reduce_rb_forces(sphx_ctx *ctx, void *rbforces, void *rbtorques, const uint32_t *rbnum,
+	const uint32_t *h_lastindex, float *h_totalforce3, float *h_totaltorque3,
+	uint32_t numforcesbodies, uint32_t numForcesBodiesParticles, void *stream_)
+{
+	SPHX_REQUIRE(ctx && rbforces && rbtorques && rbnum && h_lastindex && h_totalforce3 && h_totaltorque3,
+		"sphx_reduce_rb_forces: NULL argument");
+	SPHX_REQUIRE(numforcesbodies <= SPHX_MAX_BODIES, "sphx_reduce_rb_forces: too many bodies");
+	if (!numforcesbodies) return SPHX_OK;
+	hipStream_t stream = (hipStream_t)stream_;
+	uint32_t *d_last = nullptr; float *d_tot = nullptr;
+	SPHX_HIP(hipMalloc((void**)&d_last, sizeof(uint32_t)*numforcesbodies));
+	SPHX_HIP(hipMalloc((void**)&d_tot, sizeof(float)*6*numforcesbodies));
+	SPHX_HIP(hipMemcpyAsync(d_last, h_lastindex, sizeof(uint32_t)*numforcesbodies, hipMemcpyHostToDevice, stream));
+	rb_reduce_kernel<<<numforcesbodies, 256, 0, stream>>>((const float4*)rbforces, (const float4*)rbtorques,
+		rbnum, d_last, d_tot, numForcesBodiesParticles);
+	float tot[6*SPHX_MAX_BODIES];
+	SPHX_HIP(hipMemcpyAsync(tot, d_tot, sizeof(float)*6*numforcesbodies, hipMemcpyDeviceToHost, stream));
+	SPHX_HIP(hipStreamSynchronize(stream));
+	(void)hipFree(d_last); (void)hipFree(d_tot);
+	for (uint32_t b = 0; b < numforcesbodies; ++b)
+		for (int c = 0; c < 3; ++c) {
+			h_totalforce3[3*b + c] = tot[6*b + c];
+			h_totaltorque3[3*b + c] = tot[6*b + 3 + c];
+		}
+	return SPHX_OK;
+}
+
+extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2, float *spsturbvisc,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd,
+	float deltap, float slength, float influenceradius, void *stream)
+{
+	(void)deltap; (void)numParticles;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_calc_visc: constants not set");
+	if (ctx->dev.turbmodel != SPHX_SPS)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_calc_visc: only the SPS branch is built");
+	SPHX_REQUIRE(pos && vel && info && hash && cellStart && neibsList, "sphx_calc_visc: missing buffer");
+	SPHX_REQUIRE((tau0 && tau1 && tau2) || (!tau0 && !tau1 && !tau2), "sphx_calc_visc: the three TAU arrays must come together");
+	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
+		"sphx_calc_visc: slength/influenceradius differ from set_constants");
+	if (!particleRangeEnd) return SPHX_OK;
+	SpsArgs a;
+	a.tau0 = (float2*)tau0; a.tau1 = (float2*)tau1; a.tau2 = (float2*)tau2; a.turbvisc = spsturbvisc;
+	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.info = (const particleinfo*)info;
+	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
+	const dim3 grid(div_up_u(particleRangeEnd, 128));
+	switch (ctx->dev.kerneltype) {
+	case SPHX_CUBICSPLINE: sps_kernel<SPHX_CUBICSPLINE><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); break;
+	case SPHX_QUADRATIC:   sps_kernel<SPHX_QUADRATIC><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); break;
+	case SPHX_WENDLAND:    sps_kernel<SPHX_WENDLAND><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); break;
+	default:               sps_kernel<SPHX_GAUSSIAN><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); break;
+	}
+	SPHX_LAUNCH_CHECK("sps_kernel");
+	return SPHX_OK;
+}

@@ -1,0 +1,558 @@
+// neibs.hip -- neighbour engine for gfx950: cell hash, cell-binning sort, reorder + cell
+// start/end, cell-linked neighbour list.  Replaces CUDANeibsEngine (GPUSPH
+// src/cuda/buildneibs.cu:68-496, kernels src/cuda/buildneibs_kernel.cu:659-1185); results are
+// bit-identical to the reference algorithm restated in oracle/sph_oracle.c.
+//
+// Numerics (DESIGN.md "Numerics"): compiled with -ffp-contract=off; `a - b*c` shapes are
+// explicit fmaf, squared lengths are fmaf(z,z,fmaf(y,y,x*x)), division is IEEE.
+#include "sphx_internal.h"
+#include <cstring>
+
+#define BLOCK_HASH    256
+#define BLOCK_SORT    256
+#define BLOCK_REORDER 256
+#define BLOCK_NEIBS   256
+#define SCAN_ITEMS    1024   // elements per scan block (256 threads x 4)
+
+// ------------------------------------------------------------------------------------------
+// calcHash: src/cuda/buildneibs_kernel.cu:659-776 (clampGridPos :225-298)
+// 52 B/particle streaming: R pos16 info8 hash4 (+4 devmap), W pos16 hash4 partIndex4
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int clamp_axis(int gp, int &off, int gs, bool periodic, bool &toofar)
+{
+	int ng = gp + off;
+	if (periodic) {
+		if (ng < 0) ng += gs;
+		if (ng >= gs) ng -= gs;
+	} else {
+		ng = min(max(0, ng), gs - 1);
+		if (abs(off) > 1 && ng == gp)
+			toofar = true;
+		off = ng - gp;
+	}
+	return ng;
+}
+
+__global__ void __launch_bounds__(BLOCK_HASH)
+calc_hash_kernel(DevParams p, float4 *__restrict__ posArray, uint32_t *__restrict__ particleHash,
+	uint32_t *__restrict__ particleIndex, const particleinfo *__restrict__ particleInfo,
+	const uint32_t *__restrict__ compactDeviceMap, uint32_t numParticles)
+{
+	const uint32_t index = blockIdx.x*BLOCK_HASH + threadIdx.x;
+	if (index >= numParticles) return;
+
+	const particleinfo info = particleInfo[index];
+	uint32_t gridHash = particleHash[index] & CELLTYPE_BITMASK;
+
+	if (IS_FLUID(info) || IS_MOVING(info) || (IS_SURFACE(info) && !IS_FLUID(info))) {
+		float4 pos = posArray[index];
+		const int3 gridPos = grid_pos_from_hash(p, gridHash);
+
+		// floor(pos/cellSize + (pos<0 ? 0.5 : 0.49999997)), see the long comment at :696-725
+		int ox = (int)floorf(pos.x/p.cs[0] + (pos.x < 0 ? 0.5f : 0.49999997f));
+		int oy = (int)floorf(pos.y/p.cs[1] + (pos.y < 0 ? 0.5f : 0.49999997f));
+		int oz = (int)floorf(pos.z/p.cs[2] + (pos.z < 0 ? 0.5f : 0.49999997f));
+
+		bool toofar = false;
+		const int nx = clamp_axis(gridPos.x, ox, p.gs[0], p.periodic & SPHX_PERIODIC_X, toofar);
+		const int ny = clamp_axis(gridPos.y, oy, p.gs[1], p.periodic & SPHX_PERIODIC_Y, toofar);
+		const int nz = clamp_axis(gridPos.z, oz, p.gs[2], p.periodic & SPHX_PERIODIC_Z, toofar);
+		gridHash = grid_hash(p, nx, ny, nz);
+
+		pos.x = fmaf(-(float)ox, p.cs[0], pos.x);
+		pos.y = fmaf(-(float)oy, p.cs[1], pos.y);
+		pos.z = fmaf(-(float)oz, p.cs[2], pos.z);
+
+		if (toofar)
+			pos.w = __uint_as_float(0x7fc00000u); // disable_particle: mass = NaN
+
+		if (!is_active_w(pos.w))
+			gridHash = CELL_HASH_MAX;
+
+		posArray[index] = pos;
+	}
+
+	if (compactDeviceMap && gridHash != CELL_HASH_MAX)
+		gridHash |= compactDeviceMap[gridHash];
+
+	particleHash[index] = gridHash;
+	particleIndex[index] = index;
+}
+
+// fixHash: src/cuda/buildneibs_kernel.cu:786-814
+__global__ void __launch_bounds__(BLOCK_HASH)
+fix_hash_kernel(uint32_t *__restrict__ particleHash, uint32_t *__restrict__ particleIndex,
+	const uint32_t *__restrict__ compactDeviceMap, uint32_t numParticles)
+{
+	const uint32_t index = blockIdx.x*BLOCK_HASH + threadIdx.x;
+	if (index >= numParticles) return;
+	if (particleHash) {
+		const uint32_t h = particleHash[index];
+		if (compactDeviceMap)
+			particleHash[index] = h | compactDeviceMap[h & CELLTYPE_BITMASK];
+	}
+	particleIndex[index] = index;
+}
+
+// ------------------------------------------------------------------------------------------
+// sort: the reference calls thrust::sort_by_key with the comparator ptype_hash_compare
+// (src/cuda/buildneibs.cu:358-412): total order (hash incl. cell-type bits, PART_TYPE, id).
+// Because the order is total, any correct sort yields the same permutation.  Here: a
+// cell-binning sort -- histogram of the hash with wave-aggregated atomics, exclusive scan of
+// the bins, scatter, then an in-bin rank by (type, id).  ~60 B/particle instead of the
+// ~200 B/particle of an 8-pass 64-bit LSD radix sort, and no comparison sort at all.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t hash_to_bin(uint32_t h, uint32_t cells, uint32_t lastBin)
+{
+	return (h == CELL_HASH_MAX) ? lastBin : (h >> 30)*cells + (h & CELLTYPE_BITMASK);
+}
+
+__global__ void __launch_bounds__(BLOCK_SORT)
+sort_count_kernel(const uint32_t *__restrict__ hash, uint32_t *__restrict__ binCount,
+	uint32_t *__restrict__ slot, uint32_t cells, uint32_t lastBin, uint32_t n)
+{
+	const uint32_t i = blockIdx.x*BLOCK_SORT + threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
+	const bool valid = i < n;
+	const uint32_t bin = valid ? hash_to_bin(hash[i], cells, lastBin) : 0xFFFFFFFFu;
+
+	// particles arrive almost sorted from the previous rebuild: consecutive lanes mostly share
+	// a bin.  One atomic per run of equal bins instead of one per particle.
+	const uint32_t prev = __shfl_up(bin, 1);
+	const bool head = (lane == 0) || (bin != prev);
+	const unsigned long long heads = __ballot(head);
+	const unsigned long long upto = heads & ((lane == 63u) ? ~0ull : ((2ull << lane) - 1ull));
+	const int head_lane = 63 - __clzll((long long)upto);
+	const unsigned long long above = (head_lane == 63) ? 0ull : (heads & ~((2ull << head_lane) - 1ull));
+	const int next_head = above ? (__ffsll((long long)above) - 1) : 64;
+	uint32_t base = 0;
+	if (valid && (int)lane == head_lane)
+		base = atomicAdd(&binCount[bin], (uint32_t)(next_head - head_lane));
+	base = __shfl(base, head_lane);
+	if (valid)
+		slot[i] = base + (lane - (uint32_t)head_lane);
+}
+
+// exclusive scan of uint32 in three launches (reduce / scan partials / downsweep)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) {
+		const uint32_t t = __shfl_up(v, d);
+		if ((int)lane >= d) v += t;
+	}
+	return v;
+}
+
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t &blockTotal)
+{
+	__shared__ uint32_t waveSums[4];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const uint32_t incl = wave_incl_scan(v, lane);
+	if (lane == 63u) waveSums[wave] = incl;
+	__syncthreads();
+	uint32_t offset = 0;
+	for (uint32_t w = 0; w < wave; ++w) offset += waveSums[w];
+	blockTotal = waveSums[0] + waveSums[1] + waveSums[2] + waveSums[3];
+	__syncthreads();
+	return offset + incl - v;
+}
+
+__global__ void __launch_bounds__(256)
+scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ partials, uint32_t n)
+{
+	const uint32_t base = blockIdx.x*SCAN_ITEMS + threadIdx.x*4;
+	uint32_t s = 0;
+	if (base + 3 < n) {
+		const uint4 v = *reinterpret_cast<const uint4*>(in + base);
+		s = v.x + v.y + v.z + v.w;
+	} else {
+		for (uint32_t k = 0; k < 4; ++k) if (base + k < n) s += in[base + k];
+	}
+	uint32_t total;
+	(void)block_excl_scan_256(s, total);
+	if (threadIdx.x == 0) partials[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256)
+scan_partials_kernel(uint32_t *__restrict__ partials, uint32_t numPartials)
+{
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < numPartials; base += 256) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < numPartials ? partials[i] : 0;
+		uint32_t total;
+		const uint32_t ex = block_excl_scan_256(v, total);
+		if (i < numPartials) partials[i] = carry + ex;
+		carry += total;
+	}
+}
+
+__global__ void __launch_bounds__(256)
+scan_final_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+	const uint32_t *__restrict__ partials, uint32_t n)
+{
+	const uint32_t base = blockIdx.x*SCAN_ITEMS + threadIdx.x*4;
+	uint32_t v[4] = {0, 0, 0, 0};
+	if (base + 3 < n) {
+		const uint4 t = *reinterpret_cast<const uint4*>(in + base);
+		v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+	} else {
+		for (uint32_t k = 0; k < 4; ++k) if (base + k < n) v[k] = in[base + k];
+	}
+	const uint32_t s = v[0] + v[1] + v[2] + v[3];
+	uint32_t total;
+	uint32_t ex = block_excl_scan_256(s, total) + partials[blockIdx.x];
+	uint32_t o[4];
+	o[0] = ex; o[1] = o[0] + v[0]; o[2] = o[1] + v[1]; o[3] = o[2] + v[2];
+	if (base + 3 < n) {
+		*reinterpret_cast<uint4*>(out + base) = make_uint4(o[0], o[1], o[2], o[3]);
+	} else {
+		for (uint32_t k = 0; k < 4; ++k) if (base + k < n) out[base + k] = o[k];
+	}
+}
+
+__global__ void __launch_bounds__(BLOCK_SORT)
+sort_scatter_kernel(const uint32_t *__restrict__ hash, const uint2 *__restrict__ info,
+	const uint32_t *__restrict__ partIndex, const uint32_t *__restrict__ slot,
+	const uint32_t *__restrict__ binStart,
+	uint32_t *__restrict__ tmpHash, uint2 *__restrict__ tmpInfo, uint32_t *__restrict__ tmpIndex,
+	uint32_t cells, uint32_t lastBin, uint32_t n)
+{
+	const uint32_t i = blockIdx.x*BLOCK_SORT + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t h = hash[i];
+	const uint32_t p = binStart[hash_to_bin(h, cells, lastBin)] + slot[i];
+	tmpHash[p] = h;
+	tmpInfo[p] = info[i];
+	tmpIndex[p] = partIndex[i];
+}
+
+// (PART_TYPE, id) as one 64-bit key; particleinfo viewed as uint2: .x = type|flags + fluid/object<<16,
+// .y = id (z | w<<16)
+__device__ __forceinline__ unsigned long long type_id_key(uint2 info)
+{
+	return ((unsigned long long)(info.x & 7u) << 32) | (unsigned long long)info.y;
+}
+
+__global__ void __launch_bounds__(BLOCK_SORT)
+sort_rank_kernel(const uint32_t *__restrict__ tmpHash, const uint2 *__restrict__ tmpInfo,
+	const uint32_t *__restrict__ tmpIndex,
+	const uint32_t *__restrict__ binStart, const uint32_t *__restrict__ binCount,
+	uint32_t *__restrict__ hash, uint2 *__restrict__ info, uint32_t *__restrict__ partIndex,
+	uint32_t cells, uint32_t lastBin, uint32_t n)
+{
+	const uint32_t p = blockIdx.x*BLOCK_SORT + threadIdx.x;
+	if (p >= n) return;
+	const uint32_t h = tmpHash[p];
+	const uint32_t bin = hash_to_bin(h, cells, lastBin);
+	const uint32_t s = binStart[bin];
+	const uint32_t e = s + binCount[bin];
+	const uint2 myInfo = tmpInfo[p];
+	const unsigned long long key = type_id_key(myInfo);
+	uint32_t rank = 0;
+	for (uint32_t q = s; q < e; ++q) {
+		const unsigned long long k = type_id_key(tmpInfo[q]);
+		rank += (k < key) || (k == key && q < p);
+	}
+	const uint32_t dst = s + rank;
+	hash[dst] = h;
+	info[dst] = myInfo;
+	partIndex[dst] = tmpIndex[p];
+}
+
+// ------------------------------------------------------------------------------------------
+// reorderDataAndFindCellStart: src/cuda/buildneibs_kernel.cu:836-992.  The neighbouring hash
+// comes from the L1-resident previous element instead of a shared-memory stage.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK_REORDER)
+reorder_kernel(uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
+	uint32_t *__restrict__ segmentStart,
+	float4 *__restrict__ sortedPos, float4 *__restrict__ sortedVel,
+	const float4 *__restrict__ unsortedPos, const float4 *__restrict__ unsortedVel,
+	const uint32_t *__restrict__ particleHash, const uint32_t *__restrict__ particleIndex,
+	uint32_t numParticles, uint32_t *__restrict__ newNumParticles)
+{
+	const uint32_t index = blockIdx.x*BLOCK_REORDER + threadIdx.x;
+	if (index >= numParticles) return;
+
+	const uint32_t cellHash = particleHash[index];
+	const uint32_t prevHash = index > 0 ? particleHash[index - 1] : 0u;
+
+	if (index == 0 || cellHash != prevHash) {
+		if (cellHash != CELL_HASH_MAX)
+			cellStart[cellHash & CELLTYPE_BITMASK] = index;
+		else
+			*newNumParticles = index;
+		if (index > 0)
+			cellEnd[prevHash & CELLTYPE_BITMASK] = index;
+	}
+
+	if (cellHash == CELL_HASH_MAX)
+		return;
+
+	if (index == numParticles - 1) {
+		cellEnd[cellHash & CELLTYPE_BITMASK] = index + 1;
+		*newNumParticles = numParticles;
+	}
+
+	if (segmentStart) {
+		const uint32_t curr_type = cellHash >> 30;
+		const uint32_t prev_type = prevHash >> 30;
+		if (index == 0 || curr_type != prev_type)
+			segmentStart[curr_type] = index;
+	}
+
+	const uint32_t sortedIndex = particleIndex[index];
+	sortedPos[index] = unsortedPos[sortedIndex];
+	sortedVel[index] = unsortedVel[sortedIndex];
+}
+
+// ------------------------------------------------------------------------------------------
+// buildNeibsList: src/cuda/buildneibs_kernel.cu:1019-1185, neibsInCell :536-644
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t neib_list_offset(const DevParams &p, uint32_t neib_num, uint32_t neib_type)
+{
+	return (neib_type == PT_FLUID) ? neib_num :
+		(neib_type == PT_BOUNDARY) ? p.neibboundpos - neib_num :
+		neib_num + p.neibboundpos + 1;
+}
+
+__device__ __forceinline__ bool too_many_neibs(const DevParams &p, uint32_t nf, uint32_t nb, uint32_t nv, uint32_t neib_type)
+{
+	switch (neib_type) {
+	case PT_FLUID:    return !(nf < p.neibboundpos);
+	case PT_BOUNDARY: return !(nf + nb < p.neibboundpos);
+	case PT_VERTEX:   return !(nv < p.neiblistsize - p.neibboundpos - 1);
+	default: return true;
+	}
+}
+
+__device__ __forceinline__ bool neib_cell_axis(int &g, int off, int gs, bool periodic)
+{
+	g += off;
+	if (g < 0) { if (periodic) g = gs - 1; else return false; }
+	else if (g >= gs) { if (periodic) g = 0; else return false; }
+	return true;
+}
+
+__global__ void __launch_bounds__(BLOCK_NEIBS)
+build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
+	const float4 *__restrict__ posArray, const particleinfo *__restrict__ infoArray,
+	const uint32_t *__restrict__ particleHash,
+	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
+	uint32_t particleRangeEnd, float sqinfluenceradius, NeibsCounters *__restrict__ counters)
+{
+	const uint32_t index = blockIdx.x*BLOCK_NEIBS + threadIdx.x;
+	uint32_t nf = 0, nb = 0, nv = 0; // neibs_num[PT_FLUID, PT_BOUNDARY, PT_VERTEX]
+
+	do {
+		if (index >= particleRangeEnd) break;
+		const particleinfo info = infoArray[index];
+		bool build_nl = IS_FLUID(info) || IS_TESTPOINT(info) || IS_FLOATING(info) || HAS_COMPUTE_FORCE(info);
+		if (p.boundarytype == SPHX_DYN_BOUNDARY) build_nl = true;
+		if (!build_nl) break;
+		const float4 pos = posArray[index];
+		if (!is_active_w(pos.w)) break;
+		const int3 gridPos = grid_pos_from_hash(p, particleHash[index] & CELLTYPE_BITMASK);
+		const bool boundary = IS_BOUNDARY(info);
+
+		for (int z = -1; z <= 1; z++) for (int y = -1; y <= 1; y++) for (int x = -1; x <= 1; x++) {
+			int gx = gridPos.x, gy = gridPos.y, gz = gridPos.z;
+			if (!neib_cell_axis(gx, x, p.gs[0], p.periodic & SPHX_PERIODIC_X)) continue;
+			if (!neib_cell_axis(gy, y, p.gs[1], p.periodic & SPHX_PERIODIC_Y)) continue;
+			if (!neib_cell_axis(gz, z, p.gs[2], p.periodic & SPHX_PERIODIC_Z)) continue;
+			const uint32_t cellHash = grid_hash(p, gx, gy, gz);
+			const uint32_t bucketStart = cellStart[cellHash];
+			if (bucketStart == CELL_EMPTY) continue;
+			const uint32_t bucketEnd = cellEnd[cellHash];
+			const uint32_t cell = (uint32_t)((x + 1) + (y + 1)*3 + (z + 1)*9);
+
+			const float px = fmaf(-(float)x, p.cs[0], pos.x);
+			const float py = fmaf(-(float)y, p.cs[1], pos.y);
+			const float pz = fmaf(-(float)z, p.cs[2], pos.z);
+
+			bool encode_cell = true;
+			uint32_t neib_type = PT_FLUID;
+			for (uint32_t neib_index = bucketStart; neib_index < bucketEnd; ++neib_index) {
+				if (neib_index == index) continue;
+				const particleinfo neib_info = infoArray[neib_index];
+				if (IS_TESTPOINT(neib_info)) continue;
+				if (!encode_cell && neib_type != PART_TYPE(neib_info))
+					encode_cell = true;
+				neib_type = PART_TYPE(neib_info);
+				if ((p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY) &&
+					boundary && IS_BOUNDARY(neib_info))
+					continue;
+				const float4 neib_pos = posArray[neib_index];
+				if (!is_active_w(neib_pos.w)) continue;
+				const float rx = px - neib_pos.x, ry = py - neib_pos.y, rz = pz - neib_pos.z;
+				const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
+				if (r2 < sqinfluenceradius) {
+					const uint32_t num = (neib_type == PT_FLUID) ? nf : (neib_type == PT_BOUNDARY) ? nb : nv;
+					const uint32_t offset = neib_list_offset(p, num, neib_type);
+					if (neib_type == PT_FLUID) nf++; else if (neib_type == PT_BOUNDARY) nb++; else nv++;
+					if (!too_many_neibs(p, nf, nb, nv, neib_type)) {
+						const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
+						neibsList[(size_t)offset*p.stride + index] = (neibdata)((neib_index - bucketStart) + enc);
+						encode_cell = false;
+					}
+				}
+			}
+		}
+	} while (0);
+
+	if (index < particleRangeEnd) {
+		bool overflow = too_many_neibs(p, nf, nb, nv, PT_FLUID);
+		const uint32_t marker_pos = overflow ? p.neibboundpos : nf;
+		neibsList[(size_t)marker_pos*p.stride + index] = NEIBS_END;
+		overflow |= too_many_neibs(p, nf, nb, nv, PT_BOUNDARY);
+		if (!overflow)
+			neibsList[(size_t)neib_list_offset(p, nb, PT_BOUNDARY)*p.stride + index] = NEIBS_END;
+		if (overflow) {
+			const int pid = (int)info_id(infoArray[index]);
+			if (atomicCAS(&counters->hasTooManyNeibs, -1, pid) == -1) {
+				counters->hasMaxNeibs[0] = nf; counters->hasMaxNeibs[1] = nb; counters->hasMaxNeibs[2] = nv;
+			}
+		}
+	}
+
+	// neibcount: per-block max / total, one atomic pair per wave
+	uint32_t total = nf + nb + nv;
+	uint32_t mx = nf + nb;
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) {
+		total += __shfl_down(total, d);
+		mx = max(mx, (uint32_t)__shfl_down(mx, d));
+	}
+	if ((threadIdx.x & 63u) == 0 && total) {
+		atomicMax(&counters->maxFluidBoundaryNeibs, (int)mx);
+		atomicAdd(&counters->numInteractions, (int)total);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+extern "C" int sphx_calc_hash(sphx_ctx *ctx, void *pos, uint32_t *hash, uint32_t *partIndex,
+	const void *info, const uint32_t *compactDeviceMap, uint32_t n, void *stream)
+{
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_calc_hash: constants not set");
+	SPHX_REQUIRE(pos && hash && partIndex && info, "sphx_calc_hash: missing buffer (POS, HASH, PARTINDEX, INFO)");
+	if (!n) return SPHX_OK;
+	calc_hash_kernel<<<div_up_u(n, BLOCK_HASH), BLOCK_HASH, 0, (hipStream_t)stream>>>(ctx->dev,
+		(float4*)pos, hash, partIndex, (const particleinfo*)info, compactDeviceMap, n);
+	SPHX_LAUNCH_CHECK("calc_hash_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_fix_hash(sphx_ctx *ctx, uint32_t *hash, uint32_t *partIndex,
+	const void *info, const uint32_t *compactDeviceMap, uint32_t n, void *stream)
+{
+	(void)info;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_fix_hash: constants not set");
+	SPHX_REQUIRE(partIndex, "sphx_fix_hash: missing PARTINDEX buffer");
+	if (!n) return SPHX_OK;
+	fix_hash_kernel<<<div_up_u(n, BLOCK_HASH), BLOCK_HASH, 0, (hipStream_t)stream>>>(hash, partIndex, compactDeviceMap, n);
+	SPHX_LAUNCH_CHECK("fix_hash_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sort(sphx_ctx *ctx, uint32_t *hash, void *info, uint32_t *partIndex,
+	uint32_t n, void *stream_)
+{
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_sort: constants not set");
+	SPHX_REQUIRE(hash && info && partIndex, "sphx_sort: missing buffer (HASH, INFO, PARTINDEX)");
+	if (!n) return SPHX_OK;
+	hipStream_t stream = (hipStream_t)stream_;
+	int rc = sphx_ensure_scratch(ctx, n);
+	if (rc != SPHX_OK) return rc;
+	const uint32_t cells = ctx->params.gridSize[0]*ctx->params.gridSize[1]*ctx->params.gridSize[2];
+	const uint32_t bins = 4*cells + 1;
+	const uint32_t lastBin = bins - 1;
+	const uint32_t nb = div_up_u(n, BLOCK_SORT);
+	const uint32_t scanBlocks = div_up_u(bins, SCAN_ITEMS);
+
+	SPHX_HIP(hipMemsetAsync(ctx->bin_count, 0, sizeof(uint32_t)*(size_t)bins, stream));
+	sort_count_kernel<<<nb, BLOCK_SORT, 0, stream>>>(hash, ctx->bin_count, ctx->slot, cells, lastBin, n);
+	SPHX_LAUNCH_CHECK("sort_count_kernel");
+	scan_reduce_kernel<<<scanBlocks, 256, 0, stream>>>(ctx->bin_count, ctx->scan_partials, bins);
+	scan_partials_kernel<<<1, 256, 0, stream>>>(ctx->scan_partials, scanBlocks);
+	scan_final_kernel<<<scanBlocks, 256, 0, stream>>>(ctx->bin_count, ctx->bin_start, ctx->scan_partials, bins);
+	SPHX_LAUNCH_CHECK("scan kernels");
+	sort_scatter_kernel<<<nb, BLOCK_SORT, 0, stream>>>(hash, (const uint2*)info, partIndex, ctx->slot,
+		ctx->bin_start, ctx->tmp_hash, ctx->tmp_info, ctx->tmp_index, cells, lastBin, n);
+	SPHX_LAUNCH_CHECK("sort_scatter_kernel");
+	sort_rank_kernel<<<nb, BLOCK_SORT, 0, stream>>>(ctx->tmp_hash, ctx->tmp_info, ctx->tmp_index,
+		ctx->bin_start, ctx->bin_count, hash, (uint2*)info, partIndex, cells, lastBin, n);
+	SPHX_LAUNCH_CHECK("sort_rank_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_reorder(sphx_ctx *ctx, uint32_t *segmentStart,
+	uint32_t *cellStart, uint32_t *cellEnd,
+	void *sortedPos, void *sortedVel, const void *unsortedPos, const void *unsortedVel,
+	const void *sortedInfo, const uint32_t *sortedHash, const uint32_t *partIndex,
+	uint32_t n, uint32_t *newNumParticles, void *stream_)
+{
+	(void)sortedInfo;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_reorder: constants not set");
+	SPHX_REQUIRE(cellStart && cellEnd && sortedPos && sortedVel && unsortedPos && unsortedVel &&
+		sortedHash && partIndex && newNumParticles, "sphx_reorder: missing buffer");
+	SPHX_REQUIRE(sortedPos != unsortedPos && sortedVel != unsortedVel, "sphx_reorder: sorted and unsorted buffers alias");
+	hipStream_t stream = (hipStream_t)stream_;
+	if (segmentStart)
+		SPHX_HIP(hipMemsetAsync(segmentStart, 0xFF, 4*sizeof(uint32_t), stream)); // EMPTY_SEGMENT
+	if (!n) return SPHX_OK;
+	reorder_kernel<<<div_up_u(n, BLOCK_REORDER), BLOCK_REORDER, 0, stream>>>(cellStart, cellEnd, segmentStart,
+		(float4*)sortedPos, (float4*)sortedVel, (const float4*)unsortedPos, (const float4*)unsortedVel,
+		sortedHash, partIndex, n, newNumParticles);
+	SPHX_LAUNCH_CHECK("reorder_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
+	const void *pos, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint32_t *cellEnd,
+	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t gridCells,
+	float sqinfluenceradius, float boundNlSqInflRad, void *stream)
+{
+	(void)boundNlSqInflRad; (void)numParticles;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_build_neibs: constants not set");
+	SPHX_REQUIRE(neibsList && pos && info && hash && cellStart && cellEnd, "sphx_build_neibs: missing buffer");
+	SPHX_REQUIRE(gridCells == ctx->params.gridSize[0]*ctx->params.gridSize[1]*ctx->params.gridSize[2],
+		"sphx_build_neibs: gridCells does not match the grid set by set_constants");
+	SPHX_REQUIRE(particleRangeEnd <= ctx->params.neiblist_stride, "sphx_build_neibs: range exceeds the neighbour list stride");
+	if (!particleRangeEnd) return SPHX_OK;
+	build_neibs_kernel<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, (hipStream_t)stream>>>(ctx->dev,
+		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd,
+		particleRangeEnd, sqinfluenceradius, ctx->counters_dev);
+	SPHX_LAUNCH_CHECK("build_neibs_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_neibs_resetinfo(sphx_ctx *ctx, void *stream)
+{
+	SPHX_REQUIRE(ctx != nullptr, "sphx_neibs_resetinfo: NULL ctx");
+	NeibsCounters z;
+	std::memset(&z, 0, sizeof(z));
+	z.hasTooManyNeibs = -1;
+	// small H2D of a stack object: use the synchronous-with-respect-to-host staging of hipMemcpyAsync
+	// from pageable memory (the runtime copies the source before returning)
+	SPHX_HIP(hipMemcpyAsync(ctx->counters_dev, &z, sizeof(z), hipMemcpyHostToDevice, (hipStream_t)stream));
+	return SPHX_OK;
+}
+
+extern "C" int sphx_neibs_getinfo(sphx_ctx *ctx, sphx_neibs_info *out, void *stream)
+{
+	SPHX_REQUIRE(ctx && out, "sphx_neibs_getinfo: NULL argument");
+	NeibsCounters c;
+	SPHX_HIP(hipMemcpyAsync(&c, ctx->counters_dev, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+	SPHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+	out->numInteractions = c.numInteractions;
+	out->maxFluidBoundaryNeibs = c.maxFluidBoundaryNeibs;
+	out->maxVertexNeibs = c.maxVertexNeibs;
+	out->hasTooManyNeibs = c.hasTooManyNeibs;
+	for (int i = 0; i < 3; ++i) out->hasMaxNeibs[i] = c.hasMaxNeibs[i];
+	return SPHX_OK;
+}

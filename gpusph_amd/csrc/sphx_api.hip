@@ -1,0 +1,251 @@
+// sphx_api.hip -- context, constants and error plumbing of libsphx (C ABI in include/sphx.h).
+#include "sphx_internal.h"
+#include <cmath>
+#include <cstring>
+
+static thread_local std::string g_last_error;
+
+int sphx_set_error(int code, const std::string &msg)
+{
+	g_last_error = msg;
+	return code;
+}
+
+extern "C" const char *sphx_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *sphx_version(void) { return "sphx 0.1 (gfx950)"; }
+
+extern "C" int sphx_create(sphx_ctx **out, int device)
+{
+	SPHX_REQUIRE(out != nullptr, "sphx_create: out is NULL");
+	int ndev = 0;
+	SPHX_HIP(hipGetDeviceCount(&ndev));
+	if (device < 0 || device >= ndev)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_create: no such HIP device");
+	SPHX_HIP(hipSetDevice(device));
+	sphx_ctx *ctx = new sphx_ctx();
+	memset((void*)ctx, 0, sizeof(*ctx));
+	ctx->device = device;
+	SPHX_HIP(hipMalloc((void**)&ctx->rb_dev, sizeof(RbParams)));
+	SPHX_HIP(hipMemset(ctx->rb_dev, 0, sizeof(RbParams)));
+	SPHX_HIP(hipMalloc((void**)&ctx->counters_dev, sizeof(NeibsCounters)));
+	SPHX_HIP(hipMemset(ctx->counters_dev, 0, sizeof(NeibsCounters)));
+	SPHX_HIP(hipMalloc((void**)&ctx->dt_scratch, 4*sizeof(float)));
+	*out = ctx;
+	return SPHX_OK;
+}
+
+static void free_scratch(sphx_ctx *ctx)
+{
+	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
+		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info };
+	for (void *p : ptrs) if (p) (void)hipFree(p);
+	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
+	ctx->tmp_hash = ctx->tmp_index = nullptr;
+	ctx->tmp_info = nullptr;
+	ctx->reserved_particles = ctx->reserved_bins = 0;
+}
+
+extern "C" void sphx_destroy(sphx_ctx *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	free_scratch(ctx);
+	if (ctx->rb_dev) (void)hipFree(ctx->rb_dev);
+	if (ctx->counters_dev) (void)hipFree(ctx->counters_dev);
+	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
+	delete ctx;
+}
+
+// number of sort bins: one per (cell type, cell) + 1 for inactive particles (CELL_HASH_MAX)
+static uint32_t num_bins(const sphx_ctx *ctx)
+{
+	const uint64_t cells = (uint64_t)ctx->params.gridSize[0]*ctx->params.gridSize[1]*ctx->params.gridSize[2];
+	return (uint32_t)(4*cells + 1);
+}
+
+int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
+{
+	SPHX_REQUIRE(ctx->have_params, "sphx: set_constants must be called before using the engines");
+	const uint32_t bins = num_bins(ctx);
+	if (numParticles <= ctx->reserved_particles && bins <= ctx->reserved_bins)
+		return SPHX_OK;
+	hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+	(void)cs;
+	const uint32_t n = numParticles > ctx->reserved_particles ? numParticles : ctx->reserved_particles;
+	free_scratch(ctx);
+	SPHX_HIP(hipMalloc((void**)&ctx->bin_count, sizeof(uint32_t)*((size_t)bins + 1)));
+	SPHX_HIP(hipMalloc((void**)&ctx->bin_start, sizeof(uint32_t)*((size_t)bins + 1)));
+	SPHX_HIP(hipMalloc((void**)&ctx->scan_partials, sizeof(uint32_t)*((size_t)bins/1024 + 2)));
+	SPHX_HIP(hipMalloc((void**)&ctx->slot, sizeof(uint32_t)*(size_t)n));
+	SPHX_HIP(hipMalloc((void**)&ctx->tmp_hash, sizeof(uint32_t)*(size_t)n));
+	SPHX_HIP(hipMalloc((void**)&ctx->tmp_index, sizeof(uint32_t)*(size_t)n));
+	SPHX_HIP(hipMalloc((void**)&ctx->tmp_info, sizeof(uint2)*(size_t)n));
+	ctx->reserved_particles = n;
+	ctx->reserved_bins = bins;
+	return SPHX_OK;
+}
+
+extern "C" int sphx_reserve(sphx_ctx *ctx, uint32_t maxParticles)
+{
+	SPHX_REQUIRE(ctx != nullptr, "sphx_reserve: ctx is NULL");
+	SPHX_HIP(hipSetDevice(ctx->device));
+	return sphx_ensure_scratch(ctx, maxParticles);
+}
+
+// Kernel coefficients exactly as CUDAForcesEngine::setconstants computes them
+// (src/cuda/forces.cu:274-309): float powers of h, double M_PI, result rounded to float.
+static void kernel_coeffs(const sphx_params &sp, float &wcoeff, float &fcoeff, float &wsub)
+{
+	const float h = sp.slength;
+	const float h2 = h*h;
+	const float h3 = h2*h;
+	const float h4 = h2*h2;
+	const float h5 = h4*h;
+	wsub = 0.0f;
+	switch (sp.kerneltype) {
+	case SPHX_CUBICSPLINE:
+		wcoeff = 1.0f/(M_PI*h3); fcoeff = 3.0f/(4.0f*M_PI*h4); break;
+	case SPHX_QUADRATIC:
+		wcoeff = 15.0f/(16.0f*M_PI*h3); fcoeff = 15.0f/(32.0f*M_PI*h4); break;
+	case SPHX_WENDLAND:
+		wcoeff = 21.0f/(16.0f*M_PI*h3); fcoeff = 105.0f/(128.0f*M_PI*h5); break;
+	case SPHX_GAUSSIAN: {
+		const float R = sp.kernelradius;
+		const float R2 = R*R;
+		const float exp_R2 = exp(-R2);
+		wsub = exp_R2;
+		float kc = -2*exp_R2/3 * h3 * M_PI * R*(3+2*R2)
+			+ h3 * 5.5683279968317078452848179821188357020136243902832439 * erf(R);
+		kc = 1/kc;
+		wcoeff = kc;
+		kc *= 2/h2;
+		fcoeff = kc;
+		break;
+	}
+	default: wcoeff = fcoeff = NAN;
+	}
+}
+
+extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
+{
+	SPHX_REQUIRE(ctx && sp, "sphx_set_constants: NULL argument");
+	SPHX_REQUIRE(sp->gridSize[0] && sp->gridSize[1] && sp->gridSize[2], "sphx_set_constants: empty grid");
+	const uint64_t cells = (uint64_t)sp->gridSize[0]*sp->gridSize[1]*sp->gridSize[2];
+	SPHX_REQUIRE(cells <= (0xFFFFFFFFull >> 2), "sphx_set_constants: more than MAX_CELLS cells"); // multi_gpu_defines.h:54
+	int seen = 0;
+	for (int i = 0; i < 3; ++i) {
+		SPHX_REQUIRE(sp->coord[i] >= 0 && sp->coord[i] < 3, "sphx_set_constants: coord[] must be a permutation of 0,1,2");
+		seen |= 1 << sp->coord[i];
+	}
+	SPHX_REQUIRE(seen == 7, "sphx_set_constants: coord[] must be a permutation of 0,1,2");
+	SPHX_REQUIRE(sp->kerneltype >= SPHX_CUBICSPLINE && sp->kerneltype <= SPHX_GAUSSIAN, "sphx_set_constants: invalid kernel type");
+	SPHX_REQUIRE(sp->numfluids >= 1 && sp->numfluids <= SPHX_MAX_FLUIDS, "sphx_set_constants: numfluids out of range");
+	SPHX_REQUIRE(sp->neiblistsize >= 2 && sp->neibboundpos < sp->neiblistsize, "sphx_set_constants: invalid neighbour list geometry");
+	// option combinations built into this library (the rest is SURVEY.md 8f "next")
+	if (sp->sph_formulation != SPHX_SPH_F1)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only SPH_F1 is built");
+	if (sp->boundarytype != SPHX_DYN_BOUNDARY && sp->boundarytype != SPHX_LJ_BOUNDARY)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only DYN_BOUNDARY and LJ_BOUNDARY neighbour lists are built");
+	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only Colagrossi (or no) density diffusion is built");
+	if (sp->rheologytype != SPHX_INVISCID)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only INVISCID rheology (+ARTIFICIAL or SPS turbulence) is built");
+	if (sp->turbmodel != SPHX_ARTIFICIAL && sp->turbmodel != SPHX_SPS && sp->turbmodel != SPHX_LAMINAR_FLOW)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: turbulence model not built");
+	if (sp->simflags & SPHX_ENABLE_XSPH)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: XSPH is not built");
+
+	ctx->params = *sp;
+	DevParams &d = ctx->dev;
+	memset(&d, 0, sizeof(d));
+	for (int a = 0; a < 3; ++a) { d.gs[a] = (int)sp->gridSize[a]; d.cs[a] = sp->cellSize[a]; }
+	d.c1 = sp->coord[0]; d.c2 = sp->coord[1]; d.c3 = sp->coord[2];
+	d.gs1 = d.gs[d.c1];
+	d.gs12 = d.gs[d.c1]*d.gs[d.c2];
+	d.hs[d.c1] = 1; d.hs[d.c2] = d.gs1; d.hs[d.c3] = d.gs12;
+	d.periodic = sp->periodic;
+	d.neiblistsize = sp->neiblistsize; d.neibboundpos = sp->neibboundpos; d.stride = sp->neiblist_stride;
+	d.kerneltype = sp->kerneltype; d.formulation = sp->sph_formulation; d.densitydiff = sp->densitydiffusiontype;
+	d.boundarytype = sp->boundarytype; d.rheology = sp->rheologytype; d.turbmodel = sp->turbmodel;
+	d.simflags = sp->simflags;
+	d.slength = sp->slength; d.influenceradius = sp->influenceradius; d.deltap = sp->deltap;
+	kernel_coeffs(*sp, d.wcoeff, d.fcoeff, d.wsub_gaussian);
+	d.densityDiffCoeff = sp->densityDiffCoeff; d.epsxsph = sp->epsxsph;
+	d.numfluids = sp->numfluids;
+	for (int f = 0; f < SPHX_MAX_FLUIDS; ++f) {
+		d.rho0[f] = sp->rho0[f]; d.bcoeff[f] = sp->bcoeff[f]; d.gammacoeff[f] = sp->gammacoeff[f];
+		d.sscoeff[f] = sp->sscoeff[f]; d.sspowercoeff[f] = sp->sspowercoeff[f];
+	}
+	for (int a = 0; a < 3; ++a) d.gravity[a] = sp->gravity[a];
+	d.artvisccoeff = sp->artvisccoeff; d.epsartvisc = sp->epsartvisc;
+	d.smagfactor = sp->smagfactor; d.kspsfactor = sp->kspsfactor;
+	ctx->have_params = true;
+	return SPHX_OK;
+}
+
+extern "C" int sphx_get_params(sphx_ctx *ctx, sphx_params *out)
+{
+	SPHX_REQUIRE(ctx && out, "sphx_get_params: NULL argument");
+	SPHX_REQUIRE(ctx->have_params, "sphx_get_params: constants not set");
+	*out = ctx->params;
+	return SPHX_OK;
+}
+
+extern "C" int sphx_set_gravity(sphx_ctx *ctx, const float g[3])
+{
+	SPHX_REQUIRE(ctx && g, "sphx_set_gravity: NULL argument");
+	for (int a = 0; a < 3; ++a) { ctx->params.gravity[a] = g[a]; ctx->dev.gravity[a] = g[a]; }
+	return SPHX_OK;
+}
+
+static int upload_rb(sphx_ctx *ctx)
+{
+	SPHX_HIP(hipSetDevice(ctx->device));
+	// stream-ordered after whatever the default stream holds, like cudaMemcpyToSymbol in the reference
+	SPHX_HIP(hipMemcpy(ctx->rb_dev, &ctx->rb_host, sizeof(RbParams), hipMemcpyHostToDevice));
+	return SPHX_OK;
+}
+
+extern "C" int sphx_set_rb_cg(sphx_ctx *ctx, const int32_t *cgGridPos, const float *cgPos, int numbodies)
+{
+	SPHX_REQUIRE(ctx && cgGridPos && cgPos, "sphx_set_rb_cg: NULL argument");
+	SPHX_REQUIRE(numbodies >= 0 && numbodies <= SPHX_MAX_BODIES, "sphx_set_rb_cg: too many bodies");
+	for (int b = 0; b < numbodies; ++b)
+		for (int a = 0; a < 3; ++a) {
+			ctx->rb_host.cgGridPos[b][a] = cgGridPos[3*b + a];
+			ctx->rb_host.cgPos[b][a] = cgPos[3*b + a];
+		}
+	return upload_rb(ctx);
+}
+
+extern "C" int sphx_set_rb_start(sphx_ctx *ctx, const int32_t *rbfirstindex, int numbodies)
+{
+	SPHX_REQUIRE(ctx && rbfirstindex, "sphx_set_rb_start: NULL argument");
+	SPHX_REQUIRE(numbodies >= 0 && numbodies <= SPHX_MAX_BODIES, "sphx_set_rb_start: too many bodies");
+	for (int b = 0; b < numbodies; ++b) ctx->rb_host.rbstart[b] = rbfirstindex[b];
+	return upload_rb(ctx);
+}
+
+extern "C" int sphx_set_rb_motion(sphx_ctx *ctx, const float *trans, const float *steprot,
+	const float *linearvel, const float *angularvel, int numbodies)
+{
+	SPHX_REQUIRE(ctx != nullptr, "sphx_set_rb_motion: NULL ctx");
+	SPHX_REQUIRE(numbodies >= 0 && numbodies <= SPHX_MAX_BODIES, "sphx_set_rb_motion: too many bodies");
+	for (int b = 0; b < numbodies; ++b) {
+		for (int a = 0; a < 3; ++a) {
+			if (trans) ctx->rb_host.trans[b][a] = trans[3*b + a];
+			if (linearvel) ctx->rb_host.linearvel[b][a] = linearvel[3*b + a];
+			if (angularvel) ctx->rb_host.angularvel[b][a] = angularvel[3*b + a];
+		}
+		if (steprot) for (int a = 0; a < 9; ++a) ctx->rb_host.steprot[b][a] = steprot[9*b + a];
+	}
+	return upload_rb(ctx);
+}
+
+extern "C" int sphx_memset_async(void *ptr, int value, size_t bytes, void *stream)
+{
+	if (!bytes) return SPHX_OK;
+	SPHX_REQUIRE(ptr != nullptr, "sphx_memset_async: NULL pointer");
+	SPHX_HIP(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream));
+	return SPHX_OK;
+}

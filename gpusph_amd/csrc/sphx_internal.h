@@ -1,0 +1,160 @@
+// sphx_internal.h -- shared declarations of the gfx950 WCSPH engine (not part of the C ABI).
+#ifndef SPHX_INTERNAL_H
+#define SPHX_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include "sphx.h"
+
+// ---- data model (GPUSPH: src/particleinfo.h:79-300, src/multi_gpu_defines.h:56-83,
+//      src/common_types.h:57-72, src/hashkey.h:44-47) ------------------------------------------
+typedef ushort4 particleinfo;
+typedef uint16_t neibdata;
+
+#define CELLTYPE_BITMASK   (~(3u << 30))
+#define CELL_HASH_MAX      0xFFFFFFFFu
+#define EMPTY_SEGMENT      0xFFFFFFFFu
+#define CELL_EMPTY         0xFFFFFFFFu
+#define CELLNUM_SHIFT      11
+#define CELLNUM_ENCODED    (1u << CELLNUM_SHIFT)
+#define NEIBINDEX_MASK     (CELLNUM_ENCODED - 1u)
+#define NEIBS_END          0xFFFFu
+
+enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE = 4 };
+#define PART_FLAG_START      (1u << 3)
+#define FG_COMPUTE_FORCE     (PART_FLAG_START << 0)
+#define FG_MOVING_BOUNDARY   (PART_FLAG_START << 1)
+#define FG_SURFACE           (PART_FLAG_START << 6)
+
+#define SPHX_BLOCK_FORCES 128   // one CFL entry per 128 particles (getFmaxElements contract)
+
+// ---- per-kernel constants, passed BY VALUE as a kernel argument (kernarg/SGPR resident;
+//      replaces the reference's ~70 __constant__ symbols, so there is no per-device global
+//      state and one library instance serves any number of devices / host threads) ----------
+struct DevParams {
+	int      gs[3];           // grid size per axis
+	float    cs[3];           // cell size per axis
+	int      hs[3];           // hash stride per axis: hash = gx*hs[0] + gy*hs[1] + gz*hs[2]
+	int      c1, c2, c3;      // axis index of COORD1..3
+	int      gs1, gs12;       // gridSize[COORD1], gridSize[COORD1]*gridSize[COORD2]
+	uint32_t periodic;
+	uint32_t neiblistsize, neibboundpos;
+	uint64_t stride;
+	int      kerneltype, formulation, densitydiff, boundarytype, rheology, turbmodel;
+	uint64_t simflags;
+	float    slength, influenceradius, deltap;
+	float    wcoeff, fcoeff, wsub_gaussian;
+	float    densityDiffCoeff, epsxsph;
+	uint32_t numfluids;
+	float    rho0[SPHX_MAX_FLUIDS], bcoeff[SPHX_MAX_FLUIDS], gammacoeff[SPHX_MAX_FLUIDS];
+	float    sscoeff[SPHX_MAX_FLUIDS], sspowercoeff[SPHX_MAX_FLUIDS];
+	float    gravity[3];
+	float    artvisccoeff, epsartvisc, smagfactor, kspsfactor;
+};
+
+// rigid-body tables live in device memory owned by the ctx (1.6 KB, too big for kernarg)
+struct RbParams {
+	int   cgGridPos[SPHX_MAX_BODIES][3];
+	float cgPos[SPHX_MAX_BODIES][3];
+	int   rbstart[SPHX_MAX_BODIES];
+	float trans[SPHX_MAX_BODIES][3];
+	float steprot[SPHX_MAX_BODIES][9];
+	float linearvel[SPHX_MAX_BODIES][3];
+	float angularvel[SPHX_MAX_BODIES][3];
+};
+
+struct NeibsCounters {   // device counters of cuneibs (src/cuda/buildneibs_kernel.cu:88-93)
+	int numInteractions;
+	int maxFluidBoundaryNeibs;
+	int maxVertexNeibs;
+	int hasTooManyNeibs;
+	int hasMaxNeibs[3];
+	int pad;
+};
+
+struct sphx_ctx {
+	int         device;
+	bool        have_params;
+	sphx_params params;
+	DevParams   dev;
+	RbParams    rb_host;
+	RbParams   *rb_dev;
+	NeibsCounters *counters_dev;
+	// sort scratch
+	uint32_t    reserved_particles;
+	uint32_t    reserved_bins;
+	uint32_t   *bin_count;     // [bins+1]
+	uint32_t   *bin_start;     // [bins+1] exclusive scan
+	uint32_t   *scan_partials; // per scan block
+	uint32_t   *slot;          // [n]
+	uint32_t   *tmp_hash;      // [n]
+	uint32_t   *tmp_index;     // [n]
+	uint2      *tmp_info;      // [n] particleinfo as 8 bytes
+	float      *dt_scratch;    // 1 float, for the sync dtreduce
+};
+
+// ---- error plumbing ---------------------------------------------------------------------------
+int  sphx_set_error(int code, const std::string &msg);
+#define SPHX_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) \
+	return sphx_set_error(SPHX_ERR_RUNTIME, std::string(#call) + ": " + hipGetErrorString(_e)); } while (0)
+#define SPHX_LAUNCH_CHECK(name) do { hipError_t _e = hipGetLastError(); if (_e != hipSuccess) \
+	return sphx_set_error(SPHX_ERR_RUNTIME, std::string("launch of " name ": ") + hipGetErrorString(_e)); } while (0)
+#define SPHX_REQUIRE(cond, msg) do { if (!(cond)) return sphx_set_error(SPHX_ERR_INVALID, msg); } while (0)
+
+static inline uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1)/b; }
+static inline uint32_t round_up_u(uint32_t a, uint32_t b) { return div_up_u(a, b)*b; }
+
+int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles);
+
+// ---- device helpers -----------------------------------------------------------------------------
+#ifdef __HIPCC__
+#define PART_TYPE(f)       ((f).x & 7u)
+#define IS_FLUID(f)        (PART_TYPE(f) == PT_FLUID)
+#define IS_BOUNDARY(f)     (PART_TYPE(f) == PT_BOUNDARY)
+#define IS_VERTEX(f)       (PART_TYPE(f) == PT_VERTEX)
+#define IS_TESTPOINT(f)    (PART_TYPE(f) == PT_TESTPOINT)
+#define IS_MOVING(f)       ((f).x & FG_MOVING_BOUNDARY)
+#define IS_FLOATING(f)     ((f).x & (FG_MOVING_BOUNDARY | FG_COMPUTE_FORCE))
+#define HAS_COMPUTE_FORCE(f) ((f).x & FG_COMPUTE_FORCE)
+#define IS_SURFACE(f)      ((f).x & FG_SURFACE)
+#define FLUID_NUM(f)       ((f).y >> 12)
+#define OBJECT_NUM(f)      ((f).y & 0xfffu)
+
+__device__ __forceinline__ uint32_t info_id(const particleinfo &i) { return (uint32_t)i.z | ((uint32_t)i.w << 16); }
+__device__ __forceinline__ bool is_active_w(float w) { return (__float_as_uint(w) & 0x7f800000u) != 0x7f800000u; }
+
+// calcGridHash (src/cuda/cellgrid.cuh:98-104) with run-time linearisation
+__device__ __forceinline__ uint32_t grid_hash(const DevParams &p, int gx, int gy, int gz)
+{
+	return (uint32_t)(gx*p.hs[0] + gy*p.hs[1] + gz*p.hs[2]);
+}
+
+// calcGridPosFromCellHash (src/cuda/cellgrid.cuh:115-127)
+__device__ __forceinline__ int3 grid_pos_from_hash(const DevParams &p, uint32_t cellHash)
+{
+	const int q3 = (int)(cellHash / (uint32_t)p.gs12);
+	const int rem = (int)cellHash - q3*p.gs12;
+	const int q2 = rem / p.gs1;
+	const int q1 = rem - q2*p.gs1;
+	int3 g;
+	g.x = (p.c1 == 0) ? q1 : ((p.c2 == 0) ? q2 : q3);
+	g.y = (p.c1 == 1) ? q1 : ((p.c2 == 1) ? q2 : q3);
+	g.z = (p.c1 == 2) ? q1 : ((p.c2 == 2) ? q2 : q3);
+	return g;
+}
+
+// calcGridHashPeriodic (src/cuda/cellgrid.cuh:177-187)
+__device__ __forceinline__ uint32_t grid_hash_periodic(const DevParams &p, int gx, int gy, int gz)
+{
+	if (gx < 0) gx = p.gs[0] - 1;
+	if (gx >= p.gs[0]) gx = 0;
+	if (gy < 0) gy = p.gs[1] - 1;
+	if (gy >= p.gs[1]) gy = 0;
+	if (gz < 0) gz = p.gs[2] - 1;
+	if (gz >= p.gs[2]) gz = 0;
+	return grid_hash(p, gx, gy, gz);
+}
+#endif // __HIPCC__
+
+#endif

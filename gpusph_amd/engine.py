@@ -1,0 +1,233 @@
+"""One-GPU WCSPH timestep driver.
+
+Mirrors the command stream GPUSPH's host side sends to one GPUWorker (paths relative to the
+GPUSPH tree), calling the HIP engines through the C ABI (include/sphx.h):
+
+  neighbour phase  Integrator::buildNeibsPhase          src/Integrator.cc:94-250
+                   GPUWorker::runCommand<CALCHASH..BUILDNEIBS>   src/GPUWorker.cc:1779-1905
+  predictor/corr.  PredictorCorrector::initializePredCorrSequence
+                                                         src/integrators/PredictorCorrectorIntegrator.cc:386-685
+                   runCommand<FORCES_SYNC>, <EULER>      src/GPUWorker.cc:2188-2270
+  dt feedback      GPUWorker.cc:2226-2229, GPUSPH.cc:636-699 (dt_next = min over both passes)
+
+MI355X-first differences from the reference's control flow (results are unchanged):
+  * the adaptive dt stays on the device: dtreduce writes a device scalar that the next
+    step's Euler kernels read, so a step issues no host<->device synchronisation at all
+    (the reference does a blocking 4-byte D2H after every forces pass);
+  * everything is enqueued on one HIP stream and can be captured into a hipGraph;
+  * torch is only the allocator / stream provider here.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import defs as D
+from . import capi
+
+
+def _dev_u32(arr, device):
+    return torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(device)
+
+
+class TimestepEngine:
+    def __init__(self, problem, device="cuda:0", allocated=None, clobber_neibslist=False,
+                 track_particle_count=True):
+        if not torch.cuda.is_available():
+            raise capi.SphxError("TimestepEngine needs a HIP device (there is no CPU fallback)")
+        self.problem = problem
+        self.device = torch.device(device)
+        self.dev_index = self.device.index or 0
+        torch.cuda.set_device(self.device)
+        self.lib = capi.load()
+        self.ctx = capi.Context(self.dev_index)
+        arrs = problem.copy_to_array()
+        self.n = len(arrs["hash"])
+        self.alloc = int(allocated or self.n)
+        self.params = problem.sphx_params(self.alloc)
+        self.ctx.set_constants(self.params)
+        self.ctx.reserve(self.alloc)
+        sp, pp = problem.simparams, problem.physparams
+        self.sp = sp
+        self.ncells = problem.grid_cells
+        self.clobber_neibslist = clobber_neibslist
+        self.track_particle_count = track_particle_count
+        dev = self.device
+        A = self.alloc
+        f32, i32, i16 = torch.float32, torch.int32, torch.int16
+
+        def up4(a):
+            t = torch.zeros((A, 4), dtype=f32, device=dev)
+            t[: self.n] = torch.from_numpy(a).to(dev)
+            return t
+
+        # state "step n" and "step n*" (double buffered like BUFFER_POS / BUFFER_VEL)
+        self.pos = up4(arrs["pos"]); self.vel = up4(arrs["vel"])
+        self.pos2 = torch.zeros_like(self.pos); self.vel2 = torch.zeros_like(self.vel)
+        self.info = torch.zeros((A, 4), dtype=i16, device=dev)
+        self.info[: self.n] = torch.from_numpy(arrs["info"].view(np.int16)).to(dev)
+        self.hash = torch.zeros(A, dtype=i32, device=dev)
+        self.hash[: self.n] = _dev_u32(arrs["hash"], dev)
+        self.partindex = torch.zeros(A, dtype=i32, device=dev)
+        self.cellStart = torch.empty(self.ncells, dtype=i32, device=dev)
+        self.cellEnd = torch.empty(self.ncells, dtype=i32, device=dev)
+        self.neibslist = torch.empty(int(sp.neiblistsize) * A, dtype=i16, device=dev)
+        self.forces = torch.zeros((A, 4), dtype=f32, device=dev)
+        self.cfl_elems = int(self.lib.sphx_forces_fmax_elements(A))
+        self.cfl = torch.zeros(self.cfl_elems, dtype=f32, device=dev)
+        self.cfl_temp = torch.zeros(max(int(self.lib.sphx_forces_fmax_temp_elements(self.cfl_elems)), 4), dtype=f32, device=dev)
+        self.new_num = torch.zeros(1, dtype=i32, device=dev)
+        self.segment_start = torch.zeros(4, dtype=i32, device=dev)
+        self.num_bodies_parts = getattr(problem, "num_obstacle", 0)
+        self.rbforces = torch.zeros((max(self.num_bodies_parts, 1), 4), dtype=f32, device=dev)
+        self.rbtorques = torch.zeros_like(self.rbforces)
+        # device-resident time step: dt of the current step, and the running min for the next
+        self.dt = float(np.float32(sp.dt))
+        self.d_dt = torch.full((1,), self.dt, dtype=f32, device=dev)
+        self.d_dt_next = torch.full((1,), self.dt, dtype=f32, device=dev)
+        self.d_t = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.iterations = 0
+        self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(pp.sscoeff))) * 1.1))  # GPUWorker.cc:3010-3011
+        self.max_kinvisc = 0.0
+        self.compute_object_forces = 1 if sp.numforcesbodies > 0 else 0
+        if self.num_bodies_parts:
+            gp = np.ascontiguousarray(problem.rb_cg_gridpos, dtype=np.int32)
+            lp = np.ascontiguousarray(problem.rb_cg_pos, dtype=np.float32)
+            fi = np.ascontiguousarray(problem.rb_firstindex, dtype=np.int32)
+            nb = len(fi)
+            capi.check(self.lib.sphx_set_rb_cg(self.ctx.handle, gp.ctypes.data, lp.ctypes.data, nb))
+            capi.check(self.lib.sphx_set_rb_start(self.ctx.handle, fi.ctypes.data, nb))
+            ident = np.tile(np.eye(3, dtype=np.float32).ravel(), nb)
+            z3 = np.zeros(3 * nb, dtype=np.float32)
+            capi.check(self.lib.sphx_set_rb_motion(self.ctx.handle, z3.ctypes.data, ident.ctypes.data,
+                                                   z3.ctypes.data, z3.ctypes.data, nb))
+        self.sq_nl_radius = float(np.float32(sp.nlSqInfluenceRadius))
+        self.last_neibs_info = None
+        self.profile_forces = None   # list of (start,end) torch events around each forces launch when enabled
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _memset(self, t, value, stream):
+        capi.check(self.lib.sphx_memset_async(t.data_ptr(), value, t.numel() * t.element_size(), stream))
+
+    # ------------------------------------------------------------------ neighbour phase
+    def build_neibs(self):
+        L, h, s = self.lib, self.ctx.handle, self._stream()
+        n = self.n
+        p = capi.ptr
+        if self.iterations == 0:
+            capi.check(L.sphx_fix_hash(h, p(self.hash), p(self.partindex), p(self.info), None, n, s))
+        else:
+            capi.check(L.sphx_calc_hash(h, p(self.pos), p(self.hash), p(self.partindex), p(self.info), None, n, s))
+        capi.check(L.sphx_sort(h, p(self.hash), p(self.info), p(self.partindex), n, s))
+        self._memset(self.cellStart, 0xFF, s)
+        self._memset(self.cellEnd, 0xFF, s)
+        capi.check(L.sphx_reorder(h, None, p(self.cellStart), p(self.cellEnd), p(self.pos2), p(self.vel2),
+                                  p(self.pos), p(self.vel), p(self.info), p(self.hash), p(self.partindex),
+                                  n, p(self.new_num), s))
+        self.pos, self.pos2 = self.pos2, self.pos
+        self.vel, self.vel2 = self.vel2, self.vel
+        if self.track_particle_count:
+            self.n = int(self.new_num.item()) & 0xFFFFFFFF   # DOWNLOAD_NEWNUMPARTS (sync), GPUWorker.cc:1471-1515
+            n = self.n
+        if self.clobber_neibslist:
+            self._memset(self.neibslist, 0xFF, s)
+        capi.check(L.sphx_neibs_resetinfo(h, s))
+        capi.check(L.sphx_build_neibs(h, p(self.neibslist), p(self.pos), p(self.info), p(self.hash),
+                                      p(self.cellStart), p(self.cellEnd), n, n, self.ncells,
+                                      self.sq_nl_radius, self.sq_nl_radius, s))
+
+    def neibs_info(self):
+        """getinfo + CHECK_NEIBSNUM (GPUSPH.cc:1850-1880); synchronises."""
+        info = capi.NeibsInfo()
+        capi.check(self.lib.sphx_neibs_getinfo(self.ctx.handle, C.byref(info), self._stream()))
+        self.last_neibs_info = info
+        if info.hasTooManyNeibs >= 0:
+            raise capi.SphxError("particle id %d has too many neighbours (%d fluid + %d boundary)"
+                                 % (info.hasTooManyNeibs, info.hasMaxNeibs[0], info.hasMaxNeibs[1]))
+        return info
+
+    # ------------------------------------------------------------------ forces / euler
+    def _forces(self, pos, vel, step, combine_min):
+        L, h, s = self.lib, self.ctx.handle, self._stream()
+        p = capi.ptr
+        sp = self.sp
+        n = self.n
+        nb = C.c_uint32(0)
+        rb = self.num_bodies_parts > 0
+        prof = self.profile_forces is not None
+        if prof:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        capi.check(L.sphx_forces_basicstep(h, p(self.forces), p(self.cfl), p(self.rbforces) if rb else None,
+                                           p(self.rbtorques) if rb else None, p(pos), p(vel), p(self.info), p(self.hash),
+                                           p(self.cellStart), p(self.neibslist), None, None, None,
+                                           n, 0, n, self.params.deltap, self.params.slength, self.params.dtadaptfactor,
+                                           self.params.influenceradius, 0, D.SIMULATE, step, self.dt,
+                                           self.compute_object_forces, C.byref(nb), s))
+        if prof:
+            e1.record()
+            self.profile_forces.append((e0, e1))
+        capi.check(L.sphx_forces_dtreduce_device(h, self.params.slength, self.params.dtadaptfactor, self.sspeed_cfl,
+                                                 self.max_kinvisc, p(self.cfl), p(self.cfl_temp), nb.value,
+                                                 p(self.d_dt_next), combine_min, s))
+
+    def _euler(self, step, dt_scale):
+        L, h, s = self.lib, self.ctx.handle, self._stream()
+        p = capi.ptr
+        n = self.n
+        capi.check(L.sphx_euler_basicstep(h, p(self.pos2), p(self.vel2), p(self.pos), p(self.vel), p(self.info),
+                                          p(self.hash), p(self.forces), None, n, n, 0.0, p(self.d_dt), dt_scale,
+                                          step, 0.0, self.params.slength, self.params.influenceradius, D.SIMULATE, s))
+
+    def step(self):
+        """one full predictor-corrector time step; no host synchronisation."""
+        if self.iterations % self.sp.buildneibsfreq == 0:
+            self.build_neibs()
+        # predictor: forces(step n) -> n* = n + dt/2 f
+        self._forces(self.pos, self.vel, 1, 0)
+        self._euler(1, 0.5)
+        # corrector: forces(step n*) -> n+1 = n + dt f*   (written over n*, then renamed to n)
+        self._forces(self.pos2, self.vel2, 2, 1)
+        self._euler(2, 1.0)
+        self.pos, self.pos2 = self.pos2, self.pos
+        self.vel, self.vel2 = self.vel2, self.vel
+        # TIME_STEP_EPILOGUE: t += dt ; dt = min(dt_pred, dt_corr)
+        self.d_t.add_(self.d_dt.double())
+        self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt
+        self.iterations += 1
+
+    def run(self, steps):
+        for _ in range(steps):
+            self.step()
+
+    # ------------------------------------------------------------------ host views
+    def current_dt(self):
+        return float(self.d_dt.item())
+
+    def time(self):
+        return float(self.d_t.item())
+
+    def download(self):
+        n = self.n
+        out = {
+            "pos": self.pos[:n].cpu().numpy(), "vel": self.vel[:n].cpu().numpy(),
+            "info": self.info[:n].cpu().numpy().view(np.uint16),
+            "hash": self.hash[:n].cpu().numpy().view(np.uint32),
+            "forces": self.forces[:n].cpu().numpy(),
+        }
+        return out
+
+    def reduce_rb_forces(self):
+        """REDUCE_BODIES_FORCES for the single obstacle body; returns (force3, torque3)."""
+        if not self.num_bodies_parts:
+            return None
+        nbp = self.num_bodies_parts
+        keys = torch.zeros(nbp, dtype=torch.int32, device=self.device)
+        last = np.array([nbp - 1], dtype=np.uint32)
+        tf = np.zeros(3, dtype=np.float32); tt = np.zeros(3, dtype=np.float32)
+        capi.check(self.lib.sphx_reduce_rb_forces(self.ctx.handle, capi.ptr(self.rbforces), capi.ptr(self.rbtorques),
+                                                  capi.ptr(keys), last.ctypes.data, tf.ctypes.data, tt.ctypes.data,
+                                                  1, nbp, self._stream()))
+        return tf, tt

@@ -1,0 +1,176 @@
+"""SimParams / PhysParams mirror (GPUSPH src/simparams.h:262-389, src/physparams.h) and their
+flattening into the C ABI's sphx_params (include/sphx.h)."""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+import numpy as np
+from . import defs as D
+
+
+class SphxParams(C.Structure):
+    """ctypes image of `struct sphx_params` (include/sphx.h) -- keep field order in sync."""
+    _fields_ = [
+        ("gridSize", C.c_uint32 * 3), ("cellSize", C.c_float * 3), ("worldOrigin", C.c_float * 3),
+        ("coord", C.c_int32 * 3), ("periodic", C.c_uint32),
+        ("neiblistsize", C.c_uint32), ("neibboundpos", C.c_uint32), ("neiblist_stride", C.c_uint64),
+        ("kerneltype", C.c_int32), ("sph_formulation", C.c_int32), ("densitydiffusiontype", C.c_int32),
+        ("boundarytype", C.c_int32), ("rheologytype", C.c_int32), ("turbmodel", C.c_int32),
+        ("compvisc", C.c_int32), ("viscmodel", C.c_int32), ("avgop", C.c_int32),
+        ("simflags", C.c_uint64),
+        ("slength", C.c_float), ("kernelradius", C.c_float), ("influenceradius", C.c_float),
+        ("deltap", C.c_float), ("dtadaptfactor", C.c_float), ("densityDiffCoeff", C.c_float),
+        ("epsxsph", C.c_float),
+        ("numfluids", C.c_uint32),
+        ("rho0", C.c_float * 4), ("bcoeff", C.c_float * 4), ("gammacoeff", C.c_float * 4),
+        ("sscoeff", C.c_float * 4), ("sspowercoeff", C.c_float * 4), ("visccoeff", C.c_float * 4),
+        ("gravity", C.c_float * 3),
+        ("artvisccoeff", C.c_float), ("epsartvisc", C.c_float),
+        ("smagfactor", C.c_float), ("kspsfactor", C.c_float),
+        ("dcoeff", C.c_float), ("p1coeff", C.c_float), ("p2coeff", C.c_float), ("r0", C.c_float),
+    ]
+
+
+@dataclass
+class PhysParams:
+    """src/physparams.h: defaults :380-420, set_equation_of_state :506-516."""
+    rho0: list = field(default_factory=list)
+    bcoeff: list = field(default_factory=list)
+    gammacoeff: list = field(default_factory=list)
+    sscoeff: list = field(default_factory=list)
+    sspowercoeff: list = field(default_factory=list)
+    visccoeff: list = field(default_factory=list)
+    gravity: tuple = (0.0, 0.0, -9.81)
+    artvisccoeff: float = 0.3          # physparams.h:392
+    epsartvisc: float = float("nan")   # defaulted to 0.01 h^2 in ProblemCore.cc:160-163
+    smagfactor: float = float("nan")
+    kspsfactor: float = float("nan")
+    dcoeff: float = 0.0
+    p1coeff: float = 12.0
+    p2coeff: float = 6.0
+    r0: float = float("nan")
+
+    def numFluids(self):
+        return len(self.rho0)
+
+    def add_fluid(self, rho):
+        self.rho0.append(float(np.float32(rho)))
+        for lst in (self.bcoeff, self.gammacoeff, self.sscoeff, self.sspowercoeff, self.visccoeff):
+            lst.append(float("nan"))
+        return len(self.rho0) - 1
+
+    def set_equation_of_state(self, fluid_idx, gamma, c0):
+        if fluid_idx >= self.numFluids():
+            raise IndexError("trying to set equation of state for a non-existing fluid")
+        f32 = np.float32
+        g, c = f32(gamma), f32(c0)
+        self.gammacoeff[fluid_idx] = float(g)
+        self.bcoeff[fluid_idx] = float(f32(f32(f32(self.rho0[fluid_idx]) * c) * c) / g)
+        self.sscoeff[fluid_idx] = float(c)
+        self.sspowercoeff[fluid_idx] = float((g - f32(1)) / f32(2))
+
+
+@dataclass
+class SimParams:
+    """src/simparams.h:262-314 defaults."""
+    kerneltype: int = D.WENDLAND
+    sph_formulation: int = D.SPH_F1
+    densitydiffusiontype: int = D.DENSITY_DIFFUSION_NONE
+    boundarytype: int = D.LJ_BOUNDARY
+    rheologytype: int = D.INVISCID
+    turbmodel: int = D.ARTIFICIAL
+    compvisc: int = D.KINEMATIC
+    viscmodel: int = D.MORRIS
+    avgop: int = D.ARITHMETIC
+    periodicbound: int = D.PERIODIC_NONE
+    simflags: int = D.ENABLE_DTADAPT
+    sfactor: float = 1.3
+    kernelradius: float = 2.0
+    slength: float = 0.0
+    influenceRadius: float = 0.0
+    nlexpansionfactor: float = 1.0
+    nlInfluenceRadius: float = 0.0
+    nlSqInfluenceRadius: float = 0.0
+    dtadaptfactor: float = 0.3
+    buildneibsfreq: int = 10
+    neiblistsize: int = 0
+    neibboundpos: int = 0
+    densityDiffCoeff: float = float("nan")
+    epsxsph: float = 0.5
+    dt: float = 0.0
+    numbodies: int = 0
+    numforcesbodies: int = 0
+
+    def set_smoothing(self, smooth, deltap):
+        """simparams.h:325-336 (double arithmetic)."""
+        self.sfactor = smooth
+        self.slength = smooth * deltap
+        self.set_influenceradius()
+        return self.slength
+
+    def set_influenceradius(self):
+        """simparams.h:368-375."""
+        self.influenceRadius = self.slength * self.kernelradius
+        self.nlInfluenceRadius = self.nlexpansionfactor * self.influenceRadius
+        self.nlSqInfluenceRadius = self.nlInfluenceRadius * self.nlInfluenceRadius
+        return self.influenceRadius
+
+
+def check_neiblistsize(sp: SimParams, pp: PhysParams, deltap: float):
+    """ProblemCore::check_neiblistsize (src/ProblemCore.cc:806-887), non-SA branch."""
+    r = math.ceil(sp.sfactor * sp.kernelradius)
+    vol = math.ceil(4 * 3.2 * r * r * r / 3)
+    neiblistsize = ((int(vol) + 31) // 32) * 32
+    qq = deltap / pp.r0 if pp.r0 and not math.isnan(pp.r0) else 1.0
+    ratio = max(qq * qq / r, 1.0)
+    neiblistsize = int(math.ceil(ratio * neiblistsize))
+    neiblistsize = ((neiblistsize + 31) // 32) * 32
+    if sp.neiblistsize == 0:
+        sp.neiblistsize = neiblistsize
+    if sp.neibboundpos == 0:
+        sp.neibboundpos = sp.neiblistsize - 1
+    return sp.neiblistsize, sp.neibboundpos
+
+
+def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origin, deltap,
+                     allocated, linearization=D.DEFAULT_LINEARIZATION) -> SphxParams:
+    """What the three setconstants() calls upload (src/cuda/forces.cu:268-399 etc.)."""
+    p = SphxParams()
+    f32 = lambda v: float(np.float32(v))
+    for a in range(3):
+        p.gridSize[a] = int(gridsize[a])
+        p.cellSize[a] = f32(cellsize[a])
+        p.worldOrigin[a] = f32(origin[a])
+        p.coord[a] = D.LINEARIZATIONS[linearization][a]
+        p.gravity[a] = f32(pp.gravity[a])
+    p.periodic = sp.periodicbound
+    p.neiblistsize = sp.neiblistsize
+    p.neibboundpos = sp.neibboundpos
+    p.neiblist_stride = int(allocated)
+    p.kerneltype = sp.kerneltype
+    p.sph_formulation = sp.sph_formulation
+    p.densitydiffusiontype = sp.densitydiffusiontype
+    p.boundarytype = sp.boundarytype
+    p.rheologytype = sp.rheologytype
+    p.turbmodel = sp.turbmodel
+    p.compvisc = sp.compvisc
+    p.viscmodel = sp.viscmodel
+    p.avgop = sp.avgop
+    p.simflags = sp.simflags
+    p.slength = f32(sp.slength)
+    p.kernelradius = f32(sp.kernelradius)
+    p.influenceradius = f32(sp.influenceRadius)
+    p.deltap = f32(deltap)
+    p.dtadaptfactor = f32(sp.dtadaptfactor)
+    p.densityDiffCoeff = f32(sp.densityDiffCoeff) if not math.isnan(sp.densityDiffCoeff) else 0.0
+    p.epsxsph = f32(sp.epsxsph)
+    p.numfluids = pp.numFluids()
+    for f in range(pp.numFluids()):
+        p.rho0[f] = f32(pp.rho0[f]); p.bcoeff[f] = f32(pp.bcoeff[f]); p.gammacoeff[f] = f32(pp.gammacoeff[f])
+        p.sscoeff[f] = f32(pp.sscoeff[f]); p.sspowercoeff[f] = f32(pp.sspowercoeff[f])
+        p.visccoeff[f] = f32(pp.visccoeff[f]) if not math.isnan(pp.visccoeff[f]) else 0.0
+    p.artvisccoeff = f32(pp.artvisccoeff)
+    p.epsartvisc = f32(pp.epsartvisc)
+    nz = lambda v: 0.0 if (v is None or math.isnan(v)) else f32(v)
+    p.smagfactor = nz(pp.smagfactor); p.kspsfactor = nz(pp.kspsfactor)
+    p.dcoeff = nz(pp.dcoeff); p.p1coeff = nz(pp.p1coeff); p.p2coeff = nz(pp.p2coeff); p.r0 = nz(pp.r0)
+    return p

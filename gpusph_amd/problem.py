@@ -1,0 +1,319 @@
+"""Problem-style host set-up of the synthetic "uniform dam-break box" (SURVEY.md 8d).
+
+Mirrors, on the host and in numpy, the parts of GPUSPH's Problem API that decide what the
+engines see (paths relative to the GPUSPH tree):
+  DamBreak3D ctor            src/problems/DamBreak3D.cu:37-214  (geometry, options, EOS)
+  ProblemCore::set_grid_params           src/ProblemCore.cc:1432-1508
+  ProblemCore::calc_localpos_and_hash    src/ProblemCore.cc:1553-1583
+  ProblemCore::check_neiblistsize        src/ProblemCore.cc:806-887
+  ProblemCore::check_dt                  src/ProblemCore.cc:748-800
+  ProblemAPI<1>::copy_to_array (ids)     src/problem_api/ProblemAPI_1.cc:1766-1817
+The particle fill is a deterministic lattice (no RNG unless `jitter` is requested, then
+numpy default_rng(12345)); it follows DamBreak3D's layout -- 1.6 x 0.67 x 0.6 box with 3 layers
+of dynamic-boundary particles on the inside of every face, a 0.4 x (Ly-6dp) x 0.4 water column
+3 dp away from the walls, optional 0.12 x 0.12 x 0.6 obstacle at x = 0.9 -- but it is NOT claimed
+to reproduce GPUSPH's Cube::Fill particle-for-particle.
+"""
+from dataclasses import dataclass
+import math
+import numpy as np
+from . import defs as D
+from .params import SimParams, PhysParams, check_neiblistsize, make_sphx_params
+
+INFO_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("z", "<u2"), ("w", "<u2")])
+
+
+def make_particleinfo(ptype_flags, obj_fluid, ids):
+    """particleinfo = ushort4 {type|flags, fluid<<12|object, id lo, id hi} (src/particleinfo.h:50-79)."""
+    n = len(ids)
+    info = np.zeros((n, 4), dtype=np.uint16)
+    info[:, 0] = ptype_flags
+    info[:, 1] = obj_fluid
+    ids = np.asarray(ids, dtype=np.uint32)
+    info[:, 2] = ids & 0xFFFF
+    info[:, 3] = ids >> 16
+    return info
+
+
+def info_id(info):
+    return info[:, 2].astype(np.uint32) | (info[:, 3].astype(np.uint32) << 16)
+
+
+def info_type(info):
+    return info[:, 0] & 7
+
+
+def _lattice(i0, i1, j0, j1, k0, k1):
+    """integer lattice indices of the closed box [i0,i1]x[j0,j1]x[k0,k1] as (n,3) int32."""
+    if i1 < i0 or j1 < j0 or k1 < k0:
+        return np.zeros((0, 3), dtype=np.int32)
+    ii, jj, kk = np.meshgrid(np.arange(i0, i1 + 1, dtype=np.int32),
+                             np.arange(j0, j1 + 1, dtype=np.int32),
+                             np.arange(k0, k1 + 1, dtype=np.int32), indexing="ij")
+    return np.stack([ii.ravel(), jj.ravel(), kk.ravel()], axis=1)
+
+
+@dataclass
+class HostParticles:
+    pos_global: np.ndarray   # (n,4) float64 : x,y,z,mass
+    vel: np.ndarray          # (n,4) float32 : vx,vy,vz,rho_tilde
+    info: np.ndarray         # (n,4) uint16
+
+
+class Problem:
+    """The slice of ProblemCore the hot path depends on."""
+
+    def __init__(self):
+        self.simparams = SimParams()
+        self.physparams = PhysParams()
+        self.m_deltap = 0.0
+        self.m_origin = np.zeros(3)
+        self.m_size = np.zeros(3)
+        self.m_gridsize = np.zeros(3, dtype=np.int64)
+        self.m_cellsize = np.zeros(3)
+        self.linearization = D.DEFAULT_LINEARIZATION
+        self.m_name = "Problem"
+        self.parts = None
+
+    # -- ProblemCore::set_deltap / set_smoothing --
+    def set_deltap(self, dp):
+        self.m_deltap = float(np.float32(dp))
+        self.simparams.set_smoothing(self.simparams.sfactor, self.m_deltap)
+
+    # -- ProblemCore::set_grid_params (src/ProblemCore.cc:1432-1508) --
+    def set_grid_params(self):
+        sp = self.simparams
+        if sp.nlInfluenceRadius < sp.influenceRadius:
+            raise RuntimeError("neighbor search radius < kernel influence radius")
+        cellSide = sp.nlInfluenceRadius
+        self.m_gridsize = np.floor(self.m_size / cellSide).astype(np.int64)
+        if (self.m_gridsize == 0).any():
+            raise RuntimeError("resolution %g is too low! Resulting grid size would be %s" % (sp.slength, self.m_gridsize))
+        self.m_cellsize = self.m_size / self.m_gridsize
+        if int(np.prod(self.m_gridsize)) > D.MAX_CELLS:
+            raise RuntimeError("too many cells")
+
+    # -- ProblemCore::check_dt (src/ProblemCore.cc:748-800), inviscid branch --
+    def check_dt(self):
+        sp, pp = self.simparams, self.physparams
+        f32 = np.float32
+        dt_ss = min(f32(sp.slength) / f32(c) for c in pp.sscoeff) * f32(sp.dtadaptfactor)
+        g = math.sqrt(sum(x * x for x in pp.gravity))
+        dt_g = f32(math.sqrt(sp.slength / g)) * f32(sp.dtadaptfactor) if g > 0 else np.inf
+        cfl_dt = float(min(dt_ss, dt_g))
+        if not sp.dt:
+            sp.dt = cfl_dt
+        return sp.dt
+
+    # -- ProblemCore::calc_grid_pos / calc_localpos_and_hash (src/ProblemCore.cc:1513-1583) --
+    def calc_grid_pos(self, pos):
+        g = np.floor((pos[:, :3] - self.m_origin) / self.m_cellsize).astype(np.int64)
+        return np.clip(g, 0, self.m_gridsize - 1)
+
+    def calc_grid_hash(self, g):
+        c1, c2, c3 = D.LINEARIZATIONS[self.linearization]
+        gs = self.m_gridsize
+        return ((g[:, c3] * gs[c2]) * gs[c1] + g[:, c2] * gs[c1] + g[:, c1]).astype(np.uint32)
+
+    def calc_localpos_and_hash(self, pos_global):
+        g = self.calc_grid_pos(pos_global)
+        h = self.calc_grid_hash(g)
+        local = np.empty((len(pos_global), 4), dtype=np.float32)
+        local[:, :3] = (pos_global[:, :3] - self.m_origin - (g + 0.5) * self.m_cellsize).astype(np.float32)
+        local[:, 3] = pos_global[:, 3].astype(np.float32)
+        return local, h
+
+    def global_pos(self, local_pos, hashes):
+        """inverse of calc_localpos_and_hash, in float64 (for analysis / tests)."""
+        g = self.grid_pos_from_hash(hashes)
+        return self.m_origin + (g + 0.5) * self.m_cellsize + local_pos[:, :3].astype(np.float64)
+
+    def grid_pos_from_hash(self, hashes):
+        c1, c2, c3 = D.LINEARIZATIONS[self.linearization]
+        gs = self.m_gridsize
+        h = (np.asarray(hashes, dtype=np.int64) & D.CELLTYPE_BITMASK)
+        g = np.empty((len(h), 3), dtype=np.int64)
+        t = gs[c2] * gs[c1]
+        g[:, c3] = h // t
+        rem = h - g[:, c3] * t
+        g[:, c2] = rem // gs[c1]
+        g[:, c1] = rem - g[:, c2] * gs[c1]
+        return g
+
+    def initialize(self):
+        """ProblemCore::initialize order: grid, neighbour list size, defaults, dt."""
+        sp, pp = self.simparams, self.physparams
+        self.set_grid_params()
+        if math.isnan(pp.r0):
+            pp.r0 = self.m_deltap
+        check_neiblistsize(sp, pp, self.m_deltap)
+        if math.isnan(pp.epsartvisc):   # ProblemCore.cc:160-163
+            pp.epsartvisc = float(np.float32(0.01 * sp.slength * sp.slength))
+        if sp.densitydiffusiontype == D.COLAGROSSI:  # ProblemCore.cc:1406-1416
+            if math.isnan(sp.densityDiffCoeff):
+                sp.densityDiffCoeff = float(np.float32(0.1))
+            sp.densityDiffCoeff = float(np.float32(np.float32(sp.densityDiffCoeff) * np.float32(2.0) * np.float32(sp.slength)))
+        self.check_dt()
+
+    def sphx_params(self, allocated):
+        return make_sphx_params(self.simparams, self.physparams, gridsize=self.m_gridsize,
+                                cellsize=self.m_cellsize, origin=self.m_origin, deltap=self.m_deltap,
+                                allocated=allocated, linearization=self.linearization)
+
+    def copy_to_array(self):
+        """host arrays as GPUSPH uploads them: cell-local float4 pos, float4 vel, ushort4 info, hash."""
+        local, h = self.calc_localpos_and_hash(self.parts.pos_global)
+        return {"pos": local, "vel": self.parts.vel.copy(), "info": self.parts.info.copy(), "hash": h}
+
+    @property
+    def num_particles(self):
+        return len(self.parts.info)
+
+    @property
+    def grid_cells(self):
+        return int(np.prod(self.m_gridsize))
+
+
+class DamBreak3D(Problem):
+    """Synthetic DamBreak3D (src/problems/DamBreak3D.cu:37-214): WENDLAND, SPH_F1, COLAGROSSI,
+    ARTVISC (INVISCID + ARTIFICIAL), DYN_BOUNDARY, no periodicity, ENABLE_DTADAPT|ENABLE_REPACKING,
+    3 dynamic-boundary layers, 128-slot neighbour list, c0 = 20, gamma = 7, rho0 = 1000, xi = 0.1."""
+
+    DIM = (1.6, 0.67, 0.6)
+    WATER_LENGTH = 0.4
+    H = 0.4
+    OBSTACLE_SIDE = 0.12
+    OBSTACLE_XPOS = 0.9
+    LAYERS = 3
+
+    def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
+                 jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND):
+        super().__init__()
+        self.m_name = "DamBreak3D"
+        sp, pp = self.simparams, self.physparams
+        sp.kerneltype = kerneltype
+        if kerneltype == D.GAUSSIAN:
+            sp.kernelradius = 3.0
+        sp.boundarytype = D.DYN_BOUNDARY
+        sp.rheologytype = D.INVISCID
+        sp.turbmodel = D.ARTIFICIAL
+        sp.densitydiffusiontype = density_diffusion
+        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | (D.ENABLE_MOVING_BODIES if obstacle else 0)
+        sp.neiblistsize = 128               # resize_neiblist(128), DamBreak3D.cu:76
+        sp.densityDiffCoeff = 0.1           # DamBreak3D.cu:95
+        self.linearization = linearization
+        self.set_deltap(deltap)
+        pp.gravity = (0.0, 0.0, -9.81)
+        pp.add_fluid(1000.0)
+        pp.set_equation_of_state(0, 7.0, 20.0)
+        self.m_origin = np.zeros(3)
+        self.m_size = np.array(self.DIM, dtype=np.float64)
+        self.obstacle = obstacle
+        self.hydrostatic = hydrostatic
+        self.jitter = jitter
+        if obstacle:
+            sp.numbodies = 1
+            sp.numforcesbodies = 1
+        self.initialize()
+        self.fill_parts()
+
+    # analytic particle count for a given dp (used to hit a target N)
+    @classmethod
+    def count(cls, dp, obstacle=True):
+        n = [int(round(L / dp)) for L in cls.DIM]
+        total = (n[0] + 1) * (n[1] + 1) * (n[2] + 1)
+        inner = max(n[0] + 1 - 2 * cls.LAYERS, 0) * max(n[1] + 1 - 2 * cls.LAYERS, 0) * max(n[2] + 1 - 2 * cls.LAYERS, 0)
+        walls = total - inner
+        bd = cls.LAYERS * dp
+        fl = [int(round(L / dp)) + 1 for L in (cls.WATER_LENGTH - bd, cls.DIM[1] - 2 * bd, cls.H - bd)]
+        fluid = fl[0] * fl[1] * fl[2]
+        obst = 0
+        if obstacle:
+            m = int(round(cls.OBSTACLE_SIDE / dp)) + 1
+            mz = n[2] + 1 - 2 * cls.LAYERS
+            obst = (m * m - max(m - 2 * cls.LAYERS, 0) ** 2) * mz
+        return fluid + walls + obst
+
+    @classmethod
+    def deltap_for(cls, target, obstacle=True):
+        lo, hi = 1e-4, 0.2
+        for _ in range(80):
+            mid = math.sqrt(lo * hi)
+            if cls.count(mid, obstacle) > target:
+                lo = mid
+            else:
+                hi = mid
+        return float(np.float32(hi))
+
+    def fill_parts(self):
+        dp = self.m_deltap
+        L = self.m_size
+        n = [int(round(L[a] / dp)) for a in range(3)]
+        dx = [L[a] / n[a] for a in range(3)]
+        Lr = self.LAYERS
+        # --- walls: three layers on the inside of each face (DYN_BOUNDARY, FillIn with -layers) ---
+        slabs = [
+            _lattice(0, n[0], 0, n[1], 0, Lr - 1), _lattice(0, n[0], 0, n[1], n[2] - Lr + 1, n[2]),
+            _lattice(0, n[0], 0, Lr - 1, Lr, n[2] - Lr), _lattice(0, n[0], n[1] - Lr + 1, n[1], Lr, n[2] - Lr),
+            _lattice(0, Lr - 1, Lr, n[1] - Lr, Lr, n[2] - Lr), _lattice(n[0] - Lr + 1, n[0], Lr, n[1] - Lr, Lr, n[2] - Lr),
+        ]
+        wall_idx = np.concatenate(slabs, axis=0)
+        wall = wall_idx.astype(np.float64) * np.array(dx)
+        # --- water column (DamBreak3D.cu:139-145) ---
+        bd = Lr * dp
+        fsize = np.array([self.WATER_LENGTH - bd, L[1] - 2 * bd, self.H - bd])
+        fn = [max(int(round(fsize[a] / dp)), 1) for a in range(3)]
+        fdx = fsize / np.array(fn)
+        fluid = _lattice(0, fn[0], 0, fn[1], 0, fn[2]).astype(np.float64) * fdx + bd
+        if self.jitter:
+            rng = np.random.default_rng(12345)
+            fluid = fluid + rng.uniform(-self.jitter * dp, self.jitter * dp, size=fluid.shape)
+        # --- obstacle: axis-aligned 3-layer shell standing on the floor layers (DamBreak3D.cu:160-178) ---
+        obst = np.zeros((0, 3))
+        if self.obstacle:
+            m = max(int(round(self.OBSTACLE_SIDE / dp)), 1)
+            odx = self.OBSTACLE_SIDE / m
+            o = _lattice(0, m, 0, m, 0, n[2] - 2 * Lr)
+            shell = ((o[:, 0] < Lr) | (o[:, 0] > m - Lr) | (o[:, 1] < Lr) | (o[:, 1] > m - Lr))
+            o = o[shell].astype(np.float64)
+            ox0 = self.OBSTACLE_XPOS
+            oy0 = L[1] / 2 - self.OBSTACLE_SIDE / 2
+            obst = np.stack([ox0 + o[:, 0] * odx, oy0 + o[:, 1] * odx, (Lr + o[:, 2]) * dx[2]], axis=1)
+        nf, nw, no = len(fluid), len(wall), len(obst)
+        ntot = nf + nw + no
+        pos = np.empty((ntot, 4), dtype=np.float64)
+        pos[:nf, :3] = fluid
+        pos[nf:nf + nw, :3] = wall
+        pos[nf + nw:, :3] = obst
+        rho0 = self.physparams.rho0[0]
+        pos[:, 3] = rho0 * dp ** 3           # mass = rho0 dp^3
+        vel = np.zeros((ntot, 4), dtype=np.float32)
+        if self.hydrostatic:
+            # rho~ from the hydrostatic pressure under the initial free surface (inverse Tait EOS)
+            B = self.physparams.bcoeff[0]
+            gam = self.physparams.gammacoeff[0]
+            g = -self.physparams.gravity[2]
+            depth = np.clip(self.H - pos[:, 2], 0.0, None)
+            in_col = pos[:, 0] <= self.WATER_LENGTH + 0.5 * dp
+            depth = np.where(in_col, depth, 0.0)
+            vel[:, 3] = (np.power(1.0 + rho0 * g * depth / B, 1.0 / gam) - 1.0).astype(np.float32)
+        # ids: sequential, fluid first then boundary then bodies (ProblemAPI_1.cc:1766-1817)
+        ids = np.arange(ntot, dtype=np.uint32)
+        tf = np.empty(ntot, dtype=np.uint16)
+        tf[:nf] = D.PT_FLUID
+        tf[nf:nf + nw] = D.PT_BOUNDARY
+        tf[nf + nw:] = D.PT_BOUNDARY | D.FG_MOVING_BOUNDARY | D.FG_COMPUTE_FORCE
+        objfl = np.zeros(ntot, dtype=np.uint16)   # fluid number 0; object number 0 for the obstacle
+        info = make_particleinfo(tf, objfl, ids)
+        self.parts = HostParticles(pos, vel, info)
+        self.num_fluid, self.num_wall, self.num_obstacle = nf, nw, no
+        # rigid body bookkeeping (GPUSPH.cc: s_hRbFirstIndex = -(first id of the body), rbcg)
+        self.rb_firstindex = np.array([-(nf + nw)], dtype=np.int32) if no else np.zeros(0, dtype=np.int32)
+        if no:
+            cg = np.array([[self.OBSTACLE_XPOS + self.OBSTACLE_SIDE / 2, L[1] / 2, L[2] / 2, 0.0]])
+            g = self.calc_grid_pos(cg)
+            self.rb_cg_gridpos = g.astype(np.int32)
+            self.rb_cg_pos = (cg[:, :3] - self.m_origin - (g + 0.5) * self.m_cellsize).astype(np.float32)
+        else:
+            self.rb_cg_gridpos = np.zeros((0, 3), dtype=np.int32)
+            self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)

@@ -1,0 +1,219 @@
+/*
+ * sphx.h -- C ABI of the MI355X-native WCSPH timestep engine (libsphx.so).
+ *
+ * This is the drop-in boundary for GPUSPH's per-step hot path.  Each entry point replaces
+ * one virtual of the reference's abstract engines (paths relative to the GPUSPH tree):
+ *
+ *   AbstractNeibsEngine        src/engine_neibs.h:46-107
+ *   AbstractForcesEngine       src/engine_forces.h:43-180
+ *   AbstractViscEngine         src/engine_visc.h:42-109
+ *   AbstractIntegrationEngine  src/engine_integration.h:42-144
+ *
+ * The reference selects physics at compile time through template arguments
+ * (CUDASimFramework<kernel<>, boundary<>, ...>, src/cuda/cudasimframework.cu:379-606); here
+ * the same options travel in the run-time POD `sphx_params` and select pre-compiled kernel
+ * specialisations inside the library.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every array pointer is a DEVICE pointer unless the name
+ *     starts with h_.  Element types follow src/define_buffers.h:48-235:
+ *       pos, vel, forces, rbforces, rbtorques : float4     info : ushort4 (particleinfo)
+ *       hash, partIndex, cellStart, cellEnd   : uint32     neibsList : uint16 (neibdata)
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are
+ *     stream-ordered and do not synchronise the host unless documented ("sync").
+ *   - one sphx_ctx per device (the per-device __constant__ state of the reference); a ctx may
+ *     be used from one host thread at a time, different ctxs concurrently (GPUWorker model,
+ *     src/GPUWorker.cc:3238-3331).
+ *   - every function returns SPHX_OK (0) or a negative status; sphx_last_error() gives the
+ *     message of the last failure on the calling thread.  The C++ adapters in
+ *     gpusph_amd/host/ rethrow it as std::runtime_error / std::invalid_argument like
+ *     CUDA_SAFE_CALL / KERNEL_CHECK_ERROR do (src/cuda/cuda_call.h:57-85).
+ *   - callers clobber output buffers exactly as GPUWorker does (FORCES/CFL = 0,
+ *     NEIBSLIST/CELLSTART/CELLEND = 0xFF; src/GPUWorker.cc:1847,1885,1949-1979).
+ */
+#ifndef SPHX_H
+#define SPHX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPHX_OK              0
+#define SPHX_ERR_INVALID    -1   /* inconsistent arguments (std::invalid_argument in the reference) */
+#define SPHX_ERR_RUNTIME    -2   /* HIP runtime / launch failure (std::runtime_error) */
+#define SPHX_ERR_UNSUPPORTED -3  /* option combination not built into this library */
+
+#define SPHX_MAX_FLUIDS 4        /* MAX_FLUID_TYPES, src/particledefine.h:327 */
+#define SPHX_MAX_BODIES 16       /* MAX_BODIES, src/particledefine.h:329 */
+
+/* Option codes carry the reference's enum values (src/particledefine.h:79-224, src/visc_spec.h) */
+enum sphx_kernel      { SPHX_CUBICSPLINE = 1, SPHX_QUADRATIC = 2, SPHX_WENDLAND = 3, SPHX_GAUSSIAN = 4 };
+enum sphx_formulation { SPHX_SPH_F1 = 1, SPHX_SPH_F2 = 2, SPHX_SPH_GRENIER = 3, SPHX_SPH_HA = 4 };
+enum sphx_densitydiff { SPHX_DENSITY_DIFFUSION_NONE = 0, SPHX_FERRARI = 1, SPHX_COLAGROSSI = 2, SPHX_BREZZI = 3 };
+enum sphx_boundary    { SPHX_LJ_BOUNDARY = 0, SPHX_MK_BOUNDARY = 1, SPHX_SA_BOUNDARY = 2, SPHX_DYN_BOUNDARY = 3 };
+enum sphx_rheology    { SPHX_INVISCID = 0, SPHX_NEWTONIAN = 1 };
+enum sphx_turbulence  { SPHX_LAMINAR_FLOW = 0, SPHX_ARTIFICIAL = 1, SPHX_SPS = 2, SPHX_KEPSILON = 3 };
+enum sphx_runmode     { SPHX_REPACK = 0, SPHX_SIMULATE = 1 };
+#define SPHX_PERIODIC_X 1u
+#define SPHX_PERIODIC_Y 2u
+#define SPHX_PERIODIC_Z 4u
+/* simflags, src/simflags.h:62-160 */
+#define SPHX_ENABLE_DTADAPT        (1ull << 0)
+#define SPHX_ENABLE_XSPH           (1ull << 1)
+#define SPHX_ENABLE_PLANES         (1ull << 2)
+#define SPHX_ENABLE_DEM            (1ull << 3)
+#define SPHX_ENABLE_MOVING_BODIES  (1ull << 4)
+#define SPHX_ENABLE_REPACKING      (1ull << 9)
+
+/* Everything the three setconstants() upload (src/cuda/forces.cu:268-399,
+ * src/cuda/buildneibs.cu:85-96, src/cuda/euler.cu:51-69), as one POD. */
+typedef struct sphx_params {
+	/* grid: d_worldOrigin, d_cellSize, d_gridSize (src/cuda/cellgrid.cuh:63-66) */
+	uint32_t gridSize[3];
+	float    cellSize[3];
+	float    worldOrigin[3];
+	int32_t  coord[3];            /* axis (0=x,1=y,2=z) of COORD1,COORD2,COORD3 (src/linearization.h); yzx = {1,2,0} */
+	uint32_t periodic;            /* Periodicity bits */
+	/* neighbour list geometry: d_neiblistsize, d_neibboundpos, d_neiblist_stride */
+	uint32_t neiblistsize;
+	uint32_t neibboundpos;
+	uint64_t neiblist_stride;     /* = allocated particles */
+	/* framework options (template parameters in the reference) */
+	int32_t  kerneltype, sph_formulation, densitydiffusiontype, boundarytype;
+	int32_t  rheologytype, turbmodel, compvisc, viscmodel, avgop;
+	uint64_t simflags;
+	/* SimParams */
+	float    slength, kernelradius, influenceradius, deltap, dtadaptfactor;
+	float    densityDiffCoeff;    /* Colagrossi: xi*2h (src/ProblemCore.cc:1406-1416) */
+	float    epsxsph;
+	/* PhysParams */
+	uint32_t numfluids;
+	float    rho0[SPHX_MAX_FLUIDS], bcoeff[SPHX_MAX_FLUIDS], gammacoeff[SPHX_MAX_FLUIDS];
+	float    sscoeff[SPHX_MAX_FLUIDS], sspowercoeff[SPHX_MAX_FLUIDS], visccoeff[SPHX_MAX_FLUIDS];
+	float    gravity[3];
+	float    artvisccoeff, epsartvisc;
+	float    smagfactor, kspsfactor;
+	float    dcoeff, p1coeff, p2coeff, r0;
+} sphx_params;
+
+/* TimingInfo fields filled by getinfo (src/timing.h:43-100, src/cuda/buildneibs.cu:137-145) */
+typedef struct sphx_neibs_info {
+	int32_t numInteractions;
+	int32_t maxFluidBoundaryNeibs;
+	int32_t maxVertexNeibs;
+	int32_t hasTooManyNeibs;
+	int32_t hasMaxNeibs[3];
+} sphx_neibs_info;
+
+typedef struct sphx_ctx sphx_ctx;
+
+/* ---- lifetime / errors ------------------------------------------------------------------ */
+const char *sphx_last_error(void);
+const char *sphx_version(void);
+/* creates the per-device state on HIP device `device` (hipSetDevice is called) */
+int  sphx_create(sphx_ctx **out, int device);
+void sphx_destroy(sphx_ctx *ctx);
+/* pre-allocates internal scratch (sort bins, scan partials) so that no allocation happens
+ * inside the step (required before stream capture into a hipGraph) */
+int  sphx_reserve(sphx_ctx *ctx, uint32_t maxParticles);
+
+/* ---- constants: {Neibs,Forces,Integration}Engine::setconstants --------------------------- */
+int sphx_set_constants(sphx_ctx *ctx, const sphx_params *params);
+int sphx_get_params(sphx_ctx *ctx, sphx_params *out);
+/* AbstractForcesEngine::setgravity (src/engine_forces.h) */
+int sphx_set_gravity(sphx_ctx *ctx, const float h_gravity[3]);
+/* AbstractForcesEngine::setrbcg / setrbstart; AbstractIntegrationEngine::setrbcg/setrbtrans/
+ * setrbsteprot/setrblinearvel/setrbangularvel (src/engine_integration.h) */
+int sphx_set_rb_cg(sphx_ctx *ctx, const int32_t *h_cgGridPos3, const float *h_cgPos3, int numbodies);
+int sphx_set_rb_start(sphx_ctx *ctx, const int32_t *h_rbfirstindex, int numbodies);
+int sphx_set_rb_motion(sphx_ctx *ctx, const float *h_trans3, const float *h_steprot9,
+	const float *h_linearvel3, const float *h_angularvel3, int numbodies);
+
+/* ---- AbstractNeibsEngine ------------------------------------------------------------------ */
+/* calcHash (src/cuda/buildneibs.cu:157-175): pos and hash updated in place, partIndex[i]=i */
+int sphx_calc_hash(sphx_ctx *ctx, void *pos, uint32_t *hash, uint32_t *partIndex,
+	const void *info, const uint32_t *compactDeviceMap, uint32_t numParticles, void *stream);
+/* fixHash (src/cuda/buildneibs.cu:182-197) */
+int sphx_fix_hash(sphx_ctx *ctx, uint32_t *hash, uint32_t *partIndex,
+	const void *info, const uint32_t *compactDeviceMap, uint32_t numParticles, void *stream);
+/* sort (src/cuda/buildneibs.cu:384-412): sorts (hash, info) keys and partIndex values in place
+ * by (hash incl. cell-type bits, PART_TYPE, id) */
+int sphx_sort(sphx_ctx *ctx, uint32_t *hash, void *info, uint32_t *partIndex,
+	uint32_t numParticles, void *stream);
+/* reorderDataAndFindCellStart (src/cuda/buildneibs.cu:213-354).  segmentStart (4 uint) and
+ * newNumParticles (1 uint) are device pointers; segmentStart may be NULL. */
+int sphx_reorder(sphx_ctx *ctx, uint32_t *segmentStart,
+	uint32_t *cellStart, uint32_t *cellEnd,
+	void *sortedPos, void *sortedVel,
+	const void *unsortedPos, const void *unsortedVel,
+	const void *sortedInfo, const uint32_t *sortedHash, const uint32_t *partIndex,
+	uint32_t numParticles, uint32_t *newNumParticles, void *stream);
+/* buildNeibsList (src/cuda/buildneibs.cu:421-492) */
+int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
+	const void *pos, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint32_t *cellEnd,
+	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t gridCells,
+	float sqinfluenceradius, float boundNlSqInflRad, void *stream);
+/* resetinfo / getinfo (src/cuda/buildneibs.cu:119-145); getinfo is sync */
+int sphx_neibs_resetinfo(sphx_ctx *ctx, void *stream);
+int sphx_neibs_getinfo(sphx_ctx *ctx, sphx_neibs_info *h_out, void *stream);
+
+/* ---- AbstractForcesEngine ----------------------------------------------------------------- */
+uint32_t sphx_forces_fmax_elements(uint32_t n);       /* getFmaxElements, src/cuda/forces.cu:539-543 */
+uint32_t sphx_forces_fmax_temp_elements(uint32_t n);  /* getFmaxTempElements, :548-552 */
+uint32_t sphx_forces_round_particles(uint32_t n);     /* round_particles, :960-964 */
+/* basicstep (src/cuda/forces.cu:897-935): pair summation over [fromParticle,toParticle) +
+ * finalize (gravity, /rho0, CFL block maxima into cfl[cflOffset..]).  tau0..2 may be NULL
+ * (SPS only), rbforces/rbtorques may be NULL.  *h_numBlocks receives the return value of
+ * the reference's basicstep (#CFL elements written). */
+int sphx_forces_basicstep(sphx_ctx *ctx,
+	void *forces, float *cfl, void *rbforces, void *rbtorques,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *tau0, const void *tau1, const void *tau2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius,
+	uint32_t cflOffset, int run_mode, int step, float dt, int compute_object_forces,
+	uint32_t *h_numBlocks, void *stream);
+/* dtreduce (src/cuda/forces.cu:556-606): sync, returns dt through *h_dt */
+int sphx_forces_dtreduce(sphx_ctx *ctx, float slength, float dtadaptfactor, float sspeed_cfl,
+	float max_kinematic, const float *cfl, float *cflTemp, uint32_t numBlocks,
+	float *h_dt, void *stream);
+/* device-resident variant (no host sync): d_dt[0] = (combine_min ? min(d_dt[0], dt) : dt) */
+int sphx_forces_dtreduce_device(sphx_ctx *ctx, float slength, float dtadaptfactor, float sspeed_cfl,
+	float max_kinematic, const float *cfl, float *cflTemp, uint32_t numBlocks,
+	float *d_dt, int combine_min, void *stream);
+/* reduceRbForces (src/cuda/forces.cu:966-1004): sync; h_total* receive 3 floats per body */
+int sphx_reduce_rb_forces(sphx_ctx *ctx, void *rbforces, void *rbtorques, const uint32_t *rbnum,
+	const uint32_t *h_lastindex, float *h_totalforce3, float *h_totaltorque3,
+	uint32_t numforcesbodies, uint32_t numForcesBodiesParticles, void *stream);
+
+/* ---- AbstractViscEngine ------------------------------------------------------------------- */
+/* calc_visc, SPS branch (src/cuda/visc.cu:175-234): tau0..2 are float2 arrays, turbvisc may be NULL */
+int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2, float *spsturbvisc,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd,
+	float deltap, float slength, float influenceradius, void *stream);
+
+/* ---- AbstractIntegrationEngine ------------------------------------------------------------ */
+/* basicstep (src/cuda/euler.cu:329-366).  dt is the step's dt or dt/2 exactly as the
+ * reference passes it; if d_dt is not NULL the kernel instead uses d_dt[0]*dt_scale read on
+ * the device (no host round trip of the adaptive dt). */
+int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
+	const void *oldPos, const void *oldVel, const void *info, const uint32_t *hash,
+	const void *forces, const void *xsph,
+	uint32_t numParticles, uint32_t particleRangeEnd,
+	float dt, const float *d_dt, float dt_scale, int step, float t,
+	float slength, float influenceradius, int run_mode, void *stream);
+
+/* ---- small stream-ordered helpers the callers of the reference get from cudaMemset -------- */
+int sphx_memset_async(void *ptr, int value, size_t bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPHX_H */

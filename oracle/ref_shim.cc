@@ -1,0 +1,93 @@
+// ref_shim.cc -- exports, with C linkage, the parts of the GPUSPH reference that compile
+// AS THEY ARE (sources included from /root/reference where they lie, nothing copied, no
+// stand-ins for missing headers / intrinsics / generated files) with g++ and the CUDA
+// headers that ship inside this image's triton package:
+//   src/cuda/sph_core.cu      W<>, F<> for all four kernel types
+//   src/particleinfo.h        id(), PART_TYPE, flag predicates, object(), fluid_num()
+//   src/hashkey.h, src/multi_gpu_defines.h   cellHashFromParticleHash, CELLTYPE_* constants
+//   src/common_types.h        ENCODE_CELL / DECODE_CELL / NEIBINDEX_MASK / NEIBS_END
+// Everything else on the hot path needs nvcc (__powf, texture references, thrust) or the
+// Makefile-generated options/*.opt files and is therefore NOT built (DESIGN.md "Oracle").
+// TEST INFRASTRUCTURE ONLY: used to pin oracle/sph_oracle.c and to generate tests/golden/ref_*.npz.
+#include <cuda_runtime.h>
+#include <math.h>
+#include <climits>
+#include "particledefine.h"
+#include "sph_core.cu"
+
+extern "C" {
+
+float ref_W(int kerneltype, float r, float slength, float coeff, float wsub_gaussian)
+{
+	switch (kerneltype) {
+	case CUBICSPLINE: cusph::d_wcoeff_cubicspline = coeff; return cusph::W<CUBICSPLINE>(r, slength);
+	case QUADRATIC:   cusph::d_wcoeff_quadratic = coeff;   return cusph::W<QUADRATIC>(r, slength);
+	case WENDLAND:    cusph::d_wcoeff_wendland = coeff;    return cusph::W<WENDLAND>(r, slength);
+	case GAUSSIAN:    cusph::d_wcoeff_gaussian = coeff; cusph::d_wsub_gaussian = wsub_gaussian;
+	                  return cusph::W<GAUSSIAN>(r, slength);
+	}
+	return NAN;
+}
+
+float ref_F(int kerneltype, float r, float slength, float coeff)
+{
+	switch (kerneltype) {
+	case CUBICSPLINE: cusph::d_fcoeff_cubicspline = coeff; return cusph::F<CUBICSPLINE>(r, slength);
+	case QUADRATIC:   cusph::d_fcoeff_quadratic = coeff;   return cusph::F<QUADRATIC>(r, slength);
+	case WENDLAND:    cusph::d_fcoeff_wendland = coeff;    return cusph::F<WENDLAND>(r, slength);
+	case GAUSSIAN:    cusph::d_fcoeff_gaussian = coeff;    return cusph::F<GAUSSIAN>(r, slength);
+	}
+	return NAN;
+}
+
+static particleinfo mk(unsigned short x, unsigned short y, unsigned short z, unsigned short w)
+{ particleinfo i; i.x = x; i.y = y; i.z = z; i.w = w; return i; }
+
+unsigned ref_info_id(unsigned short x, unsigned short y, unsigned short z, unsigned short w) { return id(mk(x,y,z,w)); }
+int ref_info_part_type(unsigned short x, unsigned short y, unsigned short z, unsigned short w) { return PART_TYPE(mk(x,y,z,w)); }
+int ref_info_object(unsigned short x, unsigned short y, unsigned short z, unsigned short w) { return object(mk(x,y,z,w)); }
+int ref_info_fluid_num(unsigned short x, unsigned short y, unsigned short z, unsigned short w) { return fluid_num(mk(x,y,z,w)); }
+// bit0 FLUID, bit1 BOUNDARY, bit2 VERTEX, bit3 TESTPOINT, bit4 MOVING, bit5 FLOATING, bit6 COMPUTE_FORCE, bit7 SURFACE
+unsigned ref_info_predicates(unsigned short x, unsigned short y, unsigned short z, unsigned short w)
+{
+	const particleinfo f = mk(x,y,z,w);
+	return (FLUID(f) ? 1u : 0) | (BOUNDARY(f) ? 2u : 0) | (VERTEX(f) ? 4u : 0) | (TESTPOINT(f) ? 8u : 0) |
+		(MOVING(f) ? 16u : 0) | (FLOATING(f) ? 32u : 0) | (COMPUTE_FORCE(f) ? 64u : 0) | (SURFACE(f) ? 128u : 0);
+}
+int ref_active(float w) { float4 p = make_float4(0, 0, 0, w); return ACTIVE(p) ? 1 : 0; }
+
+unsigned ref_cell_hash_from_particle_hash(unsigned h, int preserve) { return cellHashFromParticleHash(h, preserve != 0); }
+unsigned ref_encode_cell(unsigned cell) { return ENCODE_CELL(cell); }
+int ref_decode_cell(unsigned data) { return DECODE_CELL(data); }
+// 0 CELLTYPE_BITMASK, 1 CELL_HASH_MAX, 2 NEIBINDEX_MASK, 3 NEIBS_END, 4 CELLNUM_ENCODED,
+// 5..8 CELLTYPE_*_SHIFTED (inner, inner edge, outer edge, outer), 9 EMPTY_SEGMENT, 10 MAX_CELLS
+unsigned ref_constant(int which)
+{
+	switch (which) {
+	case 0: return CELLTYPE_BITMASK;
+	case 1: return CELL_HASH_MAX;
+	case 2: return NEIBINDEX_MASK;
+	case 3: return NEIBS_END;
+	case 4: return CELLNUM_ENCODED;
+	case 5: return CELLTYPE_INNER_CELL_SHIFTED;
+	case 6: return CELLTYPE_INNER_EDGE_CELL_SHIFTED;
+	case 7: return CELLTYPE_OUTER_EDGE_CELL_SHIFTED;
+	case 8: return CELLTYPE_OUTER_CELL_SHIFTED;
+	case 9: return EMPTY_SEGMENT;
+	case 10: return MAX_CELLS;
+	}
+	return 0;
+}
+// enum values, to pin the numeric option codes of include/sphx.h
+// 0..3 kernels, 4 SPH_F1, 5 COLAGROSSI, 6 DYN_BOUNDARY, 7 LJ_BOUNDARY, 8 PERIODIC_Z
+int ref_enum(int which)
+{
+	switch (which) {
+	case 0: return CUBICSPLINE; case 1: return QUADRATIC; case 2: return WENDLAND; case 3: return GAUSSIAN;
+	case 4: return SPH_F1; case 5: return COLAGROSSI; case 6: return DYN_BOUNDARY; case 7: return LJ_BOUNDARY;
+	case 8: return PERIODIC_Z; case 9: return SA_BOUNDARY; case 10: return FERRARI;
+	}
+	return -1;
+}
+
+} // extern "C"

@@ -1,0 +1,990 @@
+/*
+ * sph_oracle.c -- CPU oracle for the WCSPH timestep hot path (TEST INFRASTRUCTURE ONLY).
+ * See sph_oracle.h for scope, pinning status and floating-point conventions.
+ * Every function cites the reference source (relative to /root/reference) it restates.
+ *
+ * Build: oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp)
+ */
+#include "sph_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- data-model constants --------------------------------------------------------- */
+/* src/multi_gpu_defines.h:56-83, src/hashkey.h:44-47, src/common_types.h:57-72 */
+#define CELLTYPE_BITMASK   (~(3u << 30))
+#define CELL_HASH_MAX      UINT_MAX
+#define EMPTY_SEGMENT      UINT_MAX
+#define CELL_EMPTY         UINT_MAX
+#define CELLNUM_SHIFT      11
+#define CELLNUM_ENCODED    (1u << CELLNUM_SHIFT)
+#define NEIBINDEX_MASK     (CELLNUM_ENCODED - 1)
+#define ENCODE_CELL(cell)  (((cell) + 1) << CELLNUM_SHIFT)
+#define DECODE_CELL(data)  (((data) >> CELLNUM_SHIFT) - 1)
+#define NEIBS_END          USHRT_MAX
+/* src/particleinfo.h:144-300 */
+enum { PT_FLUID = 0, PT_BOUNDARY, PT_VERTEX, PT_TESTPOINT, PT_NONE };
+#define PART_FLAG_START      (1 << 3)
+#define FG_COMPUTE_FORCE     (PART_FLAG_START << 0)
+#define FG_MOVING_BOUNDARY   (PART_FLAG_START << 1)
+#define FG_SURFACE           (PART_FLAG_START << 6)
+#define PART_TYPE(f)         ((f).x & 7)
+#define FLUID(f)             (PART_TYPE(f) == PT_FLUID)
+#define BOUNDARY(f)          (PART_TYPE(f) == PT_BOUNDARY)
+#define VERTEX(f)            (PART_TYPE(f) == PT_VERTEX)
+#define TESTPOINT(f)         (PART_TYPE(f) == PT_TESTPOINT)
+#define MOVING(f)            ((f).x & FG_MOVING_BOUNDARY)
+#define FLOATING(f)          ((f).x & (FG_MOVING_BOUNDARY | FG_COMPUTE_FORCE))
+#define COMPUTE_FORCE(f)     ((f).x & FG_COMPUTE_FORCE)
+#define SURFACE(f)           ((f).x & FG_SURFACE)
+#define ACTIVE(p)            (isfinite((p).w))
+#define INACTIVE(p)          (!ACTIVE(p))
+#define FLUID_NUM(f)         ((f).y >> 12)
+#define OBJECT_NUM(f)        ((f).y & 0xfff)
+
+#define BLOCK_SIZE_FORCES 128   /* src/cuda/forces.cu (BLOCK_SIZE_FORCES) */
+#define BLOCK_SIZE_FMAX   256
+
+/* src/particleinfo.h:437-441 */
+uint32_t orc_info_id(orc_info i) { return (uint32_t)i.z | ((uint32_t)i.w << 16); }
+int orc_info_type(orc_info i) { return PART_TYPE(i); }
+
+int orc_num_threads(void)
+{
+#ifdef _OPENMP
+	return omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
+
+/* ---- kernel functions: src/cuda/sph_core.cu:66-191 -------------------------------- */
+
+/* coefficients: src/cuda/forces.cu:274-309 (computed in double, stored as float) */
+float orc_wcoeff(int kerneltype, float slength, float kernelradius)
+{
+	const float h = slength;
+	const float h2 = h*h;
+	const float h3 = h2*h;
+	switch (kerneltype) {
+	case ORC_CUBICSPLINE: return (float)(1.0f/(M_PI*h3));
+	case ORC_QUADRATIC:   return (float)(15.0f/(16.0f*M_PI*h3));
+	case ORC_WENDLAND:    return (float)(21.0f/(16.0f*M_PI*h3));
+	case ORC_GAUSSIAN: {
+		const float R = kernelradius;
+		const float R2 = R*R;
+		const float exp_R2 = exp(-R2);
+		float kc = -2*exp_R2/3 * h3 * M_PI * R*(3+2*R2)
+			+ h3 * 5.5683279968317078452848179821188357020136243902832439 * erf(R);
+		kc = 1/kc;
+		return kc;
+	}
+	}
+	return NAN;
+}
+
+float orc_fcoeff(int kerneltype, float slength, float kernelradius)
+{
+	const float h = slength;
+	const float h2 = h*h;
+	const float h4 = h2*h2;
+	const float h5 = h4*h;
+	switch (kerneltype) {
+	case ORC_CUBICSPLINE: return (float)(3.0f/(4.0f*M_PI*h4));
+	case ORC_QUADRATIC:   return (float)(15.0f/(32.0f*M_PI*h4));
+	case ORC_WENDLAND:    return (float)(105.0f/(128.0f*M_PI*h5));
+	case ORC_GAUSSIAN: {
+		float kc = orc_wcoeff(ORC_GAUSSIAN, slength, kernelradius);
+		kc *= 2/h2;
+		return kc;
+	}
+	}
+	return NAN;
+}
+
+/* kernel value with an explicit coefficient (coefficient lives in __constant__ in the reference) */
+static float W_c(int kerneltype, float r, float slength, float coeff, float wsub_gaussian)
+{
+	const float R = r/slength;
+	float val;
+	switch (kerneltype) {
+	case ORC_CUBICSPLINE: /* sph_core.cu:72-84 */
+		if (R < 1)
+			val = 1.0f - 1.5f*R*R + 0.75f*R*R*R;
+		else
+			val = 0.25f*(2.0f - R)*(2.0f - R)*(2.0f - R);
+		return val*coeff;
+	case ORC_QUADRATIC: /* sph_core.cu:90-99 */
+		val = 0.25f*R*R - R + 1.0f;
+		return val*coeff;
+	case ORC_WENDLAND: /* sph_core.cu:105-118 */
+		val = 1.0f - 0.5f*R;
+		val *= val;
+		val *= val;
+		val *= 1.0f + 2.0f*R;
+		return val*coeff;
+	case ORC_GAUSSIAN: /* sph_core.cu:128-137 */
+		val = expf(-R*R);
+		val -= wsub_gaussian;
+		return val*coeff;
+	}
+	return NAN;
+}
+
+static float F_c(int kerneltype, float r, float slength, float coeff)
+{
+	const float R = r/slength;
+	float val;
+	switch (kerneltype) {
+	case ORC_CUBICSPLINE: /* sph_core.cu:146-158 */
+		if (R < 1.0f)
+			val = (-4.0f + 3.0f*R)/slength;
+		else
+			val = -(-2.0f + R)*(-2.0f + R)/r;
+		return val*coeff;
+	case ORC_QUADRATIC: /* sph_core.cu:162-170 */
+		val = (-2.0f + R)/r;
+		return val*coeff;
+	case ORC_WENDLAND: { /* sph_core.cu:174-181 */
+		const float qm2 = r/slength - 2.0f;
+		return qm2*qm2*qm2*coeff;
+	}
+	case ORC_GAUSSIAN: /* sph_core.cu:185-191 */
+		return -expf(-R*R)*coeff;
+	}
+	return NAN;
+}
+
+float orc_W(int kerneltype, float r, float slength)
+{
+	const float kr = (kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	return W_c(kerneltype, r, slength, orc_wcoeff(kerneltype, slength, kr), expf(-kr*kr));
+}
+float orc_F(int kerneltype, float r, float slength)
+{
+	const float kr = (kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	return F_c(kerneltype, r, slength, orc_fcoeff(kerneltype, slength, kr));
+}
+
+/* ---- equation of state: src/cuda/phys_core.cu:99-142 (__powf -> powf) --------------- */
+float orc_P(const orc_params *p, float rho_tilde, int i)
+{
+	const float rho_ratio = rho_tilde + 1.0f;
+	return p->bcoeff[i]*(powf(rho_ratio, p->gammacoeff[i]) - 1.0f);
+}
+float orc_soundSpeed(const orc_params *p, float rho_tilde, int i)
+{
+	const float rho_ratio = rho_tilde + 1.0f;
+	return p->sscoeff[i]*powf(rho_ratio, p->sspowercoeff[i]);
+}
+static inline float physical_density(const orc_params *p, float rho_tilde, int i)
+{
+	return (rho_tilde + 1.0f)*p->rho0[i];
+}
+
+/* ---- cell grid: src/cuda/cellgrid.cuh:98-127 ------------------------------------- */
+uint32_t orc_calc_grid_hash(const orc_params *p, int gx, int gy, int gz)
+{
+	const int g[3] = { gx, gy, gz };
+	const int c1 = p->coord[0], c2 = p->coord[1], c3 = p->coord[2];
+	return (uint32_t)((g[c3]*(int)p->gridSize[c2])*(int)p->gridSize[c1]
+		+ g[c2]*(int)p->gridSize[c1] + g[c1]);
+}
+
+void orc_grid_pos_from_hash(const orc_params *p, uint32_t cellHash, int g[3])
+{
+	const int c1 = p->coord[0], c2 = p->coord[1], c3 = p->coord[2];
+	int temp = (int)(p->gridSize[c2]*p->gridSize[c1]);
+	g[c3] = cellHash / temp;
+	temp = cellHash - g[c3]*temp;
+	g[c2] = temp / (int)p->gridSize[c1];
+	g[c1] = temp - g[c2]*(int)p->gridSize[c1];
+}
+
+/* calcGridHashPeriodic, cellgrid.cuh:177-187 */
+static uint32_t calc_grid_hash_periodic(const orc_params *p, int gx, int gy, int gz)
+{
+	if (gx < 0) gx = p->gridSize[0] - 1;
+	if (gx >= (int)p->gridSize[0]) gx = 0;
+	if (gy < 0) gy = p->gridSize[1] - 1;
+	if (gy >= (int)p->gridSize[1]) gy = 0;
+	if (gz < 0) gz = p->gridSize[2] - 1;
+	if (gz >= (int)p->gridSize[2]) gz = 0;
+	return orc_calc_grid_hash(p, gx, gy, gz);
+}
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+
+/* clampGridPos<periodicbound>: src/cuda/buildneibs_kernel.cu:225-298 */
+static void clamp_grid_pos(const orc_params *p, const int gridPos[3], int gridOffset[3],
+	int newGridPos[3], int *toofar)
+{
+	for (int a = 0; a < 3; ++a) {
+		const int gs = (int)p->gridSize[a];
+		newGridPos[a] = gridPos[a] + gridOffset[a];
+		if (p->periodic & (1u << a)) {
+			if (newGridPos[a] < 0) newGridPos[a] += gs;
+			if (newGridPos[a] >= gs) newGridPos[a] -= gs;
+		} else {
+			newGridPos[a] = imin(imax(0, newGridPos[a]), gs - 1);
+			if (abs(gridOffset[a]) > 1 && newGridPos[a] == gridPos[a])
+				*toofar = 1;
+			gridOffset[a] = newGridPos[a] - gridPos[a];
+		}
+	}
+}
+
+/* ---- calcHashDevice: src/cuda/buildneibs_kernel.cu:659-776 -------------------------- */
+void orc_calc_hash(const orc_params *p, orc_f4 *posArray, uint32_t *particleHash, uint32_t *particleIndex,
+	const orc_info *particleInfo, const uint32_t *compactDeviceMap, uint32_t numParticles)
+{
+#pragma omp parallel for schedule(static)
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = particleInfo[index];
+		uint32_t gridHash = particleHash[index] & CELLTYPE_BITMASK;
+
+		if (FLUID(info) || MOVING(info) || (SURFACE(info) && !FLUID(info))) {
+			orc_f4 pos = posArray[index];
+			int gridPos[3];
+			orc_grid_pos_from_hash(p, gridHash, gridPos);
+
+			const float pc[3] = { pos.x, pos.y, pos.z };
+			int gridOffset[3];
+			for (int a = 0; a < 3; ++a) {
+				const float half_check = pc[a] < 0 ? 0.5f : 0.49999997f;
+				gridOffset[a] = (int)floorf(pc[a]/p->cellSize[a] + half_check);
+			}
+
+			int toofar = 0;
+			int newGridPos[3];
+			clamp_grid_pos(p, gridPos, gridOffset, newGridPos, &toofar);
+			gridHash = orc_calc_grid_hash(p, newGridPos[0], newGridPos[1], newGridPos[2]);
+
+			/* as_float3(pos) -= gridOffset*d_cellSize : contracted a - b*c */
+			pos.x = fmaf(-(float)gridOffset[0], p->cellSize[0], pos.x);
+			pos.y = fmaf(-(float)gridOffset[1], p->cellSize[1], pos.y);
+			pos.z = fmaf(-(float)gridOffset[2], p->cellSize[2], pos.z);
+
+			if (toofar)
+				pos.w = NAN; /* disable_particle */
+
+			if (INACTIVE(pos))
+				gridHash = CELL_HASH_MAX;
+
+			posArray[index] = pos;
+		}
+
+		if (compactDeviceMap && gridHash != CELL_HASH_MAX)
+			gridHash |= compactDeviceMap[gridHash];
+
+		particleHash[index] = gridHash;
+		particleIndex[index] = index;
+	}
+}
+
+/* fixHashDevice: src/cuda/buildneibs_kernel.cu:786-814 */
+void orc_fix_hash(const orc_params *p, uint32_t *particleHash, uint32_t *particleIndex,
+	const orc_info *info, const uint32_t *compactDeviceMap, uint32_t numParticles)
+{
+	(void)p; (void)info;
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		if (particleHash) {
+			const uint32_t gridHash = particleHash[index] & CELLTYPE_BITMASK;
+			if (compactDeviceMap)
+				particleHash[index] = particleHash[index] | compactDeviceMap[gridHash];
+		}
+		particleIndex[index] = index;
+	}
+}
+
+/* ---- sort: ptype_hash_compare, src/cuda/buildneibs.cu:358-412 ---------------------- */
+typedef struct { uint32_t hash; orc_info info; uint32_t idx; } sort_rec;
+
+static int sort_cmp(const void *pa, const void *pb)
+{
+	const sort_rec *a = (const sort_rec*)pa, *b = (const sort_rec*)pb;
+	const uint32_t ha = a->hash, hb = b->hash; /* preserveHighbits = true */
+	if (ha == hb) {
+		const int pta = PART_TYPE(a->info), ptb = PART_TYPE(b->info);
+		if (pta == ptb) {
+			const uint32_t ia = orc_info_id(a->info), ib = orc_info_id(b->info);
+			return ia < ib ? -1 : (ia > ib ? 1 : 0);
+		}
+		return pta < ptb ? -1 : 1;
+	}
+	return ha < hb ? -1 : 1;
+}
+
+void orc_sort(uint32_t *hash, orc_info *info, uint32_t *partIndex, uint32_t numParticles)
+{
+	if (!numParticles) return;
+	sort_rec *r = (sort_rec*)malloc(sizeof(sort_rec)*(size_t)numParticles);
+	for (uint32_t i = 0; i < numParticles; ++i) {
+		r[i].hash = hash[i]; r[i].info = info[i]; r[i].idx = partIndex[i];
+	}
+	qsort(r, numParticles, sizeof(sort_rec), sort_cmp);
+	for (uint32_t i = 0; i < numParticles; ++i) {
+		hash[i] = r[i].hash; info[i] = r[i].info; partIndex[i] = r[i].idx;
+	}
+	free(r);
+}
+
+/* ---- reorderDataAndFindCellStartDevice: src/cuda/buildneibs_kernel.cu:836-992 ------- */
+void orc_reorder(const orc_params *p, uint32_t *cellStart, uint32_t *cellEnd, uint32_t *segmentStart,
+	orc_f4 *sortedPos, orc_f4 *sortedVel,
+	const orc_f4 *unsortedPos, const orc_f4 *unsortedVel,
+	const orc_info *sortedInfo, const uint32_t *particleHash, const uint32_t *particleIndex,
+	uint32_t numParticles, uint32_t *newNumParticles)
+{
+	(void)p; (void)sortedInfo;
+	if (segmentStart)
+		for (int i = 0; i < 4; ++i) segmentStart[i] = EMPTY_SEGMENT;
+
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const uint32_t cellHash = particleHash[index];
+		const uint32_t prevHash = index > 0 ? particleHash[index - 1] : 0;
+
+		if (index == 0 || cellHash != prevHash) {
+			if (cellHash != CELL_HASH_MAX)
+				cellStart[cellHash & CELLTYPE_BITMASK] = index;
+			else
+				*newNumParticles = index;
+			if (index > 0)
+				cellEnd[prevHash & CELLTYPE_BITMASK] = index;
+		}
+
+		if (cellHash == CELL_HASH_MAX)
+			continue;
+
+		if (index == numParticles - 1) {
+			cellEnd[cellHash & CELLTYPE_BITMASK] = index + 1;
+			*newNumParticles = numParticles;
+		}
+
+		if (segmentStart) {
+			const uint8_t curr_type = cellHash >> 30;
+			const uint8_t prev_type = prevHash >> 30;
+			if (index == 0 || curr_type != prev_type)
+				segmentStart[curr_type] = index;
+		}
+
+		const uint32_t sortedIndex = particleIndex[index];
+		sortedPos[index] = unsortedPos[sortedIndex];
+		sortedVel[index] = unsortedVel[sortedIndex];
+	}
+}
+
+/* ---- neighbour list: src/cuda/buildneibs_kernel.cu:300-644,1019-1185 ---------------- */
+
+/* calcNeibCell<periodicbound>, :311-383 */
+static int calc_neib_cell(const orc_params *p, int g[3], const int off[3])
+{
+	for (int a = 0; a < 3; ++a) {
+		const int gs = (int)p->gridSize[a];
+		g[a] += off[a];
+		if (g[a] < 0) {
+			if (p->periodic & (1u << a)) g[a] = gs - 1; else return 0;
+		} else if (g[a] >= gs) {
+			if (p->periodic & (1u << a)) g[a] = 0; else return 0;
+		}
+	}
+	return 1;
+}
+
+/* neibListOffset, :464-470 */
+static inline uint32_t neib_list_offset(const orc_params *p, uint32_t neib_num, int neib_type)
+{
+	return (neib_type == PT_FLUID) ? neib_num :
+		(neib_type == PT_BOUNDARY) ? p->neibboundpos - neib_num :
+		neib_num + p->neibboundpos + 1;
+}
+
+/* too_many_neibs, :489-509 */
+static inline int too_many_neibs(const orc_params *p, const uint32_t *neibs_num, int neib_type)
+{
+	switch (neib_type) {
+	case PT_FLUID:    return !(neibs_num[PT_FLUID] < p->neibboundpos);
+	case PT_BOUNDARY: return !(neibs_num[PT_FLUID] + neibs_num[PT_BOUNDARY] < p->neibboundpos);
+	case PT_VERTEX:   return !(neibs_num[PT_VERTEX] < p->neiblistsize - p->neibboundpos - 1);
+	default: return 1;
+	}
+}
+
+static inline float sqlength3(float x, float y, float z)
+{
+	return fmaf(z, z, fmaf(y, y, x*x));
+}
+
+/* neibsInCell, :536-644 (non-SA) */
+static void neibs_in_cell(const orc_params *p, uint16_t *neibsList,
+	const orc_f4 *posArray, const orc_info *infoArray,
+	const uint32_t *cellStart, const uint32_t *cellEnd,
+	const int gridPos_in[3], const int gridOffset[3], unsigned cell,
+	uint32_t index, const float pos_in[3], uint32_t *neibs_num, int boundary, float sqinfluenceradius)
+{
+	int gridPos[3] = { gridPos_in[0], gridPos_in[1], gridPos_in[2] };
+	if (!calc_neib_cell(p, gridPos, gridOffset))
+		return;
+
+	const uint32_t gridHash = orc_calc_grid_hash(p, gridPos[0], gridPos[1], gridPos[2]);
+	const uint32_t bucketStart = cellStart[gridHash];
+	const uint32_t bucketEnd = cellEnd[gridHash];
+	if (bucketStart == CELL_EMPTY)
+		return;
+
+	/* pos -= gridOffset*d_cellSize (:564) : contracted a - b*c */
+	float pos[3];
+	for (int a = 0; a < 3; ++a)
+		pos[a] = fmaf(-(float)gridOffset[a], p->cellSize[a], pos_in[a]);
+
+	int encode_cell = 1;
+	int neib_type = PT_FLUID;
+	for (uint32_t neib_index = bucketStart; neib_index < bucketEnd; ++neib_index) {
+		if (neib_index == index)
+			continue;
+		const orc_info neib_info = infoArray[neib_index];
+		if (TESTPOINT(neib_info))
+			continue;
+		if (!encode_cell && neib_type != PART_TYPE(neib_info))
+			encode_cell = 1;
+		neib_type = PART_TYPE(neib_info);
+
+		/* ViscSpec::rheologytype != GRANULAR always here */
+		if (p->boundarytype == ORC_LJ_BOUNDARY && boundary && BOUNDARY(neib_info))
+			continue;
+		if (p->boundarytype == ORC_DYN_BOUNDARY /* && formulation != GRENIER */) {
+			if (boundary && BOUNDARY(neib_info))
+				continue;
+		}
+
+		const orc_f4 neib_pos = posArray[neib_index];
+		if (INACTIVE(neib_pos))
+			continue;
+
+		const float rx = pos[0] - neib_pos.x, ry = pos[1] - neib_pos.y, rz = pos[2] - neib_pos.z;
+		const int close_enough = sqlength3(rx, ry, rz) < sqinfluenceradius;
+
+		if (close_enough) {
+			const uint32_t offset = neib_list_offset(p, neibs_num[neib_type], neib_type);
+			neibs_num[neib_type]++;
+			if (!too_many_neibs(p, neibs_num, neib_type)) {
+				const int neib_bucket_offset = neib_index - bucketStart;
+				const int encode_offset = encode_cell ? ENCODE_CELL(cell) : 0;
+				neibsList[(size_t)offset*p->neiblist_stride + index] =
+					(uint16_t)(neib_bucket_offset + encode_offset);
+				encode_cell = 0;
+			}
+		}
+	}
+}
+
+void orc_build_neibs(const orc_params *p, uint16_t *neibsList,
+	const orc_f4 *posArray, const orc_info *infoArray, const uint32_t *particleHash,
+	const uint32_t *cellStart, const uint32_t *cellEnd,
+	uint32_t numParticles, uint32_t particleRangeEnd, float sqinfluenceradius,
+	orc_neibs_info *out)
+{
+	(void)numParticles;
+	long long numInteractions = 0;
+	int maxNeibs = 0;
+	int hasTooMany = -1;
+	int hasMax[3] = {0, 0, 0};
+
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+:numInteractions) reduction(max:maxNeibs)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		uint32_t neibs_num[PT_TESTPOINT] = {0, 0, 0};
+		do {
+			const orc_info info = infoArray[index];
+			int build_nl = FLUID(info) || TESTPOINT(info) || FLOATING(info) || COMPUTE_FORCE(info);
+			if (p->boundarytype == ORC_SA_BOUNDARY)
+				build_nl = build_nl || VERTEX(info) || BOUNDARY(info);
+			if (p->boundarytype == ORC_DYN_BOUNDARY)
+				build_nl = 1;
+			if (!build_nl)
+				break;
+			const orc_f4 pos = posArray[index];
+			if (INACTIVE(pos))
+				break;
+			const float pos3[3] = { pos.x, pos.y, pos.z };
+			int gridPos[3];
+			orc_grid_pos_from_hash(p, particleHash[index] & CELLTYPE_BITMASK, gridPos);
+			for (int z = -1; z <= 1; z++)
+				for (int y = -1; y <= 1; y++)
+					for (int x = -1; x <= 1; x++) {
+						const int off[3] = { x, y, z };
+						neibs_in_cell(p, neibsList, posArray, infoArray, cellStart, cellEnd,
+							gridPos, off, (x + 1) + (y + 1)*3 + (z + 1)*9,
+							index, pos3, neibs_num, BOUNDARY(info), sqinfluenceradius);
+					}
+		} while (0);
+
+		/* list terminators, :1105-1138 */
+		int overflow = too_many_neibs(p, neibs_num, PT_FLUID);
+		int marker_pos = overflow ? p->neibboundpos : neibs_num[PT_FLUID];
+		neibsList[(size_t)marker_pos*p->neiblist_stride + index] = NEIBS_END;
+		overflow |= too_many_neibs(p, neibs_num, PT_BOUNDARY);
+		if (!overflow)
+			neibsList[(size_t)neib_list_offset(p, neibs_num[PT_BOUNDARY], PT_BOUNDARY)*p->neiblist_stride + index] = NEIBS_END;
+		if (p->boundarytype == ORC_SA_BOUNDARY) {
+			overflow |= too_many_neibs(p, neibs_num, PT_VERTEX);
+			marker_pos = overflow ? p->neiblistsize - 1 : p->neibboundpos + 1 + neibs_num[PT_VERTEX];
+			neibsList[(size_t)marker_pos*p->neiblist_stride + index] = NEIBS_END;
+		}
+		if (overflow) {
+#pragma omp critical
+			{
+				/* the reference records whichever overflowing particle wins the atomicCAS;
+				 * the oracle records the lowest index one */
+				const int pid = (int)orc_info_id(infoArray[index]);
+				if (hasTooMany == -1 || pid < hasTooMany) {
+					hasTooMany = pid;
+					hasMax[0] = neibs_num[0]; hasMax[1] = neibs_num[1]; hasMax[2] = neibs_num[2];
+				}
+			}
+		}
+		/* neibcount reduction, :1141-1182 */
+		const int nm = neibs_num[PT_FLUID] + neibs_num[PT_BOUNDARY];
+		if (nm > maxNeibs) maxNeibs = nm;
+		numInteractions += nm + neibs_num[PT_VERTEX];
+	}
+	if (out) {
+		out->numInteractions = (int32_t)numInteractions;
+		out->maxFluidBoundaryNeibs = maxNeibs;
+		out->maxVertexNeibs = 0;
+		out->hasTooManyNeibs = hasTooMany;
+		out->hasMaxNeibs[0] = hasMax[0]; out->hasMaxNeibs[1] = hasMax[1]; out->hasMaxNeibs[2] = hasMax[2];
+	}
+}
+
+/* ---- neighbour list traversal: src/cuda/neibs_iteration.cuh:83-190, cellgrid.cuh:200-228 ---- */
+typedef struct {
+	const orc_params *p;
+	const uint32_t *cellStart;
+	const uint16_t *neibsList;
+	float pos[3];
+	int gridPos[3];
+	uint32_t index;
+	float pos_corr[3];
+	int64_t i;               /* idx_t list offset */
+	uint32_t neib_cell_base_index;
+	int neib_cellnum;
+	int64_t step;
+} neib_iter;
+
+static void neib_iter_init(neib_iter *it, const orc_params *p, int ptype, uint32_t index,
+	const orc_f4 *pos, const int gridPos[3], const uint32_t *cellStart, const uint16_t *neibsList)
+{
+	it->p = p; it->cellStart = cellStart; it->neibsList = neibsList;
+	it->pos[0] = pos->x; it->pos[1] = pos->y; it->pos[2] = pos->z;
+	it->gridPos[0] = gridPos[0]; it->gridPos[1] = gridPos[1]; it->gridPos[2] = gridPos[2];
+	it->index = index;
+	it->pos_corr[0] = it->pos_corr[1] = it->pos_corr[2] = 0.0f;
+	it->neib_cell_base_index = 0;
+	it->neib_cellnum = 0;
+	const int64_t stride = (int64_t)p->neiblist_stride;
+	const int64_t first = (ptype == PT_FLUID) ? 0 : (ptype == PT_BOUNDARY) ? p->neibboundpos : p->neibboundpos + 1;
+	it->step = (ptype == PT_BOUNDARY) ? -stride : stride;
+	it->i = first*stride - it->step;
+}
+
+/* returns neighbour index, or UINT_MAX at end of list */
+static uint32_t neib_iter_next(neib_iter *it)
+{
+	it->i += it->step;
+	uint16_t neib_data = it->neibsList[it->i + it->index];
+	if (neib_data == NEIBS_END) return UINT_MAX;
+	if (neib_data >= CELLNUM_ENCODED) {
+		const orc_params *p = it->p;
+		it->neib_cellnum = DECODE_CELL(neib_data);
+		neib_data &= NEIBINDEX_MASK;
+		/* d_cell_to_offset[c] = (c%3-1, (c/3)%3-1, c/9-1), src/cuda/forces.cu:376-386 */
+		const int c = it->neib_cellnum;
+		const int off[3] = { c % 3 - 1, (c / 3) % 3 - 1, c / 9 - 1 };
+		/* pos_corr = pos - d_cell_to_offset*d_cellSize : contracted a - b*c */
+		for (int a = 0; a < 3; ++a)
+			it->pos_corr[a] = fmaf(-(float)off[a], p->cellSize[a], it->pos[a]);
+		it->neib_cell_base_index = it->cellStart[calc_grid_hash_periodic(p,
+			it->gridPos[0] + off[0], it->gridPos[1] + off[1], it->gridPos[2] + off[2])];
+	}
+	return it->neib_cell_base_index + neib_data;
+}
+
+/* ---- forces: src/cuda/forces_kernel.def ------------------------------------------- */
+
+/* artvisc: src/cuda/visc_kernel.cu:74-85 */
+static inline float artvisc(const orc_params *p, float vel_dot_pos, float rho, float neib_rho,
+	float sspeed, float neib_sspeed, float r, float slength)
+{
+	return vel_dot_pos*slength*p->artvisccoeff*(sspeed + neib_sspeed)/
+		((r*r + p->epsartvisc)*(rho + neib_rho));
+}
+
+static inline float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+	return fmaf(az, bz, fmaf(ay, by, ax*bx));
+}
+
+/* one forcesDevice<cptype,nptype> launch over [from,to): forces_kernel.def:3914-4029 */
+static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *forces,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *tauArray,
+	uint32_t fromParticle, uint32_t toParticle)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f; /* kernelradius */
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
+
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = fromParticle; index < toParticle; ++index) {
+		const orc_info info = infoArray[index];
+		if (PART_TYPE(info) != cptype) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+
+		/* forces_particle_data, :759-812 */
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const orc_f4 vel = velArray[index];
+		const int p_fluid = FLUID_NUM(info);
+		const float p_sspeed = orc_soundSpeed(p, vel.w, p_fluid);
+		const float p_rho = physical_density(p, vel.w, p_fluid);
+		/* precalc_pressure SPH_F1: P/rho^2, :419-429 */
+		const float p_precalc = orc_P(p, vel.w, p_fluid)/(p_rho*p_rho);
+		const float *p_tau = tauArray ? tauArray + 6*(size_t)index : NULL;
+
+		orc_f4 force = forces[index]; /* common_particle_output, :886-895 */
+
+		neib_iter it;
+		neib_iter_init(&it, p, nptype, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			/* relPos = pos_corr - neibPos, .w = neib mass (vector_math.h:1064-1067) */
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const float nmass = npos.w;
+			if (!isfinite(nmass)) continue;
+			const float r = sqrtf(sqlength3(rx, ry, rz));
+			const orc_info neib_info = infoArray[neib_index];
+			if (r >= p->influenceradius) continue;
+
+			/* common_neib_data, :1099-1130 */
+			const orc_f4 nvel = velArray[neib_index];
+			const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+			const float n_rhot = nvel.w;
+			const float vel_dot_pos = dot3(vx, vy, vz, rx, ry, rz);
+			const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+			const int n_fluid = FLUID_NUM(neib_info);
+			const float n_sspeed = orc_soundSpeed(p, n_rhot, n_fluid);
+			const float n_rho = physical_density(p, n_rhot, n_fluid);
+			const float n_precalc = orc_P(p, n_rhot, n_fluid)/(n_rho*n_rho);
+
+			float DvDt[3] = {0.0f, 0.0f, 0.0f};
+			float DrDt = 0.0f;
+
+			const int all_pp = (cptype == PT_FLUID && nptype == PT_FLUID) ||
+				(cptype == PT_FLUID && nptype == PT_BOUNDARY && p->boundarytype == ORC_DYN_BOUNDARY);
+			const int dyn_bf = (cptype == PT_BOUNDARY && nptype == PT_FLUID && p->boundarytype == ORC_DYN_BOUNDARY);
+
+			if (all_pp || dyn_bf) {
+				/* compute_density_derivative, :2176-2190 */
+				DrDt = nmass*vel_dot_pos*f; /* mass_continuity_div_vel_term :2140-2151 */
+				/* compute_density_diffusion (Colagrossi, nptype==FLUID only), :1916-1952 */
+				if (p->densitydiffusiontype == ORC_COLAGROSSI && nptype == PT_FLUID) {
+					const int fType = p_fluid;
+					if (fType == n_fluid) {
+						const float gdotr = dot3(p->gravity[0], p->gravity[1], p->gravity[2], rx, ry, rz);
+						if (!(fabsf(orc_P(p, vel.w, fType) - orc_P(p, n_rhot, fType)) <
+								fabsf(gdotr*p_rho))) {
+							const float diff_term = p->densityDiffCoeff*p->sscoeff[fType]*
+								(n_rho/p_rho - 1)*f*nmass;
+							DrDt -= diff_term;
+						}
+					}
+				}
+				force.w += DrDt;
+			}
+
+			if (all_pp || (dyn_bf && COMPUTE_FORCE(info))) {
+				/* compute_pressure_contrib general, :2451-2466 */
+				const float pGradTerm = p_precalc + n_precalc;
+				const float s = pGradTerm*nmass*f;
+				DvDt[0] -= s*rx; DvDt[1] -= s*ry; DvDt[2] -= s*rz;
+
+				/* compute_viscous_contrib: turbulent first, then laminar, :2881-2886 */
+				if (p->turbmodel == ORC_ARTIFICIAL) { /* :2748-2764 */
+					if (vel_dot_pos < 0.0f) {
+						const float visc = artvisc(p, vel_dot_pos, p_rho, n_rho, p_sspeed, n_sspeed, r, p->slength);
+						DvDt[0] += visc*rx*nmass*f;
+						DvDt[1] += visc*ry*nmass*f;
+						DvDt[2] += visc*rz*nmass*f;
+					}
+				} else if (p->turbmodel == ORC_SPS && p_tau) { /* :2777-2798 */
+					const float *n_tau = tauArray + 6*(size_t)neib_index;
+					/* symtensor3 order: xx, xy, xz, yy, yz, zz (src/cuda/tensor.h) */
+					DvDt[0] += nmass*f*(
+						(p_tau[0] + n_tau[0])*rx + (p_tau[1] + n_tau[1])*ry + (p_tau[2] + n_tau[2])*rz);
+					DvDt[1] += nmass*f*(
+						(p_tau[1] + n_tau[1])*rx + (p_tau[3] + n_tau[3])*ry + (p_tau[4] + n_tau[4])*rz);
+					DvDt[2] += nmass*f*(
+						(p_tau[2] + n_tau[2])*rx + (p_tau[4] + n_tau[4])*ry + (p_tau[5] + n_tau[5])*rz);
+				}
+				if (all_pp || COMPUTE_FORCE(info)) {
+					force.x += DvDt[0]; force.y += DvDt[1]; force.z += DvDt[2];
+				}
+			}
+		}
+		forces[index] = force;
+	}
+}
+
+/* getFmaxElements / reducefmax / round_particles: src/cuda/forces.cu:105-140,539-552,960-964 */
+static inline uint32_t div_up(uint32_t a, uint32_t b) { return (a + b - 1)/b; }
+static inline uint32_t round_up(uint32_t a, uint32_t b) { return div_up(a, b)*b; }
+uint32_t orc_fmax_elements(uint32_t n) { return round_up(div_up(n, BLOCK_SIZE_FORCES), 4u); }
+uint32_t orc_fmax_temp_elements(uint32_t nels)
+{
+	const uint32_t numquarts = nels/4;
+	uint32_t numBlocks = div_up(numquarts, BLOCK_SIZE_FMAX);
+	if (numBlocks > 1) {
+		numBlocks = round_up(numBlocks, 4u);
+		if (numBlocks > BLOCK_SIZE_FMAX*4) numBlocks = BLOCK_SIZE_FMAX*4;
+	}
+	return numBlocks;
+}
+uint32_t orc_round_particles(uint32_t n) { return (n/BLOCK_SIZE_FORCES)*BLOCK_SIZE_FORCES; }
+
+/* finalizeforcesDevice: forces_kernel.def:4032-4150 */
+static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
+	orc_f4 *rbforces, orc_f4 *rbtorques,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	uint32_t fromParticle, uint32_t toParticle, uint32_t numBlocks, uint32_t cflOffset)
+{
+	const int dtadapt = !!(p->simflags & ORC_ENABLE_DTADAPT);
+#pragma omp parallel for schedule(static)
+	for (uint32_t block = 0; block < numBlocks; ++block) {
+		float block_max = 0.0f; /* shared.init() */
+		for (uint32_t t = 0; t < BLOCK_SIZE_FORCES; ++t) {
+			const uint32_t index = block*BLOCK_SIZE_FORCES + t + fromParticle;
+			if (index >= toParticle) break;
+			const orc_info info = infoArray[index];
+			const orc_f4 pos = posArray[index];
+			if (INACTIVE(pos)) continue;
+			const orc_f4 vel = velArray[index];
+			orc_f4 force = forces[index];
+			const int fl = FLUID_NUM(info);
+
+			/* forces_fixup (non-SA, non-Grenier), :3212-3218 */
+			force.w /= p->rho0[fl];
+
+			if (FLUID(info)) {
+				force.x += p->gravity[0]; force.y += p->gravity[1]; force.z += p->gravity[2];
+				if (dtadapt) { /* dyndt_forces_shared_data::store, :3436-3457 */
+					const float sspeed = orc_soundSpeed(p, vel.w, fl);
+					const float a = sqrtf(sqlength3(force.x, force.y, force.z));
+					block_max = fmaxf(block_max, fmaxf(a, sspeed*sspeed/p->slength));
+				}
+			}
+
+			if (COMPUTE_FORCE(info) && !VERTEX(info) && rbforces) { /* :4121-4142 */
+				force.x *= pos.w; force.y *= pos.w; force.z *= pos.w;
+				const int obj = OBJECT_NUM(info);
+				const uint32_t rbindex = (uint32_t)((int)orc_info_id(info) + p->rbstartindex[obj]);
+				rbforces[rbindex] = force;
+				int gp[3];
+				orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
+				/* globalDistance, cellgrid.cuh:147-154 */
+				const float ax = (gp[0] - p->rbcgGridPos[obj][0])*p->cellSize[0] + (pos.x - p->rbcgPos[obj][0]);
+				const float ay = (gp[1] - p->rbcgGridPos[obj][1])*p->cellSize[1] + (pos.y - p->rbcgPos[obj][1]);
+				const float az = (gp[2] - p->rbcgGridPos[obj][2])*p->cellSize[2] + (pos.z - p->rbcgPos[obj][2]);
+				orc_f4 tq;
+				tq.x = ay*force.z - az*force.y;
+				tq.y = az*force.x - ax*force.z;
+				tq.z = ax*force.y - ay*force.x;
+				tq.w = 0.0f;
+				rbtorques[rbindex] = tq;
+			}
+			forces[index] = force;
+		}
+		if (dtadapt && cfl)
+			cfl[cflOffset + block] = block_max; /* maxBlockReduce, src/cuda/device_core.cu:40-59 */
+	}
+}
+
+/* run_forces: src/cuda/forces.cu:717-806 */
+uint32_t orc_forces(const orc_params *p, orc_f4 *forces, float *cfl,
+	orc_f4 *rbforces, orc_f4 *rbtorques,
+	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *tau,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	uint32_t cflOffset, int compute_object_forces)
+{
+	(void)numParticles;
+	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
+	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle);
+	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle);
+	if (compute_object_forces || p->boundarytype == ORC_DYN_BOUNDARY)
+		forces_pass(p, PT_BOUNDARY, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle);
+	finalize_forces(p, forces, cfl, rbforces, rbtorques, pos, vel, info, hash,
+		fromParticle, toParticle, numBlocks, cflOffset);
+	return numBlocks;
+}
+
+/* cflmax + dtreduce: src/cuda/forces.cu:150-176,556-606 ; fmaxDevice forces_kernel.cu:734-793 */
+float orc_dtreduce(const orc_params *p, const float *cfl, uint32_t numBlocks,
+	float sspeed_cfl, float max_kinematic)
+{
+	float maxcfl = 0.0f;
+	for (uint32_t i = 0; i < numBlocks; ++i) maxcfl = fmaxf(maxcfl, cfl[i]);
+	float dt = p->dtadaptfactor*fminf(sqrtf(p->slength/maxcfl), p->slength/sspeed_cfl);
+	if (p->rheologytype != ORC_INVISCID || p->turbmodel > ORC_ARTIFICIAL) {
+		float visccoeff = max_kinematic;
+		float dt_visc = p->slength*p->slength/visccoeff;
+		dt_visc *= 0.125;
+		if (dt_visc < dt) dt = dt_visc;
+	}
+	return dt;
+}
+
+/* ---- SPS: SPSstressMatrixDevice src/cuda/visc_kernel.cu:759-811, shearRate<MIXED_TENSOR> :307-367,
+ *      shear_rate_contrib (non-SA) :207-215, shearRateNorm2<MIXED_TENSOR> :385-407 ---------------- */
+void orc_sps(const orc_params *p, float *tau, float *turbvisc,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd)
+{
+	(void)numParticles;
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		const orc_f4 vel = velArray[index];
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+
+		float dvx[3] = {0,0,0}, dvy[3] = {0,0,0}, dvz[3] = {0,0,0};
+		/* for_every_neib: PT_FLUID then PT_BOUNDARY (non-SA), neibs_iteration.cuh:325-343 */
+		for (int ptype = PT_FLUID; ptype <= PT_BOUNDARY; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				const float r = sqrtf(sqlength3(rx, ry, rz));
+				if (!isfinite(npos.w) || r >= p->influenceradius) continue;
+				const orc_f4 nvel = velArray[neib_index];
+				const orc_info ninfo = infoArray[neib_index];
+				const float n_rho = physical_density(p, nvel.w, FLUID_NUM(ninfo));
+				const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+				const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+				const float weight = f*npos.w/n_rho;
+				const float mx = rx*weight, my = ry*weight, mz = rz*weight;
+				dvx[0] -= vx*mx; dvx[1] -= vx*my; dvx[2] -= vx*mz;
+				dvy[0] -= vy*mx; dvy[1] -= vy*my; dvy[2] -= vy*mz;
+				dvz[0] -= vz*mx; dvz[1] -= vz*my; dvz[2] -= vz*mz;
+			}
+		}
+		/* mixed tensor: non-doubled diagonal, doubled off-diagonal */
+		float txx = dvx[0], txy = dvx[1] + dvy[0], txz = dvx[2] + dvz[0];
+		float tyy = dvy[1], tyz = dvy[2] + dvz[1], tzz = dvz[2];
+		float diag_terms = txx*txx + tyy*tyy + tzz*tzz;
+		diag_terms *= 2.0f;
+		const float off_terms = txy*txy + txz*txz + tyz*tyz;
+		const float SijSij_bytwo = diag_terms + off_terms;
+		const float S = sqrtf(SijSij_bytwo);
+		const float nu_SPS = p->smagfactor*S;
+		const float divu_SPS = 0.6666666666f*nu_SPS*(txx + tyy + tzz);
+		const float Blinetal_SPS = p->kspsfactor*SijSij_bytwo;
+		if (turbvisc) turbvisc[index] = nu_SPS;
+		const float rho = physical_density(p, vel.w, FLUID_NUM(info));
+		txx = nu_SPS*(txx + txx) - divu_SPS - Blinetal_SPS; txx /= rho;
+		txy *= nu_SPS/rho;
+		txz *= nu_SPS/rho;
+		tyy = nu_SPS*(tyy + tyy) - divu_SPS - Blinetal_SPS; tyy /= rho;
+		tyz *= nu_SPS/rho;
+		tzz = nu_SPS*(tzz + tzz) - divu_SPS - Blinetal_SPS; tzz /= rho;
+		float *t = tau + 6*(size_t)index;
+		t[0] = txx; t[1] = txy; t[2] = txz; t[3] = tyy; t[4] = tyz; t[5] = tzz;
+	}
+}
+
+/* ---- eulerDevice<step>: src/cuda/euler_kernel.def:396-538 --------------------------- */
+void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
+	const orc_f4 *oldPos, const orc_f4 *oldVel, const orc_info *infoArray, const uint32_t *hashArray,
+	const orc_f4 *forces, const orc_f4 *xsph,
+	uint32_t numParticles, float dt, int step)
+{
+	const int integrateBoundary = (p->boundarytype == ORC_DYN_BOUNDARY || p->boundarytype == ORC_SA_BOUNDARY);
+#pragma omp parallel for schedule(static)
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		const int ptype = PART_TYPE(info);
+		const orc_f4 force = forces[index];
+		orc_f4 pos = oldPos[index];
+		orc_f4 vel = oldVel[index];
+		do {
+			if (!ACTIVE(pos) || (ptype == PT_BOUNDARY && !integrateBoundary && !MOVING(info)))
+				break;
+			/* standard_corrected_velocity, :147-169: velc = vel (+ force*(dt/2) on step 2) */
+			float velc[3] = { vel.x, vel.y, vel.z };
+			if (step == 2) {
+				const float hdt = dt/2;
+				velc[0] = fmaf(force.x, hdt, velc[0]);
+				velc[1] = fmaf(force.y, hdt, velc[1]);
+				velc[2] = fmaf(force.z, hdt, velc[2]);
+			}
+			if ((p->simflags & ORC_ENABLE_XSPH) && xsph) {
+				velc[0] = fmaf(p->epsxsph, xsph[index].x, velc[0]);
+				velc[1] = fmaf(p->epsxsph, xsph[index].y, velc[1]);
+				velc[2] = fmaf(p->epsxsph, xsph[index].z, velc[2]);
+			}
+			const int obj = OBJECT_NUM(info);
+			switch (ptype) {
+			case PT_FLUID:
+				pos.x = fmaf(velc[0], dt, pos.x);
+				pos.y = fmaf(velc[1], dt, pos.y);
+				pos.z = fmaf(velc[2], dt, pos.z);
+				vel.w = fmaf(dt, force.w, vel.w); /* continuity_integration :203-209 */
+				vel.x = fmaf(dt, force.x, vel.x);
+				vel.y = fmaf(dt, force.y, vel.y);
+				vel.z = fmaf(dt, force.z, vel.z);
+				break;
+			case PT_VERTEX:
+			case PT_BOUNDARY:
+				if (MOVING(info)) {
+					int gp[3];
+					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
+					const float rx = (gp[0] - p->rbcgGridPos[obj][0])*p->cellSize[0] + (pos.x - p->rbcgPos[obj][0]);
+					const float ry = (gp[1] - p->rbcgGridPos[obj][1])*p->cellSize[1] + (pos.y - p->rbcgPos[obj][1]);
+					const float rz = (gp[2] - p->rbcgGridPos[obj][2])*p->cellSize[2] + (pos.z - p->rbcgPos[obj][2]);
+					const float *rot = p->rbsteprot[obj];
+					/* applyrot, src/cuda/euler_kernel.cu:67-74 */
+					pos.x += (rot[0] - 1.0f)*rx + rot[1]*ry + rot[2]*rz;
+					pos.y += rot[3]*rx + (rot[4] - 1.0f)*ry + rot[5]*rz;
+					pos.z += rot[6]*rx + rot[7]*ry + (rot[8] - 1.0f)*rz;
+					pos.x += p->rbtrans[obj][0];
+					pos.y += p->rbtrans[obj][1];
+					pos.z += p->rbtrans[obj][2];
+					const float *w = p->rbangularvel[obj];
+					vel.x = p->rblinearvel[obj][0] + (w[1]*rz - w[2]*ry);
+					vel.y = p->rblinearvel[obj][1] + (w[2]*rx - w[0]*rz);
+					vel.z = p->rblinearvel[obj][2] + (w[0]*ry - w[1]*rx);
+				}
+				if (p->boundarytype == ORC_DYN_BOUNDARY)
+					vel.w = fmaf(dt, force.w, vel.w);
+				break;
+			default:
+				break;
+			}
+		} while (0);
+		newPos[index] = pos;
+		newVel[index] = vel;
+	}
+}

@@ -1,0 +1,262 @@
+"""ctypes binding of the CPU oracle (oracle/libsph_oracle.so) and of oracle/_ref -- tests only."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+class OrcParams(C.Structure):
+    _fields_ = [
+        ("gridSize", C.c_uint32 * 3), ("cellSize", C.c_float * 3), ("worldOrigin", C.c_float * 3),
+        ("coord", C.c_int32 * 3), ("periodic", C.c_uint32),
+        ("neiblistsize", C.c_uint32), ("neibboundpos", C.c_uint32), ("neiblist_stride", C.c_uint64),
+        ("kerneltype", C.c_int32), ("sph_formulation", C.c_int32), ("densitydiffusiontype", C.c_int32),
+        ("boundarytype", C.c_int32), ("rheologytype", C.c_int32), ("turbmodel", C.c_int32),
+        ("compvisc", C.c_int32), ("viscmodel", C.c_int32), ("avgop", C.c_int32),
+        ("simflags", C.c_uint64),
+        ("slength", C.c_float), ("influenceradius", C.c_float), ("deltap", C.c_float), ("dtadaptfactor", C.c_float),
+        ("densityDiffCoeff", C.c_float), ("epsxsph", C.c_float),
+        ("numfluids", C.c_uint32),
+        ("rho0", C.c_float * 4), ("bcoeff", C.c_float * 4), ("gammacoeff", C.c_float * 4),
+        ("sscoeff", C.c_float * 4), ("sspowercoeff", C.c_float * 4), ("visccoeff", C.c_float * 4),
+        ("gravity", C.c_float * 3),
+        ("artvisccoeff", C.c_float), ("epsartvisc", C.c_float),
+        ("smagfactor", C.c_float), ("kspsfactor", C.c_float),
+        ("dcoeff", C.c_float), ("p1coeff", C.c_float), ("p2coeff", C.c_float), ("r0", C.c_float),
+        ("numplanes", C.c_uint32),
+        ("plane_normal", (C.c_float * 3) * 8), ("plane_gridpos", (C.c_int32 * 3) * 8), ("plane_pos", (C.c_float * 3) * 8),
+        ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),
+        ("rbtrans", (C.c_float * 3) * 16), ("rbsteprot", (C.c_float * 9) * 16),
+        ("rblinearvel", (C.c_float * 3) * 16), ("rbangularvel", (C.c_float * 3) * 16),
+    ]
+
+
+class OrcNeibsInfo(C.Structure):
+    _fields_ = [("numInteractions", C.c_int32), ("maxFluidBoundaryNeibs", C.c_int32),
+                ("maxVertexNeibs", C.c_int32), ("hasTooManyNeibs", C.c_int32), ("hasMaxNeibs", C.c_int32 * 3)]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(ORACLE_DIR, "libsph_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _lib = C.CDLL(path)
+        _lib.orc_W.restype = C.c_float; _lib.orc_W.argtypes = [C.c_int, C.c_float, C.c_float]
+        _lib.orc_F.restype = C.c_float; _lib.orc_F.argtypes = [C.c_int, C.c_float, C.c_float]
+        _lib.orc_wcoeff.restype = C.c_float; _lib.orc_wcoeff.argtypes = [C.c_int, C.c_float, C.c_float]
+        _lib.orc_fcoeff.restype = C.c_float; _lib.orc_fcoeff.argtypes = [C.c_int, C.c_float, C.c_float]
+        _lib.orc_P.restype = C.c_float; _lib.orc_P.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        _lib.orc_soundSpeed.restype = C.c_float; _lib.orc_soundSpeed.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        _lib.orc_forces.restype = C.c_uint32
+        _lib.orc_dtreduce.restype = C.c_float
+        _lib.orc_dtreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float]
+        _lib.orc_fmax_elements.restype = C.c_uint32; _lib.orc_fmax_elements.argtypes = [C.c_uint32]
+        _lib.orc_fmax_temp_elements.restype = C.c_uint32; _lib.orc_fmax_temp_elements.argtypes = [C.c_uint32]
+        _lib.orc_round_particles.restype = C.c_uint32; _lib.orc_round_particles.argtypes = [C.c_uint32]
+        _lib.orc_calc_grid_hash.restype = C.c_uint32
+        _lib.orc_num_threads.restype = C.c_int
+    return _lib
+
+
+def ref():
+    """oracle/_ref: the reference's own sources compiled here; None when not built (GPU box without it)."""
+    global _ref
+    if _ref is None:
+        path = os.path.join(ORACLE_DIR, "_ref", "libgpusph_ref.so")
+        if not os.path.exists(path):
+            return None
+        _ref = C.CDLL(path)
+        _ref.ref_W.restype = C.c_float; _ref.ref_W.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        _ref.ref_F.restype = C.c_float; _ref.ref_F.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float]
+        for n in ("ref_info_id", "ref_info_predicates"):
+            getattr(_ref, n).restype = C.c_uint32
+            getattr(_ref, n).argtypes = [C.c_uint16] * 4
+        for n in ("ref_info_part_type", "ref_info_object", "ref_info_fluid_num"):
+            getattr(_ref, n).restype = C.c_int
+            getattr(_ref, n).argtypes = [C.c_uint16] * 4
+        _ref.ref_active.restype = C.c_int; _ref.ref_active.argtypes = [C.c_float]
+        _ref.ref_cell_hash_from_particle_hash.restype = C.c_uint32
+        _ref.ref_cell_hash_from_particle_hash.argtypes = [C.c_uint32, C.c_int]
+        _ref.ref_encode_cell.restype = C.c_uint32; _ref.ref_encode_cell.argtypes = [C.c_uint32]
+        _ref.ref_decode_cell.restype = C.c_int; _ref.ref_decode_cell.argtypes = [C.c_uint32]
+        _ref.ref_constant.restype = C.c_uint32; _ref.ref_constant.argtypes = [C.c_int]
+        _ref.ref_enum.restype = C.c_int; _ref.ref_enum.argtypes = [C.c_int]
+    return _ref
+
+
+def orc_params_from(sphx_params, problem=None):
+    """OrcParams from the product's SphxParams (same numbers, independent struct)."""
+    o = OrcParams()
+    names = {f[0] for f in OrcParams._fields_}
+    for fname, _ in sphx_params._fields_:
+        if fname in names:
+            v = getattr(sphx_params, fname)
+            if hasattr(v, "__len__"):
+                dst = getattr(o, fname)
+                for i in range(len(v)):
+                    dst[i] = v[i]
+            else:
+                setattr(o, fname, v)
+    for b in range(16):
+        for a in (0, 4, 8):
+            o.rbsteprot[b][a] = 1.0
+    if problem is not None and getattr(problem, "num_obstacle", 0):
+        for a in range(3):
+            o.rbcgGridPos[0][a] = int(problem.rb_cg_gridpos[0][a])
+            o.rbcgPos[0][a] = float(problem.rb_cg_pos[0][a])
+        o.rbstartindex[0] = int(problem.rb_firstindex[0])
+    return o
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Oracle:
+    """numpy-level wrapper: every method takes/returns host arrays."""
+
+    def __init__(self, params: OrcParams):
+        self.p = params
+        self.L = lib()
+
+    def calc_hash(self, pos, hash_, info, devmap=None):
+        n = len(hash_)
+        pidx = np.empty(n, dtype=np.uint32)
+        self.L.orc_calc_hash(C.byref(self.p), P(pos), P(hash_), P(pidx), P(info), P(devmap), C.c_uint32(n))
+        return pidx
+
+    def fix_hash(self, hash_, info, devmap=None):
+        n = len(hash_)
+        pidx = np.empty(n, dtype=np.uint32)
+        self.L.orc_fix_hash(C.byref(self.p), P(hash_), P(pidx), P(info), P(devmap), C.c_uint32(n))
+        return pidx
+
+    def sort(self, hash_, info, pidx):
+        self.L.orc_sort(P(hash_), P(info), P(pidx), C.c_uint32(len(hash_)))
+
+    def reorder(self, upos, uvel, sinfo, shash, pidx, ncells, segments=True):
+        n = len(shash)
+        cs = np.full(ncells, 0xFFFFFFFF, dtype=np.uint32)
+        ce = np.full(ncells, 0xFFFFFFFF, dtype=np.uint32)
+        seg = np.zeros(4, dtype=np.uint32)
+        spos = np.zeros_like(upos); svel = np.zeros_like(uvel)
+        newn = np.zeros(1, dtype=np.uint32)
+        self.L.orc_reorder(C.byref(self.p), P(cs), P(ce), P(seg) if segments else None, P(spos), P(svel),
+                           P(upos), P(uvel), P(sinfo), P(shash), P(pidx), C.c_uint32(n), P(newn))
+        return cs, ce, seg, spos, svel, int(newn[0])
+
+    def build_neibs(self, pos, info, hash_, cs, ce, n, range_end, sqinfl):
+        stride = int(self.p.neiblist_stride)
+        nl = np.full(int(self.p.neiblistsize) * stride, 0xFFFF, dtype=np.uint16)
+        out = OrcNeibsInfo()
+        self.L.orc_build_neibs(C.byref(self.p), P(nl), P(pos), P(info), P(hash_), P(cs), P(ce),
+                               C.c_uint32(n), C.c_uint32(range_end), C.c_float(sqinfl), C.byref(out))
+        return nl, out
+
+    def forces(self, pos, vel, info, hash_, cs, nl, n, frm=0, to=None, cfl_offset=0, compute_object_forces=0,
+               rb_count=0, tau=None):
+        to = n if to is None else to
+        forces = np.zeros((len(pos), 4), dtype=np.float32)
+        nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
+        cfl = np.zeros(nblk + cfl_offset, dtype=np.float32)
+        rbf = np.zeros((max(rb_count, 1), 4), dtype=np.float32)
+        rbt = np.zeros((max(rb_count, 1), 4), dtype=np.float32)
+        nb = self.L.orc_forces(C.byref(self.p), P(forces), P(cfl), P(rbf) if rb_count else None,
+                               P(rbt) if rb_count else None, P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), P(tau),
+                               C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
+                               C.c_int(compute_object_forces))
+        return forces, cfl, int(nb), rbf, rbt
+
+    def dtreduce(self, cfl, nblocks, sspeed_cfl, max_kinematic=0.0):
+        return float(self.L.orc_dtreduce(C.byref(self.p), P(cfl), C.c_uint32(nblocks), C.c_float(sspeed_cfl),
+                                         C.c_float(max_kinematic)))
+
+    def euler(self, old_pos, old_vel, info, hash_, forces, n, dt, step):
+        npos = np.zeros_like(old_pos); nvel = np.zeros_like(old_vel)
+        self.L.orc_euler(C.byref(self.p), P(npos), P(nvel), P(old_pos), P(old_vel), P(info), P(hash_), P(forces), None,
+                         C.c_uint32(n), C.c_float(dt), C.c_int(step))
+        return npos, nvel
+
+    def sps(self, pos, vel, info, hash_, cs, nl, n, range_end):
+        tau = np.zeros((len(pos), 6), dtype=np.float32)
+        tv = np.zeros(len(pos), dtype=np.float32)
+        self.L.orc_sps(C.byref(self.p), P(tau), P(tv), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl),
+                       C.c_uint32(n), C.c_uint32(range_end))
+        return tau, tv
+
+
+class OracleSim:
+    """Whole-step driver on the host following the reference's command sequence
+    (Integrator::buildNeibsPhase src/Integrator.cc:94-250, PredictorCorrector
+    src/integrators/PredictorCorrectorIntegrator.cc:386-685, dt: GPUWorker.cc:2226-2229, GPUSPH.cc:636-699)."""
+
+    def __init__(self, problem, allocated=None):
+        import gpusph_amd.defs as D
+        self.D = D
+        self.problem = problem
+        arrs = problem.copy_to_array()
+        self.n = len(arrs["hash"])
+        self.alloc = allocated or self.n
+        self.sp = problem.sphx_params(self.alloc)
+        self.op = orc_params_from(self.sp, problem)
+        self.o = Oracle(self.op)
+        self.pos, self.vel, self.info, self.hash = arrs["pos"], arrs["vel"], arrs["info"], arrs["hash"]
+        self.dt = float(np.float32(problem.simparams.dt))
+        self.t = 0.0
+        self.iterations = 0
+        self.ncells = problem.grid_cells
+        sscoeff = max(problem.physparams.sscoeff)
+        self.sspeed_cfl = float(np.float32(np.float64(np.float32(sscoeff)) * 1.1))  # GPUWorker.cc:3010-3011
+        self.neibs_info = None
+
+    def build_neibs(self):
+        o = self.o
+        if self.iterations == 0:
+            pidx = o.fix_hash(self.hash, self.info)
+        else:
+            pidx = o.calc_hash(self.pos, self.hash, self.info)
+        o.sort(self.hash, self.info, pidx)
+        self.cs, self.ce, self.seg, spos, svel, newn = o.reorder(self.pos, self.vel, self.info, self.hash, pidx, self.ncells,
+                                                                 segments=False)
+        self.pos, self.vel = spos, svel
+        self.partindex = pidx
+        self.n = newn
+        sq = float(np.float32(self.problem.simparams.nlSqInfluenceRadius))
+        self.nl, self.neibs_info = o.build_neibs(self.pos, self.info, self.hash, self.cs, self.ce, self.n, self.n, sq)
+
+    def step(self):
+        sp = self.problem.simparams
+        o = self.o
+        if self.iterations % sp.buildneibsfreq == 0:
+            self.build_neibs()
+        n = self.n
+        cof = 1 if sp.numforcesbodies > 0 else 0
+        rb = getattr(self.problem, "num_obstacle", 0)
+        dt = float(np.float32(self.dt))
+        # predictor
+        f1, cfl, nb, self.rbf, self.rbt = o.forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n,
+                                                   compute_object_forces=cof, rb_count=rb)
+        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl)
+        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1)
+        # corrector
+        f2, cfl, nb, self.rbf, self.rbt = o.forces(ps, vs, self.info, self.hash, self.cs, self.nl, n,
+                                                   compute_object_forces=cof, rb_count=rb)
+        dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl)
+        self.pos, self.vel = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
+        self.forces = f2
+        self.t += dt
+        self.iterations += 1
+        self.dt = min(dt1, dt2)
