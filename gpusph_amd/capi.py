@@ -69,11 +69,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _hip_runtimes_loaded():
+    """paths of every libamdhip64 mapped into this process"""
+    libs = set()
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "libamdhip64" in line:
+                    libs.add(line.split()[-1])
+    except OSError:
+        pass
+    return libs
+
+
 def load(path=None):
-    """dlopen libsphx.so and type every entry point.  Raises if the library is absent."""
+    """dlopen libsphx.so and type every entry point.  Raises if the library is absent.
+
+    torch is imported FIRST on purpose: its wheel bundles a libamdhip64.so with the same SONAME as
+    /opt/rocm's, and device pointers / hipStream_t handles are shared between torch and libsphx, so
+    both must resolve to ONE HIP runtime instance.  Loading libsphx first would map a second runtime
+    (observed: "no ROCm-capable device is detected"); that situation is detected and refused.
+    """
     global _lib
     if _lib is not None and path is None:
         return _lib
+    import torch  # noqa: F401  (device memory / stream provider; must own the HIP runtime)
     p = path or LIB_PATH
     if not os.path.exists(p):
         raise SphxError("libsphx.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -83,6 +103,10 @@ def load(path=None):
         fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    rts = _hip_runtimes_loaded()
+    if len(rts) > 1:
+        raise SphxError("two HIP runtimes are mapped into this process (%s): import torch before anything "
+                        "that links libamdhip64" % ", ".join(sorted(rts)))
     if path is None:
         _lib = lib
     return lib

@@ -28,6 +28,7 @@ struct ForcesArgs {
 	const uint32_t *cellStart;
 	const neibdata *neibsList;
 	const float2 *tau0, *tau1, *tau2;
+	const float4 *aux;   // per-particle EOS pre-pass {P/rho^2, c, P, rho}
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
 	int compute_object_forces;
@@ -80,85 +81,151 @@ struct Self {
 	float tau[6];
 };
 
+// per-particle EOS pre-pass: aux[i] = {P/rho^2, c, P, rho}.  The reference recomputes these for
+// the NEIGHBOUR inside every pair (2 __powf + 1 division per pair, forces_kernel.def:690-702,
+// 1126-1128); they are pure functions of the neighbour's own rho~, so computing them once per
+// particle and gathering 16 B gives the same numbers with ~20 fewer issue slots per pair.
+__global__ void __launch_bounds__(256)
+eos_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__restrict__ info,
+	float4 *__restrict__ aux, uint32_t n)
+{
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t fl = (p.numfluids > 1) ? FLUID_NUM(info[i]) : 0u;
+	const Eos e = eos(p, vel[i].w, fl);
+	aux[i] = make_float4(e.p_precalc, e.sspeed, e.P, e.rho);
+}
+
+#define NB 4   // neighbours resolved per batch: list entries, cell bases and particle rows of a
+               // batch are each fetched with independent loads in flight (3 dependent round trips per
+               // NB neighbours instead of per neighbour); the next batch's list entries are
+               // prefetched while the current one is computed
+
+template<int NPTYPE>
+__device__ __forceinline__ void load_list_batch(const DevParams &p, const neibdata *__restrict__ list,
+	uint32_t index, int slot, uint32_t nd[NB])
+{
+#pragma unroll
+	for (int k = 0; k < NB; ++k) {
+		// entries past the terminator are never used; the clamp only keeps the address in bounds
+		const int sl = (NPTYPE == PT_FLUID) ? min(slot + k, (int)p.neiblistsize - 1) : max(slot - k, 0);
+		nd[k] = list[(size_t)sl*p.stride + index];
+	}
+}
+
 // walk one typed section of the neighbour list (neiblist_iterator_simple,
 // src/cuda/neibs_iteration.cuh:165-205; getNeibIndex src/cuda/cellgrid.cuh:200-228)
 template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID, int NPTYPE, bool MOMENTUM, bool DIFFUSE>
 __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArgs &a, uint32_t index,
 	const Self &s, float inv_h, float4 &force)
 {
-	const size_t stride = p.stride;
-	size_t loc = (NPTYPE == PT_FLUID) ? (size_t)index : (size_t)p.neibboundpos*stride + index;
-	float pcx = 0.0f, pcy = 0.0f, pcz = 0.0f;
+	int slot = (NPTYPE == PT_FLUID) ? 0 : (int)p.neibboundpos;
+	uint32_t nd[NB], ndn[NB];
+	load_list_batch<NPTYPE>(p, a.neibsList, index, slot, nd);
+
+	int cell = 0;
 	uint32_t cell_base = 0;
+	const float inv_rho_i = fast_rcp(s.e.rho);
+	bool done = false;
 
-	for (;;) {
-		uint32_t nd = a.neibsList[loc];
-		if (nd == NEIBS_END) break;
-		loc = (NPTYPE == PT_FLUID) ? loc + stride : loc - stride;
+	while (!done) {
+		slot = (NPTYPE == PT_FLUID) ? slot + NB : slot - NB;
+		load_list_batch<NPTYPE>(p, a.neibsList, index, slot, ndn);
 
-		if (nd >= CELLNUM_ENCODED) {
-			const int c = (int)(nd >> CELLNUM_SHIFT) - 1;
-			nd &= NEIBINDEX_MASK;
-			const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
-			const int ox = cx - 1, oy = cy - 1, oz = cz - 1;
-			pcx = fmaf(-(float)ox, p.cs[0], s.pos.x);
-			pcy = fmaf(-(float)oy, p.cs[1], s.pos.y);
-			pcz = fmaf(-(float)oz, p.cs[2], s.pos.z);
-			cell_base = a.cellStart[grid_hash_periodic(p, s.gridPos.x + ox, s.gridPos.y + oy, s.gridPos.z + oz)];
-		}
-		const uint32_t j = cell_base + nd;
-
-		const float4 npos = a.pos[j];
-		const float4 nvel = a.vel[j];
-		const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
-		const float nmass = npos.w;
-		if (!is_active_w(nmass)) continue;
-		const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
-		const float r = fast_sqrt(r2);
-		if (r >= p.influenceradius) continue;
-
-		uint32_t nfl = 0;
-		if (MULTIFLUID) nfl = FLUID_NUM(a.info[j]);
-
-		const float vx = s.vel.x - nvel.x, vy = s.vel.y - nvel.y, vz = s.vel.z - nvel.z;
-		const float vel_dot_pos = fmaf(vz, rz, fmaf(vy, ry, vx*rx));
-		const float f = kernel_F<KERNEL>(p, r, inv_h);
-		const Eos ne = eos(p, nvel.w, nfl);
-		const float mf = nmass*f;
-
-		// mass_continuity_div_vel_term (forces_kernel.def:2140-2151)
-		float DrDt = mf*vel_dot_pos;
-		if (COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
-			if (!MULTIFLUID || nfl == s.fl) {
-				const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
-				if (!(fabsf(s.e.P - ne.P) < fabsf(gdotr*s.e.rho)))
-					DrDt -= p.densityDiffCoeff*p.sscoeff[s.fl]*(ne.rho*fast_rcp(s.e.rho) - 1.0f)*mf;
+		// stage 1: decode entries, fetch the base index of every cell that changes in this batch
+		bool valid[NB], enc[NB];
+		int c[NB];
+		uint32_t cb[NB];
+		bool alive = true;
+#pragma unroll
+		for (int k = 0; k < NB; ++k) {
+			const uint32_t d = nd[k];
+			alive = alive && (d != NEIBS_END);
+			valid[k] = alive;
+			enc[k] = alive && (d >= CELLNUM_ENCODED);
+			c[k] = enc[k] ? (int)(d >> CELLNUM_SHIFT) - 1 : (k ? c[k > 0 ? k - 1 : 0] : cell);
+			cb[k] = 0;
+			if (enc[k]) {
+				const int cz = c[k]/9, cy = (c[k] - cz*9)/3, cx = c[k] - cz*9 - cy*3;
+				cb[k] = a.cellStart[grid_hash_periodic(p, s.gridPos.x + cx - 1, s.gridPos.y + cy - 1, s.gridPos.z + cz - 1)];
 			}
 		}
-		force.w += DrDt;
+		done = !alive;
+#pragma unroll
+		for (int k = 0; k < NB; ++k)
+			if (!enc[k]) cb[k] = k ? cb[k > 0 ? k - 1 : 0] : cell_base;
+		cell = c[NB - 1];
+		cell_base = cb[NB - 1];
 
-		if (MOMENTUM) {
-			// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
-			float k = -(s.e.p_precalc + ne.p_precalc)*mf;
-			if (TURB == SPHX_ARTIFICIAL) {
-				// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764)
-				if (vel_dot_pos < 0.0f) {
-					const float visc = vel_dot_pos*p.slength*p.artvisccoeff*(s.e.sspeed + ne.sspeed)*
-						fast_rcp((r2 + p.epsartvisc)*(s.e.rho + ne.rho));
-					k = fmaf(visc, mf, k);
+		// stage 2: gather the neighbour rows of the whole batch
+		float4 npos[NB], nvel[NB], naux[NB];
+		uint32_t nfl[NB];
+		float2 t0[NB], t1[NB], t2[NB];
+#pragma unroll
+		for (int k = 0; k < NB; ++k) {
+			const uint32_t j = valid[k] ? cb[k] + (nd[k] & NEIBINDEX_MASK) : index;
+			npos[k] = a.pos[j];
+			nvel[k] = a.vel[j];
+			naux[k] = a.aux[j];
+			nfl[k] = 0;
+			if (MULTIFLUID) nfl[k] = FLUID_NUM(a.info[j]);
+			if (TURB == SPHX_SPS && MOMENTUM) { t0[k] = a.tau0[j]; t1[k] = a.tau1[j]; t2[k] = a.tau2[j]; }
+		}
+
+		// stage 3: pair interactions, in list order
+#pragma unroll
+		for (int k = 0; k < NB; ++k) {
+			const int cz = c[k]/9, cy = (c[k] - cz*9)/3, cx = c[k] - cz*9 - cy*3;
+			const float pcx = fmaf(-(float)(cx - 1), p.cs[0], s.pos.x);
+			const float pcy = fmaf(-(float)(cy - 1), p.cs[1], s.pos.y);
+			const float pcz = fmaf(-(float)(cz - 1), p.cs[2], s.pos.z);
+			const float rx = pcx - npos[k].x, ry = pcy - npos[k].y, rz = pcz - npos[k].z;
+			const float nmass = npos[k].w;
+			const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
+			const float r = fast_sqrt(r2);
+			if (!valid[k] || !is_active_w(nmass) || r >= p.influenceradius) continue;
+
+			const float vx = s.vel.x - nvel[k].x, vy = s.vel.y - nvel[k].y, vz = s.vel.z - nvel[k].z;
+			const float vel_dot_pos = fmaf(vz, rz, fmaf(vy, ry, vx*rx));
+			const float f = kernel_F<KERNEL>(p, r, inv_h);
+			const float n_precalc = naux[k].x, n_sspeed = naux[k].y, n_P = naux[k].z, n_rho = naux[k].w;
+			const float mf = nmass*f;
+
+			// mass_continuity_div_vel_term (forces_kernel.def:2140-2151)
+			float DrDt = mf*vel_dot_pos;
+			if (COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
+				if (!MULTIFLUID || nfl[k] == s.fl) {
+					const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
+					if (!(fabsf(s.e.P - n_P) < fabsf(gdotr*s.e.rho)))
+						DrDt -= p.densityDiffCoeff*p.sscoeff[s.fl]*(n_rho*inv_rho_i - 1.0f)*mf;
 				}
 			}
-			float ax = k*rx, ay = k*ry, az = k*rz;
-			if (TURB == SPHX_SPS) { // forces_kernel.def:2777-2798
-				const float2 t0 = a.tau0[j], t1 = a.tau1[j], t2 = a.tau2[j];
-				const float xx = s.tau[0] + t0.x, xy = s.tau[1] + t0.y, xz = s.tau[2] + t1.x;
-				const float yy = s.tau[3] + t1.y, yz = s.tau[4] + t2.x, zz = s.tau[5] + t2.y;
-				ax = fmaf(mf, fmaf(xz, rz, fmaf(xy, ry, xx*rx)), ax);
-				ay = fmaf(mf, fmaf(yz, rz, fmaf(yy, ry, xy*rx)), ay);
-				az = fmaf(mf, fmaf(zz, rz, fmaf(yz, ry, xz*rx)), az);
+			force.w += DrDt;
+
+			if (MOMENTUM) {
+				// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
+				float kk = -(s.e.p_precalc + n_precalc)*mf;
+				if (TURB == SPHX_ARTIFICIAL) {
+					// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764)
+					if (vel_dot_pos < 0.0f) {
+						const float visc = vel_dot_pos*p.slength*p.artvisccoeff*(s.e.sspeed + n_sspeed)*
+							fast_rcp((r2 + p.epsartvisc)*(s.e.rho + n_rho));
+						kk = fmaf(visc, mf, kk);
+					}
+				}
+				float ax = kk*rx, ay = kk*ry, az = kk*rz;
+				if (TURB == SPHX_SPS) { // forces_kernel.def:2777-2798
+					const float xx = s.tau[0] + t0[k].x, xy = s.tau[1] + t0[k].y, xz = s.tau[2] + t1[k].x;
+					const float yy = s.tau[3] + t1[k].y, yz = s.tau[4] + t2[k].x, zz = s.tau[5] + t2[k].y;
+					ax = fmaf(mf, fmaf(xz, rz, fmaf(xy, ry, xx*rx)), ax);
+					ay = fmaf(mf, fmaf(yz, rz, fmaf(yy, ry, xy*rx)), ay);
+					az = fmaf(mf, fmaf(zz, rz, fmaf(yz, ry, xz*rx)), az);
+				}
+				force.x += ax; force.y += ay; force.z += az;
 			}
-			force.x += ax; force.y += ay; force.z += az;
 		}
+#pragma unroll
+		for (int k = 0; k < NB; ++k) nd[k] = ndn[k];
 	}
 }
 
@@ -181,7 +248,7 @@ forces_kernel(DevParams p, ForcesArgs a)
 		s.vel = a.vel[index];
 		s.gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 		s.fl = MULTIFLUID ? FLUID_NUM(info) : 0u;
-		s.e = eos(p, s.vel.w, s.fl);
+		{ const float4 ax = a.aux[index]; s.e.p_precalc = ax.x; s.e.sspeed = ax.y; s.e.P = ax.z; s.e.rho = ax.w; }
 		if (TURB == SPHX_SPS) {
 			const float2 t0 = a.tau0[index], t1 = a.tau1[index], t2 = a.tau2[index];
 			s.tau[0] = t0.x; s.tau[1] = t0.y; s.tau[2] = t1.x; s.tau[3] = t1.y; s.tau[4] = t2.x; s.tau[5] = t2.y;
@@ -501,6 +568,13 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	if (h_numBlocks) *h_numBlocks = numBlocks;
 	if (!numBlocks) return SPHX_OK;
 
+	{	// EOS pre-pass over ALL particles: neighbours may lie outside [fromParticle,toParticle)
+		int rc0 = sphx_ensure_scratch(ctx, numParticles);
+		if (rc0 != SPHX_OK) return rc0;
+		eos_kernel<<<div_up_u(numParticles, 256), 256, 0, (hipStream_t)stream>>>(ctx->dev, (const float4*)vel,
+			(const particleinfo*)info, ctx->eos_aux, numParticles);
+		SPHX_LAUNCH_CHECK("eos_kernel");
+	}
 	ForcesArgs a;
 	a.forces = (float4*)forces; a.cfl = (ctx->dev.simflags & SPHX_ENABLE_DTADAPT) ? cfl : nullptr;
 	a.rbforces = (float4*)rbforces; a.rbtorques = (float4*)rbtorques;
@@ -508,6 +582,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.tau0 = (const float2*)tau0; a.tau1 = (const float2*)tau1; a.tau2 = (const float2*)tau2;
 	a.rb = ctx->rb_dev;
+	a.aux = ctx->eos_aux;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
 	a.compute_object_forces = compute_object_forces;
 

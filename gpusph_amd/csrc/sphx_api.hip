@@ -37,11 +37,12 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
-		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info };
+		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
+	ctx->eos_aux = nullptr;
 	ctx->reserved_particles = ctx->reserved_bins = 0;
 }
 
@@ -80,6 +81,7 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_hash, sizeof(uint32_t)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_index, sizeof(uint32_t)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_info, sizeof(uint2)*(size_t)n));
+	SPHX_HIP(hipMalloc((void**)&ctx->eos_aux, sizeof(float4)*(size_t)n));
 	ctx->reserved_particles = n;
 	ctx->reserved_bins = bins;
 	return SPHX_OK;

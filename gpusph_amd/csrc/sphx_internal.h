@@ -91,6 +91,7 @@ struct sphx_ctx {
 	uint32_t   *tmp_hash;      // [n]
 	uint32_t   *tmp_index;     // [n]
 	uint2      *tmp_info;      // [n] particleinfo as 8 bytes
+	float4     *eos_aux;       // [n] per-particle EOS pre-pass of the forces engine
 	float      *dt_scratch;    // 1 float, for the sync dtreduce
 };
 

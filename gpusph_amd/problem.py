@@ -243,7 +243,12 @@ class DamBreak3D(Problem):
                 lo = mid
             else:
                 hi = mid
-        return float(np.float32(hi))
+        dp = float(np.float32(hi))
+        while cls.count(dp, obstacle) > target:     # float32 rounding of dp may tip a lattice count over
+            dp = float(np.nextafter(np.float32(dp), np.float32(1.0)))
+            dp *= 1.0005
+            dp = float(np.float32(dp))
+        return dp
 
     def fill_parts(self):
         dp = self.m_deltap

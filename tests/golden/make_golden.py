@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures under tests/golden/.
+
+  ref_kernels.npz, ref_datamodel.npz   outputs of the REFERENCE's own code (oracle/_ref, compiled here
+                                       from /root/reference/src/cuda/sph_core.cu, src/particleinfo.h, ...)
+  oracle_pipeline.npz                  outputs of the CPU oracle on a small DamBreak3D (regression data for
+                                       the GPU path; the oracle itself is unpinned for these stages)
+
+Run in the build container (needs /root/reference for oracle/_ref):  python tests/golden/make_golden.py
+"""
+import os
+import sys
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import oracle_lib as ol  # noqa: E402
+from gpusph_amd.problem import DamBreak3D  # noqa: E402
+
+
+def kernels():
+    ref = ol.ref()
+    assert ref is not None, "oracle/_ref not built (needs /root/reference)"
+    L = ol.lib()
+    rng = np.random.default_rng(2024)
+    rows = []
+    for k in (1, 2, 3, 4):
+        kr = 3.0 if k == 4 else 2.0
+        for h in (np.float32(0.013), np.float32(0.0052), np.float32(0.00208), np.float32(0.39)):
+            wc = np.float32(L.orc_wcoeff(k, float(h), kr)); fc = np.float32(L.orc_fcoeff(k, float(h), kr))
+            wsub = np.float32(np.exp(np.float32(-kr * kr)))
+            rs = np.concatenate([rng.uniform(1e-4, kr, 40).astype(np.float32) * h,
+                                 np.array([0.5, 1.0, 1.5, 1.9999, 2.0], dtype=np.float32) * h])
+            for r in rs:
+                rows.append((k, float(r), float(h), float(wc), float(fc), float(wsub),
+                             ref.ref_W(k, float(r), float(h), float(wc), float(wsub)),
+                             ref.ref_F(k, float(r), float(h), float(fc))))
+    a = np.array(rows, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "ref_kernels.npz"), kerneltype=a[:, 0].astype(np.int32),
+                        r=a[:, 1].astype(np.float32), slength=a[:, 2].astype(np.float32),
+                        wcoeff=a[:, 3].astype(np.float32), fcoeff=a[:, 4].astype(np.float32),
+                        wsub=a[:, 5].astype(np.float32), W=a[:, 6].astype(np.float32), F=a[:, 7].astype(np.float32))
+
+
+def datamodel():
+    ref = ol.ref()
+    rng = np.random.default_rng(99)
+    info = rng.integers(0, 65536, size=(512, 4), dtype=np.uint16)
+    info[:64, 0] = np.arange(64, dtype=np.uint16)          # all type/flag low-bit combinations
+    ids = np.array([ref.ref_info_id(*map(int, i)) for i in info], dtype=np.uint32)
+    ptype = np.array([ref.ref_info_part_type(*map(int, i)) for i in info], dtype=np.int32)
+    obj = np.array([ref.ref_info_object(*map(int, i)) for i in info], dtype=np.int32)
+    fl = np.array([ref.ref_info_fluid_num(*map(int, i)) for i in info], dtype=np.int32)
+    pred = np.array([ref.ref_info_predicates(*map(int, i)) for i in info], dtype=np.uint32)
+    hashes = np.concatenate([rng.integers(0, 2**32, size=64, dtype=np.uint64).astype(np.uint32),
+                             np.array([0, 1, 0x3FFFFFFF, 0x40000000, 0x80000000, 0xC0000000, 0xFFFFFFFF], dtype=np.uint32)])
+    h_reset = np.array([ref.ref_cell_hash_from_particle_hash(int(h), 0) for h in hashes], dtype=np.uint32)
+    h_keep = np.array([ref.ref_cell_hash_from_particle_hash(int(h), 1) for h in hashes], dtype=np.uint32)
+    cells = np.arange(27, dtype=np.uint32)
+    enc = np.array([ref.ref_encode_cell(int(c)) for c in cells], dtype=np.uint32)
+    dec = np.array([ref.ref_decode_cell(int(e) + 37) for e in enc], dtype=np.int32)
+    consts = np.array([ref.ref_constant(i) for i in range(11)], dtype=np.uint32)
+    enums = np.array([ref.ref_enum(i) for i in range(11)], dtype=np.int32)
+    wvals = np.array([0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45], dtype=np.float32)
+    active = np.array([ref.ref_active(float(w)) for w in wvals], dtype=np.int32)
+    np.savez_compressed(os.path.join(HERE, "ref_datamodel.npz"), info=info, id=ids, ptype=ptype, object=obj, fluid=fl,
+                        predicates=pred, hashes=hashes, hash_reset=h_reset, hash_keep=h_keep, cells=cells,
+                        encoded=enc, decoded=dec, constants=consts, enums=enums, wvals=wvals, active=active)
+
+
+def pipeline():
+    prob = DamBreak3D(0.05, obstacle=True, jitter=0.05)
+    sim = ol.OracleSim(prob)
+    arrs = prob.copy_to_array()
+    out = {"in_pos": arrs["pos"], "in_vel": arrs["vel"], "in_info": arrs["info"], "in_hash": arrs["hash"]}
+    sim.step()
+    out.update(s1_hash=sim.hash.copy(), s1_info=sim.info.copy(), s1_partindex=sim.partindex.copy(),
+               s1_cellStart=sim.cs.copy(), s1_cellEnd=sim.ce.copy(), s1_neibs=sim.nl.copy(),
+               s1_numInteractions=np.int64(sim.neibs_info.numInteractions),
+               s1_maxneibs=np.int64(sim.neibs_info.maxFluidBoundaryNeibs),
+               s1_pos=sim.pos.copy(), s1_vel=sim.vel.copy(), s1_forces=sim.forces.copy(), s1_dt=np.float32(sim.dt))
+    for _ in range(10):
+        sim.step()
+    out.update(s11_hash=sim.hash.copy(), s11_info=sim.info.copy(), s11_pos=sim.pos.copy(), s11_vel=sim.vel.copy(),
+               s11_dt=np.float32(sim.dt), deltap=np.float32(0.05))
+    np.savez_compressed(os.path.join(HERE, "oracle_pipeline.npz"), **out)
+
+
+if __name__ == "__main__":
+    kernels(); datamodel(); pipeline()
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,106 @@
+"""CPU-side checks of the product: libsphx.so loads and exports every symbol include/sphx.h declares
+(with the argument counts the Python binding assumes), error behaviour of the argument checks that need
+no GPU, Problem set-up."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+
+from gpusph_amd import capi, defs as D
+from gpusph_amd.params import SphxParams
+from gpusph_amd.problem import DamBreak3D, info_id
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_prototypes():
+    txt = open(os.path.join(ROOT, "include", "sphx.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(sphx_\w+)\s*\(([^;{}]*?)\)\s*;", txt, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",")])
+        protos[m.group(1)] = n
+    return protos
+
+
+def test_library_exports_every_declared_symbol():
+    protos = _header_prototypes()
+    assert len(protos) >= 25
+    lib = capi.load()
+    for name, nargs in protos.items():
+        assert hasattr(lib, name), "libsphx.so does not export %s" % name
+        assert name in capi.SIGNATURES, "python binding lacks %s" % name
+        assert len(capi.SIGNATURES[name][1]) == nargs, "%s: header has %d args, binding %d" % (
+            name, nargs, len(capi.SIGNATURES[name][1]))
+    assert set(capi.SIGNATURES) == set(protos)
+
+
+def test_sphx_params_struct_matches_header():
+    txt = open(os.path.join(ROOT, "include", "sphx.h")).read()
+    body = re.search(r"typedef struct sphx_params \{(.*?)\} sphx_params;", txt, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(uint32_t|uint64_t|int32_t|float)\s+", "", decl)
+        for part in decl.split(","):
+            names.append(re.sub(r"\[.*?\]", "", part).strip())
+    assert names == [f[0] for f in SphxParams._fields_]
+
+
+def test_pure_helpers_match_reference_formulas():
+    lib = capi.load()
+    # getFmaxElements = round_up(div_up(n,128),4); round_particles; reducefmax (src/cuda/forces.cu:105-140,539-552,960-964)
+    import oracle_lib as ol
+    L = ol.lib()
+    for n in (0, 1, 127, 128, 129, 511, 512, 513, 100000, 32_000_000):
+        assert lib.sphx_forces_fmax_elements(n) == ((n + 127) // 128 + 3) // 4 * 4 == L.orc_fmax_elements(n)
+        assert lib.sphx_forces_round_particles(n) == n // 128 * 128 == L.orc_round_particles(n)
+        fe = lib.sphx_forces_fmax_elements(n)
+        assert lib.sphx_forces_fmax_temp_elements(fe) == L.orc_fmax_temp_elements(fe)
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    lib = capi.load()
+    h = C.c_void_p()
+    rc = lib.sphx_create(C.byref(h), 0)
+    assert rc != 0 and lib.sphx_last_error()
+    from gpusph_amd.engine import TimestepEngine
+    with pytest.raises(capi.SphxError):
+        TimestepEngine(DamBreak3D(0.05))
+
+
+def test_dambreak_problem_setup():
+    p = DamBreak3D(0.04)
+    assert p.num_particles == DamBreak3D.count(0.04) == p.num_fluid + p.num_wall + p.num_obstacle
+    sp, pp = p.simparams, p.physparams
+    assert sp.neiblistsize == 128 and sp.neibboundpos == 127                     # DamBreak3D.cu:76, ProblemCore.cc:851
+    assert abs(sp.slength - 1.3 * p.m_deltap) < 1e-12 and abs(sp.influenceRadius - 2 * sp.slength) < 1e-12
+    assert (p.m_cellsize >= sp.influenceRadius).all()                             # ProblemCore.cc:1425-1431
+    assert abs(pp.bcoeff[0] - 1000 * 400 / 7) < 1e-2 and pp.sspowercoeff[0] == 3.0
+    assert abs(sp.densityDiffCoeff - 0.1 * 2 * sp.slength) < 1e-9                # ProblemCore.cc:1406-1416
+    arrs = p.copy_to_array()
+    assert (np.abs(arrs["pos"][:, :3]) <= p.m_cellsize / 2 * (1 + 1e-6)).all()  # cell-local, centred
+    back = p.global_pos(arrs["pos"], arrs["hash"])
+    assert np.abs(back - p.parts.pos_global[:, :3]).max() < 1e-6
+    ids = info_id(arrs["info"])
+    assert np.array_equal(ids, np.arange(p.num_particles, dtype=np.uint32))
+    assert len(np.unique(np.round(p.parts.pos_global[:, :3] / (0.01 * p.m_deltap)).astype(np.int64), axis=0)) == p.num_particles
+    for lin in D.LINEARIZATIONS:
+        q = DamBreak3D(0.05, linearization=lin)
+        g = q.calc_grid_pos(q.parts.pos_global)
+        assert np.array_equal(q.grid_pos_from_hash(q.calc_grid_hash(g)), g)
+
+
+def test_deltap_for_targets():
+    for target in (1.6e4, 1e6, 8e6, 3.2e7):
+        dp = DamBreak3D.deltap_for(target)
+        c = DamBreak3D.count(dp)
+        assert c <= target and c > 0.95 * target

@@ -1,0 +1,115 @@
+"""Pins the oracle against the REFERENCE: golden vectors produced by oracle/_ref (the reference's own
+sph_core.cu / particleinfo.h / hashkey.h / common_types.h compiled here, tests/golden/make_golden.py),
+and -- when oracle/_ref is present -- against the live reference library too."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from gpusph_amd import defs as D
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _w_f(k, r, h):
+    """oracle W/F through the same entry points the oracle's force loop uses"""
+    L = ol.lib()
+    return L.orc_W(int(k), float(r), float(h)), L.orc_F(int(k), float(r), float(h))
+
+
+def test_kernel_functions_match_reference_golden():
+    g = np.load(os.path.join(GOLD, "ref_kernels.npz"))
+    L = ol.lib()
+    for i in range(len(g["r"])):
+        k, r, h = int(g["kerneltype"][i]), float(g["r"][i]), float(g["slength"][i])
+        kr = 3.0 if k == D.GAUSSIAN else 2.0
+        # coefficient formulas restate src/cuda/forces.cu:274-309; W/F bodies are pinned bit-for-bit
+        assert np.float32(L.orc_wcoeff(k, h, kr)) == g["wcoeff"][i]
+        assert np.float32(L.orc_fcoeff(k, h, kr)) == g["fcoeff"][i]
+        w, f = _w_f(k, r, h)
+        assert np.float32(w) == g["W"][i], (k, r, h)
+        assert np.float32(f) == g["F"][i], (k, r, h)
+
+
+def test_kernel_functions_match_live_reference():
+    ref = ol.ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built here (needs /root/reference)")
+    L = ol.lib()
+    rng = np.random.default_rng(5)
+    for k in (1, 2, 3, 4):
+        kr = 3.0 if k == 4 else 2.0
+        h = float(np.float32(rng.uniform(1e-3, 0.5)))
+        wc, fc = L.orc_wcoeff(k, h, kr), L.orc_fcoeff(k, h, kr)
+        wsub = float(np.float32(np.exp(np.float32(-kr * kr))))
+        for r in rng.uniform(1e-4, kr, 200).astype(np.float32) * np.float32(h):
+            w, f = _w_f(k, float(r), h)
+            assert np.float32(w) == np.float32(ref.ref_W(k, float(r), h, wc, wsub))
+            assert np.float32(f) == np.float32(ref.ref_F(k, float(r), h, fc))
+
+
+def test_wendland_kernel_analytic():
+    """known answers independent of any code: W(0) = 21/(16 pi h^3), W(2h) = 0, F(2h) = 0"""
+    h = 0.0195
+    w0, _ = _w_f(D.WENDLAND, 0.0, h)
+    assert abs(w0 - 21.0 / (16.0 * np.pi * h ** 3)) <= 1e-6 * w0
+    w2, f2 = _w_f(D.WENDLAND, 2 * h, h)
+    assert abs(w2) <= 1e-6 * w0 and abs(f2) <= 1e-12 * abs(_w_f(D.WENDLAND, h, h)[1]) + 1e-3
+
+
+def test_datamodel_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "ref_datamodel.npz"))
+    L = ol.lib()
+
+    class Info(C.Structure):
+        _fields_ = [("x", C.c_uint16), ("y", C.c_uint16), ("z", C.c_uint16), ("w", C.c_uint16)]
+    L.orc_info_id.restype = C.c_uint32; L.orc_info_id.argtypes = [Info]
+    L.orc_info_type.restype = C.c_int; L.orc_info_type.argtypes = [Info]
+    for i, row in enumerate(g["info"]):
+        inf = Info(*map(int, row))
+        assert L.orc_info_id(inf) == g["id"][i]
+        assert L.orc_info_type(inf) == g["ptype"][i]
+    # python-side mirrors used by the host code
+    from gpusph_amd.problem import info_id, info_type
+    assert np.array_equal(info_id(g["info"]), g["id"])
+    assert np.array_equal(info_type(g["info"]).astype(np.int32), g["ptype"])
+    assert np.array_equal((g["info"][:, 1] & 0xFFF).astype(np.int32), g["object"])
+    assert np.array_equal((g["info"][:, 1] >> 12).astype(np.int32), g["fluid"])
+    x = g["info"][:, 0].astype(np.uint32)
+    t = x & 7
+    pred = ((t == 0) * 1 | (t == 1) * 2 | (t == 2) * 4 | (t == 3) * 8 | ((x & D.FG_MOVING_BOUNDARY) != 0) * 16 |
+            ((x & (D.FG_MOVING_BOUNDARY | D.FG_COMPUTE_FORCE)) != 0) * 32 | ((x & D.FG_COMPUTE_FORCE) != 0) * 64 |
+            ((x & D.FG_SURFACE) != 0) * 128).astype(np.uint32)
+    assert np.array_equal(pred, g["predicates"])
+    assert np.array_equal(g["hashes"] & D.CELLTYPE_BITMASK, g["hash_reset"])
+    assert np.array_equal(g["hashes"], g["hash_keep"])
+    assert np.array_equal((g["cells"] + 1) << D.CELLNUM_SHIFT, g["encoded"])
+    assert np.array_equal((((g["encoded"] + 37) >> D.CELLNUM_SHIFT).astype(np.int32) - 1), g["decoded"])
+    c = g["constants"]
+    assert list(c) == [D.CELLTYPE_BITMASK, D.CELL_HASH_MAX, D.NEIBINDEX_MASK, D.NEIBS_END, D.CELLNUM_ENCODED,
+                       0 << 30, 1 << 30, 2 << 30, (3 << 30) & 0xFFFFFFFF, D.EMPTY_SEGMENT, D.MAX_CELLS]
+    e = g["enums"]
+    assert list(e) == [D.CUBICSPLINE, D.QUADRATIC, D.WENDLAND, D.GAUSSIAN, D.SPH_F1, D.COLAGROSSI, D.DYN_BOUNDARY,
+                       D.LJ_BOUNDARY, D.PERIODIC_Z, D.SA_BOUNDARY, D.FERRARI]
+    assert list(np.isfinite(g["wvals"]).astype(np.int32)) == list(g["active"])
+
+
+def test_oracle_pipeline_regression():
+    """the oracle reproduces its own committed outputs (guards the fixture the GPU tests compare with)"""
+    from gpusph_amd.problem import DamBreak3D
+    g = np.load(os.path.join(GOLD, "oracle_pipeline.npz"))
+    prob = DamBreak3D(float(g["deltap"]), obstacle=True, jitter=0.05)
+    arrs = prob.copy_to_array()
+    assert np.array_equal(arrs["pos"].view(np.uint32), g["in_pos"].view(np.uint32))
+    assert np.array_equal(arrs["hash"], g["in_hash"])
+    sim = ol.OracleSim(prob)
+    sim.step()
+    assert np.array_equal(sim.hash, g["s1_hash"]) and np.array_equal(sim.nl, g["s1_neibs"])
+    assert np.array_equal(sim.cs, g["s1_cellStart"]) and np.array_equal(sim.ce, g["s1_cellEnd"])
+    assert np.array_equal(sim.pos.view(np.uint32), g["s1_pos"].view(np.uint32))
+    assert np.array_equal(sim.forces.view(np.uint32), g["s1_forces"].view(np.uint32))
+    for _ in range(10):
+        sim.step()
+    assert np.array_equal(sim.pos.view(np.uint32), g["s11_pos"].view(np.uint32))
+    assert np.float32(sim.dt) == g["s11_dt"]
