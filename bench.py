@@ -64,8 +64,11 @@ def main():
     ap.add_argument("--particles", type=float, default=DEFAULT_PARTICLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-obstacle", action="store_true")
+    ap.add_argument("--no-tiles", action="store_true", help="A/B: use the generic gather forces kernel")
     args = ap.parse_args()
 
+    if args.no_tiles:
+        os.environ["SPHX_DISABLE_TILES"] = "1"
     import torch
     from gpusph_amd.problem import DamBreak3D
 

@@ -36,22 +36,7 @@ struct ForcesArgs {
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// Tait EOS pieces sharing one log2 (P: src/cuda/phys_core.cu:99-104, soundSpeed :130-135)
-struct Eos { float P, sspeed, rho, p_precalc; };
-__device__ __forceinline__ Eos eos(const DevParams &p, float rho_tilde, uint32_t fl)
-{
-	Eos e;
-	const float ratio = rho_tilde + 1.0f;
-	const float L = fast_log2(ratio);
-	e.P = p.bcoeff[fl]*(fast_exp2(p.gammacoeff[fl]*L) - 1.0f);
-	e.sspeed = p.sscoeff[fl]*fast_exp2(p.sspowercoeff[fl]*L);
-	e.rho = ratio*p.rho0[fl];
-	e.p_precalc = e.P*fast_rcp(e.rho*e.rho); // precalc_pressure SPH_F1: P/rho^2 (forces_kernel.def:419-429)
-	return e;
-}
 
 // F<kerneltype>(r, h): src/cuda/sph_core.cu:146-191
 template<int KERNEL>
@@ -73,18 +58,14 @@ __device__ __forceinline__ float kernel_F(const DevParams &p, float r, float inv
 	}
 }
 
-struct Self {
-	float4 pos, vel;
-	int3 gridPos;
-	Eos e;
-	uint32_t fl;
-	float tau[6];
-};
-
-// per-particle EOS pre-pass: aux[i] = {P/rho^2, c, P, rho}.  The reference recomputes these for
-// the NEIGHBOUR inside every pair (2 __powf + 1 division per pair, forces_kernel.def:690-702,
-// 1126-1128); they are pure functions of the neighbour's own rho~, so computing them once per
-// particle and gathering 16 B gives the same numbers with ~20 fewer issue slots per pair.
+// ------------------------------------------------------------------------------------------
+// per-particle EOS pre-pass: aux[i] = {P/rho^2, c, P, rho}.
+// The reference recomputes P (__powf), soundSpeed (__powf) and P/rho^2 (division) of the
+// NEIGHBOUR inside every pair (forces_kernel.def:690-702,1126-1128; phys_core.cu:99-135).  They are
+// pure functions of the neighbour's own rho~, so evaluating them once per particle and gathering
+// 16 B gives the same numbers with ~20 fewer issue slots per pair -- and, being per particle, can
+// afford the accurate powf and IEEE division (closer to the oracle than __powf would be).
+// ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 eos_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__restrict__ info,
 	float4 *__restrict__ aux, uint32_t n)
@@ -92,26 +73,139 @@ eos_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__re
 	const uint32_t i = blockIdx.x*256 + threadIdx.x;
 	if (i >= n) return;
 	const uint32_t fl = (p.numfluids > 1) ? FLUID_NUM(info[i]) : 0u;
-	const Eos e = eos(p, vel[i].w, fl);
-	aux[i] = make_float4(e.p_precalc, e.sspeed, e.P, e.rho);
+	const float ratio = vel[i].w + 1.0f;
+	const float P = p.bcoeff[fl]*(powf(ratio, p.gammacoeff[fl]) - 1.0f);
+	const float c = p.sscoeff[fl]*powf(ratio, p.sspowercoeff[fl]);
+	const float rho = ratio*p.rho0[fl];
+	aux[i] = make_float4(P/(rho*rho), c, P, rho);
 }
 
-#define NB 4   // neighbours resolved per batch: list entries, cell bases and particle rows of a
-               // batch are each fetched with independent loads in flight (3 dependent round trips per
-               // NB neighbours instead of per neighbour); the next batch's list entries are
-               // prefetched while the current one is computed
+struct Self {
+	float4 pos, vel;
+	int3 gridPos;
+	float p_precalc, sspeed, P, rho, inv_rho;
+	uint32_t fl;
+	float tau[6];
+};
 
-template<int NPTYPE>
+// one pair (i <- j).  Terms, in the reference's order (compute_all_pp_interaction,
+// forces_kernel.def:3565-3610): continuity + density diffusion -> force.w; pressure + viscous ->
+// force.xyz.  (pcx,pcy,pcz) = own position shifted into the neighbour's cell frame.
+template<int KERNEL, int TURB, bool COLAGROSSI, bool MOMENTUM, bool DIFFUSE>
+__device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s, float inv_h,
+	float pcx, float pcy, float pcz, const float4 &npos, const float4 &nvel, const float4 &naux,
+	bool same_fluid, bool valid, const float *ntau, float4 &force)
+{
+	const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
+	const float nmass = npos.w;
+	const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
+	const float r = fast_sqrt(r2);
+	if (!valid || !is_active_w(nmass) || r >= p.influenceradius) return;
+
+	const float vx = s.vel.x - nvel.x, vy = s.vel.y - nvel.y, vz = s.vel.z - nvel.z;
+	const float vel_dot_pos = fmaf(vz, rz, fmaf(vy, ry, vx*rx));
+	const float f = kernel_F<KERNEL>(p, r, inv_h);
+	const float n_precalc = naux.x, n_sspeed = naux.y, n_P = naux.z, n_rho = naux.w;
+	const float mf = nmass*f;
+
+	// mass_continuity_div_vel_term (forces_kernel.def:2140-2151)
+	float DrDt = mf*vel_dot_pos;
+	if (COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
+		if (same_fluid) {
+			const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
+			if (!(fabsf(s.P - n_P) < fabsf(gdotr*s.rho)))
+				DrDt -= p.densityDiffCoeff*p.sscoeff[s.fl]*(n_rho*s.inv_rho - 1.0f)*mf;
+		}
+	}
+	force.w += DrDt;
+
+	if (MOMENTUM) {
+		// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
+		float kk = -(s.p_precalc + n_precalc)*mf;
+		if (TURB == SPHX_ARTIFICIAL) {
+			// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764)
+			if (vel_dot_pos < 0.0f) {
+				const float visc = vel_dot_pos*p.slength*p.artvisccoeff*(s.sspeed + n_sspeed)*
+					fast_rcp((r2 + p.epsartvisc)*(s.rho + n_rho));
+				kk = fmaf(visc, mf, kk);
+			}
+		}
+		float ax = kk*rx, ay = kk*ry, az = kk*rz;
+		if (TURB == SPHX_SPS) { // forces_kernel.def:2777-2798
+			const float xx = s.tau[0] + ntau[0], xy = s.tau[1] + ntau[1], xz = s.tau[2] + ntau[2];
+			const float yy = s.tau[3] + ntau[3], yz = s.tau[4] + ntau[4], zz = s.tau[5] + ntau[5];
+			ax = fmaf(mf, fmaf(xz, rz, fmaf(xy, ry, xx*rx)), ax);
+			ay = fmaf(mf, fmaf(yz, rz, fmaf(yy, ry, xy*rx)), ay);
+			az = fmaf(mf, fmaf(zz, rz, fmaf(yz, ry, xz*rx)), az);
+		}
+		force.x += ax; force.y += ay; force.z += az;
+	}
+}
+
+// finalizeforcesDevice (forces_kernel.def:4032-4150) for one particle; returns its CFL term
+__device__ __forceinline__ float finalize_particle(const DevParams &p, const ForcesArgs &a, uint32_t index,
+	const particleinfo &info, const Self &s, float4 force)
+{
+	float cfl_term = 0.0f;
+	const uint32_t ptype = PART_TYPE(info);
+	force.w /= p.rho0[s.fl]; // forces_fixup :3212-3218
+	if (ptype == PT_FLUID) {
+		force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
+		// dyndt_forces_shared_data::store (:3436-3457)
+		const float amag = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
+		cfl_term = fmaxf(amag, s.sspeed*s.sspeed/p.slength);
+	}
+	if (HAS_COMPUTE_FORCE(info) && ptype != PT_VERTEX && a.rbforces) { // :4121-4142
+		force.x *= s.pos.w; force.y *= s.pos.w; force.z *= s.pos.w;
+		const uint32_t obj = OBJECT_NUM(info);
+		const uint32_t rbindex = (uint32_t)((int)info_id(info) + a.rb->rbstart[obj]);
+		a.rbforces[rbindex] = force;
+		const float armx = (s.gridPos.x - a.rb->cgGridPos[obj][0])*p.cs[0] + (s.pos.x - a.rb->cgPos[obj][0]);
+		const float army = (s.gridPos.y - a.rb->cgGridPos[obj][1])*p.cs[1] + (s.pos.y - a.rb->cgPos[obj][1]);
+		const float armz = (s.gridPos.z - a.rb->cgGridPos[obj][2])*p.cs[2] + (s.pos.z - a.rb->cgPos[obj][2]);
+		a.rbtorques[rbindex] = make_float4(army*force.z - armz*force.y,
+			armz*force.x - armx*force.z, armx*force.y - army*force.x, 0.0f);
+	}
+	a.forces[index] = force;
+	return cfl_term;
+}
+
+template<int TURB>
+__device__ __forceinline__ void load_self(const DevParams &p, const ForcesArgs &a, uint32_t index,
+	const particleinfo &info, const float4 &pos, bool multifluid, Self &s)
+{
+	s.pos = pos;
+	s.vel = a.vel[index];
+	s.gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	s.fl = multifluid ? FLUID_NUM(info) : 0u;
+	const float4 ax = a.aux[index];
+	s.p_precalc = ax.x; s.sspeed = ax.y; s.P = ax.z; s.rho = ax.w;
+	s.inv_rho = fast_rcp(ax.w);
+	if (TURB == SPHX_SPS) {
+		const float2 t0 = a.tau0[index], t1 = a.tau1[index], t2 = a.tau2[index];
+		s.tau[0] = t0.x; s.tau[1] = t0.y; s.tau[2] = t1.x; s.tau[3] = t1.y; s.tau[4] = t2.x; s.tau[5] = t2.y;
+	}
+}
+
+template<int NPTYPE, int N>
 __device__ __forceinline__ void load_list_batch(const DevParams &p, const neibdata *__restrict__ list,
-	uint32_t index, int slot, uint32_t nd[NB])
+	uint32_t index, int slot, uint32_t nd[N])
 {
 #pragma unroll
-	for (int k = 0; k < NB; ++k) {
+	for (int k = 0; k < N; ++k) {
 		// entries past the terminator are never used; the clamp only keeps the address in bounds
 		const int sl = (NPTYPE == PT_FLUID) ? min(slot + k, (int)p.neiblistsize - 1) : max(slot - k, 0);
 		nd[k] = list[(size_t)sl*p.stride + index];
 	}
 }
+
+// ==========================================================================================
+// Generic path: neighbour rows gathered through L2.  Used for multi-fluid and SPS runs, for
+// neighbour lists not built by this context, and whenever the tiling below overflowed.
+// ==========================================================================================
+#define NB 4   // neighbours resolved per batch: list entries, cell bases and particle rows of a
+               // batch are fetched with independent loads in flight (3 dependent round trips per NB
+               // neighbours instead of per neighbour); the next batch's list entries are prefetched
 
 // walk one typed section of the neighbour list (neiblist_iterator_simple,
 // src/cuda/neibs_iteration.cuh:165-205; getNeibIndex src/cuda/cellgrid.cuh:200-228)
@@ -121,16 +215,15 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 {
 	int slot = (NPTYPE == PT_FLUID) ? 0 : (int)p.neibboundpos;
 	uint32_t nd[NB], ndn[NB];
-	load_list_batch<NPTYPE>(p, a.neibsList, index, slot, nd);
+	load_list_batch<NPTYPE, NB>(p, a.neibsList, index, slot, nd);
 
 	int cell = 0;
 	uint32_t cell_base = 0;
-	const float inv_rho_i = fast_rcp(s.e.rho);
 	bool done = false;
 
 	while (!done) {
 		slot = (NPTYPE == PT_FLUID) ? slot + NB : slot - NB;
-		load_list_batch<NPTYPE>(p, a.neibsList, index, slot, ndn);
+		load_list_batch<NPTYPE, NB>(p, a.neibsList, index, slot, ndn);
 
 		// stage 1: decode entries, fetch the base index of every cell that changes in this batch
 		bool valid[NB], enc[NB];
@@ -159,17 +252,20 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 
 		// stage 2: gather the neighbour rows of the whole batch
 		float4 npos[NB], nvel[NB], naux[NB];
-		uint32_t nfl[NB];
-		float2 t0[NB], t1[NB], t2[NB];
+		bool same[NB];
+		float ntau[NB][6];
 #pragma unroll
 		for (int k = 0; k < NB; ++k) {
 			const uint32_t j = valid[k] ? cb[k] + (nd[k] & NEIBINDEX_MASK) : index;
 			npos[k] = a.pos[j];
 			nvel[k] = a.vel[j];
 			naux[k] = a.aux[j];
-			nfl[k] = 0;
-			if (MULTIFLUID) nfl[k] = FLUID_NUM(a.info[j]);
-			if (TURB == SPHX_SPS && MOMENTUM) { t0[k] = a.tau0[j]; t1[k] = a.tau1[j]; t2[k] = a.tau2[j]; }
+			same[k] = true;
+			if (MULTIFLUID) same[k] = FLUID_NUM(a.info[j]) == s.fl;
+			if (TURB == SPHX_SPS && MOMENTUM) {
+				const float2 t0 = a.tau0[j], t1 = a.tau1[j], t2 = a.tau2[j];
+				ntau[k][0] = t0.x; ntau[k][1] = t0.y; ntau[k][2] = t1.x; ntau[k][3] = t1.y; ntau[k][4] = t2.x; ntau[k][5] = t2.y;
+			}
 		}
 
 		// stage 3: pair interactions, in list order
@@ -179,50 +275,8 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 			const float pcx = fmaf(-(float)(cx - 1), p.cs[0], s.pos.x);
 			const float pcy = fmaf(-(float)(cy - 1), p.cs[1], s.pos.y);
 			const float pcz = fmaf(-(float)(cz - 1), p.cs[2], s.pos.z);
-			const float rx = pcx - npos[k].x, ry = pcy - npos[k].y, rz = pcz - npos[k].z;
-			const float nmass = npos[k].w;
-			const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
-			const float r = fast_sqrt(r2);
-			if (!valid[k] || !is_active_w(nmass) || r >= p.influenceradius) continue;
-
-			const float vx = s.vel.x - nvel[k].x, vy = s.vel.y - nvel[k].y, vz = s.vel.z - nvel[k].z;
-			const float vel_dot_pos = fmaf(vz, rz, fmaf(vy, ry, vx*rx));
-			const float f = kernel_F<KERNEL>(p, r, inv_h);
-			const float n_precalc = naux[k].x, n_sspeed = naux[k].y, n_P = naux[k].z, n_rho = naux[k].w;
-			const float mf = nmass*f;
-
-			// mass_continuity_div_vel_term (forces_kernel.def:2140-2151)
-			float DrDt = mf*vel_dot_pos;
-			if (COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
-				if (!MULTIFLUID || nfl[k] == s.fl) {
-					const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
-					if (!(fabsf(s.e.P - n_P) < fabsf(gdotr*s.e.rho)))
-						DrDt -= p.densityDiffCoeff*p.sscoeff[s.fl]*(n_rho*inv_rho_i - 1.0f)*mf;
-				}
-			}
-			force.w += DrDt;
-
-			if (MOMENTUM) {
-				// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
-				float kk = -(s.e.p_precalc + n_precalc)*mf;
-				if (TURB == SPHX_ARTIFICIAL) {
-					// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764)
-					if (vel_dot_pos < 0.0f) {
-						const float visc = vel_dot_pos*p.slength*p.artvisccoeff*(s.e.sspeed + n_sspeed)*
-							fast_rcp((r2 + p.epsartvisc)*(s.e.rho + n_rho));
-						kk = fmaf(visc, mf, kk);
-					}
-				}
-				float ax = kk*rx, ay = kk*ry, az = kk*rz;
-				if (TURB == SPHX_SPS) { // forces_kernel.def:2777-2798
-					const float xx = s.tau[0] + t0[k].x, xy = s.tau[1] + t0[k].y, xz = s.tau[2] + t1[k].x;
-					const float yy = s.tau[3] + t1[k].y, yz = s.tau[4] + t2[k].x, zz = s.tau[5] + t2[k].y;
-					ax = fmaf(mf, fmaf(xz, rz, fmaf(xy, ry, xx*rx)), ax);
-					ay = fmaf(mf, fmaf(yz, rz, fmaf(yy, ry, xy*rx)), ay);
-					az = fmaf(mf, fmaf(zz, rz, fmaf(yz, ry, xz*rx)), az);
-				}
-				force.x += ax; force.y += ay; force.z += az;
-			}
+			pair_interact<KERNEL, TURB, COLAGROSSI, MOMENTUM, DIFFUSE>(p, s, inv_h, pcx, pcy, pcz,
+				npos[k], nvel[k], naux[k], same[k], valid[k], ntau[k], force);
 		}
 #pragma unroll
 		for (int k = 0; k < NB; ++k) nd[k] = ndn[k];
@@ -231,8 +285,10 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 
 template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID>
 __global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
-forces_kernel(DevParams p, ForcesArgs a)
+forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZero)
 {
+	// when the tiled kernel handles this launch the generic one is skipped on the device side
+	if (runIfNonZero && *runIfNonZero == 0) return;
 	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
 	float cfl_term = 0.0f;
 
@@ -244,15 +300,7 @@ forces_kernel(DevParams p, ForcesArgs a)
 		if (!is_active_w(pos.w)) break;
 
 		Self s;
-		s.pos = pos;
-		s.vel = a.vel[index];
-		s.gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-		s.fl = MULTIFLUID ? FLUID_NUM(info) : 0u;
-		{ const float4 ax = a.aux[index]; s.e.p_precalc = ax.x; s.e.sspeed = ax.y; s.e.P = ax.z; s.e.rho = ax.w; }
-		if (TURB == SPHX_SPS) {
-			const float2 t0 = a.tau0[index], t1 = a.tau1[index], t2 = a.tau2[index];
-			s.tau[0] = t0.x; s.tau[1] = t0.y; s.tau[2] = t1.x; s.tau[3] = t1.y; s.tau[4] = t2.x; s.tau[5] = t2.y;
-		}
+		load_self<TURB>(p, a, index, info, pos, MULTIFLUID, s);
 		const float inv_h = fast_rcp(p.slength);
 		const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
 
@@ -267,37 +315,15 @@ forces_kernel(DevParams p, ForcesArgs a)
 			// no density diffusion from boundary neighbours (:1596-1606)
 			if (dyn)
 				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_BOUNDARY, true, false>(p, a, index, s, inv_h, force);
-		} else if (ptype == PT_BOUNDARY && (dyn || a.compute_object_forces)) {
+		} else if (ptype == PT_BOUNDARY && dyn) {
 			// boundary <- fluid (forces_kernel.def:3650-3679): DYN always evolves density; momentum
 			// only for particles of bodies with force feedback
-			if (dyn) {
-				if (HAS_COMPUTE_FORCE(info))
-					walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, true, true>(p, a, index, s, inv_h, force);
-				else
-					walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, false, true>(p, a, index, s, inv_h, force);
-			}
+			if (HAS_COMPUTE_FORCE(info))
+				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, true, true>(p, a, index, s, inv_h, force);
+			else
+				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, false, true>(p, a, index, s, inv_h, force);
 		}
-
-		// ---- finalizeforcesDevice (forces_kernel.def:4032-4150) ----
-		force.w /= p.rho0[s.fl]; // forces_fixup :3212-3218
-		if (ptype == PT_FLUID) {
-			force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
-			// dyndt_forces_shared_data::store (:3436-3457)
-			const float amag = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
-			cfl_term = fmaxf(amag, s.e.sspeed*s.e.sspeed/p.slength);
-		}
-		if (HAS_COMPUTE_FORCE(info) && ptype != PT_VERTEX && a.rbforces) { // :4121-4142
-			force.x *= pos.w; force.y *= pos.w; force.z *= pos.w;
-			const uint32_t obj = OBJECT_NUM(info);
-			const uint32_t rbindex = (uint32_t)((int)info_id(info) + a.rb->rbstart[obj]);
-			a.rbforces[rbindex] = force;
-			const float armx = (s.gridPos.x - a.rb->cgGridPos[obj][0])*p.cs[0] + (pos.x - a.rb->cgPos[obj][0]);
-			const float army = (s.gridPos.y - a.rb->cgGridPos[obj][1])*p.cs[1] + (pos.y - a.rb->cgPos[obj][1]);
-			const float armz = (s.gridPos.z - a.rb->cgGridPos[obj][2])*p.cs[2] + (pos.z - a.rb->cgPos[obj][2]);
-			a.rbtorques[rbindex] = make_float4(army*force.z - armz*force.y,
-				armz*force.x - armx*force.z, armx*force.y - army*force.x, 0.0f);
-		}
-		a.forces[index] = force;
+		cfl_term = finalize_particle(p, a, index, info, s, force);
 	} while (0);
 
 	// maxBlockReduce (src/cuda/device_core.cu:40-59) as wave shuffles + one LDS word per wave
@@ -312,6 +338,233 @@ forces_kernel(DevParams p, ForcesArgs a)
 			float m = wave_max[0];
 			for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) m = fmaxf(m, wave_max[w]);
 			a.cfl[a.cflOffset + blockIdx.x] = m;
+		}
+	}
+}
+
+// ==========================================================================================
+// Tiled path (the fast one): LDS staging of the 27-cell neighbour window per workgroup.
+//
+// A tile is a run of consecutive non-empty cells of one grid row (cells along COORD1 are
+// contiguous in the sorted particle arrays) holding <= 128 particles; its neighbour window is
+// the 9 rows x (cells+2) block around it, i.e. 9 contiguous particle ranges.  The workgroup
+// copies those ranges (pos, vel, EOS aux: 48 B/particle, fully coalesced) into LDS once, then
+// every thread walks its particle's neighbour list reading the neighbour rows from LDS with
+// ds_read_b128 instead of gathering them through L1/L2 (where a 64-lane gather touches 12-20
+// different cache lines per instruction and the L2->L1 line fills, ~1/4 used, were the
+// bottleneck: 4.0 ms per launch at 8 M particles).  Tiles are produced by build_tiles_kernel
+// (neibs.hip) at neighbour-list build time.  Persistent grid: 2 workgroups per CU (LDS bound),
+// each looping over tiles, so one workgroup's staging overlaps the other's pair loop.
+// ==========================================================================================
+template<int NPTYPE, bool MOMENTUM, bool DIFFUSE, int KERNEL, int TURB, bool COLAGROSSI>
+__device__ __forceinline__ void walk_section_lds(const DevParams &p, const neibdata *__restrict__ list,
+	uint32_t index, const Self &s, float inv_h, int myCol,
+	const float4 *sPos, const float4 *sVel, const float4 *sAux, const uint32_t *sCellBase, const float4 *sCode,
+	float4 &force)
+{
+	int slot = (NPTYPE == PT_FLUID) ? 0 : (int)p.neibboundpos;
+	uint32_t nd[TILE_NB], ndn[TILE_NB];
+	load_list_batch<NPTYPE, TILE_NB>(p, list, index, slot, nd);
+	float pcx = 0.0f, pcy = 0.0f, pcz = 0.0f;
+	uint32_t cbase = 0;
+	bool done = false;
+	while (!done) {
+		slot = (NPTYPE == PT_FLUID) ? slot + TILE_NB : slot - TILE_NB;
+		load_list_batch<NPTYPE, TILE_NB>(p, list, index, slot, ndn);   // HBM latency hidden behind TILE_NB pairs
+
+		float4 npos[TILE_NB], nvel[TILE_NB], naux[TILE_NB];
+		float qx[TILE_NB], qy[TILE_NB], qz[TILE_NB];
+		bool valid[TILE_NB];
+		bool alive = true;
+#pragma unroll
+		for (int k = 0; k < TILE_NB; ++k) {
+			const uint32_t d = nd[k];
+			alive = alive && (d != NEIBS_END);
+			valid[k] = alive;
+			if (alive && d >= CELLNUM_ENCODED) {
+				const float4 ct = sCode[(d >> CELLNUM_SHIFT) - 1];
+				pcx = fmaf(-ct.x, p.cs[0], s.pos.x);
+				pcy = fmaf(-ct.y, p.cs[1], s.pos.y);
+				pcz = fmaf(-ct.z, p.cs[2], s.pos.z);
+				cbase = sCellBase[__float_as_uint(ct.w) + (uint32_t)myCol];
+			}
+			qx[k] = pcx; qy[k] = pcy; qz[k] = pcz;
+			const uint32_t L = alive ? cbase + (d & NEIBINDEX_MASK) : 0u;
+			npos[k] = sPos[L]; nvel[k] = sVel[L]; naux[k] = sAux[L];
+		}
+		done = !alive;
+#pragma unroll
+		for (int k = 0; k < TILE_NB; ++k)
+			pair_interact<KERNEL, TURB, COLAGROSSI, MOMENTUM, DIFFUSE>(p, s, inv_h, qx[k], qy[k], qz[k],
+				npos[k], nvel[k], naux[k], true, valid[k], nullptr, force);
+#pragma unroll
+		for (int k = 0; k < TILE_NB; ++k) nd[k] = ndn[k];
+	}
+}
+
+template<int KERNEL, int TURB, bool COLAGROSSI>
+__global__ void __launch_bounds__(TILE_THREADS, 1)
+forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
+	const uint32_t *__restrict__ tileCtl /* [0]=count, [1]=overflow */, const uint32_t *__restrict__ cellEnd)
+{
+	__shared__ float4 sPos[TILE_WCAP];
+	__shared__ float4 sVel[TILE_WCAP];
+	__shared__ float4 sAux[TILE_WCAP];
+	__shared__ uint32_t sCellBase[9*TILE_KW];
+	__shared__ uint32_t sCnt[9*TILE_KW];
+	__shared__ uint32_t sStart[9*TILE_KW];
+	__shared__ float4 sCode[27];
+	__shared__ uint32_t sRowStart[9], sRowTotal[9], sRowBase[9], sRowContig[9];
+	__shared__ float sWaveMax[TILE_THREADS/64];
+
+	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this launch
+	const uint32_t numTiles = tileCtl[0];
+	const uint32_t tid = threadIdx.x;
+
+	if (tid < 27) {
+		// neighbour-cell code -> {offset as floats, index of that cell in the window table relative to
+		// the particle's own column}; d_cell_to_offset order (src/cuda/forces.cu:376-386)
+		const int c = (int)tid;
+		const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
+		const int o[3] = { cx - 1, cy - 1, cz - 1 };
+		const int o1 = (p.c1 == 0) ? o[0] : (p.c1 == 1) ? o[1] : o[2];
+		const int o2 = (p.c2 == 0) ? o[0] : (p.c2 == 1) ? o[1] : o[2];
+		const int o3 = (p.c3 == 0) ? o[0] : (p.c3 == 1) ? o[1] : o[2];
+		const uint32_t off = (uint32_t)(((o2 + 1) + 3*(o3 + 1))*TILE_KW + o1 + 1);
+		sCode[c] = make_float4((float)o[0], (float)o[1], (float)o[2], __uint_as_float(off));
+	}
+	const float inv_h = fast_rcp(p.slength);
+	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
+
+	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+		const uint32_t *d = tiles + (size_t)TILE_DESC*tile;
+		const int g2 = (int)d[0], g3 = (int)d[1], ca = (int)d[2], ncells = (int)d[3];
+		const uint32_t first = d[4], hc = d[5];
+		if (first >= a.toParticle || first + hc <= a.fromParticle) continue;
+		__syncthreads();   // the previous tile's readers are done with LDS
+
+		// 1. start/count of every window cell
+		for (uint32_t w = tid; w < 9*TILE_KW; w += TILE_THREADS) {
+			const int r = (int)(w/TILE_KW), col = (int)(w - r*TILE_KW);
+			uint32_t cnt = 0, start = 0;
+			if (col < ncells + 2) {
+				int v[3];
+				v[0] = ca - 1 + col; v[1] = g2 + (r % 3) - 1; v[2] = g3 + r/3 - 1;
+				int gx = (p.c1 == 0) ? v[0] : (p.c2 == 0) ? v[1] : v[2];
+				int gy = (p.c1 == 1) ? v[0] : (p.c2 == 1) ? v[1] : v[2];
+				int gz = (p.c1 == 2) ? v[0] : (p.c2 == 2) ? v[1] : v[2];
+				bool ok = true;
+				if (gx < 0) { if (p.periodic & SPHX_PERIODIC_X) gx = p.gs[0] - 1; else ok = false; }
+				else if (gx >= p.gs[0]) { if (p.periodic & SPHX_PERIODIC_X) gx = 0; else ok = false; }
+				if (gy < 0) { if (p.periodic & SPHX_PERIODIC_Y) gy = p.gs[1] - 1; else ok = false; }
+				else if (gy >= p.gs[1]) { if (p.periodic & SPHX_PERIODIC_Y) gy = 0; else ok = false; }
+				if (gz < 0) { if (p.periodic & SPHX_PERIODIC_Z) gz = p.gs[2] - 1; else ok = false; }
+				else if (gz >= p.gs[2]) { if (p.periodic & SPHX_PERIODIC_Z) gz = 0; else ok = false; }
+				if (ok) {
+					const uint32_t h = grid_hash(p, gx, gy, gz);
+					const uint32_t cs = a.cellStart[h];
+					if (cs != CELL_EMPTY) { start = cs; cnt = cellEnd[h] - cs; }
+				}
+			}
+			sCnt[w] = cnt; sStart[w] = start;
+		}
+		__syncthreads();
+		// 2. per-row extent
+		if (tid < 9) {
+			uint32_t total = 0, rs = 0, lastEnd = 0;
+			bool have = false;
+			for (int col = 0; col < ncells + 2; ++col) {
+				const uint32_t cnt = sCnt[tid*TILE_KW + col];
+				if (cnt) {
+					const uint32_t st = sStart[tid*TILE_KW + col];
+					if (!have) { rs = st; have = true; }
+					lastEnd = st + cnt; total += cnt;
+				}
+			}
+			sRowStart[tid] = rs; sRowTotal[tid] = total;
+			sRowContig[tid] = (!have || lastEnd - rs == total) ? 1u : 0u;
+		}
+		__syncthreads();
+		// 3. LDS slot of the first particle of every window cell
+		if (tid < 9) {
+			uint32_t base = 0;
+			for (uint32_t r = 0; r < tid; ++r) base += sRowTotal[r];
+			sRowBase[tid] = base;
+			uint32_t run = base;
+			for (int col = 0; col < ncells + 2; ++col) {
+				sCellBase[tid*TILE_KW + col] = run;
+				run += sCnt[tid*TILE_KW + col];
+			}
+		}
+		__syncthreads();
+		// 4. stage the window: 9 contiguous particle ranges -> LDS (coalesced 16 B/lane loads)
+		for (int r = 0; r < 9; ++r) {
+			const uint32_t total = sRowTotal[r], base = sRowBase[r];
+			if (sRowContig[r]) {
+				const uint32_t rs = sRowStart[r];
+				for (uint32_t q = tid; q < total; q += TILE_THREADS) {
+					if (base + q < TILE_WCAP) {
+						sPos[base + q] = a.pos[rs + q]; sVel[base + q] = a.vel[rs + q]; sAux[base + q] = a.aux[rs + q];
+					}
+				}
+			} else {   // a row crossing cell-type segments (multi-GPU device maps not split on COORD3)
+				for (int col = 0; col < ncells + 2; ++col) {
+					const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = sCellBase[r*TILE_KW + col];
+					for (uint32_t q = tid; q < cnt; q += TILE_THREADS) {
+						if (cb + q < TILE_WCAP) {
+							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q]; sAux[cb + q] = a.aux[st + q];
+						}
+					}
+				}
+			}
+		}
+		__syncthreads();
+
+		// 5. pair loop for the tile's own particles (<= 128, one per thread)
+		float cfl_term = 0.0f;
+		const uint32_t index = first + tid;
+		if (tid < hc && index >= a.fromParticle && index < a.toParticle) {
+			const particleinfo info = a.info[index];
+			const uint32_t ptype = PART_TYPE(info);
+			const float4 pos = a.pos[index];
+			if (is_active_w(pos.w)) {
+				Self s;
+				load_self<TURB>(p, a, index, info, pos, false, s);
+				const int myG1 = (p.c1 == 0) ? s.gridPos.x : (p.c1 == 1) ? s.gridPos.y : s.gridPos.z;
+				const int myCol = myG1 - ca;
+				float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				if (ptype == PT_FLUID) {
+					walk_section_lds<PT_FLUID, true, true, KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myCol,
+						sPos, sVel, sAux, sCellBase, sCode, force);
+					if (dyn)
+						walk_section_lds<PT_BOUNDARY, true, false, KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myCol,
+							sPos, sVel, sAux, sCellBase, sCode, force);
+				} else if (ptype == PT_BOUNDARY && dyn) {
+					if (HAS_COMPUTE_FORCE(info))
+						walk_section_lds<PT_FLUID, true, true, KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myCol,
+							sPos, sVel, sAux, sCellBase, sCode, force);
+					else
+						walk_section_lds<PT_FLUID, false, true, KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myCol,
+							sPos, sVel, sAux, sCellBase, sCode, force);
+				}
+				cfl_term = finalize_particle(p, a, index, info, s, force);
+			}
+		}
+		// 6. CFL: the array keeps the reference's one-entry-per-128-particles layout
+		// (getFmaxElements); tiles are not 128-aligned, so they max into the entry of their first
+		// particle.  Non-negative floats order like their bit patterns; the caller zeroed CFL.
+		if (a.cfl) {
+#pragma unroll
+			for (int dd = 32; dd > 0; dd >>= 1)
+				cfl_term = fmaxf(cfl_term, __shfl_down(cfl_term, dd));
+			if ((tid & 63u) == 0) sWaveMax[tid >> 6] = cfl_term;
+			__syncthreads();
+			if (tid == 0) {
+				float m = sWaveMax[0];
+				for (int w = 1; w < TILE_THREADS/64; ++w) m = fmaxf(m, sWaveMax[w]);
+				const uint32_t rel = first > a.fromParticle ? first - a.fromParticle : 0u;
+				atomicMax(reinterpret_cast<unsigned int*>(a.cfl + a.cflOffset + rel/SPHX_BLOCK_FORCES), __float_as_uint(m));
+			}
 		}
 	}
 }
@@ -504,32 +757,45 @@ extern "C" uint32_t sphx_forces_fmax_temp_elements(uint32_t nels)
 extern "C" uint32_t sphx_forces_round_particles(uint32_t n) { return (n/SPHX_BLOCK_FORCES)*SPHX_BLOCK_FORCES; }
 
 template<int KERNEL, int TURB, bool COLA>
-static void launch_forces_mf(bool multifluid, dim3 grid, hipStream_t stream, const DevParams &p, const ForcesArgs &a)
+static void launch_forces_mf(bool multifluid, dim3 grid, hipStream_t stream, const DevParams &p, const ForcesArgs &a,
+	const uint32_t *guard)
 {
 	if (multifluid)
-		forces_kernel<KERNEL, TURB, COLA, true><<<grid, SPHX_BLOCK_FORCES, 0, stream>>>(p, a);
+		forces_kernel<KERNEL, TURB, COLA, true><<<grid, SPHX_BLOCK_FORCES, 0, stream>>>(p, a, guard);
 	else
-		forces_kernel<KERNEL, TURB, COLA, false><<<grid, SPHX_BLOCK_FORCES, 0, stream>>>(p, a);
+		forces_kernel<KERNEL, TURB, COLA, false><<<grid, SPHX_BLOCK_FORCES, 0, stream>>>(p, a, guard);
 }
 
+template<int KERNEL, int TURB, bool COLA>
+static void launch_tile(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &a)
+{
+	forces_tile_kernel<KERNEL, TURB, COLA><<<ctx->tile_grid, TILE_THREADS, 0, stream>>>(ctx->dev, a,
+		ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy);
+}
+
+// launches the tiled kernel when the tiling of this neighbour list is available, plus the generic
+// kernel guarded by the device-side overflow flag (it returns at once when the tiles were used)
 template<int KERNEL>
-static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const ForcesArgs &a)
+static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const ForcesArgs &a, bool use_tiles)
 {
 	const DevParams &p = ctx->dev;
 	const bool mf = p.numfluids > 1;
 	const bool cola = p.densitydiff == SPHX_COLAGROSSI;
+	const uint32_t *guard = use_tiles ? ctx->tile_ctl + 1 : nullptr;
 	switch (p.turbmodel) {
 	case SPHX_ARTIFICIAL:
-		if (cola) launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, true>(mf, grid, stream, p, a);
-		else launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, false>(mf, grid, stream, p, a);
+		if (use_tiles) { if (cola) launch_tile<KERNEL, SPHX_ARTIFICIAL, true>(ctx, stream, a); else launch_tile<KERNEL, SPHX_ARTIFICIAL, false>(ctx, stream, a); }
+		if (cola) launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, true>(mf, grid, stream, p, a, guard);
+		else launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, false>(mf, grid, stream, p, a, guard);
 		break;
 	case SPHX_SPS:
-		if (cola) launch_forces_mf<KERNEL, SPHX_SPS, true>(mf, grid, stream, p, a);
-		else launch_forces_mf<KERNEL, SPHX_SPS, false>(mf, grid, stream, p, a);
+		if (cola) launch_forces_mf<KERNEL, SPHX_SPS, true>(mf, grid, stream, p, a, nullptr);
+		else launch_forces_mf<KERNEL, SPHX_SPS, false>(mf, grid, stream, p, a, nullptr);
 		break;
 	case SPHX_LAMINAR_FLOW:
-		if (cola) launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, true>(mf, grid, stream, p, a);
-		else launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, false>(mf, grid, stream, p, a);
+		if (use_tiles) { if (cola) launch_tile<KERNEL, SPHX_LAMINAR_FLOW, true>(ctx, stream, a); else launch_tile<KERNEL, SPHX_LAMINAR_FLOW, false>(ctx, stream, a); }
+		if (cola) launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, true>(mf, grid, stream, p, a, guard);
+		else launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, false>(mf, grid, stream, p, a, guard);
 		break;
 	default:
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: turbulence model not built");
@@ -586,12 +852,15 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
 	a.compute_object_forces = compute_object_forces;
 
+	// the tiling belongs to the neighbour list built last by this context from these very buffers
+	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
+		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && !ctx->disable_tiles;
 	int rc;
 	switch (ctx->dev.kerneltype) {
-	case SPHX_CUBICSPLINE: rc = launch_forces_k<SPHX_CUBICSPLINE>(ctx, dim3(numBlocks), (hipStream_t)stream, a); break;
-	case SPHX_QUADRATIC:   rc = launch_forces_k<SPHX_QUADRATIC>(ctx, dim3(numBlocks), (hipStream_t)stream, a); break;
-	case SPHX_WENDLAND:    rc = launch_forces_k<SPHX_WENDLAND>(ctx, dim3(numBlocks), (hipStream_t)stream, a); break;
-	case SPHX_GAUSSIAN:    rc = launch_forces_k<SPHX_GAUSSIAN>(ctx, dim3(numBlocks), (hipStream_t)stream, a); break;
+	case SPHX_CUBICSPLINE: rc = launch_forces_k<SPHX_CUBICSPLINE>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
+	case SPHX_QUADRATIC:   rc = launch_forces_k<SPHX_QUADRATIC>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
+	case SPHX_WENDLAND:    rc = launch_forces_k<SPHX_WENDLAND>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
+	case SPHX_GAUSSIAN:    rc = launch_forces_k<SPHX_GAUSSIAN>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
 	default: return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid kernel type");
 	}
 	if (rc != SPHX_OK) return rc;

@@ -431,6 +431,72 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------
+// forces tiles (consumed by forces_tile_kernel, forces.hip).  One thread per grid row (fixed
+// COORD2, COORD3) walks the cells along COORD1 and greedily groups consecutive non-empty cells
+// into tiles of <= TILE_THREADS particles whose 9-row neighbour window fits TILE_WCAP records.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
+	uint32_t rangeEnd, uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t capacity)
+{
+	const int gs1 = p.gs1;
+	const int gs2 = (p.c2 == 0) ? p.gs[0] : (p.c2 == 1) ? p.gs[1] : p.gs[2];
+	const int gs3 = (p.c3 == 0) ? p.gs[0] : (p.c3 == 1) ? p.gs[1] : p.gs[2];
+	const int row = (int)(blockIdx.x*256 + threadIdx.x);
+	if (row >= gs2*gs3) return;
+	const int g2 = row % gs2, g3 = row / gs2;
+	const bool per1 = p.periodic & (1u << p.c1), per2 = p.periodic & (1u << p.c2), per3 = p.periodic & (1u << p.c3);
+
+	auto cell_cnt = [&](int c1v, int c2v, int c3v, uint32_t &start) -> uint32_t {
+		if (c1v < 0) { if (per1) c1v = gs1 - 1; else return 0u; } else if (c1v >= gs1) { if (per1) c1v = 0; else return 0u; }
+		if (c2v < 0) { if (per2) c2v = gs2 - 1; else return 0u; } else if (c2v >= gs2) { if (per2) c2v = 0; else return 0u; }
+		if (c3v < 0) { if (per3) c3v = gs3 - 1; else return 0u; } else if (c3v >= gs3) { if (per3) c3v = 0; else return 0u; }
+		const uint32_t h = (uint32_t)(c1v + c2v*gs1 + c3v*p.gs12);
+		const uint32_t cs = cellStart[h];
+		if (cs == CELL_EMPTY) return 0u;
+		start = cs;
+		return cellEnd[h] - cs;
+	};
+	auto colsum = [&](int c) -> uint32_t {
+		uint32_t s = 0, st;
+		for (int d3 = -1; d3 <= 1; ++d3) for (int d2 = -1; d2 <= 1; ++d2) s += cell_cnt(c, g2 + d2, g3 + d3, st);
+		return s;
+	};
+	auto emit = [&](int ca, int ncells, uint32_t first, uint32_t hc, uint32_t wc) {
+		const uint32_t idx = atomicAdd(&ctl[0], 1u);
+		if (idx >= capacity) { ctl[1] = 1u; return; }
+		uint32_t *d = tiles + (size_t)TILE_DESC*idx;
+		d[0] = (uint32_t)g2; d[1] = (uint32_t)g3; d[2] = (uint32_t)ca; d[3] = (uint32_t)ncells;
+		d[4] = first; d[5] = hc; d[6] = wc; d[7] = 0u;
+	};
+
+	uint32_t hc = 0, wc = 0, first = 0;
+	int ca = 0;
+	uint32_t cs_prev = colsum(-1), cs_cur = colsum(0);
+	for (int c = 0; c < gs1; ++c) {
+		const uint32_t cs_next = colsum(c + 1);
+		uint32_t st = 0;
+		uint32_t n_c = cell_cnt(c, g2, g3, st);
+		if (n_c && st >= rangeEnd) n_c = 0;   // halo cells hold no particle with a neighbour list
+		const bool fits = hc && n_c && (hc + n_c <= TILE_THREADS) && (wc + cs_next <= TILE_WCAP) &&
+			(c - ca + 1 <= TILE_MAXCELLS) && (st == first + hc);
+		if (fits) {
+			hc += n_c; wc += cs_next;
+		} else {
+			if (hc) emit(ca, c - ca, first, hc, wc);
+			hc = 0;
+			if (n_c) {
+				ca = c; hc = n_c; first = st; wc = cs_prev + cs_cur + cs_next;
+				if (n_c > TILE_THREADS || wc > TILE_WCAP) ctl[1] = 1u;   // would not fit: generic kernel
+			}
+		}
+		cs_prev = cs_cur; cs_cur = cs_next;
+	}
+	if (hc) emit(ca, gs1 - ca, first, hc, wc);
+}
+
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
@@ -528,6 +594,21 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd,
 		particleRangeEnd, sqinfluenceradius, ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
+
+	// tiling of this neighbour list for the forces engine (forces.hip "Tiled path")
+	ctx->tiles_built = false;
+	if (ctx->tiles && gridCells <= ctx->cells_reserved && !ctx->disable_tiles) {
+		hipStream_t st = (hipStream_t)stream;
+		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
+		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), st));
+		const uint32_t rows = gridCells/(uint32_t)ctx->dev.gs1;
+		build_tiles_kernel<<<div_up_u(rows, 256), 256, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy, particleRangeEnd,
+			ctx->tiles, ctx->tile_ctl, ctx->tile_capacity);
+		SPHX_LAUNCH_CHECK("build_tiles_kernel");
+		ctx->tiles_built = true;
+		ctx->tiles_cellstart = cellStart;
+		ctx->tiles_neibslist = neibsList;
+	}
 	return SPHX_OK;
 }
 

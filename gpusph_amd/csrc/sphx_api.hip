@@ -2,6 +2,7 @@
 #include "sphx_internal.h"
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 
 static thread_local std::string g_last_error;
 
@@ -30,6 +31,13 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	SPHX_HIP(hipMalloc((void**)&ctx->counters_dev, sizeof(NeibsCounters)));
 	SPHX_HIP(hipMemset(ctx->counters_dev, 0, sizeof(NeibsCounters)));
 	SPHX_HIP(hipMalloc((void**)&ctx->dt_scratch, 4*sizeof(float)));
+	SPHX_HIP(hipMalloc((void**)&ctx->tile_ctl, 4*sizeof(uint32_t)));
+	SPHX_HIP(hipMemset(ctx->tile_ctl, 0, 4*sizeof(uint32_t)));
+	int cus = 0;
+	SPHX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+	ctx->tile_grid = (uint32_t)(cus > 0 ? 2*cus : 512);
+	const char *dis = getenv("SPHX_DISABLE_TILES");
+	ctx->disable_tiles = dis && dis[0] == '1';
 	*out = ctx;
 	return SPHX_OK;
 }
@@ -37,12 +45,14 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
-		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux };
+		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tiles, ctx->cell_end_copy };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
 	ctx->eos_aux = nullptr;
+	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr;
+	ctx->tile_capacity = 0; ctx->cells_reserved = 0; ctx->tiles_built = false;
 	ctx->reserved_particles = ctx->reserved_bins = 0;
 }
 
@@ -54,6 +64,7 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->rb_dev) (void)hipFree(ctx->rb_dev);
 	if (ctx->counters_dev) (void)hipFree(ctx->counters_dev);
 	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
+	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
 	delete ctx;
 }
 
@@ -82,6 +93,10 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_index, sizeof(uint32_t)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_info, sizeof(uint2)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->eos_aux, sizeof(float4)*(size_t)n));
+	ctx->tile_capacity = n/8 + 4096;
+	SPHX_HIP(hipMalloc((void**)&ctx->tiles, sizeof(uint32_t)*TILE_DESC*(size_t)ctx->tile_capacity));
+	ctx->cells_reserved = (bins - 1)/4;
+	SPHX_HIP(hipMalloc((void**)&ctx->cell_end_copy, sizeof(uint32_t)*(size_t)ctx->cells_reserved));
 	ctx->reserved_particles = n;
 	ctx->reserved_bins = bins;
 	return SPHX_OK;

@@ -29,6 +29,14 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 
 #define SPHX_BLOCK_FORCES 128   // one CFL entry per 128 particles (getFmaxElements contract)
 
+// forces tiles (see forces.hip "Tiled path")
+#define TILE_THREADS  128                  // particles per tile (one thread each)
+#define TILE_MAXCELLS 30                   // cells per tile along COORD1
+#define TILE_KW       (TILE_MAXCELLS + 2)  // window columns
+#define TILE_WCAP     1536                 // window records that fit LDS (48 B each, 2 workgroups per CU)
+#define TILE_DESC     8                    // uint32 per tile: g2, g3, firstCell, numCells, firstParticle, numParticles, windowRecords, 0
+#define TILE_NB       8                    // neighbours per batch in the tiled pair loop
+
 // ---- per-kernel constants, passed BY VALUE as a kernel argument (kernarg/SGPR resident;
 //      replaces the reference's ~70 __constant__ symbols, so there is no per-device global
 //      state and one library instance serves any number of devices / host threads) ----------
@@ -93,6 +101,16 @@ struct sphx_ctx {
 	uint2      *tmp_info;      // [n] particleinfo as 8 bytes
 	float4     *eos_aux;       // [n] per-particle EOS pre-pass of the forces engine
 	float      *dt_scratch;    // 1 float, for the sync dtreduce
+	// forces tiles, built by sphx_build_neibs
+	uint32_t   *tiles;         // [tile_capacity][TILE_DESC]
+	uint32_t   *tile_ctl;      // [0] = number of tiles, [1] = overflow flag (generic kernel takes over)
+	uint32_t   *cell_end_copy; // [cells] cellEnd of the build the tiles belong to
+	uint32_t    tile_capacity;
+	uint32_t    cells_reserved;
+	bool        tiles_built;
+	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
+	const void *tiles_cellstart, *tiles_neibslist;
+	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
 };
 
 // ---- error plumbing ---------------------------------------------------------------------------

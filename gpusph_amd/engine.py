@@ -157,6 +157,7 @@ class TimestepEngine:
         nb = C.c_uint32(0)
         rb = self.num_bodies_parts > 0
         prof = self.profile_forces is not None
+        self._memset(self.cfl, 0, s)          # pre_forces clobbers BUFFER_CFL (GPUWorker.cc:1970-1972)
         if prof:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()

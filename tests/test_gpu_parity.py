@@ -90,8 +90,10 @@ def test_forces_and_dt_tolerance(case):
     assert np.abs(f[:, :3] - f_ref[:n, :3]).max() <= 2e-5 * scale
     wscale = np.abs(f_ref[:, 3]).max()
     assert np.abs(f[:, 3] - f_ref[:n, 3]).max() <= 2e-5 * wscale + 1e-7
+    # the CFL array is only ever max-reduced (dtreduce); the tiled kernel bins its maxima differently
+    # from the reference's one-block-one-entry layout, so the contract is the maximum
     cfl = _np(eng.cfl)[:nb]
-    assert np.allclose(cfl, cfl_ref[:nb], rtol=2e-5, atol=0)
+    assert abs(cfl.max() - cfl_ref[:nb].max()) <= 2e-5 * cfl_ref[:nb].max()
     dt = float(eng.d_dt_next.item())
     assert abs(dt - dt_ref) <= 2e-5 * dt_ref
     if prob.num_obstacle:
@@ -207,3 +209,27 @@ def test_against_committed_golden_fixture():
     assert same.mean() > 0.999
     sel = same
     assert np.abs(out["vel"][sel][:, :3] - g["s11_vel"][:n][sel][:, :3]).max() <= 1e-3 * max(np.abs(g["s11_vel"][:, :3]).max(), 1e-3)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_tiled_and_generic_kernels_agree(case, monkeypatch):
+    """the LDS-tiled forces kernel and the generic gather kernel implement the same sum in the same order:
+    identical accumulation order and per-pair arithmetic -> bit-identical forces"""
+    import torch
+    prob = DamBreak3D(**case)
+    outs = []
+    for disable in ("0", "1"):
+        monkeypatch.setenv("SPHX_DISABLE_TILES", disable)
+        eng = _engine(prob, clobber_neibslist=True)
+        eng.build_neibs()
+        n = eng.n
+        rng = np.random.default_rng(11)
+        vel = _np(eng.vel).copy()
+        vel[:n, :3] += rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32)
+        vel[:n, 3] += rng.uniform(0, 2e-3, size=n).astype(np.float32)
+        eng.vel.copy_(torch.from_numpy(vel).to(eng.device))
+        eng._forces(eng.pos, eng.vel, 1, 0)
+        outs.append((_np(eng.forces)[:n].copy(), float(eng.d_dt_next.item()), _np(eng.rbforces).copy()))
+    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32))
