@@ -50,6 +50,7 @@ SIGNATURES = {
     "sphx_fix_hash": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "sphx_sort": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sphx_reorder": (_i, [_vp] + [_vp] * 10 + [_u32, _vp, _vp]),
+    "sphx_find_cell_start": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "sphx_build_neibs": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _u32, _f, _f, _vp]),
     "sphx_neibs_resetinfo": (_i, [_vp, _vp]),
     "sphx_neibs_getinfo": (_i, [_vp, C.POINTER(NeibsInfo), _vp]),

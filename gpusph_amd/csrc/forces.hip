@@ -32,6 +32,7 @@ struct ForcesArgs {
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
 	int compute_object_forces;
+	int dbg;   // SPHX_TILE_DEBUG: 1 = skip pair loops, 2 = skip window staging (timing experiments only)
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -94,7 +95,7 @@ struct Self {
 template<int KERNEL, int TURB, bool COLAGROSSI, bool MOMENTUM, bool DIFFUSE>
 __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s, float inv_h,
 	float pcx, float pcy, float pcz, const float4 &npos, const float4 &nvel, const float4 &naux,
-	bool same_fluid, bool valid, const float *ntau, float4 &force)
+	bool same_fluid, bool valid, const float *ntau, float4 &force, bool rt_momentum = true, bool rt_diffuse = true)
 {
 	const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
 	const float nmass = npos.w;
@@ -111,7 +112,7 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 	// mass_continuity_div_vel_term (forces_kernel.def:2140-2151)
 	float DrDt = mf*vel_dot_pos;
 	if (COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
-		if (same_fluid) {
+		if (same_fluid && rt_diffuse) {
 			const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
 			if (!(fabsf(s.P - n_P) < fabsf(gdotr*s.rho)))
 				DrDt -= p.densityDiffCoeff*p.sscoeff[s.fl]*(n_rho*s.inv_rho - 1.0f)*mf;
@@ -119,7 +120,7 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 	}
 	force.w += DrDt;
 
-	if (MOMENTUM) {
+	if (MOMENTUM && rt_momentum) {
 		// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
 		float kk = -(s.p_precalc + n_precalc)*mf;
 		if (TURB == SPHX_ARTIFICIAL) {
@@ -184,6 +185,19 @@ __device__ __forceinline__ void load_self(const DevParams &p, const ForcesArgs &
 	if (TURB == SPHX_SPS) {
 		const float2 t0 = a.tau0[index], t1 = a.tau1[index], t2 = a.tau2[index];
 		s.tau[0] = t0.x; s.tau[1] = t0.y; s.tau[2] = t1.x; s.tau[3] = t1.y; s.tau[4] = t2.x; s.tau[5] = t2.y;
+	}
+}
+
+// run-time section: sec 0 = fluid neighbours (slots 0 upward), sec 1 = boundary neighbours
+// (slots neibboundpos downward); `batch` counts TILE_NB-entry batches from the section start
+__device__ __forceinline__ void load_list_rt(const DevParams &p, const neibdata *__restrict__ list,
+	uint32_t index, int sec, int batch, uint32_t nd[TILE_NB])
+{
+#pragma unroll
+	for (int k = 0; k < TILE_NB; ++k) {
+		const int e = batch*TILE_NB + k;
+		const int sl = sec ? max((int)p.neibboundpos - e, 0) : min(e, (int)p.neiblistsize - 1);
+		nd[k] = list[(size_t)sl*p.stride + index];
 	}
 }
 
@@ -356,204 +370,303 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 // (neibs.hip) at neighbour-list build time.  Persistent grid: 2 workgroups per CU (LDS bound),
 // each looping over tiles, so one workgroup's staging overlaps the other's pair loop.
 // ==========================================================================================
-template<int NPTYPE, bool MOMENTUM, bool DIFFUSE, int KERNEL, int TURB, bool COLAGROSSI>
-__device__ __forceinline__ void walk_section_lds(const DevParams &p, const neibdata *__restrict__ list,
-	uint32_t index, const Self &s, float inv_h, int myCol,
-	const float4 *sPos, const float4 *sVel, const float4 *sAux, const uint32_t *sCellBase, const float4 *sCode,
-	float4 &force)
-{
-	int slot = (NPTYPE == PT_FLUID) ? 0 : (int)p.neibboundpos;
-	uint32_t nd[TILE_NB], ndn[TILE_NB];
-	load_list_batch<NPTYPE, TILE_NB>(p, list, index, slot, nd);
-	float pcx = 0.0f, pcy = 0.0f, pcz = 0.0f;
-	uint32_t cbase = 0;
-	bool done = false;
-	while (!done) {
-		slot = (NPTYPE == PT_FLUID) ? slot + TILE_NB : slot - TILE_NB;
-		load_list_batch<NPTYPE, TILE_NB>(p, list, index, slot, ndn);   // HBM latency hidden behind TILE_NB pairs
+// list entries of one section, TILE_AHEAD batches deep: buffer q[j] holds batch j (mod TILE_AHEAD)
+struct ListWindow { uint32_t q[TILE_AHEAD][TILE_NB]; };
 
-		float4 npos[TILE_NB], nvel[TILE_NB], naux[TILE_NB];
-		float qx[TILE_NB], qy[TILE_NB], qz[TILE_NB];
-		bool valid[TILE_NB];
-		bool alive = true;
+__device__ __forceinline__ void preload_list(const DevParams &p, const neibdata *__restrict__ list, uint32_t index, int sec, ListWindow &lw)
+{
 #pragma unroll
-		for (int k = 0; k < TILE_NB; ++k) {
-			const uint32_t d = nd[k];
-			alive = alive && (d != NEIBS_END);
-			valid[k] = alive;
-			if (alive && d >= CELLNUM_ENCODED) {
-				const float4 ct = sCode[(d >> CELLNUM_SHIFT) - 1];
-				pcx = fmaf(-ct.x, p.cs[0], s.pos.x);
-				pcy = fmaf(-ct.y, p.cs[1], s.pos.y);
-				pcz = fmaf(-ct.z, p.cs[2], s.pos.z);
-				cbase = sCellBase[__float_as_uint(ct.w) + (uint32_t)myCol];
-			}
-			qx[k] = pcx; qy[k] = pcy; qz[k] = pcz;
-			const uint32_t L = alive ? cbase + (d & NEIBINDEX_MASK) : 0u;
-			npos[k] = sPos[L]; nvel[k] = sVel[L]; naux[k] = sAux[L];
+	for (int j = 0; j < TILE_AHEAD; ++j)
+		load_list_rt(p, list, index, sec, j, lw.q[j]);
+}
+
+struct WalkState { float pcx, pcy, pcz; uint32_t cbase; bool alive; };
+struct CodeMap { int mx, my, mz, c0; };   // neighbour-cell offset -> window-table offset (uniform)
+
+#define TILE_HB 2   // pairs per pipeline stage ("half batch")
+struct Gathered {
+	float4 npos[TILE_HB], nvel[TILE_HB], naux[TILE_HB];
+	float qx[TILE_HB], qy[TILE_HB], qz[TILE_HB];
+	bool valid[TILE_HB];
+	bool last;     // the terminator was seen in (or before) this half
+};
+
+// stage 1 of the pair pipeline: decode TILE_HB list entries and issue the LDS reads of their rows
+__device__ __forceinline__ void gather_half(const DevParams &p, const uint32_t *nd, const Self &s, int myOff,
+	const CodeMap &cm, const float4 *sPos, const float4 *sVel, const float4 *sAux, const uint32_t *sCellBase,
+	WalkState &w, Gathered &g)
+{
+#pragma unroll
+	for (int k = 0; k < TILE_HB; ++k) {
+		const uint32_t d = nd[k];
+		w.alive = w.alive && (d != NEIBS_END);
+		g.valid[k] = w.alive;
+		if (w.alive && d >= CELLNUM_ENCODED) {
+			// d_cell_to_offset order (src/cuda/forces.cu:376-386): code = (x+1) + 3(y+1) + 9(z+1)
+			const int c = (int)(d >> CELLNUM_SHIFT) - 1;
+			const int cz = (c*57) >> 9;            // c/9 for 0 <= c < 27
+			const int r9 = c - cz*9;
+			const int cy = (r9*11) >> 5;           // r9/3 for 0 <= r9 < 9
+			const int ox = r9 - cy*3 - 1, oy = cy - 1, oz = cz - 1;
+			w.pcx = fmaf(-(float)ox, p.cs[0], s.pos.x);
+			w.pcy = fmaf(-(float)oy, p.cs[1], s.pos.y);
+			w.pcz = fmaf(-(float)oz, p.cs[2], s.pos.z);
+			w.cbase = sCellBase[ox*cm.mx + oy*cm.my + oz*cm.mz + cm.c0 + myOff];
 		}
-		done = !alive;
+		g.qx[k] = w.pcx; g.qy[k] = w.pcy; g.qz[k] = w.pcz;
+		const uint32_t L = w.alive ? w.cbase + (d & NEIBINDEX_MASK) : 0u;
+		g.npos[k] = sPos[L]; g.nvel[k] = sVel[L]; g.naux[k] = sAux[L];
+	}
+	g.last = !w.alive;
+}
+
+// stage 2: the pair interactions of a gathered half, in list order
+template<int KERNEL, int TURB, bool COLAGROSSI>
+__device__ __forceinline__ void compute_half(const DevParams &p, const Gathered &g, const Self &s, float inv_h,
+	bool momentum, bool diffuse, float4 &force)
+{
 #pragma unroll
-		for (int k = 0; k < TILE_NB; ++k)
-			pair_interact<KERNEL, TURB, COLAGROSSI, MOMENTUM, DIFFUSE>(p, s, inv_h, qx[k], qy[k], qz[k],
-				npos[k], nvel[k], naux[k], true, valid[k], nullptr, force);
-#pragma unroll
-		for (int k = 0; k < TILE_NB; ++k) nd[k] = ndn[k];
+	for (int k = 0; k < TILE_HB; ++k)
+		pair_interact<KERNEL, TURB, COLAGROSSI, true, true>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k],
+			g.npos[k], g.nvel[k], g.naux[k], true, g.valid[k], nullptr, force, momentum, diffuse);
+}
+
+// Walk one section of a particle's neighbour list against the LDS window.
+//  * list entries (HBM, 2 B per pair: the dominant algorithmic traffic) are fetched TILE_AHEAD-1
+//    batches ahead into a ring of register buffers, rotated by unrolling, not by copying (a copy of
+//    an in-flight load would wait for it);
+//  * the LDS reads of the next TILE_HB pairs are issued before the current TILE_HB pairs are
+//    computed, so the ds_read latency (and its bank conflicts) hides behind the pair arithmetic;
+//  * section, momentum and diffusion switches are run-time values so that the pair code exists
+//    once in the kernel (the instruction cache is 64 KB; four template copies did not fit).
+template<int KERNEL, int TURB, bool COLAGROSSI>
+__device__ __forceinline__ void walk_section_lds(const DevParams &p, const neibdata *__restrict__ list,
+	uint32_t index, const Self &s, float inv_h, int myOff, const CodeMap &cm,
+	const float4 *sPos, const float4 *sVel, const float4 *sAux, const uint32_t *sCellBase,
+	int sec, bool momentum, bool diffuse,
+	ListWindow &lw /* batches 0..TILE_AHEAD-1 preloaded */, float4 &force)
+{
+	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
+	WalkState w; w.pcx = w.pcy = w.pcz = 0.0f; w.cbase = 0; w.alive = true;
+	int next = TILE_AHEAD;   // index of the next batch to fetch
+	Gathered A, B;
+	gather_half(p, lw.q[0], s, myOff, cm, sPos, sVel, sAux, sCellBase, w, A);
+#define SPHX_RING_STEP(J, JN) \
+	gather_half(p, lw.q[J] + TILE_HB, s, myOff, cm, sPos, sVel, sAux, sCellBase, w, B); \
+	compute_half<KERNEL, TURB, COLAGROSSI>(p, A, s, inv_h, momentum, diffuse, force); \
+	if (A.last) return; \
+	load_list_rt(p, list, index, sec, next, lw.q[J]); \
+	++next; \
+	gather_half(p, lw.q[JN], s, myOff, cm, sPos, sVel, sAux, sCellBase, w, A); \
+	compute_half<KERNEL, TURB, COLAGROSSI>(p, B, s, inv_h, momentum, diffuse, force); \
+	if (B.last) return;
+	for (;;) {
+		SPHX_RING_STEP(0, 1)
+		SPHX_RING_STEP(1, 2)
+		SPHX_RING_STEP(2, 3)
+		SPHX_RING_STEP(3, 0)
+	}
+#undef SPHX_RING_STEP
+}
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// async global -> LDS copy of `count` float4 records (LDS-DMA, no VGPR round trip): every wave copies
+// 64-record chunks, LDS destination = wave-uniform base + lane*16 (cdna_hip_programming.md "global_load_lds")
+__device__ __forceinline__ void stage_rows(const float4 *__restrict__ src, float4 *dst, uint32_t count, uint32_t tid)
+{
+	const uint32_t wave = tid >> 6, lane = tid & 63u;
+	for (uint32_t c0 = wave*64u; c0 < count; c0 += TILE_THREADS) {
+		const uint32_t cu = __builtin_amdgcn_readfirstlane(c0);
+		if (cu + lane < count)
+			__builtin_amdgcn_global_load_lds((gptr_t)(src + cu + lane), (lptr_t)(dst + cu), 16, 0, 0);
 	}
 }
 
+// window cell (row r of 16, column col) of a tile -> start/count of its particles
+__device__ __forceinline__ void window_cell(const DevParams &p, const uint32_t *__restrict__ cellStart,
+	const uint32_t *__restrict__ cellEnd, int g2, int g3, int ca, int ncells, int r, int col,
+	uint32_t &start, uint32_t &cnt)
+{
+	start = 0; cnt = 0;
+	if (col >= ncells + 2) return;
+	const int v0 = ca - 1 + col, v1 = g2 + (r & 3) - 1, v2 = g3 + (r >> 2) - 1;
+	int gx = (p.c1 == 0) ? v0 : (p.c2 == 0) ? v1 : v2;
+	int gy = (p.c1 == 1) ? v0 : (p.c2 == 1) ? v1 : v2;
+	int gz = (p.c1 == 2) ? v0 : (p.c2 == 2) ? v1 : v2;
+	if (gx < 0) { if (p.periodic & SPHX_PERIODIC_X) gx = p.gs[0] - 1; else return; }
+	else if (gx >= p.gs[0]) { if (p.periodic & SPHX_PERIODIC_X) gx = 0; else return; }
+	if (gy < 0) { if (p.periodic & SPHX_PERIODIC_Y) gy = p.gs[1] - 1; else return; }
+	else if (gy >= p.gs[1]) { if (p.periodic & SPHX_PERIODIC_Y) gy = 0; else return; }
+	if (gz < 0) { if (p.periodic & SPHX_PERIODIC_Z) gz = p.gs[2] - 1; else return; }
+	else if (gz >= p.gs[2]) { if (p.periodic & SPHX_PERIODIC_Z) gz = 0; else return; }
+	const uint32_t h = grid_hash(p, gx, gy, gz);
+	const uint32_t cs = cellStart[h];
+	if (cs != CELL_EMPTY) { start = cs; cnt = cellEnd[h] - cs; }
+}
+
 template<int KERNEL, int TURB, bool COLAGROSSI>
-__global__ void __launch_bounds__(TILE_THREADS, 1)
+__global__ void __launch_bounds__(TILE_THREADS, 2)
 forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
 	const uint32_t *__restrict__ tileCtl /* [0]=count, [1]=overflow */, const uint32_t *__restrict__ cellEnd)
 {
-	__shared__ float4 sPos[TILE_WCAP];
-	__shared__ float4 sVel[TILE_WCAP];
-	__shared__ float4 sAux[TILE_WCAP];
-	__shared__ uint32_t sCellBase[9*TILE_KW];
-	__shared__ uint32_t sCnt[9*TILE_KW];
-	__shared__ uint32_t sStart[9*TILE_KW];
-	__shared__ float4 sCode[27];
-	__shared__ uint32_t sRowStart[9], sRowTotal[9], sRowBase[9], sRowContig[9];
+	__shared__ __attribute__((aligned(16))) float4 sPos[TILE_WCAP];
+	__shared__ __attribute__((aligned(16))) float4 sVel[TILE_WCAP];
+	__shared__ __attribute__((aligned(16))) float4 sAux[TILE_WCAP];
+	__shared__ uint32_t sCellBase[TILE_WROWS*TILE_KW];   // LDS slot of the first particle of each window cell
+	__shared__ uint32_t sCnt[TILE_WROWS*TILE_KW];
+	__shared__ uint32_t sStart[TILE_WROWS*TILE_KW];
+	__shared__ uint32_t sRowStart[TILE_WROWS], sRowTotal[TILE_WROWS], sRowContig[TILE_WROWS];
 	__shared__ float sWaveMax[TILE_THREADS/64];
 
 	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this launch
 	const uint32_t numTiles = tileCtl[0];
 	const uint32_t tid = threadIdx.x;
+	uint32_t tile = blockIdx.x;
+	if (tile >= numTiles) return;
 
-	if (tid < 27) {
-		// neighbour-cell code -> {offset as floats, index of that cell in the window table relative to
-		// the particle's own column}; d_cell_to_offset order (src/cuda/forces.cu:376-386)
-		const int c = (int)tid;
-		const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
-		const int o[3] = { cx - 1, cy - 1, cz - 1 };
-		const int o1 = (p.c1 == 0) ? o[0] : (p.c1 == 1) ? o[1] : o[2];
-		const int o2 = (p.c2 == 0) ? o[0] : (p.c2 == 1) ? o[1] : o[2];
-		const int o3 = (p.c3 == 0) ? o[0] : (p.c3 == 1) ? o[1] : o[2];
-		const uint32_t off = (uint32_t)(((o2 + 1) + 3*(o3 + 1))*TILE_KW + o1 + 1);
-		sCode[c] = make_float4((float)o[0], (float)o[1], (float)o[2], __uint_as_float(off));
-	}
+	// neighbour-cell offset (ox,oy,oz) -> index of that cell in the window table, relative to the
+	// particle's own (row, column): o1 + KW*(o2+1) + 4*KW*(o3+1) + 1 with (o1,o2,o3) the offsets along COORD1..3
+	CodeMap cm;
+	cm.mx = (p.c1 == 0) ? 1 : (p.c2 == 0) ? TILE_KW : 4*TILE_KW;
+	cm.my = (p.c1 == 1) ? 1 : (p.c2 == 1) ? TILE_KW : 4*TILE_KW;
+	cm.mz = (p.c1 == 2) ? 1 : (p.c2 == 2) ? TILE_KW : 4*TILE_KW;
+	cm.c0 = 1 + TILE_KW + 4*TILE_KW;
 	const float inv_h = fast_rcp(p.slength);
 	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
+	const int wr = (int)(tid/TILE_KW), wcol = (int)(tid - (tid/TILE_KW)*TILE_KW);   // my window cell (tid < 256)
 
-	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
-		const uint32_t *d = tiles + (size_t)TILE_DESC*tile;
-		const int g2 = (int)d[0], g3 = (int)d[1], ca = (int)d[2], ncells = (int)d[3];
-		const uint32_t first = d[4], hc = d[5];
-		if (first >= a.toParticle || first + hc <= a.fromParticle) continue;
+	// software pipeline over tiles: the descriptor and the window-cell extents of the NEXT tile are
+	// fetched while the current one computes, so a tile costs one memory round trip (the window DMA)
+	uint32_t dc[TILE_DESC], dn[TILE_DESC];
+#pragma unroll
+	for (int k = 0; k < TILE_DESC; ++k) dc[k] = tiles[(size_t)TILE_DESC*tile + k];
+	uint32_t wStart = 0, wCnt = 0;
+	if (tid < TILE_WROWS*TILE_KW)
+		window_cell(p, a.cellStart, cellEnd, (int)dc[0], (int)dc[1], (int)dc[2], (int)dc[3], wr, wcol, wStart, wCnt);
+
+	for (;;) {
+		const uint32_t nextTile = tile + gridDim.x;
+		const bool haveNext = nextTile < numTiles;
+		if (haveNext) {
+#pragma unroll
+			for (int k = 0; k < TILE_DESC; ++k) dn[k] = tiles[(size_t)TILE_DESC*nextTile + k];
+		}
+		const int ca = (int)dc[2], ncells = (int)dc[3];
+		const uint32_t c0 = dc[8], c1n = dc[9], c2n = dc[10], c3n = dc[11];
+		const uint32_t hcTot = c0 + c1n + c2n + c3n;
+		uint32_t firstMin = 0xFFFFFFFFu, lastMax = 0u;
+#pragma unroll
+		for (int r = 0; r < TILE_HROWS; ++r)
+			if (dc[8 + r]) { firstMin = min(firstMin, dc[4 + r]); lastMax = max(lastMax, dc[4 + r] + dc[8 + r]); }
+		const bool inRange = !(firstMin >= a.toParticle || lastMax <= a.fromParticle);
+		const bool pairs = (dc[13] & 1u) && a.dbg != 1;   // no fluid anywhere in the window: nothing interacts
+
+		// 0. own rows and the first two list batches of both sections: issued now, consumed after the
+		//    window is staged, so their HBM latency overlaps the staging
+		int hrow = 0; uint32_t hoff = tid;
+		if (hoff >= c0) { hoff -= c0; hrow = 1; if (hoff >= c1n) { hoff -= c1n; hrow = 2; if (hoff >= c2n) { hoff -= c2n; hrow = 3; } } }
+		const uint32_t hfirst = (hrow == 0) ? dc[4] : (hrow == 1) ? dc[5] : (hrow == 2) ? dc[6] : dc[7];
+		const uint32_t index = hfirst + hoff;
+		const bool mine = inRange && tid < hcTot && index >= a.fromParticle && index < a.toParticle;
+		const uint32_t li = mine ? index : (firstMin != 0xFFFFFFFFu ? firstMin : 0u);   // idle lanes read a valid row
+		const particleinfo info = a.info[li];
+		const float4 pos = a.pos[li];
+		ListWindow lwF, lwB;
+		Self s;
+		if (inRange) {
+			preload_list(p, a.neibsList, li, 0, lwF);
+			preload_list(p, a.neibsList, li, 1, lwB);
+			load_self<TURB>(p, a, li, info, pos, false, s);
+		}
+
 		__syncthreads();   // the previous tile's readers are done with LDS
 
-		// 1. start/count of every window cell
-		for (uint32_t w = tid; w < 9*TILE_KW; w += TILE_THREADS) {
-			const int r = (int)(w/TILE_KW), col = (int)(w - r*TILE_KW);
-			uint32_t cnt = 0, start = 0;
-			if (col < ncells + 2) {
-				int v[3];
-				v[0] = ca - 1 + col; v[1] = g2 + (r % 3) - 1; v[2] = g3 + r/3 - 1;
-				int gx = (p.c1 == 0) ? v[0] : (p.c2 == 0) ? v[1] : v[2];
-				int gy = (p.c1 == 1) ? v[0] : (p.c2 == 1) ? v[1] : v[2];
-				int gz = (p.c1 == 2) ? v[0] : (p.c2 == 2) ? v[1] : v[2];
-				bool ok = true;
-				if (gx < 0) { if (p.periodic & SPHX_PERIODIC_X) gx = p.gs[0] - 1; else ok = false; }
-				else if (gx >= p.gs[0]) { if (p.periodic & SPHX_PERIODIC_X) gx = 0; else ok = false; }
-				if (gy < 0) { if (p.periodic & SPHX_PERIODIC_Y) gy = p.gs[1] - 1; else ok = false; }
-				else if (gy >= p.gs[1]) { if (p.periodic & SPHX_PERIODIC_Y) gy = 0; else ok = false; }
-				if (gz < 0) { if (p.periodic & SPHX_PERIODIC_Z) gz = p.gs[2] - 1; else ok = false; }
-				else if (gz >= p.gs[2]) { if (p.periodic & SPHX_PERIODIC_Z) gz = 0; else ok = false; }
-				if (ok) {
-					const uint32_t h = grid_hash(p, gx, gy, gz);
-					const uint32_t cs = a.cellStart[h];
-					if (cs != CELL_EMPTY) { start = cs; cnt = cellEnd[h] - cs; }
+		if (inRange && pairs) {
+			// 1. prefix of the window-cell counts within each row (16-lane segmented scans), row extents
+			if (tid < TILE_WROWS*TILE_KW) {
+				uint32_t incl = wCnt;
+				uint32_t lo = wCnt ? wStart : 0xFFFFFFFFu;
+				uint32_t hi = wCnt ? wStart + wCnt : 0u;
+#pragma unroll
+				for (int dd = 1; dd < TILE_KW; dd <<= 1) {
+					const uint32_t t = __shfl_up(incl, dd, TILE_KW);
+					if (wcol >= dd) incl += t;
+				}
+#pragma unroll
+				for (int dd = TILE_KW/2; dd > 0; dd >>= 1) {
+					lo = min(lo, (uint32_t)__shfl_xor(lo, dd, TILE_KW));
+					hi = max(hi, (uint32_t)__shfl_xor(hi, dd, TILE_KW));
+				}
+				sCnt[tid] = wCnt; sStart[tid] = wStart;
+				sCellBase[tid] = incl - wCnt;                 // row-relative for now
+				if (wcol == TILE_KW - 1) {
+					sRowTotal[wr] = incl;
+					sRowStart[wr] = lo;
+					sRowContig[wr] = (incl == 0u || hi - lo == incl) ? 1u : 0u;
 				}
 			}
-			sCnt[w] = cnt; sStart[w] = start;
-		}
-		__syncthreads();
-		// 2. per-row extent
-		if (tid < 9) {
-			uint32_t total = 0, rs = 0, lastEnd = 0;
-			bool have = false;
-			for (int col = 0; col < ncells + 2; ++col) {
-				const uint32_t cnt = sCnt[tid*TILE_KW + col];
-				if (cnt) {
-					const uint32_t st = sStart[tid*TILE_KW + col];
-					if (!have) { rs = st; have = true; }
-					lastEnd = st + cnt; total += cnt;
-				}
-			}
-			sRowStart[tid] = rs; sRowTotal[tid] = total;
-			sRowContig[tid] = (!have || lastEnd - rs == total) ? 1u : 0u;
-		}
-		__syncthreads();
-		// 3. LDS slot of the first particle of every window cell
-		if (tid < 9) {
-			uint32_t base = 0;
-			for (uint32_t r = 0; r < tid; ++r) base += sRowTotal[r];
-			sRowBase[tid] = base;
-			uint32_t run = base;
-			for (int col = 0; col < ncells + 2; ++col) {
-				sCellBase[tid*TILE_KW + col] = run;
-				run += sCnt[tid*TILE_KW + col];
-			}
-		}
-		__syncthreads();
-		// 4. stage the window: 9 contiguous particle ranges -> LDS (coalesced 16 B/lane loads)
-		for (int r = 0; r < 9; ++r) {
-			const uint32_t total = sRowTotal[r], base = sRowBase[r];
-			if (sRowContig[r]) {
-				const uint32_t rs = sRowStart[r];
-				for (uint32_t q = tid; q < total; q += TILE_THREADS) {
-					if (base + q < TILE_WCAP) {
-						sPos[base + q] = a.pos[rs + q]; sVel[base + q] = a.vel[rs + q]; sAux[base + q] = a.aux[rs + q];
-					}
-				}
-			} else {   // a row crossing cell-type segments (multi-GPU device maps not split on COORD3)
-				for (int col = 0; col < ncells + 2; ++col) {
-					const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = sCellBase[r*TILE_KW + col];
-					for (uint32_t q = tid; q < cnt; q += TILE_THREADS) {
-						if (cb + q < TILE_WCAP) {
+			__syncthreads();
+			// 2. row bases (16-entry prefix, computed redundantly by every thread) and the window DMA
+			uint32_t myRowBase = 0, run = 0;
+#pragma unroll 1
+			for (int r = 0; r < TILE_WROWS; ++r) {
+				const uint32_t total = sRowTotal[r];
+				const uint32_t base = __builtin_amdgcn_readfirstlane(run);
+				if (r == wr) myRowBase = base;
+				run += total;
+				if (base + total > TILE_WCAP || a.dbg == 2) continue;   // cannot overflow for tiles of build_tiles_kernel
+				if (sRowContig[r]) {
+					const uint32_t rs = __builtin_amdgcn_readfirstlane(sRowStart[r]);
+					stage_rows(a.pos + rs, sPos + base, total, tid);
+					stage_rows(a.vel + rs, sVel + base, total, tid);
+					stage_rows(a.aux + rs, sAux + base, total, tid);
+				} else {   // a row crossing cell-type segments (multi-GPU device maps not split on COORD3)
+					for (int col = 0; col < ncells + 2; ++col) {
+						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = base + sCellBase[r*TILE_KW + col];
+						for (uint32_t q = tid; q < cnt; q += TILE_THREADS) {
 							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q]; sAux[cb + q] = a.aux[st + q];
 						}
 					}
 				}
 			}
+			if (tid < TILE_WROWS*TILE_KW) sCellBase[tid] += myRowBase;   // make absolute (own entry)
 		}
-		__syncthreads();
+		// prefetch the next tile's window-cell extents
+		uint32_t nStart = 0, nCnt = 0;
+		if (haveNext && tid < TILE_WROWS*TILE_KW)
+			window_cell(p, a.cellStart, cellEnd, (int)dn[0], (int)dn[1], (int)dn[2], (int)dn[3], wr, wcol, nStart, nCnt);
+		__syncthreads();   // waits for the LDS-DMA (vmcnt(0)) and publishes the tables
 
-		// 5. pair loop for the tile's own particles (<= 128, one per thread)
+		// 3. pair loop for the tile's own particles (<= 512, one per thread)
 		float cfl_term = 0.0f;
-		const uint32_t index = first + tid;
-		if (tid < hc && index >= a.fromParticle && index < a.toParticle) {
-			const particleinfo info = a.info[index];
+		if (mine && is_active_w(pos.w)) {
 			const uint32_t ptype = PART_TYPE(info);
-			const float4 pos = a.pos[index];
-			if (is_active_w(pos.w)) {
-				Self s;
-				load_self<TURB>(p, a, index, info, pos, false, s);
-				const int myG1 = (p.c1 == 0) ? s.gridPos.x : (p.c1 == 1) ? s.gridPos.y : s.gridPos.z;
-				const int myCol = myG1 - ca;
-				float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-				if (ptype == PT_FLUID) {
-					walk_section_lds<PT_FLUID, true, true, KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myCol,
-						sPos, sVel, sAux, sCellBase, sCode, force);
-					if (dyn)
-						walk_section_lds<PT_BOUNDARY, true, false, KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myCol,
-							sPos, sVel, sAux, sCellBase, sCode, force);
-				} else if (ptype == PT_BOUNDARY && dyn) {
-					if (HAS_COMPUTE_FORCE(info))
-						walk_section_lds<PT_FLUID, true, true, KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myCol,
-							sPos, sVel, sAux, sCellBase, sCode, force);
-					else
-						walk_section_lds<PT_FLUID, false, true, KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myCol,
-							sPos, sVel, sAux, sCellBase, sCode, force);
+			const int myG1 = (p.c1 == 0) ? s.gridPos.x : (p.c1 == 1) ? s.gridPos.y : s.gridPos.z;
+			const int myOff = ((hrow & 1) + 4*(hrow >> 1))*TILE_KW + (myG1 - ca);
+			float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			const bool isFluid = ptype == PT_FLUID, isDynBound = ptype == PT_BOUNDARY && dyn;
+			if (pairs && (isFluid || isDynBound)) {
+				// fluid: fluid section then (DYN) boundary section; DYN boundary: fluid section only, with the
+				// momentum part only for bodies with force feedback (forces_kernel.def:3650-3679)
+				const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
+				const int nsec = (isFluid && dyn) ? 2 : 1;
+				for (int sec = 0; sec < nsec; ++sec) {
+					walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myOff, cm,
+						sPos, sVel, sAux, sCellBase, sec, momentum, sec == 0, lwF, force);
+#pragma unroll
+					for (int j = 0; j < TILE_AHEAD; ++j)
+#pragma unroll
+						for (int k = 0; k < TILE_NB; ++k) lwF.q[j][k] = lwB.q[j][k];
 				}
-				cfl_term = finalize_particle(p, a, index, info, s, force);
 			}
+			cfl_term = finalize_particle(p, a, index, info, s, force);
 		}
-		// 6. CFL: the array keeps the reference's one-entry-per-128-particles layout
+		// 4. CFL: the array keeps the reference's one-entry-per-128-particles layout
 		// (getFmaxElements); tiles are not 128-aligned, so they max into the entry of their first
 		// particle.  Non-negative floats order like their bit patterns; the caller zeroed CFL.
-		if (a.cfl) {
+		if (a.cfl && inRange) {
 #pragma unroll
 			for (int dd = 32; dd > 0; dd >>= 1)
 				cfl_term = fmaxf(cfl_term, __shfl_down(cfl_term, dd));
@@ -562,10 +675,15 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			if (tid == 0) {
 				float m = sWaveMax[0];
 				for (int w = 1; w < TILE_THREADS/64; ++w) m = fmaxf(m, sWaveMax[w]);
-				const uint32_t rel = first > a.fromParticle ? first - a.fromParticle : 0u;
+				const uint32_t rel = firstMin > a.fromParticle ? firstMin - a.fromParticle : 0u;
 				atomicMax(reinterpret_cast<unsigned int*>(a.cfl + a.cflOffset + rel/SPHX_BLOCK_FORCES), __float_as_uint(m));
 			}
 		}
+		if (!haveNext) break;
+		tile = nextTile;
+#pragma unroll
+		for (int k = 0; k < TILE_DESC; ++k) dc[k] = dn[k];
+		wStart = nStart; wCnt = nCnt;
 	}
 }
 
@@ -851,6 +969,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.aux = ctx->eos_aux;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
 	a.compute_object_forces = compute_object_forces;
+	a.dbg = ctx->tile_debug;
 
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&

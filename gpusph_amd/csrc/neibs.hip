@@ -308,6 +308,26 @@ reorder_kernel(uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
 	sortedVel[index] = unsortedVel[sortedIndex];
 }
 
+// cell ranges of a sorted sub-range (imported halo), same scan as above without the gather
+__global__ void __launch_bounds__(BLOCK_REORDER)
+find_cell_start_kernel(uint32_t *__restrict__ cellStart, uint32_t *__restrict__ cellEnd,
+	const uint32_t *__restrict__ particleHash, uint32_t from, uint32_t to)
+{
+	const uint32_t index = from + blockIdx.x*BLOCK_REORDER + threadIdx.x;
+	if (index >= to) return;
+	const uint32_t cellHash = particleHash[index];
+	if (cellHash == CELL_HASH_MAX) return;
+	if (index == from || cellHash != particleHash[index - 1]) {
+		cellStart[cellHash & CELLTYPE_BITMASK] = index;
+		if (index > from) {
+			const uint32_t prev = particleHash[index - 1];
+			if (prev != CELL_HASH_MAX) cellEnd[prev & CELLTYPE_BITMASK] = index;
+		}
+	}
+	if (index == to - 1)
+		cellEnd[cellHash & CELLTYPE_BITMASK] = index + 1;
+}
+
 // ------------------------------------------------------------------------------------------
 // buildNeibsList: src/cuda/buildneibs_kernel.cu:1019-1185, neibsInCell :536-644
 // ------------------------------------------------------------------------------------------
@@ -433,68 +453,93 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 
 
 // ------------------------------------------------------------------------------------------
-// forces tiles (consumed by forces_tile_kernel, forces.hip).  One thread per grid row (fixed
-// COORD2, COORD3) walks the cells along COORD1 and greedily groups consecutive non-empty cells
-// into tiles of <= TILE_THREADS particles whose 9-row neighbour window fits TILE_WCAP records.
+// forces tiles (consumed by forces_tile_kernel, forces.hip).  A tile is a block of k x 2 x 2 cells
+// (k consecutive cells along COORD1 in each of 4 adjacent grid rows) holding <= TILE_THREADS
+// particles; its neighbour window is the (k+2) x 4 x 4 block around it (16 contiguous particle
+// ranges) and must fit TILE_WCAP records.  One thread per 2x2 bundle of rows walks the cells along
+// COORD1 and closes a tile greedily.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(128)
 build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
-	uint32_t rangeEnd, uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t capacity)
+	const particleinfo *__restrict__ info, uint32_t rangeEnd,
+	uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t capacity)
 {
 	const int gs1 = p.gs1;
 	const int gs2 = (p.c2 == 0) ? p.gs[0] : (p.c2 == 1) ? p.gs[1] : p.gs[2];
 	const int gs3 = (p.c3 == 0) ? p.gs[0] : (p.c3 == 1) ? p.gs[1] : p.gs[2];
-	const int row = (int)(blockIdx.x*256 + threadIdx.x);
-	if (row >= gs2*gs3) return;
-	const int g2 = row % gs2, g3 = row / gs2;
+	const int nG2 = (gs2 + 1)/2, nG3 = (gs3 + 1)/2;
+	const int sr = (int)(blockIdx.x*128 + threadIdx.x);
+	if (sr >= nG2*nG3) return;
+	const int g2 = 2*(sr % nG2), g3 = 2*(sr / nG2);
 	const bool per1 = p.periodic & (1u << p.c1), per2 = p.periodic & (1u << p.c2), per3 = p.periodic & (1u << p.c3);
 
-	auto cell_cnt = [&](int c1v, int c2v, int c3v, uint32_t &start) -> uint32_t {
-		if (c1v < 0) { if (per1) c1v = gs1 - 1; else return 0u; } else if (c1v >= gs1) { if (per1) c1v = 0; else return 0u; }
-		if (c2v < 0) { if (per2) c2v = gs2 - 1; else return 0u; } else if (c2v >= gs2) { if (per2) c2v = 0; else return 0u; }
-		if (c3v < 0) { if (per3) c3v = gs3 - 1; else return 0u; } else if (c3v >= gs3) { if (per3) c3v = 0; else return 0u; }
+	auto cell_cnt = [&](int c1v, int c2v, int c3v, bool wrap, uint32_t &start) -> uint32_t {
+		if (c1v < 0) { if (per1 && wrap) c1v = gs1 - 1; else return 0u; } else if (c1v >= gs1) { if (per1 && wrap) c1v = 0; else return 0u; }
+		if (c2v < 0) { if (per2 && wrap) c2v = gs2 - 1; else return 0u; } else if (c2v >= gs2) { if (per2 && wrap) c2v = 0; else return 0u; }
+		if (c3v < 0) { if (per3 && wrap) c3v = gs3 - 1; else return 0u; } else if (c3v >= gs3) { if (per3 && wrap) c3v = 0; else return 0u; }
 		const uint32_t h = (uint32_t)(c1v + c2v*gs1 + c3v*p.gs12);
 		const uint32_t cs = cellStart[h];
 		if (cs == CELL_EMPTY) return 0u;
 		start = cs;
 		return cellEnd[h] - cs;
 	};
-	auto colsum = [&](int c) -> uint32_t {
-		uint32_t s = 0, st;
-		for (int d3 = -1; d3 <= 1; ++d3) for (int d2 = -1; d2 <= 1; ++d2) s += cell_cnt(c, g2 + d2, g3 + d3, st);
+	// window column c: records in the 16 rows, and whether any of those cells holds fluid (cells are
+	// sorted fluid-first, so the first particle tells)
+	auto column = [&](int c, uint32_t &hasFluid) -> uint32_t {
+		uint32_t s = 0;
+		hasFluid = 0;
+		for (int d3 = -1; d3 <= 2; ++d3) for (int d2 = -1; d2 <= 2; ++d2) {
+			uint32_t st = 0;
+			const uint32_t n = cell_cnt(c, g2 + d2, g3 + d3, true, st);
+			if (n) { s += n; if (IS_FLUID(info[st])) hasFluid = 1; }
+		}
 		return s;
 	};
-	auto emit = [&](int ca, int ncells, uint32_t first, uint32_t hc, uint32_t wc) {
+	uint32_t hc[TILE_HROWS] = {0, 0, 0, 0}, first[TILE_HROWS] = {0, 0, 0, 0};
+	auto emit = [&](int ca, int ncells, uint32_t wc, uint32_t fl) {
 		const uint32_t idx = atomicAdd(&ctl[0], 1u);
 		if (idx >= capacity) { ctl[1] = 1u; return; }
 		uint32_t *d = tiles + (size_t)TILE_DESC*idx;
 		d[0] = (uint32_t)g2; d[1] = (uint32_t)g3; d[2] = (uint32_t)ca; d[3] = (uint32_t)ncells;
-		d[4] = first; d[5] = hc; d[6] = wc; d[7] = 0u;
+		for (int r = 0; r < TILE_HROWS; ++r) { d[4 + r] = first[r]; d[8 + r] = hc[r]; }
+		d[12] = wc; d[13] = fl; d[14] = 0u; d[15] = 0u;
 	};
 
-	uint32_t hc = 0, wc = 0, first = 0;
+	uint32_t hsum = 0, wc = 0, wfl = 0;
 	int ca = 0;
-	uint32_t cs_prev = colsum(-1), cs_cur = colsum(0);
+	uint32_t f_prev, f_cur, f_next;
+	uint32_t cs_prev = column(-1, f_prev), cs_cur = column(0, f_cur);
 	for (int c = 0; c < gs1; ++c) {
-		const uint32_t cs_next = colsum(c + 1);
-		uint32_t st = 0;
-		uint32_t n_c = cell_cnt(c, g2, g3, st);
-		if (n_c && st >= rangeEnd) n_c = 0;   // halo cells hold no particle with a neighbour list
-		const bool fits = hc && n_c && (hc + n_c <= TILE_THREADS) && (wc + cs_next <= TILE_WCAP) &&
-			(c - ca + 1 <= TILE_MAXCELLS) && (st == first + hc);
+		const uint32_t cs_next = column(c + 1, f_next);
+		uint32_t n4[TILE_HROWS], st4[TILE_HROWS];
+		uint32_t ncol = 0;
+		bool contiguous = true;
+		for (int r = 0; r < TILE_HROWS; ++r) {
+			st4[r] = 0;
+			n4[r] = cell_cnt(c, g2 + (r & 1), g3 + (r >> 1), false, st4[r]);
+			if (n4[r] && st4[r] >= rangeEnd) n4[r] = 0;     // halo cells hold no particle with a neighbour list
+			ncol += n4[r];
+			if (n4[r] && hc[r] && st4[r] != first[r] + hc[r]) contiguous = false;
+		}
+		const bool fits = hsum && ncol && (hsum + ncol <= TILE_THREADS) && (wc + cs_next <= TILE_WCAP) &&
+			(c - ca + 1 <= TILE_MAXCELLS) && contiguous;
 		if (fits) {
-			hc += n_c; wc += cs_next;
+			for (int r = 0; r < TILE_HROWS; ++r) { if (n4[r] && !hc[r]) first[r] = st4[r]; hc[r] += n4[r]; }
+			hsum += ncol; wc += cs_next; wfl |= f_next;
 		} else {
-			if (hc) emit(ca, c - ca, first, hc, wc);
-			hc = 0;
-			if (n_c) {
-				ca = c; hc = n_c; first = st; wc = cs_prev + cs_cur + cs_next;
-				if (n_c > TILE_THREADS || wc > TILE_WCAP) ctl[1] = 1u;   // would not fit: generic kernel
+			if (hsum) emit(ca, c - ca, wc, wfl);
+			hsum = 0;
+			for (int r = 0; r < TILE_HROWS; ++r) hc[r] = 0;
+			if (ncol) {
+				ca = c; hsum = ncol;
+				for (int r = 0; r < TILE_HROWS; ++r) { hc[r] = n4[r]; first[r] = st4[r]; }
+				wc = cs_prev + cs_cur + cs_next; wfl = f_prev | f_cur | f_next;
+				if (ncol > TILE_THREADS || wc > TILE_WCAP) ctl[1] = 1u;   // would not fit: generic kernel
 			}
 		}
-		cs_prev = cs_cur; cs_cur = cs_next;
+		cs_prev = cs_cur; cs_cur = cs_next; f_prev = f_cur; f_cur = f_next;
 	}
-	if (hc) emit(ca, gs1 - ca, first, hc, wc);
+	if (hsum) emit(ca, gs1 - ca, wc, wfl);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -577,6 +622,19 @@ extern "C" int sphx_reorder(sphx_ctx *ctx, uint32_t *segmentStart,
 	return SPHX_OK;
 }
 
+extern "C" int sphx_find_cell_start(sphx_ctx *ctx, uint32_t *cellStart, uint32_t *cellEnd, const uint32_t *sortedHash,
+	uint32_t from, uint32_t to, void *stream)
+{
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_find_cell_start: constants not set");
+	SPHX_REQUIRE(cellStart && cellEnd && sortedHash, "sphx_find_cell_start: missing buffer");
+	SPHX_REQUIRE(from <= to, "sphx_find_cell_start: invalid range");
+	if (from == to) return SPHX_OK;
+	find_cell_start_kernel<<<div_up_u(to - from, BLOCK_REORDER), BLOCK_REORDER, 0, (hipStream_t)stream>>>(cellStart, cellEnd,
+		sortedHash, from, to);
+	SPHX_LAUNCH_CHECK("find_cell_start_kernel");
+	return SPHX_OK;
+}
+
 extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 	const void *pos, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint32_t *cellEnd,
@@ -601,9 +659,11 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		hipStream_t st = (hipStream_t)stream;
 		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
 		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), st));
-		const uint32_t rows = gridCells/(uint32_t)ctx->dev.gs1;
-		build_tiles_kernel<<<div_up_u(rows, 256), 256, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy, particleRangeEnd,
-			ctx->tiles, ctx->tile_ctl, ctx->tile_capacity);
+		const DevParams &dp = ctx->dev;
+		const uint32_t gs2 = (uint32_t)dp.gs[dp.c2], gs3 = (uint32_t)dp.gs[dp.c3];
+		const uint32_t bundles = ((gs2 + 1)/2)*((gs3 + 1)/2);
+		build_tiles_kernel<<<div_up_u(bundles, 128), 128, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy,
+			(const particleinfo*)info, particleRangeEnd, ctx->tiles, ctx->tile_ctl, ctx->tile_capacity);
 		SPHX_LAUNCH_CHECK("build_tiles_kernel");
 		ctx->tiles_built = true;
 		ctx->tiles_cellstart = cellStart;

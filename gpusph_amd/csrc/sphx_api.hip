@@ -35,9 +35,11 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	SPHX_HIP(hipMemset(ctx->tile_ctl, 0, 4*sizeof(uint32_t)));
 	int cus = 0;
 	SPHX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-	ctx->tile_grid = (uint32_t)(cus > 0 ? 2*cus : 512);
+	ctx->tile_grid = (uint32_t)(cus > 0 ? cus : 256);   // persistent grid: one 512-thread workgroup per CU (LDS bound)
 	const char *dis = getenv("SPHX_DISABLE_TILES");
 	ctx->disable_tiles = dis && dis[0] == '1';
+	const char *dbg = getenv("SPHX_TILE_DEBUG");
+	ctx->tile_debug = dbg ? atoi(dbg) : 0;
 	*out = ctx;
 	return SPHX_OK;
 }

@@ -29,13 +29,16 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 
 #define SPHX_BLOCK_FORCES 128   // one CFL entry per 128 particles (getFmaxElements contract)
 
-// forces tiles (see forces.hip "Tiled path")
-#define TILE_THREADS  128                  // particles per tile (one thread each)
-#define TILE_MAXCELLS 30                   // cells per tile along COORD1
-#define TILE_KW       (TILE_MAXCELLS + 2)  // window columns
-#define TILE_WCAP     1536                 // window records that fit LDS (48 B each, 2 workgroups per CU)
-#define TILE_DESC     8                    // uint32 per tile: g2, g3, firstCell, numCells, firstParticle, numParticles, windowRecords, 0
-#define TILE_NB       8                    // neighbours per batch in the tiled pair loop
+// forces tiles (see forces.hip "Tiled path"): a tile is a k x 2 x 2 block of cells (k along COORD1)
+#define TILE_THREADS  512                  // home particles per tile (one thread each), 8 waves
+#define TILE_HROWS    4                    // home rows: 2 (COORD2) x 2 (COORD3)
+#define TILE_WROWS    16                   // window rows: 4 x 4
+#define TILE_MAXCELLS 14                   // cells per tile along COORD1
+#define TILE_KW       16                   // window columns (TILE_MAXCELLS + 2)
+#define TILE_WCAP     3200                 // window records that fit LDS (48 B each, 1 workgroup per CU)
+#define TILE_DESC     16                   // uint32 per tile: g2, g3, firstCell, numCells, first[4], count[4], window, flags, 0, 0
+#define TILE_NB       4                    // neighbours per batch in the tiled pair loop
+#define TILE_AHEAD    4                    // list batches kept in flight per section (register ring)
 
 // ---- per-kernel constants, passed BY VALUE as a kernel argument (kernarg/SGPR resident;
 //      replaces the reference's ~70 __constant__ symbols, so there is no per-device global
@@ -109,6 +112,7 @@ struct sphx_ctx {
 	uint32_t    cells_reserved;
 	bool        tiles_built;
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
+	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments)
 	const void *tiles_cellstart, *tiles_neibslist;
 	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
 };

@@ -1,0 +1,115 @@
+"""HipKernels -- the product's kernel backend: torch tensors in, C-ABI calls (include/sphx.h) out.
+
+The multi-GPU driver (multigpu.py) talks to the device only through this small interface so that its
+host logic -- slab partition, halo bookkeeping, exchange order -- can be exercised by the CPU test
+suite with a test-only backend (tests/oracle_kernels.py).  There is no CPU implementation in the
+package: constructing HipKernels without a HIP device raises.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import capi, defs as D
+
+
+class HipKernels:
+    def __init__(self, problem, alloc, device):
+        if not torch.cuda.is_available():
+            raise capi.SphxError("HipKernels needs a HIP device (there is no CPU fallback)")
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.lib = capi.load()
+        self.ctx = capi.Context(self.device.index or 0)
+        self.params = problem.sphx_params(alloc)
+        self.ctx.set_constants(self.params)
+        self.ctx.reserve(alloc)
+        self.ncells = problem.grid_cells
+        sp = problem.simparams
+        self.compute_object_forces = 1 if sp.numforcesbodies > 0 else 0
+        self.sq_nl_radius = float(np.float32(sp.nlSqInfluenceRadius))
+        pp = problem.physparams
+        self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(pp.sscoeff))) * 1.1))  # GPUWorker.cc:3010-3011
+        if getattr(problem, "num_obstacle", 0):
+            gp = np.ascontiguousarray(problem.rb_cg_gridpos, dtype=np.int32)
+            lp = np.ascontiguousarray(problem.rb_cg_pos, dtype=np.float32)
+            fi = np.ascontiguousarray(problem.rb_firstindex, dtype=np.int32)
+            nb = len(fi)
+            capi.check(self.lib.sphx_set_rb_cg(self.ctx.handle, gp.ctypes.data, lp.ctypes.data, nb))
+            capi.check(self.lib.sphx_set_rb_start(self.ctx.handle, fi.ctypes.data, nb))
+            ident = np.tile(np.eye(3, dtype=np.float32).ravel(), nb)
+            z3 = np.zeros(3 * nb, dtype=np.float32)
+            capi.check(self.lib.sphx_set_rb_motion(self.ctx.handle, z3.ctypes.data, ident.ctypes.data,
+                                                   z3.ctypes.data, z3.ctypes.data, nb))
+
+    # ---- helpers
+    def _s(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def fmax_elements(self, n):
+        return int(self.lib.sphx_forces_fmax_elements(int(n)))
+
+    def fmax_temp_elements(self, n):
+        return int(self.lib.sphx_forces_fmax_temp_elements(int(n)))
+
+    def memset(self, t, byte):
+        capi.check(self.lib.sphx_memset_async(t.data_ptr(), byte, t.numel() * t.element_size(), self._s()))
+
+    # ---- AbstractNeibsEngine
+    def calc_hash(self, pos, hash_, partindex, info, devmap, n):
+        p = capi.ptr
+        capi.check(self.lib.sphx_calc_hash(self.ctx.handle, p(pos), p(hash_), p(partindex), p(info), p(devmap), n, self._s()))
+
+    def fix_hash(self, hash_, partindex, info, devmap, n):
+        p = capi.ptr
+        capi.check(self.lib.sphx_fix_hash(self.ctx.handle, p(hash_), p(partindex), p(info), p(devmap), n, self._s()))
+
+    def sort(self, hash_, info, partindex, n):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sort(self.ctx.handle, p(hash_), p(info), p(partindex), n, self._s()))
+
+    def reorder(self, segment_start, cellStart, cellEnd, spos, svel, upos, uvel, info, hash_, partindex, n, new_num):
+        p = capi.ptr
+        capi.check(self.lib.sphx_reorder(self.ctx.handle, p(segment_start), p(cellStart), p(cellEnd), p(spos), p(svel),
+                                         p(upos), p(uvel), p(info), p(hash_), p(partindex), n, p(new_num), self._s()))
+
+    def find_cell_start(self, cellStart, cellEnd, hash_, frm, to):
+        p = capi.ptr
+        capi.check(self.lib.sphx_find_cell_start(self.ctx.handle, p(cellStart), p(cellEnd), p(hash_), frm, to, self._s()))
+
+    def build_neibs(self, neibslist, pos, info, hash_, cellStart, cellEnd, n, range_end):
+        p = capi.ptr
+        capi.check(self.lib.sphx_neibs_resetinfo(self.ctx.handle, self._s()))
+        capi.check(self.lib.sphx_build_neibs(self.ctx.handle, p(neibslist), p(pos), p(info), p(hash_), p(cellStart),
+                                             p(cellEnd), n, range_end, self.ncells, self.sq_nl_radius, self.sq_nl_radius,
+                                             self._s()))
+
+    def neibs_info(self):
+        info = capi.NeibsInfo()
+        capi.check(self.lib.sphx_neibs_getinfo(self.ctx.handle, C.byref(info), self._s()))
+        return info
+
+    # ---- AbstractForcesEngine
+    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset):
+        p = capi.ptr
+        nb = C.c_uint32(0)
+        P = self.params
+        capi.check(self.lib.sphx_forces_basicstep(self.ctx.handle, p(forces), p(cfl), p(rbforces), p(rbtorques), p(pos), p(vel),
+                                                  p(info), p(hash_), p(cellStart), p(neibslist), None, None, None,
+                                                  n, frm, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius,
+                                                  cfl_offset, D.SIMULATE, 1, 0.0, self.compute_object_forces,
+                                                  C.byref(nb), self._s()))
+        return nb.value
+
+    def dtreduce(self, cfl, cfl_temp, nblocks, d_dt, combine_min):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_forces_dtreduce_device(self.ctx.handle, P.slength, P.dtadaptfactor, self.sspeed_cfl, 0.0,
+                                                        p(cfl), p(cfl_temp), nblocks, p(d_dt), combine_min, self._s()))
+
+    # ---- AbstractIntegrationEngine
+    def euler(self, npos, nvel, opos, ovel, info, hash_, forces, n, d_dt, dt_scale, step):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_euler_basicstep(self.ctx.handle, p(npos), p(nvel), p(opos), p(ovel), p(info), p(hash_),
+                                                 p(forces), None, n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
+                                                 P.slength, P.influenceradius, D.SIMULATE, self._s()))

@@ -1,0 +1,305 @@
+"""Slab-decomposed multi-GPU timestep driver: one process per GPU, halo exchange over torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU in the test suite).
+
+What it mirrors in GPUSPH (paths relative to the GPUSPH tree) and what it changes:
+  * device map: equal split of the cells along COORD3, the slowest linearisation axis, so that each
+    device's edge layer and each imported halo is ONE contiguous index range (src/linearization.h:28-35;
+    ProblemCore::fillDeviceMapByAxis src/ProblemCore.cc:1061-1116).  DamBreak3D splits along Y
+    (src/problems/DamBreak3D.cu:217-220): use linearisation "xzy" so that COORD3 = y.
+  * cell types INNER / INNER_EDGE / OUTER_EDGE / OUTER in the two high hash bits
+    (GPUWorker::createCompactDeviceMap src/GPUWorker.cc:1560-1634, src/multi_gpu_defines.h:56-83): the
+    sort then orders particles [inner | inner edge | outer edge | outer] and REORDER returns the
+    segment starts.
+  * migration is implicit as in the reference (src/GPUWorker.cc:358-365,1432-1460): halo copies are
+    integrated redundantly (EULER runs on all particles), a particle that crosses the slab boundary sorts
+    into the other segment at the next rebuild, the old owner crops it, the new owner already has it.
+  * halo import: the reference PULLS bursts with cudaMemcpyPeerAsync per (burst, buffer) and keeps the
+    per-cell offsets on the host (src/GPUWorker.cc:711-921).  Here each rank SENDS its two edge layers
+    (contiguous ranges) to its two neighbours and receives theirs, as ONE grouped send/recv per
+    exchange on a dedicated stream: after each re-sort pos+vel+info+hash (44 B/particle), after each
+    forces pass the forces (16 B/particle) -- strictly nearest-neighbour traffic, one xGMI link per
+    pair of devices, no collective on the data path.  The forces of the edge stripe are computed
+    first and exchanged while the inner stripe computes (FORCES_ENQUEUE/COMPLETE, GPUWorker.cc:2086-2185).
+  * dt: min over devices (GPUSPH.cc:650-657) as an all_reduce(MIN) of one device float per step.
+Results are bit-identical to the single-device run (same per-particle neighbour order and arithmetic).
+"""
+import numpy as np
+import torch
+
+from . import defs as D
+
+
+class SlabPartition:
+    """equal split of the COORD3 planes among `world` devices"""
+
+    def __init__(self, problem, world):
+        c1, c2, c3 = D.LINEARIZATIONS[problem.linearization]
+        gs = problem.m_gridsize
+        self.gs3 = int(gs[c3])
+        self.plane = int(gs[c1]) * int(gs[c2])          # cells per COORD3 plane = contiguous hash range
+        self.world = world
+        per = self.gs3 // world
+        if world > 1 and per < 2:
+            raise ValueError("need at least 2 cell planes per device along the split axis (have %d planes, %d devices)"
+                             % (self.gs3, world))
+        self.lo = [d * per for d in range(world)]
+        self.hi = [(d + 1) * per for d in range(world)]
+        self.hi[-1] = self.gs3
+
+    def plane_types(self, rank):
+        """CELLTYPE_* of every COORD3 plane as seen by `rank`"""
+        t = np.full(self.gs3, D.CELLTYPE_OUTER_CELL, dtype=np.uint32)
+        lo, hi = self.lo[rank], self.hi[rank]
+        t[lo:hi] = D.CELLTYPE_INNER_CELL
+        if rank > 0:
+            t[lo] = D.CELLTYPE_INNER_EDGE_CELL
+            t[lo - 1] = D.CELLTYPE_OUTER_EDGE_CELL
+        if rank < self.world - 1:
+            t[hi - 1] = D.CELLTYPE_INNER_EDGE_CELL
+            t[hi] = D.CELLTYPE_OUTER_EDGE_CELL
+        return t
+
+    def compact_device_map(self, rank):
+        """per-cell CELLTYPE_*_SHIFTED (BUFFER_COMPACT_DEV_MAP)"""
+        return np.repeat(self.plane_types(rank) << np.uint32(30), self.plane).astype(np.uint32)
+
+    def local_mask(self, rank, hashes):
+        """particles a rank holds initially: its own planes plus the one-plane halo on each side"""
+        c3 = (hashes & D.CELLTYPE_BITMASK) // self.plane
+        lo = self.lo[rank] - (1 if rank > 0 else 0)
+        hi = self.hi[rank] + (1 if rank < self.world - 1 else 0)
+        return (c3 >= lo) & (c3 < hi)
+
+
+class MultiGpuEngine:
+    def __init__(self, problem, device, rank, world, kernels=None, track_particle_count=True, margin=1.25,
+                 overlap=True):
+        self.problem = problem
+        self.rank, self.world = rank, world
+        self.device = torch.device(device)
+        self.is_cuda = self.device.type == "cuda"
+        self.sp = problem.simparams
+        self.part = SlabPartition(problem, world)
+        arrs = problem.copy_to_array()
+        mask = self.part.local_mask(rank, arrs["hash"]) if world > 1 else np.ones(len(arrs["hash"]), dtype=bool)
+        n0 = int(mask.sum())
+        self.alloc = int(n0 * margin) + 4096
+        if kernels is None:
+            from .kernels import HipKernels
+            kernels = HipKernels(problem, self.alloc, self.device)
+        self.k = kernels
+        if world > 1:
+            import torch.distributed as dist
+            self.dist = dist
+        else:
+            self.dist = None
+        dev, A = self.device, self.alloc
+        f32, i32, i16 = torch.float32, torch.int32, torch.int16
+
+        def up(a, dtype, shape):
+            t = torch.zeros(shape, dtype=dtype, device=dev)
+            t[:n0] = torch.from_numpy(a[mask]).to(dev)
+            return t
+
+        self.n_local = n0
+        self.pos = up(arrs["pos"], f32, (A, 4)); self.vel = up(arrs["vel"], f32, (A, 4))
+        self.pos2 = torch.zeros_like(self.pos); self.vel2 = torch.zeros_like(self.vel)
+        self.info = up(arrs["info"].view(np.int16), i16, (A, 4))
+        self.hash = up(arrs["hash"].view(np.int32), i32, (A,))
+        self.partindex = torch.zeros(A, dtype=i32, device=dev)
+        self.ncells = problem.grid_cells
+        self.cellStart = torch.empty(self.ncells, dtype=i32, device=dev)
+        self.cellEnd = torch.empty(self.ncells, dtype=i32, device=dev)
+        self.neibslist = torch.empty(int(self.sp.neiblistsize) * A, dtype=i16, device=dev)
+        self.forces = torch.zeros((A, 4), dtype=f32, device=dev)
+        self.cfl = torch.zeros(self.k.fmax_elements(A) + 8, dtype=f32, device=dev)
+        self.cfl_temp = torch.zeros(max(self.k.fmax_temp_elements(self.cfl.numel()), 4), dtype=f32, device=dev)
+        self.new_num = torch.zeros(1, dtype=i32, device=dev)
+        self.segment_start = torch.zeros(4, dtype=i32, device=dev)
+        nrb = max(getattr(problem, "num_obstacle", 0), 1)
+        self.rbforces = torch.zeros((nrb, 4), dtype=f32, device=dev) if getattr(problem, "num_obstacle", 0) else None
+        self.rbtorques = torch.zeros((nrb, 4), dtype=f32, device=dev) if getattr(problem, "num_obstacle", 0) else None
+        self.devmap = (torch.from_numpy(self.part.compact_device_map(rank).view(np.int32)).to(dev)
+                       if world > 1 else None)
+        dt0 = float(np.float32(self.sp.dt))
+        self.d_dt = torch.full((1,), dt0, dtype=f32, device=dev)
+        self.d_dt_next = torch.full((1,), dt0, dtype=f32, device=dev)
+        self.iterations = 0
+        self.n_int = n0
+        self.edge_start = n0
+        self.send_l = self.send_r = self.recv_l = self.recv_r = (0, 0)
+        self.overlap = overlap and self.is_cuda and world > 1
+        self.comm_stream = torch.cuda.Stream(device=dev) if self.overlap else None
+        self.profile_forces = None
+        self.track_particle_count = track_particle_count
+
+    # ------------------------------------------------------------------ exchange
+    def _neighbours(self):
+        left = self.rank - 1 if self.rank > 0 else None
+        right = self.rank + 1 if self.rank < self.world - 1 else None
+        return left, right
+
+    def _exchange(self, tensors):
+        """send my edge layers / receive the halo layers of every tensor in `tensors` (dim-0 ranges),
+        as one grouped batch of point-to-point operations"""
+        dist = self.dist
+        left, right = self._neighbours()
+        ops = []
+        for t in tensors:
+            if left is not None:
+                if self.send_l[1] > self.send_l[0]:
+                    ops.append(dist.P2POp(dist.isend, t[self.send_l[0]:self.send_l[1]], left))
+                if self.recv_l[1] > self.recv_l[0]:
+                    ops.append(dist.P2POp(dist.irecv, t[self.recv_l[0]:self.recv_l[1]], left))
+            if right is not None:
+                if self.send_r[1] > self.send_r[0]:
+                    ops.append(dist.P2POp(dist.isend, t[self.send_r[0]:self.send_r[1]], right))
+                if self.recv_r[1] > self.recv_r[0]:
+                    ops.append(dist.P2POp(dist.irecv, t[self.recv_r[0]:self.recv_r[1]], right))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+
+    # ------------------------------------------------------------------ neighbour phase
+    def build_neibs(self):
+        K = self.k
+        n = self.n_local
+        if self.iterations == 0:
+            K.fix_hash(self.hash, self.partindex, self.info, self.devmap, n)
+        else:
+            K.calc_hash(self.pos, self.hash, self.partindex, self.info, self.devmap, n)
+        K.sort(self.hash, self.info, self.partindex, n)
+        K.memset(self.cellStart, 0xFF)
+        K.memset(self.cellEnd, 0xFF)
+        K.reorder(self.segment_start if self.world > 1 else None, self.cellStart, self.cellEnd, self.pos2, self.vel2,
+                  self.pos, self.vel, self.info, self.hash, self.partindex, n, self.new_num)
+        self.pos, self.pos2 = self.pos2, self.pos
+        self.vel, self.vel2 = self.vel2, self.vel
+        if self.world == 1:
+            if self.track_particle_count:
+                self.n_local = int(self.new_num.item()) & 0xFFFFFFFF
+            self.n_int = self.n_local
+            self.edge_start = self.n_int
+        else:
+            self._update_segments_and_halo()
+        K.build_neibs(self.neibslist, self.pos, self.info, self.hash, self.cellStart, self.cellEnd, self.n_local, self.n_int)
+
+    def _update_segments_and_halo(self):
+        """UPDATE_SEGMENTS + CROP + APPEND_EXTERNAL (src/Integrator.cc:170-230)"""
+        K, dist = self.k, self.dist
+        seg = [int(v) & 0xFFFFFFFF for v in self.segment_start.cpu().tolist()]       # DOWNLOAD (sync)
+        newn = int(self.new_num.item()) & 0xFFFFFFFF
+        starts = list(seg) + [newn]
+        for i in range(3, -1, -1):                 # EMPTY_SEGMENT -> start of the next non-empty one
+            if starts[i] == D.EMPTY_SEGMENT:
+                starts[i] = starts[i + 1]
+        edge_start, n_int = starts[1], starts[2]   # internal = inner + inner edge; the rest is cropped
+        self.edge_start, self.n_int = edge_start, n_int
+        left, right = self._neighbours()
+        # my inner-edge segment is sorted by hash: the plane facing the left neighbour comes first
+        if left is not None and right is not None:
+            key = (D.CELLTYPE_INNER_EDGE_CELL << 30) | ((self.part.hi[self.rank] - 1) * self.part.plane)
+            h = self.hash[edge_start:n_int].to(torch.int64) & 0xFFFFFFFF
+            split = edge_start + int(torch.searchsorted(h, torch.tensor([key], dtype=torch.int64, device=h.device)).item())
+        elif left is not None:
+            split = n_int
+        else:
+            split = edge_start
+        self.send_l = (edge_start, split) if left is not None else (0, 0)
+        self.send_r = (split, n_int) if right is not None else (0, 0)
+        # counts of the layers my neighbours send me
+        mine = torch.tensor([self.send_l[1] - self.send_l[0], self.send_r[1] - self.send_r[0]], dtype=torch.int64,
+                            device=self.device)
+        allc = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(allc, mine)
+        rl = int(allc[left][1].item()) if left is not None else 0      # left neighbour's right layer
+        rr = int(allc[right][0].item()) if right is not None else 0    # right neighbour's left layer
+        if n_int + rl + rr > self.alloc:
+            raise RuntimeError("rank %d: %d internal + %d halo particles exceed the %d allocated"
+                               % (self.rank, n_int, rl + rr, self.alloc))
+        self.recv_l = (n_int, n_int + rl)
+        self.recv_r = (n_int + rl, n_int + rl + rr)
+        self.n_local = n_int + rl + rr
+        self._exchange([self.pos, self.vel, self.info, self.hash])
+        # imported cells are OUTER_EDGE cells here whatever they are at home
+        if self.n_local > n_int:
+            hs = self.hash[n_int:self.n_local]
+            hs.bitwise_and_(D.CELLTYPE_BITMASK).bitwise_or_(-2147483648)          # CELLTYPE_OUTER_EDGE_CELL << 30
+        # cell ranges: forget everything outside my own planes, then index the fresh halo
+        lo, hi, plane = self.part.lo[self.rank] * self.part.plane, self.part.hi[self.rank] * self.part.plane, self.part.plane
+        for t in (self.cellStart, self.cellEnd):
+            if lo > 0:
+                K.memset(t[:lo], 0xFF)
+            if hi < self.ncells:
+                K.memset(t[hi:], 0xFF)
+        K.find_cell_start(self.cellStart, self.cellEnd, self.hash, n_int, self.n_local)
+
+    # ------------------------------------------------------------------ forces / euler
+    def _forces_pass(self, pos, vel, combine_min):
+        K = self.k
+        K.memset(self.cfl, 0)
+        prof = self.profile_forces is not None and self.is_cuda
+        if prof:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+        args = (self.forces, self.cfl, self.rbforces, self.rbtorques, pos, vel, self.info, self.hash, self.cellStart,
+                self.neibslist, self.n_local)
+        if self.world > 1 and self.n_int > self.edge_start:
+            # edge stripe first, then the inner stripe while the edge forces travel
+            nb1 = K.forces(*args, self.edge_start, self.n_int, 0)
+            if self.overlap:
+                ev = torch.cuda.Event(); ev.record()
+            nb2 = K.forces(*args, 0, self.edge_start, nb1)
+            if prof:
+                e1.record(); self.profile_forces.append((e0, e1))
+            if self.overlap:
+                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_event(ev)
+                    self._exchange([self.forces])
+                torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+            else:
+                self._exchange([self.forces])
+        else:
+            nb1 = K.forces(*args, 0, self.n_int, 0)
+            nb2 = 0
+            if prof:
+                e1.record(); self.profile_forces.append((e0, e1))
+            if self.world > 1:
+                self._exchange([self.forces])
+        K.dtreduce(self.cfl, self.cfl_temp, nb1 + nb2, self.d_dt_next, combine_min)
+
+    def step(self):
+        K = self.k
+        if self.iterations % self.sp.buildneibsfreq == 0:
+            self.build_neibs()
+        n = self.n_local
+        self._forces_pass(self.pos, self.vel, 0)
+        K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1)
+        self._forces_pass(self.pos2, self.vel2, 1)
+        K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2)
+        self.pos, self.pos2 = self.pos2, self.pos
+        self.vel, self.vel2 = self.vel2, self.vel
+        if self.world > 1:
+            self.dist.all_reduce(self.d_dt_next, op=self.dist.ReduceOp.MIN)       # dt = min over devices
+        self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt
+        self.iterations += 1
+
+    # ------------------------------------------------------------------ views
+    @property
+    def n(self):
+        return self.n_int
+
+    def internal_particles(self):
+        return self.n_int
+
+    def neibs_info(self):
+        return self.k.neibs_info()
+
+    def current_dt(self):
+        return float(self.d_dt.item())
+
+    def download_internal(self):
+        n = self.n_int
+        return {"pos": self.pos[:n].cpu().numpy(), "vel": self.vel[:n].cpu().numpy(),
+                "info": self.info[:n].cpu().numpy().view(np.uint16), "hash": self.hash[:n].cpu().numpy().view(np.uint32),
+                "forces": self.forces[:n].cpu().numpy()}

@@ -151,6 +151,12 @@ int sphx_reorder(sphx_ctx *ctx, uint32_t *segmentStart,
 	const void *unsortedPos, const void *unsortedVel,
 	const void *sortedInfo, const uint32_t *sortedHash, const uint32_t *partIndex,
 	uint32_t numParticles, uint32_t *newNumParticles, void *stream);
+/* cellStart/cellEnd of the already sorted range [fromParticle, toParticle) only (no gather).  The
+ * reference rebuilds the cell ranges of imported halo cells on the host from the neighbour
+ * device's s_dCellStarts (src/GPUWorker.cc:754-776,1391-1430); with the halo arriving in sorted
+ * order this is the same adjacent-hash scan as reorderDataAndFindCellStart, run on the device. */
+int sphx_find_cell_start(sphx_ctx *ctx, uint32_t *cellStart, uint32_t *cellEnd, const uint32_t *sortedHash,
+	uint32_t fromParticle, uint32_t toParticle, void *stream);
 /* buildNeibsList (src/cuda/buildneibs.cu:421-492) */
 int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 	const void *pos, const void *info, const uint32_t *hash,

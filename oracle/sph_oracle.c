@@ -379,6 +379,25 @@ void orc_reorder(const orc_params *p, uint32_t *cellStart, uint32_t *cellEnd, ui
 	}
 }
 
+/* cell ranges of an already sorted sub-range (imported halo cells).  The reference derives them on
+ * the host from the neighbour device's cell starts (src/GPUWorker.cc:754-776,1391-1430); the result
+ * is what the adjacent-hash scan of reorderDataAndFindCellStartDevice gives on that range. */
+void orc_find_cell_start(uint32_t *cellStart, uint32_t *cellEnd, const uint32_t *particleHash,
+	uint32_t from, uint32_t to)
+{
+	for (uint32_t index = from; index < to; ++index) {
+		const uint32_t cellHash = particleHash[index];
+		if (cellHash == CELL_HASH_MAX) continue;
+		if (index == from || cellHash != particleHash[index - 1]) {
+			cellStart[cellHash & CELLTYPE_BITMASK] = index;
+			if (index > from && particleHash[index - 1] != CELL_HASH_MAX)
+				cellEnd[particleHash[index - 1] & CELLTYPE_BITMASK] = index;
+		}
+		if (index == to - 1)
+			cellEnd[cellHash & CELLTYPE_BITMASK] = index + 1;
+	}
+}
+
 /* ---- neighbour list: src/cuda/buildneibs_kernel.cu:300-644,1019-1185 ---------------- */
 
 /* calcNeibCell<periodicbound>, :311-383 */

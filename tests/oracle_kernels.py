@@ -1,0 +1,75 @@
+"""TEST-ONLY kernel backend: the interface of gpusph_amd.kernels.HipKernels implemented with the CPU
+oracle on CPU torch tensors.  It exists so that the host logic of gpusph_amd.multigpu (slab partition,
+segments, halo exchange order, index bookkeeping) can run under torch.distributed/gloo without a GPU.
+It lives under tests/ on purpose: the product never imports it."""
+import ctypes as C
+import numpy as np
+import torch
+
+import oracle_lib as ol
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class OracleKernels:
+    def __init__(self, problem, alloc):
+        self.sp = problem.sphx_params(alloc)
+        self.op = ol.orc_params_from(self.sp, problem)
+        self.L = ol.lib()
+        self.ncells = problem.grid_cells
+        s = problem.simparams
+        self.compute_object_forces = 1 if s.numforcesbodies > 0 else 0
+        self.sq = float(np.float32(s.nlSqInfluenceRadius))
+        self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(problem.physparams.sscoeff))) * 1.1))
+        self.info_ = ol.OrcNeibsInfo()
+
+    def fmax_elements(self, n):
+        return int(self.L.orc_fmax_elements(C.c_uint32(n)))
+
+    def fmax_temp_elements(self, n):
+        return int(self.L.orc_fmax_temp_elements(C.c_uint32(n)))
+
+    def memset(self, t, byte):
+        t.view(torch.uint8).fill_(byte) if t.numel() else None
+
+    def calc_hash(self, pos, hash_, partindex, info, devmap, n):
+        self.L.orc_calc_hash(C.byref(self.op), _p(pos), _p(hash_), _p(partindex), _p(info), _p(devmap), C.c_uint32(n))
+
+    def fix_hash(self, hash_, partindex, info, devmap, n):
+        self.L.orc_fix_hash(C.byref(self.op), _p(hash_), _p(partindex), _p(info), _p(devmap), C.c_uint32(n))
+
+    def sort(self, hash_, info, partindex, n):
+        self.L.orc_sort(_p(hash_), _p(info), _p(partindex), C.c_uint32(n))
+
+    def reorder(self, segment_start, cellStart, cellEnd, spos, svel, upos, uvel, info, hash_, partindex, n, new_num):
+        self.L.orc_reorder(C.byref(self.op), _p(cellStart), _p(cellEnd), _p(segment_start), _p(spos), _p(svel), _p(upos),
+                           _p(uvel), _p(info), _p(hash_), _p(partindex), C.c_uint32(n), _p(new_num))
+
+    def find_cell_start(self, cellStart, cellEnd, hash_, frm, to):
+        self.L.orc_find_cell_start(_p(cellStart), _p(cellEnd), _p(hash_), C.c_uint32(frm), C.c_uint32(to))
+
+    def build_neibs(self, neibslist, pos, info, hash_, cellStart, cellEnd, n, range_end):
+        self.L.orc_build_neibs(C.byref(self.op), _p(neibslist), _p(pos), _p(info), _p(hash_), _p(cellStart), _p(cellEnd),
+                               C.c_uint32(n), C.c_uint32(range_end), C.c_float(self.sq), C.byref(self.info_))
+
+    def neibs_info(self):
+        return self.info_
+
+    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset):
+        if to > frm:
+            forces[frm:to] = 0          # pre_forces clobber (GPUWorker.cc:1949); the oracle does the reference's RMW
+        self.L.orc_forces.restype = C.c_uint32
+        return int(self.L.orc_forces(C.byref(self.op), _p(forces), _p(cfl), _p(rbforces), _p(rbtorques), _p(pos), _p(vel),
+                                     _p(info), _p(hash_), _p(cellStart), _p(neibslist), None, C.c_uint32(n), C.c_uint32(frm),
+                                     C.c_uint32(to), C.c_uint32(cfl_offset), C.c_int(self.compute_object_forces)))
+
+    def dtreduce(self, cfl, cfl_temp, nblocks, d_dt, combine_min):
+        dt = float(self.L.orc_dtreduce(C.byref(self.op), _p(cfl), C.c_uint32(nblocks), C.c_float(self.sspeed_cfl), C.c_float(0.0)))
+        d_dt[0] = min(float(d_dt[0]), dt) if combine_min else dt
+
+    def euler(self, npos, nvel, opos, ovel, info, hash_, forces, n, d_dt, dt_scale, step):
+        dt = float(np.float32(d_dt[0].item()) * np.float32(dt_scale))
+        self.L.orc_euler(C.byref(self.op), _p(npos), _p(nvel), _p(opos), _p(ovel), _p(info), _p(hash_), _p(forces), None,
+                         C.c_uint32(n), C.c_float(dt), C.c_int(step))

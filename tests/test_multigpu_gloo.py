@@ -1,0 +1,101 @@
+"""N > 1 host logic on CPU: world_size-2 and -3 gloo runs of gpusph_amd.multigpu with the test-only
+oracle kernel backend; the slab-decomposed trajectory must equal the single-domain one BIT FOR BIT
+(per-particle neighbour order and arithmetic do not depend on the decomposition)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, steps, case, outdir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch.distributed as dist
+    from gpusph_amd.problem import DamBreak3D
+    from gpusph_amd.multigpu import MultiGpuEngine
+    from oracle_kernels import OracleKernels
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = DamBreak3D(**case)
+    eng = MultiGpuEngine(prob, "cpu", rank, world, kernels=None if False else _mk(prob, rank, world))
+    for _ in range(steps):
+        eng.step()
+    out = eng.download_internal()
+    np.savez(os.path.join(outdir, "r%d_of_%d.npz" % (rank, world)), n_local=eng.n_local, dt=eng.current_dt(),
+             interactions=eng.neibs_info().numInteractions, **out)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
+def _mk(prob, rank, world):
+    # allocation must match what MultiGpuEngine computes: build the engine's alloc the same way
+    from gpusph_amd.multigpu import SlabPartition
+    from oracle_kernels import OracleKernels
+    arrs = prob.copy_to_array()
+    part = SlabPartition(prob, world)
+    n0 = int(part.local_mask(rank, arrs["hash"]).sum()) if world > 1 else len(arrs["hash"])
+    return OracleKernels(prob, int(n0 * 1.25) + 4096)
+
+
+def _run(world, steps, case, outdir):
+    port = _free_port()
+    if world == 1:
+        _worker(0, 1, port, steps, case, outdir)
+    else:
+        mp.spawn(_worker, args=(world, port, steps, case, outdir), nprocs=world, join=True)
+
+
+def _gather(outdir, world):
+    parts = [np.load(os.path.join(outdir, "r%d_of_%d.npz" % (r, world))) for r in range(world)]
+    ids = np.concatenate([p["info"][:, 2].astype(np.uint32) | (p["info"][:, 3].astype(np.uint32) << 16) for p in parts])
+    order = np.argsort(ids)
+    cat = {k: np.concatenate([p[k] for p in parts])[order] for k in ("pos", "vel", "info", "hash", "forces")}
+    return ids[order], cat, parts
+
+
+@pytest.mark.parametrize("world,lin", [(2, "xzy"), (3, "yzx")])
+def test_slab_runs_equal_single_domain(tmp_path, world, lin):
+    case = dict(deltap=0.04, obstacle=True, linearization=lin, jitter=0.05)
+    steps = 13                                   # spans two neighbour-list rebuilds (iterations 0 and 10)
+    _run(1, steps, case, str(tmp_path))
+    _run(world, steps, case, str(tmp_path))
+    ids1, one, p1 = _gather(str(tmp_path), 1)
+    idsN, many, pN = _gather(str(tmp_path), world)
+    assert np.array_equal(ids1, idsN)            # every particle is owned by exactly one rank
+    for k in ("pos", "vel", "forces"):
+        assert np.array_equal(one[k].view(np.uint32), many[k].view(np.uint32)), k
+    assert np.array_equal(one["hash"] & 0x3FFFFFFF, many["hash"] & 0x3FFFFFFF)
+    assert all(float(p["dt"]) == float(p1[0]["dt"]) for p in pN)
+    assert sum(int(p["interactions"]) for p in pN) == int(p1[0]["interactions"])
+    assert all(int(p["n_local"]) > len(p["pos"]) for p in pN)      # every rank holds a halo
+
+
+def test_partition_and_device_map():
+    sys.path[:0] = [ROOT]
+    from gpusph_amd.problem import DamBreak3D
+    from gpusph_amd.multigpu import SlabPartition
+    from gpusph_amd import defs as D
+    prob = DamBreak3D(0.02, linearization="xzy", obstacle=False)
+    part = SlabPartition(prob, 4)
+    assert part.lo[0] == 0 and part.hi[-1] == part.gs3 and all(part.hi[d] == part.lo[d + 1] for d in range(3))
+    for r in range(4):
+        t = part.plane_types(r)
+        assert (t[part.lo[r]:part.hi[r]] <= D.CELLTYPE_INNER_EDGE_CELL).all()
+        assert (t == D.CELLTYPE_OUTER_EDGE_CELL).sum() == (r > 0) + (r < 3)
+        dm = part.compact_device_map(r)
+        assert len(dm) == prob.grid_cells and set(np.unique(dm >> 30)) <= {0, 1, 2, 3}
+    with pytest.raises(ValueError):
+        SlabPartition(prob, 64)
