@@ -141,24 +141,41 @@ class MultiGpuEngine:
 
     def _exchange(self, tensors):
         """send my edge layers / receive the halo layers of every tensor in `tensors` (dim-0 ranges),
-        as one grouped batch of point-to-point operations"""
+        as one grouped batch of point-to-point operations.  Payloads travel as raw bytes (RCCL has no
+        16-bit integer type for the ushort4 particleinfo)."""
         dist = self.dist
         left, right = self._neighbours()
-        ops = []
+        stage = self.is_cuda and dist.get_backend() == "gloo"     # test rigs only: gloo moves host memory
+        ops, copies = [], []
+
+        def view(t, rng):
+            v = t[rng[0]:rng[1]].view(torch.uint8)
+            return v
+
+        def send(t, rng, peer):
+            if rng[1] > rng[0]:
+                v = view(t, rng)
+                ops.append(dist.P2POp(dist.isend, v.cpu() if stage else v, peer))
+
+        def recv(t, rng, peer):
+            if rng[1] > rng[0]:
+                v = view(t, rng)
+                if stage:
+                    h = torch.empty(v.shape, dtype=torch.uint8)
+                    copies.append((v, h))
+                    v = h
+                ops.append(dist.P2POp(dist.irecv, v, peer))
+
         for t in tensors:
             if left is not None:
-                if self.send_l[1] > self.send_l[0]:
-                    ops.append(dist.P2POp(dist.isend, t[self.send_l[0]:self.send_l[1]], left))
-                if self.recv_l[1] > self.recv_l[0]:
-                    ops.append(dist.P2POp(dist.irecv, t[self.recv_l[0]:self.recv_l[1]], left))
+                send(t, self.send_l, left); recv(t, self.recv_l, left)
             if right is not None:
-                if self.send_r[1] > self.send_r[0]:
-                    ops.append(dist.P2POp(dist.isend, t[self.send_r[0]:self.send_r[1]], right))
-                if self.recv_r[1] > self.recv_r[0]:
-                    ops.append(dist.P2POp(dist.irecv, t[self.recv_r[0]:self.recv_r[1]], right))
+                send(t, self.send_r, right); recv(t, self.recv_r, right)
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
+        for v, h in copies:
+            v.copy_(h)
 
     # ------------------------------------------------------------------ neighbour phase
     def build_neibs(self):

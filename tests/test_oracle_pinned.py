@@ -99,7 +99,7 @@ def test_oracle_pipeline_regression():
     """the oracle reproduces its own committed outputs (guards the fixture the GPU tests compare with)"""
     from gpusph_amd.problem import DamBreak3D
     g = np.load(os.path.join(GOLD, "oracle_pipeline.npz"))
-    prob = DamBreak3D(float(g["deltap"]), obstacle=True, jitter=0.05)
+    prob = DamBreak3D(float(g["deltap"]), obstacle=True, jitter=0.05, hydrostatic=False)
     arrs = prob.copy_to_array()
     assert np.array_equal(arrs["pos"].view(np.uint32), g["in_pos"].view(np.uint32))
     assert np.array_equal(arrs["hash"], g["in_hash"])
