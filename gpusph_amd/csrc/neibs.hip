@@ -356,12 +356,40 @@ __device__ __forceinline__ bool neib_cell_axis(int &g, int off, int gs, bool per
 	return true;
 }
 
+// first non-fluid particle of every cell (cells are sorted fluid-first, ptype_hash_compare): lets the
+// list build know a candidate's type from its index alone in the fluid segment of a cell
+__global__ void __launch_bounds__(256)
+cell_fluid_end_kernel(uint32_t *__restrict__ cellFluidEnd, const uint32_t *__restrict__ particleHash,
+	const particleinfo *__restrict__ infoArray, uint32_t numParticles)
+{
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	if (i >= numParticles) return;
+	const uint32_t h = particleHash[i];
+	if (h == CELL_HASH_MAX) return;
+	const bool fluid = IS_FLUID(infoArray[i]);
+	const bool firstOfCell = (i == 0) || (particleHash[i - 1] != h);
+	const bool lastOfCell = (i == numParticles - 1) || (particleHash[i + 1] != h);
+	if (!fluid && (firstOfCell || IS_FLUID(infoArray[i - 1])))
+		cellFluidEnd[h & CELLTYPE_BITMASK] = i;              // first non-fluid particle of the cell
+	else if (fluid && lastOfCell)
+		cellFluidEnd[h & CELLTYPE_BITMASK] = i + 1;          // all fluid: the segment ends with the cell
+}
+
+#define NEIB_MLP 4   // candidate positions fetched per batch in the fluid segment
+
+// buildNeibsListDevice + neibsInCell (src/cuda/buildneibs_kernel.cu:536-644,1019-1185).  The candidate
+// scan is a gather through L1/L2 and is bound by the number of gather instructions, so it avoids the
+// ones the reference cannot: the particleinfo of a candidate is only read in the non-fluid tail of a
+// cell (in the fluid segment the type is known from the index), and DYN/LJ boundary particles, which
+// never list boundary neighbours, do not visit the non-fluid tail at all.  Candidate order, tests and
+// encodings are the reference's, so the list is bit-identical.
 __global__ void __launch_bounds__(BLOCK_NEIBS)
 build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	const float4 *__restrict__ posArray, const particleinfo *__restrict__ infoArray,
 	const uint32_t *__restrict__ particleHash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
-	uint32_t particleRangeEnd, float sqinfluenceradius, NeibsCounters *__restrict__ counters)
+	const uint32_t *__restrict__ cellFluidEnd,
+	uint32_t particleRangeEnd, float sqinfluenceradius, NeibsCounters *__restrict__ counters, int dbg)
 {
 	const uint32_t index = blockIdx.x*BLOCK_NEIBS + threadIdx.x;
 	uint32_t nf = 0, nb = 0, nv = 0; // neibs_num[PT_FLUID, PT_BOUNDARY, PT_VERTEX]
@@ -376,6 +404,8 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 		if (!is_active_w(pos.w)) break;
 		const int3 gridPos = grid_pos_from_hash(p, particleHash[index] & CELLTYPE_BITMASK);
 		const bool boundary = IS_BOUNDARY(info);
+		// boundary particles never list non-fluid neighbours with LJ/DYN boundaries (:596-607)
+		const bool fluidOnly = boundary && (p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY);
 
 		for (int z = -1; z <= 1; z++) for (int y = -1; y <= 1; y++) for (int x = -1; x <= 1; x++) {
 			int gx = gridPos.x, gy = gridPos.y, gz = gridPos.z;
@@ -385,7 +415,8 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 			const uint32_t cellHash = grid_hash(p, gx, gy, gz);
 			const uint32_t bucketStart = cellStart[cellHash];
 			if (bucketStart == CELL_EMPTY) continue;
-			const uint32_t bucketEnd = cellEnd[cellHash];
+			const uint32_t fluidEnd = cellFluidEnd[cellHash];
+			const uint32_t bucketEnd = fluidOnly ? fluidEnd : cellEnd[cellHash];
 			const uint32_t cell = (uint32_t)((x + 1) + (y + 1)*3 + (z + 1)*9);
 
 			const float px = fmaf(-(float)x, p.cs[0], pos.x);
@@ -394,7 +425,30 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 
 			bool encode_cell = true;
 			uint32_t neib_type = PT_FLUID;
-			for (uint32_t neib_index = bucketStart; neib_index < bucketEnd; ++neib_index) {
+			// --- fluid segment: type known, NEIB_MLP position gathers in flight ---
+			for (uint32_t j0 = bucketStart; j0 < fluidEnd; j0 += NEIB_MLP) {
+				float4 cp[NEIB_MLP];
+#pragma unroll
+				for (int u = 0; u < NEIB_MLP; ++u) cp[u] = posArray[min(j0 + (uint32_t)u, fluidEnd - 1u)];
+#pragma unroll
+				for (int u = 0; u < NEIB_MLP; ++u) {
+					const uint32_t neib_index = j0 + (uint32_t)u;
+					if (neib_index >= fluidEnd || neib_index == index || !is_active_w(cp[u].w)) continue;
+					const float rx = px - cp[u].x, ry = py - cp[u].y, rz = pz - cp[u].z;
+					const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
+					if (r2 < sqinfluenceradius) {
+						const uint32_t offset = nf;       // neibListOffset(PT_FLUID)
+						nf++;
+						if (!too_many_neibs(p, nf, nb, nv, PT_FLUID)) {
+							const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
+							if (!(dbg & 64)) neibsList[(size_t)offset*p.stride + index] = (neibdata)((neib_index - bucketStart) + enc);
+							encode_cell = false;
+						}
+					}
+				}
+			}
+			// --- non-fluid tail (boundary / vertex / testpoint candidates): the reference's loop as is ---
+			for (uint32_t neib_index = max(fluidEnd, bucketStart); neib_index < bucketEnd; ++neib_index) {
 				if (neib_index == index) continue;
 				const particleinfo neib_info = infoArray[neib_index];
 				if (IS_TESTPOINT(neib_info)) continue;
@@ -414,7 +468,7 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 					if (neib_type == PT_FLUID) nf++; else if (neib_type == PT_BOUNDARY) nb++; else nv++;
 					if (!too_many_neibs(p, nf, nb, nv, neib_type)) {
 						const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
-						neibsList[(size_t)offset*p.stride + index] = (neibdata)((neib_index - bucketStart) + enc);
+						if (!(dbg & 64)) neibsList[(size_t)offset*p.stride + index] = (neibdata)((neib_index - bucketStart) + enc);
 						encode_cell = false;
 					}
 				}
@@ -450,7 +504,6 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 		atomicAdd(&counters->numInteractions, (int)total);
 	}
 }
-
 
 // ------------------------------------------------------------------------------------------
 // forces tiles (consumed by forces_tile_kernel, forces.hip).  A tile is a block of k x 2 x 2 cells
@@ -541,6 +594,7 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 	}
 	if (hsum) emit(ca, gs1 - ca, wc, wfl);
 }
+
 
 // ------------------------------------------------------------------------------------------
 // C ABI
@@ -648,15 +702,22 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		"sphx_build_neibs: gridCells does not match the grid set by set_constants");
 	SPHX_REQUIRE(particleRangeEnd <= ctx->params.neiblist_stride, "sphx_build_neibs: range exceeds the neighbour list stride");
 	if (!particleRangeEnd) return SPHX_OK;
-	build_neibs_kernel<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, (hipStream_t)stream>>>(ctx->dev,
-		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd,
-		particleRangeEnd, sqinfluenceradius, ctx->counters_dev);
+	hipStream_t st = (hipStream_t)stream;
+	int rc = sphx_ensure_scratch(ctx, numParticles);
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(gridCells <= ctx->cells_reserved, "sphx_build_neibs: grid larger than reserved");
+	// per-cell end of the fluid segment (particles of a cell are sorted fluid-first)
+	SPHX_HIP(hipMemcpyAsync(ctx->cell_fluid_end, cellStart, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
+	cell_fluid_end_kernel<<<div_up_u(numParticles, 256), 256, 0, st>>>(ctx->cell_fluid_end, hash, (const particleinfo*)info, numParticles);
+	SPHX_LAUNCH_CHECK("cell_fluid_end_kernel");
+	build_neibs_kernel<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
+		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
+		particleRangeEnd, sqinfluenceradius, ctx->counters_dev, ctx->tile_debug);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 
-	// tiling of this neighbour list for the forces engine (forces.hip "Tiled path")
+	// tiling of the sorted particles for the forces engine (forces.hip "Tiled path")
 	ctx->tiles_built = false;
-	if (ctx->tiles && gridCells <= ctx->cells_reserved && !ctx->disable_tiles) {
-		hipStream_t st = (hipStream_t)stream;
+	if (ctx->tiles && !ctx->disable_tiles) {
 		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
 		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), st));
 		const DevParams &dp = ctx->dev;

@@ -47,13 +47,13 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
-		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tiles, ctx->cell_end_copy };
+		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
 	ctx->eos_aux = nullptr;
-	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr;
+	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr; ctx->cell_fluid_end = nullptr;
 	ctx->tile_capacity = 0; ctx->cells_reserved = 0; ctx->tiles_built = false;
 	ctx->reserved_particles = ctx->reserved_bins = 0;
 }
@@ -99,6 +99,7 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	SPHX_HIP(hipMalloc((void**)&ctx->tiles, sizeof(uint32_t)*TILE_DESC*(size_t)ctx->tile_capacity));
 	ctx->cells_reserved = (bins - 1)/4;
 	SPHX_HIP(hipMalloc((void**)&ctx->cell_end_copy, sizeof(uint32_t)*(size_t)ctx->cells_reserved));
+	SPHX_HIP(hipMalloc((void**)&ctx->cell_fluid_end, sizeof(uint32_t)*(size_t)ctx->cells_reserved));
 	ctx->reserved_particles = n;
 	ctx->reserved_bins = bins;
 	return SPHX_OK;

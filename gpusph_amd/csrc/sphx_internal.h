@@ -108,6 +108,7 @@ struct sphx_ctx {
 	uint32_t   *tiles;         // [tile_capacity][TILE_DESC]
 	uint32_t   *tile_ctl;      // [0] = number of tiles, [1] = overflow flag (generic kernel takes over)
 	uint32_t   *cell_end_copy; // [cells] cellEnd of the build the tiles belong to
+	uint32_t   *cell_fluid_end;// [cells] first non-fluid particle of each cell (neighbour-list build)
 	uint32_t    tile_capacity;
 	uint32_t    cells_reserved;
 	bool        tiles_built;
@@ -178,6 +179,46 @@ __device__ __forceinline__ uint32_t grid_hash_periodic(const DevParams &p, int g
 	if (gz >= p.gs[2]) gz = 0;
 	return grid_hash(p, gx, gy, gz);
 }
+
+// window cell (row r of 16, column col) of a tile -> start/count of its particles
+__device__ __forceinline__ void window_cell(const DevParams &p, const uint32_t *__restrict__ cellStart,
+	const uint32_t *__restrict__ cellEnd, int g2, int g3, int ca, int ncells, int r, int col,
+	uint32_t &start, uint32_t &cnt)
+{
+	start = 0; cnt = 0;
+	if (col >= ncells + 2) return;
+	const int v0 = ca - 1 + col, v1 = g2 + (r & 3) - 1, v2 = g3 + (r >> 2) - 1;
+	int gx = (p.c1 == 0) ? v0 : (p.c2 == 0) ? v1 : v2;
+	int gy = (p.c1 == 1) ? v0 : (p.c2 == 1) ? v1 : v2;
+	int gz = (p.c1 == 2) ? v0 : (p.c2 == 2) ? v1 : v2;
+	if (gx < 0) { if (p.periodic & SPHX_PERIODIC_X) gx = p.gs[0] - 1; else return; }
+	else if (gx >= p.gs[0]) { if (p.periodic & SPHX_PERIODIC_X) gx = 0; else return; }
+	if (gy < 0) { if (p.periodic & SPHX_PERIODIC_Y) gy = p.gs[1] - 1; else return; }
+	else if (gy >= p.gs[1]) { if (p.periodic & SPHX_PERIODIC_Y) gy = 0; else return; }
+	if (gz < 0) { if (p.periodic & SPHX_PERIODIC_Z) gz = p.gs[2] - 1; else return; }
+	else if (gz >= p.gs[2]) { if (p.periodic & SPHX_PERIODIC_Z) gz = 0; else return; }
+	const uint32_t h = grid_hash(p, gx, gy, gz);
+	const uint32_t cs = cellStart[h];
+	if (cs != CELL_EMPTY) { start = cs; cnt = cellEnd[h] - cs; }
+}
+
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// async global -> LDS copy of `count` float4 records (LDS-DMA, no VGPR round trip): every wave copies
+// 64-record chunks, LDS destination = wave-uniform base + lane*16 (cdna_hip_programming.md "global_load_lds")
+template<int NT>
+__device__ __forceinline__ void stage_rows(const float4 *__restrict__ src, float4 *dst, uint32_t count, uint32_t tid)
+{
+	const uint32_t wave = tid >> 6, lane = tid & 63u;
+	for (uint32_t c0 = wave*64u; c0 < count; c0 += NT) {
+		const uint32_t cu = __builtin_amdgcn_readfirstlane(c0);
+		if (cu + lane < count)
+			__builtin_amdgcn_global_load_lds((gptr_t)(src + cu + lane), (lptr_t)(dst + cu), 16, 0, 0);
+	}
+}
+
 #endif // __HIPCC__
 
 #endif
