@@ -56,6 +56,26 @@ def cpu_baseline(target_particles=400_000, steps=2):
     }
 
 
+def pmc_traffic(n_total, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (profiles/*pmc_traffic*.json: separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH doubled
+    per the gfx950 correction).  PMC collection needs rocprofv3 around the process, so it cannot be taken
+    live here; the number is only reported when the profiled workload is the one being run."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "*pmc_traffic*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if int(d.get("particles", -1)) != int(n_total):
+            continue
+        for name, k in d.get("kernels", {}).items():
+            if name.startswith(kernel + "<") or name == kernel:
+                return int(k["hbm_bytes_per_launch"])
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -139,6 +159,8 @@ def main():
         bytes_per_launch = n_internal * (64.0 + 2.0 * nbar)
         avg_ms = float(np.mean(forces_ms)) if forces_ms else float("nan")
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if forces_ms else float("nan")
+        kernel = "forces_kernel" if args.no_tiles else "forces_tile_kernel"
+        traffic = None if (args.no_tiles or world > 1) else pmc_traffic(n_total, kernel)
         out = {
             "metric": "M particle-updates/sec, DamBreak3D", "value": round(value, 2),
             "unit": "M particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -148,8 +170,8 @@ def main():
                                    "Colagrossi diffusion, DYN boundary, neib rebuild every 10 steps" % (n_total, dp),
                        "particles": n_total, "parallelism": "slab%d" % world if world > 1 else "single",
                        "mean_neibs": round(nbar, 2)},
-            "roofline": {"bound": "hbm", "kernel": "forces_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launch_ms": round(avg_ms, 4), "bytes_per_launch": int(bytes_per_launch)},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -104,3 +104,19 @@ def test_deltap_for_targets():
         dp = DamBreak3D.deltap_for(target)
         c = DamBreak3D.count(dp)
         assert c <= target and c > 0.95 * target
+
+
+def test_sphx_params_size_matches_the_c_struct(tmp_path):
+    """ctypes image and the C struct must have the same size and tail offset (gcc is the arbiter)."""
+    import subprocess, ctypes as C
+    from gpusph_amd.params import SphxParams
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "sz.c"
+    last = SphxParams._fields_[-1][0]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sphx.h"\n'
+                   'int main(){printf("%%zu %%zu", sizeof(sphx_params), offsetof(sphx_params, %s));return 0;}\n' % last)
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)])
+    size, off = map(int, subprocess.check_output([str(exe)]).split())
+    assert size == C.sizeof(SphxParams)
+    assert off == getattr(SphxParams, last).offset

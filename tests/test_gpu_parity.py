@@ -302,3 +302,120 @@ def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path):
         got = np.concatenate([p[k] for p in parts])[order]
         assert np.array_equal(got.view(np.uint32), _np(t)[:n][ro].view(np.uint32)), k
     assert all(float(p["dt"]) == ref.current_dt() for p in parts)
+
+
+# ---------------------------------------------------------------------------------------------
+# C++ adapters (gpusph_amd/host/sphx_host.h): the binding INTEGRATION.md describes, driven by
+# gpusph_amd/host/example_engines through the reference's blocking-dtreduce command order, must give
+# bit-identical particles to the Python driver (same C-ABI calls, device-resident dt).
+class _DumpHeader(C.Structure):
+    from gpusph_amd.params import SphxParams as _SP
+    _fields_ = [("magic", C.c_char * 8), ("n", C.c_uint32), ("alloc", C.c_uint32), ("steps", C.c_uint32),
+                ("num_rb_particles", C.c_uint32), ("dt", C.c_float), ("sspeed_cfl", C.c_float),
+                ("nlSq", C.c_float), ("numforcesbodies", C.c_int32), ("rb_cgGridPos", C.c_int32 * 3),
+                ("rb_cgPos", C.c_float * 3), ("rb_firstindex", C.c_int32), ("params", _SP)]
+
+
+def test_cpp_adapters_match_python_engine(tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "gpusph_amd", "host", "example_engines")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
+    steps = 12   # spans one re-sort (buildneibsfreq = 10)
+    prob = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.05, hydrostatic=False)
+    eng = _engine(prob)
+    arrs = prob.copy_to_array()
+    n = len(arrs["hash"])
+    h = _DumpHeader()
+    h.magic = b"SPHXDMP1"
+    h.n = n; h.alloc = n; h.steps = steps; h.num_rb_particles = prob.num_obstacle
+    h.dt = eng.dt; h.sspeed_cfl = eng.sspeed_cfl; h.nlSq = eng.sq_nl_radius
+    h.numforcesbodies = prob.simparams.numforcesbodies
+    if prob.num_obstacle:
+        h.rb_cgGridPos[:] = [int(v) for v in prob.rb_cg_gridpos[0]]
+        h.rb_cgPos[:] = [float(v) for v in prob.rb_cg_pos[0]]
+        h.rb_firstindex = int(prob.rb_firstindex[0])
+    h.params = eng.params
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(bytes(h))
+        f.write(np.ascontiguousarray(arrs["pos"], dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(arrs["vel"], dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(arrs["info"]).view(np.uint16).tobytes())
+        f.write(np.ascontiguousarray(arrs["hash"]).view(np.uint32).tobytes())
+    r = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    eng.run(steps)
+    ref = eng.download()
+    raw = open(fout, "rb").read()
+    n2 = int(np.frombuffer(raw, np.uint32, 1, 0)[0]); dt2 = np.frombuffer(raw, np.float32, 1, 4)[0]
+    assert n2 == eng.n
+    o = 8
+    pos = np.frombuffer(raw, np.float32, 4 * n2, o).reshape(n2, 4); o += 16 * n2
+    vel = np.frombuffer(raw, np.float32, 4 * n2, o).reshape(n2, 4); o += 16 * n2
+    info = np.frombuffer(raw, np.uint16, 4 * n2, o).reshape(n2, 4); o += 8 * n2
+    hsh = np.frombuffer(raw, np.uint32, n2, o)
+    assert np.float32(eng.current_dt()) == dt2
+    assert np.array_equal(info, ref["info"].reshape(n2, 4)) and np.array_equal(hsh, ref["hash"])
+    assert np.array_equal(pos.view(np.uint32), ref["pos"].view(np.uint32))
+    assert np.array_equal(vel.view(np.uint32), ref["vel"].view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------
+# SPS turbulence: sphx_calc_visc (SPSstressMatrix, src/cuda/visc_kernel.cu:759-811) and the SPS term of the
+# forces kernel (generic gather path) against the oracle.  fp32 tolerance 2e-5 of the largest entry.
+def test_sps_stress_and_forces_tolerance():
+    import torch
+    from gpusph_amd import capi
+    prob = DamBreak3D(deltap=0.04, obstacle=False, jitter=0.1, hydrostatic=False)
+    prob.simparams.turbmodel = D.SPS
+    dp = prob.m_deltap
+    prob.physparams.smagfactor = float(np.float32((0.12 * dp) ** 2))              # src/GPUSPH.cc Smagorinsky set-up
+    prob.physparams.kspsfactor = float(np.float32((2.0 / 3.0) * 0.0066 * dp * dp))
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    rng = np.random.default_rng(11)
+    vel = sim.vel.copy()
+    fluid = (sim.info[:, 0] & 7) == 0
+    vel[fluid, :3] += rng.uniform(-0.5, 0.5, size=(fluid.sum(), 3)).astype(np.float32)
+    vel[:, 3] += rng.uniform(0, 2e-3, size=len(vel)).astype(np.float32)
+    sim.vel = vel
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    tau_ref, tv_ref = sim.o.sps(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n, n)
+    A = eng.alloc
+    tau = [torch.zeros((A, 2), dtype=torch.float32, device=eng.device) for _ in range(3)]
+    tv = torch.zeros(A, dtype=torch.float32, device=eng.device)
+    p = capi.ptr
+    capi.check(eng.lib.sphx_calc_visc(eng.ctx.handle, p(tau[0]), p(tau[1]), p(tau[2]), p(tv), p(eng.pos), p(eng.vel),
+                                      p(eng.info), p(eng.hash), p(eng.cellStart), p(eng.neibslist), n, n,
+                                      eng.params.deltap, eng.params.slength, eng.params.influenceradius, eng._stream()))
+    tau_gpu = np.concatenate([_np(t)[:n] for t in tau], axis=1)
+    scale = np.abs(tau_ref[:n]).max()
+    assert scale > 0
+    assert np.abs(tau_gpu - tau_ref[:n]).max() <= 2e-5 * scale
+    assert np.abs(_np(tv)[:n] - tv_ref[:n]).max() <= 2e-5 * np.abs(tv_ref[:n]).max()
+    # forces with the SPS divergence term, fed with the ORACLE's tau on both sides
+    f_ref, cfl_ref, nb, _, _ = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n, tau=tau_ref)
+    for k in range(3):
+        tau[k][:n] = torch.from_numpy(np.ascontiguousarray(tau_ref[:n, 2 * k:2 * k + 2])).to(eng.device)
+    nbl = C.c_uint32(0)
+    eng._memset(eng.cfl, 0, eng._stream())
+    capi.check(eng.lib.sphx_forces_basicstep(eng.ctx.handle, p(eng.forces), p(eng.cfl), None, None, p(eng.pos), p(eng.vel),
+                                             p(eng.info), p(eng.hash), p(eng.cellStart), p(eng.neibslist),
+                                             p(tau[0]), p(tau[1]), p(tau[2]), n, 0, n, eng.params.deltap,
+                                             eng.params.slength, eng.params.dtadaptfactor, eng.params.influenceradius,
+                                             0, D.SIMULATE, 1, eng.dt, 0, C.byref(nbl), eng._stream()))
+    f = _np(eng.forces)[:n]
+    fs = np.abs(f_ref[:, :3]).max()
+    assert np.abs(f[:, :3] - f_ref[:n, :3]).max() <= 2e-5 * fs
+    assert np.abs(f[:, 3] - f_ref[:n, 3]).max() <= 2e-5 * np.abs(f_ref[:, 3]).max() + 1e-7
+    # without tau the call must be refused, not silently computed without the term
+    with pytest.raises((capi.SphxError, capi.SphxInvalidArgument)):
+        capi.check(eng.lib.sphx_forces_basicstep(eng.ctx.handle, p(eng.forces), p(eng.cfl), None, None, p(eng.pos),
+                                                 p(eng.vel), p(eng.info), p(eng.hash), p(eng.cellStart), p(eng.neibslist),
+                                                 None, None, None, n, 0, n, eng.params.deltap, eng.params.slength,
+                                                 eng.params.dtadaptfactor, eng.params.influenceradius, 0, D.SIMULATE, 1,
+                                                 eng.dt, 0, C.byref(nbl), eng._stream()))
