@@ -376,51 +376,75 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 // list entries of one section, TILE_AHEAD batches deep: buffer q[j] holds batch j (mod TILE_AHEAD)
 struct ListWindow { uint32_t q[TILE_AHEAD][TILE_NB]; };
 
-__device__ __forceinline__ void preload_list(const DevParams &p, const neibdata *__restrict__ list, uint32_t index, int sec, ListWindow &lw)
+__device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+
+// One batch (TILE_NB entries) of list entries of section `sec` (0 = fluid slots 0 upward, 1 = boundary slots
+// neibboundpos downward).  The pair loop is wave-uniform, so the batch number is a scalar and the four rows
+// of a batch are addressed as buffer loads: SGPR descriptor (row base) + SGPR row offset + the per-lane byte
+// offset index*2, which is fixed for the whole tile -- no vector address arithmetic at all.
+// Needs neiblistsize % TILE_NB == 0 and (neibboundpos+1) % TILE_NB == 0 (checked by the host, else generic path).
+struct ListRows { const neibdata *list; uint32_t rowBytes; };
+
+__device__ __forceinline__ void load_list_u(const DevParams &p, const ListRows &lr,
+	uint32_t voff, int sec, int batch, uint32_t nd[TILE_NB])
+{
+	const int b = __builtin_amdgcn_readfirstlane(batch);
+	const int maxb = sec ? ((int)p.neibboundpos + 1)/TILE_NB - 1 : (int)p.neiblistsize/TILE_NB - 1;
+	if (b > maxb) {   // past the section's last possible slot: terminate lists that have no terminator
+#pragma unroll
+		for (int k = 0; k < TILE_NB; ++k) nd[k] = NEIBS_END;
+		return;
+	}
+	const int lowSlot = sec ? (int)p.neibboundpos - (b*TILE_NB + TILE_NB - 1) : b*TILE_NB;
+	const neibdata *row = lr.list + (size_t)lowSlot*p.stride;
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<neibdata*>(row), 0, 0xFFFFFFFF, 0x00020000);
+#pragma unroll
+	for (int k = 0; k < TILE_NB; ++k) {
+		const int up = sec ? TILE_NB - 1 - k : k;     // rows above lowSlot
+		nd[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)voff, (int)(up*lr.rowBytes), 0);
+	}
+}
+
+__device__ __forceinline__ void preload_list(const DevParams &p, const ListRows &lr, uint32_t voff, int sec, ListWindow &lw)
 {
 #pragma unroll
 	for (int j = 0; j < TILE_AHEAD; ++j)
-		load_list_rt(p, list, index, sec, j, lw.q[j]);
+		load_list_u(p, lr, voff, sec, j, lw.q[j]);
 }
 
-struct WalkState { float pcx, pcy, pcz; uint32_t cbase; bool alive; };
-struct CodeMap { int mx, my, mz, c0; };   // neighbour-cell offset -> window-table offset (uniform)
+struct WalkState { uint32_t code; bool alive; };
 
 #define TILE_HB 2   // pairs per pipeline stage ("half batch")
 struct Gathered {
 	float4 npos[TILE_HB], nvel[TILE_HB], naux[TILE_HB];
 	float qx[TILE_HB], qy[TILE_HB], qz[TILE_HB];
 	bool valid[TILE_HB];
-	bool last;     // the terminator was seen in (or before) this half
 };
 
-// stage 1 of the pair pipeline: decode TILE_HB list entries and issue the LDS reads of their rows
-__device__ __forceinline__ void gather_half(const DevParams &p, const uint32_t *nd, const Self &s, int myOff,
-	const CodeMap &cm, const float4 *sPos, const float4 *sVel, const float4 *sAux, const uint32_t *sCellBase,
+// stage 1 of the pair pipeline: decode TILE_HB list entries and issue the LDS reads of their rows.
+// Branch-free: the walk state is the current CELL CODE (updated with one select when an entry carries a
+// code); every entry looks it up in two small LDS tables -- sShift[code] = own-position shift into that
+// neighbour cell's frame (d_cell_to_offset order, src/cuda/forces.cu:376-386: code-1 = (x+1) + 3(y+1) + 9(z+1)),
+// myCB[code] = LDS slot of that cell's first particle as seen from this particle's cell.  No divergent
+// branch means a whole ring step is one basic block, so the scheduler can overlap these LDS round trips
+// with the arithmetic of the previous pairs.
+__device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
+	const float4 *sShift, const uint16_t *myCB, const float4 *sPos, const float4 *sVel, const float4 *sAux,
 	WalkState &w, Gathered &g)
 {
 #pragma unroll
 	for (int k = 0; k < TILE_HB; ++k) {
 		const uint32_t d = nd[k];
 		w.alive = w.alive && (d != NEIBS_END);
+		w.code = (d >= CELLNUM_ENCODED) ? (d >> CELLNUM_SHIFT) : w.code;   // 1..27 = cell code, 31 = terminator
+		const float4 sh = sShift[w.code];
+		const uint32_t cb = myCB[w.code];
 		g.valid[k] = w.alive;
-		if (w.alive && d >= CELLNUM_ENCODED) {
-			// d_cell_to_offset order (src/cuda/forces.cu:376-386): code = (x+1) + 3(y+1) + 9(z+1)
-			const int c = (int)(d >> CELLNUM_SHIFT) - 1;
-			const int cz = (c*57) >> 9;            // c/9 for 0 <= c < 27
-			const int r9 = c - cz*9;
-			const int cy = (r9*11) >> 5;           // r9/3 for 0 <= r9 < 9
-			const int ox = r9 - cy*3 - 1, oy = cy - 1, oz = cz - 1;
-			w.pcx = fmaf(-(float)ox, p.cs[0], s.pos.x);
-			w.pcy = fmaf(-(float)oy, p.cs[1], s.pos.y);
-			w.pcz = fmaf(-(float)oz, p.cs[2], s.pos.z);
-			w.cbase = sCellBase[ox*cm.mx + oy*cm.my + oz*cm.mz + cm.c0 + myOff];
-		}
-		g.qx[k] = w.pcx; g.qy[k] = w.pcy; g.qz[k] = w.pcz;
-		const uint32_t L = w.alive ? w.cbase + (d & NEIBINDEX_MASK) : 0u;
+		// == fmaf(-ox, cellsize, pos): ox in {-1,0,1}, so the product is exact
+		g.qx[k] = s.pos.x + sh.x; g.qy[k] = s.pos.y + sh.y; g.qz[k] = s.pos.z + sh.z;
+		const uint32_t L = w.alive ? cb + (d & NEIBINDEX_MASK) : 0u;
 		g.npos[k] = sPos[L]; g.nvel[k] = sVel[L]; g.naux[k] = sAux[L];
 	}
-	g.last = !w.alive;
 }
 
 // stage 2: the pair interactions of a gathered half, in list order
@@ -434,7 +458,11 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 			g.npos[k], g.nvel[k], g.naux[k], true, g.valid[k], nullptr, force, momentum, diffuse);
 }
 
-// Walk one section of a particle's neighbour list against the LDS window.
+// Walk one section of the neighbour lists of a whole wave against the LDS window.
+//  * WAVE-UNIFORM control: the loop runs until no lane of the wave has entries left (lanes past their
+//    terminator contribute pairs of weight 0, pair_interact is branch-free).  Lanes that finish early would
+//    idle in SIMD execution anyway; uniform control removes the exec-mask bookkeeping and makes batch
+//    numbers and list row addresses scalar;
 //  * list entries (HBM, 2 B per pair: the dominant algorithmic traffic) are fetched TILE_AHEAD-1
 //    batches ahead into a ring of register buffers, rotated by unrolling, not by copying (a copy of
 //    an in-flight load would wait for it);
@@ -443,26 +471,27 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 //  * section, momentum and diffusion switches are run-time values so that the pair code exists
 //    once in the kernel (the instruction cache is 64 KB; four template copies did not fit).
 template<int KERNEL, int TURB, bool COLAGROSSI>
-__device__ __forceinline__ void walk_section_lds(const DevParams &p, const neibdata *__restrict__ list,
-	uint32_t index, const Self &s, float inv_h, int myOff, const CodeMap &cm,
-	const float4 *sPos, const float4 *sVel, const float4 *sAux, const uint32_t *sCellBase,
-	int sec, bool momentum, bool diffuse,
+__device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListRows &list,
+	uint32_t voff, const Self &s, float inv_h, const float4 *sShift, const uint16_t *myCB,
+	const float4 *sPos, const float4 *sVel, const float4 *sAux,
+	int sec, bool take, bool momentum, bool diffuse,
 	ListWindow &lw /* batches 0..TILE_AHEAD-1 preloaded */, float4 &force)
 {
 	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
-	WalkState w; w.pcx = w.pcy = w.pcz = 0.0f; w.cbase = 0; w.alive = true;
-	int next = TILE_AHEAD;   // index of the next batch to fetch
+	WalkState w; w.code = 0; w.alive = take;
+	int next = TILE_AHEAD;   // index of the next batch to fetch (scalar)
 	Gathered A, B;
-	gather_half(p, lw.q[0], s, myOff, cm, sPos, sVel, sAux, sCellBase, w, A);
+	gather_half(lw.q[0], s, sShift, myCB, sPos, sVel, sAux, w, A);
+	if (!wave_any(A.valid[0])) return;
 #define SPHX_RING_STEP(J, JN) \
-	gather_half(p, lw.q[J] + TILE_HB, s, myOff, cm, sPos, sVel, sAux, sCellBase, w, B); \
+	gather_half(lw.q[J] + TILE_HB, s, sShift, myCB, sPos, sVel, sAux, w, B); \
 	compute_half<KERNEL, TURB, COLAGROSSI>(p, A, s, inv_h, momentum, diffuse, force); \
-	if (A.last) return; \
-	load_list_rt(p, list, index, sec, next, lw.q[J]); \
+	if (!wave_any(B.valid[0])) return; \
+	load_list_u(p, list, voff, sec, next, lw.q[J]); \
 	++next; \
-	gather_half(p, lw.q[JN], s, myOff, cm, sPos, sVel, sAux, sCellBase, w, A); \
+	gather_half(lw.q[JN], s, sShift, myCB, sPos, sVel, sAux, w, A); \
 	compute_half<KERNEL, TURB, COLAGROSSI>(p, B, s, inv_h, momentum, diffuse, force); \
-	if (B.last) return;
+	if (!wave_any(A.valid[0])) return;
 	for (;;) {
 		SPHX_RING_STEP(0, 1)
 		SPHX_RING_STEP(1, 2)
@@ -485,6 +514,9 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	__shared__ uint32_t sStart[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sRowStart[TILE_WROWS], sRowTotal[TILE_WROWS], sRowContig[TILE_WROWS];
 	__shared__ float sWaveMax[TILE_THREADS/64];
+	__shared__ __attribute__((aligned(16))) float4 sShift[32];   // cell code -> own-position shift (x,y,z)
+	__shared__ int sCodeOff[32];                                   // cell code-1 -> window-table offset
+	__shared__ uint16_t sCB[TILE_HROWS*TILE_MAXCELLS*27 + 8];      // [home cell][code] -> LDS slot of the cell's first record
 
 	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this launch
 	const uint32_t numTiles = tileCtl[0];
@@ -503,13 +535,20 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 
 	// neighbour-cell offset (ox,oy,oz) -> index of that cell in the window table, relative to the
 	// particle's own (row, column): o1 + KW*(o2+1) + 4*KW*(o3+1) + 1 with (o1,o2,o3) the offsets along COORD1..3
-	CodeMap cm;
-	cm.mx = (p.c1 == 0) ? 1 : (p.c2 == 0) ? TILE_KW : 4*TILE_KW;
-	cm.my = (p.c1 == 1) ? 1 : (p.c2 == 1) ? TILE_KW : 4*TILE_KW;
-	cm.mz = (p.c1 == 2) ? 1 : (p.c2 == 2) ? TILE_KW : 4*TILE_KW;
-	cm.c0 = 1 + TILE_KW + 4*TILE_KW;
+	if (tid < 32) {   // published by the first barrier of the tile loop
+		const int c = (int)tid - 1;                // d_cell_to_offset order: c = (x+1) + 3(y+1) + 9(z+1)
+		const bool real = c >= 0 && c < 27;
+		const int cz = c/9, cy = (c - cz*9)/3;
+		const int ox = real ? c - cz*9 - cy*3 - 1 : 0, oy = real ? cy - 1 : 0, oz = real ? cz - 1 : 0;
+		const int mx = (p.c1 == 0) ? 1 : (p.c2 == 0) ? TILE_KW : 4*TILE_KW;
+		const int my = (p.c1 == 1) ? 1 : (p.c2 == 1) ? TILE_KW : 4*TILE_KW;
+		const int mz = (p.c1 == 2) ? 1 : (p.c2 == 2) ? TILE_KW : 4*TILE_KW;
+		sShift[tid] = make_float4(-(float)ox*p.cs[0], -(float)oy*p.cs[1], -(float)oz*p.cs[2], 0.0f);
+		if (real) sCodeOff[c] = ox*mx + oy*my + oz*mz + 1 + TILE_KW + 4*TILE_KW;
+	}
 	const float inv_h = fast_rcp(p.slength);
 	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
+	ListRows listRows; listRows.list = a.neibsList; listRows.rowBytes = (uint32_t)(p.stride*sizeof(neibdata));
 	const int wr = (int)(tid/TILE_KW), wcol = (int)(tid - (tid/TILE_KW)*TILE_KW);   // my window cell (tid < 256)
 
 	// software pipeline over tiles: the descriptor and the window-cell extents of the NEXT tile are
@@ -550,9 +589,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		const float4 pos = a.pos[li];
 		ListWindow lwF, lwB;
 		Self s;
+		const uint32_t voff = li*2u;   // byte offset of this particle inside every list row (n < 2^31)
 		if (inRange) {
-			preload_list(p, a.neibsList, li, 0, lwF);
-			preload_list(p, a.neibsList, li, 1, lwB);
+			preload_list(p, listRows, voff, 0, lwF);
+			preload_list(p, listRows, voff, 1, lwB);
 			load_self<TURB>(p, a, li, info, pos, false, s);
 		}
 
@@ -614,30 +654,35 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			window_cell(p, a.cellStart, cellEnd, (int)dn[0], (int)dn[1], (int)dn[2], (int)dn[3], wr, wcol, nStart, nCnt);
 		__syncthreads();   // waits for the LDS-DMA (vmcnt(0)) and publishes the tables
 
-		// 3. pair loop for the tile's own particles (<= 512, one per thread)
+		// 3. pair loop for the tile's own particles (<= 512, one per thread); wave-uniform control
 		float cfl_term = 0.0f;
-		if (mine && is_active_w(pos.w)) {
+		const bool active = mine && is_active_w(pos.w);
+		float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (inRange && pairs) {
+			// per-home-cell code table: slot of the first record of each of the 27 neighbour cells
+			for (uint32_t e = tid; e < TILE_HROWS*TILE_MAXCELLS*27; e += TILE_THREADS) {
+				const uint32_t m = e/27u, c1 = e - m*27u;
+				const uint32_t hr = m/TILE_MAXCELLS, col = m - hr*TILE_MAXCELLS;
+				sCB[e + 1] = (uint16_t)sCellBase[sCodeOff[c1] + (int)(((hr & 1u) + 4u*(hr >> 1))*TILE_KW + col)];
+			}
+			__syncthreads();
 			const uint32_t ptype = PART_TYPE(info);
 			const int myG1 = (p.c1 == 0) ? s.gridPos.x : (p.c1 == 1) ? s.gridPos.y : s.gridPos.z;
-			const int myOff = ((hrow & 1) + 4*(hrow >> 1))*TILE_KW + (myG1 - ca);
-			float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
+			const uint16_t *myCB = sCB + (hrow*TILE_MAXCELLS + myCol)*27;
 			const bool isFluid = ptype == PT_FLUID, isDynBound = ptype == PT_BOUNDARY && dyn;
-			if (pairs && (isFluid || isDynBound)) {
-				// fluid: fluid section then (DYN) boundary section; DYN boundary: fluid section only, with the
-				// momentum part only for bodies with force feedback (forces_kernel.def:3650-3679)
-				const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
-				const int nsec = (isFluid && dyn) ? 2 : 1;
-				for (int sec = 0; sec < nsec; ++sec) {
-					walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, a.neibsList, index, s, inv_h, myOff, cm,
-						sPos, sVel, sAux, sCellBase, sec, momentum, sec == 0, lwF, force);
-#pragma unroll
-					for (int j = 0; j < TILE_AHEAD; ++j)
-#pragma unroll
-						for (int k = 0; k < TILE_NB; ++k) lwF.q[j][k] = lwB.q[j][k];
-				}
-			}
-			cfl_term = finalize_particle(p, a, index, info, s, force);
+			// fluid: fluid section then (DYN) boundary section; DYN boundary: fluid section only, with the
+			// momentum part only for bodies with force feedback (forces_kernel.def:3650-3679)
+			const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
+			const bool take0 = active && (isFluid || isDynBound), take1 = active && isFluid && dyn;
+			walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
+				sPos, sVel, sAux, 0, take0, momentum, true, lwF, force);
+			if (wave_any(take1))
+				walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
+					sPos, sVel, sAux, 1, take1, momentum, false, lwB, force);
 		}
+		if (active)
+			cfl_term = finalize_particle(p, a, index, info, s, force);
 		// 4. CFL: the array keeps the reference's one-entry-per-128-particles layout
 		// (getFmaxElements); tiles are not 128-aligned, so they max into the entry of their first
 		// particle.  Non-negative floats order like their bit patterns; the caller zeroed CFL.
@@ -948,7 +993,9 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
-		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && !ctx->disable_tiles;
+		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && !ctx->disable_tiles &&
+		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
+		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
 	int rc;
 	switch (ctx->dev.kerneltype) {
 	case SPHX_CUBICSPLINE: rc = launch_forces_k<SPHX_CUBICSPLINE>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
