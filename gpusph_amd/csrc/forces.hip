@@ -32,6 +32,7 @@ struct ForcesArgs {
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
 	int compute_object_forces;
+	unsigned long long *prof;   // SPHX_TILE_DEBUG & 16: per-workgroup phase times (100 MHz ticks), else NULL
 	int dbg;   // SPHX_TILE_DEBUG: 1 = skip pair loops, 2 = skip window staging (timing experiments only)
 };
 
@@ -385,12 +386,13 @@ __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballo
 // Needs neiblistsize % TILE_NB == 0 and (neibboundpos+1) % TILE_NB == 0 (checked by the host, else generic path).
 struct ListRows { const neibdata *list; uint32_t rowBytes; };
 
+template<bool CHECKED>
 __device__ __forceinline__ void load_list_u(const DevParams &p, const ListRows &lr,
 	uint32_t voff, int sec, int batch, uint32_t nd[TILE_NB])
 {
 	const int b = __builtin_amdgcn_readfirstlane(batch);
 	const int maxb = sec ? ((int)p.neibboundpos + 1)/TILE_NB - 1 : (int)p.neiblistsize/TILE_NB - 1;
-	if (b > maxb) {   // past the section's last possible slot: terminate lists that have no terminator
+	if (CHECKED && b > maxb) {   // past the section's last possible slot: terminate lists that have no terminator
 #pragma unroll
 		for (int k = 0; k < TILE_NB; ++k) nd[k] = NEIBS_END;
 		return;
@@ -409,7 +411,7 @@ __device__ __forceinline__ void preload_list(const DevParams &p, const ListRows 
 {
 #pragma unroll
 	for (int j = 0; j < TILE_AHEAD; ++j)
-		load_list_u(p, lr, voff, sec, j, lw.q[j]);
+		load_list_u<false>(p, lr, voff, sec, j, lw.q[j]);   // batches 0..TILE_AHEAD-1 always exist (host check)
 }
 
 struct WalkState { uint32_t code; bool alive; };
@@ -487,7 +489,7 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	gather_half(lw.q[J] + TILE_HB, s, sShift, myCB, sPos, sVel, sAux, w, B); \
 	compute_half<KERNEL, TURB, COLAGROSSI>(p, A, s, inv_h, momentum, diffuse, force); \
 	if (!wave_any(B.valid[0])) return; \
-	load_list_u(p, list, voff, sec, next, lw.q[J]); \
+	load_list_u<true>(p, list, voff, sec, next, lw.q[J]); \
 	++next; \
 	gather_half(lw.q[JN], s, sShift, myCB, sPos, sVel, sAux, w, A); \
 	compute_half<KERNEL, TURB, COLAGROSSI>(p, B, s, inv_h, momentum, diffuse, force); \
@@ -560,7 +562,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	if (tid < TILE_WROWS*TILE_KW)
 		window_cell(p, a.cellStart, cellEnd, (int)dc[0], (int)dc[1], (int)dc[2], (int)dc[3], wr, wcol, wStart, wCnt);
 
+	__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): first descriptor and window extents
+	const bool prof = a.prof != nullptr && tid == 0;
+	unsigned long long tBegin = 0, t0 = 0, tA = 0, tB = 0, accStage = 0, accPairs = 0, accTail = 0, s1 = 0, s2 = 0, s3 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+	if (prof) tBegin = wall_clock64();
 	for (;;) {
+		if (prof) t0 = wall_clock64();
 		const uint32_t nextTile = tile + tileStride;
 		const bool haveNext = nextTile < tileEnd;
 		if (haveNext) {
@@ -587,16 +594,18 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		const uint32_t li = mine ? index : (firstMin != 0xFFFFFFFFu ? firstMin : 0u);   // idle lanes read a valid row
 		const particleinfo info = a.info[li];
 		const float4 pos = a.pos[li];
+		// vmcnt is in-order: waiting for ANY of these loads before the window barrier would wait for all of them
+		// (an HBM round trip) ahead of the DMA issue, so nothing below is consumed until the window has landed
+		const float4 rawVel = a.vel[li];
+		const uint32_t rawHash = a.hash[li];
+		const float4 rawAux = a.aux[li];
 		ListWindow lwF, lwB;
-		Self s;
 		const uint32_t voff = li*2u;   // byte offset of this particle inside every list row (n < 2^31)
-		if (inRange) {
-			preload_list(p, listRows, voff, 0, lwF);
-			preload_list(p, listRows, voff, 1, lwB);
-			load_self<TURB>(p, a, li, info, pos, false, s);
-		}
+		preload_list(p, listRows, voff, 0, lwF);
+		preload_list(p, listRows, voff, 1, lwB);
 
 		__syncthreads();   // the previous tile's readers are done with LDS
+		if (prof) { s1 = wall_clock64(); s2 = s1; s3 = s1; }
 
 		if (inRange && pairs) {
 			// 1. prefix of the window-cell counts within each row (16-lane segmented scans), row extents
@@ -623,24 +632,35 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				}
 			}
 			__syncthreads();
-			// 2. row bases (16-entry prefix, computed redundantly by every thread) and the window DMA
-			uint32_t myRowBase = 0, run = 0;
+			if (prof) { s2 = wall_clock64(); s3 = s2; }
+			// 2. row bases: every wave scans the 16 row totals in its first 16 lanes; then the window DMA, with
+			//    the rows dealt out to the waves (wave w stages rows w, w+8, ...: a row is ~3 chunks of 64 records
+			//    per array, so walking all rows in every wave left most waves idle behind a serial 16-step loop)
+			const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+			const uint32_t rowTot = (lane < TILE_WROWS) ? sRowTotal[lane] : 0u;
+			uint32_t rowIncl = rowTot;
+#pragma unroll
+			for (int dd = 1; dd < TILE_WROWS; dd <<= 1) {
+				const uint32_t t = __shfl_up(rowIncl, dd, 64);
+				if ((int)lane >= dd) rowIncl += t;
+			}
+			const uint32_t rowBase = rowIncl - rowTot;
+			const uint32_t myRowBase = __shfl(rowBase, wr, 64);
+			static_assert(TILE_WROWS <= 64, "row totals are scanned inside one wave");
 #pragma unroll 1
-			for (int r = 0; r < TILE_WROWS; ++r) {
-				const uint32_t total = sRowTotal[r];
-				const uint32_t base = __builtin_amdgcn_readfirstlane(run);
-				if (r == wr) myRowBase = base;
-				run += total;
-				if (base + total > TILE_WCAP || (a.dbg & 3) == 2) continue;   // cannot overflow for tiles of build_tiles_kernel
+			for (uint32_t r = wave; r < TILE_WROWS; r += TILE_THREADS/64) {
+				const uint32_t total = __builtin_amdgcn_readlane(rowTot, r);
+				const uint32_t base = __builtin_amdgcn_readlane(rowBase, r);
+				if (base + total > TILE_WCAP || (a.dbg & 3) == 2 || !total) continue;   // cannot overflow for tiles of build_tiles_kernel
 				if (sRowContig[r]) {
 					const uint32_t rs = __builtin_amdgcn_readfirstlane(sRowStart[r]);
-					stage_rows<TILE_THREADS>(a.pos + rs, sPos + base, total, tid);
-					stage_rows<TILE_THREADS>(a.vel + rs, sVel + base, total, tid);
-					stage_rows<TILE_THREADS>(a.aux + rs, sAux + base, total, tid);
+					stage_row_wave(a.pos + rs, sPos + base, total, lane);
+					stage_row_wave(a.vel + rs, sVel + base, total, lane);
+					stage_row_wave(a.aux + rs, sAux + base, total, lane);
 				} else {   // a row crossing cell-type segments (multi-GPU device maps not split on COORD3)
 					for (int col = 0; col < ncells + 2; ++col) {
 						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = base + sCellBase[r*TILE_KW + col];
-						for (uint32_t q = tid; q < cnt; q += TILE_THREADS) {
+						for (uint32_t q = lane; q < cnt; q += 64u) {
 							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q]; sAux[cb + q] = a.aux[st + q];
 						}
 					}
@@ -648,11 +668,22 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			}
 			if (tid < TILE_WROWS*TILE_KW) sCellBase[tid] += myRowBase;   // make absolute (own entry)
 		}
-		// prefetch the next tile's window-cell extents
-		uint32_t nStart = 0, nCnt = 0;
-		if (haveNext && tid < TILE_WROWS*TILE_KW)
-			window_cell(p, a.cellStart, cellEnd, (int)dn[0], (int)dn[1], (int)dn[2], (int)dn[3], wr, wcol, nStart, nCnt);
-		__syncthreads();   // waits for the LDS-DMA (vmcnt(0)) and publishes the tables
+		if (prof) s3 = wall_clock64();
+		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA (and its own rows, list batches) have landed
+		__syncthreads();                      // ... everybody's have; the tables are published
+		if (prof) tA = wall_clock64();
+		// prefetch the next tile's window-cell extents (two independent loads, consumed at the end of the iteration)
+		uint32_t nCS = CELL_EMPTY, nCE = 0;
+		if (haveNext && tid < TILE_WROWS*TILE_KW) {
+			const uint32_t h = window_cell_hash(p, (int)dn[0], (int)dn[1], (int)dn[2], (int)dn[3], wr, wcol);
+			if (h != 0xFFFFFFFFu) { nCS = a.cellStart[h]; nCE = cellEnd[h]; }
+		}
+		Self s;
+		s.pos = pos; s.vel = rawVel;
+		s.gridPos = grid_pos_from_hash(p, rawHash & CELLTYPE_BITMASK);
+		s.fl = 0u;
+		s.p_precalc = rawAux.x; s.sspeed = rawAux.y; s.P = rawAux.z; s.rho = rawAux.w;
+		s.inv_rho = fast_rcp(rawAux.w);
 
 		// 3. pair loop for the tile's own particles (<= 512, one per thread); wave-uniform control
 		float cfl_term = 0.0f;
@@ -681,6 +712,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
 					sPos, sVel, sAux, 1, take1, momentum, false, lwB, force);
 		}
+		if (prof) tB = wall_clock64();
 		if (active)
 			cfl_term = finalize_particle(p, a, index, info, s, force);
 		// 4. CFL: the array keeps the reference's one-entry-per-128-particles layout
@@ -699,11 +731,18 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				atomicMax(reinterpret_cast<unsigned int*>(a.cfl + a.cflOffset + rel/SPHX_BLOCK_FORCES), __float_as_uint(m));
 			}
 		}
+		if (prof) { const unsigned long long tC = wall_clock64(); accStage += tA - t0; acc1 += s1 - t0; acc2 += s2 - s1; acc3 += s3 - s2; accPairs += tB - tA; accTail += tC - tB; }
 		if (!haveNext) break;
+		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): long complete; tells the compiler nothing is pending at the loop head
+		const uint32_t nStart = (nCS != CELL_EMPTY) ? nCS : 0u, nCnt = (nCS != CELL_EMPTY) ? nCE - nCS : 0u;
 		tile = nextTile;
 #pragma unroll
 		for (int k = 0; k < TILE_DESC; ++k) dc[k] = dn[k];
 		wStart = nStart; wCnt = nCnt;
+	}
+	if (prof) {
+		unsigned long long *o = a.prof + 8*(size_t)blockIdx.x;
+		o[0] = wall_clock64() - tBegin; o[1] = accStage; o[2] = accPairs; o[3] = accTail; o[4] = acc1; o[5] = acc2; o[6] = acc3; o[7] = 0;
 	}
 }
 
@@ -990,11 +1029,18 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
 	a.compute_object_forces = compute_object_forces;
 	a.dbg = ctx->tile_debug;
+	a.prof = nullptr;
+	if (ctx->tile_debug & 16) {
+		if (!ctx->tile_prof && hipMalloc((void**)&ctx->tile_prof, 8*sizeof(unsigned long long)*ctx->tile_grid) != hipSuccess)
+			return sphx_set_error(SPHX_ERR_RUNTIME, "sphx_forces_basicstep: cannot allocate the tile profile buffer");
+		a.prof = ctx->tile_prof;
+	}
 
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && !ctx->disable_tiles &&
 		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
+		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
 		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
 	int rc;
 	switch (ctx->dev.kerneltype) {
@@ -1101,4 +1147,14 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	}
 	SPHX_LAUNCH_CHECK("sps_kernel");
 	return SPHX_OK;
+}
+
+// timing experiments only (SPHX_TILE_DEBUG & 16), not part of include/sphx.h: per-workgroup {total, stage, pairs, tail}
+// of the last tiled launch, in 100 MHz ticks
+extern "C" int sphx_dbg_tile_profile(sphx_ctx *ctx, unsigned long long *host, uint32_t maxGroups)
+{
+	if (!ctx || !ctx->tile_prof) return -1;
+	const uint32_t n = maxGroups < ctx->tile_grid ? maxGroups : ctx->tile_grid;
+	if (hipMemcpy(host, ctx->tile_prof, 8*sizeof(unsigned long long)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (int)n;
 }

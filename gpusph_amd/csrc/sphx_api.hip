@@ -35,7 +35,7 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	SPHX_HIP(hipMemset(ctx->tile_ctl, 0, 4*sizeof(uint32_t)));
 	int cus = 0;
 	SPHX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-	ctx->tile_grid = (uint32_t)(cus > 0 ? cus : 256);   // persistent grid: one 512-thread workgroup per CU (LDS bound)
+	ctx->tile_grid = (uint32_t)(cus > 0 ? cus : 256)*TILE_WGS_PER_CU;   // persistent grid: one 512-thread workgroup per CU (LDS bound)
 	const char *dis = getenv("SPHX_DISABLE_TILES");
 	ctx->disable_tiles = dis && dis[0] == '1';
 	const char *dbg = getenv("SPHX_TILE_DEBUG");
@@ -67,6 +67,7 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->counters_dev) (void)hipFree(ctx->counters_dev);
 	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
 	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
+	if (ctx->tile_prof) (void)hipFree(ctx->tile_prof);
 	delete ctx;
 }
 

@@ -30,12 +30,15 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #define SPHX_BLOCK_FORCES 128   // one CFL entry per 128 particles (getFmaxElements contract)
 
 // forces tiles (see forces.hip "Tiled path"): a tile is a k x 2 x 2 block of cells (k along COORD1)
+#ifndef TILE_THREADS
 #define TILE_THREADS  512                  // home particles per tile (one thread each), 8 waves
+#define TILE_WCAP     3200                 // window records that fit LDS (48 B each, 1 workgroup per CU)
+#define TILE_WGS_PER_CU 1                  // persistent workgroups per CU (LDS bound)
+#endif
 #define TILE_HROWS    4                    // home rows: 2 (COORD2) x 2 (COORD3)
 #define TILE_WROWS    16                   // window rows: 4 x 4
 #define TILE_MAXCELLS 14                   // cells per tile along COORD1
 #define TILE_KW       16                   // window columns (TILE_MAXCELLS + 2)
-#define TILE_WCAP     3200                 // window records that fit LDS (48 B each, 1 workgroup per CU)
 #define TILE_DESC     16                   // uint32 per tile: g2, g3, firstCell, numCells, first[4], count[4], window, flags, 0, 0
 #define TILE_NB       4                    // neighbours per batch in the tiled pair loop
 #define TILE_AHEAD    4                    // list batches kept in flight per section (register ring)
@@ -114,6 +117,7 @@ struct sphx_ctx {
 	bool        tiles_built;
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
 	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments)
+	unsigned long long *tile_prof;   // SPHX_TILE_DEBUG & 16
 	const void *tiles_cellstart, *tiles_neibslist;
 	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
 };
@@ -180,24 +184,31 @@ __device__ __forceinline__ uint32_t grid_hash_periodic(const DevParams &p, int g
 	return grid_hash(p, gx, gy, gz);
 }
 
-// window cell (row r of 16, column col) of a tile -> start/count of its particles
+// window cell (row r of 16, column col) of a tile -> its cell hash, or 0xFFFFFFFF outside the tile's window / the grid
+__device__ __forceinline__ uint32_t window_cell_hash(const DevParams &p, int g2, int g3, int ca, int ncells, int r, int col)
+{
+	if (col >= ncells + 2) return 0xFFFFFFFFu;
+	const int v0 = ca - 1 + col, v1 = g2 + (r & 3) - 1, v2 = g3 + (r >> 2) - 1;
+	int gx = (p.c1 == 0) ? v0 : (p.c2 == 0) ? v1 : v2;
+	int gy = (p.c1 == 1) ? v0 : (p.c2 == 1) ? v1 : v2;
+	int gz = (p.c1 == 2) ? v0 : (p.c2 == 2) ? v1 : v2;
+	if (gx < 0) { if (p.periodic & SPHX_PERIODIC_X) gx = p.gs[0] - 1; else return 0xFFFFFFFFu; }
+	else if (gx >= p.gs[0]) { if (p.periodic & SPHX_PERIODIC_X) gx = 0; else return 0xFFFFFFFFu; }
+	if (gy < 0) { if (p.periodic & SPHX_PERIODIC_Y) gy = p.gs[1] - 1; else return 0xFFFFFFFFu; }
+	else if (gy >= p.gs[1]) { if (p.periodic & SPHX_PERIODIC_Y) gy = 0; else return 0xFFFFFFFFu; }
+	if (gz < 0) { if (p.periodic & SPHX_PERIODIC_Z) gz = p.gs[2] - 1; else return 0xFFFFFFFFu; }
+	else if (gz >= p.gs[2]) { if (p.periodic & SPHX_PERIODIC_Z) gz = 0; else return 0xFFFFFFFFu; }
+	return grid_hash(p, gx, gy, gz);
+}
+
+// ... -> start/count of its particles
 __device__ __forceinline__ void window_cell(const DevParams &p, const uint32_t *__restrict__ cellStart,
 	const uint32_t *__restrict__ cellEnd, int g2, int g3, int ca, int ncells, int r, int col,
 	uint32_t &start, uint32_t &cnt)
 {
 	start = 0; cnt = 0;
-	if (col >= ncells + 2) return;
-	const int v0 = ca - 1 + col, v1 = g2 + (r & 3) - 1, v2 = g3 + (r >> 2) - 1;
-	int gx = (p.c1 == 0) ? v0 : (p.c2 == 0) ? v1 : v2;
-	int gy = (p.c1 == 1) ? v0 : (p.c2 == 1) ? v1 : v2;
-	int gz = (p.c1 == 2) ? v0 : (p.c2 == 2) ? v1 : v2;
-	if (gx < 0) { if (p.periodic & SPHX_PERIODIC_X) gx = p.gs[0] - 1; else return; }
-	else if (gx >= p.gs[0]) { if (p.periodic & SPHX_PERIODIC_X) gx = 0; else return; }
-	if (gy < 0) { if (p.periodic & SPHX_PERIODIC_Y) gy = p.gs[1] - 1; else return; }
-	else if (gy >= p.gs[1]) { if (p.periodic & SPHX_PERIODIC_Y) gy = 0; else return; }
-	if (gz < 0) { if (p.periodic & SPHX_PERIODIC_Z) gz = p.gs[2] - 1; else return; }
-	else if (gz >= p.gs[2]) { if (p.periodic & SPHX_PERIODIC_Z) gz = 0; else return; }
-	const uint32_t h = grid_hash(p, gx, gy, gz);
+	const uint32_t h = window_cell_hash(p, g2, g3, ca, ncells, r, col);
+	if (h == 0xFFFFFFFFu) return;
 	const uint32_t cs = cellStart[h];
 	if (cs != CELL_EMPTY) { start = cs; cnt = cellEnd[h] - cs; }
 }
@@ -217,6 +228,14 @@ __device__ __forceinline__ void stage_rows(const float4 *__restrict__ src, float
 		if (cu + lane < count)
 			__builtin_amdgcn_global_load_lds((gptr_t)(src + cu + lane), (lptr_t)(dst + cu), 16, 0, 0);
 	}
+}
+
+// one wave copies a whole row: 64-record chunks
+__device__ __forceinline__ void stage_row_wave(const float4 *__restrict__ src, float4 *dst, uint32_t count, uint32_t lane)
+{
+	for (uint32_t c0 = 0; c0 < count; c0 += 64u)
+		if (c0 + lane < count)
+			__builtin_amdgcn_global_load_lds((gptr_t)(src + c0 + lane), (lptr_t)(dst + c0), 16, 0, 0);
 }
 
 #endif // __HIPCC__
