@@ -32,6 +32,7 @@ struct ForcesArgs {
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
 	int compute_object_forces;
+	uint32_t *pin;              // always NULL (see pin_batch)
 	unsigned long long *prof;   // SPHX_TILE_DEBUG & 16: per-workgroup phase times (100 MHz ticks), else NULL
 	int dbg;   // SPHX_TILE_DEBUG: 1 = skip pair loops, 2 = skip window staging (timing experiments only)
 };
@@ -377,6 +378,16 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 // list entries of one section, TILE_AHEAD batches deep: buffer q[j] holds batch j (mod TILE_AHEAD)
 struct ListWindow { uint32_t q[TILE_AHEAD][TILE_NB]; };
 
+// workgroup barrier that orders LDS traffic only.  __syncthreads() is a release/acquire fence over ALL address
+// spaces: with global stores or loads in flight it drains vmcnt, i.e. it exposes an HBM round trip (the forces
+// stores of the previous tile, the list batches just requested) at every barrier of the tile loop.
+__device__ __forceinline__ void lds_barrier()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
 
 // One batch (TILE_NB entries) of list entries of section `sec` (0 = fluid slots 0 upward, 1 = boundary slots
@@ -384,19 +395,19 @@ __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballo
 // of a batch are addressed as buffer loads: SGPR descriptor (row base) + SGPR row offset + the per-lane byte
 // offset index*2, which is fixed for the whole tile -- no vector address arithmetic at all.
 // Needs neiblistsize % TILE_NB == 0 and (neibboundpos+1) % TILE_NB == 0 (checked by the host, else generic path).
-struct ListRows { const neibdata *list; uint32_t rowBytes; };
+struct ListRows { const neibdata *list; uint32_t rowBytes; uint32_t *pin; };
 
-template<bool CHECKED>
+__device__ __forceinline__ int list_last_batch(const DevParams &p, int sec)
+{
+	return sec ? ((int)p.neibboundpos + 1)/TILE_NB - 1 : (int)p.neiblistsize/TILE_NB - 1;
+}
+
 __device__ __forceinline__ void load_list_u(const DevParams &p, const ListRows &lr,
 	uint32_t voff, int sec, int batch, uint32_t nd[TILE_NB])
 {
-	const int b = __builtin_amdgcn_readfirstlane(batch);
-	const int maxb = sec ? ((int)p.neibboundpos + 1)/TILE_NB - 1 : (int)p.neiblistsize/TILE_NB - 1;
-	if (CHECKED && b > maxb) {   // past the section's last possible slot: terminate lists that have no terminator
-#pragma unroll
-		for (int k = 0; k < TILE_NB; ++k) nd[k] = NEIBS_END;
-		return;
-	}
+	// batches past the section's last slot are never consumed (the walk stops there); the clamp only keeps the
+	// prefetch in bounds.  No branch around the loads: the compiler must be able to count them (s_waitcnt vmcnt(N)).
+	const int b = min(__builtin_amdgcn_readfirstlane(batch), list_last_batch(p, sec));
 	const int lowSlot = sec ? (int)p.neibboundpos - (b*TILE_NB + TILE_NB - 1) : b*TILE_NB;
 	const neibdata *row = lr.list + (size_t)lowSlot*p.stride;
 	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<neibdata*>(row), 0, 0xFFFFFFFF, 0x00020000);
@@ -407,11 +418,20 @@ __device__ __forceinline__ void load_list_u(const DevParams &p, const ListRows &
 	}
 }
 
+// LLVM sinks a load whose first use is three ring steps (and several side exits) away down to that use, which
+// undoes the prefetch distance.  A use in a never-taken side block (pin is always NULL, but a kernel argument
+// the compiler cannot see through) keeps the loads where they are issued; the main path pays one scalar branch.
+__device__ __forceinline__ void pin_batch(const ListRows &lr, const uint32_t nd[TILE_NB])
+{
+	if (__builtin_expect(lr.pin != nullptr, 0))
+		lr.pin[threadIdx.x] = nd[0] ^ nd[1] ^ nd[2] ^ nd[3];
+}
+
 __device__ __forceinline__ void preload_list(const DevParams &p, const ListRows &lr, uint32_t voff, int sec, ListWindow &lw)
 {
 #pragma unroll
 	for (int j = 0; j < TILE_AHEAD; ++j)
-		load_list_u<false>(p, lr, voff, sec, j, lw.q[j]);   // batches 0..TILE_AHEAD-1 always exist (host check)
+		load_list_u(p, lr, voff, sec, j, lw.q[j]);   // batches 0..TILE_AHEAD-1 always exist (host check)
 }
 
 struct WalkState { uint32_t code; bool alive; };
@@ -482,6 +502,7 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
 	WalkState w; w.code = 0; w.alive = take;
 	int next = TILE_AHEAD;   // index of the next batch to fetch (scalar)
+	const int lastBatch = list_last_batch(p, sec);   // a list without terminator ends with its section
 	Gathered A, B;
 	gather_half(lw.q[0], s, sShift, myCB, sPos, sVel, sAux, w, A);
 	if (!wave_any(A.valid[0])) return;
@@ -489,11 +510,12 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	gather_half(lw.q[J] + TILE_HB, s, sShift, myCB, sPos, sVel, sAux, w, B); \
 	compute_half<KERNEL, TURB, COLAGROSSI>(p, A, s, inv_h, momentum, diffuse, force); \
 	if (!wave_any(B.valid[0])) return; \
-	load_list_u<true>(p, list, voff, sec, next, lw.q[J]); \
+	load_list_u(p, list, voff, sec, next, lw.q[J]); \
+	pin_batch(list, lw.q[J]); \
 	++next; \
 	gather_half(lw.q[JN], s, sShift, myCB, sPos, sVel, sAux, w, A); \
 	compute_half<KERNEL, TURB, COLAGROSSI>(p, B, s, inv_h, momentum, diffuse, force); \
-	if (!wave_any(A.valid[0])) return;
+	if (!wave_any(A.valid[0]) || next - TILE_AHEAD > lastBatch) return;   /* A now holds batch next-TILE_AHEAD */
 	for (;;) {
 		SPHX_RING_STEP(0, 1)
 		SPHX_RING_STEP(1, 2)
@@ -551,6 +573,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	const float inv_h = fast_rcp(p.slength);
 	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
 	ListRows listRows; listRows.list = a.neibsList; listRows.rowBytes = (uint32_t)(p.stride*sizeof(neibdata));
+	listRows.pin = a.pin;
 	const int wr = (int)(tid/TILE_KW), wcol = (int)(tid - (tid/TILE_KW)*TILE_KW);   // my window cell (tid < 256)
 
 	// software pipeline over tiles: the descriptor and the window-cell extents of the NEXT tile are
@@ -604,7 +627,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		preload_list(p, listRows, voff, 0, lwF);
 		preload_list(p, listRows, voff, 1, lwB);
 
-		__syncthreads();   // the previous tile's readers are done with LDS
+		lds_barrier();   // the previous tile's readers are done with LDS
 		if (prof) { s1 = wall_clock64(); s2 = s1; s3 = s1; }
 
 		if (inRange && pairs) {
@@ -631,7 +654,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					sRowContig[wr] = (incl == 0u || hi - lo == incl) ? 1u : 0u;
 				}
 			}
-			__syncthreads();
+			lds_barrier();
 			if (prof) { s2 = wall_clock64(); s3 = s2; }
 			// 2. row bases: every wave scans the 16 row totals in its first 16 lanes; then the window DMA, with
 			//    the rows dealt out to the waves (wave w stages rows w, w+8, ...: a row is ~3 chunks of 64 records
@@ -696,7 +719,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				const uint32_t hr = m/TILE_MAXCELLS, col = m - hr*TILE_MAXCELLS;
 				sCB[e + 1] = (uint16_t)sCellBase[sCodeOff[c1] + (int)(((hr & 1u) + 4u*(hr >> 1))*TILE_KW + col)];
 			}
-			__syncthreads();
+			lds_barrier();
 			const uint32_t ptype = PART_TYPE(info);
 			const int myG1 = (p.c1 == 0) ? s.gridPos.x : (p.c1 == 1) ? s.gridPos.y : s.gridPos.z;
 			const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
@@ -713,6 +736,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					sPos, sVel, sAux, 1, take1, momentum, false, lwB, force);
 		}
 		if (prof) tB = wall_clock64();
+		// vmcnt(0): only the list batches fetched past the terminators and the next tile's window extents are in
+		// flight, all long complete; from here to the loop head only stores are issued, which nobody waits for
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+		const uint32_t nCSv = nCS, nCEv = nCE;
 		if (active)
 			cfl_term = finalize_particle(p, a, index, info, s, force);
 		// 4. CFL: the array keeps the reference's one-entry-per-128-particles layout
@@ -723,7 +750,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			for (int dd = 32; dd > 0; dd >>= 1)
 				cfl_term = fmaxf(cfl_term, __shfl_down(cfl_term, dd));
 			if ((tid & 63u) == 0) sWaveMax[tid >> 6] = cfl_term;
-			__syncthreads();
+			lds_barrier();
 			if (tid == 0) {
 				float m = sWaveMax[0];
 				for (int w = 1; w < TILE_THREADS/64; ++w) m = fmaxf(m, sWaveMax[w]);
@@ -733,8 +760,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		}
 		if (prof) { const unsigned long long tC = wall_clock64(); accStage += tA - t0; acc1 += s1 - t0; acc2 += s2 - s1; acc3 += s3 - s2; accPairs += tB - tA; accTail += tC - tB; }
 		if (!haveNext) break;
-		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): long complete; tells the compiler nothing is pending at the loop head
-		const uint32_t nStart = (nCS != CELL_EMPTY) ? nCS : 0u, nCnt = (nCS != CELL_EMPTY) ? nCE - nCS : 0u;
+		const uint32_t nStart = (nCSv != CELL_EMPTY) ? nCSv : 0u, nCnt = (nCSv != CELL_EMPTY) ? nCEv - nCSv : 0u;
 		tile = nextTile;
 #pragma unroll
 		for (int k = 0; k < TILE_DESC; ++k) dc[k] = dn[k];
@@ -1030,6 +1056,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.compute_object_forces = compute_object_forces;
 	a.dbg = ctx->tile_debug;
 	a.prof = nullptr;
+	a.pin = nullptr;
 	if (ctx->tile_debug & 16) {
 		if (!ctx->tile_prof && hipMalloc((void**)&ctx->tile_prof, 8*sizeof(unsigned long long)*ctx->tile_grid) != hipSuccess)
 			return sphx_set_error(SPHX_ERR_RUNTIME, "sphx_forces_basicstep: cannot allocate the tile profile buffer");
@@ -1156,5 +1183,16 @@ extern "C" int sphx_dbg_tile_profile(sphx_ctx *ctx, unsigned long long *host, ui
 	if (!ctx || !ctx->tile_prof) return -1;
 	const uint32_t n = maxGroups < ctx->tile_grid ? maxGroups : ctx->tile_grid;
 	if (hipMemcpy(host, ctx->tile_prof, 8*sizeof(unsigned long long)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (int)n;
+}
+
+// timing experiments only, not part of include/sphx.h: the tile descriptors of the last neighbour-list build
+extern "C" int sphx_dbg_tiles(sphx_ctx *ctx, uint32_t *host, uint32_t maxTiles)
+{
+	if (!ctx || !ctx->tiles || !ctx->tiles_built) return -1;
+	uint32_t ctl[4];
+	if (hipMemcpy(ctl, ctx->tile_ctl, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	const uint32_t n = ctl[0] < maxTiles ? ctl[0] : maxTiles;
+	if (hipMemcpy(host, ctx->tiles, (size_t)TILE_DESC*sizeof(uint32_t)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return (int)n;
 }
