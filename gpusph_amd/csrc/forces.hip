@@ -361,6 +361,17 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 	}
 }
 
+// the last workgroup of a launch re-arms the tile tickets for the next one (no memset launch in between)
+__device__ __forceinline__ void tile_group_done(uint32_t *tileCtl)
+{
+	__threadfence();
+	if (atomicAdd(tileCtl + 2, 1u) == gridDim.x - 1u) {
+#pragma unroll
+		for (int k = 0; k < 8; ++k) tileCtl[4 + k] = 0u;
+		tileCtl[2] = 0u;
+	}
+}
+
 // ==========================================================================================
 // Tiled path (the fast one): LDS staging of the 27-cell neighbour window per workgroup.
 //
@@ -528,7 +539,8 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 template<int KERNEL, int TURB, bool COLAGROSSI>
 __global__ void __launch_bounds__(TILE_THREADS, 2)
 forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
-	const uint32_t *__restrict__ tileCtl /* [0]=count, [1]=overflow */, const uint32_t *__restrict__ cellEnd)
+	uint32_t *tileCtl /* [0]=count, [1]=overflow, [2]=finished workgroups, [4..11]=per-XCD tile tickets */,
+	const uint32_t *__restrict__ cellEnd)
 {
 	__shared__ __attribute__((aligned(16))) float4 sPos[TILE_WCAP];
 	__shared__ __attribute__((aligned(16))) float4 sVel[TILE_WCAP];
@@ -538,6 +550,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	__shared__ uint32_t sStart[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sRowStart[TILE_WROWS], sRowTotal[TILE_WROWS], sRowContig[TILE_WROWS];
 	__shared__ float sWaveMax[TILE_THREADS/64];
+	__shared__ uint32_t sTileQ[2];                                 // [0] first tile, [1] next tile of this workgroup
 	__shared__ __attribute__((aligned(16))) float4 sShift[32];   // cell code -> own-position shift (x,y,z)
 	__shared__ int sCodeOff[32];                                   // cell code-1 -> window-table offset
 	__shared__ uint16_t sCB[TILE_HROWS*TILE_MAXCELLS*27 + 8];      // [home cell][code] -> LDS slot of the cell's first record
@@ -551,11 +564,40 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	// shared rows then hit in that XCD's L2.  Rounds still interleave all XCDs, which keeps them balanced
 	// (giving each XCD one contiguous eighth of the list measured 40 % slower: unequal work per eighth).
 	// Placement only affects speed, never results.
-	uint32_t tile = blockIdx.x;
-	const uint32_t tileStride = gridDim.x, tileEnd = numTiles;
-	if ((gridDim.x & 7u) == 0u && !(a.dbg & 4))
-		tile = (blockIdx.x & 7u)*(gridDim.x >> 3) + (blockIdx.x >> 3);
-	if (tile >= tileEnd) return;
+	// Tiles are handed out dynamically, one ticket counter per XCD: ticket n of XCD x is tile
+	// (n / perRound)*gridDim + x*perRound + n % perRound, i.e. the same placement as above, but a workgroup that
+	// drew cheap tiles simply draws more (static round-robin left the slowest workgroup ~5 % behind the mean).
+	// Tickets are drawn two tiles ahead by thread 0 and published through LDS, so the atomic's latency is hidden.
+	const bool xcdAware = (gridDim.x & 7u) == 0u && !(a.dbg & 4);
+	const uint32_t xcd = xcdAware ? (blockIdx.x & 7u) : 0u;
+	const uint32_t perRound = xcdAware ? (gridDim.x >> 3) : 1u;
+	uint32_t src = xcd;   // XCD whose tickets this workgroup currently draws (thread 0 only): its own, until they run out
+	auto tile_of = [&](uint32_t from, uint32_t n) -> uint32_t {
+		return xcdAware ? (n / perRound)*gridDim.x + from*perRound + n % perRound : n;
+	};
+	const uint32_t tileEnd = numTiles;
+	// a ticket past the end of `src`'s share: steal from the other XCDs' shares (synchronous atomics, but only in
+	// the last few tiles of a launch); returns a tile >= tileEnd once every share is exhausted
+	auto resolve = [&](uint32_t n) -> uint32_t {
+		uint32_t t = tile_of(src, n);
+		for (int tries = 1; t >= tileEnd && xcdAware && tries < 8; ++tries) {
+			src = (src + 1u) & 7u;
+			t = tile_of(src, atomicAdd(tileCtl + 4 + src, 1u));
+		}
+		return t;
+	};
+	if (tid == 0) {
+		const uint32_t n0 = atomicAdd(tileCtl + 4 + src, 1u);
+		sTileQ[0] = resolve(n0);
+		const uint32_t n1 = atomicAdd(tileCtl + 4 + src, 1u);
+		sTileQ[1] = resolve(n1);
+	}
+	__syncthreads();
+	uint32_t tile = sTileQ[0];
+	if (tile >= tileEnd) {
+		if (tid == 0) tile_group_done(tileCtl);
+		return;
+	}
 
 	// neighbour-cell offset (ox,oy,oz) -> index of that cell in the window table, relative to the
 	// particle's own (row, column): o1 + KW*(o2+1) + 4*KW*(o3+1) + 1 with (o1,o2,o3) the offsets along COORD1..3
@@ -591,12 +633,8 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	if (prof) tBegin = wall_clock64();
 	for (;;) {
 		if (prof) t0 = wall_clock64();
-		const uint32_t nextTile = tile + tileStride;
-		const bool haveNext = nextTile < tileEnd;
-		if (haveNext) {
-#pragma unroll
-			for (int k = 0; k < TILE_DESC; ++k) dn[k] = tiles[(size_t)TILE_DESC*nextTile + k];
-		}
+		uint32_t drawn = 0;
+		if (tid == 0) drawn = atomicAdd(tileCtl + 4 + src, 1u);   // the tile after next; consumed after the window barrier
 		const int ca = (int)dc[2], ncells = (int)dc[3];
 		const uint32_t c0 = dc[8], c1n = dc[9], c2n = dc[10], c3n = dc[11];
 		const uint32_t hcTot = c0 + c1n + c2n + c3n;
@@ -628,6 +666,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		preload_list(p, listRows, voff, 1, lwB);
 
 		lds_barrier();   // the previous tile's readers are done with LDS
+		const uint32_t nextTile = sTileQ[1];
+		const bool haveNext = nextTile < tileEnd;
+		if (haveNext) {
+#pragma unroll
+			for (int k = 0; k < TILE_DESC; ++k) dn[k] = tiles[(size_t)TILE_DESC*nextTile + k];
+		}
 		if (prof) { s1 = wall_clock64(); s2 = s1; s3 = s1; }
 
 		if (inRange && pairs) {
@@ -694,6 +738,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		if (prof) s3 = wall_clock64();
 		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA (and its own rows, list batches) have landed
 		__syncthreads();                      // ... everybody's have; the tables are published
+		if (tid == 0) sTileQ[1] = resolve(drawn);   // read after the first barrier of the next iteration
 		if (prof) tA = wall_clock64();
 		// prefetch the next tile's window-cell extents (two independent loads, consumed at the end of the iteration)
 		uint32_t nCS = CELL_EMPTY, nCE = 0;
@@ -766,6 +811,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		for (int k = 0; k < TILE_DESC; ++k) dc[k] = dn[k];
 		wStart = nStart; wCnt = nCnt;
 	}
+	if (tid == 0) tile_group_done(tileCtl);
 	if (prof) {
 		unsigned long long *o = a.prof + 8*(size_t)blockIdx.x;
 		o[0] = wall_clock64() - tBegin; o[1] = accStage; o[2] = accPairs; o[3] = accTail; o[4] = acc1; o[5] = acc2; o[6] = acc3; o[7] = 0;

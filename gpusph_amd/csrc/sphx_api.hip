@@ -31,8 +31,8 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	SPHX_HIP(hipMalloc((void**)&ctx->counters_dev, sizeof(NeibsCounters)));
 	SPHX_HIP(hipMemset(ctx->counters_dev, 0, sizeof(NeibsCounters)));
 	SPHX_HIP(hipMalloc((void**)&ctx->dt_scratch, 4*sizeof(float)));
-	SPHX_HIP(hipMalloc((void**)&ctx->tile_ctl, 4*sizeof(uint32_t)));
-	SPHX_HIP(hipMemset(ctx->tile_ctl, 0, 4*sizeof(uint32_t)));
+	SPHX_HIP(hipMalloc((void**)&ctx->tile_ctl, 16*sizeof(uint32_t)));
+	SPHX_HIP(hipMemset(ctx->tile_ctl, 0, 16*sizeof(uint32_t)));
 	int cus = 0;
 	SPHX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
 	ctx->tile_grid = (uint32_t)(cus > 0 ? cus : 256)*TILE_WGS_PER_CU;   // persistent grid: one 512-thread workgroup per CU (LDS bound)
