@@ -508,12 +508,16 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	uint32_t voff, const Self &s, float inv_h, const float4 *sShift, const uint16_t *myCB,
 	const float4 *sPos, const float4 *sVel, const float4 *sAux,
 	int sec, bool take, bool momentum, bool diffuse,
-	ListWindow &lw /* batches 0..TILE_AHEAD-1 preloaded */, float4 &force)
+	ListWindow &lw /* batches 0..preloaded-1 already requested */, int preloaded, float4 &force)
 {
 	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
 	WalkState w; w.code = 0; w.alive = take;
 	int next = TILE_AHEAD;   // index of the next batch to fetch (scalar)
 	const int lastBatch = list_last_batch(p, sec);   // a list without terminator ends with its section
+	for (int j = preloaded; j < TILE_AHEAD; ++j) {
+		load_list_u(p, list, voff, sec, j, lw.q[j]);
+		pin_batch(list, lw.q[j]);
+	}
 	Gathered A, B;
 	gather_half(lw.q[0], s, sShift, myCB, sPos, sVel, sAux, w, A);
 	if (!wave_any(A.valid[0])) return;
@@ -663,7 +667,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		ListWindow lwF, lwB;
 		const uint32_t voff = li*2u;   // byte offset of this particle inside every list row (n < 2^31)
 		preload_list(p, listRows, voff, 0, lwF);
-		preload_list(p, listRows, voff, 1, lwB);
+		// boundary section: most particles have none, so only its first batch is requested up front (every
+		// vector memory instruction costs ~20 issue cycles of the CU's address unit; 8 waves x 40 of them
+		// were 3 us per tile); the walk requests the rest when a wave does have boundary neighbours
+		load_list_u(p, listRows, voff, 1, 0, lwB.q[0]);
 
 		lds_barrier();   // the previous tile's readers are done with LDS
 		const uint32_t nextTile = sTileQ[1];
@@ -775,10 +782,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
 			const bool take0 = active && (isFluid || isDynBound), take1 = active && isFluid && dyn;
 			walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
-				sPos, sVel, sAux, 0, take0, momentum, true, lwF, force);
+				sPos, sVel, sAux, 0, take0, momentum, true, lwF, TILE_AHEAD, force);
 			if (wave_any(take1))
 				walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
-					sPos, sVel, sAux, 1, take1, momentum, false, lwB, force);
+					sPos, sVel, sAux, 1, take1, momentum, false, lwB, 1, force);
 		}
 		if (prof) tB = wall_clock64();
 		// vmcnt(0): only the list batches fetched past the terminators and the next tile's window extents are in

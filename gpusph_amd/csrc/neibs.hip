@@ -376,6 +376,21 @@ cell_fluid_end_kernel(uint32_t *__restrict__ cellFluidEnd, const uint32_t *__res
 }
 
 #define NEIB_MLP 4   // candidate positions fetched per batch in the fluid segment
+#define NEIB_FRING 32   // rows of the fluid section a wave keeps in LDS before writing them out as full lines
+#define NEIB_BRING 8    // ... of the boundary section
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d));
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d));
+	return v;
+}
 
 // buildNeibsListDevice + neibsInCell (src/cuda/buildneibs_kernel.cu:536-644,1019-1185).  The candidate
 // scan is a gather through L1/L2 and is bound by the number of gather instructions, so it avoids the
@@ -383,6 +398,13 @@ cell_fluid_end_kernel(uint32_t *__restrict__ cellFluidEnd, const uint32_t *__res
 // cell (in the fluid segment the type is known from the index), and DYN/LJ boundary particles, which
 // never list boundary neighbours, do not visit the non-fluid tail at all.  Candidate order, tests and
 // encodings are the reference's, so the list is bit-identical.
+//
+// Stores: the list is slot-major ([slot*stride + particle], 2 B), and the lanes of a wave reach a given slot at
+// different times, so storing entries as they are found wrote every 128-B line of the list ~12 times (measured:
+// 53 GB of HBM writes for a 4.3 GB list at 32 M particles; the kernel was write-bandwidth bound).  Instead a wave
+// parks its entries in an LDS ring of NEIB_FRING rows x 64 lanes; after every neighbour cell (a wave-uniform
+// point) the rows that EVERY walking lane has filled are written out as whole 128-B lines.  A lane that runs more
+// than a ring ahead of the slowest one falls back to direct stores for the rest of its list.
 __global__ void __launch_bounds__(BLOCK_NEIBS)
 build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	const float4 *__restrict__ posArray, const particleinfo *__restrict__ infoArray,
@@ -391,30 +413,78 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	const uint32_t *__restrict__ cellFluidEnd,
 	uint32_t particleRangeEnd, float sqinfluenceradius, NeibsCounters *__restrict__ counters, int dbg)
 {
-	const uint32_t index = blockIdx.x*BLOCK_NEIBS + threadIdx.x;
-	uint32_t nf = 0, nb = 0, nv = 0; // neibs_num[PT_FLUID, PT_BOUNDARY, PT_VERTEX]
+	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING][64];
+	const uint32_t lane = threadIdx.x & 63u;
+	neibdata (*fring)[64] = sRing[threadIdx.x >> 6];
+	neibdata (*bring)[64] = sRing[threadIdx.x >> 6] + NEIB_FRING;
 
-	do {
-		if (index >= particleRangeEnd) break;
-		const particleinfo info = infoArray[index];
+	const uint32_t index = blockIdx.x*BLOCK_NEIBS + threadIdx.x;
+	const bool inRange = index < particleRangeEnd;
+	uint32_t nf = 0, nb = 0, nv = 0; // neibs_num[PT_FLUID, PT_BOUNDARY, PT_VERTEX]
+	uint32_t sf = 0, sb = 0;         // entries stored (== nf, nb unless the list overflowed)
+	uint32_t rf = 0, rb = 0;         // ... of which the first rf / rb live in the rings (a prefix)
+	bool fdirect = false, bdirect = false;
+	uint32_t fbase = 0, bbase = 0;   // wave-uniform: rows below were written out
+	neibdata *const column = neibsList + (inRange ? index : 0u);
+
+	auto store_f = [&](uint32_t slot, uint32_t val) {
+		if (!fdirect && slot - fbase < NEIB_FRING) { fring[slot % NEIB_FRING][lane] = (neibdata)val; rf = slot + 1u; }
+		else { fdirect = true; column[(size_t)slot*p.stride] = (neibdata)val; }
+	};
+	auto store_b = [&](uint32_t k, uint32_t val) {   // k-th boundary entry, slot neibboundpos - k
+		if (!bdirect && k - bbase < NEIB_BRING) { bring[k % NEIB_BRING][lane] = (neibdata)val; rb = k + 1u; }
+		else { bdirect = true; column[(size_t)(p.neibboundpos - k)*p.stride] = (neibdata)val; }
+	};
+	// rows every walking lane has filled -> global, one 128-B line per row (wave-uniform control)
+	auto flush = [&](bool walking) {
+		const uint32_t mf = wave_min_u32(walking ? sf : 0xFFFFFFFFu);
+		if (mf != 0xFFFFFFFFu) {
+			const uint32_t to = min(mf, fbase + NEIB_FRING);
+			for (uint32_t r = fbase; r < to; ++r) {
+				const neibdata v = fring[r % NEIB_FRING][lane];
+				if (r < rf) column[(size_t)r*p.stride] = v;
+			}
+			fbase = max(fbase, to);
+			const uint32_t mb = wave_min_u32(walking ? sb : 0xFFFFFFFFu);
+			const uint32_t tob = min(mb, bbase + NEIB_BRING);
+			for (uint32_t k = bbase; k < tob; ++k) {
+				const neibdata v = bring[k % NEIB_BRING][lane];
+				if (k < rb) column[(size_t)(p.neibboundpos - k)*p.stride] = v;
+			}
+			bbase = max(bbase, tob);
+		}
+	};
+
+	particleinfo info = make_ushort4(0, 0, 0, 0);
+	float4 pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	bool walking = false;
+	if (inRange) {
+		info = infoArray[index];
 		bool build_nl = IS_FLUID(info) || IS_TESTPOINT(info) || IS_FLOATING(info) || HAS_COMPUTE_FORCE(info);
 		if (p.boundarytype == SPHX_DYN_BOUNDARY) build_nl = true;
-		if (!build_nl) break;
-		const float4 pos = posArray[index];
-		if (!is_active_w(pos.w)) break;
-		const int3 gridPos = grid_pos_from_hash(p, particleHash[index] & CELLTYPE_BITMASK);
-		const bool boundary = IS_BOUNDARY(info);
-		// boundary particles never list non-fluid neighbours with LJ/DYN boundaries (:596-607)
-		const bool fluidOnly = boundary && (p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY);
+		if (build_nl) {
+			pos = posArray[index];
+			walking = is_active_w(pos.w);
+		}
+	}
+	const int3 gridPos = walking ? grid_pos_from_hash(p, particleHash[index] & CELLTYPE_BITMASK) : make_int3(0, 0, 0);
+	const bool boundary = IS_BOUNDARY(info);
+	// boundary particles never list non-fluid neighbours with LJ/DYN boundaries (:596-607)
+	const bool fluidOnly = boundary && (p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY);
 
-		for (int z = -1; z <= 1; z++) for (int y = -1; y <= 1; y++) for (int x = -1; x <= 1; x++) {
-			int gx = gridPos.x, gy = gridPos.y, gz = gridPos.z;
-			if (!neib_cell_axis(gx, x, p.gs[0], p.periodic & SPHX_PERIODIC_X)) continue;
-			if (!neib_cell_axis(gy, y, p.gs[1], p.periodic & SPHX_PERIODIC_Y)) continue;
-			if (!neib_cell_axis(gz, z, p.gs[2], p.periodic & SPHX_PERIODIC_Z)) continue;
-			const uint32_t cellHash = grid_hash(p, gx, gy, gz);
-			const uint32_t bucketStart = cellStart[cellHash];
-			if (bucketStart == CELL_EMPTY) continue;
+	if (wave_max_u32(walking ? 1u : 0u))
+	for (int z = -1; z <= 1; z++) for (int y = -1; y <= 1; y++) for (int x = -1; x <= 1; x++) {
+		int gx = gridPos.x, gy = gridPos.y, gz = gridPos.z;
+		bool valid = walking;
+		valid = valid && neib_cell_axis(gx, x, p.gs[0], p.periodic & SPHX_PERIODIC_X);
+		valid = valid && neib_cell_axis(gy, y, p.gs[1], p.periodic & SPHX_PERIODIC_Y);
+		valid = valid && neib_cell_axis(gz, z, p.gs[2], p.periodic & SPHX_PERIODIC_Z);
+		uint32_t cellHash = 0, bucketStart = CELL_EMPTY;
+		if (valid) {
+			cellHash = grid_hash(p, gx, gy, gz);
+			bucketStart = cellStart[cellHash];
+		}
+		if (bucketStart != CELL_EMPTY) {
 			const uint32_t fluidEnd = cellFluidEnd[cellHash];
 			const uint32_t bucketEnd = fluidOnly ? fluidEnd : cellEnd[cellHash];
 			const uint32_t cell = (uint32_t)((x + 1) + (y + 1)*3 + (z + 1)*9);
@@ -441,7 +511,8 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 						nf++;
 						if (!too_many_neibs(p, nf, nb, nv, PT_FLUID)) {
 							const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
-							if (!(dbg & 64)) neibsList[(size_t)offset*p.stride + index] = (neibdata)((neib_index - bucketStart) + enc);
+							store_f(offset, (neib_index - bucketStart) + enc);
+							sf = nf;
 							encode_cell = false;
 						}
 					}
@@ -464,30 +535,44 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 				const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
 				if (r2 < sqinfluenceradius) {
 					const uint32_t num = (neib_type == PT_FLUID) ? nf : (neib_type == PT_BOUNDARY) ? nb : nv;
-					const uint32_t offset = neib_list_offset(p, num, neib_type);
 					if (neib_type == PT_FLUID) nf++; else if (neib_type == PT_BOUNDARY) nb++; else nv++;
 					if (!too_many_neibs(p, nf, nb, nv, neib_type)) {
 						const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
-						if (!(dbg & 64)) neibsList[(size_t)offset*p.stride + index] = (neibdata)((neib_index - bucketStart) + enc);
+						const uint32_t val = (neib_index - bucketStart) + enc;
+						if (neib_type == PT_FLUID) { store_f(num, val); sf = nf; }
+						else if (neib_type == PT_BOUNDARY) { store_b(num, val); sb = nb; }
+						else column[(size_t)neib_list_offset(p, num, neib_type)*p.stride] = (neibdata)val;
 						encode_cell = false;
 					}
 				}
 			}
 		}
-	} while (0);
+		flush(walking);
+	}
 
-	if (index < particleRangeEnd) {
+	// terminators (every particle below particleRangeEnd gets them, walking or not), then what is left in the rings
+	if (inRange) {
 		bool overflow = too_many_neibs(p, nf, nb, nv, PT_FLUID);
-		const uint32_t marker_pos = overflow ? p.neibboundpos : nf;
-		neibsList[(size_t)marker_pos*p.stride + index] = NEIBS_END;
+		if (overflow) column[(size_t)p.neibboundpos*p.stride] = NEIBS_END;
+		else store_f(nf, NEIBS_END);
 		overflow |= too_many_neibs(p, nf, nb, nv, PT_BOUNDARY);
-		if (!overflow)
-			neibsList[(size_t)neib_list_offset(p, nb, PT_BOUNDARY)*p.stride + index] = NEIBS_END;
+		if (!overflow) store_b(nb, NEIBS_END);
 		if (overflow) {
-			const int pid = (int)info_id(infoArray[index]);
+			const int pid = (int)info_id(info);
 			if (atomicCAS(&counters->hasTooManyNeibs, -1, pid) == -1) {
 				counters->hasMaxNeibs[0] = nf; counters->hasMaxNeibs[1] = nb; counters->hasMaxNeibs[2] = nv;
 			}
+		}
+	}
+	{
+		const uint32_t tf = wave_max_u32(rf), tb = wave_max_u32(rb);
+		for (uint32_t r = fbase; r < tf; ++r) {
+			const neibdata v = fring[r % NEIB_FRING][lane];
+			if (r < rf) column[(size_t)r*p.stride] = v;
+		}
+		for (uint32_t k = bbase; k < tb; ++k) {
+			const neibdata v = bring[k % NEIB_BRING][lane];
+			if (k < rb) column[(size_t)(p.neibboundpos - k)*p.stride] = v;
 		}
 	}
 
