@@ -46,7 +46,7 @@ template<int KERNEL>
 __device__ __forceinline__ float kernel_F(const DevParams &p, float r, float inv_h)
 {
 	if (KERNEL == SPHX_WENDLAND) {
-		const float qm2 = r*inv_h - 2.0f;
+		const float qm2 = fmaf(r, inv_h, -2.0f);
 		return qm2*qm2*qm2*p.fcoeff;
 	} else if (KERNEL == SPHX_CUBICSPLINE) {
 		const float R = r*inv_h;
@@ -99,15 +99,18 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 	float pcx, float pcy, float pcz, const float4 &npos, const float4 &nvel, const float4 &naux,
 	bool same_fluid, bool valid, const float *ntau, float4 &force, bool rt_momentum = true, bool rt_diffuse = true)
 {
-	// Branch-free on purpose: a rejected pair (list terminator passed, inactive neighbour, r >= influence
-	// radius) gets the weight m_j F_ij = 0 and every term below becomes +-0, which leaves the accumulators
-	// untouched -- the same result as the reference's `continue`, without ~6 exec-mask branch sequences
-	// per pair and without paying for lane divergence inside a wave.
+	// Branch-free on purpose: a rejected pair (list terminator passed, r >= influence radius) gets the weight
+	// m_j F_ij = 0 and every term below becomes +-0, which leaves the accumulators untouched -- the same result
+	// as the reference's `continue`, without ~6 exec-mask branch sequences per pair and without paying for lane
+	// divergence inside a wave.  (Inactive particles sit outside every cell after the sort, so they are never
+	// listed and need no test here.)
+	// Multiply-adds are written as explicit fmaf where nvcc's default -fmad=true contracts them in the
+	// reference as well: the pair loop is VALU-bound and these are ~10 % of its instructions.
 	const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
 	const float nmass = npos.w;
 	const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
 	const float r = fast_sqrt(r2);
-	const bool on = valid && is_active_w(nmass) && (r < p.influenceradius);
+	const bool on = valid && (r < p.influenceradius);
 
 	const float vx = s.vel.x - nvel.x, vy = s.vel.y - nvel.y, vz = s.vel.z - nvel.z;
 	const float vel_dot_pos = fmaf(vz, rz, fmaf(vy, ry, vx*rx));
@@ -116,14 +119,14 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 	const float mf = on ? nmass*f : 0.0f;
 
 	// mass_continuity_div_vel_term (forces_kernel.def:2140-2151)
-	float DrDt = mf*vel_dot_pos;
+	float dsel = 0.0f;
 	if (COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
 		const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
 		const bool diff = same_fluid && rt_diffuse && !(fabsf(s.P - n_P) < fabsf(gdotr*s.rho));
-		const float dterm = p.densityDiffCoeff*p.sscoeff[s.fl]*(n_rho*s.inv_rho - 1.0f)*mf;
-		DrDt -= diff ? dterm : 0.0f;
+		const float dterm = p.densityDiffCoeff*p.sscoeff[s.fl]*fmaf(n_rho, s.inv_rho, -1.0f)*mf;
+		dsel = diff ? dterm : 0.0f;
 	}
-	force.w += DrDt;
+	force.w += fmaf(mf, vel_dot_pos, -dsel);
 
 	if (MOMENTUM) {
 		// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
@@ -131,20 +134,20 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 		if (TURB == SPHX_ARTIFICIAL) {
 			// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764): only for approaching pairs
 			const float vdpn = fminf(vel_dot_pos, 0.0f);
-			const float visc = vdpn*p.slength*p.artvisccoeff*(s.sspeed + n_sspeed)*
+			const float visc = vdpn*(p.slength*p.artvisccoeff)*(s.sspeed + n_sspeed)*
 				fast_rcp((r2 + p.epsartvisc)*(s.rho + n_rho));
 			kk = fmaf(visc, mf, kk);
 		}
-		float ax = kk*rx, ay = kk*ry, az = kk*rz;
+		kk = rt_momentum ? kk : 0.0f;
 		if (TURB == SPHX_SPS) { // forces_kernel.def:2777-2798
+			const float mg = rt_momentum ? mf : 0.0f;
 			const float xx = s.tau[0] + ntau[0], xy = s.tau[1] + ntau[1], xz = s.tau[2] + ntau[2];
 			const float yy = s.tau[3] + ntau[3], yz = s.tau[4] + ntau[4], zz = s.tau[5] + ntau[5];
-			ax = fmaf(mf, fmaf(xz, rz, fmaf(xy, ry, xx*rx)), ax);
-			ay = fmaf(mf, fmaf(yz, rz, fmaf(yy, ry, xy*rx)), ay);
-			az = fmaf(mf, fmaf(zz, rz, fmaf(yz, ry, xz*rx)), az);
+			force.x = fmaf(mg, fmaf(xz, rz, fmaf(xy, ry, xx*rx)), force.x);
+			force.y = fmaf(mg, fmaf(yz, rz, fmaf(yy, ry, xy*rx)), force.y);
+			force.z = fmaf(mg, fmaf(zz, rz, fmaf(yz, ry, xz*rx)), force.z);
 		}
-		const float gate = rt_momentum ? 1.0f : 0.0f;
-		force.x = fmaf(gate, ax, force.x); force.y = fmaf(gate, ay, force.y); force.z = fmaf(gate, az, force.z);
+		force.x = fmaf(kk, rx, force.x); force.y = fmaf(kk, ry, force.y); force.z = fmaf(kk, rz, force.z);
 	}
 }
 
@@ -792,8 +795,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		// flight, all long complete; from here to the loop head only stores are issued, which nobody waits for
 		__builtin_amdgcn_s_waitcnt(0x0F70);
 		const uint32_t nCSv = nCS, nCEv = nCE;
+		if (prof) s1 = wall_clock64();
 		if (active)
 			cfl_term = finalize_particle(p, a, index, info, s, force);
+		if (prof) s2 = wall_clock64();
 		// 4. CFL: the array keeps the reference's one-entry-per-128-particles layout
 		// (getFmaxElements); tiles are not 128-aligned, so they max into the entry of their first
 		// particle.  Non-negative floats order like their bit patterns; the caller zeroed CFL.
@@ -810,7 +815,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				atomicMax(reinterpret_cast<unsigned int*>(a.cfl + a.cflOffset + rel/SPHX_BLOCK_FORCES), __float_as_uint(m));
 			}
 		}
-		if (prof) { const unsigned long long tC = wall_clock64(); accStage += tA - t0; acc1 += s1 - t0; acc2 += s2 - s1; acc3 += s3 - s2; accPairs += tB - tA; accTail += tC - tB; }
+		if (prof) { const unsigned long long tC = wall_clock64(); accStage += tA - t0; acc1 += s1 - tB; acc2 += s2 - s1; acc3 += tC - s2; accPairs += tB - tA; accTail += tC - tB; }
 		if (!haveNext) break;
 		const uint32_t nStart = (nCSv != CELL_EMPTY) ? nCSv : 0u, nCnt = (nCSv != CELL_EMPTY) ? nCEv - nCSv : 0u;
 		tile = nextTile;

@@ -18,7 +18,7 @@ f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]; f.restype = C.c_int
 g = f(eng.ctx.handle, buf.ctypes.data, 1024)
 t = buf[:g].astype(np.float64) * 1e-5   # 100 MHz ticks -> ms
 print("groups", g)
-for k, name in enumerate(["total", "stage", "pairs(wave0)", "tail", "st:to-bar1", "st:scan+bar2", "st:dma-issue"]):
+for k, name in enumerate(["total", "stage", "pairs(wave0)", "tail", "tail:drain", "tail:finalize", "tail:cfl+barrier"]):
     print("%-13s mean %.3f  min %.3f  max %.3f ms" % (name, t[:, k].mean(), t[:, k].min(), t[:, k].max()))
 x = t[:, 0].reshape(-1, 8)
 print("per-XCD mean total:", np.round(x.mean(axis=0), 3))
