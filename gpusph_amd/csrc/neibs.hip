@@ -379,18 +379,83 @@ cell_fluid_end_kernel(uint32_t *__restrict__ cellFluidEnd, const uint32_t *__res
 #define NEIB_FRING 32   // rows of the fluid section a wave keeps in LDS before writing them out as full lines
 #define NEIB_BRING 8    // ... of the boundary section
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d));
-	return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d));
-	return v;
-}
+// Per-wave LDS staging of list entries.  The list is slot-major
+// ([slot*stride + particle], 2 B) and the lanes of a wave reach a given slot at different times, so storing
+// entries as they are found wrote every 128-B line of the list ~12 times (measured: 53 GB of HBM writes for a
+// 4.3 GB list at 32 M particles).  A wave parks its entries in a ring of FR (fluid) + BR (boundary) rows x 64
+// lanes; at wave-uniform points the rows that EVERY walking lane has filled are written out as whole 128-B
+// lines.  A lane that runs more than a ring ahead of the slowest one falls back to direct stores for the rest
+// of its list (its ring-resident entries stay a prefix [.., rf) of what it stored).
+template<int FR, int BR>
+struct NeibRing {
+	neibdata (*fring)[64];
+	neibdata (*bring)[64];
+	neibdata *column;        // &list[particle]
+	size_t stride;
+	uint32_t nbp, lane;
+	uint32_t sf, sb;         // entries stored (== neibs_num unless the list overflowed)
+	uint32_t rf, rb;         // ... of which the first rf / rb went through the rings
+	uint32_t fbase, bbase;   // wave-uniform: rows below were written out
+	bool fdirect, bdirect;
+
+	__device__ __forceinline__ void init(neibdata (*rows)[64], neibdata *col, size_t str, uint32_t neibboundpos, uint32_t ln)
+	{
+		fring = rows; bring = rows + FR; column = col; stride = str; nbp = neibboundpos; lane = ln;
+		sf = sb = rf = rb = fbase = bbase = 0; fdirect = bdirect = false;
+	}
+	__device__ __forceinline__ void store_f(uint32_t slot, uint32_t val)
+	{
+		if (!fdirect && slot - fbase < (uint32_t)FR) { fring[slot % FR][lane] = (neibdata)val; rf = slot + 1u; }
+		else { fdirect = true; column[(size_t)slot*stride] = (neibdata)val; }
+	}
+	// branch-light variant for the hot fluid-segment loop: every lane writes (lanes with nothing to park hit the
+	// spare row FR+BR), only the rare direct store sits behind a branch.  ok = this lane stores `val` at `slot`.
+	// Returns true if the entry could not be parked and the caller must store it with store_direct().
+	__device__ __forceinline__ bool store_f_sel(uint32_t slot, uint32_t val, bool ok)
+	{
+		const bool inring = ok && !fdirect && (slot - fbase < (uint32_t)FR);
+		fring[inring ? slot % FR : (uint32_t)(FR + BR)][lane] = (neibdata)val;
+		rf = inring ? slot + 1u : rf;
+		const bool direct = ok && !inring;
+		fdirect = fdirect || direct;
+		return direct;
+	}
+	__device__ __forceinline__ void store_direct(uint32_t slot, uint32_t val) { column[(size_t)slot*stride] = (neibdata)val; }
+	__device__ __forceinline__ void store_b(uint32_t k, uint32_t val)   // k-th boundary entry, slot neibboundpos - k
+	{
+		if (!bdirect && k - bbase < (uint32_t)BR) { bring[k % BR][lane] = (neibdata)val; rb = k + 1u; }
+		else { bdirect = true; column[(size_t)(nbp - k)*stride] = (neibdata)val; }
+	}
+	// write out the rows every walking lane has filled (wave-uniform control; one ballot per row, no reduction)
+	__device__ __forceinline__ void flush(bool walking, unsigned long long wmask)
+	{
+		if (!wmask) return;
+		while (__builtin_amdgcn_ballot_w64(walking && sf > fbase) == wmask) {
+			const neibdata v = fring[fbase % FR][lane];
+			if (fbase < rf) column[(size_t)fbase*stride] = v;
+			++fbase;
+		}
+		while (__builtin_amdgcn_ballot_w64(walking && sb > bbase) == wmask) {
+			const neibdata v = bring[bbase % BR][lane];
+			if (bbase < rb) column[(size_t)(nbp - bbase)*stride] = v;
+			++bbase;
+		}
+	}
+	// end of the walk: whatever is still parked (terminators included)
+	__device__ __forceinline__ void finish()
+	{
+		while (__builtin_amdgcn_ballot_w64(fbase < rf)) {
+			const neibdata v = fring[fbase % FR][lane];
+			if (fbase < rf) column[(size_t)fbase*stride] = v;
+			++fbase;
+		}
+		while (__builtin_amdgcn_ballot_w64(bbase < rb)) {
+			const neibdata v = bring[bbase % BR][lane];
+			if (bbase < rb) column[(size_t)(nbp - bbase)*stride] = v;
+			++bbase;
+		}
+	}
+};
 
 // buildNeibsListDevice + neibsInCell (src/cuda/buildneibs_kernel.cu:536-644,1019-1185).  The candidate
 // scan is a gather through L1/L2 and is bound by the number of gather instructions, so it avoids the
@@ -398,62 +463,23 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // cell (in the fluid segment the type is known from the index), and DYN/LJ boundary particles, which
 // never list boundary neighbours, do not visit the non-fluid tail at all.  Candidate order, tests and
 // encodings are the reference's, so the list is bit-identical.
-//
-// Stores: the list is slot-major ([slot*stride + particle], 2 B), and the lanes of a wave reach a given slot at
-// different times, so storing entries as they are found wrote every 128-B line of the list ~12 times (measured:
-// 53 GB of HBM writes for a 4.3 GB list at 32 M particles; the kernel was write-bandwidth bound).  Instead a wave
-// parks its entries in an LDS ring of NEIB_FRING rows x 64 lanes; after every neighbour cell (a wave-uniform
-// point) the rows that EVERY walking lane has filled are written out as whole 128-B lines.  A lane that runs more
-// than a ring ahead of the slowest one falls back to direct stores for the rest of its list.
+// Stores go through NeibRing (above), flushed after every neighbour cell.
 __global__ void __launch_bounds__(BLOCK_NEIBS)
 build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	const float4 *__restrict__ posArray, const particleinfo *__restrict__ infoArray,
 	const uint32_t *__restrict__ particleHash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
 	const uint32_t *__restrict__ cellFluidEnd,
-	uint32_t particleRangeEnd, float sqinfluenceradius, NeibsCounters *__restrict__ counters, int dbg)
+	uint32_t particleRangeEnd, float sqinfluenceradius, NeibsCounters *__restrict__ counters)
 {
-	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING][64];
+	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING + 1][64];
 	const uint32_t lane = threadIdx.x & 63u;
-	neibdata (*fring)[64] = sRing[threadIdx.x >> 6];
-	neibdata (*bring)[64] = sRing[threadIdx.x >> 6] + NEIB_FRING;
-
 	const uint32_t index = blockIdx.x*BLOCK_NEIBS + threadIdx.x;
 	const bool inRange = index < particleRangeEnd;
 	uint32_t nf = 0, nb = 0, nv = 0; // neibs_num[PT_FLUID, PT_BOUNDARY, PT_VERTEX]
-	uint32_t sf = 0, sb = 0;         // entries stored (== nf, nb unless the list overflowed)
-	uint32_t rf = 0, rb = 0;         // ... of which the first rf / rb live in the rings (a prefix)
-	bool fdirect = false, bdirect = false;
-	uint32_t fbase = 0, bbase = 0;   // wave-uniform: rows below were written out
 	neibdata *const column = neibsList + (inRange ? index : 0u);
-
-	auto store_f = [&](uint32_t slot, uint32_t val) {
-		if (!fdirect && slot - fbase < NEIB_FRING) { fring[slot % NEIB_FRING][lane] = (neibdata)val; rf = slot + 1u; }
-		else { fdirect = true; column[(size_t)slot*p.stride] = (neibdata)val; }
-	};
-	auto store_b = [&](uint32_t k, uint32_t val) {   // k-th boundary entry, slot neibboundpos - k
-		if (!bdirect && k - bbase < NEIB_BRING) { bring[k % NEIB_BRING][lane] = (neibdata)val; rb = k + 1u; }
-		else { bdirect = true; column[(size_t)(p.neibboundpos - k)*p.stride] = (neibdata)val; }
-	};
-	// rows every walking lane has filled -> global, one 128-B line per row (wave-uniform control)
-	auto flush = [&](bool walking) {
-		const uint32_t mf = wave_min_u32(walking ? sf : 0xFFFFFFFFu);
-		if (mf != 0xFFFFFFFFu) {
-			const uint32_t to = min(mf, fbase + NEIB_FRING);
-			for (uint32_t r = fbase; r < to; ++r) {
-				const neibdata v = fring[r % NEIB_FRING][lane];
-				if (r < rf) column[(size_t)r*p.stride] = v;
-			}
-			fbase = max(fbase, to);
-			const uint32_t mb = wave_min_u32(walking ? sb : 0xFFFFFFFFu);
-			const uint32_t tob = min(mb, bbase + NEIB_BRING);
-			for (uint32_t k = bbase; k < tob; ++k) {
-				const neibdata v = bring[k % NEIB_BRING][lane];
-				if (k < rb) column[(size_t)(p.neibboundpos - k)*p.stride] = v;
-			}
-			bbase = max(bbase, tob);
-		}
-	};
+	NeibRing<NEIB_FRING, NEIB_BRING> ring;
+	ring.init(sRing[threadIdx.x >> 6], column, p.stride, p.neibboundpos, lane);
 
 	particleinfo info = make_ushort4(0, 0, 0, 0);
 	float4 pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -472,7 +498,8 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	// boundary particles never list non-fluid neighbours with LJ/DYN boundaries (:596-607)
 	const bool fluidOnly = boundary && (p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY);
 
-	if (wave_max_u32(walking ? 1u : 0u))
+	const unsigned long long wmask = __builtin_amdgcn_ballot_w64(walking);
+	if (wmask)
 	for (int z = -1; z <= 1; z++) for (int y = -1; y <= 1; y++) for (int x = -1; x <= 1; x++) {
 		int gx = gridPos.x, gy = gridPos.y, gz = gridPos.z;
 		bool valid = walking;
@@ -500,22 +527,34 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 				float4 cp[NEIB_MLP];
 #pragma unroll
 				for (int u = 0; u < NEIB_MLP; ++u) cp[u] = posArray[min(j0 + (uint32_t)u, fluidEnd - 1u)];
+				// branch-free: the scan is instruction-issue bound and every divergent `if` costs 3-4 scalar
+				// instructions of exec-mask bookkeeping per wave (PMC: 1.5 scalar per vector instruction before).
+				// The distance test comes first in the && chain so that the compiler keeps the arithmetic out
+				// of a conditional block; the rare direct stores share one branch per batch.
+				float r2[NEIB_MLP];
+#pragma unroll
+				for (int u = 0; u < NEIB_MLP; ++u) {
+					const float rx = px - cp[u].x, ry = py - cp[u].y, rz = pz - cp[u].z;
+					r2[u] = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
+				}
+				uint32_t dslot[NEIB_MLP], dval[NEIB_MLP], dmask = 0;
 #pragma unroll
 				for (int u = 0; u < NEIB_MLP; ++u) {
 					const uint32_t neib_index = j0 + (uint32_t)u;
-					if (neib_index >= fluidEnd || neib_index == index || !is_active_w(cp[u].w)) continue;
-					const float rx = px - cp[u].x, ry = py - cp[u].y, rz = pz - cp[u].z;
-					const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
-					if (r2 < sqinfluenceradius) {
-						const uint32_t offset = nf;       // neibListOffset(PT_FLUID)
-						nf++;
-						if (!too_many_neibs(p, nf, nb, nv, PT_FLUID)) {
-							const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
-							store_f(offset, (neib_index - bucketStart) + enc);
-							sf = nf;
-							encode_cell = false;
-						}
-					}
+					const bool acc = (r2[u] < sqinfluenceradius) && (neib_index < fluidEnd) && (neib_index != index) &&
+						is_active_w(cp[u].w);
+					const uint32_t offset = nf;       // neibListOffset(PT_FLUID)
+					nf += acc ? 1u : 0u;
+					const bool ok = acc && !too_many_neibs(p, nf, nb, nv, PT_FLUID);
+					const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
+					dslot[u] = offset; dval[u] = (neib_index - bucketStart) + enc;
+					dmask |= ring.store_f_sel(offset, dval[u], ok) ? (1u << u) : 0u;
+					ring.sf = ok ? nf : ring.sf;
+					encode_cell = encode_cell && !ok;
+				}
+				if (dmask) {
+#pragma unroll
+					for (int u = 0; u < NEIB_MLP; ++u) if (dmask & (1u << u)) ring.store_direct(dslot[u], dval[u]);
 				}
 			}
 			// --- non-fluid tail (boundary / vertex / testpoint candidates): the reference's loop as is ---
@@ -539,24 +578,24 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 					if (!too_many_neibs(p, nf, nb, nv, neib_type)) {
 						const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
 						const uint32_t val = (neib_index - bucketStart) + enc;
-						if (neib_type == PT_FLUID) { store_f(num, val); sf = nf; }
-						else if (neib_type == PT_BOUNDARY) { store_b(num, val); sb = nb; }
+						if (neib_type == PT_FLUID) { ring.store_f(num, val); ring.sf = nf; }
+						else if (neib_type == PT_BOUNDARY) { ring.store_b(num, val); ring.sb = nb; }
 						else column[(size_t)neib_list_offset(p, num, neib_type)*p.stride] = (neibdata)val;
 						encode_cell = false;
 					}
 				}
 			}
 		}
-		flush(walking);
+		ring.flush(walking, wmask);
 	}
 
 	// terminators (every particle below particleRangeEnd gets them, walking or not), then what is left in the rings
 	if (inRange) {
 		bool overflow = too_many_neibs(p, nf, nb, nv, PT_FLUID);
 		if (overflow) column[(size_t)p.neibboundpos*p.stride] = NEIBS_END;
-		else store_f(nf, NEIBS_END);
+		else ring.store_f(nf, NEIBS_END);
 		overflow |= too_many_neibs(p, nf, nb, nv, PT_BOUNDARY);
-		if (!overflow) store_b(nb, NEIBS_END);
+		if (!overflow) ring.store_b(nb, NEIBS_END);
 		if (overflow) {
 			const int pid = (int)info_id(info);
 			if (atomicCAS(&counters->hasTooManyNeibs, -1, pid) == -1) {
@@ -564,17 +603,7 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 			}
 		}
 	}
-	{
-		const uint32_t tf = wave_max_u32(rf), tb = wave_max_u32(rb);
-		for (uint32_t r = fbase; r < tf; ++r) {
-			const neibdata v = fring[r % NEIB_FRING][lane];
-			if (r < rf) column[(size_t)r*p.stride] = v;
-		}
-		for (uint32_t k = bbase; k < tb; ++k) {
-			const neibdata v = bring[k % NEIB_BRING][lane];
-			if (k < rb) column[(size_t)(p.neibboundpos - k)*p.stride] = v;
-		}
-	}
+	ring.finish();
 
 	// neibcount: per-block max / total, one atomic pair per wave
 	uint32_t total = nf + nb + nv;
@@ -795,11 +824,6 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 	SPHX_HIP(hipMemcpyAsync(ctx->cell_fluid_end, cellStart, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
 	cell_fluid_end_kernel<<<div_up_u(numParticles, 256), 256, 0, st>>>(ctx->cell_fluid_end, hash, (const particleinfo*)info, numParticles);
 	SPHX_LAUNCH_CHECK("cell_fluid_end_kernel");
-	build_neibs_kernel<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
-		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
-		particleRangeEnd, sqinfluenceradius, ctx->counters_dev, ctx->tile_debug);
-	SPHX_LAUNCH_CHECK("build_neibs_kernel");
-
 	// tiling of the sorted particles for the forces engine (forces.hip "Tiled path")
 	ctx->tiles_built = false;
 	if (ctx->tiles && !ctx->disable_tiles) {
@@ -815,6 +839,10 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		ctx->tiles_cellstart = cellStart;
 		ctx->tiles_neibslist = neibsList;
 	}
+	build_neibs_kernel<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
+		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
+		particleRangeEnd, sqinfluenceradius, ctx->counters_dev);
+	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	return SPHX_OK;
 }
 
