@@ -543,6 +543,33 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 #undef SPHX_RING_STEP
 }
 
+// which particle of a tile a thread owns (from the tile descriptor alone)
+struct TileHome { uint32_t index, li, firstMin, hcTot; int hrow; bool inRange, mine; };
+
+__device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t tid, uint32_t fromParticle, uint32_t toParticle)
+{
+	TileHome h;
+	const uint32_t c0 = d[8], c1n = d[9], c2n = d[10], c3n = d[11];
+	h.hcTot = c0 + c1n + c2n + c3n;
+	uint32_t firstMin = 0xFFFFFFFFu, lastMax = 0u;
+#pragma unroll
+	for (int r = 0; r < TILE_HROWS; ++r)
+		if (d[8 + r]) { firstMin = min(firstMin, d[4 + r]); lastMax = max(lastMax, d[4 + r] + d[8 + r]); }
+	h.firstMin = firstMin;
+	h.inRange = !(firstMin >= toParticle || lastMax <= fromParticle);
+	int hrow = 0; uint32_t hoff = tid;
+	if (hoff >= c0) { hoff -= c0; hrow = 1; if (hoff >= c1n) { hoff -= c1n; hrow = 2; if (hoff >= c2n) { hoff -= c2n; hrow = 3; } } }
+	const uint32_t hfirst = (hrow == 0) ? d[4] : (hrow == 1) ? d[5] : (hrow == 2) ? d[6] : d[7];
+	h.hrow = hrow;
+	h.index = hfirst + hoff;
+	h.mine = h.inRange && tid < h.hcTot && h.index >= fromParticle && h.index < toParticle;
+	h.li = h.mine ? h.index : (firstMin != 0xFFFFFFFFu ? firstMin : 0u);   // idle lanes read a valid row
+	return h;
+}
+
+// a thread's own rows and the first batches of its neighbour list, requested one tile ahead
+struct TileOwn { particleinfo info; float4 pos, vel, aux; uint32_t hash; ListWindow lwF; uint32_t lwB0[TILE_NB]; };
+
 template<int KERNEL, int TURB, bool COLAGROSSI>
 __global__ void __launch_bounds__(TILE_THREADS, 2)
 forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
@@ -635,6 +662,21 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		window_cell(p, a.cellStart, cellEnd, (int)dc[0], (int)dc[1], (int)dc[2], (int)dc[3], wr, wcol, wStart, wCnt);
 
 	__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): first descriptor and window extents
+	// own rows and first list batches: always requested one tile ahead (here: for the first tile), consumed
+	// after the window barrier of their tile.  Their ~28 vector memory instructions per thread cost ~3 us of
+	// address-unit issue per tile, which now overlaps the previous tile's pair loop instead of sitting at the
+	// head of the staging chain.
+	auto request_own = [&](const TileHome &h, TileOwn &o) {
+		o.info = a.info[h.li]; o.pos = a.pos[h.li]; o.vel = a.vel[h.li]; o.hash = a.hash[h.li]; o.aux = a.aux[h.li];
+		const uint32_t vo = h.li*2u;   // byte offset of this particle inside every list row (n < 2^31)
+		preload_list(p, listRows, vo, 0, o.lwF);
+		// boundary section: most particles have none, so only its first batch is requested up front; the walk
+		// requests the rest when a wave does have boundary neighbours
+		load_list_u(p, listRows, vo, 1, 0, o.lwB0);
+	};
+	TileHome hc = tile_home(dc, tid, a.fromParticle, a.toParticle);
+	TileOwn own;
+	request_own(hc, own);
 	const bool prof = a.prof != nullptr && tid == 0;
 	unsigned long long tBegin = 0, t0 = 0, tA = 0, tB = 0, accStage = 0, accPairs = 0, accTail = 0, s1 = 0, s2 = 0, s3 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 	if (prof) tBegin = wall_clock64();
@@ -643,37 +685,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		uint32_t drawn = 0;
 		if (tid == 0) drawn = atomicAdd(tileCtl + 4 + src, 1u);   // the tile after next; consumed after the window barrier
 		const int ca = (int)dc[2], ncells = (int)dc[3];
-		const uint32_t c0 = dc[8], c1n = dc[9], c2n = dc[10], c3n = dc[11];
-		const uint32_t hcTot = c0 + c1n + c2n + c3n;
-		uint32_t firstMin = 0xFFFFFFFFu, lastMax = 0u;
-#pragma unroll
-		for (int r = 0; r < TILE_HROWS; ++r)
-			if (dc[8 + r]) { firstMin = min(firstMin, dc[4 + r]); lastMax = max(lastMax, dc[4 + r] + dc[8 + r]); }
-		const bool inRange = !(firstMin >= a.toParticle || lastMax <= a.fromParticle);
+		const uint32_t firstMin = hc.firstMin;
+		const bool inRange = hc.inRange, mine = hc.mine;
+		const int hrow = hc.hrow;
+		const uint32_t index = hc.index;
 		const bool pairs = (dc[13] & 1u) && (a.dbg & 3) != 1;   // no fluid anywhere in the window: nothing interacts
-
-		// 0. own rows and the first two list batches of both sections: issued now, consumed after the
-		//    window is staged, so their HBM latency overlaps the staging
-		int hrow = 0; uint32_t hoff = tid;
-		if (hoff >= c0) { hoff -= c0; hrow = 1; if (hoff >= c1n) { hoff -= c1n; hrow = 2; if (hoff >= c2n) { hoff -= c2n; hrow = 3; } } }
-		const uint32_t hfirst = (hrow == 0) ? dc[4] : (hrow == 1) ? dc[5] : (hrow == 2) ? dc[6] : dc[7];
-		const uint32_t index = hfirst + hoff;
-		const bool mine = inRange && tid < hcTot && index >= a.fromParticle && index < a.toParticle;
-		const uint32_t li = mine ? index : (firstMin != 0xFFFFFFFFu ? firstMin : 0u);   // idle lanes read a valid row
-		const particleinfo info = a.info[li];
-		const float4 pos = a.pos[li];
-		// vmcnt is in-order: waiting for ANY of these loads before the window barrier would wait for all of them
-		// (an HBM round trip) ahead of the DMA issue, so nothing below is consumed until the window has landed
-		const float4 rawVel = a.vel[li];
-		const uint32_t rawHash = a.hash[li];
-		const float4 rawAux = a.aux[li];
-		ListWindow lwF, lwB;
-		const uint32_t voff = li*2u;   // byte offset of this particle inside every list row (n < 2^31)
-		preload_list(p, listRows, voff, 0, lwF);
-		// boundary section: most particles have none, so only its first batch is requested up front (every
-		// vector memory instruction costs ~20 issue cycles of the CU's address unit; 8 waves x 40 of them
-		// were 3 us per tile); the walk requests the rest when a wave does have boundary neighbours
-		load_list_u(p, listRows, voff, 1, 0, lwB.q[0]);
+		const uint32_t voff = hc.li*2u;
 
 		lds_barrier();   // the previous tile's readers are done with LDS
 		const uint32_t nextTile = sTileQ[1];
@@ -756,12 +773,23 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			const uint32_t h = window_cell_hash(p, (int)dn[0], (int)dn[1], (int)dn[2], (int)dn[3], wr, wcol);
 			if (h != 0xFFFFFFFFu) { nCS = a.cellStart[h]; nCE = cellEnd[h]; }
 		}
+		TileHome hn = hc;
+		TileOwn ownNext;
+		if (haveNext) {
+			hn = tile_home(dn, tid, a.fromParticle, a.toParticle);
+			request_own(hn, ownNext);
+		}
+		const particleinfo info = own.info;
+		const float4 pos = own.pos;
 		Self s;
-		s.pos = pos; s.vel = rawVel;
-		s.gridPos = grid_pos_from_hash(p, rawHash & CELLTYPE_BITMASK);
+		s.pos = pos; s.vel = own.vel;
+		s.gridPos = grid_pos_from_hash(p, own.hash & CELLTYPE_BITMASK);
 		s.fl = 0u;
-		s.p_precalc = rawAux.x; s.sspeed = rawAux.y; s.P = rawAux.z; s.rho = rawAux.w;
-		s.inv_rho = fast_rcp(rawAux.w);
+		s.p_precalc = own.aux.x; s.sspeed = own.aux.y; s.P = own.aux.z; s.rho = own.aux.w;
+		s.inv_rho = fast_rcp(own.aux.w);
+		ListWindow lwB;
+#pragma unroll
+		for (int k = 0; k < TILE_NB; ++k) lwB.q[0][k] = own.lwB0[k];
 
 		// 3. pair loop for the tile's own particles (<= 512, one per thread); wave-uniform control
 		float cfl_term = 0.0f;
@@ -785,7 +813,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
 			const bool take0 = active && (isFluid || isDynBound), take1 = active && isFluid && dyn;
 			walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
-				sPos, sVel, sAux, 0, take0, momentum, true, lwF, TILE_AHEAD, force);
+				sPos, sVel, sAux, 0, take0, momentum, true, own.lwF, TILE_AHEAD, force);
 			if (wave_any(take1))
 				walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
 					sPos, sVel, sAux, 1, take1, momentum, false, lwB, 1, force);
@@ -822,6 +850,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 #pragma unroll
 		for (int k = 0; k < TILE_DESC; ++k) dc[k] = dn[k];
 		wStart = nStart; wCnt = nCnt;
+		hc = hn; own = ownNext;
 	}
 	if (tid == 0) tile_group_done(tileCtl);
 	if (prof) {
