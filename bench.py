@@ -99,12 +99,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                              % (args.gpus, args.gpus))
+    if os.environ.get("SPHX_BENCH_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("SPHX_BENCH_BACKEND", "nccl")   # "gloo": test rigs with several ranks on ONE GPU
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     dp = DamBreak3D.deltap_for(args.particles, obstacle=not args.no_obstacle)
     lin = "xzy" if world > 1 else "yzx"   # multi-GPU: split along Y like DamBreak3D::fillDeviceMap, COORD3 = y
