@@ -1,0 +1,274 @@
+// filters.hip -- density filter engines for gfx950: Shepard and MLS corrections of rho~.
+// Replaces CUDAFilterEngine<SHEPARD_FILTER|MLS_FILTER> (GPUSPH src/cuda/forces.cu:1008-1147) and the kernels
+// shepardDevice / MlsDevice (src/cuda/forces_kernel.cu:418-505, 508-721).
+//
+// Filters run every N-th iteration (WaveTank: Shepard every 20), so they are not on the roofline path; they are
+// written for fidelity: compiled without FMA contraction, IEEE division and sqrt, the reference's operation
+// order, so that the result is bit-identical to the CPU oracle for the polynomial kernels.
+#include "sphx_internal.h"
+#include <cfloat>
+
+struct FilterArgs {
+	float4 *newVel;
+	const float4 *pos, *vel;
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+};
+
+// W<kerneltype>(r, h): src/cuda/sph_core.cu:66-137
+template<int KERNEL>
+__device__ __forceinline__ float kernel_W(const DevParams &p, float r)
+{
+	const float R = r/p.slength;
+	float val;
+	if (KERNEL == SPHX_CUBICSPLINE) {
+		if (R < 1) val = 1.0f - 1.5f*R*R + 0.75f*R*R*R;
+		else val = 0.25f*(2.0f - R)*(2.0f - R)*(2.0f - R);
+	} else if (KERNEL == SPHX_QUADRATIC) {
+		val = 0.25f*R*R - R + 1.0f;
+	} else if (KERNEL == SPHX_WENDLAND) {
+		val = 1.0f - 0.5f*R;
+		val *= val;
+		val *= val;
+		val *= 1.0f + 2.0f*R;
+	} else {
+		val = expf(-R*R);
+		val -= p.wsub_gaussian;
+	}
+	return val*p.wcoeff;
+}
+
+// neiblist_iterator (src/cuda/neibs_iteration.cuh:83-360) over one section of a particle's list:
+// f(neib_index, relPos.x, relPos.y, relPos.z) for every stored neighbour, in list order
+template<int NPTYPE, class F>
+__device__ __forceinline__ void for_each_neib(const DevParams &p, const FilterArgs &a, uint32_t index,
+	const float4 &pos, const int3 &gridPos, F &&f)
+{
+	const size_t stride = p.stride;
+	size_t loc = (NPTYPE == PT_FLUID) ? (size_t)index : (size_t)p.neibboundpos*stride + index;
+	float pcx = 0.0f, pcy = 0.0f, pcz = 0.0f;
+	uint32_t cell_base = 0;
+	for (;;) {
+		uint32_t nd = a.neibsList[loc];
+		if (nd == NEIBS_END) break;
+		loc = (NPTYPE == PT_FLUID) ? loc + stride : loc - stride;
+		if (nd >= CELLNUM_ENCODED) {
+			const int c = (int)(nd >> CELLNUM_SHIFT) - 1;
+			nd &= NEIBINDEX_MASK;
+			const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
+			pcx = fmaf(-(float)(cx - 1), p.cs[0], pos.x);
+			pcy = fmaf(-(float)(cy - 1), p.cs[1], pos.y);
+			pcz = fmaf(-(float)(cz - 1), p.cs[2], pos.z);
+			cell_base = a.cellStart[grid_hash_periodic(p, gridPos.x + cx - 1, gridPos.y + cy - 1, gridPos.z + cz - 1)];
+		}
+		const uint32_t j = cell_base + nd;
+		const float4 npos = a.pos[j];
+		f(j, npos, pcx - npos.x, pcy - npos.y, pcz - npos.z);
+	}
+}
+
+template<int KERNEL>
+__global__ void __launch_bounds__(128)
+shepard_kernel(DevParams p, FilterArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	const float4 pos = a.pos[index];
+	if (!is_active_w(pos.w)) return;          // inactive: nothing is written (as the reference)
+	float4 vel = a.vel[index];
+	if (PART_TYPE(info) != PT_FLUID) { a.newVel[index] = vel; return; }
+	const uint32_t fl = FLUID_NUM(info);
+	float temp1 = pos.w*kernel_W<KERNEL>(p, 0.0f);
+	float temp2 = temp1/((vel.w + 1.0f)*p.rho0[fl]);
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	auto pair = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		const float neib_rho = (a.vel[j].w + 1.0f)*p.rho0[FLUID_NUM(a.info[j])];
+		if (r < p.influenceradius) {
+			const float w = kernel_W<KERNEL>(p, r)*npos.w;
+			temp1 += w;
+			temp2 += w/neib_rho;
+		}
+	};
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, pair);
+	if (p.boundarytype == SPHX_DYN_BOUNDARY)
+		for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, pair);
+	vel.w = (temp1/temp2)/p.rho0[fl] - 1.0f;
+	a.newVel[index] = vel;
+}
+
+// symmetric 4x4 tensor helpers: src/cuda/tensor.cu:65-100 (det), :240-282 (dot, ddot, adjugate_row1)
+struct SymTensor4 { float xx, xy, xz, xw, yy, yz, yw, zz, zw, ww; };
+
+__device__ __forceinline__ float st4_det(const SymTensor4 &T)
+{
+	float ret = 0, M = 0;
+	M += T.xx*(T.yy*T.zz - T.yz*T.yz);
+	M -= T.xy*(T.xy*T.zz - T.xz*T.yz);
+	M += T.xz*(T.xy*T.yz - T.xz*T.yy);
+	ret += M*T.ww;
+	M = 0;
+	M += T.xx*(T.yy*T.zw - T.yz*T.yw);
+	M -= T.xy*(T.xy*T.zw - T.xz*T.yw);
+	M += T.xw*(T.xy*T.yz - T.xz*T.yy);
+	ret -= M*T.zw;
+	M = 0;
+	M += T.xx*(T.yz*T.zw - T.zz*T.yw);
+	M -= T.xz*(T.xy*T.zw - T.xz*T.yw);
+	M += T.xw*(T.xy*T.zz - T.xz*T.yz);
+	ret += M*T.yw;
+	M = 0;
+	M += T.xy*(T.yz*T.zw - T.zz*T.yw);
+	M -= T.xz*(T.yy*T.zw - T.yz*T.yw);
+	M += T.xw*(T.yy*T.zz - T.yz*T.yz);
+	ret -= M*T.xw;
+	return ret;
+}
+__device__ __forceinline__ float4 st4_adjugate_row1(const SymTensor4 &T)
+{
+	return make_float4(
+		T.yy*T.zz*T.ww + T.yz*T.zw*T.yw + T.yw*T.yz*T.zw - T.yy*T.zw*T.zw - T.yz*T.yz*T.ww - T.yw*T.zz*T.yw,
+		T.xy*T.zw*T.zw + T.yz*T.xz*T.ww + T.yw*T.zz*T.xw - T.xy*T.zz*T.ww - T.yz*T.zw*T.xw - T.yw*T.xz*T.zw,
+		T.xy*T.yz*T.ww + T.yy*T.zw*T.xw + T.yw*T.xz*T.yw - T.xy*T.zw*T.yw - T.yy*T.xz*T.ww - T.yw*T.yz*T.xw,
+		T.xy*T.zz*T.yw + T.yy*T.xz*T.zw + T.yz*T.yz*T.xw - T.xy*T.yz*T.zw - T.yy*T.zz*T.xw - T.yz*T.xz*T.yw);
+}
+__device__ __forceinline__ float4 st4_dot(const SymTensor4 &T, const float4 &v)
+{
+	return make_float4(
+		T.xx*v.x + T.xy*v.y + T.xz*v.z + T.xw*v.w,
+		T.xy*v.x + T.yy*v.y + T.yz*v.z + T.yw*v.w,
+		T.xz*v.x + T.yz*v.y + T.zz*v.z + T.zw*v.w,
+		T.xw*v.x + T.yw*v.y + T.zw*v.z + T.ww*v.w);
+}
+__device__ __forceinline__ float st4_ddot(const SymTensor4 &T, const float4 &v)
+{
+	return T.xx*v.x*v.x + T.yy*v.y*v.y + T.zz*v.z*v.z + T.ww*v.w*v.w +
+		2*((T.xy*v.y + T.xw*v.w)*v.x + (T.yz*v.z + T.yw*v.w)*v.y + (T.xz*v.x + T.zw*v.w)*v.z);
+}
+__device__ __forceinline__ float f4_dot(const float4 &a, const float4 &b) { return a.x*b.x + a.y*b.y + a.z*b.z + a.w*b.w; }
+__device__ __forceinline__ float4 f4_scale(const float4 &a, float s) { return make_float4(a.x*s, a.y*s, a.z*s, a.w*s); }
+__device__ __forceinline__ float f4_hypot(const float4 &v)   // src/vector_math.h:1231-1240
+{
+	const float pm = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+	if (!pm) return 0;
+	const float4 w = f4_scale(v, 1.0f/pm);
+	return pm*sqrtf(f4_dot(w, w));
+}
+
+template<int KERNEL>
+__global__ void __launch_bounds__(128)
+mls_kernel(DevParams p, FilterArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	const float4 pos = a.pos[index];
+	if (!is_active_w(pos.w)) return;
+	float4 vel = a.vel[index];
+	const uint32_t fl = FLUID_NUM(info);
+	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
+	const float inv_h = 1.0f/p.slength;
+	SymTensor4 mls = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+	mls.xx = kernel_W<KERNEL>(p, 0.0f)*pos.w/((vel.w + 1.0f)*p.rho0[fl]);
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	auto first = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		const float neib_rho = (a.vel[j].w + 1.0f)*p.rho0[FLUID_NUM(a.info[j])];
+		if (r < p.influenceradius) {
+			const float w = kernel_W<KERNEL>(p, r)*npos.w/neib_rho;   // Wij*Vj
+			const float sx = rx*inv_h, sy = ry*inv_h, sz = rz*inv_h;     // relPos/slength
+			mls.xx += w;
+			mls.xy += sx*w; mls.xz += sy*w; mls.xw += sz*w;
+			mls.yy += sx*sx*w; mls.yz += sx*sy*w; mls.yw += sx*sz*w;
+			mls.zz += sy*sy*w; mls.zw += sy*sz*w; mls.ww += sz*sz*w;
+		}
+	};
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, first);
+	if (dyn) for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, first);
+
+	// M B = E, E = (1,0,0,0): adjugate start + conjugate-residual refinement (forces_kernel.cu:602-656)
+	const float4 E = make_float4(1, 0, 0, 0);
+	const float D = st4_det(mls);
+	float4 B;
+	if (fabsf(D) < FLT_EPSILON) {
+		SymTensor4 me = mls;
+		const float eps = fabsf(D) + FLT_EPSILON;
+		me.xx += eps; me.yy += eps; me.zz += eps; me.ww += eps;
+		const float De = st4_det(me);
+		B = f4_scale(st4_adjugate_row1(me), 1.0f/De);
+	} else {
+		B = f4_scale(st4_adjugate_row1(mls), 1.0f/D);
+	}
+	for (unsigned steps = 0; steps < 32; ++steps) {
+		const float lenB = f4_hypot(B);
+		const float4 MdotB = st4_dot(mls, B);
+		const float4 residual = make_float4(E.x - MdotB.x, E.y - MdotB.y, E.z - MdotB.z, E.w - MdotB.w);
+		const float num = st4_ddot(mls, residual);
+		const float4 Mp = st4_dot(mls, residual);
+		const float den = f4_dot(Mp, Mp);
+		const float4 corr = f4_scale(residual, num/den);
+		const float lencorr = f4_hypot(corr);
+		if (f4_hypot(residual) < lenB*FLT_EPSILON) break;
+		if (lencorr < 2*lenB*FLT_EPSILON) break;
+		B.x += corr.x; B.y += corr.y; B.z += corr.z; B.w += corr.w;
+	}
+	B.y /= p.slength; B.z /= p.slength; B.w /= p.slength;
+
+	float rho = B.x*kernel_W<KERNEL>(p, 0.0f)*pos.w;
+	auto second = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		if (r < p.influenceradius && (dyn || PART_TYPE(a.info[j]) == PT_FLUID)) {
+			const float w = kernel_W<KERNEL>(p, r)*npos.w;   // rho_j*Wij*Vj = mj*Wij
+			rho += (B.x + B.y*rx + B.z*ry + B.w*rz)*w;
+		}
+	};
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, second);
+	if (dyn) for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, second);
+	vel.w = rho/p.rho0[fl] - 1.0f;
+	a.newVel[index] = vel;
+}
+
+template<int KERNEL>
+static void launch_filter(int filtertype, dim3 grid, hipStream_t st, const DevParams &p, const FilterArgs &a)
+{
+	if (filtertype == SPHX_SHEPARD_FILTER) shepard_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a);
+	else mls_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a);
+}
+
+extern "C" int sphx_filter_process(sphx_ctx *ctx, int filtertype, void *newVel,
+	const void *pos, const void *oldVel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float slength, float influenceradius, void *stream)
+{
+	(void)numParticles;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_filter_process: constants not set");
+	SPHX_REQUIRE(filtertype == SPHX_SHEPARD_FILTER || filtertype == SPHX_MLS_FILTER, "sphx_filter_process: non-existing filter invoked");
+	SPHX_REQUIRE(newVel && pos && oldVel && info && hash && cellStart && neibsList, "sphx_filter_process: missing buffer");
+	SPHX_REQUIRE(newVel != oldVel, "sphx_filter_process: the filter reads neighbours' old densities, it cannot run in place");
+	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
+		"sphx_filter_process: slength/influenceradius differ from set_constants");
+	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY && ctx->dev.boundarytype != SPHX_LJ_BOUNDARY)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_filter_process: only LJ/DYN boundaries are built");
+	if (!particleRangeEnd) return SPHX_OK;
+	FilterArgs a;
+	a.newVel = (float4*)newVel; a.pos = (const float4*)pos; a.vel = (const float4*)oldVel;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.numParticles = particleRangeEnd;
+	const dim3 grid(div_up_u(particleRangeEnd, 128));
+	hipStream_t st = (hipStream_t)stream;
+	switch (ctx->dev.kerneltype) {
+	case SPHX_CUBICSPLINE: launch_filter<SPHX_CUBICSPLINE>(filtertype, grid, st, ctx->dev, a); break;
+	case SPHX_QUADRATIC:   launch_filter<SPHX_QUADRATIC>(filtertype, grid, st, ctx->dev, a); break;
+	case SPHX_WENDLAND:    launch_filter<SPHX_WENDLAND>(filtertype, grid, st, ctx->dev, a); break;
+	case SPHX_GAUSSIAN:    launch_filter<SPHX_GAUSSIAN>(filtertype, grid, st, ctx->dev, a); break;
+	default: return sphx_set_error(SPHX_ERR_INVALID, "sphx_filter_process: invalid kernel type");
+	}
+	SPHX_LAUNCH_CHECK("shepard_kernel/mls_kernel");
+	return SPHX_OK;
+}

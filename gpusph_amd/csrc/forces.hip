@@ -678,7 +678,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	TileOwn own;
 	request_own(hc, own);
 	const bool prof = a.prof != nullptr && tid == 0;
-	unsigned long long tBegin = 0, t0 = 0, tA = 0, tB = 0, accStage = 0, accPairs = 0, accTail = 0, s1 = 0, s2 = 0, s3 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+	unsigned long long tBegin = 0, t0 = 0, tA = 0, tB = 0, accStage = 0, accPairs = 0, accTail = 0, s1 = 0, s2 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 	if (prof) tBegin = wall_clock64();
 	for (;;) {
 		if (prof) t0 = wall_clock64();
@@ -699,7 +699,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 #pragma unroll
 			for (int k = 0; k < TILE_DESC; ++k) dn[k] = tiles[(size_t)TILE_DESC*nextTile + k];
 		}
-		if (prof) { s1 = wall_clock64(); s2 = s1; s3 = s1; }
+		if (prof) { s1 = wall_clock64(); s2 = s1; }
 
 		if (inRange && pairs) {
 			// 1. prefix of the window-cell counts within each row (16-lane segmented scans), row extents
@@ -726,7 +726,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				}
 			}
 			lds_barrier();
-			if (prof) { s2 = wall_clock64(); s3 = s2; }
+			if (prof) s2 = wall_clock64();
 			// 2. row bases: every wave scans the 16 row totals in its first 16 lanes; then the window DMA, with
 			//    the rows dealt out to the waves (wave w stages rows w, w+8, ...: a row is ~3 chunks of 64 records
 			//    per array, so walking all rows in every wave left most waves idle behind a serial 16-step loop)
@@ -762,7 +762,6 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			}
 			if (tid < TILE_WROWS*TILE_KW) sCellBase[tid] += myRowBase;   // make absolute (own entry)
 		}
-		if (prof) s3 = wall_clock64();
 		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA (and its own rows, list batches) have landed
 		__syncthreads();                      // ... everybody's have; the tables are published
 		if (tid == 0) sTileQ[1] = resolve(drawn);   // read after the first barrier of the next iteration

@@ -63,3 +63,6 @@ LINEARIZATIONS = {
     "yzx": (1, 2, 0), "zxy": (2, 0, 1), "zyx": (2, 1, 0),
 }
 DEFAULT_LINEARIZATION = "yzx"
+
+# FilterType (src/particledefine.h:255-260)
+SHEPARD_FILTER, MLS_FILTER = 0, 1

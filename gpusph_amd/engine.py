@@ -102,6 +102,7 @@ class TimestepEngine:
                                                    z3.ctypes.data, z3.ctypes.data, nb))
         self.sq_nl_radius = float(np.float32(sp.nlSqInfluenceRadius))
         self.last_neibs_info = None
+        self.filters = []            # [(FilterType, frequency)], Problem::addFilter order
         self.profile_forces = None   # list of (start,end) torch events around each forces launch when enabled
 
     # ------------------------------------------------------------------ helpers
@@ -148,6 +149,22 @@ class TimestepEngine:
                                  % (info.hasTooManyNeibs, info.hasMaxNeibs[0], info.hasMaxNeibs[1]))
         return info
 
+    # ------------------------------------------------------------------ density filters
+    def add_filter(self, filtertype, frequency):
+        """ProblemCore::addFilter: run `filtertype` every `frequency` iterations (src/ProblemCore.h addFilter)."""
+        self.filters.append((int(filtertype), int(frequency)))
+
+    def apply_filter(self, filtertype):
+        """FILTER_CALL phase (src/integrators/PredictorCorrectorIntegrator.cc:831-859): read the unfiltered
+        velocities, write the filtered ones, swap the two VEL buffers."""
+        L, h, s = self.lib, self.ctx.handle, self._stream()
+        p = capi.ptr
+        n = self.n
+        capi.check(L.sphx_filter_process(h, int(filtertype), p(self.vel2), p(self.pos), p(self.vel), p(self.info), p(self.hash),
+                                         p(self.cellStart), p(self.neibslist), n, n, self.params.slength,
+                                         self.params.influenceradius, s))
+        self.vel, self.vel2 = self.vel2, self.vel
+
     # ------------------------------------------------------------------ forces / euler
     def _forces(self, pos, vel, step, combine_min):
         L, h, s = self.lib, self.ctx.handle, self._stream()
@@ -186,6 +203,12 @@ class TimestepEngine:
         """one full predictor-corrector time step; no host synchronisation."""
         if self.iterations % self.sp.buildneibsfreq == 0:
             self.build_neibs()
+        # filters run after the neighbour phase of every iteration > 0 whose number their frequency divides
+        # (PredictorCorrector::next_phase, src/integrators/PredictorCorrectorIntegrator.cc:1011-1041)
+        if self.iterations > 0:
+            for ftype, freq in self.filters:
+                if self.iterations % freq == 0:
+                    self.apply_filter(ftype)
         # predictor: forces(step n) -> n* = n + dt/2 f
         self._forces(self.pos, self.vel, 1, 0)
         self._euler(1, 0.5)

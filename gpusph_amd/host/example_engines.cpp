@@ -19,6 +19,7 @@ struct DumpHeader {
 	int32_t rb_cgGridPos[3];
 	float rb_cgPos[3];
 	int32_t rb_firstindex;
+	int32_t filter_type, filter_freq;   // density filter (FilterType) every filter_freq iterations; freq 0 = none
 	sphx_params params;
 };
 
@@ -110,6 +111,9 @@ int main(int argc, char **argv)
 		uint *d_newNum = nullptr;
 		hip_throw(hipMalloc((void**)&d_newNum, 4), "hipMalloc");
 
+		std::unique_ptr<AbstractFilterEngine> filterEngine;
+		if (h.filter_freq > 0) filterEngine.reset(fw.newFilterEngine((FilterType)h.filter_type, h.filter_freq));
+
 		BufferList *cur = &a, *oth = &b;
 		uint n = n0;
 		float dt = h.dt;
@@ -126,6 +130,12 @@ int main(int argc, char **argv)
 				neibsEngine->buildNeibsList(*cur, *cur, n, n, gridCells, h.nlSqInfluenceRadius, h.nlSqInfluenceRadius);
 				TimingInfo ti; neibsEngine->getinfo(ti);
 				if (ti.hasTooManyNeibs >= 0) throw std::runtime_error("too many neighbours");
+			}
+			// FILTER_CALL + SWAP_STATE_BUFFERS(BUFFER_VEL) (src/integrators/PredictorCorrectorIntegrator.cc:831-859,1011-1041)
+			if (filterEngine && it > 0 && it % filterEngine->frequency() == 0) {
+				filterEngine->process(*cur, *oth, n, n, (float)sp.slength, (float)sp.influenceRadius);
+				std::shared_ptr<AbstractBuffer> filtered = (*oth)[BUFFER_VEL], unfiltered = (*cur)[BUFFER_VEL];
+				cur->add(BUFFER_VEL, filtered); oth->add(BUFFER_VEL, unfiltered);
 			}
 			float dts[2];
 			for (int step = 1; step <= 2; ++step) {

@@ -268,6 +268,22 @@ public:
 		const RunMode run_mode) = 0;
 };
 
+// src/engine_filter.h:41-78
+enum FilterType { FIRST_FILTER = 0, SHEPARD_FILTER = FIRST_FILTER, MLS_FILTER, INVALID_FILTER };   // src/particledefine.h:255-260
+
+class AbstractFilterEngine {
+	uint m_frequency;   // frequency of the filter (iterations)
+public:
+	explicit AbstractFilterEngine(uint _frequency) : m_frequency(_frequency) {}
+	virtual ~AbstractFilterEngine() {}
+	void set_frequency(uint _frequency) { m_frequency = _frequency; }
+	uint frequency() const { return m_frequency; }
+	virtual void setconstants() = 0;
+	virtual void getconstants() = 0;
+	virtual void process(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint particleRangeEnd,
+		float slength, float influenceradius) = 0;
+};
+
 class AbstractIntegrationEngine {
 public:
 	virtual ~AbstractIntegrationEngine() {}
@@ -480,6 +496,26 @@ public:
 	}
 };
 
+// CUDAFilterEngine<filtertype, kerneltype, boundarytype> (src/cuda/forces.cu:1008-1147): the kernel and boundary
+// type are run-time options of the context here, so one class serves both filters
+class HIPFilterEngine : public AbstractFilterEngine {
+	std::shared_ptr<HIPEngineContext> m_c;
+	FilterType m_type;
+public:
+	HIPFilterEngine(std::shared_ptr<HIPEngineContext> c, FilterType type, uint frequency) :
+		AbstractFilterEngine(frequency), m_c(c), m_type(type) {}
+	void setconstants() override {}
+	void getconstants() override {}
+	void process(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint particleRangeEnd,
+		float slength, float influenceradius) override
+	{
+		sphx_throw(sphx_filter_process(m_c->ctx(), (int)m_type, bufwrite.getData<BUFFER_VEL>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			numParticles, particleRangeEnd, slength, influenceradius, nullptr));
+	}
+};
+
 // ---- factory: the engine-owning part of SimFramework (src/simframework.h:65-136) ----
 class HIPSimFramework {
 	std::shared_ptr<HIPEngineContext> m_c;
@@ -495,6 +531,13 @@ public:
 	AbstractForcesEngine *getForcesEngine() { return m_forces.get(); }
 	AbstractViscEngine *getViscEngine() { return m_visc.get(); }
 	AbstractIntegrationEngine *getIntegrationEngine() { return m_integration.get(); }
+	// SimFramework::addFilterEngine -> newFilterEngine (src/cuda/cudasimframework.cu:236-251): caller owns the engine
+	AbstractFilterEngine *newFilterEngine(FilterType filtertype, int frequency)
+	{
+		if (filtertype != SHEPARD_FILTER && filtertype != MLS_FILTER)
+			throw std::runtime_error("Invalid filter type");
+		return new HIPFilterEngine(m_c, filtertype, (uint)frequency);
+	}
 };
 
 #endif // SPHX_HOST_H

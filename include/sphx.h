@@ -57,6 +57,7 @@ enum sphx_boundary    { SPHX_LJ_BOUNDARY = 0, SPHX_MK_BOUNDARY = 1, SPHX_SA_BOUN
 enum sphx_rheology    { SPHX_INVISCID = 0, SPHX_NEWTONIAN = 1 };
 enum sphx_turbulence  { SPHX_LAMINAR_FLOW = 0, SPHX_ARTIFICIAL = 1, SPHX_SPS = 2, SPHX_KEPSILON = 3 };
 enum sphx_runmode     { SPHX_REPACK = 0, SPHX_SIMULATE = 1 };
+enum sphx_filter      { SPHX_SHEPARD_FILTER = 0, SPHX_MLS_FILTER = 1 };   /* FilterType, src/particledefine.h:255-260 */
 #define SPHX_PERIODIC_X 1u
 #define SPHX_PERIODIC_Y 2u
 #define SPHX_PERIODIC_Z 4u
@@ -204,6 +205,16 @@ int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2, float *sps
 	const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd,
 	float deltap, float slength, float influenceradius, void *stream);
+
+/* ---- AbstractFilterEngine (density filters, run every N-th iteration) --------------------- */
+/* process (src/engine_filter.h:69-77, CUDAFilterEngine src/cuda/forces.cu:1008-1147; kernels shepardDevice /
+ * MlsDevice src/cuda/forces_kernel.cu:418-721): newVel = oldVel with rho~ replaced by the Shepard- or
+ * MLS-corrected density (Shepard: fluid particles only, others are copied; inactive particles are not written).
+ * newVel must not alias oldVel. */
+int sphx_filter_process(sphx_ctx *ctx, int filtertype, void *newVel,
+	const void *pos, const void *oldVel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float slength, float influenceradius, void *stream);
 
 /* ---- AbstractIntegrationEngine ------------------------------------------------------------ */
 /* basicstep (src/cuda/euler.cu:329-366).  dt is the step's dt or dt/2 exactly as the

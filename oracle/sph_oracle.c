@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <limits.h>
+#include <float.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -1004,6 +1005,199 @@ void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 			}
 		} while (0);
 		newPos[index] = pos;
+		newVel[index] = vel;
+	}
+}
+
+/* ==== density filters: shepardDevice src/cuda/forces_kernel.cu:418-505, MlsDevice :508-721 ==========
+ * vector helpers follow src/vector_math.h: float4/float = float4*(1.0f/s) (:1093-1097), dot(float4,float4) (:1129-1132),
+ * hypot(float4) (:1231-1240); tensor helpers src/cuda/tensor.cu:65-100 (det), :240-282 (dot, ddot, adjugate_row1). */
+static inline float numerical_density(const orc_params *p, float rho, int i) { return rho/p->rho0[i] - 1.0f; }
+
+void orc_shepard(const orc_params *p, orc_f4 *newVel,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		orc_f4 vel = velArray[index];
+		if (PART_TYPE(info) != PT_FLUID) { newVel[index] = vel; continue; }
+		float temp1 = pos.w*W_c(p->kerneltype, 0.0f, p->slength, wcoeff, wsub);
+		float temp2 = temp1/physical_density(p, vel.w, FLUID_NUM(info));
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		/* for_each_neib2(PT_FLUID, DYN ? PT_BOUNDARY : PT_NONE) */
+		const int last = (p->boundarytype == ORC_DYN_BOUNDARY) ? PT_BOUNDARY : PT_FLUID;
+		for (int ptype = PT_FLUID; ptype <= last; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				if (!isfinite(npos.w)) continue;
+				const float r = sqrtf(rx*rx + ry*ry + rz*rz);   /* length(as_float3(relPos)) */
+				const float neib_rho = physical_density(p, velArray[neib_index].w, FLUID_NUM(infoArray[neib_index]));
+				if (r < p->influenceradius) {
+					const float w = W_c(p->kerneltype, r, p->slength, wcoeff, wsub)*npos.w;
+					temp1 += w;
+					temp2 += w/neib_rho;
+				}
+			}
+		}
+		vel.w = numerical_density(p, temp1/temp2, FLUID_NUM(info));
+		newVel[index] = vel;
+	}
+}
+
+typedef struct { float xx, xy, xz, xw, yy, yz, yw, zz, zw, ww; } symtensor4;
+typedef struct { float x, y, z, w; } f4v;
+
+static float st4_det(const symtensor4 *T)
+{
+	float ret = 0, M = 0;
+	M += T->xx*(T->yy*T->zz - T->yz*T->yz);
+	M -= T->xy*(T->xy*T->zz - T->xz*T->yz);
+	M += T->xz*(T->xy*T->yz - T->xz*T->yy);
+	ret += M*T->ww;
+	M = 0;
+	M += T->xx*(T->yy*T->zw - T->yz*T->yw);
+	M -= T->xy*(T->xy*T->zw - T->xz*T->yw);
+	M += T->xw*(T->xy*T->yz - T->xz*T->yy);
+	ret -= M*T->zw;
+	M = 0;
+	M += T->xx*(T->yz*T->zw - T->zz*T->yw);
+	M -= T->xz*(T->xy*T->zw - T->xz*T->yw);
+	M += T->xw*(T->xy*T->zz - T->xz*T->yz);
+	ret += M*T->yw;
+	M = 0;
+	M += T->xy*(T->yz*T->zw - T->zz*T->yw);
+	M -= T->xz*(T->yy*T->zw - T->yz*T->yw);
+	M += T->xw*(T->yy*T->zz - T->yz*T->yz);
+	ret -= M*T->xw;
+	return ret;
+}
+static f4v st4_adjugate_row1(const symtensor4 *T)
+{
+	f4v r;
+	r.x = T->yy*T->zz*T->ww + T->yz*T->zw*T->yw + T->yw*T->yz*T->zw - T->yy*T->zw*T->zw - T->yz*T->yz*T->ww - T->yw*T->zz*T->yw;
+	r.y = T->xy*T->zw*T->zw + T->yz*T->xz*T->ww + T->yw*T->zz*T->xw - T->xy*T->zz*T->ww - T->yz*T->zw*T->xw - T->yw*T->xz*T->zw;
+	r.z = T->xy*T->yz*T->ww + T->yy*T->zw*T->xw + T->yw*T->xz*T->yw - T->xy*T->zw*T->yw - T->yy*T->xz*T->ww - T->yw*T->yz*T->xw;
+	r.w = T->xy*T->zz*T->yw + T->yy*T->xz*T->zw + T->yz*T->yz*T->xw - T->xy*T->yz*T->zw - T->yy*T->zz*T->xw - T->yz*T->xz*T->yw;
+	return r;
+}
+static f4v st4_dot(const symtensor4 *T, f4v v)
+{
+	f4v r;
+	r.x = T->xx*v.x + T->xy*v.y + T->xz*v.z + T->xw*v.w;
+	r.y = T->xy*v.x + T->yy*v.y + T->yz*v.z + T->yw*v.w;
+	r.z = T->xz*v.x + T->yz*v.y + T->zz*v.z + T->zw*v.w;
+	r.w = T->xw*v.x + T->yw*v.y + T->zw*v.z + T->ww*v.w;
+	return r;
+}
+static float st4_ddot(const symtensor4 *T, f4v v)
+{
+	return T->xx*v.x*v.x + T->yy*v.y*v.y + T->zz*v.z*v.z + T->ww*v.w*v.w +
+		2*((T->xy*v.y + T->xw*v.w)*v.x + (T->yz*v.z + T->yw*v.w)*v.y + (T->xz*v.x + T->zw*v.w)*v.z);
+}
+static float f4v_dot(f4v a, f4v b) { return a.x*b.x + a.y*b.y + a.z*b.z + a.w*b.w; }
+static f4v f4v_scale(f4v a, float s) { f4v r = { a.x*s, a.y*s, a.z*s, a.w*s }; return r; }
+static float f4v_hypot(f4v v)
+{
+	const float pm = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
+	if (!pm) return 0;
+	const f4v w = f4v_scale(v, 1.0f/pm);
+	return pm*sqrtf(f4v_dot(w, w));
+}
+
+void orc_mls(const orc_params *p, orc_f4 *newVel,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const int dyn = p->boundarytype == ORC_DYN_BOUNDARY;
+	const int last = dyn ? PT_BOUNDARY : PT_FLUID;
+	const float inv_h = 1.0f/p->slength;
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		orc_f4 vel = velArray[index];
+		symtensor4 mls = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+		mls.xx = W_c(p->kerneltype, 0.0f, p->slength, wcoeff, wsub)*pos.w/physical_density(p, vel.w, FLUID_NUM(info));
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		for (int ptype = PT_FLUID; ptype <= last; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				if (!isfinite(npos.w)) continue;
+				const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+				const float neib_rho = physical_density(p, velArray[neib_index].w, FLUID_NUM(infoArray[neib_index]));
+				if (r < p->influenceradius) {
+					const float w = W_c(p->kerneltype, r, p->slength, wcoeff, wsub)*npos.w/neib_rho;
+					const float sx = rx*inv_h, sy = ry*inv_h, sz = rz*inv_h;   /* relPos/slength */
+					mls.xx += w;
+					mls.xy += sx*w; mls.xz += sy*w; mls.xw += sz*w;
+					mls.yy += sx*sx*w; mls.yz += sx*sy*w; mls.yw += sx*sz*w;
+					mls.zz += sy*sy*w; mls.zw += sy*sz*w; mls.ww += sz*sz*w;
+				}
+			}
+		}
+		const f4v E = { 1, 0, 0, 0 };
+		const float D = st4_det(&mls);
+		f4v B;
+		if (fabsf(D) < FLT_EPSILON) {
+			symtensor4 me = mls;
+			const float eps = fabsf(D) + FLT_EPSILON;
+			me.xx += eps; me.yy += eps; me.zz += eps; me.ww += eps;
+			const float De = st4_det(&me);
+			B = f4v_scale(st4_adjugate_row1(&me), 1.0f/De);
+		} else {
+			B = f4v_scale(st4_adjugate_row1(&mls), 1.0f/D);
+		}
+		for (unsigned steps = 0; steps < 32; ++steps) {
+			const float lenB = f4v_hypot(B);
+			const f4v MdotB = st4_dot(&mls, B);
+			const f4v residual = { E.x - MdotB.x, E.y - MdotB.y, E.z - MdotB.z, E.w - MdotB.w };
+			const float num = st4_ddot(&mls, residual);
+			const f4v Mp = st4_dot(&mls, residual);
+			const float den = f4v_dot(Mp, Mp);
+			const f4v corr = f4v_scale(residual, num/den);
+			const float lencorr = f4v_hypot(corr);
+			if (f4v_hypot(residual) < lenB*FLT_EPSILON) break;
+			if (lencorr < 2*lenB*FLT_EPSILON) break;
+			B.x += corr.x; B.y += corr.y; B.z += corr.z; B.w += corr.w;
+		}
+		B.y /= p->slength; B.z /= p->slength; B.w /= p->slength;
+		vel.w = B.x*W_c(p->kerneltype, 0.0f, p->slength, wcoeff, wsub)*pos.w;
+		for (int ptype = PT_FLUID; ptype <= last; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				if (!isfinite(npos.w)) continue;
+				const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+				const orc_info ninfo = infoArray[neib_index];
+				if (r < p->influenceradius && (dyn || PART_TYPE(ninfo) == PT_FLUID)) {
+					const float w = W_c(p->kerneltype, r, p->slength, wcoeff, wsub)*npos.w;
+					vel.w += (B.x + B.y*rx + B.z*ry + B.w*rz)*w;
+				}
+			}
+		}
+		vel.w = numerical_density(p, vel.w, FLUID_NUM(info));
 		newVel[index] = vel;
 	}
 }

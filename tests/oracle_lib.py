@@ -190,6 +190,13 @@ class Oracle:
                          C.c_uint32(n), C.c_float(dt), C.c_int(step))
         return npos, nvel
 
+    def filter(self, filtertype, pos, vel, info, hash_, cs, nl, range_end):
+        """shepard (0) / MLS (1); inactive particles keep their input velocity in the returned copy"""
+        new = vel.copy()
+        fn = self.L.orc_shepard if filtertype == 0 else self.L.orc_mls
+        fn(C.byref(self.p), P(new), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), C.c_uint32(range_end))
+        return new
+
     def sps(self, pos, vel, info, hash_, cs, nl, n, range_end):
         tau = np.zeros((len(pos), 6), dtype=np.float32)
         tv = np.zeros(len(pos), dtype=np.float32)
@@ -243,6 +250,10 @@ class OracleSim:
         if self.iterations % sp.buildneibsfreq == 0:
             self.build_neibs()
         n = self.n
+        if self.iterations > 0:   # FILTER phases, PredictorCorrectorIntegrator.cc:1011-1041
+            for ftype, freq in getattr(self, "filters", []):
+                if self.iterations % freq == 0:
+                    self.vel = o.filter(ftype, self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n)
         cof = 1 if sp.numforcesbodies > 0 else 0
         rb = getattr(self.problem, "num_obstacle", 0)
         dt = float(np.float32(self.dt))

@@ -313,7 +313,8 @@ class _DumpHeader(C.Structure):
     _fields_ = [("magic", C.c_char * 8), ("n", C.c_uint32), ("alloc", C.c_uint32), ("steps", C.c_uint32),
                 ("num_rb_particles", C.c_uint32), ("dt", C.c_float), ("sspeed_cfl", C.c_float),
                 ("nlSq", C.c_float), ("numforcesbodies", C.c_int32), ("rb_cgGridPos", C.c_int32 * 3),
-                ("rb_cgPos", C.c_float * 3), ("rb_firstindex", C.c_int32), ("params", _SP)]
+                ("rb_cgPos", C.c_float * 3), ("rb_firstindex", C.c_int32), ("filter_type", C.c_int32),
+                ("filter_freq", C.c_int32), ("params", _SP)]
 
 
 def test_cpp_adapters_match_python_engine(tmp_path):
@@ -336,6 +337,8 @@ def test_cpp_adapters_match_python_engine(tmp_path):
         h.rb_cgGridPos[:] = [int(v) for v in prob.rb_cg_gridpos[0]]
         h.rb_cgPos[:] = [float(v) for v in prob.rb_cg_pos[0]]
         h.rb_firstindex = int(prob.rb_firstindex[0])
+    h.filter_type = D.SHEPARD_FILTER; h.filter_freq = 5        # also drives HIPFilterEngine through the adapters
+    eng.add_filter(D.SHEPARD_FILTER, 5)
     h.params = eng.params
     fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(fin, "wb") as f:
@@ -419,3 +422,59 @@ def test_sps_stress_and_forces_tolerance():
                                                  None, None, None, n, 0, n, eng.params.deltap, eng.params.slength,
                                                  eng.params.dtadaptfactor, eng.params.influenceradius, 0, D.SIMULATE, 1,
                                                  eng.dt, 0, C.byref(nbl), eng._stream()))
+
+
+# ---------------------------------------------------------------------------------------------
+# density filters: sphx_filter_process vs the oracle.  filters.hip is compiled without FMA
+# contraction, with IEEE division and sqrt and the reference's operation order: bit-exact for the polynomial kernels.
+@pytest.mark.parametrize("ftype", [D.SHEPARD_FILTER, D.MLS_FILTER])
+@pytest.mark.parametrize("case", [dict(deltap=0.04, obstacle=True, jitter=0.1, hydrostatic=False),
+                                  dict(deltap=0.03, obstacle=False, jitter=0.05, linearization="xzy")])
+def test_filters_bit_exact(ftype, case):
+    import torch
+    prob = DamBreak3D(**case)
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    rng = np.random.default_rng(3)
+    vel = sim.vel.copy()
+    vel[:, 3] += rng.uniform(-2e-3, 2e-3, size=len(vel)).astype(np.float32)
+    vel[:, :3] += rng.uniform(-0.1, 0.1, size=(len(vel), 3)).astype(np.float32)
+    sim.vel = vel
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    ref = sim.o.filter(ftype, sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng.apply_filter(ftype)
+    out = _np(eng.vel)[:n]
+    assert np.array_equal(out[:, :3].view(np.uint32), ref[:n, :3].view(np.uint32))
+    assert np.array_equal(out[:, 3].view(np.uint32), ref[:n, 3].view(np.uint32)), \
+        "max |d rho~| = %g" % np.abs(out[:, 3] - ref[:n, 3]).max()
+    # aliasing the two velocity buffers is refused
+    from gpusph_amd import capi
+    p = capi.ptr
+    with pytest.raises((capi.SphxError, capi.SphxInvalidArgument)):
+        capi.check(eng.lib.sphx_filter_process(eng.ctx.handle, int(ftype), p(eng.vel), p(eng.pos), p(eng.vel), p(eng.info),
+                                               p(eng.hash), p(eng.cellStart), p(eng.neibslist), n, n,
+                                               eng.params.slength, eng.params.influenceradius, eng._stream()))
+
+
+def test_trajectory_with_shepard_filter():
+    """WaveTank-style run: Shepard every 3 iterations (addFilter), 8 steps; same tolerances as TRAJ."""
+    case = dict(deltap=0.04, obstacle=False, jitter=0.05, hydrostatic=False)
+    prob = DamBreak3D(**case)
+    eng = _engine(prob)
+    eng.add_filter(D.SHEPARD_FILTER, 3)
+    sim = ol.OracleSim(prob)
+    sim.filters = [(D.SHEPARD_FILTER, 3)]
+    steps = 8
+    for _ in range(steps):
+        sim.step(); eng.step()
+    out = eng.download()
+    n = eng.n
+    assert n == sim.n
+    assert np.array_equal(out["hash"], sim.hash[:n])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    vmax = max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * vmax
+    assert np.abs(out["vel"][:, 3] - sim.vel[:n, 3]).max() <= 2e-6

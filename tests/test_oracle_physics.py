@@ -190,3 +190,50 @@ def test_dtreduce_formula(built):
     dt = sim.o.dtreduce(cfl, 4, sim.sspeed_cfl)
     expect = 0.3 * min(np.sqrt(h / 40.0), h / sim.sspeed_cfl)
     assert abs(dt - expect) <= 1e-6 * expect
+
+
+# ---------------------------------------------------------------------------------------------
+# density filters: known answers that do not depend on the restatement
+@pytest.mark.parametrize("ftype", [0, 1])
+def test_filters_reproduce_a_constant_density(ftype):
+    """Shepard: rho = sum m W / sum (m/rho) W; MLS: zeroth-order consistent by construction.  A uniform density
+    field is a fixed point of both, also next to walls and the free surface (DYN boundary neighbours take part)."""
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.2, hydrostatic=False)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    rho_t = np.float32(2.5e-3)
+    vel = sim.vel.copy(); vel[:, 3] = rho_t
+    out = sim.o.filter(ftype, sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    fluid = (sim.info[:n, 0] & 7) == 0
+    assert np.array_equal(out[:n, :3], vel[:n, :3])                 # only rho~ is filtered
+    tol = 2e-6 if ftype == 0 else 2e-5
+    assert np.abs(out[:n, 3][fluid] - rho_t).max() < tol
+    if ftype == 0:   # Shepard copies non-fluid particles (forces_kernel.cu:451-454)
+        assert np.array_equal(out[:n][~fluid], vel[:n][~fluid])
+
+
+def test_mls_reproduces_a_linear_density_field_in_the_bulk():
+    """first-order consistency: with rho_j = rho0 (1 + a.x_j) on a full (jittered) neighbourhood the MLS-corrected
+    density of particle i is the field value at x_i; Shepard is only zeroth order and must be farther off."""
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.2, hydrostatic=False)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    a = np.array([0.02, -0.01, 0.015])
+    field = (gp @ a).astype(np.float32)                               # rho~ = a.x
+    vel = sim.vel.copy(); vel[:n, 3] = field
+    mls = sim.o.filter(1, sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    she = sim.o.filter(0, sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    # bulk fluid particles: full neighbour sphere (count near the lattice maximum)
+    nl = sim.nl.reshape(-1, len(sim.pos))[:, :n]
+    cnt = (nl != 0xFFFF).sum(axis=0)
+    fluid = (sim.info[:n, 0] & 7) == 0
+    bulk = fluid & (cnt >= np.percentile(cnt[fluid], 60))
+    assert bulk.sum() > 100
+    # m_j = const, so sum_j m_j W_ij (B.(1,r_ij)) reproduces rho where rho is what V_j = m_j/rho_j was built from
+    err_mls = np.abs(mls[:n, 3][bulk] - field[bulk]).max()
+    err_she = np.abs(she[:n, 3][bulk] - field[bulk]).max()
+    assert err_mls < 2e-4
+    assert err_mls < err_she
