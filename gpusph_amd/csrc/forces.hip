@@ -151,6 +151,20 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 	}
 }
 
+// Lennard-Jones repulsion of a boundary particle (compute_repulsive_force forces_kernel.def:3001-3016, LJForce
+// src/cuda/forces_kernel.cu:94-103): the whole fluid<-boundary (and, for bodies with force feedback,
+// boundary<-fluid) interaction of LJ_BOUNDARY.  Few pairs, generic kernel only: accurate powf and IEEE division.
+__device__ __forceinline__ void lj_interact(const DevParams &p, float pcx, float pcy, float pcz,
+	const float4 &npos, bool valid, float4 &force)
+{
+	const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
+	const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+	float ljf = 0.0f;
+	if (valid && is_active_w(npos.w) && r < p.influenceradius && r <= p.r0)
+		ljf = p.dcoeff*(powf(p.r0/r, p.p1coeff) - powf(p.r0/r, p.p2coeff))/(r*r);
+	force.x += ljf*rx; force.y += ljf*ry; force.z += ljf*rz;
+}
+
 // finalizeforcesDevice (forces_kernel.def:4032-4150) for one particle; returns its CFL term
 __device__ __forceinline__ float finalize_particle(const DevParams &p, const ForcesArgs &a, uint32_t index,
 	const particleinfo &info, const Self &s, float4 force)
@@ -233,7 +247,7 @@ __device__ __forceinline__ void load_list_batch(const DevParams &p, const neibda
 // src/cuda/neibs_iteration.cuh:165-205; getNeibIndex src/cuda/cellgrid.cuh:200-228)
 template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID, int NPTYPE, bool MOMENTUM, bool DIFFUSE>
 __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArgs &a, uint32_t index,
-	const Self &s, float inv_h, float4 &force)
+	const Self &s, float inv_h, float4 &force, bool lj = false)
 {
 	int slot = (NPTYPE == PT_FLUID) ? 0 : (int)p.neibboundpos;
 	uint32_t nd[NB], ndn[NB];
@@ -297,8 +311,11 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 			const float pcx = fmaf(-(float)(cx - 1), p.cs[0], s.pos.x);
 			const float pcy = fmaf(-(float)(cy - 1), p.cs[1], s.pos.y);
 			const float pcz = fmaf(-(float)(cz - 1), p.cs[2], s.pos.z);
-			pair_interact<KERNEL, TURB, COLAGROSSI, MOMENTUM, DIFFUSE>(p, s, inv_h, pcx, pcy, pcz,
-				npos[k], nvel[k], naux[k], same[k], valid[k], ntau[k], force);
+			if (lj)
+				lj_interact(p, pcx, pcy, pcz, npos[k], valid[k], force);
+			else
+				pair_interact<KERNEL, TURB, COLAGROSSI, MOMENTUM, DIFFUSE>(p, s, inv_h, pcx, pcy, pcz,
+					npos[k], nvel[k], naux[k], same[k], valid[k], ntau[k], force);
 		}
 #pragma unroll
 		for (int k = 0; k < NB; ++k) nd[k] = ndn[k];
@@ -324,7 +341,7 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 		Self s;
 		load_self<TURB>(p, a, index, info, pos, MULTIFLUID, s);
 		const float inv_h = fast_rcp(p.slength);
-		const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
+		const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY, lj = p.boundarytype == SPHX_LJ_BOUNDARY;
 
 		// the caller clobbers FORCES to 0 before basicstep (src/GPUWorker.cc:1949): the accumulator
 		// starts from that value without re-reading it
@@ -335,8 +352,14 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 			walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, true, true>(p, a, index, s, inv_h, force);
 			// fluid <- boundary : same interaction for DYN_BOUNDARY (forces_kernel.def:3717-3726),
 			// no density diffusion from boundary neighbours (:1596-1606)
-			if (dyn)
-				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_BOUNDARY, true, false>(p, a, index, s, inv_h, force);
+			// ... Lennard-Jones repulsion for LJ_BOUNDARY (:3688-3705)
+			if (dyn || lj)
+				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_BOUNDARY, true, false>(p, a, index, s, inv_h, force, lj);
+		} else if (ptype == PT_BOUNDARY && lj) {
+			// boundary <- fluid with LJ_BOUNDARY (:3620-3645): only particles of bodies with force feedback, and only
+			// when the caller asked for object forces (run_forces launches this pass only then, src/cuda/forces.cu:775-782)
+			if (HAS_COMPUTE_FORCE(info) && a.compute_object_forces)
+				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, true, false>(p, a, index, s, inv_h, force, true);
 		} else if (ptype == PT_BOUNDARY && dyn) {
 			// boundary <- fluid (forces_kernel.def:3650-3679): DYN always evolves density; momentum
 			// only for particles of bodies with force feedback
@@ -1110,8 +1133,8 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 		"sphx_forces_basicstep: slength/influenceradius differ from set_constants");
 	if (run_mode != SPHX_SIMULATE)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: REPACK run mode is not built");
-	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: only DYN_BOUNDARY pair interactions are built");
+	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY && ctx->dev.boundarytype != SPHX_LJ_BOUNDARY)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: only DYN_BOUNDARY and LJ_BOUNDARY pair interactions are built");
 	if (ctx->dev.turbmodel == SPHX_SPS)
 		SPHX_REQUIRE(tau0 && tau1 && tau2, "sphx_forces_basicstep: SPS needs the three TAU arrays");
 	if ((ctx->dev.simflags & SPHX_ENABLE_DTADAPT))
@@ -1152,6 +1175,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && !ctx->disable_tiles &&
+		ctx->dev.boundarytype == SPHX_DYN_BOUNDARY &&   // LJ repulsion is only in the generic kernel so far
 		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
 		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
 		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit

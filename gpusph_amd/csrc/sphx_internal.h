@@ -65,6 +65,7 @@ struct DevParams {
 	float    sscoeff[SPHX_MAX_FLUIDS], sspowercoeff[SPHX_MAX_FLUIDS];
 	float    gravity[3];
 	float    artvisccoeff, epsartvisc, smagfactor, kspsfactor;
+	float    dcoeff, p1coeff, p2coeff, r0;   // Lennard-Jones boundary repulsion
 };
 
 // rigid-body tables live in device memory owned by the ctx (1.6 KB, too big for kernarg)

@@ -187,14 +187,20 @@ class DamBreak3D(Problem):
     LAYERS = 3
 
     def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
-                 jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND):
+                 jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY):
         super().__init__()
         self.m_name = "DamBreak3D"
         sp, pp = self.simparams, self.physparams
         sp.kerneltype = kerneltype
         if kerneltype == D.GAUSSIAN:
             sp.kernelradius = 3.0
-        sp.boundarytype = D.DYN_BOUNDARY
+        if boundary not in (D.DYN_BOUNDARY, D.LJ_BOUNDARY):
+            raise ValueError("DamBreak3D mirror: DYN_BOUNDARY or LJ_BOUNDARY")
+        sp.boundarytype = boundary
+        if boundary == D.LJ_BOUNDARY:
+            # one layer of repulsive particles on the box faces instead of three dynamic layers
+            # (DamBreak3D.cu:74,131-134: layers only for DYN_BOUNDARY)
+            self.LAYERS = 1
         sp.rheologytype = D.INVISCID
         sp.turbmodel = D.ARTIFICIAL
         sp.densitydiffusiontype = density_diffusion
@@ -204,6 +210,10 @@ class DamBreak3D(Problem):
         self.linearization = linearization
         self.set_deltap(deltap)
         pp.gravity = (0.0, 0.0, -9.81)
+        if boundary == D.LJ_BOUNDARY:
+            # ProblemCore::check_dt/initialize defaults: r0 = deltap, D = 5|g| (src/ProblemCore.cc:132-150)
+            pp.r0 = self.m_deltap
+            pp.dcoeff = 5.0 * 9.81
         pp.add_fluid(1000.0)
         pp.set_equation_of_state(0, 7.0, 20.0)
         self.m_origin = np.zeros(3)

@@ -709,6 +709,19 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				(cptype == PT_FLUID && nptype == PT_BOUNDARY && p->boundarytype == ORC_DYN_BOUNDARY);
 			const int dyn_bf = (cptype == PT_BOUNDARY && nptype == PT_FLUID && p->boundarytype == ORC_DYN_BOUNDARY);
 
+			/* repulsive boundary models: fluid <- boundary always, boundary <- fluid only for particles of bodies
+			 * with force feedback (compute_pp_interaction :3620-3645,3688-3705; compute_repulsive_force :3001-3016;
+			 * LJForce src/cuda/forces_kernel.cu:94-103, __powf -> powf) */
+			if (p->boundarytype == ORC_LJ_BOUNDARY &&
+				((cptype == PT_FLUID && nptype == PT_BOUNDARY) ||
+				 (cptype == PT_BOUNDARY && nptype == PT_FLUID && COMPUTE_FORCE(info)))) {
+				float ljf = 0.0f;
+				if (r <= p->r0)
+					ljf = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
+				force.x += ljf*rx; force.y += ljf*ry; force.z += ljf*rz;
+				continue;
+			}
+
 			if (all_pp || dyn_bf) {
 				/* compute_density_derivative, :2176-2190 */
 				DrDt = nmass*vel_dot_pos*f; /* mass_continuity_div_vel_term :2140-2151 */

@@ -478,3 +478,46 @@ def test_trajectory_with_shepard_filter():
     vmax = max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
     assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * vmax
     assert np.abs(out["vel"][:, 3] - sim.vel[:n, 3]).max() <= 2e-6
+
+
+# ---------------------------------------------------------------------------------------------
+# LJ_BOUNDARY (Lennard-Jones repulsive boundary particles, generic forces kernel)
+def test_lj_boundary_forces_and_trajectory():
+    import torch
+    case = dict(deltap=0.04, obstacle=False, jitter=0.2, hydrostatic=False, boundary=D.LJ_BOUNDARY)
+    prob = DamBreak3D(**case)
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    assert np.array_equal(_np(eng.neibslist, np.uint16).reshape(-1, eng.alloc)[:, :n],
+                          sim.nl.reshape(-1, len(sim.pos))[:, :n])
+    rng = np.random.default_rng(5)
+    vel = sim.vel.copy()
+    fluid = (sim.info[:, 0] & 7) == 0
+    vel[fluid, :3] += rng.uniform(-0.3, 0.3, size=(fluid.sum(), 3)).astype(np.float32)
+    vel[fluid, 3] += rng.uniform(0, 2e-3, size=fluid.sum()).astype(np.float32)
+    sim.vel = vel
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    f_ref, cfl_ref, nb, _, _ = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng._forces(eng.pos, eng.vel, 1, 0)
+    f = _np(eng.forces)[:n]
+    scale = np.abs(f_ref[:, :3]).max()
+    assert np.abs(f[:, :3] - f_ref[:n, :3]).max() <= 2e-5 * scale
+    assert np.abs(f[:, 3] - f_ref[:n, 3]).max() <= 2e-5 * np.abs(f_ref[:, 3]).max() + 1e-7
+    assert not np.any(f[~fluid[:n], :3])
+    dt_ref = sim.o.dtreduce(cfl_ref, nb, sim.sspeed_cfl)
+    assert abs(float(eng.d_dt_next.item()) - dt_ref) <= 2e-5 * dt_ref
+    # a few full steps (the engine and the oracle both start again from the perturbed state)
+    eng2 = _engine(prob); sim2 = ol.OracleSim(prob)
+    steps = 6
+    for _ in range(steps):
+        sim2.step(); eng2.step()
+    out = eng2.download()
+    n2 = eng2.n
+    assert np.array_equal(out["hash"], sim2.hash[:n2])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim2.pos[:n2, :3]).max() <= 1e-6 * cs * steps
+    vmax = max(np.abs(sim2.vel[:n2, :3]).max(), 1e-6)
+    assert np.abs(out["vel"][:, :3] - sim2.vel[:n2, :3]).max() <= 1e-3 * vmax
+    assert np.abs(out["vel"][:, 3] - sim2.vel[:n2, 3]).max() <= 2e-6

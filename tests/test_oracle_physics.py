@@ -237,3 +237,43 @@ def test_mls_reproduces_a_linear_density_field_in_the_bulk():
     err_she = np.abs(she[:n, 3][bulk] - field[bulk]).max()
     assert err_mls < 2e-4
     assert err_mls < err_she
+
+
+def test_lj_boundary_repulsion_equals_brute_force():
+    """LJ_BOUNDARY: the boundary contribution to a fluid particle's acceleration is
+    sum_j D ((r0/r)^p1 - (r0/r)^p2)/r^2 r_ij over boundary neighbours with r <= r0 (LJForce,
+    src/cuda/forces_kernel.cu:94-103).  It is linear in D, so F(D) - F(0) isolates it; compared with a float64
+    brute-force sum over global positions.  Boundary particles themselves get no force and are not integrated."""
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.25, hydrostatic=False, boundary=D.LJ_BOUNDARY)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    f_full = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    d_coeff = float(sim.o.p.dcoeff)
+    sim.o.p.dcoeff = 0.0
+    f_zero = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    sim.o.p.dcoeff = d_coeff
+    lj = (f_full[:n, :3].astype(np.float64) - f_zero[:n, :3])
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    ptype = sim.info[:n, 0] & 7
+    fl, bd = np.where(ptype == 0)[0], np.where(ptype == 1)[0]
+    r0, p1, p2 = float(sim.o.p.r0), float(sim.o.p.p1coeff), float(sim.o.p.p2coeff)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(gp[bd])
+    ref = np.zeros((n, 3))
+    for i, nb in zip(fl, tree.query_ball_point(gp[fl], r0)):
+        if nb:
+            d = gp[i] - gp[bd[nb]]
+            r = np.linalg.norm(d, axis=1)
+            ref[i] = ((d_coeff * ((r0 / r) ** p1 - (r0 / r) ** p2) / r ** 2)[:, None] * d).sum(axis=0)
+    touched = np.abs(ref).max(axis=1) > 0
+    assert touched.sum() > 50
+    scale = np.abs(ref).max()
+    assert np.abs(lj - ref).max() <= 2e-4 * scale
+    assert not np.any(f_full[:n][ptype == 1, :3])        # fixed boundary particles: no force feedback requested
+    # and they stay where they are through a step
+    before = sim.pos[:n].copy()
+    ids_before = sim.info[:n, 2:].copy()
+    sim.step()
+    assert np.array_equal(sim.info[:n, 2:], ids_before)
+    assert np.array_equal(sim.pos[:n][ptype == 1], before[ptype == 1])
