@@ -174,6 +174,21 @@ __device__ __forceinline__ float finalize_particle(const DevParams &p, const For
 	force.w /= p.rho0[s.fl]; // forces_fixup :3212-3218
 	if (ptype == PT_FLUID) {
 		force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
+		// GeometryForce / PlaneForce (src/cuda/forces_kernel.cu:140-203): Lennard-Jones repulsion along the plane
+		// normal; the friction term vanishes for the inviscid rheology built here (viscous_plane_coefficient :3103-3107)
+		if ((p.simflags & SPHX_ENABLE_PLANES) && p.numplanes) {
+			for (uint32_t k = 0; k < p.numplanes; ++k) {
+				const float dx = (s.gridPos.x - p.plane_gridpos[k][0])*p.cs[0] + (s.pos.x - p.plane_pos[k][0]);
+				const float dy = (s.gridPos.y - p.plane_gridpos[k][1])*p.cs[1] + (s.pos.y - p.plane_pos[k][1]);
+				const float dz = (s.gridPos.z - p.plane_gridpos[k][2])*p.cs[2] + (s.pos.z - p.plane_pos[k][2]);
+				const float r = fabsf(dx*p.plane_normal[k][0] + dy*p.plane_normal[k][1] + dz*p.plane_normal[k][2]);
+				if (r < p.r0) {
+					const float DvDt = p.dcoeff*(powf(p.r0/r, p.p1coeff) - powf(p.r0/r, p.p2coeff))/(r*r);
+					force.x += DvDt*(p.plane_normal[k][0]*r); force.y += DvDt*(p.plane_normal[k][1]*r);
+					force.z += DvDt*(p.plane_normal[k][2]*r);
+				}
+			}
+		}
 		// dyndt_forces_shared_data::store (:3436-3457)
 		const float amag = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
 		cfl_term = fmaxf(amag, s.sspeed*s.sspeed/p.slength);

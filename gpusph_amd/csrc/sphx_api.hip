@@ -178,7 +178,12 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 
 	ctx->params = *sp;
 	DevParams &d = ctx->dev;
+	const DevParams planes_keep = d;   // planes are uploaded separately (setplanes) and survive a new setconstants
 	memset(&d, 0, sizeof(d));
+	d.numplanes = planes_keep.numplanes;
+	memcpy(d.plane_normal, planes_keep.plane_normal, sizeof(d.plane_normal));
+	memcpy(d.plane_gridpos, planes_keep.plane_gridpos, sizeof(d.plane_gridpos));
+	memcpy(d.plane_pos, planes_keep.plane_pos, sizeof(d.plane_pos));
 	for (int a = 0; a < 3; ++a) { d.gs[a] = (int)sp->gridSize[a]; d.cs[a] = sp->cellSize[a]; }
 	d.c1 = sp->coord[0]; d.c2 = sp->coord[1]; d.c3 = sp->coord[2];
 	d.gs1 = d.gs[d.c1];
@@ -210,6 +215,21 @@ extern "C" int sphx_get_params(sphx_ctx *ctx, sphx_params *out)
 	SPHX_REQUIRE(ctx && out, "sphx_get_params: NULL argument");
 	SPHX_REQUIRE(ctx->have_params, "sphx_get_params: constants not set");
 	*out = ctx->params;
+	return SPHX_OK;
+}
+
+extern "C" int sphx_set_planes(sphx_ctx *ctx, const float *normals, const int32_t *gridPos, const float *pos, int numPlanes)
+{
+	SPHX_REQUIRE(ctx != nullptr, "sphx_set_planes: NULL ctx");
+	SPHX_REQUIRE(numPlanes >= 0 && numPlanes <= SPHX_MAX_PLANES, "sphx_set_planes: too many planes");
+	SPHX_REQUIRE(numPlanes == 0 || (normals && gridPos && pos), "sphx_set_planes: missing array");
+	ctx->dev.numplanes = (uint32_t)numPlanes;
+	for (int k = 0; k < numPlanes; ++k)
+		for (int a = 0; a < 3; ++a) {
+			ctx->dev.plane_normal[k][a] = normals[3*k + a];
+			ctx->dev.plane_gridpos[k][a] = gridPos[3*k + a];
+			ctx->dev.plane_pos[k][a] = pos[3*k + a];
+		}
 	return SPHX_OK;
 }
 

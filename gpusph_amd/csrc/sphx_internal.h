@@ -66,6 +66,10 @@ struct DevParams {
 	float    gravity[3];
 	float    artvisccoeff, epsartvisc, smagfactor, kspsfactor;
 	float    dcoeff, p1coeff, p2coeff, r0;   // Lennard-Jones boundary repulsion
+	uint32_t numplanes;                       // geometric planes (src/planes.h:43-47, MAX_PLANES src/particledefine.h:325)
+	float    plane_normal[SPHX_MAX_PLANES][3];
+	int      plane_gridpos[SPHX_MAX_PLANES][3];
+	float    plane_pos[SPHX_MAX_PLANES][3];
 };
 
 // rigid-body tables live in device memory owned by the ctx (1.6 KB, too big for kernarg)

@@ -46,6 +46,9 @@ class TimestepEngine:
         self.params = problem.sphx_params(self.alloc)
         self.ctx.set_constants(self.params)
         self.ctx.reserve(self.alloc)
+        if getattr(problem, "planes", None):      # GPUWorker::uploadPlanes -> setplanes
+            nrm, gpos, lpos = problem.plane_tables()
+            capi.check(self.lib.sphx_set_planes(self.ctx.handle, nrm.ctypes.data, gpos.ctypes.data, lpos.ctypes.data, len(nrm)))
         sp, pp = problem.simparams, problem.physparams
         self.sp = sp
         self.ncells = problem.grid_cells

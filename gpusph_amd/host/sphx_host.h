@@ -194,6 +194,10 @@ public:
 	void mark_valid() { for (map_type::iterator it = m_map.begin(); it != m_map.end(); ++it) it->second->mark_valid(); }
 };
 
+// src/planes.h:43-61
+struct plane_t { float3 normal; int3 gridPos; float3 pos; };
+typedef std::vector<plane_t> PlaneList;
+
 // ---- parameter structs: the fields setconstants() consumes (src/simparams.h, src/physparams.h) ----
 struct SimParams {
 	int kerneltype = SPHX_WENDLAND, sph_formulation = SPHX_SPH_F1, densitydiffusiontype = SPHX_DENSITY_DIFFUSION_NONE;
@@ -243,6 +247,7 @@ public:
 	virtual void setconstants(const SimParams *simparams, const PhysParams *physparams,
 		float3 const& worldOrigin, uint3 const& gridSize, float3 const& cellSize, idx_t const& allocatedParticles) = 0;
 	virtual void setgravity(float3 const& gravity) = 0;
+	virtual void setplanes(PlaneList const& planes) = 0;
 	virtual void setrbcg(const int3 *cgGridPos, const float3 *cgPos, int numbodies) = 0;
 	virtual void setrbstart(const int *rbfirstindex, int numbodies) = 0;
 	virtual void reduceRbForces(BufferList& bufwrite, uint *lastindex, float3 *totalforce, float3 *totaltorque,
@@ -414,6 +419,15 @@ public:
 		uint3 const& gridSize, float3 const& cellSize, idx_t const& allocatedParticles) override
 	{ m_c->fill(simparams, physparams, worldOrigin, gridSize, cellSize, allocatedParticles); }
 	void setgravity(float3 const& g) override { const float v[3] = { g.x, g.y, g.z }; sphx_throw(sphx_set_gravity(m_c->ctx(), v)); }
+	void setplanes(PlaneList const& planes) override {   // CUDAForcesEngine::setplanes, src/cuda/forces.cu:442-448
+		std::vector<float> nrm, pos; std::vector<int32_t> gp;
+		for (plane_t const& pl : planes) {
+			nrm.insert(nrm.end(), { pl.normal.x, pl.normal.y, pl.normal.z });
+			gp.insert(gp.end(), { pl.gridPos.x, pl.gridPos.y, pl.gridPos.z });
+			pos.insert(pos.end(), { pl.pos.x, pl.pos.y, pl.pos.z });
+		}
+		sphx_throw(sphx_set_planes(m_c->ctx(), nrm.data(), gp.data(), pos.data(), (int)planes.size()));
+	}
 	void setrbcg(const int3 *cgGridPos, const float3 *cgPos, int numbodies) override {
 		sphx_throw(sphx_set_rb_cg(m_c->ctx(), (const int32_t*)cgGridPos, (const float*)cgPos, numbodies));
 	}

@@ -23,6 +23,9 @@ class HipKernels:
         self.params = problem.sphx_params(alloc)
         self.ctx.set_constants(self.params)
         self.ctx.reserve(alloc)
+        if getattr(problem, "planes", None):
+            nrm, gpos, lpos = problem.plane_tables()
+            capi.check(self.lib.sphx_set_planes(self.ctx.handle, nrm.ctypes.data, gpos.ctypes.data, lpos.ctypes.data, len(nrm)))
         self.ncells = problem.grid_cells
         sp = problem.simparams
         self.compute_object_forces = 1 if sp.numforcesbodies > 0 else 0

@@ -74,6 +74,22 @@ class Problem:
         self.linearization = D.DEFAULT_LINEARIZATION
         self.m_name = "Problem"
         self.parts = None
+        self.planes = []            # [(unit normal (3), reference point (3), global coordinates)], PlaneList
+
+    def plane_tables(self):
+        """plane_t arrays as ProblemCore::copy_planes hands them to setplanes: unit normal, grid cell and
+        cell-local position of the reference point (src/planes.h:43-59)."""
+        n = len(self.planes)
+        normals = np.zeros((n, 3), dtype=np.float32)
+        gridpos = np.zeros((n, 3), dtype=np.int32)
+        pos = np.zeros((n, 3), dtype=np.float32)
+        for k, (nrm, pt) in enumerate(self.planes):
+            nrm = np.asarray(nrm, dtype=np.float64)
+            normals[k] = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+            g = self.calc_grid_pos(np.asarray(pt, dtype=np.float64)[None, :])[0]
+            gridpos[k] = g
+            pos[k] = (np.asarray(pt, dtype=np.float64) - self.m_origin - (g + 0.5) * self.m_cellsize).astype(np.float32)
+        return normals, gridpos, pos
 
     # -- ProblemCore::set_deltap / set_smoothing --
     def set_deltap(self, dp):
@@ -187,7 +203,8 @@ class DamBreak3D(Problem):
     LAYERS = 3
 
     def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
-                 jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY):
+                 jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY,
+                 walls="particles"):
         super().__init__()
         self.m_name = "DamBreak3D"
         sp, pp = self.simparams, self.physparams
@@ -197,6 +214,9 @@ class DamBreak3D(Problem):
         if boundary not in (D.DYN_BOUNDARY, D.LJ_BOUNDARY):
             raise ValueError("DamBreak3D mirror: DYN_BOUNDARY or LJ_BOUNDARY")
         sp.boundarytype = boundary
+        if walls not in ("particles", "planes") or (walls == "planes" and boundary != D.LJ_BOUNDARY):
+            raise ValueError("walls: 'particles', or 'planes' with LJ_BOUNDARY (m_usePlanes)")
+        self.walls = walls
         if boundary == D.LJ_BOUNDARY:
             # one layer of repulsive particles on the box faces instead of three dynamic layers
             # (DamBreak3D.cu:74,131-134: layers only for DYN_BOUNDARY)
@@ -204,7 +224,8 @@ class DamBreak3D(Problem):
         sp.rheologytype = D.INVISCID
         sp.turbmodel = D.ARTIFICIAL
         sp.densitydiffusiontype = density_diffusion
-        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | (D.ENABLE_MOVING_BODIES if obstacle else 0)
+        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | (D.ENABLE_MOVING_BODIES if obstacle else 0) | \
+            (D.ENABLE_PLANES if walls == "planes" else 0)
         sp.neiblistsize = 128               # resize_neiblist(128), DamBreak3D.cu:76
         sp.densityDiffCoeff = 0.1           # DamBreak3D.cu:95
         self.linearization = linearization
@@ -274,6 +295,11 @@ class DamBreak3D(Problem):
         ]
         wall_idx = np.concatenate(slabs, axis=0)
         wall = wall_idx.astype(np.float64) * np.array(dx)
+        if self.walls == "planes":
+            # geometric planes instead of boundary particles: floor and the four side walls, normals pointing inwards
+            wall = np.zeros((0, 3))
+            self.planes = [((0, 0, 1), (0, 0, 0)), ((1, 0, 0), (0, 0, 0)), ((-1, 0, 0), (L[0], 0, 0)),
+                           ((0, 1, 0), (0, 0, 0)), ((0, -1, 0), (0, L[1], 0))]
         # --- water column (DamBreak3D.cu:139-145) ---
         bd = Lr * dp
         fsize = np.array([self.WATER_LENGTH - bd, L[1] - 2 * bd, self.H - bd])

@@ -126,6 +126,11 @@ int sphx_set_constants(sphx_ctx *ctx, const sphx_params *params);
 int sphx_get_params(sphx_ctx *ctx, sphx_params *out);
 /* AbstractForcesEngine::setgravity (src/engine_forces.h) */
 int sphx_set_gravity(sphx_ctx *ctx, const float h_gravity[3]);
+/* setplanes (src/engine_forces.h, CUDAForcesEngine::setplanes src/cuda/forces.cu:442-448): up to SPHX_MAX_PLANES
+ * geometric planes, each a unit normal and a reference point given as grid cell + cell-local position
+ * (plane_t, src/planes.h:43-47); arrays of 3*numPlanes values.  Used when SPHX_ENABLE_PLANES is set. */
+#define SPHX_MAX_PLANES 8
+int sphx_set_planes(sphx_ctx *ctx, const float *normals, const int32_t *gridPos, const float *pos, int numPlanes);
 /* AbstractForcesEngine::setrbcg / setrbstart; AbstractIntegrationEngine::setrbcg/setrbtrans/
  * setrbsteprot/setrblinearvel/setrbangularvel (src/engine_integration.h) */
 int sphx_set_rb_cg(sphx_ctx *ctx, const int32_t *h_cgGridPos3, const float *h_cgPos3, int numbodies);

@@ -815,6 +815,26 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 
 			if (FLUID(info)) {
 				force.x += p->gravity[0]; force.y += p->gravity[1]; force.z += p->gravity[2];
+				/* GeometryForce/PlaneForce (src/cuda/forces_kernel.cu:140-203), PlaneDistance + globalDistance
+				 * (src/cuda/geom_core.cu:63-85, cellgrid.cuh:153-161).  Inviscid: the wall-friction coefficient is
+				 * -0 (viscous_plane_coefficient :3103-3107), only the Lennard-Jones repulsion along the normal acts. */
+				if ((p->simflags & ORC_ENABLE_PLANES) && p->numplanes) {
+					int gp[3];
+					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
+					for (uint32_t k = 0; k < p->numplanes; ++k) {
+						const float dx = (gp[0] - p->plane_gridpos[k][0])*p->cellSize[0] + (pos.x - p->plane_pos[k][0]);
+						const float dy = (gp[1] - p->plane_gridpos[k][1])*p->cellSize[1] + (pos.y - p->plane_pos[k][1]);
+						const float dz = (gp[2] - p->plane_gridpos[k][2])*p->cellSize[2] + (pos.z - p->plane_pos[k][2]);
+						const float *nrm = p->plane_normal[k];
+						const float r = fabsf(dx*nrm[0] + dy*nrm[1] + dz*nrm[2]);
+						if (r < p->r0) {
+							float DvDt = 0.0f;   /* LJForce(r) */
+							if (r <= p->r0)
+								DvDt = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
+							force.x += DvDt*(nrm[0]*r); force.y += DvDt*(nrm[1]*r); force.z += DvDt*(nrm[2]*r);
+						}
+					}
+				}
 				if (dtadapt) { /* dyndt_forces_shared_data::store, :3436-3457 */
 					const float sspeed = orc_soundSpeed(p, vel.w, fl);
 					const float a = sqrtf(sqlength3(force.x, force.y, force.z));

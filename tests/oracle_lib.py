@@ -113,6 +113,12 @@ def orc_params_from(sphx_params, problem=None):
     for b in range(16):
         for a in (0, 4, 8):
             o.rbsteprot[b][a] = 1.0
+    if problem is not None and getattr(problem, "planes", None):
+        nrm, gpos, lpos = problem.plane_tables()
+        o.numplanes = len(nrm)
+        for k in range(len(nrm)):
+            for a in range(3):
+                o.plane_normal[k][a] = float(nrm[k][a]); o.plane_gridpos[k][a] = int(gpos[k][a]); o.plane_pos[k][a] = float(lpos[k][a])
     if problem is not None and getattr(problem, "num_obstacle", 0):
         for a in range(3):
             o.rbcgGridPos[0][a] = int(problem.rb_cg_gridpos[0][a])

@@ -521,3 +521,32 @@ def test_lj_boundary_forces_and_trajectory():
     vmax = max(np.abs(sim2.vel[:n2, :3]).max(), 1e-6)
     assert np.abs(out["vel"][:, :3] - sim2.vel[:n2, :3]).max() <= 1e-3 * vmax
     assert np.abs(out["vel"][:, 3] - sim2.vel[:n2, 3]).max() <= 2e-6
+
+
+def test_planes_forces_and_trajectory():
+    """ENABLE_PLANES with LJ_BOUNDARY: plane repulsion in the finalize stage (sphx_set_planes)."""
+    import torch
+    prob = DamBreak3D(deltap=0.04, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes")
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    f_ref, cfl_ref, nb, _, _ = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng._forces(eng.pos, eng.vel, 1, 0)
+    f = _np(eng.forces)[:n]
+    scale = np.abs(f_ref[:, :3]).max()
+    assert scale > 20.0                                          # the planes do push (|g| alone is 9.81)
+    assert np.abs(f[:, :3] - f_ref[:n, :3]).max() <= 2e-5 * scale
+    dt_ref = sim.o.dtreduce(cfl_ref, nb, sim.sspeed_cfl)
+    assert abs(float(eng.d_dt_next.item()) - dt_ref) <= 2e-5 * dt_ref
+    eng2 = _engine(prob); sim2 = ol.OracleSim(prob)
+    steps = 6
+    for _ in range(steps):
+        sim2.step(); eng2.step()
+    out = eng2.download()
+    n2 = eng2.n
+    assert np.array_equal(out["hash"], sim2.hash[:n2])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim2.pos[:n2, :3]).max() <= 1e-6 * cs * steps
+    vmax = max(np.abs(sim2.vel[:n2, :3]).max(), 1e-6)
+    assert np.abs(out["vel"][:, :3] - sim2.vel[:n2, :3]).max() <= 1e-3 * vmax

@@ -277,3 +277,30 @@ def test_lj_boundary_repulsion_equals_brute_force():
     sim.step()
     assert np.array_equal(sim.info[:n, 2:], ids_before)
     assert np.array_equal(sim.pos[:n][ptype == 1], before[ptype == 1])
+
+
+def test_plane_repulsion_equals_brute_force():
+    """ENABLE_PLANES: each plane within r0 of a fluid particle adds LJForce(r) r n (PlaneForce,
+    src/cuda/forces_kernel.cu:140-180).  Linear in D: F(D) - F(0) against a float64 evaluation from global positions."""
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes")
+    assert prob.num_wall == 0 and len(prob.planes) == 5
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    f_full = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    d_coeff = float(sim.o.p.dcoeff)
+    sim.o.p.dcoeff = 0.0
+    f_zero = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    sim.o.p.dcoeff = d_coeff
+    lj = f_full[:n, :3].astype(np.float64) - f_zero[:n, :3]
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    r0, p1, p2 = float(sim.o.p.r0), float(sim.o.p.p1coeff), float(sim.o.p.p2coeff)
+    ref = np.zeros((n, 3))
+    for nrm, pt in prob.planes:
+        nrm = np.asarray(nrm, dtype=np.float64)
+        r = np.abs((gp - np.asarray(pt, dtype=np.float64)) @ nrm)
+        m = r < r0
+        f = d_coeff * ((r0 / r[m]) ** p1 - (r0 / r[m]) ** p2) / r[m] ** 2
+        ref[m] += (f * r[m])[:, None] * nrm
+    assert (np.abs(ref).max(axis=1) > 0).sum() > 50
+    assert np.abs(lj - ref).max() <= 2e-4 * np.abs(ref).max()
