@@ -234,6 +234,207 @@ mls_kernel(DevParams p, FilterArgs a)
 	a.newVel[index] = vel;
 }
 
+// ==========================================================================================
+// post-processing engines (run before writes): src/cuda/post_process_kernel.cu:58-392, host src/cuda/post_process.cu
+// ==========================================================================================
+// F<kerneltype>(r, h) with the reference's operations (src/cuda/sph_core.cu:146-191); the forces kernel has its own
+// fast variant
+template<int KERNEL>
+__device__ __forceinline__ float kernel_F_exact(const DevParams &p, float r)
+{
+	const float R = r/p.slength;
+	if (KERNEL == SPHX_CUBICSPLINE) {
+		const float val = (R < 1.0f) ? (-4.0f + 3.0f*R)/p.slength : -(-2.0f + R)*(-2.0f + R)/r;
+		return val*p.fcoeff;
+	} else if (KERNEL == SPHX_QUADRATIC) {
+		return ((-2.0f + R)/r)*p.fcoeff;
+	} else if (KERNEL == SPHX_WENDLAND) {
+		const float qm2 = r/p.slength - 2.0f;
+		return qm2*qm2*qm2*p.fcoeff;
+	} else {
+		return -expf(-R*R)*p.fcoeff;
+	}
+}
+
+struct PostArgs {
+	float *vorticity;          // VORTICITY: 3 floats per particle
+	float4 *velInOut;          // TESTPOINTS: updated in place
+	particleinfo *infoInOut;   // SURFACE_DETECTION: updated in place
+	float4 *normals;           // SURFACE_DETECTION, optional
+	float cosconeanglefluid, cosconeanglenonfluid;
+};
+
+// calcVortDevice (:58-135)
+template<int KERNEL>
+__global__ void __launch_bounds__(128)
+vorticity_kernel(DevParams p, FilterArgs a, PostArgs o)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	const float4 pos = a.pos[index];
+	float *out = o.vorticity + 3*(size_t)index;
+	if (PART_TYPE(info) != PT_FLUID || !is_active_w(pos.w)) { out[0] = out[1] = out[2] = NAN; return; }
+	const float4 vel = a.vel[index];
+	float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		const float4 nvel = a.vel[j];
+		const float ux = vel.x - nvel.x, uy = vel.y - nvel.y, uz = vel.z - nvel.z;
+		if (r < p.influenceradius) {
+			const float f = kernel_F_exact<KERNEL>(p, r)*npos.w/((nvel.w + 1.0f)*p.rho0[FLUID_NUM(a.info[j])]);
+			vx += f*(uy*rz - uz*ry);
+			vy += f*(uz*rx - ux*rz);
+			vz += f*(ux*ry - uy*rx);
+		}
+	});
+	out[0] = vx; out[1] = vy; out[2] = vz;
+}
+
+// calcTestpointsVelocityDevice (:138-236), non-SA, no k-epsilon buffers
+template<int KERNEL>
+__global__ void __launch_bounds__(128)
+testpoints_kernel(DevParams p, FilterArgs a, PostArgs o)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (!IS_TESTPOINT(info)) return;
+	const float4 pos = a.pos[index];
+	float4 avg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	float alpha = 0.0f;
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		if (r < p.influenceradius) {
+			const float4 nvel = o.velInOut[j];
+			const uint32_t nfl = FLUID_NUM(a.info[j]);
+			const float w = kernel_W<KERNEL>(p, r)*npos.w/((nvel.w + 1.0f)*p.rho0[nfl]);
+			avg.x += w*nvel.x; avg.y += w*nvel.y; avg.z += w*nvel.z;
+			avg.w += w*(p.bcoeff[nfl]*(powf(nvel.w + 1.0f, p.gammacoeff[nfl]) - 1.0f));
+			alpha += w;
+		}
+	});
+	if (alpha > 1e-5f) {
+		const float inv = 1.0f/alpha;
+		avg.x *= inv; avg.y *= inv; avg.z *= inv; avg.w *= inv;
+	} else {
+		avg = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
+	o.velInOut[index] = avg;
+}
+
+// calcSurfaceparticleDevice (:239-392), non-SA
+template<int KERNEL>
+__global__ void __launch_bounds__(128)
+surface_kernel(DevParams p, FilterArgs a, PostArgs o)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	particleinfo info = o.infoInOut[index];
+	const float4 pos = a.pos[index];
+	if (PART_TYPE(info) != PT_FLUID || !is_active_w(pos.w)) {
+		if (o.normals) o.normals[index] = make_float4(NAN, NAN, NAN, NAN);
+		return;
+	}
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	info.x &= (unsigned short)~FG_SURFACE;
+	float4 normal = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	normal.w = kernel_W<KERNEL>(p, 0.0f)*pos.w/((a.vel[index].w + 1.0f)*p.rho0[FLUID_NUM(info)]);
+	auto first = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		const float neib_vol = npos.w/((a.vel[j].w + 1.0f)*p.rho0[FLUID_NUM(o.infoInOut[j])]);
+		if (r < p.influenceradius) {
+			const float f = kernel_F_exact<KERNEL>(p, r)*neib_vol;
+			normal.x -= f*rx; normal.y -= f*ry; normal.z -= f*rz;
+			normal.w += kernel_W<KERNEL>(p, r)*neib_vol;
+		}
+	};
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, first);
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, first);
+	if (p.simflags & SPHX_ENABLE_PLANES)
+		for (uint32_t k = 0; k < p.numplanes; ++k) {
+			const float dx = (gridPos.x - p.plane_gridpos[k][0])*p.cs[0] + (pos.x - p.plane_pos[k][0]);
+			const float dy = (gridPos.y - p.plane_gridpos[k][1])*p.cs[1] + (pos.y - p.plane_pos[k][1]);
+			const float dz = (gridPos.z - p.plane_gridpos[k][2])*p.cs[2] + (pos.z - p.plane_pos[k][2]);
+			const float r = fabsf(dx*p.plane_normal[k][0] + dy*p.plane_normal[k][1] + dz*p.plane_normal[k][2]);
+			if (r < p.influenceradius) {
+				const float len = sqrtf(normal.x*normal.x + normal.y*normal.y + normal.z*normal.z);
+				normal.x += p.plane_normal[k][0]*len; normal.y += p.plane_normal[k][1]*len; normal.z += p.plane_normal[k][2]*len;
+			}
+		}
+	const float normal_length = sqrtf(normal.x*normal.x + normal.y*normal.y + normal.z*normal.z);
+	int nc = 0;
+	auto second = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		if (r < p.influenceradius) {
+			const float criteria = -(normal.x*rx + normal.y*ry + normal.z*rz);
+			const float cosconeangle = (PART_TYPE(o.infoInOut[j]) == PT_FLUID) ? o.cosconeanglefluid : o.cosconeanglenonfluid;
+			if (criteria > r*normal_length*cosconeangle) nc++;
+		}
+	};
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, second);
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, second);
+	if (!nc) info.x |= FG_SURFACE;
+	o.infoInOut[index] = info;
+	if (o.normals) {
+		normal.x /= normal_length; normal.y /= normal_length; normal.z /= normal_length;
+		o.normals[index] = normal;
+	}
+}
+
+template<int KERNEL>
+static void launch_post(int type, dim3 grid, hipStream_t st, const DevParams &p, const FilterArgs &a, const PostArgs &o)
+{
+	if (type == SPHX_VORTICITY) vorticity_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a, o);
+	else if (type == SPHX_TESTPOINTS) testpoints_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a, o);
+	else surface_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a, o);
+}
+
+extern "C" int sphx_postprocess(sphx_ctx *ctx, int type,
+	void *vorticity, void *velInOut, void *infoInOut, void *normals,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float cosconeanglefluid, float cosconeanglenonfluid, void *stream)
+{
+	(void)numParticles;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_postprocess: constants not set");
+	SPHX_REQUIRE(type == SPHX_VORTICITY || type == SPHX_TESTPOINTS || type == SPHX_SURFACE_DETECTION,
+		"sphx_postprocess: non-existing postprocess filter invoked");
+	SPHX_REQUIRE(pos && hash && cellStart && neibsList, "sphx_postprocess: missing buffer (POS, HASH, CELLSTART, NEIBSLIST)");
+	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY && ctx->dev.boundarytype != SPHX_LJ_BOUNDARY)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_postprocess: only LJ/DYN boundaries are built");
+	if (!particleRangeEnd) return SPHX_OK;
+	FilterArgs a;
+	a.newVel = nullptr; a.pos = (const float4*)pos; a.vel = (const float4*)vel;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.numParticles = particleRangeEnd;
+	PostArgs o;
+	o.vorticity = (float*)vorticity; o.velInOut = (float4*)velInOut; o.infoInOut = (particleinfo*)infoInOut;
+	o.normals = (float4*)normals; o.cosconeanglefluid = cosconeanglefluid; o.cosconeanglenonfluid = cosconeanglenonfluid;
+	if (type == SPHX_VORTICITY) SPHX_REQUIRE(vorticity && vel && info, "sphx_postprocess(VORTICITY): needs VORTICITY, VEL, INFO");
+	if (type == SPHX_TESTPOINTS) SPHX_REQUIRE(velInOut && info, "sphx_postprocess(TESTPOINTS): needs VEL (updated in place), INFO");
+	if (type == SPHX_SURFACE_DETECTION) {
+		SPHX_REQUIRE(infoInOut && vel, "sphx_postprocess(SURFACE_DETECTION): needs INFO (updated in place), VEL");
+		a.info = (const particleinfo*)infoInOut;
+	}
+	const dim3 grid(div_up_u(particleRangeEnd, 128));
+	hipStream_t st = (hipStream_t)stream;
+	switch (ctx->dev.kerneltype) {
+	case SPHX_CUBICSPLINE: launch_post<SPHX_CUBICSPLINE>(type, grid, st, ctx->dev, a, o); break;
+	case SPHX_QUADRATIC:   launch_post<SPHX_QUADRATIC>(type, grid, st, ctx->dev, a, o); break;
+	case SPHX_WENDLAND:    launch_post<SPHX_WENDLAND>(type, grid, st, ctx->dev, a, o); break;
+	case SPHX_GAUSSIAN:    launch_post<SPHX_GAUSSIAN>(type, grid, st, ctx->dev, a, o); break;
+	default: return sphx_set_error(SPHX_ERR_INVALID, "sphx_postprocess: invalid kernel type");
+	}
+	SPHX_LAUNCH_CHECK("postprocess kernel");
+	return SPHX_OK;
+}
+
 template<int KERNEL>
 static void launch_filter(int filtertype, dim3 grid, hipStream_t st, const DevParams &p, const FilterArgs &a)
 {

@@ -66,3 +66,6 @@ DEFAULT_LINEARIZATION = "yzx"
 
 # FilterType (src/particledefine.h:255-260)
 SHEPARD_FILTER, MLS_FILTER = 0, 1
+
+# PostProcessType (src/particledefine.h:290-299)
+VORTICITY, TESTPOINTS, SURFACE_DETECTION = 0, 1, 2

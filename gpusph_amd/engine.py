@@ -168,6 +168,28 @@ class TimestepEngine:
                                          self.params.influenceradius, s))
         self.vel, self.vel2 = self.vel2, self.vel
 
+    # ------------------------------------------------------------------ post-processing (before writes)
+    def postprocess(self, pptype, normals=False):
+        """POSTPROCESS command (src/GPUWorker.cc runCommand<POSTPROCESS>): VORTICITY returns a [n,3] tensor,
+        TESTPOINTS updates the velocity rows of test points in place, SURFACE_DETECTION updates FG_SURFACE in
+        INFO in place (and returns the normals when asked)."""
+        L, h, s = self.lib, self.ctx.handle, self._stream()
+        p = capi.ptr
+        n = self.n
+        pp = self.problem.physparams
+        out = None
+        vort = nrm = None
+        if pptype == D.VORTICITY:
+            vort = out = torch.empty((self.alloc, 3), dtype=torch.float32, device=self.device)
+        if pptype == D.SURFACE_DETECTION and normals:
+            nrm = out = torch.empty((self.alloc, 4), dtype=torch.float32, device=self.device)
+        capi.check(L.sphx_postprocess(h, int(pptype), p(vort), p(self.vel) if pptype == D.TESTPOINTS else None,
+                                      p(self.info) if pptype == D.SURFACE_DETECTION else None, p(nrm),
+                                      p(self.pos), p(self.vel), p(self.info), p(self.hash), p(self.cellStart),
+                                      p(self.neibslist), n, n, float(getattr(pp, "cosconeanglefluid", 0.86)),
+                                      float(getattr(pp, "cosconeanglenonfluid", 0.5)), s))
+        return None if out is None else out[:n]
+
     # ------------------------------------------------------------------ forces / euler
     def _forces(self, pos, vel, step, combine_min):
         L, h, s = self.lib, self.ctx.handle, self._stream()

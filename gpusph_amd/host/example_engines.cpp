@@ -151,6 +151,10 @@ int main(int argc, char **argv)
 			std::swap(cur, oth);
 			dt = std::min(dts[0], dts[1]);     // TIME_STEP_EPILOGUE (src/GPUSPH.cc:650-657)
 		}
+		// POSTPROCESS before a write (src/GPUWorker.cc runCommand<POSTPROCESS>): free-surface flags into INFO
+		std::unique_ptr<AbstractPostProcessEngine> surf(fw.newPostProcessEngine(SURFACE_DETECTION));
+		surf->setconstants(&sp, &pp, A);
+		surf->process(*cur, *cur, n, n, 0, nullptr);
 		hip_throw(hipDeviceSynchronize(), "sync");
 		hip_throw(hipMemcpy(hpos.data(), cur->getData<BUFFER_POS>(), 16*(size_t)n, hipMemcpyDeviceToHost), "download");
 		hip_throw(hipMemcpy(hvel.data(), cur->getData<BUFFER_VEL>(), 16*(size_t)n, hipMemcpyDeviceToHost), "download");

@@ -56,6 +56,8 @@ typedef size_t idx_t;                  // src/common_types.h:75
 #define BUFFER_RB_KEYS          ((flag_t)1U << 13)
 #define BUFFER_XSPH             ((flag_t)1U << 16)
 #define BUFFER_TAU              ((flag_t)1U << 17)
+#define BUFFER_VORTICITY        (BUFFER_TAU << 1)
+#define BUFFER_NORMALS          (BUFFER_VORTICITY << 1)
 #define BUFFER_CFL              ((flag_t)1ULL << 33)
 #define BUFFER_CFL_TEMP         ((flag_t)1ULL << 35)
 #define BUFFER_SPS_TURBVISC     ((flag_t)1ULL << 37)
@@ -77,6 +79,8 @@ SPHX_BUFFER_TRAITS(BUFFER_FORCES, float4, 1, "Force");
 SPHX_BUFFER_TRAITS(BUFFER_RB_FORCES, float4, 1, "Object forces");
 SPHX_BUFFER_TRAITS(BUFFER_RB_TORQUES, float4, 1, "Object torques");
 SPHX_BUFFER_TRAITS(BUFFER_RB_KEYS, uint, 1, "Object particle key");
+SPHX_BUFFER_TRAITS(BUFFER_VORTICITY, float3, 1, "Vorticity");
+SPHX_BUFFER_TRAITS(BUFFER_NORMALS, float4, 1, "Normals");
 SPHX_BUFFER_TRAITS(BUFFER_XSPH, float4, 1, "XSPH");
 SPHX_BUFFER_TRAITS(BUFFER_TAU, float2, 3, "Tau");
 SPHX_BUFFER_TRAITS(BUFFER_CFL, float, 1, "CFL array");
@@ -215,6 +219,7 @@ struct PhysParams {
 	float3 gravity = make_float3(0, 0, -9.81f);
 	float artvisccoeff = 0.3f, epsartvisc = 0, smagfactor = 0, kspsfactor = 0;
 	float dcoeff = 0, p1coeff = 12, p2coeff = 6, r0 = 0;
+	float cosconeanglefluid = 0.86f, cosconeanglenonfluid = 0.5f;
 	size_t numFluids() const { return rho0.size(); }
 };
 struct TimingInfo {   // src/timing.h:43-100
@@ -287,6 +292,28 @@ public:
 	virtual void getconstants() = 0;
 	virtual void process(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint particleRangeEnd,
 		float slength, float influenceradius) = 0;
+};
+
+// src/engine_postprocess.h:49-105 (host-side hooks hostAllocate/hostProcess/write belong to FLUX/CALC_PRIVATE and
+// the writers: not part of the device path)
+enum PostProcessType { FIRST_POSTPROC = 0, VORTICITY = FIRST_POSTPROC, TESTPOINTS, SURFACE_DETECTION,
+	INTERFACE_DETECTION, FLUX_COMPUTATION, CALC_PRIVATE, INVALID_POSTPROC };   // src/particledefine.h:290-299
+#define NO_FLAGS ((flag_t)0)
+struct GlobalData;
+
+class AbstractPostProcessEngine {
+protected:
+	flag_t m_options;
+public:
+	explicit AbstractPostProcessEngine(flag_t options = NO_FLAGS) : m_options(options) {}
+	virtual ~AbstractPostProcessEngine() {}
+	flag_t const& get_options() const { return m_options; }
+	virtual void setconstants(const SimParams *simparams, const PhysParams *physparams, idx_t const& allocatedParticles) const = 0;
+	virtual void getconstants() = 0;
+	virtual void process(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint particleRangeEnd,
+		uint deviceIndex, const GlobalData * const gdata) = 0;
+	virtual flag_t get_written_buffers() const = 0;
+	virtual flag_t get_updated_buffers() const = 0;
 };
 
 class AbstractIntegrationEngine {
@@ -530,6 +557,38 @@ public:
 	}
 };
 
+// CUDAPostProcessEngine<pptype, kerneltype, boundarytype, simflags> (src/cuda/post_process.cu:88-300)
+class HIPPostProcessEngine : public AbstractPostProcessEngine {
+	std::shared_ptr<HIPEngineContext> m_c;
+	PostProcessType m_type;
+	mutable float m_cosf = 0.86f, m_cosn = 0.5f;   // PhysParams::cosconeangle{fluid,nonfluid}, src/physparams.h:418-419
+public:
+	HIPPostProcessEngine(std::shared_ptr<HIPEngineContext> c, PostProcessType type, flag_t options) :
+		AbstractPostProcessEngine(options), m_c(c), m_type(type) {}
+	void setconstants(const SimParams *, const PhysParams *pp, idx_t const&) const override {
+		if (pp) { m_cosf = pp->cosconeanglefluid; m_cosn = pp->cosconeanglenonfluid; }
+	}
+	void getconstants() override {}
+	flag_t get_written_buffers() const override {
+		return m_type == VORTICITY ? BUFFER_VORTICITY : m_type == SURFACE_DETECTION ? (m_options & BUFFER_NORMALS) : BUFFER_NONE;
+	}
+	flag_t get_updated_buffers() const override {
+		return m_type == TESTPOINTS ? BUFFER_VEL : m_type == SURFACE_DETECTION ? BUFFER_INFO : BUFFER_NONE;
+	}
+	void process(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint particleRangeEnd,
+		uint, const GlobalData * const) override
+	{
+		sphx_throw(sphx_postprocess(m_c->ctx(), (int)m_type,
+			m_type == VORTICITY ? bufwrite.getData<BUFFER_VORTICITY>() : nullptr,
+			m_type == TESTPOINTS ? bufwrite.getData<BUFFER_VEL>() : nullptr,
+			m_type == SURFACE_DETECTION ? bufwrite.getData<BUFFER_INFO>() : nullptr,
+			(m_type == SURFACE_DETECTION && (m_options & BUFFER_NORMALS)) ? bufwrite.getData<BUFFER_NORMALS>() : nullptr,
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			numParticles, particleRangeEnd, m_cosf, m_cosn, nullptr));
+	}
+};
+
 // ---- factory: the engine-owning part of SimFramework (src/simframework.h:65-136) ----
 class HIPSimFramework {
 	std::shared_ptr<HIPEngineContext> m_c;
@@ -551,6 +610,13 @@ public:
 		if (filtertype != SHEPARD_FILTER && filtertype != MLS_FILTER)
 			throw std::runtime_error("Invalid filter type");
 		return new HIPFilterEngine(m_c, filtertype, (uint)frequency);
+	}
+	// newPostProcessEngine (src/cuda/cudasimframework.cu:249-268): the engines not built here throw like the reference's default
+	AbstractPostProcessEngine *newPostProcessEngine(PostProcessType pptype, flag_t options = NO_FLAGS)
+	{
+		if (pptype != VORTICITY && pptype != TESTPOINTS && pptype != SURFACE_DETECTION)
+			throw std::runtime_error("Unknown filter type");
+		return new HIPPostProcessEngine(m_c, pptype, options);
 	}
 };
 

@@ -48,6 +48,8 @@ class PhysParams:
     p1coeff: float = 12.0
     p2coeff: float = 6.0
     r0: float = float("nan")
+    cosconeanglefluid: float = 0.86     # free-surface detection cone angles (src/physparams.h:418-419)
+    cosconeanglenonfluid: float = 0.5
 
     def numFluids(self):
         return len(self.rho0)

@@ -204,7 +204,7 @@ class DamBreak3D(Problem):
 
     def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
                  jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY,
-                 walls="particles"):
+                 walls="particles", testpoints=()):
         super().__init__()
         self.m_name = "DamBreak3D"
         sp, pp = self.simparams, self.physparams
@@ -240,6 +240,7 @@ class DamBreak3D(Problem):
         self.m_origin = np.zeros(3)
         self.m_size = np.array(self.DIM, dtype=np.float64)
         self.obstacle = obstacle
+        self.testpoints = np.asarray(list(testpoints), dtype=np.float64).reshape(-1, 3)   # add_testpoint()
         self.hydrostatic = hydrostatic
         self.jitter = jitter
         if obstacle:
@@ -321,11 +322,13 @@ class DamBreak3D(Problem):
             oy0 = L[1] / 2 - self.OBSTACLE_SIDE / 2
             obst = np.stack([ox0 + o[:, 0] * odx, oy0 + o[:, 1] * odx, (Lr + o[:, 2]) * dx[2]], axis=1)
         nf, nw, no = len(fluid), len(wall), len(obst)
-        ntot = nf + nw + no
+        nt = len(self.testpoints)
+        ntot = nf + nw + no + nt
         pos = np.empty((ntot, 4), dtype=np.float64)
         pos[:nf, :3] = fluid
         pos[nf:nf + nw, :3] = wall
-        pos[nf + nw:, :3] = obst
+        pos[nf + nw:nf + nw + no, :3] = obst
+        pos[nf + nw + no:, :3] = self.testpoints     # appended last here (the reference numbers them first)
         rho0 = self.physparams.rho0[0]
         pos[:, 3] = rho0 * dp ** 3           # mass = rho0 dp^3
         vel = np.zeros((ntot, 4), dtype=np.float32)
@@ -343,7 +346,8 @@ class DamBreak3D(Problem):
         tf = np.empty(ntot, dtype=np.uint16)
         tf[:nf] = D.PT_FLUID
         tf[nf:nf + nw] = D.PT_BOUNDARY
-        tf[nf + nw:] = D.PT_BOUNDARY | D.FG_MOVING_BOUNDARY | D.FG_COMPUTE_FORCE
+        tf[nf + nw:nf + nw + no] = D.PT_BOUNDARY | D.FG_MOVING_BOUNDARY | D.FG_COMPUTE_FORCE
+        tf[nf + nw + no:] = D.PT_TESTPOINT
         objfl = np.zeros(ntot, dtype=np.uint16)   # fluid number 0; object number 0 for the obstacle
         info = make_particleinfo(tf, objfl, ids)
         self.parts = HostParticles(pos, vel, info)

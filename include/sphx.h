@@ -58,6 +58,7 @@ enum sphx_rheology    { SPHX_INVISCID = 0, SPHX_NEWTONIAN = 1 };
 enum sphx_turbulence  { SPHX_LAMINAR_FLOW = 0, SPHX_ARTIFICIAL = 1, SPHX_SPS = 2, SPHX_KEPSILON = 3 };
 enum sphx_runmode     { SPHX_REPACK = 0, SPHX_SIMULATE = 1 };
 enum sphx_filter      { SPHX_SHEPARD_FILTER = 0, SPHX_MLS_FILTER = 1 };   /* FilterType, src/particledefine.h:255-260 */
+enum sphx_postproc    { SPHX_VORTICITY = 0, SPHX_TESTPOINTS = 1, SPHX_SURFACE_DETECTION = 2 };   /* PostProcessType, :290-299 */
 #define SPHX_PERIODIC_X 1u
 #define SPHX_PERIODIC_Y 2u
 #define SPHX_PERIODIC_Z 4u
@@ -220,6 +221,21 @@ int sphx_filter_process(sphx_ctx *ctx, int filtertype, void *newVel,
 	const void *pos, const void *oldVel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, float slength, float influenceradius, void *stream);
+
+/* ---- AbstractPostProcessEngine (run before writes) ---------------------------------------- */
+/* process (src/engine_postprocess.h:80-87, CUDAPostProcessEngine src/cuda/post_process.cu:88-300; kernels
+ * calcVortDevice / calcTestpointsVelocityDevice / calcSurfaceparticleDevice src/cuda/post_process_kernel.cu:58-392):
+ *   SPHX_VORTICITY          writes vorticity (3 floats per particle, NaN for non-fluid / inactive); reads vel, info
+ *   SPHX_TESTPOINTS         overwrites the velocity rows of test points in velInOut with the Shepard-normalised
+ *                           velocity (xyz) and pressure (w) of their fluid neighbours; reads info
+ *   SPHX_SURFACE_DETECTION  sets/clears FG_SURFACE of fluid particles in infoInOut; reads vel; normals (float4,
+ *                           BUFFER_NORMALS option) may be NULL; cosconeangle*: PhysParams, src/physparams.h:370-371
+ * Buffers a type does not use may be NULL. */
+int sphx_postprocess(sphx_ctx *ctx, int type,
+	void *vorticity, void *velInOut, void *infoInOut, void *normals,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float cosconeanglefluid, float cosconeanglenonfluid, void *stream);
 
 /* ---- AbstractIntegrationEngine ------------------------------------------------------------ */
 /* basicstep (src/cuda/euler.cu:329-366).  dt is the step's dt or dt/2 exactly as the

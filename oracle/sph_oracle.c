@@ -1234,3 +1234,167 @@ void orc_mls(const orc_params *p, orc_f4 *newVel,
 		newVel[index] = vel;
 	}
 }
+
+/* ==== post-processing engines: src/cuda/post_process_kernel.cu:58-392 ============================== */
+
+/* calcVortDevice :58-135: vorticity of active fluid particles from their FLUID neighbours, NaN elsewhere */
+void orc_vorticity(const orc_params *p, float *vorticity /* 3 per particle */,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		const orc_f4 pos = posArray[index];
+		float *out = vorticity + 3*(size_t)index;
+		if (PART_TYPE(info) != PT_FLUID || INACTIVE(pos)) { out[0] = out[1] = out[2] = NAN; continue; }
+		const orc_f4 vel = velArray[index];
+		float vx = 0.0f, vy = 0.0f, vz = 0.0f;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			if (!isfinite(npos.w)) continue;
+			const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+			const orc_f4 nvel = velArray[neib_index];
+			const float ux = vel.x - nvel.x, uy = vel.y - nvel.y, uz = vel.z - nvel.z;   /* relVel, .w = neib rho~ */
+			if (r < p->influenceradius) {
+				const float f = F_c(p->kerneltype, r, p->slength, fcoeff)*npos.w/
+					physical_density(p, nvel.w, FLUID_NUM(infoArray[neib_index]));
+				vx += f*(uy*rz - uz*ry);
+				vy += f*(uz*rx - ux*rz);
+				vz += f*(ux*ry - uy*rx);
+			}
+		}
+		out[0] = vx; out[1] = vy; out[2] = vz;
+	}
+}
+
+/* calcTestpointsVelocityDevice :138-236 (non-SA, no k-epsilon): Shepard-normalised velocity and pressure of the
+ * FLUID neighbours, written over the test point's own velocity row (the kernel reads and writes the same array) */
+void orc_testpoints(const orc_params *p, orc_f4 *velArray,
+	const orc_f4 *posArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!TESTPOINT(info)) continue;
+		const orc_f4 pos = posArray[index];
+		orc_f4 avg = {0, 0, 0, 0};
+		float alpha = 0.0f;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+			if (r < p->influenceradius) {
+				const orc_f4 nvel = velArray[neib_index];
+				const int nfl = FLUID_NUM(infoArray[neib_index]);
+				const float w = W_c(p->kerneltype, r, p->slength, wcoeff, wsub)*npos.w/physical_density(p, nvel.w, nfl);
+				avg.x += w*nvel.x; avg.y += w*nvel.y; avg.z += w*nvel.z;
+				avg.w += w*orc_P(p, nvel.w, nfl);
+				alpha += w;
+			}
+		}
+		if (alpha > 1e-5f) {
+			const float inv = 1.0f/alpha;     /* float4 /= float, src/vector_math.h */
+			avg.x *= inv; avg.y *= inv; avg.z *= inv; avg.w *= inv;
+		} else {
+			avg.x = avg.y = avg.z = avg.w = 0.0f;
+		}
+		velArray[index] = avg;
+	}
+}
+
+/* calcSurfaceparticleDevice :239-392 (non-SA): FG_SURFACE flag of fluid particles from the cone test around the
+ * (unnormalised) SPH normal; optional normals (xyz normalised, w = Shepard sum).  infoArray is updated in place. */
+void orc_surface(const orc_params *p, orc_info *infoArray, orc_f4 *normals /* may be NULL */,
+	const orc_f4 *posArray, const orc_f4 *velArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd,
+	float cosconeanglefluid, float cosconeanglenonfluid)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
+	/* first pass reads the type bits only, which the second pass never changes: in-place update is race free */
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		orc_info info = infoArray[index];
+		const orc_f4 pos = posArray[index];
+		if (PART_TYPE(info) != PT_FLUID || INACTIVE(pos)) {
+			if (normals) { const orc_f4 nn = { NAN, NAN, NAN, NAN }; normals[index] = nn; }
+			continue;
+		}
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		info.x &= (uint16_t)~FG_SURFACE;
+		orc_f4 normal = {0, 0, 0, 0};
+		normal.w = W_c(p->kerneltype, 0.0f, p->slength, wcoeff, wsub)*pos.w/physical_density(p, velArray[index].w, FLUID_NUM(info));
+		for (int ptype = PT_FLUID; ptype <= PT_BOUNDARY; ++ptype) {   /* for_every_neib, non-SA */
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				if (!isfinite(npos.w)) continue;
+				const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+				const float neib_vol = npos.w/physical_density(p, velArray[neib_index].w, FLUID_NUM(infoArray[neib_index]));
+				if (r < p->influenceradius) {
+					const float f = F_c(p->kerneltype, r, p->slength, fcoeff)*neib_vol;
+					normal.x -= f*rx; normal.y -= f*ry; normal.z -= f*rz;
+					normal.w += W_c(p->kerneltype, r, p->slength, wcoeff, wsub)*neib_vol;
+				}
+			}
+		}
+		if ((p->simflags & ORC_ENABLE_PLANES))
+			for (uint32_t k = 0; k < p->numplanes; ++k) {
+				const float dx = (gridPos[0] - p->plane_gridpos[k][0])*p->cellSize[0] + (pos.x - p->plane_pos[k][0]);
+				const float dy = (gridPos[1] - p->plane_gridpos[k][1])*p->cellSize[1] + (pos.y - p->plane_pos[k][1]);
+				const float dz = (gridPos[2] - p->plane_gridpos[k][2])*p->cellSize[2] + (pos.z - p->plane_pos[k][2]);
+				const float *nrm = p->plane_normal[k];
+				const float r = fabsf(dx*nrm[0] + dy*nrm[1] + dz*nrm[2]);
+				if (r < p->influenceradius) {
+					const float len = sqrtf(normal.x*normal.x + normal.y*normal.y + normal.z*normal.z);
+					normal.x += nrm[0]*len; normal.y += nrm[1]*len; normal.z += nrm[2]*len;
+				}
+			}
+		const float normal_length = sqrtf(normal.x*normal.x + normal.y*normal.y + normal.z*normal.z);
+		int nc = 0;
+		for (int ptype = PT_FLUID; ptype <= PT_BOUNDARY; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				if (!isfinite(npos.w)) continue;
+				const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+				if (r < p->influenceradius) {
+					const float criteria = -(normal.x*rx + normal.y*ry + normal.z*rz);
+					const float cosconeangle = (PART_TYPE(infoArray[neib_index]) == PT_FLUID) ? cosconeanglefluid : cosconeanglenonfluid;
+					if (criteria > r*normal_length*cosconeangle) nc++;
+				}
+			}
+		}
+		if (!nc) info.x |= FG_SURFACE;
+		infoArray[index] = info;
+		if (normals) {
+			normal.x /= normal_length; normal.y /= normal_length; normal.z /= normal_length;
+			normals[index] = normal;
+		}
+	}
+}

@@ -203,6 +203,23 @@ class Oracle:
         fn(C.byref(self.p), P(new), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), C.c_uint32(range_end))
         return new
 
+    def vorticity(self, pos, vel, info, hash_, cs, nl, range_end):
+        out = np.zeros((len(pos), 3), dtype=np.float32)
+        self.L.orc_vorticity(C.byref(self.p), P(out), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), C.c_uint32(range_end))
+        return out
+
+    def testpoints(self, pos, vel, info, hash_, cs, nl, range_end):
+        new = vel.copy()
+        self.L.orc_testpoints(C.byref(self.p), P(new), P(pos), P(info), P(hash_), P(cs), P(nl), C.c_uint32(range_end))
+        return new
+
+    def surface(self, pos, vel, info, hash_, cs, nl, range_end, normals=False, cosf=0.86, cosn=0.5):
+        new = info.copy()
+        nrm = np.zeros((len(pos), 4), dtype=np.float32) if normals else None
+        self.L.orc_surface(C.byref(self.p), P(new), P(nrm), P(pos), P(vel), P(hash_), P(cs), P(nl), C.c_uint32(range_end),
+                           C.c_float(cosf), C.c_float(cosn))
+        return new, nrm
+
     def sps(self, pos, vel, info, hash_, cs, nl, n, range_end):
         tau = np.zeros((len(pos), 6), dtype=np.float32)
         tv = np.zeros(len(pos), dtype=np.float32)

@@ -350,7 +350,9 @@ def test_cpp_adapters_match_python_engine(tmp_path):
     r = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     eng.run(steps)
+    eng.postprocess(D.SURFACE_DETECTION)       # the driver runs HIPPostProcessEngine(SURFACE_DETECTION) before its dump
     ref = eng.download()
+    assert ((ref["info"].reshape(-1, 4)[:, 0] & D.FG_SURFACE) != 0).sum() > 50
     raw = open(fout, "rb").read()
     n2 = int(np.frombuffer(raw, np.uint32, 1, 0)[0]); dt2 = np.frombuffer(raw, np.float32, 1, 4)[0]
     assert n2 == eng.n
@@ -550,3 +552,43 @@ def test_planes_forces_and_trajectory():
     assert np.abs(out["pos"][:, :3] - sim2.pos[:n2, :3]).max() <= 1e-6 * cs * steps
     vmax = max(np.abs(sim2.vel[:n2, :3]).max(), 1e-6)
     assert np.abs(out["vel"][:, :3] - sim2.vel[:n2, :3]).max() <= 1e-3 * vmax
+
+
+# ---------------------------------------------------------------------------------------------
+# post-processing engines (vorticity, test points, free-surface detection): bit-exact vs the oracle
+def test_postprocess_bit_exact():
+    import torch
+    pts = [(0.2, 0.3, 0.2), (0.25, 0.35, 0.1), (1.2, 0.3, 0.3)]
+    prob = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.1, hydrostatic=False, testpoints=pts)
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    assert np.array_equal(_np(eng.neibslist, np.uint16).reshape(-1, eng.alloc)[:, :n],
+                          sim.nl.reshape(-1, len(sim.pos))[:, :n])
+    rng = np.random.default_rng(9)
+    vel = sim.vel.copy()
+    vel[:, :3] += rng.uniform(-0.4, 0.4, size=(len(vel), 3)).astype(np.float32)
+    vel[:, 3] += rng.uniform(0, 2e-3, size=len(vel)).astype(np.float32)
+    sim.vel = vel
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    # vorticity
+    ref = sim.o.vorticity(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    out = _np(eng.postprocess(D.VORTICITY))
+    assert np.array_equal(out.view(np.uint32), ref[:n].view(np.uint32))      # NaN rows included
+    # surface detection (+ normals)
+    ref_info, ref_nrm = sim.o.surface(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n, normals=True)
+    nrm = _np(eng.postprocess(D.SURFACE_DETECTION, normals=True))
+    assert np.array_equal(_np(eng.info, np.uint16)[:n], ref_info[:n])
+    assert ((ref_info[:n, 0] & D.FG_SURFACE) != 0).sum() > 100
+    assert np.array_equal(nrm.view(np.uint32), ref_nrm[:n].view(np.uint32))
+    # test points (last: it overwrites velocity rows)
+    ref_vel = sim.o.testpoints(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng.postprocess(D.TESTPOINTS)
+    got = _np(eng.vel)[:n]
+    tp = (sim.info[:n, 0] & 7) == D.PT_TESTPOINT
+    assert tp.sum() == 3
+    assert np.array_equal(got[~tp].view(np.uint32), vel[:n][~tp].view(np.uint32))
+    assert np.array_equal(got[tp, :3].view(np.uint32), ref_vel[:n][tp, :3].view(np.uint32))
+    # pressure goes through powf: device libm vs glibc, 2 ulp
+    assert np.abs(got[tp, 3] - ref_vel[:n][tp, 3]).max() <= 4e-7 * np.abs(ref_vel[:n][tp, 3]).max()

@@ -304,3 +304,90 @@ def test_plane_repulsion_equals_brute_force():
         ref[m] += (f * r[m])[:, None] * nrm
     assert (np.abs(ref).max(axis=1) > 0).sum() > 50
     assert np.abs(lj - ref).max() <= 2e-4 * np.abs(ref).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# post-processing engines: known answers
+def _bulk_mask(sim, n, pct=60):
+    nl = sim.nl.reshape(-1, len(sim.pos))[:, :n]
+    cnt = (nl != 0xFFFF).sum(axis=0)
+    fluid = (sim.info[:n, 0] & 7) == 0
+    return fluid & (cnt >= np.percentile(cnt[fluid], pct)), fluid
+
+
+def test_vorticity_of_a_rigid_rotation():
+    """v = Omega x (x - c): curl v = 2 Omega everywhere.  The kernel sums f (v_ij x r_ij) with f = F V_j =
+    (1/r dW/dr) V_j <= 0, which is the SPH estimate of -curl... sign and factor are the reference's: for a rigid
+    rotation sum_j F V_j (Omega x r_ij) x r_ij = -Omega sum F V r^2 + ..., i.e. 2 Omega for a full kernel support
+    (sum_j F V_j r_a r_b = -delta_ab).  Checked in the bulk of a jittered lattice to a few per cent."""
+    prob = DamBreak3D(deltap=0.03, obstacle=False, jitter=0.1, hydrostatic=False)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    omega = np.array([0.3, -0.2, 0.5])
+    vel = sim.vel.copy()
+    vel[:n, :3] = np.cross(omega, gp - gp.mean(axis=0)).astype(np.float32)
+    vort = sim.o.vorticity(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    fluid = (sim.info[:n, 0] & 7) == 0
+    # full support of FLUID neighbours only (vorticity ignores boundary particles): an influence radius inside the column
+    R = float(sim.o.p.influenceradius) + prob.m_deltap
+    lo, hi = gp[fluid].min(axis=0), gp[fluid].max(axis=0)
+    sel = fluid & np.all(gp > lo + R, axis=1) & np.all(gp < hi - R, axis=1)
+    assert sel.sum() > 20
+    # the discrete moment sum_j F V_j r_a r_b of a jittered lattice at h = 1.3 dp is ~ -0.9 delta_ab (the same ~10 %
+    # deficit as the Shepard sum in test_kernel_partition_of_unity), so the estimate is c * 2 Omega with one common c
+    w = vort[:n][sel].astype(np.float64)
+    c = (w @ (2 * omega)) / np.dot(2 * omega, 2 * omega)
+    assert np.all(c > 0.85) and np.all(c < 1.02)
+    assert np.abs(w - c[:, None] * (2 * omega)).max() < 0.03 * np.linalg.norm(2 * omega)
+    assert np.all(np.isnan(vort[:n][~fluid]))
+
+
+def test_testpoints_sample_a_uniform_flow():
+    pts = [(0.2, 0.3, 0.2), (0.25, 0.35, 0.1), (1.2, 0.3, 0.3)]      # two inside the water column, one in the dry part
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.1, hydrostatic=False, testpoints=pts)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    u = np.array([0.4, -0.1, 0.25], dtype=np.float32)
+    rho_t = np.float32(1.5e-3)
+    vel = sim.vel.copy(); vel[:n, :3] = u; vel[:n, 3] = rho_t
+    out = sim.o.testpoints(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    tp = np.where((sim.info[:n, 0] & 7) == D.PT_TESTPOINT)[0]
+    assert len(tp) == 3
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    wet = tp[gp[tp, 0] < 0.4]
+    dry = tp[gp[tp, 0] > 0.4]
+    assert len(wet) == 2 and len(dry) == 1
+    P = float(sim.o.p.bcoeff[0]) * ((1.0 + float(rho_t)) ** float(sim.o.p.gammacoeff[0]) - 1.0)
+    assert np.abs(out[wet, :3] - u).max() < 1e-5
+    assert np.abs(out[wet, 3] - P).max() < 1e-4 * P
+    assert not np.any(out[dry])                                      # no fluid in reach: zeroed (alpha <= 1e-5)
+    others = np.setdiff1d(np.arange(n), tp)
+    assert np.array_equal(out[others], vel[others])
+
+
+def test_surface_detection_finds_the_free_surface():
+    prob = DamBreak3D(deltap=0.04, obstacle=False, hydrostatic=False)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    info, nrm = sim.o.surface(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n, normals=True)
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    fluid = (sim.info[:n, 0] & 7) == 0
+    surf = (info[:n, 0] & D.FG_SURFACE) != 0
+    assert not np.any(surf[~fluid])
+    top = fluid & (gp[:, 2] > gp[fluid, 2].max() - 0.5 * prob.m_deltap)
+    front = fluid & (gp[:, 0] > gp[fluid, 0].max() - 0.5 * prob.m_deltap)
+    # the top layer and the dam front (away from edges) are free surface; the deep interior is not
+    inner_top = top & (gp[:, 0] < gp[fluid, 0].max() - 3 * prob.m_deltap) & (gp[:, 0] > gp[fluid, 0].min() + 4 * prob.m_deltap) & \
+        (gp[:, 1] > 0.27) & (gp[:, 1] < 0.40)      # away from the walls, which rise above the water
+    assert surf[inner_top].mean() > 0.95
+    deep = fluid & (gp[:, 2] < gp[fluid, 2].max() - 4 * prob.m_deltap) & (gp[:, 0] < gp[fluid, 0].max() - 4 * prob.m_deltap)
+    assert surf[deep].mean() < 0.01
+    assert surf[front & (gp[:, 2] > 0.2) & (gp[:, 2] < 0.3) & (gp[:, 1] > 0.27) & (gp[:, 1] < 0.40)].mean() > 0.95   # dam front, away from the side walls
+    # normals of flat top-surface particles point up, unit length; w = Shepard sum in (0, 1]
+    nn = nrm[:n][inner_top]
+    assert np.all(nn[:, 2] > 0.9) and np.abs(np.linalg.norm(nn[:, :3], axis=1) - 1).max() < 1e-5
+    assert np.all(np.isnan(nrm[:n][~fluid]))
