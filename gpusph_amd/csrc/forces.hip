@@ -1093,9 +1093,24 @@ static void launch_forces_mf(bool multifluid, dim3 grid, hipStream_t stream, con
 		forces_kernel<KERNEL, TURB, COLA, false><<<grid, SPHX_BLOCK_FORCES, 0, stream>>>(p, a, guard);
 }
 
+// sphx_forces_timing: HIP events on the launch stream around the dominant kernel of a forces pass
+struct ForcesTimer {
+	const sphx_ctx *ctx; hipStream_t stream; hipEvent_t stop;
+	ForcesTimer(const sphx_ctx *c, hipStream_t s, bool on) : ctx(c), stream(s), stop(nullptr) {
+		if (!on || !c->time_forces || !c->forces_events) return;
+		hipEvent_t e0, e1;
+		if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return;
+		(void)hipEventRecord(e0, s);
+		c->forces_events->push_back(std::make_pair(e0, e1));
+		stop = e1;
+	}
+	~ForcesTimer() { if (stop) (void)hipEventRecord(stop, stream); }
+};
+
 template<int KERNEL, int TURB, bool COLA>
 static void launch_tile(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &a)
 {
+	ForcesTimer t(ctx, stream, true);
 	forces_tile_kernel<KERNEL, TURB, COLA><<<ctx->tile_grid, TILE_THREADS, 0, stream>>>(ctx->dev, a,
 		ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy);
 }
@@ -1109,6 +1124,7 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 	const bool mf = p.numfluids > 1;
 	const bool cola = p.densitydiff == SPHX_COLAGROSSI;
 	const uint32_t *guard = use_tiles ? ctx->tile_ctl + 1 : nullptr;
+	ForcesTimer t(ctx, stream, !use_tiles);   // without tiles the generic kernel is the dominant one
 	switch (p.turbmodel) {
 	case SPHX_ARTIFICIAL:
 		if (use_tiles) { if (cola) launch_tile<KERNEL, SPHX_ARTIFICIAL, true>(ctx, stream, a); else launch_tile<KERNEL, SPHX_ARTIFICIAL, false>(ctx, stream, a); }
@@ -1320,4 +1336,32 @@ extern "C" int sphx_dbg_tiles(sphx_ctx *ctx, uint32_t *host, uint32_t maxTiles)
 	const uint32_t n = ctl[0] < maxTiles ? ctl[0] : maxTiles;
 	if (hipMemcpy(host, ctx->tiles, (size_t)TILE_DESC*sizeof(uint32_t)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return (int)n;
+}
+
+// Optional profiling hook (bench.py): when enabled, every forces pass records a pair of HIP events on its launch
+// stream around its dominant kernel (forces_tile_kernel, or forces_kernel when the tiling is not used);
+// sphx_forces_timing_read synchronises the recorded events, returns their summed elapsed time and count, and
+// releases them.
+extern "C" int sphx_forces_timing(sphx_ctx *ctx, int enable)
+{
+	SPHX_REQUIRE(ctx != nullptr, "sphx_forces_timing: NULL ctx");
+	if (!ctx->forces_events) ctx->forces_events = new std::vector<std::pair<hipEvent_t, hipEvent_t> >();
+	ctx->time_forces = enable != 0;
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_timing_read(sphx_ctx *ctx, double *total_ms, uint32_t *launches)
+{
+	SPHX_REQUIRE(ctx && total_ms && launches, "sphx_forces_timing_read: NULL argument");
+	double sum = 0.0; uint32_t n = 0;
+	if (ctx->forces_events) {
+		for (auto &e : *ctx->forces_events) {
+			float ms = 0.0f;
+			if (hipEventSynchronize(e.second) == hipSuccess && hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { sum += ms; ++n; }
+			(void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+		}
+		ctx->forces_events->clear();
+	}
+	*total_ms = sum; *launches = n;
+	return SPHX_OK;
 }

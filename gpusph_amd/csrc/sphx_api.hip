@@ -68,6 +68,7 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
 	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
 	if (ctx->tile_prof) (void)hipFree(ctx->tile_prof);
+	delete ctx->forces_events;
 	delete ctx;
 }
 

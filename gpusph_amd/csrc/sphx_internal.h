@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
+#include <utility>
 #include "sphx.h"
 
 // ---- data model (GPUSPH: src/particleinfo.h:79-300, src/multi_gpu_defines.h:56-83,
@@ -123,6 +125,8 @@ struct sphx_ctx {
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
 	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments)
 	unsigned long long *tile_prof;   // SPHX_TILE_DEBUG & 16
+	bool        time_forces;   // sphx_forces_timing: bracket the dominant forces kernel with HIP events
+	std::vector<std::pair<hipEvent_t, hipEvent_t> > *forces_events;
 	const void *tiles_cellstart, *tiles_neibslist;
 	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
 };

@@ -204,6 +204,12 @@ int sphx_reduce_rb_forces(sphx_ctx *ctx, void *rbforces, void *rbtorques, const 
 	const uint32_t *h_lastindex, float *h_totalforce3, float *h_totaltorque3,
 	uint32_t numforcesbodies, uint32_t numForcesBodiesParticles, void *stream);
 
+/* Optional profiling hook (not a reference interface; used by bench.py for the roofline figure): when enabled,
+ * every sphx_forces_basicstep records HIP events on its launch stream around its dominant kernel.  _read waits
+ * for the recorded events, returns the summed elapsed time [ms] and the number of launches, and releases them. */
+int sphx_forces_timing(sphx_ctx *ctx, int enable);
+int sphx_forces_timing_read(sphx_ctx *ctx, double *total_ms, uint32_t *launches);
+
 /* ---- AbstractViscEngine ------------------------------------------------------------------- */
 /* calc_visc, SPS branch (src/cuda/visc.cu:175-234): tau0..2 are float2 arrays, turbvisc may be NULL */
 int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2, float *spsturbvisc,
