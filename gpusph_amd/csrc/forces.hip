@@ -522,14 +522,26 @@ __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 }
 
 // stage 2: the pair interactions of a gathered half, in list order
-template<int KERNEL, int TURB, bool COLAGROSSI>
+// LJ = the run uses LJ_BOUNDARY: pairs of the boundary section (ljsec, wave-uniform) and all pairs of boundary
+// particles with force feedback (ljlane) are Lennard-Jones repulsions instead of SPH interactions
+template<int KERNEL, int TURB, bool COLAGROSSI, bool LJ>
 __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered &g, const Self &s, float inv_h,
-	bool momentum, bool diffuse, float4 &force)
+	bool momentum, bool diffuse, bool ljsec, bool ljlane, float4 &force)
 {
+	if (LJ && ljsec) {
 #pragma unroll
-	for (int k = 0; k < TILE_HB; ++k)
+		for (int k = 0; k < TILE_HB; ++k)
+			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.valid[k], force);
+		return;
+	}
+	const bool anyLj = LJ && wave_any(ljlane);
+#pragma unroll
+	for (int k = 0; k < TILE_HB; ++k) {
 		pair_interact<KERNEL, TURB, COLAGROSSI, true, true>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k],
-			g.npos[k], g.nvel[k], g.naux[k], true, g.valid[k], nullptr, force, momentum, diffuse);
+			g.npos[k], g.nvel[k], g.naux[k], true, g.valid[k] && !(LJ && ljlane), nullptr, force, momentum, diffuse);
+		if (anyLj)
+			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.valid[k] && ljlane, force);
+	}
 }
 
 // Walk one section of the neighbour lists of a whole wave against the LDS window.
@@ -544,11 +556,11 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 //    computed, so the ds_read latency (and its bank conflicts) hides behind the pair arithmetic;
 //  * section, momentum and diffusion switches are run-time values so that the pair code exists
 //    once in the kernel (the instruction cache is 64 KB; four template copies did not fit).
-template<int KERNEL, int TURB, bool COLAGROSSI>
+template<int KERNEL, int TURB, bool COLAGROSSI, bool LJ>
 __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListRows &list,
 	uint32_t voff, const Self &s, float inv_h, const float4 *sShift, const uint16_t *myCB,
 	const float4 *sPos, const float4 *sVel, const float4 *sAux,
-	int sec, bool take, bool momentum, bool diffuse,
+	int sec, bool take, bool momentum, bool diffuse, bool ljlane,
 	ListWindow &lw /* batches 0..preloaded-1 already requested */, int preloaded, float4 &force)
 {
 	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
@@ -564,13 +576,13 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	if (!wave_any(A.valid[0])) return;
 #define SPHX_RING_STEP(J, JN) \
 	gather_half(lw.q[J] + TILE_HB, s, sShift, myCB, sPos, sVel, sAux, w, B); \
-	compute_half<KERNEL, TURB, COLAGROSSI>(p, A, s, inv_h, momentum, diffuse, force); \
+	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, inv_h, momentum, diffuse, sec == 1, ljlane, force); \
 	if (!wave_any(B.valid[0])) return; \
 	load_list_u(p, list, voff, sec, next, lw.q[J]); \
 	pin_batch(list, lw.q[J]); \
 	++next; \
 	gather_half(lw.q[JN], s, sShift, myCB, sPos, sVel, sAux, w, A); \
-	compute_half<KERNEL, TURB, COLAGROSSI>(p, B, s, inv_h, momentum, diffuse, force); \
+	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, inv_h, momentum, diffuse, sec == 1, ljlane, force); \
 	if (!wave_any(A.valid[0]) || next - TILE_AHEAD > lastBatch) return;   /* A now holds batch next-TILE_AHEAD */
 	for (;;) {
 		SPHX_RING_STEP(0, 1)
@@ -608,7 +620,7 @@ __device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t tid, u
 // a thread's own rows and the first batches of its neighbour list, requested one tile ahead
 struct TileOwn { particleinfo info; float4 pos, vel, aux; uint32_t hash; ListWindow lwF; uint32_t lwB0[TILE_NB]; };
 
-template<int KERNEL, int TURB, bool COLAGROSSI>
+template<int KERNEL, int TURB, bool COLAGROSSI, bool LJ>
 __global__ void __launch_bounds__(TILE_THREADS, 2)
 forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
 	uint32_t *tileCtl /* [0]=count, [1]=overflow, [2]=finished workgroups, [4..11]=per-XCD tile tickets */,
@@ -844,16 +856,19 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			const int myG1 = (p.c1 == 0) ? s.gridPos.x : (p.c1 == 1) ? s.gridPos.y : s.gridPos.z;
 			const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
 			const uint16_t *myCB = sCB + (hrow*TILE_MAXCELLS + myCol)*27;
-			const bool isFluid = ptype == PT_FLUID, isDynBound = ptype == PT_BOUNDARY && dyn;
-			// fluid: fluid section then (DYN) boundary section; DYN boundary: fluid section only, with the
-			// momentum part only for bodies with force feedback (forces_kernel.def:3650-3679)
+			const bool isFluid = ptype == PT_FLUID, isBound = ptype == PT_BOUNDARY, isDynBound = isBound && dyn;
+			// fluid: fluid section then boundary section (DYN: SPH pairs, LJ: repulsion); DYN boundary: fluid section
+			// only, with the momentum part only for bodies with force feedback (forces_kernel.def:3650-3679);
+			// LJ boundary: fluid section only for bodies with force feedback, when object forces are asked for (:3620-3645)
 			const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
-			const bool take0 = active && (isFluid || isDynBound), take1 = active && isFluid && dyn;
-			walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
-				sPos, sVel, sAux, 0, take0, momentum, true, own.lwF, TILE_AHEAD, force);
+			const bool ljlane = LJ && isBound;
+			const bool take0 = active && (isFluid || isDynBound || (ljlane && HAS_COMPUTE_FORCE(info) && a.compute_object_forces));
+			const bool take1 = active && isFluid && (dyn || LJ);
+			walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift, myCB,
+				sPos, sVel, sAux, 0, take0, momentum, true, ljlane, own.lwF, TILE_AHEAD, force);
 			if (wave_any(take1))
-				walk_section_lds<KERNEL, TURB, COLAGROSSI>(p, listRows, voff, s, inv_h, sShift, myCB,
-					sPos, sVel, sAux, 1, take1, momentum, false, lwB, 1, force);
+				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift, myCB,
+					sPos, sVel, sAux, 1, take1, momentum, false, false, lwB, 1, force);
 		}
 		if (prof) tB = wall_clock64();
 		// vmcnt(0): only the list batches fetched past the terminators and the next tile's window extents are in
@@ -1111,8 +1126,12 @@ template<int KERNEL, int TURB, bool COLA>
 static void launch_tile(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &a)
 {
 	ForcesTimer t(ctx, stream, true);
-	forces_tile_kernel<KERNEL, TURB, COLA><<<ctx->tile_grid, TILE_THREADS, 0, stream>>>(ctx->dev, a,
-		ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy);
+	if (ctx->dev.boundarytype == SPHX_LJ_BOUNDARY)
+		forces_tile_kernel<KERNEL, TURB, COLA, true><<<ctx->tile_grid, TILE_THREADS, 0, stream>>>(ctx->dev, a,
+			ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy);
+	else
+		forces_tile_kernel<KERNEL, TURB, COLA, false><<<ctx->tile_grid, TILE_THREADS, 0, stream>>>(ctx->dev, a,
+			ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy);
 }
 
 // launches the tiled kernel when the tiling of this neighbour list is available, plus the generic
@@ -1206,7 +1225,6 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && !ctx->disable_tiles &&
-		ctx->dev.boundarytype == SPHX_DYN_BOUNDARY &&   // LJ repulsion is only in the generic kernel so far
 		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
 		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
 		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit

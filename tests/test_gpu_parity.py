@@ -222,7 +222,11 @@ def test_against_committed_golden_fixture():
     assert np.abs(out["vel"][sel][:, :3] - g["s11_vel"][:n][sel][:, :3]).max() <= 1e-3 * max(np.abs(g["s11_vel"][:, :3]).max(), 1e-3)
 
 
-@pytest.mark.parametrize("case", CASES)
+LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.LJ_BOUNDARY),
+            dict(deltap=0.04, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes")]
+
+
+@pytest.mark.parametrize("case", CASES + LJ_CASES)
 def test_tiled_and_generic_kernels_agree(case, monkeypatch):
     """the LDS-tiled forces kernel and the generic gather kernel implement the same sum in the same order:
     identical accumulation order and per-pair arithmetic -> bit-identical forces"""
