@@ -31,6 +31,7 @@ struct ForcesArgs {
 	const float4 *aux;   // per-particle EOS pre-pass {P/rho^2, c, P, rho}
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
+	uint32_t numBlocks;   // generic kernel: blocks of SPHX_BLOCK_FORCES particles to cover
 	int compute_object_forces;
 	uint32_t *pin;              // always NULL (see pin_batch)
 	unsigned long long *prof;   // SPHX_TILE_DEBUG & 16: per-workgroup phase times (100 MHz ticks), else NULL
@@ -343,7 +344,10 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 {
 	// when the tiled kernel handles this launch the generic one is skipped on the device side
 	if (runIfNonZero && *runIfNonZero == 0) return;
-	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
+	// block-stride loop: as the stand-by of the tiled kernel this one is launched with a small grid (a quarter
+	// of a million workgroups that return at once cost 50 us), and still covers every block if it has to run
+	for (uint32_t blk = blockIdx.x; blk < a.numBlocks; blk += gridDim.x) {
+	const uint32_t index = blk*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
 	float cfl_term = 0.0f;
 
 	do {
@@ -397,8 +401,10 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 		if (threadIdx.x == 0) {
 			float m = wave_max[0];
 			for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) m = fmaxf(m, wave_max[w]);
-			a.cfl[a.cflOffset + blockIdx.x] = m;
+			a.cfl[a.cflOffset + blk] = m;
 		}
+		__syncthreads();   // wave_max is reused by the next block of this workgroup
+	}
 	}
 }
 
@@ -414,18 +420,17 @@ __device__ __forceinline__ void tile_group_done(uint32_t *tileCtl)
 }
 
 // ==========================================================================================
-// Tiled path (the fast one): LDS staging of the 27-cell neighbour window per workgroup.
+// Tiled path (the fast one): LDS staging of the neighbour window per workgroup.
 //
-// A tile is a run of consecutive non-empty cells of one grid row (cells along COORD1 are
-// contiguous in the sorted particle arrays) holding <= 128 particles; its neighbour window is
-// the 9 rows x (cells+2) block around it, i.e. 9 contiguous particle ranges.  The workgroup
-// copies those ranges (pos, vel, EOS aux: 48 B/particle, fully coalesced) into LDS once, then
-// every thread walks its particle's neighbour list reading the neighbour rows from LDS with
-// ds_read_b128 instead of gathering them through L1/L2 (where a 64-lane gather touches 12-20
-// different cache lines per instruction and the L2->L1 line fills, ~1/4 used, were the
-// bottleneck: 4.0 ms per launch at 8 M particles).  Tiles are produced by build_tiles_kernel
-// (neibs.hip) at neighbour-list build time.  Persistent grid: 2 workgroups per CU (LDS bound),
-// each looping over tiles, so one workgroup's staging overlaps the other's pair loop.
+// A tile is a block of k x 2 x 2 cells (k consecutive cells along COORD1 in four adjacent grid rows) holding
+// <= TILE_THREADS particles; its neighbour window is the (k+2) x 4 x 4 block around it, i.e. 16 contiguous
+// particle ranges, because cells along COORD1 are contiguous in the sorted particle arrays.  The workgroup
+// copies those ranges (pos, vel, EOS aux: 48 B/particle) into LDS once by DMA, then every thread walks its
+// particle's neighbour list reading the neighbour rows from LDS with ds_read_b128 instead of gathering them
+// through L1/L2 (where a 64-lane gather touches 12-20 different cache lines per instruction and the L2->L1
+// line fills, ~1/4 used, were the bottleneck).  Tiles are produced by build_tiles_kernel (neibs.hip) at
+// neighbour-list build time.  Persistent grid: one workgroup per CU (the window is the LDS), tiles handed out
+// by per-XCD ticket counters.  DESIGN.md 5.2 has the full account.
 // ==========================================================================================
 // list entries of one section, TILE_AHEAD batches deep: buffer q[j] holds batch j (mod TILE_AHEAD)
 struct ListWindow { uint32_t q[TILE_AHEAD][TILE_NB]; };
@@ -1102,6 +1107,7 @@ template<int KERNEL, int TURB, bool COLA>
 static void launch_forces_mf(bool multifluid, dim3 grid, hipStream_t stream, const DevParams &p, const ForcesArgs &a,
 	const uint32_t *guard)
 {
+	if (guard) grid.x = grid.x < 2048u ? grid.x : 2048u;   // stand-by launch (see forces_kernel)
 	if (multifluid)
 		forces_kernel<KERNEL, TURB, COLA, true><<<grid, SPHX_BLOCK_FORCES, 0, stream>>>(p, a, guard);
 	else
@@ -1212,6 +1218,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.rb = ctx->rb_dev;
 	a.aux = ctx->eos_aux;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
+	a.numBlocks = numBlocks;
 	a.compute_object_forces = compute_object_forces;
 	a.dbg = ctx->tile_debug;
 	a.prof = nullptr;
