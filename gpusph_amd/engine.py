@@ -268,6 +268,45 @@ class TimestepEngine:
         }
         return out
 
+    # ------------------------------------------------------------------ checkpoints (GPUSPH HotFile v1)
+    def save_hotfile(self, path):
+        """HotFile::save of the current state (src/writers/HotFile.cc:86-118); readable by GPUSPH --resume and by
+        the reference's scripts/hotdiff.py."""
+        from . import hotfile
+        st = self.download()
+        bodies = []
+        if self.num_bodies_parts:
+            pr = self.problem
+            cg = pr.m_origin + (pr.rb_cg_gridpos[0] + 0.5) * pr.m_cellsize + pr.rb_cg_pos[0]
+            first = int(pr.rb_firstindex[0])
+            bodies.append(dict(index=0, id=0, type=hotfile.MB_FORCES_MOVING, numparts=self.num_bodies_parts,
+                               firstindex=first, lastindex=self.num_bodies_parts - 1, crot=cg, lvel=[0, 0, 0], avel=[0, 0, 0],
+                               orientation=[1, 0, 0, 0]))
+        hotfile.write_hotfile(path, dict(pos=st["pos"], vel=st["vel"], info=st["info"].reshape(-1, 4), hash=st["hash"]),
+                              self.iterations, self.time(), self.current_dt(), bodies=bodies)
+
+    def load_hotfile(self, path):
+        """HotFile::load + resume: particle buffers, iteration count, t and dt come from the file; the neighbour
+        phase of the next step re-hashes and re-sorts them (calcHash, not the iteration-0 fixHash)."""
+        from . import hotfile
+        hf = hotfile.read_hotfile(path)
+        a = hf["arrays"]
+        n = hf["particles"]
+        if n > self.alloc:
+            raise capi.SphxError("HotFile has %d particles, %d allocated" % (n, self.alloc))
+        dev = self.device
+        self.n = n
+        self.pos[:n] = torch.from_numpy(a["pos"]).to(dev); self.vel[:n] = torch.from_numpy(a["vel"]).to(dev)
+        self.info[:n] = torch.from_numpy(a["info"].view(np.int16)).to(dev)
+        self.hash[:n] = torch.from_numpy(a["hash"].view(np.int32)).to(dev)
+        self.iterations = int(hf["iterations"])
+        self.dt = float(np.float32(hf["dt"]))
+        self.d_dt.fill_(self.dt); self.d_dt_next.fill_(self.dt)
+        self.d_t.fill_(float(hf["t"]))
+        if self.iterations % self.sp.buildneibsfreq != 0:
+            self.build_neibs()      # a resumed run always starts with a neighbour phase (GPUSPH::runSimulation)
+        return hf
+
     def reduce_rb_forces(self):
         """REDUCE_BODIES_FORCES for the single obstacle body; returns (force3, torque3)."""
         if not self.num_bodies_parts:

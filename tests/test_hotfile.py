@@ -1,0 +1,85 @@
+"""GPUSPH HotFile v1 round trip and the struct layouts the reference's scripts/hotdiff.py expects."""
+import struct
+import numpy as np
+import pytest
+
+from gpusph_amd import hotfile
+from gpusph_amd.problem import DamBreak3D
+
+
+def test_layouts_match_hotdiff():
+    # scripts/hotdiff.py: header '@IIIII48xLdf12x', buffer '@I64sII'; sizeof(header_t) = 104, encoded_buffer_t = 76,
+    # encoded_body_t = 6 x 4 + 26 x 8 + 10 x 4 = 272 (src/writers/HotFile.h:45-56, HotFile.cc:40-73)
+    assert struct.calcsize(hotfile.HEADER) == 104
+    assert struct.calcsize(hotfile.BUFFER) == 76
+    assert struct.calcsize(hotfile.BODY) == 272
+
+
+def test_round_trip(tmp_path):
+    prob = DamBreak3D(deltap=0.08, obstacle=True)
+    arrs = prob.copy_to_array()
+    n = len(arrs["hash"])
+    body = dict(index=0, id=0, type=hotfile.MB_FORCES_MOVING, numparts=prob.num_obstacle, firstindex=int(prob.rb_firstindex[0]),
+                lastindex=prob.num_obstacle - 1, crot=[0.96, 0.335, 0.3], lvel=[0, 0, 0], avel=[0, 0, 0], orientation=[1, 0, 0, 0])
+    path = tmp_path / "hot_00010.bin"
+    hotfile.write_hotfile(path, arrs, iterations=10, t=0.0123, dt=3.5e-4, bodies=[body])
+    hf = hotfile.read_hotfile(path)
+    assert (hf["version"], hf["particles"], hf["iterations"], hf["buffer_count"]) == (1, n, 10, 5)
+    assert hf["t"] == 0.0123 and hf["dt"] == np.float32(3.5e-4)
+    for k in ("pos", "vel", "info", "hash"):
+        assert np.array_equal(np.asarray(hf["arrays"][k]).view(np.uint8).ravel(), np.ascontiguousarray(arrs[k]).view(np.uint8).ravel())
+    assert len(hf["bodies"]) == 1 and hf["bodies"][0]["numparts"] == prob.num_obstacle
+    assert hf["bodies"][0]["crot"] == (0.96, 0.335, 0.3) and hf["bodies"][0]["initial_orientation"] == (1.0, 0.0, 0.0, 0.0)
+    # the reference tool walks the file the same way: header, then (76-byte record + element_size*n) per buffer
+    raw = open(path, "rb").read()
+    o = 104
+    names = []
+    while o < len(raw) - 272:
+        ln, name, elsize, cnt = struct.unpack("@I64sII", raw[o:o + 76])
+        names.append(name[:ln].decode()); o += 76 + elsize * n
+    assert names == ["Position", "Velocity", "Info", "Hash"] and o == len(raw) - 272
+
+
+@pytest.mark.gpu
+def test_resume_is_bit_identical(tmp_path):
+    """save at a neighbour-rebuild iteration, resume in a fresh engine: same particles as the uninterrupted run"""
+    from gpusph_amd.engine import TimestepEngine
+    prob = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.05, hydrostatic=False)
+    a = TimestepEngine(prob)
+    a.run(10)
+    path = tmp_path / "hot.bin"
+    a.save_hotfile(path)
+    a.run(7)
+    ref = a.download()
+    b = TimestepEngine(prob)
+    hf = b.load_hotfile(path)
+    assert hf["iterations"] == 10 and b.iterations == 10
+    b.run(7)
+    out = b.download()
+    assert b.n == a.n and b.current_dt() == a.current_dt() and abs(b.time() - a.time()) < 1e-12
+    for k in ("pos", "vel", "info", "hash"):
+        assert np.array_equal(np.asarray(out[k]).view(np.uint8), np.asarray(ref[k]).view(np.uint8)), k
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/scripts/hotdiff.py"),
+                    reason="the reference tree is only present in the build container")
+def test_reference_hotdiff_reads_our_files(tmp_path):
+    """the reference's own comparison tool walks two of our HotFiles end to end and finds no difference"""
+    import subprocess, sys
+    prob = DamBreak3D(deltap=0.08, obstacle=False)
+    arrs = prob.copy_to_array()
+    f1, f2 = tmp_path / "a.bin", tmp_path / "b.bin"
+    for f in (f1, f2):
+        hotfile.write_hotfile(f, arrs, iterations=20, t=0.5, dt=1e-4, host_buffer_count=4)
+    r = subprocess.run([sys.executable, "/root/reference/scripts/hotdiff.py", str(f1), str(f2)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ("Position", "Velocity", "Info", "Hash"):
+        assert name in r.stdout
+    assert "First difference" not in r.stdout
+    # and it does see a difference when there is one
+    arrs["vel"][7, 0] += 1.0
+    hotfile.write_hotfile(f2, arrs, iterations=20, t=0.5, dt=1e-4, host_buffer_count=4)
+    r = subprocess.run([sys.executable, "/root/reference/scripts/hotdiff.py", str(f1), str(f2)],
+                       capture_output=True, text=True, timeout=120)
+    assert "First difference at particle index 7" in r.stdout
