@@ -35,7 +35,8 @@ struct ForcesArgs {
 	int compute_object_forces;
 	uint32_t *pin;              // always NULL (see pin_batch)
 	unsigned long long *prof;   // SPHX_TILE_DEBUG & 16: per-workgroup phase times (100 MHz ticks), else NULL
-	int dbg;   // SPHX_TILE_DEBUG: 1 = skip pair loops, 2 = skip window staging (timing experiments only)
+	int dbg;   // SPHX_TILE_DEBUG bits, timing experiments only (results are wrong with 1 or 2): 1 = skip the pair loops,
+	           // 2 = skip the window staging, 4 = plain round-robin tile order instead of the XCD-aware one, 16 = phase timers
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }

@@ -38,6 +38,7 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	ctx->tile_grid = (uint32_t)(cus > 0 ? cus : 256)*TILE_WGS_PER_CU;   // persistent grid: one 512-thread workgroup per CU (LDS bound)
 	const char *dis = getenv("SPHX_DISABLE_TILES");
 	ctx->disable_tiles = dis && dis[0] == '1';
+	// SPHX_DISABLE_TILES=1: always the generic gather kernel (A/B runs, tests); SPHX_TILE_DEBUG: see ForcesArgs::dbg
 	const char *dbg = getenv("SPHX_TILE_DEBUG");
 	ctx->tile_debug = dbg ? atoi(dbg) : 0;
 	*out = ctx;
