@@ -732,7 +732,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	};
 	TileHome hc = tile_home(dc, tid, a.fromParticle, a.toParticle);
 	TileOwn own;
-	request_own(hc, own);
+	if (hc.inRange) request_own(hc, own);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
 	const bool prof = a.prof != nullptr && tid == 0;
 	unsigned long long tBegin = 0, t0 = 0, tA = 0, tB = 0, accStage = 0, accPairs = 0, accTail = 0, s1 = 0, s2 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 	if (prof) tBegin = wall_clock64();
@@ -832,7 +832,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		TileOwn ownNext;
 		if (haveNext) {
 			hn = tile_home(dn, tid, a.fromParticle, a.toParticle);
-			request_own(hn, ownNext);
+			if (hn.inRange) request_own(hn, ownNext);
 		}
 		const particleinfo info = own.info;
 		const float4 pos = own.pos;
