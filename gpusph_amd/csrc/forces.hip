@@ -636,6 +636,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	__shared__ __attribute__((aligned(16))) float4 sVel[TILE_WCAP];
 	__shared__ __attribute__((aligned(16))) float4 sAux[TILE_WCAP];
 	__shared__ uint32_t sCellBase[TILE_WROWS*TILE_KW];   // LDS slot of the first particle of each window cell
+	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW];    // ... relative to the start of its window row (never modified after the scan)
 	__shared__ uint32_t sCnt[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sStart[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sRowStart[TILE_WROWS], sRowTotal[TILE_WROWS], sRowContig[TILE_WROWS];
@@ -774,11 +775,18 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					hi = max(hi, (uint32_t)__shfl_xor(hi, dd, TILE_KW));
 				}
 				sCnt[tid] = wCnt; sStart[tid] = wStart;
-				sCellBase[tid] = incl - wCnt;                 // row-relative for now
+				sCellRel[tid] = incl - wCnt;
+				// one DMA per row needs the cells to lie in memory in window order: each non-empty cell starts where
+				// the previous ones end.  (Extent == count alone is not enough: a periodic row that is wholly inside
+				// the window has the wrapped column first in the window but last in memory.)
+				uint32_t inOrder = (wCnt == 0u || wStart - lo == incl - wCnt) ? 1u : 0u;
+#pragma unroll
+				for (int dd = TILE_KW/2; dd > 0; dd >>= 1)
+					inOrder &= (uint32_t)__shfl_xor(inOrder, dd, TILE_KW);
 				if (wcol == TILE_KW - 1) {
 					sRowTotal[wr] = incl;
 					sRowStart[wr] = lo;
-					sRowContig[wr] = (incl == 0u || hi - lo == incl) ? 1u : 0u;
+					sRowContig[wr] = (incl == 0u || (hi - lo == incl && inOrder)) ? 1u : 0u;
 				}
 			}
 			lds_barrier();
@@ -809,14 +817,16 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					stage_row_wave(a.aux + rs, sAux + base, total, lane);
 				} else {   // a row crossing cell-type segments (multi-GPU device maps not split on COORD3)
 					for (int col = 0; col < ncells + 2; ++col) {
-						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = base + sCellBase[r*TILE_KW + col];
+						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = base + sCellRel[r*TILE_KW + col];
 						for (uint32_t q = lane; q < cnt; q += 64u) {
 							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q]; sAux[cb + q] = a.aux[st + q];
 						}
 					}
 				}
 			}
-			if (tid < TILE_WROWS*TILE_KW) sCellBase[tid] += myRowBase;   // make absolute (own entry)
+			// absolute slot of each window cell; a separate array from sCellRel: the waves stage their rows
+			// concurrently, and the per-cell copy above reads the relative offsets of OTHER threads' cells
+			if (tid < TILE_WROWS*TILE_KW) sCellBase[tid] = sCellRel[tid] + myRowBase;
 		}
 		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA (and its own rows, list batches) have landed
 		__syncthreads();                      // ... everybody's have; the tables are published

@@ -362,3 +362,52 @@ class DamBreak3D(Problem):
         else:
             self.rb_cg_gridpos = np.zeros((0, 3), dtype=np.int32)
             self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)
+
+
+class PeriodicBox(Problem):
+    """A box of fluid with periodic faces and no walls: the smallest problem that exercises the periodic branches of
+    the hot path (clampGridPos / calcGridHashPeriodic, src/cuda/buildneibs_kernel.cu:225-298, cellgrid.cuh:163-196).
+    The lattice wraps seamlessly (box side = n dp), so with jitter = 0 every particle sees the same neighbourhood."""
+
+    def __init__(self, deltap=0.05, n=(12, 10, 9), periodic=D.PERIODIC_X | D.PERIODIC_Y | D.PERIODIC_Z, jitter=0.1, velocity=(0.0, 0.0, 0.0),
+                 gravity=(0.0, 0.0, 0.0), linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND,
+                 density_diffusion=D.COLAGROSSI):
+        super().__init__()
+        self.m_name = "PeriodicBox"
+        sp, pp = self.simparams, self.physparams
+        sp.kerneltype = kerneltype
+        sp.boundarytype = D.DYN_BOUNDARY
+        sp.rheologytype = D.INVISCID
+        sp.turbmodel = D.ARTIFICIAL
+        sp.densitydiffusiontype = density_diffusion
+        sp.periodicbound = periodic
+        sp.simflags = D.ENABLE_DTADAPT
+        sp.neiblistsize = 128
+        sp.densityDiffCoeff = 0.1
+        self.linearization = linearization
+        self.set_deltap(deltap)
+        pp.gravity = tuple(float(g) for g in gravity)
+        pp.add_fluid(1000.0)
+        pp.set_equation_of_state(0, 7.0, 20.0)
+        self.m_origin = np.zeros(3)
+        self.m_size = np.array(n, dtype=np.float64) * self.m_deltap
+        self.initialize()
+        idx = _lattice(0, n[0] - 1, 0, n[1] - 1, 0, n[2] - 1).astype(np.float64)
+        pos3 = (idx + 0.5) * self.m_deltap
+        if jitter:
+            rng = np.random.default_rng(4321)
+            pos3 = pos3 + rng.uniform(-jitter * self.m_deltap, jitter * self.m_deltap, size=pos3.shape)
+            pos3 = np.mod(pos3, self.m_size)
+        ntot = len(pos3)
+        pos = np.empty((ntot, 4), dtype=np.float64)
+        pos[:, :3] = pos3
+        pos[:, 3] = pp.rho0[0] * self.m_deltap ** 3
+        vel = np.zeros((ntot, 4), dtype=np.float32)
+        vel[:, :3] = np.asarray(velocity, dtype=np.float32)
+        info = make_particleinfo(np.full(ntot, D.PT_FLUID, dtype=np.uint16), np.zeros(ntot, dtype=np.uint16),
+                                 np.arange(ntot, dtype=np.uint32))
+        self.parts = HostParticles(pos, vel, info)
+        self.num_fluid, self.num_wall, self.num_obstacle = ntot, 0, 0
+        self.rb_firstindex = np.zeros(0, dtype=np.int32)
+        self.rb_cg_gridpos = np.zeros((0, 3), dtype=np.int32)
+        self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)

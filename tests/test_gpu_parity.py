@@ -596,3 +596,56 @@ def test_postprocess_bit_exact():
     assert np.array_equal(got[tp, :3].view(np.uint32), ref_vel[:n][tp, :3].view(np.uint32))
     # pressure goes through powf: device libm vs glibc, 2 ulp
     assert np.abs(got[tp, 3] - ref_vel[:n][tp, 3]).max() <= 4e-7 * np.abs(ref_vel[:n][tp, 3]).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# periodic boundaries (clampGridPos / calcGridHashPeriodic; the tiled kernel's wrapped window rows)
+PERIODIC_CASES = [dict(n=(30, 24, 20), jitter=0.2, velocity=(5.0, -3.0, 2.0)),
+                  dict(n=(26, 22, 18), jitter=0.15, velocity=(-4.0, 2.0, 6.0), periodic=D.PERIODIC_X | D.PERIODIC_Y,
+                       linearization="xzy")]
+
+
+@pytest.mark.parametrize("case", PERIODIC_CASES)
+def test_periodic_neibs_forces_and_trajectory(case, monkeypatch):
+    import torch
+    from gpusph_amd.problem import PeriodicBox
+    prob = PeriodicBox(deltap=0.05, **case)
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    assert n == sim.n
+    assert np.array_equal(_np(eng.hash, np.uint32)[:n], sim.hash[:n])
+    assert np.array_equal(_np(eng.neibslist, np.uint16).reshape(-1, eng.alloc)[:, :n], sim.nl.reshape(-1, len(sim.pos))[:, :n])
+    rng = np.random.default_rng(21)
+    vel = sim.vel.copy()
+    vel[:, :3] += rng.uniform(-0.3, 0.3, size=(len(vel), 3)).astype(np.float32)
+    vel[:, 3] += rng.uniform(0, 2e-3, size=len(vel)).astype(np.float32)
+    sim.vel = vel
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    f_ref, cfl_ref, nb, _, _ = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng._forces(eng.pos, eng.vel, 1, 0)
+    f = _np(eng.forces)[:n]
+    assert np.abs(f[:, :3] - f_ref[:n, :3]).max() <= 2e-5 * np.abs(f_ref[:, :3]).max()
+    assert np.abs(f[:, 3] - f_ref[:n, 3]).max() <= 2e-5 * np.abs(f_ref[:, 3]).max() + 1e-7
+    # tiled == generic on the same state
+    monkeypatch.setenv("SPHX_DISABLE_TILES", "1")
+    eng_g = _engine(prob, clobber_neibslist=True)
+    eng_g.build_neibs()
+    eng_g.vel[:n] = torch.from_numpy(vel[:n]).to(eng_g.device)
+    eng_g._forces(eng_g.pos, eng_g.vel, 1, 0)
+    assert np.array_equal(_np(eng_g.forces)[:n].view(np.uint32), f.view(np.uint32))
+    monkeypatch.setenv("SPHX_DISABLE_TILES", "0")
+    # trajectory across two re-sorts: particles leave through one face and come back through the opposite one
+    eng2 = _engine(prob); sim2 = ol.OracleSim(prob)
+    steps = 22
+    for _ in range(steps):
+        sim2.step(); eng2.step()
+    out = eng2.download()
+    assert eng2.n == sim2.n == n
+    assert np.array_equal(out["hash"], sim2.hash[:n]) and np.array_equal(out["info"].reshape(-1, 4), sim2.info[:n])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim2.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    vmax = np.abs(sim2.vel[:n, :3]).max()
+    assert np.abs(out["vel"][:, :3] - sim2.vel[:n, :3]).max() <= 1e-3 * vmax
+    assert np.abs(out["vel"][:, 3] - sim2.vel[:n, 3]).max() <= 2e-6

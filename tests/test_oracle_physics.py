@@ -391,3 +391,52 @@ def test_surface_detection_finds_the_free_surface():
     nn = nrm[:n][inner_top]
     assert np.all(nn[:, 2] > 0.9) and np.abs(np.linalg.norm(nn[:, :3], axis=1) - 1).max() < 1e-5
     assert np.all(np.isnan(nrm[:n][~fluid]))
+
+
+# ---------------------------------------------------------------------------------------------
+# periodic boundaries
+def test_periodic_lattice_is_homogeneous_and_translates_rigidly():
+    """A seamless periodic lattice: every particle has the same neighbour count, zero force, and a uniform velocity
+    carries it rigidly through the periodic faces (calcHash wraps cell and position, neighbour cells wrap)."""
+    from gpusph_amd.problem import PeriodicBox
+    u = (6.0, -4.0, 2.0)
+    prob = PeriodicBox(deltap=0.05, n=(16, 12, 10), jitter=0.0, velocity=u)
+    sim = ol.OracleSim(prob)
+    gp0 = prob.parts.pos_global[:, :3].copy()
+    ids0 = info_id(prob.parts.info)
+    steps = 25
+    for _ in range(steps):
+        sim.step()
+    n = sim.n
+    assert n == len(gp0)
+    nl = sim.nl.reshape(-1, len(sim.pos))[:, :n]
+    cnt = (nl != 0xFFFF).sum(axis=0)
+    assert cnt.min() == cnt.max() and cnt.max() > 70
+    assert np.abs(sim.forces[:n]).max() < 1e-3            # lattice symmetry (rounding of the re-based positions only)
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    order = np.argsort(info_id(sim.info[:n]))
+    L = prob.m_size
+    expect = np.mod(gp0[np.argsort(ids0)] + np.array(u) * sim.t, L)
+    d = np.abs(gp[order] - expect)
+    d = np.minimum(d, L - d)                              # distance on the torus
+    assert d.max() < 2e-5
+    assert (sim.t * max(abs(c) for c in u)) > 0.5 * prob.m_cellsize.min()   # particles did change cell / wrap
+    crossed = np.floor((gp0[np.argsort(ids0)] + np.array(u) * sim.t) / L).astype(int)
+    assert np.any(crossed != 0)
+
+
+def test_periodic_momentum_conservation():
+    from gpusph_amd.problem import PeriodicBox
+    prob = PeriodicBox(deltap=0.05, n=(16, 12, 10), jitter=0.2)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(2)
+    sim.vel[:n, :3] += rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32)
+    sim.vel[:n, 3] += rng.uniform(0, 2e-3, size=n).astype(np.float32)
+    f = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    m = sim.pos[:n, 3].astype(np.float64)
+    tot = (f[:n, :3].astype(np.float64) * m[:, None]).sum(axis=0)
+    assert np.abs(tot).max() < 1e-5 * (np.abs(f[:n, :3]).astype(np.float64) * m[:, None]).sum()
+    nl = sim.nl.reshape(-1, len(sim.pos))[:, :n]
+    assert (nl != 0xFFFF).sum(axis=0).min() > 50           # nobody is short of neighbours at a "face": there are none
