@@ -204,7 +204,7 @@ class DamBreak3D(Problem):
 
     def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
                  jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY,
-                 walls="particles", testpoints=()):
+                 walls="particles", testpoints=(), two_fluids=False):
         super().__init__()
         self.m_name = "DamBreak3D"
         sp, pp = self.simparams, self.physparams
@@ -227,6 +227,8 @@ class DamBreak3D(Problem):
         sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | (D.ENABLE_MOVING_BODIES if obstacle else 0) | \
             (D.ENABLE_PLANES if walls == "planes" else 0)
         sp.neiblistsize = 128               # resize_neiblist(128), DamBreak3D.cu:76
+        if kerneltype == D.GAUSSIAN:
+            sp.neiblistsize = 384           # radius 3h: ~250 neighbours in the bulk
         sp.densityDiffCoeff = 0.1           # DamBreak3D.cu:95
         self.linearization = linearization
         self.set_deltap(deltap)
@@ -237,6 +239,10 @@ class DamBreak3D(Problem):
             pp.dcoeff = 5.0 * 9.81
         pp.add_fluid(1000.0)
         pp.set_equation_of_state(0, 7.0, 20.0)
+        self.two_fluids = bool(two_fluids)
+        if two_fluids:      # a lighter fluid on top of the water column (multi-fluid branch of the forces engine)
+            pp.add_fluid(850.0)
+            pp.set_equation_of_state(1, 7.0, 22.0)
         self.m_origin = np.zeros(3)
         self.m_size = np.array(self.DIM, dtype=np.float64)
         self.obstacle = obstacle
@@ -349,6 +355,11 @@ class DamBreak3D(Problem):
         tf[nf + nw:nf + nw + no] = D.PT_BOUNDARY | D.FG_MOVING_BOUNDARY | D.FG_COMPUTE_FORCE
         tf[nf + nw + no:] = D.PT_TESTPOINT
         objfl = np.zeros(ntot, dtype=np.uint16)   # fluid number 0; object number 0 for the obstacle
+        if self.two_fluids:
+            upper = np.zeros(ntot, dtype=bool)
+            upper[:nf] = pos[:nf, 2] > 0.5 * self.H
+            objfl[upper] = 1 << 12                  # fluid number lives in the high 4 bits (src/particleinfo.h:144-161)
+            pos[upper, 3] = self.physparams.rho0[1] * dp ** 3
         info = make_particleinfo(tf, objfl, ids)
         self.parts = HostParticles(pos, vel, info)
         self.num_fluid, self.num_wall, self.num_obstacle = nf, nw, no
