@@ -132,3 +132,34 @@ def test_euler_with_a_moving_rigid_body():
         assert np.array_equal(_np(eng.pos2)[:n].view(np.uint32), pr[:n].view(np.uint32))
         assert np.array_equal(_np(eng.vel2)[:n].view(np.uint32), vr[:n].view(np.uint32))
         assert np.abs(vr[:n][body, :3]).max() > 0.1            # the body rows did move with the prescribed motion
+
+
+def test_neighbour_list_overflow_is_reported():
+    """a list that is too short: overflow is reported through getinfo (hasTooManyNeibs / hasMaxNeibs,
+    src/cuda/buildneibs.cu:137-145), not as an error of the call; the host aborts the run on it (CHECK_NEIBSNUM).
+    Particles whose list did fit are stored exactly as by the oracle.  The slots of a particle whose fluid and
+    boundary sections collided are unspecified here: the reference resolves the collision in program order, the
+    LDS-staged build in flush order, and nobody reads such a list."""
+    from gpusph_amd import capi
+    prob = DamBreak3D(deltap=0.045, obstacle=False, jitter=0.1, hydrostatic=False)
+    prob.simparams.neiblistsize = 64
+    prob.simparams.neibboundpos = 63
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    assert sim.neibs_info.hasTooManyNeibs >= 0
+    gl = _np(eng.neibslist, np.uint16).reshape(-1, eng.alloc)[:, :n]
+    ol_ = sim.nl.reshape(-1, len(sim.pos))[:, :n]
+    assert gl.shape[0] == 64
+    stored = (ol_ != 0xFFFF).sum(axis=0)
+    fits = stored <= 63 - 2                       # both terminators had room: no collision
+    assert fits.sum() > 0.5 * n and (~fits).sum() > 10
+    assert np.array_equal(gl[:, fits], ol_[:, fits])
+    with pytest.raises(capi.SphxError):
+        eng.neibs_info()                      # CHECK_NEIBSNUM in the driver turns the report into an error
+    info = eng.last_neibs_info
+    assert info.hasTooManyNeibs >= 0
+    assert info.hasMaxNeibs[0] + info.hasMaxNeibs[1] >= 63
+    assert info.numInteractions == sim.neibs_info.numInteractions
+    assert info.maxFluidBoundaryNeibs == sim.neibs_info.maxFluidBoundaryNeibs
