@@ -626,9 +626,40 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 // ranges) and must fit TILE_WCAP records.  One thread per 2x2 bundle of rows walks the cells along
 // COORD1 and closes a tile greedily.
 // ------------------------------------------------------------------------------------------
+// pre-pass of the tile builder, one thread per (row bundle, column): records in the 16 window rows of that column
+// and whether any of those cells holds fluid (cells are sorted fluid-first, so the first particle tells).  The
+// greedy walk below is serial per bundle (a few thousand threads); summing 16 cells per step inside it made it
+// latency bound (2.5 ms per build at 32 M particles).
+__global__ void __launch_bounds__(256)
+tile_columns_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
+	const particleinfo *__restrict__ info, uint32_t *__restrict__ cols)
+{
+	const int gs1 = p.gs1;
+	const int gs2 = (p.c2 == 0) ? p.gs[0] : (p.c2 == 1) ? p.gs[1] : p.gs[2];
+	const int gs3 = (p.c3 == 0) ? p.gs[0] : (p.c3 == 1) ? p.gs[1] : p.gs[2];
+	const int nG2 = (gs2 + 1)/2, nG3 = (gs3 + 1)/2;
+	const uint32_t t = blockIdx.x*256 + threadIdx.x;
+	if (t >= (uint32_t)(nG2*nG3*gs1)) return;
+	const int c = (int)(t % (uint32_t)gs1), sr = (int)(t / (uint32_t)gs1);
+	const int g2 = 2*(sr % nG2), g3 = 2*(sr / nG2);
+	const bool per2 = p.periodic & (1u << p.c2), per3 = p.periodic & (1u << p.c3);
+	uint32_t sum = 0, fluid = 0;
+	for (int d3 = -1; d3 <= 2; ++d3) for (int d2 = -1; d2 <= 2; ++d2) {
+		int c2v = g2 + d2, c3v = g3 + d3;
+		if (c2v < 0) { if (per2) c2v = gs2 - 1; else continue; } else if (c2v >= gs2) { if (per2) c2v = 0; else continue; }
+		if (c3v < 0) { if (per3) c3v = gs3 - 1; else continue; } else if (c3v >= gs3) { if (per3) c3v = 0; else continue; }
+		const uint32_t h = (uint32_t)(c + c2v*gs1 + c3v*p.gs12);
+		const uint32_t cs = cellStart[h];
+		if (cs == CELL_EMPTY) continue;
+		sum += cellEnd[h] - cs;
+		if (IS_FLUID(info[cs])) fluid = 0x80000000u;
+	}
+	cols[t] = sum | fluid;
+}
+
 __global__ void __launch_bounds__(128)
 build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
-	const particleinfo *__restrict__ info, uint32_t rangeEnd,
+	const uint32_t *__restrict__ cols, uint32_t rangeEnd,
 	uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t capacity)
 {
 	const int gs1 = p.gs1;
@@ -650,17 +681,14 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 		start = cs;
 		return cellEnd[h] - cs;
 	};
-	// window column c: records in the 16 rows, and whether any of those cells holds fluid (cells are
-	// sorted fluid-first, so the first particle tells)
+	// window column c (tile_columns_kernel); columns -1 and gs1 wrap with periodicity along COORD1
+	const uint32_t *myCols = cols + (size_t)sr*gs1;
 	auto column = [&](int c, uint32_t &hasFluid) -> uint32_t {
-		uint32_t s = 0;
 		hasFluid = 0;
-		for (int d3 = -1; d3 <= 2; ++d3) for (int d2 = -1; d2 <= 2; ++d2) {
-			uint32_t st = 0;
-			const uint32_t n = cell_cnt(c, g2 + d2, g3 + d3, true, st);
-			if (n) { s += n; if (IS_FLUID(info[st])) hasFluid = 1; }
-		}
-		return s;
+		if (c < 0) { if (per1) c = gs1 - 1; else return 0u; } else if (c >= gs1) { if (per1) c = 0; else return 0u; }
+		const uint32_t v = myCols[c];
+		hasFluid = v >> 31;
+		return v & 0x7FFFFFFFu;
 	};
 	uint32_t hc[TILE_HROWS] = {0, 0, 0, 0}, first[TILE_HROWS] = {0, 0, 0, 0};
 	auto emit = [&](int ca, int ncells, uint32_t wc, uint32_t fl) {
@@ -826,14 +854,19 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 	SPHX_LAUNCH_CHECK("cell_fluid_end_kernel");
 	// tiling of the sorted particles for the forces engine (forces.hip "Tiled path")
 	ctx->tiles_built = false;
-	if (ctx->tiles && !ctx->disable_tiles) {
+	const bool tile_cols_fit = (size_t)((ctx->dev.gs[ctx->dev.c2] + 1)/2)*(size_t)((ctx->dev.gs[ctx->dev.c3] + 1)/2)*(size_t)ctx->dev.gs1
+		<= (size_t)ctx->cells_reserved/2 + 1024;   // tile_cols allocation (degenerate 1-D grids: generic kernels)
+	if (ctx->tiles && !ctx->disable_tiles && tile_cols_fit) {
 		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
 		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), st));
 		const DevParams &dp = ctx->dev;
 		const uint32_t gs2 = (uint32_t)dp.gs[dp.c2], gs3 = (uint32_t)dp.gs[dp.c3];
 		const uint32_t bundles = ((gs2 + 1)/2)*((gs3 + 1)/2);
+		tile_columns_kernel<<<div_up_u(bundles*(uint32_t)dp.gs1, 256), 256, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy,
+			(const particleinfo*)info, ctx->tile_cols);
+		SPHX_LAUNCH_CHECK("tile_columns_kernel");
 		build_tiles_kernel<<<div_up_u(bundles, 128), 128, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy,
-			(const particleinfo*)info, particleRangeEnd, ctx->tiles, ctx->tile_ctl, ctx->tile_capacity);
+			ctx->tile_cols, particleRangeEnd, ctx->tiles, ctx->tile_ctl, ctx->tile_capacity);
 		SPHX_LAUNCH_CHECK("build_tiles_kernel");
 		ctx->tiles_built = true;
 		ctx->tiles_cellstart = cellStart;

@@ -48,13 +48,13 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
-		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end };
+		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
 	ctx->eos_aux = nullptr;
-	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr; ctx->cell_fluid_end = nullptr;
+	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr; ctx->cell_fluid_end = nullptr; ctx->tile_cols = nullptr;
 	ctx->tile_capacity = 0; ctx->cells_reserved = 0; ctx->tiles_built = false;
 	ctx->reserved_particles = ctx->reserved_bins = 0;
 }
@@ -103,6 +103,8 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	ctx->cells_reserved = (bins - 1)/4;
 	SPHX_HIP(hipMalloc((void**)&ctx->cell_end_copy, sizeof(uint32_t)*(size_t)ctx->cells_reserved));
 	SPHX_HIP(hipMalloc((void**)&ctx->cell_fluid_end, sizeof(uint32_t)*(size_t)ctx->cells_reserved));
+	// row bundles x columns <= ceil(gs2/2) ceil(gs3/2) gs1 <= cells/4 rounded up generously for odd grid sizes
+	SPHX_HIP(hipMalloc((void**)&ctx->tile_cols, sizeof(uint32_t)*((size_t)ctx->cells_reserved/2 + 1024)));
 	ctx->reserved_particles = n;
 	ctx->reserved_bins = bins;
 	return SPHX_OK;

@@ -116,6 +116,7 @@ struct sphx_ctx {
 	float      *dt_scratch;    // 1 float, for the sync dtreduce
 	// forces tiles, built by sphx_build_neibs
 	uint32_t   *tiles;         // [tile_capacity][TILE_DESC]
+	uint32_t   *tile_cols;     // [row bundles][gs1]: window records of a column (16 rows), bit 31 = a cell of it holds fluid
 	uint32_t   *tile_ctl;      // [0] = number of tiles, [1] = overflow flag (generic kernel takes over), [2] finished groups, [4..11] tile tickets
 	uint32_t   *cell_end_copy; // [cells] cellEnd of the build the tiles belong to
 	uint32_t   *cell_fluid_end;// [cells] first non-fluid particle of each cell (neighbour-list build)
