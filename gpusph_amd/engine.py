@@ -268,6 +268,17 @@ class TimestepEngine:
         }
         return out
 
+    # ------------------------------------------------------------------ output
+    def write_vtp(self, path, vorticity=False, surface=False, forces=False):
+        """VTKWriter::write (src/writers/VTKWriter.cc:610-830): a PART_*.vtp particle file; the post-processing
+        engines run first when their output is asked for (SAVE command order of GPUSPH::doWrite)."""
+        from . import vtkwriter
+        vort = self.postprocess(D.VORTICITY).cpu().numpy() if vorticity else None
+        nrm = self.postprocess(D.SURFACE_DETECTION, normals=True).cpu().numpy() if surface else None
+        st = self.download()
+        vtkwriter.write_vtp(path, self.problem, dict(pos=st["pos"], vel=st["vel"], info=st["info"].reshape(-1, 4), hash=st["hash"]),
+                            vorticity=vort, normals=nrm, forces=st["forces"] if forces else None)
+
     # ------------------------------------------------------------------ checkpoints (GPUSPH HotFile v1)
     def save_hotfile(self, path):
         """HotFile::save of the current state (src/writers/HotFile.cc:86-118); readable by GPUSPH --resume and by
