@@ -87,7 +87,73 @@ def pipeline():
     np.savez_compressed(os.path.join(HERE, "oracle_pipeline.npz"), **out)
 
 
+def features():
+    """SURVEY 8c fixtures (iv), (v) and the widened rows: SPS tau, moving-body Euler rows, density filters,
+    post-processing, LJ + planes forces -- inputs are rebuilt from the problem mirror, outputs are stored."""
+    from gpusph_amd import defs as D
+    out = {}
+    # --- one DYN problem with an obstacle and test points: SPS, filters, post-processing, moving-body Euler
+    pts = [(0.2, 0.3, 0.2), (0.3, 0.4, 0.1)]
+    prob = DamBreak3D(0.05, obstacle=True, jitter=0.1, hydrostatic=False, testpoints=pts)
+    prob.simparams.turbmodel = D.SPS
+    dp = prob.m_deltap
+    prob.physparams.smagfactor = float(np.float32((0.12 * dp) ** 2))
+    prob.physparams.kspsfactor = float(np.float32((2.0 / 3.0) * 0.0066 * dp * dp))
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(77)
+    vel = sim.vel.copy()
+    vel[:, :3] += rng.uniform(-0.4, 0.4, size=(len(vel), 3)).astype(np.float32)
+    vel[:, 3] += rng.uniform(0, 2e-3, size=len(vel)).astype(np.float32)
+    out["a_vel"] = vel
+    tau, tv = sim.o.sps(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, n)
+    out["a_tau"] = tau; out["a_turbvisc"] = tv
+    out["a_forces_sps"] = sim.o.forces(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, tau=tau)[0]
+    out["a_shepard"] = sim.o.filter(0, sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    out["a_mls"] = sim.o.filter(1, sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    out["a_vorticity"] = sim.o.vorticity(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    info_s, nrm = sim.o.surface(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, normals=True)
+    out["a_surface_info"] = info_s; out["a_normals"] = nrm
+    out["a_testpoints"] = sim.o.testpoints(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    th = 0.01
+    rot = np.array([np.cos(th), -np.sin(th), 0, np.sin(th), np.cos(th), 0, 0, 0, 1], dtype=np.float32)
+    motion = dict(trans=np.array([1e-3, -2e-3, 5e-4], np.float32), rot=rot, lvel=np.array([0.3, -0.1, 0.05], np.float32),
+                  avel=np.array([0.0, 0.2, 1.5], np.float32))
+    for a in range(3):
+        sim.o.p.rbtrans[0][a] = float(motion["trans"][a]); sim.o.p.rblinearvel[0][a] = float(motion["lvel"][a])
+        sim.o.p.rbangularvel[0][a] = float(motion["avel"][a])
+    for a in range(9):
+        sim.o.p.rbsteprot[0][a] = float(rot[a])
+    frc = rng.normal(0, 5, size=(len(sim.pos), 4)).astype(np.float32)
+    out["a_euler_forces"] = frc
+    out.update({"a_rb_" + k: v for k, v in motion.items()})
+    out["a_euler_dt"] = np.float32(2.7e-4)
+    for step, scale in ((1, 0.5), (2, 1.0)):
+        pr, vr = sim.o.euler(sim.pos, vel, sim.info, sim.hash, frc, n, float(np.float32(2.7e-4) * np.float32(scale)), step)
+        out["a_euler%d_pos" % step] = pr; out["a_euler%d_vel" % step] = vr
+    out["a_deltap"] = np.float32(0.05)
+    # --- LJ boundary particles + a feedback body; planes instead of walls
+    for tag, kw in (("b", dict(obstacle=True, boundary=D.LJ_BOUNDARY)), ("c", dict(obstacle=False, boundary=D.LJ_BOUNDARY, walls="planes"))):
+        prob = DamBreak3D(0.05, jitter=0.25, hydrostatic=False, **kw)
+        sim = ol.OracleSim(prob)
+        sim.build_neibs()
+        n = sim.n
+        vel = sim.vel.copy()
+        fl = (sim.info[:, 0] & 7) == 0
+        vel[fl, :3] += rng.uniform(-0.3, 0.3, size=(fl.sum(), 3)).astype(np.float32)
+        vel[fl, 3] += rng.uniform(0, 2e-3, size=fl.sum()).astype(np.float32)
+        cof = 1 if prob.simparams.numforcesbodies else 0
+        f, cfl, nb, rbf, rbt = sim.o.forces(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, compute_object_forces=cof,
+                                            rb_count=prob.num_obstacle)
+        out[tag + "_vel"] = vel; out[tag + "_forces"] = f; out[tag + "_neibs"] = sim.nl.copy()
+        out[tag + "_dt"] = np.float32(sim.o.dtreduce(cfl, nb, sim.sspeed_cfl))
+        if prob.num_obstacle:
+            out[tag + "_rbforces"] = rbf
+    np.savez_compressed(os.path.join(HERE, "oracle_features.npz"), **out)
+
+
 if __name__ == "__main__":
-    kernels(); datamodel(); pipeline()
+    kernels(); datamodel(); pipeline(); features()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -649,3 +649,70 @@ def test_periodic_neibs_forces_and_trajectory(case, monkeypatch):
     vmax = np.abs(sim2.vel[:n, :3]).max()
     assert np.abs(out["vel"][:, :3] - sim2.vel[:n, :3]).max() <= 1e-3 * vmax
     assert np.abs(out["vel"][:, 3] - sim2.vel[:n, 3]).max() <= 2e-6
+
+
+def test_against_committed_feature_fixture():
+    """tests/golden/oracle_features.npz (SURVEY 8c fixtures iv, v and the widened rows): the HIP path against committed
+    vectors, without the oracle in the loop -- SPS tau and forces, Shepard/MLS, vorticity, surface flags + normals, test
+    points, moving-body Euler rows, LJ boundary particles with a feedback body, planes."""
+    import os, torch
+    from gpusph_amd import capi
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_features.npz"))
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    prob = DamBreak3D(float(g["a_deltap"]), obstacle=True, jitter=0.1, hydrostatic=False, testpoints=[(0.2, 0.3, 0.2), (0.3, 0.4, 0.1)])
+    prob.simparams.turbmodel = D.SPS
+    dp = prob.m_deltap
+    prob.physparams.smagfactor = float(np.float32((0.12 * dp) ** 2))
+    prob.physparams.kspsfactor = float(np.float32((2.0 / 3.0) * 0.0066 * dp * dp))
+    eng = _engine(prob, clobber_neibslist=True)
+    eng.build_neibs()
+    n = eng.n
+    vel = g["a_vel"]
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    p = capi.ptr
+    A = eng.alloc
+    tau = [torch.zeros((A, 2), dtype=torch.float32, device=eng.device) for _ in range(3)]
+    tv = torch.zeros(A, dtype=torch.float32, device=eng.device)
+    capi.check(eng.lib.sphx_calc_visc(eng.ctx.handle, p(tau[0]), p(tau[1]), p(tau[2]), p(tv), p(eng.pos), p(eng.vel), p(eng.info),
+                                      p(eng.hash), p(eng.cellStart), p(eng.neibslist), n, n, eng.params.deltap, eng.params.slength,
+                                      eng.params.influenceradius, eng._stream()))
+    tau_gpu = np.concatenate([_np(t)[:n] for t in tau], axis=1)
+    assert np.abs(tau_gpu - g["a_tau"][:n]).max() <= 2e-5 * np.abs(g["a_tau"]).max()
+    # filters and post-processing: bit-exact
+    for ftype, key in ((D.SHEPARD_FILTER, "a_shepard"), (D.MLS_FILTER, "a_mls")):
+        eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+        eng.apply_filter(ftype)
+        assert np.array_equal(bits(_np(eng.vel)[:n]), bits(g[key][:n])), key
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    assert np.array_equal(bits(_np(eng.postprocess(D.VORTICITY))), bits(g["a_vorticity"][:n]))
+    nrm = _np(eng.postprocess(D.SURFACE_DETECTION, normals=True))
+    assert np.array_equal(_np(eng.info, np.uint16)[:n], g["a_surface_info"][:n]) and np.array_equal(bits(nrm), bits(g["a_normals"][:n]))
+    eng.postprocess(D.TESTPOINTS)
+    tp = (g["a_surface_info"][:n, 0] & 7) == D.PT_TESTPOINT
+    got = _np(eng.vel)[:n]
+    assert np.array_equal(bits(got[tp, :3]), bits(g["a_testpoints"][:n][tp, :3]))
+    assert np.abs(got[tp, 3] - g["a_testpoints"][:n][tp, 3]).max() <= 4e-7 * np.abs(g["a_testpoints"][:n][tp, 3]).max() + 1e-12
+    # moving-body Euler rows
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    rb = [np.ascontiguousarray(g[k], dtype=np.float32) for k in ("a_rb_trans", "a_rb_rot", "a_rb_lvel", "a_rb_avel")]   # keep alive
+    capi.check(eng.lib.sphx_set_rb_motion(eng.ctx.handle, rb[0].ctypes.data, rb[1].ctypes.data, rb[2].ctypes.data, rb[3].ctypes.data, 1))
+    eng.forces[:n] = torch.from_numpy(g["a_euler_forces"][:n]).to(eng.device)
+    eng.d_dt.fill_(float(g["a_euler_dt"]))
+    for step, scale in ((1, 0.5), (2, 1.0)):
+        eng._euler(step, scale)
+        assert np.array_equal(bits(_np(eng.pos2)[:n]), bits(g["a_euler%d_pos" % step][:n]))
+        assert np.array_equal(bits(_np(eng.vel2)[:n]), bits(g["a_euler%d_vel" % step][:n]))
+    # LJ boundary particles (+ feedback body) and planes
+    for tag, kw in (("b", dict(obstacle=True, boundary=D.LJ_BOUNDARY)), ("c", dict(obstacle=False, boundary=D.LJ_BOUNDARY, walls="planes"))):
+        prob = DamBreak3D(float(g["a_deltap"]), jitter=0.25, hydrostatic=False, **kw)
+        eng = _engine(prob, clobber_neibslist=True)
+        eng.build_neibs()
+        n = eng.n
+        assert np.array_equal(_np(eng.neibslist, np.uint16), g[tag + "_neibs"])
+        eng.vel[:n] = torch.from_numpy(g[tag + "_vel"][:n]).to(eng.device)
+        eng._forces(eng.pos, eng.vel, 1, 0)
+        f, fr = _np(eng.forces)[:n], g[tag + "_forces"][:n]
+        assert np.abs(f[:, :3] - fr[:, :3]).max() <= 2e-5 * np.abs(fr[:, :3]).max()
+        assert abs(float(eng.d_dt_next.item()) - float(g[tag + "_dt"])) <= 2e-5 * float(g[tag + "_dt"])
+        if prob.num_obstacle:
+            assert np.abs(_np(eng.rbforces) - g[tag + "_rbforces"]).max() <= 2e-5 * max(np.abs(g[tag + "_rbforces"]).max(), 1e-12)

@@ -113,3 +113,30 @@ def test_oracle_pipeline_regression():
         sim.step()
     assert np.array_equal(sim.pos.view(np.uint32), g["s11_pos"].view(np.uint32))
     assert np.float32(sim.dt) == g["s11_dt"]
+
+
+def test_oracle_features_regression():
+    """tests/golden/oracle_features.npz: the oracle still produces the committed SPS / filter / post-processing /
+    LJ / planes / moving-body vectors bit for bit (guards the restatement against accidental edits)."""
+    import oracle_lib as ol
+    from gpusph_amd import defs as D
+    from gpusph_amd.problem import DamBreak3D
+    g = np.load(os.path.join(GOLD, "oracle_features.npz"))
+    prob = DamBreak3D(float(g["a_deltap"]), obstacle=True, jitter=0.1, hydrostatic=False, testpoints=[(0.2, 0.3, 0.2), (0.3, 0.4, 0.1)])
+    prob.simparams.turbmodel = D.SPS
+    dp = prob.m_deltap
+    prob.physparams.smagfactor = float(np.float32((0.12 * dp) ** 2))
+    prob.physparams.kspsfactor = float(np.float32((2.0 / 3.0) * 0.0066 * dp * dp))
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    vel = g["a_vel"]
+    eq = lambda a, b: np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+    tau, tv = sim.o.sps(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, n)
+    assert eq(tau, g["a_tau"]) and eq(tv, g["a_turbvisc"])
+    assert eq(sim.o.filter(0, sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n), g["a_shepard"])
+    assert eq(sim.o.filter(1, sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n), g["a_mls"])
+    assert eq(sim.o.vorticity(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n), g["a_vorticity"])
+    info_s, nrm = sim.o.surface(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, normals=True)
+    assert eq(info_s, g["a_surface_info"]) and eq(nrm, g["a_normals"])
+    assert eq(sim.o.testpoints(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n), g["a_testpoints"])
