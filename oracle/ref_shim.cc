@@ -86,6 +86,13 @@ int ref_enum(int which)
 	case 0: return CUBICSPLINE; case 1: return QUADRATIC; case 2: return WENDLAND; case 3: return GAUSSIAN;
 	case 4: return SPH_F1; case 5: return COLAGROSSI; case 6: return DYN_BOUNDARY; case 7: return LJ_BOUNDARY;
 	case 8: return PERIODIC_Z; case 9: return SA_BOUNDARY; case 10: return FERRARI;
+	// codes of the widened rows: filters, post-processing, turbulence models, run modes, flags, limits
+	case 11: return SHEPARD_FILTER; case 12: return MLS_FILTER;
+	case 13: return VORTICITY; case 14: return TESTPOINTS; case 15: return SURFACE_DETECTION;
+	case 16: return ARTIFICIAL; case 17: return SPS; case 18: return LAMINAR_FLOW;
+	case 19: return MK_BOUNDARY; case 20: return (int)ENABLE_PLANES; case 21: return (int)ENABLE_DTADAPT;
+	case 22: return MAX_PLANES; case 23: return MAX_FLUID_TYPES; case 24: return (int)FG_SURFACE;
+	case 25: return PT_TESTPOINT; case 26: return INVISCID;
 	}
 	return -1;
 }

@@ -91,7 +91,10 @@ def test_datamodel_matches_reference_golden():
                        0 << 30, 1 << 30, 2 << 30, (3 << 30) & 0xFFFFFFFF, D.EMPTY_SEGMENT, D.MAX_CELLS]
     e = g["enums"]
     assert list(e) == [D.CUBICSPLINE, D.QUADRATIC, D.WENDLAND, D.GAUSSIAN, D.SPH_F1, D.COLAGROSSI, D.DYN_BOUNDARY,
-                       D.LJ_BOUNDARY, D.PERIODIC_Z, D.SA_BOUNDARY, D.FERRARI]
+                       D.LJ_BOUNDARY, D.PERIODIC_Z, D.SA_BOUNDARY, D.FERRARI,
+                       D.SHEPARD_FILTER, D.MLS_FILTER, D.VORTICITY, D.TESTPOINTS, D.SURFACE_DETECTION,
+                       D.ARTIFICIAL, D.SPS, D.LAMINAR_FLOW, D.MK_BOUNDARY, D.ENABLE_PLANES, D.ENABLE_DTADAPT,
+                       8, 4, D.FG_SURFACE, D.PT_TESTPOINT, D.INVISCID]     # 8 = SPHX_MAX_PLANES, 4 = SPHX_MAX_FLUIDS
     assert list(np.isfinite(g["wvals"]).astype(np.int32)) == list(g["active"])
 
 
