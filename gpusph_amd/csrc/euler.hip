@@ -20,7 +20,9 @@ struct EulerArgs {
 	uint32_t numParticles;
 };
 
-template<int STEP>
+// REPACK = eulerDevice with euler_repack_params (src/cuda/euler_params.h:203, euler.cu:346-353): boundaries are not
+// integrated, bodies do not move, the density is not evolved
+template<int STEP, bool REPACK>
 __global__ void __launch_bounds__(BLOCK_EULER)
 euler_kernel(DevParams p, EulerArgs a)
 {
@@ -35,7 +37,7 @@ euler_kernel(DevParams p, EulerArgs a)
 	float4 pos = a.oldPos[index];
 	float4 vel = a.oldVel[index];
 
-	const bool integrateBoundary = (p.boundarytype == SPHX_DYN_BOUNDARY || p.boundarytype == SPHX_SA_BOUNDARY);
+	const bool integrateBoundary = !REPACK && (p.boundarytype == SPHX_DYN_BOUNDARY || p.boundarytype == SPHX_SA_BOUNDARY);
 	if (is_active_w(pos.w) && !(ptype == PT_BOUNDARY && !integrateBoundary && !IS_MOVING(info))) {
 		// standard_corrected_velocity (euler_kernel.def:147-169)
 		float vcx = vel.x, vcy = vel.y, vcz = vel.z;
@@ -49,12 +51,12 @@ euler_kernel(DevParams p, EulerArgs a)
 			pos.x = fmaf(vcx, dt, pos.x);
 			pos.y = fmaf(vcy, dt, pos.y);
 			pos.z = fmaf(vcz, dt, pos.z);
-			vel.w = fmaf(dt, force.w, vel.w);   // continuity_integration :203-209
+			if (!REPACK) vel.w = fmaf(dt, force.w, vel.w);   // continuity_integration :203-209
 			vel.x = fmaf(dt, force.x, vel.x);
 			vel.y = fmaf(dt, force.y, vel.y);
 			vel.z = fmaf(dt, force.z, vel.z);
 		} else if (ptype == PT_BOUNDARY || ptype == PT_VERTEX) {
-			if (IS_MOVING(info)) { // rigid motion, euler_kernel.def:470-497, applyrot euler_kernel.cu:67-74
+			if (!REPACK && IS_MOVING(info)) { // rigid motion, euler_kernel.def:470-497, applyrot euler_kernel.cu:67-74
 				const uint32_t obj = OBJECT_NUM(info);
 				const int3 gp = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 				const float rx = (gp.x - a.rb->cgGridPos[obj][0])*p.cs[0] + (pos.x - a.rb->cgPos[obj][0]);
@@ -90,8 +92,8 @@ extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	(void)t; (void)slength; (void)influenceradius; (void)xsph; (void)numParticles;
 	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_euler_basicstep: constants not set");
 	SPHX_REQUIRE(newPos && newVel && oldPos && oldVel && info && hash && forces, "sphx_euler_basicstep: missing buffer");
-	if (run_mode != SPHX_SIMULATE)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_euler_basicstep: REPACK run mode is not built");
+	if (run_mode != SPHX_SIMULATE && run_mode != SPHX_REPACK)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_euler_basicstep: invalid run mode");
 	if (step != 1 && step != 2)
 		return sphx_set_error(SPHX_ERR_INVALID, "unsupported predcorr timestep"); // src/cuda/euler.cu:361
 	if (!particleRangeEnd) return SPHX_OK;
@@ -101,10 +103,42 @@ extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	a.info = (const particleinfo*)info; a.hash = hash; a.rb = ctx->rb_dev;
 	a.d_dt = d_dt; a.dt = dt; a.dt_scale = dt_scale; a.numParticles = particleRangeEnd;
 	const dim3 grid(div_up_u(particleRangeEnd, BLOCK_EULER));
-	if (step == 1)
-		euler_kernel<1><<<grid, BLOCK_EULER, 0, (hipStream_t)stream>>>(ctx->dev, a);
-	else
-		euler_kernel<2><<<grid, BLOCK_EULER, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	const bool repack = run_mode == SPHX_REPACK;
+	if (step == 1) {
+		if (repack) euler_kernel<1, true><<<grid, BLOCK_EULER, 0, (hipStream_t)stream>>>(ctx->dev, a);
+		else euler_kernel<1, false><<<grid, BLOCK_EULER, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	} else {
+		if (repack) euler_kernel<2, true><<<grid, BLOCK_EULER, 0, (hipStream_t)stream>>>(ctx->dev, a);
+		else euler_kernel<2, false><<<grid, BLOCK_EULER, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	}
 	SPHX_LAUNCH_CHECK("euler_kernel");
+	return SPHX_OK;
+}
+
+// disableFreeSurfPartsDevice (src/cuda/euler_kernel.cu:158-180)
+__global__ void __launch_bounds__(BLOCK_EULER)
+disable_free_surf_kernel(float4 *pos, const particleinfo *info, uint32_t n)
+{
+	const uint32_t index = blockIdx.x*BLOCK_EULER + threadIdx.x;
+	if (index >= n) return;
+	const particleinfo pi = info[index];
+	if (IS_SURFACE(pi) && PART_TYPE(pi) != PT_FLUID) {
+		float4 p = pos[index];
+		if (is_active_w(p.w)) {
+			p.w = __builtin_nanf("");
+			pos[index] = p;
+		}
+	}
+}
+
+extern "C" int sphx_disable_free_surf_parts(sphx_ctx *ctx, void *pos, const void *info,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+{
+	(void)numParticles;
+	SPHX_REQUIRE(ctx && pos && info, "sphx_disable_free_surf_parts: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	disable_free_surf_kernel<<<div_up_u(particleRangeEnd, BLOCK_EULER), BLOCK_EULER, 0, (hipStream_t)stream>>>(
+		(float4*)pos, (const particleinfo*)info, particleRangeEnd);
+	SPHX_LAUNCH_CHECK("disable_free_surf_kernel");
 	return SPHX_OK;
 }

@@ -435,6 +435,126 @@ extern "C" int sphx_postprocess(sphx_ctx *ctx, int type,
 	return SPHX_OK;
 }
 
+// ==========================================================================================
+// Repacking run mode: run_repack (src/cuda/forces.cu:828-896) = repackDevice<fluid,fluid> +
+// repackDevice<fluid,boundary> (forces_kernel.def:4155-4262, compute_repacking_contrib :3024-3055) +
+// finalizeRepackDevice (:4263-4349) as ONE kernel: the accumulator that the reference carries through the FORCES
+// buffer between its launches stays in a register (same additions, same order).  A preparation run of at most
+// repack_maxiter iterations, not a roofline path: written for fidelity like the filters above.
+// ==========================================================================================
+struct RepackArgs {
+	float4 *forces, *rbforces, *rbtorques;
+	float *cfl;
+	const RbParams *rb;
+	uint32_t fromParticle, toParticle, cflOffset;
+};
+
+template<int KERNEL>
+__global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
+repack_kernel(DevParams p, FilterArgs a, RepackArgs o)
+{
+	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + o.fromParticle;
+	float cfl_term = 0.0f;
+	do {
+		if (index >= o.toParticle) break;
+		const particleinfo info = a.info[index];
+		const float4 pos = a.pos[index];
+		if (!is_active_w(pos.w)) break;
+		const uint32_t fl = FLUID_NUM(info);
+		// the caller clobbers FORCES before basicstep (src/GPUWorker.cc:1949)
+		float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		if (PART_TYPE(info) == PT_FLUID) {
+			auto pair = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+				if (!is_active_w(npos.w)) return;
+				const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+				if (r >= p.influenceradius) return;
+				const float n_rho = (a.vel[j].w + 1.0f)*p.rho0[FLUID_NUM(a.info[j])];
+				const float f = kernel_F_exact<KERNEL>(p, r);
+				const float s = p.repack_a*p.sscoeff[fl]*p.sscoeff[fl]*npos.w/n_rho*f;
+				force.x -= s*rx; force.y -= s*ry; force.z -= s*rz;
+			};
+			for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, pair);
+			for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, pair);
+		}
+		// finalizeRepackDevice
+		force.w /= p.rho0[fl];   // repack_fixup :3238-3244
+		if (PART_TYPE(info) == PT_FLUID) {
+			const float4 vel = a.vel[index];
+			const float damp = p.repack_alpha*p.sscoeff[fl]/p.deltap;
+			force.x += damp*vel.x; force.y += damp*vel.y; force.z += damp*vel.z;
+			if ((p.simflags & SPHX_ENABLE_PLANES) && p.numplanes) {   // GeometryForce, friction coefficient 0
+				for (uint32_t k = 0; k < p.numplanes; ++k) {
+					const float dx = (gridPos.x - p.plane_gridpos[k][0])*p.cs[0] + (pos.x - p.plane_pos[k][0]);
+					const float dy = (gridPos.y - p.plane_gridpos[k][1])*p.cs[1] + (pos.y - p.plane_pos[k][1]);
+					const float dz = (gridPos.z - p.plane_gridpos[k][2])*p.cs[2] + (pos.z - p.plane_pos[k][2]);
+					const float r = fabsf(dx*p.plane_normal[k][0] + dy*p.plane_normal[k][1] + dz*p.plane_normal[k][2]);
+					if (r < p.r0) {
+						const float DvDt = p.dcoeff*(powf(p.r0/r, p.p1coeff) - powf(p.r0/r, p.p2coeff))/(r*r);
+						force.x += DvDt*(p.plane_normal[k][0]*r); force.y += DvDt*(p.plane_normal[k][1]*r);
+						force.z += DvDt*(p.plane_normal[k][2]*r);
+					}
+				}
+			}
+			const float sspeed = p.sscoeff[fl]*powf(vel.w + 1.0f, p.sspowercoeff[fl]);
+			const float amag = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
+			cfl_term = fmaxf(amag, sspeed*sspeed/p.slength);
+		}
+		if (HAS_COMPUTE_FORCE(info) && PART_TYPE(info) != PT_VERTEX && o.rbforces) {
+			const uint32_t rbindex = (uint32_t)((int)info_id(info) + o.rb->rbstart[OBJECT_NUM(info)]);
+			o.rbforces[rbindex] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			o.rbtorques[rbindex] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		}
+		o.forces[index] = force;
+	} while (0);
+
+	if (o.cfl) {   // maxBlockReduce (src/cuda/device_core.cu:40-59)
+		__shared__ float wave_max[SPHX_BLOCK_FORCES/64];
+#pragma unroll
+		for (int d = 32; d > 0; d >>= 1)
+			cfl_term = fmaxf(cfl_term, __shfl_down(cfl_term, d));
+		if ((threadIdx.x & 63u) == 0) wave_max[threadIdx.x >> 6] = cfl_term;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			float m = wave_max[0];
+			for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) m = fmaxf(m, wave_max[w]);
+			o.cfl[o.cflOffset + blockIdx.x] = m;
+		}
+	}
+}
+
+// called by sphx_forces_basicstep (forces.hip) when run_mode == SPHX_REPACK, after its argument checks
+int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, void *rbtorques,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, uint32_t numBlocks, hipStream_t st)
+{
+	if (!(ctx->dev.simflags & SPHX_ENABLE_REPACKING))   // src/main.cc:357-358
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: REPACK run mode needs ENABLE_REPACKING in simflags");
+	if ((ctx->dev.simflags & SPHX_ENABLE_PLANES) && ctx->dev.numplanes)
+		for (uint32_t f = 0; f < ctx->dev.numfluids; ++f)
+			if (ctx->params.visccoeff[f] != 0.0f)
+				return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: repacking against planes is built without wall friction (visccoeff must be 0)");
+	FilterArgs a;
+	a.newVel = nullptr; a.pos = (const float4*)pos; a.vel = (const float4*)vel;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.numParticles = toParticle;
+	RepackArgs o;
+	o.forces = (float4*)forces; o.rbforces = (float4*)rbforces; o.rbtorques = (float4*)rbtorques;
+	o.cfl = (ctx->dev.simflags & SPHX_ENABLE_DTADAPT) ? cfl : nullptr;
+	o.rb = ctx->rb_dev; o.fromParticle = fromParticle; o.toParticle = toParticle; o.cflOffset = cflOffset;
+	const dim3 grid(numBlocks);
+	switch (ctx->dev.kerneltype) {
+	case SPHX_CUBICSPLINE: repack_kernel<SPHX_CUBICSPLINE><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a, o); break;
+	case SPHX_QUADRATIC:   repack_kernel<SPHX_QUADRATIC><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a, o); break;
+	case SPHX_WENDLAND:    repack_kernel<SPHX_WENDLAND><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a, o); break;
+	case SPHX_GAUSSIAN:    repack_kernel<SPHX_GAUSSIAN><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a, o); break;
+	default: return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid kernel type");
+	}
+	SPHX_LAUNCH_CHECK("repack_kernel");
+	return SPHX_OK;
+}
+
 template<int KERNEL>
 static void launch_filter(int filtertype, dim3 grid, hipStream_t st, const DevParams &p, const FilterArgs &a)
 {

@@ -1198,8 +1198,8 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_forces_basicstep: invalid particle range");
 	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
 		"sphx_forces_basicstep: slength/influenceradius differ from set_constants");
-	if (run_mode != SPHX_SIMULATE)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: REPACK run mode is not built");
+	if (run_mode != SPHX_SIMULATE && run_mode != SPHX_REPACK)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid run mode");
 	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY && ctx->dev.boundarytype != SPHX_LJ_BOUNDARY)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: only DYN_BOUNDARY and LJ_BOUNDARY pair interactions are built");
 	if (ctx->dev.turbmodel == SPHX_SPS)
@@ -1212,6 +1212,9 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	const uint32_t numBlocks = round_up_u(div_up_u(nrange, SPHX_BLOCK_FORCES), 4u);
 	if (h_numBlocks) *h_numBlocks = numBlocks;
 	if (!numBlocks) return SPHX_OK;
+	if (run_mode == SPHX_REPACK)   // run_repack, src/cuda/forces.cu:828-896 (filters.hip)
+		return sphx_repack_launch(ctx, forces, cfl, rbforces, rbtorques, pos, vel, info, hash, cellStart, neibsList,
+			fromParticle, toParticle, cflOffset, numBlocks, (hipStream_t)stream);
 
 	{	// EOS pre-pass over ALL particles: neighbours may lie outside [fromParticle,toParticle)
 		int rc0 = sphx_ensure_scratch(ctx, numParticles);

@@ -210,6 +210,7 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	d.artvisccoeff = sp->artvisccoeff; d.epsartvisc = sp->epsartvisc;
 	d.smagfactor = sp->smagfactor; d.kspsfactor = sp->kspsfactor;
 	d.dcoeff = sp->dcoeff; d.p1coeff = sp->p1coeff; d.p2coeff = sp->p2coeff; d.r0 = sp->r0;
+	d.repack_a = sp->repack_a; d.repack_alpha = sp->repack_alpha;
 	ctx->have_params = true;
 	return SPHX_OK;
 }

@@ -68,6 +68,7 @@ struct DevParams {
 	float    gravity[3];
 	float    artvisccoeff, epsartvisc, smagfactor, kspsfactor;
 	float    dcoeff, p1coeff, p2coeff, r0;   // Lennard-Jones boundary repulsion
+	float    repack_a, repack_alpha;         // repacking (d_repack_a, d_repack_alpha: src/cuda/phys_core.cu:93-94)
 	uint32_t numplanes;                       // geometric planes (src/planes.h:43-47, MAX_PLANES src/particledefine.h:325)
 	float    plane_normal[SPHX_MAX_PLANES][3];
 	int      plane_gridpos[SPHX_MAX_PLANES][3];
@@ -144,6 +145,11 @@ static inline uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1)/b; 
 static inline uint32_t round_up_u(uint32_t a, uint32_t b) { return div_up_u(a, b)*b; }
 
 int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles);
+// repacking forces (filters.hip), reached through sphx_forces_basicstep(run_mode = SPHX_REPACK)
+int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, void *rbtorques,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, uint32_t numBlocks, hipStream_t st);
 
 // ---- device helpers -----------------------------------------------------------------------------
 #ifdef __HIPCC__

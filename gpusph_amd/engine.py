@@ -191,7 +191,7 @@ class TimestepEngine:
         return None if out is None else out[:n]
 
     # ------------------------------------------------------------------ forces / euler
-    def _forces(self, pos, vel, step, combine_min):
+    def _forces(self, pos, vel, step, combine_min, run_mode=D.SIMULATE):
         L, h, s = self.lib, self.ctx.handle, self._stream()
         p = capi.ptr
         sp = self.sp
@@ -207,7 +207,7 @@ class TimestepEngine:
                                            p(self.rbtorques) if rb else None, p(pos), p(vel), p(self.info), p(self.hash),
                                            p(self.cellStart), p(self.neibslist), None, None, None,
                                            n, 0, n, self.params.deltap, self.params.slength, self.params.dtadaptfactor,
-                                           self.params.influenceradius, 0, D.SIMULATE, step, self.dt,
+                                           self.params.influenceradius, 0, run_mode, step, self.dt,
                                            self.compute_object_forces, C.byref(nb), s))
         if prof:
             e1.record()
@@ -216,13 +216,13 @@ class TimestepEngine:
                                                  self.max_kinvisc, p(self.cfl), p(self.cfl_temp), nb.value,
                                                  p(self.d_dt_next), combine_min, s))
 
-    def _euler(self, step, dt_scale):
+    def _euler(self, step, dt_scale, run_mode=D.SIMULATE):
         L, h, s = self.lib, self.ctx.handle, self._stream()
         p = capi.ptr
         n = self.n
         capi.check(L.sphx_euler_basicstep(h, p(self.pos2), p(self.vel2), p(self.pos), p(self.vel), p(self.info),
                                           p(self.hash), p(self.forces), None, n, n, 0.0, p(self.d_dt), dt_scale,
-                                          step, 0.0, self.params.slength, self.params.influenceradius, D.SIMULATE, s))
+                                          step, 0.0, self.params.slength, self.params.influenceradius, run_mode, s))
 
     def step(self):
         """one full predictor-corrector time step; no host synchronisation."""
@@ -250,6 +250,49 @@ class TimestepEngine:
     def run(self, steps):
         for _ in range(steps):
             self.step()
+
+    # ------------------------------------------------------------------ repacking run mode
+    def repack_step(self):
+        """one iteration of the repacking integrator (RepackingIntegrator::initializeRepackingSequence,
+        src/integrators/RepackingIntegrator.cc:278-420): forces(REPACK) on step n, one full-dt Euler step."""
+        if self.iterations % self.sp.buildneibsfreq == 0:
+            self.build_neibs()
+        self._forces(self.pos, self.vel, 1, 0, D.REPACK)
+        self._euler(1, 1.0, D.REPACK)
+        self.pos, self.pos2 = self.pos2, self.pos
+        self.vel, self.vel2 = self.vel2, self.vel
+        self.d_t.add_(self.d_dt.double())
+        self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt
+        self.iterations += 1
+
+    def repack(self, maxiter=None, reset=True):
+        """`GPUSPH --repack`: run the repacking integrator for repack_maxiter iterations (GPUSPH.cc:196-201,
+        676-692), disable the free-surface lid particles, rebuild the neighbour list (FINISH_REPACKING -> NEIBS_LIST ->
+        PREPARE_SIMULATION), then, like a run resumed from the repack file (GPUSPH.cc:425-450, ProblemCore::resetBuffers),
+        restart the clock with zero velocities and the problem's initial density at the new positions."""
+        if not (self.sp.simflags & D.ENABLE_REPACKING):
+            raise ValueError("Repacking is not enabled in the problem")      # src/main.cc:357-358
+        maxiter = int(self.sp.repack_maxiter if maxiter is None else maxiter)
+        for _ in range(maxiter):
+            self.repack_step()
+        s = self._stream()
+        capi.check(self.lib.sphx_disable_free_surf_parts(self.ctx.handle, capi.ptr(self.pos), capi.ptr(self.info),
+                                                         self.n, self.n, s))
+        if self.iterations > 0:
+            self.build_neibs()
+        if not reset:
+            return
+        self.iterations = 0
+        self.d_t.zero_()
+        self.dt = float(np.float32(self.sp.dt))
+        self.d_dt.fill_(self.dt); self.d_dt_next.fill_(self.dt)
+        n = self.n
+        pos = self.pos[:n].cpu().numpy()
+        hsh = self.hash[:n].cpu().numpy().view(np.uint32)
+        rho = self.problem.initial_density(self.problem.global_pos(pos, hsh))
+        vel = np.zeros((n, 4), dtype=np.float32)
+        vel[:, 3] = rho
+        self.vel[:n] = torch.from_numpy(vel).to(self.device)
 
     # ------------------------------------------------------------------ host views
     def current_dt(self):

@@ -212,6 +212,7 @@ struct SimParams {
 	float dtadaptfactor = 0.3f, densityDiffCoeff = 0, epsxsph = 0.5f, dt = 0;
 	uint neiblistsize = 0, neibboundpos = 0, buildneibsfreq = 10, numbodies = 0, numforcesbodies = 0;
 	float deltap = 0;          // Problem::m_deltap
+	uint repack_maxiter = 2000; float repack_a = 0.1f, repack_alpha = 0.01f;   // src/simparams.h:308-310
 	int coord[3] = {1, 2, 0};  // linearisation, yzx by default (src/linearization.h, Makefile:517-519)
 };
 struct PhysParams {
@@ -329,6 +330,9 @@ public:
 	virtual void basicstep(BufferList const& bufread, BufferList& bufwrite, const uint numParticles,
 		const uint particleRangeEnd, const float dt, const int step, const float t, const float slength,
 		const float influenceradius, const RunMode run_mode) = 0;
+	// end of a repacking run (src/engine_integration.h:137-142)
+	virtual void disableFreeSurfParts(float4 *pos, const particleinfo *info, const uint numParticles,
+		const uint particleRangeEnd) = 0;
 };
 
 // ---- shared per-device state of the HIP engines ----
@@ -379,6 +383,7 @@ public:
 		p.artvisccoeff = pp->artvisccoeff; p.epsartvisc = pp->epsartvisc;
 		p.smagfactor = pp->smagfactor; p.kspsfactor = pp->kspsfactor;
 		p.dcoeff = pp->dcoeff; p.p1coeff = pp->p1coeff; p.p2coeff = pp->p2coeff; p.r0 = pp->r0;
+		p.repack_a = sp->repack_a; p.repack_alpha = sp->repack_alpha;
 		sphx_throw(sphx_set_constants(ctx(), &p));
 		sphx_throw(sphx_reserve(ctx(), (uint32_t)allocatedParticles));
 	}
@@ -534,6 +539,11 @@ public:
 			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
 			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_XSPH>(),
 			numParticles, particleRangeEnd, dt, nullptr, 1.0f, step, t, slength, influenceradius, run_mode, nullptr));
+	}
+	void disableFreeSurfParts(float4 *pos, const particleinfo *info, const uint numParticles,
+		const uint particleRangeEnd) override
+	{
+		sphx_throw(sphx_disable_free_surf_parts(m_c->ctx(), pos, info, numParticles, particleRangeEnd, nullptr));
 	}
 };
 

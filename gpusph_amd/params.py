@@ -27,6 +27,7 @@ class SphxParams(C.Structure):
         ("artvisccoeff", C.c_float), ("epsartvisc", C.c_float),
         ("smagfactor", C.c_float), ("kspsfactor", C.c_float),
         ("dcoeff", C.c_float), ("p1coeff", C.c_float), ("p2coeff", C.c_float), ("r0", C.c_float),
+        ("repack_a", C.c_float), ("repack_alpha", C.c_float),
     ]
 
 
@@ -101,6 +102,9 @@ class SimParams:
     dt: float = 0.0
     numbodies: int = 0
     numforcesbodies: int = 0
+    repack_maxiter: int = 2000         # simparams.h:308-310
+    repack_a: float = 0.1
+    repack_alpha: float = 0.01
 
     def set_smoothing(self, smooth, deltap):
         """simparams.h:325-336 (double arithmetic)."""
@@ -175,4 +179,5 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
     nz = lambda v: 0.0 if (v is None or math.isnan(v)) else f32(v)
     p.smagfactor = nz(pp.smagfactor); p.kspsfactor = nz(pp.kspsfactor)
     p.dcoeff = nz(pp.dcoeff); p.p1coeff = nz(pp.p1coeff); p.p2coeff = nz(pp.p2coeff); p.r0 = nz(pp.r0)
+    p.repack_a = f32(sp.repack_a); p.repack_alpha = f32(sp.repack_alpha)
     return p

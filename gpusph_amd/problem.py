@@ -176,6 +176,11 @@ class Problem:
                                 cellsize=self.m_cellsize, origin=self.m_origin, deltap=self.m_deltap,
                                 allocated=allocated, linearization=self.linearization)
 
+    def initial_density(self, pos_global):
+        """rho~ the problem starts from at the given global positions; also used to reset the state at the end of a
+        repacking run (ProblemCore::resetBuffers, src/ProblemCore.cc:1773-1796)."""
+        return np.zeros(len(pos_global), dtype=np.float32)
+
     def copy_to_array(self):
         """host arrays as GPUSPH uploads them: cell-local float4 pos, float4 vel, ushort4 info, hash."""
         local, h = self.calc_localpos_and_hash(self.parts.pos_global)
@@ -288,6 +293,19 @@ class DamBreak3D(Problem):
             dp = float(np.float32(dp))
         return dp
 
+    def initial_density(self, pos_global):
+        if not self.hydrostatic:
+            return np.zeros(len(pos_global), dtype=np.float32)
+        # rho~ from the hydrostatic pressure under the initial free surface (inverse Tait EOS)
+        rho0 = self.physparams.rho0[0]
+        B = self.physparams.bcoeff[0]
+        gam = self.physparams.gammacoeff[0]
+        g = -self.physparams.gravity[2]
+        depth = np.clip(self.H - pos_global[:, 2], 0.0, None)
+        in_col = pos_global[:, 0] <= self.WATER_LENGTH + 0.5 * self.m_deltap
+        depth = np.where(in_col, depth, 0.0)
+        return (np.power(1.0 + rho0 * g * depth / B, 1.0 / gam) - 1.0).astype(np.float32)
+
     def fill_parts(self):
         dp = self.m_deltap
         L = self.m_size
@@ -338,15 +356,7 @@ class DamBreak3D(Problem):
         rho0 = self.physparams.rho0[0]
         pos[:, 3] = rho0 * dp ** 3           # mass = rho0 dp^3
         vel = np.zeros((ntot, 4), dtype=np.float32)
-        if self.hydrostatic:
-            # rho~ from the hydrostatic pressure under the initial free surface (inverse Tait EOS)
-            B = self.physparams.bcoeff[0]
-            gam = self.physparams.gammacoeff[0]
-            g = -self.physparams.gravity[2]
-            depth = np.clip(self.H - pos[:, 2], 0.0, None)
-            in_col = pos[:, 0] <= self.WATER_LENGTH + 0.5 * dp
-            depth = np.where(in_col, depth, 0.0)
-            vel[:, 3] = (np.power(1.0 + rho0 * g * depth / B, 1.0 / gam) - 1.0).astype(np.float32)
+        vel[:, 3] = self.initial_density(pos)
         # ids: sequential, fluid first then boundary then bodies (ProblemAPI_1.cc:1766-1817)
         ids = np.arange(ntot, dtype=np.uint32)
         tf = np.empty(ntot, dtype=np.uint16)
@@ -382,7 +392,7 @@ class PeriodicBox(Problem):
 
     def __init__(self, deltap=0.05, n=(12, 10, 9), periodic=D.PERIODIC_X | D.PERIODIC_Y | D.PERIODIC_Z, jitter=0.1, velocity=(0.0, 0.0, 0.0),
                  gravity=(0.0, 0.0, 0.0), linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND,
-                 density_diffusion=D.COLAGROSSI):
+                 density_diffusion=D.COLAGROSSI, repacking=False):
         super().__init__()
         self.m_name = "PeriodicBox"
         sp, pp = self.simparams, self.physparams
@@ -392,7 +402,7 @@ class PeriodicBox(Problem):
         sp.turbmodel = D.ARTIFICIAL
         sp.densitydiffusiontype = density_diffusion
         sp.periodicbound = periodic
-        sp.simflags = D.ENABLE_DTADAPT
+        sp.simflags = D.ENABLE_DTADAPT | (D.ENABLE_REPACKING if repacking else 0)
         sp.neiblistsize = 128
         sp.densityDiffCoeff = 0.1
         self.linearization = linearization

@@ -99,6 +99,8 @@ typedef struct sphx_params {
 	float    artvisccoeff, epsartvisc;
 	float    smagfactor, kspsfactor;
 	float    dcoeff, p1coeff, p2coeff, r0;
+	/* repacking (src/simparams.h:220-234): mixing intensity a, velocity damping alpha */
+	float    repack_a, repack_alpha;
 } sphx_params;
 
 /* TimingInfo fields filled by getinfo (src/timing.h:43-100, src/cuda/buildneibs.cu:137-145) */
@@ -181,7 +183,9 @@ uint32_t sphx_forces_round_particles(uint32_t n);     /* round_particles, :960-9
 /* basicstep (src/cuda/forces.cu:897-935): pair summation over [fromParticle,toParticle) +
  * finalize (gravity, /rho0, CFL block maxima into cfl[cflOffset..]).  tau0..2 may be NULL
  * (SPS only), rbforces/rbtorques may be NULL.  *h_numBlocks receives the return value of
- * the reference's basicstep (#CFL elements written). */
+ * the reference's basicstep (#CFL elements written).
+ * run_mode = SPHX_REPACK selects run_repack (src/cuda/forces.cu:828-896): the mixing force of the repacking
+ * integrator on fluid particles (needs SPHX_ENABLE_REPACKING in simflags, src/main.cc:357-358). */
 int sphx_forces_basicstep(sphx_ctx *ctx,
 	void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
@@ -246,13 +250,19 @@ int sphx_postprocess(sphx_ctx *ctx, int type,
 /* ---- AbstractIntegrationEngine ------------------------------------------------------------ */
 /* basicstep (src/cuda/euler.cu:329-366).  dt is the step's dt or dt/2 exactly as the
  * reference passes it; if d_dt is not NULL the kernel instead uses d_dt[0]*dt_scale read on
- * the device (no host round trip of the adaptive dt). */
+ * the device (no host round trip of the adaptive dt).  run_mode = SPHX_REPACK: euler_repack_params
+ * (src/cuda/euler.cu:346-353), only fluid positions and velocities are advanced. */
 int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	const void *oldPos, const void *oldVel, const void *info, const uint32_t *hash,
 	const void *forces, const void *xsph,
 	uint32_t numParticles, uint32_t particleRangeEnd,
 	float dt, const float *d_dt, float dt_scale, int step, float t,
 	float slength, float influenceradius, int run_mode, void *stream);
+
+/* disableFreeSurfParts (src/engine_integration.h:137, src/cuda/euler.cu:368-391): at the end of a repacking run,
+ * disable (mass = NaN) the non-fluid particles flagged FG_SURFACE */
+int sphx_disable_free_surf_parts(sphx_ctx *ctx, void *pos, const void *info,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
 
 /* ---- small stream-ordered helpers the callers of the reference get from cudaMemset -------- */
 int sphx_memset_async(void *ptr, int value, size_t bytes, void *stream);

@@ -886,6 +886,108 @@ uint32_t orc_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	return numBlocks;
 }
 
+/* ==== repacking: run_repack src/cuda/forces.cu:828-896, repackDevice forces_kernel.def:4155-4262,
+ * compute_repacking_contrib (non-SA: fluid and boundary neighbours alike) :3024-3055, finalizeRepackDevice
+ * :4263-4349, repack_fixup :3238-3244.  Only fluid particles receive the mixing force
+ *   F_a = -a c0^2 sum_b (m_b/rho_b) F(r_ab) r_ab ,
+ * finalize adds the term alpha c0/deltap v_a with the reference's sign, the plane repulsion, and the CFL term. */
+static void repack_pass(const orc_params *p, int nptype, orc_f4 *forces,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = fromParticle; index < toParticle; ++index) {
+		const orc_info info = infoArray[index];
+		if (PART_TYPE(info) != PT_FLUID) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const int fl = FLUID_NUM(info);
+		orc_f4 force = forces[index];
+		neib_iter it;
+		neib_iter_init(&it, p, nptype, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			if (!isfinite(npos.w)) continue;
+			const float r = sqrtf(sqlength3(rx, ry, rz));
+			if (r >= p->influenceradius) continue;
+			const float n_rho = physical_density(p, velArray[neib_index].w, FLUID_NUM(infoArray[neib_index]));
+			const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+			const float s = p->repack_a*p->sscoeff[fl]*p->sscoeff[fl]*npos.w/n_rho*f;
+			force.x -= s*rx; force.y -= s*ry; force.z -= s*rz;
+		}
+		forces[index] = force;
+	}
+}
+
+uint32_t orc_repack_forces(const orc_params *p, orc_f4 *forces, float *cfl,
+	orc_f4 *rbforces, orc_f4 *rbtorques,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset)
+{
+	(void)numParticles;
+	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
+	const int dtadapt = !!(p->simflags & ORC_ENABLE_DTADAPT);
+	repack_pass(p, PT_FLUID, forces, posArray, velArray, infoArray, hashArray, cellStart, neibsList, fromParticle, toParticle);
+	repack_pass(p, PT_BOUNDARY, forces, posArray, velArray, infoArray, hashArray, cellStart, neibsList, fromParticle, toParticle);
+#pragma omp parallel for schedule(static)
+	for (uint32_t block = 0; block < numBlocks; ++block) {
+		float block_max = 0.0f;
+		for (uint32_t t = 0; t < BLOCK_SIZE_FORCES; ++t) {
+			const uint32_t index = block*BLOCK_SIZE_FORCES + t + fromParticle;
+			if (index >= toParticle) break;
+			const orc_info info = infoArray[index];
+			const orc_f4 pos = posArray[index];
+			if (INACTIVE(pos)) continue;
+			const orc_f4 vel = velArray[index];
+			orc_f4 force = forces[index];
+			const int fl = FLUID_NUM(info);
+			force.w /= p->rho0[fl];
+			if (FLUID(info)) {
+				const float damp = p->repack_alpha*p->sscoeff[fl]/p->deltap;
+				force.x += damp*vel.x; force.y += damp*vel.y; force.z += damp*vel.z;
+				/* planes: Lennard-Jones part of PlaneForce; the friction term -mu partsurf/(m r) v_t is taken with
+				 * mu = 0 (visccoeff of the inviscid problems built here) */
+				if ((p->simflags & ORC_ENABLE_PLANES) && p->numplanes) {
+					int gp[3];
+					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
+					for (uint32_t k = 0; k < p->numplanes; ++k) {
+						const float dx = (gp[0] - p->plane_gridpos[k][0])*p->cellSize[0] + (pos.x - p->plane_pos[k][0]);
+						const float dy = (gp[1] - p->plane_gridpos[k][1])*p->cellSize[1] + (pos.y - p->plane_pos[k][1]);
+						const float dz = (gp[2] - p->plane_gridpos[k][2])*p->cellSize[2] + (pos.z - p->plane_pos[k][2]);
+						const float *nrm = p->plane_normal[k];
+						const float r = fabsf(dx*nrm[0] + dy*nrm[1] + dz*nrm[2]);
+						if (r < p->r0) {
+							const float DvDt = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
+							force.x += DvDt*(nrm[0]*r); force.y += DvDt*(nrm[1]*r); force.z += DvDt*(nrm[2]*r);
+						}
+					}
+				}
+				if (dtadapt) {
+					const float sspeed = orc_soundSpeed(p, vel.w, fl);
+					const float a = sqrtf(sqlength3(force.x, force.y, force.z));
+					block_max = fmaxf(block_max, fmaxf(a, sspeed*sspeed/p->slength));
+				}
+			}
+			if (COMPUTE_FORCE(info) && !VERTEX(info) && rbforces) {
+				const uint32_t rbindex = (uint32_t)((int)orc_info_id(info) + p->rbstartindex[OBJECT_NUM(info)]);
+				const orc_f4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+				rbforces[rbindex] = zero; rbtorques[rbindex] = zero;
+			}
+			forces[index] = force;
+		}
+		if (dtadapt && cfl)
+			cfl[cflOffset + block] = block_max;
+	}
+	return numBlocks;
+}
+
 /* cflmax + dtreduce: src/cuda/forces.cu:150-176,556-606 ; fmaxDevice forces_kernel.cu:734-793 */
 float orc_dtreduce(const orc_params *p, const float *cfl, uint32_t numBlocks,
 	float sspeed_cfl, float max_kinematic)
@@ -969,12 +1071,14 @@ void orc_sps(const orc_params *p, float *tau, float *turbvisc,
 }
 
 /* ---- eulerDevice<step>: src/cuda/euler_kernel.def:396-538 --------------------------- */
-void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
+static void euler_body(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 	const orc_f4 *oldPos, const orc_f4 *oldVel, const orc_info *infoArray, const uint32_t *hashArray,
 	const orc_f4 *forces, const orc_f4 *xsph,
-	uint32_t numParticles, float dt, int step)
+	uint32_t numParticles, float dt, int step, int repacking)
 {
-	const int integrateBoundary = (p->boundarytype == ORC_DYN_BOUNDARY || p->boundarytype == ORC_SA_BOUNDARY);
+	/* euler_repack_params (src/cuda/euler_params.h:203): no boundary integration, no continuity, no XSPH, no body motion */
+	const int integrateBoundary = !repacking &&
+		(p->boundarytype == ORC_DYN_BOUNDARY || p->boundarytype == ORC_SA_BOUNDARY);
 #pragma omp parallel for schedule(static)
 	for (uint32_t index = 0; index < numParticles; ++index) {
 		const orc_info info = infoArray[index];
@@ -993,7 +1097,7 @@ void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 				velc[1] = fmaf(force.y, hdt, velc[1]);
 				velc[2] = fmaf(force.z, hdt, velc[2]);
 			}
-			if ((p->simflags & ORC_ENABLE_XSPH) && xsph) {
+			if ((p->simflags & ORC_ENABLE_XSPH) && xsph && !repacking) {
 				velc[0] = fmaf(p->epsxsph, xsph[index].x, velc[0]);
 				velc[1] = fmaf(p->epsxsph, xsph[index].y, velc[1]);
 				velc[2] = fmaf(p->epsxsph, xsph[index].z, velc[2]);
@@ -1004,14 +1108,15 @@ void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 				pos.x = fmaf(velc[0], dt, pos.x);
 				pos.y = fmaf(velc[1], dt, pos.y);
 				pos.z = fmaf(velc[2], dt, pos.z);
-				vel.w = fmaf(dt, force.w, vel.w); /* continuity_integration :203-209 */
+				if (!repacking)
+					vel.w = fmaf(dt, force.w, vel.w); /* continuity_integration :203-209 */
 				vel.x = fmaf(dt, force.x, vel.x);
 				vel.y = fmaf(dt, force.y, vel.y);
 				vel.z = fmaf(dt, force.z, vel.z);
 				break;
 			case PT_VERTEX:
 			case PT_BOUNDARY:
-				if (MOVING(info)) {
+				if (!repacking && MOVING(info)) {
 					int gp[3];
 					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
 					const float rx = (gp[0] - p->rbcgGridPos[obj][0])*p->cellSize[0] + (pos.x - p->rbcgPos[obj][0]);
@@ -1039,6 +1144,33 @@ void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 		} while (0);
 		newPos[index] = pos;
 		newVel[index] = vel;
+	}
+}
+
+void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
+	const orc_f4 *oldPos, const orc_f4 *oldVel, const orc_info *infoArray, const uint32_t *hashArray,
+	const orc_f4 *forces, const orc_f4 *xsph,
+	uint32_t numParticles, float dt, int step)
+{
+	euler_body(p, newPos, newVel, oldPos, oldVel, infoArray, hashArray, forces, xsph, numParticles, dt, step, 0);
+}
+
+/* run_mode == REPACK: eulerDevice with euler_repack_params (src/cuda/euler.cu:346-353) */
+void orc_euler_repack(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
+	const orc_f4 *oldPos, const orc_f4 *oldVel, const orc_info *infoArray, const uint32_t *hashArray,
+	const orc_f4 *forces, uint32_t numParticles, float dt, int step)
+{
+	euler_body(p, newPos, newVel, oldPos, oldVel, infoArray, hashArray, forces, NULL, numParticles, dt, step, 1);
+}
+
+/* disableFreeSurfPartsDevice (src/cuda/euler_kernel.cu:158-180): at the end of repacking the non-fluid particles
+ * flagged FG_SURFACE (the lid that kept the free surface in place) are disabled */
+void orc_disable_free_surf_parts(orc_f4 *pos, const orc_info *infoArray, uint32_t numParticles)
+{
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		if (SURFACE(info) && !FLUID(info) && ACTIVE(pos[index]))
+			pos[index].w = NAN; /* disable_particle */
 	}
 }
 

@@ -26,6 +26,7 @@ class OrcParams(C.Structure):
         ("artvisccoeff", C.c_float), ("epsartvisc", C.c_float),
         ("smagfactor", C.c_float), ("kspsfactor", C.c_float),
         ("dcoeff", C.c_float), ("p1coeff", C.c_float), ("p2coeff", C.c_float), ("r0", C.c_float),
+        ("repack_a", C.c_float), ("repack_alpha", C.c_float),
         ("numplanes", C.c_uint32),
         ("plane_normal", (C.c_float * 3) * 8), ("plane_gridpos", (C.c_int32 * 3) * 8), ("plane_pos", (C.c_float * 3) * 8),
         ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),
@@ -196,6 +197,28 @@ class Oracle:
                          C.c_uint32(n), C.c_float(dt), C.c_int(step))
         return npos, nvel
 
+    def repack_forces(self, pos, vel, info, hash_, cs, nl, n, frm=0, to=None, cfl_offset=0, rb_count=0):
+        to = n if to is None else to
+        forces = np.zeros((len(pos), 4), dtype=np.float32)
+        nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
+        cfl = np.zeros(nblk + cfl_offset, dtype=np.float32)
+        rbf = np.ones((max(rb_count, 1), 4), dtype=np.float32)
+        rbt = np.ones((max(rb_count, 1), 4), dtype=np.float32)
+        self.L.orc_repack_forces.restype = C.c_uint32
+        nb = self.L.orc_repack_forces(C.byref(self.p), P(forces), P(cfl), P(rbf) if rb_count else None,
+                                      P(rbt) if rb_count else None, P(pos), P(vel), P(info), P(hash_), P(cs), P(nl),
+                                      C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset))
+        return forces, cfl, int(nb), rbf, rbt
+
+    def euler_repack(self, old_pos, old_vel, info, hash_, forces, n, dt, step=1):
+        npos = np.zeros_like(old_pos); nvel = np.zeros_like(old_vel)
+        self.L.orc_euler_repack(C.byref(self.p), P(npos), P(nvel), P(old_pos), P(old_vel), P(info), P(hash_), P(forces),
+                                C.c_uint32(n), C.c_float(dt), C.c_int(step))
+        return npos, nvel
+
+    def disable_free_surf_parts(self, pos, info, n):
+        self.L.orc_disable_free_surf_parts(P(pos), P(info), C.c_uint32(n))
+
     def filter(self, filtertype, pos, vel, info, hash_, cs, nl, range_end):
         """shepard (0) / MLS (1); inactive particles keep their input velocity in the returned copy"""
         new = vel.copy()
@@ -266,6 +289,40 @@ class OracleSim:
         self.n = newn
         sq = float(np.float32(self.problem.simparams.nlSqInfluenceRadius))
         self.nl, self.neibs_info = o.build_neibs(self.pos, self.info, self.hash, self.cs, self.ce, self.n, self.n, sq)
+
+    def repack_step(self):
+        """RepackingIntegrator::initializeRepackingSequence (src/integrators/RepackingIntegrator.cc:278-420)"""
+        sp = self.problem.simparams
+        o = self.o
+        if self.iterations % sp.buildneibsfreq == 0:
+            self.build_neibs()
+        n = self.n
+        dt = float(np.float32(self.dt))
+        rb = getattr(self.problem, "num_obstacle", 0)
+        f, cfl, nb, self.rbf, self.rbt = o.repack_forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n, rb_count=rb)
+        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl)
+        self.pos, self.vel = o.euler_repack(self.pos, self.vel, self.info, self.hash, f, n, dt, 1)
+        self.forces = f
+        self.t += dt
+        self.iterations += 1
+        self.dt = dt1
+
+    def repack(self, maxiter=None, reset=True):
+        sp = self.problem.simparams
+        for _ in range(int(sp.repack_maxiter if maxiter is None else maxiter)):
+            self.repack_step()
+        self.o.disable_free_surf_parts(self.pos, self.info, self.n)
+        if self.iterations > 0:
+            self.build_neibs()
+        if not reset:
+            return
+        self.iterations = 0
+        self.t = 0.0
+        self.dt = float(np.float32(sp.dt))
+        n = self.n
+        rho = self.problem.initial_density(self.problem.global_pos(self.pos[:n], self.hash[:n]))
+        self.vel[:n] = 0
+        self.vel[:n, 3] = rho
 
     def step(self):
         sp = self.problem.simparams

@@ -716,3 +716,133 @@ def test_against_committed_feature_fixture():
         assert abs(float(eng.d_dt_next.item()) - float(g[tag + "_dt"])) <= 2e-5 * float(g[tag + "_dt"])
         if prob.num_obstacle:
             assert np.abs(_np(eng.rbforces) - g[tag + "_rbforces"]).max() <= 2e-5 * max(np.abs(g[tag + "_rbforces"]).max(), 1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# repacking run mode (run_mode = REPACK through the same basicstep entry points): no fast-math in this kernel, so
+# the forces are BIT-EXACT against the oracle for the polynomial kernels; the CFL term holds a powf (sound speed)
+# and is compared to 1e-6
+def _repack_cases():
+    from gpusph_amd.problem import PeriodicBox
+    return [
+        ("dambreak", lambda: DamBreak3D(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=True)),
+        ("dambreak-cubic", lambda: DamBreak3D(deltap=0.05, obstacle=False, jitter=0.2, kerneltype=D.CUBICSPLINE)),
+        ("dambreak-quadratic", lambda: DamBreak3D(deltap=0.05, obstacle=False, jitter=0.2, kerneltype=D.QUADRATIC)),
+        ("periodic", lambda: PeriodicBox(deltap=0.05, n=(20, 16, 12), jitter=0.25, repacking=True)),
+        ("lj-planes", lambda: DamBreak3D(deltap=0.04, obstacle=False, jitter=0.3, hydrostatic=False,
+                                         boundary=D.LJ_BOUNDARY, walls="planes")),
+    ]
+
+
+@pytest.mark.parametrize("name", [c[0] for c in _repack_cases()])
+def test_repack_forces_bit_exact(name):
+    import torch
+    prob = dict(_repack_cases())[name]()
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    rng = np.random.default_rng(9)
+    v = sim.vel.copy()
+    v[:n, :3] = rng.uniform(-0.2, 0.2, size=(n, 3)).astype(np.float32)
+    sim.vel = v
+    eng.vel[: len(v)] = torch.from_numpy(v).to(eng.device)
+    rb = getattr(prob, "num_obstacle", 0)
+    f_ref, cfl_ref, nb, rbf_ref, rbt_ref = sim.o.repack_forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n, rb_count=rb)
+    eng.rbforces.fill_(1.0); eng.rbtorques.fill_(1.0)
+    eng.forces.zero_()
+    eng._forces(eng.pos, eng.vel, 1, 0, D.REPACK)
+    f = _np(eng.forces)[:n]
+    assert np.abs(f_ref[:n, :3]).max() > 1.0
+    if name == "lj-planes":     # powf in the plane repulsion
+        scale = np.abs(f_ref[:n, :3]).max()
+        assert np.abs(f - f_ref[:n]).max() <= 2e-6 * scale
+    else:
+        assert np.array_equal(f.view(np.uint32), f_ref[:n].view(np.uint32))
+    cfl = _np(eng.cfl)[:nb]
+    np.testing.assert_allclose(cfl, cfl_ref[:nb], rtol=1e-6)
+    dt_ref = sim.o.dtreduce(cfl_ref, nb, sim.sspeed_cfl)
+    assert abs(float(eng.d_dt_next.item()) - dt_ref) <= 1e-6 * dt_ref
+    if rb:
+        assert not np.any(_np(eng.rbforces)[:rb]) and not np.any(_np(eng.rbtorques)[:rb])   # zeroed, like the oracle
+        assert not np.any(rbf_ref[:rb]) and not np.any(rbt_ref[:rb])
+
+
+def test_repack_euler_bit_exact_and_lid_removal():
+    import torch
+    from gpusph_amd import capi
+    prob = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.1, hydrostatic=True)
+    eng = _engine(prob)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    rng = np.random.default_rng(10)
+    f = rng.uniform(-50, 50, size=(len(sim.pos), 4)).astype(np.float32)
+    v = sim.vel.copy()
+    v[:n, :3] = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    sim.vel = v
+    eng.vel[: len(v)] = torch.from_numpy(v).to(eng.device)
+    eng.forces[: len(f)] = torch.from_numpy(f).to(eng.device)
+    for step in (1, 2):
+        dt = float(np.float32(eng.dt))
+        p_ref, v_ref = sim.o.euler_repack(sim.pos, sim.vel, sim.info, sim.hash, f, n, dt, step)
+        eng._euler(step, 1.0, D.REPACK)
+        assert np.array_equal(_np(eng.pos2)[:n].view(np.uint32), p_ref[:n].view(np.uint32))
+        assert np.array_equal(_np(eng.vel2)[:n].view(np.uint32), v_ref[:n].view(np.uint32))
+    # the lid
+    info = sim.info.copy()
+    ptype = info[:n, 0] & 7
+    info[np.where(ptype == 1)[0][:33], 0] |= D.FG_SURFACE
+    info[np.where(ptype == 0)[0][:20], 0] |= D.FG_SURFACE
+    pos_ref = sim.pos.copy()
+    sim.o.disable_free_surf_parts(pos_ref, info, n)
+    d_info = torch.from_numpy(info.view(np.int16)).to(eng.device)
+    capi.check(eng.lib.sphx_disable_free_surf_parts(eng.ctx.handle, capi.ptr(eng.pos), capi.ptr(d_info), n, n, None))
+    got = _np(eng.pos)[:n]
+    assert np.array_equal(np.isnan(got[:, 3]), np.isnan(pos_ref[:n, 3])) and np.isnan(got[:, 3]).sum() == 33
+    assert np.array_equal(got[:, :3].view(np.uint32), pos_ref[:n, :3].view(np.uint32))
+
+
+@pytest.mark.parametrize("name", ["dambreak", "periodic"])
+def test_repack_run_matches_oracle(name):
+    """`--repack`: repack_maxiter iterations spanning a re-sort, lid removal, rebuild, state reset; then the simulation
+    proper starts from the repacked particles."""
+    prob = dict(_repack_cases())[name]()
+    prob.simparams.repack_maxiter = 14
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    eng.repack(reset=False); sim.repack(reset=False)
+    n = eng.n
+    assert n == sim.n and eng.iterations == sim.iterations == 14
+    out = eng.download()
+    assert np.array_equal(out["hash"], sim.hash[:n])
+    assert np.array_equal(out["info"], sim.info[:n])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs
+    vmax = np.abs(sim.vel[:n, :3]).max()
+    assert vmax > 0.05
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-5 * vmax
+    assert np.array_equal(out["vel"][:, 3], sim.vel[:n, 3])                     # density untouched
+    assert abs(eng.time() - sim.t) <= 1e-6 * sim.t
+    eng.repack(maxiter=0); sim.repack(maxiter=0)                                 # reset only
+    assert eng.iterations == 0 and eng.time() == 0.0
+    out = eng.download()
+    assert not np.any(out["vel"][:, :3])
+    np.testing.assert_allclose(out["vel"][:, 3], sim.vel[:n, 3], rtol=0, atol=2e-7)   # hydrostatic rho~ at the new positions
+    for _ in range(3):
+        eng.step(); sim.step()
+    out = eng.download()
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 3e-6 * cs
+    vmax = max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * vmax
+
+
+def test_repack_needs_the_framework_flag():
+    from gpusph_amd import capi
+    from gpusph_amd.problem import PeriodicBox
+    prob = PeriodicBox(deltap=0.05, n=(12, 10, 9), jitter=0.1)       # ENABLE_REPACKING not set
+    eng = _engine(prob)
+    eng.build_neibs()
+    with pytest.raises(capi.SphxInvalidArgument, match="ENABLE_REPACKING"):
+        eng._forces(eng.pos, eng.vel, 1, 0, D.REPACK)
+    with pytest.raises(ValueError, match="not enabled"):
+        eng.repack()

@@ -440,3 +440,132 @@ def test_periodic_momentum_conservation():
     assert np.abs(tot).max() < 1e-5 * (np.abs(f[:n, :3]).astype(np.float64) * m[:, None]).sum()
     nl = sim.nl.reshape(-1, len(sim.pos))[:, :n]
     assert (nl != 0xFFFF).sum(axis=0).min() > 50           # nobody is short of neighbours at a "face": there are none
+
+
+# ---------------------------------------------------------------------------------------------- repacking (8f-3)
+def test_repack_force_equals_brute_force():
+    """run_repack: F_a = -a c0^2 sum_b (m_b/rho_b) F(r_ab) r_ab over fluid AND boundary neighbours (fluid particles
+    only), plus alpha c0/deltap v_a in finalize; the density rate stays zero.  Compared with a float64 brute-force sum."""
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.25, hydrostatic=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(5)
+    sim.vel[:n, :3] = rng.uniform(-0.2, 0.2, size=(n, 3)).astype(np.float32)
+    f, cfl, nb, _, _ = sim.o.repack_forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    ptype = sim.info[:n, 0] & 7
+    fl = np.where(ptype == 0)[0]
+    p = sim.o.p
+    a, alpha, c0, h, dp = float(p.repack_a), float(p.repack_alpha), float(p.sscoeff[0]), float(p.slength), float(p.deltap)
+    assert a == pytest.approx(0.1) and alpha == pytest.approx(0.01)            # DamBreak3D.cu:99-100
+    from scipy.spatial import cKDTree
+    tree = cKDTree(gp)
+    m = sim.pos[:n, 3].astype(np.float64)
+    rho = (sim.vel[:n, 3].astype(np.float64) + 1.0) * float(p.rho0[0])
+    fcoeff = 105.0 / (128.0 * np.pi * h ** 5)
+    ref = np.zeros((n, 3))
+    for i, nbs in zip(fl, tree.query_ball_point(gp[fl], 2 * h * (1 - 1e-7))):
+        nbs = [j for j in nbs if j != i and ptype[j] in (0, 1)]
+        d = gp[i] - gp[nbs]
+        r = np.linalg.norm(d, axis=1)
+        F = (r / h - 2.0) ** 3 * fcoeff
+        ref[i] = -(a * c0 * c0 * (m[nbs] / rho[nbs] * F)[:, None] * d).sum(axis=0)
+        ref[i] += alpha * c0 / dp * sim.vel[i, :3]
+    scale = np.abs(ref).max()
+    assert scale > 1.0
+    assert np.abs(f[:n, :3] - ref).max() <= 2e-4 * scale
+    assert not np.any(f[:n, 3])                                    # no continuity equation while repacking
+    assert not np.any(f[:n][ptype != 0])                            # only fluid particles are moved
+    # the mixing force points away from crowding: towards the free surface for a particle just under it
+    top = fl[np.argsort(gp[fl, 2])[-50:]]
+    sim.vel[:n, :3] = 0
+    f0 = sim.o.repack_forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    assert np.mean(f0[top, 2]) > 0
+    # CFL: max(|F|, c^2/h) per block of 128
+    blk0 = slice(0, 128)
+    c = np.array([ol.lib().orc_soundSpeed(ol.C.byref(p), float(sim.vel[i, 3]), 0) for i in range(128)])
+    expect = np.where(ptype[blk0] == 0, np.maximum(np.linalg.norm(f0[blk0, :3].astype(np.float64), axis=1), c * c / h), 0.0)
+    assert cfl.shape[0] >= nb
+    cfl0 = sim.o.repack_forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[1]
+    assert cfl0[0] == pytest.approx(expect.max(), rel=1e-6)
+
+
+def test_repack_force_vanishes_on_a_seamless_lattice_and_relaxes_a_jittered_one():
+    from gpusph_amd.problem import PeriodicBox
+    prob = PeriodicBox(deltap=0.05, n=(12, 10, 9), jitter=0.0, repacking=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    f = sim.o.repack_forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    p = sim.o.p
+    one_pair = float(p.repack_a) * float(p.sscoeff[0]) ** 2 * 0.05 ** 3 * 0.05 * abs(ol.lib().orc_F(D.WENDLAND, 0.05, float(p.slength)))
+    assert np.abs(f[:n, :3]).max() < 1e-4 * one_pair * 50         # lattice symmetry
+
+    def disorder(s):
+        """std of the particle concentration sum_b V_b W_ab"""
+        m = s.n
+        g = prob.global_pos(s.pos[:m], s.hash[:m])
+        from scipy.spatial import cKDTree
+        L = prob.m_size
+        tree = cKDTree(np.mod(g, L), boxsize=L)
+        h = float(p.slength)
+        pairs = tree.query_pairs(2 * h, output_type="ndarray")
+        d = g[pairs[:, 0]] - g[pairs[:, 1]]
+        d -= np.round(d / L) * L
+        q = np.linalg.norm(d, axis=1) / h
+        w = 21.0 / (16.0 * np.pi * h ** 3) * (1 - q / 2) ** 4 * (1 + 2 * q) * 0.05 ** 3
+        conc = np.full(m, 21.0 / (16.0 * np.pi * h ** 3) * 0.05 ** 3)
+        np.add.at(conc, pairs[:, 0], w); np.add.at(conc, pairs[:, 1], w)
+        return conc.std()
+
+    # The mixing force is conservative and the reference adds its velocity term with a positive sign
+    # (forces_kernel.def:4308-4310), so the particles oscillate about the uniform arrangement rather than settle: the
+    # iteration count is the stopping rule (DamBreak3D.cu:99-101 uses a = 0.1, 10 iterations = a quarter period here).
+    prob = PeriodicBox(deltap=0.05, n=(12, 10, 9), jitter=0.25, repacking=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    d0 = disorder(sim)
+    rho_before = np.sort(sim.vel[:sim.n, 3].copy())
+    sim.repack(maxiter=10, reset=False)
+    d1 = disorder(sim)
+    assert d1 < 0.5 * d0                                          # the particle distribution got more uniform
+    assert np.array_equal(np.sort(sim.vel[:sim.n, 3]), rho_before)   # density untouched by the repacking Euler step
+    assert sim.iterations == 10 and sim.t > 0
+    sim.repack(maxiter=0)                                          # reset as when resuming from the repack file
+    assert sim.iterations == 0 and sim.t == 0.0 and not np.any(sim.vel[:sim.n, :3])
+
+
+def test_repack_euler_and_lid_removal():
+    prob = DamBreak3D(deltap=0.05, obstacle=True, jitter=0.1, hydrostatic=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(6)
+    f = rng.uniform(-1, 1, size=(len(sim.pos), 4)).astype(np.float32)
+    sim.vel[:n, :3] = rng.uniform(-0.2, 0.2, size=(n, 3)).astype(np.float32)
+    dt = 1e-4
+    p1, v1 = sim.o.euler_repack(sim.pos, sim.vel, sim.info, sim.hash, f, n, dt, 1)
+    ptype = sim.info[:n, 0] & 7
+    fl = ptype == 0
+    moving = (sim.info[:n, 0] & D.FG_MOVING_BOUNDARY) != 0
+    assert moving.sum() > 0
+    assert np.array_equal(p1[:n][~fl], sim.pos[:n][~fl])                       # nobody but the fluid moves, bodies included
+    assert np.array_equal(v1[:n][~fl, :3], sim.vel[:n][~fl, :3])
+    assert np.array_equal(v1[:n][~fl & ~moving], sim.vel[:n][~fl & ~moving])
+    # particles of moving bodies pass the early exit and, with DYN_BOUNDARY, still integrate FORCES.w
+    # (euler_kernel.def:426-431,503-506); the repacking forces leave it at zero
+    np.testing.assert_allclose(v1[:n][moving, 3], sim.vel[:n][moving, 3] + np.float32(dt) * f[:n][moving, 3], rtol=0, atol=1e-7)
+    assert np.array_equal(v1[:n][~moving, 3], sim.vel[:n][~moving, 3])
+    np.testing.assert_allclose(p1[:n][fl, :3], sim.pos[:n][fl, :3] + np.float32(dt) * sim.vel[:n][fl, :3], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(v1[:n][fl, :3], sim.vel[:n][fl, :3] + np.float32(dt) * f[:n][fl, :3], rtol=0, atol=1e-7)
+    # lid: non-fluid particles flagged FG_SURFACE are disabled, flagged fluid particles are not
+    info = sim.info.copy()
+    bd = np.where(ptype == 1)[0][:7]
+    flu = np.where(fl)[0][:5]
+    info[bd, 0] |= D.FG_SURFACE
+    info[flu, 0] |= D.FG_SURFACE
+    pos = sim.pos.copy()
+    sim.o.disable_free_surf_parts(pos, info, n)
+    dead = ~np.isfinite(pos[:n, 3])
+    assert set(np.where(dead)[0]) == set(bd)
