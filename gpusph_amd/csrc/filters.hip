@@ -483,7 +483,10 @@ repack_kernel(DevParams p, FilterArgs a, RepackArgs o)
 			const float4 vel = a.vel[index];
 			const float damp = p.repack_alpha*p.sscoeff[fl]/p.deltap;
 			force.x += damp*vel.x; force.y += damp*vel.y; force.z += damp*vel.z;
-			if ((p.simflags & SPHX_ENABLE_PLANES) && p.numplanes) {   // GeometryForce, friction coefficient 0
+			// GeometryForce with dynvisc = d_visccoeff*rho (:4314); d_visccoeff is NaN for inviscid problems in the
+			// reference (GPUSPH.cc:1488-1493), taken as 0 = free slip here
+			const float dynvisc = (p.rheology == SPHX_NEWTONIAN) ? p.visccoeff[fl]*((vel.w + 1.0f)*p.rho0[fl]) : 0.0f;
+			if ((p.simflags & SPHX_ENABLE_PLANES) && p.numplanes) {
 				for (uint32_t k = 0; k < p.numplanes; ++k) {
 					const float dx = (gridPos.x - p.plane_gridpos[k][0])*p.cs[0] + (pos.x - p.plane_pos[k][0]);
 					const float dy = (gridPos.y - p.plane_gridpos[k][1])*p.cs[1] + (pos.y - p.plane_pos[k][1]);
@@ -491,8 +494,14 @@ repack_kernel(DevParams p, FilterArgs a, RepackArgs o)
 					const float r = fabsf(dx*p.plane_normal[k][0] + dy*p.plane_normal[k][1] + dz*p.plane_normal[k][2]);
 					if (r < p.r0) {
 						const float DvDt = p.dcoeff*(powf(p.r0/r, p.p1coeff) - powf(p.r0/r, p.p2coeff))/(r*r);
-						force.x += DvDt*(p.plane_normal[k][0]*r); force.y += DvDt*(p.plane_normal[k][1]*r);
-						force.z += DvDt*(p.plane_normal[k][2]*r);
+						const float qx = p.plane_normal[k][0]*r, qy = p.plane_normal[k][1]*r, qz = p.plane_normal[k][2]*r;
+						force.x += DvDt*qx; force.y += DvDt*qy; force.z += DvDt*qz;
+						if (dynvisc != 0.0f) {
+							const float d = (vel.x*qx + vel.y*qy + vel.z*qz)/r, inv = 1.0f/r;
+							const float coeff = -dynvisc*p.partsurf/(pos.w*r);
+							force.x += coeff*(vel.x - (d*qx)*inv); force.y += coeff*(vel.y - (d*qy)*inv);
+							force.z += coeff*(vel.z - (d*qz)*inv);
+						}
 					}
 				}
 			}
@@ -531,10 +540,6 @@ int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, 
 {
 	if (!(ctx->dev.simflags & SPHX_ENABLE_REPACKING))   // src/main.cc:357-358
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: REPACK run mode needs ENABLE_REPACKING in simflags");
-	if ((ctx->dev.simflags & SPHX_ENABLE_PLANES) && ctx->dev.numplanes)
-		for (uint32_t f = 0; f < ctx->dev.numfluids; ++f)
-			if (ctx->params.visccoeff[f] != 0.0f)
-				return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: repacking against planes is built without wall friction (visccoeff must be 0)");
 	FilterArgs a;
 	a.newVel = nullptr; a.pos = (const float4*)pos; a.vel = (const float4*)vel;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;

@@ -96,10 +96,40 @@ struct Self {
 // one pair (i <- j).  Terms, in the reference's order (compute_all_pp_interaction,
 // forces_kernel.def:3565-3610): continuity + density diffusion -> force.w; pressure + viscous ->
 // force.xyz.  (pcx,pcy,pcz) = own position shifted into the neighbour's cell frame.
+// TURB template codes: the turbulence model in the low bits, SPHX_TURB_NEWT set for the NEWTONIAN rheology
+#define SPHX_TURB_NEWT 8
+#define TURB_MODEL(T) ((T) & 7)
+
+// select chain on the (at most four) kernel-argument values instead of a lane-indexed load from the argument block
+__device__ __forceinline__ float visc_of(const DevParams &p, uint32_t fl)
+{
+	const float lo = (fl & 1u) ? p.visccoeff[1] : p.visccoeff[0], hi = (fl & 1u) ? p.visccoeff[3] : p.visccoeff[2];
+	return (fl & 2u) ? hi : lo;
+}
+
+// visc_avg (src/cuda/visc_avg.cu:40-190) without the neighbour mass: the per-pair factor of the laminar Morris term
+// nu-or-mu averaged over the pair / densities.  All selectors are wave-uniform (kernel arguments).
+__device__ __forceinline__ float laminar_factor(const DevParams &p, uint32_t fl, uint32_t nfl, float rho, float n_rho)
+{
+	const float c = visc_of(p, fl);
+	if (p.is_const_visc) {
+		if (p.compvisc == SPHX_DYNAMIC) return 2.0f*c*fast_rcp(rho*n_rho);
+		if (p.avgop == SPHX_ARITHMETIC) return c*(rho + n_rho)*fast_rcp(rho*n_rho);
+		if (p.avgop == SPHX_HARMONIC) return 4.0f*c*fast_rcp(rho + n_rho);
+		return 2.0f*c*__builtin_amdgcn_rsqf(rho*n_rho);
+	}
+	const float nc = visc_of(p, nfl);
+	const float mu = (p.compvisc == SPHX_KINEMATIC) ? c*rho : c, nmu = (p.compvisc == SPHX_KINEMATIC) ? nc*n_rho : nc;
+	if (p.avgop == SPHX_ARITHMETIC) return (mu + nmu)*fast_rcp(rho*n_rho);
+	if (p.avgop == SPHX_HARMONIC) return 4.0f*(mu*nmu)*fast_rcp((mu + nmu)*(rho*n_rho));
+	return 2.0f*fast_sqrt(mu*nmu)*fast_rcp(rho*n_rho);
+}
+
 template<int KERNEL, int TURB, bool COLAGROSSI, bool MOMENTUM, bool DIFFUSE>
 __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s, float inv_h,
 	float pcx, float pcy, float pcz, const float4 &npos, const float4 &nvel, const float4 &naux,
-	bool same_fluid, bool valid, const float *ntau, float4 &force, bool rt_momentum = true, bool rt_diffuse = true)
+	bool same_fluid, bool valid, const float *ntau, float4 &force, bool rt_momentum = true, bool rt_diffuse = true,
+	uint32_t nfl = 0)
 {
 	// Branch-free on purpose: a rejected pair (list terminator passed, r >= influence radius) gets the weight
 	// m_j F_ij = 0 and every term below becomes +-0, which leaves the accumulators untouched -- the same result
@@ -133,7 +163,7 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 	if (MOMENTUM) {
 		// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
 		float kk = -(s.p_precalc + n_precalc)*mf;
-		if (TURB == SPHX_ARTIFICIAL) {
+		if (TURB_MODEL(TURB) == SPHX_ARTIFICIAL) {
 			// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764): only for approaching pairs
 			const float vdpn = fminf(vel_dot_pos, 0.0f);
 			const float visc = vdpn*(p.slength*p.artvisccoeff)*(s.sspeed + n_sspeed)*
@@ -141,7 +171,7 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 			kk = fmaf(visc, mf, kk);
 		}
 		kk = rt_momentum ? kk : 0.0f;
-		if (TURB == SPHX_SPS) { // forces_kernel.def:2777-2798
+		if (TURB_MODEL(TURB) == SPHX_SPS) { // forces_kernel.def:2777-2798
 			const float mg = rt_momentum ? mf : 0.0f;
 			const float xx = s.tau[0] + ntau[0], xy = s.tau[1] + ntau[1], xz = s.tau[2] + ntau[2];
 			const float yy = s.tau[3] + ntau[3], yz = s.tau[4] + ntau[4], zz = s.tau[5] + ntau[5];
@@ -150,6 +180,12 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 			force.z = fmaf(mg, fmaf(zz, rz, fmaf(yz, ry, xz*rx)), force.z);
 		}
 		force.x = fmaf(kk, rx, force.x); force.y = fmaf(kk, ry, force.y); force.z = fmaf(kk, rz, force.z);
+		if (TURB & SPHX_TURB_NEWT) {
+			// compute_laminar_visc_contrib, MORRIS (forces_kernel.def:2606-2625): visc_avg * F * (v_i - v_j), after the
+			// turbulent term (compute_viscous_contrib :2881-2886)
+			const float lv = rt_momentum ? laminar_factor(p, s.fl, nfl, s.rho, n_rho)*mf : 0.0f;
+			force.x = fmaf(lv, vx, force.x); force.y = fmaf(lv, vy, force.y); force.z = fmaf(lv, vz, force.z);
+		}
 	}
 }
 
@@ -186,8 +222,16 @@ __device__ __forceinline__ float finalize_particle(const DevParams &p, const For
 				const float r = fabsf(dx*p.plane_normal[k][0] + dy*p.plane_normal[k][1] + dz*p.plane_normal[k][2]);
 				if (r < p.r0) {
 					const float DvDt = p.dcoeff*(powf(p.r0/r, p.p1coeff) - powf(p.r0/r, p.p2coeff))/(r*r);
-					force.x += DvDt*(p.plane_normal[k][0]*r); force.y += DvDt*(p.plane_normal[k][1]*r);
-					force.z += DvDt*(p.plane_normal[k][2]*r);
+					const float qx = p.plane_normal[k][0]*r, qy = p.plane_normal[k][1]*r, qz = p.plane_normal[k][2]*r;
+					force.x += DvDt*qx; force.y += DvDt*qy; force.z += DvDt*qz;
+					if (p.rheology == SPHX_NEWTONIAN) {
+						// wall friction of PlaneForce (:153-185): -mu partsurf/(m r) v_t, mu = get_laminar_dyn_visc
+						const float dynvisc = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[s.fl]*s.rho : p.visccoeff[s.fl];
+						const float d = (s.vel.x*qx + s.vel.y*qy + s.vel.z*qz)/r, inv = 1.0f/r;
+						const float coeff = -dynvisc*p.partsurf/(s.pos.w*r);
+						force.x += coeff*(s.vel.x - (d*qx)*inv); force.y += coeff*(s.vel.y - (d*qy)*inv);
+						force.z += coeff*(s.vel.z - (d*qz)*inv);
+					}
 				}
 			}
 		}
@@ -221,7 +265,7 @@ __device__ __forceinline__ void load_self(const DevParams &p, const ForcesArgs &
 	const float4 ax = a.aux[index];
 	s.p_precalc = ax.x; s.sspeed = ax.y; s.P = ax.z; s.rho = ax.w;
 	s.inv_rho = fast_rcp(ax.w);
-	if (TURB == SPHX_SPS) {
+	if (TURB_MODEL(TURB) == SPHX_SPS) {
 		const float2 t0 = a.tau0[index], t1 = a.tau1[index], t2 = a.tau2[index];
 		s.tau[0] = t0.x; s.tau[1] = t0.y; s.tau[2] = t1.x; s.tau[3] = t1.y; s.tau[4] = t2.x; s.tau[5] = t2.y;
 	}
@@ -262,9 +306,13 @@ __device__ __forceinline__ void load_list_batch(const DevParams &p, const neibda
 
 // walk one typed section of the neighbour list (neiblist_iterator_simple,
 // src/cuda/neibs_iteration.cuh:165-205; getNeibIndex src/cuda/cellgrid.cuh:200-228)
-template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID, int NPTYPE, bool MOMENTUM, bool DIFFUSE>
+// LJW: the section is a Lennard-Jones repulsion walk (positions only).  A template flag, not a run-time one: a uniform
+// `if (lj)` around the two interaction bodies inside this loop made the compiler lose the wave-uniform viscosity
+// selectors after the first batch (generic kernel took the constant-viscosity branch of laminar_factor from the
+// second batch of the boundary section on; found by the two-fluid non-constant-viscosity parity test).
+template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID, int NPTYPE, bool MOMENTUM, bool DIFFUSE, bool LJW = false>
 __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArgs &a, uint32_t index,
-	const Self &s, float inv_h, float4 &force, bool lj = false)
+	const Self &s, float inv_h, float4 &force)
 {
 	int slot = (NPTYPE == PT_FLUID) ? 0 : (int)p.neibboundpos;
 	uint32_t nd[NB], ndn[NB];
@@ -306,6 +354,7 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 		// stage 2: gather the neighbour rows of the whole batch
 		float4 npos[NB], nvel[NB], naux[NB];
 		bool same[NB];
+		uint32_t nfl[NB];
 		float ntau[NB][6];
 #pragma unroll
 		for (int k = 0; k < NB; ++k) {
@@ -313,9 +362,9 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 			npos[k] = a.pos[j];
 			nvel[k] = a.vel[j];
 			naux[k] = a.aux[j];
-			same[k] = true;
-			if (MULTIFLUID) same[k] = FLUID_NUM(a.info[j]) == s.fl;
-			if (TURB == SPHX_SPS && MOMENTUM) {
+			same[k] = true; nfl[k] = 0u;
+			if (MULTIFLUID) { nfl[k] = FLUID_NUM(a.info[j]); same[k] = nfl[k] == s.fl; }
+			if (TURB_MODEL(TURB) == SPHX_SPS && MOMENTUM) {
 				const float2 t0 = a.tau0[j], t1 = a.tau1[j], t2 = a.tau2[j];
 				ntau[k][0] = t0.x; ntau[k][1] = t0.y; ntau[k][2] = t1.x; ntau[k][3] = t1.y; ntau[k][4] = t2.x; ntau[k][5] = t2.y;
 			}
@@ -328,11 +377,11 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 			const float pcx = fmaf(-(float)(cx - 1), p.cs[0], s.pos.x);
 			const float pcy = fmaf(-(float)(cy - 1), p.cs[1], s.pos.y);
 			const float pcz = fmaf(-(float)(cz - 1), p.cs[2], s.pos.z);
-			if (lj)
+			if (LJW)
 				lj_interact(p, pcx, pcy, pcz, npos[k], valid[k], force);
 			else
 				pair_interact<KERNEL, TURB, COLAGROSSI, MOMENTUM, DIFFUSE>(p, s, inv_h, pcx, pcy, pcz,
-					npos[k], nvel[k], naux[k], same[k], valid[k], ntau[k], force);
+					npos[k], nvel[k], naux[k], same[k], valid[k], ntau[k], force, true, true, nfl[k]);
 		}
 #pragma unroll
 		for (int k = 0; k < NB; ++k) nd[k] = ndn[k];
@@ -373,13 +422,15 @@ forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZe
 			// fluid <- boundary : same interaction for DYN_BOUNDARY (forces_kernel.def:3717-3726),
 			// no density diffusion from boundary neighbours (:1596-1606)
 			// ... Lennard-Jones repulsion for LJ_BOUNDARY (:3688-3705)
-			if (dyn || lj)
-				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_BOUNDARY, true, false>(p, a, index, s, inv_h, force, lj);
+			if (dyn)
+				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_BOUNDARY, true, false>(p, a, index, s, inv_h, force);
+			else if (lj)
+				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_BOUNDARY, true, false, true>(p, a, index, s, inv_h, force);
 		} else if (ptype == PT_BOUNDARY && lj) {
 			// boundary <- fluid with LJ_BOUNDARY (:3620-3645): only particles of bodies with force feedback, and only
 			// when the caller asked for object forces (run_forces launches this pass only then, src/cuda/forces.cu:775-782)
 			if (HAS_COMPUTE_FORCE(info) && a.compute_object_forces)
-				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, true, false>(p, a, index, s, inv_h, force, true);
+				walk_section<KERNEL, TURB, COLAGROSSI, MULTIFLUID, PT_FLUID, true, false, true>(p, a, index, s, inv_h, force);
 		} else if (ptype == PT_BOUNDARY && dyn) {
 			// boundary <- fluid (forces_kernel.def:3650-3679): DYN always evolves density; momentum
 			// only for particles of bodies with force feedback
@@ -1159,6 +1210,7 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 	const DevParams &p = ctx->dev;
 	const bool mf = p.numfluids > 1;
 	const bool cola = p.densitydiff == SPHX_COLAGROSSI;
+	const bool newt = p.rheology == SPHX_NEWTONIAN;
 	const uint32_t *guard = use_tiles ? ctx->tile_ctl + 1 : nullptr;
 	ForcesTimer t(ctx, stream, !use_tiles);   // without tiles the generic kernel is the dominant one
 	switch (p.turbmodel) {
@@ -1168,13 +1220,25 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 		else launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, false>(mf, grid, stream, p, a, guard);
 		break;
 	case SPHX_SPS:
-		if (cola) launch_forces_mf<KERNEL, SPHX_SPS, true>(mf, grid, stream, p, a, nullptr);
-		else launch_forces_mf<KERNEL, SPHX_SPS, false>(mf, grid, stream, p, a, nullptr);
+		if (newt) {
+			if (cola) launch_forces_mf<KERNEL, SPHX_SPS | SPHX_TURB_NEWT, true>(mf, grid, stream, p, a, nullptr);
+			else launch_forces_mf<KERNEL, SPHX_SPS | SPHX_TURB_NEWT, false>(mf, grid, stream, p, a, nullptr);
+		} else {
+			if (cola) launch_forces_mf<KERNEL, SPHX_SPS, true>(mf, grid, stream, p, a, nullptr);
+			else launch_forces_mf<KERNEL, SPHX_SPS, false>(mf, grid, stream, p, a, nullptr);
+		}
 		break;
 	case SPHX_LAMINAR_FLOW:
-		if (use_tiles) { if (cola) launch_tile<KERNEL, SPHX_LAMINAR_FLOW, true>(ctx, stream, a); else launch_tile<KERNEL, SPHX_LAMINAR_FLOW, false>(ctx, stream, a); }
-		if (cola) launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, true>(mf, grid, stream, p, a, guard);
-		else launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, false>(mf, grid, stream, p, a, guard);
+		if (newt) {
+			constexpr int T = SPHX_LAMINAR_FLOW | SPHX_TURB_NEWT;
+			if (use_tiles) { if (cola) launch_tile<KERNEL, T, true>(ctx, stream, a); else launch_tile<KERNEL, T, false>(ctx, stream, a); }
+			if (cola) launch_forces_mf<KERNEL, T, true>(mf, grid, stream, p, a, guard);
+			else launch_forces_mf<KERNEL, T, false>(mf, grid, stream, p, a, guard);
+		} else {
+			if (use_tiles) { if (cola) launch_tile<KERNEL, SPHX_LAMINAR_FLOW, true>(ctx, stream, a); else launch_tile<KERNEL, SPHX_LAMINAR_FLOW, false>(ctx, stream, a); }
+			if (cola) launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, true>(mf, grid, stream, p, a, guard);
+			else launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, false>(mf, grid, stream, p, a, guard);
+		}
 		break;
 	default:
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: turbulence model not built");
@@ -1202,7 +1266,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid run mode");
 	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY && ctx->dev.boundarytype != SPHX_LJ_BOUNDARY)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: only DYN_BOUNDARY and LJ_BOUNDARY pair interactions are built");
-	if (ctx->dev.turbmodel == SPHX_SPS)
+	if (ctx->dev.turbmodel == SPHX_SPS && run_mode == SPHX_SIMULATE)
 		SPHX_REQUIRE(tau0 && tau1 && tau2, "sphx_forces_basicstep: SPS needs the three TAU arrays");
 	if ((ctx->dev.simflags & SPHX_ENABLE_DTADAPT))
 		SPHX_REQUIRE(cfl != nullptr, "sphx_forces_basicstep: ENABLE_DTADAPT needs the CFL buffer");

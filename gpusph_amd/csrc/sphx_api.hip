@@ -173,8 +173,18 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only DYN_BOUNDARY and LJ_BOUNDARY neighbour lists are built");
 	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only Colagrossi (or no) density diffusion is built");
-	if (sp->rheologytype != SPHX_INVISCID)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only INVISCID rheology (+ARTIFICIAL or SPS turbulence) is built");
+	if (sp->rheologytype != SPHX_INVISCID && sp->rheologytype != SPHX_NEWTONIAN)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only INVISCID and NEWTONIAN rheologies are built");
+	if (sp->rheologytype == SPHX_NEWTONIAN) {
+		if (sp->viscmodel != SPHX_MORRIS)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only the MORRIS viscous model is built");
+		if (sp->turbmodel == SPHX_ARTIFICIAL)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: NEWTONIAN rheology is built with LAMINAR_FLOW or SPS");
+		SPHX_REQUIRE(sp->compvisc == SPHX_KINEMATIC || sp->compvisc == SPHX_DYNAMIC, "sphx_set_constants: invalid computational viscosity");
+		SPHX_REQUIRE(sp->avgop >= SPHX_ARITHMETIC && sp->avgop <= SPHX_GEOMETRIC, "sphx_set_constants: invalid averaging operator");
+		for (uint32_t f = 0; f < sp->numfluids; ++f)
+			SPHX_REQUIRE(sp->visccoeff[f] == sp->visccoeff[f], "sphx_set_constants: NEWTONIAN rheology needs visccoeff for every fluid");
+	}
 	if (sp->turbmodel != SPHX_ARTIFICIAL && sp->turbmodel != SPHX_SPS && sp->turbmodel != SPHX_LAMINAR_FLOW)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: turbulence model not built");
 	if (sp->simflags & SPHX_ENABLE_XSPH)
@@ -211,6 +221,10 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	d.smagfactor = sp->smagfactor; d.kspsfactor = sp->kspsfactor;
 	d.dcoeff = sp->dcoeff; d.p1coeff = sp->p1coeff; d.p2coeff = sp->p2coeff; d.r0 = sp->r0;
 	d.repack_a = sp->repack_a; d.repack_alpha = sp->repack_alpha;
+	for (uint32_t f = 0; f < sp->numfluids; ++f)
+		d.visccoeff[f] = (sp->rheologytype == SPHX_INVISCID || sp->visccoeff[f] != sp->visccoeff[f]) ? 0.0f : sp->visccoeff[f];
+	d.compvisc = sp->compvisc; d.avgop = sp->avgop; d.is_const_visc = sp->is_const_visc;
+	d.partsurf = (sp->partsurf == 0.0f) ? sp->r0*sp->r0 : sp->partsurf;
 	ctx->have_params = true;
 	return SPHX_OK;
 }

@@ -69,6 +69,9 @@ struct DevParams {
 	float    artvisccoeff, epsartvisc, smagfactor, kspsfactor;
 	float    dcoeff, p1coeff, p2coeff, r0;   // Lennard-Jones boundary repulsion
 	float    repack_a, repack_alpha;         // repacking (d_repack_a, d_repack_alpha: src/cuda/phys_core.cu:93-94)
+	float    visccoeff[SPHX_MAX_FLUIDS];     // Newtonian: nu (KINEMATIC) or mu (DYNAMIC) per fluid; 0 when inviscid
+	int      compvisc, avgop, is_const_visc; // FullViscSpec (src/visc_spec.h:255-312)
+	float    partsurf;                       // d_partsurf: wall friction of planes
 	uint32_t numplanes;                       // geometric planes (src/planes.h:43-47, MAX_PLANES src/particledefine.h:325)
 	float    plane_normal[SPHX_MAX_PLANES][3];
 	int      plane_gridpos[SPHX_MAX_PLANES][3];

@@ -90,7 +90,8 @@ class TimestepEngine:
         self.d_t = torch.zeros(1, dtype=torch.float64, device=dev)
         self.iterations = 0
         self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(pp.sscoeff))) * 1.1))  # GPUWorker.cc:3010-3011
-        self.max_kinvisc = 0.0
+        # GPUWorker::uploadConstants (src/GPUWorker.cc:3003-3006): maximum kinematic viscosity for the viscous dt limit
+        self.max_kinvisc = float(np.float32(max(pp.kinematicvisc))) if sp.rheologytype == D.NEWTONIAN else 0.0
         self.compute_object_forces = 1 if sp.numforcesbodies > 0 else 0
         if self.num_bodies_parts:
             gp = np.ascontiguousarray(problem.rb_cg_gridpos, dtype=np.int32)
@@ -105,6 +106,11 @@ class TimestepEngine:
                                                    z3.ctypes.data, z3.ctypes.data, nb))
         self.sq_nl_radius = float(np.float32(sp.nlSqInfluenceRadius))
         self.last_neibs_info = None
+        # SPS: BUFFER_TAU (3 x float2) and BUFFER_SPS_TURBVISC, recomputed by CALC_VISC before every forces pass
+        self.sps = sp.turbmodel == D.SPS
+        if self.sps:
+            self.tau = [torch.zeros((A, 2), dtype=f32, device=dev) for _ in range(3)]
+            self.turbvisc = torch.zeros(A, dtype=f32, device=dev)
         self.filters = []            # [(FilterType, frequency)], Problem::addFilter order
         self.profile_forces = None   # list of (start,end) torch events around each forces launch when enabled
 
@@ -199,13 +205,20 @@ class TimestepEngine:
         nb = C.c_uint32(0)
         rb = self.num_bodies_parts > 0
         prof = self.profile_forces is not None
+        tau = [None, None, None]
+        if self.sps and run_mode == D.SIMULATE:
+            # CALC_VISC on the state the forces read (PredictorCorrectorIntegrator.cc:460-480)
+            capi.check(L.sphx_calc_visc(h, p(self.tau[0]), p(self.tau[1]), p(self.tau[2]), p(self.turbvisc), p(pos), p(vel),
+                                        p(self.info), p(self.hash), p(self.cellStart), p(self.neibslist), n, n,
+                                        self.params.deltap, self.params.slength, self.params.influenceradius, s))
+            tau = [p(t) for t in self.tau]
         self._memset(self.cfl, 0, s)          # pre_forces clobbers BUFFER_CFL (GPUWorker.cc:1970-1972)
         if prof:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
         capi.check(L.sphx_forces_basicstep(h, p(self.forces), p(self.cfl), p(self.rbforces) if rb else None,
                                            p(self.rbtorques) if rb else None, p(pos), p(vel), p(self.info), p(self.hash),
-                                           p(self.cellStart), p(self.neibslist), None, None, None,
+                                           p(self.cellStart), p(self.neibslist), tau[0], tau[1], tau[2],
                                            n, 0, n, self.params.deltap, self.params.slength, self.params.dtadaptfactor,
                                            self.params.influenceradius, 0, run_mode, step, self.dt,
                                            self.compute_object_forces, C.byref(nb), s))

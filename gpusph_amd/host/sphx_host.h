@@ -207,6 +207,7 @@ struct SimParams {
 	int kerneltype = SPHX_WENDLAND, sph_formulation = SPHX_SPH_F1, densitydiffusiontype = SPHX_DENSITY_DIFFUSION_NONE;
 	int boundarytype = SPHX_LJ_BOUNDARY, rheologytype = SPHX_INVISCID, turbmodel = SPHX_ARTIFICIAL;
 	int compvisc = 0, viscmodel = 0, avgop = 0, periodicbound = 0;
+	bool is_const_visc = false;   // FullViscSpec::is_const_visc of the framework (src/visc_spec.h:265-282, simparams.h:261-274)
 	flag_t simflags = SPHX_ENABLE_DTADAPT;
 	double sfactor = 1.3, slength = 0, kernelradius = 2.0, influenceRadius = 0, nlSqInfluenceRadius = 0;
 	float dtadaptfactor = 0.3f, densityDiffCoeff = 0, epsxsph = 0.5f, dt = 0;
@@ -221,6 +222,7 @@ struct PhysParams {
 	float artvisccoeff = 0.3f, epsartvisc = 0, smagfactor = 0, kspsfactor = 0;
 	float dcoeff = 0, p1coeff = 12, p2coeff = 6, r0 = 0;
 	float cosconeanglefluid = 0.86f, cosconeanglenonfluid = 0.5f;
+	float partsurf = 0;
 	size_t numFluids() const { return rho0.size(); }
 };
 struct TimingInfo {   // src/timing.h:43-100
@@ -384,6 +386,7 @@ public:
 		p.smagfactor = pp->smagfactor; p.kspsfactor = pp->kspsfactor;
 		p.dcoeff = pp->dcoeff; p.p1coeff = pp->p1coeff; p.p2coeff = pp->p2coeff; p.r0 = pp->r0;
 		p.repack_a = sp->repack_a; p.repack_alpha = sp->repack_alpha;
+		p.is_const_visc = sp->is_const_visc ? 1 : 0; p.partsurf = pp->partsurf;
 		sphx_throw(sphx_set_constants(ctx(), &p));
 		sphx_throw(sphx_reserve(ctx(), (uint32_t)allocatedParticles));
 	}

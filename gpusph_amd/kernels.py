@@ -32,6 +32,7 @@ class HipKernels:
         self.sq_nl_radius = float(np.float32(sp.nlSqInfluenceRadius))
         pp = problem.physparams
         self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(pp.sscoeff))) * 1.1))  # GPUWorker.cc:3010-3011
+        self.max_kinvisc = float(np.float32(max(pp.kinematicvisc))) if sp.rheologytype == D.NEWTONIAN else 0.0   # :3003-3006
         if getattr(problem, "num_obstacle", 0):
             gp = np.ascontiguousarray(problem.rb_cg_gridpos, dtype=np.int32)
             lp = np.ascontiguousarray(problem.rb_cg_pos, dtype=np.float32)
@@ -106,7 +107,7 @@ class HipKernels:
     def dtreduce(self, cfl, cfl_temp, nblocks, d_dt, combine_min):
         p = capi.ptr
         P = self.params
-        capi.check(self.lib.sphx_forces_dtreduce_device(self.ctx.handle, P.slength, P.dtadaptfactor, self.sspeed_cfl, 0.0,
+        capi.check(self.lib.sphx_forces_dtreduce_device(self.ctx.handle, P.slength, P.dtadaptfactor, self.sspeed_cfl, self.max_kinvisc,
                                                         p(cfl), p(cfl_temp), nblocks, p(d_dt), combine_min, self._s()))
 
     # ---- AbstractIntegrationEngine

@@ -28,6 +28,7 @@ class SphxParams(C.Structure):
         ("smagfactor", C.c_float), ("kspsfactor", C.c_float),
         ("dcoeff", C.c_float), ("p1coeff", C.c_float), ("p2coeff", C.c_float), ("r0", C.c_float),
         ("repack_a", C.c_float), ("repack_alpha", C.c_float),
+        ("is_const_visc", C.c_int32), ("partsurf", C.c_float),
     ]
 
 
@@ -40,9 +41,14 @@ class PhysParams:
     sscoeff: list = field(default_factory=list)
     sspowercoeff: list = field(default_factory=list)
     visccoeff: list = field(default_factory=list)
+    kinematicvisc: list = field(default_factory=list)      # nu per fluid (physparams.h:175)
+    visc_consistency: list = field(default_factory=list)   # mu per fluid for Newtonian fluids
+    partsurf: float = 0.0                                  # physparams.h:328,403 (0 -> r0^2 on upload)
     gravity: tuple = (0.0, 0.0, -9.81)
     artvisccoeff: float = 0.3          # physparams.h:392
     epsartvisc: float = float("nan")   # defaulted to 0.01 h^2 in ProblemCore.cc:160-163
+    smagorinsky_constant: float = 0.12  # physparams.h:411-412
+    isotropic_sps_constant: float = 0.0066
     smagfactor: float = float("nan")
     kspsfactor: float = float("nan")
     dcoeff: float = 0.0
@@ -57,9 +63,32 @@ class PhysParams:
 
     def add_fluid(self, rho):
         self.rho0.append(float(np.float32(rho)))
-        for lst in (self.bcoeff, self.gammacoeff, self.sscoeff, self.sspowercoeff, self.visccoeff):
+        for lst in (self.bcoeff, self.gammacoeff, self.sscoeff, self.sspowercoeff, self.visccoeff,
+                    self.kinematicvisc, self.visc_consistency):
             lst.append(float("nan"))
         return len(self.rho0) - 1
+
+    def set_kinematic_visc(self, fluid_idx, nu):
+        """physparams.h:609-616"""
+        nu = np.float32(nu)
+        self.kinematicvisc[fluid_idx] = float(nu)
+        self.visc_consistency[fluid_idx] = float(nu * np.float32(self.rho0[fluid_idx]))
+
+    def set_dynamic_visc(self, fluid_idx, mu):
+        """physparams.h:622-629"""
+        mu = np.float32(mu)
+        self.kinematicvisc[fluid_idx] = float(mu / np.float32(self.rho0[fluid_idx]))
+        self.visc_consistency[fluid_idx] = float(mu)
+
+    def update_visccoeff(self, sp):
+        """GPUSPH::setViscosityCoefficient (src/GPUSPH.cc:1480-1508): what d_visccoeff holds"""
+        for f in range(self.numFluids()):
+            if sp.rheologytype == D.INVISCID:
+                self.visccoeff[f] = float("nan")
+            elif sp.compvisc == D.KINEMATIC:
+                self.visccoeff[f] = self.kinematicvisc[f]
+            else:
+                self.visccoeff[f] = self.visc_consistency[f]
 
     def set_equation_of_state(self, fluid_idx, gamma, c0):
         if fluid_idx >= self.numFluids():
@@ -105,6 +134,7 @@ class SimParams:
     repack_maxiter: int = 2000         # simparams.h:308-310
     repack_a: float = 0.1
     repack_alpha: float = 0.01
+    is_const_visc: object = None       # None: FullViscSpec default (single fluid, NEWTONIAN, not k-epsilon; visc_spec.h:268-272)
 
     def set_smoothing(self, smooth, deltap):
         """simparams.h:325-336 (double arithmetic)."""
@@ -140,6 +170,7 @@ def check_neiblistsize(sp: SimParams, pp: PhysParams, deltap: float):
 def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origin, deltap,
                      allocated, linearization=D.DEFAULT_LINEARIZATION) -> SphxParams:
     """What the three setconstants() calls upload (src/cuda/forces.cu:268-399 etc.)."""
+    pp.update_visccoeff(sp)
     p = SphxParams()
     f32 = lambda v: float(np.float32(v))
     for a in range(3):
@@ -180,4 +211,9 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
     p.smagfactor = nz(pp.smagfactor); p.kspsfactor = nz(pp.kspsfactor)
     p.dcoeff = nz(pp.dcoeff); p.p1coeff = nz(pp.p1coeff); p.p2coeff = nz(pp.p2coeff); p.r0 = nz(pp.r0)
     p.repack_a = f32(sp.repack_a); p.repack_alpha = f32(sp.repack_alpha)
+    const = sp.is_const_visc
+    if const is None:
+        const = pp.numFluids() == 1 and sp.rheologytype == D.NEWTONIAN
+    p.is_const_visc = 1 if const else 0
+    p.partsurf = f32(pp.partsurf)
     return p

@@ -117,6 +117,9 @@ class Problem:
         g = math.sqrt(sum(x * x for x in pp.gravity))
         dt_g = f32(math.sqrt(sp.slength / g)) * f32(sp.dtadaptfactor) if g > 0 else np.inf
         cfl_dt = float(min(dt_ss, dt_g))
+        if sp.rheologytype != D.INVISCID:      # get_dt_from_visc<NEWTONIAN>, ProblemCore.cc:728-745,767-786
+            nu = max(pp.kinematicvisc)
+            cfl_dt = float(min(f32(cfl_dt), f32(sp.slength) * f32(sp.slength) / f32(nu) * f32(0.125)))
         if not sp.dt:
             sp.dt = cfl_dt
         return sp.dt
@@ -169,12 +172,36 @@ class Problem:
             if math.isnan(sp.densityDiffCoeff):
                 sp.densityDiffCoeff = float(np.float32(0.1))
             sp.densityDiffCoeff = float(np.float32(np.float32(sp.densityDiffCoeff) * np.float32(2.0) * np.float32(sp.slength)))
+        if sp.turbmodel == D.SPS:        # GPUSPH.cc:1540-1556: (Cs dp)^2 and (2/3) Ci dp^2, in double
+            dp = self.m_deltap
+            if math.isnan(pp.smagfactor):
+                x = float(np.float32(np.float64(np.float32(pp.smagorinsky_constant)) * dp))
+                pp.smagfactor = float(np.float32(x) * np.float32(x))
+            if math.isnan(pp.kspsfactor):
+                pp.kspsfactor = float(np.float32((2 * np.float64(np.float32(pp.isotropic_sps_constant)) / 3) * dp * dp))
         self.check_dt()
 
     def sphx_params(self, allocated):
         return make_sphx_params(self.simparams, self.physparams, gridsize=self.m_gridsize,
                                 cellsize=self.m_cellsize, origin=self.m_origin, deltap=self.m_deltap,
                                 allocated=allocated, linearization=self.linearization)
+
+    def set_viscosity(self, spec):
+        """viscosity<...> selector of the framework (src/visc_spec.h:314-391): a legacy name ("ARTVISC",
+        "KINEMATICVISC", "DYNAMICVISC", "SPSVISC") or a dict(rheologytype, turbmodel, compvisc, viscmodel, avgop,
+        is_const_visc) of FullViscSpec parameters; None = ARTVISC."""
+        sp = self.simparams
+        legacy = {
+            None: dict(rheologytype=D.INVISCID, turbmodel=D.ARTIFICIAL),
+            "ARTVISC": dict(rheologytype=D.INVISCID, turbmodel=D.ARTIFICIAL),
+            "KINEMATICVISC": dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, avgop=D.HARMONIC, is_const_visc=True),
+            "DYNAMICVISC": dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW),
+            "SPSVISC": dict(rheologytype=D.NEWTONIAN, turbmodel=D.SPS, avgop=D.HARMONIC, is_const_visc=True),
+        }
+        opts = dict(compvisc=D.KINEMATIC, viscmodel=D.MORRIS, avgop=D.ARITHMETIC, is_const_visc=None)
+        opts.update(legacy[spec] if (spec is None or isinstance(spec, str)) else spec)
+        for k, v in opts.items():
+            setattr(sp, k, v)
 
     def initial_density(self, pos_global):
         """rho~ the problem starts from at the given global positions; also used to reset the state at the end of a
@@ -209,7 +236,7 @@ class DamBreak3D(Problem):
 
     def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
                  jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY,
-                 walls="particles", testpoints=(), two_fluids=False):
+                 walls="particles", testpoints=(), two_fluids=False, viscosity=None, kinematic_visc=1.0e-2):
         super().__init__()
         self.m_name = "DamBreak3D"
         sp, pp = self.simparams, self.physparams
@@ -226,8 +253,7 @@ class DamBreak3D(Problem):
             # one layer of repulsive particles on the box faces instead of three dynamic layers
             # (DamBreak3D.cu:74,131-134: layers only for DYN_BOUNDARY)
             self.LAYERS = 1
-        sp.rheologytype = D.INVISCID
-        sp.turbmodel = D.ARTIFICIAL
+        self.set_viscosity(viscosity)       # DamBreak3D.cu:54 viscosity<ARTVISC>
         sp.densitydiffusiontype = density_diffusion
         sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | (D.ENABLE_MOVING_BODIES if obstacle else 0) | \
             (D.ENABLE_PLANES if walls == "planes" else 0)
@@ -244,10 +270,12 @@ class DamBreak3D(Problem):
             pp.dcoeff = 5.0 * 9.81
         pp.add_fluid(1000.0)
         pp.set_equation_of_state(0, 7.0, 20.0)
+        pp.set_kinematic_visc(0, kinematic_visc)            # DamBreak3D.cu:89
         self.two_fluids = bool(two_fluids)
         if two_fluids:      # a lighter fluid on top of the water column (multi-fluid branch of the forces engine)
             pp.add_fluid(850.0)
             pp.set_equation_of_state(1, 7.0, 22.0)
+            pp.set_kinematic_visc(1, 3.0 * kinematic_visc)
         self.m_origin = np.zeros(3)
         self.m_size = np.array(self.DIM, dtype=np.float64)
         self.obstacle = obstacle
@@ -392,14 +420,13 @@ class PeriodicBox(Problem):
 
     def __init__(self, deltap=0.05, n=(12, 10, 9), periodic=D.PERIODIC_X | D.PERIODIC_Y | D.PERIODIC_Z, jitter=0.1, velocity=(0.0, 0.0, 0.0),
                  gravity=(0.0, 0.0, 0.0), linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND,
-                 density_diffusion=D.COLAGROSSI, repacking=False):
+                 density_diffusion=D.COLAGROSSI, repacking=False, viscosity=None, kinematic_visc=1.0e-2):
         super().__init__()
         self.m_name = "PeriodicBox"
         sp, pp = self.simparams, self.physparams
         sp.kerneltype = kerneltype
         sp.boundarytype = D.DYN_BOUNDARY
-        sp.rheologytype = D.INVISCID
-        sp.turbmodel = D.ARTIFICIAL
+        self.set_viscosity(viscosity)
         sp.densitydiffusiontype = density_diffusion
         sp.periodicbound = periodic
         sp.simflags = D.ENABLE_DTADAPT | (D.ENABLE_REPACKING if repacking else 0)
@@ -410,6 +437,7 @@ class PeriodicBox(Problem):
         pp.gravity = tuple(float(g) for g in gravity)
         pp.add_fluid(1000.0)
         pp.set_equation_of_state(0, 7.0, 20.0)
+        pp.set_kinematic_visc(0, kinematic_visc)
         self.m_origin = np.zeros(3)
         self.m_size = np.array(n, dtype=np.float64) * self.m_deltap
         self.initialize()

@@ -56,6 +56,9 @@ enum sphx_densitydiff { SPHX_DENSITY_DIFFUSION_NONE = 0, SPHX_FERRARI = 1, SPHX_
 enum sphx_boundary    { SPHX_LJ_BOUNDARY = 0, SPHX_MK_BOUNDARY = 1, SPHX_SA_BOUNDARY = 2, SPHX_DYN_BOUNDARY = 3 };
 enum sphx_rheology    { SPHX_INVISCID = 0, SPHX_NEWTONIAN = 1 };
 enum sphx_turbulence  { SPHX_LAMINAR_FLOW = 0, SPHX_ARTIFICIAL = 1, SPHX_SPS = 2, SPHX_KEPSILON = 3 };
+enum sphx_compvisc    { SPHX_KINEMATIC = 0, SPHX_DYNAMIC = 1 };                          /* src/visc_spec.h */
+enum sphx_viscmodel   { SPHX_MORRIS = 0, SPHX_MONAGHAN = 1, SPHX_ESPANOL_REVENGA = 2 };
+enum sphx_avgop       { SPHX_ARITHMETIC = 0, SPHX_HARMONIC = 1, SPHX_GEOMETRIC = 2 };      /* src/average.h */
 enum sphx_runmode     { SPHX_REPACK = 0, SPHX_SIMULATE = 1 };
 enum sphx_filter      { SPHX_SHEPARD_FILTER = 0, SPHX_MLS_FILTER = 1 };   /* FilterType, src/particledefine.h:255-260 */
 enum sphx_postproc    { SPHX_VORTICITY = 0, SPHX_TESTPOINTS = 1, SPHX_SURFACE_DETECTION = 2 };   /* PostProcessType, :290-299 */
@@ -101,6 +104,11 @@ typedef struct sphx_params {
 	float    dcoeff, p1coeff, p2coeff, r0;
 	/* repacking (src/simparams.h:220-234): mixing intensity a, velocity damping alpha */
 	float    repack_a, repack_alpha;
+	/* Newtonian rheology: visccoeff[] holds nu (compvisc KINEMATIC) or mu (DYNAMIC) per fluid (GPUSPH.cc:1486-1502);
+	 * is_const_visc = FullViscSpec::is_const_visc (src/visc_spec.h:265-282, forced true by KINEMATICVISC/SPSVISC);
+	 * partsurf = particle surface for the wall friction of planes, 0 -> r0^2 (src/cuda/forces.cu:364-368) */
+	int32_t  is_const_visc;
+	float    partsurf;
 } sphx_params;
 
 /* TimingInfo fields filled by getinfo (src/timing.h:43-100, src/cuda/buildneibs.cu:137-145) */

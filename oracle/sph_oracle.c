@@ -650,6 +650,35 @@ static inline float dot3(float ax, float ay, float az, float bx, float by, float
 }
 
 /* one forcesDevice<cptype,nptype> launch over [from,to): forces_kernel.def:3914-4029 */
+/* visc_avg (src/cuda/visc_avg.cu:40-190): the per-pair factor of the laminar (Morris) viscous term, neighbour mass
+ * included.  visc/neib_visc = get_visc_coeff = d_visccoeff of each particle's fluid (Newtonian, no k-epsilon:
+ * forces_kernel.def:247-270). */
+static inline float visc_avg_rho(int avgop, float rho, float neib_rho, float neib_mass)
+{
+	switch (avgop) {
+	case ORC_ARITHMETIC: return neib_mass*(rho + neib_rho)/(rho*neib_rho);
+	case ORC_HARMONIC:   return 4*neib_mass/(rho + neib_rho);
+	default:             return 2*neib_mass*(1.0f/sqrtf(rho*neib_rho));   /* rsqrt */
+	}
+}
+static inline float visc_avg_dyn(int avgop, int is_const, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
+{
+	if (is_const) return 2*neib_mass*visc/(rho*neib_rho);
+	switch (avgop) {
+	case ORC_ARITHMETIC: return neib_mass*(visc + neib_visc)/(rho*neib_rho);
+	case ORC_HARMONIC:   return 4*neib_mass*(visc*neib_visc)/(visc + neib_visc)/(rho*neib_rho);
+	default:             return 2*neib_mass*sqrtf(visc*neib_visc)/(rho*neib_rho);
+	}
+}
+static inline float visc_avg(const orc_params *p, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
+{
+	if (p->compvisc == ORC_DYNAMIC)
+		return visc_avg_dyn(p->avgop, p->is_const_visc, visc, neib_visc, rho, neib_rho, neib_mass);
+	if (p->is_const_visc)
+		return visc*visc_avg_rho(p->avgop, rho, neib_rho, neib_mass);
+	return visc_avg_dyn(p->avgop, 0, visc*rho, neib_visc*neib_rho, rho, neib_rho, neib_mass);
+}
+
 static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *forces,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
 	const uint32_t *cellStart, const uint16_t *neibsList, const float *tauArray,
@@ -765,6 +794,13 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 					DvDt[2] += nmass*f*(
 						(p_tau[2] + n_tau[2])*rx + (p_tau[4] + n_tau[4])*ry + (p_tau[5] + n_tau[5])*rz);
 				}
+				/* compute_laminar_visc_contrib, Newtonian + MORRIS (:2606-2625): fluid neighbours, and boundary neighbours
+				 * of DYN_BOUNDARY (wants_volumic_visc_term :150-158; LJ pairs never get here) */
+				if (p->rheologytype == ORC_NEWTONIAN) {
+					const float visc = visc_avg(p, p->visccoeff[p_fluid], p->visccoeff[n_fluid], p_rho, n_rho, nmass);
+					const float vf = visc*f;
+					DvDt[0] += vf*vx; DvDt[1] += vf*vy; DvDt[2] += vf*vz;
+				}
 				if (all_pp || COMPUTE_FORCE(info)) {
 					force.x += DvDt[0]; force.y += DvDt[1]; force.z += DvDt[2];
 				}
@@ -789,6 +825,19 @@ uint32_t orc_fmax_temp_elements(uint32_t nels)
 	return numBlocks;
 }
 uint32_t orc_round_particles(uint32_t n) { return (n/BLOCK_SIZE_FORCES)*BLOCK_SIZE_FORCES; }
+
+/* viscous part of PlaneForce (src/cuda/forces_kernel.cu:153-185): v_t = vel - dot(vel, relPos)/r*relPos/r,
+ * force += -dynvisc*partsurf/(mass*r) * v_t ; float3/float multiplies by the reciprocal (src/vector_math.h:526-530) */
+static inline void plane_friction(const orc_params *p, orc_f4 *force, const orc_f4 *vel, const float rp[3], float r,
+	float mass, float dynvisc)
+{
+	const float partsurf = (p->partsurf == 0.0f) ? p->r0*p->r0 : p->partsurf;
+	const float d = (vel->x*rp[0] + vel->y*rp[1] + vel->z*rp[2])/r;
+	const float inv = 1.0f/r;
+	const float vt[3] = { vel->x - (d*rp[0])*inv, vel->y - (d*rp[1])*inv, vel->z - (d*rp[2])*inv };
+	const float coeff = -dynvisc*partsurf/(mass*r);
+	force->x += coeff*vt[0]; force->y += coeff*vt[1]; force->z += coeff*vt[2];
+}
 
 /* finalizeforcesDevice: forces_kernel.def:4032-4150 */
 static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
@@ -817,7 +866,10 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 				force.x += p->gravity[0]; force.y += p->gravity[1]; force.z += p->gravity[2];
 				/* GeometryForce/PlaneForce (src/cuda/forces_kernel.cu:140-203), PlaneDistance + globalDistance
 				 * (src/cuda/geom_core.cu:63-85, cellgrid.cuh:153-161).  Inviscid: the wall-friction coefficient is
-				 * -0 (viscous_plane_coefficient :3103-3107), only the Lennard-Jones repulsion along the normal acts. */
+				 * -0 (viscous_plane_coefficient :3103-3107), only the Lennard-Jones repulsion along the normal acts;
+				 * Newtonian: get_laminar_dyn_visc (:322-340) = nu rho or mu. */
+				const float dynvisc = (p->rheologytype == ORC_NEWTONIAN) ?
+					(p->compvisc == ORC_KINEMATIC ? p->visccoeff[fl]*physical_density(p, vel.w, fl) : p->visccoeff[fl]) : 0.0f;
 				if ((p->simflags & ORC_ENABLE_PLANES) && p->numplanes) {
 					int gp[3];
 					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
@@ -831,7 +883,10 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 							float DvDt = 0.0f;   /* LJForce(r) */
 							if (r <= p->r0)
 								DvDt = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
-							force.x += DvDt*(nrm[0]*r); force.y += DvDt*(nrm[1]*r); force.z += DvDt*(nrm[2]*r);
+							const float rp[3] = { nrm[0]*r, nrm[1]*r, nrm[2]*r };
+							force.x += DvDt*rp[0]; force.y += DvDt*rp[1]; force.z += DvDt*rp[2];
+							if (dynvisc != 0.0f)
+								plane_friction(p, &force, &vel, rp, r, pos.w, dynvisc);
 						}
 					}
 				}
@@ -952,8 +1007,9 @@ uint32_t orc_repack_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 			if (FLUID(info)) {
 				const float damp = p->repack_alpha*p->sscoeff[fl]/p->deltap;
 				force.x += damp*vel.x; force.y += damp*vel.y; force.z += damp*vel.z;
-				/* planes: Lennard-Jones part of PlaneForce; the friction term -mu partsurf/(m r) v_t is taken with
-				 * mu = 0 (visccoeff of the inviscid problems built here) */
+				/* planes: dynvisc = d_visccoeff*rho whatever the computational viscosity (:4314); the reference leaves
+				 * d_visccoeff NaN for inviscid problems (GPUSPH.cc:1488-1493) -- taken as 0 (free slip) here */
+				const float dynvisc = (p->rheologytype == ORC_NEWTONIAN) ? p->visccoeff[fl]*physical_density(p, vel.w, fl) : 0.0f;
 				if ((p->simflags & ORC_ENABLE_PLANES) && p->numplanes) {
 					int gp[3];
 					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
@@ -965,7 +1021,10 @@ uint32_t orc_repack_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 						const float r = fabsf(dx*nrm[0] + dy*nrm[1] + dz*nrm[2]);
 						if (r < p->r0) {
 							const float DvDt = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
-							force.x += DvDt*(nrm[0]*r); force.y += DvDt*(nrm[1]*r); force.z += DvDt*(nrm[2]*r);
+							const float rp[3] = { nrm[0]*r, nrm[1]*r, nrm[2]*r };
+							force.x += DvDt*rp[0]; force.y += DvDt*rp[1]; force.z += DvDt*rp[2];
+							if (dynvisc != 0.0f)
+								plane_friction(p, &force, &vel, rp, r, pos.w, dynvisc);
 						}
 					}
 				}

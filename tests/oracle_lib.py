@@ -27,6 +27,7 @@ class OrcParams(C.Structure):
         ("smagfactor", C.c_float), ("kspsfactor", C.c_float),
         ("dcoeff", C.c_float), ("p1coeff", C.c_float), ("p2coeff", C.c_float), ("r0", C.c_float),
         ("repack_a", C.c_float), ("repack_alpha", C.c_float),
+        ("is_const_visc", C.c_int32), ("partsurf", C.c_float),
         ("numplanes", C.c_uint32),
         ("plane_normal", (C.c_float * 3) * 8), ("plane_gridpos", (C.c_int32 * 3) * 8), ("plane_pos", (C.c_float * 3) * 8),
         ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),
@@ -273,6 +274,8 @@ class OracleSim:
         self.ncells = problem.grid_cells
         sscoeff = max(problem.physparams.sscoeff)
         self.sspeed_cfl = float(np.float32(np.float64(np.float32(sscoeff)) * 1.1))  # GPUWorker.cc:3010-3011
+        pp, sp = problem.physparams, problem.simparams
+        self.max_kinvisc = float(np.float32(max(pp.kinematicvisc))) if sp.rheologytype == D.NEWTONIAN else 0.0   # :3003-3006
         self.neibs_info = None
 
     def build_neibs(self):
@@ -300,7 +303,7 @@ class OracleSim:
         dt = float(np.float32(self.dt))
         rb = getattr(self.problem, "num_obstacle", 0)
         f, cfl, nb, self.rbf, self.rbt = o.repack_forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n, rb_count=rb)
-        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl)
+        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
         self.pos, self.vel = o.euler_repack(self.pos, self.vel, self.info, self.hash, f, n, dt, 1)
         self.forces = f
         self.t += dt
@@ -337,15 +340,18 @@ class OracleSim:
         cof = 1 if sp.numforcesbodies > 0 else 0
         rb = getattr(self.problem, "num_obstacle", 0)
         dt = float(np.float32(self.dt))
-        # predictor
+        sps = sp.turbmodel == self.D.SPS
+        # predictor (CALC_VISC before the forces when SPS, PredictorCorrectorIntegrator.cc:460-480)
+        tau = o.sps(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n, n)[0] if sps else None
         f1, cfl, nb, self.rbf, self.rbt = o.forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n,
-                                                   compute_object_forces=cof, rb_count=rb)
-        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl)
+                                                   compute_object_forces=cof, rb_count=rb, tau=tau)
+        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
         ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1)
         # corrector
+        tau = o.sps(ps, vs, self.info, self.hash, self.cs, self.nl, n, n)[0] if sps else None
         f2, cfl, nb, self.rbf, self.rbt = o.forces(ps, vs, self.info, self.hash, self.cs, self.nl, n,
-                                                   compute_object_forces=cof, rb_count=rb)
-        dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl)
+                                                   compute_object_forces=cof, rb_count=rb, tau=tau)
+        dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
         self.pos, self.vel = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
         self.forces = f2
         self.t += dt

@@ -222,7 +222,8 @@ def test_against_committed_golden_fixture():
     assert np.abs(out["vel"][sel][:, :3] - g["s11_vel"][:n][sel][:, :3]).max() <= 1e-3 * max(np.abs(g["s11_vel"][:, :3]).max(), 1e-3)
 
 
-LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.LJ_BOUNDARY),
+LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, viscosity="KINEMATICVISC", kinematic_visc=0.05),
+            dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.LJ_BOUNDARY),
             dict(deltap=0.04, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes")]
 
 
@@ -374,10 +375,13 @@ def test_cpp_adapters_match_python_engine(tmp_path):
 # ---------------------------------------------------------------------------------------------
 # SPS turbulence: sphx_calc_visc (SPSstressMatrix, src/cuda/visc_kernel.cu:759-811) and the SPS term of the
 # forces kernel (generic gather path) against the oracle.  fp32 tolerance 2e-5 of the largest entry.
-def test_sps_stress_and_forces_tolerance():
+@pytest.mark.parametrize("visc", [None, "SPSVISC"])
+def test_sps_stress_and_forces_tolerance(visc):
+    """SPS stress tensor + its divergence in the forces; "SPSVISC" = the framework's legacy selector (KINEMATICVISC + SPS:
+    Newtonian laminar term with harmonic density averaging on top), None = the SPS term alone"""
     import torch
     from gpusph_amd import capi
-    prob = DamBreak3D(deltap=0.04, obstacle=False, jitter=0.1, hydrostatic=False)
+    prob = DamBreak3D(deltap=0.04, obstacle=False, jitter=0.1, hydrostatic=False, viscosity=visc, kinematic_visc=0.02)
     prob.simparams.turbmodel = D.SPS
     dp = prob.m_deltap
     prob.physparams.smagfactor = float(np.float32((0.12 * dp) ** 2))              # src/GPUSPH.cc Smagorinsky set-up

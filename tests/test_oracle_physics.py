@@ -569,3 +569,147 @@ def test_repack_euler_and_lid_removal():
     sim.o.disable_free_surf_parts(pos, info, n)
     dead = ~np.isfinite(pos[:n, 3])
     assert set(np.where(dead)[0]) == set(bd)
+
+
+# ---------------------------------------------------------------------------------------------- Newtonian viscosity
+VISC_FLAVOURS = [
+    dict(compvisc=D.KINEMATIC, avgop=D.ARITHMETIC, is_const_visc=True),     # DYNAMICVISC of a single fluid
+    dict(compvisc=D.KINEMATIC, avgop=D.HARMONIC, is_const_visc=True),       # KINEMATICVISC
+    dict(compvisc=D.KINEMATIC, avgop=D.GEOMETRIC, is_const_visc=True),
+    dict(compvisc=D.DYNAMIC, avgop=D.ARITHMETIC, is_const_visc=True),
+    dict(compvisc=D.KINEMATIC, avgop=D.ARITHMETIC, is_const_visc=False),
+    dict(compvisc=D.KINEMATIC, avgop=D.HARMONIC, is_const_visc=False),
+    dict(compvisc=D.DYNAMIC, avgop=D.GEOMETRIC, is_const_visc=False),
+    dict(compvisc=D.DYNAMIC, avgop=D.HARMONIC, is_const_visc=False),
+]
+
+
+def _visc_pair_factor(fl, compvisc, avgop, is_const_visc, nu, mu, rho_i, rho_j, fi, fj):
+    """visc_avg without the neighbour mass (src/cuda/visc_avg.cu), float64"""
+    if is_const_visc:
+        if compvisc == D.DYNAMIC:
+            return 2 * mu[fi] / (rho_i * rho_j)
+        return nu[fi] * {D.ARITHMETIC: (rho_i + rho_j) / (rho_i * rho_j), D.HARMONIC: 4 / (rho_i + rho_j),
+                         D.GEOMETRIC: 2 / np.sqrt(rho_i * rho_j)}[avgop]
+    mi = nu[fi] * rho_i if compvisc == D.KINEMATIC else mu[fi]
+    mj = nu[fj] * rho_j if compvisc == D.KINEMATIC else mu[fj]
+    avg = {D.ARITHMETIC: (mi + mj), D.HARMONIC: 4 * mi * mj / (mi + mj), D.GEOMETRIC: 2 * np.sqrt(mi * mj)}[avgop]
+    return avg / (rho_i * rho_j)
+
+
+@pytest.mark.parametrize("flavour", VISC_FLAVOURS)
+def test_laminar_viscous_term_equals_brute_force(flavour):
+    """NEWTONIAN + LAMINAR_FLOW + MORRIS: a_i += sum_j visc_avg(i,j) F(r_ij) (v_i - v_j) over fluid neighbours and
+    DYN boundary neighbours (compute_laminar_visc_contrib).  Every flavour is homogeneous of degree one in the
+    viscosities, so the term is isolated as 2 (F(nu) - F(nu/2))."""
+    spec = dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, **flavour)
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.25, hydrostatic=True, viscosity=spec, two_fluids=True,
+                      density_diffusion=D.DENSITY_DIFFUSION_NONE)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(8)
+    sim.vel[:n, :3] = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    p = sim.o.p
+    assert p.rheologytype == D.NEWTONIAN and p.compvisc == flavour["compvisc"] and p.is_const_visc == int(flavour["is_const_visc"])
+    f_full = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    keep = [float(p.visccoeff[0]), float(p.visccoeff[1])]
+    p.visccoeff[0], p.visccoeff[1] = 0.5 * keep[0], 0.5 * keep[1]
+    f_half = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    p.visccoeff[0], p.visccoeff[1] = keep
+    lam = 2.0 * (f_full[:n, :3].astype(np.float64) - f_half[:n, :3])
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    ptype = sim.info[:n, 0] & 7
+    fluidnum = (sim.info[:n, 1] >> 12).astype(int)
+    assert set(fluidnum[ptype == 0]) == {0, 1}
+    pp = prob.physparams
+    nu = [pp.kinematicvisc[0], pp.kinematicvisc[1]]
+    mu = [pp.visc_consistency[0], pp.visc_consistency[1]]
+    assert keep == pytest.approx(nu if flavour["compvisc"] == D.KINEMATIC else mu)
+    h = float(p.slength)
+    fcoeff = 105.0 / (128.0 * np.pi * h ** 5)
+    m = sim.pos[:n, 3].astype(np.float64)
+    rho = (sim.vel[:n, 3].astype(np.float64) + 1.0) * np.array([float(p.rho0[f]) for f in fluidnum])
+    v = sim.vel[:n, :3].astype(np.float64)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(gp)
+    fl = np.where(ptype == 0)[0]
+    ref = np.zeros((n, 3))
+    for i, nbs in zip(fl, tree.query_ball_point(gp[fl], 2 * h * (1 - 1e-7))):
+        for j in nbs:
+            if j == i:
+                continue
+            r = np.linalg.norm(gp[i] - gp[j])
+            F = (r / h - 2.0) ** 3 * fcoeff
+            fac = _visc_pair_factor(None, flavour["compvisc"], flavour["avgop"], flavour["is_const_visc"], nu, mu,
+                                    rho[i], rho[j], fluidnum[i], fluidnum[j])
+            ref[i] += m[j] * fac * F * (v[i] - v[j])
+    scale = np.abs(ref).max()
+    assert scale > 0.05
+    # the term is a small difference of two float32 force fields dominated by the pressure gradient
+    assert np.abs(lam[fl] - ref[fl]).max() <= 4e-5 * np.abs(f_full[:n, :3]).max() + 1e-4 * scale
+
+
+def test_viscous_decay_of_a_shear_wave():
+    """u_x = U sin(k y) in a periodic box decays like exp(-nu k^2 t) (no artificial viscosity: NEWTONIAN + LAMINAR_FLOW)."""
+    from gpusph_amd.problem import PeriodicBox
+    nu = 0.05
+    prob = PeriodicBox(deltap=0.05, n=(8, 16, 8), jitter=0.0, viscosity="KINEMATICVISC", kinematic_visc=nu,
+                       density_diffusion=D.DENSITY_DIFFUSION_NONE)
+    sim = ol.OracleSim(prob)
+    L = prob.m_size[1]
+    k = 2 * np.pi / L
+    U = 0.5
+    gp = prob.parts.pos_global
+    sim.vel[:, 0] = (U * np.sin(k * gp[:, 1])).astype(np.float32)
+
+    def amplitude():
+        m = sim.n
+        g = prob.global_pos(sim.pos[:m], sim.hash[:m])
+        s = np.sin(k * g[:, 1])
+        return 2.0 * np.mean(sim.vel[:m, 0] * s)
+
+    a0 = amplitude()
+    assert a0 == pytest.approx(U, rel=1e-3)
+    assert sim.dt == pytest.approx(min(0.3 * 0.065 / 20.0, 0.125 * 0.065 ** 2 / nu), rel=1e-3)   # check_dt incl. the viscous limit
+    for _ in range(60):
+        sim.step()
+    rate = -np.log(amplitude() / a0) / sim.t
+    assert rate == pytest.approx(nu * k * k, rel=0.12)       # SPH second-derivative operator at h/dp = 1.3: a few %
+    assert sim.dt <= 0.125 * 0.065 ** 2 / nu * 1.0001       # dtreduce applies the viscous limit with max_kinvisc
+
+
+def test_plane_friction_equals_brute_force():
+    """Newtonian fluid against geometric planes: PlaneForce adds -mu partsurf/(m r) v_t within r0 of a plane; the term is
+    linear in partsurf, so F(partsurf = A) - F(partsurf = B) isolates it."""
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes",
+                      viscosity="KINEMATICVISC", kinematic_visc=0.02)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(12)
+    sim.vel[:n, :3] = rng.uniform(-0.5, 0.5, size=(n, 3)).astype(np.float32)
+    p = sim.o.p
+    r0 = float(p.r0)
+    fA = fB = None
+    p.partsurf = 3.0 * r0 * r0
+    fA = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    p.partsurf = 0.0            # -> r0^2
+    fB = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    diff = fA[:n, :3].astype(np.float64) - fB[:n, :3]
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    ptype = sim.info[:n, 0] & 7
+    m = sim.pos[:n, 3].astype(np.float64)
+    rho = (sim.vel[:n, 3].astype(np.float64) + 1.0) * float(p.rho0[0])
+    v = sim.vel[:n, :3].astype(np.float64)
+    ref = np.zeros((n, 3))
+    for nrm, pt in prob.planes:
+        nrm = np.asarray(nrm, dtype=np.float64)
+        dist = np.abs((gp - np.asarray(pt, dtype=np.float64)) @ nrm)
+        near = (dist < r0) & (ptype == 0)
+        vt = v[near] - (v[near] @ nrm)[:, None] * nrm
+        mu = 0.02 * rho[near]
+        ref[near] += (-(mu * (2.0 * r0 * r0) / (m[near] * dist[near])))[:, None] * vt
+    assert (np.abs(ref).max(axis=1) > 0).sum() > 30
+    scale = np.abs(ref).max()
+    assert np.abs(diff - ref).max() <= 1e-4 * max(scale, np.abs(fA[:n, :3]).max())
