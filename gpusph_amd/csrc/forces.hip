@@ -91,6 +91,9 @@ struct Self {
 	float p_precalc, sspeed, P, rho, inv_rho;
 	uint32_t fl;
 	float tau[6];
+	// NEWTONIAN rheology: own viscosity terms and the averaging selectors, per lane (see laminar_factor)
+	float visc_c, visc_mu, visc_kin, visc_onemk, visc_wA, visc_wH, visc_wG;
+	uint32_t visc_constmask;
 };
 
 // one pair (i <- j).  Terms, in the reference's order (compute_all_pp_interaction,
@@ -107,22 +110,37 @@ __device__ __forceinline__ float visc_of(const DevParams &p, uint32_t fl)
 	return (fl & 2u) ? hi : lo;
 }
 
-// visc_avg (src/cuda/visc_avg.cu:40-190) without the neighbour mass: the per-pair factor of the laminar Morris term
-// nu-or-mu averaged over the pair / densities.  All selectors are wave-uniform (kernel arguments).
-__device__ __forceinline__ float laminar_factor(const DevParams &p, uint32_t fl, uint32_t nfl, float rho, float n_rho)
+// visc_avg (src/cuda/visc_avg.cu:40-190) without the neighbour mass: the per-pair factor of the laminar Morris term,
+// nu-or-mu averaged over the pair / densities.  Every flavour of the reference is one instance of
+//   mu_i = c_i rho_i^k , mu_j = c'_j rho_j^k  (k = 1 kinematic, 0 dynamic; c'_j = c_i when the viscosity is declared
+//   constant, the neighbour's fluid coefficient otherwise),
+//   arithmetic (mu_i + mu_j)/(rho_i rho_j), harmonic 4 mu_i mu_j/((mu_i + mu_j) rho_i rho_j), geometric 2 sqrt(mu_i mu_j)/(rho_i rho_j)
+// (the constant-viscosity shortcuts of visc_avg.cu are these with c'_j = c_i, up to rounding).  It is evaluated
+// branch-free with per-lane selector values prepared once per particle (init_visc) instead of wave-uniform branches on
+// the kernel arguments: with the branches, the generic kernel took the constant-viscosity path from the second list
+// batch of the boundary section on (the uniform condition did not survive that loop), which the two-fluid
+// non-constant-viscosity parity test exposed; the select form is also what keeps the tiled and generic kernels bit-equal.
+__device__ __forceinline__ void init_visc(const DevParams &p, Self &s)
 {
-	const float c = visc_of(p, fl);
-	if (p.is_const_visc) {
-		if (p.compvisc == SPHX_DYNAMIC) return 2.0f*c*fast_rcp(rho*n_rho);
-		if (p.avgop == SPHX_ARITHMETIC) return c*(rho + n_rho)*fast_rcp(rho*n_rho);
-		if (p.avgop == SPHX_HARMONIC) return 4.0f*c*fast_rcp(rho + n_rho);
-		return 2.0f*c*__builtin_amdgcn_rsqf(rho*n_rho);
-	}
-	const float nc = visc_of(p, nfl);
-	const float mu = (p.compvisc == SPHX_KINEMATIC) ? c*rho : c, nmu = (p.compvisc == SPHX_KINEMATIC) ? nc*n_rho : nc;
-	if (p.avgop == SPHX_ARITHMETIC) return (mu + nmu)*fast_rcp(rho*n_rho);
-	if (p.avgop == SPHX_HARMONIC) return 4.0f*(mu*nmu)*fast_rcp((mu + nmu)*(rho*n_rho));
-	return 2.0f*fast_sqrt(mu*nmu)*fast_rcp(rho*n_rho);
+	float c = visc_of(p, s.fl);
+	uint32_t cm = p.is_const_visc ? 0xFFFFFFFFu : 0u;
+	float kin = (p.compvisc == SPHX_KINEMATIC) ? 1.0f : 0.0f;
+	float wA = (p.avgop == SPHX_ARITHMETIC) ? 1.0f : 0.0f, wH = (p.avgop == SPHX_HARMONIC) ? 4.0f : 0.0f,
+		wG = (p.avgop == SPHX_GEOMETRIC) ? 2.0f : 0.0f;
+	asm volatile("" : "+v"(c), "+v"(cm), "+v"(kin), "+v"(wA), "+v"(wH), "+v"(wG));   // keep them per-lane values
+	s.visc_c = c; s.visc_constmask = cm; s.visc_kin = kin; s.visc_onemk = 1.0f - kin;
+	s.visc_wA = wA; s.visc_wH = wH; s.visc_wG = wG;
+	s.visc_mu = c*fmaf(kin, s.rho, s.visc_onemk);      // c rho or c, exactly
+}
+
+__device__ __forceinline__ float laminar_factor(const DevParams &p, const Self &s, uint32_t nfl, float n_rho)
+{
+	const uint32_t cb = __float_as_uint(s.visc_c), nb = __float_as_uint(visc_of(p, nfl));
+	const float nc = __uint_as_float((cb & s.visc_constmask) | (nb & ~s.visc_constmask));
+	const float nmu = nc*fmaf(s.visc_kin, n_rho, s.visc_onemk);
+	const float S = s.visc_mu + nmu, P = s.visc_mu*nmu;
+	const float num = fmaf(s.visc_wA, S, fmaf(s.visc_wH*P, fast_rcp(fmaxf(S, 1.0e-30f)), s.visc_wG*fast_sqrt(P)));
+	return num*fast_rcp(s.rho*n_rho);
 }
 
 template<int KERNEL, int TURB, bool COLAGROSSI, bool MOMENTUM, bool DIFFUSE>
@@ -183,7 +201,7 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 		if (TURB & SPHX_TURB_NEWT) {
 			// compute_laminar_visc_contrib, MORRIS (forces_kernel.def:2606-2625): visc_avg * F * (v_i - v_j), after the
 			// turbulent term (compute_viscous_contrib :2881-2886)
-			const float lv = rt_momentum ? laminar_factor(p, s.fl, nfl, s.rho, n_rho)*mf : 0.0f;
+			const float lv = rt_momentum ? laminar_factor(p, s, nfl, n_rho)*mf : 0.0f;
 			force.x = fmaf(lv, vx, force.x); force.y = fmaf(lv, vy, force.y); force.z = fmaf(lv, vz, force.z);
 		}
 	}
@@ -265,6 +283,7 @@ __device__ __forceinline__ void load_self(const DevParams &p, const ForcesArgs &
 	const float4 ax = a.aux[index];
 	s.p_precalc = ax.x; s.sspeed = ax.y; s.P = ax.z; s.rho = ax.w;
 	s.inv_rho = fast_rcp(ax.w);
+	if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
 	if (TURB_MODEL(TURB) == SPHX_SPS) {
 		const float2 t0 = a.tau0[index], t1 = a.tau1[index], t2 = a.tau2[index];
 		s.tau[0] = t0.x; s.tau[1] = t0.y; s.tau[2] = t1.x; s.tau[3] = t1.y; s.tau[4] = t2.x; s.tau[5] = t2.y;
@@ -306,10 +325,8 @@ __device__ __forceinline__ void load_list_batch(const DevParams &p, const neibda
 
 // walk one typed section of the neighbour list (neiblist_iterator_simple,
 // src/cuda/neibs_iteration.cuh:165-205; getNeibIndex src/cuda/cellgrid.cuh:200-228)
-// LJW: the section is a Lennard-Jones repulsion walk (positions only).  A template flag, not a run-time one: a uniform
-// `if (lj)` around the two interaction bodies inside this loop made the compiler lose the wave-uniform viscosity
-// selectors after the first batch (generic kernel took the constant-viscosity branch of laminar_factor from the
-// second batch of the boundary section on; found by the two-fluid non-constant-viscosity parity test).
+// LJW: the section is a Lennard-Jones repulsion walk (positions only): a template flag, so that the pair loop holds one
+// interaction body
 template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID, int NPTYPE, bool MOMENTUM, bool DIFFUSE, bool LJW = false>
 __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArgs &a, uint32_t index,
 	const Self &s, float inv_h, float4 &force)
@@ -903,6 +920,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		s.fl = 0u;
 		s.p_precalc = own.aux.x; s.sspeed = own.aux.y; s.P = own.aux.z; s.rho = own.aux.w;
 		s.inv_rho = fast_rcp(own.aux.w);
+		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
 		ListWindow lwB;
 #pragma unroll
 		for (int k = 0; k < TILE_NB; ++k) lwB.q[0][k] = own.lwB0[k];
