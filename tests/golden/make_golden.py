@@ -153,7 +153,53 @@ def features():
     np.savez_compressed(os.path.join(HERE, "oracle_features.npz"), **out)
 
 
+def features2_cases():
+    """(tag, problem factory) of the second feature fixture: repacking run mode and Newtonian viscosity.  Shared by
+    the generator and the tests so that both rebuild the same inputs."""
+    from gpusph_amd import defs as D
+    newt = lambda **kw: dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, **kw)
+    return [
+        ("r", "repack", lambda: DamBreak3D(0.05, obstacle=True, jitter=0.2, hydrostatic=True)),
+        ("k", "forces", lambda: DamBreak3D(0.05, obstacle=True, jitter=0.15, hydrostatic=False, viscosity="KINEMATICVISC",
+                                           kinematic_visc=0.05)),
+        ("m", "forces", lambda: DamBreak3D(0.05, obstacle=False, jitter=0.15, hydrostatic=False, two_fluids=True, kinematic_visc=0.05,
+                                           viscosity=newt(compvisc=D.KINEMATIC, avgop=D.HARMONIC, is_const_visc=False))),
+        ("g", "forces", lambda: DamBreak3D(0.05, obstacle=False, jitter=0.15, hydrostatic=False, two_fluids=True, kinematic_visc=0.05,
+                                           density_diffusion=D.DENSITY_DIFFUSION_NONE,
+                                           viscosity=newt(compvisc=D.DYNAMIC, avgop=D.GEOMETRIC, is_const_visc=False))),
+        ("w", "forces", lambda: DamBreak3D(0.05, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes",
+                                           viscosity="KINEMATICVISC", kinematic_visc=0.2)),
+    ]
+
+
+def features2():
+    out = {}
+    rng = np.random.default_rng(78)
+    for tag, kind, make in features2_cases():
+        prob = make()
+        sim = ol.OracleSim(prob)
+        sim.build_neibs()
+        n = sim.n
+        vel = sim.vel.copy()
+        fl = (sim.info[:, 0] & 7) == 0
+        vel[fl, :3] += rng.uniform(-0.3, 0.3, size=(fl.sum(), 3)).astype(np.float32)
+        if kind == "forces":
+            vel[:, 3] += rng.uniform(0, 2e-3, size=len(vel)).astype(np.float32)
+        out[tag + "_vel"] = vel
+        rb = getattr(prob, "num_obstacle", 0)
+        if kind == "repack":
+            f, cfl, nb, _, _ = sim.o.repack_forces(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, rb_count=rb)
+            pr, vr = sim.o.euler_repack(sim.pos, vel, sim.info, sim.hash, f, n, float(np.float32(1.3e-4)), 1)
+            out[tag + "_euler_pos"] = pr; out[tag + "_euler_vel"] = vr
+        else:
+            cof = 1 if prob.simparams.numforcesbodies else 0
+            f, cfl, nb, _, _ = sim.o.forces(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, compute_object_forces=cof, rb_count=rb)
+        out[tag + "_forces"] = f
+        out[tag + "_dt"] = np.float32(sim.o.dtreduce(cfl, nb, sim.sspeed_cfl, sim.max_kinvisc))
+    np.savez_compressed(os.path.join(HERE, "oracle_features2.npz"), **out)
+
+
 if __name__ == "__main__":
-    kernels(); datamodel(); pipeline(); features()
+    kernels(); datamodel(); pipeline(); features(); features2()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -722,6 +722,40 @@ def test_against_committed_feature_fixture():
             assert np.abs(_np(eng.rbforces) - g[tag + "_rbforces"]).max() <= 2e-5 * max(np.abs(g[tag + "_rbforces"]).max(), 1e-12)
 
 
+def test_against_committed_feature_fixture_2():
+    """tests/golden/oracle_features2.npz: repacking run mode (bit-exact) and Newtonian viscosity cases against committed
+    vectors, without the oracle in the loop"""
+    import importlib.util, os, torch
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    g = np.load(os.path.join(here, "oracle_features2.npz"))
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint32)
+    for tag, kind, make in mg.features2_cases():
+        prob = make()
+        eng = _engine(prob, clobber_neibslist=True)
+        eng.build_neibs()
+        n = eng.n
+        vel = np.ascontiguousarray(g[tag + "_vel"])
+        eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+        fr = g[tag + "_forces"][:n]
+        if kind == "repack":
+            eng._forces(eng.pos, eng.vel, 1, 0, D.REPACK)
+            assert np.array_equal(bits(_np(eng.forces)[:n]), bits(fr)), tag
+            eng.d_dt.fill_(float(np.float32(1.3e-4)))
+            eng._euler(1, 1.0, D.REPACK)
+            assert np.array_equal(bits(_np(eng.pos2)[:n]), bits(g[tag + "_euler_pos"][:n]))
+            assert np.array_equal(bits(_np(eng.vel2)[:n]), bits(g[tag + "_euler_vel"][:n]))
+            tol = 1e-6
+        else:
+            eng._forces(eng.pos, eng.vel, 1, 0)
+            f = _np(eng.forces)[:n]
+            assert np.abs(f[:, :3] - fr[:, :3]).max() <= 2e-5 * np.abs(fr[:, :3]).max(), tag
+            assert np.abs(f[:, 3] - fr[:, 3]).max() <= 1e-3 * np.abs(fr[:, 3]).max() + 1e-7, tag   # Colagrossi switch pairs (two fluids)
+            tol = 2e-5
+        assert abs(float(eng.d_dt_next.item()) - float(g[tag + "_dt"])) <= tol * float(g[tag + "_dt"]), tag
+
+
 # ---------------------------------------------------------------------------------------------
 # repacking run mode (run_mode = REPACK through the same basicstep entry points): no fast-math in this kernel, so
 # the forces are BIT-EXACT against the oracle for the polynomial kernels; the CFL term holds a powf (sound speed)

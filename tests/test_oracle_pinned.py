@@ -143,3 +143,30 @@ def test_oracle_features_regression():
     info_s, nrm = sim.o.surface(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, normals=True)
     assert eq(info_s, g["a_surface_info"]) and eq(nrm, g["a_normals"])
     assert eq(sim.o.testpoints(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n), g["a_testpoints"])
+
+
+def test_oracle_features2_regression():
+    """tests/golden/oracle_features2.npz: repacking forces + Euler, Newtonian viscosity (KINEMATICVISC with a feedback body,
+    two fluids with non-constant kinematic/harmonic and dynamic/geometric averaging, planes with wall friction)"""
+    import importlib.util
+    import oracle_lib as ol
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLD, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    g = np.load(os.path.join(GOLD, "oracle_features2.npz"))
+    eq = lambda a, b: np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+    for tag, kind, make in mg.features2_cases():
+        prob = make()
+        sim = ol.OracleSim(prob)
+        sim.build_neibs()
+        n = sim.n
+        vel = np.ascontiguousarray(g[tag + "_vel"])
+        rb = getattr(prob, "num_obstacle", 0)
+        if kind == "repack":
+            f, cfl, nb, _, _ = sim.o.repack_forces(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, rb_count=rb)
+            pr, vr = sim.o.euler_repack(sim.pos, vel, sim.info, sim.hash, f, n, float(np.float32(1.3e-4)), 1)
+            assert eq(pr, g[tag + "_euler_pos"]) and eq(vr, g[tag + "_euler_vel"]), tag
+        else:
+            cof = 1 if prob.simparams.numforcesbodies else 0
+            f, cfl, nb, _, _ = sim.o.forces(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, compute_object_forces=cof, rb_count=rb)
+        assert eq(f, g[tag + "_forces"]), tag
+        assert np.float32(sim.o.dtreduce(cfl, nb, sim.sspeed_cfl, sim.max_kinvisc)) == g[tag + "_dt"], tag
