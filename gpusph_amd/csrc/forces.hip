@@ -99,6 +99,11 @@ struct Self {
 // one pair (i <- j).  Terms, in the reference's order (compute_all_pp_interaction,
 // forces_kernel.def:3565-3610): continuity + density diffusion -> force.w; pressure + viscous ->
 // force.xyz.  (pcx,pcy,pcz) = own position shifted into the neighbour's cell frame.
+// density-diffusion template codes (the parameter keeps its historical name COLAGROSSI): 1 keeps `true` = Colagrossi
+#define DIFF_NONE 0
+#define DIFF_COLAGROSSI 1
+#define DIFF_FERRARI 2
+
 // TURB template codes: the turbulence model in the low bits, SPHX_TURB_NEWT set for the NEWTONIAN rheology
 #define SPHX_TURB_NEWT 8
 #define TURB_MODEL(T) ((T) & 7)
@@ -143,7 +148,7 @@ __device__ __forceinline__ float laminar_factor(const DevParams &p, const Self &
 	return num*fast_rcp(s.rho*n_rho);
 }
 
-template<int KERNEL, int TURB, bool COLAGROSSI, bool MOMENTUM, bool DIFFUSE>
+template<int KERNEL, int TURB, int COLAGROSSI, bool MOMENTUM, bool DIFFUSE>
 __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s, float inv_h,
 	float pcx, float pcy, float pcz, const float4 &npos, const float4 &nvel, const float4 &naux,
 	bool same_fluid, bool valid, const float *ntau, float4 &force, bool rt_momentum = true, bool rt_diffuse = true,
@@ -170,7 +175,15 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 
 	// mass_continuity_div_vel_term (forces_kernel.def:2140-2151)
 	float dsel = 0.0f;
-	if (COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
+	if (COLAGROSSI == DIFF_FERRARI && DIFFUSE) { // compute_density_diffusion, Ferrari (forces_kernel.def:1607-1635)
+		const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
+		const float c0 = p.sscoeff[s.fl];
+		const float grav_corr = -gdotr*p.rho0[s.fl]*fast_rcp(c0*c0);
+		const float sc = fmaxf(s.sspeed, n_sspeed)*(s.rho - n_rho + grav_corr)*s.inv_rho*fast_rcp(r);
+		const float fterm = p.densityDiffCoeff*mf*(sc*r2);
+		dsel = (rt_diffuse && r > 1e-4f*p.slength) ? -fterm : 0.0f;
+	}
+	if (COLAGROSSI == DIFF_COLAGROSSI && DIFFUSE) { // compute_density_diffusion (forces_kernel.def:1916-1952)
 		const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
 		const bool diff = same_fluid && rt_diffuse && !(fabsf(s.P - n_P) < fabsf(gdotr*s.rho));
 		const float dterm = p.densityDiffCoeff*p.sscoeff[s.fl]*fmaf(n_rho, s.inv_rho, -1.0f)*mf;
@@ -327,7 +340,7 @@ __device__ __forceinline__ void load_list_batch(const DevParams &p, const neibda
 // src/cuda/neibs_iteration.cuh:165-205; getNeibIndex src/cuda/cellgrid.cuh:200-228)
 // LJW: the section is a Lennard-Jones repulsion walk (positions only): a template flag, so that the pair loop holds one
 // interaction body
-template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID, int NPTYPE, bool MOMENTUM, bool DIFFUSE, bool LJW = false>
+template<int KERNEL, int TURB, int COLAGROSSI, bool MULTIFLUID, int NPTYPE, bool MOMENTUM, bool DIFFUSE, bool LJW = false>
 __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArgs &a, uint32_t index,
 	const Self &s, float inv_h, float4 &force)
 {
@@ -405,7 +418,7 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 	}
 }
 
-template<int KERNEL, int TURB, bool COLAGROSSI, bool MULTIFLUID>
+template<int KERNEL, int TURB, int COLAGROSSI, bool MULTIFLUID>
 __global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
 forces_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ runIfNonZero)
 {
@@ -598,7 +611,7 @@ __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 // stage 2: the pair interactions of a gathered half, in list order
 // LJ = the run uses LJ_BOUNDARY: pairs of the boundary section (ljsec, wave-uniform) and all pairs of boundary
 // particles with force feedback (ljlane) are Lennard-Jones repulsions instead of SPH interactions
-template<int KERNEL, int TURB, bool COLAGROSSI, bool LJ>
+template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered &g, const Self &s, float inv_h,
 	bool momentum, bool diffuse, bool ljsec, bool ljlane, float4 &force)
 {
@@ -630,7 +643,7 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 //    computed, so the ds_read latency (and its bank conflicts) hides behind the pair arithmetic;
 //  * section, momentum and diffusion switches are run-time values so that the pair code exists
 //    once in the kernel (the instruction cache is 64 KB; four template copies did not fit).
-template<int KERNEL, int TURB, bool COLAGROSSI, bool LJ>
+template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListRows &list,
 	uint32_t voff, const Self &s, float inv_h, const float4 *sShift, const uint16_t *myCB,
 	const float4 *sPos, const float4 *sVel, const float4 *sAux,
@@ -694,7 +707,7 @@ __device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t tid, u
 // a thread's own rows and the first batches of its neighbour list, requested one tile ahead
 struct TileOwn { particleinfo info; float4 pos, vel, aux; uint32_t hash; ListWindow lwF; uint32_t lwB0[TILE_NB]; };
 
-template<int KERNEL, int TURB, bool COLAGROSSI, bool LJ>
+template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __global__ void __launch_bounds__(TILE_THREADS, 2)
 forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
 	uint32_t *tileCtl /* [0]=count, [1]=overflow, [2]=finished workgroups, [4..11]=per-XCD tile tickets */,
@@ -1183,7 +1196,7 @@ extern "C" uint32_t sphx_forces_fmax_temp_elements(uint32_t nels)
 }
 extern "C" uint32_t sphx_forces_round_particles(uint32_t n) { return (n/SPHX_BLOCK_FORCES)*SPHX_BLOCK_FORCES; }
 
-template<int KERNEL, int TURB, bool COLA>
+template<int KERNEL, int TURB, int COLA>
 static void launch_forces_mf(bool multifluid, dim3 grid, hipStream_t stream, const DevParams &p, const ForcesArgs &a,
 	const uint32_t *guard)
 {
@@ -1208,7 +1221,7 @@ struct ForcesTimer {
 	~ForcesTimer() { if (stop) (void)hipEventRecord(stop, stream); }
 };
 
-template<int KERNEL, int TURB, bool COLA>
+template<int KERNEL, int TURB, int COLA>
 static void launch_tile(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &a)
 {
 	ForcesTimer t(ctx, stream, true);
@@ -1227,40 +1240,41 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 {
 	const DevParams &p = ctx->dev;
 	const bool mf = p.numfluids > 1;
-	const bool cola = p.densitydiff == SPHX_COLAGROSSI;
+	const int diff = (p.densitydiff == SPHX_COLAGROSSI) ? DIFF_COLAGROSSI : (p.densitydiff == SPHX_FERRARI) ? DIFF_FERRARI : DIFF_NONE;
 	const bool newt = p.rheology == SPHX_NEWTONIAN;
 	const uint32_t *guard = use_tiles ? ctx->tile_ctl + 1 : nullptr;
 	ForcesTimer t(ctx, stream, !use_tiles);   // without tiles the generic kernel is the dominant one
+	// tiled kernel (never with Ferrari diffusion: use_tiles is false then), then the generic one, guarded by the overflow flag
+#define SPHX_LAUNCH_TILE(T) do { if (use_tiles) { \
+		if (diff == DIFF_COLAGROSSI) launch_tile<KERNEL, T, DIFF_COLAGROSSI>(ctx, stream, a); \
+		else launch_tile<KERNEL, T, DIFF_NONE>(ctx, stream, a); } } while (0)
+#define SPHX_LAUNCH_GENERIC(T, G) do { \
+		if (diff == DIFF_COLAGROSSI) launch_forces_mf<KERNEL, T, DIFF_COLAGROSSI>(mf, grid, stream, p, a, G); \
+		else if (diff == DIFF_FERRARI) launch_forces_mf<KERNEL, T, DIFF_FERRARI>(mf, grid, stream, p, a, G); \
+		else launch_forces_mf<KERNEL, T, DIFF_NONE>(mf, grid, stream, p, a, G); } while (0)
 	switch (p.turbmodel) {
 	case SPHX_ARTIFICIAL:
-		if (use_tiles) { if (cola) launch_tile<KERNEL, SPHX_ARTIFICIAL, true>(ctx, stream, a); else launch_tile<KERNEL, SPHX_ARTIFICIAL, false>(ctx, stream, a); }
-		if (cola) launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, true>(mf, grid, stream, p, a, guard);
-		else launch_forces_mf<KERNEL, SPHX_ARTIFICIAL, false>(mf, grid, stream, p, a, guard);
+		SPHX_LAUNCH_TILE(SPHX_ARTIFICIAL);
+		SPHX_LAUNCH_GENERIC(SPHX_ARTIFICIAL, guard);
 		break;
 	case SPHX_SPS:
-		if (newt) {
-			if (cola) launch_forces_mf<KERNEL, SPHX_SPS | SPHX_TURB_NEWT, true>(mf, grid, stream, p, a, nullptr);
-			else launch_forces_mf<KERNEL, SPHX_SPS | SPHX_TURB_NEWT, false>(mf, grid, stream, p, a, nullptr);
-		} else {
-			if (cola) launch_forces_mf<KERNEL, SPHX_SPS, true>(mf, grid, stream, p, a, nullptr);
-			else launch_forces_mf<KERNEL, SPHX_SPS, false>(mf, grid, stream, p, a, nullptr);
-		}
+		if (newt) SPHX_LAUNCH_GENERIC(SPHX_SPS | SPHX_TURB_NEWT, nullptr);
+		else SPHX_LAUNCH_GENERIC(SPHX_SPS, nullptr);
 		break;
 	case SPHX_LAMINAR_FLOW:
 		if (newt) {
-			constexpr int T = SPHX_LAMINAR_FLOW | SPHX_TURB_NEWT;
-			if (use_tiles) { if (cola) launch_tile<KERNEL, T, true>(ctx, stream, a); else launch_tile<KERNEL, T, false>(ctx, stream, a); }
-			if (cola) launch_forces_mf<KERNEL, T, true>(mf, grid, stream, p, a, guard);
-			else launch_forces_mf<KERNEL, T, false>(mf, grid, stream, p, a, guard);
+			SPHX_LAUNCH_TILE(SPHX_LAMINAR_FLOW | SPHX_TURB_NEWT);
+			SPHX_LAUNCH_GENERIC(SPHX_LAMINAR_FLOW | SPHX_TURB_NEWT, guard);
 		} else {
-			if (use_tiles) { if (cola) launch_tile<KERNEL, SPHX_LAMINAR_FLOW, true>(ctx, stream, a); else launch_tile<KERNEL, SPHX_LAMINAR_FLOW, false>(ctx, stream, a); }
-			if (cola) launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, true>(mf, grid, stream, p, a, guard);
-			else launch_forces_mf<KERNEL, SPHX_LAMINAR_FLOW, false>(mf, grid, stream, p, a, guard);
+			SPHX_LAUNCH_TILE(SPHX_LAMINAR_FLOW);
+			SPHX_LAUNCH_GENERIC(SPHX_LAMINAR_FLOW, guard);
 		}
 		break;
 	default:
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: turbulence model not built");
 	}
+#undef SPHX_LAUNCH_TILE
+#undef SPHX_LAUNCH_GENERIC
 	return SPHX_OK;
 }
 
@@ -1327,7 +1341,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
-		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && !ctx->disable_tiles &&
+		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && ctx->dev.densitydiff != SPHX_FERRARI && !ctx->disable_tiles &&
 		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
 		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
 		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit

@@ -171,8 +171,9 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only SPH_F1 is built");
 	if (sp->boundarytype != SPHX_DYN_BOUNDARY && sp->boundarytype != SPHX_LJ_BOUNDARY)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only DYN_BOUNDARY and LJ_BOUNDARY neighbour lists are built");
-	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only Colagrossi (or no) density diffusion is built");
+	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI &&
+		sp->densitydiffusiontype != SPHX_FERRARI)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: Brezzi density diffusion (an SA_BOUNDARY option in the reference's problems) is not built");
 	if (sp->rheologytype != SPHX_INVISCID && sp->rheologytype != SPHX_NEWTONIAN)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only INVISCID and NEWTONIAN rheologies are built");
 	if (sp->rheologytype == SPHX_NEWTONIAN) {

@@ -172,6 +172,10 @@ class Problem:
             if math.isnan(sp.densityDiffCoeff):
                 sp.densityDiffCoeff = float(np.float32(0.1))
             sp.densityDiffCoeff = float(np.float32(np.float32(sp.densityDiffCoeff) * np.float32(2.0) * np.float32(sp.slength)))
+        if sp.densitydiffusiontype == D.FERRARI:     # ProblemCore.cc:1379-1396
+            if math.isnan(sp.densityDiffCoeff):
+                ls = getattr(sp, "ferrariLengthScale", float("nan"))
+                sp.densityDiffCoeff = 0.0 if math.isnan(ls) else float(np.float32(np.float32(ls) * np.float32(1e-3) / np.float32(self.m_deltap)))
         if sp.turbmodel == D.SPS:        # GPUSPH.cc:1540-1556: (Cs dp)^2 and (2/3) Ci dp^2, in double
             dp = self.m_deltap
             if math.isnan(pp.smagfactor):

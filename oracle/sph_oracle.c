@@ -767,6 +767,19 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 						}
 					}
 				}
+				/* compute_density_diffusion (Ferrari, fluid neighbours only outside SA), :1607-1635; d_sqC0 = sscoeff^2
+				 * in float (src/cuda/forces.cu:319-325) */
+				if (p->densitydiffusiontype == ORC_FERRARI && nptype == PT_FLUID) {
+					const int fType = p_fluid;
+					const float sqC0 = p->sscoeff[fType]*p->sscoeff[fType];
+					const float grav_corr = -dot3(p->gravity[0], p->gravity[1], p->gravity[2], rx, ry, rz)*p->rho0[fType]/sqC0;
+					float fc[3] = {0.0f, 0.0f, 0.0f};
+					if (r > 1e-4f*p->slength) {
+						const float sc = fmaxf(p_sspeed, n_sspeed)*(p_rho - n_rho + grav_corr)/p_rho/r;
+						fc[0] = sc*rx; fc[1] = sc*ry; fc[2] = sc*rz;
+					}
+					DrDt += p->densityDiffCoeff*nmass*dot3(fc[0], fc[1], fc[2], rx, ry, rz)*f;
+				}
 				force.w += DrDt;
 			}
 

@@ -88,11 +88,39 @@ def test_every_kernel(kernel, monkeypatch):
 
 
 @pytest.mark.parametrize("turb,diff", [(D.LAMINAR_FLOW, D.COLAGROSSI), (D.ARTIFICIAL, D.DENSITY_DIFFUSION_NONE),
-                                       (D.LAMINAR_FLOW, D.DENSITY_DIFFUSION_NONE)])
+                                       (D.LAMINAR_FLOW, D.DENSITY_DIFFUSION_NONE), (D.ARTIFICIAL, D.FERRARI)])
 def test_viscosity_and_diffusion_switches(turb, diff, monkeypatch):
     prob = DamBreak3D(deltap=0.045, obstacle=True, jitter=0.1, hydrostatic=False, density_diffusion=diff)
     prob.simparams.turbmodel = turb
     _check_neibs_and_forces(prob, 33, monkeypatch)
+
+
+def test_ferrari_diffusion_with_lj_boundaries_and_trajectory():
+    """Spheric2LJ's option set on the dam-break mirror: LJ_BOUNDARY + Ferrari density diffusion + artificial viscosity
+    (generic forces kernel), forces and a 10-step trajectory; also two fluids (the Ferrari term crosses the interface)"""
+    prob = DamBreak3D(deltap=0.045, obstacle=True, jitter=0.1, hydrostatic=True, boundary=D.LJ_BOUNDARY, density_diffusion=D.FERRARI)
+    _check_neibs_and_forces(prob, 39)
+    prob2 = DamBreak3D(deltap=0.045, obstacle=False, jitter=0.1, hydrostatic=False, two_fluids=True, density_diffusion=D.FERRARI)
+    _check_neibs_and_forces(prob2, 40)
+    # the term matters at this tolerance
+    sim = ol.OracleSim(prob); sim.build_neibs()
+    n = sim.n
+    sim.vel[:n, 3] += np.random.default_rng(39).uniform(0, 2e-3, size=n).astype(np.float32)
+    f1 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    sim.o.p.densityDiffCoeff = 0.0
+    f0 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    assert np.abs(f1[:n, 3] - f0[:n, 3]).max() > 100 * 2e-5 * np.abs(f1[:n, 3]).max()
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    steps = 10
+    for _ in range(steps):
+        sim.step(); eng.step()
+    out = eng.download()
+    n = eng.n
+    assert np.array_equal(out["hash"], sim.hash[:n])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
+    assert np.abs(out["vel"][:, 3] - sim.vel[:n, 3]).max() <= 1e-6 * steps
 
 
 def test_two_fluids():

@@ -713,3 +713,60 @@ def test_plane_friction_equals_brute_force():
     assert (np.abs(ref).max(axis=1) > 0).sum() > 30
     scale = np.abs(ref).max()
     assert np.abs(diff - ref).max() <= 1e-4 * max(scale, np.abs(fA[:n, :3]).max())
+
+
+# ---------------------------------------------------------------------------------------------- Ferrari density diffusion
+def test_ferrari_diffusion_equals_brute_force_and_vanishes_at_hydrostatic_equilibrium():
+    """Ferrari (Mayrhofer et al. 2013): drho_i/dt += D sum_j m_j F_ij max(c_i, c_j) (rho_i - rho_j + gc_ij)/rho_i |r_ij| over fluid
+    neighbours, gc_ij = -(g.r_ij) rho0/c0^2 (the hydrostatic density difference).  Linear in D: F(D) - F(0) is the term."""
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.2, hydrostatic=True, density_diffusion=D.FERRARI)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(21)
+    sim.vel[:n, 3] += rng.uniform(0, 2e-3, size=n).astype(np.float32)
+    p = sim.o.p
+    Dc = float(p.densityDiffCoeff)
+    assert p.densitydiffusiontype == D.FERRARI and Dc == pytest.approx(0.1)
+    f_full = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    p.densityDiffCoeff = 0.0
+    f_zero = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    p.densityDiffCoeff = Dc
+    term = (f_full[:n, 3].astype(np.float64) - f_zero[:n, 3]) * float(p.rho0[0])     # forces.w is d(rho~)/dt = drho/dt / rho0
+    assert np.array_equal(f_full[:n, :3], f_zero[:n, :3])                           # the momentum equation is untouched
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    ptype = sim.info[:n, 0] & 7
+    fl = np.where(ptype == 0)[0]
+    h, c0, rho0, g = float(p.slength), float(p.sscoeff[0]), float(p.rho0[0]), np.array([p.gravity[0], p.gravity[1], p.gravity[2]])
+    fcoeff = 105.0 / (128.0 * np.pi * h ** 5)
+    rt = sim.vel[:n, 3].astype(np.float64)
+    rho = (rt + 1.0) * rho0
+    cs = c0 * (rt + 1.0) ** 3
+    m = sim.pos[:n, 3].astype(np.float64)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(gp)
+    ref = np.zeros(n)
+    # central particles: fluid, and the DYN boundary particles (their density evolves with the same continuity equation);
+    # neighbours: fluid only (boundary neighbours contribute nothing outside SA, forces_kernel.def:1596-1606)
+    for i, nbs in enumerate(tree.query_ball_point(gp, 2 * h * (1 - 1e-7))):
+        nbs = np.array([j for j in nbs if j != i and ptype[j] == 0])
+        if not len(nbs):
+            continue
+        d = gp[i] - gp[nbs]
+        r = np.linalg.norm(d, axis=1)
+        F = (r / h - 2.0) ** 3 * fcoeff
+        gc = -(d @ g) * rho0 / c0 ** 2
+        ref[i] = Dc * np.sum(m[nbs] * F * np.maximum(cs[i], cs[nbs]) * (rho[i] - rho[nbs] + gc) / rho[i] * r)
+    scale = np.abs(ref).max()
+    assert scale > 10.0
+    assert np.abs(term - ref).max() <= 2e-3 * scale           # F(D) - F(0) of float32 density rates
+    assert np.abs(ref[ptype == 1]).max() > 0.1 * scale         # boundary particles next to the fluid do get the term
+    # at hydrostatic equilibrium the gravity correction cancels the density differences
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.0, hydrostatic=True, density_diffusion=D.FERRARI)
+    sim = ol.OracleSim(prob); sim.build_neibs()
+    n = sim.n
+    fh = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    sim.o.p.densityDiffCoeff = 0.0
+    f0 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    bulk = ((sim.info[:n, 0] & 7) == 0)
+    assert np.abs(fh[:n, 3] - f0[:n, 3])[bulk].max() * float(p.rho0[0]) < 0.02 * scale
