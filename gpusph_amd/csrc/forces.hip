@@ -94,6 +94,7 @@ struct Self {
 	// NEWTONIAN rheology: own viscosity terms and the averaging selectors, per lane (see laminar_factor)
 	float visc_c, visc_mu, visc_kin, visc_onemk, visc_wA, visc_wH, visc_wG;
 	uint32_t visc_constmask;
+	uint32_t f2mask;   // all ones for SPH_F2 (generic kernel only), per lane like the viscosity selectors
 };
 
 // one pair (i <- j).  Terms, in the reference's order (compute_all_pp_interaction,
@@ -152,7 +153,7 @@ template<int KERNEL, int TURB, int COLAGROSSI, bool MOMENTUM, bool DIFFUSE>
 __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s, float inv_h,
 	float pcx, float pcy, float pcz, const float4 &npos, const float4 &nvel, const float4 &naux,
 	bool same_fluid, bool valid, const float *ntau, float4 &force, bool rt_momentum = true, bool rt_diffuse = true,
-	uint32_t nfl = 0)
+	uint32_t nfl = 0, bool f2cap = false)
 {
 	// Branch-free on purpose: a rejected pair (list terminator passed, r >= influence radius) gets the weight
 	// m_j F_ij = 0 and every term below becomes +-0, which leaves the accumulators untouched -- the same result
@@ -189,11 +190,21 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 		const float dterm = p.densityDiffCoeff*p.sscoeff[s.fl]*fmaf(n_rho, s.inv_rho, -1.0f)*mf;
 		dsel = diff ? dterm : 0.0f;
 	}
-	force.w += fmaf(mf, vel_dot_pos, -dsel);
+	float drdt = fmaf(mf, vel_dot_pos, -dsel);
+	if (f2cap) {   // SPH_F2: density ratio applied after the diffusion term (mass_continuity_density_ratio :2154-2165)
+		const float ratio = s.rho*fast_rcp(n_rho);
+		drdt *= __uint_as_float((__float_as_uint(ratio) & s.f2mask) | (0x3f800000u & ~s.f2mask));
+	}
+	force.w += drdt;
 
 	if (MOMENTUM) {
 		// compute_pressure_contrib (forces_kernel.def:2451-2466): -(P_i/rho_i^2 + P_j/rho_j^2) m_j F r_ij
-		float kk = -(s.p_precalc + n_precalc)*mf;
+		float pgrad = s.p_precalc + n_precalc;
+		if (f2cap) {   // SPH_F2: (P_i + P_j)/(rho_i rho_j) (pressure_gradient_term :2253-2266)
+			const float pg2 = (s.P + n_P)*fast_rcp(s.rho*n_rho);
+			pgrad = __uint_as_float((__float_as_uint(pg2) & s.f2mask) | (__float_as_uint(pgrad) & ~s.f2mask));
+		}
+		float kk = -pgrad*mf;
 		if (TURB_MODEL(TURB) == SPHX_ARTIFICIAL) {
 			// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764): only for approaching pairs
 			const float vdpn = fminf(vel_dot_pos, 0.0f);
@@ -297,6 +308,9 @@ __device__ __forceinline__ void load_self(const DevParams &p, const ForcesArgs &
 	s.p_precalc = ax.x; s.sspeed = ax.y; s.P = ax.z; s.rho = ax.w;
 	s.inv_rho = fast_rcp(ax.w);
 	if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
+	uint32_t f2 = (p.formulation == SPHX_SPH_F2) ? 0xFFFFFFFFu : 0u;
+	asm volatile("" : "+v"(f2));
+	s.f2mask = f2;
 	if (TURB_MODEL(TURB) == SPHX_SPS) {
 		const float2 t0 = a.tau0[index], t1 = a.tau1[index], t2 = a.tau2[index];
 		s.tau[0] = t0.x; s.tau[1] = t0.y; s.tau[2] = t1.x; s.tau[3] = t1.y; s.tau[4] = t2.x; s.tau[5] = t2.y;
@@ -411,7 +425,7 @@ __device__ __forceinline__ void walk_section(const DevParams &p, const ForcesArg
 				lj_interact(p, pcx, pcy, pcz, npos[k], valid[k], force);
 			else
 				pair_interact<KERNEL, TURB, COLAGROSSI, MOMENTUM, DIFFUSE>(p, s, inv_h, pcx, pcy, pcz,
-					npos[k], nvel[k], naux[k], same[k], valid[k], ntau[k], force, true, true, nfl[k]);
+					npos[k], nvel[k], naux[k], same[k], valid[k], ntau[k], force, true, true, nfl[k], true);
 		}
 #pragma unroll
 		for (int k = 0; k < NB; ++k) nd[k] = ndn[k];
@@ -1341,7 +1355,8 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
-		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && ctx->dev.densitydiff != SPHX_FERRARI && !ctx->disable_tiles &&
+		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && ctx->dev.densitydiff != SPHX_FERRARI &&
+		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles &&
 		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
 		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
 		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit

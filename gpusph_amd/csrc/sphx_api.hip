@@ -167,8 +167,8 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	SPHX_REQUIRE(sp->numfluids >= 1 && sp->numfluids <= SPHX_MAX_FLUIDS, "sphx_set_constants: numfluids out of range");
 	SPHX_REQUIRE(sp->neiblistsize >= 2 && sp->neibboundpos < sp->neiblistsize, "sphx_set_constants: invalid neighbour list geometry");
 	// option combinations built into this library (the rest is SURVEY.md 8f "next")
-	if (sp->sph_formulation != SPHX_SPH_F1)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only SPH_F1 is built");
+	if (sp->sph_formulation != SPHX_SPH_F1 && sp->sph_formulation != SPHX_SPH_F2)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only SPH_F1 and SPH_F2 are built");
 	if (sp->boundarytype != SPHX_DYN_BOUNDARY && sp->boundarytype != SPHX_LJ_BOUNDARY)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only DYN_BOUNDARY and LJ_BOUNDARY neighbour lists are built");
 	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI &&

@@ -240,7 +240,8 @@ class DamBreak3D(Problem):
 
     def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
                  jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY,
-                 walls="particles", testpoints=(), two_fluids=False, viscosity=None, kinematic_visc=1.0e-2):
+                 walls="particles", testpoints=(), two_fluids=False, viscosity=None, kinematic_visc=1.0e-2,
+                 formulation=D.SPH_F1):
         super().__init__()
         self.m_name = "DamBreak3D"
         sp, pp = self.simparams, self.physparams
@@ -258,6 +259,7 @@ class DamBreak3D(Problem):
             # (DamBreak3D.cu:74,131-134: layers only for DYN_BOUNDARY)
             self.LAYERS = 1
         self.set_viscosity(viscosity)       # DamBreak3D.cu:54 viscosity<ARTVISC>
+        sp.sph_formulation = formulation
         sp.densitydiffusiontype = density_diffusion
         sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | (D.ENABLE_MOVING_BODIES if obstacle else 0) | \
             (D.ENABLE_PLANES if walls == "planes" else 0)

@@ -702,7 +702,9 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 		const float p_sspeed = orc_soundSpeed(p, vel.w, p_fluid);
 		const float p_rho = physical_density(p, vel.w, p_fluid);
 		/* precalc_pressure SPH_F1: P/rho^2, :419-429 */
-		const float p_precalc = orc_P(p, vel.w, p_fluid)/(p_rho*p_rho);
+		/* ... SPH_F2: P (:431-441) */
+		const int f2 = p->sph_formulation == ORC_SPH_F2;
+		const float p_precalc = f2 ? orc_P(p, vel.w, p_fluid) : orc_P(p, vel.w, p_fluid)/(p_rho*p_rho);
 		const float *p_tau = tauArray ? tauArray + 6*(size_t)index : NULL;
 
 		orc_f4 force = forces[index]; /* common_particle_output, :886-895 */
@@ -729,7 +731,7 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			const int n_fluid = FLUID_NUM(neib_info);
 			const float n_sspeed = orc_soundSpeed(p, n_rhot, n_fluid);
 			const float n_rho = physical_density(p, n_rhot, n_fluid);
-			const float n_precalc = orc_P(p, n_rhot, n_fluid)/(n_rho*n_rho);
+			const float n_precalc = f2 ? orc_P(p, n_rhot, n_fluid) : orc_P(p, n_rhot, n_fluid)/(n_rho*n_rho);
 
 			float DvDt[3] = {0.0f, 0.0f, 0.0f};
 			float DrDt = 0.0f;
@@ -780,12 +782,14 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 					}
 					DrDt += p->densityDiffCoeff*nmass*dot3(fc[0], fc[1], fc[2], rx, ry, rz)*f;
 				}
+				if (f2) DrDt *= p_rho/n_rho;   /* mass_continuity_density_ratio, after the diffusion term (:2154-2188) */
 				force.w += DrDt;
 			}
 
 			if (all_pp || (dyn_bf && COMPUTE_FORCE(info))) {
 				/* compute_pressure_contrib general, :2451-2466 */
-				const float pGradTerm = p_precalc + n_precalc;
+				/* pressure_gradient_term: SPH_F1 P_i/rho_i^2 + P_j/rho_j^2 (:2358-2371), SPH_F2 (P_i + P_j)/(rho_i rho_j) (:2253-2266) */
+				const float pGradTerm = f2 ? (p_precalc + n_precalc)/(p_rho*n_rho) : p_precalc + n_precalc;
 				const float s = pGradTerm*nmass*f;
 				DvDt[0] -= s*rx; DvDt[1] -= s*ry; DvDt[2] -= s*rz;
 

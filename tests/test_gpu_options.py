@@ -123,6 +123,33 @@ def test_ferrari_diffusion_with_lj_boundaries_and_trajectory():
     assert np.abs(out["vel"][:, 3] - sim.vel[:n, 3]).max() <= 1e-6 * steps
 
 
+def test_sph_f2_formulation():
+    """SPH_F2 (Bubble, LockExchange, RTInstability in the reference: two fluids): generic kernel, forces + trajectory;
+    and single fluid, where it must not disturb anything"""
+    prob = DamBreak3D(deltap=0.045, obstacle=False, jitter=0.1, hydrostatic=False, two_fluids=True, formulation=D.SPH_F2)
+    _check_neibs_and_forces(prob, 41, switch_flips=3)
+    prob1 = DamBreak3D(deltap=0.045, obstacle=True, jitter=0.1, hydrostatic=True, formulation=D.SPH_F2)
+    _check_neibs_and_forces(prob1, 42)
+    # F2 differs from F1 for two fluids by much more than the tolerance
+    sims = {}
+    for form in (D.SPH_F1, D.SPH_F2):
+        pr = DamBreak3D(deltap=0.045, obstacle=False, jitter=0.1, hydrostatic=False, two_fluids=True, formulation=form)
+        sim = ol.OracleSim(pr); sim.build_neibs()
+        sim.vel[:sim.n, 3] += np.random.default_rng(41).uniform(0, 2e-3, size=sim.n).astype(np.float32)
+        sims[form] = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, sim.n)[0][:sim.n]
+    assert np.abs(sims[D.SPH_F1] - sims[D.SPH_F2])[:, :3].max() > 100 * 2e-5 * np.abs(sims[D.SPH_F1][:, :3]).max()
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    steps = 8
+    for _ in range(steps):
+        sim.step(); eng.step()
+    out = eng.download()
+    n = eng.n
+    assert np.array_equal(out["hash"], sim.hash[:n])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
+
+
 def test_two_fluids():
     """multi-fluid branch (generic kernel): per-fluid EOS, Colagrossi diffusion only between particles of the same fluid"""
     prob = DamBreak3D(deltap=0.045, obstacle=False, jitter=0.1, hydrostatic=False, two_fluids=True)

@@ -770,3 +770,55 @@ def test_ferrari_diffusion_equals_brute_force_and_vanishes_at_hydrostatic_equili
     f0 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
     bulk = ((sim.info[:n, 0] & 7) == 0)
     assert np.abs(fh[:n, 3] - f0[:n, 3])[bulk].max() * float(p.rho0[0]) < 0.02 * scale
+
+
+def test_sph_f2_formulation_known_answers():
+    """SPH_F2: pressure term (P_i + P_j)/(rho_i rho_j) and the continuity contribution scaled by rho_i/rho_j.  With
+    uniform density both reduce to SPH_F1 (rounding aside); with two fluids of different rest density they differ, and
+    the pressure forces still conserve momentum pairwise (the term is symmetric in i, j up to the mass factor)."""
+    from gpusph_amd.problem import PeriodicBox
+    res = {}
+    for form in (D.SPH_F1, D.SPH_F2):
+        prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.2, hydrostatic=False, formulation=form,
+                          density_diffusion=D.DENSITY_DIFFUSION_NONE)
+        sim = ol.OracleSim(prob); sim.build_neibs()
+        n = sim.n
+        rng = np.random.default_rng(31)
+        sim.vel[:n, :3] += rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32)
+        res[form] = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0][:n]
+    scale = np.abs(res[D.SPH_F1][:, :3]).max()
+    assert np.abs(res[D.SPH_F1] - res[D.SPH_F2])[:, :3].max() <= 1e-5 * scale       # rho~ = 0 everywhere: identical physics
+    assert np.abs(res[D.SPH_F1] - res[D.SPH_F2])[:, 3].max() <= 1e-5 * np.abs(res[D.SPH_F1][:, 3]).max()
+    # two fluids (1000 and 850 kg/m^3), perturbed densities: brute force of the F2 continuity + pressure sums
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.2, hydrostatic=False, formulation=D.SPH_F2, two_fluids=True,
+                      density_diffusion=D.DENSITY_DIFFUSION_NONE)
+    prob.simparams.turbmodel = D.LAMINAR_FLOW            # no viscosity: pressure + gravity only
+    sim = ol.OracleSim(prob); sim.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(32)
+    sim.vel[:n, :3] += rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32)
+    sim.vel[:n, 3] += rng.uniform(0, 2e-3, size=n).astype(np.float32)
+    f = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0][:n]
+    p = sim.o.p
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    ptype = sim.info[:n, 0] & 7
+    fl = (sim.info[:n, 1] >> 12).astype(int)
+    rho0 = np.array([float(p.rho0[0]), float(p.rho0[1])]); B = np.array([float(p.bcoeff[0]), float(p.bcoeff[1])])
+    rt = sim.vel[:n, 3].astype(np.float64)
+    rho = (rt + 1.0) * rho0[fl]
+    P = B[fl] * ((rt + 1.0) ** 7 - 1.0)
+    m = sim.pos[:n, 3].astype(np.float64); v = sim.vel[:n, :3].astype(np.float64)
+    h = float(p.slength); fcoeff = 105.0 / (128.0 * np.pi * h ** 5)
+    from scipy.spatial import cKDTree
+    tree = cKDTree(gp)
+    acc = np.zeros((n, 3)); drho = np.zeros(n)
+    fluid = np.where(ptype == 0)[0]
+    for i, nbs in zip(fluid, tree.query_ball_point(gp[fluid], 2 * h * (1 - 1e-7))):
+        nbs = np.array([j for j in nbs if j != i])
+        d = gp[i] - gp[nbs]; r = np.linalg.norm(d, axis=1)
+        F = (r / h - 2.0) ** 3 * fcoeff
+        acc[i] = (-((P[i] + P[nbs]) / (rho[i] * rho[nbs]) * m[nbs] * F)[:, None] * d).sum(axis=0)
+        drho[i] = np.sum(m[nbs] * np.einsum("ij,ij->i", v[i] - v[nbs], d) * F * rho[i] / rho[nbs]) / rho0[fl[i]]
+    acc[fluid, 2] += -9.81
+    assert np.abs(f[fluid, :3] - acc[fluid]).max() <= 2e-4 * np.abs(acc[fluid]).max()
+    assert np.abs(f[fluid, 3] - drho[fluid]).max() <= 2e-4 * np.abs(drho[fluid]).max()
