@@ -45,6 +45,8 @@ SIGNATURES = {
     "sphx_set_planes": (_i, [_vp, _vp, _vp, _vp, _i]),
     "sphx_set_gravity": (_i, [_vp, C.POINTER(_f)]),
     "sphx_set_rb_cg": (_i, [_vp, _vp, _vp, _i]),
+    "sphx_set_rb_cg_forces": (_i, [_vp, _vp, _vp, _i]),
+    "sphx_set_rb_cg_integration": (_i, [_vp, _vp, _vp, _i]),
     "sphx_set_rb_start": (_i, [_vp, _vp, _i]),
     "sphx_set_rb_motion": (_i, [_vp, _vp, _vp, _vp, _vp, _i]),
     "sphx_calc_hash": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp]),

@@ -59,9 +59,9 @@ euler_kernel(DevParams p, EulerArgs a)
 			if (!REPACK && IS_MOVING(info)) { // rigid motion, euler_kernel.def:470-497, applyrot euler_kernel.cu:67-74
 				const uint32_t obj = OBJECT_NUM(info);
 				const int3 gp = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-				const float rx = (gp.x - a.rb->cgGridPos[obj][0])*p.cs[0] + (pos.x - a.rb->cgPos[obj][0]);
-				const float ry = (gp.y - a.rb->cgGridPos[obj][1])*p.cs[1] + (pos.y - a.rb->cgPos[obj][1]);
-				const float rz = (gp.z - a.rb->cgGridPos[obj][2])*p.cs[2] + (pos.z - a.rb->cgPos[obj][2]);
+				const float rx = (gp.x - a.rb->cgGridPosE[obj][0])*p.cs[0] + (pos.x - a.rb->cgPosE[obj][0]);
+				const float ry = (gp.y - a.rb->cgGridPosE[obj][1])*p.cs[1] + (pos.y - a.rb->cgPosE[obj][1]);
+				const float rz = (gp.z - a.rb->cgGridPosE[obj][2])*p.cs[2] + (pos.z - a.rb->cgPosE[obj][2]);
 				const float *rot = a.rb->steprot[obj];
 				pos.x += (rot[0] - 1.0f)*rx + rot[1]*ry + rot[2]*rz;
 				pos.y += rot[3]*rx + (rot[4] - 1.0f)*ry + rot[5]*rz;

@@ -268,17 +268,23 @@ static int upload_rb(sphx_ctx *ctx)
 	return SPHX_OK;
 }
 
-extern "C" int sphx_set_rb_cg(sphx_ctx *ctx, const int32_t *cgGridPos, const float *cgPos, int numbodies)
+static int set_rb_cg(sphx_ctx *ctx, const int32_t *cgGridPos, const float *cgPos, int numbodies, bool forces, bool euler)
 {
 	SPHX_REQUIRE(ctx && cgGridPos && cgPos, "sphx_set_rb_cg: NULL argument");
 	SPHX_REQUIRE(numbodies >= 0 && numbodies <= SPHX_MAX_BODIES, "sphx_set_rb_cg: too many bodies");
 	for (int b = 0; b < numbodies; ++b)
 		for (int a = 0; a < 3; ++a) {
-			ctx->rb_host.cgGridPos[b][a] = cgGridPos[3*b + a];
-			ctx->rb_host.cgPos[b][a] = cgPos[3*b + a];
+			if (forces) { ctx->rb_host.cgGridPos[b][a] = cgGridPos[3*b + a]; ctx->rb_host.cgPos[b][a] = cgPos[3*b + a]; }
+			if (euler) { ctx->rb_host.cgGridPosE[b][a] = cgGridPos[3*b + a]; ctx->rb_host.cgPosE[b][a] = cgPos[3*b + a]; }
 		}
 	return upload_rb(ctx);
 }
+extern "C" int sphx_set_rb_cg(sphx_ctx *ctx, const int32_t *cgGridPos, const float *cgPos, int numbodies)
+{ return set_rb_cg(ctx, cgGridPos, cgPos, numbodies, true, true); }
+extern "C" int sphx_set_rb_cg_forces(sphx_ctx *ctx, const int32_t *cgGridPos, const float *cgPos, int numbodies)
+{ return set_rb_cg(ctx, cgGridPos, cgPos, numbodies, true, false); }
+extern "C" int sphx_set_rb_cg_integration(sphx_ctx *ctx, const int32_t *cgGridPos, const float *cgPos, int numbodies)
+{ return set_rb_cg(ctx, cgGridPos, cgPos, numbodies, false, true); }
 
 extern "C" int sphx_set_rb_start(sphx_ctx *ctx, const int32_t *rbfirstindex, int numbodies)
 {

@@ -80,8 +80,10 @@ struct DevParams {
 
 // rigid-body tables live in device memory owned by the ctx (1.6 KB, too big for kernarg)
 struct RbParams {
-	int   cgGridPos[SPHX_MAX_BODIES][3];
+	int   cgGridPos[SPHX_MAX_BODIES][3];    // forces engine's copy (d_rbcgGridPos/d_rbcgPos of cuforces)
 	float cgPos[SPHX_MAX_BODIES][3];
+	int   cgGridPosE[SPHX_MAX_BODIES][3];   // integration engine's copy (cueuler): the reference uploads them at different
+	float cgPosE[SPHX_MAX_BODIES][3];       // points of a step (FORCES_/EULER_UPLOAD_OBJECTS_CG)
 	int   rbstart[SPHX_MAX_BODIES];
 	float trans[SPHX_MAX_BODIES][3];
 	float steprot[SPHX_MAX_BODIES][9];

@@ -111,6 +111,11 @@ class TimestepEngine:
         if self.sps:
             self.tau = [torch.zeros((A, 2), dtype=f32, device=dev) for _ in range(3)]
             self.turbvisc = torch.zeros(A, dtype=f32, device=dev)
+        # bodies with prescribed motion: host kinematics per integrator step (MOVE_BODIES), see bodies.py
+        self.bodies = None
+        if getattr(problem, "moving_bodies_callback", None) is not None and self.num_bodies_parts:
+            from .bodies import MovingBodies
+            self.bodies = MovingBodies(problem, problem.rb_cg_global)
         self.filters = []            # [(FilterType, frequency)], Problem::addFilter order
         self.profile_forces = None   # list of (start,end) torch events around each forces launch when enabled
 
@@ -247,18 +252,38 @@ class TimestepEngine:
             for ftype, freq in self.filters:
                 if self.iterations % freq == 0:
                     self.apply_filter(ftype)
+        if self.bodies is not None:     # the callback needs t and dt on the host: one synchronisation per step
+            t_host, dt_host = float(self.d_t.item()), float(self.d_dt.item())
         # predictor: forces(step n) -> n* = n + dt/2 f
         self._forces(self.pos, self.vel, 1, 0)
+        if self.bodies is not None:
+            self._move_bodies(1, dt_host, t_host)
         self._euler(1, 0.5)
         # corrector: forces(step n*) -> n+1 = n + dt f*   (written over n*, then renamed to n)
         self._forces(self.pos2, self.vel2, 2, 1)
+        if self.bodies is not None:
+            self._move_bodies(2, dt_host, t_host)
         self._euler(2, 1.0)
+        if self.bodies is not None:     # EULER_UPLOAD_OBJECTS_CG in the post-corrector phase (PredictorCorrectorIntegrator.cc:331-332)
+            m = self._last_motion
+            capi.check(self.lib.sphx_set_rb_cg_integration(self.ctx.handle, m["cg_grid"].ctypes.data, m["cg_pos"].ctypes.data, len(self.bodies)))
         self.pos, self.pos2 = self.pos2, self.pos
         self.vel, self.vel2 = self.vel2, self.vel
         # TIME_STEP_EPILOGUE: t += dt ; dt = min(dt_pred, dt_corr)
         self.d_t.add_(self.d_dt.double())
         self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt
         self.iterations += 1
+
+    def _move_bodies(self, step, dt, t):
+        """MOVE_BODIES + UPLOAD_OBJECTS_MATRICES/VELOCITIES (+ FORCES_UPLOAD_OBJECTS_CG for bodies with force feedback),
+        src/integrators/PredictorCorrectorIntegrator.cc:550-570"""
+        m = self.bodies.timestep(step, dt, t)
+        self._last_motion = m          # keeps the host arrays alive until the calls have consumed them
+        nb = len(self.bodies)
+        capi.check(self.lib.sphx_set_rb_motion(self.ctx.handle, m["trans"].ctypes.data, m["rot"].ctypes.data,
+                                               m["lvel"].ctypes.data, m["avel"].ctypes.data, nb))
+        if self.sp.numforcesbodies > 0:
+            capi.check(self.lib.sphx_set_rb_cg_forces(self.ctx.handle, m["cg_grid"].ctypes.data, m["cg_pos"].ctypes.data, nb))
 
     def run(self, steps):
         for _ in range(steps):

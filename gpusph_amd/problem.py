@@ -75,6 +75,7 @@ class Problem:
         self.m_name = "Problem"
         self.parts = None
         self.planes = []            # [(unit normal (3), reference point (3), global coordinates)], PlaneList
+        self.moving_bodies_callback = None   # ProblemCore::moving_bodies_callback: f(index, t0, t1, initial_kdata, kdata) -> (dx, dr)
 
     def plane_tables(self):
         """plane_t arrays as ProblemCore::copy_planes hands them to setplanes: unit normal, grid cell and
@@ -411,6 +412,7 @@ class DamBreak3D(Problem):
         self.rb_firstindex = np.array([-(nf + nw)], dtype=np.int32) if no else np.zeros(0, dtype=np.int32)
         if no:
             cg = np.array([[self.OBSTACLE_XPOS + self.OBSTACLE_SIDE / 2, L[1] / 2, L[2] / 2, 0.0]])
+            self.rb_cg_global = cg[:, :3].copy()
             g = self.calc_grid_pos(cg)
             self.rb_cg_gridpos = g.astype(np.int32)
             self.rb_cg_pos = (cg[:, :3] - self.m_origin - (g + 0.5) * self.m_cellsize).astype(np.float32)

@@ -145,6 +145,11 @@ int sphx_set_planes(sphx_ctx *ctx, const float *normals, const int32_t *gridPos,
 /* AbstractForcesEngine::setrbcg / setrbstart; AbstractIntegrationEngine::setrbcg/setrbtrans/
  * setrbsteprot/setrblinearvel/setrbangularvel (src/engine_integration.h) */
 int sphx_set_rb_cg(sphx_ctx *ctx, const int32_t *h_cgGridPos3, const float *h_cgPos3, int numbodies);
+/* the two engines keep their own copy of the centres of gravity and the reference uploads them at different points of
+ * a step (FORCES_UPLOAD_OBJECTS_CG after MOVE_BODIES, EULER_UPLOAD_OBJECTS_CG after the corrector,
+ * src/integrators/PredictorCorrectorIntegrator.cc:331-332,566-570): sphx_set_rb_cg sets both, these set one */
+int sphx_set_rb_cg_forces(sphx_ctx *ctx, const int32_t *h_cgGridPos3, const float *h_cgPos3, int numbodies);
+int sphx_set_rb_cg_integration(sphx_ctx *ctx, const int32_t *h_cgGridPos3, const float *h_cgPos3, int numbodies);
 int sphx_set_rb_start(sphx_ctx *ctx, const int32_t *h_rbfirstindex, int numbodies);
 int sphx_set_rb_motion(sphx_ctx *ctx, const float *h_trans3, const float *h_steprot9,
 	const float *h_linearvel3, const float *h_angularvel3, int numbodies);

@@ -1195,9 +1195,9 @@ static void euler_body(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 				if (!repacking && MOVING(info)) {
 					int gp[3];
 					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
-					const float rx = (gp[0] - p->rbcgGridPos[obj][0])*p->cellSize[0] + (pos.x - p->rbcgPos[obj][0]);
-					const float ry = (gp[1] - p->rbcgGridPos[obj][1])*p->cellSize[1] + (pos.y - p->rbcgPos[obj][1]);
-					const float rz = (gp[2] - p->rbcgGridPos[obj][2])*p->cellSize[2] + (pos.z - p->rbcgPos[obj][2]);
+					const float rx = (gp[0] - p->rbcgGridPosE[obj][0])*p->cellSize[0] + (pos.x - p->rbcgPosE[obj][0]);
+					const float ry = (gp[1] - p->rbcgGridPosE[obj][1])*p->cellSize[1] + (pos.y - p->rbcgPosE[obj][1]);
+					const float rz = (gp[2] - p->rbcgGridPosE[obj][2])*p->cellSize[2] + (pos.z - p->rbcgPosE[obj][2]);
 					const float *rot = p->rbsteprot[obj];
 					/* applyrot, src/cuda/euler_kernel.cu:67-74 */
 					pos.x += (rot[0] - 1.0f)*rx + rot[1]*ry + rot[2]*rz;

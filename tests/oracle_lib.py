@@ -33,6 +33,7 @@ class OrcParams(C.Structure):
         ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),
         ("rbtrans", (C.c_float * 3) * 16), ("rbsteprot", (C.c_float * 9) * 16),
         ("rblinearvel", (C.c_float * 3) * 16), ("rbangularvel", (C.c_float * 3) * 16),
+        ("rbcgGridPosE", (C.c_int32 * 3) * 16), ("rbcgPosE", (C.c_float * 3) * 16),
     ]
 
 
@@ -123,8 +124,8 @@ def orc_params_from(sphx_params, problem=None):
                 o.plane_normal[k][a] = float(nrm[k][a]); o.plane_gridpos[k][a] = int(gpos[k][a]); o.plane_pos[k][a] = float(lpos[k][a])
     if problem is not None and getattr(problem, "num_obstacle", 0):
         for a in range(3):
-            o.rbcgGridPos[0][a] = int(problem.rb_cg_gridpos[0][a])
-            o.rbcgPos[0][a] = float(problem.rb_cg_pos[0][a])
+            o.rbcgGridPos[0][a] = o.rbcgGridPosE[0][a] = int(problem.rb_cg_gridpos[0][a])
+            o.rbcgPos[0][a] = o.rbcgPosE[0][a] = float(problem.rb_cg_pos[0][a])
         o.rbstartindex[0] = int(problem.rb_firstindex[0])
     return o
 
@@ -277,6 +278,23 @@ class OracleSim:
         pp, sp = problem.physparams, problem.simparams
         self.max_kinvisc = float(np.float32(max(pp.kinematicvisc))) if sp.rheologytype == D.NEWTONIAN else 0.0   # :3003-3006
         self.neibs_info = None
+        self.bodies = None
+        if getattr(problem, "moving_bodies_callback", None) is not None and getattr(problem, "num_obstacle", 0):
+            from gpusph_amd.bodies import MovingBodies
+            self.bodies = MovingBodies(problem, problem.rb_cg_global)
+
+    def _move_bodies(self, step, dt, t):
+        m = self.bodies.timestep(step, dt, t)
+        p = self.o.p
+        for b in range(len(self.bodies)):
+            for a in range(3):
+                p.rbtrans[b][a] = float(m["trans"][b][a]); p.rblinearvel[b][a] = float(m["lvel"][b][a])
+                p.rbangularvel[b][a] = float(m["avel"][b][a])
+                if self.problem.simparams.numforcesbodies > 0:
+                    p.rbcgGridPos[b][a] = int(m["cg_grid"][b][a]); p.rbcgPos[b][a] = float(m["cg_pos"][b][a])
+            for a in range(9):
+                p.rbsteprot[b][a] = float(m["rot"][b][a])
+        self._last_motion = m
 
     def build_neibs(self):
         o = self.o
@@ -346,13 +364,22 @@ class OracleSim:
         f1, cfl, nb, self.rbf, self.rbt = o.forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n,
                                                    compute_object_forces=cof, rb_count=rb, tau=tau)
         dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        if self.bodies is not None:
+            self._move_bodies(1, dt, self.t)
         ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1)
         # corrector
         tau = o.sps(ps, vs, self.info, self.hash, self.cs, self.nl, n, n)[0] if sps else None
         f2, cfl, nb, self.rbf, self.rbt = o.forces(ps, vs, self.info, self.hash, self.cs, self.nl, n,
                                                    compute_object_forces=cof, rb_count=rb, tau=tau)
         dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        if self.bodies is not None:
+            self._move_bodies(2, dt, self.t)
         self.pos, self.vel = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
+        if self.bodies is not None:
+            m = self._last_motion
+            for b in range(len(self.bodies)):
+                for a in range(3):
+                    self.o.p.rbcgGridPosE[b][a] = int(m["cg_grid"][b][a]); self.o.p.rbcgPosE[b][a] = float(m["cg_pos"][b][a])
         self.forces = f2
         self.t += dt
         self.iterations += 1

@@ -337,3 +337,25 @@ def test_neighbour_list_overflow_is_reported():
     assert info.hasMaxNeibs[0] + info.hasMaxNeibs[1] >= 63
     assert info.numInteractions == sim.neibs_info.numInteractions
     assert info.maxFluidBoundaryNeibs == sim.neibs_info.maxFluidBoundaryNeibs
+
+
+def test_body_with_prescribed_motion_trajectory():
+    """MOVE_BODIES: the engine's host kinematics (gpusph_amd/bodies.py) + separate forces / integration centres of gravity,
+    against the oracle driver running the same callback; 14 steps spanning a rebuild, a body with force feedback"""
+    from test_oracle_physics import _gate_callback
+    prob = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.05, hydrostatic=True)
+    prob.moving_bodies_callback = _gate_callback(2.0, 60.0, 2.0)
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    steps = 14
+    for _ in range(steps):
+        sim.step(); eng.step()
+    out = eng.download()
+    n = eng.n
+    assert np.array_equal(out["hash"], sim.hash[:n]) and np.array_equal(out["info"], sim.info[:n])
+    body = (out["info"][:, 0] & D.FG_MOVING_BOUNDARY) != 0
+    assert np.array_equal(out["pos"][body].view(np.uint32), sim.pos[:n][body].view(np.uint32))     # rigid rows: bit-exact
+    assert np.array_equal(out["vel"][body, :3].view(np.uint32), sim.vel[:n][body, :3].view(np.uint32))
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * np.abs(sim.vel[:n, :3]).max()
+    assert abs(eng.time() - sim.t) <= 1e-6 * sim.t

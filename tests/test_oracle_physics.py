@@ -822,3 +822,53 @@ def test_sph_f2_formulation_known_answers():
     acc[fluid, 2] += -9.81
     assert np.abs(f[fluid, :3] - acc[fluid]).max() <= 2e-4 * np.abs(acc[fluid]).max()
     assert np.abs(f[fluid, 3] - drho[fluid]).max() <= 2e-4 * np.abs(drho[fluid]).max()
+
+
+# ---------------------------------------------------------------------------------------------- prescribed body motion
+def _gate_callback(U=0.3, w=40.0, W=2.0):
+    """a body that oscillates along x and turns about z: advance kdata from t0 to t1, return (dx, dr)"""
+    def cb(index, t0, t1, kd0, kd):
+        x = lambda t: U / w * (1.0 - np.cos(w * t))
+        dx = np.array([x(t1) - x(t0), 0.0, 0.0])
+        kd.crot = kd.crot + dx
+        kd.lvel = np.array([U * np.sin(w * t1), 0.0, 0.0])
+        kd.avel = np.array([0.0, 0.0, W])
+        th = W * (t1 - t0)
+        c, s = np.cos(th), np.sin(th)
+        return dx, np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    return cb
+
+
+def test_body_with_prescribed_motion_follows_the_callback():
+    """MOVE_BODIES host kinematics (ProblemCore::bodies_timestep): predictor moves the body over [t, t+dt/2], the corrector
+    over [t, t+dt] from the state at t; its particles carry V = v + w x r; the centre used by the integration engine is
+    the one of time t during the step.  After N steps every body particle sits at R(theta) (x0 - c0) + c(t)."""
+    U, w, W = 2.0, 60.0, 2.0
+    prob = DamBreak3D(deltap=0.05, obstacle=True, jitter=0.0, hydrostatic=True)
+    prob.moving_bodies_callback = _gate_callback(U, w, W)
+    sim = ol.OracleSim(prob)
+    ids0 = info_id(prob.parts.info)
+    body0 = (prob.parts.info[:, 0] & D.FG_MOVING_BOUNDARY) != 0
+    x0 = {int(i): prob.parts.pos_global[k, :3].copy() for k, i in enumerate(ids0) if body0[k]}
+    c0 = prob.rb_cg_global[0].copy()
+    steps = 14
+    for _ in range(steps):
+        sim.step()
+    n = sim.n
+    t = sim.t
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    body = (sim.info[:n, 0] & D.FG_MOVING_BOUNDARY) != 0
+    assert body.sum() == len(x0) > 50
+    th = W * t
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    c = c0 + np.array([U / w * (1 - np.cos(w * t)), 0, 0])
+    exp = np.array([R @ (x0[int(i)] - c0) + c for i in info_id(sim.info[:n][body])])
+    assert np.abs(gp[body] - exp).max() < 5e-6                     # a product of 14 float32 step rotations
+    assert np.linalg.norm(c - c0) > 0.1 * prob.m_deltap           # it did move
+    v = sim.vel[:n][body, :3]
+    r = gp[body] - c
+    vexp = np.array([U * np.sin(w * t), 0, 0]) + np.cross(np.array([0, 0, W]), r)
+    assert np.abs(v - vexp).max() < 5e-4          # the kernel takes w x r with r of time t (euler_kernel.def:477-497)
+    assert np.allclose(sim.bodies.kdata[0].crot, c, atol=1e-12)
+    # the fluid feels it: the water next to the gate is pushed
+    assert np.abs(sim.forces[:n][(sim.info[:n, 0] & 7) == 0, :3]).max() > 9.81
