@@ -81,6 +81,7 @@ int main(int argc, char **argv)
 			const int3 g = make_int3(h.rb_cgGridPos[0], h.rb_cgGridPos[1], h.rb_cgGridPos[2]);
 			const float3 c = make_float3(h.rb_cgPos[0], h.rb_cgPos[1], h.rb_cgPos[2]);
 			forcesEngine->setrbcg(&g, &c, 1);
+			integrationEngine->setrbcg(&g, &c, 1);   // each engine keeps its own copy (uploadForces/EulerBodiesCentersOfGravity)
 			forcesEngine->setrbstart(&h.rb_firstindex, 1);
 			const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
 			const float3 z = make_float3(0, 0, 0);

@@ -463,8 +463,8 @@ public:
 		}
 		sphx_throw(sphx_set_planes(m_c->ctx(), nrm.data(), gp.data(), pos.data(), (int)planes.size()));
 	}
-	void setrbcg(const int3 *cgGridPos, const float3 *cgPos, int numbodies) override {
-		sphx_throw(sphx_set_rb_cg(m_c->ctx(), (const int32_t*)cgGridPos, (const float*)cgPos, numbodies));
+	void setrbcg(const int3 *cgGridPos, const float3 *cgPos, int numbodies) override {   // cuforces' copy
+		sphx_throw(sphx_set_rb_cg_forces(m_c->ctx(), (const int32_t*)cgGridPos, (const float*)cgPos, numbodies));
 	}
 	void setrbstart(const int *rbfirstindex, int numbodies) override { sphx_throw(sphx_set_rb_start(m_c->ctx(), rbfirstindex, numbodies)); }
 	void reduceRbForces(BufferList& bufwrite, uint *lastindex, float3 *totalforce, float3 *totaltorque,
@@ -527,8 +527,8 @@ class HIPPredCorrEngine : public AbstractIntegrationEngine {
 public:
 	explicit HIPPredCorrEngine(std::shared_ptr<HIPEngineContext> c) : m_c(c) {}
 	void setconstants(const PhysParams *, float3 const&, uint3 const&, float3 const&, idx_t const&, int const&, float const&) override {}
-	void setrbcg(const int3 *cgGridPos, const float3 *cgPos, int numbodies) override {
-		sphx_throw(sphx_set_rb_cg(m_c->ctx(), (const int32_t*)cgGridPos, (const float*)cgPos, numbodies));
+	void setrbcg(const int3 *cgGridPos, const float3 *cgPos, int numbodies) override {   // cueuler's copy
+		sphx_throw(sphx_set_rb_cg_integration(m_c->ctx(), (const int32_t*)cgGridPos, (const float*)cgPos, numbodies));
 	}
 	void setrbtrans(const float3 *trans, int n) override { sphx_throw(sphx_set_rb_motion(m_c->ctx(), (const float*)trans, nullptr, nullptr, nullptr, n)); }
 	void setrbsteprot(const float *rot, int n) override { sphx_throw(sphx_set_rb_motion(m_c->ctx(), nullptr, rot, nullptr, nullptr, n)); }
