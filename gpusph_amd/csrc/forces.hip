@@ -239,9 +239,18 @@ __device__ __forceinline__ void lj_interact(const DevParams &p, float pcx, float
 {
 	const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
 	const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+	const bool in = valid && is_active_w(npos.w) && r < p.influenceradius;
 	float ljf = 0.0f;
-	if (valid && is_active_w(npos.w) && r < p.influenceradius && r <= p.r0)
+	if (in && r <= p.r0)
 		ljf = p.dcoeff*(powf(p.r0/r, p.p1coeff) - powf(p.r0/r, p.p2coeff))/(r*r);
+	// Monaghan-Kajtar law (MKForce src/cuda/forces_kernel.cu:105-133, both masses = the central particle's, so they
+	// cancel): K w(q)/(beta max(eps, r - d) r), w = 1.8 (1 - q/2)^4 (2q + 1); chosen per lane by a mask
+	const float qq = r/p.slength, om = 1.0f - 0.5f*qq;
+	const float w = 1.8f*((om*om)*(om*om))*(2.0f*qq + 1.0f);
+	const float mkf = (in && r <= 2.0f*p.slength) ? p.MK_K*w/(p.MK_beta*fmaxf(p.epsartvisc, r - p.MK_d)*r) : 0.0f;
+	uint32_t mk = p.mk_mask;
+	asm volatile("" : "+v"(mk));
+	ljf = __uint_as_float((__float_as_uint(mkf) & mk) | (__float_as_uint(ljf) & ~mk));
 	force.x += ljf*rx; force.y += ljf*ry; force.z += ljf*rz;
 }
 

@@ -169,8 +169,8 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	// option combinations built into this library (the rest is SURVEY.md 8f "next")
 	if (sp->sph_formulation != SPHX_SPH_F1 && sp->sph_formulation != SPHX_SPH_F2)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only SPH_F1 and SPH_F2 are built");
-	if (sp->boundarytype != SPHX_DYN_BOUNDARY && sp->boundarytype != SPHX_LJ_BOUNDARY)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only DYN_BOUNDARY and LJ_BOUNDARY neighbour lists are built");
+	if (sp->boundarytype != SPHX_DYN_BOUNDARY && sp->boundarytype != SPHX_LJ_BOUNDARY && sp->boundarytype != SPHX_MK_BOUNDARY)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only DYN_BOUNDARY, LJ_BOUNDARY and MK_BOUNDARY are built (SA_BOUNDARY is not)");
 	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI &&
 		sp->densitydiffusiontype != SPHX_FERRARI)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: Brezzi density diffusion (an SA_BOUNDARY option in the reference's problems) is not built");
@@ -226,6 +226,10 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 		d.visccoeff[f] = (sp->rheologytype == SPHX_INVISCID || sp->visccoeff[f] != sp->visccoeff[f]) ? 0.0f : sp->visccoeff[f];
 	d.compvisc = sp->compvisc; d.avgop = sp->avgop; d.is_const_visc = sp->is_const_visc;
 	d.partsurf = (sp->partsurf == 0.0f) ? sp->r0*sp->r0 : sp->partsurf;
+	// MK_BOUNDARY shares every code path of LJ_BOUNDARY (lists, sections, feedback bodies, Euler) but the force law
+	d.MK_K = sp->MK_K; d.MK_d = sp->MK_d; d.MK_beta = sp->MK_beta;
+	d.mk_mask = (sp->boundarytype == SPHX_MK_BOUNDARY) ? 0xFFFFFFFFu : 0u;
+	if (sp->boundarytype == SPHX_MK_BOUNDARY) d.boundarytype = SPHX_LJ_BOUNDARY;
 	ctx->have_params = true;
 	return SPHX_OK;
 }

@@ -223,6 +223,7 @@ struct PhysParams {
 	float dcoeff = 0, p1coeff = 12, p2coeff = 6, r0 = 0;
 	float cosconeanglefluid = 0.86f, cosconeanglenonfluid = 0.5f;
 	float partsurf = 0;
+	float MK_K = 0, MK_d = 0, MK_beta = 2;
 	size_t numFluids() const { return rho0.size(); }
 };
 struct TimingInfo {   // src/timing.h:43-100
@@ -387,6 +388,7 @@ public:
 		p.dcoeff = pp->dcoeff; p.p1coeff = pp->p1coeff; p.p2coeff = pp->p2coeff; p.r0 = pp->r0;
 		p.repack_a = sp->repack_a; p.repack_alpha = sp->repack_alpha;
 		p.is_const_visc = sp->is_const_visc ? 1 : 0; p.partsurf = pp->partsurf;
+		p.MK_K = pp->MK_K; p.MK_d = pp->MK_d; p.MK_beta = pp->MK_beta;
 		sphx_throw(sphx_set_constants(ctx(), &p));
 		sphx_throw(sphx_reserve(ctx(), (uint32_t)allocatedParticles));
 	}

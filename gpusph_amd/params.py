@@ -29,6 +29,7 @@ class SphxParams(C.Structure):
         ("dcoeff", C.c_float), ("p1coeff", C.c_float), ("p2coeff", C.c_float), ("r0", C.c_float),
         ("repack_a", C.c_float), ("repack_alpha", C.c_float),
         ("is_const_visc", C.c_int32), ("partsurf", C.c_float),
+        ("MK_K", C.c_float), ("MK_d", C.c_float), ("MK_beta", C.c_float),
     ]
 
 
@@ -44,6 +45,9 @@ class PhysParams:
     kinematicvisc: list = field(default_factory=list)      # nu per fluid (physparams.h:175)
     visc_consistency: list = field(default_factory=list)   # mu per fluid for Newtonian fluids
     partsurf: float = 0.0                                  # physparams.h:328,403 (0 -> r0^2 on upload)
+    MK_K: float = float("nan")                             # physparams.h:336-338,405-407
+    MK_d: float = float("nan")
+    MK_beta: float = 2.0
     gravity: tuple = (0.0, 0.0, -9.81)
     artvisccoeff: float = 0.3          # physparams.h:392
     epsartvisc: float = float("nan")   # defaulted to 0.01 h^2 in ProblemCore.cc:160-163
@@ -216,4 +220,5 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
         const = pp.numFluids() == 1 and sp.rheologytype == D.NEWTONIAN
     p.is_const_visc = 1 if const else 0
     p.partsurf = f32(pp.partsurf)
+    p.MK_K = nz(pp.MK_K); p.MK_d = nz(pp.MK_d); p.MK_beta = nz(pp.MK_beta)
     return p

@@ -173,6 +173,11 @@ class Problem:
             if math.isnan(sp.densityDiffCoeff):
                 sp.densityDiffCoeff = float(np.float32(0.1))
             sp.densityDiffCoeff = float(np.float32(np.float32(sp.densityDiffCoeff) * np.float32(2.0) * np.float32(sp.slength)))
+        if sp.boundarytype == D.MK_BOUNDARY:         # ProblemCore.cc:141-154
+            if math.isnan(pp.MK_d):
+                pp.MK_d = float(np.float32(1.1 * self.m_deltap / pp.MK_beta))
+            if math.isnan(pp.MK_K):
+                pp.MK_K = float(np.float32(math.sqrt(sum(x * x for x in pp.gravity))))
         if sp.densitydiffusiontype == D.FERRARI:     # ProblemCore.cc:1379-1396
             if math.isnan(sp.densityDiffCoeff):
                 ls = getattr(sp, "ferrariLengthScale", float("nan"))
@@ -249,13 +254,13 @@ class DamBreak3D(Problem):
         sp.kerneltype = kerneltype
         if kerneltype == D.GAUSSIAN:
             sp.kernelradius = 3.0
-        if boundary not in (D.DYN_BOUNDARY, D.LJ_BOUNDARY):
-            raise ValueError("DamBreak3D mirror: DYN_BOUNDARY or LJ_BOUNDARY")
+        if boundary not in (D.DYN_BOUNDARY, D.LJ_BOUNDARY, D.MK_BOUNDARY):
+            raise ValueError("DamBreak3D mirror: DYN_BOUNDARY, LJ_BOUNDARY or MK_BOUNDARY")
         sp.boundarytype = boundary
-        if walls not in ("particles", "planes") or (walls == "planes" and boundary != D.LJ_BOUNDARY):
+        if walls not in ("particles", "planes") or (walls == "planes" and boundary == D.DYN_BOUNDARY):
             raise ValueError("walls: 'particles', or 'planes' with LJ_BOUNDARY (m_usePlanes)")
         self.walls = walls
-        if boundary == D.LJ_BOUNDARY:
+        if boundary in (D.LJ_BOUNDARY, D.MK_BOUNDARY):
             # one layer of repulsive particles on the box faces instead of three dynamic layers
             # (DamBreak3D.cu:74,131-134: layers only for DYN_BOUNDARY)
             self.LAYERS = 1
@@ -271,7 +276,7 @@ class DamBreak3D(Problem):
         self.linearization = linearization
         self.set_deltap(deltap)
         pp.gravity = (0.0, 0.0, -9.81)
-        if boundary == D.LJ_BOUNDARY:
+        if boundary in (D.LJ_BOUNDARY, D.MK_BOUNDARY):
             # ProblemCore::check_dt/initialize defaults: r0 = deltap, D = 5|g| (src/ProblemCore.cc:132-150)
             pp.r0 = self.m_deltap
             pp.dcoeff = 5.0 * 9.81

@@ -109,6 +109,8 @@ typedef struct sphx_params {
 	 * partsurf = particle surface for the wall friction of planes, 0 -> r0^2 (src/cuda/forces.cu:364-368) */
 	int32_t  is_const_visc;
 	float    partsurf;
+	/* Monaghan-Kajtar boundary repulsion (src/physparams.h:336-338) */
+	float    MK_K, MK_d, MK_beta;
 } sphx_params;
 
 /* TimingInfo fields filled by getinfo (src/timing.h:43-100, src/cuda/buildneibs.cu:137-145) */

@@ -475,8 +475,8 @@ static void neibs_in_cell(const orc_params *p, uint16_t *neibsList,
 		neib_type = PART_TYPE(neib_info);
 
 		/* ViscSpec::rheologytype != GRANULAR always here */
-		if (p->boundarytype == ORC_LJ_BOUNDARY && boundary && BOUNDARY(neib_info))
-			continue;
+		if ((p->boundarytype == ORC_LJ_BOUNDARY || p->boundarytype == ORC_MK_BOUNDARY) && boundary && BOUNDARY(neib_info))
+			continue;   /* src/cuda/buildneibs_kernel.cu:1061 */
 		if (p->boundarytype == ORC_DYN_BOUNDARY /* && formulation != GRENIER */) {
 			if (boundary && BOUNDARY(neib_info))
 				continue;
@@ -743,12 +743,21 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			/* repulsive boundary models: fluid <- boundary always, boundary <- fluid only for particles of bodies
 			 * with force feedback (compute_pp_interaction :3620-3645,3688-3705; compute_repulsive_force :3001-3016;
 			 * LJForce src/cuda/forces_kernel.cu:94-103, __powf -> powf) */
-			if (p->boundarytype == ORC_LJ_BOUNDARY &&
+			if ((p->boundarytype == ORC_LJ_BOUNDARY || p->boundarytype == ORC_MK_BOUNDARY) &&
 				((cptype == PT_FLUID && nptype == PT_BOUNDARY) ||
 				 (cptype == PT_BOUNDARY && nptype == PT_FLUID && COMPUTE_FORCE(info)))) {
 				float ljf = 0.0f;
-				if (r <= p->r0)
-					ljf = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
+				if (p->boundarytype == ORC_LJ_BOUNDARY) {
+					if (r <= p->r0)
+						ljf = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
+				} else if (r <= 2*p->slength) {
+					/* MKForce(r, slength, mass_f, mass_b) with both masses = the central particle's
+					 * (src/cuda/forces_kernel.cu:105-133, compute_repulsive_force :3011-3013) */
+					const float qq = r/p->slength;
+					const float w = 1.8f*powf(1.0f - 0.5f*qq, 4.0f)*(2.0f*qq + 1.0f);
+					const float dist = fmaxf(p->epsartvisc, r - p->MK_d);
+					ljf = p->MK_K*w*2*pos.w/(p->MK_beta*dist*r*(pos.w + pos.w));
+				}
 				force.x += ljf*rx; force.y += ljf*ry; force.z += ljf*rz;
 				continue;
 			}

@@ -28,6 +28,7 @@ class OrcParams(C.Structure):
         ("dcoeff", C.c_float), ("p1coeff", C.c_float), ("p2coeff", C.c_float), ("r0", C.c_float),
         ("repack_a", C.c_float), ("repack_alpha", C.c_float),
         ("is_const_visc", C.c_int32), ("partsurf", C.c_float),
+        ("MK_K", C.c_float), ("MK_d", C.c_float), ("MK_beta", C.c_float),
         ("numplanes", C.c_uint32),
         ("plane_normal", (C.c_float * 3) * 8), ("plane_gridpos", (C.c_int32 * 3) * 8), ("plane_pos", (C.c_float * 3) * 8),
         ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),

@@ -150,6 +150,27 @@ def test_sph_f2_formulation():
     assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
 
 
+def test_mk_boundary_forces_and_trajectory():
+    """MK_BOUNDARY: same lists, sections and feedback-body handling as LJ_BOUNDARY, Monaghan-Kajtar force law"""
+    prob = DamBreak3D(deltap=0.045, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.MK_BOUNDARY)
+    _check_neibs_and_forces(prob, 43, monkeypatch=None)
+    sim = ol.OracleSim(prob); sim.build_neibs()
+    f1 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, sim.n)[0]
+    sim.o.p.MK_K = 0.0
+    f0 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, sim.n)[0]
+    assert np.abs(f1[:sim.n, :3] - f0[:sim.n, :3]).max() > 100 * 2e-5 * np.abs(f1[:sim.n, :3]).max()
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    steps = 8
+    for _ in range(steps):
+        sim.step(); eng.step()
+    out = eng.download()
+    n = eng.n
+    assert np.array_equal(out["hash"], sim.hash[:n])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
+
+
 def test_two_fluids():
     """multi-fluid branch (generic kernel): per-fluid EOS, Colagrossi diffusion only between particles of the same fluid"""
     prob = DamBreak3D(deltap=0.045, obstacle=False, jitter=0.1, hydrostatic=False, two_fluids=True)

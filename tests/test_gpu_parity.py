@@ -224,7 +224,8 @@ def test_against_committed_golden_fixture():
 
 LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, viscosity="KINEMATICVISC", kinematic_visc=0.05),
             dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.LJ_BOUNDARY),
-            dict(deltap=0.04, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes")]
+            dict(deltap=0.04, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes"),
+            dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.MK_BOUNDARY)]
 
 
 @pytest.mark.parametrize("case", CASES + LJ_CASES)

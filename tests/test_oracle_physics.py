@@ -872,3 +872,36 @@ def test_body_with_prescribed_motion_follows_the_callback():
     assert np.allclose(sim.bodies.kdata[0].crot, c, atol=1e-12)
     # the fluid feels it: the water next to the gate is pushed
     assert np.abs(sim.forces[:n][(sim.info[:n, 0] & 7) == 0, :3]).max() > 9.81
+
+
+def test_mk_boundary_repulsion_equals_brute_force():
+    """MK_BOUNDARY (Monaghan & Kajtar 2009): fluid <- boundary force K w(q)/(beta max(eps, r - d) r) r_ij with
+    w = 1.8 (1 - q/2)^4 (2q + 1), q = r/h, within 2h (MKForce, src/cuda/forces_kernel.cu:105-133).  Linear in K."""
+    prob = DamBreak3D(deltap=0.05, obstacle=False, jitter=0.25, hydrostatic=False, boundary=D.MK_BOUNDARY)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    p = sim.o.p
+    K, d, beta, eps, h = float(p.MK_K), float(p.MK_d), float(p.MK_beta), float(p.epsartvisc), float(p.slength)
+    assert K == pytest.approx(9.81) and d == pytest.approx(1.1 * 0.05 / 2.0) and beta == 2.0      # ProblemCore.cc:141-154
+    f_full = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    p.MK_K = 0.0
+    f_zero = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    p.MK_K = K
+    mk = f_full[:n, :3].astype(np.float64) - f_zero[:n, :3]
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    ptype = sim.info[:n, 0] & 7
+    fl, bd = np.where(ptype == 0)[0], np.where(ptype == 1)[0]
+    from scipy.spatial import cKDTree
+    tree = cKDTree(gp[bd])
+    ref = np.zeros((n, 3))
+    for i, nb in zip(fl, tree.query_ball_point(gp[fl], 2 * h * (1 - 1e-7))):
+        if nb:
+            dd = gp[i] - gp[bd[nb]]
+            r = np.linalg.norm(dd, axis=1)
+            q = r / h
+            w = 1.8 * (1 - q / 2) ** 4 * (2 * q + 1)
+            ref[i] = ((K * w / (beta * np.maximum(eps, r - d) * r))[:, None] * dd).sum(axis=0)
+    assert (np.abs(ref).max(axis=1) > 0).sum() > 100
+    assert np.abs(mk - ref).max() <= 2e-4 * np.abs(ref).max()
+    assert not np.any(f_full[:n][ptype == 1, :3])
