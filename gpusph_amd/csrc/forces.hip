@@ -93,7 +93,7 @@ struct Self {
 	float tau[6];
 	// NEWTONIAN rheology: own viscosity terms and the averaging selectors, per lane (see laminar_factor)
 	float visc_c, visc_mu, visc_kin, visc_onemk, visc_wA, visc_wH, visc_wG;
-	uint32_t visc_constmask;
+	uint32_t visc_constmask, visc_ownmask;
 	uint32_t f2mask;   // all ones for SPH_F2 (generic kernel only), per lane like the viscosity selectors
 };
 
@@ -133,8 +133,14 @@ __device__ __forceinline__ void init_visc(const DevParams &p, Self &s)
 	float kin = (p.compvisc == SPHX_KINEMATIC) ? 1.0f : 0.0f;
 	float wA = (p.avgop == SPHX_ARITHMETIC) ? 1.0f : 0.0f, wH = (p.avgop == SPHX_HARMONIC) ? 4.0f : 0.0f,
 		wG = (p.avgop == SPHX_GEOMETRIC) ? 2.0f : 0.0f;
-	asm volatile("" : "+v"(c), "+v"(cm), "+v"(kin), "+v"(wA), "+v"(wH), "+v"(wG));   // keep them per-lane values
-	s.visc_c = c; s.visc_constmask = cm; s.visc_kin = kin; s.visc_onemk = 1.0f - kin;
+	// a single-fluid framework forced to non-constant KINEMATIC viscosity: the reference's with_computational_visc<DYNAMIC>
+	// re-derives is_const_visc = true (src/visc_spec.h:268-272,298-300, src/cuda/visc_avg.cu:180-190) and evaluates the
+	// constant dynamic formula 2 mu_i/(rho_i rho_j): mu_j := mu_i with the arithmetic weights (pinned by ref_viscavg.npz)
+	const bool own = !p.is_const_visc && p.compvisc == SPHX_KINEMATIC && !(p.simflags & SPHX_ENABLE_MULTIFLUID);
+	uint32_t om = own ? 0xFFFFFFFFu : 0u;
+	if (own) { wA = 1.0f; wH = 0.0f; wG = 0.0f; }
+	asm volatile("" : "+v"(c), "+v"(cm), "+v"(kin), "+v"(wA), "+v"(wH), "+v"(wG), "+v"(om));   // keep them per-lane values
+	s.visc_c = c; s.visc_constmask = cm; s.visc_ownmask = om; s.visc_kin = kin; s.visc_onemk = 1.0f - kin;
 	s.visc_wA = wA; s.visc_wH = wH; s.visc_wG = wG;
 	s.visc_mu = c*fmaf(kin, s.rho, s.visc_onemk);      // c rho or c, exactly
 }
@@ -143,7 +149,8 @@ __device__ __forceinline__ float laminar_factor(const DevParams &p, const Self &
 {
 	const uint32_t cb = __float_as_uint(s.visc_c), nb = __float_as_uint(visc_of(p, nfl));
 	const float nc = __uint_as_float((cb & s.visc_constmask) | (nb & ~s.visc_constmask));
-	const float nmu = nc*fmaf(s.visc_kin, n_rho, s.visc_onemk);
+	const float nmu0 = nc*fmaf(s.visc_kin, n_rho, s.visc_onemk);
+	const float nmu = __uint_as_float((__float_as_uint(s.visc_mu) & s.visc_ownmask) | (__float_as_uint(nmu0) & ~s.visc_ownmask));
 	const float S = s.visc_mu + nmu, P = s.visc_mu*nmu;
 	const float num = fmaf(s.visc_wA, S, fmaf(s.visc_wH*P, fast_rcp(fmaxf(S, 1.0e-30f)), s.visc_wG*fast_sqrt(P)));
 	return num*fast_rcp(s.rho*n_rho);

@@ -268,7 +268,7 @@ class DamBreak3D(Problem):
         sp.sph_formulation = formulation
         sp.densitydiffusiontype = density_diffusion
         sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | (D.ENABLE_MOVING_BODIES if obstacle else 0) | \
-            (D.ENABLE_PLANES if walls == "planes" else 0)
+            (D.ENABLE_PLANES if walls == "planes" else 0) | (D.ENABLE_MULTIFLUID if two_fluids else 0)
         sp.neiblistsize = 128               # resize_neiblist(128), DamBreak3D.cu:76
         if kerneltype == D.GAUSSIAN:
             sp.neiblistsize = 384           # radius 3h: ~250 neighbours in the bulk

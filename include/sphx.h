@@ -72,6 +72,7 @@ enum sphx_postproc    { SPHX_VORTICITY = 0, SPHX_TESTPOINTS = 1, SPHX_SURFACE_DE
 #define SPHX_ENABLE_DEM            (1ull << 3)
 #define SPHX_ENABLE_MOVING_BODIES  (1ull << 4)
 #define SPHX_ENABLE_REPACKING      (1ull << 9)
+#define SPHX_ENABLE_MULTIFLUID     (1ull << 11)
 
 /* Everything the three setconstants() upload (src/cuda/forces.cu:268-399,
  * src/cuda/buildneibs.cu:85-96, src/cuda/euler.cu:51-69), as one POD. */

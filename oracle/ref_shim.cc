@@ -6,6 +6,7 @@
 //   src/particleinfo.h        id(), PART_TYPE, flag predicates, object(), fluid_num()
 //   src/hashkey.h, src/multi_gpu_defines.h   cellHashFromParticleHash, CELLTYPE_* constants
 //   src/common_types.h        ENCODE_CELL / DECODE_CELL / NEIBINDEX_MASK / NEIBS_END
+//   src/cuda/visc_avg.cu      visc_avg<FullViscSpec<...>> for every computational viscosity / averaging / constness
 // Everything else on the hot path needs nvcc (__powf, texture references, thrust) or the
 // Makefile-generated options/*.opt files and is therefore NOT built (DESIGN.md "Oracle").
 // TEST INFRASTRUCTURE ONLY: used to pin oracle/sph_oracle.c and to generate tests/golden/ref_*.npz.
@@ -14,6 +15,17 @@
 #include <climits>
 #include "particledefine.h"
 #include "sph_core.cu"
+#include "visc_avg.cu"       // visc_avg<ViscSpec> in all its specialisations (+ average.h, visc_spec.h)
+
+// visc_avg of the reference for a Newtonian laminar MORRIS spec: compvisc 0/1 (KINEMATIC/DYNAMIC), avgop 0/1/2, is_const 0/1
+template<ComputationalViscosityType cv, AverageOperator av, bool cst>
+static float ref_visc_avg_t(float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
+{
+	// non-constant viscosity = a multi-fluid framework: with ENABLE_NONE the kinematic non-constant case would re-derive
+	// is_const_visc = true through with_computational_visc<DYNAMIC> (src/visc_spec.h:268-272,298-300)
+	using Spec = FullViscSpec<NEWTONIAN, LAMINAR_FLOW, cv, MORRIS, av, cst ? ENABLE_NONE : ENABLE_MULTIFLUID, cst>;
+	return visc_avg<Spec>(visc, neib_visc, rho, neib_rho, neib_mass);
+}
 
 extern "C" {
 
@@ -93,8 +105,31 @@ int ref_enum(int which)
 	case 19: return MK_BOUNDARY; case 20: return (int)ENABLE_PLANES; case 21: return (int)ENABLE_DTADAPT;
 	case 22: return MAX_PLANES; case 23: return MAX_FLUID_TYPES; case 24: return (int)FG_SURFACE;
 	case 25: return PT_TESTPOINT; case 26: return INVISCID;
+	case 27: return (int)ENABLE_MULTIFLUID; case 28: return (int)ENABLE_REPACKING; case 29: return NEWTONIAN;
+	case 30: return KINEMATIC; case 31: return DYNAMIC; case 32: return MORRIS; case 33: return ARITHMETIC;
+	case 34: return HARMONIC; case 35: return GEOMETRIC; case 36: return REPACK; case 37: return SIMULATE;
 	}
 	return -1;
 }
 
+
+// the same for a SINGLE-fluid framework (ENABLE_NONE) whose viscosity is forced non-constant (assume_const_visc<false>), kinematic
+float ref_visc_avg_singlefluid_nonconst_kinematic(int avgop, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
+{
+	switch (avgop) {
+	case 0: return visc_avg<FullViscSpec<NEWTONIAN, LAMINAR_FLOW, KINEMATIC, MORRIS, ARITHMETIC, ENABLE_NONE, false>>(visc, neib_visc, rho, neib_rho, neib_mass);
+	case 1: return visc_avg<FullViscSpec<NEWTONIAN, LAMINAR_FLOW, KINEMATIC, MORRIS, HARMONIC, ENABLE_NONE, false>>(visc, neib_visc, rho, neib_rho, neib_mass);
+	case 2: return visc_avg<FullViscSpec<NEWTONIAN, LAMINAR_FLOW, KINEMATIC, MORRIS, GEOMETRIC, ENABLE_NONE, false>>(visc, neib_visc, rho, neib_rho, neib_mass);
+	}
+	return NAN;
+}
+float ref_visc_avg(int compvisc, int avgop, int is_const, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
+{
+#define RVA(cv, av, cst) if (compvisc == cv && avgop == av && is_const == cst) \
+		return ref_visc_avg_t<(ComputationalViscosityType)cv, (AverageOperator)av, (bool)cst>(visc, neib_visc, rho, neib_rho, neib_mass);
+	RVA(0,0,0) RVA(0,1,0) RVA(0,2,0) RVA(1,0,0) RVA(1,1,0) RVA(1,2,0)
+	RVA(0,0,1) RVA(0,1,1) RVA(0,2,1) RVA(1,0,1) RVA(1,1,1) RVA(1,2,1)
+#undef RVA
+	return NAN;
+}
 } // extern "C"

@@ -61,7 +61,7 @@ def datamodel():
     enc = np.array([ref.ref_encode_cell(int(c)) for c in cells], dtype=np.uint32)
     dec = np.array([ref.ref_decode_cell(int(e) + 37) for e in enc], dtype=np.int32)
     consts = np.array([ref.ref_constant(i) for i in range(11)], dtype=np.uint32)
-    enums = np.array([ref.ref_enum(i) for i in range(27)], dtype=np.int32)
+    enums = np.array([ref.ref_enum(i) for i in range(38)], dtype=np.int32)
     wvals = np.array([0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45], dtype=np.float32)
     active = np.array([ref.ref_active(float(w)) for w in wvals], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, "ref_datamodel.npz"), info=info, id=ids, ptype=ptype, object=obj, fluid=fl,
@@ -153,6 +153,29 @@ def features():
     np.savez_compressed(os.path.join(HERE, "oracle_features.npz"), **out)
 
 
+def viscavg():
+    """the reference's own visc_avg<FullViscSpec<...>> (src/cuda/visc_avg.cu compiled as it is into oracle/_ref) on a
+    grid of viscosities, densities and masses, for the 12 (computational viscosity, average, constness) flavours"""
+    ref = ol.ref()
+    rng = np.random.default_rng(99)
+    n = 400
+    visc = rng.uniform(1e-6, 0.3, n).astype(np.float32); nvisc = rng.uniform(1e-6, 0.3, n).astype(np.float32)
+    rho = rng.uniform(800, 1100, n).astype(np.float32); nrho = rng.uniform(800, 1100, n).astype(np.float32)
+    mass = rng.uniform(1e-6, 0.2, n).astype(np.float32)
+    out = dict(visc=visc, nvisc=nvisc, rho=rho, nrho=nrho, mass=mass)
+    for cv in (0, 1):
+        for av in (0, 1, 2):
+            for cst in (0, 1):
+                out["va_%d%d%d" % (cv, av, cst)] = np.array(
+                    [ref.ref_visc_avg(cv, av, cst, float(visc[i]), float(nvisc[i]), float(rho[i]), float(nrho[i]), float(mass[i]))
+                     for i in range(n)], dtype=np.float32)
+    for av in (0, 1, 2):     # single-fluid framework forced to non-constant kinematic viscosity (with_computational_visc quirk)
+        out["va_single_0%d0" % av] = np.array(
+            [ref.ref_visc_avg_singlefluid_nonconst_kinematic(av, float(visc[i]), float(nvisc[i]), float(rho[i]), float(nrho[i]), float(mass[i]))
+             for i in range(n)], dtype=np.float32)
+    np.savez_compressed(os.path.join(HERE, "ref_viscavg.npz"), **out)
+
+
 def features2_cases():
     """(tag, problem factory) of the second feature fixture: repacking run mode and Newtonian viscosity.  Shared by
     the generator and the tests so that both rebuild the same inputs."""
@@ -200,6 +223,6 @@ def features2():
 
 
 if __name__ == "__main__":
-    kernels(); datamodel(); pipeline(); features(); features2()
+    kernels(); datamodel(); viscavg(); pipeline(); features(); features2()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

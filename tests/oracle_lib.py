@@ -72,6 +72,7 @@ def lib():
         _lib.orc_round_particles.restype = C.c_uint32; _lib.orc_round_particles.argtypes = [C.c_uint32]
         _lib.orc_calc_grid_hash.restype = C.c_uint32
         _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_visc_avg.restype = C.c_float; _lib.orc_visc_avg.argtypes = [C.c_void_p] + [C.c_float] * 5
     return _lib
 
 
@@ -98,6 +99,9 @@ def ref():
         _ref.ref_decode_cell.restype = C.c_int; _ref.ref_decode_cell.argtypes = [C.c_uint32]
         _ref.ref_constant.restype = C.c_uint32; _ref.ref_constant.argtypes = [C.c_int]
         _ref.ref_enum.restype = C.c_int; _ref.ref_enum.argtypes = [C.c_int]
+        _ref.ref_visc_avg.restype = C.c_float; _ref.ref_visc_avg.argtypes = [C.c_int] * 3 + [C.c_float] * 5
+        _ref.ref_visc_avg_singlefluid_nonconst_kinematic.restype = C.c_float
+        _ref.ref_visc_avg_singlefluid_nonconst_kinematic.argtypes = [C.c_int] + [C.c_float] * 5
     return _ref
 
 

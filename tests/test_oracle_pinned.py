@@ -94,7 +94,9 @@ def test_datamodel_matches_reference_golden():
                        D.LJ_BOUNDARY, D.PERIODIC_Z, D.SA_BOUNDARY, D.FERRARI,
                        D.SHEPARD_FILTER, D.MLS_FILTER, D.VORTICITY, D.TESTPOINTS, D.SURFACE_DETECTION,
                        D.ARTIFICIAL, D.SPS, D.LAMINAR_FLOW, D.MK_BOUNDARY, D.ENABLE_PLANES, D.ENABLE_DTADAPT,
-                       8, 4, D.FG_SURFACE, D.PT_TESTPOINT, D.INVISCID]     # 8 = SPHX_MAX_PLANES, 4 = SPHX_MAX_FLUIDS
+                       8, 4, D.FG_SURFACE, D.PT_TESTPOINT, D.INVISCID,     # 8 = SPHX_MAX_PLANES, 4 = SPHX_MAX_FLUIDS
+                       D.ENABLE_MULTIFLUID, D.ENABLE_REPACKING, D.NEWTONIAN, D.KINEMATIC, D.DYNAMIC, D.MORRIS, D.ARITHMETIC,
+                       D.HARMONIC, D.GEOMETRIC, D.REPACK, D.SIMULATE]
     assert list(np.isfinite(g["wvals"]).astype(np.int32)) == list(g["active"])
 
 
@@ -170,3 +172,31 @@ def test_oracle_features2_regression():
             f, cfl, nb, _, _ = sim.o.forces(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, n, compute_object_forces=cof, rb_count=rb)
         assert eq(f, g[tag + "_forces"]), tag
         assert np.float32(sim.o.dtreduce(cfl, nb, sim.sspeed_cfl, sim.max_kinvisc)) == g[tag + "_dt"], tag
+
+
+def test_visc_avg_matches_reference_golden():
+    """tests/golden/ref_viscavg.npz was produced by the reference's own src/cuda/visc_avg.cu (compiled unmodified into
+    oracle/_ref): the oracle's restatement of all 12 visc_avg flavours must reproduce it bit for bit."""
+    import ctypes as C
+    import oracle_lib as ol
+    g = np.load(os.path.join(GOLD, "ref_viscavg.npz"))
+    L = ol.lib()
+    p = ol.OrcParams()
+    n = len(g["visc"])
+    for av in (0, 1, 2):     # single-fluid framework forced non-constant, kinematic: the reference lands in 2 m mu_i/(rho_i rho_j)
+        p.compvisc, p.avgop, p.is_const_visc, p.simflags = 0, av, 0, 0
+        got = np.array([L.orc_visc_avg(C.byref(p), float(g["visc"][i]), float(g["nvisc"][i]), float(g["rho"][i]),
+                                       float(g["nrho"][i]), float(g["mass"][i])) for i in range(n)], dtype=np.float32)
+        assert np.array_equal(got.view(np.uint32), g["va_single_0%d0" % av].view(np.uint32)), av
+    for cv in (0, 1):
+        for av in (0, 1, 2):
+            for cst in (0, 1):
+                p.compvisc, p.avgop, p.is_const_visc = cv, av, cst
+                p.simflags = 0 if cst else (1 << 11)        # non-constant viscosity = multi-fluid framework
+                got = np.array([L.orc_visc_avg(C.byref(p), float(g["visc"][i]), float(g["nvisc"][i]), float(g["rho"][i]),
+                                               float(g["nrho"][i]), float(g["mass"][i])) for i in range(n)], dtype=np.float32)
+                ref = g["va_%d%d%d" % (cv, av, cst)]
+                if (cv, av, cst) == (0, 2, 1):      # 2 m rsqrt(rho rho'): rsqrt is not correctly rounded (host double 1/sqrt here,
+                    np.testing.assert_allclose(got, ref, rtol=2.5e-7, atol=0)       # MUFU.RSQ on the device): one ulp
+                else:
+                    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (cv, av, cst, np.abs(got - ref).max())
