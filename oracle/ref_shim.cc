@@ -7,6 +7,7 @@
 //   src/hashkey.h, src/multi_gpu_defines.h   cellHashFromParticleHash, CELLTYPE_* constants
 //   src/common_types.h        ENCODE_CELL / DECODE_CELL / NEIBINDEX_MASK / NEIBS_END
 //   src/cuda/visc_avg.cu      visc_avg<FullViscSpec<...>> for every computational viscosity / averaging / constness
+//   src/physparams.h, src/simparams.h   host parameter structs: defaults, EOS / viscosity setters, smoothing + influence radii
 // Everything else on the hot path needs nvcc (__powf, texture references, thrust) or the
 // Makefile-generated options/*.opt files and is therefore NOT built (DESIGN.md "Oracle").
 // TEST INFRASTRUCTURE ONLY: used to pin oracle/sph_oracle.c and to generate tests/golden/ref_*.npz.
@@ -16,6 +17,8 @@
 #include "particledefine.h"
 #include "sph_core.cu"
 #include "visc_avg.cu"       // visc_avg<ViscSpec> in all its specialisations (+ average.h, visc_spec.h)
+#include "physparams.h"      // PhysParams: defaults, add_fluid, set_equation_of_state, set_kinematic_visc / set_dynamic_visc
+#include "simparams.h"       // SimParams: defaults, set_smoothing / set_kernel_radius / set_influenceradius
 
 // visc_avg of the reference for a Newtonian laminar MORRIS spec: compvisc 0/1 (KINEMATIC/DYNAMIC), avgop 0/1/2, is_const 0/1
 template<ComputationalViscosityType cv, AverageOperator av, bool cst>
@@ -26,6 +29,28 @@ static float ref_visc_avg_t(float visc, float neib_visc, float rho, float neib_r
 	using Spec = FullViscSpec<NEWTONIAN, LAMINAR_FLOW, cv, MORRIS, av, cst ? ENABLE_NONE : ENABLE_MULTIFLUID, cst>;
 	return visc_avg<Spec>(visc, neib_visc, rho, neib_rho, neib_mass);
 }
+
+// client code, as a Problem / framework would write it: access to PhysParams' protected fluid setters, and the static
+// option members SimParams' constructor template reads from its framework type (src/simparams.h:261-274)
+struct ShimPhysParams : PhysParams {
+	ShimPhysParams() : PhysParams(NEWTONIAN) {}
+	using PhysParams::add_fluid; using PhysParams::set_equation_of_state;
+	using PhysParams::set_kinematic_visc; using PhysParams::set_dynamic_visc;
+};
+template<KernelType K> struct ShimFramework {
+	static constexpr KernelType kerneltype = K;
+	static constexpr SPHFormulation sph_formulation = SPH_F1;
+	static constexpr DensityDiffusionType densitydiffusiontype = DENSITY_DIFFUSION_NONE;
+	static constexpr RheologyType rheologytype = INVISCID;
+	static constexpr TurbulenceModel turbmodel = ARTIFICIAL;
+	static constexpr ComputationalViscosityType compvisc = KINEMATIC;
+	static constexpr ViscousModel viscmodel = MORRIS;
+	static constexpr AverageOperator viscavgop = ARITHMETIC;
+	static constexpr bool is_const_visc = false;
+	static constexpr BoundaryType boundarytype = DYN_BOUNDARY;
+	static constexpr Periodicity periodicbound = PERIODIC_NONE;
+	static constexpr flag_t simflags = ENABLE_DTADAPT;
+};
 
 extern "C" {
 
@@ -131,5 +156,32 @@ float ref_visc_avg(int compvisc, int avgop, int is_const, float visc, float neib
 	RVA(0,0,1) RVA(0,1,1) RVA(0,2,1) RVA(1,0,1) RVA(1,1,1) RVA(1,2,1)
 #undef RVA
 	return NAN;
+}
+
+// PhysParams as the reference builds them: one fluid (rho0, gamma, c0, nu).  out[16]
+void ref_physparams(float rho0, float gamma, float c0, float nu, float mu_second, float *out)
+{
+	ShimPhysParams pp;
+	const size_t f = pp.add_fluid(rho0);
+	pp.set_equation_of_state(f, gamma, c0);
+	pp.set_kinematic_visc(f, nu);
+	out[0] = pp.bcoeff[f]; out[1] = pp.gammacoeff[f]; out[2] = pp.sscoeff[f]; out[3] = pp.sspowercoeff[f];
+	out[4] = pp.kinematicvisc[f]; out[5] = pp.visc_consistency[f];
+	const size_t g = pp.add_fluid(rho0);
+	pp.set_dynamic_visc(g, mu_second);
+	out[6] = pp.kinematicvisc[g]; out[7] = pp.visc_consistency[g];
+	out[8] = pp.artvisccoeff; out[9] = pp.p1coeff; out[10] = pp.p2coeff; out[11] = pp.MK_beta; out[12] = pp.partsurf;
+	out[13] = pp.smagorinsky_constant; out[14] = pp.isotropic_sps_constant; out[15] = pp.cosconeanglefluid;
+	out[16] = pp.cosconeanglenonfluid; out[17] = pp.gravity.z;
+}
+// SimParams: defaults and the smoothing / influence-radius arithmetic.  out[12] (doubles)
+void ref_simparams(int gaussian, double sfactor, double deltap, double *out)
+{
+	ShimFramework<WENDLAND> fw; ShimFramework<GAUSSIAN> fg;
+	SimParams sp = gaussian ? SimParams(&fg) : SimParams(&fw);
+	out[0] = sp.sfactor; out[1] = sp.kernelradius; out[2] = sp.buildneibsfreq; out[3] = sp.dtadaptfactor;
+	out[4] = sp.repack_maxiter; out[5] = sp.repack_a; out[6] = sp.repack_alpha; out[7] = sp.nlexpansionfactor;
+	sp.set_smoothing(sfactor, deltap);
+	out[8] = sp.slength; out[9] = sp.influenceRadius; out[10] = sp.nlInfluenceRadius; out[11] = sp.nlSqInfluenceRadius;
 }
 } // extern "C"

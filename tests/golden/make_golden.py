@@ -176,6 +176,22 @@ def viscavg():
     np.savez_compressed(os.path.join(HERE, "ref_viscavg.npz"), **out)
 
 
+def hostparams():
+    """the reference's own PhysParams / SimParams (src/physparams.h, src/simparams.h compiled into oracle/_ref): defaults,
+    equation-of-state and viscosity setters, smoothing length and influence radii"""
+    ref = ol.ref()
+    cases = [(1000.0, 7.0, 20.0, 1.0e-2, 1.0e-3), (850.0, 7.0, 22.0, 3.0e-2, 0.5), (1.0, 1.4, 340.0, 1.5e-5, 1.8e-5)]
+    phys = np.zeros((len(cases), 18), dtype=np.float32)
+    for k, c in enumerate(cases):
+        ref.ref_physparams(*[float(np.float32(x)) for x in c], phys[k].ctypes.data)
+    sims = [(0, 1.3, 0.0159), (0, 1.3, 0.04), (1, 1.3, 0.05), (0, 1.5, 0.001590)]
+    sim = np.zeros((len(sims), 12), dtype=np.float64)
+    for k, c in enumerate(sims):
+        ref.ref_simparams(c[0], c[1], c[2], sim[k].ctypes.data)
+    np.savez_compressed(os.path.join(HERE, "ref_hostparams.npz"), phys_in=np.array(cases, dtype=np.float32), phys=phys,
+                        sim_in=np.array(sims, dtype=np.float64), sim=sim)
+
+
 def features2_cases():
     """(tag, problem factory) of the second feature fixture: repacking run mode and Newtonian viscosity.  Shared by
     the generator and the tests so that both rebuild the same inputs."""
@@ -223,6 +239,6 @@ def features2():
 
 
 if __name__ == "__main__":
-    kernels(); datamodel(); viscavg(); pipeline(); features(); features2()
+    kernels(); datamodel(); viscavg(); hostparams(); pipeline(); features(); features2()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

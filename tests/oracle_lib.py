@@ -100,6 +100,8 @@ def ref():
         _ref.ref_constant.restype = C.c_uint32; _ref.ref_constant.argtypes = [C.c_int]
         _ref.ref_enum.restype = C.c_int; _ref.ref_enum.argtypes = [C.c_int]
         _ref.ref_visc_avg.restype = C.c_float; _ref.ref_visc_avg.argtypes = [C.c_int] * 3 + [C.c_float] * 5
+        _ref.ref_physparams.restype = None; _ref.ref_physparams.argtypes = [C.c_float] * 5 + [C.c_void_p]
+        _ref.ref_simparams.restype = None; _ref.ref_simparams.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p]
         _ref.ref_visc_avg_singlefluid_nonconst_kinematic.restype = C.c_float
         _ref.ref_visc_avg_singlefluid_nonconst_kinematic.argtypes = [C.c_int] + [C.c_float] * 5
     return _ref

@@ -200,3 +200,32 @@ def test_visc_avg_matches_reference_golden():
                     np.testing.assert_allclose(got, ref, rtol=2.5e-7, atol=0)       # MUFU.RSQ on the device): one ulp
                 else:
                     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (cv, av, cst, np.abs(got - ref).max())
+
+
+def test_host_parameter_mirrors_match_reference_golden():
+    """tests/golden/ref_hostparams.npz was produced by the reference's own PhysParams / SimParams (compiled into oracle/_ref):
+    gpusph_amd/params.py must give the same defaults, equation-of-state and viscosity coefficients and radii."""
+    from gpusph_amd.params import PhysParams, SimParams
+    from gpusph_amd import defs as D
+    g = np.load(os.path.join(GOLD, "ref_hostparams.npz"))
+    for c, out in zip(g["phys_in"], g["phys"]):
+        pp = PhysParams()
+        f = pp.add_fluid(float(c[0]))
+        pp.set_equation_of_state(f, float(c[1]), float(c[2]))
+        pp.set_kinematic_visc(f, float(c[3]))
+        h = pp.add_fluid(float(c[0]))
+        pp.set_dynamic_visc(h, float(c[4]))
+        mine = [pp.bcoeff[f], pp.gammacoeff[f], pp.sscoeff[f], pp.sspowercoeff[f], pp.kinematicvisc[f], pp.visc_consistency[f],
+                pp.kinematicvisc[h], pp.visc_consistency[h], pp.artvisccoeff, pp.p1coeff, pp.p2coeff, pp.MK_beta, pp.partsurf,
+                pp.smagorinsky_constant, pp.isotropic_sps_constant, pp.cosconeanglefluid, pp.cosconeanglenonfluid, pp.gravity[2]]
+        assert np.array_equal(np.array(mine, dtype=np.float32).view(np.uint32), out.view(np.uint32)), (c, mine, out)
+    for c, out in zip(g["sim_in"], g["sim"]):
+        sp = SimParams()
+        if int(c[0]):
+            sp.kerneltype = D.GAUSSIAN
+            sp.kernelradius = 3.0
+        defaults = [sp.sfactor, sp.kernelradius, sp.buildneibsfreq, sp.dtadaptfactor, sp.repack_maxiter, sp.repack_a,
+                    sp.repack_alpha, sp.nlexpansionfactor]
+        assert np.array_equal(np.array(defaults, dtype=np.float32), out[:8].astype(np.float32)), (defaults, out[:8])
+        sp.set_smoothing(float(c[1]), float(c[2]))
+        assert [sp.slength, sp.influenceRadius, sp.nlInfluenceRadius, sp.nlSqInfluenceRadius] == list(out[8:12])
