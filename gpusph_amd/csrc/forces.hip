@@ -80,7 +80,12 @@ eos_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__re
 	const uint32_t fl = (p.numfluids > 1) ? FLUID_NUM(info[i]) : 0u;
 	const float ratio = vel[i].w + 1.0f;
 	const float P = p.bcoeff[fl]*(powf(ratio, p.gammacoeff[fl]) - 1.0f);
-	const float c = p.sscoeff[fl]*powf(ratio, p.sspowercoeff[fl]);
+	float c = p.sscoeff[fl]*powf(ratio, p.sspowercoeff[fl]);
+	// multi-fluid runs: the fluid number replaces the two lowest mantissa bits of the sound speed (2^-22 relative; c only
+	// enters the artificial viscosity, Ferrari and CFL terms), so that the LDS window of the tiled kernel, which holds
+	// pos / vel / this row but not the particle info, can tell same-fluid pairs and per-fluid viscosities.  Both forces
+	// kernels read the same tagged value; single-fluid runs are untouched.
+	if (p.numfluids > 1) c = __uint_as_float((__float_as_uint(c) & ~3u) | fl);
 	const float rho = ratio*p.rho0[fl];
 	aux[i] = make_float4(P/(rho*rho), c, P, rho);
 }
@@ -107,6 +112,7 @@ struct Self {
 
 // TURB template codes: the turbulence model in the low bits, SPHX_TURB_NEWT set for the NEWTONIAN rheology
 #define SPHX_TURB_NEWT 8
+#define SPHX_TURB_MF 16     // tiled kernel only: more than one fluid, the neighbour's fluid number rides in the EOS row (eos_kernel)
 #define TURB_MODEL(T) ((T) & 7)
 
 // select chain on the (at most four) kernel-argument values instead of a lane-indexed load from the argument block
@@ -654,8 +660,10 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 	const bool anyLj = LJ && wave_any(ljlane);
 #pragma unroll
 	for (int k = 0; k < TILE_HB; ++k) {
+		uint32_t nfl = 0u;
+		if (TURB & SPHX_TURB_MF) nfl = __float_as_uint(g.naux[k].y) & 3u;     // fluid number tag of the EOS row
 		pair_interact<KERNEL, TURB, COLAGROSSI, true, true>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k],
-			g.npos[k], g.nvel[k], g.naux[k], true, g.valid[k] && !(LJ && ljlane), nullptr, force, momentum, diffuse);
+			g.npos[k], g.nvel[k], g.naux[k], nfl == s.fl, g.valid[k] && !(LJ && ljlane), nullptr, force, momentum, diffuse, nfl);
 		if (anyLj)
 			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.valid[k] && ljlane, force);
 	}
@@ -960,7 +968,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		Self s;
 		s.pos = pos; s.vel = own.vel;
 		s.gridPos = grid_pos_from_hash(p, own.hash & CELLTYPE_BITMASK);
-		s.fl = 0u;
+		s.fl = (TURB & SPHX_TURB_MF) ? FLUID_NUM(info) : 0u;
 		s.p_precalc = own.aux.x; s.sspeed = own.aux.y; s.P = own.aux.z; s.rho = own.aux.w;
 		s.inv_rho = fast_rcp(own.aux.w);
 		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
@@ -1275,8 +1283,13 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 	const uint32_t *guard = use_tiles ? ctx->tile_ctl + 1 : nullptr;
 	ForcesTimer t(ctx, stream, !use_tiles);   // without tiles the generic kernel is the dominant one
 	// tiled kernel (never with Ferrari diffusion: use_tiles is false then), then the generic one, guarded by the overflow flag
+	// more than one fluid: tiled only for the Wendland kernel (every multi-fluid problem of the reference uses it), to bound
+	// the number of kernel instantiations
 #define SPHX_LAUNCH_TILE(T) do { if (use_tiles) { \
-		if (diff == DIFF_COLAGROSSI) launch_tile<KERNEL, T, DIFF_COLAGROSSI>(ctx, stream, a); \
+		if (mf) { if (KERNEL == SPHX_WENDLAND) { \
+			if (diff == DIFF_COLAGROSSI) launch_tile<SPHX_WENDLAND, (T) | SPHX_TURB_MF, DIFF_COLAGROSSI>(ctx, stream, a); \
+			else launch_tile<SPHX_WENDLAND, (T) | SPHX_TURB_MF, DIFF_NONE>(ctx, stream, a); } } \
+		else if (diff == DIFF_COLAGROSSI) launch_tile<KERNEL, T, DIFF_COLAGROSSI>(ctx, stream, a); \
 		else launch_tile<KERNEL, T, DIFF_NONE>(ctx, stream, a); } } while (0)
 #define SPHX_LAUNCH_GENERIC(T, G) do { \
 		if (diff == DIFF_COLAGROSSI) launch_forces_mf<KERNEL, T, DIFF_COLAGROSSI>(mf, grid, stream, p, a, G); \
@@ -1371,7 +1384,8 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
-		ctx->dev.numfluids == 1 && ctx->dev.turbmodel != SPHX_SPS && ctx->dev.densitydiff != SPHX_FERRARI &&
+		(ctx->dev.numfluids == 1 || ctx->dev.kerneltype == SPHX_WENDLAND) && ctx->dev.turbmodel != SPHX_SPS &&
+		ctx->dev.densitydiff != SPHX_FERRARI &&
 		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles &&
 		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
 		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&

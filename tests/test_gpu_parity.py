@@ -225,7 +225,15 @@ def test_against_committed_golden_fixture():
 LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, viscosity="KINEMATICVISC", kinematic_visc=0.05),
             dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.LJ_BOUNDARY),
             dict(deltap=0.04, obstacle=False, jitter=0.3, hydrostatic=False, boundary=D.LJ_BOUNDARY, walls="planes"),
-            dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.MK_BOUNDARY)]
+            dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, boundary=D.MK_BOUNDARY),
+            # two fluids in the tiled kernel (fluid number tag in the EOS row): Colagrossi between same-fluid pairs only,
+            # per-fluid non-constant viscosity, LJ walls
+            dict(deltap=0.04, obstacle=False, jitter=0.2, hydrostatic=False, two_fluids=True),
+            dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, two_fluids=True, kinematic_visc=0.05,
+                 viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.KINEMATIC, avgop=D.HARMONIC,
+                                is_const_visc=False)),
+            dict(deltap=0.04, obstacle=False, jitter=0.2, hydrostatic=False, two_fluids=True, boundary=D.LJ_BOUNDARY,
+                 density_diffusion=D.DENSITY_DIFFUSION_NONE)]
 
 
 @pytest.mark.parametrize("case", CASES + LJ_CASES)
