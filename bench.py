@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-obstacle", action="store_true")
     ap.add_argument("--no-tiles", action="store_true", help="A/B: use the generic gather forces kernel")
     ap.add_argument("--two-fluids", action="store_true", help="A/B: a lighter second fluid on top (multi-fluid code path)")
+    ap.add_argument("--viscosity", default=None, help="A/B: legacy viscosity selector instead of ARTVISC (KINEMATICVISC, DYNAMICVISC, SPSVISC)")
     args = ap.parse_args()
 
     if args.no_tiles:
@@ -115,7 +116,8 @@ def main():
 
     dp = DamBreak3D.deltap_for(args.particles, obstacle=not args.no_obstacle)
     lin = "xzy" if world > 1 else "yzx"   # multi-GPU: split along Y like DamBreak3D::fillDeviceMap, COORD3 = y
-    prob = DamBreak3D(dp, obstacle=not args.no_obstacle, linearization=lin, two_fluids=args.two_fluids)
+    prob = DamBreak3D(dp, obstacle=not args.no_obstacle, linearization=lin, two_fluids=args.two_fluids,
+                      viscosity=args.viscosity, kinematic_visc=1.0e-6)
     n_total = prob.num_particles
 
     if world > 1:

@@ -29,6 +29,8 @@ struct ForcesArgs {
 	const neibdata *neibsList;
 	const float2 *tau0, *tau1, *tau2;
 	const float4 *aux;   // per-particle EOS pre-pass {P/rho^2, c, P, rho}
+	const float4 *tauPack;   // SPS + tiled kernel: [0,n) = {xx,xy,xz,yy}, [n,2n) = {yz,zz,0,0} (tau_pack_kernel); tauPackN = n
+	uint32_t tauPackN;
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
 	uint32_t numBlocks;   // generic kernel: blocks of SPHX_BLOCK_FORCES particles to cover
@@ -88,6 +90,19 @@ eos_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__re
 	if (p.numfluids > 1) c = __uint_as_float((__float_as_uint(c) & ~3u) | fl);
 	const float rho = ratio*p.rho0[fl];
 	aux[i] = make_float4(P/(rho*rho), c, P, rho);
+}
+
+// SPS + tiled kernel: the three float2 arrays of BUFFER_TAU repacked as two float4 rows per particle, so that the window
+// rows can be staged with the same 16-byte LDS DMA as pos / vel / the EOS row
+__global__ void __launch_bounds__(256)
+tau_pack_kernel(const float2 *__restrict__ t0, const float2 *__restrict__ t1, const float2 *__restrict__ t2,
+	float4 *__restrict__ out, uint32_t n)
+{
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	if (i >= n) return;
+	const float2 a = t0[i], b = t1[i], c = t2[i];
+	out[i] = make_float4(a.x, a.y, b.x, b.y);
+	out[(size_t)n + i] = make_float4(c.x, c.y, 0.0f, 0.0f);
 }
 
 struct Self {
@@ -612,8 +627,11 @@ __device__ __forceinline__ void preload_list(const DevParams &p, const ListRows 
 struct WalkState { uint32_t code; bool alive; };
 
 #define TILE_HB 2   // pairs per pipeline stage ("half batch")
+// window capacity of a tiled-kernel instantiation, and the LDS placement of the SPS rows behind the EOS rows
+#define TILE_WC(T) ((TURB_MODEL(T) == SPHX_SPS) ? TILE_WCAP_SPS : TILE_WCAP)
 struct Gathered {
 	float4 npos[TILE_HB], nvel[TILE_HB], naux[TILE_HB];
+	float ntau[TILE_HB][6];   // SPS only
 	float qx[TILE_HB], qy[TILE_HB], qz[TILE_HB];
 	bool valid[TILE_HB];
 };
@@ -625,6 +643,7 @@ struct Gathered {
 // myCB[code] = LDS slot of that cell's first particle as seen from this particle's cell.  No divergent
 // branch means a whole ring step is one basic block, so the scheduler can overlap these LDS round trips
 // with the arithmetic of the previous pairs.
+template<int TURB>
 __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 	const float4 *sShift, const uint16_t *myCB, const float4 *sPos, const float4 *sVel, const float4 *sAux,
 	WalkState &w, Gathered &g)
@@ -641,6 +660,10 @@ __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 		g.qx[k] = s.pos.x + sh.x; g.qy[k] = s.pos.y + sh.y; g.qz[k] = s.pos.z + sh.z;
 		const uint32_t L = w.alive ? cb + (d & NEIBINDEX_MASK) : 0u;
 		g.npos[k] = sPos[L]; g.nvel[k] = sVel[L]; g.naux[k] = sAux[L];
+		if (TURB_MODEL(TURB) == SPHX_SPS) {   // the SPS rows lie behind the EOS rows: sAux[WC + L], sAux[2 WC + L]
+			const float4 ta = sAux[TILE_WC(TURB) + L], tb = sAux[2*TILE_WC(TURB) + L];
+			g.ntau[k][0] = ta.x; g.ntau[k][1] = ta.y; g.ntau[k][2] = ta.z; g.ntau[k][3] = ta.w; g.ntau[k][4] = tb.x; g.ntau[k][5] = tb.y;
+		}
 	}
 }
 
@@ -663,7 +686,7 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 		uint32_t nfl = 0u;
 		if (TURB & SPHX_TURB_MF) nfl = __float_as_uint(g.naux[k].y) & 3u;     // fluid number tag of the EOS row
 		pair_interact<KERNEL, TURB, COLAGROSSI, true, true>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k],
-			g.npos[k], g.nvel[k], g.naux[k], nfl == s.fl, g.valid[k] && !(LJ && ljlane), nullptr, force, momentum, diffuse, nfl);
+			g.npos[k], g.nvel[k], g.naux[k], nfl == s.fl, g.valid[k] && !(LJ && ljlane), g.ntau[k], force, momentum, diffuse, nfl);
 		if (anyLj)
 			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.valid[k] && ljlane, force);
 	}
@@ -697,16 +720,16 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 		pin_batch(list, lw.q[j]);
 	}
 	Gathered A, B;
-	gather_half(lw.q[0], s, sShift, myCB, sPos, sVel, sAux, w, A);
+	gather_half<TURB>(lw.q[0], s, sShift, myCB, sPos, sVel, sAux, w, A);
 	if (!wave_any(A.valid[0])) return;
 #define SPHX_RING_STEP(J, JN) \
-	gather_half(lw.q[J] + TILE_HB, s, sShift, myCB, sPos, sVel, sAux, w, B); \
+	gather_half<TURB>(lw.q[J] + TILE_HB, s, sShift, myCB, sPos, sVel, sAux, w, B); \
 	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, inv_h, momentum, diffuse, sec == 1, ljlane, force); \
 	if (!wave_any(B.valid[0])) return; \
 	load_list_u(p, list, voff, sec, next, lw.q[J]); \
 	pin_batch(list, lw.q[J]); \
 	++next; \
-	gather_half(lw.q[JN], s, sShift, myCB, sPos, sVel, sAux, w, A); \
+	gather_half<TURB>(lw.q[JN], s, sShift, myCB, sPos, sVel, sAux, w, A); \
 	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, inv_h, momentum, diffuse, sec == 1, ljlane, force); \
 	if (!wave_any(A.valid[0]) || next - TILE_AHEAD > lastBatch) return;   /* A now holds batch next-TILE_AHEAD */
 	for (;;) {
@@ -751,9 +774,11 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	uint32_t *tileCtl /* [0]=count, [1]=overflow, [2]=finished workgroups, [4..11]=per-XCD tile tickets */,
 	const uint32_t *__restrict__ cellEnd)
 {
-	__shared__ __attribute__((aligned(16))) float4 sPos[TILE_WCAP];
-	__shared__ __attribute__((aligned(16))) float4 sVel[TILE_WCAP];
-	__shared__ __attribute__((aligned(16))) float4 sAux[TILE_WCAP];
+	constexpr uint32_t WC = TILE_WC(TURB);
+	constexpr bool SPSW = TURB_MODEL(TURB) == SPHX_SPS;
+	__shared__ __attribute__((aligned(16))) float4 sPos[WC];
+	__shared__ __attribute__((aligned(16))) float4 sVel[WC];
+	__shared__ __attribute__((aligned(16))) float4 sAux[SPSW ? 3*WC : WC];   // SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}
 	__shared__ uint32_t sCellBase[TILE_WROWS*TILE_KW];   // LDS slot of the first particle of each window cell
 	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW];    // ... relative to the start of its window row (never modified after the scan)
 	__shared__ uint32_t sCnt[TILE_WROWS*TILE_KW];
@@ -928,17 +953,22 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			for (uint32_t r = wave; r < TILE_WROWS; r += TILE_THREADS/64) {
 				const uint32_t total = __builtin_amdgcn_readlane(rowTot, r);
 				const uint32_t base = __builtin_amdgcn_readlane(rowBase, r);
-				if (base + total > TILE_WCAP || (a.dbg & 3) == 2 || !total) continue;   // cannot overflow for tiles of build_tiles_kernel
+				if (base + total > WC || (a.dbg & 3) == 2 || !total) continue;   // cannot overflow for tiles of build_tiles_kernel
 				if (sRowContig[r]) {
 					const uint32_t rs = __builtin_amdgcn_readfirstlane(sRowStart[r]);
 					stage_row_wave(a.pos + rs, sPos + base, total, lane);
 					stage_row_wave(a.vel + rs, sVel + base, total, lane);
 					stage_row_wave(a.aux + rs, sAux + base, total, lane);
+					if (SPSW) {
+						stage_row_wave(a.tauPack + rs, sAux + WC + base, total, lane);
+						stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + 2*WC + base, total, lane);
+					}
 				} else {   // a row crossing cell-type segments (multi-GPU device maps not split on COORD3)
 					for (int col = 0; col < ncells + 2; ++col) {
 						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = base + sCellRel[r*TILE_KW + col];
 						for (uint32_t q = lane; q < cnt; q += 64u) {
 							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q]; sAux[cb + q] = a.aux[st + q];
+							if (SPSW) { sAux[WC + cb + q] = a.tauPack[st + q]; sAux[2*WC + cb + q] = a.tauPack[a.tauPackN + st + q]; }
 						}
 					}
 				}
@@ -972,6 +1002,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		s.p_precalc = own.aux.x; s.sspeed = own.aux.y; s.P = own.aux.z; s.rho = own.aux.w;
 		s.inv_rho = fast_rcp(own.aux.w);
 		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
+		if (SPSW) {   // own stress tensor (hc.li is a valid row for idle lanes too)
+			const float4 ta = a.tauPack[hc.li], tb = a.tauPack[a.tauPackN + hc.li];
+			s.tau[0] = ta.x; s.tau[1] = ta.y; s.tau[2] = ta.z; s.tau[3] = ta.w; s.tau[4] = tb.x; s.tau[5] = tb.y;
+		}
 		ListWindow lwB;
 #pragma unroll
 		for (int k = 0; k < TILE_NB; ++k) lwB.q[0][k] = own.lwB0[k];
@@ -1142,45 +1176,78 @@ struct SpsArgs {
 	uint32_t numParticles;
 };
 
-template<int KERNEL, int NPTYPE>
+// one typed section of the list, NB entries per batch like walk_section: the list entries of the next batch, the cell bases
+// and the neighbour rows of a batch are independent loads in flight together (the one-neighbour-at-a-time version spent
+// 8.6 ms per call at 8 M particles on dependent L2 round trips); branch-free, rejected pairs get weight 0
+template<int KERNEL, int NPTYPE, bool MULTIFLUID>
 __device__ __forceinline__ void sps_section(const DevParams &p, const SpsArgs &a, uint32_t index,
 	const float4 &pos, const float4 &vel, const int3 &gridPos, float inv_h, float dv[9])
 {
-	const size_t stride = p.stride;
-	size_t loc = (NPTYPE == PT_FLUID) ? (size_t)index : (size_t)p.neibboundpos*stride + index;
-	float pcx = 0.0f, pcy = 0.0f, pcz = 0.0f;
+	int slot = (NPTYPE == PT_FLUID) ? 0 : (int)p.neibboundpos;
+	uint32_t nd[NB], ndn[NB];
+	load_list_batch<NPTYPE, NB>(p, a.neibsList, index, slot, nd);
+	int cell = 0;
 	uint32_t cell_base = 0;
-	for (;;) {
-		uint32_t nd = a.neibsList[loc];
-		if (nd == NEIBS_END) break;
-		loc = (NPTYPE == PT_FLUID) ? loc + stride : loc - stride;
-		if (nd >= CELLNUM_ENCODED) {
-			const int c = (int)(nd >> CELLNUM_SHIFT) - 1;
-			nd &= NEIBINDEX_MASK;
-			const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
-			pcx = fmaf(-(float)(cx - 1), p.cs[0], pos.x);
-			pcy = fmaf(-(float)(cy - 1), p.cs[1], pos.y);
-			pcz = fmaf(-(float)(cz - 1), p.cs[2], pos.z);
-			cell_base = a.cellStart[grid_hash_periodic(p, gridPos.x + cx - 1, gridPos.y + cy - 1, gridPos.z + cz - 1)];
+	bool done = false;
+	while (!done) {
+		slot = (NPTYPE == PT_FLUID) ? slot + NB : slot - NB;
+		load_list_batch<NPTYPE, NB>(p, a.neibsList, index, slot, ndn);
+		bool valid[NB], enc[NB];
+		int c[NB];
+		uint32_t cb[NB];
+		bool alive = true;
+#pragma unroll
+		for (int k = 0; k < NB; ++k) {
+			const uint32_t d = nd[k];
+			alive = alive && (d != NEIBS_END);
+			valid[k] = alive;
+			enc[k] = alive && (d >= CELLNUM_ENCODED);
+			c[k] = enc[k] ? (int)(d >> CELLNUM_SHIFT) - 1 : (k ? c[k > 0 ? k - 1 : 0] : cell);
+			cb[k] = 0;
+			if (enc[k]) {
+				const int cz = c[k]/9, cy = (c[k] - cz*9)/3, cx = c[k] - cz*9 - cy*3;
+				cb[k] = a.cellStart[grid_hash_periodic(p, gridPos.x + cx - 1, gridPos.y + cy - 1, gridPos.z + cz - 1)];
+			}
 		}
-		const uint32_t j = cell_base + nd;
-		const float4 npos = a.pos[j];
-		const float rx = pcx - npos.x, ry = pcy - npos.y, rz = pcz - npos.z;
-		const float r = fast_sqrt(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
-		if (!is_active_w(npos.w) || r >= p.influenceradius) continue;
-		const float4 nvel = a.vel[j];
-		const uint32_t nfl = FLUID_NUM(a.info[j]);
-		const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
-		const float weight = kernel_F<KERNEL>(p, r, inv_h)*npos.w*fast_rcp(n_rho);
-		const float mx = rx*weight, my = ry*weight, mz = rz*weight;
-		const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
-		dv[0] -= vx*mx; dv[1] -= vx*my; dv[2] -= vx*mz;
-		dv[3] -= vy*mx; dv[4] -= vy*my; dv[5] -= vy*mz;
-		dv[6] -= vz*mx; dv[7] -= vz*my; dv[8] -= vz*mz;
+		done = !alive;
+#pragma unroll
+		for (int k = 0; k < NB; ++k)
+			if (!enc[k]) cb[k] = k ? cb[k > 0 ? k - 1 : 0] : cell_base;
+		cell = c[NB - 1];
+		cell_base = cb[NB - 1];
+		float4 npos[NB], nvel[NB];
+		uint32_t nfl[NB];
+#pragma unroll
+		for (int k = 0; k < NB; ++k) {
+			const uint32_t j = valid[k] ? cb[k] + (nd[k] & NEIBINDEX_MASK) : index;
+			npos[k] = a.pos[j];
+			nvel[k] = a.vel[j];
+			nfl[k] = 0u;
+			if (MULTIFLUID) nfl[k] = FLUID_NUM(a.info[j]);
+		}
+#pragma unroll
+		for (int k = 0; k < NB; ++k) {
+			const int cz = c[k]/9, cy = (c[k] - cz*9)/3, cx = c[k] - cz*9 - cy*3;
+			const float rx = fmaf(-(float)(cx - 1), p.cs[0], pos.x) - npos[k].x;
+			const float ry = fmaf(-(float)(cy - 1), p.cs[1], pos.y) - npos[k].y;
+			const float rz = fmaf(-(float)(cz - 1), p.cs[2], pos.z) - npos[k].z;
+			const float r = fast_sqrt(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+			const bool on = valid[k] && is_active_w(npos[k].w) && r < p.influenceradius;
+			const float n_rho = (nvel[k].w + 1.0f)*p.rho0[nfl[k]];
+			const float wgt = kernel_F<KERNEL>(p, r, inv_h)*npos[k].w*fast_rcp(n_rho);
+			const float weight = on ? wgt : 0.0f;
+			const float mx = rx*weight, my = ry*weight, mz = rz*weight;
+			const float vx = vel.x - nvel[k].x, vy = vel.y - nvel[k].y, vz = vel.z - nvel[k].z;
+			dv[0] -= vx*mx; dv[1] -= vx*my; dv[2] -= vx*mz;
+			dv[3] -= vy*mx; dv[4] -= vy*my; dv[5] -= vy*mz;
+			dv[6] -= vz*mx; dv[7] -= vz*my; dv[8] -= vz*mz;
+		}
+#pragma unroll
+		for (int k = 0; k < NB; ++k) nd[k] = ndn[k];
 	}
 }
 
-template<int KERNEL>
+template<int KERNEL, bool MULTIFLUID>
 __global__ void __launch_bounds__(128)
 sps_kernel(DevParams p, SpsArgs a)
 {
@@ -1193,8 +1260,8 @@ sps_kernel(DevParams p, SpsArgs a)
 	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 	const float inv_h = fast_rcp(p.slength);
 	float dv[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-	sps_section<KERNEL, PT_FLUID>(p, a, index, pos, vel, gridPos, inv_h, dv);
-	sps_section<KERNEL, PT_BOUNDARY>(p, a, index, pos, vel, gridPos, inv_h, dv);
+	sps_section<KERNEL, PT_FLUID, MULTIFLUID>(p, a, index, pos, vel, gridPos, inv_h, dv);
+	sps_section<KERNEL, PT_BOUNDARY, MULTIFLUID>(p, a, index, pos, vel, gridPos, inv_h, dv);
 
 	float txx = dv[0], txy = dv[1] + dv[3], txz = dv[2] + dv[6];
 	float tyy = dv[4], tyz = dv[5] + dv[7], tzz = dv[8];
@@ -1301,8 +1368,13 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 		SPHX_LAUNCH_GENERIC(SPHX_ARTIFICIAL, guard);
 		break;
 	case SPHX_SPS:
-		if (newt) SPHX_LAUNCH_GENERIC(SPHX_SPS | SPHX_TURB_NEWT, nullptr);
-		else SPHX_LAUNCH_GENERIC(SPHX_SPS, nullptr);
+		if (newt) {
+			SPHX_LAUNCH_TILE(SPHX_SPS | SPHX_TURB_NEWT);
+			SPHX_LAUNCH_GENERIC(SPHX_SPS | SPHX_TURB_NEWT, guard);
+		} else {
+			SPHX_LAUNCH_TILE(SPHX_SPS);
+			SPHX_LAUNCH_GENERIC(SPHX_SPS, guard);
+		}
 		break;
 	case SPHX_LAMINAR_FLOW:
 		if (newt) {
@@ -1384,12 +1456,20 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
-		(ctx->dev.numfluids == 1 || ctx->dev.kerneltype == SPHX_WENDLAND) && ctx->dev.turbmodel != SPHX_SPS &&
+		(ctx->dev.numfluids == 1 || ctx->dev.kerneltype == SPHX_WENDLAND) &&
 		ctx->dev.densitydiff != SPHX_FERRARI &&
 		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles &&
 		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
 		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
 		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
+	a.tauPack = nullptr; a.tauPackN = 0;
+	if (use_tiles && ctx->dev.turbmodel == SPHX_SPS) {   // window rows of the stress tensor (see tau_pack_kernel)
+		SPHX_REQUIRE(ctx->tau_pack != nullptr && numParticles <= ctx->reserved_particles, "sphx_forces_basicstep: SPS scratch not reserved");
+		tau_pack_kernel<<<div_up_u(numParticles, 256), 256, 0, (hipStream_t)stream>>>((const float2*)tau0, (const float2*)tau1,
+			(const float2*)tau2, ctx->tau_pack, numParticles);
+		SPHX_LAUNCH_CHECK("tau_pack_kernel");
+		a.tauPack = ctx->tau_pack; a.tauPackN = numParticles;
+	}
 	int rc;
 	switch (ctx->dev.kerneltype) {
 	case SPHX_CUBICSPLINE: rc = launch_forces_k<SPHX_CUBICSPLINE>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
@@ -1488,10 +1568,13 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
 	const dim3 grid(div_up_u(particleRangeEnd, 128));
 	switch (ctx->dev.kerneltype) {
-	case SPHX_CUBICSPLINE: sps_kernel<SPHX_CUBICSPLINE><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); break;
-	case SPHX_QUADRATIC:   sps_kernel<SPHX_QUADRATIC><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); break;
-	case SPHX_WENDLAND:    sps_kernel<SPHX_WENDLAND><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); break;
-	default:               sps_kernel<SPHX_GAUSSIAN><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); break;
+#define SPHX_SPS_LAUNCH(K) do { if (ctx->dev.numfluids > 1) sps_kernel<K, true><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); \
+		else sps_kernel<K, false><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); } while (0)
+	case SPHX_CUBICSPLINE: SPHX_SPS_LAUNCH(SPHX_CUBICSPLINE); break;
+	case SPHX_QUADRATIC:   SPHX_SPS_LAUNCH(SPHX_QUADRATIC); break;
+	case SPHX_WENDLAND:    SPHX_SPS_LAUNCH(SPHX_WENDLAND); break;
+	default:               SPHX_SPS_LAUNCH(SPHX_GAUSSIAN); break;
+#undef SPHX_SPS_LAUNCH
 	}
 	SPHX_LAUNCH_CHECK("sps_kernel");
 	return SPHX_OK;

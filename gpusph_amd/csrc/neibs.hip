@@ -662,6 +662,7 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 	const uint32_t *__restrict__ cols, uint32_t rangeEnd,
 	uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t capacity)
 {
+	const uint32_t wcap = (p.turbmodel == SPHX_SPS) ? TILE_WCAP_SPS : TILE_WCAP;   // the SPS window also holds tau
 	const int gs1 = p.gs1;
 	const int gs2 = (p.c2 == 0) ? p.gs[0] : (p.c2 == 1) ? p.gs[1] : p.gs[2];
 	const int gs3 = (p.c3 == 0) ? p.gs[0] : (p.c3 == 1) ? p.gs[1] : p.gs[2];
@@ -716,7 +717,7 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 			ncol += n4[r];
 			if (n4[r] && hc[r] && st4[r] != first[r] + hc[r]) contiguous = false;
 		}
-		const bool fits = hsum && ncol && (hsum + ncol <= TILE_THREADS) && (wc + cs_next <= TILE_WCAP) &&
+		const bool fits = hsum && ncol && (hsum + ncol <= TILE_THREADS) && (wc + cs_next <= wcap) &&
 			(c - ca + 1 <= TILE_MAXCELLS) && contiguous;
 		if (fits) {
 			for (int r = 0; r < TILE_HROWS; ++r) { if (n4[r] && !hc[r]) first[r] = st4[r]; hc[r] += n4[r]; }
@@ -729,7 +730,7 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 				ca = c; hsum = ncol;
 				for (int r = 0; r < TILE_HROWS; ++r) { hc[r] = n4[r]; first[r] = st4[r]; }
 				wc = cs_prev + cs_cur + cs_next; wfl = f_prev | f_cur | f_next;
-				if (ncol > TILE_THREADS || wc > TILE_WCAP) ctl[1] = 1u;   // would not fit: generic kernel
+				if (ncol > TILE_THREADS || wc > wcap) ctl[1] = 1u;   // would not fit: generic kernel
 			}
 		}
 		cs_prev = cs_cur; cs_cur = cs_next; f_prev = f_cur; f_cur = f_next;

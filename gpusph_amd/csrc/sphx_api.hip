@@ -48,12 +48,12 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
-		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols };
+		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tau_pack, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
-	ctx->eos_aux = nullptr;
+	ctx->eos_aux = nullptr; ctx->tau_pack = nullptr;
 	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr; ctx->cell_fluid_end = nullptr; ctx->tile_cols = nullptr;
 	ctx->tile_capacity = 0; ctx->cells_reserved = 0; ctx->tiles_built = false;
 	ctx->reserved_particles = ctx->reserved_bins = 0;
@@ -98,6 +98,8 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_index, sizeof(uint32_t)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_info, sizeof(uint2)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->eos_aux, sizeof(float4)*(size_t)n));
+	if (ctx->dev.turbmodel == SPHX_SPS)
+		SPHX_HIP(hipMalloc((void**)&ctx->tau_pack, sizeof(float4)*2*(size_t)n));
 	ctx->tile_capacity = n/8 + 4096;
 	SPHX_HIP(hipMalloc((void**)&ctx->tiles, sizeof(uint32_t)*TILE_DESC*(size_t)ctx->tile_capacity));
 	ctx->cells_reserved = (bins - 1)/4;

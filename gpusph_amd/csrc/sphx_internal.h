@@ -35,6 +35,7 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #ifndef TILE_THREADS
 #define TILE_THREADS  512                  // home particles per tile (one thread each), 8 waves
 #define TILE_WCAP     3200                 // window records that fit LDS (48 B each, 1 workgroup per CU)
+#define TILE_WCAP_SPS 1900                 // ... with the SPS stress tensor of every window particle (80 B each)
 #define TILE_WGS_PER_CU 1                  // persistent workgroups per CU (LDS bound)
 #endif
 #define TILE_HROWS    4                    // home rows: 2 (COORD2) x 2 (COORD3)
@@ -121,6 +122,7 @@ struct sphx_ctx {
 	uint32_t   *tmp_index;     // [n]
 	uint2      *tmp_info;      // [n] particleinfo as 8 bytes
 	float4     *eos_aux;       // [n] per-particle EOS pre-pass of the forces engine
+	float4     *tau_pack;      // [2n] SPS: tau repacked as two float4 rows per particle for the LDS window (tiled kernel)
 	float      *dt_scratch;    // 1 float, for the sync dtreduce
 	// forces tiles, built by sphx_build_neibs
 	uint32_t   *tiles;         // [tile_capacity][TILE_DESC]

@@ -233,7 +233,10 @@ LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, visc
                  viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.KINEMATIC, avgop=D.HARMONIC,
                                 is_const_visc=False)),
             dict(deltap=0.04, obstacle=False, jitter=0.2, hydrostatic=False, two_fluids=True, boundary=D.LJ_BOUNDARY,
-                 density_diffusion=D.DENSITY_DIFFUSION_NONE)]
+                 density_diffusion=D.DENSITY_DIFFUSION_NONE),
+            # SPS stress tensor rows in the LDS window (smaller window capacity): WaveTank's viscosity<SPSVISC>, and two fluids
+            dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, viscosity="SPSVISC", kinematic_visc=1.0e-3),
+            dict(deltap=0.03, obstacle=False, jitter=0.2, hydrostatic=True, viscosity="SPSVISC", kinematic_visc=1.0e-6, two_fluids=True)]
 
 
 @pytest.mark.parametrize("case", CASES + LJ_CASES)
