@@ -255,6 +255,8 @@ class MultiGpuEngine:
     def _forces_pass(self, pos, vel, combine_min):
         K = self.k
         K.memset(self.cfl, 0)
+        if self.rbforces is not None:      # rows of body particles owned by other ranks must read zero in the reduction
+            K.memset(self.rbforces, 0); K.memset(self.rbtorques, 0)
         prof = self.profile_forces is not None and self.is_cuda
         if prof:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -314,6 +316,18 @@ class MultiGpuEngine:
 
     def current_dt(self):
         return float(self.d_dt.item())
+
+    def reduce_rb_forces(self):
+        """REDUCE_BODIES_FORCES + REDUCE_BODIES_FORCES_HOST (src/GPUSPH.cc): total force and torque on the feedback body,
+        per device over the rows of its own particles, then summed over the devices (one all_reduce of 6 floats).
+        The order of the float sum is implementation-defined in the reference too (thrust scan): tolerance-only."""
+        if self.rbforces is None:
+            return None
+        tot = torch.cat([self.rbforces[:, :3].double().sum(0), self.rbtorques[:, :3].double().sum(0)])
+        if self.world > 1:
+            self.dist.all_reduce(tot)
+        tot = tot.cpu().numpy()
+        return tot[:3].astype(np.float32), tot[3:].astype(np.float32)
 
     def download_internal(self):
         n = self.n_int

@@ -34,8 +34,9 @@ def _worker(rank, world, port, steps, case, outdir):
     for _ in range(steps):
         eng.step()
     out = eng.download_internal()
+    rb = eng.reduce_rb_forces()
     np.savez(os.path.join(outdir, "r%d_of_%d.npz" % (rank, world)), n_local=eng.n_local, dt=eng.current_dt(),
-             interactions=eng.neibs_info().numInteractions, **out)
+             interactions=eng.neibs_info().numInteractions, rbf=rb[0], rbt=rb[1], **out)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
 
@@ -81,6 +82,12 @@ def test_slab_runs_equal_single_domain(tmp_path, world, lin):
     assert all(float(p["dt"]) == float(p1[0]["dt"]) for p in pN)
     assert sum(int(p["interactions"]) for p in pN) == int(p1[0]["interactions"])
     assert all(int(p["n_local"]) > len(p["pos"]) for p in pN)      # every rank holds a halo
+    # total force / torque on the feedback body: every rank gets the all-reduced sum, equal to the single-domain one
+    scale = max(np.abs(p1[0]["rbf"]).max(), 1e-12)
+    assert scale > 0
+    for p in pN:
+        assert np.abs(p["rbf"] - p1[0]["rbf"]).max() <= 1e-5 * scale
+        assert np.abs(p["rbt"] - p1[0]["rbt"]).max() <= 1e-5 * max(np.abs(p1[0]["rbt"]).max(), 1e-12)
 
 
 def test_partition_and_device_map():
