@@ -93,12 +93,13 @@ class HipKernels:
         return info
 
     # ---- AbstractForcesEngine
-    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset):
+    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset, tau=None):
         p = capi.ptr
+        t0, t1, t2 = (p(t) for t in tau) if tau is not None else (None, None, None)
         nb = C.c_uint32(0)
         P = self.params
         capi.check(self.lib.sphx_forces_basicstep(self.ctx.handle, p(forces), p(cfl), p(rbforces), p(rbtorques), p(pos), p(vel),
-                                                  p(info), p(hash_), p(cellStart), p(neibslist), None, None, None,
+                                                  p(info), p(hash_), p(cellStart), p(neibslist), t0, t1, t2,
                                                   n, frm, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius,
                                                   cfl_offset, D.SIMULATE, 1, 0.0, self.compute_object_forces,
                                                   C.byref(nb), self._s()))
@@ -109,6 +110,19 @@ class HipKernels:
         P = self.params
         capi.check(self.lib.sphx_forces_dtreduce_device(self.ctx.handle, P.slength, P.dtadaptfactor, self.sspeed_cfl, self.max_kinvisc,
                                                         p(cfl), p(cfl_temp), nblocks, p(d_dt), combine_min, self._s()))
+
+    # ---- AbstractViscEngine / AbstractFilterEngine
+    def calc_visc(self, tau, pos, vel, info, hash_, cellStart, neibslist, n, range_end):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_calc_visc(self.ctx.handle, p(tau[0]), p(tau[1]), p(tau[2]), None, p(pos), p(vel), p(info), p(hash_),
+                                           p(cellStart), p(neibslist), n, range_end, P.deltap, P.slength, P.influenceradius, self._s()))
+
+    def filter(self, filtertype, newvel, pos, oldvel, info, hash_, cellStart, neibslist, n, range_end):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_filter_process(self.ctx.handle, filtertype, p(newvel), p(pos), p(oldvel), p(info), p(hash_),
+                                                p(cellStart), p(neibslist), n, range_end, P.slength, P.influenceradius, self._s()))
 
     # ---- AbstractIntegrationEngine
     def euler(self, npos, nvel, opos, ovel, info, hash_, forces, n, d_dt, dt_scale, step):

@@ -132,6 +132,11 @@ class MultiGpuEngine:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.overlap else None
         self.profile_forces = None
         self.track_particle_count = track_particle_count
+        # SPS: BUFFER_TAU as three float2 arrays, computed for the internal particles before each forces pass and imported
+        # for the halo (CALC_VISC + UPDATE_EXTERNAL, src/integrators/PredictorCorrectorIntegrator.cc:460-480)
+        self.sps = self.sp.turbmodel == D.SPS
+        self.tau = [torch.zeros((A, 2), dtype=f32, device=dev) for _ in range(3)] if self.sps else None
+        self.filters = []            # [(FilterType, frequency)]
 
     # ------------------------------------------------------------------ exchange
     def _neighbours(self):
@@ -261,14 +266,19 @@ class MultiGpuEngine:
         if prof:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
+        if self.sps:
+            K.calc_visc(self.tau, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, self.n_int)
+            if self.world > 1:
+                self._exchange(self.tau)
         args = (self.forces, self.cfl, self.rbforces, self.rbtorques, pos, vel, self.info, self.hash, self.cellStart,
                 self.neibslist, self.n_local)
+        kw = dict(tau=self.tau) if self.sps else {}
         if self.world > 1 and self.n_int > self.edge_start:
             # edge stripe first, then the inner stripe while the edge forces travel
-            nb1 = K.forces(*args, self.edge_start, self.n_int, 0)
+            nb1 = K.forces(*args, self.edge_start, self.n_int, 0, **kw)
             if self.overlap:
                 ev = torch.cuda.Event(); ev.record()
-            nb2 = K.forces(*args, 0, self.edge_start, nb1)
+            nb2 = K.forces(*args, 0, self.edge_start, nb1, **kw)
             if prof:
                 e1.record(); self.profile_forces.append((e0, e1))
             if self.overlap:
@@ -279,7 +289,7 @@ class MultiGpuEngine:
             else:
                 self._exchange([self.forces])
         else:
-            nb1 = K.forces(*args, 0, self.n_int, 0)
+            nb1 = K.forces(*args, 0, self.n_int, 0, **kw)
             nb2 = 0
             if prof:
                 e1.record(); self.profile_forces.append((e0, e1))
@@ -292,6 +302,13 @@ class MultiGpuEngine:
         if self.iterations % self.sp.buildneibsfreq == 0:
             self.build_neibs()
         n = self.n_local
+        if self.iterations > 0:      # FILTER phases: internal particles, then UPDATE_EXTERNAL of the velocity buffer
+            for ftype, freq in self.filters:
+                if self.iterations % freq == 0:
+                    K.filter(ftype, self.vel2, self.pos, self.vel, self.info, self.hash, self.cellStart, self.neibslist, n, self.n_int)
+                    if self.world > 1:
+                        self._exchange([self.vel2])
+                    self.vel, self.vel2 = self.vel2, self.vel
         self._forces_pass(self.pos, self.vel, 0)
         K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1)
         self._forces_pass(self.pos2, self.vel2, 1)
@@ -313,6 +330,9 @@ class MultiGpuEngine:
 
     def neibs_info(self):
         return self.k.neibs_info()
+
+    def add_filter(self, filtertype, frequency):
+        self.filters.append((int(filtertype), int(frequency)))
 
     def current_dt(self):
         return float(self.d_dt.item())

@@ -24,6 +24,7 @@ class OracleKernels:
         self.sq = float(np.float32(s.nlSqInfluenceRadius))
         self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(problem.physparams.sscoeff))) * 1.1))
         self.info_ = ol.OrcNeibsInfo()
+        self.max_kinvisc = float(np.float32(max(problem.physparams.kinematicvisc))) if s.rheologytype == 1 else 0.0
 
     def fmax_elements(self, n):
         return int(self.L.orc_fmax_elements(C.c_uint32(n)))
@@ -57,16 +58,28 @@ class OracleKernels:
     def neibs_info(self):
         return self.info_
 
-    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset):
+    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset, tau=None):
         if to > frm:
             forces[frm:to] = 0          # pre_forces clobber (GPUWorker.cc:1949); the oracle does the reference's RMW
         self.L.orc_forces.restype = C.c_uint32
+        tau6 = torch.cat(list(tau), dim=1).contiguous() if tau is not None else None      # oracle layout: 6 floats per particle
         return int(self.L.orc_forces(C.byref(self.op), _p(forces), _p(cfl), _p(rbforces), _p(rbtorques), _p(pos), _p(vel),
-                                     _p(info), _p(hash_), _p(cellStart), _p(neibslist), None, C.c_uint32(n), C.c_uint32(frm),
+                                     _p(info), _p(hash_), _p(cellStart), _p(neibslist), _p(tau6), C.c_uint32(n), C.c_uint32(frm),
                                      C.c_uint32(to), C.c_uint32(cfl_offset), C.c_int(self.compute_object_forces)))
 
+    def calc_visc(self, tau, pos, vel, info, hash_, cellStart, neibslist, n, range_end):
+        tau6 = torch.zeros((len(pos), 6), dtype=torch.float32)
+        self.L.orc_sps(C.byref(self.op), _p(tau6), None, _p(pos), _p(vel), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
+                       C.c_uint32(n), C.c_uint32(range_end))
+        for k in range(3):
+            tau[k][:range_end] = tau6[:range_end, 2 * k:2 * k + 2]
+
+    def filter(self, filtertype, newvel, pos, oldvel, info, hash_, cellStart, neibslist, n, range_end):
+        fn = self.L.orc_shepard if filtertype == 0 else self.L.orc_mls
+        fn(C.byref(self.op), _p(newvel), _p(pos), _p(oldvel), _p(info), _p(hash_), _p(cellStart), _p(neibslist), C.c_uint32(range_end))
+
     def dtreduce(self, cfl, cfl_temp, nblocks, d_dt, combine_min):
-        dt = float(self.L.orc_dtreduce(C.byref(self.op), _p(cfl), C.c_uint32(nblocks), C.c_float(self.sspeed_cfl), C.c_float(0.0)))
+        dt = float(self.L.orc_dtreduce(C.byref(self.op), _p(cfl), C.c_uint32(nblocks), C.c_float(self.sspeed_cfl), C.c_float(self.max_kinvisc)))
         d_dt[0] = min(float(d_dt[0]), dt) if combine_min else dt
 
     def euler(self, npos, nvel, opos, ovel, info, hash_, forces, n, d_dt, dt_scale, step):

@@ -278,15 +278,24 @@ def test_multigpu_engine_world1_equals_single_engine():
     assert a.current_dt() == b.current_dt()
 
 
-def _mg_worker(rank, world, port, outdir):
+_MG_CASES = {
+    "default": (dict(), ()),
+    "spsvisc+shepard": (dict(viscosity="SPSVISC", kinematic_visc=1.0e-6), ((0, 4),)),
+}
+
+
+def _mg_worker(rank, world, port, outdir, casename):
     import os, sys
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     import torch
     import torch.distributed as dist
     from gpusph_amd.multigpu import MultiGpuEngine
     dist.init_process_group("gloo", rank=rank, world_size=world)      # one GPU on this box: RCCL needs one per rank
-    prob = DamBreak3D(0.03, obstacle=True, jitter=0.05, linearization="xzy")
+    kw, filters = _MG_CASES[casename]
+    prob = DamBreak3D(0.03, obstacle=True, jitter=0.05, linearization="xzy", **kw)
     eng = MultiGpuEngine(prob, "cuda:0", rank, world)
+    for f in filters:
+        eng.add_filter(*f)
     for _ in range(12):
         eng.step()
     torch.cuda.synchronize()
@@ -295,16 +304,20 @@ def _mg_worker(rank, world, port, outdir):
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path):
+@pytest.mark.parametrize("casename", sorted(_MG_CASES))
+def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename):
     """the real HIP kernels under the slab decomposition (2 ranks sharing the one GPU of this box, host-staged
     gloo transport standing in for RCCL): bit-identical to the single-domain run, including the overlapped
     edge-stripe / inner-stripe forces"""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    mp.spawn(_mg_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    prob = DamBreak3D(0.03, obstacle=True, jitter=0.05, linearization="xzy")
+    mp.spawn(_mg_worker, args=(2, port, str(tmp_path), casename), nprocs=2, join=True)
+    kw, filters = _MG_CASES[casename]
+    prob = DamBreak3D(0.03, obstacle=True, jitter=0.05, linearization="xzy", **kw)
     ref = _engine(prob)
+    for f in filters:
+        ref.add_filter(*f)
     for _ in range(12):
         ref.step()
     n = ref.n

@@ -17,7 +17,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, steps, case, outdir):
+def _worker(rank, world, port, steps, case, outdir, filters=()):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -31,6 +31,8 @@ def _worker(rank, world, port, steps, case, outdir):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     prob = DamBreak3D(**case)
     eng = MultiGpuEngine(prob, "cpu", rank, world, kernels=None if False else _mk(prob, rank, world))
+    for ftype, freq in filters:
+        eng.add_filter(ftype, freq)
     for _ in range(steps):
         eng.step()
     out = eng.download_internal()
@@ -51,12 +53,12 @@ def _mk(prob, rank, world):
     return OracleKernels(prob, int(n0 * 1.25) + 4096)
 
 
-def _run(world, steps, case, outdir):
+def _run(world, steps, case, outdir, filters=()):
     port = _free_port()
     if world == 1:
-        _worker(0, 1, port, steps, case, outdir)
+        _worker(0, 1, port, steps, case, outdir, filters)
     else:
-        mp.spawn(_worker, args=(world, port, steps, case, outdir), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, port, steps, case, outdir, filters), nprocs=world, join=True)
 
 
 def _gather(outdir, world):
@@ -88,6 +90,23 @@ def test_slab_runs_equal_single_domain(tmp_path, world, lin):
     for p in pN:
         assert np.abs(p["rbf"] - p1[0]["rbf"]).max() <= 1e-5 * scale
         assert np.abs(p["rbt"] - p1[0]["rbt"]).max() <= 1e-5 * max(np.abs(p1[0]["rbt"]).max(), 1e-12)
+
+
+def test_slab_run_with_sps_and_shepard_filter_equals_single_domain(tmp_path):
+    """WaveTank's option set over two slabs: viscosity<SPSVISC> (stress tensor computed for the internal particles and
+    imported for the halo before each forces pass) and a Shepard filter every 4 iterations (filtered velocities imported
+    for the halo): bit-equal to the single-domain run"""
+    case = dict(deltap=0.04, obstacle=True, linearization="xzy", jitter=0.05, viscosity="SPSVISC", kinematic_visc=1.0e-6)
+    filters = ((0, 4),)
+    steps = 12
+    _run(1, steps, case, str(tmp_path), filters)
+    _run(2, steps, case, str(tmp_path), filters)
+    ids1, one, p1 = _gather(str(tmp_path), 1)
+    ids2, two, p2 = _gather(str(tmp_path), 2)
+    assert np.array_equal(ids1, ids2)
+    for k in ("pos", "vel", "forces"):
+        assert np.array_equal(one[k].view(np.uint32), two[k].view(np.uint32)), k
+    assert all(float(p["dt"]) == float(p1[0]["dt"]) for p in p2)
 
 
 def test_partition_and_device_map():
