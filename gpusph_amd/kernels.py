@@ -45,6 +45,17 @@ class HipKernels:
             capi.check(self.lib.sphx_set_rb_motion(self.ctx.handle, z3.ctypes.data, ident.ctypes.data,
                                                    z3.ctypes.data, z3.ctypes.data, nb))
 
+    # ---- MOVE_BODIES uploads (see gpusph_amd/bodies.py); `m` keeps its host arrays alive until the calls return
+    def set_body_motion(self, m, forces_cg):
+        nb = len(m["trans"])
+        capi.check(self.lib.sphx_set_rb_motion(self.ctx.handle, m["trans"].ctypes.data, m["rot"].ctypes.data,
+                                               m["lvel"].ctypes.data, m["avel"].ctypes.data, nb))
+        if forces_cg:
+            capi.check(self.lib.sphx_set_rb_cg_forces(self.ctx.handle, m["cg_grid"].ctypes.data, m["cg_pos"].ctypes.data, nb))
+
+    def set_body_cg_integration(self, m):
+        capi.check(self.lib.sphx_set_rb_cg_integration(self.ctx.handle, m["cg_grid"].ctypes.data, m["cg_pos"].ctypes.data, len(m["trans"])))
+
     # ---- helpers
     def _s(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)

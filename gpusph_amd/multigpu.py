@@ -137,6 +137,12 @@ class MultiGpuEngine:
         self.sps = self.sp.turbmodel == D.SPS
         self.tau = [torch.zeros((A, 2), dtype=f32, device=dev) for _ in range(3)] if self.sps else None
         self.filters = []            # [(FilterType, frequency)]
+        # bodies with prescribed motion: every rank runs the same host kinematics (the callback is a pure function of time)
+        self.bodies = None
+        if getattr(problem, "moving_bodies_callback", None) is not None and getattr(problem, "num_obstacle", 0):
+            from .bodies import MovingBodies
+            self.bodies = MovingBodies(problem, problem.rb_cg_global)
+        self.t_host = 0.0
 
     # ------------------------------------------------------------------ exchange
     def _neighbours(self):
@@ -309,10 +315,19 @@ class MultiGpuEngine:
                     if self.world > 1:
                         self._exchange([self.vel2])
                     self.vel, self.vel2 = self.vel2, self.vel
+        if self.bodies is not None:
+            dt_host = float(self.d_dt.item())       # the callback needs dt on the host: one synchronisation per step
         self._forces_pass(self.pos, self.vel, 0)
+        if self.bodies is not None:
+            m = self.bodies.timestep(1, dt_host, self.t_host); K.set_body_motion(m, self.sp.numforcesbodies > 0)
         K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1)
         self._forces_pass(self.pos2, self.vel2, 1)
+        if self.bodies is not None:
+            m = self.bodies.timestep(2, dt_host, self.t_host); K.set_body_motion(m, self.sp.numforcesbodies > 0)
         K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2)
+        if self.bodies is not None:
+            K.set_body_cg_integration(m)
+            self.t_host += dt_host
         self.pos, self.pos2 = self.pos2, self.pos
         self.vel, self.vel2 = self.vel2, self.vel
         if self.world > 1:

@@ -67,6 +67,23 @@ class OracleKernels:
                                      _p(info), _p(hash_), _p(cellStart), _p(neibslist), _p(tau6), C.c_uint32(n), C.c_uint32(frm),
                                      C.c_uint32(to), C.c_uint32(cfl_offset), C.c_int(self.compute_object_forces)))
 
+    def set_body_motion(self, m, forces_cg):
+        p = self.op
+        for b in range(len(m["trans"])):
+            for a in range(3):
+                p.rbtrans[b][a] = float(m["trans"][b][a]); p.rblinearvel[b][a] = float(m["lvel"][b][a])
+                p.rbangularvel[b][a] = float(m["avel"][b][a])
+                if forces_cg:
+                    p.rbcgGridPos[b][a] = int(m["cg_grid"][b][a]); p.rbcgPos[b][a] = float(m["cg_pos"][b][a])
+            for a in range(9):
+                p.rbsteprot[b][a] = float(m["rot"][b][a])
+
+    def set_body_cg_integration(self, m):
+        p = self.op
+        for b in range(len(m["trans"])):
+            for a in range(3):
+                p.rbcgGridPosE[b][a] = int(m["cg_grid"][b][a]); p.rbcgPosE[b][a] = float(m["cg_pos"][b][a])
+
     def calc_visc(self, tau, pos, vel, info, hash_, cellStart, neibslist, n, range_end):
         tau6 = torch.zeros((len(pos), 6), dtype=torch.float32)
         self.L.orc_sps(C.byref(self.op), _p(tau6), None, _p(pos), _p(vel), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
