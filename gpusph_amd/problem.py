@@ -473,3 +473,124 @@ class PeriodicBox(Problem):
         self.rb_firstindex = np.zeros(0, dtype=np.int32)
         self.rb_cg_gridpos = np.zeros((0, 3), dtype=np.int32)
         self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)
+
+
+class WaveTank(Problem):
+    """Mirror of src/problems/WaveTank.cu (BASELINE configs[4]'s option set): a 9 x 0.6 x 1 m flume with a hinged paddle
+    (a moving body with prescribed rotation about y), a sloping beach as a geometric plane, Lennard-Jones box particles
+    plus five wall planes, viscosity<SPSVISC>, a Shepard filter every 20 iterations (the caller adds it:
+    `engine.add_filter(SHEPARD_FILTER, 20)`), dtadaptfactor 0.2.  The particle layout follows the problem's own loops
+    (fluid rows between paddle and beach, WaveTank.cu:158-168); box and paddle surfaces are dp lattices."""
+    LX, LY, LZ = 9.0, 0.6, 1.0
+    SLOPE_LENGTH, H_LENGTH, HEIGHT, H = 8.5, 0.5, 0.63, 0.45
+    BETA = 4.2364 * math.pi / 180.0
+
+    def __init__(self, deltap=0.03, *, paddle_tstart=0.5, linearization=D.DEFAULT_LINEARIZATION, viscosity="SPSVISC"):
+        super().__init__()
+        self.m_name = "WaveTank"
+        sp, pp = self.simparams, self.physparams
+        sp.kerneltype = D.WENDLAND
+        sp.boundarytype = D.LJ_BOUNDARY
+        self.set_viscosity(viscosity)                      # WaveTank.cu:58
+        sp.densitydiffusiontype = D.DENSITY_DIFFUSION_NONE
+        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_PLANES | D.ENABLE_MOVING_BODIES
+        sp.dtadaptfactor = 0.2
+        sp.dt = 1.0e-4                                     # set_timestep(0.0001)
+        self.linearization = linearization
+        self.set_deltap(deltap)
+        pp.gravity = (0.0, 0.0, -9.81)
+        r0 = self.m_deltap
+        pp.r0 = r0
+        pp.dcoeff = 5.0 * 9.81 * self.H                    # setMaxFall(H): D = 5 g H (ProblemAPI_1.cc)
+        pp.add_fluid(1000.0)
+        pp.set_equation_of_state(0, 7.0, 20.0)
+        pp.set_kinematic_visc(0, 1.0e-6)
+        pp.artvisccoeff = 0.2
+        self.m_origin = np.zeros(3)
+        self.m_size = np.array([self.LX, self.LY, self.LZ], dtype=np.float64)
+        self.paddle_origin = np.array([0.25, r0, 0.0])
+        self.paddle_length = 0.7
+        self.paddle_tstart, self.paddle_tend = float(paddle_tstart), 30.0
+        self.paddle_amplitude = math.atan(0.2 / (2.0 * (self.H - self.paddle_origin[2])))
+        self.paddle_omega = 2.0 * math.pi / 0.8
+        sp.numbodies = 1
+        sp.numforcesbodies = 0
+        sb, cb = math.sin(self.BETA), math.cos(self.BETA)
+        L = self.H_LENGTH + self.SLOPE_LENGTH
+        # copy_planes (WaveTank.cu:245-258): unit normal n and a point on n.x + d = 0
+        self.planes = [((0, 0, 1), (0, 0, 0)), ((0, 1, 0), (0, 0, 0)), ((0, -1, 0), (0, self.LY, 0)), ((1, 0, 0), (0, 0, 0)),
+                       ((-1, 0, 0), (L, 0, 0)), ((-sb, 0, cb), (self.H_LENGTH, 0, 0))]
+        self.moving_bodies_callback = self._paddle
+        self.initialize()
+        self.fill_parts()
+
+    # WaveTank::moving_bodies_callback (WaveTank.cu:221-243): hinge rotation about y, first-order quaternion step
+    def _paddle(self, index, t0, t1, kd0, kd):
+        kd.lvel = np.zeros(3)
+        if self.paddle_tstart < t1 < self.paddle_tend:
+            w = self.paddle_amplitude * self.paddle_omega * math.sin(self.paddle_omega * (t1 - self.paddle_tstart))
+            kd.avel = np.array([0.0, w, 0.0])
+            # dr = normalize(1 + (t1 - t0)/2 (0, avel)): a rotation about y by 2 atan(w dt / 2)
+            e0, e2 = 1.0, 0.5 * (t1 - t0) * w
+            nrm = math.hypot(e0, e2)
+            e0, e2 = e0 / nrm, e2 / nrm
+            c, s = e0 * e0 - e2 * e2, 2.0 * e0 * e2          # cos, sin of the step angle
+            return np.zeros(3), np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
+        kd.avel = np.zeros(3)
+        return np.zeros(3), np.eye(3)
+
+    def fill_parts(self):
+        dp = self.m_deltap
+        r0 = dp
+        amp = -self.paddle_amplitude
+        po = self.paddle_origin
+        # fluid rows (WaveTank.cu:158-168)
+        rows = []
+        z, n = 0.0, 0
+        while z < self.H:
+            z = n * dp + 1.5 * r0
+            x = po[0] + (z - po[2]) * math.tan(amp) + 1.0 * r0 / math.cos(amp)
+            l = self.H_LENGTH + z / math.tan(self.BETA) - 1.5 * r0 / math.sin(self.BETA) - x
+            nx, ny = int(l / dp) + 1, int((self.LY - 2.0 * r0) / dp) + 1
+            ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+            rows.append(np.stack([x + ix.ravel() * dp, r0 + iy.ravel() * dp, np.full(ix.size, z)], axis=1))
+            n += 1
+        fluid = np.concatenate(rows)
+        # experiment box (FT_BORDER): dp lattice on the six faces of [0, h_length + slope_length] x [0, ly] x [0, height]
+        Lx = self.H_LENGTH + self.SLOPE_LENGTH
+        nb = [int(round(Lx / dp)), int(round(self.LY / dp)), int(round(self.HEIGHT / dp))]
+        g = _lattice(0, nb[0], 0, nb[1], 0, nb[2])
+        surf = (g[:, 0] == 0) | (g[:, 0] == nb[0]) | (g[:, 1] == 0) | (g[:, 1] == nb[1]) | (g[:, 2] == 0) | (g[:, 2] == nb[2])
+        wall = g[surf].astype(np.float64) * np.array([Lx / nb[0], self.LY / nb[1], self.HEIGHT / nb[2]])
+        # paddle: a plate of width ly - 2 r0 and length 0.7 from the hinge, tilted by -amplitude about y
+        npy, npz = int(round((self.LY - 2 * r0) / dp)), int(round(self.paddle_length / dp))
+        jy, jz = np.meshgrid(np.arange(npy + 1), np.arange(npz + 1), indexing="ij")
+        s = jz.ravel() * (self.paddle_length / npz)
+        padd = np.stack([po[0] + s * math.sin(-amp) * (-1.0), po[1] + jy.ravel() * ((self.LY - 2 * r0) / npy), po[2] + s * math.cos(amp)], axis=1)
+        nf, nw, no = len(fluid), len(wall), len(padd)
+        ntot = nf + nw + no
+        pos = np.empty((ntot, 4), dtype=np.float64)
+        pos[:nf, :3] = fluid; pos[nf:nf + nw, :3] = wall; pos[nf + nw:, :3] = padd
+        pos[:, :3] = np.clip(pos[:, :3], 1e-9, self.m_size - 1e-9)
+        pos[:, 3] = self.physparams.rho0[0] * dp ** 3
+        vel = np.zeros((ntot, 4), dtype=np.float32)
+        vel[:, 3] = self.initial_density(pos)
+        tf = np.empty(ntot, dtype=np.uint16)
+        tf[:nf] = D.PT_FLUID
+        tf[nf:nf + nw] = D.PT_BOUNDARY
+        tf[nf + nw:] = D.PT_BOUNDARY | D.FG_MOVING_BOUNDARY
+        info = make_particleinfo(tf, np.zeros(ntot, dtype=np.uint16), np.arange(ntot, dtype=np.uint32))
+        self.parts = HostParticles(pos, vel, info)
+        self.num_fluid, self.num_wall, self.num_obstacle = nf, nw, no
+        self.rb_firstindex = np.zeros(1, dtype=np.int32)
+        cg = self.paddle_origin[None, :].copy()
+        self.rb_cg_global = cg.copy()
+        gcell = self.calc_grid_pos(cg)
+        self.rb_cg_gridpos = gcell.astype(np.int32)
+        self.rb_cg_pos = (cg - self.m_origin - (gcell + 0.5) * self.m_cellsize).astype(np.float32)
+
+    def initial_density(self, pos_global):
+        # hydrostatic filling under the still-water level H (m_hydrostaticFilling, m_waterLevel)
+        pp = self.physparams
+        depth = np.clip(self.H - pos_global[:, 2], 0.0, None)
+        return (np.power(1.0 + pp.rho0[0] * 9.81 * depth / pp.bcoeff[0], 1.0 / pp.gammacoeff[0]) - 1.0).astype(np.float32)

@@ -380,3 +380,26 @@ def test_body_with_prescribed_motion_trajectory():
     assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
     assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * np.abs(sim.vel[:n, :3]).max()
     assert abs(eng.time() - sim.t) <= 1e-6 * sim.t
+
+
+def test_wavetank_mirror_trajectory():
+    """BASELINE configs[4]'s option set in one run: LJ box particles + six planes (sloping beach), viscosity<SPSVISC> in the
+    tiled kernel, Shepard filter, hinged paddle driven by the problem's callback -- 24 steps against the oracle driver"""
+    from gpusph_amd.problem import WaveTank
+    prob = WaveTank(0.03, paddle_tstart=0.0)
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    eng.add_filter(D.SHEPARD_FILTER, 10); sim.filters = [(D.SHEPARD_FILTER, 10)]
+    steps = 24
+    for _ in range(steps):
+        sim.step(); eng.step()
+    out = eng.download()
+    n = eng.n
+    assert n == sim.n and np.array_equal(out["hash"], sim.hash[:n]) and np.array_equal(out["info"], sim.info[:n])
+    pad = (out["info"][:, 0] & D.FG_MOVING_BOUNDARY) != 0
+    assert pad.sum() > 100
+    assert np.array_equal(out["pos"][pad].view(np.uint32), sim.pos[:n][pad].view(np.uint32))      # rigid rows bit-exact
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * np.abs(sim.vel[:n, :3]).max()
+    assert np.abs(out["vel"][:, 3] - sim.vel[:n, 3]).max() <= 1e-6 * steps
+    assert abs(eng.current_dt() - sim.dt) <= 2e-5 * sim.dt

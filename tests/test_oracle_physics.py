@@ -905,3 +905,36 @@ def test_mk_boundary_repulsion_equals_brute_force():
     assert (np.abs(ref).max(axis=1) > 0).sum() > 100
     assert np.abs(mk - ref).max() <= 2e-4 * np.abs(ref).max()
     assert not np.any(f_full[:n][ptype == 1, :3])
+
+
+def test_wavetank_mirror_paddle_and_planes():
+    """The WaveTank mirror (BASELINE configs[4]'s option set: LJ box + 6 planes incl. the sloping beach, SPSVISC, hinged
+    paddle) on the oracle driver: the paddle turns about its hinge by the integrated angle of the callback's quaternion
+    steps, the water stays between the planes, and the wave maker pushes it."""
+    from gpusph_amd.problem import WaveTank
+    prob = WaveTank(0.04, paddle_tstart=0.0)
+    assert len(prob.planes) == 6 and prob.simparams.turbmodel == D.SPS and prob.simparams.rheologytype == D.NEWTONIAN
+    sim = ol.OracleSim(prob)
+    sim.filters = [(D.SHEPARD_FILTER, 5)]
+    ids0 = info_id(prob.parts.info)
+    pad0 = (prob.parts.info[:, 0] & D.FG_MOVING_BOUNDARY) != 0
+    x0 = {int(i): prob.parts.pos_global[k, :3].copy() for k, i in enumerate(ids0) if pad0[k]}
+    theta, t = 0.0, 0.0
+    for _ in range(12):
+        dt = float(np.float32(sim.dt))
+        w = prob.paddle_amplitude * prob.paddle_omega * np.sin(prob.paddle_omega * (t + dt))
+        theta += 2.0 * np.arctan(0.5 * dt * w)            # corrector interval [t, t + dt] of each step
+        t += dt
+        sim.step()
+    n = sim.n
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    pad = (sim.info[:n, 0] & D.FG_MOVING_BOUNDARY) != 0
+    assert pad.sum() == len(x0) > 100
+    c0 = prob.paddle_origin
+    R = np.array([[np.cos(theta), 0, np.sin(theta)], [0, 1, 0], [-np.sin(theta), 0, np.cos(theta)]])
+    exp = np.array([R @ (x0[int(i)] - c0) + c0 for i in info_id(sim.info[:n][pad])])
+    assert abs(theta) > 1e-4 and np.abs(gp[pad] - exp).max() < 2e-6
+    fluid = (sim.info[:n, 0] & 7) == 0
+    for nrm, pt in prob.planes:
+        assert ((gp[fluid] - np.asarray(pt)) @ np.asarray(nrm)).min() > 0.0     # nobody crossed a wall or the beach
+    assert np.abs(sim.vel[:n][fluid, 0]).max() > 1e-3
