@@ -182,8 +182,9 @@ def main():
             "unit": "M particle-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DamBreak3D %d particles (dp=%.6f), Wendland, WCSPH + artificial viscosity, "
-                                   "Colagrossi diffusion, DYN boundary, neib rebuild every 10 steps" % (n_total, dp),
+            "config": {"workload": "DamBreak3D %d particles (dp=%.6f), Wendland, WCSPH + %s, "
+                                   "Colagrossi diffusion, DYN boundary, neib rebuild every 10 steps"
+                                   % (n_total, dp, "viscosity<%s>" % args.viscosity if args.viscosity else "artificial viscosity"),
                        "particles": n_total, "parallelism": "slab%d" % world if world > 1 else "single",
                        "mean_neibs": round(nbar, 2)},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,

@@ -29,6 +29,7 @@ struct ForcesArgs {
 	const neibdata *neibsList;
 	const float2 *tau0, *tau1, *tau2;
 	const float4 *aux;   // per-particle EOS pre-pass {P/rho^2, c, P, rho}
+	float2 *otau0, *otau1, *otau2; float *oturbvisc;   // stress mode of the tiled kernel (SPHX_TURB_STRESS): outputs
 	const float4 *tauPack;   // SPS + tiled kernel: [0,n) = {xx,xy,xz,yy}, [n,2n) = {yz,zz,0,0} (tau_pack_kernel); tauPackN = n
 	uint32_t tauPackN;
 	const RbParams *rb;
@@ -128,6 +129,7 @@ struct Self {
 // TURB template codes: the turbulence model in the low bits, SPHX_TURB_NEWT set for the NEWTONIAN rheology
 #define SPHX_TURB_NEWT 8
 #define SPHX_TURB_MF 16     // tiled kernel only: more than one fluid, the neighbour's fluid number rides in the EOS row (eos_kernel)
+#define SPHX_TURB_STRESS 32 // tiled kernel only: not a forces pass but the SPS stress tensor (SPSstressMatrixDevice) over the same tiles
 #define TURB_MODEL(T) ((T) & 7)
 
 // select chain on the (at most four) kernel-argument values instead of a lane-indexed load from the argument block
@@ -625,6 +627,27 @@ __device__ __forceinline__ void preload_list(const DevParams &p, const ListRows 
 }
 
 struct WalkState { uint32_t code; bool alive; };
+struct StressAcc { float x, y, z, w, u; };   // stress mode: the accumulators that do not fit the float4 of the forces
+
+// one pair of SPSstressMatrixDevice (src/cuda/visc_kernel.cu:759-811) in the tiled kernel: dv_ab -= (v_a - nv_a) r_b F m/rho_n,
+// the nine sums in the order and arithmetic of sps_kernel, so both give the same bits (single fluid: rho_n from the
+// neighbour's relative density); acc = dv[0..3], acc2 = dv[4..8]
+template<int KERNEL>
+__device__ __forceinline__ void stress_interact(const DevParams &p, const Self &s, float inv_h, float qx, float qy, float qz,
+	const float4 &npos, const float4 &nvel, bool valid, float4 &acc, StressAcc &acc2)
+{
+	const float rx = qx - npos.x, ry = qy - npos.y, rz = qz - npos.z;
+	const float r = fast_sqrt(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+	const bool on = valid && is_active_w(npos.w) && r < p.influenceradius;
+	const float n_rho = (nvel.w + 1.0f)*p.rho0[0];
+	const float wgt = kernel_F<KERNEL>(p, r, inv_h)*npos.w*fast_rcp(n_rho);
+	const float weight = on ? wgt : 0.0f;
+	const float mx = rx*weight, my = ry*weight, mz = rz*weight;
+	const float vx = s.vel.x - nvel.x, vy = s.vel.y - nvel.y, vz = s.vel.z - nvel.z;
+	acc.x -= vx*mx; acc.y -= vx*my; acc.z -= vx*mz;
+	acc.w -= vy*mx; acc2.x -= vy*my; acc2.y -= vy*mz;
+	acc2.z -= vz*mx; acc2.w -= vz*my; acc2.u -= vz*mz;
+}
 
 #define TILE_HB 2   // pairs per pipeline stage ("half batch")
 // window capacity of a tiled-kernel instantiation, and the LDS placement of the SPS rows behind the EOS rows
@@ -659,7 +682,8 @@ __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 		// == fmaf(-ox, cellsize, pos): ox in {-1,0,1}, so the product is exact
 		g.qx[k] = s.pos.x + sh.x; g.qy[k] = s.pos.y + sh.y; g.qz[k] = s.pos.z + sh.z;
 		const uint32_t L = w.alive ? cb + (d & NEIBINDEX_MASK) : 0u;
-		g.npos[k] = sPos[L]; g.nvel[k] = sVel[L]; g.naux[k] = sAux[L];
+		g.npos[k] = sPos[L]; g.nvel[k] = sVel[L];
+		if (!(TURB & SPHX_TURB_STRESS)) g.naux[k] = sAux[L];
 		if (TURB_MODEL(TURB) == SPHX_SPS) {   // the SPS rows lie behind the EOS rows: sAux[WC + L], sAux[2 WC + L]
 			const float4 ta = sAux[TILE_WC(TURB) + L], tb = sAux[2*TILE_WC(TURB) + L];
 			g.ntau[k][0] = ta.x; g.ntau[k][1] = ta.y; g.ntau[k][2] = ta.z; g.ntau[k][3] = ta.w; g.ntau[k][4] = tb.x; g.ntau[k][5] = tb.y;
@@ -672,8 +696,14 @@ __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 // particles with force feedback (ljlane) are Lennard-Jones repulsions instead of SPH interactions
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered &g, const Self &s, float inv_h,
-	bool momentum, bool diffuse, bool ljsec, bool ljlane, float4 &force)
+	bool momentum, bool diffuse, bool ljsec, bool ljlane, float4 &force, StressAcc &fx)
 {
+	if (TURB & SPHX_TURB_STRESS) {   // velocity-gradient sums of the SPS stress tensor: force = dv[0..3], fx = dv[4..8]
+#pragma unroll
+		for (int k = 0; k < TILE_HB; ++k)
+			stress_interact<KERNEL>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.nvel[k], g.valid[k], force, fx);
+		return;
+	}
 	if (LJ && ljsec) {
 #pragma unroll
 		for (int k = 0; k < TILE_HB; ++k)
@@ -709,7 +739,7 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	uint32_t voff, const Self &s, float inv_h, const float4 *sShift, const uint16_t *myCB,
 	const float4 *sPos, const float4 *sVel, const float4 *sAux,
 	int sec, bool take, bool momentum, bool diffuse, bool ljlane,
-	ListWindow &lw /* batches 0..preloaded-1 already requested */, int preloaded, float4 &force)
+	ListWindow &lw /* batches 0..preloaded-1 already requested */, int preloaded, float4 &force, StressAcc &fx)
 {
 	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
 	WalkState w; w.code = 0; w.alive = take;
@@ -724,13 +754,13 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	if (!wave_any(A.valid[0])) return;
 #define SPHX_RING_STEP(J, JN) \
 	gather_half<TURB>(lw.q[J] + TILE_HB, s, sShift, myCB, sPos, sVel, sAux, w, B); \
-	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, inv_h, momentum, diffuse, sec == 1, ljlane, force); \
+	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, inv_h, momentum, diffuse, sec == 1, ljlane, force, fx); \
 	if (!wave_any(B.valid[0])) return; \
 	load_list_u(p, list, voff, sec, next, lw.q[J]); \
 	pin_batch(list, lw.q[J]); \
 	++next; \
 	gather_half<TURB>(lw.q[JN], s, sShift, myCB, sPos, sVel, sAux, w, A); \
-	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, inv_h, momentum, diffuse, sec == 1, ljlane, force); \
+	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, inv_h, momentum, diffuse, sec == 1, ljlane, force, fx); \
 	if (!wave_any(A.valid[0]) || next - TILE_AHEAD > lastBatch) return;   /* A now holds batch next-TILE_AHEAD */
 	for (;;) {
 		SPHX_RING_STEP(0, 1)
@@ -768,6 +798,31 @@ __device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t tid, u
 // a thread's own rows and the first batches of its neighbour list, requested one tile ahead
 struct TileOwn { particleinfo info; float4 pos, vel, aux; uint32_t hash; ListWindow lwF; uint32_t lwB0[TILE_NB]; };
 
+// tail of SPSstressMatrixDevice (src/cuda/visc_kernel.cu:780-811): shear rate -> nu_SPS, tau
+__device__ __forceinline__ void stress_finalize(const DevParams &p, const ForcesArgs &a, uint32_t index, float rho,
+	const float4 &acc, const StressAcc &acc2)
+{
+	float txx = acc.x, txy = acc.y + acc.w, txz = acc.z + acc2.z;
+	float tyy = acc2.x, tyz = acc2.y + acc2.w, tzz = acc2.u;
+	const float SijSij_bytwo = 2.0f*(txx*txx + tyy*tyy + tzz*tzz) + (txy*txy + txz*txz + tyz*tyz);
+	const float S = sqrtf(SijSij_bytwo);
+	const float nu_SPS = p.smagfactor*S;
+	const float divu_SPS = 0.6666666666f*nu_SPS*(txx + tyy + tzz);
+	const float Blinetal_SPS = p.kspsfactor*SijSij_bytwo;
+	if (a.oturbvisc) a.oturbvisc[index] = nu_SPS;
+	if (a.otau0) {
+		txx = (nu_SPS*(txx + txx) - divu_SPS - Blinetal_SPS)/rho;
+		txy *= nu_SPS/rho;
+		txz *= nu_SPS/rho;
+		tyy = (nu_SPS*(tyy + tyy) - divu_SPS - Blinetal_SPS)/rho;
+		tyz *= nu_SPS/rho;
+		tzz = (nu_SPS*(tzz + tzz) - divu_SPS - Blinetal_SPS)/rho;
+		a.otau0[index] = make_float2(txx, txy);
+		a.otau1[index] = make_float2(txz, tyy);
+		a.otau2[index] = make_float2(tyz, tzz);
+	}
+}
+
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __global__ void __launch_bounds__(TILE_THREADS, 2)
 forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
@@ -776,9 +831,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 {
 	constexpr uint32_t WC = TILE_WC(TURB);
 	constexpr bool SPSW = TURB_MODEL(TURB) == SPHX_SPS;
+	constexpr bool STRESS = (TURB & SPHX_TURB_STRESS) != 0;   // stress mode: no EOS rows, every active particle walks both sections
 	__shared__ __attribute__((aligned(16))) float4 sPos[WC];
 	__shared__ __attribute__((aligned(16))) float4 sVel[WC];
-	__shared__ __attribute__((aligned(16))) float4 sAux[SPSW ? 3*WC : WC];   // SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}
+	__shared__ __attribute__((aligned(16))) float4 sAux[SPSW ? 3*WC : STRESS ? 1 : WC];   // SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}
 	__shared__ uint32_t sCellBase[TILE_WROWS*TILE_KW];   // LDS slot of the first particle of each window cell
 	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW];    // ... relative to the start of its window row (never modified after the scan)
 	__shared__ uint32_t sCnt[TILE_WROWS*TILE_KW];
@@ -868,7 +924,8 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	// address-unit issue per tile, which now overlaps the previous tile's pair loop instead of sitting at the
 	// head of the staging chain.
 	auto request_own = [&](const TileHome &h, TileOwn &o) {
-		o.info = a.info[h.li]; o.pos = a.pos[h.li]; o.vel = a.vel[h.li]; o.hash = a.hash[h.li]; o.aux = a.aux[h.li];
+		o.info = a.info[h.li]; o.pos = a.pos[h.li]; o.vel = a.vel[h.li]; o.hash = a.hash[h.li];
+		if (!STRESS) o.aux = a.aux[h.li];
 		const uint32_t vo = h.li*2u;   // byte offset of this particle inside every list row (n < 2^31)
 		preload_list(p, listRows, vo, 0, o.lwF);
 		// boundary section: most particles have none, so only its first batch is requested up front; the walk
@@ -890,7 +947,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		const bool inRange = hc.inRange, mine = hc.mine;
 		const int hrow = hc.hrow;
 		const uint32_t index = hc.index;
-		const bool pairs = (dc[13] & 1u) && (a.dbg & 3) != 1;   // no fluid anywhere in the window: nothing interacts
+		const bool pairs = ((dc[13] & 1u) || STRESS) && (a.dbg & 3) != 1;   // no fluid anywhere in the window: nothing interacts
 		const uint32_t voff = hc.li*2u;
 
 		lds_barrier();   // the previous tile's readers are done with LDS
@@ -958,7 +1015,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					const uint32_t rs = __builtin_amdgcn_readfirstlane(sRowStart[r]);
 					stage_row_wave(a.pos + rs, sPos + base, total, lane);
 					stage_row_wave(a.vel + rs, sVel + base, total, lane);
-					stage_row_wave(a.aux + rs, sAux + base, total, lane);
+					if (!STRESS) stage_row_wave(a.aux + rs, sAux + base, total, lane);
 					if (SPSW) {
 						stage_row_wave(a.tauPack + rs, sAux + WC + base, total, lane);
 						stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + 2*WC + base, total, lane);
@@ -967,7 +1024,8 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					for (int col = 0; col < ncells + 2; ++col) {
 						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = base + sCellRel[r*TILE_KW + col];
 						for (uint32_t q = lane; q < cnt; q += 64u) {
-							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q]; sAux[cb + q] = a.aux[st + q];
+							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q];
+							if (!STRESS) sAux[cb + q] = a.aux[st + q];
 							if (SPSW) { sAux[WC + cb + q] = a.tauPack[st + q]; sAux[2*WC + cb + q] = a.tauPack[a.tauPackN + st + q]; }
 						}
 					}
@@ -999,8 +1057,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		s.pos = pos; s.vel = own.vel;
 		s.gridPos = grid_pos_from_hash(p, own.hash & CELLTYPE_BITMASK);
 		s.fl = (TURB & SPHX_TURB_MF) ? FLUID_NUM(info) : 0u;
-		s.p_precalc = own.aux.x; s.sspeed = own.aux.y; s.P = own.aux.z; s.rho = own.aux.w;
-		s.inv_rho = fast_rcp(own.aux.w);
+		if (STRESS) {
+			s.rho = (own.vel.w + 1.0f)*p.rho0[0];
+		} else {
+			s.p_precalc = own.aux.x; s.sspeed = own.aux.y; s.P = own.aux.z; s.rho = own.aux.w;
+			s.inv_rho = fast_rcp(own.aux.w);
+		}
 		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
 		if (SPSW) {   // own stress tensor (hc.li is a valid row for idle lanes too)
 			const float4 ta = a.tauPack[hc.li], tb = a.tauPack[a.tauPackN + hc.li];
@@ -1014,6 +1076,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		float cfl_term = 0.0f;
 		const bool active = mine && is_active_w(pos.w);
 		float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		StressAcc fx = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 		if (inRange && pairs) {
 			// per-home-cell code table: slot of the first record of each of the 27 neighbour cells
 			for (uint32_t e = tid; e < TILE_HROWS*TILE_MAXCELLS*27; e += TILE_THREADS) {
@@ -1032,13 +1095,13 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			// LJ boundary: fluid section only for bodies with force feedback, when object forces are asked for (:3620-3645)
 			const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
 			const bool ljlane = LJ && isBound;
-			const bool take0 = active && (isFluid || isDynBound || (ljlane && HAS_COMPUTE_FORCE(info) && a.compute_object_forces));
-			const bool take1 = active && isFluid && (dyn || LJ);
+			const bool take0 = active && (STRESS || isFluid || isDynBound || (ljlane && HAS_COMPUTE_FORCE(info) && a.compute_object_forces));
+			const bool take1 = active && (STRESS || (isFluid && (dyn || LJ)));
 			walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift, myCB,
-				sPos, sVel, sAux, 0, take0, momentum, true, ljlane, own.lwF, TILE_AHEAD, force);
+				sPos, sVel, sAux, 0, take0, momentum, true, ljlane, own.lwF, TILE_AHEAD, force, fx);
 			if (wave_any(take1))
 				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift, myCB,
-					sPos, sVel, sAux, 1, take1, momentum, false, false, lwB, 1, force);
+					sPos, sVel, sAux, 1, take1, momentum, false, false, lwB, 1, force, fx);
 		}
 		if (prof) tB = wall_clock64();
 		// vmcnt(0): only the list batches fetched past the terminators and the next tile's window extents are in
@@ -1046,13 +1109,15 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		__builtin_amdgcn_s_waitcnt(0x0F70);
 		const uint32_t nCSv = nCS, nCEv = nCE;
 		if (prof) s1 = wall_clock64();
-		if (active)
-			cfl_term = finalize_particle(p, a, index, info, s, force);
+		if (active) {
+			if (STRESS) stress_finalize(p, a, index, s.rho, force, fx);
+			else cfl_term = finalize_particle(p, a, index, info, s, force);
+		}
 		if (prof) s2 = wall_clock64();
 		// 4. CFL: the array keeps the reference's one-entry-per-128-particles layout
 		// (getFmaxElements); tiles are not 128-aligned, so they max into the entry of their first
 		// particle.  Non-negative floats order like their bit patterns; the caller zeroed CFL.
-		if (a.cfl && inRange) {
+		if (!STRESS && a.cfl && inRange) {
 #pragma unroll
 			for (int dd = 32; dd > 0; dd >>= 1)
 				cfl_term = fmaxf(cfl_term, __shfl_down(cfl_term, dd));
@@ -1249,12 +1314,15 @@ __device__ __forceinline__ void sps_section(const DevParams &p, const SpsArgs &a
 
 template<int KERNEL, bool MULTIFLUID>
 __global__ void __launch_bounds__(128)
-sps_kernel(DevParams p, SpsArgs a)
+sps_kernel(DevParams p, SpsArgs a, const uint32_t *runIfNonZero)
 {
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
+	if (runIfNonZero && !*runIfNonZero) return;   // the tiled stress pass covered this launch
+	// block-stride loop: as the stand-by of the tiled pass this kernel is launched with a capped grid (see forces_kernel)
+	for (uint32_t blk = blockIdx.x; blk*128u < a.numParticles; blk += gridDim.x) {
+	const uint32_t index = blk*128 + threadIdx.x;
+	if (index >= a.numParticles) continue;
 	const float4 pos = a.pos[index];
-	if (!is_active_w(pos.w)) return;
+	if (!is_active_w(pos.w)) continue;
 	const float4 vel = a.vel[index];
 	const particleinfo info = a.info[index];
 	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
@@ -1282,6 +1350,7 @@ sps_kernel(DevParams p, SpsArgs a)
 		a.tau0[index] = make_float2(txx, txy);
 		a.tau1[index] = make_float2(txz, tyy);
 		a.tau2[index] = make_float2(tyz, tzz);
+	}
 	}
 }
 
@@ -1463,6 +1532,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
 		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
 	a.tauPack = nullptr; a.tauPackN = 0;
+	a.otau0 = a.otau1 = a.otau2 = nullptr; a.oturbvisc = nullptr;
 	if (use_tiles && ctx->dev.turbmodel == SPHX_SPS) {   // window rows of the stress tensor (see tau_pack_kernel)
 		SPHX_REQUIRE(ctx->tau_pack != nullptr && numParticles <= ctx->reserved_particles, "sphx_forces_basicstep: SPS scratch not reserved");
 		tau_pack_kernel<<<div_up_u(numParticles, 256), 256, 0, (hipStream_t)stream>>>((const float2*)tau0, (const float2*)tau1,
@@ -1566,10 +1636,37 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	a.tau0 = (float2*)tau0; a.tau1 = (float2*)tau1; a.tau2 = (float2*)tau2; a.turbvisc = spsturbvisc;
 	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.info = (const particleinfo*)info;
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
-	const dim3 grid(div_up_u(particleRangeEnd, 128));
+	dim3 grid(div_up_u(particleRangeEnd, 128));
+	// single fluid with the tiling of this neighbour list at hand: the stress mode of the tiled kernel (neighbour rows from
+	// the LDS window instead of gathers), then the gather kernel as a stand-by guarded by the tiling's overflow flag
+	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
+		ctx->dev.numfluids == 1 && !ctx->disable_tiles &&
+		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
+		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
+		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;
+	const uint32_t *guard = nullptr;
+	if (use_tiles) {
+		ForcesArgs fa = ForcesArgs();
+		fa.pos = a.pos; fa.vel = a.vel; fa.info = a.info; fa.hash = hash; fa.cellStart = cellStart; fa.neibsList = neibsList;
+		fa.otau0 = a.tau0; fa.otau1 = a.tau1; fa.otau2 = a.tau2; fa.oturbvisc = spsturbvisc;
+		fa.fromParticle = 0; fa.toParticle = particleRangeEnd;
+		fa.dbg = ctx->tile_debug & 4;
+		switch (ctx->dev.kerneltype) {
+#define SPHX_STRESS_TILE(K) forces_tile_kernel<K, SPHX_ARTIFICIAL | SPHX_TURB_STRESS, DIFF_NONE, false> \
+			<<<ctx->tile_grid, TILE_THREADS, 0, (hipStream_t)stream>>>(ctx->dev, fa, ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy)
+		case SPHX_CUBICSPLINE: SPHX_STRESS_TILE(SPHX_CUBICSPLINE); break;
+		case SPHX_QUADRATIC:   SPHX_STRESS_TILE(SPHX_QUADRATIC); break;
+		case SPHX_WENDLAND:    SPHX_STRESS_TILE(SPHX_WENDLAND); break;
+		default:               SPHX_STRESS_TILE(SPHX_GAUSSIAN); break;
+#undef SPHX_STRESS_TILE
+		}
+		SPHX_LAUNCH_CHECK("forces_tile_kernel (SPS stress)");
+		guard = ctx->tile_ctl + 1;
+		grid.x = grid.x < 2048u ? grid.x : 2048u;   // stand-by launch: every block returns at once unless the tiling overflowed
+	}
 	switch (ctx->dev.kerneltype) {
-#define SPHX_SPS_LAUNCH(K) do { if (ctx->dev.numfluids > 1) sps_kernel<K, true><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); \
-		else sps_kernel<K, false><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a); } while (0)
+#define SPHX_SPS_LAUNCH(K) do { if (ctx->dev.numfluids > 1) sps_kernel<K, true><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a, guard); \
+		else sps_kernel<K, false><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a, guard); } while (0)
 	case SPHX_CUBICSPLINE: SPHX_SPS_LAUNCH(SPHX_CUBICSPLINE); break;
 	case SPHX_QUADRATIC:   SPHX_SPS_LAUNCH(SPHX_QUADRATIC); break;
 	case SPHX_WENDLAND:    SPHX_SPS_LAUNCH(SPHX_WENDLAND); break;

@@ -257,10 +257,15 @@ def test_tiled_and_generic_kernels_agree(case, monkeypatch):
         vel[:n, 3] += rng.uniform(0, 2e-3, size=n).astype(np.float32)
         eng.vel.copy_(torch.from_numpy(vel).to(eng.device))
         eng._forces(eng.pos, eng.vel, 1, 0)
-        outs.append((_np(eng.forces)[:n].copy(), float(eng.d_dt_next.item()), _np(eng.rbforces).copy()))
+        tau = np.concatenate([_np(t)[:n] for t in eng.tau], axis=1) if getattr(eng, "tau", None) else np.zeros((n, 6), np.float32)
+        outs.append((_np(eng.forces)[:n].copy(), float(eng.d_dt_next.item()), _np(eng.rbforces).copy(), tau.copy()))
     assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
     assert outs[0][1] == outs[1][1]
     assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32))
+    # SPS: the stress mode of the tiled kernel (single fluid) and sps_kernel give the same tensor, bit for bit
+    assert np.array_equal(outs[0][3].view(np.uint32), outs[1][3].view(np.uint32))
+    if case.get("viscosity") == "SPSVISC":
+        assert np.abs(outs[0][3]).max() > 0
 
 
 def test_multigpu_engine_world1_equals_single_engine():
