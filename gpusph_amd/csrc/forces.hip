@@ -1418,14 +1418,16 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 	const bool newt = p.rheology == SPHX_NEWTONIAN;
 	const uint32_t *guard = use_tiles ? ctx->tile_ctl + 1 : nullptr;
 	ForcesTimer t(ctx, stream, !use_tiles);   // without tiles the generic kernel is the dominant one
-	// tiled kernel (never with Ferrari diffusion: use_tiles is false then), then the generic one, guarded by the overflow flag
-	// more than one fluid: tiled only for the Wendland kernel (every multi-fluid problem of the reference uses it), to bound
-	// the number of kernel instantiations
+	// tiled kernel, then the generic one, guarded by the overflow flag
+	// more than one fluid or Ferrari diffusion: tiled only for the Wendland kernel (every such problem of the reference uses
+	// it), to bound the number of kernel instantiations; use_tiles is false for the other kernels then
 #define SPHX_LAUNCH_TILE(T) do { if (use_tiles) { \
 		if (mf) { if (KERNEL == SPHX_WENDLAND) { \
 			if (diff == DIFF_COLAGROSSI) launch_tile<SPHX_WENDLAND, (T) | SPHX_TURB_MF, DIFF_COLAGROSSI>(ctx, stream, a); \
+			else if (diff == DIFF_FERRARI) launch_tile<SPHX_WENDLAND, (T) | SPHX_TURB_MF, DIFF_FERRARI>(ctx, stream, a); \
 			else launch_tile<SPHX_WENDLAND, (T) | SPHX_TURB_MF, DIFF_NONE>(ctx, stream, a); } } \
 		else if (diff == DIFF_COLAGROSSI) launch_tile<KERNEL, T, DIFF_COLAGROSSI>(ctx, stream, a); \
+		else if (diff == DIFF_FERRARI) { if (KERNEL == SPHX_WENDLAND) launch_tile<SPHX_WENDLAND, T, DIFF_FERRARI>(ctx, stream, a); } \
 		else launch_tile<KERNEL, T, DIFF_NONE>(ctx, stream, a); } } while (0)
 #define SPHX_LAUNCH_GENERIC(T, G) do { \
 		if (diff == DIFF_COLAGROSSI) launch_forces_mf<KERNEL, T, DIFF_COLAGROSSI>(mf, grid, stream, p, a, G); \
@@ -1525,8 +1527,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
-		(ctx->dev.numfluids == 1 || ctx->dev.kerneltype == SPHX_WENDLAND) &&
-		ctx->dev.densitydiff != SPHX_FERRARI &&
+		((ctx->dev.numfluids == 1 && ctx->dev.densitydiff != SPHX_FERRARI) || ctx->dev.kerneltype == SPHX_WENDLAND) &&
 		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles &&
 		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
 		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&

@@ -594,3 +594,132 @@ class WaveTank(Problem):
         pp = self.physparams
         depth = np.clip(self.H - pos_global[:, 2], 0.0, None)
         return (np.power(1.0 + pp.rho0[0] * 9.81 * depth / pp.bcoeff[0], 1.0 / pp.gammacoeff[0]) - 1.0).astype(np.float32)
+
+
+class StillWater(Problem):
+    """Mirror of src/problems/StillWater.cu (the problem of BASELINE configs[2], with the boundary models built here): a
+    sqrt(2)H x sqrt(2)H x 1.1H box of still water of depth H = 1, viscosity<DYNAMICVISC> (nu = 3e-2), DYN_BOUNDARY walls of
+    ceil(kernelradius sfactor) particle layers (or one layer plus five planes with use_planes), Ferrari density diffusion
+    with length scale H by default (--density-diffusion), deltap = H/ppH, c0 = ceil(10 sqrt(2 g H)), dt0 = 4e-5,
+    dtadaptfactor 0.3, neighbour rebuild every 20 iterations, optional MLS filter (the caller adds it, like --mls N).
+    StillWater.cu:50-143 for the parameters and the box / fluid extents."""
+    H = 1.0
+
+    def __init__(self, ppH=16, *, use_planes=False, density_diffusion=D.FERRARI, viscosity="DYNAMICVISC",
+                 linearization=D.DEFAULT_LINEARIZATION, jitter=0.0):
+        super().__init__()
+        self.m_name = "StillWater"
+        sp, pp = self.simparams, self.physparams
+        sp.kerneltype = D.WENDLAND
+        sp.boundarytype = D.DYN_BOUNDARY
+        self.set_viscosity(viscosity)
+        sp.densitydiffusiontype = density_diffusion
+        sp.simflags = D.ENABLE_DTADAPT | (D.ENABLE_PLANES if use_planes else 0)
+        sp.dtadaptfactor = 0.3
+        sp.buildneibsfreq = 20
+        sp.dt = 4.0e-5
+        sp.ferrariLengthScale = self.H
+        self.linearization = linearization
+        self.use_planes = bool(use_planes)
+        self.jitter = jitter
+        self.set_deltap(self.H / ppH)
+        dp = self.m_deltap
+        l = w = math.sqrt(2.0) * self.H
+        h = 1.1 * self.H
+        self.l, self.w, self.h = l, w, h
+        self.m_origin = np.zeros(3)
+        self.m_size = np.array([l, w, h], dtype=np.float64)
+        if not use_planes:   # the box grows by the extra boundary layers (StillWater.cu:82-87)
+            self.dyn_layers = int(math.ceil(sp.kernelradius * sp.sfactor))
+            extra = (self.dyn_layers - 1) * dp
+            self.m_origin = self.m_origin - extra
+            self.m_size = self.m_size + 2 * extra
+        else:
+            self.dyn_layers = 1
+        g = 9.81
+        pp.gravity = (0.0, 0.0, -g)
+        c0 = math.ceil(10.0 * math.sqrt(2.0 * g * self.H))
+        pp.add_fluid(1000.0)
+        pp.set_equation_of_state(0, 7.0, float(c0))
+        pp.set_kinematic_visc(0, 3.0e-2)
+        if use_planes:   # copy_planes (StillWater.cu:145-154): floor and the four side walls
+            o = self.m_origin
+            self.planes = [((0, 0, 1), (0, 0, o[2])), ((0, 1, 0), (0, o[0], 0)), ((0, -1, 0), (0, o[0] + w, 0)),
+                           ((1, 0, 0), (o[1], 0, 0)), ((-1, 0, 0), (o[1] + l, 0, 0))]
+        self.initialize()
+        self.fill_parts()
+
+    def fill_parts(self):
+        dp = self.m_deltap
+        Lr = self.dyn_layers
+        L = self.m_size
+        n = [int(round(L[a] / dp)) for a in range(3)]
+        dx = np.array([L[a] / n[a] for a in range(3)])
+        # box walls (FT_BORDER filled inwards with dyn_layers layers): lattice nodes within Lr layers of a face
+        g = _lattice(0, n[0], 0, n[1], 0, n[2])
+        near = np.zeros(len(g), dtype=bool)
+        for a in range(3):
+            near |= (g[:, a] < Lr) | (g[:, a] > n[a] - Lr)
+        wall = g[near].astype(np.float64) * dx + self.m_origin
+        # fluid box (StillWater.cu:125-136)
+        wd = dp
+        fo = self.m_origin.copy()
+        if Lr > 1:
+            fo = fo + Lr * dp
+        fo = fo + wd
+        shift = 2 * wd if Lr == 1 else (Lr - 1) * dp * 2
+        fsize = np.array([self.l - shift, self.w - shift, self.H - shift])
+        fn = [max(int(round(fsize[a] / dp)), 1) for a in range(3)]
+        fluid = _lattice(0, fn[0], 0, fn[1], 0, fn[2]).astype(np.float64) * (fsize / np.array(fn)) + fo
+        if self.jitter:
+            rng = np.random.default_rng(4242)
+            fluid = fluid + rng.uniform(-self.jitter * dp, self.jitter * dp, size=fluid.shape)
+        self.water_level = float(fo[2] + fsize[2])
+        nf, nw = len(fluid), len(wall)
+        ntot = nf + nw
+        pos = np.empty((ntot, 4), dtype=np.float64)
+        pos[:nf, :3] = fluid
+        pos[nf:, :3] = wall
+        eps = 1e-9
+        pos[:, :3] = np.clip(pos[:, :3], self.m_origin + eps, self.m_origin + self.m_size - eps)
+        pos[:, 3] = self.physparams.rho0[0] * dp ** 3
+        vel = np.zeros((ntot, 4), dtype=np.float32)
+        vel[:, 3] = self.initial_density(pos)
+        tf = np.empty(ntot, dtype=np.uint16)
+        tf[:nf] = D.PT_FLUID
+        tf[nf:] = D.PT_BOUNDARY
+        info = make_particleinfo(tf, np.zeros(ntot, dtype=np.uint16), np.arange(ntot, dtype=np.uint32))
+        self.parts = HostParticles(pos, vel, info)
+        self.num_fluid, self.num_wall, self.num_obstacle = nf, nw, 0
+        self.rb_firstindex = np.zeros(0, dtype=np.int32)
+        self.rb_cg_gridpos = np.zeros((0, 3), dtype=np.int32)
+        self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)
+
+    def initial_density(self, pos_global):
+        # hydrostatic filling below the still-water level (m_hydrostaticFilling, ProblemAPI_1.cc)
+        pp = self.physparams
+        depth = np.clip(self.water_level - pos_global[:, 2], 0.0, None)
+        return (np.power(1.0 + pp.rho0[0] * 9.81 * depth / pp.bcoeff[0], 1.0 / pp.gammacoeff[0]) - 1.0).astype(np.float32)
+
+    @classmethod
+    def ppH_for(cls, target):
+        """ppH whose particle count is closest to `target` from below (fluid ~ 2 ppH^3, plus the walls)"""
+        p = max(int((target / 2.0) ** (1.0 / 3.0)), 4)
+        while p > 4 and cls.count(p) > target:
+            p -= 1
+        return p
+
+    @classmethod
+    def count(cls, ppH):
+        dp = cls.H / ppH
+        Lr = 3
+        ext = 2 * (Lr - 1) * dp
+        n = [int(round((math.sqrt(2.0) * cls.H + ext) / dp)), int(round((math.sqrt(2.0) * cls.H + ext) / dp)), int(round((1.1 * cls.H + ext) / dp))]
+        full = (n[0] + 1) * (n[1] + 1) * (n[2] + 1)
+        inner = max(n[0] + 1 - 2 * Lr, 0) * max(n[1] + 1 - 2 * Lr, 0) * max(n[2] + 1 - 2 * Lr, 0)
+        shift = (Lr - 1) * dp * 2
+        fs = [math.sqrt(2.0) * cls.H - shift, math.sqrt(2.0) * cls.H - shift, cls.H - shift]
+        fl = 1
+        for a in range(3):
+            fl *= max(int(round(fs[a] / dp)), 1) + 1
+        return full - inner + fl

@@ -403,3 +403,26 @@ def test_wavetank_mirror_trajectory():
     assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * np.abs(sim.vel[:n, :3]).max()
     assert np.abs(out["vel"][:, 3] - sim.vel[:n, 3]).max() <= 1e-6 * steps
     assert abs(eng.current_dt() - sim.dt) <= 2e-5 * sim.dt
+
+
+@pytest.mark.parametrize("use_planes", [False, True])
+def test_stillwater_mirror_trajectory(use_planes):
+    """The StillWater mirror (BASELINE configs[2]'s problem with the boundary models built here): DYNAMICVISC + Ferrari
+    diffusion in the tiled kernel, DYN walls (or planes), MLS filter -- 24 steps against the oracle driver across a
+    neighbour-list rebuild"""
+    from gpusph_amd.problem import StillWater
+    prob = StillWater(10, use_planes=use_planes, jitter=0.05)
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    eng.add_filter(D.MLS_FILTER, 6); sim.filters = [(D.MLS_FILTER, 6)]
+    steps = 24
+    for _ in range(steps):
+        sim.step(); eng.step()
+    out = eng.download()
+    n = eng.n
+    assert n == sim.n and np.array_equal(out["hash"], sim.hash[:n]) and np.array_equal(out["info"], sim.info[:n])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    vs = max(np.abs(sim.vel[:n, :3]).max(), 1e-3)
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * vs
+    assert np.abs(out["vel"][:, 3] - sim.vel[:n, 3]).max() <= 1e-6 * steps
+    assert abs(eng.current_dt() - sim.dt) <= 2e-5 * sim.dt

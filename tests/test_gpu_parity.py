@@ -236,7 +236,12 @@ LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, visc
                  density_diffusion=D.DENSITY_DIFFUSION_NONE),
             # SPS stress tensor rows in the LDS window (smaller window capacity): WaveTank's viscosity<SPSVISC>, and two fluids
             dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, viscosity="SPSVISC", kinematic_visc=1.0e-3),
-            dict(deltap=0.03, obstacle=False, jitter=0.2, hydrostatic=True, viscosity="SPSVISC", kinematic_visc=1.0e-6, two_fluids=True)]
+            dict(deltap=0.03, obstacle=False, jitter=0.2, hydrostatic=True, viscosity="SPSVISC", kinematic_visc=1.0e-6, two_fluids=True),
+            # Ferrari density diffusion in the tiled kernel (StillWater's default): DYN walls with a feedback body, two fluids + LJ
+            dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, density_diffusion=D.FERRARI,
+                 viscosity="DYNAMICVISC", kinematic_visc=3.0e-2),
+            dict(deltap=0.04, obstacle=False, jitter=0.2, hydrostatic=False, two_fluids=True, boundary=D.LJ_BOUNDARY,
+                 density_diffusion=D.FERRARI)]
 
 
 @pytest.mark.parametrize("case", CASES + LJ_CASES)

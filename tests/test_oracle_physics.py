@@ -938,3 +938,30 @@ def test_wavetank_mirror_paddle_and_planes():
     for nrm, pt in prob.planes:
         assert ((gp[fluid] - np.asarray(pt)) @ np.asarray(nrm)).min() > 0.0     # nobody crossed a wall or the beach
     assert np.abs(sim.vel[:n][fluid, 0]).max() > 1e-3
+
+
+@pytest.mark.parametrize("use_planes", [False, True])
+def test_stillwater_mirror_stays_still(use_planes):
+    """The StillWater mirror (src/problems/StillWater.cu: DYNAMICVISC, DYN walls or planes, Ferrari diffusion with length
+    scale H, optional MLS) on the oracle driver: hydrostatically filled water only settles -- velocities stay far
+    below the sound speed and the density stays within the hydrostatic range."""
+    from gpusph_amd.problem import StillWater
+    prob = StillWater(8, use_planes=use_planes)
+    sp, pp = prob.simparams, prob.physparams
+    assert sp.rheologytype == D.NEWTONIAN and sp.turbmodel == D.LAMINAR_FLOW and sp.avgop == D.ARITHMETIC
+    assert sp.densitydiffusiontype == D.FERRARI and sp.buildneibsfreq == 20
+    assert abs(sp.densityDiffCoeff - np.float32(1e-3 * prob.H / prob.m_deltap)) < 1e-9
+    assert pp.sscoeff[0] == 45.0
+    sim = ol.OracleSim(prob)
+    sim.filters = [(D.MLS_FILTER, 4)]
+    for _ in range(10):
+        sim.step()
+    n = sim.n
+    fluid = (sim.info[:n, 0] & 7) == 0
+    assert fluid.sum() == prob.num_fluid
+    assert np.isfinite(sim.vel[:n]).all()
+    # the fluid box starts one empty lattice layer away from the walls (StillWater.cu:125-136), so the column first settles
+    # into that gap: bounded, subsonic motion, no blow-up
+    vmax = np.abs(sim.vel[:n][fluid, :3]).max()
+    assert 0.0 < vmax < 0.05 * pp.sscoeff[0]
+    assert np.abs(sim.vel[:n][fluid, 3]).max() < 2.0 * 1000.0 * 9.81 * prob.H / pp.bcoeff[0]
