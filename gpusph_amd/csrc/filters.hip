@@ -429,11 +429,83 @@ surface_kernel(DevParams p, FilterArgs a, PostArgs o)
 	}
 }
 
+// calcInterfaceparticleDevice (:388-560), non-SA: FG_SURFACE and FG_INTERFACE of a multi-fluid run.  Two SPH normals per
+// particle (all neighbours / same-fluid and non-fluid neighbours); the gradient sums take the particle's own volume after
+// the loop, planes do not enter (unlike the surface kernel)
+template<int KERNEL>
+__global__ void __launch_bounds__(128)
+interface_kernel(DevParams p, FilterArgs a, PostArgs o)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	particleinfo info = o.infoInOut[index];
+	const float4 pos = a.pos[index];
+	if (PART_TYPE(info) != PT_FLUID || !is_active_w(pos.w)) {
+		if (o.normals) o.normals[index] = make_float4(NAN, NAN, NAN, NAN);
+		return;
+	}
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	info.x &= (unsigned short)~(FG_SURFACE | FG_INTERFACE);
+	const uint32_t fnum = FLUID_NUM(info);
+	const float p_volume = pos.w/((a.vel[index].w + 1.0f)*p.rho0[fnum]);
+	float4 nfs = make_float4(0.0f, 0.0f, 0.0f, 0.0f), nif = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	nfs.w = kernel_W<KERNEL>(p, 0.0f)*p_volume;
+	nif.w = kernel_W<KERNEL>(p, 0.0f)*p_volume;
+	auto first = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const particleinfo n_info = o.infoInOut[j];
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		const float n_volume = npos.w/((a.vel[j].w + 1.0f)*p.rho0[FLUID_NUM(n_info)]);
+		if (r < p.influenceradius) {
+			const float f = kernel_F_exact<KERNEL>(p, r);
+			nfs.x -= f*rx; nfs.y -= f*ry; nfs.z -= f*rz;
+			nfs.w += kernel_W<KERNEL>(p, r)*n_volume;
+		}
+		if (r < p.influenceradius && (fnum == FLUID_NUM(n_info) || PART_TYPE(n_info) != PT_FLUID)) {
+			const float f = kernel_F_exact<KERNEL>(p, r);
+			nif.x -= f*rx; nif.y -= f*ry; nif.z -= f*rz;
+			nif.w += kernel_W<KERNEL>(p, r)*n_volume;
+		}
+	};
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, first);
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, first);
+	nfs.x *= p_volume; nfs.y *= p_volume; nfs.z *= p_volume;
+	nif.x *= p_volume; nif.y *= p_volume; nif.z *= p_volume;
+	const float lfs = sqrtf(nfs.x*nfs.x + nfs.y*nfs.y + nfs.z*nfs.z);
+	const float lif = sqrtf(nif.x*nif.x + nif.y*nif.y + nif.z*nif.z);
+	int nc_fs = 0, nc_if = 0;
+	auto second = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		const particleinfo n_info = o.infoInOut[j];
+		const float cosconeangle = (PART_TYPE(n_info) == PT_FLUID) ? o.cosconeanglefluid : o.cosconeanglenonfluid;
+		if (r < p.influenceradius) {
+			const float criteria = -(nfs.x*rx + nfs.y*ry + nfs.z*rz);
+			if (criteria > r*lfs*cosconeangle) nc_fs++;
+		}
+		if (r < p.influenceradius && (fnum == FLUID_NUM(n_info) || PART_TYPE(n_info) != PT_FLUID)) {
+			const float criteria = -(nif.x*rx + nif.y*ry + nif.z*rz);
+			if (criteria > r*lif*cosconeangle) nc_if++;
+		}
+	};
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, second);
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, second);
+	if (!nc_fs) info.x |= FG_SURFACE;
+	if (!nc_if && nc_fs) info.x |= FG_INTERFACE;
+	o.infoInOut[index] = info;
+	if (o.normals) {
+		nfs.x /= lfs; nfs.y /= lfs; nfs.z /= lfs;
+		nif.x /= lif; nif.y /= lif; nif.z /= lif;
+		o.normals[index] = (!nc_if && nc_fs) ? nif : nfs;
+	}
+}
+
 template<int KERNEL>
 static void launch_post(int type, dim3 grid, hipStream_t st, const DevParams &p, const FilterArgs &a, const PostArgs &o)
 {
 	if (type == SPHX_VORTICITY) vorticity_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a, o);
 	else if (type == SPHX_TESTPOINTS) testpoints_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a, o);
+	else if (type == SPHX_INTERFACE_DETECTION) interface_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a, o);
 	else surface_kernel<KERNEL><<<grid, 128, 0, st>>>(p, a, o);
 }
 
@@ -445,7 +517,7 @@ extern "C" int sphx_postprocess(sphx_ctx *ctx, int type,
 {
 	(void)numParticles;
 	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_postprocess: constants not set");
-	SPHX_REQUIRE(type == SPHX_VORTICITY || type == SPHX_TESTPOINTS || type == SPHX_SURFACE_DETECTION,
+	SPHX_REQUIRE(type == SPHX_VORTICITY || type == SPHX_TESTPOINTS || type == SPHX_SURFACE_DETECTION || type == SPHX_INTERFACE_DETECTION,
 		"sphx_postprocess: non-existing postprocess filter invoked");
 	SPHX_REQUIRE(pos && hash && cellStart && neibsList, "sphx_postprocess: missing buffer (POS, HASH, CELLSTART, NEIBSLIST)");
 	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY && ctx->dev.boundarytype != SPHX_LJ_BOUNDARY)
@@ -460,8 +532,8 @@ extern "C" int sphx_postprocess(sphx_ctx *ctx, int type,
 	o.normals = (float4*)normals; o.cosconeanglefluid = cosconeanglefluid; o.cosconeanglenonfluid = cosconeanglenonfluid;
 	if (type == SPHX_VORTICITY) SPHX_REQUIRE(vorticity && vel && info, "sphx_postprocess(VORTICITY): needs VORTICITY, VEL, INFO");
 	if (type == SPHX_TESTPOINTS) SPHX_REQUIRE(velInOut && info, "sphx_postprocess(TESTPOINTS): needs VEL (updated in place), INFO");
-	if (type == SPHX_SURFACE_DETECTION) {
-		SPHX_REQUIRE(infoInOut && vel, "sphx_postprocess(SURFACE_DETECTION): needs INFO (updated in place), VEL");
+	if (type == SPHX_SURFACE_DETECTION || type == SPHX_INTERFACE_DETECTION) {
+		SPHX_REQUIRE(infoInOut && vel, "sphx_postprocess(SURFACE/INTERFACE_DETECTION): needs INFO (updated in place), VEL");
 		a.info = (const particleinfo*)infoInOut;
 	}
 	const dim3 grid(div_up_u(particleRangeEnd, 128));

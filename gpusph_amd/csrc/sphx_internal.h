@@ -28,6 +28,7 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #define FG_COMPUTE_FORCE     (PART_FLAG_START << 0)
 #define FG_MOVING_BOUNDARY   (PART_FLAG_START << 1)
 #define FG_SURFACE           (PART_FLAG_START << 6)
+#define FG_INTERFACE         (PART_FLAG_START << 7)
 
 #define SPHX_BLOCK_FORCES 128   // one CFL entry per 128 particles (getFmaxElements contract)
 

@@ -42,6 +42,7 @@ PART_FLAG_SHIFT = 3
 FG_COMPUTE_FORCE = 1 << 3
 FG_MOVING_BOUNDARY = 1 << 4
 FG_SURFACE = 1 << 9
+FG_INTERFACE = 1 << 10
 # cell types / hash
 CELLTYPE_INNER_CELL, CELLTYPE_INNER_EDGE_CELL, CELLTYPE_OUTER_EDGE_CELL, CELLTYPE_OUTER_CELL = 0, 1, 2, 3
 CELLTYPE_BITMASK = 0x3FFFFFFF
@@ -68,4 +69,4 @@ DEFAULT_LINEARIZATION = "yzx"
 SHEPARD_FILTER, MLS_FILTER = 0, 1
 
 # PostProcessType (src/particledefine.h:290-299)
-VORTICITY, TESTPOINTS, SURFACE_DETECTION = 0, 1, 2
+VORTICITY, TESTPOINTS, SURFACE_DETECTION, INTERFACE_DETECTION = 0, 1, 2, 3

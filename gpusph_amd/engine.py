@@ -182,8 +182,8 @@ class TimestepEngine:
     # ------------------------------------------------------------------ post-processing (before writes)
     def postprocess(self, pptype, normals=False):
         """POSTPROCESS command (src/GPUWorker.cc runCommand<POSTPROCESS>): VORTICITY returns a [n,3] tensor,
-        TESTPOINTS updates the velocity rows of test points in place, SURFACE_DETECTION updates FG_SURFACE in
-        INFO in place (and returns the normals when asked)."""
+        TESTPOINTS updates the velocity rows of test points in place, SURFACE_DETECTION updates FG_SURFACE (and
+        INTERFACE_DETECTION also FG_INTERFACE) in INFO in place, and returns the normals when asked."""
         L, h, s = self.lib, self.ctx.handle, self._stream()
         p = capi.ptr
         n = self.n
@@ -192,10 +192,11 @@ class TimestepEngine:
         vort = nrm = None
         if pptype == D.VORTICITY:
             vort = out = torch.empty((self.alloc, 3), dtype=torch.float32, device=self.device)
-        if pptype == D.SURFACE_DETECTION and normals:
+        detect = pptype in (D.SURFACE_DETECTION, D.INTERFACE_DETECTION)
+        if detect and normals:
             nrm = out = torch.empty((self.alloc, 4), dtype=torch.float32, device=self.device)
         capi.check(L.sphx_postprocess(h, int(pptype), p(vort), p(self.vel) if pptype == D.TESTPOINTS else None,
-                                      p(self.info) if pptype == D.SURFACE_DETECTION else None, p(nrm),
+                                      p(self.info) if detect else None, p(nrm),
                                       p(self.pos), p(self.vel), p(self.info), p(self.hash), p(self.cellStart),
                                       p(self.neibslist), n, n, float(getattr(pp, "cosconeanglefluid", 0.86)),
                                       float(getattr(pp, "cosconeanglenonfluid", 0.5)), s))

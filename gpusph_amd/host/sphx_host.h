@@ -584,11 +584,12 @@ public:
 		if (pp) { m_cosf = pp->cosconeanglefluid; m_cosn = pp->cosconeanglenonfluid; }
 	}
 	void getconstants() override {}
+	bool detects() const { return m_type == SURFACE_DETECTION || m_type == INTERFACE_DETECTION; }
 	flag_t get_written_buffers() const override {
-		return m_type == VORTICITY ? BUFFER_VORTICITY : m_type == SURFACE_DETECTION ? (m_options & BUFFER_NORMALS) : BUFFER_NONE;
+		return m_type == VORTICITY ? BUFFER_VORTICITY : detects() ? (m_options & BUFFER_NORMALS) : BUFFER_NONE;
 	}
 	flag_t get_updated_buffers() const override {
-		return m_type == TESTPOINTS ? BUFFER_VEL : m_type == SURFACE_DETECTION ? BUFFER_INFO : BUFFER_NONE;
+		return m_type == TESTPOINTS ? BUFFER_VEL : detects() ? BUFFER_INFO : BUFFER_NONE;
 	}
 	void process(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint particleRangeEnd,
 		uint, const GlobalData * const) override
@@ -596,8 +597,8 @@ public:
 		sphx_throw(sphx_postprocess(m_c->ctx(), (int)m_type,
 			m_type == VORTICITY ? bufwrite.getData<BUFFER_VORTICITY>() : nullptr,
 			m_type == TESTPOINTS ? bufwrite.getData<BUFFER_VEL>() : nullptr,
-			m_type == SURFACE_DETECTION ? bufwrite.getData<BUFFER_INFO>() : nullptr,
-			(m_type == SURFACE_DETECTION && (m_options & BUFFER_NORMALS)) ? bufwrite.getData<BUFFER_NORMALS>() : nullptr,
+			detects() ? bufwrite.getData<BUFFER_INFO>() : nullptr,
+			(detects() && (m_options & BUFFER_NORMALS)) ? bufwrite.getData<BUFFER_NORMALS>() : nullptr,
 			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
 			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
 			numParticles, particleRangeEnd, m_cosf, m_cosn, nullptr));
@@ -629,7 +630,7 @@ public:
 	// newPostProcessEngine (src/cuda/cudasimframework.cu:249-268): the engines not built here throw like the reference's default
 	AbstractPostProcessEngine *newPostProcessEngine(PostProcessType pptype, flag_t options = NO_FLAGS)
 	{
-		if (pptype != VORTICITY && pptype != TESTPOINTS && pptype != SURFACE_DETECTION)
+		if (pptype != VORTICITY && pptype != TESTPOINTS && pptype != SURFACE_DETECTION && pptype != INTERFACE_DETECTION)
 			throw std::runtime_error("Unknown filter type");
 		return new HIPPostProcessEngine(m_c, pptype, options);
 	}

@@ -61,7 +61,7 @@ enum sphx_viscmodel   { SPHX_MORRIS = 0, SPHX_MONAGHAN = 1, SPHX_ESPANOL_REVENGA
 enum sphx_avgop       { SPHX_ARITHMETIC = 0, SPHX_HARMONIC = 1, SPHX_GEOMETRIC = 2 };      /* src/average.h */
 enum sphx_runmode     { SPHX_REPACK = 0, SPHX_SIMULATE = 1 };
 enum sphx_filter      { SPHX_SHEPARD_FILTER = 0, SPHX_MLS_FILTER = 1 };   /* FilterType, src/particledefine.h:255-260 */
-enum sphx_postproc    { SPHX_VORTICITY = 0, SPHX_TESTPOINTS = 1, SPHX_SURFACE_DETECTION = 2 };   /* PostProcessType, :290-299 */
+enum sphx_postproc    { SPHX_VORTICITY = 0, SPHX_TESTPOINTS = 1, SPHX_SURFACE_DETECTION = 2, SPHX_INTERFACE_DETECTION = 3 };   /* PostProcessType, :290-299 */
 #define SPHX_PERIODIC_X 1u
 #define SPHX_PERIODIC_Y 2u
 #define SPHX_PERIODIC_Z 4u
@@ -256,6 +256,8 @@ int sphx_filter_process(sphx_ctx *ctx, int filtertype, void *newVel,
  *                           velocity (xyz) and pressure (w) of their fluid neighbours; reads info
  *   SPHX_SURFACE_DETECTION  sets/clears FG_SURFACE of fluid particles in infoInOut; reads vel; normals (float4,
  *                           BUFFER_NORMALS option) may be NULL; cosconeangle*: PhysParams, src/physparams.h:370-371
+ *   SPHX_INTERFACE_DETECTION  multi-fluid runs (calcInterfaceparticleDevice, post_process_kernel.cu:388-560): FG_SURFACE as
+ *                           above plus FG_INTERFACE for fluid particles whose same-fluid cone is empty; same buffers
  * Buffers a type does not use may be NULL. */
 int sphx_postprocess(sphx_ctx *ctx, int type,
 	void *vorticity, void *velInOut, void *infoInOut, void *normals,

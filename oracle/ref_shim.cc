@@ -133,6 +133,7 @@ int ref_enum(int which)
 	case 27: return (int)ENABLE_MULTIFLUID; case 28: return (int)ENABLE_REPACKING; case 29: return NEWTONIAN;
 	case 30: return KINEMATIC; case 31: return DYNAMIC; case 32: return MORRIS; case 33: return ARITHMETIC;
 	case 34: return HARMONIC; case 35: return GEOMETRIC; case 36: return REPACK; case 37: return SIMULATE;
+	case 38: return INTERFACE_DETECTION; case 39: return FG_INTERFACE;
 	}
 	return -1;
 }

@@ -33,6 +33,7 @@ enum { PT_FLUID = 0, PT_BOUNDARY, PT_VERTEX, PT_TESTPOINT, PT_NONE };
 #define FG_COMPUTE_FORCE     (PART_FLAG_START << 0)
 #define FG_MOVING_BOUNDARY   (PART_FLAG_START << 1)
 #define FG_SURFACE           (PART_FLAG_START << 6)
+#define FG_INTERFACE         (PART_FLAG_START << 7)
 #define PART_TYPE(f)         ((f).x & 7)
 #define FLUID(f)             (PART_TYPE(f) == PT_FLUID)
 #define BOUNDARY(f)          (PART_TYPE(f) == PT_BOUNDARY)
@@ -1541,6 +1542,95 @@ void orc_testpoints(const orc_params *p, orc_f4 *velArray,
 			avg.x = avg.y = avg.z = avg.w = 0.0f;
 		}
 		velArray[index] = avg;
+	}
+}
+
+/* calcInterfaceparticleDevice :388-560 (non-SA): FG_SURFACE / FG_INTERFACE flags of fluid particles of a multi-fluid run.
+ * Two SPH normals per particle: one over all neighbours (free surface), one over the neighbours of the same fluid and the
+ * non-fluid ones (interface); a particle whose cone is empty for the first is at the free surface, one whose cone is empty
+ * only for the second is at the interface.  Unlike the surface kernel the gradient sum carries the particle's own volume
+ * (applied after the loop) and planes do not enter.  infoArray is updated in place. */
+void orc_interface(const orc_params *p, orc_info *infoArray, orc_f4 *normals /* may be NULL */,
+	const orc_f4 *posArray, const orc_f4 *velArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd,
+	float cosconeanglefluid, float cosconeanglenonfluid)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
+	/* only type bits and fluid numbers of the neighbours are read, which this pass never changes: in place is race free */
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		orc_info info = infoArray[index];
+		const orc_f4 pos = posArray[index];
+		if (PART_TYPE(info) != PT_FLUID || INACTIVE(pos)) {
+			if (normals) { const orc_f4 nn = { NAN, NAN, NAN, NAN }; normals[index] = nn; }
+			continue;
+		}
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		info.x &= (uint16_t)~(FG_SURFACE | FG_INTERFACE);
+		const float p_volume = pos.w/physical_density(p, velArray[index].w, FLUID_NUM(info));
+		orc_f4 nfs = {0, 0, 0, 0}, nif = {0, 0, 0, 0};
+		nfs.w = W_c(p->kerneltype, 0.0f, p->slength, wcoeff, wsub)*p_volume;
+		nif.w = W_c(p->kerneltype, 0.0f, p->slength, wcoeff, wsub)*p_volume;
+		for (int ptype = PT_FLUID; ptype <= PT_BOUNDARY; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				if (!isfinite(npos.w)) continue;
+				const orc_info n_info = infoArray[neib_index];
+				const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+				const float n_volume = npos.w/physical_density(p, velArray[neib_index].w, FLUID_NUM(n_info));
+				if (r < p->influenceradius) {
+					const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+					nfs.x -= f*rx; nfs.y -= f*ry; nfs.z -= f*rz;
+					nfs.w += W_c(p->kerneltype, r, p->slength, wcoeff, wsub)*n_volume;
+				}
+				if (r < p->influenceradius && (FLUID_NUM(info) == FLUID_NUM(n_info) || PART_TYPE(n_info) != PT_FLUID)) {
+					const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+					nif.x -= f*rx; nif.y -= f*ry; nif.z -= f*rz;
+					nif.w += W_c(p->kerneltype, r, p->slength, wcoeff, wsub)*n_volume;
+				}
+			}
+		}
+		nfs.x *= p_volume; nfs.y *= p_volume; nfs.z *= p_volume;
+		nif.x *= p_volume; nif.y *= p_volume; nif.z *= p_volume;
+		const float lfs = sqrtf(nfs.x*nfs.x + nfs.y*nfs.y + nfs.z*nfs.z);
+		const float lif = sqrtf(nif.x*nif.x + nif.y*nif.y + nif.z*nif.z);
+		int nc_fs = 0, nc_if = 0;
+		for (int ptype = PT_FLUID; ptype <= PT_BOUNDARY; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				if (!isfinite(npos.w)) continue;
+				const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+				const orc_info n_info = infoArray[neib_index];
+				const float cosconeangle = (PART_TYPE(n_info) == PT_FLUID) ? cosconeanglefluid : cosconeanglenonfluid;
+				if (r < p->influenceradius) {
+					const float criteria = -(nfs.x*rx + nfs.y*ry + nfs.z*rz);
+					if (criteria > r*lfs*cosconeangle) nc_fs++;
+				}
+				if (r < p->influenceradius && (FLUID_NUM(info) == FLUID_NUM(n_info) || PART_TYPE(n_info) != PT_FLUID)) {
+					const float criteria = -(nif.x*rx + nif.y*ry + nif.z*rz);
+					if (criteria > r*lif*cosconeangle) nc_if++;
+				}
+			}
+		}
+		if (!nc_fs) info.x |= FG_SURFACE;
+		if (!nc_if && nc_fs) info.x |= FG_INTERFACE;
+		infoArray[index] = info;
+		if (normals) {
+			nfs.x /= lfs; nfs.y /= lfs; nfs.z /= lfs;
+			nif.x /= lif; nif.y /= lif; nif.z /= lif;
+			normals[index] = (!nc_if && nc_fs) ? nif : nfs;
+		}
 	}
 }
 

@@ -61,7 +61,7 @@ def datamodel():
     enc = np.array([ref.ref_encode_cell(int(c)) for c in cells], dtype=np.uint32)
     dec = np.array([ref.ref_decode_cell(int(e) + 37) for e in enc], dtype=np.int32)
     consts = np.array([ref.ref_constant(i) for i in range(11)], dtype=np.uint32)
-    enums = np.array([ref.ref_enum(i) for i in range(38)], dtype=np.int32)
+    enums = np.array([ref.ref_enum(i) for i in range(40)], dtype=np.int32)
     wvals = np.array([0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45], dtype=np.float32)
     active = np.array([ref.ref_active(float(w)) for w in wvals], dtype=np.int32)
     np.savez_compressed(os.path.join(HERE, "ref_datamodel.npz"), info=info, id=ids, ptype=ptype, object=obj, fluid=fl,

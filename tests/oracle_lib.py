@@ -252,6 +252,13 @@ class Oracle:
                            C.c_float(cosf), C.c_float(cosn))
         return new, nrm
 
+    def interface(self, pos, vel, info, hash_, cs, nl, range_end, normals=False, cosf=0.86, cosn=0.5):
+        new = info.copy()
+        nrm = np.zeros((len(pos), 4), dtype=np.float32) if normals else None
+        self.L.orc_interface(C.byref(self.p), P(new), P(nrm), P(pos), P(vel), P(hash_), P(cs), P(nl), C.c_uint32(range_end),
+                             C.c_float(cosf), C.c_float(cosn))
+        return new, nrm
+
     def sps(self, pos, vel, info, hash_, cs, nl, n, range_end):
         tau = np.zeros((len(pos), 6), dtype=np.float32)
         tv = np.zeros(len(pos), dtype=np.float32)

@@ -426,3 +426,22 @@ def test_stillwater_mirror_trajectory(use_planes):
     assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * vs
     assert np.abs(out["vel"][:, 3] - sim.vel[:n, 3]).max() <= 1e-6 * steps
     assert abs(eng.current_dt() - sim.dt) <= 2e-5 * sim.dt
+
+
+def test_interface_detection_bit_exact():
+    """INTERFACE_DETECTION post-processing (calcInterfaceparticleDevice) on a jittered two-fluid column with a feedback body:
+    flags and normals equal the oracle's bit for bit (polynomial kernel, IEEE division and sqrt, the reference's order)"""
+    import torch
+    prob = DamBreak3D(deltap=0.03, obstacle=True, jitter=0.2, hydrostatic=True, two_fluids=True)
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    eng.build_neibs(); sim.build_neibs()
+    n = eng.n
+    ref_info, ref_nrm = sim.o.interface(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n, normals=True)
+    nrm = _np(eng.postprocess(D.INTERFACE_DETECTION, normals=True))
+    got = _np(eng.info, np.uint16)[:n]
+    assert np.array_equal(got, ref_info[:n])
+    assert ((got[:, 0] & D.FG_INTERFACE) != 0).sum() > 100 and ((got[:, 0] & D.FG_SURFACE) != 0).sum() > 100
+    assert np.array_equal(nrm.view(np.uint32), ref_nrm[:n].view(np.uint32))
+    # running it again on the flagged INFO is idempotent (the pass clears both flags first)
+    eng.postprocess(D.INTERFACE_DETECTION)
+    assert np.array_equal(_np(eng.info, np.uint16)[:n], ref_info[:n])

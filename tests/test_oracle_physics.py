@@ -965,3 +965,41 @@ def test_stillwater_mirror_stays_still(use_planes):
     vmax = np.abs(sim.vel[:n][fluid, :3]).max()
     assert 0.0 < vmax < 0.05 * pp.sscoeff[0]
     assert np.abs(sim.vel[:n][fluid, 3]).max() < 2.0 * 1000.0 * 9.81 * prob.H / pp.bcoeff[0]
+
+
+def test_interface_detection_two_fluids():
+    """INTERFACE_DETECTION (calcInterfaceparticleDevice) on a two-fluid column: the top layer is free surface, the layers
+    either side of the fluid-fluid interface are flagged FG_INTERFACE (and not FG_SURFACE), the bulk carries neither;
+    interface normals point from each fluid towards the other"""
+    prob = DamBreak3D(deltap=0.03, obstacle=False, hydrostatic=False, two_fluids=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs()
+    n = sim.n
+    info, nrm = sim.o.interface(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n, normals=True)
+    gp = prob.global_pos(sim.pos[:n], sim.hash[:n])
+    fluid = (sim.info[:n, 0] & 7) == 0
+    fnum = (sim.info[:n, 1] >> 12) & 0xF
+    surf = (info[:n, 0] & D.FG_SURFACE) != 0
+    inter = (info[:n, 0] & D.FG_INTERFACE) != 0
+    assert not np.any(surf[~fluid]) and not np.any(inter[~fluid]) and not np.any(surf & inter)
+    assert np.array_equal(info[:n, 1:], sim.info[:n, 1:])
+    dp = prob.m_deltap
+    inner = fluid & (gp[:, 0] < gp[fluid, 0].max() - 3 * dp) & (gp[:, 0] > gp[fluid, 0].min() + 3 * dp) & (gp[:, 1] > 0.2) & (gp[:, 1] < 0.47)
+    zi = 0.5 * prob.H
+    lower_if = inner & (fnum == 0) & (gp[:, 2] > gp[fluid & (fnum == 0), 2].max() - 0.5 * dp)
+    upper_if = inner & (fnum == 1) & (gp[:, 2] < gp[fluid & (fnum == 1), 2].min() + 0.5 * dp)
+    assert lower_if.sum() > 20 and upper_if.sum() > 20
+    assert inter[lower_if].mean() > 0.95 and inter[upper_if].mean() > 0.95
+    top = inner & (gp[:, 2] > gp[fluid, 2].max() - 0.5 * dp)
+    assert surf[top].mean() > 0.95 and inter[top].mean() < 0.05
+    bulk = inner & (np.abs(gp[:, 2] - zi) > 2.5 * dp) & (gp[:, 2] < gp[fluid, 2].max() - 2.5 * dp)
+    assert bulk.sum() > 20 and surf[bulk].mean() < 0.01 and inter[bulk].mean() < 0.01
+    # normals: the lower fluid's interface normal points up (out of its own phase), the upper fluid's points down
+    assert np.all(nrm[:n][lower_if & inter][:, 2] > 0.9) and np.all(nrm[:n][upper_if & inter][:, 2] < -0.9)
+    # with one fluid the interface pass flags exactly the free surface of the surface pass (no planes)
+    prob1 = DamBreak3D(deltap=0.04, obstacle=False, hydrostatic=False)
+    s1 = ol.OracleSim(prob1); s1.build_neibs()
+    i_if, _ = s1.o.interface(s1.pos, s1.vel, s1.info, s1.hash, s1.cs, s1.nl, s1.n)
+    i_fs, _ = s1.o.surface(s1.pos, s1.vel, s1.info, s1.hash, s1.cs, s1.nl, s1.n)
+    assert not np.any(i_if[:s1.n, 0] & D.FG_INTERFACE)
+    assert ((i_if[:s1.n, 0] ^ i_fs[:s1.n, 0]) & D.FG_SURFACE != 0).mean() < 0.002

@@ -96,7 +96,7 @@ def test_datamodel_matches_reference_golden():
                        D.ARTIFICIAL, D.SPS, D.LAMINAR_FLOW, D.MK_BOUNDARY, D.ENABLE_PLANES, D.ENABLE_DTADAPT,
                        8, 4, D.FG_SURFACE, D.PT_TESTPOINT, D.INVISCID,     # 8 = SPHX_MAX_PLANES, 4 = SPHX_MAX_FLUIDS
                        D.ENABLE_MULTIFLUID, D.ENABLE_REPACKING, D.NEWTONIAN, D.KINEMATIC, D.DYNAMIC, D.MORRIS, D.ARITHMETIC,
-                       D.HARMONIC, D.GEOMETRIC, D.REPACK, D.SIMULATE]
+                       D.HARMONIC, D.GEOMETRIC, D.REPACK, D.SIMULATE, D.INTERFACE_DETECTION, D.FG_INTERFACE]
     assert list(np.isfinite(g["wvals"]).astype(np.int32)) == list(g["active"])
 
 
