@@ -28,13 +28,28 @@ DEFAULT_PARTICLES = 32_000_000     # BASELINE.json configs[3]: DamBreak3D 32M (f
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
 
 
-def cpu_baseline(target_particles=400_000, steps=2):
+def usable_cpus():
+    """CPUs this process may really run on: the affinity mask capped by the cgroup CPU quota (the GPU boxes show 256 CPUs
+    with a quota of 16; 128 OpenMP threads there run 2.3x slower than 16)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(int(int(quota) / int(period)), 1))
+    except (OSError, ValueError):
+        pass
+    return max(n, 1)
+
+
+def cpu_baseline(target_particles=4_000_000, steps=6):
     """Oracle (OpenMP port of the reference algorithm) on a bounded sample of the same workload."""
     import oracle_lib as ol
     from gpusph_amd.problem import DamBreak3D
+    ol.lib().orc_set_num_threads(usable_cpus())
     dp = DamBreak3D.deltap_for(target_particles)
     prob = DamBreak3D(dp, obstacle=True)
     sim = ol.OracleSim(prob)
+    sim.o.reuse_nl = True            # the list buffer is allocated once, like the device buffer it stands for
     sim.step()                       # includes the neighbour build (iteration 0)
     t0 = time.perf_counter()
     done = 0

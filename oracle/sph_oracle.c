@@ -55,6 +55,16 @@ enum { PT_FLUID = 0, PT_BOUNDARY, PT_VERTEX, PT_TESTPOINT, PT_NONE };
 uint32_t orc_info_id(orc_info i) { return (uint32_t)i.z | ((uint32_t)i.w << 16); }
 int orc_info_type(orc_info i) { return PART_TYPE(i); }
 
+/* timing runs set this to the CPUs the process may really use (cgroup quota), tests leave the OpenMP default */
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+	if (n > 0) omp_set_num_threads(n);
+#else
+	(void)n;
+#endif
+}
+
 int orc_num_threads(void)
 {
 #ifdef _OPENMP
