@@ -74,7 +74,7 @@ __device__ __forceinline__ float kernel_F(const DevParams &p, float r, float inv
 // 16 B gives the same numbers with ~20 fewer issue slots per pair -- and, being per particle, can
 // afford the accurate powf and IEEE division (closer to the oracle than __powf would be).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 eos_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__restrict__ info,
 	float4 *__restrict__ aux, uint32_t n)
 {
@@ -95,7 +95,7 @@ eos_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__re
 
 // SPS + tiled kernel: the three float2 arrays of BUFFER_TAU repacked as two float4 rows per particle, so that the window
 // rows can be staged with the same 16-byte LDS DMA as pos / vel / the EOS row
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 tau_pack_kernel(const float2 *__restrict__ t0, const float2 *__restrict__ t1, const float2 *__restrict__ t2,
 	float4 *__restrict__ out, uint32_t n)
 {
@@ -1165,7 +1165,7 @@ __device__ __forceinline__ float block_max_256(float v)
 	return v;
 }
 
-__global__ void __launch_bounds__(BLOCK_FMAX)
+static __global__ void __launch_bounds__(BLOCK_FMAX)
 fmax_kernel(float *__restrict__ output, const float4 *__restrict__ input, uint32_t numquarts)
 {
 	float m = 0.0f;
@@ -1177,7 +1177,7 @@ fmax_kernel(float *__restrict__ output, const float4 *__restrict__ input, uint32
 	if (threadIdx.x == 0) output[blockIdx.x] = m;
 }
 
-__global__ void __launch_bounds__(BLOCK_FMAX)
+static __global__ void __launch_bounds__(BLOCK_FMAX)
 dt_final_kernel(float *__restrict__ d_dt, const float *__restrict__ partial, uint32_t numPartials,
 	float slength, float dtadaptfactor, float sspeed_cfl, float max_kinematic, int viscous, int combine_min)
 {
@@ -1200,7 +1200,7 @@ dt_final_kernel(float *__restrict__ d_dt, const float *__restrict__ partial, uin
 // element of each segment (src/cuda/forces.cu:966-1004); only those totals are consumed
 // (src/GPUWorker.cc REDUCE_BODIES_FORCES), so they are produced directly: one block per body.
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
+static __global__ void __launch_bounds__(256)
 rb_reduce_kernel(const float4 *__restrict__ rbforces, const float4 *__restrict__ rbtorques,
 	const uint32_t *__restrict__ rbnum, const uint32_t *__restrict__ lastindex,
 	float *__restrict__ totals /* 6 per body */, uint32_t numParts)
@@ -1357,6 +1357,19 @@ sps_kernel(DevParams p, SpsArgs a, const uint32_t *runIfNonZero)
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
+// This file is compiled five times (see the Makefile): once per SPH kernel type with SPHX_FORCES_PART = that type, for the
+// template instantiations of the type (each is minutes of compile time: ~30 tiled + ~30 generic kernels), and once without
+// SPHX_FORCES_PART for the C ABI, which reaches the instantiations through the sphx_part_* functions below.
+struct SpsArgs;
+#define SPHX_PART_DECL(K) \
+	int sphx_part_forces_k##K(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const ForcesArgs &a, bool use_tiles); \
+	void sphx_part_stress_k##K(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &fa); \
+	void sphx_part_sps_k##K(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const SpsArgs &a, const uint32_t *guard);
+SPHX_PART_DECL(1) SPHX_PART_DECL(2) SPHX_PART_DECL(3) SPHX_PART_DECL(4)
+#undef SPHX_PART_DECL
+static_assert(SPHX_CUBICSPLINE == 1 && SPHX_QUADRATIC == 2 && SPHX_WENDLAND == 3 && SPHX_GAUSSIAN == 4, "part numbering = kernel type");
+
+#ifndef SPHX_FORCES_PART
 extern "C" uint32_t sphx_forces_fmax_elements(uint32_t n) { return round_up_u(div_up_u(n, SPHX_BLOCK_FORCES), 4u); }
 extern "C" uint32_t sphx_forces_fmax_temp_elements(uint32_t nels)
 {
@@ -1369,6 +1382,7 @@ extern "C" uint32_t sphx_forces_fmax_temp_elements(uint32_t nels)
 	return numBlocks;
 }
 extern "C" uint32_t sphx_forces_round_particles(uint32_t n) { return (n/SPHX_BLOCK_FORCES)*SPHX_BLOCK_FORCES; }
+#endif
 
 template<int KERNEL, int TURB, int COLA>
 static void launch_forces_mf(bool multifluid, dim3 grid, hipStream_t stream, const DevParams &p, const ForcesArgs &a,
@@ -1464,6 +1478,25 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 	return SPHX_OK;
 }
 
+#ifdef SPHX_FORCES_PART
+#define SPHX_PASTE2(a, b) a##b
+#define SPHX_PASTE(a, b) SPHX_PASTE2(a, b)
+int SPHX_PASTE(sphx_part_forces_k, SPHX_FORCES_PART)(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const ForcesArgs &a, bool use_tiles)
+{
+	return launch_forces_k<SPHX_FORCES_PART>(ctx, grid, stream, a, use_tiles);
+}
+void SPHX_PASTE(sphx_part_stress_k, SPHX_FORCES_PART)(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &fa)
+{
+	forces_tile_kernel<SPHX_FORCES_PART, SPHX_ARTIFICIAL | SPHX_TURB_STRESS, DIFF_NONE, false>
+		<<<ctx->tile_grid, TILE_THREADS, 0, stream>>>(ctx->dev, fa, ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy);
+}
+void SPHX_PASTE(sphx_part_sps_k, SPHX_FORCES_PART)(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const SpsArgs &a, const uint32_t *guard)
+{
+	if (ctx->dev.numfluids > 1) sps_kernel<SPHX_FORCES_PART, true><<<grid, 128, 0, stream>>>(ctx->dev, a, guard);
+	else sps_kernel<SPHX_FORCES_PART, false><<<grid, 128, 0, stream>>>(ctx->dev, a, guard);
+}
+#else   // the C ABI, to the end of the file
+
 extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
@@ -1543,10 +1576,10 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	}
 	int rc;
 	switch (ctx->dev.kerneltype) {
-	case SPHX_CUBICSPLINE: rc = launch_forces_k<SPHX_CUBICSPLINE>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
-	case SPHX_QUADRATIC:   rc = launch_forces_k<SPHX_QUADRATIC>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
-	case SPHX_WENDLAND:    rc = launch_forces_k<SPHX_WENDLAND>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
-	case SPHX_GAUSSIAN:    rc = launch_forces_k<SPHX_GAUSSIAN>(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
+	case SPHX_CUBICSPLINE: rc = sphx_part_forces_k1(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
+	case SPHX_QUADRATIC:   rc = sphx_part_forces_k2(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
+	case SPHX_WENDLAND:    rc = sphx_part_forces_k3(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
+	case SPHX_GAUSSIAN:    rc = sphx_part_forces_k4(ctx, dim3(numBlocks), (hipStream_t)stream, a, use_tiles); break;
 	default: return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid kernel type");
 	}
 	if (rc != SPHX_OK) return rc;
@@ -1653,26 +1686,20 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 		fa.fromParticle = 0; fa.toParticle = particleRangeEnd;
 		fa.dbg = ctx->tile_debug & 4;
 		switch (ctx->dev.kerneltype) {
-#define SPHX_STRESS_TILE(K) forces_tile_kernel<K, SPHX_ARTIFICIAL | SPHX_TURB_STRESS, DIFF_NONE, false> \
-			<<<ctx->tile_grid, TILE_THREADS, 0, (hipStream_t)stream>>>(ctx->dev, fa, ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy)
-		case SPHX_CUBICSPLINE: SPHX_STRESS_TILE(SPHX_CUBICSPLINE); break;
-		case SPHX_QUADRATIC:   SPHX_STRESS_TILE(SPHX_QUADRATIC); break;
-		case SPHX_WENDLAND:    SPHX_STRESS_TILE(SPHX_WENDLAND); break;
-		default:               SPHX_STRESS_TILE(SPHX_GAUSSIAN); break;
-#undef SPHX_STRESS_TILE
+		case SPHX_CUBICSPLINE: sphx_part_stress_k1(ctx, (hipStream_t)stream, fa); break;
+		case SPHX_QUADRATIC:   sphx_part_stress_k2(ctx, (hipStream_t)stream, fa); break;
+		case SPHX_WENDLAND:    sphx_part_stress_k3(ctx, (hipStream_t)stream, fa); break;
+		default:               sphx_part_stress_k4(ctx, (hipStream_t)stream, fa); break;
 		}
 		SPHX_LAUNCH_CHECK("forces_tile_kernel (SPS stress)");
 		guard = ctx->tile_ctl + 1;
 		grid.x = grid.x < 2048u ? grid.x : 2048u;   // stand-by launch: every block returns at once unless the tiling overflowed
 	}
 	switch (ctx->dev.kerneltype) {
-#define SPHX_SPS_LAUNCH(K) do { if (ctx->dev.numfluids > 1) sps_kernel<K, true><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a, guard); \
-		else sps_kernel<K, false><<<grid, 128, 0, (hipStream_t)stream>>>(ctx->dev, a, guard); } while (0)
-	case SPHX_CUBICSPLINE: SPHX_SPS_LAUNCH(SPHX_CUBICSPLINE); break;
-	case SPHX_QUADRATIC:   SPHX_SPS_LAUNCH(SPHX_QUADRATIC); break;
-	case SPHX_WENDLAND:    SPHX_SPS_LAUNCH(SPHX_WENDLAND); break;
-	default:               SPHX_SPS_LAUNCH(SPHX_GAUSSIAN); break;
-#undef SPHX_SPS_LAUNCH
+	case SPHX_CUBICSPLINE: sphx_part_sps_k1(ctx, grid, (hipStream_t)stream, a, guard); break;
+	case SPHX_QUADRATIC:   sphx_part_sps_k2(ctx, grid, (hipStream_t)stream, a, guard); break;
+	case SPHX_WENDLAND:    sphx_part_sps_k3(ctx, grid, (hipStream_t)stream, a, guard); break;
+	default:               sphx_part_sps_k4(ctx, grid, (hipStream_t)stream, a, guard); break;
 	}
 	SPHX_LAUNCH_CHECK("sps_kernel");
 	return SPHX_OK;
@@ -1726,3 +1753,4 @@ extern "C" int sphx_forces_timing_read(sphx_ctx *ctx, double *total_ms, uint32_t
 	*total_ms = sum; *launches = n;
 	return SPHX_OK;
 }
+#endif // !SPHX_FORCES_PART
