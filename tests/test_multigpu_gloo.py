@@ -31,9 +31,13 @@ def _worker(rank, world, port, steps, case, outdir, filters=()):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     case = dict(case)
     gate = case.pop("moving_gate", False)
-    if case.pop("problem", "DamBreak3D") == "StillWater":
+    which = case.pop("problem", "DamBreak3D")
+    if which == "StillWater":
         from gpusph_amd.problem import StillWater
         prob = StillWater(**case)
+    elif which == "WaveTank":
+        from gpusph_amd.problem import WaveTank
+        prob = WaveTank(**case)
     else:
         prob = DamBreak3D(**case)
     if gate:
@@ -168,3 +172,23 @@ def test_slab_run_of_the_stillwater_mirror_equals_single_domain(tmp_path):
         assert np.array_equal(one[k].view(np.uint32), two[k].view(np.uint32)), k
     assert all(float(p["dt"]) == float(p1[0]["dt"]) for p in p2)
     assert all(int(p["n_local"]) < len(ids1) for p in p2)      # each rank holds a slab plus its halo, not the whole domain
+
+
+def test_slab_run_of_the_wavetank_mirror_equals_single_domain(tmp_path):
+    """WaveTank's option set (BASELINE configs[4]) over two slabs split along y: LJ box particles + six planes, SPSVISC (stress
+    tensor imported for the halo), the hinged paddle straddling the slab boundary and driven by the same host kinematics on
+    every rank, Shepard filter every 4 iterations, 10 steps: bit-equal to the single-domain run"""
+    case = dict(problem="WaveTank", deltap=0.04, paddle_tstart=0.0, linearization="xzy")
+    filters = ((0, 4),)      # SHEPARD_FILTER
+    steps = 10
+    _run(1, steps, case, str(tmp_path), filters)
+    _run(2, steps, case, str(tmp_path), filters)
+    ids1, one, p1 = _gather(str(tmp_path), 1)
+    ids2, two, p2 = _gather(str(tmp_path), 2)
+    assert np.array_equal(ids1, ids2)
+    for k in ("pos", "vel", "forces"):
+        assert np.array_equal(one[k].view(np.uint32), two[k].view(np.uint32)), k
+    assert all(float(p["dt"]) == float(p1[0]["dt"]) for p in p2)
+    paddle = (one["info"][:, 0] & 0x10) != 0
+    assert paddle.sum() > 50 and np.abs(one["vel"][paddle, :3]).max() > 1e-3     # the paddle moves
+    assert all(int(p["n_local"]) < len(ids1) for p in p2)
