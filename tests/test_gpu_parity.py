@@ -324,6 +324,9 @@ def test_multigpu_engine_world1_equals_single_engine():
 _MG_CASES = {
     "default": (dict(), ()),
     "spsvisc+shepard": (dict(viscosity="SPSVISC", kinematic_visc=1.0e-6), ((0, 4),)),
+    # StillWater's option set (laminar viscosity + Ferrari diffusion in the tiled stripes, MLS filter) and two fluids
+    "dynamicvisc+ferrari+mls": (dict(viscosity="DYNAMICVISC", kinematic_visc=3.0e-2, density_diffusion=D.FERRARI), ((1, 4),)),
+    "two-fluids": (dict(two_fluids=True), ()),
 }
 
 
