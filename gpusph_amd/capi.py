@@ -53,6 +53,7 @@ SIGNATURES = {
     "sphx_fix_hash": (_i, [_vp, _vp, _vp, _vp, _vp, _u32, _vp]),
     "sphx_sort": (_i, [_vp, _vp, _vp, _vp, _u32, _vp]),
     "sphx_reorder": (_i, [_vp] + [_vp] * 10 + [_u32, _vp, _vp]),
+    "sphx_gather_rows": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _vp]),
     "sphx_find_cell_start": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "sphx_build_neibs": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _u32, _f, _f, _vp]),
     "sphx_neibs_resetinfo": (_i, [_vp, _vp]),
@@ -60,7 +61,7 @@ SIGNATURES = {
     "sphx_forces_fmax_elements": (_u32, [_u32]),
     "sphx_forces_fmax_temp_elements": (_u32, [_u32]),
     "sphx_forces_round_particles": (_u32, [_u32]),
-    "sphx_forces_basicstep": (_i, [_vp] + [_vp] * 13 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _i,
+    "sphx_forces_basicstep": (_i, [_vp] + [_vp] * 14 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _i,
                                                        C.POINTER(_u32), _vp]),
     "sphx_forces_dtreduce": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _u32, C.POINTER(_f), _vp]),
     "sphx_forces_dtreduce_device": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _u32, _vp, _i, _vp]),
@@ -73,6 +74,16 @@ SIGNATURES = {
     "sphx_euler_basicstep": (_i, [_vp] + [_vp] * 8 + [_u32, _u32, _f, _vp, _f, _i, _f, _f, _f, _i, _vp]),
     "sphx_disable_free_surf_parts": (_i, [_vp, _vp, _vp, _u32, _u32, _vp]),
     "sphx_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
+    "sphx_device_count": (_i, [C.POINTER(_i)]),
+    "sphx_set_device": (_i, [_i]),
+    "sphx_get_device": (_i, [C.POINTER(_i)]),
+    "sphx_device_synchronize": (_i, []),
+    "sphx_malloc": (_i, [C.POINTER(_vp), C.c_size_t]),
+    "sphx_free": (_i, [_vp]),
+    "sphx_memset": (_i, [_vp, _i, C.c_size_t]),
+    "sphx_memcpy_h2d": (_i, [_vp, _vp, C.c_size_t]),
+    "sphx_memcpy_d2h": (_i, [_vp, _vp, C.c_size_t]),
+    "sphx_memcpy_d2d": (_i, [_vp, _vp, C.c_size_t]),
 }
 
 _lib = None

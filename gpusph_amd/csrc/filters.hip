@@ -650,10 +650,15 @@ repack_kernel(DevParams p, FilterArgs a, RepackArgs o)
 int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
-	uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, uint32_t numBlocks, hipStream_t st)
+	uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, uint32_t numBlocks, float deltap, hipStream_t st)
 {
 	if (!(ctx->dev.simflags & SPHX_ENABLE_REPACKING))   // src/main.cc:357-358
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: REPACK run mode needs ENABLE_REPACKING in simflags");
+	// the particle spacing of the velocity damping term is an argument of basicstep in the reference (run_repack,
+	// src/cuda/forces.cu:828-896), not an uploaded constant
+	DevParams dev = ctx->dev;
+	if (deltap > 0.0f) dev.deltap = deltap;
+	SPHX_REQUIRE(dev.deltap > 0.0f, "sphx_forces_basicstep: REPACK run mode needs the particle spacing deltap");
 	FilterArgs a;
 	a.newVel = nullptr; a.pos = (const float4*)pos; a.vel = (const float4*)vel;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
@@ -664,10 +669,10 @@ int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, 
 	o.rb = ctx->rb_dev; o.fromParticle = fromParticle; o.toParticle = toParticle; o.cflOffset = cflOffset;
 	const dim3 grid(numBlocks);
 	switch (ctx->dev.kerneltype) {
-	case SPHX_CUBICSPLINE: repack_kernel<SPHX_CUBICSPLINE><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a, o); break;
-	case SPHX_QUADRATIC:   repack_kernel<SPHX_QUADRATIC><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a, o); break;
-	case SPHX_WENDLAND:    repack_kernel<SPHX_WENDLAND><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a, o); break;
-	case SPHX_GAUSSIAN:    repack_kernel<SPHX_GAUSSIAN><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a, o); break;
+	case SPHX_CUBICSPLINE: repack_kernel<SPHX_CUBICSPLINE><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(dev, a, o); break;
+	case SPHX_QUADRATIC:   repack_kernel<SPHX_QUADRATIC><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(dev, a, o); break;
+	case SPHX_WENDLAND:    repack_kernel<SPHX_WENDLAND><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(dev, a, o); break;
+	case SPHX_GAUSSIAN:    repack_kernel<SPHX_GAUSSIAN><<<grid, SPHX_BLOCK_FORCES, 0, st>>>(dev, a, o); break;
 	default: return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid kernel type");
 	}
 	SPHX_LAUNCH_CHECK("repack_kernel");

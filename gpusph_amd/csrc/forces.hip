@@ -1501,13 +1501,13 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
-	const void *tau0, const void *tau1, const void *tau2,
+	const void *tau0, const void *tau1, const void *tau2, void *xsph,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
 	float deltap, float slength, float dtadaptfactor, float influenceradius,
 	uint32_t cflOffset, int run_mode, int step, float dt, int compute_object_forces,
 	uint32_t *h_numBlocks, void *stream)
 {
-	(void)deltap; (void)dtadaptfactor; (void)step; (void)dt;
+	(void)dtadaptfactor; (void)step; (void)dt;
 	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_forces_basicstep: constants not set");
 	SPHX_REQUIRE(forces && pos && vel && info && hash && cellStart && neibsList, "sphx_forces_basicstep: missing buffer");
 	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_forces_basicstep: invalid particle range");
@@ -1522,6 +1522,8 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	if ((ctx->dev.simflags & SPHX_ENABLE_DTADAPT))
 		SPHX_REQUIRE(cfl != nullptr, "sphx_forces_basicstep: ENABLE_DTADAPT needs the CFL buffer");
 	SPHX_REQUIRE((rbforces == nullptr) == (rbtorques == nullptr), "sphx_forces_basicstep: RB_FORCES and RB_TORQUES must come together");
+	if ((ctx->dev.simflags & SPHX_ENABLE_XSPH) && run_mode == SPHX_SIMULATE)
+		SPHX_REQUIRE(xsph != nullptr, "sphx_forces_basicstep: ENABLE_XSPH needs the XSPH buffer");
 
 	const uint32_t nrange = toParticle - fromParticle;
 	const uint32_t numBlocks = round_up_u(div_up_u(nrange, SPHX_BLOCK_FORCES), 4u);
@@ -1529,7 +1531,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	if (!numBlocks) return SPHX_OK;
 	if (run_mode == SPHX_REPACK)   // run_repack, src/cuda/forces.cu:828-896 (filters.hip)
 		return sphx_repack_launch(ctx, forces, cfl, rbforces, rbtorques, pos, vel, info, hash, cellStart, neibsList,
-			fromParticle, toParticle, cflOffset, numBlocks, (hipStream_t)stream);
+			fromParticle, toParticle, cflOffset, numBlocks, deltap, (hipStream_t)stream);
 
 	{	// EOS pre-pass over ALL particles: neighbours may lie outside [fromParticle,toParticle)
 		int rc0 = sphx_ensure_scratch(ctx, numParticles);

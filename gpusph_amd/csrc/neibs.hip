@@ -819,6 +819,34 @@ extern "C" int sphx_reorder(sphx_ctx *ctx, uint32_t *segmentStart,
 	return SPHX_OK;
 }
 
+// Reorder of the optional per-particle arrays the reference gathers in the same kernel when they are present in the buffer
+// lists (src/cuda/buildneibs.cu:263-311: VOLUME, INTERNAL_ENERGY, BOUNDELEMENTS, GRADGAMMA, VERTICES, TKE, EPSILON, TURBVISC,
+// EFFPRES, EULERVEL): sorted[i] = unsorted[partIndex[i]] for rows of 4, 8 or 16 bytes
+template<typename T>
+__global__ void __launch_bounds__(BLOCK_REORDER)
+gather_rows_kernel(T * __restrict__ sorted, const T * __restrict__ unsorted, const uint32_t * __restrict__ partIndex, uint32_t n)
+{
+	const uint32_t i = blockIdx.x*BLOCK_REORDER + threadIdx.x;
+	if (i < n) sorted[i] = unsorted[partIndex[i]];
+}
+
+extern "C" int sphx_gather_rows(sphx_ctx *ctx, void *sorted, const void *unsorted, uint32_t rowBytes,
+	const uint32_t *partIndex, uint32_t n, void *stream_)
+{
+	SPHX_REQUIRE(ctx != nullptr, "sphx_gather_rows: NULL ctx");
+	SPHX_REQUIRE(sorted && unsorted && partIndex, "sphx_gather_rows: missing buffer");
+	SPHX_REQUIRE(sorted != unsorted, "sphx_gather_rows: sorted and unsorted buffers alias");
+	SPHX_REQUIRE(rowBytes == 4 || rowBytes == 8 || rowBytes == 16, "sphx_gather_rows: rows of 4, 8 or 16 bytes");
+	if (!n) return SPHX_OK;
+	hipStream_t stream = (hipStream_t)stream_;
+	const dim3 grid(div_up_u(n, BLOCK_REORDER));
+	if (rowBytes == 4) gather_rows_kernel<uint32_t><<<grid, BLOCK_REORDER, 0, stream>>>((uint32_t*)sorted, (const uint32_t*)unsorted, partIndex, n);
+	else if (rowBytes == 8) gather_rows_kernel<uint2><<<grid, BLOCK_REORDER, 0, stream>>>((uint2*)sorted, (const uint2*)unsorted, partIndex, n);
+	else gather_rows_kernel<uint4><<<grid, BLOCK_REORDER, 0, stream>>>((uint4*)sorted, (const uint4*)unsorted, partIndex, n);
+	SPHX_LAUNCH_CHECK("gather_rows_kernel");
+	return SPHX_OK;
+}
+
 extern "C" int sphx_find_cell_start(sphx_ctx *ctx, uint32_t *cellStart, uint32_t *cellEnd, const uint32_t *sortedHash,
 	uint32_t from, uint32_t to, void *stream)
 {

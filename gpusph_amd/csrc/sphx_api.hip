@@ -323,3 +323,49 @@ extern "C" int sphx_memset_async(void *ptr, int value, size_t bytes, void *strea
 	SPHX_HIP(hipMemsetAsync(ptr, value, bytes, (hipStream_t)stream));
 	return SPHX_OK;
 }
+
+// ---- device memory service (see include/sphx.h) ----
+extern "C" int sphx_device_count(int *count)
+{
+	SPHX_REQUIRE(count != nullptr, "sphx_device_count: NULL argument");
+	SPHX_HIP(hipGetDeviceCount(count));
+	return SPHX_OK;
+}
+extern "C" int sphx_set_device(int device) { SPHX_HIP(hipSetDevice(device)); return SPHX_OK; }
+extern "C" int sphx_get_device(int *device)
+{
+	SPHX_REQUIRE(device != nullptr, "sphx_get_device: NULL argument");
+	SPHX_HIP(hipGetDevice(device));
+	return SPHX_OK;
+}
+extern "C" int sphx_device_synchronize(void) { SPHX_HIP(hipDeviceSynchronize()); return SPHX_OK; }
+extern "C" int sphx_malloc(void **ptr, size_t bytes)
+{
+	SPHX_REQUIRE(ptr != nullptr, "sphx_malloc: NULL argument");
+	*ptr = nullptr;
+	if (!bytes) return SPHX_OK;
+	SPHX_HIP(hipMalloc(ptr, bytes));
+	return SPHX_OK;
+}
+extern "C" int sphx_free(void *ptr)
+{
+	if (ptr) SPHX_HIP(hipFree(ptr));
+	return SPHX_OK;
+}
+extern "C" int sphx_memset(void *ptr, int value, size_t bytes)
+{
+	if (!bytes) return SPHX_OK;
+	SPHX_REQUIRE(ptr != nullptr, "sphx_memset: NULL pointer");
+	SPHX_HIP(hipMemset(ptr, value, bytes));
+	return SPHX_OK;
+}
+static int copy_blocking(void *dst, const void *src, size_t bytes, hipMemcpyKind kind, const char *what)
+{
+	if (!bytes) return SPHX_OK;
+	if (!dst || !src) return sphx_set_error(SPHX_ERR_INVALID, std::string(what) + ": NULL pointer");
+	SPHX_HIP(hipMemcpy(dst, src, bytes, kind));
+	return SPHX_OK;
+}
+extern "C" int sphx_memcpy_h2d(void *dst, const void *src, size_t bytes) { return copy_blocking(dst, src, bytes, hipMemcpyHostToDevice, "sphx_memcpy_h2d"); }
+extern "C" int sphx_memcpy_d2h(void *dst, const void *src, size_t bytes) { return copy_blocking(dst, src, bytes, hipMemcpyDeviceToHost, "sphx_memcpy_d2h"); }
+extern "C" int sphx_memcpy_d2d(void *dst, const void *src, size_t bytes) { return copy_blocking(dst, src, bytes, hipMemcpyDeviceToDevice, "sphx_memcpy_d2d"); }

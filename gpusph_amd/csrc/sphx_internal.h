@@ -159,7 +159,7 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles);
 int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
-	uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, uint32_t numBlocks, hipStream_t st);
+	uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, uint32_t numBlocks, float deltap, hipStream_t st);
 
 // ---- device helpers -----------------------------------------------------------------------------
 #ifdef __HIPCC__

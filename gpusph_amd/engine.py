@@ -224,7 +224,7 @@ class TimestepEngine:
             e0.record()
         capi.check(L.sphx_forces_basicstep(h, p(self.forces), p(self.cfl), p(self.rbforces) if rb else None,
                                            p(self.rbtorques) if rb else None, p(pos), p(vel), p(self.info), p(self.hash),
-                                           p(self.cellStart), p(self.neibslist), tau[0], tau[1], tau[2],
+                                           p(self.cellStart), p(self.neibslist), tau[0], tau[1], tau[2], p(getattr(self, "xsph", None)),
                                            n, 0, n, self.params.deltap, self.params.slength, self.params.dtadaptfactor,
                                            self.params.influenceradius, 0, run_mode, step, self.dt,
                                            self.compute_object_forces, C.byref(nb), s))

@@ -1,171 +1,277 @@
-// example_engines.cpp -- drives the four HIP*Engine adapters (sphx_host.h) through the command sequence
-// GPUWorker runs for one device (src/GPUWorker.cc:1779-1905 CALCHASH/SORT/REORDER/BUILDNEIBS,
-// :2188-2230 FORCES_SYNC with the blocking dtreduce, :2232-2270 EULER; predictor/corrector order of
-// src/integrators/PredictorCorrectorIntegrator.cc:386-685).  Input: a problem dump written by
-// tests/helpers (header + pos/vel/info/hash); output: pos/vel/info/hash after `steps` time steps.
-//   example_engines <in.bin> <out.bin>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <vector>
+// example_engines.cpp -- one GPUWorker's command stream, through GPUSPH's own interfaces, onto the MI355X engines.
+//
+// Everything this program touches that is not named HIP* / sphx_* is the reference's: the framework comes out of
+// SETUP_FRAMEWORK-style expressions (problem_setup.h) via cudasimframework.cu of this directory, the engines are reached
+// as SimFramework::get*Engine() -> Abstract*Engine virtuals, buffers are BufferList / Buffer<Key> objects with the
+// HIPBuffer allocation policy, parameters are the tree's SimParams / PhysParams.  The command order is the one the
+// integrator sends to a worker:
+//   neighbour phase   CALCHASH|fixHash, SORT, REORDER, BUILDNEIBS     src/Integrator.cc:94-250, src/GPUWorker.cc:1779-1905
+//   filters           FILTER + swap of the VEL buffers                src/integrators/PredictorCorrectorIntegrator.cc:831-859
+//   predictor/corr.   CALC_VISC, FORCES_SYNC (+ dtreduce), MOVE_BODIES uploads, EULER    :386-685, src/GPUWorker.cc:2188-2270
+//   post-processing   before a write                                   src/GPUWorker.cc:2540-2590
+// tests/test_gpu_parity.py runs it next to the Python driver (gpusph_amd/engine.py) on the same inputs: results bit-equal.
+//
+//   example_engines <case file> <state.bin> <out.bin>
+#define GPUSPH_MAIN
 #include <algorithm>
-#include "sphx_host.h"
+#include <cmath>
+#include <cstring>
+#include "problem_setup.h"
 
-struct DumpHeader {
-	char magic[8];
-	uint32_t n, alloc, steps, num_rb_particles;
-	float dt, sspeed_cfl, nlSqInfluenceRadius;
-	int32_t numforcesbodies;
-	int32_t rb_cgGridPos[3];
-	float rb_cgPos[3];
-	int32_t rb_firstindex;
-	int32_t filter_type, filter_freq;   // density filter (FilterType) every filter_freq iterations; freq 0 = none
-	sphx_params params;
+// a BufferList holding one freshly allocated device buffer (lists are then combined with operator|)
+template<flag_t Key>
+static BufferList one_buffer(size_t elems, int init = 0)
+{
+	BufferList l;
+	l.addBuffer<HIPBuffer, Key>(init);
+	l[Key]->alloc(elems);
+	l.mark_valid();
+	return l;
+}
+
+// ---- bodies with prescribed motion: the Chrono-free part of ProblemCore::bodies_timestep (src/ProblemCore.cc:484-610) ----
+struct Kinematics { double crot[3], lvel[3], avel[3]; };
+struct Body {
+	int firstindex; uint numparts;
+	std::string motion;             // "static" | "paddle_y"
+	double amplitude, omega, tstart, tend;
+	Kinematics initial, kdata, storage;
 };
 
-template<flag_t Key> static typename BufferTraits<Key>::element_type *alloc_buf(BufferList &bl, size_t n, int init = 0)
+// WaveTank::moving_bodies_callback (src/problems/WaveTank.cu:221-243): rotation about y through the hinge, first-order
+// quaternion step dr = normalize(1 + dt/2 (0, avel))
+static void body_callback(Body &b, double t0, double t1, double dx[3], double dr[9])
 {
-	bl.addBuffer<Key>(init);
-	bl[Key]->alloc(n);
-	bl[Key]->mark_valid();
-	return static_cast<typename BufferTraits<Key>::element_type*>(bl[Key]->get_buffer());
+	const double ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+	std::memcpy(dr, ident, sizeof(ident));
+	dx[0] = dx[1] = dx[2] = 0;
+	Kinematics &kd = b.kdata;
+	kd.lvel[0] = kd.lvel[1] = kd.lvel[2] = 0;
+	kd.avel[0] = kd.avel[1] = kd.avel[2] = 0;
+	if (b.motion == "paddle_y" && b.tstart < t1 && t1 < b.tend) {
+		const double w = b.amplitude*b.omega*sin(b.omega*(t1 - b.tstart));
+		kd.avel[1] = w;
+		double e0 = 1.0, e2 = 0.5*(t1 - t0)*w;
+		const double nrm = hypot(e0, e2);
+		e0 /= nrm; e2 /= nrm;
+		const double c = e0*e0 - e2*e2, s = 2.0*e0*e2;
+		dr[0] = c; dr[2] = s; dr[6] = -s; dr[8] = c;
+	}
 }
 
 int main(int argc, char **argv)
 {
-	if (argc < 3) { fprintf(stderr, "usage: %s in.bin out.bin\n", argv[0]); return 2; }
-	FILE *f = fopen(argv[1], "rb");
-	if (!f) { perror("open"); return 2; }
-	DumpHeader h;
-	if (fread(&h, sizeof(h), 1, f) != 1 || strncmp(h.magic, "SPHXDMP1", 8)) { fprintf(stderr, "bad dump\n"); return 2; }
-	const uint32_t n0 = h.n, A = h.alloc;
-	std::vector<float4> hpos(n0), hvel(n0);
-	std::vector<particleinfo> hinfo(n0);
-	std::vector<hashKey> hhash(n0);
-	if (fread(hpos.data(), 16, n0, f) != n0 || fread(hvel.data(), 16, n0, f) != n0 ||
-		fread(hinfo.data(), 8, n0, f) != n0 || fread(hhash.data(), 4, n0, f) != n0) { fprintf(stderr, "short dump\n"); return 2; }
-	fclose(f);
-
+	if (argc < 4) { fprintf(stderr, "usage: %s <case file> <state.bin> <out.bin>\n", argv[0]); return 2; }
 	try {
-		hip_throw(hipSetDevice(0), "hipSetDevice");
-		const sphx_params &P = h.params;
-		SimParams sp; PhysParams pp;
-		sp.kerneltype = P.kerneltype; sp.sph_formulation = P.sph_formulation; sp.densitydiffusiontype = P.densitydiffusiontype;
-		sp.boundarytype = P.boundarytype; sp.rheologytype = P.rheologytype; sp.turbmodel = P.turbmodel;
-		sp.periodicbound = P.periodic; sp.simflags = P.simflags;
-		sp.slength = P.slength; sp.kernelradius = P.kernelradius; sp.influenceRadius = P.influenceradius;
-		sp.nlSqInfluenceRadius = h.nlSqInfluenceRadius; sp.dtadaptfactor = P.dtadaptfactor;
-		sp.densityDiffCoeff = P.densityDiffCoeff; sp.neiblistsize = P.neiblistsize; sp.neibboundpos = P.neibboundpos;
-		sp.deltap = P.deltap; sp.numforcesbodies = h.numforcesbodies;
-		for (int a = 0; a < 3; ++a) sp.coord[a] = P.coord[a];
-		for (uint32_t fl = 0; fl < P.numfluids; ++fl) {
-			pp.rho0.push_back(P.rho0[fl]); pp.bcoeff.push_back(P.bcoeff[fl]); pp.gammacoeff.push_back(P.gammacoeff[fl]);
-			pp.sscoeff.push_back(P.sscoeff[fl]); pp.sspowercoeff.push_back(P.sspowercoeff[fl]); pp.visccoeff.push_back(P.visccoeff[fl]);
-		}
-		pp.gravity = make_float3(P.gravity[0], P.gravity[1], P.gravity[2]);
-		pp.artvisccoeff = P.artvisccoeff; pp.epsartvisc = P.epsartvisc;
-		const float3 origin = make_float3(P.worldOrigin[0], P.worldOrigin[1], P.worldOrigin[2]);
-		const uint3 gridSize = make_uint3(P.gridSize[0], P.gridSize[1], P.gridSize[2]);
-		const float3 cellSize = make_float3(P.cellSize[0], P.cellSize[1], P.cellSize[2]);
-		const uint gridCells = gridSize.x*gridSize.y*gridSize.z;
+		const Case c = read_case(argv[1]);
+		sphx_throw(sphx_set_device(0));                                   // checkCUDA / cudaSetDevice of the worker thread
+		std::unique_ptr<SimFramework> fw(make_framework(c));
+		SimParams *sp = fw->simparams();
+		ProblemPhysParams pp(sp->rheologytype);
+		configure_params(c, sp, pp);
+		const GridSetup g = read_grid(c);
+		const uint A = (uint)g.allocated;
+		const uint gridCells = g.gridSize.x*g.gridSize.y*g.gridSize.z;
+		const double origin[3] = { num(c, "origin", 0), num(c, "origin", 1), num(c, "origin", 2) };
+		const double cell[3] = { num(c, "cell", 0), num(c, "cell", 1), num(c, "cell", 2) };
+		const float deltap = (float)num(c, "deltap");
+		const float slength = (float)sp->slength, influenceRadius = (float)sp->influenceRadius;
+		const float sqNlRadius = (float)sp->nlSqInfluenceRadius;
+		const uint steps = (uint)num(c, "steps");
+		const float sspeed_cfl = (float)num(c, "sspeed_cfl"), max_kinvisc = (float)num(c, "max_kinvisc");
 
-		HIPSimFramework fw;
-		AbstractNeibsEngine *neibsEngine = fw.getNeibsEngine();
-		AbstractForcesEngine *forcesEngine = fw.getForcesEngine();
-		AbstractIntegrationEngine *integrationEngine = fw.getIntegrationEngine();
+		// ---- initial particle state ----
+		FILE *f = fopen(argv[2], "rb");
+		if (!f) throw std::runtime_error(std::string("cannot open ") + argv[2]);
+		uint n0 = 0;
+		if (fread(&n0, 4, 1, f) != 1 || n0 > A) throw std::runtime_error("bad state file");
+		std::vector<float4> hpos(n0), hvel(n0);
+		std::vector<particleinfo> hinfo(n0);
+		std::vector<hashKey> hhash(n0);
+		if (fread(hpos.data(), 16, n0, f) != n0 || fread(hvel.data(), 16, n0, f) != n0 ||
+			fread(hinfo.data(), 8, n0, f) != n0 || fread(hhash.data(), 4, n0, f) != n0) throw std::runtime_error("short state file");
+		fclose(f);
+
+		AbstractNeibsEngine *neibsEngine = fw->getNeibsEngine();
+		AbstractForcesEngine *forcesEngine = fw->getForcesEngine();
+		AbstractViscEngine *viscEngine = fw->getViscEngine();
+		AbstractIntegrationEngine *integrationEngine = fw->getIntegrationEngine();
+
 		// GPUWorker::uploadConstants (src/GPUWorker.cc:2989-3001)
-		forcesEngine->setconstants(&sp, &pp, origin, gridSize, cellSize, A);
-		integrationEngine->setconstants(&pp, origin, gridSize, cellSize, A, sp.neiblistsize, (float)sp.slength);
-		neibsEngine->setconstants(&sp, &pp, origin, gridSize, cellSize, A);
-		if (h.num_rb_particles) {
-			const int3 g = make_int3(h.rb_cgGridPos[0], h.rb_cgGridPos[1], h.rb_cgGridPos[2]);
-			const float3 c = make_float3(h.rb_cgPos[0], h.rb_cgPos[1], h.rb_cgPos[2]);
-			forcesEngine->setrbcg(&g, &c, 1);
-			integrationEngine->setrbcg(&g, &c, 1);   // each engine keeps its own copy (uploadForces/EulerBodiesCentersOfGravity)
-			forcesEngine->setrbstart(&h.rb_firstindex, 1);
-			const float ident[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-			const float3 z = make_float3(0, 0, 0);
-			integrationEngine->setrbsteprot(ident, 1); integrationEngine->setrbtrans(&z, 1);
-			integrationEngine->setrblinearvel(&z, 1); integrationEngine->setrbangularvel(&z, 1);
+		forcesEngine->setconstants(sp, &pp, g.origin, g.gridSize, g.cellSize, A);
+		integrationEngine->setconstants(&pp, g.origin, g.gridSize, g.cellSize, A, sp->neiblistsize, slength);
+		neibsEngine->setconstants(sp, &pp, g.origin, g.gridSize, g.cellSize, A);
+
+		// GPUWorker::uploadPlanes
+		if (has(c, "plane")) {
+			PlaneList planes;
+			const size_t np = c.at("plane").size()/9;
+			for (size_t k = 0; k < np; ++k)
+				planes.push_back(make_plane(
+					make_float3((float)num(c, "plane", 9*k), (float)num(c, "plane", 9*k + 1), (float)num(c, "plane", 9*k + 2)),
+					make_int3((int)num(c, "plane", 9*k + 3), (int)num(c, "plane", 9*k + 4), (int)num(c, "plane", 9*k + 5)),
+					make_float3((float)num(c, "plane", 9*k + 6), (float)num(c, "plane", 9*k + 7), (float)num(c, "plane", 9*k + 8))));
+			forcesEngine->setplanes(planes);
 		}
 
-		// buffers: state "n" (a) and "n*" / "sorted" (b) as in GPUWorker::m_dBuffers
-		BufferList a, b, shared;
-		float4 *posA = alloc_buf<BUFFER_POS>(a, A), *velA = alloc_buf<BUFFER_VEL>(a, A);
-		alloc_buf<BUFFER_POS>(b, A); alloc_buf<BUFFER_VEL>(b, A);
-		particleinfo *info = alloc_buf<BUFFER_INFO>(shared, A);
-		hashKey *hash = alloc_buf<BUFFER_HASH>(shared, A);
-		alloc_buf<BUFFER_PARTINDEX>(shared, A);
-		alloc_buf<BUFFER_CELLSTART>(shared, gridCells, 0xFF); alloc_buf<BUFFER_CELLEND>(shared, gridCells, 0xFF);
-		alloc_buf<BUFFER_NEIBSLIST>(shared, (size_t)sp.neiblistsize*A, 0xFF);
-		alloc_buf<BUFFER_FORCES>(shared, A);
-		alloc_buf<BUFFER_CFL>(shared, forcesEngine->getFmaxElements(A));
-		alloc_buf<BUFFER_CFL_TEMP>(shared, std::max(4u, forcesEngine->getFmaxTempElements(forcesEngine->getFmaxElements(A))));
-		if (h.num_rb_particles) { alloc_buf<BUFFER_RB_FORCES>(shared, h.num_rb_particles); alloc_buf<BUFFER_RB_TORQUES>(shared, h.num_rb_particles); }
-		for (flag_t k : { BUFFER_INFO, BUFFER_HASH, BUFFER_PARTINDEX, BUFFER_CELLSTART, BUFFER_CELLEND, BUFFER_NEIBSLIST,
-				BUFFER_FORCES, BUFFER_CFL, BUFFER_CFL_TEMP, BUFFER_RB_FORCES, BUFFER_RB_TORQUES })
-			if (shared.has(k)) { a.add(k, shared[k]); b.add(k, shared[k]); }
-		hip_throw(hipMemcpy(posA, hpos.data(), 16*(size_t)n0, hipMemcpyHostToDevice), "upload");
-		hip_throw(hipMemcpy(velA, hvel.data(), 16*(size_t)n0, hipMemcpyHostToDevice), "upload");
-		hip_throw(hipMemcpy(info, hinfo.data(), 8*(size_t)n0, hipMemcpyHostToDevice), "upload");
-		hip_throw(hipMemcpy(hash, hhash.data(), 4*(size_t)n0, hipMemcpyHostToDevice), "upload");
-		uint *d_newNum = nullptr;
-		hip_throw(hipMalloc((void**)&d_newNum, 4), "hipMalloc");
+		// ---- bodies ----
+		std::vector<Body> bodies;
+		uint numBodiesParticles = 0;
+		if (has(c, "body")) {
+			const size_t per = 10, nb = c.at("body").size()/per;   // firstindex numparts cgx cgy cgz motion amplitude omega tstart tend
+			for (size_t k = 0; k < nb; ++k) {
+				Body b;
+				b.firstindex = (int)num(c, "body", per*k); b.numparts = (uint)num(c, "body", per*k + 1);
+				for (int a = 0; a < 3; ++a) { b.initial.crot[a] = num(c, "body", per*k + 2 + a); b.initial.lvel[a] = b.initial.avel[a] = 0; }
+				b.motion = c.at("body").at(per*k + 5);
+				b.amplitude = num(c, "body", per*k + 6); b.omega = num(c, "body", per*k + 7);
+				b.tstart = num(c, "body", per*k + 8); b.tend = num(c, "body", per*k + 9);
+				b.kdata = b.storage = b.initial;
+				numBodiesParticles += b.numparts;
+				bodies.push_back(b);
+			}
+		}
+		const int numbodies = (int)bodies.size();
+		std::vector<int3> cgGrid(std::max(numbodies, 1));
+		std::vector<float3> cgPos(std::max(numbodies, 1)), trans(std::max(numbodies, 1)), lvel(std::max(numbodies, 1)), avel(std::max(numbodies, 1));
+		std::vector<float> steprot(9*std::max(numbodies, 1));
+		// calc_grid_and_local_pos of the centres of rotation (src/ProblemCore.cc:1560-1583)
+		auto grid_and_local = [&](const double x[3], int3 &gp, float3 &lp) {
+			int gi[3]; float li[3];
+			const uint gs[3] = { g.gridSize.x, g.gridSize.y, g.gridSize.z };
+			for (int a = 0; a < 3; ++a) {
+				long v = (long)floor((x[a] - origin[a])/cell[a]);
+				v = std::max(0L, std::min(v, (long)gs[a] - 1));
+				gi[a] = (int)v;
+				li[a] = (float)(x[a] - origin[a] - (v + 0.5)*cell[a]);
+			}
+			gp = make_int3(gi[0], gi[1], gi[2]); lp = make_float3(li[0], li[1], li[2]);
+		};
+		if (numbodies) {
+			std::vector<int> first(numbodies);
+			for (int b = 0; b < numbodies; ++b) { grid_and_local(bodies[b].initial.crot, cgGrid[b], cgPos[b]); first[b] = bodies[b].firstindex; }
+			integrationEngine->setrbcg(cgGrid.data(), cgPos.data(), numbodies);     // uploadEulerBodiesCentersOfGravity
+			forcesEngine->setrbcg(cgGrid.data(), cgPos.data(), numbodies);          // uploadForcesBodiesCentersOfGravity
+			forcesEngine->setrbstart(first.data(), numbodies);
+			for (int b = 0; b < numbodies; ++b) {
+				trans[b] = lvel[b] = avel[b] = make_float3(0, 0, 0);
+				for (int a = 0; a < 9; ++a) steprot[9*b + a] = (a % 4 == 0) ? 1.0f : 0.0f;
+			}
+			integrationEngine->setrbtrans(trans.data(), numbodies); integrationEngine->setrbsteprot(steprot.data(), numbodies);
+			integrationEngine->setrblinearvel(lvel.data(), numbodies); integrationEngine->setrbangularvel(avel.data(), numbodies);
+		}
+		const bool moving = std::any_of(bodies.begin(), bodies.end(), [](Body const& b) { return b.motion != "static"; });
 
-		std::unique_ptr<AbstractFilterEngine> filterEngine;
-		if (h.filter_freq > 0) filterEngine.reset(fw.newFilterEngine((FilterType)h.filter_type, h.filter_freq));
+		// ---- device buffers: double-buffered POS / VEL ("step n", "step n*"), the rest shared (GPUWorker::m_dBuffers) ----
+		BufferList posA = one_buffer<BUFFER_POS>(A), posB = one_buffer<BUFFER_POS>(A);
+		BufferList velA = one_buffer<BUFFER_VEL>(A), velB = one_buffer<BUFFER_VEL>(A);
+		BufferList shared = one_buffer<BUFFER_INFO>(A) | one_buffer<BUFFER_HASH>(A) | one_buffer<BUFFER_PARTINDEX>(A) |
+			one_buffer<BUFFER_CELLSTART>(gridCells, 0xFF) | one_buffer<BUFFER_CELLEND>(gridCells, 0xFF) |
+			one_buffer<BUFFER_NEIBSLIST>((size_t)sp->neiblistsize*A, 0xFF) | one_buffer<BUFFER_FORCES>(A) |
+			one_buffer<BUFFER_CFL>(forcesEngine->getFmaxElements(A)) |
+			one_buffer<BUFFER_CFL_TEMP>(std::max(4u, forcesEngine->getFmaxTempElements(forcesEngine->getFmaxElements(A))));
+		if (numBodiesParticles)
+			shared |= one_buffer<BUFFER_RB_FORCES>(numBodiesParticles) | one_buffer<BUFFER_RB_TORQUES>(numBodiesParticles);
+		if (sp->turbmodel == SPS)
+			shared |= one_buffer<BUFFER_TAU>(A) | one_buffer<BUFFER_SPS_TURBVISC>(A);
+		if (sp->simflags & ENABLE_XSPH)
+			shared |= one_buffer<BUFFER_XSPH>(A);
+		sphx_throw(sphx_memcpy_h2d(posA.getData<BUFFER_POS>(), hpos.data(), 16*(size_t)n0));
+		sphx_throw(sphx_memcpy_h2d(velA.getData<BUFFER_VEL>(), hvel.data(), 16*(size_t)n0));
+		sphx_throw(sphx_memcpy_h2d(shared.getData<BUFFER_INFO>(), hinfo.data(), 8*(size_t)n0));
+		sphx_throw(sphx_memcpy_h2d(shared.getData<BUFFER_HASH>(), hhash.data(), 4*(size_t)n0));
+		uint *d_newNum = NULL;
+		sphx_throw(sphx_malloc((void**)&d_newNum, 4));
 
-		BufferList *cur = &a, *oth = &b;
+		// Problem::addFilter (SimFramework::addFilterEngine keeps them ordered by type)
+		if (has(c, "filter"))
+			for (size_t k = 0; k + 1 < c.at("filter").size(); k += 2)
+				fw->addFilterEngine((FilterType)(int)num(c, "filter", k), (int)num(c, "filter", k + 1));
+
+		BufferList *curPos = &posA, *othPos = &posB, *curVel = &velA, *othVel = &velB;
 		uint n = n0;
-		float dt = h.dt;
-		for (uint32_t it = 0; it < h.steps; ++it) {
-			if (it % sp.buildneibsfreq == 0) {
-				if (it == 0) neibsEngine->fixHash(*cur, *cur, n); else neibsEngine->calcHash(*cur, *cur, n);
-				neibsEngine->sort(*cur, *cur, n);
+		float dt = (float)num(c, "dt0");
+		double t = 0;
+		for (uint it = 0; it < steps; ++it) {
+			if (it % sp->buildneibsfreq == 0) {
+				BufferList unsorted = *curPos | *curVel | shared, sorted = *othPos | *othVel | shared;
+				if (it == 0) neibsEngine->fixHash(unsorted, unsorted, n); else neibsEngine->calcHash(unsorted, unsorted, n);
+				neibsEngine->sort(unsorted, unsorted, n);
 				shared[BUFFER_CELLSTART]->clobber(); shared[BUFFER_CELLEND]->clobber();
-				neibsEngine->reorderDataAndFindCellStart(nullptr, *oth, *cur, n, d_newNum);
-				std::swap(cur, oth);
-				hip_throw(hipMemcpy(&n, d_newNum, 4, hipMemcpyDeviceToHost), "DOWNLOAD_NEWNUMPARTS");
+				neibsEngine->reorderDataAndFindCellStart(NULL, sorted, unsorted, n, d_newNum);
+				std::swap(curPos, othPos); std::swap(curVel, othVel);
+				sphx_throw(sphx_memcpy_d2h(&n, d_newNum, 4));                     // DOWNLOAD_NEWNUMPARTS
 				neibsEngine->resetinfo();
 				shared[BUFFER_NEIBSLIST]->clobber();
-				neibsEngine->buildNeibsList(*cur, *cur, n, n, gridCells, h.nlSqInfluenceRadius, h.nlSqInfluenceRadius);
+				BufferList state = *curPos | *curVel | shared;
+				neibsEngine->buildNeibsList(state, state, n, n, gridCells, sqNlRadius, sqNlRadius);
 				TimingInfo ti; neibsEngine->getinfo(ti);
-				if (ti.hasTooManyNeibs >= 0) throw std::runtime_error("too many neighbours");
+				if (ti.hasTooManyNeibs >= 0) throw std::runtime_error("too many neighbours");   // CHECK_NEIBSNUM
 			}
-			// FILTER_CALL + SWAP_STATE_BUFFERS(BUFFER_VEL) (src/integrators/PredictorCorrectorIntegrator.cc:831-859,1011-1041)
-			if (filterEngine && it > 0 && it % filterEngine->frequency() == 0) {
-				filterEngine->process(*cur, *oth, n, n, (float)sp.slength, (float)sp.influenceRadius);
-				std::shared_ptr<AbstractBuffer> filtered = (*oth)[BUFFER_VEL], unfiltered = (*cur)[BUFFER_VEL];
-				cur->add(BUFFER_VEL, filtered); oth->add(BUFFER_VEL, unfiltered);
-			}
+			if (it > 0)
+				for (FilterFreqList::const_iterator flt = fw->getFilterFreqList().begin(); flt != fw->getFilterFreqList().end(); ++flt)
+					if (it % flt->second == 0) {
+						BufferList rd = *curPos | *curVel | shared, wr = *othVel;
+						fw->getFilterEngines().at(flt->first)->process(rd, wr, n, n, slength, influenceRadius);
+						std::swap(curVel, othVel);                                    // SWAP_STATE_BUFFERS(BUFFER_VEL)
+					}
 			float dts[2];
 			for (int step = 1; step <= 2; ++step) {
-				BufferList &state = (step == 1) ? *cur : *oth;      // forces on n (predictor) or n* (corrector)
-				shared[BUFFER_FORCES]->clobber(); shared[BUFFER_CFL]->clobber();
-				const uint nb = forcesEngine->basicstep(state, state, n, 0, n, sp.deltap, (float)sp.slength, sp.dtadaptfactor,
-					(float)sp.influenceRadius, 0.0f, nullptr, 0, SIMULATE, step, dt, sp.numforcesbodies > 0);
-				dts[step - 1] = forcesEngine->dtreduce((float)sp.slength, sp.dtadaptfactor, h.sspeed_cfl, 0.0f, state, state, nb, n);
-				// EULER always reads step n, writes n* (src/integrators/PredictorCorrectorIntegrator.cc:587-609)
-				integrationEngine->basicstep(*cur, *oth, n, n, step == 1 ? dt/2 : dt, step, 0.0f, (float)sp.slength,
-					(float)sp.influenceRadius, SIMULATE);
+				// forces on step n (predictor) or on n* (corrector); Euler always reads n and writes n*
+				BufferList state = (step == 1) ? (*curPos | *curVel | shared) : (*othPos | *othVel | shared);
+				if (sp->turbmodel == SPS)                                             // CALC_VISC
+					viscEngine->calc_visc(state, state, n, n, deltap, slength, influenceRadius);
+				shared[BUFFER_FORCES]->clobber(); shared[BUFFER_CFL]->clobber();      // pre_forces
+				forcesEngine->bind_textures(state, n, SIMULATE);
+				const uint nb = forcesEngine->basicstep(state, state, n, 0, n, deltap, slength, sp->dtadaptfactor,
+					influenceRadius, sp->epsilon, NULL, 0, SIMULATE, step, dt, sp->numforcesbodies > 0);
+				forcesEngine->unbind_textures(SIMULATE);
+				dts[step - 1] = forcesEngine->dtreduce(slength, sp->dtadaptfactor, sspeed_cfl, max_kinvisc, state, state, nb, n);
+				if (moving) {                                                         // MOVE_BODIES + uploads
+					const double dt1 = (step == 1) ? dt/2.0 : (double)dt;
+					for (int b = 0; b < numbodies; ++b) {
+						Body &B = bodies[b];
+						if (step == 1) B.storage = B.kdata; else B.kdata = B.storage;
+						double dx[3], dr[9];
+						body_callback(B, t, t + dt1, dx, dr);
+						trans[b] = make_float3((float)dx[0], (float)dx[1], (float)dx[2]);
+						for (int a = 0; a < 9; ++a) steprot[9*b + a] = (float)dr[a];
+						lvel[b] = make_float3((float)B.kdata.lvel[0], (float)B.kdata.lvel[1], (float)B.kdata.lvel[2]);
+						avel[b] = make_float3((float)B.kdata.avel[0], (float)B.kdata.avel[1], (float)B.kdata.avel[2]);
+						grid_and_local(B.kdata.crot, cgGrid[b], cgPos[b]);
+					}
+					integrationEngine->setrbtrans(trans.data(), numbodies); integrationEngine->setrbsteprot(steprot.data(), numbodies);
+					integrationEngine->setrblinearvel(lvel.data(), numbodies); integrationEngine->setrbangularvel(avel.data(), numbodies);
+					if (sp->numforcesbodies > 0) forcesEngine->setrbcg(cgGrid.data(), cgPos.data(), numbodies);   // FORCES_UPLOAD_OBJECTS_CG
+				}
+				BufferList rd = *curPos | *curVel | shared, wr = *othPos | *othVel;
+				integrationEngine->basicstep(rd, wr, n, n, step == 1 ? dt/2 : dt, step, (float)t, slength, influenceRadius, SIMULATE);
 			}
-			std::swap(cur, oth);
-			dt = std::min(dts[0], dts[1]);     // TIME_STEP_EPILOGUE (src/GPUSPH.cc:650-657)
+			if (moving) integrationEngine->setrbcg(cgGrid.data(), cgPos.data(), numbodies);   // EULER_UPLOAD_OBJECTS_CG
+			std::swap(curPos, othPos); std::swap(curVel, othVel);
+			t += dt;
+			dt = std::min(dts[0], dts[1]);                                            // TIME_STEP_EPILOGUE (src/GPUSPH.cc:650-657)
 		}
-		// POSTPROCESS before a write (src/GPUWorker.cc runCommand<POSTPROCESS>): free-surface flags into INFO
-		std::unique_ptr<AbstractPostProcessEngine> surf(fw.newPostProcessEngine(SURFACE_DETECTION));
-		surf->setconstants(&sp, &pp, A);
-		surf->process(*cur, *cur, n, n, 0, nullptr);
-		hip_throw(hipDeviceSynchronize(), "sync");
-		hip_throw(hipMemcpy(hpos.data(), cur->getData<BUFFER_POS>(), 16*(size_t)n, hipMemcpyDeviceToHost), "download");
-		hip_throw(hipMemcpy(hvel.data(), cur->getData<BUFFER_VEL>(), 16*(size_t)n, hipMemcpyDeviceToHost), "download");
-		hip_throw(hipMemcpy(hinfo.data(), info, 8*(size_t)n, hipMemcpyDeviceToHost), "download");
-		hip_throw(hipMemcpy(hhash.data(), hash, 4*(size_t)n, hipMemcpyDeviceToHost), "download");
-		FILE *o = fopen(argv[2], "wb");
-		fwrite(&n, 4, 1, o); fwrite(&dt, 4, 1, o);
+
+		if (has(c, "final_surface")) {       // POSTPROCESS before a write: free-surface flags into INFO
+			fw->addPostProcessEngine(SURFACE_DETECTION);
+			AbstractPostProcessEngine *surf = fw->hasPostProcessEngine(SURFACE_DETECTION);
+			surf->setconstants(sp, &pp, A);
+			BufferList rd = *curPos | *curVel | shared, wr = shared;   // INFO is updated in place (get_updated_buffers)
+			surf->process(rd, wr, n, n, 0, NULL);
+		}
+		sphx_throw(sphx_device_synchronize());
+		sphx_throw(sphx_memcpy_d2h(hpos.data(), as_const(*curPos).getData<BUFFER_POS>(), 16*(size_t)n));
+		sphx_throw(sphx_memcpy_d2h(hvel.data(), as_const(*curVel).getData<BUFFER_VEL>(), 16*(size_t)n));
+		sphx_throw(sphx_memcpy_d2h(hinfo.data(), as_const(shared).getData<BUFFER_INFO>(), 8*(size_t)n));
+		sphx_throw(sphx_memcpy_d2h(hhash.data(), as_const(shared).getData<BUFFER_HASH>(), 4*(size_t)n));
+		sphx_throw(sphx_free(d_newNum));
+		FILE *o = fopen(argv[3], "wb");
+		if (!o) throw std::runtime_error(std::string("cannot write ") + argv[3]);
+		fwrite(&n, 4, 1, o); fwrite(&dt, 4, 1, o); fwrite(&t, 8, 1, o);
 		fwrite(hpos.data(), 16, n, o); fwrite(hvel.data(), 16, n, o); fwrite(hinfo.data(), 8, n, o); fwrite(hhash.data(), 4, n, o);
 		fclose(o);
-		printf("example_engines: %u particles, %u steps, dt=%g\n", n, h.steps, dt);
+		printf("example_engines: %s, %u particles, %u steps, t=%g dt=%g\n", str(c, "framework").c_str(), n, steps, t, dt);
 	} catch (const std::exception &e) {
 		fprintf(stderr, "example_engines: %s\n", e.what());
 		return 1;

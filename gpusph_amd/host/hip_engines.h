@@ -1,0 +1,567 @@
+// hip_engines.h -- the MI355X engines behind GPUSPH's abstract engine interfaces.
+//
+// This header is compiled INSIDE the GPUSPH source tree: every type it uses that is not named HIP* or sphx_*
+// is GPUSPH's own (AbstractNeibsEngine src/engine_neibs.h:46-107, AbstractForcesEngine src/engine_forces.h:43-180,
+// AbstractViscEngine src/engine_visc.h:42-109, AbstractIntegrationEngine src/engine_integration.h:42-144,
+// AbstractFilterEngine src/engine_filter.h:41-78, AbstractPostProcessEngine src/engine_postprocess.h:49-105,
+// BufferList / Buffer<Key> src/buffer.h, the keys of src/define_buffers.h, SimParams, PhysParams, TimingInfo,
+// PlaneList, RunMode).  The classes below take the place of the CUDA*Engine templates of src/cuda/{buildneibs,
+// forces,visc,euler,post_process}.cu: they unpack the buffer lists into raw device pointers and call the C ABI of
+// libsphx.so (include/sphx.h).  The physics options that the reference bakes into template arguments travel in
+// the run-time POD sphx_params, so none of these classes is a template.
+//
+// No HIP header is needed on this side of the boundary (device memory comes from the sphx_* memory service), so
+// the translation unit builds with the host compiler GPUSPH's .cc files are built with.
+//
+// Semantics kept from the reference engines:
+//  * non-const BufferList::getData<>() is called for exactly the buffers a method writes (it marks them dirty and
+//    records them for GPUWorker, src/buffer.h:643-674, src/GPUWorker.cc:1826); everything else is read through the
+//    const list; an optional buffer that is absent yields NULL = "feature off" (src/buffer.h:633-637)
+//  * errors of the library are rethrown as CUDA_SAFE_CALL / KERNEL_CHECK_ERROR throw them
+//    (src/cuda/cuda_call.h:57-85): std::invalid_argument for inconsistent arguments, std::runtime_error otherwise
+//  * one engine object serves every GPUWorker thread: per-device state is looked up by the calling thread's current
+//    device (the reference relies on per-device __constant__ memory and thread_local scratch, src/cuda/forces.cu:89-96)
+//  * every pure virtual of the abstract classes is implemented; the ones whose physics is not built into libsphx
+//    (SA boundaries, density sum, DEM, Jacobi solver of the granular rheology) throw std::runtime_error naming the method
+#ifndef SPHX_HIP_ENGINES_H
+#define SPHX_HIP_ENGINES_H
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "engine_neibs.h"
+#include "engine_forces.h"
+#include "engine_visc.h"
+#include "engine_integration.h"
+#include "engine_filter.h"
+#include "engine_postprocess.h"
+#include "engine_boundary_conditions.h"
+#include "linearization.h"
+
+#include "sphx.h"
+
+inline void sphx_throw(int rc)
+{
+	if (rc == SPHX_OK) return;
+	const std::string msg = sphx_last_error();
+	if (rc == SPHX_ERR_INVALID) throw std::invalid_argument(msg);
+	throw std::runtime_error(msg);
+}
+
+[[noreturn]] inline void sphx_not_built(const char *method)
+{
+	throw std::runtime_error(std::string(method) + ": not built into libsphx (see DESIGN.md, out of scope of the hot path)");
+}
+
+// ---- HIPBuffer<Key>: device allocation policy of a Buffer<Key> (role of CUDABuffer, src/cuda/cudabuffer.h:47-131) ----
+template<flag_t Key>
+class HIPBuffer : public Buffer<Key>
+{
+	typedef Buffer<Key> baseclass;
+public:
+	typedef typename baseclass::element_type element_type;
+
+	HIPBuffer(int _init = -1) : Buffer<Key>(_init) {}
+
+	virtual ~HIPBuffer() {
+		element_type **bufs = baseclass::get_raw_ptr();
+		for (int i = 0; i < baseclass::array_count; ++i) {
+			if (bufs[i]) (void)sphx_free(bufs[i]);   // a destructor must not throw
+			bufs[i] = NULL;
+		}
+	}
+
+	// memset of every array to the initial value (0, or 0xFF for neighbour list / cell start / cell end)
+	virtual void clobber() {
+		const size_t bufmem = AbstractBuffer::get_allocated_elements()*sizeof(element_type);
+		element_type **bufs = baseclass::get_raw_ptr();
+		for (int i = 0; i < baseclass::array_count; ++i)
+			sphx_throw(sphx_memset(bufs[i], baseclass::get_init_value(), bufmem));
+	}
+
+	virtual size_t alloc(size_t elems) {
+		AbstractBuffer::set_allocated_elements(elems);
+		const size_t bufmem = elems*sizeof(element_type);
+		element_type **bufs = baseclass::get_raw_ptr();
+		for (int i = 0; i < baseclass::array_count; ++i) {
+			sphx_throw(sphx_malloc((void**)(bufs + i), bufmem));
+			sphx_throw(sphx_memset(bufs[i], baseclass::get_init_value(), bufmem));
+		}
+		return bufmem*baseclass::array_count;
+	}
+
+	virtual void swap_elements(uint idx1, uint idx2, uint _buf = 0) {
+		element_type tmp;
+		sphx_throw(sphx_memcpy_d2h(&tmp, this->get_offset_buffer(_buf, idx1), sizeof(element_type)));
+		sphx_throw(sphx_memcpy_d2d(this->get_offset_buffer(_buf, idx1), this->get_offset_buffer(_buf, idx2), sizeof(element_type)));
+		sphx_throw(sphx_memcpy_h2d(this->get_offset_buffer(_buf, idx2), &tmp, sizeof(element_type)));
+	}
+
+	virtual const char* get_buffer_class() const
+	{ return "HIPBuffer"; }
+};
+
+// ---- per-device state shared by the engines of one framework ----
+class HIPEngineContext
+{
+	std::mutex m_lock;
+	std::map<int, sphx_ctx*> m_ctx;
+	sphx_params m_params;
+
+public:
+	HIPEngineContext() { std::memset(&m_params, 0, sizeof(m_params)); }
+	~HIPEngineContext() { for (auto &kv : m_ctx) sphx_destroy(kv.second); }
+
+	sphx_ctx *ctx() {
+		int dev = 0;
+		sphx_throw(sphx_get_device(&dev));
+		std::lock_guard<std::mutex> guard(m_lock);
+		std::map<int, sphx_ctx*>::iterator it = m_ctx.find(dev);
+		if (it != m_ctx.end()) return it->second;
+		sphx_ctx *c = NULL;
+		sphx_throw(sphx_create(&c, dev));
+		m_ctx[dev] = c;
+		return c;
+	}
+
+	sphx_params const& params() const { return m_params; }
+
+	// host part of the three setconstants(): SimParams + PhysParams + grid -> sphx_params.  Pure host code
+	static void fill_params(sphx_params &p, const SimParams *sp, const PhysParams *pp, float3 const& worldOrigin,
+		uint3 const& gridSize, float3 const& cellSize, idx_t allocatedParticles)
+	{
+		// option codes of libsphx are the reference's enum values (pinned by tests/test_oracle_pinned.py), so the
+		// conversion is a cast; the linearisation comes from the tree's COORD1..3 (src/linearization.h)
+		std::memset(&p, 0, sizeof(p));
+		p.gridSize[0] = gridSize.x; p.gridSize[1] = gridSize.y; p.gridSize[2] = gridSize.z;
+		p.cellSize[0] = cellSize.x; p.cellSize[1] = cellSize.y; p.cellSize[2] = cellSize.z;
+		p.worldOrigin[0] = worldOrigin.x; p.worldOrigin[1] = worldOrigin.y; p.worldOrigin[2] = worldOrigin.z;
+		const int3 axes = make_int3(0, 1, 2);
+		p.coord[0] = axes.COORD1; p.coord[1] = axes.COORD2; p.coord[2] = axes.COORD3;
+		p.periodic = (uint32_t)sp->periodicbound;
+		p.neiblistsize = sp->neiblistsize; p.neibboundpos = sp->neibboundpos; p.neiblist_stride = allocatedParticles;
+		p.kerneltype = (int32_t)sp->kerneltype; p.sph_formulation = (int32_t)sp->sph_formulation;
+		p.densitydiffusiontype = (int32_t)sp->densitydiffusiontype; p.boundarytype = (int32_t)sp->boundarytype;
+		p.rheologytype = (int32_t)sp->rheologytype; p.turbmodel = (int32_t)sp->turbmodel;
+		p.compvisc = (int32_t)sp->compvisc; p.viscmodel = (int32_t)sp->viscmodel; p.avgop = (int32_t)sp->viscavgop;
+		p.is_const_visc = sp->is_const_visc ? 1 : 0;
+		p.simflags = sp->simflags;
+		p.slength = (float)sp->slength; p.kernelradius = (float)sp->kernelradius;
+		p.influenceradius = (float)sp->influenceRadius;
+		p.deltap = 0;   // not a constant of the reference engines: forces basicstep receives it per call
+		p.dtadaptfactor = sp->dtadaptfactor; p.densityDiffCoeff = sp->densityDiffCoeff; p.epsxsph = pp->epsxsph;
+		p.numfluids = (uint32_t)pp->numFluids();
+		if (pp->numFluids() > SPHX_MAX_FLUIDS) throw std::invalid_argument("setconstants: more fluids than MAX_FLUID_TYPES");
+		for (size_t f = 0; f < pp->numFluids(); ++f) {
+			p.rho0[f] = pp->rho0[f]; p.bcoeff[f] = pp->bcoeff[f]; p.gammacoeff[f] = pp->gammacoeff[f];
+			p.sscoeff[f] = pp->sscoeff[f]; p.sspowercoeff[f] = pp->sspowercoeff[f];
+			p.visccoeff[f] = f < pp->visccoeff.size() ? pp->visccoeff[f] : 0.0f;
+		}
+		p.gravity[0] = pp->gravity.x; p.gravity[1] = pp->gravity.y; p.gravity[2] = pp->gravity.z;
+		p.artvisccoeff = pp->artvisccoeff; p.epsartvisc = pp->epsartvisc;
+		p.smagfactor = pp->smagfactor; p.kspsfactor = pp->kspsfactor;
+		p.dcoeff = pp->dcoeff; p.p1coeff = pp->p1coeff; p.p2coeff = pp->p2coeff; p.r0 = pp->r0;
+		p.repack_a = sp->repack_a; p.repack_alpha = sp->repack_alpha;
+		p.partsurf = pp->partsurf;
+		p.MK_K = pp->MK_K; p.MK_d = pp->MK_d; p.MK_beta = pp->MK_beta;
+	}
+
+	void upload(const SimParams *sp, const PhysParams *pp, float3 const& worldOrigin, uint3 const& gridSize,
+		float3 const& cellSize, idx_t allocatedParticles)
+	{
+		sphx_params p;
+		fill_params(p, sp, pp, worldOrigin, gridSize, cellSize, allocatedParticles);
+		sphx_ctx *c = ctx();
+		sphx_throw(sphx_set_constants(c, &p));
+		sphx_throw(sphx_reserve(c, (uint32_t)allocatedParticles));
+		std::lock_guard<std::mutex> guard(m_lock);
+		m_params = p;
+	}
+};
+
+typedef std::shared_ptr<HIPEngineContext> HIPEngineContextPtr;
+
+// ---- neighbour engine (CUDANeibsEngine, src/cuda/buildneibs.cu:70-500) ----
+class HIPNeibsEngine : public AbstractNeibsEngine
+{
+	HIPEngineContextPtr m_c;
+
+	// one optional per-particle array of the reorder (src/cuda/buildneibs.cu:263-311)
+	template<flag_t Key>
+	void gather_optional(BufferList& sorted_buffers, BufferList const& unsorted_buffers, const uint *partIndex, uint numParticles)
+	{
+		typedef typename BufferTraits<Key>::element_type T;
+		for (uint idx = 0; idx < (uint)BufferTraits<Key>::num_buffers; ++idx) {
+			const T *oldp = unsorted_buffers.getData<Key>(idx);
+			if (!oldp) return;
+			T *newp = sorted_buffers.getData<Key>(idx);
+			if (!newp) throw std::invalid_argument(std::string("reorderDataAndFindCellStart: sorted ") + BufferTraits<Key>::name + " is null");
+			sphx_throw(sphx_gather_rows(m_c->ctx(), newp, oldp, (uint32_t)sizeof(T), partIndex, numParticles, NULL));
+		}
+	}
+public:
+	explicit HIPNeibsEngine(HIPEngineContextPtr c) : m_c(c) {}
+
+	void setconstants(const SimParams *simparams, const PhysParams *physparams, float3 const& worldOrigin,
+		uint3 const& gridSize, float3 const& cellSize, idx_t const& allocatedParticles)
+	{ m_c->upload(simparams, physparams, worldOrigin, gridSize, cellSize, allocatedParticles); }
+
+	void getconstants(SimParams *simparams, PhysParams *)
+	{
+		sphx_params p;
+		sphx_throw(sphx_get_params(m_c->ctx(), &p));
+		simparams->neibboundpos = p.neibboundpos;
+	}
+
+	void resetinfo() { sphx_throw(sphx_neibs_resetinfo(m_c->ctx(), NULL)); }
+
+	void getinfo(TimingInfo &ti)
+	{
+		sphx_neibs_info i;
+		sphx_throw(sphx_neibs_getinfo(m_c->ctx(), &i, NULL));
+		ti.numInteractions = i.numInteractions; ti.maxFluidBoundaryNeibs = i.maxFluidBoundaryNeibs;
+		ti.maxVertexNeibs = i.maxVertexNeibs; ti.hasTooManyNeibs = i.hasTooManyNeibs;
+		for (int k = 0; k < PT_TESTPOINT; ++k) ti.hasMaxNeibs[k] = i.hasMaxNeibs[k];
+	}
+
+	void calcHash(const BufferList& bufread, BufferList& bufwrite, const uint numParticles)
+	{
+		sphx_throw(sphx_calc_hash(m_c->ctx(), bufwrite.getData<BUFFER_POS>(), bufwrite.getData<BUFFER_HASH>(),
+			bufwrite.getData<BUFFER_PARTINDEX>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_COMPACT_DEV_MAP>(), numParticles, NULL));
+	}
+
+	void fixHash(const BufferList& bufread, BufferList& bufwrite, const uint numParticles)
+	{
+		sphx_throw(sphx_fix_hash(m_c->ctx(), bufwrite.getData<BUFFER_HASH>(), bufwrite.getData<BUFFER_PARTINDEX>(),
+			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_COMPACT_DEV_MAP>(), numParticles, NULL));
+	}
+
+	// keys (HASH, INFO) and values (PARTINDEX) are sorted in place (src/cuda/buildneibs.cu:384-412)
+	void sort(const BufferList&, BufferList& bufwrite, uint numParticles)
+	{
+		sphx_throw(sphx_sort(m_c->ctx(), bufwrite.getData<BUFFER_HASH>(), bufwrite.getData<BUFFER_INFO>(),
+			bufwrite.getData<BUFFER_PARTINDEX>(), numParticles, NULL));
+	}
+
+	void reorderDataAndFindCellStart(uint *segmentStart, BufferList& sorted_buffers,
+		const BufferList& unsorted_buffers, const uint numParticles, uint *newNumParticles)
+	{
+		// HASH, PARTINDEX and INFO were sorted in place and are only read here
+		const hashKey *particleHash = sorted_buffers.getConstData<BUFFER_HASH>();
+		const uint *particleIndex = sorted_buffers.getConstData<BUFFER_PARTINDEX>();
+		const particleinfo *particleInfo = sorted_buffers.getConstData<BUFFER_INFO>();
+		uint *cellStart = sorted_buffers.getData<BUFFER_CELLSTART>();
+		uint *cellEnd = sorted_buffers.getData<BUFFER_CELLEND>();
+		sphx_throw(sphx_reorder(m_c->ctx(), segmentStart, cellStart, cellEnd,
+			sorted_buffers.getData<BUFFER_POS>(), sorted_buffers.getData<BUFFER_VEL>(),
+			unsorted_buffers.getData<BUFFER_POS>(), unsorted_buffers.getData<BUFFER_VEL>(),
+			particleInfo, particleHash, particleIndex, numParticles, newNumParticles, NULL));
+		gather_optional<BUFFER_VOLUME>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_INTERNAL_ENERGY>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_BOUNDELEMENTS>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_GRADGAMMA>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_VERTICES>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_TKE>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_EPSILON>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_TURBVISC>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_EFFPRES>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		gather_optional<BUFFER_EULERVEL>(sorted_buffers, unsorted_buffers, particleIndex, numParticles);
+		// BUFFER_NEXTID (particle creation at open boundaries) is reordered and extended by the SA path only
+		if (unsorted_buffers.getData<BUFFER_NEXTID>())
+			sphx_not_built("reorderDataAndFindCellStart with BUFFER_NEXTID (open boundaries)");
+	}
+
+	void buildNeibsList(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
+		const uint particleRangeEnd, const uint gridCells, const float sqinfluenceradius, const float boundNlSqInflRad)
+	{
+		// consistency rule of the reference (src/cuda/buildneibs.cu:444-455): SA arrays come together or not at all
+		const bool has_vertices = bufread.getData<BUFFER_VERTICES>() != NULL;
+		const bool has_boundelements = bufread.getData<BUFFER_BOUNDELEMENTS>() != NULL;
+		if (has_vertices != has_boundelements)
+			throw std::invalid_argument("buildNeibsList: BUFFER_VERTICES and BUFFER_BOUNDELEMENTS must be both present or both absent");
+		if (has_vertices)
+			sphx_not_built("buildNeibsList with SA_BOUNDARY vertex/segment lists");
+		sphx_throw(sphx_build_neibs(m_c->ctx(), bufwrite.getData<BUFFER_NEIBSLIST>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+			bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_CELLEND>(),
+			numParticles, particleRangeEnd, gridCells, sqinfluenceradius, boundNlSqInflRad, NULL));
+	}
+};
+
+// ---- forces engine (CUDAForcesEngine, src/cuda/forces.cu:180-1005) ----
+class HIPForcesEngine : public AbstractForcesEngine
+{
+	HIPEngineContextPtr m_c;
+public:
+	explicit HIPForcesEngine(HIPEngineContextPtr c) : m_c(c) {}
+
+	void setconstants(const SimParams *simparams, const PhysParams *physparams, float3 const& worldOrigin,
+		uint3 const& gridSize, float3 const& cellSize, idx_t const& allocatedParticles)
+	{ m_c->upload(simparams, physparams, worldOrigin, gridSize, cellSize, allocatedParticles); }
+
+	// read back what setconstants uploaded (src/cuda/forces.cu:403-440)
+	void getconstants(PhysParams *physparams)
+	{
+		sphx_params p;
+		sphx_throw(sphx_get_params(m_c->ctx(), &p));
+		if (p.numfluids != physparams->numFluids())
+			throw std::runtime_error("wrong number of fluids");
+		for (uint32_t f = 0; f < p.numfluids; ++f) {
+			physparams->visccoeff[f] = p.visccoeff[f];
+			physparams->rho0[f] = p.rho0[f]; physparams->bcoeff[f] = p.bcoeff[f]; physparams->gammacoeff[f] = p.gammacoeff[f];
+			physparams->sscoeff[f] = p.sscoeff[f]; physparams->sspowercoeff[f] = p.sspowercoeff[f];
+		}
+		physparams->gravity = make_float3(p.gravity[0], p.gravity[1], p.gravity[2]);
+		physparams->dcoeff = p.dcoeff; physparams->p1coeff = p.p1coeff; physparams->p2coeff = p.p2coeff;
+		physparams->MK_K = p.MK_K; physparams->MK_d = p.MK_d; physparams->MK_beta = p.MK_beta;
+		physparams->r0 = p.r0; physparams->epsartvisc = p.epsartvisc;
+	}
+
+	void setplanes(PlaneList const& planes)
+	{
+		std::vector<float> nrm, pos; std::vector<int32_t> gp;
+		for (PlaneList::const_iterator pl = planes.begin(); pl != planes.end(); ++pl) {
+			nrm.push_back(pl->normal.x); nrm.push_back(pl->normal.y); nrm.push_back(pl->normal.z);
+			gp.push_back(pl->gridPos.x); gp.push_back(pl->gridPos.y); gp.push_back(pl->gridPos.z);
+			pos.push_back(pl->pos.x); pos.push_back(pl->pos.y); pos.push_back(pl->pos.z);
+		}
+		sphx_throw(sphx_set_planes(m_c->ctx(), nrm.data(), gp.data(), pos.data(), (int)planes.size()));
+	}
+
+	void setgravity(float3 const& g)
+	{
+		const float v[3] = { g.x, g.y, g.z };
+		sphx_throw(sphx_set_gravity(m_c->ctx(), v));
+	}
+
+	// the forces engine's own copy of the centres of gravity (cuforces::d_rbcgGridPos/d_rbcgPos)
+	void setrbcg(const int3 *cgGridPos, const float3 *cgPos, int numbodies)
+	{ sphx_throw(sphx_set_rb_cg_forces(m_c->ctx(), (const int32_t*)cgGridPos, (const float*)cgPos, numbodies)); }
+
+	void setrbstart(const int *rbfirstindex, int numbodies)
+	{ sphx_throw(sphx_set_rb_start(m_c->ctx(), rbfirstindex, numbodies)); }
+
+	void reduceRbForces(BufferList& bufwrite, uint *lastindex, float3 *totalforce, float3 *totaltorque,
+		uint numbodies, uint numBodiesParticles)
+	{
+		float4 *forces = bufwrite.getData<BUFFER_RB_FORCES>();
+		float4 *torques = bufwrite.getData<BUFFER_RB_TORQUES>();
+		const uint *rbnum = bufwrite.getConstData<BUFFER_RB_KEYS>();
+		sphx_throw(sphx_reduce_rb_forces(m_c->ctx(), forces, torques, rbnum, lastindex,
+			(float*)totalforce, (float*)totaltorque, numbodies, numBodiesParticles, NULL));
+	}
+
+	// there are no texture references on this path: loads go through L2 / LDS (src/cuda/forces.cu:469-532 has no equivalent)
+	void bind_textures(const BufferList&, uint, RunMode) {}
+	void unbind_textures(RunMode) {}
+
+	void setDEM(const float *, int, int) { sphx_not_built("setDEM (ENABLE_DEM)"); }
+	void unsetDEM() {}
+
+	uint round_particles(uint numparts) { return sphx_forces_round_particles(numparts); }
+
+	void compute_density(const BufferList&, BufferList&, uint, float, float)
+	{ sphx_not_built("compute_density (SPH_GRENIER)"); }
+
+	void compute_density_diffusion(const BufferList&, BufferList&, const uint, const uint, const float, const float,
+		const float, const float)
+	{ sphx_not_built("compute_density_diffusion (ENABLE_DENSITY_SUM)"); }
+
+	uint basicstep(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint fromParticle,
+		uint toParticle, float deltap, float slength, float dtadaptfactor, float influenceradius,
+		const float, uint *, uint cflOffset, const RunMode run_mode, const int step, const float dt,
+		const bool compute_object_forces)
+	{
+		const sphx_params &P = m_c->params();
+		// the write set follows the structures forces_params is assembled from (src/cuda/forces_params.h:86-220)
+		float4 *forces = bufwrite.getData<BUFFER_FORCES>();
+		float *cfl = (P.simflags & ENABLE_DTADAPT) ? bufwrite.getData<BUFFER_CFL>() : NULL;
+		float4 *rbforces = bufwrite.getData<BUFFER_RB_FORCES>();
+		float4 *rbtorques = bufwrite.getData<BUFFER_RB_TORQUES>();
+		float4 *xsph = (P.simflags & ENABLE_XSPH) ? bufwrite.getData<BUFFER_XSPH>() : NULL;
+		const float2 *const *tau = (P.turbmodel == SPS && run_mode == SIMULATE) ? bufread.getRawPtr<BUFFER_TAU>() : NULL;
+		uint32_t numBlocks = 0;
+		sphx_throw(sphx_forces_basicstep(m_c->ctx(), forces, cfl, rbforces, rbtorques,
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			tau ? tau[0] : NULL, tau ? tau[1] : NULL, tau ? tau[2] : NULL, xsph,
+			numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor, influenceradius,
+			cflOffset, (int)run_mode, step, dt, compute_object_forces ? 1 : 0, &numBlocks, NULL));
+		return numBlocks;
+	}
+
+	uint getFmaxElements(const uint n) { return sphx_forces_fmax_elements(n); }
+	uint getFmaxTempElements(const uint n) { return sphx_forces_fmax_temp_elements(n); }
+
+	float dtreduce(float slength, float dtadaptfactor, float sspeed_cfl, float max_kinematic,
+		BufferList const& bufread, BufferList& bufwrite, uint numBlocks, uint)
+	{
+		float dt = 0;
+		sphx_throw(sphx_forces_dtreduce(m_c->ctx(), slength, dtadaptfactor, sspeed_cfl, max_kinematic,
+			bufread.getData<BUFFER_CFL>(), bufwrite.getData<BUFFER_CFL_TEMP>(), numBlocks, &dt, NULL));
+		return dt;
+	}
+};
+
+// ---- viscous engine (CUDAViscEngine, src/cuda/visc.cu:60-640) ----
+class HIPViscEngine : public AbstractViscEngine
+{
+	HIPEngineContextPtr m_c;
+public:
+	explicit HIPViscEngine(HIPEngineContextPtr c) : m_c(c) {}
+
+	void setconstants() {}
+	void getconstants() {}
+
+	// SPS: stress tensor + turbulent viscosity; Newtonian rheologies have nothing to compute per particle
+	// (CUDAViscEngineHelper's default, src/cuda/visc.cu:66-85).  Returns NAN as the reference does when there is
+	// no per-particle kinematic viscosity to bound the time step with (src/cuda/visc.cu:232)
+	float calc_visc(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
+		const uint particleRangeEnd, const float deltap, const float slength, const float influenceradius)
+	{
+		const sphx_params &P = m_c->params();
+		if (P.rheologytype != INVISCID && P.rheologytype != NEWTONIAN)
+			sphx_not_built("calc_visc for generalized Newtonian / granular rheologies");
+		if (P.turbmodel != SPS)
+			return NAN;
+		float2 **tau = bufwrite.getRawPtr<BUFFER_TAU>();
+		float *turbvisc = bufwrite.getData<BUFFER_SPS_TURBVISC>();
+		if (!tau) throw std::invalid_argument("calc_visc: SPS needs BUFFER_TAU");
+		sphx_throw(sphx_calc_visc(m_c->ctx(), tau[0], tau[1], tau[2], turbvisc,
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			numParticles, particleRangeEnd, deltap, slength, influenceradius, NULL));
+		return NAN;
+	}
+
+	void enforce_jacobi_fs_boundary_conditions(const BufferList&, BufferList&, const uint, const uint, const float, const float, const float)
+	{ sphx_not_built("enforce_jacobi_fs_boundary_conditions (GRANULAR rheology)"); }
+	float enforce_jacobi_wall_boundary_conditions(const BufferList&, BufferList&, const uint, const uint, const float, const float, const float)
+	{ sphx_not_built("enforce_jacobi_wall_boundary_conditions (GRANULAR rheology)"); }
+	void build_jacobi_vectors(const BufferList&, BufferList&, const uint, const uint, const float, const float, const float)
+	{ sphx_not_built("build_jacobi_vectors (GRANULAR rheology)"); }
+	float update_jacobi_effpres(const BufferList&, BufferList&, const uint, const uint, const float, const float, const float)
+	{ sphx_not_built("update_jacobi_effpres (GRANULAR rheology)"); }
+};
+
+// ---- predictor-corrector integration engine (CUDAPredCorrEngine, src/cuda/euler.cu:40-395) ----
+class HIPPredCorrEngine : public AbstractIntegrationEngine
+{
+	HIPEngineContextPtr m_c;
+public:
+	explicit HIPPredCorrEngine(HIPEngineContextPtr c) : m_c(c) {}
+
+	// the constants of cueuler (grid, EOS, neighbour list geometry, src/cuda/euler.cu:51-69) are those the forces and
+	// neighbour engines upload into the same per-device state
+	void setconstants(const PhysParams *, float3 const&, uint3 const&, float3 const&, idx_t const&, int const&, float const&) {}
+	void getconstants(PhysParams *) {}
+
+	// the integration engine's own copy of the centres of gravity (cueuler::d_rbcgGridPos/d_rbcgPos)
+	void setrbcg(const int3 *cgGridPos, const float3 *cgPos, int numbodies)
+	{ sphx_throw(sphx_set_rb_cg_integration(m_c->ctx(), (const int32_t*)cgGridPos, (const float*)cgPos, numbodies)); }
+	void setrbtrans(const float3 *trans, int n)
+	{ sphx_throw(sphx_set_rb_motion(m_c->ctx(), (const float*)trans, NULL, NULL, NULL, n)); }
+	void setrbsteprot(const float *rot, int n)
+	{ sphx_throw(sphx_set_rb_motion(m_c->ctx(), NULL, rot, NULL, NULL, n)); }
+	void setrblinearvel(const float3 *v, int n)
+	{ sphx_throw(sphx_set_rb_motion(m_c->ctx(), NULL, NULL, (const float*)v, NULL, n)); }
+	void setrbangularvel(const float3 *w, int n)
+	{ sphx_throw(sphx_set_rb_motion(m_c->ctx(), NULL, NULL, NULL, (const float*)w, n)); }
+
+	void density_sum(const BufferList&, BufferList&, const uint, const uint, const float, const int, const float,
+		const float, const float, const float, const float)
+	{ sphx_not_built("density_sum (ENABLE_DENSITY_SUM, SA_BOUNDARY)"); }
+	void integrate_gamma(const BufferList&, BufferList&, const uint, const uint, const float, const int, const float,
+		const float, const float, const float, const RunMode)
+	{ sphx_not_built("integrate_gamma (SA_BOUNDARY)"); }
+	void apply_density_diffusion(const BufferList&, BufferList&, const uint, const uint, const float)
+	{ sphx_not_built("apply_density_diffusion (ENABLE_DENSITY_SUM)"); }
+
+	void basicstep(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
+		const uint particleRangeEnd, const float dt, const int step, const float t, const float slength,
+		const float influenceRadius, const RunMode run_mode)
+	{
+		sphx_throw(sphx_euler_basicstep(m_c->ctx(), bufwrite.getData<BUFFER_POS>(), bufwrite.getData<BUFFER_VEL>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_XSPH>(),
+			numParticles, particleRangeEnd, dt, NULL, 1.0f, step, t, slength, influenceRadius, (int)run_mode, NULL));
+	}
+
+	void disableFreeSurfParts(float4 *pos, const particleinfo *info, const uint numParticles, const uint particleRangeEnd)
+	{ sphx_throw(sphx_disable_free_surf_parts(m_c->ctx(), pos, info, numParticles, particleRangeEnd, NULL)); }
+};
+
+// ---- density filters (CUDAFilterEngine<filtertype, kerneltype, boundarytype>, src/cuda/forces.cu:1008-1147) ----
+class HIPFilterEngine : public AbstractFilterEngine
+{
+	HIPEngineContextPtr m_c;
+	FilterType m_type;
+public:
+	HIPFilterEngine(HIPEngineContextPtr c, FilterType type, uint frequency) :
+		AbstractFilterEngine(frequency), m_c(c), m_type(type) {}
+	void setconstants() {}
+	void getconstants() {}
+	void process(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint particleRangeEnd,
+		float slength, float influenceradius)
+	{
+		sphx_throw(sphx_filter_process(m_c->ctx(), (int)m_type, bufwrite.getData<BUFFER_VEL>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			numParticles, particleRangeEnd, slength, influenceradius, NULL));
+	}
+};
+
+// ---- post-processing (CUDAPostProcessEngine<pptype, kerneltype, boundarytype, simflags>, src/cuda/post_process.cu:88-660) ----
+class HIPPostProcessEngine : public AbstractPostProcessEngine
+{
+	HIPEngineContextPtr m_c;
+	PostProcessType m_type;
+	mutable float m_cosf, m_cosn;   // PhysParams::cosconeangle{fluid,nonfluid}, read by setconstants
+
+	bool detects() const { return m_type == SURFACE_DETECTION || m_type == INTERFACE_DETECTION; }
+public:
+	HIPPostProcessEngine(HIPEngineContextPtr c, PostProcessType type, flag_t options) :
+		AbstractPostProcessEngine(options), m_c(c), m_type(type), m_cosf(0.86f), m_cosn(0.5f) {}
+
+	void setconstants(const SimParams *, const PhysParams *physparams, idx_t const&) const
+	{
+		if (physparams) { m_cosf = physparams->cosconeanglefluid; m_cosn = physparams->cosconeanglenonfluid; }
+	}
+	void getconstants() {}
+
+	flag_t get_written_buffers() const
+	{ return m_type == VORTICITY ? BUFFER_VORTICITY : detects() ? (m_options & BUFFER_NORMALS) : BUFFER_NONE; }
+	flag_t get_updated_buffers() const
+	{ return m_type == TESTPOINTS ? BUFFER_VEL : detects() ? BUFFER_INFO : BUFFER_NONE; }
+
+	void process(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint particleRangeEnd,
+		uint, const GlobalData * const)
+	{
+		// test points and surface flags are updated in place: GPUWorker puts the buffers named by get_updated_buffers()
+		// in the write list too (src/GPUWorker.cc:2559-2572) and the reference takes them from there
+		// (src/cuda/post_process.cu:175-177,252-254; INFO is shared between states, hence MULTISTATE_SAFE)
+		float4 *velInOut = m_type == TESTPOINTS ? bufwrite.getData<BUFFER_VEL>() : NULL;
+		particleinfo *infoInOut = detects() ? bufwrite.getData<BUFFER_INFO, BufferList::MULTISTATE_SAFE>() : NULL;
+		sphx_throw(sphx_postprocess(m_c->ctx(), (int)m_type,
+			m_type == VORTICITY ? bufwrite.getData<BUFFER_VORTICITY>() : NULL,
+			velInOut, infoInOut,
+			(detects() && (m_options & BUFFER_NORMALS)) ? bufwrite.getData<BUFFER_NORMALS>() : NULL,
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			numParticles, particleRangeEnd, m_cosf, m_cosn, NULL));
+	}
+
+	// host-side hooks: only FLUX_COMPUTATION has any (src/cuda/post_process.cu:64-75,534-568)
+	void hostAllocate(const GlobalData * const) {}
+	void hostProcess(const GlobalData * const) {}
+	void write(WriterMap, double) {}
+};
+
+#endif // SPHX_HIP_ENGINES_H

@@ -104,13 +104,13 @@ class HipKernels:
         return info
 
     # ---- AbstractForcesEngine
-    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset, tau=None):
+    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset, tau=None, xsph=None):
         p = capi.ptr
         t0, t1, t2 = (p(t) for t in tau) if tau is not None else (None, None, None)
         nb = C.c_uint32(0)
         P = self.params
         capi.check(self.lib.sphx_forces_basicstep(self.ctx.handle, p(forces), p(cfl), p(rbforces), p(rbtorques), p(pos), p(vel),
-                                                  p(info), p(hash_), p(cellStart), p(neibslist), t0, t1, t2,
+                                                  p(info), p(hash_), p(cellStart), p(neibslist), t0, t1, t2, p(xsph),
                                                   n, frm, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius,
                                                   cfl_offset, D.SIMULATE, 1, 0.0, self.compute_object_forces,
                                                   C.byref(nb), self._s()))

@@ -55,7 +55,7 @@ class PhysParams:
     isotropic_sps_constant: float = 0.0066
     smagfactor: float = float("nan")
     kspsfactor: float = float("nan")
-    dcoeff: float = 0.0
+    dcoeff: float = float("nan")       # physparams.h:399 (defaulted for LJ_BOUNDARY in ProblemCore.cc:126-138)
     p1coeff: float = 12.0
     p2coeff: float = 6.0
     r0: float = float("nan")
@@ -202,16 +202,16 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
     p.influenceradius = f32(sp.influenceRadius)
     p.deltap = f32(deltap)
     p.dtadaptfactor = f32(sp.dtadaptfactor)
-    p.densityDiffCoeff = f32(sp.densityDiffCoeff) if not math.isnan(sp.densityDiffCoeff) else 0.0
+    p.densityDiffCoeff = f32(sp.densityDiffCoeff)      # NaN when no density diffusion is selected (simparams.h:287)
     p.epsxsph = f32(sp.epsxsph)
     p.numfluids = pp.numFluids()
     for f in range(pp.numFluids()):
         p.rho0[f] = f32(pp.rho0[f]); p.bcoeff[f] = f32(pp.bcoeff[f]); p.gammacoeff[f] = f32(pp.gammacoeff[f])
         p.sscoeff[f] = f32(pp.sscoeff[f]); p.sspowercoeff[f] = f32(pp.sspowercoeff[f])
-        p.visccoeff[f] = f32(pp.visccoeff[f]) if not math.isnan(pp.visccoeff[f]) else 0.0
+        p.visccoeff[f] = f32(pp.visccoeff[f])      # NaN for INVISCID, as GPUSPH::setViscosityCoefficient leaves it
     p.artvisccoeff = f32(pp.artvisccoeff)
     p.epsartvisc = f32(pp.epsartvisc)
-    nz = lambda v: 0.0 if (v is None or math.isnan(v)) else f32(v)
+    nz = lambda v: float('nan') if v is None else f32(v)   # unset coefficients stay NaN, as in the tree's PhysParams
     p.smagfactor = nz(pp.smagfactor); p.kspsfactor = nz(pp.kspsfactor)
     p.dcoeff = nz(pp.dcoeff); p.p1coeff = nz(pp.p1coeff); p.p2coeff = nz(pp.p2coeff); p.r0 = nz(pp.r0)
     p.repack_a = f32(sp.repack_a); p.repack_alpha = f32(sp.repack_alpha)

@@ -76,6 +76,7 @@ class Problem:
         self.parts = None
         self.planes = []            # [(unit normal (3), reference point (3), global coordinates)], PlaneList
         self.moving_bodies_callback = None   # ProblemCore::moving_bodies_callback: f(index, t0, t1, initial_kdata, kdata) -> (dx, dr)
+        self.m_maxFall = float("nan")        # ProblemAPI<1>::setMaxFall
 
     def plane_tables(self):
         """plane_t arrays as ProblemCore::copy_planes hands them to setplanes: unit normal, grid cell and
@@ -167,6 +168,9 @@ class Problem:
         if math.isnan(pp.r0):
             pp.r0 = self.m_deltap
         check_neiblistsize(sp, pp, self.m_deltap)
+        if not math.isfinite(pp.dcoeff) and math.isfinite(self.m_maxFall):   # ProblemAPI<1>::initialize, ProblemAPI_1.cc:322-326
+            g = float(np.float32(math.sqrt(sum(x * x for x in pp.gravity))))
+            pp.dcoeff = float(np.float32(np.float32(5.0) * np.float32(g) * self.m_maxFall))
         if math.isnan(pp.epsartvisc):   # ProblemCore.cc:160-163
             pp.epsartvisc = float(np.float32(0.01 * sp.slength * sp.slength))
         if sp.densitydiffusiontype == D.COLAGROSSI:  # ProblemCore.cc:1406-1416
@@ -206,7 +210,9 @@ class Problem:
             "ARTVISC": dict(rheologytype=D.INVISCID, turbmodel=D.ARTIFICIAL),
             "KINEMATICVISC": dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, avgop=D.HARMONIC, is_const_visc=True),
             "DYNAMICVISC": dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW),
-            "SPSVISC": dict(rheologytype=D.NEWTONIAN, turbmodel=D.SPS, avgop=D.HARMONIC, is_const_visc=True),
+            # constant viscosity only by the single-fluid rule: the framework looks at the legacy NAME, and that is not
+            # KINEMATICVISC (src/cuda/cudasimframework.cu:123-128); make_sphx_params applies the rule for None
+            "SPSVISC": dict(rheologytype=D.NEWTONIAN, turbmodel=D.SPS, avgop=D.HARMONIC),
         }
         opts = dict(compvisc=D.KINEMATIC, viscmodel=D.MORRIS, avgop=D.ARITHMETIC, is_const_visc=None)
         opts.update(legacy[spec] if (spec is None or isinstance(spec, str)) else spec)
@@ -267,7 +273,7 @@ class DamBreak3D(Problem):
         self.set_viscosity(viscosity)       # DamBreak3D.cu:54 viscosity<ARTVISC>
         sp.sph_formulation = formulation
         sp.densitydiffusiontype = density_diffusion
-        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | (D.ENABLE_MOVING_BODIES if obstacle else 0) | \
+        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | \
             (D.ENABLE_PLANES if walls == "planes" else 0) | (D.ENABLE_MULTIFLUID if two_fluids else 0)
         sp.neiblistsize = 128               # resize_neiblist(128), DamBreak3D.cu:76
         if kerneltype == D.GAUSSIAN:
@@ -493,7 +499,7 @@ class WaveTank(Problem):
         sp.boundarytype = D.LJ_BOUNDARY
         self.set_viscosity(viscosity)                      # WaveTank.cu:58
         sp.densitydiffusiontype = D.DENSITY_DIFFUSION_NONE
-        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_PLANES | D.ENABLE_MOVING_BODIES
+        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_PLANES      # WaveTank.cu:55-62 (ENABLE_MOVING_BODIES only matters to SA_BOUNDARY)
         sp.dtadaptfactor = 0.2
         sp.dt = 1.0e-4                                     # set_timestep(0.0001)
         self.linearization = linearization
@@ -638,6 +644,7 @@ class StillWater(Problem):
             self.dyn_layers = 1
         g = 9.81
         pp.gravity = (0.0, 0.0, -g)
+        self.m_maxFall = self.H                             # setMaxFall(H), StillWater.cu:70
         c0 = math.ceil(10.0 * math.sqrt(2.0 * g * self.H))
         pp.add_fluid(1000.0)
         pp.set_equation_of_state(0, 7.0, float(c0))

@@ -176,6 +176,10 @@ int sphx_reorder(sphx_ctx *ctx, uint32_t *segmentStart,
 	const void *unsortedPos, const void *unsortedVel,
 	const void *sortedInfo, const uint32_t *sortedHash, const uint32_t *partIndex,
 	uint32_t numParticles, uint32_t *newNumParticles, void *stream);
+/* the optional per-particle arrays reorderDataAndFindCellStart gathers when the buffer lists hold them
+ * (src/cuda/buildneibs.cu:263-311): sorted[i] = unsorted[partIndex[i]], rows of 4, 8 or 16 bytes */
+int sphx_gather_rows(sphx_ctx *ctx, void *sorted, const void *unsorted, uint32_t rowBytes,
+	const uint32_t *partIndex, uint32_t numParticles, void *stream);
 /* cellStart/cellEnd of the already sorted range [fromParticle, toParticle) only (no gather).  The
  * reference rebuilds the cell ranges of imported halo cells on the host from the neighbour
  * device's s_dCellStarts (src/GPUWorker.cc:754-776,1391-1430); with the halo arriving in sorted
@@ -198,7 +202,8 @@ uint32_t sphx_forces_fmax_temp_elements(uint32_t n);  /* getFmaxTempElements, :5
 uint32_t sphx_forces_round_particles(uint32_t n);     /* round_particles, :960-964 */
 /* basicstep (src/cuda/forces.cu:897-935): pair summation over [fromParticle,toParticle) +
  * finalize (gravity, /rho0, CFL block maxima into cfl[cflOffset..]).  tau0..2 may be NULL
- * (SPS only), rbforces/rbtorques may be NULL.  *h_numBlocks receives the return value of
+ * (SPS only), rbforces/rbtorques may be NULL; xsph (float4, BUFFER_XSPH: mean velocity correction of fluid
+ * particles, src/cuda/forces_params.h:213-221) is written with SPHX_ENABLE_XSPH and may be NULL otherwise.  *h_numBlocks receives the return value of
  * the reference's basicstep (#CFL elements written).
  * run_mode = SPHX_REPACK selects run_repack (src/cuda/forces.cu:828-896): the mixing force of the repacking
  * integrator on fluid particles (needs SPHX_ENABLE_REPACKING in simflags, src/main.cc:357-358). */
@@ -206,7 +211,7 @@ int sphx_forces_basicstep(sphx_ctx *ctx,
 	void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
-	const void *tau0, const void *tau1, const void *tau2,
+	const void *tau0, const void *tau1, const void *tau2, void *xsph,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
 	float deltap, float slength, float dtadaptfactor, float influenceradius,
 	uint32_t cflOffset, int run_mode, int step, float dt, int compute_object_forces,
@@ -284,6 +289,25 @@ int sphx_disable_free_surf_parts(sphx_ctx *ctx, void *pos, const void *info,
 
 /* ---- small stream-ordered helpers the callers of the reference get from cudaMemset -------- */
 int sphx_memset_async(void *ptr, int value, size_t bytes, void *stream);
+
+/* ---- device memory service ------------------------------------------------------------------
+ * What the reference's host code gets from the CUDA runtime: cudaMalloc / cudaFree / cudaMemset of
+ * CUDABuffer (src/cuda/cudabuffer.h:47-131), the device selection of the worker threads
+ * (checkCUDA, src/cuda/cudautil.cc:41; GPUWorker.cc:3245) and the blocking copies of GPUWorker's
+ * uploads / dumps (src/GPUWorker.cc:1186-1330).  With these the host adapters (gpusph_amd/host/)
+ * compile with a plain C++ compiler against GPUSPH's own headers: no HIP header on the host side of
+ * the boundary.  All of them act on the calling thread's current device; copies and sphx_memset are
+ * blocking like their cuda* counterparts. */
+int sphx_device_count(int *count);
+int sphx_set_device(int device);
+int sphx_get_device(int *device);
+int sphx_device_synchronize(void);
+int sphx_malloc(void **ptr, size_t bytes);
+int sphx_free(void *ptr);
+int sphx_memset(void *ptr, int value, size_t bytes);
+int sphx_memcpy_h2d(void *dst, const void *h_src, size_t bytes);
+int sphx_memcpy_d2h(void *h_dst, const void *src, size_t bytes);
+int sphx_memcpy_d2d(void *dst, const void *src, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -381,66 +381,57 @@ def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename):
 
 
 # ---------------------------------------------------------------------------------------------
-# C++ adapters (gpusph_amd/host/sphx_host.h): the binding INTEGRATION.md describes, driven by
-# gpusph_amd/host/example_engines through the reference's blocking-dtreduce command order, must give
-# bit-identical particles to the Python driver (same C-ABI calls, device-resident dt).
-class _DumpHeader(C.Structure):
-    from gpusph_amd.params import SphxParams as _SP
-    _fields_ = [("magic", C.c_char * 8), ("n", C.c_uint32), ("alloc", C.c_uint32), ("steps", C.c_uint32),
-                ("num_rb_particles", C.c_uint32), ("dt", C.c_float), ("sspeed_cfl", C.c_float),
-                ("nlSq", C.c_float), ("numforcesbodies", C.c_int32), ("rb_cgGridPos", C.c_int32 * 3),
-                ("rb_cgPos", C.c_float * 3), ("rb_firstindex", C.c_int32), ("filter_type", C.c_int32),
-                ("filter_freq", C.c_int32), ("params", _SP)]
+# The host side of the boundary: gpusph_amd/host/example_engines is built INSIDE the GPUSPH tree (hip_engines.h derives
+# from the reference's own abstract engines, cudasimframework.cu answers the problems' SETUP_FRAMEWORK, buffers are the
+# tree's BufferList with the HIPBuffer policy) and sends one worker's command stream through those interfaces, with the
+# reference's blocking dtreduce.  It must leave bit-identical particles to the Python driver (same C-ABI calls,
+# device-resident dt).  The binary is prebuilt in the build container (the GPU box has no GPUSPH tree).
+def _cpp_case(name):
+    from gpusph_amd.problem import StillWater, WaveTank
+    if name == "dambreak":      # DamBreak3D.cu framework; obstacle with force feedback, Shepard filter, surface detection
+        prob = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.05, hydrostatic=False)
+        return prob, "DamBreak3D", dict(rhodiff=D.COLAGROSSI, use_planes=0), [(D.SHEPARD_FILTER, 5)], 12
+    if name == "wavetank":      # WaveTank.cu: SPSVISC + planes + LJ box + moving paddle + Shepard
+        prob = WaveTank(0.06, paddle_tstart=0.0)
+        return prob, "WaveTank", {}, [(D.SHEPARD_FILTER, 4)], 13
+    if name == "stillwater":    # StillWater.cu: DYNAMICVISC + Ferrari + MLS, rebuild every 20
+        prob = StillWater(8, jitter=0.05)
+        return prob, "StillWater", dict(rhodiff=D.FERRARI, use_planes=0), [(D.MLS_FILTER, 3)], 22
+    raise KeyError(name)
 
 
-def test_cpp_adapters_match_python_engine(tmp_path):
+@pytest.mark.parametrize("name", ["dambreak", "wavetank", "stillwater"])
+def test_cpp_adapters_match_python_engine(tmp_path, name):
     import os, subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "gpusph_amd", "host", "example_engines")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-C", os.path.dirname(exe)])
-    steps = 12   # spans one re-sort (buildneibsfreq = 10)
-    prob = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.05, hydrostatic=False)
+    import host_case as hc
+    exe = hc.exe("example_engines")
+    assert os.path.exists(exe), "gpusph_amd/host/example_engines is not built (make -C gpusph_amd/host, needs the GPUSPH tree)"
+    prob, framework, selectors, filters, steps = _cpp_case(name)
     eng = _engine(prob)
+    for ft, fq in filters:
+        eng.add_filter(ft, fq)
     arrs = prob.copy_to_array()
-    n = len(arrs["hash"])
-    h = _DumpHeader()
-    h.magic = b"SPHXDMP1"
-    h.n = n; h.alloc = n; h.steps = steps; h.num_rb_particles = prob.num_obstacle
-    h.dt = eng.dt; h.sspeed_cfl = eng.sspeed_cfl; h.nlSq = eng.sq_nl_radius
-    h.numforcesbodies = prob.simparams.numforcesbodies
-    if prob.num_obstacle:
-        h.rb_cgGridPos[:] = [int(v) for v in prob.rb_cg_gridpos[0]]
-        h.rb_cgPos[:] = [float(v) for v in prob.rb_cg_pos[0]]
-        h.rb_firstindex = int(prob.rb_firstindex[0])
-    h.filter_type = D.SHEPARD_FILTER; h.filter_freq = 5        # also drives HIPFilterEngine through the adapters
-    eng.add_filter(D.SHEPARD_FILTER, 5)
-    h.params = eng.params
-    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
-    with open(fin, "wb") as f:
-        f.write(bytes(h))
-        f.write(np.ascontiguousarray(arrs["pos"], dtype=np.float32).tobytes())
-        f.write(np.ascontiguousarray(arrs["vel"], dtype=np.float32).tobytes())
-        f.write(np.ascontiguousarray(arrs["info"]).view(np.uint16).tobytes())
-        f.write(np.ascontiguousarray(arrs["hash"]).view(np.uint32).tobytes())
-    r = subprocess.run([exe, str(fin), str(fout)], capture_output=True, text=True, timeout=300)
+    case, state, fout = tmp_path / "case.txt", tmp_path / "state.bin", tmp_path / "out.bin"
+    lines = hc.case_lines(prob, framework, **selectors) + hc.driver_lines(prob, eng, steps, filters=filters, final_surface=True)
+    case.write_text("\n".join(lines) + "\n")
+    hc.write_state(state, arrs)
+    r = subprocess.run([exe, str(case), str(state), str(fout)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     eng.run(steps)
-    eng.postprocess(D.SURFACE_DETECTION)       # the driver runs HIPPostProcessEngine(SURFACE_DETECTION) before its dump
+    eng.postprocess(D.SURFACE_DETECTION)       # the driver runs the SURFACE_DETECTION engine before its dump
     ref = eng.download()
-    assert ((ref["info"].reshape(-1, 4)[:, 0] & D.FG_SURFACE) != 0).sum() > 50
-    raw = open(fout, "rb").read()
-    n2 = int(np.frombuffer(raw, np.uint32, 1, 0)[0]); dt2 = np.frombuffer(raw, np.float32, 1, 4)[0]
+    if name == "dambreak":
+        assert ((ref["info"].reshape(-1, 4)[:, 0] & D.FG_SURFACE) != 0).sum() > 20
+    out = hc.read_out(fout)
+    n2 = out["n"]
     assert n2 == eng.n
-    o = 8
-    pos = np.frombuffer(raw, np.float32, 4 * n2, o).reshape(n2, 4); o += 16 * n2
-    vel = np.frombuffer(raw, np.float32, 4 * n2, o).reshape(n2, 4); o += 16 * n2
-    info = np.frombuffer(raw, np.uint16, 4 * n2, o).reshape(n2, 4); o += 8 * n2
-    hsh = np.frombuffer(raw, np.uint32, n2, o)
-    assert np.float32(eng.current_dt()) == dt2
-    assert np.array_equal(info, ref["info"].reshape(n2, 4)) and np.array_equal(hsh, ref["hash"])
-    assert np.array_equal(pos.view(np.uint32), ref["pos"].view(np.uint32))
-    assert np.array_equal(vel.view(np.uint32), ref["vel"].view(np.uint32))
+    assert np.float32(eng.current_dt()) == out["dt"] and eng.time() == out["t"]
+    assert np.array_equal(out["info"], ref["info"].reshape(n2, 4)) and np.array_equal(out["hash"], ref["hash"])
+    assert np.array_equal(out["pos"].view(np.uint32), ref["pos"].view(np.uint32))
+    assert np.array_equal(out["vel"].view(np.uint32), ref["vel"].view(np.uint32))
+    if name == "wavetank":      # the paddle really moved
+        moved = np.abs(out["vel"][(out["info"][:, 0] & 7) == D.PT_BOUNDARY, :3]).max()
+        assert moved > 1e-3
 
 
 # ---------------------------------------------------------------------------------------------
@@ -489,7 +480,7 @@ def test_sps_stress_and_forces_tolerance(visc):
     eng._memset(eng.cfl, 0, eng._stream())
     capi.check(eng.lib.sphx_forces_basicstep(eng.ctx.handle, p(eng.forces), p(eng.cfl), None, None, p(eng.pos), p(eng.vel),
                                              p(eng.info), p(eng.hash), p(eng.cellStart), p(eng.neibslist),
-                                             p(tau[0]), p(tau[1]), p(tau[2]), n, 0, n, eng.params.deltap,
+                                             p(tau[0]), p(tau[1]), p(tau[2]), None, n, 0, n, eng.params.deltap,
                                              eng.params.slength, eng.params.dtadaptfactor, eng.params.influenceradius,
                                              0, D.SIMULATE, 1, eng.dt, 0, C.byref(nbl), eng._stream()))
     f = _np(eng.forces)[:n]
@@ -500,7 +491,7 @@ def test_sps_stress_and_forces_tolerance(visc):
     with pytest.raises((capi.SphxError, capi.SphxInvalidArgument)):
         capi.check(eng.lib.sphx_forces_basicstep(eng.ctx.handle, p(eng.forces), p(eng.cfl), None, None, p(eng.pos),
                                                  p(eng.vel), p(eng.info), p(eng.hash), p(eng.cellStart), p(eng.neibslist),
-                                                 None, None, None, n, 0, n, eng.params.deltap, eng.params.slength,
+                                                 None, None, None, None, n, 0, n, eng.params.deltap, eng.params.slength,
                                                  eng.params.dtadaptfactor, eng.params.influenceradius, 0, D.SIMULATE, 1,
                                                  eng.dt, 0, C.byref(nbl), eng._stream()))
 
