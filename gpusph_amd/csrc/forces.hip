@@ -32,6 +32,10 @@ struct ForcesArgs {
 	float2 *otau0, *otau1, *otau2; float *oturbvisc;   // stress mode of the tiled kernel (SPHX_TURB_STRESS): outputs
 	const float4 *tauPack;   // SPS + tiled kernel: [0,n) = {xx,xy,xz,yy}, [n,2n) = {yz,zz,0,0} (tau_pack_kernel); tauPackN = n
 	uint32_t tauPackN;
+	// tiled kernel: the tile lists of this neighbour list (tile_lists_kernel), [rows][stride] uint32, and the rows per wave
+	const uint32_t *tileList; uint32_t tileListRows, tileListStride;
+	const uint32_t *tileWaves;
+	float4 *xsph;        // ENABLE_XSPH: mean velocity correction of fluid particles, else NULL
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
 	uint32_t numBlocks;   // generic kernel: blocks of SPHX_BLOCK_FORCES particles to cover
@@ -183,8 +187,10 @@ template<int KERNEL, int TURB, int COLAGROSSI, bool MOMENTUM, bool DIFFUSE>
 __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s, float inv_h,
 	float pcx, float pcy, float pcz, const float4 &npos, const float4 &nvel, const float4 &naux,
 	bool same_fluid, bool valid, const float *ntau, float4 &force, bool rt_momentum = true, bool rt_diffuse = true,
-	uint32_t nfl = 0, bool f2cap = false)
+	uint32_t nfl = 0, bool f2cap = false, float range = -1.0f)
 {
+	// range: the influence radius as the caller holds it (the tiled kernel reads it from the shift-table row so that the
+	// row is read whole); < 0 = the kernel argument
 	// Branch-free on purpose: a rejected pair (list terminator passed, r >= influence radius) gets the weight
 	// m_j F_ij = 0 and every term below becomes +-0, which leaves the accumulators untouched -- the same result
 	// as the reference's `continue`, without ~6 exec-mask branch sequences per pair and without paying for lane
@@ -196,7 +202,7 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 	const float nmass = npos.w;
 	const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
 	const float r = fast_sqrt(r2);
-	const bool on = valid && (r < p.influenceradius);
+	const bool on = valid && (r < (range < 0.0f ? p.influenceradius : range));
 
 	const float vx = s.vel.x - nvel.x, vy = s.vel.y - nvel.y, vz = s.vel.z - nvel.z;
 	const float vel_dot_pos = fmaf(vz, rz, fmaf(vy, ry, vx*rx));
@@ -237,7 +243,10 @@ __device__ __forceinline__ void pair_interact(const DevParams &p, const Self &s,
 		float kk = -pgrad*mf;
 		if (TURB_MODEL(TURB) == SPHX_ARTIFICIAL) {
 			// artvisc (src/cuda/visc_kernel.cu:74-85, forces_kernel.def:2748-2764): only for approaching pairs
-			const float vdpn = fminf(vel_dot_pos, 0.0f);
+			// |rho~_j| >= 0 never wins the minimum: it only keeps the fourth component of the neighbour's velocity row live,
+			// so that the tiled kernel reads the row as one 16-byte LDS access (v_min3_f32 with an abs modifier: no extra
+			// instruction; a 12-byte read costs twice the LDS cycles)
+			const float vdpn = fminf(fminf(vel_dot_pos, 0.0f), fabsf(nvel.w));
 			const float visc = vdpn*(p.slength*p.artvisccoeff)*(s.sspeed + n_sspeed)*
 				fast_rcp((r2 + p.epsartvisc)*(s.rho + n_rho));
 			kk = fmaf(visc, mf, kk);
@@ -582,31 +591,34 @@ __device__ __forceinline__ void lds_barrier()
 
 __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
 
-// One batch (TILE_NB entries) of list entries of section `sec` (0 = fluid slots 0 upward, 1 = boundary slots
-// neibboundpos downward).  The pair loop is wave-uniform, so the batch number is a scalar and the four rows
-// of a batch are addressed as buffer loads: SGPR descriptor (row base) + SGPR row offset + the per-lane byte
-// offset index*2, which is fixed for the whole tile -- no vector address arithmetic at all.
-// Needs neiblistsize % TILE_NB == 0 and (neibboundpos+1) % TILE_NB == 0 (checked by the host, else generic path).
-struct ListRows { const neibdata *list; uint32_t rowBytes; uint32_t *pin; };
+// Tile lists.  The reference-format neighbour list (u16 entries: index within the neighbour cell, cell code on the
+// first entry of each cell run) costs the pair loop a running cell code, two dependent LDS table look-ups (code ->
+// first window slot of that cell as seen from the home cell, then the row itself) and a per-lane "still alive" flag:
+// ~14 of ~70 vector instructions per pair plus a serial LDS round trip.  All of that depends only on the list and the
+// tiling, i.e. it changes once per neighbour-list build, not once per forces pass (20 passes per build), so
+// tile_lists_kernel (below) does it at build time and leaves, per stored neighbour, one uint32:
+//     bits 0..15   LDS byte offset of the neighbour's row in the tile's window (slot*16; the window arrays are parallel)
+//     bits 16..31  byte offset of the shift-table entry of the neighbour's cell (cell code*16)
+// Rows [0, nF) hold the fluid section, rows [R-nB, R) the boundary section (first entry in row R-1, like the
+// reference's list runs down from neibboundpos); nF and nB are PER WAVE (multiples of TILE_LIST_BATCH): lanes with
+// shorter lists are padded with the offset of a dummy row (mass 0, far away), so the pair loop has a scalar trip
+// count, no terminator test and no validity flag.  The pair loop is wave-uniform, so the batch number is a scalar
+// and the four rows of a batch are addressed as buffer loads: SGPR descriptor (row base) + SGPR row offset + the
+// per-lane byte offset index*4, which is fixed for the whole tile -- no vector address arithmetic at all.
+struct ListRows { const uint32_t *list; uint32_t rowBytes; uint32_t rows; uint32_t *pin; };
 
-__device__ __forceinline__ int list_last_batch(const DevParams &p, int sec)
+__device__ __forceinline__ void load_list_u(const ListRows &lr, uint32_t voff, int sec, int batch, uint32_t nd[TILE_NB])
 {
-	return sec ? ((int)p.neibboundpos + 1)/TILE_NB - 1 : (int)p.neiblistsize/TILE_NB - 1;
-}
-
-__device__ __forceinline__ void load_list_u(const DevParams &p, const ListRows &lr,
-	uint32_t voff, int sec, int batch, uint32_t nd[TILE_NB])
-{
-	// batches past the section's last slot are never consumed (the walk stops there); the clamp only keeps the
+	// batches past a section's end are never consumed (the walk stops there); the clamp only keeps the
 	// prefetch in bounds.  No branch around the loads: the compiler must be able to count them (s_waitcnt vmcnt(N)).
-	const int b = min(__builtin_amdgcn_readfirstlane(batch), list_last_batch(p, sec));
-	const int lowSlot = sec ? (int)p.neibboundpos - (b*TILE_NB + TILE_NB - 1) : b*TILE_NB;
-	const neibdata *row = lr.list + (size_t)lowSlot*p.stride;
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<neibdata*>(row), 0, 0xFFFFFFFF, 0x00020000);
+	const int b = min(__builtin_amdgcn_readfirstlane(batch), (int)lr.rows/TILE_NB - 1);
+	const int lowRow = sec ? (int)lr.rows - (b*TILE_NB + TILE_NB) : b*TILE_NB;
+	const uint32_t *row = lr.list + (size_t)lowRow*(lr.rowBytes/4u);
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row), 0, 0xFFFFFFFF, 0x00020000);
 #pragma unroll
 	for (int k = 0; k < TILE_NB; ++k) {
-		const int up = sec ? TILE_NB - 1 - k : k;     // rows above lowSlot
-		nd[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)voff, (int)(up*lr.rowBytes), 0);
+		const int up = sec ? TILE_NB - 1 - k : k;     // rows above lowRow
+		nd[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(up*lr.rowBytes), 0);
 	}
 }
 
@@ -619,14 +631,13 @@ __device__ __forceinline__ void pin_batch(const ListRows &lr, const uint32_t nd[
 		lr.pin[threadIdx.x] = nd[0] ^ nd[1] ^ nd[2] ^ nd[3];
 }
 
-__device__ __forceinline__ void preload_list(const DevParams &p, const ListRows &lr, uint32_t voff, int sec, ListWindow &lw)
+__device__ __forceinline__ void preload_list(const ListRows &lr, uint32_t voff, int sec, ListWindow &lw)
 {
 #pragma unroll
 	for (int j = 0; j < TILE_AHEAD; ++j)
-		load_list_u(p, lr, voff, sec, j, lw.q[j]);   // batches 0..TILE_AHEAD-1 always exist (host check)
+		load_list_u(lr, voff, sec, j, lw.q[j]);   // rows 0..TILE_AHEAD*TILE_NB-1 always exist (tile_list_rows >= 16)
 }
 
-struct WalkState { uint32_t code; bool alive; };
 struct StressAcc { float x, y, z, w, u; };   // stress mode: the accumulators that do not fit the float4 of the forces
 
 // one pair of SPSstressMatrixDevice (src/cuda/visc_kernel.cu:759-811) in the tiled kernel: dv_ab -= (v_a - nv_a) r_b F m/rho_n,
@@ -655,37 +666,34 @@ __device__ __forceinline__ void stress_interact(const DevParams &p, const Self &
 struct Gathered {
 	float4 npos[TILE_HB], nvel[TILE_HB], naux[TILE_HB];
 	float ntau[TILE_HB][6];   // SPS only
-	float qx[TILE_HB], qy[TILE_HB], qz[TILE_HB];
-	bool valid[TILE_HB];
+	float qx[TILE_HB], qy[TILE_HB], qz[TILE_HB], qw[TILE_HB];   // own position in the neighbour's cell frame; the influence radius
 };
 
-// stage 1 of the pair pipeline: decode TILE_HB list entries and issue the LDS reads of their rows.
-// Branch-free: the walk state is the current CELL CODE (updated with one select when an entry carries a
-// code); every entry looks it up in two small LDS tables -- sShift[code] = own-position shift into that
-// neighbour cell's frame (d_cell_to_offset order, src/cuda/forces.cu:376-386: code-1 = (x+1) + 3(y+1) + 9(z+1)),
-// myCB[code] = LDS slot of that cell's first particle as seen from this particle's cell.  No divergent
-// branch means a whole ring step is one basic block, so the scheduler can overlap these LDS round trips
-// with the arithmetic of the previous pairs.
+__device__ __forceinline__ const float4 &lds_row(const float4 *base, uint32_t byteOffset)
+{
+	return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byteOffset);
+}
+
+// stage 1 of the pair pipeline: issue the LDS reads of TILE_HB neighbours.  A tile-list entry holds the byte offsets
+// of the neighbour's window row and of the own-position shift into that neighbour's cell frame (sShift[code]:
+// d_cell_to_offset order, src/cuda/forces.cu:376-386: code-1 = (x+1) + 3(y+1) + 9(z+1)); nothing here depends on a
+// previous LDS read, so the round trips overlap with the arithmetic of the previous pairs.
 template<int TURB>
 __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
-	const float4 *sShift, const uint16_t *myCB, const float4 *sPos, const float4 *sVel, const float4 *sAux,
-	WalkState &w, Gathered &g)
+	const float4 *sShift, const float4 *sPos, const float4 *sVel, const float4 *sAux, Gathered &g)
 {
+	constexpr uint32_t WS = TILE_WC(TURB) + 1u;
 #pragma unroll
 	for (int k = 0; k < TILE_HB; ++k) {
 		const uint32_t d = nd[k];
-		w.alive = w.alive && (d != NEIBS_END);
-		w.code = (d >= CELLNUM_ENCODED) ? (d >> CELLNUM_SHIFT) : w.code;   // 1..27 = cell code, 31 = terminator
-		const float4 sh = sShift[w.code];
-		const uint32_t cb = myCB[w.code];
-		g.valid[k] = w.alive;
+		const uint32_t L = d & 0xFFFFu;
+		const float4 sh = lds_row(sShift, d >> 16);
 		// == fmaf(-ox, cellsize, pos): ox in {-1,0,1}, so the product is exact
-		g.qx[k] = s.pos.x + sh.x; g.qy[k] = s.pos.y + sh.y; g.qz[k] = s.pos.z + sh.z;
-		const uint32_t L = w.alive ? cb + (d & NEIBINDEX_MASK) : 0u;
-		g.npos[k] = sPos[L]; g.nvel[k] = sVel[L];
-		if (!(TURB & SPHX_TURB_STRESS)) g.naux[k] = sAux[L];
-		if (TURB_MODEL(TURB) == SPHX_SPS) {   // the SPS rows lie behind the EOS rows: sAux[WC + L], sAux[2 WC + L]
-			const float4 ta = sAux[TILE_WC(TURB) + L], tb = sAux[2*TILE_WC(TURB) + L];
+		g.qx[k] = s.pos.x + sh.x; g.qy[k] = s.pos.y + sh.y; g.qz[k] = s.pos.z + sh.z; g.qw[k] = sh.w;
+		g.npos[k] = lds_row(sPos, L); g.nvel[k] = lds_row(sVel, L);
+		if (!(TURB & SPHX_TURB_STRESS)) g.naux[k] = lds_row(sAux, L);
+		if (TURB_MODEL(TURB) == SPHX_SPS) {   // the SPS rows lie behind the EOS rows: sAux[WS + slot], sAux[2 WS + slot]
+			const float4 ta = lds_row(sAux + WS, L), tb = lds_row(sAux + 2*WS, L);
 			g.ntau[k][0] = ta.x; g.ntau[k][1] = ta.y; g.ntau[k][2] = ta.z; g.ntau[k][3] = ta.w; g.ntau[k][4] = tb.x; g.ntau[k][5] = tb.y;
 		}
 	}
@@ -696,18 +704,18 @@ __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 // particles with force feedback (ljlane) are Lennard-Jones repulsions instead of SPH interactions
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered &g, const Self &s, float inv_h,
-	bool momentum, bool diffuse, bool ljsec, bool ljlane, float4 &force, StressAcc &fx)
+	bool take, bool momentum, bool diffuse, bool ljsec, bool ljlane, float4 &force, StressAcc &fx)
 {
 	if (TURB & SPHX_TURB_STRESS) {   // velocity-gradient sums of the SPS stress tensor: force = dv[0..3], fx = dv[4..8]
 #pragma unroll
 		for (int k = 0; k < TILE_HB; ++k)
-			stress_interact<KERNEL>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.nvel[k], g.valid[k], force, fx);
+			stress_interact<KERNEL>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.nvel[k], take, force, fx);
 		return;
 	}
 	if (LJ && ljsec) {
 #pragma unroll
 		for (int k = 0; k < TILE_HB; ++k)
-			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.valid[k], force);
+			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], take, force);
 		return;
 	}
 	const bool anyLj = LJ && wave_any(ljlane);
@@ -716,18 +724,18 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 		uint32_t nfl = 0u;
 		if (TURB & SPHX_TURB_MF) nfl = __float_as_uint(g.naux[k].y) & 3u;     // fluid number tag of the EOS row
 		pair_interact<KERNEL, TURB, COLAGROSSI, true, true>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k],
-			g.npos[k], g.nvel[k], g.naux[k], nfl == s.fl, g.valid[k] && !(LJ && ljlane), g.ntau[k], force, momentum, diffuse, nfl);
+			g.npos[k], g.nvel[k], g.naux[k], nfl == s.fl, take && !(LJ && ljlane), g.ntau[k], force, momentum, diffuse, nfl, false, g.qw[k]);
 		if (anyLj)
-			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.valid[k] && ljlane, force);
+			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], take && ljlane, force);
 	}
 }
 
-// Walk one section of the neighbour lists of a whole wave against the LDS window.
-//  * WAVE-UNIFORM control: the loop runs until no lane of the wave has entries left (lanes past their
-//    terminator contribute pairs of weight 0, pair_interact is branch-free).  Lanes that finish early would
-//    idle in SIMD execution anyway; uniform control removes the exec-mask bookkeeping and makes batch
+// Walk one section of the tile lists of a whole wave against the LDS window.
+//  * WAVE-UNIFORM control with a scalar trip count: `rows` entries per lane (the wave's longest list of the section,
+//    padded by tile_lists_kernel; pad entries are pairs of weight 0, pair_interact is branch-free).  Lanes with short
+//    lists would idle in SIMD execution anyway; uniform control removes the exec-mask bookkeeping and makes batch
 //    numbers and list row addresses scalar;
-//  * list entries (HBM, 2 B per pair: the dominant algorithmic traffic) are fetched TILE_AHEAD-1
+//  * list entries (HBM, 4 B per pair: the dominant traffic of the pass) are fetched TILE_AHEAD-1
 //    batches ahead into a ring of register buffers, rotated by unrolling, not by copying (a copy of
 //    an in-flight load would wait for it);
 //  * the LDS reads of the next TILE_HB pairs are issued before the current TILE_HB pairs are
@@ -736,32 +744,35 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 //    once in the kernel (the instruction cache is 64 KB; four template copies did not fit).
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListRows &list,
-	uint32_t voff, const Self &s, float inv_h, const float4 *sShift, const uint16_t *myCB,
+	uint32_t voff, const Self &s, float inv_h, const float4 *sShift,
 	const float4 *sPos, const float4 *sVel, const float4 *sAux,
-	int sec, bool take, bool momentum, bool diffuse, bool ljlane,
+	int sec, int rows, bool take, bool momentum, bool diffuse, bool ljlane,
 	ListWindow &lw /* batches 0..preloaded-1 already requested */, int preloaded, float4 &force, StressAcc &fx)
 {
 	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
-	WalkState w; w.code = 0; w.alive = take;
+	static_assert(TILE_LIST_BATCH % TILE_NB == 0, "section lengths are whole batches");
+	const int nb = __builtin_amdgcn_readfirstlane(rows)/TILE_NB;   // batches to process (scalar)
+	if (nb == 0) return;
 	int next = TILE_AHEAD;   // index of the next batch to fetch (scalar)
-	const int lastBatch = list_last_batch(p, sec);   // a list without terminator ends with its section
 	for (int j = preloaded; j < TILE_AHEAD; ++j) {
-		load_list_u(p, list, voff, sec, j, lw.q[j]);
+		load_list_u(list, voff, sec, j, lw.q[j]);
 		pin_batch(list, lw.q[j]);
 	}
+	int left = nb;
 	Gathered A, B;
-	gather_half<TURB>(lw.q[0], s, sShift, myCB, sPos, sVel, sAux, w, A);
-	if (!wave_any(A.valid[0])) return;
+	gather_half<TURB>(lw.q[0], s, sShift, sPos, sVel, sAux, A);
+	// one batch per step; the first half of the NEXT batch is gathered before the second half of this one is computed,
+	// also after the last batch (a clamped, in-bounds prefetch whose rows are never computed): one exit per step and no
+	// second copy of the pair code
 #define SPHX_RING_STEP(J, JN) \
-	gather_half<TURB>(lw.q[J] + TILE_HB, s, sShift, myCB, sPos, sVel, sAux, w, B); \
-	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, inv_h, momentum, diffuse, sec == 1, ljlane, force, fx); \
-	if (!wave_any(B.valid[0])) return; \
-	load_list_u(p, list, voff, sec, next, lw.q[J]); \
+	gather_half<TURB>(lw.q[J] + TILE_HB, s, sShift, sPos, sVel, sAux, B); \
+	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
+	load_list_u(list, voff, sec, next, lw.q[J]); \
 	pin_batch(list, lw.q[J]); \
 	++next; \
-	gather_half<TURB>(lw.q[JN], s, sShift, myCB, sPos, sVel, sAux, w, A); \
-	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, inv_h, momentum, diffuse, sec == 1, ljlane, force, fx); \
-	if (!wave_any(A.valid[0]) || next - TILE_AHEAD > lastBatch) return;   /* A now holds batch next-TILE_AHEAD */
+	gather_half<TURB>(lw.q[JN], s, sShift, sPos, sVel, sAux, A); \
+	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
+	if (--left == 0) return;
 	for (;;) {
 		SPHX_RING_STEP(0, 1)
 		SPHX_RING_STEP(1, 2)
@@ -796,7 +807,7 @@ __device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t tid, u
 }
 
 // a thread's own rows and the first batches of its neighbour list, requested one tile ahead
-struct TileOwn { particleinfo info; float4 pos, vel, aux; uint32_t hash; ListWindow lwF; uint32_t lwB0[TILE_NB]; };
+struct TileOwn { particleinfo info; float4 pos, vel, aux; uint32_t hash; ListWindow lwF; uint32_t lwB0[TILE_NB]; uint32_t waveRows; };
 
 // tail of SPSstressMatrixDevice (src/cuda/visc_kernel.cu:780-811): shear rate -> nu_SPS, tau
 __device__ __forceinline__ void stress_finalize(const DevParams &p, const ForcesArgs &a, uint32_t index, float rho,
@@ -832,10 +843,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	constexpr uint32_t WC = TILE_WC(TURB);
 	constexpr bool SPSW = TURB_MODEL(TURB) == SPHX_SPS;
 	constexpr bool STRESS = (TURB & SPHX_TURB_STRESS) != 0;   // stress mode: no EOS rows, every active particle walks both sections
-	__shared__ __attribute__((aligned(16))) float4 sPos[WC];
-	__shared__ __attribute__((aligned(16))) float4 sVel[WC];
-	__shared__ __attribute__((aligned(16))) float4 sAux[SPSW ? 3*WC : STRESS ? 1 : WC];   // SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}
-	__shared__ uint32_t sCellBase[TILE_WROWS*TILE_KW];   // LDS slot of the first particle of each window cell
+	constexpr uint32_t WS = WC + 1;   // window arrays: the dummy row the pad entries of the tile lists point to (slot 0) + WC records
+	__shared__ __attribute__((aligned(16))) float4 sPos[WS];
+	__shared__ __attribute__((aligned(16))) float4 sVel[WS];
+	__shared__ __attribute__((aligned(16))) float4 sAux[SPSW ? 3*WS : WS];   // SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}
 	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW];    // ... relative to the start of its window row (never modified after the scan)
 	__shared__ uint32_t sCnt[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sStart[TILE_WROWS*TILE_KW];
@@ -843,8 +854,6 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	__shared__ float sWaveMax[TILE_THREADS/64];
 	__shared__ uint32_t sTileQ[2];                                 // [0] first tile, [1] next tile of this workgroup
 	__shared__ __attribute__((aligned(16))) float4 sShift[32];   // cell code -> own-position shift (x,y,z)
-	__shared__ int sCodeOff[32];                                   // cell code-1 -> window-table offset
-	__shared__ uint16_t sCB[TILE_HROWS*TILE_MAXCELLS*27 + 8];      // [home cell][code] -> LDS slot of the cell's first record
 
 	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this launch
 	const uint32_t numTiles = tileCtl[0];
@@ -890,23 +899,25 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		return;
 	}
 
-	// neighbour-cell offset (ox,oy,oz) -> index of that cell in the window table, relative to the
-	// particle's own (row, column): o1 + KW*(o2+1) + 4*KW*(o3+1) + 1 with (o1,o2,o3) the offsets along COORD1..3
 	if (tid < 32) {   // published by the first barrier of the tile loop
 		const int c = (int)tid - 1;                // d_cell_to_offset order: c = (x+1) + 3(y+1) + 9(z+1)
 		const bool real = c >= 0 && c < 27;
 		const int cz = c/9, cy = (c - cz*9)/3;
 		const int ox = real ? c - cz*9 - cy*3 - 1 : 0, oy = real ? cy - 1 : 0, oz = real ? cz - 1 : 0;
-		const int mx = (p.c1 == 0) ? 1 : (p.c2 == 0) ? TILE_KW : 4*TILE_KW;
-		const int my = (p.c1 == 1) ? 1 : (p.c2 == 1) ? TILE_KW : 4*TILE_KW;
-		const int mz = (p.c1 == 2) ? 1 : (p.c2 == 2) ? TILE_KW : 4*TILE_KW;
-		sShift[tid] = make_float4(-(float)ox*p.cs[0], -(float)oy*p.cs[1], -(float)oz*p.cs[2], 0.0f);
-		if (real) sCodeOff[c] = ox*mx + oy*my + oz*mz + 1 + TILE_KW + 4*TILE_KW;
+		// .w = the influence radius: the pair's range test reads it from here, which makes the whole 16-byte entry live
+		// (a 12-byte LDS read costs twice the LDS cycles of a 16-byte one, MI355X_MICROARCH.md LDS table)
+		sShift[tid] = make_float4(-(float)ox*p.cs[0], -(float)oy*p.cs[1], -(float)oz*p.cs[2], p.influenceradius);
+	}
+	if (tid == 32) {   // the dummy row (slot 0): no mass, a kilometre away, finite everywhere -> every term of the pair is +-0
+		sPos[0] = make_float4(1.0e3f, 1.0e3f, 1.0e3f, 0.0f);
+		sVel[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		sAux[0] = make_float4(0.0f, 1.0f, 0.0f, 1.0f);
+		if (SPSW) { sAux[WS] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); sAux[2*WS] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 	}
 	const float inv_h = fast_rcp(p.slength);
 	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
-	ListRows listRows; listRows.list = a.neibsList; listRows.rowBytes = (uint32_t)(p.stride*sizeof(neibdata));
-	listRows.pin = a.pin;
+	ListRows listRows; listRows.list = a.tileList; listRows.rowBytes = a.tileListStride*(uint32_t)sizeof(uint32_t);
+	listRows.rows = a.tileListRows; listRows.pin = a.pin;
 	const int wr = (int)(tid/TILE_KW), wcol = (int)(tid - (tid/TILE_KW)*TILE_KW);   // my window cell (tid < 256)
 
 	// software pipeline over tiles: the descriptor and the window-cell extents of the NEXT tile are
@@ -923,18 +934,19 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	// after the window barrier of their tile.  Their ~28 vector memory instructions per thread cost ~3 us of
 	// address-unit issue per tile, which now overlaps the previous tile's pair loop instead of sitting at the
 	// head of the staging chain.
-	auto request_own = [&](const TileHome &h, TileOwn &o) {
+	auto request_own = [&](const TileHome &h, uint32_t t, TileOwn &o) {
 		o.info = a.info[h.li]; o.pos = a.pos[h.li]; o.vel = a.vel[h.li]; o.hash = a.hash[h.li];
 		if (!STRESS) o.aux = a.aux[h.li];
-		const uint32_t vo = h.li*2u;   // byte offset of this particle inside every list row (n < 2^31)
-		preload_list(p, listRows, vo, 0, o.lwF);
+		o.waveRows = a.tileWaves[(size_t)t*(TILE_THREADS/64) + (tid >> 6)];
+		const uint32_t vo = h.li*4u;   // byte offset of this particle inside every list row (n < 2^30)
+		preload_list(listRows, vo, 0, o.lwF);
 		// boundary section: most particles have none, so only its first batch is requested up front; the walk
 		// requests the rest when a wave does have boundary neighbours
-		load_list_u(p, listRows, vo, 1, 0, o.lwB0);
+		load_list_u(listRows, vo, 1, 0, o.lwB0);
 	};
 	TileHome hc = tile_home(dc, tid, a.fromParticle, a.toParticle);
 	TileOwn own;
-	if (hc.inRange) request_own(hc, own);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
+	if (hc.inRange) request_own(hc, tile, own);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
 	const bool prof = a.prof != nullptr && tid == 0;
 	unsigned long long tBegin = 0, t0 = 0, tA = 0, tB = 0, accStage = 0, accPairs = 0, accTail = 0, s1 = 0, s2 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 	if (prof) tBegin = wall_clock64();
@@ -942,13 +954,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		if (prof) t0 = wall_clock64();
 		uint32_t drawn = 0;
 		if (tid == 0) drawn = atomicAdd(tileCtl + 4 + src, 1u);   // the tile after next; consumed after the window barrier
-		const int ca = (int)dc[2], ncells = (int)dc[3];
+		const int ncells = (int)dc[3];
 		const uint32_t firstMin = hc.firstMin;
 		const bool inRange = hc.inRange, mine = hc.mine;
-		const int hrow = hc.hrow;
 		const uint32_t index = hc.index;
 		const bool pairs = ((dc[13] & 1u) || STRESS) && (a.dbg & 3) != 1;   // no fluid anywhere in the window: nothing interacts
-		const uint32_t voff = hc.li*2u;
+		const uint32_t voff = hc.li*4u;
 
 		lds_barrier();   // the previous tile's readers are done with LDS
 		const uint32_t nextTile = sTileQ[1];
@@ -1004,7 +1015,6 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				if ((int)lane >= dd) rowIncl += t;
 			}
 			const uint32_t rowBase = rowIncl - rowTot;
-			const uint32_t myRowBase = __shfl(rowBase, wr, 64);
 			static_assert(TILE_WROWS <= 64, "row totals are scanned inside one wave");
 #pragma unroll 1
 			for (uint32_t r = wave; r < TILE_WROWS; r += TILE_THREADS/64) {
@@ -1013,27 +1023,24 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				if (base + total > WC || (a.dbg & 3) == 2 || !total) continue;   // cannot overflow for tiles of build_tiles_kernel
 				if (sRowContig[r]) {
 					const uint32_t rs = __builtin_amdgcn_readfirstlane(sRowStart[r]);
-					stage_row_wave(a.pos + rs, sPos + base, total, lane);
-					stage_row_wave(a.vel + rs, sVel + base, total, lane);
-					if (!STRESS) stage_row_wave(a.aux + rs, sAux + base, total, lane);
+					stage_row_wave(a.pos + rs, sPos + 1 + base, total, lane);
+					stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
+					if (!STRESS) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
 					if (SPSW) {
-						stage_row_wave(a.tauPack + rs, sAux + WC + base, total, lane);
-						stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + 2*WC + base, total, lane);
+						stage_row_wave(a.tauPack + rs, sAux + WS + 1 + base, total, lane);
+						stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + 2*WS + 1 + base, total, lane);
 					}
 				} else {   // a row crossing cell-type segments (multi-GPU device maps not split on COORD3)
 					for (int col = 0; col < ncells + 2; ++col) {
-						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = base + sCellRel[r*TILE_KW + col];
+						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = 1u + base + sCellRel[r*TILE_KW + col];
 						for (uint32_t q = lane; q < cnt; q += 64u) {
 							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q];
 							if (!STRESS) sAux[cb + q] = a.aux[st + q];
-							if (SPSW) { sAux[WC + cb + q] = a.tauPack[st + q]; sAux[2*WC + cb + q] = a.tauPack[a.tauPackN + st + q]; }
+							if (SPSW) { sAux[WS + cb + q] = a.tauPack[st + q]; sAux[2*WS + cb + q] = a.tauPack[a.tauPackN + st + q]; }
 						}
 					}
 				}
 			}
-			// absolute slot of each window cell; a separate array from sCellRel: the waves stage their rows
-			// concurrently, and the per-cell copy above reads the relative offsets of OTHER threads' cells
-			if (tid < TILE_WROWS*TILE_KW) sCellBase[tid] = sCellRel[tid] + myRowBase;
 		}
 		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA (and its own rows, list batches) have landed
 		__syncthreads();                      // ... everybody's have; the tables are published
@@ -1049,7 +1056,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		TileOwn ownNext;
 		if (haveNext) {
 			hn = tile_home(dn, tid, a.fromParticle, a.toParticle);
-			if (hn.inRange) request_own(hn, ownNext);
+			if (hn.inRange) request_own(hn, nextTile, ownNext);
 		}
 		const particleinfo info = own.info;
 		const float4 pos = own.pos;
@@ -1078,17 +1085,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		StressAcc fx = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 		if (inRange && pairs) {
-			// per-home-cell code table: slot of the first record of each of the 27 neighbour cells
-			for (uint32_t e = tid; e < TILE_HROWS*TILE_MAXCELLS*27; e += TILE_THREADS) {
-				const uint32_t m = e/27u, c1 = e - m*27u;
-				const uint32_t hr = m/TILE_MAXCELLS, col = m - hr*TILE_MAXCELLS;
-				sCB[e + 1] = (uint16_t)sCellBase[sCodeOff[c1] + (int)(((hr & 1u) + 4u*(hr >> 1))*TILE_KW + col)];
-			}
-			lds_barrier();
 			const uint32_t ptype = PART_TYPE(info);
-			const int myG1 = (p.c1 == 0) ? s.gridPos.x : (p.c1 == 1) ? s.gridPos.y : s.gridPos.z;
-			const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
-			const uint16_t *myCB = sCB + (hrow*TILE_MAXCELLS + myCol)*27;
 			const bool isFluid = ptype == PT_FLUID, isBound = ptype == PT_BOUNDARY, isDynBound = isBound && dyn;
 			// fluid: fluid section then boundary section (DYN: SPH pairs, LJ: repulsion); DYN boundary: fluid section
 			// only, with the momentum part only for bodies with force feedback (forces_kernel.def:3650-3679);
@@ -1097,11 +1094,13 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			const bool ljlane = LJ && isBound;
 			const bool take0 = active && (STRESS || isFluid || isDynBound || (ljlane && HAS_COMPUTE_FORCE(info) && a.compute_object_forces));
 			const bool take1 = active && (STRESS || (isFluid && (dyn || LJ)));
-			walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift, myCB,
-				sPos, sVel, sAux, 0, take0, momentum, true, ljlane, own.lwF, TILE_AHEAD, force, fx);
+			const int rowsF = (int)(own.waveRows & 0xFFFFu), rowsB = (int)(own.waveRows >> 16);
+			if (wave_any(take0))
+				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift,
+					sPos, sVel, sAux, 0, rowsF, take0, momentum, true, ljlane, own.lwF, TILE_AHEAD, force, fx);
 			if (wave_any(take1))
-				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift, myCB,
-					sPos, sVel, sAux, 1, take1, momentum, false, false, lwB, 1, force, fx);
+				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift,
+					sPos, sVel, sAux, 1, rowsB, take1, momentum, false, false, lwB, 1, force, fx);
 		}
 		if (prof) tB = wall_clock64();
 		// vmcnt(0): only the list batches fetched past the terminators and the next tile's window extents are in
@@ -1497,6 +1496,126 @@ void SPHX_PASTE(sphx_part_sps_k, SPHX_FORCES_PART)(const sphx_ctx *ctx, dim3 gri
 }
 #else   // the C ABI, to the end of the file
 
+// ------------------------------------------------------------------------------------------
+// Tile lists: the reference-format neighbour lists of the tiled particles, translated once per neighbour-list build
+// into the form the tiled pair loop walks (see ListRows above).  One workgroup per tile with the forces kernel's
+// thread -> particle map (tile_home) and its window layout: window row r holds the cells of grid row (g2-1+(r&3),
+// g3-1+(r>>2)) from column ca-1 on, rows follow each other without gaps, so the slot of a record is
+// (records of the rows before) + (records of the cells before it in its row) + its index in its cell.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(TILE_THREADS)
+tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t *__restrict__ hash,
+	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
+	const uint32_t *__restrict__ tiles, uint32_t *tileCtl,
+	uint32_t *__restrict__ tileList, uint32_t listStride, uint32_t listRows, uint32_t *__restrict__ tileWaves)
+{
+	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW], sCellBase[TILE_WROWS*TILE_KW];
+	__shared__ uint32_t sRowTotal[TILE_WROWS];
+	__shared__ int sCodeOff[32];                                   // cell code-1 -> window-table offset
+	__shared__ uint16_t sCB[TILE_HROWS*TILE_MAXCELLS*27 + 8];      // [home cell][code] -> slot of the cell's first record
+	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this list
+	const uint32_t numTiles = tileCtl[0];
+	const uint32_t tid = threadIdx.x;
+	const uint32_t dummy = 0u;              // slot 0 of every window is the dummy record; shift code 0
+	// neighbour-cell offset (ox,oy,oz) -> index of that cell in the window table, relative to the
+	// particle's own (row, column): o1 + KW*(o2+1) + 4*KW*(o3+1) + 1 with (o1,o2,o3) the offsets along COORD1..3
+	if (tid < 27) {
+		const int c = (int)tid;                    // d_cell_to_offset order: c = (x+1) + 3(y+1) + 9(z+1)
+		const int cz = c/9, cy = (c - cz*9)/3;
+		const int ox = c - cz*9 - cy*3 - 1, oy = cy - 1, oz = cz - 1;
+		const int mx = (p.c1 == 0) ? 1 : (p.c2 == 0) ? TILE_KW : 4*TILE_KW;
+		const int my = (p.c1 == 1) ? 1 : (p.c2 == 1) ? TILE_KW : 4*TILE_KW;
+		const int mz = (p.c1 == 2) ? 1 : (p.c2 == 2) ? TILE_KW : 4*TILE_KW;
+		sCodeOff[c] = ox*mx + oy*my + oz*mz + 1 + TILE_KW + 4*TILE_KW;
+	}
+	const int wr = (int)(tid/TILE_KW), wcol = (int)(tid - (tid/TILE_KW)*TILE_KW);   // my window cell (tid < 256)
+	const size_t stride = (size_t)p.stride;
+	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
+		__syncthreads();   // the previous tile's tables are no longer read
+		uint32_t d[TILE_DESC];
+#pragma unroll
+		for (int k = 0; k < TILE_DESC; ++k) d[k] = tiles[(size_t)TILE_DESC*tile + k];
+		const int ca = (int)d[2];
+		if (tid < TILE_WROWS*TILE_KW) {
+			uint32_t wStart = 0, wCnt = 0;
+			window_cell(p, cellStart, cellEnd, (int)d[0], (int)d[1], ca, (int)d[3], wr, wcol, wStart, wCnt);
+			uint32_t incl = wCnt;
+#pragma unroll
+			for (int dd = 1; dd < TILE_KW; dd <<= 1) {
+				const uint32_t t = __shfl_up(incl, dd, TILE_KW);
+				if (wcol >= dd) incl += t;
+			}
+			sCellRel[tid] = incl - wCnt;
+			if (wcol == TILE_KW - 1) sRowTotal[wr] = incl;
+		}
+		__syncthreads();
+		if (tid < TILE_WROWS*TILE_KW) {
+			uint32_t base = 0;
+			for (int r = 0; r < wr; ++r) base += sRowTotal[r];
+			sCellBase[tid] = sCellRel[tid] + base;
+		}
+		__syncthreads();
+		for (uint32_t e = tid; e < TILE_HROWS*TILE_MAXCELLS*27; e += TILE_THREADS) {
+			const uint32_t m = e/27u, c1 = e - m*27u;
+			const uint32_t hr = m/TILE_MAXCELLS, col = m - hr*TILE_MAXCELLS;
+			sCB[e + 1] = (uint16_t)sCellBase[sCodeOff[c1] + (int)(((hr & 1u) + 4u*(hr >> 1))*TILE_KW + col)];
+		}
+		__syncthreads();
+		const TileHome h = tile_home(d, tid, 0u, 0xFFFFFFFFu);
+		const bool mine = tid < h.hcTot;
+		const uint32_t index = h.li;
+		const int3 gp = grid_pos_from_hash(p, hash[index] & CELLTYPE_BITMASK);
+		const int myG1 = (p.c1 == 0) ? gp.x : (p.c1 == 1) ? gp.y : gp.z;
+		const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
+		const uint16_t *myCB = sCB + (h.hrow*TILE_MAXCELLS + myCol)*27;
+		uint32_t rowsSec[2] = {0u, 0u};
+		bool overflow = false;
+#pragma unroll 1
+		for (int sec = 0; sec < 2 && !overflow; ++sec) {
+			// section 0: slots 0 upward, section 1: slots neibboundpos downward; each ends at its terminator
+			const int maxSlots = sec ? (int)p.neibboundpos + 1 : (int)p.neiblistsize;
+			bool alive = mine;
+			uint32_t code = 0, rows = 0;
+#pragma unroll 1
+			for (int s0 = 0; s0 < maxSlots && wave_any(alive); s0 += TILE_LIST_BATCH) {
+				if (rowsSec[0] + rows + TILE_LIST_BATCH > listRows) { overflow = true; break; }
+				uint32_t e[TILE_LIST_BATCH];
+#pragma unroll
+				for (int k = 0; k < TILE_LIST_BATCH; ++k) {
+					const int slot = min(s0 + k, maxSlots - 1);   // a clamped re-read is only reached by dead lanes or dropped below
+					const int src = sec ? (int)p.neibboundpos - slot : slot;
+					e[k] = list[(size_t)src*stride + index];
+				}
+				if (!wave_any(alive && e[0] != NEIBS_END)) break;   // every list of the wave ended exactly at the previous batch
+#pragma unroll
+				for (int k = 0; k < TILE_LIST_BATCH; ++k) {
+					const uint32_t dd = e[k];
+					alive = alive && (s0 + k < maxSlots) && (dd != NEIBS_END);
+					code = (dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
+					const uint32_t slotOff = (1u + (uint32_t)myCB[code & 31u] + (dd & NEIBINDEX_MASK))*16u;   // slot 0 = dummy
+					const uint32_t out = alive ? (slotOff | (code << 20)) : dummy;   // code*16 in the high half
+					const uint32_t row = sec ? listRows - 1u - (rows + k) : rows + k;
+					if (mine) tileList[(size_t)row*listStride + index] = out;
+				}
+				rows += TILE_LIST_BATCH;
+			}
+			rowsSec[sec] = rows;
+		}
+		if (overflow) tileCtl[1] = 1u;      // some wave needs more rows than the tile lists have: generic kernel
+		if ((tid & 63u) == 0u) tileWaves[(size_t)tile*(TILE_THREADS/64) + (tid >> 6)] = rowsSec[0] | (rowsSec[1] << 16);
+	}
+}
+
+int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, hipStream_t st)
+{
+	if (!ctx->tile_list || !ctx->tile_waves) { ctx->tiles_built = false; return SPHX_OK; }
+	const uint32_t grid = ctx->tile_grid*8u < ctx->tile_capacity ? ctx->tile_grid*8u : ctx->tile_capacity;
+	tile_lists_kernel<<<grid, TILE_THREADS, 0, st>>>(ctx->dev, neibsList, hash, cellStart, ctx->cell_end_copy,
+		ctx->tiles, ctx->tile_ctl, ctx->tile_list, ctx->tile_list_stride, ctx->tile_list_rows, ctx->tile_waves);
+	SPHX_LAUNCH_CHECK("tile_lists_kernel");
+	return SPHX_OK;
+}
+
 extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
@@ -1548,6 +1667,9 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.tau0 = (const float2*)tau0; a.tau1 = (const float2*)tau1; a.tau2 = (const float2*)tau2;
 	a.rb = ctx->rb_dev;
 	a.aux = ctx->eos_aux;
+	a.tileList = ctx->tile_list; a.tileListRows = ctx->tile_list_rows; a.tileListStride = ctx->tile_list_stride;
+	a.tileWaves = ctx->tile_waves;
+	a.xsph = (float4*)xsph;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
 	a.numBlocks = numBlocks;
 	a.compute_object_forces = compute_object_forces;
@@ -1563,10 +1685,8 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		((ctx->dev.numfluids == 1 && ctx->dev.densitydiff != SPHX_FERRARI) || ctx->dev.kerneltype == SPHX_WENDLAND) &&
-		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles &&
-		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
-		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
-		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
+		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles && ctx->tile_list != nullptr &&
+		(uint64_t)ctx->tile_list_stride*sizeof(uint32_t)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
 	a.tauPack = nullptr; a.tauPackN = 0;
 	a.otau0 = a.otau1 = a.otau2 = nullptr; a.oturbvisc = nullptr;
 	if (use_tiles && ctx->dev.turbmodel == SPHX_SPS) {   // window rows of the stress tensor (see tau_pack_kernel)
@@ -1676,16 +1796,16 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	// single fluid with the tiling of this neighbour list at hand: the stress mode of the tiled kernel (neighbour rows from
 	// the LDS window instead of gathers), then the gather kernel as a stand-by guarded by the tiling's overflow flag
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
-		ctx->dev.numfluids == 1 && !ctx->disable_tiles &&
-		ctx->dev.neiblistsize % TILE_NB == 0 && (ctx->dev.neibboundpos + 1) % TILE_NB == 0 &&
-		ctx->dev.neiblistsize >= TILE_NB*TILE_AHEAD && ctx->dev.neibboundpos + 1 >= TILE_NB*TILE_AHEAD &&
-		(uint64_t)ctx->dev.stride*sizeof(neibdata)*(TILE_NB - 1) < 0x80000000ull;
+		ctx->dev.numfluids == 1 && !ctx->disable_tiles && ctx->tile_list != nullptr &&
+		(uint64_t)ctx->tile_list_stride*sizeof(uint32_t)*(TILE_NB - 1) < 0x80000000ull;
 	const uint32_t *guard = nullptr;
 	if (use_tiles) {
 		ForcesArgs fa = ForcesArgs();
 		fa.pos = a.pos; fa.vel = a.vel; fa.info = a.info; fa.hash = hash; fa.cellStart = cellStart; fa.neibsList = neibsList;
 		fa.otau0 = a.tau0; fa.otau1 = a.tau1; fa.otau2 = a.tau2; fa.oturbvisc = spsturbvisc;
 		fa.fromParticle = 0; fa.toParticle = particleRangeEnd;
+		fa.tileList = ctx->tile_list; fa.tileListRows = ctx->tile_list_rows; fa.tileListStride = ctx->tile_list_stride;
+		fa.tileWaves = ctx->tile_waves;
 		fa.dbg = ctx->tile_debug & 4;
 		switch (ctx->dev.kerneltype) {
 		case SPHX_CUBICSPLINE: sphx_part_stress_k1(ctx, (hipStream_t)stream, fa); break;

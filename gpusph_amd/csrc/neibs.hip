@@ -905,6 +905,10 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
 		particleRangeEnd, sqinfluenceradius, ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
+	if (ctx->tiles_built) {   // the lists of the tiled particles in the form the tiled forces kernel walks (forces.hip)
+		rc = sphx_tile_lists_launch(ctx, neibsList, hash, cellStart, st);
+		if (rc != SPHX_OK) return rc;
+	}
 	return SPHX_OK;
 }
 

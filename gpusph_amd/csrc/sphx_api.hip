@@ -48,12 +48,14 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
-		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tau_pack, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols };
+		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tau_pack, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols,
+		ctx->tile_list, ctx->tile_waves };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
 	ctx->eos_aux = nullptr; ctx->tau_pack = nullptr;
+	ctx->tile_list = nullptr; ctx->tile_waves = nullptr; ctx->tile_list_rows = ctx->tile_list_stride = 0;
 	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr; ctx->cell_fluid_end = nullptr; ctx->tile_cols = nullptr;
 	ctx->tile_capacity = 0; ctx->cells_reserved = 0; ctx->tiles_built = false;
 	ctx->reserved_particles = ctx->reserved_bins = 0;
@@ -102,6 +104,12 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 		SPHX_HIP(hipMalloc((void**)&ctx->tau_pack, sizeof(float4)*2*(size_t)n));
 	ctx->tile_capacity = n/8 + 4096;
 	SPHX_HIP(hipMalloc((void**)&ctx->tiles, sizeof(uint32_t)*TILE_DESC*(size_t)ctx->tile_capacity));
+	if (!ctx->disable_tiles) {   // tile lists: 4 B x (neiblistsize + extra) rows per particle; only the rows in use are ever touched
+		ctx->tile_list_rows = (ctx->dev.neiblistsize + TILE_LIST_EXTRA)/TILE_LIST_BATCH*TILE_LIST_BATCH;
+		ctx->tile_list_stride = n;
+		SPHX_HIP(hipMalloc((void**)&ctx->tile_list, sizeof(uint32_t)*(size_t)ctx->tile_list_rows*(size_t)n));
+		SPHX_HIP(hipMalloc((void**)&ctx->tile_waves, sizeof(uint32_t)*(TILE_THREADS/64)*(size_t)ctx->tile_capacity));
+	}
 	ctx->cells_reserved = (bins - 1)/4;
 	SPHX_HIP(hipMalloc((void**)&ctx->cell_end_copy, sizeof(uint32_t)*(size_t)ctx->cells_reserved));
 	SPHX_HIP(hipMalloc((void**)&ctx->cell_fluid_end, sizeof(uint32_t)*(size_t)ctx->cells_reserved));

@@ -46,6 +46,8 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #define TILE_DESC     16                   // uint32 per tile: g2, g3, firstCell, numCells, first[4], count[4], window, flags, 0, 0
 #define TILE_NB       4                    // neighbours per batch in the tiled pair loop
 #define TILE_AHEAD    4                    // list batches kept in flight per section (register ring)
+#define TILE_LIST_EXTRA 64                 // rows of the tile lists beyond neiblistsize (both sections are padded per wave)
+#define TILE_LIST_BATCH 4                  // rows the tile-list builder handles per step (section lengths are multiples of it)
 
 // ---- per-kernel constants, passed BY VALUE as a kernel argument (kernarg/SGPR resident;
 //      replaces the reference's ~70 __constant__ symbols, so there is no per-device global
@@ -131,6 +133,12 @@ struct sphx_ctx {
 	uint32_t   *tile_ctl;      // [0] = number of tiles, [1] = overflow flag (generic kernel takes over), [2] finished groups, [4..11] tile tickets
 	uint32_t   *cell_end_copy; // [cells] cellEnd of the build the tiles belong to
 	uint32_t   *cell_fluid_end;// [cells] first non-fluid particle of each cell (neighbour-list build)
+	// tile lists (forces.hip "Tile lists"): the neighbour lists of the tiled particles translated, at build time, into the
+	// LDS byte offset of each neighbour's window row + the offset of its shift-table entry; [rows][stride] uint32,
+	// fluid section in rows 0 upward, boundary section in rows tile_list_rows-1 downward, both padded per wave
+	uint32_t   *tile_list;
+	uint32_t    tile_list_rows, tile_list_stride;
+	uint32_t   *tile_waves;    // [tile][TILE_THREADS/64]: rows of the fluid section | rows of the boundary section << 16
 	uint32_t    tile_capacity;
 	uint32_t    cells_reserved;
 	bool        tiles_built;
@@ -156,6 +164,7 @@ static inline uint32_t round_up_u(uint32_t a, uint32_t b) { return div_up_u(a, b
 
 int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles);
 // repacking forces (filters.hip), reached through sphx_forces_basicstep(run_mode = SPHX_REPACK)
+int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, hipStream_t st);
 int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
