@@ -26,6 +26,7 @@ import numpy as np  # noqa: E402
 
 DEFAULT_PARTICLES = 32_000_000     # BASELINE.json configs[3]: DamBreak3D 32M (fits one MI355X)
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: 8 TB/s spec
+FP32_PEAK_TFLOPS = 157.3           # MI355X_MICROARCH.md: fp32 vector (packed) peak
 
 
 def usable_cpus():
@@ -78,12 +79,17 @@ def pmc_traffic(n_total, kernel):
     live here; the number is only reported when the profiled workload is the one being run."""
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "scripts"))
+    from make_traffic_json import kernel_source_sha
+    sha = kernel_source_sha()
     for path in sorted(glob.glob(os.path.join(here, "profiles", "*pmc_traffic*.json")), reverse=True):
         try:
             d = json.load(open(path))
         except (OSError, ValueError):
             continue
         if int(d.get("particles", -1)) != int(n_total):
+            continue
+        if d.get("kernel_source_sha") != sha:      # a profile of another build says nothing about this one
             continue
         for name, k in d.get("kernels", {}).items():
             if name.startswith(kernel + "<") or name == kernel:
@@ -204,7 +210,13 @@ def main():
                        "mean_neibs": round(nbar, 2)},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "launch_ms": round(avg_ms, 4), "bytes_per_launch": int(bytes_per_launch)},
+                         "launch_ms": round(avg_ms, 4), "bytes_per_launch": int(bytes_per_launch),
+                         # what actually binds the pair loop: fp32 vector issue.  ~60 flop per stored pair
+                         # against the packed-fp32 peak of the chip
+                         "valu": {"bound": "valu", "achieved": round(interactions * 60.0 / (avg_ms * 1e-3) / 1e12, 2),
+                                  "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(interactions * 60.0 / (avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
+                                  "flop_per_pair": 60}},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

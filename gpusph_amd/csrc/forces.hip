@@ -699,6 +699,64 @@ __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 	}
 }
 
+// Two pairs at once on packed fp32 (v_pk_mul/add/fma_f32: two results per instruction at the issue cost of one).
+// Same operations in the same order as pair_interact for each of the two pairs -- every packed lane is an IEEE
+// mul/add/fma -- so the results are the bits pair_interact gives.  What is packed: everything computed from computed
+// values (r^2, v.r, F, g.r, the viscous and diffusive coefficients).  What is not: the first consumer of every value
+// read from LDS (the two rows sit in unrelated registers; pairing them up would cost the moves the packing saves),
+// sqrt / rcp / min / compares / selects (no packed forms), and the accumulation into force (list order is kept).
+// Instantiated for the Wendland kernel with artificial viscosity, one fluid, no or Colagrossi diffusion.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_splat(float a) { return v2f{a, a}; }
+
+template<int COLAGROSSI>
+__device__ __forceinline__ void pair_interact_pk(const DevParams &p, const Self &s, float inv_h, const Gathered &g,
+	bool valid, bool rt_momentum, bool rt_diffuse, float4 &force)
+{
+	static_assert(TILE_HB == 2, "two pairs per packed operation");
+	const float4 &n0 = g.npos[0], &n1 = g.npos[1];
+	const v2f rx = {g.qx[0] - n0.x, g.qx[1] - n1.x}, ry = {g.qy[0] - n0.y, g.qy[1] - n1.y}, rz = {g.qz[0] - n0.z, g.qz[1] - n1.z};
+	const v2f r2 = pk_fma(rz, rz, pk_fma(ry, ry, rx*rx));
+	const v2f r = {fast_sqrt(r2.x), fast_sqrt(r2.y)};
+	const bool on0 = valid && (r.x < g.qw[0]), on1 = valid && (r.y < g.qw[1]);
+	const float4 &w0 = g.nvel[0], &w1 = g.nvel[1];
+	const v2f vx = {s.vel.x - w0.x, s.vel.x - w1.x}, vy = {s.vel.y - w0.y, s.vel.y - w1.y}, vz = {s.vel.z - w0.z, s.vel.z - w1.z};
+	const v2f vel_dot_pos = pk_fma(vz, rz, pk_fma(vy, ry, vx*rx));
+	const v2f qm2 = pk_fma(r, pk_splat(inv_h), pk_splat(-2.0f));
+	const v2f f = qm2*qm2*qm2*pk_splat(p.fcoeff);
+	const float4 &a0 = g.naux[0], &a1 = g.naux[1];   // {P/rho^2, c, P, rho}
+	const float m0 = n0.w*f.x, m1 = n1.w*f.y;
+	const v2f mf = {on0 ? m0 : 0.0f, on1 ? m1 : 0.0f};
+
+	v2f dsel = {0.0f, 0.0f};
+	if (COLAGROSSI == DIFF_COLAGROSSI) {
+		const v2f gdotr = pk_fma(pk_splat(p.gravity[2]), rz, pk_fma(pk_splat(p.gravity[1]), ry, pk_splat(p.gravity[0])*rx));
+		const v2f gr = gdotr*pk_splat(s.rho);
+		const bool d0 = rt_diffuse && !(fabsf(s.P - a0.z) < fabsf(gr.x)), d1 = rt_diffuse && !(fabsf(s.P - a1.z) < fabsf(gr.y));
+		const v2f ratio = {fmaf(a0.w, s.inv_rho, -1.0f), fmaf(a1.w, s.inv_rho, -1.0f)};
+		const v2f dterm = pk_splat(p.densityDiffCoeff*p.sscoeff[s.fl])*ratio*mf;
+		dsel = v2f{d0 ? dterm.x : 0.0f, d1 ? dterm.y : 0.0f};
+	}
+	const v2f drdt = pk_fma(mf, vel_dot_pos, -dsel);
+	force.w += drdt.x;
+	force.w += drdt.y;
+
+	// compute_pressure_contrib + artvisc, as in pair_interact
+	const v2f pgrad = {s.p_precalc + a0.x, s.p_precalc + a1.x};
+	v2f kk = -pgrad*mf;
+	const v2f vdpn = {fminf(fminf(vel_dot_pos.x, 0.0f), fabsf(w0.w)), fminf(fminf(vel_dot_pos.y, 0.0f), fabsf(w1.w))};
+	const v2f ssum = {s.sspeed + a0.y, s.sspeed + a1.y};
+	const v2f rsum = {s.rho + a0.w, s.rho + a1.w};
+	const v2f den = (r2 + pk_splat(p.epsartvisc))*rsum;
+	const v2f iden = {fast_rcp(den.x), fast_rcp(den.y)};
+	const v2f visc = vdpn*pk_splat(p.slength*p.artvisccoeff)*ssum*iden;
+	kk = pk_fma(visc, mf, kk);
+	const float k0 = rt_momentum ? kk.x : 0.0f, k1 = rt_momentum ? kk.y : 0.0f;
+	force.x = fmaf(k0, rx.x, force.x); force.y = fmaf(k0, ry.x, force.y); force.z = fmaf(k0, rz.x, force.z);
+	force.x = fmaf(k1, rx.y, force.x); force.y = fmaf(k1, ry.y, force.y); force.z = fmaf(k1, rz.y, force.z);
+}
+
 // stage 2: the pair interactions of a gathered half, in list order
 // LJ = the run uses LJ_BOUNDARY: pairs of the boundary section (ljsec, wave-uniform) and all pairs of boundary
 // particles with force feedback (ljlane) are Lennard-Jones repulsions instead of SPH interactions
@@ -716,6 +774,10 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 #pragma unroll
 		for (int k = 0; k < TILE_HB; ++k)
 			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], take, force);
+		return;
+	}
+	if (KERNEL == SPHX_WENDLAND && TURB == SPHX_ARTIFICIAL && COLAGROSSI != DIFF_FERRARI && !LJ) {
+		pair_interact_pk<COLAGROSSI>(p, s, inv_h, g, take, momentum, diffuse, force);
 		return;
 	}
 	const bool anyLj = LJ && wave_any(ljlane);
