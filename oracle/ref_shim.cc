@@ -8,6 +8,11 @@
 //   src/common_types.h        ENCODE_CELL / DECODE_CELL / NEIBINDEX_MASK / NEIBS_END
 //   src/cuda/visc_avg.cu      visc_avg<FullViscSpec<...>> for every computational viscosity / averaging / constness
 //   src/physparams.h, src/simparams.h   host parameter structs: defaults, EOS / viscosity setters, smoothing + influence radii
+//   src/vector_math.h         float4 / float (= multiply by the reciprocal), dot3, length: operation order of the filters
+//   src/utils.h               div_up / round_up: the arithmetic of getFmaxElements / round_particles (src/cuda/forces.cu:539-552,960-964)
+//   src/predcorr_alloc_policy.{h,cc}   which buffers the predictor-corrector scheme double-buffers
+//   src/timing.h              IPPSCounter: the definition of the reported metric (iterations x particles per second)
+// (src/cuda/phys_core.cu does not link: its non-inline R() drags in the nvcc intrinsic __powf, which has no host definition.)
 // Everything else on the hot path needs nvcc (__powf, texture references, thrust) or the
 // Makefile-generated options/*.opt files and is therefore NOT built (DESIGN.md "Oracle").
 // TEST INFRASTRUCTURE ONLY: used to pin oracle/sph_oracle.c and to generate tests/golden/ref_*.npz.
@@ -19,6 +24,12 @@
 #include "visc_avg.cu"       // visc_avg<ViscSpec> in all its specialisations (+ average.h, visc_spec.h)
 #include "physparams.h"      // PhysParams: defaults, add_fluid, set_equation_of_state, set_kinematic_visc / set_dynamic_visc
 #include "simparams.h"       // SimParams: defaults, set_smoothing / set_kernel_radius / set_influenceradius
+#include "vector_math.h"
+#include "utils.h"
+#include "predcorr_alloc_policy.cc"
+#include "timing.h"
+#include <thread>
+#include <chrono>
 
 // visc_avg of the reference for a Newtonian laminar MORRIS spec: compvisc 0/1 (KINEMATIC/DYNAMIC), avgop 0/1/2, is_const 0/1
 template<ComputationalViscosityType cv, AverageOperator av, bool cst>
@@ -184,5 +195,41 @@ void ref_simparams(int gaussian, double sfactor, double deltap, double *out)
 	out[4] = sp.repack_maxiter; out[5] = sp.repack_a; out[6] = sp.repack_alpha; out[7] = sp.nlexpansionfactor;
 	sp.set_smoothing(sfactor, deltap);
 	out[8] = sp.slength; out[9] = sp.influenceRadius; out[10] = sp.nlInfluenceRadius; out[11] = sp.nlSqInfluenceRadius;
+}
+
+// out[4] = (x,y,z,w)/s with the reference's operator/ ; returns dot3 of the inputs' xyz; out[4] = length of xyz
+float ref_float4_div(float x, float y, float z, float w, float s, float *out)
+{
+	const float4 v = make_float4(x, y, z, w);
+	const float4 q = v/s;
+	out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+	out[4] = length(make_float3(x, y, z));
+	return dot3(v, v);
+}
+unsigned ref_div_up(unsigned a, unsigned b) { return div_up(a, b); }
+unsigned ref_round_up(unsigned a, unsigned b) { return round_up(a, b); }
+// number of copies the predictor-corrector allocation policy keeps of a buffer (flag_t key)
+unsigned ref_predcorr_buffer_count(unsigned long long key) { PredCorrAllocPolicy p; return (unsigned)p.get_buffer_count((flag_t)key); }
+unsigned long long ref_predcorr_multi_buffered(unsigned long long keys) { PredCorrAllocPolicy p; return p.get_multi_buffered((flag_t)keys); }
+// buffer keys by name index: 0 POS 1 VEL 2 INFO 3 HASH 4 PARTINDEX 5 CELLSTART 6 CELLEND 7 NEIBSLIST 8 FORCES 9 TAU 10 CFL 11 XSPH
+// 12 RB_FORCES 13 SPS_TURBVISC 14 VORTICITY 15 NORMALS 16 COMPACT_DEV_MAP 17 CFL_TEMP 18 RB_TORQUES 19 RB_KEYS
+unsigned long long ref_buffer_key(int which)
+{
+	static const flag_t keys[] = { BUFFER_POS, BUFFER_VEL, BUFFER_INFO, BUFFER_HASH, BUFFER_PARTINDEX, BUFFER_CELLSTART, BUFFER_CELLEND,
+		BUFFER_NEIBSLIST, BUFFER_FORCES, BUFFER_TAU, BUFFER_CFL, BUFFER_XSPH, BUFFER_RB_FORCES, BUFFER_SPS_TURBVISC, BUFFER_VORTICITY,
+		BUFFER_NORMALS, BUFFER_COMPACT_DEV_MAP, BUFFER_CFL_TEMP, BUFFER_RB_TORQUES, BUFFER_RB_KEYS };
+	return (which >= 0 && which < (int)(sizeof(keys)/sizeof(keys[0]))) ? keys[which] : 0;
+}
+// the metric: `increments` calls of incItersTimesParts(particles) spread over ~millis ms; out = {MIPPS, elapsed seconds}
+void ref_ipps(unsigned long particles, int increments, int millis, double *out)
+{
+	IPPSCounter c;
+	c.start();
+	for (int i = 0; i < increments; ++i) {
+		std::this_thread::sleep_for(std::chrono::microseconds(1000L*millis/increments));
+		c.incItersTimesParts(particles);
+	}
+	out[0] = c.getMIPPS();
+	out[1] = c.getElapsedSeconds();
 }
 } // extern "C"

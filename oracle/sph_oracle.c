@@ -197,6 +197,12 @@ static inline float physical_density(const orc_params *p, float rho_tilde, int i
 {
 	return (rho_tilde + 1.0f)*p->rho0[i];
 }
+/* exported for the pin against src/vector_math.h:1093-1097 (tests/test_oracle_pinned.py) */
+void orc_f4_div(const float v[4], float s, float out[4])
+{
+	const float inv = 1.0f/s;     /* float4 / float, as every use in this file spells it out */
+	out[0] = v[0]*inv; out[1] = v[1]*inv; out[2] = v[2]*inv; out[3] = v[3]*inv;
+}
 
 /* ---- cell grid: src/cuda/cellgrid.cuh:98-127 ------------------------------------- */
 uint32_t orc_calc_grid_hash(const orc_params *p, int gx, int gy, int gz)

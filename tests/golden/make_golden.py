@@ -238,7 +238,29 @@ def features2():
     np.savez_compressed(os.path.join(HERE, "oracle_features2.npz"), **out)
 
 
+def refmisc():
+    """ref_misc.npz: small arithmetic and policy facts of the reference's own code (oracle/_ref): float4/float of src/vector_math.h, div_up/round_up of src/utils.h, the predictor-corrector
+    buffer allocation policy, buffer keys"""
+    import ctypes as C
+    ref = ol.ref()
+    rng = np.random.default_rng(31)
+    v = rng.normal(0, 3, size=(200, 4)).astype(np.float32)
+    sdiv = rng.uniform(0.01, 7, 200).astype(np.float32)
+    q = np.zeros((200, 5), dtype=np.float32); d3 = np.zeros(200, dtype=np.float32)
+    for i in range(200):
+        buf = (C.c_float * 5)()
+        d3[i] = ref.ref_float4_div(*[float(x) for x in v[i]], float(sdiv[i]), buf)
+        q[i] = list(buf)
+    ab = np.array([(a, b) for a in (0, 1, 127, 128, 129, 511, 512, 513, 100000, 31844148) for b in (4, 128, 256)], dtype=np.uint32)
+    du = np.array([ref.ref_div_up(int(a), int(b)) for a, b in ab], dtype=np.uint32)
+    ru = np.array([ref.ref_round_up(int(a), int(b)) for a, b in ab], dtype=np.uint32)
+    keys = np.array([ref.ref_buffer_key(k) for k in range(20)], dtype=np.uint64)
+    counts = np.array([ref.ref_predcorr_buffer_count(int(k)) for k in keys], dtype=np.uint32)
+    np.savez_compressed(os.path.join(HERE, "ref_misc.npz"), v=v, s=sdiv, v_over_s=q[:, :4], length3=q[:, 4], dot3=d3, ab=ab, div_up=du, round_up=ru,
+                        buffer_keys=keys, predcorr_buffer_count=counts)
+
+
 if __name__ == "__main__":
-    kernels(); datamodel(); viscavg(); hostparams(); pipeline(); features(); features2()
+    kernels(); datamodel(); viscavg(); hostparams(); refmisc(); pipeline(); features(); features2()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

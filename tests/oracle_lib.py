@@ -68,6 +68,7 @@ def lib():
         _lib.orc_dtreduce.restype = C.c_float
         _lib.orc_dtreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float]
         _lib.orc_fmax_elements.restype = C.c_uint32; _lib.orc_fmax_elements.argtypes = [C.c_uint32]
+        _lib.orc_f4_div.restype = None; _lib.orc_f4_div.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
         _lib.orc_fmax_temp_elements.restype = C.c_uint32; _lib.orc_fmax_temp_elements.argtypes = [C.c_uint32]
         _lib.orc_round_particles.restype = C.c_uint32; _lib.orc_round_particles.argtypes = [C.c_uint32]
         _lib.orc_calc_grid_hash.restype = C.c_uint32
@@ -102,6 +103,13 @@ def ref():
         _ref.ref_visc_avg.restype = C.c_float; _ref.ref_visc_avg.argtypes = [C.c_int] * 3 + [C.c_float] * 5
         _ref.ref_physparams.restype = None; _ref.ref_physparams.argtypes = [C.c_float] * 5 + [C.c_void_p]
         _ref.ref_simparams.restype = None; _ref.ref_simparams.argtypes = [C.c_int, C.c_double, C.c_double, C.c_void_p]
+        _ref.ref_float4_div.restype = C.c_float; _ref.ref_float4_div.argtypes = [C.c_float] * 5 + [C.c_void_p]
+        _ref.ref_div_up.restype = C.c_uint32; _ref.ref_div_up.argtypes = [C.c_uint32, C.c_uint32]
+        _ref.ref_round_up.restype = C.c_uint32; _ref.ref_round_up.argtypes = [C.c_uint32, C.c_uint32]
+        _ref.ref_predcorr_buffer_count.restype = C.c_uint32; _ref.ref_predcorr_buffer_count.argtypes = [C.c_uint64]
+        _ref.ref_predcorr_multi_buffered.restype = C.c_uint64; _ref.ref_predcorr_multi_buffered.argtypes = [C.c_uint64]
+        _ref.ref_buffer_key.restype = C.c_uint64; _ref.ref_buffer_key.argtypes = [C.c_int]
+        _ref.ref_ipps.restype = None; _ref.ref_ipps.argtypes = [C.c_ulong, C.c_int, C.c_int, C.c_void_p]
         _ref.ref_visc_avg_singlefluid_nonconst_kinematic.restype = C.c_float
         _ref.ref_visc_avg_singlefluid_nonconst_kinematic.argtypes = [C.c_int] + [C.c_float] * 5
     return _ref

@@ -229,3 +229,51 @@ def test_host_parameter_mirrors_match_reference_golden():
         assert np.array_equal(np.array(defaults, dtype=np.float32), out[:8].astype(np.float32)), (defaults, out[:8])
         sp.set_smoothing(float(c[1]), float(c[2]))
         assert [sp.slength, sp.influenceRadius, sp.nlInfluenceRadius, sp.nlSqInfluenceRadius] == list(out[8:12])
+
+
+def test_small_arithmetic_and_policies_match_reference_golden():
+    """tests/golden/ref_misc.npz was produced by the reference's own src/vector_math.h, src/utils.h and
+    src/predcorr_alloc_policy.cc (compiled into oracle/_ref):
+     * float4/float multiplies by the reciprocal (the operation order of the filters and of MLS), dot3, length
+     * div_up / round_up, i.e. the arithmetic of getFmaxElements / round_particles (src/cuda/forces.cu:539-552,960-964)
+     * the predictor-corrector scheme keeps two copies of POS and VEL and one of everything else the drivers allocate"""
+    import ctypes as C
+    g = np.load(os.path.join(GOLD, "ref_misc.npz"))
+    L = ol.lib()
+    for v, s, want in zip(g["v"], g["s"], g["v_over_s"]):
+        out = (C.c_float * 4)()
+        L.orc_f4_div(np.ascontiguousarray(v).ctypes.data, float(s), out)
+        assert np.array_equal(np.array(list(out), dtype=np.float32).view(np.uint32), want.view(np.uint32))
+        assert np.array_equal((v * (np.float32(1.0) / s)).view(np.uint32), want.view(np.uint32))
+    d3 = (g["v"][:, 0] * g["v"][:, 0] + g["v"][:, 1] * g["v"][:, 1]) + g["v"][:, 2] * g["v"][:, 2]
+    assert np.allclose(d3, g["dot3"], rtol=2e-7)
+    from gpusph_amd import capi
+    lib = capi.load()
+    for (a, b), du, ru in zip(g["ab"], g["div_up"], g["round_up"]):
+        assert du == (int(a) + int(b) - 1) // int(b) and ru == du * int(b)
+    for n in (0, 1, 127, 128, 129, 100000, 31844148):
+        k = list(map(tuple, g["ab"])).index((n, 128)) if (n, 128) in set(map(tuple, g["ab"])) else None
+        if k is not None:     # getFmaxElements = round_up(div_up(n, 128), 4)
+            want = (int(g["div_up"][k]) + 3) // 4 * 4
+            assert lib.sphx_forces_fmax_elements(n) == want == L.orc_fmax_elements(n)
+    keys = {name: int(k) for name, k in zip(
+        ["POS", "VEL", "INFO", "HASH", "PARTINDEX", "CELLSTART", "CELLEND", "NEIBSLIST", "FORCES", "TAU", "CFL", "XSPH",
+         "RB_FORCES", "SPS_TURBVISC", "VORTICITY", "NORMALS", "COMPACT_DEV_MAP", "CFL_TEMP", "RB_TORQUES", "RB_KEYS"], g["buffer_keys"])}
+    counts = dict(zip(keys, (int(c) for c in g["predcorr_buffer_count"])))
+    assert counts["POS"] == 2 and counts["VEL"] == 2
+    assert all(c == 1 for name, c in counts.items() if name not in ("POS", "VEL"))
+    assert len(set(keys.values())) == len(keys) and all(k and (k & (k - 1)) == 0 for k in keys.values())   # distinct single bits
+
+
+def test_metric_definition_of_the_reference():
+    """IPPSCounter (src/timing.h:103-164, compiled into oracle/_ref) is the metric bench.py reports: the sum over the timed
+    iterations of the particle count, divided by the wall time; MIPPS = that / 1e6"""
+    import ctypes as C
+    ref = ol.ref()
+    if ref is None:
+        pytest.skip("oracle/_ref not built")
+    out = (C.c_double * 2)()
+    ref.ref_ipps(1_000_000, 20, 200, out)
+    mipps, elapsed = out[0], out[1]
+    assert 0.19 < elapsed < 1.0
+    assert abs(mipps * elapsed - 20.0) < 0.02 * 20.0        # 20 iterations x 1e6 particles / elapsed / 1e6
