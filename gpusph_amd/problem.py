@@ -481,6 +481,87 @@ class PeriodicBox(Problem):
         self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)
 
 
+class Poiseuille(Problem):
+    """Mirror of src/problems/Poiseuille.inc (the problem behind the reference's own analytic validator,
+    scripts/validate-poiseuille.py): a unit cube of fluid between two DYN_BOUNDARY walls at z = +-lz/2, periodic in x and
+    y, driven by a body force along x; Newtonian rheology, laminar flow, MORRIS, computational viscosity and averaging
+    operator selectable as the validator does (--compvisc kin|dyn, --viscavg arithmetic|harmonic|geometric), Wendland
+    kernel, no density diffusion by default, c0 = 20 max(sqrt(2 F lz), u_max).  Geometry as the problem places it
+    (Poiseuille.inc:115-131): wall planes of (influence layers + 1) particle layers starting at z = +-lz/2 and growing
+    outward, fluid lattice from -lz/2 + dp to lz/2 - dp, ppH particles per height.  The steady state is
+    u(z) = F/(2 nu) (lz^2/4 - z^2) (compute_poiseuille_vel)."""
+
+    def __init__(self, ppH=16, *, compvisc=D.KINEMATIC, viscavg=D.HARMONIC, rho=1.0, kinvisc=0.1, driving_force=0.05,
+                 density_diffusion=D.DENSITY_DIFFUSION_NONE, steady_init=False, linearization=D.DEFAULT_LINEARIZATION):
+        super().__init__()
+        self.m_name = "Poiseuille"
+        self.lz = self.ly = self.lx = 1.0
+        self.rho, self.kinvisc, self.driving_force = float(rho), float(kinvisc), float(driving_force)
+        sp, pp = self.simparams, self.physparams
+        sp.kerneltype = D.WENDLAND
+        sp.boundarytype = D.DYN_BOUNDARY
+        self.set_viscosity(dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=compvisc, viscmodel=D.MORRIS,
+                                avgop=viscavg))
+        sp.densitydiffusiontype = density_diffusion
+        sp.periodicbound = D.PERIODIC_X | D.PERIODIC_Y
+        sp.simflags = D.ENABLE_DTADAPT
+        self.linearization = linearization
+        self.set_deltap(self.lz / ppH)
+        dp = self.m_deltap
+        pp.gravity = (self.driving_force, 0.0, 0.0)
+        pp.add_fluid(self.rho)
+        pp.set_kinematic_visc(0, self.kinvisc)
+        self.max_vel = self.compute_poiseuille_vel(0.0)
+        hydrostatic_vel = math.sqrt(2.0 * self.driving_force * self.lz)
+        pp.set_equation_of_state(0, 7.0, 20.0 * max(hydrostatic_vel, self.max_vel))
+        self.dyn_layers = int(math.ceil(sp.sfactor * sp.kernelradius)) + 1      # suggestedDynamicBoundaryLayers
+        # world box (ProblemAPI<1>::initialize, ProblemAPI_1.cc:255-300): bounding box of the geometries + dp/2, + the
+        # extra boundary layers in the non-periodic direction
+        half = np.array([(self.lx - dp) / 2, (self.ly - dp) / 2, self.lz / 2])
+        gmin = -half - dp / 2
+        gmax = half + dp / 2
+        gmin[2] -= (self.dyn_layers - 1) * dp
+        gmax[2] += (self.dyn_layers - 1) * dp
+        self.m_origin = gmin
+        self.m_size = gmax - gmin
+        self.m_maxFall = float(self.lz + (self.dyn_layers - 1) * dp + dp / 2)   # water level - lowest point (autocomputed)
+        self.initialize()
+        # particles: lattice centred on the origin in x and y; fluid rows k = 1..ppH-1 at z = -lz/2 + k dp
+        nxy = int(round((self.lx - dp) / dp)) + 1
+        x0 = -(self.lx - dp) / 2
+        ij = _lattice(0, nxy - 1, 0, nxy - 1, 0, 0)[:, :2].astype(np.float64) * dp + x0
+        nz_f = ppH - 1
+        fl = np.concatenate([np.column_stack([ij, np.full(len(ij), -self.lz / 2 + k * dp)]) for k in range(1, nz_f + 1)])
+        lo = np.concatenate([np.column_stack([ij, np.full(len(ij), -self.lz / 2 - k * dp)]) for k in range(self.dyn_layers)])
+        hi = np.concatenate([np.column_stack([ij, np.full(len(ij), self.lz / 2 + k * dp)]) for k in range(self.dyn_layers)])
+        pos3 = np.concatenate([fl, lo, hi])
+        nf, nw = len(fl), len(lo) + len(hi)
+        ntot = nf + nw
+        pos = np.empty((ntot, 4), dtype=np.float64)
+        pos[:, :3] = pos3
+        pos[:, 3] = pp.rho0[0] * dp ** 3
+        vel = np.zeros((ntot, 4), dtype=np.float32)
+        if steady_init:      # --steady-init: fluid starts from the analytic profile (Poiseuille.inc:136-150)
+            vel[:nf, 0] = [self.compute_poiseuille_vel(z) for z in pos3[:nf, 2]]
+        ptype = np.concatenate([np.full(nf, D.PT_FLUID, dtype=np.uint16), np.full(nw, D.PT_BOUNDARY, dtype=np.uint16)])
+        info = make_particleinfo(ptype, np.zeros(ntot, dtype=np.uint16), np.arange(ntot, dtype=np.uint32))
+        self.parts = HostParticles(pos, vel, info)
+        self.num_fluid, self.num_wall, self.num_obstacle = nf, nw, 0
+        self.rb_firstindex = np.zeros(0, dtype=np.int32)
+        self.rb_cg_gridpos = np.zeros((0, 3), dtype=np.int32)
+        self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)
+
+    def compute_poiseuille_vel(self, z):
+        """Poiseuille::compute_poiseuille_vel for the Newtonian fluid (n = 1, no plug): Poiseuille.inc:153-195, in float
+        like the reference; scripts/validate-poiseuille.py:33-38 is the same formula in double"""
+        f32 = np.float32
+        A = f32(f32(self.driving_force) / f32(self.kinvisc))
+        A = f32(f32(1.0) * A) / f32(2.0)
+        B = f32(f32(self.lz) / f32(2.0)); B = f32(B * B)
+        C = f32(z); C = f32(C * C)
+        return float(f32(A * f32(B - C))) if abs(z) <= self.lz / 2 else 0.0
+
+
 class WaveTank(Problem):
     """Mirror of src/problems/WaveTank.cu (BASELINE configs[4]'s option set): a 9 x 0.6 x 1 m flume with a hinged paddle
     (a moving body with prescribed rotation about y), a sloping beach as a geometric plane, Lennard-Jones box particles
