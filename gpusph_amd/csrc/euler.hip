@@ -12,6 +12,7 @@
 struct EulerArgs {
 	float4 *newPos, *newVel;
 	const float4 *oldPos, *oldVel, *forces;
+	const float4 *xsph;      // ENABLE_XSPH: mean neighbourhood velocity from the forces pass, else NULL
 	const particleinfo *info;
 	const uint32_t *hash;
 	const RbParams *rb;
@@ -46,6 +47,12 @@ euler_kernel(DevParams p, EulerArgs a)
 			vcx = fmaf(force.x, hdt, vcx);
 			vcy = fmaf(force.y, hdt, vcy);
 			vcz = fmaf(force.z, hdt, vcz);
+		}
+		if (!REPACK && a.xsph) {   // XSPH correction of the advecting velocity (compute_corrected_velocity :171-180)
+			const float4 xs = a.xsph[index];
+			vcx = fmaf(p.epsxsph, xs.x, vcx);
+			vcy = fmaf(p.epsxsph, xs.y, vcy);
+			vcz = fmaf(p.epsxsph, xs.z, vcz);
 		}
 		if (ptype == PT_FLUID) {
 			pos.x = fmaf(vcx, dt, pos.x);
@@ -89,9 +96,11 @@ extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	float dt, const float *d_dt, float dt_scale, int step, float t,
 	float slength, float influenceradius, int run_mode, void *stream)
 {
-	(void)t; (void)slength; (void)influenceradius; (void)xsph; (void)numParticles;
+	(void)t; (void)slength; (void)influenceradius; (void)numParticles;
 	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_euler_basicstep: constants not set");
 	SPHX_REQUIRE(newPos && newVel && oldPos && oldVel && info && hash && forces, "sphx_euler_basicstep: missing buffer");
+	if ((ctx->dev.simflags & SPHX_ENABLE_XSPH) && run_mode == SPHX_SIMULATE)
+		SPHX_REQUIRE(xsph != nullptr, "sphx_euler_basicstep: ENABLE_XSPH needs the XSPH buffer");
 	if (run_mode != SPHX_SIMULATE && run_mode != SPHX_REPACK)
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_euler_basicstep: invalid run mode");
 	if (step != 1 && step != 2)
@@ -101,6 +110,7 @@ extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	a.newPos = (float4*)newPos; a.newVel = (float4*)newVel;
 	a.oldPos = (const float4*)oldPos; a.oldVel = (const float4*)oldVel; a.forces = (const float4*)forces;
 	a.info = (const particleinfo*)info; a.hash = hash; a.rb = ctx->rb_dev;
+	a.xsph = (ctx->dev.simflags & SPHX_ENABLE_XSPH) ? (const float4*)xsph : nullptr;
 	a.d_dt = d_dt; a.dt = dt; a.dt_scale = dt_scale; a.numParticles = particleRangeEnd;
 	const dim3 grid(div_up_u(particleRangeEnd, BLOCK_EULER));
 	const bool repack = run_mode == SPHX_REPACK;

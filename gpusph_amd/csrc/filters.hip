@@ -335,6 +335,59 @@ vorticity_kernel(DevParams p, FilterArgs a, PostArgs o)
 	out[0] = vx; out[1] = vy; out[2] = vz;
 }
 
+// XSPH mean velocity of the forces pass (ENABLE_XSPH; compute_mean_vel forces_kernel.def:2986-2994, write_xsph :3366-3368):
+// xsph_i = 2 * sum over fluid neighbours j of -m_j W(r_ij) (v_i - v_j) / (rho_i + rho_j), fluid particles only.  The reference
+// accumulates it inside its fluid-fluid forces launch; here it is a pass of its own with this file's exact arithmetic (the
+// option is rare: none of the reference's shipped problems enables it), which keeps the ~10 extra instructions per pair
+// out of the hot kernels.  Same operations as the oracle (fmaf where nvcc contracts): bit-equal.
+template<int KERNEL>
+__global__ void __launch_bounds__(128)
+xsph_kernel(DevParams p, FilterArgs a, float4 *__restrict__ xsph, uint32_t fromParticle)
+{
+	const uint32_t index = fromParticle + blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	const float4 pos = a.pos[index];
+	if (PART_TYPE(info) != PT_FLUID || !is_active_w(pos.w)) return;
+	const float4 vel = a.vel[index];
+	const float rho = (vel.w + 1.0f)*p.rho0[FLUID_NUM(info)];
+	float mx = 0.0f, my = 0.0f, mz = 0.0f;
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+		if (r >= p.influenceradius) return;
+		const float4 nvel = a.vel[j];
+		const float n_rho = (nvel.w + 1.0f)*p.rho0[FLUID_NUM(a.info[j])];
+		const float t = npos.w*kernel_W<KERNEL>(p, r);
+		const float inv = 1.0f/(rho + n_rho);
+		mx = fmaf(-(t*(vel.x - nvel.x)), inv, mx);
+		my = fmaf(-(t*(vel.y - nvel.y)), inv, my);
+		mz = fmaf(-(t*(vel.z - nvel.z)), inv, mz);
+	});
+	xsph[index] = make_float4(2.0f*mx, 2.0f*my, 2.0f*mz, 0.0f);
+}
+
+int sphx_xsph_launch(sphx_ctx *ctx, void *xsph, const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle, hipStream_t st)
+{
+	if (toParticle <= fromParticle) return SPHX_OK;
+	FilterArgs a;
+	a.newVel = nullptr; a.pos = (const float4*)pos; a.vel = (const float4*)vel;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.numParticles = toParticle;
+	const dim3 grid(div_up_u(toParticle - fromParticle, 128));
+	switch (ctx->dev.kerneltype) {
+	case SPHX_CUBICSPLINE: xsph_kernel<SPHX_CUBICSPLINE><<<grid, 128, 0, st>>>(ctx->dev, a, (float4*)xsph, fromParticle); break;
+	case SPHX_QUADRATIC:   xsph_kernel<SPHX_QUADRATIC><<<grid, 128, 0, st>>>(ctx->dev, a, (float4*)xsph, fromParticle); break;
+	case SPHX_WENDLAND:    xsph_kernel<SPHX_WENDLAND><<<grid, 128, 0, st>>>(ctx->dev, a, (float4*)xsph, fromParticle); break;
+	case SPHX_GAUSSIAN:    xsph_kernel<SPHX_GAUSSIAN><<<grid, 128, 0, st>>>(ctx->dev, a, (float4*)xsph, fromParticle); break;
+	default: return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid kernel type");
+	}
+	SPHX_LAUNCH_CHECK("xsph_kernel");
+	return SPHX_OK;
+}
+
 // calcTestpointsVelocityDevice (:138-236), non-SA, no k-epsilon buffers
 template<int KERNEL>
 __global__ void __launch_bounds__(128)

@@ -1768,6 +1768,8 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	}
 	if (rc != SPHX_OK) return rc;
 	SPHX_LAUNCH_CHECK("forces_kernel");
+	if (ctx->dev.simflags & SPHX_ENABLE_XSPH)   // mean neighbourhood velocity of the fluid particles (filters.hip)
+		return sphx_xsph_launch(ctx, xsph, pos, vel, info, hash, cellStart, neibsList, fromParticle, toParticle, (hipStream_t)stream);
 	return SPHX_OK;
 }
 

@@ -198,8 +198,6 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	}
 	if (sp->turbmodel != SPHX_ARTIFICIAL && sp->turbmodel != SPHX_SPS && sp->turbmodel != SPHX_LAMINAR_FLOW)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: turbulence model not built");
-	if (sp->simflags & SPHX_ENABLE_XSPH)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: XSPH is not built");
 
 	ctx->params = *sp;
 	DevParams &d = ctx->dev;

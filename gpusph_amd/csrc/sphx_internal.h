@@ -164,6 +164,8 @@ static inline uint32_t round_up_u(uint32_t a, uint32_t b) { return div_up_u(a, b
 
 int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles);
 // repacking forces (filters.hip), reached through sphx_forces_basicstep(run_mode = SPHX_REPACK)
+int sphx_xsph_launch(sphx_ctx *ctx, void *xsph, const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle, hipStream_t st);
 int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, hipStream_t st);
 int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,

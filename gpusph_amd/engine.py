@@ -116,6 +116,8 @@ class TimestepEngine:
         if getattr(problem, "moving_bodies_callback", None) is not None and self.num_bodies_parts:
             from .bodies import MovingBodies
             self.bodies = MovingBodies(problem, problem.rb_cg_global)
+        # ENABLE_XSPH: BUFFER_XSPH, written by every forces pass for the fluid particles, read by the Euler steps
+        self.xsph = torch.zeros((A, 4), dtype=f32, device=dev) if (sp.simflags & D.ENABLE_XSPH) else None
         self.filters = []            # [(FilterType, frequency)], Problem::addFilter order
         self.profile_forces = None   # list of (start,end) torch events around each forces launch when enabled
 
@@ -224,7 +226,7 @@ class TimestepEngine:
             e0.record()
         capi.check(L.sphx_forces_basicstep(h, p(self.forces), p(self.cfl), p(self.rbforces) if rb else None,
                                            p(self.rbtorques) if rb else None, p(pos), p(vel), p(self.info), p(self.hash),
-                                           p(self.cellStart), p(self.neibslist), tau[0], tau[1], tau[2], p(getattr(self, "xsph", None)),
+                                           p(self.cellStart), p(self.neibslist), tau[0], tau[1], tau[2], p(self.xsph),
                                            n, 0, n, self.params.deltap, self.params.slength, self.params.dtadaptfactor,
                                            self.params.influenceradius, 0, run_mode, step, self.dt,
                                            self.compute_object_forces, C.byref(nb), s))
@@ -240,7 +242,7 @@ class TimestepEngine:
         p = capi.ptr
         n = self.n
         capi.check(L.sphx_euler_basicstep(h, p(self.pos2), p(self.vel2), p(self.pos), p(self.vel), p(self.info),
-                                          p(self.hash), p(self.forces), None, n, n, 0.0, p(self.d_dt), dt_scale,
+                                          p(self.hash), p(self.forces), p(self.xsph), n, n, 0.0, p(self.d_dt), dt_scale,
                                           step, 0.0, self.params.slength, self.params.influenceradius, run_mode, s))
 
     def step(self):

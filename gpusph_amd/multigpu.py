@@ -74,6 +74,8 @@ class SlabPartition:
 class MultiGpuEngine:
     def __init__(self, problem, device, rank, world, kernels=None, track_particle_count=True, margin=1.25,
                  overlap=True):
+        if problem.simparams.simflags & D.ENABLE_XSPH:
+            raise ValueError("ENABLE_XSPH is not wired into the slab driver (single-domain engine only)")
         self.problem = problem
         self.rank, self.world = rank, world
         self.device = torch.device(device)

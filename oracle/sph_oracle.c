@@ -1479,6 +1479,47 @@ void orc_mls(const orc_params *p, orc_f4 *newVel,
 
 /* ==== post-processing engines: src/cuda/post_process_kernel.cu:58-392 ============================== */
 
+/* XSPH mean velocity of the forces pass (ENABLE_XSPH): compute_mean_vel forces_kernel.def:2986-2994 accumulated over the
+ * fluid neighbours of fluid particles, written as 2*mean_vel by write_xsph :3366-3368; consumed by
+ * compute_corrected_velocity (euler_body above).  Other particles' rows are left alone, as in the reference.
+ *   mean_vel -= m_j W(r, h) (v_i - v_j) / (rho_i + rho_j)     (float3/float = multiply by the reciprocal) */
+void orc_xsph(const orc_params *p, orc_f4 *xsph,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = fromParticle; index < toParticle; ++index) {
+		const orc_info info = infoArray[index];
+		const orc_f4 pos = posArray[index];
+		if (PART_TYPE(info) != PT_FLUID || INACTIVE(pos)) continue;
+		const orc_f4 vel = velArray[index];
+		const float rho = physical_density(p, vel.w, FLUID_NUM(info));
+		float mx = 0.0f, my = 0.0f, mz = 0.0f;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			if (!isfinite(npos.w)) continue;
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const float r = sqrtf(sqlength3(rx, ry, rz));
+			if (r >= p->influenceradius) continue;
+			const orc_f4 nvel = velArray[neib_index];
+			const float n_rho = physical_density(p, nvel.w, FLUID_NUM(infoArray[neib_index]));
+			const float t = npos.w*W_c(p->kerneltype, r, p->slength, wcoeff, wsub);
+			const float inv = 1.0f/(rho + n_rho);
+			mx = fmaf(-(t*(vel.x - nvel.x)), inv, mx);
+			my = fmaf(-(t*(vel.y - nvel.y)), inv, my);
+			mz = fmaf(-(t*(vel.z - nvel.z)), inv, mz);
+		}
+		xsph[index].x = 2.0f*mx; xsph[index].y = 2.0f*my; xsph[index].z = 2.0f*mz; xsph[index].w = 0.0f;
+	}
+}
+
 /* calcVortDevice :58-135: vorticity of active fluid particles from their FLUID neighbours, NaN elsewhere */
 void orc_vorticity(const orc_params *p, float *vorticity /* 3 per particle */,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,

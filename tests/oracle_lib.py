@@ -214,11 +214,17 @@ class Oracle:
         return float(self.L.orc_dtreduce(C.byref(self.p), P(cfl), C.c_uint32(nblocks), C.c_float(sspeed_cfl),
                                          C.c_float(max_kinematic)))
 
-    def euler(self, old_pos, old_vel, info, hash_, forces, n, dt, step):
+    def euler(self, old_pos, old_vel, info, hash_, forces, n, dt, step, xsph=None):
         npos = np.zeros_like(old_pos); nvel = np.zeros_like(old_vel)
-        self.L.orc_euler(C.byref(self.p), P(npos), P(nvel), P(old_pos), P(old_vel), P(info), P(hash_), P(forces), None,
+        self.L.orc_euler(C.byref(self.p), P(npos), P(nvel), P(old_pos), P(old_vel), P(info), P(hash_), P(forces), P(xsph),
                          C.c_uint32(n), C.c_float(dt), C.c_int(step))
         return npos, nvel
+
+    def xsph(self, pos, vel, info, hash_, cs, nl, n, out=None):
+        """mean neighbourhood velocity of the forces pass (ENABLE_XSPH); rows of non-fluid particles keep their content"""
+        out = np.zeros((len(pos), 4), dtype=np.float32) if out is None else out
+        self.L.orc_xsph(C.byref(self.p), P(out), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), C.c_uint32(0), C.c_uint32(n))
+        return out
 
     def repack_forces(self, pos, vel, info, hash_, cs, nl, n, frm=0, to=None, cfl_offset=0, rb_count=0):
         to = n if to is None else to
@@ -392,17 +398,23 @@ class OracleSim:
         f1, cfl, nb, self.rbf, self.rbt = o.forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n,
                                                    compute_object_forces=cof, rb_count=rb, tau=tau)
         dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        xsph_on = bool(sp.simflags & self.D.ENABLE_XSPH)
+        if xsph_on:     # BUFFER_XSPH is allocated once and rewritten for the fluid particles by every forces pass
+            self.xsph = o.xsph(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n, getattr(self, "xsph", None))
+        xs = self.xsph if xsph_on else None
         if self.bodies is not None:
             self._move_bodies(1, dt, self.t)
-        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1)
+        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1, xsph=xs)
         # corrector
         tau = o.sps(ps, vs, self.info, self.hash, self.cs, self.nl, n, n)[0] if sps else None
         f2, cfl, nb, self.rbf, self.rbt = o.forces(ps, vs, self.info, self.hash, self.cs, self.nl, n,
                                                    compute_object_forces=cof, rb_count=rb, tau=tau)
         dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        if xsph_on:
+            self.xsph = o.xsph(ps, vs, self.info, self.hash, self.cs, self.nl, n, self.xsph)
         if self.bodies is not None:
             self._move_bodies(2, dt, self.t)
-        self.pos, self.vel = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
+        self.pos, self.vel = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2, xsph=xs)
         if self.bodies is not None:
             m = self._last_motion
             for b in range(len(self.bodies)):

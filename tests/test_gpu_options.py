@@ -445,3 +445,46 @@ def test_interface_detection_bit_exact():
     # running it again on the flagged INFO is idempotent (the pass clears both flags first)
     eng.postprocess(D.INTERFACE_DETECTION)
     assert np.array_equal(_np(eng.info, np.uint16)[:n], ref_info[:n])
+
+
+def test_xsph_mean_velocity_and_trajectory():
+    """ENABLE_XSPH (rows a9/a15): the forces pass writes 2 * mean neighbourhood velocity for the fluid particles
+    (compute_mean_vel forces_kernel.def:2986-2994), Euler advects with v + eps * that (compute_corrected_velocity
+    euler_kernel.def:171-180).  XSPH array bit-exact vs the oracle, then a trajectory with the usual tolerances"""
+    import torch
+    prob = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.05, hydrostatic=False)
+    prob.simparams.simflags |= D.ENABLE_XSPH
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    rng = np.random.default_rng(5)
+    vel = sim.vel.copy()
+    fluid = (sim.info[:, 0] & 7) == 0
+    vel[fluid, :3] += rng.uniform(-0.3, 0.3, size=(int(fluid.sum()), 3)).astype(np.float32)
+    vel[:, 3] += rng.uniform(0, 2e-3, size=len(vel)).astype(np.float32)
+    sim.vel = vel
+    eng.vel[:n] = torch.from_numpy(vel[:n]).to(eng.device)
+    xs_ref = sim.o.xsph(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng._forces(eng.pos, eng.vel, 1, 0)
+    xs = eng.xsph[:n].cpu().numpy()
+    assert np.abs(xs_ref[:n][fluid[:n], :3]).max() > 1e-3
+    assert np.array_equal(xs.view(np.uint32), xs_ref[:n].view(np.uint32))
+    assert not xs[~fluid[:n]].any()                     # boundary rows are never written
+    # the correction changes where particles go: same run without the flag differs, with the flag follows the oracle
+    for _ in range(12):
+        sim.step(); eng.step()
+    out = eng.download()
+    same = (out["info"] == sim.info[:n]).all(axis=1)
+    assert same.mean() > 0.999
+    m = same
+    assert np.abs(out["pos"][m, :3] - sim.pos[:n][m, :3]).max() <= 12e-6 * prob.m_cellsize.min()
+    vscale = max(np.abs(sim.vel[:n, :3]).max(), 1e-3)
+    assert np.abs(out["vel"][m, :3] - sim.vel[:n][m, :3]).max() <= 1e-3 * vscale
+    plain = DamBreak3D(deltap=0.04, obstacle=True, jitter=0.05, hydrostatic=False)
+    e2 = _engine(plain)
+    e2.vel[:n] = torch.from_numpy(vel[:n]).to(e2.device)
+    e3 = _engine(prob)
+    e3.vel[:n] = torch.from_numpy(vel[:n]).to(e3.device)
+    e2.step(); e3.step()
+    assert np.abs(e2.download()["pos"][:, :3] - e3.download()["pos"][:, :3]).max() > 1e-7
