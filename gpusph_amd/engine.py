@@ -364,31 +364,54 @@ class TimestepEngine:
                             vorticity=vort, normals=nrm, forces=st["forces"] if forces else None)
 
     # ------------------------------------------------------------------ checkpoints (GPUSPH HotFile v1)
+    def _host_buffer_count(self):
+        """size of GPUSPH's host buffer list for this option set, which HotFile::load compares with the header
+        (src/writers/HotFile.cc:143): POS_GLOBAL, POS, VEL, INFO, HASH, + SPS_TURBVISC with SPS (GPUSPH.cc host allocation)"""
+        return 5 + (1 if self.sps else 0)
+
     def save_hotfile(self, path):
         """HotFile::save of the current state (src/writers/HotFile.cc:86-118); readable by GPUSPH --resume and by
-        the reference's scripts/hotdiff.py."""
+        the reference's scripts/hotdiff.py.  One body record per body, from the LIVE kinematic data (writeBody :285-340)."""
         from . import hotfile
         st = self.download()
         bodies = []
         if self.num_bodies_parts:
             pr = self.problem
-            cg = pr.m_origin + (pr.rb_cg_gridpos[0] + 0.5) * pr.m_cellsize + pr.rb_cg_pos[0]
-            first = int(pr.rb_firstindex[0])
-            bodies.append(dict(index=0, id=0, type=hotfile.MB_FORCES_MOVING, numparts=self.num_bodies_parts,
-                               firstindex=first, lastindex=self.num_bodies_parts - 1, crot=cg, lvel=[0, 0, 0], avel=[0, 0, 0],
-                               orientation=[1, 0, 0, 0]))
+            nb = len(pr.rb_firstindex)
+            for b in range(nb):
+                first = int(pr.rb_firstindex[b])
+                forces_body = self.sp.numforcesbodies > b
+                if self.bodies is not None:
+                    kd, kd0 = self.bodies.kdata[b], self.bodies.initial[b]
+                    crot, lvel, avel = kd.crot, kd.lvel, kd.avel
+                    icrot = kd0.crot
+                else:
+                    crot = icrot = pr.m_origin + (pr.rb_cg_gridpos[b] + 0.5) * pr.m_cellsize + pr.rb_cg_pos[b]
+                    lvel = avel = [0.0, 0.0, 0.0]
+                bodies.append(dict(index=b, id=b, type=hotfile.MB_FORCES_MOVING if forces_body else hotfile.MB_MOVING,
+                                   numparts=self.num_bodies_parts // nb,
+                                   firstindex=first if forces_body else 0,
+                                   lastindex=(self.num_bodies_parts // nb - 1) if forces_body else 0,
+                                   crot=crot, lvel=lvel, avel=avel, orientation=[1, 0, 0, 0],
+                                   initial_crot=icrot, initial_lvel=[0, 0, 0], initial_avel=[0, 0, 0],
+                                   initial_orientation=[1, 0, 0, 0]))
         hotfile.write_hotfile(path, dict(pos=st["pos"], vel=st["vel"], info=st["info"].reshape(-1, 4), hash=st["hash"]),
-                              self.iterations, self.time(), self.current_dt(), bodies=bodies)
+                              self.iterations, self.time(), self.current_dt(), bodies=bodies,
+                              host_buffer_count=self._host_buffer_count())
 
     def load_hotfile(self, path):
         """HotFile::load + resume: particle buffers, iteration count, t and dt come from the file; the neighbour
-        phase of the next step re-hashes and re-sorts them (calcHash, not the iteration-0 fixHash)."""
+        phase of the next step re-hashes and re-sorts them (calcHash, not the iteration-0 fixHash).  Body records restore
+        the kinematic data of the moving bodies (readBody) and the centres of rotation of both engines."""
         from . import hotfile
         hf = hotfile.read_hotfile(path)
         a = hf["arrays"]
         n = hf["particles"]
         if n > self.alloc:
             raise capi.SphxError("HotFile has %d particles, %d allocated" % (n, self.alloc))
+        nb_sim = len(self.problem.rb_firstindex) if self.num_bodies_parts else 0
+        if len(hf["bodies"]) != nb_sim:       # check_counts_match("body", ...), HotFile.cc:148
+            raise capi.SphxError("mismatched body count; HotFile has %d, simulation has %d" % (len(hf["bodies"]), nb_sim))
         dev = self.device
         self.n = n
         self.pos[:n] = torch.from_numpy(a["pos"]).to(dev); self.vel[:n] = torch.from_numpy(a["vel"]).to(dev)
@@ -398,6 +421,19 @@ class TimestepEngine:
         self.dt = float(np.float32(hf["dt"]))
         self.d_dt.fill_(self.dt); self.d_dt_next.fill_(self.dt)
         self.d_t.fill_(float(hf["t"]))
+        if self.bodies is not None:
+            for rec in hf["bodies"]:
+                b = int(rec["index"])
+                kd = self.bodies.kdata[b]
+                kd.crot = np.array(rec["crot"], dtype=np.float64)
+                kd.lvel = np.array(rec["lvel"], dtype=np.float64); kd.avel = np.array(rec["avel"], dtype=np.float64)
+                self.bodies.storage[b] = type(kd)(crot=kd.crot.copy(), lvel=kd.lvel.copy(), avel=kd.avel.copy())
+                self.bodies.initial[b].crot = np.array(rec["initial_crot"], dtype=np.float64)
+            nb = len(self.bodies)
+            gp = np.zeros((nb, 3), dtype=np.int32); lp = np.zeros((nb, 3), dtype=np.float32)
+            for b in range(nb):
+                gp[b], lp[b] = self.bodies.grid_and_local(self.bodies.kdata[b].crot)
+            capi.check(self.lib.sphx_set_rb_cg(self.ctx.handle, gp.ctypes.data, lp.ctypes.data, nb))
         if self.iterations % self.sp.buildneibsfreq != 0:
             self.build_neibs()      # a resumed run always starts with a neighbour phase (GPUSPH::runSimulation)
         return hf

@@ -38,6 +38,11 @@ class SlabPartition:
         self.gs3 = int(gs[c3])
         self.plane = int(gs[c1]) * int(gs[c2])          # cells per COORD3 plane = contiguous hash range
         self.world = world
+        # the split axis must not be periodic: ranks 0 and world-1 would have to exchange their outermost planes as halos,
+        # which this partition does not set up (the reference does it through the device map, src/ProblemCore.cc:1061-1116)
+        if world > 1 and (problem.simparams.periodicbound & (1 << c3)):
+            raise ValueError("the domain is periodic along the split axis (COORD3 = %s): not supported by the slab "
+                             "partition; choose a linearisation whose COORD3 is a non-periodic axis" % "xyz"[c3])
         per = self.gs3 // world
         if world > 1 and per < 2:
             raise ValueError("need at least 2 cell planes per device along the split axis (have %d planes, %d devices)"

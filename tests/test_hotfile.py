@@ -61,6 +61,32 @@ def test_resume_is_bit_identical(tmp_path):
         assert np.array_equal(np.asarray(out[k]).view(np.uint8), np.asarray(ref[k]).view(np.uint8)), k
 
 
+@pytest.mark.gpu
+def test_resume_with_a_moving_body_is_bit_identical(tmp_path):
+    """WaveTank mirror (hinged paddle with prescribed motion, SPS: 6 host buffers): the body records carry the live
+    kinematic data, a resumed run continues the paddle where it was"""
+    from gpusph_amd.engine import TimestepEngine
+    from gpusph_amd.problem import WaveTank
+    from gpusph_amd import hotfile
+    prob = WaveTank(0.06, paddle_tstart=0.0)
+    a = TimestepEngine(prob)
+    a.run(10)
+    path = tmp_path / "hot.bin"
+    a.save_hotfile(path)
+    hf0 = hotfile.read_hotfile(path)
+    assert hf0["buffer_count"] == 6 and len(hf0["bodies"]) == 1           # + BUFFER_SPS_TURBVISC; simparams.numbodies
+    assert hf0["bodies"][0]["type"] == hotfile.MB_MOVING and np.abs(hf0["bodies"][0]["avel"]).max() > 0
+    a.run(7)
+    ref = a.download()
+    b = TimestepEngine(WaveTank(0.06, paddle_tstart=0.0))
+    b.load_hotfile(path)
+    b.run(7)
+    out = b.download()
+    assert b.n == a.n and b.current_dt() == a.current_dt()
+    for k in ("pos", "vel", "info", "hash"):
+        assert np.array_equal(np.asarray(out[k]).view(np.uint8), np.asarray(ref[k]).view(np.uint8)), k
+
+
 @pytest.mark.skipif(not __import__("os").path.exists("/root/reference/scripts/hotdiff.py"),
                     reason="the reference tree is only present in the build container")
 def test_reference_hotdiff_reads_our_files(tmp_path):

@@ -192,3 +192,16 @@ def test_slab_run_of_the_wavetank_mirror_equals_single_domain(tmp_path):
     paddle = (one["info"][:, 0] & 0x10) != 0
     assert paddle.sum() > 50 and np.abs(one["vel"][paddle, :3]).max() > 1e-3     # the paddle moves
     assert all(int(p["n_local"]) < len(ids1) for p in p2)
+
+
+def test_split_axis_must_not_be_periodic():
+    from gpusph_amd import defs as D
+    """a domain periodic along COORD3 needs the two end ranks to exchange halos: refused, not silently wrong"""
+    from gpusph_amd.multigpu import SlabPartition
+    from gpusph_amd.problem import PeriodicBox
+    prob = PeriodicBox(0.05, n=(12, 12, 12), periodic=D.PERIODIC_X | D.PERIODIC_Y | D.PERIODIC_Z)
+    with pytest.raises(ValueError, match="periodic along the split axis"):
+        SlabPartition(prob, 2)
+    SlabPartition(prob, 1)
+    ok = PeriodicBox(0.05, n=(12, 12, 12), periodic=D.PERIODIC_Y | D.PERIODIC_Z)       # default yzx: COORD3 = x
+    SlabPartition(ok, 2)
