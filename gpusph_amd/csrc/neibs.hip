@@ -107,6 +107,32 @@ __device__ __forceinline__ uint32_t hash_to_bin(uint32_t h, uint32_t cells, uint
 	return (h == CELL_HASH_MAX) ? lastBin : (h >> 30)*cells + (h & CELLTYPE_BITMASK);
 }
 
+// The in-bin rank below compares every particle of a bin with every other one: fine for cells (~18 particles), quadratic
+// for the one bin all INACTIVE particles share (hash CELL_HASH_MAX): tens of thousands of them after an outflow or after
+// disableFreeSurfParts would cost 1e9-1e10 comparisons on a single bin.  When that bin holds more than SORT_BIG_BIN
+// particles its members instead keep their relative order (slot = number of inactive particles before them, from a scan
+// of flags) and are not ranked.  The reference orders them by (type, id) like everything else; nothing reads that order:
+// the caller drops the inactive tail (newNumParticles, src/cuda/buildneibs_kernel.cu:905-909, GPUWorker.cc:1471-1515).
+// All of it is decided on the device from the bin's count (the kernels return at once for a small bin): no host sync.
+#define SORT_BIG_BIN 4096u
+
+__global__ void __launch_bounds__(BLOCK_SORT)
+inactive_flags_kernel(const uint32_t *__restrict__ hash, uint32_t *__restrict__ flags, uint32_t n, const uint32_t *__restrict__ guard)
+{
+	if (*guard <= SORT_BIG_BIN) return;
+	const uint32_t i = blockIdx.x*BLOCK_SORT + threadIdx.x;
+	if (i < n) flags[i] = hash[i] == CELL_HASH_MAX ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(BLOCK_SORT)
+inactive_slots_kernel(const uint32_t *__restrict__ hash, const uint32_t *__restrict__ before, uint32_t *__restrict__ slot,
+	uint32_t n, const uint32_t *__restrict__ guard)
+{
+	if (*guard <= SORT_BIG_BIN) return;
+	const uint32_t i = blockIdx.x*BLOCK_SORT + threadIdx.x;
+	if (i < n && hash[i] == CELL_HASH_MAX) slot[i] = before[i];
+}
+
 __global__ void __launch_bounds__(BLOCK_SORT)
 sort_count_kernel(const uint32_t *__restrict__ hash, uint32_t *__restrict__ binCount,
 	uint32_t *__restrict__ slot, uint32_t cells, uint32_t lastBin, uint32_t n)
@@ -159,8 +185,10 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, uint32_t &bl
 }
 
 __global__ void __launch_bounds__(256)
-scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ partials, uint32_t n)
+scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ partials, uint32_t n,
+	const uint32_t *__restrict__ guard = nullptr)
 {
+	if (guard && *guard <= SORT_BIG_BIN) return;
 	const uint32_t base = blockIdx.x*SCAN_ITEMS + threadIdx.x*4;
 	uint32_t s = 0;
 	if (base + 3 < n) {
@@ -175,8 +203,9 @@ scan_reduce_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ parti
 }
 
 __global__ void __launch_bounds__(256)
-scan_partials_kernel(uint32_t *__restrict__ partials, uint32_t numPartials)
+scan_partials_kernel(uint32_t *__restrict__ partials, uint32_t numPartials, const uint32_t *__restrict__ guard = nullptr)
 {
+	if (guard && *guard <= SORT_BIG_BIN) return;
 	uint32_t carry = 0;
 	for (uint32_t base = 0; base < numPartials; base += 256) {
 		const uint32_t i = base + threadIdx.x;
@@ -190,8 +219,9 @@ scan_partials_kernel(uint32_t *__restrict__ partials, uint32_t numPartials)
 
 __global__ void __launch_bounds__(256)
 scan_final_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-	const uint32_t *__restrict__ partials, uint32_t n)
+	const uint32_t *__restrict__ partials, uint32_t n, const uint32_t *__restrict__ guard = nullptr)
 {
+	if (guard && *guard <= SORT_BIG_BIN) return;
 	const uint32_t base = blockIdx.x*SCAN_ITEMS + threadIdx.x*4;
 	uint32_t v[4] = {0, 0, 0, 0};
 	if (base + 3 < n) {
@@ -251,9 +281,13 @@ sort_rank_kernel(const uint32_t *__restrict__ tmpHash, const uint2 *__restrict__
 	const uint2 myInfo = tmpInfo[p];
 	const unsigned long long key = type_id_key(myInfo);
 	uint32_t rank = 0;
-	for (uint32_t q = s; q < e; ++q) {
-		const unsigned long long k = type_id_key(tmpInfo[q]);
-		rank += (k < key) || (k == key && q < p);
+	if (bin == lastBin && e - s > SORT_BIG_BIN) {
+		rank = p - s;          // a big inactive bin arrives in its final (stable) order, see SORT_BIG_BIN
+	} else {
+		for (uint32_t q = s; q < e; ++q) {
+			const unsigned long long k = type_id_key(tmpInfo[q]);
+			rank += (k < key) || (k == key && q < p);
+		}
 	}
 	const uint32_t dst = s + rank;
 	hash[dst] = h;
@@ -788,6 +822,16 @@ extern "C" int sphx_sort(sphx_ctx *ctx, uint32_t *hash, void *info, uint32_t *pa
 	scan_partials_kernel<<<1, 256, 0, stream>>>(ctx->scan_partials, scanBlocks);
 	scan_final_kernel<<<scanBlocks, 256, 0, stream>>>(ctx->bin_count, ctx->bin_start, ctx->scan_partials, bins);
 	SPHX_LAUNCH_CHECK("scan kernels");
+	{	// a big bin of inactive particles: stable slots from a scan of flags (tmp_hash / tmp_index are free until the scatter)
+		const uint32_t *guard = ctx->bin_count + lastBin;
+		const uint32_t nScan = div_up_u(n, SCAN_ITEMS);
+		inactive_flags_kernel<<<nb, BLOCK_SORT, 0, stream>>>(hash, ctx->tmp_hash, n, guard);
+		scan_reduce_kernel<<<nScan, 256, 0, stream>>>(ctx->tmp_hash, ctx->scan_partials, n, guard);
+		scan_partials_kernel<<<1, 256, 0, stream>>>(ctx->scan_partials, nScan, guard);
+		scan_final_kernel<<<nScan, 256, 0, stream>>>(ctx->tmp_hash, ctx->tmp_index, ctx->scan_partials, n, guard);
+		inactive_slots_kernel<<<nb, BLOCK_SORT, 0, stream>>>(hash, ctx->tmp_index, ctx->slot, n, guard);
+		SPHX_LAUNCH_CHECK("inactive slot kernels");
+	}
 	sort_scatter_kernel<<<nb, BLOCK_SORT, 0, stream>>>(hash, (const uint2*)info, partIndex, ctx->slot,
 		ctx->bin_start, ctx->tmp_hash, ctx->tmp_info, ctx->tmp_index, cells, lastBin, n);
 	SPHX_LAUNCH_CHECK("sort_scatter_kernel");

@@ -94,7 +94,7 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	free_scratch(ctx);
 	SPHX_HIP(hipMalloc((void**)&ctx->bin_count, sizeof(uint32_t)*((size_t)bins + 1)));
 	SPHX_HIP(hipMalloc((void**)&ctx->bin_start, sizeof(uint32_t)*((size_t)bins + 1)));
-	SPHX_HIP(hipMalloc((void**)&ctx->scan_partials, sizeof(uint32_t)*((size_t)bins/1024 + 2)));
+	SPHX_HIP(hipMalloc((void**)&ctx->scan_partials, sizeof(uint32_t)*((size_t)(bins > n ? bins : n)/1024 + 2)));   // scans over bins and over particles
 	SPHX_HIP(hipMalloc((void**)&ctx->slot, sizeof(uint32_t)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_hash, sizeof(uint32_t)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_index, sizeof(uint32_t)*(size_t)n));

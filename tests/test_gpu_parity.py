@@ -63,6 +63,43 @@ def test_neibs_phase_bit_exact(case):
     assert info.hasTooManyNeibs == -1
 
 
+def test_many_inactive_particles_sort_without_a_quadratic_bin():
+    """1e5 disabled particles (outflow, disableFreeSurfParts at scale): they all share the CELL_HASH_MAX bin.  The
+    active prefix is bit-identical to the oracle's (hash, info, permutation, cells, lists), the tail holds exactly the
+    disabled particles, and the rebuild does not take seconds (the in-bin rank is quadratic; big inactive bins skip it)"""
+    import time
+    import torch
+    prob = DamBreak3D(DamBreak3D.deltap_for(5.0e5), obstacle=False, hydrostatic=False)
+    n0 = prob.num_particles
+    assert n0 > 400_000
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.step(); eng.step()                       # iteration 0 -> 1 (so that the next rebuild goes through calcHash)
+    rng = np.random.default_rng(17)
+    fluid_idx = np.nonzero((sim.info[:n0, 0] & 7) == 0)[0]          # calcHash re-hashes fluid particles (fixed boundaries keep theirs)
+    kill = rng.choice(fluid_idx, size=100_000, replace=False)
+    sim.pos[kill, 3] = np.nan
+    eng.pos[torch.from_numpy(kill).to(eng.device), 3] = float("nan")
+    sim.iterations = eng.iterations = prob.simparams.buildneibsfreq        # force a rebuild now
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    eng.build_neibs()
+    torch.cuda.synchronize(); t_rebuild = time.perf_counter() - t0
+    sim.build_neibs()
+    n = eng.n
+    assert n == sim.n == n0 - 100_000
+    assert t_rebuild < 0.25, "rebuild took %.3f s" % t_rebuild
+    assert np.array_equal(_np(eng.hash, np.uint32)[:n], sim.hash[:n])
+    assert np.array_equal(_np(eng.info, np.uint16)[:n], sim.info[:n])
+    assert np.array_equal(_np(eng.partindex, np.uint32)[:n], sim.partindex[:n])
+    assert np.array_equal(_np(eng.cellStart, np.uint32), sim.cs) and np.array_equal(_np(eng.cellEnd, np.uint32), sim.ce)
+    assert np.array_equal(_np(eng.pos)[:n].view(np.uint32), sim.pos[:n].view(np.uint32))
+    assert np.array_equal(_np(eng.neibslist, np.uint16).reshape(-1, eng.alloc)[:, :n], sim.nl.reshape(-1, eng.alloc)[:, :n])
+    tail = _np(eng.hash, np.uint32)[n:n0]
+    assert (tail == 0xFFFFFFFF).all()
+    ids = lambda info: info[:, 2].astype(np.uint32) | (info[:, 3].astype(np.uint32) << 16)
+    assert np.array_equal(np.sort(ids(_np(eng.info, np.uint16)[n:n0])), np.sort(ids(sim.info[n:n0])))   # the same particles
+
+
 @pytest.mark.parametrize("case", CASES[:2])
 def test_forces_and_dt_tolerance(case):
     import torch
