@@ -106,6 +106,7 @@ extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	if (step != 1 && step != 2)
 		return sphx_set_error(SPHX_ERR_INVALID, "unsupported predcorr timestep"); // src/cuda/euler.cu:361
 	if (!particleRangeEnd) return SPHX_OK;
+	{ const int rcf = sphx_rb_flush(ctx, (hipStream_t)stream); if (rcf != SPHX_OK) return rcf; }
 	EulerArgs a;
 	a.newPos = (float4*)newPos; a.newVel = (float4*)newVel;
 	a.oldPos = (const float4*)oldPos; a.oldVel = (const float4*)oldVel; a.forces = (const float4*)forces;

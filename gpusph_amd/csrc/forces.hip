@@ -1710,6 +1710,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	const uint32_t numBlocks = round_up_u(div_up_u(nrange, SPHX_BLOCK_FORCES), 4u);
 	if (h_numBlocks) *h_numBlocks = numBlocks;
 	if (!numBlocks) return SPHX_OK;
+	{ const int rcf = sphx_rb_flush(ctx, (hipStream_t)stream); if (rcf != SPHX_OK) return rcf; }
 	if (run_mode == SPHX_REPACK)   // run_repack, src/cuda/forces.cu:828-896 (filters.hip)
 		return sphx_repack_launch(ctx, forces, cfl, rbforces, rbtorques, pos, vel, info, hash, cellStart, neibsList,
 			fromParticle, toParticle, cflOffset, numBlocks, deltap, (hipStream_t)stream);

@@ -28,6 +28,8 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	ctx->device = device;
 	SPHX_HIP(hipMalloc((void**)&ctx->rb_dev, sizeof(RbParams)));
 	SPHX_HIP(hipMemset(ctx->rb_dev, 0, sizeof(RbParams)));
+	SPHX_HIP(hipHostMalloc((void**)&ctx->rb_staging, sizeof(RbParams)*SPHX_RB_RING, hipHostMallocDefault));
+	for (int k = 0; k < SPHX_RB_RING; ++k) SPHX_HIP(hipEventCreateWithFlags(&ctx->rb_staged[k], hipEventDisableTiming));
 	SPHX_HIP(hipMalloc((void**)&ctx->counters_dev, sizeof(NeibsCounters)));
 	SPHX_HIP(hipMemset(ctx->counters_dev, 0, sizeof(NeibsCounters)));
 	SPHX_HIP(hipMalloc((void**)&ctx->dt_scratch, 4*sizeof(float)));
@@ -67,6 +69,10 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	(void)hipSetDevice(ctx->device);
 	free_scratch(ctx);
 	if (ctx->rb_dev) (void)hipFree(ctx->rb_dev);
+	if (ctx->rb_staging) {
+		(void)hipHostFree(ctx->rb_staging);
+		for (int k = 0; k < SPHX_RB_RING; ++k) (void)hipEventDestroy(ctx->rb_staged[k]);
+	}
 	if (ctx->counters_dev) (void)hipFree(ctx->counters_dev);
 	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
 	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
@@ -272,11 +278,26 @@ extern "C" int sphx_set_gravity(sphx_ctx *ctx, const float g[3])
 	return SPHX_OK;
 }
 
+// The reference uploads these tables with cudaMemcpyToSymbol on the default stream, in order with its kernels.  Here the
+// engines run on whatever stream the caller passes, so the upload is deferred to the next engine call that reads the
+// tables and issued on that call's stream (also capturable into a hipGraph): kernels already enqueued keep the old values,
+// kernels enqueued afterwards see the new ones, whichever stream is used.
 static int upload_rb(sphx_ctx *ctx)
 {
-	SPHX_HIP(hipSetDevice(ctx->device));
-	// stream-ordered after whatever the default stream holds, like cudaMemcpyToSymbol in the reference
-	SPHX_HIP(hipMemcpy(ctx->rb_dev, &ctx->rb_host, sizeof(RbParams), hipMemcpyHostToDevice));
+	ctx->rb_dirty = true;
+	return SPHX_OK;
+}
+
+int sphx_rb_flush(sphx_ctx *ctx, hipStream_t st)
+{
+	if (!ctx->rb_dirty) return SPHX_OK;
+	const uint32_t k = ctx->rb_ring++ % SPHX_RB_RING;
+	if (ctx->rb_ring > SPHX_RB_RING)      // the slot was used before: its copy must have executed before it is overwritten
+		SPHX_HIP(hipEventSynchronize(ctx->rb_staged[k]));
+	ctx->rb_staging[k] = ctx->rb_host;
+	SPHX_HIP(hipMemcpyAsync(ctx->rb_dev, &ctx->rb_staging[k], sizeof(RbParams), hipMemcpyHostToDevice, st));
+	SPHX_HIP(hipEventRecord(ctx->rb_staged[k], st));
+	ctx->rb_dirty = false;
 	return SPHX_OK;
 }
 

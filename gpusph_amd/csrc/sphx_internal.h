@@ -113,6 +113,12 @@ struct sphx_ctx {
 	DevParams   dev;
 	RbParams    rb_host;
 	RbParams   *rb_dev;
+	// rigid-body tables reach the device in stream order: the setters only mark them dirty; the next engine call that reads
+	// them copies them from a ring of pinned staging slots on ITS stream before launching (sphx_rb_flush)
+	bool        rb_dirty;
+	RbParams   *rb_staging;              // [SPHX_RB_RING] pinned
+	hipEvent_t  rb_staged[16];           // copy of slot k has executed
+	uint32_t    rb_ring;
 	NeibsCounters *counters_dev;
 	// sort scratch
 	uint32_t    reserved_particles;
@@ -164,6 +170,8 @@ static inline uint32_t round_up_u(uint32_t a, uint32_t b) { return div_up_u(a, b
 
 int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles);
 // repacking forces (filters.hip), reached through sphx_forces_basicstep(run_mode = SPHX_REPACK)
+#define SPHX_RB_RING 16
+int sphx_rb_flush(sphx_ctx *ctx, hipStream_t st);
 int sphx_xsph_launch(sphx_ctx *ctx, void *xsph, const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle, hipStream_t st);
 int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, hipStream_t st);
