@@ -156,6 +156,9 @@ def main():
 
     for _ in range(args.warmup):
         eng.step()
+    if world > 1:                           # exchange accounting over the timed region
+        eng.halo_bytes = 0
+        eng.exchange_events = []
     info = eng.neibs_info()                 # also checks for neighbour-list overflow
     # HIP events on the launch stream around the dominant kernel of every forces pass, recorded by the library
     import ctypes as C
@@ -187,6 +190,17 @@ def main():
     else:
         n_sum, interactions_sum = n_internal, interactions
 
+    exch = None
+    if dist is not None:                    # per rank: halo bytes per step and the compute stream's stall on the exchange
+        torch.cuda.synchronize()
+        stall_ms = sum(b.elapsed_time(a) for b, a in (eng.exchange_events or []))
+        mine = torch.tensor([eng.halo_bytes / args.steps, stall_ms / args.steps, float(n_internal)], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        exch = {"halo_bytes_per_step": [int(r[0].item()) for r in allr],
+                "exposed_exchange_ms_per_step": [round(float(r[1].item()), 4) for r in allr],
+                "internal_particles": [int(r[2].item()) for r in allr],
+                "comm_cus_reserved": int(getattr(eng, "comm_cus", 0))}
     if rank == 0:
         updates = n_sum * args.steps
         value = 1e-6 * updates / elapsed
@@ -218,6 +232,8 @@ def main():
                                   "frac": round(interactions * 60.0 / (avg_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, 4),
                                   "flop_per_pair": 60}},
         }
+        if exch is not None:
+            out["exchange"] = exch
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

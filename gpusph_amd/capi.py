@@ -66,6 +66,7 @@ SIGNATURES = {
     "sphx_forces_dtreduce": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _u32, C.POINTER(_f), _vp]),
     "sphx_forces_dtreduce_device": (_i, [_vp, _f, _f, _f, _f, _vp, _vp, _u32, _vp, _i, _vp]),
     "sphx_reduce_rb_forces": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "sphx_forces_reserve_cus": (_i, [_vp, _u32]),
     "sphx_forces_timing": (_i, [_vp, _i]),
     "sphx_forces_timing_read": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_u32)]),
     "sphx_calc_visc": (_i, [_vp] + [_vp] * 10 + [_u32, _u32, _f, _f, _f, _vp]),

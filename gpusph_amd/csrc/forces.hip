@@ -1774,6 +1774,18 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	return SPHX_OK;
 }
 
+extern "C" int sphx_forces_reserve_cus(sphx_ctx *ctx, uint32_t cus)
+{
+	SPHX_REQUIRE(ctx != nullptr, "sphx_forces_reserve_cus: NULL ctx");
+	int total = 0;
+	SPHX_HIP(hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, ctx->device));
+	const uint32_t all = (uint32_t)(total > 0 ? total : 256);
+	const uint32_t k = (cus + 7u)/8u*8u;
+	SPHX_REQUIRE(k < all, "sphx_forces_reserve_cus: more CUs reserved than the device has");
+	ctx->tile_grid = (all - k)*TILE_WGS_PER_CU;
+	return SPHX_OK;
+}
+
 static int dtreduce_launch(sphx_ctx *ctx, float slength, float dtadaptfactor, float sspeed_cfl,
 	float max_kinematic, const float *cfl, float *cflTemp, uint32_t numBlocks,
 	float *d_dt, int combine_min, hipStream_t stream)

@@ -88,6 +88,7 @@ class TimestepEngine:
         self.d_dt = torch.full((1,), self.dt, dtype=f32, device=dev)
         self.d_dt_next = torch.full((1,), self.dt, dtype=f32, device=dev)
         self.d_t = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.t_host = 0.0                  # host copy of t, kept only for the callbacks of moving bodies
         self.iterations = 0
         self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(pp.sscoeff))) * 1.1))  # GPUWorker.cc:3010-3011
         # GPUWorker::uploadConstants (src/GPUWorker.cc:3003-3006): maximum kinematic viscosity for the viscous dt limit
@@ -255,8 +256,9 @@ class TimestepEngine:
             for ftype, freq in self.filters:
                 if self.iterations % freq == 0:
                     self.apply_filter(ftype)
-        if self.bodies is not None:     # the callback needs t and dt on the host: one synchronisation per step
-            t_host, dt_host = float(self.d_t.item()), float(self.d_dt.item())
+        if self.bodies is not None:     # the callback needs dt on the host: ONE synchronisation per step (t is summed on both sides)
+            dt_host = float(self.d_dt.item())
+            t_host = self.t_host
         # predictor: forces(step n) -> n* = n + dt/2 f
         self._forces(self.pos, self.vel, 1, 0)
         if self.bodies is not None:
@@ -274,6 +276,8 @@ class TimestepEngine:
         self.vel, self.vel2 = self.vel2, self.vel
         # TIME_STEP_EPILOGUE: t += dt ; dt = min(dt_pred, dt_corr)
         self.d_t.add_(self.d_dt.double())
+        if self.bodies is not None:
+            self.t_host += dt_host         # the same double += float as on the device
         self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt
         self.iterations += 1
 
@@ -325,6 +329,7 @@ class TimestepEngine:
             return
         self.iterations = 0
         self.d_t.zero_()
+        self.t_host = 0.0
         self.dt = float(np.float32(self.sp.dt))
         self.d_dt.fill_(self.dt); self.d_dt_next.fill_(self.dt)
         n = self.n
@@ -421,6 +426,7 @@ class TimestepEngine:
         self.dt = float(np.float32(hf["dt"]))
         self.d_dt.fill_(self.dt); self.d_dt_next.fill_(self.dt)
         self.d_t.fill_(float(hf["t"]))
+        self.t_host = float(hf["t"])
         if self.bodies is not None:
             for rec in hf["bodies"]:
                 b = int(rec["index"])

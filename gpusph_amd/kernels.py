@@ -98,6 +98,10 @@ class HipKernels:
                                              p(cellEnd), n, range_end, self.ncells, self.sq_nl_radius, self.sq_nl_radius,
                                              self._s()))
 
+    def reserve_comm_cus(self, cus):
+        """leave CUs out of the persistent forces grid for the communication kernels of the halo exchange"""
+        capi.check(self.lib.sphx_forces_reserve_cus(self.ctx.handle, int(cus)))
+
     def neibs_info(self):
         info = capi.NeibsInfo()
         capi.check(self.lib.sphx_neibs_getinfo(self.ctx.handle, C.byref(info), self._s()))

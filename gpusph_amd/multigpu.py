@@ -23,6 +23,7 @@ What it mirrors in GPUSPH (paths relative to the GPUSPH tree) and what it change
   * dt: min over devices (GPUSPH.cc:650-657) as an all_reduce(MIN) of one device float per step.
 Results are bit-identical to the single-device run (same per-particle neighbour order and arithmetic).
 """
+import os
 import numpy as np
 import torch
 
@@ -137,6 +138,15 @@ class MultiGpuEngine:
         self.send_l = self.send_r = self.recv_l = self.recv_r = (0, 0)
         self.overlap = overlap and self.is_cuda and world > 1
         self.comm_stream = torch.cuda.Stream(device=dev) if self.overlap else None
+        # The tiled forces kernel is a persistent grid of one workgroup per CU that owns almost all of the CU's LDS, so the
+        # RCCL send/recv kernels of the overlapped exchange would queue behind the inner stripe.  Leave a few CUs (one per
+        # XCD by default) out of that grid when the exchange is overlapped (SPHX_COMM_CUS overrides; 0 = none).
+        self.comm_cus = int(os.environ.get("SPHX_COMM_CUS", "8")) if self.overlap else 0
+        if self.comm_cus and hasattr(self.k, "reserve_comm_cus"):
+            self.k.reserve_comm_cus(self.comm_cus)
+        # exchange accounting (bench.py --gpus N): bytes sent + received per call, stall of the compute stream on the exchange
+        self.halo_bytes = 0
+        self.exchange_events = None      # list of (before, after) events on the compute stream around the wait, when enabled
         self.profile_forces = None
         self.track_particle_count = track_particle_count
         # SPS: BUFFER_TAU as three float2 arrays, computed for the internal particles before each forces pass and imported
@@ -185,10 +195,13 @@ class MultiGpuEngine:
                 ops.append(dist.P2POp(dist.irecv, v, peer))
 
         for t in tensors:
+            row = t[0:1].view(torch.uint8).numel() if t.shape[0] else 0
             if left is not None:
                 send(t, self.send_l, left); recv(t, self.recv_l, left)
+                self.halo_bytes += row * (self.send_l[1] - self.send_l[0] + self.recv_l[1] - self.recv_l[0])
             if right is not None:
                 send(t, self.send_r, right); recv(t, self.recv_r, right)
+                self.halo_bytes += row * (self.send_r[1] - self.send_r[0] + self.recv_r[1] - self.recv_r[0])
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
@@ -298,7 +311,12 @@ class MultiGpuEngine:
                 with torch.cuda.stream(self.comm_stream):
                     self.comm_stream.wait_event(ev)
                     self._exchange([self.forces])
+                if self.exchange_events is not None:     # how long the compute stream sits waiting for the halo forces
+                    b = torch.cuda.Event(enable_timing=True); a_ = torch.cuda.Event(enable_timing=True)
+                    b.record()
                 torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+                if self.exchange_events is not None:
+                    a_.record(); self.exchange_events.append((b, a_))
             else:
                 self._exchange([self.forces])
         else:

@@ -229,6 +229,13 @@ int sphx_reduce_rb_forces(sphx_ctx *ctx, void *rbforces, void *rbtorques, const 
 	const uint32_t *h_lastindex, float *h_totalforce3, float *h_totaltorque3,
 	uint32_t numforcesbodies, uint32_t numForcesBodiesParticles, void *stream);
 
+/* Multi-GPU runs: leave `cus` compute units (rounded up to a multiple of 8, one per XCD) out of the persistent grid of
+ * the tiled forces kernel, so that the communication kernels of the halo exchange (RCCL send/recv on a second stream) find
+ * free CUs and LDS while the inner stripe computes.  The reference moves its halos with copy engines
+ * (cudaMemcpyPeerAsync, src/GPUWorker.cc:396-407), which cost no SMs; this is the equivalent knob for kernel-based
+ * transports.  0 (the default) = every CU runs a tile workgroup. */
+int sphx_forces_reserve_cus(sphx_ctx *ctx, uint32_t cus);
+
 /* Optional profiling hook (not a reference interface; used by bench.py for the roofline figure): when enabled,
  * every sphx_forces_basicstep records HIP events on its launch stream around its dominant kernel.  _read waits
  * for the recorded events, returns the summed elapsed time [ms] and the number of launches, and releases them. */
