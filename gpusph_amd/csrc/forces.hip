@@ -1638,28 +1638,38 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			const int maxSlots = sec ? (int)p.neibboundpos + 1 : (int)p.neiblistsize;
 			bool alive = mine;
 			uint32_t code = 0, rows = 0;
+			bool done = false;
+			// TILE_LIST_LOADS entries per lane in flight (the walk is latency bound: one dependent round trip per step);
+			// the rows are still counted in steps of TILE_LIST_BATCH, so the padding per wave stays below one batch
+			constexpr int LOADS = 16;
+			static_assert(LOADS % TILE_LIST_BATCH == 0, "whole batches per load group");
 #pragma unroll 1
-			for (int s0 = 0; s0 < maxSlots && wave_any(alive); s0 += TILE_LIST_BATCH) {
-				if (rowsSec[0] + rows + TILE_LIST_BATCH > listRows) { overflow = true; break; }
-				uint32_t e[TILE_LIST_BATCH];
+			for (int s0 = 0; s0 < maxSlots && !done; s0 += LOADS) {
+				uint32_t e[LOADS];
 #pragma unroll
-				for (int k = 0; k < TILE_LIST_BATCH; ++k) {
+				for (int k = 0; k < LOADS; ++k) {
 					const int slot = min(s0 + k, maxSlots - 1);   // a clamped re-read is only reached by dead lanes or dropped below
 					const int src = sec ? (int)p.neibboundpos - slot : slot;
 					e[k] = list[(size_t)src*stride + index];
 				}
-				if (!wave_any(alive && e[0] != NEIBS_END)) break;   // every list of the wave ended exactly at the previous batch
 #pragma unroll
-				for (int k = 0; k < TILE_LIST_BATCH; ++k) {
-					const uint32_t dd = e[k];
-					alive = alive && (s0 + k < maxSlots) && (dd != NEIBS_END);
-					code = (dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
-					const uint32_t slotOff = (1u + (uint32_t)myCB[code & 31u] + (dd & NEIBINDEX_MASK))*16u;   // slot 0 = dummy
-					const uint32_t out = alive ? (slotOff | (code << 20)) : dummy;   // code*16 in the high half
-					const uint32_t row = sec ? listRows - 1u - (rows + k) : rows + k;
-					if (mine) tileList[(size_t)row*listStride + index] = out;
+				for (int b0 = 0; b0 < LOADS; b0 += TILE_LIST_BATCH) {
+					if (done) break;
+					// every list of the wave has ended (or the section has): stop without counting this batch
+					if (s0 + b0 >= maxSlots || !wave_any(alive && e[b0] != NEIBS_END)) { done = true; break; }
+					if (rowsSec[0] + rows + TILE_LIST_BATCH > listRows) { overflow = true; done = true; break; }
+#pragma unroll
+					for (int k = b0; k < b0 + TILE_LIST_BATCH; ++k) {
+						const uint32_t dd = e[k];
+						alive = alive && (s0 + k < maxSlots) && (dd != NEIBS_END);
+						code = (dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
+						const uint32_t slotOff = (1u + (uint32_t)myCB[code & 31u] + (dd & NEIBINDEX_MASK))*16u;   // slot 0 = dummy
+						const uint32_t out = alive ? (slotOff | (code << 20)) : dummy;   // code*16 in the high half
+						const uint32_t row = sec ? listRows - 1u - (rows + (uint32_t)(k - b0)) : rows + (uint32_t)(k - b0);
+						if (mine) tileList[(size_t)row*listStride + index] = out;
+					}
+					rows += TILE_LIST_BATCH;
 				}
-				rows += TILE_LIST_BATCH;
 			}
 			rowsSec[sec] = rows;
 		}

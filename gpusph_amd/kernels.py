@@ -108,7 +108,8 @@ class HipKernels:
         return info
 
     # ---- AbstractForcesEngine
-    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset, tau=None, xsph=None):
+    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset, tau=None,
+               xsph=None, run_mode=D.SIMULATE, step=1):
         p = capi.ptr
         t0, t1, t2 = (p(t) for t in tau) if tau is not None else (None, None, None)
         nb = C.c_uint32(0)
@@ -116,7 +117,7 @@ class HipKernels:
         capi.check(self.lib.sphx_forces_basicstep(self.ctx.handle, p(forces), p(cfl), p(rbforces), p(rbtorques), p(pos), p(vel),
                                                   p(info), p(hash_), p(cellStart), p(neibslist), t0, t1, t2, p(xsph),
                                                   n, frm, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius,
-                                                  cfl_offset, D.SIMULATE, 1, 0.0, self.compute_object_forces,
+                                                  cfl_offset, run_mode, step, 0.0, self.compute_object_forces,
                                                   C.byref(nb), self._s()))
         return nb.value
 
@@ -127,10 +128,10 @@ class HipKernels:
                                                         p(cfl), p(cfl_temp), nblocks, p(d_dt), combine_min, self._s()))
 
     # ---- AbstractViscEngine / AbstractFilterEngine
-    def calc_visc(self, tau, pos, vel, info, hash_, cellStart, neibslist, n, range_end):
+    def calc_visc(self, tau, pos, vel, info, hash_, cellStart, neibslist, n, range_end, turbvisc=None):
         p = capi.ptr
         P = self.params
-        capi.check(self.lib.sphx_calc_visc(self.ctx.handle, p(tau[0]), p(tau[1]), p(tau[2]), None, p(pos), p(vel), p(info), p(hash_),
+        capi.check(self.lib.sphx_calc_visc(self.ctx.handle, p(tau[0]), p(tau[1]), p(tau[2]), p(turbvisc), p(pos), p(vel), p(info), p(hash_),
                                            p(cellStart), p(neibslist), n, range_end, P.deltap, P.slength, P.influenceradius, self._s()))
 
     def filter(self, filtertype, newvel, pos, oldvel, info, hash_, cellStart, neibslist, n, range_end):
@@ -140,9 +141,19 @@ class HipKernels:
                                                 p(cellStart), p(neibslist), n, range_end, P.slength, P.influenceradius, self._s()))
 
     # ---- AbstractIntegrationEngine
-    def euler(self, npos, nvel, opos, ovel, info, hash_, forces, n, d_dt, dt_scale, step):
+    def euler(self, npos, nvel, opos, ovel, info, hash_, forces, n, d_dt, dt_scale, step, xsph=None, run_mode=D.SIMULATE):
         p = capi.ptr
         P = self.params
         capi.check(self.lib.sphx_euler_basicstep(self.ctx.handle, p(npos), p(nvel), p(opos), p(ovel), p(info), p(hash_),
-                                                 p(forces), None, n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
-                                                 P.slength, P.influenceradius, D.SIMULATE, self._s()))
+                                                 p(forces), p(xsph), n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
+                                                 P.slength, P.influenceradius, run_mode, self._s()))
+
+    def disable_free_surf_parts(self, pos, info, n):
+        capi.check(self.lib.sphx_disable_free_surf_parts(self.ctx.handle, capi.ptr(pos), capi.ptr(info), n, n, self._s()))
+
+    # ---- AbstractPostProcessEngine
+    def postprocess(self, pptype, vort, vel_inout, info_inout, normals, pos, vel, info, hash_, cellStart, neibslist, n, cosf, cosn):
+        p = capi.ptr
+        capi.check(self.lib.sphx_postprocess(self.ctx.handle, int(pptype), p(vort), p(vel_inout), p(info_inout), p(normals),
+                                             p(pos), p(vel), p(info), p(hash_), p(cellStart), p(neibslist), n, n,
+                                             float(cosf), float(cosn), self._s()))

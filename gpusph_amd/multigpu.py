@@ -79,9 +79,9 @@ class SlabPartition:
 
 class MultiGpuEngine:
     def __init__(self, problem, device, rank, world, kernels=None, track_particle_count=True, margin=1.25,
-                 overlap=True):
-        if problem.simparams.simflags & D.ENABLE_XSPH:
-            raise ValueError("ENABLE_XSPH is not wired into the slab driver (single-domain engine only)")
+                 overlap=True, allocated=None, clobber_neibslist=False):
+        if world > 1 and (problem.simparams.simflags & D.ENABLE_XSPH):
+            raise ValueError("ENABLE_XSPH needs the mean velocity of the halo particles' neighbourhoods: single domain only")
         self.problem = problem
         self.rank, self.world = rank, world
         self.device = torch.device(device)
@@ -91,7 +91,8 @@ class MultiGpuEngine:
         arrs = problem.copy_to_array()
         mask = self.part.local_mask(rank, arrs["hash"]) if world > 1 else np.ones(len(arrs["hash"]), dtype=bool)
         n0 = int(mask.sum())
-        self.alloc = int(n0 * margin) + 4096
+        self.alloc = int(allocated) if allocated is not None else int(n0 * margin) + 4096
+        self.clobber_neibslist = clobber_neibslist
         if kernels is None:
             from .kernels import HipKernels
             kernels = HipKernels(problem, self.alloc, self.device)
@@ -125,13 +126,15 @@ class MultiGpuEngine:
         self.new_num = torch.zeros(1, dtype=i32, device=dev)
         self.segment_start = torch.zeros(4, dtype=i32, device=dev)
         nrb = max(getattr(problem, "num_obstacle", 0), 1)
-        self.rbforces = torch.zeros((nrb, 4), dtype=f32, device=dev) if getattr(problem, "num_obstacle", 0) else None
-        self.rbtorques = torch.zeros((nrb, 4), dtype=f32, device=dev) if getattr(problem, "num_obstacle", 0) else None
+        self.has_rb = bool(getattr(problem, "num_obstacle", 0))      # BUFFER_RB_FORCES / RB_TORQUES rows of body particles
+        self.rbforces = torch.zeros((nrb, 4), dtype=f32, device=dev)
+        self.rbtorques = torch.zeros((nrb, 4), dtype=f32, device=dev)
         self.devmap = (torch.from_numpy(self.part.compact_device_map(rank).view(np.int32)).to(dev)
                        if world > 1 else None)
         dt0 = float(np.float32(self.sp.dt))
         self.d_dt = torch.full((1,), dt0, dtype=f32, device=dev)
         self.d_dt_next = torch.full((1,), dt0, dtype=f32, device=dev)
+        self.d_t = torch.zeros(1, dtype=torch.float64, device=dev)      # simulated time, summed on the device like dt
         self.iterations = 0
         self.n_int = n0
         self.edge_start = n0
@@ -153,6 +156,9 @@ class MultiGpuEngine:
         # for the halo (CALC_VISC + UPDATE_EXTERNAL, src/integrators/PredictorCorrectorIntegrator.cc:460-480)
         self.sps = self.sp.turbmodel == D.SPS
         self.tau = [torch.zeros((A, 2), dtype=f32, device=dev) for _ in range(3)] if self.sps else None
+        self.turbvisc = torch.zeros(A, dtype=f32, device=dev) if self.sps else None      # BUFFER_SPS_TURBVISC
+        # ENABLE_XSPH: BUFFER_XSPH, written by every forces pass for the fluid particles, read by the Euler steps
+        self.xsph = torch.zeros((A, 4), dtype=f32, device=dev) if (self.sp.simflags & D.ENABLE_XSPH) else None
         self.filters = []            # [(FilterType, frequency)]
         # bodies with prescribed motion: every rank runs the same host kinematics (the callback is a pure function of time)
         self.bodies = None
@@ -230,6 +236,8 @@ class MultiGpuEngine:
             self.edge_start = self.n_int
         else:
             self._update_segments_and_halo()
+        if self.clobber_neibslist:
+            K.memset(self.neibslist, 0xFF)
         K.build_neibs(self.neibslist, self.pos, self.info, self.hash, self.cellStart, self.cellEnd, self.n_local, self.n_int)
 
     def _update_segments_and_halo(self):
@@ -283,22 +291,28 @@ class MultiGpuEngine:
         K.find_cell_start(self.cellStart, self.cellEnd, self.hash, n_int, self.n_local)
 
     # ------------------------------------------------------------------ forces / euler
-    def _forces_pass(self, pos, vel, combine_min):
+    def _forces_pass(self, pos, vel, combine_min, run_mode=D.SIMULATE, step=1):
         K = self.k
         K.memset(self.cfl, 0)
-        if self.rbforces is not None:      # rows of body particles owned by other ranks must read zero in the reduction
+        if self.has_rb:      # rows of body particles owned by other ranks must read zero in the reduction
             K.memset(self.rbforces, 0); K.memset(self.rbtorques, 0)
         prof = self.profile_forces is not None and self.is_cuda
         if prof:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-        if self.sps:
-            K.calc_visc(self.tau, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, self.n_int)
+        sps = self.sps and run_mode == D.SIMULATE
+        if sps:   # CALC_VISC on the state the forces read (PredictorCorrectorIntegrator.cc:460-480)
+            K.calc_visc(self.tau, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, self.n_int,
+                        turbvisc=self.turbvisc)
             if self.world > 1:
                 self._exchange(self.tau)
-        args = (self.forces, self.cfl, self.rbforces, self.rbtorques, pos, vel, self.info, self.hash, self.cellStart,
+        args = (self.forces, self.cfl, self.rbforces if self.has_rb else None, self.rbtorques if self.has_rb else None, pos, vel, self.info, self.hash, self.cellStart,
                 self.neibslist, self.n_local)
-        kw = dict(tau=self.tau) if self.sps else {}
+        kw = dict(tau=self.tau) if sps else {}
+        if self.xsph is not None:
+            kw["xsph"] = self.xsph
+        if run_mode != D.SIMULATE or step != 1:
+            kw.update(run_mode=run_mode, step=step)
         if self.world > 1 and self.n_int > self.edge_start:
             # edge stripe first, then the inner stripe while the edge forces travel
             nb1 = K.forces(*args, self.edge_start, self.n_int, 0, **kw)
@@ -340,25 +354,38 @@ class MultiGpuEngine:
                     if self.world > 1:
                         self._exchange([self.vel2])
                     self.vel, self.vel2 = self.vel2, self.vel
+        ekw = dict(xsph=self.xsph) if self.xsph is not None else {}
         if self.bodies is not None:
             dt_host = float(self.d_dt.item())       # the callback needs dt on the host: one synchronisation per step
-        self._forces_pass(self.pos, self.vel, 0)
-        if self.bodies is not None:
+        # predictor: forces(step n) -> n* = n + dt/2 f
+        self._forces_pass(self.pos, self.vel, 0, step=1)
+        if self.bodies is not None:                 # MOVE_BODIES + uploads (PredictorCorrectorIntegrator.cc:550-570)
             m = self.bodies.timestep(1, dt_host, self.t_host); K.set_body_motion(m, self.sp.numforcesbodies > 0)
-        K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1)
-        self._forces_pass(self.pos2, self.vel2, 1)
+        K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1, **ekw)
+        # corrector: forces(step n*) -> n+1 = n + dt f*   (written over n*, then renamed to n)
+        self._forces_pass(self.pos2, self.vel2, 1, step=2)
         if self.bodies is not None:
             m = self.bodies.timestep(2, dt_host, self.t_host); K.set_body_motion(m, self.sp.numforcesbodies > 0)
-        K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2)
-        if self.bodies is not None:
+        K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2, **ekw)
+        if self.bodies is not None:                 # EULER_UPLOAD_OBJECTS_CG in the post-corrector phase (:331-332)
             K.set_body_cg_integration(m)
-            self.t_host += dt_host
+            self._last_motion = m
+            self.t_host += dt_host                  # the same double += float as on the device
         self.pos, self.pos2 = self.pos2, self.pos
         self.vel, self.vel2 = self.vel2, self.vel
+        # TIME_STEP_EPILOGUE: t += dt ; dt = min(dt_pred, dt_corr), over all devices (GPUSPH.cc:650-657)
+        self.d_t.add_(self.d_dt.double())
         if self.world > 1:
-            self.dist.all_reduce(self.d_dt_next, op=self.dist.ReduceOp.MIN)       # dt = min over devices
+            self.dist.all_reduce(self.d_dt_next, op=self.dist.ReduceOp.MIN)
         self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt
         self.iterations += 1
+
+    def run(self, steps):
+        for _ in range(steps):
+            self.step()
+
+    def time(self):
+        return float(self.d_t.item())
 
     # ------------------------------------------------------------------ views
     @property
@@ -381,7 +408,7 @@ class MultiGpuEngine:
         """REDUCE_BODIES_FORCES + REDUCE_BODIES_FORCES_HOST (src/GPUSPH.cc): total force and torque on the feedback body,
         per device over the rows of its own particles, then summed over the devices (one all_reduce of 6 floats).
         The order of the float sum is implementation-defined in the reference too (thrust scan): tolerance-only."""
-        if self.rbforces is None:
+        if not self.has_rb:
             return None
         tot = torch.cat([self.rbforces[:, :3].double().sum(0), self.rbtorques[:, :3].double().sum(0)])
         if self.world > 1:

@@ -58,7 +58,9 @@ class OracleKernels:
     def neibs_info(self):
         return self.info_
 
-    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset, tau=None):
+    def forces(self, forces, cfl, rbforces, rbtorques, pos, vel, info, hash_, cellStart, neibslist, n, frm, to, cfl_offset, tau=None,
+               xsph=None, run_mode=1, step=1):
+        assert xsph is None and run_mode == 1, "the test backend runs SIMULATE without XSPH"
         if to > frm:
             forces[frm:to] = 0          # pre_forces clobber (GPUWorker.cc:1949); the oracle does the reference's RMW
         self.L.orc_forces.restype = C.c_uint32
@@ -84,7 +86,7 @@ class OracleKernels:
             for a in range(3):
                 p.rbcgGridPosE[b][a] = int(m["cg_grid"][b][a]); p.rbcgPosE[b][a] = float(m["cg_pos"][b][a])
 
-    def calc_visc(self, tau, pos, vel, info, hash_, cellStart, neibslist, n, range_end):
+    def calc_visc(self, tau, pos, vel, info, hash_, cellStart, neibslist, n, range_end, turbvisc=None):
         tau6 = torch.zeros((len(pos), 6), dtype=torch.float32)
         self.L.orc_sps(C.byref(self.op), _p(tau6), None, _p(pos), _p(vel), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
                        C.c_uint32(n), C.c_uint32(range_end))
@@ -99,7 +101,7 @@ class OracleKernels:
         dt = float(self.L.orc_dtreduce(C.byref(self.op), _p(cfl), C.c_uint32(nblocks), C.c_float(self.sspeed_cfl), C.c_float(self.max_kinvisc)))
         d_dt[0] = min(float(d_dt[0]), dt) if combine_min else dt
 
-    def euler(self, npos, nvel, opos, ovel, info, hash_, forces, n, d_dt, dt_scale, step):
+    def euler(self, npos, nvel, opos, ovel, info, hash_, forces, n, d_dt, dt_scale, step, xsph=None, run_mode=1):
         dt = float(np.float32(d_dt[0].item()) * np.float32(dt_scale))
         self.L.orc_euler(C.byref(self.op), _p(npos), _p(nvel), _p(opos), _p(ovel), _p(info), _p(hash_), _p(forces), None,
                          C.c_uint32(n), C.c_float(dt), C.c_int(step))
