@@ -32,8 +32,8 @@ struct ForcesArgs {
 	float2 *otau0, *otau1, *otau2; float *oturbvisc;   // stress mode of the tiled kernel (SPHX_TURB_STRESS): outputs
 	const float4 *tauPack;   // SPS + tiled kernel: [0,n) = {xx,xy,xz,yy}, [n,2n) = {yz,zz,0,0} (tau_pack_kernel); tauPackN = n
 	uint32_t tauPackN;
-	// tiled kernel: the tile lists of this neighbour list (tile_lists_kernel), [rows][stride] uint32, and the rows per wave
-	const uint32_t *tileList; uint32_t tileListRows, tileListStride;
+	// tiled kernel: the tile lists of this neighbour list (tile_lists_kernel), [rows][stride] uint16, and the rows per wave
+	const uint16_t *tileList; uint32_t tileListRows, tileListStride;
 	const uint32_t *tileWaves;
 	float4 *xsph;        // ENABLE_XSPH: mean velocity correction of fluid particles, else NULL
 	const RbParams *rb;
@@ -596,16 +596,21 @@ __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballo
 // first window slot of that cell as seen from the home cell, then the row itself) and a per-lane "still alive" flag:
 // ~14 of ~70 vector instructions per pair plus a serial LDS round trip.  All of that depends only on the list and the
 // tiling, i.e. it changes once per neighbour-list build, not once per forces pass (20 passes per build), so
-// tile_lists_kernel (below) does it at build time and leaves, per stored neighbour, one uint32:
-//     bits 0..15   LDS byte offset of the neighbour's row in the tile's window (slot*16; the window arrays are parallel)
-//     bits 16..31  byte offset of the shift-table entry of the neighbour's cell (cell code*16)
+// tile_lists_kernel (below) does it at build time and leaves, per stored neighbour, one uint16:
+//     bits 4..15   slot of the neighbour's row in the tile's window, i.e. entry & 0xFFF0 = its LDS byte offset (the window
+//                  arrays are parallel, 16 B per row, <= 4095 rows)
+//     bits 0..3    how far the cell code advances at this entry (codes only grow along a list: the reference visits the 27
+//                  cells in code order); the running code*16 is the byte offset of the shift-table entry.  A jump of more
+//                  than 15 codes is spelled with filler entries (dummy row, advance 15)
+// (A first version kept both offsets in a uint32: two instructions less per pair, but 9.9 GB of list traffic per forces
+// pass at 32 M particles instead of 4.9, at a point where the pass moves 4 TB/s.)
 // Rows [0, nF) hold the fluid section, rows [R-nB, R) the boundary section (first entry in row R-1, like the
 // reference's list runs down from neibboundpos); nF and nB are PER WAVE (multiples of TILE_LIST_BATCH): lanes with
 // shorter lists are padded with the offset of a dummy row (mass 0, far away), so the pair loop has a scalar trip
 // count, no terminator test and no validity flag.  The pair loop is wave-uniform, so the batch number is a scalar
 // and the four rows of a batch are addressed as buffer loads: SGPR descriptor (row base) + SGPR row offset + the
-// per-lane byte offset index*4, which is fixed for the whole tile -- no vector address arithmetic at all.
-struct ListRows { const uint32_t *list; uint32_t rowBytes; uint32_t rows; uint32_t *pin; };
+// per-lane byte offset index*2, which is fixed for the whole tile -- no vector address arithmetic at all.
+struct ListRows { const uint16_t *list; uint32_t rowBytes; uint32_t rows; uint32_t *pin; };
 
 __device__ __forceinline__ void load_list_u(const ListRows &lr, uint32_t voff, int sec, int batch, uint32_t nd[TILE_NB])
 {
@@ -613,12 +618,12 @@ __device__ __forceinline__ void load_list_u(const ListRows &lr, uint32_t voff, i
 	// prefetch in bounds.  No branch around the loads: the compiler must be able to count them (s_waitcnt vmcnt(N)).
 	const int b = min(__builtin_amdgcn_readfirstlane(batch), (int)lr.rows/TILE_NB - 1);
 	const int lowRow = sec ? (int)lr.rows - (b*TILE_NB + TILE_NB) : b*TILE_NB;
-	const uint32_t *row = lr.list + (size_t)lowRow*(lr.rowBytes/4u);
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(row), 0, 0xFFFFFFFF, 0x00020000);
+	const uint16_t *row = lr.list + (size_t)lowRow*(lr.rowBytes/2u);
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(row), 0, 0xFFFFFFFF, 0x00020000);
 #pragma unroll
 	for (int k = 0; k < TILE_NB; ++k) {
 		const int up = sec ? TILE_NB - 1 - k : k;     // rows above lowRow
-		nd[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(up*lr.rowBytes), 0);
+		nd[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)voff, (int)(up*lr.rowBytes), 0);
 	}
 }
 
@@ -680,14 +685,15 @@ __device__ __forceinline__ const float4 &lds_row(const float4 *base, uint32_t by
 // previous LDS read, so the round trips overlap with the arithmetic of the previous pairs.
 template<int TURB>
 __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
-	const float4 *sShift, const float4 *sPos, const float4 *sVel, const float4 *sAux, Gathered &g)
+	const float4 *sShift, const float4 *sPos, const float4 *sVel, const float4 *sAux, uint32_t &codeOff, Gathered &g)
 {
 	constexpr uint32_t WS = TILE_WC(TURB) + 1u;
 #pragma unroll
 	for (int k = 0; k < TILE_HB; ++k) {
 		const uint32_t d = nd[k];
-		const uint32_t L = d & 0xFFFFu;
-		const float4 sh = lds_row(sShift, d >> 16);
+		const uint32_t L = d & 0xFFF0u;
+		codeOff += (d & 0xFu) << 4;                 // v_and + v_lshl_add
+		const float4 sh = lds_row(sShift, codeOff);
 		// == fmaf(-ox, cellsize, pos): ox in {-1,0,1}, so the product is exact
 		g.qx[k] = s.pos.x + sh.x; g.qy[k] = s.pos.y + sh.y; g.qz[k] = s.pos.z + sh.z; g.qw[k] = sh.w;
 		g.npos[k] = lds_row(sPos, L); g.nvel[k] = lds_row(sVel, L);
@@ -822,17 +828,18 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	}
 	int left = nb;
 	Gathered A, B;
-	gather_half<TURB>(lw.q[0], s, sShift, sPos, sVel, sAux, A);
+	uint32_t codeOff = 0;   // running cell code * 16 of this lane's walk through the section
+	gather_half<TURB>(lw.q[0], s, sShift, sPos, sVel, sAux, codeOff, A);
 	// one batch per step; the first half of the NEXT batch is gathered before the second half of this one is computed,
 	// also after the last batch (a clamped, in-bounds prefetch whose rows are never computed): one exit per step and no
 	// second copy of the pair code
 #define SPHX_RING_STEP(J, JN) \
-	gather_half<TURB>(lw.q[J] + TILE_HB, s, sShift, sPos, sVel, sAux, B); \
+	gather_half<TURB>(lw.q[J] + TILE_HB, s, sShift, sPos, sVel, sAux, codeOff, B); \
 	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
 	load_list_u(list, voff, sec, next, lw.q[J]); \
 	pin_batch(list, lw.q[J]); \
 	++next; \
-	gather_half<TURB>(lw.q[JN], s, sShift, sPos, sVel, sAux, A); \
+	gather_half<TURB>(lw.q[JN], s, sShift, sPos, sVel, sAux, codeOff, A); \
 	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
 	if (--left == 0) return;
 	for (;;) {
@@ -978,7 +985,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	}
 	const float inv_h = fast_rcp(p.slength);
 	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
-	ListRows listRows; listRows.list = a.tileList; listRows.rowBytes = a.tileListStride*(uint32_t)sizeof(uint32_t);
+	ListRows listRows; listRows.list = a.tileList; listRows.rowBytes = a.tileListStride*(uint32_t)sizeof(uint16_t);
 	listRows.rows = a.tileListRows; listRows.pin = a.pin;
 	const int wr = (int)(tid/TILE_KW), wcol = (int)(tid - (tid/TILE_KW)*TILE_KW);   // my window cell (tid < 256)
 
@@ -1000,7 +1007,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		o.info = a.info[h.li]; o.pos = a.pos[h.li]; o.vel = a.vel[h.li]; o.hash = a.hash[h.li];
 		if (!STRESS) o.aux = a.aux[h.li];
 		o.waveRows = a.tileWaves[(size_t)t*(TILE_THREADS/64) + (tid >> 6)];
-		const uint32_t vo = h.li*4u;   // byte offset of this particle inside every list row (n < 2^30)
+		const uint32_t vo = h.li*2u;   // byte offset of this particle inside every list row (n < 2^31)
 		preload_list(listRows, vo, 0, o.lwF);
 		// boundary section: most particles have none, so only its first batch is requested up front; the walk
 		// requests the rest when a wave does have boundary neighbours
@@ -1021,7 +1028,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		const bool inRange = hc.inRange, mine = hc.mine;
 		const uint32_t index = hc.index;
 		const bool pairs = ((dc[13] & 1u) || STRESS) && (a.dbg & 3) != 1;   // no fluid anywhere in the window: nothing interacts
-		const uint32_t voff = hc.li*4u;
+		const uint32_t voff = hc.li*2u;
 
 		lds_barrier();   // the previous tile's readers are done with LDS
 		const uint32_t nextTile = sTileQ[1];
@@ -1569,7 +1576,7 @@ __global__ void __launch_bounds__(TILE_THREADS)
 tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t *__restrict__ hash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
 	const uint32_t *__restrict__ tiles, uint32_t *tileCtl,
-	uint32_t *__restrict__ tileList, uint32_t listStride, uint32_t listRows, uint32_t *__restrict__ tileWaves)
+	uint16_t *__restrict__ tileList, uint32_t listStride, uint32_t listRows, uint32_t *__restrict__ tileWaves)
 {
 	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW], sCellBase[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sRowTotal[TILE_WROWS];
@@ -1578,7 +1585,6 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this list
 	const uint32_t numTiles = tileCtl[0];
 	const uint32_t tid = threadIdx.x;
-	const uint32_t dummy = 0u;              // slot 0 of every window is the dummy record; shift code 0
 	// neighbour-cell offset (ox,oy,oz) -> index of that cell in the window table, relative to the
 	// particle's own (row, column): o1 + KW*(o2+1) + 4*KW*(o3+1) + 1 with (o1,o2,o3) the offsets along COORD1..3
 	if (tid < 27) {
@@ -1634,43 +1640,51 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 		bool overflow = false;
 #pragma unroll 1
 		for (int sec = 0; sec < 2 && !overflow; ++sec) {
-			// section 0: slots 0 upward, section 1: slots neibboundpos downward; each ends at its terminator
+			// section 0: slots 0 upward, section 1: slots neibboundpos downward; each ends at its terminator.
+			// Every lane writes its own translated list from row 0 on (`cur`: fillers make lists grow by different amounts),
+			// then all lanes are padded with dummy entries up to the wave's longest, rounded up to whole batches
 			const int maxSlots = sec ? (int)p.neibboundpos + 1 : (int)p.neiblistsize;
 			bool alive = mine;
-			uint32_t code = 0, rows = 0;
+			uint32_t code = 0, prev = 0, cur = 0;
 			bool done = false;
-			// TILE_LIST_LOADS entries per lane in flight (the walk is latency bound: one dependent round trip per step);
-			// the rows are still counted in steps of TILE_LIST_BATCH, so the padding per wave stays below one batch
-			constexpr int LOADS = 16;
-			static_assert(LOADS % TILE_LIST_BATCH == 0, "whole batches per load group");
+			auto put = [&](uint32_t r, uint32_t val) {
+				if (rowsSec[0]*(uint32_t)sec + r >= listRows) { overflow = true; return; }
+				const uint32_t row = sec ? listRows - 1u - r : r;
+				tileList[(size_t)row*listStride + index] = (uint16_t)val;
+			};
+			constexpr int LOADS = 16;   // entries per lane in flight: the walk is latency bound
 #pragma unroll 1
 			for (int s0 = 0; s0 < maxSlots && !done; s0 += LOADS) {
 				uint32_t e[LOADS];
 #pragma unroll
 				for (int k = 0; k < LOADS; ++k) {
-					const int slot = min(s0 + k, maxSlots - 1);   // a clamped re-read is only reached by dead lanes or dropped below
+					const int slot = min(s0 + k, maxSlots - 1);   // a clamped re-read is only reached by dead lanes
 					const int src = sec ? (int)p.neibboundpos - slot : slot;
 					e[k] = list[(size_t)src*stride + index];
 				}
+				if (!wave_any(alive && e[0] != NEIBS_END)) break;   // every list of the wave has ended
 #pragma unroll
-				for (int b0 = 0; b0 < LOADS; b0 += TILE_LIST_BATCH) {
-					if (done) break;
-					// every list of the wave has ended (or the section has): stop without counting this batch
-					if (s0 + b0 >= maxSlots || !wave_any(alive && e[b0] != NEIBS_END)) { done = true; break; }
-					if (rowsSec[0] + rows + TILE_LIST_BATCH > listRows) { overflow = true; done = true; break; }
-#pragma unroll
-					for (int k = b0; k < b0 + TILE_LIST_BATCH; ++k) {
-						const uint32_t dd = e[k];
-						alive = alive && (s0 + k < maxSlots) && (dd != NEIBS_END);
-						code = (dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
-						const uint32_t slotOff = (1u + (uint32_t)myCB[code & 31u] + (dd & NEIBINDEX_MASK))*16u;   // slot 0 = dummy
-						const uint32_t out = alive ? (slotOff | (code << 20)) : dummy;   // code*16 in the high half
-						const uint32_t row = sec ? listRows - 1u - (rows + (uint32_t)(k - b0)) : rows + (uint32_t)(k - b0);
-						if (mine) tileList[(size_t)row*listStride + index] = out;
+				for (int k = 0; k < LOADS; ++k) {
+					const uint32_t dd = e[k];
+					alive = alive && (s0 + k < maxSlots) && (dd != NEIBS_END);
+					code = (dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
+					if (alive && code < prev) { overflow = true; alive = false; }   // not a list of the builder (an overflowed one): generic kernel
+					if (alive && mine) {
+						while (code - prev > 15u) { put(cur++, 15u); prev += 15u; }   // filler: dummy row, advance 15 (rare)
+						const uint32_t slot = 1u + (uint32_t)myCB[code & 31u] + (dd & NEIBINDEX_MASK);   // slot 0 = dummy
+						put(cur++, (slot << 4) | (code - prev));
+						prev = code;
 					}
-					rows += TILE_LIST_BATCH;
 				}
 			}
+			// wave maximum, whole batches
+			uint32_t rows = cur;
+#pragma unroll
+			for (int dd = 32; dd > 0; dd >>= 1) rows = max(rows, (uint32_t)__shfl_xor(rows, dd));
+			rows = (rows + TILE_LIST_BATCH - 1u)/TILE_LIST_BATCH*TILE_LIST_BATCH;
+			if (rowsSec[0]*(uint32_t)sec + rows > listRows) overflow = true;
+			if (mine && !overflow)
+				for (uint32_t r = cur; r < rows; ++r) put(r, 0u);     // pad: dummy row, same cell
 			rowsSec[sec] = rows;
 		}
 		if (overflow) tileCtl[1] = 1u;      // some wave needs more rows than the tile lists have: generic kernel
@@ -1759,7 +1773,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		((ctx->dev.numfluids == 1 && ctx->dev.densitydiff != SPHX_FERRARI) || ctx->dev.kerneltype == SPHX_WENDLAND) &&
 		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles && ctx->tile_list != nullptr &&
-		(uint64_t)ctx->tile_list_stride*sizeof(uint32_t)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
+		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
 	a.tauPack = nullptr; a.tauPackN = 0;
 	a.otau0 = a.otau1 = a.otau2 = nullptr; a.oturbvisc = nullptr;
 	if (use_tiles && ctx->dev.turbmodel == SPHX_SPS) {   // window rows of the stress tensor (see tau_pack_kernel)
@@ -1884,7 +1898,7 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	// the LDS window instead of gathers), then the gather kernel as a stand-by guarded by the tiling's overflow flag
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		ctx->dev.numfluids == 1 && !ctx->disable_tiles && ctx->tile_list != nullptr &&
-		(uint64_t)ctx->tile_list_stride*sizeof(uint32_t)*(TILE_NB - 1) < 0x80000000ull;
+		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*(TILE_NB - 1) < 0x80000000ull;
 	const uint32_t *guard = nullptr;
 	if (use_tiles) {
 		ForcesArgs fa = ForcesArgs();

@@ -701,9 +701,18 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 	const int gs2 = (p.c2 == 0) ? p.gs[0] : (p.c2 == 1) ? p.gs[1] : p.gs[2];
 	const int gs3 = (p.c3 == 0) ? p.gs[0] : (p.c3 == 1) ? p.gs[1] : p.gs[2];
 	const int nG2 = (gs2 + 1)/2, nG3 = (gs3 + 1)/2;
-	const int sr = (int)(blockIdx.x*128 + threadIdx.x);
-	if (sr >= nG2*nG3) return;
-	const int g2 = 2*(sr % nG2), g3 = 2*(sr / nG2);
+	// thread -> row bundle in blocks of 8 x 4 bundles (COORD2 x COORD3): the threads of a wave emit their tiles in step, so
+	// consecutive tile numbers are neighbouring bundles at the same column range, and the forces kernel hands 32 consecutive
+	// tiles to one XCD: with 2-D blocks the windows of those 32 tiles overlap along COORD2 AND COORD3 and re-use each other's
+	// rows in that XCD's L2 (a 1-D run of 32 bundles shares rows along COORD2 only)
+	const int t = (int)(blockIdx.x*128 + threadIdx.x);
+	const int nB2 = (nG2 + 7)/8, nB3 = (nG3 + 3)/4;
+	if (t >= nB2*nB3*32) return;
+	const int blk = t >> 5, within = t & 31;
+	const int b2 = (blk % nB2)*8 + (within & 7), b3 = (blk / nB2)*4 + (within >> 3);
+	if (b2 >= nG2 || b3 >= nG3) return;
+	const int sr = b2 + nG2*b3;
+	const int g2 = 2*b2, g3 = 2*b3;
 	const bool per1 = p.periodic & (1u << p.c1), per2 = p.periodic & (1u << p.c2), per3 = p.periodic & (1u << p.c3);
 
 	auto cell_cnt = [&](int c1v, int c2v, int c3v, bool wrap, uint32_t &start) -> uint32_t {
@@ -938,7 +947,8 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		tile_columns_kernel<<<div_up_u(bundles*(uint32_t)dp.gs1, 256), 256, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy,
 			(const particleinfo*)info, ctx->tile_cols);
 		SPHX_LAUNCH_CHECK("tile_columns_kernel");
-		build_tiles_kernel<<<div_up_u(bundles, 128), 128, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy,
+		const uint32_t tileThreads = ((gs2 + 1)/2 + 7)/8*(((gs3 + 1)/2 + 3)/4)*32u;   // 8 x 4 blocks of bundles, see the kernel
+		build_tiles_kernel<<<div_up_u(tileThreads, 128), 128, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy,
 			ctx->tile_cols, particleRangeEnd, ctx->tiles, ctx->tile_ctl, ctx->tile_capacity);
 		SPHX_LAUNCH_CHECK("build_tiles_kernel");
 		ctx->tiles_built = true;

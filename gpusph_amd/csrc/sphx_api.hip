@@ -110,10 +110,10 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 		SPHX_HIP(hipMalloc((void**)&ctx->tau_pack, sizeof(float4)*2*(size_t)n));
 	ctx->tile_capacity = n/8 + 4096;
 	SPHX_HIP(hipMalloc((void**)&ctx->tiles, sizeof(uint32_t)*TILE_DESC*(size_t)ctx->tile_capacity));
-	if (!ctx->disable_tiles) {   // tile lists: 4 B x (neiblistsize + extra) rows per particle; only the rows in use are ever touched
+	if (!ctx->disable_tiles) {   // tile lists: 2 B x (neiblistsize + extra) rows per particle; only the rows in use are ever touched
 		ctx->tile_list_rows = (ctx->dev.neiblistsize + TILE_LIST_EXTRA)/TILE_LIST_BATCH*TILE_LIST_BATCH;
 		ctx->tile_list_stride = n;
-		SPHX_HIP(hipMalloc((void**)&ctx->tile_list, sizeof(uint32_t)*(size_t)ctx->tile_list_rows*(size_t)n));
+		SPHX_HIP(hipMalloc((void**)&ctx->tile_list, sizeof(uint16_t)*(size_t)ctx->tile_list_rows*(size_t)n));
 		SPHX_HIP(hipMalloc((void**)&ctx->tile_waves, sizeof(uint32_t)*(TILE_THREADS/64)*(size_t)ctx->tile_capacity));
 	}
 	ctx->cells_reserved = (bins - 1)/4;

@@ -140,9 +140,9 @@ struct sphx_ctx {
 	uint32_t   *cell_end_copy; // [cells] cellEnd of the build the tiles belong to
 	uint32_t   *cell_fluid_end;// [cells] first non-fluid particle of each cell (neighbour-list build)
 	// tile lists (forces.hip "Tile lists"): the neighbour lists of the tiled particles translated, at build time, into the
-	// LDS byte offset of each neighbour's window row + the offset of its shift-table entry; [rows][stride] uint32,
+	// window slot of each neighbour + the advance of the cell code; [rows][stride] uint16,
 	// fluid section in rows 0 upward, boundary section in rows tile_list_rows-1 downward, both padded per wave
-	uint32_t   *tile_list;
+	uint16_t   *tile_list;
 	uint32_t    tile_list_rows, tile_list_stride;
 	uint32_t   *tile_waves;    // [tile][TILE_THREADS/64]: rows of the fluid section | rows of the boundary section << 16
 	uint32_t    tile_capacity;
