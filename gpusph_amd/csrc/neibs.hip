@@ -498,13 +498,24 @@ struct NeibRing {
 // never list boundary neighbours, do not visit the non-fluid tail at all.  Candidate order, tests and
 // encodings are the reference's, so the list is bit-identical.
 // Stores go through NeibRing (above), flushed after every neighbour cell.
+typedef uint32_t neib_u32x4 __attribute__((ext_vector_type(4)));
+// candidate row j0 + u of the position array as a buffer load: descriptor in SGPRs, byte offset j0*16 in one VGPR,
+// u*16 in the instruction -- no per-candidate address arithmetic; rows past the array read as zeros
+__device__ __forceinline__ float4 load_pos_row(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int u)
+{
+	const neib_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + 16u*(uint32_t)u), 0, 0);
+	return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+}
+
+// BUF: the position array is smaller than 4 GB and is read through a buffer descriptor
+template<bool BUF>
 __global__ void __launch_bounds__(BLOCK_NEIBS)
 build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	const float4 *__restrict__ posArray, const particleinfo *__restrict__ infoArray,
 	const uint32_t *__restrict__ particleHash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
 	const uint32_t *__restrict__ cellFluidEnd,
-	uint32_t particleRangeEnd, float sqinfluenceradius, NeibsCounters *__restrict__ counters)
+	uint32_t particleRangeEnd, uint32_t posRows, float sqinfluenceradius, NeibsCounters *__restrict__ counters)
 {
 	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING + 1][64];
 	const uint32_t lane = threadIdx.x & 63u;
@@ -532,6 +543,8 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	// boundary particles never list non-fluid neighbours with LJ/DYN boundaries (:596-607)
 	const bool fluidOnly = boundary && (p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY);
 
+	const __amdgpu_buffer_rsrc_t posRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(posArray), 0,
+		BUF ? (int)(posRows*16u) : 0, 0x00020000);
 	const unsigned long long wmask = __builtin_amdgcn_ballot_w64(walking);
 	if (wmask)
 	for (int z = -1; z <= 1; z++) for (int y = -1; y <= 1; y++) for (int x = -1; x <= 1; x++) {
@@ -554,37 +567,61 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 			const float py = fmaf(-(float)y, p.cs[1], pos.y);
 			const float pz = fmaf(-(float)z, p.cs[2], pos.z);
 
-			bool encode_cell = true;
+			const uint32_t code = (cell + 1u) << CELLNUM_SHIFT;
+			uint32_t encv = code;             // cell code still owed to the first entry stored for this (cell, type) run
 			uint32_t neib_type = PT_FLUID;
 			// --- fluid segment: type known, NEIB_MLP position gathers in flight ---
+			// wave-uniform: the last slot a lane may fill in a batch without leaving the ring or the fluid section
+			const uint32_t lim = min(ring.fbase + (uint32_t)NEIB_FRING, p.neibboundpos - 1u);
+			const uint32_t selfrel = (cell == 13u) ? index - bucketStart : 0xFFFFFFFFu;
 			for (uint32_t j0 = bucketStart; j0 < fluidEnd; j0 += NEIB_MLP) {
 				float4 cp[NEIB_MLP];
+				if (BUF) {
 #pragma unroll
-				for (int u = 0; u < NEIB_MLP; ++u) cp[u] = posArray[min(j0 + (uint32_t)u, fluidEnd - 1u)];
-				// branch-free: the scan is instruction-issue bound and every divergent `if` costs 3-4 scalar
-				// instructions of exec-mask bookkeeping per wave (PMC: 1.5 scalar per vector instruction before).
-				// The distance test comes first in the && chain so that the compiler keeps the arithmetic out
-				// of a conditional block; the rare direct stores share one branch per batch.
+					for (int u = 0; u < NEIB_MLP; ++u) cp[u] = load_pos_row(posRsrc, j0*16u, u);
+				} else {
+#pragma unroll
+					for (int u = 0; u < NEIB_MLP; ++u) cp[u] = posArray[min(j0 + (uint32_t)u, fluidEnd - 1u)];
+				}
+				// The scan is instruction-issue bound (PMC: VALU + SALU of this loop), so the common case is a
+				// straight line: every lane writes the candidate at its current slot of the ring and only an accepted
+				// one advances the slot (the next candidate overwrites a rejected one); an inactive candidate turns its
+				// distance into NaN (0*w) instead of a separate test; list-full, ring-full and lanes already storing
+				// directly are excluded per batch by one wave-uniform test and take the general code below.
 				float r2[NEIB_MLP];
 #pragma unroll
 				for (int u = 0; u < NEIB_MLP; ++u) {
 					const float rx = px - cp[u].x, ry = py - cp[u].y, rz = pz - cp[u].z;
 					r2[u] = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
 				}
+				const uint32_t jrel = j0 - bucketStart, rem = fluidEnd - j0;
+				if (!__builtin_amdgcn_ballot_w64(ring.fdirect || nf + (uint32_t)NEIB_MLP > lim)) {
+#pragma unroll
+					for (int u = 0; u < NEIB_MLP; ++u) {
+						const float r2a = fmaf(0.0f, cp[u].w, r2[u]);
+						bool acc = r2a < sqinfluenceradius;
+						if (u) acc = acc && ((uint32_t)u < rem);
+						if (cell == 13u) acc = acc && (jrel + (uint32_t)u != selfrel);
+						ring.fring[nf % (uint32_t)NEIB_FRING][lane] = (neibdata)(jrel + (uint32_t)u + encv);
+						encv = acc ? 0u : encv;
+						nf += acc ? 1u : 0u;
+					}
+					ring.sf = ring.rf = nf;
+					continue;
+				}
 				uint32_t dslot[NEIB_MLP], dval[NEIB_MLP], dmask = 0;
 #pragma unroll
 				for (int u = 0; u < NEIB_MLP; ++u) {
 					const uint32_t neib_index = j0 + (uint32_t)u;
-					const bool acc = (r2[u] < sqinfluenceradius) && (neib_index < fluidEnd) && (neib_index != index) &&
+					const bool acc = (r2[u] < sqinfluenceradius) && ((uint32_t)u < rem) && (neib_index != index) &&
 						is_active_w(cp[u].w);
 					const uint32_t offset = nf;       // neibListOffset(PT_FLUID)
 					nf += acc ? 1u : 0u;
 					const bool ok = acc && !too_many_neibs(p, nf, nb, nv, PT_FLUID);
-					const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
-					dslot[u] = offset; dval[u] = (neib_index - bucketStart) + enc;
+					dslot[u] = offset; dval[u] = (neib_index - bucketStart) + encv;
 					dmask |= ring.store_f_sel(offset, dval[u], ok) ? (1u << u) : 0u;
 					ring.sf = ok ? nf : ring.sf;
-					encode_cell = encode_cell && !ok;
+					encv = ok ? 0u : encv;
 				}
 				if (dmask) {
 #pragma unroll
@@ -596,8 +633,8 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 				if (neib_index == index) continue;
 				const particleinfo neib_info = infoArray[neib_index];
 				if (IS_TESTPOINT(neib_info)) continue;
-				if (!encode_cell && neib_type != PART_TYPE(neib_info))
-					encode_cell = true;
+				if (neib_type != PART_TYPE(neib_info))
+					encv = code;
 				neib_type = PART_TYPE(neib_info);
 				if ((p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY) &&
 					boundary && IS_BOUNDARY(neib_info))
@@ -610,12 +647,11 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 					const uint32_t num = (neib_type == PT_FLUID) ? nf : (neib_type == PT_BOUNDARY) ? nb : nv;
 					if (neib_type == PT_FLUID) nf++; else if (neib_type == PT_BOUNDARY) nb++; else nv++;
 					if (!too_many_neibs(p, nf, nb, nv, neib_type)) {
-						const uint32_t enc = encode_cell ? ((cell + 1u) << CELLNUM_SHIFT) : 0u;
-						const uint32_t val = (neib_index - bucketStart) + enc;
+						const uint32_t val = (neib_index - bucketStart) + encv;
 						if (neib_type == PT_FLUID) { ring.store_f(num, val); ring.sf = nf; }
 						else if (neib_type == PT_BOUNDARY) { ring.store_b(num, val); ring.sb = nb; }
 						else column[(size_t)neib_list_offset(p, num, neib_type)*p.stride] = (neibdata)val;
-						encode_cell = false;
+						encv = 0u;
 					}
 				}
 			}
@@ -955,9 +991,10 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		ctx->tiles_cellstart = cellStart;
 		ctx->tiles_neibslist = neibsList;
 	}
-	build_neibs_kernel<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
+	const bool posBuf = (size_t)numParticles*16u < ((size_t)1 << 32);
+	(posBuf ? build_neibs_kernel<true> : build_neibs_kernel<false>)<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
 		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
-		particleRangeEnd, sqinfluenceradius, ctx->counters_dev);
+		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	if (ctx->tiles_built) {   // the lists of the tiled particles in the form the tiled forces kernel walks (forces.hip)
 		rc = sphx_tile_lists_launch(ctx, neibsList, hash, cellStart, st);
