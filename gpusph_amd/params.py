@@ -156,7 +156,7 @@ class SimParams:
 
 
 def check_neiblistsize(sp: SimParams, pp: PhysParams, deltap: float):
-    """ProblemCore::check_neiblistsize (src/ProblemCore.cc:806-887), non-SA branch."""
+    """ProblemCore::check_neiblistsize (src/ProblemCore.cc:806-887)."""
     r = math.ceil(sp.sfactor * sp.kernelradius)
     vol = math.ceil(4 * 3.2 * r * r * r / 3)
     neiblistsize = ((int(vol) + 31) // 32) * 32
@@ -164,10 +164,13 @@ def check_neiblistsize(sp: SimParams, pp: PhysParams, deltap: float):
     ratio = max(qq * qq / r, 1.0)
     neiblistsize = int(math.ceil(ratio * neiblistsize))
     neiblistsize = ((neiblistsize + 31) // 32) * 32
+    neibboundpos = neiblistsize - 1
+    if sp.boundarytype == D.SA_BOUNDARY:     # "boundary particles are doubled": the vertex section, :859-865
+        neiblistsize = ((3 * neiblistsize // 2 + 31) // 32) * 32
     if sp.neiblistsize == 0:
         sp.neiblistsize = neiblistsize
     if sp.neibboundpos == 0:
-        sp.neibboundpos = sp.neiblistsize - 1
+        sp.neibboundpos = neibboundpos if sp.boundarytype == D.SA_BOUNDARY else sp.neiblistsize - 1
     return sp.neiblistsize, sp.neibboundpos
 
 

@@ -811,3 +811,121 @@ class StillWater(Problem):
         for a in range(3):
             fl *= max(int(round(fs[a] / dp)), 1) + 1
         return full - inner + fl
+
+
+class SABox(Problem):
+    """A tank with SEMI-ANALYTICAL walls (SA_BOUNDARY), the synthetic counterpart of the reference's Crixus-meshed SA problems
+    (e.g. src/problems/CompleteSaExample.cu; the reference reads such geometry from HDF5 files, src/HDF5SphReader.cc): the floor
+    and the four side walls of an l x w x h tank are meshed by vertex particles (PT_VERTEX) on a square lattice of pitch deltap,
+    every lattice square is cut into two triangular boundary elements (PT_BOUNDARY, placed at the centroid), and water of depth
+    H fills the tank from deltap/2 off the walls.  Per particle, next to pos/vel/info (src/define_buffers.h:168-196):
+      vertices       uint4   ids of the three vertices of a segment (0 elsewhere)
+      boundelements  float4  unit normal towards the fluid and area of a segment (vertices: filled by computeVertexNormal)
+      gradgamma      float4  (grad gamma, gamma); NaN until the boundary-conditions engine initialises it
+    Wendland kernel (the only one the reference's SA code supports, src/cuda/gamma.cuh:241-250)."""
+
+    def __init__(self, deltap=0.05, *, l=0.6, w=0.5, h=0.5, H=0.35, viscosity="DYNAMICVISC", jitter=0.0,
+                 linearization=D.DEFAULT_LINEARIZATION):
+        super().__init__()
+        self.m_name = "SABox"
+        sp, pp = self.simparams, self.physparams
+        sp.kerneltype = D.WENDLAND
+        sp.boundarytype = D.SA_BOUNDARY
+        self.set_viscosity(viscosity)
+        sp.densitydiffusiontype = D.DENSITY_DIFFUSION_NONE
+        sp.simflags = D.ENABLE_DTADAPT
+        sp.dtadaptfactor = 0.3
+        self.linearization = linearization
+        self.jitter = jitter
+        self.set_deltap(deltap)
+        dp = self.m_deltap
+        self.n_l, self.n_w, self.n_h = (int(round(v / dp)) for v in (l, w, h))
+        self.l, self.w, self.h, self.H = self.n_l * dp, self.n_w * dp, self.n_h * dp, float(H)
+        self.m_origin = np.full(3, -2.0 * dp)
+        self.m_size = np.array([self.l, self.w, self.h], dtype=np.float64) + 4.0 * dp
+        g = 9.81
+        pp.gravity = (0.0, 0.0, -g)
+        self.m_maxFall = self.H
+        c0 = math.ceil(10.0 * math.sqrt(2.0 * g * self.H))
+        pp.add_fluid(1000.0)
+        pp.set_equation_of_state(0, 7.0, float(c0))
+        pp.set_kinematic_visc(0, 1.0e-2)
+        # two boundary elements per lattice square inside the wider boundary radius: near a corner of the tank a particle
+        # sees ~150 fluid + boundary neighbours, more than the default section (resize_neiblist, src/ProblemCore.h:341-353)
+        sp.neibboundpos = 256 - 1
+        sp.neiblistsize = 256 + 64
+        self.initialize()
+        self.fill_parts()
+
+    def fill_parts(self):
+        dp = self.m_deltap
+        nl, nw, nh = self.n_l, self.n_w, self.n_h
+        rho0 = self.physparams.rho0[0]
+        # --- wall mesh: faces as (origin node, u step, v step, nu, nv, inward normal) on the integer lattice
+        faces = [((0, 0, 0), (1, 0, 0), (0, 1, 0), nl, nw, (0, 0, 1)),      # floor
+                 ((0, 0, 0), (0, 1, 0), (0, 0, 1), nw, nh, (1, 0, 0)),      # x = 0
+                 ((nl, 0, 0), (0, 1, 0), (0, 0, 1), nw, nh, (-1, 0, 0)),    # x = l
+                 ((0, 0, 0), (1, 0, 0), (0, 0, 1), nl, nh, (0, 1, 0)),      # y = 0
+                 ((0, nw, 0), (1, 0, 0), (0, 0, 1), nl, nh, (0, -1, 0))]    # y = w
+        vid = {}
+        tris, normals = [], []
+        def node(c):
+            return vid.setdefault(c, len(vid))
+        for o, du, dv, nu, nv, nrm in faces:
+            o, du, dv = np.array(o), np.array(du), np.array(dv)
+            for i in range(nu):
+                for j in range(nv):
+                    a = tuple(o + i * du + j * dv); b = tuple(o + (i + 1) * du + j * dv)
+                    c = tuple(o + (i + 1) * du + (j + 1) * dv); d = tuple(o + i * du + (j + 1) * dv)
+                    tris.append((node(a), node(b), node(c))); normals.append(nrm)
+                    tris.append((node(a), node(c), node(d))); normals.append(nrm)
+        vnodes = np.array(sorted(vid, key=vid.get), dtype=np.float64)
+        vpos = vnodes * dp
+        tris = np.array(tris, dtype=np.int64)
+        spos = vpos[tris].mean(axis=1)
+        normals = np.array(normals, dtype=np.float64)
+        # vertex mass: the part of the dp^3 cube around the node that lies inside the tank
+        frac = np.ones(len(vnodes))
+        for a, n in enumerate((nl, nw, nh)):
+            frac *= np.where((vnodes[:, a] == 0) | (vnodes[:, a] == n), 0.5, 1.0)
+        # --- water
+        fn = [nl, nw, max(int(round(self.H / dp)), 1)]
+        fluid = (_lattice(0, fn[0] - 1, 0, fn[1] - 1, 0, fn[2] - 1).astype(np.float64) + 0.5) * dp
+        if self.jitter:
+            rng = np.random.default_rng(777)
+            fluid = fluid + rng.uniform(-self.jitter * dp, self.jitter * dp, size=fluid.shape)
+        self.water_level = fn[2] * dp
+        nf, ns, nv = len(fluid), len(spos), len(vpos)
+        ntot = nf + ns + nv
+        pos = np.empty((ntot, 4), dtype=np.float64)
+        pos[:nf, :3] = fluid; pos[nf:nf + ns, :3] = spos; pos[nf + ns:, :3] = vpos
+        pos[:nf + ns, 3] = rho0 * dp ** 3
+        pos[nf + ns:, 3] = rho0 * dp ** 3 * frac
+        vel = np.zeros((ntot, 4), dtype=np.float32)
+        vel[:, 3] = self.initial_density(pos)
+        tf = np.empty(ntot, dtype=np.uint16)
+        tf[:nf] = D.PT_FLUID; tf[nf:nf + ns] = D.PT_BOUNDARY; tf[nf + ns:] = D.PT_VERTEX
+        ids = np.arange(ntot, dtype=np.uint32)
+        info = make_particleinfo(tf, np.zeros(ntot, dtype=np.uint16), ids)
+        self.parts = HostParticles(pos, vel, info)
+        self.vertices = np.zeros((ntot, 4), dtype=np.uint32)
+        self.vertices[nf:nf + ns, :3] = (tris + nf + ns).astype(np.uint32)          # vertex ids
+        self.boundelements = np.full((ntot, 4), np.nan, dtype=np.float32)
+        self.boundelements[nf:nf + ns, :3] = normals
+        self.boundelements[nf:nf + ns, 3] = 0.5 * dp * dp
+        self.gradgamma = np.full((ntot, 4), np.nan, dtype=np.float32)
+        self.num_fluid, self.num_segments, self.num_vertices, self.num_obstacle = nf, ns, nv, 0
+        self.num_wall = ns + nv
+        self.rb_firstindex = np.zeros(0, dtype=np.int32)
+        self.rb_cg_gridpos = np.zeros((0, 3), dtype=np.int32)
+        self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)
+
+    def initial_density(self, pos_global):
+        pp = self.physparams
+        depth = np.clip(self.water_level - pos_global[:, 2], 0.0, None)
+        return (np.power(1.0 + pp.rho0[0] * 9.81 * depth / pp.bcoeff[0], 1.0 / pp.gammacoeff[0]) - 1.0).astype(np.float32)
+
+    def copy_to_array(self):
+        a = super().copy_to_array()
+        a.update(vertices=self.vertices.copy(), boundelements=self.boundelements.copy(), gradgamma=self.gradgamma.copy())
+        return a

@@ -457,12 +457,39 @@ static inline float sqlength3(float x, float y, float z)
 	return fmaf(z, z, fmaf(y, y, x*x));
 }
 
-/* neibsInCell, :536-644 (non-SA) */
+/* what neibsInCell needs of a segment with SA boundaries: sa_boundary_niC_vars, :147-190 */
+typedef struct {
+	float boundNlSqInflRad;
+	const uint32_t *vertices;        /* vertexinfo = uint4, src/particleinfo.h:97 */
+	float coord1[3], coord2[3];
+	float *vertPos[3];               /* float2 arrays */
+} sa_nic;
+
+static void sa_nic_coords(sa_nic *sa, const orc_f4 *boundElement)
+{
+	const float bx = boundElement->x, by = boundElement->y, bz = boundElement->z;
+	const int j = (fabsf(bz) < fabsf(by) && fabsf(bz) < fabsf(bx)) ? 2 : (fabsf(by) < fabsf(bx) ? 1 : 0);
+	/* 0 -> (0, z, -y); 1 -> (-z, 0, x); 2 -> (y, -x, 0) */
+	const float c[3] = {
+		-((j == 1)*bz) + (j == 2)*by,
+		(j == 0)*bz - ((j == 2)*bx),
+		-((j == 0)*by) + (j == 1)*bx };
+	/* normalize(float4): v*rsqrtf(sqlength(v)), src/vector_math.h:1204-1208 (w = 0) */
+	const float inv = 1.0f/sqrtf(fmaf(0.0f, 0.0f, fmaf(c[2], c[2], fmaf(c[1], c[1], c[0]*c[0]))));
+	for (int a = 0; a < 3; ++a) sa->coord1[a] = c[a]*inv;
+	/* cross3(boundElement, coord1), src/vector_math.h:1177-1180: a.y*b.z - a.z*b.y contracts to fma(a.y, b.z, -(a.z*b.y)) */
+	sa->coord2[0] = fmaf(by, sa->coord1[2], -(bz*sa->coord1[1]));
+	sa->coord2[1] = fmaf(bz, sa->coord1[0], -(bx*sa->coord1[2]));
+	sa->coord2[2] = fmaf(bx, sa->coord1[1], -(by*sa->coord1[0]));
+}
+
+/* neibsInCell, :536-644 */
 static void neibs_in_cell(const orc_params *p, uint16_t *neibsList,
 	const orc_f4 *posArray, const orc_info *infoArray,
 	const uint32_t *cellStart, const uint32_t *cellEnd,
 	const int gridPos_in[3], const int gridOffset[3], unsigned cell,
-	uint32_t index, const float pos_in[3], uint32_t *neibs_num, int boundary, float sqinfluenceradius)
+	uint32_t index, const float pos_in[3], uint32_t *neibs_num, int boundary, float sqinfluenceradius,
+	const sa_nic *sa)
 {
 	int gridPos[3] = { gridPos_in[0], gridPos_in[1], gridPos_in[2] };
 	if (!calc_neib_cell(p, gridPos, gridOffset))
@@ -504,7 +531,10 @@ static void neibs_in_cell(const orc_params *p, uint16_t *neibsList,
 			continue;
 
 		const float rx = pos[0] - neib_pos.x, ry = pos[1] - neib_pos.y, rz = pos[2] - neib_pos.z;
-		const int close_enough = sqlength3(rx, ry, rz) < sqinfluenceradius;
+		const float rp2 = sqlength3(rx, ry, rz);
+		/* isCloseEnough, :389-408: with SA boundaries, boundary neighbours a little farther out are kept */
+		const int close_enough = (rp2 < sqinfluenceradius) ||
+			(p->boundarytype == ORC_SA_BOUNDARY && sa && rp2 < sa->boundNlSqInflRad && BOUNDARY(neib_info));
 
 		if (close_enough) {
 			const uint32_t offset = neib_list_offset(p, neibs_num[neib_type], neib_type);
@@ -517,6 +547,16 @@ static void neibs_in_cell(const orc_params *p, uint16_t *neibsList,
 				encode_cell = 0;
 			}
 		}
+		/* process_niC_segment<SA_BOUNDARY>, :433-463: projected position of the segment's own vertices */
+		if (boundary && sa && sa->vertices) {
+			const uint32_t nid = orc_info_id(neib_info);
+			const uint32_t *v = sa->vertices + 4*(size_t)index;
+			const int i = (nid == v[0]) ? 0 : (nid == v[1]) ? 1 : (nid == v[2]) ? 2 : -1;
+			if (i > -1) {
+				sa->vertPos[i][2*(size_t)index]     = fmaf(rz, sa->coord1[2], fmaf(ry, sa->coord1[1], rx*sa->coord1[0]));
+				sa->vertPos[i][2*(size_t)index + 1] = fmaf(rz, sa->coord2[2], fmaf(ry, sa->coord2[1], rx*sa->coord2[0]));
+			}
+		}
 	}
 }
 
@@ -526,17 +566,39 @@ void orc_build_neibs(const orc_params *p, uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, float sqinfluenceradius,
 	orc_neibs_info *out)
 {
+	orc_build_neibs_sa(p, neibsList, NULL, NULL, NULL, posArray, infoArray, NULL, NULL, particleHash, cellStart, cellEnd,
+		numParticles, particleRangeEnd, sqinfluenceradius, sqinfluenceradius, out);
+}
+
+/* buildNeibsListDevice with the SA_BOUNDARY members of buildneibs_params (src/cuda/buildneibs_params.h:66-115):
+ * vertices / boundElements of the segments (read), vertPos0..2 (written for segments), boundNlSqInflRad */
+void orc_build_neibs_sa(const orc_params *p, uint16_t *neibsList,
+	float *vertPos0, float *vertPos1, float *vertPos2,
+	const orc_f4 *posArray, const orc_info *infoArray,
+	const uint32_t *vertices, const orc_f4 *boundElements, const uint32_t *particleHash,
+	const uint32_t *cellStart, const uint32_t *cellEnd,
+	uint32_t numParticles, uint32_t particleRangeEnd, float sqinfluenceradius, float boundNlSqInflRad,
+	orc_neibs_info *out)
+{
 	(void)numParticles;
 	long long numInteractions = 0;
-	int maxNeibs = 0;
+	int maxNeibs = 0, maxVertexNeibs = 0;
 	int hasTooMany = -1;
 	int hasMax[3] = {0, 0, 0};
 
-#pragma omp parallel for schedule(dynamic, 1024) reduction(+:numInteractions) reduction(max:maxNeibs)
+#pragma omp parallel for schedule(dynamic, 1024) reduction(+:numInteractions) reduction(max:maxNeibs) reduction(max:maxVertexNeibs)
 	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
 		uint32_t neibs_num[PT_TESTPOINT] = {0, 0, 0};
 		do {
 			const orc_info info = infoArray[index];
+			sa_nic sa;
+			const int with_sa = p->boundarytype == ORC_SA_BOUNDARY && vertices && boundElements;
+			if (with_sa) {
+				sa.boundNlSqInflRad = boundNlSqInflRad;
+				sa.vertices = vertices;
+				sa.vertPos[0] = vertPos0; sa.vertPos[1] = vertPos1; sa.vertPos[2] = vertPos2;
+				if (BOUNDARY(info)) sa_nic_coords(&sa, &boundElements[index]);   /* only a segment uses them */
+			}
 			int build_nl = FLUID(info) || TESTPOINT(info) || FLOATING(info) || COMPUTE_FORCE(info);
 			if (p->boundarytype == ORC_SA_BOUNDARY)
 				build_nl = build_nl || VERTEX(info) || BOUNDARY(info);
@@ -556,7 +618,7 @@ void orc_build_neibs(const orc_params *p, uint16_t *neibsList,
 						const int off[3] = { x, y, z };
 						neibs_in_cell(p, neibsList, posArray, infoArray, cellStart, cellEnd,
 							gridPos, off, (x + 1) + (y + 1)*3 + (z + 1)*9,
-							index, pos3, neibs_num, BOUNDARY(info), sqinfluenceradius);
+							index, pos3, neibs_num, BOUNDARY(info), sqinfluenceradius, with_sa ? &sa : NULL);
 					}
 		} while (0);
 
@@ -587,12 +649,13 @@ void orc_build_neibs(const orc_params *p, uint16_t *neibsList,
 		/* neibcount reduction, :1141-1182 */
 		const int nm = neibs_num[PT_FLUID] + neibs_num[PT_BOUNDARY];
 		if (nm > maxNeibs) maxNeibs = nm;
+		if (p->boundarytype == ORC_SA_BOUNDARY && (int)neibs_num[PT_VERTEX] > maxVertexNeibs) maxVertexNeibs = neibs_num[PT_VERTEX];
 		numInteractions += nm + neibs_num[PT_VERTEX];
 	}
 	if (out) {
 		out->numInteractions = (int32_t)numInteractions;
 		out->maxFluidBoundaryNeibs = maxNeibs;
-		out->maxVertexNeibs = 0;
+		out->maxVertexNeibs = maxVertexNeibs;
 		out->hasTooManyNeibs = hasTooMany;
 		out->hasMaxNeibs[0] = hasMax[0]; out->hasMaxNeibs[1] = hasMax[1]; out->hasMaxNeibs[2] = hasMax[2];
 	}
@@ -1768,5 +1831,170 @@ void orc_surface(const orc_params *p, orc_info *infoArray, orc_f4 *normals /* ma
 			normal.x /= normal_length; normal.y /= normal_length; normal.z /= normal_length;
 			normals[index] = normal;
 		}
+	}
+}
+
+/* ====================================================================================================
+ * Semi-analytical boundaries: solid walls, no open boundaries, no k-epsilon.
+ * src/cuda/boundary_conditions_kernel.cu; the template switches of sa_segment_bc_params / sa_vertex_bc_params
+ * (has_io, has_keps) are both off, has_moving follows ENABLE_MOVING_BODIES.
+ * ==================================================================================================== */
+
+/* RHO, src/cuda/phys_core.cu:106-112 (__powf -> powf): relative density from pressure */
+float orc_RHO(const orc_params *p, float pres, int i)
+{
+	return (float)(powf(pres/p->bcoeff[i] + 1.0f, 1.0f/p->gammacoeff[i]) - 1.0);
+}
+
+static inline int has_vertex(const uint32_t *verts, uint32_t id)   /* src/particleinfo.h has_vertex */
+{
+	return verts[0] == id || verts[1] == id || verts[2] == id;
+}
+
+/* computeVertexNormalDevice, :1766-1831 (no open boundaries: every adjacent segment contributes) */
+void orc_sa_compute_vertex_normal(const orc_params *p, orc_f4 *boundelement, const uint32_t *vertices,
+	const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t particleRangeEnd)
+{
+#pragma omp parallel for schedule(dynamic, 1024)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!VERTEX(info)) continue;
+		const orc_f4 pos = { 0.0f, 0.0f, 0.0f, 0.0f };
+		const uint32_t our_id = orc_info_id(info);
+		float avg[3] = { 0.0f, 0.0f, 0.0f };
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			if (!has_vertex(vertices + 4*(size_t)neib_index, our_id)) continue;
+			const orc_f4 be = boundelement[neib_index];
+			avg[0] += be.x*be.w; avg[1] += be.y*be.w; avg[2] += be.z*be.w;
+		}
+		const float inv = 1.0f/sqrtf(avg[0]*avg[0] + avg[1]*avg[1] + avg[2]*avg[2]);   /* normalize(): v*rsqrtf(sqlength) */
+		boundelement[index].x = avg[0]*inv; boundelement[index].y = avg[1]*inv; boundelement[index].z = avg[2]*inv;
+		boundelement[index].w = NAN;
+	}
+}
+
+/* common_ndata, :633-657: a fluid neighbour of a segment or vertex */
+typedef struct { float r, w, press; orc_f4 vel; } sa_ndata;
+static inline sa_ndata sa_fluid_ndata(const orc_params *p, float wcoeff, float wsub, const orc_f4 *velArray,
+	const orc_info *infoArray, uint32_t neib_index, float rx, float ry, float rz, float neib_mass)
+{
+	sa_ndata n;
+	const int nfl = FLUID_NUM(infoArray[neib_index]);
+	n.vel = velArray[neib_index];
+	n.r = sqrtf(rx*rx + ry*ry + rz*rz);
+	n.w = W_c(p->kerneltype, n.r, p->slength, wcoeff, wsub)*neib_mass/physical_density(p, n.vel.w, nfl);
+	n.press = orc_P(p, n.vel.w, nfl);
+	return n;
+}
+
+/* saSegmentBoundaryConditionsDevice :1425-1520 and saSegmentBoundaryConditionsRepackDevice :1544-1640
+ * (they differ by the moving-body velocity, which the repack variant leaves out).  In place: reads fluid and vertex
+ * rows, writes boundary rows of vel and gGam. */
+void orc_sa_segment_bc(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray, const orc_f4 *posArray,
+	const uint32_t *vertices, const orc_f4 *boundelement, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd, int step, int repack)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const int has_moving = (p->simflags & ORC_ENABLE_MOVING_BODIES) != 0;
+	if (step == -1) step = 0;     /* "step -1 is the same as step 0", boundary_conditions.cu:177-180 */
+#pragma omp parallel for schedule(dynamic, 1024)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!BOUNDARY(info)) continue;
+		const orc_f4 pos = posArray[index];
+		const orc_f4 normal = boundelement[index];
+		const uint32_t *verts = vertices + 4*(size_t)index;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+
+		/* common_pout, common_segment_pout :390-432 */
+		float sumpWall = 0.0f, shepard_div = 0.0f;
+		orc_f4 gGam = { 0.0f, 0.0f, 0.0f, gGamArray[index].w };
+		orc_f4 vel = { 0.0f, 0.0f, 0.0f, 0.0f };
+		const int calcGam = has_moving || !isfinite(gGam.w) || step == 0;
+		if (calcGam) gGam.w = 0.0f;
+
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_VERTEX, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			if (INACTIVE(posArray[neib_index])) continue;
+			if (!has_vertex(verts, orc_info_id(infoArray[neib_index]))) continue;
+			if (has_moving && !repack && MOVING(info)) {        /* moving_vertex_contrib :781-793 */
+				const orc_f4 nv = velArray[neib_index];
+				vel.x += nv.x; vel.y += nv.y; vel.z += nv.z;
+			}
+			if (calcGam) {
+				const orc_f4 g = gGamArray[neib_index];
+				gGam.x += g.x; gGam.y += g.y; gGam.z += g.z; gGam.w += g.w;
+			}
+		}
+		if (calcGam) {
+			const float inv = 1.0f/3;      /* float4 /= float */
+			gGam.x *= inv; gGam.y *= inv; gGam.z *= inv; gGam.w *= inv;
+			gGamArray[index] = gGam;
+			gGam.w = fmaxf(gGam.w, 1e-5f);
+		}
+		if (!repack) { vel.x /= 3; vel.y /= 3; vel.z /= 3; }
+
+		const int fl = FLUID_NUM(info);
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			if (INACTIVE(npos)) continue;
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const sa_ndata n = sa_fluid_ndata(p, wcoeff, wsub, velArray, infoArray, neib_index, rx, ry, rz, npos.w);
+			if (!(n.r < p->influenceradius && (normal.x*rx + normal.y*ry + normal.z*rz) < 0.0f)) continue;
+			const float gdot = p->gravity[0]*rx + p->gravity[1]*ry + p->gravity[2]*rz;
+			sumpWall += fmaxf(n.press + physical_density(p, n.vel.w, fl)*gdot, 0.0f)*n.w;
+			shepard_div += n.w;
+		}
+		/* impose_solid_bc :1295-1306 */
+		shepard_div = fmaxf(shepard_div, 0.1f*gGam.w);
+		vel.w = orc_RHO(p, sumpWall/shepard_div, fl);
+		velArray[index] = vel;
+	}
+}
+
+/* saVertexBoundaryConditionsDevice :2195-2253 and its Repack twin: density of vertex particles from the fluid */
+void orc_sa_vertex_bc(const orc_params *p, orc_f4 *velArray, const orc_f4 *gGamArray, const orc_f4 *posArray,
+	const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t particleRangeEnd)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+#pragma omp parallel for schedule(dynamic, 1024)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!VERTEX(info)) continue;
+		const orc_f4 pos = posArray[index];
+		const float gam = gGamArray[index].w;
+		const int fl = FLUID_NUM(info);
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		float sumpWall = 0.0f, shepard_div = 0.0f;
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			if (INACTIVE(npos)) continue;
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const sa_ndata n = sa_fluid_ndata(p, wcoeff, wsub, velArray, infoArray, neib_index, rx, ry, rz, npos.w);
+			if (n.r < p->influenceradius) {
+				const float gdot = p->gravity[0]*rx + p->gravity[1]*ry + p->gravity[2]*rz;
+				sumpWall += fmaxf(n.press + physical_density(p, n.vel.w, fl)*gdot, 0.0f)*n.w;
+				shepard_div += n.w;
+			}
+		}
+		shepard_div = fmaxf(shepard_div, 0.1f*gam);
+		velArray[index].w = orc_RHO(p, sumpWall/shepard_div, fl);
 	}
 }

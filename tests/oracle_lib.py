@@ -196,6 +196,33 @@ class Oracle:
                                C.c_uint32(n), C.c_uint32(range_end), C.c_float(sqinfl), C.byref(out))
         return nl, out
 
+    # ---- SA_BOUNDARY (oracle/sph_oracle.c "Semi-analytical boundaries")
+    def build_neibs_sa(self, pos, info, vertices, boundelements, hash_, cs, ce, n, range_end, sqinfl, bound_sqinfl):
+        stride = int(self.p.neiblist_stride)
+        nl = np.full(int(self.p.neiblistsize) * stride, 0xFFFF, dtype=np.uint16)
+        vp = [np.zeros((len(pos), 2), dtype=np.float32) for _ in range(3)]
+        out = OrcNeibsInfo()
+        self.L.orc_build_neibs_sa(C.byref(self.p), P(nl), P(vp[0]), P(vp[1]), P(vp[2]), P(pos), P(info), P(vertices),
+                                  P(boundelements), P(hash_), P(cs), P(ce), C.c_uint32(n), C.c_uint32(range_end),
+                                  C.c_float(sqinfl), C.c_float(bound_sqinfl), C.byref(out))
+        return nl, vp, out
+
+    def sa_compute_vertex_normal(self, boundelements, vertices, info, hash_, cs, nl, n):
+        be = boundelements.copy()
+        self.L.orc_sa_compute_vertex_normal(C.byref(self.p), P(be), P(vertices), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n))
+        return be
+
+    def sa_segment_bc(self, pos, vel, ggam, vertices, boundelements, info, hash_, cs, nl, n, step, repack=False):
+        v, g = vel.copy(), ggam.copy()
+        self.L.orc_sa_segment_bc(C.byref(self.p), P(v), P(g), P(pos), P(vertices), P(boundelements), P(info), P(hash_), P(cs),
+                                 P(nl), C.c_uint32(n), C.c_int(step), C.c_int(1 if repack else 0))
+        return v, g
+
+    def sa_vertex_bc(self, pos, vel, ggam, info, hash_, cs, nl, n):
+        v = vel.copy()
+        self.L.orc_sa_vertex_bc(C.byref(self.p), P(v), P(ggam), P(pos), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n))
+        return v
+
     def forces(self, pos, vel, info, hash_, cs, nl, n, frm=0, to=None, cfl_offset=0, compute_object_forces=0,
                rb_count=0, tau=None):
         to = n if to is None else to

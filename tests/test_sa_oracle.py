@@ -1,0 +1,124 @@
+"""SA_BOUNDARY data path and boundary-conditions engine, CPU side: the oracle against answers that do not depend on
+its own restatement (brute force, geometry, hydrostatics)."""
+import numpy as np
+import pytest
+
+from gpusph_amd import defs as D
+from gpusph_amd.problem import SABox, info_id, info_type
+from sa_helpers import sa_oracle_state, list_sections, analytic_vertex_gamma
+
+
+@pytest.fixture(scope="module")
+def st():
+    return sa_oracle_state(deltap=0.05)
+
+
+def test_list_geometry_follows_the_reference_rule():
+    # ProblemCore::check_neiblistsize: boundary section marker from the un-expanded size, 1.5x list for the vertex section
+    from gpusph_amd.params import SimParams, PhysParams, check_neiblistsize
+    sp, pp = SimParams(), PhysParams()
+    sp.boundarytype = D.SA_BOUNDARY
+    sp.set_smoothing(1.3, 0.05)
+    pp.r0 = 0.05
+    assert check_neiblistsize(sp, pp, 0.05) == (192, 127)
+    p = SABox(0.05)       # the mirror resizes it: resize_neiblist(256, 64)
+    assert (p.simparams.neiblistsize, p.simparams.neibboundpos) == (320, 255)
+
+
+def test_three_sections_equal_brute_force(st):
+    p = st["problem"]
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    r2 = st["sqinfl"]; rb2 = st["bound_sqinfl"]
+    rng = np.random.default_rng(5)
+    picks = np.concatenate([rng.choice(np.where(t == k)[0], 25, replace=False) for k in (D.PT_FLUID, D.PT_BOUNDARY, D.PT_VERTEX)])
+    cells = p.grid_pos_from_hash(st["hash"])
+    for i in picks:
+        d2 = ((g - g[i]) ** 2).sum(axis=1)
+        d2[i] = np.inf
+        d2[np.abs(cells - cells[i]).max(axis=1) > 1] = np.inf    # the search covers the 27 cells around the particle's own
+        fl, bd, vx = list_sections(st, int(i))
+        assert sorted(fl) == sorted(np.where((t == D.PT_FLUID) & (d2 < r2 * (1 - 1e-6)))[0].tolist()) or \
+            set(np.where((t == D.PT_FLUID) & (d2 < r2 * (1 - 1e-5)))[0]) <= set(fl) <= set(np.where((t == D.PT_FLUID) & (d2 < r2 * (1 + 1e-5)))[0])
+        # boundary neighbours are kept out to the wider radius (isCloseEnough<SA_BOUNDARY>)
+        assert set(np.where((t == D.PT_BOUNDARY) & (d2 < rb2 * (1 - 1e-5)))[0]) <= set(bd) <= set(np.where((t == D.PT_BOUNDARY) & (d2 < rb2 * (1 + 1e-5)))[0])
+        assert set(np.where((t == D.PT_VERTEX) & (d2 < r2 * (1 - 1e-5)))[0]) <= set(vx) <= set(np.where((t == D.PT_VERTEX) & (d2 < r2 * (1 + 1e-5)))[0])
+    assert rb2 > r2
+    assert st["neibs_info"].maxVertexNeibs > 0 and st["neibs_info"].hasTooManyNeibs == -1
+
+
+def test_segments_list_their_own_vertices_and_vertpos_is_the_in_plane_offset(st):
+    p = st["problem"]
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    ids = info_id(st["info"])
+    where = {int(v): k for k, v in enumerate(ids)}
+    segs = np.where(t == D.PT_BOUNDARY)[0]
+    for i in segs[::7]:
+        vx = list_sections(st, int(i))[2]
+        own = [where[int(v)] for v in st["vertices"][i, :3]]
+        assert set(own) <= set(vx)
+        nrm = st["boundelements"][i, :3].astype(np.float64)
+        for k, j in enumerate(own):
+            rel = g[i] - g[j]                       # relPos = segment - vertex
+            vp = st["vertpos"][k][i].astype(np.float64)
+            # (coord1, coord2, normal) is an orthonormal frame: the projection keeps the in-plane length
+            assert abs(np.hypot(*vp) - np.linalg.norm(rel - nrm * (rel @ nrm))) < 1e-6
+        # the three offsets of a triangle about its centroid sum to zero
+        assert np.abs(sum(st["vertpos"][k][i].astype(np.float64) for k in range(3))).max() < 1e-6
+    fluid = np.where(t == D.PT_FLUID)[0]
+    assert not any(st["vertpos"][k][fluid].any() for k in range(3))
+
+
+def test_vertex_normals_average_the_adjacent_segments(st):
+    o, p = st["oracle"], st["problem"]
+    be = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], st["info"], st["hash"], st["cs"], st["nl"], st["n"])
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    dp = p.m_deltap
+    vx = np.where(t == D.PT_VERTEX)[0]
+    assert np.allclose(np.linalg.norm(be[vx, :3], axis=1), 1.0, atol=1e-6) and np.isnan(be[vx, 3]).all()
+    # a vertex in the middle of the floor points up; one on the floor/x=0 edge points along (1,0,1)/sqrt2
+    mid = [i for i in vx if abs(g[i, 2]) < 1e-5 and 2 * dp < g[i, 0] < p.l - 2 * dp and 2 * dp < g[i, 1] < p.w - 2 * dp]
+    assert mid and np.allclose(be[mid, :3], [0, 0, 1], atol=1e-6)
+    edge = [i for i in vx if abs(g[i, 2]) < 1e-5 and abs(g[i, 0]) < 1e-5 and 2 * dp < g[i, 1] < p.w - 2 * dp]
+    assert edge and np.allclose(be[edge, :3], np.array([1, 0, 1]) / np.sqrt(2), atol=1e-6)
+    seg = np.where(t == D.PT_BOUNDARY)[0]
+    assert np.array_equal(be[seg], st["boundelements"][seg])
+
+
+def test_wall_density_of_a_hydrostatic_tank(st):
+    """Every fluid neighbour j contributes P_j + rho g (z_j - z_wall) = rho g (depth of the wall point): the Shepard mean the
+    boundary conditions impose must be the hydrostatic density AT the segment / vertex, whatever the kernel sum looks like."""
+    o, p = st["oracle"], st["problem"]
+    t = info_type(st["info"])
+    gg = st["gradgamma"].copy()
+    vx = np.where(t == D.PT_VERTEX)[0]; seg = np.where(t == D.PT_BOUNDARY)[0]; fl = np.where(t == D.PT_FLUID)[0]
+    gg[vx] = 0; gg[vx, 3] = analytic_vertex_gamma(p, st)[vx]
+    vel, gg1 = o.sa_segment_bc(st["pos"], st["vel"], gg, st["vertices"], st["boundelements"], st["info"], st["hash"], st["cs"],
+                               st["nl"], st["n"], step=0)
+    g = p.global_pos(st["pos"], st["hash"])
+    expect = p.initial_density(g)
+    wet = seg[g[seg, 2] < p.water_level - 1.5 * p.m_deltap]
+    assert len(wet) > 300
+    assert np.abs(vel[wet, 3] - expect[wet]).max() < 0.02 * expect.max()
+    dry = seg[g[seg, 2] > p.water_level + p.simparams.influenceRadius]
+    assert len(dry) and np.all(vel[dry, 3] == 0)                       # no fluid in reach: P = 0 -> rho~ = 0
+    assert np.all(vel[seg, :3] == 0)
+    assert np.array_equal(vel[fl], st["vel"][fl]) and np.array_equal(vel[vx], st["vel"][vx])
+    # gamma of a segment = mean of its three vertices (step 0): 1/2 in the middle of a wall
+    own = {int(v): k for k, v in enumerate(info_id(st["info"]))}
+    for i in seg[::11]:
+        m = np.mean([gg[own[int(v)], 3] for v in st["vertices"][i, :3]], dtype=np.float64)
+        assert abs(gg1[i, 3] - m) < 1e-6
+    assert np.array_equal(gg1[vx], gg[vx])
+    # later steps with a finite gamma leave gGam alone
+    vel2, gg2 = o.sa_segment_bc(st["pos"], vel, gg1, st["vertices"], st["boundelements"], st["info"], st["hash"], st["cs"],
+                                st["nl"], st["n"], step=1)
+    assert np.array_equal(gg2[seg], gg1[seg]) and np.array_equal(vel2[seg], vel[seg])
+    # vertices
+    velv = o.sa_vertex_bc(st["pos"], vel, gg1, st["info"], st["hash"], st["cs"], st["nl"], st["n"])
+    wetv = vx[g[vx, 2] < p.water_level - 1.5 * p.m_deltap]
+    assert len(wetv) > 200
+    assert np.abs(velv[wetv, 3] - expect[wetv]).max() < 0.02 * expect.max()
+    assert np.array_equal(velv[:, :3], vel[:, :3]) and np.array_equal(velv[seg], vel[seg]) and np.array_equal(velv[fl], vel[fl])
