@@ -56,6 +56,10 @@ SIGNATURES = {
     "sphx_gather_rows": (_i, [_vp, _vp, _vp, _u32, _vp, _u32, _vp]),
     "sphx_find_cell_start": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
     "sphx_build_neibs": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _u32, _f, _f, _vp]),
+    "sphx_build_neibs_sa": (_i, [_vp] + [_vp] * 11 + [_u32, _u32, _u32, _f, _f, _vp]),
+    "sphx_sa_compute_vertex_normal": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _vp]),
+    "sphx_sa_segment_bc": (_i, [_vp] + [_vp] * 9 + [_u32, _u32, _f, _f, _f, _i, _i, _vp]),
+    "sphx_sa_vertex_bc": (_i, [_vp] + [_vp] * 7 + [_u32, _u32, _f, _f, _f, _i, _i, _vp]),
     "sphx_neibs_resetinfo": (_i, [_vp, _vp]),
     "sphx_neibs_getinfo": (_i, [_vp, C.POINTER(NeibsInfo), _vp]),
     "sphx_forces_fmax_elements": (_u32, [_u32]),

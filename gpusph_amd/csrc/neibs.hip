@@ -507,10 +507,19 @@ __device__ __forceinline__ float4 load_pos_row(__amdgpu_buffer_rsrc_t rsrc, uint
 	return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
 
+// SA_BOUNDARY members of buildneibs_params (src/cuda/buildneibs_params.h:66-115)
+struct SaNeibArgs {
+	const uint4 *vertices;          // vertexinfo of the segments
+	const float4 *boundElements;    // normal + area of the segments
+	float2 *vertPos[3];             // [out] in-plane offsets of a segment's three vertices
+	float boundNlSqInflRad;         // search radius for boundary neighbours
+};
+
 // BUF: the position array is smaller than 4 GB and is read through a buffer descriptor
-template<bool BUF>
+// SA: semi-analytical boundaries (vertex section, wider boundary radius, VERTPOS of the segments)
+template<bool BUF, bool SA>
 __global__ void __launch_bounds__(BLOCK_NEIBS)
-build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
+build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	const float4 *__restrict__ posArray, const particleinfo *__restrict__ infoArray,
 	const uint32_t *__restrict__ particleHash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
@@ -532,6 +541,7 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	if (inRange) {
 		info = infoArray[index];
 		bool build_nl = IS_FLUID(info) || IS_TESTPOINT(info) || IS_FLOATING(info) || HAS_COMPUTE_FORCE(info);
+		if (SA) build_nl = build_nl || PART_TYPE(info) == PT_VERTEX || IS_BOUNDARY(info);
 		if (p.boundarytype == SPHX_DYN_BOUNDARY) build_nl = true;
 		if (build_nl) {
 			pos = posArray[index];
@@ -542,6 +552,22 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 	const bool boundary = IS_BOUNDARY(info);
 	// boundary particles never list non-fluid neighbours with LJ/DYN boundaries (:596-607)
 	const bool fluidOnly = boundary && (p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY);
+
+	// sa_boundary_niC_vars (:147-190): in-plane frame of a segment, the ids of its vertices
+	uint4 ownVerts = make_uint4(0, 0, 0, 0);
+	float3 coord1 = make_float3(0.0f, 0.0f, 0.0f), coord2 = coord1;
+	if (SA && walking && boundary) {
+		ownVerts = sa.vertices[index];
+		const float4 be = sa.boundElements[index];
+		const int j = (fabsf(be.z) < fabsf(be.y) && fabsf(be.z) < fabsf(be.x)) ? 2 : (fabsf(be.y) < fabsf(be.x) ? 1 : 0);
+		const float cx = -((j == 1)*be.z) + (j == 2)*be.y;
+		const float cy = (j == 0)*be.z - ((j == 2)*be.x);
+		const float cz = -((j == 0)*be.y) + (j == 1)*be.x;
+		const float inv = 1.0f/sqrtf(fmaf(0.0f, 0.0f, fmaf(cz, cz, fmaf(cy, cy, cx*cx))));
+		coord1 = make_float3(cx*inv, cy*inv, cz*inv);
+		coord2 = make_float3(fmaf(be.y, coord1.z, -(be.z*coord1.y)), fmaf(be.z, coord1.x, -(be.x*coord1.z)),
+			fmaf(be.x, coord1.y, -(be.y*coord1.x)));
+	}
 
 	const __amdgpu_buffer_rsrc_t posRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(posArray), 0,
 		BUF ? (int)(posRows*16u) : 0, 0x00020000);
@@ -643,7 +669,16 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 				if (!is_active_w(neib_pos.w)) continue;
 				const float rx = px - neib_pos.x, ry = py - neib_pos.y, rz = pz - neib_pos.z;
 				const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
-				if (r2 < sqinfluenceradius) {
+				// isCloseEnough (:389-408): boundary neighbours a little beyond the radius are kept with SA boundaries
+				const bool close_enough = (r2 < sqinfluenceradius) || (SA && r2 < sa.boundNlSqInflRad && IS_BOUNDARY(neib_info));
+				if (SA && boundary) {      // process_niC_segment (:433-463)
+					const uint32_t nid = info_id(neib_info);
+					const int k = (nid == ownVerts.x) ? 0 : (nid == ownVerts.y) ? 1 : (nid == ownVerts.z) ? 2 : -1;
+					if (k >= 0)
+						sa.vertPos[k][index] = make_float2(fmaf(rz, coord1.z, fmaf(ry, coord1.y, rx*coord1.x)),
+							fmaf(rz, coord2.z, fmaf(ry, coord2.y, rx*coord2.x)));
+				}
+				if (close_enough) {
 					const uint32_t num = (neib_type == PT_FLUID) ? nf : (neib_type == PT_BOUNDARY) ? nb : nv;
 					if (neib_type == PT_FLUID) nf++; else if (neib_type == PT_BOUNDARY) nb++; else nv++;
 					if (!too_many_neibs(p, nf, nb, nv, neib_type)) {
@@ -666,6 +701,11 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 		else ring.store_f(nf, NEIBS_END);
 		overflow |= too_many_neibs(p, nf, nb, nv, PT_BOUNDARY);
 		if (!overflow) ring.store_b(nb, NEIBS_END);
+		if (SA) {
+			overflow |= too_many_neibs(p, nf, nb, nv, PT_VERTEX);
+			const uint32_t marker_pos = overflow ? p.neiblistsize - 1u : p.neibboundpos + 1u + nv;
+			column[(size_t)marker_pos*p.stride] = NEIBS_END;
+		}
 		if (overflow) {
 			const int pid = (int)info_id(info);
 			if (atomicCAS(&counters->hasTooManyNeibs, -1, pid) == -1) {
@@ -677,14 +717,16 @@ build_neibs_kernel(DevParams p, neibdata *__restrict__ neibsList,
 
 	// neibcount: per-block max / total, one atomic pair per wave
 	uint32_t total = nf + nb + nv;
-	uint32_t mx = nf + nb;
+	uint32_t mx = nf + nb, mv = nv;
 #pragma unroll
 	for (int d = 32; d > 0; d >>= 1) {
 		total += __shfl_down(total, d);
 		mx = max(mx, (uint32_t)__shfl_down(mx, d));
+		if (SA) mv = max(mv, (uint32_t)__shfl_down(mv, d));
 	}
 	if ((threadIdx.x & 63u) == 0 && total) {
 		atomicMax(&counters->maxFluidBoundaryNeibs, (int)mx);
+		if (SA) atomicMax(&counters->maxVertexNeibs, (int)mv);
 		atomicAdd(&counters->numInteractions, (int)total);
 	}
 }
@@ -955,8 +997,22 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t gridCells,
 	float sqinfluenceradius, float boundNlSqInflRad, void *stream)
 {
-	(void)boundNlSqInflRad; (void)numParticles;
 	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_build_neibs: constants not set");
+	SPHX_REQUIRE(ctx->params.boundarytype != SPHX_SA_BOUNDARY, "sphx_build_neibs: SA_BOUNDARY lists need sphx_build_neibs_sa");
+	return sphx_build_neibs_sa(ctx, neibsList, nullptr, nullptr, nullptr, pos, info, nullptr, nullptr, hash, cellStart, cellEnd,
+		numParticles, particleRangeEnd, gridCells, sqinfluenceradius, boundNlSqInflRad, stream);
+}
+
+extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *vertPos0, void *vertPos1, void *vertPos2,
+	const void *pos, const void *info, const void *vertices, const void *boundElements, const uint32_t *hash,
+	const uint32_t *cellStart, const uint32_t *cellEnd,
+	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t gridCells,
+	float sqinfluenceradius, float boundNlSqInflRad, void *stream)
+{
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_build_neibs: constants not set");
+	const bool sa = ctx->params.boundarytype == SPHX_SA_BOUNDARY;
+	SPHX_REQUIRE(!sa || (vertPos0 && vertPos1 && vertPos2 && vertices && boundElements),
+		"sphx_build_neibs_sa: SA_BOUNDARY needs BUFFER_VERTICES, BUFFER_BOUNDELEMENTS and BUFFER_VERTPOS");
 	SPHX_REQUIRE(neibsList && pos && info && hash && cellStart && cellEnd, "sphx_build_neibs: missing buffer");
 	SPHX_REQUIRE(gridCells == ctx->params.gridSize[0]*ctx->params.gridSize[1]*ctx->params.gridSize[2],
 		"sphx_build_neibs: gridCells does not match the grid set by set_constants");
@@ -974,7 +1030,7 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 	ctx->tiles_built = false;
 	const bool tile_cols_fit = (size_t)((ctx->dev.gs[ctx->dev.c2] + 1)/2)*(size_t)((ctx->dev.gs[ctx->dev.c3] + 1)/2)*(size_t)ctx->dev.gs1
 		<= (size_t)ctx->cells_reserved/2 + 1024;   // tile_cols allocation (degenerate 1-D grids: generic kernels)
-	if (ctx->tiles && !ctx->disable_tiles && tile_cols_fit) {
+	if (ctx->tiles && !ctx->disable_tiles && tile_cols_fit && !sa) {
 		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
 		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), st));
 		const DevParams &dp = ctx->dev;
@@ -992,8 +1048,13 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		ctx->tiles_neibslist = neibsList;
 	}
 	const bool posBuf = (size_t)numParticles*16u < ((size_t)1 << 32);
-	(posBuf ? build_neibs_kernel<true> : build_neibs_kernel<false>)<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
-		neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
+	SaNeibArgs saArgs;
+	saArgs.vertices = (const uint4*)vertices; saArgs.boundElements = (const float4*)boundElements;
+	saArgs.vertPos[0] = (float2*)vertPos0; saArgs.vertPos[1] = (float2*)vertPos1; saArgs.vertPos[2] = (float2*)vertPos2;
+	saArgs.boundNlSqInflRad = boundNlSqInflRad;
+	(sa ? (posBuf ? build_neibs_kernel<true, true> : build_neibs_kernel<false, true>)
+	    : (posBuf ? build_neibs_kernel<true, false> : build_neibs_kernel<false, false>))<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
+		saArgs, neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
 		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	if (ctx->tiles_built) {   // the lists of the tiled particles in the form the tiled forces kernel walks (forces.hip)

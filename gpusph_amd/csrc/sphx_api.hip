@@ -185,8 +185,15 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	// option combinations built into this library (the rest is SURVEY.md 8f "next")
 	if (sp->sph_formulation != SPHX_SPH_F1 && sp->sph_formulation != SPHX_SPH_F2)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only SPH_F1 and SPH_F2 are built");
-	if (sp->boundarytype != SPHX_DYN_BOUNDARY && sp->boundarytype != SPHX_LJ_BOUNDARY && sp->boundarytype != SPHX_MK_BOUNDARY)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only DYN_BOUNDARY, LJ_BOUNDARY and MK_BOUNDARY are built (SA_BOUNDARY is not)");
+	// SA_BOUNDARY: the neighbour engine (vertex section, VERTPOS) and the boundary-conditions engine of solid walls are built;
+	// the forces / integration / filter engines answer SPHX_ERR_UNSUPPORTED for it (gamma terms, density summation)
+	if (sp->boundarytype < SPHX_LJ_BOUNDARY || sp->boundarytype > SPHX_DYN_BOUNDARY)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx: invalid boundary type");
+	if (sp->boundarytype == SPHX_SA_BOUNDARY) {
+		if (sp->kerneltype != SPHX_WENDLAND)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SA_BOUNDARY needs the Wendland kernel (src/cuda/gamma.cuh:241-250)");
+		SPHX_REQUIRE(sp->neibboundpos + 2 <= sp->neiblistsize, "sphx_set_constants: SA_BOUNDARY needs a vertex section in the neighbour list");
+	}
 	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI &&
 		sp->densitydiffusiontype != SPHX_FERRARI)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: Brezzi density diffusion (an SA_BOUNDARY option in the reference's problems) is not built");

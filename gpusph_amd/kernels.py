@@ -28,6 +28,7 @@ class HipKernels:
             capi.check(self.lib.sphx_set_planes(self.ctx.handle, nrm.ctypes.data, gpos.ctypes.data, lpos.ctypes.data, len(nrm)))
         self.ncells = problem.grid_cells
         sp = problem.simparams
+        self.problem_simparams = sp
         self.compute_object_forces = 1 if sp.numforcesbodies > 0 else 0
         self.sq_nl_radius = float(np.float32(sp.nlSqInfluenceRadius))
         pp = problem.physparams
@@ -97,6 +98,42 @@ class HipKernels:
         capi.check(self.lib.sphx_build_neibs(self.ctx.handle, p(neibslist), p(pos), p(info), p(hash_), p(cellStart),
                                              p(cellEnd), n, range_end, self.ncells, self.sq_nl_radius, self.sq_nl_radius,
                                              self._s()))
+
+    def gather_rows(self, sorted_, unsorted, partindex, n):
+        """the optional arrays of reorderDataAndFindCellStart: sorted[i] = unsorted[partindex[i]]"""
+        row = unsorted.element_size() * (unsorted.numel() // unsorted.shape[0])
+        capi.check(self.lib.sphx_gather_rows(self.ctx.handle, capi.ptr(sorted_), capi.ptr(unsorted), row, capi.ptr(partindex), n, self._s()))
+
+    def build_neibs_sa(self, neibslist, vertpos, pos, info, vertices, boundelements, hash_, cellStart, cellEnd, n, range_end):
+        p = capi.ptr
+        sp = self.problem_simparams
+        # GPUWorker.cc:1890: (sqrt(nlSqInfluenceRadius) + slength/sfactor/2)^2 in float
+        f32 = np.float32
+        bound_sq = float(np.power(f32(np.sqrt(f32(sp.nlSqInfluenceRadius))) + f32(sp.slength) / f32(sp.sfactor) / f32(2.0), f32(2.0), dtype=np.float32))
+        capi.check(self.lib.sphx_neibs_resetinfo(self.ctx.handle, self._s()))
+        capi.check(self.lib.sphx_build_neibs_sa(self.ctx.handle, p(neibslist), p(vertpos[0]), p(vertpos[1]), p(vertpos[2]), p(pos), p(info),
+                                                p(vertices), p(boundelements), p(hash_), p(cellStart), p(cellEnd), n, range_end,
+                                                self.ncells, self.sq_nl_radius, bound_sq, self._s()))
+
+    # ---- AbstractBoundaryConditionsEngine (SA_BOUNDARY, solid walls)
+    def sa_compute_vertex_normal(self, boundelements, vertices, info, hash_, cellStart, neibslist, n, range_end):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_compute_vertex_normal(self.ctx.handle, p(boundelements), p(vertices), p(info), p(hash_), p(cellStart),
+                                                          p(neibslist), n, range_end, self._s()))
+
+    def sa_segment_bc(self, vel, ggam, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step,
+                      run_mode=D.SIMULATE):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_sa_segment_bc(self.ctx.handle, p(vel), p(ggam), p(pos), p(vertices), p(boundelements), p(info), p(hash_),
+                                               p(cellStart), p(neibslist), n, range_end, P.deltap, P.slength, P.influenceradius,
+                                               int(step), int(run_mode), self._s()))
+
+    def sa_vertex_bc(self, vel, ggam, pos, info, hash_, cellStart, neibslist, n, range_end, step, run_mode=D.SIMULATE):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_sa_vertex_bc(self.ctx.handle, p(vel), p(ggam), p(pos), p(info), p(hash_), p(cellStart), p(neibslist),
+                                              n, range_end, P.deltap, P.slength, P.influenceradius, int(step), int(run_mode), self._s()))
 
     def reserve_comm_cus(self, cus):
         """leave CUs out of the persistent forces grid for the communication kernels of the halo exchange"""

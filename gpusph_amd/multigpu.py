@@ -82,6 +82,9 @@ class MultiGpuEngine:
                  overlap=True, allocated=None, clobber_neibslist=False):
         if world > 1 and (problem.simparams.simflags & D.ENABLE_XSPH):
             raise ValueError("ENABLE_XSPH needs the mean velocity of the halo particles' neighbourhoods: single domain only")
+        self.sa = problem.simparams.boundarytype == D.SA_BOUNDARY
+        if world > 1 and self.sa:
+            raise ValueError("SA_BOUNDARY: the vertex/segment buffers are not exchanged between slabs yet (single domain only)")
         self.problem = problem
         self.rank, self.world = rank, world
         self.device = torch.device(device)
@@ -159,6 +162,13 @@ class MultiGpuEngine:
         self.turbvisc = torch.zeros(A, dtype=f32, device=dev) if self.sps else None      # BUFFER_SPS_TURBVISC
         # ENABLE_XSPH: BUFFER_XSPH, written by every forces pass for the fluid particles, read by the Euler steps
         self.xsph = torch.zeros((A, 4), dtype=f32, device=dev) if (self.sp.simflags & D.ENABLE_XSPH) else None
+        # SA_BOUNDARY: BUFFER_VERTICES (uint4), BUFFER_BOUNDELEMENTS, BUFFER_GRADGAMMA (float4) travel through the re-sort like
+        # pos/vel; BUFFER_VERTPOS (3 x float2) is written by the list build
+        if self.sa:
+            self.vertices = up(arrs["vertices"].view(np.int32), i32, (A, 4)); self.vertices2 = torch.zeros_like(self.vertices)
+            self.boundelements = up(arrs["boundelements"], f32, (A, 4)); self.boundelements2 = torch.zeros_like(self.boundelements)
+            self.gradgamma = up(arrs["gradgamma"], f32, (A, 4)); self.gradgamma2 = torch.zeros_like(self.gradgamma)
+            self.vertpos = [torch.zeros((A, 2), dtype=f32, device=dev) for _ in range(3)]
         self.filters = []            # [(FilterType, frequency)]
         # bodies with prescribed motion: every rank runs the same host kinematics (the callback is a pure function of time)
         self.bodies = None
@@ -229,6 +239,11 @@ class MultiGpuEngine:
                   self.pos, self.vel, self.info, self.hash, self.partindex, n, self.new_num)
         self.pos, self.pos2 = self.pos2, self.pos
         self.vel, self.vel2 = self.vel2, self.vel
+        if self.sa:      # the optional arrays of reorderDataAndFindCellStart (src/cuda/buildneibs.cu:263-311)
+            for name in ("vertices", "boundelements", "gradgamma"):
+                src, dst = getattr(self, name), getattr(self, name + "2")
+                K.gather_rows(dst, src, self.partindex, n)
+                setattr(self, name, dst); setattr(self, name + "2", src)
         if self.world == 1:
             if self.track_particle_count:
                 self.n_local = int(self.new_num.item()) & 0xFFFFFFFF
@@ -238,7 +253,27 @@ class MultiGpuEngine:
             self._update_segments_and_halo()
         if self.clobber_neibslist:
             K.memset(self.neibslist, 0xFF)
-        K.build_neibs(self.neibslist, self.pos, self.info, self.hash, self.cellStart, self.cellEnd, self.n_local, self.n_int)
+        if self.sa:
+            K.build_neibs_sa(self.neibslist, self.vertpos, self.pos, self.info, self.vertices, self.boundelements, self.hash,
+                             self.cellStart, self.cellEnd, self.n_local, self.n_int)
+        else:
+            K.build_neibs(self.neibslist, self.pos, self.info, self.hash, self.cellStart, self.cellEnd, self.n_local, self.n_int)
+
+    def sa_boundary_conditions(self, step, run_mode=D.SIMULATE):
+        """initializeBoundaryConditionsSequence<SA_BOUNDARY> (src/integrators/PredictorCorrectorIntegrator.cc:117-290) without
+        open boundaries: at initialisation (step 0) the vertex normals and gamma, then in every step the segment and the vertex
+        boundary conditions, in place on the current state."""
+        if not self.sa:
+            raise ValueError("boundary conditions sequence of a problem without SA_BOUNDARY")
+        K, n = self.k, self.n_local
+        if step == 0:
+            K.sa_compute_vertex_normal(self.boundelements, self.vertices, self.info, self.hash, self.cellStart, self.neibslist, n, n)
+            K.sa_init_gamma(self.gradgamma2, self.gradgamma, self.pos, self.boundelements, self.vertpos, self.info, self.hash,
+                            self.cellStart, self.neibslist, n, n)
+            self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
+        K.sa_segment_bc(self.vel, self.gradgamma, self.pos, self.vertices, self.boundelements, self.info, self.hash, self.cellStart,
+                        self.neibslist, n, n, step, run_mode)
+        K.sa_vertex_bc(self.vel, self.gradgamma, self.pos, self.info, self.hash, self.cellStart, self.neibslist, n, n, step, run_mode)
 
     def _update_segments_and_halo(self):
         """UPDATE_SEGMENTS + CROP + APPEND_EXTERNAL (src/Integrator.cc:170-230)"""

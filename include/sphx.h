@@ -71,6 +71,10 @@ enum sphx_postproc    { SPHX_VORTICITY = 0, SPHX_TESTPOINTS = 1, SPHX_SURFACE_DE
 #define SPHX_ENABLE_PLANES         (1ull << 2)
 #define SPHX_ENABLE_DEM            (1ull << 3)
 #define SPHX_ENABLE_MOVING_BODIES  (1ull << 4)
+#define SPHX_ENABLE_INLET_OUTLET   (1ull << 5)
+#define SPHX_ENABLE_WATER_DEPTH    (1ull << 6)
+#define SPHX_ENABLE_DENSITY_SUM    (1ull << 7)
+#define SPHX_ENABLE_GAMMA_QUADRATURE (1ull << 8)
 #define SPHX_ENABLE_REPACKING      (1ull << 9)
 #define SPHX_ENABLE_MULTIFLUID     (1ull << 11)
 
@@ -192,9 +196,39 @@ int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 	const uint32_t *cellStart, const uint32_t *cellEnd,
 	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t gridCells,
 	float sqinfluenceradius, float boundNlSqInflRad, void *stream);
+/* the same with the SA_BOUNDARY members of buildneibs_params (src/cuda/buildneibs_params.h:66-115): BUFFER_VERTICES (uint4)
+ * and BUFFER_BOUNDELEMENTS (float4) are read, the three arrays of BUFFER_VERTPOS (float2) are written for the segments,
+ * boundary neighbours are kept out to boundNlSqInflRad, vertex neighbours go to the third list section.  All five may be
+ * NULL for the other boundary types (= sphx_build_neibs). */
+int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *vertPos0, void *vertPos1, void *vertPos2,
+	const void *pos, const void *info, const void *vertices, const void *boundElements, const uint32_t *hash,
+	const uint32_t *cellStart, const uint32_t *cellEnd,
+	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t gridCells,
+	float sqinfluenceradius, float boundNlSqInflRad, void *stream);
 /* resetinfo / getinfo (src/cuda/buildneibs.cu:119-145); getinfo is sync */
 int sphx_neibs_resetinfo(sphx_ctx *ctx, void *stream);
 int sphx_neibs_getinfo(sphx_ctx *ctx, sphx_neibs_info *h_out, void *stream);
+
+/* ---- AbstractBoundaryConditionsEngine (src/engine_boundary_conditions.h:46-186), SA_BOUNDARY, solid walls -------- */
+/* computeVertexNormal (src/cuda/boundary_conditions.cu:417-452): area-weighted mean normal of the segments adjacent to each
+ * vertex, written to the vertex rows of boundElements (in place; w = NaN) */
+int sphx_sa_compute_vertex_normal(sphx_ctx *ctx, void *boundElements, const void *vertices, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
+/* saSegmentBoundaryConditions (src/cuda/boundary_conditions.cu:108-235): density (vel.w) and, for moving bodies, velocity of
+ * the boundary elements from the fluid / their vertices; gamma of a segment = mean of its vertices when it is (re)computed
+ * (step 0 or -1, non-finite gamma, moving bodies).  vel and gGam are updated in place (boundary rows only).
+ * step: 0 (or -1) initialisation, 1 / 2 integrator steps; run_mode: SPHX_SIMULATE or SPHX_REPACK */
+int sphx_sa_segment_bc(sphx_ctx *ctx, void *vel, void *gGam, const void *pos, const void *vertices,
+	const void *boundElements, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
+	int step, int run_mode, void *stream);
+/* saVertexBoundaryConditions (src/cuda/boundary_conditions.cu:280-410) without open boundaries: density of the vertex
+ * particles from the fluid (vel.w of vertex rows, in place) */
+int sphx_sa_vertex_bc(sphx_ctx *ctx, void *vel, const void *gGam, const void *pos, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
+	int step, int run_mode, void *stream);
 
 /* ---- AbstractForcesEngine ----------------------------------------------------------------- */
 uint32_t sphx_forces_fmax_elements(uint32_t n);       /* getFmaxElements, src/cuda/forces.cu:539-543 */

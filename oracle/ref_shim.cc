@@ -12,6 +12,8 @@
 //   src/utils.h               div_up / round_up: the arithmetic of getFmaxElements / round_particles (src/cuda/forces.cu:539-552,960-964)
 //   src/predcorr_alloc_policy.{h,cc}   which buffers the predictor-corrector scheme double-buffers
 //   src/timing.h              IPPSCounter: the definition of the reported metric (iterations x particles per second)
+//   src/cuda/gamma.cuh        SA_BOUNDARY: wendlandOnSegment, the Gauss quadratures, calcVertexRelPos, gradGamma<WENDLAND>,
+//                             Gamma<WENDLAND, PT_FLUID|PT_VERTEX> (host math library instead of the device one)
 // (src/cuda/phys_core.cu does not link: its non-inline R() drags in the nvcc intrinsic __powf, which has no host definition.)
 // Everything else on the hot path needs nvcc (__powf, texture references, thrust) or the
 // Makefile-generated options/*.opt files and is therefore NOT built (DESIGN.md "Oracle").
@@ -28,6 +30,7 @@
 #include "utils.h"
 #include "predcorr_alloc_policy.cc"
 #include "timing.h"
+#include "gamma.cuh"
 #include <thread>
 #include <chrono>
 
@@ -231,5 +234,32 @@ void ref_ipps(unsigned long particles, int increments, int millis, double *out)
 	}
 	out[0] = c.getMIPPS();
 	out[1] = c.getElapsedSeconds();
+}
+// ---- src/cuda/gamma.cuh: vectors as float[3], q_vb as float[9] (three vertices) ----
+float ref_wendlandOnSegment(float q) { return wendlandOnSegment(q); }
+float ref_gaussQuadratureO5(const float *v0, const float *v1, const float *v2, const float *rel)
+{
+	return gaussQuadratureO5(make_float3(v0[0], v0[1], v0[2]), make_float3(v1[0], v1[1], v1[2]), make_float3(v2[0], v2[1], v2[2]),
+		make_float3(rel[0], rel[1], rel[2]));
+}
+void ref_calcVertexRelPos(const float *ns, const float *vp0, const float *vp1, const float *vp2, float slength, float *out9)
+{
+	float3 q_vb[3];
+	calcVertexRelPos(q_vb, make_float3(ns[0], ns[1], ns[2]), make_float2(vp0[0], vp0[1]), make_float2(vp1[0], vp1[1]),
+		make_float2(vp2[0], vp2[1]), slength);
+	for (int i = 0; i < 3; ++i) { out9[3*i] = q_vb[i].x; out9[3*i + 1] = q_vb[i].y; out9[3*i + 2] = q_vb[i].z; }
+}
+float ref_gradGamma(float slength, const float *q, const float *qvb9, const float *ns)
+{
+	float3 q_vb[3];
+	for (int i = 0; i < 3; ++i) q_vb[i] = make_float3(qvb9[3*i], qvb9[3*i + 1], qvb9[3*i + 2]);
+	return gradGamma<WENDLAND>(slength, make_float3(q[0], q[1], q[2]), q_vb, make_float3(ns[0], ns[1], ns[2]));
+}
+float ref_Gamma(int vertex, float slength, const float *q, const float *qvb9, const float *ns, const float *oldGGam, float epsilon)
+{
+	float3 q_vb[3];
+	for (int i = 0; i < 3; ++i) q_vb[i] = make_float3(qvb9[3*i], qvb9[3*i + 1], qvb9[3*i + 2]);
+	const float3 q3 = make_float3(q[0], q[1], q[2]), n3 = make_float3(ns[0], ns[1], ns[2]), g3 = make_float3(oldGGam[0], oldGGam[1], oldGGam[2]);
+	return vertex ? Gamma<WENDLAND, PT_VERTEX>(slength, q3, q_vb, n3, g3, epsilon) : Gamma<WENDLAND, PT_FLUID>(slength, q3, q_vb, n3, g3, epsilon);
 }
 } // extern "C"

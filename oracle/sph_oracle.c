@@ -1998,3 +1998,269 @@ void orc_sa_vertex_bc(const orc_params *p, orc_f4 *velArray, const orc_f4 *gGamA
 		velArray[index].w = orc_RHO(p, sumpWall/shepard_div, fl);
 	}
 }
+
+/* ---- gamma and its gradient: src/cuda/gamma.cuh (Wendland kernel only, as the reference) ------------------------
+ * Written without FMA contraction, like oracle/_ref (g++ -ffp-contract=off) which pins it bit for bit
+ * (tests/test_oracle_pinned.py::test_gamma_quadrature_matches_reference). */
+typedef struct { float x, y, z; } v3;
+static inline v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v3_add(v3 a, v3 b) { return v3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 v3_scale(v3 a, float s) { return v3_make(a.x*s, a.y*s, a.z*s); }
+static inline v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }
+static inline float v3_dot(v3 a, v3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }            /* vector_math.h:560-563 */
+static inline v3 v3_cross(v3 a, v3 b) { return v3_make(a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }
+static inline float v3_sqlen(v3 a) { return v3_dot(a, a); }
+static inline float v3_len(v3 a) { return sqrtf(v3_sqlen(a)); }
+static inline v3 v3_normalize(v3 a) { return v3_scale(a, 1.0f/sqrtf(v3_sqlen(a))); }      /* v*rsqrtf(sqlength(v)), :584-588 */
+static inline v3 v3_divs(v3 a, float s) { return v3_scale(a, 1.0f/s); }                   /* float3 / float = v*(1/s), vector_math.h */
+
+static const float GQ_O5_weights[3] = { 0.225f, 0.132394152788506f, 0.125939180544827f };                 /* gamma.cuh:43-55 */
+static const float GQ_O5_points[3][3] = {
+	{ 0.333333333333333f, 0.333333333333333f, 0.333333333333333f },
+	{ 0.059715871789770f, 0.470142064105115f, 0.470142064105115f },
+	{ 0.797426985353087f, 0.101286507323456f, 0.101286507323456f } };
+static const int GQ_O5_mult[3] = { 1, 3, 3 };
+
+/* wendlandOnSegment, gamma.cuh:90-110 */
+float orc_wendland_on_segment(float q)
+{
+	float intKernel = 0.0f;
+	if (q < 2.0f) {
+		float tmp = (1.0f - q/2.0f);
+		float tmp4 = tmp*tmp;
+		tmp4 *= tmp4;
+		const float uq = 1.0f/q;
+		intKernel = 0.009947183943243458485555235210782147627153727858778528046729f*tmp4*tmp*((((8.0f*uq + 20.0f)*uq + 30.0f)*uq) + 21.0f);
+	}
+	return intKernel;
+}
+
+/* gaussQuadratureO5, gamma.cuh:138-163.  NB the break test follows the accumulation, so the loop over j runs once more
+ * than mult[i] says: the centroid point (mult 1) is taken twice, the others three times (the loop ends at j = 2).
+ * Reproduced as written. */
+static float gauss_quadrature_O5(v3 vPos0, v3 vPos1, v3 vPos2, v3 relPos)
+{
+	float val = 0.0f;
+	for (int i = 0; i < 3; i++) {
+		for (int j = 0; j < 3; j++) {
+			v3 pa = v3_add(v3_add(v3_scale(vPos0, GQ_O5_points[i][j]), v3_scale(vPos1, GQ_O5_points[i][(j + 1) % 3])),
+				v3_scale(vPos2, GQ_O5_points[i][(j + 2) % 3]));
+			pa = v3_sub(pa, relPos);
+			val += GQ_O5_weights[i]*orc_wendland_on_segment(v3_len(pa));
+			if (j >= GQ_O5_mult[i])
+				break;
+		}
+	}
+	const float vol = v3_len(v3_cross(v3_sub(vPos1, vPos0), v3_sub(vPos2, vPos0)))/2.0f;
+	return val*vol;
+}
+float orc_gauss_quadrature_O5(const float *v0, const float *v1, const float *v2, const float *rel)
+{
+	return gauss_quadrature_O5(v3_make(v0[0], v0[1], v0[2]), v3_make(v1[0], v1[1], v1[2]), v3_make(v2[0], v2[1], v2[2]),
+		v3_make(rel[0], rel[1], rel[2]));
+}
+
+/* calcVertexRelPos, gamma.cuh:196-227 */
+static void calc_vertex_rel_pos(v3 q_vb[3], v3 ns, const float *vPos0, const float *vPos1, const float *vPos2, float slength)
+{
+	unsigned j = 0;
+	if (fabsf(ns.x) > fabsf(ns.y))
+		j = 1;
+	if ((1 - j)*fabsf(ns.x) + j*fabsf(ns.y) > fabsf(ns.z))
+		j = 2;
+	const v3 coord1 = v3_normalize(v3_make(
+		-((j == 1)*ns.z) + (j == 2)*ns.y,
+		(j == 0)*ns.z - ((j == 2)*ns.x),
+		-((j == 0)*ns.y) + (j == 1)*ns.x));
+	const v3 coord2 = v3_cross(ns, coord1);
+	const float *vp[3] = { vPos0, vPos1, vPos2 };
+	for (int k = 0; k < 3; ++k)
+		q_vb[k] = v3_divs(v3_neg(v3_add(v3_scale(coord1, vp[k][0]), v3_scale(coord2, vp[k][1]))), slength);
+}
+void orc_calc_vertex_rel_pos(const float *ns, const float *vp0, const float *vp1, const float *vp2, float slength, float *out9)
+{
+	v3 q_vb[3];
+	calc_vertex_rel_pos(q_vb, v3_make(ns[0], ns[1], ns[2]), vp0, vp1, vp2, slength);
+	for (int i = 0; i < 3; ++i) { out9[3*i] = q_vb[i].x; out9[3*i + 1] = q_vb[i].y; out9[3*i + 2] = q_vb[i].z; }
+}
+
+/* gradGamma<WENDLAND>, gamma.cuh:248-370 */
+static float grad_gamma_wendland(float slength, v3 q, const v3 *q_vb, v3 ns)
+{
+	float pas = v3_dot(ns, q);
+	float qas = fabsf(pas);
+	if (qas >= 2.f)
+		return 0.f;
+	float qas2 = qas*qas;
+	float qas3 = qas2*qas;
+	float qas4 = qas2*qas2;
+	float qas5 = qas3*qas2;
+	unsigned sIdx[2];
+	float gradGamma_as = 0.f;
+	float totalSumAngles = 0.f;
+	float sumAngles = 0.f;
+	for (unsigned e = 0; e < 3; e++) {
+		sIdx[0] = e % 3;
+		sIdx[1] = (e + 1) % 3;
+		v3 v01 = v3_normalize(v3_sub(q_vb[sIdx[0]], q_vb[sIdx[1]]));
+		v3 ne = v3_normalize(v3_cross(ns, v01));
+		float pae = v3_dot(ne, v3_sub(q, q_vb[sIdx[0]]));
+		float qae = v3_len(v3_add(v3_scale(ns, pas), v3_scale(ne, pae)));
+		float pav0 = -v3_dot(v3_sub(q, q_vb[sIdx[0]]), v01);
+		float pav1 = -v3_dot(v3_sub(q, q_vb[sIdx[1]]), v01);
+		totalSumAngles += copysignf(atan2f(pav1, fabsf(pae)) - atan2f(pav0, fabsf(pae)), pae);
+		if (qae < 2.0f) {
+			pav0 = copysignf(fminf(fabsf(pav0), sqrtf(4.0f - qae*qae)), pav0);
+			float pav02 = pav0*pav0;
+			pav1 = copysignf(fminf(fabsf(pav1), sqrtf(4.0f - qae*qae)), pav1);
+			float pav12 = pav1*pav1;
+			float qav0 = fminf(sqrtf(qae*qae + pav0*pav0), 2.0f);
+			float qav1 = fminf(sqrtf(qae*qae + pav1*pav1), 2.0f);
+			float pae2 = pae*pae;
+			float pae4 = pae2*pae2;
+			float pae6 = pae4*pae2;
+			gradGamma_as += 0.00015542474911f*(
+				+ 48.0f*qas5*(28.0f + qas2)*(
+						  atan2f(qas*pav1, pae*qav1) - atan2f(pav1, pae)
+						-(atan2f(qas*pav0, pae*qav0) - atan2f(pav0, pae)))
+				+ pae*(
+					 pav1*(3.0f*qas4*(-420.0f + 29.0f*qav1)
+						+ pae4*(-420.0f + 33.0f*qav1)
+						+ 2.0f*qas2*(-210.0f*(8.0f + pav12) + 756.0f*qav1 + 19.0f*pav12*qav1)
+						+ 4.0f*(336.0f + pav12*(pav12*(-21.0f + 2.0f*qav1) + 28.0f*(-5.0f + 3.0f*qav1)))
+						+ 2.0f*pae2*(420.0f*(-2.0f + qav1) + 6.0f*qas2*(-105.0f + 8.0f*qav1) + pav12*(-140.0f + 13.0f*qav1))
+						)
+					- pav0*(3.0f*qas4*(-420.0f + 29.0f*qav0)
+						+ pae4*(-420.0f + 33.0f*qav0)
+						+ 2.0f*qas2*(-210.0f*(8.0f + pav02) + 756.0f*qav0 + 19.0f*pav02*qav0)
+						+ 4.0f*(336.0f + pav02*(pav02*(-21.0f + 2.0f*qav0) + 28.0f*(-5.0f + 3.0f*qav0)))
+						+ 2.0f*pae2*(420.0f*(-2.0f + qav0) + 6.0f*qas2*(-105.0f + 8.0f*qav0) + pav02*(-140.0f + 13.0f*qav0))
+						)
+					+ 3.0f*(5.0f*pae6 + 21.0f*pae4*(8.0f + qas2) + 35.0f*pae2*qas2*(16.0f + qas2) + 35.0f*qas4*(24.0f + qas2))
+					*(
+						 copysignf(1.f, pav1)*acoshf(fmaxf(qav1/fmaxf(qae, 1e-7f), 1.f))
+						- copysignf(1.f, pav0)*acoshf(fmaxf(qav0/fmaxf(qae, 1e-7f), 1.f))
+						)
+					)
+				);
+			sumAngles += copysignf(atan2f(pav1, fabsf(pae)) - atan2f(pav0, fabsf(pae)), pae);
+		}
+	}
+	const float tmp1 = 1.0f - qas/2.0f;
+	float tmp2 = tmp1*tmp1;
+	tmp2 *= tmp2*tmp1;
+	gradGamma_as += (sumAngles - totalSumAngles)*0.05968310365947f*tmp2*(2.0f + 5.0f*qas + 4.0f*qas2);
+	return gradGamma_as/slength;
+}
+float orc_grad_gamma(float slength, const float *q, const float *qvb9, const float *ns)
+{
+	v3 q_vb[3];
+	for (int i = 0; i < 3; ++i) q_vb[i] = v3_make(qvb9[3*i], qvb9[3*i + 1], qvb9[3*i + 2]);
+	return grad_gamma_wendland(slength, v3_make(q[0], q[1], q[2]), q_vb, v3_make(ns[0], ns[1], ns[2]));
+}
+
+/* Gamma<WENDLAND, PT_FLUID> :404-435 and Gamma<WENDLAND, PT_VERTEX> :437-513 (q_vb may be permuted) */
+static float gamma_wendland(int vertex, float slength, v3 q, v3 *q_vb, v3 ns, v3 oldGGam, float epsilon)
+{
+	v3 r_aSigma = v3_scale(ns, v3_dot(ns, q));
+	float q_aSigma = fminf(v3_len(r_aSigma), 2.0f);
+	float gamma_as = 0.0f;
+	float gamma_vs = 0.0f;
+	if (vertex) {
+		const v3 ba = v3_sub(q_vb[1], q_vb[0]);
+		const v3 ca = v3_sub(q_vb[2], q_vb[0]);
+		const v3 pa = v3_sub(q, q_vb[0]);
+		const float uu = v3_sqlen(ba);
+		const float uv = v3_dot(ba, ca);
+		const float vv = v3_sqlen(ca);
+		const float wu = v3_dot(ba, pa);
+		const float wv = v3_dot(ca, pa);
+		const float invdet = 1.0f/(uv*uv - uu*vv);
+		const float u = (uv*wv - vv*wu)*invdet;
+		const float v = (uv*wu - uu*wv)*invdet;
+		if (((fabsf(u - 1.0f) < epsilon && fabsf(v) < epsilon) ||
+			 (fabsf(v - 1.0f) < epsilon && fabsf(u) < epsilon) ||
+			 (fabsf(u) < epsilon && fabsf(v) < epsilon)) && q_aSigma < epsilon) {
+			if (fabsf(u - 1.0f) < epsilon && fabsf(v) < epsilon) {
+				const v3 tmp = q_vb[1];
+				q_vb[1] = q_vb[2];
+				q_vb[2] = q_vb[0];
+				q_vb[0] = tmp;
+			} else if (fabsf(v - 1.0f) < epsilon && fabsf(u) < epsilon) {
+				const v3 tmp = q_vb[2];
+				q_vb[2] = q_vb[1];
+				q_vb[1] = q_vb[0];
+				q_vb[0] = tmp;
+			}
+			const v3 inward_normal = v3_divs(v3_neg(oldGGam), fmaxf(v3_len(oldGGam), slength*1e-3f));
+			const v3 e1 = v3_sub(q_vb[1], q_vb[0]), e2 = v3_sub(q_vb[2], q_vb[0]);
+			const float l1 = v3_len(e1);
+			const float l2 = v3_len(e2);
+			const float abc = v3_dot(e1, inward_normal)/l1 + v3_dot(e2, inward_normal)/l2 + v3_dot(e1, e2)/l1/l2;
+			const float d = v3_dot(inward_normal, v3_cross(e1, e2))/l1/l2;
+			const float SolidAngle = fabsf(2.0f*atan2f(d, 1.0f + abc));
+			gamma_vs = SolidAngle*0.079577471545947667884441881686257181017229822870228224373833f;
+		}
+	}
+	if (q_aSigma < 2.0f && q_aSigma > epsilon) {
+		const float intVal = gauss_quadrature_O5(v3_neg(q_vb[0]), v3_neg(q_vb[1]), v3_neg(q_vb[2]), q);
+		if (vertex) gamma_as += intVal*v3_dot(ns, r_aSigma);    /* "+=" in the vertex specialisation, "=" in the fluid one: */
+		else gamma_as = intVal*v3_dot(ns, r_aSigma);            /* 0 + (-0) is +0, so the sign of a zero differs */
+	}
+	return vertex ? gamma_vs + gamma_as : gamma_as;
+}
+float orc_gamma(int vertex, float slength, const float *q, const float *qvb9, const float *ns, const float *oldGGam, float epsilon)
+{
+	v3 q_vb[3];
+	for (int i = 0; i < 3; ++i) q_vb[i] = v3_make(qvb9[3*i], qvb9[3*i + 1], qvb9[3*i + 2]);
+	return gamma_wendland(vertex, slength, v3_make(q[0], q[1], q[2]), q_vb, v3_make(ns[0], ns[1], ns[2]),
+		v3_make(oldGGam[0], oldGGam[1], oldGGam[2]), epsilon);
+}
+
+/* initGammaDevice<WENDLAND, cptype> :1891-1970 for cptype = PT_FLUID then PT_VERTEX (saInitGamma, boundary_conditions.cu:463-540):
+ * grad gamma = sum over boundary neighbours of gradGamma_as n_s, then gamma = 1 - sum of Gamma_as (which needs the direction
+ * of grad gamma just computed) */
+void orc_sa_init_gamma(const orc_params *p, orc_f4 *newGGam, const orc_f4 *posArray, const orc_f4 *boundelement,
+	const float *vertPos0, const float *vertPos1, const float *vertPos2, const orc_info *infoArray,
+	const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd,
+	float deltap, float epsilon)
+{
+	const float slength = p->slength, influenceradius = p->influenceradius;
+	for (int cptype = PT_FLUID; cptype <= PT_VERTEX; cptype += 2) {
+#pragma omp parallel for schedule(dynamic, 256)
+		for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+			const orc_info info = infoArray[index];
+			if (PART_TYPE(info) != cptype) continue;
+			const orc_f4 pos = posArray[index];
+			float gam = 1.0f;
+			v3 gGam = v3_make(0.0f, 0.0f, 0.0f);
+			int gridPos[3];
+			orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+			for (int pass = 0; pass < 2; ++pass) {
+				neib_iter it;
+				uint32_t neib_index;
+				neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+				while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+					/* InitGammaVars :1833-1868 */
+					const orc_f4 npos = posArray[neib_index];
+					const v3 relPos = v3_make(it.pos_corr[0] - npos.x, it.pos_corr[1] - npos.y, it.pos_corr[2] - npos.z);
+					if (v3_len(relPos) > influenceradius + deltap*0.5f) continue;
+					const orc_f4 be = boundelement[neib_index];
+					const v3 normal = v3_make(be.x, be.y, be.z);
+					const v3 q = v3_divs(relPos, slength);
+					v3 q_vb[3];
+					calc_vertex_rel_pos(q_vb, normal, vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+						vertPos2 + 2*(size_t)neib_index, slength);
+					if (pass == 0) {
+						const float ggamma_as = grad_gamma_wendland(slength, q, q_vb, normal);
+						gGam = v3_add(gGam, v3_scale(normal, ggamma_as));
+					} else {
+						gam -= gamma_wendland(cptype == PT_VERTEX, slength, q, q_vb, normal, gGam, epsilon);
+					}
+				}
+			}
+			newGGam[index].x = gGam.x; newGGam[index].y = gGam.y; newGGam[index].z = gGam.z; newGGam[index].w = gam;
+		}
+	}
+}

@@ -260,7 +260,51 @@ def refmisc():
                         buffer_keys=keys, predcorr_buffer_count=counts)
 
 
+def gamma_inputs():
+    """inputs for the gamma.cuh pin: right-angled and random triangles of side ~deltap around the origin (as q_vb: vertex
+    positions relative to the barycentre over h), particles at random offsets within the kernel support, plus the special
+    positions the vertex specialisation tests for (on a vertex, in the plane)"""
+    rng = np.random.default_rng(77)
+    h = np.float32(0.065)
+    n = 400
+    ns = rng.normal(size=(n, 3)); ns[:60] = np.eye(3)[rng.integers(0, 3, 60)] * rng.choice([-1, 1], (60, 1))
+    ns = (ns / np.linalg.norm(ns, axis=1, keepdims=True)).astype(np.float32)
+    vp = rng.uniform(-0.05, 0.05, size=(n, 3, 2))
+    vp = (vp - vp.mean(axis=1, keepdims=True)).astype(np.float32)          # offsets about the barycentre
+    q = (rng.normal(size=(n, 3)) * rng.uniform(0.0, 1.6, (n, 1))).astype(np.float32)
+    ggam = rng.normal(size=(n, 3)).astype(np.float32)
+    return h, ns, vp, q, ggam
+
+
+def refgamma():
+    """ref_gamma.npz: src/cuda/gamma.cuh as compiled into oracle/_ref (host math library): wendlandOnSegment,
+    gaussQuadratureO5, calcVertexRelPos, gradGamma<WENDLAND>, Gamma<WENDLAND, PT_FLUID|PT_VERTEX>"""
+    import ctypes as C
+    ref = ol.ref()
+    h, ns, vp, q, ggam = gamma_inputs()
+    n = len(q)
+    F3 = C.c_float * 3
+    qs = np.concatenate([np.linspace(0.01, 2.2, 120), [2.0, 1e-3]]).astype(np.float32)
+    wos = np.array([ref.ref_wendlandOnSegment(float(x)) for x in qs], dtype=np.float32)
+    qvb = np.zeros((n, 9), dtype=np.float32)
+    gq = np.zeros(n, dtype=np.float32); gg = np.zeros(n, dtype=np.float32); gaf = np.zeros(n, dtype=np.float32); gav = np.zeros(n, dtype=np.float32)
+    qv = q.copy()
+    for i in range(n):
+        out = (C.c_float * 9)()
+        ref.ref_calcVertexRelPos(F3(*ns[i]), (C.c_float * 2)(*vp[i, 0]), (C.c_float * 2)(*vp[i, 1]), (C.c_float * 2)(*vp[i, 2]), float(h), out)
+        qvb[i] = list(out)
+        if i % 8 == 0:      # a particle ON a vertex of the element (the vertex specialisation's solid-angle branch)
+            qv[i] = qvb[i, 3 * (i // 8 % 3):3 * (i // 8 % 3) + 3]
+        v = [F3(*(-qvb[i, 3 * k:3 * k + 3])) for k in range(3)]
+        gq[i] = ref.ref_gaussQuadratureO5(v[0], v[1], v[2], F3(*q[i]))
+        gg[i] = ref.ref_gradGamma(float(h), F3(*q[i]), out, F3(*ns[i]))
+        gaf[i] = ref.ref_Gamma(0, float(h), F3(*q[i]), out, F3(*ns[i]), F3(*ggam[i]), 5e-5)
+        gav[i] = ref.ref_Gamma(1, float(h), F3(*qv[i]), out, F3(*ns[i]), F3(*ggam[i]), 5e-5)
+    np.savez_compressed(os.path.join(HERE, "ref_gamma.npz"), h=h, ns=ns, vp=vp, q=q, qv=qv, ggam=ggam, qs=qs, wendland_on_segment=wos,
+                        q_vb=qvb, gauss_quadrature_O5=gq, grad_gamma=gg, gamma_fluid=gaf, gamma_vertex=gav)
+
+
 if __name__ == "__main__":
-    kernels(); datamodel(); viscavg(); hostparams(); refmisc(); pipeline(); features(); features2()
+    kernels(); datamodel(); viscavg(); hostparams(); refmisc(); refgamma(); pipeline(); features(); features2()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))

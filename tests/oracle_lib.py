@@ -74,6 +74,12 @@ def lib():
         _lib.orc_calc_grid_hash.restype = C.c_uint32
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_visc_avg.restype = C.c_float; _lib.orc_visc_avg.argtypes = [C.c_void_p] + [C.c_float] * 5
+        _lib.orc_wendland_on_segment.restype = C.c_float; _lib.orc_wendland_on_segment.argtypes = [C.c_float]
+        _lib.orc_gauss_quadrature_O5.restype = C.c_float; _lib.orc_gauss_quadrature_O5.argtypes = [C.c_void_p] * 4
+        _lib.orc_calc_vertex_rel_pos.restype = None; _lib.orc_calc_vertex_rel_pos.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p]
+        _lib.orc_grad_gamma.restype = C.c_float; _lib.orc_grad_gamma.argtypes = [C.c_float] + [C.c_void_p] * 3
+        _lib.orc_gamma.restype = C.c_float; _lib.orc_gamma.argtypes = [C.c_int, C.c_float] + [C.c_void_p] * 4 + [C.c_float]
+        _lib.orc_RHO.restype = C.c_float; _lib.orc_RHO.argtypes = [C.c_void_p, C.c_float, C.c_int]
     return _lib
 
 
@@ -110,6 +116,11 @@ def ref():
         _ref.ref_predcorr_multi_buffered.restype = C.c_uint64; _ref.ref_predcorr_multi_buffered.argtypes = [C.c_uint64]
         _ref.ref_buffer_key.restype = C.c_uint64; _ref.ref_buffer_key.argtypes = [C.c_int]
         _ref.ref_ipps.restype = None; _ref.ref_ipps.argtypes = [C.c_ulong, C.c_int, C.c_int, C.c_void_p]
+        _ref.ref_wendlandOnSegment.restype = C.c_float; _ref.ref_wendlandOnSegment.argtypes = [C.c_float]
+        _ref.ref_gaussQuadratureO5.restype = C.c_float; _ref.ref_gaussQuadratureO5.argtypes = [C.c_void_p] * 4
+        _ref.ref_calcVertexRelPos.restype = None; _ref.ref_calcVertexRelPos.argtypes = [C.c_void_p] * 4 + [C.c_float, C.c_void_p]
+        _ref.ref_gradGamma.restype = C.c_float; _ref.ref_gradGamma.argtypes = [C.c_float] + [C.c_void_p] * 3
+        _ref.ref_Gamma.restype = C.c_float; _ref.ref_Gamma.argtypes = [C.c_int, C.c_float] + [C.c_void_p] * 4 + [C.c_float]
         _ref.ref_visc_avg_singlefluid_nonconst_kinematic.restype = C.c_float
         _ref.ref_visc_avg_singlefluid_nonconst_kinematic.argtypes = [C.c_int] + [C.c_float] * 5
     return _ref
@@ -217,6 +228,12 @@ class Oracle:
         self.L.orc_sa_segment_bc(C.byref(self.p), P(v), P(g), P(pos), P(vertices), P(boundelements), P(info), P(hash_), P(cs),
                                  P(nl), C.c_uint32(n), C.c_int(step), C.c_int(1 if repack else 0))
         return v, g
+
+    def sa_init_gamma(self, ggam, pos, boundelements, vertpos, info, hash_, cs, nl, n, deltap, epsilon=5e-5):
+        g = ggam.copy()
+        self.L.orc_sa_init_gamma(C.byref(self.p), P(g), P(pos), P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(info),
+                                 P(hash_), P(cs), P(nl), C.c_uint32(n), C.c_float(deltap), C.c_float(epsilon))
+        return g
 
     def sa_vertex_bc(self, pos, vel, ggam, info, hash_, cs, nl, n):
         v = vel.copy()

@@ -277,3 +277,38 @@ def test_metric_definition_of_the_reference():
     mipps, elapsed = out[0], out[1]
     assert 0.19 < elapsed < 1.0
     assert abs(mipps * elapsed - 20.0) < 0.02 * 20.0        # 20 iterations x 1e6 particles / elapsed / 1e6
+
+
+def test_gamma_quadrature_matches_reference():
+    """src/cuda/gamma.cuh (compiled into oracle/_ref from where it lies) against the oracle's restatement, bit for bit:
+    the integrated Wendland kernel, the 5th-order Gauss rule on a triangle, the vertex frame of a segment, the analytical
+    grad gamma of a segment and gamma for fluid and vertex particles (incl. the solid-angle branch for a particle on a vertex)"""
+    import ctypes as C
+    d = np.load(os.path.join(GOLD, "ref_gamma.npz"))
+    L = ol.lib()
+    F3 = C.c_float * 3
+    h = float(d["h"])
+    got = np.array([L.orc_wendland_on_segment(float(x)) for x in d["qs"]], dtype=np.float32)
+    assert np.array_equal(got.view(np.uint32), d["wendland_on_segment"].view(np.uint32))
+    assert d["wendland_on_segment"][-2] == 0.0 and d["wendland_on_segment"][0] > 1.0       # q = 2: outside; q -> 0: the 1/q^3 pole
+    n = len(d["q"])
+    on_vertex = 0
+    for i in range(n):
+        out = (C.c_float * 9)()
+        vp = d["vp"][i]
+        L.orc_calc_vertex_rel_pos(F3(*d["ns"][i]), (C.c_float * 2)(*vp[0]), (C.c_float * 2)(*vp[1]), (C.c_float * 2)(*vp[2]), h, out)
+        qvb = np.array(list(out), dtype=np.float32)
+        assert np.array_equal(qvb.view(np.uint32), d["q_vb"][i].view(np.uint32)), i
+        v = [F3(*(-qvb[3 * k:3 * k + 3])) for k in range(3)]
+        f32 = lambda x: np.float32(x).view(np.uint32)
+        assert f32(L.orc_gauss_quadrature_O5(v[0], v[1], v[2], F3(*d["q"][i]))) == f32(d["gauss_quadrature_O5"][i]), i
+        assert f32(L.orc_grad_gamma(h, F3(*d["q"][i]), out, F3(*d["ns"][i]))) == f32(d["grad_gamma"][i]), i
+        assert f32(L.orc_gamma(0, h, F3(*d["q"][i]), out, F3(*d["ns"][i]), F3(*d["ggam"][i]), 5e-5)) == f32(d["gamma_fluid"][i]), i
+        assert f32(L.orc_gamma(1, h, F3(*d["qv"][i]), out, F3(*d["ns"][i]), F3(*d["ggam"][i]), 5e-5)) == f32(d["gamma_vertex"][i]), i
+        on_vertex += (i % 8 == 0) and d["gamma_vertex"][i] != 0
+    assert on_vertex > 30          # the solid-angle branch was really exercised
+    ref = ol.ref()                 # and live, when the reference build is present
+    if ref is not None:
+        for i in range(0, n, 7):
+            out = (C.c_float * 9)(*d["q_vb"][i])
+            assert np.float32(ref.ref_gradGamma(h, F3(*d["q"][i]), out, F3(*d["ns"][i]))) == d["grad_gamma"][i]

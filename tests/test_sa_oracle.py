@@ -122,3 +122,58 @@ def test_wall_density_of_a_hydrostatic_tank(st):
     assert len(wetv) > 200
     assert np.abs(velv[wetv, 3] - expect[wetv]).max() < 0.02 * expect.max()
     assert np.array_equal(velv[:, :3], vel[:, :3]) and np.array_equal(velv[seg], vel[seg]) and np.array_equal(velv[fl], vel[fl])
+
+
+def _plane_integrals(h, d):
+    """for a particle at distance d from an infinite planar wall, Wendland kernel of smoothing length h (radius 2h):
+    |grad gamma| = integral of W over the plane, 1 - gamma = kernel volume beyond the plane (numerical, float64)"""
+    from scipy import integrate
+    W = lambda r: 21.0 / (16.0 * np.pi * h ** 3) * (1 - r / (2 * h)) ** 4 * (1 + 2 * r / h) if r < 2 * h else 0.0
+    gg = integrate.quad(lambda s: 2 * np.pi * s * W(np.hypot(d, s)), 0, np.sqrt(max(4 * h * h - d * d, 0)))[0]
+    cap = integrate.quad(lambda z: integrate.quad(lambda s: 2 * np.pi * s * W(np.hypot(z, s)), 0, np.sqrt(max(4 * h * h - z * z, 0)))[0], d, 2 * h)[0]
+    return gg, cap
+
+
+def test_initial_gamma_of_a_planar_wall(st):
+    o, p = st["oracle"], st["problem"]
+    t = info_type(st["info"])
+    be = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], st["info"], st["hash"], st["cs"], st["nl"], st["n"])
+    gg = o.sa_init_gamma(st["gradgamma"], st["pos"], be, st["vertpos"], st["info"], st["hash"], st["cs"], st["nl"], st["n"], p.m_deltap)
+    g = p.global_pos(st["pos"], st["hash"])
+    dp, h, R = p.m_deltap, p.simparams.slength, p.simparams.influenceRadius
+    seg = np.where(t == D.PT_BOUNDARY)[0]
+    assert np.isnan(gg[seg]).all()                               # segments get theirs from the vertices (segment BC, step 0)
+    fl = np.where(t == D.PT_FLUID)[0]; vx = np.where(t == D.PT_VERTEX)[0]
+    assert np.isfinite(gg[fl]).all() and np.isfinite(gg[vx]).all()
+    # fluid over the middle of the floor: only the floor is in reach
+    mid = [i for i in fl if R + dp < g[i, 0] < p.l - R - dp and R + dp < g[i, 1] < p.w - R - dp]
+    assert len(mid) > 20
+    for i in mid:
+        d = g[i, 2]
+        want_gg, cap = _plane_integrals(h, d)
+        if d >= R:
+            assert gg[i, 3] == 1.0 and not gg[i, :3].any()
+            continue
+        # grad gamma is analytical in the reference (gamma.cuh:248-370): exact up to the mesh being finite
+        assert abs(gg[i, 2] - want_gg) < 2e-3 * max(want_gg, 1.0) and abs(gg[i, 0]) < 1e-3 * want_gg + 1e-4 and abs(gg[i, 1]) < 1e-3 * want_gg + 1e-4
+        # gamma itself is a 5th-order Gauss rule over elements of size dp whose centroid point is taken twice (see
+        # gauss_quadrature_O5 in the oracle) applied to an integrand with a 1/q^3 pole at the wall: the missing volume comes
+        # out at 1.23x the true cap one and a half dp from the wall and at 1.36x half a dp from it (pinned to the reference
+        # bit for bit in test_oracle_pinned.py; here only that it is the cap, to that accuracy)
+        miss = 1.0 - gg[i, 3]
+        assert 0.9 * cap - 1e-4 <= miss <= 1.45 * cap + 1e-4, (d, cap, miss)
+    # vertex particles: the solid angle of the adjacent elements as seen along -grad gamma
+    def pick(cond):
+        return [i for i in vx if cond(g[i])]
+    inner = lambda v, L: 2 * dp < v < L - 2 * dp
+    face = pick(lambda q: abs(q[2]) < 1e-5 and inner(q[0], p.l) and inner(q[1], p.w))
+    edge = pick(lambda q: abs(q[2]) < 1e-5 and abs(q[0]) < 1e-5 and inner(q[1], p.w))
+    corner = pick(lambda q: abs(q[2]) < 1e-5 and abs(q[0]) < 1e-5 and abs(q[1]) < 1e-5)
+    assert len(face) > 20 and len(edge) > 3 and len(corner) == 1
+    assert np.abs(gg[face, 3] - 0.5).max() < 2e-3
+    assert np.abs(gg[edge, 3] - 0.25).max() < 0.03
+    # at a corner of the tank the true value is 1/8; the reference's sum of the solid angles of the tetrahedra spanned by the
+    # adjacent element edges and -grad gamma (Gamma<WENDLAND, PT_VERTEX>, gamma.cuh:486-497) covers only part of the wall
+    # side there and gives 0.54 -- reproduced (the function is pinned bit for bit), not asserted as physics
+    assert 0.125 < gg[corner[0], 3] < 0.6
+    assert np.allclose(gg[face, :3] / np.linalg.norm(gg[face, :3], axis=1, keepdims=True), [0, 0, 1], atol=1e-3)
