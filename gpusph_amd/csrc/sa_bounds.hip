@@ -147,6 +147,232 @@ sa_vertex_bc_kernel(DevParams p, SaArgs a)
 	a.vel[index].w = eos_rho(p, sumpWall/shepard_div, fl);
 }
 
+// ---- gamma and its gradient at initialisation: src/cuda/gamma.cuh (Wendland), initGammaDevice (_kernel.cu:1891-1970) ----
+// Same expressions, same order, no contraction; what differs from the CPU oracle is the math library (atan2f, acoshf).
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r = { x, y, z }; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x*s, a.y*s, a.z*s); }
+__device__ __forceinline__ V3 operator/(V3 a, float s) { const float inv = 1.0f/s; return a*inv; }        // vector_math.h:526-530
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { return a*(1.0f/sqrtf(dot(a, a))); }                      // v*rsqrtf(sqlength(v))
+
+__device__ __forceinline__ float wendland_on_segment(float q)      // gamma.cuh:90-110
+{
+	float intKernel = 0.0f;
+	if (q < 2.0f) {
+		float tmp = (1.0f - q/2.0f);
+		float tmp4 = tmp*tmp;
+		tmp4 *= tmp4;
+		const float uq = 1.0f/q;
+		intKernel = 0.009947183943243458485555235210782147627153727858778528046729f*tmp4*tmp*((((8.0f*uq + 20.0f)*uq + 30.0f)*uq) + 21.0f);
+	}
+	return intKernel;
+}
+
+// gaussQuadratureO5 (gamma.cuh:138-163), with its loop as written: the break test follows the accumulation, so the
+// centroid point (multiplicity 1) is evaluated twice
+__device__ __forceinline__ float gauss_quadrature_O5(V3 vPos0, V3 vPos1, V3 vPos2, V3 relPos)
+{
+	const float weights[3] = { 0.225f, 0.132394152788506f, 0.125939180544827f };
+	const float points[3][3] = {
+		{ 0.333333333333333f, 0.333333333333333f, 0.333333333333333f },
+		{ 0.059715871789770f, 0.470142064105115f, 0.470142064105115f },
+		{ 0.797426985353087f, 0.101286507323456f, 0.101286507323456f } };
+	const int mult[3] = { 1, 3, 3 };
+	float val = 0.0f;
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+#pragma unroll
+		for (int j = 0; j < 3; j++) {
+			V3 pa = vPos0*points[i][j] + vPos1*points[i][(j + 1) % 3] + vPos2*points[i][(j + 2) % 3];
+			pa = pa - relPos;
+			val += weights[i]*wendland_on_segment(length(pa));
+			if (j >= mult[i])
+				break;
+		}
+	}
+	const float vol = length(cross(vPos1 - vPos0, vPos2 - vPos0))/2.0f;
+	return val*vol;
+}
+
+__device__ __forceinline__ void calc_vertex_rel_pos(V3 q_vb[3], V3 ns, float2 vPos0, float2 vPos1, float2 vPos2, float slength)   // :196-227
+{
+	unsigned j = 0;
+	if (fabsf(ns.x) > fabsf(ns.y))
+		j = 1;
+	if ((1 - j)*fabsf(ns.x) + j*fabsf(ns.y) > fabsf(ns.z))
+		j = 2;
+	const V3 coord1 = normalize(v3(-((j == 1)*ns.z) + (j == 2)*ns.y, (j == 0)*ns.z - ((j == 2)*ns.x), -((j == 0)*ns.y) + (j == 1)*ns.x));
+	const V3 coord2 = cross(ns, coord1);
+	q_vb[0] = -(coord1*vPos0.x + coord2*vPos0.y)/slength;
+	q_vb[1] = -(coord1*vPos1.x + coord2*vPos1.y)/slength;
+	q_vb[2] = -(coord1*vPos2.x + coord2*vPos2.y)/slength;
+}
+
+__device__ float grad_gamma_wendland(float slength, V3 q, const V3 *q_vb, V3 ns)      // gamma.cuh:248-370
+{
+	float pas = dot(ns, q);
+	float qas = fabsf(pas);
+	if (qas >= 2.f)
+		return 0.f;
+	float qas2 = qas*qas;
+	float qas3 = qas2*qas;
+	float qas4 = qas2*qas2;
+	float qas5 = qas3*qas2;
+	float gradGamma_as = 0.f;
+	float totalSumAngles = 0.f;
+	float sumAngles = 0.f;
+	for (unsigned e = 0; e < 3; e++) {
+		const V3 qv0 = q_vb[e % 3], qv1 = q_vb[(e + 1) % 3];
+		V3 v01 = normalize(qv0 - qv1);
+		V3 ne = normalize(cross(ns, v01));
+		float pae = dot(ne, q - qv0);
+		float qae = length(ns*pas + ne*pae);
+		float pav0 = -dot(q - qv0, v01);
+		float pav1 = -dot(q - qv1, v01);
+		totalSumAngles += copysignf(atan2f(pav1, fabsf(pae)) - atan2f(pav0, fabsf(pae)), pae);
+		if (qae < 2.0f) {
+			pav0 = copysignf(fminf(fabsf(pav0), sqrtf(4.0f - qae*qae)), pav0);
+			float pav02 = pav0*pav0;
+			pav1 = copysignf(fminf(fabsf(pav1), sqrtf(4.0f - qae*qae)), pav1);
+			float pav12 = pav1*pav1;
+			float qav0 = fminf(sqrtf(qae*qae + pav0*pav0), 2.0f);
+			float qav1 = fminf(sqrtf(qae*qae + pav1*pav1), 2.0f);
+			float pae2 = pae*pae;
+			float pae4 = pae2*pae2;
+			float pae6 = pae4*pae2;
+			gradGamma_as += 0.00015542474911f*(
+				+ 48.0f*qas5*(28.0f + qas2)*(
+						  atan2f(qas*pav1, pae*qav1) - atan2f(pav1, pae)
+						-(atan2f(qas*pav0, pae*qav0) - atan2f(pav0, pae)))
+				+ pae*(
+					 pav1*(3.0f*qas4*(-420.0f + 29.0f*qav1)
+						+ pae4*(-420.0f + 33.0f*qav1)
+						+ 2.0f*qas2*(-210.0f*(8.0f + pav12) + 756.0f*qav1 + 19.0f*pav12*qav1)
+						+ 4.0f*(336.0f + pav12*(pav12*(-21.0f + 2.0f*qav1) + 28.0f*(-5.0f + 3.0f*qav1)))
+						+ 2.0f*pae2*(420.0f*(-2.0f + qav1) + 6.0f*qas2*(-105.0f + 8.0f*qav1) + pav12*(-140.0f + 13.0f*qav1))
+						)
+					- pav0*(3.0f*qas4*(-420.0f + 29.0f*qav0)
+						+ pae4*(-420.0f + 33.0f*qav0)
+						+ 2.0f*qas2*(-210.0f*(8.0f + pav02) + 756.0f*qav0 + 19.0f*pav02*qav0)
+						+ 4.0f*(336.0f + pav02*(pav02*(-21.0f + 2.0f*qav0) + 28.0f*(-5.0f + 3.0f*qav0)))
+						+ 2.0f*pae2*(420.0f*(-2.0f + qav0) + 6.0f*qas2*(-105.0f + 8.0f*qav0) + pav02*(-140.0f + 13.0f*qav0))
+						)
+					+ 3.0f*(5.0f*pae6 + 21.0f*pae4*(8.0f + qas2) + 35.0f*pae2*qas2*(16.0f + qas2) + 35.0f*qas4*(24.0f + qas2))
+					*(
+						 copysignf(1.f, pav1)*acoshf(fmaxf(qav1/fmaxf(qae, 1e-7f), 1.f))
+						- copysignf(1.f, pav0)*acoshf(fmaxf(qav0/fmaxf(qae, 1e-7f), 1.f))
+						)
+					)
+				);
+			sumAngles += copysignf(atan2f(pav1, fabsf(pae)) - atan2f(pav0, fabsf(pae)), pae);
+		}
+	}
+	const float tmp1 = 1.0f - qas/2.0f;
+	float tmp2 = tmp1*tmp1;
+	tmp2 *= tmp2*tmp1;
+	gradGamma_as += (sumAngles - totalSumAngles)*0.05968310365947f*tmp2*(2.0f + 5.0f*qas + 4.0f*qas2);
+	return gradGamma_as/slength;
+}
+
+// Gamma<WENDLAND, PT_FLUID> :404-435 / Gamma<WENDLAND, PT_VERTEX> :437-513 (q_vb may be permuted)
+template<bool VERTEX>
+__device__ float gamma_wendland(float slength, V3 q, V3 *q_vb, V3 ns, V3 oldGGam, float epsilon)
+{
+	V3 r_aSigma = ns*dot(ns, q);
+	float q_aSigma = fminf(length(r_aSigma), 2.0f);
+	float gamma_as = 0.0f;
+	float gamma_vs = 0.0f;
+	if (VERTEX) {
+		const V3 ba = q_vb[1] - q_vb[0];
+		const V3 ca = q_vb[2] - q_vb[0];
+		const V3 pa = q - q_vb[0];
+		const float uu = dot(ba, ba);
+		const float uv = dot(ba, ca);
+		const float vv = dot(ca, ca);
+		const float wu = dot(ba, pa);
+		const float wv = dot(ca, pa);
+		const float invdet = 1.0f/(uv*uv - uu*vv);
+		const float u = (uv*wv - vv*wu)*invdet;
+		const float v = (uv*wu - uu*wv)*invdet;
+		if (((fabsf(u - 1.0f) < epsilon && fabsf(v) < epsilon) ||
+			 (fabsf(v - 1.0f) < epsilon && fabsf(u) < epsilon) ||
+			 (fabsf(u) < epsilon && fabsf(v) < epsilon)) && q_aSigma < epsilon) {
+			if (fabsf(u - 1.0f) < epsilon && fabsf(v) < epsilon) {
+				const V3 tmp = q_vb[1];
+				q_vb[1] = q_vb[2];
+				q_vb[2] = q_vb[0];
+				q_vb[0] = tmp;
+			} else if (fabsf(v - 1.0f) < epsilon && fabsf(u) < epsilon) {
+				const V3 tmp = q_vb[2];
+				q_vb[2] = q_vb[1];
+				q_vb[1] = q_vb[0];
+				q_vb[0] = tmp;
+			}
+			const V3 inward_normal = (-oldGGam)/fmaxf(length(oldGGam), slength*1e-3f);
+			const V3 e1 = q_vb[1] - q_vb[0], e2 = q_vb[2] - q_vb[0];
+			const float l1 = length(e1);
+			const float l2 = length(e2);
+			const float abc = dot(e1, inward_normal)/l1 + dot(e2, inward_normal)/l2 + dot(e1, e2)/l1/l2;
+			const float d = dot(inward_normal, cross(e1, e2))/l1/l2;
+			const float SolidAngle = fabsf(2.0f*atan2f(d, 1.0f + abc));
+			gamma_vs = SolidAngle*0.079577471545947667884441881686257181017229822870228224373833f;
+		}
+	}
+	if (q_aSigma < 2.0f && q_aSigma > epsilon) {
+		const float intVal = gauss_quadrature_O5(-q_vb[0], -q_vb[1], -q_vb[2], q);
+		if (VERTEX) gamma_as += intVal*dot(ns, r_aSigma);
+		else gamma_as = intVal*dot(ns, r_aSigma);
+	}
+	return VERTEX ? gamma_vs + gamma_as : gamma_as;
+}
+
+struct SaGammaArgs {
+	float4 *newGGam;
+	const float4 *pos, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	float deltap, epsilon;
+};
+
+template<int CPTYPE>
+__global__ void __launch_bounds__(128)
+sa_init_gamma_kernel(DevParams p, SaGammaArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != (uint32_t)CPTYPE) return;
+	const float4 pos = a.pos[index];
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	float gam = 1.0f;
+	V3 gGam = v3(0.0f, 0.0f, 0.0f);
+	// grad gamma first (gamma needs its direction), then gamma: two walks over the boundary elements in reach
+#pragma unroll 1
+	for (int pass = 0; pass < 2; ++pass) {
+		for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float rx, float ry, float rz) {
+			const V3 relPos = v3(rx, ry, rz);                       // InitGammaVars :1833-1868
+			if (length(relPos) > p.influenceradius + a.deltap*0.5f) return;
+			const float4 be = a.boundElement[j];
+			const V3 normal = v3(be.x, be.y, be.z);
+			const V3 q = relPos/p.slength;
+			V3 q_vb[3];
+			calc_vertex_rel_pos(q_vb, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			if (pass == 0) gGam = gGam + normal*grad_gamma_wendland(p.slength, q, q_vb, normal);
+			else gam -= gamma_wendland<CPTYPE == PT_VERTEX>(p.slength, q, q_vb, normal, gGam, a.epsilon);
+		});
+	}
+	a.newGGam[index] = make_float4(gGam.x, gGam.y, gGam.z, gam);
+}
+
 static int sa_check(sphx_ctx *ctx, const char *who)
 {
 	if (!ctx || !ctx->have_params) return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa: constants not set");
@@ -219,5 +445,33 @@ extern "C" int sphx_sa_vertex_bc(sphx_ctx *ctx, void *vel, const void *gGam, con
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
 	sa_vertex_bc_kernel<SPHX_WENDLAND><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_vertex_bc_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_init_gamma(sphx_ctx *ctx, void *newGGam, const void *oldGGam, const void *pos, const void *boundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	float slength, float influenceradius, float deltap, float epsilon,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+{
+	(void)numParticles; (void)oldGGam;      // the reference's kernel does not read the old values either
+	int rc = sa_check(ctx, "saInitGamma called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(newGGam && pos && boundElements && vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList,
+		"sphx_sa_init_gamma: missing buffer");
+	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
+		"sphx_sa_init_gamma: slength / influenceradius differ from the uploaded constants");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaGammaArgs a = {};
+	a.newGGam = (float4*)newGGam; a.pos = (const float4*)pos; a.boundElement = (const float4*)boundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.numParticles = particleRangeEnd; a.deltap = deltap; a.epsilon = epsilon;
+	hipStream_t st = (hipStream_t)stream;
+	// fluid particles, then vertex particles (saInitGamma, src/cuda/boundary_conditions.cu:497-535)
+	sa_init_gamma_kernel<PT_FLUID><<<div_up_u(particleRangeEnd, 128), 128, 0, st>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_init_gamma_kernel<PT_FLUID>");
+	sa_init_gamma_kernel<PT_VERTEX><<<div_up_u(particleRangeEnd, 128), 128, 0, st>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_init_gamma_kernel<PT_VERTEX>");
 	return SPHX_OK;
 }

@@ -121,6 +121,13 @@ class HipKernels:
         capi.check(self.lib.sphx_sa_compute_vertex_normal(self.ctx.handle, p(boundelements), p(vertices), p(info), p(hash_), p(cellStart),
                                                           p(neibslist), n, range_end, self._s()))
 
+    def sa_init_gamma(self, new_ggam, old_ggam, pos, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end, epsilon=5e-5):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_sa_init_gamma(self.ctx.handle, p(new_ggam), p(old_ggam), p(pos), p(boundelements), p(vertpos[0]),
+                                               p(vertpos[1]), p(vertpos[2]), p(info), p(hash_), p(cellStart), p(neibslist),
+                                               P.slength, P.influenceradius, P.deltap, float(np.float32(epsilon)), n, range_end, self._s()))
+
     def sa_segment_bc(self, vel, ggam, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step,
                       run_mode=D.SIMULATE):
         p = capi.ptr

@@ -215,6 +215,14 @@ int sphx_neibs_getinfo(sphx_ctx *ctx, sphx_neibs_info *h_out, void *stream);
 int sphx_sa_compute_vertex_normal(sphx_ctx *ctx, void *boundElements, const void *vertices, const void *info,
 	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
+/* saInitGamma (src/cuda/boundary_conditions.cu:457-560): gamma and grad gamma of fluid and vertex particles at initialisation,
+ * grad gamma from the analytical formula of a triangular element, gamma by Gauss quadrature / solid angles
+ * (src/cuda/gamma.cuh).  Rows of boundary elements are not written.  oldGGam is accepted for interface parity (unused). */
+int sphx_sa_init_gamma(sphx_ctx *ctx, void *newGGam, const void *oldGGam, const void *pos, const void *boundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	float slength, float influenceradius, float deltap, float epsilon,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
 /* saSegmentBoundaryConditions (src/cuda/boundary_conditions.cu:108-235): density (vel.w) and, for moving bodies, velocity of
  * the boundary elements from the fluid / their vertices; gamma of a segment = mean of its vertices when it is (re)computed
  * (step 0 or -1, non-finite gamma, moving bodies).  vel and gGam are updated in place (boundary rows only).

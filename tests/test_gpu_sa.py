@@ -1,0 +1,126 @@
+"""SA_BOUNDARY on the GPU (data path + boundary-conditions engine of solid walls) against the CPU oracle:
+the neighbour phase with the SA buffers bit for bit, the boundary-conditions kernels to the tolerance of the math library."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from gpusph_amd import defs as D
+from gpusph_amd.problem import SABox, DamBreak3D, info_type
+from sa_helpers import sa_oracle_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(problem, **kw):
+    import torch
+    from gpusph_amd.engine import TimestepEngine
+    assert torch.cuda.is_available()
+    return TimestepEngine(problem, device="cuda:0", **kw)
+
+
+def _np(t, dtype=None):
+    a = t.cpu().numpy()
+    return a.view(dtype) if dtype is not None else a
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.fixture(scope="module", params=[dict(deltap=0.05), dict(deltap=0.04, jitter=0.2, linearization="xzy")])
+def pair(request):
+    st = sa_oracle_state(**request.param)
+    eng = _engine(SABox(**request.param), clobber_neibslist=True)
+    eng.build_neibs()
+    return st, eng
+
+
+def test_neighbour_phase_with_sa_buffers_is_bit_exact(pair):
+    st, eng = pair
+    n = st["n"]
+    assert eng.n == n
+    assert np.array_equal(_np(eng.hash, np.uint32)[:n], st["hash"])
+    assert np.array_equal(_np(eng.info, np.uint16)[:n], st["info"])
+    assert np.array_equal(_np(eng.cellStart, np.uint32), st["cs"]) and np.array_equal(_np(eng.cellEnd, np.uint32), st["ce"])
+    assert np.array_equal(_bits(_np(eng.pos)[:n]), _bits(st["pos"]))
+    # the optional arrays of the re-sort: vertex ids, element normals/areas, gamma (NaN rows included)
+    assert np.array_equal(_np(eng.vertices, np.uint32)[:n], st["vertices"])
+    assert np.array_equal(_bits(_np(eng.boundelements)[:n]), _bits(st["boundelements"]))
+    assert np.array_equal(_bits(_np(eng.gradgamma)[:n]), _bits(st["gradgamma"]))
+    # all three sections of the list, the in-plane vertex offsets of the segments, the counters
+    A = eng.alloc
+    nl = _np(eng.neibslist, np.uint16).reshape(-1, A)[:, :n]
+    assert np.array_equal(nl, st["nl"].reshape(-1, n))
+    for k in range(3):
+        assert np.array_equal(_bits(_np(eng.vertpos[k])[:n]), _bits(st["vertpos"][k])), k
+    info = eng.neibs_info()
+    want = st["neibs_info"]
+    assert (info.numInteractions, info.maxFluidBoundaryNeibs, info.maxVertexNeibs, info.hasTooManyNeibs) == \
+        (want.numInteractions, want.maxFluidBoundaryNeibs, want.maxVertexNeibs, -1)
+    assert info.maxVertexNeibs > 10
+
+
+def test_initialisation_sequence_of_the_boundary_conditions(pair):
+    """SA_COMPUTE_VERTEX_NORMAL, SA_INIT_GAMMA, segment and vertex boundary conditions of step 0"""
+    st, eng = pair
+    o, p, n = st["oracle"], st["problem"], st["n"]
+    t = info_type(st["info"])
+    fl, seg, vx = (np.where(t == k)[0] for k in (D.PT_FLUID, D.PT_BOUNDARY, D.PT_VERTEX))
+    be = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], st["info"], st["hash"], st["cs"], st["nl"], n)
+    gg0 = o.sa_init_gamma(st["gradgamma"], st["pos"], be, st["vertpos"], st["info"], st["hash"], st["cs"], st["nl"], n, p.m_deltap)
+    vel1, gg1 = o.sa_segment_bc(st["pos"], st["vel"], gg0, st["vertices"], be, st["info"], st["hash"], st["cs"], st["nl"], n, step=0)
+    vel2 = o.sa_vertex_bc(st["pos"], vel1, gg1, st["info"], st["hash"], st["cs"], st["nl"], n)
+
+    eng.sa_boundary_conditions(0)
+    gbe, ggg, gvel = _np(eng.boundelements)[:n], _np(eng.gradgamma)[:n], _np(eng.vel)[:n]
+    assert np.array_equal(_bits(gbe), _bits(be))                                   # vertex normals: same arithmetic
+    # gamma: the same formulas through another math library (atan2f, acoshf): |grad gamma| ~ 10, gamma ~ 1
+    scale = np.abs(gg0[np.concatenate([fl, vx]), :3]).max()
+    for rows in (fl, vx, seg):
+        assert np.abs(ggg[rows, :3] - gg1[rows, :3]).max() < 2e-5 * scale
+        assert np.abs(ggg[rows, 3] - gg1[rows, 3]).max() < 5e-6
+    # wall densities (Tait equation inverted: powf twice)
+    rho_scale = np.abs(vel2[:, 3]).max()
+    assert np.abs(gvel[:, 3] - vel2[:, 3]).max() < 2e-5 * rho_scale + 2e-7
+    assert np.array_equal(_bits(gvel[:, :3]), _bits(vel2[:, :3]))
+    assert np.array_equal(_bits(gvel[fl]), _bits(st["vel"][fl]))                   # fluid rows untouched
+    wet = seg[vel2[seg, 3] > 0]
+    assert len(wet) > 200
+
+
+def test_later_steps_and_repacking_mode(pair):
+    st, eng = pair
+    o, n = st["oracle"], st["n"]
+    t = info_type(st["info"])
+    seg = np.where(t == D.PT_BOUNDARY)[0]
+    # the state the previous test left on the device is the input of both sides
+    vel, gg, be = _np(eng.vel)[:n].copy(), _np(eng.gradgamma)[:n].copy(), _np(eng.boundelements)[:n].copy()
+    rng = np.random.default_rng(9)
+    fl = np.where(t == D.PT_FLUID)[0]
+    vel[fl, 3] *= (1 + 0.05 * rng.standard_normal(len(fl))).astype(np.float32)    # a perturbed density field
+    import torch
+    eng.vel[:n] = torch.from_numpy(vel).to(eng.device)
+    for step, repack in ((1, False), (2, False), (1, True)):
+        v1, g1 = o.sa_segment_bc(st["pos"], vel, gg, st["vertices"], be, st["info"], st["hash"], st["cs"], st["nl"], n, step=step, repack=repack)
+        v2 = o.sa_vertex_bc(st["pos"], v1, g1, st["info"], st["hash"], st["cs"], st["nl"], n)
+        eng.sa_boundary_conditions(step, run_mode=D.REPACK if repack else D.SIMULATE)
+        gvel, ggg = _np(eng.vel)[:n], _np(eng.gradgamma)[:n]
+        assert np.array_equal(_bits(ggg), _bits(gg))                    # finite gamma, no moving bodies: left alone
+        assert np.abs(gvel[:, 3] - v2[:, 3]).max() < 2e-5 * np.abs(v2[:, 3]).max() + 2e-7
+        assert np.array_equal(_bits(gvel[:, :3]), _bits(v2[:, :3]))
+        if step == 1 and not repack:
+            assert np.abs(gvel[seg, 3] - vel[seg, 3]).max() > 1e-5       # it did respond to the perturbed field
+        vel = gvel.copy()
+
+
+def test_what_is_not_built_says_so(pair):
+    from gpusph_amd import capi
+    st, eng = pair
+    with pytest.raises(capi.SphxUnsupported, match="DYN_BOUNDARY and LJ_BOUNDARY"):
+        eng.step()
+    # and the boundary-conditions engine refuses a framework without SA_BOUNDARY, like the reference's SFINAE'd implementation
+    other = _engine(DamBreak3D(deltap=0.05, obstacle=False))
+    other.build_neibs()
+    k = other.k
+    with pytest.raises(capi.SphxInvalidArgument, match="without SA_BOUNDARY"):
+        k.sa_vertex_bc(other.vel, other.vel, other.pos, other.info, other.hash, other.cellStart, other.neibslist, other.n, other.n, 1)
