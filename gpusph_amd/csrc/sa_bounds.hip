@@ -380,8 +380,8 @@ static int sa_check(sphx_ctx *ctx, const char *who)
 		return sphx_set_error(SPHX_ERR_INVALID, who);      // the reference throws "... called without SA_BOUNDARY"
 	if (ctx->params.kerneltype != SPHX_WENDLAND)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA_BOUNDARY is built for the Wendland kernel (as the reference, src/cuda/gamma.cuh:241-250)");
-	if (ctx->params.simflags & (SPHX_ENABLE_INLET_OUTLET | SPHX_ENABLE_DENSITY_SUM))
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: open boundaries and density summation are not built");
+	if (ctx->params.simflags & SPHX_ENABLE_INLET_OUTLET)     // ENABLE_DENSITY_SUM does not enter these kernels
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: open boundaries (ENABLE_INLET_OUTLET) are not built");
 	return SPHX_OK;
 }
 

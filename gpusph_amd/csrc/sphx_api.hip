@@ -194,8 +194,9 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SA_BOUNDARY needs the Wendland kernel (src/cuda/gamma.cuh:241-250)");
 		SPHX_REQUIRE(sp->neibboundpos + 2 <= sp->neiblistsize, "sphx_set_constants: SA_BOUNDARY needs a vertex section in the neighbour list");
 	}
+	// Brezzi diffusion is a term of the SA forces pass (not built); the engines that are built for SA_BOUNDARY do not read it
 	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI &&
-		sp->densitydiffusiontype != SPHX_FERRARI)
+		sp->densitydiffusiontype != SPHX_FERRARI && sp->boundarytype != SPHX_SA_BOUNDARY)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: Brezzi density diffusion (an SA_BOUNDARY option in the reference's problems) is not built");
 	if (sp->rheologytype != SPHX_INVISCID && sp->rheologytype != SPHX_NEWTONIAN)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only INVISCID and NEWTONIAN rheologies are built");

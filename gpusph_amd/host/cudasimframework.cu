@@ -149,30 +149,6 @@ template<typename O, typename... Selectors> struct ApplySelectors
 template<typename O, typename First, typename... Rest> struct ApplySelectors<O, First, Rest...>
 { typedef typename ApplySelectors<typename First::template apply<O>, Rest...>::type type; };
 
-// ---- boundary-conditions engine of SA_BOUNDARY: present so that SA problems link; nothing of it is built ----------------
-class HIPBoundaryConditionsEngine : public AbstractBoundaryConditionsEngine
-{
-public:
-	void uploadNumOpenVertices(const uint&) { sphx_not_built("uploadNumOpenVertices (SA_BOUNDARY)"); }
-	void saSegmentBoundaryConditions(BufferList&, BufferList const&, const uint, const uint, const float, const float,
-		const float, const int, const RunMode) { sphx_not_built("saSegmentBoundaryConditions (SA_BOUNDARY)"); }
-	void findOutgoingSegment(BufferList&, BufferList const&, const uint, const uint, const float, const float, const float)
-	{ sphx_not_built("findOutgoingSegment (SA_BOUNDARY)"); }
-	void saVertexBoundaryConditions(BufferList&, BufferList const&, const uint, const uint, const float, const float,
-		const float, const int, const bool, const float, uint*, const uint, const uint, const uint, const RunMode)
-	{ sphx_not_built("saVertexBoundaryConditions (SA_BOUNDARY)"); }
-	void computeVertexNormal(const BufferList&, BufferList&, const uint, const uint) { sphx_not_built("computeVertexNormal (SA_BOUNDARY)"); }
-	void saInitGamma(const BufferList&, BufferList&, const float, const float, const float, const float, const uint, const uint)
-	{ sphx_not_built("saInitGamma (SA_BOUNDARY)"); }
-	void initIOmass_vertexCount(BufferList&, const BufferList&, const uint, const uint) { sphx_not_built("initIOmass_vertexCount (SA_BOUNDARY)"); }
-	void initIOmass(BufferList&, const BufferList&, const uint, const uint, const float) { sphx_not_built("initIOmass (SA_BOUNDARY)"); }
-	void disableOutgoingParts(const BufferList&, BufferList&, const uint, const uint) { sphx_not_built("disableOutgoingParts (SA_BOUNDARY)"); }
-	void downloadIOwaterdepth(uint*, const uint*, const uint) { sphx_not_built("downloadIOwaterdepth (SA_BOUNDARY)"); }
-	void uploadIOwaterdepth(const uint*, uint*, const uint) { sphx_not_built("uploadIOwaterdepth (SA_BOUNDARY)"); }
-	void saIdentifyCornerVertices(const BufferList&, BufferList&, const uint, const uint, const float, const float)
-	{ sphx_not_built("saIdentifyCornerVertices (SA_BOUNDARY)"); }
-};
-
 // ---- the framework: option set -> SimFramework with HIP engines ----------------------------------------------------------
 template<typename Options>
 class HIPSimFrameworkImpl : public SimFramework
@@ -226,7 +202,7 @@ public:
 		m_integrationEngine = new HIPPredCorrEngine(m_context);
 		m_viscEngine = new HIPViscEngine(m_context);
 		m_forcesEngine = new HIPForcesEngine(m_context);
-		m_bcEngine = (boundarytype == SA_BOUNDARY) ? new HIPBoundaryConditionsEngine() : NULL;
+		m_bcEngine = (boundarytype == SA_BOUNDARY) ? new HIPBoundaryConditionsEngine(m_context) : NULL;
 
 		m_allocPolicy = std::make_shared<PredCorrAllocPolicy>();
 

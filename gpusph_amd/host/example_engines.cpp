@@ -188,6 +188,73 @@ int main(int argc, char **argv)
 			for (size_t k = 0; k + 1 < c.at("filter").size(); k += 2)
 				fw->addFilterEngine((FilterType)(int)num(c, "filter", k), (int)num(c, "filter", k + 1));
 
+		// ---- SA_BOUNDARY: the neighbour phase with the vertex / segment buffers and the initialisation sequence of the
+		// boundary conditions (initializeBoundaryConditionsSequence<SA_BOUNDARY>, PredictorCorrectorIntegrator.cc:117-290);
+		// the SA forces / integration engines are not built, so the run ends there (steps must be 0)
+		if (sp->boundarytype == SA_BOUNDARY) {
+			if (steps != 0) throw std::runtime_error("SA_BOUNDARY case: only the initialisation (steps 0) can be run");
+			std::vector<vertexinfo> hvert(n0);
+			std::vector<float4> hbe(n0), hgg(n0);
+			FILE *fs = fopen(argv[2], "rb");
+			fseek(fs, 4 + (long)n0*(16 + 16 + 8 + 4), SEEK_SET);
+			if (fread(hvert.data(), 16, n0, fs) != n0 || fread(hbe.data(), 16, n0, fs) != n0 || fread(hgg.data(), 16, n0, fs) != n0)
+				throw std::runtime_error("short state file (SA buffers)");
+			fclose(fs);
+			BufferList saA = one_buffer<BUFFER_VERTICES>(A) | one_buffer<BUFFER_BOUNDELEMENTS>(A) | one_buffer<BUFFER_GRADGAMMA>(A);
+			BufferList saB = one_buffer<BUFFER_VERTICES>(A) | one_buffer<BUFFER_BOUNDELEMENTS>(A) | one_buffer<BUFFER_GRADGAMMA>(A);
+			shared |= one_buffer<BUFFER_VERTPOS>(A);
+			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_VERTICES>(), hvert.data(), 16*(size_t)n0));
+			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_BOUNDELEMENTS>(), hbe.data(), 16*(size_t)n0));
+			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_GRADGAMMA>(), hgg.data(), 16*(size_t)n0));
+			uint n = n0;
+			BufferList unsorted = posA | velA | saA | shared, sorted = posB | velB | saB | shared;
+			neibsEngine->fixHash(unsorted, unsorted, n);
+			neibsEngine->sort(unsorted, unsorted, n);
+			shared[BUFFER_CELLSTART]->clobber(); shared[BUFFER_CELLEND]->clobber();
+			neibsEngine->reorderDataAndFindCellStart(NULL, sorted, unsorted, n, d_newNum);
+			sphx_throw(sphx_memcpy_d2h(&n, d_newNum, 4));
+			neibsEngine->resetinfo();
+			shared[BUFFER_NEIBSLIST]->clobber();
+			BufferList state = posB | velB | saB | shared;
+			// GPUWorker::runCommand<BUILDNEIBS> (src/GPUWorker.cc:1890): boundary elements are searched a little farther out
+			const float boundNlSqInflRad = powf(sqrt(sp->nlSqInfluenceRadius) + sp->slength/sp->sfactor/2.0f, 2.0f);
+			neibsEngine->buildNeibsList(state, state, n, n, gridCells, sqNlRadius, boundNlSqInflRad);
+			TimingInfo ti; neibsEngine->getinfo(ti);
+			if (ti.hasTooManyNeibs >= 0) throw std::runtime_error("too many neighbours");
+			AbstractBoundaryConditionsEngine *bc = fw->getBCEngine();
+			if (!bc) throw std::runtime_error("no boundary conditions engine loaded");
+			bc->computeVertexNormal(state, state, n, n);
+			bc->saInitGamma(state, state, slength, influenceRadius, deltap, sp->epsilon, n, n);
+			bc->saSegmentBoundaryConditions(state, state, n, n, deltap, slength, influenceRadius, 0, SIMULATE);
+			uint newNum = n;
+			bc->saVertexBoundaryConditions(state, state, n, n, deltap, slength, influenceRadius, 0, false, 0.0f, &newNum, 0, 1, n, SIMULATE);
+			sphx_throw(sphx_device_synchronize());
+			const BufferList &cs = state;
+			hpos.resize(n); hvel.resize(n); hinfo.resize(n); hhash.resize(n); hvert.resize(n); hbe.resize(n); hgg.resize(n);
+			sphx_throw(sphx_memcpy_d2h(hpos.data(), cs.getData<BUFFER_POS>(), 16*(size_t)n));
+			sphx_throw(sphx_memcpy_d2h(hvel.data(), cs.getData<BUFFER_VEL>(), 16*(size_t)n));
+			sphx_throw(sphx_memcpy_d2h(hinfo.data(), cs.getData<BUFFER_INFO>(), 8*(size_t)n));
+			sphx_throw(sphx_memcpy_d2h(hhash.data(), cs.getData<BUFFER_HASH>(), 4*(size_t)n));
+			sphx_throw(sphx_memcpy_d2h(hvert.data(), cs.getData<BUFFER_VERTICES>(), 16*(size_t)n));
+			sphx_throw(sphx_memcpy_d2h(hbe.data(), cs.getData<BUFFER_BOUNDELEMENTS>(), 16*(size_t)n));
+			sphx_throw(sphx_memcpy_d2h(hgg.data(), cs.getData<BUFFER_GRADGAMMA>(), 16*(size_t)n));
+			std::vector<float2> hvp(3*(size_t)n);
+			const float2 * const *vp = cs.getRawPtr<BUFFER_VERTPOS>();
+			for (int k = 0; k < 3; ++k) sphx_throw(sphx_memcpy_d2h(hvp.data() + (size_t)k*n, vp[k], 8*(size_t)n));
+			sphx_throw(sphx_free(d_newNum));
+			FILE *o = fopen(argv[3], "wb");
+			if (!o) throw std::runtime_error(std::string("cannot write ") + argv[3]);
+			const float dt0 = (float)num(c, "dt0"); const double t0 = 0;
+			fwrite(&n, 4, 1, o); fwrite(&dt0, 4, 1, o); fwrite(&t0, 8, 1, o);
+			fwrite(hpos.data(), 16, n, o); fwrite(hvel.data(), 16, n, o); fwrite(hinfo.data(), 8, n, o); fwrite(hhash.data(), 4, n, o);
+			fwrite(hvert.data(), 16, n, o); fwrite(hbe.data(), 16, n, o); fwrite(hgg.data(), 16, n, o); fwrite(hvp.data(), 8, 3*(size_t)n, o);
+			const int32_t counters[4] = { (int32_t)ti.numInteractions, (int32_t)ti.maxFluidBoundaryNeibs, (int32_t)ti.maxVertexNeibs, (int32_t)newNum };
+			fwrite(counters, 4, 4, o);
+			fclose(o);
+			printf("example_engines: %s, %u particles, SA initialisation, max vertex neighbours %d\n", str(c, "framework").c_str(), n, (int)ti.maxVertexNeibs);
+			return 0;
+		}
+
 		BufferList *curPos = &posA, *othPos = &posB, *curVel = &velA, *othVel = &velB;
 		uint n = n0;
 		float dt = (float)num(c, "dt0");

@@ -281,15 +281,21 @@ public:
 	void buildNeibsList(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
 		const uint particleRangeEnd, const uint gridCells, const float sqinfluenceradius, const float boundNlSqInflRad)
 	{
-		// consistency rule of the reference (src/cuda/buildneibs.cu:444-455): SA arrays come together or not at all
-		const bool has_vertices = bufread.getData<BUFFER_VERTICES>() != NULL;
-		const bool has_boundelements = bufread.getData<BUFFER_BOUNDELEMENTS>() != NULL;
-		if (has_vertices != has_boundelements)
-			throw std::invalid_argument("buildNeibsList: BUFFER_VERTICES and BUFFER_BOUNDELEMENTS must be both present or both absent");
-		if (has_vertices)
-			sphx_not_built("buildNeibsList with SA_BOUNDARY vertex/segment lists");
-		sphx_throw(sphx_build_neibs(m_c->ctx(), bufwrite.getData<BUFFER_NEIBSLIST>(),
-			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+		// consistency rule of the reference (src/cuda/buildneibs.cu:440-455): the SA arrays come together or not at all
+		const vertexinfo *vertices = bufread.getData<BUFFER_VERTICES>();
+		const float4 *boundelem = bufread.getData<BUFFER_BOUNDELEMENTS>();
+		float2 **vertPos = bufwrite.getRawPtr<BUFFER_VERTPOS>();
+		if (vertices || boundelem || vertPos) {
+			if (!vertices || !boundelem || !vertPos)
+				throw std::invalid_argument("inconsistent params to buildNeibsList");
+		}
+		sphx_params prm;
+		sphx_throw(sphx_get_params(m_c->ctx(), &prm));
+		if (prm.boundarytype == SPHX_SA_BOUNDARY && !vertices)
+			throw std::invalid_argument("missing data");
+		sphx_throw(sphx_build_neibs_sa(m_c->ctx(), bufwrite.getData<BUFFER_NEIBSLIST>(),
+			vertPos ? vertPos[0] : NULL, vertPos ? vertPos[1] : NULL, vertPos ? vertPos[2] : NULL,
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(), vertices, boundelem, bufread.getData<BUFFER_HASH>(),
 			bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_CELLEND>(),
 			numParticles, particleRangeEnd, gridCells, sqinfluenceradius, boundNlSqInflRad, NULL));
 	}
@@ -516,6 +522,73 @@ public:
 			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
 			numParticles, particleRangeEnd, slength, influenceradius, NULL));
 	}
+};
+
+// ---- boundary-conditions engine of SA_BOUNDARY (CUDABoundaryConditionsEngine, src/cuda/boundary_conditions.cu) ----
+// Solid walls: vertex normals, initial gamma, segment and vertex boundary conditions.  Open boundaries (particle creation and
+// removal, water depth, corner vertices, IO masses) are not built.
+#include "engine_boundary_conditions.h"
+class HIPBoundaryConditionsEngine : public AbstractBoundaryConditionsEngine
+{
+	HIPEngineContextPtr m_c;
+public:
+	explicit HIPBoundaryConditionsEngine(HIPEngineContextPtr c) : m_c(c) {}
+
+	void uploadNumOpenVertices(const uint&) { sphx_not_built("uploadNumOpenVertices (open boundaries)"); }
+
+	// vel and gGam are updated in place for the boundary elements (src/cuda/boundary_conditions.cu:134-148)
+	void saSegmentBoundaryConditions(BufferList &bufwrite, BufferList const& bufread, const uint numParticles,
+		const uint particleRangeEnd, const float deltap, const float slength, const float influenceradius,
+		const int step, const RunMode run_mode)
+	{
+		sphx_throw(sphx_sa_segment_bc(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VERTICES>(), bufread.getData<BUFFER_BOUNDELEMENTS>(),
+			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
+			bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, deltap, slength, influenceradius,
+			step, run_mode == REPACK ? SPHX_REPACK : SPHX_SIMULATE, NULL));
+	}
+
+	void findOutgoingSegment(BufferList&, BufferList const&, const uint, const uint, const float, const float, const float)
+	{ sphx_not_built("findOutgoingSegment (open boundaries)"); }
+
+	// without open boundaries: the density of the vertex particles; no particle is created, *newNumParticles is left alone
+	void saVertexBoundaryConditions(BufferList &bufwrite, BufferList const& bufread, const uint numParticles,
+		const uint particleRangeEnd, const float deltap, const float slength, const float influenceradius,
+		const int step, const bool, const float, uint*, const uint, const uint, const uint, const RunMode run_mode)
+	{
+		// sa_vertex_bc_params takes pos from the read list and vel / gGam from the write list (src/cuda/sa_bc_params.h)
+		sphx_throw(sphx_sa_vertex_bc(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+			bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd,
+			deltap, slength, influenceradius, step, run_mode == REPACK ? SPHX_REPACK : SPHX_SIMULATE, NULL));
+	}
+
+	void computeVertexNormal(const BufferList& bufread, BufferList& bufwrite, const uint numParticles, const uint particleRangeEnd)
+	{
+		sphx_throw(sphx_sa_compute_vertex_normal(m_c->ctx(), bufwrite.getData<BUFFER_BOUNDELEMENTS>(),
+			bufread.getData<BUFFER_VERTICES>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+			bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, NULL));
+	}
+
+	void saInitGamma(const BufferList& bufread, BufferList& bufwrite, const float slength, const float influenceradius,
+		const float deltap, const float epsilon, const uint numParticles, const uint particleRangeEnd)
+	{
+		const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
+		if (!vertPos)
+			throw std::invalid_argument("saInitGamma: BUFFER_VERTPOS missing");
+		sphx_throw(sphx_sa_init_gamma(m_c->ctx(), bufwrite.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_GRADGAMMA>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
+			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
+			bufread.getData<BUFFER_NEIBSLIST>(), slength, influenceradius, deltap, epsilon, numParticles, particleRangeEnd, NULL));
+	}
+
+	void initIOmass_vertexCount(BufferList&, const BufferList&, const uint, const uint) { sphx_not_built("initIOmass_vertexCount (open boundaries)"); }
+	void initIOmass(BufferList&, const BufferList&, const uint, const uint, const float) { sphx_not_built("initIOmass (open boundaries)"); }
+	void disableOutgoingParts(const BufferList&, BufferList&, const uint, const uint) { sphx_not_built("disableOutgoingParts (open boundaries)"); }
+	void downloadIOwaterdepth(uint*, const uint*, const uint) { sphx_not_built("downloadIOwaterdepth (open boundaries)"); }
+	void uploadIOwaterdepth(const uint*, uint*, const uint) { sphx_not_built("uploadIOwaterdepth (open boundaries)"); }
+	void saIdentifyCornerVertices(const BufferList&, BufferList&, const uint, const uint, const float, const float)
+	{ sphx_not_built("saIdentifyCornerVertices (open boundaries)"); }
 };
 
 // ---- post-processing (CUDAPostProcessEngine<pptype, kerneltype, boundarytype, simflags>, src/cuda/post_process.cu:88-660) ----

@@ -144,6 +144,16 @@ static SimFramework *make_framework(Case const& c)
 			boundary<DYN_BOUNDARY>,
 			add_flags<ENABLE_MULTIFLUID>
 		);
+	} else if (name == "StillWaterSA") {   // src/problems/StillWaterSA.cu:38-46: solid SA walls (the option set of the SABox mirror)
+		SETUP_FRAMEWORK(
+			kernel<WENDLAND>,
+			formulation<SPH_F1>,
+			viscosity<DYNAMICVISC>,
+			boundary<SA_BOUNDARY>,
+			periodicity<PERIODIC_NONE>,
+			densitydiffusion<BREZZI>,
+			add_flags<ENABLE_DTADAPT | ENABLE_DENSITY_SUM>
+		);
 	} else if (name == "CompleteSaExample") {   // src/problems/CompleteSaExample.cu:39-47: compiles and constructs; its physics is not built
 		SETUP_FRAMEWORK(
 			kernel<WENDLAND>,

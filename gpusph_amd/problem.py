@@ -822,7 +822,7 @@ class SABox(Problem):
       vertices       uint4   ids of the three vertices of a segment (0 elsewhere)
       boundelements  float4  unit normal towards the fluid and area of a segment (vertices: filled by computeVertexNormal)
       gradgamma      float4  (grad gamma, gamma); NaN until the boundary-conditions engine initialises it
-    Wendland kernel (the only one the reference's SA code supports, src/cuda/gamma.cuh:241-250)."""
+    Framework options, list size, deltap and smoothing are StillWaterSA's (src/problems/StillWaterSA.cu:38-57).  Wendland kernel (the only one the reference's SA code supports, src/cuda/gamma.cuh:241-250)."""
 
     def __init__(self, deltap=0.05, *, l=0.6, w=0.5, h=0.5, H=0.35, viscosity="DYNAMICVISC", jitter=0.0,
                  linearization=D.DEFAULT_LINEARIZATION):
@@ -832,9 +832,9 @@ class SABox(Problem):
         sp.kerneltype = D.WENDLAND
         sp.boundarytype = D.SA_BOUNDARY
         self.set_viscosity(viscosity)
-        sp.densitydiffusiontype = D.DENSITY_DIFFUSION_NONE
-        sp.simflags = D.ENABLE_DTADAPT
-        sp.dtadaptfactor = 0.3
+        sp.densitydiffusiontype = D.BREZZI
+        sp.densityDiffCoeff = 0.05
+        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_DENSITY_SUM
         self.linearization = linearization
         self.jitter = jitter
         self.set_deltap(deltap)
@@ -851,7 +851,8 @@ class SABox(Problem):
         pp.set_equation_of_state(0, 7.0, float(c0))
         pp.set_kinematic_visc(0, 1.0e-2)
         # two boundary elements per lattice square inside the wider boundary radius: near a corner of the tank a particle
-        # sees ~150 fluid + boundary neighbours, more than the default section (resize_neiblist, src/ProblemCore.h:341-353)
+        # sees ~150 fluid + boundary neighbours, more than the default section: resize_neiblist(128+128, 64)
+        # (src/problems/StillWaterSA.cu:54, src/ProblemCore.h:341-353)
         sp.neibboundpos = 256 - 1
         sp.neiblistsize = 256 + 64
         self.initialize()

@@ -99,6 +99,10 @@ def write_state(path, arrs):
         f.write(np.ascontiguousarray(arrs["vel"], dtype=np.float32).tobytes())
         f.write(np.ascontiguousarray(arrs["info"]).view(np.uint16).tobytes())
         f.write(np.ascontiguousarray(arrs["hash"]).view(np.uint32).tobytes())
+        if "vertices" in arrs:      # SA_BOUNDARY: BUFFER_VERTICES, BUFFER_BOUNDELEMENTS, BUFFER_GRADGAMMA
+            f.write(np.ascontiguousarray(arrs["vertices"], dtype=np.uint32).tobytes())
+            f.write(np.ascontiguousarray(arrs["boundelements"], dtype=np.float32).tobytes())
+            f.write(np.ascontiguousarray(arrs["gradgamma"], dtype=np.float32).tobytes())
 
 
 def read_out(path):
@@ -110,5 +114,12 @@ def read_out(path):
     pos = np.frombuffer(raw, np.float32, 4 * n, o).reshape(n, 4); o += 16 * n
     vel = np.frombuffer(raw, np.float32, 4 * n, o).reshape(n, 4); o += 16 * n
     info = np.frombuffer(raw, np.uint16, 4 * n, o).reshape(n, 4); o += 8 * n
-    hsh = np.frombuffer(raw, np.uint32, n, o)
-    return dict(n=n, dt=dt, t=t, pos=pos, vel=vel, info=info, hash=hsh)
+    hsh = np.frombuffer(raw, np.uint32, n, o); o += 4 * n
+    out = dict(n=n, dt=dt, t=t, pos=pos, vel=vel, info=info, hash=hsh)
+    if len(raw) > o:                # the SA initialisation run appends its buffers and the list counters
+        out["vertices"] = np.frombuffer(raw, np.uint32, 4 * n, o).reshape(n, 4); o += 16 * n
+        out["boundelements"] = np.frombuffer(raw, np.float32, 4 * n, o).reshape(n, 4); o += 16 * n
+        out["gradgamma"] = np.frombuffer(raw, np.float32, 4 * n, o).reshape(n, 4); o += 16 * n
+        out["vertpos"] = [np.frombuffer(raw, np.float32, 2 * n, o + 8 * n * k).reshape(n, 2) for k in range(3)]; o += 24 * n
+        out["counters"] = np.frombuffer(raw, np.int32, 4, o)
+    return out

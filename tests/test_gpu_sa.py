@@ -124,3 +124,33 @@ def test_what_is_not_built_says_so(pair):
     k = other.k
     with pytest.raises(capi.SphxInvalidArgument, match="without SA_BOUNDARY"):
         k.sa_vertex_bc(other.vel, other.vel, other.pos, other.info, other.hash, other.cellStart, other.neibslist, other.n, other.n, 1)
+
+
+def test_cpp_adapters_run_the_sa_initialisation(tmp_path):
+    """The engines the GPUSPH tree would load (HIPNeibsEngine, HIPBoundaryConditionsEngine behind a framework built by
+    StillWaterSA's own SETUP_FRAMEWORK expression), driven through the abstract interfaces with BufferLists: neighbour phase
+    with the SA buffers and the initialisation sequence of the boundary conditions, bit-equal to the Python driver."""
+    import subprocess
+    import host_case as hc
+    prob = SABox(deltap=0.05, jitter=0.1)
+    eng = _engine(prob, clobber_neibslist=True)
+    n = prob.num_particles
+    case = tmp_path / "case.txt"
+    case.write_text("\n".join(hc.case_lines(prob, "StillWaterSA", allocated=eng.alloc) + hc.driver_lines(prob, eng, 0)) + "\n")
+    hc.write_state(str(tmp_path / "state.bin"), prob.copy_to_array())
+    subprocess.check_call([hc.exe("example_engines"), str(case), str(tmp_path / "state.bin"), str(tmp_path / "out.bin")])
+    out = hc.read_out(str(tmp_path / "out.bin"))
+    eng.build_neibs()
+    eng.sa_boundary_conditions(0)
+    assert out["n"] == n == eng.n
+    for name, dt in (("pos", None), ("vel", None), ("boundelements", None), ("gradgamma", None)):
+        assert np.array_equal(_bits(out[name]), _bits(_np(getattr(eng, name))[:n])), name
+    assert np.array_equal(out["vertices"], _np(eng.vertices, np.uint32)[:n])
+    assert np.array_equal(out["info"], _np(eng.info, np.uint16)[:n]) and np.array_equal(out["hash"], _np(eng.hash, np.uint32)[:n])
+    for k in range(3):
+        assert np.array_equal(_bits(out["vertpos"][k]), _bits(_np(eng.vertpos[k])[:n]))
+    info = eng.neibs_info()
+    assert tuple(out["counters"][:3]) == (info.numInteractions, info.maxFluidBoundaryNeibs, info.maxVertexNeibs)
+    assert out["counters"][3] == n                      # no particle was created
+    t = info_type(out["info"])
+    assert np.isfinite(out["gradgamma"][t != D.PT_BOUNDARY]).all() and (out["vel"][t == D.PT_BOUNDARY, 3] > 0).sum() > 200
