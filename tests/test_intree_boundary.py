@@ -18,7 +18,7 @@ import pytest
 import host_case as hc
 from gpusph_amd import defs as D
 from gpusph_amd.params import SphxParams
-from gpusph_amd.problem import DamBreak3D, StillWater, WaveTank
+from gpusph_amd.problem import DamBreak3D, StillWater, WaveTank, SABox
 
 REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src")), reason="needs the GPUSPH tree")
@@ -108,6 +108,17 @@ def test_stillwater_sps_variant(tmp_path):
     prob = StillWater(8, viscosity="SPSVISC")
     out = run_check(tmp_path, hc.case_lines(prob, "StillWaterSPS", rhodiff=D.FERRARI))
     assert_options(out, prob.simparams)
+    assert_params(out, prob, prob.num_particles)
+
+
+def test_stillwater_sa_framework_and_constants(tmp_path):
+    """SA_BOUNDARY: the framework StillWaterSA's SETUP_FRAMEWORK expression builds has a boundary-conditions engine, and
+    what setconstants uploads for it equals the SABox mirror's parameters (incl. the resized three-section list)"""
+    prob = SABox(0.05)
+    out = run_check(tmp_path, hc.case_lines(prob, "StillWaterSA"))
+    assert_options(out, prob.simparams)
+    assert out["options"]["boundarytype"] == D.SA_BOUNDARY and out["options"]["densitydiffusiontype"] == D.BREZZI
+    assert out["options"]["simflags"] & D.ENABLE_DENSITY_SUM
     assert_params(out, prob, prob.num_particles)
 
 
