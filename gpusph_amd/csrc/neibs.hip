@@ -411,15 +411,18 @@ cell_fluid_end_kernel(uint32_t *__restrict__ cellFluidEnd, const uint32_t *__res
 
 #define NEIB_MLP 4   // candidate positions fetched per batch in the fluid segment
 #define NEIB_FRING 32   // rows of the fluid section a wave keeps in LDS before writing them out as full lines
-#define NEIB_BRING 8    // ... of the boundary section
+#define NEIB_BRING 16   // ... of the boundary section
 
 // Per-wave LDS staging of list entries.  The list is slot-major
 // ([slot*stride + particle], 2 B) and the lanes of a wave reach a given slot at different times, so storing
 // entries as they are found wrote every 128-B line of the list ~12 times (measured: 53 GB of HBM writes for a
-// 4.3 GB list at 32 M particles).  A wave parks its entries in a ring of FR (fluid) + BR (boundary) rows x 64
-// lanes; at wave-uniform points the rows that EVERY walking lane has filled are written out as whole 128-B
-// lines.  A lane that runs more than a ring ahead of the slowest one falls back to direct stores for the rest
-// of its list (its ring-resident entries stay a prefix [.., rf) of what it stored).
+// 4.3 GB list at 32 M particles).  Every lane parks its entries in its own column of a ring of FR (fluid) + BR
+// (boundary) rows: the ring holds the window [flushed, stored) of the lane's section.  Rows leave the ring in
+// wave-wide steps: when some lane's window is about to fill up, the oldest row r of that lane is written for
+// EVERY lane whose next row to flush is r and that has it -- in a wave of neighbouring particles, whose lists grow
+// at similar rates, that is most of a 128-B line.  Lanes that lag behind keep their entries and write the
+// row later (with the lanes that lag like them).  Nothing is ever stored around the ring, so the hot loop has no
+// "direct store" state to carry.
 template<int FR, int BR>
 struct NeibRing {
 	neibdata (*fring)[64];
@@ -427,66 +430,64 @@ struct NeibRing {
 	neibdata *column;        // &list[particle]
 	size_t stride;
 	uint32_t nbp, lane;
-	uint32_t sf, sb;         // entries stored (== neibs_num unless the list overflowed)
-	uint32_t rf, rb;         // ... of which the first rf / rb went through the rings
-	uint32_t fbase, bbase;   // wave-uniform: rows below were written out
-	bool fdirect, bdirect;
+	uint32_t sf, sb;         // entries stored so far (== neibs_num unless the list overflowed)
+	uint32_t ff, fb;         // ... of which the first ff / fb have been written to the list
 
 	__device__ __forceinline__ void init(neibdata (*rows)[64], neibdata *col, size_t str, uint32_t neibboundpos, uint32_t ln)
 	{
 		fring = rows; bring = rows + FR; column = col; stride = str; nbp = neibboundpos; lane = ln;
-		sf = sb = rf = rb = fbase = bbase = 0; fdirect = bdirect = false;
+		sf = sb = ff = fb = 0;
 	}
+	// wave-uniform control flow (call with the lanes of the wave converged): make room for `need` more fluid entries in
+	// every lane; once a lane is short of room, rows are written until it has `need + slack` free
+	__device__ __forceinline__ void room_f(uint32_t need, uint32_t slack)
+	{
+		if (!__builtin_amdgcn_ballot_w64(sf + need - ff > (uint32_t)FR)) return;
+		for (;;) {
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(sf + need + slack - ff > (uint32_t)FR && sf > ff);
+			if (!m) break;
+			const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)ff, (int)__builtin_ctzll(m));
+			if (ff == r && sf > r) { column[(size_t)r*stride] = fring[r % FR][lane]; ++ff; }
+		}
+	}
+	__device__ __forceinline__ void room_b(uint32_t need, uint32_t slack)
+	{
+		if (!__builtin_amdgcn_ballot_w64(sb + need - fb > (uint32_t)BR)) return;
+		for (;;) {
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(sb + need + slack - fb > (uint32_t)BR && sb > fb);
+			if (!m) break;
+			const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)__builtin_ctzll(m));
+			if (fb == r && sb > r) { column[(size_t)(nbp - r)*stride] = bring[r % BR][lane]; ++fb; }
+		}
+	}
+	// stores from divergent code (the non-fluid tail of a cell, the terminators): a lane whose window is full writes its
+	// own oldest entry first
 	__device__ __forceinline__ void store_f(uint32_t slot, uint32_t val)
 	{
-		if (!fdirect && slot - fbase < (uint32_t)FR) { fring[slot % FR][lane] = (neibdata)val; rf = slot + 1u; }
-		else { fdirect = true; column[(size_t)slot*stride] = (neibdata)val; }
+		if (slot - ff >= (uint32_t)FR) { column[(size_t)ff*stride] = fring[ff % FR][lane]; ++ff; }
+		fring[slot % FR][lane] = (neibdata)val;
+		sf = slot + 1u;
 	}
-	// branch-light variant for the hot fluid-segment loop: every lane writes (lanes with nothing to park hit the
-	// spare row FR+BR), only the rare direct store sits behind a branch.  ok = this lane stores `val` at `slot`.
-	// Returns true if the entry could not be parked and the caller must store it with store_direct().
-	__device__ __forceinline__ bool store_f_sel(uint32_t slot, uint32_t val, bool ok)
-	{
-		const bool inring = ok && !fdirect && (slot - fbase < (uint32_t)FR);
-		fring[inring ? slot % FR : (uint32_t)(FR + BR)][lane] = (neibdata)val;
-		rf = inring ? slot + 1u : rf;
-		const bool direct = ok && !inring;
-		fdirect = fdirect || direct;
-		return direct;
-	}
-	__device__ __forceinline__ void store_direct(uint32_t slot, uint32_t val) { column[(size_t)slot*stride] = (neibdata)val; }
 	__device__ __forceinline__ void store_b(uint32_t k, uint32_t val)   // k-th boundary entry, slot neibboundpos - k
 	{
-		if (!bdirect && k - bbase < (uint32_t)BR) { bring[k % BR][lane] = (neibdata)val; rb = k + 1u; }
-		else { bdirect = true; column[(size_t)(nbp - k)*stride] = (neibdata)val; }
+		if (k - fb >= (uint32_t)BR) { column[(size_t)(nbp - fb)*stride] = bring[fb % BR][lane]; ++fb; }
+		bring[k % BR][lane] = (neibdata)val;
+		sb = k + 1u;
 	}
-	// write out the rows every walking lane has filled (wave-uniform control; one ballot per row, no reduction)
-	__device__ __forceinline__ void flush(bool walking, unsigned long long wmask)
-	{
-		if (!wmask) return;
-		while (__builtin_amdgcn_ballot_w64(walking && sf > fbase) == wmask) {
-			const neibdata v = fring[fbase % FR][lane];
-			if (fbase < rf) column[(size_t)fbase*stride] = v;
-			++fbase;
-		}
-		while (__builtin_amdgcn_ballot_w64(walking && sb > bbase) == wmask) {
-			const neibdata v = bring[bbase % BR][lane];
-			if (bbase < rb) column[(size_t)(nbp - bbase)*stride] = v;
-			++bbase;
-		}
-	}
-	// end of the walk: whatever is still parked (terminators included)
+	// end of the walk: whatever is still parked (terminators included); wave-uniform control flow
 	__device__ __forceinline__ void finish()
 	{
-		while (__builtin_amdgcn_ballot_w64(fbase < rf)) {
-			const neibdata v = fring[fbase % FR][lane];
-			if (fbase < rf) column[(size_t)fbase*stride] = v;
-			++fbase;
+		for (;;) {
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(ff < sf);
+			if (!m) break;
+			const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)ff, (int)__builtin_ctzll(m));
+			if (ff == r && sf > r) { column[(size_t)r*stride] = fring[r % FR][lane]; ++ff; }
 		}
-		while (__builtin_amdgcn_ballot_w64(bbase < rb)) {
-			const neibdata v = bring[bbase % BR][lane];
-			if (bbase < rb) column[(size_t)(nbp - bbase)*stride] = v;
-			++bbase;
+		for (;;) {
+			const unsigned long long m = __builtin_amdgcn_ballot_w64(fb < sb);
+			if (!m) break;
+			const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)fb, (int)__builtin_ctzll(m));
+			if (fb == r && sb > r) { column[(size_t)(nbp - r)*stride] = bring[r % BR][lane]; ++fb; }
 		}
 	}
 };
@@ -497,7 +498,7 @@ struct NeibRing {
 // cell (in the fluid segment the type is known from the index), and DYN/LJ boundary particles, which
 // never list boundary neighbours, do not visit the non-fluid tail at all.  Candidate order, tests and
 // encodings are the reference's, so the list is bit-identical.
-// Stores go through NeibRing (above), flushed after every neighbour cell.
+// Stores go through NeibRing (above).
 typedef uint32_t neib_u32x4 __attribute__((ext_vector_type(4)));
 // candidate row j0 + u of the position array as a buffer load: descriptor in SGPRs, byte offset j0*16 in one VGPR,
 // u*16 in the instruction -- no per-candidate address arithmetic; rows past the array read as zeros
@@ -526,7 +527,7 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	const uint32_t *__restrict__ cellFluidEnd,
 	uint32_t particleRangeEnd, uint32_t posRows, float sqinfluenceradius, NeibsCounters *__restrict__ counters)
 {
-	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING + 1][64];
+	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING][64];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t index = blockIdx.x*BLOCK_NEIBS + threadIdx.x;
 	const bool inRange = index < particleRangeEnd;
@@ -597,63 +598,58 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 			uint32_t encv = code;             // cell code still owed to the first entry stored for this (cell, type) run
 			uint32_t neib_type = PT_FLUID;
 			// --- fluid segment: type known, NEIB_MLP position gathers in flight ---
-			// wave-uniform: the last slot a lane may fill in a batch without leaving the ring or the fluid section
-			const uint32_t lim = min(ring.fbase + (uint32_t)NEIB_FRING, p.neibboundpos - 1u);
 			const uint32_t selfrel = (cell == 13u) ? index - bucketStart : 0xFFFFFFFFu;
-			for (uint32_t j0 = bucketStart; j0 < fluidEnd; j0 += NEIB_MLP) {
+			for (uint32_t j0 = bucketStart; __builtin_amdgcn_ballot_w64(j0 < fluidEnd); j0 += NEIB_MLP) {
+				// the loop is kept wave-uniform (a lane past its segment masks its candidates) so that the ring can be
+				// flushed by the whole wave from inside it
+				const bool in = j0 < fluidEnd;
 				float4 cp[NEIB_MLP];
 				if (BUF) {
 #pragma unroll
 					for (int u = 0; u < NEIB_MLP; ++u) cp[u] = load_pos_row(posRsrc, j0*16u, u);
 				} else {
 #pragma unroll
-					for (int u = 0; u < NEIB_MLP; ++u) cp[u] = posArray[min(j0 + (uint32_t)u, fluidEnd - 1u)];
+					for (int u = 0; u < NEIB_MLP; ++u) cp[u] = posArray[in ? min(j0 + (uint32_t)u, fluidEnd - 1u) : 0u];
 				}
-				// The scan is instruction-issue bound (PMC: VALU + SALU of this loop), so the common case is a
-				// straight line: every lane writes the candidate at its current slot of the ring and only an accepted
-				// one advances the slot (the next candidate overwrites a rejected one); an inactive candidate turns its
-				// distance into NaN (0*w) instead of a separate test; list-full, ring-full and lanes already storing
-				// directly are excluded per batch by one wave-uniform test and take the general code below.
+				// The scan is instruction-issue bound (PMC: VALU + SALU of this loop), so it is a straight line: every lane
+				// writes the candidate at its current slot of the ring and only an accepted one advances the slot (the next
+				// candidate overwrites a rejected one); an inactive candidate turns its distance into NaN (0*w) instead of
+				// a separate test.  A full list is the one case left to the general code below (one wave-uniform test).
+				ring.room_f(NEIB_MLP, 4);
 				float r2[NEIB_MLP];
 #pragma unroll
 				for (int u = 0; u < NEIB_MLP; ++u) {
 					const float rx = px - cp[u].x, ry = py - cp[u].y, rz = pz - cp[u].z;
 					r2[u] = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
 				}
-				const uint32_t jrel = j0 - bucketStart, rem = fluidEnd - j0;
-				if (!__builtin_amdgcn_ballot_w64(ring.fdirect || nf + (uint32_t)NEIB_MLP > lim)) {
+				const uint32_t jrel = j0 - bucketStart;
+				const uint32_t rem = in ? fluidEnd - j0 : 0u;
+				if (!__builtin_amdgcn_ballot_w64(nf + (uint32_t)NEIB_MLP >= p.neibboundpos)) {
 #pragma unroll
 					for (int u = 0; u < NEIB_MLP; ++u) {
 						const float r2a = fmaf(0.0f, cp[u].w, r2[u]);
-						bool acc = r2a < sqinfluenceradius;
-						if (u) acc = acc && ((uint32_t)u < rem);
+						bool acc = (r2a < sqinfluenceradius) && ((uint32_t)u < rem);
 						if (cell == 13u) acc = acc && (jrel + (uint32_t)u != selfrel);
 						ring.fring[nf % (uint32_t)NEIB_FRING][lane] = (neibdata)(jrel + (uint32_t)u + encv);
 						encv = acc ? 0u : encv;
 						nf += acc ? 1u : 0u;
 					}
-					ring.sf = ring.rf = nf;
+					ring.sf = nf;
 					continue;
 				}
-				uint32_t dslot[NEIB_MLP], dval[NEIB_MLP], dmask = 0;
 #pragma unroll
 				for (int u = 0; u < NEIB_MLP; ++u) {
 					const uint32_t neib_index = j0 + (uint32_t)u;
 					const bool acc = (r2[u] < sqinfluenceradius) && ((uint32_t)u < rem) && (neib_index != index) &&
 						is_active_w(cp[u].w);
-					const uint32_t offset = nf;       // neibListOffset(PT_FLUID)
 					nf += acc ? 1u : 0u;
 					const bool ok = acc && !too_many_neibs(p, nf, nb, nv, PT_FLUID);
-					dslot[u] = offset; dval[u] = (neib_index - bucketStart) + encv;
-					dmask |= ring.store_f_sel(offset, dval[u], ok) ? (1u << u) : 0u;
-					ring.sf = ok ? nf : ring.sf;
+					ring.fring[ring.sf % (uint32_t)NEIB_FRING][lane] = (neibdata)((neib_index - bucketStart) + encv);
+					ring.sf += ok ? 1u : 0u;
 					encv = ok ? 0u : encv;
 				}
-				if (dmask) {
-#pragma unroll
-					for (int u = 0; u < NEIB_MLP; ++u) if (dmask & (1u << u)) ring.store_direct(dslot[u], dval[u]);
-				}
 			}
+			ring.room_b(NEIB_BRING/2, 0);
 			// --- non-fluid tail (boundary / vertex / testpoint candidates): the reference's loop as is ---
 			for (uint32_t neib_index = max(fluidEnd, bucketStart); neib_index < bucketEnd; ++neib_index) {
 				if (neib_index == index) continue;
@@ -683,15 +679,14 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 					if (neib_type == PT_FLUID) nf++; else if (neib_type == PT_BOUNDARY) nb++; else nv++;
 					if (!too_many_neibs(p, nf, nb, nv, neib_type)) {
 						const uint32_t val = (neib_index - bucketStart) + encv;
-						if (neib_type == PT_FLUID) { ring.store_f(num, val); ring.sf = nf; }
-						else if (neib_type == PT_BOUNDARY) { ring.store_b(num, val); ring.sb = nb; }
+						if (neib_type == PT_FLUID) ring.store_f(num, val);
+						else if (neib_type == PT_BOUNDARY) ring.store_b(num, val);
 						else column[(size_t)neib_list_offset(p, num, neib_type)*p.stride] = (neibdata)val;
 						encv = 0u;
 					}
 				}
 			}
 		}
-		ring.flush(walking, wmask);
 	}
 
 	// terminators (every particle below particleRangeEnd gets them, walking or not), then what is left in the rings
