@@ -573,22 +573,37 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	const __amdgpu_buffer_rsrc_t posRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(posArray), 0,
 		BUF ? (int)(posRows*16u) : 0, 0x00020000);
 	const unsigned long long wmask = __builtin_amdgcn_ballot_w64(walking);
-	if (wmask)
-	for (int z = -1; z <= 1; z++) for (int y = -1; y <= 1; y++) for (int x = -1; x <= 1; x++) {
+	// first particle, end of the fluid segment and end of neighbour cell `c` of every lane.  The three loads do not depend
+	// on each other and are issued one cell ahead of their use, so that a cell costs one memory round trip (its first batch
+	// of positions) instead of two
+	struct CellMeta { uint32_t start, fluidEnd, end; };
+	auto cell_meta = [&](int c) {
+		const int x = c % 3 - 1, y = (c/3) % 3 - 1, z = c/9 - 1;
 		int gx = gridPos.x, gy = gridPos.y, gz = gridPos.z;
 		bool valid = walking;
 		valid = valid && neib_cell_axis(gx, x, p.gs[0], p.periodic & SPHX_PERIODIC_X);
 		valid = valid && neib_cell_axis(gy, y, p.gs[1], p.periodic & SPHX_PERIODIC_Y);
 		valid = valid && neib_cell_axis(gz, z, p.gs[2], p.periodic & SPHX_PERIODIC_Z);
-		uint32_t cellHash = 0, bucketStart = CELL_EMPTY;
-		if (valid) {
-			cellHash = grid_hash(p, gx, gy, gz);
-			bucketStart = cellStart[cellHash];
-		}
+		const uint32_t cellHash = valid ? grid_hash(p, gx, gy, gz) : 0u;
+		CellMeta m;
+		m.start = cellStart[cellHash];
+		m.fluidEnd = cellFluidEnd[cellHash];
+		m.end = cellEnd[cellHash];
+		if (!valid) m.start = CELL_EMPTY;
+		return m;
+	};
+	CellMeta nextMeta = { CELL_EMPTY, 0u, 0u };
+	if (wmask) nextMeta = cell_meta(0);
+	if (wmask)
+	for (int c = 0; c < 27; ++c) {
+		const CellMeta cur = nextMeta;
+		nextMeta = cell_meta(min(c + 1, 26));
+		const int x = c % 3 - 1, y = (c/3) % 3 - 1, z = c/9 - 1;
+		const uint32_t bucketStart = cur.start;
 		if (bucketStart != CELL_EMPTY) {
-			const uint32_t fluidEnd = cellFluidEnd[cellHash];
-			const uint32_t bucketEnd = fluidOnly ? fluidEnd : cellEnd[cellHash];
-			const uint32_t cell = (uint32_t)((x + 1) + (y + 1)*3 + (z + 1)*9);
+			const uint32_t fluidEnd = cur.fluidEnd;
+			const uint32_t bucketEnd = fluidOnly ? fluidEnd : cur.end;
+			const uint32_t cell = (uint32_t)c;
 
 			const float px = fmaf(-(float)x, p.cs[0], pos.x);
 			const float py = fmaf(-(float)y, p.cs[1], pos.y);
