@@ -373,6 +373,203 @@ sa_init_gamma_kernel(DevParams p, SaGammaArgs a)
 	a.newGGam[index] = make_float4(gGam.x, gGam.y, gGam.z, gam);
 }
 
+// ---- forces with SA_BOUNDARY (solid walls, Newtonian laminar viscosity or inviscid, continuity equation) ----------------
+// forcesDevice<PT_FLUID, PT_FLUID | PT_VERTEX | PT_BOUNDARY> + finalizeforcesDevice (src/cuda/forces_kernel.def:3914-4150)
+// in one launch per fluid particle: fluid and vertex neighbours interact as particles, a boundary element contributes
+// through |grad gamma_as| (continuity :2079-2090, pressure :2414-2427, wall shear :2680-2718); the sums are divided by gamma
+// (forces_fixup :3192-3210).  Written like the boundary-conditions kernels above: the reference's operation order, IEEE
+// division and sqrt, no contraction other than the fmaf the CPU oracle spells out -- the SA path is not yet a roofline path.
+struct SaForcesArgs {
+	float4 *forces;
+	float *cfl;
+	const float4 *pos, *vel, *gGam, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t fromParticle, toParticle, cflOffset;
+	float deltap;
+};
+
+__device__ __forceinline__ float sa_dot3(float ax, float ay, float az, float bx, float by, float bz)
+{ return fmaf(az, bz, fmaf(ay, by, ax*bx)); }
+__device__ __forceinline__ float sa_P(const DevParams &p, float rho_tilde, uint32_t fl)
+{ return p.bcoeff[fl]*(powf(rho_tilde + 1.0f, p.gammacoeff[fl]) - 1.0f); }
+__device__ __forceinline__ float sa_sound_speed(const DevParams &p, float rho_tilde, uint32_t fl)
+{ return p.sscoeff[fl]*powf(rho_tilde + 1.0f, p.sspowercoeff[fl]); }
+
+// visc_avg<ViscSpec> (src/cuda/visc_avg.cu:40-190), neighbour mass included
+__device__ __forceinline__ float sa_visc_avg_rho(int avgop, float rho, float neib_rho, float neib_mass)
+{
+	if (avgop == SPHX_ARITHMETIC) return neib_mass*(rho + neib_rho)/(rho*neib_rho);
+	if (avgop == SPHX_HARMONIC) return 4*neib_mass/(rho + neib_rho);
+	return 2*neib_mass*(1.0f/sqrtf(rho*neib_rho));
+}
+__device__ __forceinline__ float sa_visc_avg_dyn(int avgop, bool is_const, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
+{
+	if (is_const) return 2*neib_mass*visc/(rho*neib_rho);
+	if (avgop == SPHX_ARITHMETIC) return neib_mass*(visc + neib_visc)/(rho*neib_rho);
+	if (avgop == SPHX_HARMONIC) return 4*neib_mass*(visc*neib_visc)/(visc + neib_visc)/(rho*neib_rho);
+	return 2*neib_mass*sqrtf(visc*neib_visc)/(rho*neib_rho);
+}
+__device__ __forceinline__ float sa_visc_avg(const DevParams &p, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
+{
+	if (p.compvisc == SPHX_DYNAMIC) return sa_visc_avg_dyn(p.avgop, p.is_const_visc, visc, neib_visc, rho, neib_rho, neib_mass);
+	if (p.is_const_visc) return visc*sa_visc_avg_rho(p.avgop, rho, neib_rho, neib_mass);
+	return sa_visc_avg_dyn(p.avgop, !(p.simflags & SPHX_ENABLE_MULTIFLUID), visc*rho, neib_visc*neib_rho, rho, neib_rho, neib_mass);
+}
+
+__global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
+sa_forces_kernel(DevParams p, SaForcesArgs a)
+{
+	__shared__ float sMax[SPHX_BLOCK_FORCES/64];
+	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
+	float cflTerm = 0.0f;
+	if (index < a.toParticle) {
+		const particleinfo info = a.info[index];
+		const float4 pos = a.pos[index];
+		const bool fluid = PART_TYPE(info) == PT_FLUID;
+		if (is_active_w(pos.w)) {
+			float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			const float4 vel = a.vel[index];
+			const uint32_t fl = FLUID_NUM(info);
+			if (fluid) {
+				const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+				const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
+				const float p_precalc = sa_P(p, vel.w, fl)/(p_rho*p_rho);
+				const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
+				const bool newtonian = p.rheology == SPHX_NEWTONIAN;
+				// fluid <- fluid and fluid <- vertex: compute_all_pp_interaction with the general specialisations
+				auto particle_pair = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+					if (!is_active_w(npos.w)) return;
+					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+					if (r >= p.influenceradius) return;
+					const float4 nvel = a.vel[j];
+					const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+					const float vel_dot_pos = sa_dot3(vx, vy, vz, rx, ry, rz);
+					const float qm2 = r/p.slength - 2.0f;
+					const float f = qm2*qm2*qm2*p.fcoeff;
+					const uint32_t nfl = FLUID_NUM(a.info[j]);
+					const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+					const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
+					const float nmass = npos.w;
+					if (!density_sum) force.w += nmass*vel_dot_pos*f;
+					const float s = (p_precalc + n_precalc)*nmass*f;
+					float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+					dx -= s*rx; dy -= s*ry; dz -= s*rz;
+					if (newtonian) {
+						const float vf = sa_visc_avg(p, p.visccoeff[fl], p.visccoeff[nfl], p_rho, n_rho, nmass)*f;
+						dx += vf*vx; dy += vf*vy; dz += vf*vz;
+					}
+					force.x += dx; force.y += dy; force.z += dz;
+				};
+				for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, particle_pair);
+				for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, particle_pair);
+				// fluid <- boundary element
+				for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+					if (!is_active_w(npos.w)) return;
+					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+					if (r >= p.influenceradius + a.deltap) return;
+					const float4 nvel = a.vel[j];
+					const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+					const uint32_t nfl = FLUID_NUM(a.info[j]);
+					const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+					const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
+					const float4 be = a.boundElement[j];
+					const V3 ns = v3(be.x, be.y, be.z);
+					const float inv_h = 1.0f/p.slength;
+					V3 q_vb[3];
+					calc_vertex_rel_pos(q_vb, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+					const float ggamAS = grad_gamma_wendland(p.slength, v3(rx*inv_h, ry*inv_h, rz*inv_h), q_vb, ns);
+					const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
+					if (!density_sum) {
+						float DrDt = 0.0f;
+						DrDt -= p_rho*vn*ggamAS;
+						force.w += DrDt;
+					}
+					const float ps = (p_precalc + n_precalc)*n_rho*ggamAS;
+					float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+					dx += ps*be.x; dy += ps*be.y; dz += ps*be.z;
+					if (newtonian) {
+						const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
+						const float tx = vx - vn*be.x, ty = vy - vn*be.y, tz = vz - vn*be.z;
+						const float our_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl]*p_rho : p.visccoeff[fl];
+						const float neib_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl]*n_rho : p.visccoeff[nfl];
+						const float avg = (p.avgop == SPHX_ARITHMETIC) ? (our_mu + neib_mu)*0.5f :
+							(p.avgop == SPHX_HARMONIC) ? 2*our_mu*neib_mu/(our_mu + neib_mu) : sqrtf(our_mu*neib_mu);
+						const float c = ggamAS*2*avg/r_as;
+						const float inv_rho = 1.0f/p_rho;
+						dx -= (c*tx)*inv_rho; dy -= (c*ty)*inv_rho; dz -= (c*tz)*inv_rho;
+					}
+					force.x += dx; force.y += dy; force.z += dz;
+				});
+				// forces_fixup, gravity, CFL term
+				const float gam = a.gGam[index].w;
+				force.x /= gam; force.y /= gam; force.z /= gam; force.w /= gam;
+				force.w /= p.rho0[fl];
+				force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
+				if (p.simflags & SPHX_ENABLE_DTADAPT) {
+					const float sspeed = sa_sound_speed(p, vel.w, fl);
+					const float acc = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
+					cflTerm = fmaxf(acc, sspeed*sspeed/p.slength);
+				}
+			}
+			a.forces[index] = force;
+		}
+	}
+	// one CFL entry per block of SPHX_BLOCK_FORCES particles (maxBlockReduce)
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) cflTerm = fmaxf(cflTerm, __shfl_down(cflTerm, d));
+	if ((threadIdx.x & 63u) == 0u) sMax[threadIdx.x >> 6] = cflTerm;
+	__syncthreads();
+	if (threadIdx.x == 0 && a.cfl && (p.simflags & SPHX_ENABLE_DTADAPT)) {
+		float m = sMax[0];
+		for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) m = fmaxf(m, sMax[w]);
+		a.cfl[a.cflOffset + blockIdx.x] = m;
+	}
+}
+
+// integrateGammaDevice, quadrature flavour (src/cuda/density_sum_kernel.cu:690-765) for fluid particles at their new positions;
+// the rows of the other particle types are copied (copyTypeDataDevice, src/cuda/euler.cu:253-262)
+struct SaIntGammaArgs {
+	float4 *newGGam;
+	const float4 *oldGGam, *pos, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	float epsilon;
+};
+
+__global__ void __launch_bounds__(128)
+sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	const float4 og = a.oldGGam[index];
+	if (PART_TYPE(info) != PT_FLUID) {
+		if (PART_TYPE(info) == PT_VERTEX || PART_TYPE(info) == PT_BOUNDARY) a.newGGam[index] = og;
+		return;
+	}
+	const float4 pos = a.pos[index];
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	float4 g = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+	const V3 oldg = v3(og.x, og.y, og.z);
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float rx, float ry, float rz) {
+		const float4 be = a.boundElement[j];
+		const V3 normal = v3(be.x, be.y, be.z);
+		const V3 q = v3(rx, ry, rz)/p.slength;
+		V3 q_vb[3];
+		calc_vertex_rel_pos(q_vb, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+		const float ggamAS = grad_gamma_wendland(p.slength, q, q_vb, normal);
+		g.x += ggamAS*be.x; g.y += ggamAS*be.y; g.z += ggamAS*be.z;
+		g.w -= gamma_wendland<false>(p.slength, q, q_vb, normal, oldg, a.epsilon);
+	});
+	a.newGGam[index] = g;
+}
+
 static int sa_check(sphx_ctx *ctx, const char *who)
 {
 	if (!ctx || !ctx->have_params) return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa: constants not set");
@@ -473,5 +670,89 @@ extern "C" int sphx_sa_init_gamma(sphx_ctx *ctx, void *newGGam, const void *oldG
 	SPHX_LAUNCH_CHECK("sa_init_gamma_kernel<PT_FLUID>");
 	sa_init_gamma_kernel<PT_VERTEX><<<div_up_u(particleRangeEnd, 128), 128, 0, st>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_init_gamma_kernel<PT_VERTEX>");
+	return SPHX_OK;
+}
+
+static int sa_forces_check(sphx_ctx *ctx, const char *who)
+{
+	int rc = sa_check(ctx, who);
+	if (rc != SPHX_OK) return rc;
+	const sphx_params &q = ctx->params;
+	if (q.simflags & SPHX_ENABLE_DENSITY_SUM)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: density summation (ENABLE_DENSITY_SUM) is not built; the continuity-equation form is");
+	if (!(q.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: dynamic gamma (transport equation) is not built; ENABLE_GAMMA_QUADRATURE is");
+	if (q.simflags & (SPHX_ENABLE_MOVING_BODIES | SPHX_ENABLE_XSPH | SPHX_ENABLE_PLANES))
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built without moving bodies, XSPH and planes");
+	if (q.sph_formulation != SPHX_SPH_F1 || q.densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for SPH_F1 without density diffusion");
+	if (q.turbmodel != SPHX_LAMINAR_FLOW && q.rheologytype != SPHX_INVISCID)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for laminar flow");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius, uint32_t cflOffset,
+	int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream)
+{
+	(void)numParticles; (void)dtadaptfactor; (void)step; (void)dt;
+	int rc = sa_forces_check(ctx, "forces basicstep (SA) called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	if (run_mode != SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep_sa: the repacking force with SA_BOUNDARY is not built");
+	SPHX_REQUIRE(forces && pos && vel && info && hash && cellStart && neibsList && gGam && boundElements && vertPos0 && vertPos1 && vertPos2,
+		"sphx_forces_basicstep_sa: missing buffer");
+	SPHX_REQUIRE(!(ctx->params.simflags & SPHX_ENABLE_DTADAPT) || cfl, "sphx_forces_basicstep_sa: ENABLE_DTADAPT needs the CFL buffer");
+	SPHX_REQUIRE(fromParticle <= toParticle, "sphx_forces_basicstep_sa: empty range");
+	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
+		"sphx_forces_basicstep_sa: slength / influenceradius differ from the uploaded constants");
+	// numBlocks of the reference's basicstep: rounded up to a multiple of 4 for the reduction (src/cuda/forces.cu:741-743)
+	const uint32_t blocks = div_up_u(toParticle - fromParticle, SPHX_BLOCK_FORCES);
+	const uint32_t numBlocks = (blocks + 3u)/4u*4u;
+	if (h_numBlocks) *h_numBlocks = numBlocks;
+	if (!blocks) return SPHX_OK;
+	hipStream_t st = (hipStream_t)stream;
+	if (cfl && numBlocks > blocks) SPHX_HIP(hipMemsetAsync(cfl + cflOffset + blocks, 0, sizeof(float)*(numBlocks - blocks), st));
+	SaForcesArgs a = {};
+	a.forces = (float4*)forces; a.cfl = cfl; a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.gGam = (const float4*)gGam;
+	a.boundElement = (const float4*)boundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
+	sa_forces_kernel<<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_forces_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void *oldGGam, const void *newPos,
+	const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, int step, float t,
+	float epsilon, float slength, float influenceradius, int run_mode, void *stream)
+{
+	(void)numParticles; (void)dt; (void)step; (void)t; (void)run_mode;
+	int rc = sa_check(ctx, "integrate_gamma called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	if (!(ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_integrate_gamma: dynamic gamma (transport equation) is not built; ENABLE_GAMMA_QUADRATURE is");
+	if (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_integrate_gamma: gamma of the vertices of moving bodies is not built");
+	SPHX_REQUIRE(newGGam && oldGGam && newPos && boundElements && vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList,
+		"sphx_sa_integrate_gamma: missing buffer");
+	SPHX_REQUIRE(newGGam != oldGGam, "sphx_sa_integrate_gamma: in-place use is not supported");
+	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
+		"sphx_sa_integrate_gamma: slength / influenceradius differ from the uploaded constants");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIntGammaArgs a = {};
+	a.newGGam = (float4*)newGGam; a.oldGGam = (const float4*)oldGGam; a.pos = (const float4*)newPos;
+	a.boundElement = (const float4*)boundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.numParticles = particleRangeEnd; a.epsilon = epsilon;
+	sa_integrate_gamma_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_integrate_gamma_kernel");
 	return SPHX_OK;
 }

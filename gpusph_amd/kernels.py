@@ -128,6 +128,24 @@ class HipKernels:
                                                p(vertpos[1]), p(vertpos[2]), p(info), p(hash_), p(cellStart), p(neibslist),
                                                P.slength, P.influenceradius, P.deltap, float(np.float32(epsilon)), n, range_end, self._s()))
 
+    def forces_sa(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, n, frm, to, cfl_offset):
+        p = capi.ptr
+        P = self.params
+        nb = C.c_uint32(0)
+        capi.check(self.lib.sphx_forces_basicstep_sa(self.ctx.handle, p(forces), p(cfl), p(pos), p(vel), p(info), p(hash_), p(cellStart),
+                                                     p(neibslist), p(ggam), p(boundelements), p(vertpos[0]), p(vertpos[1]), p(vertpos[2]),
+                                                     n, frm, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius, cfl_offset,
+                                                     D.SIMULATE, 1, 0.0, C.byref(nb), self._s()))
+        return nb.value
+
+    def sa_integrate_gamma(self, new_ggam, old_ggam, new_pos, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end,
+                           epsilon=5e-5):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_sa_integrate_gamma(self.ctx.handle, p(new_ggam), p(old_ggam), p(new_pos), p(boundelements), p(vertpos[0]),
+                                                    p(vertpos[1]), p(vertpos[2]), p(info), p(hash_), p(cellStart), p(neibslist), n, range_end,
+                                                    0.0, 1, 0.0, float(np.float32(epsilon)), P.slength, P.influenceradius, D.SIMULATE, self._s()))
+
     def sa_segment_bc(self, vel, ggam, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step,
                       run_mode=D.SIMULATE):
         p = capi.ptr

@@ -259,6 +259,16 @@ class MultiGpuEngine:
         else:
             K.build_neibs(self.neibslist, self.pos, self.info, self.hash, self.cellStart, self.cellEnd, self.n_local, self.n_int)
 
+    def _sa_post_euler(self, step):
+        """INTEGRATE_GAMMA on the new positions (always from the gamma of step n), then the boundary conditions of the new
+        state (PredictorCorrectorIntegrator.cc:661-684 and the post-step phases)"""
+        K, n = self.k, self.n_local
+        K.sa_integrate_gamma(self.gradgamma2, self.gradgamma, self.pos2, self.boundelements, self.vertpos, self.info, self.hash,
+                             self.cellStart, self.neibslist, n, n)
+        K.sa_segment_bc(self.vel2, self.gradgamma2, self.pos2, self.vertices, self.boundelements, self.info, self.hash, self.cellStart,
+                        self.neibslist, n, n, step, D.SIMULATE)
+        K.sa_vertex_bc(self.vel2, self.gradgamma2, self.pos2, self.info, self.hash, self.cellStart, self.neibslist, n, n, step, D.SIMULATE)
+
     def sa_boundary_conditions(self, step, run_mode=D.SIMULATE):
         """initializeBoundaryConditionsSequence<SA_BOUNDARY> (src/integrators/PredictorCorrectorIntegrator.cc:117-290) without
         open boundaries: at initialisation (step 0) the vertex normals and gamma, then in every step the segment and the vertex
@@ -341,6 +351,12 @@ class MultiGpuEngine:
                         turbvisc=self.turbvisc)
             if self.world > 1:
                 self._exchange(self.tau)
+        if self.sa:      # forces engine of SA_BOUNDARY: the state's gamma, the boundary elements, the vertex offsets of the segments
+            ggam = self.gradgamma if pos is self.pos else self.gradgamma2
+            nb = K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
+                             self.boundelements, self.vertpos, self.n_local, 0, self.n_int, 0)
+            K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
+            return
         args = (self.forces, self.cfl, self.rbforces if self.has_rb else None, self.rbtorques if self.has_rb else None, pos, vel, self.info, self.hash, self.cellStart,
                 self.neibslist, self.n_local)
         kw = dict(tau=self.tau) if sps else {}
@@ -381,6 +397,8 @@ class MultiGpuEngine:
         K = self.k
         if self.iterations % self.sp.buildneibsfreq == 0:
             self.build_neibs()
+            if self.sa and self.iterations == 0:     # initialisation step of the boundary conditions (not after a resume)
+                self.sa_boundary_conditions(0)
         n = self.n_local
         if self.iterations > 0:      # FILTER phases: internal particles, then UPDATE_EXTERNAL of the velocity buffer
             for ftype, freq in self.filters:
@@ -397,11 +415,16 @@ class MultiGpuEngine:
         if self.bodies is not None:                 # MOVE_BODIES + uploads (PredictorCorrectorIntegrator.cc:550-570)
             m = self.bodies.timestep(1, dt_host, self.t_host); K.set_body_motion(m, self.sp.numforcesbodies > 0)
         K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1, **ekw)
+        if self.sa:
+            self._sa_post_euler(1)
         # corrector: forces(step n*) -> n+1 = n + dt f*   (written over n*, then renamed to n)
         self._forces_pass(self.pos2, self.vel2, 1, step=2)
         if self.bodies is not None:
             m = self.bodies.timestep(2, dt_host, self.t_host); K.set_body_motion(m, self.sp.numforcesbodies > 0)
         K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2, **ekw)
+        if self.sa:
+            self._sa_post_euler(2)
+            self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
         if self.bodies is not None:                 # EULER_UPLOAD_OBJECTS_CG in the post-corrector phase (:331-332)
             K.set_body_cg_integration(m)
             self._last_motion = m

@@ -818,23 +818,34 @@ class SABox(Problem):
     (e.g. src/problems/CompleteSaExample.cu; the reference reads such geometry from HDF5 files, src/HDF5SphReader.cc): the floor
     and the four side walls of an l x w x h tank are meshed by vertex particles (PT_VERTEX) on a square lattice of pitch deltap,
     every lattice square is cut into two triangular boundary elements (PT_BOUNDARY, placed at the centroid), and water of depth
-    H fills the tank from deltap/2 off the walls.  Per particle, next to pos/vel/info (src/define_buffers.h:168-196):
+    H fills the tank on the same lattice, one deltap off the walls (a vertex particle carries the half, quarter or eighth
+    cell next to the wall, as in Crixus meshes).  Per particle, next to pos/vel/info (src/define_buffers.h:168-196):
       vertices       uint4   ids of the three vertices of a segment (0 elsewhere)
       boundelements  float4  unit normal towards the fluid and area of a segment (vertices: filled by computeVertexNormal)
       gradgamma      float4  (grad gamma, gamma); NaN until the boundary-conditions engine initialises it
-    Framework options, list size, deltap and smoothing are StillWaterSA's (src/problems/StillWaterSA.cu:38-57).  Wendland kernel (the only one the reference's SA code supports, src/cuda/gamma.cuh:241-250)."""
+    Framework options, list size, deltap and smoothing are StillWaterSA's (src/problems/StillWaterSA.cu:38-57) or, with
+    options="StillWaterRepackSA", those of that problem's simulation (src/problems/StillWaterRepackSA.cu:38-44: continuity
+    equation instead of density summation, gamma by quadrature, no density diffusion) -- the set the SA forces /
+    integration engines are built for.  Wendland kernel (the only one the reference's SA code supports, src/cuda/gamma.cuh:241-250)."""
 
     def __init__(self, deltap=0.05, *, l=0.6, w=0.5, h=0.5, H=0.35, viscosity="DYNAMICVISC", jitter=0.0,
-                 linearization=D.DEFAULT_LINEARIZATION):
+                 linearization=D.DEFAULT_LINEARIZATION, options="StillWaterSA"):
         super().__init__()
         self.m_name = "SABox"
         sp, pp = self.simparams, self.physparams
         sp.kerneltype = D.WENDLAND
         sp.boundarytype = D.SA_BOUNDARY
         self.set_viscosity(viscosity)
-        sp.densitydiffusiontype = D.BREZZI
-        sp.densityDiffCoeff = 0.05
-        sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_DENSITY_SUM
+        if options == "StillWaterSA":
+            sp.densitydiffusiontype = D.BREZZI
+            sp.densityDiffCoeff = 0.05
+            sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_DENSITY_SUM
+        elif options == "StillWaterRepackSA":
+            sp.densitydiffusiontype = D.DENSITY_DIFFUSION_NONE
+            sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | D.ENABLE_GAMMA_QUADRATURE
+        else:
+            raise ValueError(options)
+        self.options = options
         self.linearization = linearization
         self.jitter = jitter
         self.set_deltap(deltap)
@@ -874,12 +885,16 @@ class SABox(Problem):
             return vid.setdefault(c, len(vid))
         for o, du, dv, nu, nv, nrm in faces:
             o, du, dv = np.array(o), np.array(du), np.array(dv)
+            # the vertices of an element run anticlockwise as seen from the fluid (the side its normal points to): the
+            # analytical grad gamma of an element takes its edges in that sense (src/cuda/gamma.cuh:282-287, initConnectivity)
+            ccw = np.dot(np.cross(du, dv), nrm) > 0
             for i in range(nu):
                 for j in range(nv):
                     a = tuple(o + i * du + j * dv); b = tuple(o + (i + 1) * du + j * dv)
                     c = tuple(o + (i + 1) * du + (j + 1) * dv); d = tuple(o + i * du + (j + 1) * dv)
-                    tris.append((node(a), node(b), node(c))); normals.append(nrm)
-                    tris.append((node(a), node(c), node(d))); normals.append(nrm)
+                    for tri in ((a, b, c), (a, c, d)):
+                        tri = tri if ccw else (tri[0], tri[2], tri[1])
+                        tris.append(tuple(node(v) for v in tri)); normals.append(nrm)
         vnodes = np.array(sorted(vid, key=vid.get), dtype=np.float64)
         vpos = vnodes * dp
         tris = np.array(tris, dtype=np.int64)
@@ -890,12 +905,12 @@ class SABox(Problem):
         for a, n in enumerate((nl, nw, nh)):
             frac *= np.where((vnodes[:, a] == 0) | (vnodes[:, a] == n), 0.5, 1.0)
         # --- water
-        fn = [nl, nw, max(int(round(self.H / dp)), 1)]
-        fluid = (_lattice(0, fn[0] - 1, 0, fn[1] - 1, 0, fn[2] - 1).astype(np.float64) + 0.5) * dp
+        fn = [nl - 1, nw - 1, max(int(round(self.H / dp)) - 1, 1)]
+        fluid = _lattice(1, fn[0], 1, fn[1], 1, fn[2]).astype(np.float64) * dp
         if self.jitter:
             rng = np.random.default_rng(777)
             fluid = fluid + rng.uniform(-self.jitter * dp, self.jitter * dp, size=fluid.shape)
-        self.water_level = fn[2] * dp
+        self.water_level = (fn[2] + 0.5) * dp
         nf, ns, nv = len(fluid), len(spos), len(vpos)
         ntot = nf + ns + nv
         pos = np.empty((ntot, 4), dtype=np.float64)

@@ -209,6 +209,26 @@ int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *vertPos0, void
 int sphx_neibs_resetinfo(sphx_ctx *ctx, void *stream);
 int sphx_neibs_getinfo(sphx_ctx *ctx, sphx_neibs_info *h_out, void *stream);
 
+/* basicstep of the forces engine with SA_BOUNDARY (src/cuda/forces.cu:717-806 with the SA members of forces_params): fluid <-
+ * fluid, fluid <- vertex, fluid <- boundary element (through |grad gamma_as|, src/cuda/gamma.cuh), sums divided by gamma,
+ * gravity, CFL maxima.  Built for solid walls, SPH_F1, laminar Newtonian or inviscid flow, the continuity equation (no
+ * ENABLE_DENSITY_SUM) and ENABLE_GAMMA_QUADRATURE -- the option set of StillWaterRepackSA's simulation; everything else
+ * answers SPHX_ERR_UNSUPPORTED. */
+int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius, uint32_t cflOffset,
+	int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream);
+/* AbstractIntegrationEngine::integrate_gamma (src/cuda/euler.cu:202-290) with ENABLE_GAMMA_QUADRATURE: gamma and grad gamma
+ * of the fluid particles at their new positions by quadrature over the listed boundary elements
+ * (integrateGammaDevice, src/cuda/density_sum_kernel.cu:690-765); rows of vertex and boundary particles are copied */
+int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void *oldGGam, const void *newPos,
+	const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, int step, float t,
+	float epsilon, float slength, float influenceradius, int run_mode, void *stream);
+
 /* ---- AbstractBoundaryConditionsEngine (src/engine_boundary_conditions.h:46-186), SA_BOUNDARY, solid walls -------- */
 /* computeVertexNormal (src/cuda/boundary_conditions.cu:417-452): area-weighted mean normal of the segments adjacent to each
  * vertex, written to the vertex rows of boundElements (in place; w = NaN) */

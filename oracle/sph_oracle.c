@@ -767,10 +767,20 @@ static inline float visc_avg(const orc_params *p, float visc, float neib_visc, f
 float orc_visc_avg(const orc_params *p, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
 { return visc_avg(p, visc, neib_visc, rho, neib_rho, neib_mass); }
 
+/* SA_BOUNDARY members of forces_params / finalize_forces_params (src/cuda/forces_params.h): gamma and its gradient,
+ * the boundary elements and the in-plane vertex offsets of the segments */
+typedef struct {
+	const orc_f4 *gGam, *boundelem;
+	const float *vertPos[3];
+	float deltap;
+} sa_forces_ctx;
+float orc_grad_gamma_vp(float slength, float qx, float qy, float qz, const orc_f4 *belem,
+	const float *vp0, const float *vp1, const float *vp2);
+
 static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *forces,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
 	const uint32_t *cellStart, const uint16_t *neibsList, const float *tauArray,
-	uint32_t fromParticle, uint32_t toParticle)
+	uint32_t fromParticle, uint32_t toParticle, const sa_forces_ctx *sa)
 {
 	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f; /* kernelradius */
 	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
@@ -808,7 +818,10 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			if (!isfinite(nmass)) continue;
 			const float r = sqrtf(sqlength3(rx, ry, rz));
 			const orc_info neib_info = infoArray[neib_index];
-			if (r >= p->influenceradius) continue;
+			/* forcesDevice :3999-4006: boundary elements of SA_BOUNDARY interact a little beyond the kernel radius */
+			if (sa && nptype == PT_BOUNDARY) {
+				if (r >= p->influenceradius + sa->deltap) continue;
+			} else if (r >= p->influenceradius) continue;
 
 			/* common_neib_data, :1099-1130 */
 			const orc_f4 nvel = velArray[neib_index];
@@ -825,7 +838,48 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			float DrDt = 0.0f;
 
 			const int all_pp = (cptype == PT_FLUID && nptype == PT_FLUID) ||
-				(cptype == PT_FLUID && nptype == PT_BOUNDARY && p->boundarytype == ORC_DYN_BOUNDARY);
+				(cptype == PT_FLUID && nptype == PT_BOUNDARY && p->boundarytype == ORC_DYN_BOUNDARY) ||
+				(cptype == PT_FLUID && nptype == PT_VERTEX && sa);     /* vertex particles weigh in like fluid ones, :3783-3795 */
+
+			/* fluid <- boundary element with SA_BOUNDARY (compute_all_pp_interaction with the boundary specialisations):
+			 * everything goes through |grad gamma_as| of the element */
+			if (sa && cptype == PT_FLUID && nptype == PT_BOUNDARY) {
+				const orc_f4 belem = sa->boundelem[neib_index];
+				/* compute_gamma_gradient :1410-1428 */
+				const float inv_h = 1.0f/p->slength;        /* float3/float multiplies by the reciprocal */
+				const float ggamAS = orc_grad_gamma_vp(p->slength, rx*inv_h, ry*inv_h, rz*inv_h, &belem,
+					sa->vertPos[0] + 2*(size_t)neib_index, sa->vertPos[1] + 2*(size_t)neib_index, sa->vertPos[2] + 2*(size_t)neib_index);
+				/* mass_continuity_div_vel_term :2079-2090 (nout.DrDt starts from 0) */
+				const float vn = dot3(vx, vy, vz, belem.x, belem.y, belem.z);
+				if (!(p->simflags & ORC_ENABLE_DENSITY_SUM)) {
+					DrDt -= p_rho*vn*ggamAS;
+					if (f2) DrDt *= p_rho/n_rho;
+					force.w += DrDt;
+				}
+				/* compute_pressure_contrib :2414-2427: + (P_a/rho_a^2 + P_s/rho_s^2) rho_s |grad gamma_as| n_s */
+				const float pGradTerm = p_precalc + n_precalc;
+				const float ps = pGradTerm*n_rho*ggamAS;
+				DvDt[0] += ps*belem.x; DvDt[1] += ps*belem.y; DvDt[2] += ps*belem.z;
+				/* compute_laminar_visc_contrib, boundary term :2680-2718 (MORRIS, no k-epsilon, no open boundaries) */
+				if (p->rheologytype == ORC_NEWTONIAN) {
+					const float r_as = fmaxf(fabsf(dot3(rx, ry, rz, belem.x, belem.y, belem.z)), sa->deltap);   /* sa_boundary_neib_data :1132-1150 */
+					const float vt[3] = { vx - vn*belem.x, vy - vn*belem.y, vz - vn*belem.z };
+					/* get_laminar_dyn_visc :322-340 */
+					const float our_mu = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[p_fluid]*p_rho : p->visccoeff[p_fluid];
+					const float neib_mu = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[n_fluid]*n_rho : p->visccoeff[n_fluid];
+					float avg;
+					switch (p->avgop) {           /* average<>, src/average.h:78-100 */
+					case ORC_ARITHMETIC: avg = (our_mu + neib_mu)*0.5f; break;
+					case ORC_HARMONIC:   avg = 2*our_mu*neib_mu/(our_mu + neib_mu); break;
+					default:             avg = sqrtf(our_mu*neib_mu);
+					}
+					const float c = ggamAS*2*avg/r_as;
+					const float inv_rho = 1.0f/p_rho;
+					DvDt[0] -= (c*vt[0])*inv_rho; DvDt[1] -= (c*vt[1])*inv_rho; DvDt[2] -= (c*vt[2])*inv_rho;
+				}
+				force.x += DvDt[0]; force.y += DvDt[1]; force.z += DvDt[2];
+				continue;
+			}
 			const int dyn_bf = (cptype == PT_BOUNDARY && nptype == PT_FLUID && p->boundarytype == ORC_DYN_BOUNDARY);
 
 			/* repulsive boundary models: fluid <- boundary always, boundary <- fluid only for particles of bodies
@@ -850,7 +904,7 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				continue;
 			}
 
-			if (all_pp || dyn_bf) {
+			if ((all_pp || dyn_bf) && !(p->simflags & ORC_ENABLE_DENSITY_SUM)) {
 				/* compute_density_derivative, :2176-2190 */
 				DrDt = nmass*vel_dot_pos*f; /* mass_continuity_div_vel_term :2140-2151 */
 				/* compute_density_diffusion (Colagrossi, nptype==FLUID only), :1916-1952 */
@@ -957,7 +1011,7 @@ static inline void plane_friction(const orc_params *p, orc_f4 *force, const orc_
 static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	orc_f4 *rbforces, orc_f4 *rbtorques,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
-	uint32_t fromParticle, uint32_t toParticle, uint32_t numBlocks, uint32_t cflOffset)
+	uint32_t fromParticle, uint32_t toParticle, uint32_t numBlocks, uint32_t cflOffset, const sa_forces_ctx *sa)
 {
 	const int dtadapt = !!(p->simflags & ORC_ENABLE_DTADAPT);
 #pragma omp parallel for schedule(static)
@@ -973,8 +1027,17 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 			orc_f4 force = forces[index];
 			const int fl = FLUID_NUM(info);
 
-			/* forces_fixup (non-SA, non-Grenier), :3212-3218 */
-			force.w /= p->rho0[fl];
+			/* forces_fixup: non-SA, non-Grenier :3212-3218; SA_BOUNDARY :3192-3210 (fluid particles only: the sums are
+			 * renormalised by gamma) */
+			if (!sa)
+				force.w /= p->rho0[fl];
+			else if (FLUID(info)) {
+				const float gam = sa->gGam[index].w;
+				force.x /= gam; force.y /= gam; force.z /= gam; force.w /= gam;
+				force.w /= p->rho0[fl];
+				if (p->sph_formulation == ORC_SPH_F2 && !(p->simflags & ORC_ENABLE_DENSITY_SUM))
+					force.w *= physical_density(p, vel.w, fl);
+			}
 
 			if (FLUID(info)) {
 				force.x += p->gravity[0]; force.y += p->gravity[1]; force.z += p->gravity[2];
@@ -1046,12 +1109,31 @@ uint32_t orc_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 {
 	(void)numParticles;
 	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
-	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle);
-	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle);
+	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL);
+	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL);
 	if (compute_object_forces || p->boundarytype == ORC_DYN_BOUNDARY)
-		forces_pass(p, PT_BOUNDARY, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle);
+		forces_pass(p, PT_BOUNDARY, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL);
 	finalize_forces(p, forces, cfl, rbforces, rbtorques, pos, vel, info, hash,
-		fromParticle, toParticle, numBlocks, cflOffset);
+		fromParticle, toParticle, numBlocks, cflOffset, NULL);
+	return numBlocks;
+}
+
+/* run_forces with SA_BOUNDARY (solid walls, no k-epsilon, no moving bodies): fluid <- fluid, fluid <- vertex, then
+ * fluid <- boundary element (the launch order of src/cuda/forces.cu:751-790; vertex particles skip their own neighbour
+ * walk, skip_neiblist :1346-1358), then the finalize with the division by gamma */
+uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl,
+	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	const orc_f4 *gGam, const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, float deltap)
+{
+	(void)numParticles;
+	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap };
+	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
+	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
+	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
+	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
+	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, &sa);
 	return numBlocks;
 }
 
@@ -2160,6 +2242,16 @@ float orc_grad_gamma(float slength, const float *q, const float *qvb9, const flo
 	return grad_gamma_wendland(slength, v3_make(q[0], q[1], q[2]), q_vb, v3_make(ns[0], ns[1], ns[2]));
 }
 
+/* |grad gamma_as| of one boundary element as the forces pass asks for it (compute_gamma_gradient, forces_kernel.def:1410-1428) */
+float orc_grad_gamma_vp(float slength, float qx, float qy, float qz, const orc_f4 *belem,
+	const float *vp0, const float *vp1, const float *vp2)
+{
+	v3 q_vb[3];
+	const v3 ns = v3_make(belem->x, belem->y, belem->z);
+	calc_vertex_rel_pos(q_vb, ns, vp0, vp1, vp2, slength);
+	return grad_gamma_wendland(slength, v3_make(qx, qy, qz), q_vb, ns);
+}
+
 /* Gamma<WENDLAND, PT_FLUID> :404-435 and Gamma<WENDLAND, PT_VERTEX> :437-513 (q_vb may be permuted) */
 static float gamma_wendland(int vertex, float slength, v3 q, v3 *q_vb, v3 ns, v3 oldGGam, float epsilon)
 {
@@ -2262,5 +2354,43 @@ void orc_sa_init_gamma(const orc_params *p, orc_f4 *newGGam, const orc_f4 *posAr
 			}
 			newGGam[index].x = gGam.x; newGGam[index].y = gGam.y; newGGam[index].z = gGam.z; newGGam[index].w = gam;
 		}
+	}
+}
+
+/* integrateGammaDevice without dynamic gamma (ENABLE_GAMMA_QUADRATURE), src/cuda/density_sum_kernel.cu:690-765: like the
+ * initialisation, but every listed element counts (no distance cut) and the direction used by the vertex specialisation
+ * is the OLD grad gamma */
+void orc_sa_integrate_gamma_quadrature(const orc_params *p, orc_f4 *newGGam, const orc_f4 *oldGGam, const orc_f4 *newPos,
+	const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2, const orc_info *infoArray,
+	const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd,
+	int cptype, float epsilon)
+{
+	const float slength = p->slength;
+#pragma omp parallel for schedule(dynamic, 256)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		if (PART_TYPE(infoArray[index]) != cptype) continue;
+		const orc_f4 pos = newPos[index];
+		const orc_f4 og = oldGGam[index];
+		const v3 oldg = v3_make(og.x, og.y, og.z);
+		orc_f4 g = { 0.0f, 0.0f, 0.0f, 1.0f };
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = newPos[neib_index];
+			const v3 relPos = v3_make(it.pos_corr[0] - npos.x, it.pos_corr[1] - npos.y, it.pos_corr[2] - npos.z);
+			const orc_f4 be = boundelem[neib_index];
+			const v3 normal = v3_make(be.x, be.y, be.z);
+			const v3 q = v3_divs(relPos, slength);
+			v3 q_vb[3];
+			calc_vertex_rel_pos(q_vb, normal, vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+				vertPos2 + 2*(size_t)neib_index, slength);
+			const float ggamAS = grad_gamma_wendland(slength, q, q_vb, normal);
+			g.x += ggamAS*be.x; g.y += ggamAS*be.y; g.z += ggamAS*be.z;
+			g.w -= gamma_wendland(cptype == PT_VERTEX, slength, q, q_vb, normal, oldg, epsilon);
+		}
+		newGGam[index] = g;
 	}
 }

@@ -65,6 +65,7 @@ def lib():
         _lib.orc_P.restype = C.c_float; _lib.orc_P.argtypes = [C.c_void_p, C.c_float, C.c_int]
         _lib.orc_soundSpeed.restype = C.c_float; _lib.orc_soundSpeed.argtypes = [C.c_void_p, C.c_float, C.c_int]
         _lib.orc_forces.restype = C.c_uint32
+        _lib.orc_forces_sa.restype = C.c_uint32
         _lib.orc_dtreduce.restype = C.c_float
         _lib.orc_dtreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float]
         _lib.orc_fmax_elements.restype = C.c_uint32; _lib.orc_fmax_elements.argtypes = [C.c_uint32]
@@ -233,6 +234,23 @@ class Oracle:
         g = ggam.copy()
         self.L.orc_sa_init_gamma(C.byref(self.p), P(g), P(pos), P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(info),
                                  P(hash_), P(cs), P(nl), C.c_uint32(n), C.c_float(deltap), C.c_float(epsilon))
+        return g
+
+    def forces_sa(self, pos, vel, info, hash_, cs, nl, ggam, boundelements, vertpos, n, deltap):
+        forces = np.zeros((len(pos), 4), dtype=np.float32)
+        nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
+        cfl = np.zeros(nblk, dtype=np.float32)
+        nb = self.L.orc_forces_sa(C.byref(self.p), P(forces), P(cfl), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), P(ggam),
+                                  P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), C.c_uint32(n), C.c_uint32(0),
+                                  C.c_uint32(n), C.c_uint32(0), C.c_float(deltap))
+        return forces, cfl, int(nb)
+
+    def sa_integrate_gamma(self, old_ggam, new_pos, boundelements, vertpos, info, hash_, cs, nl, n, epsilon=5e-5):
+        """integrate_gamma with ENABLE_GAMMA_QUADRATURE: fluid rows by quadrature, the rest copied"""
+        g = old_ggam.copy()
+        self.L.orc_sa_integrate_gamma_quadrature(C.byref(self.p), P(g), P(old_ggam), P(new_pos), P(boundelements), P(vertpos[0]),
+                                                 P(vertpos[1]), P(vertpos[2]), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n),
+                                                 C.c_int(0), C.c_float(epsilon))
         return g
 
     def sa_vertex_bc(self, pos, vel, ggam, info, hash_, cs, nl, n):

@@ -64,3 +64,52 @@ def list_sections(st, i):
             slot += step
         out.append(res)
     return out
+
+
+class OracleSaSim:
+    """The predictor-corrector sequence of an SA_BOUNDARY run without density summation and with gamma by quadrature
+    (PredictorCorrectorIntegrator.cc: initializeBoundaryConditionsSequence<SA_BOUNDARY> :117-290, the step phases :386-685),
+    executed by the CPU oracle.  Test infrastructure (the GPU tests compare MultiGpuEngine.step against it)."""
+
+    def __init__(self, problem):
+        st = sa_oracle_state(problem)
+        self.st, self.problem, self.o, self.n = st, problem, st["oracle"], st["n"]
+        o, n, p = self.o, self.n, problem
+        self.pos, self.vel, self.info, self.hash, self.cs, self.nl = st["pos"], st["vel"], st["info"], st["hash"], st["cs"], st["nl"]
+        self.vertices, self.vertpos = st["vertices"], st["vertpos"]
+        self.be = o.sa_compute_vertex_normal(st["boundelements"], self.vertices, self.info, self.hash, self.cs, self.nl, n)
+        gg = o.sa_init_gamma(st["gradgamma"], self.pos, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n, p.m_deltap)
+        self.vel, self.gg = o.sa_segment_bc(self.pos, self.vel, gg, self.vertices, self.be, self.info, self.hash, self.cs, self.nl, n, step=0)
+        self.vel = o.sa_vertex_bc(self.pos, self.vel, self.gg, self.info, self.hash, self.cs, self.nl, n)
+        self.dt = float(np.float32(p.simparams.dt))
+        self.t = 0.0
+        self.iterations = 0
+        pp, sp = p.physparams, p.simparams
+        self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(pp.sscoeff))) * 1.1))
+        self.max_kinvisc = float(np.float32(max(pp.kinematicvisc))) if sp.rheologytype == D.NEWTONIAN else 0.0
+
+    def _bc(self, pos, vel, gg, step):
+        o, n = self.o, self.n
+        vel, gg = o.sa_segment_bc(pos, vel, gg, self.vertices, self.be, self.info, self.hash, self.cs, self.nl, n, step=step)
+        return o.sa_vertex_bc(pos, vel, gg, self.info, self.hash, self.cs, self.nl, n), gg
+
+    def step(self):
+        """no neighbour rebuild here: the runs compared are shorter than buildneibsfreq"""
+        o, n, p = self.o, self.n, self.problem
+        dp = p.m_deltap
+        dt = float(np.float32(self.dt))
+        f1, cfl, nb = o.forces_sa(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, self.gg, self.be, self.vertpos, n, dp)
+        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1)
+        gs = o.sa_integrate_gamma(self.gg, ps, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
+        vs, gs = self._bc(ps, vs, gs, 1)
+        f2, cfl, nb = o.forces_sa(ps, vs, self.info, self.hash, self.cs, self.nl, gs, self.be, self.vertpos, n, dp)
+        dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        pn, vn = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
+        gn = o.sa_integrate_gamma(self.gg, pn, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
+        vn, gn = self._bc(pn, vn, gn, 2)
+        self.forces = f2
+        self.pos, self.vel, self.gg = pn, vn, gn
+        self.t += dt
+        self.dt = min(dt1, dt2)
+        self.iterations += 1

@@ -116,7 +116,7 @@ def test_later_steps_and_repacking_mode(pair):
 def test_what_is_not_built_says_so(pair):
     from gpusph_amd import capi
     st, eng = pair
-    with pytest.raises(capi.SphxUnsupported, match="DYN_BOUNDARY and LJ_BOUNDARY"):
+    with pytest.raises(capi.SphxUnsupported, match="density summation"):      # StillWaterSA's option set: ENABLE_DENSITY_SUM
         eng.step()
     # and the boundary-conditions engine refuses a framework without SA_BOUNDARY, like the reference's SFINAE'd implementation
     other = _engine(DamBreak3D(deltap=0.05, obstacle=False))
@@ -154,3 +154,57 @@ def test_cpp_adapters_run_the_sa_initialisation(tmp_path):
     assert out["counters"][3] == n                      # no particle was created
     t = info_type(out["info"])
     assert np.isfinite(out["gradgamma"][t != D.PT_BOUNDARY]).all() and (out["vel"][t == D.PT_BOUNDARY, 3] > 0).sum() > 200
+
+
+def test_sa_forces_gamma_integration_and_trajectory():
+    """The SA forces engine (fluid, vertex and boundary-element terms, division by gamma), gamma by quadrature at new positions
+    and the whole predictor-corrector sequence against the CPU oracle (option set of StillWaterRepackSA's simulation)."""
+    from sa_helpers import OracleSaSim
+    import torch
+    kw = dict(deltap=0.05, jitter=0.15, options="StillWaterRepackSA")
+    sim = OracleSaSim(SABox(**kw))
+    eng = _engine(SABox(**kw), clobber_neibslist=True)
+    eng.build_neibs()
+    eng.sa_boundary_conditions(0)
+    n, o, k = sim.n, sim.o, eng.k
+    t = info_type(sim.info)
+    fl = np.where(t == D.PT_FLUID)[0]
+    # one forces evaluation on identical inputs (the oracle's initialised state uploaded)
+    for name, arr in (("vel", sim.vel), ("gradgamma", sim.gg), ("boundelements", sim.be)):
+        getattr(eng, name)[:n] = torch.from_numpy(arr).to(eng.device)
+    f, cfl, nb = o.forces_sa(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, sim.gg, sim.be, sim.vertpos, n, sim.problem.m_deltap)
+    eng.k.memset(eng.cfl, 0)
+    gnb = k.forces_sa(eng.forces, eng.cfl, eng.pos, eng.vel, eng.info, eng.hash, eng.cellStart, eng.neibslist, eng.gradgamma,
+                      eng.boundelements, eng.vertpos, n, 0, n, 0)
+    gf = _np(eng.forces)[:n]
+    assert gnb == nb
+    # tolerance: the state is hydrostatic, i.e. every force is the small remainder of pressure terms ~50x its size, and the
+    # pressures come from powf of two math libraries (1 ulp of (1+rho~)^7 is 1e-5 of P): 1e-4 of the largest force
+    scale = np.abs(f[fl, :3]).max()
+    assert np.abs(gf[fl, :3] - f[fl, :3]).max() < 1e-4 * scale, (np.abs(gf[fl, :3] - f[fl, :3]).max(), scale)
+    assert np.abs(gf[fl, 3] - f[fl, 3]).max() < 1e-4 * max(np.abs(f[fl, 3]).max(), 1e-3)
+    assert not gf[t != D.PT_FLUID].any()
+    assert np.allclose(_np(eng.cfl)[:nb], cfl[:nb], rtol=1e-4, atol=0)
+    # gamma by quadrature at displaced positions
+    rng = np.random.default_rng(3)
+    newpos = sim.pos.copy()
+    newpos[fl, :3] += (0.1 * sim.problem.m_deltap * rng.standard_normal((len(fl), 3))).astype(np.float32)
+    g1 = o.sa_integrate_gamma(sim.gg, newpos, sim.be, sim.vertpos, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng.pos2[:n] = torch.from_numpy(newpos).to(eng.device)
+    k.sa_integrate_gamma(eng.gradgamma2, eng.gradgamma, eng.pos2, eng.boundelements, eng.vertpos, eng.info, eng.hash, eng.cellStart,
+                         eng.neibslist, n, n)
+    gg1 = _np(eng.gradgamma2)[:n]
+    assert np.abs(gg1[fl, :3] - g1[fl, :3]).max() < 5e-5 * np.abs(g1[fl, :3]).max() and np.abs(gg1[fl, 3] - g1[fl, 3]).max() < 5e-6
+    assert np.array_equal(_bits(gg1[t != D.PT_FLUID]), _bits(sim.gg[t != D.PT_FLUID]))      # walls: copied
+    # six steps of the full sequence
+    eng2 = _engine(SABox(**kw))
+    for _ in range(6):
+        sim.step(); eng2.step()
+    assert eng2.iterations == sim.iterations == 6
+    gp, gv, ggg = _np(eng2.pos)[:n], _np(eng2.vel)[:n], _np(eng2.gradgamma)[:n]
+    cell = float(np.min(sim.problem.m_cellsize))
+    assert np.abs(gp[:, :3] - sim.pos[:, :3]).max() < 6e-6 * cell
+    assert np.abs(gv[:, :3] - sim.vel[:, :3]).max() < 1e-3 * max(np.abs(sim.vel[:, :3]).max(), 1e-3)
+    assert np.abs(gv[:, 3] - sim.vel[:, 3]).max() < 2e-6
+    assert np.abs(ggg[fl, 3] - sim.gg[fl, 3]).max() < 2e-5
+    assert abs(eng2.current_dt() - sim.dt) < 1e-5 * sim.dt and abs(eng2.time() - sim.t) < 1e-6 * sim.t
