@@ -190,9 +190,9 @@ int main(int argc, char **argv)
 
 		// ---- SA_BOUNDARY: the neighbour phase with the vertex / segment buffers and the initialisation sequence of the
 		// boundary conditions (initializeBoundaryConditionsSequence<SA_BOUNDARY>, PredictorCorrectorIntegrator.cc:117-290);
-		// the SA forces / integration engines are not built, so the run ends there (steps must be 0)
+		// then `steps` predictor-corrector steps: forces, Euler, INTEGRATE_GAMMA, boundary conditions (:386-685), for the option sets
+		// whose SA forces are built (continuity equation, gamma by quadrature); no neighbour rebuild in between
 		if (sp->boundarytype == SA_BOUNDARY) {
-			if (steps != 0) throw std::runtime_error("SA_BOUNDARY case: only the initialisation (steps 0) can be run");
 			std::vector<vertexinfo> hvert(n0);
 			std::vector<float4> hbe(n0), hgg(n0);
 			FILE *fs = fopen(argv[2], "rb");
@@ -228,8 +228,33 @@ int main(int argc, char **argv)
 			bc->saSegmentBoundaryConditions(state, state, n, n, deltap, slength, influenceRadius, 0, SIMULATE);
 			uint newNum = n;
 			bc->saVertexBoundaryConditions(state, state, n, n, deltap, slength, influenceRadius, 0, false, 0.0f, &newNum, 0, 1, n, SIMULATE);
+			// the boundary elements and vertex ids do not change: both states of the integrator see the same ones
+			sphx_throw(sphx_memcpy_d2d(saA.getData<BUFFER_VERTICES>(), as_const(saB).getData<BUFFER_VERTICES>(), 16*(size_t)n));
+			sphx_throw(sphx_memcpy_d2d(saA.getData<BUFFER_BOUNDELEMENTS>(), as_const(saB).getData<BUFFER_BOUNDELEMENTS>(), 16*(size_t)n));
+			BufferList stN = posB | velB | saB | shared, stS = posA | velA | saA | shared;
+			BufferList *cur = &stN, *oth = &stS;
+			float sdt = (float)num(c, "dt0");
+			double st = 0;
+			for (uint it = 0; it < steps; ++it) {
+				float dts[2];
+				for (int step = 1; step <= 2; ++step) {
+					BufferList &rd = (step == 1) ? *cur : *oth;     // forces on step n (predictor) or n* (corrector)
+					shared[BUFFER_FORCES]->clobber(); shared[BUFFER_CFL]->clobber();
+					const uint nb = forcesEngine->basicstep(rd, rd, n, 0, n, deltap, slength, sp->dtadaptfactor, influenceRadius,
+						sp->epsilon, NULL, 0, SIMULATE, step, sdt, false);
+					dts[step - 1] = forcesEngine->dtreduce(slength, sp->dtadaptfactor, sspeed_cfl, max_kinvisc, rd, rd, nb, n);
+					const float hdt = step == 1 ? sdt/2 : sdt;
+					integrationEngine->basicstep(*cur, *oth, n, n, hdt, step, (float)st, slength, influenceRadius, SIMULATE);
+					integrationEngine->integrate_gamma(*cur, *oth, n, n, hdt, step, (float)st, sp->epsilon, slength, influenceRadius, SIMULATE);
+					bc->saSegmentBoundaryConditions(*oth, *oth, n, n, deltap, slength, influenceRadius, step, SIMULATE);
+					bc->saVertexBoundaryConditions(*oth, *oth, n, n, deltap, slength, influenceRadius, step, false, hdt, &newNum, 0, 1, n, SIMULATE);
+				}
+				std::swap(cur, oth);
+				st += sdt;
+				sdt = std::min(dts[0], dts[1]);
+			}
 			sphx_throw(sphx_device_synchronize());
-			const BufferList &cs = state;
+			const BufferList &cs = *cur;
 			hpos.resize(n); hvel.resize(n); hinfo.resize(n); hhash.resize(n); hvert.resize(n); hbe.resize(n); hgg.resize(n);
 			sphx_throw(sphx_memcpy_d2h(hpos.data(), cs.getData<BUFFER_POS>(), 16*(size_t)n));
 			sphx_throw(sphx_memcpy_d2h(hvel.data(), cs.getData<BUFFER_VEL>(), 16*(size_t)n));
@@ -244,14 +269,14 @@ int main(int argc, char **argv)
 			sphx_throw(sphx_free(d_newNum));
 			FILE *o = fopen(argv[3], "wb");
 			if (!o) throw std::runtime_error(std::string("cannot write ") + argv[3]);
-			const float dt0 = (float)num(c, "dt0"); const double t0 = 0;
-			fwrite(&n, 4, 1, o); fwrite(&dt0, 4, 1, o); fwrite(&t0, 8, 1, o);
+			fwrite(&n, 4, 1, o); fwrite(&sdt, 4, 1, o); fwrite(&st, 8, 1, o);
 			fwrite(hpos.data(), 16, n, o); fwrite(hvel.data(), 16, n, o); fwrite(hinfo.data(), 8, n, o); fwrite(hhash.data(), 4, n, o);
 			fwrite(hvert.data(), 16, n, o); fwrite(hbe.data(), 16, n, o); fwrite(hgg.data(), 16, n, o); fwrite(hvp.data(), 8, 3*(size_t)n, o);
 			const int32_t counters[4] = { (int32_t)ti.numInteractions, (int32_t)ti.maxFluidBoundaryNeibs, (int32_t)ti.maxVertexNeibs, (int32_t)newNum };
 			fwrite(counters, 4, 4, o);
 			fclose(o);
-			printf("example_engines: %s, %u particles, SA initialisation, max vertex neighbours %d\n", str(c, "framework").c_str(), n, (int)ti.maxVertexNeibs);
+			printf("example_engines: %s, %u particles, SA initialisation + %u steps, max vertex neighbours %d, t=%g dt=%g\n",
+				str(c, "framework").c_str(), n, steps, (int)ti.maxVertexNeibs, st, sdt);
 			return 0;
 		}
 

@@ -389,6 +389,20 @@ public:
 		// the write set follows the structures forces_params is assembled from (src/cuda/forces_params.h:86-220)
 		float4 *forces = bufwrite.getData<BUFFER_FORCES>();
 		float *cfl = (P.simflags & ENABLE_DTADAPT) ? bufwrite.getData<BUFFER_CFL>() : NULL;
+		if (P.boundarytype == SA_BOUNDARY) {
+			// sa_boundary_forces_params (src/cuda/forces_params.h): gamma of the state that is read, the boundary elements,
+			// the vertex offsets of the segments
+			const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
+			if (!vertPos) throw std::invalid_argument("forces basicstep: SA_BOUNDARY needs BUFFER_VERTPOS");
+			uint32_t nb = 0;
+			sphx_throw(sphx_forces_basicstep_sa(m_c->ctx(), forces, cfl,
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+				bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
+				numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor, influenceradius,
+				cflOffset, (int)run_mode, step, dt, &nb, NULL));
+			return nb;
+		}
 		float4 *rbforces = bufwrite.getData<BUFFER_RB_FORCES>();
 		float4 *rbtorques = bufwrite.getData<BUFFER_RB_TORQUES>();
 		float4 *xsph = (P.simflags & ENABLE_XSPH) ? bufwrite.getData<BUFFER_XSPH>() : NULL;
@@ -484,9 +498,21 @@ public:
 	void density_sum(const BufferList&, BufferList&, const uint, const uint, const float, const int, const float,
 		const float, const float, const float, const float)
 	{ sphx_not_built("density_sum (ENABLE_DENSITY_SUM, SA_BOUNDARY)"); }
-	void integrate_gamma(const BufferList&, BufferList&, const uint, const uint, const float, const int, const float,
-		const float, const float, const float, const RunMode)
-	{ sphx_not_built("integrate_gamma (SA_BOUNDARY)"); }
+	// quadrature_gamma_params (src/cuda/density_sum_params.h:224-262): old gamma, vertex offsets, boundary elements and the
+	// list from the state that is read; the NEW positions and the new gamma from the state that is updated
+	void integrate_gamma(const BufferList& bufread, BufferList& bufreadUpdate, const uint numParticles,
+		const uint particleRangeEnd, const float dt, const int step, const float t, const float epsilon,
+		const float slength, const float influenceRadius, const RunMode run_mode)
+	{
+		const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
+		if (!vertPos) throw std::invalid_argument("integrate_gamma: BUFFER_VERTPOS missing");
+		const float4 *newPos = bufreadUpdate.getConstData<BUFFER_POS>();
+		sphx_throw(sphx_sa_integrate_gamma(m_c->ctx(), bufreadUpdate.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_GRADGAMMA>(),
+			newPos, bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
+			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
+			bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, dt, step, t, epsilon, slength, influenceRadius,
+			run_mode == REPACK ? SPHX_REPACK : SPHX_SIMULATE, NULL));
+	}
 	void apply_density_diffusion(const BufferList&, BufferList&, const uint, const uint, const float)
 	{ sphx_not_built("apply_density_diffusion (ENABLE_DENSITY_SUM)"); }
 

@@ -154,6 +154,14 @@ static SimFramework *make_framework(Case const& c)
 			densitydiffusion<BREZZI>,
 			add_flags<ENABLE_DTADAPT | ENABLE_DENSITY_SUM>
 		);
+	} else if (name == "StillWaterRepackSA") {   // src/problems/StillWaterRepackSA.cu:38-44: continuity equation, gamma by quadrature
+		SETUP_FRAMEWORK(
+			kernel<WENDLAND>,
+			viscosity<DYNAMICVISC>,
+			boundary<SA_BOUNDARY>,
+			periodicity<PERIODIC_NONE>,
+			add_flags<ENABLE_DTADAPT | ENABLE_REPACKING | ENABLE_GAMMA_QUADRATURE>
+		);
 	} else if (name == "CompleteSaExample") {   // src/problems/CompleteSaExample.cu:39-47: compiles and constructs; its physics is not built
 		SETUP_FRAMEWORK(
 			kernel<WENDLAND>,

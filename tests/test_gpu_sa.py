@@ -208,3 +208,26 @@ def test_sa_forces_gamma_integration_and_trajectory():
     assert np.abs(gv[:, 3] - sim.vel[:, 3]).max() < 2e-6
     assert np.abs(ggg[fl, 3] - sim.gg[fl, 3]).max() < 2e-5
     assert abs(eng2.current_dt() - sim.dt) < 1e-5 * sim.dt and abs(eng2.time() - sim.t) < 1e-6 * sim.t
+
+
+def test_cpp_adapters_step_an_sa_problem(tmp_path):
+    """Four predictor-corrector steps of the SA sequence through the abstract interfaces of the GPUSPH tree (forces, Euler,
+    integrate_gamma, boundary conditions; framework from StillWaterRepackSA's SETUP_FRAMEWORK): bit-equal to the Python driver."""
+    import subprocess
+    import host_case as hc
+    kw = dict(deltap=0.05, jitter=0.1, options="StillWaterRepackSA")
+    prob = SABox(**kw)
+    eng = _engine(prob)
+    n = prob.num_particles
+    case = tmp_path / "case.txt"
+    case.write_text("\n".join(hc.case_lines(prob, "StillWaterRepackSA", allocated=eng.alloc) + hc.driver_lines(prob, eng, 4)) + "\n")
+    hc.write_state(str(tmp_path / "state.bin"), prob.copy_to_array())
+    subprocess.check_call([hc.exe("example_engines"), str(case), str(tmp_path / "state.bin"), str(tmp_path / "out.bin")])
+    out = hc.read_out(str(tmp_path / "out.bin"))
+    eng.run(4)
+    assert out["n"] == n
+    for name in ("pos", "vel", "gradgamma", "boundelements"):
+        assert np.array_equal(_bits(out[name]), _bits(_np(getattr(eng, name))[:n])), name
+    assert np.float32(out["dt"]) == np.float32(eng.current_dt()) and abs(out["t"] - eng.time()) < 1e-12
+    t = info_type(out["info"])
+    assert np.abs(out["vel"][t == D.PT_FLUID, :3]).max() > 0            # it did move

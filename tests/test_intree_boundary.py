@@ -122,6 +122,15 @@ def test_stillwater_sa_framework_and_constants(tmp_path):
     assert_params(out, prob, prob.num_particles)
 
 
+def test_stillwater_repack_sa_framework_and_constants(tmp_path):
+    """the option set the SA forces / integration engines are built for"""
+    prob = SABox(0.05, options="StillWaterRepackSA")
+    out = run_check(tmp_path, hc.case_lines(prob, "StillWaterRepackSA"))
+    assert_options(out, prob.simparams)
+    assert out["options"]["simflags"] & D.ENABLE_GAMMA_QUADRATURE and not out["options"]["simflags"] & D.ENABLE_DENSITY_SUM
+    assert_params(out, prob, prob.num_particles)
+
+
 def test_wavetank_framework_and_constants(tmp_path):
     prob = WaveTank(0.06)
     out = run_check(tmp_path, hc.case_lines(prob, "WaveTank") + ["filter 0 20"])
