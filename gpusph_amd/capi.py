@@ -58,7 +58,12 @@ SIGNATURES = {
     "sphx_build_neibs": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _u32, _f, _f, _vp]),
     "sphx_build_neibs_sa": (_i, [_vp] + [_vp] * 11 + [_u32, _u32, _u32, _f, _f, _vp]),
     "sphx_sa_compute_vertex_normal": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _vp]),
-    "sphx_forces_basicstep_sa": (_i, [_vp] + [_vp] * 13 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
+    "sphx_forces_basicstep_sa": (_i, [_vp] + [_vp] * 14 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
+    "sphx_forces_dtreduce_gamma_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "sphx_forces_dtreduce_gamma": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
+    "sphx_sa_density_sum": (_i, [_vp] + [_vp] * 15 + [_u32, _u32, _f, _i, _f, _f, _f, _f, _f, _vp]),
+    "sphx_sa_compute_density_diffusion": (_i, [_vp] + [_vp] * 8 + [_u32, _u32, _f, _f, _f, _f, _vp]),
+    "sphx_apply_density_diffusion": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _f, _vp]),
     "sphx_sa_integrate_gamma": (_i, [_vp] + [_vp] * 11 + [_u32, _u32, _f, _i, _f, _f, _f, _f, _i, _vp]),
     "sphx_sa_init_gamma": (_i, [_vp] + [_vp] * 11 + [_f, _f, _f, _f, _u32, _u32, _vp]),
     "sphx_sa_segment_bc": (_i, [_vp] + [_vp] * 9 + [_u32, _u32, _f, _f, _f, _i, _i, _vp]),

@@ -99,10 +99,8 @@ extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	(void)t; (void)slength; (void)influenceradius; (void)numParticles;
 	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_euler_basicstep: constants not set");
 	SPHX_REQUIRE(newPos && newVel && oldPos && oldVel && info && hash && forces, "sphx_euler_basicstep: missing buffer");
-	// SA_BOUNDARY: the fluid integrates like everywhere else (continuity equation), walls are copied; gamma follows in
-	// sphx_sa_integrate_gamma.  With density summation the density is not integrated here (and the summation is not built).
-	if (ctx->params.boundarytype == SPHX_SA_BOUNDARY && (ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM))
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_euler_basicstep: SA_BOUNDARY with density summation (ENABLE_DENSITY_SUM) is not built");
+	// SA_BOUNDARY: the fluid integrates like everywhere else, walls are copied; gamma follows in sphx_sa_integrate_gamma or,
+	// with density summation (FORCES.w is zero then), density and gamma in sphx_sa_density_sum
 	if ((ctx->dev.simflags & SPHX_ENABLE_XSPH) && run_mode == SPHX_SIMULATE)
 		SPHX_REQUIRE(xsph != nullptr, "sphx_euler_basicstep: ENABLE_XSPH needs the XSPH buffer");
 	if (run_mode != SPHX_SIMULATE && run_mode != SPHX_REPACK)

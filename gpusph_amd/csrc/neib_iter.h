@@ -29,7 +29,8 @@ __device__ __forceinline__ float kernel_W(const DevParams &p, float r)
 // neiblist_iterator (src/cuda/neibs_iteration.cuh:83-360) over one section of a particle's list:
 // f(neib_index, relPos.x, relPos.y, relPos.z) for every stored neighbour, in list order
 // A: any struct with members pos (float4*), cellStart, neibsList
-template<int NPTYPE, class A, class F>
+// CORR: hand the callback the cell-corrected own position (pos_corr of the reference's iterator) instead of relPos
+template<int NPTYPE, bool CORR = false, class A, class F>
 __device__ __forceinline__ void for_each_neib(const DevParams &p, const A &a, uint32_t index,
 	const float4 &pos, const int3 &gridPos, F &&f)
 {
@@ -93,7 +94,8 @@ __device__ __forceinline__ void for_each_neib(const DevParams &p, const A &a, ui
 			const float pcx = fmaf(-(float)(cx - 1), p.cs[0], pos.x);
 			const float pcy = fmaf(-(float)(cy - 1), p.cs[1], pos.y);
 			const float pcz = fmaf(-(float)(cz - 1), p.cs[2], pos.z);
-			f(jj[k], npos[k], pcx - npos[k].x, pcy - npos[k].y, pcz - npos[k].z);
+			if (CORR) f(jj[k], npos[k], pcx, pcy, pcz);
+			else f(jj[k], npos[k], pcx - npos[k].x, pcy - npos[k].y, pcz - npos[k].z);
 		}
 #pragma unroll
 		for (int k = 0; k < FB; ++k) nd[k] = ndn[k];

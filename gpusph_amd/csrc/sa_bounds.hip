@@ -382,6 +382,7 @@ sa_init_gamma_kernel(DevParams p, SaGammaArgs a)
 struct SaForcesArgs {
 	float4 *forces;
 	float *cfl;
+	float *cflGamma, *cflGammaBlocks;   // BUFFER_CFL_GAMMA: per particle, and per block behind round_up(numParticles, 4)
 	const float4 *pos, *vel, *gGam, *boundElement;
 	const float2 *vertPos[3];
 	const particleinfo *info;
@@ -422,9 +423,9 @@ __device__ __forceinline__ float sa_visc_avg(const DevParams &p, float visc, flo
 __global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
 sa_forces_kernel(DevParams p, SaForcesArgs a)
 {
-	__shared__ float sMax[SPHX_BLOCK_FORCES/64];
+	__shared__ float sMax[SPHX_BLOCK_FORCES/64], sMaxG[SPHX_BLOCK_FORCES/64];
 	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
-	float cflTerm = 0.0f;
+	float cflTerm = 0.0f, gammaCfl = 0.0f;
 	if (index < a.toParticle) {
 		const particleinfo info = a.info[index];
 		const float4 pos = a.pos[index];
@@ -482,6 +483,11 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 					calc_vertex_rel_pos(q_vb, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
 					const float ggamAS = grad_gamma_wendland(p.slength, v3(rx*inv_h, ry*inv_h, rz*inv_h), q_vb, ns);
 					const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
+					if (a.cflGamma) {      // compute_gamma_cfl_solid_wall (:1458-1474): n.(v_a - v_s), n.v_a, n.v_s
+						const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
+						const float vs = sa_dot3(vel.x - vx, vel.y - vy, vel.z - vz, be.x, be.y, be.z);
+						gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
+					}
 					if (!density_sum) {
 						float DrDt = 0.0f;
 						DrDt -= p_rho*vn*ggamAS;
@@ -516,16 +522,21 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 			}
 			a.forces[index] = force;
 		}
+		if (a.cflGamma) a.cflGamma[index] = gammaCfl;
 	}
 	// one CFL entry per block of SPHX_BLOCK_FORCES particles (maxBlockReduce)
 #pragma unroll
-	for (int d = 32; d > 0; d >>= 1) cflTerm = fmaxf(cflTerm, __shfl_down(cflTerm, d));
-	if ((threadIdx.x & 63u) == 0u) sMax[threadIdx.x >> 6] = cflTerm;
+	for (int d = 32; d > 0; d >>= 1) {
+		cflTerm = fmaxf(cflTerm, __shfl_down(cflTerm, d));
+		gammaCfl = fmaxf(gammaCfl, __shfl_down(gammaCfl, d));
+	}
+	if ((threadIdx.x & 63u) == 0u) { sMax[threadIdx.x >> 6] = cflTerm; sMaxG[threadIdx.x >> 6] = gammaCfl; }
 	__syncthreads();
 	if (threadIdx.x == 0 && a.cfl && (p.simflags & SPHX_ENABLE_DTADAPT)) {
-		float m = sMax[0];
-		for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) m = fmaxf(m, sMax[w]);
+		float m = sMax[0], mg = sMaxG[0];
+		for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) { m = fmaxf(m, sMax[w]); mg = fmaxf(mg, sMaxG[w]); }
 		a.cfl[a.cflOffset + blockIdx.x] = m;
+		if (a.cflGammaBlocks) a.cflGammaBlocks[a.cflOffset + blockIdx.x] = mg;
 	}
 }
 
@@ -568,6 +579,151 @@ sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
 		g.w -= gamma_wendland<false>(p.slength, q, q_vb, normal, oldg, a.epsilon);
 	});
 	a.newGGam[index] = g;
+}
+
+// ---- density summation with dynamic gamma (src/cuda/density_sum_kernel.cu:206-250,419-478,523-655) and Brezzi diffusion ----
+struct SaDensitySumArgs {
+	float4 *newVel, *newGGam, *forces;
+	const float4 *oldPos, *pos /* new positions: what the walker prefetches is not used */, *oldVel, *oldGGam, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+};
+
+__global__ void __launch_bounds__(128)
+sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != PT_FLUID) {
+		if (PART_TYPE(info) == PT_VERTEX || PART_TYPE(info) == PT_BOUNDARY) a.newGGam[index] = a.oldGGam[index];
+		return;
+	}
+	const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
+	// the walker hands over r_ab at step n (own old position against a.pos = new neighbour rows is NOT what is wanted), so
+	// it is pointed at the OLD positions and the new neighbour row is fetched here
+	struct { const float4 *pos; const uint32_t *cellStart; const neibdata *neibsList; } w = { a.oldPos, a.cellStart, a.neibsList };
+	float sumPmwN = 0.0f, sumPmwNp1 = 0.0f;
+	auto volumic = [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
+		if (!is_active_w(nN.w)) return;
+		const float4 nNp1 = a.pos[j];
+		// r_ab at n = pos_corr - neighbour old; at n+1 = (pos_corr - neighbour new) + own displacement
+		const float rx = pcx - nN.x, ry = pcy - nN.y, rz = pcz - nN.z;
+		const float qx = (pcx - nNp1.x) + dx, qy = (pcy - nNp1.y) + dy, qz = (pcz - nNp1.z) + dz;
+		const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+		sumPmwN -= nN.w*kernel_W<SPHX_WENDLAND>(p, rN);
+		const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
+		if (rNp1 < p.influenceradius) sumPmwNp1 += nN.w*kernel_W<SPHX_WENDLAND>(p, rNp1);
+	};
+	for_each_neib<PT_FLUID, true>(p, w, index, posN, gridPos, volumic);
+	for_each_neib<PT_VERTEX, true>(p, w, index, posN, gridPos, volumic);
+	const float fw = sumPmwNp1 + sumPmwN + 0.0f;
+	a.forces[index].w = fw;
+	float gGamDotR = 0.0f;
+	V3 gGam = v3(0.0f, 0.0f, 0.0f);
+	for_each_neib<PT_BOUNDARY, true>(p, w, index, posN, gridPos, [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
+		if (!is_active_w(nN.w)) return;
+		const float4 nNp1 = a.pos[j];
+		const float inv = 1.0f/p.slength;
+		const V3 qN = v3((pcx - nN.x)*inv, (pcy - nN.y)*inv, (pcz - nN.z)*inv);
+		const V3 qNp1 = v3(((pcx - nNp1.x) + dx)*inv, ((pcy - nNp1.y) + dy)*inv, ((pcz - nNp1.z) + dz)*inv);
+		const float4 be = a.boundElement[j];
+		const V3 ns = v3(be.x, be.y, be.z);
+		V3 q_vb[3];
+		calc_vertex_rel_pos(q_vb, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+		const V3 gN = ns*grad_gamma_wendland(p.slength, qN, q_vb, ns);
+		const V3 gNp1 = ns*grad_gamma_wendland(p.slength, qNp1, q_vb, ns);
+		gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
+		gGam = gGam + gNp1;
+	});
+	gGamDotR *= p.slength;
+	const float4 gGamN = a.oldGGam[index];
+	float4 g = make_float4(gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR);
+	const uint32_t fl = FLUID_NUM(info);
+	const float rho = (gGamN.w*((a.oldVel[index].w + 1.0f)*p.rho0[fl]) + fw)/g.w;
+	if (g.w > 1.0f || sqrtf(g.x*g.x + g.y*g.y + g.z*g.z)*p.slength < 1e-10f) g.w = 1.0f;
+	else if (g.w < 0.1f) g.w = 0.1f;
+	a.newVel[index].w = rho/p.rho0[fl] - 1.0f;
+	a.newGGam[index] = g;
+}
+
+struct SaDiffusionArgs {
+	float4 *forces;
+	const float4 *pos, *vel, *gGam;
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	float dt;
+};
+
+// computeDensityDiffusionDevice<.., BREZZI, SA_BOUNDARY, PT_FLUID> (forces_kernel.def:1766-1783, 4515-4560)
+__global__ void __launch_bounds__(128)
+sa_density_diffusion_kernel(DevParams p, SaDiffusionArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != PT_FLUID) return;
+	const float4 pos = a.pos[index];
+	if (!is_active_w(pos.w)) return;
+	const float4 vel = a.vel[index];
+	const uint32_t fl = FLUID_NUM(info);
+	const float rho = (vel.w + 1.0f)*p.rho0[fl];
+	const float pres = sa_P(p, vel.w, fl);
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	float DrDt = 0.0f;
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		if (!is_active_w(npos.w)) return;
+		if (r >= p.influenceradius) return;
+		const float4 nvel = a.vel[j];
+		const uint32_t nfl = FLUID_NUM(a.info[j]);
+		const float neib_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+		const float qm2 = r/p.slength - 2.0f;
+		const float f = qm2*qm2*qm2*p.fcoeff;
+		const float gdotr = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
+		float n = 0.0f;
+		n += p.densityDiffCoeff*((2.0f/(rho + neib_rho))*(pres - sa_P(p, nvel.w, nfl)) - gdotr)*npos.w/neib_rho*f*a.dt*2.0f*rho;
+		DrDt += n;
+	});
+	DrDt /= a.gGam[index].w;
+	a.forces[index].w = DrDt/p.rho0[fl];
+}
+
+// updateDensityDevice (src/cuda/euler_kernel.cu:116-136)
+__global__ void __launch_bounds__(256)
+sa_update_density_kernel(float4 *vel, const float4 *forces, const particleinfo *info, uint32_t numParticles, float dt)
+{
+	const uint32_t index = blockIdx.x*256 + threadIdx.x;
+	if (index >= numParticles) return;
+	if (PART_TYPE(info[index]) != PT_FLUID) return;
+	const float rho = vel[index].w;
+	const float delta = forces[index].w*dt;
+	vel[index].w = rho + delta;
+}
+
+// gamma part of dtreduce with dynamic gamma (src/cuda/forces.cu:576-585), on the device scalar the step reads its dt from
+__global__ void __launch_bounds__(256)
+sa_gamma_dt_kernel(float *d_dt, const float *cflGammaBlocks, uint32_t numBlocks)
+{
+	__shared__ float s[256];
+	float m = 0.0f;
+	for (uint32_t i = threadIdx.x; i < numBlocks; i += 256) m = fmaxf(m, cflGammaBlocks[i]);
+	s[threadIdx.x] = m;
+	__syncthreads();
+	for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) s[threadIdx.x] = fmaxf(s[threadIdx.x], s[threadIdx.x + d]); __syncthreads(); }
+	if (threadIdx.x == 0) {
+		const float dt = d_dt[0];
+		const float maxcfl = fmaxf(s[0], 1e-5f/dt);
+		const float dt_gam = 0.001f/maxcfl;
+		if (dt_gam < dt) d_dt[0] = dt_gam;
+	}
 }
 
 static int sa_check(sphx_ctx *ctx, const char *who)
@@ -678,27 +834,30 @@ static int sa_forces_check(sphx_ctx *ctx, const char *who)
 	int rc = sa_check(ctx, who);
 	if (rc != SPHX_OK) return rc;
 	const sphx_params &q = ctx->params;
-	if (q.simflags & SPHX_ENABLE_DENSITY_SUM)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: density summation (ENABLE_DENSITY_SUM) is not built; the continuity-equation form is");
-	if (!(q.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: dynamic gamma (transport equation) is not built; ENABLE_GAMMA_QUADRATURE is");
+	// two forms are built: the continuity equation with gamma by quadrature (StillWaterRepackSA) and density summation with
+	// dynamic gamma and, optionally, Brezzi diffusion (StillWaterSA and most SA problems of the reference)
+	const bool dsum = (q.simflags & SPHX_ENABLE_DENSITY_SUM) != 0, quad = (q.simflags & SPHX_ENABLE_GAMMA_QUADRATURE) != 0;
+	if (dsum == quad)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: built are ENABLE_DENSITY_SUM with dynamic gamma, and the continuity equation with ENABLE_GAMMA_QUADRATURE");
 	if (q.simflags & (SPHX_ENABLE_MOVING_BODIES | SPHX_ENABLE_XSPH | SPHX_ENABLE_PLANES))
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built without moving bodies, XSPH and planes");
-	if (q.sph_formulation != SPHX_SPH_F1 || q.densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for SPH_F1 without density diffusion");
+	if (q.sph_formulation != SPHX_SPH_F1)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for SPH_F1");
+	if (!(q.densitydiffusiontype == SPHX_DENSITY_DIFFUSION_NONE || (dsum && q.densitydiffusiontype == SPHX_BREZZI)))
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: density diffusion with SA_BOUNDARY: Brezzi with density summation only");
 	if (q.turbmodel != SPHX_LAMINAR_FLOW && q.rheologytype != SPHX_INVISCID)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for laminar flow");
 	return SPHX_OK;
 }
 
-extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
+extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
 	float deltap, float slength, float dtadaptfactor, float influenceradius, uint32_t cflOffset,
 	int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream)
 {
-	(void)numParticles; (void)dtadaptfactor; (void)step; (void)dt;
+	(void)dtadaptfactor; (void)step; (void)dt;
 	int rc = sa_forces_check(ctx, "forces basicstep (SA) called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	if (run_mode != SPHX_SIMULATE)
@@ -722,6 +881,13 @@ extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
+	// the CFL condition of the gamma transport (dynamic gamma + adaptive dt): BUFFER_CFL_GAMMA in the reference's layout
+	const bool gcfl = !(ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE) && (ctx->params.simflags & SPHX_ENABLE_DTADAPT);
+	SPHX_REQUIRE(!gcfl || cflGamma, "sphx_forces_basicstep_sa: dynamic gamma with ENABLE_DTADAPT needs BUFFER_CFL_GAMMA");
+	if (gcfl) {
+		a.cflGamma = cflGamma; a.cflGammaBlocks = cflGamma + (numParticles + 3u)/4u*4u;
+		if (numBlocks > blocks) SPHX_HIP(hipMemsetAsync(a.cflGammaBlocks + cflOffset + blocks, 0, sizeof(float)*(numBlocks - blocks), st));
+	}
 	sa_forces_kernel<<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_forces_kernel");
 	return SPHX_OK;
@@ -754,5 +920,102 @@ extern "C" int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void 
 	a.numParticles = particleRangeEnd; a.epsilon = epsilon;
 	sa_integrate_gamma_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_integrate_gamma_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_dtreduce_gamma_device(sphx_ctx *ctx, const float *cflGamma, uint32_t numParticles, uint32_t numBlocks,
+	float *d_dt, void *stream)
+{
+	int rc = sa_check(ctx, "dtreduce (gamma) called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(cflGamma && d_dt, "sphx_forces_dtreduce_gamma_device: missing buffer");
+	if (!numBlocks) return SPHX_OK;
+	sa_gamma_dt_kernel<<<1, 256, 0, (hipStream_t)stream>>>(d_dt, cflGamma + (numParticles + 3u)/4u*4u, numBlocks);
+	SPHX_LAUNCH_CHECK("sa_gamma_dt_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_dtreduce_gamma(sphx_ctx *ctx, const float *cflGamma, uint32_t numParticles, uint32_t numBlocks,
+	float *h_dt_inout, void *stream)
+{
+	SPHX_REQUIRE(h_dt_inout != nullptr, "sphx_forces_dtreduce_gamma: NULL dt");
+	float *d = nullptr;
+	SPHX_HIP(hipMalloc((void**)&d, sizeof(float)));
+	SPHX_HIP(hipMemcpyAsync(d, h_dt_inout, sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+	int rc = sphx_forces_dtreduce_gamma_device(ctx, cflGamma, numParticles, numBlocks, d, stream);
+	if (rc == SPHX_OK) {
+		SPHX_HIP(hipMemcpyAsync(h_dt_inout, d, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+		SPHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+	}
+	(void)hipFree(d);
+	return rc;
+}
+
+extern "C" int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces,
+	const void *oldPos, const void *newPos, const void *oldVel, const void *oldGGam, const void *boundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, int step, float t, float epsilon,
+	float deltap, float slength, float influenceradius, void *stream)
+{
+	(void)numParticles; (void)dt; (void)step; (void)t; (void)epsilon; (void)deltap;
+	int rc = sa_check(ctx, "density_sum called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	if (!(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) || (ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_density_sum: needs ENABLE_DENSITY_SUM with dynamic gamma");
+	if (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_density_sum: moving bodies are not built");
+	if (ctx->params.sph_formulation != SPHX_SPH_F1 && ctx->params.sph_formulation != SPHX_SPH_F2)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_density_sum: SPH_HA is not built");
+	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldGGam && boundElements && vertPos0 && vertPos1 && vertPos2 &&
+		info && hash && cellStart && neibsList, "sphx_sa_density_sum: missing buffer");
+	SPHX_REQUIRE(newGGam != oldGGam, "sphx_sa_density_sum: gamma is double buffered");
+	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
+		"sphx_sa_density_sum: slength / influenceradius differ from the uploaded constants");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaDensitySumArgs a = {};
+	a.newVel = (float4*)newVel; a.newGGam = (float4*)newGGam; a.forces = (float4*)forces;
+	a.oldPos = (const float4*)oldPos; a.pos = (const float4*)newPos; a.oldVel = (const float4*)oldVel; a.oldGGam = (const float4*)oldGGam;
+	a.boundElement = (const float4*)boundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
+	sa_density_sum_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_density_sum_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_compute_density_diffusion(sphx_ctx *ctx, void *forces, const void *pos, const void *vel, const void *gGam,
+	const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius, float dt, void *stream)
+{
+	(void)numParticles; (void)deltap;
+	int rc = sa_check(ctx, "compute_density_diffusion called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	if (ctx->params.densitydiffusiontype != SPHX_BREZZI || !(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) ||
+		ctx->params.sph_formulation == SPHX_SPH_HA)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_compute_density_diffusion: built for Brezzi diffusion with density summation");
+	SPHX_REQUIRE(forces && pos && vel && gGam && info && hash && cellStart && neibsList, "sphx_sa_compute_density_diffusion: missing buffer");
+	SPHX_REQUIRE(slength == ctx->params.slength && influenceradius == ctx->params.influenceradius,
+		"sphx_sa_compute_density_diffusion: slength / influenceradius differ from the uploaded constants");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaDiffusionArgs a = {};
+	a.forces = (float4*)forces; a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.gGam = (const float4*)gGam;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.numParticles = particleRangeEnd; a.dt = dt;
+	sa_density_diffusion_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_density_diffusion_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_apply_density_diffusion(sphx_ctx *ctx, void *vel, const void *forces, const void *info,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream)
+{
+	(void)numParticles;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_apply_density_diffusion: constants not set");
+	SPHX_REQUIRE(vel && forces && info, "sphx_apply_density_diffusion: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	sa_update_density_kernel<<<div_up_u(particleRangeEnd, 256), 256, 0, (hipStream_t)stream>>>((float4*)vel, (const float4*)forces,
+		(const particleinfo*)info, particleRangeEnd, dt);
+	SPHX_LAUNCH_CHECK("sa_update_density_kernel");
 	return SPHX_OK;
 }

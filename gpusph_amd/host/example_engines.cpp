@@ -203,6 +203,9 @@ int main(int argc, char **argv)
 			BufferList saA = one_buffer<BUFFER_VERTICES>(A) | one_buffer<BUFFER_BOUNDELEMENTS>(A) | one_buffer<BUFFER_GRADGAMMA>(A);
 			BufferList saB = one_buffer<BUFFER_VERTICES>(A) | one_buffer<BUFFER_BOUNDELEMENTS>(A) | one_buffer<BUFFER_GRADGAMMA>(A);
 			shared |= one_buffer<BUFFER_VERTPOS>(A);
+			const bool dynamic_gamma = USING_DYNAMIC_GAMMA(sp->simflags), density_sum = (sp->simflags & ENABLE_DENSITY_SUM) != 0;
+			if (dynamic_gamma)      // per particle + per block behind round_up(numParticles, 4) (src/cuda/forces.cu:576-581)
+				shared |= one_buffer<BUFFER_CFL_GAMMA>((size_t)A + 4 + forcesEngine->getFmaxElements(A));
 			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_VERTICES>(), hvert.data(), 16*(size_t)n0));
 			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_BOUNDELEMENTS>(), hbe.data(), 16*(size_t)n0));
 			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_GRADGAMMA>(), hgg.data(), 16*(size_t)n0));
@@ -245,7 +248,14 @@ int main(int argc, char **argv)
 					dts[step - 1] = forcesEngine->dtreduce(slength, sp->dtadaptfactor, sspeed_cfl, max_kinvisc, rd, rd, nb, n);
 					const float hdt = step == 1 ? sdt/2 : sdt;
 					integrationEngine->basicstep(*cur, *oth, n, n, hdt, step, (float)st, slength, influenceRadius, SIMULATE);
-					integrationEngine->integrate_gamma(*cur, *oth, n, n, hdt, step, (float)st, sp->epsilon, slength, influenceRadius, SIMULATE);
+					if (density_sum) {     // DENSITY_SUM, then CALC_ / APPLY_DENSITY_DIFFUSION on the new state (:607-659)
+						integrationEngine->density_sum(*cur, *oth, n, n, hdt, step, (float)st, sp->epsilon, deltap, slength, influenceRadius);
+						if (sp->densitydiffusiontype != DENSITY_DIFFUSION_NONE) {
+							forcesEngine->compute_density_diffusion(*oth, *oth, n, n, deltap, slength, influenceRadius, hdt);
+							integrationEngine->apply_density_diffusion(*oth, *oth, n, n, hdt);
+						}
+					} else
+						integrationEngine->integrate_gamma(*cur, *oth, n, n, hdt, step, (float)st, sp->epsilon, slength, influenceRadius, SIMULATE);
 					bc->saSegmentBoundaryConditions(*oth, *oth, n, n, deltap, slength, influenceRadius, step, SIMULATE);
 					bc->saVertexBoundaryConditions(*oth, *oth, n, n, deltap, slength, influenceRadius, step, false, hdt, &newNum, 0, 1, n, SIMULATE);
 				}

@@ -376,9 +376,15 @@ public:
 	void compute_density(const BufferList&, BufferList&, uint, float, float)
 	{ sphx_not_built("compute_density (SPH_GRENIER)"); }
 
-	void compute_density_diffusion(const BufferList&, BufferList&, const uint, const uint, const float, const float,
-		const float, const float)
-	{ sphx_not_built("compute_density_diffusion (ENABLE_DENSITY_SUM)"); }
+	// Brezzi diffusion after the density summation (src/cuda/forces.cu:621-661): the diffusive density rate into FORCES.w
+	void compute_density_diffusion(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
+		const uint particleRangeEnd, const float deltap, const float slength, const float influenceRadius, const float dt)
+	{
+		sphx_throw(sphx_sa_compute_density_diffusion(m_c->ctx(), bufwrite.getData<BUFFER_FORCES>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_GRADGAMMA>(),
+			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
+			bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, deltap, slength, influenceRadius, dt, NULL));
+	}
 
 	uint basicstep(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint fromParticle,
 		uint toParticle, float deltap, float slength, float dtadaptfactor, float influenceradius,
@@ -395,7 +401,9 @@ public:
 			const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
 			if (!vertPos) throw std::invalid_argument("forces basicstep: SA_BOUNDARY needs BUFFER_VERTPOS");
 			uint32_t nb = 0;
-			sphx_throw(sphx_forces_basicstep_sa(m_c->ctx(), forces, cfl,
+			// BUFFER_CFL_GAMMA is there with dynamic gamma and adaptive dt (src/cuda/forces_params.h, dyndt + gamma)
+			const bool gcfl = !(P.simflags & ENABLE_GAMMA_QUADRATURE) && (P.simflags & ENABLE_DTADAPT);
+			sphx_throw(sphx_forces_basicstep_sa(m_c->ctx(), forces, cfl, gcfl ? bufwrite.getData<BUFFER_CFL_GAMMA>() : NULL,
 				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
 				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
 				bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
@@ -421,11 +429,16 @@ public:
 	uint getFmaxTempElements(const uint n) { return sphx_forces_fmax_temp_elements(n); }
 
 	float dtreduce(float slength, float dtadaptfactor, float sspeed_cfl, float max_kinematic,
-		BufferList const& bufread, BufferList& bufwrite, uint numBlocks, uint)
+		BufferList const& bufread, BufferList& bufwrite, uint numBlocks, uint numParticles)
 	{
 		float dt = 0;
 		sphx_throw(sphx_forces_dtreduce(m_c->ctx(), slength, dtadaptfactor, sspeed_cfl, max_kinematic,
 			bufread.getData<BUFFER_CFL>(), bufwrite.getData<BUFFER_CFL_TEMP>(), numBlocks, &dt, NULL));
+		// SA_BOUNDARY with dynamic gamma: the CFL condition of the gamma transport (src/cuda/forces.cu:576-585).  The library
+		// applies it after the viscous limit; the result is the same (the 1e-5/dt floor only matters when gamma does not limit)
+		const sphx_params &P = m_c->params();
+		if (P.boundarytype == SA_BOUNDARY && USING_DYNAMIC_GAMMA(P.simflags) && bufread.getData<BUFFER_CFL_GAMMA>())
+			sphx_throw(sphx_forces_dtreduce_gamma(m_c->ctx(), bufread.getData<BUFFER_CFL_GAMMA>(), numParticles, numBlocks, &dt, NULL));
 		return dt;
 	}
 };
@@ -495,9 +508,23 @@ public:
 	void setrbangularvel(const float3 *w, int n)
 	{ sphx_throw(sphx_set_rb_motion(m_c->ctx(), NULL, NULL, NULL, (const float*)w, n)); }
 
-	void density_sum(const BufferList&, BufferList&, const uint, const uint, const float, const int, const float,
-		const float, const float, const float, const float)
-	{ sphx_not_built("density_sum (ENABLE_DENSITY_SUM, SA_BOUNDARY)"); }
+	// common_density_sum_params (src/cuda/density_sum_params.h:60-110): old positions / velocities / gamma and the boundary
+	// elements from the state that is read; the NEW positions (read), the new density and gamma (written) and the FORCES
+	// scratch from the write list
+	void density_sum(const BufferList& bufread, BufferList& bufwrite, const uint numParticles, const uint particleRangeEnd,
+		const float dt, const int step, const float t, const float epsilon, const float deltap, const float slength,
+		const float influenceRadius)
+	{
+		const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
+		if (!vertPos) throw std::invalid_argument("density_sum: BUFFER_VERTPOS missing");
+		const float4 *newPos = bufwrite.getConstData<BUFFER_POS>();
+		sphx_throw(sphx_sa_density_sum(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+			bufwrite.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_POS>(), newPos, bufread.getData<BUFFER_VEL>(),
+			bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
+			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
+			bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, dt, step, t, epsilon, deltap, slength,
+			influenceRadius, NULL));
+	}
 	// quadrature_gamma_params (src/cuda/density_sum_params.h:224-262): old gamma, vertex offsets, boundary elements and the
 	// list from the state that is read; the NEW positions and the new gamma from the state that is updated
 	void integrate_gamma(const BufferList& bufread, BufferList& bufreadUpdate, const uint numParticles,
@@ -513,8 +540,13 @@ public:
 			bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, dt, step, t, epsilon, slength, influenceRadius,
 			run_mode == REPACK ? SPHX_REPACK : SPHX_SIMULATE, NULL));
 	}
-	void apply_density_diffusion(const BufferList&, BufferList&, const uint, const uint, const float)
-	{ sphx_not_built("apply_density_diffusion (ENABLE_DENSITY_SUM)"); }
+	// updateDensityDevice (src/cuda/euler.cu:307-326): rho~ += FORCES.w dt for the fluid
+	void apply_density_diffusion(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
+		const uint particleRangeEnd, const float dt)
+	{
+		sphx_throw(sphx_apply_density_diffusion(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufread.getData<BUFFER_FORCES>(),
+			bufread.getData<BUFFER_INFO>(), numParticles, particleRangeEnd, dt, NULL));
+	}
 
 	void basicstep(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
 		const uint particleRangeEnd, const float dt, const int step, const float t, const float slength,

@@ -128,15 +128,36 @@ class HipKernels:
                                                p(vertpos[1]), p(vertpos[2]), p(info), p(hash_), p(cellStart), p(neibslist),
                                                P.slength, P.influenceradius, P.deltap, float(np.float32(epsilon)), n, range_end, self._s()))
 
-    def forces_sa(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, n, frm, to, cfl_offset):
+    def forces_sa(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, n, frm, to, cfl_offset,
+                  cfl_gamma=None):
         p = capi.ptr
         P = self.params
         nb = C.c_uint32(0)
-        capi.check(self.lib.sphx_forces_basicstep_sa(self.ctx.handle, p(forces), p(cfl), p(pos), p(vel), p(info), p(hash_), p(cellStart),
+        capi.check(self.lib.sphx_forces_basicstep_sa(self.ctx.handle, p(forces), p(cfl), p(cfl_gamma), p(pos), p(vel), p(info), p(hash_), p(cellStart),
                                                      p(neibslist), p(ggam), p(boundelements), p(vertpos[0]), p(vertpos[1]), p(vertpos[2]),
                                                      n, frm, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius, cfl_offset,
                                                      D.SIMULATE, 1, 0.0, C.byref(nb), self._s()))
         return nb.value
+
+    def dtreduce_gamma(self, cfl_gamma, n, nblocks, d_dt):
+        capi.check(self.lib.sphx_forces_dtreduce_gamma_device(self.ctx.handle, capi.ptr(cfl_gamma), n, nblocks, capi.ptr(d_dt), self._s()))
+
+    def sa_density_sum(self, new_vel, new_ggam, forces, old_pos, new_pos, old_vel, old_ggam, boundelements, vertpos, info, hash_, cellStart,
+                       neibslist, n, range_end, dt=0.0, step=1):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_sa_density_sum(self.ctx.handle, p(new_vel), p(new_ggam), p(forces), p(old_pos), p(new_pos), p(old_vel),
+                                                p(old_ggam), p(boundelements), p(vertpos[0]), p(vertpos[1]), p(vertpos[2]), p(info), p(hash_),
+                                                p(cellStart), p(neibslist), n, range_end, float(dt), int(step), 0.0, 5e-5, P.deltap, P.slength,
+                                                P.influenceradius, self._s()))
+
+    def sa_density_diffusion(self, forces, pos, vel, ggam, info, hash_, cellStart, neibslist, n, range_end, dt):
+        """compute_density_diffusion (forces engine) + apply_density_diffusion (integration engine)"""
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_sa_compute_density_diffusion(self.ctx.handle, p(forces), p(pos), p(vel), p(ggam), p(info), p(hash_), p(cellStart),
+                                                              p(neibslist), n, range_end, P.deltap, P.slength, P.influenceradius, float(dt), self._s()))
+        capi.check(self.lib.sphx_apply_density_diffusion(self.ctx.handle, p(vel), p(forces), p(info), n, range_end, float(dt), self._s()))
 
     def sa_integrate_gamma(self, new_ggam, old_ggam, new_pos, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end,
                            epsilon=5e-5):

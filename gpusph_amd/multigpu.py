@@ -169,6 +169,10 @@ class MultiGpuEngine:
             self.boundelements = up(arrs["boundelements"], f32, (A, 4)); self.boundelements2 = torch.zeros_like(self.boundelements)
             self.gradgamma = up(arrs["gradgamma"], f32, (A, 4)); self.gradgamma2 = torch.zeros_like(self.gradgamma)
             self.vertpos = [torch.zeros((A, 2), dtype=f32, device=dev) for _ in range(3)]
+            # dynamic gamma (no ENABLE_GAMMA_QUADRATURE): BUFFER_CFL_GAMMA, per particle and, behind round_up(n, 4), per block
+            self.sa_dynamic_gamma = not (self.sp.simflags & D.ENABLE_GAMMA_QUADRATURE)
+            self.sa_density_sum = bool(self.sp.simflags & D.ENABLE_DENSITY_SUM)
+            self.cfl_gamma = (torch.zeros(A + 4 + self.cfl.numel(), dtype=f32, device=dev) if self.sa_dynamic_gamma else None)
         self.filters = []            # [(FilterType, frequency)]
         # bodies with prescribed motion: every rank runs the same host kinematics (the callback is a pure function of time)
         self.bodies = None
@@ -263,8 +267,18 @@ class MultiGpuEngine:
         """INTEGRATE_GAMMA on the new positions (always from the gamma of step n), then the boundary conditions of the new
         state (PredictorCorrectorIntegrator.cc:661-684 and the post-step phases)"""
         K, n = self.k, self.n_local
-        K.sa_integrate_gamma(self.gradgamma2, self.gradgamma, self.pos2, self.boundelements, self.vertpos, self.info, self.hash,
-                             self.cellStart, self.neibslist, n, n)
+        if self.sa_density_sum:
+            # DENSITY_SUM [+ CALC_DENSITY_DIFFUSION + APPLY_DENSITY_DIFFUSION] (PredictorCorrectorIntegrator.cc:607-659): density and
+            # gamma of the new state from the positions of step n and of the new state; BUFFER_FORCES is their scratch
+            K.sa_density_sum(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.gradgamma, self.boundelements,
+                             self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, n)
+            if self.sp.densitydiffusiontype == D.BREZZI:
+                dt = float(self.d_dt.item()) * (0.5 if step == 1 else 1.0)     # dt_op on the host, as the reference's command has it
+                K.sa_density_diffusion(self.forces, self.pos2, self.vel2, self.gradgamma2, self.info, self.hash, self.cellStart,
+                                       self.neibslist, n, n, float(np.float32(dt)))
+        else:
+            K.sa_integrate_gamma(self.gradgamma2, self.gradgamma, self.pos2, self.boundelements, self.vertpos, self.info, self.hash,
+                                 self.cellStart, self.neibslist, n, n)
         K.sa_segment_bc(self.vel2, self.gradgamma2, self.pos2, self.vertices, self.boundelements, self.info, self.hash, self.cellStart,
                         self.neibslist, n, n, step, D.SIMULATE)
         K.sa_vertex_bc(self.vel2, self.gradgamma2, self.pos2, self.info, self.hash, self.cellStart, self.neibslist, n, n, step, D.SIMULATE)
@@ -354,8 +368,10 @@ class MultiGpuEngine:
         if self.sa:      # forces engine of SA_BOUNDARY: the state's gamma, the boundary elements, the vertex offsets of the segments
             ggam = self.gradgamma if pos is self.pos else self.gradgamma2
             nb = K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
-                             self.boundelements, self.vertpos, self.n_local, 0, self.n_int, 0)
+                             self.boundelements, self.vertpos, self.n_local, 0, self.n_int, 0, cfl_gamma=self.cfl_gamma)
             K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
+            if self.sa_dynamic_gamma:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
+                K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb, self.d_dt_next)
             return
         args = (self.forces, self.cfl, self.rbforces if self.has_rb else None, self.rbtorques if self.has_rb else None, pos, vel, self.info, self.hash, self.cellStart,
                 self.neibslist, self.n_local)

@@ -211,15 +211,38 @@ int sphx_neibs_getinfo(sphx_ctx *ctx, sphx_neibs_info *h_out, void *stream);
 
 /* basicstep of the forces engine with SA_BOUNDARY (src/cuda/forces.cu:717-806 with the SA members of forces_params): fluid <-
  * fluid, fluid <- vertex, fluid <- boundary element (through |grad gamma_as|, src/cuda/gamma.cuh), sums divided by gamma,
- * gravity, CFL maxima.  Built for solid walls, SPH_F1, laminar Newtonian or inviscid flow, the continuity equation (no
- * ENABLE_DENSITY_SUM) and ENABLE_GAMMA_QUADRATURE -- the option set of StillWaterRepackSA's simulation; everything else
- * answers SPHX_ERR_UNSUPPORTED. */
-int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
+ * gravity, CFL maxima.  Built for solid walls, SPH_F1, laminar Newtonian or inviscid flow, in two forms: the continuity
+ * equation with ENABLE_GAMMA_QUADRATURE (StillWaterRepackSA's simulation) and ENABLE_DENSITY_SUM with dynamic gamma
+ * (StillWaterSA; then cflGamma = BUFFER_CFL_GAMMA receives the CFL condition of the gamma transport, per particle and, behind
+ * round_up(numParticles, 4), per block -- NULL otherwise); everything else answers SPHX_ERR_UNSUPPORTED. */
+int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
 	float deltap, float slength, float dtadaptfactor, float influenceradius, uint32_t cflOffset,
 	int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream);
+/* gamma part of dtreduce with dynamic gamma (src/cuda/forces.cu:576-585): dt = min(dt, 0.001/max(max CFL_gamma, 1e-5/dt)), on a
+ * device scalar (stream-ordered) or on a host value (synchronous) */
+int sphx_forces_dtreduce_gamma_device(sphx_ctx *ctx, const float *cflGamma, uint32_t numParticles, uint32_t numBlocks,
+	float *d_dt, void *stream);
+int sphx_forces_dtreduce_gamma(sphx_ctx *ctx, const float *cflGamma, uint32_t numParticles, uint32_t numBlocks,
+	float *h_dt_inout, void *stream);
+/* AbstractIntegrationEngine::density_sum (src/cuda/euler.cu:112-200; densitySumVolumicDevice / densitySumBoundaryDevice,
+ * src/cuda/density_sum_kernel.cu:523-655): density and (dynamic) gamma of the fluid from the old and the new positions;
+ * newVel.w and newGGam are written, forces.w is scratch, gGam rows of vertex / boundary particles are copied */
+int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces,
+	const void *oldPos, const void *newPos, const void *oldVel, const void *oldGGam, const void *boundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, int step, float t, float epsilon,
+	float deltap, float slength, float influenceradius, void *stream);
+/* AbstractForcesEngine::compute_density_diffusion (src/cuda/forces.cu:621-661) for Brezzi diffusion with density summation:
+ * the diffusive density rate into forces.w; AbstractIntegrationEngine::apply_density_diffusion (src/cuda/euler.cu:307-326) */
+int sphx_sa_compute_density_diffusion(sphx_ctx *ctx, void *forces, const void *pos, const void *vel, const void *gGam,
+	const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius, float dt, void *stream);
+int sphx_apply_density_diffusion(sphx_ctx *ctx, void *vel, const void *forces, const void *info,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream);
 /* AbstractIntegrationEngine::integrate_gamma (src/cuda/euler.cu:202-290) with ENABLE_GAMMA_QUADRATURE: gamma and grad gamma
  * of the fluid particles at their new positions by quadrature over the listed boundary elements
  * (integrateGammaDevice, src/cuda/density_sum_kernel.cu:690-765); rows of vertex and boundary particles are copied */

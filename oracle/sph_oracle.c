@@ -773,6 +773,7 @@ typedef struct {
 	const orc_f4 *gGam, *boundelem;
 	const float *vertPos[3];
 	float deltap;
+	float *gammaCfl;      /* per particle max of |grad gamma_as| |n.v| (dynamic gamma + ENABLE_DTADAPT), or NULL */
 } sa_forces_ctx;
 float orc_grad_gamma_vp(float slength, float qx, float qy, float qz, const orc_f4 *belem,
 	const float *vp0, const float *vp1, const float *vp2);
@@ -851,6 +852,11 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 					sa->vertPos[0] + 2*(size_t)neib_index, sa->vertPos[1] + 2*(size_t)neib_index, sa->vertPos[2] + 2*(size_t)neib_index);
 				/* mass_continuity_div_vel_term :2079-2090 (nout.DrDt starts from 0) */
 				const float vn = dot3(vx, vy, vz, belem.x, belem.y, belem.z);
+				if (sa->gammaCfl) {     /* compute_gamma_cfl_solid_wall :1458-1474: n.(v_a - v_s), n.v_a, n.v_s */
+					const float va = dot3(vel.x, vel.y, vel.z, belem.x, belem.y, belem.z);
+					const float vs = dot3(vel.x - vx, vel.y - vy, vel.z - vz, belem.x, belem.y, belem.z);
+					sa->gammaCfl[index] = fmaxf(sa->gammaCfl[index], ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
+				}
 				if (!(p->simflags & ORC_ENABLE_DENSITY_SUM)) {
 					DrDt -= p_rho*vn*ggamAS;
 					if (f2) DrDt *= p_rho/n_rho;
@@ -1121,19 +1127,33 @@ uint32_t orc_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 /* run_forces with SA_BOUNDARY (solid walls, no k-epsilon, no moving bodies): fluid <- fluid, fluid <- vertex, then
  * fluid <- boundary element (the launch order of src/cuda/forces.cu:751-790; vertex particles skip their own neighbour
  * walk, skip_neiblist :1346-1358), then the finalize with the division by gamma */
-uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl,
+uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *cflGamma,
 	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
 	const orc_f4 *gGam, const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, float deltap)
 {
-	(void)numParticles;
-	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap };
+	/* cflGamma: BUFFER_CFL_GAMMA in the reference's layout -- one value per particle, then, from round_up(numParticles, 4)
+	 * on, one value per block (src/cuda/forces.cu:576-581); used with dynamic gamma and ENABLE_DTADAPT only */
+	const int gcfl = cflGamma && !(p->simflags & ORC_ENABLE_GAMMA_QUADRATURE) && (p->simflags & ORC_ENABLE_DTADAPT);
+	if (gcfl) memset(cflGamma + fromParticle, 0, sizeof(float)*(toParticle - fromParticle));
+	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL };
 	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
 	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
 	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
 	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
 	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, &sa);
+	if (gcfl) {      /* per-block maxima behind the per-particle values */
+		float *blocks = cflGamma + round_up(numParticles, 4u) + cflOffset;
+		for (uint32_t b = 0; b < numBlocks; ++b) {
+			float m = 0.0f;
+			for (uint32_t t = 0; t < BLOCK_SIZE_FORCES; ++t) {
+				const uint32_t i = b*BLOCK_SIZE_FORCES + t + fromParticle;
+				if (i < toParticle) m = fmaxf(m, cflGamma[i]);
+			}
+			blocks[b] = m;
+		}
+	}
 	return numBlocks;
 }
 
@@ -2393,4 +2413,144 @@ void orc_sa_integrate_gamma_quadrature(const orc_params *p, orc_f4 *newGGam, con
 		}
 		newGGam[index] = g;
 	}
+}
+
+/* ---- SA_BOUNDARY with density summation and dynamic gamma (the form StillWaterSA and most SA problems of the reference run) ----
+ * densitySumVolumicDevice + densitySumBoundaryDevice (src/cuda/density_sum_kernel.cu:523-655), solid walls, no moving bodies:
+ * the density of a fluid particle follows from the change of its kernel sum between the old and the new positions, gamma from
+ * the mean of the old and new grad gamma along the displacement:
+ *   gamma^{n+1} = gamma^n + sum_s 1/2 (ggam_s^n + ggam_s^{n+1}) . (r^{n+1} - r^n)
+ *   rho^{n+1}   = (gamma^n rho^n + sum_b m_b W(r^{n+1}) - sum_b m_b W(r^n)) / gamma^{n+1}
+ * newVel.w and newGGam of fluid rows are written; forces.w is the scratch of the volumic sum (as in the reference); the gGam
+ * rows of vertex and boundary particles are copied (density_sum_impl, src/cuda/euler.cu:112-160). */
+void orc_sa_density_sum(const orc_params *p, orc_f4 *newVel, orc_f4 *newGGam, orc_f4 *forces,
+	const orc_f4 *oldPos, const orc_f4 *newPos, const orc_f4 *oldVel, const orc_f4 *oldGGam, const orc_f4 *boundelem,
+	const float *vertPos0, const float *vertPos1, const float *vertPos2, const orc_info *infoArray,
+	const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd)
+{
+	const float kr = 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const float slength = p->slength;
+#pragma omp parallel for schedule(dynamic, 256)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!FLUID(info)) {
+			if (VERTEX(info) || BOUNDARY(info)) newGGam[index] = oldGGam[index];
+			continue;
+		}
+		const orc_f4 posN = oldPos[index], posNp1 = newPos[index];
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;    /* posDelta */
+		/* computeDensitySumVolumicTerms (:206-250): fluid, then vertex neighbours (for_each_neib2) */
+		float sumPmwN = 0.0f, sumPmwNp1 = 0.0f;
+		for (int nptype = PT_FLUID; nptype <= PT_VERTEX; nptype += 2) {
+			neib_iter it;
+			uint32_t neib_index;
+			neib_iter_init(&it, p, nptype, index, &posN, gridPos, cellStart, neibsList);
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 nN = oldPos[neib_index];
+				if (INACTIVE(nN)) continue;
+				const orc_f4 nNp1 = newPos[neib_index];
+				const float rx = it.pos_corr[0] - nN.x, ry = it.pos_corr[1] - nN.y, rz = it.pos_corr[2] - nN.z;
+				const float qx = (it.pos_corr[0] - nNp1.x) + dx, qy = (it.pos_corr[1] - nNp1.y) + dy, qz = (it.pos_corr[2] - nNp1.z) + dz;
+				const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+				sumPmwN -= nN.w*W_c(p->kerneltype, rN, slength, wcoeff, wsub);      /* no range test on the old distance, as the reference */
+				const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
+				if (rNp1 < p->influenceradius)
+					sumPmwNp1 += nN.w*W_c(p->kerneltype, rNp1, slength, wcoeff, wsub);
+			}
+		}
+		forces[index].w = sumPmwNp1 + sumPmwN + 0.0f;     /* + sumVmwDelta (open boundaries: none) */
+		/* computeDensitySumBoundaryTerms (:419-478) */
+		float gGamDotR = 0.0f;
+		v3 gGam = v3_make(0.0f, 0.0f, 0.0f);
+		{
+			neib_iter it;
+			uint32_t neib_index;
+			neib_iter_init(&it, p, PT_BOUNDARY, index, &posN, gridPos, cellStart, neibsList);
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 nN = oldPos[neib_index];
+				if (INACTIVE(nN)) continue;
+				const orc_f4 nNp1 = newPos[neib_index];
+				const float inv = 1.0f/slength;      /* float4 / float */
+				const v3 qN = v3_make((it.pos_corr[0] - nN.x)*inv, (it.pos_corr[1] - nN.y)*inv, (it.pos_corr[2] - nN.z)*inv);
+				const v3 qNp1 = v3_make(((it.pos_corr[0] - nNp1.x) + dx)*inv, ((it.pos_corr[1] - nNp1.y) + dy)*inv,
+					((it.pos_corr[2] - nNp1.z) + dz)*inv);
+				const orc_f4 be = boundelem[neib_index];
+				const v3 ns = v3_make(be.x, be.y, be.z);
+				v3 q_vb[3];
+				calc_vertex_rel_pos(q_vb, ns, vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+					vertPos2 + 2*(size_t)neib_index, slength);
+				const v3 gN = v3_scale(ns, grad_gamma_wendland(slength, qN, q_vb, ns));
+				const v3 gNp1 = v3_scale(ns, grad_gamma_wendland(slength, qNp1, q_vb, ns));
+				gGamDotR += 0.5f*v3_dot(v3_add(gN, gNp1), v3_sub(qNp1, qN));
+				gGam = v3_add(gGam, gNp1);
+			}
+			gGamDotR *= slength;
+		}
+		/* densitySumBoundaryDevice (:606-655) */
+		const orc_f4 gGamN = oldGGam[index];
+		orc_f4 g = { gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR };
+		const int fl = FLUID_NUM(info);
+		const float rho = (gGamN.w*physical_density(p, oldVel[index].w, fl) + forces[index].w)/g.w;
+		if (g.w > 1.0f || sqrtf(g.x*g.x + g.y*g.y + g.z*g.z)*slength < 1e-10f)
+			g.w = 1.0f;
+		else if (g.w < 0.1f)
+			g.w = 0.1f;
+		newVel[index].w = rho/p->rho0[fl] - 1.0f;          /* numerical_density */
+		newGGam[index] = g;
+	}
+}
+
+/* computeDensityDiffusionDevice<.., BREZZI, SA_BOUNDARY, PT_FLUID> (src/cuda/forces_kernel.def:4515-4560): the Brezzi term over
+ * the fluid neighbours (:1766-1783; boundary elements only contribute at pressure inlets), divided by gamma and rho0,
+ * written to forces.w; updateDensityDevice (src/cuda/euler_kernel.cu:116-136) then adds forces.w dt to the density */
+void orc_sa_density_diffusion(const orc_params *p, orc_f4 *forces, const orc_f4 *posArray, const orc_f4 *velArray,
+	const orc_f4 *gGamArray, const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart,
+	const uint16_t *neibsList, uint32_t particleRangeEnd, float dt)
+{
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, 2.0f);
+#pragma omp parallel for schedule(dynamic, 256)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!FLUID(info)) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		const orc_f4 vel = velArray[index];
+		const int fl = FLUID_NUM(info);
+		const float rho = physical_density(p, vel.w, fl);
+		const float pres = orc_P(p, vel.w, fl);
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		float DrDt = 0.0f;
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+			if (INACTIVE(npos)) continue;
+			if (r >= p->influenceradius) continue;
+			const orc_f4 nvel = velArray[neib_index];
+			const int nfl = FLUID_NUM(infoArray[neib_index]);
+			const float neib_rho = physical_density(p, nvel.w, nfl);
+			const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+			const float gdotr = p->gravity[0]*rx + p->gravity[1]*ry + p->gravity[2]*rz;
+			float nDrDt = 0.0f;
+			nDrDt += p->densityDiffCoeff*((2.0f/(rho + neib_rho))*(pres - orc_P(p, nvel.w, nfl)) - gdotr)*npos.w/neib_rho*f*dt*2.0f*rho;
+			DrDt += nDrDt;
+		}
+		DrDt /= gGamArray[index].w;
+		forces[index].w = DrDt/p->rho0[fl];
+	}
+}
+
+/* gamma part of dtreduce with dynamic gamma (src/cuda/forces.cu:576-585): dt_gamma = 0.001 / max(max CFL_gamma, 1e-5/dt) */
+float orc_sa_gamma_dt(float dt, float max_gamma_cfl)
+{
+	const float maxcfl = fmaxf(max_gamma_cfl, 1e-5f/dt);
+	const float dt_gam = 0.001f/maxcfl;
+	return dt_gam < dt ? dt_gam : dt;
 }

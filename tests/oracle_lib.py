@@ -66,6 +66,7 @@ def lib():
         _lib.orc_soundSpeed.restype = C.c_float; _lib.orc_soundSpeed.argtypes = [C.c_void_p, C.c_float, C.c_int]
         _lib.orc_forces.restype = C.c_uint32
         _lib.orc_forces_sa.restype = C.c_uint32
+        _lib.orc_sa_gamma_dt.restype = C.c_float; _lib.orc_sa_gamma_dt.argtypes = [C.c_float, C.c_float]
         _lib.orc_dtreduce.restype = C.c_float
         _lib.orc_dtreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float]
         _lib.orc_fmax_elements.restype = C.c_uint32; _lib.orc_fmax_elements.argtypes = [C.c_uint32]
@@ -240,10 +241,31 @@ class Oracle:
         forces = np.zeros((len(pos), 4), dtype=np.float32)
         nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
         cfl = np.zeros(nblk, dtype=np.float32)
-        nb = self.L.orc_forces_sa(C.byref(self.p), P(forces), P(cfl), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), P(ggam),
-                                  P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), C.c_uint32(n), C.c_uint32(0),
+        # BUFFER_CFL_GAMMA: one value per particle, then one per block from round_up(n, 4) on
+        self.cfl_gamma = np.zeros(((n + 3) // 4) * 4 + nblk, dtype=np.float32)
+        nb = self.L.orc_forces_sa(C.byref(self.p), P(forces), P(cfl), P(self.cfl_gamma), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl),
+                                  P(ggam), P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), C.c_uint32(n), C.c_uint32(0),
                                   C.c_uint32(n), C.c_uint32(0), C.c_float(deltap))
+        self.max_gamma_cfl = float(self.cfl_gamma[((n + 3) // 4) * 4:((n + 3) // 4) * 4 + int(nb)].max()) if nb else 0.0
         return forces, cfl, int(nb)
+
+    def sa_density_sum(self, new_vel, old_pos, new_pos, old_vel, old_ggam, boundelements, vertpos, info, hash_, cs, nl, n):
+        """density_sum of the integration engine: new_vel.w and gamma of the fluid from the old and new positions"""
+        v = new_vel.copy(); g = old_ggam.copy()
+        scratch = np.zeros((len(old_pos), 4), dtype=np.float32)
+        self.L.orc_sa_density_sum(C.byref(self.p), P(v), P(g), P(scratch), P(old_pos), P(new_pos), P(old_vel), P(old_ggam), P(boundelements),
+                                  P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n))
+        return v, g
+
+    def sa_density_diffusion(self, pos, vel, ggam, info, hash_, cs, nl, n, dt):
+        """compute_density_diffusion (Brezzi) + apply_density_diffusion: returns the updated velocity array"""
+        f = np.zeros((len(pos), 4), dtype=np.float32)
+        self.L.orc_sa_density_diffusion(C.byref(self.p), P(f), P(pos), P(vel), P(ggam), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n),
+                                        C.c_float(dt))
+        v = vel.copy()
+        fluid = (info[:n, 0] & 7) == 0
+        v[:n][fluid, 3] = v[:n][fluid, 3] + f[:n][fluid, 3] * np.float32(dt)
+        return v, f
 
     def sa_integrate_gamma(self, old_ggam, new_pos, boundelements, vertpos, info, hash_, cs, nl, n, epsilon=5e-5):
         """integrate_gamma with ENABLE_GAMMA_QUADRATURE: fluid rows by quadrature, the rest copied"""

@@ -93,20 +93,41 @@ class OracleSaSim:
         vel, gg = o.sa_segment_bc(pos, vel, gg, self.vertices, self.be, self.info, self.hash, self.cs, self.nl, n, step=step)
         return o.sa_vertex_bc(pos, vel, gg, self.info, self.hash, self.cs, self.nl, n), gg
 
+    def _dt(self, cfl, nb):
+        dt = self.o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        sf = self.problem.simparams.simflags
+        if not (sf & D.ENABLE_GAMMA_QUADRATURE):          # dynamic gamma: its own CFL condition (src/cuda/forces.cu:576-585)
+            dt = min(dt, float(self.o.L.orc_sa_gamma_dt(np.float32(dt), np.float32(self.o.max_gamma_cfl))))
+        return dt
+
+    def _post_euler(self, ps, vs, hdt):
+        """what follows EULER on the new state (PredictorCorrectorIntegrator.cc:607-684): density summation (+ Brezzi diffusion)
+        or, with the continuity equation, the gamma integration; always from the gamma / density of step n"""
+        o, n = self.o, self.n
+        sp = self.problem.simparams
+        if sp.simflags & D.ENABLE_DENSITY_SUM:
+            vs, gs = o.sa_density_sum(vs, self.pos, ps, self.vel, self.gg, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
+            if sp.densitydiffusiontype == D.BREZZI:
+                vs, _ = o.sa_density_diffusion(ps, vs, gs, self.info, self.hash, self.cs, self.nl, n, hdt)
+        else:
+            gs = o.sa_integrate_gamma(self.gg, ps, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
+        return vs, gs
+
     def step(self):
         """no neighbour rebuild here: the runs compared are shorter than buildneibsfreq"""
         o, n, p = self.o, self.n, self.problem
         dp = p.m_deltap
         dt = float(np.float32(self.dt))
+        hdt = float(np.float32(dt) / np.float32(2))
         f1, cfl, nb = o.forces_sa(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, self.gg, self.be, self.vertpos, n, dp)
-        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
-        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1)
-        gs = o.sa_integrate_gamma(self.gg, ps, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
+        dt1 = self._dt(cfl, nb)
+        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, hdt, 1)
+        vs, gs = self._post_euler(ps, vs, hdt)
         vs, gs = self._bc(ps, vs, gs, 1)
         f2, cfl, nb = o.forces_sa(ps, vs, self.info, self.hash, self.cs, self.nl, gs, self.be, self.vertpos, n, dp)
-        dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        dt2 = self._dt(cfl, nb)
         pn, vn = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
-        gn = o.sa_integrate_gamma(self.gg, pn, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
+        vn, gn = self._post_euler(pn, vn, dt)
         vn, gn = self._bc(pn, vn, gn, 2)
         self.forces = f2
         self.pos, self.vel, self.gg = pn, vn, gn

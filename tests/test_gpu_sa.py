@@ -116,8 +116,11 @@ def test_later_steps_and_repacking_mode(pair):
 def test_what_is_not_built_says_so(pair):
     from gpusph_amd import capi
     st, eng = pair
-    with pytest.raises(capi.SphxUnsupported, match="density summation"):      # StillWaterSA's option set: ENABLE_DENSITY_SUM
-        eng.step()
+    io = SABox(deltap=0.05)
+    io.simparams.simflags |= D.ENABLE_INLET_OUTLET                        # open boundaries: not built
+    eio = _engine(io)
+    with pytest.raises(capi.SphxUnsupported, match="open boundaries"):
+        eio.step()
     # and the boundary-conditions engine refuses a framework without SA_BOUNDARY, like the reference's SFINAE'd implementation
     other = _engine(DamBreak3D(deltap=0.05, obstacle=False))
     other.build_neibs()
@@ -210,17 +213,19 @@ def test_sa_forces_gamma_integration_and_trajectory():
     assert abs(eng2.current_dt() - sim.dt) < 1e-5 * sim.dt and abs(eng2.time() - sim.t) < 1e-6 * sim.t
 
 
-def test_cpp_adapters_step_an_sa_problem(tmp_path):
-    """Four predictor-corrector steps of the SA sequence through the abstract interfaces of the GPUSPH tree (forces, Euler,
-    integrate_gamma, boundary conditions; framework from StillWaterRepackSA's SETUP_FRAMEWORK): bit-equal to the Python driver."""
+@pytest.mark.parametrize("options", ["StillWaterRepackSA", "StillWaterSA"])
+def test_cpp_adapters_step_an_sa_problem(tmp_path, options):
+    """Four predictor-corrector steps of the SA sequence through the abstract interfaces of the GPUSPH tree, framework from the
+    problem's own SETUP_FRAMEWORK: forces, dtreduce (with the gamma condition), Euler, then integrate_gamma (StillWaterRepackSA)
+    or density_sum + compute_/apply_density_diffusion (StillWaterSA), boundary conditions: bit-equal to the Python driver."""
     import subprocess
     import host_case as hc
-    kw = dict(deltap=0.05, jitter=0.1, options="StillWaterRepackSA")
+    kw = dict(deltap=0.05, jitter=0.1, options=options)
     prob = SABox(**kw)
     eng = _engine(prob)
     n = prob.num_particles
     case = tmp_path / "case.txt"
-    case.write_text("\n".join(hc.case_lines(prob, "StillWaterRepackSA", allocated=eng.alloc) + hc.driver_lines(prob, eng, 4)) + "\n")
+    case.write_text("\n".join(hc.case_lines(prob, options, allocated=eng.alloc) + hc.driver_lines(prob, eng, 4)) + "\n")
     hc.write_state(str(tmp_path / "state.bin"), prob.copy_to_array())
     subprocess.check_call([hc.exe("example_engines"), str(case), str(tmp_path / "state.bin"), str(tmp_path / "out.bin")])
     out = hc.read_out(str(tmp_path / "out.bin"))
@@ -231,3 +236,72 @@ def test_cpp_adapters_step_an_sa_problem(tmp_path):
     assert np.float32(out["dt"]) == np.float32(eng.current_dt()) and abs(out["t"] - eng.time()) < 1e-12
     t = info_type(out["info"])
     assert np.abs(out["vel"][t == D.PT_FLUID, :3]).max() > 0            # it did move
+
+
+def test_density_summation_form_on_the_gpu():
+    """StillWaterSA's own option set -- density summation, dynamic gamma with its CFL condition, Brezzi diffusion: the three
+    engines' calls one by one on identical inputs, then six steps of the whole sequence, against the CPU oracle."""
+    from sa_helpers import OracleSaSim
+    import torch
+    kw = dict(deltap=0.05, jitter=0.15, options="StillWaterSA")
+    sim = OracleSaSim(SABox(**kw))
+    eng = _engine(SABox(**kw), clobber_neibslist=True)
+    eng.build_neibs()
+    eng.sa_boundary_conditions(0)
+    n, o, k = sim.n, sim.o, eng.k
+    t = info_type(sim.info)
+    fl = np.where(t == D.PT_FLUID)[0]
+    rng = np.random.default_rng(11)
+    vel = sim.vel.copy()
+    vel[fl, :3] = (2.0 * rng.standard_normal((len(fl), 3))).astype(np.float32)           # moving fluid: a gamma CFL to speak of
+    for name, arr in (("vel", vel), ("gradgamma", sim.gg), ("boundelements", sim.be)):
+        getattr(eng, name)[:n] = torch.from_numpy(arr).to(eng.device)
+    f, cfl, nb = o.forces_sa(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, sim.gg, sim.be, sim.vertpos, n, sim.problem.m_deltap)
+    k.memset(eng.cfl, 0)
+    gnb = k.forces_sa(eng.forces, eng.cfl, eng.pos, eng.vel, eng.info, eng.hash, eng.cellStart, eng.neibslist, eng.gradgamma,
+                      eng.boundelements, eng.vertpos, n, 0, n, 0, cfl_gamma=eng.cfl_gamma)
+    assert gnb == nb
+    gf = _np(eng.forces)[:n]
+    assert np.abs(gf[fl, :3] - f[fl, :3]).max() < 1e-4 * np.abs(f[fl, :3]).max() and not gf[fl, 3].any() and not f[fl, 3].any()
+    n4 = (n + 3) // 4 * 4
+    gcg = _np(eng.cfl_gamma)
+    assert o.max_gamma_cfl > 0.1
+    gscale = o.cfl_gamma[:n].max()
+    assert np.abs(gcg[:n] - o.cfl_gamma[:n]).max() < 1e-4 * gscale and np.abs(gcg[n4:n4 + nb] - o.cfl_gamma[n4:n4 + nb]).max() < 1e-4 * gscale
+    # dt with the gamma condition
+    dt_ref = min(o.dtreduce(cfl, nb, sim.sspeed_cfl, sim.max_kinvisc), 1e9)
+    dt_ref = min(dt_ref, float(o.L.orc_sa_gamma_dt(np.float32(dt_ref), np.float32(o.max_gamma_cfl))))
+    k.dtreduce(eng.cfl, eng.cfl_temp, nb, eng.d_dt_next, 0)
+    k.dtreduce_gamma(eng.cfl_gamma, n, nb, eng.d_dt_next)
+    assert abs(float(eng.d_dt_next.item()) - dt_ref) < 1e-4 * dt_ref and dt_ref < 0.9 * o.dtreduce(cfl, nb, sim.sspeed_cfl, sim.max_kinvisc)
+    # density summation between the state and a displaced copy; Brezzi diffusion on the result
+    newpos = sim.pos.copy()
+    newpos[fl, :3] += (0.05 * sim.problem.m_deltap * rng.standard_normal((len(fl), 3))).astype(np.float32)
+    v1, g1 = o.sa_density_sum(vel, sim.pos, newpos, vel, sim.gg, sim.be, sim.vertpos, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng.pos2[:n] = torch.from_numpy(newpos).to(eng.device)
+    eng.vel2[:n] = torch.from_numpy(vel).to(eng.device)
+    k.sa_density_sum(eng.vel2, eng.gradgamma2, eng.forces, eng.pos, eng.pos2, eng.vel, eng.gradgamma, eng.boundelements, eng.vertpos,
+                     eng.info, eng.hash, eng.cellStart, eng.neibslist, n, n)
+    gv1, gg1 = _np(eng.vel2)[:n], _np(eng.gradgamma2)[:n]
+    assert np.abs(gv1[:, 3] - v1[:, 3]).max() < 2e-6 and np.array_equal(_bits(gv1[:, :3]), _bits(v1[:, :3]))
+    assert np.abs(gg1[fl, 3] - g1[fl, 3]).max() < 5e-6 and np.abs(gg1[fl, :3] - g1[fl, :3]).max() < 5e-5 * np.abs(g1[fl, :3]).max()
+    assert np.array_equal(_bits(gg1[t != D.PT_FLUID]), _bits(sim.gg[t != D.PT_FLUID]))
+    dt = 3.0e-4
+    v2, fd = o.sa_density_diffusion(newpos, v1, g1, sim.info, sim.hash, sim.cs, sim.nl, n, dt)
+    eng.vel2[:n] = torch.from_numpy(v1).to(eng.device); eng.gradgamma2[:n] = torch.from_numpy(g1).to(eng.device)
+    k.sa_density_diffusion(eng.forces, eng.pos2, eng.vel2, eng.gradgamma2, eng.info, eng.hash, eng.cellStart, eng.neibslist, n, n, dt)
+    gfd, gv2 = _np(eng.forces)[:n], _np(eng.vel2)[:n]
+    assert np.abs(fd[fl, 3]).max() > 0 and np.abs(gfd[fl, 3] - fd[fl, 3]).max() < 1e-4 * np.abs(fd[fl, 3]).max()
+    assert np.abs(gv2[:, 3] - v2[:, 3]).max() < 2e-7
+    # six steps of the full sequence
+    sim2 = OracleSaSim(SABox(**kw))
+    eng2 = _engine(SABox(**kw))
+    for _ in range(6):
+        sim2.step(); eng2.step()
+    gp, gv, ggg = _np(eng2.pos)[:n], _np(eng2.vel)[:n], _np(eng2.gradgamma)[:n]
+    cell = float(np.min(sim2.problem.m_cellsize))
+    assert np.abs(gp[:, :3] - sim2.pos[:, :3]).max() < 6e-6 * cell
+    assert np.abs(gv[:, :3] - sim2.vel[:, :3]).max() < 1e-3 * max(np.abs(sim2.vel[:, :3]).max(), 1e-3)
+    assert np.abs(gv[:, 3] - sim2.vel[:, 3]).max() < 2e-6
+    assert np.abs(ggg[fl, 3] - sim2.gg[fl, 3]).max() < 2e-5
+    assert abs(eng2.current_dt() - sim2.dt) < 1e-5 * sim2.dt and abs(eng2.time() - sim2.t) < 1e-6 * sim2.t
