@@ -161,8 +161,12 @@ class TimestepEngine(MultiGpuEngine):
         vort = self.postprocess(D.VORTICITY).cpu().numpy() if vorticity else None
         nrm = self.postprocess(D.SURFACE_DETECTION, normals=True).cpu().numpy() if surface else None
         st = self.download()
+        sa = {}
+        if self.sa:      # SA_BOUNDARY: gamma with its gradient and the vertex ids of the segments (VTKWriter.cc:669-672,743-745)
+            n = self.n
+            sa = dict(gradgamma=self.gradgamma[:n].cpu().numpy(), vertices=self.vertices[:n].cpu().numpy().view(np.uint32))
         vtkwriter.write_vtp(path, self.problem, dict(pos=st["pos"], vel=st["vel"], info=st["info"].reshape(-1, 4), hash=st["hash"]),
-                            vorticity=vort, normals=nrm, forces=st["forces"] if forces else None)
+                            vorticity=vort, normals=nrm, forces=st["forces"] if forces else None, **sa)
 
     # ------------------------------------------------------------------ checkpoints (GPUSPH HotFile v1)
     def _host_buffer_count(self):

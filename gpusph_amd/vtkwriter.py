@@ -3,8 +3,8 @@
 
   Points    Position   Float64 x3 (global coordinates, the writer's double4 BUFFER_POS_GLOBAL)
   PointData Pressure (test points keep the sampled pressure), Velocity, Density (physical; NaN for test points),
-            Mass, Part type, Part flags (shifted down by PART_FLAG_SHIFT), [Fluid number], [Part object], Part id,
-            CellIndex, [Vorticity], [Normals + Criteria], [Spatial acceleration + Continuity derivative]
+            Mass, [Gradient Gamma + Gamma], Part type, Part flags (shifted down by PART_FLAG_SHIFT), [Fluid number],
+            [Part object], Part id, [Vertices], CellIndex, [Vorticity], [Normals + Criteria], [Spatial acceleration + Continuity derivative]
   Verts     connectivity, offsets
 Existing ParaView states / scripts written for GPUSPH output read these files unchanged.
 """
@@ -16,7 +16,7 @@ _TYPES = {np.dtype(np.uint8): "UInt8", np.dtype(np.uint16): "UInt16", np.dtype(n
           np.dtype(np.float32): "Float32", np.dtype(np.float64): "Float64"}
 
 
-def particle_arrays(problem, state, vorticity=None, normals=None, forces=None):
+def particle_arrays(problem, state, vorticity=None, normals=None, forces=None, gradgamma=None, vertices=None):
     """the (name, array) list in the reference's order; `state` = dict pos/vel/info/hash (cell-local pos)"""
     pos, vel = state["pos"], state["vel"]
     info = np.asarray(state["info"]).reshape(-1, 4)
@@ -37,13 +37,18 @@ def particle_arrays(problem, state, vorticity=None, normals=None, forces=None):
         out += [("Spatial acceleration", np.ascontiguousarray(forces[:, :3], dtype=np.float32)),
                 ("Continuity derivative", np.ascontiguousarray(forces[:, 3], dtype=np.float32))]
     out += [("Pressure", pressure), ("Velocity", np.ascontiguousarray(vel[:, :3], dtype=np.float32)), ("Density", density),
-            ("Mass", pos[:, 3].astype(np.float32)), ("Part type", ptype),
-            ("Part flags", ((info[:, 0] >> 3) & 0xFF).astype(np.uint8))]
+            ("Mass", pos[:, 3].astype(np.float32))]
+    if gradgamma is not None:      # SA_BOUNDARY (VTKWriter.cc:669-672)
+        out += [("Gradient Gamma", np.ascontiguousarray(gradgamma[:, :3], dtype=np.float32)),
+                ("Gamma", np.ascontiguousarray(gradgamma[:, 3], dtype=np.float32))]
+    out += [("Part type", ptype), ("Part flags", ((info[:, 0] >> 3) & 0xFF).astype(np.uint8))]
     if pp.numFluids() > 1:
         out.append(("Fluid number", fl.astype(np.uint8)))
     if problem.simparams.numbodies > 0:
         out.append(("Part object", (info[:, 1] & 0xFFF).astype(np.uint8)))
     out.append(("Part id", (info[:, 2].astype(np.uint32) | (info[:, 3].astype(np.uint32) << 16))))
+    if vertices is not None:       # SA_BOUNDARY: vertexinfo = uint4 (VTKWriter.cc:743-745)
+        out.append(("Vertices", np.ascontiguousarray(vertices, dtype=np.uint32).reshape(-1, 4)))
     out.append(("CellIndex", (np.asarray(state["hash"]).astype(np.uint32) & np.uint32(D.CELLTYPE_BITMASK))))
     if vorticity is not None:
         out.append(("Vorticity", np.ascontiguousarray(vorticity, dtype=np.float32)))
