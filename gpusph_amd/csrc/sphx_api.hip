@@ -250,6 +250,7 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	d.partsurf = (sp->partsurf == 0.0f) ? sp->r0*sp->r0 : sp->partsurf;
 	// MK_BOUNDARY shares every code path of LJ_BOUNDARY (lists, sections, feedback bodies, Euler) but the force law
 	d.MK_K = sp->MK_K; d.MK_d = sp->MK_d; d.MK_beta = sp->MK_beta;
+	d.epsinterface = sp->epsinterface;
 	d.mk_mask = (sp->boundarytype == SPHX_MK_BOUNDARY) ? 0xFFFFFFFFu : 0u;
 	if (sp->boundarytype == SPHX_MK_BOUNDARY) d.boundarytype = SPHX_LJ_BOUNDARY;
 	ctx->have_params = true;

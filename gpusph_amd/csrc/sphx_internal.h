@@ -77,6 +77,7 @@ struct DevParams {
 	int      compvisc, avgop, is_const_visc; // FullViscSpec (src/visc_spec.h:255-312)
 	float    partsurf;                       // d_partsurf: wall friction of planes
 	float    MK_K, MK_d, MK_beta;            // Monaghan-Kajtar repulsion
+	float    epsinterface;                   // SPH_GRENIER interface term
 	uint32_t mk_mask;                        // all ones when the repulsive boundary model is MK (boundarytype then reads LJ)
 	uint32_t numplanes;                       // geometric planes (src/planes.h:43-47, MAX_PLANES src/particledefine.h:325)
 	float    plane_normal[SPHX_MAX_PLANES][3];

@@ -170,6 +170,7 @@ public:
 		p.repack_a = sp->repack_a; p.repack_alpha = sp->repack_alpha;
 		p.partsurf = pp->partsurf;
 		p.MK_K = pp->MK_K; p.MK_d = pp->MK_d; p.MK_beta = pp->MK_beta;
+		p.epsinterface = pp->epsinterface;
 	}
 
 	void upload(const SimParams *sp, const PhysParams *pp, float3 const& worldOrigin, uint3 const& gridSize,
@@ -327,6 +328,7 @@ public:
 		physparams->gravity = make_float3(p.gravity[0], p.gravity[1], p.gravity[2]);
 		physparams->dcoeff = p.dcoeff; physparams->p1coeff = p.p1coeff; physparams->p2coeff = p.p2coeff;
 		physparams->MK_K = p.MK_K; physparams->MK_d = p.MK_d; physparams->MK_beta = p.MK_beta;
+		physparams->epsinterface = p.epsinterface;
 		physparams->r0 = p.r0; physparams->epsartvisc = p.epsartvisc;
 	}
 

@@ -226,6 +226,7 @@ static void configure_params(Case const& c, SimParams *sp, ProblemPhysParams &pp
 	pp.smagfactor = (float)num(c, "smagfactor"); pp.kspsfactor = (float)num(c, "kspsfactor");
 	pp.MK_K = (float)num(c, "MK_K"); pp.MK_d = (float)num(c, "MK_d"); pp.MK_beta = (float)num(c, "MK_beta");
 	pp.partsurf = (float)num(c, "partsurf");
+	if (c.count("epsinterface")) pp.epsinterface = (float)num(c, "epsinterface");
 	pp.epsxsph = (float)num(c, "epsxsph");
 	// GPUSPH::setViscosityCoefficient (src/GPUSPH.cc:1481-1508), which runs between problem set-up and uploadConstants
 	for (size_t f = 0; f < pp.numFluids(); ++f)

@@ -30,6 +30,7 @@ class SphxParams(C.Structure):
         ("repack_a", C.c_float), ("repack_alpha", C.c_float),
         ("is_const_visc", C.c_int32), ("partsurf", C.c_float),
         ("MK_K", C.c_float), ("MK_d", C.c_float), ("MK_beta", C.c_float),
+        ("epsinterface", C.c_float),
     ]
 
 
@@ -48,6 +49,7 @@ class PhysParams:
     MK_K: float = float("nan")                             # physparams.h:336-338,405-407
     MK_d: float = float("nan")
     MK_beta: float = 2.0
+    epsinterface: float = float("nan")                     # physparams.h; ProblemCore.cc:165-166 -> 0.05 for SPH_GRENIER
     gravity: tuple = (0.0, 0.0, -9.81)
     artvisccoeff: float = 0.3          # physparams.h:392
     epsartvisc: float = float("nan")   # defaulted to 0.01 h^2 in ProblemCore.cc:160-163
@@ -224,4 +226,5 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
     p.is_const_visc = 1 if const else 0
     p.partsurf = f32(pp.partsurf)
     p.MK_K = nz(pp.MK_K); p.MK_d = nz(pp.MK_d); p.MK_beta = nz(pp.MK_beta)
+    p.epsinterface = nz(pp.epsinterface)
     return p

@@ -173,6 +173,8 @@ class Problem:
             pp.dcoeff = float(np.float32(np.float32(5.0) * np.float32(g) * self.m_maxFall))
         if math.isnan(pp.epsartvisc):   # ProblemCore.cc:160-163
             pp.epsartvisc = float(np.float32(0.01 * sp.slength * sp.slength))
+        if sp.sph_formulation == D.SPH_GRENIER and math.isnan(pp.epsinterface):   # ProblemCore.cc:165-166
+            pp.epsinterface = 0.05
         if sp.densitydiffusiontype == D.COLAGROSSI:  # ProblemCore.cc:1406-1416
             if math.isnan(sp.densityDiffCoeff):
                 sp.densityDiffCoeff = float(np.float32(0.1))
@@ -272,6 +274,8 @@ class DamBreak3D(Problem):
             self.LAYERS = 1
         self.set_viscosity(viscosity)       # DamBreak3D.cu:54 viscosity<ARTVISC>
         sp.sph_formulation = formulation
+        if formulation == D.SPH_GRENIER and (viscosity is None or isinstance(viscosity, str)):
+            sp.avgop = D.HARMONIC           # legacy viscosity names average harmonically with Grenier (cudasimframework.cu:202-210)
         sp.densitydiffusiontype = density_diffusion
         sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | \
             (D.ENABLE_PLANES if walls == "planes" else 0) | (D.ENABLE_MULTIFLUID if two_fluids else 0)

@@ -116,6 +116,9 @@ typedef struct sphx_params {
 	float    partsurf;
 	/* Monaghan-Kajtar boundary repulsion (src/physparams.h:336-338) */
 	float    MK_K, MK_d, MK_beta;
+	/* SPH_GRENIER: interface pressure coefficient between different fluids (src/physparams.h epsinterface,
+	 * src/ProblemCore.cc:165-166 default 0.05; d_epsinterface src/cuda/forces_kernel.def:2237) */
+	float    epsinterface;
 } sphx_params;
 
 /* TimingInfo fields filled by getinfo (src/timing.h:43-100, src/cuda/buildneibs.cu:137-145) */

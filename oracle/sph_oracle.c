@@ -197,6 +197,7 @@ static inline float physical_density(const orc_params *p, float rho_tilde, int i
 {
 	return (rho_tilde + 1.0f)*p->rho0[i];
 }
+static inline float numerical_density(const orc_params *p, float rho, int i) { return rho/p->rho0[i] - 1.0f; }
 /* exported for the pin against src/vector_math.h:1093-1097 (tests/test_oracle_pinned.py) */
 void orc_f4_div(const float v[4], float s, float out[4])
 {
@@ -521,7 +522,7 @@ static void neibs_in_cell(const orc_params *p, uint16_t *neibsList,
 		/* ViscSpec::rheologytype != GRANULAR always here */
 		if ((p->boundarytype == ORC_LJ_BOUNDARY || p->boundarytype == ORC_MK_BOUNDARY) && boundary && BOUNDARY(neib_info))
 			continue;   /* src/cuda/buildneibs_kernel.cu:1061 */
-		if (p->boundarytype == ORC_DYN_BOUNDARY /* && formulation != GRENIER */) {
+		if (p->boundarytype == ORC_DYN_BOUNDARY && p->sph_formulation != ORC_SPH_GRENIER) {   /* :598 */
 			if (boundary && BOUNDARY(neib_info))
 				continue;
 		}
@@ -1017,7 +1018,8 @@ static inline void plane_friction(const orc_params *p, orc_f4 *force, const orc_
 static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	orc_f4 *rbforces, orc_f4 *rbtorques,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
-	uint32_t fromParticle, uint32_t toParticle, uint32_t numBlocks, uint32_t cflOffset, const sa_forces_ctx *sa)
+	uint32_t fromParticle, uint32_t toParticle, uint32_t numBlocks, uint32_t cflOffset, const sa_forces_ctx *sa,
+	const float *sigma)
 {
 	const int dtadapt = !!(p->simflags & ORC_ENABLE_DTADAPT);
 #pragma omp parallel for schedule(static)
@@ -1035,7 +1037,11 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 
 			/* forces_fixup: non-SA, non-Grenier :3212-3218; SA_BOUNDARY :3192-3210 (fluid particles only: the sums are
 			 * renormalised by gamma) */
-			if (!sa)
+			if (sigma) {     /* SPH_GRENIER :3181-3190: DvDt was summed without 1/rho, DJ/Dt without 1/sigma; every particle */
+				const float rho = physical_density(p, vel.w, fl);
+				force.x /= rho; force.y /= rho; force.z /= rho;
+				force.w /= sigma[index];
+			} else if (!sa)
 				force.w /= p->rho0[fl];
 			else if (FLUID(info)) {
 				const float gam = sa->gGam[index].w;
@@ -1120,7 +1126,7 @@ uint32_t orc_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	if (compute_object_forces || p->boundarytype == ORC_DYN_BOUNDARY)
 		forces_pass(p, PT_BOUNDARY, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL);
 	finalize_forces(p, forces, cfl, rbforces, rbtorques, pos, vel, info, hash,
-		fromParticle, toParticle, numBlocks, cflOffset, NULL);
+		fromParticle, toParticle, numBlocks, cflOffset, NULL, NULL);
 	return numBlocks;
 }
 
@@ -1142,7 +1148,7 @@ uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *c
 	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
 	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
 	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
-	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, &sa);
+	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, &sa, NULL);
 	if (gcfl) {      /* per-block maxima behind the per-particle values */
 		float *blocks = cflGamma + round_up(numParticles, 4u) + cflOffset;
 		for (uint32_t b = 0; b < numBlocks; ++b) {
@@ -1154,6 +1160,172 @@ uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *c
 			blocks[b] = m;
 		}
 	}
+	return numBlocks;
+}
+
+/* ==== SPH_GRENIER (multi-fluid volume formulation; the options of the reference's Bubble, LockExchange, RTInstability and
+ * OilJet problems: formulation<SPH_GRENIER>, viscosity<DYNAMICVISC>, boundary<DYN_BOUNDARY>).
+ *   - densityGrenierDevice (src/cuda/forces_kernel.cu:284-398), run before each forces pass (COMPUTE_DENSITY,
+ *     src/integrators/PredictorCorrectorIntegrator.cc:443-458): sigma_a = sum_b W_ab over every neighbour, the density
+ *     rho_a = (sum m_b W_ab / sum W_ab)/omega_a over the neighbours of the same type and fluid, written into vel.w in place;
+ *   - forces: the continuity equation gives D(log J)/Dt = -1/sigma_a sum_b (v_ab . r_ab) F_ab (mass_continuity_div_vel_term
+ *     :2018-2028), the momentum equation -1/rho_a sum_b (P_a/sigma_a + P_b/sigma_b [+ eps (|.|+|.|) across an interface]) F_ab r_ab
+ *     (precalc_pressure :445-455, apply_pseudo_surface_tension :2226-2238, compute_pressure_contrib :2383-2392) and the
+ *     Morris viscous term with avg(mu_a, mu_b) (1/sigma_a + 1/sigma_b) F_ab v_ab (:2628-2646); the divisions by rho_a and
+ *     sigma_a are the fixup of the finalize kernel (:3181-3190);
+ *   - Euler integrates vol.y = log(omega/omega_0) and writes omega = exp(vol.y) omega_0 (euler_body above);
+ *   - ProblemCore::init_volume (src/ProblemCore.cc:1586-1606). */
+void orc_init_volume(const orc_params *p, orc_f4 *vol, const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, uint32_t numParticles)
+{
+	for (uint32_t i = 0; i < numParticles; ++i) {
+		orc_f4 v;
+		v.x = v.w = pos[i].w/physical_density(p, vel[i].w, FLUID_NUM(info[i]));
+		v.y = 0; v.z = 0;
+		vol[i] = v;
+	}
+}
+
+void orc_density_grenier(const orc_params *p, float *sigmaArray, orc_f4 *velArray,
+	const orc_f4 *posArray, const orc_info *infoArray, const uint32_t *hashArray, const orc_f4 *volArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, int maxFluidBoundaryNeibs)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const int dyn = p->boundarytype == ORC_DYN_BOUNDARY;
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		if (!dyn && !FLUID(info)) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		const int fnum = FLUID_NUM(info);
+		const float vol = volArray[index].w;
+		orc_f4 vel = velArray[index];
+		float corr = W_c(p->kerneltype, 0.0f, p->slength, wcoeff, wsub);   /* self contribution */
+		float sigma = corr;
+		float mass_corr = pos.w*corr;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		int has_fluid_neibs = 0;
+		const int last = dyn ? PT_BOUNDARY : PT_FLUID;
+		for (int ptype = PT_FLUID; ptype <= last; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				const orc_info neib_info = infoArray[neib_index];
+				const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+				if (!isfinite(npos.w) || r >= p->influenceradius) continue;
+				const float w = W_c(p->kerneltype, r, p->slength, wcoeff, wsub);
+				sigma += w;
+				if (FLUID(neib_info)) has_fluid_neibs = 1;
+				if ((!dyn || PART_TYPE(neib_info) == PART_TYPE(info)) && FLUID_NUM(neib_info) == fnum) {
+					mass_corr += npos.w*w;
+					corr += w;
+				}
+			}
+		}
+		if (dyn && !FLUID(info) && !has_fluid_neibs) {
+			/* 'typical' specific volume: the largest fluid + boundary neighbour count of the last list build over the
+			 * volume of the influence sphere, 3*int/(4*M_PIf*R*R*R) */
+			const float R = p->influenceradius;
+			sigma = (float)(3*maxFluidBoundaryNeibs)/(4*3.14159265358979323846f*R*R*R);
+		}
+		vel.w = mass_corr/(corr*vol);
+		vel.w = numerical_density(p, vel.w, fnum);
+		velArray[index] = vel;
+		sigmaArray[index] = sigma;
+	}
+}
+
+static void grenier_pass(const orc_params *p, int cptype, int nptype, orc_f4 *forces,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *sigmaArray,
+	uint32_t fromParticle, uint32_t toParticle)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
+	const int dyn = p->boundarytype == ORC_DYN_BOUNDARY;
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = fromParticle; index < toParticle; ++index) {
+		const orc_info info = infoArray[index];
+		if (PART_TYPE(info) != cptype) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const orc_f4 vel = velArray[index];
+		const int p_fluid = FLUID_NUM(info);
+		const float p_rho = physical_density(p, vel.w, p_fluid);
+		const float p_sigma = sigmaArray[index];
+		const float p_precalc = orc_P(p, vel.w, p_fluid)/p_sigma;
+		orc_f4 force = forces[index];
+		neib_iter it;
+		neib_iter_init(&it, p, nptype, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			if (!isfinite(npos.w)) continue;
+			const float r = sqrtf(sqlength3(rx, ry, rz));
+			if (r >= p->influenceradius) continue;
+			const orc_info neib_info = infoArray[neib_index];
+			const orc_f4 nvel = velArray[neib_index];
+			const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+			const float vel_dot_pos = dot3(vx, vy, vz, rx, ry, rz);
+			const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+			const int n_fluid = FLUID_NUM(neib_info);
+			const float n_rho = physical_density(p, nvel.w, n_fluid);
+			const float n_sigma = sigmaArray[neib_index];
+			const float n_precalc = orc_P(p, nvel.w, n_fluid)/n_sigma;
+			const int all_pp = (cptype == PT_FLUID && nptype == PT_FLUID) || (cptype == PT_FLUID && nptype == PT_BOUNDARY && dyn);
+			const int dyn_bf = (cptype == PT_BOUNDARY && nptype == PT_FLUID && dyn);
+			if (!all_pp && !dyn_bf) continue;
+			float DrDt = 0.0f;
+			DrDt -= vel_dot_pos*f;
+			force.w += DrDt;
+			if (all_pp || COMPUTE_FORCE(info)) {
+				float pGradTerm = p_precalc + n_precalc;
+				if (cptype == PT_FLUID && nptype == PT_FLUID && p_fluid != n_fluid)
+					pGradTerm += p->epsinterface*(fabsf(p_precalc) + fabsf(n_precalc));
+				const float s = pGradTerm*f;
+				float DvDt[3] = { 0.0f, 0.0f, 0.0f };
+				DvDt[0] -= s*rx; DvDt[1] -= s*ry; DvDt[2] -= s*rz;
+				if (p->rheologytype == ORC_NEWTONIAN) {
+					const float our_mu = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[p_fluid]*p_rho : p->visccoeff[p_fluid];
+					const float neib_mu = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[n_fluid]*n_rho : p->visccoeff[n_fluid];
+					float avg_mu;
+					switch (p->avgop) {           /* average<>, src/average.h:78-100 */
+					case ORC_ARITHMETIC: avg_mu = (our_mu + neib_mu)*0.5f; break;
+					case ORC_HARMONIC:   avg_mu = 2*our_mu*neib_mu/(our_mu + neib_mu); break;
+					default:             avg_mu = sqrtf(our_mu*neib_mu);
+					}
+					const float avg_sigma = 1/p_sigma + 1/n_sigma;
+					const float c = avg_mu*avg_sigma*f;
+					DvDt[0] += c*vx; DvDt[1] += c*vy; DvDt[2] += c*vz;
+				}
+				force.x += DvDt[0]; force.y += DvDt[1]; force.z += DvDt[2];
+			}
+		}
+		forces[index] = force;
+	}
+}
+
+/* run_forces with SPH_GRENIER + DYN_BOUNDARY: fluid <- fluid, fluid <- boundary, boundary <- fluid, finalize */
+uint32_t orc_forces_grenier(const orc_params *p, orc_f4 *forces, float *cfl,
+	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *sigma,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset)
+{
+	(void)numParticles;
+	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
+	grenier_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, sigma, fromParticle, toParticle);
+	grenier_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, sigma, fromParticle, toParticle);
+	if (p->boundarytype == ORC_DYN_BOUNDARY)
+		grenier_pass(p, PT_BOUNDARY, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, sigma, fromParticle, toParticle);
+	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, NULL, sigma);
 	return numBlocks;
 }
 
@@ -1349,8 +1521,11 @@ void orc_sps(const orc_params *p, float *tau, float *turbvisc,
 static void euler_body(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 	const orc_f4 *oldPos, const orc_f4 *oldVel, const orc_info *infoArray, const uint32_t *hashArray,
 	const orc_f4 *forces, const orc_f4 *xsph,
-	uint32_t numParticles, float dt, int step, int repacking)
+	uint32_t numParticles, float dt, int step, int repacking, orc_f4 *newVol, const orc_f4 *oldVol)
 {
+	/* SPH_GRENIER: the continuity equation integrates the log of the volume ratio (continuity_integration :210-216,
+	 * grenier_particle_data :84-92, write_volume :281-289) */
+	const int grenier = p->sph_formulation == ORC_SPH_GRENIER && !repacking && newVol && oldVol;
 	/* euler_repack_params (src/cuda/euler_params.h:203): no boundary integration, no continuity, no XSPH, no body motion */
 	const int integrateBoundary = !repacking &&
 		(p->boundarytype == ORC_DYN_BOUNDARY || p->boundarytype == ORC_SA_BOUNDARY);
@@ -1361,6 +1536,8 @@ static void euler_body(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 		const orc_f4 force = forces[index];
 		orc_f4 pos = oldPos[index];
 		orc_f4 vel = oldVel[index];
+		orc_f4 vol = { 0, 0, 0, 0 };
+		if (grenier) vol = oldVol[index];
 		do {
 			if (!ACTIVE(pos) || (ptype == PT_BOUNDARY && !integrateBoundary && !MOVING(info)))
 				break;
@@ -1383,7 +1560,9 @@ static void euler_body(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 				pos.x = fmaf(velc[0], dt, pos.x);
 				pos.y = fmaf(velc[1], dt, pos.y);
 				pos.z = fmaf(velc[2], dt, pos.z);
-				if (!repacking)
+				if (grenier)
+					vol.y = fmaf(dt, force.w, vol.y);
+				else if (!repacking)
 					vel.w = fmaf(dt, force.w, vel.w); /* continuity_integration :203-209 */
 				vel.x = fmaf(dt, force.x, vel.x);
 				vel.y = fmaf(dt, force.y, vel.y);
@@ -1410,8 +1589,10 @@ static void euler_body(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 					vel.y = p->rblinearvel[obj][1] + (w[2]*rx - w[0]*rz);
 					vel.z = p->rblinearvel[obj][2] + (w[0]*ry - w[1]*rx);
 				}
-				if (p->boundarytype == ORC_DYN_BOUNDARY)
-					vel.w = fmaf(dt, force.w, vel.w);
+				if (p->boundarytype == ORC_DYN_BOUNDARY) {
+					if (grenier) vol.y = fmaf(dt, force.w, vol.y);
+					else vel.w = fmaf(dt, force.w, vel.w);
+				}
 				break;
 			default:
 				break;
@@ -1419,6 +1600,10 @@ static void euler_body(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 		} while (0);
 		newPos[index] = pos;
 		newVel[index] = vel;
+		if (grenier) {
+			vol.w = expf(vol.y)*vol.x;
+			newVol[index] = vol;
+		}
 	}
 }
 
@@ -1427,7 +1612,15 @@ void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 	const orc_f4 *forces, const orc_f4 *xsph,
 	uint32_t numParticles, float dt, int step)
 {
-	euler_body(p, newPos, newVel, oldPos, oldVel, infoArray, hashArray, forces, xsph, numParticles, dt, step, 0);
+	euler_body(p, newPos, newVel, oldPos, oldVel, infoArray, hashArray, forces, xsph, numParticles, dt, step, 0, NULL, NULL);
+}
+
+/* eulerDevice with SPH_GRENIER: BUFFER_VOLUME is read (old) and written (new) next to pos and vel */
+void orc_euler_grenier(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel, orc_f4 *newVol,
+	const orc_f4 *oldPos, const orc_f4 *oldVel, const orc_f4 *oldVol, const orc_info *infoArray, const uint32_t *hashArray,
+	const orc_f4 *forces, const orc_f4 *xsph, uint32_t numParticles, float dt, int step)
+{
+	euler_body(p, newPos, newVel, oldPos, oldVel, infoArray, hashArray, forces, xsph, numParticles, dt, step, 0, newVol, oldVol);
 }
 
 /* run_mode == REPACK: eulerDevice with euler_repack_params (src/cuda/euler.cu:346-353) */
@@ -1435,7 +1628,7 @@ void orc_euler_repack(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 	const orc_f4 *oldPos, const orc_f4 *oldVel, const orc_info *infoArray, const uint32_t *hashArray,
 	const orc_f4 *forces, uint32_t numParticles, float dt, int step)
 {
-	euler_body(p, newPos, newVel, oldPos, oldVel, infoArray, hashArray, forces, NULL, numParticles, dt, step, 1);
+	euler_body(p, newPos, newVel, oldPos, oldVel, infoArray, hashArray, forces, NULL, numParticles, dt, step, 1, NULL, NULL);
 }
 
 /* disableFreeSurfPartsDevice (src/cuda/euler_kernel.cu:158-180): at the end of repacking the non-fluid particles
@@ -1452,7 +1645,6 @@ void orc_disable_free_surf_parts(orc_f4 *pos, const orc_info *infoArray, uint32_
 /* ==== density filters: shepardDevice src/cuda/forces_kernel.cu:418-505, MlsDevice :508-721 ==========
  * vector helpers follow src/vector_math.h: float4/float = float4*(1.0f/s) (:1093-1097), dot(float4,float4) (:1129-1132),
  * hypot(float4) (:1231-1240); tensor helpers src/cuda/tensor.cu:65-100 (det), :240-282 (dot, ddot, adjugate_row1). */
-static inline float numerical_density(const orc_params *p, float rho, int i) { return rho/p->rho0[i] - 1.0f; }
 
 void orc_shepard(const orc_params *p, orc_f4 *newVel,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,

@@ -52,7 +52,7 @@ def case_lines(prob, framework, allocated=None, **selectors):
           "p1coeff %s" % _g(pp.p1coeff), "p2coeff %s" % _g(pp.p2coeff),
           "smagfactor %s" % _g(_nz(pp.smagfactor)), "kspsfactor %s" % _g(_nz(pp.kspsfactor)),
           "MK_K %s" % _g(_nz(pp.MK_K)), "MK_d %s" % _g(_nz(pp.MK_d)), "MK_beta %s" % _g(_nz(pp.MK_beta)),
-          "partsurf %s" % _g(pp.partsurf), "epsxsph %s" % _g(getattr(pp, "epsxsph", sp.epsxsph)),
+          "partsurf %s" % _g(pp.partsurf), "epsinterface %s" % _g(_nz(pp.epsinterface)), "epsxsph %s" % _g(getattr(pp, "epsxsph", sp.epsxsph)),
           "origin %s %s %s" % tuple(_g(x) for x in prob.m_origin), "grid %d %d %d" % tuple(int(x) for x in prob.m_gridsize),
           "cell %s %s %s" % tuple(_g(x) for x in prob.m_cellsize),
           "allocated %d" % int(allocated if allocated is not None else prob.num_particles)]

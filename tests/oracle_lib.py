@@ -29,6 +29,7 @@ class OrcParams(C.Structure):
         ("repack_a", C.c_float), ("repack_alpha", C.c_float),
         ("is_const_visc", C.c_int32), ("partsurf", C.c_float),
         ("MK_K", C.c_float), ("MK_d", C.c_float), ("MK_beta", C.c_float),
+        ("epsinterface", C.c_float),
         ("numplanes", C.c_uint32),
         ("plane_normal", (C.c_float * 3) * 8), ("plane_gridpos", (C.c_int32 * 3) * 8), ("plane_pos", (C.c_float * 3) * 8),
         ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),
@@ -66,6 +67,7 @@ def lib():
         _lib.orc_soundSpeed.restype = C.c_float; _lib.orc_soundSpeed.argtypes = [C.c_void_p, C.c_float, C.c_int]
         _lib.orc_forces.restype = C.c_uint32
         _lib.orc_forces_sa.restype = C.c_uint32
+        _lib.orc_forces_grenier.restype = C.c_uint32
         _lib.orc_sa_gamma_dt.restype = C.c_float; _lib.orc_sa_gamma_dt.argtypes = [C.c_float, C.c_float]
         _lib.orc_dtreduce.restype = C.c_float
         _lib.orc_dtreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float]
@@ -294,6 +296,34 @@ class Oracle:
                                C.c_int(compute_object_forces))
         return forces, cfl, int(nb), rbf, rbt
 
+    # ---- SPH_GRENIER (oracle/sph_oracle.c "SPH_GRENIER")
+    def init_volume(self, pos, vel, info, n):
+        vol = np.zeros((len(pos), 4), dtype=np.float32)
+        self.L.orc_init_volume(C.byref(self.p), P(vol), P(pos), P(vel), P(info), C.c_uint32(n))
+        return vol
+
+    def density_grenier(self, pos, vel, info, hash_, vol, cs, nl, n, max_fb_neibs):
+        """COMPUTE_DENSITY: rewrites vel[:, 3] in place, returns sigma"""
+        sigma = np.zeros(len(pos), dtype=np.float32)
+        self.L.orc_density_grenier(C.byref(self.p), P(sigma), P(vel), P(pos), P(info), P(hash_), P(vol), P(cs), P(nl),
+                                   C.c_uint32(n), C.c_int(int(max_fb_neibs)))
+        return sigma
+
+    def forces_grenier(self, pos, vel, info, hash_, cs, nl, sigma, n, frm=0, to=None, cfl_offset=0):
+        to = n if to is None else to
+        forces = np.zeros((len(pos), 4), dtype=np.float32)
+        nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
+        cfl = np.zeros(nblk + cfl_offset, dtype=np.float32)
+        nb = self.L.orc_forces_grenier(C.byref(self.p), P(forces), P(cfl), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl),
+                                       P(sigma), C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset))
+        return forces, cfl, int(nb)
+
+    def euler_grenier(self, old_pos, old_vel, old_vol, info, hash_, forces, n, dt, step, xsph=None):
+        npos = np.zeros_like(old_pos); nvel = np.zeros_like(old_vel); nvol = np.zeros_like(old_vol)
+        self.L.orc_euler_grenier(C.byref(self.p), P(npos), P(nvel), P(nvol), P(old_pos), P(old_vel), P(old_vol), P(info),
+                                 P(hash_), P(forces), P(xsph), C.c_uint32(n), C.c_float(dt), C.c_int(step))
+        return npos, nvel, nvol
+
     def dtreduce(self, cfl, nblocks, sspeed_cfl, max_kinematic=0.0):
         return float(self.L.orc_dtreduce(C.byref(self.p), P(cfl), C.c_uint32(nblocks), C.c_float(sspeed_cfl),
                                          C.c_float(max_kinematic)))
@@ -397,6 +427,9 @@ class OracleSim:
         self.max_kinvisc = float(np.float32(max(pp.kinematicvisc))) if sp.rheologytype == D.NEWTONIAN else 0.0   # :3003-3006
         self.neibs_info = None
         self.bodies = None
+        self.grenier = sp.sph_formulation == D.SPH_GRENIER
+        if self.grenier:    # GPUSPH.cc:495-496
+            self.vol = self.o.init_volume(self.pos, self.vel, self.info, self.n)
         if getattr(problem, "moving_bodies_callback", None) is not None and getattr(problem, "num_obstacle", 0):
             from gpusph_amd.bodies import MovingBodies
             self.bodies = MovingBodies(problem, problem.rb_cg_global)
@@ -424,6 +457,8 @@ class OracleSim:
         self.cs, self.ce, self.seg, spos, svel, newn = o.reorder(self.pos, self.vel, self.info, self.hash, pidx, self.ncells,
                                                                  segments=False)
         self.pos, self.vel = spos, svel
+        if getattr(self, "grenier", False):
+            self.vol = np.ascontiguousarray(self.vol[pidx])
         self.partindex = pidx
         self.n = newn
         sq = float(np.float32(self.problem.simparams.nlSqInfluenceRadius))
@@ -479,6 +514,8 @@ class OracleSim:
         sps = sp.turbmodel == self.D.SPS
         # predictor (CALC_VISC before the forces when SPS, PredictorCorrectorIntegrator.cc:460-480)
         tau = o.sps(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n, n)[0] if sps else None
+        if self.grenier:
+            return self._grenier_step(n, dt)
         f1, cfl, nb, self.rbf, self.rbt = o.forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n,
                                                    compute_object_forces=cof, rb_count=rb, tau=tau)
         dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
@@ -504,6 +541,25 @@ class OracleSim:
             for b in range(len(self.bodies)):
                 for a in range(3):
                     self.o.p.rbcgGridPosE[b][a] = int(m["cg_grid"][b][a]); self.o.p.rbcgPosE[b][a] = float(m["cg_pos"][b][a])
+        self.forces = f2
+        self.t += dt
+        self.iterations += 1
+        self.dt = min(dt1, dt2)
+
+    def _grenier_step(self, n, dt):
+        """predictor/corrector with SPH_GRENIER: COMPUTE_DENSITY rewrites the density of the state the forces are computed
+        on (PredictorCorrectorIntegrator.cc:443-458), Euler integrates the volume"""
+        o = self.o
+        mfb = self.neibs_info.maxFluidBoundaryNeibs
+        self.sigma = o.density_grenier(self.pos, self.vel, self.info, self.hash, self.vol, self.cs, self.nl, n, mfb)
+        f1, cfl, nb = o.forces_grenier(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, self.sigma, n)
+        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        ps, vs, vols = o.euler_grenier(self.pos, self.vel, self.vol, self.info, self.hash, f1, n,
+                                       float(np.float32(dt) / np.float32(2)), 1)
+        self.sigma_s = o.density_grenier(ps, vs, self.info, self.hash, vols, self.cs, self.nl, n, mfb)
+        f2, cfl, nb = o.forces_grenier(ps, vs, self.info, self.hash, self.cs, self.nl, self.sigma_s, n)
+        dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        self.pos, self.vel, self.vol = o.euler_grenier(self.pos, self.vel, self.vol, self.info, self.hash, f2, n, dt, 2)
         self.forces = f2
         self.t += dt
         self.iterations += 1
