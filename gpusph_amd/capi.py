@@ -85,6 +85,10 @@ SIGNATURES = {
     "sphx_filter_process": (_i, [_vp, _i] + [_vp] * 7 + [_u32, _u32, _f, _f, _vp]),
     "sphx_postprocess": (_i, [_vp, _i] + [_vp] * 10 + [_u32, _u32, _f, _f, _vp]),
     "sphx_euler_basicstep": (_i, [_vp] + [_vp] * 8 + [_u32, _u32, _f, _vp, _f, _i, _f, _f, _f, _i, _vp]),
+    "sphx_euler_basicstep_grenier": (_i, [_vp] + [_vp] * 10 + [_u32, _u32, _f, _vp, _f, _i, _f, _f, _f, _i, _vp]),
+    "sphx_init_volume": (_i, [_vp] * 5 + [_u32, _vp]),
+    "sphx_compute_density": (_i, [_vp] * 9 + [_u32, _f, _f, _vp]),
+    "sphx_forces_basicstep_grenier": (_i, [_vp] * 10 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_disable_free_surf_parts": (_i, [_vp, _vp, _vp, _u32, _u32, _vp]),
     "sphx_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
     "sphx_device_count": (_i, [C.POINTER(_i)]),

@@ -13,6 +13,8 @@ struct EulerArgs {
 	float4 *newPos, *newVel;
 	const float4 *oldPos, *oldVel, *forces;
 	const float4 *xsph;      // ENABLE_XSPH: mean neighbourhood velocity from the forces pass, else NULL
+	float4 *newVol;          // SPH_GRENIER: BUFFER_VOLUME (x initial volume, y log of current/initial, w current), else NULL
+	const float4 *oldVol;
 	const particleinfo *info;
 	const uint32_t *hash;
 	const RbParams *rb;
@@ -37,6 +39,11 @@ euler_kernel(DevParams p, EulerArgs a)
 	const float4 force = a.forces[index];
 	float4 pos = a.oldPos[index];
 	float4 vel = a.oldVel[index];
+	// SPH_GRENIER: the continuity equation integrates the log of the volume ratio instead of the density
+	// (continuity_integration euler_kernel.def:210-216, write_volume :281-289)
+	const bool grenier = !REPACK && a.oldVol != nullptr;
+	float4 vol = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (grenier) vol = a.oldVol[index];
 
 	const bool integrateBoundary = !REPACK && (p.boundarytype == SPHX_DYN_BOUNDARY || p.boundarytype == SPHX_SA_BOUNDARY);
 	if (is_active_w(pos.w) && !(ptype == PT_BOUNDARY && !integrateBoundary && !IS_MOVING(info))) {
@@ -58,7 +65,8 @@ euler_kernel(DevParams p, EulerArgs a)
 			pos.x = fmaf(vcx, dt, pos.x);
 			pos.y = fmaf(vcy, dt, pos.y);
 			pos.z = fmaf(vcz, dt, pos.z);
-			if (!REPACK) vel.w = fmaf(dt, force.w, vel.w);   // continuity_integration :203-209
+			if (grenier) vol.y = fmaf(dt, force.w, vol.y);
+			else if (!REPACK) vel.w = fmaf(dt, force.w, vel.w);   // continuity_integration :203-209
 			vel.x = fmaf(dt, force.x, vel.x);
 			vel.y = fmaf(dt, force.y, vel.y);
 			vel.z = fmaf(dt, force.z, vel.z);
@@ -81,16 +89,22 @@ euler_kernel(DevParams p, EulerArgs a)
 				vel.y = a.rb->linearvel[obj][1] + (w[2]*rx - w[0]*rz);
 				vel.z = a.rb->linearvel[obj][2] + (w[0]*ry - w[1]*rx);
 			}
-			if (p.boundarytype == SPHX_DYN_BOUNDARY)
-				vel.w = fmaf(dt, force.w, vel.w);
+			if (p.boundarytype == SPHX_DYN_BOUNDARY) {
+				if (grenier) vol.y = fmaf(dt, force.w, vol.y);
+				else vel.w = fmaf(dt, force.w, vel.w);
+			}
 		}
 	}
 	a.newPos[index] = pos;
 	a.newVel[index] = vel;
+	if (grenier) {
+		vol.w = expf(vol.y)*vol.x;
+		a.newVol[index] = vol;
+	}
 }
 
-extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
-	const void *oldPos, const void *oldVel, const void *info, const uint32_t *hash,
+static int euler_launch(sphx_ctx *ctx, void *newPos, void *newVel, void *newVol,
+	const void *oldPos, const void *oldVel, const void *oldVol, const void *info, const uint32_t *hash,
 	const void *forces, const void *xsph,
 	uint32_t numParticles, uint32_t particleRangeEnd,
 	float dt, const float *d_dt, float dt_scale, int step, float t,
@@ -114,6 +128,7 @@ extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	a.oldPos = (const float4*)oldPos; a.oldVel = (const float4*)oldVel; a.forces = (const float4*)forces;
 	a.info = (const particleinfo*)info; a.hash = hash; a.rb = ctx->rb_dev;
 	a.xsph = (ctx->dev.simflags & SPHX_ENABLE_XSPH) ? (const float4*)xsph : nullptr;
+	a.newVol = (float4*)newVol; a.oldVol = (const float4*)oldVol;
 	a.d_dt = d_dt; a.dt = dt; a.dt_scale = dt_scale; a.numParticles = particleRangeEnd;
 	const dim3 grid(div_up_u(particleRangeEnd, BLOCK_EULER));
 	const bool repack = run_mode == SPHX_REPACK;
@@ -126,6 +141,36 @@ extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	}
 	SPHX_LAUNCH_CHECK("euler_kernel");
 	return SPHX_OK;
+}
+
+extern "C" int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
+	const void *oldPos, const void *oldVel, const void *info, const uint32_t *hash,
+	const void *forces, const void *xsph,
+	uint32_t numParticles, uint32_t particleRangeEnd,
+	float dt, const float *d_dt, float dt_scale, int step, float t,
+	float slength, float influenceradius, int run_mode, void *stream)
+{
+	if (ctx && ctx->have_params && ctx->params.sph_formulation == SPHX_SPH_GRENIER && run_mode == SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_euler_basicstep: SPH_GRENIER integrates BUFFER_VOLUME, use sphx_euler_basicstep_grenier");
+	return euler_launch(ctx, newPos, newVel, nullptr, oldPos, oldVel, nullptr, info, hash, forces, xsph, numParticles, particleRangeEnd,
+		dt, d_dt, dt_scale, step, t, slength, influenceradius, run_mode, stream);
+}
+
+// SPH_GRENIER: the same step with BUFFER_VOLUME read (old) and written (new) (euler_params.h:153-156 Vol_params)
+extern "C" int sphx_euler_basicstep_grenier(sphx_ctx *ctx, void *newPos, void *newVel, void *newVol,
+	const void *oldPos, const void *oldVel, const void *oldVol, const void *info, const uint32_t *hash,
+	const void *forces, const void *xsph,
+	uint32_t numParticles, uint32_t particleRangeEnd,
+	float dt, const float *d_dt, float dt_scale, int step, float t,
+	float slength, float influenceradius, int run_mode, void *stream)
+{
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_euler_basicstep_grenier: constants not set");
+	if (ctx->params.sph_formulation != SPHX_SPH_GRENIER)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_euler_basicstep_grenier called without SPH_GRENIER");
+	if (run_mode == SPHX_SIMULATE)
+		SPHX_REQUIRE(newVol && oldVol && newVol != oldVol, "sphx_euler_basicstep_grenier: BUFFER_VOLUME is double buffered");
+	return euler_launch(ctx, newPos, newVel, newVol, oldPos, oldVel, oldVol, info, hash, forces, xsph, numParticles, particleRangeEnd,
+		dt, d_dt, dt_scale, step, t, slength, influenceradius, run_mode, stream);
 }
 
 // disableFreeSurfPartsDevice (src/cuda/euler_kernel.cu:158-180)

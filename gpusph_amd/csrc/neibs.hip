@@ -551,8 +551,11 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	}
 	const int3 gridPos = walking ? grid_pos_from_hash(p, particleHash[index] & CELLTYPE_BITMASK) : make_int3(0, 0, 0);
 	const bool boundary = IS_BOUNDARY(info);
-	// boundary particles never list non-fluid neighbours with LJ/DYN boundaries (:596-607)
-	const bool fluidOnly = boundary && (p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY);
+	// boundary particles never list boundary neighbours with LJ boundaries, nor with DYN boundaries unless the formulation is
+	// SPH_GRENIER, whose sigma sums over them (:588-601); MK_BOUNDARY (uploaded as LJ + mk_mask) has no such rule
+	const bool noBB = (p.boundarytype == SPHX_LJ_BOUNDARY && !p.mk_mask) ||
+		(p.boundarytype == SPHX_DYN_BOUNDARY && p.formulation != SPHX_SPH_GRENIER);
+	const bool fluidOnly = boundary && noBB;
 
 	// sa_boundary_niC_vars (:147-190): in-plane frame of a segment, the ids of its vertices
 	uint4 ownVerts = make_uint4(0, 0, 0, 0);
@@ -673,8 +676,7 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 				if (neib_type != PART_TYPE(neib_info))
 					encv = code;
 				neib_type = PART_TYPE(neib_info);
-				if ((p.boundarytype == SPHX_LJ_BOUNDARY || p.boundarytype == SPHX_DYN_BOUNDARY) &&
-					boundary && IS_BOUNDARY(neib_info))
+				if (noBB && boundary && IS_BOUNDARY(neib_info))
 					continue;
 				const float4 neib_pos = posArray[neib_index];
 				if (!is_active_w(neib_pos.w)) continue;

@@ -183,8 +183,21 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	SPHX_REQUIRE(sp->numfluids >= 1 && sp->numfluids <= SPHX_MAX_FLUIDS, "sphx_set_constants: numfluids out of range");
 	SPHX_REQUIRE(sp->neiblistsize >= 2 && sp->neibboundpos < sp->neiblistsize, "sphx_set_constants: invalid neighbour list geometry");
 	// option combinations built into this library (the rest is SURVEY.md 8f "next")
-	if (sp->sph_formulation != SPHX_SPH_F1 && sp->sph_formulation != SPHX_SPH_F2)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only SPH_F1 and SPH_F2 are built");
+	if (sp->sph_formulation != SPHX_SPH_F1 && sp->sph_formulation != SPHX_SPH_F2 && sp->sph_formulation != SPHX_SPH_GRENIER)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SPH_F1, SPH_F2 and SPH_GRENIER are built, SPH_HA is not");
+	if (sp->sph_formulation == SPHX_SPH_GRENIER) {
+		// the option set of the reference's Grenier problems (Bubble, LockExchange, RTInstability, OilJet): Wendland kernel,
+		// dynamic boundaries, laminar flow, no density diffusion; grenier.hip
+		if (sp->kerneltype != SPHX_WENDLAND || sp->boundarytype != SPHX_DYN_BOUNDARY)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SPH_GRENIER is built for the Wendland kernel with DYN_BOUNDARY");
+		if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SPH_GRENIER is built without density diffusion");
+		if (sp->turbmodel != SPHX_LAMINAR_FLOW)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SPH_GRENIER is built for LAMINAR_FLOW (no artificial viscosity, no SPS)");
+		if (sp->simflags & (SPHX_ENABLE_XSPH | SPHX_ENABLE_MOVING_BODIES))
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SPH_GRENIER is built without XSPH and without moving bodies");
+		SPHX_REQUIRE(sp->epsinterface == sp->epsinterface, "sphx_set_constants: SPH_GRENIER needs epsinterface (ProblemCore.cc:165-166 default 0.05)");
+	}
 	// SA_BOUNDARY: the neighbour engine (vertex section, VERTPOS) and the boundary-conditions engine of solid walls are built;
 	// the forces / integration / filter engines answer SPHX_ERR_UNSUPPORTED for it (gamma terms, density summation)
 	if (sp->boundarytype < SPHX_LJ_BOUNDARY || sp->boundarytype > SPHX_DYN_BOUNDARY)

@@ -231,6 +231,35 @@ class HipKernels:
                                                  p(forces), p(xsph), n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
                                                  P.slength, P.influenceradius, run_mode, self._s()))
 
+    # ---- SPH_GRENIER (grenier.hip)
+    def init_volume(self, vol, pos, vel, info, n):
+        p = capi.ptr
+        capi.check(self.lib.sphx_init_volume(self.ctx.handle, p(vol), p(pos), p(vel), p(info), n, self._s()))
+
+    def compute_density(self, sigma, vel, pos, info, hash_, vol, cellStart, neibslist, n):
+        """COMPUTE_DENSITY: sigma written, vel.w rewritten in place"""
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_compute_density(self.ctx.handle, p(sigma), p(vel), p(pos), p(info), p(hash_), p(vol), p(cellStart),
+                                                 p(neibslist), n, P.slength, P.influenceradius, self._s()))
+
+    def forces_grenier(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, sigma, n, frm, to, cfl_offset=0):
+        p = capi.ptr
+        P = self.params
+        nb = C.c_uint32(0)
+        capi.check(self.lib.sphx_forces_basicstep_grenier(self.ctx.handle, p(forces), p(cfl), p(pos), p(vel), p(info), p(hash_),
+                                                          p(cellStart), p(neibslist), p(sigma), n, frm, to, P.deltap, P.slength,
+                                                          P.dtadaptfactor, P.influenceradius, cfl_offset, D.SIMULATE, 1, 0.0,
+                                                          C.byref(nb), self._s()))
+        return int(nb.value)
+
+    def euler_grenier(self, npos, nvel, nvol, opos, ovel, ovol, info, hash_, forces, n, d_dt, dt_scale, step):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_euler_basicstep_grenier(self.ctx.handle, p(npos), p(nvel), p(nvol), p(opos), p(ovel), p(ovol), p(info),
+                                                         p(hash_), p(forces), None, n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
+                                                         P.slength, P.influenceradius, D.SIMULATE, self._s()))
+
     def disable_free_surf_parts(self, pos, info, n):
         capi.check(self.lib.sphx_disable_free_surf_parts(self.ctx.handle, capi.ptr(pos), capi.ptr(info), n, n, self._s()))
 

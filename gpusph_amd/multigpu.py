@@ -85,6 +85,9 @@ class MultiGpuEngine:
         self.sa = problem.simparams.boundarytype == D.SA_BOUNDARY
         if world > 1 and self.sa:
             raise ValueError("SA_BOUNDARY: the vertex/segment buffers are not exchanged between slabs yet (single domain only)")
+        self.grenier = problem.simparams.sph_formulation == D.SPH_GRENIER
+        if world > 1 and self.grenier:
+            raise ValueError("SPH_GRENIER: sigma and the volumes are not exchanged between slabs yet (single domain only)")
         self.problem = problem
         self.rank, self.world = rank, world
         self.device = torch.device(device)
@@ -173,6 +176,11 @@ class MultiGpuEngine:
             self.sa_dynamic_gamma = not (self.sp.simflags & D.ENABLE_GAMMA_QUADRATURE)
             self.sa_density_sum = bool(self.sp.simflags & D.ENABLE_DENSITY_SUM)
             self.cfl_gamma = (torch.zeros(A + 4 + self.cfl.numel(), dtype=f32, device=dev) if self.sa_dynamic_gamma else None)
+        # SPH_GRENIER: BUFFER_VOLUME (double buffered like pos/vel, travels through the re-sort) and BUFFER_SIGMA
+        if self.grenier:
+            self.vol = torch.zeros((A, 4), dtype=f32, device=dev); self.vol2 = torch.zeros_like(self.vol)
+            self.sigma = torch.zeros(A, dtype=f32, device=dev)
+            self.k.init_volume(self.vol, self.pos, self.vel, self.info, n0)      # GPUSPH.cc:495-496
         self.filters = []            # [(FilterType, frequency)]
         # bodies with prescribed motion: every rank runs the same host kinematics (the callback is a pure function of time)
         self.bodies = None
@@ -248,6 +256,9 @@ class MultiGpuEngine:
                 src, dst = getattr(self, name), getattr(self, name + "2")
                 K.gather_rows(dst, src, self.partindex, n)
                 setattr(self, name, dst); setattr(self, name + "2", src)
+        if self.grenier:
+            K.gather_rows(self.vol2, self.vol, self.partindex, n)
+            self.vol, self.vol2 = self.vol2, self.vol
         if self.world == 1:
             if self.track_particle_count:
                 self.n_local = int(self.new_num.item()) & 0xFFFFFFFF
@@ -373,6 +384,16 @@ class MultiGpuEngine:
             if self.sa_dynamic_gamma:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
                 K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb, self.d_dt_next)
             return
+        if self.grenier and run_mode == D.SIMULATE:
+            # COMPUTE_DENSITY on the state the forces read (PredictorCorrectorIntegrator.cc:443-458), then the Grenier forces
+            vol = self.vol if pos is self.pos else self.vol2
+            K.compute_density(self.sigma, vel, pos, self.info, self.hash, vol, self.cellStart, self.neibslist, self.n_local)
+            nb = K.forces_grenier(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.sigma,
+                                  self.n_local, 0, self.n_int, 0)
+            if prof:
+                e1.record(); self.profile_forces.append((e0, e1))
+            K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
+            return
         args = (self.forces, self.cfl, self.rbforces if self.has_rb else None, self.rbtorques if self.has_rb else None, pos, vel, self.info, self.hash, self.cellStart,
                 self.neibslist, self.n_local)
         kw = dict(tau=self.tau) if sps else {}
@@ -430,14 +451,21 @@ class MultiGpuEngine:
         self._forces_pass(self.pos, self.vel, 0, step=1)
         if self.bodies is not None:                 # MOVE_BODIES + uploads (PredictorCorrectorIntegrator.cc:550-570)
             m = self.bodies.timestep(1, dt_host, self.t_host); K.set_body_motion(m, self.sp.numforcesbodies > 0)
-        K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1, **ekw)
+        if self.grenier:
+            K.euler_grenier(self.pos2, self.vel2, self.vol2, self.pos, self.vel, self.vol, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1)
+        else:
+            K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1, **ekw)
         if self.sa:
             self._sa_post_euler(1)
         # corrector: forces(step n*) -> n+1 = n + dt f*   (written over n*, then renamed to n)
         self._forces_pass(self.pos2, self.vel2, 1, step=2)
         if self.bodies is not None:
             m = self.bodies.timestep(2, dt_host, self.t_host); K.set_body_motion(m, self.sp.numforcesbodies > 0)
-        K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2, **ekw)
+        if self.grenier:     # the volumes of n* are overwritten by those of n+1, like pos and vel
+            K.euler_grenier(self.pos2, self.vel2, self.vol2, self.pos, self.vel, self.vol, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2)
+            self.vol, self.vol2 = self.vol2, self.vol
+        else:
+            K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2, **ekw)
         if self.sa:
             self._sa_post_euler(2)
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma

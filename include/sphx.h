@@ -377,6 +377,39 @@ int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	float dt, const float *d_dt, float dt_scale, int step, float t,
 	float slength, float influenceradius, int run_mode, void *stream);
 
+/* ---- SPH_GRENIER (formulation<SPH_GRENIER>, boundary<DYN_BOUNDARY>: Bubble, LockExchange, RTInstability, OilJet) ----------
+ * The volume formulation keeps two more buffers, BUFFER_VOLUME (float4: x initial volume, y log(current/initial), w current
+ * volume) and BUFFER_SIGMA (float).
+ *   sphx_init_volume               ProblemCore::init_volume (src/ProblemCore.cc:1586-1606), on the uploaded arrays
+ *   sphx_compute_density           AbstractForcesEngine::compute_density (src/engine_forces.h:118-125, CUDADensityHelper<.., SPH_GRENIER, ..>
+ *                                  src/cuda/forces.cu:208-246; the COMPUTE_DENSITY command before every forces pass,
+ *                                  src/integrators/PredictorCorrectorIntegrator.cc:443-458): writes sigma, rewrites vel.w in
+ *                                  place; the 'typical sigma' of boundary particles out of reach of the fluid uses
+ *                                  maxFluidBoundaryNeibs of the last sphx_build_neibs on this context.  Does nothing for the
+ *                                  other formulations, like the reference's helper.
+ *   sphx_forces_basicstep_grenier  basicstep of the forces engine with grenier_forces_params (src/cuda/forces_params.h:224-240):
+ *                                  the arguments of sphx_forces_basicstep that the built option set uses, plus sigma
+ *   sphx_euler_basicstep_grenier   basicstep of the integration engine with Vol_params (src/cuda/euler_params.h:153-156):
+ *                                  sphx_euler_basicstep plus BUFFER_VOLUME old/new; sphx_euler_basicstep itself answers
+ *                                  SPHX_ERR_INVALID for a SIMULATE step of this formulation */
+int sphx_init_volume(sphx_ctx *ctx, void *vol, const void *pos, const void *vel, const void *info,
+	uint32_t numParticles, void *stream);
+int sphx_compute_density(sphx_ctx *ctx, float *sigma, void *vel, const void *pos, const void *info,
+	const uint32_t *hash, const void *vol, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, float slength, float influenceradius, void *stream);
+int sphx_forces_basicstep_grenier(sphx_ctx *ctx, void *forces, float *cfl,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *sigma,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius,
+	uint32_t cflOffset, int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream);
+int sphx_euler_basicstep_grenier(sphx_ctx *ctx, void *newPos, void *newVel, void *newVol,
+	const void *oldPos, const void *oldVel, const void *oldVol, const void *info, const uint32_t *hash,
+	const void *forces, const void *xsph,
+	uint32_t numParticles, uint32_t particleRangeEnd,
+	float dt, const float *d_dt, float dt_scale, int step, float t,
+	float slength, float influenceradius, int run_mode, void *stream);
+
 /* disableFreeSurfParts (src/engine_integration.h:137, src/cuda/euler.cu:368-391): at the end of a repacking run,
  * disable (mass = NaN) the non-fluid particles flagged FG_SURFACE */
 int sphx_disable_free_surf_parts(sphx_ctx *ctx, void *pos, const void *info,

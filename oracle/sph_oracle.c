@@ -520,8 +520,8 @@ static void neibs_in_cell(const orc_params *p, uint16_t *neibsList,
 		neib_type = PART_TYPE(neib_info);
 
 		/* ViscSpec::rheologytype != GRANULAR always here */
-		if ((p->boundarytype == ORC_LJ_BOUNDARY || p->boundarytype == ORC_MK_BOUNDARY) && boundary && BOUNDARY(neib_info))
-			continue;   /* src/cuda/buildneibs_kernel.cu:1061 */
+		if (p->boundarytype == ORC_LJ_BOUNDARY && boundary && BOUNDARY(neib_info))
+			continue;   /* src/cuda/buildneibs_kernel.cu:588-593: LJ only -- the boundary particles of MK_BOUNDARY bodies keep theirs */
 		if (p->boundarytype == ORC_DYN_BOUNDARY && p->sph_formulation != ORC_SPH_GRENIER) {   /* :598 */
 			if (boundary && BOUNDARY(neib_info))
 				continue;
