@@ -291,17 +291,32 @@ int main(int argc, char **argv)
 		}
 
 		BufferList *curPos = &posA, *othPos = &posB, *curVel = &velA, *othVel = &velB;
+		// SPH_GRENIER: BUFFER_VOLUME is part of the particle state (double buffered, re-sorted), BUFFER_SIGMA is ephemeral
+		// (GPUWorker.cc:195-198); the volumes start from mass/density (ProblemCore::init_volume, src/ProblemCore.cc:1586-1606)
+		const bool grenier = sp->sph_formulation == SPH_GRENIER;
+		BufferList volA, volB, noVol;
+		if (grenier) {
+			volA = one_buffer<BUFFER_VOLUME>(A); volB = one_buffer<BUFFER_VOLUME>(A);
+			shared |= one_buffer<BUFFER_SIGMA>(A);
+			std::vector<float4> hvol(n0);
+			for (uint i = 0; i < n0; ++i) {
+				const float v = hpos[i].w/((hvel[i].w + 1.0f)*pp.rho0[fluid_num(hinfo[i])]);
+				hvol[i] = make_float4(v, 0.0f, 0.0f, v);
+			}
+			sphx_throw(sphx_memcpy_h2d(volA.getData<BUFFER_VOLUME>(), hvol.data(), 16*(size_t)n0));
+		}
+		BufferList *curVol = grenier ? &volA : &noVol, *othVol = grenier ? &volB : &noVol;
 		uint n = n0;
 		float dt = (float)num(c, "dt0");
 		double t = 0;
 		for (uint it = 0; it < steps; ++it) {
 			if (it % sp->buildneibsfreq == 0) {
-				BufferList unsorted = *curPos | *curVel | shared, sorted = *othPos | *othVel | shared;
+				BufferList unsorted = *curPos | *curVel | *curVol | shared, sorted = *othPos | *othVel | *othVol | shared;
 				if (it == 0) neibsEngine->fixHash(unsorted, unsorted, n); else neibsEngine->calcHash(unsorted, unsorted, n);
 				neibsEngine->sort(unsorted, unsorted, n);
 				shared[BUFFER_CELLSTART]->clobber(); shared[BUFFER_CELLEND]->clobber();
 				neibsEngine->reorderDataAndFindCellStart(NULL, sorted, unsorted, n, d_newNum);
-				std::swap(curPos, othPos); std::swap(curVel, othVel);
+				std::swap(curPos, othPos); std::swap(curVel, othVel); std::swap(curVol, othVol);
 				sphx_throw(sphx_memcpy_d2h(&n, d_newNum, 4));                     // DOWNLOAD_NEWNUMPARTS
 				neibsEngine->resetinfo();
 				shared[BUFFER_NEIBSLIST]->clobber();
@@ -320,7 +335,9 @@ int main(int argc, char **argv)
 			float dts[2];
 			for (int step = 1; step <= 2; ++step) {
 				// forces on step n (predictor) or on n* (corrector); Euler always reads n and writes n*
-				BufferList state = (step == 1) ? (*curPos | *curVel | shared) : (*othPos | *othVel | shared);
+				BufferList state = (step == 1) ? (*curPos | *curVel | *curVol | shared) : (*othPos | *othVel | *othVol | shared);
+				if (grenier)                                                          // COMPUTE_DENSITY (:443-458): VEL in place, SIGMA
+					forcesEngine->compute_density(state, state, n, slength, influenceRadius);
 				if (sp->turbmodel == SPS)                                             // CALC_VISC
 					viscEngine->calc_visc(state, state, n, n, deltap, slength, influenceRadius);
 				shared[BUFFER_FORCES]->clobber(); shared[BUFFER_CFL]->clobber();      // pre_forces
@@ -346,11 +363,11 @@ int main(int argc, char **argv)
 					integrationEngine->setrblinearvel(lvel.data(), numbodies); integrationEngine->setrbangularvel(avel.data(), numbodies);
 					if (sp->numforcesbodies > 0) forcesEngine->setrbcg(cgGrid.data(), cgPos.data(), numbodies);   // FORCES_UPLOAD_OBJECTS_CG
 				}
-				BufferList rd = *curPos | *curVel | shared, wr = *othPos | *othVel;
+				BufferList rd = *curPos | *curVel | *curVol | shared, wr = *othPos | *othVel | *othVol;
 				integrationEngine->basicstep(rd, wr, n, n, step == 1 ? dt/2 : dt, step, (float)t, slength, influenceRadius, SIMULATE);
 			}
 			if (moving) integrationEngine->setrbcg(cgGrid.data(), cgPos.data(), numbodies);   // EULER_UPLOAD_OBJECTS_CG
-			std::swap(curPos, othPos); std::swap(curVel, othVel);
+			std::swap(curPos, othPos); std::swap(curVel, othVel); std::swap(curVol, othVol);
 			t += dt;
 			dt = std::min(dts[0], dts[1]);                                            // TIME_STEP_EPILOGUE (src/GPUSPH.cc:650-657)
 		}
@@ -372,6 +389,11 @@ int main(int argc, char **argv)
 		if (!o) throw std::runtime_error(std::string("cannot write ") + argv[3]);
 		fwrite(&n, 4, 1, o); fwrite(&dt, 4, 1, o); fwrite(&t, 8, 1, o);
 		fwrite(hpos.data(), 16, n, o); fwrite(hvel.data(), 16, n, o); fwrite(hinfo.data(), 8, n, o); fwrite(hhash.data(), 4, n, o);
+		if (grenier) {      // the volumes behind the usual state
+			std::vector<float4> hvol(n);
+			sphx_throw(sphx_memcpy_d2h(hvol.data(), as_const(*curVol).getData<BUFFER_VOLUME>(), 16*(size_t)n));
+			fwrite(hvol.data(), 16, n, o);
+		}
 		fclose(o);
 		printf("example_engines: %s, %u particles, %u steps, t=%g dt=%g\n", str(c, "framework").c_str(), n, steps, t, dt);
 	} catch (const std::exception &e) {

@@ -375,8 +375,16 @@ public:
 
 	uint round_particles(uint numparts) { return sphx_forces_round_particles(numparts); }
 
-	void compute_density(const BufferList&, BufferList&, uint, float, float)
-	{ sphx_not_built("compute_density (SPH_GRENIER)"); }
+	// CUDADensityHelper<kerneltype, SPH_GRENIER, boundarytype>::process (src/cuda/forces.cu:208-246): vel of the write list is
+	// updated in place, sigma written; nothing for the other formulations
+	void compute_density(const BufferList& bufread, BufferList& bufwrite, uint numParticles, float slength, float influenceradius)
+	{
+		if (m_c->params().sph_formulation != SPH_GRENIER) return;
+		sphx_throw(sphx_compute_density(m_c->ctx(), bufwrite.getData<BUFFER_SIGMA>(), bufwrite.getData<BUFFER_VEL>(),
+			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+			bufread.getData<BUFFER_VOLUME>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			numParticles, slength, influenceradius, NULL));
+	}
 
 	// Brezzi diffusion after the density summation (src/cuda/forces.cu:621-661): the diffusive density rate into FORCES.w
 	void compute_density_diffusion(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
@@ -411,6 +419,18 @@ public:
 				bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
 				numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor, influenceradius,
 				cflOffset, (int)run_mode, step, dt, &nb, NULL));
+			return nb;
+		}
+		if (P.sph_formulation == SPH_GRENIER && run_mode == SIMULATE) {
+			// grenier_forces_params (src/cuda/forces_params.h:224-240): sigma of the state that is read
+			if (compute_object_forces)
+				sphx_not_built("forces basicstep: SPH_GRENIER with bodies that feel the fluid (BUFFER_RB_FORCES)");
+			uint32_t nb = 0;
+			sphx_throw(sphx_forces_basicstep_grenier(m_c->ctx(), forces, cfl,
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+				bufread.getData<BUFFER_SIGMA>(), numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor,
+				influenceradius, cflOffset, (int)run_mode, step, dt, &nb, NULL));
 			return nb;
 		}
 		float4 *rbforces = bufwrite.getData<BUFFER_RB_FORCES>();
@@ -554,6 +574,15 @@ public:
 		const uint particleRangeEnd, const float dt, const int step, const float t, const float slength,
 		const float influenceRadius, const RunMode run_mode)
 	{
+		if (m_c->params().sph_formulation == SPH_GRENIER && run_mode == SIMULATE) {
+			// Vol_params (src/cuda/euler_params.h:153-156): BUFFER_VOLUME of the read and of the write list
+			sphx_throw(sphx_euler_basicstep_grenier(m_c->ctx(), bufwrite.getData<BUFFER_POS>(), bufwrite.getData<BUFFER_VEL>(),
+				bufwrite.getData<BUFFER_VOLUME>(), bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(),
+				bufread.getData<BUFFER_VOLUME>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+				bufread.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_XSPH>(),
+				numParticles, particleRangeEnd, dt, NULL, 1.0f, step, t, slength, influenceRadius, (int)run_mode, NULL));
+			return;
+		}
 		sphx_throw(sphx_euler_basicstep(m_c->ctx(), bufwrite.getData<BUFFER_POS>(), bufwrite.getData<BUFFER_VEL>(),
 			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
 			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_XSPH>(),

@@ -145,3 +145,30 @@ def test_steps_follow_the_oracle(kw):
     np.testing.assert_allclose(_np(eng.vol)[:n, 1], sim.vol[:n, 1], atol=1e-6)
     assert abs(eng.current_dt() - sim.dt) <= 2e-5 * sim.dt
     assert np.abs(sim.vol[:n, 1]).max() > 1e-6
+
+
+def test_cpp_adapters_run_the_grenier_step_like_the_python_driver(tmp_path):
+    """example_engines (built inside the GPUSPH tree against its own headers) with the Bubble framework: COMPUTE_DENSITY through
+    AbstractForcesEngine::compute_density, the forces and Euler steps with BUFFER_SIGMA / BUFFER_VOLUME in the tree's BufferLists"""
+    import os, subprocess
+    import host_case as hc
+    exe = hc.exe("example_engines")
+    assert os.path.exists(exe), "gpusph_amd/host/example_engines is not built (make -C gpusph_amd/host, needs the GPUSPH tree)"
+    prob = grenier_problem(0.04, jitter=0.05)
+    prob.simparams.simflags &= ~D.ENABLE_REPACKING           # the Bubble selector list of problem_setup.h has no repacking flag
+    eng = _engine(prob)
+    steps = 12
+    case, state, fout = tmp_path / "case.txt", tmp_path / "state.bin", tmp_path / "out.bin"
+    case.write_text("\n".join(hc.case_lines(prob, "Bubble") + hc.driver_lines(prob, eng, steps)) + "\n")
+    hc.write_state(state, prob.copy_to_array())
+    r = subprocess.run([exe, str(case), str(state), str(fout)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    eng.run(steps)
+    ref = eng.download()
+    out = hc.read_out(fout)
+    n = out["n"]
+    assert n == eng.n and np.float32(eng.current_dt()) == out["dt"] and eng.time() == out["t"]
+    assert np.array_equal(out["hash"], ref["hash"])
+    assert np.array_equal(_bits(out["pos"]), _bits(ref["pos"])) and np.array_equal(_bits(out["vel"]), _bits(ref["vel"]))
+    assert np.array_equal(_bits(out["vol"]), _bits(_np(eng.vol)[:n]))
+    assert np.abs(out["vol"][:, 1]).max() > 1e-6

@@ -150,6 +150,19 @@ def test_two_fluid_mirror_against_the_multifluid_frameworks(tmp_path):
     assert_params(out, prob, prob.num_particles)
 
 
+def test_grenier_mirror_against_the_bubble_framework(tmp_path):
+    # formulation<SPH_GRENIER>, viscosity<DYNAMICVISC>, boundary<DYN_BOUNDARY>, ENABLE_MULTIFLUID (src/problems/Bubble.cu:55-61)
+    prob = DamBreak3D(0.05, obstacle=False, two_fluids=True, viscosity="DYNAMICVISC", formulation=D.SPH_GRENIER,
+                      density_diffusion=D.DENSITY_DIFFUSION_NONE)
+    prob.simparams.simflags &= ~D.ENABLE_REPACKING
+    out = run_check(tmp_path, hc.case_lines(prob, "Bubble"))
+    assert_options(out, prob.simparams)
+    assert out["options"]["viscavgop"] == D.HARMONIC and out["options"]["sph_formulation"] == D.SPH_GRENIER
+    assert_params(out, prob, prob.num_particles)
+    got = SphxParams.from_buffer_copy(bytes.fromhex(out["params_hex"]))
+    assert abs(got.epsinterface - 0.05) < 1e-9           # ProblemCore.cc:165-166, carried by the case file here
+
+
 def test_selector_semantics_of_the_factory(tmp_path):
     """defaults, the legacy viscosity names, Grenier's harmonic rule, run-time walks over option ranges"""
     d = run_check(tmp_path, ["framework Default"])["options"]   # TypeDefaults, src/cuda/cudasimframework.cu:346-360
