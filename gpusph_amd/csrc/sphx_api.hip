@@ -264,6 +264,11 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	// MK_BOUNDARY shares every code path of LJ_BOUNDARY (lists, sections, feedback bodies, Euler) but the force law
 	d.MK_K = sp->MK_K; d.MK_d = sp->MK_d; d.MK_beta = sp->MK_beta;
 	d.epsinterface = sp->epsinterface;
+	for (int f = 0; f < SPHX_MAX_FLUIDS; ++f) {
+		d.yield_strength[f] = sp->yield_strength[f]; d.visc_nonlinear_param[f] = sp->visc_nonlinear_param[f];
+		d.visc_regularization_param[f] = sp->visc_regularization_param[f];
+	}
+	d.limiting_kinvisc = sp->limiting_kinvisc;
 	d.mk_mask = (sp->boundarytype == SPHX_MK_BOUNDARY) ? 0xFFFFFFFFu : 0u;
 	if (sp->boundarytype == SPHX_MK_BOUNDARY) d.boundarytype = SPHX_LJ_BOUNDARY;
 	ctx->have_params = true;

@@ -78,6 +78,8 @@ struct DevParams {
 	float    partsurf;                       // d_partsurf: wall friction of planes
 	float    MK_K, MK_d, MK_beta;            // Monaghan-Kajtar repulsion
 	float    epsinterface;                   // SPH_GRENIER interface term
+	float    yield_strength[SPHX_MAX_FLUIDS], visc_nonlinear_param[SPHX_MAX_FLUIDS], visc_regularization_param[SPHX_MAX_FLUIDS];
+	float    limiting_kinvisc;               // generalized Newtonian rheologies
 	uint32_t mk_mask;                        // all ones when the repulsive boundary model is MK (boundarytype then reads LJ)
 	uint32_t numplanes;                       // geometric planes (src/planes.h:43-47, MAX_PLANES src/particledefine.h:325)
 	float    plane_normal[SPHX_MAX_PLANES][3];

@@ -171,6 +171,12 @@ public:
 		p.partsurf = pp->partsurf;
 		p.MK_K = pp->MK_K; p.MK_d = pp->MK_d; p.MK_beta = pp->MK_beta;
 		p.epsinterface = pp->epsinterface;
+		for (uint f = 0; f < MAX_FLUID_TYPES && f < SPHX_MAX_FLUIDS; ++f) {
+			p.yield_strength[f] = f < pp->yield_strength.size() ? pp->yield_strength[f] : 0.0f;
+			p.visc_nonlinear_param[f] = f < pp->visc_nonlinear_param.size() ? pp->visc_nonlinear_param[f] : 0.0f;
+			p.visc_regularization_param[f] = f < pp->visc_regularization_param.size() ? pp->visc_regularization_param[f] : 0.0f;
+		}
+		p.limiting_kinvisc = pp->limiting_kinvisc;
 	}
 
 	void upload(const SimParams *sp, const PhysParams *pp, float3 const& worldOrigin, uint3 const& gridSize,

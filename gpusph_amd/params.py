@@ -31,6 +31,8 @@ class SphxParams(C.Structure):
         ("is_const_visc", C.c_int32), ("partsurf", C.c_float),
         ("MK_K", C.c_float), ("MK_d", C.c_float), ("MK_beta", C.c_float),
         ("epsinterface", C.c_float),
+        ("yield_strength", C.c_float * 4), ("visc_nonlinear_param", C.c_float * 4),
+        ("visc_regularization_param", C.c_float * 4), ("limiting_kinvisc", C.c_float),
     ]
 
 
@@ -45,6 +47,13 @@ class PhysParams:
     visccoeff: list = field(default_factory=list)
     kinematicvisc: list = field(default_factory=list)      # nu per fluid (physparams.h:175)
     visc_consistency: list = field(default_factory=list)   # mu per fluid for Newtonian fluids
+    # generalized Newtonian rheologies (physparams.h:185-243): yield strength, power-law exponent / exponential coefficient,
+    # regularisation parameter per fluid; the effective viscosity is clamped to limiting_kinvisc (x rho0)
+    yield_strength: list = field(default_factory=list)
+    visc_nonlinear_param: list = field(default_factory=list)
+    visc_regularization_param: list = field(default_factory=list)
+    limiting_kinvisc: float = 1.0e3                         # physparams.h:395
+    rheologytype: int = 0                                   # PhysParams is built for the framework's rheology (physparams.h:380)
     partsurf: float = 0.0                                  # physparams.h:328,403 (0 -> r0^2 on upload)
     MK_K: float = float("nan")                             # physparams.h:336-338,405-407
     MK_d: float = float("nan")
@@ -72,26 +81,61 @@ class PhysParams:
         for lst in (self.bcoeff, self.gammacoeff, self.sscoeff, self.sspowercoeff, self.visccoeff,
                     self.kinematicvisc, self.visc_consistency):
             lst.append(float("nan"))
+        # the values that reduce back to a Newtonian rheology (physparams.h:469-480)
+        self.yield_strength.append(0.0)
+        self.visc_nonlinear_param.append(0.0 if self.rheologytype >= D.DEKEE_TURCOTTE else 1.0)
+        self.visc_regularization_param.append(1000.0)
         return len(self.rho0) - 1
+
+    def update_limiting_kinvisc(self, fluid_idx):
+        """physparams.h:599-603"""
+        new_limit = np.float32(self.yield_strength[fluid_idx]) * np.float32(self.visc_regularization_param[fluid_idx]) + \
+            np.float32(self.visc_consistency[fluid_idx])
+        self.limiting_kinvisc = float(np.fmax(np.float32(self.limiting_kinvisc), new_limit))      # fmaxf: a NaN operand loses
+
+    def set_consistency_index(self, fluid_idx, k):
+        self.set_dynamic_visc(fluid_idx, k)
+
+    def set_yield_strength(self, fluid_idx, ys):
+        self.yield_strength[fluid_idx] = float(np.float32(ys))
+        self.update_limiting_kinvisc(fluid_idx)
+
+    def set_visc_power_law(self, fluid_idx, n):
+        if not (D.POWER_LAW <= self.rheologytype < D.DEKEE_TURCOTTE):
+            raise ValueError("the rheological model is not power-law")          # must_be_power_law_rheology
+        self.visc_nonlinear_param[fluid_idx] = float(np.float32(n))
+
+    def set_visc_exponential_coeff(self, fluid_idx, t1):
+        if self.rheologytype < D.DEKEE_TURCOTTE:
+            raise ValueError("the rheological model is not exponential")
+        self.visc_nonlinear_param[fluid_idx] = float(np.float32(t1))
+
+    def set_visc_regularization_param(self, fluid_idx, m):
+        self.visc_regularization_param[fluid_idx] = float(np.float32(m))
+
+    def set_limiting_kinvisc(self, max_visc):
+        self.limiting_kinvisc = float(np.float32(max_visc))
 
     def set_kinematic_visc(self, fluid_idx, nu):
         """physparams.h:609-616"""
         nu = np.float32(nu)
         self.kinematicvisc[fluid_idx] = float(nu)
         self.visc_consistency[fluid_idx] = float(nu * np.float32(self.rho0[fluid_idx]))
+        self.update_limiting_kinvisc(fluid_idx)
 
     def set_dynamic_visc(self, fluid_idx, mu):
         """physparams.h:622-629"""
         mu = np.float32(mu)
         self.kinematicvisc[fluid_idx] = float(mu / np.float32(self.rho0[fluid_idx]))
         self.visc_consistency[fluid_idx] = float(mu)
+        self.update_limiting_kinvisc(fluid_idx)
 
     def update_visccoeff(self, sp):
         """GPUSPH::setViscosityCoefficient (src/GPUSPH.cc:1480-1508): what d_visccoeff holds"""
         for f in range(self.numFluids()):
             if sp.rheologytype == D.INVISCID:
                 self.visccoeff[f] = float("nan")
-            elif sp.compvisc == D.KINEMATIC:
+            elif sp.rheologytype == D.NEWTONIAN and sp.compvisc == D.KINEMATIC:
                 self.visccoeff[f] = self.kinematicvisc[f]
             else:
                 self.visccoeff[f] = self.visc_consistency[f]
@@ -227,4 +271,8 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
     p.partsurf = f32(pp.partsurf)
     p.MK_K = nz(pp.MK_K); p.MK_d = nz(pp.MK_d); p.MK_beta = nz(pp.MK_beta)
     p.epsinterface = nz(pp.epsinterface)
+    for f in range(pp.numFluids()):
+        p.yield_strength[f] = f32(pp.yield_strength[f]); p.visc_nonlinear_param[f] = f32(pp.visc_nonlinear_param[f])
+        p.visc_regularization_param[f] = f32(pp.visc_regularization_param[f])
+    p.limiting_kinvisc = f32(pp.limiting_kinvisc)
     return p

@@ -220,6 +220,7 @@ class Problem:
         opts.update(legacy[spec] if (spec is None or isinstance(spec, str)) else spec)
         for k, v in opts.items():
             setattr(sp, k, v)
+        self.physparams.rheologytype = sp.rheologytype      # PhysParams(rheologytype), physparams.h:380
 
     def initial_density(self, pos_global):
         """rho~ the problem starts from at the given global positions; also used to reset the state at the end of a
@@ -496,7 +497,8 @@ class Poiseuille(Problem):
     u(z) = F/(2 nu) (lz^2/4 - z^2) (compute_poiseuille_vel)."""
 
     def __init__(self, ppH=16, *, compvisc=D.KINEMATIC, viscavg=D.HARMONIC, rho=1.0, kinvisc=0.1, driving_force=0.05,
-                 density_diffusion=D.DENSITY_DIFFUSION_NONE, steady_init=False, linearization=D.DEFAULT_LINEARIZATION):
+                 density_diffusion=D.DENSITY_DIFFUSION_NONE, steady_init=False, linearization=D.DEFAULT_LINEARIZATION,
+                 rheology=D.NEWTONIAN, power_law_n=None, exponential_coeff=None, regularization=None):
         super().__init__()
         self.m_name = "Poiseuille"
         self.lz = self.ly = self.lx = 1.0
@@ -504,7 +506,11 @@ class Poiseuille(Problem):
         sp, pp = self.simparams, self.physparams
         sp.kerneltype = D.WENDLAND
         sp.boundarytype = D.DYN_BOUNDARY
-        self.set_viscosity(dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=compvisc, viscmodel=D.MORRIS,
+        # POISEUILLE_RHEOLOGY: NEWTONIAN (Poiseuille.cu) or a generalized Newtonian one (PoiseuillePapanastasiou.cu: PAPANASTASIOU)
+        self.rheology = rheology
+        yielding = rheology > D.NEWTONIAN and rheology not in (D.POWER_LAW, D.GRANULAR)        # YIELDING_RHEOLOGY
+        self.ys = float(np.float32(np.float32(driving_force) * np.float32(rho) * np.float32(self.lz) / np.float32(4))) if yielding else 0.0
+        self.set_viscosity(dict(rheologytype=rheology, turbmodel=D.LAMINAR_FLOW, compvisc=compvisc, viscmodel=D.MORRIS,
                                 avgop=viscavg))
         sp.densitydiffusiontype = density_diffusion
         sp.periodicbound = D.PERIODIC_X | D.PERIODIC_Y
@@ -515,6 +521,14 @@ class Poiseuille(Problem):
         pp.gravity = (self.driving_force, 0.0, 0.0)
         pp.add_fluid(self.rho)
         pp.set_kinematic_visc(0, self.kinvisc)
+        if yielding:
+            pp.set_yield_strength(0, self.ys)             # Poiseuille.inc:131-132
+        if power_law_n is not None:
+            pp.set_visc_power_law(0, power_law_n)
+        if exponential_coeff is not None:
+            pp.set_visc_exponential_coeff(0, exponential_coeff)
+        if regularization is not None:
+            pp.set_visc_regularization_param(0, regularization)
         self.max_vel = self.compute_poiseuille_vel(0.0)
         hydrostatic_vel = math.sqrt(2.0 * self.driving_force * self.lz)
         pp.set_equation_of_state(0, 7.0, 20.0 * max(hydrostatic_vel, self.max_vel))
@@ -556,14 +570,20 @@ class Poiseuille(Problem):
         self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)
 
     def compute_poiseuille_vel(self, z):
-        """Poiseuille::compute_poiseuille_vel for the Newtonian fluid (n = 1, no plug): Poiseuille.inc:153-195, in float
-        like the reference; scripts/validate-poiseuille.py:33-38 is the same formula in double"""
+        """Poiseuille::compute_poiseuille_vel for n = 1 (Newtonian, or Bingham-like with a plug of half-width
+        ys/(rho F)): Poiseuille.inc:187-229, in float like the reference (the reference evaluates the sheared branch with
+        z - plug, i.e. for z >= 0; |z| here); scripts/validate-poiseuille.py:33-38 is the Newtonian formula in double"""
         f32 = np.float32
+        plug = f32(f32(self.ys) / f32(f32(self.rho) * f32(self.driving_force))) if self.ys else f32(0.0)
         A = f32(f32(self.driving_force) / f32(self.kinvisc))
         A = f32(f32(1.0) * A) / f32(2.0)
-        B = f32(f32(self.lz) / f32(2.0)); B = f32(B * B)
-        C = f32(z); C = f32(C * C)
-        return float(f32(A * f32(B - C))) if abs(z) <= self.lz / 2 else 0.0
+        B = f32(f32(self.lz) / f32(2.0) - plug); B = f32(B * B)
+        if abs(z) > self.lz / 2:
+            return 0.0
+        if abs(z) < plug:
+            return float(f32(A * B))
+        C = f32(f32(abs(z)) - plug); C = f32(C * C)
+        return float(f32(A * f32(B - C)))
 
 
 class WaveTank(Problem):

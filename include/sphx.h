@@ -54,7 +54,8 @@ enum sphx_kernel      { SPHX_CUBICSPLINE = 1, SPHX_QUADRATIC = 2, SPHX_WENDLAND 
 enum sphx_formulation { SPHX_SPH_F1 = 1, SPHX_SPH_F2 = 2, SPHX_SPH_GRENIER = 3, SPHX_SPH_HA = 4 };
 enum sphx_densitydiff { SPHX_DENSITY_DIFFUSION_NONE = 0, SPHX_FERRARI = 1, SPHX_COLAGROSSI = 2, SPHX_BREZZI = 3 };
 enum sphx_boundary    { SPHX_LJ_BOUNDARY = 0, SPHX_MK_BOUNDARY = 1, SPHX_SA_BOUNDARY = 2, SPHX_DYN_BOUNDARY = 3 };
-enum sphx_rheology    { SPHX_INVISCID = 0, SPHX_NEWTONIAN = 1 };
+enum sphx_rheology    { SPHX_INVISCID = 0, SPHX_NEWTONIAN = 1, SPHX_GRANULAR = 2, SPHX_BINGHAM = 3, SPHX_PAPANASTASIOU = 4, SPHX_POWER_LAW = 5,
+	SPHX_HERSCHEL_BULKLEY = 6, SPHX_ALEXANDROU = 7, SPHX_DEKEE_TURCOTTE = 8, SPHX_ZHU = 9 };   /* RheologyType, src/visc_spec.h:44-56 */
 enum sphx_turbulence  { SPHX_LAMINAR_FLOW = 0, SPHX_ARTIFICIAL = 1, SPHX_SPS = 2, SPHX_KEPSILON = 3 };
 enum sphx_compvisc    { SPHX_KINEMATIC = 0, SPHX_DYNAMIC = 1 };                          /* src/visc_spec.h */
 enum sphx_viscmodel   { SPHX_MORRIS = 0, SPHX_MONAGHAN = 1, SPHX_ESPANOL_REVENGA = 2 };
@@ -119,6 +120,12 @@ typedef struct sphx_params {
 	/* SPH_GRENIER: interface pressure coefficient between different fluids (src/physparams.h epsinterface,
 	 * src/ProblemCore.cc:165-166 default 0.05; d_epsinterface src/cuda/forces_kernel.def:2237) */
 	float    epsinterface;
+	/* generalized Newtonian rheologies (rheologytype BINGHAM .. ZHU, src/visc_spec.h:44-56): per fluid the yield strength,
+	 * the power-law exponent or exponential coefficient, the regularisation parameter m (src/physparams.h:185-243,
+	 * uploaded by src/cuda/forces.cu:329-333); visccoeff[] then holds the consistency index (GPUSPH.cc:1503-1508);
+	 * limiting_kinvisc clamps the effective viscosity (x rho0) */
+	float    yield_strength[SPHX_MAX_FLUIDS], visc_nonlinear_param[SPHX_MAX_FLUIDS], visc_regularization_param[SPHX_MAX_FLUIDS];
+	float    limiting_kinvisc;
 } sphx_params;
 
 /* TimingInfo fields filled by getinfo (src/timing.h:43-100, src/cuda/buildneibs.cu:137-145) */

@@ -782,8 +782,10 @@ float orc_grad_gamma_vp(float slength, float qx, float qy, float qz, const orc_f
 static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *forces,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
 	const uint32_t *cellStart, const uint16_t *neibsList, const float *tauArray,
-	uint32_t fromParticle, uint32_t toParticle, const sa_forces_ctx *sa)
+	uint32_t fromParticle, uint32_t toParticle, const sa_forces_ctx *sa, const float *effvisc)
 {
+	/* effvisc: BUFFER_EFFVISC of the generalized Newtonian rheologies (get_laminar_visc_coeff :250-259), else NULL */
+	const int newtonian = p->rheologytype != ORC_INVISCID;      /* every viscous rheology has the laminar term */
 	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f; /* kernelradius */
 	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
 
@@ -971,8 +973,9 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				}
 				/* compute_laminar_visc_contrib, Newtonian + MORRIS (:2606-2625): fluid neighbours, and boundary neighbours
 				 * of DYN_BOUNDARY (wants_volumic_visc_term :150-158; LJ pairs never get here) */
-				if (p->rheologytype == ORC_NEWTONIAN) {
-					const float visc = visc_avg(p, p->visccoeff[p_fluid], p->visccoeff[n_fluid], p_rho, n_rho, nmass);
+				if (newtonian) {
+					const float visc = effvisc ? visc_avg(p, effvisc[index], effvisc[neib_index], p_rho, n_rho, nmass) :
+						visc_avg(p, p->visccoeff[p_fluid], p->visccoeff[n_fluid], p_rho, n_rho, nmass);
 					const float vf = visc*f;
 					DvDt[0] += vf*vx; DvDt[1] += vf*vy; DvDt[2] += vf*vz;
 				}
@@ -1019,7 +1022,7 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	orc_f4 *rbforces, orc_f4 *rbtorques,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
 	uint32_t fromParticle, uint32_t toParticle, uint32_t numBlocks, uint32_t cflOffset, const sa_forces_ctx *sa,
-	const float *sigma)
+	const float *sigma, const float *effvisc)
 {
 	const int dtadapt = !!(p->simflags & ORC_ENABLE_DTADAPT);
 #pragma omp parallel for schedule(static)
@@ -1057,8 +1060,9 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 				 * (src/cuda/geom_core.cu:63-85, cellgrid.cuh:153-161).  Inviscid: the wall-friction coefficient is
 				 * -0 (viscous_plane_coefficient :3103-3107), only the Lennard-Jones repulsion along the normal acts;
 				 * Newtonian: get_laminar_dyn_visc (:322-340) = nu rho or mu. */
-				const float dynvisc = (p->rheologytype == ORC_NEWTONIAN) ?
-					(p->compvisc == ORC_KINEMATIC ? p->visccoeff[fl]*physical_density(p, vel.w, fl) : p->visccoeff[fl]) : 0.0f;
+				const float lamvisc = effvisc ? effvisc[index] : p->visccoeff[fl];
+				const float dynvisc = (p->rheologytype != ORC_INVISCID) ?
+					(p->compvisc == ORC_KINEMATIC ? lamvisc*physical_density(p, vel.w, fl) : lamvisc) : 0.0f;
 				if ((p->simflags & ORC_ENABLE_PLANES) && p->numplanes) {
 					int gp[3];
 					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
@@ -1112,6 +1116,24 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 }
 
 /* run_forces: src/cuda/forces.cu:717-806 */
+uint32_t orc_forces_effvisc(const orc_params *p, orc_f4 *forces, float *cfl,
+	orc_f4 *rbforces, orc_f4 *rbtorques,
+	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *tau,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	uint32_t cflOffset, int compute_object_forces, const float *effvisc)
+{
+	(void)numParticles;
+	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
+	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL, effvisc);
+	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL, effvisc);
+	if (compute_object_forces || p->boundarytype == ORC_DYN_BOUNDARY)
+		forces_pass(p, PT_BOUNDARY, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL, effvisc);
+	finalize_forces(p, forces, cfl, rbforces, rbtorques, pos, vel, info, hash,
+		fromParticle, toParticle, numBlocks, cflOffset, NULL, NULL, effvisc);
+	return numBlocks;
+}
+
 uint32_t orc_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	orc_f4 *rbforces, orc_f4 *rbtorques,
 	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
@@ -1119,15 +1141,8 @@ uint32_t orc_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
 	uint32_t cflOffset, int compute_object_forces)
 {
-	(void)numParticles;
-	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
-	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL);
-	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL);
-	if (compute_object_forces || p->boundarytype == ORC_DYN_BOUNDARY)
-		forces_pass(p, PT_BOUNDARY, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, tau, fromParticle, toParticle, NULL);
-	finalize_forces(p, forces, cfl, rbforces, rbtorques, pos, vel, info, hash,
-		fromParticle, toParticle, numBlocks, cflOffset, NULL, NULL);
-	return numBlocks;
+	return orc_forces_effvisc(p, forces, cfl, rbforces, rbtorques, pos, vel, info, hash, cellStart, neibsList, tau,
+		numParticles, fromParticle, toParticle, cflOffset, compute_object_forces, NULL);
 }
 
 /* run_forces with SA_BOUNDARY (solid walls, no k-epsilon, no moving bodies): fluid <- fluid, fluid <- vertex, then
@@ -1145,10 +1160,10 @@ uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *c
 	if (gcfl) memset(cflGamma + fromParticle, 0, sizeof(float)*(toParticle - fromParticle));
 	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL };
 	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
-	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
-	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
-	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa);
-	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, &sa, NULL);
+	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
+	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
+	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
+	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, &sa, NULL, NULL);
 	if (gcfl) {      /* per-block maxima behind the per-particle values */
 		float *blocks = cflGamma + round_up(numParticles, 4u) + cflOffset;
 		for (uint32_t b = 0; b < numBlocks; ++b) {
@@ -1325,7 +1340,7 @@ uint32_t orc_forces_grenier(const orc_params *p, orc_f4 *forces, float *cfl,
 	grenier_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, sigma, fromParticle, toParticle);
 	if (p->boundarytype == ORC_DYN_BOUNDARY)
 		grenier_pass(p, PT_BOUNDARY, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, sigma, fromParticle, toParticle);
-	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, NULL, sigma);
+	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, NULL, sigma, NULL);
 	return numBlocks;
 }
 
@@ -1518,6 +1533,112 @@ void orc_sps(const orc_params *p, float *tau, float *turbvisc,
 }
 
 /* ---- eulerDevice<step>: src/cuda/euler_kernel.def:396-538 --------------------------- */
+/* ==== generalized Newtonian rheologies (BINGHAM .. ZHU): effectiveViscDevice (src/cuda/visc_kernel.cu:655-713) =========
+ * Per particle (every type, non-SA): the shear rate norm S = sqrt(D:D/2) from the velocity gradient over all neighbours
+ * (shearRate<MIXED_TENSOR> :307-367, shearRateNorm2 :383-407), then
+ *   mu_eff = shear term (k, k S^(n-1) or k exp(-t1 S); viscShearTerm :501-531) + yield term (tau_0/S, or regularised
+ *            tau_0 (1 - exp(-m S))/S with an 8th-order Horner form below m S = 1; viscYieldTerm :454-497),
+ *   clamped to limiting_kinvisc rho0 (clamp_visc :561-569); stored as it is (compvisc DYNAMIC) or divided by the density
+ *   (KINEMATIC) (store_effective_visc :605-620).  Returns the largest kinematic viscosity (the per-block reduction into the
+ *   CFL array + cflmax of src/cuda/visc.cu:86-170), which GPUWorker hands to dtreduce (src/GPUWorker.cc:2633-2645,2013-2030). */
+static float horner_one_minus_exp_minus_over8(float x)
+{
+	/* horner_one_minus_exp_minus_over<8> :420-451: (1 - x/2 (1 - x/3 (... (1 - x/9)))) */
+	float inner = fmaf(x, -1.0f/(8 + 1.0f), 1.0f);
+	for (int order = 7; order >= 2; --order)
+		inner = fmaf(x*inner, -1.0f/(order + 1.0f), 1.0f);
+	return fmaf(x*inner, -0.5f, 1.0f);
+}
+
+float orc_effective_visc_value(const orc_params *p, float S, int fluid)
+{
+	const int rh = p->rheologytype;
+	float effvisc = 0.0f;
+	if (p->visccoeff[fluid] != 0.0f) {
+		if (rh >= ORC_DEKEE_TURCOTTE) effvisc += p->visccoeff[fluid]*expf(-p->visc_nonlinear_param[fluid]*S);
+		else if (rh >= ORC_POWER_LAW) effvisc += p->visccoeff[fluid]*powf(S, p->visc_nonlinear_param[fluid] - 1);
+		else effvisc += p->visccoeff[fluid];
+	}
+	if (p->yield_strength[fluid] != 0.0f) {
+		const int reg = rh == ORC_PAPANASTASIOU || rh == ORC_ALEXANDROU || rh == ORC_ZHU;
+		const int yielding = rh > ORC_NEWTONIAN && rh != ORC_POWER_LAW && rh != ORC_GRANULAR;
+		if (reg) {
+			const float m = p->visc_regularization_param[fluid];
+			const float mx = m*S;
+			float r;
+			if (mx < 1) r = m*horner_one_minus_exp_minus_over8(mx);
+			else r = (1 - expf(-mx))/S;
+			effvisc += p->yield_strength[fluid]*r;
+		} else if (yielding)
+			effvisc += p->yield_strength[fluid]/S;
+	}
+	return fminf(effvisc, p->limiting_kinvisc*p->rho0[fluid]);
+}
+
+float orc_effective_visc(const orc_params *p, float *effviscArray, float *cfl,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t particleRangeEnd)
+{
+	(void)numParticles;
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, kr);
+	const uint32_t numBlocks = round_up(div_up(particleRangeEnd, BLOCK_SIZE_FORCES), 4u);     /* BLOCK_SIZE_SPS = 128 as well */
+	float *kin = (float*)calloc(particleRangeEnd ? particleRangeEnd : 1, sizeof(float));
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		const orc_f4 vel = velArray[index];
+		const int fluid = FLUID_NUM(info);
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		float dvx[3] = {0,0,0}, dvy[3] = {0,0,0}, dvz[3] = {0,0,0};
+		for (int ptype = PT_FLUID; ptype <= PT_BOUNDARY; ++ptype) {
+			neib_iter it;
+			neib_iter_init(&it, p, ptype, index, &pos, gridPos, cellStart, neibsList);
+			uint32_t neib_index;
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 npos = posArray[neib_index];
+				const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+				const float r = sqrtf(sqlength3(rx, ry, rz));
+				if (!isfinite(npos.w) || r >= p->influenceradius) continue;
+				const orc_f4 nvel = velArray[neib_index];
+				const float n_rho = physical_density(p, nvel.w, FLUID_NUM(infoArray[neib_index]));
+				const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+				const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+				const float weight = f*npos.w/n_rho;
+				const float mx = rx*weight, my = ry*weight, mz = rz*weight;
+				dvx[0] -= vx*mx; dvx[1] -= vx*my; dvx[2] -= vx*mz;
+				dvy[0] -= vy*mx; dvy[1] -= vy*my; dvy[2] -= vy*mz;
+				dvz[0] -= vz*mx; dvz[1] -= vz*my; dvz[2] -= vz*mz;
+			}
+		}
+		const float txx = dvx[0], txy = dvx[1] + dvy[0], txz = dvx[2] + dvz[0];
+		const float tyy = dvy[1], tyz = dvy[2] + dvz[1], tzz = dvz[2];
+		float diag_terms = txx*txx + tyy*tyy + tzz*tzz;
+		diag_terms *= 2.0f;
+		const float off_terms = txy*txy + txz*txz + tyz*tyz;
+		const float S = sqrtf(diag_terms + off_terms);
+		const float effvisc = orc_effective_visc_value(p, S, fluid);
+		const float kinvisc = effvisc/physical_density(p, vel.w, fluid);
+		effviscArray[index] = (p->compvisc == ORC_KINEMATIC) ? kinvisc : effvisc;
+		kin[index] = kinvisc;
+	}
+	float mx = 0.0f;
+	for (uint32_t b = 0; b < numBlocks; ++b) {
+		float m = 0.0f;
+		for (uint32_t t = 0; t < BLOCK_SIZE_FORCES; ++t) {
+			const uint32_t i = b*BLOCK_SIZE_FORCES + t;
+			if (i < particleRangeEnd) m = fmaxf(m, kin[i]);
+		}
+		if (cfl) cfl[b] = m;
+		mx = fmaxf(mx, m);
+	}
+	free(kin);
+	return (p->simflags & ORC_ENABLE_DTADAPT) ? mx : NAN;
+}
+
 static void euler_body(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 	const orc_f4 *oldPos, const orc_f4 *oldVel, const orc_info *infoArray, const uint32_t *hashArray,
 	const orc_f4 *forces, const orc_f4 *xsph,

@@ -30,6 +30,8 @@ class OrcParams(C.Structure):
         ("is_const_visc", C.c_int32), ("partsurf", C.c_float),
         ("MK_K", C.c_float), ("MK_d", C.c_float), ("MK_beta", C.c_float),
         ("epsinterface", C.c_float),
+        ("yield_strength", C.c_float * 4), ("visc_nonlinear_param", C.c_float * 4),
+        ("visc_regularization_param", C.c_float * 4), ("limiting_kinvisc", C.c_float),
         ("numplanes", C.c_uint32),
         ("plane_normal", (C.c_float * 3) * 8), ("plane_gridpos", (C.c_int32 * 3) * 8), ("plane_pos", (C.c_float * 3) * 8),
         ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),
@@ -69,6 +71,9 @@ def lib():
         _lib.orc_forces.restype = C.c_uint32
         _lib.orc_forces_sa.restype = C.c_uint32
         _lib.orc_forces_grenier.restype = C.c_uint32
+        _lib.orc_forces_effvisc.restype = C.c_uint32
+        _lib.orc_effective_visc.restype = C.c_float
+        _lib.orc_effective_visc_value.restype = C.c_float; _lib.orc_effective_visc_value.argtypes = [C.c_void_p, C.c_float, C.c_int]
         _lib.orc_sa_gamma_dt.restype = C.c_float; _lib.orc_sa_gamma_dt.argtypes = [C.c_float, C.c_float]
         _lib.orc_dtreduce.restype = C.c_float
         _lib.orc_dtreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float]
@@ -283,18 +288,28 @@ class Oracle:
         self.L.orc_sa_vertex_bc(C.byref(self.p), P(v), P(ggam), P(pos), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n))
         return v
 
+    def effective_visc(self, pos, vel, info, hash_, cs, nl, n, range_end=None):
+        """CALC_VISC of the generalized Newtonian rheologies: (effvisc per particle, largest kinematic viscosity)"""
+        range_end = n if range_end is None else range_end
+        eff = np.zeros(len(pos), dtype=np.float32)
+        nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
+        cfl = np.zeros(nblk, dtype=np.float32)
+        mx = self.L.orc_effective_visc(C.byref(self.p), P(eff), P(cfl), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl),
+                                       C.c_uint32(n), C.c_uint32(range_end))
+        return eff, float(mx)
+
     def forces(self, pos, vel, info, hash_, cs, nl, n, frm=0, to=None, cfl_offset=0, compute_object_forces=0,
-               rb_count=0, tau=None):
+               rb_count=0, tau=None, effvisc=None):
         to = n if to is None else to
         forces = np.zeros((len(pos), 4), dtype=np.float32)
         nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
         cfl = np.zeros(nblk + cfl_offset, dtype=np.float32)
         rbf = np.zeros((max(rb_count, 1), 4), dtype=np.float32)
         rbt = np.zeros((max(rb_count, 1), 4), dtype=np.float32)
-        nb = self.L.orc_forces(C.byref(self.p), P(forces), P(cfl), P(rbf) if rb_count else None,
-                               P(rbt) if rb_count else None, P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), P(tau),
-                               C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
-                               C.c_int(compute_object_forces))
+        nb = self.L.orc_forces_effvisc(C.byref(self.p), P(forces), P(cfl), P(rbf) if rb_count else None,
+                                       P(rbt) if rb_count else None, P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), P(tau),
+                                       C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
+                                       C.c_int(compute_object_forces), P(effvisc))
         return forces, cfl, int(nb), rbf, rbt
 
     # ---- SPH_GRENIER (oracle/sph_oracle.c "SPH_GRENIER")
@@ -429,6 +444,7 @@ class OracleSim:
         self.neibs_info = None
         self.bodies = None
         self.grenier = sp.sph_formulation == D.SPH_GRENIER
+        self.effvisc_on = sp.rheologytype > D.NEWTONIAN         # NEEDS_EFFECTIVE_VISC
         if self.grenier:    # GPUSPH.cc:495-496
             self.vol = self.o.init_volume(self.pos, self.vel, self.info, self.n)
         if getattr(problem, "moving_bodies_callback", None) is not None and getattr(problem, "num_obstacle", 0):
@@ -517,8 +533,12 @@ class OracleSim:
         tau = o.sps(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n, n)[0] if sps else None
         if self.grenier:
             return self._grenier_step(n, dt)
+        ev = None
+        if self.effvisc_on:    # CALC_VISC: effective viscosity of the state the forces read; its maximum limits dt (GPUWorker.cc:2633-2645)
+            ev, self.max_kinvisc = o.effective_visc(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n)
+            self.effvisc = ev
         f1, cfl, nb, self.rbf, self.rbt = o.forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n,
-                                                   compute_object_forces=cof, rb_count=rb, tau=tau)
+                                                   compute_object_forces=cof, rb_count=rb, tau=tau, effvisc=ev)
         dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
         xsph_on = bool(sp.simflags & self.D.ENABLE_XSPH)
         if xsph_on:     # BUFFER_XSPH is allocated once and rewritten for the fluid particles by every forces pass
@@ -529,8 +549,10 @@ class OracleSim:
         ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1, xsph=xs)
         # corrector
         tau = o.sps(ps, vs, self.info, self.hash, self.cs, self.nl, n, n)[0] if sps else None
+        if self.effvisc_on:
+            ev, self.max_kinvisc = o.effective_visc(ps, vs, self.info, self.hash, self.cs, self.nl, n)
         f2, cfl, nb, self.rbf, self.rbt = o.forces(ps, vs, self.info, self.hash, self.cs, self.nl, n,
-                                                   compute_object_forces=cof, rb_count=rb, tau=tau)
+                                                   compute_object_forces=cof, rb_count=rb, tau=tau, effvisc=ev)
         dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
         if xsph_on:
             self.xsph = o.xsph(ps, vs, self.info, self.hash, self.cs, self.nl, n, self.xsph)
