@@ -163,7 +163,7 @@ __device__ __forceinline__ void init_visc(const DevParams &p, Self &s)
 	// a single-fluid framework forced to non-constant KINEMATIC viscosity: the reference's with_computational_visc<DYNAMIC>
 	// re-derives is_const_visc = true (src/visc_spec.h:268-272,298-300, src/cuda/visc_avg.cu:180-190) and evaluates the
 	// constant dynamic formula 2 mu_i/(rho_i rho_j): mu_j := mu_i with the arithmetic weights (pinned by ref_viscavg.npz)
-	const bool own = !p.is_const_visc && p.compvisc == SPHX_KINEMATIC && !(p.simflags & SPHX_ENABLE_MULTIFLUID);
+	const bool own = !p.is_const_visc && p.compvisc == SPHX_KINEMATIC && !(p.simflags & SPHX_ENABLE_MULTIFLUID) && p.rheology == SPHX_NEWTONIAN;
 	uint32_t om = own ? 0xFFFFFFFFu : 0u;
 	if (own) { wA = 1.0f; wH = 0.0f; wG = 0.0f; }
 	asm volatile("" : "+v"(c), "+v"(cm), "+v"(kin), "+v"(wA), "+v"(wH), "+v"(wG), "+v"(om));   // keep them per-lane values
@@ -1722,6 +1722,10 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: invalid run mode");
 	if (ctx->dev.boundarytype != SPHX_DYN_BOUNDARY && ctx->dev.boundarytype != SPHX_LJ_BOUNDARY)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: only DYN_BOUNDARY and LJ_BOUNDARY pair interactions are built");
+	if (ctx->params.rheologytype > SPHX_NEWTONIAN && run_mode == SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: generalized Newtonian rheologies read BUFFER_EFFVISC, use sphx_forces_basicstep_effvisc");
+	if (ctx->params.sph_formulation == SPHX_SPH_GRENIER && run_mode == SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: SPH_GRENIER reads BUFFER_SIGMA, use sphx_forces_basicstep_grenier");
 	if (ctx->dev.turbmodel == SPHX_SPS && run_mode == SPHX_SIMULATE)
 		SPHX_REQUIRE(tau0 && tau1 && tau2, "sphx_forces_basicstep: SPS needs the three TAU arrays");
 	if ((ctx->dev.simflags & SPHX_ENABLE_DTADAPT))

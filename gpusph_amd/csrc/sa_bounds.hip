@@ -392,33 +392,7 @@ struct SaForcesArgs {
 	float deltap;
 };
 
-__device__ __forceinline__ float sa_dot3(float ax, float ay, float az, float bx, float by, float bz)
-{ return fmaf(az, bz, fmaf(ay, by, ax*bx)); }
-__device__ __forceinline__ float sa_P(const DevParams &p, float rho_tilde, uint32_t fl)
-{ return p.bcoeff[fl]*(powf(rho_tilde + 1.0f, p.gammacoeff[fl]) - 1.0f); }
-__device__ __forceinline__ float sa_sound_speed(const DevParams &p, float rho_tilde, uint32_t fl)
-{ return p.sscoeff[fl]*powf(rho_tilde + 1.0f, p.sspowercoeff[fl]); }
-
-// visc_avg<ViscSpec> (src/cuda/visc_avg.cu:40-190), neighbour mass included
-__device__ __forceinline__ float sa_visc_avg_rho(int avgop, float rho, float neib_rho, float neib_mass)
-{
-	if (avgop == SPHX_ARITHMETIC) return neib_mass*(rho + neib_rho)/(rho*neib_rho);
-	if (avgop == SPHX_HARMONIC) return 4*neib_mass/(rho + neib_rho);
-	return 2*neib_mass*(1.0f/sqrtf(rho*neib_rho));
-}
-__device__ __forceinline__ float sa_visc_avg_dyn(int avgop, bool is_const, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
-{
-	if (is_const) return 2*neib_mass*visc/(rho*neib_rho);
-	if (avgop == SPHX_ARITHMETIC) return neib_mass*(visc + neib_visc)/(rho*neib_rho);
-	if (avgop == SPHX_HARMONIC) return 4*neib_mass*(visc*neib_visc)/(visc + neib_visc)/(rho*neib_rho);
-	return 2*neib_mass*sqrtf(visc*neib_visc)/(rho*neib_rho);
-}
-__device__ __forceinline__ float sa_visc_avg(const DevParams &p, float visc, float neib_visc, float rho, float neib_rho, float neib_mass)
-{
-	if (p.compvisc == SPHX_DYNAMIC) return sa_visc_avg_dyn(p.avgop, p.is_const_visc, visc, neib_visc, rho, neib_rho, neib_mass);
-	if (p.is_const_visc) return visc*sa_visc_avg_rho(p.avgop, rho, neib_rho, neib_mass);
-	return sa_visc_avg_dyn(p.avgop, !(p.simflags & SPHX_ENABLE_MULTIFLUID), visc*rho, neib_visc*neib_rho, rho, neib_rho, neib_mass);
-}
+// sa_dot3, sa_P, sa_sound_speed, sa_visc_avg: neib_iter.h (shared with the other fidelity engines)
 
 __global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
 sa_forces_kernel(DevParams p, SaForcesArgs a)

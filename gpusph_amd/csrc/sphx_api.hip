@@ -211,9 +211,19 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	if (sp->densitydiffusiontype != SPHX_DENSITY_DIFFUSION_NONE && sp->densitydiffusiontype != SPHX_COLAGROSSI &&
 		sp->densitydiffusiontype != SPHX_FERRARI && sp->boundarytype != SPHX_SA_BOUNDARY)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: Brezzi density diffusion (an SA_BOUNDARY option in the reference's problems) is not built");
-	if (sp->rheologytype != SPHX_INVISCID && sp->rheologytype != SPHX_NEWTONIAN)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only INVISCID and NEWTONIAN rheologies are built");
-	if (sp->rheologytype == SPHX_NEWTONIAN) {
+	if (sp->rheologytype < SPHX_INVISCID || sp->rheologytype > SPHX_ZHU || sp->rheologytype == SPHX_GRANULAR)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: INVISCID, NEWTONIAN and the generalized Newtonian rheologies (BINGHAM .. ZHU) are built, GRANULAR is not");
+	if (sp->rheologytype > SPHX_NEWTONIAN) {
+		// rheology.hip: effective viscosity + the forces that read it
+		if (sp->sph_formulation != SPHX_SPH_F1 || sp->boundarytype != SPHX_DYN_BOUNDARY || sp->turbmodel != SPHX_LAMINAR_FLOW)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies are built for SPH_F1, DYN_BOUNDARY and LAMINAR_FLOW");
+		SPHX_REQUIRE(sp->limiting_kinvisc == sp->limiting_kinvisc, "sphx_set_constants: generalized Newtonian rheologies need limiting_kinvisc");
+		for (uint32_t f = 0; f < sp->numfluids; ++f)
+			SPHX_REQUIRE(sp->yield_strength[f] == sp->yield_strength[f] && sp->visc_nonlinear_param[f] == sp->visc_nonlinear_param[f] &&
+				sp->visc_regularization_param[f] == sp->visc_regularization_param[f],
+				"sphx_set_constants: generalized Newtonian rheologies need yield_strength / visc_nonlinear_param / visc_regularization_param for every fluid");
+	}
+	if (sp->rheologytype >= SPHX_NEWTONIAN) {
 		if (sp->viscmodel != SPHX_MORRIS)
 			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only the MORRIS viscous model is built");
 		if (sp->turbmodel == SPHX_ARTIFICIAL)

@@ -78,7 +78,8 @@ int main(int argc, char **argv)
 		const float slength = (float)sp->slength, influenceRadius = (float)sp->influenceRadius;
 		const float sqNlRadius = (float)sp->nlSqInfluenceRadius;
 		const uint steps = (uint)num(c, "steps");
-		const float sspeed_cfl = (float)num(c, "sspeed_cfl"), max_kinvisc = (float)num(c, "max_kinvisc");
+		const float sspeed_cfl = (float)num(c, "sspeed_cfl");
+		float max_kinvisc = (float)num(c, "max_kinvisc");     // GPUWorker::m_max_kinvisc: constant, or what calc_visc returns
 
 		// ---- initial particle state ----
 		FILE *f = fopen(argv[2], "rb");
@@ -176,6 +177,8 @@ int main(int argc, char **argv)
 			shared |= one_buffer<BUFFER_TAU>(A) | one_buffer<BUFFER_SPS_TURBVISC>(A);
 		if (sp->simflags & ENABLE_XSPH)
 			shared |= one_buffer<BUFFER_XSPH>(A);
+		if (NEEDS_EFFECTIVE_VISC(sp->rheologytype))
+			shared |= one_buffer<BUFFER_EFFVISC>(A);
 		sphx_throw(sphx_memcpy_h2d(posA.getData<BUFFER_POS>(), hpos.data(), 16*(size_t)n0));
 		sphx_throw(sphx_memcpy_h2d(velA.getData<BUFFER_VEL>(), hvel.data(), 16*(size_t)n0));
 		sphx_throw(sphx_memcpy_h2d(shared.getData<BUFFER_INFO>(), hinfo.data(), 8*(size_t)n0));
@@ -338,8 +341,10 @@ int main(int argc, char **argv)
 				BufferList state = (step == 1) ? (*curPos | *curVel | *curVol | shared) : (*othPos | *othVel | *othVol | shared);
 				if (grenier)                                                          // COMPUTE_DENSITY (:443-458): VEL in place, SIGMA
 					forcesEngine->compute_density(state, state, n, slength, influenceRadius);
-				if (sp->turbmodel == SPS)                                             // CALC_VISC
-					viscEngine->calc_visc(state, state, n, n, deltap, slength, influenceRadius);
+				if (sp->turbmodel == SPS || NEEDS_EFFECTIVE_VISC(sp->rheologytype)) {   // CALC_VISC (GPUWorker.cc:2633-2645)
+					const float mk = viscEngine->calc_visc(state, state, n, n, deltap, slength, influenceRadius);
+					if (!std::isnan(mk)) max_kinvisc = mk;
+				}
 				shared[BUFFER_FORCES]->clobber(); shared[BUFFER_CFL]->clobber();      // pre_forces
 				forcesEngine->bind_textures(state, n, SIMULATE);
 				const uint nb = forcesEngine->basicstep(state, state, n, 0, n, deltap, slength, sp->dtadaptfactor,

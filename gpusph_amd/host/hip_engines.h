@@ -427,6 +427,18 @@ public:
 				cflOffset, (int)run_mode, step, dt, &nb, NULL));
 			return nb;
 		}
+		if (NEEDS_EFFECTIVE_VISC(P.rheologytype) && run_mode == SIMULATE) {
+			// effective_visc_forces_params (src/cuda/forces_params.h): the viscosity of every particle from BUFFER_EFFVISC
+			if (compute_object_forces)
+				sphx_not_built("forces basicstep: generalized Newtonian rheologies with bodies that feel the fluid (BUFFER_RB_FORCES)");
+			uint32_t nb = 0;
+			sphx_throw(sphx_forces_basicstep_effvisc(m_c->ctx(), forces, cfl,
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+				bufread.getData<BUFFER_EFFVISC>(), numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor,
+				influenceradius, cflOffset, (int)run_mode, step, dt, &nb, NULL));
+			return nb;
+		}
 		if (P.sph_formulation == SPH_GRENIER && run_mode == SIMULATE) {
 			// grenier_forces_params (src/cuda/forces_params.h:224-240): sigma of the state that is read
 			if (compute_object_forces)
@@ -488,8 +500,18 @@ public:
 		const uint particleRangeEnd, const float deltap, const float slength, const float influenceradius)
 	{
 		const sphx_params &P = m_c->params();
-		if (P.rheologytype != INVISCID && P.rheologytype != NEWTONIAN)
-			sphx_not_built("calc_visc for generalized Newtonian / granular rheologies");
+		if (P.rheologytype == GRANULAR)
+			sphx_not_built("calc_visc for the granular rheology");
+		if (NEEDS_EFFECTIVE_VISC(P.rheologytype)) {
+			// effective viscosity of the generalized Newtonian rheologies (src/cuda/visc.cu:86-170): BUFFER_EFFVISC written, the
+			// largest kinematic viscosity returned for the viscous limit of dt
+			float max_kinvisc = NAN;
+			sphx_throw(sphx_calc_effvisc(m_c->ctx(), bufwrite.getData<BUFFER_EFFVISC>(), &max_kinvisc,
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+				numParticles, particleRangeEnd, deltap, slength, influenceradius, NULL));
+			return max_kinvisc;
+		}
 		if (P.turbmodel != SPS)
 			return NAN;
 		float2 **tau = bufwrite.getRawPtr<BUFFER_TAU>();

@@ -28,6 +28,8 @@ struct ProblemPhysParams : PhysParams {
 	using PhysParams::add_fluid; using PhysParams::set_equation_of_state;
 	using PhysParams::set_kinematic_visc; using PhysParams::set_dynamic_visc;
 	using PhysParams::set_artificial_visc;
+	using PhysParams::set_yield_strength; using PhysParams::set_visc_power_law; using PhysParams::set_visc_exponential_coeff;
+	using PhysParams::set_visc_regularization_param; using PhysParams::is_exponential_rheology;
 };
 
 typedef std::map<std::string, std::vector<std::string> > Case;
@@ -172,6 +174,24 @@ static SimFramework *make_framework(Case const& c)
 			densitydiffusion<BREZZI>,
 			add_flags<ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES>
 		);
+	} else if (name == "PoiseuillePapanastasiou") {   // src/problems/Poiseuille.inc:102-119 with POISEUILLE_RHEOLOGY = PAPANASTASIOU
+		const DensityDiffusionType RHODIFF = (DensityDiffusionType)(int)num(c, "rhodiff");
+		const ComputationalViscosityType compvisc = (ComputationalViscosityType)(int)num(c, "compvisc");
+		const AverageOperator viscavg = (AverageOperator)(int)num(c, "viscavg");
+		SETUP_FRAMEWORK(
+			kernel<WENDLAND>,
+			rheology<PAPANASTASIOU>,
+			turbulence_model<LAMINAR_FLOW>,
+			computational_visc<KINEMATIC>,
+			visc_model<MORRIS>,
+			visc_average<ARITHMETIC>,
+			periodicity<PERIODIC_XY>,
+			boundary<DYN_BOUNDARY>
+		).select_options
+			( RHODIFF  // switch to the user-selected density diffusion
+			, compvisc // switch to the user-selected computational viscosity
+			, viscavg  // switch to the user-selected viscous averaging operator
+			);
 	} else if (name == "GenericRuntime") { // every selector named (src/problems/GenericProblem.cu:55-65), kernel and periodicity chosen at run time
 		simframework = CUDASimFramework<
 			kernel<CUBICSPLINE>,
@@ -217,6 +237,15 @@ static void configure_params(Case const& c, SimParams *sp, ProblemPhysParams &pp
 		const std::string kind = c.at(key).at(3);
 		if (kind == "kin") pp.set_kinematic_visc(f, (float)num(c, key.c_str(), 4));
 		else if (kind == "dyn") pp.set_dynamic_visc(f, (float)num(c, key.c_str(), 4));
+		// generalized Newtonian parameters (Poiseuille.inc:131-132 sets the yield strength; the others keep their defaults
+		// unless the case says otherwise)
+		const std::string rkey = "rheology" + std::to_string(f);     // yield strength, nonlinear parameter (NaN: keep), m (NaN: keep)
+		if (has(c, rkey.c_str())) {
+			pp.set_yield_strength(f, (float)num(c, rkey.c_str(), 0));
+			const float nl = (float)num(c, rkey.c_str(), 1), m = (float)num(c, rkey.c_str(), 2);
+			if (!std::isnan(nl)) { if (pp.is_exponential_rheology()) pp.set_visc_exponential_coeff(f, nl); else pp.set_visc_power_law(f, nl); }
+			if (!std::isnan(m)) pp.set_visc_regularization_param(f, m);
+		}
 	}
 	pp.gravity = make_float3((float)num(c, "gravity", 0), (float)num(c, "gravity", 1), (float)num(c, "gravity", 2));
 	if (has(c, "artvisccoeff")) pp.set_artificial_visc((float)num(c, "artvisccoeff"));

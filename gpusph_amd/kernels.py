@@ -231,6 +231,29 @@ class HipKernels:
                                                  p(forces), p(xsph), n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
                                                  P.slength, P.influenceradius, run_mode, self._s()))
 
+    # ---- generalized Newtonian rheologies (rheology.hip)
+    def calc_effvisc(self, effvisc, pos, vel, info, hash_, cellStart, neibslist, n, range_end):
+        """CALC_VISC: BUFFER_EFFVISC written; returns the largest kinematic viscosity (one host synchronisation) and makes it
+        the viscous limit of the following dt reductions, as GPUWorker does with calc_visc's return value"""
+        p = capi.ptr
+        P = self.params
+        mx = C.c_float(0.0)
+        capi.check(self.lib.sphx_calc_effvisc(self.ctx.handle, p(effvisc), C.byref(mx), p(pos), p(vel), p(info), p(hash_), p(cellStart),
+                                              p(neibslist), n, range_end, P.deltap, P.slength, P.influenceradius, self._s()))
+        if mx.value == mx.value:
+            self.max_kinvisc = float(mx.value)
+        return float(mx.value)
+
+    def forces_effvisc(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, effvisc, n, frm, to, cfl_offset=0):
+        p = capi.ptr
+        P = self.params
+        nb = C.c_uint32(0)
+        capi.check(self.lib.sphx_forces_basicstep_effvisc(self.ctx.handle, p(forces), p(cfl), p(pos), p(vel), p(info), p(hash_),
+                                                          p(cellStart), p(neibslist), p(effvisc), n, frm, to, P.deltap, P.slength,
+                                                          P.dtadaptfactor, P.influenceradius, cfl_offset, D.SIMULATE, 1, 0.0,
+                                                          C.byref(nb), self._s()))
+        return int(nb.value)
+
     # ---- SPH_GRENIER (grenier.hip)
     def init_volume(self, vol, pos, vel, info, n):
         p = capi.ptr

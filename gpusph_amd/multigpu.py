@@ -86,6 +86,9 @@ class MultiGpuEngine:
         if world > 1 and self.sa:
             raise ValueError("SA_BOUNDARY: the vertex/segment buffers are not exchanged between slabs yet (single domain only)")
         self.grenier = problem.simparams.sph_formulation == D.SPH_GRENIER
+        self.effvisc_on = problem.simparams.rheologytype > D.NEWTONIAN        # NEEDS_EFFECTIVE_VISC
+        if world > 1 and self.effvisc_on:
+            raise ValueError("generalized Newtonian rheologies: BUFFER_EFFVISC is not exchanged between slabs yet (single domain only)")
         if world > 1 and self.grenier:
             raise ValueError("SPH_GRENIER: sigma and the volumes are not exchanged between slabs yet (single domain only)")
         self.problem = problem
@@ -176,6 +179,7 @@ class MultiGpuEngine:
             self.sa_dynamic_gamma = not (self.sp.simflags & D.ENABLE_GAMMA_QUADRATURE)
             self.sa_density_sum = bool(self.sp.simflags & D.ENABLE_DENSITY_SUM)
             self.cfl_gamma = (torch.zeros(A + 4 + self.cfl.numel(), dtype=f32, device=dev) if self.sa_dynamic_gamma else None)
+        self.effvisc = torch.zeros(A, dtype=f32, device=dev) if self.effvisc_on else None      # BUFFER_EFFVISC
         # SPH_GRENIER: BUFFER_VOLUME (double buffered like pos/vel, travels through the re-sort) and BUFFER_SIGMA
         if self.grenier:
             self.vol = torch.zeros((A, 4), dtype=f32, device=dev); self.vol2 = torch.zeros_like(self.vol)
@@ -383,6 +387,15 @@ class MultiGpuEngine:
             K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
             if self.sa_dynamic_gamma:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
                 K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb, self.d_dt_next)
+            return
+        if self.effvisc_on and run_mode == D.SIMULATE:
+            # CALC_VISC on the state the forces read; its largest kinematic viscosity is the viscous limit of this pass's dt
+            K.calc_effvisc(self.effvisc, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, self.n_int)
+            nb = K.forces_effvisc(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.effvisc,
+                                  self.n_local, 0, self.n_int, 0)
+            if prof:
+                e1.record(); self.profile_forces.append((e0, e1))
+            K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
             return
         if self.grenier and run_mode == D.SIMULATE:
             # COMPUTE_DENSITY on the state the forces read (PredictorCorrectorIntegrator.cc:443-458), then the Grenier forces

@@ -384,6 +384,28 @@ int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	float dt, const float *d_dt, float dt_scale, int step, float t,
 	float slength, float influenceradius, int run_mode, void *stream);
 
+/* ---- generalized Newtonian rheologies (rheology<BINGHAM | PAPANASTASIOU | POWER_LAW | HERSCHEL_BULKLEY | ALEXANDROU | DEKEE_TURCOTTE |
+ * ZHU>, e.g. PoiseuillePapanastasiou) ------------------------------------------------------------------------------------------
+ *   sphx_calc_effvisc              AbstractViscEngine::calc_visc when NEEDS_EFFECTIVE_VISC (src/cuda/visc.cu:86-170, effectiveViscDevice
+ *                                  src/cuda/visc_kernel.cu:655-713; the CALC_VISC command before every forces pass,
+ *                                  src/integrators/PredictorCorrectorIntegrator.cc:460-480): writes BUFFER_EFFVISC (mu_eff for compvisc
+ *                                  DYNAMIC, mu_eff/rho for KINEMATIC); *h_max_kinvisc (may be NULL: no host synchronisation then) gets
+ *                                  the largest kinematic viscosity, which the caller hands to sphx_forces_dtreduce as
+ *                                  max_kinematic (src/GPUWorker.cc:2633-2645,2013-2030); NaN without ENABLE_DTADAPT like the reference
+ *   sphx_forces_basicstep_effvisc  basicstep of the forces engine with effective_visc_forces_params: the arguments of
+ *                                  sphx_forces_basicstep that the built option set uses, plus effvisc; sphx_forces_basicstep itself
+ *                                  answers SPHX_ERR_INVALID for a SIMULATE pass of these rheologies */
+int sphx_calc_effvisc(sphx_ctx *ctx, float *effvisc, float *h_max_kinvisc,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius, void *stream);
+int sphx_forces_basicstep_effvisc(sphx_ctx *ctx, void *forces, float *cfl,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *effvisc,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius,
+	uint32_t cflOffset, int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream);
+
 /* ---- SPH_GRENIER (formulation<SPH_GRENIER>, boundary<DYN_BOUNDARY>: Bubble, LockExchange, RTInstability, OilJet) ----------
  * The volume formulation keeps two more buffers, BUFFER_VOLUME (float4: x initial volume, y log(current/initial), w current
  * volume) and BUFFER_SIGMA (float).

@@ -759,9 +759,10 @@ static inline float visc_avg(const orc_params *p, float visc, float neib_visc, f
 		return visc*visc_avg_rho(p->avgop, rho, neib_rho, neib_mass);
 	/* non-constant kinematic: "just call the dynvisc variant" of ViscSpec::with_computational_visc<DYNAMIC> (:180-190).
 	 * That alias does not carry is_const_visc over: the dynamic spec gets the DEFAULT constness of its framework flags,
-	 * IS_SINGLEFLUID && NEWTONIAN (src/visc_spec.h:268-272,298-300) -- so a single-fluid spec forced to non-constant
+	 * IS_SINGLEFLUID && NEWTONIAN (src/visc_spec.h:268-272,298-300) -- so a single-fluid NEWTONIAN spec forced to non-constant
 	 * viscosity ends in the constant dynamic formula 2 m mu_i/(rho_i rho_j); pinned by tests/golden/ref_viscavg.npz */
-	return visc_avg_dyn(p->avgop, !(p->simflags & ORC_ENABLE_MULTIFLUID), visc*rho, neib_visc*neib_rho, rho, neib_rho, neib_mass);
+	return visc_avg_dyn(p->avgop, !(p->simflags & ORC_ENABLE_MULTIFLUID) && p->rheologytype == ORC_NEWTONIAN,
+		visc*rho, neib_visc*neib_rho, rho, neib_rho, neib_mass);
 }
 
 /* exported for the pinning test against the reference's own visc_avg (oracle/ref_shim.cc, tests/golden/ref_viscavg.npz) */

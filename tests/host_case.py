@@ -47,6 +47,11 @@ def case_lines(prob, framework, allocated=None, **selectors):
         kind = "none" if (nu is None or math.isnan(nu)) else "kin"
         L.append("fluid%d %s %s %s %s %s" % (f, _g(pp.rho0[f]), _g(pp.gammacoeff[f]), _g(pp.sscoeff[f]), kind,
                                             _g(0.0 if kind == "none" else nu)))
+        if sp.rheologytype > D.NEWTONIAN:     # generalized Newtonian: yield strength; power-law / exponential parameter and m when set
+            nl = pp.visc_nonlinear_param[f]
+            default_nl = 0.0 if sp.rheologytype >= D.DEKEE_TURCOTTE else 1.0
+            L.append("rheology%d %s %s %s" % (f, _g(pp.yield_strength[f]), _g(float("nan") if nl == default_nl else nl),
+                                              _g(float("nan") if pp.visc_regularization_param[f] == 1000.0 else pp.visc_regularization_param[f])))
     L += ["gravity %s %s %s" % tuple(_g(x) for x in pp.gravity), "artvisccoeff %s" % _g(pp.artvisccoeff),
           "epsartvisc %s" % _g(pp.epsartvisc), "r0 %s" % _g(_nz(pp.r0)), "dcoeff %s" % _g(_nz(pp.dcoeff)),
           "p1coeff %s" % _g(pp.p1coeff), "p2coeff %s" % _g(pp.p2coeff),
