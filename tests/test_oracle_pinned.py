@@ -182,6 +182,7 @@ def test_visc_avg_matches_reference_golden():
     g = np.load(os.path.join(GOLD, "ref_viscavg.npz"))
     L = ol.lib()
     p = ol.OrcParams()
+    p.rheologytype = 1       # the golden flavours are FullViscSpec<NEWTONIAN, ...> (the re-derived constness asks for it)
     n = len(g["visc"])
     for av in (0, 1, 2):     # single-fluid framework forced non-constant, kinematic: the reference lands in 2 m mu_i/(rho_i rho_j)
         p.compvisc, p.avgop, p.is_const_visc, p.simflags = 0, av, 0, 0
