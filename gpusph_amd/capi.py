@@ -43,6 +43,7 @@ SIGNATURES = {
     "sphx_set_constants": (_i, [_vp, C.POINTER(SphxParams)]),
     "sphx_get_params": (_i, [_vp, C.POINTER(SphxParams)]),
     "sphx_set_planes": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "sphx_set_dem": (_i, [_vp, _vp, _i, _i]),
     "sphx_set_gravity": (_i, [_vp, C.POINTER(_f)]),
     "sphx_set_rb_cg": (_i, [_vp, _vp, _vp, _i]),
     "sphx_set_rb_cg_forces": (_i, [_vp, _vp, _vp, _i]),

@@ -304,26 +304,34 @@ __device__ __forceinline__ float finalize_particle(const DevParams &p, const For
 		force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
 		// GeometryForce / PlaneForce (src/cuda/forces_kernel.cu:140-203): Lennard-Jones repulsion along the plane
 		// normal; the friction term vanishes for the inviscid rheology built here (viscous_plane_coefficient :3103-3107)
-		if ((p.simflags & SPHX_ENABLE_PLANES) && p.numplanes) {
-			for (uint32_t k = 0; k < p.numplanes; ++k) {
-				const float dx = (s.gridPos.x - p.plane_gridpos[k][0])*p.cs[0] + (s.pos.x - p.plane_pos[k][0]);
-				const float dy = (s.gridPos.y - p.plane_gridpos[k][1])*p.cs[1] + (s.pos.y - p.plane_pos[k][1]);
-				const float dz = (s.gridPos.z - p.plane_gridpos[k][2])*p.cs[2] + (s.pos.z - p.plane_pos[k][2]);
-				const float r = fabsf(dx*p.plane_normal[k][0] + dy*p.plane_normal[k][1] + dz*p.plane_normal[k][2]);
-				if (r < p.r0) {
-					const float DvDt = p.dcoeff*(powf(p.r0/r, p.p1coeff) - powf(p.r0/r, p.p2coeff))/(r*r);
-					const float qx = p.plane_normal[k][0]*r, qy = p.plane_normal[k][1]*r, qz = p.plane_normal[k][2]*r;
-					force.x += DvDt*qx; force.y += DvDt*qy; force.z += DvDt*qz;
-					if (p.rheology == SPHX_NEWTONIAN) {
-						// wall friction of PlaneForce (:153-185): -mu partsurf/(m r) v_t, mu = get_laminar_dyn_visc
-						const float dynvisc = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[s.fl]*s.rho : p.visccoeff[s.fl];
-						const float d = (s.vel.x*qx + s.vel.y*qy + s.vel.z*qz)/r, inv = 1.0f/r;
-						const float coeff = -dynvisc*p.partsurf/(s.pos.w*r);
-						force.x += coeff*(s.vel.x - (d*qx)*inv); force.y += coeff*(s.vel.y - (d*qy)*inv);
-						force.z += coeff*(s.vel.z - (d*qz)*inv);
-					}
+		// PlaneForce (:140-185) of a plane given by its unit normal and the grid + local position of a point on it
+		auto plane_force = [&](const float nrm[3], const int pgp[3], const float ppos[3]) {
+			const float dx = (s.gridPos.x - pgp[0])*p.cs[0] + (s.pos.x - ppos[0]);
+			const float dy = (s.gridPos.y - pgp[1])*p.cs[1] + (s.pos.y - ppos[1]);
+			const float dz = (s.gridPos.z - pgp[2])*p.cs[2] + (s.pos.z - ppos[2]);
+			const float r = fabsf(dx*nrm[0] + dy*nrm[1] + dz*nrm[2]);
+			if (r < p.r0) {
+				const float DvDt = p.dcoeff*(powf(p.r0/r, p.p1coeff) - powf(p.r0/r, p.p2coeff))/(r*r);
+				const float qx = nrm[0]*r, qy = nrm[1]*r, qz = nrm[2]*r;
+				force.x += DvDt*qx; force.y += DvDt*qy; force.z += DvDt*qz;
+				if (p.rheology == SPHX_NEWTONIAN) {
+					// wall friction of PlaneForce (:153-185): -mu partsurf/(m r) v_t, mu = get_laminar_dyn_visc
+					const float dynvisc = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[s.fl]*s.rho : p.visccoeff[s.fl];
+					const float d = (s.vel.x*qx + s.vel.y*qy + s.vel.z*qz)/r, inv = 1.0f/r;
+					const float coeff = -dynvisc*p.partsurf/(s.pos.w*r);
+					force.x += coeff*(s.vel.x - (d*qx)*inv); force.y += coeff*(s.vel.y - (d*qy)*inv);
+					force.z += coeff*(s.vel.z - (d*qz)*inv);
 				}
 			}
+		};
+		// DemLJForce (src/cuda/forces_kernel.cu:205-226), the LJ_BOUNDARY case of the finalize kernel (forces_kernel.def:4093-4102):
+		// a particle less than demzmin above the terrain is repelled by the terrain's tangent plane below it
+		if ((p.simflags & SPHX_ENABLE_DEM) && p.dem && p.boundarytype == SPHX_LJ_BOUNDARY && !p.mk_mask) {
+			float nrm[3], ppos[3]; int pgp[3];
+			if (dem_plane(p, s.gridPos, s.pos.x, s.pos.y, s.pos.z, nrm, pgp, ppos)) plane_force(nrm, pgp, ppos);
+		}
+		if ((p.simflags & SPHX_ENABLE_PLANES) && p.numplanes) {
+			for (uint32_t k = 0; k < p.numplanes; ++k) plane_force(p.plane_normal[k], p.plane_gridpos[k], p.plane_pos[k]);
 		}
 		// dyndt_forces_shared_data::store (:3436-3457)
 		const float amag = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));

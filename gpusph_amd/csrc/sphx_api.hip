@@ -77,6 +77,7 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
 	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
 	if (ctx->tile_prof) (void)hipFree(ctx->tile_prof);
+	if (ctx->dem) (void)hipFree(ctx->dem);
 	delete ctx->forces_events;
 	delete ctx;
 }
@@ -233,6 +234,11 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 		for (uint32_t f = 0; f < sp->numfluids; ++f)
 			SPHX_REQUIRE(sp->visccoeff[f] == sp->visccoeff[f], "sphx_set_constants: NEWTONIAN rheology needs visccoeff for every fluid");
 	}
+	if (sp->simflags & SPHX_ENABLE_DEM) {
+		// DemLJForce is the LJ_BOUNDARY case of the finalize kernel (src/cuda/forces_kernel.def:4093-4102); other boundary models skip it
+		SPHX_REQUIRE(sp->ewres > 0 && sp->nsres > 0 && sp->demdx == sp->demdx && sp->demdy == sp->demdy && sp->demzmin == sp->demzmin,
+			"sphx_set_constants: ENABLE_DEM needs ewres, nsres, demdx, demdy, demzmin (computeDEMphysparams)");
+	}
 	if (sp->turbmodel != SPHX_ARTIFICIAL && sp->turbmodel != SPHX_SPS && sp->turbmodel != SPHX_LAMINAR_FLOW)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: turbulence model not built");
 
@@ -279,6 +285,9 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 		d.visc_regularization_param[f] = sp->visc_regularization_param[f];
 	}
 	d.limiting_kinvisc = sp->limiting_kinvisc;
+	d.ewres = sp->ewres; d.nsres = sp->nsres; d.demdx = sp->demdx; d.demdy = sp->demdy; d.demzmin = sp->demzmin;
+	d.wo_z = sp->worldOrigin[2];
+	d.dem = ctx->dem; d.dem_w = ctx->dem_w; d.dem_h = ctx->dem_h;
 	d.mk_mask = (sp->boundarytype == SPHX_MK_BOUNDARY) ? 0xFFFFFFFFu : 0u;
 	if (sp->boundarytype == SPHX_MK_BOUNDARY) d.boundarytype = SPHX_LJ_BOUNDARY;
 	ctx->have_params = true;
@@ -305,6 +314,23 @@ extern "C" int sphx_set_planes(sphx_ctx *ctx, const float *normals, const int32_
 			ctx->dev.plane_gridpos[k][a] = gridPos[3*k + a];
 			ctx->dev.plane_pos[k][a] = pos[3*k + a];
 		}
+	return SPHX_OK;
+}
+
+// setDEM / unsetDEM (src/cuda/forces.cu:937-958): the reference keeps the map in a 2D texture with clamped addressing and linear
+// filtering; here it is a plain row-major array and the filtering is written out (dem_interpol, sphx_internal.h)
+extern "C" int sphx_set_dem(sphx_ctx *ctx, const float *hDem, int width, int height)
+{
+	SPHX_REQUIRE(ctx != nullptr, "sphx_set_dem: NULL ctx");
+	if (ctx->dem) { (void)hipFree(ctx->dem); ctx->dem = nullptr; }
+	ctx->dem_w = ctx->dem_h = 0;
+	if (hDem) {
+		SPHX_REQUIRE(width > 0 && height > 0, "sphx_set_dem: empty DEM");
+		SPHX_HIP(hipMalloc((void**)&ctx->dem, sizeof(float)*(size_t)width*(size_t)height));
+		SPHX_HIP(hipMemcpy(ctx->dem, hDem, sizeof(float)*(size_t)width*(size_t)height, hipMemcpyHostToDevice));
+		ctx->dem_w = width; ctx->dem_h = height;
+	}
+	ctx->dev.dem = ctx->dem; ctx->dev.dem_w = ctx->dem_w; ctx->dev.dem_h = ctx->dem_h;
 	return SPHX_OK;
 }
 

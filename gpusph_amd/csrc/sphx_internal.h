@@ -80,6 +80,8 @@ struct DevParams {
 	float    epsinterface;                   // SPH_GRENIER interface term
 	float    yield_strength[SPHX_MAX_FLUIDS], visc_nonlinear_param[SPHX_MAX_FLUIDS], visc_regularization_param[SPHX_MAX_FLUIDS];
 	float    limiting_kinvisc;               // generalized Newtonian rheologies
+	float    ewres, nsres, demdx, demdy, demzmin, wo_z;   // ENABLE_DEM (+ d_worldOrigin.z)
+	const float *dem; int dem_w, dem_h;      // the height map (sphx_set_dem), row-major [h][w]
 	uint32_t mk_mask;                        // all ones when the repulsive boundary model is MK (boundarytype then reads LJ)
 	uint32_t numplanes;                       // geometric planes (src/planes.h:43-47, MAX_PLANES src/particledefine.h:325)
 	float    plane_normal[SPHX_MAX_PLANES][3];
@@ -134,6 +136,7 @@ struct sphx_ctx {
 	uint32_t   *tmp_index;     // [n]
 	uint2      *tmp_info;      // [n] particleinfo as 8 bytes
 	float4     *eos_aux;       // [n] per-particle EOS pre-pass of the forces engine
+	float      *dem; int dem_w, dem_h;   // ENABLE_DEM: the height map (sphx_set_dem)
 	float4     *tau_pack;      // [2n] SPS: tau repacked as two float4 rows per particle for the LDS window (tiled kernel)
 	float      *dt_scratch;    // 1 float, for the sync dtreduce
 	// forces tiles, built by sphx_build_neibs
@@ -221,6 +224,40 @@ __device__ __forceinline__ int3 grid_pos_from_hash(const DevParams &p, uint32_t 
 }
 
 // calcGridHashPeriodic (src/cuda/cellgrid.cuh:177-187)
+// ---- ENABLE_DEM: terrain height map (src/cuda/geom_core.cu:103-182, src/cuda/forces_kernel.cu:205-226) ------------------------
+// tex2D of an unnormalised, clamped, linearly filtered float texture: sample centres at i + 0.5; the fractional weights are kept
+// in 1.8 fixed point as the texture unit of the reference's hardware does (CUDA programming guide, "Linear Filtering")
+__device__ __forceinline__ float dem_interpol(const DevParams &p, float x, float y)
+{
+	const float xb = x - 0.5f, yb = y - 0.5f;
+	const float fx = floorf(xb), fy = floorf(yb);
+	const float al = rintf((xb - fx)*256.0f)*(1.0f/256.0f), be = rintf((yb - fy)*256.0f)*(1.0f/256.0f);
+	const int i0 = min(max((int)fx, 0), p.dem_w - 1), i1 = min(max((int)fx + 1, 0), p.dem_w - 1);
+	const int j0 = min(max((int)fy, 0), p.dem_h - 1), j1 = min(max((int)fy + 1, 0), p.dem_h - 1);
+	const float t00 = p.dem[(size_t)j0*p.dem_w + i0], t10 = p.dem[(size_t)j0*p.dem_w + i1];
+	const float t01 = p.dem[(size_t)j1*p.dem_w + i0], t11 = p.dem[(size_t)j1*p.dem_w + i1];
+	return (1.0f - al)*(1.0f - be)*t00 + al*(1.0f - be)*t10 + (1.0f - al)*be*t01 + al*be*t11;
+}
+
+// DemLJForce: is the particle less than demzmin above the terrain?  Then the terrain acts as its tangent plane there.
+// Returns true and the plane (unit normal, grid + local position of its reference point)
+__device__ __forceinline__ bool dem_plane(const DevParams &p, const int3 &gridPos, float px, float py, float pz,
+	float nrm[3], int pgp[3], float ppos[3])
+{
+	const float dx = (gridPos.x + 0.5f)*(p.cs[0]/p.ewres) + px/p.ewres + 0.5f;     // DemPos
+	const float dy = (gridPos.y + 0.5f)*(p.cs[1]/p.nsres) + py/p.nsres + 0.5f;
+	const float globalZ = p.wo_z + (gridPos.z + 0.5f)*p.cs[2] + pz;
+	const float z0 = dem_interpol(p, dx, dy);
+	if (!(globalZ - z0 < p.demzmin)) return false;
+	const float z1 = dem_interpol(p, dx + 1*p.demdx/p.ewres, dy), z2 = dem_interpol(p, dx, dy + 1*p.demdy/p.nsres);
+	const float a = p.demdy*(z0 - z1), b = p.demdx*(z0 - z2), c = p.demdx*p.demdy;
+	const float inv = 1.0f/sqrtf(a*a + b*b + c*c);       // float3/float multiplies by the reciprocal (src/vector_math.h:526-530)
+	nrm[0] = a*inv; nrm[1] = b*inv; nrm[2] = c*inv;
+	pgp[0] = gridPos.x; pgp[1] = gridPos.y; pgp[2] = (int)floorf((z0 - p.wo_z)/p.cs[2]);
+	ppos[0] = px; ppos[1] = py; ppos[2] = z0 - p.wo_z - (pgp[2] + 0.5f)*p.cs[2];
+	return true;
+}
+
 __device__ __forceinline__ uint32_t grid_hash_periodic(const DevParams &p, int gx, int gy, int gz)
 {
 	if (gx < 0) gx = p.gs[0] - 1;

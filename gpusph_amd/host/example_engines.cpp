@@ -115,6 +115,14 @@ int main(int argc, char **argv)
 			forcesEngine->setplanes(planes);
 		}
 
+		// GPUWorker::allocateDeviceBuffers -> setDEM (src/GPUWorker.cc:1070-1076): "dem <ncols> <nrows> <heights, row-major>"
+		if (has(c, "dem")) {
+			const int ncols = (int)num(c, "dem", 0), nrows = (int)num(c, "dem", 1);
+			std::vector<float> hdem((size_t)ncols*nrows);
+			for (size_t k = 0; k < hdem.size(); ++k) hdem[k] = (float)num(c, "dem", 2 + k);
+			forcesEngine->setDEM(hdem.data(), ncols, nrows);
+		}
+
 		// ---- bodies ----
 		std::vector<Body> bodies;
 		uint numBodiesParticles = 0;

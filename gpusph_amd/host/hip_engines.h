@@ -177,6 +177,10 @@ public:
 			p.visc_regularization_param[f] = f < pp->visc_regularization_param.size() ? pp->visc_regularization_param[f] : 0.0f;
 		}
 		p.limiting_kinvisc = pp->limiting_kinvisc;
+		// PhysParams leaves the DEM members uninitialised unless a DEM was added (src/physparams.h:322-327): they travel only with ENABLE_DEM
+		const bool dem = (sp->simflags & ENABLE_DEM) != 0;
+		p.ewres = dem ? pp->ewres : NAN; p.nsres = dem ? pp->nsres : NAN; p.demdx = dem ? pp->demdx : NAN;
+		p.demdy = dem ? pp->demdy : NAN; p.demzmin = dem ? pp->demzmin : NAN;
 	}
 
 	void upload(const SimParams *sp, const PhysParams *pp, float3 const& worldOrigin, uint3 const& gridSize,
@@ -376,8 +380,8 @@ public:
 	void bind_textures(const BufferList&, uint, RunMode) {}
 	void unbind_textures(RunMode) {}
 
-	void setDEM(const float *, int, int) { sphx_not_built("setDEM (ENABLE_DEM)"); }
-	void unsetDEM() {}
+	void setDEM(const float *hDem, int width, int height) { sphx_throw(sphx_set_dem(m_c->ctx(), hDem, width, height)); }
+	void unsetDEM() { sphx_throw(sphx_set_dem(m_c->ctx(), NULL, 0, 0)); }
 
 	uint round_particles(uint numparts) { return sphx_forces_round_particles(numparts); }
 

@@ -174,6 +174,15 @@ static SimFramework *make_framework(Case const& c)
 			densitydiffusion<BREZZI>,
 			add_flags<ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES>
 		);
+	} else if (name == "DEMExample") {     // src/problems/DEMExample.cu:47-52
+		const DensityDiffusionType rhodiff = (DensityDiffusionType)(int)num(c, "rhodiff");
+		SETUP_FRAMEWORK(
+			viscosity<ARTVISC>,
+			boundary<LJ_BOUNDARY>,
+			add_flags<ENABLE_DEM | ENABLE_PLANES>
+		).select_options(
+			rhodiff
+		);
 	} else if (name == "PoiseuillePapanastasiou") {   // src/problems/Poiseuille.inc:102-119 with POISEUILLE_RHEOLOGY = PAPANASTASIOU
 		const DensityDiffusionType RHODIFF = (DensityDiffusionType)(int)num(c, "rhodiff");
 		const ComputationalViscosityType compvisc = (ComputationalViscosityType)(int)num(c, "compvisc");
@@ -256,6 +265,11 @@ static void configure_params(Case const& c, SimParams *sp, ProblemPhysParams &pp
 	pp.MK_K = (float)num(c, "MK_K"); pp.MK_d = (float)num(c, "MK_d"); pp.MK_beta = (float)num(c, "MK_beta");
 	pp.partsurf = (float)num(c, "partsurf");
 	if (c.count("epsinterface")) pp.epsinterface = (float)num(c, "epsinterface");
+	if (has(c, "demparams")) {     // ProblemAPI<1>::computeDEMphysparams (src/problem_api/ProblemAPI_1.cc:1399-1418)
+		pp.ewres = (float)num(c, "demparams", 0); pp.nsres = (float)num(c, "demparams", 1);
+		pp.demdx = (float)num(c, "demparams", 2); pp.demdy = (float)num(c, "demparams", 3);
+		pp.demdxdy = pp.demdx*pp.demdy; pp.demzmin = (float)num(c, "demparams", 4);
+	}
 	pp.epsxsph = (float)num(c, "epsxsph");
 	// GPUSPH::setViscosityCoefficient (src/GPUSPH.cc:1481-1508), which runs between problem set-up and uploadConstants
 	for (size_t f = 0; f < pp.numFluids(); ++f)

@@ -26,6 +26,9 @@ class HipKernels:
         if getattr(problem, "planes", None):
             nrm, gpos, lpos = problem.plane_tables()
             capi.check(self.lib.sphx_set_planes(self.ctx.handle, nrm.ctypes.data, gpos.ctypes.data, lpos.ctypes.data, len(nrm)))
+        if getattr(problem, "dem", None) is not None:      # GPUWorker::allocateDeviceBuffers -> setDEM (GPUWorker.cc:1070-1076)
+            dem = np.ascontiguousarray(problem.dem, dtype=np.float32)
+            capi.check(self.lib.sphx_set_dem(self.ctx.handle, dem.ctypes.data, dem.shape[1], dem.shape[0]))
         self.ncells = problem.grid_cells
         sp = problem.simparams
         self.problem_simparams = sp

@@ -33,6 +33,7 @@ class SphxParams(C.Structure):
         ("epsinterface", C.c_float),
         ("yield_strength", C.c_float * 4), ("visc_nonlinear_param", C.c_float * 4),
         ("visc_regularization_param", C.c_float * 4), ("limiting_kinvisc", C.c_float),
+        ("ewres", C.c_float), ("nsres", C.c_float), ("demdx", C.c_float), ("demdy", C.c_float), ("demzmin", C.c_float),
     ]
 
 
@@ -54,6 +55,12 @@ class PhysParams:
     visc_regularization_param: list = field(default_factory=list)
     limiting_kinvisc: float = 1.0e3                         # physparams.h:395
     rheologytype: int = 0                                   # PhysParams is built for the framework's rheology (physparams.h:380)
+    # ENABLE_DEM (physparams.h:322-327; computeDEMphysparams, src/problem_api/ProblemAPI_1.cc:1399-1418)
+    ewres: float = float("nan")
+    nsres: float = float("nan")
+    demdx: float = float("nan")
+    demdy: float = float("nan")
+    demzmin: float = float("nan")
     partsurf: float = 0.0                                  # physparams.h:328,403 (0 -> r0^2 on upload)
     MK_K: float = float("nan")                             # physparams.h:336-338,405-407
     MK_d: float = float("nan")
@@ -275,4 +282,5 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
         p.yield_strength[f] = f32(pp.yield_strength[f]); p.visc_nonlinear_param[f] = f32(pp.visc_nonlinear_param[f])
         p.visc_regularization_param[f] = f32(pp.visc_regularization_param[f])
     p.limiting_kinvisc = f32(pp.limiting_kinvisc)
+    p.ewres = nz(pp.ewres); p.nsres = nz(pp.nsres); p.demdx = nz(pp.demdx); p.demdy = nz(pp.demdy); p.demzmin = nz(pp.demzmin)
     return p

@@ -256,7 +256,7 @@ class DamBreak3D(Problem):
     def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
                  jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY,
                  walls="particles", testpoints=(), two_fluids=False, viscosity=None, kinematic_visc=1.0e-2,
-                 formulation=D.SPH_F1):
+                 formulation=D.SPH_F1, dem=False):
         super().__init__()
         self.m_name = "DamBreak3D"
         sp, pp = self.simparams, self.physparams
@@ -279,7 +279,12 @@ class DamBreak3D(Problem):
             sp.avgop = D.HARMONIC           # legacy viscosity names average harmonically with Grenier (cudasimframework.cu:202-210)
         sp.densitydiffusiontype = density_diffusion
         sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | \
-            (D.ENABLE_PLANES if walls == "planes" else 0) | (D.ENABLE_MULTIFLUID if two_fluids else 0)
+            (D.ENABLE_PLANES if walls == "planes" else 0) | (D.ENABLE_MULTIFLUID if two_fluids else 0) | (D.ENABLE_DEM if dem else 0)
+        # ENABLE_DEM (DEMExample.cu's option set: LJ_BOUNDARY + DEM + side planes): a synthetic terrain instead of the floor
+        if dem and not (boundary == D.LJ_BOUNDARY and walls == "planes"):
+            raise ValueError("dem=True: LJ_BOUNDARY with walls='planes' (addDEM + addDEMPlanes)")
+        self.use_dem = bool(dem)
+        self.dem = None
         sp.neiblistsize = 128               # resize_neiblist(128), DamBreak3D.cu:76
         if kerneltype == D.GAUSSIAN:
             sp.neiblistsize = 384           # radius 3h: ~250 neighbours in the bulk
@@ -310,6 +315,24 @@ class DamBreak3D(Problem):
             sp.numforcesbodies = 1
         self.initialize()
         self.fill_parts()
+
+    def _make_dem(self, fluid):
+        """a smooth synthetic terrain on a node-centred grid (TopoCube: ewres = sizex/(ncols-1), world origin at DEM (0, 0)) and
+        the parameters computeDEMphysparams derives from it (src/problem_api/ProblemAPI_1.cc:1399-1418: displacement scale 5,
+        zmin scale 5); the water column is lifted above the highest point"""
+        pp = self.physparams
+        L = self.m_size
+        ncols, nrows = 33, 15
+        ewres, nsres = L[0] / (ncols - 1), L[1] / (nrows - 1)
+        x = np.arange(ncols) * ewres
+        y = np.arange(nrows) * nsres
+        self.dem = (0.04 + 0.03 * np.sin(2 * np.pi * x[None, :] / 0.9) * np.cos(2 * np.pi * y[:, None] / 0.5)).astype(np.float32)
+        pp.ewres = float(np.float32(ewres)); pp.nsres = float(np.float32(nsres))
+        pp.demdx = float(np.float32(pp.ewres) / np.float32(5.0)); pp.demdy = float(np.float32(pp.nsres) / np.float32(5.0))
+        pp.demzmin = float(np.float32(5.0 * self.m_deltap))
+        fluid = fluid.copy()
+        fluid[:, 2] += float(self.dem.max())
+        return fluid
 
     # analytic particle count for a given dp (used to hit a target N)
     @classmethod
@@ -376,6 +399,8 @@ class DamBreak3D(Problem):
             wall = np.zeros((0, 3))
             self.planes = [((0, 0, 1), (0, 0, 0)), ((1, 0, 0), (0, 0, 0)), ((-1, 0, 0), (L[0], 0, 0)),
                            ((0, 1, 0), (0, 0, 0)), ((0, -1, 0), (0, L[1], 0))]
+            if self.use_dem:      # addDEMPlanes: the four sides only, the terrain is the floor
+                self.planes = self.planes[1:]
         # --- water column (DamBreak3D.cu:139-145) ---
         bd = Lr * dp
         fsize = np.array([self.WATER_LENGTH - bd, L[1] - 2 * bd, self.H - bd])
@@ -385,6 +410,8 @@ class DamBreak3D(Problem):
         if self.jitter:
             rng = np.random.default_rng(12345)
             fluid = fluid + rng.uniform(-self.jitter * dp, self.jitter * dp, size=fluid.shape)
+        if self.use_dem:
+            fluid = self._make_dem(fluid)
         # --- obstacle: axis-aligned 3-layer shell standing on the floor layers (DamBreak3D.cu:160-178) ---
         obst = np.zeros((0, 3))
         if self.obstacle:

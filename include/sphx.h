@@ -126,6 +126,10 @@ typedef struct sphx_params {
 	 * limiting_kinvisc clamps the effective viscosity (x rho0) */
 	float    yield_strength[SPHX_MAX_FLUIDS], visc_nonlinear_param[SPHX_MAX_FLUIDS], visc_regularization_param[SPHX_MAX_FLUIDS];
 	float    limiting_kinvisc;
+	/* ENABLE_DEM (terrain as a height map, src/physparams.h:322-327, uploaded by src/cuda/forces.cu:353-359): cell sizes of the
+	 * DEM, displacements used for the tangent plane, height above the terrain below which the terrain repels; the map itself
+	 * goes through sphx_set_dem */
+	float    ewres, nsres, demdx, demdy, demzmin;
 } sphx_params;
 
 /* TimingInfo fields filled by getinfo (src/timing.h:43-100, src/cuda/buildneibs.cu:137-145) */
@@ -159,6 +163,10 @@ int sphx_set_gravity(sphx_ctx *ctx, const float h_gravity[3]);
  * (plane_t, src/planes.h:43-47); arrays of 3*numPlanes values.  Used when SPHX_ENABLE_PLANES is set. */
 #define SPHX_MAX_PLANES 8
 int sphx_set_planes(sphx_ctx *ctx, const float *normals, const int32_t *gridPos, const float *pos, int numPlanes);
+/* AbstractForcesEngine::setDEM / unsetDEM (src/engine_forces.h:103-110, src/cuda/forces.cu:937-958): the terrain height map of
+ * ENABLE_DEM, width x height floats, row-major (what the reference copies into its 2D texture), taken from HOST memory;
+ * hDem = NULL drops it.  Read by the finalize step of sphx_forces_basicstep with LJ_BOUNDARY (DemLJForce). */
+int sphx_set_dem(sphx_ctx *ctx, const float *hDem, int width, int height);
 /* AbstractForcesEngine::setrbcg / setrbstart; AbstractIntegrationEngine::setrbcg/setrbtrans/
  * setrbsteprot/setrblinearvel/setrbangularvel (src/engine_integration.h) */
 int sphx_set_rb_cg(sphx_ctx *ctx, const int32_t *h_cgGridPos3, const float *h_cgPos3, int numbodies);

@@ -1019,6 +1019,62 @@ static inline void plane_friction(const orc_params *p, orc_f4 *force, const orc_
 }
 
 /* finalizeforcesDevice: forces_kernel.def:4032-4150 */
+/* ---- ENABLE_DEM: the terrain as a height map (src/cuda/geom_core.cu:103-182, DemLJForce src/cuda/forces_kernel.cu:205-226).
+ * The reference reads it through a 2D texture: unnormalised coordinates, clamped addressing, linear filtering, i.e. sample
+ * centres at i + 0.5 and fractional weights kept in 1.8 fixed point by the texture unit (CUDA programming guide, "Linear
+ * Filtering"); restated here on a plain array.  The map is test state of the oracle (orc_set_dem), like the texture binding. */
+static const float *g_dem; static int g_dem_w, g_dem_h;
+void orc_set_dem(const float *dem, int width, int height) { g_dem = dem; g_dem_w = width; g_dem_h = height; }
+
+float orc_dem_interpol(float x, float y)
+{
+	const float xb = x - 0.5f, yb = y - 0.5f;
+	const float fx = floorf(xb), fy = floorf(yb);
+	const float al = rintf((xb - fx)*256.0f)*(1.0f/256.0f), be = rintf((yb - fy)*256.0f)*(1.0f/256.0f);
+#define ORC_CLAMPI(v, hi) ((v) < 0 ? 0 : ((v) > (hi) ? (hi) : (v)))
+	const int i0 = ORC_CLAMPI((int)fx, g_dem_w - 1), i1 = ORC_CLAMPI((int)fx + 1, g_dem_w - 1);
+	const int j0 = ORC_CLAMPI((int)fy, g_dem_h - 1), j1 = ORC_CLAMPI((int)fy + 1, g_dem_h - 1);
+	const float t00 = g_dem[(size_t)j0*g_dem_w + i0], t10 = g_dem[(size_t)j0*g_dem_w + i1];
+	const float t01 = g_dem[(size_t)j1*g_dem_w + i0], t11 = g_dem[(size_t)j1*g_dem_w + i1];
+	return (1.0f - al)*(1.0f - be)*t00 + al*(1.0f - be)*t10 + (1.0f - al)*be*t01 + al*be*t11;
+}
+
+/* the tangent plane of the terrain under a particle that is less than demzmin above it; 0 when it is higher */
+static int dem_plane(const orc_params *p, const int gp[3], const orc_f4 *pos, float nrm[3], int pgp[3], float ppos[3])
+{
+	const float dx = (gp[0] + 0.5f)*(p->cellSize[0]/p->ewres) + pos->x/p->ewres + 0.5f;     /* DemPos */
+	const float dy = (gp[1] + 0.5f)*(p->cellSize[1]/p->nsres) + pos->y/p->nsres + 0.5f;
+	const float globalZ = p->worldOrigin[2] + (gp[2] + 0.5f)*p->cellSize[2] + pos->z;
+	const float z0 = orc_dem_interpol(dx, dy);
+	if (!(globalZ - z0 < p->demzmin)) return 0;
+	const float z1 = orc_dem_interpol(dx + 1*p->demdx/p->ewres, dy), z2 = orc_dem_interpol(dx, dy + 1*p->demdy/p->nsres);
+	const float a = p->demdy*(z0 - z1), b = p->demdx*(z0 - z2), c = p->demdx*p->demdy;
+	const float inv = 1.0f/sqrtf(a*a + b*b + c*c);
+	nrm[0] = a*inv; nrm[1] = b*inv; nrm[2] = c*inv;
+	pgp[0] = gp[0]; pgp[1] = gp[1]; pgp[2] = (int)floorf((z0 - p->worldOrigin[2])/p->cellSize[2]);
+	ppos[0] = pos->x; ppos[1] = pos->y; ppos[2] = z0 - p->worldOrigin[2] - (pgp[2] + 0.5f)*p->cellSize[2];
+	return 1;
+}
+
+/* PlaneForce, src/cuda/forces_kernel.cu:140-185 */
+static void plane_force(const orc_params *p, orc_f4 *force, const orc_f4 *pos, const orc_f4 *vel, const int gp[3],
+	const float nrm[3], const int pgp[3], const float ppos[3], float dynvisc)
+{
+	const float dx = (gp[0] - pgp[0])*p->cellSize[0] + (pos->x - ppos[0]);
+	const float dy = (gp[1] - pgp[1])*p->cellSize[1] + (pos->y - ppos[1]);
+	const float dz = (gp[2] - pgp[2])*p->cellSize[2] + (pos->z - ppos[2]);
+	const float r = fabsf(dx*nrm[0] + dy*nrm[1] + dz*nrm[2]);
+	if (r < p->r0) {
+		float DvDt = 0.0f;   /* LJForce(r) */
+		if (r <= p->r0)
+			DvDt = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
+		const float rp[3] = { nrm[0]*r, nrm[1]*r, nrm[2]*r };
+		force->x += DvDt*rp[0]; force->y += DvDt*rp[1]; force->z += DvDt*rp[2];
+		if (dynvisc != 0.0f)
+			plane_friction(p, force, vel, rp, r, pos->w, dynvisc);
+	}
+}
+
 static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	orc_f4 *rbforces, orc_f4 *rbtorques,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
@@ -1064,25 +1120,18 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 				const float lamvisc = effvisc ? effvisc[index] : p->visccoeff[fl];
 				const float dynvisc = (p->rheologytype != ORC_INVISCID) ?
 					(p->compvisc == ORC_KINEMATIC ? lamvisc*physical_density(p, vel.w, fl) : lamvisc) : 0.0f;
-				if ((p->simflags & ORC_ENABLE_PLANES) && p->numplanes) {
+				if ((p->simflags & (ORC_ENABLE_PLANES | ORC_ENABLE_DEM))) {
 					int gp[3];
 					orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
-					for (uint32_t k = 0; k < p->numplanes; ++k) {
-						const float dx = (gp[0] - p->plane_gridpos[k][0])*p->cellSize[0] + (pos.x - p->plane_pos[k][0]);
-						const float dy = (gp[1] - p->plane_gridpos[k][1])*p->cellSize[1] + (pos.y - p->plane_pos[k][1]);
-						const float dz = (gp[2] - p->plane_gridpos[k][2])*p->cellSize[2] + (pos.z - p->plane_pos[k][2]);
-						const float *nrm = p->plane_normal[k];
-						const float r = fabsf(dx*nrm[0] + dy*nrm[1] + dz*nrm[2]);
-						if (r < p->r0) {
-							float DvDt = 0.0f;   /* LJForce(r) */
-							if (r <= p->r0)
-								DvDt = p->dcoeff*(powf(p->r0/r, p->p1coeff) - powf(p->r0/r, p->p2coeff))/(r*r);
-							const float rp[3] = { nrm[0]*r, nrm[1]*r, nrm[2]*r };
-							force.x += DvDt*rp[0]; force.y += DvDt*rp[1]; force.z += DvDt*rp[2];
-							if (dynvisc != 0.0f)
-								plane_friction(p, &force, &vel, rp, r, pos.w, dynvisc);
-						}
+					/* DEM first, LJ_BOUNDARY only (finalizeforcesDevice :4093-4102), then the planes (:4105-4109) */
+					if ((p->simflags & ORC_ENABLE_DEM) && g_dem && p->boundarytype == ORC_LJ_BOUNDARY) {
+						float nrm[3], ppos[3]; int pgp[3];
+						if (dem_plane(p, gp, &pos, nrm, pgp, ppos))
+							plane_force(p, &force, &pos, &vel, gp, nrm, pgp, ppos, dynvisc);
 					}
+					if ((p->simflags & ORC_ENABLE_PLANES))
+						for (uint32_t k = 0; k < p->numplanes; ++k)
+							plane_force(p, &force, &pos, &vel, gp, p->plane_normal[k], p->plane_gridpos[k], p->plane_pos[k], dynvisc);
 				}
 				if (dtadapt) { /* dyndt_forces_shared_data::store, :3436-3457 */
 					const float sspeed = orc_soundSpeed(p, vel.w, fl);

@@ -57,7 +57,9 @@ def case_lines(prob, framework, allocated=None, **selectors):
           "p1coeff %s" % _g(pp.p1coeff), "p2coeff %s" % _g(pp.p2coeff),
           "smagfactor %s" % _g(_nz(pp.smagfactor)), "kspsfactor %s" % _g(_nz(pp.kspsfactor)),
           "MK_K %s" % _g(_nz(pp.MK_K)), "MK_d %s" % _g(_nz(pp.MK_d)), "MK_beta %s" % _g(_nz(pp.MK_beta)),
-          "partsurf %s" % _g(pp.partsurf), "epsinterface %s" % _g(_nz(pp.epsinterface)), "epsxsph %s" % _g(getattr(pp, "epsxsph", sp.epsxsph)),
+          "partsurf %s" % _g(pp.partsurf), "epsinterface %s" % _g(_nz(pp.epsinterface)),
+          *(["demparams %s %s %s %s %s" % tuple(_g(v) for v in (pp.ewres, pp.nsres, pp.demdx, pp.demdy, pp.demzmin))]
+            if (sp.simflags & D.ENABLE_DEM) else []), "epsxsph %s" % _g(getattr(pp, "epsxsph", sp.epsxsph)),
           "origin %s %s %s" % tuple(_g(x) for x in prob.m_origin), "grid %d %d %d" % tuple(int(x) for x in prob.m_gridsize),
           "cell %s %s %s" % tuple(_g(x) for x in prob.m_cellsize),
           "allocated %d" % int(allocated if allocated is not None else prob.num_particles)]
@@ -74,6 +76,9 @@ def driver_lines(prob, eng, steps, filters=(), final_surface=False):
         for k in range(len(nrm)):
             vals += [_g(x) for x in nrm[k]] + ["%d" % x for x in gpos[k]] + [_g(x) for x in lpos[k]]
         L.append("plane " + " ".join(vals))
+    if getattr(prob, "dem", None) is not None:
+        dem = np.asarray(prob.dem, dtype=np.float32)
+        L.append("dem %d %d " % (dem.shape[1], dem.shape[0]) + " ".join(_g(v) for v in dem.ravel()))
     nobj = getattr(prob, "num_obstacle", 0)
     if nobj:
         cg = getattr(prob, "rb_cg_global", None)

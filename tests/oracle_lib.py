@@ -32,6 +32,7 @@ class OrcParams(C.Structure):
         ("epsinterface", C.c_float),
         ("yield_strength", C.c_float * 4), ("visc_nonlinear_param", C.c_float * 4),
         ("visc_regularization_param", C.c_float * 4), ("limiting_kinvisc", C.c_float),
+        ("ewres", C.c_float), ("nsres", C.c_float), ("demdx", C.c_float), ("demdy", C.c_float), ("demzmin", C.c_float),
         ("numplanes", C.c_uint32),
         ("plane_normal", (C.c_float * 3) * 8), ("plane_gridpos", (C.c_int32 * 3) * 8), ("plane_pos", (C.c_float * 3) * 8),
         ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),
@@ -73,6 +74,7 @@ def lib():
         _lib.orc_forces_grenier.restype = C.c_uint32
         _lib.orc_forces_effvisc.restype = C.c_uint32
         _lib.orc_effective_visc.restype = C.c_float
+        _lib.orc_dem_interpol.restype = C.c_float; _lib.orc_dem_interpol.argtypes = [C.c_float, C.c_float]
         _lib.orc_effective_visc_value.restype = C.c_float; _lib.orc_effective_visc_value.argtypes = [C.c_void_p, C.c_float, C.c_int]
         _lib.orc_sa_gamma_dt.restype = C.c_float; _lib.orc_sa_gamma_dt.argtypes = [C.c_float, C.c_float]
         _lib.orc_dtreduce.restype = C.c_float
@@ -158,6 +160,9 @@ def orc_params_from(sphx_params, problem=None):
         for k in range(len(nrm)):
             for a in range(3):
                 o.plane_normal[k][a] = float(nrm[k][a]); o.plane_gridpos[k][a] = int(gpos[k][a]); o.plane_pos[k][a] = float(lpos[k][a])
+    if problem is not None and getattr(problem, "dem", None) is not None:
+        problem._orc_dem = np.ascontiguousarray(problem.dem, dtype=np.float32)      # kept alive for the oracle's pointer
+        lib().orc_set_dem(P(problem._orc_dem), C.c_int(problem._orc_dem.shape[1]), C.c_int(problem._orc_dem.shape[0]))
     if problem is not None and getattr(problem, "num_obstacle", 0):
         for a in range(3):
             o.rbcgGridPos[0][a] = o.rbcgGridPosE[0][a] = int(problem.rb_cg_gridpos[0][a])

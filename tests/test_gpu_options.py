@@ -171,6 +171,35 @@ def test_mk_boundary_forces_and_trajectory():
     assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
 
 
+def test_dem_terrain_forces_and_trajectory(monkeypatch):
+    """ENABLE_DEM (DEMExample's option set: LJ_BOUNDARY + terrain height map + side planes): DemLJForce in the finalize step of
+    both forces kernels; the water column is dropped onto the hills"""
+    from test_dem_oracle import dem_problem
+    prob = dem_problem(0.04)
+    # lower the column into reach of the terrain so that the DEM term is exercised in the single-pass comparison
+    prob.parts.pos_global[:, 2] -= 0.03
+    _check_neibs_and_forces(prob, 47, monkeypatch)
+    sim = ol.OracleSim(prob); sim.build_neibs()
+    f1 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, sim.n)[0]
+    sim.o.p.simflags &= ~D.ENABLE_DEM
+    f0 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, sim.n)[0]
+    assert (np.abs(f1[:sim.n, :3] - f0[:sim.n, :3]).max(axis=1) > 1.0).sum() > 30          # the terrain acts on the bottom layer
+    prob = dem_problem(0.04)
+    eng = _engine(prob); sim = ol.OracleSim(prob)
+    steps = 24
+    for _ in range(steps):
+        sim.step(); eng.step()
+    out = eng.download()
+    n = eng.n
+    assert np.array_equal(out["hash"], sim.hash[:n])
+    cs = float(min(prob.m_cellsize))
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 1e-6 * cs * steps
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
+    # the map can be dropped again (unsetDEM): the entry point then ignores the flag's term
+    from gpusph_amd import capi
+    capi.check(eng.lib.sphx_set_dem(eng.ctx.handle, None, 0, 0))
+
+
 def test_two_fluids():
     """multi-fluid branch (generic kernel): per-fluid EOS, Colagrossi diffusion only between particles of the same fluid"""
     prob = DamBreak3D(deltap=0.045, obstacle=False, jitter=0.1, hydrostatic=False, two_fluids=True)

@@ -508,13 +508,18 @@ def _cpp_case(name):
     if name == "wavetank":      # WaveTank.cu: SPSVISC + planes + LJ box + moving paddle + Shepard
         prob = WaveTank(0.06, paddle_tstart=0.0)
         return prob, "WaveTank", {}, [(D.SHEPARD_FILTER, 4)], 13
+    if name == "dem":           # DEMExample.cu: LJ_BOUNDARY + terrain height map through setDEM + side planes
+        from test_dem_oracle import dem_problem
+        prob = dem_problem(0.04)
+        prob.simparams.simflags &= ~D.ENABLE_REPACKING
+        return prob, "DEMExample", dict(rhodiff=D.COLAGROSSI), [], 24
     if name == "stillwater":    # StillWater.cu: DYNAMICVISC + Ferrari + MLS, rebuild every 20
         prob = StillWater(8, jitter=0.05)
         return prob, "StillWater", dict(rhodiff=D.FERRARI, use_planes=0), [(D.MLS_FILTER, 3)], 22
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("name", ["dambreak", "wavetank", "stillwater"])
+@pytest.mark.parametrize("name", ["dambreak", "wavetank", "stillwater", "dem"])
 def test_cpp_adapters_match_python_engine(tmp_path, name):
     import os, subprocess
     import host_case as hc

@@ -177,6 +177,18 @@ def test_papanastasiou_mirror_against_the_poiseuille_framework(tmp_path, compvis
     assert got.visccoeff[0] == np.float32(0.1)           # the consistency index, whatever the computational viscosity
 
 
+def test_dem_mirror_against_the_demexample_framework(tmp_path):
+    from test_dem_oracle import dem_problem
+    prob = dem_problem(0.05)
+    prob.simparams.simflags &= ~D.ENABLE_REPACKING
+    out = run_check(tmp_path, hc.case_lines(prob, "DEMExample", rhodiff=D.COLAGROSSI))
+    assert_options(out, prob.simparams)
+    assert out["options"]["simflags"] & D.ENABLE_DEM and out["options"]["boundarytype"] == D.LJ_BOUNDARY
+    assert_params(out, prob, prob.num_particles)
+    got = SphxParams.from_buffer_copy(bytes.fromhex(out["params_hex"]))
+    assert got.ewres == np.float32(1.6 / 32) and got.demzmin == np.float32(5 * prob.m_deltap)
+
+
 def test_selector_semantics_of_the_factory(tmp_path):
     """defaults, the legacy viscosity names, Grenier's harmonic rule, run-time walks over option ranges"""
     d = run_check(tmp_path, ["framework Default"])["options"]   # TypeDefaults, src/cuda/cudasimframework.cu:346-360
