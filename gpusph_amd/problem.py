@@ -256,7 +256,7 @@ class DamBreak3D(Problem):
     def __init__(self, deltap=0.015, *, obstacle=True, density_diffusion=D.COLAGROSSI, hydrostatic=True,
                  jitter=0.0, linearization=D.DEFAULT_LINEARIZATION, kerneltype=D.WENDLAND, boundary=D.DYN_BOUNDARY,
                  walls="particles", testpoints=(), two_fluids=False, viscosity=None, kinematic_visc=1.0e-2,
-                 formulation=D.SPH_F1, dem=False):
+                 formulation=D.SPH_F1, dem=False, internal_energy=False):
         super().__init__()
         self.m_name = "DamBreak3D"
         sp, pp = self.simparams, self.physparams
@@ -279,7 +279,8 @@ class DamBreak3D(Problem):
             sp.avgop = D.HARMONIC           # legacy viscosity names average harmonically with Grenier (cudasimframework.cu:202-210)
         sp.densitydiffusiontype = density_diffusion
         sp.simflags = D.ENABLE_DTADAPT | D.ENABLE_REPACKING | \
-            (D.ENABLE_PLANES if walls == "planes" else 0) | (D.ENABLE_MULTIFLUID if two_fluids else 0) | (D.ENABLE_DEM if dem else 0)
+            (D.ENABLE_PLANES if walls == "planes" else 0) | (D.ENABLE_MULTIFLUID if two_fluids else 0) | (D.ENABLE_DEM if dem else 0) | \
+            (D.ENABLE_INTERNAL_ENERGY if internal_energy else 0)      # AccuracyTest.cu: add_flags<ENABLE_INTERNAL_ENERGY>
         # ENABLE_DEM (DEMExample.cu's option set: LJ_BOUNDARY + DEM + side planes): a synthetic terrain instead of the floor
         if dem and not (boundary == D.LJ_BOUNDARY and walls == "planes"):
             raise ValueError("dem=True: LJ_BOUNDARY with walls='planes' (addDEM + addDEMPlanes)")

@@ -780,6 +780,12 @@ typedef struct {
 float orc_grad_gamma_vp(float slength, float qx, float qy, float qz, const orc_f4 *belem,
 	const float *vp0, const float *vp1, const float *vp2);
 
+/* ENABLE_INTERNAL_ENERGY: BUFFER_INTERNAL_ENERGY_UPD of the forces passes (add_internal_energy, forces_kernel.def:3308-3320:
+ * DEDt -= (DvDt_pair . relVel)/2 for every pair whose momentum term is computed; internal_energy_particle_output :972-980
+ * starts from the value the previous pass left).  Test state of the oracle, set by orc_set_dedt like the texture of the DEM. */
+static float *g_dedt;
+void orc_set_dedt(float *dedt) { g_dedt = dedt; }
+
 static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *forces,
 	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
 	const uint32_t *cellStart, const uint16_t *neibsList, const float *tauArray,
@@ -811,6 +817,8 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 		const float *p_tau = tauArray ? tauArray + 6*(size_t)index : NULL;
 
 		orc_f4 force = forces[index]; /* common_particle_output, :886-895 */
+		const int energy = g_dedt && (p->simflags & ORC_ENABLE_INTERNAL_ENERGY);
+		float dedt = energy ? g_dedt[index] : 0.0f;
 
 		neib_iter it;
 		neib_iter_init(&it, p, nptype, index, &pos, gridPos, cellStart, neibsList);
@@ -911,6 +919,7 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 					ljf = p->MK_K*w*2*pos.w/(p->MK_beta*dist*r*(pos.w + pos.w));
 				}
 				force.x += ljf*rx; force.y += ljf*ry; force.z += ljf*rz;
+				if (energy) dedt -= dot3(ljf*rx, ljf*ry, ljf*rz, vx, vy, vz)/2;
 				continue;
 			}
 
@@ -947,7 +956,7 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				force.w += DrDt;
 			}
 
-			if (all_pp || (dyn_bf && COMPUTE_FORCE(info))) {
+			if (all_pp || (dyn_bf && (COMPUTE_FORCE(info) || (p->simflags & ORC_ENABLE_INTERNAL_ENERGY)))) {      /* :3661 */
 				/* compute_pressure_contrib general, :2451-2466 */
 				/* pressure_gradient_term: SPH_F1 P_i/rho_i^2 + P_j/rho_j^2 (:2358-2371), SPH_F2 (P_i + P_j)/(rho_i rho_j) (:2253-2266) */
 				const float pGradTerm = f2 ? (p_precalc + n_precalc)/(p_rho*n_rho) : p_precalc + n_precalc;
@@ -983,9 +992,11 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				if (all_pp || COMPUTE_FORCE(info)) {
 					force.x += DvDt[0]; force.y += DvDt[1]; force.z += DvDt[2];
 				}
+				if (energy) dedt -= dot3(DvDt[0], DvDt[1], DvDt[2], vx, vy, vz)/2;
 			}
 		}
 		forces[index] = force;
+		if (energy) g_dedt[index] = dedt;
 	}
 }
 
@@ -1784,6 +1795,20 @@ void orc_euler(const orc_params *p, orc_f4 *newPos, orc_f4 *newVel,
 	uint32_t numParticles, float dt, int step)
 {
 	euler_body(p, newPos, newVel, oldPos, oldVel, infoArray, hashArray, forces, xsph, numParticles, dt, step, 0, NULL, NULL);
+}
+
+/* integrate_energy / write_energy of eulerDevice (euler_kernel.def:184-199,296-309): energy += dt DEDt for the particles the
+ * kernel integrates (active fluid particles; boundary particles with DYN_BOUNDARY), copied for the others */
+void orc_euler_energy(const orc_params *p, float *newEnergy, const float *oldEnergy, const float *DEDt,
+	const orc_f4 *oldPos, const orc_info *infoArray, uint32_t numParticles, float dt)
+{
+	for (uint32_t i = 0; i < numParticles; ++i) {
+		float e = oldEnergy[i];
+		const int ptype = PART_TYPE(infoArray[i]);
+		if (ACTIVE(oldPos[i]) && (ptype == PT_FLUID || ((ptype == PT_BOUNDARY || ptype == PT_VERTEX) && p->boundarytype == ORC_DYN_BOUNDARY)))
+			e = fmaf(dt, DEDt[i], e);
+		newEnergy[i] = e;
+	}
 }
 
 /* eulerDevice with SPH_GRENIER: BUFFER_VOLUME is read (old) and written (new) next to pos and vel */

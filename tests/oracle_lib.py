@@ -304,9 +304,13 @@ class Oracle:
         return eff, float(mx)
 
     def forces(self, pos, vel, info, hash_, cs, nl, n, frm=0, to=None, cfl_offset=0, compute_object_forces=0,
-               rb_count=0, tau=None, effvisc=None):
+               rb_count=0, tau=None, effvisc=None, dedt=None):
+        """dedt: BUFFER_INTERNAL_ENERGY_UPD (ENABLE_INTERNAL_ENERGY), cleared and accumulated by the three passes"""
         to = n if to is None else to
         forces = np.zeros((len(pos), 4), dtype=np.float32)
+        if dedt is not None:
+            dedt[:] = 0          # pre_forces clobbers it (GPUWorker.cc:1961-1963)
+        self.L.orc_set_dedt(P(dedt))
         nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
         cfl = np.zeros(nblk + cfl_offset, dtype=np.float32)
         rbf = np.zeros((max(rb_count, 1), 4), dtype=np.float32)
@@ -315,6 +319,7 @@ class Oracle:
                                        P(rbt) if rb_count else None, P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), P(tau),
                                        C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
                                        C.c_int(compute_object_forces), P(effvisc))
+        self.L.orc_set_dedt(None)
         return forces, cfl, int(nb), rbf, rbt
 
     # ---- SPH_GRENIER (oracle/sph_oracle.c "SPH_GRENIER")
@@ -354,6 +359,11 @@ class Oracle:
         self.L.orc_euler(C.byref(self.p), P(npos), P(nvel), P(old_pos), P(old_vel), P(info), P(hash_), P(forces), P(xsph),
                          C.c_uint32(n), C.c_float(dt), C.c_int(step))
         return npos, nvel
+
+    def euler_energy(self, old_energy, dedt, old_pos, info, n, dt):
+        new = np.zeros_like(old_energy)
+        self.L.orc_euler_energy(C.byref(self.p), P(new), P(old_energy), P(dedt), P(old_pos), P(info), C.c_uint32(n), C.c_float(dt))
+        return new
 
     def xsph(self, pos, vel, info, hash_, cs, nl, n, out=None):
         """mean neighbourhood velocity of the forces pass (ENABLE_XSPH); rows of non-fluid particles keep their content"""
@@ -450,6 +460,10 @@ class OracleSim:
         self.bodies = None
         self.grenier = sp.sph_formulation == D.SPH_GRENIER
         self.effvisc_on = sp.rheologytype > D.NEWTONIAN         # NEEDS_EFFECTIVE_VISC
+        self.energy_on = bool(sp.simflags & D.ENABLE_INTERNAL_ENERGY)
+        if self.energy_on:      # init_internal_energy (src/ProblemCore.cc:1609-1618): zero
+            self.energy = np.zeros(len(self.pos), dtype=np.float32)
+            self.dedt = np.zeros(len(self.pos), dtype=np.float32)
         if self.grenier:    # GPUSPH.cc:495-496
             self.vol = self.o.init_volume(self.pos, self.vel, self.info, self.n)
         if getattr(problem, "moving_bodies_callback", None) is not None and getattr(problem, "num_obstacle", 0):
@@ -481,6 +495,8 @@ class OracleSim:
         self.pos, self.vel = spos, svel
         if getattr(self, "grenier", False):
             self.vol = np.ascontiguousarray(self.vol[pidx])
+        if getattr(self, "energy_on", False):
+            self.energy = np.ascontiguousarray(self.energy[pidx])
         self.partindex = pidx
         self.n = newn
         sq = float(np.float32(self.problem.simparams.nlSqInfluenceRadius))
@@ -543,7 +559,8 @@ class OracleSim:
             ev, self.max_kinvisc = o.effective_visc(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n)
             self.effvisc = ev
         f1, cfl, nb, self.rbf, self.rbt = o.forces(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, n,
-                                                   compute_object_forces=cof, rb_count=rb, tau=tau, effvisc=ev)
+                                                   compute_object_forces=cof, rb_count=rb, tau=tau, effvisc=ev,
+                                                   dedt=self.dedt if self.energy_on else None)
         dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
         xsph_on = bool(sp.simflags & self.D.ENABLE_XSPH)
         if xsph_on:     # BUFFER_XSPH is allocated once and rewritten for the fluid particles by every forces pass
@@ -552,17 +569,22 @@ class OracleSim:
         if self.bodies is not None:
             self._move_bodies(1, dt, self.t)
         ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, float(np.float32(dt) / np.float32(2)), 1, xsph=xs)
+        if self.energy_on:
+            es = o.euler_energy(self.energy, self.dedt, self.pos, self.info, n, float(np.float32(dt) / np.float32(2)))
         # corrector
         tau = o.sps(ps, vs, self.info, self.hash, self.cs, self.nl, n, n)[0] if sps else None
         if self.effvisc_on:
             ev, self.max_kinvisc = o.effective_visc(ps, vs, self.info, self.hash, self.cs, self.nl, n)
         f2, cfl, nb, self.rbf, self.rbt = o.forces(ps, vs, self.info, self.hash, self.cs, self.nl, n,
-                                                   compute_object_forces=cof, rb_count=rb, tau=tau, effvisc=ev)
+                                                   compute_object_forces=cof, rb_count=rb, tau=tau, effvisc=ev,
+                                                   dedt=self.dedt if self.energy_on else None)
         dt2 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
         if xsph_on:
             self.xsph = o.xsph(ps, vs, self.info, self.hash, self.cs, self.nl, n, self.xsph)
         if self.bodies is not None:
             self._move_bodies(2, dt, self.t)
+        if self.energy_on:      # the corrector integrates from the energy of step n with the derivative of n*
+            self.energy = o.euler_energy(self.energy, self.dedt, self.pos, self.info, n, dt)
         self.pos, self.vel = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2, xsph=xs)
         if self.bodies is not None:
             m = self._last_motion
