@@ -88,6 +88,8 @@ SIGNATURES = {
     "sphx_euler_basicstep": (_i, [_vp] + [_vp] * 8 + [_u32, _u32, _f, _vp, _f, _i, _f, _f, _f, _i, _vp]),
     "sphx_euler_basicstep_grenier": (_i, [_vp] + [_vp] * 10 + [_u32, _u32, _f, _vp, _f, _i, _f, _f, _f, _i, _vp]),
     "sphx_init_volume": (_i, [_vp] * 5 + [_u32, _vp]),
+    "sphx_forces_internal_energy": (_i, [_vp] * 8 + [_u32, _u32, _u32, _vp]),
+    "sphx_euler_internal_energy": (_i, [_vp] * 6 + [_u32, _u32, _f, _vp, _f, _vp]),
     "sphx_calc_effvisc": (_i, [_vp] * 9 + [_u32, _u32, _f, _f, _f, _vp]),
     "sphx_forces_basicstep_effvisc": (_i, [_vp] * 10 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_compute_density": (_i, [_vp] * 9 + [_u32, _f, _f, _vp]),

@@ -316,7 +316,15 @@ int main(int argc, char **argv)
 			}
 			sphx_throw(sphx_memcpy_h2d(volA.getData<BUFFER_VOLUME>(), hvol.data(), 16*(size_t)n0));
 		}
-		BufferList *curVol = grenier ? &volA : &noVol, *othVol = grenier ? &volB : &noVol;
+		// ENABLE_INTERNAL_ENERGY: BUFFER_INTERNAL_ENERGY travels with the particle state like the volumes (zero at the start,
+		// ProblemCore::init_internal_energy), BUFFER_INTERNAL_ENERGY_UPD is written by every forces pass (GPUWorker.cc:208-211)
+		const bool energy = (sp->simflags & ENABLE_INTERNAL_ENERGY) != 0;
+		if (energy) {
+			if (grenier) throw std::runtime_error("internal energy with SPH_GRENIER is not built");
+			volA = one_buffer<BUFFER_INTERNAL_ENERGY>(A); volB = one_buffer<BUFFER_INTERNAL_ENERGY>(A);
+			shared |= one_buffer<BUFFER_INTERNAL_ENERGY_UPD>(A);
+		}
+		BufferList *curVol = (grenier || energy) ? &volA : &noVol, *othVol = (grenier || energy) ? &volB : &noVol;
 		uint n = n0;
 		float dt = (float)num(c, "dt0");
 		double t = 0;
@@ -402,6 +410,11 @@ int main(int argc, char **argv)
 		if (!o) throw std::runtime_error(std::string("cannot write ") + argv[3]);
 		fwrite(&n, 4, 1, o); fwrite(&dt, 4, 1, o); fwrite(&t, 8, 1, o);
 		fwrite(hpos.data(), 16, n, o); fwrite(hvel.data(), 16, n, o); fwrite(hinfo.data(), 8, n, o); fwrite(hhash.data(), 4, n, o);
+		if (energy) {       // the internal energies behind the usual state
+			std::vector<float> he(n);
+			sphx_throw(sphx_memcpy_d2h(he.data(), as_const(*curVol).getData<BUFFER_INTERNAL_ENERGY>(), 4*(size_t)n));
+			fwrite(he.data(), 4, n, o);
+		}
 		if (grenier) {      // the volumes behind the usual state
 			std::vector<float4> hvol(n);
 			sphx_throw(sphx_memcpy_d2h(hvol.data(), as_const(*curVol).getData<BUFFER_VOLUME>(), 16*(size_t)n));

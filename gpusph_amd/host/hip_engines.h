@@ -466,6 +466,12 @@ public:
 			tau ? tau[0] : NULL, tau ? tau[1] : NULL, tau ? tau[2] : NULL, xsph,
 			numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor, influenceradius,
 			cflOffset, (int)run_mode, step, dt, compute_object_forces ? 1 : 0, &numBlocks, NULL));
+		if ((P.simflags & ENABLE_INTERNAL_ENERGY) && run_mode == SIMULATE)
+			// internal_energy_forces_params (src/cuda/forces_params.h:296-303): DEDt of this pass
+			sphx_throw(sphx_forces_internal_energy(m_c->ctx(), bufwrite.getData<BUFFER_INTERNAL_ENERGY_UPD>(),
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+				numParticles, fromParticle, toParticle, NULL));
 		return numBlocks;
 	}
 
@@ -606,6 +612,11 @@ public:
 		const uint particleRangeEnd, const float dt, const int step, const float t, const float slength,
 		const float influenceRadius, const RunMode run_mode)
 	{
+		if ((m_c->params().simflags & ENABLE_INTERNAL_ENERGY) && run_mode == SIMULATE)
+			// energy_euler_params (src/cuda/euler_params.h:121-134): BUFFER_INTERNAL_ENERGY old/new, its rate from the forces pass
+			sphx_throw(sphx_euler_internal_energy(m_c->ctx(), bufwrite.getData<BUFFER_INTERNAL_ENERGY>(),
+				bufread.getData<BUFFER_INTERNAL_ENERGY>(), bufread.getData<BUFFER_INTERNAL_ENERGY_UPD>(),
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(), numParticles, particleRangeEnd, dt, NULL, 1.0f, NULL));
 		if (m_c->params().sph_formulation == SPH_GRENIER && run_mode == SIMULATE) {
 			// Vol_params (src/cuda/euler_params.h:153-156): BUFFER_VOLUME of the read and of the write list
 			sphx_throw(sphx_euler_basicstep_grenier(m_c->ctx(), bufwrite.getData<BUFFER_POS>(), bufwrite.getData<BUFFER_VEL>(),

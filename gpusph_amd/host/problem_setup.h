@@ -174,6 +174,12 @@ static SimFramework *make_framework(Case const& c)
 			densitydiffusion<BREZZI>,
 			add_flags<ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES>
 		);
+	} else if (name == "AccuracyTest") {   // src/problems/AccuracyTest.cu:51-55
+		SETUP_FRAMEWORK(
+			viscosity<ARTVISC>,
+			boundary<DYN_BOUNDARY>,
+			add_flags<ENABLE_INTERNAL_ENERGY>
+		);
 	} else if (name == "DEMExample") {     // src/problems/DEMExample.cu:47-52
 		const DensityDiffusionType rhodiff = (DensityDiffusionType)(int)num(c, "rhodiff");
 		SETUP_FRAMEWORK(

@@ -234,6 +234,17 @@ class HipKernels:
                                                  p(forces), p(xsph), n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
                                                  P.slength, P.influenceradius, run_mode, self._s()))
 
+    # ---- ENABLE_INTERNAL_ENERGY (energy.hip)
+    def forces_internal_energy(self, dedt, pos, vel, info, hash_, cellStart, neibslist, n, frm, to):
+        p = capi.ptr
+        capi.check(self.lib.sphx_forces_internal_energy(self.ctx.handle, p(dedt), p(pos), p(vel), p(info), p(hash_), p(cellStart),
+                                                        p(neibslist), n, frm, to, self._s()))
+
+    def euler_internal_energy(self, new_energy, old_energy, dedt, old_pos, info, n, d_dt, dt_scale):
+        p = capi.ptr
+        capi.check(self.lib.sphx_euler_internal_energy(self.ctx.handle, p(new_energy), p(old_energy), p(dedt), p(old_pos), p(info), n, n,
+                                                       0.0, p(d_dt), dt_scale, self._s()))
+
     # ---- generalized Newtonian rheologies (rheology.hip)
     def calc_effvisc(self, effvisc, pos, vel, info, hash_, cellStart, neibslist, n, range_end):
         """CALC_VISC: BUFFER_EFFVISC written; returns the largest kinematic viscosity (one host synchronisation) and makes it

@@ -180,6 +180,13 @@ class MultiGpuEngine:
             self.sa_density_sum = bool(self.sp.simflags & D.ENABLE_DENSITY_SUM)
             self.cfl_gamma = (torch.zeros(A + 4 + self.cfl.numel(), dtype=f32, device=dev) if self.sa_dynamic_gamma else None)
         self.effvisc = torch.zeros(A, dtype=f32, device=dev) if self.effvisc_on else None      # BUFFER_EFFVISC
+        # ENABLE_INTERNAL_ENERGY: BUFFER_INTERNAL_ENERGY (double buffered, re-sorted; starts from zero: init_internal_energy) and its rate
+        self.energy_on = bool(self.sp.simflags & D.ENABLE_INTERNAL_ENERGY)
+        if self.energy_on:
+            if world > 1:
+                raise ValueError("ENABLE_INTERNAL_ENERGY: single domain only")
+            self.energy = torch.zeros(A, dtype=f32, device=dev); self.energy2 = torch.zeros_like(self.energy)
+            self.dedt = torch.zeros(A, dtype=f32, device=dev)
         # SPH_GRENIER: BUFFER_VOLUME (double buffered like pos/vel, travels through the re-sort) and BUFFER_SIGMA
         if self.grenier:
             self.vol = torch.zeros((A, 4), dtype=f32, device=dev); self.vol2 = torch.zeros_like(self.vol)
@@ -260,6 +267,9 @@ class MultiGpuEngine:
                 src, dst = getattr(self, name), getattr(self, name + "2")
                 K.gather_rows(dst, src, self.partindex, n)
                 setattr(self, name, dst); setattr(self, name + "2", src)
+        if self.energy_on:
+            K.gather_rows(self.energy2, self.energy, self.partindex, n)
+            self.energy, self.energy2 = self.energy2, self.energy
         if self.grenier:
             K.gather_rows(self.vol2, self.vol, self.partindex, n)
             self.vol, self.vol2 = self.vol2, self.vol
@@ -441,6 +451,8 @@ class MultiGpuEngine:
                 e1.record(); self.profile_forces.append((e0, e1))
             if self.world > 1:
                 self._exchange([self.forces])
+        if self.energy_on and run_mode == D.SIMULATE:      # the BUFFER_INTERNAL_ENERGY_UPD output of the pass
+            K.forces_internal_energy(self.dedt, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, 0, self.n_int)
         K.dtreduce(self.cfl, self.cfl_temp, nb1 + nb2, self.d_dt_next, combine_min)
 
     def step(self):
@@ -468,6 +480,8 @@ class MultiGpuEngine:
             K.euler_grenier(self.pos2, self.vel2, self.vol2, self.pos, self.vel, self.vol, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1)
         else:
             K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1, **ekw)
+        if self.energy_on:
+            K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 0.5)
         if self.sa:
             self._sa_post_euler(1)
         # corrector: forces(step n*) -> n+1 = n + dt f*   (written over n*, then renamed to n)
@@ -479,6 +493,9 @@ class MultiGpuEngine:
             self.vol, self.vol2 = self.vol2, self.vol
         else:
             K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2, **ekw)
+        if self.energy_on:
+            K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 1.0)
+            self.energy, self.energy2 = self.energy2, self.energy
         if self.sa:
             self._sa_post_euler(2)
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma

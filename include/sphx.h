@@ -77,6 +77,7 @@ enum sphx_postproc    { SPHX_VORTICITY = 0, SPHX_TESTPOINTS = 1, SPHX_SURFACE_DE
 #define SPHX_ENABLE_DENSITY_SUM    (1ull << 7)
 #define SPHX_ENABLE_GAMMA_QUADRATURE (1ull << 8)
 #define SPHX_ENABLE_REPACKING      (1ull << 9)
+#define SPHX_ENABLE_INTERNAL_ENERGY (1ull << 10)
 #define SPHX_ENABLE_MULTIFLUID     (1ull << 11)
 
 /* Everything the three setconstants() upload (src/cuda/forces.cu:268-399,
@@ -391,6 +392,22 @@ int sphx_euler_basicstep(sphx_ctx *ctx, void *newPos, void *newVel,
 	uint32_t numParticles, uint32_t particleRangeEnd,
 	float dt, const float *d_dt, float dt_scale, int step, float t,
 	float slength, float influenceradius, int run_mode, void *stream);
+
+/* ---- ENABLE_INTERNAL_ENERGY (AccuracyTest) --------------------------------------------------------------------------------------
+ *   sphx_forces_internal_energy  the BUFFER_INTERNAL_ENERGY_UPD output of a forces pass (internal_energy_forces_params,
+ *                                src/cuda/forces_params.h:296-303; add_internal_energy src/cuda/forces_kernel.def:3308-3320): call it with
+ *                                the arguments of the sphx_forces_basicstep it belongs to; DEDt[from..to) is written (the reference
+ *                                clobbers the buffer before the pass and accumulates over its three launches)
+ *   sphx_euler_internal_energy   the BUFFER_INTERNAL_ENERGY part of the integration step (energy_euler_params,
+ *                                src/cuda/euler_params.h:121-134): newEnergy = oldEnergy + dt DEDt for the particles eulerDevice
+ *                                integrates; dt / d_dt / dt_scale as in sphx_euler_basicstep */
+int sphx_forces_internal_energy(sphx_ctx *ctx, float *DEDt,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, void *stream);
+int sphx_euler_internal_energy(sphx_ctx *ctx, float *newEnergy, const float *oldEnergy, const float *DEDt,
+	const void *oldPos, const void *info, uint32_t numParticles, uint32_t particleRangeEnd,
+	float dt, const float *d_dt, float dt_scale, void *stream);
 
 /* ---- generalized Newtonian rheologies (rheology<BINGHAM | PAPANASTASIOU | POWER_LAW | HERSCHEL_BULKLEY | ALEXANDROU | DEKEE_TURCOTTE |
  * ZHU>, e.g. PoiseuillePapanastasiou) ------------------------------------------------------------------------------------------

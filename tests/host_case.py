@@ -126,7 +126,9 @@ def read_out(path):
     info = np.frombuffer(raw, np.uint16, 4 * n, o).reshape(n, 4); o += 8 * n
     hsh = np.frombuffer(raw, np.uint32, n, o); o += 4 * n
     out = dict(n=n, dt=dt, t=t, pos=pos, vel=vel, info=info, hash=hsh)
-    if len(raw) - o == 16 * n:      # SPH_GRENIER: BUFFER_VOLUME
+    if len(raw) - o == 4 * n:       # ENABLE_INTERNAL_ENERGY: BUFFER_INTERNAL_ENERGY
+        out["energy"] = np.frombuffer(raw, np.float32, n, o)
+    elif len(raw) - o == 16 * n:    # SPH_GRENIER: BUFFER_VOLUME
         out["vol"] = np.frombuffer(raw, np.float32, 4 * n, o).reshape(n, 4)
     elif len(raw) > o:              # the SA initialisation run appends its buffers and the list counters
         out["vertices"] = np.frombuffer(raw, np.uint32, 4 * n, o).reshape(n, 4); o += 16 * n

@@ -189,6 +189,15 @@ def test_dem_mirror_against_the_demexample_framework(tmp_path):
     assert got.ewres == np.float32(1.6 / 32) and got.demzmin == np.float32(5 * prob.m_deltap)
 
 
+def test_internal_energy_mirror_against_the_accuracytest_framework(tmp_path):
+    prob = DamBreak3D(0.05, obstacle=False, internal_energy=True, density_diffusion=D.DENSITY_DIFFUSION_NONE)
+    prob.simparams.simflags &= ~D.ENABLE_REPACKING
+    out = run_check(tmp_path, hc.case_lines(prob, "AccuracyTest"))
+    assert_options(out, prob.simparams)
+    assert out["options"]["simflags"] == D.ENABLE_DTADAPT | D.ENABLE_INTERNAL_ENERGY
+    assert_params(out, prob, prob.num_particles)
+
+
 def test_selector_semantics_of_the_factory(tmp_path):
     """defaults, the legacy viscosity names, Grenier's harmonic rule, run-time walks over option ranges"""
     d = run_check(tmp_path, ["framework Default"])["options"]   # TypeDefaults, src/cuda/cudasimframework.cu:346-360
