@@ -1732,6 +1732,12 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: only DYN_BOUNDARY and LJ_BOUNDARY pair interactions are built");
 	if (ctx->params.rheologytype > SPHX_NEWTONIAN && run_mode == SPHX_SIMULATE)
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: generalized Newtonian rheologies read BUFFER_EFFVISC, use sphx_forces_basicstep_effvisc");
+	if (ctx->params.sph_formulation == SPHX_SPH_HA && run_mode == SPHX_SIMULATE) {      // Hu & Adams: rheology.hip
+		if (compute_object_forces || rbforces)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: SPH_HA with bodies that feel the fluid is not built");
+		return sphx_fidelity_forces_launch(ctx, forces, cfl, pos, vel, info, hash, cellStart, neibsList, nullptr, numParticles, fromParticle,
+			toParticle, slength, influenceradius, cflOffset, h_numBlocks, stream);
+	}
 	if (ctx->params.sph_formulation == SPHX_SPH_GRENIER && run_mode == SPHX_SIMULATE)
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: SPH_GRENIER reads BUFFER_SIGMA, use sphx_forces_basicstep_grenier");
 	if (ctx->dev.turbmodel == SPHX_SPS && run_mode == SPHX_SIMULATE)

@@ -201,9 +201,14 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 			const bool fluid = ptype == PT_FLUID;
 			const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
 			const float p_P = sa_P(p, vel.w, fl);
-			const float p_precalc = p_P/(p_rho*p_rho);
+			// SPH_HA (Hu & Adams): P instead of P/rho^2, the volumes V = m/rho in the pressure term, the particle's own mass in the
+			// continuity equation (forces_kernel.def:458-468,2030-2046,2269-2286,2436-2448)
+			const bool ha = p.formulation == SPHX_SPH_HA;
+			const float p_precalc = ha ? p_P : p_P/(p_rho*p_rho);
 			const float p_sspeed = sa_sound_speed(p, vel.w, fl);
-			const float p_visc = a.effvisc[index];
+			const bool viscous = p.rheology != SPHX_INVISCID;
+			const float p_visc = a.effvisc ? a.effvisc[index] : p.visccoeff[fl];      // per particle (generalized Newtonian) or per fluid
+			const float p_volume = pos.w/p_rho;
 			const bool momentum = fluid || HAS_COMPUTE_FORCE(info);
 			auto pair = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz, bool nfluid) {
 				if (!is_active_w(npos.w)) return;
@@ -218,11 +223,28 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 				const float nmass = npos.w;
 				// compute_density_derivative: divergence of velocity + density diffusion (fluid neighbours only)
 				float DrDt = nmass*vel_dot_pos*f;
+				if (ha) DrDt = pos.w*vel_dot_pos*f;
+				const float n_volume = nmass/n_rho;
 				if (nfluid && p.densitydiff == SPHX_COLAGROSSI && nfl == fl) {
 					const float gdotr = sa_dot3(p.gravity[0], p.gravity[1], p.gravity[2], rx, ry, rz);
-					if (!(fabsf(p_P - sa_P(p, nvel.w, fl)) < fabsf(gdotr*p_rho)))
-						DrDt -= p.densityDiffCoeff*p.sscoeff[fl]*(n_rho/p_rho - 1)*f*nmass;
+					if (!(fabsf(p_P - sa_P(p, nvel.w, fl)) < fabsf(gdotr*p_rho))) {
+						if (ha) DrDt -= p.densityDiffCoeff*p.sscoeff[fl]*(p_volume/n_volume - 1)*f*pos.w;      // :1954-1996
+						else DrDt -= p.densityDiffCoeff*p.sscoeff[fl]*(n_rho/p_rho - 1)*f*nmass;
+					}
 				}
+				if (nfluid && p.densitydiff == SPHX_FERRARI && ha) {      // :1639-1677, same fluid only; the reference's 1./V makes it double
+					if (nfl == fl) {
+						const float sqC0 = p.sscoeff[fl]*p.sscoeff[fl];
+						const float grav_corr = -sa_dot3(p.gravity[0], p.gravity[1], p.gravity[2], rx, ry, rz)*p.rho0[fl]/sqC0;
+						float fx = 0.0f, fy = 0.0f, fz = 0.0f;
+						if (r > 1e-4f*p.slength) {
+							const float sc = (float)((double)fmaxf(p_sspeed, sa_sound_speed(p, nvel.w, nfl))*
+								((double)pos.w*(1./(double)p_volume - (double)(1.0f/(1.0f*n_volume))) + (double)grav_corr)/(double)p_rho/(double)r);
+							fx = sc*rx; fy = sc*ry; fz = sc*rz;
+						}
+						DrDt += p.densityDiffCoeff*nmass*sa_dot3(fx, fy, fz, rx, ry, rz)*f;
+					}
+				} else
 				if (nfluid && p.densitydiff == SPHX_FERRARI) {
 					const float sqC0 = p.sscoeff[fl]*p.sscoeff[fl];
 					const float grav_corr = -sa_dot3(p.gravity[0], p.gravity[1], p.gravity[2], rx, ry, rz)*p.rho0[fl]/sqC0;
@@ -235,12 +257,16 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 				}
 				force.w += DrDt;
 				if (!momentum) return;
-				const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
-				const float s = (p_precalc + n_precalc)*nmass*f;
+				const float n_P = sa_P(p, nvel.w, nfl);
+				const float n_precalc = ha ? n_P : n_P/(n_rho*n_rho);
+				float s = (p_precalc + n_precalc)*nmass*f;
+				if (ha) s = (p_precalc*p_volume*p_volume + n_precalc*n_volume*n_volume)/pos.w*f;
 				float dx = 0.0f, dy = 0.0f, dz = 0.0f;
 				dx -= s*rx; dy -= s*ry; dz -= s*rz;
-				const float vf = sa_visc_avg(p, p_visc, a.effvisc[j], p_rho, n_rho, nmass)*f;
-				dx += vf*vx; dy += vf*vy; dz += vf*vz;
+				if (viscous) {
+					const float vf = sa_visc_avg(p, p_visc, a.effvisc ? a.effvisc[j] : p.visccoeff[nfl], p_rho, n_rho, nmass)*f;
+					dx += vf*vx; dy += vf*vy; dz += vf*vz;
+				}
 				force.x += dx; force.y += dy; force.z += dz;
 			};
 			for_each_neib<PT_FLUID>(p, a, index, pos, gridPos,
@@ -253,7 +279,7 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 				force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
 				if ((p.simflags & SPHX_ENABLE_PLANES) && p.numplanes) {
 					// GeometryForce / PlaneForce (src/cuda/forces_kernel.cu:140-203) with mu = get_laminar_dyn_visc of the particle
-					const float dynvisc = (p.compvisc == SPHX_KINEMATIC) ? p_visc*p_rho : p_visc;
+					const float dynvisc = !viscous ? 0.0f : (p.compvisc == SPHX_KINEMATIC) ? p_visc*p_rho : p_visc;
 					for (uint32_t k = 0; k < p.numplanes; ++k) {
 						const float ddx = (gridPos.x - p.plane_gridpos[k][0])*p.cs[0] + (pos.x - p.plane_pos[k][0]);
 						const float ddy = (gridPos.y - p.plane_gridpos[k][1])*p.cs[1] + (pos.y - p.plane_pos[k][1]);
@@ -289,6 +315,14 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 	}
 }
 
+// the kernel above for a SIMULATE pass: with BUFFER_EFFVISC (generalized Newtonian rheologies, SPH_F1 or SPH_HA) or without
+// (effvisc = NULL: the SPH_HA formulation with a Newtonian or no viscosity, routed here by sphx_forces_basicstep)
+int sphx_fidelity_forces_launch(sphx_ctx *ctx, void *forces, float *cfl,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *effvisc,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float slength, float influenceradius, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream);
+
 extern "C" int sphx_forces_basicstep_effvisc(sphx_ctx *ctx, void *forces, float *cfl,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, const float *effvisc,
@@ -299,14 +333,25 @@ extern "C" int sphx_forces_basicstep_effvisc(sphx_ctx *ctx, void *forces, float 
 	(void)deltap; (void)dtadaptfactor; (void)step; (void)dt;
 	int rc = gn_check(ctx, "sphx_forces_basicstep_effvisc called for a rheology without effective viscosity");
 	if (rc != SPHX_OK) return rc;
-	const sphx_params &q = ctx->params;
 	if (run_mode != SPHX_SIMULATE)
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep_effvisc: repacking runs use sphx_forces_basicstep (no viscous term there)");
-	if (q.sph_formulation != SPHX_SPH_F1 || q.boundarytype != SPHX_DYN_BOUNDARY || q.turbmodel != SPHX_LAMINAR_FLOW || q.viscmodel != SPHX_MORRIS)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies are built for SPH_F1, DYN_BOUNDARY, LAMINAR_FLOW and the MORRIS viscous model");
+	SPHX_REQUIRE(effvisc != nullptr, "sphx_forces_basicstep_effvisc: missing buffer");
+	return sphx_fidelity_forces_launch(ctx, forces, cfl, pos, vel, info, hash, cellStart, neibsList, effvisc, numParticles, fromParticle,
+		toParticle, slength, influenceradius, cflOffset, h_numBlocks, stream);
+}
+
+int sphx_fidelity_forces_launch(sphx_ctx *ctx, void *forces, float *cfl,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *effvisc,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float slength, float influenceradius, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream)
+{
+	const sphx_params &q = ctx->params;
+	if ((q.sph_formulation != SPHX_SPH_F1 && q.sph_formulation != SPHX_SPH_HA) || q.boundarytype != SPHX_DYN_BOUNDARY || q.turbmodel != SPHX_LAMINAR_FLOW || q.viscmodel != SPHX_MORRIS)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies and SPH_HA are built for DYN_BOUNDARY, LAMINAR_FLOW and the MORRIS viscous model");
 	if (q.simflags & (SPHX_ENABLE_XSPH | SPHX_ENABLE_MOVING_BODIES))
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies are built without XSPH and without moving bodies");
-	SPHX_REQUIRE(forces && pos && vel && info && hash && cellStart && neibsList && effvisc, "sphx_forces_basicstep_effvisc: missing buffer");
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies and SPH_HA are built without XSPH and without moving bodies");
+	SPHX_REQUIRE(forces && pos && vel && info && hash && cellStart && neibsList, "sphx_forces_basicstep (SPH_HA / effective viscosity): missing buffer");
 	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_forces_basicstep_effvisc: empty or inverted range");
 	SPHX_REQUIRE(slength == q.slength && influenceradius == q.influenceradius,
 		"sphx_forces_basicstep_effvisc: slength / influenceradius differ from the uploaded constants");

@@ -184,8 +184,13 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	SPHX_REQUIRE(sp->numfluids >= 1 && sp->numfluids <= SPHX_MAX_FLUIDS, "sphx_set_constants: numfluids out of range");
 	SPHX_REQUIRE(sp->neiblistsize >= 2 && sp->neibboundpos < sp->neiblistsize, "sphx_set_constants: invalid neighbour list geometry");
 	// option combinations built into this library (the rest is SURVEY.md 8f "next")
-	if (sp->sph_formulation != SPHX_SPH_F1 && sp->sph_formulation != SPHX_SPH_F2 && sp->sph_formulation != SPHX_SPH_GRENIER)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SPH_F1, SPH_F2 and SPH_GRENIER are built, SPH_HA is not");
+	if (sp->sph_formulation < SPHX_SPH_F1 || sp->sph_formulation > SPHX_SPH_HA)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx: invalid SPH formulation");
+	if (sp->sph_formulation == SPHX_SPH_HA) {
+		// Hu & Adams (BiFluidPoiseuille): rheology.hip's forces kernel
+		if (sp->boundarytype != SPHX_DYN_BOUNDARY || sp->turbmodel != SPHX_LAMINAR_FLOW)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: SPH_HA is built for DYN_BOUNDARY and LAMINAR_FLOW");
+	}
 	if (sp->sph_formulation == SPHX_SPH_GRENIER) {
 		// the option set of the reference's Grenier problems (Bubble, LockExchange, RTInstability, OilJet): Wendland kernel,
 		// dynamic boundaries, laminar flow, no density diffusion; grenier.hip
@@ -216,8 +221,8 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: INVISCID, NEWTONIAN and the generalized Newtonian rheologies (BINGHAM .. ZHU) are built, GRANULAR is not");
 	if (sp->rheologytype > SPHX_NEWTONIAN) {
 		// rheology.hip: effective viscosity + the forces that read it
-		if (sp->sph_formulation != SPHX_SPH_F1 || sp->boundarytype != SPHX_DYN_BOUNDARY || sp->turbmodel != SPHX_LAMINAR_FLOW)
-			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies are built for SPH_F1, DYN_BOUNDARY and LAMINAR_FLOW");
+		if ((sp->sph_formulation != SPHX_SPH_F1 && sp->sph_formulation != SPHX_SPH_HA) || sp->boundarytype != SPHX_DYN_BOUNDARY || sp->turbmodel != SPHX_LAMINAR_FLOW)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies are built for SPH_F1 / SPH_HA, DYN_BOUNDARY and LAMINAR_FLOW");
 		SPHX_REQUIRE(sp->limiting_kinvisc == sp->limiting_kinvisc, "sphx_set_constants: generalized Newtonian rheologies need limiting_kinvisc");
 		for (uint32_t f = 0; f < sp->numfluids; ++f)
 			SPHX_REQUIRE(sp->yield_strength[f] == sp->yield_strength[f] && sp->visc_nonlinear_param[f] == sp->visc_nonlinear_param[f] &&

@@ -177,6 +177,11 @@ static inline uint32_t round_up_u(uint32_t a, uint32_t b) { return div_up_u(a, b
 int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles);
 // repacking forces (filters.hip), reached through sphx_forces_basicstep(run_mode = SPHX_REPACK)
 #define SPHX_RB_RING 16
+int sphx_fidelity_forces_launch(sphx_ctx *ctx, void *forces, float *cfl,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, const float *effvisc,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float slength, float influenceradius, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream);   // rheology.hip
 int sphx_rb_flush(sphx_ctx *ctx, hipStream_t st);
 int sphx_xsph_launch(sphx_ctx *ctx, void *xsph, const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle, hipStream_t st);

@@ -174,6 +174,23 @@ static SimFramework *make_framework(Case const& c)
 			densitydiffusion<BREZZI>,
 			add_flags<ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES>
 		);
+	} else if (name == "BiFluidPoiseuilleDYN") {   // src/problems/BiFluidPoiseuille.inc:45-59 with the DYN defines of BiFluidPoiseuilleDYN.cu:27-28
+		const DensityDiffusionType RHODIFF = (DensityDiffusionType)(int)num(c, "rhodiff");
+		SETUP_FRAMEWORK(
+			formulation<SPH_HA>,
+			rheology<NEWTONIAN>,
+			turbulence_model<LAMINAR_FLOW>,
+			computational_visc<DYNAMIC>,
+			visc_model<MORRIS>,
+			visc_average<HARMONIC>,
+			boundary<DYN_BOUNDARY>,
+			periodicity<PERIODIC_XY>,
+			add_flags<ENABLE_MULTIFLUID | ENABLE_DTADAPT>
+			).select_options(
+			RHODIFF == FERRARI, densitydiffusion<FERRARI>(),
+			RHODIFF == BREZZI, densitydiffusion<BREZZI>(),
+			RHODIFF == COLAGROSSI, densitydiffusion<COLAGROSSI>()
+		);
 	} else if (name == "AccuracyTest") {   // src/problems/AccuracyTest.cu:51-55
 		SETUP_FRAMEWORK(
 			viscosity<ARTVISC>,

@@ -813,7 +813,9 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 		/* precalc_pressure SPH_F1: P/rho^2, :419-429 */
 		/* ... SPH_F2: P (:431-441) */
 		const int f2 = p->sph_formulation == ORC_SPH_F2;
-		const float p_precalc = f2 ? orc_P(p, vel.w, p_fluid) : orc_P(p, vel.w, p_fluid)/(p_rho*p_rho);
+		/* SPH_HA (Hu & Adams): precalc = P (:458-468), volumes V = m/rho in the pressure term, own mass in the continuity equation */
+		const int ha = p->sph_formulation == ORC_SPH_HA;
+		const float p_precalc = (f2 || ha) ? orc_P(p, vel.w, p_fluid) : orc_P(p, vel.w, p_fluid)/(p_rho*p_rho);
 		const float *p_tau = tauArray ? tauArray + 6*(size_t)index : NULL;
 
 		orc_f4 force = forces[index]; /* common_particle_output, :886-895 */
@@ -845,7 +847,7 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			const int n_fluid = FLUID_NUM(neib_info);
 			const float n_sspeed = orc_soundSpeed(p, n_rhot, n_fluid);
 			const float n_rho = physical_density(p, n_rhot, n_fluid);
-			const float n_precalc = f2 ? orc_P(p, n_rhot, n_fluid) : orc_P(p, n_rhot, n_fluid)/(n_rho*n_rho);
+			const float n_precalc = (f2 || ha) ? orc_P(p, n_rhot, n_fluid) : orc_P(p, n_rhot, n_fluid)/(n_rho*n_rho);
 
 			float DvDt[3] = {0.0f, 0.0f, 0.0f};
 			float DrDt = 0.0f;
@@ -926,7 +928,18 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			if ((all_pp || dyn_bf) && !(p->simflags & ORC_ENABLE_DENSITY_SUM)) {
 				/* compute_density_derivative, :2176-2190 */
 				DrDt = nmass*vel_dot_pos*f; /* mass_continuity_div_vel_term :2140-2151 */
+				if (ha) DrDt = pos.w*vel_dot_pos*f;      /* SPH_HA: the particle's own mass, :2030-2046 */
 				/* compute_density_diffusion (Colagrossi, nptype==FLUID only), :1916-1952 */
+				if (ha && p->densitydiffusiontype == ORC_COLAGROSSI && nptype == PT_FLUID) {
+					/* Molteni & Colagrossi for SPH_HA (:1954-1996): volume ratio instead of density ratio, own mass */
+					if (p_fluid == n_fluid) {
+						const float gdotr = dot3(p->gravity[0], p->gravity[1], p->gravity[2], rx, ry, rz);
+						if (!(fabsf(orc_P(p, vel.w, p_fluid) - orc_P(p, n_rhot, p_fluid)) < fabsf(gdotr*p_rho))) {
+							const float p_volume = pos.w/p_rho, n_volume = nmass/n_rho;
+							DrDt -= p->densityDiffCoeff*p->sscoeff[p_fluid]*(p_volume/n_volume - 1)*f*pos.w;
+						}
+					}
+				} else
 				if (p->densitydiffusiontype == ORC_COLAGROSSI && nptype == PT_FLUID) {
 					const int fType = p_fluid;
 					if (fType == n_fluid) {
@@ -941,6 +954,22 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				}
 				/* compute_density_diffusion (Ferrari, fluid neighbours only outside SA), :1607-1635; d_sqC0 = sscoeff^2
 				 * in float (src/cuda/forces.cu:319-325) */
+				if (ha && p->densitydiffusiontype == ORC_FERRARI && nptype == PT_FLUID) {
+					/* Ferrari for SPH_HA (:1639-1677): no inter-phase diffusion; (rho - rho') becomes m (1/V - theta'/(theta V')), theta = 1 outside SA */
+					if (p_fluid == n_fluid) {
+						const float sqC0 = p->sscoeff[p_fluid]*p->sscoeff[p_fluid];
+						const float grav_corr = -dot3(p->gravity[0], p->gravity[1], p->gravity[2], rx, ry, rz)*p->rho0[p_fluid]/sqC0;
+						const float p_volume = pos.w/p_rho, n_volume = nmass/n_rho;
+						float fc[3] = {0.0f, 0.0f, 0.0f};
+						if (r > 1e-4f*p->slength) {
+							/* the reference writes 1./p_volume: the bracket, and with it the whole scalar factor, is evaluated in double */
+							const float sc = (float)((double)fmaxf(p_sspeed, n_sspeed)*
+								((double)pos.w*(1./(double)p_volume - (double)(1.0f/(1.0f*n_volume))) + (double)grav_corr)/(double)p_rho/(double)r);
+							fc[0] = sc*rx; fc[1] = sc*ry; fc[2] = sc*rz;
+						}
+						DrDt += p->densityDiffCoeff*nmass*dot3(fc[0], fc[1], fc[2], rx, ry, rz)*f;
+					}
+				} else
 				if (p->densitydiffusiontype == ORC_FERRARI && nptype == PT_FLUID) {
 					const int fType = p_fluid;
 					const float sqC0 = p->sscoeff[fType]*p->sscoeff[fType];
@@ -959,8 +988,13 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			if (all_pp || (dyn_bf && (COMPUTE_FORCE(info) || (p->simflags & ORC_ENABLE_INTERNAL_ENERGY)))) {      /* :3661 */
 				/* compute_pressure_contrib general, :2451-2466 */
 				/* pressure_gradient_term: SPH_F1 P_i/rho_i^2 + P_j/rho_j^2 (:2358-2371), SPH_F2 (P_i + P_j)/(rho_i rho_j) (:2253-2266) */
-				const float pGradTerm = f2 ? (p_precalc + n_precalc)/(p_rho*n_rho) : p_precalc + n_precalc;
-				const float s = pGradTerm*nmass*f;
+				float pGradTerm = f2 ? (p_precalc + n_precalc)/(p_rho*n_rho) : p_precalc + n_precalc;
+				float s = pGradTerm*nmass*f;
+				if (ha) {      /* pressure_gradient_term :2269-2286 (P_a V_a^2 + P_b V_b^2), compute_pressure_contrib :2436-2448 (/ m_a) */
+					const float p_volume = pos.w/p_rho, n_volume = nmass/n_rho;
+					pGradTerm = p_precalc*p_volume*p_volume + n_precalc*n_volume*n_volume;
+					s = pGradTerm/pos.w*f;
+				}
 				DvDt[0] -= s*rx; DvDt[1] -= s*ry; DvDt[2] -= s*rz;
 
 				/* compute_viscous_contrib: turbulent first, then laminar, :2881-2886 */

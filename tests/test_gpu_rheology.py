@@ -131,3 +131,65 @@ def test_cpp_adapters_run_the_papanastasiou_step_like_the_python_driver(tmp_path
     assert np.array_equal(out["hash"], ref["hash"])
     assert np.array_equal(_bits(out["pos"]), _bits(ref["pos"])) and np.array_equal(_bits(out["vel"]), _bits(ref["vel"]))
     assert np.abs(out["vel"][:, 0]).max() > 0
+
+
+HA_VISC = dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.DYNAMIC, avgop=D.HARMONIC)
+
+
+@pytest.mark.parametrize("kw", [dict(density_diffusion=D.DENSITY_DIFFUSION_NONE), dict(density_diffusion=D.COLAGROSSI),
+                                dict(density_diffusion=D.FERRARI), dict(two_fluids=False, viscosity=dict(rheologytype=D.INVISCID, turbmodel=D.LAMINAR_FLOW))])
+def test_sph_ha_forces_and_trajectory(kw):
+    """SPH_HA (Hu & Adams, BiFluidPoiseuille's formulation) through sphx_forces_basicstep, which routes it to rheology.hip's kernel"""
+    import torch
+    from gpusph_amd.problem import DamBreak3D
+    args = dict(deltap=0.045, obstacle=False, two_fluids=True, formulation=D.SPH_HA, viscosity=HA_VISC, jitter=0.15, hydrostatic=False)
+    args.update(kw)
+    sim = ol.OracleSim(DamBreak3D(**args)); sim.build_neibs()
+    eng = _engine(DamBreak3D(**args), clobber_neibslist=True); eng.build_neibs()
+    n = sim.n
+    rng = np.random.default_rng(21)
+    fluid = info_type(sim.info[:n]) == D.PT_FLUID
+    sim.vel[:n, :3][fluid] += rng.uniform(-0.3, 0.3, size=(fluid.sum(), 3)).astype(np.float32)
+    sim.vel[:n, 3] += rng.uniform(0, 3e-3, size=n).astype(np.float32)
+    eng.vel[:n].copy_(torch.from_numpy(sim.vel[:n]).to(eng.device))
+    f, cfl, nb, _, _ = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng._forces(eng.pos, eng.vel, 1, 0)
+    gf = _np(eng.forces)[:n]
+    scale = np.abs(f[:n, :3]).max()
+    assert np.abs(gf[:, :3] - f[:n, :3]).max() <= 2e-5 * scale
+    assert np.abs(gf[:, 3] - f[:n, 3]).max() <= 2e-5 * np.abs(f[:n, 3]).max() + 1e-7
+    # differs from SPH_F1 on the same state once the densities are not uniform
+    sim.o.p.sph_formulation = D.SPH_F1
+    f1 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0]
+    if args["two_fluids"]:      # with equal masses the two formulations coincide: (P_a V_a^2 + P_b V_b^2)/m = m (P_a/rho_a^2 + P_b/rho_b^2)
+        assert np.abs(f1[:n, :3] - f[:n, :3]).max() > 1e-3 * scale
+    sim2 = ol.OracleSim(DamBreak3D(**args)); eng2 = _engine(DamBreak3D(**args))
+    steps = 8
+    for _ in range(steps):
+        sim2.step(); eng2.step()
+    out = eng2.download()
+    assert np.array_equal(out["hash"], sim2.hash[:n])
+    assert np.abs(out["vel"][:, :3] - sim2.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim2.vel[:n, :3]).max(), 1e-6)
+
+
+def test_cpp_adapters_with_the_bifluid_poiseuille_framework(tmp_path):
+    import os, subprocess
+    import host_case as hc
+    from gpusph_amd.problem import DamBreak3D
+    prob = DamBreak3D(0.045, obstacle=False, two_fluids=True, formulation=D.SPH_HA, viscosity=HA_VISC, jitter=0.05,
+                      density_diffusion=D.COLAGROSSI)
+    prob.simparams.simflags &= ~D.ENABLE_REPACKING
+    # the framework of BiFluidPoiseuilleDYN is periodic in x and y; the engines do not care whether particles use it: this tank has walls
+    prob.simparams.periodicbound = D.PERIODIC_X | D.PERIODIC_Y
+    eng = _engine(prob)
+    steps = 12
+    case, state, fout = tmp_path / "case.txt", tmp_path / "state.bin", tmp_path / "out.bin"
+    case.write_text("\n".join(hc.case_lines(prob, "BiFluidPoiseuilleDYN", rhodiff=D.COLAGROSSI) + hc.driver_lines(prob, eng, steps)) + "\n")
+    hc.write_state(state, prob.copy_to_array())
+    r = subprocess.run([hc.exe("example_engines"), str(case), str(state), str(fout)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    eng.run(steps)
+    ref = eng.download()
+    out = hc.read_out(fout)
+    assert out["n"] == eng.n and np.float32(eng.current_dt()) == out["dt"]
+    assert np.array_equal(_bits(out["pos"]), _bits(ref["pos"])) and np.array_equal(_bits(out["vel"]), _bits(ref["vel"]))

@@ -198,6 +198,17 @@ def test_internal_energy_mirror_against_the_accuracytest_framework(tmp_path):
     assert_params(out, prob, prob.num_particles)
 
 
+def test_sph_ha_mirror_against_the_bifluid_poiseuille_framework(tmp_path):
+    prob = DamBreak3D(0.05, obstacle=False, two_fluids=True, formulation=D.SPH_HA, density_diffusion=D.FERRARI,
+                      viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.DYNAMIC, avgop=D.HARMONIC))
+    prob.simparams.simflags &= ~D.ENABLE_REPACKING
+    prob.simparams.periodicbound = D.PERIODIC_X | D.PERIODIC_Y
+    out = run_check(tmp_path, hc.case_lines(prob, "BiFluidPoiseuilleDYN", rhodiff=D.FERRARI))
+    assert_options(out, prob.simparams)
+    assert out["options"]["sph_formulation"] == D.SPH_HA and out["options"]["is_const_visc"] == 0
+    assert_params(out, prob, prob.num_particles)
+
+
 def test_selector_semantics_of_the_factory(tmp_path):
     """defaults, the legacy viscosity names, Grenier's harmonic rule, run-time walks over option ranges"""
     d = run_check(tmp_path, ["framework Default"])["options"]   # TypeDefaults, src/cuda/cudasimframework.cu:346-360

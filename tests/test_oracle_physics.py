@@ -1003,3 +1003,60 @@ def test_interface_detection_two_fluids():
     i_fs, _ = s1.o.surface(s1.pos, s1.vel, s1.info, s1.hash, s1.cs, s1.nl, s1.n)
     assert not np.any(i_if[:s1.n, 0] & D.FG_INTERFACE)
     assert ((i_if[:s1.n, 0] ^ i_fs[:s1.n, 0]) & D.FG_SURFACE != 0).mean() < 0.002
+
+
+def test_sph_ha_formulation_known_answers():
+    """SPH_HA (Hu & Adams; BiFluidPoiseuille's formulation): the continuity equation weighs with the particle's own mass and the
+    pressure term with the squared volumes.  For equal masses and uniform density it coincides with SPH_F1; for two fluids the
+    oracle's sums equal a float64 all-pairs evaluation of the volume form."""
+    import ctypes as C
+    from gpusph_amd.problem import DamBreak3D, info_type
+    visc = dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.DYNAMIC, avgop=D.HARMONIC)
+    def state(formulation, two):
+        pr = DamBreak3D(0.05, obstacle=False, two_fluids=two, formulation=formulation, viscosity=visc, jitter=0.15, hydrostatic=False,
+                        density_diffusion=D.DENSITY_DIFFUSION_NONE)
+        sim = ol.OracleSim(pr); sim.build_neibs()
+        n = sim.n
+        rng = np.random.default_rng(3)
+        fluid = info_type(sim.info[:n]) == D.PT_FLUID
+        sim.vel[:n, :3][fluid] += rng.uniform(-0.3, 0.3, size=(fluid.sum(), 3)).astype(np.float32)
+        return pr, sim
+    # (1) one fluid, uniform density: HA == F1
+    _, a = state(D.SPH_HA, False)
+    _, b = state(D.SPH_F1, False)
+    fa = a.o.forces(a.pos, a.vel, a.info, a.hash, a.cs, a.nl, a.n)[0][:a.n]
+    fb = b.o.forces(b.pos, b.vel, b.info, b.hash, b.cs, b.nl, b.n)[0][:b.n]
+    assert np.abs(fa - fb).max() <= 2e-6 * np.abs(fb).max()
+    # (2) two fluids, perturbed densities: float64 all pairs of the volume form
+    pr, sim = state(D.SPH_HA, True)
+    n = sim.n
+    rng = np.random.default_rng(8)
+    sim.vel[:n, 3] += rng.uniform(0, 4e-3, size=n).astype(np.float32)
+    f = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0][:n]
+    p = sim.o.p
+    g = pr.global_pos(sim.pos[:n], sim.hash[:n])
+    h, R = float(p.slength), float(p.influenceradius)
+    fc = float(sim.o.L.orc_fcoeff(C.c_int(D.WENDLAND), C.c_float(h), C.c_float(2.0)))
+    t = info_type(sim.info[:n]); fl = (sim.info[:n, 1] >> 12).astype(int)
+    rho0 = np.array([float(p.rho0[k]) for k in range(4)])
+    v = sim.vel[:n].astype(np.float64); m = sim.pos[:n, 3].astype(np.float64)
+    rho = (v[:, 3] + 1) * rho0[fl]
+    P = np.array([float(sim.o.L.orc_P(C.byref(p), C.c_float(sim.vel[i, 3]), C.c_int(int(fl[i])))) for i in range(n)])
+    V = m / rho
+    mu = np.array([float(p.visccoeff[k]) for k in range(4)])[fl]
+    grav = np.array([float(p.gravity[k]) for k in range(3)])
+    picks = rng.choice(np.where(t == D.PT_FLUID)[0], 60, replace=False)
+    scale = np.abs(f[:, :3]).max()
+    for i in picks:
+        rel = g[i] - g
+        d = np.sqrt((rel ** 2).sum(1)); near = (d < R); near[i] = False
+        F = (d[near] / h - 2) ** 3 * fc
+        dv = v[i, :3] - v[near, :3]
+        drho = (m[i] * (dv * rel[near]).sum(1) * F).sum() / rho0[fl[i]]
+        pg = P[i] * V[i] ** 2 + P[near] * V[near] ** 2
+        acc = -((pg / m[i]) * F)[:, None] * rel[near]
+        avg = 2 * mu[i] * mu[near] / (mu[i] + mu[near])                     # harmonic, dynamic
+        acc = acc + (m[near] * 2 * avg / (rho[i] * rho[near]) * F)[:, None] * dv
+        want = acc.sum(0) + grav
+        assert np.abs(f[i, :3] - want).max() <= 2e-4 * scale
+        assert abs(f[i, 3] - drho) <= 2e-4 * max(np.abs(f[:, 3]).max(), 1e-9)
