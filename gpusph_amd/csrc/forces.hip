@@ -1732,9 +1732,10 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: only DYN_BOUNDARY and LJ_BOUNDARY pair interactions are built");
 	if (ctx->params.rheologytype > SPHX_NEWTONIAN && run_mode == SPHX_SIMULATE)
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep: generalized Newtonian rheologies read BUFFER_EFFVISC, use sphx_forces_basicstep_effvisc");
-	if (ctx->params.sph_formulation == SPHX_SPH_HA && run_mode == SPHX_SIMULATE) {      // Hu & Adams: rheology.hip
+	if ((ctx->params.sph_formulation == SPHX_SPH_HA || (ctx->params.rheologytype == SPHX_NEWTONIAN && ctx->params.viscmodel != SPHX_MORRIS)) &&
+		run_mode == SPHX_SIMULATE) {      // Hu & Adams, MONAGHAN / ESPANOL_REVENGA viscous models: rheology.hip
 		if (compute_object_forces || rbforces)
-			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: SPH_HA with bodies that feel the fluid is not built");
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep: SPH_HA / MONAGHAN / ESPANOL_REVENGA with bodies that feel the fluid are not built");
 		return sphx_fidelity_forces_launch(ctx, forces, cfl, pos, vel, info, hash, cellStart, neibsList, nullptr, numParticles, fromParticle,
 			toParticle, slength, influenceradius, cflOffset, h_numBlocks, stream);
 	}

@@ -263,9 +263,29 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 				if (ha) s = (p_precalc*p_volume*p_volume + n_precalc*n_volume*n_volume)/pos.w*f;
 				float dx = 0.0f, dy = 0.0f, dz = 0.0f;
 				dx -= s*rx; dy -= s*ry; dz -= s*rz;
-				if (viscous) {
+				if (viscous && p.viscmodel == SPHX_ESPANOL_REVENGA) {
+					// Espanol & Revenga (:2650-2677): shear and bulk viscosity, along the relative velocity and the relative position
+					const float pv = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl]*p_rho : p.visccoeff[fl];
+					const float nv = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl]*n_rho : p.visccoeff[nfl];
+					const float pb = p.visc2coeff[fl], nb = p.visc2coeff[nfl];
+					float avs, avb;
+					if (p.avgop == SPHX_ARITHMETIC) { avs = (pv + nv)*0.5f; avb = (pb + nb)*0.5f; }
+					else if (p.avgop == SPHX_HARMONIC) { avs = 2*pv*nv/(pv + nv); avb = 2*pb*nb/(pb + nb); }
+					else { avs = sqrtf(pv*nv); avb = sqrtf(pb*nb); }
+					const float visc_thirds = avs/3;
+					const float coeff = nmass/(p_rho*n_rho)*f;
+					const float pos_den = sa_dot3(rx, ry, rz, rx, ry, rz) + p.epsartvisc;
+					const float cv = 5*visc_thirds - avb, cr = 5*(visc_thirds + avb)*vel_dot_pos/pos_den;
+					dx += coeff*(cv*vx + cr*rx); dy += coeff*(cv*vy + cr*ry); dz += coeff*(cv*vz + cr*rz);
+				} else if (viscous) {
 					const float vf = sa_visc_avg(p, p_visc, a.effvisc ? a.effvisc[j] : p.visccoeff[nfl], p_rho, n_rho, nmass)*f;
-					dx += vf*vx; dy += vf*vy; dz += vf*vz;
+					if (p.viscmodel == SPHX_MONAGHAN) {      // along the relative position, approaching pairs only (:2531-2562)
+						const float den = sa_dot3(rx, ry, rz, rx, ry, rz) + p.epsartvisc;
+						const float c = vel_dot_pos < 0 ? p.monaghan_visc_coeff*vel_dot_pos/den : 0.0f;
+						dx += vf*(c*rx); dy += vf*(c*ry); dz += vf*(c*rz);
+					} else {
+						dx += vf*vx; dy += vf*vy; dz += vf*vz;
+					}
 				}
 				force.x += dx; force.y += dy; force.z += dz;
 			};
@@ -347,8 +367,8 @@ int sphx_fidelity_forces_launch(sphx_ctx *ctx, void *forces, float *cfl,
 	float slength, float influenceradius, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream)
 {
 	const sphx_params &q = ctx->params;
-	if ((q.sph_formulation != SPHX_SPH_F1 && q.sph_formulation != SPHX_SPH_HA) || q.boundarytype != SPHX_DYN_BOUNDARY || q.turbmodel != SPHX_LAMINAR_FLOW || q.viscmodel != SPHX_MORRIS)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies and SPH_HA are built for DYN_BOUNDARY, LAMINAR_FLOW and the MORRIS viscous model");
+	if ((q.sph_formulation != SPHX_SPH_F1 && q.sph_formulation != SPHX_SPH_HA) || q.boundarytype != SPHX_DYN_BOUNDARY || q.turbmodel != SPHX_LAMINAR_FLOW)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies, SPH_HA and the MONAGHAN / ESPANOL_REVENGA viscous models are built for DYN_BOUNDARY and LAMINAR_FLOW");
 	if (q.simflags & (SPHX_ENABLE_XSPH | SPHX_ENABLE_MOVING_BODIES))
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: generalized Newtonian rheologies and SPH_HA are built without XSPH and without moving bodies");
 	SPHX_REQUIRE(forces && pos && vel && info && hash && cellStart && neibsList, "sphx_forces_basicstep (SPH_HA / effective viscosity): missing buffer");

@@ -230,8 +230,19 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 				"sphx_set_constants: generalized Newtonian rheologies need yield_strength / visc_nonlinear_param / visc_regularization_param for every fluid");
 	}
 	if (sp->rheologytype >= SPHX_NEWTONIAN) {
-		if (sp->viscmodel != SPHX_MORRIS)
-			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: only the MORRIS viscous model is built");
+		if (sp->viscmodel != SPHX_MORRIS) {
+			// visc_model<MONAGHAN | ESPANOL_REVENGA>: the forces kernel of rheology.hip
+			SPHX_REQUIRE(sp->viscmodel == SPHX_MONAGHAN || sp->viscmodel == SPHX_ESPANOL_REVENGA, "sphx_set_constants: invalid viscous model");
+			if (sp->rheologytype != SPHX_NEWTONIAN && sp->viscmodel == SPHX_ESPANOL_REVENGA)
+				return sphx_set_error(SPHX_ERR_INVALID, "sphx: ESPANOL_REVENGA needs the NEWTONIAN rheology (src/cuda/cudasimframework.cu:186-193)");
+			if ((sp->sph_formulation != SPHX_SPH_F1 && sp->sph_formulation != SPHX_SPH_HA) || sp->boundarytype != SPHX_DYN_BOUNDARY || sp->turbmodel != SPHX_LAMINAR_FLOW)
+				return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: the MONAGHAN and ESPANOL_REVENGA viscous models are built for SPH_F1 / SPH_HA, DYN_BOUNDARY and LAMINAR_FLOW");
+			if (sp->viscmodel == SPHX_ESPANOL_REVENGA)
+				for (uint32_t f = 0; f < sp->numfluids; ++f)
+					SPHX_REQUIRE(sp->visc2coeff[f] == sp->visc2coeff[f], "sphx_set_constants: ESPANOL_REVENGA needs the bulk viscosity (visc2coeff) of every fluid");
+			if (sp->viscmodel == SPHX_MONAGHAN)
+				SPHX_REQUIRE(sp->monaghan_visc_coeff == sp->monaghan_visc_coeff, "sphx_set_constants: MONAGHAN needs monaghan_visc_coeff");
+		}
 		if (sp->turbmodel == SPHX_ARTIFICIAL)
 			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: NEWTONIAN rheology is built with LAMINAR_FLOW or SPS");
 		SPHX_REQUIRE(sp->compvisc == SPHX_KINEMATIC || sp->compvisc == SPHX_DYNAMIC, "sphx_set_constants: invalid computational viscosity");
@@ -292,6 +303,8 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	d.limiting_kinvisc = sp->limiting_kinvisc;
 	d.ewres = sp->ewres; d.nsres = sp->nsres; d.demdx = sp->demdx; d.demdy = sp->demdy; d.demzmin = sp->demzmin;
 	d.wo_z = sp->worldOrigin[2];
+	d.viscmodel = sp->viscmodel; d.monaghan_visc_coeff = sp->monaghan_visc_coeff;
+	for (int f = 0; f < SPHX_MAX_FLUIDS; ++f) d.visc2coeff[f] = sp->visc2coeff[f];
 	d.dem = ctx->dem; d.dem_w = ctx->dem_w; d.dem_h = ctx->dem_h;
 	d.mk_mask = (sp->boundarytype == SPHX_MK_BOUNDARY) ? 0xFFFFFFFFu : 0u;
 	if (sp->boundarytype == SPHX_MK_BOUNDARY) d.boundarytype = SPHX_LJ_BOUNDARY;

@@ -82,6 +82,7 @@ struct DevParams {
 	float    limiting_kinvisc;               // generalized Newtonian rheologies
 	float    ewres, nsres, demdx, demdy, demzmin, wo_z;   // ENABLE_DEM (+ d_worldOrigin.z)
 	const float *dem; int dem_w, dem_h;      // the height map (sphx_set_dem), row-major [h][w]
+	int      viscmodel; float monaghan_visc_coeff; float visc2coeff[SPHX_MAX_FLUIDS];   // visc_model<MONAGHAN | ESPANOL_REVENGA>
 	uint32_t mk_mask;                        // all ones when the repulsive boundary model is MK (boundarytype then reads LJ)
 	uint32_t numplanes;                       // geometric planes (src/planes.h:43-47, MAX_PLANES src/particledefine.h:325)
 	float    plane_normal[SPHX_MAX_PLANES][3];

@@ -366,7 +366,9 @@ int main(int argc, char **argv)
 				const uint nb = forcesEngine->basicstep(state, state, n, 0, n, deltap, slength, sp->dtadaptfactor,
 					influenceRadius, sp->epsilon, NULL, 0, SIMULATE, step, dt, sp->numforcesbodies > 0);
 				forcesEngine->unbind_textures(SIMULATE);
-				dts[step - 1] = forcesEngine->dtreduce(slength, sp->dtadaptfactor, sspeed_cfl, max_kinvisc, state, state, nb, n);
+				// runCommand<FORCES_SYNC> (src/GPUWorker.cc:2013-2022): stricter viscous limit of the MONAGHAN / ESPANOL_REVENGA models
+				const float max_kinvisc_for_dt = max_kinvisc*(sp->viscmodel == MONAGHAN ? pp.monaghan_visc_coeff : sp->viscmodel == ESPANOL_REVENGA ? 5.0f : 1.0f);
+				dts[step - 1] = forcesEngine->dtreduce(slength, sp->dtadaptfactor, sspeed_cfl, max_kinvisc_for_dt, state, state, nb, n);
 				if (moving) {                                                         // MOVE_BODIES + uploads
 					const double dt1 = (step == 1) ? dt/2.0 : (double)dt;
 					for (int b = 0; b < numbodies; ++b) {

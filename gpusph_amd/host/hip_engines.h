@@ -181,6 +181,8 @@ public:
 		const bool dem = (sp->simflags & ENABLE_DEM) != 0;
 		p.ewres = dem ? pp->ewres : NAN; p.nsres = dem ? pp->nsres : NAN; p.demdx = dem ? pp->demdx : NAN;
 		p.demdy = dem ? pp->demdy : NAN; p.demzmin = dem ? pp->demzmin : NAN;
+		p.monaghan_visc_coeff = pp->monaghan_visc_coeff;
+		for (size_t f = 0; f < pp->numFluids(); ++f) p.visc2coeff[f] = f < pp->visc2coeff.size() ? pp->visc2coeff[f] : NAN;
 	}
 
 	void upload(const SimParams *sp, const PhysParams *pp, float3 const& worldOrigin, uint3 const& gridSize,

@@ -29,7 +29,7 @@ struct ProblemPhysParams : PhysParams {
 	using PhysParams::set_kinematic_visc; using PhysParams::set_dynamic_visc;
 	using PhysParams::set_artificial_visc;
 	using PhysParams::set_yield_strength; using PhysParams::set_visc_power_law; using PhysParams::set_visc_exponential_coeff;
-	using PhysParams::set_visc_regularization_param; using PhysParams::is_exponential_rheology;
+	using PhysParams::set_visc_regularization_param; using PhysParams::is_exponential_rheology; using PhysParams::set_bulk_visc;
 };
 
 typedef std::map<std::string, std::vector<std::string> > Case;
@@ -174,6 +174,26 @@ static SimFramework *make_framework(Case const& c)
 			densitydiffusion<BREZZI>,
 			add_flags<ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES>
 		);
+	} else if (name == "PoiseuilleViscModel") {   // src/problems/Poiseuille.inc:102-119 (Newtonian), all four run-time selectors
+		const DensityDiffusionType RHODIFF = (DensityDiffusionType)(int)num(c, "rhodiff");
+		const ComputationalViscosityType compvisc = (ComputationalViscosityType)(int)num(c, "compvisc");
+		const AverageOperator viscavg = (AverageOperator)(int)num(c, "viscavg");
+		const ViscousModel viscmodel = (ViscousModel)(int)num(c, "viscmodel");
+		SETUP_FRAMEWORK(
+			kernel<WENDLAND>,
+			rheology<NEWTONIAN>,
+			turbulence_model<LAMINAR_FLOW>,
+			computational_visc<KINEMATIC>,
+			visc_model<MORRIS>,
+			visc_average<ARITHMETIC>,
+			periodicity<PERIODIC_XY>,
+			boundary<DYN_BOUNDARY>
+		).select_options
+			( RHODIFF  // switch to the user-selected density diffusion
+			, compvisc // switch to the user-selected computational viscosity
+			, viscavg  // switch to the user-selected viscous averaging operator
+			, viscmodel // switch to the user-selected viscous model
+			);
 	} else if (name == "BiFluidPoiseuilleDYN") {   // src/problems/BiFluidPoiseuille.inc:45-59 with the DYN defines of BiFluidPoiseuilleDYN.cu:27-28
 		const DensityDiffusionType RHODIFF = (DensityDiffusionType)(int)num(c, "rhodiff");
 		SETUP_FRAMEWORK(
@@ -269,6 +289,7 @@ static void configure_params(Case const& c, SimParams *sp, ProblemPhysParams &pp
 		const std::string kind = c.at(key).at(3);
 		if (kind == "kin") pp.set_kinematic_visc(f, (float)num(c, key.c_str(), 4));
 		else if (kind == "dyn") pp.set_dynamic_visc(f, (float)num(c, key.c_str(), 4));
+		if (has(c, ("bulkvisc" + std::to_string(f)).c_str())) pp.set_bulk_visc(f, (float)num(c, ("bulkvisc" + std::to_string(f)).c_str()));
 		// generalized Newtonian parameters (Poiseuille.inc:131-132 sets the yield strength; the others keep their defaults
 		// unless the case says otherwise)
 		const std::string rkey = "rheology" + std::to_string(f);     // yield strength, nonlinear parameter (NaN: keep), m (NaN: keep)
@@ -298,6 +319,11 @@ static void configure_params(Case const& c, SimParams *sp, ProblemPhysParams &pp
 	for (size_t f = 0; f < pp.numFluids(); ++f)
 		pp.visccoeff[f] = sp->rheologytype == INVISCID ? NAN :
 			(sp->rheologytype == NEWTONIAN && sp->compvisc == KINEMATIC) ? pp.kinematicvisc[f] : pp.visc_consistency[f];
+	if (sp->viscmodel == ESPANOL_REVENGA)       // GPUSPH.cc:1511-1522
+		for (size_t f = 0; f < pp.numFluids(); ++f) {
+			if (std::isnan(pp.bulkvisc[f])) pp.bulkvisc[f] = 0;
+			pp.visc2coeff[f] = pp.bulkvisc[f];
+		}
 }
 
 struct GridSetup { float3 origin; uint3 gridSize; float3 cellSize; idx_t allocated; };

@@ -210,7 +210,9 @@ class HipKernels:
     def dtreduce(self, cfl, cfl_temp, nblocks, d_dt, combine_min):
         p = capi.ptr
         P = self.params
-        capi.check(self.lib.sphx_forces_dtreduce_device(self.ctx.handle, P.slength, P.dtadaptfactor, self.sspeed_cfl, self.max_kinvisc,
+        # stricter viscous limit of the MONAGHAN and ESPANOL_REVENGA models (GPUWorker.cc:2013-2022)
+        mk = self.max_kinvisc*(float(P.monaghan_visc_coeff) if P.viscmodel == D.MONAGHAN else 5.0 if P.viscmodel == D.ESPANOL_REVENGA else 1.0)
+        capi.check(self.lib.sphx_forces_dtreduce_device(self.ctx.handle, P.slength, P.dtadaptfactor, self.sspeed_cfl, mk,
                                                         p(cfl), p(cfl_temp), nblocks, p(d_dt), combine_min, self._s()))
 
     # ---- AbstractViscEngine / AbstractFilterEngine

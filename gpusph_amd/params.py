@@ -34,6 +34,7 @@ class SphxParams(C.Structure):
         ("yield_strength", C.c_float * 4), ("visc_nonlinear_param", C.c_float * 4),
         ("visc_regularization_param", C.c_float * 4), ("limiting_kinvisc", C.c_float),
         ("ewres", C.c_float), ("nsres", C.c_float), ("demdx", C.c_float), ("demdy", C.c_float), ("demzmin", C.c_float),
+        ("monaghan_visc_coeff", C.c_float), ("visc2coeff", C.c_float * 4),
     ]
 
 
@@ -55,6 +56,9 @@ class PhysParams:
     visc_regularization_param: list = field(default_factory=list)
     limiting_kinvisc: float = 1.0e3                         # physparams.h:395
     rheologytype: int = 0                                   # PhysParams is built for the framework's rheology (physparams.h:380)
+    monaghan_visc_coeff: float = 10.0                       # physparams.h:266,396
+    bulkvisc: list = field(default_factory=list)            # Espanol & Revenga (physparams.h:176)
+    visc2coeff: list = field(default_factory=list)          # d_visc2coeff (physparams.h:247)
     # ENABLE_DEM (physparams.h:322-327; computeDEMphysparams, src/problem_api/ProblemAPI_1.cc:1399-1418)
     ewres: float = float("nan")
     nsres: float = float("nan")
@@ -90,6 +94,7 @@ class PhysParams:
             lst.append(float("nan"))
         # the values that reduce back to a Newtonian rheology (physparams.h:469-480)
         self.yield_strength.append(0.0)
+        self.bulkvisc.append(float("nan")); self.visc2coeff.append(float("nan"))
         self.visc_nonlinear_param.append(0.0 if self.rheologytype >= D.DEKEE_TURCOTTE else 1.0)
         self.visc_regularization_param.append(1000.0)
         return len(self.rho0) - 1
@@ -99,6 +104,9 @@ class PhysParams:
         new_limit = np.float32(self.yield_strength[fluid_idx]) * np.float32(self.visc_regularization_param[fluid_idx]) + \
             np.float32(self.visc_consistency[fluid_idx])
         self.limiting_kinvisc = float(np.fmax(np.float32(self.limiting_kinvisc), new_limit))      # fmaxf: a NaN operand loses
+
+    def set_bulk_visc(self, fluid_idx, zeta):
+        self.bulkvisc[fluid_idx] = float(np.float32(zeta))
 
     def set_consistency_index(self, fluid_idx, k):
         self.set_dynamic_visc(fluid_idx, k)
@@ -146,6 +154,13 @@ class PhysParams:
                 self.visccoeff[f] = self.kinematicvisc[f]
             else:
                 self.visccoeff[f] = self.visc_consistency[f]
+        if sp.viscmodel == D.ESPANOL_REVENGA:        # GPUSPH.cc:1511-1522: unset bulk viscosity is zero; 3 zeta <= 5 mu
+            for f in range(self.numFluids()):
+                if math.isnan(self.bulkvisc[f]):
+                    self.bulkvisc[f] = 0.0
+                if self.bulkvisc[f] * 3 > self.visc_consistency[f] * 5:
+                    raise ValueError("fluid %d cannot be modelled with Espanol & Revenga (bulk viscosity too large)" % f)
+                self.visc2coeff[f] = self.bulkvisc[f]
 
     def set_equation_of_state(self, fluid_idx, gamma, c0):
         if fluid_idx >= self.numFluids():
@@ -282,5 +297,8 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
         p.yield_strength[f] = f32(pp.yield_strength[f]); p.visc_nonlinear_param[f] = f32(pp.visc_nonlinear_param[f])
         p.visc_regularization_param[f] = f32(pp.visc_regularization_param[f])
     p.limiting_kinvisc = f32(pp.limiting_kinvisc)
+    p.monaghan_visc_coeff = f32(pp.monaghan_visc_coeff)
+    for f in range(pp.numFluids()):
+        p.visc2coeff[f] = nz(pp.visc2coeff[f])
     p.ewres = nz(pp.ewres); p.nsres = nz(pp.nsres); p.demdx = nz(pp.demdx); p.demdy = nz(pp.demdy); p.demzmin = nz(pp.demzmin)
     return p

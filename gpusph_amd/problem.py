@@ -526,7 +526,8 @@ class Poiseuille(Problem):
 
     def __init__(self, ppH=16, *, compvisc=D.KINEMATIC, viscavg=D.HARMONIC, rho=1.0, kinvisc=0.1, driving_force=0.05,
                  density_diffusion=D.DENSITY_DIFFUSION_NONE, steady_init=False, linearization=D.DEFAULT_LINEARIZATION,
-                 rheology=D.NEWTONIAN, power_law_n=None, exponential_coeff=None, regularization=None):
+                 rheology=D.NEWTONIAN, power_law_n=None, exponential_coeff=None, regularization=None, viscmodel=D.MORRIS,
+                 bulk_visc=None):
         super().__init__()
         self.m_name = "Poiseuille"
         self.lz = self.ly = self.lx = 1.0
@@ -538,7 +539,7 @@ class Poiseuille(Problem):
         self.rheology = rheology
         yielding = rheology > D.NEWTONIAN and rheology not in (D.POWER_LAW, D.GRANULAR)        # YIELDING_RHEOLOGY
         self.ys = float(np.float32(np.float32(driving_force) * np.float32(rho) * np.float32(self.lz) / np.float32(4))) if yielding else 0.0
-        self.set_viscosity(dict(rheologytype=rheology, turbmodel=D.LAMINAR_FLOW, compvisc=compvisc, viscmodel=D.MORRIS,
+        self.set_viscosity(dict(rheologytype=rheology, turbmodel=D.LAMINAR_FLOW, compvisc=compvisc, viscmodel=viscmodel,
                                 avgop=viscavg))
         sp.densitydiffusiontype = density_diffusion
         sp.periodicbound = D.PERIODIC_X | D.PERIODIC_Y
@@ -549,6 +550,8 @@ class Poiseuille(Problem):
         pp.gravity = (self.driving_force, 0.0, 0.0)
         pp.add_fluid(self.rho)
         pp.set_kinematic_visc(0, self.kinvisc)
+        if bulk_visc is not None:
+            pp.set_bulk_visc(0, bulk_visc)
         if yielding:
             pp.set_yield_strength(0, self.ys)             # Poiseuille.inc:131-132
         if power_law_n is not None:

@@ -131,6 +131,10 @@ typedef struct sphx_params {
 	 * DEM, displacements used for the tangent plane, height above the terrain below which the terrain repels; the map itself
 	 * goes through sphx_set_dem */
 	float    ewres, nsres, demdx, demdy, demzmin;
+	/* visc_model<MONAGHAN>: the coefficient of the (r.v)/(r.r) r form (src/physparams.h:266, default 10);
+	 * visc_model<ESPANOL_REVENGA>: the bulk viscosity per fluid (d_visc2coeff, src/GPUSPH.cc:1511-1522) */
+	float    monaghan_visc_coeff;
+	float    visc2coeff[SPHX_MAX_FLUIDS];
 } sphx_params;
 
 /* TimingInfo fields filled by getinfo (src/timing.h:43-100, src/cuda/buildneibs.cu:137-145) */

@@ -1017,11 +1017,35 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				}
 				/* compute_laminar_visc_contrib, Newtonian + MORRIS (:2606-2625): fluid neighbours, and boundary neighbours
 				 * of DYN_BOUNDARY (wants_volumic_visc_term :150-158; LJ pairs never get here) */
-				if (newtonian) {
+				if (newtonian && p->viscmodel == ORC_ESPANOL_REVENGA) {
+					/* compute_laminar_visc_contrib, Espanol & Revenga (:2650-2677): shear and bulk viscosity, contributions along the
+					 * relative velocity and along the relative position */
+					const float pvisc = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[p_fluid]*p_rho : p->visccoeff[p_fluid];
+					const float nvisc = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[n_fluid]*n_rho : p->visccoeff[n_fluid];
+					const float pbulk = p->visc2coeff[p_fluid], nbulk = p->visc2coeff[n_fluid];
+					float avs, avb;
+					switch (p->avgop) {           /* average<>, src/average.h:78-100 */
+					case ORC_ARITHMETIC: avs = (pvisc + nvisc)*0.5f; avb = (pbulk + nbulk)*0.5f; break;
+					case ORC_HARMONIC:   avs = 2*pvisc*nvisc/(pvisc + nvisc); avb = 2*pbulk*nbulk/(pbulk + nbulk); break;
+					default:             avs = sqrtf(pvisc*nvisc); avb = sqrtf(pbulk*nbulk);
+					}
+					const float visc_thirds = avs/3;
+					const float coeff = nmass/(p_rho*n_rho)*f;      /* viscous_volume_coefficient :2575-2580 */
+					const float pos_den = dot3(rx, ry, rz, rx, ry, rz) + p->epsartvisc;
+					const float cv = 5*visc_thirds - avb, cr = 5*(visc_thirds + avb)*vel_dot_pos/pos_den;
+					DvDt[0] += coeff*(cv*vx + cr*rx); DvDt[1] += coeff*(cv*vy + cr*ry); DvDt[2] += coeff*(cv*vz + cr*rz);
+				} else if (newtonian) {
 					const float visc = effvisc ? visc_avg(p, effvisc[index], effvisc[neib_index], p_rho, n_rho, nmass) :
 						visc_avg(p, p->visccoeff[p_fluid], p->visccoeff[n_fluid], p_rho, n_rho, nmass);
 					const float vf = visc*f;
-					DvDt[0] += vf*vx; DvDt[1] += vf*vy; DvDt[2] += vf*vz;
+					if (p->viscmodel == ORC_MONAGHAN) {
+						/* viscous_vector_component<MONAGHAN> (:2531-2562): along the relative position, approaching pairs only */
+						const float den = dot3(rx, ry, rz, rx, ry, rz) + p->epsartvisc;
+						const float c = vel_dot_pos < 0 ? p->monaghan_visc_coeff*vel_dot_pos/den : 0.0f;
+						DvDt[0] += vf*(c*rx); DvDt[1] += vf*(c*ry); DvDt[2] += vf*(c*rz);
+					} else {
+						DvDt[0] += vf*vx; DvDt[1] += vf*vy; DvDt[2] += vf*vz;
+					}
 				}
 				if (all_pp || COMPUTE_FORCE(info)) {
 					force.x += DvDt[0]; force.y += DvDt[1]; force.z += DvDt[2];

@@ -47,6 +47,8 @@ def case_lines(prob, framework, allocated=None, **selectors):
         kind = "none" if (nu is None or math.isnan(nu)) else "kin"
         L.append("fluid%d %s %s %s %s %s" % (f, _g(pp.rho0[f]), _g(pp.gammacoeff[f]), _g(pp.sscoeff[f]), kind,
                                             _g(0.0 if kind == "none" else nu)))
+        if sp.viscmodel == D.ESPANOL_REVENGA:
+            L.append("bulkvisc%d %s" % (f, _g(pp.bulkvisc[f] if not math.isnan(pp.bulkvisc[f]) else 0.0)))
         if sp.rheologytype > D.NEWTONIAN:     # generalized Newtonian: yield strength; power-law / exponential parameter and m when set
             nl = pp.visc_nonlinear_param[f]
             default_nl = 0.0 if sp.rheologytype >= D.DEKEE_TURCOTTE else 1.0

@@ -33,6 +33,7 @@ class OrcParams(C.Structure):
         ("yield_strength", C.c_float * 4), ("visc_nonlinear_param", C.c_float * 4),
         ("visc_regularization_param", C.c_float * 4), ("limiting_kinvisc", C.c_float),
         ("ewres", C.c_float), ("nsres", C.c_float), ("demdx", C.c_float), ("demdy", C.c_float), ("demzmin", C.c_float),
+        ("monaghan_visc_coeff", C.c_float), ("visc2coeff", C.c_float * 4),
         ("numplanes", C.c_uint32),
         ("plane_normal", (C.c_float * 3) * 8), ("plane_gridpos", (C.c_int32 * 3) * 8), ("plane_pos", (C.c_float * 3) * 8),
         ("rbcgGridPos", (C.c_int32 * 3) * 16), ("rbcgPos", (C.c_float * 3) * 16), ("rbstartindex", C.c_int32 * 16),
@@ -351,6 +352,8 @@ class Oracle:
         return npos, nvel, nvol
 
     def dtreduce(self, cfl, nblocks, sspeed_cfl, max_kinematic=0.0):
+        # GPUWorker.cc:2013-2022: the MONAGHAN / ESPANOL_REVENGA viscous models tighten the viscous limit
+        max_kinematic = max_kinematic*(float(self.p.monaghan_visc_coeff) if self.p.viscmodel == 1 else 5.0 if self.p.viscmodel == 2 else 1.0)
         return float(self.L.orc_dtreduce(C.byref(self.p), P(cfl), C.c_uint32(nblocks), C.c_float(sspeed_cfl),
                                          C.c_float(max_kinematic)))
 

@@ -193,3 +193,43 @@ def test_cpp_adapters_with_the_bifluid_poiseuille_framework(tmp_path):
     out = hc.read_out(fout)
     assert out["n"] == eng.n and np.float32(eng.current_dt()) == out["dt"]
     assert np.array_equal(_bits(out["pos"]), _bits(ref["pos"])) and np.array_equal(_bits(out["vel"]), _bits(ref["vel"]))
+
+
+@pytest.mark.parametrize("kw", [dict(viscmodel=D.MONAGHAN, compvisc=D.KINEMATIC, viscavg=D.HARMONIC),
+                                dict(viscmodel=D.MONAGHAN, compvisc=D.DYNAMIC, viscavg=D.ARITHMETIC),
+                                dict(viscmodel=D.ESPANOL_REVENGA, compvisc=D.DYNAMIC, viscavg=D.ARITHMETIC, bulk_visc=0.04),
+                                dict(viscmodel=D.ESPANOL_REVENGA, compvisc=D.KINEMATIC, viscavg=D.GEOMETRIC, bulk_visc=0.02)])
+def test_monaghan_and_espanol_revenga_viscous_models(kw, tmp_path):
+    """visc_model<MONAGHAN | ESPANOL_REVENGA>: forces vs oracle, a trajectory with the tightened viscous dt limit, and the C++
+    adapters with Poiseuille.inc's framework (its fourth run-time selector) bit-equal to the Python driver"""
+    import os, subprocess
+    import host_case as hc
+    sim, eng = _pair(lambda: Poiseuille(12, **kw), g=1.5)
+    n = sim.n
+    f, cfl, nb, _, _ = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)
+    eng._forces(eng.pos, eng.vel, 1, 0)
+    gf = _np(eng.forces)[:n]
+    scale = np.abs(f[:n, :3]).max()
+    assert np.abs(gf[:, :3] - f[:n, :3]).max() <= 2e-5 * scale
+    dt_ref = sim.o.dtreduce(cfl, nb, sim.sspeed_cfl, sim.max_kinvisc)
+    assert abs(float(eng.d_dt_next.item()) - dt_ref) <= 2e-5 * dt_ref
+    prob = Poiseuille(12, **kw)
+    sim2 = ol.OracleSim(prob); eng2 = _engine(prob)
+    steps = 12
+    for _ in range(steps):
+        sim2.step(); eng2.step()
+    out = eng2.download()
+    assert np.array_equal(out["hash"], sim2.hash[:n])
+    assert np.abs(out["vel"][:, :3] - sim2.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim2.vel[:n, :3]).max(), 1e-6)
+    assert abs(eng2.current_dt() - sim2.dt) <= 3e-5 * sim2.dt
+    eng3 = _engine(prob)
+    case, state, fout = tmp_path / "case.txt", tmp_path / "state.bin", tmp_path / "out.bin"
+    lines = hc.case_lines(prob, "PoiseuilleViscModel", rhodiff=0, compvisc=kw["compvisc"], viscavg=kw["viscavg"], viscmodel=kw["viscmodel"]) + \
+        hc.driver_lines(prob, eng3, steps)
+    case.write_text("\n".join(lines) + "\n")
+    hc.write_state(state, prob.copy_to_array())
+    r = subprocess.run([hc.exe("example_engines"), str(case), str(state), str(fout)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = hc.read_out(fout)
+    assert res["n"] == n and np.float32(eng2.current_dt()) == res["dt"]
+    assert np.array_equal(_bits(res["pos"]), _bits(out["pos"])) and np.array_equal(_bits(res["vel"]), _bits(out["vel"]))

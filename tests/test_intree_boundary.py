@@ -209,6 +209,21 @@ def test_sph_ha_mirror_against_the_bifluid_poiseuille_framework(tmp_path):
     assert_params(out, prob, prob.num_particles)
 
 
+@pytest.mark.parametrize("viscmodel", [D.MONAGHAN, D.ESPANOL_REVENGA])
+def test_viscous_model_mirror_against_the_poiseuille_framework(tmp_path, viscmodel):
+    from gpusph_amd.problem import Poiseuille
+    kw = dict(bulk_visc=0.03) if viscmodel == D.ESPANOL_REVENGA else {}
+    prob = Poiseuille(12, viscmodel=viscmodel, compvisc=D.DYNAMIC, viscavg=D.ARITHMETIC, **kw)
+    out = run_check(tmp_path, hc.case_lines(prob, "PoiseuilleViscModel", rhodiff=0, compvisc=D.DYNAMIC, viscavg=D.ARITHMETIC, viscmodel=viscmodel))
+    assert_options(out, prob.simparams)
+    assert out["options"]["viscmodel"] == viscmodel
+    assert_params(out, prob, prob.num_particles)
+    got = SphxParams.from_buffer_copy(bytes.fromhex(out["params_hex"]))
+    assert got.monaghan_visc_coeff == 10.0
+    if viscmodel == D.ESPANOL_REVENGA:
+        assert got.visc2coeff[0] == np.float32(0.03)
+
+
 def test_selector_semantics_of_the_factory(tmp_path):
     """defaults, the legacy viscosity names, Grenier's harmonic rule, run-time walks over option ranges"""
     d = run_check(tmp_path, ["framework Default"])["options"]   # TypeDefaults, src/cuda/cudasimframework.cu:346-360

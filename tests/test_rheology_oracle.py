@@ -173,3 +173,64 @@ def test_steps_use_the_viscous_limit_of_the_largest_effective_viscosity():
     assert sim.max_kinvisc == pytest.approx(nu_max, rel=1e-3)
     assert sim.dt == pytest.approx(0.125 * h * h / sim.max_kinvisc, rel=1e-5)
     assert np.abs(sim.vel[:n, 0]).max() > 0
+
+
+@pytest.mark.parametrize("viscmodel", [D.MONAGHAN, D.ESPANOL_REVENGA])
+@pytest.mark.parametrize("compvisc", [D.KINEMATIC, D.DYNAMIC])
+def test_monaghan_and_espanol_revenga_viscous_models_equal_all_pairs(viscmodel, compvisc):
+    """visc_model<MONAGHAN> directs the Morris coefficient along r with (r.v)/(r.r) for approaching pairs; visc_model<ESPANOL_REVENGA>
+    has a shear and a bulk viscosity acting along v and along r: float64 all-pairs evaluation of the viscous acceleration
+    (forces with viscosity minus forces without)."""
+    kw = dict(viscmodel=viscmodel, compvisc=compvisc, viscavg=D.ARITHMETIC)
+    if viscmodel == D.ESPANOL_REVENGA:
+        kw["bulk_visc"] = 0.04
+    pr = Poiseuille(12, **kw)
+    sim, gp = _sheared(pr, g=1.5)
+    n = sim.n
+    rng = np.random.default_rng(1)
+    fluid = info_type(sim.info[:n]) == D.PT_FLUID
+    sim.vel[:n, :3][fluid] += rng.uniform(-0.2, 0.2, size=(fluid.sum(), 3)).astype(np.float32)
+    f = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0][:n]
+    keep = sim.o.p.rheologytype
+    sim.o.p.rheologytype = D.INVISCID
+    f0 = sim.o.forces(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, n)[0][:n]
+    sim.o.p.rheologytype = keep
+    got = (f - f0)[:, :3].astype(np.float64)
+    p = sim.o.p
+    h, R = float(p.slength), float(p.influenceradius)
+    fc = float(sim.o.L.orc_fcoeff(C.c_int(D.WENDLAND), C.c_float(h), C.c_float(2.0)))
+    L = np.array([pr.lx, pr.ly])
+    v = sim.vel[:n, :3].astype(np.float64)
+    rho = (sim.vel[:n, 3].astype(np.float64) + 1) * float(p.rho0[0])
+    m = sim.pos[:n, 3].astype(np.float64)
+    eps = float(p.epsartvisc)
+    mu, zeta = 0.1 * 1.0, 0.04           # dynamic shear viscosity (nu rho0), bulk viscosity
+    t = info_type(sim.info[:n])
+    scale = np.abs(got).max()
+    assert scale > 0.05
+    for i in rng.choice(np.where(t == D.PT_FLUID)[0], 40, replace=False):
+        rel = gp[i] - gp
+        rel[:, :2] -= np.round(rel[:, :2] / L) * L
+        d2 = (rel ** 2).sum(1); d = np.sqrt(d2)
+        near = (d < R) & (d > 0)
+        F = (d[near] / h - 2) ** 3 * fc
+        dv = v[i] - v[near]
+        vdp = (dv * rel[near]).sum(1)
+        vol = m[near] / (rho[i] * rho[near])
+        if viscmodel == D.MONAGHAN:
+            # visc_avg (arithmetic): m (mu_a + mu_b)/(rho_a rho_b) with mu = nu rho (kinematic) or mu (dynamic)
+            mu_a = 0.1 * rho[i] if compvisc == D.KINEMATIC else mu
+            mu_b = 0.1 * rho[near] if compvisc == D.KINEMATIC else mu
+            c = np.where(vdp < 0, 10.0 * vdp / (d2[near] + eps), 0.0)
+            want = ((vol * (mu_a + mu_b) * F * c)[:, None] * rel[near]).sum(0)
+        else:
+            mu_a = 0.1 * rho[i] if compvisc == D.KINEMATIC else mu
+            mu_b = 0.1 * rho[near] if compvisc == D.KINEMATIC else mu
+            vt = np.broadcast_to((mu_a + mu_b) / 2 / 3, vdp.shape)
+            want = ((vol * F)[:, None] * ((5 * vt - zeta)[:, None] * dv + (5 * (vt + zeta) * vdp / (d2[near] + eps))[:, None] * rel[near])).sum(0)
+        assert np.abs(got[i] - want).max() <= 3e-4 * scale
+    # the models tighten the viscous dt limit: x monaghan_visc_coeff (10) and x 5 (GPUWorker.cc:2013-2022)
+    sim2 = ol.OracleSim(Poiseuille(12, **kw))
+    sim2.step()
+    hh = float(sim2.o.p.slength)
+    assert sim2.dt == pytest.approx(0.125 * hh * hh / (0.1 * (10.0 if viscmodel == D.MONAGHAN else 5.0)), rel=1e-5)
