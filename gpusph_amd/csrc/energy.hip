@@ -13,7 +13,7 @@
 
 struct EnergyArgs {
 	float *dedt;
-	const float4 *pos, *vel;
+	const float4 *pos, *vel, *row;      // row: P, rho, c (fidelity_row_kernel, rheology.hip)
 	const particleinfo *info;
 	const uint32_t *hash, *cellStart;
 	const neibdata *neibsList;
@@ -48,10 +48,11 @@ internal_energy_kernel(DevParams p, EnergyArgs a)
 		const bool f2 = p.formulation == SPHX_SPH_F2;
 		const bool repulsive = p.boundarytype == SPHX_LJ_BOUNDARY;      // LJ_BOUNDARY, or MK_BOUNDARY (uploaded as LJ + mk_mask)
 		const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
-		const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
-		const float p_P = sa_P(p, vel.w, fl);
+		const float4 self = a.row[index];
+		const float p_rho = self.y;
+		const float p_P = self.x;
 		const float p_precalc = f2 ? p_P : p_P/(p_rho*p_rho);
-		const float p_sspeed = sa_sound_speed(p, vel.w, fl);
+		const float p_sspeed = self.z;
 		// the momentum terms of one pair, in the order of compute_all_pp_interaction (pressure, turbulent, laminar)
 		auto pair_pp = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
 			if (!is_active_w(npos.w)) return;
@@ -60,8 +61,9 @@ internal_energy_kernel(DevParams p, EnergyArgs a)
 			const float4 nvel = a.vel[j];
 			const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
 			const uint32_t nfl = FLUID_NUM(a.info[j]);
-			const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
-			const float n_P = sa_P(p, nvel.w, nfl);
+			const float4 nrow = a.row[j];
+			const float n_rho = nrow.y;
+			const float n_P = nrow.x;
 			const float n_precalc = f2 ? n_P : n_P/(n_rho*n_rho);
 			const float f = en_F(p, r);
 			const float nmass = npos.w;
@@ -72,7 +74,7 @@ internal_energy_kernel(DevParams p, EnergyArgs a)
 			if (p.turbmodel == SPHX_ARTIFICIAL) {
 				const float vel_dot_pos = sa_dot3(vx, vy, vz, rx, ry, rz);
 				if (vel_dot_pos < 0.0f) {
-					const float visc = vel_dot_pos*p.slength*p.artvisccoeff*(p_sspeed + sa_sound_speed(p, nvel.w, nfl))/
+					const float visc = vel_dot_pos*p.slength*p.artvisccoeff*(p_sspeed + nrow.z)/
 						((r*r + p.epsartvisc)*(p_rho + n_rho));
 					dx += visc*rx*nmass*f; dy += visc*ry*nmass*f; dz += visc*rz*nmass*f;
 				}
@@ -134,7 +136,10 @@ extern "C" int sphx_forces_internal_energy(sphx_ctx *ctx, float *DEDt,
 	SPHX_REQUIRE(DEDt && pos && vel && info && hash && cellStart && neibsList, "sphx_forces_internal_energy: missing buffer");
 	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_forces_internal_energy: empty or inverted range");
 	if (fromParticle == toParticle) return SPHX_OK;
+	{ const int rc0 = sphx_ensure_scratch(ctx, numParticles); if (rc0 != SPHX_OK) return rc0; }
+	sphx_fidelity_rows_launch(ctx, vel, info, numParticles, (hipStream_t)stream);
 	EnergyArgs a = {};
+	a.row = ctx->eos_aux;
 	a.dedt = DEDt; a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.info = (const particleinfo*)info;
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.fromParticle = fromParticle; a.toParticle = toParticle;
 	internal_energy_kernel<<<div_up_u(toParticle - fromParticle, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);

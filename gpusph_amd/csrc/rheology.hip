@@ -170,10 +170,28 @@ extern "C" int sphx_calc_effvisc(sphx_ctx *ctx, float *effvisc, float *h_max_kin
 	return SPHX_OK;
 }
 
+// what the pair loop needs from a particle besides position and velocity, evaluated once per particle instead of once per pair
+// (same expressions, same values): pressure, density, sound speed, viscosity (BUFFER_EFFVISC or the fluid's coefficient)
+__global__ void __launch_bounds__(256)
+fidelity_row_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__restrict__ info,
+	const float *__restrict__ effvisc, float4 *__restrict__ row, uint32_t n)
+{
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t fl = FLUID_NUM(info[i]);
+	const float rt = vel[i].w;
+	row[i] = make_float4(sa_P(p, rt, fl), (rt + 1.0f)*p.rho0[fl], sa_sound_speed(p, rt, fl), effvisc ? effvisc[i] : p.visccoeff[fl]);
+}
+
+void sphx_fidelity_rows_launch(sphx_ctx *ctx, const void *vel, const void *info, uint32_t numParticles, hipStream_t st)
+{
+	fidelity_row_kernel<<<div_up_u(numParticles, 256), 256, 0, st>>>(ctx->dev, (const float4*)vel, (const particleinfo*)info, nullptr, ctx->eos_aux, numParticles);
+}
+
 struct GnForcesArgs {
 	float4 *forces;
 	float *cfl;
-	const float4 *pos, *vel;
+	const float4 *pos, *vel, *row;
 	const float *effvisc;
 	const particleinfo *info;
 	const uint32_t *hash, *cellStart;
@@ -199,15 +217,16 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 			const uint32_t fl = FLUID_NUM(info);
 			const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 			const bool fluid = ptype == PT_FLUID;
-			const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
-			const float p_P = sa_P(p, vel.w, fl);
+			const float4 self = a.row[index];      // P, rho, c, viscosity
+			const float p_rho = self.y;
+			const float p_P = self.x;
 			// SPH_HA (Hu & Adams): P instead of P/rho^2, the volumes V = m/rho in the pressure term, the particle's own mass in the
 			// continuity equation (forces_kernel.def:458-468,2030-2046,2269-2286,2436-2448)
 			const bool ha = p.formulation == SPHX_SPH_HA;
 			const float p_precalc = ha ? p_P : p_P/(p_rho*p_rho);
-			const float p_sspeed = sa_sound_speed(p, vel.w, fl);
+			const float p_sspeed = self.z;
 			const bool viscous = p.rheology != SPHX_INVISCID;
-			const float p_visc = a.effvisc ? a.effvisc[index] : p.visccoeff[fl];      // per particle (generalized Newtonian) or per fluid
+			const float p_visc = self.w;      // per particle (generalized Newtonian) or per fluid
 			const float p_volume = pos.w/p_rho;
 			const bool momentum = fluid || HAS_COMPUTE_FORCE(info);
 			auto pair = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz, bool nfluid) {
@@ -219,7 +238,8 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 				const float vel_dot_pos = sa_dot3(vx, vy, vz, rx, ry, rz);
 				const float f = gn_F(p, r);
 				const uint32_t nfl = FLUID_NUM(a.info[j]);
-				const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+				const float4 nrow = a.row[j];
+				const float n_rho = nrow.y;
 				const float nmass = npos.w;
 				// compute_density_derivative: divergence of velocity + density diffusion (fluid neighbours only)
 				float DrDt = nmass*vel_dot_pos*f;
@@ -227,7 +247,7 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 				const float n_volume = nmass/n_rho;
 				if (nfluid && p.densitydiff == SPHX_COLAGROSSI && nfl == fl) {
 					const float gdotr = sa_dot3(p.gravity[0], p.gravity[1], p.gravity[2], rx, ry, rz);
-					if (!(fabsf(p_P - sa_P(p, nvel.w, fl)) < fabsf(gdotr*p_rho))) {
+					if (!(fabsf(p_P - nrow.x) < fabsf(gdotr*p_rho))) {      // same fluid: the neighbour's own pressure
 						if (ha) DrDt -= p.densityDiffCoeff*p.sscoeff[fl]*(p_volume/n_volume - 1)*f*pos.w;      // :1954-1996
 						else DrDt -= p.densityDiffCoeff*p.sscoeff[fl]*(n_rho/p_rho - 1)*f*nmass;
 					}
@@ -238,7 +258,7 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 						const float grav_corr = -sa_dot3(p.gravity[0], p.gravity[1], p.gravity[2], rx, ry, rz)*p.rho0[fl]/sqC0;
 						float fx = 0.0f, fy = 0.0f, fz = 0.0f;
 						if (r > 1e-4f*p.slength) {
-							const float sc = (float)((double)fmaxf(p_sspeed, sa_sound_speed(p, nvel.w, nfl))*
+							const float sc = (float)((double)fmaxf(p_sspeed, nrow.z)*
 								((double)pos.w*(1./(double)p_volume - (double)(1.0f/(1.0f*n_volume))) + (double)grav_corr)/(double)p_rho/(double)r);
 							fx = sc*rx; fy = sc*ry; fz = sc*rz;
 						}
@@ -250,14 +270,14 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 					const float grav_corr = -sa_dot3(p.gravity[0], p.gravity[1], p.gravity[2], rx, ry, rz)*p.rho0[fl]/sqC0;
 					float fx = 0.0f, fy = 0.0f, fz = 0.0f;
 					if (r > 1e-4f*p.slength) {
-						const float sc = fmaxf(p_sspeed, sa_sound_speed(p, nvel.w, nfl))*(p_rho - n_rho + grav_corr)/p_rho/r;
+						const float sc = fmaxf(p_sspeed, nrow.z)*(p_rho - n_rho + grav_corr)/p_rho/r;
 						fx = sc*rx; fy = sc*ry; fz = sc*rz;
 					}
 					DrDt += p.densityDiffCoeff*nmass*sa_dot3(fx, fy, fz, rx, ry, rz)*f;
 				}
 				force.w += DrDt;
 				if (!momentum) return;
-				const float n_P = sa_P(p, nvel.w, nfl);
+				const float n_P = nrow.x;
 				const float n_precalc = ha ? n_P : n_P/(n_rho*n_rho);
 				float s = (p_precalc + n_precalc)*nmass*f;
 				if (ha) s = (p_precalc*p_volume*p_volume + n_precalc*n_volume*n_volume)/pos.w*f;
@@ -278,7 +298,7 @@ gn_forces_kernel(DevParams p, GnForcesArgs a)
 					const float cv = 5*visc_thirds - avb, cr = 5*(visc_thirds + avb)*vel_dot_pos/pos_den;
 					dx += coeff*(cv*vx + cr*rx); dy += coeff*(cv*vy + cr*ry); dz += coeff*(cv*vz + cr*rz);
 				} else if (viscous) {
-					const float vf = sa_visc_avg(p, p_visc, a.effvisc ? a.effvisc[j] : p.visccoeff[nfl], p_rho, n_rho, nmass)*f;
+					const float vf = sa_visc_avg(p, p_visc, nrow.w, p_rho, n_rho, nmass)*f;
 					if (p.viscmodel == SPHX_MONAGHAN) {      // along the relative position, approaching pairs only (:2531-2562)
 						const float den = sa_dot3(rx, ry, rz, rx, ry, rz) + p.epsartvisc;
 						const float c = vel_dot_pos < 0 ? p.monaghan_visc_coeff*vel_dot_pos/den : 0.0f;
@@ -385,8 +405,12 @@ int sphx_fidelity_forces_launch(sphx_ctx *ctx, void *forces, float *cfl,
 		SPHX_REQUIRE(cfl != nullptr, "sphx_forces_basicstep_effvisc: ENABLE_DTADAPT needs the CFL buffer");
 		if (numBlocks > blocks) SPHX_HIP(hipMemsetAsync(cfl + cflOffset + blocks, 0, sizeof(float)*(numBlocks - blocks), st));
 	}
+	{ const int rc0 = sphx_ensure_scratch(ctx, numParticles); if (rc0 != SPHX_OK) return rc0; }
+	// the rows are read for the neighbours as well: every particle, not just the range
+	fidelity_row_kernel<<<div_up_u(numParticles, 256), 256, 0, st>>>(ctx->dev, (const float4*)vel, (const particleinfo*)info, effvisc, ctx->eos_aux, numParticles);
+	SPHX_LAUNCH_CHECK("fidelity_row_kernel");
 	GnForcesArgs a = {};
-	a.forces = (float4*)forces; a.cfl = cfl; a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.effvisc = effvisc;
+	a.forces = (float4*)forces; a.cfl = cfl; a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.effvisc = effvisc; a.row = ctx->eos_aux;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
 	gn_forces_kernel<<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);

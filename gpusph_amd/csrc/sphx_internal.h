@@ -183,6 +183,7 @@ int sphx_fidelity_forces_launch(sphx_ctx *ctx, void *forces, float *cfl,
 	const uint32_t *cellStart, const uint16_t *neibsList, const float *effvisc,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
 	float slength, float influenceradius, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream);   // rheology.hip
+void sphx_fidelity_rows_launch(sphx_ctx *ctx, const void *vel, const void *info, uint32_t numParticles, hipStream_t st);   // rheology.hip
 int sphx_rb_flush(sphx_ctx *ctx, hipStream_t st);
 int sphx_xsph_launch(sphx_ctx *ctx, void *xsph, const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle, hipStream_t st);
