@@ -87,10 +87,6 @@ class MultiGpuEngine:
             raise ValueError("SA_BOUNDARY: the vertex/segment buffers are not exchanged between slabs yet (single domain only)")
         self.grenier = problem.simparams.sph_formulation == D.SPH_GRENIER
         self.effvisc_on = problem.simparams.rheologytype > D.NEWTONIAN        # NEEDS_EFFECTIVE_VISC
-        if world > 1 and self.effvisc_on:
-            raise ValueError("generalized Newtonian rheologies: BUFFER_EFFVISC is not exchanged between slabs yet (single domain only)")
-        if world > 1 and self.grenier:
-            raise ValueError("SPH_GRENIER: sigma and the volumes are not exchanged between slabs yet (single domain only)")
         self.problem = problem
         self.rank, self.world = rank, world
         self.device = torch.device(device)
@@ -183,8 +179,6 @@ class MultiGpuEngine:
         # ENABLE_INTERNAL_ENERGY: BUFFER_INTERNAL_ENERGY (double buffered, re-sorted; starts from zero: init_internal_energy) and its rate
         self.energy_on = bool(self.sp.simflags & D.ENABLE_INTERNAL_ENERGY)
         if self.energy_on:
-            if world > 1:
-                raise ValueError("ENABLE_INTERNAL_ENERGY: single domain only")
             self.energy = torch.zeros(A, dtype=f32, device=dev); self.energy2 = torch.zeros_like(self.energy)
             self.dedt = torch.zeros(A, dtype=f32, device=dev)
         # SPH_GRENIER: BUFFER_VOLUME (double buffered like pos/vel, travels through the re-sort) and BUFFER_SIGMA
@@ -360,7 +354,12 @@ class MultiGpuEngine:
         self.recv_l = (n_int, n_int + rl)
         self.recv_r = (n_int + rl, n_int + rl + rr)
         self.n_local = n_int + rl + rr
-        self._exchange([self.pos, self.vel, self.info, self.hash])
+        state = [self.pos, self.vel, self.info, self.hash]
+        if self.grenier:
+            state.append(self.vol)           # BUFFER_VOLUME is particle state: the halo copies integrate theirs from the exchanged forces
+        if self.energy_on:
+            state.append(self.energy)
+        self._exchange(state)
         # imported cells are OUTER_EDGE cells here whatever they are at home
         if self.n_local > n_int:
             hs = self.hash[n_int:self.n_local]
@@ -398,44 +397,55 @@ class MultiGpuEngine:
             if self.sa_dynamic_gamma:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
                 K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb, self.d_dt_next)
             return
+        # the forces entry of this option set, as a function of the particle range and the offset into the CFL array
         if self.effvisc_on and run_mode == D.SIMULATE:
-            # CALC_VISC on the state the forces read; its largest kinematic viscosity is the viscous limit of this pass's dt
+            # CALC_VISC on the state the forces read (internal particles, then UPDATE_EXTERNAL); its largest kinematic viscosity
+            # is the viscous limit of this pass's dt on this device (the dt of the step is the minimum over the devices)
             K.calc_effvisc(self.effvisc, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, self.n_int)
-            nb = K.forces_effvisc(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.effvisc,
-                                  self.n_local, 0, self.n_int, 0)
-            if prof:
-                e1.record(); self.profile_forces.append((e0, e1))
-            K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
-            return
-        if self.grenier and run_mode == D.SIMULATE:
-            # COMPUTE_DENSITY on the state the forces read (PredictorCorrectorIntegrator.cc:443-458), then the Grenier forces
+            if self.world > 1:
+                self._exchange([self.effvisc])
+
+            def launch(frm, to, off):
+                return K.forces_effvisc(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist,
+                                        self.effvisc, self.n_local, frm, to, off)
+        elif self.grenier and run_mode == D.SIMULATE:
+            # COMPUTE_DENSITY on the state the forces read, UPDATE_EXTERNAL of sigma and of the rewritten velocity buffer
+            # (PredictorCorrectorIntegrator.cc:443-458), then the Grenier forces
             vol = self.vol if pos is self.pos else self.vol2
-            K.compute_density(self.sigma, vel, pos, self.info, self.hash, vol, self.cellStart, self.neibslist, self.n_local)
-            nb = K.forces_grenier(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.sigma,
-                                  self.n_local, 0, self.n_int, 0)
-            if prof:
-                e1.record(); self.profile_forces.append((e0, e1))
-            K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
-            return
-        args = (self.forces, self.cfl, self.rbforces if self.has_rb else None, self.rbtorques if self.has_rb else None, pos, vel, self.info, self.hash, self.cellStart,
-                self.neibslist, self.n_local)
-        kw = dict(tau=self.tau) if sps else {}
-        if self.xsph is not None:
-            kw["xsph"] = self.xsph
-        if run_mode != D.SIMULATE or step != 1:
-            kw.update(run_mode=run_mode, step=step)
+            K.compute_density(self.sigma, vel, pos, self.info, self.hash, vol, self.cellStart, self.neibslist, self.n_int)
+            if self.world > 1:
+                self._exchange([self.sigma, vel])
+
+            def launch(frm, to, off):
+                return K.forces_grenier(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist,
+                                        self.sigma, self.n_local, frm, to, off)
+        else:
+            args = (self.forces, self.cfl, self.rbforces if self.has_rb else None, self.rbtorques if self.has_rb else None, pos, vel,
+                    self.info, self.hash, self.cellStart, self.neibslist, self.n_local)
+            kw = dict(tau=self.tau) if sps else {}
+            if self.xsph is not None:
+                kw["xsph"] = self.xsph
+            if run_mode != D.SIMULATE or step != 1:
+                kw.update(run_mode=run_mode, step=step)
+
+            def launch(frm, to, off):
+                return K.forces(*args, frm, to, off, **kw)
+        energy = self.energy_on and run_mode == D.SIMULATE      # the BUFFER_INTERNAL_ENERGY_UPD output of the pass travels with the forces
+        if energy:
+            K.forces_internal_energy(self.dedt, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, 0, self.n_int)
+        outputs = [self.forces, self.dedt] if energy else [self.forces]
         if self.world > 1 and self.n_int > self.edge_start:
             # edge stripe first, then the inner stripe while the edge forces travel
-            nb1 = K.forces(*args, self.edge_start, self.n_int, 0, **kw)
+            nb1 = launch(self.edge_start, self.n_int, 0)
             if self.overlap:
                 ev = torch.cuda.Event(); ev.record()
-            nb2 = K.forces(*args, 0, self.edge_start, nb1, **kw)
+            nb2 = launch(0, self.edge_start, nb1)
             if prof:
                 e1.record(); self.profile_forces.append((e0, e1))
             if self.overlap:
                 with torch.cuda.stream(self.comm_stream):
                     self.comm_stream.wait_event(ev)
-                    self._exchange([self.forces])
+                    self._exchange(outputs)
                 if self.exchange_events is not None:     # how long the compute stream sits waiting for the halo forces
                     b = torch.cuda.Event(enable_timing=True); a_ = torch.cuda.Event(enable_timing=True)
                     b.record()
@@ -443,16 +453,14 @@ class MultiGpuEngine:
                 if self.exchange_events is not None:
                     a_.record(); self.exchange_events.append((b, a_))
             else:
-                self._exchange([self.forces])
+                self._exchange(outputs)
         else:
-            nb1 = K.forces(*args, 0, self.n_int, 0, **kw)
+            nb1 = launch(0, self.n_int, 0)
             nb2 = 0
             if prof:
                 e1.record(); self.profile_forces.append((e0, e1))
             if self.world > 1:
-                self._exchange([self.forces])
-        if self.energy_on and run_mode == D.SIMULATE:      # the BUFFER_INTERNAL_ENERGY_UPD output of the pass
-            K.forces_internal_energy(self.dedt, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, 0, self.n_int)
+                self._exchange(outputs)
         K.dtreduce(self.cfl, self.cfl_temp, nb1 + nb2, self.d_dt_next, combine_min)
 
     def step(self):
@@ -552,4 +560,6 @@ class MultiGpuEngine:
         n = self.n_int
         return {"pos": self.pos[:n].cpu().numpy(), "vel": self.vel[:n].cpu().numpy(),
                 "info": self.info[:n].cpu().numpy().view(np.uint16), "hash": self.hash[:n].cpu().numpy().view(np.uint32),
-                "forces": self.forces[:n].cpu().numpy()}
+                "forces": self.forces[:n].cpu().numpy(),
+                **({"vol": self.vol[:n].cpu().numpy()} if self.grenier else {}),
+                **({"energy": self.energy[:n].cpu().numpy()} if self.energy_on else {})}

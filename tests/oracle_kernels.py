@@ -105,3 +105,58 @@ class OracleKernels:
         dt = float(np.float32(d_dt[0].item()) * np.float32(dt_scale))
         self.L.orc_euler(C.byref(self.op), _p(npos), _p(nvel), _p(opos), _p(ovel), _p(info), _p(hash_), _p(forces), None,
                          C.c_uint32(n), C.c_float(dt), C.c_int(step))
+
+    # ---- the optional arrays of the re-sort
+    def gather_rows(self, sorted_, unsorted, partindex, n):
+        sorted_[:n] = unsorted[partindex[:n].long()]
+
+    # ---- SPH_GRENIER
+    def init_volume(self, vol, pos, vel, info, n):
+        self.L.orc_init_volume(C.byref(self.op), _p(vol), _p(pos), _p(vel), _p(info), C.c_uint32(n))
+
+    def compute_density(self, sigma, vel, pos, info, hash_, vol, cellStart, neibslist, n):
+        self.L.orc_density_grenier(C.byref(self.op), _p(sigma), _p(vel), _p(pos), _p(info), _p(hash_), _p(vol), _p(cellStart), _p(neibslist),
+                                   C.c_uint32(n), C.c_int(int(self.info_.maxFluidBoundaryNeibs)))
+
+    def forces_grenier(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, sigma, n, frm, to, cfl_offset=0):
+        if to > frm:
+            forces[frm:to] = 0
+        self.L.orc_forces_grenier.restype = C.c_uint32
+        return int(self.L.orc_forces_grenier(C.byref(self.op), _p(forces), _p(cfl), _p(pos), _p(vel), _p(info), _p(hash_), _p(cellStart),
+                                             _p(neibslist), _p(sigma), C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset)))
+
+    def euler_grenier(self, npos, nvel, nvol, opos, ovel, ovol, info, hash_, forces, n, d_dt, dt_scale, step):
+        dt = float(np.float32(d_dt[0].item()) * np.float32(dt_scale))
+        self.L.orc_euler_grenier(C.byref(self.op), _p(npos), _p(nvel), _p(nvol), _p(opos), _p(ovel), _p(ovol), _p(info), _p(hash_),
+                                 _p(forces), None, C.c_uint32(n), C.c_float(dt), C.c_int(step))
+
+    # ---- generalized Newtonian rheologies
+    def calc_effvisc(self, effvisc, pos, vel, info, hash_, cellStart, neibslist, n, range_end):
+        self.L.orc_effective_visc.restype = C.c_float
+        mx = float(self.L.orc_effective_visc(C.byref(self.op), _p(effvisc), None, _p(pos), _p(vel), _p(info), _p(hash_), _p(cellStart),
+                                             _p(neibslist), C.c_uint32(n), C.c_uint32(range_end)))
+        if mx == mx:
+            self.max_kinvisc = mx
+        return mx
+
+    def forces_effvisc(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, effvisc, n, frm, to, cfl_offset=0):
+        if to > frm:
+            forces[frm:to] = 0
+        self.L.orc_forces_effvisc.restype = C.c_uint32
+        return int(self.L.orc_forces_effvisc(C.byref(self.op), _p(forces), _p(cfl), None, None, _p(pos), _p(vel), _p(info), _p(hash_),
+                                             _p(cellStart), _p(neibslist), None, C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to),
+                                             C.c_uint32(cfl_offset), C.c_int(0), _p(effvisc)))
+
+    # ---- ENABLE_INTERNAL_ENERGY: the energy rate is an output of the oracle's forces passes; run them once more into scratch
+    def forces_internal_energy(self, dedt, pos, vel, info, hash_, cellStart, neibslist, n, frm, to):
+        scratch = torch.zeros_like(pos)
+        cfl = torch.zeros(self.fmax_elements(len(pos)) + 8, dtype=torch.float32)
+        dedt[frm:to] = 0
+        self.L.orc_set_dedt(_p(dedt))
+        self.L.orc_forces(C.byref(self.op), _p(scratch), _p(cfl), None, None, _p(pos), _p(vel), _p(info), _p(hash_), _p(cellStart),
+                          _p(neibslist), None, C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(0), C.c_int(0))
+        self.L.orc_set_dedt(None)
+
+    def euler_internal_energy(self, new_energy, old_energy, dedt, old_pos, info, n, d_dt, dt_scale):
+        dt = float(np.float32(d_dt[0].item()) * np.float32(dt_scale))
+        self.L.orc_euler_energy(C.byref(self.op), _p(new_energy), _p(old_energy), _p(dedt), _p(old_pos), _p(info), C.c_uint32(n), C.c_float(dt))

@@ -441,6 +441,12 @@ _MG_CASES = {
     # StillWater's option set (laminar viscosity + Ferrari diffusion in the tiled stripes, MLS filter) and two fluids
     "dynamicvisc+ferrari+mls": (dict(viscosity="DYNAMICVISC", kinematic_visc=3.0e-2, density_diffusion=D.FERRARI), ((1, 4),)),
     "two-fluids": (dict(two_fluids=True), ()),
+    # the fidelity engines under the slab decomposition: sigma / densities exchanged after COMPUTE_DENSITY and the volumes with
+    # the halo (SPH_GRENIER); the energy rate with the forces (internal energy); the stripes through the SPH_HA routing
+    "grenier": (dict(obstacle=False, two_fluids=True, formulation=D.SPH_GRENIER, viscosity="DYNAMICVISC", density_diffusion=D.DENSITY_DIFFUSION_NONE), ()),
+    "internal-energy": (dict(obstacle=False, internal_energy=True), ()),
+    "sph-ha": (dict(obstacle=False, two_fluids=True, formulation=D.SPH_HA, density_diffusion=D.COLAGROSSI,
+                    viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.DYNAMIC, avgop=D.HARMONIC)), ()),
 }
 
 
@@ -452,7 +458,7 @@ def _mg_worker(rank, world, port, outdir, casename):
     from gpusph_amd.multigpu import MultiGpuEngine
     dist.init_process_group("gloo", rank=rank, world_size=world)      # one GPU on this box: RCCL needs one per rank
     kw, filters = _MG_CASES[casename]
-    prob = DamBreak3D(0.03, obstacle=True, jitter=0.05, linearization="xzy", **kw)
+    prob = DamBreak3D(**{**dict(deltap=0.03, obstacle=True, jitter=0.05, linearization="xzy"), **kw})
     eng = MultiGpuEngine(prob, "cuda:0", rank, world)
     for f in filters:
         eng.add_filter(*f)
@@ -474,7 +480,7 @@ def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_mg_worker, args=(2, port, str(tmp_path), casename), nprocs=2, join=True)
     kw, filters = _MG_CASES[casename]
-    prob = DamBreak3D(0.03, obstacle=True, jitter=0.05, linearization="xzy", **kw)
+    prob = DamBreak3D(**{**dict(deltap=0.03, obstacle=True, jitter=0.05, linearization="xzy"), **kw})
     ref = _engine(prob)
     for f in filters:
         ref.add_filter(*f)

@@ -38,6 +38,9 @@ def _worker(rank, world, port, steps, case, outdir, filters=()):
     elif which == "WaveTank":
         from gpusph_amd.problem import WaveTank
         prob = WaveTank(**case)
+    elif which == "Poiseuille":
+        from gpusph_amd.problem import Poiseuille
+        prob = Poiseuille(**case)
     else:
         prob = DamBreak3D(**case)
     if gate:
@@ -78,7 +81,8 @@ def _gather(outdir, world):
     parts = [np.load(os.path.join(outdir, "r%d_of_%d.npz" % (r, world))) for r in range(world)]
     ids = np.concatenate([p["info"][:, 2].astype(np.uint32) | (p["info"][:, 3].astype(np.uint32) << 16) for p in parts])
     order = np.argsort(ids)
-    cat = {k: np.concatenate([p[k] for p in parts])[order] for k in ("pos", "vel", "info", "hash", "forces")}
+    keys = [k for k in ("pos", "vel", "info", "hash", "forces", "vol", "energy") if k in parts[0]]
+    cat = {k: np.concatenate([p[k] for p in parts])[order] for k in keys}
     return ids[order], cat, parts
 
 
@@ -205,3 +209,36 @@ def test_split_axis_must_not_be_periodic():
     SlabPartition(prob, 1)
     ok = PeriodicBox(0.05, n=(12, 12, 12), periodic=D.PERIODIC_Y | D.PERIODIC_Z)       # default yzx: COORD3 = x
     SlabPartition(ok, 2)
+
+
+FIDELITY_CASES = {
+    # SPH_GRENIER: sigma and the rewritten densities are exchanged after COMPUTE_DENSITY, the volumes travel with the halo
+    "grenier": dict(deltap=0.05, obstacle=False, two_fluids=True, formulation=3, viscosity="DYNAMICVISC", density_diffusion=0, jitter=0.1),
+    # generalized Newtonian: BUFFER_EFFVISC exchanged after CALC_VISC; each device limits dt by its own largest viscosity
+    "papanastasiou": dict(problem="Poiseuille", ppH=10, rheology=4, linearization="xyz"),
+    # internal energy: the rate travels with the forces, the energy with the halo
+    "energy": dict(deltap=0.05, obstacle=False, internal_energy=True, jitter=0.1),
+    # SPH_HA and the MONAGHAN model need no extra buffer: the ranges of the edge / inner stripes go through the same routing
+    "ha": dict(deltap=0.05, obstacle=False, two_fluids=True, formulation=4, density_diffusion=2, jitter=0.1,
+               viscosity=dict(rheologytype=1, turbmodel=0, compvisc=1, avgop=1)),
+    "monaghan": dict(problem="Poiseuille", ppH=10, viscmodel=1, linearization="xyz"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FIDELITY_CASES))
+def test_slab_runs_of_the_fidelity_option_sets_equal_single_domain(tmp_path, name):
+    case = FIDELITY_CASES[name]
+    steps = 12                     # crosses a neighbour rebuild, i.e. a new halo import
+    one, two = tmp_path / "one", tmp_path / "two"
+    one.mkdir(); two.mkdir()
+    _run(1, steps, case, str(one))
+    _run(2, steps, case, str(two))
+    ids1, a, p1 = _gather(str(one), 1)
+    ids2, b, p2 = _gather(str(two), 2)
+    assert np.array_equal(ids1, ids2)
+    for k in a:
+        if k == "hash":       # the two high bits are the cell type of the slab decomposition
+            assert np.array_equal(a[k] & 0x3FFFFFFF, b[k] & 0x3FFFFFFF)
+        else:
+            assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (name, k)
+    assert all(p["n_local"] > 0 for p in p2) and float(p2[0]["dt"]) == float(p1[0]["dt"])
