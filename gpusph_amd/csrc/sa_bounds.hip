@@ -514,6 +514,78 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 	}
 }
 
+// repackDevice x3 + finalizeRepackDevice with SA_BOUNDARY (src/cuda/forces_kernel.def:3024-3086,4155-4349; run_repack
+// src/cuda/forces.cu:828-896): the mixing force of the repacking run mode on the fluid particles -- a c0^2 V_b F r over the fluid
+// neighbours, a c0 V_b F r over the vertex neighbours (one c0: the reference's expression), + a c0^2 |grad gamma_as| n_s over
+// the boundary elements; sums divided by gamma; velocity damping and the CFL term as without SA
+__global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
+sa_repack_kernel(DevParams p, SaForcesArgs a)
+{
+	__shared__ float sMax[SPHX_BLOCK_FORCES/64];
+	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
+	float cflTerm = 0.0f;
+	if (index < a.toParticle) {
+		const particleinfo info = a.info[index];
+		const float4 pos = a.pos[index];
+		if (is_active_w(pos.w)) {
+			float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (PART_TYPE(info) == PT_FLUID) {
+				const float4 vel = a.vel[index];
+				const uint32_t fl = FLUID_NUM(info);
+				const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+				const float c0 = p.sscoeff[fl];
+				auto volumic = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz, bool vertex) {
+					if (!is_active_w(npos.w)) return;
+					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+					if (r >= p.influenceradius) return;
+					const float n_rho = (a.vel[j].w + 1.0f)*p.rho0[FLUID_NUM(a.info[j])];
+					const float qm2 = r/p.slength - 2.0f;
+					const float f = qm2*qm2*qm2*p.fcoeff;
+					const float s = vertex ? p.repack_a*c0*npos.w/n_rho*f : p.repack_a*c0*c0*npos.w/n_rho*f;
+					force.x -= s*rx; force.y -= s*ry; force.z -= s*rz;
+				};
+				for_each_neib<PT_FLUID>(p, a, index, pos, gridPos,
+					[&](uint32_t j, const float4 &npos, float rx, float ry, float rz) { volumic(j, npos, rx, ry, rz, false); });
+				for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos,
+					[&](uint32_t j, const float4 &npos, float rx, float ry, float rz) { volumic(j, npos, rx, ry, rz, true); });
+				for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+					if (!is_active_w(npos.w)) return;
+					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+					if (r >= p.influenceradius + a.deltap) return;
+					const float4 be = a.boundElement[j];
+					const V3 ns = v3(be.x, be.y, be.z);
+					const float inv_h = 1.0f/p.slength;
+					V3 q_vb[3];
+					calc_vertex_rel_pos(q_vb, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+					const float ggamAS = grad_gamma_wendland(p.slength, v3(rx*inv_h, ry*inv_h, rz*inv_h), q_vb, ns);
+					const float c = p.repack_a*c0*c0*ggamAS;
+					force.x += c*be.x; force.y += c*be.y; force.z += c*be.z;
+				});
+				const float gam = a.gGam[index].w;      // repack_fixup :3220-3236
+				force.x /= gam; force.y /= gam; force.z /= gam; force.w /= gam;
+				force.w /= p.rho0[fl];
+				const float damp = p.repack_alpha*c0/a.deltap;
+				force.x += damp*vel.x; force.y += damp*vel.y; force.z += damp*vel.z;
+				if (p.simflags & SPHX_ENABLE_DTADAPT) {
+					const float sspeed = sa_sound_speed(p, vel.w, fl);
+					const float acc = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
+					cflTerm = fmaxf(acc, sspeed*sspeed/p.slength);
+				}
+			}
+			a.forces[index] = force;
+		}
+	}
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) cflTerm = fmaxf(cflTerm, __shfl_down(cflTerm, d));
+	if ((threadIdx.x & 63u) == 0u) sMax[threadIdx.x >> 6] = cflTerm;
+	__syncthreads();
+	if (threadIdx.x == 0 && a.cfl && (p.simflags & SPHX_ENABLE_DTADAPT)) {
+		float m = sMax[0];
+		for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) m = fmaxf(m, sMax[w]);
+		a.cfl[a.cflOffset + blockIdx.x] = m;
+	}
+}
+
 // integrateGammaDevice, quadrature flavour (src/cuda/density_sum_kernel.cu:690-765) for fluid particles at their new positions;
 // the rows of the other particle types are copied (copyTypeDataDevice, src/cuda/euler.cu:253-262)
 struct SaIntGammaArgs {
@@ -834,8 +906,10 @@ extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
 	(void)dtadaptfactor; (void)step; (void)dt;
 	int rc = sa_forces_check(ctx, "forces basicstep (SA) called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
-	if (run_mode != SPHX_SIMULATE)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep_sa: the repacking force with SA_BOUNDARY is not built");
+	if (run_mode != SPHX_SIMULATE && run_mode != SPHX_REPACK)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep_sa: invalid run mode");
+	if (run_mode == SPHX_REPACK && !(ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_forces_basicstep_sa: repacking with dynamic gamma (its CFL condition) is not built; ENABLE_GAMMA_QUADRATURE is");
 	SPHX_REQUIRE(forces && pos && vel && info && hash && cellStart && neibsList && gGam && boundElements && vertPos0 && vertPos1 && vertPos2,
 		"sphx_forces_basicstep_sa: missing buffer");
 	SPHX_REQUIRE(!(ctx->params.simflags & SPHX_ENABLE_DTADAPT) || cfl, "sphx_forces_basicstep_sa: ENABLE_DTADAPT needs the CFL buffer");
@@ -855,6 +929,11 @@ extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
+	if (run_mode == SPHX_REPACK) {
+		sa_repack_kernel<<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
+		SPHX_LAUNCH_CHECK("sa_repack_kernel");
+		return SPHX_OK;
+	}
 	// the CFL condition of the gamma transport (dynamic gamma + adaptive dt): BUFFER_CFL_GAMMA in the reference's layout
 	const bool gcfl = !(ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE) && (ctx->params.simflags & SPHX_ENABLE_DTADAPT);
 	SPHX_REQUIRE(!gcfl || cflGamma, "sphx_forces_basicstep_sa: dynamic gamma with ENABLE_DTADAPT needs BUFFER_CFL_GAMMA");

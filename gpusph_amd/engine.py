@@ -113,8 +113,14 @@ class TimestepEngine(MultiGpuEngine):
         src/integrators/RepackingIntegrator.cc:278-420): forces(REPACK) on step n, one full-dt Euler step."""
         if self.iterations % self.sp.buildneibsfreq == 0:
             self.build_neibs()
+            if self.sa and self.iterations == 0:     # initialisation step of the boundary conditions, REPACK variants (:80-235)
+                self.sa_boundary_conditions(0, D.REPACK)
         self._forces(self.pos, self.vel, 1, 0, D.REPACK)
         self._euler(1, 1.0, D.REPACK)
+        if self.sa:      # INTEGRATE_GAMMA of the new state (RepackingIntegrator.cc:386-405); gamma by quadrature only
+            self.k.sa_integrate_gamma(self.gradgamma2, self.gradgamma, self.pos2, self.boundelements, self.vertpos, self.info, self.hash,
+                                      self.cellStart, self.neibslist, self.n_local, self.n_local)
+            self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
         self.pos, self.pos2 = self.pos2, self.pos
         self.vel, self.vel2 = self.vel2, self.vel
         self.d_t.add_(self.d_dt.double())

@@ -132,14 +132,14 @@ class HipKernels:
                                                P.slength, P.influenceradius, P.deltap, float(np.float32(epsilon)), n, range_end, self._s()))
 
     def forces_sa(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, n, frm, to, cfl_offset,
-                  cfl_gamma=None):
+                  cfl_gamma=None, run_mode=D.SIMULATE):
         p = capi.ptr
         P = self.params
         nb = C.c_uint32(0)
         capi.check(self.lib.sphx_forces_basicstep_sa(self.ctx.handle, p(forces), p(cfl), p(cfl_gamma), p(pos), p(vel), p(info), p(hash_), p(cellStart),
                                                      p(neibslist), p(ggam), p(boundelements), p(vertpos[0]), p(vertpos[1]), p(vertpos[2]),
                                                      n, frm, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius, cfl_offset,
-                                                     D.SIMULATE, 1, 0.0, C.byref(nb), self._s()))
+                                                     run_mode, 1, 0.0, C.byref(nb), self._s()))
         return nb.value
 
     def dtreduce_gamma(self, cfl_gamma, n, nblocks, d_dt):

@@ -392,9 +392,9 @@ class MultiGpuEngine:
         if self.sa:      # forces engine of SA_BOUNDARY: the state's gamma, the boundary elements, the vertex offsets of the segments
             ggam = self.gradgamma if pos is self.pos else self.gradgamma2
             nb = K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
-                             self.boundelements, self.vertpos, self.n_local, 0, self.n_int, 0, cfl_gamma=self.cfl_gamma)
+                             self.boundelements, self.vertpos, self.n_local, 0, self.n_int, 0, cfl_gamma=self.cfl_gamma, run_mode=run_mode)
             K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
-            if self.sa_dynamic_gamma:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
+            if self.sa_dynamic_gamma and run_mode == D.SIMULATE:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
                 K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb, self.d_dt_next)
             return
         # the forces entry of this option set, as a function of the particle range and the offset into the CFL array

@@ -1495,12 +1495,19 @@ static void repack_pass(const orc_params *p, int nptype, orc_f4 *forces,
 			if (r >= p->influenceradius) continue;
 			const float n_rho = physical_density(p, velArray[neib_index].w, FLUID_NUM(infoArray[neib_index]));
 			const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
-			const float s = p->repack_a*p->sscoeff[fl]*p->sscoeff[fl]*npos.w/n_rho*f;
+			/* fluid and (non-SA) boundary neighbours: a c0^2 V_b F r (:3024-3055); vertex neighbours of SA_BOUNDARY: the reference
+			 * has a single c0 there (:3057-3072), reproduced */
+			const float s = (nptype == PT_VERTEX) ? p->repack_a*p->sscoeff[fl]*npos.w/n_rho*f :
+				p->repack_a*p->sscoeff[fl]*p->sscoeff[fl]*npos.w/n_rho*f;
 			force.x -= s*rx; force.y -= s*ry; force.z -= s*rz;
 		}
 		forces[index] = force;
 	}
 }
+
+static void repack_finalize(const orc_params *p, orc_f4 *forces, float *cfl, orc_f4 *rbforces, orc_f4 *rbtorques,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	uint32_t fromParticle, uint32_t toParticle, uint32_t numBlocks, uint32_t cflOffset, const orc_f4 *gGam);
 
 uint32_t orc_repack_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 	orc_f4 *rbforces, orc_f4 *rbtorques,
@@ -1510,9 +1517,18 @@ uint32_t orc_repack_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 {
 	(void)numParticles;
 	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
-	const int dtadapt = !!(p->simflags & ORC_ENABLE_DTADAPT);
 	repack_pass(p, PT_FLUID, forces, posArray, velArray, infoArray, hashArray, cellStart, neibsList, fromParticle, toParticle);
 	repack_pass(p, PT_BOUNDARY, forces, posArray, velArray, infoArray, hashArray, cellStart, neibsList, fromParticle, toParticle);
+	repack_finalize(p, forces, cfl, rbforces, rbtorques, posArray, velArray, infoArray, hashArray, fromParticle, toParticle, numBlocks, cflOffset, NULL);
+	return numBlocks;
+}
+
+/* finalizeRepackDevice (:4263-4349); gGam: SA_BOUNDARY, the sums of the fluid particles are divided by gamma (repack_fixup :3220-3236) */
+static void repack_finalize(const orc_params *p, orc_f4 *forces, float *cfl, orc_f4 *rbforces, orc_f4 *rbtorques,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	uint32_t fromParticle, uint32_t toParticle, uint32_t numBlocks, uint32_t cflOffset, const orc_f4 *gGam)
+{
+	const int dtadapt = !!(p->simflags & ORC_ENABLE_DTADAPT);
 #pragma omp parallel for schedule(static)
 	for (uint32_t block = 0; block < numBlocks; ++block) {
 		float block_max = 0.0f;
@@ -1525,7 +1541,14 @@ uint32_t orc_repack_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 			const orc_f4 vel = velArray[index];
 			orc_f4 force = forces[index];
 			const int fl = FLUID_NUM(info);
-			force.w /= p->rho0[fl];
+			if (gGam) {
+				if (FLUID(info)) {
+					const float gam = gGam[index].w;
+					force.x /= gam; force.y /= gam; force.z /= gam; force.w /= gam;
+					force.w /= p->rho0[fl];
+				}
+			} else
+				force.w /= p->rho0[fl];
 			if (FLUID(info)) {
 				const float damp = p->repack_alpha*p->sscoeff[fl]/p->deltap;
 				force.x += damp*vel.x; force.y += damp*vel.y; force.z += damp*vel.z;
@@ -1566,6 +1589,49 @@ uint32_t orc_repack_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 		if (dtadapt && cfl)
 			cfl[cflOffset + block] = block_max;
 	}
+}
+
+/* run_repack with SA_BOUNDARY (src/cuda/forces.cu:828-896): fluid <- fluid, fluid <- vertex, fluid <- boundary element
+ * (+ a c0^2 |grad gamma_as| n_s, :3074-3086), finalize with the division by gamma */
+uint32_t orc_repack_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	const orc_f4 *gGam, const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, float deltap)
+{
+	(void)numParticles;
+	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
+	repack_pass(p, PT_FLUID, forces, posArray, velArray, infoArray, hashArray, cellStart, neibsList, fromParticle, toParticle);
+	repack_pass(p, PT_VERTEX, forces, posArray, velArray, infoArray, hashArray, cellStart, neibsList, fromParticle, toParticle);
+#pragma omp parallel for schedule(dynamic, 512)
+	for (uint32_t index = fromParticle; index < toParticle; ++index) {
+		const orc_info info = infoArray[index];
+		if (PART_TYPE(info) != PT_FLUID) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const int fl = FLUID_NUM(info);
+		orc_f4 force = forces[index];
+		neib_iter it;
+		neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t j;
+		while ((j = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[j];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			if (!isfinite(npos.w)) continue;
+			const float r = sqrtf(sqlength3(rx, ry, rz));
+			if (r >= p->influenceradius + deltap) continue;
+			const orc_f4 belem = boundelem[j];
+			const float inv_h = 1.0f/p->slength;
+			const float ggamAS = orc_grad_gamma_vp(p->slength, rx*inv_h, ry*inv_h, rz*inv_h, &belem,
+				vertPos0 + 2*(size_t)j, vertPos1 + 2*(size_t)j, vertPos2 + 2*(size_t)j);
+			const float c = p->repack_a*p->sscoeff[fl]*p->sscoeff[fl]*ggamAS;
+			force.x += c*belem.x; force.y += c*belem.y; force.z += c*belem.z;
+		}
+		forces[index] = force;
+	}
+	repack_finalize(p, forces, cfl, NULL, NULL, posArray, velArray, infoArray, hashArray, fromParticle, toParticle, numBlocks, cflOffset, gGam);
 	return numBlocks;
 }
 

@@ -263,6 +263,16 @@ class Oracle:
         self.max_gamma_cfl = float(self.cfl_gamma[((n + 3) // 4) * 4:((n + 3) // 4) * 4 + int(nb)].max()) if nb else 0.0
         return forces, cfl, int(nb)
 
+    def repack_forces_sa(self, pos, vel, info, hash_, cs, nl, ggam, boundelements, vertpos, n, deltap):
+        forces = np.zeros((len(pos), 4), dtype=np.float32)
+        nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
+        cfl = np.zeros(nblk, dtype=np.float32)
+        self.L.orc_repack_forces_sa.restype = C.c_uint32
+        nb = self.L.orc_repack_forces_sa(C.byref(self.p), P(forces), P(cfl), P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), P(ggam),
+                                         P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), C.c_uint32(n), C.c_uint32(0),
+                                         C.c_uint32(n), C.c_uint32(0), C.c_float(deltap))
+        return forces, cfl, int(nb)
+
     def sa_density_sum(self, new_vel, old_pos, new_pos, old_vel, old_ggam, boundelements, vertpos, info, hash_, cs, nl, n):
         """density_sum of the integration engine: new_vel.w and gamma of the fluid from the old and new positions"""
         v = new_vel.copy(); g = old_ggam.copy()

@@ -71,7 +71,7 @@ class OracleSaSim:
     (PredictorCorrectorIntegrator.cc: initializeBoundaryConditionsSequence<SA_BOUNDARY> :117-290, the step phases :386-685),
     executed by the CPU oracle.  Test infrastructure (the GPU tests compare MultiGpuEngine.step against it)."""
 
-    def __init__(self, problem):
+    def __init__(self, problem, repack=False):
         st = sa_oracle_state(problem)
         self.st, self.problem, self.o, self.n = st, problem, st["oracle"], st["n"]
         o, n, p = self.o, self.n, problem
@@ -79,7 +79,8 @@ class OracleSaSim:
         self.vertices, self.vertpos = st["vertices"], st["vertpos"]
         self.be = o.sa_compute_vertex_normal(st["boundelements"], self.vertices, self.info, self.hash, self.cs, self.nl, n)
         gg = o.sa_init_gamma(st["gradgamma"], self.pos, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n, p.m_deltap)
-        self.vel, self.gg = o.sa_segment_bc(self.pos, self.vel, gg, self.vertices, self.be, self.info, self.hash, self.cs, self.nl, n, step=0)
+        self.vel, self.gg = o.sa_segment_bc(self.pos, self.vel, gg, self.vertices, self.be, self.info, self.hash, self.cs, self.nl, n, step=0,
+                                            repack=repack)
         self.vel = o.sa_vertex_bc(self.pos, self.vel, self.gg, self.info, self.hash, self.cs, self.nl, n)
         self.dt = float(np.float32(p.simparams.dt))
         self.t = 0.0
@@ -112,6 +113,20 @@ class OracleSaSim:
         else:
             gs = o.sa_integrate_gamma(self.gg, ps, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
         return vs, gs
+
+    def repack_step(self):
+        """one iteration of the repacking integrator with SA_BOUNDARY (RepackingIntegrator.cc:278-420): forces(REPACK), one full-dt
+        Euler step of the fluid, INTEGRATE_GAMMA of the new positions; no neighbour rebuild here"""
+        o, n, p = self.o, self.n, self.problem
+        dt = float(np.float32(self.dt))
+        f, cfl, nb = o.repack_forces_sa(self.pos, self.vel, self.info, self.hash, self.cs, self.nl, self.gg, self.be, self.vertpos, n, p.m_deltap)
+        dt1 = o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        ps, vs = o.euler_repack(self.pos, self.vel, self.info, self.hash, f, n, dt, 1)
+        self.gg = o.sa_integrate_gamma(self.gg, ps, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
+        self.pos, self.vel, self.forces = ps, vs, f
+        self.t += dt
+        self.iterations += 1
+        self.dt = dt1
 
     def step(self):
         """no neighbour rebuild here: the runs compared are shorter than buildneibsfreq"""

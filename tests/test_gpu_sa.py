@@ -305,3 +305,36 @@ def test_density_summation_form_on_the_gpu():
     assert np.abs(gv[:, 3] - sim2.vel[:, 3]).max() < 2e-6
     assert np.abs(ggg[fl, 3] - sim2.gg[fl, 3]).max() < 2e-5
     assert abs(eng2.current_dt() - sim2.dt) < 1e-5 * sim2.dt and abs(eng2.time() - sim2.t) < 1e-6 * sim2.t
+
+
+def test_sa_repacking_run_follows_the_oracle():
+    """the repacking run mode with SA_BOUNDARY (StillWaterRepackSA's ENABLE_REPACKING): REPACK variants of the initial boundary
+    conditions, the mixing force with the wall term divided by gamma, Euler of the fluid, gamma by quadrature at the new positions"""
+    import torch
+    from sa_helpers import OracleSaSim
+    kw = dict(deltap=0.05, options="StillWaterRepackSA", jitter=0.2)
+    sim = OracleSaSim(SABox(**kw), repack=True)
+    eng = _engine(SABox(**kw))
+    n = sim.n
+    # single pass first: forces of the first iteration
+    eng.build_neibs()
+    eng.sa_boundary_conditions(0, D.REPACK)
+    f, cfl, nb = sim.o.repack_forces_sa(sim.pos, sim.vel, sim.info, sim.hash, sim.cs, sim.nl, sim.gg, sim.be, sim.vertpos, n, sim.problem.m_deltap)
+    eng._forces(eng.pos, eng.vel, 1, 0, D.REPACK)
+    gf = _np(eng.forces)[:n]
+    scale = np.abs(f[:n, :3]).max()
+    assert scale > 0 and np.abs(gf[:, :3] - f[:n, :3]).max() <= 5e-5 * scale          # |grad gamma| of the elements: powf-free, sums of ~100 terms
+    dt_ref = sim.o.dtreduce(cfl, nb, sim.sspeed_cfl, sim.max_kinvisc)
+    assert abs(float(eng.d_dt_next.item()) - dt_ref) <= 5e-5 * dt_ref
+    # then the loop (the engine's repack_step does its own initialisation on a fresh engine)
+    eng = _engine(SABox(**kw))
+    steps = 8
+    for _ in range(steps):
+        sim.repack_step(); eng.repack_step()
+    cs = float(min(sim.problem.m_cellsize))
+    assert np.array_equal(_np(eng.hash, np.uint32)[:n], sim.hash[:n])
+    assert np.abs(_np(eng.pos)[:n, :3] - sim.pos[:n, :3]).max() <= 2e-6 * cs * steps
+    assert np.abs(_np(eng.vel)[:n, :3] - sim.vel[:n, :3]).max() <= 1e-3 * max(np.abs(sim.vel[:n, :3]).max(), 1e-6)
+    fluid = info_type(sim.info[:n]) == D.PT_FLUID
+    np.testing.assert_allclose(_np(eng.gradgamma)[:n, 3][fluid], sim.gg[:n, 3][fluid], atol=2e-5)
+    assert np.abs(sim.vel[:n, :3][fluid]).max() > 0
