@@ -83,8 +83,6 @@ class MultiGpuEngine:
         if world > 1 and (problem.simparams.simflags & D.ENABLE_XSPH):
             raise ValueError("ENABLE_XSPH needs the mean velocity of the halo particles' neighbourhoods: single domain only")
         self.sa = problem.simparams.boundarytype == D.SA_BOUNDARY
-        if world > 1 and self.sa:
-            raise ValueError("SA_BOUNDARY: the vertex/segment buffers are not exchanged between slabs yet (single domain only)")
         self.grenier = problem.simparams.sph_formulation == D.SPH_GRENIER
         self.effvisc_on = problem.simparams.rheologytype > D.NEWTONIAN        # NEEDS_EFFECTIVE_VISC
         self.problem = problem
@@ -279,44 +277,58 @@ class MultiGpuEngine:
         if self.sa:
             K.build_neibs_sa(self.neibslist, self.vertpos, self.pos, self.info, self.vertices, self.boundelements, self.hash,
                              self.cellStart, self.cellEnd, self.n_local, self.n_int)
+            if self.world > 1:       # the vertex offsets of the halo segments (UPDATE_EXTERNAL of BUFFER_VERTPOS after BUILDNEIBS)
+                self._exchange(self.vertpos)
         else:
             K.build_neibs(self.neibslist, self.pos, self.info, self.hash, self.cellStart, self.cellEnd, self.n_local, self.n_int)
 
     def _sa_post_euler(self, step):
         """INTEGRATE_GAMMA on the new positions (always from the gamma of step n), then the boundary conditions of the new
-        state (PredictorCorrectorIntegrator.cc:661-684 and the post-step phases)"""
-        K, n = self.k, self.n_local
+        state (PredictorCorrectorIntegrator.cc:661-684 and the post-step phases); every pass covers the internal particles and is
+        followed by the UPDATE_EXTERNAL of what it wrote"""
+        K, n, ni = self.k, self.n_local, self.n_int
+        ext = (lambda ts: self._exchange(ts)) if self.world > 1 else (lambda ts: None)
         if self.sa_density_sum:
             # DENSITY_SUM [+ CALC_DENSITY_DIFFUSION + APPLY_DENSITY_DIFFUSION] (PredictorCorrectorIntegrator.cc:607-659): density and
             # gamma of the new state from the positions of step n and of the new state; BUFFER_FORCES is their scratch
             K.sa_density_sum(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.gradgamma, self.boundelements,
-                             self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, n)
+                             self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, ni)
+            ext([self.vel2, self.gradgamma2])
             if self.sp.densitydiffusiontype == D.BREZZI:
                 dt = float(self.d_dt.item()) * (0.5 if step == 1 else 1.0)     # dt_op on the host, as the reference's command has it
                 K.sa_density_diffusion(self.forces, self.pos2, self.vel2, self.gradgamma2, self.info, self.hash, self.cellStart,
-                                       self.neibslist, n, n, float(np.float32(dt)))
+                                       self.neibslist, n, ni, float(np.float32(dt)))
+                ext([self.vel2])
         else:
             K.sa_integrate_gamma(self.gradgamma2, self.gradgamma, self.pos2, self.boundelements, self.vertpos, self.info, self.hash,
-                                 self.cellStart, self.neibslist, n, n)
+                                 self.cellStart, self.neibslist, n, ni)
+            ext([self.gradgamma2])
         K.sa_segment_bc(self.vel2, self.gradgamma2, self.pos2, self.vertices, self.boundelements, self.info, self.hash, self.cellStart,
-                        self.neibslist, n, n, step, D.SIMULATE)
-        K.sa_vertex_bc(self.vel2, self.gradgamma2, self.pos2, self.info, self.hash, self.cellStart, self.neibslist, n, n, step, D.SIMULATE)
+                        self.neibslist, n, ni, step, D.SIMULATE)
+        ext([self.vel2, self.gradgamma2])
+        K.sa_vertex_bc(self.vel2, self.gradgamma2, self.pos2, self.info, self.hash, self.cellStart, self.neibslist, n, ni, step, D.SIMULATE)
+        ext([self.vel2])
 
     def sa_boundary_conditions(self, step, run_mode=D.SIMULATE):
         """initializeBoundaryConditionsSequence<SA_BOUNDARY> (src/integrators/PredictorCorrectorIntegrator.cc:117-290) without
         open boundaries: at initialisation (step 0) the vertex normals and gamma, then in every step the segment and the vertex
-        boundary conditions, in place on the current state."""
+        boundary conditions, in place on the current state; internal particles, then UPDATE_EXTERNAL."""
         if not self.sa:
             raise ValueError("boundary conditions sequence of a problem without SA_BOUNDARY")
-        K, n = self.k, self.n_local
+        K, n, ni = self.k, self.n_local, self.n_int
+        ext = (lambda ts: self._exchange(ts)) if self.world > 1 else (lambda ts: None)
         if step == 0:
-            K.sa_compute_vertex_normal(self.boundelements, self.vertices, self.info, self.hash, self.cellStart, self.neibslist, n, n)
+            K.sa_compute_vertex_normal(self.boundelements, self.vertices, self.info, self.hash, self.cellStart, self.neibslist, n, ni)
+            ext([self.boundelements])
             K.sa_init_gamma(self.gradgamma2, self.gradgamma, self.pos, self.boundelements, self.vertpos, self.info, self.hash,
-                            self.cellStart, self.neibslist, n, n)
+                            self.cellStart, self.neibslist, n, ni)
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
+            ext([self.gradgamma])
         K.sa_segment_bc(self.vel, self.gradgamma, self.pos, self.vertices, self.boundelements, self.info, self.hash, self.cellStart,
-                        self.neibslist, n, n, step, run_mode)
-        K.sa_vertex_bc(self.vel, self.gradgamma, self.pos, self.info, self.hash, self.cellStart, self.neibslist, n, n, step, run_mode)
+                        self.neibslist, n, ni, step, run_mode)
+        ext([self.vel, self.gradgamma])
+        K.sa_vertex_bc(self.vel, self.gradgamma, self.pos, self.info, self.hash, self.cellStart, self.neibslist, n, ni, step, run_mode)
+        ext([self.vel])
 
     def _update_segments_and_halo(self):
         """UPDATE_SEGMENTS + CROP + APPEND_EXTERNAL (src/Integrator.cc:170-230)"""
@@ -359,6 +371,8 @@ class MultiGpuEngine:
             state.append(self.vol)           # BUFFER_VOLUME is particle state: the halo copies integrate theirs from the exchanged forces
         if self.energy_on:
             state.append(self.energy)
+        if self.sa:      # BUFFER_VERTICES / BOUNDELEMENTS / GRADGAMMA are particle state too
+            state += [self.vertices, self.boundelements, self.gradgamma]
         self._exchange(state)
         # imported cells are OUTER_EDGE cells here whatever they are at home
         if self.n_local > n_int:
@@ -389,16 +403,14 @@ class MultiGpuEngine:
                         turbvisc=self.turbvisc)
             if self.world > 1:
                 self._exchange(self.tau)
+        # the forces entry of this option set, as a function of the particle range and the offset into the CFL array
         if self.sa:      # forces engine of SA_BOUNDARY: the state's gamma, the boundary elements, the vertex offsets of the segments
             ggam = self.gradgamma if pos is self.pos else self.gradgamma2
-            nb = K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
-                             self.boundelements, self.vertpos, self.n_local, 0, self.n_int, 0, cfl_gamma=self.cfl_gamma, run_mode=run_mode)
-            K.dtreduce(self.cfl, self.cfl_temp, nb, self.d_dt_next, combine_min)
-            if self.sa_dynamic_gamma and run_mode == D.SIMULATE:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
-                K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb, self.d_dt_next)
-            return
-        # the forces entry of this option set, as a function of the particle range and the offset into the CFL array
-        if self.effvisc_on and run_mode == D.SIMULATE:
+
+            def launch(frm, to, off):
+                return K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
+                                   self.boundelements, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma, run_mode=run_mode)
+        elif self.effvisc_on and run_mode == D.SIMULATE:
             # CALC_VISC on the state the forces read (internal particles, then UPDATE_EXTERNAL); its largest kinematic viscosity
             # is the viscous limit of this pass's dt on this device (the dt of the step is the minimum over the devices)
             K.calc_effvisc(self.effvisc, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, self.n_int)
@@ -462,6 +474,8 @@ class MultiGpuEngine:
             if self.world > 1:
                 self._exchange(outputs)
         K.dtreduce(self.cfl, self.cfl_temp, nb1 + nb2, self.d_dt_next, combine_min)
+        if self.sa and self.sa_dynamic_gamma and run_mode == D.SIMULATE:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
+            K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb1 + nb2, self.d_dt_next)
 
     def step(self):
         K = self.k

@@ -15,6 +15,7 @@ def _p(t):
 
 class OracleKernels:
     def __init__(self, problem, alloc):
+        self._problem = problem
         self.sp = problem.sphx_params(alloc)
         self.op = ol.orc_params_from(self.sp, problem)
         self.L = ol.lib()
@@ -160,3 +161,71 @@ class OracleKernels:
     def euler_internal_energy(self, new_energy, old_energy, dedt, old_pos, info, n, d_dt, dt_scale):
         dt = float(np.float32(d_dt[0].item()) * np.float32(dt_scale))
         self.L.orc_euler_energy(C.byref(self.op), _p(new_energy), _p(old_energy), _p(dedt), _p(old_pos), _p(info), C.c_uint32(n), C.c_float(dt))
+
+    # ---- SA_BOUNDARY (the interface of gpusph_amd.kernels.HipKernels' sa_* methods, in place on torch tensors)
+    def _sa_radii(self):
+        s = self._problem.simparams
+        f32 = np.float32
+        return float(np.power(f32(np.sqrt(f32(s.nlSqInfluenceRadius))) + f32(s.slength) / f32(s.sfactor) / f32(2.0), f32(2.0), dtype=np.float32))
+
+    def build_neibs_sa(self, neibslist, vertpos, pos, info, vertices, boundelements, hash_, cellStart, cellEnd, n, range_end):
+        self.L.orc_build_neibs_sa(C.byref(self.op), _p(neibslist), _p(vertpos[0]), _p(vertpos[1]), _p(vertpos[2]), _p(pos), _p(info),
+                                  _p(vertices), _p(boundelements), _p(hash_), _p(cellStart), _p(cellEnd), C.c_uint32(n), C.c_uint32(range_end),
+                                  C.c_float(self.sq), C.c_float(self._sa_radii()), C.byref(self.info_))
+
+    def sa_compute_vertex_normal(self, boundelements, vertices, info, hash_, cellStart, neibslist, n, range_end):
+        self.L.orc_sa_compute_vertex_normal(C.byref(self.op), _p(boundelements), _p(vertices), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
+                                            C.c_uint32(range_end))
+
+    def sa_init_gamma(self, new_ggam, old_ggam, pos, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end, epsilon=5e-5):
+        new_ggam[:n] = old_ggam[:n]
+        self.L.orc_sa_init_gamma(C.byref(self.op), _p(new_ggam), _p(pos), _p(boundelements), _p(vertpos[0]), _p(vertpos[1]), _p(vertpos[2]),
+                                 _p(info), _p(hash_), _p(cellStart), _p(neibslist), C.c_uint32(range_end), C.c_float(self.sp.deltap),
+                                 C.c_float(epsilon))
+
+    def sa_segment_bc(self, vel, ggam, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step, run_mode=1):
+        self.L.orc_sa_segment_bc(C.byref(self.op), _p(vel), _p(ggam), _p(pos), _p(vertices), _p(boundelements), _p(info), _p(hash_),
+                                 _p(cellStart), _p(neibslist), C.c_uint32(range_end), C.c_int(step), C.c_int(0 if run_mode == 1 else 1))
+
+    def sa_vertex_bc(self, vel, ggam, pos, info, hash_, cellStart, neibslist, n, range_end, step, run_mode=1):
+        self.L.orc_sa_vertex_bc(C.byref(self.op), _p(vel), _p(ggam), _p(pos), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
+                                C.c_uint32(range_end))
+
+    def forces_sa(self, forces, cfl, pos, vel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, n, frm, to, cfl_offset,
+                  cfl_gamma=None, run_mode=1):
+        assert run_mode == 1
+        if to > frm:
+            forces[frm:to] = 0
+        self.L.orc_forces_sa.restype = C.c_uint32
+        return int(self.L.orc_forces_sa(C.byref(self.op), _p(forces), _p(cfl), _p(cfl_gamma), _p(pos), _p(vel), _p(info), _p(hash_),
+                                        _p(cellStart), _p(neibslist), _p(ggam), _p(boundelements), _p(vertpos[0]), _p(vertpos[1]),
+                                        _p(vertpos[2]), C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
+                                        C.c_float(self.sp.deltap)))
+
+    def dtreduce_gamma(self, cfl_gamma, n, nblocks, d_dt):
+        base = ((n + 3) // 4) * 4
+        mx = float(cfl_gamma[base:base + nblocks].max()) if nblocks else 0.0
+        self.L.orc_sa_gamma_dt.restype = C.c_float
+        dt = float(d_dt[0])
+        d_dt[0] = min(dt, float(self.L.orc_sa_gamma_dt(C.c_float(dt), C.c_float(mx))))
+
+    def sa_density_sum(self, new_vel, new_ggam, forces, old_pos, new_pos, old_vel, old_ggam, boundelements, vertpos, info, hash_, cellStart,
+                       neibslist, n, range_end, dt=0.0, step=1):
+        new_ggam[:n] = old_ggam[:n]       # rows of the other particle types are copied (copyTypeDataDevice)
+        self.L.orc_sa_density_sum(C.byref(self.op), _p(new_vel), _p(new_ggam), _p(forces), _p(old_pos), _p(new_pos), _p(old_vel), _p(old_ggam),
+                                  _p(boundelements), _p(vertpos[0]), _p(vertpos[1]), _p(vertpos[2]), _p(info), _p(hash_), _p(cellStart),
+                                  _p(neibslist), C.c_uint32(range_end))
+
+    def sa_density_diffusion(self, forces, pos, vel, ggam, info, hash_, cellStart, neibslist, n, range_end, dt):
+        self.L.orc_sa_density_diffusion(C.byref(self.op), _p(forces), _p(pos), _p(vel), _p(ggam), _p(info), _p(hash_), _p(cellStart),
+                                        _p(neibslist), C.c_uint32(range_end), C.c_float(dt))
+        fluid = (info[:range_end, 0].to(torch.int32) & 7) == 0
+        rows = torch.nonzero(fluid).flatten()
+        vel[rows, 3] = vel[rows, 3] + forces[rows, 3] * np.float32(dt)
+
+    def sa_integrate_gamma(self, new_ggam, old_ggam, new_pos, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end,
+                           epsilon=5e-5):
+        new_ggam[:n] = old_ggam[:n]
+        self.L.orc_sa_integrate_gamma_quadrature(C.byref(self.op), _p(new_ggam), _p(old_ggam), _p(new_pos), _p(boundelements), _p(vertpos[0]),
+                                                 _p(vertpos[1]), _p(vertpos[2]), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
+                                                 C.c_uint32(range_end), C.c_int(0), C.c_float(epsilon))

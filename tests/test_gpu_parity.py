@@ -447,7 +447,18 @@ _MG_CASES = {
     "internal-energy": (dict(obstacle=False, internal_energy=True), ()),
     "sph-ha": (dict(obstacle=False, two_fluids=True, formulation=D.SPH_HA, density_diffusion=D.COLAGROSSI,
                     viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.DYNAMIC, avgop=D.HARMONIC)), ()),
+    # SA walls, density summation + dynamic gamma + Brezzi: every SA pass on the internal particles, then the halo import
+    "sa-walls": (dict(problem="SABox", deltap=0.04, options="StillWaterSA", jitter=0.1), ()),
 }
+
+
+def _mg_problem(kw):
+    kw = dict(kw)
+    if kw.pop("problem", None) == "SABox":
+        from gpusph_amd.problem import SABox
+        return SABox(**kw)
+    return DamBreak3D(**{**dict(deltap=0.03, obstacle=True, jitter=0.05, linearization="xzy"), **kw})
+
 
 
 def _mg_worker(rank, world, port, outdir, casename):
@@ -458,7 +469,7 @@ def _mg_worker(rank, world, port, outdir, casename):
     from gpusph_amd.multigpu import MultiGpuEngine
     dist.init_process_group("gloo", rank=rank, world_size=world)      # one GPU on this box: RCCL needs one per rank
     kw, filters = _MG_CASES[casename]
-    prob = DamBreak3D(**{**dict(deltap=0.03, obstacle=True, jitter=0.05, linearization="xzy"), **kw})
+    prob = _mg_problem(kw)
     eng = MultiGpuEngine(prob, "cuda:0", rank, world)
     for f in filters:
         eng.add_filter(*f)
@@ -480,7 +491,7 @@ def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_mg_worker, args=(2, port, str(tmp_path), casename), nprocs=2, join=True)
     kw, filters = _MG_CASES[casename]
-    prob = DamBreak3D(**{**dict(deltap=0.03, obstacle=True, jitter=0.05, linearization="xzy"), **kw})
+    prob = _mg_problem(kw)
     ref = _engine(prob)
     for f in filters:
         ref.add_filter(*f)

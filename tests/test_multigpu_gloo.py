@@ -41,6 +41,9 @@ def _worker(rank, world, port, steps, case, outdir, filters=()):
     elif which == "Poiseuille":
         from gpusph_amd.problem import Poiseuille
         prob = Poiseuille(**case)
+    elif which == "SABox":
+        from gpusph_amd.problem import SABox
+        prob = SABox(**case)
     else:
         prob = DamBreak3D(**case)
     if gate:
@@ -222,6 +225,10 @@ FIDELITY_CASES = {
     "ha": dict(deltap=0.05, obstacle=False, two_fluids=True, formulation=4, density_diffusion=2, jitter=0.1,
                viscosity=dict(rheologytype=1, turbmodel=0, compvisc=1, avgop=1)),
     "monaghan": dict(problem="Poiseuille", ppH=10, viscmodel=1, linearization="xyz"),
+    # SA_BOUNDARY in both built forms: vertices / boundary elements / gamma travel with the halo, every boundary-condition and
+    # density / gamma pass is followed by the import of what it wrote, the vertex offsets of the halo segments after the list build
+    "sa-density-sum": dict(problem="SABox", deltap=0.05, options="StillWaterSA", jitter=0.1),
+    "sa-quadrature": dict(problem="SABox", deltap=0.05, options="StillWaterRepackSA", jitter=0.1),
 }
 
 
