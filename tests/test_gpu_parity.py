@@ -1082,3 +1082,52 @@ def test_repack_needs_the_framework_flag():
         eng._forces(eng.pos, eng.vel, 1, 0, D.REPACK)
     with pytest.raises(ValueError, match="not enabled"):
         eng.repack()
+
+
+def _fidelity_case(name):
+    from gpusph_amd.problem import Poiseuille
+    dp = DamBreak3D.deltap_for(1.0e6, obstacle=False)
+    newt = dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.DYNAMIC, avgop=D.HARMONIC)
+    if name == "grenier_1M":
+        return DamBreak3D(dp, obstacle=False, two_fluids=True, formulation=D.SPH_GRENIER, viscosity="DYNAMICVISC",
+                          density_diffusion=D.DENSITY_DIFFUSION_NONE)
+    if name == "sph_ha_1M":
+        return DamBreak3D(dp, obstacle=False, two_fluids=True, formulation=D.SPH_HA, viscosity=newt, density_diffusion=D.COLAGROSSI)
+    if name == "internal_energy_1M":
+        return DamBreak3D(dp, obstacle=False, internal_energy=True)
+    if name == "papanastasiou_1M":
+        return Poiseuille(100, rheology=D.PAPANASTASIOU)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name", ["grenier_1M", "sph_ha_1M", "internal_energy_1M", "papanastasiou_1M"])
+def test_fidelity_option_sets_at_one_million_particles(name):
+    """the option sets of the fidelity engines at a million particles against the OpenMP oracle: three steps of the whole
+    sequence (COMPUTE_DENSITY / CALC_VISC, forces, dt, Euler incl. volumes / energies) from a perturbed state"""
+    import os
+    import torch
+    ol.lib().orc_set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    prob = _fidelity_case(name)
+    assert prob.num_particles > 0.9e6
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()
+    n = eng.n
+    assert n == sim.n and np.array_equal(_np(eng.neibslist, np.uint16).reshape(-1, eng.alloc)[:, :n], sim.nl.reshape(-1, len(sim.pos))[:, :n])
+    rng = np.random.default_rng(13)
+    fluid = (sim.info[:n, 0] & 7) == 0
+    sim.vel[:n, :3][fluid] += rng.uniform(-0.1, 0.1, size=(int(fluid.sum()), 3)).astype(np.float32)
+    eng.vel[:n] = torch.from_numpy(sim.vel[:n]).to(eng.device)
+    for _ in range(3):
+        sim.step(); eng.step()
+    out = eng.download()
+    assert abs(eng.current_dt() - sim.dt) <= 1e-4 * sim.dt
+    assert np.array_equal(out["info"], sim.info[:n])
+    assert np.abs(out["pos"][:, :3] - sim.pos[:n, :3]).max() <= 3e-6 * prob.m_cellsize.min()
+    vscale = max(np.abs(sim.vel[:n, :3]).max(), 1e-3)
+    assert np.abs(out["vel"][:, :3] - sim.vel[:n, :3]).max() <= 1e-4 * vscale
+    if name == "grenier_1M":
+        np.testing.assert_allclose(out["vol"][:, 3], sim.vol[:n, 3], rtol=1e-5)
+    if name == "internal_energy_1M":
+        es = np.abs(sim.energy[:n]).max()
+        assert es > 0 and np.abs(out["energy"] - sim.energy[:n]).max() <= 1e-3 * es
