@@ -69,6 +69,11 @@ SIGNATURES = {
     "sphx_sa_init_gamma": (_i, [_vp] + [_vp] * 11 + [_f, _f, _f, _f, _u32, _u32, _vp]),
     "sphx_sa_segment_bc": (_i, [_vp] + [_vp] * 9 + [_u32, _u32, _f, _f, _f, _i, _i, _vp]),
     "sphx_sa_vertex_bc": (_i, [_vp] + [_vp] * 7 + [_u32, _u32, _f, _f, _f, _i, _i, _vp]),
+    "sphx_sa_segment_bc_keps": (_i, [_vp] + [_vp] * 12 + [_u32, _u32, _f, _f, _f, _i, _i, _vp]),
+    "sphx_sa_vertex_bc_keps": (_i, [_vp] + [_vp] * 12 + [_u32, _u32, _f, _f, _f, _i, _i, _vp]),
+    "sphx_forces_basicstep_sa_keps": (_i, [_vp] + [_vp] * 20 + [_u32, _u32, _u32, _f, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
+    "sphx_euler_keps": (_i, [_vp] + [_vp] * 11 + [_u32, _u32, _f, _vp, _f, _vp]),
+    "sphx_forces_dtreduce_keps_device": (_i, [_vp, _vp, _u32, _f, _f, _vp, _vp]),
     "sphx_neibs_resetinfo": (_i, [_vp, _vp]),
     "sphx_neibs_getinfo": (_i, [_vp, C.POINTER(NeibsInfo), _vp]),
     "sphx_forces_fmax_elements": (_u32, [_u32]),

@@ -131,7 +131,7 @@ __device__ __forceinline__ float sa_visc_avg(const DevParams &p, float visc, flo
 	if (p.is_const_visc) return visc*sa_visc_avg_rho(p.avgop, rho, neib_rho, neib_mass);
 	// non-constant kinematic: the dynamic variant, whose constness is re-derived as IS_SINGLEFLUID && NEWTONIAN
 	// (src/cuda/visc_avg.cu:170-190, src/visc_spec.h:268-272)
-	return sa_visc_avg_dyn(p.avgop, !(p.simflags & SPHX_ENABLE_MULTIFLUID) && p.rheology == SPHX_NEWTONIAN,
+	return sa_visc_avg_dyn(p.avgop, !(p.simflags & SPHX_ENABLE_MULTIFLUID) && p.rheology == SPHX_NEWTONIAN && p.turbmodel != SPHX_KEPSILON,
 		visc*rho, neib_visc*neib_rho, rho, neib_rho, neib_mass);
 }
 

@@ -20,6 +20,10 @@ struct SaArgs {
 	const neibdata *neibsList;
 	uint32_t numParticles;
 	int step, repack;
+	// KEPSILON (sa_segment_bc_params / sa_vertex_bc_params with has_keps, src/cuda/sa_bc_params.h:152-200,275-320): in place
+	float *tke, *eps;
+	float4 *eulerVel;
+	float deltap;
 };
 
 __device__ __forceinline__ bool has_vertex(const uint4 &v, uint32_t id) { return v.x == id || v.y == id || v.z == id; }
@@ -64,7 +68,7 @@ sa_vertex_normal_kernel(DevParams p, SaArgs a)
 	a.boundElement[index] = make_float4(ax*inv, ay*inv, az*inv, NAN);
 }
 
-template<int KERNEL>
+template<int KERNEL, bool KEPS>
 __global__ void __launch_bounds__(128)
 sa_segment_bc_kernel(DevParams p, SaArgs a)
 {
@@ -85,10 +89,16 @@ sa_segment_bc_kernel(DevParams p, SaArgs a)
 	const bool calcGam = has_moving || !is_active_w(gGam.w) || a.step == 0;       // !isfinite
 	if (calcGam) gGam.w = 0.0f;
 	const bool moving = has_moving && !a.repack && (info.x & FG_MOVING_BOUNDARY);
+	float sumtke = 0.0f, sumeps = 0.0f;                                   // common_keps_pout (:509-520)
+	float4 eulerVel = make_float4(0.0f, 0.0f, 0.0f, 0.0f);                // eulervel_pout (:470-484)
 
 	for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float, float, float) {
 		if (!is_active_w(npos.w)) return;
 		if (!has_vertex(verts, info_id(a.info[j]))) return;
+		if (KEPS) {                       // keps_vertex_contrib (:748-758)
+			const float4 e = a.eulerVel[j];
+			eulerVel.x += e.x; eulerVel.y += e.y; eulerVel.z += e.z; eulerVel.w += e.w;
+		}
 		if (moving) {                     // moving_vertex_contrib (:781-793)
 			const float4 nv = a.vel[j];
 			vel.x += nv.x; vel.y += nv.y; vel.z += nv.z;
@@ -113,15 +123,30 @@ sa_segment_bc_kernel(DevParams p, SaArgs a)
 		if (!(n.r < p.influenceradius && (normal.x*rx + normal.y*ry + normal.z*rz) < 0.0f)) return;
 		const float gdot = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
 		sumpWall += fmaxf(n.press + ((n.vel.w + 1.0f)*p.rho0[fl])*gdot, 0.0f)*n.w;
+		if (KEPS) {      // keps_fluid_contrib (:816-826): dk/dn = 0, de/dn = 4 c_mu^(3/4) k^(3/2)/(kappa r) (de_dn_solid :806-813)
+			const float norm_dist = fmaxf(fabsf(normal.x*rx + normal.y*ry + normal.z*rz), a.deltap);
+			const float nk = a.tke[j], ne = a.eps[j];
+			sumtke += n.w*nk;
+			sumeps += n.w*(ne + 1.603090412f*powf(nk, 1.5f)/norm_dist);
+		}
 		shepard_div += n.w;
 	});
 	// impose_solid_bc (:1295-1306)
 	shepard_div = fmaxf(shepard_div, 0.1f*gGam.w);
 	vel.w = eos_rho(p, sumpWall/shepard_div, fl);
 	a.vel[index] = vel;
+	if (KEPS) {          // impose_solid_keps_bc (:1262-1277); the normal is the float4 boundary element: its .w rides along
+		a.tke[index] = sumtke/shepard_div;
+		a.eps[index] = fmaxf(sumeps/shepard_div, 1e-5f);
+		const float inv = 1.0f/3;
+		eulerVel.x *= inv; eulerVel.y *= inv; eulerVel.z *= inv; eulerVel.w *= inv;
+		const float d = eulerVel.x*normal.x + eulerVel.y*normal.y + eulerVel.z*normal.z;
+		eulerVel.x -= d*normal.x; eulerVel.y -= d*normal.y; eulerVel.z -= d*normal.z; eulerVel.w -= d*normal.w;
+		a.eulerVel[index] = eulerVel;
+	}
 }
 
-template<int KERNEL>
+template<int KERNEL, bool KEPS>
 __global__ void __launch_bounds__(128)
 sa_vertex_bc_kernel(DevParams p, SaArgs a)
 {
@@ -143,8 +168,27 @@ sa_vertex_bc_kernel(DevParams p, SaArgs a)
 			shepard_div += n.w;
 		}
 	});
+	// vertex_boundary_loop (:1002-1021) with KEPSILON: k and epsilon of a vertex are the means over its adjacent segments
+	// (keps_boundary_contrib :918-927, impose_vertex_keps_bc :1052-1072); its Eulerian velocity is made tangential to the wall
+	float sumtke = 0.0f, sumeps = 0.0f; int numseg = 0;
+	if (KEPS) {
+		const uint32_t our_id = info_id(info);
+		for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
+			if (!has_vertex(a.vertices[j], our_id)) return;
+			sumtke += a.tke[j]; sumeps += a.eps[j]; numseg += 1;
+		});
+	}
 	shepard_div = fmaxf(shepard_div, 0.1f*gam);
 	a.vel[index].w = eos_rho(p, sumpWall/shepard_div, fl);
+	if (KEPS) {
+		a.tke[index] = fmaxf(sumtke/numseg, 1e-6f);
+		a.eps[index] = fmaxf(sumeps/numseg, 1e-6f);
+		const float4 nrm = a.boundElement[index];
+		float4 e = a.eulerVel[index];
+		const float d = e.x*nrm.x + e.y*nrm.y + e.z*nrm.z;
+		e.x -= d*nrm.x; e.y -= d*nrm.y; e.z -= d*nrm.z;
+		a.eulerVel[index] = e;
+	}
 }
 
 // ---- gamma and its gradient at initialisation: src/cuda/gamma.cuh (Wendland), initGammaDevice (_kernel.cu:1891-1970) ----
@@ -390,16 +434,28 @@ struct SaForcesArgs {
 	const neibdata *neibsList;
 	uint32_t fromParticle, toParticle, cflOffset;
 	float deltap;
+	// KEPSILON (keps_forces_params, src/cuda/forces_params.h:283-320)
+	const float *tke, *eps, *turbvisc;
+	const float4 *eulerVel;
+	float *dkde;          // BUFFER_DKDE: 3 floats per particle (diffusion term of k, of epsilon, Yap's C_e2)
+	float *cflKeps;       // BUFFER_CFL_KEPS: one per block
+	float epsilon;
 };
 
 // sa_dot3, sa_P, sa_sound_speed, sa_visc_avg: neib_iter.h (shared with the other fidelity engines)
 
+// KEPS: the k-epsilon model on top (solid walls).  The reference runs forcesDevice once per neighbour type and every launch
+// starts from a fresh keps_particle_output and stores it (forces_particle_output :1003-1013, write_keps :3331-3339), so the DKDE /
+// TAU rows the finalize kernel reads hold the sums of the LAST launch over the particle: fluid <- boundary for a fluid particle,
+// a cleared row for a vertex (forcesDevice<PT_VERTEX, PT_FLUID>, whose viscous term never reaches the force, :3750-3783).  This
+// kernel therefore accumulates the k-epsilon sums over the boundary elements only; the CPU oracle restates the launches one by one.
+template<bool KEPS>
 __global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
 sa_forces_kernel(DevParams p, SaForcesArgs a)
 {
-	__shared__ float sMax[SPHX_BLOCK_FORCES/64], sMaxG[SPHX_BLOCK_FORCES/64];
+	__shared__ float sMax[SPHX_BLOCK_FORCES/64], sMaxG[SPHX_BLOCK_FORCES/64], sMaxK[SPHX_BLOCK_FORCES/64];
 	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
-	float cflTerm = 0.0f, gammaCfl = 0.0f;
+	float cflTerm = 0.0f, gammaCfl = 0.0f, kepsCfl = 0.0f;
 	if (index < a.toParticle) {
 		const particleinfo info = a.info[index];
 		const float4 pos = a.pos[index];
@@ -408,10 +464,15 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 			float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			const float4 vel = a.vel[index];
 			const uint32_t fl = FLUID_NUM(info);
+			float diff_k_out = 0.0f, diff_e_out = 0.0f, ce2yap_out = 1.92f;
 			if (fluid) {
 				const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 				const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
-				const float p_precalc = sa_P(p, vel.w, fl)/(p_rho*p_rho);
+				// keps_particle_data :633-655, eulerVel_particle_data :553-561; pressure_for_precalc :389-401: P + 2/3 k/rho
+				const float p_k = KEPS ? a.tke[index] : 0.0f, p_e = KEPS ? a.eps[index] : 0.0f, p_turb = KEPS ? a.turbvisc[index] : 0.0f;
+				const float4 p_euler = KEPS ? a.eulerVel[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				const float p_precalc = KEPS ? (sa_P(p, vel.w, fl) + 2.0f*p_k/p_rho/3.0f)/(p_rho*p_rho) : sa_P(p, vel.w, fl)/(p_rho*p_rho);
+				float diff_k = 0.0f, diff_e = 0.0f, ce2yap = 1.92f, txx = 0.0f, txy = 0.0f, txz = 0.0f, tyy = 0.0f, tyz = 0.0f, tzz = 0.0f;
 				const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
 				const bool newtonian = p.rheology == SPHX_NEWTONIAN;
 				// fluid <- fluid and fluid <- vertex: compute_all_pp_interaction with the general specialisations
@@ -426,12 +487,21 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 					const float f = qm2*qm2*qm2*p.fcoeff;
 					const uint32_t nfl = FLUID_NUM(a.info[j]);
 					const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
-					const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
+					const float n_precalc = KEPS ? (sa_P(p, nvel.w, nfl) + 2.0f*a.tke[j]/n_rho/3.0f)/(n_rho*n_rho) : sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
 					const float nmass = npos.w;
 					if (!density_sum) force.w += nmass*vel_dot_pos*f;
 					const float s = (p_precalc + n_precalc)*nmass*f;
 					float dx = 0.0f, dy = 0.0f, dz = 0.0f;
 					dx -= s*rx; dy -= s*ry; dz -= s*rz;
+					if (KEPS && newtonian) {
+						// get_visc_coeff :262-270: laminar coefficient + eddy viscosity (fluid particles only: turbViscForViscTerm :645-655),
+						// MORRIS along relVel + relEulerVel (get_viscous_relVel :2494-2507)
+						const float4 ne = a.eulerVel[j];
+						const float wx = vx + (p_euler.x - ne.x), wy = vy + (p_euler.y - ne.y), wz = vz + (p_euler.z - ne.z);
+						const float n_tvv = PART_TYPE(a.info[j]) == PT_FLUID ? a.turbvisc[j] : 0.0f;
+						const float vf = sa_visc_avg(p, p.visccoeff[fl] + p_turb, p.visccoeff[nfl] + n_tvv, p_rho, n_rho, nmass)*f;
+						dx += vf*wx; dy += vf*wy; dz += vf*wz;
+					} else
 					if (newtonian) {
 						const float vf = sa_visc_avg(p, p.visccoeff[fl], p.visccoeff[nfl], p_rho, n_rho, nmass)*f;
 						dx += vf*vx; dy += vf*vy; dz += vf*vz;
@@ -467,9 +537,47 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 						DrDt -= p_rho*vn*ggamAS;
 						force.w += DrDt;
 					}
-					const float ps = (p_precalc + n_precalc)*n_rho*ggamAS;
+					const float n_precalc_k = KEPS ? (sa_P(p, nvel.w, nfl) + 2.0f*a.tke[j]/n_rho/3.0f)/(n_rho*n_rho) : n_precalc;
+					const float ps = (p_precalc + n_precalc_k)*n_rho*ggamAS;
 					float dx = 0.0f, dy = 0.0f, dz = 0.0f;
 					dx += ps*be.x; dy += ps*be.y; dz += ps*be.z;
+					if (KEPS) {
+						const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
+						const float our_visc = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl] : p.visccoeff[fl]/p_rho;
+						const float neib_visc = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl] : p.visccoeff[nfl]/n_rho;
+						// compute_turb_visc_contrib, boundary term :2824-2878: wall shear stress from the law of the wall
+						if (!(p_k < a.epsilon)) {
+							const float ux = vx + p_euler.x, uy = vy + p_euler.y, uz = vz + p_euler.z;
+							const float un = sa_dot3(ux, uy, uz, be.x, be.y, be.z);
+							const float tx = ux - un*be.x, ty = uy - un*be.y, tz = uz - un*be.z;
+							const float abs_u_t = sqrtf(sa_dot3(tx, ty, tz, tx, ty, tz));
+							float u_star = 0.0f;
+							const float uk = 0.547722558f*sqrtf(p_k);
+							float y_plus = r_as/our_visc*uk;
+							if (y_plus < 2.43902439f)
+								u_star = abs_u_t/y_plus;
+							else {
+								float utau = 0.118599857f*neib_visc/r_as;
+								for (int i = 0; i < 10; i++) {
+									y_plus = fmaxf(r_as*utau/neib_visc, 2.43902439f);
+									utau = (0.41f*abs_u_t + utau)/(logf(y_plus) + 3.132f);
+								}
+								u_star = abs_u_t/(logf(y_plus)/0.41f + 5.2f);
+							}
+							const float sc = 2.0f*ggamAS*u_star*u_star, inv = 1.0f/fmaxf(abs_u_t, 1e-6f);
+							dx -= (sc*tx)*inv; dy -= (sc*ty)*inv; dz -= (sc*tz)*inv;
+						}
+						// compute_keps_term, boundary term :2949-2980
+						const float lyap = 0.400772603f*powf(p_k, 1.5f)/(p_e*r_as);
+						if (lyap > 1.0f)
+							ce2yap = fminf(ce2yap, fmaxf(1.92f - 0.83f*(lyap - 1.0f)*lyap*lyap, 0.0f));
+						diff_e += 0.276923077f*p_k*p_k/r_as*ggamAS;
+						const float4 ne = a.eulerVel[j];
+						const float wx = vx + (p_euler.x - ne.x), wy = vy + (p_euler.y - ne.y), wz = vz + (p_euler.z - ne.z);
+						const float mx = (ggamAS*be.x)*n_rho, my = (ggamAS*be.y)*n_rho, mz = (ggamAS*be.z)*n_rho;
+						txx += wx*mx; txy += wx*my + wy*mx; txz += wx*mz + wz*mx;      // add_strain_rate :924-937
+						tyy += wy*my; tyz += wy*mz + wz*my; tzz += wz*mz;
+					} else
 					if (newtonian) {
 						const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
 						const float tx = vx - vn*be.x, ty = vy - vn*be.y, tz = vz - vn*be.z;
@@ -487,6 +595,19 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 				const float gam = a.gGam[index].w;
 				force.x /= gam; force.y /= gam; force.z /= gam; force.w /= gam;
 				force.w /= p.rho0[fl];
+				if (KEPS) {
+					// viscous_fixup with KEPSILON + SA_BOUNDARY :3123-3170
+					const float rhoGam = p_rho*gam;
+					diff_k /= rhoGam; diff_e /= rhoGam;
+					float SijSij_bytwo = 2.0f*(txx*txx + tyy*tyy + tzz*tzz) + txy*txy + txz*txz + tyz*tyz;
+					const float S = sqrtf(SijSij_bytwo)/rhoGam;
+					SijSij_bytwo /= rhoGam*rhoGam;
+					const float Pturb = fminf(p_turb*SijSij_bytwo, 0.3f*p_k*S);
+					diff_k += Pturb;
+					diff_e += p_e*1.44f*Pturb/p_k;
+					kepsCfl = p_turb;             // dyndt_keps_shared_data :3481-3501
+					diff_k_out = diff_k; diff_e_out = diff_e; ce2yap_out = ce2yap;
+				}
 				force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
 				if (p.simflags & SPHX_ENABLE_DTADAPT) {
 					const float sspeed = sa_sound_speed(p, vel.w, fl);
@@ -495,6 +616,11 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 				}
 			}
 			a.forces[index] = force;
+			if (KEPS && (fluid || PART_TYPE(info) == PT_VERTEX)) {      // write_keps :3331-3339 (a fresh output for the vertices)
+				float *d = a.dkde + 3*(size_t)index;
+				if (fluid) { d[0] = diff_k_out; d[1] = diff_e_out; d[2] = ce2yap_out; }
+				else { d[0] = 0.0f; d[1] = 0.0f; d[2] = 1.92f; }
+			}
 		}
 		if (a.cflGamma) a.cflGamma[index] = gammaCfl;
 	}
@@ -503,14 +629,16 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 	for (int d = 32; d > 0; d >>= 1) {
 		cflTerm = fmaxf(cflTerm, __shfl_down(cflTerm, d));
 		gammaCfl = fmaxf(gammaCfl, __shfl_down(gammaCfl, d));
+		if (KEPS) kepsCfl = fmaxf(kepsCfl, __shfl_down(kepsCfl, d));
 	}
-	if ((threadIdx.x & 63u) == 0u) { sMax[threadIdx.x >> 6] = cflTerm; sMaxG[threadIdx.x >> 6] = gammaCfl; }
+	if ((threadIdx.x & 63u) == 0u) { sMax[threadIdx.x >> 6] = cflTerm; sMaxG[threadIdx.x >> 6] = gammaCfl; sMaxK[threadIdx.x >> 6] = kepsCfl; }
 	__syncthreads();
 	if (threadIdx.x == 0 && a.cfl && (p.simflags & SPHX_ENABLE_DTADAPT)) {
-		float m = sMax[0], mg = sMaxG[0];
-		for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) { m = fmaxf(m, sMax[w]); mg = fmaxf(mg, sMaxG[w]); }
+		float m = sMax[0], mg = sMaxG[0], mk = sMaxK[0];
+		for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) { m = fmaxf(m, sMax[w]); mg = fmaxf(mg, sMaxG[w]); mk = fmaxf(mk, sMaxK[w]); }
 		a.cfl[a.cflOffset + blockIdx.x] = m;
 		if (a.cflGammaBlocks) a.cflGammaBlocks[a.cflOffset + blockIdx.x] = mg;
+		if (KEPS && a.cflKeps) a.cflKeps[a.cflOffset + blockIdx.x] = mk;
 	}
 }
 
@@ -802,12 +930,13 @@ extern "C" int sphx_sa_compute_vertex_normal(sphx_ctx *ctx, void *boundElements,
 	return SPHX_OK;
 }
 
-extern "C" int sphx_sa_segment_bc(sphx_ctx *ctx, void *vel, void *gGam, const void *pos, const void *vertices,
+static int sa_segment_bc_impl(sphx_ctx *ctx, void *vel, void *gGam, float *tke, float *eps, void *eulerVel,
+	const void *pos, const void *vertices,
 	const void *boundElements, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
 	int step, int run_mode, void *stream)
 {
-	(void)numParticles; (void)deltap;
+	(void)numParticles;
 	int rc = sa_check(ctx, "saSegmentBoundaryConditions called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	SPHX_REQUIRE(vel && gGam && pos && vertices && boundElements && info && hash && cellStart && neibsList,
@@ -822,12 +951,41 @@ extern "C" int sphx_sa_segment_bc(sphx_ctx *ctx, void *vel, void *gGam, const vo
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
 	a.step = (step == -1) ? 0 : step;         // "step -1 is the same as step 0", boundary_conditions.cu:177-180
 	a.repack = (run_mode == SPHX_REPACK);
-	sa_segment_bc_kernel<SPHX_WENDLAND><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	if (tke) {
+		a.tke = tke; a.eps = eps; a.eulerVel = (float4*)eulerVel; a.deltap = deltap;
+		sa_segment_bc_kernel<SPHX_WENDLAND, true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	} else
+		sa_segment_bc_kernel<SPHX_WENDLAND, false><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_segment_bc_kernel");
 	return SPHX_OK;
 }
 
-extern "C" int sphx_sa_vertex_bc(sphx_ctx *ctx, void *vel, const void *gGam, const void *pos, const void *info,
+extern "C" int sphx_sa_segment_bc(sphx_ctx *ctx, void *vel, void *gGam, const void *pos, const void *vertices,
+	const void *boundElements, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
+	int step, int run_mode, void *stream)
+{
+	if (ctx && ctx->params.turbmodel == SPHX_KEPSILON && run_mode == SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_segment_bc: KEPSILON evolves k, epsilon and the Eulerian velocity of the walls: call sphx_sa_segment_bc_keps");
+	return sa_segment_bc_impl(ctx, vel, gGam, nullptr, nullptr, nullptr, pos, vertices, boundElements, info, hash, cellStart, neibsList,
+		numParticles, particleRangeEnd, deltap, slength, influenceradius, step, run_mode, stream);
+}
+
+extern "C" int sphx_sa_segment_bc_keps(sphx_ctx *ctx, void *vel, void *gGam, float *tke, float *eps, void *eulerVel,
+	const void *pos, const void *vertices,
+	const void *boundElements, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
+	int step, int run_mode, void *stream)
+{
+	SPHX_REQUIRE(ctx && ctx->params.turbmodel == SPHX_KEPSILON, "sphx_sa_segment_bc_keps: the uploaded option set is not KEPSILON");
+	SPHX_REQUIRE(tke && eps && eulerVel, "sphx_sa_segment_bc_keps: missing buffer");
+	SPHX_REQUIRE(run_mode == SPHX_SIMULATE, "sphx_sa_segment_bc_keps: the repacking run mode has no k-epsilon (call sphx_sa_segment_bc)");
+	return sa_segment_bc_impl(ctx, vel, gGam, tke, eps, eulerVel, pos, vertices, boundElements, info, hash, cellStart, neibsList,
+		numParticles, particleRangeEnd, deltap, slength, influenceradius, step, run_mode, stream);
+}
+
+static int sa_vertex_bc_impl(sphx_ctx *ctx, void *vel, const void *gGam, float *tke, float *eps, void *eulerVel,
+	const void *vertices, const void *boundElements, const void *pos, const void *info,
 	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
 	int step, int run_mode, void *stream)
@@ -842,9 +1000,38 @@ extern "C" int sphx_sa_vertex_bc(sphx_ctx *ctx, void *vel, const void *gGam, con
 	SaArgs a = {};
 	a.vel = (float4*)vel; a.gGam = (float4*)const_cast<void*>(gGam); a.pos = (const float4*)pos; a.info = (const particleinfo*)info;
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
-	sa_vertex_bc_kernel<SPHX_WENDLAND><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	if (tke) {
+		a.tke = tke; a.eps = eps; a.eulerVel = (float4*)eulerVel;
+		a.vertices = (const uint4*)vertices; a.boundElement = (float4*)const_cast<void*>(boundElements);
+		sa_vertex_bc_kernel<SPHX_WENDLAND, true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	} else
+		sa_vertex_bc_kernel<SPHX_WENDLAND, false><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_vertex_bc_kernel");
 	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_vertex_bc(sphx_ctx *ctx, void *vel, const void *gGam, const void *pos, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
+	int step, int run_mode, void *stream)
+{
+	if (ctx && ctx->params.turbmodel == SPHX_KEPSILON && run_mode == SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_vertex_bc: KEPSILON evolves k and epsilon of the vertices: call sphx_sa_vertex_bc_keps");
+	return sa_vertex_bc_impl(ctx, vel, gGam, nullptr, nullptr, nullptr, nullptr, nullptr, pos, info, hash, cellStart, neibsList,
+		numParticles, particleRangeEnd, deltap, slength, influenceradius, step, run_mode, stream);
+}
+
+extern "C" int sphx_sa_vertex_bc_keps(sphx_ctx *ctx, void *vel, const void *gGam, float *tke, float *eps, void *eulerVel,
+	const void *vertices, const void *boundElements, const void *pos, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
+	int step, int run_mode, void *stream)
+{
+	SPHX_REQUIRE(ctx && ctx->params.turbmodel == SPHX_KEPSILON, "sphx_sa_vertex_bc_keps: the uploaded option set is not KEPSILON");
+	SPHX_REQUIRE(tke && eps && eulerVel && vertices && boundElements, "sphx_sa_vertex_bc_keps: missing buffer");
+	SPHX_REQUIRE(run_mode == SPHX_SIMULATE, "sphx_sa_vertex_bc_keps: the repacking run mode has no k-epsilon (call sphx_sa_vertex_bc)");
+	return sa_vertex_bc_impl(ctx, vel, gGam, tke, eps, eulerVel, vertices, boundElements, pos, info, hash, cellStart, neibsList,
+		numParticles, particleRangeEnd, deltap, slength, influenceradius, step, run_mode, stream);
 }
 
 extern "C" int sphx_sa_init_gamma(sphx_ctx *ctx, void *newGGam, const void *oldGGam, const void *pos, const void *boundElements,
@@ -891,12 +1078,16 @@ static int sa_forces_check(sphx_ctx *ctx, const char *who)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for SPH_F1");
 	if (!(q.densitydiffusiontype == SPHX_DENSITY_DIFFUSION_NONE || (dsum && q.densitydiffusiontype == SPHX_BREZZI)))
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: density diffusion with SA_BOUNDARY: Brezzi with density summation only");
-	if (q.turbmodel != SPHX_LAMINAR_FLOW && q.rheologytype != SPHX_INVISCID)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for laminar flow");
+	if (q.turbmodel != SPHX_LAMINAR_FLOW && q.turbmodel != SPHX_KEPSILON && q.rheologytype != SPHX_INVISCID)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for laminar flow and the k-epsilon model");
+	if (q.turbmodel == SPHX_KEPSILON && (q.rheologytype != SPHX_NEWTONIAN || q.viscmodel != SPHX_MORRIS))
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: KEPSILON is built for a Newtonian fluid with the MORRIS viscous model");
 	return SPHX_OK;
 }
 
-extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma,
+struct SaKepsBuffers { float *cflKeps, *dkde; const float *tke, *eps, *turbvisc; const void *eulerVel; float epsilon; };
+
+static int sa_forces_impl(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, const SaKepsBuffers *ke,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
@@ -941,8 +1132,127 @@ extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
 		a.cflGamma = cflGamma; a.cflGammaBlocks = cflGamma + (numParticles + 3u)/4u*4u;
 		if (numBlocks > blocks) SPHX_HIP(hipMemsetAsync(a.cflGammaBlocks + cflOffset + blocks, 0, sizeof(float)*(numBlocks - blocks), st));
 	}
-	sa_forces_kernel<<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
+	if (ke) {
+		a.tke = ke->tke; a.eps = ke->eps; a.turbvisc = ke->turbvisc; a.eulerVel = (const float4*)ke->eulerVel;
+		a.dkde = ke->dkde; a.cflKeps = ke->cflKeps; a.epsilon = ke->epsilon;
+		if (ke->cflKeps && numBlocks > blocks) SPHX_HIP(hipMemsetAsync(ke->cflKeps + cflOffset + blocks, 0, sizeof(float)*(numBlocks - blocks), st));
+		sa_forces_kernel<true><<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
+	} else
+		sa_forces_kernel<false><<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_forces_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius, uint32_t cflOffset,
+	int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream)
+{
+	if (ctx && ctx->params.turbmodel == SPHX_KEPSILON && run_mode == SPHX_SIMULATE)
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_forces_basicstep_sa: the KEPSILON forces read k, epsilon, the eddy viscosity and the Eulerian velocity: call sphx_forces_basicstep_sa_keps");
+	return sa_forces_impl(ctx, forces, cfl, cflGamma, nullptr, pos, vel, info, hash, cellStart, neibsList, gGam, boundElements,
+		vertPos0, vertPos1, vertPos2, numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor, influenceradius,
+		cflOffset, run_mode, step, dt, h_numBlocks, stream);
+}
+
+extern "C" int sphx_forces_basicstep_sa_keps(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, float *cflKeps, float *dkde,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
+	const float *tke, const float *eps, const float *turbvisc, const void *eulerVel,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius, float epsilon, uint32_t cflOffset,
+	int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream)
+{
+	SPHX_REQUIRE(ctx && ctx->params.turbmodel == SPHX_KEPSILON, "sphx_forces_basicstep_sa_keps: the uploaded option set is not KEPSILON");
+	SPHX_REQUIRE(run_mode == SPHX_SIMULATE, "sphx_forces_basicstep_sa_keps: the repacking run mode has no k-epsilon (call sphx_forces_basicstep_sa)");
+	SPHX_REQUIRE(dkde && tke && eps && turbvisc && eulerVel, "sphx_forces_basicstep_sa_keps: missing buffer");
+	SPHX_REQUIRE(!(ctx->params.simflags & SPHX_ENABLE_DTADAPT) || cflKeps, "sphx_forces_basicstep_sa_keps: ENABLE_DTADAPT needs BUFFER_CFL_KEPS");
+	const SaKepsBuffers ke = { cflKeps, dkde, tke, eps, turbvisc, eulerVel, epsilon };
+	return sa_forces_impl(ctx, forces, cfl, cflGamma, &ke, pos, vel, info, hash, cellStart, neibsList, gGam, boundElements,
+		vertPos0, vertPos1, vertPos2, numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor, influenceradius,
+		cflOffset, run_mode, step, dt, h_numBlocks, stream);
+}
+
+// ---- Euler step of the k-epsilon model (src/cuda/euler_kernel.def:219-231,262-274,325-337): semi-implicit k and epsilon of the
+// fluid particles, Eulerian velocity of the wall particles (+= dt force), eddy viscosity 0.9 k^2/epsilon of every particle (the
+// reference's constant).  A separate launch over the rows the Euler kernel integrates; same values as the fused kernel.
+struct KepsEulerArgs {
+	float *newTke, *newEps, *newTurbVisc; float4 *newEulerVel;
+	const float *oldTke, *oldEps, *dkde; const float4 *oldEulerVel, *forces, *oldPos;
+	const particleinfo *info;
+	const float *d_dt; float dt, dt_scale;
+	uint32_t numParticles;
+};
+
+__global__ void __launch_bounds__(256)
+keps_euler_kernel(KepsEulerArgs a)
+{
+	const uint32_t index = blockIdx.x*256 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	if (!is_active_w(a.oldPos[index].w)) return;
+	const float dt = a.d_dt ? a.d_dt[0]*a.dt_scale : a.dt;
+	const particleinfo info = a.info[index];
+	float k = a.oldTke[index], e = a.oldEps[index];
+	float4 ev = a.oldEulerVel[index];
+	if (PART_TYPE(info) == PT_FLUID) {
+		const float *d = a.dkde + 3*(size_t)index;
+		const float oldK = k;
+		k = (oldK + dt*d[0])/(1.0f + dt*e/oldK);
+		e = (e + dt*d[1])/(1.0f + dt*e/oldK*d[2]);
+	} else if (PART_TYPE(info) == PT_BOUNDARY || PART_TYPE(info) == PT_VERTEX) {
+		const float4 f = a.forces[index];
+		ev.x += dt*f.x; ev.y += dt*f.y; ev.z += dt*f.z; ev.w += dt*f.w;
+	}
+	a.newTke[index] = k; a.newEps[index] = e; a.newTurbVisc[index] = 0.9f*k*k/e;
+	a.newEulerVel[index] = ev;
+}
+
+extern "C" int sphx_euler_keps(sphx_ctx *ctx, float *newTke, float *newEps, float *newTurbVisc, void *newEulerVel,
+	const float *oldTke, const float *oldEps, const void *oldEulerVel, const float *dkde, const void *forces,
+	const void *oldPos, const void *info, uint32_t numParticles, uint32_t particleRangeEnd,
+	float dt, const float *d_dt, float dt_scale, void *stream)
+{
+	(void)numParticles;
+	SPHX_REQUIRE(ctx && ctx->params.turbmodel == SPHX_KEPSILON, "sphx_euler_keps: the uploaded option set is not KEPSILON");
+	SPHX_REQUIRE(newTke && newEps && newTurbVisc && newEulerVel && oldTke && oldEps && oldEulerVel && dkde && forces && oldPos && info,
+		"sphx_euler_keps: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	KepsEulerArgs a = { newTke, newEps, newTurbVisc, (float4*)newEulerVel, oldTke, oldEps, dkde, (const float4*)oldEulerVel,
+		(const float4*)forces, (const float4*)oldPos, (const particleinfo*)info, d_dt, dt, dt_scale, particleRangeEnd };
+	keps_euler_kernel<<<div_up_u(particleRangeEnd, 256), 256, 0, (hipStream_t)stream>>>(a);
+	SPHX_LAUNCH_CHECK("keps_euler_kernel");
+	return SPHX_OK;
+}
+
+// viscous part of dtreduce with KEPSILON (src/cuda/forces.cu:585-598): dt = min(dt, 0.125 h^2/(max_kinematic + max eddy viscosity))
+__global__ void __launch_bounds__(256)
+keps_dt_kernel(float *d_dt, const float *cflKeps, uint32_t numBlocks, float slength, float max_kinematic)
+{
+	__shared__ float sm[4];
+	float m = 0.0f;
+	for (uint32_t i = threadIdx.x; i < numBlocks; i += 256) m = fmaxf(m, cflKeps[i]);
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_down(m, d));
+	if ((threadIdx.x & 63u) == 0u) sm[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+		float dt_visc = slength*slength/(max_kinematic + m);
+		dt_visc *= 0.125f;
+		if (dt_visc < d_dt[0]) d_dt[0] = dt_visc;
+	}
+}
+
+extern "C" int sphx_forces_dtreduce_keps_device(sphx_ctx *ctx, const float *cflKeps, uint32_t numBlocks, float slength,
+	float max_kinematic, float *d_dt, void *stream)
+{
+	SPHX_REQUIRE(ctx && ctx->params.turbmodel == SPHX_KEPSILON, "sphx_forces_dtreduce_keps_device: the uploaded option set is not KEPSILON");
+	SPHX_REQUIRE(cflKeps && d_dt, "sphx_forces_dtreduce_keps_device: missing buffer");
+	if (!numBlocks) return SPHX_OK;
+	keps_dt_kernel<<<1, 256, 0, (hipStream_t)stream>>>(d_dt, cflKeps, numBlocks, slength, max_kinematic);
+	SPHX_LAUNCH_CHECK("keps_dt_kernel");
 	return SPHX_OK;
 }
 

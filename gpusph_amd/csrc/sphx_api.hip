@@ -255,6 +255,13 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 		SPHX_REQUIRE(sp->ewres > 0 && sp->nsres > 0 && sp->demdx == sp->demdx && sp->demdy == sp->demdy && sp->demzmin == sp->demzmin,
 			"sphx_set_constants: ENABLE_DEM needs ewres, nsres, demdx, demdy, demzmin (computeDEMphysparams)");
 	}
+	if (sp->turbmodel == SPHX_KEPSILON) {
+		// k-epsilon only with semi-analytical walls, as the reference (src/cuda/cudasimframework.cu:155)
+		if (sp->boundarytype != SPHX_SA_BOUNDARY)
+			return sphx_set_error(SPHX_ERR_INVALID, "sphx_set_constants: KEPSILON is only supported with SA_BOUNDARY");
+		if (sp->rheologytype != SPHX_NEWTONIAN || sp->viscmodel != SPHX_MORRIS || sp->is_const_visc)
+			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: KEPSILON is built for a Newtonian fluid, the MORRIS viscous model and non-constant viscosity (FullViscSpec default)");
+	} else
 	if (sp->turbmodel != SPHX_ARTIFICIAL && sp->turbmodel != SPHX_SPS && sp->turbmodel != SPHX_LAMINAR_FLOW)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx: turbulence model not built");
 

@@ -177,8 +177,22 @@ class TimestepEngine(MultiGpuEngine):
     # ------------------------------------------------------------------ checkpoints (GPUSPH HotFile v1)
     def _host_buffer_count(self):
         """size of GPUSPH's host buffer list for this option set, which HotFile::load compares with the header
-        (src/writers/HotFile.cc:143): POS_GLOBAL, POS, VEL, INFO, HASH, + SPS_TURBVISC with SPS (GPUSPH.cc host allocation)"""
-        return 5 + (1 if self.sps else 0)
+        (src/writers/HotFile.cc:143): POS_GLOBAL, POS, VEL, INFO, HASH, + BOUNDELEMENTS, VERTICES, GRADGAMMA with
+        SA_BOUNDARY, SPS_TURBVISC with SPS, EFFVISC with a generalized Newtonian rheology, VOLUME and SIGMA with
+        SPH_GRENIER, INTERNAL_ENERGY with its flag (GPUSPH::allocateGlobalHostBuffers, GPUSPH.cc:868-941)"""
+        return (5 + (3 if self.sa else 0) + (1 if self.sps else 0) + (1 if self.effvisc_on else 0)
+                + (2 if self.grenier else 0) + (1 if self.energy_on else 0))
+
+    def _hot_extra(self):
+        """the option-dependent particle property buffers a HotFile stores beside pos/vel/info/hash: name -> device tensor"""
+        ex = {}
+        if self.energy_on:
+            ex["energy"] = self.energy
+        if self.sa:
+            ex.update(boundelements=self.boundelements, gradgamma=self.gradgamma, vertices=self.vertices)
+        if self.grenier:
+            ex["vol"] = self.vol
+        return ex
 
     def save_hotfile(self, path):
         """HotFile::save of the current state (src/writers/HotFile.cc:86-118); readable by GPUSPH --resume and by
@@ -206,7 +220,10 @@ class TimestepEngine(MultiGpuEngine):
                                    crot=crot, lvel=lvel, avel=avel, orientation=[1, 0, 0, 0],
                                    initial_crot=icrot, initial_lvel=[0, 0, 0], initial_avel=[0, 0, 0],
                                    initial_orientation=[1, 0, 0, 0]))
-        hotfile.write_hotfile(path, dict(pos=st["pos"], vel=st["vel"], info=st["info"].reshape(-1, 4), hash=st["hash"]),
+        arrays = dict(pos=st["pos"], vel=st["vel"], info=st["info"].reshape(-1, 4), hash=st["hash"])
+        for k, t in self._hot_extra().items():
+            arrays[k] = t[:self.n].cpu().numpy()
+        hotfile.write_hotfile(path, arrays,
                               self.iterations, self.time(), self.current_dt(), bodies=bodies,
                               host_buffer_count=self._host_buffer_count())
 
@@ -228,6 +245,10 @@ class TimestepEngine(MultiGpuEngine):
         self.pos[:n] = torch.from_numpy(a["pos"]).to(dev); self.vel[:n] = torch.from_numpy(a["vel"]).to(dev)
         self.info[:n] = torch.from_numpy(a["info"].view(np.int16)).to(dev)
         self.hash[:n] = torch.from_numpy(a["hash"].view(np.int32)).to(dev)
+        for k, t in self._hot_extra().items():
+            if k not in a:
+                raise capi.SphxError("HotFile lacks the '%s' buffer this option set evolves" % k)
+            t[:n] = torch.from_numpy(a[k].view(np.int32) if k == "vertices" else a[k]).to(dev)
         self.iterations = int(hf["iterations"])
         self.dt = float(np.float32(hf["dt"]))
         self.d_dt.fill_(self.dt); self.d_dt_next.fill_(self.dt)

@@ -6,9 +6,12 @@ Layout (native little-endian, C struct padding), as scripts/hotdiff.py of the re
   per stored buffer: encoded_buffer_t '@I64sII' (name_length, name, element_size, array_count)    (HotFile.cc:40-45)
                      + element_size*particle_count bytes of the first array                      (:241-272)
   per body:          encoded_body_t    (:59-73)
-Stored buffers are the non-ephemeral host buffers in key order -- for the options built here: "Position"
-(float4, cell-local), "Velocity" (float4), "Info" (ushort4), "Hash" (uint) -- while header.buffer_count counts
-ALL host buffers (that includes the ephemeral "Position (double precision)": HotFile.cc:91-101 notes the mismatch).
+Stored buffers are the non-ephemeral host buffers (define_buffers.h:279-331: particle properties and support buffers)
+in key order -- "Position" (float4, cell-local), "Velocity" (float4), "Info" (ushort4), "Hash" (uint), then, with the
+options that allocate them (GPUSPH::allocateGlobalHostBuffers, GPUSPH.cc:868-941), "Internal Energy" (float),
+"Boundary Elements", "Gamma Gradient" (float4), "Vertices" (uint4) and "Volume" (float4) -- while
+header.buffer_count counts ALL host buffers (that includes the ephemeral "Position (double precision)", the SPS and
+effective viscosities and Grenier's sigma: HotFile.cc:91-101 notes the mismatch).
 
 This is a data format on either side of the hot path: a state saved by a GPUSPH CUDA run can be loaded into
 TimestepEngine (and vice versa), and two runs can be compared with the reference's own scripts/hotdiff.py.
@@ -22,18 +25,26 @@ BODY = "@IIIIii26d10f"      # index, id, type, numparts, firstindex, lastindex, 
 MB_FLOATING, MB_FORCES_MOVING, MB_MOVING = 0, 1, 2
 
 # name -> (dtype, components); order = buffer key order (src/define_buffers.h:48-58)
-STORED = [("Position", np.float32, 4), ("Velocity", np.float32, 4), ("Info", np.uint16, 4), ("Hash", np.uint32, 1)]
-KEYS = {"Position": "pos", "Velocity": "vel", "Info": "info", "Hash": "hash"}
+STORED = [("Position", np.float32, 4), ("Velocity", np.float32, 4), ("Info", np.uint16, 4), ("Hash", np.uint32, 1),
+          ("Internal Energy", np.float32, 1), ("Boundary Elements", np.float32, 4), ("Gamma Gradient", np.float32, 4),
+          ("Vertices", np.uint32, 4), ("Volume", np.float32, 4)]
+KEYS = {"Position": "pos", "Velocity": "vel", "Info": "info", "Hash": "hash", "Internal Energy": "energy",
+        "Boundary Elements": "boundelements", "Gamma Gradient": "gradgamma", "Vertices": "vertices", "Volume": "vol"}
+REQUIRED = ("pos", "vel", "info", "hash")
 
 
 def write_hotfile(path, arrays, iterations, t, dt, bodies=(), num_open_boundaries=0, host_buffer_count=5):
-    """arrays: dict pos/vel/info/hash (n rows); bodies: iterable of dicts (index, id, type, numparts, firstindex,
+    """arrays: dict pos/vel/info/hash (n rows) [+ energy, boundelements, gradgamma, vertices, vol]; bodies: iterable of dicts (index, id, type, numparts, firstindex,
     lastindex, crot, lvel, avel, orientation [+ initial_*])."""
     n = len(arrays["hash"])
     with open(path, "wb") as f:
         f.write(struct.pack(HEADER, 1, host_buffer_count, n, len(bodies), num_open_boundaries, int(iterations),
                             float(t), float(dt)))
         for name, dtype, comps in STORED:
+            if KEYS[name] not in arrays:
+                if KEYS[name] in REQUIRED:
+                    raise KeyError(KEYS[name])
+                continue
             a = np.ascontiguousarray(arrays[KEYS[name]]).view(dtype).reshape(n, comps)
             f.write(struct.pack(BUFFER, len(name), name.encode(), a.dtype.itemsize * comps, 1))
             f.write(a.tobytes())

@@ -142,6 +142,44 @@ class HipKernels:
                                                      run_mode, 1, 0.0, C.byref(nb), self._s()))
         return nb.value
 
+    # ---- turbulence<KEPSILON> (SA_BOUNDARY, solid walls): ke = dict(tke, eps, turbvisc, eulervel) of the state
+    def forces_sa_keps(self, forces, cfl, cfl_keps, dkde, pos, vel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, ke,
+                       n, frm, to, cfl_offset, cfl_gamma=None, epsilon=5e-5):
+        p = capi.ptr
+        P = self.params
+        nb = C.c_uint32(0)
+        capi.check(self.lib.sphx_forces_basicstep_sa_keps(
+            self.ctx.handle, p(forces), p(cfl), p(cfl_gamma), p(cfl_keps), p(dkde), p(pos), p(vel), p(info), p(hash_), p(cellStart),
+            p(neibslist), p(ggam), p(boundelements), p(vertpos[0]), p(vertpos[1]), p(vertpos[2]),
+            p(ke["tke"]), p(ke["eps"]), p(ke["turbvisc"]), p(ke["eulervel"]),
+            n, frm, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius, float(epsilon), cfl_offset,
+            D.SIMULATE, 1, 0.0, C.byref(nb), self._s()))
+        return nb.value
+
+    def sa_segment_bc_keps(self, vel, ggam, ke, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_sa_segment_bc_keps(self.ctx.handle, p(vel), p(ggam), p(ke["tke"]), p(ke["eps"]), p(ke["eulervel"]), p(pos),
+                                                    p(vertices), p(boundelements), p(info), p(hash_), p(cellStart), p(neibslist), n, range_end,
+                                                    P.deltap, P.slength, P.influenceradius, int(step), D.SIMULATE, self._s()))
+
+    def sa_vertex_bc_keps(self, vel, ggam, ke, vertices, boundelements, pos, info, hash_, cellStart, neibslist, n, range_end, step):
+        p = capi.ptr
+        P = self.params
+        capi.check(self.lib.sphx_sa_vertex_bc_keps(self.ctx.handle, p(vel), p(ggam), p(ke["tke"]), p(ke["eps"]), p(ke["eulervel"]),
+                                                   p(vertices), p(boundelements), p(pos), p(info), p(hash_), p(cellStart), p(neibslist),
+                                                   n, range_end, P.deltap, P.slength, P.influenceradius, int(step), D.SIMULATE, self._s()))
+
+    def euler_keps(self, new, old, dkde, forces, old_pos, info, n, d_dt, dt_scale):
+        p = capi.ptr
+        capi.check(self.lib.sphx_euler_keps(self.ctx.handle, p(new["tke"]), p(new["eps"]), p(new["turbvisc"]), p(new["eulervel"]),
+                                            p(old["tke"]), p(old["eps"]), p(old["eulervel"]), p(dkde), p(forces), p(old_pos), p(info),
+                                            n, n, 0.0, p(d_dt), dt_scale, self._s()))
+
+    def dtreduce_keps(self, cfl_keps, nblocks, d_dt):
+        capi.check(self.lib.sphx_forces_dtreduce_keps_device(self.ctx.handle, capi.ptr(cfl_keps), nblocks, self.params.slength,
+                                                             self.max_kinvisc, capi.ptr(d_dt), self._s()))
+
     def dtreduce_gamma(self, cfl_gamma, n, nblocks, d_dt):
         capi.check(self.lib.sphx_forces_dtreduce_gamma_device(self.ctx.handle, capi.ptr(cfl_gamma), n, nblocks, capi.ptr(d_dt), self._s()))
 

@@ -85,6 +85,7 @@ class MultiGpuEngine:
         self.sa = problem.simparams.boundarytype == D.SA_BOUNDARY
         self.grenier = problem.simparams.sph_formulation == D.SPH_GRENIER
         self.effvisc_on = problem.simparams.rheologytype > D.NEWTONIAN        # NEEDS_EFFECTIVE_VISC
+        self.keps = problem.simparams.turbmodel == D.KEPSILON
         self.problem = problem
         self.rank, self.world = rank, world
         self.device = torch.device(device)
@@ -173,6 +174,16 @@ class MultiGpuEngine:
             self.sa_dynamic_gamma = not (self.sp.simflags & D.ENABLE_GAMMA_QUADRATURE)
             self.sa_density_sum = bool(self.sp.simflags & D.ENABLE_DENSITY_SUM)
             self.cfl_gamma = (torch.zeros(A + 4 + self.cfl.numel(), dtype=f32, device=dev) if self.sa_dynamic_gamma else None)
+        # turbulence<KEPSILON>: BUFFER_TKE / EPSILON / TURBVISC / EULERVEL are particle properties (double buffered, re-sorted);
+        # ProblemCore::init_keps and init_turbvisc (src/ProblemCore.cc:1623-1659) give the uniform initial state; BUFFER_DKDE and
+        # BUFFER_CFL_KEPS are outputs of the forces passes
+        if self.keps:
+            k0, e0, nut0 = problem.init_keps()
+            self.ke = dict(tke=torch.full((A,), k0, dtype=f32, device=dev), eps=torch.full((A,), e0, dtype=f32, device=dev),
+                           turbvisc=torch.full((A,), nut0, dtype=f32, device=dev), eulervel=torch.zeros((A, 4), dtype=f32, device=dev))
+            self.ke2 = {k: torch.zeros_like(v) for k, v in self.ke.items()}
+            self.dkde = torch.zeros((A, 3), dtype=f32, device=dev)
+            self.cfl_keps = torch.zeros_like(self.cfl)
         self.effvisc = torch.zeros(A, dtype=f32, device=dev) if self.effvisc_on else None      # BUFFER_EFFVISC
         # ENABLE_INTERNAL_ENERGY: BUFFER_INTERNAL_ENERGY (double buffered, re-sorted; starts from zero: init_internal_energy) and its rate
         self.energy_on = bool(self.sp.simflags & D.ENABLE_INTERNAL_ENERGY)
@@ -262,6 +273,10 @@ class MultiGpuEngine:
         if self.energy_on:
             K.gather_rows(self.energy2, self.energy, self.partindex, n)
             self.energy, self.energy2 = self.energy2, self.energy
+        if self.keps:
+            for name in self.ke:
+                K.gather_rows(self.ke2[name], self.ke[name], self.partindex, n)
+            self.ke, self.ke2 = self.ke2, self.ke
         if self.grenier:
             K.gather_rows(self.vol2, self.vol, self.partindex, n)
             self.vol, self.vol2 = self.vol2, self.vol
@@ -303,6 +318,15 @@ class MultiGpuEngine:
             K.sa_integrate_gamma(self.gradgamma2, self.gradgamma, self.pos2, self.boundelements, self.vertpos, self.info, self.hash,
                                  self.cellStart, self.neibslist, n, ni)
             ext([self.gradgamma2])
+        if self.keps:
+            ke = self.ke2
+            K.sa_segment_bc_keps(self.vel2, self.gradgamma2, ke, self.pos2, self.vertices, self.boundelements, self.info, self.hash,
+                                 self.cellStart, self.neibslist, n, ni, step)
+            ext([self.vel2, self.gradgamma2, ke["tke"], ke["eps"], ke["eulervel"]])
+            K.sa_vertex_bc_keps(self.vel2, self.gradgamma2, ke, self.vertices, self.boundelements, self.pos2, self.info, self.hash,
+                                self.cellStart, self.neibslist, n, ni, step)
+            ext([self.vel2, ke["tke"], ke["eps"], ke["eulervel"]])
+            return
         K.sa_segment_bc(self.vel2, self.gradgamma2, self.pos2, self.vertices, self.boundelements, self.info, self.hash, self.cellStart,
                         self.neibslist, n, ni, step, D.SIMULATE)
         ext([self.vel2, self.gradgamma2])
@@ -324,6 +348,15 @@ class MultiGpuEngine:
                             self.cellStart, self.neibslist, n, ni)
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
             ext([self.gradgamma])
+        if self.keps and run_mode == D.SIMULATE:
+            ke = self.ke
+            K.sa_segment_bc_keps(self.vel, self.gradgamma, ke, self.pos, self.vertices, self.boundelements, self.info, self.hash,
+                                 self.cellStart, self.neibslist, n, ni, step)
+            ext([self.vel, self.gradgamma, ke["tke"], ke["eps"], ke["eulervel"]])
+            K.sa_vertex_bc_keps(self.vel, self.gradgamma, ke, self.vertices, self.boundelements, self.pos, self.info, self.hash,
+                                self.cellStart, self.neibslist, n, ni, step)
+            ext([self.vel, ke["tke"], ke["eps"], ke["eulervel"]])
+            return
         K.sa_segment_bc(self.vel, self.gradgamma, self.pos, self.vertices, self.boundelements, self.info, self.hash, self.cellStart,
                         self.neibslist, n, ni, step, run_mode)
         ext([self.vel, self.gradgamma])
@@ -373,6 +406,8 @@ class MultiGpuEngine:
             state.append(self.energy)
         if self.sa:      # BUFFER_VERTICES / BOUNDELEMENTS / GRADGAMMA are particle state too
             state += [self.vertices, self.boundelements, self.gradgamma]
+        if self.keps:
+            state += list(self.ke.values())
         self._exchange(state)
         # imported cells are OUTER_EDGE cells here whatever they are at home
         if self.n_local > n_int:
@@ -407,7 +442,15 @@ class MultiGpuEngine:
         if self.sa:      # forces engine of SA_BOUNDARY: the state's gamma, the boundary elements, the vertex offsets of the segments
             ggam = self.gradgamma if pos is self.pos else self.gradgamma2
 
+            ke = (self.ke if pos is self.pos else self.ke2) if (self.keps and run_mode == D.SIMULATE) else None
+            if ke is not None:
+                K.memset(self.cfl_keps, 0)
+
             def launch(frm, to, off):
+                if ke is not None:
+                    return K.forces_sa_keps(self.forces, self.cfl, self.cfl_keps, self.dkde, pos, vel, self.info, self.hash, self.cellStart,
+                                            self.neibslist, ggam, self.boundelements, self.vertpos, ke, self.n_local, frm, to, off,
+                                            cfl_gamma=self.cfl_gamma)
                 return K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
                                    self.boundelements, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma, run_mode=run_mode)
         elif self.effvisc_on and run_mode == D.SIMULATE:
@@ -446,6 +489,9 @@ class MultiGpuEngine:
         if energy:
             K.forces_internal_energy(self.dedt, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, 0, self.n_int)
         outputs = [self.forces, self.dedt] if energy else [self.forces]
+        keps = self.keps and run_mode == D.SIMULATE
+        if keps:         # BUFFER_DKDE is a POST_FORCES_UPDATE_BUFFER: the halo copies integrate k and epsilon from the exchanged rates
+            outputs.append(self.dkde)
         if self.world > 1 and self.n_int > self.edge_start:
             # edge stripe first, then the inner stripe while the edge forces travel
             nb1 = launch(self.edge_start, self.n_int, 0)
@@ -474,6 +520,8 @@ class MultiGpuEngine:
             if self.world > 1:
                 self._exchange(outputs)
         K.dtreduce(self.cfl, self.cfl_temp, nb1 + nb2, self.d_dt_next, combine_min)
+        if keps:         # viscous limit with the largest eddy viscosity (src/cuda/forces.cu:585-598)
+            K.dtreduce_keps(self.cfl_keps, nb1 + nb2, self.d_dt_next)
         if self.sa and self.sa_dynamic_gamma and run_mode == D.SIMULATE:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
             K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb1 + nb2, self.d_dt_next)
 
@@ -504,6 +552,8 @@ class MultiGpuEngine:
             K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1, **ekw)
         if self.energy_on:
             K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 0.5)
+        if self.keps:
+            K.euler_keps(self.ke2, self.ke, self.dkde, self.forces, self.pos, self.info, n, self.d_dt, 0.5)
         if self.sa:
             self._sa_post_euler(1)
         # corrector: forces(step n*) -> n+1 = n + dt f*   (written over n*, then renamed to n)
@@ -518,8 +568,12 @@ class MultiGpuEngine:
         if self.energy_on:
             K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 1.0)
             self.energy, self.energy2 = self.energy2, self.energy
+        if self.keps:
+            K.euler_keps(self.ke2, self.ke, self.dkde, self.forces, self.pos, self.info, n, self.d_dt, 1.0)
         if self.sa:
             self._sa_post_euler(2)
+            if self.keps:
+                self.ke, self.ke2 = self.ke2, self.ke
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
         if self.bodies is not None:                 # EULER_UPLOAD_OBJECTS_CG in the post-corrector phase (:331-332)
             K.set_body_cg_integration(m)

@@ -288,7 +288,8 @@ def make_sphx_params(sp: SimParams, pp: PhysParams, *, gridsize, cellsize, origi
     p.repack_a = f32(sp.repack_a); p.repack_alpha = f32(sp.repack_alpha)
     const = sp.is_const_visc
     if const is None:
-        const = not (sp.simflags & D.ENABLE_MULTIFLUID) and sp.rheologytype == D.NEWTONIAN   # IS_SINGLEFLUID && NEWTONIAN
+        # IS_SINGLEFLUID && NEWTONIAN && turbmodel != KEPSILON
+        const = not (sp.simflags & D.ENABLE_MULTIFLUID) and sp.rheologytype == D.NEWTONIAN and sp.turbmodel != D.KEPSILON
     p.is_const_visc = 1 if const else 0
     p.partsurf = f32(pp.partsurf)
     p.MK_K = nz(pp.MK_K); p.MK_d = nz(pp.MK_d); p.MK_beta = nz(pp.MK_beta)

@@ -222,6 +222,16 @@ class Problem:
             setattr(sp, k, v)
         self.physparams.rheologytype = sp.rheologytype      # PhysParams(rheologytype), physparams.h:380
 
+    def init_keps(self):
+        """ProblemCore::init_keps + init_turbvisc (src/ProblemCore.cc:1623-1659): the uniform initial k, epsilon and eddy
+        viscosity of turbulence<KEPSILON>, with the reference's mix of float and double arithmetic.  -> (k0, e0, nu_t0)"""
+        f = np.float32
+        Lm = max(2.0 * float(self.m_deltap), float(f(1e-5)))                           # fmax(2*m_deltap, 1e-5f), double
+        k0 = f(float(f(0.002) * f(self.physparams.sscoeff[0])) ** 2)                 # pow(float, int) is double
+        e0 = f(float(f(0.16) * np.power(k0, f(1.5))) / Lm)                           # 0.16f*powf(k0, 1.5f) / double
+        nut0 = f(0.9 * float(k0) * float(k0) / float(e0))                            # 0.9*ki*ki/ei in double
+        return float(k0), float(e0), float(nut0)
+
     def initial_density(self, pos_global):
         """rho~ the problem starts from at the given global positions; also used to reset the state at the end of a
         repacking run (ProblemCore::resetBuffers, src/ProblemCore.cc:1773-1796)."""

@@ -304,6 +304,49 @@ int sphx_sa_vertex_bc(sphx_ctx *ctx, void *vel, const void *gGam, const void *po
 	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
 	int step, int run_mode, void *stream);
 
+/* ---- turbulence<KEPSILON> (k-epsilon model; SA_BOUNDARY with solid walls only, src/cuda/cudasimframework.cu:155) ------------
+ * Buffers of the model: BUFFER_TKE, BUFFER_EPSILON, BUFFER_TURBVISC (float), BUFFER_EULERVEL (float4) -- particle properties,
+ * re-sorted with the particles -- and the ephemeral BUFFER_DKDE (3 floats per particle: diffusion term of k, of epsilon,
+ * Yap's C_e2) and BUFFER_CFL_KEPS (one float per forces block).  With KEPSILON uploaded the plain SA entry points answer
+ * SPHX_ERR_INVALID for a SIMULATE pass; the repacking run mode has no k-epsilon and keeps using them.
+ *   sphx_sa_segment_bc_keps   saSegmentBoundaryConditions with has_keps (boundary_conditions_kernel.cu:509-541,678-693,748-758,
+ *                             806-826,1262-1277): also k = Shepard mean of the fluid's k (dk/dn = 0), epsilon from the wall law
+ *                             de/dn = 4 c_mu^(3/4) k^(3/2)/(kappa r), Eulerian velocity = tangential mean of the three vertices
+ *   sphx_sa_vertex_bc_keps    saVertexBoundaryConditions with has_keps (:918-927,1002-1021,1052-1072): k, epsilon = means over the
+ *                             adjacent segments (floors 1e-6), Eulerian velocity made tangential to the vertex normal
+ *   sphx_forces_basicstep_sa_keps  basicstep of the forces engine with keps_forces_params (forces_kernel.def:262-270,389-401,
+ *                             2824-2878,2915-2980,3123-3170): P + 2/3 rho k in the pressure term, laminar + eddy viscosity in the
+ *                             volumic MORRIS term, wall shear stress from the law of the wall instead of the laminar wall term,
+ *                             DKDE from the boundary sums (the state the reference's last forcesDevice launch leaves), the strain
+ *                             production term limited to 0.3 k S; cflKeps = per-block max eddy viscosity
+ *   sphx_euler_keps           the k-epsilon part of eulerDevice (euler_kernel.def:219-231,262-274,325-337): semi-implicit k and
+ *                             epsilon of fluid rows, eulerVel += dt force of wall rows, turbvisc = 0.9 k^2/epsilon of every row;
+ *                             dt from d_dt[0]*dt_scale when d_dt is given, like sphx_euler_basicstep
+ *   sphx_forces_dtreduce_keps_device  viscous part of dtreduce (forces.cu:585-598): d_dt = min(d_dt, 0.125 h^2/(max_kinematic + max cflKeps)) */
+int sphx_sa_segment_bc_keps(sphx_ctx *ctx, void *vel, void *gGam, float *tke, float *eps, void *eulerVel,
+	const void *pos, const void *vertices,
+	const void *boundElements, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
+	int step, int run_mode, void *stream);
+int sphx_sa_vertex_bc_keps(sphx_ctx *ctx, void *vel, const void *gGam, float *tke, float *eps, void *eulerVel,
+	const void *vertices, const void *boundElements, const void *pos, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius,
+	int step, int run_mode, void *stream);
+int sphx_forces_basicstep_sa_keps(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, float *cflKeps, float *dkde,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
+	const float *tke, const float *eps, const float *turbvisc, const void *eulerVel,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle,
+	float deltap, float slength, float dtadaptfactor, float influenceradius, float epsilon, uint32_t cflOffset,
+	int run_mode, int step, float dt, uint32_t *h_numBlocks, void *stream);
+int sphx_euler_keps(sphx_ctx *ctx, float *newTke, float *newEps, float *newTurbVisc, void *newEulerVel,
+	const float *oldTke, const float *oldEps, const void *oldEulerVel, const float *dkde, const void *forces,
+	const void *oldPos, const void *info, uint32_t numParticles, uint32_t particleRangeEnd,
+	float dt, const float *d_dt, float dt_scale, void *stream);
+int sphx_forces_dtreduce_keps_device(sphx_ctx *ctx, const float *cflKeps, uint32_t numBlocks, float slength,
+	float max_kinematic, float *d_dt, void *stream);
+
 /* ---- AbstractForcesEngine ----------------------------------------------------------------- */
 uint32_t sphx_forces_fmax_elements(uint32_t n);       /* getFmaxElements, src/cuda/forces.cu:539-543 */
 uint32_t sphx_forces_fmax_temp_elements(uint32_t n);  /* getFmaxTempElements, :548-552 */

@@ -761,7 +761,8 @@ static inline float visc_avg(const orc_params *p, float visc, float neib_visc, f
 	 * That alias does not carry is_const_visc over: the dynamic spec gets the DEFAULT constness of its framework flags,
 	 * IS_SINGLEFLUID && NEWTONIAN (src/visc_spec.h:268-272,298-300) -- so a single-fluid NEWTONIAN spec forced to non-constant
 	 * viscosity ends in the constant dynamic formula 2 m mu_i/(rho_i rho_j); pinned by tests/golden/ref_viscavg.npz */
-	return visc_avg_dyn(p->avgop, !(p->simflags & ORC_ENABLE_MULTIFLUID) && p->rheologytype == ORC_NEWTONIAN,
+	return visc_avg_dyn(p->avgop, !(p->simflags & ORC_ENABLE_MULTIFLUID) && p->rheologytype == ORC_NEWTONIAN &&
+		p->turbmodel != ORC_KEPSILON,
 		visc*rho, neib_visc*neib_rho, rho, neib_rho, neib_mass);
 }
 
@@ -771,12 +772,31 @@ float orc_visc_avg(const orc_params *p, float visc, float neib_visc, float rho, 
 
 /* SA_BOUNDARY members of forces_params / finalize_forces_params (src/cuda/forces_params.h): gamma and its gradient,
  * the boundary elements and the in-plane vertex offsets of the segments */
+/* KEPSILON members (keps_forces_params, src/cuda/forces_params.h:283-320): k, epsilon, the eddy viscosity and the Eulerian
+ * velocity are read; BUFFER_DKDE (diffusion terms of k and epsilon, Yap's C_e2) and BUFFER_TAU (the strain rate sums) are written
+ * by EVERY forcesDevice launch from a freshly initialised keps_particle_output (forces_particle_output :1003-1013 default-constructs
+ * it, write_keps :3331-3339 stores it), so what the finalize kernel reads is what the LAST launch over a particle left: for a fluid
+ * particle the fluid <- boundary sums.  Restated launch by launch, so that this follows from the structure. */
+typedef struct {
+	const float *tke, *eps, *turbvisc;
+	const orc_f4 *eulerVel;
+	float *dkde;          /* 3 per particle */
+	float *strain;        /* 6 per particle: xx, xy, xz, yy, yz, zz (off-diagonal sums premultiplied by two, :921-935) */
+	float *cflKeps;       /* one per block, or NULL */
+	float epsilon;
+} sa_keps_ctx;
 typedef struct {
 	const orc_f4 *gGam, *boundelem;
 	const float *vertPos[3];
 	float deltap;
 	float *gammaCfl;      /* per particle max of |grad gamma_as| |n.v| (dynamic gamma + ENABLE_DTADAPT), or NULL */
+	const sa_keps_ctx *ke;
 } sa_forces_ctx;
+static inline void keps_add_strain(float *t, float vx, float vy, float vz, float mx, float my, float mz)
+{	/* keps_particle_output::add_strain_rate :924-937 */
+	t[0] += vx*mx; t[1] += vx*my + vy*mx; t[2] += vx*mz + vz*mx;
+	t[3] += vy*my; t[4] += vy*mz + vz*my; t[5] += vz*mz;
+}
 float orc_grad_gamma_vp(float slength, float qx, float qy, float qz, const orc_f4 *belem,
 	const float *vp0, const float *vp1, const float *vp2);
 
@@ -815,8 +835,17 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 		const int f2 = p->sph_formulation == ORC_SPH_F2;
 		/* SPH_HA (Hu & Adams): precalc = P (:458-468), volumes V = m/rho in the pressure term, own mass in the continuity equation */
 		const int ha = p->sph_formulation == ORC_SPH_HA;
-		const float p_precalc = (f2 || ha) ? orc_P(p, vel.w, p_fluid) : orc_P(p, vel.w, p_fluid)/(p_rho*p_rho);
+		const sa_keps_ctx *ke = sa ? sa->ke : NULL;
+		/* pressure_for_precalc with KEPSILON :389-401: P + 2/3 k/rho */
+		const float p_precalc = ke ? (orc_P(p, vel.w, p_fluid) + 2.0f*ke->tke[index]/p_rho/3.0f)/(p_rho*p_rho) :
+			(f2 || ha) ? orc_P(p, vel.w, p_fluid) : orc_P(p, vel.w, p_fluid)/(p_rho*p_rho);
 		const float *p_tau = tauArray ? tauArray + 6*(size_t)index : NULL;
+		/* keps_particle_data :633-655, keps_precalc_particle_data :708-722, eulerVel_particle_data :553-561; keps_particle_output() :941-948 */
+		const float p_k = ke ? ke->tke[index] : 0.0f, p_e = ke ? ke->eps[index] : 0.0f, p_turb = ke ? ke->turbvisc[index] : 0.0f;
+		const float p_tvv = (ke && FLUID(info)) ? p_turb : 0.0f;
+		const orc_f4 p_euler = ke ? ke->eulerVel[index] : (orc_f4){ 0.0f, 0.0f, 0.0f, 0.0f };
+		const float dkdt_precalc = p_rho*(p->visccoeff[p_fluid] + p_turb), dedt_precalc = p_rho*(p->visccoeff[p_fluid] + p_turb/1.3f);
+		float diff_k = 0.0f, diff_e = 0.0f, ce2yap = 1.92f, strain[6] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
 
 		orc_f4 force = forces[index]; /* common_particle_output, :886-895 */
 		const int energy = g_dedt && (p->simflags & ORC_ENABLE_INTERNAL_ENERGY);
@@ -847,7 +876,14 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			const int n_fluid = FLUID_NUM(neib_info);
 			const float n_sspeed = orc_soundSpeed(p, n_rhot, n_fluid);
 			const float n_rho = physical_density(p, n_rhot, n_fluid);
-			const float n_precalc = (f2 || ha) ? orc_P(p, n_rhot, n_fluid) : orc_P(p, n_rhot, n_fluid)/(n_rho*n_rho);
+			const float n_precalc = ke ? (orc_P(p, n_rhot, n_fluid) + 2.0f*ke->tke[neib_index]/n_rho/3.0f)/(n_rho*n_rho) :
+				(f2 || ha) ? orc_P(p, n_rhot, n_fluid) : orc_P(p, n_rhot, n_fluid)/(n_rho*n_rho);
+			/* get_viscous_relVel :2494-2507: relVel + relEulerVel where an Eulerian velocity exists (eulerVel_neib_data :1152-1162) */
+			float wx = vx, wy = vy, wz = vz;
+			if (ke) {
+				const orc_f4 ne = ke->eulerVel[neib_index];
+				wx = vx + (p_euler.x - ne.x); wy = vy + (p_euler.y - ne.y); wz = vz + (p_euler.z - ne.z);
+			}
 
 			float DvDt[3] = {0.0f, 0.0f, 0.0f};
 			float DrDt = 0.0f;
@@ -880,6 +916,40 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				const float pGradTerm = p_precalc + n_precalc;
 				const float ps = pGradTerm*n_rho*ggamAS;
 				DvDt[0] += ps*belem.x; DvDt[1] += ps*belem.y; DvDt[2] += ps*belem.z;
+				if (ke) {
+					const float r_as = fmaxf(fabsf(dot3(rx, ry, rz, belem.x, belem.y, belem.z)), sa->deltap);
+					const float our_visc = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[p_fluid] : p->visccoeff[p_fluid]/p_rho;
+					const float neib_visc = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[n_fluid] : p->visccoeff[n_fluid]/n_rho;
+					/* compute_turb_visc_contrib, boundary term :2824-2878: the wall shear stress from the law of the wall (the laminar
+					 * wall term is left out with k-epsilon and solid walls, :2695-2702) */
+					if (!(p_k < ke->epsilon)) {
+						const float ux = vx + p_euler.x, uy = vy + p_euler.y, uz = vz + p_euler.z;     /* relVel + pdata.eulerVel */
+						const float un = dot3(ux, uy, uz, belem.x, belem.y, belem.z);
+						const float ut[3] = { ux - un*belem.x, uy - un*belem.y, uz - un*belem.z };
+						const float abs_u_t = sqrtf(dot3(ut[0], ut[1], ut[2], ut[0], ut[1], ut[2]));
+						float u_star = 0.0f;
+						const float uk = 0.547722558f*sqrtf(p_k);
+						float y_plus = r_as/our_visc*uk;
+						if (y_plus < 2.43902439f)
+							u_star = abs_u_t/y_plus;
+						else {
+							float utau = 0.118599857f*neib_visc/r_as;
+							for (int i = 0; i < 10; i++) {
+								y_plus = fmaxf(r_as*utau/neib_visc, 2.43902439f);
+								utau = (0.41f*abs_u_t + utau)/(logf(y_plus) + 3.132f);
+							}
+							u_star = abs_u_t/(logf(y_plus)/0.41f + 5.2f);
+						}
+						const float sc = 2.0f*ggamAS*u_star*u_star, inv = 1.0f/fmaxf(abs_u_t, 1e-6f);
+						DvDt[0] -= (sc*ut[0])*inv; DvDt[1] -= (sc*ut[1])*inv; DvDt[2] -= (sc*ut[2])*inv;
+					}
+					/* compute_keps_term, boundary term :2949-2980 */
+					const float lyap = 0.400772603f*powf(p_k, 1.5f)/(p_e*r_as);
+					if (lyap > 1.0f)
+						ce2yap = fminf(ce2yap, fmaxf(1.92f - 0.83f*(lyap - 1.0f)*lyap*lyap, 0.0f));
+					diff_e += 0.276923077f*p_k*p_k/r_as*ggamAS;
+					keps_add_strain(strain, wx, wy, wz, (ggamAS*belem.x)*n_rho, (ggamAS*belem.y)*n_rho, (ggamAS*belem.z)*n_rho);
+				} else
 				/* compute_laminar_visc_contrib, boundary term :2680-2718 (MORRIS, no k-epsilon, no open boundaries) */
 				if (p->rheologytype == ORC_NEWTONIAN) {
 					const float r_as = fmaxf(fabsf(dot3(rx, ry, rz, belem.x, belem.y, belem.z)), sa->deltap);   /* sa_boundary_neib_data :1132-1150 */
@@ -1034,6 +1104,18 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 					const float pos_den = dot3(rx, ry, rz, rx, ry, rz) + p->epsartvisc;
 					const float cv = 5*visc_thirds - avb, cr = 5*(visc_thirds + avb)*vel_dot_pos/pos_den;
 					DvDt[0] += coeff*(cv*vx + cr*rx); DvDt[1] += coeff*(cv*vy + cr*ry); DvDt[2] += coeff*(cv*vz + cr*rz);
+				} else if (newtonian && ke) {
+					/* get_visc_coeff with KEPSILON :262-270: the laminar coefficient + the eddy viscosity (fluid particles only,
+					 * turbViscForViscTerm :645-655); MORRIS along relVel + relEulerVel */
+					const float n_tvv = FLUID(neib_info) ? ke->turbvisc[neib_index] : 0.0f;
+					const float vf = visc_avg(p, p->visccoeff[p_fluid] + p_tvv, p->visccoeff[n_fluid] + n_tvv, p_rho, n_rho, nmass)*f;
+					DvDt[0] += vf*wx; DvDt[1] += vf*wy; DvDt[2] += vf*wz;
+					/* compute_keps_term, volumic term :2915-2946 */
+					const float n_kin = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[n_fluid] : p->visccoeff[n_fluid]/n_rho;
+					const float n_turb = ke->turbvisc[neib_index];
+					diff_k += nmass*(dkdt_precalc + n_rho*(n_kin + n_turb))*(p_k - ke->tke[neib_index])*f/n_rho;
+					diff_e += nmass*(dedt_precalc + n_rho*(n_kin + n_turb/1.3f))*(p_e - ke->eps[neib_index])*f/n_rho;
+					keps_add_strain(strain, wx, wy, wz, (-nmass*rx)*f, (-nmass*ry)*f, (-nmass*rz)*f);
 				} else if (newtonian) {
 					const float visc = effvisc ? visc_avg(p, effvisc[index], effvisc[neib_index], p_rho, n_rho, nmass) :
 						visc_avg(p, p->visccoeff[p_fluid], p->visccoeff[n_fluid], p_rho, n_rho, nmass);
@@ -1055,6 +1137,11 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 		}
 		forces[index] = force;
 		if (energy) g_dedt[index] = dedt;
+		if (ke) {      /* write_keps :3331-3339 */
+			float *d = ke->dkde + 3*(size_t)index;
+			d[0] = diff_k; d[1] = diff_e; d[2] = ce2yap;
+			memcpy(ke->strain + 6*(size_t)index, strain, sizeof strain);
+		}
 	}
 }
 
@@ -1154,6 +1241,8 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 #pragma omp parallel for schedule(static)
 	for (uint32_t block = 0; block < numBlocks; ++block) {
 		float block_max = 0.0f; /* shared.init() */
+		float block_max_keps = 0.0f;
+		const sa_keps_ctx *ke = sa ? sa->ke : NULL;
 		for (uint32_t t = 0; t < BLOCK_SIZE_FORCES; ++t) {
 			const uint32_t index = block*BLOCK_SIZE_FORCES + t + fromParticle;
 			if (index >= toParticle) break;
@@ -1180,6 +1269,22 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 					force.w *= physical_density(p, vel.w, fl);
 			}
 
+			if (FLUID(info) && ke) {
+				/* viscous_fixup with KEPSILON + SA_BOUNDARY :3123-3170: diffusion terms divided by rho gamma, production of k from the
+				 * norm of the strain rate (limited to 0.3 k S), source term of epsilon */
+				float *d = ke->dkde + 3*(size_t)index;
+				const float *tau = ke->strain + 6*(size_t)index;
+				const float rhoGam = physical_density(p, vel.w, fl)*sa->gGam[index].w;
+				d[0] /= rhoGam; d[1] /= rhoGam;
+				float SijSij_bytwo = 2.0f*(tau[0]*tau[0] + tau[3]*tau[3] + tau[5]*tau[5]) + tau[1]*tau[1] + tau[2]*tau[2] + tau[4]*tau[4];
+				const float S = sqrtf(SijSij_bytwo)/rhoGam;
+				SijSij_bytwo /= rhoGam*rhoGam;
+				const float k = ke->tke[index];
+				const float Pturb = fminf(ke->turbvisc[index]*SijSij_bytwo, 0.3f*k*S);
+				d[0] += Pturb;
+				d[1] += ke->eps[index]*1.44f*Pturb/k;
+				if (dtadapt) block_max_keps = fmaxf(block_max_keps, ke->turbvisc[index]);      /* dyndt_keps_shared_data :3481-3501 */
+			}
 			if (FLUID(info)) {
 				force.x += p->gravity[0]; force.y += p->gravity[1]; force.z += p->gravity[2];
 				/* GeometryForce/PlaneForce (src/cuda/forces_kernel.cu:140-203), PlaneDistance + globalDistance
@@ -1231,6 +1336,8 @@ static void finalize_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 		}
 		if (dtadapt && cfl)
 			cfl[cflOffset + block] = block_max; /* maxBlockReduce, src/cuda/device_core.cu:40-59 */
+		if (dtadapt && ke && ke->cflKeps)
+			ke->cflKeps[cflOffset + block] = block_max_keps;
 	}
 }
 
@@ -1277,13 +1384,53 @@ uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *c
 	 * on, one value per block (src/cuda/forces.cu:576-581); used with dynamic gamma and ENABLE_DTADAPT only */
 	const int gcfl = cflGamma && !(p->simflags & ORC_ENABLE_GAMMA_QUADRATURE) && (p->simflags & ORC_ENABLE_DTADAPT);
 	if (gcfl) memset(cflGamma + fromParticle, 0, sizeof(float)*(toParticle - fromParticle));
-	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL };
+	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL, NULL };
 	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
 	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
 	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
 	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
 	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, &sa, NULL, NULL);
 	if (gcfl) {      /* per-block maxima behind the per-particle values */
+		float *blocks = cflGamma + round_up(numParticles, 4u) + cflOffset;
+		for (uint32_t b = 0; b < numBlocks; ++b) {
+			float m = 0.0f;
+			for (uint32_t t = 0; t < BLOCK_SIZE_FORCES; ++t) {
+				const uint32_t i = b*BLOCK_SIZE_FORCES + t + fromParticle;
+				if (i < toParticle) m = fmaxf(m, cflGamma[i]);
+			}
+			blocks[b] = m;
+		}
+	}
+	return numBlocks;
+}
+
+/* run_forces with SA_BOUNDARY and the k-epsilon model (solid walls): the three fluid launches of orc_forces_sa with the keps members,
+ * then forcesDevice<PT_VERTEX, PT_FLUID> (vertex_forces, src/cuda/forces.cu:676-686), whose viscous term is computed into nout and
+ * never added to the vertex's force (compute_pp_interaction :3750-3783) -- what it leaves is a cleared DKDE / TAU row for every
+ * vertex particle -- then the finalize with viscous_fixup.  dkde: 3 floats per particle, strain: 6 (BUFFER_TAU) */
+uint32_t orc_forces_sa_keps(const orc_params *p, orc_f4 *forces, float *cfl, float *cflGamma, float *cflKeps,
+	float *dkde, float *strain,
+	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	const orc_f4 *gGam, const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2,
+	const float *tke, const float *eps, const float *turbvisc, const orc_f4 *eulerVel,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, float deltap, float epsilon)
+{
+	const int gcfl = cflGamma && !(p->simflags & ORC_ENABLE_GAMMA_QUADRATURE) && (p->simflags & ORC_ENABLE_DTADAPT);
+	if (gcfl) memset(cflGamma + fromParticle, 0, sizeof(float)*(toParticle - fromParticle));
+	const sa_keps_ctx ke = { tke, eps, turbvisc, eulerVel, dkde, strain, cflKeps, epsilon };
+	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL, &ke };
+	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
+	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
+	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
+	forces_pass(p, PT_FLUID, PT_BOUNDARY, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
+	for (uint32_t i = fromParticle; i < toParticle; ++i)      /* forcesDevice<PT_VERTEX, PT_FLUID>: write_keps of a fresh output */
+		if (VERTEX(info[i]) && !INACTIVE(pos[i])) {
+			dkde[3*(size_t)i] = 0.0f; dkde[3*(size_t)i + 1] = 0.0f; dkde[3*(size_t)i + 2] = 1.92f;
+			memset(strain + 6*(size_t)i, 0, 6*sizeof(float));
+		}
+	finalize_forces(p, forces, cfl, NULL, NULL, pos, vel, info, hash, fromParticle, toParticle, numBlocks, cflOffset, &sa, NULL, NULL);
+	if (gcfl) {
 		float *blocks = cflGamma + round_up(numParticles, 4u) + cflOffset;
 		for (uint32_t b = 0; b < numBlocks; ++b) {
 			float m = 0.0f;
@@ -2510,10 +2657,13 @@ static inline sa_ndata sa_fluid_ndata(const orc_params *p, float wcoeff, float w
 /* saSegmentBoundaryConditionsDevice :1425-1520 and saSegmentBoundaryConditionsRepackDevice :1544-1640
  * (they differ by the moving-body velocity, which the repack variant leaves out).  In place: reads fluid and vertex
  * rows, writes boundary rows of vel and gGam. */
-void orc_sa_segment_bc(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray, const orc_f4 *posArray,
+static void sa_segment_bc_impl(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray, const orc_f4 *posArray,
 	const uint32_t *vertices, const orc_f4 *boundelement, const orc_info *infoArray, const uint32_t *hashArray,
-	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd, int step, int repack)
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd, int step, int repack,
+	float *tke, float *eps, orc_f4 *eulerVelArray, float deltap)
 {
+	/* tke/eps/eulerVelArray: the k-epsilon members of sa_segment_bc_params (src/cuda/sa_bc_params.h:152-200), NULL without KEPSILON */
+	const int keps = tke != NULL && !repack;
 	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
 	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
 	const int has_moving = (p->simflags & ORC_ENABLE_MOVING_BODIES) != 0;
@@ -2534,6 +2684,8 @@ void orc_sa_segment_bc(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray,
 		orc_f4 vel = { 0.0f, 0.0f, 0.0f, 0.0f };
 		const int calcGam = has_moving || !isfinite(gGam.w) || step == 0;
 		if (calcGam) gGam.w = 0.0f;
+		float sumtke = 0.0f, sumeps = 0.0f;                  /* common_keps_pout :509-520 */
+		orc_f4 eulerVel = { 0.0f, 0.0f, 0.0f, 0.0f };        /* eulervel_pout :470-484 */
 
 		neib_iter it;
 		uint32_t neib_index;
@@ -2548,6 +2700,10 @@ void orc_sa_segment_bc(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray,
 			if (calcGam) {
 				const orc_f4 g = gGamArray[neib_index];
 				gGam.x += g.x; gGam.y += g.y; gGam.z += g.z; gGam.w += g.w;
+			}
+			if (keps) {      /* keps_vertex_contrib :748-758 */
+				const orc_f4 e = eulerVelArray[neib_index];
+				eulerVel.x += e.x; eulerVel.y += e.y; eulerVel.z += e.z; eulerVel.w += e.w;
 			}
 		}
 		if (calcGam) {
@@ -2568,19 +2724,49 @@ void orc_sa_segment_bc(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray,
 			if (!(n.r < p->influenceradius && (normal.x*rx + normal.y*ry + normal.z*rz) < 0.0f)) continue;
 			const float gdot = p->gravity[0]*rx + p->gravity[1]*ry + p->gravity[2]*rz;
 			sumpWall += fmaxf(n.press + physical_density(p, n.vel.w, fl)*gdot, 0.0f)*n.w;
+			if (keps) {      /* keps_fluid_contrib :816-826: dk/dn = 0, de/dn = 4 c_mu^(3/4) k^(3/2)/(kappa r) (de_dn_solid :806-813) */
+				const float norm_dist = fmaxf(fabsf(normal.x*rx + normal.y*ry + normal.z*rz), deltap);      /* segment_keps_ndata :678-693 */
+				const float nk = tke[neib_index], ne = eps[neib_index];
+				sumtke += n.w*nk;
+				sumeps += n.w*(ne + 1.603090412f*powf(nk, 1.5f)/norm_dist);
+			}
 			shepard_div += n.w;
 		}
 		/* impose_solid_bc :1295-1306 */
 		shepard_div = fmaxf(shepard_div, 0.1f*gGam.w);
 		vel.w = orc_RHO(p, sumpWall/shepard_div, fl);
 		velArray[index] = vel;
+		if (keps) {      /* impose_solid_keps_bc :1262-1277; the normal is the float4 boundary element, its .w (the area) rides along */
+			tke[index] = sumtke/shepard_div;
+			eps[index] = fmaxf(sumeps/shepard_div, 1e-5f);
+			const float inv = 1.0f/3;
+			eulerVel.x *= inv; eulerVel.y *= inv; eulerVel.z *= inv; eulerVel.w *= inv;
+			const float d = eulerVel.x*normal.x + eulerVel.y*normal.y + eulerVel.z*normal.z;
+			eulerVel.x -= d*normal.x; eulerVel.y -= d*normal.y; eulerVel.z -= d*normal.z; eulerVel.w -= d*normal.w;
+			eulerVelArray[index] = eulerVel;
+		}
 	}
 }
 
+void orc_sa_segment_bc(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray, const orc_f4 *posArray,
+	const uint32_t *vertices, const orc_f4 *boundelement, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd, int step, int repack)
+{
+	sa_segment_bc_impl(p, velArray, gGamArray, posArray, vertices, boundelement, infoArray, hashArray, cellStart, neibsList,
+		particleRangeEnd, step, repack, NULL, NULL, NULL, 0.0f);
+}
+void orc_sa_segment_bc_keps(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray, float *tke, float *eps, orc_f4 *eulerVel,
+	const orc_f4 *posArray, const uint32_t *vertices, const orc_f4 *boundelement, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd, int step, float deltap)
+{
+	sa_segment_bc_impl(p, velArray, gGamArray, posArray, vertices, boundelement, infoArray, hashArray, cellStart, neibsList,
+		particleRangeEnd, step, 0, tke, eps, eulerVel, deltap);
+}
+
 /* saVertexBoundaryConditionsDevice :2195-2253 and its Repack twin: density of vertex particles from the fluid */
-void orc_sa_vertex_bc(const orc_params *p, orc_f4 *velArray, const orc_f4 *gGamArray, const orc_f4 *posArray,
+static void sa_vertex_bc_impl(const orc_params *p, orc_f4 *velArray, const orc_f4 *gGamArray, const orc_f4 *posArray,
 	const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList,
-	uint32_t particleRangeEnd)
+	uint32_t particleRangeEnd, float *tke, float *eps, orc_f4 *eulerVelArray, const uint32_t *vertices, const orc_f4 *boundelement)
 {
 	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
 	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
@@ -2608,8 +2794,69 @@ void orc_sa_vertex_bc(const orc_params *p, orc_f4 *velArray, const orc_f4 *gGamA
 				shepard_div += n.w;
 			}
 		}
+		/* vertex_boundary_loop :1002-1021 (KEPSILON): k and epsilon of a vertex are the means over its adjacent segments
+		 * (keps_boundary_contrib :918-927, impose_vertex_keps_bc :1052-1072), its Eulerian velocity is made tangential to the wall */
+		float sumtke = 0.0f, sumeps = 0.0f; int numseg = 0;
+		if (tke) {
+			neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				if (!has_vertex(vertices + 4*(size_t)neib_index, orc_info_id(info))) continue;
+				sumtke += tke[neib_index]; sumeps += eps[neib_index]; numseg += 1;
+			}
+		}
 		shepard_div = fmaxf(shepard_div, 0.1f*gam);
 		velArray[index].w = orc_RHO(p, sumpWall/shepard_div, fl);
+		if (tke) {
+			tke[index] = fmaxf(sumtke/numseg, 1e-6f);
+			eps[index] = fmaxf(sumeps/numseg, 1e-6f);
+			const orc_f4 nrm = boundelement[index];
+			orc_f4 e = eulerVelArray[index];
+			const float d = e.x*nrm.x + e.y*nrm.y + e.z*nrm.z;
+			e.x -= d*nrm.x; e.y -= d*nrm.y; e.z -= d*nrm.z;
+			eulerVelArray[index] = e;
+		}
+	}
+}
+
+void orc_sa_vertex_bc(const orc_params *p, orc_f4 *velArray, const orc_f4 *gGamArray, const orc_f4 *posArray,
+	const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t particleRangeEnd)
+{
+	sa_vertex_bc_impl(p, velArray, gGamArray, posArray, infoArray, hashArray, cellStart, neibsList, particleRangeEnd,
+		NULL, NULL, NULL, NULL, NULL);
+}
+void orc_sa_vertex_bc_keps(const orc_params *p, orc_f4 *velArray, const orc_f4 *gGamArray, float *tke, float *eps, orc_f4 *eulerVel,
+	const orc_f4 *posArray, const uint32_t *vertices, const orc_f4 *boundelement, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd)
+{
+	sa_vertex_bc_impl(p, velArray, gGamArray, posArray, infoArray, hashArray, cellStart, neibsList, particleRangeEnd,
+		tke, eps, eulerVel, vertices, boundelement);
+}
+
+/* Euler step of the k-epsilon model (src/cuda/euler_kernel.def:219-231,262-274,325-337): semi-implicit k and epsilon of the fluid
+ * particles, Eulerian velocity of the wall particles (+= dt force), and the eddy viscosity 0.9 k^2/epsilon of every particle
+ * (the reference's constant: C_mu = 0.09 appears as 0.9f there).  The rows are those the Euler kernel integrates. */
+void orc_euler_keps(const orc_params *p, float *newTke, float *newEps, float *newTurbVisc, orc_f4 *newEulerVel,
+	const float *oldTke, const float *oldEps, const orc_f4 *oldEulerVel, const float *dkde, const orc_f4 *forces,
+	const orc_f4 *oldPos, const orc_info *infoArray, uint32_t particleRangeEnd, float dt)
+{
+	(void)p;
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (INACTIVE(oldPos[index])) continue;      /* the Euler kernel leaves the rows of disabled particles alone */
+		float k = oldTke[index], e = oldEps[index];
+		orc_f4 ev = oldEulerVel[index];
+		if (FLUID(info)) {
+			const float *d = dkde + 3*(size_t)index;
+			const float oldK = k;
+			k = (oldK + dt*d[0])/(1.0f + dt*e/oldK);
+			e = (e + dt*d[1])/(1.0f + dt*e/oldK*d[2]);
+		} else if (BOUNDARY(info) || VERTEX(info)) {
+			const orc_f4 f = forces[index];
+			ev.x += dt*f.x; ev.y += dt*f.y; ev.z += dt*f.z; ev.w += dt*f.w;
+		}
+		newTke[index] = k; newEps[index] = e; newTurbVisc[index] = 0.9f*k*k/e;
+		newEulerVel[index] = ev;
 	}
 }
 

@@ -245,6 +245,41 @@ class Oracle:
                                  P(nl), C.c_uint32(n), C.c_int(step), C.c_int(1 if repack else 0))
         return v, g
 
+    # ---- turbulence<KEPSILON>: ke = dict(tke, eps, turbvisc, eulervel) numpy arrays
+    def sa_bc_keps(self, pos, vel, ggam, ke, vertices, boundelements, info, hash_, cs, nl, n, step, deltap, vertex=True):
+        """segment then (vertex=True) vertex boundary conditions with the k-epsilon members; -> vel, ggam, ke (copies)"""
+        v, g = vel.copy(), ggam.copy()
+        k = {name: a.copy() for name, a in ke.items()}
+        self.L.orc_sa_segment_bc_keps(C.byref(self.p), P(v), P(g), P(k["tke"]), P(k["eps"]), P(k["eulervel"]), P(pos), P(vertices),
+                                      P(boundelements), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n), C.c_int(step), C.c_float(deltap))
+        if vertex:
+            self.L.orc_sa_vertex_bc_keps(C.byref(self.p), P(v), P(g), P(k["tke"]), P(k["eps"]), P(k["eulervel"]), P(pos), P(vertices),
+                                         P(boundelements), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n))
+        return v, g, k
+
+    def forces_sa_keps(self, pos, vel, info, hash_, cs, nl, ggam, boundelements, vertpos, ke, n, deltap, epsilon=5e-5):
+        """-> forces, cfl, numBlocks, dkde (n, 3), strain (n, 6); self.cfl_keps, self.max_gamma_cfl"""
+        forces = np.zeros((len(pos), 4), dtype=np.float32)
+        nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
+        cfl = np.zeros(nblk, dtype=np.float32)
+        self.cfl_keps = np.zeros(nblk, dtype=np.float32)
+        self.cfl_gamma = np.zeros(((n + 3) // 4) * 4 + nblk, dtype=np.float32)
+        dkde = np.zeros((len(pos), 3), dtype=np.float32); strain = np.zeros((len(pos), 6), dtype=np.float32)
+        self.L.orc_forces_sa_keps.restype = C.c_uint32
+        nb = self.L.orc_forces_sa_keps(C.byref(self.p), P(forces), P(cfl), P(self.cfl_gamma), P(self.cfl_keps), P(dkde), P(strain),
+                                       P(pos), P(vel), P(info), P(hash_), P(cs), P(nl), P(ggam), P(boundelements),
+                                       P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(ke["tke"]), P(ke["eps"]), P(ke["turbvisc"]),
+                                       P(ke["eulervel"]), C.c_uint32(n), C.c_uint32(0), C.c_uint32(n), C.c_uint32(0),
+                                       C.c_float(deltap), C.c_float(epsilon))
+        self.max_gamma_cfl = float(self.cfl_gamma[((n + 3) // 4) * 4:((n + 3) // 4) * 4 + int(nb)].max()) if nb else 0.0
+        return forces, cfl, int(nb), dkde, strain
+
+    def euler_keps(self, ke, dkde, forces, old_pos, info, n, dt):
+        new = {name: a.copy() for name, a in ke.items()}
+        self.L.orc_euler_keps(C.byref(self.p), P(new["tke"]), P(new["eps"]), P(new["turbvisc"]), P(new["eulervel"]), P(ke["tke"]),
+                              P(ke["eps"]), P(ke["eulervel"]), P(dkde), P(forces), P(old_pos), P(info), C.c_uint32(n), C.c_float(dt))
+        return new
+
     def sa_init_gamma(self, ggam, pos, boundelements, vertpos, info, hash_, cs, nl, n, deltap, epsilon=5e-5):
         g = ggam.copy()
         self.L.orc_sa_init_gamma(C.byref(self.p), P(g), P(pos), P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(info),

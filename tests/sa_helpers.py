@@ -79,9 +79,18 @@ class OracleSaSim:
         self.vertices, self.vertpos = st["vertices"], st["vertpos"]
         self.be = o.sa_compute_vertex_normal(st["boundelements"], self.vertices, self.info, self.hash, self.cs, self.nl, n)
         gg = o.sa_init_gamma(st["gradgamma"], self.pos, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n, p.m_deltap)
-        self.vel, self.gg = o.sa_segment_bc(self.pos, self.vel, gg, self.vertices, self.be, self.info, self.hash, self.cs, self.nl, n, step=0,
-                                            repack=repack)
-        self.vel = o.sa_vertex_bc(self.pos, self.vel, self.gg, self.info, self.hash, self.cs, self.nl, n)
+        self.keps = p.simparams.turbmodel == D.KEPSILON and not repack
+        if self.keps:        # ProblemCore::init_keps / init_turbvisc: uniform k, epsilon, eddy viscosity; no Eulerian velocity
+            k0, e0, nut0 = p.init_keps()
+            N = len(self.pos)
+            self.ke = dict(tke=np.full(N, k0, np.float32), eps=np.full(N, e0, np.float32), turbvisc=np.full(N, nut0, np.float32),
+                           eulervel=np.zeros((N, 4), np.float32))
+            self.vel, self.gg, self.ke = o.sa_bc_keps(self.pos, self.vel, gg, self.ke, self.vertices, self.be, self.info, self.hash,
+                                                      self.cs, self.nl, n, 0, p.m_deltap)
+        else:
+            self.vel, self.gg = o.sa_segment_bc(self.pos, self.vel, gg, self.vertices, self.be, self.info, self.hash, self.cs, self.nl, n,
+                                                step=0, repack=repack)
+            self.vel = o.sa_vertex_bc(self.pos, self.vel, self.gg, self.info, self.hash, self.cs, self.nl, n)
         self.dt = float(np.float32(p.simparams.dt))
         self.t = 0.0
         self.iterations = 0
@@ -114,6 +123,40 @@ class OracleSaSim:
             gs = o.sa_integrate_gamma(self.gg, ps, self.be, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
         return vs, gs
 
+    def _dt_keps(self, cfl, nb):
+        """dtreduce with the viscous limit of the largest eddy viscosity (src/cuda/forces.cu:585-598)"""
+        f = np.float32
+        dt = self._dt(cfl, nb)
+        h = f(self.o.p.slength)
+        dt_visc = f(f(h * h) / f(f(self.max_kinvisc) + f(self.o.cfl_keps[:nb].max()))) * f(0.125)
+        return float(min(f(dt), dt_visc))
+
+    def step_keps(self):
+        """the step with turbulence<KEPSILON>: k, epsilon, the eddy viscosity and the Eulerian velocity are part of the state, the
+        forces passes write DKDE, Euler integrates it, the boundary conditions treat the wall rows"""
+        o, n, p = self.o, self.n, self.problem
+        dp = p.m_deltap
+        dt = float(np.float32(self.dt))
+        hdt = float(np.float32(dt) / np.float32(2))
+        A = (self.info, self.hash, self.cs, self.nl)
+        f1, cfl, nb, dk1, _ = o.forces_sa_keps(self.pos, self.vel, *A, self.gg, self.be, self.vertpos, self.ke, n, dp)
+        dt1 = self._dt_keps(cfl, nb)
+        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, hdt, 1)
+        ks = o.euler_keps(self.ke, dk1, f1, self.pos, self.info, n, hdt)
+        vs, gs = self._post_euler(ps, vs, hdt)
+        vs, gs, ks = o.sa_bc_keps(ps, vs, gs, ks, self.vertices, self.be, *A, n, 1, dp)
+        f2, cfl, nb, dk2, _ = o.forces_sa_keps(ps, vs, *A, gs, self.be, self.vertpos, ks, n, dp)
+        dt2 = self._dt_keps(cfl, nb)
+        pn, vn = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
+        kn = o.euler_keps(self.ke, dk2, f2, self.pos, self.info, n, dt)
+        vn, gn = self._post_euler(pn, vn, dt)
+        vn, gn, kn = o.sa_bc_keps(pn, vn, gn, kn, self.vertices, self.be, *A, n, 2, dp)
+        self.forces, self.dkde = f2, dk2
+        self.pos, self.vel, self.gg, self.ke = pn, vn, gn, kn
+        self.t += dt
+        self.dt = min(dt1, dt2)
+        self.iterations += 1
+
     def repack_step(self):
         """one iteration of the repacking integrator with SA_BOUNDARY (RepackingIntegrator.cc:278-420): forces(REPACK), one full-dt
         Euler step of the fluid, INTEGRATE_GAMMA of the new positions; no neighbour rebuild here"""
@@ -130,6 +173,8 @@ class OracleSaSim:
 
     def step(self):
         """no neighbour rebuild here: the runs compared are shorter than buildneibsfreq"""
+        if self.keps:
+            return self.step_keps()
         o, n, p = self.o, self.n, self.problem
         dp = p.m_deltap
         dt = float(np.float32(self.dt))

@@ -1,0 +1,204 @@
+"""turbulence<KEPSILON> (SA_BOUNDARY, solid walls) on the GPU against the CPU oracle, through the C-ABI: the boundary conditions with
+their k-epsilon members, the forces pass with DKDE and the eddy-viscosity CFL array, the Euler step of k and epsilon, whole
+predictor-corrector steps, and the error behaviour of the entry points.  Tolerances: fp32 rounding of sums in a different order and
+another math library (powf, logf); integer outputs and untouched rows bit for bit."""
+import numpy as np
+import pytest
+
+from gpusph_amd import defs as D
+from gpusph_amd.problem import SABox, DamBreak3D, info_type
+from sa_helpers import OracleSaSim
+
+pytestmark = pytest.mark.gpu
+KEPS = dict(rheologytype=D.NEWTONIAN, turbmodel=D.KEPSILON)
+
+
+def _engine(problem, **kw):
+    import torch
+    from gpusph_amd.engine import TimestepEngine
+    assert torch.cuda.is_available()
+    return TimestepEngine(problem, device="cuda:0", **kw)
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _upload(eng, **arrays):
+    import torch
+    for name, a in arrays.items():
+        t = eng.ke[name] if name in eng.ke else getattr(eng, name)
+        t[:len(a)] = torch.from_numpy(np.ascontiguousarray(a)).to(eng.device)
+
+
+# density summation with dynamic gamma (StillWaterSA's options) and the continuity equation with gamma by quadrature
+@pytest.fixture(scope="module", params=[dict(deltap=0.05, jitter=0.05), dict(deltap=0.04, jitter=0.15, options="StillWaterRepackSA")])
+def pair(request):
+    kw = dict(request.param)
+    sim = OracleSaSim(SABox(viscosity=KEPS, **kw))
+    eng = _engine(SABox(viscosity=KEPS, **kw), clobber_neibslist=True)
+    eng.build_neibs()
+    eng.sa_boundary_conditions(0)
+    return sim, eng
+
+
+def _types(s):
+    t = info_type(s.info[:s.n])
+    return (np.where(t == k)[0] for k in (D.PT_FLUID, D.PT_BOUNDARY, D.PT_VERTEX))
+
+
+def test_initial_boundary_conditions(pair):
+    """step 0 of the sequence: gamma, wall densities, and k / epsilon / Eulerian velocity of segments and vertices"""
+    sim, eng = pair
+    n = sim.n
+    assert eng.n == n and eng.keps
+    fl, seg, vx = _types(sim)
+    for name, tol in (("tke", 2e-5), ("eps", 5e-5)):
+        got, want = _np(eng.ke[name])[:n], sim.ke[name]
+        assert np.array_equal(_bits(got[fl]), _bits(want[fl]))                       # fluid rows untouched
+        assert np.abs(got - want).max() < tol * np.abs(want).max(), name
+    assert not _np(eng.ke["eulervel"])[:n].any()
+    assert np.abs(_np(eng.vel)[:n, 3] - sim.vel[:n, 3]).max() < 2e-5 * np.abs(sim.vel[:n, 3]).max() + 2e-7
+    wall = np.concatenate([seg, vx])
+    assert (sim.ke["tke"][wall] > 0).sum() > 300
+
+
+def _perturbed(sim, seed):
+    """a state with velocity, k / epsilon gradients and a non-zero Eulerian velocity on the walls"""
+    fl, seg, vx = _types(sim)
+    rng = np.random.default_rng(seed)
+    vel = sim.vel.copy()
+    vel[fl, :3] = rng.normal(scale=0.3, size=(len(fl), 3)).astype(np.float32)
+    vel[fl, 3] *= (1 + 0.02 * rng.standard_normal(len(fl))).astype(np.float32)
+    ke = {k: v.copy() for k, v in sim.ke.items()}
+    ke["tke"][fl] *= rng.uniform(0.6, 1.6, len(fl)).astype(np.float32)
+    ke["eps"][fl] *= rng.uniform(0.6, 1.6, len(fl)).astype(np.float32)
+    ke["turbvisc"] = (0.9 * ke["tke"].astype(np.float64) ** 2 / np.maximum(ke["eps"], 1e-12)).astype(np.float32)
+    wall = np.concatenate([seg, vx])
+    ke["eulervel"][wall] = rng.normal(scale=0.05, size=(len(wall), 4)).astype(np.float32)
+    return vel, ke
+
+
+def test_boundary_conditions_with_gradients_and_eulerian_velocity(pair):
+    sim, eng = pair
+    n, p = sim.n, sim.problem
+    fl, seg, vx = _types(sim)
+    vel, ke = _perturbed(sim, 5)
+    _upload(eng, vel=vel, **ke)
+    for step in (1, 2):
+        v, g, k = sim.o.sa_bc_keps(sim.pos, vel, sim.gg, ke, sim.vertices, sim.be, sim.info, sim.hash, sim.cs, sim.nl, n, step, p.m_deltap)
+        eng.sa_boundary_conditions(step)
+        gk = {name: _np(t)[:n] for name, t in eng.ke.items()}
+        for name, tol in (("tke", 2e-5), ("eps", 5e-5)):
+            assert np.abs(gk[name] - k[name]).max() < tol * np.abs(k[name]).max(), (name, step)
+            assert np.array_equal(_bits(gk[name][fl]), _bits(k[name][fl]))
+        assert np.abs(gk["eulervel"] - k["eulervel"]).max() < 1e-6
+        assert np.array_equal(_bits(gk["turbvisc"]), _bits(ke["turbvisc"]))          # not an output of the boundary conditions
+        # the Eulerian velocity of a wall row is tangential to its normal
+        nrm = sim.be[:n, :3]
+        wall = np.concatenate([seg, vx])
+        assert np.abs((gk["eulervel"][wall, :3] * nrm[wall]).sum(1)).max() < 1e-6
+        assert np.abs(_np(eng.vel)[:n, 3] - v[:, 3]).max() < 2e-5 * np.abs(v[:, 3]).max() + 2e-7
+        vel, ke = v, k
+        _upload(eng, vel=vel, **ke)
+
+
+def test_forces_pass_with_dkde(pair):
+    sim, eng = pair
+    n, p = sim.n, sim.problem
+    fl, seg, vx = _types(sim)
+    vel, ke = _perturbed(sim, 11)
+    _upload(eng, vel=vel, **ke)
+    f, cfl, nb, dkde, strain = sim.o.forces_sa_keps(sim.pos, vel, sim.info, sim.hash, sim.cs, sim.nl, sim.gg, sim.be, sim.vertpos, ke, n,
+                                                    p.m_deltap)
+    K = eng.k
+    K.memset(eng.cfl, 0); K.memset(eng.cfl_keps, 0); K.memset(eng.dkde, 0xFF)
+    gnb = K.forces_sa_keps(eng.forces, eng.cfl, eng.cfl_keps, eng.dkde, eng.pos, eng.vel, eng.info, eng.hash, eng.cellStart, eng.neibslist,
+                           eng.gradgamma, eng.boundelements, eng.vertpos, eng.ke, n, 0, n, 0, cfl_gamma=eng.cfl_gamma)
+    assert gnb == nb
+    gf, gd = _np(eng.forces)[:n], _np(eng.dkde)[:n]
+    scale = np.abs(f[fl, :3]).max()
+    assert np.abs(gf[fl, :3] - f[fl, :3]).max() < 3e-5 * scale
+    assert np.abs(gf[fl, 3] - f[fl, 3]).max() < 3e-5 * np.abs(f[fl, 3]).max() + 1e-7
+    for c, tol in ((0, 1e-4), (1, 1e-4), (2, 1e-5)):
+        assert np.abs(gd[fl, c] - dkde[fl, c]).max() < tol * np.abs(dkde[fl, c]).max(), c
+    assert np.array_equal(_bits(gd[vx]), _bits(dkde[vx]))                            # (0, 0, 1.92): the vertex launch's fresh output
+    assert (_bits(gd[seg]) == 0xFFFFFFFF).all()                                      # rows of boundary elements are never written
+    assert np.array_equal(_bits(_np(eng.cfl_keps)[:nb]), _bits(sim.o.cfl_keps[:nb])) # maxima of an input array: exact
+    assert np.abs(_np(eng.cfl)[:nb] - cfl[:nb]).max() < 3e-5 * cfl[:nb].max()
+    assert (np.abs(dkde[fl, 0]) > 0).sum() > 100 and (dkde[fl, 2] < 1.92).sum() > 10     # production and Yap's correction are exercised
+    # the wall shear term is what distinguishes the pass from the laminar one: compare with k-epsilon switched off near the walls
+    assert np.abs(f[fl, :3]).max() > 0
+
+
+def test_euler_step_of_k_and_epsilon(pair):
+    sim, eng = pair
+    import torch
+    n = sim.n
+    fl, seg, vx = _types(sim)
+    rng = np.random.default_rng(2)
+    vel, ke = _perturbed(sim, 3)
+    dkde = np.stack([rng.normal(scale=1e-3, size=n), rng.normal(scale=1e-4, size=n), rng.uniform(0.3, 1.92, n)], 1).astype(np.float32)
+    forces = rng.normal(size=(n, 4)).astype(np.float32)
+    _upload(eng, **ke)
+    eng.dkde[:n] = torch.from_numpy(dkde).to(eng.device); eng.forces[:n] = torch.from_numpy(forces).to(eng.device)
+    dt = np.float32(7e-4)
+    eng.d_dt.fill_(float(dt))
+    want = sim.o.euler_keps(ke, dkde, forces, sim.pos, sim.info, n, float(dt) * 0.5)
+    eng.k.euler_keps(eng.ke2, eng.ke, eng.dkde, eng.forces, eng.pos, eng.info, n, eng.d_dt, 0.5)
+    for name in ("tke", "eps", "turbvisc"):
+        got = _np(eng.ke2[name])[:n]
+        assert np.abs(got / want[name] - 1).max() < 1e-6, name
+    assert np.abs(_np(eng.ke2["eulervel"])[:n] - want["eulervel"]).max() < 1e-7
+    wall = np.concatenate([seg, vx])
+    assert np.array_equal(_bits(_np(eng.ke2["tke"])[:n][wall]), _bits(ke["tke"][wall]))
+
+
+def test_whole_steps_follow_the_oracle():
+    """five predictor-corrector steps: positions, velocities, k, epsilon, eddy viscosity and dt"""
+    prob = lambda: SABox(deltap=0.05, viscosity=KEPS, jitter=0.05)
+    sim, eng = OracleSaSim(prob()), _engine(prob())
+    for _ in range(5):
+        sim.step(); eng.step()
+    n = sim.n
+    fl, seg, vx = _types(sim)
+    assert eng.current_dt() == pytest.approx(sim.dt, rel=1e-5)
+    st = eng.download()
+    assert np.abs(st["pos"][:n, :3] - sim.pos[:n, :3]).max() < 2e-6
+    assert np.abs(st["vel"][:n, :3] - sim.vel[:n, :3]).max() < 1e-4 * np.abs(sim.vel[:n, :3]).max() + 1e-6
+    for name in ("tke", "eps", "turbvisc"):
+        got, want = _np(eng.ke[name])[:n], sim.ke[name]
+        assert np.abs(got - want).max() < 1e-4 * np.abs(want).max(), name
+    k0 = sim.problem.init_keps()[0]
+    assert (sim.ke["tke"][fl] < k0).all() and np.ptp(sim.ke["tke"][fl]) > 0       # decay in the bulk, production at the walls
+
+
+def test_error_behaviour():
+    from gpusph_amd import capi
+    eng = _engine(SABox(deltap=0.08, viscosity=KEPS))
+    eng.build_neibs()
+    K, n = eng.k, eng.n
+    # with KEPSILON uploaded the plain SA entry points refuse a SIMULATE pass ...
+    with pytest.raises(capi.SphxError, match="sphx_forces_basicstep_sa_keps"):
+        K.forces_sa(eng.forces, eng.cfl, eng.pos, eng.vel, eng.info, eng.hash, eng.cellStart, eng.neibslist, eng.gradgamma, eng.boundelements,
+                    eng.vertpos, n, 0, n, 0, cfl_gamma=eng.cfl_gamma)
+    with pytest.raises(capi.SphxError, match="sphx_sa_segment_bc_keps"):
+        K.sa_segment_bc(eng.vel, eng.gradgamma, eng.pos, eng.vertices, eng.boundelements, eng.info, eng.hash, eng.cellStart, eng.neibslist, n, n, 1)
+    with pytest.raises(capi.SphxError, match="sphx_sa_vertex_bc_keps"):
+        K.sa_vertex_bc(eng.vel, eng.gradgamma, eng.pos, eng.info, eng.hash, eng.cellStart, eng.neibslist, n, n, 1)
+    # ... and a k-epsilon entry point refuses a missing buffer
+    with pytest.raises(capi.SphxError, match="missing buffer"):
+        K.forces_sa_keps(eng.forces, eng.cfl, eng.cfl_keps, None, eng.pos, eng.vel, eng.info, eng.hash, eng.cellStart, eng.neibslist,
+                         eng.gradgamma, eng.boundelements, eng.vertpos, eng.ke, n, 0, n, 0, cfl_gamma=eng.cfl_gamma)
+    # k-epsilon without semi-analytical walls is refused at setconstants, like the reference's framework
+    with pytest.raises(capi.SphxError, match="KEPSILON is only supported with SA_BOUNDARY"):
+        _engine(DamBreak3D(0.08, obstacle=False, viscosity=KEPS))
+    # the laminar option set keeps refusing the k-epsilon entry points
+    lam = _engine(SABox(deltap=0.08))
+    lam.build_neibs()
+    with pytest.raises(capi.SphxError, match="not KEPSILON"):
+        lam.k.dtreduce_keps(lam.cfl, 4, lam.d_dt)

@@ -109,3 +109,73 @@ def test_reference_hotdiff_reads_our_files(tmp_path):
     r = subprocess.run([sys.executable, "/root/reference/scripts/hotdiff.py", str(f1), str(f2)],
                        capture_output=True, text=True, timeout=120)
     assert "First difference at particle index 7" in r.stdout
+
+
+def test_option_dependent_property_buffers_round_trip(tmp_path):
+    """Internal Energy / Boundary Elements / Gamma Gradient / Vertices / Volume are stored after Hash, in buffer key order
+    (define_buffers.h:98-220), with the element sizes of their traits"""
+    prob = DamBreak3D(deltap=0.08, obstacle=False)
+    arrs = prob.copy_to_array()
+    n = len(arrs["hash"])
+    rng = np.random.default_rng(2)
+    extra = dict(energy=rng.normal(size=n).astype(np.float32), boundelements=rng.normal(size=(n, 4)).astype(np.float32),
+                 gradgamma=rng.normal(size=(n, 4)).astype(np.float32),
+                 vertices=rng.integers(0, 2**31, size=(n, 4)).astype(np.uint32), vol=rng.random(size=(n, 4)).astype(np.float32))
+    path = tmp_path / "x.bin"
+    hotfile.write_hotfile(path, dict(arrs, **extra), iterations=3, t=0.1, dt=1e-4, host_buffer_count=11)
+    hf = hotfile.read_hotfile(path)
+    for k, v in extra.items():
+        assert np.array_equal(hf["arrays"][k].view(np.uint8), v.view(np.uint8)), k
+    raw = open(path, "rb").read()
+    o, names, sizes = 104, [], []
+    for _ in range(9):
+        ln, nm, el, cnt = struct.unpack(hotfile.BUFFER, raw[o:o + 76])
+        names.append(nm[:ln].decode()); sizes.append(el); o += 76 + el * n
+    assert names == ["Position", "Velocity", "Info", "Hash", "Internal Energy", "Boundary Elements", "Gamma Gradient",
+                     "Vertices", "Volume"]
+    assert sizes == [16, 16, 8, 4, 4, 16, 16, 16, 16] and o == len(raw)
+
+
+def _resume_case(tmp_path, make, extra_keys, buffer_count, steps=(10, 7)):
+    from gpusph_amd.engine import TimestepEngine
+    a = TimestepEngine(make())
+    a.run(steps[0])
+    path = tmp_path / "hot.bin"
+    a.save_hotfile(path)
+    hf0 = hotfile.read_hotfile(path)
+    assert hf0["buffer_count"] == buffer_count
+    for k in extra_keys:
+        assert k in hf0["arrays"], k
+    a.run(steps[1])
+    ref = a.download()
+    ref_extra = {k: t[:a.n].cpu().numpy() for k, t in a._hot_extra().items()}
+    b = TimestepEngine(make())
+    b.load_hotfile(path)
+    b.run(steps[1])
+    out = b.download()
+    assert b.n == a.n and b.current_dt() == a.current_dt()
+    for k in ("pos", "vel", "info", "hash"):
+        assert np.array_equal(np.asarray(out[k]).view(np.uint8), np.asarray(ref[k]).view(np.uint8)), k
+    for k, t in b._hot_extra().items():
+        assert np.array_equal(t[:b.n].cpu().numpy().view(np.uint8), ref_extra[k].view(np.uint8)), k
+
+
+@pytest.mark.gpu
+def test_resume_with_grenier_volumes_is_bit_identical(tmp_path):
+    """SPH_GRENIER: the volumes are the evolving state (the density is recomputed from them): 7 host buffers, Volume stored"""
+    from gpusph_amd import defs as D
+    _resume_case(tmp_path, lambda: DamBreak3D(0.05, obstacle=False, two_fluids=True, formulation=D.SPH_GRENIER,
+                                               viscosity="DYNAMICVISC", density_diffusion=D.DENSITY_DIFFUSION_NONE, jitter=0.1),
+                 ["vol"], 7)
+
+
+@pytest.mark.gpu
+def test_resume_with_internal_energy_is_bit_identical(tmp_path):
+    _resume_case(tmp_path, lambda: DamBreak3D(0.05, obstacle=False, internal_energy=True, jitter=0.1), ["energy"], 6)
+
+
+@pytest.mark.gpu
+def test_resume_with_sa_boundary_is_bit_identical(tmp_path):
+    """SA_BOUNDARY: Boundary Elements, Gamma Gradient and Vertices are particle properties: 8 host buffers"""
+    from gpusph_amd.problem import SABox
+    _resume_case(tmp_path, lambda: SABox(), ["boundelements", "gradgamma", "vertices"], 8)
