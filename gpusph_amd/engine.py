@@ -181,7 +181,7 @@ class TimestepEngine(MultiGpuEngine):
         SA_BOUNDARY, SPS_TURBVISC with SPS, EFFVISC with a generalized Newtonian rheology, VOLUME and SIGMA with
         SPH_GRENIER, INTERNAL_ENERGY with its flag (GPUSPH::allocateGlobalHostBuffers, GPUSPH.cc:868-941)"""
         return (5 + (3 if self.sa else 0) + (1 if self.sps else 0) + (1 if self.effvisc_on else 0)
-                + (2 if self.grenier else 0) + (1 if self.energy_on else 0))
+                + (2 if self.grenier else 0) + (1 if self.energy_on else 0) + (4 if self.keps else 0))     # TKE, EPSILON, TURBVISC, EULERVEL
 
     def _hot_extra(self):
         """the option-dependent particle property buffers a HotFile stores beside pos/vel/info/hash: name -> device tensor"""
@@ -190,6 +190,8 @@ class TimestepEngine(MultiGpuEngine):
             ex["energy"] = self.energy
         if self.sa:
             ex.update(boundelements=self.boundelements, gradgamma=self.gradgamma, vertices=self.vertices)
+        if self.keps:
+            ex.update(self.ke)
         if self.grenier:
             ex["vol"] = self.vol
         return ex

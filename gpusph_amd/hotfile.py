@@ -9,7 +9,8 @@ Layout (native little-endian, C struct padding), as scripts/hotdiff.py of the re
 Stored buffers are the non-ephemeral host buffers (define_buffers.h:279-331: particle properties and support buffers)
 in key order -- "Position" (float4, cell-local), "Velocity" (float4), "Info" (ushort4), "Hash" (uint), then, with the
 options that allocate them (GPUSPH::allocateGlobalHostBuffers, GPUSPH.cc:868-941), "Internal Energy" (float),
-"Boundary Elements", "Gamma Gradient" (float4), "Vertices" (uint4) and "Volume" (float4) -- while
+"Boundary Elements", "Gamma Gradient" (float4), "Vertices" (uint4), the k-epsilon fields "Turbulent Kinetic Energy [k]",
+"Turbulent Dissipation Rate [e]", "Eddy Viscosity" (float), "Eulerian velocity" (float4) and "Volume" (float4) -- while
 header.buffer_count counts ALL host buffers (that includes the ephemeral "Position (double precision)", the SPS and
 effective viscosities and Grenier's sigma: HotFile.cc:91-101 notes the mismatch).
 
@@ -27,9 +28,12 @@ MB_FLOATING, MB_FORCES_MOVING, MB_MOVING = 0, 1, 2
 # name -> (dtype, components); order = buffer key order (src/define_buffers.h:48-58)
 STORED = [("Position", np.float32, 4), ("Velocity", np.float32, 4), ("Info", np.uint16, 4), ("Hash", np.uint32, 1),
           ("Internal Energy", np.float32, 1), ("Boundary Elements", np.float32, 4), ("Gamma Gradient", np.float32, 4),
-          ("Vertices", np.uint32, 4), ("Volume", np.float32, 4)]
+          ("Vertices", np.uint32, 4), ("Turbulent Kinetic Energy [k]", np.float32, 1), ("Turbulent Dissipation Rate [e]", np.float32, 1),
+          ("Eddy Viscosity", np.float32, 1), ("Eulerian velocity", np.float32, 4), ("Volume", np.float32, 4)]
 KEYS = {"Position": "pos", "Velocity": "vel", "Info": "info", "Hash": "hash", "Internal Energy": "energy",
-        "Boundary Elements": "boundelements", "Gamma Gradient": "gradgamma", "Vertices": "vertices", "Volume": "vol"}
+        "Boundary Elements": "boundelements", "Gamma Gradient": "gradgamma", "Vertices": "vertices", "Volume": "vol",
+        "Turbulent Kinetic Energy [k]": "tke", "Turbulent Dissipation Rate [e]": "eps", "Eddy Viscosity": "turbvisc",
+        "Eulerian velocity": "eulervel"}
 REQUIRED = ("pos", "vel", "info", "hash")
 
 

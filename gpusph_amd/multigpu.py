@@ -630,4 +630,5 @@ class MultiGpuEngine:
                 "info": self.info[:n].cpu().numpy().view(np.uint16), "hash": self.hash[:n].cpu().numpy().view(np.uint32),
                 "forces": self.forces[:n].cpu().numpy(),
                 **({"vol": self.vol[:n].cpu().numpy()} if self.grenier else {}),
-                **({"energy": self.energy[:n].cpu().numpy()} if self.energy_on else {})}
+                **({"energy": self.energy[:n].cpu().numpy()} if self.energy_on else {}),
+                **({k: v[:n].cpu().numpy() for k, v in self.ke.items()} if self.keps else {})}

@@ -449,6 +449,8 @@ _MG_CASES = {
                     viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.LAMINAR_FLOW, compvisc=D.DYNAMIC, avgop=D.HARMONIC)), ()),
     # SA walls, density summation + dynamic gamma + Brezzi: every SA pass on the internal particles, then the halo import
     "sa-walls": (dict(problem="SABox", deltap=0.04, options="StillWaterSA", jitter=0.1), ()),
+    # k-epsilon on SA walls: k, epsilon, eddy viscosity and Eulerian velocity with the halo, DKDE with the forces
+    "sa-keps": (dict(problem="SABox", deltap=0.04, jitter=0.1, viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.KEPSILON)), ()),
 }
 
 
@@ -509,6 +511,10 @@ def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename):
         got = np.concatenate([p[k] for p in parts])[order]
         assert np.array_equal(got.view(np.uint32), _np(t)[:n][ro].view(np.uint32)), k
     assert all(float(p["dt"]) == ref.current_dt() for p in parts)
+    if getattr(ref, "keps", False):
+        for k in ("tke", "eps", "turbvisc", "eulervel"):
+            got = np.concatenate([p[k] for p in parts])[order]
+            assert np.array_equal(got.view(np.uint32), _np(ref.ke[k])[:n][ro].view(np.uint32)), k
 
 
 # ---------------------------------------------------------------------------------------------

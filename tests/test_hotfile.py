@@ -175,6 +175,15 @@ def test_resume_with_internal_energy_is_bit_identical(tmp_path):
 
 
 @pytest.mark.gpu
+def test_resume_with_k_epsilon_is_bit_identical(tmp_path):
+    """KEPSILON on SA walls: + TKE, EPSILON, TURBVISC, EULERVEL: 12 host buffers"""
+    from gpusph_amd import defs as D
+    from gpusph_amd.problem import SABox
+    _resume_case(tmp_path, lambda: SABox(viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.KEPSILON)),
+                 ["boundelements", "gradgamma", "vertices", "tke", "eps", "turbvisc", "eulervel"], 12)
+
+
+@pytest.mark.gpu
 def test_resume_with_sa_boundary_is_bit_identical(tmp_path):
     """SA_BOUNDARY: Boundary Elements, Gamma Gradient and Vertices are particle properties: 8 host buffers"""
     from gpusph_amd.problem import SABox
