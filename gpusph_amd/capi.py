@@ -74,6 +74,7 @@ SIGNATURES = {
     "sphx_forces_basicstep_sa_keps": (_i, [_vp] + [_vp] * 20 + [_u32, _u32, _u32, _f, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_euler_keps": (_i, [_vp] + [_vp] * 11 + [_u32, _u32, _f, _vp, _f, _vp]),
     "sphx_forces_dtreduce_keps_device": (_i, [_vp, _vp, _u32, _f, _f, _vp, _vp]),
+    "sphx_forces_dtreduce_keps": (_i, [_vp, _vp, _u32, _f, _f, _vp, _vp]),
     "sphx_neibs_resetinfo": (_i, [_vp, _vp]),
     "sphx_neibs_getinfo": (_i, [_vp, C.POINTER(NeibsInfo), _vp]),
     "sphx_forces_fmax_elements": (_u32, [_u32]),

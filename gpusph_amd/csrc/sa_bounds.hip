@@ -1256,6 +1256,22 @@ extern "C" int sphx_forces_dtreduce_keps_device(sphx_ctx *ctx, const float *cflK
 	return SPHX_OK;
 }
 
+extern "C" int sphx_forces_dtreduce_keps(sphx_ctx *ctx, const float *cflKeps, uint32_t numBlocks, float slength,
+	float max_kinematic, float *h_dt_inout, void *stream)
+{
+	SPHX_REQUIRE(h_dt_inout != nullptr, "sphx_forces_dtreduce_keps: NULL dt");
+	float *d = nullptr;
+	SPHX_HIP(hipMalloc((void**)&d, sizeof(float)));
+	SPHX_HIP(hipMemcpyAsync(d, h_dt_inout, sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream));
+	int rc = sphx_forces_dtreduce_keps_device(ctx, cflKeps, numBlocks, slength, max_kinematic, d, stream);
+	if (rc == SPHX_OK) {
+		SPHX_HIP(hipMemcpyAsync(h_dt_inout, d, sizeof(float), hipMemcpyDeviceToHost, (hipStream_t)stream));
+		SPHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+	}
+	(void)hipFree(d);
+	return rc;
+}
+
 extern "C" int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void *oldGGam, const void *newPos,
 	const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
 	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,

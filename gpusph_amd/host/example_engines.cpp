@@ -220,6 +220,21 @@ int main(int argc, char **argv)
 			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_VERTICES>(), hvert.data(), 16*(size_t)n0));
 			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_BOUNDELEMENTS>(), hbe.data(), 16*(size_t)n0));
 			sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_GRADGAMMA>(), hgg.data(), 16*(size_t)n0));
+			// turbulence_model<KEPSILON>: BUFFER_TKE / EPSILON / TURBVISC / EULERVEL are part of both states (GPUWorker.cc:158-190),
+			// BUFFER_DKDE and BUFFER_CFL_KEPS are written by the forces; uniform start (ProblemCore::init_keps, init_turbvisc: the case
+			// file carries the three values)
+			const bool keps = sp->turbmodel == KEPSILON;
+			if (keps) {
+				saA |= one_buffer<BUFFER_TKE>(A) | one_buffer<BUFFER_EPSILON>(A) | one_buffer<BUFFER_TURBVISC>(A) | one_buffer<BUFFER_EULERVEL>(A);
+				saB |= one_buffer<BUFFER_TKE>(A) | one_buffer<BUFFER_EPSILON>(A) | one_buffer<BUFFER_TURBVISC>(A) | one_buffer<BUFFER_EULERVEL>(A);
+				shared |= one_buffer<BUFFER_DKDE>(A) | one_buffer<BUFFER_CFL_KEPS>(forcesEngine->getFmaxElements(A));
+				std::vector<float> hk(n0, (float)num(c, "keps0", 0)), he(n0, (float)num(c, "keps0", 1)), hn(n0, (float)num(c, "keps0", 2));
+				std::vector<float4> hev(n0, make_float4(0, 0, 0, 0));
+				sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_TKE>(), hk.data(), 4*(size_t)n0));
+				sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_EPSILON>(), he.data(), 4*(size_t)n0));
+				sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_TURBVISC>(), hn.data(), 4*(size_t)n0));
+				sphx_throw(sphx_memcpy_h2d(saA.getData<BUFFER_EULERVEL>(), hev.data(), 16*(size_t)n0));
+			}
 			uint n = n0;
 			BufferList unsorted = posA | velA | saA | shared, sorted = posB | velB | saB | shared;
 			neibsEngine->fixHash(unsorted, unsorted, n);
@@ -245,6 +260,9 @@ int main(int argc, char **argv)
 			// the boundary elements and vertex ids do not change: both states of the integrator see the same ones
 			sphx_throw(sphx_memcpy_d2d(saA.getData<BUFFER_VERTICES>(), as_const(saB).getData<BUFFER_VERTICES>(), 16*(size_t)n));
 			sphx_throw(sphx_memcpy_d2d(saA.getData<BUFFER_BOUNDELEMENTS>(), as_const(saB).getData<BUFFER_BOUNDELEMENTS>(), 16*(size_t)n));
+			if (keps)       // the boundary conditions wrote wall rows of k / epsilon / eulerVel in state B: state A starts from the same fields
+				for (flag_t b : { BUFFER_TKE, BUFFER_EPSILON, BUFFER_TURBVISC, BUFFER_EULERVEL })
+					sphx_throw(sphx_memcpy_d2d(saA[b]->get_buffer(0), as_const(saB)[b]->get_buffer(0), (size_t)n*saB[b]->get_element_size()));
 			BufferList stN = posB | velB | saB | shared, stS = posA | velA | saA | shared;
 			BufferList *cur = &stN, *oth = &stS;
 			float sdt = (float)num(c, "dt0");
@@ -295,6 +313,13 @@ int main(int argc, char **argv)
 			fwrite(hvert.data(), 16, n, o); fwrite(hbe.data(), 16, n, o); fwrite(hgg.data(), 16, n, o); fwrite(hvp.data(), 8, 3*(size_t)n, o);
 			const int32_t counters[4] = { (int32_t)ti.numInteractions, (int32_t)ti.maxFluidBoundaryNeibs, (int32_t)ti.maxVertexNeibs, (int32_t)newNum };
 			fwrite(counters, 4, 4, o);
+			if (keps) {      // k, epsilon, eddy viscosity behind the counters
+				std::vector<float> hk(n);
+				for (flag_t b : { BUFFER_TKE, BUFFER_EPSILON, BUFFER_TURBVISC }) {
+					sphx_throw(sphx_memcpy_d2h(hk.data(), cs[b]->get_buffer(0), 4*(size_t)n));
+					fwrite(hk.data(), 4, n, o);
+				}
+			}
 			fclose(o);
 			printf("example_engines: %s, %u particles, SA initialisation + %u steps, max vertex neighbours %d, t=%g dt=%g\n",
 				str(c, "framework").c_str(), n, steps, (int)ti.maxVertexNeibs, st, sdt);

@@ -410,7 +410,7 @@ public:
 
 	uint basicstep(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint fromParticle,
 		uint toParticle, float deltap, float slength, float dtadaptfactor, float influenceradius,
-		const float, uint *, uint cflOffset, const RunMode run_mode, const int step, const float dt,
+		const float epsilon, uint *, uint cflOffset, const RunMode run_mode, const int step, const float dt,
 		const bool compute_object_forces)
 	{
 		const sphx_params &P = m_c->params();
@@ -425,6 +425,19 @@ public:
 			uint32_t nb = 0;
 			// BUFFER_CFL_GAMMA is there with dynamic gamma and adaptive dt (src/cuda/forces_params.h, dyndt + gamma)
 			const bool gcfl = !(P.simflags & ENABLE_GAMMA_QUADRATURE) && (P.simflags & ENABLE_DTADAPT);
+			if (P.turbmodel == KEPSILON && run_mode == SIMULATE) {
+				// keps_forces_params (src/cuda/forces_params.h:283-320): k, epsilon, eddy viscosity and Eulerian velocity of the
+				// state that is read; BUFFER_DKDE and BUFFER_CFL_KEPS written (BUFFER_TAU is not needed: one launch)
+				sphx_throw(sphx_forces_basicstep_sa_keps(m_c->ctx(), forces, cfl, gcfl ? bufwrite.getData<BUFFER_CFL_GAMMA>() : NULL,
+					(P.simflags & ENABLE_DTADAPT) ? bufwrite.getData<BUFFER_CFL_KEPS>() : NULL, (float*)bufwrite.getData<BUFFER_DKDE>(),
+					bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
+					bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+					bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
+					bufread.getData<BUFFER_TKE>(), bufread.getData<BUFFER_EPSILON>(), bufread.getData<BUFFER_TURBVISC>(),
+					bufread.getData<BUFFER_EULERVEL>(), numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor,
+					influenceradius, epsilon, cflOffset, (int)run_mode, step, dt, &nb, NULL));
+				return nb;
+			}
 			sphx_throw(sphx_forces_basicstep_sa(m_c->ctx(), forces, cfl, gcfl ? bufwrite.getData<BUFFER_CFL_GAMMA>() : NULL,
 				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
 				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
@@ -491,6 +504,10 @@ public:
 		const sphx_params &P = m_c->params();
 		if (P.boundarytype == SA_BOUNDARY && USING_DYNAMIC_GAMMA(P.simflags) && bufread.getData<BUFFER_CFL_GAMMA>())
 			sphx_throw(sphx_forces_dtreduce_gamma(m_c->ctx(), bufread.getData<BUFFER_CFL_GAMMA>(), numParticles, numBlocks, &dt, NULL));
+		if (P.turbmodel == KEPSILON && bufread.getData<BUFFER_CFL_KEPS>() && numBlocks) {
+			// the viscous limit with the largest eddy viscosity added to max_kinematic (src/cuda/forces.cu:585-598)
+			sphx_throw(sphx_forces_dtreduce_keps(m_c->ctx(), bufread.getData<BUFFER_CFL_KEPS>(), numBlocks, slength, max_kinematic, &dt, NULL));
+		}
 		return dt;
 	}
 };
@@ -614,6 +631,13 @@ public:
 		const uint particleRangeEnd, const float dt, const int step, const float t, const float slength,
 		const float influenceRadius, const RunMode run_mode)
 	{
+		if (m_c->params().turbmodel == KEPSILON && run_mode == SIMULATE)
+			// keps_euler_params (src/cuda/euler_params.h:101-119): k, epsilon old/new, the eddy viscosity, DKDE; the Eulerian velocity
+			sphx_throw(sphx_euler_keps(m_c->ctx(), bufwrite.getData<BUFFER_TKE>(), bufwrite.getData<BUFFER_EPSILON>(),
+				bufwrite.getData<BUFFER_TURBVISC>(), bufwrite.getData<BUFFER_EULERVEL>(), bufread.getData<BUFFER_TKE>(),
+				bufread.getData<BUFFER_EPSILON>(), bufread.getData<BUFFER_EULERVEL>(), (const float*)bufread.getData<BUFFER_DKDE>(),
+				bufread.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(),
+				numParticles, particleRangeEnd, dt, NULL, 1.0f, NULL));
 		if ((m_c->params().simflags & ENABLE_INTERNAL_ENERGY) && run_mode == SIMULATE)
 			// energy_euler_params (src/cuda/euler_params.h:121-134): BUFFER_INTERNAL_ENERGY old/new, its rate from the forces pass
 			sphx_throw(sphx_euler_internal_energy(m_c->ctx(), bufwrite.getData<BUFFER_INTERNAL_ENERGY>(),
@@ -675,6 +699,16 @@ public:
 		const uint particleRangeEnd, const float deltap, const float slength, const float influenceradius,
 		const int step, const RunMode run_mode)
 	{
+		if (m_c->params().turbmodel == KEPSILON && run_mode != REPACK) {
+			// sa_segment_bc_params with has_keps (src/cuda/sa_bc_params.h:152-200): k, epsilon and the Eulerian velocity in place
+			sphx_throw(sphx_sa_segment_bc_keps(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+				bufwrite.getData<BUFFER_TKE>(), bufwrite.getData<BUFFER_EPSILON>(), bufwrite.getData<BUFFER_EULERVEL>(),
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VERTICES>(), bufread.getData<BUFFER_BOUNDELEMENTS>(),
+				bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
+				bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, deltap, slength, influenceradius,
+				step, SPHX_SIMULATE, NULL));
+			return;
+		}
 		sphx_throw(sphx_sa_segment_bc(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
 			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VERTICES>(), bufread.getData<BUFFER_BOUNDELEMENTS>(),
 			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
@@ -691,6 +725,15 @@ public:
 		const int step, const bool, const float, uint*, const uint, const uint, const uint, const RunMode run_mode)
 	{
 		// sa_vertex_bc_params takes pos from the read list and vel / gGam from the write list (src/cuda/sa_bc_params.h)
+		if (m_c->params().turbmodel == KEPSILON && run_mode != REPACK) {
+			sphx_throw(sphx_sa_vertex_bc_keps(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+				bufwrite.getData<BUFFER_TKE>(), bufwrite.getData<BUFFER_EPSILON>(), bufwrite.getData<BUFFER_EULERVEL>(),
+				bufread.getData<BUFFER_VERTICES>(), bufread.getData<BUFFER_BOUNDELEMENTS>(),
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+				bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd,
+				deltap, slength, influenceradius, step, SPHX_SIMULATE, NULL));
+			return;
+		}
 		sphx_throw(sphx_sa_vertex_bc(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
 			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
 			bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd,

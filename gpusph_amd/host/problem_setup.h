@@ -164,6 +164,17 @@ static SimFramework *make_framework(Case const& c)
 			periodicity<PERIODIC_NONE>,
 			add_flags<ENABLE_DTADAPT | ENABLE_REPACKING | ENABLE_GAMMA_QUADRATURE>
 		);
+	} else if (name == "StillWaterSAKeps") {   // StillWaterSA's options with turbulence_model<KEPSILON> (the GenericProblem selector, src/problems/GenericProblem.h:201)
+		SETUP_FRAMEWORK(
+			kernel<WENDLAND>,
+			formulation<SPH_F1>,
+			rheology<NEWTONIAN>,
+			turbulence_model<KEPSILON>,
+			boundary<SA_BOUNDARY>,
+			periodicity<PERIODIC_NONE>,
+			densitydiffusion<BREZZI>,
+			add_flags<ENABLE_DTADAPT | ENABLE_DENSITY_SUM>
+		);
 	} else if (name == "CompleteSaExample") {   // src/problems/CompleteSaExample.cu:39-47: compiles and constructs; its physics is not built
 		SETUP_FRAMEWORK(
 			kernel<WENDLAND>,

@@ -346,6 +346,9 @@ int sphx_euler_keps(sphx_ctx *ctx, float *newTke, float *newEps, float *newTurbV
 	float dt, const float *d_dt, float dt_scale, void *stream);
 int sphx_forces_dtreduce_keps_device(sphx_ctx *ctx, const float *cflKeps, uint32_t numBlocks, float slength,
 	float max_kinematic, float *d_dt, void *stream);
+/* the same on a host value (synchronous), for the reference's blocking dtreduce */
+int sphx_forces_dtreduce_keps(sphx_ctx *ctx, const float *cflKeps, uint32_t numBlocks, float slength,
+	float max_kinematic, float *h_dt_inout, void *stream);
 
 /* ---- AbstractForcesEngine ----------------------------------------------------------------- */
 uint32_t sphx_forces_fmax_elements(uint32_t n);       /* getFmaxElements, src/cuda/forces.cu:539-543 */

@@ -137,5 +137,8 @@ def read_out(path):
         out["boundelements"] = np.frombuffer(raw, np.float32, 4 * n, o).reshape(n, 4); o += 16 * n
         out["gradgamma"] = np.frombuffer(raw, np.float32, 4 * n, o).reshape(n, 4); o += 16 * n
         out["vertpos"] = [np.frombuffer(raw, np.float32, 2 * n, o + 8 * n * k).reshape(n, 2) for k in range(3)]; o += 24 * n
-        out["counters"] = np.frombuffer(raw, np.int32, 4, o)
+        out["counters"] = np.frombuffer(raw, np.int32, 4, o); o += 16
+        if len(raw) - o == 12 * n:  # turbulence_model<KEPSILON>: k, epsilon, eddy viscosity
+            for k, name in enumerate(("tke", "eps", "turbvisc")):
+                out[name] = np.frombuffer(raw, np.float32, n, o + 4 * n * k)
     return out

@@ -202,6 +202,40 @@ class OracleKernels:
                                         _p(vertpos[2]), C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
                                         C.c_float(self.sp.deltap)))
 
+    # ---- turbulence<KEPSILON>: the interface of HipKernels' *_keps methods
+    def sa_segment_bc_keps(self, vel, ggam, ke, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step):
+        self.L.orc_sa_segment_bc_keps(C.byref(self.op), _p(vel), _p(ggam), _p(ke["tke"]), _p(ke["eps"]), _p(ke["eulervel"]), _p(pos),
+                                      _p(vertices), _p(boundelements), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
+                                      C.c_uint32(range_end), C.c_int(step), C.c_float(self.sp.deltap))
+
+    def sa_vertex_bc_keps(self, vel, ggam, ke, vertices, boundelements, pos, info, hash_, cellStart, neibslist, n, range_end, step):
+        self.L.orc_sa_vertex_bc_keps(C.byref(self.op), _p(vel), _p(ggam), _p(ke["tke"]), _p(ke["eps"]), _p(ke["eulervel"]), _p(pos),
+                                     _p(vertices), _p(boundelements), _p(info), _p(hash_), _p(cellStart), _p(neibslist), C.c_uint32(range_end))
+
+    def forces_sa_keps(self, forces, cfl, cfl_keps, dkde, pos, vel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, ke,
+                       n, frm, to, cfl_offset, cfl_gamma=None, epsilon=5e-5):
+        if to > frm:
+            forces[frm:to] = 0
+        strain = torch.zeros((dkde.shape[0], 6), dtype=torch.float32)
+        self.L.orc_forces_sa_keps.restype = C.c_uint32
+        return int(self.L.orc_forces_sa_keps(C.byref(self.op), _p(forces), _p(cfl), _p(cfl_gamma), _p(cfl_keps), _p(dkde), _p(strain),
+                                             _p(pos), _p(vel), _p(info), _p(hash_), _p(cellStart), _p(neibslist), _p(ggam), _p(boundelements),
+                                             _p(vertpos[0]), _p(vertpos[1]), _p(vertpos[2]), _p(ke["tke"]), _p(ke["eps"]), _p(ke["turbvisc"]),
+                                             _p(ke["eulervel"]), C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
+                                             C.c_float(self.sp.deltap), C.c_float(epsilon)))
+
+    def euler_keps(self, new, old, dkde, forces, old_pos, info, n, d_dt, dt_scale):
+        dt = float(np.float32(d_dt[0].item()) * np.float32(dt_scale))
+        self.L.orc_euler_keps(C.byref(self.op), _p(new["tke"]), _p(new["eps"]), _p(new["turbvisc"]), _p(new["eulervel"]), _p(old["tke"]),
+                              _p(old["eps"]), _p(old["eulervel"]), _p(dkde), _p(forces), _p(old_pos), _p(info), C.c_uint32(n), C.c_float(dt))
+
+    def dtreduce_keps(self, cfl_keps, nblocks, d_dt):
+        f = np.float32
+        h = f(self.op.slength)
+        mx = f(cfl_keps[:nblocks].max().item()) if nblocks else f(0)
+        dt_visc = f(f(h * h) / f(f(self.max_kinvisc) + mx)) * f(0.125)
+        d_dt[0] = min(float(d_dt[0]), float(dt_visc))
+
     def dtreduce_gamma(self, cfl_gamma, n, nblocks, d_dt):
         base = ((n + 3) // 4) * 4
         mx = float(cfl_gamma[base:base + nblocks].max()) if nblocks else 0.0

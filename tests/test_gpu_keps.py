@@ -183,6 +183,34 @@ def test_whole_steps_follow_the_oracle():
     assert (sim.ke["tke"][fl] < k0).all() and np.ptp(sim.ke["tke"][fl]) > 0       # decay in the bulk, production at the walls
 
 
+def test_cpp_adapters_step_a_k_epsilon_problem(tmp_path):
+    """four steps through the abstract engines of the GPUSPH tree (framework: StillWaterSA's options + turbulence_model<KEPSILON>):
+    HIPForcesEngine::basicstep / dtreduce, HIPPredCorrEngine::basicstep and HIPBoundaryConditionsEngine take their k-epsilon
+    branches from the BufferList (TKE, EPSILON, TURBVISC, EULERVEL, DKDE, CFL_KEPS); bit-equal to the Python driver"""
+    import os, subprocess
+    import host_case as hc
+    exe = hc.exe("example_engines")
+    assert os.path.exists(exe)
+    prob = SABox(deltap=0.05, jitter=0.1, viscosity=KEPS)
+    eng = _engine(prob)
+    n = prob.num_particles
+    case = tmp_path / "case.txt"
+    k0 = prob.init_keps()
+    lines = hc.case_lines(prob, "StillWaterSAKeps", allocated=eng.alloc) + hc.driver_lines(prob, eng, 4) + ["keps0 %.9g %.9g %.9g" % k0]
+    case.write_text("\n".join(lines) + "\n")
+    hc.write_state(str(tmp_path / "state.bin"), prob.copy_to_array())
+    r = subprocess.run([exe, str(case), str(tmp_path / "state.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = hc.read_out(str(tmp_path / "out.bin"))
+    eng.run(4)
+    assert out["n"] == n
+    for name in ("pos", "vel", "gradgamma"):
+        assert np.array_equal(_bits(out[name]), _bits(_np(getattr(eng, name))[:n])), name
+    for name in ("tke", "eps", "turbvisc"):
+        assert np.array_equal(_bits(out[name]), _bits(_np(eng.ke[name])[:n])), name
+    assert np.float32(out["dt"]) == np.float32(eng.current_dt())
+
+
 def test_error_behaviour():
     from gpusph_amd import capi
     eng = _engine(SABox(deltap=0.08, viscosity=KEPS))

@@ -229,6 +229,9 @@ FIDELITY_CASES = {
     # density / gamma pass is followed by the import of what it wrote, the vertex offsets of the halo segments after the list build
     "sa-density-sum": dict(problem="SABox", deltap=0.05, options="StillWaterSA", jitter=0.1),
     "sa-quadrature": dict(problem="SABox", deltap=0.05, options="StillWaterRepackSA", jitter=0.1),
+    # k-epsilon on SA walls: k, epsilon, eddy viscosity and Eulerian velocity travel with the halo, DKDE with the forces, the
+    # boundary conditions export the wall rows they wrote
+    "sa-keps": dict(problem="SABox", deltap=0.05, jitter=0.1, viscosity=dict(rheologytype=1, turbmodel=3)),
 }
 
 
