@@ -21,6 +21,11 @@ cases = [
     ("internal energy (AccuracyTest options)", lambda: DamBreak3D(dp, obstacle=False, internal_energy=True, density_diffusion=D.DENSITY_DIFFUSION_NONE)),
     ("PAPANASTASIOU Poiseuille", lambda: Poiseuille(int(round(1.0 / (dp * 1.6))), rheology=D.PAPANASTASIOU)),
 ]
+if os.environ.get("SA_CASES"):      # the SA tank (StillWaterSA's options), laminar and with the k-epsilon model
+    from gpusph_amd.problem import SABox
+    sdp = float(os.environ["SA_CASES"])
+    cases = [("SA walls, laminar", lambda: SABox(sdp, jitter=0.05)),
+             ("SA walls, k-epsilon", lambda: SABox(sdp, jitter=0.05, viscosity=dict(rheologytype=D.NEWTONIAN, turbmodel=D.KEPSILON)))]
 for name, make in cases:
     prob = make()
     eng = TimestepEngine(prob, device="cuda:0")
