@@ -158,9 +158,11 @@ def test_euler_step_of_k_and_epsilon(pair):
     assert np.array_equal(_bits(_np(eng.ke2["tke"])[:n][wall]), _bits(ke["tke"][wall]))
 
 
-def test_whole_steps_follow_the_oracle():
-    """five predictor-corrector steps: positions, velocities, k, epsilon, eddy viscosity and dt"""
-    prob = lambda: SABox(deltap=0.05, viscosity=KEPS, jitter=0.05)
+@pytest.mark.parametrize("options", ["StillWaterSA", "StillWaterRepackSA"])
+def test_whole_steps_follow_the_oracle(options):
+    """five predictor-corrector steps in both SA forms (density summation + dynamic gamma + Brezzi; continuity equation + gamma by
+    quadrature): positions, velocities, k, epsilon, eddy viscosity and dt"""
+    prob = lambda: SABox(deltap=0.05, viscosity=KEPS, jitter=0.05, options=options)
     sim, eng = OracleSaSim(prob()), _engine(prob())
     for _ in range(5):
         sim.step(); eng.step()
