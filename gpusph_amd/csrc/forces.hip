@@ -34,7 +34,9 @@ struct ForcesArgs {
 	uint32_t tauPackN;
 	// tiled kernel: the tile lists of this neighbour list (tile_lists_kernel), [rows][stride] uint16, and the rows per wave
 	const uint16_t *tileList; uint32_t tileListRows, tileListStride;
-	const uint32_t *tileWaves;
+	const uint32_t *tileWaves;   // [tile][8]: rows of the fluid section | rows of the boundary section << 16 | chunk << 28, per WAVE
+	const uint32_t *tileRows;    // [tile][TILE_ROWDESC]: the window rows (tile_lists_kernel)
+	const uint16_t *tileOwnSlot; // [particle]: byte offset of the particle's own row in its tile's window
 	float4 *xsph;        // ENABLE_XSPH: mean velocity correction of fluid particles, else NULL
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
@@ -42,8 +44,9 @@ struct ForcesArgs {
 	int compute_object_forces;
 	uint32_t *pin;              // always NULL (see pin_batch)
 	unsigned long long *prof;   // SPHX_TILE_DEBUG & 16: per-workgroup phase times (100 MHz ticks), else NULL
-	int dbg;   // SPHX_TILE_DEBUG bits, timing experiments only (results are wrong with 1 or 2): 1 = skip the pair loops,
-	           // 2 = skip the window staging, 4 = plain round-robin tile order instead of the XCD-aware one, 16 = phase timers
+	int dbg;   // SPHX_TILE_DEBUG bits, timing experiments only (results are wrong with 1, 2, 32): 1 = skip the pair loops,
+	           // 2 = skip the window staging, 4 = plain round-robin tile order instead of the XCD-aware one, 16 = phase timers,
+	           // 32 = the list walk re-reads its first batches (no HBM list stream), 64 = alternating wave priorities in the pair loop
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -585,7 +588,7 @@ __device__ __forceinline__ void tile_group_done(uint32_t *tileCtl)
 // by per-XCD ticket counters.  DESIGN.md 5.2 has the full account.
 // ==========================================================================================
 // list entries of one section, TILE_AHEAD batches deep: buffer q[j] holds batch j (mod TILE_AHEAD)
-struct ListWindow { uint32_t q[TILE_AHEAD][TILE_NB]; };
+struct ListWindow { uint2 q[TILE_AHEAD]; };   // a batch = 4 uint16 entries in 8 bytes
 
 // workgroup barrier that orders LDS traffic only.  __syncthreads() is a release/acquire fence over ALL address
 // spaces: with global stores or loads in flight it drains vmcnt, i.e. it exposes an HBM round trip (the forces
@@ -601,54 +604,53 @@ __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballo
 
 // Tile lists.  The reference-format neighbour list (u16 entries: index within the neighbour cell, cell code on the
 // first entry of each cell run) costs the pair loop a running cell code, two dependent LDS table look-ups (code ->
-// first window slot of that cell as seen from the home cell, then the row itself) and a per-lane "still alive" flag:
-// ~14 of ~70 vector instructions per pair plus a serial LDS round trip.  All of that depends only on the list and the
-// tiling, i.e. it changes once per neighbour-list build, not once per forces pass (20 passes per build), so
-// tile_lists_kernel (below) does it at build time and leaves, per stored neighbour, one uint16:
-//     bits 4..15   slot of the neighbour's row in the tile's window, i.e. entry & 0xFFF0 = its LDS byte offset (the window
-//                  arrays are parallel, 16 B per row, <= 4095 rows)
-//     bits 0..3    how far the cell code advances at this entry (codes only grow along a list: the reference visits the 27
-//                  cells in code order); the running code*16 is the byte offset of the shift-table entry.  A jump of more
-//                  than 15 codes is spelled with filler entries (dummy row, advance 15)
-// (A first version kept both offsets in a uint32: two instructions less per pair, but 9.9 GB of list traffic per forces
-// pass at 32 M particles instead of 4.9, at a point where the pass moves 4 TB/s.)
+// first window slot of that cell as seen from the home cell, then the row itself), the shift of the own position into
+// the neighbour's cell frame and a per-lane "still alive" flag: ~20 of ~70 vector instructions per pair plus a serial
+// LDS round trip.  All of that depends only on the list and the tiling, i.e. it changes once per neighbour-list build,
+// not once per forces pass (20 passes per build), so tile_lists_kernel (below) does it at build time and leaves, per
+// stored neighbour, one uint16: the byte offset of the neighbour's row in the tile's window (slot * 16; the window arrays
+// are parallel, 16 B per row, <= 4095 rows).  The cell shift is gone from the pair altogether because the window holds
+// positions in one frame per tile (tile_shift, sphx_internal.h): the wave that stages a window row converts it.
+// (Round 2 kept cell-local positions and a 4-bit code advance in the entry: 7 more vector instructions and one more
+// 16-byte LDS read per pair.)
 // Rows [0, nF) hold the fluid section, rows [R-nB, R) the boundary section (first entry in row R-1, like the
 // reference's list runs down from neibboundpos); nF and nB are PER WAVE (multiples of TILE_LIST_BATCH): lanes with
-// shorter lists are padded with the offset of a dummy row (mass 0, far away), so the pair loop has a scalar trip
-// count, no terminator test and no validity flag.  The pair loop is wave-uniform, so the batch number is a scalar
-// and the four rows of a batch are addressed as buffer loads: SGPR descriptor (row base) + SGPR row offset + the
-// per-lane byte offset index*2, which is fixed for the whole tile -- no vector address arithmetic at all.
-struct ListRows { const uint16_t *list; uint32_t rowBytes; uint32_t rows; uint32_t *pin; };
+// shorter lists are padded with offset 0, a dummy row (mass 0, far away), so the pair loop has a scalar trip
+// count, no terminator test and no validity flag.  In memory the four rows of a batch are interleaved per particle
+// ([batch][particle][4] uint16), so a lane fetches a whole batch with ONE 8-byte buffer load -- a quarter of the vector
+// memory instructions of a row-per-load layout, whose 2-byte loads kept the CU's address unit busy for half of the
+// pair loop's duration.  The pair loop is wave-uniform, so the batch number is a scalar: SGPR descriptor (slab base) +
+// the per-lane byte offset index*8, which is fixed for the whole tile -- no vector address arithmetic at all.
+struct ListRows { const uint16_t *list; uint32_t batchBytes; uint32_t rows; uint32_t *pin; int dbg; };
 
-__device__ __forceinline__ void load_list_u(const ListRows &lr, uint32_t voff, int sec, int batch, uint32_t nd[TILE_NB])
+typedef uint32_t list_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load_list_u(const ListRows &lr, uint32_t voff, int sec, int batch, uint2 &nd)
 {
 	// batches past a section's end are never consumed (the walk stops there); the clamp only keeps the
-	// prefetch in bounds.  No branch around the loads: the compiler must be able to count them (s_waitcnt vmcnt(N)).
-	const int b = min(__builtin_amdgcn_readfirstlane(batch), (int)lr.rows/TILE_NB - 1);
-	const int lowRow = sec ? (int)lr.rows - (b*TILE_NB + TILE_NB) : b*TILE_NB;
-	const uint16_t *row = lr.list + (size_t)lowRow*(lr.rowBytes/2u);
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(row), 0, 0xFFFFFFFF, 0x00020000);
-#pragma unroll
-	for (int k = 0; k < TILE_NB; ++k) {
-		const int up = sec ? TILE_NB - 1 - k : k;     // rows above lowRow
-		nd[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc, (int)voff, (int)(up*lr.rowBytes), 0);
-	}
+	// prefetch in bounds.  No branch around the load: the compiler must be able to count it (s_waitcnt vmcnt(N)).
+	int b = min(__builtin_amdgcn_readfirstlane(batch), (int)lr.rows/TILE_NB - 1);
+	if (lr.dbg & 32) b &= 3;    // timing experiment: the walk re-reads its first batches (cache hits instead of the HBM stream)
+	const int slab = sec ? (int)lr.rows/TILE_NB - 1 - b : b;
+	const char *base = reinterpret_cast<const char*>(lr.list) + (size_t)slab*lr.batchBytes;
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xFFFFFFFF, 0x00020000);
+	const list_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, 0, 0);
+	nd = make_uint2(d.x, d.y);
 }
 
 // LLVM sinks a load whose first use is three ring steps (and several side exits) away down to that use, which
 // undoes the prefetch distance.  A use in a never-taken side block (pin is always NULL, but a kernel argument
 // the compiler cannot see through) keeps the loads where they are issued; the main path pays one scalar branch.
-__device__ __forceinline__ void pin_batch(const ListRows &lr, const uint32_t nd[TILE_NB])
+__device__ __forceinline__ void pin_batch(const ListRows &lr, const uint2 &nd)
 {
 	if (__builtin_expect(lr.pin != nullptr, 0))
-		lr.pin[threadIdx.x] = nd[0] ^ nd[1] ^ nd[2] ^ nd[3];
+		lr.pin[threadIdx.x] = nd.x ^ nd.y;
 }
 
 __device__ __forceinline__ void preload_list(const ListRows &lr, uint32_t voff, int sec, ListWindow &lw)
 {
 #pragma unroll
 	for (int j = 0; j < TILE_AHEAD; ++j)
-		load_list_u(lr, voff, sec, j, lw.q[j]);   // rows 0..TILE_AHEAD*TILE_NB-1 always exist (tile_list_rows >= 16)
+		load_list_u(lr, voff, sec, j, lw.q[j]);   // batches 0..TILE_AHEAD-1 always exist (tile_list_rows >= 16)
 }
 
 struct StressAcc { float x, y, z, w, u; };   // stress mode: the accumulators that do not fit the float4 of the forces
@@ -679,7 +681,6 @@ __device__ __forceinline__ void stress_interact(const DevParams &p, const Self &
 struct Gathered {
 	float4 npos[TILE_HB], nvel[TILE_HB], naux[TILE_HB];
 	float ntau[TILE_HB][6];   // SPS only
-	float qx[TILE_HB], qy[TILE_HB], qz[TILE_HB], qw[TILE_HB];   // own position in the neighbour's cell frame; the influence radius
 };
 
 __device__ __forceinline__ const float4 &lds_row(const float4 *base, uint32_t byteOffset)
@@ -687,23 +688,17 @@ __device__ __forceinline__ const float4 &lds_row(const float4 *base, uint32_t by
 	return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byteOffset);
 }
 
-// stage 1 of the pair pipeline: issue the LDS reads of TILE_HB neighbours.  A tile-list entry holds the byte offsets
-// of the neighbour's window row and of the own-position shift into that neighbour's cell frame (sShift[code]:
-// d_cell_to_offset order, src/cuda/forces.cu:376-386: code-1 = (x+1) + 3(y+1) + 9(z+1)); nothing here depends on a
-// previous LDS read, so the round trips overlap with the arithmetic of the previous pairs.
+// stage 1 of the pair pipeline: issue the LDS reads of TILE_HB neighbours.  A tile-list entry IS the byte offset of the
+// neighbour's row in the window arrays (positions in the tile's frame, see tile_shift): no decode, nothing here depends
+// on a previous LDS read, so the round trips overlap with the arithmetic of the previous pairs.
 template<int TURB>
-__device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
-	const float4 *sShift, const float4 *sPos, const float4 *sVel, const float4 *sAux, uint32_t &codeOff, Gathered &g)
+__device__ __forceinline__ void gather_half(uint32_t packed, const float4 *sPos, const float4 *sVel, const float4 *sAux, Gathered &g)
 {
+	static_assert(TILE_HB == 2, "a half batch is one 32-bit word of the tile list");
 	constexpr uint32_t WS = TILE_WC(TURB) + 1u;
 #pragma unroll
 	for (int k = 0; k < TILE_HB; ++k) {
-		const uint32_t d = nd[k];
-		const uint32_t L = d & 0xFFF0u;
-		codeOff += (d & 0xFu) << 4;                 // v_and + v_lshl_add
-		const float4 sh = lds_row(sShift, codeOff);
-		// == fmaf(-ox, cellsize, pos): ox in {-1,0,1}, so the product is exact
-		g.qx[k] = s.pos.x + sh.x; g.qy[k] = s.pos.y + sh.y; g.qz[k] = s.pos.z + sh.z; g.qw[k] = sh.w;
+		const uint32_t L = k ? packed >> 16 : packed & 0xFFFFu;
 		g.npos[k] = lds_row(sPos, L); g.nvel[k] = lds_row(sVel, L);
 		if (!(TURB & SPHX_TURB_STRESS)) g.naux[k] = lds_row(sAux, L);
 		if (TURB_MODEL(TURB) == SPHX_SPS) {   // the SPS rows lie behind the EOS rows: sAux[WS + slot], sAux[2 WS + slot]
@@ -714,31 +709,35 @@ __device__ __forceinline__ void gather_half(const uint32_t *nd, const Self &s,
 }
 
 // Two pairs at once on packed fp32 (v_pk_mul/add/fma_f32: two results per instruction at the issue cost of one).
-// Same operations in the same order as pair_interact for each of the two pairs -- every packed lane is an IEEE
-// mul/add/fma -- so the results are the bits pair_interact gives.  What is packed: everything computed from computed
-// values (r^2, v.r, F, g.r, the viscous and diffusive coefficients).  What is not: the first consumer of every value
+// Same terms in the same order as pair_interact for each of the two pairs.  What is packed: everything computed from
+// computed values (r^2, v.r, F, g.r, the viscous and diffusive coefficients).  What is not: the first consumer of every value
 // read from LDS (the two rows sit in unrelated registers; pairing them up would cost the moves the packing saves),
 // sqrt / rcp / min / compares / selects (no packed forms), and the accumulation into force (list order is kept).
 // Instantiated for the Wendland kernel with artificial viscosity, one fluid, no or Colagrossi diffusion.
+// Two things differ from pair_interact by rounding only: the positions are in the tile's frame (r_ij = x_i - x_j of two
+// shifted positions instead of a shift applied to x_i alone), and the window stores m_j * fcoeff (the constant factor of F
+// is folded into the mass when the window is staged), so F here is the bare (q - 2)^3.
+// The momentum switch of a lane (boundary particles without force feedback accumulate no acceleration) is applied once per
+// particle after the walk, not per pair.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f pk_splat(float a) { return v2f{a, a}; }
 
 template<int COLAGROSSI>
-__device__ __forceinline__ void pair_interact_pk(const DevParams &p, const Self &s, float inv_h, const Gathered &g,
-	bool valid, bool rt_momentum, bool rt_diffuse, float4 &force)
+__device__ __forceinline__ void pair_interact_pk(const DevParams &p, const Self &s, const float3 &q, float inv_h, const Gathered &g,
+	bool valid, bool rt_diffuse, float4 &force)
 {
 	static_assert(TILE_HB == 2, "two pairs per packed operation");
 	const float4 &n0 = g.npos[0], &n1 = g.npos[1];
-	const v2f rx = {g.qx[0] - n0.x, g.qx[1] - n1.x}, ry = {g.qy[0] - n0.y, g.qy[1] - n1.y}, rz = {g.qz[0] - n0.z, g.qz[1] - n1.z};
+	const v2f rx = {q.x - n0.x, q.x - n1.x}, ry = {q.y - n0.y, q.y - n1.y}, rz = {q.z - n0.z, q.z - n1.z};
 	const v2f r2 = pk_fma(rz, rz, pk_fma(ry, ry, rx*rx));
 	const v2f r = {fast_sqrt(r2.x), fast_sqrt(r2.y)};
-	const bool on0 = valid && (r.x < g.qw[0]), on1 = valid && (r.y < g.qw[1]);
+	const bool on0 = valid && (r.x < p.influenceradius), on1 = valid && (r.y < p.influenceradius);
 	const float4 &w0 = g.nvel[0], &w1 = g.nvel[1];
 	const v2f vx = {s.vel.x - w0.x, s.vel.x - w1.x}, vy = {s.vel.y - w0.y, s.vel.y - w1.y}, vz = {s.vel.z - w0.z, s.vel.z - w1.z};
 	const v2f vel_dot_pos = pk_fma(vz, rz, pk_fma(vy, ry, vx*rx));
 	const v2f qm2 = pk_fma(r, pk_splat(inv_h), pk_splat(-2.0f));
-	const v2f f = qm2*qm2*qm2*pk_splat(p.fcoeff);
+	const v2f f = qm2*qm2*qm2;                       // fcoeff rides in the window's mass
 	const float4 &a0 = g.naux[0], &a1 = g.naux[1];   // {P/rho^2, c, P, rho}
 	const float m0 = n0.w*f.x, m1 = n1.w*f.y;
 	const v2f mf = {on0 ? m0 : 0.0f, on1 ? m1 : 0.0f};
@@ -766,32 +765,35 @@ __device__ __forceinline__ void pair_interact_pk(const DevParams &p, const Self 
 	const v2f iden = {fast_rcp(den.x), fast_rcp(den.y)};
 	const v2f visc = vdpn*pk_splat(p.slength*p.artvisccoeff)*ssum*iden;
 	kk = pk_fma(visc, mf, kk);
-	const float k0 = rt_momentum ? kk.x : 0.0f, k1 = rt_momentum ? kk.y : 0.0f;
-	force.x = fmaf(k0, rx.x, force.x); force.y = fmaf(k0, ry.x, force.y); force.z = fmaf(k0, rz.x, force.z);
-	force.x = fmaf(k1, rx.y, force.x); force.y = fmaf(k1, ry.y, force.y); force.z = fmaf(k1, rz.y, force.z);
+	force.x = fmaf(kk.x, rx.x, force.x); force.y = fmaf(kk.x, ry.x, force.y); force.z = fmaf(kk.x, rz.x, force.z);
+	force.x = fmaf(kk.y, rx.y, force.x); force.y = fmaf(kk.y, ry.y, force.y); force.z = fmaf(kk.y, rz.y, force.z);
 }
 
-// stage 2: the pair interactions of a gathered half, in list order
+// the instantiations whose pair loop is pair_interact_pk: their window holds m * fcoeff
+template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
+struct TilePk { static constexpr bool value = KERNEL == SPHX_WENDLAND && TURB == SPHX_ARTIFICIAL && COLAGROSSI != DIFF_FERRARI && !LJ; };
+
+// stage 2: the pair interactions of a gathered half, in list order; q = own position in the tile's frame
 // LJ = the run uses LJ_BOUNDARY: pairs of the boundary section (ljsec, wave-uniform) and all pairs of boundary
 // particles with force feedback (ljlane) are Lennard-Jones repulsions instead of SPH interactions
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
-__device__ __forceinline__ void compute_half(const DevParams &p, const Gathered &g, const Self &s, float inv_h,
+__device__ __forceinline__ void compute_half(const DevParams &p, const Gathered &g, const Self &s, const float3 &q, float inv_h,
 	bool take, bool momentum, bool diffuse, bool ljsec, bool ljlane, float4 &force, StressAcc &fx)
 {
 	if (TURB & SPHX_TURB_STRESS) {   // velocity-gradient sums of the SPS stress tensor: force = dv[0..3], fx = dv[4..8]
 #pragma unroll
 		for (int k = 0; k < TILE_HB; ++k)
-			stress_interact<KERNEL>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k], g.npos[k], g.nvel[k], take, force, fx);
+			stress_interact<KERNEL>(p, s, inv_h, q.x, q.y, q.z, g.npos[k], g.nvel[k], take, force, fx);
 		return;
 	}
 	if (LJ && ljsec) {
 #pragma unroll
 		for (int k = 0; k < TILE_HB; ++k)
-			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], take, force);
+			lj_interact(p, q.x, q.y, q.z, g.npos[k], take, force);
 		return;
 	}
-	if (KERNEL == SPHX_WENDLAND && TURB == SPHX_ARTIFICIAL && COLAGROSSI != DIFF_FERRARI && !LJ) {
-		pair_interact_pk<COLAGROSSI>(p, s, inv_h, g, take, momentum, diffuse, force);
+	if (TilePk<KERNEL, TURB, COLAGROSSI, LJ>::value) {
+		pair_interact_pk<COLAGROSSI>(p, s, q, inv_h, g, take, diffuse, force);
 		return;
 	}
 	const bool anyLj = LJ && wave_any(ljlane);
@@ -799,10 +801,10 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 	for (int k = 0; k < TILE_HB; ++k) {
 		uint32_t nfl = 0u;
 		if (TURB & SPHX_TURB_MF) nfl = __float_as_uint(g.naux[k].y) & 3u;     // fluid number tag of the EOS row
-		pair_interact<KERNEL, TURB, COLAGROSSI, true, true>(p, s, inv_h, g.qx[k], g.qy[k], g.qz[k],
-			g.npos[k], g.nvel[k], g.naux[k], nfl == s.fl, take && !(LJ && ljlane), g.ntau[k], force, momentum, diffuse, nfl, false, g.qw[k]);
+		pair_interact<KERNEL, TURB, COLAGROSSI, true, true>(p, s, inv_h, q.x, q.y, q.z,
+			g.npos[k], g.nvel[k], g.naux[k], nfl == s.fl, take && !(LJ && ljlane), g.ntau[k], force, momentum, diffuse, nfl, false);
 		if (anyLj)
-			lj_interact(p, g.qx[k], g.qy[k], g.qz[k], g.npos[k], take && ljlane, force);
+			lj_interact(p, q.x, q.y, q.z, g.npos[k], take && ljlane, force);
 	}
 }
 
@@ -820,7 +822,7 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 //    once in the kernel (the instruction cache is 64 KB; four template copies did not fit).
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListRows &list,
-	uint32_t voff, const Self &s, float inv_h, const float4 *sShift,
+	uint32_t voff, const Self &s, const float3 &q, float inv_h,
 	const float4 *sPos, const float4 *sVel, const float4 *sAux,
 	int sec, int rows, bool take, bool momentum, bool diffuse, bool ljlane,
 	ListWindow &lw /* batches 0..preloaded-1 already requested */, int preloaded, float4 &force, StressAcc &fx)
@@ -836,20 +838,25 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	}
 	int left = nb;
 	Gathered A, B;
-	uint32_t codeOff = 0;   // running cell code * 16 of this lane's walk through the section
-	gather_half<TURB>(lw.q[0], s, sShift, sPos, sVel, sAux, codeOff, A);
+	gather_half<TURB>(lw.q[0].x, sPos, sVel, sAux, A);
 	// one batch per step; the first half of the NEXT batch is gathered before the second half of this one is computed,
 	// also after the last batch (a clamped, in-bounds prefetch whose rows are never computed): one exit per step and no
 	// second copy of the pair code
+	// SPHX_TILE_DEBUG & 64: the two waves of a SIMD (w and w + 4) take turns at being the one the issue arbiter prefers, batch by
+	// batch (priorities 3,0,3,0.. against 2,1,2,1..); left alone the older wave always wins and the younger one runs the last
+	// quarter of every tile alone, at the issue rate of a single wave
+	const bool prio = (list.dbg & 64) != 0, hiw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
 #define SPHX_RING_STEP(J, JN) \
-	gather_half<TURB>(lw.q[J] + TILE_HB, s, sShift, sPos, sVel, sAux, codeOff, B); \
-	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
+	if (prio) { if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } \
+	            else { if ((J) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); } } \
+	gather_half<TURB>(lw.q[J].y, sPos, sVel, sAux, B); \
+	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
 	load_list_u(list, voff, sec, next, lw.q[J]); \
 	pin_batch(list, lw.q[J]); \
 	++next; \
-	gather_half<TURB>(lw.q[JN], s, sShift, sPos, sVel, sAux, codeOff, A); \
-	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
-	if (--left == 0) return;
+	gather_half<TURB>(lw.q[JN].x, sPos, sVel, sAux, A); \
+	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
+	if (--left == 0) { if (prio) __builtin_amdgcn_s_setprio(0); return; }
 	for (;;) {
 		SPHX_RING_STEP(0, 1)
 		SPHX_RING_STEP(1, 2)
@@ -884,7 +891,7 @@ __device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t tid, u
 }
 
 // a thread's own rows and the first batches of its neighbour list, requested one tile ahead
-struct TileOwn { particleinfo info; float4 pos, vel, aux; uint32_t hash; ListWindow lwF; uint32_t lwB0[TILE_NB]; uint32_t waveRows; };
+struct TileOwn { particleinfo info; uint32_t hash, slot; ListWindow lwF; uint2 lwB0; };
 
 // tail of SPSstressMatrixDevice (src/cuda/visc_kernel.cu:780-811): shear rate -> nu_SPS, tau
 __device__ __forceinline__ void stress_finalize(const DevParams &p, const ForcesArgs &a, uint32_t index, float rho,
@@ -911,6 +918,32 @@ __device__ __forceinline__ void stress_finalize(const DevParams &p, const Forces
 	}
 }
 
+// the two window rows a wave stages (wave w: rows w and w + 8), from tile_rows.  The six words are requested one tile
+// ahead and only turned into scalars (the LDS-DMA destination and the trip counts derive from them) when their tile
+// starts: a readfirstlane at request time would wait for the load there and then
+struct RowRaw { uint32_t w[6]; };
+struct RowJobs { uint32_t start[2], total[2], base[2]; bool contig[2]; };
+__device__ __forceinline__ void request_row_jobs(const uint32_t *__restrict__ tileRows, uint32_t tile, uint32_t wave, RowRaw &r)
+{
+	const uint32_t *d = tileRows + (size_t)TILE_ROWDESC*tile;
+	r.w[0] = d[wave]; r.w[1] = d[wave + 8u];
+	r.w[2] = d[16u + (wave >> 1)]; r.w[3] = d[20u + (wave >> 1)];
+	r.w[4] = d[24u + (wave >> 1)]; r.w[5] = d[28u + (wave >> 1)];
+}
+__device__ __forceinline__ void resolve_row_jobs(const RowRaw &r, uint32_t wave, RowJobs &j)
+{
+	const uint32_t sh = 16u*(wave & 1u);
+#pragma unroll
+	for (int k = 0; k < 2; ++k) {
+		j.start[k] = __builtin_amdgcn_readfirstlane(r.w[k]);
+		const uint32_t tb = __builtin_amdgcn_readfirstlane((r.w[2 + k] >> sh) & 0xFFFFu);
+		const uint32_t bb = __builtin_amdgcn_readfirstlane((r.w[4 + k] >> sh) & 0xFFFFu);
+		j.total[k] = tb; j.base[k] = bb & 0x7FFFu; j.contig[k] = !(bb & 0x8000u);
+	}
+}
+
+#define TILE_HCH 5   // 64-record chunks of a window row whose cell hashes are fetched along with the DMA (longer rows: later)
+
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __global__ void __launch_bounds__(TILE_THREADS, 2)
 forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
@@ -920,21 +953,17 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	constexpr uint32_t WC = TILE_WC(TURB);
 	constexpr bool SPSW = TURB_MODEL(TURB) == SPHX_SPS;
 	constexpr bool STRESS = (TURB & SPHX_TURB_STRESS) != 0;   // stress mode: no EOS rows, every active particle walks both sections
+	constexpr bool PREMUL = TilePk<KERNEL, TURB, COLAGROSSI, LJ>::value;   // the window holds m * fcoeff (pair_interact_pk)
 	constexpr uint32_t WS = WC + 1;   // window arrays: the dummy row the pad entries of the tile lists point to (slot 0) + WC records
 	__shared__ __attribute__((aligned(16))) float4 sPos[WS];
 	__shared__ __attribute__((aligned(16))) float4 sVel[WS];
 	__shared__ __attribute__((aligned(16))) float4 sAux[SPSW ? 3*WS : WS];   // SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}
-	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW];    // ... relative to the start of its window row (never modified after the scan)
-	__shared__ uint32_t sCnt[TILE_WROWS*TILE_KW];
-	__shared__ uint32_t sStart[TILE_WROWS*TILE_KW];
-	__shared__ uint32_t sRowStart[TILE_WROWS], sRowTotal[TILE_WROWS], sRowContig[TILE_WROWS];
-	__shared__ float sWaveMax[TILE_THREADS/64];
 	__shared__ uint32_t sTileQ[2];                                 // [0] first tile, [1] next tile of this workgroup
-	__shared__ __attribute__((aligned(16))) float4 sShift[32];   // cell code -> own-position shift (x,y,z)
 
 	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this launch
 	const uint32_t numTiles = tileCtl[0];
 	const uint32_t tid = threadIdx.x;
+	const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	// XCD-aware tile assignment: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), each XCD has its own
 	// 4 MB L2.  Consecutive tiles are neighbouring row bundles that share window rows, so in every round of
 	// gridDim tiles XCD x takes the 32 CONSECUTIVE tiles [x*32, x*32+32) instead of every 8th one: the
@@ -970,21 +999,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		sTileQ[1] = resolve(n1);
 	}
 	__syncthreads();
-	uint32_t tile = sTileQ[0];
+	uint32_t tile = __builtin_amdgcn_readfirstlane(sTileQ[0]);
 	if (tile >= tileEnd) {
 		if (tid == 0) tile_group_done(tileCtl);
 		return;
 	}
 
-	if (tid < 32) {   // published by the first barrier of the tile loop
-		const int c = (int)tid - 1;                // d_cell_to_offset order: c = (x+1) + 3(y+1) + 9(z+1)
-		const bool real = c >= 0 && c < 27;
-		const int cz = c/9, cy = (c - cz*9)/3;
-		const int ox = real ? c - cz*9 - cy*3 - 1 : 0, oy = real ? cy - 1 : 0, oz = real ? cz - 1 : 0;
-		// .w = the influence radius: the pair's range test reads it from here, which makes the whole 16-byte entry live
-		// (a 12-byte LDS read costs twice the LDS cycles of a 16-byte one, MI355X_MICROARCH.md LDS table)
-		sShift[tid] = make_float4(-(float)ox*p.cs[0], -(float)oy*p.cs[1], -(float)oz*p.cs[2], p.influenceradius);
-	}
 	if (tid == 32) {   // the dummy row (slot 0): no mass, a kilometre away, finite everywhere -> every term of the pair is +-0
 		sPos[0] = make_float4(1.0e3f, 1.0e3f, 1.0e3f, 0.0f);
 		sVel[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -993,174 +1013,185 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	}
 	const float inv_h = fast_rcp(p.slength);
 	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
-	ListRows listRows; listRows.list = a.tileList; listRows.rowBytes = a.tileListStride*(uint32_t)sizeof(uint16_t);
-	listRows.rows = a.tileListRows; listRows.pin = a.pin;
-	const int wr = (int)(tid/TILE_KW), wcol = (int)(tid - (tid/TILE_KW)*TILE_KW);   // my window cell (tid < 256)
+	ListRows listRows; listRows.list = a.tileList; listRows.batchBytes = a.tileListStride*(uint32_t)(TILE_NB*sizeof(uint16_t));
+	listRows.rows = a.tileListRows; listRows.pin = a.pin; listRows.dbg = a.dbg;
 
-	// software pipeline over tiles: the descriptor and the window-cell extents of the NEXT tile are
-	// fetched while the current one computes, so a tile costs one memory round trip (the window DMA)
+	// software pipeline over tiles: descriptor, window rows, own rows and first list batches of the NEXT tile are fetched
+	// while the current one computes, so a tile costs one memory round trip (the window DMA)
 	uint32_t dc[TILE_DESC], dn[TILE_DESC];
 #pragma unroll
 	for (int k = 0; k < TILE_DESC; ++k) dc[k] = tiles[(size_t)TILE_DESC*tile + k];
-	uint32_t wStart = 0, wCnt = 0;
-	if (tid < TILE_WROWS*TILE_KW)
-		window_cell(p, a.cellStart, cellEnd, (int)dc[0], (int)dc[1], (int)dc[2], (int)dc[3], wr, wcol, wStart, wCnt);
+	RowRaw rrc, rrn;
+	request_row_jobs(a.tileRows, tile, wave, rrc);
+	// the 64 home particles this wave owns (a "chunk" of the tile's thread -> particle map) and the rows of their two list
+	// sections: tile_lists_kernel pairs long chunks with short ones on the waves w and w + 4, which share a SIMD
+	uint32_t wrc = a.tileWaves[(size_t)tile*(TILE_THREADS/64) + wave], wrn = 0;
 
-	__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): first descriptor and window extents
-	// own rows and first list batches: always requested one tile ahead (here: for the first tile), consumed
-	// after the window barrier of their tile.  Their ~28 vector memory instructions per thread cost ~3 us of
-	// address-unit issue per tile, which now overlaps the previous tile's pair loop instead of sitting at the
-	// head of the staging chain.
-	auto request_own = [&](const TileHome &h, uint32_t t, TileOwn &o) {
-		o.info = a.info[h.li]; o.pos = a.pos[h.li]; o.vel = a.vel[h.li]; o.hash = a.hash[h.li];
-		if (!STRESS) o.aux = a.aux[h.li];
-		o.waveRows = a.tileWaves[(size_t)t*(TILE_THREADS/64) + (tid >> 6)];
-		const uint32_t vo = h.li*2u;   // byte offset of this particle inside every list row (n < 2^31)
+	__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): first descriptor
+	// own info, hash, window slot and first list batches: always requested one tile ahead (here: for the first tile), consumed
+	// after the window barrier of their tile; a thread's own position / velocity / EOS row are read from the staged window
+	// (its home cell is part of it), not from memory
+	auto request_own = [&](const TileHome &h, TileOwn &o) {
+		o.info = a.info[h.li]; o.hash = a.hash[h.li]; o.slot = a.tileOwnSlot[h.li];
+		const uint32_t vo = h.li*(uint32_t)(TILE_NB*sizeof(uint16_t));   // byte offset of this particle inside every batch slab
 		preload_list(listRows, vo, 0, o.lwF);
 		// boundary section: most particles have none, so only its first batch is requested up front; the walk
 		// requests the rest when a wave does have boundary neighbours
 		load_list_u(listRows, vo, 1, 0, o.lwB0);
 	};
-	TileHome hc = tile_home(dc, tid, a.fromParticle, a.toParticle);
+	TileHome hc = tile_home(dc, (wrc >> 28)*64u + lane, a.fromParticle, a.toParticle);
 	TileOwn own;
-	if (hc.inRange) request_own(hc, tile, own);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
-	const bool prof = a.prof != nullptr && tid == 0;
-	unsigned long long tBegin = 0, t0 = 0, tA = 0, tB = 0, accStage = 0, accPairs = 0, accTail = 0, s1 = 0, s2 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+	if (hc.inRange) request_own(hc, own);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
+	// SPHX_TILE_DEBUG & 16: every wave adds up where its time goes (100 MHz ticks): 0 total, 1 top barrier (the slowest wave
+	// of the previous tile), 2 DMA + hash issue, 3 landing, 4 conversion, 5 window barrier, 6 set-up + requests of the next
+	// tile, 7 pair loop, 8 drain + finalize, 9 tiles
+	const bool prof = a.prof != nullptr;
+	unsigned long long tBegin = 0, tp = 0, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SPHX_PROF(K) do { if (prof) { const unsigned long long tq = wall_clock64(); pacc[K] += tq - tp; tp = tq; } } while (0)
 	if (prof) tBegin = wall_clock64();
+	float cflRun = 0.0f;   // largest CFL term of this lane's particles over all tiles of the workgroup
+	const int gs1 = p.gs1;
 	for (;;) {
-		if (prof) t0 = wall_clock64();
+		if (prof) tp = wall_clock64();
 		uint32_t drawn = 0;
 		if (tid == 0) drawn = atomicAdd(tileCtl + 4 + src, 1u);   // the tile after next; consumed after the window barrier
-		const int ncells = (int)dc[3];
-		const uint32_t firstMin = hc.firstMin;
+		const int g2 = (int)dc[0], g3 = (int)dc[1], ca = (int)dc[2], ncells = (int)dc[3];
 		const bool inRange = hc.inRange, mine = hc.mine;
 		const uint32_t index = hc.index;
 		const bool pairs = ((dc[13] & 1u) || STRESS) && (a.dbg & 3) != 1;   // no fluid anywhere in the window: nothing interacts
-		const uint32_t voff = hc.li*2u;
+		const uint32_t voff = hc.li*(uint32_t)(TILE_NB*sizeof(uint16_t));
 
 		lds_barrier();   // the previous tile's readers are done with LDS
-		const uint32_t nextTile = sTileQ[1];
+		SPHX_PROF(1);
+		const uint32_t nextTile = __builtin_amdgcn_readfirstlane(sTileQ[1]);
 		const bool haveNext = nextTile < tileEnd;
 		if (haveNext) {
 #pragma unroll
 			for (int k = 0; k < TILE_DESC; ++k) dn[k] = tiles[(size_t)TILE_DESC*nextTile + k];
 		}
-		if (prof) { s1 = wall_clock64(); s2 = s1; }
+		RowJobs rjc;
+		resolve_row_jobs(rrc, wave, rjc);
 
-		if (inRange && pairs) {
-			// 1. prefix of the window-cell counts within each row (16-lane segmented scans), row extents
-			if (tid < TILE_WROWS*TILE_KW) {
-				uint32_t incl = wCnt;
-				uint32_t lo = wCnt ? wStart : 0xFFFFFFFFu;
-				uint32_t hi = wCnt ? wStart + wCnt : 0u;
+		// 1. the window: wave w stages rows w and w + 8 (a row is ~3 chunks of 64 records per array) by LDS DMA and fetches
+		//    the cell hash of every record along with it; when both have landed it moves ITS rows into the tile's frame
+		//    (tile_shift of the record's cell: row from the row number, column from the hash) -- no other wave has to wait for
+		//    that, the one barrier below publishes the finished window
+		uint32_t hsh[2][TILE_HCH];
+		if (inRange && pairs && (a.dbg & 3) != 2) {
 #pragma unroll
-				for (int dd = 1; dd < TILE_KW; dd <<= 1) {
-					const uint32_t t = __shfl_up(incl, dd, TILE_KW);
-					if (wcol >= dd) incl += t;
+			for (int k = 0; k < 2; ++k) {
+				const uint32_t total = rjc.total[k], base = rjc.base[k], rs = rjc.start[k];
+#pragma unroll
+				for (int c = 0; c < TILE_HCH; ++c) hsh[k][c] = 0u;
+				if (!total || base + total > WC || !rjc.contig[k]) continue;
+				stage_row_wave(a.pos + rs, sPos + 1 + base, total, lane);
+				stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
+				if (!STRESS) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
+				if (SPSW) {
+					stage_row_wave(a.tauPack + rs, sAux + WS + 1 + base, total, lane);
+					stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + 2*WS + 1 + base, total, lane);
 				}
 #pragma unroll
-				for (int dd = TILE_KW/2; dd > 0; dd >>= 1) {
-					lo = min(lo, (uint32_t)__shfl_xor(lo, dd, TILE_KW));
-					hi = max(hi, (uint32_t)__shfl_xor(hi, dd, TILE_KW));
-				}
-				sCnt[tid] = wCnt; sStart[tid] = wStart;
-				sCellRel[tid] = incl - wCnt;
-				// one DMA per row needs the cells to lie in memory in window order: each non-empty cell starts where
-				// the previous ones end.  (Extent == count alone is not enough: a periodic row that is wholly inside
-				// the window has the wrapped column first in the window but last in memory.)
-				uint32_t inOrder = (wCnt == 0u || wStart - lo == incl - wCnt) ? 1u : 0u;
-#pragma unroll
-				for (int dd = TILE_KW/2; dd > 0; dd >>= 1)
-					inOrder &= (uint32_t)__shfl_xor(inOrder, dd, TILE_KW);
-				if (wcol == TILE_KW - 1) {
-					sRowTotal[wr] = incl;
-					sRowStart[wr] = lo;
-					sRowContig[wr] = (incl == 0u || (hi - lo == incl && inOrder)) ? 1u : 0u;
-				}
+				for (int c = 0; c < TILE_HCH; ++c)
+					if ((uint32_t)c*64u + lane < total) hsh[k][c] = a.hash[rs + (uint32_t)c*64u + lane];
 			}
-			lds_barrier();
-			if (prof) s2 = wall_clock64();
-			// 2. row bases: every wave scans the 16 row totals in its first 16 lanes; then the window DMA, with
-			//    the rows dealt out to the waves (wave w stages rows w, w+8, ...: a row is ~3 chunks of 64 records
-			//    per array, so walking all rows in every wave left most waves idle behind a serial 16-step loop)
-			const uint32_t lane = tid & 63u, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-			const uint32_t rowTot = (lane < TILE_WROWS) ? sRowTotal[lane] : 0u;
-			uint32_t rowIncl = rowTot;
+		}
+		if (haveNext) {   // behind the DMA in the memory pipeline, consumed when the next tile starts
+			request_row_jobs(a.tileRows, nextTile, wave, rrn);
+			wrn = a.tileWaves[(size_t)nextTile*(TILE_THREADS/64) + wave];
+		}
+		SPHX_PROF(2);
+		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA, hashes (and its own rows, list batches) have landed
+		SPHX_PROF(3);
+		if (inRange && pairs && (a.dbg & 3) != 2) {
 #pragma unroll
-			for (int dd = 1; dd < TILE_WROWS; dd <<= 1) {
-				const uint32_t t = __shfl_up(rowIncl, dd, 64);
-				if ((int)lane >= dd) rowIncl += t;
-			}
-			const uint32_t rowBase = rowIncl - rowTot;
-			static_assert(TILE_WROWS <= 64, "row totals are scanned inside one wave");
-#pragma unroll 1
-			for (uint32_t r = wave; r < TILE_WROWS; r += TILE_THREADS/64) {
-				const uint32_t total = __builtin_amdgcn_readlane(rowTot, r);
-				const uint32_t base = __builtin_amdgcn_readlane(rowBase, r);
-				if (base + total > WC || (a.dbg & 3) == 2 || !total) continue;   // cannot overflow for tiles of build_tiles_kernel
-				if (sRowContig[r]) {
-					const uint32_t rs = __builtin_amdgcn_readfirstlane(sRowStart[r]);
-					stage_row_wave(a.pos + rs, sPos + 1 + base, total, lane);
-					stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
-					if (!STRESS) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
-					if (SPSW) {
-						stage_row_wave(a.tauPack + rs, sAux + WS + 1 + base, total, lane);
-						stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + 2*WS + 1 + base, total, lane);
-					}
-				} else {   // a row crossing cell-type segments (multi-GPU device maps not split on COORD3)
+			for (int k = 0; k < 2; ++k) {
+				const uint32_t total = rjc.total[k], base = rjc.base[k], rs = rjc.start[k];
+				const int r = (int)wave + 8*k;
+				if (!total || base + total > WC) continue;     // cannot overflow for tiles of build_tiles_kernel
+				if (rjc.contig[k]) {
+					const int h0 = window_row_hash0(p, g2, g3, r) + ca - 1;      // cell hash of window column 0 of this row
+					auto shifted = [&](float4 P, uint32_t h) {
+						int col = (int)(h & CELLTYPE_BITMASK) - h0;
+						if (col > ncells + 1) col -= gs1;        // the window wraps around a periodic COORD1
+						if (col < 0) col += gs1;
+						const float3 sh = tile_shift(p, ncells, r, col);
+						P.x += sh.x; P.y += sh.y; P.z += sh.z;
+						if (PREMUL) P.w *= p.fcoeff;
+						return P;
+					};
+					float4 P[TILE_HCH];      // all reads of the row in flight, then the arithmetic, then the writes
+#pragma unroll
+					for (int c = 0; c < TILE_HCH; ++c)
+						if ((uint32_t)c*64u + lane < total) P[c] = sPos[1u + base + (uint32_t)c*64u + lane];
+#pragma unroll
+					for (int c = 0; c < TILE_HCH; ++c)
+						if ((uint32_t)c*64u + lane < total) sPos[1u + base + (uint32_t)c*64u + lane] = shifted(P[c], hsh[k][c]);
+					for (uint32_t q = (uint32_t)TILE_HCH*64u + lane; q < total; q += 64u) sPos[1u + base + q] = shifted(sPos[1u + base + q], a.hash[rs + q]);
+				} else {   // a row that is not one range in memory (cell-type segments of a device map not split on COORD3,
+					       // a periodic row lying wholly inside the window): cell by cell, in window order
+					uint32_t off = 0;
 					for (int col = 0; col < ncells + 2; ++col) {
-						const uint32_t cnt = sCnt[r*TILE_KW + col], st = sStart[r*TILE_KW + col], cb = 1u + base + sCellRel[r*TILE_KW + col];
+						const uint32_t h = window_cell_hash(p, g2, g3, ca, ncells, r, col);
+						if (h == 0xFFFFFFFFu) continue;
+						const uint32_t st = a.cellStart[h];
+						if (st == CELL_EMPTY) continue;
+						const uint32_t cnt = cellEnd[h] - st, cb = 1u + base + off;
+						const float3 sh = tile_shift(p, ncells, r, col);
 						for (uint32_t q = lane; q < cnt; q += 64u) {
-							sPos[cb + q] = a.pos[st + q]; sVel[cb + q] = a.vel[st + q];
+							float4 P = a.pos[st + q];
+							P.x += sh.x; P.y += sh.y; P.z += sh.z;
+							if (PREMUL) P.w *= p.fcoeff;
+							sPos[cb + q] = P; sVel[cb + q] = a.vel[st + q];
 							if (!STRESS) sAux[cb + q] = a.aux[st + q];
 							if (SPSW) { sAux[WS + cb + q] = a.tauPack[st + q]; sAux[2*WS + cb + q] = a.tauPack[a.tauPackN + st + q]; }
 						}
+						off += cnt;
 					}
 				}
 			}
 		}
-		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA (and its own rows, list batches) have landed
-		__syncthreads();                      // ... everybody's have; the tables are published
+		SPHX_PROF(4);
+		__syncthreads();                      // everybody's rows are in place and converted
+		SPHX_PROF(5);
 		if (tid == 0) sTileQ[1] = resolve(drawn);   // read after the first barrier of the next iteration
-		if (prof) tA = wall_clock64();
-		// prefetch the next tile's window-cell extents (two independent loads, consumed at the end of the iteration)
-		uint32_t nCS = CELL_EMPTY, nCE = 0;
-		if (haveNext && tid < TILE_WROWS*TILE_KW) {
-			const uint32_t h = window_cell_hash(p, (int)dn[0], (int)dn[1], (int)dn[2], (int)dn[3], wr, wcol);
-			if (h != 0xFFFFFFFFu) { nCS = a.cellStart[h]; nCE = cellEnd[h]; }
-		}
 		TileHome hn = hc;
 		TileOwn ownNext;
 		if (haveNext) {
-			hn = tile_home(dn, tid, a.fromParticle, a.toParticle);
-			if (hn.inRange) request_own(hn, nextTile, ownNext);
+			hn = tile_home(dn, (wrn >> 28)*64u + lane, a.fromParticle, a.toParticle);
+			if (hn.inRange) request_own(hn, ownNext);
 		}
 		const particleinfo info = own.info;
-		const float4 pos = own.pos;
+		// own rows from the window (already in the tile's frame); a tile whose window was not staged (no fluid in reach) has
+		// only wall particles at home: they read the dummy row and write zeros
+		const uint32_t oslot = (inRange && pairs) ? own.slot : 0u;
+		const float4 opos = lds_row(sPos, oslot), ovel = lds_row(sVel, oslot);
+		const float3 q = make_float3(opos.x, opos.y, opos.z);
 		Self s;
-		s.pos = pos; s.vel = own.vel;
-		s.gridPos = grid_pos_from_hash(p, own.hash & CELLTYPE_BITMASK);
+		s.pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.gridPos = make_int3(0, 0, 0);     // cell-local position: finalize stage, on demand
+		s.vel = ovel;
 		s.fl = (TURB & SPHX_TURB_MF) ? FLUID_NUM(info) : 0u;
 		if (STRESS) {
-			s.rho = (own.vel.w + 1.0f)*p.rho0[0];
+			s.rho = (ovel.w + 1.0f)*p.rho0[0];
 		} else {
-			s.p_precalc = own.aux.x; s.sspeed = own.aux.y; s.P = own.aux.z; s.rho = own.aux.w;
-			s.inv_rho = fast_rcp(own.aux.w);
+			const float4 oaux = lds_row(sAux, oslot);
+			s.p_precalc = oaux.x; s.sspeed = oaux.y; s.P = oaux.z; s.rho = oaux.w;
+			s.inv_rho = fast_rcp(oaux.w);
 		}
 		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
-		if (SPSW) {   // own stress tensor (hc.li is a valid row for idle lanes too)
-			const float4 ta = a.tauPack[hc.li], tb = a.tauPack[a.tauPackN + hc.li];
+		if (SPSW) {   // own stress tensor
+			const float4 ta = lds_row(sAux + WS, oslot), tb = lds_row(sAux + 2*WS, oslot);
 			s.tau[0] = ta.x; s.tau[1] = ta.y; s.tau[2] = ta.z; s.tau[3] = ta.w; s.tau[4] = tb.x; s.tau[5] = tb.y;
 		}
 		ListWindow lwB;
-#pragma unroll
-		for (int k = 0; k < TILE_NB; ++k) lwB.q[0][k] = own.lwB0[k];
+		lwB.q[0] = own.lwB0;
 
-		// 3. pair loop for the tile's own particles (<= 512, one per thread); wave-uniform control
+		// 2. pair loop for the tile's own particles (<= 512, one per thread); wave-uniform control
 		float cfl_term = 0.0f;
-		const bool active = mine && is_active_w(pos.w);
+		const bool active = mine;     // home particles sit in cells, i.e. they are active
 		float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		StressAcc fx = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+		SPHX_PROF(6);
 		if (inRange && pairs) {
 			const uint32_t ptype = PART_TYPE(info);
 			const bool isFluid = ptype == PT_FLUID, isBound = ptype == PT_BOUNDARY, isDynBound = isBound && dyn;
@@ -1171,55 +1202,57 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			const bool ljlane = LJ && isBound;
 			const bool take0 = active && (STRESS || isFluid || isDynBound || (ljlane && HAS_COMPUTE_FORCE(info) && a.compute_object_forces));
 			const bool take1 = active && (STRESS || (isFluid && (dyn || LJ)));
-			const int rowsF = (int)(own.waveRows & 0xFFFFu), rowsB = (int)(own.waveRows >> 16);
+			const int rowsF = (int)(wrc & 0xFFFFu), rowsB = (int)((wrc >> 16) & 0xFFFu);
 			if (wave_any(take0))
-				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift,
+				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, q, inv_h,
 					sPos, sVel, sAux, 0, rowsF, take0, momentum, true, ljlane, own.lwF, TILE_AHEAD, force, fx);
 			if (wave_any(take1))
-				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, inv_h, sShift,
+				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, q, inv_h,
 					sPos, sVel, sAux, 1, rowsB, take1, momentum, false, false, lwB, 1, force, fx);
+			if (PREMUL && !momentum) { force.x = 0.0f; force.y = 0.0f; force.z = 0.0f; }   // see pair_interact_pk
 		}
-		if (prof) tB = wall_clock64();
-		// vmcnt(0): only the list batches fetched past the terminators and the next tile's window extents are in
-		// flight, all long complete; from here to the loop head only stores are issued, which nobody waits for
+		SPHX_PROF(7);
+		// vmcnt(0): only the list batches fetched past the section ends are in flight, all long complete; from here to the
+		// loop head only stores are issued, which nobody waits for
 		__builtin_amdgcn_s_waitcnt(0x0F70);
-		const uint32_t nCSv = nCS, nCEv = nCE;
-		if (prof) s1 = wall_clock64();
 		if (active) {
 			if (STRESS) stress_finalize(p, a, index, s.rho, force, fx);
-			else cfl_term = finalize_particle(p, a, index, info, s, force);
-		}
-		if (prof) s2 = wall_clock64();
-		// 4. CFL: the array keeps the reference's one-entry-per-128-particles layout
-		// (getFmaxElements); tiles are not 128-aligned, so they max into the entry of their first
-		// particle.  Non-negative floats order like their bit patterns; the caller zeroed CFL.
-		if (!STRESS && a.cfl && inRange) {
-#pragma unroll
-			for (int dd = 32; dd > 0; dd >>= 1)
-				cfl_term = fmaxf(cfl_term, __shfl_down(cfl_term, dd));
-			if ((tid & 63u) == 0) sWaveMax[tid >> 6] = cfl_term;
-			lds_barrier();
-			if (tid == 0) {
-				float m = sWaveMax[0];
-				for (int w = 1; w < TILE_THREADS/64; ++w) m = fmaxf(m, sWaveMax[w]);
-				const uint32_t rel = firstMin > a.fromParticle ? firstMin - a.fromParticle : 0u;
-				atomicMax(reinterpret_cast<unsigned int*>(a.cfl + a.cflOffset + rel/SPHX_BLOCK_FORCES), __float_as_uint(m));
+			else {
+				// planes, terrain and rigid-body rows need the cell-local position, the mass and the cell: few runs, few particles
+				const bool geom = (PART_TYPE(info) == PT_FLUID && (p.simflags & (SPHX_ENABLE_PLANES | SPHX_ENABLE_DEM))) ||
+					(HAS_COMPUTE_FORCE(info) && a.rbforces);
+				if (geom) { s.pos = a.pos[index]; s.gridPos = grid_pos_from_hash(p, own.hash & CELLTYPE_BITMASK); }
+				cfl_term = finalize_particle(p, a, index, info, s, force);
 			}
 		}
-		if (prof) { const unsigned long long tC = wall_clock64(); accStage += tA - t0; acc1 += s1 - tB; acc2 += s2 - s1; acc3 += tC - s2; accPairs += tB - tA; accTail += tC - tB; }
+		cflRun = fmaxf(cflRun, cfl_term);
+		SPHX_PROF(8);
+		if (prof) pacc[9] += 1;
 		if (!haveNext) break;
-		const uint32_t nStart = (nCSv != CELL_EMPTY) ? nCSv : 0u, nCnt = (nCSv != CELL_EMPTY) ? nCEv - nCSv : 0u;
 		tile = nextTile;
 #pragma unroll
 		for (int k = 0; k < TILE_DESC; ++k) dc[k] = dn[k];
-		wStart = nStart; wCnt = nCnt;
+		rrc = rrn; wrc = wrn;
 		hc = hn; own = ownNext;
 	}
-	if (tid == 0) tile_group_done(tileCtl);
-	if (prof) {
-		unsigned long long *o = a.prof + 8*(size_t)blockIdx.x;
-		o[0] = wall_clock64() - tBegin; o[1] = accStage; o[2] = accPairs; o[3] = accTail; o[4] = acc1; o[5] = acc2; o[6] = acc3; o[7] = 0;
+	// CFL: the array is only ever max-reduced (fmaxDevice / dtreduce), so the maxima need not sit in the reference's
+	// one-entry-per-128-particles places: every wave maxes its running value into one entry of the caller's range, once per
+	// launch.  Non-negative floats order like their bit patterns; the caller zeroed CFL.
+	if (!STRESS && a.cfl) {
+#pragma unroll
+		for (int dd = 32; dd > 0; dd >>= 1)
+			cflRun = fmaxf(cflRun, __shfl_down(cflRun, dd));
+		if (lane == 0 && a.numBlocks)
+			atomicMax(reinterpret_cast<unsigned int*>(a.cfl + a.cflOffset + (blockIdx.x*(TILE_THREADS/64) + wave) % a.numBlocks), __float_as_uint(cflRun));
 	}
+	if (tid == 0) tile_group_done(tileCtl);
+	if (prof && lane == 0) {
+		unsigned long long *o = a.prof + 10*((size_t)blockIdx.x*(TILE_THREADS/64) + wave);
+		pacc[0] = wall_clock64() - tBegin;
+#pragma unroll
+		for (int k = 0; k < 10; ++k) o[k] = pacc[k];
+	}
+#undef SPHX_PROF
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1507,6 +1540,7 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 	const int diff = (p.densitydiff == SPHX_COLAGROSSI) ? DIFF_COLAGROSSI : (p.densitydiff == SPHX_FERRARI) ? DIFF_FERRARI : DIFF_NONE;
 	const bool newt = p.rheology == SPHX_NEWTONIAN;
 	const uint32_t *guard = use_tiles ? ctx->tile_ctl + 1 : nullptr;
+	const bool standby = !use_tiles || ctx->tiles_overflow != 0;   // the host saw the tiling succeed (sphx_neibs_getinfo): no stand-by launch
 	ForcesTimer t(ctx, stream, !use_tiles);   // without tiles the generic kernel is the dominant one
 	// tiled kernel, then the generic one, guarded by the overflow flag
 	// more than one fluid or Ferrari diffusion: tiled only for the Wendland kernel (every such problem of the reference uses
@@ -1519,7 +1553,7 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 		else if (diff == DIFF_COLAGROSSI) launch_tile<KERNEL, T, DIFF_COLAGROSSI>(ctx, stream, a); \
 		else if (diff == DIFF_FERRARI) { if (KERNEL == SPHX_WENDLAND) launch_tile<SPHX_WENDLAND, T, DIFF_FERRARI>(ctx, stream, a); } \
 		else launch_tile<KERNEL, T, DIFF_NONE>(ctx, stream, a); } } while (0)
-#define SPHX_LAUNCH_GENERIC(T, G) do { \
+#define SPHX_LAUNCH_GENERIC(T, G) do { if (!standby) break; \
 		if (diff == DIFF_COLAGROSSI) launch_forces_mf<KERNEL, T, DIFF_COLAGROSSI>(mf, grid, stream, p, a, G); \
 		else if (diff == DIFF_FERRARI) launch_forces_mf<KERNEL, T, DIFF_FERRARI>(mf, grid, stream, p, a, G); \
 		else launch_forces_mf<KERNEL, T, DIFF_NONE>(mf, grid, stream, p, a, G); } while (0)
@@ -1579,17 +1613,21 @@ void SPHX_PASTE(sphx_part_sps_k, SPHX_FORCES_PART)(const sphx_ctx *ctx, dim3 gri
 // thread -> particle map (tile_home) and its window layout: window row r holds the cells of grid row (g2-1+(r&3),
 // g3-1+(r>>2)) from column ca-1 on, rows follow each other without gaps, so the slot of a record is
 // (records of the rows before) + (records of the cells before it in its row) + its index in its cell.
+// The kernel also lays the window out for the forces kernel (tile_rows: first record, length and first slot of each of
+// the 16 rows, and whether the row is one range in memory) and balances the tile's waves (below).
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(TILE_THREADS)
 tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t *__restrict__ hash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
-	const uint32_t *__restrict__ tiles, uint32_t *tileCtl,
-	uint16_t *__restrict__ tileList, uint32_t listStride, uint32_t listRows, uint32_t *__restrict__ tileWaves)
+	const uint32_t *__restrict__ tiles, uint32_t *tileCtl, uint32_t *__restrict__ tileRows,
+	uint16_t *__restrict__ tileList, uint32_t listStride, uint32_t listRows, uint32_t *__restrict__ tileWaves,
+	uint16_t *__restrict__ tileOwnSlot)
 {
-	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW], sCellBase[TILE_WROWS*TILE_KW];
-	__shared__ uint32_t sRowTotal[TILE_WROWS];
+	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW], sCellBase[TILE_WROWS*TILE_KW], sCellStart[TILE_WROWS*TILE_KW];
+	__shared__ uint32_t sRowTotal[TILE_WROWS], sRowStart[TILE_WROWS], sRowContig[TILE_WROWS], sRowBase[TILE_WROWS];
 	__shared__ int sCodeOff[32];                                   // cell code-1 -> window-table offset
 	__shared__ uint16_t sCB[TILE_HROWS*TILE_MAXCELLS*27 + 8];      // [home cell][code] -> slot of the cell's first record
+	__shared__ uint32_t sChunkRows[TILE_THREADS/64];
 	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this list
 	const uint32_t numTiles = tileCtl[0];
 	const uint32_t tid = threadIdx.x;
@@ -1616,21 +1654,51 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			uint32_t wStart = 0, wCnt = 0;
 			window_cell(p, cellStart, cellEnd, (int)d[0], (int)d[1], ca, (int)d[3], wr, wcol, wStart, wCnt);
 			uint32_t incl = wCnt;
+			uint32_t lo = wCnt ? wStart : 0xFFFFFFFFu;
+			uint32_t hi = wCnt ? wStart + wCnt : 0u;
 #pragma unroll
 			for (int dd = 1; dd < TILE_KW; dd <<= 1) {
 				const uint32_t t = __shfl_up(incl, dd, TILE_KW);
 				if (wcol >= dd) incl += t;
 			}
+#pragma unroll
+			for (int dd = TILE_KW/2; dd > 0; dd >>= 1) {
+				lo = min(lo, (uint32_t)__shfl_xor(lo, dd, TILE_KW));
+				hi = max(hi, (uint32_t)__shfl_xor(hi, dd, TILE_KW));
+			}
 			sCellRel[tid] = incl - wCnt;
-			if (wcol == TILE_KW - 1) sRowTotal[wr] = incl;
+			sCellStart[tid] = wStart;
+			// one DMA per row needs the cells to lie in memory in window order: each non-empty cell starts where
+			// the previous ones end.  (Extent == count alone is not enough: a periodic row that is wholly inside
+			// the window has the wrapped column first in the window but last in memory.)
+			uint32_t inOrder = (wCnt == 0u || wStart - lo == incl - wCnt) ? 1u : 0u;
+#pragma unroll
+			for (int dd = TILE_KW/2; dd > 0; dd >>= 1)
+				inOrder &= (uint32_t)__shfl_xor(inOrder, dd, TILE_KW);
+			if (wcol == TILE_KW - 1) {
+				sRowTotal[wr] = incl;
+				sRowStart[wr] = incl ? lo : 0u;
+				sRowContig[wr] = (incl == 0u || (hi - lo == incl && inOrder)) ? 1u : 0u;
+			}
 		}
 		__syncthreads();
 		if (tid < TILE_WROWS*TILE_KW) {
 			uint32_t base = 0;
 			for (int r = 0; r < wr; ++r) base += sRowTotal[r];
 			sCellBase[tid] = sCellRel[tid] + base;
+			if (wcol == 0) sRowBase[wr] = base;
 		}
 		__syncthreads();
+		if (tid < TILE_WROWS) tileRows[(size_t)TILE_ROWDESC*tile + tid] = sRowStart[tid];
+		else if (tid < TILE_WROWS + 8u) {
+			const uint32_t k = tid - TILE_WROWS;
+			tileRows[(size_t)TILE_ROWDESC*tile + 16u + k] = (sRowTotal[2*k] & 0xFFFFu) | (sRowTotal[2*k + 1] << 16);
+		} else if (tid < TILE_WROWS + 16u) {
+			const uint32_t k = tid - TILE_WROWS - 8u;
+			const uint32_t b0 = (sRowBase[2*k] & 0x7FFFu) | (sRowContig[2*k] ? 0u : 0x8000u);
+			const uint32_t b1 = (sRowBase[2*k + 1] & 0x7FFFu) | (sRowContig[2*k + 1] ? 0u : 0x8000u);
+			tileRows[(size_t)TILE_ROWDESC*tile + 24u + k] = b0 | (b1 << 16);
+		}
 		for (uint32_t e = tid; e < TILE_HROWS*TILE_MAXCELLS*27; e += TILE_THREADS) {
 			const uint32_t m = e/27u, c1 = e - m*27u;
 			const uint32_t hr = m/TILE_MAXCELLS, col = m - hr*TILE_MAXCELLS;
@@ -1644,25 +1712,41 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 		const int myG1 = (p.c1 == 0) ? gp.x : (p.c1 == 1) ? gp.y : gp.z;
 		const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
 		const uint16_t *myCB = sCB + (h.hrow*TILE_MAXCELLS + myCol)*27;
-		uint32_t rowsSec[2] = {0u, 0u};
 		bool overflow = false;
+		if (mine) {   // the particle's own row in the window (the forces kernel reads its position, velocity and EOS row there)
+			const int wc = (5 + (h.hrow & 1) + 4*(h.hrow >> 1))*TILE_KW + myCol + 1;
+			const uint32_t slot = 1u + sCellBase[wc] + (index - sCellStart[wc]);
+			if (slot > 4095u) overflow = true;
+			tileOwnSlot[index] = (uint16_t)(slot << 4);
+		}
+		uint32_t rowsSec[2] = {0u, 0u};
+		const uint32_t slabs = listRows/TILE_NB;
 #pragma unroll 1
 		for (int sec = 0; sec < 2 && !overflow; ++sec) {
 			// section 0: slots 0 upward, section 1: slots neibboundpos downward; each ends at its terminator.
-			// Every lane writes its own translated list from row 0 on (`cur`: fillers make lists grow by different amounts),
+			// Every lane collects its translated entries four at a time (a batch: one 8-byte store into the batch's slab),
 			// then all lanes are padded with dummy entries up to the wave's longest, rounded up to whole batches
 			const int maxSlots = sec ? (int)p.neibboundpos + 1 : (int)p.neiblistsize;
 			bool alive = mine;
-			uint32_t code = 0, prev = 0, cur = 0;
-			bool done = false;
-			auto put = [&](uint32_t r, uint32_t val) {
-				if (rowsSec[0]*(uint32_t)sec + r >= listRows) { overflow = true; return; }
-				const uint32_t row = sec ? listRows - 1u - r : r;
-				tileList[(size_t)row*listStride + index] = (uint16_t)val;
+			uint32_t code = 0, cur = 0;
+			uint2 pend = make_uint2(0u, 0u);
+			auto put = [&](uint32_t val) {      // entry `cur` of this lane's section
+				const uint32_t k = cur & 3u;
+				if (k == 0u) pend = make_uint2(0u, 0u);
+				if (k < 2u) pend.x |= val << (16u*k); else pend.y |= val << (16u*(k - 2u));
+				if (k == 3u) {
+					const uint32_t b = cur >> 2;
+					if (rowsSec[0]/TILE_NB*(uint32_t)sec + b >= slabs) overflow = true;
+					else {
+						const uint32_t slab = sec ? slabs - 1u - b : b;
+						*reinterpret_cast<uint2*>(tileList + ((size_t)slab*listStride + index)*TILE_NB) = pend;
+					}
+				}
+				++cur;
 			};
 			constexpr int LOADS = 16;   // entries per lane in flight: the walk is latency bound
 #pragma unroll 1
-			for (int s0 = 0; s0 < maxSlots && !done; s0 += LOADS) {
+			for (int s0 = 0; s0 < maxSlots; s0 += LOADS) {
 				uint32_t e[LOADS];
 #pragma unroll
 				for (int k = 0; k < LOADS; ++k) {
@@ -1675,13 +1759,13 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 				for (int k = 0; k < LOADS; ++k) {
 					const uint32_t dd = e[k];
 					alive = alive && (s0 + k < maxSlots) && (dd != NEIBS_END);
+					const uint32_t prev = code;
 					code = (dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
-					if (alive && code < prev) { overflow = true; alive = false; }   // not a list of the builder (an overflowed one): generic kernel
+					if (alive && (code < prev || code == 0u || code > 27u)) { overflow = true; alive = false; }   // not a list of the builder (an overflowed one): generic kernel
 					if (alive && mine) {
-						while (code - prev > 15u) { put(cur++, 15u); prev += 15u; }   // filler: dummy row, advance 15 (rare)
-						const uint32_t slot = 1u + (uint32_t)myCB[code & 31u] + (dd & NEIBINDEX_MASK);   // slot 0 = dummy
-						put(cur++, (slot << 4) | (code - prev));
-						prev = code;
+						const uint32_t slot = 1u + (uint32_t)myCB[code] + (dd & NEIBINDEX_MASK);   // slot 0 = dummy
+						if (slot > 4095u) { overflow = true; alive = false; }
+						else put(slot << 4);
 					}
 				}
 			}
@@ -1692,20 +1776,35 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			rows = (rows + TILE_LIST_BATCH - 1u)/TILE_LIST_BATCH*TILE_LIST_BATCH;
 			if (rowsSec[0]*(uint32_t)sec + rows > listRows) overflow = true;
 			if (mine && !overflow)
-				for (uint32_t r = cur; r < rows; ++r) put(r, 0u);     // pad: dummy row, same cell
+				while (cur < rows) put(0u);     // pad: the dummy row
 			rowsSec[sec] = rows;
 		}
 		if (overflow) tileCtl[1] = 1u;      // some wave needs more rows than the tile lists have: generic kernel
-		if ((tid & 63u) == 0u) tileWaves[(size_t)tile*(TILE_THREADS/64) + (tid >> 6)] = rowsSec[0] | (rowsSec[1] << 16);
+		// Balance: the forces kernel's waves w and w + 4 share a SIMD (a workgroup's waves go round the four SIMDs), and a
+		// tile takes as long as its busiest SIMD.  The chunk (64 consecutive threads of the thread -> particle map) with the
+		// k-th most rows goes to wave k for k < 4 and to wave 11 - k above: the longest shares a SIMD with the shortest.
+		if ((tid & 63u) == 0u) sChunkRows[tid >> 6] = rowsSec[0] | (rowsSec[1] << 16);
+		__syncthreads();
+		if (tid < TILE_THREADS/64) {
+			const uint32_t mineRows = sChunkRows[tid], w = (mineRows & 0xFFFFu) + (mineRows >> 16);
+			uint32_t rank = 0;
+			for (uint32_t c = 0; c < TILE_THREADS/64; ++c) {
+				const uint32_t o = sChunkRows[c], ow = (o & 0xFFFFu) + (o >> 16);
+				rank += (ow > w || (ow == w && c < tid)) ? 1u : 0u;
+			}
+			const uint32_t wv = rank < 4u ? rank : 11u - rank;
+			tileWaves[(size_t)tile*(TILE_THREADS/64) + wv] = (mineRows & 0x0FFFFFFFu) | (tid << 28);
+		}
 	}
 }
 
 int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, hipStream_t st)
 {
-	if (!ctx->tile_list || !ctx->tile_waves) { ctx->tiles_built = false; return SPHX_OK; }
+	if (!ctx->tile_list || !ctx->tile_waves || !ctx->tile_rows || !ctx->tile_ownslot) { ctx->tiles_built = false; return SPHX_OK; }
 	const uint32_t grid = ctx->tile_grid*8u < ctx->tile_capacity ? ctx->tile_grid*8u : ctx->tile_capacity;
 	tile_lists_kernel<<<grid, TILE_THREADS, 0, st>>>(ctx->dev, neibsList, hash, cellStart, ctx->cell_end_copy,
-		ctx->tiles, ctx->tile_ctl, ctx->tile_list, ctx->tile_list_stride, ctx->tile_list_rows, ctx->tile_waves);
+		ctx->tiles, ctx->tile_ctl, ctx->tile_rows, ctx->tile_list, ctx->tile_list_stride, ctx->tile_list_rows, ctx->tile_waves,
+		ctx->tile_ownslot);
 	SPHX_LAUNCH_CHECK("tile_lists_kernel");
 	return SPHX_OK;
 }
@@ -1774,7 +1873,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.rb = ctx->rb_dev;
 	a.aux = ctx->eos_aux;
 	a.tileList = ctx->tile_list; a.tileListRows = ctx->tile_list_rows; a.tileListStride = ctx->tile_list_stride;
-	a.tileWaves = ctx->tile_waves;
+	a.tileWaves = ctx->tile_waves; a.tileRows = ctx->tile_rows; a.tileOwnSlot = ctx->tile_ownslot;
 	a.xsph = (float4*)xsph;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
 	a.numBlocks = numBlocks;
@@ -1783,16 +1882,17 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.prof = nullptr;
 	a.pin = nullptr;
 	if (ctx->tile_debug & 16) {
-		if (!ctx->tile_prof && hipMalloc((void**)&ctx->tile_prof, 8*sizeof(unsigned long long)*ctx->tile_grid) != hipSuccess)
+		if (!ctx->tile_prof && hipMalloc((void**)&ctx->tile_prof, 10*(TILE_THREADS/64)*sizeof(unsigned long long)*ctx->tile_grid) != hipSuccess)
 			return sphx_set_error(SPHX_ERR_RUNTIME, "sphx_forces_basicstep: cannot allocate the tile profile buffer");
 		a.prof = ctx->tile_prof;
 	}
 
+	sphx_tiles_overflow_poll(ctx);
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
-	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
+	const bool use_tiles = ctx->tiles_built && ctx->tiles_overflow != 1 && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		((ctx->dev.numfluids == 1 && ctx->dev.densitydiff != SPHX_FERRARI) || ctx->dev.kerneltype == SPHX_WENDLAND) &&
 		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles && ctx->tile_list != nullptr &&
-		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*(TILE_NB - 1) < 0x80000000ull;   // buffer-load row offsets are 31-bit
+		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*TILE_NB < 0x80000000ull;   // buffer-load offsets are 31-bit
 	a.tauPack = nullptr; a.tauPackN = 0;
 	a.otau0 = a.otau1 = a.otau2 = nullptr; a.oturbvisc = nullptr;
 	if (use_tiles && ctx->dev.turbmodel == SPHX_SPS) {   // window rows of the stress tensor (see tau_pack_kernel)
@@ -1913,11 +2013,12 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.info = (const particleinfo*)info;
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
 	dim3 grid(div_up_u(particleRangeEnd, 128));
+	sphx_tiles_overflow_poll(ctx);
 	// single fluid with the tiling of this neighbour list at hand: the stress mode of the tiled kernel (neighbour rows from
 	// the LDS window instead of gathers), then the gather kernel as a stand-by guarded by the tiling's overflow flag
-	const bool use_tiles = ctx->tiles_built && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
+	const bool use_tiles = ctx->tiles_built && ctx->tiles_overflow != 1 && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		ctx->dev.numfluids == 1 && !ctx->disable_tiles && ctx->tile_list != nullptr &&
-		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*(TILE_NB - 1) < 0x80000000ull;
+		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*TILE_NB < 0x80000000ull;
 	const uint32_t *guard = nullptr;
 	if (use_tiles) {
 		ForcesArgs fa = ForcesArgs();
@@ -1925,7 +2026,7 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 		fa.otau0 = a.tau0; fa.otau1 = a.tau1; fa.otau2 = a.tau2; fa.oturbvisc = spsturbvisc;
 		fa.fromParticle = 0; fa.toParticle = particleRangeEnd;
 		fa.tileList = ctx->tile_list; fa.tileListRows = ctx->tile_list_rows; fa.tileListStride = ctx->tile_list_stride;
-		fa.tileWaves = ctx->tile_waves;
+		fa.tileWaves = ctx->tile_waves; fa.tileRows = ctx->tile_rows; fa.tileOwnSlot = ctx->tile_ownslot;
 		fa.dbg = ctx->tile_debug & 4;
 		switch (ctx->dev.kerneltype) {
 		case SPHX_CUBICSPLINE: sphx_part_stress_k1(ctx, (hipStream_t)stream, fa); break;
@@ -1936,6 +2037,7 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 		SPHX_LAUNCH_CHECK("forces_tile_kernel (SPS stress)");
 		guard = ctx->tile_ctl + 1;
 		grid.x = grid.x < 2048u ? grid.x : 2048u;   // stand-by launch: every block returns at once unless the tiling overflowed
+		if (ctx->tiles_overflow == 0) return SPHX_OK;   // the host saw the tiling succeed: no stand-by
 	}
 	switch (ctx->dev.kerneltype) {
 	case SPHX_CUBICSPLINE: sphx_part_sps_k1(ctx, grid, (hipStream_t)stream, a, guard); break;
@@ -1953,7 +2055,7 @@ extern "C" int sphx_dbg_tile_profile(sphx_ctx *ctx, unsigned long long *host, ui
 {
 	if (!ctx || !ctx->tile_prof) return -1;
 	const uint32_t n = maxGroups < ctx->tile_grid ? maxGroups : ctx->tile_grid;
-	if (hipMemcpy(host, ctx->tile_prof, 8*sizeof(unsigned long long)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	if (hipMemcpy(host, ctx->tile_prof, 10*(TILE_THREADS/64)*sizeof(unsigned long long)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return (int)n;
 }
 

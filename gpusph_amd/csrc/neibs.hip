@@ -1040,9 +1040,16 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	SPHX_LAUNCH_CHECK("cell_fluid_end_kernel");
 	// tiling of the sorted particles for the forces engine (forces.hip "Tiled path")
 	ctx->tiles_built = false;
+	ctx->tiles_overflow = -1;
 	const bool tile_cols_fit = (size_t)((ctx->dev.gs[ctx->dev.c2] + 1)/2)*(size_t)((ctx->dev.gs[ctx->dev.c3] + 1)/2)*(size_t)ctx->dev.gs1
 		<= (size_t)ctx->cells_reserved/2 + 1024;   // tile_cols allocation (degenerate 1-D grids: generic kernels)
-	if (ctx->tiles && !ctx->disable_tiles && tile_cols_fit && !sa) {
+	// tiles serve sphx_forces_basicstep's pair loop only (SPH_F1, inviscid or Newtonian, DYN / LJ / MK boundaries) and sphx_calc_visc
+	const bool tiled_options = !sa && ctx->params.sph_formulation == SPHX_SPH_F1 && ctx->params.rheologytype <= SPHX_NEWTONIAN;
+	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit) {
+		rc = sphx_ensure_tile_lists(ctx);      // first tiled build: the tile lists are allocated now (or never: generic kernels)
+		if (rc != SPHX_OK) return rc;
+	}
+	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit && ctx->tile_list) {
 		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
 		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), st));
 		const DevParams &dp = ctx->dev;
@@ -1072,6 +1079,13 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	if (ctx->tiles_built) {   // the lists of the tiled particles in the form the tiled forces kernel walks (forces.hip)
 		rc = sphx_tile_lists_launch(ctx, neibsList, hash, cellStart, st);
 		if (rc != SPHX_OK) return rc;
+		// the tiling's overflow flag travels to the host behind the build, without a synchronisation: the forces passes that
+		// find it arrived (sphx_tiles_overflow_poll) launch exactly one kernel, the others keep the guarded stand-by
+		if (ctx->tiles_built && ctx->ovf_host) {
+			SPHX_HIP(hipMemcpyAsync(ctx->ovf_host, ctx->tile_ctl, 2*sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+			SPHX_HIP(hipEventRecord(ctx->ovf_event, st));
+			ctx->ovf_pending = true;
+		}
 	}
 	return SPHX_OK;
 }

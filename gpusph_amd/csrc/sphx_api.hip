@@ -35,6 +35,9 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	SPHX_HIP(hipMalloc((void**)&ctx->dt_scratch, 4*sizeof(float)));
 	SPHX_HIP(hipMalloc((void**)&ctx->tile_ctl, 16*sizeof(uint32_t)));
 	SPHX_HIP(hipMemset(ctx->tile_ctl, 0, 16*sizeof(uint32_t)));
+	SPHX_HIP(hipHostMalloc((void**)&ctx->ovf_host, 2*sizeof(uint32_t), hipHostMallocDefault));
+	SPHX_HIP(hipEventCreateWithFlags(&ctx->ovf_event, hipEventDisableTiming));
+	ctx->tiles_overflow = -1;
 	int cus = 0;
 	SPHX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
 	ctx->tile_grid = (uint32_t)(cus > 0 ? cus : 256)*TILE_WGS_PER_CU;   // persistent grid: one 512-thread workgroup per CU (LDS bound)
@@ -51,13 +54,13 @@ static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
 		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tau_pack, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols,
-		ctx->tile_list, ctx->tile_waves };
+		ctx->tile_list, ctx->tile_waves, ctx->tile_rows, ctx->tile_ownslot };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
 	ctx->eos_aux = nullptr; ctx->tau_pack = nullptr;
-	ctx->tile_list = nullptr; ctx->tile_waves = nullptr; ctx->tile_list_rows = ctx->tile_list_stride = 0;
+	ctx->tile_list = nullptr; ctx->tile_waves = nullptr; ctx->tile_rows = nullptr; ctx->tile_ownslot = nullptr; ctx->tile_list_rows = ctx->tile_list_stride = 0;
 	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr; ctx->cell_fluid_end = nullptr; ctx->tile_cols = nullptr;
 	ctx->tile_capacity = 0; ctx->cells_reserved = 0; ctx->tiles_built = false;
 	ctx->reserved_particles = ctx->reserved_bins = 0;
@@ -77,6 +80,7 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
 	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
 	if (ctx->tile_prof) (void)hipFree(ctx->tile_prof);
+	if (ctx->ovf_host) { (void)hipHostFree(ctx->ovf_host); (void)hipEventDestroy(ctx->ovf_event); }
 	if (ctx->dem) (void)hipFree(ctx->dem);
 	delete ctx->forces_events;
 	delete ctx;
@@ -111,12 +115,6 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 		SPHX_HIP(hipMalloc((void**)&ctx->tau_pack, sizeof(float4)*2*(size_t)n));
 	ctx->tile_capacity = n/8 + 4096;
 	SPHX_HIP(hipMalloc((void**)&ctx->tiles, sizeof(uint32_t)*TILE_DESC*(size_t)ctx->tile_capacity));
-	if (!ctx->disable_tiles) {   // tile lists: 2 B x (neiblistsize + extra) rows per particle; only the rows in use are ever touched
-		ctx->tile_list_rows = (ctx->dev.neiblistsize + TILE_LIST_EXTRA)/TILE_LIST_BATCH*TILE_LIST_BATCH;
-		ctx->tile_list_stride = n;
-		SPHX_HIP(hipMalloc((void**)&ctx->tile_list, sizeof(uint16_t)*(size_t)ctx->tile_list_rows*(size_t)n));
-		SPHX_HIP(hipMalloc((void**)&ctx->tile_waves, sizeof(uint32_t)*(TILE_THREADS/64)*(size_t)ctx->tile_capacity));
-	}
 	ctx->cells_reserved = (bins - 1)/4;
 	SPHX_HIP(hipMalloc((void**)&ctx->cell_end_copy, sizeof(uint32_t)*(size_t)ctx->cells_reserved));
 	SPHX_HIP(hipMalloc((void**)&ctx->cell_fluid_end, sizeof(uint32_t)*(size_t)ctx->cells_reserved));
@@ -124,6 +122,35 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	SPHX_HIP(hipMalloc((void**)&ctx->tile_cols, sizeof(uint32_t)*((size_t)ctx->cells_reserved/2 + 1024)));
 	ctx->reserved_particles = n;
 	ctx->reserved_bins = bins;
+	return SPHX_OK;
+}
+
+// Tile lists of the tiled forces kernel (forces.hip): 2 B x (neiblistsize + extra) rows per particle, more than the neighbour
+// list itself, so they are allocated on the first neighbour-list build that really tiles (sphx_build_neibs_sa decides: not with
+// SA_BOUNDARY, not for the formulations that have their own forces kernels).  When the memory is not there the context simply
+// keeps running on the generic kernels: tile_list stays NULL and tiles_built false.
+int sphx_ensure_tile_lists(sphx_ctx *ctx)
+{
+	if (ctx->disable_tiles || !ctx->reserved_particles) return SPHX_OK;
+	if (ctx->tile_list && ctx->tile_waves && ctx->tile_rows && ctx->tile_ownslot) return SPHX_OK;
+	const size_t n = ctx->reserved_particles;
+	const uint32_t rows = (ctx->dev.neiblistsize + TILE_LIST_EXTRA)/TILE_LIST_BATCH*TILE_LIST_BATCH;
+	bool ok = hipMalloc((void**)&ctx->tile_list, sizeof(uint16_t)*(size_t)rows*n) == hipSuccess;
+	ok = ok && hipMalloc((void**)&ctx->tile_waves, sizeof(uint32_t)*(TILE_THREADS/64)*(size_t)ctx->tile_capacity) == hipSuccess;
+	ok = ok && hipMalloc((void**)&ctx->tile_rows, sizeof(uint32_t)*TILE_ROWDESC*(size_t)ctx->tile_capacity) == hipSuccess;
+	ok = ok && hipMalloc((void**)&ctx->tile_ownslot, sizeof(uint16_t)*n) == hipSuccess;
+	if (!ok) {
+		(void)hipGetLastError();   // out of memory is not an error of the caller's command: the generic kernels take over
+		if (ctx->tile_list) (void)hipFree(ctx->tile_list);
+		if (ctx->tile_waves) (void)hipFree(ctx->tile_waves);
+		if (ctx->tile_rows) (void)hipFree(ctx->tile_rows);
+		if (ctx->tile_ownslot) (void)hipFree(ctx->tile_ownslot);
+		ctx->tile_list = nullptr; ctx->tile_waves = nullptr; ctx->tile_rows = nullptr; ctx->tile_ownslot = nullptr;
+		ctx->tile_list_rows = ctx->tile_list_stride = 0;
+		return SPHX_OK;
+	}
+	ctx->tile_list_rows = rows;
+	ctx->tile_list_stride = (uint32_t)n;
 	return SPHX_OK;
 }
 
@@ -277,6 +304,8 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	d.c1 = sp->coord[0]; d.c2 = sp->coord[1]; d.c3 = sp->coord[2];
 	d.gs1 = d.gs[d.c1];
 	d.gs12 = d.gs[d.c1]*d.gs[d.c2];
+	d.gsc2 = d.gs[d.c2]; d.gsc3 = d.gs[d.c3];
+	d.csc1 = d.cs[d.c1]; d.csc2 = d.cs[d.c2]; d.csc3 = d.cs[d.c3];
 	d.hs[d.c1] = 1; d.hs[d.c2] = d.gs1; d.hs[d.c3] = d.gs12;
 	d.periodic = sp->periodic;
 	d.neiblistsize = sp->neiblistsize; d.neibboundpos = sp->neibboundpos; d.stride = sp->neiblist_stride;

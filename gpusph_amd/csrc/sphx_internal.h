@@ -43,7 +43,10 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #define TILE_WROWS    16                   // window rows: 4 x 4
 #define TILE_MAXCELLS 14                   // cells per tile along COORD1
 #define TILE_KW       16                   // window columns (TILE_MAXCELLS + 2)
-#define TILE_DESC     16                   // uint32 per tile: g2, g3, firstCell, numCells, first[4], count[4], window, flags, 0, 0
+#define TILE_DESC     16                   // uint32 per tile: g2, g3, firstCell, numCells, first[4], count[4], window, flags,
+                                           // mask of window rows that are not one contiguous range, wave -> chunk permutation
+#define TILE_ROWDESC  32                   // uint32 per tile (tile_rows, written by tile_lists_kernel): first record of each of the 16
+                                           // window rows, then records per row and window slot of the row's first record as uint16 pairs
 #define TILE_NB       4                    // neighbours per batch in the tiled pair loop
 #define TILE_AHEAD    4                    // list batches kept in flight per section (register ring)
 #define TILE_LIST_EXTRA 64                 // rows of the tile lists beyond neiblistsize (both sections are padded per wave)
@@ -58,6 +61,9 @@ struct DevParams {
 	int      hs[3];           // hash stride per axis: hash = gx*hs[0] + gy*hs[1] + gz*hs[2]
 	int      c1, c2, c3;      // axis index of COORD1..3
 	int      gs1, gs12;       // gridSize[COORD1], gridSize[COORD1]*gridSize[COORD2]
+	int      gsc2, gsc3;      // gridSize[COORD2], gridSize[COORD3]
+	float    csc1, csc2, csc3;// cell size along COORD1..3 (kept as scalars: a run-time index into cs[] would send the kernel
+	                          // argument block to scratch memory)
 	uint32_t periodic;
 	uint32_t neiblistsize, neibboundpos;
 	uint64_t stride;
@@ -142,6 +148,8 @@ struct sphx_ctx {
 	float      *dt_scratch;    // 1 float, for the sync dtreduce
 	// forces tiles, built by sphx_build_neibs
 	uint32_t   *tiles;         // [tile_capacity][TILE_DESC]
+	uint16_t   *tile_ownslot;  // [n]: window slot * 16 of every tiled particle's own row
+	uint32_t   *tile_rows;     // [tile_capacity][TILE_ROWDESC]: the window rows of every tile, laid out once per neighbour-list build
 	uint32_t   *tile_cols;     // [row bundles][gs1]: window records of a column (16 rows), bit 31 = a cell of it holds fluid
 	uint32_t   *tile_ctl;      // [0] = number of tiles, [1] = overflow flag (generic kernel takes over), [2] finished groups, [4..11] tile tickets
 	uint32_t   *cell_end_copy; // [cells] cellEnd of the build the tiles belong to
@@ -155,6 +163,11 @@ struct sphx_ctx {
 	uint32_t    tile_capacity;
 	uint32_t    cells_reserved;
 	bool        tiles_built;
+	int         tiles_overflow;// device-side overflow flag of the tiling as last seen by the host: -1 not seen yet (the forces
+	                           // engine then launches the generic kernel as a guarded stand-by), 0 tiles usable, 1 generic kernels
+	uint32_t   *ovf_host;      // pinned: copy of tile_ctl[0..1] made behind every tiled build
+	hipEvent_t  ovf_event;     // ... has arrived
+	bool        ovf_pending;
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
 	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments)
 	unsigned long long *tile_prof;   // SPHX_TILE_DEBUG & 16
@@ -176,6 +189,14 @@ static inline uint32_t div_up_u(uint32_t a, uint32_t b) { return (a + b - 1)/b; 
 static inline uint32_t round_up_u(uint32_t a, uint32_t b) { return div_up_u(a, b)*b; }
 
 int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles);
+int sphx_ensure_tile_lists(sphx_ctx *ctx);
+static inline void sphx_tiles_overflow_poll(sphx_ctx *ctx)
+{
+	if (ctx->tiles_overflow == -1 && ctx->ovf_pending && hipEventQuery(ctx->ovf_event) == hipSuccess) {
+		ctx->tiles_overflow = ctx->ovf_host[1] ? 1 : 0;
+		ctx->ovf_pending = false;
+	}
+}
 // repacking forces (filters.hip), reached through sphx_forces_basicstep(run_mode = SPHX_REPACK)
 #define SPHX_RB_RING 16
 int sphx_fidelity_forces_launch(sphx_ctx *ctx, void *forces, float *cfl,
@@ -291,6 +312,34 @@ __device__ __forceinline__ uint32_t window_cell_hash(const DevParams &p, int g2,
 	if (gz < 0) { if (p.periodic & SPHX_PERIODIC_Z) gz = p.gs[2] - 1; else return 0xFFFFFFFFu; }
 	else if (gz >= p.gs[2]) { if (p.periodic & SPHX_PERIODIC_Z) gz = 0; else return 0xFFFFFFFFu; }
 	return grid_hash(p, gx, gy, gz);
+}
+
+// The tiled forces kernel keeps its window in ONE frame per tile: a record of window cell (row r, column col) is stored as
+// its cell-local position + tile_shift(r, col), the offset of that cell's centre from the centre of the window; home
+// particles are shifted the same way, so that a pair needs no per-cell shift.  The same function is used for both sides.
+__device__ __forceinline__ float3 tile_shift(const DevParams &p, int ncells, int r, int col)
+{
+	const float a1 = ((float)col - 0.5f*(float)(ncells + 1))*p.csc1;
+	const float a2 = ((float)(r & 3) - 1.5f)*p.csc2;
+	const float a3 = ((float)(r >> 2) - 1.5f)*p.csc3;
+	float3 s;
+	s.x = (p.c1 == 0) ? a1 : (p.c2 == 0) ? a2 : a3;
+	s.y = (p.c1 == 1) ? a1 : (p.c2 == 1) ? a2 : a3;
+	s.z = (p.c1 == 2) ? a1 : (p.c2 == 2) ? a2 : a3;
+	return s;
+}
+
+// hash of the cell at COORD1 = 0 of window row r (grid row g2-1+(r&3), g3-1+(r>>2), wrapped where periodic): the COORD1
+// index of a record of that row is its cell hash minus this.  -1 for a row outside the grid
+__device__ __forceinline__ int window_row_hash0(const DevParams &p, int g2, int g3, int r)
+{
+	const int gs2 = p.gsc2, gs3 = p.gsc3;
+	int v1 = g2 + (r & 3) - 1, v2 = g3 + (r >> 2) - 1;
+	if (v1 < 0) { if (p.periodic & (1u << p.c2)) v1 = gs2 - 1; else return -1; }
+	else if (v1 >= gs2) { if (p.periodic & (1u << p.c2)) v1 = 0; else return -1; }
+	if (v2 < 0) { if (p.periodic & (1u << p.c3)) v2 = gs3 - 1; else return -1; }
+	else if (v2 >= gs3) { if (p.periodic & (1u << p.c3)) v2 = 0; else return -1; }
+	return v1*p.gs1 + v2*p.gs12;
 }
 
 // ... -> start/count of its particles

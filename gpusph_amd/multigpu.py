@@ -631,4 +631,5 @@ class MultiGpuEngine:
                 "forces": self.forces[:n].cpu().numpy(),
                 **({"vol": self.vol[:n].cpu().numpy()} if self.grenier else {}),
                 **({"energy": self.energy[:n].cpu().numpy()} if self.energy_on else {}),
+                **({"gradgamma": self.gradgamma[:n].cpu().numpy(), "boundelements": self.boundelements[:n].cpu().numpy()} if self.sa else {}),
                 **({k: v[:n].cpu().numpy() for k, v in self.ke.items()} if self.keps else {})}

@@ -67,12 +67,8 @@ def _check_neibs_and_forces(prob, seed, monkeypatch=None, tol=2e-5, switch_flips
         eng_g._forces(eng_g.pos, eng_g.vel, 1, 0)
         monkeypatch.setenv("SPHX_DISABLE_TILES", "0")
         fg = _np(eng_g.forces)[:n]
-        if kernels_ulp == 0:
-            assert np.array_equal(fg.view(np.uint32), f.view(np.uint32))
-        else:   # rounding-level agreement (see test_newtonian_laminar_viscosity)
-            ulp = np.spacing(np.abs(f[:, :3]).max(axis=1).astype(np.float32))[:, None]    # of the particle's largest component
-            assert (np.abs(fg[:, :3] - f[:, :3]) <= kernels_ulp * ulp).all() and (fg != f).any(axis=1).mean() < 0.05
-            assert np.array_equal(fg[:, 3].view(np.uint32), f[:, 3].view(np.uint32))
+        from kernel_agreement import assert_forces_agree
+        assert_forces_agree(f, fg)
 
 
 @pytest.mark.parametrize("lin", sorted(D.LINEARIZATIONS))

@@ -306,8 +306,8 @@ def test_full_size_against_the_oracle(name):
 
 def test_full_size_32M_tiled_equals_generic_and_invariants():
     """BASELINE configs[3] size (the bench workload, 31.8 M particles) through properties that need no oracle: the two
-    independent HIP implementations of the forces pass (LDS-tiled, gather) give the same bits for every particle and the
-    same dt after a few steps and a neighbour rebuild; hash sorted, cells partition the particles, list within capacity"""
+    independent HIP implementations of the forces pass (LDS-tiled, gather) agree to rounding (kernel_agreement.py) for every
+    particle and in dt after a few steps and a neighbour rebuild; hash sorted, cells partition the particles, list within capacity"""
     import torch
     prob = DamBreak3D(DamBreak3D.deltap_for(32.0e6), obstacle=True)
     eng = _engine(prob, track_particle_count=False)
@@ -330,8 +330,9 @@ def test_full_size_32M_tiled_equals_generic_and_invariants():
     eng.forces.zero_()
     eng._forces(eng.pos, eng.vel, 1, 0)
     eng.neibslist = own
-    assert torch.equal(eng.forces[:n].view(torch.int32), f_tiled.view(torch.int32))
-    assert float(eng.d_dt_next.item()) == dt_tiled
+    from kernel_agreement import assert_forces_agree
+    assert_forces_agree(f_tiled.cpu().numpy(), eng.forces[:n].cpu().numpy())
+    assert abs(float(eng.d_dt_next.item()) - dt_tiled) <= 1e-5 * dt_tiled
     fluid = (eng.info[:n, 0].to(torch.int32) & 7) == 0
     az = f_tiled[fluid, 2].mean().item()
     assert -9.81 < az < 1.0
@@ -393,8 +394,8 @@ LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, visc
 
 @pytest.mark.parametrize("case", CASES + LJ_CASES)
 def test_tiled_and_generic_kernels_agree(case, monkeypatch):
-    """the LDS-tiled forces kernel and the generic gather kernel implement the same sum in the same order:
-    identical accumulation order and per-pair arithmetic -> bit-identical forces"""
+    """the LDS-tiled forces kernel and the generic gather kernel implement the same sum in the same order; the tiled one in
+    the tile's frame of reference: agreement to rounding (kernel_agreement.py)"""
     import torch
     prob = DamBreak3D(**case)
     outs = []
@@ -411,11 +412,14 @@ def test_tiled_and_generic_kernels_agree(case, monkeypatch):
         eng._forces(eng.pos, eng.vel, 1, 0)
         tau = np.concatenate([_np(t)[:n] for t in eng.tau], axis=1) if getattr(eng, "tau", None) else np.zeros((n, 6), np.float32)
         outs.append((_np(eng.forces)[:n].copy(), float(eng.d_dt_next.item()), _np(eng.rbforces).copy(), tau.copy()))
-    assert np.array_equal(outs[0][0].view(np.uint32), outs[1][0].view(np.uint32))
-    assert outs[0][1] == outs[1][1]
-    assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32))
-    # SPS: the stress mode of the tiled kernel (single fluid) and sps_kernel give the same tensor, bit for bit
-    assert np.array_equal(outs[0][3].view(np.uint32), outs[1][3].view(np.uint32))
+    from kernel_agreement import assert_forces_agree
+    assert_forces_agree(outs[0][0], outs[1][0])
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-5 * outs[1][1]
+    if np.abs(outs[1][2]).max() > 0:
+        assert_forces_agree(outs[0][2], outs[1][2], what="rigid-body rows")
+    # SPS: the stress mode of the tiled kernel (single fluid) and sps_kernel give the same tensor
+    if np.abs(outs[1][3]).max() > 0:
+        assert_forces_agree(outs[0][3], outs[1][3], what="SPS stress tensor")
     if case.get("viscosity") == "SPSVISC":
         assert np.abs(outs[0][3]).max() > 0
 
@@ -483,13 +487,16 @@ def _mg_worker(rank, world, port, outdir, casename):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("casename", sorted(_MG_CASES))
-def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename):
+@pytest.mark.parametrize("casename,kernels", [(c, "generic") for c in sorted(_MG_CASES)] + [("default", "tiled"), ("spsvisc+shepard", "tiled")])
+def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename, kernels, monkeypatch):
     """the real HIP kernels under the slab decomposition (2 ranks sharing the one GPU of this box, host-staged
-    gloo transport standing in for RCCL): bit-identical to the single-domain run, including the overlapped
-    edge-stripe / inner-stripe forces"""
+    gloo transport standing in for RCCL), including the overlapped edge-stripe / inner-stripe forces.
+    With the gather kernels every particle sees the same arithmetic whatever the decomposition: bit-identical to the
+    single-domain run.  The LDS-tiled kernels work in a frame per tile and the slabs tile differently, so there the two
+    runs agree to rounding (12 steps: positions to 1e-6 of a cell per step, velocities to 1e-4 of the largest)."""
     import socket
     import torch.multiprocessing as mp
+    monkeypatch.setenv("SPHX_DISABLE_TILES", "1" if kernels == "generic" else "0")     # read when a context is created; the workers inherit it
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_mg_worker, args=(2, port, str(tmp_path), casename), nprocs=2, join=True)
     kw, filters = _MG_CASES[casename]
@@ -507,6 +514,19 @@ def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename):
     rid = rinfo[:, 2].astype(np.uint32) | (rinfo[:, 3].astype(np.uint32) << 16)
     ro = np.argsort(rid)
     assert np.array_equal(ids[order], rid[ro])
+    if kernels == "tiled":
+        cs = float(min(prob.m_cellsize))
+        got = np.concatenate([p["pos"] for p in parts])[order]; want = _np(ref.pos)[:n][ro]
+        assert np.array_equal(got[:, 3].view(np.uint32), want[:, 3].view(np.uint32))
+        hg = np.concatenate([p["hash"] for p in parts])[order] if "hash" in parts[0] else None
+        same_cell = np.ones(n, bool) if hg is None else (hg & 0x3FFFFFFF) == (_np(ref.hash, np.uint32)[:n][ro] & 0x3FFFFFFF)
+        assert same_cell.mean() > 0.999        # a particle within rounding of a cell face may sit on either side of it
+        assert np.abs(got[same_cell, :3] - want[same_cell, :3]).max() <= 12e-6 * cs
+        got = np.concatenate([p["vel"] for p in parts])[order]; want = _np(ref.vel)[:n][ro]
+        assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-4 * max(np.abs(want[:, :3]).max(), 1e-3)
+        assert np.abs(got[:, 3] - want[:, 3]).max() <= 3e-6
+        assert all(abs(float(p["dt"]) - ref.current_dt()) <= 1e-4 * ref.current_dt() for p in parts)
+        return
     for k, t in (("pos", ref.pos), ("vel", ref.vel)):
         got = np.concatenate([p[k] for p in parts])[order]
         assert np.array_equal(got.view(np.uint32), _np(t)[:n][ro].view(np.uint32)), k
@@ -842,7 +862,8 @@ def test_periodic_neibs_forces_and_trajectory(case, monkeypatch):
     eng_g.build_neibs()
     eng_g.vel[:n] = torch.from_numpy(vel[:n]).to(eng_g.device)
     eng_g._forces(eng_g.pos, eng_g.vel, 1, 0)
-    assert np.array_equal(_np(eng_g.forces)[:n].view(np.uint32), f.view(np.uint32))
+    from kernel_agreement import assert_forces_agree
+    assert_forces_agree(f, _np(eng_g.forces)[:n])
     monkeypatch.setenv("SPHX_DISABLE_TILES", "0")
     # trajectory across two re-sorts: particles leave through one face and come back through the opposite one
     eng2 = _engine(prob); sim2 = ol.OracleSim(prob)

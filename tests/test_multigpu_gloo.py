@@ -84,7 +84,8 @@ def _gather(outdir, world):
     parts = [np.load(os.path.join(outdir, "r%d_of_%d.npz" % (r, world))) for r in range(world)]
     ids = np.concatenate([p["info"][:, 2].astype(np.uint32) | (p["info"][:, 3].astype(np.uint32) << 16) for p in parts])
     order = np.argsort(ids)
-    keys = [k for k in ("pos", "vel", "info", "hash", "forces", "vol", "energy") if k in parts[0]]
+    keys = [k for k in ("pos", "vel", "info", "hash", "forces", "vol", "energy", "gradgamma", "boundelements",
+                        "tke", "eps", "turbvisc", "eulervel") if k in parts[0]]
     cat = {k: np.concatenate([p[k] for p in parts])[order] for k in keys}
     return ids[order], cat, parts
 
