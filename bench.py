@@ -44,6 +44,20 @@ def usable_cpus():
 
 def cpu_baseline(target_particles=4_000_000, steps=6):
     """Oracle (OpenMP port of the reference algorithm) on a bounded sample of the same workload."""
+    # SURVEY 8d: the baseline is the oracle compiled -O3 -march=native -fopenmp.  The committed build of the oracle (the parity
+    # checker) is -O2 without -march so that it runs on any box; for the timing the same source is compiled here, on the CPU
+    # it is timed on (same results: no fast-math, no contraction)
+    import subprocess, tempfile
+    flags = "-O2 -fopenmp (prebuilt)"
+    odir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle")
+    tmp = os.path.join(tempfile.gettempdir(), "libsph_oracle_native_%d.so" % os.getpid())
+    try:
+        subprocess.run(["gcc", "-O3", "-march=native", "-g0", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-std=gnu11",
+                        "-shared", "-o", tmp, os.path.join(odir, "sph_oracle.c"), "-lm"], check=True, capture_output=True, timeout=300)
+        os.environ["SPH_ORACLE_LIB"] = tmp
+        flags = "-O3 -march=native -fopenmp"
+    except Exception:
+        pass
     import oracle_lib as ol
     from gpusph_amd.problem import DamBreak3D
     ol.lib().orc_set_num_threads(usable_cpus())
@@ -68,7 +82,7 @@ def cpu_baseline(target_particles=4_000_000, steps=6):
         "value": round(1e-6 * sim.n / per_step, 4), "unit": "M particle-updates/s",
         "cores": int(ol.lib().orc_num_threads()), "kind": "port",
         "sample": "DamBreak3D %d particles (dp=%.5f), %d steps + 1 rebuild amortised over 10 steps, "
-                  "oracle/sph_oracle.c -O2 -fopenmp" % (sim.n, dp, steps),
+                  "oracle/sph_oracle.c %s" % (sim.n, dp, steps, flags),
     }
 
 

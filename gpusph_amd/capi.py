@@ -101,6 +101,7 @@ SIGNATURES = {
     "sphx_compute_density": (_i, [_vp] * 9 + [_u32, _f, _f, _vp]),
     "sphx_forces_basicstep_grenier": (_i, [_vp] * 10 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_disable_free_surf_parts": (_i, [_vp, _vp, _vp, _u32, _u32, _vp]),
+    "sphx_time_advance": (_i, [_vp, _vp, _vp, _vp]),
     "sphx_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
     "sphx_device_count": (_i, [C.POINTER(_i)]),
     "sphx_set_device": (_i, [_i]),

@@ -200,3 +200,15 @@ extern "C" int sphx_disable_free_surf_parts(sphx_ctx *ctx, void *pos, const void
 	SPHX_LAUNCH_CHECK("disable_free_surf_kernel");
 	return SPHX_OK;
 }
+
+// TIME_STEP_EPILOGUE of a run whose dt lives on the device: t += dt as GPUSPH::runSimulation adds them (double += float,
+// src/GPUSPH.cc:650-657), without a trip to the host
+static __global__ void time_advance_kernel(double *t, const float *dt) { *t += (double)*dt; }
+
+extern "C" int sphx_time_advance(sphx_ctx *ctx, double *d_t, const float *d_dt, void *stream)
+{
+	SPHX_REQUIRE(ctx && d_t && d_dt, "sphx_time_advance: missing buffer");
+	time_advance_kernel<<<1, 1, 0, (hipStream_t)stream>>>(d_t, d_dt);
+	SPHX_LAUNCH_CHECK("time_advance_kernel");
+	return SPHX_OK;
+}

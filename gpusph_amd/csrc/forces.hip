@@ -46,7 +46,7 @@ struct ForcesArgs {
 	unsigned long long *prof;   // SPHX_TILE_DEBUG & 16: per-workgroup phase times (100 MHz ticks), else NULL
 	int dbg;   // SPHX_TILE_DEBUG bits, timing experiments only (results are wrong with 1, 2, 32): 1 = skip the pair loops,
 	           // 2 = skip the window staging, 4 = plain round-robin tile order instead of the XCD-aware one, 16 = phase timers,
-	           // 32 = the list walk re-reads its first batches (no HBM list stream), 64 = alternating wave priorities in the pair loop
+	           // 32 = the list walk re-reads its first batches (no HBM list stream), 64 / 128 = other patterns of the alternating wave priorities in the pair loop, 256 = none
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -723,24 +723,26 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ v2f pk_splat(float a) { return v2f{a, a}; }
 
+// A lane that does not take the section at all (another particle type, an idle lane) computes along and its accumulator is
+// put back by the caller (walk_section_lds), so the pair has no validity flag; outside the kernel's support (q >= 2, which
+// includes every pad entry: the dummy row is a thousand cells away) F = (q - 2)^3 >= 0 while it is negative inside, so the
+// range test is min(m F, 0).
 template<int COLAGROSSI>
 __device__ __forceinline__ void pair_interact_pk(const DevParams &p, const Self &s, const float3 &q, float inv_h, const Gathered &g,
-	bool valid, bool rt_diffuse, float4 &force)
+	bool rt_diffuse, float4 &force)
 {
 	static_assert(TILE_HB == 2, "two pairs per packed operation");
 	const float4 &n0 = g.npos[0], &n1 = g.npos[1];
 	const v2f rx = {q.x - n0.x, q.x - n1.x}, ry = {q.y - n0.y, q.y - n1.y}, rz = {q.z - n0.z, q.z - n1.z};
 	const v2f r2 = pk_fma(rz, rz, pk_fma(ry, ry, rx*rx));
 	const v2f r = {fast_sqrt(r2.x), fast_sqrt(r2.y)};
-	const bool on0 = valid && (r.x < p.influenceradius), on1 = valid && (r.y < p.influenceradius);
 	const float4 &w0 = g.nvel[0], &w1 = g.nvel[1];
 	const v2f vx = {s.vel.x - w0.x, s.vel.x - w1.x}, vy = {s.vel.y - w0.y, s.vel.y - w1.y}, vz = {s.vel.z - w0.z, s.vel.z - w1.z};
 	const v2f vel_dot_pos = pk_fma(vz, rz, pk_fma(vy, ry, vx*rx));
 	const v2f qm2 = pk_fma(r, pk_splat(inv_h), pk_splat(-2.0f));
 	const v2f f = qm2*qm2*qm2;                       // fcoeff rides in the window's mass
 	const float4 &a0 = g.naux[0], &a1 = g.naux[1];   // {P/rho^2, c, P, rho}
-	const float m0 = n0.w*f.x, m1 = n1.w*f.y;
-	const v2f mf = {on0 ? m0 : 0.0f, on1 ? m1 : 0.0f};
+	const v2f mf = {fminf(n0.w*f.x, 0.0f), fminf(n1.w*f.y, 0.0f)};
 
 	v2f dsel = {0.0f, 0.0f};
 	if (COLAGROSSI == DIFF_COLAGROSSI) {
@@ -793,7 +795,7 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 		return;
 	}
 	if (TilePk<KERNEL, TURB, COLAGROSSI, LJ>::value) {
-		pair_interact_pk<COLAGROSSI>(p, s, q, inv_h, g, take, diffuse, force);
+		pair_interact_pk<COLAGROSSI>(p, s, q, inv_h, g, diffuse, force);
 		return;
 	}
 	const bool anyLj = LJ && wave_any(ljlane);
@@ -845,10 +847,14 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	// SPHX_TILE_DEBUG & 64: the two waves of a SIMD (w and w + 4) take turns at being the one the issue arbiter prefers, batch by
 	// batch (priorities 3,0,3,0.. against 2,1,2,1..); left alone the older wave always wins and the younger one runs the last
 	// quarter of every tile alone, at the issue rate of a single wave
-	const bool prio = (list.dbg & 64) != 0, hiw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
+	// pattern: the older wave is preferred in batches 0,1 of every 4 (default); SPHX_TILE_DEBUG 64: in 0,2; 128: in 0,1,2; 256: priorities
+	// left alone.  Measured at 32 M particles: 4.67 ms per launch left alone, 4.52 / 4.50 / 4.49 with patterns 1 / 2 / 3
+	const int prio = (list.dbg & 256) ? 0 : (((list.dbg >> 6) & 3) ? ((list.dbg >> 6) & 3) : 3);
+	const bool hiw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
 #define SPHX_RING_STEP(J, JN) \
 	if (prio) { if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } \
-	            else { if ((J) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); } } \
+	            else { const bool hi = (prio == 1) ? !((J) & 1) : (prio == 2) ? ((J) != 3) : ((J) < 2); \
+	                   if (hi) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); } } \
 	gather_half<TURB>(lw.q[J].y, sPos, sVel, sAux, B); \
 	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
 	load_list_u(list, voff, sec, next, lw.q[J]); \
@@ -1111,12 +1117,19 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				if (!total || base + total > WC) continue;     // cannot overflow for tiles of build_tiles_kernel
 				if (rjc.contig[k]) {
 					const int h0 = window_row_hash0(p, g2, g3, r) + ca - 1;      // cell hash of window column 0 of this row
+					// shift of a record of window cell (r, col): the row's part is wave-uniform, the column's part is col * cell size
+					// along COORD1 (home particles read their own row from the window, so nothing else has to reproduce this sum)
+					const float3 sh0 = tile_shift(p, ncells, r, 0);
+					const float stx = (p.c1 == 0) ? p.csc1 : 0.0f, sty = (p.c1 == 1) ? p.csc1 : 0.0f, stz = (p.c1 == 2) ? p.csc1 : 0.0f;
+					const bool wrap1 = (p.periodic & (1u << p.c1)) != 0u;
 					auto shifted = [&](float4 P, uint32_t h) {
 						int col = (int)(h & CELLTYPE_BITMASK) - h0;
-						if (col > ncells + 1) col -= gs1;        // the window wraps around a periodic COORD1
-						if (col < 0) col += gs1;
-						const float3 sh = tile_shift(p, ncells, r, col);
-						P.x += sh.x; P.y += sh.y; P.z += sh.z;
+						if (wrap1) {      // the window wraps around a periodic COORD1
+							if (col > ncells + 1) col -= gs1;
+							if (col < 0) col += gs1;
+						}
+						const float fc = (float)col;
+						P.x += fmaf(fc, stx, sh0.x); P.y += fmaf(fc, sty, sh0.y); P.z += fmaf(fc, stz, sh0.z);
 						if (PREMUL) P.w *= p.fcoeff;
 						return P;
 					};
@@ -1137,7 +1150,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 						const uint32_t st = a.cellStart[h];
 						if (st == CELL_EMPTY) continue;
 						const uint32_t cnt = cellEnd[h] - st, cb = 1u + base + off;
-						const float3 sh = tile_shift(p, ncells, r, col);
+						const float3 sh0 = tile_shift(p, ncells, r, 0);
+						const float fc = (float)col;
+						const float3 sh = make_float3(fmaf(fc, (p.c1 == 0) ? p.csc1 : 0.0f, sh0.x), fmaf(fc, (p.c1 == 1) ? p.csc1 : 0.0f, sh0.y),
+							fmaf(fc, (p.c1 == 2) ? p.csc1 : 0.0f, sh0.z));
 						for (uint32_t q = lane; q < cnt; q += 64u) {
 							float4 P = a.pos[st + q];
 							P.x += sh.x; P.y += sh.y; P.z += sh.z;
@@ -1206,10 +1222,14 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			if (wave_any(take0))
 				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, q, inv_h,
 					sPos, sVel, sAux, 0, rowsF, take0, momentum, true, ljlane, own.lwF, TILE_AHEAD, force, fx);
-			if (wave_any(take1))
+			if (PREMUL && !take0) force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // pair_interact_pk has no per-lane validity flag
+			if (wave_any(take1)) {
+				const float4 keep = force;
 				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, q, inv_h,
 					sPos, sVel, sAux, 1, rowsB, take1, momentum, false, false, lwB, 1, force, fx);
-			if (PREMUL && !momentum) { force.x = 0.0f; force.y = 0.0f; force.z = 0.0f; }   // see pair_interact_pk
+				if (PREMUL && !take1) force = keep;
+			}
+			if (PREMUL && !momentum) { force.x = 0.0f; force.y = 0.0f; force.z = 0.0f; }   // ... and no momentum switch
 		}
 		SPHX_PROF(7);
 		// vmcnt(0): only the list batches fetched past the section ends are in flight, all long complete; from here to the

@@ -191,190 +191,7 @@ sa_vertex_bc_kernel(DevParams p, SaArgs a)
 	}
 }
 
-// ---- gamma and its gradient at initialisation: src/cuda/gamma.cuh (Wendland), initGammaDevice (_kernel.cu:1891-1970) ----
-// Same expressions, same order, no contraction; what differs from the CPU oracle is the math library (atan2f, acoshf).
-struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r = { x, y, z }; return r; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
-__device__ __forceinline__ V3 operator*(V3 a, float s) { return v3(a.x*s, a.y*s, a.z*s); }
-__device__ __forceinline__ V3 operator/(V3 a, float s) { const float inv = 1.0f/s; return a*inv; }        // vector_math.h:526-530
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) { return v3(a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }
-__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
-__device__ __forceinline__ V3 normalize(V3 a) { return a*(1.0f/sqrtf(dot(a, a))); }                      // v*rsqrtf(sqlength(v))
-
-__device__ __forceinline__ float wendland_on_segment(float q)      // gamma.cuh:90-110
-{
-	float intKernel = 0.0f;
-	if (q < 2.0f) {
-		float tmp = (1.0f - q/2.0f);
-		float tmp4 = tmp*tmp;
-		tmp4 *= tmp4;
-		const float uq = 1.0f/q;
-		intKernel = 0.009947183943243458485555235210782147627153727858778528046729f*tmp4*tmp*((((8.0f*uq + 20.0f)*uq + 30.0f)*uq) + 21.0f);
-	}
-	return intKernel;
-}
-
-// gaussQuadratureO5 (gamma.cuh:138-163), with its loop as written: the break test follows the accumulation, so the
-// centroid point (multiplicity 1) is evaluated twice
-__device__ __forceinline__ float gauss_quadrature_O5(V3 vPos0, V3 vPos1, V3 vPos2, V3 relPos)
-{
-	const float weights[3] = { 0.225f, 0.132394152788506f, 0.125939180544827f };
-	const float points[3][3] = {
-		{ 0.333333333333333f, 0.333333333333333f, 0.333333333333333f },
-		{ 0.059715871789770f, 0.470142064105115f, 0.470142064105115f },
-		{ 0.797426985353087f, 0.101286507323456f, 0.101286507323456f } };
-	const int mult[3] = { 1, 3, 3 };
-	float val = 0.0f;
-#pragma unroll
-	for (int i = 0; i < 3; i++) {
-#pragma unroll
-		for (int j = 0; j < 3; j++) {
-			V3 pa = vPos0*points[i][j] + vPos1*points[i][(j + 1) % 3] + vPos2*points[i][(j + 2) % 3];
-			pa = pa - relPos;
-			val += weights[i]*wendland_on_segment(length(pa));
-			if (j >= mult[i])
-				break;
-		}
-	}
-	const float vol = length(cross(vPos1 - vPos0, vPos2 - vPos0))/2.0f;
-	return val*vol;
-}
-
-__device__ __forceinline__ void calc_vertex_rel_pos(V3 q_vb[3], V3 ns, float2 vPos0, float2 vPos1, float2 vPos2, float slength)   // :196-227
-{
-	unsigned j = 0;
-	if (fabsf(ns.x) > fabsf(ns.y))
-		j = 1;
-	if ((1 - j)*fabsf(ns.x) + j*fabsf(ns.y) > fabsf(ns.z))
-		j = 2;
-	const V3 coord1 = normalize(v3(-((j == 1)*ns.z) + (j == 2)*ns.y, (j == 0)*ns.z - ((j == 2)*ns.x), -((j == 0)*ns.y) + (j == 1)*ns.x));
-	const V3 coord2 = cross(ns, coord1);
-	q_vb[0] = -(coord1*vPos0.x + coord2*vPos0.y)/slength;
-	q_vb[1] = -(coord1*vPos1.x + coord2*vPos1.y)/slength;
-	q_vb[2] = -(coord1*vPos2.x + coord2*vPos2.y)/slength;
-}
-
-__device__ float grad_gamma_wendland(float slength, V3 q, const V3 *q_vb, V3 ns)      // gamma.cuh:248-370
-{
-	float pas = dot(ns, q);
-	float qas = fabsf(pas);
-	if (qas >= 2.f)
-		return 0.f;
-	float qas2 = qas*qas;
-	float qas3 = qas2*qas;
-	float qas4 = qas2*qas2;
-	float qas5 = qas3*qas2;
-	float gradGamma_as = 0.f;
-	float totalSumAngles = 0.f;
-	float sumAngles = 0.f;
-	for (unsigned e = 0; e < 3; e++) {
-		const V3 qv0 = q_vb[e % 3], qv1 = q_vb[(e + 1) % 3];
-		V3 v01 = normalize(qv0 - qv1);
-		V3 ne = normalize(cross(ns, v01));
-		float pae = dot(ne, q - qv0);
-		float qae = length(ns*pas + ne*pae);
-		float pav0 = -dot(q - qv0, v01);
-		float pav1 = -dot(q - qv1, v01);
-		totalSumAngles += copysignf(atan2f(pav1, fabsf(pae)) - atan2f(pav0, fabsf(pae)), pae);
-		if (qae < 2.0f) {
-			pav0 = copysignf(fminf(fabsf(pav0), sqrtf(4.0f - qae*qae)), pav0);
-			float pav02 = pav0*pav0;
-			pav1 = copysignf(fminf(fabsf(pav1), sqrtf(4.0f - qae*qae)), pav1);
-			float pav12 = pav1*pav1;
-			float qav0 = fminf(sqrtf(qae*qae + pav0*pav0), 2.0f);
-			float qav1 = fminf(sqrtf(qae*qae + pav1*pav1), 2.0f);
-			float pae2 = pae*pae;
-			float pae4 = pae2*pae2;
-			float pae6 = pae4*pae2;
-			gradGamma_as += 0.00015542474911f*(
-				+ 48.0f*qas5*(28.0f + qas2)*(
-						  atan2f(qas*pav1, pae*qav1) - atan2f(pav1, pae)
-						-(atan2f(qas*pav0, pae*qav0) - atan2f(pav0, pae)))
-				+ pae*(
-					 pav1*(3.0f*qas4*(-420.0f + 29.0f*qav1)
-						+ pae4*(-420.0f + 33.0f*qav1)
-						+ 2.0f*qas2*(-210.0f*(8.0f + pav12) + 756.0f*qav1 + 19.0f*pav12*qav1)
-						+ 4.0f*(336.0f + pav12*(pav12*(-21.0f + 2.0f*qav1) + 28.0f*(-5.0f + 3.0f*qav1)))
-						+ 2.0f*pae2*(420.0f*(-2.0f + qav1) + 6.0f*qas2*(-105.0f + 8.0f*qav1) + pav12*(-140.0f + 13.0f*qav1))
-						)
-					- pav0*(3.0f*qas4*(-420.0f + 29.0f*qav0)
-						+ pae4*(-420.0f + 33.0f*qav0)
-						+ 2.0f*qas2*(-210.0f*(8.0f + pav02) + 756.0f*qav0 + 19.0f*pav02*qav0)
-						+ 4.0f*(336.0f + pav02*(pav02*(-21.0f + 2.0f*qav0) + 28.0f*(-5.0f + 3.0f*qav0)))
-						+ 2.0f*pae2*(420.0f*(-2.0f + qav0) + 6.0f*qas2*(-105.0f + 8.0f*qav0) + pav02*(-140.0f + 13.0f*qav0))
-						)
-					+ 3.0f*(5.0f*pae6 + 21.0f*pae4*(8.0f + qas2) + 35.0f*pae2*qas2*(16.0f + qas2) + 35.0f*qas4*(24.0f + qas2))
-					*(
-						 copysignf(1.f, pav1)*acoshf(fmaxf(qav1/fmaxf(qae, 1e-7f), 1.f))
-						- copysignf(1.f, pav0)*acoshf(fmaxf(qav0/fmaxf(qae, 1e-7f), 1.f))
-						)
-					)
-				);
-			sumAngles += copysignf(atan2f(pav1, fabsf(pae)) - atan2f(pav0, fabsf(pae)), pae);
-		}
-	}
-	const float tmp1 = 1.0f - qas/2.0f;
-	float tmp2 = tmp1*tmp1;
-	tmp2 *= tmp2*tmp1;
-	gradGamma_as += (sumAngles - totalSumAngles)*0.05968310365947f*tmp2*(2.0f + 5.0f*qas + 4.0f*qas2);
-	return gradGamma_as/slength;
-}
-
-// Gamma<WENDLAND, PT_FLUID> :404-435 / Gamma<WENDLAND, PT_VERTEX> :437-513 (q_vb may be permuted)
-template<bool VERTEX>
-__device__ float gamma_wendland(float slength, V3 q, V3 *q_vb, V3 ns, V3 oldGGam, float epsilon)
-{
-	V3 r_aSigma = ns*dot(ns, q);
-	float q_aSigma = fminf(length(r_aSigma), 2.0f);
-	float gamma_as = 0.0f;
-	float gamma_vs = 0.0f;
-	if (VERTEX) {
-		const V3 ba = q_vb[1] - q_vb[0];
-		const V3 ca = q_vb[2] - q_vb[0];
-		const V3 pa = q - q_vb[0];
-		const float uu = dot(ba, ba);
-		const float uv = dot(ba, ca);
-		const float vv = dot(ca, ca);
-		const float wu = dot(ba, pa);
-		const float wv = dot(ca, pa);
-		const float invdet = 1.0f/(uv*uv - uu*vv);
-		const float u = (uv*wv - vv*wu)*invdet;
-		const float v = (uv*wu - uu*wv)*invdet;
-		if (((fabsf(u - 1.0f) < epsilon && fabsf(v) < epsilon) ||
-			 (fabsf(v - 1.0f) < epsilon && fabsf(u) < epsilon) ||
-			 (fabsf(u) < epsilon && fabsf(v) < epsilon)) && q_aSigma < epsilon) {
-			if (fabsf(u - 1.0f) < epsilon && fabsf(v) < epsilon) {
-				const V3 tmp = q_vb[1];
-				q_vb[1] = q_vb[2];
-				q_vb[2] = q_vb[0];
-				q_vb[0] = tmp;
-			} else if (fabsf(v - 1.0f) < epsilon && fabsf(u) < epsilon) {
-				const V3 tmp = q_vb[2];
-				q_vb[2] = q_vb[1];
-				q_vb[1] = q_vb[0];
-				q_vb[0] = tmp;
-			}
-			const V3 inward_normal = (-oldGGam)/fmaxf(length(oldGGam), slength*1e-3f);
-			const V3 e1 = q_vb[1] - q_vb[0], e2 = q_vb[2] - q_vb[0];
-			const float l1 = length(e1);
-			const float l2 = length(e2);
-			const float abc = dot(e1, inward_normal)/l1 + dot(e2, inward_normal)/l2 + dot(e1, e2)/l1/l2;
-			const float d = dot(inward_normal, cross(e1, e2))/l1/l2;
-			const float SolidAngle = fabsf(2.0f*atan2f(d, 1.0f + abc));
-			gamma_vs = SolidAngle*0.079577471545947667884441881686257181017229822870228224373833f;
-		}
-	}
-	if (q_aSigma < 2.0f && q_aSigma > epsilon) {
-		const float intVal = gauss_quadrature_O5(-q_vb[0], -q_vb[1], -q_vb[2], q);
-		if (VERTEX) gamma_as += intVal*dot(ns, r_aSigma);
-		else gamma_as = intVal*dot(ns, r_aSigma);
-	}
-	return VERTEX ? gamma_vs + gamma_as : gamma_as;
-}
+#include "sa_wall_gamma.h"
 
 struct SaGammaArgs {
 	float4 *newGGam;
@@ -408,10 +225,10 @@ sa_init_gamma_kernel(DevParams p, SaGammaArgs a)
 			const float4 be = a.boundElement[j];
 			const V3 normal = v3(be.x, be.y, be.z);
 			const V3 q = relPos/p.slength;
-			V3 q_vb[3];
-			calc_vertex_rel_pos(q_vb, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			if (pass == 0) gGam = gGam + normal*grad_gamma_wendland(p.slength, q, q_vb, normal);
-			else gam -= gamma_wendland<CPTYPE == PT_VERTEX>(p.slength, q, q_vb, normal, gGam, a.epsilon);
+			WallTri tri;
+			wall_tri_setup(tri, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			if (pass == 0) gGam = gGam + normal*(wall_grad_gamma(tri, q)/p.slength);
+			else gam -= wall_gamma<CPTYPE == PT_VERTEX>(tri, q, gGam, p.slength, a.epsilon);
 		});
 	}
 	a.newGGam[index] = make_float4(gGam.x, gGam.y, gGam.z, gam);
@@ -523,9 +340,9 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 					const float4 be = a.boundElement[j];
 					const V3 ns = v3(be.x, be.y, be.z);
 					const float inv_h = 1.0f/p.slength;
-					V3 q_vb[3];
-					calc_vertex_rel_pos(q_vb, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-					const float ggamAS = grad_gamma_wendland(p.slength, v3(rx*inv_h, ry*inv_h, rz*inv_h), q_vb, ns);
+					WallTri tri;
+					wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+					const float ggamAS = wall_grad_gamma(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
 					const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
 					if (a.cflGamma) {      // compute_gamma_cfl_solid_wall (:1458-1474): n.(v_a - v_s), n.v_a, n.v_s
 						const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
@@ -683,9 +500,9 @@ sa_repack_kernel(DevParams p, SaForcesArgs a)
 					const float4 be = a.boundElement[j];
 					const V3 ns = v3(be.x, be.y, be.z);
 					const float inv_h = 1.0f/p.slength;
-					V3 q_vb[3];
-					calc_vertex_rel_pos(q_vb, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-					const float ggamAS = grad_gamma_wendland(p.slength, v3(rx*inv_h, ry*inv_h, rz*inv_h), q_vb, ns);
+					WallTri tri;
+					wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+					const float ggamAS = wall_grad_gamma(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
 					const float c = p.repack_a*c0*c0*ggamAS;
 					force.x += c*be.x; force.y += c*be.y; force.z += c*be.z;
 				});
@@ -746,11 +563,11 @@ sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
 		const float4 be = a.boundElement[j];
 		const V3 normal = v3(be.x, be.y, be.z);
 		const V3 q = v3(rx, ry, rz)/p.slength;
-		V3 q_vb[3];
-		calc_vertex_rel_pos(q_vb, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-		const float ggamAS = grad_gamma_wendland(p.slength, q, q_vb, normal);
+		WallTri tri;
+		wall_tri_setup(tri, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+		const float ggamAS = wall_grad_gamma(tri, q)/p.slength;
 		g.x += ggamAS*be.x; g.y += ggamAS*be.y; g.z += ggamAS*be.z;
-		g.w -= gamma_wendland<false>(p.slength, q, q_vb, normal, oldg, a.epsilon);
+		g.w -= wall_gamma<false>(tri, q, oldg, p.slength, a.epsilon);
 	});
 	a.newGGam[index] = g;
 }
@@ -808,10 +625,10 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 		const V3 qNp1 = v3(((pcx - nNp1.x) + dx)*inv, ((pcy - nNp1.y) + dy)*inv, ((pcz - nNp1.z) + dz)*inv);
 		const float4 be = a.boundElement[j];
 		const V3 ns = v3(be.x, be.y, be.z);
-		V3 q_vb[3];
-		calc_vertex_rel_pos(q_vb, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-		const V3 gN = ns*grad_gamma_wendland(p.slength, qN, q_vb, ns);
-		const V3 gNp1 = ns*grad_gamma_wendland(p.slength, qNp1, q_vb, ns);
+		WallTri tri;       // one set-up, two positions
+		wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+		const V3 gN = ns*(wall_grad_gamma(tri, qN)/p.slength);
+		const V3 gNp1 = ns*(wall_grad_gamma(tri, qNp1)/p.slength);
 		gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
 		gGam = gGam + gNp1;
 	});

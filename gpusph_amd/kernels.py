@@ -274,6 +274,9 @@ class HipKernels:
                                                  p(forces), p(xsph), n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
                                                  P.slength, P.influenceradius, run_mode, self._s()))
 
+    def time_advance(self, d_t, d_dt):
+        capi.check(self.lib.sphx_time_advance(self.ctx.handle, capi.ptr(d_t), capi.ptr(d_dt), self._s()))
+
     # ---- ENABLE_INTERNAL_ENERGY (energy.hip)
     def forces_internal_energy(self, dedt, pos, vel, info, hash_, cellStart, neibslist, n, frm, to):
         p = capi.ptr

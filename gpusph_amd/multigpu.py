@@ -582,7 +582,7 @@ class MultiGpuEngine:
         self.pos, self.pos2 = self.pos2, self.pos
         self.vel, self.vel2 = self.vel2, self.vel
         # TIME_STEP_EPILOGUE: t += dt ; dt = min(dt_pred, dt_corr), over all devices (GPUSPH.cc:650-657)
-        self.d_t.add_(self.d_dt.double())
+        K.time_advance(self.d_t, self.d_dt)
         if self.world > 1:
             self.dist.all_reduce(self.d_dt_next, op=self.dist.ReduceOp.MIN)
         self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt

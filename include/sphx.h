@@ -519,6 +519,10 @@ int sphx_euler_basicstep_grenier(sphx_ctx *ctx, void *newPos, void *newVel, void
 int sphx_disable_free_surf_parts(sphx_ctx *ctx, void *pos, const void *info,
 	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
 
+/* t += dt on the device (double += float, the sum GPUSPH::runSimulation keeps on the host, src/GPUSPH.cc:650-657): for
+ * callers that keep dt device-resident (sphx_forces_dtreduce_device) and do not want a host round trip per step */
+int sphx_time_advance(sphx_ctx *ctx, double *d_t, const float *d_dt, void *stream);
+
 /* ---- small stream-ordered helpers the callers of the reference get from cudaMemset -------- */
 int sphx_memset_async(void *ptr, int value, size_t bytes, void *stream);
 

@@ -107,6 +107,9 @@ class OracleKernels:
         self.L.orc_euler(C.byref(self.op), _p(npos), _p(nvel), _p(opos), _p(ovel), _p(info), _p(hash_), _p(forces), None,
                          C.c_uint32(n), C.c_float(dt), C.c_int(step))
 
+    def time_advance(self, d_t, d_dt):
+        d_t.add_(d_dt.double())
+
     # ---- the optional arrays of the re-sort
     def gather_rows(self, sorted_, unsorted, partindex, n):
         sorted_[:n] = unsorted[partindex[:n].long()]

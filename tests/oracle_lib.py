@@ -61,7 +61,10 @@ def lib():
     if _lib is None:
         path = os.path.join(ORACLE_DIR, "libsph_oracle.so")
         src = [os.path.join(ORACLE_DIR, f) for f in ("sph_oracle.c", "sph_oracle.h")]
-        if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in src):
+        override = os.environ.get("SPH_ORACLE_LIB")      # bench.py's CPU baseline: the same source built -O3 -march=native on the box it runs on
+        if override and os.path.exists(override):
+            path = override
+        elif not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in src):
             build()      # a library older than its source would silently test yesterday's restatement
         _lib = C.CDLL(path)
         _lib.orc_W.restype = C.c_float; _lib.orc_W.argtypes = [C.c_int, C.c_float, C.c_float]

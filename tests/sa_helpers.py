@@ -6,6 +6,25 @@ from gpusph_amd.problem import SABox
 from oracle_lib import Oracle, orc_params_from
 
 
+def assert_close_but_for_gamma_spikes(got, want, tol, scale=None, frac=0.01, spike=50.0, what=""):
+    """|got - want| <= tol * scale for all but a fraction `frac` of the entries, and <= spike * tol * scale for those.
+
+    The closed form of |grad gamma_as| (edge antiderivatives that cancel against each other and against the angle
+    bookkeeping) is ill-conditioned for some positions of a particle relative to an element: two float evaluations of the
+    SAME formula in different operation orders differ there by up to ~1e-3 of |grad gamma|, and the reference's own float
+    evaluation is that far from the float64 value of its formula (tests/test_sa_wall_gamma.py measures both against the
+    reference's numbers).  The kernels integrate the same expressions in their own order of operations (set-up of an element
+    once, polynomial collected by powers of the distance), so the few particles that have such an element in reach carry a
+    difference the bulk does not; everything derived from gamma (SA forces, density summation, trajectories) inherits it."""
+    got = np.asarray(got, dtype=np.float64); want = np.asarray(want, dtype=np.float64)
+    s = float(np.abs(want).max() if scale is None else scale)
+    err = np.abs(got - want)
+    bad = float((err > tol * s).mean()) if err.size else 0.0
+    worst = float(err.max()) if err.size else 0.0
+    assert bad <= frac and worst <= spike * tol * s, "%s: %.3g of the entries beyond %.1e of the scale %.3g (allowed %.3g), worst %.3g of the scale (allowed %.3g)" % (
+        what, bad, tol, s, frac, worst / max(s, 1e-300), spike * tol)
+
+
 def analytic_vertex_gamma(problem, st):
     """gamma of a particle ON a planar wall is 1/2, on an edge 1/4, in a corner 1/8 (the fraction of the kernel support
     inside the tank); rim vertices of the open top are treated like face/edge vertices of an infinitely tall wall"""
