@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--no-tiles", action="store_true", help="A/B: use the generic gather forces kernel")
     ap.add_argument("--two-fluids", action="store_true", help="A/B: a lighter second fluid on top (multi-fluid code path)")
     ap.add_argument("--viscosity", default=None, help="A/B: legacy viscosity selector instead of ARTVISC (KINEMATICVISC, DYNAMICVISC, SPSVISC)")
+    ap.add_argument("--linearization", default="xzy", help="cell linearisation; the default makes COORD3 = y, DamBreak3D's own split "
+                    "axis (src/problems/DamBreak3D.cu:217-220), for every --gpus so that the points of a scaling curve share one memory layout")
     args = ap.parse_args()
 
     if args.no_tiles:
@@ -150,14 +152,21 @@ def main():
             dist.init_process_group(backend=backend)
 
     dp = DamBreak3D.deltap_for(args.particles, obstacle=not args.no_obstacle)
-    lin = "xzy" if world > 1 else "yzx"   # multi-GPU: split along Y like DamBreak3D::fillDeviceMap, COORD3 = y
+    lin = args.linearization
     prob = DamBreak3D(dp, obstacle=not args.no_obstacle, linearization=lin, two_fluids=args.two_fluids,
                       viscosity=args.viscosity, kinematic_visc=1.0e-6)
     n_total = prob.num_particles
 
     if world > 1:
         from gpusph_amd.multigpu import MultiGpuEngine
-        eng = MultiGpuEngine(prob, device=device, rank=rank, world=world, track_particle_count=True)
+        transport = None
+        if os.environ.get("SPHX_HALO", "torch") == "capi":      # the library's own RCCL entry points (include/sphx.h sphx_halo_*)
+            from gpusph_amd import capi
+            from gpusph_amd.halo import CapiTransport
+            box = [CapiTransport.new_unique_id(capi.load()) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            transport = lambda k: CapiTransport(k, rank, world, unique_id=box[0])
+        eng = MultiGpuEngine(prob, device=device, rank=rank, world=world, track_particle_count=True, transport=transport)
     else:
         from gpusph_amd.engine import TimestepEngine
         eng = TimestepEngine(prob, device=device, track_particle_count=False)
@@ -234,7 +243,7 @@ def main():
             "config": {"workload": "DamBreak3D %d particles (dp=%.6f), Wendland, WCSPH + %s, "
                                    "Colagrossi diffusion, DYN boundary, neib rebuild every 10 steps"
                                    % (n_total, dp, "viscosity<%s>" % args.viscosity if args.viscosity else "artificial viscosity"),
-                       "particles": n_total, "parallelism": "slab%d" % world if world > 1 else "single",
+                       "particles": n_total, "parallelism": "slab%d" % world if world > 1 else "single", "linearization": lin,
                        "mean_neibs": round(nbar, 2)},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -102,6 +102,17 @@ SIGNATURES = {
     "sphx_forces_basicstep_grenier": (_i, [_vp] * 10 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_disable_free_surf_parts": (_i, [_vp, _vp, _vp, _u32, _u32, _vp]),
     "sphx_time_advance": (_i, [_vp, _vp, _vp, _vp]),
+    "sphx_halo_group_create": (_i, [_i, C.POINTER(_vp)]),
+    "sphx_halo_group_destroy": (_i, [_vp]),
+    "sphx_halo_create_threads": (_i, [_vp, _vp, _i, C.POINTER(_vp)]),
+    "sphx_halo_unique_id": (_i, [_vp]),
+    "sphx_halo_create_rccl": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "sphx_halo_destroy": (_i, [_vp]),
+    "sphx_halo_exchange": (_i, [_vp, _i, _vp, _vp, _i, _u32, _u32, _u32, _u32, _i, _u32, _u32, _u32, _u32, _vp]),
+    "sphx_halo_allreduce_min_f32": (_i, [_vp, _vp, _vp]),
+    "sphx_halo_allreduce_sum_f32": (_i, [_vp, _vp, _u32, _vp]),
+    "sphx_halo_allgather_u64x2": (_i, [_vp, _vp, _vp, _vp]),
+    "sphx_halo_barrier": (_i, [_vp, _vp]),
     "sphx_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),
     "sphx_device_count": (_i, [C.POINTER(_i)]),
     "sphx_set_device": (_i, [_i]),

@@ -44,12 +44,14 @@ class SlabPartition:
         if world > 1 and (problem.simparams.periodicbound & (1 << c3)):
             raise ValueError("the domain is periodic along the split axis (COORD3 = %s): not supported by the slab "
                              "partition; choose a linearisation whose COORD3 is a non-periodic axis" % "xyz"[c3])
-        per = self.gs3 // world
-        if world > 1 and per < 2:
-            raise ValueError("need at least 2 cell planes per device along the split axis (have %d planes, %d devices)"
-                             % (self.gs3, world))
-        self.lo = [d * per for d in range(world)]
-        self.hi = [(d + 1) * per for d in range(world)]
+        # fillDeviceMapByAxis (src/ProblemCore.cc:1061-1116): fewer than 3 planes per device on average are refused; a device
+        # takes round(planes / devices) planes, the last one what is left
+        if world > 1 and self.gs3 / float(world) < 3.0:
+            raise ValueError("not enough cells along the split axis (%d planes, %d devices: fewer than 3 per device; "
+                             "src/ProblemCore.cc:1089-1090)" % (self.gs3, world))
+        per = int(np.floor(self.gs3 / float(world) + 0.5))
+        self.lo = [min(d * per, self.gs3) for d in range(world)]
+        self.hi = [min((d + 1) * per, self.gs3) for d in range(world)]
         self.hi[-1] = self.gs3
 
     def plane_types(self, rank):
@@ -79,7 +81,7 @@ class SlabPartition:
 
 class MultiGpuEngine:
     def __init__(self, problem, device, rank, world, kernels=None, track_particle_count=True, margin=1.25,
-                 overlap=True, allocated=None, clobber_neibslist=False):
+                 overlap=True, allocated=None, clobber_neibslist=False, transport=None):
         if world > 1 and (problem.simparams.simflags & D.ENABLE_XSPH):
             raise ValueError("ENABLE_XSPH needs the mean velocity of the halo particles' neighbourhoods: single domain only")
         self.sa = problem.simparams.boundarytype == D.SA_BOUNDARY
@@ -101,11 +103,17 @@ class MultiGpuEngine:
             from .kernels import HipKernels
             kernels = HipKernels(problem, self.alloc, self.device)
         self.k = kernels
+        # who moves the edge layers: torch.distributed by default, or a transport the caller built (halo.CapiTransport:
+        # the library's own sphx_halo_* entry points; a callable gets the kernels of this rank and returns the transport)
+        self.transport = None
         if world > 1:
-            import torch.distributed as dist
-            self.dist = dist
-        else:
-            self.dist = None
+            if callable(transport):
+                transport = transport(self.k)
+            if transport is None:
+                import torch.distributed as dist
+                from .halo import TorchTransport
+                transport = TorchTransport(dist, self.is_cuda)
+            self.transport = transport
         dev, A = self.device, self.alloc
         f32, i32, i16 = torch.float32, torch.int32, torch.int16
 
@@ -210,45 +218,9 @@ class MultiGpuEngine:
         return left, right
 
     def _exchange(self, tensors):
-        """send my edge layers / receive the halo layers of every tensor in `tensors` (dim-0 ranges),
-        as one grouped batch of point-to-point operations.  Payloads travel as raw bytes (RCCL has no
-        16-bit integer type for the ushort4 particleinfo)."""
-        dist = self.dist
+        """send my edge layers / receive the halo layers of every tensor in `tensors` (dim-0 ranges)"""
         left, right = self._neighbours()
-        stage = self.is_cuda and dist.get_backend() == "gloo"     # test rigs only: gloo moves host memory
-        ops, copies = [], []
-
-        def view(t, rng):
-            v = t[rng[0]:rng[1]].view(torch.uint8)
-            return v
-
-        def send(t, rng, peer):
-            if rng[1] > rng[0]:
-                v = view(t, rng)
-                ops.append(dist.P2POp(dist.isend, v.cpu() if stage else v, peer))
-
-        def recv(t, rng, peer):
-            if rng[1] > rng[0]:
-                v = view(t, rng)
-                if stage:
-                    h = torch.empty(v.shape, dtype=torch.uint8)
-                    copies.append((v, h))
-                    v = h
-                ops.append(dist.P2POp(dist.irecv, v, peer))
-
-        for t in tensors:
-            row = t[0:1].view(torch.uint8).numel() if t.shape[0] else 0
-            if left is not None:
-                send(t, self.send_l, left); recv(t, self.recv_l, left)
-                self.halo_bytes += row * (self.send_l[1] - self.send_l[0] + self.recv_l[1] - self.recv_l[0])
-            if right is not None:
-                send(t, self.send_r, right); recv(t, self.recv_r, right)
-                self.halo_bytes += row * (self.send_r[1] - self.send_r[0] + self.recv_r[1] - self.recv_r[0])
-        if ops:
-            for r in dist.batch_isend_irecv(ops):
-                r.wait()
-        for v, h in copies:
-            v.copy_(h)
+        self.halo_bytes += self.transport.exchange(tensors, left, right, self.send_l, self.recv_l, self.send_r, self.recv_r)
 
     # ------------------------------------------------------------------ neighbour phase
     def build_neibs(self):
@@ -365,7 +337,7 @@ class MultiGpuEngine:
 
     def _update_segments_and_halo(self):
         """UPDATE_SEGMENTS + CROP + APPEND_EXTERNAL (src/Integrator.cc:170-230)"""
-        K, dist = self.k, self.dist
+        K = self.k
         seg = [int(v) & 0xFFFFFFFF for v in self.segment_start.cpu().tolist()]       # DOWNLOAD (sync)
         newn = int(self.new_num.item()) & 0xFFFFFFFF
         starts = list(seg) + [newn]
@@ -387,12 +359,9 @@ class MultiGpuEngine:
         self.send_l = (edge_start, split) if left is not None else (0, 0)
         self.send_r = (split, n_int) if right is not None else (0, 0)
         # counts of the layers my neighbours send me
-        mine = torch.tensor([self.send_l[1] - self.send_l[0], self.send_r[1] - self.send_r[0]], dtype=torch.int64,
-                            device=self.device)
-        allc = [torch.zeros_like(mine) for _ in range(self.world)]
-        dist.all_gather(allc, mine)
-        rl = int(allc[left][1].item()) if left is not None else 0      # left neighbour's right layer
-        rr = int(allc[right][0].item()) if right is not None else 0    # right neighbour's left layer
+        allc = self.transport.allgather_pair(self.send_l[1] - self.send_l[0], self.send_r[1] - self.send_r[0], self.device)
+        rl = allc[left][1] if left is not None else 0      # left neighbour's right layer
+        rr = allc[right][0] if right is not None else 0    # right neighbour's left layer
         if n_int + rl + rr > self.alloc:
             raise RuntimeError("rank %d: %d internal + %d halo particles exceed the %d allocated"
                                % (self.rank, n_int, rl + rr, self.alloc))
@@ -584,7 +553,7 @@ class MultiGpuEngine:
         # TIME_STEP_EPILOGUE: t += dt ; dt = min(dt_pred, dt_corr), over all devices (GPUSPH.cc:650-657)
         K.time_advance(self.d_t, self.d_dt)
         if self.world > 1:
-            self.dist.all_reduce(self.d_dt_next, op=self.dist.ReduceOp.MIN)
+            self.transport.allreduce_min(self.d_dt_next)
         self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt
         self.iterations += 1
 
@@ -620,7 +589,7 @@ class MultiGpuEngine:
             return None
         tot = torch.cat([self.rbforces[:, :3].double().sum(0), self.rbtorques[:, :3].double().sum(0)])
         if self.world > 1:
-            self.dist.all_reduce(tot)
+            self.transport.allreduce_sum(tot)
         tot = tot.cpu().numpy()
         return tot[:3].astype(np.float32), tot[3:].astype(np.float32)
 

@@ -545,6 +545,44 @@ int sphx_memcpy_h2d(void *dst, const void *h_src, size_t bytes);
 int sphx_memcpy_d2h(void *h_dst, const void *src, size_t bytes);
 int sphx_memcpy_d2d(void *dst, const void *src, size_t bytes);
 
+/* ---- halo exchange of the slab decomposition -----------------------------------------------------------------
+ * What GPUWorker::importExternalCells / transferBursts / peerAsyncTransfer / networkTransfer do
+ * (src/GPUWorker.cc:396-407, 711-822, 825-948): after a re-sort every device sends the particles of its inner-edge layers
+ * (pos, vel, info, hash, and whatever particle state the option set adds) to the neighbouring devices and receives theirs
+ * behind its own particles; after each forces pass the same for the forces.  REORDER leaves each layer one contiguous range
+ * of rows (device map split on COORD3), so a layer of a buffer is [start, start + count) rows of rowBytes bytes.
+ *
+ * Two transports behind the same calls:
+ *   sphx_halo_create_threads   one worker THREAD per device in one process, the reference's own model
+ *                              (GPUWorker::simulationThread): a layer is one peer copy on the caller's stream
+ *                              (hipMemcpyPeerAsync, over xGMI between two devices), the workers meet at a barrier around
+ *                              it like the reference's threadSynchronizer.  Every worker calls each collective below.
+ *   sphx_halo_create_rccl      one PROCESS per device: ncclSend / ncclRecv of the layers in one group per exchange on the
+ *                              caller's stream (no host synchronisation), dt by ncclAllReduce(min).  The 128-byte id comes
+ *                              from sphx_halo_unique_id on one rank and reaches the others by the host's own means.
+ *                              RCCL is dlopen'ed on first use.
+ * leftRank / rightRank: the ranks owning the neighbouring slabs, -1 for none.  All calls of a collective must be made by
+ * every rank of the group (thread transport: they block on a barrier). */
+typedef struct sphx_halo sphx_halo;
+typedef struct sphx_halo_group sphx_halo_group;
+int sphx_halo_group_create(int world, sphx_halo_group **out);
+int sphx_halo_group_destroy(sphx_halo_group *group);
+int sphx_halo_create_threads(sphx_halo_group *group, sphx_ctx *ctx, int rank, sphx_halo **out);
+int sphx_halo_unique_id(void *id128);
+int sphx_halo_create_rccl(sphx_ctx *ctx, const void *id128, int rank, int world, sphx_halo **out);
+int sphx_halo_destroy(sphx_halo *h);
+/* UPDATE_EXTERNAL of `nbuf` buffers: send my two edge layers, receive the two halo layers */
+int sphx_halo_exchange(sphx_halo *h, int nbuf, void *const *bufs, const uint32_t *rowBytes,
+	int leftRank, uint32_t sendLeftStart, uint32_t sendLeftCount, uint32_t recvLeftStart, uint32_t recvLeftCount,
+	int rightRank, uint32_t sendRightStart, uint32_t sendRightCount, uint32_t recvRightStart, uint32_t recvRightCount,
+	void *stream);
+/* dt of the step = the smallest of the devices' (GPUSPH.cc:650-657 over gdata->dts); total force / torque on a body */
+int sphx_halo_allreduce_min_f32(sphx_halo *h, float *d_value, void *stream);
+int sphx_halo_allreduce_sum_f32(sphx_halo *h, float *d_values, uint32_t n, void *stream);
+/* the sizes of the layers every rank is about to send (host values: the receiver sizes its halo with them) */
+int sphx_halo_allgather_u64x2(sphx_halo *h, const uint64_t mine[2], uint64_t *all /* [2*world] */, void *stream);
+int sphx_halo_barrier(sphx_halo *h, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

