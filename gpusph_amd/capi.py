@@ -8,7 +8,7 @@ import os
 from .params import SphxParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsphx.so")
+LIB_PATH = os.environ.get("SPHX_LIB") or os.path.join(_HERE, "libsphx.so")      # SPHX_LIB: A/B runs of another build
 
 SPHX_OK, SPHX_ERR_INVALID, SPHX_ERR_RUNTIME, SPHX_ERR_UNSUPPORTED = 0, -1, -2, -3
 
