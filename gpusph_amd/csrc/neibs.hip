@@ -646,8 +646,9 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 #pragma unroll
 					for (int u = 0; u < NEIB_MLP; ++u) {
 						const float r2a = fmaf(0.0f, cp[u].w, r2[u]);
-						bool acc = (r2a < sqinfluenceradius) && ((uint32_t)u < rem);
-						if (cell == 13u) acc = acc && (jrel + (uint32_t)u != selfrel);
+						// (selfrel is no index of any other cell, so the self test needs no "is this the home cell" around it: as a
+						// select between two per-lane flags that guard cost five vector instructions per candidate)
+						const bool acc = (r2a < sqinfluenceradius) && ((uint32_t)u < rem) && (jrel + (uint32_t)u != selfrel);
 						ring.fring[nf % (uint32_t)NEIB_FRING][lane] = (neibdata)(jrel + (uint32_t)u + encv);
 						encv = acc ? 0u : encv;
 						nf += acc ? 1u : 0u;

@@ -397,8 +397,11 @@ extern "C" int sphx_set_gravity(sphx_ctx *ctx, const float g[3])
 
 // The reference uploads these tables with cudaMemcpyToSymbol on the default stream, in order with its kernels.  Here the
 // engines run on whatever stream the caller passes, so the upload is deferred to the next engine call that reads the
-// tables and issued on that call's stream (also capturable into a hipGraph): kernels already enqueued keep the old values,
-// kernels enqueued afterwards see the new ones, whichever stream is used.
+// tables (forces, Euler) and issued on THAT call's stream: kernels already enqueued there keep the old values, kernels
+// enqueued there afterwards see the new ones.  One stream at a time: an engine call on another stream that reads the tables is
+// not ordered against that copy -- a caller that runs forces and Euler on different streams orders them itself (the drivers
+// here use one compute stream).  Not for stream capture: the copy reads a pinned staging slot when it executes, and a slot is
+// re-used after SPHX_RB_RING uploads behind a host-side event wait.
 static int upload_rb(sphx_ctx *ctx)
 {
 	ctx->rb_dirty = true;

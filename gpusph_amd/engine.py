@@ -123,7 +123,7 @@ class TimestepEngine(MultiGpuEngine):
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
         self.pos, self.pos2 = self.pos2, self.pos
         self.vel, self.vel2 = self.vel2, self.vel
-        self.d_t.add_(self.d_dt.double())
+        self.k.time_advance(self.d_t, self.d_dt)
         self.d_dt, self.d_dt_next = self.d_dt_next, self.d_dt
         self.iterations += 1
 
@@ -142,6 +142,13 @@ class TimestepEngine(MultiGpuEngine):
             self.build_neibs()
         if not reset:
             return
+        # the restart below re-initialises velocities and densities only.  Option sets that carry more evolved state would need
+        # what a run resumed from the repack file re-initialises as well (volumes: GPUSPH.cc:495; internal energy, k-epsilon
+        # fields, the gamma of dynamic-gamma SA runs): refused rather than left half reset
+        if self.grenier or self.energy_on or self.keps or (self.sa and getattr(self, "sa_dynamic_gamma", False)):
+            raise ValueError("repack(reset=True) is built for runs whose evolved state is positions, velocities and densities: "
+                             "not with SPH_GRENIER volumes, internal energy, k-epsilon or dynamic gamma (use reset=False and "
+                             "re-initialise those buffers)")
         self.iterations = 0
         self.d_t.zero_()
         self.t_host = 0.0

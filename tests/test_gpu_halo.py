@@ -104,3 +104,16 @@ def test_rccl_transport_on_one_rank():
     assert torch.equal(pos[100:120], want_pos) and torch.equal(info[100:120], want_info)
     assert moved == 2 * 20 * (16 + 8)
     tr.close()
+
+
+def test_cpp_worker_threads_exchange_through_the_c_abi():
+    """gpusph_amd/host/halo_check: C++ worker threads (one context each, as GPUWorker's) exchange edge layers of buffers shaped
+    like BUFFER_POS / INFO / HASH, reduce dt and a body total and gather layer counts through sphx_halo_*; three slabs, so that
+    the middle one has both neighbours"""
+    import os, subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpusph_amd", "host", "halo_check")
+    assert os.path.exists(exe), "gpusph_amd/host/halo_check is not built (make -C gpusph_amd/host halo_check)"
+    for world in (2, 3):
+        r = subprocess.run([exe, str(world)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "as expected" in r.stdout
