@@ -38,6 +38,8 @@ struct ForcesArgs {
 	const uint32_t *tileRows;    // [tile][TILE_ROWDESC]: the window rows (tile_lists_kernel)
 	const uint16_t *tileOwnSlot; // [particle]: byte offset of the particle's own row in its tile's window
 	float4 *xsph;        // ENABLE_XSPH: mean velocity correction of fluid particles, else NULL
+	const float4 *saGam; // SA_BOUNDARY modes of the tiled kernel (SPHX_TURB_SA*): gamma in .w (diffusion mode), the step's dt
+	float saDt;
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
 	uint32_t numBlocks;   // generic kernel: blocks of SPHX_BLOCK_FORCES particles to cover
@@ -123,6 +125,7 @@ struct Self {
 	float visc_c, visc_mu, visc_kin, visc_onemk, visc_wA, visc_wH, visc_wG;
 	uint32_t visc_constmask, visc_ownmask;
 	uint32_t f2mask;   // all ones for SPH_F2 (generic kernel only), per lane like the viscosity selectors
+	float sa_dt2rho;   // SA density diffusion mode of the tiled kernel: dt * 2 * rho_i
 };
 
 // one pair (i <- j).  Terms, in the reference's order (compute_all_pp_interaction,
@@ -137,6 +140,13 @@ struct Self {
 #define SPHX_TURB_NEWT 8
 #define SPHX_TURB_MF 16     // tiled kernel only: more than one fluid, the neighbour's fluid number rides in the EOS row (eos_kernel)
 #define SPHX_TURB_STRESS 32 // tiled kernel only: not a forces pass but the SPS stress tensor (SPSstressMatrixDevice) over the same tiles
+// SA_BOUNDARY over the same tiles (sa_bounds.hip finishes each of them with the boundary-element terms, by the list walker):
+// the particle <- particle sums of the forces (fluid and vertex neighbours; the vertex section takes the place of the boundary
+// section in the tile lists), of the density summation and of the Brezzi density diffusion
+#define SPHX_TURB_SA 64
+#define SPHX_TURB_SA_DSUM 128
+#define SPHX_TURB_SA_DIFF 256
+#define SPHX_TURB_SA_ANY (SPHX_TURB_SA | SPHX_TURB_SA_DSUM | SPHX_TURB_SA_DIFF)
 #define TURB_MODEL(T) ((T) & 7)
 
 // select chain on the (at most four) kernel-argument values instead of a lane-indexed load from the argument block
@@ -675,6 +685,42 @@ __device__ __forceinline__ void stress_interact(const DevParams &p, const Self &
 	acc2.z -= vz*mx; acc2.w -= vz*my; acc2.u -= vz*mz;
 }
 
+// SA_BOUNDARY, density summation (densitySumVolumicDevice, src/cuda/density_sum_kernel.cu:206-250): -m W(r^n) for every stored
+// neighbour, + m W(r^n+1) for those still in range, as two sums (acc.x, acc.y).  The window holds the positions at step n and, in
+// place of the velocities, the displacement n -> n+1 of every particle: r^n+1 = r^n + (d_i - d_j).  Pad entries have mass 0.
+__device__ __forceinline__ void sa_dsum_interact(const DevParams &p, const Self &s, float inv_h, float qx, float qy, float qz,
+	const float4 &npos, const float4 &ndisp, bool valid, float4 &acc)
+{
+	const float rx = qx - npos.x, ry = qy - npos.y, rz = qz - npos.z;
+	const float m = valid ? npos.w : 0.0f;
+	auto W = [&](float r) {
+		const float R = r*inv_h;
+		float val = fmaf(-0.5f, R, 1.0f);
+		val *= val; val *= val;
+		return val*fmaf(2.0f, R, 1.0f)*p.wcoeff;
+	};
+	const float rN = fast_sqrt(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+	acc.x = fmaf(-m, W(rN), acc.x);
+	const float ux = rx + (s.vel.x - ndisp.x), uy = ry + (s.vel.y - ndisp.y), uz = rz + (s.vel.z - ndisp.z);
+	const float rNp1 = fast_sqrt(fmaf(uz, uz, fmaf(uy, uy, ux*ux)));
+	acc.y = fmaf((rNp1 < p.influenceradius) ? m : 0.0f, W(rNp1), acc.y);
+}
+
+// SA_BOUNDARY, Brezzi density diffusion (computeDensityDiffusionDevice, src/cuda/forces_kernel.def:1766-1783,4515-4560) of one
+// fluid neighbour; the EOS rows give the neighbour's pressure and density.  acc.w accumulates, dt2rho = dt * 2 * rho_i
+__device__ __forceinline__ void sa_diff_interact(const DevParams &p, const Self &s, float inv_h, float qx, float qy, float qz,
+	const float4 &npos, const float4 &naux, bool valid, float dt2rho, float4 &acc)
+{
+	const float rx = qx - npos.x, ry = qy - npos.y, rz = qz - npos.z;
+	const float r = fast_sqrt(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+	const bool on = valid && r < p.influenceradius;
+	const float f = kernel_F<SPHX_WENDLAND>(p, r, inv_h);
+	const float gdotr = fmaf(p.gravity[2], rz, fmaf(p.gravity[1], ry, p.gravity[0]*rx));
+	const float n_rho = naux.w;
+	const float t = p.densityDiffCoeff*fmaf(2.0f*fast_rcp(s.rho + n_rho), s.P - naux.z, -gdotr)*npos.w*fast_rcp(n_rho)*f*dt2rho;
+	acc.w += on ? t : 0.0f;
+}
+
 #define TILE_HB 2   // pairs per pipeline stage ("half batch")
 // window capacity of a tiled-kernel instantiation, and the LDS placement of the SPS rows behind the EOS rows
 #define TILE_WC(T) ((TURB_MODEL(T) == SPHX_SPS) ? TILE_WCAP_SPS : TILE_WCAP)
@@ -699,8 +745,9 @@ __device__ __forceinline__ void gather_half(uint32_t packed, const float4 *sPos,
 #pragma unroll
 	for (int k = 0; k < TILE_HB; ++k) {
 		const uint32_t L = k ? packed >> 16 : packed & 0xFFFFu;
-		g.npos[k] = lds_row(sPos, L); g.nvel[k] = lds_row(sVel, L);
-		if (!(TURB & SPHX_TURB_STRESS)) g.naux[k] = lds_row(sAux, L);
+		g.npos[k] = lds_row(sPos, L);
+		if (!(TURB & SPHX_TURB_SA_DIFF)) g.nvel[k] = lds_row(sVel, L);
+		if (!(TURB & (SPHX_TURB_STRESS | SPHX_TURB_SA_DSUM))) g.naux[k] = lds_row(sAux, L);
 		if (TURB_MODEL(TURB) == SPHX_SPS) {   // the SPS rows lie behind the EOS rows: sAux[WS + slot], sAux[2 WS + slot]
 			const float4 ta = lds_row(sAux + WS, L), tb = lds_row(sAux + 2*WS, L);
 			g.ntau[k][0] = ta.x; g.ntau[k][1] = ta.y; g.ntau[k][2] = ta.z; g.ntau[k][3] = ta.w; g.ntau[k][4] = tb.x; g.ntau[k][5] = tb.y;
@@ -786,6 +833,18 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 #pragma unroll
 		for (int k = 0; k < TILE_HB; ++k)
 			stress_interact<KERNEL>(p, s, inv_h, q.x, q.y, q.z, g.npos[k], g.nvel[k], take, force, fx);
+		return;
+	}
+	if (TURB & SPHX_TURB_SA_DSUM) {
+#pragma unroll
+		for (int k = 0; k < TILE_HB; ++k)
+			sa_dsum_interact(p, s, inv_h, q.x, q.y, q.z, g.npos[k], g.nvel[k], take, force);
+		return;
+	}
+	if (TURB & SPHX_TURB_SA_DIFF) {
+#pragma unroll
+		for (int k = 0; k < TILE_HB; ++k)
+			sa_diff_interact(p, s, inv_h, q.x, q.y, q.z, g.npos[k], g.naux[k], take, s.sa_dt2rho, force);
 		return;
 	}
 	if (LJ && ljsec) {
@@ -960,6 +1019,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	constexpr bool SPSW = TURB_MODEL(TURB) == SPHX_SPS;
 	constexpr bool STRESS = (TURB & SPHX_TURB_STRESS) != 0;   // stress mode: no EOS rows, every active particle walks both sections
 	constexpr bool PREMUL = TilePk<KERNEL, TURB, COLAGROSSI, LJ>::value;   // the window holds m * fcoeff (pair_interact_pk)
+	// SA_BOUNDARY modes: sums over the fluid and vertex neighbours of the fluid particles, finished by sa_bounds.hip
+	constexpr bool SA = (TURB & SPHX_TURB_SA_ANY) != 0, SA_DSUM = (TURB & SPHX_TURB_SA_DSUM) != 0, SA_DIFF = (TURB & SPHX_TURB_SA_DIFF) != 0;
+	constexpr bool NOAUX = STRESS || SA_DSUM;   // no EOS rows in the window
+	constexpr bool NOVEL = SA_DIFF;             // no velocity rows
 	constexpr uint32_t WS = WC + 1;   // window arrays: the dummy row the pad entries of the tile lists point to (slot 0) + WC records
 	__shared__ __attribute__((aligned(16))) float4 sPos[WS];
 	__shared__ __attribute__((aligned(16))) float4 sVel[WS];
@@ -1091,8 +1154,8 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				for (int c = 0; c < TILE_HCH; ++c) hsh[k][c] = 0u;
 				if (!total || base + total > WC || !rjc.contig[k]) continue;
 				stage_row_wave(a.pos + rs, sPos + 1 + base, total, lane);
-				stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
-				if (!STRESS) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
+				if (!NOVEL) stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
+				if (!NOAUX) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
 				if (SPSW) {
 					stage_row_wave(a.tauPack + rs, sAux + WS + 1 + base, total, lane);
 					stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + 2*WS + 1 + base, total, lane);
@@ -1158,8 +1221,9 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 							float4 P = a.pos[st + q];
 							P.x += sh.x; P.y += sh.y; P.z += sh.z;
 							if (PREMUL) P.w *= p.fcoeff;
-							sPos[cb + q] = P; sVel[cb + q] = a.vel[st + q];
-							if (!STRESS) sAux[cb + q] = a.aux[st + q];
+							sPos[cb + q] = P;
+							if (!NOVEL) sVel[cb + q] = a.vel[st + q];
+							if (!NOAUX) sAux[cb + q] = a.aux[st + q];
 							if (SPSW) { sAux[WS + cb + q] = a.tauPack[st + q]; sAux[2*WS + cb + q] = a.tauPack[a.tauPackN + st + q]; }
 						}
 						off += cnt;
@@ -1181,7 +1245,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		// own rows from the window (already in the tile's frame); a tile whose window was not staged (no fluid in reach) has
 		// only wall particles at home: they read the dummy row and write zeros
 		const uint32_t oslot = (inRange && pairs) ? own.slot : 0u;
-		const float4 opos = lds_row(sPos, oslot), ovel = lds_row(sVel, oslot);
+		const float4 opos = lds_row(sPos, oslot), ovel = NOVEL ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : lds_row(sVel, oslot);
 		const float3 q = make_float3(opos.x, opos.y, opos.z);
 		Self s;
 		s.pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.gridPos = make_int3(0, 0, 0);     // cell-local position: finalize stage, on demand
@@ -1189,11 +1253,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		s.fl = (TURB & SPHX_TURB_MF) ? FLUID_NUM(info) : 0u;
 		if (STRESS) {
 			s.rho = (ovel.w + 1.0f)*p.rho0[0];
-		} else {
+		} else if (!NOAUX) {
 			const float4 oaux = lds_row(sAux, oslot);
 			s.p_precalc = oaux.x; s.sspeed = oaux.y; s.P = oaux.z; s.rho = oaux.w;
 			s.inv_rho = fast_rcp(oaux.w);
 		}
+		if (SA_DIFF) s.sa_dt2rho = a.saDt*2.0f*s.rho;
 		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
 		if (SPSW) {   // own stress tensor
 			const float4 ta = lds_row(sAux + WS, oslot), tb = lds_row(sAux + 2*WS, oslot);
@@ -1216,8 +1281,9 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			// LJ boundary: fluid section only for bodies with force feedback, when object forces are asked for (:3620-3645)
 			const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
 			const bool ljlane = LJ && isBound;
-			const bool take0 = active && (STRESS || isFluid || isDynBound || (ljlane && HAS_COMPUTE_FORCE(info) && a.compute_object_forces));
-			const bool take1 = active && (STRESS || (isFluid && (dyn || LJ)));
+			// SA_BOUNDARY modes: fluid particles only, fluid section then vertex section (none in the diffusion)
+			const bool take0 = active && (SA ? isFluid : (STRESS || isFluid || isDynBound || (ljlane && HAS_COMPUTE_FORCE(info) && a.compute_object_forces)));
+			const bool take1 = active && (SA ? (isFluid && !SA_DIFF) : (STRESS || (isFluid && (dyn || LJ))));
 			const int rowsF = (int)(wrc & 0xFFFFu), rowsB = (int)((wrc >> 16) & 0xFFFu);
 			if (wave_any(take0))
 				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, q, inv_h,
@@ -1237,7 +1303,16 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		__builtin_amdgcn_s_waitcnt(0x0F70);
 		if (active) {
 			if (STRESS) stress_finalize(p, a, index, s.rho, force, fx);
-			else {
+			else if (SA) {
+				if (PART_TYPE(info) == PT_FLUID) {
+					if (SA_DSUM) a.forces[index].w = force.y + force.x + 0.0f;     // sumPmwNp1 + sumPmwN
+					else if (SA_DIFF) a.forces[index].w = (force.w/a.saGam[index].w)/p.rho0[s.fl];
+					else {
+						if (p.simflags & SPHX_ENABLE_DENSITY_SUM) force.w = 0.0f;   // no continuity equation then
+						a.forces[index] = force;      // unfinished: sa_forces_kernel adds the boundary elements, divides by gamma, ...
+					}
+				}
+			} else {
 				// planes, terrain and rigid-body rows need the cell-local position, the mass and the cell: few runs, few particles
 				const bool geom = (PART_TYPE(info) == PT_FLUID && (p.simflags & (SPHX_ENABLE_PLANES | SPHX_ENABLE_DEM))) ||
 					(HAS_COMPUTE_FORCE(info) && a.rbforces);
@@ -1496,6 +1571,8 @@ struct SpsArgs;
 	void sphx_part_sps_k##K(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const SpsArgs &a, const uint32_t *guard);
 SPHX_PART_DECL(1) SPHX_PART_DECL(2) SPHX_PART_DECL(3) SPHX_PART_DECL(4)
 #undef SPHX_PART_DECL
+// SA_BOUNDARY modes of the tiled kernel (Wendland; its own translation unit: -DSPHX_FORCES_PART=3 -DSPHX_FORCES_SA)
+void sphx_part_sa_tile(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &fa, int mode, bool newtonian);
 static_assert(SPHX_CUBICSPLINE == 1 && SPHX_QUADRATIC == 2 && SPHX_WENDLAND == 3 && SPHX_GAUSSIAN == 4, "part numbering = kernel type");
 
 #ifndef SPHX_FORCES_PART
@@ -1608,7 +1685,18 @@ static int launch_forces_k(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, c
 	return SPHX_OK;
 }
 
-#ifdef SPHX_FORCES_PART
+#if defined(SPHX_FORCES_PART) && defined(SPHX_FORCES_SA)
+void sphx_part_sa_tile(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &fa, int mode, bool newtonian)
+{
+#define SPHX_SA_TILE(T) forces_tile_kernel<SPHX_WENDLAND, (T), DIFF_NONE, false><<<ctx->tile_grid, TILE_THREADS, 0, stream>>>(ctx->dev, fa, \
+		ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy)
+	if (mode == SPHX_SA_TILE_DSUM) SPHX_SA_TILE(SPHX_LAMINAR_FLOW | SPHX_TURB_SA_DSUM);
+	else if (mode == SPHX_SA_TILE_DIFF) SPHX_SA_TILE(SPHX_LAMINAR_FLOW | SPHX_TURB_SA_DIFF);
+	else if (newtonian) SPHX_SA_TILE(SPHX_LAMINAR_FLOW | SPHX_TURB_NEWT | SPHX_TURB_SA);
+	else SPHX_SA_TILE(SPHX_LAMINAR_FLOW | SPHX_TURB_SA);
+#undef SPHX_SA_TILE
+}
+#elif defined(SPHX_FORCES_PART)
 #define SPHX_PASTE2(a, b) a##b
 #define SPHX_PASTE(a, b) SPHX_PASTE2(a, b)
 int SPHX_PASTE(sphx_part_forces_k, SPHX_FORCES_PART)(const sphx_ctx *ctx, dim3 grid, hipStream_t stream, const ForcesArgs &a, bool use_tiles)
@@ -1641,7 +1729,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
 	const uint32_t *__restrict__ tiles, uint32_t *tileCtl, uint32_t *__restrict__ tileRows,
 	uint16_t *__restrict__ tileList, uint32_t listStride, uint32_t listRows, uint32_t *__restrict__ tileWaves,
-	uint16_t *__restrict__ tileOwnSlot)
+	uint16_t *__restrict__ tileOwnSlot, int saVertex /* SA_BOUNDARY lists: the second section is the VERTEX section */)
 {
 	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW], sCellBase[TILE_WROWS*TILE_KW], sCellStart[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sRowTotal[TILE_WROWS], sRowStart[TILE_WROWS], sRowContig[TILE_WROWS], sRowBase[TILE_WROWS];
@@ -1743,10 +1831,12 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 		const uint32_t slabs = listRows/TILE_NB;
 #pragma unroll 1
 		for (int sec = 0; sec < 2 && !overflow; ++sec) {
-			// section 0: slots 0 upward, section 1: slots neibboundpos downward; each ends at its terminator.
+			// section 0: slots 0 upward, section 1: slots neibboundpos downward (SA_BOUNDARY: the vertex section, slots
+			// neibboundpos + 1 upward; the boundary elements are not particles of a window); each ends at its terminator.
 			// Every lane collects its translated entries four at a time (a batch: one 8-byte store into the batch's slab),
 			// then all lanes are padded with dummy entries up to the wave's longest, rounded up to whole batches
-			const int maxSlots = sec ? (int)p.neibboundpos + 1 : (int)p.neiblistsize;
+			const int maxSlots = !sec ? (int)p.neiblistsize : saVertex ? (int)p.neiblistsize - (int)p.neibboundpos - 1 : (int)p.neibboundpos + 1;
+			if (maxSlots <= 0) continue;
 			bool alive = mine;
 			uint32_t code = 0, cur = 0;
 			uint2 pend = make_uint2(0u, 0u);
@@ -1771,7 +1861,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 #pragma unroll
 				for (int k = 0; k < LOADS; ++k) {
 					const int slot = min(s0 + k, maxSlots - 1);   // a clamped re-read is only reached by dead lanes
-					const int src = sec ? (int)p.neibboundpos - slot : slot;
+					const int src = !sec ? slot : saVertex ? (int)p.neibboundpos + 1 + slot : (int)p.neibboundpos - slot;
 					e[k] = list[(size_t)src*stride + index];
 				}
 				if (!wave_any(alive && e[0] != NEIBS_END)) break;   // every list of the wave has ended
@@ -1818,13 +1908,13 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	}
 }
 
-int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, hipStream_t st)
+int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st)
 {
 	if (!ctx->tile_list || !ctx->tile_waves || !ctx->tile_rows || !ctx->tile_ownslot) { ctx->tiles_built = false; return SPHX_OK; }
 	const uint32_t grid = ctx->tile_grid*8u < ctx->tile_capacity ? ctx->tile_grid*8u : ctx->tile_capacity;
 	tile_lists_kernel<<<grid, TILE_THREADS, 0, st>>>(ctx->dev, neibsList, hash, cellStart, ctx->cell_end_copy,
 		ctx->tiles, ctx->tile_ctl, ctx->tile_rows, ctx->tile_list, ctx->tile_list_stride, ctx->tile_list_rows, ctx->tile_waves,
-		ctx->tile_ownslot);
+		ctx->tile_ownslot, sa ? 1 : 0);
 	SPHX_LAUNCH_CHECK("tile_lists_kernel");
 	return SPHX_OK;
 }
@@ -1934,6 +2024,59 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	SPHX_LAUNCH_CHECK("forces_kernel");
 	if (ctx->dev.simflags & SPHX_ENABLE_XSPH)   // mean neighbourhood velocity of the fluid particles (filters.hip)
 		return sphx_xsph_launch(ctx, xsph, pos, vel, info, hash, cellStart, neibsList, fromParticle, toParticle, (hipStream_t)stream);
+	return SPHX_OK;
+}
+
+// displacement of every particle over the step (cell-local positions of the same cell: the hash only changes at the next sort)
+static __global__ void __launch_bounds__(256)
+sa_displacement_kernel(const float4 *__restrict__ oldPos, const float4 *__restrict__ newPos, float4 *__restrict__ disp, uint32_t n)
+{
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	if (i >= n) return;
+	const float4 a = oldPos[i], b = newPos[i];
+	disp[i] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, 0.0f);
+}
+
+// The particle <- particle sums of an SA_BOUNDARY engine over the tiles of the current neighbour list (see SPHX_TURB_SA).
+// *used = the tiled kernel was launched: the caller's list-walker kernel then only finishes the particles (boundary elements,
+// division by gamma, ...) unless the device-side overflow flag *guard says the tiles could not be used after all.
+int sphx_sa_tiles_run(sphx_ctx *ctx, int mode, void *forces, const void *pos, const void *vel, const void *newPos,
+	const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList, const void *gGam,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, float dt, hipStream_t stream,
+	bool *used, const uint32_t **guard)
+{
+	*used = false; *guard = nullptr;
+	sphx_tiles_overflow_poll(ctx);
+	const DevParams &d = ctx->dev;
+	const bool ok = ctx->tiles_built && ctx->tiles_overflow != 1 && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
+		!ctx->disable_tiles && ctx->tile_list != nullptr && d.boundarytype == SPHX_SA_BOUNDARY && d.kerneltype == SPHX_WENDLAND &&
+		d.numfluids == 1 && d.turbmodel == SPHX_LAMINAR_FLOW && d.formulation == SPHX_SPH_F1 && d.rheology <= SPHX_NEWTONIAN &&
+		numParticles <= ctx->reserved_particles &&
+		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*TILE_NB < 0x80000000ull;
+	if (!ok || fromParticle >= toParticle) return SPHX_OK;
+	ForcesArgs a = {};
+	a.forces = (float4*)forces;
+	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.info = (const particleinfo*)info;
+	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.aux = ctx->eos_aux;
+	if (mode == SPHX_SA_TILE_DSUM) {      // the window's second array holds the displacements
+		sa_displacement_kernel<<<div_up_u(numParticles, 256), 256, 0, stream>>>((const float4*)pos, (const float4*)newPos, ctx->eos_aux, numParticles);
+		SPHX_LAUNCH_CHECK("sa_displacement_kernel");
+		a.vel = ctx->eos_aux;
+	} else {
+		eos_kernel<<<div_up_u(numParticles, 256), 256, 0, stream>>>(ctx->dev, (const float4*)vel, (const particleinfo*)info, ctx->eos_aux, numParticles);
+		SPHX_LAUNCH_CHECK("eos_kernel");
+	}
+	a.tileList = ctx->tile_list; a.tileListRows = ctx->tile_list_rows; a.tileListStride = ctx->tile_list_stride;
+	a.tileWaves = ctx->tile_waves; a.tileRows = ctx->tile_rows; a.tileOwnSlot = ctx->tile_ownslot;
+	a.saGam = (const float4*)gGam; a.saDt = dt;
+	a.rb = ctx->rb_dev;
+	a.fromParticle = fromParticle; a.toParticle = toParticle;
+	a.dbg = ctx->tile_debug & ~16;
+	sphx_part_sa_tile(ctx, stream, a, mode, d.rheology == SPHX_NEWTONIAN);
+	SPHX_LAUNCH_CHECK("forces_tile_kernel (SA_BOUNDARY)");
+	*used = true;
+	*guard = ctx->tiles_overflow == 0 ? nullptr : ctx->tile_ctl + 1;     // NULL: the host has seen the tiling succeed
 	return SPHX_OK;
 }
 

@@ -1045,7 +1045,10 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	const bool tile_cols_fit = (size_t)((ctx->dev.gs[ctx->dev.c2] + 1)/2)*(size_t)((ctx->dev.gs[ctx->dev.c3] + 1)/2)*(size_t)ctx->dev.gs1
 		<= (size_t)ctx->cells_reserved/2 + 1024;   // tile_cols allocation (degenerate 1-D grids: generic kernels)
 	// tiles serve sphx_forces_basicstep's pair loop only (SPH_F1, inviscid or Newtonian, DYN / LJ / MK boundaries) and sphx_calc_visc
-	const bool tiled_options = !sa && ctx->params.sph_formulation == SPHX_SPH_F1 && ctx->params.rheologytype <= SPHX_NEWTONIAN;
+	// ... and, with SA_BOUNDARY, the particle <- particle sums of the SA forces, density summation and density diffusion
+	// (one fluid, no k-epsilon: sphx_sa_tiles_run, forces.hip)
+	const bool tiled_options = ctx->params.sph_formulation == SPHX_SPH_F1 && ctx->params.rheologytype <= SPHX_NEWTONIAN &&
+		(!sa || (ctx->dev.numfluids == 1 && ctx->dev.turbmodel == SPHX_LAMINAR_FLOW));
 	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit) {
 		rc = sphx_ensure_tile_lists(ctx);      // first tiled build: the tile lists are allocated now (or never: generic kernels)
 		if (rc != SPHX_OK) return rc;
@@ -1078,7 +1081,7 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	if (ctx->tiles_built) {   // the lists of the tiled particles in the form the tiled forces kernel walks (forces.hip)
-		rc = sphx_tile_lists_launch(ctx, neibsList, hash, cellStart, st);
+		rc = sphx_tile_lists_launch(ctx, neibsList, hash, cellStart, sa, st);
 		if (rc != SPHX_OK) return rc;
 		// the tiling's overflow flag travels to the host behind the build, without a synchronisation: the forces passes that
 		// find it arrived (sphx_tiles_overflow_poll) launch exactly one kernel, the others keep the guarded stand-by

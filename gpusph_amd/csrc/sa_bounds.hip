@@ -257,6 +257,10 @@ struct SaForcesArgs {
 	float *dkde;          // BUFFER_DKDE: 3 floats per particle (diffusion term of k, of epsilon, Yap's C_e2)
 	float *cflKeps;       // BUFFER_CFL_KEPS: one per block
 	float epsilon;
+	// the tiled kernel (forces.hip, SPHX_TURB_SA) has left the fluid <- fluid and fluid <- vertex sums in FORCES: only the
+	// boundary elements and the fix-ups remain -- unless the tiling overflowed (*tileGuard != 0: the tiled kernel did nothing)
+	int tiled;
+	const uint32_t *tileGuard;
 };
 
 // sa_dot3, sa_P, sa_sound_speed, sa_visc_avg: neib_iter.h (shared with the other fidelity engines)
@@ -325,8 +329,12 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 					}
 					force.x += dx; force.y += dy; force.z += dz;
 				};
-				for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, particle_pair);
-				for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, particle_pair);
+				if (a.tiled && !(a.tileGuard && *a.tileGuard))
+					force = a.forces[index];
+				else {
+					for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, particle_pair);
+					for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, particle_pair);
+				}
 				// fluid <- boundary element
 				for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
 					if (!is_active_w(npos.w)) return;
@@ -581,6 +589,8 @@ struct SaDensitySumArgs {
 	const uint32_t *hash, *cellStart;
 	const neibdata *neibsList;
 	uint32_t numParticles;
+	int tiled;                    // the volumic sums are in FORCES.w already (tiled kernel, SPHX_TURB_SA_DSUM), see SaForcesArgs
+	const uint32_t *tileGuard;
 };
 
 __global__ void __launch_bounds__(128)
@@ -611,10 +621,15 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 		const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
 		if (rNp1 < p.influenceradius) sumPmwNp1 += nN.w*kernel_W<SPHX_WENDLAND>(p, rNp1);
 	};
-	for_each_neib<PT_FLUID, true>(p, w, index, posN, gridPos, volumic);
-	for_each_neib<PT_VERTEX, true>(p, w, index, posN, gridPos, volumic);
-	const float fw = sumPmwNp1 + sumPmwN + 0.0f;
-	a.forces[index].w = fw;
+	float fw;
+	if (a.tiled && !(a.tileGuard && *a.tileGuard))
+		fw = a.forces[index].w;
+	else {
+		for_each_neib<PT_FLUID, true>(p, w, index, posN, gridPos, volumic);
+		for_each_neib<PT_VERTEX, true>(p, w, index, posN, gridPos, volumic);
+		fw = sumPmwNp1 + sumPmwN + 0.0f;
+		a.forces[index].w = fw;
+	}
 	float gGamDotR = 0.0f;
 	V3 gGam = v3(0.0f, 0.0f, 0.0f);
 	for_each_neib<PT_BOUNDARY, true>(p, w, index, posN, gridPos, [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
@@ -651,12 +666,14 @@ struct SaDiffusionArgs {
 	const neibdata *neibsList;
 	uint32_t numParticles;
 	float dt;
+	const uint32_t *tileGuard;    // stand-by launch behind the tiled kernel (SPHX_TURB_SA_DIFF): only if the tiling overflowed
 };
 
 // computeDensityDiffusionDevice<.., BREZZI, SA_BOUNDARY, PT_FLUID> (forces_kernel.def:1766-1783, 4515-4560)
 __global__ void __launch_bounds__(128)
 sa_density_diffusion_kernel(DevParams p, SaDiffusionArgs a)
 {
+	if (a.tileGuard && !*a.tileGuard) return;
 	const uint32_t index = blockIdx.x*128 + threadIdx.x;
 	if (index >= a.numParticles) return;
 	const particleinfo info = a.info[index];
@@ -954,8 +971,14 @@ static int sa_forces_impl(sphx_ctx *ctx, void *forces, float *cfl, float *cflGam
 		a.dkde = ke->dkde; a.cflKeps = ke->cflKeps; a.epsilon = ke->epsilon;
 		if (ke->cflKeps && numBlocks > blocks) SPHX_HIP(hipMemsetAsync(ke->cflKeps + cflOffset + blocks, 0, sizeof(float)*(numBlocks - blocks), st));
 		sa_forces_kernel<true><<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
-	} else
+	} else {
+		bool used = false;
+		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_FORCES, forces, pos, vel, nullptr, info, hash, cellStart, neibsList, gGam,
+			numParticles, fromParticle, toParticle, 0.0f, st, &used, &a.tileGuard);
+		if (rc != SPHX_OK) return rc;
+		a.tiled = used ? 1 : 0;
 		sa_forces_kernel<false><<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
+	}
 	SPHX_LAUNCH_CHECK("sa_forces_kernel");
 	return SPHX_OK;
 }
@@ -1154,7 +1177,7 @@ extern "C" int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, v
 	uint32_t numParticles, uint32_t particleRangeEnd, float dt, int step, float t, float epsilon,
 	float deltap, float slength, float influenceradius, void *stream)
 {
-	(void)numParticles; (void)dt; (void)step; (void)t; (void)epsilon; (void)deltap;
+	(void)dt; (void)step; (void)t; (void)epsilon; (void)deltap;
 	int rc = sa_check(ctx, "density_sum called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	if (!(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) || (ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
@@ -1175,6 +1198,13 @@ extern "C" int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, v
 	a.boundElement = (const float4*)boundElements;
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
+	{
+		bool used = false;
+		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_DSUM, forces, oldPos, nullptr, newPos, info, hash, cellStart, neibsList, nullptr,
+			numParticles, 0u, particleRangeEnd, 0.0f, (hipStream_t)stream, &used, &a.tileGuard);
+		if (rc != SPHX_OK) return rc;
+		a.tiled = used ? 1 : 0;
+	}
 	sa_density_sum_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_kernel");
 	return SPHX_OK;
@@ -1184,7 +1214,7 @@ extern "C" int sphx_sa_compute_density_diffusion(sphx_ctx *ctx, void *forces, co
 	const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float slength, float influenceradius, float dt, void *stream)
 {
-	(void)numParticles; (void)deltap;
+	(void)deltap;
 	int rc = sa_check(ctx, "compute_density_diffusion called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	if (ctx->params.densitydiffusiontype != SPHX_BREZZI || !(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) ||
@@ -1198,6 +1228,13 @@ extern "C" int sphx_sa_compute_density_diffusion(sphx_ctx *ctx, void *forces, co
 	a.forces = (float4*)forces; a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.gGam = (const float4*)gGam;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.numParticles = particleRangeEnd; a.dt = dt;
+	{
+		bool used = false;
+		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_DIFF, forces, pos, vel, nullptr, info, hash, cellStart, neibsList, gGam,
+			numParticles, 0u, particleRangeEnd, dt, (hipStream_t)stream, &used, &a.tileGuard);
+		if (rc != SPHX_OK) return rc;
+		if (used && !a.tileGuard) return SPHX_OK;      // the host has seen the tiling succeed: no stand-by launch
+	}
 	sa_density_diffusion_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_diffusion_kernel");
 	return SPHX_OK;

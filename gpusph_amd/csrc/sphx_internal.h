@@ -208,7 +208,15 @@ void sphx_fidelity_rows_launch(sphx_ctx *ctx, const void *vel, const void *info,
 int sphx_rb_flush(sphx_ctx *ctx, hipStream_t st);
 int sphx_xsph_launch(sphx_ctx *ctx, void *xsph, const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle, hipStream_t st);
-int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, hipStream_t st);
+int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st);
+// SA_BOUNDARY engines over the tiles (forces.hip): which sums the tiled kernel forms
+#define SPHX_SA_TILE_FORCES 0
+#define SPHX_SA_TILE_DSUM 1
+#define SPHX_SA_TILE_DIFF 2
+int sphx_sa_tiles_run(sphx_ctx *ctx, int mode, void *forces, const void *pos, const void *vel, const void *newPos,
+	const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList, const void *gGam,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, float dt, hipStream_t stream,
+	bool *used, const uint32_t **guard);
 int sphx_repack_launch(sphx_ctx *ctx, void *forces, float *cfl, void *rbforces, void *rbtorques,
 	const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
