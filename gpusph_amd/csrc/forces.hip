@@ -2233,6 +2233,16 @@ extern "C" int sphx_dbg_tiles(sphx_ctx *ctx, uint32_t *host, uint32_t maxTiles)
 	return (int)n;
 }
 
+// tests only, not part of include/sphx.h: 1 when the last neighbour-list build left a usable tiling (built, lists allocated, no
+// overflow), i.e. the tiled kernels are the ones that run; synchronises
+extern "C" int sphx_dbg_tiles_usable(sphx_ctx *ctx)
+{
+	if (!ctx || !ctx->tiles || !ctx->tiles_built || !ctx->tile_list || ctx->disable_tiles) return 0;
+	uint32_t ctl[2];
+	if (hipMemcpy(ctl, ctx->tile_ctl, sizeof(ctl), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (ctl[0] > 0u && ctl[1] == 0u) ? 1 : 0;
+}
+
 // Optional profiling hook (bench.py): when enabled, every forces pass records a pair of HIP events on its launch
 // stream around its dominant kernel (forces_tile_kernel, or forces_kernel when the tiling is not used);
 // sphx_forces_timing_read synchronises the recorded events, returns their summed elapsed time and count, and

@@ -1016,6 +1016,24 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		numParticles, particleRangeEnd, gridCells, sqinfluenceradius, boundNlSqInflRad, stream);
 }
 
+// SA_BOUNDARY: the active fluid particles whose boundary section is not empty, in no particular order (wave-aggregated append)
+static __global__ void __launch_bounds__(256)
+sa_wall_list_kernel(const neibdata *__restrict__ list, const particleinfo *__restrict__ info, const float4 *__restrict__ pos,
+	uint32_t n, uint32_t stride, uint32_t neibboundpos, uint32_t *__restrict__ wall)
+{
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	bool has = false;
+	if (i < n)
+		has = PART_TYPE(info[i]) == PT_FLUID && is_active_w(pos[i].w) && list[(size_t)neibboundpos*stride + i] != NEIBS_END;
+	const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
+	if (!m) return;
+	const uint32_t lane = threadIdx.x & 63u;
+	uint32_t base = 0;
+	if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(wall, (uint32_t)__builtin_popcountll(m));
+	base = __shfl(base, __builtin_ctzll(m));
+	if (has) wall[1u + base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+}
+
 extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *vertPos0, void *vertPos1, void *vertPos2,
 	const void *pos, const void *info, const void *vertices, const void *boundElements, const uint32_t *hash,
 	const uint32_t *cellStart, const uint32_t *cellEnd,
@@ -1080,6 +1098,20 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		saArgs, neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
 		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
+	if (sa) {   // the fluid particles with boundary elements in reach
+		if (!ctx->sa_wall && hipMalloc((void**)&ctx->sa_wall, sizeof(uint32_t)*((size_t)ctx->reserved_particles + 1)) != hipSuccess) {
+			(void)hipGetLastError();
+			ctx->sa_wall = nullptr;      // the engines fall back to one thread per particle
+		}
+		ctx->sa_wall_neibslist = nullptr;
+		if (ctx->sa_wall) {
+			SPHX_HIP(hipMemsetAsync(ctx->sa_wall, 0, sizeof(uint32_t), st));
+			sa_wall_list_kernel<<<div_up_u(particleRangeEnd, 256), 256, 0, st>>>(neibsList, (const particleinfo*)info, (const float4*)pos,
+				particleRangeEnd, ctx->dev.stride, ctx->dev.neibboundpos, ctx->sa_wall);
+			SPHX_LAUNCH_CHECK("sa_wall_list_kernel");
+			ctx->sa_wall_neibslist = neibsList;
+		}
+	}
 	if (ctx->tiles_built) {   // the lists of the tiled particles in the form the tiled forces kernel walks (forces.hip)
 		rc = sphx_tile_lists_launch(ctx, neibsList, hash, cellStart, sa, st);
 		if (rc != SPHX_OK) return rc;

@@ -94,7 +94,11 @@ SPHX_WG_FN EdgeEnd wall_edge_end(const EdgePowers &k, float s, float d)
 }
 
 // |grad gamma_as| * h at the point q (relative to the element's centre)
-SPHX_WG_FN_NOINLINE float wall_grad_gamma(const WallTri &w, V3 q)
+// FLAT: the three edges unrolled and the whole inlined into the caller, so that the element lives in registers (the kernels
+// that give a wave to every wall particle); otherwise a real function with a loop over the edges, the element in memory (the
+// one-thread-per-particle kernels, where it is called from many places).  Same operations in the same order either way.
+template<bool FLAT>
+SPHX_WG_FN float wall_grad_gamma_body(const WallTri &w, V3 q)
 {
 	const float pn = dot(w.n, q);
 	EdgePowers k;
@@ -104,7 +108,8 @@ SPHX_WG_FN_NOINLINE float wall_grad_gamma(const WallTri &w, V3 q)
 	k.a2 = k.a*k.a; k.a4 = k.a2*k.a2;
 	const float a5 = k.a4*k.a;
 	float edges = 0.0f, angleAll = 0.0f, angleIn = 0.0f;
-#pragma unroll 1
+	constexpr int unrollEdges = FLAT ? 3 : 1;
+#pragma unroll unrollEdges
 	for (int e = 0; e < 3; ++e) {
 		const V3 d0 = q - w.corner[e], d1 = q - w.corner[(e + 1) % 3];
 		k.b = dot(w.across[e], d0);
@@ -129,6 +134,8 @@ SPHX_WG_FN_NOINLINE float wall_grad_gamma(const WallTri &w, V3 q)
 	const float t2 = t*t;
 	return edges + (angleIn - angleAll)*0.05968310365947f*(t2*t2*t)*(2.0f + 5.0f*k.a + 4.0f*k.a2);
 }
+SPHX_WG_FN_NOINLINE float wall_grad_gamma(const WallTri &w, V3 q) { return wall_grad_gamma_body<false>(w, q); }
+SPHX_WG_FN float wall_grad_gamma_flat(const WallTri &w, V3 q) { return wall_grad_gamma_body<true>(w, q); }
 
 // the Wendland kernel integrated along a ray from distance d to the edge of the support (times h^2)
 SPHX_WG_FN float wall_kernel_along_ray(float d)
@@ -142,7 +149,7 @@ SPHX_WG_FN float wall_kernel_along_ray(float d)
 // midpoints).  The centroid carries TWICE its weight: the reference's loop tests its exit after accumulating
 // (gamma.cuh:150-158), and what the reference computes is what its problems were validated with.
 template<bool VERTEX>
-SPHX_WG_FN_NOINLINE float wall_gamma(const WallTri &w, V3 q, V3 oldGradGamma, float h, float epsilon)
+SPHX_WG_FN float wall_gamma_body(const WallTri &w, V3 q, V3 oldGradGamma, float h, float epsilon)
 {
 	const float pn = dot(w.n, q);
 	const float dist = fminf(fabsf(pn), 2.0f);
@@ -184,5 +191,11 @@ SPHX_WG_FN_NOINLINE float wall_gamma(const WallTri &w, V3 q, V3 oldGradGamma, fl
 	}
 	return solid + vol;
 }
+template<bool VERTEX>
+SPHX_WG_FN_NOINLINE float wall_gamma(const WallTri &w, V3 q, V3 oldGradGamma, float h, float epsilon)
+{ return wall_gamma_body<VERTEX>(w, q, oldGradGamma, h, epsilon); }
+template<bool VERTEX>
+SPHX_WG_FN float wall_gamma_flat(const WallTri &w, V3 q, V3 oldGradGamma, float h, float epsilon)
+{ return wall_gamma_body<VERTEX>(w, q, oldGradGamma, h, epsilon); }
 
 #endif

@@ -174,6 +174,10 @@ struct sphx_ctx {
 	bool        time_forces;   // sphx_forces_timing: bracket the dominant forces kernel with HIP events
 	std::vector<std::pair<hipEvent_t, hipEvent_t> > *forces_events;
 	const void *tiles_cellstart, *tiles_neibslist;
+	// SA_BOUNDARY: [0] = number of, [1..] = the fluid particles whose list has boundary elements (built with the neighbour list;
+	// the boundary-element terms are evaluated one element per lane for these, sa_bounds.hip); sa_wall_neibslist = that list
+	uint32_t   *sa_wall;
+	const void *sa_wall_neibslist;
 	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
 };
 

@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/c22
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | grep -v '^E   +\|^E  +' | grep 'passed\|failed\|FAILED\|^>\|^E  ' > gpurun_out/c22/pytest.txt
+python scripts/time_sa.py 0.008 StillWaterSA 20 > gpurun_out/c22/sa_4M_tiled.txt 2>&1
+python scripts/time_sa.py 0.008 StillWaterRepackSA 20 > gpurun_out/c22/sa_4M_quad_tiled.txt 2>&1
+SPHX_DISABLE_TILES=1 python scripts/time_sa.py 0.008 StillWaterSA 20 > gpurun_out/c22/sa_4M_generic.txt 2>&1

@@ -18,6 +18,19 @@ def _engine(problem, **kw):
     return TimestepEngine(problem, device="cuda:0", **kw)
 
 
+def _tiles_usable(eng):
+    """Whether the neighbour list built last left a usable tiling (then the tiled kernels form the particle <- particle sums)."""
+    return int(eng.k.lib.sphx_dbg_tiles_usable(eng.k.ctx.handle))
+
+
+@pytest.fixture(params=["tiled", "list-walkers"])
+def kernels(request, monkeypatch):
+    """Both ways the SA engines form their sums: tiled window + one boundary element per lane, or one thread per particle
+    walking the whole list (the CPU oracle's mirror).  SPHX_DISABLE_TILES is read when a context is created."""
+    monkeypatch.setenv("SPHX_DISABLE_TILES", "0" if request.param == "tiled" else "1")
+    return request.param
+
+
 def _np(t, dtype=None):
     a = t.cpu().numpy()
     return a.view(dtype) if dtype is not None else a
@@ -159,7 +172,7 @@ def test_cpp_adapters_run_the_sa_initialisation(tmp_path):
     assert np.isfinite(out["gradgamma"][t != D.PT_BOUNDARY]).all() and (out["vel"][t == D.PT_BOUNDARY, 3] > 0).sum() > 200
 
 
-def test_sa_forces_gamma_integration_and_trajectory():
+def test_sa_forces_gamma_integration_and_trajectory(kernels):
     """The SA forces engine (fluid, vertex and boundary-element terms, division by gamma), gamma by quadrature at new positions
     and the whole predictor-corrector sequence against the CPU oracle (option set of StillWaterRepackSA's simulation)."""
     from sa_helpers import OracleSaSim
@@ -168,6 +181,7 @@ def test_sa_forces_gamma_integration_and_trajectory():
     sim = OracleSaSim(SABox(**kw))
     eng = _engine(SABox(**kw), clobber_neibslist=True)
     eng.build_neibs()
+    assert _tiles_usable(eng) == (kernels == "tiled")
     eng.sa_boundary_conditions(0)
     n, o, k = sim.n, sim.o, eng.k
     t = info_type(sim.info)
@@ -239,7 +253,7 @@ def test_cpp_adapters_step_an_sa_problem(tmp_path, options):
     assert np.abs(out["vel"][t == D.PT_FLUID, :3]).max() > 0            # it did move
 
 
-def test_density_summation_form_on_the_gpu():
+def test_density_summation_form_on_the_gpu(kernels):
     """StillWaterSA's own option set -- density summation, dynamic gamma with its CFL condition, Brezzi diffusion: the three
     engines' calls one by one on identical inputs, then six steps of the whole sequence, against the CPU oracle."""
     from sa_helpers import OracleSaSim
@@ -248,6 +262,7 @@ def test_density_summation_form_on_the_gpu():
     sim = OracleSaSim(SABox(**kw))
     eng = _engine(SABox(**kw), clobber_neibslist=True)
     eng.build_neibs()
+    assert _tiles_usable(eng) == (kernels == "tiled")
     eng.sa_boundary_conditions(0)
     n, o, k = sim.n, sim.o, eng.k
     t = info_type(sim.info)
@@ -396,3 +411,41 @@ def test_sa_tank_at_4M_particles_through_properties():
     assert deep.sum() > 2.0e6 and np.abs(vel[fl, 3] - rho_hyd)[deep].max() < 0.25 * rho_hyd.max()      # the start-up transient of the density summation
     assert np.abs(vel[fl, 3] - rho_hyd).max() < 0.5 * rho_hyd.max()
     assert 0 < eng.current_dt() <= prob.simparams.dt * 1.0001
+
+
+@pytest.mark.parametrize("options", ["StillWaterSA", "StillWaterRepackSA"])
+def test_sa_tiled_kernels_agree_with_the_list_walkers(options, monkeypatch):
+    """The two ways of forming the SA sums (tiled window + a wave per wall particle / one thread per particle in list order) on a
+    tank too large for the CPU oracle in test time: twelve steps across a neighbour-list rebuild, a sloshing start so that
+    every term is alive.  They differ by the order of the sums and the fast reciprocal / square root of the tiled pair."""
+    import torch
+    def run(disable):
+        monkeypatch.setenv("SPHX_DISABLE_TILES", disable)
+        prob = SABox(0.02, l=1.2, w=0.8, h=0.8, H=0.6, jitter=0.1, options=options)
+        eng = _engine(prob)
+        n = prob.num_particles
+        g = prob.global_pos(_np(eng.pos)[:n], _np(eng.hash, np.uint32)[:n])
+        fl = info_type(_np(eng.info, np.uint16)[:n]) == D.PT_FLUID
+        v = _np(eng.vel)[:n].copy()
+        v[fl, 0] = 0.3 * np.sin(np.pi * g[fl, 0] / prob.l) * (g[fl, 2] / prob.H)        # a first sloshing mode
+        v[fl, 2] = -0.3 * np.cos(np.pi * g[fl, 0] / prob.l) * (g[fl, 2] / prob.H) * 0.5
+        eng.vel[:n] = torch.from_numpy(v.astype(np.float32)).to(eng.device)
+        eng.build_neibs()
+        usable = _tiles_usable(eng)
+        for _ in range(12):
+            eng.step()
+        return prob, usable, _np(eng.pos)[:n].copy(), _np(eng.vel)[:n].copy(), _np(eng.gradgamma)[:n].copy(), \
+            _np(eng.hash, np.uint32)[:n].copy(), eng.current_dt(), fl
+    prob, used_t, pos_t, vel_t, gg_t, hash_t, dt_t, fl = run("0")
+    _, used_w, pos_w, vel_w, gg_w, hash_w, dt_w, _ = run("1")
+    assert used_t == 1 and used_w == 0
+    assert prob.num_particles > 9.0e4
+    assert np.array_equal(hash_t, hash_w)
+    cell = float(np.min(prob.m_cellsize))
+    vmax = np.abs(vel_w[:, :3]).max()
+    assert vmax > 0.2
+    assert np.abs(pos_t[:, :3] - pos_w[:, :3]).max() < 2e-5 * cell
+    assert_close_but_for_gamma_spikes(vel_t[:, :3], vel_w[:, :3], 2e-4, vmax, spike=10.0, what="velocities, tiled against list walkers")
+    assert_close_but_for_gamma_spikes(vel_t[:, 3], vel_w[:, 3], 2e-6, 1.0, spike=10.0, what="densities, tiled against list walkers")
+    assert np.abs(gg_t[fl, 3] - gg_w[fl, 3]).max() < 2e-5
+    assert abs(dt_t - dt_w) < 1e-4 * dt_w
