@@ -1,0 +1,61 @@
+// sa_args.h -- argument blocks of the SA_BOUNDARY engines that two translation units share: sa_bounds.hip (everything, in the
+// reference's operation order: EXACT compile flags) and sa_wall.hip (the boundary-element terms with one element per lane).
+#pragma once
+#include "sphx_internal.h"
+
+// forces with SA_BOUNDARY: see sa_forces_kernel (sa_bounds.hip)
+struct SaForcesArgs {
+	float4 *forces;
+	float *cfl;
+	float *cflGamma, *cflGammaBlocks;   // BUFFER_CFL_GAMMA: per particle, and per block behind round_up(numParticles, 4)
+	const float4 *pos, *vel, *gGam, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t fromParticle, toParticle, cflOffset;
+	float deltap;
+	// KEPSILON (keps_forces_params, src/cuda/forces_params.h:283-320)
+	const float *tke, *eps, *turbvisc;
+	const float4 *eulerVel;
+	float *dkde;          // BUFFER_DKDE: 3 floats per particle (diffusion term of k, of epsilon, Yap's C_e2)
+	float *cflKeps;       // BUFFER_CFL_KEPS: one per block
+	float epsilon;
+	// the tiled kernel (forces.hip, SPHX_TURB_SA) has left the fluid <- fluid and fluid <- vertex sums in FORCES: only the
+	// boundary elements and the fix-ups remain -- unless the tiling overflowed (*tileGuard != 0: the tiled kernel did nothing)
+	int tiled;
+	const uint32_t *tileGuard;
+	int wallDone;         // ... and sa_forces_wall_kernel has added the boundary elements (needs `tiled`)
+};
+
+// integrateGammaDevice, quadrature flavour: see sa_integrate_gamma_kernel (sa_bounds.hip)
+struct SaIntGammaArgs {
+	float4 *newGGam;
+	const float4 *oldGGam, *pos, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	float epsilon;
+	int wallDone;      // the fluid particles with boundary elements in reach are done by sa_integrate_gamma_wall_kernel
+};
+
+// density summation with dynamic gamma: see sa_density_sum_kernel (sa_bounds.hip)
+struct SaDensitySumArgs {
+	float4 *newVel, *newGGam, *forces;
+	const float4 *oldPos, *pos /* new positions: what the walker prefetches is not used */, *oldVel, *oldGGam, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	int tiled;                    // the volumic sums are in FORCES.w already (tiled kernel, SPHX_TURB_SA_DSUM), see SaForcesArgs
+	const uint32_t *tileGuard;
+	int wallDone;                 // sa_density_sum_wall_kernel has left {sum grad gamma, sum grad gamma . dr} in newGGam (needs `tiled`)
+};
+
+// sa_wall.hip: the boundary-element terms of the three engines for the particles of ctx->sa_wall
+int sphx_sa_wall_forces(sphx_ctx *ctx, const SaForcesArgs &a, hipStream_t st);
+int sphx_sa_wall_density_sum(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st);
+int sphx_sa_wall_integrate_gamma(sphx_ctx *ctx, const SaIntGammaArgs &a, hipStream_t st);

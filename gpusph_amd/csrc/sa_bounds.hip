@@ -8,6 +8,7 @@
 // operation order -- bit-identical to the CPU oracle except for powf in the equation of state.
 #include "sphx_internal.h"
 #include "neib_iter.h"
+#include "sa_args.h"
 
 struct SaArgs {
 	float4 *vel;                 // in place: boundary rows (segment kernel) / vertex rows (vertex kernel) are written
@@ -240,29 +241,6 @@ sa_init_gamma_kernel(DevParams p, SaGammaArgs a)
 // through |grad gamma_as| (continuity :2079-2090, pressure :2414-2427, wall shear :2680-2718); the sums are divided by gamma
 // (forces_fixup :3192-3210).  Written like the boundary-conditions kernels above: the reference's operation order, IEEE
 // division and sqrt, no contraction other than the fmaf the CPU oracle spells out -- the SA path is not yet a roofline path.
-struct SaForcesArgs {
-	float4 *forces;
-	float *cfl;
-	float *cflGamma, *cflGammaBlocks;   // BUFFER_CFL_GAMMA: per particle, and per block behind round_up(numParticles, 4)
-	const float4 *pos, *vel, *gGam, *boundElement;
-	const float2 *vertPos[3];
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t fromParticle, toParticle, cflOffset;
-	float deltap;
-	// KEPSILON (keps_forces_params, src/cuda/forces_params.h:283-320)
-	const float *tke, *eps, *turbvisc;
-	const float4 *eulerVel;
-	float *dkde;          // BUFFER_DKDE: 3 floats per particle (diffusion term of k, of epsilon, Yap's C_e2)
-	float *cflKeps;       // BUFFER_CFL_KEPS: one per block
-	float epsilon;
-	// the tiled kernel (forces.hip, SPHX_TURB_SA) has left the fluid <- fluid and fluid <- vertex sums in FORCES: only the
-	// boundary elements and the fix-ups remain -- unless the tiling overflowed (*tileGuard != 0: the tiled kernel did nothing)
-	int tiled;
-	const uint32_t *tileGuard;
-	int wallDone;         // ... and sa_forces_wall_kernel has added the boundary elements (needs `tiled`)
-};
 
 // sa_dot3, sa_P, sa_sound_speed, sa_visc_avg: neib_iter.h (shared with the other fidelity engines)
 
@@ -546,17 +524,6 @@ sa_repack_kernel(DevParams p, SaForcesArgs a)
 
 // integrateGammaDevice, quadrature flavour (src/cuda/density_sum_kernel.cu:690-765) for fluid particles at their new positions;
 // the rows of the other particle types are copied (copyTypeDataDevice, src/cuda/euler.cu:253-262)
-struct SaIntGammaArgs {
-	float4 *newGGam;
-	const float4 *oldGGam, *pos, *boundElement;
-	const float2 *vertPos[3];
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t numParticles;
-	float epsilon;
-	int wallDone;      // the fluid particles with boundary elements in reach are done by sa_integrate_gamma_wall_kernel
-};
 
 __global__ void __launch_bounds__(128)
 sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
@@ -592,18 +559,6 @@ sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
 }
 
 // ---- density summation with dynamic gamma (src/cuda/density_sum_kernel.cu:206-250,419-478,523-655) and Brezzi diffusion ----
-struct SaDensitySumArgs {
-	float4 *newVel, *newGGam, *forces;
-	const float4 *oldPos, *pos /* new positions: what the walker prefetches is not used */, *oldVel, *oldGGam, *boundElement;
-	const float2 *vertPos[3];
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t numParticles;
-	int tiled;                    // the volumic sums are in FORCES.w already (tiled kernel, SPHX_TURB_SA_DSUM), see SaForcesArgs
-	const uint32_t *tileGuard;
-	int wallDone;                 // sa_density_sum_wall_kernel has left {sum grad gamma, sum grad gamma . dr} in newGGam (needs `tiled`)
-};
 
 __global__ void __launch_bounds__(128)
 sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
@@ -751,204 +706,6 @@ sa_gamma_dt_kernel(float *d_dt, const float *cflGammaBlocks, uint32_t numBlocks)
 		if (dt_gam < dt) d_dt[0] = dt_gam;
 	}
 }
-
-// ---- boundary-element terms with one element per lane ---------------------------------------------------------------------
-// A boundary element costs hundreds of instructions (wall_grad_gamma, wall_gamma) and only the few per cent of the fluid
-// particles next to a wall have any: with one thread per particle those few waves run long and alone, each through its
-// 25..80 elements one after the other.  The kernels below give every such particle (sa_wall_list_kernel, neibs.hip) a whole
-// wave: lane l evaluates the l-th entry of the boundary section, the lanes' terms are summed by a butterfly.  The sums differ
-// from the list-order sums of the one-thread kernels by rounding only; these stay as the fallback and the CPU oracle's mirror.
-struct WallEntry { bool alive; uint32_t j; float pcx, pcy, pcz; };
-
-// entries s0 .. s0+63 of the boundary section of particle `index` (it runs down from neibboundpos): decoded in parallel, the
-// cell code of an entry is that of the nearest encoded entry at or before it (cellCarry: from the chunks before)
-__device__ __forceinline__ WallEntry wall_chunk(const DevParams &p, const neibdata *__restrict__ list, const uint32_t *__restrict__ cellStart,
-	uint32_t index, const float4 &pos, const int3 &gridPos, int s0, uint32_t lane, int &cellCarry, bool &more)
-{
-	WallEntry e;
-	const int slot = (int)p.neibboundpos - (s0 + (int)lane);
-	const uint32_t d = slot >= 0 ? (uint32_t)list[(size_t)slot*p.stride + index] : NEIBS_END;
-	const unsigned long long endmask = __builtin_amdgcn_ballot_w64(d == NEIBS_END);
-	const int firstEnd = endmask ? __builtin_ctzll(endmask) : 64;
-	e.alive = (int)lane < firstEnd;
-	const bool enc = e.alive && d >= CELLNUM_ENCODED;
-	const unsigned long long encmask = __builtin_amdgcn_ballot_w64(enc);
-	const unsigned long long le = encmask & (~0ull >> (63u - lane));      // encoded entries at or before this lane
-	const int src = le ? 63 - __builtin_clzll(le) : 0;
-	const int codeSrc = __shfl((int)(d >> CELLNUM_SHIFT), src) - 1;
-	const int c = le ? codeSrc : cellCarry;
-	cellCarry = __shfl(c, 63);
-	more = firstEnd == 64;
-	const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
-	e.j = index; e.pcx = pos.x; e.pcy = pos.y; e.pcz = pos.z;
-	if (e.alive) {
-		e.j = cellStart[grid_hash_periodic(p, gridPos.x + cx - 1, gridPos.y + cy - 1, gridPos.z + cz - 1)] + (d & NEIBINDEX_MASK);
-		e.pcx = fmaf(-(float)(cx - 1), p.cs[0], pos.x);
-		e.pcy = fmaf(-(float)(cy - 1), p.cs[1], pos.y);
-		e.pcz = fmaf(-(float)(cz - 1), p.cs[2], pos.z);
-	}
-	return e;
-}
-
-__device__ __forceinline__ float wave_sum(float v)
-{
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
-	return v;
-}
-__device__ __forceinline__ float wave_max(float v)
-{
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
-	return v;
-}
-
-#define SA_WALL_THREADS 256
-// the wave's particles: wall[1 + w], w = wave number, +waves in the grid, ...
-#define SA_WALL_LOOP(wall) \
-	const uint32_t lane = threadIdx.x & 63u; \
-	const uint32_t nWaves = gridDim.x*(SA_WALL_THREADS/64), count = (wall)[0]; \
-	for (uint32_t w = blockIdx.x*(SA_WALL_THREADS/64) + (threadIdx.x >> 6); w < count; w += nWaves)
-
-// the fluid <- boundary-element part of sa_forces_kernel<false> (same terms, see there), added to the sums the tiled kernel left
-__global__ void __launch_bounds__(SA_WALL_THREADS)
-sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ wall)
-{
-	if (a.tileGuard && *a.tileGuard) return;      // no tiles after all: sa_forces_kernel does everything
-	SA_WALL_LOOP(wall) {
-		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
-		if (index < a.fromParticle || index >= a.toParticle) continue;
-		const float4 pos = a.pos[index], vel = a.vel[index];
-		const uint32_t fl = FLUID_NUM(a.info[index]);
-		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-		const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
-		const float p_precalc = sa_P(p, vel.w, fl)/(p_rho*p_rho);
-		const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
-		const bool newtonian = p.rheology == SPHX_NEWTONIAN;
-		float fx = 0.0f, fy = 0.0f, fz = 0.0f, fw = 0.0f, gammaCfl = 0.0f;
-		int cellCarry = 0;
-		bool more = true;
-		for (int s0 = 0; more; s0 += 64) {
-			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, pos, gridPos, s0, lane, cellCarry, more);
-			const uint32_t j = e.j;
-			const float4 npos = a.pos[j];
-			const float rx = e.pcx - npos.x, ry = e.pcy - npos.y, rz = e.pcz - npos.z;
-			const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
-			if (!e.alive || !is_active_w(npos.w) || r >= p.influenceradius + a.deltap) continue;
-			const float4 nvel = a.vel[j];
-			const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
-			const uint32_t nfl = FLUID_NUM(a.info[j]);
-			const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
-			const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
-			const float4 be = a.boundElement[j];
-			const float inv_h = 1.0f/p.slength;
-			WallTri tri;
-			wall_tri_setup(tri, v3(be.x, be.y, be.z), a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			const float ggamAS = wall_grad_gamma_flat(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
-			const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
-			if (a.cflGamma) {
-				const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
-				const float vs = sa_dot3(vel.x - vx, vel.y - vy, vel.z - vz, be.x, be.y, be.z);
-				gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
-			}
-			if (!density_sum) fw -= p_rho*vn*ggamAS;
-			const float ps = (p_precalc + n_precalc)*n_rho*ggamAS;
-			float dx = ps*be.x, dy = ps*be.y, dz = ps*be.z;
-			if (newtonian) {
-				const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
-				const float tx = vx - vn*be.x, ty = vy - vn*be.y, tz = vz - vn*be.z;
-				const float our_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl]*p_rho : p.visccoeff[fl];
-				const float neib_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl]*n_rho : p.visccoeff[nfl];
-				const float avg = (p.avgop == SPHX_ARITHMETIC) ? (our_mu + neib_mu)*0.5f :
-					(p.avgop == SPHX_HARMONIC) ? 2*our_mu*neib_mu/(our_mu + neib_mu) : sqrtf(our_mu*neib_mu);
-				const float c = ggamAS*2*avg/r_as;
-				const float inv_rho = 1.0f/p_rho;
-				dx -= (c*tx)*inv_rho; dy -= (c*ty)*inv_rho; dz -= (c*tz)*inv_rho;
-			}
-			fx += dx; fy += dy; fz += dz;
-		}
-		fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz); fw = wave_sum(fw); gammaCfl = wave_max(gammaCfl);
-		if (lane == 0) {
-			float4 f = a.forces[index];
-			f.x += fx; f.y += fy; f.z += fz; f.w += fw;
-			a.forces[index] = f;
-			if (a.cflGamma) a.cflGamma[index] = gammaCfl;
-		}
-	}
-}
-
-// the boundary-element sums of sa_density_sum_kernel: {sum grad gamma(n+1), sum 1/2 (grad gamma(n) + grad gamma(n+1)) . (q(n+1) - q(n))}
-// into the particle's row of newGGam, where sa_density_sum_kernel picks them up
-__global__ void __launch_bounds__(SA_WALL_THREADS)
-sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__restrict__ wall)
-{
-	if (a.tileGuard && *a.tileGuard) return;
-	SA_WALL_LOOP(wall) {
-		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
-		if (index >= a.numParticles) continue;
-		const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
-		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
-		float gx = 0.0f, gy = 0.0f, gz = 0.0f, gGamDotR = 0.0f;
-		int cellCarry = 0;
-		bool more = true;
-		for (int s0 = 0; more; s0 += 64) {
-			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, posN, gridPos, s0, lane, cellCarry, more);
-			const uint32_t j = e.j;
-			const float4 nN = a.oldPos[j];
-			if (!e.alive || !is_active_w(nN.w)) continue;
-			const float4 nNp1 = a.pos[j];
-			const float inv = 1.0f/p.slength;
-			const V3 qN = v3((e.pcx - nN.x)*inv, (e.pcy - nN.y)*inv, (e.pcz - nN.z)*inv);
-			const V3 qNp1 = v3(((e.pcx - nNp1.x) + dx)*inv, ((e.pcy - nNp1.y) + dy)*inv, ((e.pcz - nNp1.z) + dz)*inv);
-			const float4 be = a.boundElement[j];
-			const V3 ns = v3(be.x, be.y, be.z);
-			WallTri tri;
-			wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			const V3 gN = ns*(wall_grad_gamma_flat(tri, qN)/p.slength);
-			const V3 gNp1 = ns*(wall_grad_gamma_flat(tri, qNp1)/p.slength);
-			gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
-			gx += gNp1.x; gy += gNp1.y; gz += gNp1.z;
-		}
-		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gGamDotR = wave_sum(gGamDotR);
-		if (lane == 0) a.newGGam[index] = make_float4(gx, gy, gz, gGamDotR);
-	}
-}
-
-// sa_integrate_gamma_kernel for the particles with boundary elements in reach
-__global__ void __launch_bounds__(SA_WALL_THREADS)
-sa_integrate_gamma_wall_kernel(DevParams p, SaIntGammaArgs a, const uint32_t *__restrict__ wall)
-{
-	SA_WALL_LOOP(wall) {
-		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
-		if (index >= a.numParticles) continue;
-		const float4 pos = a.pos[index], og = a.oldGGam[index];
-		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-		const V3 oldg = v3(og.x, og.y, og.z);
-		float gx = 0.0f, gy = 0.0f, gz = 0.0f, gam = 0.0f;
-		int cellCarry = 0;
-		bool more = true;
-		for (int s0 = 0; more; s0 += 64) {
-			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, pos, gridPos, s0, lane, cellCarry, more);
-			if (!e.alive) continue;
-			const uint32_t j = e.j;
-			const float4 npos = a.pos[j];
-			const float4 be = a.boundElement[j];
-			const V3 normal = v3(be.x, be.y, be.z);
-			const V3 q = v3(e.pcx - npos.x, e.pcy - npos.y, e.pcz - npos.z)/p.slength;
-			WallTri tri;
-			wall_tri_setup(tri, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			const float ggamAS = wall_grad_gamma_flat(tri, q)/p.slength;
-			gx += ggamAS*be.x; gy += ggamAS*be.y; gz += ggamAS*be.z;
-			gam += wall_gamma_flat<false>(tri, q, oldg, p.slength, a.epsilon);
-		}
-		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gam = wave_sum(gam);
-		if (lane == 0) a.newGGam[index] = make_float4(gx, gy, gz, 1.0f - gam);
-	}
-}
-
-// a grid that fills the device with waves; each takes every (number of waves)-th wall particle
-static uint32_t sa_wall_grid(const sphx_ctx *ctx) { return ctx->tile_grid*8u; }
 
 static int sa_check(sphx_ctx *ctx, const char *who)
 {
@@ -1195,8 +952,8 @@ static int sa_forces_impl(sphx_ctx *ctx, void *forces, float *cfl, float *cflGam
 		a.tiled = used ? 1 : 0;
 		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
 			a.wallDone = 1;
-			sa_forces_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
-			SPHX_LAUNCH_CHECK("sa_forces_wall_kernel");
+			rc = sphx_sa_wall_forces(ctx, a, st);
+			if (rc != SPHX_OK) return rc;
 		}
 		sa_forces_kernel<false><<<blocks, SPHX_BLOCK_FORCES, 0, st>>>(ctx->dev, a);
 	}
@@ -1360,8 +1117,8 @@ extern "C" int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void 
 	a.numParticles = particleRangeEnd; a.epsilon = epsilon;
 	if (ctx->sa_wall && ctx->sa_wall_neibslist == neibsList && !ctx->disable_tiles) {
 		a.wallDone = 1;
-		sa_integrate_gamma_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, (hipStream_t)stream>>>(ctx->dev, a, ctx->sa_wall);
-		SPHX_LAUNCH_CHECK("sa_integrate_gamma_wall_kernel");
+		rc = sphx_sa_wall_integrate_gamma(ctx, a, (hipStream_t)stream);
+		if (rc != SPHX_OK) return rc;
 	}
 	sa_integrate_gamma_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_integrate_gamma_kernel");
@@ -1432,8 +1189,8 @@ extern "C" int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, v
 		a.tiled = used ? 1 : 0;
 		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
 			a.wallDone = 1;
-			sa_density_sum_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, (hipStream_t)stream>>>(ctx->dev, a, ctx->sa_wall);
-			SPHX_LAUNCH_CHECK("sa_density_sum_wall_kernel");
+			rc = sphx_sa_wall_density_sum(ctx, a, (hipStream_t)stream);
+			if (rc != SPHX_OK) return rc;
 		}
 	}
 	sa_density_sum_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);

@@ -1,0 +1,253 @@
+// sa_wall.hip -- SA_BOUNDARY: the boundary-element terms of the forces, of the density summation and of the gamma quadrature
+// for the fluid particles next to a wall, one element per lane.  Compiled with floating-point contraction and with its own
+// arctangent: these sums are formed in another order than the one-thread-per-particle kernels of sa_bounds.hip (which mirror the
+// CPU oracle operation by operation) anyway, and agree with them to rounding (tests/test_gpu_sa.py runs every SA test both ways).
+#include "sphx_internal.h"
+#include "neib_iter.h"
+#include "sa_args.h"
+
+// atan2 for the edge integrals: quotient by reciprocal + one correction step, arctangent on [0, 1] as t + t s q(s), s = t^2, q
+// fitted here (minimax of the error of atan(t)/t, degree 9: 0.8 ulp on [0, 1]; the whole function stays within 1.8 ulp of the
+// correctly rounded arctangent over random arguments, scripts/fit_atan.py) -- about 25 instructions, against ~50 of the library's
+__device__ __forceinline__ float wall_fast_atan2(float y, float x)
+{
+	const float ax = fabsf(x), ay = fabsf(y);
+	const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+	const float r = __builtin_amdgcn_rcpf(mx);
+	float t = mn*r;
+	t = fmaf(fmaf(-mx, t, mn), r, t);
+	t = (mx == 0.0f || !(mx < 3.0e38f)) ? ((mn == mx && mx != 0.0f) ? 1.0f : 0.0f) : t;     // atan2(0, 0) = 0; infinities
+	const float s = t*t;
+	float q = -1.8272230183369424e-3f;
+	q = fmaf(q, s, 1.1064477995577955e-2f);
+	q = fmaf(q, s, -3.145575541231577e-2f);
+	q = fmaf(q, s, 5.823458879035968e-2f);
+	q = fmaf(q, s, -8.419460484655855e-2f);
+	q = fmaf(q, s, 1.0957576381515889e-1f);
+	q = fmaf(q, s, -1.4265245372329702e-1f);
+	q = fmaf(q, s, 1.9998638615746267e-1f);
+	q = fmaf(q, s, -3.3333301866324133e-1f);
+	float a = fmaf(t*s, q, t);
+	a = (ay > ax) ? 1.57079632679489661923f - a : a;
+	a = (x < 0.0f) ? 3.14159265358979323846f - a : a;
+	return copysignf(a, y);
+}
+#define SPHX_WG_ATAN2 wall_fast_atan2
+#include "sa_wall_gamma.h"
+
+// ---- boundary-element terms with one element per lane ---------------------------------------------------------------------
+// A boundary element costs hundreds of instructions (wall_grad_gamma, wall_gamma) and only the few per cent of the fluid
+// particles next to a wall have any: with one thread per particle those few waves run long and alone, each through its
+// 25..80 elements one after the other.  The kernels below give every such particle (sa_wall_list_kernel, neibs.hip) a whole
+// wave: lane l evaluates the l-th entry of the boundary section, the lanes' terms are summed by a butterfly.  The sums differ
+// from the list-order sums of the one-thread kernels by rounding only; these stay as the fallback and the CPU oracle's mirror.
+struct WallEntry { bool alive; uint32_t j; float pcx, pcy, pcz; };
+
+// entries s0 .. s0+63 of the boundary section of particle `index` (it runs down from neibboundpos): decoded in parallel, the
+// cell code of an entry is that of the nearest encoded entry at or before it (cellCarry: from the chunks before)
+__device__ __forceinline__ WallEntry wall_chunk(const DevParams &p, const neibdata *__restrict__ list, const uint32_t *__restrict__ cellStart,
+	uint32_t index, const float4 &pos, const int3 &gridPos, int s0, uint32_t lane, int &cellCarry, bool &more)
+{
+	WallEntry e;
+	const int slot = (int)p.neibboundpos - (s0 + (int)lane);
+	const uint32_t d = slot >= 0 ? (uint32_t)list[(size_t)slot*p.stride + index] : NEIBS_END;
+	const unsigned long long endmask = __builtin_amdgcn_ballot_w64(d == NEIBS_END);
+	const int firstEnd = endmask ? __builtin_ctzll(endmask) : 64;
+	e.alive = (int)lane < firstEnd;
+	const bool enc = e.alive && d >= CELLNUM_ENCODED;
+	const unsigned long long encmask = __builtin_amdgcn_ballot_w64(enc);
+	const unsigned long long le = encmask & (~0ull >> (63u - lane));      // encoded entries at or before this lane
+	const int src = le ? 63 - __builtin_clzll(le) : 0;
+	const int codeSrc = __shfl((int)(d >> CELLNUM_SHIFT), src) - 1;
+	const int c = le ? codeSrc : cellCarry;
+	cellCarry = __shfl(c, 63);
+	more = firstEnd == 64;
+	const int cz = c/9, cy = (c - cz*9)/3, cx = c - cz*9 - cy*3;
+	e.j = index; e.pcx = pos.x; e.pcy = pos.y; e.pcz = pos.z;
+	if (e.alive) {
+		e.j = cellStart[grid_hash_periodic(p, gridPos.x + cx - 1, gridPos.y + cy - 1, gridPos.z + cz - 1)] + (d & NEIBINDEX_MASK);
+		e.pcx = fmaf(-(float)(cx - 1), p.cs[0], pos.x);
+		e.pcy = fmaf(-(float)(cy - 1), p.cs[1], pos.y);
+		e.pcz = fmaf(-(float)(cz - 1), p.cs[2], pos.z);
+	}
+	return e;
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+	return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+	return v;
+}
+
+#define SA_WALL_THREADS 256
+// the wave's particles: wall[1 + w], w = wave number, +waves in the grid, ...
+#define SA_WALL_LOOP(wall) \
+	const uint32_t lane = threadIdx.x & 63u; \
+	const uint32_t nWaves = gridDim.x*(SA_WALL_THREADS/64), count = (wall)[0]; \
+	for (uint32_t w = blockIdx.x*(SA_WALL_THREADS/64) + (threadIdx.x >> 6); w < count; w += nWaves)
+
+// the fluid <- boundary-element part of sa_forces_kernel<false> (same terms, see there), added to the sums the tiled kernel left
+__global__ void __launch_bounds__(SA_WALL_THREADS)
+sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ wall)
+{
+	if (a.tileGuard && *a.tileGuard) return;      // no tiles after all: sa_forces_kernel does everything
+	SA_WALL_LOOP(wall) {
+		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
+		if (index < a.fromParticle || index >= a.toParticle) continue;
+		const float4 pos = a.pos[index], vel = a.vel[index];
+		const uint32_t fl = FLUID_NUM(a.info[index]);
+		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
+		const float p_precalc = sa_P(p, vel.w, fl)/(p_rho*p_rho);
+		const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
+		const bool newtonian = p.rheology == SPHX_NEWTONIAN;
+		float fx = 0.0f, fy = 0.0f, fz = 0.0f, fw = 0.0f, gammaCfl = 0.0f;
+		int cellCarry = 0;
+		bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, pos, gridPos, s0, lane, cellCarry, more);
+			const uint32_t j = e.j;
+			const float4 npos = a.pos[j];
+			const float rx = e.pcx - npos.x, ry = e.pcy - npos.y, rz = e.pcz - npos.z;
+			const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+			if (!e.alive || !is_active_w(npos.w) || r >= p.influenceradius + a.deltap) continue;
+			const float4 nvel = a.vel[j];
+			const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+			const uint32_t nfl = FLUID_NUM(a.info[j]);
+			const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+			const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
+			const float4 be = a.boundElement[j];
+			const float inv_h = 1.0f/p.slength;
+			WallTri tri;
+			wall_tri_setup(tri, v3(be.x, be.y, be.z), a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			const float ggamAS = wall_grad_gamma_flat(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
+			const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
+			if (a.cflGamma) {
+				const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
+				const float vs = sa_dot3(vel.x - vx, vel.y - vy, vel.z - vz, be.x, be.y, be.z);
+				gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
+			}
+			if (!density_sum) fw -= p_rho*vn*ggamAS;
+			const float ps = (p_precalc + n_precalc)*n_rho*ggamAS;
+			float dx = ps*be.x, dy = ps*be.y, dz = ps*be.z;
+			if (newtonian) {
+				const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
+				const float tx = vx - vn*be.x, ty = vy - vn*be.y, tz = vz - vn*be.z;
+				const float our_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl]*p_rho : p.visccoeff[fl];
+				const float neib_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl]*n_rho : p.visccoeff[nfl];
+				const float avg = (p.avgop == SPHX_ARITHMETIC) ? (our_mu + neib_mu)*0.5f :
+					(p.avgop == SPHX_HARMONIC) ? 2*our_mu*neib_mu/(our_mu + neib_mu) : sqrtf(our_mu*neib_mu);
+				const float c = ggamAS*2*avg/r_as;
+				const float inv_rho = 1.0f/p_rho;
+				dx -= (c*tx)*inv_rho; dy -= (c*ty)*inv_rho; dz -= (c*tz)*inv_rho;
+			}
+			fx += dx; fy += dy; fz += dz;
+		}
+		fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz); fw = wave_sum(fw); gammaCfl = wave_max(gammaCfl);
+		if (lane == 0) {
+			float4 f = a.forces[index];
+			f.x += fx; f.y += fy; f.z += fz; f.w += fw;
+			a.forces[index] = f;
+			if (a.cflGamma) a.cflGamma[index] = gammaCfl;
+		}
+	}
+}
+
+// the boundary-element sums of sa_density_sum_kernel: {sum grad gamma(n+1), sum 1/2 (grad gamma(n) + grad gamma(n+1)) . (q(n+1) - q(n))}
+// into the particle's row of newGGam, where sa_density_sum_kernel picks them up
+__global__ void __launch_bounds__(SA_WALL_THREADS)
+sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__restrict__ wall)
+{
+	if (a.tileGuard && *a.tileGuard) return;
+	SA_WALL_LOOP(wall) {
+		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
+		if (index >= a.numParticles) continue;
+		const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
+		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
+		float gx = 0.0f, gy = 0.0f, gz = 0.0f, gGamDotR = 0.0f;
+		int cellCarry = 0;
+		bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, posN, gridPos, s0, lane, cellCarry, more);
+			const uint32_t j = e.j;
+			const float4 nN = a.oldPos[j];
+			if (!e.alive || !is_active_w(nN.w)) continue;
+			const float4 nNp1 = a.pos[j];
+			const float inv = 1.0f/p.slength;
+			const V3 qN = v3((e.pcx - nN.x)*inv, (e.pcy - nN.y)*inv, (e.pcz - nN.z)*inv);
+			const V3 qNp1 = v3(((e.pcx - nNp1.x) + dx)*inv, ((e.pcy - nNp1.y) + dy)*inv, ((e.pcz - nNp1.z) + dz)*inv);
+			const float4 be = a.boundElement[j];
+			const V3 ns = v3(be.x, be.y, be.z);
+			WallTri tri;
+			wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			const V3 gN = ns*(wall_grad_gamma_flat(tri, qN)/p.slength);
+			const V3 gNp1 = ns*(wall_grad_gamma_flat(tri, qNp1)/p.slength);
+			gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
+			gx += gNp1.x; gy += gNp1.y; gz += gNp1.z;
+		}
+		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gGamDotR = wave_sum(gGamDotR);
+		if (lane == 0) a.newGGam[index] = make_float4(gx, gy, gz, gGamDotR);
+	}
+}
+
+// sa_integrate_gamma_kernel for the particles with boundary elements in reach
+__global__ void __launch_bounds__(SA_WALL_THREADS)
+sa_integrate_gamma_wall_kernel(DevParams p, SaIntGammaArgs a, const uint32_t *__restrict__ wall)
+{
+	SA_WALL_LOOP(wall) {
+		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
+		if (index >= a.numParticles) continue;
+		const float4 pos = a.pos[index], og = a.oldGGam[index];
+		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		const V3 oldg = v3(og.x, og.y, og.z);
+		float gx = 0.0f, gy = 0.0f, gz = 0.0f, gam = 0.0f;
+		int cellCarry = 0;
+		bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, pos, gridPos, s0, lane, cellCarry, more);
+			if (!e.alive) continue;
+			const uint32_t j = e.j;
+			const float4 npos = a.pos[j];
+			const float4 be = a.boundElement[j];
+			const V3 normal = v3(be.x, be.y, be.z);
+			const V3 q = v3(e.pcx - npos.x, e.pcy - npos.y, e.pcz - npos.z)/p.slength;
+			WallTri tri;
+			wall_tri_setup(tri, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			const float ggamAS = wall_grad_gamma_flat(tri, q)/p.slength;
+			gx += ggamAS*be.x; gy += ggamAS*be.y; gz += ggamAS*be.z;
+			gam += wall_gamma_flat<false>(tri, q, oldg, p.slength, a.epsilon);
+		}
+		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gam = wave_sum(gam);
+		if (lane == 0) a.newGGam[index] = make_float4(gx, gy, gz, 1.0f - gam);
+	}
+}
+
+// a grid that fills the device with waves; each takes every (number of waves)-th wall particle
+static uint32_t sa_wall_grid(const sphx_ctx *ctx) { return ctx->tile_grid*8u; }
+
+int sphx_sa_wall_forces(sphx_ctx *ctx, const SaForcesArgs &a, hipStream_t st)
+{
+	sa_forces_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	SPHX_LAUNCH_CHECK("sa_forces_wall_kernel");
+	return SPHX_OK;
+}
+int sphx_sa_wall_density_sum(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st)
+{
+	sa_density_sum_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	SPHX_LAUNCH_CHECK("sa_density_sum_wall_kernel");
+	return SPHX_OK;
+}
+int sphx_sa_wall_integrate_gamma(sphx_ctx *ctx, const SaIntGammaArgs &a, hipStream_t st)
+{
+	sa_integrate_gamma_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	SPHX_LAUNCH_CHECK("sa_integrate_gamma_wall_kernel");
+	return SPHX_OK;
+}

@@ -28,6 +28,9 @@ struct float2 { float x, y; };
 // Lengths are in units of the smoothing length.  Same integrals as the reference, another order of operations: the results
 // agree with the oracle's transcription of gamma.cuh (pinned bit for bit to the reference, tests/golden/ref_gamma.npz) to
 // the rounding of a few dozen float operations (bounds in tests/test_gpu_sa.py).
+#ifndef SPHX_WG_ATAN2
+#define SPHX_WG_ATAN2 atan2f      // sa_wall.hip brings its own
+#endif
 struct V3 { float x, y, z; };
 SPHX_WG_FN V3 v3(float x, float y, float z) { V3 r = { x, y, z }; return r; }
 SPHX_WG_FN V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -88,7 +91,7 @@ SPHX_WG_FN EdgeEnd wall_edge_end(const EdgePowers &k, float s, float d)
 	const float p0 = 1344.0f - 1260.0f*k.a4 - 420.0f*k.b4 - k.a2*(3360.0f + 420.0f*s2) - s2*(84.0f*s2 + 560.0f)
 		- k.b2*(1680.0f + 1260.0f*k.a2 + 280.0f*s2);
 	r.poly = s*(p0 + d*p1);
-	r.angle = atan2f(k.a*s, k.b*d) - atan2f(s, k.b);
+	r.angle = SPHX_WG_ATAN2(k.a*s, k.b*d) - SPHX_WG_ATAN2(s, k.b);
 	r.log = copysignf(acoshf(fmaxf(d/fmaxf(k.c, 1e-7f), 1.0f)), s);
 	return r;
 }
@@ -116,7 +119,7 @@ SPHX_WG_FN float wall_grad_gamma_body(const WallTri &w, V3 q)
 		k.c = sqrtf(pn*pn + k.b*k.b);
 		float s0 = -dot(d0, w.along[e]), s1 = -dot(d1, w.along[e]);
 		const float bAbs = fabsf(k.b);
-		angleAll += copysignf(atan2f(s1, bAbs) - atan2f(s0, bAbs), k.b);
+		angleAll += copysignf(SPHX_WG_ATAN2(s1, bAbs) - SPHX_WG_ATAN2(s0, bAbs), k.b);
 		if (k.c < 2.0f) {
 			const float half = sqrtf(4.0f - k.c*k.c);         // half length of the edge line's chord inside the support
 			s0 = copysignf(fminf(fabsf(s0), half), s0);
@@ -127,7 +130,7 @@ SPHX_WG_FN float wall_grad_gamma_body(const WallTri &w, V3 q)
 			const float logw = ((5.0f*k.b2 + 21.0f*(8.0f + k.a2))*k.b2 + 35.0f*k.a2*(16.0f + k.a2))*k.b2 + 35.0f*k.a4*(24.0f + k.a2);
 			edges += 0.00015542474911f*(48.0f*a5*(28.0f + k.a2)*(e1.angle - e0.angle)
 				+ k.b*((e1.poly - e0.poly) + 3.0f*logw*(e1.log - e0.log)));
-			angleIn += copysignf(atan2f(s1, bAbs) - atan2f(s0, bAbs), k.b);
+			angleIn += copysignf(SPHX_WG_ATAN2(s1, bAbs) - SPHX_WG_ATAN2(s0, bAbs), k.b);
 		}
 	}
 	const float t = 1.0f - 0.5f*k.a;
@@ -171,7 +174,7 @@ SPHX_WG_FN float wall_gamma_body(const WallTri &w, V3 q, V3 oldGradGamma, float 
 			const float i1 = 1.0f/length(f1), i2 = 1.0f/length(f2);
 			const float den = 1.0f + dot(f1, in)*i1 + dot(f2, in)*i2 + dot(f1, f2)*i1*i2;
 			const float num = dot(in, cross(f1, f2))*i1*i2;
-			solid = fabsf(2.0f*atan2f(num, den))*0.079577471545947667884441881686257181017229822870228224373833f;
+			solid = fabsf(2.0f*SPHX_WG_ATAN2(num, den))*0.079577471545947667884441881686257181017229822870228224373833f;
 		}
 	}
 	float vol = 0.0f;

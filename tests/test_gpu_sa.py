@@ -444,7 +444,9 @@ def test_sa_tiled_kernels_agree_with_the_list_walkers(options, monkeypatch):
     cell = float(np.min(prob.m_cellsize))
     vmax = np.abs(vel_w[:, :3]).max()
     assert vmax > 0.2
-    assert np.abs(pos_t[:, :3] - pos_w[:, :3]).max() < 2e-5 * cell
+    # (a particle with an ill-conditioned element among its neighbours is pushed a little differently by the two: see
+    # assert_close_but_for_gamma_spikes)
+    assert_close_but_for_gamma_spikes(pos_t[:, :3], pos_w[:, :3], 2e-5, cell, spike=10.0, what="positions, tiled against list walkers")
     assert_close_but_for_gamma_spikes(vel_t[:, :3], vel_w[:, :3], 2e-4, vmax, spike=10.0, what="velocities, tiled against list walkers")
     assert_close_but_for_gamma_spikes(vel_t[:, 3], vel_w[:, 3], 2e-6, 1.0, spike=10.0, what="densities, tiled against list walkers")
     assert np.abs(gg_t[fl, 3] - gg_w[fl, 3]).max() < 2e-5
