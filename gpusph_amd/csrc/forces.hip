@@ -909,7 +909,7 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	// pattern: the older wave is preferred in batches 0,1 of every 4 (default); SPHX_TILE_DEBUG 64: in 0,2; 128: in 0,1,2; 256: priorities
 	// left alone.  Measured at 32 M particles: 4.67 ms per launch left alone, 4.52 / 4.50 / 4.49 with patterns 1 / 2 / 3
 	const int prio = (list.dbg & 256) ? 0 : (((list.dbg >> 6) & 3) ? ((list.dbg >> 6) & 3) : 3);
-	const bool hiw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0;
+	const bool hiw = (TILE_WAVES > 4) ? (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0) : (((blockIdx.x/256u) & 1u) != 0u);
 #define SPHX_RING_STEP(J, JN) \
 	if (prio) { if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } \
 	            else { const bool hi = (prio == 1) ? !((J) & 1) : (prio == 2) ? ((J) != 3) : ((J) < 2); \
@@ -986,28 +986,34 @@ __device__ __forceinline__ void stress_finalize(const DevParams &p, const Forces
 // the two window rows a wave stages (wave w: rows w and w + 8), from tile_rows.  The six words are requested one tile
 // ahead and only turned into scalars (the LDS-DMA destination and the trip counts derive from them) when their tile
 // starts: a readfirstlane at request time would wait for the load there and then
-struct RowRaw { uint32_t w[6]; };
-struct RowJobs { uint32_t start[2], total[2], base[2]; bool contig[2]; };
+// (a workgroup of TILE_WAVES waves: wave w stages the TILE_RPW rows w, w + TILE_WAVES, ...)
+static_assert(TILE_WAVES*TILE_RPW == TILE_WROWS && (TILE_WAVES % 2) == 0, "the window rows are dealt out evenly, two rows per table word");
+struct RowRaw { uint32_t w[3*TILE_RPW]; };
+struct RowJobs { uint32_t start[TILE_RPW], total[TILE_RPW], base[TILE_RPW]; bool contig[TILE_RPW]; };
 __device__ __forceinline__ void request_row_jobs(const uint32_t *__restrict__ tileRows, uint32_t tile, uint32_t wave, RowRaw &r)
 {
 	const uint32_t *d = tileRows + (size_t)TILE_ROWDESC*tile;
-	r.w[0] = d[wave]; r.w[1] = d[wave + 8u];
-	r.w[2] = d[16u + (wave >> 1)]; r.w[3] = d[20u + (wave >> 1)];
-	r.w[4] = d[24u + (wave >> 1)]; r.w[5] = d[28u + (wave >> 1)];
+#pragma unroll
+	for (int k = 0; k < TILE_RPW; ++k) {
+		const uint32_t row = wave + (uint32_t)(TILE_WAVES*k);      // same parity as the wave: TILE_WAVES is even
+		r.w[k] = d[row];
+		r.w[TILE_RPW + k] = d[16u + (row >> 1)];
+		r.w[2*TILE_RPW + k] = d[24u + (row >> 1)];
+	}
 }
 __device__ __forceinline__ void resolve_row_jobs(const RowRaw &r, uint32_t wave, RowJobs &j)
 {
 	const uint32_t sh = 16u*(wave & 1u);
 #pragma unroll
-	for (int k = 0; k < 2; ++k) {
+	for (int k = 0; k < TILE_RPW; ++k) {
 		j.start[k] = __builtin_amdgcn_readfirstlane(r.w[k]);
-		const uint32_t tb = __builtin_amdgcn_readfirstlane((r.w[2 + k] >> sh) & 0xFFFFu);
-		const uint32_t bb = __builtin_amdgcn_readfirstlane((r.w[4 + k] >> sh) & 0xFFFFu);
+		const uint32_t tb = __builtin_amdgcn_readfirstlane((r.w[TILE_RPW + k] >> sh) & 0xFFFFu);
+		const uint32_t bb = __builtin_amdgcn_readfirstlane((r.w[2*TILE_RPW + k] >> sh) & 0xFFFFu);
 		j.total[k] = tb; j.base[k] = bb & 0x7FFFu; j.contig[k] = !(bb & 0x8000u);
 	}
 }
 
-#define TILE_HCH 5   // 64-record chunks of a window row whose cell hashes are fetched along with the DMA (longer rows: later)
+#define TILE_HCH (TILE_RPW > 2 ? 3 : 5)   // 64-record chunks of a window row whose cell hashes are fetched along with the DMA (longer rows: later)
 
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __global__ void __launch_bounds__(TILE_THREADS, 2)
@@ -1145,10 +1151,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		//    the cell hash of every record along with it; when both have landed it moves ITS rows into the tile's frame
 		//    (tile_shift of the record's cell: row from the row number, column from the hash) -- no other wave has to wait for
 		//    that, the one barrier below publishes the finished window
-		uint32_t hsh[2][TILE_HCH];
+		uint32_t hsh[TILE_RPW][TILE_HCH];
 		if (inRange && pairs && (a.dbg & 3) != 2) {
 #pragma unroll
-			for (int k = 0; k < 2; ++k) {
+			for (int k = 0; k < TILE_RPW; ++k) {
 				const uint32_t total = rjc.total[k], base = rjc.base[k], rs = rjc.start[k];
 #pragma unroll
 				for (int c = 0; c < TILE_HCH; ++c) hsh[k][c] = 0u;
@@ -1174,9 +1180,9 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		SPHX_PROF(3);
 		if (inRange && pairs && (a.dbg & 3) != 2) {
 #pragma unroll
-			for (int k = 0; k < 2; ++k) {
+			for (int k = 0; k < TILE_RPW; ++k) {
 				const uint32_t total = rjc.total[k], base = rjc.base[k], rs = rjc.start[k];
-				const int r = (int)wave + 8*k;
+				const int r = (int)wave + TILE_WAVES*k;
 				if (!total || base + total > WC) continue;     // cannot overflow for tiles of build_tiles_kernel
 				if (rjc.contig[k]) {
 					const int h0 = window_row_hash0(p, g2, g3, r) + ca - 1;      // cell hash of window column 0 of this row
@@ -1902,7 +1908,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 				const uint32_t o = sChunkRows[c], ow = (o & 0xFFFFu) + (o >> 16);
 				rank += (ow > w || (ow == w && c < tid)) ? 1u : 0u;
 			}
-			const uint32_t wv = rank < 4u ? rank : 11u - rank;
+			const uint32_t wv = (TILE_WAVES == 8) ? (rank < 4u ? rank : 11u - rank) : rank;
 			tileWaves[(size_t)tile*(TILE_THREADS/64) + wv] = (mineRows & 0x0FFFFFFFu) | (tid << 28);
 		}
 	}

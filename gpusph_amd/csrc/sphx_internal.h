@@ -41,6 +41,8 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #endif
 #define TILE_HROWS    4                    // home rows: 2 (COORD2) x 2 (COORD3)
 #define TILE_WROWS    16                   // window rows: 4 x 4
+#define TILE_WAVES    (TILE_THREADS/64)    // waves of a tile's workgroup ...
+#define TILE_RPW      (TILE_WROWS/TILE_WAVES)   // ... and the window rows each of them stages
 #define TILE_MAXCELLS 14                   // cells per tile along COORD1
 #define TILE_KW       16                   // window columns (TILE_MAXCELLS + 2)
 #define TILE_DESC     16                   // uint32 per tile: g2, g3, firstCell, numCells, first[4], count[4], window, flags,
