@@ -30,7 +30,7 @@ struct ForcesArgs {
 	const float2 *tau0, *tau1, *tau2;
 	const float4 *aux;   // per-particle EOS pre-pass {P/rho^2, c, P, rho}
 	float2 *otau0, *otau1, *otau2; float *oturbvisc;   // stress mode of the tiled kernel (SPHX_TURB_STRESS): outputs
-	const float4 *tauPack;   // SPS + tiled kernel: [0,n) = {xx,xy,xz,yy}, [n,2n) = {yz,zz,0,0} (tau_pack_kernel); tauPackN = n
+	const float4 *tauPack;   // SPS + tiled kernel: [0,n) = {xx,xy,xz,yy}, [n,2n) = {yz,zz,P/rho^2,c or P} (tau_pack_kernel); tauPackN = n
 	uint32_t tauPackN;
 	// tiled kernel: the tile lists of this neighbour list (tile_lists_kernel), [rows][stride] uint16, and the rows per wave
 	const uint16_t *tileList; uint32_t tileListRows, tileListStride;
@@ -103,16 +103,21 @@ eos_kernel(DevParams p, const float4 *__restrict__ vel, const particleinfo *__re
 }
 
 // SPS + tiled kernel: the three float2 arrays of BUFFER_TAU repacked as two float4 rows per particle, so that the window
-// rows can be staged with the same 16-byte LDS DMA as pos / vel / the EOS row
+// rows can be staged with the same 16-byte LDS DMA as pos / vel / the EOS row.  The two free slots of the second row carry what
+// a pair needs of the neighbour's EOS row besides the density (which is one add and one multiply away from the velocity row's
+// rho~): P/rho^2 and the one of {sound speed, pressure} the run's density diffusion reads (Ferrari / none: c; Colagrossi: P).
+// With one fluid the window of an SPS run then needs no EOS rows at all: 64 instead of 80 bytes per record, tiles of six
+// instead of four cells (TILE_WCAP_SPS1), 82 % instead of 55 % of the lanes of a tile occupied.
 static __global__ void __launch_bounds__(256)
 tau_pack_kernel(const float2 *__restrict__ t0, const float2 *__restrict__ t1, const float2 *__restrict__ t2,
-	float4 *__restrict__ out, uint32_t n)
+	const float4 *__restrict__ aux, int wantPressure, float4 *__restrict__ out, uint32_t n)
 {
 	const uint32_t i = blockIdx.x*256 + threadIdx.x;
 	if (i >= n) return;
 	const float2 a = t0[i], b = t1[i], c = t2[i];
+	const float4 e = aux[i];
 	out[i] = make_float4(a.x, a.y, b.x, b.y);
-	out[(size_t)n + i] = make_float4(c.x, c.y, 0.0f, 0.0f);
+	out[(size_t)n + i] = make_float4(c.x, c.y, e.x, wantPressure ? e.z : e.y);
 }
 
 struct Self {
@@ -723,7 +728,9 @@ __device__ __forceinline__ void sa_diff_interact(const DevParams &p, const Self 
 
 #define TILE_HB 2   // pairs per pipeline stage ("half batch")
 // window capacity of a tiled-kernel instantiation, and the LDS placement of the SPS rows behind the EOS rows
-#define TILE_WC(T) ((TURB_MODEL(T) == SPHX_SPS) ? TILE_WCAP_SPS : TILE_WCAP)
+#define TILE_WC(T) ((TURB_MODEL(T) == SPHX_SPS) ? (((T) & SPHX_TURB_MF) ? TILE_WCAP_SPS : TILE_WCAP_SPS1) : TILE_WCAP)
+// SPS, one fluid: no EOS rows in the window, see tau_pack_kernel
+#define TILE_SPS_COMPACT(T) (TURB_MODEL(T) == SPHX_SPS && !((T) & SPHX_TURB_MF))
 struct Gathered {
 	float4 npos[TILE_HB], nvel[TILE_HB], naux[TILE_HB];
 	float ntau[TILE_HB][6];   // SPS only
@@ -738,7 +745,7 @@ __device__ __forceinline__ const float4 &lds_row(const float4 *base, uint32_t by
 // neighbour's row in the window arrays (positions in the tile's frame, see tile_shift): no decode, nothing here depends
 // on a previous LDS read, so the round trips overlap with the arithmetic of the previous pairs.
 template<int TURB>
-__device__ __forceinline__ void gather_half(uint32_t packed, const float4 *sPos, const float4 *sVel, const float4 *sAux, Gathered &g)
+__device__ __forceinline__ void gather_half(uint32_t packed, const float4 *sPos, const float4 *sVel, const float4 *sAux, float rho0, Gathered &g)
 {
 	static_assert(TILE_HB == 2, "a half batch is one 32-bit word of the tile list");
 	constexpr uint32_t WS = TILE_WC(TURB) + 1u;
@@ -747,6 +754,13 @@ __device__ __forceinline__ void gather_half(uint32_t packed, const float4 *sPos,
 		const uint32_t L = k ? packed >> 16 : packed & 0xFFFFu;
 		g.npos[k] = lds_row(sPos, L);
 		if (!(TURB & SPHX_TURB_SA_DIFF)) g.nvel[k] = lds_row(sVel, L);
+		if (TILE_SPS_COMPACT(TURB)) {      // two stress rows, the EOS values in the second one's spare slots (tau_pack_kernel)
+			const float4 ta = lds_row(sAux, L), tb = lds_row(sAux + WS, L);
+			g.ntau[k][0] = ta.x; g.ntau[k][1] = ta.y; g.ntau[k][2] = ta.z; g.ntau[k][3] = ta.w; g.ntau[k][4] = tb.x; g.ntau[k][5] = tb.y;
+			// {P/rho^2, c, P, rho} as eos_kernel makes them; only one of c, P is there, the one the pair reads
+			g.naux[k] = make_float4(tb.z, tb.w, tb.w, (g.nvel[k].w + 1.0f)*rho0);
+			continue;
+		}
 		if (!(TURB & (SPHX_TURB_STRESS | SPHX_TURB_SA_DSUM))) g.naux[k] = lds_row(sAux, L);
 		if (TURB_MODEL(TURB) == SPHX_SPS) {   // the SPS rows lie behind the EOS rows: sAux[WS + slot], sAux[2 WS + slot]
 			const float4 ta = lds_row(sAux + WS, L), tb = lds_row(sAux + 2*WS, L);
@@ -899,7 +913,7 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	}
 	int left = nb;
 	Gathered A, B;
-	gather_half<TURB>(lw.q[0].x, sPos, sVel, sAux, A);
+	gather_half<TURB>(lw.q[0].x, sPos, sVel, sAux, p.rho0[0], A);
 	// one batch per step; the first half of the NEXT batch is gathered before the second half of this one is computed,
 	// also after the last batch (a clamped, in-bounds prefetch whose rows are never computed): one exit per step and no
 	// second copy of the pair code
@@ -914,12 +928,12 @@ __device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListR
 	if (prio) { if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } \
 	            else { const bool hi = (prio == 1) ? !((J) & 1) : (prio == 2) ? ((J) != 3) : ((J) < 2); \
 	                   if (hi) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); } } \
-	gather_half<TURB>(lw.q[J].y, sPos, sVel, sAux, B); \
+	gather_half<TURB>(lw.q[J].y, sPos, sVel, sAux, p.rho0[0], B); \
 	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
 	load_list_u(list, voff, sec, next, lw.q[J]); \
 	pin_batch(list, lw.q[J]); \
 	++next; \
-	gather_half<TURB>(lw.q[JN].x, sPos, sVel, sAux, A); \
+	gather_half<TURB>(lw.q[JN].x, sPos, sVel, sAux, p.rho0[0], A); \
 	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
 	if (--left == 0) { if (prio) __builtin_amdgcn_s_setprio(0); return; }
 	for (;;) {
@@ -956,7 +970,7 @@ __device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t tid, u
 }
 
 // a thread's own rows and the first batches of its neighbour list, requested one tile ahead
-struct TileOwn { particleinfo info; uint32_t hash, slot; ListWindow lwF; uint2 lwB0; };
+struct TileOwn { particleinfo info; uint32_t hash, slot; ListWindow lwF; uint2 lwB0; float4 aux; };
 
 // tail of SPSstressMatrixDevice (src/cuda/visc_kernel.cu:780-811): shear rate -> nu_SPS, tau
 __device__ __forceinline__ void stress_finalize(const DevParams &p, const ForcesArgs &a, uint32_t index, float rho,
@@ -1023,16 +1037,19 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 {
 	constexpr uint32_t WC = TILE_WC(TURB);
 	constexpr bool SPSW = TURB_MODEL(TURB) == SPHX_SPS;
+	constexpr bool SPSC = TILE_SPS_COMPACT(TURB);      // ... whose window holds no EOS rows (one fluid)
 	constexpr bool STRESS = (TURB & SPHX_TURB_STRESS) != 0;   // stress mode: no EOS rows, every active particle walks both sections
 	constexpr bool PREMUL = TilePk<KERNEL, TURB, COLAGROSSI, LJ>::value;   // the window holds m * fcoeff (pair_interact_pk)
 	// SA_BOUNDARY modes: sums over the fluid and vertex neighbours of the fluid particles, finished by sa_bounds.hip
 	constexpr bool SA = (TURB & SPHX_TURB_SA_ANY) != 0, SA_DSUM = (TURB & SPHX_TURB_SA_DSUM) != 0, SA_DIFF = (TURB & SPHX_TURB_SA_DIFF) != 0;
-	constexpr bool NOAUX = STRESS || SA_DSUM;   // no EOS rows in the window
+	constexpr bool NOAUX = STRESS || SA_DSUM || SPSC;   // no EOS rows in the window
 	constexpr bool NOVEL = SA_DIFF;             // no velocity rows
 	constexpr uint32_t WS = WC + 1;   // window arrays: the dummy row the pad entries of the tile lists point to (slot 0) + WC records
 	__shared__ __attribute__((aligned(16))) float4 sPos[WS];
 	__shared__ __attribute__((aligned(16))) float4 sVel[WS];
-	__shared__ __attribute__((aligned(16))) float4 sAux[SPSW ? 3*WS : WS];   // SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}
+	// SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}; with one fluid only the two stress rows (SPSC)
+	__shared__ __attribute__((aligned(16))) float4 sAux[SPSC ? 2*WS : SPSW ? 3*WS : WS];
+	constexpr uint32_t TAU0 = SPSC ? 0u : WS;     // where the stress rows start in sAux
 	__shared__ uint32_t sTileQ[2];                                 // [0] first tile, [1] next tile of this workgroup
 
 	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this launch
@@ -1084,7 +1101,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		sPos[0] = make_float4(1.0e3f, 1.0e3f, 1.0e3f, 0.0f);
 		sVel[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		sAux[0] = make_float4(0.0f, 1.0f, 0.0f, 1.0f);
-		if (SPSW) { sAux[WS] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); sAux[2*WS] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+		if (SPSW) { sAux[TAU0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); sAux[TAU0 + WS] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); }
 	}
 	const float inv_h = fast_rcp(p.slength);
 	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
@@ -1108,6 +1125,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	// (its home cell is part of it), not from memory
 	auto request_own = [&](const TileHome &h, TileOwn &o) {
 		o.info = a.info[h.li]; o.hash = a.hash[h.li]; o.slot = a.tileOwnSlot[h.li];
+		if (SPSC) o.aux = a.aux[h.li];
 		const uint32_t vo = h.li*(uint32_t)(TILE_NB*sizeof(uint16_t));   // byte offset of this particle inside every batch slab
 		preload_list(listRows, vo, 0, o.lwF);
 		// boundary section: most particles have none, so only its first batch is requested up front; the walk
@@ -1163,8 +1181,8 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				if (!NOVEL) stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
 				if (!NOAUX) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
 				if (SPSW) {
-					stage_row_wave(a.tauPack + rs, sAux + WS + 1 + base, total, lane);
-					stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + 2*WS + 1 + base, total, lane);
+					stage_row_wave(a.tauPack + rs, sAux + TAU0 + 1 + base, total, lane);
+					stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + TAU0 + WS + 1 + base, total, lane);
 				}
 #pragma unroll
 				for (int c = 0; c < TILE_HCH; ++c)
@@ -1230,7 +1248,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 							sPos[cb + q] = P;
 							if (!NOVEL) sVel[cb + q] = a.vel[st + q];
 							if (!NOAUX) sAux[cb + q] = a.aux[st + q];
-							if (SPSW) { sAux[WS + cb + q] = a.tauPack[st + q]; sAux[2*WS + cb + q] = a.tauPack[a.tauPackN + st + q]; }
+							if (SPSW) { sAux[TAU0 + cb + q] = a.tauPack[st + q]; sAux[TAU0 + WS + cb + q] = a.tauPack[a.tauPackN + st + q]; }
 						}
 						off += cnt;
 					}
@@ -1259,15 +1277,15 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		s.fl = (TURB & SPHX_TURB_MF) ? FLUID_NUM(info) : 0u;
 		if (STRESS) {
 			s.rho = (ovel.w + 1.0f)*p.rho0[0];
-		} else if (!NOAUX) {
-			const float4 oaux = lds_row(sAux, oslot);
+		} else if (!NOAUX || SPSC) {
+			const float4 oaux = SPSC ? own.aux : lds_row(sAux, oslot);      // SPSC: the own EOS row came with the own info, from memory
 			s.p_precalc = oaux.x; s.sspeed = oaux.y; s.P = oaux.z; s.rho = oaux.w;
 			s.inv_rho = fast_rcp(oaux.w);
 		}
 		if (SA_DIFF) s.sa_dt2rho = a.saDt*2.0f*s.rho;
 		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
 		if (SPSW) {   // own stress tensor
-			const float4 ta = lds_row(sAux + WS, oslot), tb = lds_row(sAux + 2*WS, oslot);
+			const float4 ta = lds_row(sAux + TAU0, oslot), tb = lds_row(sAux + TAU0 + WS, oslot);
 			s.tau[0] = ta.x; s.tau[1] = ta.y; s.tau[2] = ta.z; s.tau[3] = ta.w; s.tau[4] = tb.x; s.tau[5] = tb.y;
 		}
 		ListWindow lwB;
@@ -2014,7 +2032,7 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	if (use_tiles && ctx->dev.turbmodel == SPHX_SPS) {   // window rows of the stress tensor (see tau_pack_kernel)
 		SPHX_REQUIRE(ctx->tau_pack != nullptr && numParticles <= ctx->reserved_particles, "sphx_forces_basicstep: SPS scratch not reserved");
 		tau_pack_kernel<<<div_up_u(numParticles, 256), 256, 0, (hipStream_t)stream>>>((const float2*)tau0, (const float2*)tau1,
-			(const float2*)tau2, ctx->tau_pack, numParticles);
+			(const float2*)tau2, ctx->eos_aux, ctx->dev.densitydiff == SPHX_COLAGROSSI ? 1 : 0, ctx->tau_pack, numParticles);
 		SPHX_LAUNCH_CHECK("tau_pack_kernel");
 		a.tauPack = ctx->tau_pack; a.tauPackN = numParticles;
 	}

@@ -787,7 +787,8 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 	const uint32_t *__restrict__ cols, uint32_t rangeEnd,
 	uint32_t *__restrict__ tiles, uint32_t *__restrict__ ctl, uint32_t capacity)
 {
-	const uint32_t wcap = (p.turbmodel == SPHX_SPS) ? TILE_WCAP_SPS : TILE_WCAP;   // the SPS window also holds tau
+	// the SPS window also holds tau (and, with several fluids, the EOS rows as well)
+	const uint32_t wcap = (p.turbmodel == SPHX_SPS) ? (p.numfluids > 1 ? TILE_WCAP_SPS : TILE_WCAP_SPS1) : TILE_WCAP;
 	const int gs1 = p.gs1;
 	const int gs2 = (p.c2 == 0) ? p.gs[0] : (p.c2 == 1) ? p.gs[1] : p.gs[2];
 	const int gs3 = (p.c3 == 0) ? p.gs[0] : (p.c3 == 1) ? p.gs[1] : p.gs[2];

@@ -37,6 +37,7 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #define TILE_THREADS  512                  // home particles per tile (one thread each), 8 waves
 #define TILE_WCAP     3200                 // window records that fit LDS (48 B each, 1 workgroup per CU)
 #define TILE_WCAP_SPS 1900                 // ... with the SPS stress tensor of every window particle (80 B each)
+#define TILE_WCAP_SPS1 2400                // ... of an SPS run with one fluid (64 B each: no EOS rows, see tau_pack_kernel)
 #define TILE_WGS_PER_CU 1                  // persistent workgroups per CU (LDS bound)
 #endif
 #define TILE_HROWS    4                    // home rows: 2 (COORD2) x 2 (COORD3)
