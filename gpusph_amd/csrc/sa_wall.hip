@@ -161,7 +161,12 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 }
 
 // the boundary-element sums of sa_density_sum_kernel: {sum grad gamma(n+1), sum 1/2 (grad gamma(n) + grad gamma(n+1)) . (q(n+1) - q(n))}
-// into the particle's row of newGGam, where sa_density_sum_kernel picks them up
+// into the particle's row of newGGam, where sa_density_sum_kernel picks them up.
+// ONE evaluation of |grad gamma_as| per element, not two: the walls this entry point is built for do not move (it refuses
+// ENABLE_MOVING_BODIES), so q(n+1) - q(n) is the particle's own displacement for every element and the step-n half of the
+// second sum is 1/2 (sum_s grad gamma_as(n)) . dq -- and that sum is the particle's grad gamma of step n, which BUFFER_GRADGAMMA
+// holds (oldGGam.xyz: written by this same engine at the end of the previous step, or by saInitGamma).  The one-thread kernel
+// keeps the reference's two evaluations per element; the two agree to rounding.
 __global__ void __launch_bounds__(SA_WALL_THREADS)
 sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__restrict__ wall)
 {
@@ -172,7 +177,9 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 		const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
 		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
-		float gx = 0.0f, gy = 0.0f, gz = 0.0f, gGamDotR = 0.0f;
+		const float4 gGamN = a.oldGGam[index];
+		const float inv = 1.0f/p.slength;
+		float gx = 0.0f, gy = 0.0f, gz = 0.0f, dotNp1 = 0.0f;
 		int cellCarry = 0;
 		bool more = true;
 		for (int s0 = 0; more; s0 += 64) {
@@ -181,20 +188,21 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 			const float4 nN = a.oldPos[j];
 			if (!e.alive || !is_active_w(nN.w)) continue;
 			const float4 nNp1 = a.pos[j];
-			const float inv = 1.0f/p.slength;
 			const V3 qN = v3((e.pcx - nN.x)*inv, (e.pcy - nN.y)*inv, (e.pcz - nN.z)*inv);
 			const V3 qNp1 = v3(((e.pcx - nNp1.x) + dx)*inv, ((e.pcy - nNp1.y) + dy)*inv, ((e.pcz - nNp1.z) + dz)*inv);
 			const float4 be = a.boundElement[j];
 			const V3 ns = v3(be.x, be.y, be.z);
 			WallTri tri;
 			wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			const V3 gN = ns*(wall_grad_gamma_flat(tri, qN)/p.slength);
 			const V3 gNp1 = ns*(wall_grad_gamma_flat(tri, qNp1)/p.slength);
-			gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
+			dotNp1 += dot(gNp1, qNp1 - qN);
 			gx += gNp1.x; gy += gNp1.y; gz += gNp1.z;
 		}
-		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gGamDotR = wave_sum(gGamDotR);
-		if (lane == 0) a.newGGam[index] = make_float4(gx, gy, gz, gGamDotR);
+		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); dotNp1 = wave_sum(dotNp1);
+		if (lane == 0) {
+			const float dotN = (gGamN.x*dx + gGamN.y*dy + gGamN.z*dz)*inv;
+			a.newGGam[index] = make_float4(gx, gy, gz, 0.5f*(dotN + dotNp1));
+		}
 	}
 }
 
