@@ -82,8 +82,6 @@ class SlabPartition:
 class MultiGpuEngine:
     def __init__(self, problem, device, rank, world, kernels=None, track_particle_count=True, margin=1.25,
                  overlap=True, allocated=None, clobber_neibslist=False, transport=None):
-        if world > 1 and (problem.simparams.simflags & D.ENABLE_XSPH):
-            raise ValueError("ENABLE_XSPH needs the mean velocity of the halo particles' neighbourhoods: single domain only")
         self.sa = problem.simparams.boundarytype == D.SA_BOUNDARY
         self.grenier = problem.simparams.sph_formulation == D.SPH_GRENIER
         self.effvisc_on = problem.simparams.rheologytype > D.NEWTONIAN        # NEEDS_EFFECTIVE_VISC
@@ -458,6 +456,8 @@ class MultiGpuEngine:
         if energy:
             K.forces_internal_energy(self.dedt, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, 0, self.n_int)
         outputs = [self.forces, self.dedt] if energy else [self.forces]
+        if self.xsph is not None and run_mode == D.SIMULATE:      # BUFFER_XSPH is a POST_FORCES_UPDATE_BUFFER: the halo copies are moved with it
+            outputs.append(self.xsph)
         keps = self.keps and run_mode == D.SIMULATE
         if keps:         # BUFFER_DKDE is a POST_FORCES_UPDATE_BUFFER: the halo copies integrate k and epsilon from the exchanged rates
             outputs.append(self.dkde)

@@ -454,6 +454,8 @@ _MG_CASES = {
     # StillWater's option set (laminar viscosity + Ferrari diffusion in the tiled stripes, MLS filter) and two fluids
     "dynamicvisc+ferrari+mls": (dict(viscosity="DYNAMICVISC", kinematic_visc=3.0e-2, density_diffusion=D.FERRARI), ((1, 4),)),
     "two-fluids": (dict(two_fluids=True), ()),
+    # ENABLE_XSPH: the mean neighbourhood velocity of the particles next to the cut is formed from halo rows as well
+    "xsph": (dict(xsph=True), ()),
     # the fidelity engines under the slab decomposition: sigma / densities exchanged after COMPUTE_DENSITY and the volumes with
     # the halo (SPH_GRENIER); the energy rate with the forces (internal energy); the stripes through the SPH_HA routing
     "grenier": (dict(obstacle=False, two_fluids=True, formulation=D.SPH_GRENIER, viscosity="DYNAMICVISC", density_diffusion=D.DENSITY_DIFFUSION_NONE), ()),
@@ -472,7 +474,11 @@ def _mg_problem(kw):
     if kw.pop("problem", None) == "SABox":
         from gpusph_amd.problem import SABox
         return SABox(**kw)
-    return DamBreak3D(**{**dict(deltap=0.03, obstacle=True, jitter=0.05, linearization="xzy"), **kw})
+    xsph = kw.pop("xsph", False)
+    prob = DamBreak3D(**{**dict(deltap=0.03, obstacle=True, jitter=0.05, linearization="xzy"), **kw})
+    if xsph:
+        prob.simparams.simflags |= D.ENABLE_XSPH
+    return prob
 
 
 
@@ -496,7 +502,7 @@ def _mg_worker(rank, world, port, outdir, casename):
     dist.barrier(); dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("casename,kernels", [(c, "generic") for c in sorted(_MG_CASES)] + [("default", "tiled"), ("spsvisc+shepard", "tiled")])
+@pytest.mark.parametrize("casename,kernels", [(c, "generic") for c in sorted(_MG_CASES)] + [("default", "tiled"), ("spsvisc+shepard", "tiled"), ("sa-walls", "tiled")])
 def test_two_ranks_on_one_gpu_equal_single_domain(tmp_path, casename, kernels, monkeypatch):
     """the real HIP kernels under the slab decomposition (2 ranks sharing the one GPU of this box, host-staged
     gloo transport standing in for RCCL), including the overlapped edge-stripe / inner-stripe forces.
