@@ -117,3 +117,72 @@ def test_cpp_worker_threads_exchange_through_the_c_abi():
         r = subprocess.run([exe, str(world)], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stdout + r.stderr
         assert "as expected" in r.stdout
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world,lin", [(2, "xzy"), (3, "yzx")])
+def test_cpp_workers_run_a_decomposed_dam_break(tmp_path, monkeypatch, world, lin):
+    """gpusph_amd/host/slab_run: the decomposed run driven from C++ through the C ABI alone (one worker thread and one context
+    per slab; neighbour phase with the device map, segments, halo import, stripes of the forces, UPDATE_EXTERNAL of the forces,
+    Euler on every row, dt = minimum over the slabs), on the dam break of the headline benchmark (DYN walls, artificial
+    viscosity, Colagrossi diffusion) over a neighbour-list rebuild.  With the gather kernels the particles it leaves are
+    bit-identical to the single-domain run of the Python driver."""
+    import ctypes as C
+    import os, struct, subprocess
+    import torch
+    from gpusph_amd.engine import TimestepEngine
+    from gpusph_amd.kernels import HipKernels
+    from gpusph_amd.multigpu import SlabPartition
+    monkeypatch.setenv("SPHX_DISABLE_TILES", "1")
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpusph_amd", "host", "slab_run")
+    assert os.path.exists(exe), "gpusph_amd/host/slab_run is not built (make -C gpusph_amd/host slab_run)"
+    kw = dict(deltap=0.03, obstacle=False, jitter=0.05, linearization=lin)
+    steps = 12
+    prob = DamBreak3D(**kw)
+    part = SlabPartition(prob, world)
+    arrs = prob.copy_to_array()
+    n = len(arrs["hash"])
+    alloc = int(max(part.local_mask(r, arrs["hash"]).sum() for r in range(world)) * 1.3) + 4096
+    k = HipKernels(prob, alloc, torch.device("cuda:0"))      # the uploaded constants and the host-side numbers of the Python driver
+    params = bytes(k.params)
+    sp = prob.simparams
+    case = tmp_path / "case.bin"
+    with open(case, "wb") as f:
+        f.write(struct.pack("<10I", 0x31424C53, world, steps, n, prob.grid_cells, alloc, part.plane, part.gs3, int(sp.neiblistsize), len(params)))
+        f.write(params)
+        f.write(struct.pack("<4fI", float(np.float32(sp.dt)), k.sspeed_cfl, k.max_kinvisc, k.sq_nl_radius, int(sp.buildneibsfreq)))
+        f.write(np.asarray(part.lo, dtype=np.uint32).tobytes()); f.write(np.asarray(part.hi, dtype=np.uint32).tobytes())
+        f.write(np.ascontiguousarray(arrs["pos"], dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(arrs["vel"], dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(arrs["info"]).view(np.uint16).tobytes())
+        f.write(np.ascontiguousarray(arrs["hash"]).view(np.uint32).tobytes())
+    del k
+    env = dict(os.environ, SPHX_DISABLE_TILES="1")
+    r = subprocess.run([exe, str(case), str(tmp_path / "out")], capture_output=True, text=True, timeout=500, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    parts = []
+    for rank in range(world):
+        raw = open(tmp_path / ("out.%d.bin" % rank), "rb").read()
+        ni, dt, t = struct.unpack_from("<Ifd", raw, 0)
+        off = 16
+        pos = np.frombuffer(raw, np.float32, 4 * ni, off).reshape(ni, 4); off += 16 * ni
+        vel = np.frombuffer(raw, np.float32, 4 * ni, off).reshape(ni, 4); off += 16 * ni
+        info = np.frombuffer(raw, np.uint16, 4 * ni, off).reshape(ni, 4); off += 8 * ni
+        parts.append(dict(pos=pos, vel=vel, info=info, dt=dt, t=t, n=ni))
+    assert all(p["n"] > 0 for p in parts)
+    ref = TimestepEngine(DamBreak3D(**kw), device="cuda:0")
+    for _ in range(steps):
+        ref.step()
+    nr = ref.n
+    assert sum(p["n"] for p in parts) == nr
+    ids = np.concatenate([p["info"][:, 2].astype(np.uint32) | (p["info"][:, 3].astype(np.uint32) << 16) for p in parts])
+    order = np.argsort(ids)
+    rinfo = _np(ref.info, np.uint16)[:nr]
+    rid = rinfo[:, 2].astype(np.uint32) | (rinfo[:, 3].astype(np.uint32) << 16)
+    ro = np.argsort(rid)
+    assert np.array_equal(ids[order], rid[ro])                       # every particle owned by exactly one slab
+    for key, tns in (("pos", ref.pos), ("vel", ref.vel)):
+        got = np.concatenate([p[key] for p in parts])[order]
+        assert np.array_equal(got.view(np.uint32), _np(tns)[:nr][ro].view(np.uint32)), key
+    assert all(p["dt"] == np.float32(ref.current_dt()) for p in parts)
+    assert all(p["t"] == ref.time() for p in parts)
