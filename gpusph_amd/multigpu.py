@@ -39,11 +39,15 @@ class SlabPartition:
         self.gs3 = int(gs[c3])
         self.plane = int(gs[c1]) * int(gs[c2])          # cells per COORD3 plane = contiguous hash range
         self.world = world
-        # the split axis must not be periodic: ranks 0 and world-1 would have to exchange their outermost planes as halos,
-        # which this partition does not set up (the reference does it through the device map, src/ProblemCore.cc:1061-1116)
-        if world > 1 and (problem.simparams.periodicbound & (1 << c3)):
-            raise ValueError("the domain is periodic along the split axis (COORD3 = %s): not supported by the slab "
-                             "partition; choose a linearisation whose COORD3 is a non-periodic axis" % "xyz"[c3])
+        # a split axis that is periodic closes the chain of slabs into a ring: the first and the last slab are neighbours through
+        # the periodic face and exchange their outermost planes like any two neighbours (in the reference this falls out of the
+        # device map and the periodic neighbour cells, src/ProblemCore.cc:1061-1116).  Two slabs on a ring would be each other's
+        # neighbour on both sides, which the pairwise exchange (one send and one receive per neighbour) does not tell apart.
+        self.ring = world > 1 and bool(problem.simparams.periodicbound & (1 << c3))
+        if self.ring and world == 2:
+            raise ValueError("the domain is periodic along the split axis (COORD3 = %s): two devices would be each other's "
+                             "neighbour on both sides; use three or more devices, or a linearisation whose COORD3 is a "
+                             "non-periodic axis" % "xyz"[c3])
         # fillDeviceMapByAxis (src/ProblemCore.cc:1061-1116): fewer than 3 planes per device on average are refused; a device
         # takes round(planes / devices) planes, the last one what is left
         if world > 1 and self.gs3 / float(world) < 3.0:
@@ -59,12 +63,12 @@ class SlabPartition:
         t = np.full(self.gs3, D.CELLTYPE_OUTER_CELL, dtype=np.uint32)
         lo, hi = self.lo[rank], self.hi[rank]
         t[lo:hi] = D.CELLTYPE_INNER_CELL
-        if rank > 0:
+        if rank > 0 or self.ring:
             t[lo] = D.CELLTYPE_INNER_EDGE_CELL
-            t[lo - 1] = D.CELLTYPE_OUTER_EDGE_CELL
-        if rank < self.world - 1:
+            t[(lo - 1) % self.gs3] = D.CELLTYPE_OUTER_EDGE_CELL
+        if rank < self.world - 1 or self.ring:
             t[hi - 1] = D.CELLTYPE_INNER_EDGE_CELL
-            t[hi] = D.CELLTYPE_OUTER_EDGE_CELL
+            t[hi % self.gs3] = D.CELLTYPE_OUTER_EDGE_CELL
         return t
 
     def compact_device_map(self, rank):
@@ -74,9 +78,7 @@ class SlabPartition:
     def local_mask(self, rank, hashes):
         """particles a rank holds initially: its own planes plus the one-plane halo on each side"""
         c3 = (hashes & D.CELLTYPE_BITMASK) // self.plane
-        lo = self.lo[rank] - (1 if rank > 0 else 0)
-        hi = self.hi[rank] + (1 if rank < self.world - 1 else 0)
-        return (c3 >= lo) & (c3 < hi)
+        return self.plane_types(rank)[c3] != D.CELLTYPE_OUTER_CELL
 
 
 class MultiGpuEngine:
@@ -211,6 +213,8 @@ class MultiGpuEngine:
 
     # ------------------------------------------------------------------ exchange
     def _neighbours(self):
+        if self.world > 1 and self.part.ring:
+            return (self.rank - 1) % self.world, (self.rank + 1) % self.world
         left = self.rank - 1 if self.rank > 0 else None
         right = self.rank + 1 if self.rank < self.world - 1 else None
         return left, right

@@ -44,6 +44,9 @@ def _worker(rank, world, port, steps, case, outdir, filters=()):
     elif which == "SABox":
         from gpusph_amd.problem import SABox
         prob = SABox(**case)
+    elif which == "PeriodicBox":
+        from gpusph_amd.problem import PeriodicBox
+        prob = PeriodicBox(**case)
     else:
         prob = DamBreak3D(**case)
     if gate:
@@ -202,9 +205,10 @@ def test_slab_run_of_the_wavetank_mirror_equals_single_domain(tmp_path):
     assert all(int(p["n_local"]) < len(ids1) for p in p2)
 
 
-def test_split_axis_must_not_be_periodic():
+def test_two_slabs_on_a_periodic_split_axis_are_refused():
     from gpusph_amd import defs as D
-    """a domain periodic along COORD3 needs the two end ranks to exchange halos: refused, not silently wrong"""
+    """a domain periodic along COORD3 makes a ring of the slabs; with two of them each would be the other's neighbour on both
+    sides, which the pairwise exchange does not tell apart: refused, not silently wrong.  Three or more are a ring (below)."""
     from gpusph_amd.multigpu import SlabPartition
     from gpusph_amd.problem import PeriodicBox
     prob = PeriodicBox(0.05, n=(20, 20, 20), periodic=D.PERIODIC_X | D.PERIODIC_Y | D.PERIODIC_Z)
@@ -213,6 +217,41 @@ def test_split_axis_must_not_be_periodic():
     SlabPartition(prob, 1)
     ok = PeriodicBox(0.05, n=(20, 20, 20), periodic=D.PERIODIC_Y | D.PERIODIC_Z)       # default yzx: COORD3 = x
     SlabPartition(ok, 2)
+    ring = SlabPartition(PeriodicBox(0.05, n=(12, 12, 40), linearization="xyz"), 3)     # 15 planes along z, periodic
+    assert ring.ring and ring.gs3 == 15
+    t0, t2 = ring.plane_types(0), ring.plane_types(2)
+    assert t0[0] == D.CELLTYPE_INNER_EDGE_CELL and t0[14] == D.CELLTYPE_OUTER_EDGE_CELL      # the first slab sees the last plane as halo
+    assert t2[14] == D.CELLTYPE_INNER_EDGE_CELL and t2[0] == D.CELLTYPE_OUTER_EDGE_CELL      # ... and the last slab the first plane
+
+
+def test_ring_of_slabs_on_a_periodic_split_axis_equals_single_domain(tmp_path):
+    """three slabs along a periodic axis: the first and the last one exchange their outermost planes through the periodic face,
+    a stream along the axis carries particles across the cuts and across the face; bit-identical to the single domain"""
+    case = dict(problem="PeriodicBox", deltap=0.05, n=(12, 12, 40), linearization="xyz", jitter=0.2, velocity=(0.1, 0.0, 1.5))
+    steps = 23                                   # three neighbour-list rebuilds
+    _run(1, steps, case, str(tmp_path))
+    _run(3, steps, case, str(tmp_path))
+    ids1, one, p1 = _gather(str(tmp_path), 1)
+    idsN, many, pN = _gather(str(tmp_path), 3)
+    assert np.array_equal(ids1, idsN)            # every particle is owned by exactly one rank
+    for k in ("pos", "vel", "forces"):
+        assert np.array_equal(one[k].view(np.uint32), many[k].view(np.uint32)), k
+    assert np.array_equal(one["hash"] & 0x3FFFFFFF, many["hash"] & 0x3FFFFFFF)
+    assert all(float(p["dt"]) == float(p1[0]["dt"]) for p in pN)
+    assert sum(int(p["interactions"]) for p in pN) == int(p1[0]["interactions"])
+    assert all(int(p["n_local"]) > len(p["pos"]) for p in pN)      # every rank holds a halo on both sides
+    # the run did carry particles through the periodic face and across the cuts between the slabs
+    from gpusph_amd.problem import PeriodicBox
+    from gpusph_amd.multigpu import SlabPartition
+    prob = PeriodicBox(**{k: v for k, v in case.items() if k != "problem"})
+    part = SlabPartition(prob, 3)
+    a0 = prob.copy_to_array()
+    id0 = a0["info"].view(np.uint16).reshape(-1, 4)
+    id0 = id0[:, 2].astype(np.uint32) | (id0[:, 3].astype(np.uint32) << 16)
+    plane0 = ((a0["hash"].view(np.uint32) & 0x3FFFFFFF) // part.plane)[np.argsort(id0)]
+    plane1 = (one["hash"] & 0x3FFFFFFF) // part.plane
+    assert ((plane0 == part.gs3 - 1) & (plane1 == 0)).sum() > 0
+    assert ((plane0 == part.hi[0] - 1) & (plane1 == part.lo[1])).sum() > 0
 
 
 FIDELITY_CASES = {
