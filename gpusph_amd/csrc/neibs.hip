@@ -1105,6 +1105,20 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 			ctx->sa_wall = nullptr;      // the engines fall back to one thread per particle
 		}
 		ctx->sa_wall_neibslist = nullptr;
+		++ctx->sa_wall_gen;      // what was kept of |grad gamma_as| per list entry belongs to the previous list
+		if (!ctx->sa_wall_gen) ctx->sa_wall_gen = 1u;
+		if (ctx->sa_wall && !ctx->sa_wall_cache) {      // room for a quarter of the particles next to a wall; the rest recompute
+			const size_t cap = (size_t)ctx->reserved_particles/4u + 1024u;
+			if (hipMalloc((void**)&ctx->sa_wall_cache, sizeof(float)*SA_WALL_CACHE_ENTRIES*cap) == hipSuccess &&
+			    hipMalloc((void**)&ctx->sa_wall_tag, sizeof(float4)*cap) == hipSuccess) {
+				ctx->sa_wall_capacity = (uint32_t)cap;
+				SPHX_HIP(hipMemsetAsync(ctx->sa_wall_tag, 0, sizeof(float4)*cap, st));
+			} else {
+				(void)hipGetLastError();
+				if (ctx->sa_wall_cache) (void)hipFree(ctx->sa_wall_cache);
+				ctx->sa_wall_cache = nullptr; ctx->sa_wall_tag = nullptr; ctx->sa_wall_capacity = 0;
+			}
+		}
 		if (ctx->sa_wall) {
 			SPHX_HIP(hipMemsetAsync(ctx->sa_wall, 0, sizeof(uint32_t), st));
 			sa_wall_list_kernel<<<div_up_u(particleRangeEnd, 256), 256, 0, st>>>(neibsList, (const particleinfo*)info, (const float4*)pos,

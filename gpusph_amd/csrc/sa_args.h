@@ -3,6 +3,14 @@
 #pragma once
 #include "sphx_internal.h"
 
+// |grad gamma_as| per (wall particle, boundary-section entry) handed from the density summation / gamma quadrature of a step to
+// the forces pass that follows at the same positions (sphx_ctx::sa_wall_cache); all zero = not in use
+struct SaWallCache {
+	float *values;        // [wall particle][SA_WALL_CACHE_ENTRIES]
+	float4 *tag;          // per wall particle: position bits of the particle when its row was written, generation of the list
+	uint32_t capacity, gen;
+};
+
 // forces with SA_BOUNDARY: see sa_forces_kernel (sa_bounds.hip)
 struct SaForcesArgs {
 	float4 *forces;
@@ -26,6 +34,7 @@ struct SaForcesArgs {
 	int tiled;
 	const uint32_t *tileGuard;
 	int wallDone;         // ... and sa_forces_wall_kernel has added the boundary elements (needs `tiled`)
+	SaWallCache wc;
 };
 
 // integrateGammaDevice, quadrature flavour: see sa_integrate_gamma_kernel (sa_bounds.hip)
@@ -39,6 +48,7 @@ struct SaIntGammaArgs {
 	uint32_t numParticles;
 	float epsilon;
 	int wallDone;      // the fluid particles with boundary elements in reach are done by sa_integrate_gamma_wall_kernel
+	SaWallCache wc;
 };
 
 // density summation with dynamic gamma: see sa_density_sum_kernel (sa_bounds.hip)
@@ -53,6 +63,7 @@ struct SaDensitySumArgs {
 	int tiled;                    // the volumic sums are in FORCES.w already (tiled kernel, SPHX_TURB_SA_DSUM), see SaForcesArgs
 	const uint32_t *tileGuard;
 	int wallDone;                 // sa_density_sum_wall_kernel has left {sum grad gamma, sum grad gamma . dr} in newGGam (needs `tiled`)
+	SaWallCache wc;
 };
 
 // sa_wall.hip: the boundary-element terms of the three engines for the particles of ctx->sa_wall

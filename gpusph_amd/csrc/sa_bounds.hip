@@ -952,6 +952,7 @@ static int sa_forces_impl(sphx_ctx *ctx, void *forces, float *cfl, float *cflGam
 		a.tiled = used ? 1 : 0;
 		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
 			a.wallDone = 1;
+			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
 			rc = sphx_sa_wall_forces(ctx, a, st);
 			if (rc != SPHX_OK) return rc;
 		}
@@ -1117,6 +1118,7 @@ extern "C" int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void 
 	a.numParticles = particleRangeEnd; a.epsilon = epsilon;
 	if (ctx->sa_wall && ctx->sa_wall_neibslist == neibsList && !ctx->disable_tiles) {
 		a.wallDone = 1;
+		a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
 		rc = sphx_sa_wall_integrate_gamma(ctx, a, (hipStream_t)stream);
 		if (rc != SPHX_OK) return rc;
 	}
@@ -1189,6 +1191,7 @@ extern "C" int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, v
 		a.tiled = used ? 1 : 0;
 		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
 			a.wallDone = 1;
+			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
 			rc = sphx_sa_wall_density_sum(ctx, a, (hipStream_t)stream);
 			if (rc != SPHX_OK) return rc;
 		}

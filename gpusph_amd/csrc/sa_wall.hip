@@ -93,6 +93,31 @@ __device__ __forceinline__ float wave_max(float v)
 	const uint32_t nWaves = gridDim.x*(SA_WALL_THREADS/64), count = (wall)[0]; \
 	for (uint32_t w = blockIdx.x*(SA_WALL_THREADS/64) + (threadIdx.x >> 6); w < count; w += nWaves)
 
+// |grad gamma_as| handed from one pass to the next (SaWallCache).  The density summation (or the gamma quadrature) of a step
+// evaluates it for every element in reach of a particle at the particle's NEW position; the forces pass that follows runs at
+// those very positions with the same list, so it would evaluate the same numbers again -- a third of an SA step.  The writers
+// leave them per (wall particle w, entry of the boundary section) together with a tag: the bits of the position they were
+// evaluated at and the generation of the neighbour list.  The reader takes a row only if both match what it sees itself, so
+// anything that moved the particle or rebuilt the list in between simply makes it evaluate afresh.  (The walls themselves do
+// not move: the engines this serves refuse moving SA bodies.)  Rows of particles with more than SA_WALL_CACHE_ENTRIES entries,
+// and of wall particles beyond the capacity, are not kept.
+__device__ __forceinline__ bool wall_cache_row(const SaWallCache &wc, uint32_t w) { return wc.values != nullptr && w < wc.capacity; }
+__device__ __forceinline__ void wall_cache_put(const SaWallCache &wc, uint32_t w, uint32_t entry, float ggamAS)
+{
+	if (entry < SA_WALL_CACHE_ENTRIES) wc.values[(size_t)w*SA_WALL_CACHE_ENTRIES + entry] = ggamAS;
+}
+__device__ __forceinline__ void wall_cache_seal(const SaWallCache &wc, uint32_t w, const float4 &pos, bool complete)
+{
+	wc.tag[w] = make_float4(pos.x, pos.y, pos.z, __uint_as_float(complete ? wc.gen : 0u));
+}
+__device__ __forceinline__ bool wall_cache_valid(const SaWallCache &wc, uint32_t w, const float4 &pos)
+{
+	if (!wall_cache_row(wc, w) || !wc.gen) return false;
+	const float4 t = wc.tag[w];
+	return __float_as_uint(t.x) == __float_as_uint(pos.x) && __float_as_uint(t.y) == __float_as_uint(pos.y) &&
+		__float_as_uint(t.z) == __float_as_uint(pos.z) && __float_as_uint(t.w) == wc.gen;
+}
+
 // the fluid <- boundary-element part of sa_forces_kernel<false> (same terms, see there), added to the sums the tiled kernel left
 __global__ void __launch_bounds__(SA_WALL_THREADS)
 sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ wall)
@@ -109,6 +134,8 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 		const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
 		const bool newtonian = p.rheology == SPHX_NEWTONIAN;
 		float fx = 0.0f, fy = 0.0f, fz = 0.0f, fw = 0.0f, gammaCfl = 0.0f;
+		// |grad gamma_as| of this particle's elements as the previous pass left them, if they were evaluated at this very position
+		const bool kept = __builtin_amdgcn_readfirstlane((int)wall_cache_valid(a.wc, w, pos)) != 0;
 		int cellCarry = 0;
 		bool more = true;
 		for (int s0 = 0; more; s0 += 64) {
@@ -124,10 +151,15 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 			const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
 			const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
 			const float4 be = a.boundElement[j];
-			const float inv_h = 1.0f/p.slength;
-			WallTri tri;
-			wall_tri_setup(tri, v3(be.x, be.y, be.z), a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			const float ggamAS = wall_grad_gamma_flat(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
+			float ggamAS;
+			if (kept)
+				ggamAS = a.wc.values[(size_t)w*SA_WALL_CACHE_ENTRIES + (uint32_t)s0 + lane];
+			else {
+				const float inv_h = 1.0f/p.slength;
+				WallTri tri;
+				wall_tri_setup(tri, v3(be.x, be.y, be.z), a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+				ggamAS = wall_grad_gamma_flat(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
+			}
 			const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
 			if (a.cflGamma) {
 				const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
@@ -180,10 +212,13 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 		const float4 gGamN = a.oldGGam[index];
 		const float inv = 1.0f/p.slength;
 		float gx = 0.0f, gy = 0.0f, gz = 0.0f, dotNp1 = 0.0f;
+		const bool keep = wall_cache_row(a.wc, w);
+		bool complete = true;
 		int cellCarry = 0;
 		bool more = true;
 		for (int s0 = 0; more; s0 += 64) {
 			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, posN, gridPos, s0, lane, cellCarry, more);
+			if (__builtin_amdgcn_ballot_w64(e.alive && (uint32_t)s0 + lane >= SA_WALL_CACHE_ENTRIES)) complete = false;
 			const uint32_t j = e.j;
 			const float4 nN = a.oldPos[j];
 			if (!e.alive || !is_active_w(nN.w)) continue;
@@ -194,7 +229,9 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 			const V3 ns = v3(be.x, be.y, be.z);
 			WallTri tri;
 			wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			const V3 gNp1 = ns*(wall_grad_gamma_flat(tri, qNp1)/p.slength);
+			const float ggamAS = wall_grad_gamma_flat(tri, qNp1)/p.slength;
+			if (keep) wall_cache_put(a.wc, w, (uint32_t)s0 + lane, ggamAS);
+			const V3 gNp1 = ns*ggamAS;
 			dotNp1 += dot(gNp1, qNp1 - qN);
 			gx += gNp1.x; gy += gNp1.y; gz += gNp1.z;
 		}
@@ -202,6 +239,7 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 		if (lane == 0) {
 			const float dotN = (gGamN.x*dx + gGamN.y*dy + gGamN.z*dz)*inv;
 			a.newGGam[index] = make_float4(gx, gy, gz, 0.5f*(dotN + dotNp1));
+			if (keep) wall_cache_seal(a.wc, w, posNp1, complete);
 		}
 	}
 }
@@ -217,10 +255,13 @@ sa_integrate_gamma_wall_kernel(DevParams p, SaIntGammaArgs a, const uint32_t *__
 		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 		const V3 oldg = v3(og.x, og.y, og.z);
 		float gx = 0.0f, gy = 0.0f, gz = 0.0f, gam = 0.0f;
+		const bool keep = wall_cache_row(a.wc, w);
+		bool complete = true;
 		int cellCarry = 0;
 		bool more = true;
 		for (int s0 = 0; more; s0 += 64) {
 			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, pos, gridPos, s0, lane, cellCarry, more);
+			if (__builtin_amdgcn_ballot_w64(e.alive && (uint32_t)s0 + lane >= SA_WALL_CACHE_ENTRIES)) complete = false;
 			if (!e.alive) continue;
 			const uint32_t j = e.j;
 			const float4 npos = a.pos[j];
@@ -230,11 +271,15 @@ sa_integrate_gamma_wall_kernel(DevParams p, SaIntGammaArgs a, const uint32_t *__
 			WallTri tri;
 			wall_tri_setup(tri, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
 			const float ggamAS = wall_grad_gamma_flat(tri, q)/p.slength;
+			if (keep) wall_cache_put(a.wc, w, (uint32_t)s0 + lane, ggamAS);
 			gx += ggamAS*be.x; gy += ggamAS*be.y; gz += ggamAS*be.z;
 			gam += wall_gamma_flat<false>(tri, q, oldg, p.slength, a.epsilon);
 		}
 		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); gam = wave_sum(gam);
-		if (lane == 0) a.newGGam[index] = make_float4(gx, gy, gz, 1.0f - gam);
+		if (lane == 0) {
+			a.newGGam[index] = make_float4(gx, gy, gz, 1.0f - gam);
+			if (keep) wall_cache_seal(a.wc, w, pos, complete);
+		}
 	}
 }
 

@@ -54,13 +54,14 @@ static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
 		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tau_pack, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols,
-		ctx->tile_list, ctx->tile_waves, ctx->tile_rows, ctx->tile_ownslot, ctx->sa_wall };
+		ctx->tile_list, ctx->tile_waves, ctx->tile_rows, ctx->tile_ownslot, ctx->sa_wall, ctx->sa_wall_cache, ctx->sa_wall_tag };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
 	ctx->eos_aux = nullptr; ctx->tau_pack = nullptr;
 	ctx->sa_wall = nullptr; ctx->sa_wall_neibslist = nullptr;
+	ctx->sa_wall_cache = nullptr; ctx->sa_wall_tag = nullptr; ctx->sa_wall_capacity = 0;
 	ctx->tile_list = nullptr; ctx->tile_waves = nullptr; ctx->tile_rows = nullptr; ctx->tile_ownslot = nullptr; ctx->tile_list_rows = ctx->tile_list_stride = 0;
 	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr; ctx->cell_fluid_end = nullptr; ctx->tile_cols = nullptr;
 	ctx->tile_capacity = 0; ctx->cells_reserved = 0; ctx->tiles_built = false;

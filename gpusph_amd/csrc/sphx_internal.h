@@ -40,6 +40,7 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #define TILE_WCAP_SPS1 2400                // ... of an SPS run with one fluid (64 B each: no EOS rows, see tau_pack_kernel)
 #define TILE_WGS_PER_CU 1                  // persistent workgroups per CU (LDS bound)
 #endif
+#define SA_WALL_CACHE_ENTRIES 96           // boundary-section entries per wall particle whose |grad gamma_as| is kept (more: recomputed)
 #define TILE_HROWS    4                    // home rows: 2 (COORD2) x 2 (COORD3)
 #define TILE_WROWS    16                   // window rows: 4 x 4
 #define TILE_WAVES    (TILE_THREADS/64)    // waves of a tile's workgroup ...
@@ -181,6 +182,12 @@ struct sphx_ctx {
 	// the boundary-element terms are evaluated one element per lane for these, sa_bounds.hip); sa_wall_neibslist = that list
 	uint32_t   *sa_wall;
 	const void *sa_wall_neibslist;
+	// |grad gamma_as| of every (wall particle, entry of its boundary section) as the density summation / gamma quadrature of a
+	// step evaluates it at the new positions, kept for the forces pass that follows at those very positions (sa_wall.hip):
+	// [wall particle][SA_WALL_CACHE_ENTRIES] floats + a tag per wall particle {position bits, list generation}
+	float      *sa_wall_cache;
+	float4     *sa_wall_tag;
+	uint32_t    sa_wall_capacity, sa_wall_gen;
 	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
 };
 
