@@ -205,7 +205,9 @@ def main():
     # one figure per forces PASS (a multi-GPU pass is an edge-stripe plus an inner-stripe launch)
     forces_ms = [tot_ms.value / (2 * args.steps)] if launches.value else []
     n_internal = eng.internal_particles() if hasattr(eng, "internal_particles") else eng.n
-    interactions = info.numInteractions
+    n64 = C.c_uint64(0)      # the 32-bit counter of the reference's interface wraps at 33 M particles x 65 neighbours
+    capi.check(lib.sphx_neibs_interactions64(ctx.handle, C.byref(n64), None))
+    interactions = int(n64.value)
     if dist is not None:
         c = torch.tensor([n_internal, interactions], dtype=torch.float64, device=device)
         dist.all_reduce(c)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "sphx_create": (_i, [C.POINTER(_vp), _i]),
     "sphx_destroy": (None, [_vp]),
     "sphx_reserve": (_i, [_vp, _u32]),
+    "sphx_neibs_interactions64": (_i, [_vp, C.POINTER(C.c_uint64), _vp]),
     "sphx_set_constants": (_i, [_vp, C.POINTER(SphxParams)]),
     "sphx_get_params": (_i, [_vp, C.POINTER(SphxParams)]),
     "sphx_set_planes": (_i, [_vp, _vp, _vp, _vp, _i]),

@@ -741,6 +741,7 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 		atomicMax(&counters->maxFluidBoundaryNeibs, (int)mx);
 		if (SA) atomicMax(&counters->maxVertexNeibs, (int)mv);
 		atomicAdd(&counters->numInteractions, (int)total);
+		atomicAdd(&counters->numInteractions64, (unsigned long long)total);
 	}
 }
 
@@ -1150,6 +1151,16 @@ extern "C" int sphx_neibs_resetinfo(sphx_ctx *ctx, void *stream)
 	// small H2D of a stack object: use the synchronous-with-respect-to-host staging of hipMemcpyAsync
 	// from pageable memory (the runtime copies the source before returning)
 	SPHX_HIP(hipMemcpyAsync(ctx->counters_dev, &z, sizeof(z), hipMemcpyHostToDevice, (hipStream_t)stream));
+	return SPHX_OK;
+}
+
+extern "C" int sphx_neibs_interactions64(sphx_ctx *ctx, uint64_t *out, void *stream)
+{
+	SPHX_REQUIRE(ctx && out, "sphx_neibs_interactions64: NULL argument");
+	NeibsCounters c;
+	SPHX_HIP(hipMemcpyAsync(&c, ctx->counters_dev, sizeof(c), hipMemcpyDeviceToHost, (hipStream_t)stream));
+	SPHX_HIP(hipStreamSynchronize((hipStream_t)stream));
+	*out = (uint64_t)c.numInteractions64;
 	return SPHX_OK;
 }
 

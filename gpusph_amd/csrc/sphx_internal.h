@@ -120,6 +120,7 @@ struct NeibsCounters {   // device counters of cuneibs (src/cuda/buildneibs_kern
 	int hasTooManyNeibs;
 	int hasMaxNeibs[3];
 	int pad;
+	unsigned long long numInteractions64;   // the same sum without the reference's 32-bit wrap (2^31 is 33 M particles x 65 neighbours)
 };
 
 struct sphx_ctx {

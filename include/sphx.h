@@ -231,6 +231,9 @@ int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *vertPos0, void
 /* resetinfo / getinfo (src/cuda/buildneibs.cu:119-145); getinfo is sync */
 int sphx_neibs_resetinfo(sphx_ctx *ctx, void *stream);
 int sphx_neibs_getinfo(sphx_ctx *ctx, sphx_neibs_info *h_out, void *stream);
+/* numInteractions of the last list build as a 64-bit sum (the reference's counter is a 32-bit uint, src/timing.h:63: it wraps
+ * beyond ~66 M particles with ~65 neighbours each; as a signed int beyond ~33 M); sync */
+int sphx_neibs_interactions64(sphx_ctx *ctx, uint64_t *h_out, void *stream);
 
 /* basicstep of the forces engine with SA_BOUNDARY (src/cuda/forces.cu:717-806 with the SA members of forces_params): fluid <-
  * fluid, fluid <- vertex, fluid <- boundary element (through |grad gamma_as|, src/cuda/gamma.cuh), sums divided by gamma,
