@@ -526,6 +526,7 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
 	const uint32_t *__restrict__ cellFluidEnd,
 	uint32_t particleRangeEnd, uint32_t posRows, float sqinfluenceradius, NeibsCounters *__restrict__ counters)
+	// (the partial counter sets lie behind *counters: NeibsSpread)
 {
 	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING][64];
 	const uint32_t lane = threadIdx.x & 63u;
@@ -738,10 +739,10 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 		if (SA) mv = max(mv, (uint32_t)__shfl_down(mv, d));
 	}
 	if ((threadIdx.x & 63u) == 0 && total) {
-		atomicMax(&counters->maxFluidBoundaryNeibs, (int)mx);
-		if (SA) atomicMax(&counters->maxVertexNeibs, (int)mv);
-		atomicAdd(&counters->numInteractions, (int)total);
-		atomicAdd(&counters->numInteractions64, (unsigned long long)total);
+		NeibsSpread *part = reinterpret_cast<NeibsSpread*>(counters + 1) + (blockIdx.x & (NEIBS_SPREAD - 1u));
+		atomicMax(&part->maxFluidBoundaryNeibs, (int)mx);
+		if (SA) atomicMax(&part->maxVertexNeibs, (int)mv);
+		atomicAdd(&part->numInteractions, (unsigned long long)total);
 	}
 }
 
@@ -1018,6 +1019,33 @@ extern "C" int sphx_build_neibs(sphx_ctx *ctx, uint16_t *neibsList,
 		numParticles, particleRangeEnd, gridCells, sqinfluenceradius, boundNlSqInflRad, stream);
 }
 
+// the partial counter sets of a list build into the counters (and emptied for the next build); accumulating, like the
+// reference's atomics: resetinfo starts a new count
+static __global__ void __launch_bounds__(NEIBS_SPREAD)
+neibs_counters_fold_kernel(NeibsCounters *counters)
+{
+	__shared__ int sMaxFB[NEIBS_SPREAD], sMaxV[NEIBS_SPREAD];
+	__shared__ unsigned long long sSum[NEIBS_SPREAD];
+	NeibsSpread *part = reinterpret_cast<NeibsSpread*>(counters + 1) + threadIdx.x;
+	sMaxFB[threadIdx.x] = part->maxFluidBoundaryNeibs; sMaxV[threadIdx.x] = part->maxVertexNeibs; sSum[threadIdx.x] = part->numInteractions;
+	part->maxFluidBoundaryNeibs = 0; part->maxVertexNeibs = 0; part->numInteractions = 0ull;
+	__syncthreads();
+	for (int d = NEIBS_SPREAD/2; d > 0; d >>= 1) {
+		if ((int)threadIdx.x < d) {
+			sMaxFB[threadIdx.x] = max(sMaxFB[threadIdx.x], sMaxFB[threadIdx.x + d]);
+			sMaxV[threadIdx.x] = max(sMaxV[threadIdx.x], sMaxV[threadIdx.x + d]);
+			sSum[threadIdx.x] += sSum[threadIdx.x + d];
+		}
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) {
+		counters->maxFluidBoundaryNeibs = max(counters->maxFluidBoundaryNeibs, sMaxFB[0]);
+		counters->maxVertexNeibs = max(counters->maxVertexNeibs, sMaxV[0]);
+		counters->numInteractions += (int)(unsigned int)sSum[0];      // wraps like the reference's 32-bit counter
+		counters->numInteractions64 += sSum[0];
+	}
+}
+
 // SA_BOUNDARY: the active fluid particles whose boundary section is not empty, in no particular order (wave-aggregated append)
 static __global__ void __launch_bounds__(256)
 sa_wall_list_kernel(const neibdata *__restrict__ list, const particleinfo *__restrict__ info, const float4 *__restrict__ pos,
@@ -1100,6 +1128,8 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		saArgs, neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
 		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
+	neibs_counters_fold_kernel<<<1, NEIBS_SPREAD, 0, st>>>(ctx->counters_dev);
+	SPHX_LAUNCH_CHECK("neibs_counters_fold_kernel");
 	if (sa) {   // the fluid particles with boundary elements in reach
 		if (!ctx->sa_wall && hipMalloc((void**)&ctx->sa_wall, sizeof(uint32_t)*((size_t)ctx->reserved_particles + 1)) != hipSuccess) {
 			(void)hipGetLastError();

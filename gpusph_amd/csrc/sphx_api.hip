@@ -30,8 +30,9 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	SPHX_HIP(hipMemset(ctx->rb_dev, 0, sizeof(RbParams)));
 	SPHX_HIP(hipHostMalloc((void**)&ctx->rb_staging, sizeof(RbParams)*SPHX_RB_RING, hipHostMallocDefault));
 	for (int k = 0; k < SPHX_RB_RING; ++k) SPHX_HIP(hipEventCreateWithFlags(&ctx->rb_staged[k], hipEventDisableTiming));
-	SPHX_HIP(hipMalloc((void**)&ctx->counters_dev, sizeof(NeibsCounters)));
-	SPHX_HIP(hipMemset(ctx->counters_dev, 0, sizeof(NeibsCounters)));
+	// the counters, then their NEIBS_SPREAD partial sets (see NeibsSpread)
+	SPHX_HIP(hipMalloc((void**)&ctx->counters_dev, sizeof(NeibsCounters) + NEIBS_SPREAD*sizeof(NeibsSpread)));
+	SPHX_HIP(hipMemset(ctx->counters_dev, 0, sizeof(NeibsCounters) + NEIBS_SPREAD*sizeof(NeibsSpread)));
 	SPHX_HIP(hipMalloc((void**)&ctx->dt_scratch, 4*sizeof(float)));
 	SPHX_HIP(hipMalloc((void**)&ctx->tile_ctl, 16*sizeof(uint32_t)));
 	SPHX_HIP(hipMemset(ctx->tile_ctl, 0, 16*sizeof(uint32_t)));

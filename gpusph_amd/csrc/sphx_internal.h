@@ -122,6 +122,11 @@ struct NeibsCounters {   // device counters of cuneibs (src/cuda/buildneibs_kern
 	int pad;
 	unsigned long long numInteractions64;   // the same sum without the reference's 32-bit wrap (2^31 is 33 M particles x 65 neighbours)
 };
+// what every wave of the list build adds to those counters goes to one of NEIBS_SPREAD partial sets first (by block number) and
+// is folded into the counters by a one-block kernel behind the build: three atomics per wave on ONE address were 1.5 M
+// serialised read-modify-writes in one L2 channel per build of 32 M particles, and slowed the whole kernel down
+#define NEIBS_SPREAD 256
+struct NeibsSpread { int maxFluidBoundaryNeibs, maxVertexNeibs; unsigned long long numInteractions; };
 
 struct sphx_ctx {
 	int         device;
