@@ -240,7 +240,9 @@ sa_init_gamma_kernel(DevParams p, SaGammaArgs a)
 // in one launch per fluid particle: fluid and vertex neighbours interact as particles, a boundary element contributes
 // through |grad gamma_as| (continuity :2079-2090, pressure :2414-2427, wall shear :2680-2718); the sums are divided by gamma
 // (forces_fixup :3192-3210).  Written like the boundary-conditions kernels above: the reference's operation order, IEEE
-// division and sqrt, no contraction other than the fmaf the CPU oracle spells out -- the SA path is not yet a roofline path.
+// division and sqrt, no contraction other than the fmaf the CPU oracle spells out.  This kernel is the CPU oracle's mirror and the
+// fallback; on a tiled neighbour list the particle <- particle sums come from forces_tile_kernel (SPHX_TURB_SA, forces.hip), the
+// boundary-element terms from sa_forces_wall_kernel (sa_wall.hip), and this kernel only finishes the particle (a.tiled, a.wallDone).
 
 // sa_dot3, sa_P, sa_sound_speed, sa_visc_avg: neib_iter.h (shared with the other fidelity engines)
 

@@ -129,8 +129,8 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 }
 
 // Tile lists of the tiled forces kernel (forces.hip): 2 B x (neiblistsize + extra) rows per particle, more than the neighbour
-// list itself, so they are allocated on the first neighbour-list build that really tiles (sphx_build_neibs_sa decides: not with
-// SA_BOUNDARY, not for the formulations that have their own forces kernels).  When the memory is not there the context simply
+// list itself, so they are allocated on the first neighbour-list build that really tiles (sphx_build_neibs_sa decides: not for
+// the formulations that have their own forces kernels, nor for SA_BOUNDARY with several fluids or k-epsilon).  When the memory is not there the context simply
 // keeps running on the generic kernels: tile_list stays NULL and tiles_built false.
 int sphx_ensure_tile_lists(sphx_ctx *ctx)
 {
