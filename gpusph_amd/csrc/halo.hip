@@ -202,16 +202,21 @@ extern "C" int sphx_halo_exchange(sphx_halo *h, int nbuf, void *const *bufs, con
 
 	if (h->comm) {      // one process per device: RCCL send / recv, all of them in one group
 		const Rccl *R = rccl();
+		// Two slabs on a ring (a periodic split axis) are each other's neighbour on both sides; sends and receives between one
+		// pair of ranks are matched in posting order and my LEFT layer is my peer's RIGHT halo: the receives go right halo first.
+		const bool samePeer = peer[0] >= 0 && peer[0] == peer[1];
 		SPHX_NCCL(R, R->GroupStart());
-		for (int b = 0; b < nbuf; ++b)
-			for (int s = 0; s < 2; ++s) {
-				if (peer[s] < 0) continue;
-				char *base = (char*)bufs[b];
-				if (sendCount[s])
+		for (int b = 0; b < nbuf; ++b) {
+			char *base = (char*)bufs[b];
+			for (int s = 0; s < 2; ++s)
+				if (peer[s] >= 0 && sendCount[s])
 					SPHX_NCCL(R, R->Send(base + (size_t)sendStart[s]*rowBytes[b], (size_t)sendCount[s]*rowBytes[b], ncclUint8, peer[s], h->comm, stream));
-				if (recvCount[s])
+			for (int k = 0; k < 2; ++k) {
+				const int s = samePeer ? 1 - k : k;
+				if (peer[s] >= 0 && recvCount[s])
 					SPHX_NCCL(R, R->Recv(base + (size_t)recvStart[s]*rowBytes[b], (size_t)recvCount[s]*rowBytes[b], ncclUint8, peer[s], h->comm, stream));
 			}
+		}
 		SPHX_NCCL(R, R->GroupEnd());
 		return SPHX_OK;
 	}

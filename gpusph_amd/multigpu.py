@@ -41,13 +41,9 @@ class SlabPartition:
         self.world = world
         # a split axis that is periodic closes the chain of slabs into a ring: the first and the last slab are neighbours through
         # the periodic face and exchange their outermost planes like any two neighbours (in the reference this falls out of the
-        # device map and the periodic neighbour cells, src/ProblemCore.cc:1061-1116).  Two slabs on a ring would be each other's
-        # neighbour on both sides, which the pairwise exchange (one send and one receive per neighbour) does not tell apart.
+        # device map and the periodic neighbour cells, src/ProblemCore.cc:1061-1116).  Two slabs on a ring are each other's
+        # neighbour on both sides: the transports order their receives for that (halo.py, halo.hip).
         self.ring = world > 1 and bool(problem.simparams.periodicbound & (1 << c3))
-        if self.ring and world == 2:
-            raise ValueError("the domain is periodic along the split axis (COORD3 = %s): two devices would be each other's "
-                             "neighbour on both sides; use three or more devices, or a linearisation whose COORD3 is a "
-                             "non-periodic axis" % "xyz"[c3])
         # fillDeviceMapByAxis (src/ProblemCore.cc:1061-1116): fewer than 3 planes per device on average are refused; a device
         # takes round(planes / devices) planes, the last one what is left
         if world > 1 and self.gs3 / float(world) < 3.0:

@@ -205,34 +205,35 @@ def test_slab_run_of_the_wavetank_mirror_equals_single_domain(tmp_path):
     assert all(int(p["n_local"]) < len(ids1) for p in p2)
 
 
-def test_two_slabs_on_a_periodic_split_axis_are_refused():
+def test_partition_of_a_periodic_split_axis_is_a_ring():
     from gpusph_amd import defs as D
-    """a domain periodic along COORD3 makes a ring of the slabs; with two of them each would be the other's neighbour on both
-    sides, which the pairwise exchange does not tell apart: refused, not silently wrong.  Three or more are a ring (below)."""
+    """a domain periodic along COORD3 makes a ring of the slabs: the first and the last one are neighbours through the face"""
     from gpusph_amd.multigpu import SlabPartition
     from gpusph_amd.problem import PeriodicBox
-    prob = PeriodicBox(0.05, n=(20, 20, 20), periodic=D.PERIODIC_X | D.PERIODIC_Y | D.PERIODIC_Z)
-    with pytest.raises(ValueError, match="periodic along the split axis"):
-        SlabPartition(prob, 2)
-    SlabPartition(prob, 1)
-    ok = PeriodicBox(0.05, n=(20, 20, 20), periodic=D.PERIODIC_Y | D.PERIODIC_Z)       # default yzx: COORD3 = x
-    SlabPartition(ok, 2)
+    assert not SlabPartition(PeriodicBox(0.05, n=(20, 20, 20)), 1).ring
+    assert not SlabPartition(PeriodicBox(0.05, n=(20, 20, 20), periodic=D.PERIODIC_Y | D.PERIODIC_Z), 2).ring    # default yzx: COORD3 = x
     ring = SlabPartition(PeriodicBox(0.05, n=(12, 12, 40), linearization="xyz"), 3)     # 15 planes along z, periodic
     assert ring.ring and ring.gs3 == 15
     t0, t2 = ring.plane_types(0), ring.plane_types(2)
     assert t0[0] == D.CELLTYPE_INNER_EDGE_CELL and t0[14] == D.CELLTYPE_OUTER_EDGE_CELL      # the first slab sees the last plane as halo
     assert t2[14] == D.CELLTYPE_INNER_EDGE_CELL and t2[0] == D.CELLTYPE_OUTER_EDGE_CELL      # ... and the last slab the first plane
+    two = SlabPartition(PeriodicBox(0.05, n=(12, 12, 40), linearization="xyz"), 2)      # each slab is the other's neighbour on both sides
+    t = two.plane_types(0)
+    assert [int(t[0]), int(t[two.hi[0] - 1]), int(t[two.hi[0]]), int(t[14])] == [
+        D.CELLTYPE_INNER_EDGE_CELL, D.CELLTYPE_INNER_EDGE_CELL, D.CELLTYPE_OUTER_EDGE_CELL, D.CELLTYPE_OUTER_EDGE_CELL]
 
 
-def test_ring_of_slabs_on_a_periodic_split_axis_equals_single_domain(tmp_path):
-    """three slabs along a periodic axis: the first and the last one exchange their outermost planes through the periodic face,
-    a stream along the axis carries particles across the cuts and across the face; bit-identical to the single domain"""
+@pytest.mark.parametrize("world", [2, 3])
+def test_ring_of_slabs_on_a_periodic_split_axis_equals_single_domain(tmp_path, world):
+    """slabs along a periodic axis: the first and the last one exchange their outermost planes through the periodic face (with
+    two slabs each is the other's neighbour on both sides), a stream along the axis carries particles across the cuts and
+    across the face; bit-identical to the single domain"""
     case = dict(problem="PeriodicBox", deltap=0.05, n=(12, 12, 40), linearization="xyz", jitter=0.2, velocity=(0.1, 0.0, 1.5))
     steps = 23                                   # three neighbour-list rebuilds
     _run(1, steps, case, str(tmp_path))
-    _run(3, steps, case, str(tmp_path))
+    _run(world, steps, case, str(tmp_path))
     ids1, one, p1 = _gather(str(tmp_path), 1)
-    idsN, many, pN = _gather(str(tmp_path), 3)
+    idsN, many, pN = _gather(str(tmp_path), world)
     assert np.array_equal(ids1, idsN)            # every particle is owned by exactly one rank
     for k in ("pos", "vel", "forces"):
         assert np.array_equal(one[k].view(np.uint32), many[k].view(np.uint32)), k
@@ -244,7 +245,7 @@ def test_ring_of_slabs_on_a_periodic_split_axis_equals_single_domain(tmp_path):
     from gpusph_amd.problem import PeriodicBox
     from gpusph_amd.multigpu import SlabPartition
     prob = PeriodicBox(**{k: v for k, v in case.items() if k != "problem"})
-    part = SlabPartition(prob, 3)
+    part = SlabPartition(prob, world)
     a0 = prob.copy_to_array()
     id0 = a0["info"].view(np.uint16).reshape(-1, 4)
     id0 = id0[:, 2].astype(np.uint32) | (id0[:, 3].astype(np.uint32) << 16)
