@@ -17,7 +17,7 @@
 // case.bin (little endian; written by the test from the Python problem mirror):
 //   u32 magic 'SLB1', world, steps, n, ncells, alloc, plane (cells per COORD3 plane), gs3, neiblistsize, sizeof(sphx_params)
 //   sphx_params
-//   f32 dt0, sspeed_cfl, max_kinvisc, sq_nl_radius; u32 buildneibsfreq
+//   f32 dt0, sspeed_cfl, max_kinvisc, sq_nl_radius; u32 buildneibsfreq, ring (1: the split axis is periodic, the slabs form a ring)
 //   u32 lo[world], hi[world]                   COORD3 planes [lo, hi) of every slab
 //   f32 pos[n][4], vel[n][4]; u16 info[n][4]; u32 hash[n]
 // <out>.<rank>.bin: u32 n_int, f32 dt, f64 t, then pos, vel, info, hash of the n_int internal particles
@@ -39,7 +39,7 @@ static const uint32_t CELLTYPE_INNER = 0, CELLTYPE_INNER_EDGE = 1, CELLTYPE_OUTE
 static const uint32_t CELLTYPE_BITMASK = 0x3FFFFFFFu, EMPTY_SEGMENT = 0xFFFFFFFFu;
 
 struct Case {
-	uint32_t world, steps, n, ncells, alloc, plane, gs3, neiblistsize, buildneibsfreq;
+	uint32_t world, steps, n, ncells, alloc, plane, gs3, neiblistsize, buildneibsfreq, ring;
 	sphx_params params;
 	float dt0, sspeed_cfl, max_kinvisc, sq_nl_radius;
 	std::vector<uint32_t> lo, hi;
@@ -70,6 +70,7 @@ static Case read_case(const char *path)
 	rd(f, s, 4);
 	c.dt0 = s[0]; c.sspeed_cfl = s[1]; c.max_kinvisc = s[2]; c.sq_nl_radius = s[3];
 	rd(f, &c.buildneibsfreq, 1);
+	rd(f, &c.ring, 1);
 	c.lo.resize(c.world); c.hi.resize(c.world);
 	rd(f, c.lo.data(), c.world); rd(f, c.hi.data(), c.world);
 	c.pos.resize(4*(size_t)c.n); c.vel.resize(4*(size_t)c.n); c.info.resize(4*(size_t)c.n); c.hash.resize(c.n);
@@ -95,8 +96,9 @@ struct Worker {
 	uint64_t iterations;
 };
 
-static int left_of(const Worker &w) { return w.rank > 0 ? w.rank - 1 : -1; }
-static int right_of(const Worker &w) { return w.rank < w.world - 1 ? w.rank + 1 : -1; }
+// the neighbours of a slab; on a periodic split axis the first and the last slab are neighbours through the periodic face
+static int left_of(const Worker &w) { return w.rank > 0 ? w.rank - 1 : (w.c->ring && w.world > 1 ? w.world - 1 : -1); }
+static int right_of(const Worker &w) { return w.rank < w.world - 1 ? w.rank + 1 : (w.c->ring && w.world > 1 ? 0 : -1); }
 
 // UPDATE_EXTERNAL of row buffers: my edge layers out, my neighbours' edge layers into my halo rows
 static void exchange(Worker &w, int nbuf, void *const *bufs, const uint32_t *rowBytes)
@@ -249,11 +251,17 @@ static void worker(const Case *c, int rank, sphx_halo_group *group, const std::s
 	// the particles this slab starts with: its own planes plus one plane of each neighbour (they are sorted out by the first
 	// neighbour phase); the device map: CELLTYPE of every cell as seen from here (fillDeviceMapByAxis, src/ProblemCore.cc:1061-1116)
 	const uint32_t lo = c->lo[rank], hi = c->hi[rank];
-	const uint32_t keepLo = lo - (rank > 0 ? 1u : 0u), keepHi = hi + (rank < w.world - 1 ? 1u : 0u);
+	std::vector<uint32_t> planeType(c->gs3, w.world > 1 ? CELLTYPE_OUTER : CELLTYPE_INNER);
+	if (w.world > 1) {
+		const bool hasLeft = rank > 0 || c->ring, hasRight = rank < w.world - 1 || c->ring;
+		for (uint32_t p = lo; p < hi; ++p) planeType[p] = CELLTYPE_INNER;
+		if (hasLeft) { planeType[lo] = CELLTYPE_INNER_EDGE; planeType[(lo + c->gs3 - 1u) % c->gs3] = CELLTYPE_OUTER_EDGE; }
+		if (hasRight) { planeType[hi - 1u] = CELLTYPE_INNER_EDGE; planeType[hi % c->gs3] = CELLTYPE_OUTER_EDGE; }
+	}
 	std::vector<float> pos, vel; std::vector<uint16_t> info; std::vector<uint32_t> hash;
 	for (uint32_t i = 0; i < c->n; ++i) {
 		const uint32_t plane = (c->hash[i] & CELLTYPE_BITMASK)/c->plane;
-		if (w.world > 1 && (plane < keepLo || plane >= keepHi)) continue;
+		if (planeType[plane] == CELLTYPE_OUTER) continue;
 		pos.insert(pos.end(), &c->pos[4*(size_t)i], &c->pos[4*(size_t)i] + 4);
 		vel.insert(vel.end(), &c->vel[4*(size_t)i], &c->vel[4*(size_t)i] + 4);
 		info.insert(info.end(), &c->info[4*(size_t)i], &c->info[4*(size_t)i] + 4);
@@ -278,14 +286,8 @@ static void worker(const Case *c, int rank, sphx_halo_group *group, const std::s
 	CALL(sphx_memcpy_h2d(w.info, info.data(), info.size()*sizeof(uint16_t))); CALL(sphx_memcpy_h2d(w.hash, hash.data(), hash.size()*sizeof(uint32_t)));
 	if (w.world > 1) {
 		std::vector<uint32_t> map(c->ncells);
-		for (uint32_t p = 0; p < c->gs3; ++p) {
-			uint32_t t = (p >= lo && p < hi) ? CELLTYPE_INNER : CELLTYPE_OUTER;
-			if (rank > 0 && p == lo) t = CELLTYPE_INNER_EDGE;
-			if (rank > 0 && p + 1 == lo) t = CELLTYPE_OUTER_EDGE;
-			if (rank < w.world - 1 && p + 1 == hi) t = CELLTYPE_INNER_EDGE;
-			if (rank < w.world - 1 && p == hi) t = CELLTYPE_OUTER_EDGE;
-			std::fill(map.begin() + (size_t)p*c->plane, map.begin() + (size_t)(p + 1)*c->plane, t << 30);
-		}
+		for (uint32_t p = 0; p < c->gs3; ++p)
+			std::fill(map.begin() + (size_t)p*c->plane, map.begin() + (size_t)(p + 1)*c->plane, planeType[p] << 30);
 		w.devmap = dev_alloc<uint32_t>(c->ncells);
 		CALL(sphx_memcpy_h2d(w.devmap, map.data(), map.size()*sizeof(uint32_t)));
 	}

@@ -120,7 +120,7 @@ def test_cpp_worker_threads_exchange_through_the_c_abi():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,lin", [(2, "xzy"), (3, "yzx")])
+@pytest.mark.parametrize("world,lin", [(2, "xzy"), (3, "yzx"), (2, "ring"), (3, "ring")])
 def test_cpp_workers_run_a_decomposed_dam_break(tmp_path, monkeypatch, world, lin):
     """gpusph_amd/host/slab_run: the decomposed run driven from C++ through the C ABI alone (one worker thread and one context
     per slab; neighbour phase with the device map, segments, halo import, stripes of the forces, UPDATE_EXTERNAL of the forces,
@@ -136,9 +136,15 @@ def test_cpp_workers_run_a_decomposed_dam_break(tmp_path, monkeypatch, world, li
     monkeypatch.setenv("SPHX_DISABLE_TILES", "1")
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpusph_amd", "host", "slab_run")
     assert os.path.exists(exe), "gpusph_amd/host/slab_run is not built (make -C gpusph_amd/host slab_run)"
-    kw = dict(deltap=0.03, obstacle=False, jitter=0.05, linearization=lin)
     steps = 12
-    prob = DamBreak3D(**kw)
+    if lin == "ring":      # a box periodic along the split axis with a stream through the periodic face: the slabs form a ring
+        from gpusph_amd.problem import PeriodicBox
+        kw = dict(deltap=0.05, n=(12, 12, 40), linearization="xyz", jitter=0.2, velocity=(0.1, 0.0, 1.5))
+        make = lambda: PeriodicBox(**kw)
+    else:
+        kw = dict(deltap=0.03, obstacle=False, jitter=0.05, linearization=lin)
+        make = lambda: DamBreak3D(**kw)
+    prob = make()
     part = SlabPartition(prob, world)
     arrs = prob.copy_to_array()
     n = len(arrs["hash"])
@@ -150,7 +156,7 @@ def test_cpp_workers_run_a_decomposed_dam_break(tmp_path, monkeypatch, world, li
     with open(case, "wb") as f:
         f.write(struct.pack("<10I", 0x31424C53, world, steps, n, prob.grid_cells, alloc, part.plane, part.gs3, int(sp.neiblistsize), len(params)))
         f.write(params)
-        f.write(struct.pack("<4fI", float(np.float32(sp.dt)), k.sspeed_cfl, k.max_kinvisc, k.sq_nl_radius, int(sp.buildneibsfreq)))
+        f.write(struct.pack("<4fII", float(np.float32(sp.dt)), k.sspeed_cfl, k.max_kinvisc, k.sq_nl_radius, int(sp.buildneibsfreq), int(part.ring)))
         f.write(np.asarray(part.lo, dtype=np.uint32).tobytes()); f.write(np.asarray(part.hi, dtype=np.uint32).tobytes())
         f.write(np.ascontiguousarray(arrs["pos"], dtype=np.float32).tobytes())
         f.write(np.ascontiguousarray(arrs["vel"], dtype=np.float32).tobytes())
@@ -170,7 +176,7 @@ def test_cpp_workers_run_a_decomposed_dam_break(tmp_path, monkeypatch, world, li
         info = np.frombuffer(raw, np.uint16, 4 * ni, off).reshape(ni, 4); off += 8 * ni
         parts.append(dict(pos=pos, vel=vel, info=info, dt=dt, t=t, n=ni))
     assert all(p["n"] > 0 for p in parts)
-    ref = TimestepEngine(DamBreak3D(**kw), device="cuda:0")
+    ref = TimestepEngine(make(), device="cuda:0")
     for _ in range(steps):
         ref.step()
     nr = ref.n
