@@ -2074,7 +2074,8 @@ int sphx_sa_tiles_run(sphx_ctx *ctx, int mode, void *forces, const void *pos, co
 	const DevParams &d = ctx->dev;
 	const bool ok = ctx->tiles_built && ctx->tiles_overflow != 1 && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		!ctx->disable_tiles && ctx->tile_list != nullptr && d.boundarytype == SPHX_SA_BOUNDARY && d.kerneltype == SPHX_WENDLAND &&
-		d.numfluids == 1 && d.turbmodel == SPHX_LAMINAR_FLOW && d.formulation == SPHX_SPH_F1 && d.rheology <= SPHX_NEWTONIAN &&
+		d.numfluids == 1 && (d.turbmodel == SPHX_LAMINAR_FLOW || (d.turbmodel == SPHX_KEPSILON && mode != SPHX_SA_TILE_FORCES)) &&
+		d.formulation == SPHX_SPH_F1 && d.rheology <= SPHX_NEWTONIAN &&
 		numParticles <= ctx->reserved_particles &&
 		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*TILE_NB < 0x80000000ull;
 	if (!ok || fromParticle >= toParticle) return SPHX_OK;

@@ -1094,9 +1094,9 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		<= (size_t)ctx->cells_reserved/2 + 1024;   // tile_cols allocation (degenerate 1-D grids: generic kernels)
 	// tiles serve sphx_forces_basicstep's pair loop only (SPH_F1, inviscid or Newtonian, DYN / LJ / MK boundaries) and sphx_calc_visc
 	// ... and, with SA_BOUNDARY, the particle <- particle sums of the SA forces, density summation and density diffusion
-	// (one fluid, no k-epsilon: sphx_sa_tiles_run, forces.hip)
+	// (one fluid; with k-epsilon the density summation and the diffusion, which do not involve the model: sphx_sa_tiles_run, forces.hip)
 	const bool tiled_options = ctx->params.sph_formulation == SPHX_SPH_F1 && ctx->params.rheologytype <= SPHX_NEWTONIAN &&
-		(!sa || (ctx->dev.numfluids == 1 && ctx->dev.turbmodel == SPHX_LAMINAR_FLOW));
+		(!sa || (ctx->dev.numfluids == 1 && (ctx->dev.turbmodel == SPHX_LAMINAR_FLOW || ctx->dev.turbmodel == SPHX_KEPSILON)));
 	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit) {
 		rc = sphx_ensure_tile_lists(ctx);      // first tiled build: the tile lists are allocated now (or never: generic kernels)
 		if (rc != SPHX_OK) return rc;
