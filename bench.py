@@ -111,6 +111,25 @@ def pmc_traffic(n_total, kernel):
     return None
 
 
+def self_launch(n):
+    """one rank per GPU under torch.distributed.run on this node (what the driver's command line does for N > 1), same arguments"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL between processes needs it on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def sphx_env():
+    """the SPHX_* switches in effect: part of the configuration of a measured line"""
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith("SPHX_")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,10 +153,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` typed as it is: become the launcher of N ranks (one per GPU) and hand their line through
+        sys.exit(self_launch(args.gpus))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                             % (args.gpus, args.gpus))
+        raise SystemExit("bench.py --gpus %d inside a job of WORLD_SIZE %d: launch it as `python bench.py --gpus N` or under "
+                         "torch.distributed.run --nproc-per-node N" % (args.gpus, world))
     if os.environ.get("SPHX_BENCH_BACKEND", "nccl") != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -159,13 +180,23 @@ def main():
 
     if world > 1:
         from gpusph_amd.multigpu import MultiGpuEngine
-        transport = None
-        if os.environ.get("SPHX_HALO", "torch") == "capi":      # the library's own RCCL entry points (include/sphx.h sphx_halo_*)
+        # the exchange goes through the library's own RCCL entry points (include/sphx.h sphx_halo_*: what a GPUSPH host calls
+        # in place of GPUWorker::transferBursts) unless SPHX_HALO=torch asks for torch.distributed's; torch.distributed only
+        # carries the 128-byte communicator id and the bench's own bookkeeping then
+        transport, transport_name = None, "torch.distributed"
+        if os.environ.get("SPHX_HALO", "capi") == "capi" and os.environ.get("SPHX_BENCH_BACKEND", "nccl") == "nccl":
             from gpusph_amd import capi
             from gpusph_amd.halo import CapiTransport
-            box = [CapiTransport.new_unique_id(capi.load()) if rank == 0 else None]
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = CapiTransport.new_unique_id(capi.load())
+                except Exception as exc:       # no librccl for the library: every rank takes the torch transport
+                    print("bench.py: sphx_halo_unique_id failed (%s); exchange over torch.distributed" % exc, file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
-            transport = lambda k: CapiTransport(k, rank, world, unique_id=box[0])
+            if box[0] is not None:
+                transport = lambda k: CapiTransport(k, rank, world, unique_id=box[0])
+                transport_name = "sphx_halo (RCCL)"
         eng = MultiGpuEngine(prob, device=device, rank=rank, world=world, track_particle_count=True, transport=transport)
     else:
         from gpusph_amd.engine import TimestepEngine
@@ -225,7 +256,7 @@ def main():
         exch = {"halo_bytes_per_step": [int(r[0].item()) for r in allr],
                 "exposed_exchange_ms_per_step": [round(float(r[1].item()), 4) for r in allr],
                 "internal_particles": [int(r[2].item()) for r in allr],
-                "comm_cus_reserved": int(getattr(eng, "comm_cus", 0))}
+                "comm_cus_reserved": int(getattr(eng, "comm_cus", 0)), "transport": transport_name}
     if rank == 0:
         updates = n_sum * args.steps
         value = 1e-6 * updates / elapsed
@@ -246,7 +277,7 @@ def main():
                                    "Colagrossi diffusion, DYN boundary, neib rebuild every 10 steps"
                                    % (n_total, dp, "viscosity<%s>" % args.viscosity if args.viscosity else "artificial viscosity"),
                        "particles": n_total, "parallelism": "slab%d" % world if world > 1 else "single", "linearization": lin,
-                       "mean_neibs": round(nbar, 2)},
+                       "mean_neibs": round(nbar, 2), "env": sphx_env()},
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "launch_ms": round(avg_ms, 4), "bytes_per_launch": int(bytes_per_launch),

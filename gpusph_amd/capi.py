@@ -112,6 +112,7 @@ SIGNATURES = {
     "sphx_halo_exchange": (_i, [_vp, _i, _vp, _vp, _i, _u32, _u32, _u32, _u32, _i, _u32, _u32, _u32, _u32, _vp]),
     "sphx_halo_allreduce_min_f32": (_i, [_vp, _vp, _vp]),
     "sphx_halo_allreduce_sum_f32": (_i, [_vp, _vp, _u32, _vp]),
+    "sphx_halo_allreduce_sum_f64": (_i, [_vp, _vp, _u32, _vp]),
     "sphx_halo_allgather_u64x2": (_i, [_vp, _vp, _vp, _vp]),
     "sphx_halo_barrier": (_i, [_vp, _vp]),
     "sphx_memset_async": (_i, [_vp, _i, C.c_size_t, _vp]),

@@ -69,6 +69,7 @@ struct Posted {
 	int device;
 	hipEvent_t ready, done;
 	double scalar[8];                      // all-reduce / all-gather payload
+	int err;                               // this rank failed inside the collective in flight: its peers return an error too
 };
 
 }   // namespace
@@ -221,23 +222,31 @@ extern "C" int sphx_halo_exchange(sphx_halo *h, int nbuf, void *const *bufs, con
 		return SPHX_OK;
 	}
 
-	// one thread per device: publish, meet, pull, meet (GPUWorker::transferBursts + the synchroniser's barriers)
+	// one thread per device: publish, meet, pull, meet (GPUWorker::transferBursts + the synchroniser's barriers).
+	// Failure semantics: once a rank has entered the collective it passes ALL its barriers whatever happens to it (a rank that
+	// returned early would leave every other worker thread blocked in pthread_barrier_wait for good); it records the error,
+	// raises its `err` flag for the peers, and every rank that sees a flag returns an error after the last barrier.
 	sphx_halo_group *g = h->group;
 	SPHX_REQUIRE(g != nullptr, "sphx_halo_exchange: handle without a transport");
-	SPHX_HIP(hipSetDevice(h->ctx->device));
+	int rc = SPHX_OK;
+	auto fail = [&](int code, const std::string &msg) { if (rc == SPHX_OK) rc = sphx_set_error(code, msg); };
 	Posted &me = g->posted[h->rank];
+	me.err = 0;
+	if (hipSetDevice(h->ctx->device) != hipSuccess) fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipSetDevice failed");
 	me.nbuf = nbuf;
 	for (int b = 0; b < nbuf; ++b) { me.buf[b] = bufs[b]; me.rowBytes[b] = rowBytes[b]; }
 	for (int s = 0; s < 2; ++s) { me.sendStart[s] = sendStart[s]; me.sendCount[s] = peer[s] >= 0 ? sendCount[s] : 0u; }
-	SPHX_HIP(hipEventRecord(me.ready, stream));      // what I send has been produced once this event has happened
+	// what I send has been produced once this event has happened
+	if (rc == SPHX_OK && hipEventRecord(me.ready, stream) != hipSuccess) fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipEventRecord failed");
+	if (rc != SPHX_OK) me.err = 1;
 	pthread_barrier_wait(&g->barrier);
-	int rc = SPHX_OK;
 	for (int s = 0; s < 2 && rc == SPHX_OK; ++s) {
 		if (peer[s] < 0 || !recvCount[s]) continue;
 		const Posted &nb = g->posted[peer[s]];
 		const int theirs = 1 - s;                     // my left neighbour sends me its RIGHT layer
+		if (nb.err) { fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: a neighbour rank failed before posting its layers"); break; }
 		if (nb.nbuf != nbuf || nb.sendCount[theirs] != recvCount[s]) {
-			rc = sphx_set_error(SPHX_ERR_INVALID, "sphx_halo_exchange: neighbour posted a different layer than this rank expects");
+			fail(SPHX_ERR_INVALID, "sphx_halo_exchange: neighbour posted a different layer than this rank expects");
 			break;
 		}
 		if (nb.device != h->ctx->device && h->peer_seen[s] != nb.device) {     // direct loads over the link instead of a staged copy
@@ -245,23 +254,27 @@ extern "C" int sphx_halo_exchange(sphx_halo *h, int nbuf, void *const *bufs, con
 			(void)hipGetLastError();                                            // "already enabled" is fine
 			h->peer_seen[s] = nb.device;
 		}
-		if (hipStreamWaitEvent(stream, nb.ready, 0) != hipSuccess) { rc = sphx_set_error(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipStreamWaitEvent failed"); break; }
+		if (hipStreamWaitEvent(stream, nb.ready, 0) != hipSuccess) { fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipStreamWaitEvent failed"); break; }
 		for (int b = 0; b < nbuf; ++b) {
-			if (nb.rowBytes[b] != rowBytes[b]) { rc = sphx_set_error(SPHX_ERR_INVALID, "sphx_halo_exchange: row size mismatch between neighbours"); break; }
+			if (nb.rowBytes[b] != rowBytes[b]) { fail(SPHX_ERR_INVALID, "sphx_halo_exchange: row size mismatch between neighbours"); break; }
 			const size_t bytes = (size_t)recvCount[s]*rowBytes[b];
 			char *dst = (char*)bufs[b] + (size_t)recvStart[s]*rowBytes[b];
 			const char *src = (const char*)nb.buf[b] + (size_t)nb.sendStart[theirs]*rowBytes[b];
 			const hipError_t e = (nb.device == h->ctx->device) ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream)
 				: hipMemcpyPeerAsync(dst, h->ctx->device, src, nb.device, bytes, stream);
-			if (e != hipSuccess) { rc = sphx_set_error(SPHX_ERR_RUNTIME, std::string("sphx_halo_exchange: peer copy: ") + hipGetErrorString(e)); break; }
+			if (e != hipSuccess) { fail(SPHX_ERR_RUNTIME, std::string("sphx_halo_exchange: peer copy: ") + hipGetErrorString(e)); break; }
 		}
 	}
-	if (hipEventRecord(me.done, stream) != hipSuccess && rc == SPHX_OK) rc = sphx_set_error(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipEventRecord failed");
+	if (hipEventRecord(me.done, stream) != hipSuccess) fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipEventRecord failed");
+	if (rc != SPHX_OK) me.err = 1;
 	pthread_barrier_wait(&g->barrier);
 	// nobody may overwrite its edge rows before its neighbours have pulled them: my stream waits for their copies
-	for (int s = 0; s < 2; ++s)
-		if (peer[s] >= 0 && sendCount[s] && hipStreamWaitEvent(stream, g->posted[peer[s]].done, 0) != hipSuccess && rc == SPHX_OK)
-			rc = sphx_set_error(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipStreamWaitEvent failed");
+	for (int s = 0; s < 2; ++s) {
+		if (peer[s] < 0) continue;
+		if (g->posted[peer[s]].err) fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: a neighbour rank failed during the exchange");
+		else if (sendCount[s] && hipStreamWaitEvent(stream, g->posted[peer[s]].done, 0) != hipSuccess)
+			fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipStreamWaitEvent failed");
+	}
 	pthread_barrier_wait(&g->barrier);               // the slots may be rewritten from here on
 	return rc;
 }
@@ -270,29 +283,40 @@ extern "C" int sphx_halo_exchange(sphx_halo *h, int nbuf, void *const *bufs, con
 // the small collectives of a step: dt (min over the devices, GPUSPH.cc:650-657 through gdata->dts), body forces (sum),
 // layer counts after a re-sort (all-gather; host values: the caller sizes its halo with them)
 // ------------------------------------------------------------------------------------------
-static int thread_allreduce(sphx_halo *h, float *d_vals, uint32_t n, bool take_min, hipStream_t stream)
+// T = float or double.  Same failure rule as the exchange: every rank passes both barriers; a rank that fails raises its flag
+// and every rank returns an error.
+template<typename T>
+static int thread_allreduce(sphx_halo *h, T *d_vals, uint32_t n, bool take_min, hipStream_t stream)
 {
 	sphx_halo_group *g = h->group;
-	SPHX_REQUIRE(n <= 8, "sphx_halo_allreduce: at most 8 values");
-	float mine[8], out[8];
-	SPHX_HIP(hipSetDevice(h->ctx->device));
-	SPHX_HIP(hipMemcpyAsync(mine, d_vals, sizeof(float)*n, hipMemcpyDeviceToHost, stream));
-	SPHX_HIP(hipStreamSynchronize(stream));          // through the host, like the reference's dt (gdata->dts[], one float per device)
+	int rc = SPHX_OK;
+	auto fail = [&](const char *msg) { if (rc == SPHX_OK) rc = sphx_set_error(SPHX_ERR_RUNTIME, msg); };
+	T mine[8], out[8];
 	Posted &me = g->posted[h->rank];
-	for (uint32_t k = 0; k < n; ++k) me.scalar[k] = (double)mine[k];
+	me.err = 0;
+	if (n > 8) { n = 0; rc = sphx_set_error(SPHX_ERR_INVALID, "sphx_halo_allreduce: at most 8 values between worker threads"); }
+	if (hipSetDevice(h->ctx->device) != hipSuccess) fail("sphx_halo_allreduce: hipSetDevice failed");
+	// through the host, like the reference's dt (gdata->dts[], one float per device)
+	if (rc == SPHX_OK && (hipMemcpyAsync(mine, d_vals, sizeof(T)*n, hipMemcpyDeviceToHost, stream) != hipSuccess ||
+	                      hipStreamSynchronize(stream) != hipSuccess)) fail("sphx_halo_allreduce: device to host copy failed");
+	if (rc == SPHX_OK) for (uint32_t k = 0; k < n; ++k) me.scalar[k] = (double)mine[k];
+	if (rc != SPHX_OK) me.err = 1;
 	pthread_barrier_wait(&g->barrier);
-	for (uint32_t k = 0; k < n; ++k) {
-		float acc = (float)g->posted[0].scalar[k];
-		for (int r = 1; r < g->world; ++r) {
-			const float v = (float)g->posted[r].scalar[k];
-			acc = take_min ? (v < acc ? v : acc) : acc + v;       // rank order: every thread computes the same sum
+	for (int r = 0; r < g->world; ++r)
+		if (g->posted[r].err) fail("sphx_halo_allreduce: a rank of the group failed");
+	if (rc == SPHX_OK)
+		for (uint32_t k = 0; k < n; ++k) {
+			T acc = (T)g->posted[0].scalar[k];
+			for (int r = 1; r < g->world; ++r) {
+				const T v = (T)g->posted[r].scalar[k];
+				acc = take_min ? (v < acc ? v : acc) : acc + v;       // rank order: every thread computes the same sum
+			}
+			out[k] = acc;
 		}
-		out[k] = acc;
-	}
 	pthread_barrier_wait(&g->barrier);
-	SPHX_HIP(hipMemcpyAsync(d_vals, out, sizeof(float)*n, hipMemcpyHostToDevice, stream));
-	SPHX_HIP(hipStreamSynchronize(stream));          // `out` is a stack array
-	return SPHX_OK;
+	if (rc == SPHX_OK && (hipMemcpyAsync(d_vals, out, sizeof(T)*n, hipMemcpyHostToDevice, stream) != hipSuccess ||
+	                      hipStreamSynchronize(stream) != hipSuccess)) fail("sphx_halo_allreduce: host to device copy failed");   // `out` is a stack array
+	return rc;
 }
 
 extern "C" int sphx_halo_allreduce_min_f32(sphx_halo *h, float *d_value, void *stream)
@@ -303,7 +327,7 @@ extern "C" int sphx_halo_allreduce_min_f32(sphx_halo *h, float *d_value, void *s
 		SPHX_NCCL(R, R->AllReduce(d_value, d_value, 1, ncclFloat, ncclMin, h->comm, (hipStream_t)stream));
 		return SPHX_OK;
 	}
-	return thread_allreduce(h, d_value, 1, true, (hipStream_t)stream);
+	return thread_allreduce<float>(h, d_value, 1, true, (hipStream_t)stream);
 }
 
 extern "C" int sphx_halo_allreduce_sum_f32(sphx_halo *h, float *d_values, uint32_t n, void *stream)
@@ -315,7 +339,21 @@ extern "C" int sphx_halo_allreduce_sum_f32(sphx_halo *h, float *d_values, uint32
 		SPHX_NCCL(R, R->AllReduce(d_values, d_values, n, ncclFloat, ncclSum, h->comm, (hipStream_t)stream));
 		return SPHX_OK;
 	}
-	return thread_allreduce(h, d_values, n, false, (hipStream_t)stream);
+	return thread_allreduce<float>(h, d_values, n, false, (hipStream_t)stream);
+}
+
+// the rigid-body force / torque totals are summed in double by the driver: the same wire format here, so that a decomposed run
+// gives the totals of the single domain whatever the transport
+extern "C" int sphx_halo_allreduce_sum_f64(sphx_halo *h, double *d_values, uint32_t n, void *stream)
+{
+	SPHX_REQUIRE(h && d_values, "sphx_halo_allreduce_sum_f64: NULL argument");
+	if (!n) return SPHX_OK;
+	if (h->comm) {
+		const Rccl *R = rccl();
+		SPHX_NCCL(R, R->AllReduce(d_values, d_values, n, ncclDouble, ncclSum, h->comm, (hipStream_t)stream));
+		return SPHX_OK;
+	}
+	return thread_allreduce<double>(h, d_values, n, false, (hipStream_t)stream);
 }
 
 extern "C" int sphx_halo_allgather_u64x2(sphx_halo *h, const uint64_t mine[2], uint64_t *all /* [2*world], host */, void *stream_)

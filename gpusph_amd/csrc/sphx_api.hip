@@ -1,5 +1,6 @@
 // sphx_api.hip -- context, constants and error plumbing of libsphx (C ABI in include/sphx.h).
 #include "sphx_internal.h"
+#include <cstdio>
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -44,9 +45,17 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	ctx->tile_grid = (uint32_t)(cus > 0 ? cus : 256)*TILE_WGS_PER_CU;   // persistent grid: one 512-thread workgroup per CU (LDS bound)
 	const char *dis = getenv("SPHX_DISABLE_TILES");
 	ctx->disable_tiles = dis && dis[0] == '1';
-	// SPHX_DISABLE_TILES=1: always the generic gather kernel (A/B runs, tests); SPHX_TILE_DEBUG: see ForcesArgs::dbg
+	// SPHX_DISABLE_TILES=1: always the generic gather kernel (A/B runs, tests).
+	// SPHX_TILE_DEBUG (ForcesArgs::dbg: timing experiments, some of which skip work and give wrong results) only exists in a
+	// library built with -DSPHX_TILE_DEBUG_BUILD (make EXTRA=-DSPHX_TILE_DEBUG_BUILD); the product library ignores the variable
+	ctx->tile_debug = 0;
+#ifdef SPHX_TILE_DEBUG_BUILD
 	const char *dbg = getenv("SPHX_TILE_DEBUG");
 	ctx->tile_debug = dbg ? atoi(dbg) : 0;
+#else
+	if (getenv("SPHX_TILE_DEBUG"))
+		fprintf(stderr, "libsphx: SPHX_TILE_DEBUG is ignored (library built without -DSPHX_TILE_DEBUG_BUILD)\n");
+#endif
 	*out = ctx;
 	return SPHX_OK;
 }

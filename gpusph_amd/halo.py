@@ -138,9 +138,15 @@ class CapiTransport:
         capi.check(self.lib.sphx_halo_allreduce_min_f32(self.handle, capi.ptr(t), self.k._s()))
 
     def allreduce_sum(self, t):
-        if t.dtype != torch.float32:                 # body totals are summed in double by the driver; the wire format is float
-            f = t.float().contiguous()
-            capi.check(self.lib.sphx_halo_allreduce_sum_f32(self.handle, capi.ptr(f), f.numel(), self.k._s()))
-            t.copy_(f.to(t.dtype))
+        """float32 or float64 (the body totals), reduced in the tensor's own precision like TorchTransport does"""
+        if t.dtype == torch.float64:
+            n = t.numel()
+            for k in range(0, n, 8):         # worker threads reduce at most 8 values per call
+                v = t.view(-1)[k:k + 8]
+                capi.check(self.lib.sphx_halo_allreduce_sum_f64(self.handle, capi.ptr(v), v.numel(), self.k._s()))
             return
-        capi.check(self.lib.sphx_halo_allreduce_sum_f32(self.handle, capi.ptr(t), t.numel(), self.k._s()))
+        assert t.dtype == torch.float32
+        n = t.numel()
+        for k in range(0, n, 8):
+            v = t.view(-1)[k:k + 8]
+            capi.check(self.lib.sphx_halo_allreduce_sum_f32(self.handle, capi.ptr(v), v.numel(), self.k._s()))

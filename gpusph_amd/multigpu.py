@@ -53,6 +53,18 @@ class SlabPartition:
         self.lo = [min(d * per, self.gs3) for d in range(world)]
         self.hi = [min((d + 1) * per, self.gs3) for d in range(world)]
         self.hi[-1] = self.gs3
+        # the rounding rule can starve the last device (28 planes on 8 devices: 7 x 4 and nothing left; 21 on 6: one plane),
+        # which the average test above does not see.  A slab needs its two edge planes to be different planes (each is sent
+        # to one neighbour and has its own outer edge plane behind it), so such a split is replaced by the even one:
+        # floor(planes / devices) each, the first planes % devices slabs one more
+        if world > 1 and min(h - l for l, h in zip(self.lo, self.hi)) < 2:
+            base, rem = divmod(self.gs3, world)
+            counts = [base + (1 if d < rem else 0) for d in range(world)]
+            self.lo = [sum(counts[:d]) for d in range(world)]
+            self.hi = [self.lo[d] + counts[d] for d in range(world)]
+        if world > 1 and min(h - l for l, h in zip(self.lo, self.hi)) < 2:
+            raise ValueError("slab split of %d planes over %d devices leaves a device with fewer than 2 planes: %s"
+                             % (self.gs3, world, list(zip(self.lo, self.hi))))
 
     def plane_types(self, rank):
         """CELLTYPE_* of every COORD3 plane as seen by `rank`"""

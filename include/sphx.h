@@ -565,7 +565,10 @@ int sphx_memcpy_d2d(void *dst, const void *src, size_t bytes);
  *                              from sphx_halo_unique_id on one rank and reaches the others by the host's own means.
  *                              RCCL is dlopen'ed on first use.
  * leftRank / rightRank: the ranks owning the neighbouring slabs, -1 for none.  All calls of a collective must be made by
- * every rank of the group (thread transport: they block on a barrier). */
+ * every rank of the group (thread transport: they block on a barrier).
+ * Failure: a rank that fails inside a collective of the thread transport (a HIP error, a layer that does not match what its
+ * neighbour posted) still passes every barrier of that collective and flags the failure to the group: the call returns an
+ * error on that rank AND on the ranks that depend on it, nobody is left blocked.  With RCCL an error is local to the rank. */
 typedef struct sphx_halo sphx_halo;
 typedef struct sphx_halo_group sphx_halo_group;
 int sphx_halo_group_create(int world, sphx_halo_group **out);
@@ -582,6 +585,9 @@ int sphx_halo_exchange(sphx_halo *h, int nbuf, void *const *bufs, const uint32_t
 /* dt of the step = the smallest of the devices' (GPUSPH.cc:650-657 over gdata->dts); total force / torque on a body */
 int sphx_halo_allreduce_min_f32(sphx_halo *h, float *d_value, void *stream);
 int sphx_halo_allreduce_sum_f32(sphx_halo *h, float *d_values, uint32_t n, void *stream);
+/* ... in double, the precision the body totals are reduced in on the host (REDUCE_BODIES_FORCES_HOST, src/GPUSPH.cc:1905-1960);
+ * worker threads: n <= 8 */
+int sphx_halo_allreduce_sum_f64(sphx_halo *h, double *d_values, uint32_t n, void *stream);
 /* the sizes of the layers every rank is about to send (host values: the receiver sizes its halo with them) */
 int sphx_halo_allgather_u64x2(sphx_halo *h, const uint64_t mine[2], uint64_t *all /* [2*world] */, void *stream);
 int sphx_halo_barrier(sphx_halo *h, void *stream);

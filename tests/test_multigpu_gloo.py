@@ -168,6 +168,39 @@ def test_partition_and_device_map():
         SlabPartition(prob, 64)
 
 
+@pytest.mark.parametrize("planes,world", [(28, 8), (21, 6), (35, 10), (24, 8), (30, 4), (9, 3), (200, 8)])
+def test_partition_never_starves_a_device(planes, world):
+    """the reference's rounding rule (round(planes / devices) each, the last device the rest) leaves the last device 0 planes at
+    (28, 8) and one at (21, 6) although the average is >= 3: every slab must keep two distinct edge planes, on a chain and on a ring"""
+    sys.path[:0] = [ROOT]
+    from gpusph_amd.multigpu import SlabPartition
+    from gpusph_amd import defs as D
+
+    class P:      # what SlabPartition reads of a problem
+        linearization = "xzy"
+
+        class simparams:
+            periodicbound = 0
+
+    for ring in (False, True):
+        P.m_gridsize = np.array([5, planes, 4])           # xzy: COORD3 = y
+        P.simparams.periodicbound = D.PERIODIC_Y if ring else 0
+        part = SlabPartition(P, world)
+        assert part.ring == ring
+        assert part.lo[0] == 0 and part.hi[-1] == planes and all(part.hi[d] == part.lo[d + 1] for d in range(world - 1))
+        assert min(h - l for l, h in zip(part.lo, part.hi)) >= 2
+        assert max(h - l for l, h in zip(part.lo, part.hi)) - min(h - l for l, h in zip(part.lo, part.hi)) <= max(2, planes // world)
+        owned = np.zeros(planes, dtype=int)
+        for r in range(world):
+            t = part.plane_types(r)
+            inner = t <= D.CELLTYPE_INNER_EDGE_CELL
+            owned += inner
+            assert inner.sum() == part.hi[r] - part.lo[r]
+            edges = (r > 0 or ring) + (r < world - 1 or ring)
+            assert (t == D.CELLTYPE_INNER_EDGE_CELL).sum() == edges and (t == D.CELLTYPE_OUTER_EDGE_CELL).sum() == edges
+        assert (owned == 1).all()      # every plane belongs to exactly one device
+
+
 def test_slab_run_of_the_stillwater_mirror_equals_single_domain(tmp_path):
     """StillWater's option set over two slabs: viscosity<DYNAMICVISC>, Ferrari density diffusion, DYN walls, MLS filter every
     4 iterations (filtered velocities imported for the halo), 12 steps: bit-equal to the single-domain run"""
