@@ -32,11 +32,12 @@ struct ForcesArgs {
 	float2 *otau0, *otau1, *otau2; float *oturbvisc;   // stress mode of the tiled kernel (SPHX_TURB_STRESS): outputs
 	const float4 *tauPack;   // SPS + tiled kernel: [0,n) = {xx,xy,xz,yy}, [n,2n) = {yz,zz,P/rho^2,c or P} (tau_pack_kernel); tauPackN = n
 	uint32_t tauPackN;
-	// tiled kernel: the tile lists of this neighbour list (tile_lists_kernel), [rows][stride] uint16, and the rows per wave
-	const uint16_t *tileList; uint32_t tileListRows, tileListStride;
-	const uint32_t *tileWaves;   // [tile][8]: rows of the fluid section | rows of the boundary section << 16 | chunk << 28, per WAVE
-	const uint32_t *tileRows;    // [tile][TILE_ROWDESC]: the window rows (tile_lists_kernel)
-	const uint16_t *tileOwnSlot; // [particle]: byte offset of the particle's own row in its tile's window
+	// tiled kernel: the tile lists of this neighbour list (tile_lists_kernel)
+	const uint2 *tileList;       // the stream of list batches: [batch][64 lanes] x 4 uint16 window offsets
+	const uint32_t *tileRuns;    // [tile][TILE_RUNTAB]: which wave walks which batches of which chunk (sphx_internal.h)
+	const uint32_t *tileRows;    // [tile][TILE_ROWDESC]: the window rows
+	const uint32_t *tileLaneRec; // per lane of every chunk: byte offset of the particle's own row in its tile's window | flags << 16
+	const uint32_t *tileLaneIndex; // ... the particle (0xFFFFFFFF: idle lane)
 	float4 *xsph;        // ENABLE_XSPH: mean velocity correction of fluid particles, else NULL
 	const float4 *saGam; // SA_BOUNDARY modes of the tiled kernel (SPHX_TURB_SA*): gamma in .w (diffusion mode), the step's dt
 	float saDt;
@@ -45,10 +46,6 @@ struct ForcesArgs {
 	uint32_t numBlocks;   // generic kernel: blocks of SPHX_BLOCK_FORCES particles to cover
 	int compute_object_forces;
 	uint32_t *pin;              // always NULL (see pin_batch)
-	unsigned long long *prof;   // SPHX_TILE_DEBUG & 16: per-workgroup phase times (100 MHz ticks), else NULL
-	int dbg;   // SPHX_TILE_DEBUG bits, timing experiments only (results are wrong with 1, 2, 32): 1 = skip the pair loops,
-	           // 2 = skip the window staging, 4 = plain round-robin tile order instead of the XCD-aware one, 16 = phase timers,
-	           // 32 = the list walk re-reads its first batches (no HBM list stream), 64 / 128 = other patterns of the alternating wave priorities in the pair loop, 256 = none
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -636,38 +633,6 @@ __device__ __forceinline__ bool wave_any(bool x) { return __builtin_amdgcn_ballo
 // memory instructions of a row-per-load layout, whose 2-byte loads kept the CU's address unit busy for half of the
 // pair loop's duration.  The pair loop is wave-uniform, so the batch number is a scalar: SGPR descriptor (slab base) +
 // the per-lane byte offset index*8, which is fixed for the whole tile -- no vector address arithmetic at all.
-struct ListRows { const uint16_t *list; uint32_t batchBytes; uint32_t rows; uint32_t *pin; int dbg; };
-
-typedef uint32_t list_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void load_list_u(const ListRows &lr, uint32_t voff, int sec, int batch, uint2 &nd)
-{
-	// batches past a section's end are never consumed (the walk stops there); the clamp only keeps the
-	// prefetch in bounds.  No branch around the load: the compiler must be able to count it (s_waitcnt vmcnt(N)).
-	int b = min(__builtin_amdgcn_readfirstlane(batch), (int)lr.rows/TILE_NB - 1);
-	if (lr.dbg & 32) b &= 3;    // timing experiment: the walk re-reads its first batches (cache hits instead of the HBM stream)
-	const int slab = sec ? (int)lr.rows/TILE_NB - 1 - b : b;
-	const char *base = reinterpret_cast<const char*>(lr.list) + (size_t)slab*lr.batchBytes;
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xFFFFFFFF, 0x00020000);
-	const list_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, 0, 0);
-	nd = make_uint2(d.x, d.y);
-}
-
-// LLVM sinks a load whose first use is three ring steps (and several side exits) away down to that use, which
-// undoes the prefetch distance.  A use in a never-taken side block (pin is always NULL, but a kernel argument
-// the compiler cannot see through) keeps the loads where they are issued; the main path pays one scalar branch.
-__device__ __forceinline__ void pin_batch(const ListRows &lr, const uint2 &nd)
-{
-	if (__builtin_expect(lr.pin != nullptr, 0))
-		lr.pin[threadIdx.x] = nd.x ^ nd.y;
-}
-
-__device__ __forceinline__ void preload_list(const ListRows &lr, uint32_t voff, int sec, ListWindow &lw)
-{
-#pragma unroll
-	for (int j = 0; j < TILE_AHEAD; ++j)
-		load_list_u(lr, voff, sec, j, lw.q[j]);   // batches 0..TILE_AHEAD-1 always exist (tile_list_rows >= 16)
-}
-
 struct StressAcc { float x, y, z, w, u; };   // stress mode: the accumulators that do not fit the float4 of the forces
 
 // one pair of SPSstressMatrixDevice (src/cuda/visc_kernel.cu:759-811) in the tiled kernel: dv_ab -= (v_a - nv_a) r_b F m/rho_n,
@@ -836,6 +801,11 @@ __device__ __forceinline__ void pair_interact_pk(const DevParams &p, const Self 
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 struct TilePk { static constexpr bool value = KERNEL == SPHX_WENDLAND && TURB == SPHX_ARTIFICIAL && COLAGROSSI != DIFF_FERRARI && !LJ; };
 
+// the instantiations whose list ring is hand-managed (load_list_b<true>): those that keep every value in registers.  The SPS
+// ones spill (their pair holds twelve more values per neighbour) and stay on compiler-managed loads
+template<int TURB>
+struct TileAsmRing { static constexpr bool value = TURB_MODEL(TURB) != SPHX_SPS; };
+
 // stage 2: the pair interactions of a gathered half, in list order; q = own position in the tile's frame
 // LJ = the run uses LJ_BOUNDARY: pairs of the boundary section (ljsec, wave-uniform) and all pairs of boundary
 // particles with force feedback (ljlane) are Lennard-Jones repulsions instead of SPH interactions
@@ -883,94 +853,284 @@ __device__ __forceinline__ void compute_half(const DevParams &p, const Gathered 
 	}
 }
 
-// Walk one section of the tile lists of a whole wave against the LDS window.
-//  * WAVE-UNIFORM control with a scalar trip count: `rows` entries per lane (the wave's longest list of the section,
-//    padded by tile_lists_kernel; pad entries are pairs of weight 0, pair_interact is branch-free).  Lanes with short
-//    lists would idle in SIMD execution anyway; uniform control removes the exec-mask bookkeeping and makes batch
-//    numbers and list row addresses scalar;
-//  * list entries (HBM, 4 B per pair: the dominant traffic of the pass) are fetched TILE_AHEAD-1
-//    batches ahead into a ring of register buffers, rotated by unrolling, not by copying (a copy of
-//    an in-flight load would wait for it);
-//  * the LDS reads of the next TILE_HB pairs are issued before the current TILE_HB pairs are
-//    computed, so the ds_read latency (and its bank conflicts) hides behind the pair arithmetic;
-//  * section, momentum and diffusion switches are run-time values so that the pair code exists
-//    once in the kernel (the instruction cache is 64 KB; four template copies did not fit).
+// Walk the runs of one wave of a tile against the LDS window.
+//
+// The neighbour lists of a tile's home particles are dealt out to the eight waves of the workgroup BATCH BY BATCH, not
+// particle by particle (tile_lists_kernel): the home particles are sorted by list length and cut into chunks of 64 (one per
+// lane), the list batches of all chunks are laid end to end -- chunk after chunk, fluid section then second section, every
+// section padded to the chunk's longest list -- and every wave takes an eighth of that sequence.  A RUN is the part of one
+// chunk's batches that one wave walks; a wave has one to three of them per tile.  At the start of a run the lanes load their
+// particle of that chunk (own row from the window), at its end they park the accumulator in LDS (sPart, one slot per run);
+// when all waves are through, the finalize stage adds up the slots of each chunk in list order.  What this buys: all eight
+// waves (two per SIMD: the fp32 issue rate needs both) stay busy to the end of every tile whatever its number of particles
+// and however uneven their lists -- with whole chunks per wave a tile of 363 particles occupied six waves, a tile took as long
+// as its longest chunk, and a wave alone on its SIMD issued at half rate.
+//  * WAVE-UNIFORM control with scalar trip counts: pad entries are pairs of weight 0 (slot 0 of the window is a dummy record a
+//    kilometre away), pair_interact is branch-free, a lane that does not take a section computes along and gets its
+//    accumulator back at the end of the section;
+//  * the wave's batches are ONE stream in memory (512 B per batch: 64 lanes x 4 window offsets), fetched TILE_AHEAD batches
+//    ahead into a ring of register buffers that runs through the section and run boundaries (rotated by unrolling, not by
+//    copying: a copy of an in-flight load would wait for it); its first batches are requested one tile ahead;
+//  * the LDS reads of the next TILE_HB pairs are issued before the current TILE_HB pairs are computed;
+//  * section, momentum and diffusion switches are run-time values so that the pair code exists once in the kernel.
+struct ListStream { const uint2 *list; uint32_t *pin; };
+
+typedef uint32_t list_u32x2 __attribute__((ext_vector_type(2)));
+// A buffer load the compiler sees.  It then also decides where to wait for it, and in the four-buffer ring of walk_runs it
+// decides badly: it rotates the buffers with register copies at the loop latch and has to drain the whole ring
+// (s_waitcnt vmcnt(0)) in front of the copies -- once every four batches the walk waits out the latency of its youngest load,
+// which was issued one batch before (the state of rounds 1-3: the ISA shows it, the source did not).  Kept for the
+// instantiations that spill (AccRing below explains why) and for the requests made one tile ahead.
+__device__ __forceinline__ void load_list_b(const ListStream &ls, uint32_t firstBatch /* of this wave, absolute */,
+	int batch /* relative */, int lastBatch, uint32_t lane8, uint2 &nd)
+{
+	// batches past the end are never computed (the walk stops there); the clamp only keeps the prefetch inside the tile's
+	// stream.  No branch around the load: one load per step, whatever happens.
+	const int b = min(__builtin_amdgcn_readfirstlane(batch), lastBatch);
+	const char *base = reinterpret_cast<const char*>(ls.list + ((size_t)__builtin_amdgcn_readfirstlane(firstBatch) + (uint32_t)b)*64u);
+	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xFFFFFFFF, 0x00020000);
+	const list_u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)lane8, 0, 0);
+	nd = make_uint2(d.x, d.y);
+}
+
+// The hand-managed ring: the list batches in flight live in ACCUMULATION registers, which the compiler does not use in a kernel
+// that spills nothing (gfx950 gives a wave 512 registers, 256 of them a0..a255; with two waves per SIMD the 256 a wave may
+// have are split as the kernel declares).  A value in flight in a register the compiler manages can be copied or spilled by
+// it at any moment -- it has no idea the load has not landed (tried: tied asm operands; the compiler peeled the loop and moved
+// the buffers between registers) --, a register it never touches cannot.
+//   a[2J : 2J+1], J < 4      buffer J of the running tile's ring
+//   a[8+2k : 9+2k], k < 4    batch k of the NEXT tile's stream, requested one tile ahead
+// All statements are asm volatile (kept in order among themselves) and name the registers in the clobber list, which is also
+// what makes the compiler count them in the kernel's register budget.  vmcnt counts loads in issue order and the ring issues
+// exactly one load per batch, so "at most three younger loads outstanding" (acc_wait) is "this buffer has landed".
+// scripts/check_ring_isa.py verifies on the ISA that nothing but these statements touches an accumulation register.
+#define SPHX_ACC_CLOBBERS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"
+template<int REG>
+__device__ __forceinline__ void acc_load(const ListStream &ls, uint32_t firstBatch, int batch, int lastBatch, uint32_t lane8)
+{
+	const int b = min(__builtin_amdgcn_readfirstlane(batch), lastBatch);
+	const char *base = reinterpret_cast<const char*>(ls.list + ((size_t)__builtin_amdgcn_readfirstlane(firstBatch) + (uint32_t)b)*64u);
+	static_assert(REG >= 0 && REG < 16 && (REG & 1) == 0, "a register pair");
+#define SPHX_ACC_LOAD(R0, R1) asm volatile("global_load_dwordx2 a[" #R0 ":" #R1 "], %0, %1 ; ACCRING" :: "v"(lane8), "s"(base) : SPHX_ACC_CLOBBERS)
+	if (REG == 0) SPHX_ACC_LOAD(0, 1); else if (REG == 2) SPHX_ACC_LOAD(2, 3); else if (REG == 4) SPHX_ACC_LOAD(4, 5);
+	else if (REG == 6) SPHX_ACC_LOAD(6, 7); else if (REG == 8) SPHX_ACC_LOAD(8, 9); else if (REG == 10) SPHX_ACC_LOAD(10, 11);
+	else if (REG == 12) SPHX_ACC_LOAD(12, 13); else SPHX_ACC_LOAD(14, 15);
+#undef SPHX_ACC_LOAD
+}
+// buffer REG/2 of the ring -> two ordinary registers (the batch has landed: acc_wait, or it was requested a tile ahead)
+template<int REG>
+__device__ __forceinline__ uint2 acc_read()
+{
+	uint2 r;
+#define SPHX_ACC_READ(R0, R1) asm volatile("v_accvgpr_read_b32 %0, a" #R0 " ; ACCRING\n\tv_accvgpr_read_b32 %1, a" #R1 " ; ACCRING" : "=v"(r.x), "=v"(r.y) :: SPHX_ACC_CLOBBERS)
+	if (REG == 0) SPHX_ACC_READ(0, 1); else if (REG == 2) SPHX_ACC_READ(2, 3); else if (REG == 4) SPHX_ACC_READ(4, 5); else if (REG == 6) SPHX_ACC_READ(6, 7);
+	else if (REG == 8) SPHX_ACC_READ(8, 9); else if (REG == 10) SPHX_ACC_READ(10, 11); else if (REG == 12) SPHX_ACC_READ(12, 13); else SPHX_ACC_READ(14, 15);
+#undef SPHX_ACC_READ
+	return r;
+}
+__device__ __forceinline__ void acc_wait()
+{
+	static_assert(TILE_AHEAD == 4, "vmcnt(TILE_AHEAD - 1)");
+	asm volatile("s_waitcnt vmcnt(3) ; ACCRING" ::: SPHX_ACC_CLOBBERS);
+}
+// The batches requested one tile ahead (a8..a15) spend the stretch between two pair phases -- the finalize stage, the window
+// conversion: long code with temporaries of its own, where the compiler does reach for low accumulation registers -- in ordinary
+// registers: acc_fetch_ahead once everything has landed (the caller waited vmcnt(0)), acc_start_ring right before the walk.
+// What is left for the compiler to respect are the gaps between the ring's own statements inside the pair loop.
+__device__ __forceinline__ void acc_fetch_ahead(ListWindow &lw)
+{
+	lw.q[0] = acc_read<8>(); lw.q[1] = acc_read<10>(); lw.q[2] = acc_read<12>(); lw.q[3] = acc_read<14>();
+}
+__device__ __forceinline__ void acc_start_ring(const ListWindow &lw)
+{
+	asm volatile("v_accvgpr_write_b32 a0, %0 ; ACCRING\n\tv_accvgpr_write_b32 a1, %1 ; ACCRING\n\tv_accvgpr_write_b32 a2, %2 ; ACCRING\n\t"
+		"v_accvgpr_write_b32 a3, %3 ; ACCRING\n\tv_accvgpr_write_b32 a4, %4 ; ACCRING\n\tv_accvgpr_write_b32 a5, %5 ; ACCRING\n\t"
+		"v_accvgpr_write_b32 a6, %6 ; ACCRING\n\tv_accvgpr_write_b32 a7, %7 ; ACCRING"
+		:: "v"(lw.q[0].x), "v"(lw.q[0].y), "v"(lw.q[1].x), "v"(lw.q[1].y), "v"(lw.q[2].x), "v"(lw.q[2].y), "v"(lw.q[3].x), "v"(lw.q[3].y)
+		: SPHX_ACC_CLOBBERS);
+}
+
+// (compiler-managed ring) LLVM sinks a load whose first use is three ring steps (and several side exits) away down to that use, which
+// undoes the prefetch distance.  A use in a never-taken side block (pin is always NULL, but a kernel argument
+// the compiler cannot see through) keeps the loads where they are issued; the main path pays one scalar branch.
+__device__ __forceinline__ void pin_batch(const ListStream &ls, const uint2 &nd)
+{
+	if (__builtin_expect(ls.pin != nullptr, 0))
+		ls.pin[threadIdx.x] = nd.x ^ nd.y;
+}
+
+// flags of a lane record (tile_lists_kernel): what the pair loop needs of the particle info
+#define LANE_TYPE_MASK 7u
+#define LANE_COMPUTE_FORCE 8u
+#define LANE_FLUID_SHIFT 4
+#define LANE_VALID 64u
+
+// the part of a tile's run table a wave works from (all scalar)
+struct WaveJob { uint32_t firstRun, nRuns, firstBatch, nBatches, laneBase, chunks; };
+__device__ __forceinline__ WaveJob wave_job(uint32_t rt /* this lane's word of the run table */, const uint32_t *d, uint32_t wave)
+{
+	WaveJob j;
+	const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rt, (int)wave);
+	j.firstRun = w & 31u; j.nRuns = (w >> 5) & 31u;
+	j.firstBatch = __builtin_amdgcn_readfirstlane(d[14]) + ((w >> 10) & 4095u);
+	j.nBatches = w >> 22;
+	j.laneBase = __builtin_amdgcn_readfirstlane(d[15]);
+	j.chunks = (uint32_t)__builtin_amdgcn_readlane((int)rt, 8) & 255u;
+	return j;
+}
+
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
-__device__ __forceinline__ void walk_section_lds(const DevParams &p, const ListRows &list,
-	uint32_t voff, const Self &s, const float3 &q, float inv_h,
-	const float4 *sPos, const float4 *sVel, const float4 *sAux,
-	int sec, int rows, bool take, bool momentum, bool diffuse, bool ljlane,
-	ListWindow &lw /* batches 0..preloaded-1 already requested */, int preloaded, float4 &force, StressAcc &fx)
+__device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &a, const ListStream &ls, const WaveJob &wj, uint32_t rt,
+	uint32_t lane, float inv_h, const float4 *sPos, const float4 *sVel, const float4 *sAux, float4 *sPart, const uint32_t *sLaneRec,
+	ListWindow &lw /* batches 0..TILE_AHEAD-1 of the wave's stream, already requested */)
 {
 	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
-	static_assert(TILE_LIST_BATCH % TILE_NB == 0, "section lengths are whole batches");
-	const int nb = __builtin_amdgcn_readfirstlane(rows)/TILE_NB;   // batches to process (scalar)
-	if (nb == 0) return;
-	int next = TILE_AHEAD;   // index of the next batch to fetch (scalar)
-	for (int j = preloaded; j < TILE_AHEAD; ++j) {
-		load_list_u(list, voff, sec, j, lw.q[j]);
-		pin_batch(list, lw.q[j]);
-	}
-	int left = nb;
+	constexpr uint32_t WC = TILE_WC(TURB), WS = WC + 1;
+	constexpr bool SPSW = TURB_MODEL(TURB) == SPHX_SPS, SPSC = TILE_SPS_COMPACT(TURB), STRESS = (TURB & SPHX_TURB_STRESS) != 0;
+	constexpr bool PREMUL = TilePk<KERNEL, TURB, COLAGROSSI, LJ>::value;
+	constexpr bool SA = (TURB & SPHX_TURB_SA_ANY) != 0, SA_DSUM = (TURB & SPHX_TURB_SA_DSUM) != 0, SA_DIFF = (TURB & SPHX_TURB_SA_DIFF) != 0;
+	constexpr bool NOAUX = STRESS || SA_DSUM || SPSC, NOVEL = SA_DIFF;
+	constexpr uint32_t TAU0 = SPSC ? 0u : WS;
+	constexpr bool ASMR = TileAsmRing<TURB>::value;
+	const uint32_t lane8 = lane*(uint32_t)(TILE_NB*sizeof(uint16_t));
+	const int last = (int)wj.nBatches - 1;
+	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
+	int next = TILE_AHEAD;                 // next batch of the stream to fetch (scalar)
+	uint32_t run = wj.firstRun;            // scalar
+	const uint32_t runsEnd = wj.firstRun + wj.nRuns;
+
+	// state of the run / section being walked
+	Self s;
+	float3 q = make_float3(0.0f, 0.0f, 0.0f);
+	float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f), keep = force;
+	StressAcc fx = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+	bool take = false, take0 = false, take1 = false, momentum = false, ljlane = false, diffuse = true;
+	int sec = 0, leftSeg = 0;
+	uint32_t secondLeft = 0;               // batches of the run's second section still to come (scalar)
+	s.pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.gridPos = make_int3(0, 0, 0); s.fl = 0u;
+
+	auto start_run = [&]() {
+		const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rt, (int)(TILE_RT_RUN + run));
+		const uint32_t nF = (w >> 4) & 255u;
+		secondLeft = (w >> 12) & 255u;
+		// the lanes' particles of this run's chunk.  From LDS (staged with the window): a global load here would sit between
+		// the loads of the list ring, whose in-order completion count (s_waitcnt vmcnt(N)) the compiler can then no longer tell
+		const uint32_t rec = sLaneRec[(w & 15u)*64u + lane];
+		const uint32_t oslot = rec & 0xFFFFu, fl = rec >> 16;
+		// own rows from the window (already in the tile's frame); idle lanes read the dummy row
+		const float4 opos = lds_row(sPos, oslot), ovel = NOVEL ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : lds_row(sVel, oslot);
+		q = make_float3(opos.x, opos.y, opos.z);
+		s.vel = ovel;
+		s.fl = (TURB & SPHX_TURB_MF) ? ((fl >> LANE_FLUID_SHIFT) & 3u) : 0u;
+		if (STRESS) {
+			s.rho = (ovel.w + 1.0f)*p.rho0[0];
+		} else if (SPSC) {      // no EOS rows in the window: P/rho^2 and the one of {c, P} the pair reads ride in the stress rows
+			const float4 tb = lds_row(sAux + TAU0 + WS, oslot);
+			s.p_precalc = tb.z; s.sspeed = tb.w; s.P = tb.w; s.rho = (ovel.w + 1.0f)*p.rho0[0];
+			s.inv_rho = fast_rcp(s.rho);
+		} else if (!NOAUX) {
+			const float4 oaux = lds_row(sAux, oslot);
+			s.p_precalc = oaux.x; s.sspeed = oaux.y; s.P = oaux.z; s.rho = oaux.w;
+			s.inv_rho = fast_rcp(oaux.w);
+		}
+		if (SA_DIFF) s.sa_dt2rho = a.saDt*2.0f*s.rho;
+		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
+		if (SPSW) {   // own stress tensor
+			const float4 ta = lds_row(sAux + TAU0, oslot), tb = lds_row(sAux + TAU0 + WS, oslot);
+			s.tau[0] = ta.x; s.tau[1] = ta.y; s.tau[2] = ta.z; s.tau[3] = ta.w; s.tau[4] = tb.x; s.tau[5] = tb.y;
+		}
+		const uint32_t ptype = fl & LANE_TYPE_MASK;
+		const bool active = (fl & LANE_VALID) != 0u, hasCF = (fl & LANE_COMPUTE_FORCE) != 0u;
+		const bool isFluid = ptype == PT_FLUID, isBound = ptype == PT_BOUNDARY, isDynBound = isBound && dyn;
+		// fluid: fluid section then boundary section (DYN: SPH pairs, LJ: repulsion); DYN boundary: fluid section
+		// only, with the momentum part only for bodies with force feedback (forces_kernel.def:3650-3679);
+		// LJ boundary: fluid section only for bodies with force feedback, when object forces are asked for (:3620-3645)
+		momentum = isFluid || hasCF;
+		ljlane = LJ && isBound;
+		// SA_BOUNDARY modes: fluid particles only, fluid section then vertex section (none in the diffusion)
+		take0 = active && (SA ? isFluid : (STRESS || isFluid || isDynBound || (ljlane && hasCF && a.compute_object_forces)));
+		take1 = active && (SA ? (isFluid && !SA_DIFF) : (STRESS || (isFluid && (dyn || LJ))));
+		force = make_float4(0.0f, 0.0f, 0.0f, 0.0f); keep = force;
+		fx.x = 0.0f; fx.y = 0.0f; fx.z = 0.0f; fx.w = 0.0f; fx.u = 0.0f;
+		if (nF) { sec = 0; leftSeg = (int)nF; take = take0; diffuse = true; }
+		else { sec = 1; leftSeg = (int)secondLeft; secondLeft = 0u; take = take1; diffuse = false; }
+	};
+	// end of a section: false when the wave has walked its last run
+	auto end_segment = [&]() -> bool {
+		// pair_interact_pk has no per-lane validity flag: a lane that does not take the section gets its accumulator back
+		force.x = take ? force.x : keep.x; force.y = take ? force.y : keep.y; force.z = take ? force.z : keep.z; force.w = take ? force.w : keep.w;
+		if (sec == 0 && secondLeft) {
+			sec = 1; leftSeg = (int)secondLeft; secondLeft = 0u; take = take1; diffuse = false; keep = force;
+			return true;
+		}
+		if (PREMUL && !momentum) { force.x = 0.0f; force.y = 0.0f; force.z = 0.0f; }   // ... and no momentum switch
+		float4 *dst = sPart + (size_t)run*64u + lane;
+		dst[0] = force;
+		if (STRESS) {
+			dst[TILE_RUNS_MAX*64] = make_float4(fx.x, fx.y, fx.z, fx.w);
+			dst[2*TILE_RUNS_MAX*64] = make_float4(fx.u, 0.0f, 0.0f, 0.0f);
+		}
+		if (++run == runsEnd) return false;
+		start_run();
+		return true;
+	};
+
+	start_run();
 	Gathered A, B;
-	gather_half<TURB>(lw.q[0].x, sPos, sVel, sAux, p.rho0[0], A);
 	// one batch per step; the first half of the NEXT batch is gathered before the second half of this one is computed,
-	// also after the last batch (a clamped, in-bounds prefetch whose rows are never computed): one exit per step and no
-	// second copy of the pair code
-	// SPHX_TILE_DEBUG & 64: the two waves of a SIMD (w and w + 4) take turns at being the one the issue arbiter prefers, batch by
-	// batch (priorities 3,0,3,0.. against 2,1,2,1..); left alone the older wave always wins and the younger one runs the last
-	// quarter of every tile alone, at the issue rate of a single wave
-	// pattern: the older wave is preferred in batches 0,1 of every 4 (default); SPHX_TILE_DEBUG 64: in 0,2; 128: in 0,1,2; 256: priorities
-	// left alone.  Measured at 32 M particles: 4.67 ms per launch left alone, 4.52 / 4.50 / 4.49 with patterns 1 / 2 / 3
-	const int prio = (list.dbg & 256) ? 0 : (((list.dbg >> 6) & 3) ? ((list.dbg >> 6) & 3) : 3);
+	// also after the last batch (a clamped, in-bounds prefetch whose rows are never computed).
+	// The two waves of a SIMD (w and w + 4) take turns at being the one the issue arbiter prefers, batch by batch (priorities
+	// 3,3,0,0 against 2,1,2,1): left alone the older wave always wins and the younger one is starved while both have work
 	const bool hiw = (TILE_WAVES > 4) ? (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0) : (((blockIdx.x/256u) & 1u) != 0u);
+#define SPHX_RING_PRIO(J) \
+	if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } \
+	else { if ((J) < 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+	if (ASMR) {
+		// the ring lives in a0..a7 (AccRing above); `cur` is the batch being walked, in ordinary registers
+		acc_start_ring(lw);
+		uint2 cur = lw.q[0];
+		gather_half<TURB>(cur.x, sPos, sVel, sAux, p.rho0[0], A);
 #define SPHX_RING_STEP(J, JN) \
-	if (prio) { if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } \
-	            else { const bool hi = (prio == 1) ? !((J) & 1) : (prio == 2) ? ((J) != 3) : ((J) < 2); \
-	                   if (hi) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); } } \
-	gather_half<TURB>(lw.q[J].y, sPos, sVel, sAux, p.rho0[0], B); \
-	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
-	load_list_u(list, voff, sec, next, lw.q[J]); \
-	pin_batch(list, lw.q[J]); \
-	++next; \
-	gather_half<TURB>(lw.q[JN].x, sPos, sVel, sAux, p.rho0[0], A); \
-	compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
-	if (--left == 0) { if (prio) __builtin_amdgcn_s_setprio(0); return; }
-	for (;;) {
-		SPHX_RING_STEP(0, 1)
-		SPHX_RING_STEP(1, 2)
-		SPHX_RING_STEP(2, 3)
-		SPHX_RING_STEP(3, 0)
+		SPHX_RING_PRIO(J) \
+		gather_half<TURB>(cur.y, sPos, sVel, sAux, p.rho0[0], B); \
+		compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
+		acc_load<2*(J)>(ls, wj.firstBatch, next, last, lane8);      /* buffer J is free: its batch is in `cur` */ \
+		++next; \
+		/* the batch to gather next: requested a tile ahead if it is one of the first TILE_AHEAD, else TILE_AHEAD - 1 loads ago */ \
+		if (next >= 2*TILE_AHEAD) acc_wait(); \
+		cur = acc_read<2*(JN)>(); \
+		gather_half<TURB>(cur.x, sPos, sVel, sAux, p.rho0[0], A); \
+		compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
+		if (--leftSeg == 0) { if (!end_segment()) { __builtin_amdgcn_s_setprio(0); return; } }
+		for (;;) {
+			SPHX_RING_STEP(0, 1)
+			SPHX_RING_STEP(1, 2)
+			SPHX_RING_STEP(2, 3)
+			SPHX_RING_STEP(3, 0)
+		}
+#undef SPHX_RING_STEP
+	} else {
+		gather_half<TURB>(lw.q[0].x, sPos, sVel, sAux, p.rho0[0], A);
+#define SPHX_RING_STEP(J, JN) \
+		SPHX_RING_PRIO(J) \
+		gather_half<TURB>(lw.q[J].y, sPos, sVel, sAux, p.rho0[0], B); \
+		compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
+		load_list_b(ls, wj.firstBatch, next, last, lane8, lw.q[J]); \
+		pin_batch(ls, lw.q[J]); \
+		++next; \
+		gather_half<TURB>(lw.q[JN].x, sPos, sVel, sAux, p.rho0[0], A); \
+		compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
+		if (--leftSeg == 0) { if (!end_segment()) { __builtin_amdgcn_s_setprio(0); return; } }
+		for (;;) {
+			SPHX_RING_STEP(0, 1)
+			SPHX_RING_STEP(1, 2)
+			SPHX_RING_STEP(2, 3)
+			SPHX_RING_STEP(3, 0)
+		}
 	}
+#undef SPHX_RING_PRIO
 #undef SPHX_RING_STEP
 }
-
-// which particle of a tile a thread owns (from the tile descriptor alone)
-struct TileHome { uint32_t index, li, firstMin, hcTot; int hrow; bool inRange, mine; };
-
-__device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t tid, uint32_t fromParticle, uint32_t toParticle)
-{
-	TileHome h;
-	const uint32_t c0 = d[8], c1n = d[9], c2n = d[10], c3n = d[11];
-	h.hcTot = c0 + c1n + c2n + c3n;
-	uint32_t firstMin = 0xFFFFFFFFu, lastMax = 0u;
-#pragma unroll
-	for (int r = 0; r < TILE_HROWS; ++r)
-		if (d[8 + r]) { firstMin = min(firstMin, d[4 + r]); lastMax = max(lastMax, d[4 + r] + d[8 + r]); }
-	h.firstMin = firstMin;
-	h.inRange = !(firstMin >= toParticle || lastMax <= fromParticle);
-	int hrow = 0; uint32_t hoff = tid;
-	if (hoff >= c0) { hoff -= c0; hrow = 1; if (hoff >= c1n) { hoff -= c1n; hrow = 2; if (hoff >= c2n) { hoff -= c2n; hrow = 3; } } }
-	const uint32_t hfirst = (hrow == 0) ? d[4] : (hrow == 1) ? d[5] : (hrow == 2) ? d[6] : d[7];
-	h.hrow = hrow;
-	h.index = hfirst + hoff;
-	h.mine = h.inRange && tid < h.hcTot && h.index >= fromParticle && h.index < toParticle;
-	h.li = h.mine ? h.index : (firstMin != 0xFFFFFFFFu ? firstMin : 0u);   // idle lanes read a valid row
-	return h;
-}
-
-// a thread's own rows and the first batches of its neighbour list, requested one tile ahead
-struct TileOwn { particleinfo info; uint32_t hash, slot; ListWindow lwF; uint2 lwB0; float4 aux; };
 
 // tail of SPSstressMatrixDevice (src/cuda/visc_kernel.cu:780-811): shear rate -> nu_SPS, tau
 __device__ __forceinline__ void stress_finalize(const DevParams &p, const ForcesArgs &a, uint32_t index, float rho,
@@ -1002,6 +1162,8 @@ __device__ __forceinline__ void stress_finalize(const DevParams &p, const Forces
 // starts: a readfirstlane at request time would wait for the load there and then
 // (a workgroup of TILE_WAVES waves: wave w stages the TILE_RPW rows w, w + TILE_WAVES, ...)
 static_assert(TILE_WAVES*TILE_RPW == TILE_WROWS && (TILE_WAVES % 2) == 0, "the window rows are dealt out evenly, two rows per table word");
+static_assert(TILE_WAVES == 8 && TILE_CHUNKS <= 2*TILE_WAVES && TILE_CHUNKS <= 15 && TILE_RUNS_MAX <= 24 && TILE_RT_RUN + TILE_RUNS_MAX <= TILE_RUNTAB && TILE_RUNTAB <= 64,
+	"run table: a wave finalizes the chunks w and w + 8; chunk numbers are 4 bits, run numbers 5; one table word per lane");
 struct RowRaw { uint32_t w[3*TILE_RPW]; };
 struct RowJobs { uint32_t start[TILE_RPW], total[TILE_RPW], base[TILE_RPW]; bool contig[TILE_RPW]; };
 __device__ __forceinline__ void request_row_jobs(const uint32_t *__restrict__ tileRows, uint32_t tile, uint32_t wave, RowRaw &r)
@@ -1029,6 +1191,16 @@ __device__ __forceinline__ void resolve_row_jobs(const RowRaw &r, uint32_t wave,
 
 #define TILE_HCH (TILE_RPW > 2 ? 3 : 5)   // 64-record chunks of a window row whose cell hashes are fetched along with the DMA (longer rows: later)
 
+// does the tile hold particles of [fromParticle, toParticle)?  (multi-GPU stripes launch the kernel on a range)
+__device__ __forceinline__ bool tile_in_range(const uint32_t *d, uint32_t fromParticle, uint32_t toParticle)
+{
+	uint32_t firstMin = 0xFFFFFFFFu, lastMax = 0u;
+#pragma unroll
+	for (int r = 0; r < TILE_HROWS; ++r)
+		if (d[8 + r]) { firstMin = min(firstMin, d[4 + r]); lastMax = max(lastMax, d[4 + r] + d[8 + r]); }
+	return !(firstMin >= toParticle || lastMax <= fromParticle);
+}
+
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __global__ void __launch_bounds__(TILE_THREADS, 2)
 forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles,
@@ -1045,10 +1217,13 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	constexpr bool NOAUX = STRESS || SA_DSUM || SPSC;   // no EOS rows in the window
 	constexpr bool NOVEL = SA_DIFF;             // no velocity rows
 	constexpr uint32_t WS = WC + 1;   // window arrays: the dummy row the pad entries of the tile lists point to (slot 0) + WC records
+	constexpr int PARTV = STRESS ? 3 : 1;      // float4 rows per lane of a run's partial sums
 	__shared__ __attribute__((aligned(16))) float4 sPos[WS];
-	__shared__ __attribute__((aligned(16))) float4 sVel[WS];
+	__shared__ __attribute__((aligned(16))) float4 sVel[NOVEL ? 1 : WS];
 	// SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}; with one fluid only the two stress rows (SPSC)
-	__shared__ __attribute__((aligned(16))) float4 sAux[SPSC ? 2*WS : SPSW ? 3*WS : WS];
+	__shared__ __attribute__((aligned(16))) float4 sAux[SPSC ? 2*WS : SPSW ? 3*WS : (NOAUX ? 1 : WS)];
+	__shared__ __attribute__((aligned(16))) float4 sPart[PARTV*TILE_RUNS_MAX*64];   // partial sums of the tile's runs (walk_runs)
+	__shared__ uint32_t sLaneRec[TILE_CHUNKS*64];                  // lane records of the tile's chunks: own window row | flags << 16
 	constexpr uint32_t TAU0 = SPSC ? 0u : WS;     // where the stress rows start in sAux
 	__shared__ uint32_t sTileQ[2];                                 // [0] first tile, [1] next tile of this workgroup
 
@@ -1066,7 +1241,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	// (n / perRound)*gridDim + x*perRound + n % perRound, i.e. the same placement as above, but a workgroup that
 	// drew cheap tiles simply draws more (static round-robin left the slowest workgroup ~5 % behind the mean).
 	// Tickets are drawn two tiles ahead by thread 0 and published through LDS, so the atomic's latency is hidden.
-	const bool xcdAware = (gridDim.x & 7u) == 0u && !(a.dbg & 4);
+	const bool xcdAware = (gridDim.x & 7u) == 0u;
 	const uint32_t xcd = xcdAware ? (blockIdx.x & 7u) : 0u;
 	const uint32_t perRound = xcdAware ? (gridDim.x >> 3) : 1u;
 	uint32_t src = xcd;   // XCD whose tickets this workgroup currently draws (thread 0 only): its own, until they run out
@@ -1104,58 +1279,125 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		if (SPSW) { sAux[TAU0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); sAux[TAU0 + WS] = make_float4(0.0f, 0.0f, 0.0f, 1.0f); }
 	}
 	const float inv_h = fast_rcp(p.slength);
-	const bool dyn = p.boundarytype == SPHX_DYN_BOUNDARY;
-	ListRows listRows; listRows.list = a.tileList; listRows.batchBytes = a.tileListStride*(uint32_t)(TILE_NB*sizeof(uint16_t));
-	listRows.rows = a.tileListRows; listRows.pin = a.pin; listRows.dbg = a.dbg;
+	ListStream stream; stream.list = a.tileList; stream.pin = a.pin;
 
-	// software pipeline over tiles: descriptor, window rows, own rows and first list batches of the NEXT tile are fetched
-	// while the current one computes, so a tile costs one memory round trip (the window DMA)
+	// software pipeline over tiles: descriptor, window rows, run table, the lanes' first run and their first list batches of
+	// the NEXT tile are fetched while the current one computes, so a tile costs one memory round trip (the window DMA); the
+	// particles of the PREVIOUS tile are finalized while that DMA is in flight
 	uint32_t dc[TILE_DESC], dn[TILE_DESC];
 #pragma unroll
 	for (int k = 0; k < TILE_DESC; ++k) dc[k] = tiles[(size_t)TILE_DESC*tile + k];
 	RowRaw rrc, rrn;
 	request_row_jobs(a.tileRows, tile, wave, rrc);
-	// the 64 home particles this wave owns (a "chunk" of the tile's thread -> particle map) and the rows of their two list
-	// sections: tile_lists_kernel pairs long chunks with short ones on the waves w and w + 4, which share a SIMD
-	uint32_t wrc = a.tileWaves[(size_t)tile*(TILE_THREADS/64) + wave], wrn = 0;
+	// the tile's run table, one word per lane
+	uint32_t rtc = a.tileRuns[(size_t)TILE_RUNTAB*tile + min(lane, (uint32_t)(TILE_RUNTAB - 1))], rtn = 0u;
+	__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): first descriptor, first run table
 
-	__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): first descriptor
-	// own info, hash, window slot and first list batches: always requested one tile ahead (here: for the first tile), consumed
-	// after the window barrier of their tile; a thread's own position / velocity / EOS row are read from the staged window
-	// (its home cell is part of it), not from memory
-	auto request_own = [&](const TileHome &h, TileOwn &o) {
-		o.info = a.info[h.li]; o.hash = a.hash[h.li]; o.slot = a.tileOwnSlot[h.li];
-		if (SPSC) o.aux = a.aux[h.li];
-		const uint32_t vo = h.li*(uint32_t)(TILE_NB*sizeof(uint16_t));   // byte offset of this particle inside every batch slab
-		preload_list(listRows, vo, 0, o.lwF);
-		// boundary section: most particles have none, so only its first batch is requested up front; the walk
-		// requests the rest when a wave does have boundary neighbours
-		load_list_u(listRows, vo, 1, 0, o.lwB0);
+	// what a wave asks for one tile ahead, once that tile's descriptor and run table are there: the first batches of its list
+	// stream and the particles it will finalize (chunks `wave` and `wave + 8`)
+	struct Ahead { ListWindow lw; uint32_t idx[2]; };
+	auto request_ahead = [&](const uint32_t *d, uint32_t rt, Ahead &o) {
+		const WaveJob j = wave_job(rt, d, wave);
+		if (j.nRuns) {
+			const uint32_t lane8 = lane*(uint32_t)(TILE_NB*sizeof(uint16_t));
+			if (TileAsmRing<TURB>::value) {
+				acc_load<8>(stream, j.firstBatch, 0, (int)j.nBatches - 1, lane8); acc_load<10>(stream, j.firstBatch, 1, (int)j.nBatches - 1, lane8);
+				acc_load<12>(stream, j.firstBatch, 2, (int)j.nBatches - 1, lane8); acc_load<14>(stream, j.firstBatch, 3, (int)j.nBatches - 1, lane8);
+			} else {
+#pragma unroll
+				for (int k = 0; k < TILE_AHEAD; ++k) load_list_b(stream, j.firstBatch, k, (int)j.nBatches - 1, lane8, o.lw.q[k]);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const uint32_t c = wave + (uint32_t)(TILE_WAVES*k);
+			o.idx[k] = (c < j.chunks) ? a.tileLaneIndex[j.laneBase + c*64u + lane] : 0xFFFFFFFFu;
+		}
 	};
-	TileHome hc = tile_home(dc, (wrc >> 28)*64u + lane, a.fromParticle, a.toParticle);
-	TileOwn own;
-	if (hc.inRange) request_own(hc, own);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
-	// SPHX_TILE_DEBUG & 16: every wave adds up where its time goes (100 MHz ticks): 0 total, 1 top barrier (the slowest wave
-	// of the previous tile), 2 DMA + hash issue, 3 landing, 4 conversion, 5 window barrier, 6 set-up + requests of the next
-	// tile, 7 pair loop, 8 drain + finalize, 9 tiles
-	const bool prof = a.prof != nullptr;
-	unsigned long long tBegin = 0, tp = 0, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#define SPHX_PROF(K) do { if (prof) { const unsigned long long tq = wall_clock64(); pacc[K] += tq - tp; tp = tq; } } while (0)
-	if (prof) tBegin = wall_clock64();
+	Ahead ac, an;
+	ac.idx[0] = ac.idx[1] = 0xFFFFFFFFu;
+#pragma unroll
+	for (int k = 0; k < TILE_AHEAD; ++k) ac.lw.q[k] = make_uint2(0u, 0u);
+	an = ac;
+	if (tile_in_range(dc, a.fromParticle, a.toParticle)) request_ahead(dc, rtc, ac);
+
+	// the particles of the tile whose pair phase has just ended, waiting to be finalized: particle, info bits, one value of
+	// its own (sound speed; stress mode: relative density; SA diffusion: gamma) and where its partial sums lie
+	uint32_t fIdx[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+	uint2 fInfo[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+	float fVal[2] = {0.0f, 0.0f};
+	uint32_t fTab[2] = {0u, 0u};           // scalar: first run | runs << 8 of the chunks this wave finalizes
+	bool havePrev = false;
 	float cflRun = 0.0f;   // largest CFL term of this lane's particles over all tiles of the workgroup
+
+	auto finalize_prev = [&]() {
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const uint32_t rf = fTab[k] & 255u, rn = (fTab[k] >> 8) & 255u;     // scalar
+			if (k && !__builtin_amdgcn_ballot_w64(fIdx[k] != 0xFFFFFFFFu)) continue;
+			// the chunk's sums: its runs in list order
+			float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			StressAcc fx = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+			for (uint32_t j = 0; j < rn; ++j) {
+				const float4 *src = sPart + (size_t)(rf + j)*64u + lane;
+				const float4 f0 = src[0];
+				force.x += f0.x; force.y += f0.y; force.z += f0.z; force.w += f0.w;
+				if (STRESS) {
+					const float4 f1 = src[TILE_RUNS_MAX*64], f2 = src[2*TILE_RUNS_MAX*64];
+					fx.x += f1.x; fx.y += f1.y; fx.z += f1.z; fx.w += f1.w; fx.u += f2.x;
+				}
+			}
+			const uint32_t index = fIdx[k];
+			const bool mine = index != 0xFFFFFFFFu && index >= a.fromParticle && index < a.toParticle;
+			if (!mine) continue;
+			particleinfo info;
+			info.x = (unsigned short)(fInfo[k].x & 0xFFFFu); info.y = (unsigned short)(fInfo[k].x >> 16);
+			info.z = (unsigned short)(fInfo[k].y & 0xFFFFu); info.w = (unsigned short)(fInfo[k].y >> 16);
+			if (STRESS) stress_finalize(p, a, index, (fVal[k] + 1.0f)*p.rho0[0], force, fx);
+			else if (SA) {
+				if (PART_TYPE(info) == PT_FLUID) {
+					if (SA_DSUM) a.forces[index].w = force.y + force.x + 0.0f;     // sumPmwNp1 + sumPmwN
+					else if (SA_DIFF) a.forces[index].w = (force.w/fVal[k])/p.rho0[0];
+					else {
+						if (p.simflags & SPHX_ENABLE_DENSITY_SUM) force.w = 0.0f;   // no continuity equation then
+						a.forces[index] = force;      // unfinished: sa_forces_kernel adds the boundary elements, divides by gamma, ...
+					}
+				}
+			} else {
+				Self s;
+				s.pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.gridPos = make_int3(0, 0, 0);
+				s.vel = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.rho = 0.0f;
+				s.fl = (TURB & SPHX_TURB_MF) ? FLUID_NUM(info) : 0u;
+				s.sspeed = fVal[k];
+				// planes, terrain and rigid-body rows need the cell-local position, the mass, the cell (and plane friction the
+				// velocity and the density): few runs, few particles
+				const bool geom = (PART_TYPE(info) == PT_FLUID && (p.simflags & (SPHX_ENABLE_PLANES | SPHX_ENABLE_DEM))) ||
+					(HAS_COMPUTE_FORCE(info) && a.rbforces);
+				if (geom) {
+					s.pos = a.pos[index]; s.gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+					s.vel = a.vel[index]; s.rho = a.aux[index].w;
+				}
+				cflRun = fmaxf(cflRun, finalize_particle(p, a, index, info, s, force));
+			}
+		}
+	};
+
 	const int gs1 = p.gs1;
 	for (;;) {
-		if (prof) tp = wall_clock64();
 		uint32_t drawn = 0;
 		if (tid == 0) drawn = atomicAdd(tileCtl + 4 + src, 1u);   // the tile after next; consumed after the window barrier
 		const int g2 = (int)dc[0], g3 = (int)dc[1], ca = (int)dc[2], ncells = (int)dc[3];
-		const bool inRange = hc.inRange, mine = hc.mine;
-		const uint32_t index = hc.index;
-		const bool pairs = ((dc[13] & 1u) || STRESS) && (a.dbg & 3) != 1;   // no fluid anywhere in the window: nothing interacts
-		const uint32_t voff = hc.li*(uint32_t)(TILE_NB*sizeof(uint16_t));
+		const bool inRange = tile_in_range(dc, a.fromParticle, a.toParticle);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
+		const bool pairs = (dc[13] & 1u) || STRESS;   // no fluid anywhere in the window: nothing interacts
 
-		lds_barrier();   // the previous tile's readers are done with LDS
-		SPHX_PROF(1);
+		lds_barrier();   // the previous tile's pair phase is over: its partial sums are complete, the window is free
+		// everything requested so far landed long ago (the requests were made before the pair phase); waiting for it HERE
+		// keeps the finalize stage below from queueing behind the DMA that is issued next
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+#pragma unroll
+		for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(fInfo[k].x), "+v"(fInfo[k].y), "+v"(fVal[k]), "+v"(fIdx[k]));
+		// ... which includes what the previous tile's ring fetched past its end and the batches requested for this tile
+		if (TileAsmRing<TURB>::value) acc_fetch_ahead(ac.lw);
 		const uint32_t nextTile = __builtin_amdgcn_readfirstlane(sTileQ[1]);
 		const bool haveNext = nextTile < tileEnd;
 		if (haveNext) {
@@ -1170,7 +1412,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		//    (tile_shift of the record's cell: row from the row number, column from the hash) -- no other wave has to wait for
 		//    that, the one barrier below publishes the finished window
 		uint32_t hsh[TILE_RPW][TILE_HCH];
-		if (inRange && pairs && (a.dbg & 3) != 2) {
+		if (inRange && pairs) {
 #pragma unroll
 			for (int k = 0; k < TILE_RPW; ++k) {
 				const uint32_t total = rjc.total[k], base = rjc.base[k], rs = rjc.start[k];
@@ -1189,14 +1431,24 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					if ((uint32_t)c*64u + lane < total) hsh[k][c] = a.hash[rs + (uint32_t)c*64u + lane];
 			}
 		}
+		const WaveJob wj = wave_job(rtc, dc, wave);
+		if (inRange && pairs) {      // ... and the lane records of the chunks (wave w: chunks w and w + 8), 4 bytes per lane
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				const uint32_t c = wave + (uint32_t)(TILE_WAVES*k);
+				if (c < wj.chunks)
+					__builtin_amdgcn_global_load_lds((gptr_t)(a.tileLaneRec + wj.laneBase + c*64u + lane), (lptr_t)(sLaneRec + c*64u), 4, 0, 0);
+			}
+		}
 		if (haveNext) {   // behind the DMA in the memory pipeline, consumed when the next tile starts
 			request_row_jobs(a.tileRows, nextTile, wave, rrn);
-			wrn = a.tileWaves[(size_t)nextTile*(TILE_THREADS/64) + wave];
+			rtn = a.tileRuns[(size_t)TILE_RUNTAB*nextTile + min(lane, (uint32_t)(TILE_RUNTAB - 1))];
 		}
-		SPHX_PROF(2);
-		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA, hashes (and its own rows, list batches) have landed
-		SPHX_PROF(3);
-		if (inRange && pairs && (a.dbg & 3) != 2) {
+		// 2. finalize the previous tile while the DMA is in flight: partial sums from LDS, the particle's own data from
+		//    registers (requested before that tile's pair phase), results to memory
+		if (havePrev) finalize_prev();
+		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA and hashes have landed
+		if (inRange && pairs) {
 #pragma unroll
 			for (int k = 0; k < TILE_RPW; ++k) {
 				const uint32_t total = rjc.total[k], base = rjc.base[k], rs = rjc.start[k];
@@ -1255,109 +1507,44 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				}
 			}
 		}
-		SPHX_PROF(4);
-		__syncthreads();                      // everybody's rows are in place and converted
-		SPHX_PROF(5);
+		__syncthreads();                      // everybody's rows are in place and converted; the previous tile's sums are consumed
 		if (tid == 0) sTileQ[1] = resolve(drawn);   // read after the first barrier of the next iteration
-		TileHome hn = hc;
-		TileOwn ownNext;
-		if (haveNext) {
-			hn = tile_home(dn, (wrn >> 28)*64u + lane, a.fromParticle, a.toParticle);
-			if (hn.inRange) request_own(hn, ownNext);
+		// 3. requests: the next tile's first batches and lanes; the own data of THIS tile's particles for its finalize stage
+		const bool nextInRange = haveNext && tile_in_range(dn, a.fromParticle, a.toParticle);
+		if (nextInRange) request_ahead(dn, rtn, an);
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const uint32_t c = wave + (uint32_t)(TILE_WAVES*k);
+			fIdx[k] = inRange ? ac.idx[k] : 0xFFFFFFFFu;
+			// a tile whose window was not staged (no fluid in reach) has only wall particles at home: no runs were walked
+			fTab[k] = (inRange && pairs && c < wj.chunks) ? (uint32_t)__builtin_amdgcn_readlane((int)rtc, (int)(TILE_RT_CHUNK + c)) : 0u;
+			const uint32_t li = (fIdx[k] != 0xFFFFFFFFu) ? fIdx[k] : 0u;
+			if (k == 0 || __builtin_amdgcn_ballot_w64(fIdx[k] != 0xFFFFFFFFu)) {
+				fInfo[k] = reinterpret_cast<const uint2*>(a.info)[li];
+				if (STRESS) fVal[k] = reinterpret_cast<const float*>(a.vel)[4u*(size_t)li + 3u];
+				else if (SA_DIFF) fVal[k] = reinterpret_cast<const float*>(a.saGam)[4u*(size_t)li + 3u];
+				else if (!SA) fVal[k] = reinterpret_cast<const float*>(a.aux)[4u*(size_t)li + 1u];
+			}
 		}
-		const particleinfo info = own.info;
-		// own rows from the window (already in the tile's frame); a tile whose window was not staged (no fluid in reach) has
-		// only wall particles at home: they read the dummy row and write zeros
-		const uint32_t oslot = (inRange && pairs) ? own.slot : 0u;
-		const float4 opos = lds_row(sPos, oslot), ovel = NOVEL ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : lds_row(sVel, oslot);
-		const float3 q = make_float3(opos.x, opos.y, opos.z);
-		Self s;
-		s.pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.gridPos = make_int3(0, 0, 0);     // cell-local position: finalize stage, on demand
-		s.vel = ovel;
-		s.fl = (TURB & SPHX_TURB_MF) ? FLUID_NUM(info) : 0u;
-		if (STRESS) {
-			s.rho = (ovel.w + 1.0f)*p.rho0[0];
-		} else if (!NOAUX || SPSC) {
-			const float4 oaux = SPSC ? own.aux : lds_row(sAux, oslot);      // SPSC: the own EOS row came with the own info, from memory
-			s.p_precalc = oaux.x; s.sspeed = oaux.y; s.P = oaux.z; s.rho = oaux.w;
-			s.inv_rho = fast_rcp(oaux.w);
-		}
-		if (SA_DIFF) s.sa_dt2rho = a.saDt*2.0f*s.rho;
-		if (TURB & SPHX_TURB_NEWT) init_visc(p, s);
-		if (SPSW) {   // own stress tensor
-			const float4 ta = lds_row(sAux + TAU0, oslot), tb = lds_row(sAux + TAU0 + WS, oslot);
-			s.tau[0] = ta.x; s.tau[1] = ta.y; s.tau[2] = ta.z; s.tau[3] = ta.w; s.tau[4] = tb.x; s.tau[5] = tb.y;
-		}
-		ListWindow lwB;
-		lwB.q[0] = own.lwB0;
 
-		// 2. pair loop for the tile's own particles (<= 512, one per thread); wave-uniform control
-		float cfl_term = 0.0f;
-		const bool active = mine;     // home particles sit in cells, i.e. they are active
-		float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		StressAcc fx = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-		SPHX_PROF(6);
-		if (inRange && pairs) {
-			const uint32_t ptype = PART_TYPE(info);
-			const bool isFluid = ptype == PT_FLUID, isBound = ptype == PT_BOUNDARY, isDynBound = isBound && dyn;
-			// fluid: fluid section then boundary section (DYN: SPH pairs, LJ: repulsion); DYN boundary: fluid section
-			// only, with the momentum part only for bodies with force feedback (forces_kernel.def:3650-3679);
-			// LJ boundary: fluid section only for bodies with force feedback, when object forces are asked for (:3620-3645)
-			const bool momentum = isFluid || HAS_COMPUTE_FORCE(info);
-			const bool ljlane = LJ && isBound;
-			// SA_BOUNDARY modes: fluid particles only, fluid section then vertex section (none in the diffusion)
-			const bool take0 = active && (SA ? isFluid : (STRESS || isFluid || isDynBound || (ljlane && HAS_COMPUTE_FORCE(info) && a.compute_object_forces)));
-			const bool take1 = active && (SA ? (isFluid && !SA_DIFF) : (STRESS || (isFluid && (dyn || LJ))));
-			const int rowsF = (int)(wrc & 0xFFFFu), rowsB = (int)((wrc >> 16) & 0xFFFu);
-			if (wave_any(take0))
-				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, q, inv_h,
-					sPos, sVel, sAux, 0, rowsF, take0, momentum, true, ljlane, own.lwF, TILE_AHEAD, force, fx);
-			if (PREMUL && !take0) force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // pair_interact_pk has no per-lane validity flag
-			if (wave_any(take1)) {
-				const float4 keep = force;
-				walk_section_lds<KERNEL, TURB, COLAGROSSI, LJ>(p, listRows, voff, s, q, inv_h,
-					sPos, sVel, sAux, 1, rowsB, take1, momentum, false, false, lwB, 1, force, fx);
-				if (PREMUL && !take1) force = keep;
-			}
-			if (PREMUL && !momentum) { force.x = 0.0f; force.y = 0.0f; force.z = 0.0f; }   // ... and no momentum switch
-		}
-		SPHX_PROF(7);
-		// vmcnt(0): only the list batches fetched past the section ends are in flight, all long complete; from here to the
-		// loop head only stores are issued, which nobody waits for
-		__builtin_amdgcn_s_waitcnt(0x0F70);
-		if (active) {
-			if (STRESS) stress_finalize(p, a, index, s.rho, force, fx);
-			else if (SA) {
-				if (PART_TYPE(info) == PT_FLUID) {
-					if (SA_DSUM) a.forces[index].w = force.y + force.x + 0.0f;     // sumPmwNp1 + sumPmwN
-					else if (SA_DIFF) a.forces[index].w = (force.w/a.saGam[index].w)/p.rho0[s.fl];
-					else {
-						if (p.simflags & SPHX_ENABLE_DENSITY_SUM) force.w = 0.0f;   // no continuity equation then
-						a.forces[index] = force;      // unfinished: sa_forces_kernel adds the boundary elements, divides by gamma, ...
-					}
-				}
-			} else {
-				// planes, terrain and rigid-body rows need the cell-local position, the mass and the cell: few runs, few particles
-				const bool geom = (PART_TYPE(info) == PT_FLUID && (p.simflags & (SPHX_ENABLE_PLANES | SPHX_ENABLE_DEM))) ||
-					(HAS_COMPUTE_FORCE(info) && a.rbforces);
-				if (geom) { s.pos = a.pos[index]; s.gridPos = grid_pos_from_hash(p, own.hash & CELLTYPE_BITMASK); }
-				cfl_term = finalize_particle(p, a, index, info, s, force);
-			}
-		}
-		cflRun = fmaxf(cflRun, cfl_term);
-		SPHX_PROF(8);
-		if (prof) pacc[9] += 1;
+		// 4. the pair phase: this wave's share of the tile's list batches
+		if (inRange && pairs && wj.nRuns)
+			walk_runs<KERNEL, TURB, COLAGROSSI, LJ>(p, a, stream, wj, rtc, lane, inv_h, sPos, sVel, sAux, sPart, sLaneRec, ac.lw);
+		havePrev = inRange;
 		if (!haveNext) break;
 		tile = nextTile;
 #pragma unroll
 		for (int k = 0; k < TILE_DESC; ++k) dc[k] = dn[k];
-		rrc = rrn; wrc = wrn;
-		hc = hn; own = ownNext;
+		rrc = rrn; rtc = rtn;
+		ac = an;
 	}
+	lds_barrier();
+	__builtin_amdgcn_s_waitcnt(0x0F70);
+	if (havePrev) finalize_prev();
 	// CFL: the array is only ever max-reduced (fmaxDevice / dtreduce), so the maxima need not sit in the reference's
 	// one-entry-per-128-particles places: every wave maxes its running value into one entry of the caller's range, once per
 	// launch.  Non-negative floats order like their bit patterns; the caller zeroed CFL.
-	if (!STRESS && a.cfl) {
+	if (!STRESS && !SA && a.cfl) {
 #pragma unroll
 		for (int dd = 32; dd > 0; dd >>= 1)
 			cflRun = fmaxf(cflRun, __shfl_down(cflRun, dd));
@@ -1365,13 +1552,6 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			atomicMax(reinterpret_cast<unsigned int*>(a.cfl + a.cflOffset + (blockIdx.x*(TILE_THREADS/64) + wave) % a.numBlocks), __float_as_uint(cflRun));
 	}
 	if (tid == 0) tile_group_done(tileCtl);
-	if (prof && lane == 0) {
-		unsigned long long *o = a.prof + 10*((size_t)blockIdx.x*(TILE_THREADS/64) + wave);
-		pacc[0] = wall_clock64() - tBegin;
-#pragma unroll
-		for (int k = 0; k < 10; ++k) o[k] = pacc[k];
-	}
-#undef SPHX_PROF
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1741,28 +1921,64 @@ void SPHX_PASTE(sphx_part_sps_k, SPHX_FORCES_PART)(const sphx_ctx *ctx, dim3 gri
 
 // ------------------------------------------------------------------------------------------
 // Tile lists: the reference-format neighbour lists of the tiled particles, translated once per neighbour-list build
-// into the form the tiled pair loop walks (see ListRows above).  One workgroup per tile with the forces kernel's
-// thread -> particle map (tile_home) and its window layout: window row r holds the cells of grid row (g2-1+(r&3),
-// g3-1+(r>>2)) from column ca-1 on, rows follow each other without gaps, so the slot of a record is
-// (records of the rows before) + (records of the cells before it in its row) + its index in its cell.
-// The kernel also lays the window out for the forces kernel (tile_rows: first record, length and first slot of each of
-// the 16 rows, and whether the row is one range in memory) and balances the tile's waves (below).
+// into the form the tiled pair loop walks (see walk_runs above).  One workgroup per tile, one thread per home particle:
+//  1. the window layout of the tile (tile_rows: first record, length and first slot of each of the 16 rows, and whether the
+//     row is one range in memory): window row r holds the cells of grid row (g2-1+(r&3), g3-1+(r>>2)) from column ca-1 on, rows
+//     follow each other without gaps, so the slot of a record is (records of the rows before) + (records of the cells before
+//     it in its row) + its index in its cell;
+//  2. the home particles sorted by the length of their fluid section, longest first (a stable counting sort on the lengths the
+//     list builder left in neib_counts), and cut into chunks of 64: the lanes of a wave then walk lists of nearly equal
+//     length (in home order a chunk is padded to its longest list: 14 % of the pair slots were padding);
+//  3. the schedule: all batches of the tile (chunk after chunk, fluid section then second section, each padded to the chunk's
+//     longest) split evenly over the eight waves of the forces kernel -> runs (a wave's stretch of one chunk), the run table;
+//  4. space for the tile's list stream and lane tables from two global cursors (tile_ctl[12], [13]);
+//  5. the translation: every lane rewrites its particle's entries as window offsets (slot * 16: the byte offset of the
+//     neighbour's row in the window arrays, used as the LDS address as it is), four to a batch, padded with offset 0 (the
+//     dummy record), straight into the stream position its wave will read it from (512-byte coalesced stores).
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(TILE_THREADS)
-tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t *__restrict__ hash,
+#define TL_THREADS TILE_PMAX
+#define TL_BINS 132      // list lengths 0..128 (+ padding)
+
+// which home particle of the tile thread t stands for: the four home rows one after the other (build_tiles_kernel)
+struct TileHome { uint32_t index; int hrow; };
+__device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t t)
+{
+	TileHome h;
+	const uint32_t c0 = d[8], c1n = d[9], c2n = d[10];
+	int hrow = 0; uint32_t hoff = t;
+	if (hoff >= c0) { hoff -= c0; hrow = 1; if (hoff >= c1n) { hoff -= c1n; hrow = 2; if (hoff >= c2n) { hoff -= c2n; hrow = 3; } } }
+	const uint32_t hfirst = (hrow == 0) ? d[4] : (hrow == 1) ? d[5] : (hrow == 2) ? d[6] : d[7];
+	h.hrow = hrow;
+	h.index = hfirst + hoff;
+	return h;
+}
+
+__global__ void __launch_bounds__(TL_THREADS)
+tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t *__restrict__ neibCounts,
+	const particleinfo *__restrict__ info, const uint32_t *__restrict__ hash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
-	const uint32_t *__restrict__ tiles, uint32_t *tileCtl, uint32_t *__restrict__ tileRows,
-	uint16_t *__restrict__ tileList, uint32_t listStride, uint32_t listRows, uint32_t *__restrict__ tileWaves,
-	uint16_t *__restrict__ tileOwnSlot, int saVertex /* SA_BOUNDARY lists: the second section is the VERTEX section */)
+	uint32_t *__restrict__ tiles, uint32_t *tileCtl, uint32_t *__restrict__ tileRows, uint32_t *__restrict__ tileRuns,
+	uint2 *__restrict__ tileList, uint32_t listCapBatches, uint32_t *__restrict__ laneRec, uint32_t *__restrict__ laneIndex,
+	uint32_t laneCap, int saVertex /* SA_BOUNDARY lists: the second section is the VERTEX section */)
 {
 	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW], sCellBase[TILE_WROWS*TILE_KW], sCellStart[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sRowTotal[TILE_WROWS], sRowStart[TILE_WROWS], sRowContig[TILE_WROWS], sRowBase[TILE_WROWS];
 	__shared__ int sCodeOff[32];                                   // cell code-1 -> window-table offset
 	__shared__ uint16_t sCB[TILE_HROWS*TILE_MAXCELLS*27 + 8];      // [home cell][code] -> slot of the cell's first record
-	__shared__ uint32_t sChunkRows[TILE_THREADS/64];
-	if (tileCtl[1]) return;                 // tiling overflowed: the generic kernel handles this list
+	__shared__ uint16_t sHist[TILE_CHUNKS][TL_BINS];               // per wave: particles with a fluid section of that length; then: ... in the waves before
+	__shared__ uint16_t sBinTot[TL_BINS], sBinStart[TL_BINS];
+	__shared__ uint16_t sPerm[TILE_PMAX], sLenF[TILE_PMAX], sLenB[TILE_PMAX];   // by lane of the tile: home-order number, list lengths
+	__shared__ uint32_t sChunkF[TILE_CHUNKS + 1], sChunkB[TILE_CHUNKS + 1], sChunkStart[TILE_CHUNKS + 1];   // batches per section; first batch
+	__shared__ uint32_t sSorted[32];
+	__shared__ uint32_t sRunTab[TILE_RUNTAB];
+	__shared__ uint32_t sBase[4];                                  // list base, lane base, overflow
+	const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+	// tiling overflowed: the generic kernel handles this list.  (One read per workgroup: another workgroup of this very kernel may
+	// raise the flag at any time, and threads that disagree about it would not meet at the barriers below)
+	if (tid == 0) sBase[3] = tileCtl[1];
+	__syncthreads();
+	if (sBase[3]) return;
 	const uint32_t numTiles = tileCtl[0];
-	const uint32_t tid = threadIdx.x;
 	// neighbour-cell offset (ox,oy,oz) -> index of that cell in the window table, relative to the
 	// particle's own (row, column): o1 + KW*(o2+1) + 4*KW*(o3+1) + 1 with (o1,o2,o3) the offsets along COORD1..3
 	if (tid < 27) {
@@ -1782,6 +1998,9 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 #pragma unroll
 		for (int k = 0; k < TILE_DESC; ++k) d[k] = tiles[(size_t)TILE_DESC*tile + k];
 		const int ca = (int)d[2];
+		const uint32_t P = d[8] + d[9] + d[10] + d[11];        // home particles (<= TILE_PMAX)
+		const uint32_t C = (P + 63u)/64u;
+		for (uint32_t e = tid; e < TILE_CHUNKS*TL_BINS; e += TL_THREADS) (&sHist[0][0])[e] = 0;
 		if (tid < TILE_WROWS*TILE_KW) {
 			uint32_t wStart = 0, wCnt = 0;
 			window_cell(p, cellStart, cellEnd, (int)d[0], (int)d[1], ca, (int)d[3], wr, wcol, wStart, wCnt);
@@ -1831,114 +2050,214 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			const uint32_t b1 = (sRowBase[2*k + 1] & 0x7FFFu) | (sRowContig[2*k + 1] ? 0u : 0x8000u);
 			tileRows[(size_t)TILE_ROWDESC*tile + 24u + k] = b0 | (b1 << 16);
 		}
-		for (uint32_t e = tid; e < TILE_HROWS*TILE_MAXCELLS*27; e += TILE_THREADS) {
+		for (uint32_t e = tid; e < TILE_HROWS*TILE_MAXCELLS*27; e += TL_THREADS) {
 			const uint32_t m = e/27u, c1 = e - m*27u;
 			const uint32_t hr = m/TILE_MAXCELLS, col = m - hr*TILE_MAXCELLS;
 			sCB[e + 1] = (uint16_t)sCellBase[sCodeOff[c1] + (int)(((hr & 1u) + 4u*(hr >> 1))*TILE_KW + col)];
 		}
+
+		// ---- 2. sort the home particles by the length of their fluid section, longest first; equal lengths keep their home order
+		bool overflow = false;
+		uint32_t F = 0, B = 0;
+		const bool inHome = tid < P;
+		if (inHome) {
+			const uint32_t cnt = neibCounts[tile_home(d, tid).index];
+			F = cnt & 0xFFFFu; B = cnt >> 16;
+			const uint32_t maxF = p.neiblistsize, maxB = saVertex ? p.neiblistsize - p.neibboundpos - 1u : p.neibboundpos + 1u;
+			if (F > 128u || F > maxF || B > 128u || B > maxB) { overflow = true; F = 0; B = 0; }   // not a list of the builder (an overflowed one)
+		}
+		uint32_t rankInWave = 0;
+		{
+			unsigned long long rem = __builtin_amdgcn_ballot_w64(inHome);
+			while (rem) {
+				const int lead = __builtin_ctzll(rem);
+				const uint32_t v = (uint32_t)__builtin_amdgcn_readlane((int)F, lead);
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(inHome && F == v);
+				if (inHome && F == v) rankInWave = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+				if ((int)lane == lead) sHist[wave][v] = (uint16_t)__builtin_popcountll(m);
+				rem &= ~m;
+			}
+		}
 		__syncthreads();
-		const TileHome h = tile_home(d, tid, 0u, 0xFFFFFFFFu);
-		const bool mine = tid < h.hcTot;
-		const uint32_t index = h.li;
+		if (tid < 129u) {      // per length: particles in the waves before each wave, and in all
+			uint32_t run = 0;
+			for (uint32_t w = 0; w < TILE_CHUNKS; ++w) { const uint32_t c = sHist[w][tid]; sHist[w][tid] = (uint16_t)run; run += c; }
+			sBinTot[tid] = (uint16_t)run;
+		}
+		__syncthreads();
+		if (tid < 129u) {      // longest first: a length starts behind all longer ones
+			uint32_t s = 0;
+			for (uint32_t b2 = tid + 1u; b2 <= 128u; ++b2) s += sBinTot[b2];
+			sBinStart[tid] = (uint16_t)s;
+		}
+		__syncthreads();
+		if (inHome) {
+			const uint32_t pos = (uint32_t)sBinStart[F] + sHist[wave][F] + rankInWave;
+			sPerm[pos] = (uint16_t)tid; sLenF[pos] = (uint16_t)F; sLenB[pos] = (uint16_t)B;
+		}
+		__syncthreads();
+		// from here on thread L is LANE L of the tile: lane L & 63 of chunk L >> 6 (= this thread's wave)
+		const uint32_t L = tid;
+		const bool valid = L < P;
+		const uint32_t myF = valid ? sLenF[L] : 0u, myB = valid ? sLenB[L] : 0u;
+		const TileHome h = tile_home(d, valid ? (uint32_t)sPerm[L] : 0u);
+		const uint32_t index = h.index;
+		{	// the chunk's sections are padded to its longest list, in whole batches
+			uint32_t mxF = myF, mxB = myB;
+#pragma unroll
+			for (int dd = 32; dd > 0; dd >>= 1) {
+				mxF = max(mxF, (uint32_t)__shfl_xor(mxF, dd)); mxB = max(mxB, (uint32_t)__shfl_xor(mxB, dd));
+			}
+			if (lane == 0) { sChunkF[wave] = (mxF + TILE_NB - 1u)/TILE_NB; sChunkB[wave] = (mxB + TILE_NB - 1u)/TILE_NB; }
+		}
+		__syncthreads();
+		// ---- 3. + 4. the schedule, by the first wave.  Lane c < 10 stands for chunk c, lane 16 + w for wave w.  The batches of
+		// the tile are numbered 0..T-1 (chunk after chunk); wave w walks [w share, (w+1) share).  A run starts wherever a chunk
+		// or a wave's share starts: the run boundaries are the set S of those numbers, a run's number is its rank in S.
+		if (wave == 0) {
+			uint32_t nF = 0, nB = 0;
+			if (lane < C) { nF = sChunkF[lane]; nB = sChunkB[lane]; }
+			uint32_t incl = nF + nB;            // inclusive scan over the chunk lanes -> first batch of every chunk
+#pragma unroll
+			for (int dd = 1; dd < 16; dd <<= 1) {
+				const uint32_t t = __shfl_up(incl, dd, 16);
+				if ((lane & 15u) >= (uint32_t)dd) incl += t;
+			}
+			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
+			const uint32_t share = (T + TILE_WAVES - 1u)/TILE_WAVES;
+			const uint32_t cStart = incl - (nF + nB), cEnd = incl;
+			const bool isChunk = lane < C && nF + nB > 0u;
+			const bool isWave = lane >= 16u && lane < 16u + TILE_WAVES;
+			const uint32_t ws = isWave ? min((lane - 16u)*share, T) : 0u, we = isWave ? min((lane - 15u)*share, T) : 0u;
+			// my boundary point (chunk lanes: the chunk's first batch; wave lanes: the share's first batch) and the range I ask about
+			const uint32_t lo = isChunk ? cStart : ws, hi = isChunk ? cEnd : we;
+			// a wave's start that is also a chunk's start is one boundary, the chunk's
+			bool dup = false;
+			uint32_t cntLt = 0, cntIn = 0, cstar = 0;
+			// chunk lanes first: which wave starts coincide with a chunk start
+			for (int q = 0; q < (int)TILE_CHUNKS; ++q) {
+				const bool qv = (__builtin_amdgcn_ballot_w64(isChunk) >> q) & 1ull;
+				if (!qv) continue;
+				const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)cStart, q);
+				if (isWave && x == ws) dup = true;
+				if (x <= lo) cstar = (uint32_t)q;                    // the chunk my boundary point lies in (the last one starting at or before it)
+				cntLt += (x < lo) ? 1u : 0u; cntIn += (x >= lo && x < hi) ? 1u : 0u;
+			}
+			const bool inS = isChunk || (isWave && ws < T && !dup);
+			for (int q = 16; q < 16 + (int)TILE_WAVES; ++q) {
+				const bool qv = (__builtin_amdgcn_ballot_w64(inS) >> q) & 1ull;
+				if (!qv) continue;
+				const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)ws, q);
+				cntLt += (x < lo) ? 1u : 0u; cntIn += (x >= lo && x < hi) ? 1u : 0u;
+			}
+			const uint32_t R = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(inS));   // runs of the tile
+			if (inS) sSorted[cntLt] = lo;         // cntLt = my rank in S
+			if (lane < TILE_RUNTAB) sRunTab[lane] = 0u;
+			// (one wave: its LDS operations execute in order; the fences only keep the compiler from moving them)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+			const uint32_t chunkSel = isChunk ? lane : cstar;
+			const uint32_t chStart = __shfl(cStart, (int)chunkSel), chF = __shfl(nF, (int)chunkSel);
+			if (inS) {         // my run: from my boundary point to the next one
+				const uint32_t r = cntLt;
+				const uint32_t end = (r + 1u < R) ? sSorted[r + 1u] : T;
+				const uint32_t a0 = lo - chStart, len = end - lo;
+				const uint32_t runF = (a0 < chF) ? min(chF - a0, len) : 0u;
+				sRunTab[TILE_RT_RUN + min(r, (uint32_t)(TILE_RUNS_MAX - 1))] = chunkSel | (runF << 4) | ((len - runF) << 12);
+			}
+			// wave (lane - 16): first run (the one starting at its first batch: that batch is a boundary), the runs that start
+			// inside its share, first batch, batches
+			if (isWave) sRunTab[lane - 16u] = (ws < T) ? (cntLt | (cntIn << 5) | (ws << 10) | ((we - ws) << 22)) : 0u;
+			if (lane < TILE_CHUNKS) {
+				sRunTab[TILE_RT_CHUNK + lane] = isChunk ? (cntLt | (cntIn << 8)) : 0u;
+				sChunkStart[lane] = cStart;
+			}
+			if (lane == 0) {
+				sRunTab[8] = C | (P << 8) | (R << 24);
+				// ---- 4. room in the list stream and in the lane tables
+				const uint32_t lb = atomicAdd(tileCtl + 12, T), nb2 = atomicAdd(tileCtl + 13, C*64u);
+				const bool ovf = (uint64_t)lb + T > listCapBatches || (uint64_t)nb2 + C*64u > laneCap || R > TILE_RUNS_MAX || T >= 4096u || share >= 1024u;
+				sBase[0] = lb; sBase[1] = nb2; sBase[2] = ovf ? 1u : 0u;
+			}
+		}
+		__syncthreads();
+		if (sBase[2]) overflow = true;
+		const uint32_t listBase = sBase[0], laneBase = sBase[1];
+		if (!sBase[2]) {
+			if (tid == 0) { tiles[(size_t)TILE_DESC*tile + 14] = listBase; tiles[(size_t)TILE_DESC*tile + 15] = laneBase; }
+			if (tid < TILE_RUNTAB) tileRuns[(size_t)TILE_RUNTAB*tile + tid] = sRunTab[tid];
+		}
+		// ---- 5. the lane tables and the translated lists
 		const int3 gp = grid_pos_from_hash(p, hash[index] & CELLTYPE_BITMASK);
 		const int myG1 = (p.c1 == 0) ? gp.x : (p.c1 == 1) ? gp.y : gp.z;
 		const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
 		const uint16_t *myCB = sCB + (h.hrow*TILE_MAXCELLS + myCol)*27;
-		bool overflow = false;
-		if (mine) {   // the particle's own row in the window (the forces kernel reads its position, velocity and EOS row there)
-			const int wc = (5 + (h.hrow & 1) + 4*(h.hrow >> 1))*TILE_KW + myCol + 1;
-			const uint32_t slot = 1u + sCellBase[wc] + (index - sCellStart[wc]);
-			if (slot > 4095u) overflow = true;
-			tileOwnSlot[index] = (uint16_t)(slot << 4);
-		}
-		uint32_t rowsSec[2] = {0u, 0u};
-		const uint32_t slabs = listRows/TILE_NB;
+		if (wave < C && !sBase[2]) {
+			uint32_t rec = 0u, idx = 0xFFFFFFFFu;
+			if (valid) {   // the particle's own row in the window (the forces kernel reads its position, velocity and EOS row there)
+				const int wc = (5 + (h.hrow & 1) + 4*(h.hrow >> 1))*TILE_KW + myCol + 1;
+				const uint32_t slot = 1u + sCellBase[wc] + (index - sCellStart[wc]);
+				if (slot > 4095u) overflow = true;
+				const particleinfo pi = info[index];
+				const uint32_t flags = PART_TYPE(pi) | (HAS_COMPUTE_FORCE(pi) ? LANE_COMPUTE_FORCE : 0u) | ((FLUID_NUM(pi) & 3u) << LANE_FLUID_SHIFT) | LANE_VALID;
+				rec = ((slot << 4) & 0xFFFFu) | (flags << 16);
+				idx = index;
+			}
+			laneRec[laneBase + L] = rec; laneIndex[laneBase + L] = idx;
+			const uint32_t chunkStart = sChunkStart[wave];
 #pragma unroll 1
-		for (int sec = 0; sec < 2 && !overflow; ++sec) {
-			// section 0: slots 0 upward, section 1: slots neibboundpos downward (SA_BOUNDARY: the vertex section, slots
-			// neibboundpos + 1 upward; the boundary elements are not particles of a window); each ends at its terminator.
-			// Every lane collects its translated entries four at a time (a batch: one 8-byte store into the batch's slab),
-			// then all lanes are padded with dummy entries up to the wave's longest, rounded up to whole batches
-			const int maxSlots = !sec ? (int)p.neiblistsize : saVertex ? (int)p.neiblistsize - (int)p.neibboundpos - 1 : (int)p.neibboundpos + 1;
-			if (maxSlots <= 0) continue;
-			bool alive = mine;
-			uint32_t code = 0, cur = 0;
-			uint2 pend = make_uint2(0u, 0u);
-			auto put = [&](uint32_t val) {      // entry `cur` of this lane's section
-				const uint32_t k = cur & 3u;
-				if (k == 0u) pend = make_uint2(0u, 0u);
-				if (k < 2u) pend.x |= val << (16u*k); else pend.y |= val << (16u*(k - 2u));
-				if (k == 3u) {
-					const uint32_t b = cur >> 2;
-					if (rowsSec[0]/TILE_NB*(uint32_t)sec + b >= slabs) overflow = true;
-					else {
-						const uint32_t slab = sec ? slabs - 1u - b : b;
-						*reinterpret_cast<uint2*>(tileList + ((size_t)slab*listStride + index)*TILE_NB) = pend;
-					}
-				}
-				++cur;
-			};
-			constexpr int LOADS = 16;   // entries per lane in flight: the walk is latency bound
+			for (int sec = 0; sec < 2; ++sec) {
+				// section 0: slots 0 upward, section 1: slots neibboundpos downward (SA_BOUNDARY: the vertex section, slots
+				// neibboundpos + 1 upward; the boundary elements are not particles of a window).  The chunk's batches of the
+				// section are wave-uniform: every lane writes all of them, padded with the dummy row's offset
+				const uint32_t nbat = sec ? sChunkB[wave] : sChunkF[wave];
+				const uint32_t cnt = sec ? myB : myF;
+				uint2 *out = tileList + ((size_t)listBase + chunkStart + (sec ? sChunkF[wave] : 0u))*64u + lane;
+				uint32_t code = 0;
+				constexpr int LOADS = 16;   // entries per lane in flight: the walk is latency bound
 #pragma unroll 1
-			for (int s0 = 0; s0 < maxSlots; s0 += LOADS) {
-				uint32_t e[LOADS];
+				for (uint32_t b0 = 0; b0 < nbat; b0 += LOADS/TILE_NB) {
+					uint32_t e[LOADS];
 #pragma unroll
-				for (int k = 0; k < LOADS; ++k) {
-					const int slot = min(s0 + k, maxSlots - 1);   // a clamped re-read is only reached by dead lanes
-					const int src = !sec ? slot : saVertex ? (int)p.neibboundpos + 1 + slot : (int)p.neibboundpos - slot;
-					e[k] = list[(size_t)src*stride + index];
-				}
-				if (!wave_any(alive && e[0] != NEIBS_END)) break;   // every list of the wave has ended
-#pragma unroll
-				for (int k = 0; k < LOADS; ++k) {
-					const uint32_t dd = e[k];
-					alive = alive && (s0 + k < maxSlots) && (dd != NEIBS_END);
-					const uint32_t prev = code;
-					code = (dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
-					if (alive && (code < prev || code == 0u || code > 27u)) { overflow = true; alive = false; }   // not a list of the builder (an overflowed one): generic kernel
-					if (alive && mine) {
-						const uint32_t slot = 1u + (uint32_t)myCB[code] + (dd & NEIBINDEX_MASK);   // slot 0 = dummy
-						if (slot > 4095u) { overflow = true; alive = false; }
-						else put(slot << 4);
+					for (int k = 0; k < LOADS; ++k) {
+						const uint32_t sl = min(b0*TILE_NB + (uint32_t)k, cnt ? cnt - 1u : 0u);   // a clamped re-read is never used
+						const uint32_t src = !sec ? sl : saVertex ? p.neibboundpos + 1u + sl : p.neibboundpos - sl;
+						e[k] = cnt ? (uint32_t)list[(size_t)src*stride + index] : 0u;
 					}
+					uint32_t val[LOADS];
+#pragma unroll
+					for (int k = 0; k < LOADS; ++k) {
+						const uint32_t dd = e[k];
+						const bool live = b0*TILE_NB + (uint32_t)k < cnt;
+						const uint32_t prev = code;
+						code = (live && dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
+						// not a list of the builder (an overflowed one, or counts of another list): generic kernel
+						if (live && (dd == NEIBS_END || code < prev || code == 0u || code > 27u)) { overflow = true; code = 1u; }
+						const uint32_t slot = 1u + (uint32_t)myCB[min(code, 27u)] + (dd & NEIBINDEX_MASK);   // slot 0 = dummy
+						if (live && slot > 4095u) overflow = true;
+						val[k] = live ? ((slot << 4) & 0xFFFFu) : 0u;
+					}
+#pragma unroll
+					for (int k = 0; k < LOADS/TILE_NB; ++k)
+						if (b0 + (uint32_t)k < nbat)
+							out[(size_t)(b0 + (uint32_t)k)*64u] = make_uint2(val[4*k] | (val[4*k + 1] << 16), val[4*k + 2] | (val[4*k + 3] << 16));
 				}
 			}
-			// wave maximum, whole batches
-			uint32_t rows = cur;
-#pragma unroll
-			for (int dd = 32; dd > 0; dd >>= 1) rows = max(rows, (uint32_t)__shfl_xor(rows, dd));
-			rows = (rows + TILE_LIST_BATCH - 1u)/TILE_LIST_BATCH*TILE_LIST_BATCH;
-			if (rowsSec[0]*(uint32_t)sec + rows > listRows) overflow = true;
-			if (mine && !overflow)
-				while (cur < rows) put(0u);     // pad: the dummy row
-			rowsSec[sec] = rows;
 		}
-		if (overflow) tileCtl[1] = 1u;      // some wave needs more rows than the tile lists have: generic kernel
-		// Balance: the forces kernel's waves w and w + 4 share a SIMD (a workgroup's waves go round the four SIMDs), and a
-		// tile takes as long as its busiest SIMD.  The chunk (64 consecutive threads of the thread -> particle map) with the
-		// k-th most rows goes to wave k for k < 4 and to wave 11 - k above: the longest shares a SIMD with the shortest.
-		if ((tid & 63u) == 0u) sChunkRows[tid >> 6] = rowsSec[0] | (rowsSec[1] << 16);
-		__syncthreads();
-		if (tid < TILE_THREADS/64) {
-			const uint32_t mineRows = sChunkRows[tid], w = (mineRows & 0xFFFFu) + (mineRows >> 16);
-			uint32_t rank = 0;
-			for (uint32_t c = 0; c < TILE_THREADS/64; ++c) {
-				const uint32_t o = sChunkRows[c], ow = (o & 0xFFFFu) + (o >> 16);
-				rank += (ow > w || (ow == w && c < tid)) ? 1u : 0u;
-			}
-			const uint32_t wv = (TILE_WAVES == 8) ? (rank < 4u ? rank : 11u - rank) : rank;
-			tileWaves[(size_t)tile*(TILE_THREADS/64) + wv] = (mineRows & 0x0FFFFFFFu) | (tid << 28);
-		}
+		if (overflow) tileCtl[1] = 1u;      // generic kernel
 	}
 }
 
-int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st)
+int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void *info, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st)
 {
-	if (!ctx->tile_list || !ctx->tile_waves || !ctx->tile_rows || !ctx->tile_ownslot) { ctx->tiles_built = false; return SPHX_OK; }
+	if (!ctx->tile_list || !ctx->tile_runs || !ctx->tile_rows || !ctx->tile_lane_rec || !ctx->tile_lane_index || !ctx->neib_counts) {
+		ctx->tiles_built = false;
+		return SPHX_OK;
+	}
 	const uint32_t grid = ctx->tile_grid*8u < ctx->tile_capacity ? ctx->tile_grid*8u : ctx->tile_capacity;
-	tile_lists_kernel<<<grid, TILE_THREADS, 0, st>>>(ctx->dev, neibsList, hash, cellStart, ctx->cell_end_copy,
-		ctx->tiles, ctx->tile_ctl, ctx->tile_rows, ctx->tile_list, ctx->tile_list_stride, ctx->tile_list_rows, ctx->tile_waves,
-		ctx->tile_ownslot, sa ? 1 : 0);
+	tile_lists_kernel<<<grid, TL_THREADS, 0, st>>>(ctx->dev, neibsList, ctx->neib_counts, (const particleinfo*)info, hash, cellStart, ctx->cell_end_copy,
+		ctx->tiles, ctx->tile_ctl, ctx->tile_rows, ctx->tile_runs, ctx->tile_list, ctx->tile_list_batches, ctx->tile_lane_rec, ctx->tile_lane_index,
+		ctx->tile_lane_cap, sa ? 1 : 0);
 	SPHX_LAUNCH_CHECK("tile_lists_kernel");
 	return SPHX_OK;
 }
@@ -2006,27 +2325,19 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.tau0 = (const float2*)tau0; a.tau1 = (const float2*)tau1; a.tau2 = (const float2*)tau2;
 	a.rb = ctx->rb_dev;
 	a.aux = ctx->eos_aux;
-	a.tileList = ctx->tile_list; a.tileListRows = ctx->tile_list_rows; a.tileListStride = ctx->tile_list_stride;
-	a.tileWaves = ctx->tile_waves; a.tileRows = ctx->tile_rows; a.tileOwnSlot = ctx->tile_ownslot;
+	a.tileList = ctx->tile_list; a.tileRuns = ctx->tile_runs; a.tileRows = ctx->tile_rows;
+	a.tileLaneRec = ctx->tile_lane_rec; a.tileLaneIndex = ctx->tile_lane_index;
 	a.xsph = (float4*)xsph;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
 	a.numBlocks = numBlocks;
 	a.compute_object_forces = compute_object_forces;
-	a.dbg = ctx->tile_debug;
-	a.prof = nullptr;
 	a.pin = nullptr;
-	if (ctx->tile_debug & 16) {
-		if (!ctx->tile_prof && hipMalloc((void**)&ctx->tile_prof, 10*(TILE_THREADS/64)*sizeof(unsigned long long)*ctx->tile_grid) != hipSuccess)
-			return sphx_set_error(SPHX_ERR_RUNTIME, "sphx_forces_basicstep: cannot allocate the tile profile buffer");
-		a.prof = ctx->tile_prof;
-	}
 
 	sphx_tiles_overflow_poll(ctx);
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_overflow != 1 && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
 		((ctx->dev.numfluids == 1 && ctx->dev.densitydiff != SPHX_FERRARI) || ctx->dev.kerneltype == SPHX_WENDLAND) &&
-		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles && ctx->tile_list != nullptr &&
-		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*TILE_NB < 0x80000000ull;   // buffer-load offsets are 31-bit
+		ctx->dev.formulation == SPHX_SPH_F1 && !ctx->disable_tiles && ctx->tile_list != nullptr;
 	a.tauPack = nullptr; a.tauPackN = 0;
 	a.otau0 = a.otau1 = a.otau2 = nullptr; a.oturbvisc = nullptr;
 	if (use_tiles && ctx->dev.turbmodel == SPHX_SPS) {   // window rows of the stress tensor (see tau_pack_kernel)
@@ -2076,8 +2387,7 @@ int sphx_sa_tiles_run(sphx_ctx *ctx, int mode, void *forces, const void *pos, co
 		!ctx->disable_tiles && ctx->tile_list != nullptr && d.boundarytype == SPHX_SA_BOUNDARY && d.kerneltype == SPHX_WENDLAND &&
 		d.numfluids == 1 && (d.turbmodel == SPHX_LAMINAR_FLOW || (d.turbmodel == SPHX_KEPSILON && mode != SPHX_SA_TILE_FORCES)) &&
 		d.formulation == SPHX_SPH_F1 && d.rheology <= SPHX_NEWTONIAN &&
-		numParticles <= ctx->reserved_particles &&
-		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*TILE_NB < 0x80000000ull;
+		numParticles <= ctx->reserved_particles;
 	if (!ok || fromParticle >= toParticle) return SPHX_OK;
 	ForcesArgs a = {};
 	a.forces = (float4*)forces;
@@ -2092,12 +2402,11 @@ int sphx_sa_tiles_run(sphx_ctx *ctx, int mode, void *forces, const void *pos, co
 		eos_kernel<<<div_up_u(numParticles, 256), 256, 0, stream>>>(ctx->dev, (const float4*)vel, (const particleinfo*)info, ctx->eos_aux, numParticles);
 		SPHX_LAUNCH_CHECK("eos_kernel");
 	}
-	a.tileList = ctx->tile_list; a.tileListRows = ctx->tile_list_rows; a.tileListStride = ctx->tile_list_stride;
-	a.tileWaves = ctx->tile_waves; a.tileRows = ctx->tile_rows; a.tileOwnSlot = ctx->tile_ownslot;
+	a.tileList = ctx->tile_list; a.tileRuns = ctx->tile_runs; a.tileRows = ctx->tile_rows;
+	a.tileLaneRec = ctx->tile_lane_rec; a.tileLaneIndex = ctx->tile_lane_index;
 	a.saGam = (const float4*)gGam; a.saDt = dt;
 	a.rb = ctx->rb_dev;
 	a.fromParticle = fromParticle; a.toParticle = toParticle;
-	a.dbg = ctx->tile_debug & ~16;
 	sphx_part_sa_tile(ctx, stream, a, mode, d.rheology == SPHX_NEWTONIAN);
 	SPHX_LAUNCH_CHECK("forces_tile_kernel (SA_BOUNDARY)");
 	*used = true;
@@ -2205,17 +2514,15 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	// single fluid with the tiling of this neighbour list at hand: the stress mode of the tiled kernel (neighbour rows from
 	// the LDS window instead of gathers), then the gather kernel as a stand-by guarded by the tiling's overflow flag
 	const bool use_tiles = ctx->tiles_built && ctx->tiles_overflow != 1 && ctx->tiles_cellstart == cellStart && ctx->tiles_neibslist == neibsList &&
-		ctx->dev.numfluids == 1 && !ctx->disable_tiles && ctx->tile_list != nullptr &&
-		(uint64_t)ctx->tile_list_stride*sizeof(uint16_t)*TILE_NB < 0x80000000ull;
+		ctx->dev.numfluids == 1 && !ctx->disable_tiles && ctx->tile_list != nullptr;
 	const uint32_t *guard = nullptr;
 	if (use_tiles) {
 		ForcesArgs fa = ForcesArgs();
 		fa.pos = a.pos; fa.vel = a.vel; fa.info = a.info; fa.hash = hash; fa.cellStart = cellStart; fa.neibsList = neibsList;
 		fa.otau0 = a.tau0; fa.otau1 = a.tau1; fa.otau2 = a.tau2; fa.oturbvisc = spsturbvisc;
 		fa.fromParticle = 0; fa.toParticle = particleRangeEnd;
-		fa.tileList = ctx->tile_list; fa.tileListRows = ctx->tile_list_rows; fa.tileListStride = ctx->tile_list_stride;
-		fa.tileWaves = ctx->tile_waves; fa.tileRows = ctx->tile_rows; fa.tileOwnSlot = ctx->tile_ownslot;
-		fa.dbg = ctx->tile_debug & 4;
+		fa.tileList = ctx->tile_list; fa.tileRuns = ctx->tile_runs; fa.tileRows = ctx->tile_rows;
+		fa.tileLaneRec = ctx->tile_lane_rec; fa.tileLaneIndex = ctx->tile_lane_index;
 		switch (ctx->dev.kerneltype) {
 		case SPHX_CUBICSPLINE: sphx_part_stress_k1(ctx, (hipStream_t)stream, fa); break;
 		case SPHX_QUADRATIC:   sphx_part_stress_k2(ctx, (hipStream_t)stream, fa); break;
@@ -2237,16 +2544,6 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	return SPHX_OK;
 }
 
-// timing experiments only (SPHX_TILE_DEBUG & 16), not part of include/sphx.h: per-workgroup {total, stage, pairs, tail}
-// of the last tiled launch, in 100 MHz ticks
-extern "C" int sphx_dbg_tile_profile(sphx_ctx *ctx, unsigned long long *host, uint32_t maxGroups)
-{
-	if (!ctx || !ctx->tile_prof) return -1;
-	const uint32_t n = maxGroups < ctx->tile_grid ? maxGroups : ctx->tile_grid;
-	if (hipMemcpy(host, ctx->tile_prof, 10*(TILE_THREADS/64)*sizeof(unsigned long long)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-	return (int)n;
-}
-
 // timing experiments only, not part of include/sphx.h: the tile descriptors of the last neighbour-list build
 extern "C" int sphx_dbg_tiles(sphx_ctx *ctx, uint32_t *host, uint32_t maxTiles)
 {
@@ -2256,6 +2553,18 @@ extern "C" int sphx_dbg_tiles(sphx_ctx *ctx, uint32_t *host, uint32_t maxTiles)
 	const uint32_t n = ctl[0] < maxTiles ? ctl[0] : maxTiles;
 	if (hipMemcpy(host, ctx->tiles, (size_t)TILE_DESC*sizeof(uint32_t)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
 	return (int)n;
+}
+
+// diagnostics only, not part of include/sphx.h: raw copies of the tiling's tables (0 descriptors, 1 run tables, 2 lane records,
+// 3 lane particles, 4 the list stream, 5 tile_ctl, 6 window rows), `bytes` from the start; synchronises
+extern "C" int sphx_dbg_tile_table(sphx_ctx *ctx, int which, void *host, size_t bytes)
+{
+	if (!ctx || !host) return -1;
+	const void *src = which == 0 ? (const void*)ctx->tiles : which == 1 ? (const void*)ctx->tile_runs : which == 2 ? (const void*)ctx->tile_lane_rec :
+		which == 3 ? (const void*)ctx->tile_lane_index : which == 4 ? (const void*)ctx->tile_list : which == 5 ? (const void*)ctx->tile_ctl :
+		which == 6 ? (const void*)ctx->tile_rows : nullptr;
+	if (!src) return -1;
+	return hipMemcpy(host, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
 }
 
 // tests only, not part of include/sphx.h: 1 when the last neighbour-list build left a usable tiling (built, lists allocated, no

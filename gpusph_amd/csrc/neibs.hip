@@ -525,7 +525,8 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	const uint32_t *__restrict__ particleHash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
 	const uint32_t *__restrict__ cellFluidEnd,
-	uint32_t particleRangeEnd, uint32_t posRows, float sqinfluenceradius, NeibsCounters *__restrict__ counters)
+	uint32_t particleRangeEnd, uint32_t posRows, float sqinfluenceradius, NeibsCounters *__restrict__ counters,
+	uint32_t *__restrict__ neibCounts /* [out] entries of the fluid section | of the second section << 16, for the tile lists */)
 	// (the partial counter sets lie behind *counters: NeibsSpread)
 {
 	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING][64];
@@ -728,6 +729,9 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 		}
 	}
 	ring.finish();
+	// the section lengths of this list, for the builder of the tile lists (forces.hip): it sizes the rows of a chunk of 64
+	// particles from them before it reads a single entry (second section: boundary particles, or the vertices with SA_BOUNDARY)
+	if (inRange) neibCounts[index] = min(nf, 0xFFFFu) | (min(SA ? nv : nb, 0xFFFFu) << 16);
 
 	// neibcount: per-block max / total, one atomic pair per wave
 	uint32_t total = nf + nb + nv;
@@ -748,7 +752,7 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 
 // ------------------------------------------------------------------------------------------
 // forces tiles (consumed by forces_tile_kernel, forces.hip).  A tile is a block of k x 2 x 2 cells
-// (k consecutive cells along COORD1 in each of 4 adjacent grid rows) holding <= TILE_THREADS
+// (k consecutive cells along COORD1 in each of 4 adjacent grid rows) holding <= TILE_PMAX
 // particles; its neighbour window is the (k+2) x 4 x 4 block around it (16 contiguous particle
 // ranges) and must fit TILE_WCAP records.  One thread per 2x2 bundle of rows walks the cells along
 // COORD1 and closes a tile greedily.
@@ -854,7 +858,7 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 			ncol += n4[r];
 			if (n4[r] && hc[r] && st4[r] != first[r] + hc[r]) contiguous = false;
 		}
-		const bool fits = hsum && ncol && (hsum + ncol <= TILE_THREADS) && (wc + cs_next <= wcap) &&
+		const bool fits = hsum && ncol && (hsum + ncol <= TILE_PMAX) && (wc + cs_next <= wcap) &&
 			(c - ca + 1 <= TILE_MAXCELLS) && contiguous;
 		if (fits) {
 			for (int r = 0; r < TILE_HROWS; ++r) { if (n4[r] && !hc[r]) first[r] = st4[r]; hc[r] += n4[r]; }
@@ -867,7 +871,7 @@ build_tiles_kernel(DevParams p, const uint32_t *__restrict__ cellStart, const ui
 				ca = c; hsum = ncol;
 				for (int r = 0; r < TILE_HROWS; ++r) { hc[r] = n4[r]; first[r] = st4[r]; }
 				wc = cs_prev + cs_cur + cs_next; wfl = f_prev | f_cur | f_next;
-				if (ncol > TILE_THREADS || wc > wcap) ctl[1] = 1u;   // would not fit: generic kernel
+				if (ncol > TILE_PMAX || wc > wcap) ctl[1] = 1u;   // would not fit: generic kernel
 			}
 		}
 		cs_prev = cs_cur; cs_cur = cs_next; f_prev = f_cur; f_cur = f_next;
@@ -1104,6 +1108,7 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit && ctx->tile_list) {
 		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
 		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), st));
+		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl + 12, 0, 2*sizeof(uint32_t), st));      // cursors of the list stream and of the lane tables
 		const DevParams &dp = ctx->dev;
 		const uint32_t gs2 = (uint32_t)dp.gs[dp.c2], gs3 = (uint32_t)dp.gs[dp.c3];
 		const uint32_t bundles = ((gs2 + 1)/2)*((gs3 + 1)/2);
@@ -1126,7 +1131,7 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	(sa ? (posBuf ? build_neibs_kernel<true, true> : build_neibs_kernel<false, true>)
 	    : (posBuf ? build_neibs_kernel<true, false> : build_neibs_kernel<false, false>))<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
 		saArgs, neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
-		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev);
+		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev, ctx->neib_counts);
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	neibs_counters_fold_kernel<<<1, NEIBS_SPREAD, 0, st>>>(ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("neibs_counters_fold_kernel");
@@ -1159,7 +1164,7 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		}
 	}
 	if (ctx->tiles_built) {   // the lists of the tiled particles in the form the tiled forces kernel walks (forces.hip)
-		rc = sphx_tile_lists_launch(ctx, neibsList, hash, cellStart, sa, st);
+		rc = sphx_tile_lists_launch(ctx, neibsList, info, hash, cellStart, sa, st);
 		if (rc != SPHX_OK) return rc;
 		// the tiling's overflow flag travels to the host behind the build, without a synchronisation: the forces passes that
 		// find it arrived (sphx_tiles_overflow_poll) launch exactly one kernel, the others keep the guarded stand-by

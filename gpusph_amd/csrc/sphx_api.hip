@@ -64,7 +64,8 @@ static void free_scratch(sphx_ctx *ctx)
 {
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
 		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tau_pack, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols,
-		ctx->tile_list, ctx->tile_waves, ctx->tile_rows, ctx->tile_ownslot, ctx->sa_wall, ctx->sa_wall_cache, ctx->sa_wall_tag };
+		ctx->tile_list, ctx->tile_runs, ctx->tile_rows, ctx->tile_lane_rec, ctx->tile_lane_index, ctx->neib_counts,
+		ctx->sa_wall, ctx->sa_wall_cache, ctx->sa_wall_tag };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
@@ -72,7 +73,8 @@ static void free_scratch(sphx_ctx *ctx)
 	ctx->eos_aux = nullptr; ctx->tau_pack = nullptr;
 	ctx->sa_wall = nullptr; ctx->sa_wall_neibslist = nullptr;
 	ctx->sa_wall_cache = nullptr; ctx->sa_wall_tag = nullptr; ctx->sa_wall_capacity = 0;
-	ctx->tile_list = nullptr; ctx->tile_waves = nullptr; ctx->tile_rows = nullptr; ctx->tile_ownslot = nullptr; ctx->tile_list_rows = ctx->tile_list_stride = 0;
+	ctx->tile_list = nullptr; ctx->tile_runs = nullptr; ctx->tile_rows = nullptr; ctx->tile_lane_rec = nullptr; ctx->tile_lane_index = nullptr;
+	ctx->tile_list_batches = ctx->tile_lane_cap = 0; ctx->neib_counts = nullptr;
 	ctx->tiles = nullptr; ctx->cell_end_copy = nullptr; ctx->cell_fluid_end = nullptr; ctx->tile_cols = nullptr;
 	ctx->tile_capacity = 0; ctx->cells_reserved = 0; ctx->tiles_built = false;
 	ctx->reserved_particles = ctx->reserved_bins = 0;
@@ -91,7 +93,6 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->counters_dev) (void)hipFree(ctx->counters_dev);
 	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
 	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
-	if (ctx->tile_prof) (void)hipFree(ctx->tile_prof);
 	if (ctx->ovf_host) { (void)hipHostFree(ctx->ovf_host); (void)hipEventDestroy(ctx->ovf_event); }
 	if (ctx->dem) (void)hipFree(ctx->dem);
 	delete ctx->forces_events;
@@ -123,6 +124,7 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_index, sizeof(uint32_t)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->tmp_info, sizeof(uint2)*(size_t)n));
 	SPHX_HIP(hipMalloc((void**)&ctx->eos_aux, sizeof(float4)*(size_t)n));
+	SPHX_HIP(hipMalloc((void**)&ctx->neib_counts, sizeof(uint32_t)*(size_t)n));
 	if (ctx->dev.turbmodel == SPHX_SPS)
 		SPHX_HIP(hipMalloc((void**)&ctx->tau_pack, sizeof(float4)*2*(size_t)n));
 	ctx->tile_capacity = n/8 + 4096;
@@ -137,32 +139,35 @@ int sphx_ensure_scratch(sphx_ctx *ctx, uint32_t numParticles)
 	return SPHX_OK;
 }
 
-// Tile lists of the tiled forces kernel (forces.hip): 2 B x (neiblistsize + extra) rows per particle, more than the neighbour
-// list itself, so they are allocated on the first neighbour-list build that really tiles (sphx_build_neibs_sa decides: not for
-// the formulations that have their own forces kernels, nor for SA_BOUNDARY with several fluids or k-epsilon).  When the memory is not there the context simply
-// keeps running on the generic kernels: tile_list stays NULL and tiles_built false.
+// Tile lists of the tiled forces kernel (forces.hip): the stream of list batches (room for 160 two-byte entries per particle on
+// average incl. the padding of a chunk's lanes to its longest list, + a floor for small cases whose tiles are mostly padding),
+// the lane tables and the run tables.  More than the neighbour list itself, so they are allocated on the first neighbour-list
+// build that really tiles (sphx_build_neibs_sa decides: not for the formulations that have their own forces kernels, nor for
+// SA_BOUNDARY with several fluids).  When the memory is not there the context simply keeps running on the generic kernels:
+// tile_list stays NULL and tiles_built false.  A build that needs more than this reserves flags the tiling as overflowed.
 int sphx_ensure_tile_lists(sphx_ctx *ctx)
 {
 	if (ctx->disable_tiles || !ctx->reserved_particles) return SPHX_OK;
-	if (ctx->tile_list && ctx->tile_waves && ctx->tile_rows && ctx->tile_ownslot) return SPHX_OK;
+	if (ctx->tile_list && ctx->tile_runs && ctx->tile_rows && ctx->tile_lane_rec && ctx->tile_lane_index) return SPHX_OK;
 	const size_t n = ctx->reserved_particles;
-	const uint32_t rows = (ctx->dev.neiblistsize + TILE_LIST_EXTRA)/TILE_LIST_BATCH*TILE_LIST_BATCH;
-	bool ok = hipMalloc((void**)&ctx->tile_list, sizeof(uint16_t)*(size_t)rows*n) == hipSuccess;
-	ok = ok && hipMalloc((void**)&ctx->tile_waves, sizeof(uint32_t)*(TILE_THREADS/64)*(size_t)ctx->tile_capacity) == hipSuccess;
+	const size_t batches = n*5u/8u + 262144u;
+	const size_t lanes = 2u*n + 262144u;
+	if (batches >= ((size_t)1 << 31) || lanes >= ((size_t)1 << 31)) return SPHX_OK;      // 32-bit cursors
+	bool ok = hipMalloc((void**)&ctx->tile_list, sizeof(uint2)*64u*batches) == hipSuccess;
+	ok = ok && hipMalloc((void**)&ctx->tile_runs, sizeof(uint32_t)*TILE_RUNTAB*(size_t)ctx->tile_capacity) == hipSuccess;
 	ok = ok && hipMalloc((void**)&ctx->tile_rows, sizeof(uint32_t)*TILE_ROWDESC*(size_t)ctx->tile_capacity) == hipSuccess;
-	ok = ok && hipMalloc((void**)&ctx->tile_ownslot, sizeof(uint16_t)*n) == hipSuccess;
+	ok = ok && hipMalloc((void**)&ctx->tile_lane_rec, sizeof(uint32_t)*lanes) == hipSuccess;
+	ok = ok && hipMalloc((void**)&ctx->tile_lane_index, sizeof(uint32_t)*lanes) == hipSuccess;
 	if (!ok) {
 		(void)hipGetLastError();   // out of memory is not an error of the caller's command: the generic kernels take over
-		if (ctx->tile_list) (void)hipFree(ctx->tile_list);
-		if (ctx->tile_waves) (void)hipFree(ctx->tile_waves);
-		if (ctx->tile_rows) (void)hipFree(ctx->tile_rows);
-		if (ctx->tile_ownslot) (void)hipFree(ctx->tile_ownslot);
-		ctx->tile_list = nullptr; ctx->tile_waves = nullptr; ctx->tile_rows = nullptr; ctx->tile_ownslot = nullptr;
-		ctx->tile_list_rows = ctx->tile_list_stride = 0;
+		void *ptrs[] = { ctx->tile_list, ctx->tile_runs, ctx->tile_rows, ctx->tile_lane_rec, ctx->tile_lane_index };
+		for (void *q : ptrs) if (q) (void)hipFree(q);
+		ctx->tile_list = nullptr; ctx->tile_runs = nullptr; ctx->tile_rows = nullptr; ctx->tile_lane_rec = nullptr; ctx->tile_lane_index = nullptr;
+		ctx->tile_list_batches = ctx->tile_lane_cap = 0;
 		return SPHX_OK;
 	}
-	ctx->tile_list_rows = rows;
-	ctx->tile_list_stride = (uint32_t)n;
+	ctx->tile_list_batches = (uint32_t)batches;
+	ctx->tile_lane_cap = (uint32_t)lanes;
 	return SPHX_OK;
 }
 

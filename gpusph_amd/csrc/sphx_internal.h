@@ -34,10 +34,11 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 
 // forces tiles (see forces.hip "Tiled path"): a tile is a k x 2 x 2 block of cells (k along COORD1)
 #ifndef TILE_THREADS
-#define TILE_THREADS  512                  // home particles per tile (one thread each), 8 waves
-#define TILE_WCAP     3200                 // window records that fit LDS (48 B each, 1 workgroup per CU)
-#define TILE_WCAP_SPS 1900                 // ... with the SPS stress tensor of every window particle (80 B each)
-#define TILE_WCAP_SPS1 2400                // ... of an SPS run with one fluid (64 B each: no EOS rows, see tau_pack_kernel)
+#define TILE_THREADS  512                  // threads of the tiled kernel's workgroup: 8 waves, two per SIMD
+#define TILE_PMAX     640                  // home particles per tile: ten chunks of 64, dealt out to the eight waves batch by batch
+#define TILE_WCAP     2984                 // window records that fit LDS (48 B each, 1 workgroup per CU) next to the partial sums and the lane records
+#define TILE_WCAP_SPS 1786                 // ... with the SPS stress tensor of every window particle (80 B each)
+#define TILE_WCAP_SPS1 2238                // ... of an SPS run with one fluid (64 B each: no EOS rows, see tau_pack_kernel)
 #define TILE_WGS_PER_CU 1                  // persistent workgroups per CU (LDS bound)
 #endif
 #define SA_WALL_CACHE_ENTRIES 96           // boundary-section entries per wall particle whose |grad gamma_as| is kept (more: recomputed)
@@ -45,16 +46,24 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #define TILE_WROWS    16                   // window rows: 4 x 4
 #define TILE_WAVES    (TILE_THREADS/64)    // waves of a tile's workgroup ...
 #define TILE_RPW      (TILE_WROWS/TILE_WAVES)   // ... and the window rows each of them stages
+#define TILE_CHUNKS   (TILE_PMAX/64)       // chunks of 64 home particles (one per lane of a wave) a tile can have
+#define TILE_RUNS_MAX (TILE_CHUNKS + TILE_WAVES - 1)   // runs of a tile: a run is a stretch of ONE chunk's list batches walked by ONE wave
 #define TILE_MAXCELLS 14                   // cells per tile along COORD1
 #define TILE_KW       16                   // window columns (TILE_MAXCELLS + 2)
-#define TILE_DESC     16                   // uint32 per tile: g2, g3, firstCell, numCells, first[4], count[4], window, flags,
-                                           // mask of window rows that are not one contiguous range, wave -> chunk permutation
+#define TILE_DESC     16                   // uint32 per tile: g2, g3, firstCell, numCells, first[4], count[4], window, flags (build_tiles_kernel),
+                                           // first batch of its list stream, first entry of its lane tables (tile_lists_kernel)
 #define TILE_ROWDESC  32                   // uint32 per tile (tile_rows, written by tile_lists_kernel): first record of each of the 16
                                            // window rows, then records per row and window slot of the row's first record as uint16 pairs
+// uint32 per tile of the run table (tile_runs, tile_lists_kernel): who walks what.
+//   [w], w < 8        wave w: first run | runs << 5 | first batch (tile-relative) << 10 | batches << 22
+//   [8]               chunks | home particles << 8 | runs << 24
+//   [9 + c], c < 10   chunk c: first run | runs << 8   (its partial sums, in list order)
+//   [24 + r], r < 17  run r: chunk | batches of the fluid section << 4 | batches of the second section << 12
+#define TILE_RUNTAB   48
+#define TILE_RT_CHUNK 9
+#define TILE_RT_RUN   24
 #define TILE_NB       4                    // neighbours per batch in the tiled pair loop
-#define TILE_AHEAD    4                    // list batches kept in flight per section (register ring)
-#define TILE_LIST_EXTRA 64                 // rows of the tile lists beyond neiblistsize (both sections are padded per wave)
-#define TILE_LIST_BATCH 4                  // rows the tile-list builder handles per step (section lengths are multiples of it)
+#define TILE_AHEAD    4                    // list batches kept in flight (register ring)
 
 // ---- per-kernel constants, passed BY VALUE as a kernel argument (kernarg/SGPR resident;
 //      replaces the reference's ~70 __constant__ symbols, so there is no per-device global
@@ -158,18 +167,21 @@ struct sphx_ctx {
 	float      *dt_scratch;    // 1 float, for the sync dtreduce
 	// forces tiles, built by sphx_build_neibs
 	uint32_t   *tiles;         // [tile_capacity][TILE_DESC]
-	uint16_t   *tile_ownslot;  // [n]: window slot * 16 of every tiled particle's own row
 	uint32_t   *tile_rows;     // [tile_capacity][TILE_ROWDESC]: the window rows of every tile, laid out once per neighbour-list build
 	uint32_t   *tile_cols;     // [row bundles][gs1]: window records of a column (16 rows), bit 31 = a cell of it holds fluid
-	uint32_t   *tile_ctl;      // [0] = number of tiles, [1] = overflow flag (generic kernel takes over), [2] finished groups, [4..11] tile tickets
+	uint32_t   *tile_ctl;      // [0] = number of tiles, [1] = overflow flag (generic kernel takes over), [2] finished groups, [4..11] tile tickets,
+	                           // [12] batches of the list stream handed out, [13] entries of the lane tables handed out
 	uint32_t   *cell_end_copy; // [cells] cellEnd of the build the tiles belong to
 	uint32_t   *cell_fluid_end;// [cells] first non-fluid particle of each cell (neighbour-list build)
-	// tile lists (forces.hip "Tile lists"): the neighbour lists of the tiled particles translated, at build time, into the
-	// window slot of each neighbour + the advance of the cell code; [rows][stride] uint16,
-	// fluid section in rows 0 upward, boundary section in rows tile_list_rows-1 downward, both padded per wave
-	uint16_t   *tile_list;
-	uint32_t    tile_list_rows, tile_list_stride;
-	uint32_t   *tile_waves;    // [tile][TILE_THREADS/64]: rows of the fluid section | rows of the boundary section << 16
+	uint32_t   *neib_counts;   // [n] entries of the fluid section | entries of the second section << 16 of every list (build_neibs_kernel)
+	// tile lists (forces.hip "Tile lists"): the neighbour lists of the tiled particles as the tiled kernel walks them -- one
+	// stream of 512-byte batches (64 lanes x 4 window offsets) per tile, in the order its waves consume them
+	uint2      *tile_list;     // [tile_list_batches][64]
+	uint32_t    tile_list_batches;
+	uint32_t   *tile_lane_rec; // [tile_lane_cap] per lane of every chunk: window offset of the particle's own row | flags << 16
+	uint32_t   *tile_lane_index;// [tile_lane_cap] ... its particle (0xFFFFFFFF: idle lane)
+	uint32_t    tile_lane_cap;
+	uint32_t   *tile_runs;     // [tile_capacity][TILE_RUNTAB]
 	uint32_t    tile_capacity;
 	uint32_t    cells_reserved;
 	bool        tiles_built;
@@ -179,8 +191,7 @@ struct sphx_ctx {
 	hipEvent_t  ovf_event;     // ... has arrived
 	bool        ovf_pending;
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
-	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments)
-	unsigned long long *tile_prof;   // SPHX_TILE_DEBUG & 16
+	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments; only with -DSPHX_TILE_DEBUG_BUILD)
 	bool        time_forces;   // sphx_forces_timing: bracket the dominant forces kernel with HIP events
 	std::vector<std::pair<hipEvent_t, hipEvent_t> > *forces_events;
 	const void *tiles_cellstart, *tiles_neibslist;
@@ -228,7 +239,7 @@ void sphx_fidelity_rows_launch(sphx_ctx *ctx, const void *vel, const void *info,
 int sphx_rb_flush(sphx_ctx *ctx, hipStream_t st);
 int sphx_xsph_launch(sphx_ctx *ctx, void *xsph, const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle, hipStream_t st);
-int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st);
+int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void *info, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st);
 // SA_BOUNDARY engines over the tiles (forces.hip): which sums the tiled kernel forms
 #define SPHX_SA_TILE_FORCES 0
 #define SPHX_SA_TILE_DSUM 1
