@@ -43,9 +43,13 @@ struct ForcesArgs {
 	float saDt;
 	const RbParams *rb;
 	uint32_t fromParticle, toParticle, cflOffset;
+	int wholeRange;       // tiled kernel: [fromParticle, toParticle) holds every tiled particle (no per-tile / per-particle range test)
 	uint32_t numBlocks;   // generic kernel: blocks of SPHX_BLOCK_FORCES particles to cover
 	int compute_object_forces;
 	uint32_t *pin;              // always NULL (see pin_batch)
+#ifdef SPHX_TILE_DEBUG_BUILD
+	unsigned long long *prof;   // per wave of every workgroup: cycles per phase of the tile loop (SPHX_TILE_DEBUG=16), else NULL
+#endif
 };
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -967,14 +971,14 @@ __device__ __forceinline__ void pin_batch(const ListStream &ls, const uint2 &nd)
 
 // the part of a tile's run table a wave works from (all scalar)
 struct WaveJob { uint32_t firstRun, nRuns, firstBatch, nBatches, laneBase, chunks; };
-__device__ __forceinline__ WaveJob wave_job(uint32_t rt /* this lane's word of the run table */, const uint32_t *d, uint32_t wave)
+__device__ __forceinline__ WaveJob wave_job(uint32_t rt /* this lane's word of the run table */, uint32_t dw /* ... of the descriptor */, uint32_t wave)
 {
 	WaveJob j;
 	const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rt, (int)wave);
 	j.firstRun = w & 31u; j.nRuns = (w >> 5) & 31u;
-	j.firstBatch = __builtin_amdgcn_readfirstlane(d[14]) + ((w >> 10) & 4095u);
+	j.firstBatch = (uint32_t)__builtin_amdgcn_readlane((int)dw, 14) + ((w >> 10) & 4095u);
 	j.nBatches = w >> 22;
-	j.laneBase = __builtin_amdgcn_readfirstlane(d[15]);
+	j.laneBase = (uint32_t)__builtin_amdgcn_readlane((int)dw, 15);
 	j.chunks = (uint32_t)__builtin_amdgcn_readlane((int)rt, 8) & 255u;
 	return j;
 }
@@ -982,7 +986,7 @@ __device__ __forceinline__ WaveJob wave_job(uint32_t rt /* this lane's word of t
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &a, const ListStream &ls, const WaveJob &wj, uint32_t rt,
 	uint32_t lane, float inv_h, const float4 *sPos, const float4 *sVel, const float4 *sAux, float4 *sPart, const uint32_t *sLaneRec,
-	ListWindow &lw /* batches 0..TILE_AHEAD-1 of the wave's stream, already requested */)
+	float *sVal, ListWindow &lw /* batches 0..TILE_AHEAD-1 of the wave's stream, already requested */)
 {
 	static_assert(TILE_AHEAD == 4 && TILE_NB == 2*TILE_HB, "the ring below is unrolled by hand: 4 buffers of 2 halves");
 	constexpr uint32_t WC = TILE_WC(TURB), WS = WC + 1;
@@ -1007,10 +1011,12 @@ __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &
 	bool take = false, take0 = false, take1 = false, momentum = false, ljlane = false, diffuse = true;
 	int sec = 0, leftSeg = 0;
 	uint32_t secondLeft = 0;               // batches of the run's second section still to come (scalar)
+	uint32_t runWord = 0;                  // the run's table word (scalar)
 	s.pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.gridPos = make_int3(0, 0, 0); s.fl = 0u;
 
 	auto start_run = [&]() {
 		const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)rt, (int)(TILE_RT_RUN + run));
+		runWord = w;
 		const uint32_t nF = (w >> 4) & 255u;
 		secondLeft = (w >> 12) & 255u;
 		// the lanes' particles of this run's chunk.  From LDS (staged with the window): a global load here would sit between
@@ -1070,6 +1076,9 @@ __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &
 			dst[TILE_RUNS_MAX*64] = make_float4(fx.x, fx.y, fx.z, fx.w);
 			dst[2*TILE_RUNS_MAX*64] = make_float4(fx.u, 0.0f, 0.0f, 0.0f);
 		}
+		// the chunk's last run leaves what the finalize stage needs of the particle itself: its sound speed (CFL term), or in
+		// stress mode its relative density
+		if (runWord & TILE_RUN_LAST) sVal[(runWord & 15u)*64u + lane] = STRESS ? s.vel.w : s.sspeed;
 		if (++run == runsEnd) return false;
 		start_run();
 		return true;
@@ -1157,34 +1166,29 @@ __device__ __forceinline__ void stress_finalize(const DevParams &p, const Forces
 	}
 }
 
-// the two window rows a wave stages (wave w: rows w and w + 8), from tile_rows.  The six words are requested one tile
-// ahead and only turned into scalars (the LDS-DMA destination and the trip counts derive from them) when their tile
-// starts: a readfirstlane at request time would wait for the load there and then
+// the two window rows a wave stages (wave w: rows w and w + 8), from tile_rows.  The table is requested one tile
+// ahead and only turned into scalars (the LDS-DMA destination and the trip counts derive from them) when its tile
+// starts: a readlane at request time would wait for the load there and then
 // (a workgroup of TILE_WAVES waves: wave w stages the TILE_RPW rows w, w + TILE_WAVES, ...)
-static_assert(TILE_WAVES*TILE_RPW == TILE_WROWS && (TILE_WAVES % 2) == 0, "the window rows are dealt out evenly, two rows per table word");
-static_assert(TILE_WAVES == 8 && TILE_CHUNKS <= 2*TILE_WAVES && TILE_CHUNKS <= 15 && TILE_RUNS_MAX <= 24 && TILE_RT_RUN + TILE_RUNS_MAX <= TILE_RUNTAB && TILE_RUNTAB <= 64,
-	"run table: a wave finalizes the chunks w and w + 8; chunk numbers are 4 bits, run numbers 5; one table word per lane");
-struct RowRaw { uint32_t w[3*TILE_RPW]; };
+static_assert(TILE_WAVES*TILE_RPW == TILE_WROWS && (TILE_WAVES % 2) == 0 && TILE_ROWDESC == 32 && TILE_DESC == 16, "the window rows are dealt out evenly, two rows per table word; tables of 32 and 16 words");
+static_assert((TILE_WAVES == 8 || TILE_WAVES == 4) && TILE_CHUNKS <= 2*TILE_WAVES && TILE_CHUNKS <= 15 && TILE_RUNS_MAX <= 24 && TILE_RT_RUN + TILE_RUNS_MAX <= TILE_RUNTAB && TILE_RUNTAB <= 64,
+	"run table: a wave finalizes the chunks w and w + TILE_WAVES; chunk numbers are 4 bits, run numbers 5; one table word per lane");
+// (every 64-lane load costs the CU's address unit the same ~16 cycles however little it fetches, and that unit is what bounds the
+// staging of a tile: a table is fetched with ONE load, a word per lane, and read out with v_readlane)
 struct RowJobs { uint32_t start[TILE_RPW], total[TILE_RPW], base[TILE_RPW]; bool contig[TILE_RPW]; };
-__device__ __forceinline__ void request_row_jobs(const uint32_t *__restrict__ tileRows, uint32_t tile, uint32_t wave, RowRaw &r)
+__device__ __forceinline__ uint32_t request_row_jobs(const uint32_t *__restrict__ tileRows, uint32_t tile, uint32_t lane)
 {
-	const uint32_t *d = tileRows + (size_t)TILE_ROWDESC*tile;
-#pragma unroll
-	for (int k = 0; k < TILE_RPW; ++k) {
-		const uint32_t row = wave + (uint32_t)(TILE_WAVES*k);      // same parity as the wave: TILE_WAVES is even
-		r.w[k] = d[row];
-		r.w[TILE_RPW + k] = d[16u + (row >> 1)];
-		r.w[2*TILE_RPW + k] = d[24u + (row >> 1)];
-	}
+	return tileRows[(size_t)TILE_ROWDESC*tile + (lane & (uint32_t)(TILE_ROWDESC - 1))];
 }
-__device__ __forceinline__ void resolve_row_jobs(const RowRaw &r, uint32_t wave, RowJobs &j)
+__device__ __forceinline__ void resolve_row_jobs(uint32_t rr /* this lane's word of the tile's row table */, uint32_t wave, RowJobs &j)
 {
 	const uint32_t sh = 16u*(wave & 1u);
 #pragma unroll
 	for (int k = 0; k < TILE_RPW; ++k) {
-		j.start[k] = __builtin_amdgcn_readfirstlane(r.w[k]);
-		const uint32_t tb = __builtin_amdgcn_readfirstlane((r.w[TILE_RPW + k] >> sh) & 0xFFFFu);
-		const uint32_t bb = __builtin_amdgcn_readfirstlane((r.w[2*TILE_RPW + k] >> sh) & 0xFFFFu);
+		const uint32_t row = wave + (uint32_t)(TILE_WAVES*k);      // same parity as the wave: TILE_WAVES is even
+		j.start[k] = (uint32_t)__builtin_amdgcn_readlane((int)rr, (int)row);
+		const uint32_t tb = ((uint32_t)__builtin_amdgcn_readlane((int)rr, (int)(16u + (row >> 1))) >> sh) & 0xFFFFu;
+		const uint32_t bb = ((uint32_t)__builtin_amdgcn_readlane((int)rr, (int)(24u + (row >> 1))) >> sh) & 0xFFFFu;
 		j.total[k] = tb; j.base[k] = bb & 0x7FFFu; j.contig[k] = !(bb & 0x8000u);
 	}
 }
@@ -1192,12 +1196,14 @@ __device__ __forceinline__ void resolve_row_jobs(const RowRaw &r, uint32_t wave,
 #define TILE_HCH (TILE_RPW > 2 ? 3 : 5)   // 64-record chunks of a window row whose cell hashes are fetched along with the DMA (longer rows: later)
 
 // does the tile hold particles of [fromParticle, toParticle)?  (multi-GPU stripes launch the kernel on a range)
-__device__ __forceinline__ bool tile_in_range(const uint32_t *d, uint32_t fromParticle, uint32_t toParticle)
+__device__ __forceinline__ bool tile_in_range(uint32_t dw /* this lane's word of the descriptor */, uint32_t fromParticle, uint32_t toParticle)
 {
 	uint32_t firstMin = 0xFFFFFFFFu, lastMax = 0u;
 #pragma unroll
-	for (int r = 0; r < TILE_HROWS; ++r)
-		if (d[8 + r]) { firstMin = min(firstMin, d[4 + r]); lastMax = max(lastMax, d[4 + r] + d[8 + r]); }
+	for (int r = 0; r < TILE_HROWS; ++r) {
+		const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)dw, 4 + r), cnt = (uint32_t)__builtin_amdgcn_readlane((int)dw, 8 + r);
+		if (cnt) { firstMin = min(firstMin, first); lastMax = max(lastMax, first + cnt); }
+	}
 	return !(firstMin >= toParticle || lastMax <= fromParticle);
 }
 
@@ -1223,7 +1229,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	// SPS: EOS rows, then tau {xx,xy,xz,yy}, then {yz,zz,-,-}; with one fluid only the two stress rows (SPSC)
 	__shared__ __attribute__((aligned(16))) float4 sAux[SPSC ? 2*WS : SPSW ? 3*WS : (NOAUX ? 1 : WS)];
 	__shared__ __attribute__((aligned(16))) float4 sPart[PARTV*TILE_RUNS_MAX*64];   // partial sums of the tile's runs (walk_runs)
-	__shared__ uint32_t sLaneRec[TILE_CHUNKS*64];                  // lane records of the tile's chunks: own window row | flags << 16
+	// lane records of the tile's chunks (own window row | flags << 16): of the tile being walked and of the one being finalized
+	__shared__ uint32_t sLaneRec[2][TILE_CHUNKS*64];
+	__shared__ float sVal[TILE_CHUNKS*64];                         // per lane of every chunk: see walk_runs
+	// the own value the finalize stage needs comes from LDS (sVal) unless the window does not hold it: SPS with one fluid keeps
+	// P instead of c with Colagrossi diffusion; SA diffusion needs gamma, the other SA modes nothing
+	constexpr bool VAL_LDS = !SPSC && !SA;
 	constexpr uint32_t TAU0 = SPSC ? 0u : WS;     // where the stress rows start in sAux
 	__shared__ uint32_t sTileQ[2];                                 // [0] first tile, [1] next tile of this workgroup
 
@@ -1284,20 +1295,18 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	// software pipeline over tiles: descriptor, window rows, run table, the lanes' first run and their first list batches of
 	// the NEXT tile are fetched while the current one computes, so a tile costs one memory round trip (the window DMA); the
 	// particles of the PREVIOUS tile are finalized while that DMA is in flight
-	uint32_t dc[TILE_DESC], dn[TILE_DESC];
-#pragma unroll
-	for (int k = 0; k < TILE_DESC; ++k) dc[k] = tiles[(size_t)TILE_DESC*tile + k];
-	RowRaw rrc, rrn;
-	request_row_jobs(a.tileRows, tile, wave, rrc);
-	// the tile's run table, one word per lane
+	// the tile's descriptor, row table and run table: one load each, a word per lane
+	uint32_t dwc = tiles[(size_t)TILE_DESC*tile + (lane & (uint32_t)(TILE_DESC - 1))], dwn = 0u;
+	uint32_t rrc = request_row_jobs(a.tileRows, tile, lane), rrn = 0u;
 	uint32_t rtc = a.tileRuns[(size_t)TILE_RUNTAB*tile + min(lane, (uint32_t)(TILE_RUNTAB - 1))], rtn = 0u;
 	__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): first descriptor, first run table
+	const bool wholeRange = a.wholeRange != 0;
 
 	// what a wave asks for one tile ahead, once that tile's descriptor and run table are there: the first batches of its list
 	// stream and the particles it will finalize (chunks `wave` and `wave + 8`)
 	struct Ahead { ListWindow lw; uint32_t idx[2]; };
-	auto request_ahead = [&](const uint32_t *d, uint32_t rt, Ahead &o) {
-		const WaveJob j = wave_job(rt, d, wave);
+	auto request_ahead = [&](uint32_t dw, uint32_t rt, Ahead &o) {
+		const WaveJob j = wave_job(rt, dw, wave);
 		if (j.nRuns) {
 			const uint32_t lane8 = lane*(uint32_t)(TILE_NB*sizeof(uint16_t));
 			if (TileAsmRing<TURB>::value) {
@@ -1319,16 +1328,25 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 #pragma unroll
 	for (int k = 0; k < TILE_AHEAD; ++k) ac.lw.q[k] = make_uint2(0u, 0u);
 	an = ac;
-	if (tile_in_range(dc, a.fromParticle, a.toParticle)) request_ahead(dc, rtc, ac);
+	if (wholeRange || tile_in_range(dwc, a.fromParticle, a.toParticle)) request_ahead(dwc, rtc, ac);
 
-	// the particles of the tile whose pair phase has just ended, waiting to be finalized: particle, info bits, one value of
-	// its own (sound speed; stress mode: relative density; SA diffusion: gamma) and where its partial sums lie
+	// the particles of the tile whose pair phase has just ended, waiting to be finalized: particle, where its partial sums
+	// lie, and (where LDS does not have it, see VAL_LDS) one value of its own
 	uint32_t fIdx[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-	uint2 fInfo[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
 	float fVal[2] = {0.0f, 0.0f};
+	uint32_t par = 0u;                     // scalar: which half of sLaneRec the tile being walked uses
 	uint32_t fTab[2] = {0u, 0u};           // scalar: first run | runs << 8 of the chunks this wave finalizes
 	bool havePrev = false;
 	float cflRun = 0.0f;   // largest CFL term of this lane's particles over all tiles of the workgroup
+#ifdef SPHX_TILE_DEBUG_BUILD
+	// phase timers (shader cycles, per wave): 0 total, 1 top barrier, 2 descriptor + DMA issue, 3 finalize of the previous tile,
+	// 4 landing of the DMA, 5 conversion, 6 window barrier, 7 requests, 8 pair phase, 9 tiles
+	const bool prof = a.prof != nullptr;
+	unsigned long long tBegin = prof ? __builtin_amdgcn_s_memtime() : 0ull, tp = tBegin, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define SPHX_PROF(K) do { if (prof) { const unsigned long long tq = __builtin_amdgcn_s_memtime(); pacc[K] += tq - tp; tp = tq; } } while (0)
+#else
+#define SPHX_PROF(K) do { } while (0)
+#endif
 
 	auto finalize_prev = [&]() {
 #pragma unroll
@@ -1348,16 +1366,27 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				}
 			}
 			const uint32_t index = fIdx[k];
-			const bool mine = index != 0xFFFFFFFFu && index >= a.fromParticle && index < a.toParticle;
+			const bool mine = index != 0xFFFFFFFFu && (wholeRange || (index >= a.fromParticle && index < a.toParticle));
+			// the lane's flags: the record of the finalized tile is in the other half of sLaneRec
+			const uint32_t c = wave + (uint32_t)(TILE_WAVES*k);
+			const uint32_t fl = sLaneRec[par ^ 1u][min(c, (uint32_t)(TILE_CHUNKS - 1))*64u + lane] >> 16;
+			float val = fVal[k];
+			if (VAL_LDS) {
+				val = sVal[min(c, (uint32_t)(TILE_CHUNKS - 1))*64u + lane];
+				// a chunk none of whose lists has an entry has no run to leave the value: from memory (the forces need it of fluid
+				// particles only, the stress tensor of every particle)
+				if (rn == 0u && __builtin_amdgcn_ballot_w64(mine && (STRESS || (fl & LANE_TYPE_MASK) == PT_FLUID)))
+					val = mine ? (STRESS ? reinterpret_cast<const float*>(a.vel)[4u*(size_t)index + 3u] : reinterpret_cast<const float*>(a.aux)[4u*(size_t)index + 1u]) : 0.0f;
+			}
 			if (!mine) continue;
-			particleinfo info;
-			info.x = (unsigned short)(fInfo[k].x & 0xFFFFu); info.y = (unsigned short)(fInfo[k].x >> 16);
-			info.z = (unsigned short)(fInfo[k].y & 0xFFFFu); info.w = (unsigned short)(fInfo[k].y >> 16);
-			if (STRESS) stress_finalize(p, a, index, (fVal[k] + 1.0f)*p.rho0[0], force, fx);
+			particleinfo info;      // what the finalize stage reads of it: type, force-feedback flag, fluid (rigid-body rows: the real one)
+			info.x = (unsigned short)((fl & LANE_TYPE_MASK) | ((fl & LANE_COMPUTE_FORCE) ? FG_COMPUTE_FORCE : 0u));
+			info.y = (unsigned short)(((fl >> LANE_FLUID_SHIFT) & 3u) << 12); info.z = 0; info.w = 0;
+			if (STRESS) stress_finalize(p, a, index, (val + 1.0f)*p.rho0[0], force, fx);
 			else if (SA) {
 				if (PART_TYPE(info) == PT_FLUID) {
 					if (SA_DSUM) a.forces[index].w = force.y + force.x + 0.0f;     // sumPmwNp1 + sumPmwN
-					else if (SA_DIFF) a.forces[index].w = (force.w/fVal[k])/p.rho0[0];
+					else if (SA_DIFF) a.forces[index].w = (force.w/val)/p.rho0[0];
 					else {
 						if (p.simflags & SPHX_ENABLE_DENSITY_SUM) force.w = 0.0f;   // no continuity equation then
 						a.forces[index] = force;      // unfinished: sa_forces_kernel adds the boundary elements, divides by gamma, ...
@@ -1368,7 +1397,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				s.pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.gridPos = make_int3(0, 0, 0);
 				s.vel = make_float4(0.0f, 0.0f, 0.0f, 0.0f); s.rho = 0.0f;
 				s.fl = (TURB & SPHX_TURB_MF) ? FLUID_NUM(info) : 0u;
-				s.sspeed = fVal[k];
+				s.sspeed = val;
 				// planes, terrain and rigid-body rows need the cell-local position, the mass, the cell (and plane friction the
 				// velocity and the density): few runs, few particles
 				const bool geom = (PART_TYPE(info) == PT_FLUID && (p.simflags & (SPHX_ENABLE_PLANES | SPHX_ENABLE_DEM))) ||
@@ -1376,6 +1405,7 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				if (geom) {
 					s.pos = a.pos[index]; s.gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 					s.vel = a.vel[index]; s.rho = a.aux[index].w;
+					info = a.info[index];
 				}
 				cflRun = fmaxf(cflRun, finalize_particle(p, a, index, info, s, force));
 			}
@@ -1386,24 +1416,24 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	for (;;) {
 		uint32_t drawn = 0;
 		if (tid == 0) drawn = atomicAdd(tileCtl + 4 + src, 1u);   // the tile after next; consumed after the window barrier
-		const int g2 = (int)dc[0], g3 = (int)dc[1], ca = (int)dc[2], ncells = (int)dc[3];
-		const bool inRange = tile_in_range(dc, a.fromParticle, a.toParticle);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
-		const bool pairs = (dc[13] & 1u) || STRESS;   // no fluid anywhere in the window: nothing interacts
+		const int g2 = __builtin_amdgcn_readlane((int)dwc, 0), g3 = __builtin_amdgcn_readlane((int)dwc, 1);
+		const int ca = __builtin_amdgcn_readlane((int)dwc, 2), ncells = __builtin_amdgcn_readlane((int)dwc, 3);
+		const bool inRange = wholeRange || tile_in_range(dwc, a.fromParticle, a.toParticle);   // tiles outside [fromParticle, toParticle) (multi-GPU stripes) are skipped whole
+		const bool pairs = ((uint32_t)__builtin_amdgcn_readlane((int)dwc, 13) & 1u) || STRESS;   // no fluid anywhere in the window: nothing interacts
 
+		SPHX_PROF(8);
 		lds_barrier();   // the previous tile's pair phase is over: its partial sums are complete, the window is free
+		SPHX_PROF(1);
 		// everything requested so far landed long ago (the requests were made before the pair phase); waiting for it HERE
 		// keeps the finalize stage below from queueing behind the DMA that is issued next
 		__builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
-		for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(fInfo[k].x), "+v"(fInfo[k].y), "+v"(fVal[k]), "+v"(fIdx[k]));
+		for (int k = 0; k < 2; ++k) asm volatile("" : "+v"(fVal[k]), "+v"(fIdx[k]));
 		// ... which includes what the previous tile's ring fetched past its end and the batches requested for this tile
 		if (TileAsmRing<TURB>::value) acc_fetch_ahead(ac.lw);
 		const uint32_t nextTile = __builtin_amdgcn_readfirstlane(sTileQ[1]);
 		const bool haveNext = nextTile < tileEnd;
-		if (haveNext) {
-#pragma unroll
-			for (int k = 0; k < TILE_DESC; ++k) dn[k] = tiles[(size_t)TILE_DESC*nextTile + k];
-		}
+		if (haveNext) dwn = tiles[(size_t)TILE_DESC*nextTile + (lane & (uint32_t)(TILE_DESC - 1))];
 		RowJobs rjc;
 		resolve_row_jobs(rrc, wave, rjc);
 
@@ -1431,23 +1461,26 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					if ((uint32_t)c*64u + lane < total) hsh[k][c] = a.hash[rs + (uint32_t)c*64u + lane];
 			}
 		}
-		const WaveJob wj = wave_job(rtc, dc, wave);
-		if (inRange && pairs) {      // ... and the lane records of the chunks (wave w: chunks w and w + 8), 4 bytes per lane
+		const WaveJob wj = wave_job(rtc, dwc, wave);
+		if (inRange) {      // ... and the lane records of the chunks (wave w: chunks w and w + 8), 4 bytes per lane
 #pragma unroll
 			for (int k = 0; k < 2; ++k) {
 				const uint32_t c = wave + (uint32_t)(TILE_WAVES*k);
 				if (c < wj.chunks)
-					__builtin_amdgcn_global_load_lds((gptr_t)(a.tileLaneRec + wj.laneBase + c*64u + lane), (lptr_t)(sLaneRec + c*64u), 4, 0, 0);
+					__builtin_amdgcn_global_load_lds((gptr_t)(a.tileLaneRec + wj.laneBase + c*64u + lane), (lptr_t)(sLaneRec[par] + c*64u), 4, 0, 0);
 			}
 		}
 		if (haveNext) {   // behind the DMA in the memory pipeline, consumed when the next tile starts
-			request_row_jobs(a.tileRows, nextTile, wave, rrn);
+			rrn = request_row_jobs(a.tileRows, nextTile, lane);
 			rtn = a.tileRuns[(size_t)TILE_RUNTAB*nextTile + min(lane, (uint32_t)(TILE_RUNTAB - 1))];
 		}
+		SPHX_PROF(2);
 		// 2. finalize the previous tile while the DMA is in flight: partial sums from LDS, the particle's own data from
 		//    registers (requested before that tile's pair phase), results to memory
 		if (havePrev) finalize_prev();
+		SPHX_PROF(3);
 		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA and hashes have landed
+		SPHX_PROF(4);
 		if (inRange && pairs) {
 #pragma unroll
 			for (int k = 0; k < TILE_RPW; ++k) {
@@ -1507,39 +1540,46 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 				}
 			}
 		}
+		SPHX_PROF(5);
 		__syncthreads();                      // everybody's rows are in place and converted; the previous tile's sums are consumed
+		SPHX_PROF(6);
 		if (tid == 0) sTileQ[1] = resolve(drawn);   // read after the first barrier of the next iteration
 		// 3. requests: the next tile's first batches and lanes; the own data of THIS tile's particles for its finalize stage
-		const bool nextInRange = haveNext && tile_in_range(dn, a.fromParticle, a.toParticle);
-		if (nextInRange) request_ahead(dn, rtn, an);
+		const bool nextInRange = haveNext && (wholeRange || tile_in_range(dwn, a.fromParticle, a.toParticle));
+		if (nextInRange) request_ahead(dwn, rtn, an);
 #pragma unroll
 		for (int k = 0; k < 2; ++k) {
 			const uint32_t c = wave + (uint32_t)(TILE_WAVES*k);
 			fIdx[k] = inRange ? ac.idx[k] : 0xFFFFFFFFu;
 			// a tile whose window was not staged (no fluid in reach) has only wall particles at home: no runs were walked
 			fTab[k] = (inRange && pairs && c < wj.chunks) ? (uint32_t)__builtin_amdgcn_readlane((int)rtc, (int)(TILE_RT_CHUNK + c)) : 0u;
-			const uint32_t li = (fIdx[k] != 0xFFFFFFFFu) ? fIdx[k] : 0u;
-			if (k == 0 || __builtin_amdgcn_ballot_w64(fIdx[k] != 0xFFFFFFFFu)) {
-				fInfo[k] = reinterpret_cast<const uint2*>(a.info)[li];
-				if (STRESS) fVal[k] = reinterpret_cast<const float*>(a.vel)[4u*(size_t)li + 3u];
-				else if (SA_DIFF) fVal[k] = reinterpret_cast<const float*>(a.saGam)[4u*(size_t)li + 3u];
-				else if (!SA) fVal[k] = reinterpret_cast<const float*>(a.aux)[4u*(size_t)li + 1u];
+			if (!VAL_LDS && SA_DIFF && (k == 0 || __builtin_amdgcn_ballot_w64(fIdx[k] != 0xFFFFFFFFu))) {
+				const uint32_t li = (fIdx[k] != 0xFFFFFFFFu) ? fIdx[k] : 0u;
+				fVal[k] = reinterpret_cast<const float*>(a.saGam)[4u*(size_t)li + 3u];
+			}
+			if (!VAL_LDS && SPSC && (k == 0 || __builtin_amdgcn_ballot_w64(fIdx[k] != 0xFFFFFFFFu))) {
+				const uint32_t li = (fIdx[k] != 0xFFFFFFFFu) ? fIdx[k] : 0u;
+				fVal[k] = reinterpret_cast<const float*>(a.aux)[4u*(size_t)li + 1u];
 			}
 		}
 
+		SPHX_PROF(7);
 		// 4. the pair phase: this wave's share of the tile's list batches
 		if (inRange && pairs && wj.nRuns)
-			walk_runs<KERNEL, TURB, COLAGROSSI, LJ>(p, a, stream, wj, rtc, lane, inv_h, sPos, sVel, sAux, sPart, sLaneRec, ac.lw);
+			walk_runs<KERNEL, TURB, COLAGROSSI, LJ>(p, a, stream, wj, rtc, lane, inv_h, sPos, sVel, sAux, sPart, sLaneRec[par], sVal, ac.lw);
 		havePrev = inRange;
+#ifdef SPHX_TILE_DEBUG_BUILD
+		if (prof) pacc[9] += 1;
+#endif
 		if (!haveNext) break;
 		tile = nextTile;
-#pragma unroll
-		for (int k = 0; k < TILE_DESC; ++k) dc[k] = dn[k];
-		rrc = rrn; rtc = rtn;
+		dwc = dwn; rrc = rrn; rtc = rtn;
 		ac = an;
+		par ^= 1u;
 	}
 	lds_barrier();
 	__builtin_amdgcn_s_waitcnt(0x0F70);
+	par ^= 1u;      // finalize_prev reads the other half
 	if (havePrev) finalize_prev();
 	// CFL: the array is only ever max-reduced (fmaxDevice / dtreduce), so the maxima need not sit in the reference's
 	// one-entry-per-128-particles places: every wave maxes its running value into one entry of the caller's range, once per
@@ -1552,6 +1592,15 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			atomicMax(reinterpret_cast<unsigned int*>(a.cfl + a.cflOffset + (blockIdx.x*(TILE_THREADS/64) + wave) % a.numBlocks), __float_as_uint(cflRun));
 	}
 	if (tid == 0) tile_group_done(tileCtl);
+#ifdef SPHX_TILE_DEBUG_BUILD
+	if (prof && lane == 0) {
+		unsigned long long *o = a.prof + 10*((size_t)blockIdx.x*(TILE_THREADS/64) + wave);
+		pacc[0] = __builtin_amdgcn_s_memtime() - tBegin;
+#pragma unroll
+		for (int k = 0; k < 10; ++k) o[k] = pacc[k];
+	}
+#endif
+#undef SPHX_PROF
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1941,19 +1990,31 @@ void SPHX_PASTE(sphx_part_sps_k, SPHX_FORCES_PART)(const sphx_ctx *ctx, dim3 gri
 
 // which home particle of the tile thread t stands for: the four home rows one after the other (build_tiles_kernel)
 struct TileHome { uint32_t index; int hrow; };
-__device__ __forceinline__ TileHome tile_home(const uint32_t *d, uint32_t t)
+__device__ __forceinline__ TileHome tile_home(uint32_t dw /* this lane's word of the descriptor */, uint32_t t)
 {
 	TileHome h;
-	const uint32_t c0 = d[8], c1n = d[9], c2n = d[10];
+	const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)dw, 8), c1n = (uint32_t)__builtin_amdgcn_readlane((int)dw, 9),
+		c2n = (uint32_t)__builtin_amdgcn_readlane((int)dw, 10);
 	int hrow = 0; uint32_t hoff = t;
 	if (hoff >= c0) { hoff -= c0; hrow = 1; if (hoff >= c1n) { hoff -= c1n; hrow = 2; if (hoff >= c2n) { hoff -= c2n; hrow = 3; } } }
-	const uint32_t hfirst = (hrow == 0) ? d[4] : (hrow == 1) ? d[5] : (hrow == 2) ? d[6] : d[7];
+	const uint32_t f0 = (uint32_t)__builtin_amdgcn_readlane((int)dw, 4), f1 = (uint32_t)__builtin_amdgcn_readlane((int)dw, 5),
+		f2 = (uint32_t)__builtin_amdgcn_readlane((int)dw, 6), f3 = (uint32_t)__builtin_amdgcn_readlane((int)dw, 7);
+	const uint32_t hfirst = (hrow == 0) ? f0 : (hrow == 1) ? f1 : (hrow == 2) ? f2 : f3;
 	h.hrow = hrow;
 	h.index = hfirst + hoff;
 	return h;
 }
 
-__global__ void __launch_bounds__(TL_THREADS)
+// Measured at 32 M particles (scripts/ab_builder.sh, round 4): the kernel is bound by its traffic pattern, not by latency -- the
+// reference-format list is slot-major with the allocation as its stride, so the 128 rows a particle's list lies in are 64 MB
+// apart, every one in another page.  MORE loads in flight or MORE waves per CU make it slower (16 -> 32 entries per lane in
+// flight: 7.8 -> 13.2 ms; two workgroups per CU instead of one: 7.8 -> 9.2 ms): they only widen the set of pages and lines in use
+#ifndef TL_MINWAVES
+#define TL_MINWAVES 1
+#define TL_LOADS 16
+#define TL_GRIDMUL 8
+#endif
+__global__ void __launch_bounds__(TL_THREADS, TL_MINWAVES)
 tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t *__restrict__ neibCounts,
 	const particleinfo *__restrict__ info, const uint32_t *__restrict__ hash,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
@@ -1967,7 +2028,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	__shared__ uint16_t sCB[TILE_HROWS*TILE_MAXCELLS*27 + 8];      // [home cell][code] -> slot of the cell's first record
 	__shared__ uint16_t sHist[TILE_CHUNKS][TL_BINS];               // per wave: particles with a fluid section of that length; then: ... in the waves before
 	__shared__ uint16_t sBinTot[TL_BINS], sBinStart[TL_BINS];
-	__shared__ uint16_t sPerm[TILE_PMAX], sLenF[TILE_PMAX], sLenB[TILE_PMAX];   // by lane of the tile: home-order number, list lengths
+	__shared__ uint16_t sLaneOf[TILE_PMAX], sLenF[TILE_PMAX], sLenB[TILE_PMAX];   // lane of the tile by home-order number; list lengths by lane
 	__shared__ uint32_t sChunkF[TILE_CHUNKS + 1], sChunkB[TILE_CHUNKS + 1], sChunkStart[TILE_CHUNKS + 1];   // batches per section; first batch
 	__shared__ uint32_t sSorted[32];
 	__shared__ uint32_t sRunTab[TILE_RUNTAB];
@@ -1994,16 +2055,16 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	const size_t stride = (size_t)p.stride;
 	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
 		__syncthreads();   // the previous tile's tables are no longer read
-		uint32_t d[TILE_DESC];
-#pragma unroll
-		for (int k = 0; k < TILE_DESC; ++k) d[k] = tiles[(size_t)TILE_DESC*tile + k];
-		const int ca = (int)d[2];
-		const uint32_t P = d[8] + d[9] + d[10] + d[11];        // home particles (<= TILE_PMAX)
+		const uint32_t d = tiles[(size_t)TILE_DESC*tile + (lane & (uint32_t)(TILE_DESC - 1))];      // the descriptor, a word per lane
+		const int dg2 = __builtin_amdgcn_readlane((int)d, 0), dg3 = __builtin_amdgcn_readlane((int)d, 1);
+		const int ca = __builtin_amdgcn_readlane((int)d, 2), dnc = __builtin_amdgcn_readlane((int)d, 3);
+		const uint32_t P = (uint32_t)(__builtin_amdgcn_readlane((int)d, 8) + __builtin_amdgcn_readlane((int)d, 9) +
+			__builtin_amdgcn_readlane((int)d, 10) + __builtin_amdgcn_readlane((int)d, 11));        // home particles (<= TILE_PMAX)
 		const uint32_t C = (P + 63u)/64u;
 		for (uint32_t e = tid; e < TILE_CHUNKS*TL_BINS; e += TL_THREADS) (&sHist[0][0])[e] = 0;
 		if (tid < TILE_WROWS*TILE_KW) {
 			uint32_t wStart = 0, wCnt = 0;
-			window_cell(p, cellStart, cellEnd, (int)d[0], (int)d[1], ca, (int)d[3], wr, wcol, wStart, wCnt);
+			window_cell(p, cellStart, cellEnd, dg2, dg3, ca, dnc, wr, wcol, wStart, wCnt);
 			uint32_t incl = wCnt;
 			uint32_t lo = wCnt ? wStart : 0xFFFFFFFFu;
 			uint32_t hi = wCnt ? wStart + wCnt : 0u;
@@ -2093,15 +2154,12 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 		__syncthreads();
 		if (inHome) {
 			const uint32_t pos = (uint32_t)sBinStart[F] + sHist[wave][F] + rankInWave;
-			sPerm[pos] = (uint16_t)tid; sLenF[pos] = (uint16_t)F; sLenB[pos] = (uint16_t)B;
+			sLaneOf[tid] = (uint16_t)pos; sLenF[pos] = (uint16_t)F; sLenB[pos] = (uint16_t)B;
 		}
 		__syncthreads();
-		// from here on thread L is LANE L of the tile: lane L & 63 of chunk L >> 6 (= this thread's wave)
+		// for a moment thread L is LANE L of the tile (lane L & 63 of chunk L >> 6 = this thread's wave)
 		const uint32_t L = tid;
-		const bool valid = L < P;
-		const uint32_t myF = valid ? sLenF[L] : 0u, myB = valid ? sLenB[L] : 0u;
-		const TileHome h = tile_home(d, valid ? (uint32_t)sPerm[L] : 0u);
-		const uint32_t index = h.index;
+		const uint32_t myF = L < P ? sLenF[L] : 0u, myB = L < P ? sLenB[L] : 0u;
 		{	// the chunk's sections are padded to its longest list, in whole batches
 			uint32_t mxF = myF, mxB = myB;
 #pragma unroll
@@ -2157,13 +2215,13 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 			const uint32_t chunkSel = isChunk ? lane : cstar;
-			const uint32_t chStart = __shfl(cStart, (int)chunkSel), chF = __shfl(nF, (int)chunkSel);
+			const uint32_t chStart = __shfl(cStart, (int)chunkSel), chF = __shfl(nF, (int)chunkSel), chEnd = __shfl(cEnd, (int)chunkSel);
 			if (inS) {         // my run: from my boundary point to the next one
 				const uint32_t r = cntLt;
 				const uint32_t end = (r + 1u < R) ? sSorted[r + 1u] : T;
 				const uint32_t a0 = lo - chStart, len = end - lo;
 				const uint32_t runF = (a0 < chF) ? min(chF - a0, len) : 0u;
-				sRunTab[TILE_RT_RUN + min(r, (uint32_t)(TILE_RUNS_MAX - 1))] = chunkSel | (runF << 4) | ((len - runF) << 12);
+				sRunTab[TILE_RT_RUN + min(r, (uint32_t)(TILE_RUNS_MAX - 1))] = chunkSel | (runF << 4) | ((len - runF) << 12) | (end == chEnd ? TILE_RUN_LAST : 0u);
 			}
 			// wave (lane - 16): first run (the one starting at its first batch: that batch is a boundary), the runs that start
 			// inside its share, first batch, batches
@@ -2187,36 +2245,49 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			if (tid == 0) { tiles[(size_t)TILE_DESC*tile + 14] = listBase; tiles[(size_t)TILE_DESC*tile + 15] = laneBase; }
 			if (tid < TILE_RUNTAB) tileRuns[(size_t)TILE_RUNTAB*tile + tid] = sRunTab[tid];
 		}
-		// ---- 5. the lane tables and the translated lists
+		// ---- 5. the lane tables and the translated lists.  Back in home order: thread t stands for home particle t (consecutive
+		// threads read consecutive columns of the neighbour list: whole lines; in lane order a wave gathered two-byte entries
+		// from all over the tile) and, from P on, for the idle lanes of the last chunk.  The eight-byte stores go to the lane's
+		// place in its chunk's batches (scattered, but a quarter as many as the loads)
+		const bool isHome = tid < P, isLane = tid < C*64u;
+		const uint32_t myLane = isHome ? (uint32_t)sLaneOf[tid] : tid;
+		const uint32_t ch = min(myLane >> 6, (uint32_t)(TILE_CHUNKS - 1)), ln = myLane & 63u;
+		const TileHome h = tile_home(d, isHome ? tid : 0u);
+		const uint32_t index = h.index;
 		const int3 gp = grid_pos_from_hash(p, hash[index] & CELLTYPE_BITMASK);
 		const int myG1 = (p.c1 == 0) ? gp.x : (p.c1 == 1) ? gp.y : gp.z;
 		const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
 		const uint16_t *myCB = sCB + (h.hrow*TILE_MAXCELLS + myCol)*27;
-		if (wave < C && !sBase[2]) {
-			uint32_t rec = 0u, idx = 0xFFFFFFFFu;
-			if (valid) {   // the particle's own row in the window (the forces kernel reads its position, velocity and EOS row there)
-				const int wc = (5 + (h.hrow & 1) + 4*(h.hrow >> 1))*TILE_KW + myCol + 1;
-				const uint32_t slot = 1u + sCellBase[wc] + (index - sCellStart[wc]);
-				if (slot > 4095u) overflow = true;
-				const particleinfo pi = info[index];
-				const uint32_t flags = PART_TYPE(pi) | (HAS_COMPUTE_FORCE(pi) ? LANE_COMPUTE_FORCE : 0u) | ((FLUID_NUM(pi) & 3u) << LANE_FLUID_SHIFT) | LANE_VALID;
-				rec = ((slot << 4) & 0xFFFFu) | (flags << 16);
-				idx = index;
+		if (!sBase[2]) {
+			if (isLane) {
+				uint32_t rec = 0u, idx = 0xFFFFFFFFu;
+				if (isHome) {   // the particle's own row in the window (the forces kernel reads its position, velocity and EOS row there)
+					const int wc = (5 + (h.hrow & 1) + 4*(h.hrow >> 1))*TILE_KW + myCol + 1;
+					const uint32_t slot = 1u + sCellBase[wc] + (index - sCellStart[wc]);
+					if (slot > 4095u) overflow = true;
+					const particleinfo pi = info[index];
+					const uint32_t flags = PART_TYPE(pi) | (HAS_COMPUTE_FORCE(pi) ? LANE_COMPUTE_FORCE : 0u) | ((FLUID_NUM(pi) & 3u) << LANE_FLUID_SHIFT) | LANE_VALID;
+					rec = ((slot << 4) & 0xFFFFu) | (flags << 16);
+					idx = index;
+				}
+				laneRec[laneBase + myLane] = rec; laneIndex[laneBase + myLane] = idx;
 			}
-			laneRec[laneBase + L] = rec; laneIndex[laneBase + L] = idx;
-			const uint32_t chunkStart = sChunkStart[wave];
+			const uint32_t chunkStart = sChunkStart[ch], chF = sChunkF[ch], chB = sChunkB[ch];
 #pragma unroll 1
 			for (int sec = 0; sec < 2; ++sec) {
 				// section 0: slots 0 upward, section 1: slots neibboundpos downward (SA_BOUNDARY: the vertex section, slots
-				// neibboundpos + 1 upward; the boundary elements are not particles of a window).  The chunk's batches of the
-				// section are wave-uniform: every lane writes all of them, padded with the dummy row's offset
-				const uint32_t nbat = sec ? sChunkB[wave] : sChunkF[wave];
-				const uint32_t cnt = sec ? myB : myF;
-				uint2 *out = tileList + ((size_t)listBase + chunkStart + (sec ? sChunkF[wave] : 0u))*64u + lane;
+				// neibboundpos + 1 upward; the boundary elements are not particles of a window).  Every lane of a chunk writes all
+				// the chunk's batches of the section, padded with the dummy row's offset
+				const uint32_t nbat = isLane ? (sec ? chB : chF) : 0u;
+				const uint32_t cnt = isHome ? (sec ? B : F) : 0u;
+				uint2 *out = tileList + ((size_t)listBase + chunkStart + (sec ? chF : 0u))*64u + ln;
+				uint32_t nbatWave = nbat;      // the wave walks to the longest of its lanes' chunks
+#pragma unroll
+				for (int dd = 32; dd > 0; dd >>= 1) nbatWave = max(nbatWave, (uint32_t)__shfl_xor(nbatWave, dd));
 				uint32_t code = 0;
-				constexpr int LOADS = 16;   // entries per lane in flight: the walk is latency bound
+				constexpr int LOADS = TL_LOADS;   // entries per lane in flight: the walk is latency bound
 #pragma unroll 1
-				for (uint32_t b0 = 0; b0 < nbat; b0 += LOADS/TILE_NB) {
+				for (uint32_t b0 = 0; b0 < nbatWave; b0 += LOADS/TILE_NB) {
 					uint32_t e[LOADS];
 #pragma unroll
 					for (int k = 0; k < LOADS; ++k) {
@@ -2254,7 +2325,7 @@ int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void 
 		ctx->tiles_built = false;
 		return SPHX_OK;
 	}
-	const uint32_t grid = ctx->tile_grid*8u < ctx->tile_capacity ? ctx->tile_grid*8u : ctx->tile_capacity;
+	const uint32_t grid = ctx->tile_grid*TL_GRIDMUL < ctx->tile_capacity ? ctx->tile_grid*TL_GRIDMUL : ctx->tile_capacity;
 	tile_lists_kernel<<<grid, TL_THREADS, 0, st>>>(ctx->dev, neibsList, ctx->neib_counts, (const particleinfo*)info, hash, cellStart, ctx->cell_end_copy,
 		ctx->tiles, ctx->tile_ctl, ctx->tile_rows, ctx->tile_runs, ctx->tile_list, ctx->tile_list_batches, ctx->tile_lane_rec, ctx->tile_lane_index,
 		ctx->tile_lane_cap, sa ? 1 : 0);
@@ -2329,9 +2400,18 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	a.tileLaneRec = ctx->tile_lane_rec; a.tileLaneIndex = ctx->tile_lane_index;
 	a.xsph = (float4*)xsph;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset;
+	a.wholeRange = (fromParticle == 0u && toParticle == numParticles) ? 1 : 0;
 	a.numBlocks = numBlocks;
 	a.compute_object_forces = compute_object_forces;
 	a.pin = nullptr;
+#ifdef SPHX_TILE_DEBUG_BUILD
+	a.prof = nullptr;
+	if (ctx->tile_debug & 16) {
+		if (!ctx->tile_prof && hipMalloc((void**)&ctx->tile_prof, 10*(TILE_THREADS/64)*sizeof(unsigned long long)*ctx->tile_grid) != hipSuccess)
+			return sphx_set_error(SPHX_ERR_RUNTIME, "sphx_forces_basicstep: cannot allocate the tile profile buffer");
+		a.prof = ctx->tile_prof;
+	}
+#endif
 
 	sphx_tiles_overflow_poll(ctx);
 	// the tiling belongs to the neighbour list built last by this context from these very buffers
@@ -2407,6 +2487,7 @@ int sphx_sa_tiles_run(sphx_ctx *ctx, int mode, void *forces, const void *pos, co
 	a.saGam = (const float4*)gGam; a.saDt = dt;
 	a.rb = ctx->rb_dev;
 	a.fromParticle = fromParticle; a.toParticle = toParticle;
+	a.wholeRange = (fromParticle == 0u && toParticle == numParticles) ? 1 : 0;
 	sphx_part_sa_tile(ctx, stream, a, mode, d.rheology == SPHX_NEWTONIAN);
 	SPHX_LAUNCH_CHECK("forces_tile_kernel (SA_BOUNDARY)");
 	*used = true;
@@ -2543,6 +2624,18 @@ extern "C" int sphx_calc_visc(sphx_ctx *ctx, void *tau0, void *tau1, void *tau2,
 	SPHX_LAUNCH_CHECK("sps_kernel");
 	return SPHX_OK;
 }
+
+#ifdef SPHX_TILE_DEBUG_BUILD
+// timing experiments only (library built with -DSPHX_TILE_DEBUG_BUILD, SPHX_TILE_DEBUG=16): cycles per phase of every wave of
+// the last tiled forces launch
+extern "C" int sphx_dbg_tile_profile(sphx_ctx *ctx, unsigned long long *host, uint32_t maxGroups)
+{
+	if (!ctx || !ctx->tile_prof) return -1;
+	const uint32_t n = maxGroups < ctx->tile_grid ? maxGroups : ctx->tile_grid;
+	if (hipMemcpy(host, ctx->tile_prof, 10*(TILE_THREADS/64)*sizeof(unsigned long long)*n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+	return (int)n;
+}
+#endif
 
 // timing experiments only, not part of include/sphx.h: the tile descriptors of the last neighbour-list build
 extern "C" int sphx_dbg_tiles(sphx_ctx *ctx, uint32_t *host, uint32_t maxTiles)

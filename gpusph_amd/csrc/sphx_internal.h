@@ -36,9 +36,9 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 #ifndef TILE_THREADS
 #define TILE_THREADS  512                  // threads of the tiled kernel's workgroup: 8 waves, two per SIMD
 #define TILE_PMAX     640                  // home particles per tile: ten chunks of 64, dealt out to the eight waves batch by batch
-#define TILE_WCAP     2984                 // window records that fit LDS (48 B each, 1 workgroup per CU) next to the partial sums and the lane records
-#define TILE_WCAP_SPS 1786                 // ... with the SPS stress tensor of every window particle (80 B each)
-#define TILE_WCAP_SPS1 2238                // ... of an SPS run with one fluid (64 B each: no EOS rows, see tau_pack_kernel)
+#define TILE_WCAP     2876                 // window records that fit LDS (48 B each, 1 workgroup per CU) next to the partial sums and the lane records
+#define TILE_WCAP_SPS 1720                 // ... with the SPS stress tensor of every window particle (80 B each)
+#define TILE_WCAP_SPS1 2156                // ... of an SPS run with one fluid (64 B each: no EOS rows, see tau_pack_kernel)
 #define TILE_WGS_PER_CU 1                  // persistent workgroups per CU (LDS bound)
 #endif
 #define SA_WALL_CACHE_ENTRIES 96           // boundary-section entries per wall particle whose |grad gamma_as| is kept (more: recomputed)
@@ -58,8 +58,9 @@ enum { PT_FLUID = 0, PT_BOUNDARY = 1, PT_VERTEX = 2, PT_TESTPOINT = 3, PT_NONE =
 //   [w], w < 8        wave w: first run | runs << 5 | first batch (tile-relative) << 10 | batches << 22
 //   [8]               chunks | home particles << 8 | runs << 24
 //   [9 + c], c < 10   chunk c: first run | runs << 8   (its partial sums, in list order)
-//   [24 + r], r < 17  run r: chunk | batches of the fluid section << 4 | batches of the second section << 12
+//   [24 + r], r < 17  run r: chunk | batches of the fluid section << 4 | batches of the second section << 12 | TILE_RUN_LAST if it ends its chunk
 #define TILE_RUNTAB   48
+#define TILE_RUN_LAST (1u << 20)
 #define TILE_RT_CHUNK 9
 #define TILE_RT_RUN   24
 #define TILE_NB       4                    // neighbours per batch in the tiled pair loop
@@ -192,6 +193,7 @@ struct sphx_ctx {
 	bool        ovf_pending;
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
 	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments; only with -DSPHX_TILE_DEBUG_BUILD)
+	unsigned long long *tile_prof;   // ... & 16: phase timers of the tiled forces kernel
 	bool        time_forces;   // sphx_forces_timing: bracket the dominant forces kernel with HIP events
 	std::vector<std::pair<hipEvent_t, hipEvent_t> > *forces_events;
 	const void *tiles_cellstart, *tiles_neibslist;

@@ -6,8 +6,20 @@ from gpusph_amd.problem import SABox
 from oracle_lib import Oracle, orc_params_from
 
 
-def assert_close_but_for_gamma_spikes(got, want, tol, scale=None, frac=0.01, spike=200.0, what=""):
+def wall_rows(problem, nl, info, n):
+    """which of the n sorted particles have a boundary element in reach: a non-empty boundary section of the neighbour list
+    (walls and vertices sit on the elements themselves: always)"""
+    sp = problem.simparams
+    nl2 = np.asarray(nl).view(np.uint16).reshape(sp.neiblistsize, -1)[:, :n]
+    fluid = (np.asarray(info).view(np.uint16).reshape(-1, 4)[:n, 0] & 7) == D.PT_FLUID
+    return (nl2[sp.neibboundpos] != 0xFFFF) | ~fluid
+
+
+def assert_close_but_for_gamma_spikes(got, want, tol, scale=None, frac=0.01, spike=200.0, what="", wall=None):
     """|got - want| <= tol * scale for all but a fraction `frac` of the entries, and <= spike * tol * scale for those.
+    `wall` (one flag per row of got / want, see wall_rows): the allowance is for the rows that have a boundary element in
+    reach ONLY -- every other row must hold tol * scale, so that an indexing or ordering bug of the particle <- particle
+    sums cannot hide behind it.
 
     The closed form of |grad gamma_as| (edge antiderivatives that cancel against each other and against the angle
     bookkeeping) is ill-conditioned for some positions of a particle relative to an element: two float evaluations of the
@@ -23,6 +35,12 @@ def assert_close_but_for_gamma_spikes(got, want, tol, scale=None, frac=0.01, spi
     worst = float(err.max()) if err.size else 0.0
     assert bad <= frac and worst <= spike * tol * s, "%s: %.3g of the entries beyond %.1e of the scale %.3g (allowed %.3g), worst %.3g of the scale (allowed %.3g)" % (
         what, bad, tol, s, frac, worst / max(s, 1e-300), spike * tol)
+    if wall is not None:
+        wall = np.asarray(wall, dtype=bool)
+        assert len(wall) == len(err), "%s: one wall flag per row" % what
+        away = err[~wall]
+        assert away.size == 0 or away.max() <= tol * s, "%s: a row with no boundary element in reach is %.3g of the scale off (allowed %.1e)" % (
+            what, away.max() / max(s, 1e-300), tol)
 
 
 def analytic_vertex_gamma(problem, st):

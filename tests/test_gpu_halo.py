@@ -192,3 +192,77 @@ def test_cpp_workers_run_a_decomposed_dam_break(tmp_path, monkeypatch, world, li
         assert np.array_equal(got.view(np.uint32), _np(tns)[:nr][ro].view(np.uint32)), key
     assert all(p["dt"] == np.float32(ref.current_dt()) for p in parts)
     assert all(p["t"] == ref.time() for p in parts)
+
+
+@pytest.mark.timeout(900)
+def test_two_slabs_of_8M_particles_on_one_gpu():
+    """BASELINE configs[3]'s decomposition at a size that matters: DamBreak3D with 8 M particles cut into two slabs on COORD3,
+    both on the one device of this box, two worker threads exchanging their edge layers through sphx_halo_* (peer copies),
+    edge stripe first and the inner stripe overlapped, the TILED kernels (the ones the bench runs).  Against the single
+    domain after 4 steps incl. the neighbour-list build: every particle owned by exactly one slab, same cells, positions to
+    1e-6 of a cell per step, velocities to 1e-4 of the largest (the slabs tile differently: agreement to rounding)."""
+    import torch
+    from gpusph_amd import capi
+    from gpusph_amd.engine import TimestepEngine
+    from gpusph_amd.halo import CapiTransport
+    from gpusph_amd.multigpu import MultiGpuEngine
+    dp = DamBreak3D.deltap_for(8e6)
+    kw = dict(deltap=dp, obstacle=True, linearization="xzy")
+    steps = 4
+    lib = capi.load()
+    group = CapiTransport.new_group(lib, 2)
+    out, errors = [None, None], []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            eng = MultiGpuEngine(DamBreak3D(**kw), "cuda:0", rank, 2, track_particle_count=False,
+                                 transport=lambda k: CapiTransport(k, rank, 2, group=group))
+            for _ in range(steps):
+                eng.step()
+            torch.cuda.synchronize()
+            usable = int(eng.k.lib.sphx_dbg_tiles_usable(eng.k.ctx.handle))
+            out[rank] = (eng.download_internal(), eng.current_dt(), eng.halo_bytes, eng.n_local, usable)
+            eng.transport.close()
+            del eng
+        except BaseException as e:
+            errors.append((rank, repr(e)))
+            raise
+
+    threads = [threading.Thread(target=worker, args=(r,), daemon=True) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=800)
+    assert not errors, errors
+    assert all(o is not None for o in out), "a worker did not finish"
+    lib.sphx_halo_group_destroy(group)
+    assert all(o[4] == 1 for o in out), "the slabs did not run on the tiled kernels"
+
+    prob = DamBreak3D(**kw)
+    ref = TimestepEngine(prob, device="cuda:0", track_particle_count=False)
+    for _ in range(steps):
+        ref.step()
+    n = ref.n
+    assert n > 7.5e6
+    parts = [o[0] for o in out]
+    ids = np.concatenate([p["info"][:, 2].astype(np.uint32) | (p["info"][:, 3].astype(np.uint32) << 16) for p in parts])
+    order = np.argsort(ids)
+    rinfo = _np(ref.info, np.uint16)[:n]
+    rid = rinfo[:, 2].astype(np.uint32) | (rinfo[:, 3].astype(np.uint32) << 16)
+    ro = np.argsort(rid)
+    assert np.array_equal(ids[order], rid[ro])                       # every particle owned by exactly one slab
+    cs = float(min(prob.m_cellsize))
+    got = np.concatenate([p["pos"] for p in parts])[order]; want = _np(ref.pos)[:n][ro]
+    assert np.array_equal(got[:, 3].view(np.uint32), want[:, 3].view(np.uint32))
+    hg = np.concatenate([p["hash"] for p in parts])[order]
+    same_cell = (hg & 0x3FFFFFFF) == (_np(ref.hash, np.uint32)[:n][ro] & 0x3FFFFFFF)
+    assert same_cell.mean() > 0.9999
+    assert np.abs(got[same_cell, :3] - want[same_cell, :3]).max() <= steps * 1e-6 * cs
+    got = np.concatenate([p["vel"] for p in parts])[order]; want = _np(ref.vel)[:n][ro]
+    assert np.abs(got[:, :3] - want[:, :3]).max() <= 1e-4 * max(np.abs(want[:, :3]).max(), 1e-3)
+    assert np.abs(got[:, 3] - want[:, 3]).max() <= 3e-6
+    assert all(abs(o[1] - ref.current_dt()) <= 1e-4 * ref.current_dt() for o in out)
+    assert all(o[2] > 0 and o[3] > len(o[0]["pos"]) for o in out)   # bytes did move, every slab holds a halo
+    # the slabs are halves: the edge layers are two planes of ~200 x 200 cells
+    assert abs(len(parts[0]["pos"]) - len(parts[1]["pos"])) < 0.2 * n

@@ -6,7 +6,7 @@ import pytest
 
 from gpusph_amd import defs as D
 from gpusph_amd.problem import SABox, DamBreak3D, info_type
-from sa_helpers import sa_oracle_state, assert_close_but_for_gamma_spikes
+from sa_helpers import sa_oracle_state, assert_close_but_for_gamma_spikes, wall_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -198,8 +198,10 @@ def test_sa_forces_gamma_integration_and_trajectory(kernels):
     # tolerance: the state is hydrostatic, i.e. every force is the small remainder of pressure terms ~50x its size, and the
     # pressures come from powf of two math libraries (1 ulp of (1+rho~)^7 is 1e-5 of P): 1e-4 of the largest force
     scale = np.abs(f[fl, :3]).max()
-    assert_close_but_for_gamma_spikes(gf[fl, :3], f[fl, :3], 1e-4, scale, what="SA forces")
-    assert_close_but_for_gamma_spikes(gf[fl, 3], f[fl, 3], 1e-4, max(np.abs(f[fl, 3]).max(), 1e-3), what="SA continuity")
+    wall = wall_rows(sim.problem, sim.nl, sim.info, n)      # the gamma allowance is for particles next to a wall only
+    assert 0.05 < wall[fl].mean() < 0.95
+    assert_close_but_for_gamma_spikes(gf[fl, :3], f[fl, :3], 1e-4, scale, what="SA forces", wall=wall[fl])
+    assert_close_but_for_gamma_spikes(gf[fl, 3], f[fl, 3], 1e-4, max(np.abs(f[fl, 3]).max(), 1e-3), what="SA continuity", wall=wall[fl])
     assert not gf[t != D.PT_FLUID].any()
     assert_close_but_for_gamma_spikes(_np(eng.cfl)[:nb], cfl[:nb], 1e-4, what="SA CFL maxima")
     # gamma by quadrature at displaced positions
@@ -211,7 +213,7 @@ def test_sa_forces_gamma_integration_and_trajectory(kernels):
     k.sa_integrate_gamma(eng.gradgamma2, eng.gradgamma, eng.pos2, eng.boundelements, eng.vertpos, eng.info, eng.hash, eng.cellStart,
                          eng.neibslist, n, n)
     gg1 = _np(eng.gradgamma2)[:n]
-    assert_close_but_for_gamma_spikes(gg1[fl, :3], g1[fl, :3], 5e-5, what="grad gamma by quadrature")
+    assert_close_but_for_gamma_spikes(gg1[fl, :3], g1[fl, :3], 5e-5, what="grad gamma by quadrature", wall=wall[fl])
     assert np.abs(gg1[fl, 3] - g1[fl, 3]).max() < 5e-6
     assert np.array_equal(_bits(gg1[t != D.PT_FLUID]), _bits(sim.gg[t != D.PT_FLUID]))      # walls: copied
     # six steps of the full sequence
@@ -278,13 +280,14 @@ def test_density_summation_form_on_the_gpu(kernels):
                       eng.boundelements, eng.vertpos, n, 0, n, 0, cfl_gamma=eng.cfl_gamma)
     assert gnb == nb
     gf = _np(eng.forces)[:n]
-    assert_close_but_for_gamma_spikes(gf[fl, :3], f[fl, :3], 1e-4, what="SA forces (density-summation form)")
+    wall = wall_rows(sim.problem, sim.nl, sim.info, n)      # the gamma allowance is for particles next to a wall only
+    assert_close_but_for_gamma_spikes(gf[fl, :3], f[fl, :3], 1e-4, what="SA forces (density-summation form)", wall=wall[fl])
     assert not gf[fl, 3].any() and not f[fl, 3].any()
     n4 = (n + 3) // 4 * 4
     gcg = _np(eng.cfl_gamma)
     assert o.max_gamma_cfl > 0.1
     gscale = o.cfl_gamma[:n].max()
-    assert_close_but_for_gamma_spikes(gcg[:n], o.cfl_gamma[:n], 1e-4, gscale, what="gamma CFL terms")
+    assert_close_but_for_gamma_spikes(gcg[:n], o.cfl_gamma[:n], 1e-4, gscale, what="gamma CFL terms", wall=wall)
     assert_close_but_for_gamma_spikes(gcg[n4:n4 + nb], o.cfl_gamma[n4:n4 + nb], 1e-4, gscale, what="gamma CFL maxima")
     # dt with the gamma condition
     dt_ref = min(o.dtreduce(cfl, nb, sim.sspeed_cfl, sim.max_kinvisc), 1e9)
@@ -301,10 +304,10 @@ def test_density_summation_form_on_the_gpu(kernels):
     k.sa_density_sum(eng.vel2, eng.gradgamma2, eng.forces, eng.pos, eng.pos2, eng.vel, eng.gradgamma, eng.boundelements, eng.vertpos,
                      eng.info, eng.hash, eng.cellStart, eng.neibslist, n, n)
     gv1, gg1 = _np(eng.vel2)[:n], _np(eng.gradgamma2)[:n]
-    assert_close_but_for_gamma_spikes(gv1[:, 3], v1[:, 3], 2e-6, 1.0, what="density summation")
+    assert_close_but_for_gamma_spikes(gv1[:, 3], v1[:, 3], 2e-6, 1.0, what="density summation", wall=wall)
     assert np.array_equal(_bits(gv1[:, :3]), _bits(v1[:, :3]))
-    assert_close_but_for_gamma_spikes(gg1[fl, 3], g1[fl, 3], 5e-6, 1.0, what="dynamic gamma")
-    assert_close_but_for_gamma_spikes(gg1[fl, :3], g1[fl, :3], 5e-5, what="grad gamma at the new positions")
+    assert_close_but_for_gamma_spikes(gg1[fl, 3], g1[fl, 3], 5e-6, 1.0, what="dynamic gamma", wall=wall[fl])
+    assert_close_but_for_gamma_spikes(gg1[fl, :3], g1[fl, :3], 5e-5, what="grad gamma at the new positions", wall=wall[fl])
     assert np.array_equal(_bits(gg1[t != D.PT_FLUID]), _bits(sim.gg[t != D.PT_FLUID]))
     dt = 3.0e-4
     v2, fd = o.sa_density_diffusion(newpos, v1, g1, sim.info, sim.hash, sim.cs, sim.nl, n, dt)
