@@ -195,9 +195,32 @@ def main():
                     print("bench.py: sphx_halo_unique_id failed (%s); exchange over torch.distributed" % exc, file=sys.stderr)
             dist.broadcast_object_list(box, src=0)
             if box[0] is not None:
-                transport = lambda k: CapiTransport(k, rank, world, unique_id=box[0])
-                transport_name = "sphx_halo (RCCL)"
+                # every rank creates its communicator, then all agree (over torch.distributed) on whether every one succeeded: a
+                # rank left alone with another transport than its neighbours would hang the run.  The exchange is the same
+                # either way; the line says which transport carried it
+                name_box = [transport_name]
+
+                def make_transport(k):
+                    from gpusph_amd.halo import TorchTransport
+                    t, ok = None, 1
+                    try:
+                        t = CapiTransport(k, rank, world, unique_id=box[0])
+                    except Exception as exc:
+                        ok = 0
+                        print("bench.py: rank %d: sphx_halo_create_rccl failed (%s)" % (rank, exc), file=sys.stderr)
+                    flag = torch.tensor([ok], dtype=torch.int32, device=device)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if int(flag.item()) == 1:
+                        name_box[0] = "sphx_halo (RCCL)"
+                        return t
+                    if t is not None:
+                        t.close()
+                    return TorchTransport(dist, True)
+
+                transport = make_transport
         eng = MultiGpuEngine(prob, device=device, rank=rank, world=world, track_particle_count=True, transport=transport)
+        if transport is not None:
+            transport_name = name_box[0]
     else:
         from gpusph_amd.engine import TimestepEngine
         eng = TimestepEngine(prob, device=device, track_particle_count=False)

@@ -805,10 +805,13 @@ __device__ __forceinline__ void pair_interact_pk(const DevParams &p, const Self 
 template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
 struct TilePk { static constexpr bool value = KERNEL == SPHX_WENDLAND && TURB == SPHX_ARTIFICIAL && COLAGROSSI != DIFF_FERRARI && !LJ; };
 
+#ifndef SPHX_ASMRING_ALL
+#define SPHX_ASMRING_ALL 0
+#endif
 // the instantiations whose list ring is hand-managed (load_list_b<true>): those that keep every value in registers.  The SPS
 // ones spill (their pair holds twelve more values per neighbour) and stay on compiler-managed loads
 template<int TURB>
-struct TileAsmRing { static constexpr bool value = TURB_MODEL(TURB) != SPHX_SPS; };
+struct TileAsmRing { static constexpr bool value = SPHX_ASMRING_ALL || TURB_MODEL(TURB) != SPHX_SPS; };
 
 // stage 2: the pair interactions of a gathered half, in list order; q = own position in the tile's frame
 // LJ = the run uses LJ_BOUNDARY: pairs of the boundary section (ljsec, wave-uniform) and all pairs of boundary
@@ -1091,9 +1094,28 @@ __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &
 	// The two waves of a SIMD (w and w + 4) take turns at being the one the issue arbiter prefers, batch by batch (priorities
 	// 3,3,0,0 against 2,1,2,1): left alone the older wave always wins and the younger one is starved while both have work
 	const bool hiw = (TILE_WAVES > 4) ? (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0) : (((blockIdx.x/256u) & 1u) != 0u);
+#ifndef TILE_PRIO_VARIANT
+#define TILE_PRIO_VARIANT 0
+#endif
+#if TILE_PRIO_VARIANT == 0
 #define SPHX_RING_PRIO(J) \
 	if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } \
 	else { if ((J) < 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+#elif TILE_PRIO_VARIANT == 1
+#define SPHX_RING_PRIO(J)
+#elif TILE_PRIO_VARIANT == 2
+#define SPHX_RING_PRIO(J) \
+	if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2); } \
+	else { if ((J) < 3) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+#elif TILE_PRIO_VARIANT == 3
+#define SPHX_RING_PRIO(J) \
+	if (hiw) { __builtin_amdgcn_s_setprio(1); } \
+	else { if ((J) < 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+#else
+#define SPHX_RING_PRIO(J) \
+	if (hiw) { if ((J) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); } \
+	else { if ((J) & 1) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+#endif
 	if (ASMR) {
 		// the ring lives in a0..a7 (AccRing above); `cur` is the batch being walked, in ordinary registers
 		acc_start_ring(lw);
@@ -1442,25 +1464,31 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 		//    (tile_shift of the record's cell: row from the row number, column from the hash) -- no other wave has to wait for
 		//    that, the one barrier below publishes the finished window
 		uint32_t hsh[TILE_RPW][TILE_HCH];
-		if (inRange && pairs) {
+		float4 posr[TILE_RPW][TILE_HCH];
+		auto stage_window_row = [&](int k) {
+			const uint32_t total = rjc.total[k], base = rjc.base[k], rs = rjc.start[k];
 #pragma unroll
-			for (int k = 0; k < TILE_RPW; ++k) {
-				const uint32_t total = rjc.total[k], base = rjc.base[k], rs = rjc.start[k];
+			for (int c = 0; c < TILE_HCH; ++c) hsh[k][c] = 0u;
+			if (!(inRange && pairs) || !total || base + total > WC || !rjc.contig[k]) return;
+			// positions go through registers: they are moved into the tile's frame on their way into the window (a DMA'd row had to
+			// be read back from LDS for that); everything else by DMA.  Rows longer than TILE_HCH chunks: the rest by DMA + a pass
 #pragma unroll
-				for (int c = 0; c < TILE_HCH; ++c) hsh[k][c] = 0u;
-				if (!total || base + total > WC || !rjc.contig[k]) continue;
-				stage_row_wave(a.pos + rs, sPos + 1 + base, total, lane);
-				if (!NOVEL) stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
-				if (!NOAUX) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
-				if (SPSW) {
-					stage_row_wave(a.tauPack + rs, sAux + TAU0 + 1 + base, total, lane);
-					stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + TAU0 + WS + 1 + base, total, lane);
-				}
-#pragma unroll
-				for (int c = 0; c < TILE_HCH; ++c)
-					if ((uint32_t)c*64u + lane < total) hsh[k][c] = a.hash[rs + (uint32_t)c*64u + lane];
+			for (int c = 0; c < TILE_HCH; ++c)
+				if ((uint32_t)c*64u + lane < total) posr[k][c] = a.pos[rs + (uint32_t)c*64u + lane];
+			if (total > (uint32_t)TILE_HCH*64u)
+				stage_row_wave(a.pos + rs + TILE_HCH*64, sPos + 1 + base + TILE_HCH*64, total - (uint32_t)TILE_HCH*64u, lane);
+			if (!NOVEL) stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
+			if (!NOAUX) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
+			if (SPSW) {
+				stage_row_wave(a.tauPack + rs, sAux + TAU0 + 1 + base, total, lane);
+				stage_row_wave(a.tauPack + a.tauPackN + rs, sAux + TAU0 + WS + 1 + base, total, lane);
 			}
-		}
+#pragma unroll
+			for (int c = 0; c < TILE_HCH; ++c)
+				if ((uint32_t)c*64u + lane < total) hsh[k][c] = a.hash[rs + (uint32_t)c*64u + lane];
+		};
+#pragma unroll
+		for (int k = 0; k < TILE_RPW; ++k) stage_window_row(k);
 		const WaveJob wj = wave_job(rtc, dwc, wave);
 		if (inRange) {      // ... and the lane records of the chunks (wave w: chunks w and w + 8), 4 bytes per lane
 #pragma unroll
@@ -1475,8 +1503,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			rtn = a.tileRuns[(size_t)TILE_RUNTAB*nextTile + min(lane, (uint32_t)(TILE_RUNTAB - 1))];
 		}
 		SPHX_PROF(2);
-		// 2. finalize the previous tile while the DMA is in flight: partial sums from LDS, the particle's own data from
-		//    registers (requested before that tile's pair phase), results to memory
+		// 2. finalize the previous tile while the DMA drains: partial sums from LDS, the particle's own data from LDS and
+		//    registers, results to memory.  (What bounds the staging is the rate at which the CU's address unit takes the DMA
+		//    instructions, ~16 cycles each; they are all queued first.  Measured: with the finalize stage between the two rows
+		//    of a wave the unit runs dry while all eight waves compute, 3.90 -> 4.02 ms per launch)
 		if (havePrev) finalize_prev();
 		SPHX_PROF(3);
 		__builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's LDS-DMA and hashes have landed
@@ -1505,13 +1535,9 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 						if (PREMUL) P.w *= p.fcoeff;
 						return P;
 					};
-					float4 P[TILE_HCH];      // all reads of the row in flight, then the arithmetic, then the writes
 #pragma unroll
 					for (int c = 0; c < TILE_HCH; ++c)
-						if ((uint32_t)c*64u + lane < total) P[c] = sPos[1u + base + (uint32_t)c*64u + lane];
-#pragma unroll
-					for (int c = 0; c < TILE_HCH; ++c)
-						if ((uint32_t)c*64u + lane < total) sPos[1u + base + (uint32_t)c*64u + lane] = shifted(P[c], hsh[k][c]);
+						if ((uint32_t)c*64u + lane < total) sPos[1u + base + (uint32_t)c*64u + lane] = shifted(posr[k][c], hsh[k][c]);
 					for (uint32_t q = (uint32_t)TILE_HCH*64u + lane; q < total; q += 64u) sPos[1u + base + q] = shifted(sPos[1u + base + q], a.hash[rs + q]);
 				} else {   // a row that is not one range in memory (cell-type segments of a device map not split on COORD3,
 					       // a periodic row lying wholly inside the window): cell by cell, in window order
@@ -2182,11 +2208,14 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 				if ((lane & 15u) >= (uint32_t)dd) incl += t;
 			}
 			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
-			const uint32_t share = (T + TILE_WAVES - 1u)/TILE_WAVES;
+			// T/8 batches each; the T % 8 left over go one each to the first waves, i.e. to different SIMDs (waves w and w + 4
+			// share one): with ceil(T/8) for all but the last wave, T = 57 made seven waves walk 8 batches and the eighth 1
+			const uint32_t share = (T + TILE_WAVES - 1u)/TILE_WAVES, sbase = T/TILE_WAVES, srem = T - sbase*TILE_WAVES;
 			const uint32_t cStart = incl - (nF + nB), cEnd = incl;
 			const bool isChunk = lane < C && nF + nB > 0u;
 			const bool isWave = lane >= 16u && lane < 16u + TILE_WAVES;
-			const uint32_t ws = isWave ? min((lane - 16u)*share, T) : 0u, we = isWave ? min((lane - 15u)*share, T) : 0u;
+			const uint32_t wv = lane - 16u;
+			const uint32_t ws = isWave ? wv*sbase + min(wv, srem) : 0u, we = isWave ? ws + sbase + (wv < srem ? 1u : 0u) : 0u;
 			// my boundary point (chunk lanes: the chunk's first batch; wave lanes: the share's first batch) and the range I ask about
 			const uint32_t lo = isChunk ? cStart : ws, hi = isChunk ? cEnd : we;
 			// a wave's start that is also a chunk's start is one boundary, the chunk's
@@ -2201,7 +2230,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 				if (x <= lo) cstar = (uint32_t)q;                    // the chunk my boundary point lies in (the last one starting at or before it)
 				cntLt += (x < lo) ? 1u : 0u; cntIn += (x >= lo && x < hi) ? 1u : 0u;
 			}
-			const bool inS = isChunk || (isWave && ws < T && !dup);
+			const bool inS = isChunk || (isWave && ws < we && !dup);
 			for (int q = 16; q < 16 + (int)TILE_WAVES; ++q) {
 				const bool qv = (__builtin_amdgcn_ballot_w64(inS) >> q) & 1ull;
 				if (!qv) continue;
@@ -2225,7 +2254,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			}
 			// wave (lane - 16): first run (the one starting at its first batch: that batch is a boundary), the runs that start
 			// inside its share, first batch, batches
-			if (isWave) sRunTab[lane - 16u] = (ws < T) ? (cntLt | (cntIn << 5) | (ws << 10) | ((we - ws) << 22)) : 0u;
+			if (isWave) sRunTab[lane - 16u] = (ws < we) ? (cntLt | (cntIn << 5) | (ws << 10) | ((we - ws) << 22)) : 0u;
 			if (lane < TILE_CHUNKS) {
 				sRunTab[TILE_RT_CHUNK + lane] = isChunk ? (cntLt | (cntIn << 8)) : 0u;
 				sChunkStart[lane] = cStart;
