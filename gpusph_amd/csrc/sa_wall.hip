@@ -199,6 +199,13 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 // second sum is 1/2 (sum_s grad gamma_as(n)) . dq -- and that sum is the particle's grad gamma of step n, which BUFFER_GRADGAMMA
 // holds (oldGGam.xyz: written by this same engine at the end of the previous step, or by saInitGamma).  The one-thread kernel
 // keeps the reference's two evaluations per element; the two agree to rounding.
+// What that rests on: the stored grad gamma(n) and the sum over THIS list are sums over the same elements.  The lists differ after
+// a rebuild between the two steps, and a halo copy's grad gamma was summed by the rank that owns the particle -- but only in
+// elements that contribute nothing: an element wholly outside the kernel's support has |grad gamma_as| = 0 exactly
+// (sa_wall_gamma.h dismisses it before any arithmetic) and every element inside the support is in any valid list (the boundary
+// section is built out to boundNlSqInflRad >= the support).  So the assumption is the validity of the neighbour list itself,
+// which every sum of this engine already needs.  Held by tests/test_gpu_sa.py (this kernel against the one-thread kernel over
+// 12 sloshing steps across a rebuild) and by the two-rank run test_two_ranks_on_one_gpu_equal_single_domain[sa-walls-tiled] of tests/test_gpu_parity.py.
 __global__ void __launch_bounds__(SA_WALL_THREADS)
 sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__restrict__ wall)
 {
