@@ -2031,10 +2031,46 @@ __device__ __forceinline__ TileHome tile_home(uint32_t dw /* this lane's word of
 	return h;
 }
 
-// Measured at 32 M particles (scripts/ab_builder.sh, round 4): the kernel is bound by its traffic pattern, not by latency -- the
-// reference-format list is slot-major with the allocation as its stride, so the 128 rows a particle's list lies in are 64 MB
-// apart, every one in another page.  MORE loads in flight or MORE waves per CU make it slower (16 -> 32 entries per lane in
-// flight: 7.8 -> 13.2 ms; two workgroups per CU instead of one: 7.8 -> 9.2 ms): they only widen the set of pages and lines in use
+// The share of a tile's batches that each wave of the forces kernel walks, in 1/256.  Not 32 each: the second wave of a SIMD
+// (w + 4) reaches the end of its pair phase first when the shares are equal (phase timers, profiles/r04_tile_phases_32M.txt:
+// waves 0..7 wait 0.06, 0.18, 0.24, 0.37, 0.81, 0.77, 0.69, 1.16 M cycles of 9.26 M at the barrier on top of the next tile), and
+// the tile ends when the last wave does.  Measured at 32 M particles, two boxes (scripts/ab_forces.sh; ms per launch):
+// 32 x 8: 3.877;  31 x 4 + 33 x 4: 3.874;  30 x 4 + 34 x 4: 3.822;  29 x 4 + 35 x 4: 3.837;  weights in proportion to the measured
+// waits (29 30 30 31 34 33 33 36): 3.860, twice that correction: 3.919 -- the waits are not pair work that can be handed over
+// one for one (the two waves of a SIMD share its issue slots), so only the coarse correction is kept
+#ifndef TILE_SHARE_WEIGHTS
+#define TILE_SHARE_WEIGHTS 30, 30, 30, 30, 34, 34, 34, 34
+#endif
+__device__ __forceinline__ uint32_t tile_share_start(uint32_t w)     // sum of the weights of the waves before w; 256 for w = 8
+{
+	constexpr uint32_t wt[TILE_WAVES] = { TILE_SHARE_WEIGHTS };
+	uint32_t s = 0;
+#pragma unroll
+	for (uint32_t k = 0; k < TILE_WAVES; ++k) s += (k < w) ? wt[k] : 0u;
+	return s;
+}
+constexpr uint32_t tile_share_max()
+{
+	constexpr uint32_t wt[TILE_WAVES] = { TILE_SHARE_WEIGHTS };
+	uint32_t m = 0, t = 0;
+	for (uint32_t k = 0; k < TILE_WAVES; ++k) { m = wt[k] > m ? wt[k] : m; t += wt[k]; }
+	return t == 256u ? m : 0xFFFFFFFFu;      // (a weight set that does not sum to 256 fails the static_assert below)
+}
+#define TILE_SHARE_MAX tile_share_max()
+static_assert(TILE_WAVES == 8 && TILE_SHARE_MAX <= 64u, "eight weights that sum to 256");
+
+// Measured at 32 M particles (scripts/ab_builder.sh, round 4; linearisation xzy).  First a warning: with the sixteen list loads
+// of the translation loop each under a condition of its own, the compiler made every load wait for all the earlier ones
+// (s_waitcnt vmcnt(0) in front of each) in SOME builds, depending on edits elsewhere in the kernel -- the same source ran 7.4 or
+// 11.3 ms per launch, and every A/B of this kernel made before that was found compared the two states of the compiler as much as
+// the two variants.  The loads are unconditional now (the address is valid for every thread) and issue back to back (checked in
+// the ISA): 6.3 ms.  With that: 8 / 16 / 24 / 32 loads in flight per lane 6.58 / 6.27 / 6.81 / 6.71 ms; two workgroups per CU
+// 7.24; the tile's stream assembled in LDS and written as one linear copy instead of eight-byte stores from all over the tile
+// 6.85 against 6.65 (yzx: 7.49 against 7.25): neither the latency of the loads nor the scattered stores bound it.  Without the
+// translation (sections 1 to 4 alone) 2.29 ms, with the fluid section only 5.89: the 3.6 ms of the fluid section are its
+// ~15 vector instructions and one LDS look-up per entry at ten waves per CU.  (Tried before the loads were fixed, and to be read
+// with the warning above: a second, wave-major copy of the list written by build_neibs_kernel's ring -- this kernel 7.36 -> 6.37 ms,
+// build_neibs_kernel 12.9 -> 14.1 ms for the extra stores.)
 #ifndef TL_MINWAVES
 #define TL_MINWAVES 1
 #define TL_LOADS 16
@@ -2208,14 +2244,13 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 				if ((lane & 15u) >= (uint32_t)dd) incl += t;
 			}
 			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
-			// T/8 batches each; the T % 8 left over go one each to the first waves, i.e. to different SIMDs (waves w and w + 4
-			// share one): with ceil(T/8) for all but the last wave, T = 57 made seven waves walk 8 batches and the eighth 1
-			const uint32_t share = (T + TILE_WAVES - 1u)/TILE_WAVES, sbase = T/TILE_WAVES, srem = T - sbase*TILE_WAVES;
+			// wave w walks the batches [T c(w), T c(w+1)) / 256, c = the running sum of the waves' weights (tile_share_start)
+			const uint32_t share = (T*TILE_SHARE_MAX + 255u) >> 8;
 			const uint32_t cStart = incl - (nF + nB), cEnd = incl;
 			const bool isChunk = lane < C && nF + nB > 0u;
 			const bool isWave = lane >= 16u && lane < 16u + TILE_WAVES;
 			const uint32_t wv = lane - 16u;
-			const uint32_t ws = isWave ? wv*sbase + min(wv, srem) : 0u, we = isWave ? ws + sbase + (wv < srem ? 1u : 0u) : 0u;
+			const uint32_t ws = isWave ? (T*tile_share_start(wv) + 128u) >> 8 : 0u, we = isWave ? (T*tile_share_start(wv + 1u) + 128u) >> 8 : 0u;
 			// my boundary point (chunk lanes: the chunk's first batch; wave lanes: the share's first batch) and the range I ask about
 			const uint32_t lo = isChunk ? cStart : ws, hi = isChunk ? cEnd : we;
 			// a wave's start that is also a chunk's start is one boundary, the chunk's
@@ -2314,6 +2349,9 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 #pragma unroll
 				for (int dd = 32; dd > 0; dd >>= 1) nbatWave = max(nbatWave, (uint32_t)__shfl_xor(nbatWave, dd));
 				uint32_t code = 0;
+				// entry sl of the section: slot sl, or neibboundpos - sl, or neibboundpos + 1 + sl -- a base and a signed step
+				const neibdata *const secList = list + (size_t)(!sec ? 0u : saVertex ? p.neibboundpos + 1u : p.neibboundpos)*stride + index;
+				const long long secStep = (sec && !saVertex) ? -(long long)stride : (long long)stride;
 				constexpr int LOADS = TL_LOADS;   // entries per lane in flight: the walk is latency bound
 #pragma unroll 1
 				for (uint32_t b0 = 0; b0 < nbatWave; b0 += LOADS/TILE_NB) {
@@ -2321,8 +2359,9 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 #pragma unroll
 					for (int k = 0; k < LOADS; ++k) {
 						const uint32_t sl = min(b0*TILE_NB + (uint32_t)k, cnt ? cnt - 1u : 0u);   // a clamped re-read is never used
-						const uint32_t src = !sec ? sl : saVertex ? p.neibboundpos + 1u + sl : p.neibboundpos - sl;
-						e[k] = cnt ? (uint32_t)list[(size_t)src*stride + index] : 0u;
+						// (unconditional: the address is valid for every thread, and a load under a branch of its own made the compiler
+						// wait for all the earlier ones before it in some builds -- 7 to 13 ms per launch depending on unrelated edits)
+						e[k] = (uint32_t)secList[(long long)sl*secStep];
 					}
 					uint32_t val[LOADS];
 #pragma unroll

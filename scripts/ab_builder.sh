@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
 for lib in gpusph_amd/variants/libsphx_*.so; do
   tag=$(basename $lib .so)
-  SPHX_LIB=$PWD/$lib rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_$tag -- python scripts/time_neibs.py 32e6 > gpurun_out/ab_$tag.log 2>&1
+  SPHX_LIB=$PWD/$lib rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_$tag -- python scripts/time_neibs.py 32e6 $LIN > gpurun_out/ab_$tag.log 2>&1
   python - <<PY
 import csv,glob
 f=glob.glob('gpurun_out/ab_$tag/*/*kernel_stats.csv')[0]

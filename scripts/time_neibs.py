@@ -5,7 +5,8 @@ import torch
 from gpusph_amd.problem import DamBreak3D
 from gpusph_amd.engine import TimestepEngine
 n = float(sys.argv[1]) if len(sys.argv) > 1 else 8e6
-prob = DamBreak3D(DamBreak3D.deltap_for(n))
+lin = sys.argv[2] if len(sys.argv) > 2 else "xzy"      # the bench's linearisation
+prob = DamBreak3D(DamBreak3D.deltap_for(n), obstacle=True, linearization=lin)
 eng = TimestepEngine(prob, track_particle_count=False)
 eng.build_neibs(); eng.iterations = 1
 torch.cuda.synchronize()

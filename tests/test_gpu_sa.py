@@ -450,7 +450,10 @@ def test_sa_tiled_kernels_agree_with_the_list_walkers(options, monkeypatch):
     # (a particle with an ill-conditioned element among its neighbours is pushed a little differently by the two: see
     # assert_close_but_for_gamma_spikes)
     assert_close_but_for_gamma_spikes(pos_t[:, :3], pos_w[:, :3], 2e-5, cell, spike=10.0, what="positions, tiled against list walkers")
-    assert_close_but_for_gamma_spikes(vel_t[:, :3], vel_w[:, :3], 2e-4, vmax, spike=10.0, what="velocities, tiled against list walkers")
+    # (velocities: the one or two worst particles end between 1.6e-3 and 2.1e-3 of max |v| after the twelve steps, depending on how
+    # a build happens to group the partial sums of a tile -- the cut points of the waves' shares moved in round 4 --; the share
+    # of the entries beyond the plain tolerance is 3e-4, held to 2e-3 here instead of the helper's 1e-2)
+    assert_close_but_for_gamma_spikes(vel_t[:, :3], vel_w[:, :3], 2e-4, vmax, frac=2e-3, spike=15.0, what="velocities, tiled against list walkers")
     assert_close_but_for_gamma_spikes(vel_t[:, 3], vel_w[:, 3], 2e-6, 1.0, spike=10.0, what="densities, tiled against list walkers")
     assert np.abs(gg_t[fl, 3] - gg_w[fl, 3]).max() < 2e-5
     assert abs(dt_t - dt_w) < 1e-4 * dt_w
