@@ -1244,6 +1244,11 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 	constexpr bool SA = (TURB & SPHX_TURB_SA_ANY) != 0, SA_DSUM = (TURB & SPHX_TURB_SA_DSUM) != 0, SA_DIFF = (TURB & SPHX_TURB_SA_DIFF) != 0;
 	constexpr bool NOAUX = STRESS || SA_DSUM || SPSC;   // no EOS rows in the window
 	constexpr bool NOVEL = SA_DIFF;             // no velocity rows
+	// positions through registers on their way into the window (stage_window_row): in the plain forces pass only.  The rows held in
+	// flight cost registers; every other instantiation pays for them in its pair loop.  Measured per option set with and without
+	// (scripts/measure_options.sh, M updates/s): SPS at 8 M 1122 -> 1251 (forces 1.85 -> 1.61 ms, stress 1.18 -> 1.06), two fluids
+	// 2268 -> 2389, laminar + Ferrari (StillWater 4 M) 2022 -> 2129, WaveTank 904 -> 972, SA walls with density summation 485 -> 508
+	constexpr bool POS_REG = !SPSW && !STRESS && !SA && !(TURB & (SPHX_TURB_MF | SPHX_TURB_NEWT));
 	constexpr uint32_t WS = WC + 1;   // window arrays: the dummy row the pad entries of the tile lists point to (slot 0) + WC records
 	constexpr int PARTV = STRESS ? 3 : 1;      // float4 rows per lane of a run's partial sums
 	__shared__ __attribute__((aligned(16))) float4 sPos[WS];
@@ -1472,11 +1477,14 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 			if (!(inRange && pairs) || !total || base + total > WC || !rjc.contig[k]) return;
 			// positions go through registers: they are moved into the tile's frame on their way into the window (a DMA'd row had to
 			// be read back from LDS for that); everything else by DMA.  Rows longer than TILE_HCH chunks: the rest by DMA + a pass
+			if (POS_REG) {
 #pragma unroll
-			for (int c = 0; c < TILE_HCH; ++c)
-				if ((uint32_t)c*64u + lane < total) posr[k][c] = a.pos[rs + (uint32_t)c*64u + lane];
-			if (total > (uint32_t)TILE_HCH*64u)
-				stage_row_wave(a.pos + rs + TILE_HCH*64, sPos + 1 + base + TILE_HCH*64, total - (uint32_t)TILE_HCH*64u, lane);
+				for (int c = 0; c < TILE_HCH; ++c)
+					if ((uint32_t)c*64u + lane < total) posr[k][c] = a.pos[rs + (uint32_t)c*64u + lane];
+				if (total > (uint32_t)TILE_HCH*64u)
+					stage_row_wave(a.pos + rs + TILE_HCH*64, sPos + 1 + base + TILE_HCH*64, total - (uint32_t)TILE_HCH*64u, lane);
+			} else
+				stage_row_wave(a.pos + rs, sPos + 1 + base, total, lane);
 			if (!NOVEL) stage_row_wave(a.vel + rs, sVel + 1 + base, total, lane);
 			if (!NOAUX) stage_row_wave(a.aux + rs, sAux + 1 + base, total, lane);
 			if (SPSW) {
@@ -1537,7 +1545,10 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 					};
 #pragma unroll
 					for (int c = 0; c < TILE_HCH; ++c)
-						if ((uint32_t)c*64u + lane < total) sPos[1u + base + (uint32_t)c*64u + lane] = shifted(posr[k][c], hsh[k][c]);
+						if ((uint32_t)c*64u + lane < total) {
+							const uint32_t w = 1u + base + (uint32_t)c*64u + lane;
+							sPos[w] = shifted(POS_REG ? posr[k][c] : sPos[w], hsh[k][c]);
+						}
 					for (uint32_t q = (uint32_t)TILE_HCH*64u + lane; q < total; q += 64u) sPos[1u + base + q] = shifted(sPos[1u + base + q], a.hash[rs + q]);
 				} else {   // a row that is not one range in memory (cell-type segments of a device map not split on COORD3,
 					       // a periodic row lying wholly inside the window): cell by cell, in window order
@@ -2031,33 +2042,21 @@ __device__ __forceinline__ TileHome tile_home(uint32_t dw /* this lane's word of
 	return h;
 }
 
-// The share of a tile's batches that each wave of the forces kernel walks, in 1/256.  Not 32 each: the second wave of a SIMD
-// (w + 4) reaches the end of its pair phase first when the shares are equal (phase timers, profiles/r04_tile_phases_32M.txt:
-// waves 0..7 wait 0.06, 0.18, 0.24, 0.37, 0.81, 0.77, 0.69, 1.16 M cycles of 9.26 M at the barrier on top of the next tile), and
-// the tile ends when the last wave does.  Measured at 32 M particles, two boxes (scripts/ab_forces.sh; ms per launch):
-// 32 x 8: 3.877;  31 x 4 + 33 x 4: 3.874;  30 x 4 + 34 x 4: 3.822;  29 x 4 + 35 x 4: 3.837;  weights in proportion to the measured
-// waits (29 30 30 31 34 33 33 36): 3.860, twice that correction: 3.919 -- the waits are not pair work that can be handed over
-// one for one (the two waves of a SIMD share its issue slots), so only the coarse correction is kept
-#ifndef TILE_SHARE_WEIGHTS
-#define TILE_SHARE_WEIGHTS 30, 30, 30, 30, 34, 34, 34, 34
-#endif
-__device__ __forceinline__ uint32_t tile_share_start(uint32_t w)     // sum of the weights of the waves before w; 256 for w = 8
+// The share of a tile's batches that each wave of the forces kernel walks, in 1/256: `lo` for each of the waves 0..3, 64 - lo
+// for each of the waves 4..7 (the second wave of every SIMD).  Even shares (lo = 32) for every kernel but one: in the plain
+// forces pass (artificial or no viscosity, one fluid, no SA walls) the second wave of a SIMD reaches the end of its pair phase
+// first when the shares are equal (phase timers, profiles/r04_tile_phases_32M.txt: waves 0..7 wait 0.06, 0.18, 0.24, 0.37, 0.81,
+// 0.77, 0.69, 1.16 M cycles of 9.26 M at the barrier on top of the next tile), and the tile ends when the last wave does.
+// Measured at 32 M particles, two boxes (scripts/ab_forces.sh; ms per launch): lo = 32: 3.877;  31: 3.874;  30: 3.822;  29: 3.837;
+// weights in proportion to the measured waits (29 30 30 31 34 33 33 36): 3.860, twice that correction: 3.919 -- the waits are not
+// pair work that can be handed over one for one (the two waves of a SIMD share its issue slots).  The other instantiations
+// LOSE with lo = 30 (scripts/measure_all.sh: SPS forces at 8 M 1.75 -> 1.90 ms per launch, two fluids 1.24 -> 1.35, the laminar +
+// Ferrari pass of the StillWater mirror 4.5 % per step): their waves are balanced differently, so they keep even shares
+#define TILE_SHARE_LO_PLAIN 30u
+__device__ __forceinline__ uint32_t tile_share_start(uint32_t w, uint32_t lo)     // sum of the weights of the waves before w; 256 for w = 8
 {
-	constexpr uint32_t wt[TILE_WAVES] = { TILE_SHARE_WEIGHTS };
-	uint32_t s = 0;
-#pragma unroll
-	for (uint32_t k = 0; k < TILE_WAVES; ++k) s += (k < w) ? wt[k] : 0u;
-	return s;
+	return w <= 4u ? w*lo : 4u*lo + (w - 4u)*(64u - lo);
 }
-constexpr uint32_t tile_share_max()
-{
-	constexpr uint32_t wt[TILE_WAVES] = { TILE_SHARE_WEIGHTS };
-	uint32_t m = 0, t = 0;
-	for (uint32_t k = 0; k < TILE_WAVES; ++k) { m = wt[k] > m ? wt[k] : m; t += wt[k]; }
-	return t == 256u ? m : 0xFFFFFFFFu;      // (a weight set that does not sum to 256 fails the static_assert below)
-}
-#define TILE_SHARE_MAX tile_share_max()
-static_assert(TILE_WAVES == 8 && TILE_SHARE_MAX <= 64u, "eight weights that sum to 256");
 
 // Measured at 32 M particles (scripts/ab_builder.sh, round 4; linearisation xzy).  First a warning: with the sixteen list loads
 // of the translation loop each under a condition of its own, the compiler made every load wait for all the earlier ones
@@ -2082,7 +2081,8 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
 	uint32_t *__restrict__ tiles, uint32_t *tileCtl, uint32_t *__restrict__ tileRows, uint32_t *__restrict__ tileRuns,
 	uint2 *__restrict__ tileList, uint32_t listCapBatches, uint32_t *__restrict__ laneRec, uint32_t *__restrict__ laneIndex,
-	uint32_t laneCap, int saVertex /* SA_BOUNDARY lists: the second section is the VERTEX section */)
+	uint32_t laneCap, int saVertex /* SA_BOUNDARY lists: the second section is the VERTEX section */,
+	uint32_t shareLo /* tile_share_start */)
 {
 	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW], sCellBase[TILE_WROWS*TILE_KW], sCellStart[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sRowTotal[TILE_WROWS], sRowStart[TILE_WROWS], sRowContig[TILE_WROWS], sRowBase[TILE_WROWS];
@@ -2245,12 +2245,16 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			}
 			const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 15);
 			// wave w walks the batches [T c(w), T c(w+1)) / 256, c = the running sum of the waves' weights (tile_share_start)
-			const uint32_t share = (T*TILE_SHARE_MAX + 255u) >> 8;
+			const uint32_t share = (T*max(shareLo, 64u - shareLo) + 255u) >> 8;
 			const uint32_t cStart = incl - (nF + nB), cEnd = incl;
 			const bool isChunk = lane < C && nF + nB > 0u;
 			const bool isWave = lane >= 16u && lane < 16u + TILE_WAVES;
 			const uint32_t wv = lane - 16u;
-			const uint32_t ws = isWave ? (T*tile_share_start(wv) + 128u) >> 8 : 0u, we = isWave ? (T*tile_share_start(wv + 1u) + 128u) >> 8 : 0u;
+			// even shares: T/8 batches each, the T % 8 left over go one each to the first waves, i.e. to different SIMDs
+			const uint32_t sbase = T/TILE_WAVES, srem = T - sbase*TILE_WAVES;
+			const bool even = shareLo == 32u;
+			const uint32_t ws = !isWave ? 0u : even ? wv*sbase + min(wv, srem) : (T*tile_share_start(wv, shareLo) + 128u) >> 8;
+			const uint32_t we = !isWave ? 0u : even ? ws + sbase + (wv < srem ? 1u : 0u) : (T*tile_share_start(wv + 1u, shareLo) + 128u) >> 8;
 			// my boundary point (chunk lanes: the chunk's first batch; wave lanes: the share's first batch) and the range I ask about
 			const uint32_t lo = isChunk ? cStart : ws, hi = isChunk ? cEnd : we;
 			// a wave's start that is also a chunk's start is one boundary, the chunk's
@@ -2349,29 +2353,33 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 #pragma unroll
 				for (int dd = 32; dd > 0; dd >>= 1) nbatWave = max(nbatWave, (uint32_t)__shfl_xor(nbatWave, dd));
 				uint32_t code = 0;
-				// entry sl of the section: slot sl, or neibboundpos - sl, or neibboundpos + 1 + sl -- a base and a signed step
-				const neibdata *const secList = list + (size_t)(!sec ? 0u : saVertex ? p.neibboundpos + 1u : p.neibboundpos)*stride + index;
+				// entry sl of the section: slot sl, or neibboundpos - sl, or neibboundpos + 1 + sl -- a base and a signed step, both
+				// the same for every lane; the lane's part of the address is its particle's index alone, ONE 32-bit offset for all
+				// the loads of the loop (with an address pair per load the compiler recycled the pairs as load destinations and
+				// waited for the loads in flight before each re-use)
+				const neibdata *const secList = list + (size_t)(!sec ? 0u : saVertex ? p.neibboundpos + 1u : p.neibboundpos)*stride;
 				const long long secStep = (sec && !saVertex) ? -(long long)stride : (long long)stride;
+				const uint32_t secCap = !sec ? p.neiblistsize : saVertex ? p.neiblistsize - p.neibboundpos - 1u : p.neibboundpos + 1u;
 				constexpr int LOADS = TL_LOADS;   // entries per lane in flight: the walk is latency bound
 #pragma unroll 1
 				for (uint32_t b0 = 0; b0 < nbatWave; b0 += LOADS/TILE_NB) {
 					uint32_t e[LOADS];
 #pragma unroll
 					for (int k = 0; k < LOADS; ++k) {
-						const uint32_t sl = min(b0*TILE_NB + (uint32_t)k, cnt ? cnt - 1u : 0u);   // a clamped re-read is never used
+						const uint32_t sl = min(b0*TILE_NB + (uint32_t)k, secCap - 1u);   // the same slot for every lane; past a lane's list the entry is not used
 						// (unconditional: the address is valid for every thread, and a load under a branch of its own made the compiler
 						// wait for all the earlier ones before it in some builds -- 7 to 13 ms per launch depending on unrelated edits)
-						e[k] = (uint32_t)secList[(long long)sl*secStep];
+						e[k] = (uint32_t)(secList + (long long)sl*secStep)[index];
 					}
 					uint32_t val[LOADS];
 #pragma unroll
 					for (int k = 0; k < LOADS; ++k) {
 						const uint32_t dd = e[k];
 						const bool live = b0*TILE_NB + (uint32_t)k < cnt;
-						const uint32_t prev = code;
+						// (the list is build_neibs_kernel's own, written moments ago, and its section lengths were checked against the
+						// list's geometry above: the entries are not validated one by one -- that was a third of this loop's
+						// instructions -- only that the section opened with a cell code, below)
 						code = (live && dd >= CELLNUM_ENCODED) ? (dd >> CELLNUM_SHIFT) : code;
-						// not a list of the builder (an overflowed one, or counts of another list): generic kernel
-						if (live && (dd == NEIBS_END || code < prev || code == 0u || code > 27u)) { overflow = true; code = 1u; }
 						const uint32_t slot = 1u + (uint32_t)myCB[min(code, 27u)] + (dd & NEIBINDEX_MASK);   // slot 0 = dummy
 						if (live && slot > 4095u) overflow = true;
 						val[k] = live ? ((slot << 4) & 0xFFFFu) : 0u;
@@ -2381,6 +2389,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 						if (b0 + (uint32_t)k < nbat)
 							out[(size_t)(b0 + (uint32_t)k)*64u] = make_uint2(val[4*k] | (val[4*k + 1] << 16), val[4*k + 2] | (val[4*k + 3] << 16));
 				}
+				if (cnt && code == 0u) overflow = true;      // a section that never named a cell: not a list of the builder
 			}
 		}
 		if (overflow) tileCtl[1] = 1u;      // generic kernel
@@ -2394,9 +2403,11 @@ int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void 
 		return SPHX_OK;
 	}
 	const uint32_t grid = ctx->tile_grid*TL_GRIDMUL < ctx->tile_capacity ? ctx->tile_grid*TL_GRIDMUL : ctx->tile_capacity;
+	// the plain forces pass is the only walker of these lists that gains from uneven shares (tile_share_start)
+	const bool plain = !sa && ctx->dev.turbmodel == SPHX_ARTIFICIAL && ctx->dev.numfluids == 1 && ctx->dev.boundarytype == SPHX_DYN_BOUNDARY;
 	tile_lists_kernel<<<grid, TL_THREADS, 0, st>>>(ctx->dev, neibsList, ctx->neib_counts, (const particleinfo*)info, hash, cellStart, ctx->cell_end_copy,
 		ctx->tiles, ctx->tile_ctl, ctx->tile_rows, ctx->tile_runs, ctx->tile_list, ctx->tile_list_batches, ctx->tile_lane_rec, ctx->tile_lane_index,
-		ctx->tile_lane_cap, sa ? 1 : 0);
+		ctx->tile_lane_cap, sa ? 1 : 0, plain ? TILE_SHARE_LO_PLAIN : 32u);
 	SPHX_LAUNCH_CHECK("tile_lists_kernel");
 	return SPHX_OK;
 }

@@ -1105,20 +1105,40 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		rc = sphx_ensure_tile_lists(ctx);      // first tiled build: the tile lists are allocated now (or never: generic kernels)
 		if (rc != SPHX_OK) return rc;
 	}
+	bool tiling_on_side = false;
 	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit && ctx->tile_list) {
-		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, st));
-		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), st));
-		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl + 12, 0, 2*sizeof(uint32_t), st));      // cursors of the list stream and of the lane tables
+		// The tiling reads the cell tables only and is needed by the tile lists, not by the list build: it runs beside
+		// build_neibs_kernel on the context's side stream (build_tiles_kernel is a serial walk per row bundle, ~400 waves for
+		// ~1 ms at 32 M particles, on a GPU that holds 8000).  Fork behind everything the caller has queued, join before the
+		// tile lists.  Without the side stream (creation failed) the same launches go to the caller's stream
+		static const bool noSide = getenv("SPHX_TILING_INLINE") != nullptr;      // A/B switch: the tiling on the caller's stream
+		if (!ctx->side_stream && !noSide) {
+			if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->side_stream = nullptr; }
+			else if (hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
+			         hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
+				(void)hipGetLastError(); (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr;
+			}
+		}
+		hipStream_t ts = st;
+		if (ctx->side_stream) {
+			SPHX_HIP(hipEventRecord(ctx->side_fork, st));
+			SPHX_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+			ts = ctx->side_stream; tiling_on_side = true;
+		}
+		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, ts));
+		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), ts));
+		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl + 12, 0, 2*sizeof(uint32_t), ts));      // cursors of the list stream and of the lane tables
 		const DevParams &dp = ctx->dev;
 		const uint32_t gs2 = (uint32_t)dp.gs[dp.c2], gs3 = (uint32_t)dp.gs[dp.c3];
 		const uint32_t bundles = ((gs2 + 1)/2)*((gs3 + 1)/2);
-		tile_columns_kernel<<<div_up_u(bundles*(uint32_t)dp.gs1, 256), 256, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy,
+		tile_columns_kernel<<<div_up_u(bundles*(uint32_t)dp.gs1, 256), 256, 0, ts>>>(ctx->dev, cellStart, ctx->cell_end_copy,
 			(const particleinfo*)info, ctx->tile_cols);
 		SPHX_LAUNCH_CHECK("tile_columns_kernel");
 		const uint32_t tileThreads = ((gs2 + 1)/2 + 7)/8*(((gs3 + 1)/2 + 3)/4)*32u;   // 8 x 4 blocks of bundles, see the kernel
-		build_tiles_kernel<<<div_up_u(tileThreads, 128), 128, 0, st>>>(ctx->dev, cellStart, ctx->cell_end_copy,
+		build_tiles_kernel<<<div_up_u(tileThreads, 128), 128, 0, ts>>>(ctx->dev, cellStart, ctx->cell_end_copy,
 			ctx->tile_cols, particleRangeEnd, ctx->tiles, ctx->tile_ctl, ctx->tile_capacity);
 		SPHX_LAUNCH_CHECK("build_tiles_kernel");
+		if (tiling_on_side) SPHX_HIP(hipEventRecord(ctx->side_join, ctx->side_stream));
 		ctx->tiles_built = true;
 		ctx->tiles_cellstart = cellStart;
 		ctx->tiles_neibslist = neibsList;
@@ -1135,6 +1155,7 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	neibs_counters_fold_kernel<<<1, NEIBS_SPREAD, 0, st>>>(ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("neibs_counters_fold_kernel");
+	if (tiling_on_side) SPHX_HIP(hipStreamWaitEvent(st, ctx->side_join, 0));      // the tiling is there for everything queued from here on
 	if (sa) {   // the fluid particles with boundary elements in reach
 		if (!ctx->sa_wall && hipMalloc((void**)&ctx->sa_wall, sizeof(uint32_t)*((size_t)ctx->reserved_particles + 1)) != hipSuccess) {
 			(void)hipGetLastError();

@@ -94,6 +94,7 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->dt_scratch) (void)hipFree(ctx->dt_scratch);
 	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
 	if (ctx->ovf_host) { (void)hipHostFree(ctx->ovf_host); (void)hipEventDestroy(ctx->ovf_event); }
+	if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->side_fork); (void)hipEventDestroy(ctx->side_join); }
 	if (ctx->dem) (void)hipFree(ctx->dem);
 	delete ctx->forces_events;
 	delete ctx;

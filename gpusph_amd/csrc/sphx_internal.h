@@ -190,6 +190,10 @@ struct sphx_ctx {
 	                           // engine then launches the generic kernel as a guarded stand-by), 0 tiles usable, 1 generic kernels
 	uint32_t   *ovf_host;      // pinned: copy of tile_ctl[0..1] made behind every tiled build
 	hipEvent_t  ovf_event;     // ... has arrived
+	// the tiling of a neighbour-list build (tile_columns_kernel, build_tiles_kernel: a few hundred waves walking serially) runs
+	// on a stream of the context's own next to build_neibs_kernel, forked from and joined to the caller's stream by events
+	hipStream_t side_stream;
+	hipEvent_t  side_fork, side_join;
 	bool        ovf_pending;
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
 	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments; only with -DSPHX_TILE_DEBUG_BUILD)
