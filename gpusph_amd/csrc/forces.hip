@@ -2089,7 +2089,8 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	__shared__ int sCodeOff[32];                                   // cell code-1 -> window-table offset
 	__shared__ uint16_t sCB[TILE_HROWS*TILE_MAXCELLS*27 + 8];      // [home cell][code] -> slot of the cell's first record
 	__shared__ uint16_t sHist[TILE_CHUNKS][TL_BINS];               // per wave: particles with a fluid section of that length; then: ... in the waves before
-	__shared__ uint16_t sBinTot[TL_BINS], sBinStart[TL_BINS];
+	__shared__ uint16_t sBinStart[TL_BINS];
+	__shared__ uint32_t sBinWave[4];
 	__shared__ uint16_t sLaneOf[TILE_PMAX], sLenF[TILE_PMAX], sLenB[TILE_PMAX];   // lane of the tile by home-order number; list lengths by lane
 	__shared__ uint32_t sChunkF[TILE_CHUNKS + 1], sChunkB[TILE_CHUNKS + 1], sChunkStart[TILE_CHUNKS + 1];   // batches per section; first batch
 	__shared__ uint32_t sSorted[32];
@@ -2202,16 +2203,26 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			}
 		}
 		__syncthreads();
-		if (tid < 129u) {      // per length: particles in the waves before each wave, and in all
-			uint32_t run = 0;
-			for (uint32_t w = 0; w < TILE_CHUNKS; ++w) { const uint32_t c = sHist[w][tid]; sHist[w][tid] = (uint16_t)run; run += c; }
-			sBinTot[tid] = (uint16_t)run;
+		uint32_t binTot = 0, binSuffix = 0;      // threads 0..128: particles of this length; ... of this length and the longer ones of my wave's 64 lengths
+		if (tid < 192u) {      // per length: particles in the waves before each wave, and in all
+			if (tid < 129u)
+				for (uint32_t w = 0; w < TILE_CHUNKS; ++w) { const uint32_t c = sHist[w][tid]; sHist[w][tid] = (uint16_t)binTot; binTot += c; }
+			// longest first: a length starts behind all longer ones -- a suffix scan over the 129 lengths in three waves (a loop
+			// over the longer lengths per thread was 128 dependent LDS reads for length 0: ~3 us of the ~8 a tile takes before
+			// its lists are translated)
+			binSuffix = binTot;
+#pragma unroll
+			for (int dd = 1; dd < 64; dd <<= 1) {
+				const uint32_t t2 = (uint32_t)__shfl_down((int)binSuffix, dd);
+				if (lane + (uint32_t)dd < 64u) binSuffix += t2;
+			}
+			if (lane == 0) sBinWave[wave] = binSuffix;
 		}
 		__syncthreads();
-		if (tid < 129u) {      // longest first: a length starts behind all longer ones
-			uint32_t s = 0;
-			for (uint32_t b2 = tid + 1u; b2 <= 128u; ++b2) s += sBinTot[b2];
-			sBinStart[tid] = (uint16_t)s;
+		if (tid < 129u) {
+			uint32_t behind = 0;
+			for (uint32_t w2 = wave + 1u; w2 < 3u; ++w2) behind += sBinWave[w2];
+			sBinStart[tid] = (uint16_t)(binSuffix - binTot + behind);
 		}
 		__syncthreads();
 		if (inHome) {
