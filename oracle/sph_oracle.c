@@ -3313,3 +3313,267 @@ float orc_sa_gamma_dt(float dt, float max_gamma_cfl)
 	const float dt_gam = 0.001f/maxcfl;
 	return dt_gam < dt ? dt_gam : dt;
 }
+
+/* ====================================================================================================
+ * Open boundaries of SA_BOUNDARY (the half that is NOT built): GROUNDWORK ONLY.
+ * The leaf functions and the initialisation kernels of ENABLE_INLET_OUTLET, restated so that the engines of a later round
+ * have their checker; the product (libsphx) has no counterpart of anything below and answers SPHX_ERR_UNSUPPORTED.
+ * Not restated yet: the IO branches of saSegment/VertexBoundaryConditions (:1427-1545, 2197-2270), findOutgoingSegment (:1647),
+ * particle creation, the IO branches of density_sum / forces / Euler, the water depth.  Parity unpinned (no reference fixture
+ * holds these; the known answers are in tests/test_sa_io_oracle.py).
+ * ==================================================================================================== */
+#define FG_INLET             (PART_FLAG_START << 2)      /* src/particleinfo.h:153-156 */
+#define FG_OUTLET            (PART_FLAG_START << 3)
+#define FG_VELOCITY_DRIVEN   (PART_FLAG_START << 4)
+#define FG_CORNER            (PART_FLAG_START << 5)
+#define IO_BOUNDARY(f)       ((f).x & (FG_INLET | FG_OUTLET))      /* :222 */
+#define VEL_IO(f)            ((f).x & FG_VELOCITY_DRIVEN)           /* :227 */
+#define CORNER(f)            ((f).x & FG_CORNER)                    /* :241 */
+#define MAXNEIBVERTS 30                                             /* boundary_conditions_kernel.cu:1977 */
+
+/* Riemann celerity and its inverse, src/cuda/phys_core.cu:114-127 (__powf -> powf; the double constants of RHOR as written) */
+float orc_R(const orc_params *p, float rho_tilde, int i)
+{
+	const float rho_ratio = rho_tilde + 1.0f;
+	return 2.0f/(p->gammacoeff[i] - 1.0f)*p->sscoeff[i]*powf(rho_ratio, 0.5f*p->gammacoeff[i] - 0.5f);
+}
+float orc_RHOR(const orc_params *p, float r, int i)
+{
+	return (float)(powf((float)((p->gammacoeff[i] - 1.)*r/(2.*p->sscoeff[i])), (float)(2./(p->gammacoeff[i] - 1.))) - 1.0);
+}
+
+/* calculateIOboundaryCondition, src/cuda/boundary_conditions_kernel.cu:111-200: velocity imposed -> density from the Riemann
+ * invariant; pressure (density) imposed -> normal velocity from it.  eulerVel: in {imposed u, imposed rho~}, out the condition */
+void orc_io_boundary_condition(const orc_params *p, float eulerVel[4], int velocity_driven, int fluid, float rhoInt, float rhoExt,
+	const float uInt[3], float unInt, float unExt, const float normal[3])
+{
+	const int a = fluid;
+	const float rInt = orc_R(p, rhoInt, a);
+	if (velocity_driven) {
+		float riemannR = 0.0f;
+		if (unExt <= unInt)      /* expansion wave */
+			riemannR = rInt + (unExt - unInt);
+		else {                   /* shock wave */
+			const float riemannRho = orc_RHO(p, orc_P(p, rhoInt, a) + physical_density(p, rhoInt, a)*unInt*(unInt - unExt), a);
+			riemannR = orc_R(p, riemannRho, a);
+			const float riemannC = orc_soundSpeed(p, riemannRho, a);
+			const float lambda = unExt + riemannC;
+			const float cInt = orc_soundSpeed(p, rhoInt, a);
+			const float lambdaInt = unInt + cInt;
+			if (lambda <= lambdaInt)   /* a contact discontinuity */
+				riemannR = rInt;
+		}
+		eulerVel[3] = orc_RHOR(p, riemannR, a);
+	} else {
+		float flux = 0.0f;
+		const float cExt = orc_soundSpeed(p, rhoExt, a);
+		const float cInt = orc_soundSpeed(p, rhoInt, a);
+		const float lambdaInt = unInt + cInt;
+		const float rExt = orc_R(p, rhoExt, a);
+		if (rhoExt <= rhoInt) {      /* expansion wave */
+			flux = unInt + (rExt - rInt);
+			float lambda = flux + cExt;
+			if (lambda > lambdaInt) {   /* shock wave */
+				flux = (orc_P(p, rhoInt, a) - orc_P(p, rhoExt, a))/(physical_density(p, rhoInt, a)*fmaxf(unInt, 1e-5f*p->sscoeff[a])) + unInt;
+				if (fabsf(flux) > p->sscoeff[a]*0.1f)      /* unInt was too small */
+					flux = unInt;
+				lambda = flux + cExt;
+				if (lambda <= lambdaInt)   /* contact discontinuity */
+					flux = unInt;
+			}
+		} else {                     /* shock wave */
+			flux = (orc_P(p, rhoInt, a) - orc_P(p, rhoExt, a))/(physical_density(p, rhoInt, a)*fmaxf(unInt, 1e-5f*p->sscoeff[a])) + unInt;
+			if (fabsf(flux) > p->sscoeff[a]*0.1f)
+				flux = unInt;
+			float lambda = flux + cExt;
+			if (lambda <= lambdaInt) {   /* expansion wave */
+				flux = unInt + (rExt - rInt);
+				lambda = flux + cExt;
+				if (lambda > lambdaInt)    /* contact discontinuity */
+					flux = unInt;
+			}
+		}
+		eulerVel[0] = eulerVel[1] = eulerVel[2] = 0.0f;
+		if (rhoExt < 0.0f)           /* a negative imposed pressure only lets fluid out */
+			flux = fminf(flux, 0.0f);
+		if (flux < 0.0f) {           /* outflow: dv/dn = 0, the normal component removed */
+			const float un = uInt[0]*normal[0] + uInt[1]*normal[1] + uInt[2]*normal[2];
+			for (int k = 0; k < 3; ++k) eulerVel[k] = uInt[k] - un*normal[k];
+		}
+		for (int k = 0; k < 3; ++k) eulerVel[k] += normal[k]*flux;
+		eulerVel[3] = rhoExt;
+	}
+}
+
+/* getMassRepartitionFactor, :213-283: the share of each of a segment's three vertices in a mass that sits at the origin of
+ * vertexRelPos (the segment's centre, or a particle that crosses the segment): sub-triangle areas, clipped to the segment */
+void orc_mass_repartition(const float vrp[9], const float n[3], float beta[3])
+{
+	const v3 nn = { n[0], n[1], n[2] };
+	const v3 q0 = { vrp[0], vrp[1], vrp[2] }, q1 = { vrp[3], vrp[4], vrp[5] }, q2 = { vrp[6], vrp[7], vrp[8] };
+	const v3 v01 = v3_sub(q0, q1), v02 = v3_sub(q0, q2);
+	v3 p0 = v3_sub(q0, v3_scale(nn, v3_dot(q0, nn)));
+	v3 p1 = v3_sub(q1, v3_scale(nn, v3_dot(q1, nn)));
+	v3 p2 = v3_sub(q2, v3_scale(nn, v3_dot(q2, nn)));
+	const float refSurface = (float)(0.5*v3_dot(v3_cross(v01, v02), nn));
+	const v3 v21 = v3_sub(q2, q1);
+	float surface0 = (float)(0.5*v3_dot(v3_cross(p2, v21), nn));
+	float surface1 = (float)(0.5*v3_dot(v3_cross(p0, v02), nn));
+	float surface2 = (float)(-0.5*v3_dot(v3_cross(p1, v01), nn));
+	if (surface0 < 0. && surface2 < 0.) { surface0 = 0.; surface1 = refSurface; surface2 = 0.; }          /* clipped to v1 */
+	else if (surface0 < 0. && surface1 < 0.) { surface0 = 0.; surface1 = 0.; surface2 = refSurface; }      /* clipped to v2 */
+	else if (surface1 < 0. && surface2 < 0.) { surface0 = refSurface; surface1 = 0.; surface2 = 0.; }      /* clipped to v0 */
+	else if (surface0 < 0.) {
+		const float coef = (float)(surface0/(0.5*v3_dot(v3_cross(p0, v21), nn)));
+		p1 = v3_sub(p1, v3_scale(p0, coef));
+		p0 = v3_scale(p0, (float)(1. - coef));
+		surface0 = 0.;
+		surface1 = (float)(0.5*v3_dot(v3_cross(p0, v02), nn));
+		surface2 = (float)(-0.5*v3_dot(v3_cross(p1, v01), nn));
+	} else if (surface1 < 0.) {
+		const float coef = (float)(surface1/(0.5*v3_dot(v3_cross(p1, v02), nn)));
+		p2 = v3_sub(p2, v3_scale(p1, coef));
+		p1 = v3_scale(p1, (float)(1. - coef));
+		surface0 = (float)(0.5*v3_dot(v3_cross(p2, v21), nn));
+		surface1 = 0.;
+		surface2 = (float)(-0.5*v3_dot(v3_cross(p1, v01), nn));
+	} else if (surface2 < 0.) {
+		const float coef = (float)(-surface2/(0.5*v3_dot(v3_cross(p2, v01), nn)));
+		p0 = v3_sub(p0, v3_scale(p2, coef));
+		p2 = v3_scale(p2, (float)(1. - coef));
+		surface0 = (float)(0.5*v3_dot(v3_cross(p2, v21), nn));
+		surface1 = (float)(0.5*v3_dot(v3_cross(p0, v02), nn));
+		surface2 = 0.;
+	}
+	beta[0] = surface0/refSurface; beta[1] = surface1/refSurface; beta[2] = surface2/refSurface;
+}
+
+/* saIdentifyCornerVerticesDevice, :2319-2362: a vertex of an open boundary that also belongs to a segment which is not of that
+ * open boundary gets FG_CORNER */
+void orc_sa_identify_corner_vertices(const orc_params *p, const orc_f4 *posArray, orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *vertices, const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles)
+{
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		orc_info info = infoArray[index];
+		if (!(VERTEX(info) && IO_BOUNDARY(info))) continue;
+		const uint32_t obj = OBJECT_NUM(info);
+		const orc_f4 pos = posArray[index];
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_info neib_info = infoArray[neib_index];
+			if (!(obj == OBJECT_NUM(neib_info) && IO_BOUNDARY(neib_info)) &&
+			    has_vertex(vertices + 4*(size_t)neib_index, orc_info_id(info))) {
+				info.x |= FG_CORNER;
+				infoArray[index] = info;
+				break;
+			}
+		}
+	}
+}
+
+/* the ids of the other vertices of the open-boundary segments a vertex belongs to (shared by the two kernels below) */
+static uint32_t io_adjacent_vertex_ids(const orc_params *p, uint32_t index, const orc_f4 *pos, const orc_info *infoArray,
+	const uint32_t *hashArray, const uint32_t *vertices, const uint32_t *cellStart, const uint16_t *neibsList, uint32_t *ids)
+{
+	const uint32_t my_id = orc_info_id(infoArray[index]);
+	uint32_t count = 0;
+	int gridPos[3];
+	orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+	neib_iter it;
+	neib_iter_init(&it, p, PT_BOUNDARY, index, pos, gridPos, cellStart, neibsList);
+	uint32_t neib_index;
+	while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+		if (!IO_BOUNDARY(infoArray[neib_index])) continue;
+		const uint32_t *nv = vertices + 4*(size_t)neib_index;
+		if (!has_vertex(nv, my_id)) continue;
+		for (int k = 0; k < 3; ++k)
+			if (my_id != nv[k] && count < MAXNEIBVERTS) ids[count++] = nv[k];
+	}
+	return count;
+}
+
+/* initIOmass_vertexCountDevice, :1999-2064: per non-corner open-boundary vertex, how many non-corner vertices share a segment
+ * with it (one count per shared segment), into forces.w */
+void orc_sa_init_io_mass_vertex_count(const orc_params *p, const uint32_t *vertices, const uint32_t *hashArray,
+	const orc_info *infoArray, const uint32_t *cellStart, const uint16_t *neibsList, orc_f4 *forces, uint32_t numParticles)
+{
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		if (!(VERTEX(info) && IO_BOUNDARY(info) && !CORNER(info))) continue;
+		const orc_f4 pos = { 0.0f, 0.0f, 0.0f, 0.0f };
+		uint32_t ids[MAXNEIBVERTS];
+		const uint32_t nids = io_adjacent_vertex_ids(p, index, &pos, infoArray, hashArray, vertices, cellStart, neibsList, ids);
+		uint32_t vertexCount = 0;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		neib_iter_init(&it, p, PT_VERTEX, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_info neib_info = infoArray[neib_index];
+			for (uint32_t j = 0; j < nids; ++j)
+				if (orc_info_id(neib_info) == ids[j] && !CORNER(neib_info)) vertexCount += 1;
+		}
+		forces[index].w = (float)vertexCount;
+	}
+}
+
+/* initIOmassDevice, :2078-2172: the open-boundary vertices start from half a fluid particle's mass -- vertices with an odd id
+ * take the difference from their even-numbered partners along the segments they share, equal shares */
+void orc_sa_init_io_mass(const orc_params *p, const orc_f4 *oldPos, const orc_f4 *forces, const uint32_t *vertices,
+	const uint32_t *hashArray, const orc_info *infoArray, const uint32_t *cellStart, const uint16_t *neibsList,
+	orc_f4 *newPos, uint32_t numParticles, float deltap)
+{
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		const orc_f4 pos = oldPos[index];
+		newPos[index] = pos;
+		if (!(VERTEX(info) && IO_BOUNDARY(info) && !CORNER(info))) continue;
+		const int getMass = (int)(orc_info_id(info) % 2u);
+		float massChange = 0.0f;
+		const float refMass = 0.5f*deltap*deltap*deltap*p->rho0[FLUID_NUM(info)];
+		const float massDiff = refMass - pos.w;
+		const float vertexCount = forces[index].w;
+		uint32_t ids[MAXNEIBVERTS];
+		const uint32_t nids = io_adjacent_vertex_ids(p, index, &pos, infoArray, hashArray, vertices, cellStart, neibsList, ids);
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		neib_iter_init(&it, p, PT_VERTEX, index, &pos, gridPos, cellStart, neibsList);
+		uint32_t neib_index;
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_info neib_info = infoArray[neib_index];
+			for (uint32_t j = 0; j < nids; ++j) {
+				if (orc_info_id(neib_info) != ids[j]) continue;
+				const int neib_getMass = (int)(orc_info_id(neib_info) % 2u);
+				if (getMass != neib_getMass && !CORNER(neib_info)) {
+					if (getMass) {
+						if (massDiff > 0.0f) massChange += massDiff/vertexCount;
+					} else {
+						const float neib_massDiff = refMass - oldPos[neib_index].w;
+						if (neib_massDiff > 0.0f) massChange -= neib_massDiff/forces[neib_index].w;
+					}
+				}
+			}
+		}
+		newPos[index].w += massChange;
+	}
+}
+
+/* disableOutgoingPartsDevice, :2374-2398: a fluid particle marked by findOutgoingSegment (vertexinfo .x | .y != 0) is disabled and
+ * its mark cleared */
+void orc_disable_outgoing_parts(orc_f4 *posArray, uint32_t *vertices, const orc_info *infoArray, uint32_t numParticles)
+{
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		if (PART_TYPE(infoArray[index]) != PT_FLUID || !ACTIVE(posArray[index])) continue;
+		uint32_t *v = vertices + 4*(size_t)index;
+		if ((v[0] | v[1]) != 0u) {
+			posArray[index].w = NAN;      /* disable_particle */
+			v[0] = v[1] = v[2] = v[3] = 0u;
+		}
+	}
+}

@@ -73,6 +73,9 @@ def lib():
         _lib.orc_fcoeff.restype = C.c_float; _lib.orc_fcoeff.argtypes = [C.c_int, C.c_float, C.c_float]
         _lib.orc_P.restype = C.c_float; _lib.orc_P.argtypes = [C.c_void_p, C.c_float, C.c_int]
         _lib.orc_soundSpeed.restype = C.c_float; _lib.orc_soundSpeed.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        _lib.orc_R.restype = C.c_float; _lib.orc_R.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        _lib.orc_RHOR.restype = C.c_float; _lib.orc_RHOR.argtypes = [C.c_void_p, C.c_float, C.c_int]
+        _lib.orc_RHO.restype = C.c_float; _lib.orc_RHO.argtypes = [C.c_void_p, C.c_float, C.c_int]
         _lib.orc_forces.restype = C.c_uint32
         _lib.orc_forces_sa.restype = C.c_uint32
         _lib.orc_forces_grenier.restype = C.c_uint32
@@ -341,6 +344,56 @@ class Oracle:
         v = vel.copy()
         self.L.orc_sa_vertex_bc(C.byref(self.p), P(v), P(ggam), P(pos), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n))
         return v
+
+    # ---- open boundaries of SA_BOUNDARY: oracle GROUNDWORK only (oracle/sph_oracle.c "Open boundaries"), no product counterpart
+    def riemann_R(self, rho_tilde, fluid=0):
+        return float(self.L.orc_R(C.byref(self.p), C.c_float(rho_tilde), C.c_int(fluid)))
+
+    def riemann_RHOR(self, r, fluid=0):
+        return float(self.L.orc_RHOR(C.byref(self.p), C.c_float(r), C.c_int(fluid)))
+
+    def eos_P(self, rho_tilde, fluid=0):
+        return float(self.L.orc_P(C.byref(self.p), C.c_float(rho_tilde), C.c_int(fluid)))
+
+    def eos_RHO(self, pressure, fluid=0):
+        return float(self.L.orc_RHO(C.byref(self.p), C.c_float(pressure), C.c_int(fluid)))
+
+    def sound_speed(self, rho_tilde, fluid=0):
+        return float(self.L.orc_soundSpeed(C.byref(self.p), C.c_float(rho_tilde), C.c_int(fluid)))
+
+    def io_boundary_condition(self, euler_vel, velocity_driven, rho_int, rho_ext, u_int, un_int, un_ext, normal, fluid=0):
+        """calculateIOboundaryCondition: the (u, rho~) imposed on an open-boundary element -> the completed condition"""
+        ev = np.asarray(euler_vel, dtype=np.float32).copy()
+        u = np.asarray(u_int, dtype=np.float32); nrm = np.asarray(normal, dtype=np.float32)
+        self.L.orc_io_boundary_condition(C.byref(self.p), P(ev), C.c_int(1 if velocity_driven else 0), C.c_int(fluid),
+                                         C.c_float(rho_int), C.c_float(rho_ext), P(u), C.c_float(un_int), C.c_float(un_ext), P(nrm))
+        return ev
+
+    def mass_repartition(self, vertex_rel_pos, normal):
+        v = np.ascontiguousarray(np.asarray(vertex_rel_pos, dtype=np.float32).reshape(9))
+        nrm = np.asarray(normal, dtype=np.float32)
+        beta = np.zeros(3, dtype=np.float32)
+        self.L.orc_mass_repartition(P(v), P(nrm), P(beta))
+        return beta
+
+    def sa_identify_corner_vertices(self, pos, info, hash_, vertices, cs, nl, n):
+        out = info.copy()
+        self.L.orc_sa_identify_corner_vertices(C.byref(self.p), P(pos), P(out), P(hash_), P(vertices), P(cs), P(nl), C.c_uint32(n))
+        return out
+
+    def sa_init_io_mass(self, pos, info, hash_, vertices, cs, nl, n, deltap):
+        """INIT_IO_MASS_VERTEX_COUNT + INIT_IO_MASS: (vertex counts, positions with the new vertex masses)"""
+        forces = np.zeros((len(pos), 4), dtype=np.float32)
+        self.L.orc_sa_init_io_mass_vertex_count(C.byref(self.p), P(vertices), P(hash_), P(info), P(cs), P(nl), P(forces), C.c_uint32(n))
+        new_pos = np.zeros_like(pos)
+        self.L.orc_sa_init_io_mass(C.byref(self.p), P(pos), P(forces), P(vertices), P(hash_), P(info), P(cs), P(nl), P(new_pos),
+                                   C.c_uint32(n), C.c_float(deltap))
+        return forces[:, 3].copy(), new_pos
+
+    def disable_outgoing_parts(self, pos, vertices, info, n):
+        p2, v2 = pos.copy(), vertices.copy()
+        self.L.orc_disable_outgoing_parts(P(p2), P(v2), P(info), C.c_uint32(n))
+        return p2, v2
 
     def effective_visc(self, pos, vel, info, hash_, cs, nl, n, range_end=None):
         """CALC_VISC of the generalized Newtonian rheologies: (effvisc per particle, largest kinematic viscosity)"""

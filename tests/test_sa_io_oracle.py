@@ -1,0 +1,196 @@
+"""Open boundaries of SA_BOUNDARY (the half that is not built): known answers for the GROUNDWORK in the oracle --
+the Riemann-invariant boundary condition, the mass repartition of a segment, corner identification, the initial masses of the
+open-boundary vertices, the removal of outgoing particles.  There is no product counterpart yet: these tests pin the checker a
+later round builds the engines against (oracle/sph_oracle.c "Open boundaries"; src/cuda/boundary_conditions_kernel.cu:111-283,
+1999-2172, 2319-2398 of the reference).  Parity unpinned: the reference holds no fixture for any of it."""
+import numpy as np
+import pytest
+
+from gpusph_amd import defs as D
+from gpusph_amd.problem import SABox, info_id, info_type
+from sa_helpers import sa_oracle_state
+
+
+@pytest.fixture(scope="module")
+def st():
+    return sa_oracle_state(deltap=0.05)
+
+
+def _eos(st):
+    pp = st["problem"].physparams
+    return float(pp.gammacoeff[0]), float(pp.sscoeff[0]), float(pp.bcoeff[0]), float(pp.rho0[0])
+
+
+def test_riemann_celerity_and_its_inverse(st):
+    o = st["oracle"]
+    gam, c0, _, _ = _eos(st)
+    for rt in (-0.01, 0.0, 0.003, 0.02, 0.05):
+        assert abs(o.riemann_RHOR(o.riemann_R(rt)) - rt) < 2e-6
+        # R = 2 c / (gamma - 1)
+        assert abs(o.riemann_R(rt) * (gam - 1.0) / 2.0 - o.sound_speed(rt)) < 2e-6 * c0
+        assert abs(o.eos_RHO(o.eos_P(rt)) - rt) < 2e-6
+
+
+def test_velocity_inlet_takes_its_density_from_the_outgoing_invariant(st):
+    o = st["oracle"]
+    gam, c0, B, rho0 = _eos(st)
+    n = np.array([1.0, 0.0, 0.0])
+    rho_int = 0.01
+    # imposed normal velocity equal to the fluid's: nothing to adjust
+    ev = o.io_boundary_condition([0.3, 0, 0, 0], True, rho_int, 0.0, [0.3, 0, 0], 0.3, 0.3, n)
+    assert abs(ev[3] - rho_int) < 2e-6 and np.allclose(ev[:3], [0.3, 0, 0])
+    # expansion (the boundary recedes from the fluid: unExt < unInt): c_b = c_int + (gamma - 1)/2 (unExt - unInt)
+    for un_ext in (0.2, 0.0, -0.5):
+        ev = o.io_boundary_condition([un_ext, 0, 0, 0], True, rho_int, 0.0, [0.3, 0, 0], 0.3, un_ext, n)
+        c_int = c0 * (1.0 + rho_int) ** ((gam - 1.0) / 2.0)
+        c_b = c_int + 0.5 * (gam - 1.0) * (un_ext - 0.3)
+        want = (c_b / c0) ** (2.0 / (gam - 1.0)) - 1.0
+        assert abs(ev[3] - want) < 5e-6 and ev[3] < rho_int
+    # compression (unExt > unInt): the density rises; the momentum jump P_b = P_int + rho u_int (u_int - u_ext) only when the
+    # wave it implies outruns the fluid's own characteristic, the fluid's state otherwise (a contact discontinuity)
+    for un_int, un_ext in ((0.3, 0.6), (-0.4, -0.1)):
+        ev = o.io_boundary_condition([un_ext, 0, 0, 0], True, rho_int, 0.0, [un_int, 0, 0], un_int, un_ext, n)
+        P_int = B * ((1.0 + rho_int) ** gam - 1.0)
+        P_b = P_int + rho0 * (1.0 + rho_int) * un_int * (un_int - un_ext)
+        rho_b = (P_b / B + 1.0) ** (1.0 / gam) - 1.0
+        c = lambda r: c0 * (1.0 + r) ** ((gam - 1.0) / 2.0)
+        want = rho_b if un_ext + c(rho_b) > un_int + c(rho_int) else rho_int
+        assert abs(ev[3] - want) < 5e-6
+
+
+def test_pressure_outlet_takes_its_normal_velocity_from_the_invariant(st):
+    o = st["oracle"]
+    gam, c0, _, _ = _eos(st)
+    n = np.array([0.0, 0.0, 1.0])
+    u_int = np.array([0.2, -0.1, -0.3])          # leaving through a boundary whose normal points into the fluid
+    un = float(u_int @ n)
+    # the imposed density is the fluid's: the normal velocity is the fluid's, the tangential one is kept (dv/dn = 0 on outflow)
+    ev = o.io_boundary_condition([9, 9, 9, 0.01], False, 0.01, 0.01, u_int, un, 0.0, n)
+    assert np.allclose(ev[:3], u_int, atol=2e-6) and ev[3] == np.float32(0.01)
+    # a lower imposed pressure draws the fluid out faster, by the difference of the Riemann celerities
+    ev = o.io_boundary_condition([0, 0, 0, 0.0], False, 0.01, 0.0, u_int, un, 0.0, n)
+    want = un + (o.riemann_R(0.0) - o.riemann_R(0.01))
+    assert abs(ev[2] - want) < 2e-5 and ev[2] < un and np.allclose(ev[:2], u_int[:2], atol=1e-6) and ev[3] == 0.0
+    # inflow (flux > 0): no tangential velocity is imposed
+    u_in = np.array([0.2, -0.1, 0.3])
+    ev = o.io_boundary_condition([0, 0, 0, 0.01], False, 0.01, 0.01, u_in, 0.3, 0.0, n)
+    assert abs(ev[2] - 0.3) < 2e-6 and ev[0] == 0.0 and ev[1] == 0.0
+    # a negative imposed pressure never lets fluid in
+    ev = o.io_boundary_condition([0, 0, 0, -0.001], False, -0.02, -0.001, [0, 0, 0.05], 0.05, 0.0, n)
+    assert ev[2] <= 0.0 and ev[3] == np.float32(-0.001)
+
+
+def test_mass_repartition_is_barycentric_inside_and_clipped_outside(st):
+    o = st["oracle"]
+    rng = np.random.default_rng(11)
+    tri = np.array([[0.0, 0.0, 0.0], [0.05, 0.0, 0.0], [0.0, 0.05, 0.0]])
+    nrm = np.array([0.0, 0.0, 1.0])
+    assert np.allclose(o.mass_repartition(tri - tri.mean(axis=0), nrm), 1.0 / 3.0, atol=1e-6)
+    for k in range(3):       # at a vertex: all of it
+        want = np.zeros(3); want[k] = 1.0
+        assert np.allclose(o.mass_repartition(tri - tri[k], nrm), want, atol=1e-6)
+    for _ in range(200):
+        lam = rng.dirichlet(np.ones(3))
+        x = lam @ tri + np.array([0, 0, rng.uniform(-0.02, 0.02)])       # a point above / below the segment projects onto it
+        assert np.allclose(o.mass_repartition(tri - x, nrm), lam, atol=2e-5)
+    for _ in range(200):     # outside: the weights stay a partition of the mass over the three vertices
+        x = np.array([rng.uniform(-0.1, 0.15), rng.uniform(-0.1, 0.15), 0.0])
+        b = o.mass_repartition(tri - x, nrm)
+        assert (b >= -1e-6).all() and abs(b.sum() - 1.0) < 1e-5
+
+
+def _open_wall(st, flags):
+    """the x = 0 wall of the tank as open boundary number 1: (info with the flags set, masks of its segments and vertices)"""
+    p = st["problem"]
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    seg = (t == D.PT_BOUNDARY) & (st["boundelements"][:, 0] > 0.5) & (np.abs(g[:, 0]) < 1e-6)
+    vtx = (t == D.PT_VERTEX) & (np.abs(g[:, 0]) < 1e-6)
+    info = st["info"].copy()
+    info[seg | vtx, 0] |= flags
+    info[seg | vtx, 1] = (info[seg | vtx, 1] & 0xF000) | 1
+    return info, seg, vtx, g
+
+
+def test_corner_vertices_are_those_shared_with_another_wall(st):
+    p, o = st["problem"], st["oracle"]
+    info, seg, vtx, g = _open_wall(st, D.FG_INLET | D.FG_VELOCITY_DRIVEN)
+    out = o.sa_identify_corner_vertices(st["pos"], info, st["hash"], st["vertices"], st["cs"], st["nl"], st["n"])
+    corner = (out[:, 0] & D.FG_CORNER) != 0
+    eps = 1e-6
+    on_edge = vtx & ((np.abs(g[:, 1]) < eps) | (np.abs(g[:, 1] - p.w) < eps) | (np.abs(g[:, 2]) < eps))   # y = 0, y = w, floor; open on top
+    assert np.array_equal(corner, on_edge) and corner.sum() > 0 and (vtx & ~corner).sum() > 0
+    assert np.array_equal(out[:, 0] & ~np.uint16(D.FG_CORNER), info[:, 0])      # nothing else touched
+
+
+def _mesh_counts(st, info, deltap):
+    """vertex counts and new masses from the connectivity alone (no neighbour lists)"""
+    ids = info_id(st["info"])
+    where = {int(v): k for k, v in enumerate(ids)}
+    io = (info[:, 0] & (D.FG_INLET | D.FG_OUTLET)) != 0
+    corner = (info[:, 0] & D.FG_CORNER) != 0
+    t = info_type(info)
+    segs = np.where((t == D.PT_BOUNDARY) & io)[0]
+    partners = {}       # vertex index -> list of partner vertex indices, one per shared segment
+    for s in segs:
+        vs = [where[int(v)] for v in st["vertices"][s, :3]]
+        for a in vs:
+            partners.setdefault(a, []).extend(b for b in vs if b != a)
+    count = np.zeros(len(info), dtype=np.float64)
+    for a, lst in partners.items():
+        if not corner[a]:
+            count[a] = sum(1 for b in lst if not corner[b])
+    ref = 0.5 * deltap ** 3 * st["problem"].physparams.rho0[0]
+    mass = st["pos"][:, 3].astype(np.float64).copy()
+    new = mass.copy()
+    for a, lst in partners.items():
+        if corner[a]:
+            continue
+        get_a = int(ids[a]) % 2
+        for b in lst:
+            if corner[b] or int(ids[b]) % 2 == get_a:
+                continue
+            if get_a:
+                if ref - mass[a] > 0:
+                    new[a] += (ref - mass[a]) / count[a]
+            elif ref - mass[b] > 0:
+                new[a] -= (ref - mass[b]) / count[b]
+    return count, new
+
+
+def test_initial_masses_of_the_open_boundary_vertices(st):
+    p, o = st["problem"], st["oracle"]
+    dp = p.m_deltap
+    info, seg, vtx, g = _open_wall(st, D.FG_INLET | D.FG_VELOCITY_DRIVEN)
+    info = o.sa_identify_corner_vertices(st["pos"], info, st["hash"], st["vertices"], st["cs"], st["nl"], st["n"])
+    # lighter vertices than half a particle, so that there is something to hand over
+    pos = st["pos"].copy()
+    inner = vtx & ((info[:, 0] & D.FG_CORNER) == 0)
+    rng = np.random.default_rng(3)
+    pos[inner, 3] *= rng.uniform(0.5, 0.9, size=int(inner.sum())).astype(np.float32)
+    st2 = dict(st, pos=pos)
+    count, new_pos = o.sa_init_io_mass(pos, info, st["hash"], st["vertices"], st["cs"], st["nl"], st["n"], dp)
+    want_count, want_mass = _mesh_counts(st2, info, dp)
+    assert np.array_equal(count, want_count.astype(np.float32)) and count[inner].min() >= 2
+    assert np.allclose(new_pos[:, 3], want_mass, rtol=2e-6, atol=0)
+    assert np.array_equal(new_pos[:, :3], pos[:, :3])
+    untouched = ~inner
+    assert np.array_equal(new_pos[untouched, 3], pos[untouched, 3])
+    # what the odd vertices take, the even ones give: the wall's mass is conserved
+    assert abs(new_pos[inner, 3].astype(np.float64).sum() - pos[inner, 3].astype(np.float64).sum()) < 1e-6 * pos[inner, 3].sum()
+    odd = inner & (info_id(st["info"]) % 2 == 1)
+    assert (new_pos[odd, 3] >= pos[odd, 3]).all() and (new_pos[inner & ~odd, 3] <= pos[inner & ~odd, 3]).all()
+    assert (new_pos[odd, 3] > pos[odd, 3]).any()
+
+
+def test_outgoing_particles_are_disabled_and_their_marks_cleared(st):
+    o = st["oracle"]
+    t = info_type(st["info"])
+    fl = np.where(t == D.PT_FLUID)[0]
+    vertices = st["vertices"].copy()
+    vertices[fl[3]] = (17, 0, 0, 5)            # marked by findOutgoingSegment: the segment's vertices and the weights' tag
+    vertices[fl[8]] = (0, 23, 41, 0)
+    pos, v2 = o.disable_outgoing_parts(st["pos"], vertices, st["info"], st["n"])
+    gone = np.zeros(len(pos), dtype=bool); gone[[fl[3], fl[8]]] = True
+    assert np.isnan(pos[gone, 3]).all() and np.array_equal(pos[~gone], st["pos"][~gone])
+    assert (v2[gone] == 0).all() and np.array_equal(v2[~gone], st["vertices"][~gone])
