@@ -3577,3 +3577,109 @@ void orc_disable_outgoing_parts(orc_f4 *posArray, uint32_t *vertices, const orc_
 		}
 	}
 }
+
+/* saSegmentBoundaryConditionsDevice with has_io (:1427-1520; laminar, not repacking): the solid-wall condition of sa_segment_bc_impl
+ * for the segments of solid walls (whose Eulerian velocity is cleared, impose_solid_eulerVel :1287-1293) and, for the segments of an
+ * open boundary, the Shepard means of the fluid's velocity (+ its Eulerian velocity) and pressure (io_fluid_contrib :852-866)
+ * completed by the Riemann-invariant condition (impose_io_bc :1362-1413).  eulerVelArray: in, what IMPOSE_OPEN_BOUNDARY_CONDITION
+ * set on the open-boundary rows; out, the completed condition; the density of an open-boundary segment is its Eulerian density.
+ * GROUNDWORK, as the section above: nothing in the product calls for it yet. */
+void orc_sa_segment_bc_io(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArray, orc_f4 *eulerVelArray, const orc_f4 *posArray,
+	const uint32_t *vertices, const orc_f4 *boundelement, const orc_info *infoArray, const uint32_t *hashArray,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd, int step)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const int has_moving = (p->simflags & ORC_ENABLE_MOVING_BODIES) != 0;
+	if (step == -1) step = 0;
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!BOUNDARY(info)) continue;
+		const orc_f4 pos = posArray[index];
+		const orc_f4 normal = boundelement[index];
+		const uint32_t *verts = vertices + 4*(size_t)index;
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		float sumpWall = 0.0f, shepard_div = 0.0f, sump = 0.0f;
+		float sumvel[3] = { 0.0f, 0.0f, 0.0f };
+		orc_f4 gGam = { 0.0f, 0.0f, 0.0f, gGamArray[index].w };
+		orc_f4 vel = { 0.0f, 0.0f, 0.0f, 0.0f };
+		const int calcGam = has_moving || !isfinite(gGam.w) || step == 0;
+		if (calcGam) gGam.w = 0.0f;
+		orc_f4 eulerVel = { 0.0f, 0.0f, 0.0f, 0.0f };      /* eulervel_pout, IO constructor :488-505 */
+		if (IO_BOUNDARY(info)) {
+			eulerVel = eulerVelArray[index];
+			if (VEL_IO(info)) eulerVel.w = 0.0f;
+		}
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_VERTEX, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			if (INACTIVE(posArray[neib_index])) continue;
+			if (!has_vertex(verts, orc_info_id(infoArray[neib_index]))) continue;
+			if (has_moving && MOVING(info)) {
+				const orc_f4 nv = velArray[neib_index];
+				vel.x += nv.x; vel.y += nv.y; vel.z += nv.z;
+			}
+			if (calcGam) {
+				const orc_f4 g = gGamArray[neib_index];
+				gGam.x += g.x; gGam.y += g.y; gGam.z += g.z; gGam.w += g.w;
+			}
+		}
+		if (calcGam) {
+			const float inv = 1.0f/3;
+			gGam.x *= inv; gGam.y *= inv; gGam.z *= inv; gGam.w *= inv;
+			gGamArray[index] = gGam;
+			gGam.w = fmaxf(gGam.w, 1e-5f);
+		}
+		vel.x /= 3; vel.y /= 3; vel.z /= 3;
+		const int fl = FLUID_NUM(info);
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			if (INACTIVE(npos)) continue;
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const sa_ndata n = sa_fluid_ndata(p, wcoeff, wsub, velArray, infoArray, neib_index, rx, ry, rz, npos.w);
+			if (!(n.r < p->influenceradius && (normal.x*rx + normal.y*ry + normal.z*rz) < 0.0f)) continue;
+			const float gdot = p->gravity[0]*rx + p->gravity[1]*ry + p->gravity[2]*rz;
+			sumpWall += fmaxf(n.press + physical_density(p, n.vel.w, fl)*gdot, 0.0f)*n.w;
+			if (IO_BOUNDARY(info)) {      /* io_fluid_contrib, segments */
+				const orc_f4 ne = eulerVelArray[neib_index];
+				sumvel[0] += n.w*(n.vel.x + ne.x); sumvel[1] += n.w*(n.vel.y + ne.y); sumvel[2] += n.w*(n.vel.z + ne.z);
+				sump += n.w*fmaxf(0.0f, n.press);
+			}
+			shepard_div += n.w;
+		}
+		if (IO_BOUNDARY(info)) {      /* impose_io_bc */
+			if (shepard_div > 0.1f*gGam.w) {
+				sumvel[0] /= shepard_div; sumvel[1] /= shepard_div; sumvel[2] /= shepard_div;
+				sump /= shepard_div;
+				vel.w = orc_RHO(p, sump, fl);
+				if (!VEL_IO(info)) { const orc_f4 z = { 0.0f, 0.0f, 0.0f, 0.0f }; eulerVelArray[index] = z; }
+			} else {
+				sump = 0.0f;
+				if (VEL_IO(info)) {
+					sumvel[0] = eulerVel.x; sumvel[1] = eulerVel.y; sumvel[2] = eulerVel.z;
+					vel.w = 0.0f;
+				} else {
+					sumvel[0] = sumvel[1] = sumvel[2] = 0.0f;
+					vel.w = eulerVelArray[index].w;
+				}
+			}
+			const float nrm[3] = { normal.x, normal.y, normal.z };
+			const float unInt = sumvel[0]*nrm[0] + sumvel[1]*nrm[1] + sumvel[2]*nrm[2];
+			const float unExt = eulerVel.x*nrm[0] + eulerVel.y*nrm[1] + eulerVel.z*nrm[2];
+			float ev[4] = { eulerVel.x, eulerVel.y, eulerVel.z, eulerVel.w };
+			orc_io_boundary_condition(p, ev, VEL_IO(info) != 0, fl, vel.w, eulerVel.w, sumvel, unInt, unExt, nrm);
+			const orc_f4 out = { ev[0], ev[1], ev[2], ev[3] };
+			eulerVelArray[index] = out;
+			vel.w = out.w;
+		} else {                       /* impose_solid_bc<true> */
+			shepard_div = fmaxf(shepard_div, 0.1f*gGam.w);
+			vel.w = orc_RHO(p, sumpWall/shepard_div, fl);
+			const orc_f4 z = { 0.0f, 0.0f, 0.0f, 0.0f };
+			eulerVelArray[index] = z;
+		}
+		velArray[index] = vel;
+	}
+}

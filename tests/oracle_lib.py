@@ -390,6 +390,13 @@ class Oracle:
                                    C.c_uint32(n), C.c_float(deltap))
         return forces[:, 3].copy(), new_pos
 
+    def sa_segment_bc_io(self, pos, vel, ggam, euler_vel, vertices, boundelements, info, hash_, cs, nl, n, step):
+        """the segment conditions with open boundaries enabled: (vel, gradgamma, eulerVel) after the pass"""
+        v, g, e = vel.copy(), ggam.copy(), euler_vel.copy()
+        self.L.orc_sa_segment_bc_io(C.byref(self.p), P(v), P(g), P(e), P(pos), P(vertices), P(boundelements), P(info), P(hash_), P(cs),
+                                    P(nl), C.c_uint32(n), C.c_int(step))
+        return v, g, e
+
     def disable_outgoing_parts(self, pos, vertices, info, n):
         p2, v2 = pos.copy(), vertices.copy()
         self.L.orc_disable_outgoing_parts(P(p2), P(v2), P(info), C.c_uint32(n))
