@@ -3683,3 +3683,54 @@ void orc_sa_segment_bc_io(const orc_params *p, orc_f4 *velArray, orc_f4 *gGamArr
 		velArray[index] = vel;
 	}
 }
+
+/* findOutgoingSegmentDevice, :1647-1750: a fluid particle that is behind an open-boundary segment and moving out relative to it
+ * is marked with that segment's vertices (the closest such segment within the influence radius), its share of each vertex
+ * (getMassRepartitionFactor at the particle's position) and its mass go where grad gamma used to be: the vertices take the mass
+ * over in the vertex conditions of the last step, disableOutgoingParts removes the particle.  GROUNDWORK (see above). */
+void orc_find_outgoing_segment(const orc_params *p, const orc_f4 *posArray, const orc_f4 *velArray, uint32_t *vertices,
+	orc_f4 *gGam, const float *vertPos0, const float *vertPos1, const float *vertPos2, const orc_f4 *boundelement,
+	const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, float influenceradius)
+{
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		if (PART_TYPE(info) != PT_FLUID) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		if (vertices[4*(size_t)index] | vertices[4*(size_t)index + 1]) continue;      /* already marked ("this shouldn't happen") */
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const orc_f4 vel = velArray[index];
+		float r2_min = influenceradius*influenceradius;
+		uint32_t index_min = UINT_MAX;
+		v3 normal_min = v3_make(0.0f, 0.0f, 0.0f), relPos_min = normal_min;
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			if (!IO_BOUNDARY(infoArray[neib_index])) continue;
+			const orc_f4 npos = posArray[neib_index];
+			const v3 relPos = v3_make(it.pos_corr[0] - npos.x, it.pos_corr[1] - npos.y, it.pos_corr[2] - npos.z);
+			const orc_f4 nrm = boundelement[neib_index];
+			const v3 normal = v3_make(nrm.x, nrm.y, nrm.z);
+			const orc_f4 nvel = velArray[neib_index];
+			const v3 relVel = v3_make(vel.x - nvel.x, vel.y - nvel.y, vel.z - nvel.z);
+			const float r2 = v3_sqlen(relPos);
+			if (r2 < r2_min && v3_dot(normal, relPos) <= 0.0f && v3_dot(normal, relVel) < 0.0f) {
+				r2_min = r2; index_min = neib_index; normal_min = normal; relPos_min = relPos;
+			}
+		}
+		if (index_min == UINT_MAX) continue;
+		v3 vx[3];
+		calc_vertex_rel_pos(vx, normal_min, vertPos0 + 2*(size_t)index_min, vertPos1 + 2*(size_t)index_min, vertPos2 + 2*(size_t)index_min, 1.0f);
+		for (int k = 0; k < 3; ++k) vx[k] = v3_sub(relPos_min, vx[k]);      /* relative to the particle, not to the barycentre */
+		const float vrp[9] = { vx[0].x, vx[0].y, vx[0].z, vx[1].x, vx[1].y, vx[1].z, vx[2].x, vx[2].y, vx[2].z };
+		const float nn[3] = { normal_min.x, normal_min.y, normal_min.z };
+		float beta[3];
+		orc_mass_repartition(vrp, nn, beta);
+		for (int k = 0; k < 4; ++k) vertices[4*(size_t)index + k] = vertices[4*(size_t)index_min + k];
+		const orc_f4 w = { beta[0], beta[1], beta[2], pos.w };
+		gGam[index] = w;
+	}
+}

@@ -397,6 +397,13 @@ class Oracle:
                                     P(nl), C.c_uint32(n), C.c_int(step))
         return v, g, e
 
+    def find_outgoing_segment(self, pos, vel, vertices, ggam, vertpos, boundelements, info, hash_, cs, nl, n, influenceradius):
+        """FIND_OUTGOING_SEGMENT: (vertices, gradgamma) with the marks of the fluid particles that left through an open boundary"""
+        v, g = vertices.copy(), ggam.copy()
+        self.L.orc_find_outgoing_segment(C.byref(self.p), P(pos), P(vel), P(v), P(g), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]),
+                                         P(boundelements), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n), C.c_float(influenceradius))
+        return v, g
+
     def disable_outgoing_parts(self, pos, vertices, info, n):
         p2, v2 = pos.copy(), vertices.copy()
         self.L.orc_disable_outgoing_parts(P(p2), P(v2), P(info), C.c_uint32(n))

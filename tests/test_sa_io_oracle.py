@@ -274,3 +274,53 @@ def test_pressure_outlet_segments_draw_by_the_difference_of_the_celerities(st):
             assert abs(ev[i, 0] - want) < 1e-4 * max(1.0, abs(want)) + 2e-5 or ev[i, 0] == 0.0
         assert ev[i, 1] == 0.0 and ev[i, 2] == 0.0
         assert abs(ev[i, 0]) < 0.1 * p.physparams.sscoeff[0]
+
+
+def test_particles_that_cross_an_open_boundary_are_marked_with_the_segment_they_crossed(st):
+    p, o = st["problem"], st["oracle"]
+    dp = p.m_deltap
+    info, seg, vtx, g = _open_wall(st, D.FG_OUTLET)
+    fl = np.where(info_type(info) == D.PT_FLUID)[0]
+    near = fl[np.abs(g[fl, 0] - dp) < 1e-6]                  # the fluid layer next to the x = 0 wall
+    pos, vel = st["pos"].copy(), st["vel"].copy()
+    out, back, still = near[5], near[9], near[13]
+    for i in (out, back, still):
+        pos[i, 0] -= np.float32(1.3 * dp)                    # 0.3 dp behind the wall (the lists are those of the last build)
+    pos[out, 1] += np.float32(0.22 * dp); pos[out, 2] += np.float32(0.09 * dp)      # off the lattice: one closest segment
+    vel[out, 0] = -0.4                                       # leaving
+    vel[back, 0] = +0.4                                      # behind the wall but coming back in
+    vel[still, 0] = 0.0                                      # not moving relative to the segment
+    inside = near[21]
+    vel[inside, 0] = -0.4                                    # moving out, but still in front of the wall
+    infl = float(p.simparams.influenceRadius)
+    v2, g2 = o.find_outgoing_segment(pos, vel, st["vertices"], _with_gamma(st), st["vertpos"], st["boundelements"], info,
+                                     st["hash"], st["cs"], st["nl"], st["n"], infl)
+    marked = np.where((v2[:, 0] | v2[:, 1]) != 0)[0]
+    assert set(marked) - set(np.where(info_type(info) != D.PT_FLUID)[0]) == {int(out)}
+    # the mark: the vertices of the closest open-boundary segment behind which the particle lies, its barycentric shares, its mass
+    gp = p.global_pos(pos, st["hash"])
+    segs = np.where(seg)[0]
+    d = np.linalg.norm(g[segs] - gp[out], axis=1)
+    closest = segs[np.argmin(d)]
+    assert np.array_equal(v2[out], st["vertices"][closest])
+    w = g2[out]
+    assert abs(w[:3].sum() - 1.0) < 1e-5 and (w[:3] >= -1e-6).all() and w[3] == st["pos"][out, 3]
+    ids = info_id(st["info"])
+    where = {int(v): k for k, v in enumerate(ids)}
+    corners = np.array([g[where[int(v)]] for v in st["vertices"][closest, :3]])
+    proj = gp[out].copy(); proj[0] = 0.0                      # the particle projected onto the wall
+    assert np.allclose(w[:3] @ corners, proj, atol=2e-6 + 1e-3 * dp) or not _inside(corners, proj)
+    # everybody else keeps grad gamma and has no mark
+    others = np.ones(len(pos), dtype=bool); others[out] = False
+    assert np.array_equal(g2[others], _with_gamma(st)[others], equal_nan=True)
+    # ... and the marked particle is what disableOutgoingParts removes
+    pos3, v3 = o.disable_outgoing_parts(pos, v2, info, st["n"])
+    assert np.isnan(pos3[out, 3]) and (v3[out] == 0).all() and np.isfinite(pos3[[back, still, inside], 3]).all()
+
+
+def _inside(tri, x):
+    """is x (in the triangle's plane) inside the triangle"""
+    a, b, c = tri
+    n = np.cross(b - a, c - a)
+    s = [np.dot(np.cross(q - p_, x - p_), n) for p_, q in ((a, b), (b, c), (c, a))]
+    return min(s) >= 0 or max(s) <= 0
