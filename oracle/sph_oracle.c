@@ -3734,3 +3734,148 @@ void orc_find_outgoing_segment(const orc_params *p, const orc_f4 *posArray, cons
 		gGam[index] = w;
 	}
 }
+
+/* saVertexBoundaryConditionsDevice with has_io (:2197-2252; laminar, not repacking): the solid-wall density of every vertex
+ * (sa_vertex_bc_impl), and for the vertices of an open boundary that are not corners (impose_vertex_io_bc :1168-1252):
+ *   - the Shepard means of the fluid's velocity (+ Eulerian velocity) and pressure, completed by the Riemann condition into the
+ *     vertex's Eulerian velocity and density (io_fluid_contrib for vertices :868-909);
+ *   - the mass flux through the adjacent open-boundary segments, each segment's flux rho A (eulerVel . n) shared out by
+ *     getMassRepartitionFactor at the segment's centre (io_boundary_contrib :937-988), integrated into the vertex mass over dt
+ *     (steps 1 and 2), clipped to +/- 2 reference masses (the second clip, by refMass * normal.w, is written against a vertex normal
+ *     whose .w is NaN, computeVertexNormalDevice :1830: fminf / fmaxf return the other operand -- reproduced, a no-op);
+ *   - in the last step (2): the mass of the fluid particles findOutgoingSegment marked, by their share for this vertex, and one
+ *     new fluid particle of the reference mass at the vertex when it holds more than half of it, the flux is positive and the
+ *     imposed normal velocity (or, at a pressure boundary, the density) is (generate_new_particles :1101-1159, createNewFluidParticle
+ *     :73-104): appended at *newNumParticles, id nextIDs[vertex] which then advances by numOpenVertices.
+ * newPos: the caller's copy of posArray, updated in the rows of the open-boundary vertices and extended by the clones (as the
+ * other clone* arrays are: vel, gGam, eulerVel, forces, vertices, boundelement, info, hash, nextIDs have room for totParticles rows).
+ * GROUNDWORK (see above). */
+void orc_sa_vertex_bc_io(const orc_params *p, orc_f4 *velArray, const orc_f4 *posArray, orc_f4 *newPos, orc_f4 *gGamArray,
+	orc_f4 *eulerVelArray, orc_f4 *forces, uint32_t *vertices, orc_f4 *boundelement, const float *vertPos0, const float *vertPos1,
+	const float *vertPos2, orc_info *infoArray, uint32_t *hashArray, uint32_t *nextIDs, uint32_t *newNumParticles,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t totParticles,
+	float deltap, float dt, int step, uint32_t numOpenVertices)
+{
+	const float kr = (p->kerneltype == ORC_GAUSSIAN) ? 3.0f : 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	if (step == -1) step = 0;
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		if (!VERTEX(info)) continue;
+		const orc_f4 pos = posArray[index];
+		const float gam = gGamArray[index].w;
+		const int fl = FLUID_NUM(info);
+		const int io = IO_BOUNDARY(info) != 0, corner = CORNER(info) != 0;
+		const orc_f4 normal = boundelement[index];
+		const float refMass = deltap*deltap*deltap*p->rho0[fl];
+		const uint32_t my_id = orc_info_id(info);
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		float sumpWall = 0.0f, shepard_div = 0.0f, sump = 0.0f, sumMdot = 0.0f, massFluid = 0.0f;
+		float sumvel[3] = { 0.0f, 0.0f, 0.0f };
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			if (INACTIVE(npos)) continue;
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const sa_ndata n = sa_fluid_ndata(p, wcoeff, wsub, velArray, infoArray, neib_index, rx, ry, rz, npos.w);
+			if (!(n.r < p->influenceradius)) continue;
+			const float gdot = p->gravity[0]*rx + p->gravity[1]*ry + p->gravity[2]*rz;
+			sumpWall += fmaxf(n.press + physical_density(p, n.vel.w, fl)*gdot, 0.0f)*n.w;
+			shepard_div += n.w;
+			if (!io) continue;             /* io_fluid_contrib, vertices */
+			if (!corner) {
+				const orc_f4 ne = eulerVelArray[neib_index];
+				sumvel[0] += n.w*(n.vel.x + ne.x); sumvel[1] += n.w*(n.vel.y + ne.y); sumvel[2] += n.w*(n.vel.z + ne.z);
+				sump += n.w*fmaxf(0.0f, n.press);
+			}
+			if (step == 2) {               /* a particle marked by findOutgoingSegment: its mass, by this vertex's share */
+				const uint32_t *nv = vertices + 4*(size_t)neib_index;
+				if ((nv[0] | nv[1]) != 0u) {
+					const orc_f4 w = gGamArray[neib_index];
+					const float weight = nv[0] == my_id ? w.x : nv[1] == my_id ? w.y : nv[2] == my_id ? w.z : 0.0f;
+					if (weight > 0) massFluid += weight*w.w;
+				}
+			}
+		}
+		/* vertex_boundary_loop with has_io: the adjacent segments */
+		neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const uint32_t *nv = vertices + 4*(size_t)neib_index;
+			if (!has_vertex(nv, my_id)) continue;
+			if (!io || corner) continue;   /* (a corner only sums the wall normals of its solid segments, for k-epsilon) */
+			const orc_info ninfo = infoArray[neib_index];
+			if (!IO_BOUNDARY(ninfo)) continue;
+			const orc_f4 nn = boundelement[neib_index];
+			v3 vx[3];
+			calc_vertex_rel_pos(vx, v3_make(nn.x, nn.y, nn.z), vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+				vertPos2 + 2*(size_t)neib_index, -1.0f);
+			const float vrp[9] = { vx[0].x, vx[0].y, vx[0].z, vx[1].x, vx[1].y, vx[1].z, vx[2].x, vx[2].y, vx[2].z };
+			const float nrm[3] = { nn.x, nn.y, nn.z };
+			float beta[3];
+			orc_mass_repartition(vrp, nrm, beta);
+			const float weight = nv[0] == my_id ? beta[0] : nv[1] == my_id ? beta[1] : nv[2] == my_id ? beta[2] : 0.0f;
+			const orc_f4 ne = eulerVelArray[neib_index];
+			sumMdot += physical_density(p, velArray[neib_index].w, FLUID_NUM(ninfo))*nn.w*weight*(ne.x*nn.x + ne.y*nn.y + ne.z*nn.z);
+		}
+		shepard_div = fmaxf(shepard_div, 0.1f*gam);
+		velArray[index].w = orc_RHO(p, sumpWall/shepard_div, fl);
+		if (!io || corner) continue;
+		/* impose_vertex_io_bc */
+		orc_f4 eulerVel = eulerVelArray[index];
+		if (shepard_div > 0.1f*gam) {
+			sumvel[0] /= shepard_div; sumvel[1] /= shepard_div; sumvel[2] /= shepard_div;
+			sump /= shepard_div;
+			const float nrm[3] = { normal.x, normal.y, normal.z };
+			const float unInt = sumvel[0]*nrm[0] + sumvel[1]*nrm[1] + sumvel[2]*nrm[2];
+			const float unExt = eulerVel.x*nrm[0] + eulerVel.y*nrm[1] + eulerVel.z*nrm[2];
+			const float rhoInt = orc_RHO(p, sump, fl);
+			float ev[4] = { eulerVel.x, eulerVel.y, eulerVel.z, eulerVel.w };
+			orc_io_boundary_condition(p, ev, VEL_IO(info) != 0, fl, rhoInt, eulerVel.w, sumvel, unInt, unExt, nrm);
+			eulerVel.x = ev[0]; eulerVel.y = ev[1]; eulerVel.z = ev[2]; eulerVel.w = ev[3];
+		} else if (VEL_IO(info))
+			eulerVel.w = 0.0f;
+		else
+			eulerVel.x = eulerVel.y = eulerVel.z = 0.0f;
+		eulerVelArray[index] = eulerVel;
+		velArray[index].w = eulerVel.w;
+		orc_f4 np = pos;
+		const float un = normal.x*eulerVel.x + normal.y*eulerVel.y + normal.z*eulerVel.z;
+		if (step != 0) {
+			np.w += dt*sumMdot;
+			if (shepard_div < 0.1f*gam && sumMdot < 0.0f) np.w = 0.0f;
+			np.w = fmaxf(-2.0f*refMass, fminf(2.0f*refMass, np.w));
+			if (sumMdot < 0.0f || un < 1e-5f*p->sscoeff[fl]) {
+				const float weightedMass = refMass*normal.w;
+				np.w = fmaxf(-weightedMass, fminf(weightedMass, np.w));
+			}
+		}
+		if (step == 2 && np.w > refMass*0.5f && sumMdot > 0 && un > 1e-5f && (VEL_IO(info) || eulerVel.w > 1e-5f)) {
+			const uint32_t clone = (*newNumParticles)++;            /* createNewFluidParticle */
+			if (clone < totParticles) {
+				const uint32_t new_id = nextIDs[index];
+				nextIDs[index] = new_id + numOpenVertices;
+				orc_info ci;
+				ci.x = PT_FLUID; ci.y = (uint16_t)(fl << 12); ci.z = (uint16_t)(new_id & 0xFFFFu); ci.w = (uint16_t)(new_id >> 16);
+				orc_f4 cp = np;
+				cp.w = refMass;
+				massFluid -= cp.w;
+				newPos[clone] = cp;
+				infoArray[clone] = ci;
+				hashArray[clone] = hashArray[index] & CELLTYPE_BITMASK;      /* calcGridHash(gridPos): the vertex's cell */
+				velArray[clone] = eulerVel;
+				gGamArray[clone] = gGamArray[index];
+				const orc_f4 z = { 0.0f, 0.0f, 0.0f, 0.0f }, nanv = { -NAN, -NAN, -NAN, -NAN };
+				eulerVelArray[clone] = z;
+				forces[clone] = z;
+				vertices[4*(size_t)clone] = vertices[4*(size_t)clone + 1] = vertices[4*(size_t)clone + 2] = vertices[4*(size_t)clone + 3] = 0u;
+				nextIDs[clone] = UINT_MAX;
+				boundelement[clone] = nanv;
+			}
+		}
+		np.w += massFluid;
+		newPos[index] = np;
+	}
+}

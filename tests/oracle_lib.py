@@ -404,6 +404,28 @@ class Oracle:
                                          P(boundelements), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n), C.c_float(influenceradius))
         return v, g
 
+    def sa_vertex_bc_io(self, pos, vel, ggam, euler_vel, vertices, boundelements, vertpos, info, hash_, next_ids, cs, nl, n,
+                        deltap, dt, step, num_open_vertices, room=None):
+        """the vertex conditions with open boundaries enabled.  Every per-particle array is grown by `room` rows for the particles
+        the pass creates; returns a dict of the arrays after the pass and the new particle count"""
+        room = int(num_open_vertices) if room is None else int(room)
+        tot = len(pos) + room
+        def grow(a, fill=0):
+            out = np.full((tot,) + a.shape[1:], fill, dtype=a.dtype)
+            out[:len(a)] = a
+            return out
+        a = dict(vel=grow(vel), new_pos=grow(pos), ggam=grow(ggam), euler_vel=grow(euler_vel),
+                 forces=grow(np.zeros((len(pos), 4), dtype=np.float32)), vertices=grow(vertices), boundelements=grow(boundelements),
+                 info=grow(info), hash=grow(hash_), next_ids=grow(next_ids.astype(np.uint32), 0xFFFFFFFF))
+        old_pos = grow(pos)
+        newn = C.c_uint32(n)
+        self.L.orc_sa_vertex_bc_io(C.byref(self.p), P(a["vel"]), P(old_pos), P(a["new_pos"]), P(a["ggam"]), P(a["euler_vel"]),
+                                   P(a["forces"]), P(a["vertices"]), P(a["boundelements"]), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]),
+                                   P(a["info"]), P(a["hash"]), P(a["next_ids"]), C.byref(newn), P(cs), P(nl), C.c_uint32(n),
+                                   C.c_uint32(tot), C.c_float(deltap), C.c_float(dt), C.c_int(step), C.c_uint32(num_open_vertices))
+        a["n"] = int(newn.value)
+        return a
+
     def disable_outgoing_parts(self, pos, vertices, info, n):
         p2, v2 = pos.copy(), vertices.copy()
         self.L.orc_disable_outgoing_parts(P(p2), P(v2), P(info), C.c_uint32(n))

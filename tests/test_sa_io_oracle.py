@@ -324,3 +324,107 @@ def _inside(tri, x):
     n = np.cross(b - a, c - a)
     s = [np.dot(np.cross(q - p_, x - p_), n) for p_, q in ((a, b), (b, c), (c, a))]
     return min(s) >= 0 or max(s) <= 0
+
+
+def _inlet_state(st, U, flags):
+    """the x = 0 wall as an open boundary in a uniform stream U ex: arrays after corner identification, vertex normals and the
+    segment conditions of the last step"""
+    p, o = st["problem"], st["oracle"]
+    info, seg, vtx, g = _open_wall(st, flags)
+    info = o.sa_identify_corner_vertices(st["pos"], info, st["hash"], st["vertices"], st["cs"], st["nl"], st["n"])
+    be = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], info, st["hash"], st["cs"], st["nl"], st["n"])
+    vel = st["vel"].copy()
+    vel[info_type(info) == D.PT_FLUID, 0] = U
+    ev0 = np.zeros_like(vel)
+    if flags & D.FG_VELOCITY_DRIVEN:
+        ev0[seg | vtx, 0] = U
+    else:
+        ev0[seg | vtx, 3] = p.initial_density(g)[seg | vtx]
+    gg = _with_gamma(st)
+    v, gg2, ev = o.sa_segment_bc_io(st["pos"], vel, gg, ev0, st["vertices"], be, info, st["hash"], st["cs"], st["nl"], st["n"], 2)
+    return dict(info=info, seg=seg, vtx=vtx, g=g, be=be, vel=v, ggam=gg2, ev=ev)
+
+
+def test_inlet_vertices_collect_the_mass_flux_of_their_segments_and_release_particles(st):
+    p, o = st["problem"], st["oracle"]
+    dp = p.m_deltap
+    rho0 = float(p.physparams.rho0[0])
+    U, dt = 0.2, 2.0e-3
+    s = _inlet_state(st, U, D.FG_INLET | D.FG_VELOCITY_DRIVEN)
+    info, vtx, g = s["info"], s["vtx"], s["g"]
+    inner = vtx & ((info[:, 0] & D.FG_CORNER) == 0)
+    nopen = int(vtx.sum())
+    next_ids = np.full(st["n"], 0xFFFFFFFF, dtype=np.uint32)
+    next_ids[vtx] = st["n"] + np.arange(nopen, dtype=np.uint32)          # as the host hands them out
+    ref = rho0 * dp ** 3
+    # --- a step that is not the last: the masses integrate the flux, nobody is created
+    a = o.sa_vertex_bc_io(st["pos"], s["vel"], s["ggam"], s["ev"], st["vertices"], s["be"], st["vertpos"], info, st["hash"],
+                          next_ids, st["cs"], st["nl"], st["n"], dp, dt, 1, nopen)
+    assert a["n"] == st["n"]
+    gain = a["new_pos"][:st["n"], 3].astype(np.float64) - st["pos"][:, 3]
+    assert (gain[~inner] == 0).all()
+    # a vertex in the middle of the wall belongs to six triangles of area dp^2/2 and takes a third of each: rho U dp^2 per unit time
+    mid = inner & (g[:, 1] > 1.5 * dp) & (g[:, 1] < p.w - 1.5 * dp) & (g[:, 2] > 1.5 * dp) & (g[:, 2] < p.h - 1.5 * dp)
+    rho_seg = rho0 * (1.0 + np.abs(s["ev"][s["seg"], 3]).max())
+    assert mid.sum() > 20
+    assert (gain[mid] > dt * rho0 * U * dp * dp * (1 - 1e-4)).all() and (gain[mid] < dt * rho_seg * U * dp * dp * (1 + 1e-4)).all()
+    # the whole wall: the flux through the open-boundary segments, less the thirds that belong to corner vertices
+    assert 0.6 * dt * rho0 * U * p.w * p.h < gain[inner].sum() < dt * rho_seg * U * p.w * p.h
+    # the vertex takes the imposed velocity and, where the wall is wet, the fluid's density
+    assert np.allclose(a["euler_vel"][:st["n"]][inner, :3], [U, 0, 0], atol=1e-6)
+    assert np.array_equal(a["vel"][:st["n"]][inner, 3], a["euler_vel"][:st["n"]][inner, 3])
+    wet = mid & (g[:, 2] < p.water_level - 2 * dp)
+    hyd = p.initial_density(g)
+    assert np.abs(a["euler_vel"][:st["n"]][wet, 3] - hyd[wet]).max() < 0.25 * hyd[wet].max()
+    # --- the last step: a vertex that holds more than half a particle lets one go
+    b = o.sa_vertex_bc_io(st["pos"], s["vel"], s["ggam"], s["ev"], st["vertices"], s["be"], st["vertpos"], info, st["hash"],
+                          next_ids, st["cs"], st["nl"], st["n"], dp, dt, 2, nopen)
+    half = inner & (st["pos"][:, 3] + gain > 0.5 * ref)
+    assert half.sum() > 20 and b["n"] == st["n"] + int(half.sum())
+    clones = slice(st["n"], b["n"])
+    parents = np.where(half)[0]
+    # (the pass runs over the particles in order here, so the clones follow their parents' order)
+    assert np.array_equal(b["new_pos"][clones, :3], st["pos"][parents, :3]) and np.allclose(b["new_pos"][clones, 3], ref)
+    assert np.array_equal(b["vel"][clones], b["euler_vel"][:st["n"]][parents])
+    assert (info_type(b["info"][clones]) == D.PT_FLUID).all() and (b["info"][clones, 0] == D.PT_FLUID).all()
+    assert np.array_equal(info_id(b["info"][clones]), next_ids[parents])
+    assert np.array_equal(b["next_ids"][:st["n"]][parents], next_ids[parents] + nopen)
+    assert np.array_equal(b["hash"][clones], st["hash"][parents] & D.CELLTYPE_BITMASK)
+    assert (b["euler_vel"][clones] == 0).all() and (b["vertices"][clones] == 0).all() and np.isnan(b["boundelements"][clones]).all()
+    # mass: what the vertices gained from the flux went into the released particles or stayed with the vertices
+    new_m = b["new_pos"][:st["n"], 3].astype(np.float64)
+    assert abs((new_m[inner].sum() + ref * half.sum()) - (st["pos"][inner, 3].astype(np.float64).sum() + gain[inner].sum())) < 1e-6 * ref * half.sum()
+
+
+def test_outlet_vertices_take_over_the_mass_of_the_particles_that_left(st):
+    p, o = st["problem"], st["oracle"]
+    dp = p.m_deltap
+    s = _inlet_state(st, -0.2, D.FG_OUTLET)           # the stream leaves through x = 0
+    info, vtx, g = s["info"], s["vtx"], s["g"]
+    inner = vtx & ((info[:, 0] & D.FG_CORNER) == 0)
+    fl = np.where(info_type(info) == D.PT_FLUID)[0]
+    near = fl[np.abs(g[fl, 0] - dp) < 1e-6]
+    out = near[len(near) // 2]
+    pos, vel = st["pos"].copy(), s["vel"].copy()
+    pos[out, 0] -= np.float32(1.3 * dp); pos[out, 1] += np.float32(0.22 * dp); pos[out, 2] += np.float32(0.09 * dp)
+    v2, g2 = o.find_outgoing_segment(pos, vel, st["vertices"], s["ggam"], st["vertpos"], s["be"], info, st["hash"], st["cs"],
+                                     st["nl"], st["n"], float(p.simparams.influenceRadius))
+    assert (v2[out, 0] | v2[out, 1]) != 0
+    next_ids = np.full(st["n"], 0xFFFFFFFF, dtype=np.uint32)
+    kw = dict(deltap=dp, dt=1.0e-3, step=2, num_open_vertices=int(vtx.sum()))
+    a = o.sa_vertex_bc_io(pos, vel, g2, s["ev"], v2, s["be"], st["vertpos"], info, st["hash"], next_ids, st["cs"], st["nl"], st["n"], **kw)
+    b = o.sa_vertex_bc_io(pos, vel, s["ggam"], s["ev"], st["vertices"], s["be"], st["vertpos"], info, st["hash"], next_ids, st["cs"],
+                          st["nl"], st["n"], **kw)      # the same pass without the mark
+    assert a["n"] == st["n"] and b["n"] == st["n"]     # an outlet creates nobody
+    extra = a["new_pos"][:st["n"], 3].astype(np.float64) - b["new_pos"][:st["n"], 3]
+    ids = info_id(st["info"])
+    where = {int(v): k for k, v in enumerate(ids)}
+    owners = [where[int(v)] for v in v2[out, :3]]
+    w = g2[out]
+    for k, own in enumerate(owners):
+        want = float(w[k]) * float(w[3]) if inner[own] else 0.0      # corner vertices do not take part
+        assert abs(extra[own] - want) < 1e-6 * float(w[3])
+    others = np.ones(st["n"], dtype=bool); others[owners] = False
+    assert (extra[others] == 0).all()
+    if all(inner[o_] for o_ in owners):
+        assert abs(extra.sum() - float(st["pos"][out, 3])) < 1e-5 * float(st["pos"][out, 3])
