@@ -3879,3 +3879,107 @@ void orc_sa_vertex_bc_io(const orc_params *p, orc_f4 *velArray, const orc_f4 *po
 		newPos[index] = np;
 	}
 }
+
+/* densitySumVolumicDevice + densitySumBoundaryDevice with ENABLE_INLET_OUTLET (src/cuda/density_sum_kernel.cu:119-140, 206-250,
+ * 374-420, 606-655): orc_sa_density_sum with the open boundaries' terms.  The particles of an open boundary (its vertices, in the
+ * volumic sums; its segments, in the gamma sums) count as if they had moved with their Eulerian velocity over the step: they are
+ * left out of -sum m W(r^n), and -sum m W(|r^n + dt (u_E - u)|) takes their place (sumVmwDelta); the gamma the old density is
+ * weighted with is advanced by the same virtual displacement through the open segments only (compute_imposed_gamma), clipped
+ * to [0.1, 1].  A stream that crosses an inlet at the inlet's Eulerian velocity therefore sees neither the inlet's vertices nor
+ * the change of its gamma.  GROUNDWORK (see above). */
+void orc_sa_density_sum_io(const orc_params *p, orc_f4 *newVel, orc_f4 *newGGam, orc_f4 *forces,
+	const orc_f4 *oldPos, const orc_f4 *newPos, const orc_f4 *oldVel, const orc_f4 *oldEulerVel, const orc_f4 *oldGGam,
+	const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2, const orc_info *infoArray,
+	const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd, float dt)
+{
+	const float kr = 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const float slength = p->slength;
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!FLUID(info)) {
+			if (VERTEX(info) || BOUNDARY(info)) newGGam[index] = oldGGam[index];
+			continue;
+		}
+		const orc_f4 posN = oldPos[index], posNp1 = newPos[index];
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
+		float sumPmwN = 0.0f, sumPmwNp1 = 0.0f, sumVmwDelta = 0.0f;
+		for (int nptype = PT_FLUID; nptype <= PT_VERTEX; nptype += 2) {
+			neib_iter it;
+			uint32_t neib_index;
+			neib_iter_init(&it, p, nptype, index, &posN, gridPos, cellStart, neibsList);
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 nN = oldPos[neib_index];
+				if (INACTIVE(nN)) continue;
+				const orc_info ninfo = infoArray[neib_index];
+				const orc_f4 nNp1 = newPos[neib_index];
+				const float rx = it.pos_corr[0] - nN.x, ry = it.pos_corr[1] - nN.y, rz = it.pos_corr[2] - nN.z;
+				const float qx = (it.pos_corr[0] - nNp1.x) + dx, qy = (it.pos_corr[1] - nNp1.y) + dy, qz = (it.pos_corr[2] - nNp1.z) + dz;
+				if (!IO_BOUNDARY(ninfo)) {
+					const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+					sumPmwN -= nN.w*W_c(p->kerneltype, rN, slength, wcoeff, wsub);
+				}
+				const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
+				if (rNp1 < p->influenceradius)
+					sumPmwNp1 += nN.w*W_c(p->kerneltype, rNp1, slength, wcoeff, wsub);
+				if (IO_BOUNDARY(ninfo)) {      /* densitySumOpenBoundaryContribution */
+					const orc_f4 e = oldEulerVel[neib_index], v = oldVel[neib_index];
+					const float ex = rx + dt*(e.x - v.x), ey = ry + dt*(e.y - v.y), ez = rz + dt*(e.z - v.z);
+					const float newDist = sqrtf(ex*ex + ey*ey + ez*ez);
+					if (newDist < p->influenceradius)
+						sumVmwDelta -= nN.w*W_c(p->kerneltype, newDist, slength, wcoeff, wsub);
+				}
+			}
+		}
+		forces[index].w = sumPmwNp1 + sumPmwN + sumVmwDelta;
+		float gGamDotR = 0.0f, sumSgamDelta = 0.0f, sumSgamN = 0.0f;
+		v3 gGam = v3_make(0.0f, 0.0f, 0.0f);
+		{
+			neib_iter it;
+			uint32_t neib_index;
+			neib_iter_init(&it, p, PT_BOUNDARY, index, &posN, gridPos, cellStart, neibsList);
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 nN = oldPos[neib_index];
+				if (INACTIVE(nN)) continue;
+				const orc_f4 nNp1 = newPos[neib_index];
+				const float inv = 1.0f/slength;
+				const v3 qN = v3_make((it.pos_corr[0] - nN.x)*inv, (it.pos_corr[1] - nN.y)*inv, (it.pos_corr[2] - nN.z)*inv);
+				const v3 qNp1 = v3_make(((it.pos_corr[0] - nNp1.x) + dx)*inv, ((it.pos_corr[1] - nNp1.y) + dy)*inv,
+					((it.pos_corr[2] - nNp1.z) + dz)*inv);
+				const orc_f4 be = boundelem[neib_index];
+				const v3 ns = v3_make(be.x, be.y, be.z);
+				v3 q_vb[3];
+				calc_vertex_rel_pos(q_vb, ns, vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+					vertPos2 + 2*(size_t)neib_index, slength);
+				const v3 gN = v3_scale(ns, grad_gamma_wendland(slength, qN, q_vb, ns));
+				const v3 gNp1 = v3_scale(ns, grad_gamma_wendland(slength, qNp1, q_vb, ns));
+				gGamDotR += 0.5f*v3_dot(v3_add(gN, gNp1), v3_sub(qNp1, qN));
+				gGam = v3_add(gGam, gNp1);
+				if (IO_BOUNDARY(infoArray[neib_index])) {      /* io_gamma_contrib */
+					const orc_f4 e = oldEulerVel[neib_index], v = oldVel[neib_index];
+					const v3 deltaR = v3_make(dt*(e.x - v.x), dt*(e.y - v.y), dt*(e.z - v.z));
+					const v3 qDelta = v3_add(qN, v3_divs(deltaR, slength));
+					const v3 gDelta = v3_scale(ns, grad_gamma_wendland(slength, qDelta, q_vb, ns));
+					sumSgamDelta += v3_dot(deltaR, gDelta);
+					sumSgamN += v3_dot(deltaR, gN);
+				}
+			}
+			gGamDotR *= slength;
+		}
+		const orc_f4 gGamN = oldGGam[index];
+		orc_f4 g = { gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR };
+		float imposedGam = gGamN.w + (sumSgamDelta + sumSgamN)/2.0f;      /* compute_imposed_gamma */
+		if (imposedGam > 1.0f) imposedGam = 1.0f;
+		else if (imposedGam < 0.1f) imposedGam = 0.1f;
+		const int fl = FLUID_NUM(info);
+		const float rho = (imposedGam*physical_density(p, oldVel[index].w, fl) + forces[index].w)/g.w;
+		if (g.w > 1.0f || sqrtf(g.x*g.x + g.y*g.y + g.z*g.z)*slength < 1e-10f)
+			g.w = 1.0f;
+		else if (g.w < 0.1f)
+			g.w = 0.1f;
+		newVel[index].w = rho/p->rho0[fl] - 1.0f;
+		newGGam[index] = g;
+	}
+}

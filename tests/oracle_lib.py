@@ -426,6 +426,16 @@ class Oracle:
         a["n"] = int(newn.value)
         return a
 
+    def sa_density_sum_io(self, new_vel, old_pos, new_pos, old_vel, old_euler_vel, old_ggam, boundelements, vertpos, info, hash_,
+                          cs, nl, n, dt):
+        """density_sum with open boundaries enabled: (new_vel, gamma, the volumic sums in forces.w)"""
+        v = new_vel.copy(); g = old_ggam.copy()
+        scratch = np.zeros((len(old_pos), 4), dtype=np.float32)
+        self.L.orc_sa_density_sum_io(C.byref(self.p), P(v), P(g), P(scratch), P(old_pos), P(new_pos), P(old_vel), P(old_euler_vel),
+                                     P(old_ggam), P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(info), P(hash_),
+                                     P(cs), P(nl), C.c_uint32(n), C.c_float(dt))
+        return v, g, scratch[:, 3].copy()
+
     def disable_outgoing_parts(self, pos, vertices, info, n):
         p2, v2 = pos.copy(), vertices.copy()
         self.L.orc_disable_outgoing_parts(P(p2), P(v2), P(info), C.c_uint32(n))
