@@ -38,6 +38,7 @@ enum { PT_FLUID = 0, PT_BOUNDARY, PT_VERTEX, PT_TESTPOINT, PT_NONE };
 #define FLUID(f)             (PART_TYPE(f) == PT_FLUID)
 #define BOUNDARY(f)          (PART_TYPE(f) == PT_BOUNDARY)
 #define VERTEX(f)            (PART_TYPE(f) == PT_VERTEX)
+#define IO_BOUNDARY_X(f)     ((f).x & ((PART_FLAG_START << 2) | (PART_FLAG_START << 3)))   /* IO_BOUNDARY, defined with its section below */
 #define TESTPOINT(f)         (PART_TYPE(f) == PT_TESTPOINT)
 #define MOVING(f)            ((f).x & FG_MOVING_BOUNDARY)
 #define FLOATING(f)          ((f).x & (FG_MOVING_BOUNDARY | FG_COMPUTE_FORCE))
@@ -791,6 +792,9 @@ typedef struct {
 	float deltap;
 	float *gammaCfl;      /* per particle max of |grad gamma_as| |n.v| (dynamic gamma + ENABLE_DTADAPT), or NULL */
 	const sa_keps_ctx *ke;
+	/* ENABLE_INLET_OUTLET without k-epsilon (GROUNDWORK, see "Open boundaries" at the end of the file): BUFFER_EULERVEL, or NULL.
+	 * Every use below is behind `io`, so that the passes without open boundaries are the instructions they were */
+	const orc_f4 *ioEulerVel;
 } sa_forces_ctx;
 static inline void keps_add_strain(float *t, float vx, float vy, float vz, float mx, float my, float mz)
 {	/* keps_particle_output::add_strain_rate :924-937 */
@@ -836,6 +840,7 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 		/* SPH_HA (Hu & Adams): precalc = P (:458-468), volumes V = m/rho in the pressure term, own mass in the continuity equation */
 		const int ha = p->sph_formulation == ORC_SPH_HA;
 		const sa_keps_ctx *ke = sa ? sa->ke : NULL;
+		const int io = sa && sa->ioEulerVel != NULL && !ke;
 		/* pressure_for_precalc with KEPSILON :389-401: P + 2/3 k/rho */
 		const float p_precalc = ke ? (orc_P(p, vel.w, p_fluid) + 2.0f*ke->tke[index]/p_rho/3.0f)/(p_rho*p_rho) :
 			(f2 || ha) ? orc_P(p, vel.w, p_fluid) : orc_P(p, vel.w, p_fluid)/(p_rho*p_rho);
@@ -883,6 +888,9 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 			if (ke) {
 				const orc_f4 ne = ke->eulerVel[neib_index];
 				wx = vx + (p_euler.x - ne.x); wy = vy + (p_euler.y - ne.y); wz = vz + (p_euler.z - ne.z);
+			} else if (io && cptype != nptype) {      /* eulerVel_neib_data exists for cptype != nptype only (:1183-1185) */
+				const orc_f4 pe = sa->ioEulerVel[index], ne = sa->ioEulerVel[neib_index];
+				wx = vx + (pe.x - ne.x); wy = vy + (pe.y - ne.y); wz = vz + (pe.z - ne.z);
 			}
 
 			float DvDt[3] = {0.0f, 0.0f, 0.0f};
@@ -906,6 +914,12 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 					const float va = dot3(vel.x, vel.y, vel.z, belem.x, belem.y, belem.z);
 					const float vs = dot3(vel.x - vx, vel.y - vy, vel.z - vz, belem.x, belem.y, belem.z);
 					sa->gammaCfl[index] = fmaxf(sa->gammaCfl[index], ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
+					if (io) {           /* compute_gamma_cfl_open_boundary :1485-1497: n.(v_a + relEulerVel), n.(v_s - relEulerVel) */
+						const float ex = wx - vx, ey = wy - vy, ez = wz - vz;      /* relEulerVel */
+						const float a1 = dot3(vel.x + ex, vel.y + ey, vel.z + ez, belem.x, belem.y, belem.z);
+						const float a2 = dot3(-vx + vel.x - ex, -vy + vel.y - ey, -vz + vel.z - ez, belem.x, belem.y, belem.z);
+						sa->gammaCfl[index] = fmaxf(sa->gammaCfl[index], ggamAS*fmaxf(fabsf(a1), fabsf(a2)));
+					}
 				}
 				if (!(p->simflags & ORC_ENABLE_DENSITY_SUM)) {
 					DrDt -= p_rho*vn*ggamAS;
@@ -953,7 +967,11 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 				/* compute_laminar_visc_contrib, boundary term :2680-2718 (MORRIS, no k-epsilon, no open boundaries) */
 				if (p->rheologytype == ORC_NEWTONIAN) {
 					const float r_as = fmaxf(fabsf(dot3(rx, ry, rz, belem.x, belem.y, belem.z)), sa->deltap);   /* sa_boundary_neib_data :1132-1150 */
-					const float vt[3] = { vx - vn*belem.x, vy - vn*belem.y, vz - vn*belem.z };
+					float vt[3] = { vx - vn*belem.x, vy - vn*belem.y, vz - vn*belem.z };
+					if (io) {           /* :2703-2708: relVel + relEulerVel; against an open-boundary segment the whole of it, not the tangential part */
+						const float wn = IO_BOUNDARY_X(neib_info) ? 0.0f : dot3(wx, wy, wz, belem.x, belem.y, belem.z);
+						vt[0] = wx - wn*belem.x; vt[1] = wy - wn*belem.y; vt[2] = wz - wn*belem.z;
+					}
 					/* get_laminar_dyn_visc :322-340 */
 					const float our_mu = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[p_fluid]*p_rho : p->visccoeff[p_fluid];
 					const float neib_mu = (p->compvisc == ORC_KINEMATIC) ? p->visccoeff[n_fluid]*n_rho : p->visccoeff[n_fluid];
@@ -1125,6 +1143,8 @@ static void forces_pass(const orc_params *p, int cptype, int nptype, orc_f4 *for
 						const float den = dot3(rx, ry, rz, rx, ry, rz) + p->epsartvisc;
 						const float c = vel_dot_pos < 0 ? p->monaghan_visc_coeff*vel_dot_pos/den : 0.0f;
 						DvDt[0] += vf*(c*rx); DvDt[1] += vf*(c*ry); DvDt[2] += vf*(c*rz);
+					} else if (io) {      /* get_viscous_relVel :2494-2507 */
+						DvDt[0] += vf*wx; DvDt[1] += vf*wy; DvDt[2] += vf*wz;
 					} else {
 						DvDt[0] += vf*vx; DvDt[1] += vf*vy; DvDt[2] += vf*vz;
 					}
@@ -1374,17 +1394,17 @@ uint32_t orc_forces(const orc_params *p, orc_f4 *forces, float *cfl,
 /* run_forces with SA_BOUNDARY (solid walls, no k-epsilon, no moving bodies): fluid <- fluid, fluid <- vertex, then
  * fluid <- boundary element (the launch order of src/cuda/forces.cu:751-790; vertex particles skip their own neighbour
  * walk, skip_neiblist :1346-1358), then the finalize with the division by gamma */
-uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *cflGamma,
+static uint32_t forces_sa_impl(const orc_params *p, orc_f4 *forces, float *cfl, float *cflGamma,
 	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
 	const orc_f4 *gGam, const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2,
-	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, float deltap)
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, float deltap, const orc_f4 *ioEulerVel)
 {
 	/* cflGamma: BUFFER_CFL_GAMMA in the reference's layout -- one value per particle, then, from round_up(numParticles, 4)
 	 * on, one value per block (src/cuda/forces.cu:576-581); used with dynamic gamma and ENABLE_DTADAPT only */
 	const int gcfl = cflGamma && !(p->simflags & ORC_ENABLE_GAMMA_QUADRATURE) && (p->simflags & ORC_ENABLE_DTADAPT);
 	if (gcfl) memset(cflGamma + fromParticle, 0, sizeof(float)*(toParticle - fromParticle));
-	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL, NULL };
+	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL, NULL, ioEulerVel };
 	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
 	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
 	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
@@ -1403,6 +1423,28 @@ uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *c
 	}
 	return numBlocks;
 }
+uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *cflGamma,
+	const orc_f4 *pos, const orc_f4 *vel, const orc_info *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	const orc_f4 *gGam, const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, float deltap)
+{
+	return forces_sa_impl(p, forces, cfl, cflGamma, pos, vel, info, hash, cellStart, neibsList, gGam, boundelem, vertPos0, vertPos1,
+		vertPos2, numParticles, fromParticle, toParticle, cflOffset, deltap, NULL);
+}
+/* the same three launches with ENABLE_INLET_OUTLET (laminar): the viscous terms see the Eulerian velocity of the open boundaries'
+ * vertices and segments (get_viscous_relVel :2494-2507; against an open segment the whole relative velocity, :2703-2708), the
+ * gamma CFL condition their normal velocity (:1485-1497).  GROUNDWORK ("Open boundaries" at the end of the file); not restated:
+ * the forces pass of the pressure-driven open vertices (skip_neiblist :1375-1389), the water depth (:192-205, 3285-3330) */
+uint32_t orc_forces_sa_io(const orc_params *p, orc_f4 *forces, float *cfl, float *cflGamma,
+	const orc_f4 *pos, const orc_f4 *vel, const orc_f4 *eulerVel, const orc_info *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList,
+	const orc_f4 *gGam, const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, uint32_t cflOffset, float deltap)
+{
+	return forces_sa_impl(p, forces, cfl, cflGamma, pos, vel, info, hash, cellStart, neibsList, gGam, boundelem, vertPos0, vertPos1,
+		vertPos2, numParticles, fromParticle, toParticle, cflOffset, deltap, eulerVel);
+}
 
 /* run_forces with SA_BOUNDARY and the k-epsilon model (solid walls): the three fluid launches of orc_forces_sa with the keps members,
  * then forcesDevice<PT_VERTEX, PT_FLUID> (vertex_forces, src/cuda/forces.cu:676-686), whose viscous term is computed into nout and
@@ -1419,7 +1461,7 @@ uint32_t orc_forces_sa_keps(const orc_params *p, orc_f4 *forces, float *cfl, flo
 	const int gcfl = cflGamma && !(p->simflags & ORC_ENABLE_GAMMA_QUADRATURE) && (p->simflags & ORC_ENABLE_DTADAPT);
 	if (gcfl) memset(cflGamma + fromParticle, 0, sizeof(float)*(toParticle - fromParticle));
 	const sa_keps_ctx ke = { tke, eps, turbvisc, eulerVel, dkde, strain, cflKeps, epsilon };
-	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL, &ke };
+	const sa_forces_ctx sa = { gGam, boundelem, { vertPos0, vertPos1, vertPos2 }, deltap, gcfl ? cflGamma : NULL, &ke, NULL };
 	const uint32_t numBlocks = round_up(div_up(toParticle - fromParticle, BLOCK_SIZE_FORCES), 4u);
 	forces_pass(p, PT_FLUID, PT_FLUID, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);
 	forces_pass(p, PT_FLUID, PT_VERTEX, forces, pos, vel, info, hash, cellStart, neibsList, NULL, fromParticle, toParticle, &sa, NULL);

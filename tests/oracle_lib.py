@@ -304,6 +304,19 @@ class Oracle:
         self.max_gamma_cfl = float(self.cfl_gamma[((n + 3) // 4) * 4:((n + 3) // 4) * 4 + int(nb)].max()) if nb else 0.0
         return forces, cfl, int(nb)
 
+    def forces_sa_io(self, pos, vel, euler_vel, info, hash_, cs, nl, ggam, boundelements, vertpos, n, deltap):
+        """forces_sa with open boundaries enabled (oracle groundwork): the viscous terms and the gamma CFL see BUFFER_EULERVEL"""
+        forces = np.zeros((len(pos), 4), dtype=np.float32)
+        nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))
+        cfl = np.zeros(nblk, dtype=np.float32)
+        self.cfl_gamma = np.zeros(((n + 3) // 4) * 4 + nblk, dtype=np.float32)
+        self.L.orc_forces_sa_io.restype = C.c_uint32
+        nb = self.L.orc_forces_sa_io(C.byref(self.p), P(forces), P(cfl), P(self.cfl_gamma), P(pos), P(vel), P(euler_vel), P(info), P(hash_),
+                                     P(cs), P(nl), P(ggam), P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), C.c_uint32(n),
+                                     C.c_uint32(0), C.c_uint32(n), C.c_uint32(0), C.c_float(deltap))
+        self.max_gamma_cfl = float(self.cfl_gamma[((n + 3) // 4) * 4:((n + 3) // 4) * 4 + int(nb)].max()) if nb else 0.0
+        return forces, cfl, int(nb)
+
     def repack_forces_sa(self, pos, vel, info, hash_, cs, nl, ggam, boundelements, vertpos, n, deltap):
         forces = np.zeros((len(pos), 4), dtype=np.float32)
         nblk = int(self.L.orc_fmax_elements(C.c_uint32(len(pos))))

@@ -483,3 +483,34 @@ def test_a_stream_entering_at_the_inlets_own_velocity_does_not_see_the_inlet(st)
     # neighbourhood, and gamma is advanced on both sides of the quotient (imposed gamma = new gamma when only the inlet is in reach)
     assert np.abs(v[near, 3] - s["vel"][near, 3]).max() < 2e-4
     assert np.abs(v_plain[near, 3] - s["vel"][near, 3]).max() > 5 * np.abs(v[near, 3] - s["vel"][near, 3]).max()
+
+
+def test_viscous_terms_see_the_eulerian_velocity_of_an_open_boundary(st):
+    """A stream at U next to an inlet whose Eulerian velocity is U is not braked by it; next to a solid wall it is.  (The forces
+    pass of the pressure-driven open vertices and the water depth are not restated.)"""
+    p, o = st["problem"], st["oracle"]
+    dp = p.m_deltap
+    U = 0.2
+    s = _stream_state(st, U, 1e-3)
+    n = st["n"]
+    common = (st["hash"], st["cs"], st["nl"], s["gg"], s["be"], st["vertpos"], n, dp)
+    f_plain, _, _ = o.forces_sa(st["pos"], s["vel"], st["info"], *common)
+    # open boundaries enabled but none flagged, stale Eulerian velocities cleared: the plain pass
+    f_none, _, _ = o.forces_sa_io(st["pos"], s["vel"], np.zeros_like(s["vel"]), st["info"], *common)
+    assert np.array_equal(f_plain, f_none)
+    f_io, _, _ = o.forces_sa_io(st["pos"], s["vel"], s["ev"], s["info"], *common)
+    g, fl = s["g"], s["fl"]
+    near = fl & (np.abs(g[:, 0] - dp) < 1e-6) & (g[:, 2] < p.water_level - 2 * dp) & (g[:, 2] > 2.5 * dp) \
+        & (g[:, 1] > 2.5 * dp) & (g[:, 1] < p.w - 2.5 * dp)
+    far = fl & (g[:, 0] > 0.3) & (g[:, 0] < p.l - 0.3)
+    assert near.sum() >= 8 and far.sum() > 10
+    assert np.array_equal(f_io[far], f_plain[far])             # out of reach of the inlet nothing changes
+    # the wall at x = 0 as a solid wall brakes the layer next to it (the relative velocity is U); as an inlet moving with the
+    # stream it does not: the x component of the two passes differs by that viscous force, and with the inlet it is the
+    # pressure gradient alone, the same as for a fluid at rest next to a solid wall
+    rest = s["vel"].copy(); rest[fl, 0] = 0.0
+    f_rest, _, _ = o.forces_sa(st["pos"], rest, st["info"], *common)
+    brake = f_plain[near, 0] - f_rest[near, 0]
+    assert (brake < 0).all()
+    assert np.abs(f_io[near, 0] - f_rest[near, 0]).max() < 0.02 * np.abs(brake).max()
+    assert np.allclose(f_io[near, 1:3], f_rest[near, 1:3], atol=1e-3 * np.abs(f_rest[near, 1:3]).max())
