@@ -2654,7 +2654,7 @@ static inline int has_vertex(const uint32_t *verts, uint32_t id)   /* src/partic
 	return verts[0] == id || verts[1] == id || verts[2] == id;
 }
 
-/* computeVertexNormalDevice, :1766-1831 (no open boundaries: every adjacent segment contributes) */
+/* computeVertexNormalDevice, :1766-1831 */
 void orc_sa_compute_vertex_normal(const orc_params *p, orc_f4 *boundelement, const uint32_t *vertices,
 	const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t particleRangeEnd)
@@ -2672,6 +2672,9 @@ void orc_sa_compute_vertex_normal(const orc_params *p, orc_f4 *boundelement, con
 		neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
 		uint32_t neib_index;
 		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			/* :1813-1814: a vertex of an open boundary averages over that boundary's segments, any other vertex over the solid
+			 * ones (no open-boundary flags anywhere: every adjacent segment, as before) */
+			if (!IO_BOUNDARY_X(info) != !IO_BOUNDARY_X(infoArray[neib_index])) continue;
 			if (!has_vertex(vertices + 4*(size_t)neib_index, our_id)) continue;
 			const orc_f4 be = boundelement[neib_index];
 			avg[0] += be.x*be.w; avg[1] += be.y*be.w; avg[2] += be.z*be.w;

@@ -2,7 +2,7 @@
 import numpy as np
 
 from gpusph_amd import defs as D
-from gpusph_amd.problem import SABox
+from gpusph_amd.problem import SABox, info_id, info_type
 from oracle_lib import Oracle, orc_params_from
 
 
@@ -228,6 +228,159 @@ class OracleSaSim:
         vn, gn = self._bc(pn, vn, gn, 2)
         self.forces = f2
         self.pos, self.vel, self.gg = pn, vn, gn
+        self.t += dt
+        self.dt = min(dt1, dt2)
+        self.iterations += 1
+
+
+class OracleSaIoSim:
+    """An open channel on the CPU oracle: an SABox (density summation form) whose x = 0 wall is a velocity inlet (u_E = U ex) and
+    whose x = l wall is a pressure outlet (hydrostatic for the still water level), the command sequence of
+    PredictorCorrectorIntegrator.cc with ENABLE_INLET_OUTLET (:127-300 the boundary-condition phases, :386-685 the step), a
+    neighbour-list rebuild before every step as the reference's ChannelIO does (src/problems/ChannelIO.cu:63) -- the particles an
+    inlet vertex releases exist from the next rebuild on -- and the imposed values of that problem's callback (:104-131).
+    GROUNDWORK: the checker of engines that are not built yet; nothing in the product mirrors it."""
+
+    def __init__(self, problem, U, room=1.6):
+        self.problem, self.U = problem, float(U)
+        p = problem
+        a = p.copy_to_array()
+        n0 = p.num_particles
+        self.cap = cap = int(n0 * room)
+        self.o = o = Oracle(orc_params_from(p.sphx_params(cap), p))
+        # open boundaries: flags and object numbers on the unsorted arrays (global positions known)
+        g = p.global_pos(a["pos"], a["hash"])
+        t = info_type(a["info"])
+        wall = (t == D.PT_BOUNDARY) | (t == D.PT_VERTEX)
+        nrm = a["boundelements"]
+        inlet = wall & (np.abs(g[:, 0]) < 1e-6) & ((t == D.PT_VERTEX) | (nrm[:, 0] > 0.5))
+        outlet = wall & (np.abs(g[:, 0] - p.l) < 1e-6) & ((t == D.PT_VERTEX) | (nrm[:, 0] < -0.5))
+        info = a["info"].copy()
+        info[inlet, 0] |= D.FG_INLET | D.FG_VELOCITY_DRIVEN
+        info[inlet, 1] = (info[inlet, 1] & 0xF000) | 1
+        info[outlet, 0] |= D.FG_OUTLET
+        info[outlet, 1] = (info[outlet, 1] & 0xF000) | 2
+        self.num_open_vertices = int(((inlet | outlet) & (t == D.PT_VERTEX)).sum())
+
+        def pad(x, fill):
+            out = np.full((cap,) + x.shape[1:], fill, dtype=x.dtype)
+            out[:n0] = x
+            return out
+        self.pos = pad(a["pos"], np.nan)                       # unused rows: inactive particles, sorted behind the active ones
+        vel = a["vel"].copy()
+        vel[t == D.PT_FLUID, 0] = self.U                       # the stream is there from the start
+        self.vel = pad(vel, 0)
+        self.info = pad(info, 0)
+        self.hash = pad(a["hash"], D.CELL_HASH_MAX)
+        self.vertices = pad(a["vertices"], 0)
+        self.be = pad(a["boundelements"], np.nan)
+        self.gg = pad(a["gradgamma"], np.nan)
+        self.ev = np.zeros((cap, 4), dtype=np.float32)
+        ids = info_id(info)
+        nid = np.full(n0, 0xFFFFFFFF, dtype=np.uint32)
+        openv = (inlet | outlet) & (t == D.PT_VERTEX)
+        nid[openv] = int(ids.max()) + 1 + np.arange(int(openv.sum()), dtype=np.uint32)      # GPUSPH hands out ids past the last one
+        self.next_ids = pad(nid, 0xFFFFFFFF)
+        self.n = n0
+        self.t, self.iterations = 0.0, 0
+        self.dt = float(np.float32(p.simparams.dt))
+        pp, sp = p.physparams, p.simparams
+        self.sspeed_cfl = float(np.float32(np.float64(np.float32(max(pp.sscoeff))) * 1.1))
+        self.max_kinvisc = float(np.float32(max(pp.kinematicvisc))) if sp.rheologytype == D.NEWTONIAN else 0.0
+        f32 = np.float32
+        self.sqinfl = float(f32(sp.nlSqInfluenceRadius))
+        self.bound_sqinfl = float(np.power(f32(np.sqrt(f32(sp.nlSqInfluenceRadius))) + f32(sp.slength) / f32(sp.sfactor) / f32(2.0), f32(2.0), dtype=f32))
+        self.created = self.removed = 0
+        # --- initialisation (initializeBoundaryConditionsSequence<SA_BOUNDARY>, init_step)
+        self._rebuild()
+        o, n = self.o, self.n
+        A = (self.hash, self.cs, self.nl)
+        self.be = o.sa_compute_vertex_normal(self.be, self.vertices, self.info, *A, n)
+        self.gg = o.sa_init_gamma(self.gg, self.pos, self.be, self.vertpos, self.info, *A, n, p.m_deltap)
+        self.info = o.sa_identify_corner_vertices(self.pos, self.info, self.hash, self.vertices, self.cs, self.nl, n)
+        _, self.pos = o.sa_init_io_mass(self.pos, self.info, self.hash, self.vertices, self.cs, self.nl, n, p.m_deltap)
+        self.vel, self.ev = self._impose(self.pos, self.vel, self.ev)
+        self.vel, self.gg, self.ev = o.sa_segment_bc_io(self.pos, self.vel, self.gg, self.ev, self.vertices, self.be, self.info, *A, n, 0)
+        self._vertex_bc(self.pos, self.vel, self.gg, self.ev, self.vertices, 0.0, 0)
+
+    # ChannelIO_imposeBoundaryCondition (src/problems/ChannelIO.cu:104-131): the Lagrangian velocity of the open boundaries'
+    # particles is cleared, a velocity boundary gets u_E = U ex, a pressure boundary the density of the hydrostatic pressure
+    def _impose(self, pos, vel, ev):
+        p = self.problem
+        n = self.n
+        io = (self.info[:n, 0] & (D.FG_INLET | D.FG_OUTLET)) != 0
+        vdriven = (self.info[:n, 0] & D.FG_VELOCITY_DRIVEN) != 0
+        vel, ev = vel.copy(), ev.copy()
+        vel[:n][io] = 0.0
+        ev[:n][io] = 0.0
+        rows = np.where(io & vdriven)[0]
+        ev[rows, 0] = np.float32(self.U)
+        rows = np.where(io & ~vdriven)[0]
+        z = p.global_pos(pos[:n], self.hash[:n])[rows, 2]
+        pres = np.float32(9.81) * np.maximum(np.float32(p.water_level) - z.astype(np.float32), np.float32(0)) * np.float32(p.physparams.rho0[0])
+        ev[rows, 3] = [self.o.eos_RHO(float(x)) for x in pres]
+        return vel, ev
+
+    def _rebuild(self):
+        o = self.o
+        self.pos[self.n:] = np.nan          # rows behind the particles in use: inactive (Euler and the reorder leave them cleared)
+        pidx = o.fix_hash(self.hash, self.info) if self.iterations == 0 else o.calc_hash(self.pos, self.hash, self.info)
+        o.sort(self.hash, self.info, pidx)
+        self.cs, self.ce, _, self.pos, self.vel, self.n = o.reorder(self.pos, self.vel, self.info, self.hash, pidx,
+                                                                    self.problem.grid_cells, segments=False)
+        for name in ("vertices", "be", "gg", "ev", "next_ids"):
+            setattr(self, name, np.ascontiguousarray(getattr(self, name)[pidx]))
+        n = self.n
+        self.nl, self.vertpos, self.neibs_info = o.build_neibs_sa(self.pos, self.info, self.vertices, self.be, self.hash, self.cs,
+                                                                  self.ce, n, n, self.sqinfl, self.bound_sqinfl)
+        assert self.neibs_info.hasTooManyNeibs == -1
+
+    def _vertex_bc(self, pos, vel, gg, ev, vertices, dt, step):
+        """SA_CALC_VERTEX_BOUNDARY_CONDITIONS on the given state; the arrays it may extend (last step) become the sim's"""
+        a = self.o.sa_vertex_bc_io(pos, vel, gg, ev, vertices, self.be, self.vertpos, self.info, self.hash, self.next_ids, self.cs,
+                                   self.nl, self.n, self.problem.m_deltap, dt, step, self.num_open_vertices, room=0)
+        if step == 2:
+            self.created += a["n"] - self.n
+            self.info, self.hash, self.next_ids, self.be = a["info"], a["hash"], a["next_ids"], a["boundelements"]
+        return a
+
+    def _dtmin(self, cfl, nb):
+        dt = self.o.dtreduce(cfl, nb, self.sspeed_cfl, self.max_kinvisc)
+        return min(dt, float(self.o.L.orc_sa_gamma_dt(np.float32(dt), np.float32(self.o.max_gamma_cfl))))
+
+    def step(self):
+        o, p = self.o, self.problem
+        dp = p.m_deltap
+        if self.iterations > 0:
+            self._rebuild()
+        n = self.n
+        A = (self.hash, self.cs, self.nl)
+        dt = float(np.float32(self.dt)); hdt = float(np.float32(dt) / np.float32(2))
+        infl = float(p.simparams.influenceRadius)
+        # predictor
+        f1, cfl, nb = o.forces_sa_io(self.pos, self.vel, self.ev, self.info, *A, self.gg, self.be, self.vertpos, n, dp)
+        dt1 = self._dtmin(cfl, nb)
+        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, hdt, 1)
+        vs, gs, _ = o.sa_density_sum_io(vs, self.pos, ps, self.vel, self.ev, self.gg, self.be, self.vertpos, self.info, *A, n, hdt)
+        vs, evs = self._impose(ps, vs, self.ev)
+        vs, gs, evs = o.sa_segment_bc_io(ps, vs, gs, evs, self.vertices, self.be, self.info, *A, n, 1)
+        a = self._vertex_bc(ps, vs, gs, evs, self.vertices, hdt, 1)
+        ps, vs, evs = a["new_pos"], a["vel"], a["euler_vel"]
+        # corrector
+        f2, cfl, nb = o.forces_sa_io(ps, vs, evs, self.info, *A, gs, self.be, self.vertpos, n, dp)
+        dt2 = self._dtmin(cfl, nb)
+        pn, vn = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
+        vn, gn, _ = o.sa_density_sum_io(vn, self.pos, pn, self.vel, self.ev, self.gg, self.be, self.vertpos, self.info, *A, n, dt)
+        vn, evn = self._impose(pn, vn, self.ev)
+        vn, gn, evn = o.sa_segment_bc_io(pn, vn, gn, evn, self.vertices, self.be, self.info, *A, n, 2)
+        vert2, gn = o.find_outgoing_segment(pn, vn, self.vertices, gn, self.vertpos, self.be, self.info, *A, n, infl)
+        a = self._vertex_bc(pn, vn, gn, evn, vert2, dt, 2)
+        n2 = a["n"]
+        pn, vert3 = o.disable_outgoing_parts(a["new_pos"], a["vertices"], self.info, n2)
+        self.removed += int(np.isnan(pn[:n2, 3]).sum() - np.isnan(a["new_pos"][:n2, 3]).sum())
+        self.pos, self.vel, self.gg, self.ev, self.vertices = pn, a["vel"], a["ggam"], a["euler_vel"], vert3
+        self.forces = f2
+        self.n = n2
         self.t += dt
         self.dt = min(dt1, dt2)
         self.iterations += 1

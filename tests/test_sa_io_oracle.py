@@ -514,3 +514,44 @@ def test_viscous_terms_see_the_eulerian_velocity_of_an_open_boundary(st):
     assert (brake < 0).all()
     assert np.abs(f_io[near, 0] - f_rest[near, 0]).max() < 0.02 * np.abs(brake).max()
     assert np.allclose(f_io[near, 1:3], f_rest[near, 1:3], atol=1e-3 * np.abs(f_rest[near, 1:3]).max())
+
+
+def test_an_open_channel_runs_through_the_whole_sequence():
+    """Inlet on the left, pressure outlet on the right, a rebuild before every step: particles are released at the inlet at the
+    rate the imposed velocity asks for, those that cross the outlet are taken out, the stream in between keeps its velocity and
+    its hydrostatic density, every id is handed out once.  (160 steps of the oracle sequence, tests/sa_helpers.py OracleSaIoSim.)"""
+    from sa_helpers import OracleSaIoSim
+    p = SABox(0.05, l=1.0, w=0.4, h=0.4, H=0.25)
+    dp, U = p.m_deltap, 0.6
+    sim = OracleSaIoSim(p, U)
+    n0 = sim.n
+    t = info_type(sim.info[:n0])
+    inlet_vertices = int(((sim.info[:n0, 0] & D.FG_INLET) != 0).__and__(t == D.PT_VERTEX).__and__((sim.info[:n0, 0] & D.FG_CORNER) == 0).sum())
+    fluid0 = int((t == D.PT_FLUID).sum())
+    ref = float(p.physparams.rho0[0]) * dp ** 3
+    for _ in range(160):
+        sim.step()
+    n = sim.n
+    t = info_type(sim.info[:n])
+    active = np.isfinite(sim.pos[:n, 3])
+    fl = (t == D.PT_FLUID) & active
+    g = p.global_pos(sim.pos[:n], sim.hash[:n])
+    assert np.isfinite(sim.vel[:n][fl]).all() and np.isfinite(sim.pos[:n][fl]).all()
+    # released: one per inlet vertex in the first step (they start at half a particle), then one per vertex every dp / U
+    layers = U * sim.t / dp
+    assert inlet_vertices <= sim.created <= inlet_vertices * (2 + int(layers))
+    assert sim.created >= inlet_vertices * int(layers)
+    # taken out: the first layer next to the outlet had dp to go; nobody is left beyond it
+    assert sim.removed > 0 and int(fl.sum()) == fluid0 + sim.created - sim.removed
+    assert g[fl, 0].max() < p.l + 2 * U * sim.dt and g[fl, 0].min() > -1e-6
+    # ids: everybody who was ever released got a different one
+    ids = info_id(sim.info[:n])
+    assert len(np.unique(ids[t == D.PT_FLUID])) == int((t == D.PT_FLUID).sum())
+    # the stream below the surface keeps its velocity and its hydrostatic density
+    bulk = fl & (g[:, 0] > 0.2) & (g[:, 0] < p.l - 0.2) & (g[:, 2] < p.water_level - dp)
+    assert bulk.sum() > 100
+    assert 0.85 * U < sim.vel[:n][bulk, 0].mean() < 1.25 * U
+    assert np.abs(sim.vel[:n][bulk, 3] - p.initial_density(g)[bulk]).max() < 0.01
+    # the open vertices' masses stay within the clip of +/- 2 reference masses
+    ov = (t == D.PT_VERTEX) & ((sim.info[:n, 0] & (D.FG_INLET | D.FG_OUTLET)) != 0)
+    assert np.abs(sim.pos[:n][ov, 3]).max() <= 2 * ref * (1 + 1e-6)
