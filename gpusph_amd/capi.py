@@ -60,6 +60,11 @@ SIGNATURES = {
     "sphx_build_neibs": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _u32, _f, _f, _vp]),
     "sphx_build_neibs_sa": (_i, [_vp] + [_vp] * 11 + [_u32, _u32, _u32, _f, _f, _vp]),
     "sphx_sa_compute_vertex_normal": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _vp]),
+    "sphx_sa_identify_corner_vertices": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _vp]),
+    "sphx_sa_init_io_mass_vertex_count": (_i, [_vp] + [_vp] * 7 + [_u32, _u32, _vp]),
+    "sphx_sa_init_io_mass": (_i, [_vp] + [_vp] * 8 + [_u32, _u32, _f, _vp]),
+    "sphx_sa_find_outgoing_segment": (_i, [_vp] + [_vp] * 12 + [_u32, _u32, _f, _vp]),
+    "sphx_sa_disable_outgoing_parts": (_i, [_vp] + [_vp] * 3 + [_u32, _vp]),
     "sphx_forces_basicstep_sa": (_i, [_vp] + [_vp] * 14 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_forces_dtreduce_gamma_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "sphx_forces_dtreduce_gamma": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),

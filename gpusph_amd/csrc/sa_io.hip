@@ -1,0 +1,339 @@
+// sa_io.hip -- open boundaries of the semi-analytical wall model (SA_BOUNDARY + ENABLE_INLET_OUTLET): the FIRST
+// kernels of that half of the row, for gfx950.  Replaces, of CUDABoundaryConditionsEngine,
+//   saIdentifyCornerVertices   src/cuda/boundary_conditions.cu:667   saIdentifyCornerVerticesDevice   _kernel.cu:2319-2362
+//   initIOmass_vertexCount     src/cuda/boundary_conditions.cu:578   initIOmass_vertexCountDevice     _kernel.cu:1999-2064
+//   initIOmass                 src/cuda/boundary_conditions.cu:610   initIOmassDevice                 _kernel.cu:2078-2172
+//   findOutgoingSegment        src/cuda/boundary_conditions.cu:238   findOutgoingSegmentDevice        _kernel.cu:1647-1750
+//   disableOutgoingParts       src/cuda/boundary_conditions.cu:76    disableOutgoingPartsDevice       _kernel.cu:2374-2398
+// The boundary-condition passes with open boundaries, the density summation and the forces with the Eulerian velocity, and the
+// command sequence are NOT built (sphx_sa_segment_bc & co. still refuse ENABLE_INLET_OUTLET); the CPU oracle restates all of
+// them already (oracle/sph_oracle.c "Open boundaries", tests/test_sa_io_oracle.py), so these five are what a run needs besides.
+// One thread per particle over the reference's u16 list, the reference's operation order (no FMA contraction; the areas of
+// getMassRepartitionFactor in double where the reference's 0.5*dot(...) promotes them): bit-identical to the oracle.
+#include "sphx_internal.h"
+#include "neib_iter.h"
+
+// particleinfo flags of open boundaries (src/particleinfo.h:153-156, 222-241)
+#define FG_INLET             (PART_FLAG_START << 2)
+#define FG_OUTLET            (PART_FLAG_START << 3)
+#define FG_VELOCITY_DRIVEN   (PART_FLAG_START << 4)
+#define FG_CORNER            (PART_FLAG_START << 5)
+#define IS_IO_BOUNDARY(f)    ((f).x & (FG_INLET | FG_OUTLET))
+#define IS_CORNER(f)         ((f).x & FG_CORNER)
+#define SA_IO_MAXNEIBVERTS 30       // boundary_conditions_kernel.cu:1977
+
+struct SaIoArgs {
+	const float4 *pos;             // the walker prefetches a position row per list entry
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	const uint4 *vertices;
+	const particleinfo *info;
+	uint32_t numParticles;
+};
+
+__device__ __forceinline__ bool io_has_vertex(const uint4 &v, uint32_t id) { return v.x == id || v.y == id || v.z == id; }
+
+__global__ void __launch_bounds__(128)
+sa_identify_corner_vertices_kernel(DevParams p, SaIoArgs a, particleinfo *infoOut)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	particleinfo info = a.info[index];
+	if (!(PART_TYPE(info) == PT_VERTEX && IS_IO_BOUNDARY(info))) return;
+	const uint32_t obj = OBJECT_NUM(info), my_id = info_id(info);
+	const float4 pos = a.pos[index];
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	bool corner = false;
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
+		const particleinfo ninfo = a.info[j];
+		// a segment that is not of this open boundary and holds this vertex
+		if (!(obj == OBJECT_NUM(ninfo) && IS_IO_BOUNDARY(ninfo)) && io_has_vertex(a.vertices[j], my_id)) corner = true;
+	});
+	if (corner) { info.x |= FG_CORNER; infoOut[index] = info; }
+}
+
+// the ids of the other vertices of the open-boundary segments vertex `index` belongs to, in list order (both kernels below)
+__device__ __forceinline__ uint32_t io_adjacent_vertex_ids(const DevParams &p, const SaIoArgs &a, uint32_t index, const float4 &pos,
+	const int3 &gridPos, uint32_t my_id, uint32_t *ids)
+{
+	uint32_t count = 0;
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
+		if (!IS_IO_BOUNDARY(a.info[j])) return;
+		const uint4 nv = a.vertices[j];
+		if (!io_has_vertex(nv, my_id)) return;
+		if (my_id != nv.x && count < SA_IO_MAXNEIBVERTS) ids[count++] = nv.x;
+		if (my_id != nv.y && count < SA_IO_MAXNEIBVERTS) ids[count++] = nv.y;
+		if (my_id != nv.z && count < SA_IO_MAXNEIBVERTS) ids[count++] = nv.z;
+	});
+	return count;
+}
+
+__global__ void __launch_bounds__(128)
+sa_init_io_mass_vertex_count_kernel(DevParams p, SaIoArgs a, float4 *forces)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (!(PART_TYPE(info) == PT_VERTEX && IS_IO_BOUNDARY(info) && !IS_CORNER(info))) return;
+	const float4 pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	uint32_t ids[SA_IO_MAXNEIBVERTS];
+	const uint32_t nids = io_adjacent_vertex_ids(p, a, index, pos, gridPos, info_id(info), ids);
+	uint32_t vertexCount = 0;
+	for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
+		const particleinfo ninfo = a.info[j];
+		const uint32_t nid = info_id(ninfo);
+		for (uint32_t k = 0; k < nids; ++k)
+			if (nid == ids[k] && !IS_CORNER(ninfo)) vertexCount += 1;
+	});
+	forces[index].w = (float)vertexCount;
+}
+
+__global__ void __launch_bounds__(128)
+sa_init_io_mass_kernel(DevParams p, SaIoArgs a, const float4 *forces, float4 *newPos, float deltap)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	const float4 pos = a.pos[index];
+	newPos[index] = pos;
+	if (!(PART_TYPE(info) == PT_VERTEX && IS_IO_BOUNDARY(info) && !IS_CORNER(info))) return;
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	const bool getMass = (info_id(info) % 2u) != 0u;      // odd ids take, even ids give
+	float massChange = 0.0f;
+	const float refMass = 0.5f*deltap*deltap*deltap*p.rho0[FLUID_NUM(info)];      // half a fluid particle
+	const float massDiff = refMass - pos.w;
+	const float vertexCount = forces[index].w;
+	uint32_t ids[SA_IO_MAXNEIBVERTS];
+	const uint32_t nids = io_adjacent_vertex_ids(p, a, index, pos, gridPos, info_id(info), ids);
+	for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float, float, float) {
+		const particleinfo ninfo = a.info[j];
+		const uint32_t nid = info_id(ninfo);
+		for (uint32_t k = 0; k < nids; ++k) {
+			if (nid != ids[k]) continue;
+			const bool neibGetMass = (nid % 2u) != 0u;
+			if (getMass != neibGetMass && !IS_CORNER(ninfo)) {
+				if (getMass) {
+					if (massDiff > 0.0f) massChange += massDiff/vertexCount;
+				} else {
+					const float neibMassDiff = refMass - npos.w;
+					if (neibMassDiff > 0.0f) massChange -= neibMassDiff/forces[j].w;
+				}
+			}
+		}
+	});
+	newPos[index].w = pos.w + massChange;
+}
+
+// ---- getMassRepartitionFactor (_kernel.cu:213-283) and calcVertexRelPos (src/cuda/gamma.cuh) for findOutgoingSegment ----
+struct IoV3 { float x, y, z; };
+__device__ __forceinline__ IoV3 iov(float x, float y, float z) { IoV3 r = { x, y, z }; return r; }
+__device__ __forceinline__ IoV3 io_sub(IoV3 a, IoV3 b) { return iov(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ IoV3 io_scale(IoV3 a, float s) { return iov(a.x*s, a.y*s, a.z*s); }
+__device__ __forceinline__ float io_dot(IoV3 a, IoV3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
+__device__ __forceinline__ IoV3 io_cross(IoV3 a, IoV3 b) { return iov(a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }
+
+__device__ __forceinline__ void io_vertex_rel_pos(IoV3 q[3], IoV3 ns, float2 v0, float2 v1, float2 v2, float slength)
+{
+	unsigned j = 0;
+	if (fabsf(ns.x) > fabsf(ns.y)) j = 1;
+	if ((1 - j)*fabsf(ns.x) + j*fabsf(ns.y) > fabsf(ns.z)) j = 2;
+	IoV3 c1 = iov(-((j == 1)*ns.z) + (j == 2)*ns.y, (j == 0)*ns.z - ((j == 2)*ns.x), -((j == 0)*ns.y) + (j == 1)*ns.x);
+	c1 = io_scale(c1, 1.0f/sqrtf(io_dot(c1, c1)));
+	const IoV3 c2 = io_cross(ns, c1);
+	const float2 vp[3] = { v0, v1, v2 };
+	const float inv = 1.0f/slength;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) {
+		const IoV3 s = iov(c1.x*vp[k].x + c2.x*vp[k].y, c1.y*vp[k].x + c2.y*vp[k].y, c1.z*vp[k].x + c2.z*vp[k].y);
+		q[k] = io_scale(iov(-s.x, -s.y, -s.z), inv);
+	}
+}
+
+__device__ __forceinline__ void io_mass_repartition(const IoV3 q[3], IoV3 n, float beta[3])
+{
+	const IoV3 v01 = io_sub(q[0], q[1]), v02 = io_sub(q[0], q[2]);
+	IoV3 p0 = io_sub(q[0], io_scale(n, io_dot(q[0], n)));
+	IoV3 p1 = io_sub(q[1], io_scale(n, io_dot(q[1], n)));
+	IoV3 p2 = io_sub(q[2], io_scale(n, io_dot(q[2], n)));
+	const float refSurface = (float)(0.5*(double)io_dot(io_cross(v01, v02), n));
+	const IoV3 v21 = io_sub(q[2], q[1]);
+	float s0 = (float)(0.5*(double)io_dot(io_cross(p2, v21), n));
+	float s1 = (float)(0.5*(double)io_dot(io_cross(p0, v02), n));
+	float s2 = (float)(-0.5*(double)io_dot(io_cross(p1, v01), n));
+	if (s0 < 0.0f && s2 < 0.0f) { s0 = 0.0f; s1 = refSurface; s2 = 0.0f; }
+	else if (s0 < 0.0f && s1 < 0.0f) { s0 = 0.0f; s1 = 0.0f; s2 = refSurface; }
+	else if (s1 < 0.0f && s2 < 0.0f) { s0 = refSurface; s1 = 0.0f; s2 = 0.0f; }
+	else if (s0 < 0.0f) {
+		const float coef = (float)((double)s0/(0.5*(double)io_dot(io_cross(p0, v21), n)));
+		p1 = io_sub(p1, io_scale(p0, coef));
+		p0 = io_scale(p0, (float)(1.0 - (double)coef));
+		s0 = 0.0f;
+		s1 = (float)(0.5*(double)io_dot(io_cross(p0, v02), n));
+		s2 = (float)(-0.5*(double)io_dot(io_cross(p1, v01), n));
+	} else if (s1 < 0.0f) {
+		const float coef = (float)((double)s1/(0.5*(double)io_dot(io_cross(p1, v02), n)));
+		p2 = io_sub(p2, io_scale(p1, coef));
+		p1 = io_scale(p1, (float)(1.0 - (double)coef));
+		s0 = (float)(0.5*(double)io_dot(io_cross(p2, v21), n));
+		s1 = 0.0f;
+		s2 = (float)(-0.5*(double)io_dot(io_cross(p1, v01), n));
+	} else if (s2 < 0.0f) {
+		const float coef = (float)(-(double)s2/(0.5*(double)io_dot(io_cross(p2, v01), n)));
+		p0 = io_sub(p0, io_scale(p2, coef));
+		p2 = io_scale(p2, (float)(1.0 - (double)coef));
+		s0 = (float)(0.5*(double)io_dot(io_cross(p2, v21), n));
+		s1 = (float)(0.5*(double)io_dot(io_cross(p0, v02), n));
+		s2 = 0.0f;
+	}
+	beta[0] = s0/refSurface; beta[1] = s1/refSurface; beta[2] = s2/refSurface;
+}
+
+struct SaIoOutArgs {
+	const float4 *vel, *boundElement;
+	const float2 *vertPos0, *vertPos1, *vertPos2;
+	uint4 *vertices;
+	float4 *gGam;
+	float influenceradius;
+};
+
+__global__ void __launch_bounds__(128)
+sa_find_outgoing_segment_kernel(DevParams p, SaIoArgs a, SaIoOutArgs o)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != PT_FLUID) return;
+	const float4 pos = a.pos[index];
+	if (!is_active_w(pos.w)) return;
+	const uint4 mine = o.vertices[index];
+	if (mine.x | mine.y) return;           // already marked ("this shouldn't happen", :1679-1686)
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	const float4 vel = o.vel[index];
+	float r2_min = o.influenceradius*o.influenceradius;
+	uint32_t index_min = 0xFFFFFFFFu;
+	IoV3 normal_min = iov(0.0f, 0.0f, 0.0f), relPos_min = normal_min;
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float rx, float ry, float rz) {
+		if (!IS_IO_BOUNDARY(a.info[j])) return;
+		const float4 nrm = o.boundElement[j];
+		const float4 nvel = o.vel[j];
+		const IoV3 relPos = iov(rx, ry, rz), normal = iov(nrm.x, nrm.y, nrm.z);
+		const IoV3 relVel = iov(vel.x - nvel.x, vel.y - nvel.y, vel.z - nvel.z);
+		const float r2 = io_dot(relPos, relPos);
+		// closer than the others, behind the element, moving out relative to it
+		if (r2 < r2_min && io_dot(normal, relPos) <= 0.0f && io_dot(normal, relVel) < 0.0f) {
+			r2_min = r2; index_min = j; normal_min = normal; relPos_min = relPos;
+		}
+	});
+	if (index_min == 0xFFFFFFFFu) return;
+	IoV3 vx[3];
+	io_vertex_rel_pos(vx, normal_min, o.vertPos0[index_min], o.vertPos1[index_min], o.vertPos2[index_min], 1.0f);
+	for (int k = 0; k < 3; ++k) vx[k] = io_sub(relPos_min, vx[k]);
+	float beta[3];
+	io_mass_repartition(vx, normal_min, beta);
+	o.vertices[index] = o.vertices[index_min];
+	o.gGam[index] = make_float4(beta[0], beta[1], beta[2], pos.w);      // the shares and the mass travel where grad gamma was
+}
+
+__global__ void __launch_bounds__(256)
+sa_disable_outgoing_parts_kernel(float4 *pos, uint4 *vertices, const particleinfo *info, uint32_t numParticles)
+{
+	const uint32_t index = blockIdx.x*256 + threadIdx.x;
+	if (index >= numParticles) return;
+	if (PART_TYPE(info[index]) != PT_FLUID) return;
+	float4 ps = pos[index];
+	if (!is_active_w(ps.w)) return;
+	const uint4 v = vertices[index];
+	if ((v.x | v.y) != 0u) {
+		ps.w = __uint_as_float(0x7fc00000u);      // disable_particle
+		pos[index] = ps;
+		vertices[index] = make_uint4(0u, 0u, 0u, 0u);
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------
+static int sa_io_check(sphx_ctx *ctx, const char *who)
+{
+	if (!ctx || !ctx->have_params) return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_io: constants not set");
+	if (ctx->params.boundarytype != SPHX_SA_BOUNDARY) return sphx_set_error(SPHX_ERR_INVALID, who);
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_identify_corner_vertices(sphx_ctx *ctx, const void *pos, void *info, const uint32_t *hash, const void *vertices,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_check(ctx, "saIdentifyCornerVertices called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(pos && info && hash && vertices && cellStart && neibsList, "sphx_sa_identify_corner_vertices: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
+	sa_identify_corner_vertices_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a, (particleinfo*)info);
+	SPHX_LAUNCH_CHECK("sa_identify_corner_vertices_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_init_io_mass_vertex_count(sphx_ctx *ctx, const void *vertices, const uint32_t *hash, const void *info,
+	const uint32_t *cellStart, const uint16_t *neibsList, void *forces, const void *pos,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_check(ctx, "initIOmass_vertexCount called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(vertices && hash && info && cellStart && neibsList && forces && pos, "sphx_sa_init_io_mass_vertex_count: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
+	sa_init_io_mass_vertex_count_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a, (float4*)forces);
+	SPHX_LAUNCH_CHECK("sa_init_io_mass_vertex_count_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_init_io_mass(sphx_ctx *ctx, const void *oldPos, const void *forces, const void *vertices, const uint32_t *hash,
+	const void *info, const uint32_t *cellStart, const uint16_t *neibsList, void *newPos,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_check(ctx, "initIOmass called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(oldPos && forces && vertices && hash && info && cellStart && neibsList && newPos && oldPos != newPos,
+		"sphx_sa_init_io_mass: missing buffer (newPos must not be oldPos)");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIoArgs a = { (const float4*)oldPos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
+	sa_init_io_mass_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a, (const float4*)forces,
+		(float4*)newPos, deltap);
+	SPHX_LAUNCH_CHECK("sa_init_io_mass_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_find_outgoing_segment(sphx_ctx *ctx, const void *pos, const void *vel, void *vertices, void *gGam,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *boundElements, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float influenceradius, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_check(ctx, "findOutgoingSegment called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(pos && vel && vertices && gGam && vertPos0 && vertPos1 && vertPos2 && boundElements && info && hash && cellStart && neibsList,
+		"sphx_sa_find_outgoing_segment: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
+	SaIoOutArgs o = { (const float4*)vel, (const float4*)boundElements, (const float2*)vertPos0, (const float2*)vertPos1,
+		(const float2*)vertPos2, (uint4*)vertices, (float4*)gGam, influenceradius };
+	sa_find_outgoing_segment_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a, o);
+	SPHX_LAUNCH_CHECK("sa_find_outgoing_segment_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *vertices, const void *info, uint32_t numParticles, void *stream)
+{
+	int rc = sa_io_check(ctx, "disableOutgoingParts called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(pos && vertices && info, "sphx_sa_disable_outgoing_parts: missing buffer");
+	if (!numParticles) return SPHX_OK;
+	sa_disable_outgoing_parts_kernel<<<div_up_u(numParticles, 256), 256, 0, (hipStream_t)stream>>>((float4*)pos, (uint4*)vertices,
+		(const particleinfo*)info, numParticles);
+	SPHX_LAUNCH_CHECK("sa_disable_outgoing_parts_kernel");
+	return SPHX_OK;
+}

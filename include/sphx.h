@@ -284,6 +284,33 @@ int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void *oldGGam, c
 int sphx_sa_compute_vertex_normal(sphx_ctx *ctx, void *boundElements, const void *vertices, const void *info,
 	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
+/* ---- the same engine, open boundaries (ENABLE_INLET_OUTLET): the initialisation kernels and the outgoing-particle kernels.
+ * The boundary-condition passes, the density summation and the forces with open boundaries are NOT built: the entry points
+ * above and sphx_forces_basicstep_sa / sphx_sa_density_sum still answer SPHX_ERR_UNSUPPORTED when the flag is set. ---- */
+/* saIdentifyCornerVertices (src/cuda/boundary_conditions.cu:667-700): a vertex of an open boundary that also belongs to a
+ * segment not of that open boundary gets FG_CORNER in info (in place) */
+int sphx_sa_identify_corner_vertices(sphx_ctx *ctx, const void *pos, void *info, const uint32_t *hash, const void *vertices,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
+/* initIOmass_vertexCount (src/cuda/boundary_conditions.cu:578-606): per non-corner open-boundary vertex, the number of
+ * non-corner vertices it shares an open-boundary segment with (one per shared segment), into forces.w (BUFFER_FORCES as
+ * scratch, PredictorCorrectorIntegrator.cc:176-185).  pos: any float4 array of the particles (rows are prefetched, not used) */
+int sphx_sa_init_io_mass_vertex_count(sphx_ctx *ctx, const void *vertices, const uint32_t *hash, const void *info,
+	const uint32_t *cellStart, const uint16_t *neibsList, void *forces, const void *pos,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
+/* initIOmass (src/cuda/boundary_conditions.cu:610-645): newPos = oldPos with the masses of the non-corner open-boundary
+ * vertices moved towards half a fluid particle's mass: odd ids take the difference from the even ids they share segments with */
+int sphx_sa_init_io_mass(sphx_ctx *ctx, const void *oldPos, const void *forces, const void *vertices, const uint32_t *hash,
+	const void *info, const uint32_t *cellStart, const uint16_t *neibsList, void *newPos,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, void *stream);
+/* findOutgoingSegment (src/cuda/boundary_conditions.cu:238-278): a fluid particle behind an open-boundary segment and moving out
+ * relative to it is marked with that segment's vertexinfo (vertices, in place) and its mass repartition over the segment's
+ * vertices + its mass (gGam, in place: {beta0, beta1, beta2, mass}) */
+int sphx_sa_find_outgoing_segment(sphx_ctx *ctx, const void *pos, const void *vel, void *vertices, void *gGam,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *boundElements, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float influenceradius, void *stream);
+/* disableOutgoingParts (src/cuda/boundary_conditions.cu:76-104): marked fluid particles are disabled (NaN mass), marks cleared */
+int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *vertices, const void *info, uint32_t numParticles, void *stream);
 /* saInitGamma (src/cuda/boundary_conditions.cu:457-560): gamma and grad gamma of fluid and vertex particles at initialisation,
  * grad gamma from the analytical formula of a triangular element, gamma by Gauss quadrature / solid angles
  * (src/cuda/gamma.cuh).  Rows of boundary elements are not written.  oldGGam is accepted for interface parity (unused). */

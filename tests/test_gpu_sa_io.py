@@ -1,0 +1,109 @@
+"""Open boundaries of SA_BOUNDARY on the GPU (the half being started): the five kernels of gpusph_amd/csrc/sa_io.hip
+-- corner identification, the two initial-mass kernels, the marking and the removal of outgoing particles -- against the CPU
+oracle, bit for bit (integer work, and float work in the oracle's operation order).  The boundary-condition passes, the density
+summation and the forces with open boundaries exist in the oracle only (tests/test_sa_io_oracle.py)."""
+import numpy as np
+import pytest
+
+from gpusph_amd import capi
+from gpusph_amd import defs as D
+from gpusph_amd.problem import SABox, info_type
+from sa_helpers import sa_oracle_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t, dtype=None):
+    a = t.cpu().numpy()
+    return a.view(dtype) if dtype is not None else a
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_open_boundary_kernels_are_bit_exact():
+    import torch
+    from gpusph_amd.engine import TimestepEngine
+    kw = dict(deltap=0.05)
+    st = sa_oracle_state(**kw)
+    eng = TimestepEngine(SABox(**kw), device="cuda:0", clobber_neibslist=False)
+    eng.build_neibs()
+    p, o, n = st["problem"], st["oracle"], st["n"]
+    assert eng.n == n and np.array_equal(_np(eng.info, np.uint16)[:n], st["info"])       # same order on both sides
+    dev = eng.device
+    lib, h, P = eng.k.lib, eng.k.ctx.handle, capi.ptr
+    s0 = None                                                                               # the default stream
+
+    # the x = 0 wall as open boundary number 1 (a velocity inlet), flagged on both sides
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    seg = (t == D.PT_BOUNDARY) & (st["boundelements"][:, 0] > 0.5) & (np.abs(g[:, 0]) < 1e-6)
+    vtx = (t == D.PT_VERTEX) & (np.abs(g[:, 0]) < 1e-6)
+    info = st["info"].copy()
+    info[seg | vtx, 0] |= D.FG_INLET | D.FG_VELOCITY_DRIVEN
+    info[seg | vtx, 1] = (info[seg | vtx, 1] & 0xF000) | 1
+    d_info = eng.info.clone()
+    d_info[:n] = torch.from_numpy(info.view(np.int16)).to(dev)
+    common = (P(eng.hash), P(eng.cellStart), P(eng.neibslist))
+
+    # saIdentifyCornerVertices
+    want_info = o.sa_identify_corner_vertices(st["pos"], info, st["hash"], st["vertices"], st["cs"], st["nl"], n)
+    capi.check(lib.sphx_sa_identify_corner_vertices(h, P(eng.pos), P(d_info), P(eng.hash), P(eng.vertices), P(eng.cellStart),
+                                                    P(eng.neibslist), n, n, s0))
+    got_info = _np(d_info, np.uint16).reshape(-1, 4)[:n]
+    assert np.array_equal(got_info, want_info) and ((want_info[:, 0] & D.FG_CORNER) != 0).sum() > 0
+
+    # initIOmass_vertexCount + initIOmass (lighter vertices, so that masses move)
+    pos = st["pos"].copy()
+    inner = vtx & ((want_info[:, 0] & D.FG_CORNER) == 0)
+    rng = np.random.default_rng(3)
+    pos[inner, 3] *= rng.uniform(0.5, 0.9, size=int(inner.sum())).astype(np.float32)
+    want_count, want_pos = o.sa_init_io_mass(pos, want_info, st["hash"], st["vertices"], st["cs"], st["nl"], n, p.m_deltap)
+    d_pos = eng.pos.clone(); d_pos[:n] = torch.from_numpy(pos).to(dev)
+    d_forces = torch.zeros_like(eng.pos)
+    d_newpos = torch.zeros_like(eng.pos)
+    capi.check(lib.sphx_sa_init_io_mass_vertex_count(h, P(eng.vertices), P(eng.hash), P(d_info), P(eng.cellStart), P(eng.neibslist),
+                                                     P(d_forces), P(d_pos), n, n, s0))
+    assert np.array_equal(_np(d_forces)[:n, 3], want_count)
+    capi.check(lib.sphx_sa_init_io_mass(h, P(d_pos), P(d_forces), P(eng.vertices), P(eng.hash), P(d_info), P(eng.cellStart),
+                                        P(eng.neibslist), P(d_newpos), n, n, float(np.float32(p.m_deltap)), s0))
+    assert np.array_equal(_bits(_np(d_newpos)[:n]), _bits(want_pos[:n]))
+    assert not np.array_equal(want_pos[inner, 3], pos[inner, 3])
+
+    # findOutgoingSegment + disableOutgoingParts: the wall as an outlet, one particle 0.3 dp behind it and leaving, one coming
+    # back, one at rest, one leaving but still inside
+    info_o = st["info"].copy()
+    info_o[seg | vtx, 0] |= D.FG_OUTLET
+    info_o[seg | vtx, 1] = (info_o[seg | vtx, 1] & 0xF000) | 1
+    d_info_o = d_info.clone(); d_info_o[:n] = torch.from_numpy(info_o.view(np.int16)).to(dev)
+    dp = p.m_deltap
+    fl = np.where(t == D.PT_FLUID)[0]
+    near = fl[np.abs(g[fl, 0] - dp) < 1e-6]
+    out, back, still, inside = near[5], near[9], near[13], near[21]
+    pos2, vel2 = st["pos"].copy(), st["vel"].copy()
+    for i in (out, back, still):
+        pos2[i, 0] -= np.float32(1.3 * dp)
+    pos2[out, 1] += np.float32(0.22 * dp); pos2[out, 2] += np.float32(0.09 * dp)
+    vel2[out, 0] = -0.4; vel2[back, 0] = 0.4; vel2[inside, 0] = -0.4
+    gg = st["gradgamma"].copy()
+    gg[t == D.PT_VERTEX] = (0.0, 0.0, 0.0, 0.5); gg[t == D.PT_FLUID] = (0.0, 0.0, 0.0, 1.0)
+    infl = float(np.float32(p.simparams.influenceRadius))
+    want_v, want_g = o.find_outgoing_segment(pos2, vel2, st["vertices"], gg, st["vertpos"], st["boundelements"], info_o, st["hash"],
+                                             st["cs"], st["nl"], n, infl)
+    d_pos2 = eng.pos.clone(); d_pos2[:n] = torch.from_numpy(pos2).to(dev)
+    d_vel2 = eng.vel.clone(); d_vel2[:n] = torch.from_numpy(vel2).to(dev)
+    d_vert = eng.vertices.clone()
+    d_gg = eng.gradgamma.clone(); d_gg[:n] = torch.from_numpy(gg).to(dev)
+    capi.check(lib.sphx_sa_find_outgoing_segment(h, P(d_pos2), P(d_vel2), P(d_vert), P(d_gg), P(eng.vertpos[0]), P(eng.vertpos[1]),
+                                                 P(eng.vertpos[2]), P(eng.boundelements), P(d_info_o), P(eng.hash), P(eng.cellStart),
+                                                 P(eng.neibslist), n, n, infl, s0))
+    assert np.array_equal(_np(d_vert, np.uint32).reshape(-1, 4)[:n], want_v)
+    assert np.array_equal(_bits(_np(d_gg)[:n]), _bits(want_g))
+    assert (want_v[out, 0] | want_v[out, 1]) != 0 and (want_v[[back, still, inside], :2] == 0).all()
+    want_p3, want_v3 = o.disable_outgoing_parts(pos2, want_v, info_o, n)
+    capi.check(lib.sphx_sa_disable_outgoing_parts(h, P(d_pos2), P(d_vert), P(d_info_o), n, s0))
+    got_p3 = _np(d_pos2)[:n]
+    assert np.array_equal(np.isnan(got_p3[:, 3]), np.isnan(want_p3[:, 3])) and np.isnan(got_p3[out, 3])
+    assert np.array_equal(_bits(got_p3[:, :3]), _bits(want_p3[:, :3]))
+    assert np.array_equal(_np(d_vert, np.uint32).reshape(-1, 4)[:n], want_v3)
