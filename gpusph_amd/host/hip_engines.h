@@ -683,8 +683,9 @@ public:
 };
 
 // ---- boundary-conditions engine of SA_BOUNDARY (CUDABoundaryConditionsEngine, src/cuda/boundary_conditions.cu) ----
-// Solid walls: vertex normals, initial gamma, segment and vertex boundary conditions.  Open boundaries (particle creation and
-// removal, water depth, corner vertices, IO masses) are not built.
+// Solid walls: vertex normals, initial gamma, segment and vertex boundary conditions.  Open boundaries: corner vertices, the initial
+// masses of the open vertices, the marking and removal of outgoing particles (sa_io.hip); the boundary-condition passes with open
+// boundaries (Riemann conditions, mass evolution, particle creation) and the water depth are not built.
 #include "engine_boundary_conditions.h"
 class HIPBoundaryConditionsEngine : public AbstractBoundaryConditionsEngine
 {
@@ -716,8 +717,20 @@ public:
 			step, run_mode == REPACK ? SPHX_REPACK : SPHX_SIMULATE, NULL));
 	}
 
-	void findOutgoingSegment(BufferList&, BufferList const&, const uint, const uint, const float, const float, const float)
-	{ sphx_not_built("findOutgoingSegment (open boundaries)"); }
+	// marks in BUFFER_VERTICES and BUFFER_GRADGAMMA of the write list, as the reference (src/cuda/boundary_conditions.cu:238-278: the
+	// vertices array is taken with MULTISTATE_SAFE because it is shared between states)
+	void findOutgoingSegment(BufferList &bufwrite, BufferList const& bufread, const uint numParticles, const uint particleRangeEnd,
+		const float, const float, const float influenceradius)
+	{
+		const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
+		if (!vertPos)
+			throw std::invalid_argument("findOutgoingSegment: BUFFER_VERTPOS missing");
+		sphx_throw(sphx_sa_find_outgoing_segment(m_c->ctx(), bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(),
+			bufwrite.getData<BUFFER_VERTICES, BufferList::AccessSafety::MULTISTATE_SAFE>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+			vertPos[0], vertPos[1], vertPos[2], bufread.getData<BUFFER_BOUNDELEMENTS>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			numParticles, particleRangeEnd, influenceradius, NULL));
+	}
 
 	// without open boundaries: the density of the vertex particles; no particle is created, *newNumParticles is left alone
 	void saVertexBoundaryConditions(BufferList &bufwrite, BufferList const& bufread, const uint numParticles,
@@ -759,13 +772,35 @@ public:
 			bufread.getData<BUFFER_NEIBSLIST>(), slength, influenceradius, deltap, epsilon, numParticles, particleRangeEnd, NULL));
 	}
 
-	void initIOmass_vertexCount(BufferList&, const BufferList&, const uint, const uint) { sphx_not_built("initIOmass_vertexCount (open boundaries)"); }
-	void initIOmass(BufferList&, const BufferList&, const uint, const uint, const float) { sphx_not_built("initIOmass (open boundaries)"); }
-	void disableOutgoingParts(const BufferList&, BufferList&, const uint, const uint) { sphx_not_built("disableOutgoingParts (open boundaries)"); }
+	// BUFFER_FORCES of the write list is the scratch that carries the counts to initIOmass (PredictorCorrectorIntegrator.cc:176-195)
+	void initIOmass_vertexCount(BufferList &bufwrite, const BufferList &bufread, const uint numParticles, const uint particleRangeEnd)
+	{
+		sphx_throw(sphx_sa_init_io_mass_vertex_count(m_c->ctx(), bufread.getData<BUFFER_VERTICES>(), bufread.getData<BUFFER_HASH>(),
+			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+			bufwrite.getData<BUFFER_FORCES>(), bufwrite.getData<BUFFER_FORCES>(), numParticles, particleRangeEnd, NULL));
+	}
+	void initIOmass(BufferList &bufwrite, const BufferList &bufread, const uint numParticles, const uint particleRangeEnd, const float deltap)
+	{
+		sphx_throw(sphx_sa_init_io_mass(m_c->ctx(), bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_FORCES>(),
+			bufread.getData<BUFFER_VERTICES>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), bufwrite.getData<BUFFER_POS>(),
+			numParticles, particleRangeEnd, deltap, NULL));
+	}
+	void disableOutgoingParts(const BufferList &bufread, BufferList &bufwrite, const uint, const uint particleRangeEnd)
+	{
+		sphx_throw(sphx_sa_disable_outgoing_parts(m_c->ctx(), bufwrite.getData<BUFFER_POS>(),
+			bufwrite.getData<BUFFER_VERTICES, BufferList::AccessSafety::MULTISTATE_SAFE>(), bufread.getData<BUFFER_INFO>(),
+			particleRangeEnd, NULL));
+	}
 	void downloadIOwaterdepth(uint*, const uint*, const uint) { sphx_not_built("downloadIOwaterdepth (open boundaries)"); }
 	void uploadIOwaterdepth(const uint*, uint*, const uint) { sphx_not_built("uploadIOwaterdepth (open boundaries)"); }
-	void saIdentifyCornerVertices(const BufferList&, BufferList&, const uint, const uint, const float, const float)
-	{ sphx_not_built("saIdentifyCornerVertices (open boundaries)"); }
+	void saIdentifyCornerVertices(const BufferList &bufread, BufferList &bufwrite, const uint numParticles, const uint particleRangeEnd,
+		const float, const float)
+	{
+		sphx_throw(sphx_sa_identify_corner_vertices(m_c->ctx(), bufread.getData<BUFFER_POS>(), bufwrite.getData<BUFFER_INFO>(),
+			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_VERTICES>(), bufread.getData<BUFFER_CELLSTART>(),
+			bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, NULL));
+	}
 };
 
 // ---- post-processing (CUDAPostProcessEngine<pptype, kerneltype, boundarytype, simflags>, src/cuda/post_process.cu:88-660) ----
