@@ -65,6 +65,8 @@ SIGNATURES = {
     "sphx_sa_init_io_mass": (_i, [_vp] + [_vp] * 8 + [_u32, _u32, _f, _vp]),
     "sphx_sa_find_outgoing_segment": (_i, [_vp] + [_vp] * 12 + [_u32, _u32, _f, _vp]),
     "sphx_sa_disable_outgoing_parts": (_i, [_vp] + [_vp] * 3 + [_u32, _vp]),
+    "sphx_sa_segment_bc_io": (_i, [_vp] + [_vp] * 10 + [_u32, _u32, _i, _vp]),
+    "sphx_sa_vertex_bc_io": (_i, [_vp] + [_vp] * 17 + [_u32, _u32, _u32, _f, _f, _i, _u32, _vp]),
     "sphx_forces_basicstep_sa": (_i, [_vp] + [_vp] * 14 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_forces_dtreduce_gamma_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "sphx_forces_dtreduce_gamma": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),

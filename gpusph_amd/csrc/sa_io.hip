@@ -337,3 +337,348 @@ extern "C" int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *ve
 	SPHX_LAUNCH_CHECK("sa_disable_outgoing_parts_kernel");
 	return SPHX_OK;
 }
+
+// ==========================================================================================
+// The boundary-condition passes with open boundaries (saSegmentBoundaryConditionsDevice / saVertexBoundaryConditionsDevice with
+// has_io, _kernel.cu:1427-1520, 2197-2252; laminar, not repacking, Wendland).  WRITTEN AT THE END OF ROUND 4 AND NOT YET RUN ON
+// A GPU: ports of the oracle's orc_sa_segment_bc_io / orc_sa_vertex_bc_io (which are held by known answers and by a whole
+// open-channel run on the CPU, tests/test_sa_io_oracle.py); their GPU parity test is in tests/test_gpu_sa_io.py behind
+// SPHX_TEST_SA_IO_BC=1 until it has passed once.  Nothing in the engines calls them yet.
+// ==========================================================================================
+__device__ __forceinline__ float io_eos_rho(const DevParams &p, float pres, uint32_t fl)      // RHO, phys_core.cu:106-112
+{ return powf(pres/p.bcoeff[fl] + 1.0f, 1.0f/p.gammacoeff[fl]) - 1.0f; }
+__device__ __forceinline__ float io_R(const DevParams &p, float rho_tilde, uint32_t fl)       // Riemann celerity, :114-120
+{ return 2.0f/(p.gammacoeff[fl] - 1.0f)*p.sscoeff[fl]*powf(rho_tilde + 1.0f, 0.5f*p.gammacoeff[fl] - 0.5f); }
+__device__ __forceinline__ float io_RHOR(const DevParams &p, float r, uint32_t fl)            // its inverse, :122-127 (double constants)
+{ return (float)((double)powf((float)(((double)p.gammacoeff[fl] - 1.)*(double)r/(2.*(double)p.sscoeff[fl])), (float)(2./((double)p.gammacoeff[fl] - 1.))) - 1.0); }
+
+// calculateIOboundaryCondition, _kernel.cu:111-200
+__device__ __forceinline__ void io_boundary_condition(const DevParams &p, float4 &eulerVel, bool velocity_driven, uint32_t a,
+	float rhoInt, float rhoExt, float ux, float uy, float uz, float unInt, float unExt, float nx, float ny, float nz)
+{
+	const float rInt = io_R(p, rhoInt, a);
+	if (velocity_driven) {
+		float riemannR = 0.0f;
+		if (unExt <= unInt)
+			riemannR = rInt + (unExt - unInt);
+		else {
+			const float riemannRho = io_eos_rho(p, sa_P(p, rhoInt, a) + ((rhoInt + 1.0f)*p.rho0[a])*unInt*(unInt - unExt), a);
+			riemannR = io_R(p, riemannRho, a);
+			const float lambda = unExt + sa_sound_speed(p, riemannRho, a);
+			const float lambdaInt = unInt + sa_sound_speed(p, rhoInt, a);
+			if (lambda <= lambdaInt) riemannR = rInt;
+		}
+		eulerVel.w = io_RHOR(p, riemannR, a);
+	} else {
+		float flux = 0.0f;
+		const float cExt = sa_sound_speed(p, rhoExt, a), cInt = sa_sound_speed(p, rhoInt, a);
+		const float lambdaInt = unInt + cInt;
+		const float rExt = io_R(p, rhoExt, a);
+		const float shock = (sa_P(p, rhoInt, a) - sa_P(p, rhoExt, a))/(((rhoInt + 1.0f)*p.rho0[a])*fmaxf(unInt, 1e-5f*p.sscoeff[a])) + unInt;
+		if (rhoExt <= rhoInt) {
+			flux = unInt + (rExt - rInt);
+			float lambda = flux + cExt;
+			if (lambda > lambdaInt) {
+				flux = shock;
+				if (fabsf(flux) > p.sscoeff[a]*0.1f) flux = unInt;
+				lambda = flux + cExt;
+				if (lambda <= lambdaInt) flux = unInt;
+			}
+		} else {
+			flux = shock;
+			if (fabsf(flux) > p.sscoeff[a]*0.1f) flux = unInt;
+			float lambda = flux + cExt;
+			if (lambda <= lambdaInt) {
+				flux = unInt + (rExt - rInt);
+				lambda = flux + cExt;
+				if (lambda > lambdaInt) flux = unInt;
+			}
+		}
+		eulerVel.x = eulerVel.y = eulerVel.z = 0.0f;
+		if (rhoExt < 0.0f) flux = fminf(flux, 0.0f);
+		if (flux < 0.0f) {
+			const float un = ux*nx + uy*ny + uz*nz;
+			eulerVel.x = ux - un*nx; eulerVel.y = uy - un*ny; eulerVel.z = uz - un*nz;
+		}
+		eulerVel.x += nx*flux; eulerVel.y += ny*flux; eulerVel.z += nz*flux;
+		eulerVel.w = rhoExt;
+	}
+}
+
+struct SaIoBcArgs {
+	float4 *vel, *gGam, *eulerVel;          // in place (boundary / vertex rows; the clones' rows in the last vertex pass)
+	const float4 *pos;                      // the walker's position rows
+	const float4 *boundElementRO;           // segment pass: read only
+	const uint4 *verticesRO;
+	const particleinfo *infoRO;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	int step;
+	// vertex pass
+	float4 *newPos, *forces, *boundElement;
+	uint4 *vertices;
+	particleinfo *info;
+	uint32_t *hashW, *nextIDs, *newNumParticles;
+	const float2 *vertPos0, *vertPos1, *vertPos2;
+	uint32_t totParticles, numOpenVertices;
+	float deltap, dt;
+	// what the walker reads
+	const uint32_t *hashRO;
+};
+
+struct IoNdata { float r, w, press; float4 vel; };
+__device__ __forceinline__ IoNdata io_fluid_ndata(const DevParams &p, const float4 *vel, const particleinfo *info, uint32_t j,
+	float rx, float ry, float rz, float mass)
+{
+	IoNdata n;
+	const uint32_t nfl = FLUID_NUM(info[j]);
+	n.vel = vel[j];
+	n.r = sqrtf(rx*rx + ry*ry + rz*rz);
+	n.w = kernel_W<SPHX_WENDLAND>(p, n.r)*mass/((n.vel.w + 1.0f)*p.rho0[nfl]);
+	n.press = p.bcoeff[nfl]*(powf(n.vel.w + 1.0f, p.gammacoeff[nfl]) - 1.0f);
+	return n;
+}
+
+struct IoWalk {       // what for_each_neib needs
+	const float4 *pos; const uint32_t *cellStart; const neibdata *neibsList;
+};
+
+__global__ void __launch_bounds__(128)
+sa_segment_bc_io_kernel(DevParams p, SaIoBcArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.infoRO[index];
+	if (!IS_BOUNDARY(info)) return;
+	const IoWalk wk = { a.pos, a.cellStart, a.neibsList };
+	const float4 pos = a.pos[index];
+	const float4 normal = a.boundElementRO[index];
+	const uint4 verts = a.verticesRO[index];
+	const int3 gridPos = grid_pos_from_hash(p, a.hashRO[index] & CELLTYPE_BITMASK);
+	const bool has_moving = (p.simflags & SPHX_ENABLE_MOVING_BODIES) != 0;
+	const bool io = IS_IO_BOUNDARY(info) != 0, vdriven = (info.x & FG_VELOCITY_DRIVEN) != 0;
+	float sumpWall = 0.0f, shepard_div = 0.0f, sump = 0.0f, svx = 0.0f, svy = 0.0f, svz = 0.0f;
+	float4 gGam = make_float4(0.0f, 0.0f, 0.0f, a.gGam[index].w);
+	float4 vel = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	const bool calcGam = has_moving || !is_active_w(gGam.w) || a.step == 0;
+	if (calcGam) gGam.w = 0.0f;
+	const bool moving = has_moving && (info.x & FG_MOVING_BOUNDARY);
+	float4 eulerVel = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // eulervel_pout, IO constructor (:488-505)
+	if (io) { eulerVel = a.eulerVel[index]; if (vdriven) eulerVel.w = 0.0f; }
+	for_each_neib<PT_VERTEX>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float, float, float) {
+		if (!is_active_w(npos.w)) return;
+		if (!io_has_vertex(verts, info_id(a.infoRO[j]))) return;
+		if (moving) { const float4 nv = a.vel[j]; vel.x += nv.x; vel.y += nv.y; vel.z += nv.z; }
+		if (calcGam) { const float4 g = a.gGam[j]; gGam.x += g.x; gGam.y += g.y; gGam.z += g.z; gGam.w += g.w; }
+	});
+	if (calcGam) {
+		const float inv = 1.0f/3;
+		gGam.x *= inv; gGam.y *= inv; gGam.z *= inv; gGam.w *= inv;
+		a.gGam[index] = gGam;
+		gGam.w = fmaxf(gGam.w, 1e-5f);
+	}
+	vel.x /= 3; vel.y /= 3; vel.z /= 3;
+	const uint32_t fl = FLUID_NUM(info);
+	for_each_neib<PT_FLUID>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const IoNdata n = io_fluid_ndata(p, a.vel, a.infoRO, j, rx, ry, rz, npos.w);
+		if (!(n.r < p.influenceradius && (normal.x*rx + normal.y*ry + normal.z*rz) < 0.0f)) return;
+		const float gdot = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
+		sumpWall += fmaxf(n.press + ((n.vel.w + 1.0f)*p.rho0[fl])*gdot, 0.0f)*n.w;
+		if (io) {         // io_fluid_contrib, segments (:852-866)
+			const float4 ne = a.eulerVel[j];
+			svx += n.w*(n.vel.x + ne.x); svy += n.w*(n.vel.y + ne.y); svz += n.w*(n.vel.z + ne.z);
+			sump += n.w*fmaxf(0.0f, n.press);
+		}
+		shepard_div += n.w;
+	});
+	if (io) {             // impose_io_bc (:1362-1413)
+		if (shepard_div > 0.1f*gGam.w) {
+			svx /= shepard_div; svy /= shepard_div; svz /= shepard_div;
+			sump /= shepard_div;
+			vel.w = io_eos_rho(p, sump, fl);
+			if (!vdriven) a.eulerVel[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		} else {
+			sump = 0.0f;
+			if (vdriven) { svx = eulerVel.x; svy = eulerVel.y; svz = eulerVel.z; vel.w = 0.0f; }
+			else { svx = svy = svz = 0.0f; vel.w = a.eulerVel[index].w; }
+		}
+		const float unInt = svx*normal.x + svy*normal.y + svz*normal.z;
+		const float unExt = eulerVel.x*normal.x + eulerVel.y*normal.y + eulerVel.z*normal.z;
+		float4 ev = eulerVel;
+		io_boundary_condition(p, ev, vdriven, fl, vel.w, eulerVel.w, svx, svy, svz, unInt, unExt, normal.x, normal.y, normal.z);
+		a.eulerVel[index] = ev;
+		vel.w = ev.w;
+	} else {              // impose_solid_bc<true>, impose_solid_eulerVel
+		shepard_div = fmaxf(shepard_div, 0.1f*gGam.w);
+		vel.w = io_eos_rho(p, sumpWall/shepard_div, fl);
+		a.eulerVel[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+	}
+	a.vel[index] = vel;
+}
+
+__global__ void __launch_bounds__(128)
+sa_vertex_bc_io_kernel(DevParams p, SaIoBcArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != PT_VERTEX) return;
+	const IoWalk wk = { a.pos, a.cellStart, a.neibsList };
+	const float4 pos = a.pos[index];
+	const float gam = a.gGam[index].w;
+	const uint32_t fl = FLUID_NUM(info), my_id = info_id(info);
+	const bool io = IS_IO_BOUNDARY(info) != 0, corner = IS_CORNER(info) != 0, vdriven = (info.x & FG_VELOCITY_DRIVEN) != 0;
+	const float4 normal = a.boundElement[index];
+	const float refMass = a.deltap*a.deltap*a.deltap*p.rho0[fl];
+	const int3 gridPos = grid_pos_from_hash(p, a.hashW[index] & CELLTYPE_BITMASK);
+	float sumpWall = 0.0f, shepard_div = 0.0f, sump = 0.0f, sumMdot = 0.0f, massFluid = 0.0f, svx = 0.0f, svy = 0.0f, svz = 0.0f;
+	for_each_neib<PT_FLUID>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		if (!is_active_w(npos.w)) return;
+		const IoNdata n = io_fluid_ndata(p, a.vel, a.info, j, rx, ry, rz, npos.w);
+		if (!(n.r < p.influenceradius)) return;
+		const float gdot = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
+		sumpWall += fmaxf(n.press + ((n.vel.w + 1.0f)*p.rho0[fl])*gdot, 0.0f)*n.w;
+		shepard_div += n.w;
+		if (!io) return;      // io_fluid_contrib, vertices (:868-909)
+		if (!corner) {
+			const float4 ne = a.eulerVel[j];
+			svx += n.w*(n.vel.x + ne.x); svy += n.w*(n.vel.y + ne.y); svz += n.w*(n.vel.z + ne.z);
+			sump += n.w*fmaxf(0.0f, n.press);
+		}
+		if (a.step == 2) {    // a particle marked by findOutgoingSegment: its mass, by this vertex's share
+			const uint4 nv = a.vertices[j];
+			if ((nv.x | nv.y) != 0u) {
+				const float4 w = a.gGam[j];
+				const float weight = nv.x == my_id ? w.x : nv.y == my_id ? w.y : nv.z == my_id ? w.z : 0.0f;
+				if (weight > 0) massFluid += weight*w.w;
+			}
+		}
+	});
+	if (io && !corner) {      // vertex_boundary_loop / io_boundary_contrib (:937-988): the mass flux through the adjacent open segments
+		for_each_neib<PT_BOUNDARY>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
+			const uint4 nv = a.vertices[j];
+			if (!io_has_vertex(nv, my_id)) return;
+			const particleinfo ninfo = a.info[j];
+			if (!IS_IO_BOUNDARY(ninfo)) return;
+			const float4 nn = a.boundElement[j];
+			IoV3 vx[3];
+			io_vertex_rel_pos(vx, iov(nn.x, nn.y, nn.z), a.vertPos0[j], a.vertPos1[j], a.vertPos2[j], -1.0f);
+			float beta[3];
+			io_mass_repartition(vx, iov(nn.x, nn.y, nn.z), beta);
+			const float weight = nv.x == my_id ? beta[0] : nv.y == my_id ? beta[1] : nv.z == my_id ? beta[2] : 0.0f;
+			const float4 ne = a.eulerVel[j];
+			sumMdot += ((a.vel[j].w + 1.0f)*p.rho0[FLUID_NUM(ninfo)])*nn.w*weight*(ne.x*nn.x + ne.y*nn.y + ne.z*nn.z);
+		});
+	}
+	shepard_div = fmaxf(shepard_div, 0.1f*gam);
+	a.vel[index].w = io_eos_rho(p, sumpWall/shepard_div, fl);
+	if (!io || corner) return;
+	// impose_vertex_io_bc (:1168-1252)
+	float4 eulerVel = a.eulerVel[index];
+	if (shepard_div > 0.1f*gam) {
+		svx /= shepard_div; svy /= shepard_div; svz /= shepard_div;
+		sump /= shepard_div;
+		const float unInt = svx*normal.x + svy*normal.y + svz*normal.z;
+		const float unExt = eulerVel.x*normal.x + eulerVel.y*normal.y + eulerVel.z*normal.z;
+		const float rhoInt = io_eos_rho(p, sump, fl);
+		io_boundary_condition(p, eulerVel, vdriven, fl, rhoInt, eulerVel.w, svx, svy, svz, unInt, unExt, normal.x, normal.y, normal.z);
+	} else if (vdriven)
+		eulerVel.w = 0.0f;
+	else
+		eulerVel.x = eulerVel.y = eulerVel.z = 0.0f;
+	a.eulerVel[index] = eulerVel;
+	a.vel[index].w = eulerVel.w;
+	float4 np = pos;
+	const float un = normal.x*eulerVel.x + normal.y*eulerVel.y + normal.z*eulerVel.z;
+	if (a.step != 0) {
+		np.w += a.dt*sumMdot;
+		if (shepard_div < 0.1f*gam && sumMdot < 0.0f) np.w = 0.0f;
+		np.w = fmaxf(-2.0f*refMass, fminf(2.0f*refMass, np.w));
+		if (sumMdot < 0.0f || un < 1e-5f*p.sscoeff[fl]) {
+			const float weightedMass = refMass*normal.w;      // normal.w of a vertex is NaN: fminf / fmaxf return the other operand
+			np.w = fmaxf(-weightedMass, fminf(weightedMass, np.w));
+		}
+	}
+	// generate_new_particles (:1101-1159), createNewFluidParticle (:73-104)
+	if (a.step == 2 && np.w > refMass*0.5f && sumMdot > 0 && un > 1e-5f && (vdriven || eulerVel.w > 1e-5f)) {
+		const uint32_t clone = atomicAdd(a.newNumParticles, 1u);
+		if (clone < a.totParticles) {
+			const uint32_t new_id = a.nextIDs[index];
+			a.nextIDs[index] = new_id + a.numOpenVertices;
+			particleinfo ci;
+			ci.x = PT_FLUID; ci.y = (unsigned short)(fl << 12); ci.z = (unsigned short)(new_id & 0xFFFFu); ci.w = (unsigned short)(new_id >> 16);
+			float4 cp = np;
+			cp.w = refMass;
+			massFluid -= cp.w;
+			a.newPos[clone] = cp;
+			a.info[clone] = ci;
+			a.hashW[clone] = a.hashW[index] & CELLTYPE_BITMASK;
+			a.vel[clone] = eulerVel;
+			a.gGam[clone] = a.gGam[index];
+			a.eulerVel[clone] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			a.forces[clone] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			a.vertices[clone] = make_uint4(0u, 0u, 0u, 0u);
+			a.nextIDs[clone] = 0xFFFFFFFFu;
+			const float nanv = __uint_as_float(0xffc00000u);      // -NAN
+			a.boundElement[clone] = make_float4(nanv, nanv, nanv, nanv);
+		}
+	}
+	np.w += massFluid;
+	a.newPos[index] = np;
+}
+
+static int sa_io_bc_check(sphx_ctx *ctx, const char *who)
+{
+	int rc = sa_io_check(ctx, who);
+	if (rc != SPHX_OK) return rc;
+	if (ctx->params.kerneltype != SPHX_WENDLAND)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_io: SA_BOUNDARY is built for the Wendland kernel");
+	if (ctx->dev.turbmodel == SPHX_KEPSILON)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_io: open boundaries with k-epsilon are not built");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_segment_bc_io(sphx_ctx *ctx, void *vel, void *gGam, void *eulerVel, const void *pos, const void *vertices,
+	const void *boundElements, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, int step, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_bc_check(ctx, "saSegmentBoundaryConditions called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(vel && gGam && eulerVel && pos && vertices && boundElements && info && hash && cellStart && neibsList,
+		"sphx_sa_segment_bc_io: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIoBcArgs a = {};
+	a.vel = (float4*)vel; a.gGam = (float4*)gGam; a.eulerVel = (float4*)eulerVel; a.pos = (const float4*)pos;
+	a.boundElementRO = (const float4*)boundElements; a.verticesRO = (const uint4*)vertices; a.infoRO = (const particleinfo*)info;
+	a.hashRO = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd; a.step = step == -1 ? 0 : step;
+	sa_segment_bc_io_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_segment_bc_io_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, void *newPos, void *gGam, void *eulerVel, void *forces,
+	void *vertices, void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, void *info, uint32_t *hash,
+	uint32_t *nextIDs, uint32_t *newNumParticles, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t totParticles, float deltap, float dt, int step,
+	uint32_t numOpenVertices, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_bc_check(ctx, "saVertexBoundaryConditions called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(vel && pos && newPos && pos != newPos && gGam && eulerVel && forces && vertices && boundElements && vertPos0 && vertPos1 &&
+		vertPos2 && info && hash && nextIDs && newNumParticles && cellStart && neibsList, "sphx_sa_vertex_bc_io: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIoBcArgs a = {};
+	a.vel = (float4*)vel; a.gGam = (float4*)gGam; a.eulerVel = (float4*)eulerVel; a.pos = (const float4*)pos; a.newPos = (float4*)newPos;
+	a.forces = (float4*)forces; a.vertices = (uint4*)vertices; a.boundElement = (float4*)boundElements; a.info = (particleinfo*)info;
+	a.hashW = hash; a.nextIDs = nextIDs; a.newNumParticles = newNumParticles; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.vertPos0 = (const float2*)vertPos0; a.vertPos1 = (const float2*)vertPos1; a.vertPos2 = (const float2*)vertPos2;
+	a.numParticles = particleRangeEnd; a.totParticles = totParticles; a.numOpenVertices = numOpenVertices;
+	a.deltap = deltap; a.dt = dt; a.step = step == -1 ? 0 : step;
+	sa_vertex_bc_io_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_vertex_bc_io_kernel");
+	return SPHX_OK;
+}

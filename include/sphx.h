@@ -311,6 +311,24 @@ int sphx_sa_find_outgoing_segment(sphx_ctx *ctx, const void *pos, const void *ve
 	uint32_t numParticles, uint32_t particleRangeEnd, float influenceradius, void *stream);
 /* disableOutgoingParts (src/cuda/boundary_conditions.cu:76-104): marked fluid particles are disabled (NaN mass), marks cleared */
 int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *vertices, const void *info, uint32_t numParticles, void *stream);
+/* saSegmentBoundaryConditions / saVertexBoundaryConditions with open boundaries (src/cuda/boundary_conditions.cu:108-235,280-410
+ * with has_io; laminar, SPHX_SIMULATE).  WRITTEN, NOT YET RUN ON A GPU (end of round 4): ports of the oracle's restatements, their
+ * parity test waits behind SPHX_TEST_SA_IO_BC=1 in tests/test_gpu_sa_io.py; no engine calls them.
+ * segment pass: vel, gGam, eulerVel in place (boundary rows): an open-boundary segment gets the Riemann-invariant condition from
+ * the Shepard means of the fluid next to it and what IMPOSE_OPEN_BOUNDARY_CONDITION left in eulerVel, a solid one the wall density
+ * and a cleared Eulerian velocity.
+ * vertex pass: vel.w of every vertex; for the non-corner vertices of open boundaries eulerVel, the mass in newPos (mass flux of the
+ * adjacent open segments over dt, the mass of marked outgoing particles in step 2) and, in step 2, new fluid particles appended at
+ * *newNumParticles (device counter, starts at numParticles; rows up to totParticles must exist in newPos, vel, gGam, eulerVel,
+ * forces, vertices, boundElements, info, hash, nextIDs), ids from nextIDs[vertex], which advances by numOpenVertices */
+int sphx_sa_segment_bc_io(sphx_ctx *ctx, void *vel, void *gGam, void *eulerVel, const void *pos, const void *vertices,
+	const void *boundElements, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, int step, void *stream);
+int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, void *newPos, void *gGam, void *eulerVel, void *forces,
+	void *vertices, void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, void *info, uint32_t *hash,
+	uint32_t *nextIDs, uint32_t *newNumParticles, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t totParticles, float deltap, float dt, int step,
+	uint32_t numOpenVertices, void *stream);
 /* saInitGamma (src/cuda/boundary_conditions.cu:457-560): gamma and grad gamma of fluid and vertex particles at initialisation,
  * grad gamma from the analytical formula of a triangular element, gamma by Gauss quadrature / solid angles
  * (src/cuda/gamma.cuh).  Rows of boundary elements are not written.  oldGGam is accepted for interface parity (unused). */
