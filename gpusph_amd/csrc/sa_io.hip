@@ -682,3 +682,288 @@ extern "C" int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, v
 	SPHX_LAUNCH_CHECK("sa_vertex_bc_io_kernel");
 	return SPHX_OK;
 }
+
+// ==========================================================================================
+// Density summation and forces with open boundaries (density_sum_kernel.cu:119-140,206-250,374-420,606-655;
+// forces_kernel.def:1485-1497,2494-2507,2703-2708), one thread per particle over the list -- the list-walker kernels of
+// sa_bounds.hip (sa_density_sum_kernel, sa_forces_kernel without k-epsilon) with the open boundaries' terms, as the oracle's
+// orc_sa_density_sum_io / orc_forces_sa_io have them.  WRITTEN AT THE END OF ROUND 4, NOT YET RUN ON A GPU (see above); the
+// tiled fast paths do not know open boundaries, so these are the whole pass for such a run.
+// ==========================================================================================
+#include "sa_wall_gamma.h"
+#include "sa_args.h"
+
+struct SaIoDensitySumArgs {
+	float4 *newVel, *newGGam, *forces;
+	const float4 *oldPos, *pos, *oldVel, *oldEulerVel, *oldGGam, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	float dt;
+};
+
+__global__ void __launch_bounds__(128)
+sa_density_sum_io_kernel(DevParams p, SaIoDensitySumArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != PT_FLUID) {
+		if (PART_TYPE(info) == PT_VERTEX || PART_TYPE(info) == PT_BOUNDARY) a.newGGam[index] = a.oldGGam[index];
+		return;
+	}
+	const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
+	const IoWalk w = { a.oldPos, a.cellStart, a.neibsList };      // r_ab at step n: the walker reads the OLD positions
+	float sumPmwN = 0.0f, sumPmwNp1 = 0.0f, sumVmwDelta = 0.0f;
+	auto volumic = [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
+		if (!is_active_w(nN.w)) return;
+		const particleinfo ninfo = a.info[j];
+		const float4 nNp1 = a.pos[j];
+		const float rx = pcx - nN.x, ry = pcy - nN.y, rz = pcz - nN.z;
+		const float qx = (pcx - nNp1.x) + dx, qy = (pcy - nNp1.y) + dy, qz = (pcz - nNp1.z) + dz;
+		if (!IS_IO_BOUNDARY(ninfo)) {
+			const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+			sumPmwN -= nN.w*kernel_W<SPHX_WENDLAND>(p, rN);
+		}
+		const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
+		if (rNp1 < p.influenceradius) sumPmwNp1 += nN.w*kernel_W<SPHX_WENDLAND>(p, rNp1);
+		if (IS_IO_BOUNDARY(ninfo)) {      // densitySumOpenBoundaryContribution: the neighbour displaced by its Eulerian velocity
+			const float4 e = a.oldEulerVel[j], v = a.oldVel[j];
+			const float ex = rx + a.dt*(e.x - v.x), ey = ry + a.dt*(e.y - v.y), ez = rz + a.dt*(e.z - v.z);
+			const float newDist = sqrtf(ex*ex + ey*ey + ez*ez);
+			if (newDist < p.influenceradius) sumVmwDelta -= nN.w*kernel_W<SPHX_WENDLAND>(p, newDist);
+		}
+	};
+	for_each_neib<PT_FLUID, true>(p, w, index, posN, gridPos, volumic);
+	for_each_neib<PT_VERTEX, true>(p, w, index, posN, gridPos, volumic);
+	const float fw = sumPmwNp1 + sumPmwN + sumVmwDelta;
+	a.forces[index].w = fw;
+	float gGamDotR = 0.0f, sumSgamDelta = 0.0f, sumSgamN = 0.0f;
+	V3 gGam = v3(0.0f, 0.0f, 0.0f);
+	for_each_neib<PT_BOUNDARY, true>(p, w, index, posN, gridPos, [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
+		if (!is_active_w(nN.w)) return;
+		const float4 nNp1 = a.pos[j];
+		const float inv = 1.0f/p.slength;
+		const V3 qN = v3((pcx - nN.x)*inv, (pcy - nN.y)*inv, (pcz - nN.z)*inv);
+		const V3 qNp1 = v3(((pcx - nNp1.x) + dx)*inv, ((pcy - nNp1.y) + dy)*inv, ((pcz - nNp1.z) + dz)*inv);
+		const float4 be = a.boundElement[j];
+		const V3 ns = v3(be.x, be.y, be.z);
+		WallTri tri;
+		wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+		const V3 gN = ns*(wall_grad_gamma(tri, qN)/p.slength);
+		const V3 gNp1 = ns*(wall_grad_gamma(tri, qNp1)/p.slength);
+		gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
+		gGam = gGam + gNp1;
+		if (IS_IO_BOUNDARY(a.info[j])) {      // io_gamma_contrib (:374-395)
+			const float4 e = a.oldEulerVel[j], v = a.oldVel[j];
+			const V3 deltaR = v3(a.dt*(e.x - v.x), a.dt*(e.y - v.y), a.dt*(e.z - v.z));
+			const V3 qDelta = qN + deltaR/p.slength;
+			const V3 gDelta = ns*(wall_grad_gamma(tri, qDelta)/p.slength);
+			sumSgamDelta += dot(deltaR, gDelta);
+			sumSgamN += dot(deltaR, gN);
+		}
+	});
+	gGamDotR *= p.slength;
+	const float4 gGamN = a.oldGGam[index];
+	float4 g = make_float4(gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR);
+	float imposedGam = gGamN.w + (sumSgamDelta + sumSgamN)/2.0f;      // compute_imposed_gamma (:404-417)
+	if (imposedGam > 1.0f) imposedGam = 1.0f;
+	else if (imposedGam < 0.1f) imposedGam = 0.1f;
+	const uint32_t fl = FLUID_NUM(info);
+	const float rho = (imposedGam*((a.oldVel[index].w + 1.0f)*p.rho0[fl]) + fw)/g.w;
+	if (g.w > 1.0f || sqrtf(g.x*g.x + g.y*g.y + g.z*g.z)*p.slength < 1e-10f) g.w = 1.0f;
+	else if (g.w < 0.1f) g.w = 0.1f;
+	a.newVel[index].w = rho/p.rho0[fl] - 1.0f;
+	a.newGGam[index] = g;
+}
+
+struct SaIoForcesArgs {
+	float4 *forces;
+	float *cfl, *cflGamma, *cflGammaBlocks;
+	const float4 *pos, *vel, *eulerVel, *gGam, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t fromParticle, toParticle, cflOffset;
+	float deltap;
+};
+
+__global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
+sa_forces_io_kernel(DevParams p, SaIoForcesArgs a)
+{
+	__shared__ float sMax[SPHX_BLOCK_FORCES/64], sMaxG[SPHX_BLOCK_FORCES/64];
+	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
+	float cflTerm = 0.0f, gammaCfl = 0.0f;
+	if (index < a.toParticle) {
+		const particleinfo info = a.info[index];
+		const float4 pos = a.pos[index];
+		if (is_active_w(pos.w)) {
+			float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			const float4 vel = a.vel[index];
+			const uint32_t fl = FLUID_NUM(info);
+			if (PART_TYPE(info) == PT_FLUID) {
+				const IoWalk wk = { a.pos, a.cellStart, a.neibsList };
+				const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+				const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
+				const float p_precalc = sa_P(p, vel.w, fl)/(p_rho*p_rho);
+				const float4 p_euler = a.eulerVel[index];
+				const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
+				const bool newtonian = p.rheology == SPHX_NEWTONIAN;
+				// fluid <- fluid (VERT false) and fluid <- vertex (VERT true: the viscous term sees relVel + relEulerVel, :2494-2507)
+				auto particle_pair = [&](bool VERT, uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+					if (!is_active_w(npos.w)) return;
+					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+					if (r >= p.influenceradius) return;
+					const float4 nvel = a.vel[j];
+					const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+					const float vel_dot_pos = sa_dot3(vx, vy, vz, rx, ry, rz);
+					const float qm2 = r/p.slength - 2.0f;
+					const float f = qm2*qm2*qm2*p.fcoeff;
+					const uint32_t nfl = FLUID_NUM(a.info[j]);
+					const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+					const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
+					const float nmass = npos.w;
+					if (!density_sum) force.w += nmass*vel_dot_pos*f;
+					const float s = (p_precalc + n_precalc)*nmass*f;
+					float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+					dx -= s*rx; dy -= s*ry; dz -= s*rz;
+					if (newtonian) {
+						float wx = vx, wy = vy, wz = vz;
+						if (VERT) { const float4 ne = a.eulerVel[j]; wx = vx + (p_euler.x - ne.x); wy = vy + (p_euler.y - ne.y); wz = vz + (p_euler.z - ne.z); }
+						const float vf = sa_visc_avg(p, p.visccoeff[fl], p.visccoeff[nfl], p_rho, n_rho, nmass)*f;
+						dx += vf*wx; dy += vf*wy; dz += vf*wz;
+					}
+					force.x += dx; force.y += dy; force.z += dz;
+				};
+				for_each_neib<PT_FLUID>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &np_, float rx, float ry, float rz) { particle_pair(false, j, np_, rx, ry, rz); });
+				for_each_neib<PT_VERTEX>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &np_, float rx, float ry, float rz) { particle_pair(true, j, np_, rx, ry, rz); });
+				for_each_neib<PT_BOUNDARY>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+					if (!is_active_w(npos.w)) return;
+					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+					if (r >= p.influenceradius + a.deltap) return;
+					const particleinfo ninfo = a.info[j];
+					const float4 nvel = a.vel[j];
+					const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+					const float4 ne = a.eulerVel[j];
+					const float wx = vx + (p_euler.x - ne.x), wy = vy + (p_euler.y - ne.y), wz = vz + (p_euler.z - ne.z);
+					const uint32_t nfl = FLUID_NUM(ninfo);
+					const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+					const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
+					const float4 be = a.boundElement[j];
+					const V3 ns = v3(be.x, be.y, be.z);
+					const float inv_h = 1.0f/p.slength;
+					WallTri tri;
+					wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+					const float ggamAS = wall_grad_gamma(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
+					const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
+					if (a.cflGamma) {
+						const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
+						const float vs = sa_dot3(vel.x - vx, vel.y - vy, vel.z - vz, be.x, be.y, be.z);
+						gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
+						// compute_gamma_cfl_open_boundary (:1485-1497): n.(v_a + relEulerVel), n.(v_s - relEulerVel)
+						const float ex = wx - vx, ey = wy - vy, ez = wz - vz;
+						const float a1 = sa_dot3(vel.x + ex, vel.y + ey, vel.z + ez, be.x, be.y, be.z);
+						const float a2 = sa_dot3(-vx + vel.x - ex, -vy + vel.y - ey, -vz + vel.z - ez, be.x, be.y, be.z);
+						gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(a1), fabsf(a2)));
+					}
+					if (!density_sum) { float DrDt = 0.0f; DrDt -= p_rho*vn*ggamAS; force.w += DrDt; }
+					const float ps = (p_precalc + n_precalc)*n_rho*ggamAS;
+					float dx = 0.0f, dy = 0.0f, dz = 0.0f;
+					dx += ps*be.x; dy += ps*be.y; dz += ps*be.z;
+					if (newtonian) {      // compute_laminar_visc_contrib, boundary term (:2680-2718) with open boundaries
+						const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
+						const float wn = IS_IO_BOUNDARY(ninfo) ? 0.0f : sa_dot3(wx, wy, wz, be.x, be.y, be.z);
+						const float tx = wx - wn*be.x, ty = wy - wn*be.y, tz = wz - wn*be.z;
+						const float our_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl]*p_rho : p.visccoeff[fl];
+						const float neib_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl]*n_rho : p.visccoeff[nfl];
+						const float avg = (p.avgop == SPHX_ARITHMETIC) ? (our_mu + neib_mu)*0.5f :
+							(p.avgop == SPHX_HARMONIC) ? 2*our_mu*neib_mu/(our_mu + neib_mu) : sqrtf(our_mu*neib_mu);
+						const float c = ggamAS*2*avg/r_as;
+						const float inv_rho = 1.0f/p_rho;
+						dx -= (c*tx)*inv_rho; dy -= (c*ty)*inv_rho; dz -= (c*tz)*inv_rho;
+					}
+					force.x += dx; force.y += dy; force.z += dz;
+				});
+				const float gam = a.gGam[index].w;
+				force.x /= gam; force.y /= gam; force.z /= gam; force.w /= gam;
+				force.w /= p.rho0[fl];
+				force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
+				if (p.simflags & SPHX_ENABLE_DTADAPT) {
+					const float sspeed = sa_sound_speed(p, vel.w, fl);
+					const float acc = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
+					cflTerm = fmaxf(acc, sspeed*sspeed/p.slength);
+				}
+			}
+			a.forces[index] = force;
+		}
+		if (a.cflGamma) a.cflGamma[index] = gammaCfl;
+	}
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) {
+		cflTerm = fmaxf(cflTerm, __shfl_down(cflTerm, d));
+		gammaCfl = fmaxf(gammaCfl, __shfl_down(gammaCfl, d));
+	}
+	if ((threadIdx.x & 63u) == 0u) { sMax[threadIdx.x >> 6] = cflTerm; sMaxG[threadIdx.x >> 6] = gammaCfl; }
+	__syncthreads();
+	if (threadIdx.x == 0 && a.cfl && (p.simflags & SPHX_ENABLE_DTADAPT)) {
+		float m = sMax[0], mg = sMaxG[0];
+		for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) { m = fmaxf(m, sMax[w]); mg = fmaxf(mg, sMaxG[w]); }
+		a.cfl[a.cflOffset + blockIdx.x] = m;
+		if (a.cflGammaBlocks) a.cflGammaBlocks[a.cflOffset + blockIdx.x] = mg;
+	}
+}
+
+extern "C" int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces, const void *oldPos, const void *newPos,
+	const void *oldVel, const void *oldEulerVel, const void *oldGGam, const void *boundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_bc_check(ctx, "density_sum called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldEulerVel && oldGGam && boundElements && vertPos0 && vertPos1 &&
+		vertPos2 && info && hash && cellStart && neibsList, "sphx_sa_density_sum_io: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIoDensitySumArgs a = { (float4*)newVel, (float4*)newGGam, (float4*)forces, (const float4*)oldPos, (const float4*)newPos,
+		(const float4*)oldVel, (const float4*)oldEulerVel, (const float4*)oldGGam, (const float4*)boundElements,
+		{ (const float2*)vertPos0, (const float2*)vertPos1, (const float2*)vertPos2 }, (const particleinfo*)info, hash, cellStart,
+		neibsList, particleRangeEnd, dt };
+	sa_density_sum_io_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_density_sum_io_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, const void *pos, const void *vel,
+	const void *eulerVel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, float deltap, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream)
+{
+	int rc = sa_io_bc_check(ctx, "forces called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(forces && pos && vel && eulerVel && info && hash && cellStart && neibsList && gGam && boundElements && vertPos0 && vertPos1 && vertPos2,
+		"sphx_forces_basicstep_sa_io: missing buffer");
+	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_forces_basicstep_sa_io: invalid particle range");
+	const uint32_t numBlocks = round_up_u(div_up_u(toParticle - fromParticle, SPHX_BLOCK_FORCES), 4u);
+	if (h_numBlocks) *h_numBlocks = numBlocks;
+	if (!numBlocks) return SPHX_OK;
+	const bool dtadapt = (ctx->dev.simflags & SPHX_ENABLE_DTADAPT) != 0;
+	if (dtadapt) SPHX_REQUIRE(cfl != nullptr, "sphx_forces_basicstep_sa_io: ENABLE_DTADAPT needs the CFL buffer");
+	const bool gcfl = cflGamma && dtadapt && !(ctx->dev.simflags & SPHX_ENABLE_GAMMA_QUADRATURE);
+	SaIoForcesArgs a = {};
+	a.forces = (float4*)forces; a.cfl = dtadapt ? cfl : nullptr;
+	a.cflGamma = gcfl ? cflGamma : nullptr; a.cflGammaBlocks = gcfl ? cflGamma + round_up_u(numParticles, 4u) : nullptr;
+	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.eulerVel = (const float4*)eulerVel; a.gGam = (const float4*)gGam;
+	a.boundElement = (const float4*)boundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
+	sa_forces_io_kernel<<<numBlocks, SPHX_BLOCK_FORCES, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_forces_io_kernel");
+	return SPHX_OK;
+}

@@ -329,6 +329,22 @@ int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, void *newPos
 	uint32_t *nextIDs, uint32_t *newNumParticles, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t totParticles, float deltap, float dt, int step,
 	uint32_t numOpenVertices, void *stream);
+/* density_sum and the forces of SA_BOUNDARY with open boundaries (src/cuda/density_sum.cu + density_sum_kernel.cu:119-140,206-250,
+ * 374-420,606-655; src/cuda/forces.cu:751-795 + forces_kernel.def:1485-1497,2494-2507,2703-2708; laminar or inviscid, Wendland,
+ * one thread per particle over the list).  WRITTEN, NOT YET RUN ON A GPU (see sphx_sa_segment_bc_io).
+ * sphx_sa_density_sum_io: sphx_sa_density_sum with the open boundaries' terms; oldEulerVel = BUFFER_EULERVEL of step n; dt = the
+ *   integration interval of the Euler step just taken.  forces.w receives the volumic sums, as in sphx_sa_density_sum.
+ * sphx_forces_basicstep_sa_io: sphx_forces_basicstep_sa (SPHX_SIMULATE) with BUFFER_EULERVEL in the viscous terms and the gamma CFL;
+ *   cfl / cflGamma as there (cflGamma: one value per particle, then one per block from round_up(numParticles, 4) on) */
+int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces, const void *oldPos, const void *newPos,
+	const void *oldVel, const void *oldEulerVel, const void *oldGGam, const void *boundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream);
+int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, const void *pos, const void *vel,
+	const void *eulerVel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, float deltap, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream);
 /* saInitGamma (src/cuda/boundary_conditions.cu:457-560): gamma and grad gamma of fluid and vertex particles at initialisation,
  * grad gamma from the analytical formula of a triangular element, gamma by Gauss quadrature / solid angles
  * (src/cuda/gamma.cuh).  Rows of boundary elements are not written.  oldGGam is accepted for interface parity (unused). */

@@ -197,3 +197,67 @@ def test_boundary_condition_passes_with_open_boundaries():
             assert (_np(d_ev)[n:n2] == 0).all() and (_np(d_vert, np.uint32).reshape(-1, 4)[n:n2] == 0).all()
             assert np.isnan(_np(d_be2)[n:n2]).all()
             assert np.array_equal(_np(d_ids, np.uint32)[:n], a["next_ids"][:n])
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SPHX_TEST_SA_IO_BC") != "1",
+                    reason="sa_density_sum_io / sa_forces_io were written at the end of round 4 and have not run on a GPU yet")
+def test_density_summation_and_forces_with_open_boundaries():
+    """sphx_sa_density_sum_io and sphx_forces_basicstep_sa_io against the oracle on the uniform stream through an inlet of
+    tests/test_sa_io_oracle.py (to the tolerance of the SA engines: the product's |grad gamma_as| is its own formulation)."""
+    import torch
+    from gpusph_amd.engine import TimestepEngine
+    from sa_helpers import assert_close_but_for_gamma_spikes, wall_rows
+    kw = dict(deltap=0.05)
+    st = sa_oracle_state(**kw)
+    eng = TimestepEngine(SABox(**kw), device="cuda:0", clobber_neibslist=False)
+    eng.build_neibs()
+    p, o, n = st["problem"], st["oracle"], st["n"]
+    dev = eng.device
+    lib, h, P = eng.k.lib, eng.k.ctx.handle, capi.ptr
+    dp, U, dt = p.m_deltap, 0.2, 1.0e-3
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    fl = t == D.PT_FLUID
+    seg = (t == D.PT_BOUNDARY) & (st["boundelements"][:, 0] > 0.5) & (np.abs(g[:, 0]) < 1e-6)
+    vtx = (t == D.PT_VERTEX) & (np.abs(g[:, 0]) < 1e-6)
+    info = st["info"].copy()
+    info[seg | vtx, 0] |= D.FG_INLET | D.FG_VELOCITY_DRIVEN
+    info[seg | vtx, 1] = (info[seg | vtx, 1] & 0xF000) | 1
+    be = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], st["info"], st["hash"], st["cs"], st["nl"], n)
+    gg = o.sa_init_gamma(st["gradgamma"], st["pos"], be, st["vertpos"], st["info"], st["hash"], st["cs"], st["nl"], n, dp)
+    vel = st["vel"].copy(); vel[fl, 0] = U
+    ev = np.zeros_like(vel); ev[seg | vtx, 0] = U
+    new_pos = st["pos"].copy(); new_pos[fl, 0] = st["pos"][fl, 0] + np.float32(dt) * np.float32(U)
+
+    def up(a, like):
+        out = torch.zeros_like(like)
+        out[:n] = torch.from_numpy(np.ascontiguousarray(a)).to(dev).view(like.dtype).reshape((n,) + tuple(like.shape[1:]))
+        return out
+    d_info, d_be, d_gg = up(info.view(np.int16), eng.info), up(be, eng.boundelements), up(gg, eng.gradgamma)
+    d_vel, d_ev, d_new = up(vel, eng.vel), up(ev, eng.vel), up(new_pos, eng.pos)
+    wall = wall_rows(p, st["nl"], info, n)
+    # density summation
+    want_v, want_g, want_s = o.sa_density_sum_io(vel, st["pos"], new_pos, vel, ev, gg, be, st["vertpos"], info, st["hash"], st["cs"],
+                                                 st["nl"], n, dt)
+    d_nv, d_ng, d_f = d_vel.clone(), torch.zeros_like(eng.gradgamma), torch.zeros_like(eng.pos)
+    capi.check(lib.sphx_sa_density_sum_io(h, P(d_nv), P(d_ng), P(d_f), P(eng.pos), P(d_new), P(d_vel), P(d_ev), P(d_gg), P(d_be),
+                                          P(eng.vertpos[0]), P(eng.vertpos[1]), P(eng.vertpos[2]), P(d_info), P(eng.hash), P(eng.cellStart),
+                                          P(eng.neibslist), n, n, float(np.float32(dt)), None))
+    assert np.abs(_np(d_f)[:n][fl, 3] - want_s[fl]).max() < 2e-5 * np.abs(want_s[fl]).max() + 1e-3
+    assert_close_but_for_gamma_spikes(_np(d_nv)[:n][fl, 3], want_v[fl, 3], 2e-6, 1.0, what="density after the summation", wall=wall[fl])
+    assert_close_but_for_gamma_spikes(_np(d_ng)[:n][fl], want_g[fl], 2e-5, np.abs(want_g[fl, :3]).max(), what="gamma after the summation", wall=wall[fl])
+    # forces
+    want_f, want_cfl, nb = o.forces_sa_io(st["pos"], vel, ev, info, st["hash"], st["cs"], st["nl"], gg, be, st["vertpos"], n, dp)
+    d_forces = torch.zeros_like(eng.pos)
+    nblk = eng.k.fmax_elements(eng.alloc)
+    d_cfl = torch.zeros(nblk, dtype=torch.float32, device=dev)
+    d_cflg = torch.zeros(((eng.alloc + 3) // 4) * 4 + nblk, dtype=torch.float32, device=dev)
+    import ctypes as C
+    hnb = C.c_uint32(0)
+    capi.check(lib.sphx_forces_basicstep_sa_io(h, P(d_forces), P(d_cfl), P(d_cflg), P(eng.pos), P(d_vel), P(d_ev), P(d_info), P(eng.hash),
+                                               P(eng.cellStart), P(eng.neibslist), P(d_gg), P(d_be), P(eng.vertpos[0]), P(eng.vertpos[1]),
+                                               P(eng.vertpos[2]), n, 0, n, float(np.float32(dp)), 0, C.addressof(hnb), None))
+    assert hnb.value == nb
+    scale = np.abs(want_f[fl, :3]).max()
+    assert_close_but_for_gamma_spikes(_np(d_forces)[:n][fl, :3], want_f[fl, :3], 3e-5, scale, what="forces with open boundaries", wall=wall[fl])
+    assert np.abs(_np(d_cfl)[:nb] - want_cfl[:nb]).max() < 1e-4 * np.abs(want_cfl[:nb]).max()
