@@ -120,14 +120,15 @@ def test_boundary_condition_passes_with_open_boundaries():
     from gpusph_amd.engine import TimestepEngine
     kw = dict(deltap=0.05)
     st = sa_oracle_state(**kw)
-    eng = TimestepEngine(SABox(**kw), device="cuda:0", clobber_neibslist=False)
-    eng.build_neibs()
     p, o, n = st["problem"], st["oracle"], st["n"]
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    room = int(((t == D.PT_VERTEX) & (np.abs(g[:, 0]) < 1e-6)).sum())           # one released particle per open vertex at most
+    eng = TimestepEngine(SABox(**kw), device="cuda:0", allocated=n + room, clobber_neibslist=False)
+    eng.build_neibs()
     dev = eng.device
     lib, h, P = eng.k.lib, eng.k.ctx.handle, capi.ptr
     dp, U, dt = p.m_deltap, 0.2, 2.0e-3
-    g = p.global_pos(st["pos"], st["hash"])
-    t = info_type(st["info"])
     seg = (t == D.PT_BOUNDARY) & (st["boundelements"][:, 0] > 0.5) & (np.abs(g[:, 0]) < 1e-6)
     vtx = (t == D.PT_VERTEX) & (np.abs(g[:, 0]) < 1e-6)
     info = st["info"].copy()
