@@ -19,6 +19,7 @@
 #define FG_VELOCITY_DRIVEN   (PART_FLAG_START << 4)
 #define FG_CORNER            (PART_FLAG_START << 5)
 #define IS_IO_BOUNDARY(f)    ((f).x & (FG_INLET | FG_OUTLET))
+#define IS_VEL_IO(f)         ((f).x & FG_VELOCITY_DRIVEN)
 #define IS_CORNER(f)         ((f).x & FG_CORNER)
 #define SA_IO_MAXNEIBVERTS 30       // boundary_conditions_kernel.cu:1977
 
@@ -965,5 +966,150 @@ extern "C" int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *c
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
 	sa_forces_io_kernel<<<numBlocks, SPHX_BLOCK_FORCES, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_forces_io_kernel");
+	return SPHX_OK;
+}
+
+// ==========================================================================================
+// The Brezzi diffusion with open boundaries and the water depth at the pressure-driven ones: computeDensityDiffusionDevice
+// with ENABLE_INLET_OUTLET (forces_kernel.def:4536-4582; the boundary term :1836-1852) and what forcesDevice<PT_VERTEX, PT_FLUID>
+// leaves behind with ENABLE_WATER_DEPTH (:192-205, 1375-1389, 3285-3303).  One thread per particle over the list; the checkers
+// are orc_sa_density_diffusion_io / orc_sa_io_water_depth.  WRITTEN AT THE END OF ROUND 4, NOT YET RUN ON A GPU (see above).
+// ==========================================================================================
+struct SaIoDiffusionArgs {
+	float4 *forces;
+	const float4 *pos, *vel, *gGam, *boundElement;
+	const float2 *vertPos[3];
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	float dt, deltap;
+};
+
+__global__ void __launch_bounds__(128)
+sa_density_diffusion_io_kernel(DevParams p, SaIoDiffusionArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (index >= a.numParticles) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != PT_FLUID) return;
+	const float4 pos = a.pos[index];
+	if (!is_active_w(pos.w)) return;
+	const float4 vel = a.vel[index];
+	const uint32_t fl = FLUID_NUM(info);
+	const float rho = (vel.w + 1.0f)*p.rho0[fl];
+	const float pres = sa_P(p, vel.w, fl);
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	float DrDt = 0.0f;
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		if (!is_active_w(npos.w)) return;
+		if (r >= p.influenceradius) return;
+		const float4 nvel = a.vel[j];
+		const uint32_t nfl = FLUID_NUM(a.info[j]);
+		const float neib_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+		const float qm2 = r/p.slength - 2.0f;
+		const float f = qm2*qm2*qm2*p.fcoeff;
+		const float gdotr = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
+		float n = 0.0f;
+		n += p.densityDiffCoeff*((2.0f/(rho + neib_rho))*(pres - sa_P(p, nvel.w, nfl)) - gdotr)*npos.w/neib_rho*f*a.dt*2.0f*rho;
+		DrDt += n;
+	});
+	// the segments of PRESSURE-driven open boundaries: V_b grad W -> |grad gamma_as| / r_as, no diffusion coefficient, in double
+	// as the reference's literals make it (:1848)
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		if (!is_active_w(npos.w)) return;
+		if (r >= p.influenceradius + a.deltap) return;
+		const particleinfo ninfo = a.info[j];
+		if (!(IS_IO_BOUNDARY(ninfo) && !IS_VEL_IO(ninfo))) return;      // nout.DrDt stays 0: DrDt += 0 changes nothing
+		const float4 be = a.boundElement[j];
+		const V3 ns = v3(be.x, be.y, be.z);
+		const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
+		const float inv_h = 1.0f/p.slength;
+		WallTri tri;
+		wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+		const float ggamAS = wall_grad_gamma(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
+		const float nrt = a.vel[j].w;
+		const uint32_t nfl = FLUID_NUM(ninfo);
+		const float neib_rho = (nrt + 1.0f)*p.rho0[nfl];
+		const float gdotr = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
+		const double t = ((2.0/(rho + neib_rho))*(pres - sa_P(p, nrt, nfl)) - gdotr)*ggamAS/r_as*a.dt*2.0f*rho;
+		float n = 0.0f;
+		n = (float)(n - t);
+		DrDt += n;
+	});
+	DrDt /= a.gGam[index].w;
+	a.forces[index].w = DrDt/p.rho0[fl];
+}
+
+struct SaIoDepthArgs {
+	uint32_t *IOwaterdepth;
+	const float4 *pos;
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t fromParticle, toParticle;
+};
+
+__global__ void __launch_bounds__(128)
+sa_io_water_depth_kernel(DevParams p, SaIoDepthArgs a)
+{
+	const uint32_t index = blockIdx.x*128 + threadIdx.x + a.fromParticle;
+	if (index >= a.toParticle) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != PT_VERTEX) return;
+	const float4 pos = a.pos[index];
+	if (!is_active_w(pos.w)) return;
+	if (!(IS_IO_BOUNDARY(info) && !IS_VEL_IO(info))) return;      // skip_neiblist (:1375-1389)
+	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	uint32_t best = 0u;
+	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		(void)j;
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		if (!is_active_w(npos.w)) return;
+		if (r >= p.influenceradius) return;
+		if (rz < 0.0f) return;
+		float nZpos = pos.z - rz + gridPos.z*p.cs[2] + 0.5f*p.cs[2];
+		nZpos *= ((float)UINT_MAX)/(p.gs[2]*p.cs[2]);
+		const uint32_t u = (uint32_t)nZpos;
+		best = u > best ? u : best;
+	});
+	if (best) atomicMax(a.IOwaterdepth + OBJECT_NUM(info), best);      // a maximum: one atomic per vertex gives the same number
+}
+
+extern "C" int sphx_sa_compute_density_diffusion_io(sphx_ctx *ctx, void *forces, const void *pos, const void *vel, const void *gGam,
+	const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float dt, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_bc_check(ctx, "compute_density_diffusion called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	if (ctx->params.densitydiffusiontype != SPHX_BREZZI || !(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) ||
+		ctx->params.sph_formulation == SPHX_SPH_HA)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_compute_density_diffusion_io: built for Brezzi diffusion with density summation");
+	SPHX_REQUIRE(forces && pos && vel && gGam && boundElements && vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList,
+		"sphx_sa_compute_density_diffusion_io: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaIoDiffusionArgs a = { (float4*)forces, (const float4*)pos, (const float4*)vel, (const float4*)gGam, (const float4*)boundElements,
+		{ (const float2*)vertPos0, (const float2*)vertPos1, (const float2*)vertPos2 }, (const particleinfo*)info, hash, cellStart,
+		neibsList, particleRangeEnd, dt, deltap };
+	sa_density_diffusion_io_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_density_diffusion_io_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_io_water_depth(sphx_ctx *ctx, uint32_t *IOwaterdepth, const void *pos, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, void *stream)
+{
+	int rc = sa_io_bc_check(ctx, "the water depth is measured with SA_BOUNDARY only");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(IOwaterdepth && pos && info && hash && cellStart && neibsList, "sphx_sa_io_water_depth: missing buffer");
+	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_sa_io_water_depth: invalid particle range");
+	if (fromParticle == toParticle) return SPHX_OK;
+	SaIoDepthArgs a = { IOwaterdepth, (const float4*)pos, (const particleinfo*)info, hash, cellStart, neibsList, fromParticle, toParticle };
+	sa_io_water_depth_kernel<<<div_up_u(toParticle - fromParticle, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_io_water_depth_kernel");
 	return SPHX_OK;
 }

@@ -345,6 +345,22 @@ int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *cfl, float *
 	const void *eulerVel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, float deltap, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream);
+/* The Brezzi diffusion with open boundaries and the water depth at the pressure-driven ones.  WRITTEN, NOT YET RUN ON A GPU (see
+ * sphx_sa_segment_bc_io); the checkers are orc_sa_density_diffusion_io / orc_sa_io_water_depth.
+ * sphx_sa_compute_density_diffusion_io: computeDensityDiffusionDevice with ENABLE_INLET_OUTLET (src/cuda/forces.cu
+ *   compute_density_diffusion + forces_kernel.def:4536-4582): sphx_sa_compute_density_diffusion plus the boundary term of the
+ *   segments of pressure-driven open boundaries (:1836-1852), which reads the elements and their vertices' positions.
+ * sphx_sa_io_water_depth: what forcesDevice<PT_VERTEX, PT_FLUID> leaves in IOwaterdepth with ENABLE_WATER_DEPTH (vertex_forces,
+ *   src/cuda/forces.cu:676-686; forces_kernel.def:192-205, 1375-1389, 3285-3303): per open boundary (the object number of its
+ *   vertices) the largest height of a fluid particle below one of its pressure-driven vertices, scaled to [0, UINT_MAX] over the
+ *   domain's height.  IOwaterdepth (device, one uint per open boundary) is an atomicMax target: the caller clears it, as the
+ *   problem's imposeBoundaryConditionHost does (src/problems/CompleteSaExample.cu:323-325). */
+int sphx_sa_compute_density_diffusion_io(sphx_ctx *ctx, void *forces, const void *pos, const void *vel, const void *gGam,
+	const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float dt, void *stream);
+int sphx_sa_io_water_depth(sphx_ctx *ctx, uint32_t *IOwaterdepth, const void *pos, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, void *stream);
 /* saInitGamma (src/cuda/boundary_conditions.cu:457-560): gamma and grad gamma of fluid and vertex particles at initialisation,
  * grad gamma from the analytical formula of a triangular element, gamma by Gauss quadrature / solid angles
  * (src/cuda/gamma.cuh).  Rows of boundary elements are not written.  oldGGam is accepted for interface parity (unused). */

@@ -1434,8 +1434,8 @@ uint32_t orc_forces_sa(const orc_params *p, orc_f4 *forces, float *cfl, float *c
 }
 /* the same three launches with ENABLE_INLET_OUTLET (laminar): the viscous terms see the Eulerian velocity of the open boundaries'
  * vertices and segments (get_viscous_relVel :2494-2507; against an open segment the whole relative velocity, :2703-2708), the
- * gamma CFL condition their normal velocity (:1485-1497).  GROUNDWORK ("Open boundaries" at the end of the file); not restated:
- * the forces pass of the pressure-driven open vertices (skip_neiblist :1375-1389), the water depth (:192-205, 3285-3330) */
+ * gamma CFL condition their normal velocity (:1485-1497).  GROUNDWORK ("Open boundaries" at the end of the file).  The forces
+ * pass of the pressure-driven open vertices (skip_neiblist :1375-1389) leaves the water depth only: orc_sa_io_water_depth */
 uint32_t orc_forces_sa_io(const orc_params *p, orc_f4 *forces, float *cfl, float *cflGamma,
 	const orc_f4 *pos, const orc_f4 *vel, const orc_f4 *eulerVel, const orc_info *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList,
@@ -3363,8 +3363,9 @@ float orc_sa_gamma_dt(float dt, float max_gamma_cfl)
  * Open boundaries of SA_BOUNDARY (the half that is NOT built): GROUNDWORK ONLY.
  * The leaf functions and the initialisation kernels of ENABLE_INLET_OUTLET, restated so that the engines of a later round
  * have their checker; the product (libsphx) has no counterpart of anything below and answers SPHX_ERR_UNSUPPORTED.
- * Not restated yet: the IO branches of saSegment/VertexBoundaryConditions (:1427-1545, 2197-2270), findOutgoingSegment (:1647),
- * particle creation, the IO branches of density_sum / forces / Euler, the water depth.  Parity unpinned (no reference fixture
+ * Further down, added later in the round: the IO branches of saSegment/VertexBoundaryConditions (:1427-1545, 2197-2270) with
+ * particle creation, findOutgoingSegment (:1647), the IO branches of density_sum and of the forces, the water depth and the
+ * Brezzi term of pressure-driven segments.  Not restated: the download / maximum over devices / upload of the water depth.  Parity unpinned (no reference fixture
  * holds these; the known answers are in tests/test_sa_io_oracle.py).
  * ==================================================================================================== */
 #define FG_INLET             (PART_FLAG_START << 2)      /* src/particleinfo.h:153-156 */
@@ -4026,5 +4027,123 @@ void orc_sa_density_sum_io(const orc_params *p, orc_f4 *newVel, orc_f4 *newGGam,
 			g.w = 0.1f;
 		newVel[index].w = rho/p->rho0[fl] - 1.0f;
 		newGGam[index] = g;
+	}
+}
+
+/* Water depth at the pressure-driven open boundaries: the one thing forcesDevice<PT_VERTEX, PT_FLUID> leaves behind when
+ * ENABLE_INLET_OUTLET | ENABLE_WATER_DEPTH are set and the model is not k-epsilon (vertex_forces, src/cuda/forces.cu:676-686;
+ * needs_waterdepth, forces_kernel.def:192-205; skip_neiblist :1375-1389: only the vertices of PRESSURE-driven open boundaries
+ * walk their lists; compute_water_depth_at_outflow :3285-3303).  Of every fluid neighbour in range that is not above the vertex,
+ * the height above the bottom of the domain is scaled to [0, UINT_MAX] and the maximum per open boundary (the object number of
+ * the vertex) is kept: IOwaterdepth[numOpenBoundaries] is an atomicMax target, so it is updated and never cleared here (the
+ * problem's imposeBoundaryConditionHost clears it, problems/CompleteSaExample.cu:323-325).  GROUNDWORK (see above). */
+void orc_sa_io_water_depth(const orc_params *p, uint32_t *IOwaterdepth, const orc_f4 *posArray, const orc_info *infoArray,
+	const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle)
+{
+	/* serial: the reduction is a max, its result does not depend on the order, and the lists of the vertices are short */
+	for (uint32_t index = fromParticle; index < toParticle; ++index) {
+		const orc_info info = infoArray[index];
+		if (!VERTEX(info)) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		if (!(IO_BOUNDARY(info) && !VEL_IO(info))) continue;        /* skip_neiblist */
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+			if (INACTIVE(npos)) continue;
+			if (r >= p->influenceradius) continue;          /* forcesDevice's range test for a non-boundary neighbour */
+			if (rz < 0.0f) continue;                        /* the fluid particle is higher than the vertex */
+			float nZpos = pos.z - rz + gridPos[2]*p->cellSize[2] + 0.5f*p->cellSize[2];
+			nZpos *= ((float)UINT_MAX)/(p->gridSize[2]*p->cellSize[2]);
+			const uint32_t u = (uint32_t)nZpos;
+			if (u > IOwaterdepth[OBJECT_NUM(info)]) IOwaterdepth[OBJECT_NUM(info)] = u;
+		}
+	}
+}
+
+/* what the problem's boundary-condition kernel makes of it (problems/CompleteSaExample.cu:266-272): an absolute z */
+float orc_sa_io_water_depth_z(const orc_params *p, uint32_t waterdepth)
+{
+	float z = ((float)waterdepth)/((float)UINT_MAX);
+	z *= p->cellSize[2]*p->gridSize[2];
+	z += p->worldOrigin[2];
+	return z;
+}
+
+/* computeDensityDiffusionDevice with ENABLE_INLET_OUTLET (forces_kernel.def:4536-4582): orc_sa_density_diffusion plus the
+ * boundary term of the Brezzi diffusion on the segments of PRESSURE-driven open boundaries (:1836-1852): the fluid term with
+ * V_b grad W replaced by |grad gamma_as| / r_as, r_as = max(|n_s . r_as|, deltap) (sa_boundary_neib_data :1133-1149), WITHOUT
+ * the diffusion coefficient, evaluated in double (the literals 2.0 of :1848 promote the whole product) and subtracted.
+ * Segments are in range up to influenceradius + deltap (:4476-4478).  GROUNDWORK (see above). */
+void orc_sa_density_diffusion_io(const orc_params *p, orc_f4 *forces, const orc_f4 *posArray, const orc_f4 *velArray,
+	const orc_f4 *gGamArray, const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart,
+	const uint16_t *neibsList, const orc_f4 *boundelem, const float *vertPos0, const float *vertPos1, const float *vertPos2,
+	uint32_t particleRangeEnd, float dt, float deltap)
+{
+	const float fcoeff = orc_fcoeff(p->kerneltype, p->slength, 2.0f);
+#pragma omp parallel for schedule(dynamic, 256)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!FLUID(info)) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		const orc_f4 vel = velArray[index];
+		const int fl = FLUID_NUM(info);
+		const float rho = physical_density(p, vel.w, fl);
+		const float pres = orc_P(p, vel.w, fl);
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		float DrDt = 0.0f;
+		neib_iter it;
+		uint32_t neib_index;
+		neib_iter_init(&it, p, PT_FLUID, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+			if (INACTIVE(npos)) continue;
+			if (r >= p->influenceradius) continue;
+			const orc_f4 nvel = velArray[neib_index];
+			const int nfl = FLUID_NUM(infoArray[neib_index]);
+			const float neib_rho = physical_density(p, nvel.w, nfl);
+			const float f = F_c(p->kerneltype, r, p->slength, fcoeff);
+			const float gdotr = p->gravity[0]*rx + p->gravity[1]*ry + p->gravity[2]*rz;
+			float nDrDt = 0.0f;
+			nDrDt += p->densityDiffCoeff*((2.0f/(rho + neib_rho))*(pres - orc_P(p, nvel.w, nfl)) - gdotr)*npos.w/neib_rho*f*dt*2.0f*rho;
+			DrDt += nDrDt;
+		}
+		neib_iter_init(&it, p, PT_BOUNDARY, index, &pos, gridPos, cellStart, neibsList);
+		while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+			const orc_f4 npos = posArray[neib_index];
+			const float rx = it.pos_corr[0] - npos.x, ry = it.pos_corr[1] - npos.y, rz = it.pos_corr[2] - npos.z;
+			const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+			if (INACTIVE(npos)) continue;
+			if (r >= p->influenceradius + deltap) continue;
+			const orc_info neib_info = infoArray[neib_index];
+			/* the element, its r_as and |grad gamma_as| are made for every segment in range (the output struct's constructor) */
+			const orc_f4 belem = boundelem[neib_index];
+			const float r_as = fmaxf(fabsf(dot3(rx, ry, rz, belem.x, belem.y, belem.z)), deltap);
+			const float inv_h = 1.0f/p->slength;
+			const float ggamAS = orc_grad_gamma_vp(p->slength, rx*inv_h, ry*inv_h, rz*inv_h, &belem,
+				vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index, vertPos2 + 2*(size_t)neib_index);
+			float nDrDt = 0.0f;
+			if (IO_BOUNDARY(neib_info) && !VEL_IO(neib_info)) {
+				const float nrt = velArray[neib_index].w;
+				const int nfl = FLUID_NUM(neib_info);
+				const float neib_rho = physical_density(p, nrt, nfl);
+				const float gdotr = p->gravity[0]*rx + p->gravity[1]*ry + p->gravity[2]*rz;
+				const double t = ((2.0/(rho + neib_rho))*(pres - orc_P(p, nrt, nfl)) - gdotr)*ggamAS/r_as*dt*2.0f*rho;
+				nDrDt = (float)(nDrDt - t);
+			}
+			DrDt += nDrDt;
+		}
+		DrDt /= gGamArray[index].w;
+		forces[index].w = DrDt/p->rho0[fl];
 	}
 }

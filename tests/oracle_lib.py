@@ -449,6 +449,27 @@ class Oracle:
                                      P(cs), P(nl), C.c_uint32(n), C.c_float(dt))
         return v, g, scratch[:, 3].copy()
 
+    def sa_density_diffusion_io(self, pos, vel, ggam, info, hash_, cs, nl, boundelements, vertpos, n, dt, deltap):
+        """the Brezzi diffusion with open boundaries enabled: (updated velocity, forces with the diffusion in .w)"""
+        f = np.zeros((len(pos), 4), dtype=np.float32)
+        self.L.orc_sa_density_diffusion_io(C.byref(self.p), P(f), P(pos), P(vel), P(ggam), P(info), P(hash_), P(cs), P(nl),
+                                           P(boundelements), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), C.c_uint32(n),
+                                           C.c_float(dt), C.c_float(deltap))
+        v = vel.copy()
+        fluid = (info[:n, 0] & 7) == 0
+        v[:n][fluid, 3] = v[:n][fluid, 3] + f[:n][fluid, 3] * np.float32(dt)
+        return v, f
+
+    def sa_io_water_depth(self, depth, pos, info, hash_, cs, nl, n, frm=0):
+        """the water depth the vertex pass of the forces leaves behind: depth (uint32 per open boundary) is updated in place"""
+        self.L.orc_sa_io_water_depth(C.byref(self.p), P(depth), P(pos), P(info), P(hash_), P(cs), P(nl), C.c_uint32(frm),
+                                     C.c_uint32(n))
+        return depth
+
+    def sa_io_water_depth_z(self, u):
+        self.L.orc_sa_io_water_depth_z.restype = C.c_float
+        return float(self.L.orc_sa_io_water_depth_z(C.byref(self.p), C.c_uint32(int(u))))
+
     def disable_outgoing_parts(self, pos, vertices, info, n):
         p2, v2 = pos.copy(), vertices.copy()
         self.L.orc_disable_outgoing_parts(P(p2), P(v2), P(info), C.c_uint32(n))

@@ -241,8 +241,14 @@ class OracleSaIoSim:
     inlet vertex releases exist from the next rebuild on -- and the imposed values of that problem's callback (:104-131).
     GROUNDWORK: the checker of engines that are not built yet; nothing in the product mirrors it."""
 
-    def __init__(self, problem, U, room=1.6):
+    def __init__(self, problem, U, room=1.6, brezzi=False, water_depth=False):
+        """brezzi: the Brezzi diffusion after every density summation (its open-boundary term on the pressure outlet);
+        water_depth: ENABLE_WATER_DEPTH -- the outlet's hydrostatic pressure follows the level the vertex pass of the forces
+        measured, as ChannelIO's callback does (:124-127), instead of the still water level"""
         self.problem, self.U = problem, float(U)
+        self.brezzi, self.water_depth = brezzi, water_depth
+        self.depth = np.zeros(3, dtype=np.uint32)             # IOwaterdepth[numOpenBoundaries + 1]: objects 1 (inlet) and 2 (outlet)
+        self.level_seen = []
         p = problem
         a = p.copy_to_array()
         n0 = p.num_particles
@@ -317,9 +323,34 @@ class OracleSaIoSim:
         ev[rows, 0] = np.float32(self.U)
         rows = np.where(io & ~vdriven)[0]
         z = p.global_pos(pos[:n], self.hash[:n])[rows, 2]
-        pres = np.float32(9.81) * np.maximum(np.float32(p.water_level) - z.astype(np.float32), np.float32(0)) * np.float32(p.physparams.rho0[0])
+        level = np.float32(p.water_level)
+        if self.water_depth:
+            # <Problem>_imposeBoundaryConditionDevice (problems/CompleteSaExample.cu:266-272): the scaled maximum back to a height;
+            # imposeBoundaryConditionHost clears the array after the launch (:323-325)
+            level = np.float32(self.o.sa_io_water_depth_z(self.depth[2]))
+            self.level_seen.append(float(level))
+            self.depth[:] = 0
+        pres = np.float32(9.81) * np.maximum(level - z.astype(np.float32), np.float32(0)) * np.float32(p.physparams.rho0[0])
         ev[rows, 3] = [self.o.eos_RHO(float(x)) for x in pres]
         return vel, ev
+
+    def _forces(self, pos, vel, ev, gg):
+        """the forces of one half step; with ENABLE_WATER_DEPTH the vertex pass that follows the fluid's (vertex_forces,
+        src/cuda/forces.cu:676-686) leaves the water depth of the pressure-driven open boundaries"""
+        o, n = self.o, self.n
+        out = o.forces_sa_io(pos, vel, ev, self.info, self.hash, self.cs, self.nl, gg, self.be, self.vertpos, n, self.problem.m_deltap)
+        if self.water_depth:
+            o.sa_io_water_depth(self.depth, pos, self.info, self.hash, self.cs, self.nl, n)
+        return out
+
+    def _density(self, vs, ps, dt):
+        """density summation (+ the Brezzi diffusion with the open boundaries' term) on the moved particles"""
+        o, n = self.o, self.n
+        A = (self.hash, self.cs, self.nl)
+        vs, gs, _ = o.sa_density_sum_io(vs, self.pos, ps, self.vel, self.ev, self.gg, self.be, self.vertpos, self.info, *A, n, dt)
+        if self.brezzi:
+            vs, _ = o.sa_density_diffusion_io(ps, vs, gs, self.info, *A, self.be, self.vertpos, n, dt, self.problem.m_deltap)
+        return vs, gs
 
     def _rebuild(self):
         o = self.o
@@ -358,19 +389,19 @@ class OracleSaIoSim:
         dt = float(np.float32(self.dt)); hdt = float(np.float32(dt) / np.float32(2))
         infl = float(p.simparams.influenceRadius)
         # predictor
-        f1, cfl, nb = o.forces_sa_io(self.pos, self.vel, self.ev, self.info, *A, self.gg, self.be, self.vertpos, n, dp)
+        f1, cfl, nb = self._forces(self.pos, self.vel, self.ev, self.gg)
         dt1 = self._dtmin(cfl, nb)
         ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, hdt, 1)
-        vs, gs, _ = o.sa_density_sum_io(vs, self.pos, ps, self.vel, self.ev, self.gg, self.be, self.vertpos, self.info, *A, n, hdt)
+        vs, gs = self._density(vs, ps, hdt)
         vs, evs = self._impose(ps, vs, self.ev)
         vs, gs, evs = o.sa_segment_bc_io(ps, vs, gs, evs, self.vertices, self.be, self.info, *A, n, 1)
         a = self._vertex_bc(ps, vs, gs, evs, self.vertices, hdt, 1)
         ps, vs, evs = a["new_pos"], a["vel"], a["euler_vel"]
         # corrector
-        f2, cfl, nb = o.forces_sa_io(ps, vs, evs, self.info, *A, gs, self.be, self.vertpos, n, dp)
+        f2, cfl, nb = self._forces(ps, vs, evs, gs)
         dt2 = self._dtmin(cfl, nb)
         pn, vn = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
-        vn, gn, _ = o.sa_density_sum_io(vn, self.pos, pn, self.vel, self.ev, self.gg, self.be, self.vertpos, self.info, *A, n, dt)
+        vn, gn = self._density(vn, pn, dt)
         vn, evn = self._impose(pn, vn, self.ev)
         vn, gn, evn = o.sa_segment_bc_io(pn, vn, gn, evn, self.vertices, self.be, self.info, *A, n, 2)
         vert2, gn = o.find_outgoing_segment(pn, vn, self.vertices, gn, self.vertpos, self.be, self.info, *A, n, infl)

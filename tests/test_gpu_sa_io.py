@@ -262,3 +262,57 @@ def test_density_summation_and_forces_with_open_boundaries():
     scale = np.abs(want_f[fl, :3]).max()
     assert_close_but_for_gamma_spikes(_np(d_forces)[:n][fl, :3], want_f[fl, :3], 3e-5, scale, what="forces with open boundaries", wall=wall[fl])
     assert np.abs(_np(d_cfl)[:nb] - want_cfl[:nb]).max() < 1e-4 * np.abs(want_cfl[:nb]).max()
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SPHX_TEST_SA_IO_BC") != "1",
+                    reason="sa_density_diffusion_io / sa_io_water_depth were written at the end of round 4 and have not run on a GPU yet")
+def test_brezzi_diffusion_and_water_depth_with_open_boundaries():
+    """sphx_sa_compute_density_diffusion_io against the oracle with the x = 0 wall a pressure outlet held off the fluid's pressure
+    (tests/test_sa_io_oracle.py), and sphx_sa_io_water_depth bit for bit: a maximum of integers."""
+    import torch
+    from gpusph_amd.engine import TimestepEngine
+    from sa_helpers import assert_close_but_for_gamma_spikes, wall_rows
+    kw = dict(deltap=0.05)
+    st = sa_oracle_state(**kw)
+    eng = TimestepEngine(SABox(**kw), device="cuda:0", clobber_neibslist=False)
+    eng.build_neibs()
+    p, o, n = st["problem"], st["oracle"], st["n"]
+    dev = eng.device
+    lib, h, P = eng.k.lib, eng.k.ctx.handle, capi.ptr
+    dp, dt = p.m_deltap, 1.0e-3
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    fl = t == D.PT_FLUID
+    seg = (t == D.PT_BOUNDARY) & (st["boundelements"][:, 0] > 0.5) & (np.abs(g[:, 0]) < 1e-6)
+    vtx = (t == D.PT_VERTEX) & (np.abs(g[:, 0]) < 1e-6)
+    info = st["info"].copy()
+    info[seg | vtx, 0] |= D.FG_OUTLET
+    info[seg | vtx, 1] = (info[seg | vtx, 1] & 0xF000) | 1
+    be = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], st["info"], st["hash"], st["cs"], st["nl"], n)
+    gg = o.sa_init_gamma(st["gradgamma"], st["pos"], be, st["vertpos"], st["info"], st["hash"], st["cs"], st["nl"], n, dp)
+    vel = st["vel"].copy()
+    vel[seg, 3] = vel[seg, 3] + np.float32(0.01)
+
+    def up(a, like):
+        out = torch.zeros_like(like)
+        out[:n] = torch.from_numpy(np.ascontiguousarray(a)).to(dev).view(like.dtype).reshape((n,) + tuple(like.shape[1:]))
+        return out
+    d_info, d_be, d_gg, d_vel = up(info.view(np.int16), eng.info), up(be, eng.boundelements), up(gg, eng.gradgamma), up(vel, eng.vel)
+    _, want = o.sa_density_diffusion_io(st["pos"], vel, gg, info, st["hash"], st["cs"], st["nl"], be, st["vertpos"], n, dt, dp)
+    _, plain = o.sa_density_diffusion(st["pos"], vel, gg, st["info"], st["hash"], st["cs"], st["nl"], n, dt)
+    assert np.abs(want[fl, 3] - plain[fl, 3]).max() > 100 * np.abs(plain[fl, 3]).max()       # the boundary term is what is tested
+    d_f = torch.zeros_like(eng.pos)
+    capi.check(lib.sphx_sa_compute_density_diffusion_io(h, P(d_f), P(eng.pos), P(d_vel), P(d_gg), P(d_be), P(eng.vertpos[0]),
+                                                        P(eng.vertpos[1]), P(eng.vertpos[2]), P(d_info), P(eng.hash), P(eng.cellStart),
+                                                        P(eng.neibslist), n, n, float(np.float32(dp)), float(np.float32(dt)), None))
+    wall = wall_rows(p, st["nl"], info, n)
+    assert_close_but_for_gamma_spikes(_np(d_f)[:n][fl, 3], want[fl, 3], 3e-5, np.abs(want[fl, 3]).max(),
+                                      what="Brezzi diffusion with a pressure outlet", wall=wall[fl])
+    # water depth: object 1 is the pressure outlet
+    want_d = o.sa_io_water_depth(np.zeros(2, dtype=np.uint32), st["pos"], info, st["hash"], st["cs"], st["nl"], n)
+    assert want_d[1] > 0
+    d_depth = torch.zeros(2, dtype=torch.int32, device=dev)
+    capi.check(lib.sphx_sa_io_water_depth(h, P(d_depth), P(eng.pos), P(d_info), P(eng.hash), P(eng.cellStart), P(eng.neibslist),
+                                          n, 0, n, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(d_depth.cpu().numpy().view(np.uint32), want_d)

@@ -516,6 +516,136 @@ def test_viscous_terms_see_the_eulerian_velocity_of_an_open_boundary(st):
     assert np.allclose(f_io[near, 1:3], f_rest[near, 1:3], atol=1e-3 * np.abs(f_rest[near, 1:3]).max())
 
 
+def _outlet_wall(st):
+    """the x = l wall as pressure-driven open boundary number 2 (on top of whatever _open_wall made of the x = 0 wall)"""
+    p = st["problem"]
+    g = p.global_pos(st["pos"], st["hash"])
+    t = info_type(st["info"])
+    seg = (t == D.PT_BOUNDARY) & (st["boundelements"][:, 0] < -0.5) & (np.abs(g[:, 0] - p.l) < 1e-6)
+    vtx = (t == D.PT_VERTEX) & (np.abs(g[:, 0] - p.l) < 1e-6)
+    return seg, vtx, g
+
+
+def test_water_depth_is_the_highest_fluid_particle_an_outlet_vertex_looks_down_on(st):
+    p, o = st["problem"], st["oracle"]
+    info, _, _, _ = _open_wall(st, D.FG_INLET | D.FG_VELOCITY_DRIVEN)          # object 1: velocity driven, never measured
+    seg, vtx, g = _outlet_wall(st)
+    info[seg | vtx, 0] |= D.FG_OUTLET
+    info[seg | vtx, 1] = (info[seg | vtx, 1] & 0xF000) | 2
+    n = st["n"]
+    depth = np.zeros(3, dtype=np.uint32)
+    o.sa_io_water_depth(depth, st["pos"], info, st["hash"], st["cs"], st["nl"], n)
+    assert depth[0] == 0 and depth[1] == 0 and depth[2] > 0
+    z = o.sa_io_water_depth_z(depth[2])
+    # by hand, in double on the global positions: fluid particles within the influence radius of an outlet vertex that is
+    # not below them; pairs at the edge of either test (lattice!) may fall on either side in float
+    R = float(p.simparams.influenceRadius)
+    fl = np.where(info_type(info) == D.PT_FLUID)[0]
+    lo, hi = -np.inf, -np.inf
+    for v in np.where(vtx)[0]:
+        d = g[fl] - g[v]
+        r = np.sqrt((d * d).sum(axis=1))
+        dz = g[v, 2] - g[fl, 2]
+        sure = (r < R - 1e-5) & (dz > 1e-6)
+        maybe = (r < R + 1e-5) & (dz > -1e-6)
+        if sure.any():
+            lo = max(lo, g[fl[sure], 2].max())
+        if maybe.any():
+            hi = max(hi, g[fl[maybe], 2].max())
+    assert np.isfinite(lo) and lo - 1e-5 <= z <= hi + 1e-5
+    # the tank's wall reaches above the water: that is the top layer of the fluid
+    assert abs(z - g[fl, 2].max()) < 1e-5
+    # a maximum that is never cleared here: with the fluid's top layers taken out the number stays; on a cleared array it drops
+    pos2 = st["pos"].copy()
+    pos2[fl[g[fl, 2] > p.water_level - 2.5 * p.m_deltap], 3] = np.nan
+    before = depth.copy()
+    o.sa_io_water_depth(depth, pos2, info, st["hash"], st["cs"], st["nl"], n)
+    assert np.array_equal(depth, before)
+    low = o.sa_io_water_depth(np.zeros(3, dtype=np.uint32), pos2, info, st["hash"], st["cs"], st["nl"], n)
+    assert 1.5 * p.m_deltap < z - o.sa_io_water_depth_z(low[2]) < 2.5 * p.m_deltap
+    # the scale: 0 is the bottom of the domain, UINT_MAX its top
+    assert o.sa_io_water_depth_z(0) == pytest.approx(float(o.p.worldOrigin[2]), abs=1e-7)
+    top = float(o.p.worldOrigin[2]) + float(o.p.cellSize[2]) * int(o.p.gridSize[2])
+    assert o.sa_io_water_depth_z(0xFFFFFFFF) == pytest.approx(top, rel=1e-6)
+
+
+def _brezzi_state(st, delta):
+    """fluid and walls at the reference density, the segments of the x = 0 wall -- a pressure outlet -- at 1 + delta"""
+    p, o = st["problem"], st["oracle"]
+    info, seg, vtx, g = _open_wall(st, D.FG_OUTLET)
+    be = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], st["info"], st["hash"], st["cs"], st["nl"], st["n"])
+    gg = o.sa_init_gamma(st["gradgamma"], st["pos"], be, st["vertpos"], st["info"], st["hash"], st["cs"], st["nl"], st["n"], p.m_deltap)
+    vel = np.zeros_like(st["vel"])
+    vel[seg, 3] = delta
+    return info, seg, g, be, gg, vel
+
+
+def test_brezzi_diffusion_without_pressure_driven_segments_is_the_plain_one(st):
+    p, o = st["problem"], st["oracle"]
+    n, dt = st["n"], 1e-3
+    _, _, _, be, gg, _ = _brezzi_state(st, 0.0)
+    common = (st["hash"], st["cs"], st["nl"])
+    v0, f0 = o.sa_density_diffusion(st["pos"], st["vel"], gg, st["info"], *common, n, dt)
+    v1, f1 = o.sa_density_diffusion_io(st["pos"], st["vel"], gg, st["info"], *common, be, st["vertpos"], n, dt, p.m_deltap)
+    assert np.array_equal(f0, f1) and np.array_equal(v0, v1)
+    # a velocity-driven inlet has no such term either
+    info_v, _, _, _ = _open_wall(st, D.FG_INLET | D.FG_VELOCITY_DRIVEN)
+    _, f2 = o.sa_density_diffusion_io(st["pos"], st["vel"], gg, info_v, *common, be, st["vertpos"], n, dt, p.m_deltap)
+    assert np.array_equal(f0, f2)
+
+
+def test_brezzi_boundary_term_of_a_pressure_outlet(st):
+    """The fluid term with V_b grad W -> |grad gamma_as| / r_as: against the plane x = 0 held at another pressure, a particle whose
+    only wall in reach is that plane gets  -2 rho dt (2/(rho + rho_s)) (P - P_s) |grad gamma| / r_as / gamma / rho0."""
+    p, o = st["problem"], st["oracle"]
+    n, dt, dp = st["n"], 1e-3, p.m_deltap
+    rho0 = float(p.physparams.rho0[0])
+    common = (st["hash"], st["cs"], st["nl"])
+    res = {}
+    for delta in (0.0, 0.01, 0.02):
+        info, seg, g, be, gg, vel = _brezzi_state(st, delta)
+        _, f = o.sa_density_diffusion_io(st["pos"], vel, gg, info, *common, be, st["vertpos"], n, dt, dp)
+        res[delta] = f[:, 3].astype(np.float64)
+    fl = info_type(st["info"]) == D.PT_FLUID
+    R = float(p.simparams.influenceRadius)
+    far = fl & (g[:, 0] > R + dp + 1e-4)
+    assert far.sum() > 100 and np.array_equal(res[0.0][far], res[0.01][far])            # out of reach of the wall: nothing
+    # in reach of the plane and of no other wall (their segments are not pressure driven, but gamma's gradient must be the plane's)
+    near = fl & (g[:, 0] < 1.6 * dp) & (g[:, 2] > R + 1.1 * dp) & (g[:, 1] > R + 1.1 * dp) & (g[:, 1] < p.w - R - 1.1 * dp)
+    assert near.sum() >= 4
+    for delta in (0.01, 0.02):
+        rho_s = rho0 * (1 + delta)
+        Ps = o.eos_P(delta)
+        r_as = np.maximum(g[near, 0], dp)
+        want = -((2.0 / (rho0 + rho_s)) * (0.0 - Ps)) * gg[near, 0] / r_as * dt * 2.0 * rho0 / gg[near, 3] / rho0
+        got = res[delta][near] - res[0.0][near]
+        assert (got > 0).all()                       # a boundary at higher pressure raises the density next to it
+        assert np.abs(got - want).max() < 2e-3 * np.abs(want).max()
+
+
+def test_brezzi_boundary_term_leaves_a_hydrostatic_column_alone(st):
+    """(2/(rho + rho_s)) (P - P_s) - g.r vanishes between two points of a hydrostatic column: with the outlet's segments at the
+    hydrostatic pressure of their height the term is what the linearisation of the density leaves, orders below the term of a
+    boundary that is off by the pressure of the whole column."""
+    p, o = st["problem"], st["oracle"]
+    n, dt, dp = st["n"], 1e-3, p.m_deltap
+    common = (st["hash"], st["cs"], st["nl"])
+    info, seg, g, be, gg, _ = _brezzi_state(st, 0.0)
+    vel = st["vel"].copy()                                     # the problem's initial state is the hydrostatic one
+    hyd = p.initial_density(g)
+    vel[seg, 3] = hyd[seg]
+    _, f_plain = o.sa_density_diffusion(st["pos"], vel, gg, st["info"], *common, n, dt)
+    _, f_hyd = o.sa_density_diffusion_io(st["pos"], vel, gg, info, *common, be, st["vertpos"], n, dt, dp)
+    vel_b = vel.copy(); vel_b[seg, 3] = hyd[seg] + np.float32(hyd.max())        # the whole column's pressure on top, everywhere
+    _, f_off = o.sa_density_diffusion_io(st["pos"], vel_b, gg, info, *common, be, st["vertpos"], n, dt, dp)
+    fl = info_type(st["info"]) == D.PT_FLUID
+    near = fl & (g[:, 0] < 1.6 * dp) & (g[:, 2] > 2.5 * dp) & (g[:, 2] < p.water_level - 2 * dp)
+    assert near.sum() >= 6
+    still = np.abs(f_hyd[near, 3] - f_plain[near, 3])
+    pushed = np.abs(f_off[near, 3] - f_plain[near, 3])
+    assert still.max() < 1e-3 * pushed.min()
+
+
 def test_an_open_channel_runs_through_the_whole_sequence():
     """Inlet on the left, pressure outlet on the right, a rebuild before every step: particles are released at the inlet at the
     rate the imposed velocity asks for, those that cross the outlet are taken out, the stream in between keeps its velocity and
@@ -555,3 +685,31 @@ def test_an_open_channel_runs_through_the_whole_sequence():
     # the open vertices' masses stay within the clip of +/- 2 reference masses
     ov = (t == D.PT_VERTEX) & ((sim.info[:n, 0] & (D.FG_INLET | D.FG_OUTLET)) != 0)
     assert np.abs(sim.pos[:n][ov, 3]).max() <= 2 * ref * (1 + 1e-6)
+
+
+def test_the_channel_with_brezzi_diffusion_and_the_measured_water_depth():
+    """ChannelIO's options (densitydiffusion<BREZZI>, ENABLE_WATER_DEPTH, src/problems/ChannelIO.cu:45-46): the outlet's pressure
+    follows the level the vertex pass measured -- nothing measured yet when the initial conditions are imposed, the top layer of the
+    fluid afterwards -- and the diffusion with its open-boundary term keeps the stream as the plain sequence does."""
+    from sa_helpers import OracleSaIoSim
+    p = SABox(0.05, l=1.0, w=0.4, h=0.4, H=0.25)
+    dp, U = p.m_deltap, 0.6
+    sim = OracleSaIoSim(p, U, brezzi=True, water_depth=True)
+    bottom = float(sim.o.p.worldOrigin[2])
+    assert sim.level_seen == [pytest.approx(bottom, abs=1e-7)]         # (the reference reads an array it never cleared here)
+    for _ in range(60):
+        sim.step()
+    n = sim.n
+    t = info_type(sim.info[:n])
+    fl = (t == D.PT_FLUID) & np.isfinite(sim.pos[:n, 3])
+    g = p.global_pos(sim.pos[:n], sim.hash[:n])
+    assert np.isfinite(sim.vel[:n][fl]).all() and np.isfinite(sim.pos[:n][fl]).all()
+    assert len(sim.level_seen) == 1 + 2 * 60
+    levels = np.array(sim.level_seen[1:])
+    top = p.water_level - 0.5 * dp                                   # the lattice's top layer
+    assert np.abs(levels - top).max() < dp
+    assert sim.created > 0
+    bulk = fl & (g[:, 0] > 0.2) & (g[:, 0] < p.l - 0.2) & (g[:, 2] < p.water_level - dp)
+    assert bulk.sum() > 100
+    assert 0.85 * U < sim.vel[:n][bulk, 0].mean() < 1.25 * U
+    assert np.abs(sim.vel[:n][bulk, 3] - p.initial_density(g)[bulk]).max() < 0.01
