@@ -13,6 +13,13 @@
 #include "sphx_internal.h"
 #include "neib_iter.h"
 
+// Every launch of this file goes through one macro, so that tests/hostemu can run the kernels' SOURCE on the host, thread after
+// thread, against the oracle before a GPU is at hand (a test harness: the library has no CPU path and the macro below is what
+// hipcc sees).
+#ifndef SPHX_LAUNCH
+#define SPHX_LAUNCH(kernel, grid, block, stream, ...) kernel<<<(grid), (block), 0, (stream)>>>(__VA_ARGS__)
+#endif
+
 // particleinfo flags of open boundaries (src/particleinfo.h:153-156, 222-241)
 #define FG_INLET             (PART_FLAG_START << 2)
 #define FG_OUTLET            (PART_FLAG_START << 3)
@@ -271,7 +278,7 @@ extern "C" int sphx_sa_identify_corner_vertices(sphx_ctx *ctx, const void *pos, 
 	SPHX_REQUIRE(pos && info && hash && vertices && cellStart && neibsList, "sphx_sa_identify_corner_vertices: missing buffer");
 	if (!particleRangeEnd) return SPHX_OK;
 	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
-	sa_identify_corner_vertices_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a, (particleinfo*)info);
+	SPHX_LAUNCH(sa_identify_corner_vertices_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a, (particleinfo*)info);
 	SPHX_LAUNCH_CHECK("sa_identify_corner_vertices_kernel");
 	return SPHX_OK;
 }
@@ -286,7 +293,7 @@ extern "C" int sphx_sa_init_io_mass_vertex_count(sphx_ctx *ctx, const void *vert
 	SPHX_REQUIRE(vertices && hash && info && cellStart && neibsList && forces && pos, "sphx_sa_init_io_mass_vertex_count: missing buffer");
 	if (!particleRangeEnd) return SPHX_OK;
 	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
-	sa_init_io_mass_vertex_count_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a, (float4*)forces);
+	SPHX_LAUNCH(sa_init_io_mass_vertex_count_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a, (float4*)forces);
 	SPHX_LAUNCH_CHECK("sa_init_io_mass_vertex_count_kernel");
 	return SPHX_OK;
 }
@@ -302,7 +309,7 @@ extern "C" int sphx_sa_init_io_mass(sphx_ctx *ctx, const void *oldPos, const voi
 		"sphx_sa_init_io_mass: missing buffer (newPos must not be oldPos)");
 	if (!particleRangeEnd) return SPHX_OK;
 	SaIoArgs a = { (const float4*)oldPos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
-	sa_init_io_mass_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a, (const float4*)forces,
+	SPHX_LAUNCH(sa_init_io_mass_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a, (const float4*)forces,
 		(float4*)newPos, deltap);
 	SPHX_LAUNCH_CHECK("sa_init_io_mass_kernel");
 	return SPHX_OK;
@@ -322,7 +329,7 @@ extern "C" int sphx_sa_find_outgoing_segment(sphx_ctx *ctx, const void *pos, con
 	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
 	SaIoOutArgs o = { (const float4*)vel, (const float4*)boundElements, (const float2*)vertPos0, (const float2*)vertPos1,
 		(const float2*)vertPos2, (uint4*)vertices, (float4*)gGam, influenceradius };
-	sa_find_outgoing_segment_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a, o);
+	SPHX_LAUNCH(sa_find_outgoing_segment_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a, o);
 	SPHX_LAUNCH_CHECK("sa_find_outgoing_segment_kernel");
 	return SPHX_OK;
 }
@@ -333,7 +340,7 @@ extern "C" int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *ve
 	if (rc != SPHX_OK) return rc;
 	SPHX_REQUIRE(pos && vertices && info, "sphx_sa_disable_outgoing_parts: missing buffer");
 	if (!numParticles) return SPHX_OK;
-	sa_disable_outgoing_parts_kernel<<<div_up_u(numParticles, 256), 256, 0, (hipStream_t)stream>>>((float4*)pos, (uint4*)vertices,
+	SPHX_LAUNCH(sa_disable_outgoing_parts_kernel, div_up_u(numParticles, 256), 256, (hipStream_t)stream, (float4*)pos, (uint4*)vertices,
 		(const particleinfo*)info, numParticles);
 	SPHX_LAUNCH_CHECK("sa_disable_outgoing_parts_kernel");
 	return SPHX_OK;
@@ -655,7 +662,7 @@ extern "C" int sphx_sa_segment_bc_io(sphx_ctx *ctx, void *vel, void *gGam, void 
 	a.vel = (float4*)vel; a.gGam = (float4*)gGam; a.eulerVel = (float4*)eulerVel; a.pos = (const float4*)pos;
 	a.boundElementRO = (const float4*)boundElements; a.verticesRO = (const uint4*)vertices; a.infoRO = (const particleinfo*)info;
 	a.hashRO = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd; a.step = step == -1 ? 0 : step;
-	sa_segment_bc_io_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH(sa_segment_bc_io_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_segment_bc_io_kernel");
 	return SPHX_OK;
 }
@@ -679,7 +686,7 @@ extern "C" int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, v
 	a.vertPos0 = (const float2*)vertPos0; a.vertPos1 = (const float2*)vertPos1; a.vertPos2 = (const float2*)vertPos2;
 	a.numParticles = particleRangeEnd; a.totParticles = totParticles; a.numOpenVertices = numOpenVertices;
 	a.deltap = deltap; a.dt = dt; a.step = step == -1 ? 0 : step;
-	sa_vertex_bc_io_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH(sa_vertex_bc_io_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_vertex_bc_io_kernel");
 	return SPHX_OK;
 }
@@ -935,7 +942,7 @@ extern "C" int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam
 		(const float4*)oldVel, (const float4*)oldEulerVel, (const float4*)oldGGam, (const float4*)boundElements,
 		{ (const float2*)vertPos0, (const float2*)vertPos1, (const float2*)vertPos2 }, (const particleinfo*)info, hash, cellStart,
 		neibsList, particleRangeEnd, dt };
-	sa_density_sum_io_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH(sa_density_sum_io_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_io_kernel");
 	return SPHX_OK;
 }
@@ -964,7 +971,7 @@ extern "C" int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *c
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
-	sa_forces_io_kernel<<<numBlocks, SPHX_BLOCK_FORCES, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH(sa_forces_io_kernel, numBlocks, SPHX_BLOCK_FORCES, (hipStream_t)stream, ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_forces_io_kernel");
 	return SPHX_OK;
 }
@@ -1095,7 +1102,7 @@ extern "C" int sphx_sa_compute_density_diffusion_io(sphx_ctx *ctx, void *forces,
 	SaIoDiffusionArgs a = { (float4*)forces, (const float4*)pos, (const float4*)vel, (const float4*)gGam, (const float4*)boundElements,
 		{ (const float2*)vertPos0, (const float2*)vertPos1, (const float2*)vertPos2 }, (const particleinfo*)info, hash, cellStart,
 		neibsList, particleRangeEnd, dt, deltap };
-	sa_density_diffusion_io_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH(sa_density_diffusion_io_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_diffusion_io_kernel");
 	return SPHX_OK;
 }
@@ -1109,7 +1116,7 @@ extern "C" int sphx_sa_io_water_depth(sphx_ctx *ctx, uint32_t *IOwaterdepth, con
 	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_sa_io_water_depth: invalid particle range");
 	if (fromParticle == toParticle) return SPHX_OK;
 	SaIoDepthArgs a = { IOwaterdepth, (const float4*)pos, (const particleinfo*)info, hash, cellStart, neibsList, fromParticle, toParticle };
-	sa_io_water_depth_kernel<<<div_up_u(toParticle - fromParticle, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH(sa_io_water_depth_kernel, div_up_u(toParticle - fromParticle, 128), 128, (hipStream_t)stream, ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_io_water_depth_kernel");
 	return SPHX_OK;
 }
