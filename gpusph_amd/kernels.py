@@ -349,3 +349,77 @@ class HipKernels:
         capi.check(self.lib.sphx_postprocess(self.ctx.handle, int(pptype), p(vort), p(vel_inout), p(info_inout), p(normals),
                                              p(pos), p(vel), p(info), p(hash_), p(cellStart), p(neibslist), n, n,
                                              float(cosf), float(cosn), self._s()))
+
+    # ---- SA open boundaries (ENABLE_INLET_OUTLET): the passes of gpusph_amd/csrc/sa_io.hip behind the driver sequence of
+    # gpusph_amd.multigpu (_sa_post_euler_io).  The first five entry points are verified on the GPU; the condition passes, the
+    # density summation, the forces, the diffusion and the water depth have run over their own source on the CPU only
+    # (tests/hostemu) and the library's SA entry points still refuse ENABLE_INLET_OUTLET: a run of such a problem on the device
+    # stops at its first SA call with SphxUnsupported until those kernels have passed their GPU parity tests.
+    def sa_identify_corner_vertices(self, pos, info, hash_, vertices, cellStart, neibslist, n, range_end):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_identify_corner_vertices(self.ctx.handle, p(pos), p(info), p(hash_), p(vertices), p(cellStart),
+                                                             p(neibslist), n, range_end, self._s()))
+
+    def sa_init_io_mass(self, new_pos, pos, forces, vertices, hash_, info, cellStart, neibslist, n, range_end):
+        p = capi.ptr
+        self.memset(forces, 0)
+        capi.check(self.lib.sphx_sa_init_io_mass_vertex_count(self.ctx.handle, p(vertices), p(hash_), p(info), p(cellStart), p(neibslist),
+                                                              p(forces), p(pos), n, range_end, self._s()))
+        capi.check(self.lib.sphx_sa_init_io_mass(self.ctx.handle, p(pos), p(forces), p(vertices), p(hash_), p(info), p(cellStart),
+                                                 p(neibslist), p(new_pos), n, range_end, self.params.deltap, self._s()))
+
+    def sa_segment_bc_io(self, vel, ggam, eulervel, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_segment_bc_io(self.ctx.handle, p(vel), p(ggam), p(eulervel), p(pos), p(vertices), p(boundelements),
+                                                  p(info), p(hash_), p(cellStart), p(neibslist), n, range_end, int(step), self._s()))
+
+    def sa_vertex_bc_io(self, vel, old_pos, new_pos, ggam, eulervel, forces, vertices, boundelements, vertpos, info, hash_, next_ids,
+                        count, cellStart, neibslist, n, range_end, max_particles, dt, step, num_open_vertices):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_vertex_bc_io(self.ctx.handle, p(vel), p(old_pos), p(new_pos), p(ggam), p(eulervel), p(forces),
+                                                 p(vertices), p(boundelements), p(vertpos[0]), p(vertpos[1]), p(vertpos[2]), p(info),
+                                                 p(hash_), p(next_ids), p(count), p(cellStart), p(neibslist), n, range_end,
+                                                 int(max_particles), self.params.deltap, float(np.float32(dt)), int(step),
+                                                 int(num_open_vertices), self._s()))
+
+    def sa_find_outgoing_segment(self, pos, vel, vertices, ggam, vertpos, boundelements, info, hash_, cellStart, neibslist, n, range_end):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_find_outgoing_segment(self.ctx.handle, p(pos), p(vel), p(vertices), p(ggam), p(vertpos[0]), p(vertpos[1]),
+                                                          p(vertpos[2]), p(boundelements), p(info), p(hash_), p(cellStart), p(neibslist),
+                                                          n, range_end, self.params.influenceradius, self._s()))
+
+    def sa_disable_outgoing_parts(self, pos, vertices, info, n):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_disable_outgoing_parts(self.ctx.handle, p(pos), p(vertices), p(info), n, self._s()))
+
+    def sa_density_sum_io(self, new_vel, new_ggam, forces, old_pos, new_pos, old_vel, old_eulervel, old_ggam, boundelements, vertpos, info,
+                          hash_, cellStart, neibslist, n, range_end, dt):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_density_sum_io(self.ctx.handle, p(new_vel), p(new_ggam), p(forces), p(old_pos), p(new_pos), p(old_vel),
+                                                   p(old_eulervel), p(old_ggam), p(boundelements), p(vertpos[0]), p(vertpos[1]),
+                                                   p(vertpos[2]), p(info), p(hash_), p(cellStart), p(neibslist), n, range_end,
+                                                   float(np.float32(dt)), self._s()))
+
+    def sa_density_diffusion_io(self, forces, pos, vel, ggam, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end, dt):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_compute_density_diffusion_io(self.ctx.handle, p(forces), p(pos), p(vel), p(ggam), p(boundelements),
+                                                                 p(vertpos[0]), p(vertpos[1]), p(vertpos[2]), p(info), p(hash_),
+                                                                 p(cellStart), p(neibslist), n, range_end, self.params.deltap,
+                                                                 float(np.float32(dt)), self._s()))
+        capi.check(self.lib.sphx_apply_density_diffusion(self.ctx.handle, p(vel), p(forces), p(info), n, range_end, float(np.float32(dt)),
+                                                         self._s()))
+
+    def forces_sa_io(self, forces, cfl, pos, vel, eulervel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, n, frm, to,
+                     cfl_offset, cfl_gamma=None):
+        p = capi.ptr
+        nb = C.c_uint32(0)
+        capi.check(self.lib.sphx_forces_basicstep_sa_io(self.ctx.handle, p(forces), p(cfl), p(cfl_gamma), p(pos), p(vel), p(eulervel),
+                                                        p(info), p(hash_), p(cellStart), p(neibslist), p(ggam), p(boundelements),
+                                                        p(vertpos[0]), p(vertpos[1]), p(vertpos[2]), n, frm, to, self.params.deltap,
+                                                        cfl_offset, C.byref(nb), self._s()))
+        return int(nb.value)
+
+    def sa_io_water_depth(self, depth, pos, info, hash_, cellStart, neibslist, n, frm, to):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_io_water_depth(self.ctx.handle, p(depth), p(pos), p(info), p(hash_), p(cellStart), p(neibslist),
+                                                   n, frm, to, self._s()))

@@ -190,6 +190,34 @@ class MultiGpuEngine:
             self.sa_dynamic_gamma = not (self.sp.simflags & D.ENABLE_GAMMA_QUADRATURE)
             self.sa_density_sum = bool(self.sp.simflags & D.ENABLE_DENSITY_SUM)
             self.cfl_gamma = (torch.zeros(A + 4 + self.cfl.numel(), dtype=f32, device=dev) if self.sa_dynamic_gamma else None)
+        # SA open boundaries (ENABLE_INLET_OUTLET): BUFFER_EULERVEL (double buffered) and BUFFER_NEXTID travel through the re-sort,
+        # IOwaterdepth is one uint per open boundary, the particle count grows inside the allocation.  One device, the density
+        # summation form, a rebuild in every iteration (the reference's open-boundary problems set buildneibsfreq = 1: a released
+        # particle exists for the lists from the next rebuild on).  See _sa_post_euler_io.
+        self.io = self.sa and bool(self.sp.simflags & D.ENABLE_INLET_OUTLET)
+        if self.io:
+            if world > 1:
+                raise NotImplementedError("open boundaries over several devices are not built")
+            if not self.sa_density_sum or self.keps or self.sp.buildneibsfreq != 1:
+                raise NotImplementedError("open boundaries are built for the density summation form without k-epsilon, buildneibsfreq = 1")
+            if not hasattr(problem, "impose_open_boundaries"):
+                raise ValueError("a problem with ENABLE_INLET_OUTLET needs impose_open_boundaries (its imposeBoundaryConditionHost)")
+            self.eulervel = torch.zeros((A, 4), dtype=f32, device=dev); self.eulervel2 = torch.zeros_like(self.eulervel)
+            # initializeNextIDs (src/GPUSPH.cc:1256-1302): the vertices of open boundaries get totParticles, totParticles + 1, ...
+            # in particle order; nobody else has one
+            flags = arrs["info"][:, 0]
+            openv = ((flags & 7) == D.PT_VERTEX) & ((flags & (D.FG_INLET | D.FG_OUTLET)) != 0)
+            nid = np.full(len(flags), 0xFFFFFFFF, dtype=np.uint32)
+            nid[openv] = len(flags) + np.arange(int(openv.sum()), dtype=np.uint32)
+            self.num_open_vertices = int(openv.sum())
+            self.next_ids = torch.full((A,), -1, dtype=i32, device=dev)
+            self.next_ids[:n0] = torch.from_numpy(nid.view(np.int32)[mask]).to(dev)
+            self.next_ids2 = torch.full((A,), -1, dtype=i32, device=dev)
+            self.water_depth_on = bool(self.sp.simflags & D.ENABLE_WATER_DEPTH)
+            self.iowaterdepth = torch.zeros(max(int(problem.num_open_boundaries), 1), dtype=i32, device=dev) if self.water_depth_on else None
+            self.io_count = torch.zeros(1, dtype=i32, device=dev)         # newNumParticles of the vertex pass
+            self.io_scratch = torch.zeros((A, 4), dtype=f32, device=dev)  # the positions the vertex pass reads while it writes masses
+            self.io_created = self.io_removed = 0
         # turbulence<KEPSILON>: BUFFER_TKE / EPSILON / TURBVISC / EULERVEL are particle properties (double buffered, re-sorted);
         # ProblemCore::init_keps and init_turbvisc (src/ProblemCore.cc:1623-1659) give the uniform initial state; BUFFER_DKDE and
         # BUFFER_CFL_KEPS are outputs of the forces passes
@@ -252,6 +280,11 @@ class MultiGpuEngine:
                 src, dst = getattr(self, name), getattr(self, name + "2")
                 K.gather_rows(dst, src, self.partindex, n)
                 setattr(self, name, dst); setattr(self, name + "2", src)
+        if self.io:      # BUFFER_EULERVEL and BUFFER_NEXTID are particle state too
+            for name in ("eulervel", "next_ids"):
+                src, dst = getattr(self, name), getattr(self, name + "2")
+                K.gather_rows(dst, src, self.partindex, n)
+                setattr(self, name, dst); setattr(self, name + "2", src)
         if self.energy_on:
             K.gather_rows(self.energy2, self.energy, self.partindex, n)
             self.energy, self.energy2 = self.energy2, self.energy
@@ -264,7 +297,10 @@ class MultiGpuEngine:
             self.vol, self.vol2 = self.vol2, self.vol
         if self.world == 1:
             if self.track_particle_count:
+                before = self.n_local
                 self.n_local = int(self.new_num.item()) & 0xFFFFFFFF
+                if self.io:
+                    self.io_removed += before - self.n_local
             self.n_int = self.n_local
             self.edge_start = self.n_int
         else:
@@ -315,6 +351,46 @@ class MultiGpuEngine:
         K.sa_vertex_bc(self.vel2, self.gradgamma2, self.pos2, self.info, self.hash, self.cellStart, self.neibslist, n, ni, step, D.SIMULATE)
         ext([self.vel2])
 
+    def _sa_post_euler_io(self, step):
+        """The post-Euler commands of a step with ENABLE_INLET_OUTLET (src/integrators/PredictorCorrectorIntegrator.cc:127-300,
+        607-684), one device: DENSITY_SUM [+ density diffusion] with the open boundaries' terms from the state of step n,
+        IMPOSE_OPEN_BOUNDARY_CONDITION (the problem's values; it consumes and clears the water depth), the segment conditions,
+        in the last step FIND_OUTGOING_SEGMENT, the vertex conditions (vertex masses; in the last step the take-over of outgoing
+        particles and the release of new ones: the particle count grows), in the last step DISABLE_OUTGOING_PARTS."""
+        K, n = self.k, self.n_local
+        dt = float(np.float32(np.float32(self.d_dt.item()) * np.float32(0.5 if step == 1 else 1.0)))      # dt_op, on the host
+        K.sa_density_sum_io(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.eulervel, self.gradgamma,
+                            self.boundelements, self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, n, dt)
+        if self.sp.densitydiffusiontype == D.BREZZI:
+            K.sa_density_diffusion_io(self.forces, self.pos2, self.vel2, self.gradgamma2, self.boundelements, self.vertpos, self.info,
+                                      self.hash, self.cellStart, self.neibslist, n, n, dt)
+        self.eulervel2[:n] = self.eulervel[:n]
+        self.problem.impose_open_boundaries(self.pos2, self.vel2, self.eulervel2, self.info, self.hash, self.iowaterdepth,
+                                            self.time(), n)
+        K.sa_segment_bc_io(self.vel2, self.gradgamma2, self.eulervel2, self.pos2, self.vertices, self.boundelements, self.info,
+                           self.hash, self.cellStart, self.neibslist, n, n, step)
+        if step == 2:
+            K.sa_find_outgoing_segment(self.pos2, self.vel2, self.vertices, self.gradgamma2, self.vertpos, self.boundelements,
+                                       self.info, self.hash, self.cellStart, self.neibslist, n, n)
+        self._io_vertex_bc(self.pos2, self.vel2, self.gradgamma2, self.eulervel2, dt, step)
+        if step == 2:
+            K.sa_disable_outgoing_parts(self.pos2, self.vertices, self.info, self.n_local)
+
+    def _io_vertex_bc(self, pos, vel, ggam, eulervel, dt, step):
+        """SA_CALC_VERTEX_BOUNDARY_CONDITIONS with open boundaries: the pass reads the positions and masses it was given and writes
+        the vertex masses (and the rows of released particles) into `pos`; the new particle count comes back in a device word"""
+        K, n = self.k, self.n_local
+        self.io_scratch[:n] = pos[:n]
+        self.io_count[0] = n
+        K.sa_vertex_bc_io(vel, self.io_scratch, pos, ggam, eulervel, self.forces, self.vertices, self.boundelements, self.vertpos,
+                          self.info, self.hash, self.next_ids, self.io_count, self.cellStart, self.neibslist, n, n, self.alloc,
+                          dt, step, self.num_open_vertices)
+        n2 = int(self.io_count.item()) & 0xFFFFFFFF
+        if n2 > self.alloc:
+            raise RuntimeError("open boundaries released more particles than the allocation holds (%d > %d)" % (n2, self.alloc))
+        self.io_created += n2 - n
+        self.n_local = self.n_int = self.edge_start = n2
+
     def sa_boundary_conditions(self, step, run_mode=D.SIMULATE):
         """initializeBoundaryConditionsSequence<SA_BOUNDARY> (src/integrators/PredictorCorrectorIntegrator.cc:117-290) without
         open boundaries: at initialisation (step 0) the vertex normals and gamma, then in every step the segment and the vertex
@@ -330,6 +406,20 @@ class MultiGpuEngine:
                             self.cellStart, self.neibslist, n, ni)
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
             ext([self.gradgamma])
+        if self.io:
+            # with open boundaries (:150-290): corner vertices, the initial masses of the open vertices, the imposed values, then
+            # the two condition passes of step 0
+            if step != 0 or run_mode != D.SIMULATE:
+                raise NotImplementedError("open boundaries: only the initialisation sequence goes through sa_boundary_conditions")
+            K.sa_identify_corner_vertices(self.pos, self.info, self.hash, self.vertices, self.cellStart, self.neibslist, n, n)
+            K.sa_init_io_mass(self.pos2, self.pos, self.forces, self.vertices, self.hash, self.info, self.cellStart, self.neibslist, n, n)
+            self.pos, self.pos2 = self.pos2, self.pos
+            self.problem.impose_open_boundaries(self.pos, self.vel, self.eulervel, self.info, self.hash, self.iowaterdepth,
+                                                self.time(), n)
+            K.sa_segment_bc_io(self.vel, self.gradgamma, self.eulervel, self.pos, self.vertices, self.boundelements, self.info,
+                               self.hash, self.cellStart, self.neibslist, n, n, 0)
+            self._io_vertex_bc(self.pos, self.vel, self.gradgamma, self.eulervel, 0.0, 0)
+            return
         if self.keps and run_mode == D.SIMULATE:
             ke = self.ke
             K.sa_segment_bc_keps(self.vel, self.gradgamma, ke, self.pos, self.vertices, self.boundelements, self.info, self.hash,
@@ -430,6 +520,10 @@ class MultiGpuEngine:
                     return K.forces_sa_keps(self.forces, self.cfl, self.cfl_keps, self.dkde, pos, vel, self.info, self.hash, self.cellStart,
                                             self.neibslist, ggam, self.boundelements, self.vertpos, ke, self.n_local, frm, to, off,
                                             cfl_gamma=self.cfl_gamma)
+                if self.io:      # the Eulerian velocity of the open boundaries in the viscous terms and in the gamma CFL condition
+                    ev = self.eulervel if pos is self.pos else self.eulervel2
+                    return K.forces_sa_io(self.forces, self.cfl, pos, vel, ev, self.info, self.hash, self.cellStart, self.neibslist, ggam,
+                                          self.boundelements, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma)
                 return K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
                                    self.boundelements, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma, run_mode=run_mode)
         elif self.effvisc_on and run_mode == D.SIMULATE:
@@ -505,6 +599,8 @@ class MultiGpuEngine:
             K.dtreduce_keps(self.cfl_keps, nb1 + nb2, self.d_dt_next)
         if self.sa and self.sa_dynamic_gamma and run_mode == D.SIMULATE:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
             K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb1 + nb2, self.d_dt_next)
+        if self.io and self.water_depth_on:      # the vertex pass of the forces (vertex_forces, src/cuda/forces.cu:676-686)
+            K.sa_io_water_depth(self.iowaterdepth, pos, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, 0, self.n_local)
 
     def step(self):
         K = self.k
@@ -535,7 +631,9 @@ class MultiGpuEngine:
             K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 0.5)
         if self.keps:
             K.euler_keps(self.ke2, self.ke, self.dkde, self.forces, self.pos, self.info, n, self.d_dt, 0.5)
-        if self.sa:
+        if self.io:
+            self._sa_post_euler_io(1)
+        elif self.sa:
             self._sa_post_euler(1)
         # corrector: forces(step n*) -> n+1 = n + dt f*   (written over n*, then renamed to n)
         self._forces_pass(self.pos2, self.vel2, 1, step=2)
@@ -551,7 +649,11 @@ class MultiGpuEngine:
             self.energy, self.energy2 = self.energy2, self.energy
         if self.keps:
             K.euler_keps(self.ke2, self.ke, self.dkde, self.forces, self.pos, self.info, n, self.d_dt, 1.0)
-        if self.sa:
+        if self.io:
+            self._sa_post_euler_io(2)        # (the particle count has grown by the released particles: n is stale from here on)
+            self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
+            self.eulervel, self.eulervel2 = self.eulervel2, self.eulervel
+        elif self.sa:
             self._sa_post_euler(2)
             if self.keps:
                 self.ke, self.ke2 = self.ke2, self.ke

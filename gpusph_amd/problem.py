@@ -1010,3 +1010,95 @@ class SABox(Problem):
         a = super().copy_to_array()
         a.update(vertices=self.vertices.copy(), boundelements=self.boundelements.copy(), gradgamma=self.gradgamma.copy())
         return a
+
+
+class SAChannelIO(SABox):
+    """An open channel on the SABox mesh, the synthetic counterpart of src/problems/ChannelIO.cu (whose geometry is a set of
+    Crixus HDF5 files): the x = 0 wall of the tank is a VELOCITY-driven open boundary (u_E = U ex, setVelocityDriven(inlet, 1),
+    :85-88), the x = l wall a PRESSURE-driven one (the hydrostatic pressure under the measured water level, :90-93), the fluid
+    starts as a stream at U.  Framework options of that problem (:38-47): Brezzi diffusion, density summation, ENABLE_INLET_OUTLET |
+    ENABLE_WATER_DEPTH, a neighbour-list rebuild in every iteration (:62).  Open boundaries are numbered 0 (inlet) and 1 (outlet):
+    the object number of their segments and vertices, the index into BUFFER IOwaterdepth.
+
+    STATUS: the driver sequence of gpusph_amd.multigpu runs this problem on the CPU over the oracle's kernels (tests); the HIP
+    kernels of the open-boundary passes have not run on a GPU yet and the library still refuses ENABLE_INLET_OUTLET in its SA entry
+    points."""
+
+    def __init__(self, deltap=0.05, *, U=0.6, l=1.0, w=0.4, h=0.4, H=0.25, water_depth=True, **kw):
+        super().__init__(deltap, l=l, w=w, h=h, H=H, **kw)
+        self.m_name = "SAChannelIO"
+        self.U = float(U)
+        sp = self.simparams
+        sp.simflags |= D.ENABLE_INLET_OUTLET | (D.ENABLE_WATER_DEPTH if water_depth else 0)
+        sp.buildneibsfreq = 1
+        self.num_open_boundaries = 2
+        info, g = self.parts.info, self.parts.pos_global
+        t = info_type(info)
+        wall = (t == D.PT_BOUNDARY) | (t == D.PT_VERTEX)
+        nrm = self.boundelements
+        inlet = wall & (np.abs(g[:, 0]) < 1e-6) & ((t == D.PT_VERTEX) | (nrm[:, 0] > 0.5))
+        outlet = wall & (np.abs(g[:, 0] - self.l) < 1e-6) & ((t == D.PT_VERTEX) | (nrm[:, 0] < -0.5))
+        info[inlet, 0] |= D.FG_INLET | D.FG_VELOCITY_DRIVEN
+        info[inlet, 1] = (info[inlet, 1] & 0xF000) | 0
+        info[outlet, 0] |= D.FG_OUTLET
+        info[outlet, 1] = (info[outlet, 1] & 0xF000) | 1
+        self.parts.vel[t == D.PT_FLUID, 0] = np.float32(self.U)
+
+    def open_boundary_condition(self, io_info, abs_pos, waterdepth, t):
+        """ChannelIO_imposeBoundaryCondition (src/problems/ChannelIO.cu:104-139) for the rows of the open boundaries' particles, on
+        torch tensors of any device: -> (vel, eulerVel) rows.  The Lagrangian velocity is cleared; a velocity-driven boundary gets
+        u_E = U ex, a pressure-driven one the density of the hydrostatic pressure under `waterdepth` (absolute z)."""
+        import torch
+        f32 = torch.float32
+        m = io_info.shape[0]
+        vel = torch.zeros((m, 4), dtype=f32, device=abs_pos.device)
+        ev = torch.zeros((m, 4), dtype=f32, device=abs_pos.device)
+        vdriven = (io_info[:, 0].to(torch.int32) & D.FG_VELOCITY_DRIVEN) != 0
+        pp = self.physparams
+        localdepth = torch.clamp(waterdepth - abs_pos[:, 2], min=0.0)
+        pressure = np.float32(9.81) * localdepth * np.float32(pp.rho0[0])
+        # RHO (src/cuda/phys_core.cu:108-112)
+        rho = torch.pow(pressure / np.float32(pp.bcoeff[0]) + np.float32(1.0), float(np.float32(1.0) / np.float32(pp.gammacoeff[0]))) - np.float32(1.0)
+        ev[:, 3] = torch.where(vdriven, torch.zeros_like(rho), rho)
+        ev[:, 0] = torch.where(vdriven, torch.full_like(rho, np.float32(self.U)), torch.zeros_like(rho))
+        return vel, ev
+
+    def impose_open_boundaries(self, pos, vel, euler_vel, info, hash_, iowaterdepth, t, n):
+        """<Problem>_imposeBoundaryConditionDevice + imposeBoundaryConditionHost (src/problems/ChannelIO.cu:142-230): for every
+        particle of an open boundary the absolute position, the water level of its boundary from IOwaterdepth (pressure-driven ones;
+        0 -> the bottom of the domain), the problem's condition, written to vel / eulerVel in place; then IOwaterdepth is cleared.
+        Tensors of the engine (device or CPU), the first n rows."""
+        import torch
+        flags = info[:n, 0].to(torch.int32)
+        rows = torch.nonzero((flags & (D.FG_INLET | D.FG_OUTLET)) != 0).flatten()
+        if rows.numel():
+            f32 = torch.float32
+            dev = pos.device
+            c1, c2, c3 = D.LINEARIZATIONS[self.linearization]
+            gs = [int(v) for v in self.m_gridsize]
+            h = hash_[rows].to(torch.int64) & D.CELLTYPE_BITMASK
+            g = [None, None, None]
+            tt = gs[c2] * gs[c1]
+            g[c3] = torch.div(h, tt, rounding_mode="floor")
+            rem = h - g[c3] * tt
+            g[c2] = torch.div(rem, gs[c1], rounding_mode="floor")
+            g[c1] = rem - g[c2] * gs[c1]
+            cell = [np.float32(v) for v in self.m_cellsize]
+            org = [np.float32(v) for v in self.m_origin]
+            # d_worldOrigin + pos + gridPos*d_cellSize + 0.5f*d_cellSize, left to right in float
+            ap = torch.stack([((org[a] + pos[rows, a]) + g[a].to(f32) * cell[a]) + np.float32(0.5) * cell[a] for a in range(3)], dim=1)
+            io_info = info[rows]
+            wd = torch.zeros(rows.numel(), dtype=f32, device=dev)
+            if iowaterdepth is not None:
+                obj = io_info[:, 1].to(torch.int32) & 0xFFF
+                u = (iowaterdepth.to(torch.int64) & 0xFFFFFFFF)[obj.to(torch.int64)].to(f32)
+                wd = u / np.float32(4294967296.0)                           # ((float)IOwaterdepth)/((float)UINT_MAX)
+                wd = wd * (cell[2] * np.float32(gs[2]))
+                wd = wd + org[2]
+                vdriven = (io_info[:, 0].to(torch.int32) & D.FG_VELOCITY_DRIVEN) != 0
+                wd = torch.where(vdriven, torch.zeros_like(wd), wd)
+            v, e = self.open_boundary_condition(io_info, ap, wd, t)
+            vel[rows] = v
+            euler_vel[rows] = e
+        if iowaterdepth is not None:
+            iowaterdepth.zero_()

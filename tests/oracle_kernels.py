@@ -266,3 +266,66 @@ class OracleKernels:
         self.L.orc_sa_integrate_gamma_quadrature(C.byref(self.op), _p(new_ggam), _p(old_ggam), _p(new_pos), _p(boundelements), _p(vertpos[0]),
                                                  _p(vertpos[1]), _p(vertpos[2]), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
                                                  C.c_uint32(range_end), C.c_int(0), C.c_float(epsilon))
+
+    # ---- SA open boundaries (ENABLE_INLET_OUTLET): the interface of HipKernels' *_io methods over the oracle's restatements
+    def _vp(self, vertpos):
+        return _p(vertpos[0]), _p(vertpos[1]), _p(vertpos[2])
+
+    def sa_identify_corner_vertices(self, pos, info, hash_, vertices, cellStart, neibslist, n, range_end):
+        self.L.orc_sa_identify_corner_vertices(C.byref(self.op), _p(pos), _p(info), _p(hash_), _p(vertices), _p(cellStart), _p(neibslist),
+                                               C.c_uint32(range_end))
+
+    def sa_init_io_mass(self, new_pos, pos, forces, vertices, hash_, info, cellStart, neibslist, n, range_end):
+        forces[:n] = 0
+        self.L.orc_sa_init_io_mass_vertex_count(C.byref(self.op), _p(vertices), _p(hash_), _p(info), _p(cellStart), _p(neibslist),
+                                                _p(forces), C.c_uint32(range_end))
+        self.L.orc_sa_init_io_mass(C.byref(self.op), _p(pos), _p(forces), _p(vertices), _p(hash_), _p(info), _p(cellStart), _p(neibslist),
+                                   _p(new_pos), C.c_uint32(range_end), C.c_float(self.sp.deltap))
+
+    def sa_segment_bc_io(self, vel, ggam, eulervel, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step):
+        self.L.orc_sa_segment_bc_io(C.byref(self.op), _p(vel), _p(ggam), _p(eulervel), _p(pos), _p(vertices), _p(boundelements), _p(info),
+                                    _p(hash_), _p(cellStart), _p(neibslist), C.c_uint32(range_end), C.c_int(step))
+
+    def sa_vertex_bc_io(self, vel, old_pos, new_pos, ggam, eulervel, forces, vertices, boundelements, vertpos, info, hash_, next_ids,
+                        count, cellStart, neibslist, n, range_end, max_particles, dt, step, num_open_vertices):
+        self.L.orc_sa_vertex_bc_io(C.byref(self.op), _p(vel), _p(old_pos), _p(new_pos), _p(ggam), _p(eulervel), _p(forces), _p(vertices),
+                                   _p(boundelements), *self._vp(vertpos), _p(info), _p(hash_), _p(next_ids), _p(count), _p(cellStart),
+                                   _p(neibslist), C.c_uint32(range_end), C.c_uint32(max_particles), C.c_float(self.sp.deltap),
+                                   C.c_float(dt), C.c_int(step), C.c_uint32(num_open_vertices))
+
+    def sa_find_outgoing_segment(self, pos, vel, vertices, ggam, vertpos, boundelements, info, hash_, cellStart, neibslist, n, range_end):
+        self.L.orc_find_outgoing_segment(C.byref(self.op), _p(pos), _p(vel), _p(vertices), _p(ggam), *self._vp(vertpos), _p(boundelements),
+                                         _p(info), _p(hash_), _p(cellStart), _p(neibslist), C.c_uint32(range_end),
+                                         C.c_float(self.sp.influenceradius))
+
+    def sa_disable_outgoing_parts(self, pos, vertices, info, n):
+        self.L.orc_disable_outgoing_parts(_p(pos), _p(vertices), _p(info), C.c_uint32(n))
+
+    def sa_density_sum_io(self, new_vel, new_ggam, forces, old_pos, new_pos, old_vel, old_eulervel, old_ggam, boundelements, vertpos, info,
+                          hash_, cellStart, neibslist, n, range_end, dt):
+        new_ggam[:n] = old_ggam[:n]       # rows of the other particle types are copied
+        self.L.orc_sa_density_sum_io(C.byref(self.op), _p(new_vel), _p(new_ggam), _p(forces), _p(old_pos), _p(new_pos), _p(old_vel),
+                                     _p(old_eulervel), _p(old_ggam), _p(boundelements), *self._vp(vertpos), _p(info), _p(hash_),
+                                     _p(cellStart), _p(neibslist), C.c_uint32(range_end), C.c_float(dt))
+
+    def sa_density_diffusion_io(self, forces, pos, vel, ggam, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end, dt):
+        self.L.orc_sa_density_diffusion_io(C.byref(self.op), _p(forces), _p(pos), _p(vel), _p(ggam), _p(info), _p(hash_), _p(cellStart),
+                                           _p(neibslist), _p(boundelements), *self._vp(vertpos), C.c_uint32(range_end), C.c_float(dt),
+                                           C.c_float(self.sp.deltap))
+        fluid = (info[:range_end, 0].to(torch.int32) & 7) == 0
+        rows = torch.nonzero(fluid).flatten()
+        vel[rows, 3] = vel[rows, 3] + forces[rows, 3] * np.float32(dt)
+
+    def forces_sa_io(self, forces, cfl, pos, vel, eulervel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, n, frm, to,
+                     cfl_offset, cfl_gamma=None):
+        if to > frm:
+            forces[frm:to] = 0
+        self.L.orc_forces_sa_io.restype = C.c_uint32
+        return int(self.L.orc_forces_sa_io(C.byref(self.op), _p(forces), _p(cfl), _p(cfl_gamma), _p(pos), _p(vel), _p(eulervel), _p(info),
+                                           _p(hash_), _p(cellStart), _p(neibslist), _p(ggam), _p(boundelements), *self._vp(vertpos),
+                                           C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
+                                           C.c_float(self.sp.deltap)))
+
+    def sa_io_water_depth(self, depth, pos, info, hash_, cellStart, neibslist, n, frm, to):
+        self.L.orc_sa_io_water_depth(C.byref(self.op), _p(depth), _p(pos), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
+                                     C.c_uint32(frm), C.c_uint32(to))

@@ -262,10 +262,19 @@ class OracleSaIoSim:
         inlet = wall & (np.abs(g[:, 0]) < 1e-6) & ((t == D.PT_VERTEX) | (nrm[:, 0] > 0.5))
         outlet = wall & (np.abs(g[:, 0] - p.l) < 1e-6) & ((t == D.PT_VERTEX) | (nrm[:, 0] < -0.5))
         info = a["info"].copy()
-        info[inlet, 0] |= D.FG_INLET | D.FG_VELOCITY_DRIVEN
-        info[inlet, 1] = (info[inlet, 1] & 0xF000) | 1
-        info[outlet, 0] |= D.FG_OUTLET
-        info[outlet, 1] = (info[outlet, 1] & 0xF000) | 2
+        # a problem that is an open channel itself (gpusph_amd.problem.SAChannelIO) comes flagged, numbers its open boundaries
+        # from 0 and imposes its own values (the engine's driver is held against this sim with such a problem)
+        self.own_problem = hasattr(problem, "impose_open_boundaries")
+        if self.own_problem:
+            assert ((info[inlet, 0] & D.FG_INLET) != 0).all() and ((info[outlet, 0] & D.FG_OUTLET) != 0).all()
+            self.outlet_obj = 1
+            self.depth = np.zeros(problem.num_open_boundaries, dtype=np.uint32)
+        else:
+            self.outlet_obj = 2
+            info[inlet, 0] |= D.FG_INLET | D.FG_VELOCITY_DRIVEN
+            info[inlet, 1] = (info[inlet, 1] & 0xF000) | 1
+            info[outlet, 0] |= D.FG_OUTLET
+            info[outlet, 1] = (info[outlet, 1] & 0xF000) | 2
         self.num_open_vertices = int(((inlet | outlet) & (t == D.PT_VERTEX)).sum())
 
         def pad(x, fill):
@@ -274,7 +283,7 @@ class OracleSaIoSim:
             return out
         self.pos = pad(a["pos"], np.nan)                       # unused rows: inactive particles, sorted behind the active ones
         vel = a["vel"].copy()
-        vel[t == D.PT_FLUID, 0] = self.U                       # the stream is there from the start
+        vel[t == D.PT_FLUID, 0] = np.float32(self.U)           # the stream is there from the start
         self.vel = pad(vel, 0)
         self.info = pad(info, 0)
         self.hash = pad(a["hash"], D.CELL_HASH_MAX)
@@ -307,13 +316,24 @@ class OracleSaIoSim:
         _, self.pos = o.sa_init_io_mass(self.pos, self.info, self.hash, self.vertices, self.cs, self.nl, n, p.m_deltap)
         self.vel, self.ev = self._impose(self.pos, self.vel, self.ev)
         self.vel, self.gg, self.ev = o.sa_segment_bc_io(self.pos, self.vel, self.gg, self.ev, self.vertices, self.be, self.info, *A, n, 0)
-        self._vertex_bc(self.pos, self.vel, self.gg, self.ev, self.vertices, 0.0, 0)
+        a = self._vertex_bc(self.pos, self.vel, self.gg, self.ev, self.vertices, 0.0, 0)      # in place in the reference: kept
+        self.pos, self.vel, self.ev = a["new_pos"], a["vel"], a["euler_vel"]
 
     # ChannelIO_imposeBoundaryCondition (src/problems/ChannelIO.cu:104-131): the Lagrangian velocity of the open boundaries'
     # particles is cleared, a velocity boundary gets u_E = U ex, a pressure boundary the density of the hydrostatic pressure
     def _impose(self, pos, vel, ev):
         p = self.problem
         n = self.n
+        if self.own_problem:
+            import torch
+            vel, ev = vel.copy(), ev.copy()
+            depth = torch.from_numpy(self.depth.view(np.int32)) if self.water_depth else None
+            if self.water_depth:
+                self.level_seen.append(self.o.sa_io_water_depth_z(self.depth[self.outlet_obj]))
+            p.impose_open_boundaries(torch.from_numpy(pos), torch.from_numpy(vel), torch.from_numpy(ev),
+                                     torch.from_numpy(self.info.view(np.int16)), torch.from_numpy(self.hash.view(np.int32)), depth,
+                                     self.t, n)
+            return vel, ev
         io = (self.info[:n, 0] & (D.FG_INLET | D.FG_OUTLET)) != 0
         vdriven = (self.info[:n, 0] & D.FG_VELOCITY_DRIVEN) != 0
         vel, ev = vel.copy(), ev.copy()
@@ -327,7 +347,7 @@ class OracleSaIoSim:
         if self.water_depth:
             # <Problem>_imposeBoundaryConditionDevice (problems/CompleteSaExample.cu:266-272): the scaled maximum back to a height;
             # imposeBoundaryConditionHost clears the array after the launch (:323-325)
-            level = np.float32(self.o.sa_io_water_depth_z(self.depth[2]))
+            level = np.float32(self.o.sa_io_water_depth_z(self.depth[self.outlet_obj]))
             self.level_seen.append(float(level))
             self.depth[:] = 0
         pres = np.float32(9.81) * np.maximum(level - z.astype(np.float32), np.float32(0)) * np.float32(p.physparams.rho0[0])

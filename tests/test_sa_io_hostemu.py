@@ -293,3 +293,97 @@ def test_the_open_channel_over_the_emulated_kernels_follows_the_oracle():
     assert np.abs(spos[act, 3] - rpos[act, 3]).max() < 1e-3 * mref
     assert np.abs(np.array(sim.level_seen) - np.array(ref.level_seen)).max() < 1e-5
     emu.close()
+
+
+def test_the_engines_driver_over_the_bindings_and_the_emulated_kernels():
+    """gpusph_amd.multigpu's open-boundary sequence with the open-boundary passes going through HipKernels' OWN binding code
+    (gpusph_amd/kernels.py: argument order, scalars, the two-call passes) into the emulated library, everything else through the
+    oracle backend -- against the same driver over the oracle alone (which tests/test_engine_sa_io.py holds bit for bit against
+    the independent restatement of the command sequence)."""
+    import types
+    import torch
+    from gpusph_amd.kernels import HipKernels
+    from gpusph_amd.multigpu import MultiGpuEngine
+    from gpusph_amd.problem import SAChannelIO, info_id
+    from oracle_kernels import OracleKernels
+
+    IO = ("sa_identify_corner_vertices", "sa_init_io_mass", "sa_segment_bc_io", "sa_vertex_bc_io", "sa_find_outgoing_segment",
+          "sa_disable_outgoing_parts", "sa_density_sum_io", "sa_io_water_depth")
+
+    class EmuIoKernels(OracleKernels):
+        def __init__(self, problem, alloc):
+            super().__init__(problem, alloc)
+            self.emu = Emu(problem.sphx_params(alloc))
+            shim = object.__new__(HipKernels)
+            shim.lib, shim.ctx, shim.params = self.emu.lib, types.SimpleNamespace(handle=self.emu.h), self.sp
+            shim._s = lambda: None
+            shim.memset = lambda t, byte: t.view(torch.uint8).fill_(byte)
+            self.shim = shim
+            self.calls = {}
+            for name in IO:
+                setattr(self, name, self._bound(name))
+
+        def _bound(self, name):
+            fn = getattr(HipKernels, name)
+
+            def call(*a, **kw):
+                self.calls[name] = self.calls.get(name, 0) + 1
+                return fn(self.shim, *a, **kw)
+            return call
+
+        def forces_sa_io(self, forces, cfl, pos, vel, eulervel, *rest, **kw):
+            # the CFL maxima are block reductions (not emulated): the oracle's; the forces: the emulated kernel's
+            nb = OracleKernels.forces_sa_io(self, forces, cfl, pos, vel, eulervel, *rest, **kw)
+            keep = forces.clone()
+            scr_cfl = torch.zeros_like(cfl)
+            scr_g = torch.zeros_like(kw["cfl_gamma"]) if kw.get("cfl_gamma") is not None else None
+            self.calls["forces_sa_io"] = self.calls.get("forces_sa_io", 0) + 1
+            nb2 = HipKernels.forces_sa_io(self.shim, forces, scr_cfl, pos, vel, eulervel, *rest, cfl_gamma=scr_g)
+            assert nb2 == nb
+            self.last_force_gap = float((forces - keep).abs().max())
+            return nb
+
+    def diffusion(self_k):
+        # HipKernels.sa_density_diffusion_io is two calls; the second (sphx_apply_density_diffusion) belongs to the integration
+        # engine, which is not among the emulated files: the first call as the binding makes it, the update by hand
+        def call(forces, pos, vel, ggam, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end, dt):
+            p = capi_ptr
+            self_k.calls["sa_density_diffusion_io"] = self_k.calls.get("sa_density_diffusion_io", 0) + 1
+            rc = self_k.emu.lib.sphx_sa_compute_density_diffusion_io(self_k.emu.h, p(forces), p(pos), p(vel), p(ggam), p(boundelements),
+                                                                     p(vertpos[0]), p(vertpos[1]), p(vertpos[2]), p(info), p(hash_),
+                                                                     p(cellStart), p(neibslist), n, range_end, self_k.sp.deltap,
+                                                                     float(np.float32(dt)), None)
+            assert rc == 0
+            fluid = (info[:range_end, 0].to(torch.int32) & 7) == 0
+            rows = torch.nonzero(fluid).flatten()
+            vel[rows, 3] = vel[rows, 3] + forces[rows, 3] * np.float32(dt)
+        return call
+    from gpusph_amd.capi import ptr as capi_ptr
+
+    mk = lambda: SAChannelIO(0.05, U=0.6)
+    alloc = int(mk().num_particles * 1.6)
+    ref = MultiGpuEngine(mk(), "cpu", 0, 1, kernels=OracleKernels(mk(), alloc), allocated=alloc)
+    ke = EmuIoKernels(mk(), alloc)
+    ke.sa_density_diffusion_io = diffusion(ke)
+    eng = MultiGpuEngine(mk(), "cpu", 0, 1, kernels=ke, allocated=alloc)
+    for it in range(30):
+        ref.step(); eng.step()
+        assert eng.n_local == ref.n_local and eng.io_created == ref.io_created, it
+    for name in IO + ("forces_sa_io", "sa_density_diffusion_io"):
+        assert ke.calls.get(name, 0) >= (1 if name in ("sa_identify_corner_vertices", "sa_init_io_mass") else 30), name
+    n = eng.n_local
+    a = np.argsort(info_id(eng.info[:n].numpy().view(np.uint16)), kind="stable")
+    b = np.argsort(info_id(ref.info[:n].numpy().view(np.uint16)), kind="stable")
+    assert np.array_equal(eng.info[:n].numpy()[a], ref.info[:n].numpy()[b])
+    p = eng.problem
+    gp = p.global_pos(eng.pos[:n].numpy(), eng.hash[:n].numpy().view(np.uint32))[a]
+    gr = p.global_pos(ref.pos[:n].numpy(), ref.hash[:n].numpy().view(np.uint32))[b]
+    act = np.isfinite(ref.pos[:n].numpy()[b][:, 3])
+    cell = float(p.m_cellsize[0])
+    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, cell, spike=10.0, what="positions after 30 steps")
+    assert_close_but_for_gamma_spikes(eng.vel[:n].numpy()[a][act, :3], ref.vel[:n].numpy()[b][act, :3], 1e-3, 0.6, spike=10.0,
+                                      what="velocities after 30 steps")
+    assert_close_but_for_gamma_spikes(eng.vel[:n].numpy()[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.15, spike=50.0,
+                                      what="densities after 30 steps")
+    assert np.array_equal(eng.next_ids[:n].numpy()[a], ref.next_ids[:n].numpy()[b])
+    ke.emu.close()
