@@ -316,3 +316,39 @@ def test_brezzi_diffusion_and_water_depth_with_open_boundaries():
                                           n, 0, n, None))
     torch.cuda.synchronize()
     assert np.array_equal(d_depth.cpu().numpy().view(np.uint32), want_d)
+
+
+@pytest.mark.skipif(__import__("os").environ.get("SPHX_TEST_SA_IO_BC") != "1",
+                    reason="the open-boundary passes have not run on a GPU yet; SPHX_TEST_SA_IO_BC=1 runs the whole sequence on the device")
+def test_open_channel_on_the_device_follows_the_cpu_run(monkeypatch):
+    """SAChannelIO through the engine's open-boundary sequence on the GPU (the library's refusal of ENABLE_INLET_OUTLET lifted by
+    name for this test) against the same driver over the oracle's kernels on the CPU, which tests/test_engine_sa_io.py holds bit
+    for bit against the independent restatement of the reference's command sequence."""
+    from gpusph_amd.engine import TimestepEngine
+    from gpusph_amd.multigpu import MultiGpuEngine
+    from gpusph_amd.problem import SAChannelIO, info_id
+    from oracle_kernels import OracleKernels
+    from sa_helpers import assert_close_but_for_gamma_spikes
+    monkeypatch.setenv("SPHX_EXPERIMENTAL_SA_IO", "1")
+    mk = lambda: SAChannelIO(0.05, U=0.6)
+    alloc = int(mk().num_particles * 1.6)
+    ref = MultiGpuEngine(mk(), "cpu", 0, 1, kernels=OracleKernels(mk(), alloc), allocated=alloc)
+    eng = TimestepEngine(mk(), device="cuda:0", allocated=alloc)
+    for it in range(20):
+        ref.step(); eng.step()
+        assert eng.n_local == ref.n_local and eng.io_created == ref.io_created, it
+    n = eng.n_local
+    a = np.argsort(info_id(_np(eng.info[:n], np.uint16)), kind="stable")
+    b = np.argsort(info_id(ref.info[:n].numpy().view(np.uint16)), kind="stable")
+    assert np.array_equal(_np(eng.info[:n], np.uint16)[a], ref.info[:n].numpy().view(np.uint16)[b])
+    p = eng.problem
+    gp = p.global_pos(_np(eng.pos[:n]), _np(eng.hash[:n], np.uint32))[a]
+    gr = p.global_pos(ref.pos[:n].numpy(), ref.hash[:n].numpy().view(np.uint32))[b]
+    act = np.isfinite(ref.pos[:n].numpy()[b][:, 3])
+    assert np.array_equal(act, np.isfinite(_np(eng.pos[:n])[a][:, 3]))
+    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, float(p.m_cellsize[0]), spike=10.0, what="positions after 20 steps")
+    assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, :3], ref.vel[:n].numpy()[b][act, :3], 1e-3, 0.6, spike=10.0,
+                                      what="velocities after 20 steps")
+    assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.15, spike=50.0,
+                                      what="densities after 20 steps")
+    assert np.array_equal(_np(eng.next_ids[:n], np.uint32)[a], ref.next_ids[:n].numpy().view(np.uint32)[b])
