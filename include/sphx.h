@@ -313,7 +313,10 @@ int sphx_sa_find_outgoing_segment(sphx_ctx *ctx, const void *pos, const void *ve
 int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *vertices, const void *info, uint32_t numParticles, void *stream);
 /* saSegmentBoundaryConditions / saVertexBoundaryConditions with open boundaries (src/cuda/boundary_conditions.cu:108-235,280-410
  * with has_io; laminar, SPHX_SIMULATE).  WRITTEN, NOT YET RUN ON A GPU (end of round 4): ports of the oracle's restatements, their
- * parity test waits behind SPHX_TEST_SA_IO_BC=1 in tests/test_gpu_sa_io.py; no engine calls them.
+ * parity test waits behind SPHX_TEST_SA_IO_BC=1 in tests/test_gpu_sa_io.py.  Until it has passed, these and the other unverified
+ * open-boundary passes (density_sum_io, forces_basicstep_sa_io, compute_density_diffusion_io, io_water_depth) answer
+ * SPHX_ERR_UNSUPPORTED unless the environment holds SPHX_EXPERIMENTAL_SA_IO=1; the same word lets a context with
+ * ENABLE_INLET_OUTLET past the refusal of the other SA entry points.  The driver that calls them: gpusph_amd/multigpu.py.
  * segment pass: vel, gGam, eulerVel in place (boundary rows): an open-boundary segment gets the Riemann-invariant condition from
  * the Shepard means of the fluid next to it and what IMPOSE_OPEN_BOUNDARY_CONDITION left in eulerVel, a solid one the wall density
  * and a cleared Eulerian velocity.

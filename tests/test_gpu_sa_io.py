@@ -13,6 +13,14 @@ from sa_helpers import sa_oracle_state
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _ask_for_the_unverified_passes_by_name(monkeypatch):
+    """the library refuses the open-boundary passes that have not been verified on a GPU unless SPHX_EXPERIMENTAL_SA_IO=1; the
+    tests that run them (SPHX_TEST_SA_IO_BC=1) are that verification"""
+    if __import__("os").environ.get("SPHX_TEST_SA_IO_BC") == "1":
+        monkeypatch.setenv("SPHX_EXPERIMENTAL_SA_IO", "1")
+
+
 def _np(t, dtype=None):
     a = t.cpu().numpy()
     return a.view(dtype) if dtype is not None else a
