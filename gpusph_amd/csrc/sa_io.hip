@@ -682,9 +682,11 @@ extern "C" int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, v
 	(void)numParticles;
 	int rc = sa_io_bc_check(ctx, "saVertexBoundaryConditions called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
-	SPHX_REQUIRE(vel && pos && newPos && pos != newPos && gGam && eulerVel && forces && vertices && boundElements && vertPos0 && vertPos1 &&
+	SPHX_REQUIRE(vel && pos && newPos && gGam && eulerVel && forces && vertices && boundElements && vertPos0 && vertPos1 &&
 		vertPos2 && info && hash && nextIDs && newNumParticles && cellStart && neibsList, "sphx_sa_vertex_bc_io: missing buffer");
 	if (!particleRangeEnd) return SPHX_OK;
+	// pos == newPos (the reference's call: the read and the write list hold the same array) is fine: a thread writes its own row,
+	// xyz unchanged, and reads the masses of fluid rows only, which the pass does not write
 	SaIoBcArgs a = {};
 	a.vel = (float4*)vel; a.gGam = (float4*)gGam; a.eulerVel = (float4*)eulerVel; a.pos = (const float4*)pos; a.newPos = (float4*)newPos;
 	a.forces = (float4*)forces; a.vertices = (uint4*)vertices; a.boundElement = (float4*)boundElements; a.info = (particleinfo*)info;

@@ -402,6 +402,18 @@ public:
 	void compute_density_diffusion(const BufferList& bufread, BufferList& bufwrite, const uint numParticles,
 		const uint particleRangeEnd, const float deltap, const float slength, const float influenceRadius, const float dt)
 	{
+		if (m_c->params().simflags & ENABLE_INLET_OUTLET) {
+			// with open boundaries the term of the pressure-driven segments reads the elements and their vertices
+			// (sa_boundary_density_diffusion_params, src/cuda/density_diffusion_params.h:80-100)
+			const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
+			if (!vertPos) throw std::invalid_argument("compute_density_diffusion: open boundaries need BUFFER_VERTPOS");
+			sphx_throw(sphx_sa_compute_density_diffusion_io(m_c->ctx(), bufwrite.getData<BUFFER_FORCES>(),
+				bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_GRADGAMMA>(),
+				bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2], bufread.getData<BUFFER_INFO>(),
+				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(),
+				numParticles, particleRangeEnd, deltap, dt, NULL));
+			return;
+		}
 		sphx_throw(sphx_sa_compute_density_diffusion(m_c->ctx(), bufwrite.getData<BUFFER_FORCES>(),
 			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_GRADGAMMA>(),
 			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
@@ -410,7 +422,7 @@ public:
 
 	uint basicstep(const BufferList& bufread, BufferList& bufwrite, uint numParticles, uint fromParticle,
 		uint toParticle, float deltap, float slength, float dtadaptfactor, float influenceradius,
-		const float epsilon, uint *, uint cflOffset, const RunMode run_mode, const int step, const float dt,
+		const float epsilon, uint *IOwaterdepth, uint cflOffset, const RunMode run_mode, const int step, const float dt,
 		const bool compute_object_forces)
 	{
 		const sphx_params &P = m_c->params();
@@ -436,6 +448,20 @@ public:
 					bufread.getData<BUFFER_TKE>(), bufread.getData<BUFFER_EPSILON>(), bufread.getData<BUFFER_TURBVISC>(),
 					bufread.getData<BUFFER_EULERVEL>(), numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor,
 					influenceradius, epsilon, cflOffset, (int)run_mode, step, dt, &nb, NULL));
+				return nb;
+			}
+			if ((P.simflags & ENABLE_INLET_OUTLET) && run_mode == SIMULATE) {
+				// open boundaries: BUFFER_EULERVEL of the state that is read in the viscous terms and in the gamma CFL condition;
+				// then what the vertex pass leaves behind with ENABLE_WATER_DEPTH (vertex_forces, src/cuda/forces.cu:676-686)
+				sphx_throw(sphx_forces_basicstep_sa_io(m_c->ctx(), forces, cfl, gcfl ? bufwrite.getData<BUFFER_CFL_GAMMA>() : NULL,
+					bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_EULERVEL>(),
+					bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
+					bufread.getData<BUFFER_NEIBSLIST>(), bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(),
+					vertPos[0], vertPos[1], vertPos[2], numParticles, fromParticle, toParticle, deltap, cflOffset, &nb, NULL));
+				if ((P.simflags & ENABLE_WATER_DEPTH) && IOwaterdepth)
+					sphx_throw(sphx_sa_io_water_depth(m_c->ctx(), IOwaterdepth, bufread.getData<BUFFER_POS>(),
+						bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
+						bufread.getData<BUFFER_NEIBSLIST>(), numParticles, fromParticle, toParticle, NULL));
 				return nb;
 			}
 			sphx_throw(sphx_forces_basicstep_sa(m_c->ctx(), forces, cfl, gcfl ? bufwrite.getData<BUFFER_CFL_GAMMA>() : NULL,
@@ -597,6 +623,15 @@ public:
 		const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
 		if (!vertPos) throw std::invalid_argument("density_sum: BUFFER_VERTPOS missing");
 		const float4 *newPos = bufwrite.getConstData<BUFFER_POS>();
+		if (m_c->params().simflags & ENABLE_INLET_OUTLET) {
+			// io_density_sum_params (src/cuda/density_sum_params.h): BUFFER_EULERVEL of the state that is read
+			sphx_throw(sphx_sa_density_sum_io(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+				bufwrite.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_POS>(), newPos, bufread.getData<BUFFER_VEL>(),
+				bufread.getData<BUFFER_EULERVEL>(), bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(),
+				vertPos[0], vertPos[1], vertPos[2], bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+				bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, dt, NULL));
+			return;
+		}
 		sphx_throw(sphx_sa_density_sum(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
 			bufwrite.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_POS>(), newPos, bufread.getData<BUFFER_VEL>(),
 			bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
@@ -684,16 +719,18 @@ public:
 
 // ---- boundary-conditions engine of SA_BOUNDARY (CUDABoundaryConditionsEngine, src/cuda/boundary_conditions.cu) ----
 // Solid walls: vertex normals, initial gamma, segment and vertex boundary conditions.  Open boundaries: corner vertices, the initial
-// masses of the open vertices, the marking and removal of outgoing particles (sa_io.hip); the boundary-condition passes with open
-// boundaries (Riemann conditions, mass evolution, particle creation) and the water depth are not built.
+// masses of the open vertices, the marking and removal of outgoing particles (sa_io.hip, verified on the GPU); the boundary-condition
+// passes with open boundaries (Riemann conditions, mass evolution, particle creation) and the water depth are bound to entry points
+// the library refuses until they have passed their GPU tests (SPHX_ERR_UNSUPPORTED -> the exception a "not built" call throws).
 #include "engine_boundary_conditions.h"
 class HIPBoundaryConditionsEngine : public AbstractBoundaryConditionsEngine
 {
 	HIPEngineContextPtr m_c;
+	uint m_numOpenVertices;      // d_numOpenVertices of cubounds (src/cuda/boundary_conditions_kernel.cu:57): a member, passed by value
 public:
-	explicit HIPBoundaryConditionsEngine(HIPEngineContextPtr c) : m_c(c) {}
+	explicit HIPBoundaryConditionsEngine(HIPEngineContextPtr c) : m_c(c), m_numOpenVertices(0) {}
 
-	void uploadNumOpenVertices(const uint&) { sphx_not_built("uploadNumOpenVertices (open boundaries)"); }
+	void uploadNumOpenVertices(const uint &numOpenVertices) { m_numOpenVertices = numOpenVertices; }
 
 	// vel and gGam are updated in place for the boundary elements (src/cuda/boundary_conditions.cu:134-148)
 	void saSegmentBoundaryConditions(BufferList &bufwrite, BufferList const& bufread, const uint numParticles,
@@ -708,6 +745,14 @@ public:
 				bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
 				bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, deltap, slength, influenceradius,
 				step, SPHX_SIMULATE, NULL));
+			return;
+		}
+		if ((m_c->params().simflags & ENABLE_INLET_OUTLET) && run_mode != REPACK) {
+			// sa_segment_bc_params with has_io (src/cuda/sa_bc_params.h): the Eulerian velocity in place
+			sphx_throw(sphx_sa_segment_bc_io(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+				bufwrite.getData<BUFFER_EULERVEL>(), bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VERTICES>(),
+				bufread.getData<BUFFER_BOUNDELEMENTS>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+				bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, step, NULL));
 			return;
 		}
 		sphx_throw(sphx_sa_segment_bc(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
@@ -732,11 +777,32 @@ public:
 			numParticles, particleRangeEnd, influenceradius, NULL));
 	}
 
-	// without open boundaries: the density of the vertex particles; no particle is created, *newNumParticles is left alone
+	// without open boundaries: the density of the vertex particles; no particle is created, *newNumParticles is left alone.
+	// With them (sa_io_params + sa_cloning_params, src/cuda/sa_bc_params.h:209-270): the vertex masses into BUFFER_POS of the write
+	// list and, in the last step, new particles at *newNumParticles (a device word) in the arrays the reference opens
+	// MULTISTATE_SAFE; one device (the ids of new particles do not carry a device number)
 	void saVertexBoundaryConditions(BufferList &bufwrite, BufferList const& bufread, const uint numParticles,
 		const uint particleRangeEnd, const float deltap, const float slength, const float influenceradius,
-		const int step, const bool, const float, uint*, const uint, const uint, const uint, const RunMode run_mode)
+		const int step, const bool, const float dt, uint *newNumParticles, const uint, const uint numDevices, const uint totParticles,
+		const RunMode run_mode)
 	{
+		if ((m_c->params().simflags & ENABLE_INLET_OUTLET) && run_mode != REPACK && m_c->params().turbmodel != KEPSILON) {
+			if (numDevices > 1)
+				sphx_not_built("saVertexBoundaryConditions with open boundaries on several devices");
+			const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
+			if (!vertPos)
+				throw std::invalid_argument("saVertexBoundaryConditions: BUFFER_VERTPOS missing");
+			typedef BufferList::AccessSafety AS;
+			sphx_throw(sphx_sa_vertex_bc_io(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufread.getData<BUFFER_POS>(),
+				bufwrite.getData<BUFFER_POS>(), bufwrite.getData<BUFFER_GRADGAMMA>(), bufwrite.getData<BUFFER_EULERVEL>(),
+				bufwrite.getData<BUFFER_FORCES>(), bufwrite.getData<BUFFER_VERTICES, AS::MULTISTATE_SAFE>(),
+				bufwrite.getData<BUFFER_BOUNDELEMENTS, AS::MULTISTATE_SAFE>(), vertPos[0], vertPos[1], vertPos[2],
+				bufwrite.getData<BUFFER_INFO, AS::MULTISTATE_SAFE>(), bufwrite.getData<BUFFER_HASH, AS::MULTISTATE_SAFE>(),
+				bufwrite.getData<BUFFER_NEXTID, AS::MULTISTATE_SAFE>(), newNumParticles, bufread.getData<BUFFER_CELLSTART>(),
+				bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, totParticles, deltap, dt, step,
+				m_numOpenVertices, NULL));
+			return;
+		}
 		// sa_vertex_bc_params takes pos from the read list and vel / gGam from the write list (src/cuda/sa_bc_params.h)
 		if (m_c->params().turbmodel == KEPSILON && run_mode != REPACK) {
 			sphx_throw(sphx_sa_vertex_bc_keps(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
@@ -792,8 +858,11 @@ public:
 			bufwrite.getData<BUFFER_VERTICES, BufferList::AccessSafety::MULTISTATE_SAFE>(), bufread.getData<BUFFER_INFO>(),
 			particleRangeEnd, NULL));
 	}
-	void downloadIOwaterdepth(uint*, const uint*, const uint) { sphx_not_built("downloadIOwaterdepth (open boundaries)"); }
-	void uploadIOwaterdepth(const uint*, uint*, const uint) { sphx_not_built("uploadIOwaterdepth (open boundaries)"); }
+	// src/cuda/boundary_conditions.cu:644-663: the per-device maxima to the host and the global ones back
+	void downloadIOwaterdepth(uint *h_IOwaterdepth, const uint *d_IOwaterdepth, const uint numOpenBoundaries)
+	{ sphx_throw(sphx_memcpy_d2h(h_IOwaterdepth, d_IOwaterdepth, numOpenBoundaries*sizeof(uint))); }
+	void uploadIOwaterdepth(const uint *h_IOwaterdepth, uint *d_IOwaterdepth, const uint numOpenBoundaries)
+	{ sphx_throw(sphx_memcpy_h2d(d_IOwaterdepth, h_IOwaterdepth, numOpenBoundaries*sizeof(uint))); }
 	void saIdentifyCornerVertices(const BufferList &bufread, BufferList &bufwrite, const uint numParticles, const uint particleRangeEnd,
 		const float, const float)
 	{

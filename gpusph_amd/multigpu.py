@@ -216,7 +216,6 @@ class MultiGpuEngine:
             self.water_depth_on = bool(self.sp.simflags & D.ENABLE_WATER_DEPTH)
             self.iowaterdepth = torch.zeros(max(int(problem.num_open_boundaries), 1), dtype=i32, device=dev) if self.water_depth_on else None
             self.io_count = torch.zeros(1, dtype=i32, device=dev)         # newNumParticles of the vertex pass
-            self.io_scratch = torch.zeros((A, 4), dtype=f32, device=dev)  # the positions the vertex pass reads while it writes masses
             self.io_created = self.io_removed = 0
         # turbulence<KEPSILON>: BUFFER_TKE / EPSILON / TURBVISC / EULERVEL are particle properties (double buffered, re-sorted);
         # ProblemCore::init_keps and init_turbvisc (src/ProblemCore.cc:1623-1659) give the uniform initial state; BUFFER_DKDE and
@@ -377,12 +376,11 @@ class MultiGpuEngine:
             K.sa_disable_outgoing_parts(self.pos2, self.vertices, self.info, self.n_local)
 
     def _io_vertex_bc(self, pos, vel, ggam, eulervel, dt, step):
-        """SA_CALC_VERTEX_BOUNDARY_CONDITIONS with open boundaries: the pass reads the positions and masses it was given and writes
-        the vertex masses (and the rows of released particles) into `pos`; the new particle count comes back in a device word"""
+        """SA_CALC_VERTEX_BOUNDARY_CONDITIONS with open boundaries: the pass writes the vertex masses (and the rows of released
+        particles) into `pos`, in place as the reference has it; the new particle count comes back in a device word"""
         K, n = self.k, self.n_local
-        self.io_scratch[:n] = pos[:n]
         self.io_count[0] = n
-        K.sa_vertex_bc_io(vel, self.io_scratch, pos, ggam, eulervel, self.forces, self.vertices, self.boundelements, self.vertpos,
+        K.sa_vertex_bc_io(vel, pos, pos, ggam, eulervel, self.forces, self.vertices, self.boundelements, self.vertpos,
                           self.info, self.hash, self.next_ids, self.io_count, self.cellStart, self.neibslist, n, n, self.alloc,
                           dt, step, self.num_open_vertices)
         n2 = int(self.io_count.item()) & 0xFFFFFFFF
