@@ -1128,3 +1128,39 @@ extern "C" int sphx_sa_io_water_depth(sphx_ctx *ctx, uint32_t *IOwaterdepth, con
 	SPHX_LAUNCH_CHECK("sa_io_water_depth_kernel");
 	return SPHX_OK;
 }
+
+// ==========================================================================================
+// FLUX_COMPUTATION of the post-processing engine (src/cuda/post_process.cu:485-570, fluxComputationDevice
+// src/cuda/post_process_kernel.cu:822-840): per open boundary the volume flux sum A_s (u_E . n_s) over its segments.  The reference
+// adds onto a freshly allocated, uncleared device array; the sums start from zero here.  WRITTEN AT THE END OF ROUND 4, NOT YET RUN
+// ON A GPU (see above); the checker is orc_flux_computation.
+// ==========================================================================================
+__global__ void __launch_bounds__(256)
+sa_io_flux_kernel(const particleinfo *pinfo, const float4 *eulerVel, const float4 *boundElement, float *IOflux, uint32_t numOpenBoundaries,
+	uint32_t numParticles)
+{
+	const uint32_t index = blockIdx.x*256 + threadIdx.x;
+	if (index >= numParticles) return;
+	const particleinfo info = pinfo[index];
+	if (!(IS_IO_BOUNDARY(info) && PART_TYPE(info) == PT_BOUNDARY)) return;
+	const uint32_t ob = OBJECT_NUM(info);
+	if (ob >= numOpenBoundaries) return;      // (the reference would write out of bounds)
+	const float4 normal = boundElement[index], e = eulerVel[index];
+	atomicAdd(IOflux + ob, normal.w*(e.x*normal.x + e.y*normal.y + e.z*normal.z));
+}
+
+extern "C" int sphx_flux_computation(sphx_ctx *ctx, float *IOflux, const void *info, const void *eulerVel, const void *boundElements,
+	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t numOpenBoundaries, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_io_bc_check(ctx, "the flux through open boundaries is computed with SA_BOUNDARY only");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(IOflux && info && eulerVel && boundElements, "sphx_flux_computation: missing buffer");
+	if (!numOpenBoundaries) return SPHX_OK;
+	SPHX_HIP(hipMemsetAsync(IOflux, 0, numOpenBoundaries*sizeof(float), (hipStream_t)stream));
+	if (!particleRangeEnd) return SPHX_OK;
+	SPHX_LAUNCH(sa_io_flux_kernel, div_up_u(particleRangeEnd, 256), 256, (hipStream_t)stream, (const particleinfo*)info,
+		(const float4*)eulerVel, (const float4*)boundElements, IOflux, numOpenBoundaries, particleRangeEnd);
+	SPHX_LAUNCH_CHECK("sa_io_flux_kernel");
+	return SPHX_OK;
+}

@@ -423,3 +423,9 @@ class HipKernels:
         p = capi.ptr
         capi.check(self.lib.sphx_sa_io_water_depth(self.ctx.handle, p(depth), p(pos), p(info), p(hash_), p(cellStart), p(neibslist),
                                                    n, frm, to, self._s()))
+
+    def flux_computation(self, flux, info, eulervel, boundelements, n, num_open_boundaries):
+        """FLUX_COMPUTATION: flux[num_open_boundaries] (float32, device) = sum A_s (u_E . n_s) over the segments of each open boundary"""
+        p = capi.ptr
+        capi.check(self.lib.sphx_flux_computation(self.ctx.handle, p(flux), p(info), p(eulervel), p(boundelements), n, n,
+                                                  int(num_open_boundaries), self._s()))

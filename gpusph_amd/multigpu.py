@@ -389,6 +389,16 @@ class MultiGpuEngine:
         self.io_created += n2 - n
         self.n_local = self.n_int = self.edge_start = n2
 
+    def open_boundary_flux(self):
+        """FLUX_COMPUTATION of the post-processing engine (src/cuda/post_process.cu:485-570) on the current state: per open boundary
+        the volume flux sum A_s (u_E . n_s) through its segments, positive into the domain.  -> float32 tensor [num_open_boundaries]"""
+        if not self.io:
+            raise ValueError("the flux through open boundaries needs ENABLE_INLET_OUTLET")
+        nob = int(self.problem.num_open_boundaries)
+        flux = torch.zeros(max(nob, 1), dtype=torch.float32, device=self.device)
+        self.k.flux_computation(flux, self.info, self.eulervel, self.boundelements, self.n_local, nob)
+        return flux[:nob]
+
     def sa_boundary_conditions(self, step, run_mode=D.SIMULATE):
         """initializeBoundaryConditionsSequence<SA_BOUNDARY> (src/integrators/PredictorCorrectorIntegrator.cc:117-290) without
         open boundaries: at initialisation (step 0) the vertex normals and gamma, then in every step the segment and the vertex

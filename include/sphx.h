@@ -364,6 +364,12 @@ int sphx_sa_compute_density_diffusion_io(sphx_ctx *ctx, void *forces, const void
 	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float dt, void *stream);
 int sphx_sa_io_water_depth(sphx_ctx *ctx, uint32_t *IOwaterdepth, const void *pos, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, void *stream);
+/* FLUX_COMPUTATION of the post-processing engine (src/cuda/post_process.cu:485-570; fluxComputationDevice
+ * src/cuda/post_process_kernel.cu:822-840): IOflux[numOpenBoundaries] (device) = per open boundary the volume flux
+ * sum A_s (u_E . n_s) over its segments, from zero (the reference adds onto uncleared memory).  WRITTEN, NOT YET RUN ON A GPU:
+ * refused like the other unverified open-boundary passes (see sphx_sa_segment_bc_io). */
+int sphx_flux_computation(sphx_ctx *ctx, float *IOflux, const void *info, const void *eulerVel, const void *boundElements,
+	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t numOpenBoundaries, void *stream);
 /* saInitGamma (src/cuda/boundary_conditions.cu:457-560): gamma and grad gamma of fluid and vertex particles at initialisation,
  * grad gamma from the analytical formula of a triangular element, gamma by Gauss quadrature / solid angles
  * (src/cuda/gamma.cuh).  Rows of boundary elements are not written.  oldGGam is accepted for interface parity (unused). */

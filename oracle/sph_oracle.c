@@ -4147,3 +4147,20 @@ void orc_sa_density_diffusion_io(const orc_params *p, orc_f4 *forces, const orc_
 		forces[index].w = DrDt/p->rho0[fl];
 	}
 }
+
+/* fluxComputationDevice (src/cuda/post_process_kernel.cu:822-840; FLUX_COMPUTATION of the post-processing engine,
+ * src/cuda/post_process.cu:485-570): per open boundary (the object number of its segments) the volume flux sum A_s (u_E . n_s)
+ * over its segments -- positive into the domain, the normals point at the fluid.  The reference adds onto a device array it has
+ * just allocated and never cleared; here the sums start from zero.  Serial, in particle order (the device adds atomically, in any
+ * order: compare to rounding).  GROUNDWORK (see above). */
+void orc_flux_computation(float *IOflux, const orc_info *infoArray, const orc_f4 *eulerVel, const orc_f4 *boundelement,
+	uint32_t numParticles, uint32_t numOpenBoundaries)
+{
+	for (uint32_t ob = 0; ob < numOpenBoundaries; ++ob) IOflux[ob] = 0.0f;
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		if (!(IO_BOUNDARY(info) && BOUNDARY(info))) continue;
+		const orc_f4 normal = boundelement[index], e = eulerVel[index];
+		IOflux[OBJECT_NUM(info)] += normal.w*(e.x*normal.x + e.y*normal.y + e.z*normal.z);
+	}
+}

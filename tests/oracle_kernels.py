@@ -329,3 +329,6 @@ class OracleKernels:
     def sa_io_water_depth(self, depth, pos, info, hash_, cellStart, neibslist, n, frm, to):
         self.L.orc_sa_io_water_depth(C.byref(self.op), _p(depth), _p(pos), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
                                      C.c_uint32(frm), C.c_uint32(to))
+
+    def flux_computation(self, flux, info, eulervel, boundelements, n, num_open_boundaries):
+        self.L.orc_flux_computation(_p(flux), _p(info), _p(eulervel), _p(boundelements), C.c_uint32(n), C.c_uint32(num_open_boundaries))

@@ -67,3 +67,22 @@ def test_open_boundaries_need_what_the_driver_is_built_for():
     p.simparams.buildneibsfreq = 10
     with pytest.raises(NotImplementedError):
         _engine(p, p.num_particles + 4096)
+
+
+def test_flux_through_the_open_boundaries():
+    """FLUX_COMPUTATION: the inlet carries U over its whole wall (the imposed u_E is the same on dry segments), the outlet draws
+    about what the wet part of the inlet delivers"""
+    p = SAChannelIO(0.05, U=0.6)
+    eng = _engine(p, p.num_particles + 4096)
+    for _ in range(12):
+        eng.step()
+    flux = eng.open_boundary_flux().numpy()
+    assert flux.shape == (2,)
+    assert flux[0] == pytest.approx(0.6 * p.w * p.h, rel=1e-5)
+    assert -1.3 * 0.6 * p.w * p.water_level < flux[1] < -0.6 * 0.6 * p.w * p.water_level
+    # by hand
+    n = eng.n_local
+    info = eng.info[:n].numpy().view(np.uint16)
+    seg = (info_type(info) == D.PT_BOUNDARY) & ((info[:, 0] & D.FG_OUTLET) != 0)
+    be, ev = eng.boundelements[:n].numpy()[seg].astype(np.float64), eng.eulervel[:n].numpy()[seg].astype(np.float64)
+    assert flux[1] == pytest.approx(float((be[:, 3] * (ev[:, :3] * be[:, :3]).sum(axis=1)).sum()), rel=1e-5)

@@ -403,3 +403,20 @@ def test_the_unverified_passes_are_refused_unless_asked_for_by_name(ctx, monkeyp
     monkeypatch.setenv("SPHX_EXPERIMENTAL_SA_IO", "1")
     emu.call("sphx_sa_io_water_depth", depth, st["pos"], info, st["hash"], st["cs"], st["nl"], n, 0, n, None)
     assert depth[1] > 0
+
+
+def test_flux_computation_in_emulation(ctx):
+    st, emu, seg, vtx = ctx["st"], ctx["emu"], ctx["seg"], ctx["vtx"]
+    o, n = st["oracle"], st["n"]
+    info = _flag(ctx, D.FG_INLET | D.FG_VELOCITY_DRIVEN)
+    ev = np.random.default_rng(9).normal(size=(n, 4)).astype(np.float32)
+    be = st["boundelements"]
+    want = np.full(3, 7.0, dtype=np.float32)
+    o.L.orc_flux_computation(want.ctypes.data_as(__import__("ctypes").c_void_p), info.ctypes.data_as(__import__("ctypes").c_void_p),
+                             ev.ctypes.data_as(__import__("ctypes").c_void_p), be.ctypes.data_as(__import__("ctypes").c_void_p),
+                             __import__("ctypes").c_uint32(n), __import__("ctypes").c_uint32(3))
+    got = np.full(3, -3.0, dtype=np.float32)
+    emu.call("sphx_flux_computation", got, info, ev, be, n, n, 3, None)
+    assert np.array_equal(got, want) and want[1] != 0 and want[0] == 0 and want[2] == 0
+    by_hand = (be[seg, 3].astype(np.float64) * (ev[seg, :3].astype(np.float64) * be[seg, :3]).sum(axis=1)).sum()
+    assert want[1] == pytest.approx(by_hand, rel=1e-4)
