@@ -324,6 +324,17 @@ def test_brezzi_diffusion_and_water_depth_with_open_boundaries():
                                           n, 0, n, None))
     torch.cuda.synchronize()
     assert np.array_equal(d_depth.cpu().numpy().view(np.uint32), want_d)
+    # FLUX_COMPUTATION: float atomics in any order
+    import ctypes as C
+    ev = np.random.default_rng(9).normal(size=(n, 4)).astype(np.float32)
+    want_f = np.zeros(2, dtype=np.float32)
+    vp_ = lambda a: a.ctypes.data_as(C.c_void_p)
+    o.L.orc_flux_computation(vp_(want_f), vp_(info), vp_(ev), vp_(be), C.c_uint32(n), C.c_uint32(2))
+    d_flux = torch.full((2,), 5.0, dtype=torch.float32, device=dev)
+    capi.check(lib.sphx_flux_computation(h, P(d_flux), P(d_info), P(up(ev, eng.vel)), P(d_be), n, n, 2, None))
+    got_f = d_flux.cpu().numpy()
+    assert want_f[1] != 0 and got_f[0] == 0
+    assert abs(got_f[1] - want_f[1]) < 1e-5 * np.abs(be[seg, 3]).sum() * 3
 
 
 @pytest.mark.skipif(__import__("os").environ.get("SPHX_TEST_SA_IO_BC") != "1",
