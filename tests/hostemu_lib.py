@@ -13,7 +13,7 @@ from gpusph_amd import capi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _EMU = os.path.join(_HERE, "hostemu")
 _ROOT = os.path.dirname(_HERE)
-_SO = os.path.join(_EMU, "_build", "libsphx_emu.so")
+_SO = os.path.join(_EMU, "_build", "libsphx_emu_asan.so" if os.environ.get("SPHX_HOSTEMU_ASAN") == "1" else "libsphx_emu.so")
 _SOURCES = [os.path.join(_EMU, "emu_sphx.cc"), os.path.join(_EMU, "hip", "hip_runtime.h")] + \
     [os.path.join(_ROOT, "gpusph_amd", "csrc", f) for f in ("sphx_api.hip", "sa_io.hip", "sphx_internal.h", "neib_iter.h",
                                                               "sa_wall_gamma.h", "sa_args.h")] + \
@@ -31,7 +31,10 @@ def build():
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in _SOURCES):
         return _SO
     # -ffp-contract=off as the library's own build of these files; -O1: compile time
-    cmd = ["g++", "-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes",
+    # SPHX_HOSTEMU_ASAN=1: an address-sanitised build, for a run under LD_PRELOAD=libasan.so (out-of-bounds reads and writes of the
+    # kernels on the exact-size numpy buffers of these tests; see tests/hostemu/README)
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if os.environ.get("SPHX_HOSTEMU_ASAN") == "1" else []
+    cmd = ["g++", "-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes"] + san + [
            "-I" + _EMU, "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_ROOT, "gpusph_amd", "csrc"),
            "-o", _SO, os.path.join(_EMU, "emu_sphx.cc")]
     subprocess.run(cmd, check=True, capture_output=True)
