@@ -360,11 +360,15 @@ class HipKernels:
         capi.check(self.lib.sphx_sa_identify_corner_vertices(self.ctx.handle, p(pos), p(info), p(hash_), p(vertices), p(cellStart),
                                                              p(neibslist), n, range_end, self._s()))
 
-    def sa_init_io_mass(self, new_pos, pos, forces, vertices, hash_, info, cellStart, neibslist, n, range_end):
+    def sa_init_io_mass_vertex_count(self, forces, pos, vertices, hash_, info, cellStart, neibslist, n, range_end):
+        """INIT_IO_MASS_VERTEX_COUNT: the counts in forces.w (BUFFER_FORCES as scratch); the halo's come by UPDATE_EXTERNAL"""
         p = capi.ptr
         self.memset(forces, 0)
         capi.check(self.lib.sphx_sa_init_io_mass_vertex_count(self.ctx.handle, p(vertices), p(hash_), p(info), p(cellStart), p(neibslist),
                                                               p(forces), p(pos), n, range_end, self._s()))
+
+    def sa_init_io_mass(self, new_pos, pos, forces, vertices, hash_, info, cellStart, neibslist, n, range_end):
+        p = capi.ptr
         capi.check(self.lib.sphx_sa_init_io_mass(self.ctx.handle, p(pos), p(forces), p(vertices), p(hash_), p(info), p(cellStart),
                                                  p(neibslist), p(new_pos), n, range_end, self.params.deltap, self._s()))
 

@@ -191,13 +191,11 @@ class MultiGpuEngine:
             self.sa_density_sum = bool(self.sp.simflags & D.ENABLE_DENSITY_SUM)
             self.cfl_gamma = (torch.zeros(A + 4 + self.cfl.numel(), dtype=f32, device=dev) if self.sa_dynamic_gamma else None)
         # SA open boundaries (ENABLE_INLET_OUTLET): BUFFER_EULERVEL (double buffered) and BUFFER_NEXTID travel through the re-sort,
-        # IOwaterdepth is one uint per open boundary, the particle count grows inside the allocation.  One device, the density
+        # IOwaterdepth is one uint per open boundary, the particle count grows inside the allocation.  The density
         # summation form, a rebuild in every iteration (the reference's open-boundary problems set buildneibsfreq = 1: a released
         # particle exists for the lists from the next rebuild on).  See _sa_post_euler_io.
         self.io = self.sa and bool(self.sp.simflags & D.ENABLE_INLET_OUTLET)
         if self.io:
-            if world > 1:
-                raise NotImplementedError("open boundaries over several devices are not built")
             if not self.sa_density_sum or self.keps or self.sp.buildneibsfreq != 1:
                 raise NotImplementedError("open boundaries are built for the density summation form without k-epsilon, buildneibsfreq = 1")
             if not hasattr(problem, "impose_open_boundaries"):
@@ -352,42 +350,65 @@ class MultiGpuEngine:
 
     def _sa_post_euler_io(self, step):
         """The post-Euler commands of a step with ENABLE_INLET_OUTLET (src/integrators/PredictorCorrectorIntegrator.cc:127-300,
-        607-684), one device: DENSITY_SUM [+ density diffusion] with the open boundaries' terms from the state of step n,
-        IMPOSE_OPEN_BOUNDARY_CONDITION (the problem's values; it consumes and clears the water depth), the segment conditions,
-        in the last step FIND_OUTGOING_SEGMENT, the vertex conditions (vertex masses; in the last step the take-over of outgoing
-        particles and the release of new ones: the particle count grows), in the last step DISABLE_OUTGOING_PARTS."""
-        K, n = self.k, self.n_local
+        607-684): DENSITY_SUM [+ density diffusion] with the open boundaries' terms from the state of step n,
+        IMPOSE_OPEN_BOUNDARY_CONDITION (the problem's values; it consumes and clears the water depth, the maximum over the devices),
+        the segment conditions, in the last step FIND_OUTGOING_SEGMENT, the vertex conditions (vertex masses; in the last step
+        the take-over of outgoing particles and the release of new ones: the particle count grows), in the last step
+        DISABLE_OUTGOING_PARTS.  Every pass covers the internal particles and is followed by the UPDATE_EXTERNAL of what it wrote."""
+        K, n, ni = self.k, self.n_local, self.n_int
+        ext = (lambda ts: self._exchange(ts)) if self.world > 1 else (lambda ts: None)
         dt = float(np.float32(np.float32(self.d_dt.item()) * np.float32(0.5 if step == 1 else 1.0)))      # dt_op, on the host
         K.sa_density_sum_io(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.eulervel, self.gradgamma,
-                            self.boundelements, self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, n, dt)
+                            self.boundelements, self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, ni, dt)
+        ext([self.vel2, self.gradgamma2])
         if self.sp.densitydiffusiontype == D.BREZZI:
             K.sa_density_diffusion_io(self.forces, self.pos2, self.vel2, self.gradgamma2, self.boundelements, self.vertpos, self.info,
-                                      self.hash, self.cellStart, self.neibslist, n, n, dt)
+                                      self.hash, self.cellStart, self.neibslist, n, ni, dt)
+            ext([self.vel2])
         self.eulervel2[:n] = self.eulervel[:n]
-        self.problem.impose_open_boundaries(self.pos2, self.vel2, self.eulervel2, self.info, self.hash, self.iowaterdepth,
-                                            self.time(), n)
+        self._io_impose(self.pos2, self.vel2, self.eulervel2)
         K.sa_segment_bc_io(self.vel2, self.gradgamma2, self.eulervel2, self.pos2, self.vertices, self.boundelements, self.info,
-                           self.hash, self.cellStart, self.neibslist, n, n, step)
+                           self.hash, self.cellStart, self.neibslist, n, ni, step)
+        ext([self.vel2, self.gradgamma2, self.eulervel2])
         if step == 2:
             K.sa_find_outgoing_segment(self.pos2, self.vel2, self.vertices, self.gradgamma2, self.vertpos, self.boundelements,
-                                       self.info, self.hash, self.cellStart, self.neibslist, n, n)
+                                       self.info, self.hash, self.cellStart, self.neibslist, n, ni)
+            ext([self.vertices, self.gradgamma2])      # the marks: a vertex takes over from the halo's particles too
         self._io_vertex_bc(self.pos2, self.vel2, self.gradgamma2, self.eulervel2, dt, step)
         if step == 2:
             K.sa_disable_outgoing_parts(self.pos2, self.vertices, self.info, self.n_local)
 
+    def _io_impose(self, pos, vel, eulervel):
+        """IMPOSE_OPEN_BOUNDARY_CONDITION on every particle this device holds (the values are a function of position, time and
+        the water level); over several devices the level is the maximum of theirs first (DOWNLOAD_IOWATERDEPTH,
+        FIND_MAX_IOWATERDEPTH, UPLOAD_IOWATERDEPTH: src/integrators/PredictorCorrectorIntegrator.cc:214-222, GPUSPH.cc:2206-2226)"""
+        if self.world > 1 and self.iowaterdepth is not None:
+            mine = (self.iowaterdepth.to(torch.int64) & 0xFFFFFFFF).cpu().tolist()
+            best = [max(v for v, _ in self.transport.allgather_pair(m, 0, self.device)) for m in mine]
+            self.iowaterdepth.copy_(torch.tensor(best, dtype=torch.int64).to(torch.int32).to(self.device)
+                                    if max(best) < 2 ** 31 else
+                                    torch.from_numpy(np.array(best, dtype=np.uint32).view(np.int32)).to(self.device))
+        self.problem.impose_open_boundaries(pos, vel, eulervel, self.info, self.hash, self.iowaterdepth, self.time(), self.n_local)
+
     def _io_vertex_bc(self, pos, vel, ggam, eulervel, dt, step):
         """SA_CALC_VERTEX_BOUNDARY_CONDITIONS with open boundaries: the pass writes the vertex masses (and the rows of released
-        particles) into `pos`, in place as the reference has it; the new particle count comes back in a device word"""
-        K, n = self.k, self.n_local
+        particles) into `pos`, in place as the reference has it; the new particle count comes back in a device word.  Released
+        particles are appended behind everything this device holds (its halo included); they belong to it (the hash of the vertex
+        that released them) and are sorted in at the next rebuild"""
+        K, n, ni = self.k, self.n_local, self.n_int
         self.io_count[0] = n
         K.sa_vertex_bc_io(vel, pos, pos, ggam, eulervel, self.forces, self.vertices, self.boundelements, self.vertpos,
-                          self.info, self.hash, self.next_ids, self.io_count, self.cellStart, self.neibslist, n, n, self.alloc,
+                          self.info, self.hash, self.next_ids, self.io_count, self.cellStart, self.neibslist, n, ni, self.alloc,
                           dt, step, self.num_open_vertices)
         n2 = int(self.io_count.item()) & 0xFFFFFFFF
         if n2 > self.alloc:
             raise RuntimeError("open boundaries released more particles than the allocation holds (%d > %d)" % (n2, self.alloc))
+        if self.world > 1:
+            self._exchange([pos, vel, eulervel])      # vertex masses, densities and Eulerian velocities of the halo's vertices
         self.io_created += n2 - n
-        self.n_local = self.n_int = self.edge_start = n2
+        self.n_local = n2
+        if self.world == 1:
+            self.n_int = self.edge_start = n2
 
     def open_boundary_flux(self):
         """FLUX_COMPUTATION of the post-processing engine (src/cuda/post_process.cu:485-570) on the current state: per open boundary
@@ -419,13 +440,18 @@ class MultiGpuEngine:
             # the two condition passes of step 0
             if step != 0 or run_mode != D.SIMULATE:
                 raise NotImplementedError("open boundaries: only the initialisation sequence goes through sa_boundary_conditions")
-            K.sa_identify_corner_vertices(self.pos, self.info, self.hash, self.vertices, self.cellStart, self.neibslist, n, n)
-            K.sa_init_io_mass(self.pos2, self.pos, self.forces, self.vertices, self.hash, self.info, self.cellStart, self.neibslist, n, n)
+            K.sa_identify_corner_vertices(self.pos, self.info, self.hash, self.vertices, self.cellStart, self.neibslist, n, ni)
+            ext([self.info])
+            K.sa_init_io_mass_vertex_count(self.forces, self.pos, self.vertices, self.hash, self.info, self.cellStart, self.neibslist, n, ni)
+            ext([self.forces])      # a vertex divides by the counts of the vertices it shares segments with, the halo's among them
+            K.sa_init_io_mass(self.pos2, self.pos, self.forces, self.vertices, self.hash, self.info, self.cellStart, self.neibslist, n, ni)
+            self.pos2[ni:n] = self.pos[ni:n]      # (the pass writes the internal rows)
             self.pos, self.pos2 = self.pos2, self.pos
-            self.problem.impose_open_boundaries(self.pos, self.vel, self.eulervel, self.info, self.hash, self.iowaterdepth,
-                                                self.time(), n)
+            ext([self.pos])
+            self._io_impose(self.pos, self.vel, self.eulervel)
             K.sa_segment_bc_io(self.vel, self.gradgamma, self.eulervel, self.pos, self.vertices, self.boundelements, self.info,
-                               self.hash, self.cellStart, self.neibslist, n, n, 0)
+                               self.hash, self.cellStart, self.neibslist, n, ni, 0)
+            ext([self.vel, self.gradgamma, self.eulervel])
             self._io_vertex_bc(self.pos, self.vel, self.gradgamma, self.eulervel, 0.0, 0)
             return
         if self.keps and run_mode == D.SIMULATE:
@@ -483,6 +509,8 @@ class MultiGpuEngine:
             state.append(self.energy)
         if self.sa:      # BUFFER_VERTICES / BOUNDELEMENTS / GRADGAMMA are particle state too
             state += [self.vertices, self.boundelements, self.gradgamma]
+        if self.io:      # ... and BUFFER_EULERVEL (the halo's vertices and segments enter the forces with theirs)
+            state.append(self.eulervel)
         if self.keps:
             state += list(self.ke.values())
         self._exchange(state)
@@ -608,7 +636,7 @@ class MultiGpuEngine:
         if self.sa and self.sa_dynamic_gamma and run_mode == D.SIMULATE:     # the CFL condition of the gamma transport (src/cuda/forces.cu:576-585)
             K.dtreduce_gamma(self.cfl_gamma, self.n_local, nb1 + nb2, self.d_dt_next)
         if self.io and self.water_depth_on:      # the vertex pass of the forces (vertex_forces, src/cuda/forces.cu:676-686)
-            K.sa_io_water_depth(self.iowaterdepth, pos, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, 0, self.n_local)
+            K.sa_io_water_depth(self.iowaterdepth, pos, self.info, self.hash, self.cellStart, self.neibslist, self.n_local, 0, self.n_int)
 
     def step(self):
         K = self.k

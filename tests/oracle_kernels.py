@@ -275,10 +275,12 @@ class OracleKernels:
         self.L.orc_sa_identify_corner_vertices(C.byref(self.op), _p(pos), _p(info), _p(hash_), _p(vertices), _p(cellStart), _p(neibslist),
                                                C.c_uint32(range_end))
 
-    def sa_init_io_mass(self, new_pos, pos, forces, vertices, hash_, info, cellStart, neibslist, n, range_end):
+    def sa_init_io_mass_vertex_count(self, forces, pos, vertices, hash_, info, cellStart, neibslist, n, range_end):
         forces[:n] = 0
         self.L.orc_sa_init_io_mass_vertex_count(C.byref(self.op), _p(vertices), _p(hash_), _p(info), _p(cellStart), _p(neibslist),
                                                 _p(forces), C.c_uint32(range_end))
+
+    def sa_init_io_mass(self, new_pos, pos, forces, vertices, hash_, info, cellStart, neibslist, n, range_end):
         self.L.orc_sa_init_io_mass(C.byref(self.op), _p(pos), _p(forces), _p(vertices), _p(hash_), _p(info), _p(cellStart), _p(neibslist),
                                    _p(new_pos), C.c_uint32(range_end), C.c_float(self.sp.deltap))
 

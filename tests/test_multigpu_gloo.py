@@ -44,6 +44,9 @@ def _worker(rank, world, port, steps, case, outdir, filters=()):
     elif which == "SABox":
         from gpusph_amd.problem import SABox
         prob = SABox(**case)
+    elif which == "SAChannelIO":
+        from gpusph_amd.problem import SAChannelIO
+        prob = SAChannelIO(**case)
     elif which == "PeriodicBox":
         from gpusph_amd.problem import PeriodicBox
         prob = PeriodicBox(**case)
@@ -57,7 +60,13 @@ def _worker(rank, world, port, steps, case, outdir, filters=()):
         eng.add_filter(ftype, freq)
     for _ in range(steps):
         eng.step()
+    if getattr(eng, "io", False):
+        eng.build_neibs()        # the particles released in the last step are sorted in (and the removed ones dropped) by a rebuild
     out = eng.download_internal()
+    if getattr(eng, "io", False):
+        out["eulervel"] = eng.eulervel[:eng.n_int].numpy()
+        out["io_created"] = np.array(eng.io_created)
+        out["n0"] = np.array(prob.num_particles)
     rb = eng.reduce_rb_forces() or (np.zeros((0, 3)), np.zeros((0, 3)))     # no bodies with force feedback: nothing to reduce
     np.savez(os.path.join(outdir, "r%d_of_%d.npz" % (rank, world)), n_local=eng.n_local, dt=eng.current_dt(),
              interactions=eng.neibs_info().numInteractions, rbf=rb[0], rbt=rb[1], **out)
@@ -326,3 +335,38 @@ def test_slab_runs_of_the_fidelity_option_sets_equal_single_domain(tmp_path, nam
         else:
             assert np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), (name, k)
     assert all(p["n_local"] > 0 for p in p2) and float(p2[0]["dt"]) == float(p1[0]["dt"])
+
+
+@pytest.mark.parametrize("cut", ["across the stream", "along the stream", "along the stream, until particles leave"])
+def test_open_channel_over_two_slabs_equals_single_domain(tmp_path, cut):
+    """SAChannelIO (open boundaries: inlet on the first slab, pressure outlet on the last, the water level the outlet's pressure
+    follows measured on one device and used on both) cut across the stream: every pass of the open-boundary sequence over the
+    internal particles with the UPDATE_EXTERNAL of what it wrote, the water depth as the maximum over the devices, particles
+    released behind the halo rows and sorted in at the next rebuild -- bit-equal to the single-domain run."""
+    if cut == "across the stream":
+        case = dict(problem="SAChannelIO", deltap=0.05, U=0.6, linearization="yzx")
+    else:
+        # slabs along y: both open boundaries on both devices, their vertices and segments in each other's halo, particles released
+        # next to the cut, the outlet's water level measured on both
+        case = dict(problem="SAChannelIO", deltap=0.05, U=0.6, l=0.6, w=0.8, linearization="xzy")
+    steps = 14
+    if cut.endswith("leave"):
+        # a fast stream in a short tank: the first layer crosses the outlet within the run -- the marks of FIND_OUTGOING_SEGMENT
+        # travel to the halo, a vertex takes over the mass of a neighbour device's particle, both devices disable their copy
+        case = dict(problem="SAChannelIO", deltap=0.05, U=2.0, l=0.5, w=0.8, h=0.3, H=0.2, linearization="xzy")
+        steps = 74
+    _run(1, steps, case, str(tmp_path))
+    _run(2, steps, case, str(tmp_path))
+    ids1, one, p1 = _gather(str(tmp_path), 1)
+    ids2, two, p2 = _gather(str(tmp_path), 2)
+    assert np.array_equal(ids1, ids2)
+    if cut.endswith("leave"):
+        assert len(ids1) < int(p1[0]["n0"]) + int(p1[0]["io_created"])       # somebody left
+    assert int(p1[0]["io_created"]) > 0 and sum(int(p["io_created"]) for p in p2) == int(p1[0]["io_created"])
+    for k in ("pos", "vel", "gradgamma", "eulervel"):
+        a, b = one[k], two[k]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), k
+        assert np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32)), k
+    assert np.array_equal(one["info"], two["info"])
+    assert all(float(p["dt"]) == float(p1[0]["dt"]) for p in p2)
+    assert all(int(p["n_local"]) > len(p["pos"]) for p in p2)

@@ -307,7 +307,7 @@ def test_the_engines_driver_over_the_bindings_and_the_emulated_kernels():
     from gpusph_amd.problem import SAChannelIO, info_id
     from oracle_kernels import OracleKernels
 
-    IO = ("sa_identify_corner_vertices", "sa_init_io_mass", "sa_segment_bc_io", "sa_vertex_bc_io", "sa_find_outgoing_segment",
+    IO = ("sa_identify_corner_vertices", "sa_init_io_mass_vertex_count", "sa_init_io_mass", "sa_segment_bc_io", "sa_vertex_bc_io", "sa_find_outgoing_segment",
           "sa_disable_outgoing_parts", "sa_density_sum_io", "sa_io_water_depth")
 
     class EmuIoKernels(OracleKernels):
@@ -370,7 +370,7 @@ def test_the_engines_driver_over_the_bindings_and_the_emulated_kernels():
         ref.step(); eng.step()
         assert eng.n_local == ref.n_local and eng.io_created == ref.io_created, it
     for name in IO + ("forces_sa_io", "sa_density_diffusion_io"):
-        assert ke.calls.get(name, 0) >= (1 if name in ("sa_identify_corner_vertices", "sa_init_io_mass") else 30), name
+        assert ke.calls.get(name, 0) >= (1 if name in ("sa_identify_corner_vertices", "sa_init_io_mass_vertex_count", "sa_init_io_mass") else 30), name
     n = eng.n_local
     a = np.argsort(info_id(eng.info[:n].numpy().view(np.uint16)), kind="stable")
     b = np.argsort(info_id(ref.info[:n].numpy().view(np.uint16)), kind="stable")
