@@ -780,15 +780,13 @@ public:
 	// without open boundaries: the density of the vertex particles; no particle is created, *newNumParticles is left alone.
 	// With them (sa_io_params + sa_cloning_params, src/cuda/sa_bc_params.h:209-270): the vertex masses into BUFFER_POS of the write
 	// list and, in the last step, new particles at *newNumParticles (a device word) in the arrays the reference opens
-	// MULTISTATE_SAFE; one device (the ids of new particles do not carry a device number)
+	// MULTISTATE_SAFE (ids come from BUFFER_NEXTID, unique over the devices: deviceId / numDevices do not enter the kernel)
 	void saVertexBoundaryConditions(BufferList &bufwrite, BufferList const& bufread, const uint numParticles,
 		const uint particleRangeEnd, const float deltap, const float slength, const float influenceradius,
-		const int step, const bool, const float dt, uint *newNumParticles, const uint, const uint numDevices, const uint totParticles,
+		const int step, const bool, const float dt, uint *newNumParticles, const uint, const uint, const uint totParticles,
 		const RunMode run_mode)
 	{
 		if ((m_c->params().simflags & ENABLE_INLET_OUTLET) && run_mode != REPACK && m_c->params().turbmodel != KEPSILON) {
-			if (numDevices > 1)
-				sphx_not_built("saVertexBoundaryConditions with open boundaries on several devices");
 			const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
 			if (!vertPos)
 				throw std::invalid_argument("saVertexBoundaryConditions: BUFFER_VERTPOS missing");
