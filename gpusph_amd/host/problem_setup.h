@@ -156,6 +156,16 @@ static SimFramework *make_framework(Case const& c)
 			densitydiffusion<BREZZI>,
 			add_flags<ENABLE_DTADAPT | ENABLE_DENSITY_SUM>
 		);
+	} else if (name == "ChannelIO") {   // src/problems/ChannelIO.cu:38-47: SA walls with open boundaries (the option set of the SAChannelIO mirror)
+		SETUP_FRAMEWORK(
+			kernel<WENDLAND>,
+			formulation<SPH_F1>,
+			viscosity<DYNAMICVISC>,
+			boundary<SA_BOUNDARY>,
+			periodicity<PERIODIC_NONE>,
+			densitydiffusion<BREZZI>,
+			add_flags<ENABLE_DTADAPT | ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_WATER_DEPTH>
+		);
 	} else if (name == "StillWaterRepackSA") {   // src/problems/StillWaterRepackSA.cu:38-44: continuity equation, gamma by quadrature
 		SETUP_FRAMEWORK(
 			kernel<WENDLAND>,

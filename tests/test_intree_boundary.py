@@ -122,6 +122,19 @@ def test_stillwater_sa_framework_and_constants(tmp_path):
     assert_params(out, prob, prob.num_particles)
 
 
+def test_channelio_framework_and_constants(tmp_path):
+    """open boundaries: the framework ChannelIO's SETUP_FRAMEWORK expression builds (ENABLE_INLET_OUTLET | ENABLE_WATER_DEPTH on
+    top of StillWaterSA's options) constructs with the HIP engines, and what setconstants uploads for it equals the SAChannelIO
+    mirror's parameters"""
+    from gpusph_amd.problem import SAChannelIO
+    prob = SAChannelIO(0.05)
+    out = run_check(tmp_path, hc.case_lines(prob, "ChannelIO"))
+    assert_options(out, prob.simparams)
+    assert out["options"]["simflags"] == D.ENABLE_DTADAPT | D.ENABLE_INLET_OUTLET | D.ENABLE_DENSITY_SUM | D.ENABLE_WATER_DEPTH
+    assert out["engines"]["bc"] == 1
+    assert_params(out, prob, prob.num_particles)
+
+
 def test_stillwater_repack_sa_framework_and_constants(tmp_path):
     """the option set the SA forces / integration engines are built for"""
     prob = SABox(0.05, options="StillWaterRepackSA")
