@@ -1102,3 +1102,80 @@ class SAChannelIO(SABox):
             euler_vel[rows] = e
         if iowaterdepth is not None:
             iowaterdepth.zero_()
+
+
+class OpenChannel(Problem):
+    """The option set and dimensions of src/problems/OpenChannel.cu: a channel inclined by 4.5 degrees whose flow is driven by
+    gravity, periodic along the stream (and across it without side walls), DYN_BOUNDARY bottom (and side walls) of
+    ceil(influenceRadius/dp) + 1 particle layers, viscosity<KINEMATICVISC> with mu = 110 Pa s of a fluid of 2650 kg/m^3,
+    EOS gamma = 2, c0 = 20 m/s, dt0 = 4e-5, dtadaptfactor 0.3, rebuild every 10 iterations, water level H = 0.5, width
+    a = 1, length 15 influence radii (:41-112).  The particle placement is this repository's lattice (seamless across the periodic
+    faces: first layer at dp/2, as the reference's periodicity_gap has it), not a reproduction of the tree's Cube fill."""
+
+    def __init__(self, deltap=0.02, *, sidewalls=True, linearization=D.DEFAULT_LINEARIZATION):
+        super().__init__()
+        self.m_name = "OpenChannel"
+        self.sidewalls = bool(sidewalls)
+        sp, pp = self.simparams, self.physparams
+        sp.kerneltype = D.WENDLAND
+        sp.boundarytype = D.DYN_BOUNDARY
+        self.set_viscosity("KINEMATICVISC")
+        sp.densitydiffusiontype = D.DENSITY_DIFFUSION_NONE
+        sp.periodicbound = D.PERIODIC_X if self.sidewalls else (D.PERIODIC_X | D.PERIODIC_Y)
+        sp.simflags = D.ENABLE_DTADAPT
+        self.linearization = linearization
+        self.set_deltap(deltap)
+        dp = self.m_deltap
+        sp.dt = 0.00004
+        sp.dtadaptfactor = 0.3
+        sp.buildneibsfreq = 10
+        self.H = 0.5
+        self.m_maxFall = self.H
+        infl = float(sp.influenceRadius)
+        self.dyn_layers = int(math.ceil(infl / dp)) + 1
+        ru = lambda x: math.ceil(round(x / dp, 9)) * dp           # round_up(x, dp)
+        self.a, self.h, self.l = ru(1.0), ru(self.H * 1.4), ru(15.0 * infl)
+        margin = np.array([0.0, 0.1 if self.sidewalls else 0.0, 0.1])
+        lay = (self.dyn_layers - 1) * dp
+        # the world holds the boundary layers (the reference's 0.1 margin does at its deltap = 0.02; kept at least that wide)
+        margin = np.maximum(margin, np.array([0.0, lay + dp if self.sidewalls else 0.0, lay + dp]))
+        self.m_size = np.array([self.l, self.a, self.h]) + 2.0 * margin
+        self.m_origin = -margin
+        angle, g = 4.5, float(np.float32(9.81))
+        pp.gravity = (g * math.sin(math.pi * angle / 180.0), 0.0, -g * math.cos(math.pi * angle / 180.0))
+        pp.add_fluid(2650.0)
+        pp.set_equation_of_state(0, 2.0, 20.0)
+        pp.set_dynamic_visc(0, 110.0)
+        self.initialize()
+        nl, na, nH, nh = (int(round(v / dp)) for v in (self.l, self.a, self.H, self.h))
+        x = (np.arange(nl) + 0.5) * dp
+        if self.sidewalls:
+            yf = np.arange(1, na) * dp                        # fluid one dp off the walls at y = 0 and y = a
+            yb = np.arange(-(self.dyn_layers - 1), na + self.dyn_layers) * dp
+        else:
+            yf = (np.arange(na) + 0.5) * dp
+            yb = yf
+        zf = np.arange(1, nH) * dp
+        grid = lambda xs, ys, zs: np.stack(np.meshgrid(xs, ys, zs, indexing="ij"), axis=-1).reshape(-1, 3)
+        fl = grid(x, yf, zf)
+        walls = [grid(x, yb, -np.arange(self.dyn_layers) * dp)]             # bottom: layers at z = 0, -dp, ...
+        if self.sidewalls:
+            zw = np.arange(1, nh) * dp
+            walls.append(grid(x, -np.arange(self.dyn_layers) * dp, zw))
+            walls.append(grid(x, self.a + np.arange(self.dyn_layers) * dp, zw))
+        wl = np.concatenate(walls)
+        nf, nw = len(fl), len(wl)
+        pos = np.empty((nf + nw, 4), dtype=np.float64)
+        pos[:nf, :3], pos[nf:, :3] = fl, wl
+        pos[:, 3] = pp.rho0[0] * dp ** 3
+        vel = np.zeros((nf + nw, 4), dtype=np.float32)
+        # hydrostatic filling normal to the bed
+        depth = np.clip(self.H - pos[:, 2], 0.0, None)
+        vel[:, 3] = (np.power(1.0 + pp.rho0[0] * (-pp.gravity[2]) * depth / pp.bcoeff[0], 1.0 / pp.gammacoeff[0]) - 1.0).astype(np.float32)
+        types = np.concatenate([np.full(nf, D.PT_FLUID, dtype=np.uint16), np.full(nw, D.PT_BOUNDARY, dtype=np.uint16)])
+        info = make_particleinfo(types, np.zeros(nf + nw, dtype=np.uint16), np.arange(nf + nw, dtype=np.uint32))
+        self.parts = HostParticles(pos, vel, info)
+        self.num_fluid, self.num_wall, self.num_obstacle = nf, nw, 0
+        self.rb_firstindex = np.zeros(0, dtype=np.int32)
+        self.rb_cg_gridpos = np.zeros((0, 3), dtype=np.int32)
+        self.rb_cg_pos = np.zeros((0, 3), dtype=np.float32)

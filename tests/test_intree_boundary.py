@@ -122,6 +122,19 @@ def test_stillwater_sa_framework_and_constants(tmp_path):
     assert_params(out, prob, prob.num_particles)
 
 
+@pytest.mark.parametrize("sidewalls", [True, False])
+def test_openchannel_framework_and_constants(tmp_path, sidewalls):
+    """src/problems/OpenChannel.cu's SETUP_FRAMEWORK expression with its run-time selector (side walls: periodic along the stream
+    only) against the OpenChannel mirror: options and every uploaded constant"""
+    from gpusph_amd.problem import OpenChannel
+    prob = OpenChannel(0.05, sidewalls=sidewalls)
+    out = run_check(tmp_path, hc.case_lines(prob, "OpenChannel", use_side_walls=int(sidewalls)))
+    assert_options(out, prob.simparams)
+    assert out["options"]["periodicbound"] == (D.PERIODIC_X if sidewalls else D.PERIODIC_X | D.PERIODIC_Y)
+    assert out["options"]["is_const_visc"] == 1
+    assert_params(out, prob, prob.num_particles)
+
+
 def test_channelio_framework_and_constants(tmp_path):
     """open boundaries: the framework ChannelIO's SETUP_FRAMEWORK expression builds (ENABLE_INLET_OUTLET | ENABLE_WATER_DEPTH on
     top of StillWaterSA's options) constructs with the HIP engines, and what setconstants uploads for it equals the SAChannelIO
