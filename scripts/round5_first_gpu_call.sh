@@ -4,6 +4,7 @@
 #   1. the guarded parity tests of tests/test_gpu_sa_io.py (SPHX_TEST_SA_IO_BC=1: segment / vertex conditions, density summation,
 #      forces, Brezzi diffusion, water depth, then SAChannelIO through the engine's driver against the CPU run), each test on its own
 #      so that one failure does not hide the others;
+#   1b. the OpenChannel mirror on the device (tests/test_gpu_openchannel.py, SPHX_TEST_OPENCHANNEL=1);
 #   2. the whole GPU suite as the driver runs it (-x), to see that nothing else moved;
 #   3. a bench line.
 # usage: /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash scripts/round5_first_gpu_call.sh'
@@ -21,6 +22,8 @@ for t in test_open_boundary_kernels_are_bit_exact test_boundary_condition_passes
 	echo "$t: exit $?" | tee -a $OUT/summary.txt
 done
 unset SPHX_TEST_SA_IO_BC
+SPHX_TEST_OPENCHANNEL=1 timeout 300 python -m pytest tests/test_gpu_openchannel.py -q -m gpu > $OUT/openchannel.log 2>&1
+echo "openchannel mirror: exit $?" | tee -a $OUT/summary.txt
 timeout 900 python -m pytest tests -x -q -m gpu > $OUT/gpu_suite.log 2>&1
 echo "gpu suite: exit $?" | tee -a $OUT/summary.txt
 tail -3 $OUT/gpu_suite.log | tee -a $OUT/summary.txt
