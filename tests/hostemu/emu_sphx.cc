@@ -4,3 +4,13 @@
 thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
 #include "../../gpusph_amd/csrc/sphx_api.hip"
 #include "../../gpusph_amd/csrc/sa_io.hip"
+// sa_bounds.hip (the solid-wall SA passes: verified on the GPU, emulated for the regression value and because an open-boundary
+// run calls some of them) with its launches rewritten into _build/sa_bounds_emu.inc by tests/hostemu_lib.py.  The tiled window and
+// the wall-particle kernels it can hand over to live in other files: absent here, so every pass is its list walker.
+#include "sa_bounds_emu.inc"
+int sphx_sa_tiles_run(sphx_ctx *, int, void *, const void *, const void *, const void *, const void *, const uint32_t *, const uint32_t *,
+	const uint16_t *, const void *, uint32_t, uint32_t, uint32_t, float, hipStream_t, bool *used, const uint32_t **guard)
+{ if (used) *used = false; if (guard) *guard = nullptr; return SPHX_OK; }
+int sphx_sa_wall_forces(sphx_ctx *, const SaForcesArgs &, hipStream_t) { return SPHX_OK; }
+int sphx_sa_wall_density_sum(sphx_ctx *, const SaDensitySumArgs &, hipStream_t) { return SPHX_OK; }
+int sphx_sa_wall_integrate_gamma(sphx_ctx *, const SaIntGammaArgs &, hipStream_t) { return SPHX_OK; }

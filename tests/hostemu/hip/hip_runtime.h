@@ -119,3 +119,11 @@ static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 	gridDim = dim3(g_); blockDim = dim3(b_); \
 	for (unsigned bi_ = 0; bi_ < g_; ++bi_) for (unsigned ti_ = 0; ti_ < b_; ++ti_) { \
 		blockIdx = dim3(bi_); threadIdx = dim3(ti_); kernel(__VA_ARGS__); } } while (0)
+
+// the same for sources whose launches are rewritten by tests/hostemu_lib.py instead of going through a macro of their own
+// (sa_bounds.hip: verified on the GPU and left as it is; kernel<<<grid, block, 0, stream>>>(args) -> SPHX_EMU_LAUNCH((kernel), grid, block, args))
+#define SPHX_EMU_LAUNCH(kernel, grid, block, ...) do { \
+	const unsigned g_ = (unsigned)(grid), b_ = (unsigned)(block); \
+	gridDim = dim3(g_); blockDim = dim3(b_); \
+	for (unsigned bi_ = 0; bi_ < g_; ++bi_) for (unsigned ti_ = 0; ti_ < b_; ++ti_) { \
+		blockIdx = dim3(bi_); threadIdx = dim3(ti_); kernel(__VA_ARGS__); } } while (0)

@@ -15,7 +15,7 @@ _EMU = os.path.join(_HERE, "hostemu")
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_EMU, "_build", "libsphx_emu_asan.so" if os.environ.get("SPHX_HOSTEMU_ASAN") == "1" else "libsphx_emu.so")
 _SOURCES = [os.path.join(_EMU, "emu_sphx.cc"), os.path.join(_EMU, "hip", "hip_runtime.h")] + \
-    [os.path.join(_ROOT, "gpusph_amd", "csrc", f) for f in ("sphx_api.hip", "sa_io.hip", "sphx_internal.h", "neib_iter.h",
+    [os.path.join(_ROOT, "gpusph_amd", "csrc", f) for f in ("sphx_api.hip", "sa_io.hip", "sa_bounds.hip", "sphx_internal.h", "neib_iter.h",
                                                               "sa_wall_gamma.h", "sa_args.h")] + \
     [os.path.join(_ROOT, "include", "sphx.h")]
 
@@ -23,19 +23,34 @@ _SOURCES = [os.path.join(_EMU, "emu_sphx.cc"), os.path.join(_EMU, "hip", "hip_ru
 NAMES = ["sphx_create", "sphx_destroy", "sphx_set_constants", "sphx_last_error",
          "sphx_sa_identify_corner_vertices", "sphx_sa_init_io_mass_vertex_count", "sphx_sa_init_io_mass",
          "sphx_sa_find_outgoing_segment", "sphx_sa_disable_outgoing_parts", "sphx_sa_segment_bc_io", "sphx_sa_vertex_bc_io",
-         "sphx_sa_density_sum_io", "sphx_forces_basicstep_sa_io", "sphx_sa_compute_density_diffusion_io", "sphx_sa_io_water_depth", "sphx_flux_computation"]
+         "sphx_sa_density_sum_io", "sphx_forces_basicstep_sa_io", "sphx_sa_compute_density_diffusion_io", "sphx_sa_io_water_depth", "sphx_flux_computation",
+         # sa_bounds.hip, list walkers only
+         "sphx_sa_compute_vertex_normal", "sphx_sa_init_gamma", "sphx_sa_segment_bc", "sphx_sa_vertex_bc", "sphx_sa_density_sum",
+         "sphx_sa_compute_density_diffusion", "sphx_apply_density_diffusion", "sphx_sa_integrate_gamma", "sphx_forces_basicstep_sa"]
+
+
+def _rewrite_launches(src, dst):
+    """kernel<<<grid, block, 0, stream>>>(args -> SPHX_EMU_LAUNCH((kernel), grid, block, args  (the source stays as it is)"""
+    import re
+    text = open(src).read()
+    pat = re.compile(r'(\b\w+(?:<[^<>;()]*>)?)<<<(.+?), (\w+), 0, ([^>;]+?)>>>\(')
+    out, n = pat.subn(lambda m: 'SPHX_EMU_LAUNCH((%s), %s, %s, ' % (m.group(1), m.group(2), m.group(3)), text)
+    assert n > 0 and '<<<' not in out, "a launch of %s was not understood" % src
+    with open(dst, "w") as f:
+        f.write(out)
 
 
 def build():
     os.makedirs(os.path.dirname(_SO), exist_ok=True)
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in _SOURCES):
         return _SO
+    _rewrite_launches(os.path.join(_ROOT, "gpusph_amd", "csrc", "sa_bounds.hip"), os.path.join(_EMU, "_build", "sa_bounds_emu.inc"))
     # -ffp-contract=off as the library's own build of these files; -O1: compile time
     # SPHX_HOSTEMU_ASAN=1: an address-sanitised build, for a run under LD_PRELOAD=libasan.so (out-of-bounds reads and writes of the
     # kernels on the exact-size numpy buffers of these tests; see tests/hostemu/README)
     san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if os.environ.get("SPHX_HOSTEMU_ASAN") == "1" else []
     cmd = ["g++", "-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes"] + san + [
-           "-I" + _EMU, "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_ROOT, "gpusph_amd", "csrc"),
+           "-I" + _EMU, "-I" + os.path.join(_EMU, "_build"), "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_ROOT, "gpusph_amd", "csrc"),
            "-o", _SO, os.path.join(_EMU, "emu_sphx.cc")]
     subprocess.run(cmd, check=True, capture_output=True)
     return _SO

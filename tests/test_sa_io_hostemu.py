@@ -420,3 +420,46 @@ def test_flux_computation_in_emulation(ctx):
     assert np.array_equal(got, want) and want[1] != 0 and want[0] == 0 and want[2] == 0
     by_hand = (be[seg, 3].astype(np.float64) * (ev[seg, :3].astype(np.float64) * be[seg, :3]).sum(axis=1)).sum()
     assert want[1] == pytest.approx(by_hand, rel=1e-4)
+
+
+def test_solid_wall_passes_in_emulation(ctx):
+    """sa_bounds.hip (verified on the GPU; its launches rewritten by the harness, the source untouched) over its list walkers: the
+    vertex normals -- bit for bit, with and without open-boundary flags: a vertex of an open boundary averages over that boundary's
+    segments only --, the initial gamma, the segment and vertex conditions and the density summation to the tolerances of their
+    GPU tests (tests/test_gpu_sa.py)."""
+    from gpusph_amd import defs as DD
+    st, emu = ctx["st"], ctx["emu"]
+    p, o, n = st["problem"], st["oracle"], st["n"]
+    P = emu.params
+    vp = _vp(st)
+    for info in (st["info"], _flag(ctx, D.FG_INLET | D.FG_VELOCITY_DRIVEN)):
+        want = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], info, st["hash"], st["cs"], st["nl"], n)
+        got = st["boundelements"].copy()
+        emu.call("sphx_sa_compute_vertex_normal", got, st["vertices"], info, st["hash"], st["cs"], st["nl"], n, n, None)
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert np.array_equal(_bits(got)[~np.isnan(got)], _bits(want)[~np.isnan(want)])
+    flagged = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], _flag(ctx, D.FG_INLET), st["hash"], st["cs"], st["nl"], n)
+    plain = o.sa_compute_vertex_normal(st["boundelements"], st["vertices"], st["info"], st["hash"], st["cs"], st["nl"], n)
+    edge = ctx["vtx"] & (np.abs(ctx["g"][:, 2]) < 1e-6)            # on the edge between the open wall and the floor
+    assert edge.sum() > 0 and not np.array_equal(flagged[edge, :3], plain[edge, :3])
+    be = plain
+    want_g = o.sa_init_gamma(st["gradgamma"], st["pos"], be, st["vertpos"], st["info"], st["hash"], st["cs"], st["nl"], n, p.m_deltap)
+    got_g = st["gradgamma"].copy()
+    emu.call("sphx_sa_init_gamma", got_g, st["gradgamma"], st["pos"], be, vp[0], vp[1], vp[2], st["info"], st["hash"], st["cs"], st["nl"],
+             float(P.slength), float(P.influenceradius), float(np.float32(p.m_deltap)), 5e-5, n, n, None)
+    rows = info_type(st["info"]) != DD.PT_BOUNDARY
+    assert np.abs(got_g[rows, 3] - want_g[rows, 3]).max() < 2e-6
+    assert_close_but_for_gamma_spikes(got_g[rows, :3], want_g[rows, :3], 2e-5, np.abs(want_g[rows, :3]).max(), what="grad gamma")
+    # boundary conditions of step 1 on the initial state
+    vel = st["vel"].copy()
+    want_v, want_gg = o.sa_segment_bc(st["pos"], vel, want_g, st["vertices"], be, st["info"], st["hash"], st["cs"], st["nl"], n, 1)
+    gv, gg = vel.copy(), want_g.copy()
+    emu.call("sphx_sa_segment_bc", gv, gg, st["pos"], st["vertices"], be, st["info"], st["hash"], st["cs"], st["nl"], n, n,
+             float(np.float32(p.m_deltap)), float(P.slength), float(P.influenceradius), 1, DD.SIMULATE, None)
+    assert np.abs(gv[:, 3] - want_v[:, 3]).max() < 2e-5 * np.abs(want_v[:, 3]).max() + 2e-7
+    assert np.array_equal(np.isnan(gg), np.isnan(want_gg)) and np.allclose(gg[~np.isnan(gg)], want_gg[~np.isnan(want_gg)], rtol=0, atol=1e-6)
+    want_v2 = o.sa_vertex_bc(st["pos"], want_v, want_gg, st["info"], st["hash"], st["cs"], st["nl"], n)
+    gv2 = want_v.copy()
+    emu.call("sphx_sa_vertex_bc", gv2, want_gg, st["pos"], st["info"], st["hash"], st["cs"], st["nl"], n, n,
+             float(np.float32(p.m_deltap)), float(P.slength), float(P.influenceradius), 1, DD.SIMULATE, None)
+    assert np.abs(gv2[:, 3] - want_v2[:, 3]).max() < 2e-5 * np.abs(want_v2[:, 3]).max() + 2e-7
