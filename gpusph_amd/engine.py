@@ -35,6 +35,8 @@ class TimestepEngine(MultiGpuEngine):
         if not torch.cuda.is_available():
             raise capi.SphxError("TimestepEngine needs a HIP device (there is no CPU fallback)")
         n = len(problem.parts.info)
+        if allocated is None and hasattr(problem, "max_parts"):      # a problem that creates particles says how many it may hold
+            allocated = problem.max_parts(n)
         super().__init__(problem, device=device, rank=0, world=1, track_particle_count=track_particle_count,
                          allocated=int(allocated or n), clobber_neibslist=clobber_neibslist)
         self.lib, self.ctx, self.params = self.k.lib, self.k.ctx, self.k.params

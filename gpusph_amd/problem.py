@@ -1044,6 +1044,10 @@ class SAChannelIO(SABox):
         info[outlet, 1] = (info[outlet, 1] & 0xF000) | 1
         self.parts.vel[t == D.PT_FLUID, 0] = np.float32(self.U)
 
+    def max_parts(self, numpart):
+        """room for the particles the inlet releases (ChannelIO::max_parts, src/problems/ChannelIO.cu:95-98)"""
+        return int(np.float32(numpart) * np.float32(1.2))
+
     def open_boundary_condition(self, io_info, abs_pos, waterdepth, t):
         """ChannelIO_imposeBoundaryCondition (src/problems/ChannelIO.cu:104-139) for the rows of the open boundaries' particles, on
         torch tensors of any device: -> (vel, eulerVel) rows.  The Lagrangian velocity is cleared; a velocity-driven boundary gets
