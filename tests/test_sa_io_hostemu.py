@@ -406,15 +406,15 @@ def test_the_unverified_passes_are_refused_unless_asked_for_by_name(ctx, monkeyp
 
 
 def test_flux_computation_in_emulation(ctx):
-    st, emu, seg, vtx = ctx["st"], ctx["emu"], ctx["seg"], ctx["vtx"]
+    import ctypes as C
+    st, emu, seg = ctx["st"], ctx["emu"], ctx["seg"]
     o, n = st["oracle"], st["n"]
     info = _flag(ctx, D.FG_INLET | D.FG_VELOCITY_DRIVEN)
     ev = np.random.default_rng(9).normal(size=(n, 4)).astype(np.float32)
     be = st["boundelements"]
-    want = np.full(3, 7.0, dtype=np.float32)
-    o.L.orc_flux_computation(want.ctypes.data_as(__import__("ctypes").c_void_p), info.ctypes.data_as(__import__("ctypes").c_void_p),
-                             ev.ctypes.data_as(__import__("ctypes").c_void_p), be.ctypes.data_as(__import__("ctypes").c_void_p),
-                             __import__("ctypes").c_uint32(n), __import__("ctypes").c_uint32(3))
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    want = np.full(3, 7.0, dtype=np.float32)                     # (the sums start from zero whatever the array held)
+    o.L.orc_flux_computation(ptr(want), ptr(info), ptr(ev), ptr(be), C.c_uint32(n), C.c_uint32(3))
     got = np.full(3, -3.0, dtype=np.float32)
     emu.call("sphx_flux_computation", got, info, ev, be, n, n, 3, None)
     assert np.array_equal(got, want) and want[1] != 0 and want[0] == 0 and want[2] == 0
