@@ -74,4 +74,4 @@ DEFAULT_LINEARIZATION = "yzx"
 SHEPARD_FILTER, MLS_FILTER = 0, 1
 
 # PostProcessType (src/particledefine.h:290-299)
-VORTICITY, TESTPOINTS, SURFACE_DETECTION, INTERFACE_DETECTION = 0, 1, 2, 3
+VORTICITY, TESTPOINTS, SURFACE_DETECTION, INTERFACE_DETECTION, FLUX_COMPUTATION, CALC_PRIVATE = 0, 1, 2, 3, 4, 5

@@ -95,7 +95,12 @@ class TimestepEngine(MultiGpuEngine):
     def postprocess(self, pptype, normals=False):
         """POSTPROCESS command (src/GPUWorker.cc runCommand<POSTPROCESS>): VORTICITY returns a [n,3] tensor,
         TESTPOINTS updates the velocity rows of test points in place, SURFACE_DETECTION updates FG_SURFACE (and
-        INTERFACE_DETECTION also FG_INTERFACE) in INFO in place, and returns the normals when asked."""
+        INTERFACE_DETECTION also FG_INTERFACE) in INFO in place, and returns the normals when asked; FLUX_COMPUTATION returns the
+        flux per open boundary, CALC_PRIVATE what the problem's calc_private makes of the state."""
+        if pptype == D.FLUX_COMPUTATION:
+            return self.open_boundary_flux()
+        if pptype == D.CALC_PRIVATE:
+            return self.calc_private()
         n = self.n
         pp = self.problem.physparams
         out = vort = nrm = None

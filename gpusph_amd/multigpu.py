@@ -410,6 +410,18 @@ class MultiGpuEngine:
         if self.world == 1:
             self.n_int = self.edge_start = n2
 
+    def calc_private(self):
+        """CALC_PRIVATE of the post-processing engine (src/cuda/post_process.cu:575-640: Problem::calcPrivate fills BUFFER_PRIVATE
+        with whatever the problem defines, from positions, velocities, info, the hash and the neighbour list): the problem's
+        `calc_private(engine)` gets the engine (its tensors live on the device) and returns one row per particle"""
+        fn = getattr(self.problem, "calc_private", None)
+        if fn is None:
+            raise NotImplementedError("CALC_PRIVATE: the problem defines no calc_private (the reference's default throws as well)")
+        out = fn(self)
+        if out.shape[0] != self.n_local:
+            raise ValueError("calc_private: one row per particle held by this device expected")
+        return out
+
     def open_boundary_flux(self):
         """FLUX_COMPUTATION of the post-processing engine (src/cuda/post_process.cu:485-570) on the current state: per open boundary
         the volume flux sum A_s (u_E . n_s) through its segments, positive into the domain.  -> float32 tensor [num_open_boundaries]"""

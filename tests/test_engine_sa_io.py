@@ -86,3 +86,17 @@ def test_flux_through_the_open_boundaries():
     seg = (info_type(info) == D.PT_BOUNDARY) & ((info[:, 0] & D.FG_OUTLET) != 0)
     be, ev = eng.boundelements[:n].numpy()[seg].astype(np.float64), eng.eulervel[:n].numpy()[seg].astype(np.float64)
     assert flux[1] == pytest.approx(float((be[:, 3] * (ev[:, :3] * be[:, :3]).sum(axis=1)).sum()), rel=1e-5)
+
+
+def test_private_post_processing_is_the_problems_hook():
+    """CALC_PRIVATE: the engine hands itself to Problem.calc_private and returns its rows; a problem without one is told so"""
+    p = SAChannelIO(0.05)
+    eng = _engine(p, p.num_particles + 4096)
+    eng.step()
+    with pytest.raises(NotImplementedError):
+        eng.calc_private()
+    p.calc_private = lambda e: (e.vel[:e.n_local, :3] ** 2).sum(dim=1).sqrt()          # e.g. the speed
+    speed = eng.calc_private().numpy()
+    n = eng.n_local
+    fl = info_type(eng.info[:n].numpy().view(np.uint16)) == D.PT_FLUID
+    assert speed.shape == (n,) and abs(np.median(speed[fl]) - 0.6) < 0.02
