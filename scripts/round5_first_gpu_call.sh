@@ -29,3 +29,10 @@ echo "gpu suite: exit $?" | tee -a $OUT/summary.txt
 tail -3 $OUT/gpu_suite.log | tee -a $OUT/summary.txt
 timeout 300 python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/bench.json | tee -a $OUT/summary.txt
+#   4. the prepared experiments against the committed build (scripts/build_variants.sh puts them under gpusph_amd/variants/ first:
+#      the list ring with a running base, + one list descriptor per walk for the SPS passes), bench lines at 32 M and 8 M each
+if ls gpusph_amd/variants/libsphx_*.so > /dev/null 2>&1; then
+	timeout 600 bash scripts/ab_forces.sh > $OUT/ab_forces.txt 2>&1
+	cat $OUT/ab_forces.txt | tee -a $OUT/summary.txt
+fi
+
