@@ -7,7 +7,8 @@
 #   1b. the OpenChannel mirror on the device (tests/test_gpu_openchannel.py, SPHX_TEST_OPENCHANNEL=1);
 #   2. the whole GPU suite as the driver runs it (-x), to see that nothing else moved;
 #   3. a bench line.
-# usage: /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash scripts/round5_first_gpu_call.sh'
+# before: delete the gpusph_amd/variants/ line from .gpurunignore (and run scripts/build_variants.sh if the directory is empty)
+# usage: /usr/local/graft/bin/gpurun --timeout 1800 -- 'bash scripts/round5_first_gpu_call.sh'
 # output: gpurun_out/round5_first/*.log.  When 1. is green: drop the skipif marks of those tests, then the refusal in
 # sa_io_bc_check (gpusph_amd/csrc/sa_io.hip) and in sa_check (gpusph_amd/csrc/sa_bounds.hip), then the "WRITTEN, NOT YET RUN" notes.
 set -u
