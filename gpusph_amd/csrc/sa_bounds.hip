@@ -721,14 +721,8 @@ static int sa_check(sphx_ctx *ctx, const char *who)
 		return sphx_set_error(SPHX_ERR_INVALID, who);      // the reference throws "... called without SA_BOUNDARY"
 	if (ctx->params.kerneltype != SPHX_WENDLAND)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA_BOUNDARY is built for the Wendland kernel (as the reference, src/cuda/gamma.cuh:241-250)");
-	// Open boundaries: the entry points an open-boundary run calls besides those of sa_io.hip (vertex normals, initial gamma)
-	// do what such a run needs, but the passes of sa_io.hip have not all run on a GPU yet: refused, unless the caller asks for
-	// the unverified path by name (SPHX_EXPERIMENTAL_SA_IO=1: the GPU parity tests of those passes, tests/test_gpu_sa_io.py)
-	if (ctx->params.simflags & SPHX_ENABLE_INLET_OUTLET) {
-		const char *e = getenv("SPHX_EXPERIMENTAL_SA_IO");
-		if (!(e && e[0] == '1'))
-			return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: open boundaries (ENABLE_INLET_OUTLET) are not built");
-	}
+	// Open boundaries (ENABLE_INLET_OUTLET): the entry points such a run calls besides those of sa_io.hip (vertex normals, initial
+	// gamma) do what it needs; the passes of sa_io.hip ran against the oracle on an MI355X in round 5 (tests/test_gpu_sa_io.py)
 	return SPHX_OK;
 }
 

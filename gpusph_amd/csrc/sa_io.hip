@@ -641,12 +641,6 @@ static int sa_io_bc_check(sphx_ctx *ctx, const char *who)
 {
 	int rc = sa_io_check(ctx, who);
 	if (rc != SPHX_OK) return rc;
-	// the passes behind this check have not run on a GPU yet: refused, unless the caller asks for them by name (their GPU parity
-	// tests and the CPU emulation of tests/hostemu do); the five entry points above are verified and need no such word
-	const char *e = getenv("SPHX_EXPERIMENTAL_SA_IO");
-	if (!(e && e[0] == '1'))
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_io: this open-boundary pass has not been verified on a GPU yet "
-			"(SPHX_EXPERIMENTAL_SA_IO=1 runs it all the same)");
 	if (ctx->params.kerneltype != SPHX_WENDLAND)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_io: SA_BOUNDARY is built for the Wendland kernel");
 	if (ctx->dev.turbmodel == SPHX_KEPSILON)

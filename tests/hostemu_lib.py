@@ -60,7 +60,6 @@ class Emu:
     """the emulated library with a context whose constants are set: emu.call("sphx_...", args...) with numpy arrays for buffers"""
 
     def __init__(self, params):
-        os.environ["SPHX_EXPERIMENTAL_SA_IO"] = "1"      # the unverified passes are refused unless asked for by name
         self.lib = C.CDLL(build())
         for name in NAMES:
             res, args = capi.SIGNATURES[name]

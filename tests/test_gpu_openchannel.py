@@ -1,15 +1,11 @@
-"""The OpenChannel mirror on the GPU against the same driver over the oracle's kernels.  Written at the end of round 4 without a
-GPU at hand: the option set (KINEMATICVISC, DYN_BOUNDARY, periodic along the stream) is that of verified paths, but the test has
-not run yet, so it waits behind SPHX_TEST_OPENCHANNEL=1 (scripts/round5_first_gpu_call.sh) instead of risking the suite's -x."""
-import os
-
+"""The OpenChannel mirror on the GPU against the same driver over the oracle's kernels (KINEMATICVISC, DYN_BOUNDARY, periodic
+along the stream).  First run on an MI355X in round 5 (profiles/r05_first_gpu_call.txt)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.skipif(os.environ.get("SPHX_TEST_OPENCHANNEL") != "1", reason="not run on a GPU yet (SPHX_TEST_OPENCHANNEL=1)")
 @pytest.mark.parametrize("sidewalls", [True, False])
 def test_openchannel_mirror_follows_the_oracle_driver(sidewalls):
     from gpusph_amd.engine import TimestepEngine

@@ -129,17 +129,12 @@ def test_later_steps_and_repacking_mode(pair):
 def test_what_is_not_built_says_so(pair):
     from gpusph_amd import capi
     st, eng = pair
-    # open boundaries: the driver has the sequence (tests/test_engine_sa_io.py) for a problem that brings its imposed values and
-    # rebuilds in every iteration; the library refuses the flag at the first SA call until its open-boundary passes have passed
-    # their GPU tests
+    # open boundaries: the driver has the sequence (tests/test_engine_sa_io.py, tests/test_gpu_sa_io.py) for a problem that
+    # brings its imposed values and rebuilds in every iteration; a problem that only sets the flag is refused by the driver
     io = SABox(deltap=0.05)
     io.simparams.simflags |= D.ENABLE_INLET_OUTLET
     with pytest.raises((NotImplementedError, ValueError)):
         _engine(io)
-    from gpusph_amd.problem import SAChannelIO
-    eio = _engine(SAChannelIO(0.05))
-    with pytest.raises(capi.SphxUnsupported, match="open boundaries"):
-        eio.step()
     # and the boundary-conditions engine refuses a framework without SA_BOUNDARY, like the reference's SFINAE'd implementation
     other = _engine(DamBreak3D(deltap=0.05, obstacle=False))
     other.build_neibs()

@@ -13,14 +13,6 @@ from sa_helpers import sa_oracle_state
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _ask_for_the_unverified_passes_by_name(monkeypatch):
-    """the library refuses the open-boundary passes that have not been verified on a GPU unless SPHX_EXPERIMENTAL_SA_IO=1; the
-    tests that run them (SPHX_TEST_SA_IO_BC=1) are that verification"""
-    if __import__("os").environ.get("SPHX_TEST_SA_IO_BC") == "1":
-        monkeypatch.setenv("SPHX_EXPERIMENTAL_SA_IO", "1")
-
-
 def _np(t, dtype=None):
     a = t.cpu().numpy()
     return a.view(dtype) if dtype is not None else a
@@ -117,9 +109,6 @@ def test_open_boundary_kernels_are_bit_exact():
     assert np.array_equal(_np(d_vert, np.uint32).reshape(-1, 4)[:n], want_v3)
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SPHX_TEST_SA_IO_BC") != "1",
-                    reason="sa_segment_bc_io / sa_vertex_bc_io were written at the end of round 4 and have not run on a GPU yet; "
-                           "SPHX_TEST_SA_IO_BC=1 runs their parity test")
 def test_boundary_condition_passes_with_open_boundaries():
     """sphx_sa_segment_bc_io and sphx_sa_vertex_bc_io against the oracle's restatements on the inlet of tests/test_sa_io_oracle.py
     (a uniform stream through the x = 0 wall): Eulerian velocities and densities of the open segments and vertices, the vertex masses
@@ -208,8 +197,6 @@ def test_boundary_condition_passes_with_open_boundaries():
             assert np.array_equal(_np(d_ids, np.uint32)[:n], a["next_ids"][:n])
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SPHX_TEST_SA_IO_BC") != "1",
-                    reason="sa_density_sum_io / sa_forces_io were written at the end of round 4 and have not run on a GPU yet")
 def test_density_summation_and_forces_with_open_boundaries():
     """sphx_sa_density_sum_io and sphx_forces_basicstep_sa_io against the oracle on the uniform stream through an inlet of
     tests/test_sa_io_oracle.py (to the tolerance of the SA engines: the product's |grad gamma_as| is its own formulation)."""
@@ -272,8 +259,6 @@ def test_density_summation_and_forces_with_open_boundaries():
     assert np.abs(_np(d_cfl)[:nb] - want_cfl[:nb]).max() < 1e-4 * np.abs(want_cfl[:nb]).max()
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SPHX_TEST_SA_IO_BC") != "1",
-                    reason="sa_density_diffusion_io / sa_io_water_depth were written at the end of round 4 and have not run on a GPU yet")
 def test_brezzi_diffusion_and_water_depth_with_open_boundaries():
     """sphx_sa_compute_density_diffusion_io against the oracle with the x = 0 wall a pressure outlet held off the fluid's pressure
     (tests/test_sa_io_oracle.py), and sphx_sa_io_water_depth bit for bit: a maximum of integers."""
@@ -337,18 +322,14 @@ def test_brezzi_diffusion_and_water_depth_with_open_boundaries():
     assert abs(got_f[1] - want_f[1]) < 1e-5 * np.abs(be[seg, 3]).sum() * 3
 
 
-@pytest.mark.skipif(__import__("os").environ.get("SPHX_TEST_SA_IO_BC") != "1",
-                    reason="the open-boundary passes have not run on a GPU yet; SPHX_TEST_SA_IO_BC=1 runs the whole sequence on the device")
-def test_open_channel_on_the_device_follows_the_cpu_run(monkeypatch):
-    """SAChannelIO through the engine's open-boundary sequence on the GPU (the library's refusal of ENABLE_INLET_OUTLET lifted by
-    name for this test) against the same driver over the oracle's kernels on the CPU, which tests/test_engine_sa_io.py holds bit
+def test_open_channel_on_the_device_follows_the_cpu_run():
+    """SAChannelIO through the engine's open-boundary sequence on the GPU against the same driver over the oracle's kernels on the CPU, which tests/test_engine_sa_io.py holds bit
     for bit against the independent restatement of the reference's command sequence."""
     from gpusph_amd.engine import TimestepEngine
     from gpusph_amd.multigpu import MultiGpuEngine
     from gpusph_amd.problem import SAChannelIO, info_id
     from oracle_kernels import OracleKernels
     from sa_helpers import assert_close_but_for_gamma_spikes
-    monkeypatch.setenv("SPHX_EXPERIMENTAL_SA_IO", "1")
     mk = lambda: SAChannelIO(0.05, U=0.6)
     alloc = int(mk().num_particles * 1.6)
     ref = MultiGpuEngine(mk(), "cpu", 0, 1, kernels=OracleKernels(mk(), alloc), allocated=alloc)

@@ -389,22 +389,6 @@ def test_the_engines_driver_over_the_bindings_and_the_emulated_kernels():
     ke.emu.close()
 
 
-def test_the_unverified_passes_are_refused_unless_asked_for_by_name(ctx, monkeypatch):
-    st, emu = ctx["st"], ctx["emu"]
-    n = st["n"]
-    info = _flag(ctx, D.FG_OUTLET)
-    depth = np.zeros(2, dtype=np.uint32)
-    monkeypatch.delenv("SPHX_EXPERIMENTAL_SA_IO")
-    with pytest.raises(RuntimeError, match="not been verified on a GPU"):
-        emu.call("sphx_sa_io_water_depth", depth, st["pos"], info, st["hash"], st["cs"], st["nl"], n, 0, n, None)
-    # the five verified entry points need no such word
-    got = info.copy()
-    emu.call("sphx_sa_identify_corner_vertices", st["pos"], got, st["hash"], st["vertices"], st["cs"], st["nl"], n, n, None)
-    monkeypatch.setenv("SPHX_EXPERIMENTAL_SA_IO", "1")
-    emu.call("sphx_sa_io_water_depth", depth, st["pos"], info, st["hash"], st["cs"], st["nl"], n, 0, n, None)
-    assert depth[1] > 0
-
-
 def test_flux_computation_in_emulation(ctx):
     import ctypes as C
     st, emu, seg = ctx["st"], ctx["emu"], ctx["seg"]
