@@ -115,6 +115,8 @@ SIGNATURES = {
     "sphx_forces_basicstep_grenier": (_i, [_vp] * 10 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_disable_free_surf_parts": (_i, [_vp, _vp, _vp, _u32, _u32, _vp]),
     "sphx_time_advance": (_i, [_vp, _vp, _vp, _vp]),
+    "sphx_eos_rows_follow_euler": (_i, [_vp, _i]),
+    "sphx_eos_rows_current": (_i, [_vp, _vp, _u32]),
     "sphx_halo_group_create": (_i, [_i, C.POINTER(_vp)]),
     "sphx_halo_group_destroy": (_i, [_vp]),
     "sphx_halo_create_threads": (_i, [_vp, _vp, _i, C.POINTER(_vp)]),

@@ -2187,8 +2187,11 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 		if (inHome) {
 			const uint32_t cnt = neibCounts[tile_home(d, tid).index];
 			F = cnt & 0xFFFFu; B = cnt >> 16;
-			const uint32_t maxF = p.neiblistsize, maxB = saVertex ? p.neiblistsize - p.neibboundpos - 1u : p.neibboundpos + 1u;
-			if (F > 128u || F > maxF || B > 128u || B > maxB) { overflow = true; F = 0; B = 0; }   // not a list of the builder (an overflowed one)
+			// A list that overflowed while it was built (build_neibs_kernel: nf >= neibboundpos, nf + nb >= neibboundpos, with
+			// SA_BOUNDARY nv >= neiblistsize - neibboundpos - 1) keeps COUNTING its entries but stops writing them: its counts
+			// name slots of the other section, or slots that were never written.  Such a tiling goes to the generic kernel
+			const bool unwritten = F >= p.neibboundpos || (saVertex ? B >= p.neiblistsize - p.neibboundpos - 1u : F + B >= p.neibboundpos);
+			if (F > 128u || B > 128u || unwritten) { overflow = true; F = 0; B = 0; }
 		}
 		uint32_t rankInWave = 0;
 		{
@@ -2474,9 +2477,18 @@ extern "C" int sphx_forces_basicstep(sphx_ctx *ctx,
 	{	// EOS pre-pass over ALL particles: neighbours may lie outside [fromParticle,toParticle)
 		int rc0 = sphx_ensure_scratch(ctx, numParticles);
 		if (rc0 != SPHX_OK) return rc0;
-		eos_kernel<<<div_up_u(numParticles, 256), 256, 0, (hipStream_t)stream>>>(ctx->dev, (const float4*)vel,
-			(const particleinfo*)info, ctx->eos_aux, numParticles);
-		SPHX_LAUNCH_CHECK("eos_kernel");
+		// ... unless the Euler step that wrote these densities left the rows behind and the caller vouches for the buffer
+		// (sphx_eos_rows_current, euler.hip)
+		const bool current = ctx->eos_armed && ctx->eos_tag_vel == vel && ctx->eos_tag_n == numParticles;
+		ctx->eos_armed = false;
+		if (!current) {
+			// the rows are this buffer's from here on (a second stripe of the same pass may be vouched for as well)
+			ctx->eos_tag_vel = ctx->eos_follow ? vel : nullptr;
+			ctx->eos_tag_n = numParticles;
+			eos_kernel<<<div_up_u(numParticles, 256), 256, 0, (hipStream_t)stream>>>(ctx->dev, (const float4*)vel,
+				(const particleinfo*)info, ctx->eos_aux, numParticles);
+			SPHX_LAUNCH_CHECK("eos_kernel");
+		}
 	}
 	ForcesArgs a;
 	a.forces = (float4*)forces; a.cfl = (ctx->dev.simflags & SPHX_ENABLE_DTADAPT) ? cfl : nullptr;
@@ -2564,6 +2576,7 @@ int sphx_sa_tiles_run(sphx_ctx *ctx, int mode, void *forces, const void *pos, co
 	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.info = (const particleinfo*)info;
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.aux = ctx->eos_aux;
+	ctx->eos_tag_vel = nullptr;      // the scratch rows change hands
 	if (mode == SPHX_SA_TILE_DSUM) {      // the window's second array holds the displacements
 		sa_displacement_kernel<<<div_up_u(numParticles, 256), 256, 0, stream>>>((const float4*)pos, (const float4*)newPos, ctx->eos_aux, numParticles);
 		SPHX_LAUNCH_CHECK("sa_displacement_kernel");

@@ -255,6 +255,7 @@ extern "C" int sphx_forces_basicstep_grenier(sphx_ctx *ctx, void *forces, float 
 		if (numBlocks > blocks) SPHX_HIP(hipMemsetAsync(cfl + cflOffset + blocks, 0, sizeof(float)*(numBlocks - blocks), st));
 	}
 	// the rows are read for the neighbours as well: every particle, not just the range
+	ctx->eos_tag_vel = nullptr;      // the scratch rows change hands
 	grenier_row_kernel<<<div_up_u(numParticles, 256), 256, 0, st>>>(ctx->dev, (const float4*)vel, (const particleinfo*)info, sigma,
 		ctx->eos_aux, numParticles);
 	SPHX_LAUNCH_CHECK("grenier_row_kernel");

@@ -275,6 +275,12 @@ extern "C" int sphx_halo_exchange(sphx_halo *h, int nbuf, void *const *bufs, con
 		else if (sendCount[s] && hipStreamWaitEvent(stream, g->posted[peer[s]].done, 0) != hipSuccess)
 			fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: hipStreamWaitEvent failed");
 	}
+	if (rc != SPHX_OK) me.err = 1;
+	pthread_barrier_wait(&g->barrier);
+	// the verdict is the group's, not the neighbourhood's: a rank two slabs away from the failure would otherwise return
+	// SPHX_OK, enter the next collective and wait there for ranks that have returned an error and will not come
+	for (int r = 0; r < g->world; ++r)
+		if (g->posted[r].err) fail(SPHX_ERR_RUNTIME, "sphx_halo_exchange: a rank of the group failed during the exchange");
 	pthread_barrier_wait(&g->barrier);               // the slots may be rewritten from here on
 	return rc;
 }

@@ -1099,13 +1099,28 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	// tiles serve sphx_forces_basicstep's pair loop only (SPH_F1, inviscid or Newtonian, DYN / LJ / MK boundaries) and sphx_calc_visc
 	// ... and, with SA_BOUNDARY, the particle <- particle sums of the SA forces, density summation and density diffusion
 	// (one fluid; with k-epsilon the density summation and the diffusion, which do not involve the model: sphx_sa_tiles_run, forces.hip)
+	// (a run with open boundaries goes through the list walkers: its passes carry terms the tiled window does not know, and it
+	// rebuilds the list in every step -- tiles nobody reads are not built)
 	const bool tiled_options = ctx->params.sph_formulation == SPHX_SPH_F1 && ctx->params.rheologytype <= SPHX_NEWTONIAN &&
-		(!sa || (ctx->dev.numfluids == 1 && (ctx->dev.turbmodel == SPHX_LAMINAR_FLOW || ctx->dev.turbmodel == SPHX_KEPSILON)));
+		(!sa || (ctx->dev.numfluids == 1 && (ctx->dev.turbmodel == SPHX_LAMINAR_FLOW || ctx->dev.turbmodel == SPHX_KEPSILON) &&
+		         !(ctx->params.simflags & SPHX_ENABLE_INLET_OUTLET)));
 	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit) {
 		rc = sphx_ensure_tile_lists(ctx);      // first tiled build: the tile lists are allocated now (or never: generic kernels)
 		if (rc != SPHX_OK) return rc;
 	}
 	bool tiling_on_side = false;
+	// whatever exit this function takes once the tiling has been forked to the side stream, the caller's stream waits for it:
+	// a retry or the next build would otherwise race with kernels still writing the tiles (and such a tiling is not used)
+	struct SideJoin {
+		sphx_ctx *ctx; hipStream_t st; bool armed;
+		~SideJoin() {
+			if (!armed) return;
+			(void)hipEventRecord(ctx->side_join, ctx->side_stream);
+			(void)hipStreamWaitEvent(st, ctx->side_join, 0);
+			(void)hipGetLastError();
+			ctx->tiles_built = false;
+		}
+	} sideJoin = { ctx, st, false };
 	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit && ctx->tile_list) {
 		// The tiling reads the cell tables only and is needed by the tile lists, not by the list build: it runs beside
 		// build_neibs_kernel on the context's side stream (build_tiles_kernel is a serial walk per row bundle, ~400 waves for
@@ -1123,7 +1138,7 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		if (ctx->side_stream) {
 			SPHX_HIP(hipEventRecord(ctx->side_fork, st));
 			SPHX_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-			ts = ctx->side_stream; tiling_on_side = true;
+			ts = ctx->side_stream; tiling_on_side = true; sideJoin.armed = true;
 		}
 		SPHX_HIP(hipMemcpyAsync(ctx->cell_end_copy, cellEnd, sizeof(uint32_t)*(size_t)gridCells, hipMemcpyDeviceToDevice, ts));
 		SPHX_HIP(hipMemsetAsync(ctx->tile_ctl, 0, 2*sizeof(uint32_t), ts));
@@ -1155,7 +1170,10 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	neibs_counters_fold_kernel<<<1, NEIBS_SPREAD, 0, st>>>(ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("neibs_counters_fold_kernel");
-	if (tiling_on_side) SPHX_HIP(hipStreamWaitEvent(st, ctx->side_join, 0));      // the tiling is there for everything queued from here on
+	if (tiling_on_side) {      // the tiling is there for everything queued from here on
+		SPHX_HIP(hipStreamWaitEvent(st, ctx->side_join, 0));
+		sideJoin.armed = false;
+	}
 	if (sa) {   // the fluid particles with boundary elements in reach
 		if (!ctx->sa_wall && hipMalloc((void**)&ctx->sa_wall, sizeof(uint32_t)*((size_t)ctx->reserved_particles + 1)) != hipSuccess) {
 			(void)hipGetLastError();

@@ -185,6 +185,7 @@ fidelity_row_kernel(DevParams p, const float4 *__restrict__ vel, const particlei
 
 void sphx_fidelity_rows_launch(sphx_ctx *ctx, const void *vel, const void *info, uint32_t numParticles, hipStream_t st)
 {
+	ctx->eos_tag_vel = nullptr;      // the scratch rows change hands
 	fidelity_row_kernel<<<div_up_u(numParticles, 256), 256, 0, st>>>(ctx->dev, (const float4*)vel, (const particleinfo*)info, nullptr, ctx->eos_aux, numParticles);
 }
 
@@ -407,6 +408,7 @@ int sphx_fidelity_forces_launch(sphx_ctx *ctx, void *forces, float *cfl,
 	}
 	{ const int rc0 = sphx_ensure_scratch(ctx, numParticles); if (rc0 != SPHX_OK) return rc0; }
 	// the rows are read for the neighbours as well: every particle, not just the range
+	ctx->eos_tag_vel = nullptr;      // the scratch rows change hands
 	fidelity_row_kernel<<<div_up_u(numParticles, 256), 256, 0, st>>>(ctx->dev, (const float4*)vel, (const particleinfo*)info, effvisc, ctx->eos_aux, numParticles);
 	SPHX_LAUNCH_CHECK("fidelity_row_kernel");
 	GnForcesArgs a = {};

@@ -11,6 +11,36 @@ struct SaWallCache {
 	uint32_t capacity, gen;
 };
 
+// open boundaries of a run with ENABLE_INLET_OUTLET: flags of particleinfo.x (src/particleinfo.h:153-156, 222-241)
+#define SA_FG_INLET            (PART_FLAG_START << 2)
+#define SA_FG_OUTLET           (PART_FLAG_START << 3)
+#define SA_FG_VELOCITY_DRIVEN  (PART_FLAG_START << 4)
+#define SA_FG_CORNER           (PART_FLAG_START << 5)
+#define SA_IS_OPEN(f)          (((f).x & (SA_FG_INLET | SA_FG_OUTLET)) != 0)
+#define SA_IS_VELOCITY_DRIVEN(f) (((f).x & SA_FG_VELOCITY_DRIVEN) != 0)
+#define SA_IS_CORNER(f)        (((f).x & SA_FG_CORNER) != 0)
+
+// the two boundary-condition passes: see sa_segment_bc_kernel / sa_vertex_bc_kernel (sa_bounds.hip)
+struct SaArgs {
+	float4 *vel;                 // in place: boundary rows (segment kernel) / vertex rows (vertex kernel) are written
+	float4 *gGam;                // in place: boundary rows written when gamma is (re)computed
+	float4 *boundElement;        // vertex-normal kernel: vertex rows written
+	const float4 *pos;
+	const uint4 *vertices;
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	int step, repack;
+	// KEPSILON (sa_segment_bc_params / sa_vertex_bc_params with has_keps, src/cuda/sa_bc_params.h:152-200,275-320): in place
+	float *tke, *eps;
+	float4 *eulerVel;
+	float deltap;
+	int openFaces;                // a run with open boundaries: their segments and (non-corner) vertices are left to sa_io.hip
+};
+// the solid-wall rows of the two passes in a run with open boundaries (sa_io.hip launches its own kernels for the open faces)
+int sphx_sa_solid_rows_launch(sphx_ctx *ctx, const SaArgs &a, bool vertexPass, hipStream_t st);
+
 // forces with SA_BOUNDARY: see sa_forces_kernel (sa_bounds.hip)
 struct SaForcesArgs {
 	float4 *forces;
@@ -64,6 +94,8 @@ struct SaDensitySumArgs {
 	const uint32_t *tileGuard;
 	int wallDone;                 // sa_density_sum_wall_kernel has left {sum grad gamma, sum grad gamma . dr} in newGGam (needs `tiled`)
 	SaWallCache wc;
+	const float4 *oldEulerVel;    // a run with open boundaries (sa_density_sum_kernel<true>)
+	float dt;
 };
 
 // sa_wall.hip: the boundary-element terms of the three engines for the particles of ctx->sa_wall

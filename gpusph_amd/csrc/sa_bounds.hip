@@ -10,22 +10,6 @@
 #include "neib_iter.h"
 #include "sa_args.h"
 
-struct SaArgs {
-	float4 *vel;                 // in place: boundary rows (segment kernel) / vertex rows (vertex kernel) are written
-	float4 *gGam;                // in place: boundary rows written when gamma is (re)computed
-	float4 *boundElement;        // vertex-normal kernel: vertex rows written
-	const float4 *pos;
-	const uint4 *vertices;
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t numParticles;
-	int step, repack;
-	// KEPSILON (sa_segment_bc_params / sa_vertex_bc_params with has_keps, src/cuda/sa_bc_params.h:152-200,275-320): in place
-	float *tke, *eps;
-	float4 *eulerVel;
-	float deltap;
-};
 
 __device__ __forceinline__ bool has_vertex(const uint4 &v, uint32_t id) { return v.x == id || v.y == id || v.z == id; }
 
@@ -82,6 +66,7 @@ sa_segment_bc_kernel(DevParams p, SaArgs a)
 	if (index >= a.numParticles) return;
 	const particleinfo info = a.info[index];
 	if (!IS_BOUNDARY(info)) return;
+	if (a.openFaces && SA_IS_OPEN(info)) return;       // the segments of the open faces are sa_io.hip's (one wave each)
 	const float4 pos = a.pos[index];
 	const float4 normal = a.boundElement[index];
 	const uint4 verts = a.vertices[index];
@@ -141,6 +126,7 @@ sa_segment_bc_kernel(DevParams p, SaArgs a)
 	shepard_div = fmaxf(shepard_div, 0.1f*gGam.w);
 	vel.w = eos_rho(p, sumpWall/shepard_div, fl);
 	a.vel[index] = vel;
+	if (!KEPS && a.openFaces) a.eulerVel[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);      // impose_solid_eulerVel of a run with open boundaries
 	if (KEPS) {          // impose_solid_keps_bc (:1262-1277); the normal is the float4 boundary element: its .w rides along
 		a.tke[index] = sumtke/shepard_div;
 		a.eps[index] = fmaxf(sumeps/shepard_div, 1e-5f);
@@ -160,6 +146,7 @@ sa_vertex_bc_kernel(DevParams p, SaArgs a)
 	if (index >= a.numParticles) return;
 	const particleinfo info = a.info[index];
 	if (PART_TYPE(info) != PT_VERTEX) return;
+	if (a.openFaces && SA_IS_OPEN(info) && !SA_IS_CORNER(info)) return;      // sa_io.hip's; corner vertices are walls to this pass
 	const float4 pos = a.pos[index];
 	const float gam = a.gGam[index].w;
 	const uint32_t fl = FLUID_NUM(info);
@@ -256,7 +243,10 @@ sa_init_gamma_kernel(DevParams p, SaGammaArgs a)
 // TAU rows the finalize kernel reads hold the sums of the LAST launch over the particle: fluid <- boundary for a fluid particle,
 // a cleared row for a vertex (forcesDevice<PT_VERTEX, PT_FLUID>, whose viscous term never reaches the force, :3750-3783).  This
 // kernel therefore accumulates the k-epsilon sums over the boundary elements only; the CPU oracle restates the launches one by one.
-template<bool KEPS>
+// OPEN: a run with open boundaries (laminar): the viscous term of a fluid <- vertex pair and of a boundary element sees the
+// relative velocity plus the relative Eulerian velocity (get_viscous_relVel, forces_kernel.def:2494-2507; no normal part is taken
+// out for the segment of an open face, :2703-2708), and the gamma CFL term gains compute_gamma_cfl_open_boundary (:1485-1497)
+template<bool KEPS, bool OPEN = false>
 __global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
 sa_forces_kernel(DevParams p, SaForcesArgs a)
 {
@@ -277,13 +267,13 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 				const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
 				// keps_particle_data :633-655, eulerVel_particle_data :553-561; pressure_for_precalc :389-401: P + 2/3 k/rho
 				const float p_k = KEPS ? a.tke[index] : 0.0f, p_e = KEPS ? a.eps[index] : 0.0f, p_turb = KEPS ? a.turbvisc[index] : 0.0f;
-				const float4 p_euler = KEPS ? a.eulerVel[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+				const float4 p_euler = (KEPS || OPEN) ? a.eulerVel[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 				const float p_precalc = KEPS ? (sa_P(p, vel.w, fl) + 2.0f*p_k/p_rho/3.0f)/(p_rho*p_rho) : sa_P(p, vel.w, fl)/(p_rho*p_rho);
 				float diff_k = 0.0f, diff_e = 0.0f, ce2yap = 1.92f, txx = 0.0f, txy = 0.0f, txz = 0.0f, tyy = 0.0f, tyz = 0.0f, tzz = 0.0f;
 				const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
 				const bool newtonian = p.rheology == SPHX_NEWTONIAN;
 				// fluid <- fluid and fluid <- vertex: compute_all_pp_interaction with the general specialisations
-				auto particle_pair = [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+				auto particle_pair = [&](bool vertexSection, uint32_t j, const float4 &npos, float rx, float ry, float rz) {
 					if (!is_active_w(npos.w)) return;
 					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
 					if (r >= p.influenceradius) return;
@@ -310,8 +300,13 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 						dx += vf*wx; dy += vf*wy; dz += vf*wz;
 					} else
 					if (newtonian) {
+						float wx = vx, wy = vy, wz = vz;
+						if (OPEN && vertexSection) {
+							const float4 ne = a.eulerVel[j];
+							wx = vx + (p_euler.x - ne.x); wy = vy + (p_euler.y - ne.y); wz = vz + (p_euler.z - ne.z);
+						}
 						const float vf = sa_visc_avg(p, p.visccoeff[fl], p.visccoeff[nfl], p_rho, n_rho, nmass)*f;
-						dx += vf*vx; dy += vf*vy; dz += vf*vz;
+						dx += vf*wx; dy += vf*wy; dz += vf*wz;
 					}
 					force.x += dx; force.y += dy; force.z += dz;
 				};
@@ -319,8 +314,8 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 				if (finish)
 					force = a.forces[index];
 				else {
-					for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, particle_pair);
-					for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, particle_pair);
+					for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &np_, float rx, float ry, float rz) { particle_pair(false, j, np_, rx, ry, rz); });
+					for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &np_, float rx, float ry, float rz) { particle_pair(true, j, np_, rx, ry, rz); });
 				}
 				if (finish && a.wallDone) {      // sa_forces_wall_kernel: the sums are in `force`, the gamma CFL term in its place
 					if (a.cflGamma && a.neibsList[(size_t)p.neibboundpos*p.stride + index] != NEIBS_END) gammaCfl = a.cflGamma[index];
@@ -346,6 +341,13 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 						const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
 						const float vs = sa_dot3(vel.x - vx, vel.y - vy, vel.z - vz, be.x, be.y, be.z);
 						gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
+						if (OPEN) {      // n.(v_a + relEulerVel), n.(v_s - relEulerVel)
+							const float4 ne = a.eulerVel[j];
+							const float ex = (vx + (p_euler.x - ne.x)) - vx, ey = (vy + (p_euler.y - ne.y)) - vy, ez = (vz + (p_euler.z - ne.z)) - vz;
+							const float a1 = sa_dot3(vel.x + ex, vel.y + ey, vel.z + ez, be.x, be.y, be.z);
+							const float a2 = sa_dot3(-vx + vel.x - ex, -vy + vel.y - ey, -vz + vel.z - ez, be.x, be.y, be.z);
+							gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(a1), fabsf(a2)));
+						}
 					}
 					if (!density_sum) {
 						float DrDt = 0.0f;
@@ -395,7 +397,13 @@ sa_forces_kernel(DevParams p, SaForcesArgs a)
 					} else
 					if (newtonian) {
 						const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
-						const float tx = vx - vn*be.x, ty = vy - vn*be.y, tz = vz - vn*be.z;
+						float tx, ty, tz;
+						if (OPEN) {
+							const float4 ne = a.eulerVel[j];
+							const float wx = vx + (p_euler.x - ne.x), wy = vy + (p_euler.y - ne.y), wz = vz + (p_euler.z - ne.z);
+							const float wn = SA_IS_OPEN(a.info[j]) ? 0.0f : sa_dot3(wx, wy, wz, be.x, be.y, be.z);
+							tx = wx - wn*be.x; ty = wy - wn*be.y; tz = wz - wn*be.z;
+						} else { tx = vx - vn*be.x; ty = vy - vn*be.y; tz = vz - vn*be.z; }
 						const float our_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl]*p_rho : p.visccoeff[fl];
 						const float neib_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl]*n_rho : p.visccoeff[nfl];
 						const float avg = (p.avgop == SPHX_ARITHMETIC) ? (our_mu + neib_mu)*0.5f :
@@ -566,7 +574,11 @@ sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
 }
 
 // ---- density summation with dynamic gamma (src/cuda/density_sum_kernel.cu:206-250,419-478,523-655) and Brezzi diffusion ----
-
+// OPEN: a run with open boundaries.  A vertex of an open face is not a reservoir of mass at rest: its term at step n is dropped
+// and replaced by the kernel at the distance it would have after moving with its Eulerian velocity instead of its own for dt
+// (densitySumOpenBoundaryContribution, density_sum_kernel.cu:119-140); the segments of an open face add to the gamma that
+// multiplies the old density the flux of gamma through them (io_gamma_contrib / compute_imposed_gamma, :374-417)
+template<bool OPEN>
 __global__ void __launch_bounds__(128)
 sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 {
@@ -583,17 +595,26 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 	// the walker hands over r_ab at step n (own old position against a.pos = new neighbour rows is NOT what is wanted), so
 	// it is pointed at the OLD positions and the new neighbour row is fetched here
 	struct { const float4 *pos; const uint32_t *cellStart; const neibdata *neibsList; } w = { a.oldPos, a.cellStart, a.neibsList };
-	float sumPmwN = 0.0f, sumPmwNp1 = 0.0f;
+	float sumPmwN = 0.0f, sumPmwNp1 = 0.0f, sumOpen = 0.0f;
 	auto volumic = [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
 		if (!is_active_w(nN.w)) return;
 		const float4 nNp1 = a.pos[j];
 		// r_ab at n = pos_corr - neighbour old; at n+1 = (pos_corr - neighbour new) + own displacement
 		const float rx = pcx - nN.x, ry = pcy - nN.y, rz = pcz - nN.z;
 		const float qx = (pcx - nNp1.x) + dx, qy = (pcy - nNp1.y) + dy, qz = (pcz - nNp1.z) + dz;
-		const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
-		sumPmwN -= nN.w*kernel_W<SPHX_WENDLAND>(p, rN);
+		const bool openNeib = OPEN && SA_IS_OPEN(a.info[j]);
+		if (!openNeib) {
+			const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+			sumPmwN -= nN.w*kernel_W<SPHX_WENDLAND>(p, rN);
+		}
 		const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
 		if (rNp1 < p.influenceradius) sumPmwNp1 += nN.w*kernel_W<SPHX_WENDLAND>(p, rNp1);
+		if (openNeib) {
+			const float4 e = a.oldEulerVel[j], v = a.oldVel[j];
+			const float ex = rx + a.dt*(e.x - v.x), ey = ry + a.dt*(e.y - v.y), ez = rz + a.dt*(e.z - v.z);
+			const float moved = sqrtf(ex*ex + ey*ey + ez*ez);
+			if (moved < p.influenceradius) sumOpen -= nN.w*kernel_W<SPHX_WENDLAND>(p, moved);
+		}
 	};
 	float fw;
 	if (a.tiled && !(a.tileGuard && *a.tileGuard))
@@ -601,10 +622,10 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 	else {
 		for_each_neib<PT_FLUID, true>(p, w, index, posN, gridPos, volumic);
 		for_each_neib<PT_VERTEX, true>(p, w, index, posN, gridPos, volumic);
-		fw = sumPmwNp1 + sumPmwN + 0.0f;
+		fw = sumPmwNp1 + sumPmwN + sumOpen;
 		a.forces[index].w = fw;
 	}
-	float gGamDotR = 0.0f;
+	float gGamDotR = 0.0f, gamFluxMoved = 0.0f, gamFluxN = 0.0f;
 	V3 gGam = v3(0.0f, 0.0f, 0.0f);
 	if (a.wallDone && a.tiled && !(a.tileGuard && *a.tileGuard)) {     // sa_density_sum_wall_kernel
 		if (a.neibsList[(size_t)p.neibboundpos*p.stride + index] != NEIBS_END && is_active_w(posN.w)) {
@@ -626,12 +647,24 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 		const V3 gNp1 = ns*(wall_grad_gamma(tri, qNp1)/p.slength);
 		gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
 		gGam = gGam + gNp1;
+		if (OPEN && SA_IS_OPEN(a.info[j])) {
+			const float4 e = a.oldEulerVel[j], v = a.oldVel[j];
+			const V3 drift = v3(a.dt*(e.x - v.x), a.dt*(e.y - v.y), a.dt*(e.z - v.z));
+			const V3 gMoved = ns*(wall_grad_gamma(tri, qN + drift/p.slength)/p.slength);
+			gamFluxMoved += dot(drift, gMoved);
+			gamFluxN += dot(drift, gN);
+		}
 	});
 	gGamDotR *= p.slength;
 	const float4 gGamN = a.oldGGam[index];
 	float4 g = make_float4(gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR);
 	const uint32_t fl = FLUID_NUM(info);
-	const float rho = (gGamN.w*((a.oldVel[index].w + 1.0f)*p.rho0[fl]) + fw)/g.w;
+	float gamOld = gGamN.w;
+	if (OPEN) {
+		gamOld = gGamN.w + (gamFluxMoved + gamFluxN)/2.0f;
+		gamOld = gamOld > 1.0f ? 1.0f : (gamOld < 0.1f ? 0.1f : gamOld);
+	}
+	const float rho = (gamOld*((a.oldVel[index].w + 1.0f)*p.rho0[fl]) + fw)/g.w;
 	if (g.w > 1.0f || sqrtf(g.x*g.x + g.y*g.y + g.z*g.z)*p.slength < 1e-10f) g.w = 1.0f;
 	else if (g.w < 0.1f) g.w = 0.1f;
 	a.newVel[index].w = rho/p.rho0[fl] - 1.0f;
@@ -647,9 +680,17 @@ struct SaDiffusionArgs {
 	uint32_t numParticles;
 	float dt;
 	const uint32_t *tileGuard;    // stand-by launch behind the tiled kernel (SPHX_TURB_SA_DIFF): only if the tiling overflowed
+	// a run with open boundaries (sa_density_diffusion_kernel<true>): the segments of the pressure-driven faces take part
+	const float4 *boundElement;
+	const float2 *vertPos[3];
+	float deltap;
 };
 
 // computeDensityDiffusionDevice<.., BREZZI, SA_BOUNDARY, PT_FLUID> (forces_kernel.def:1766-1783, 4515-4560)
+// OPEN: with ENABLE_INLET_OUTLET the segments of PRESSURE-driven open faces exchange density with the fluid as a fluid neighbour
+// would, with |grad gamma_as| / r_as in the place of V_b F, no diffusion coefficient, evaluated in double as the literals of the
+// reference's expression make it (:1836-1852, 4536-4582)
+template<bool OPEN>
 __global__ void __launch_bounds__(128)
 sa_density_diffusion_kernel(DevParams p, SaDiffusionArgs a)
 {
@@ -678,6 +719,28 @@ sa_density_diffusion_kernel(DevParams p, SaDiffusionArgs a)
 		const float gdotr = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
 		float n = 0.0f;
 		n += p.densityDiffCoeff*((2.0f/(rho + neib_rho))*(pres - sa_P(p, nvel.w, nfl)) - gdotr)*npos.w/neib_rho*f*a.dt*2.0f*rho;
+		DrDt += n;
+	});
+	if (OPEN)
+	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
+		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+		if (!is_active_w(npos.w)) return;
+		if (r >= p.influenceradius + a.deltap) return;
+		const particleinfo ninfo = a.info[j];
+		if (!SA_IS_OPEN(ninfo) || SA_IS_VELOCITY_DRIVEN(ninfo)) return;
+		const float4 be = a.boundElement[j];
+		const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
+		const float inv_h = 1.0f/p.slength;
+		WallTri tri;
+		wall_tri_setup(tri, v3(be.x, be.y, be.z), a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+		const float ggamAS = wall_grad_gamma(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
+		const float nrt = a.vel[j].w;
+		const uint32_t nfl = FLUID_NUM(ninfo);
+		const float neib_rho = (nrt + 1.0f)*p.rho0[nfl];
+		const float gdotr = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
+		const double t = ((2.0/(rho + neib_rho))*(pres - sa_P(p, nrt, nfl)) - gdotr)*ggamAS/r_as*a.dt*2.0f*rho;
+		float n = 0.0f;
+		n = (float)(n - t);
 		DrDt += n;
 	});
 	DrDt /= a.gGam[index].w;
@@ -1203,7 +1266,7 @@ extern "C" int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, v
 			if (rc != SPHX_OK) return rc;
 		}
 	}
-	sa_density_sum_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	sa_density_sum_kernel<false><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_kernel");
 	return SPHX_OK;
 }
@@ -1233,7 +1296,7 @@ extern "C" int sphx_sa_compute_density_diffusion(sphx_ctx *ctx, void *forces, co
 		if (rc != SPHX_OK) return rc;
 		if (used && !a.tileGuard) return SPHX_OK;      // the host has seen the tiling succeed: no stand-by launch
 	}
-	sa_density_diffusion_kernel<<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	sa_density_diffusion_kernel<false><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_diffusion_kernel");
 	return SPHX_OK;
 }
@@ -1248,5 +1311,108 @@ extern "C" int sphx_apply_density_diffusion(sphx_ctx *ctx, void *vel, const void
 	sa_update_density_kernel<<<div_up_u(particleRangeEnd, 256), 256, 0, (hipStream_t)stream>>>((float4*)vel, (const float4*)forces,
 		(const particleinfo*)info, particleRangeEnd, dt);
 	SPHX_LAUNCH_CHECK("sa_update_density_kernel");
+	return SPHX_OK;
+}
+
+// ==========================================================================================
+// A run with open boundaries (SA_BOUNDARY + ENABLE_INLET_OUTLET, laminar): the passes over the FLUID particles.  They are the list
+// walkers above with their OPEN terms (the tiled window and the wave-per-wall-particle kernels do not know those terms, so the
+// walkers are the whole pass here); the passes over the elements of the open faces themselves are sa_io.hip's.
+//   density_sum       src/cuda/density_sum_kernel.cu:119-140,206-250,374-420,606-655
+//   forces            src/cuda/forces_kernel.def:1485-1497,2494-2507,2703-2708
+//   density diffusion src/cuda/forces_kernel.def:1836-1852,4536-4582
+// ==========================================================================================
+static int sa_open_check(sphx_ctx *ctx, const char *who)
+{
+	int rc = sa_check(ctx, who);
+	if (rc != SPHX_OK) return rc;
+	if (ctx->dev.turbmodel == SPHX_KEPSILON)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_io: open boundaries with k-epsilon are not built");
+	return SPHX_OK;
+}
+
+int sphx_sa_solid_rows_launch(sphx_ctx *ctx, const SaArgs &a, bool vertexPass, hipStream_t st)
+{
+	if (vertexPass) sa_vertex_bc_kernel<SPHX_WENDLAND, false><<<div_up_u(a.numParticles, 128), 128, 0, st>>>(ctx->dev, a);
+	else sa_segment_bc_kernel<SPHX_WENDLAND, false><<<div_up_u(a.numParticles, 128), 128, 0, st>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_segment_bc_kernel / sa_vertex_bc_kernel (solid rows of a run with open boundaries)");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces, const void *oldPos, const void *newPos,
+	const void *oldVel, const void *oldEulerVel, const void *oldGGam, const void *boundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_open_check(ctx, "density_sum called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldEulerVel && oldGGam && boundElements && vertPos0 && vertPos1 &&
+		vertPos2 && info && hash && cellStart && neibsList, "sphx_sa_density_sum_io: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaDensitySumArgs a = {};
+	a.newVel = (float4*)newVel; a.newGGam = (float4*)newGGam; a.forces = (float4*)forces;
+	a.oldPos = (const float4*)oldPos; a.pos = (const float4*)newPos; a.oldVel = (const float4*)oldVel; a.oldGGam = (const float4*)oldGGam;
+	a.boundElement = (const float4*)boundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
+	a.oldEulerVel = (const float4*)oldEulerVel; a.dt = dt;
+	sa_density_sum_kernel<true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_density_sum_kernel<open>");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, const void *pos, const void *vel,
+	const void *eulerVel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
+	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, float deltap, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream)
+{
+	int rc = sa_open_check(ctx, "forces called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(forces && pos && vel && eulerVel && info && hash && cellStart && neibsList && gGam && boundElements && vertPos0 && vertPos1 && vertPos2,
+		"sphx_forces_basicstep_sa_io: missing buffer");
+	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_forces_basicstep_sa_io: invalid particle range");
+	const uint32_t numBlocks = round_up_u(div_up_u(toParticle - fromParticle, SPHX_BLOCK_FORCES), 4u);
+	if (h_numBlocks) *h_numBlocks = numBlocks;
+	if (!numBlocks) return SPHX_OK;
+	const bool dtadapt = (ctx->dev.simflags & SPHX_ENABLE_DTADAPT) != 0;
+	if (dtadapt) SPHX_REQUIRE(cfl != nullptr, "sphx_forces_basicstep_sa_io: ENABLE_DTADAPT needs the CFL buffer");
+	const bool gcfl = cflGamma && dtadapt && !(ctx->dev.simflags & SPHX_ENABLE_GAMMA_QUADRATURE);
+	SaForcesArgs a = {};
+	a.forces = (float4*)forces; a.cfl = dtadapt ? cfl : nullptr;
+	a.cflGamma = gcfl ? cflGamma : nullptr; a.cflGammaBlocks = gcfl ? cflGamma + round_up_u(numParticles, 4u) : nullptr;
+	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.eulerVel = (const float4*)eulerVel; a.gGam = (const float4*)gGam;
+	a.boundElement = (const float4*)boundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
+	sa_forces_kernel<false, true><<<numBlocks, SPHX_BLOCK_FORCES, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_forces_kernel<open>");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_compute_density_diffusion_io(sphx_ctx *ctx, void *forces, const void *pos, const void *vel, const void *gGam,
+	const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float dt, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_open_check(ctx, "compute_density_diffusion called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	if (ctx->params.densitydiffusiontype != SPHX_BREZZI || !(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) ||
+		ctx->params.sph_formulation == SPHX_SPH_HA)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_compute_density_diffusion_io: built for Brezzi diffusion with density summation");
+	SPHX_REQUIRE(forces && pos && vel && gGam && boundElements && vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList,
+		"sphx_sa_compute_density_diffusion_io: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaDiffusionArgs a = {};
+	a.forces = (float4*)forces; a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.gGam = (const float4*)gGam;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
+	a.numParticles = particleRangeEnd; a.dt = dt;
+	a.boundElement = (const float4*)boundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2; a.deltap = deltap;
+	sa_density_diffusion_kernel<true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_density_diffusion_kernel<open>");
 	return SPHX_OK;
 }

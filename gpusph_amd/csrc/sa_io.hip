@@ -1,645 +1,722 @@
-// sa_io.hip -- open boundaries of the semi-analytical wall model (SA_BOUNDARY + ENABLE_INLET_OUTLET): the FIRST
-// kernels of that half of the row, for gfx950.  Replaces, of CUDABoundaryConditionsEngine,
-//   saIdentifyCornerVertices   src/cuda/boundary_conditions.cu:667   saIdentifyCornerVerticesDevice   _kernel.cu:2319-2362
-//   initIOmass_vertexCount     src/cuda/boundary_conditions.cu:578   initIOmass_vertexCountDevice     _kernel.cu:1999-2064
-//   initIOmass                 src/cuda/boundary_conditions.cu:610   initIOmassDevice                 _kernel.cu:2078-2172
-//   findOutgoingSegment        src/cuda/boundary_conditions.cu:238   findOutgoingSegmentDevice        _kernel.cu:1647-1750
-//   disableOutgoingParts       src/cuda/boundary_conditions.cu:76    disableOutgoingPartsDevice       _kernel.cu:2374-2398
-// The boundary-condition passes with open boundaries, the density summation and the forces with the Eulerian velocity, and the
-// command sequence are NOT built (sphx_sa_segment_bc & co. still refuse ENABLE_INLET_OUTLET); the CPU oracle restates all of
-// them already (oracle/sph_oracle.c "Open boundaries", tests/test_sa_io_oracle.py), so these five are what a run needs besides.
-// One thread per particle over the reference's u16 list, the reference's operation order (no FMA contraction; the areas of
-// getMassRepartitionFactor in double where the reference's 0.5*dot(...) promotes them): bit-identical to the oracle.
+// sa_io.hip -- open boundaries of the semi-analytical wall model (SA_BOUNDARY + ENABLE_INLET_OUTLET): the passes over
+// the ELEMENTS of the open faces -- their vertices, their segments and the fluid particles about to leave through them -- for gfx950.
+//
+// What these passes do, and which entry points of CUDABoundaryConditionsEngine / the forces engine they stand in for:
+//   sphx_sa_identify_corner_vertices    saIdentifyCornerVertices   src/cuda/boundary_conditions.cu:667   (_kernel.cu:2319-2362)
+//   sphx_sa_init_io_mass_vertex_count   initIOmass_vertexCount     src/cuda/boundary_conditions.cu:578   (_kernel.cu:1999-2064)
+//   sphx_sa_init_io_mass                initIOmass                 src/cuda/boundary_conditions.cu:610   (_kernel.cu:2078-2172)
+//   sphx_sa_find_outgoing_segment       findOutgoingSegment        src/cuda/boundary_conditions.cu:238   (_kernel.cu:1647-1750)
+//   sphx_sa_disable_outgoing_parts      disableOutgoingParts       src/cuda/boundary_conditions.cu:76    (_kernel.cu:2374-2398)
+//   sphx_sa_segment_bc_io               saSegmentBoundaryConditions with open boundaries                  (_kernel.cu:1427-1520)
+//   sphx_sa_vertex_bc_io                saVertexBoundaryConditions with open boundaries                   (_kernel.cu:2197-2252)
+//   sphx_sa_io_water_depth              ENABLE_WATER_DEPTH in the vertex forces pass    src/cuda/forces_kernel.def:192-205,3285-3303
+//   sphx_flux_computation               FLUX_COMPUTATION           src/cuda/post_process.cu:485-570
+// The passes of such a run over ALL fluid particles (density summation, forces, density diffusion) are the list walkers of
+// sa_bounds.hip with their open-boundary terms.
+//
+// Design.  A run has a few thousand open elements among millions of particles, each with ~100 neighbours and two powf per
+// neighbour.  Every pass here therefore runs in two launches: (1) one coalesced sweep over particleinfo that appends the rows the
+// pass is about to an index (wave-aggregated: one atomic per wave), (2) a grid of waves that take those rows one WAVE per row:
+// lane l decodes and evaluates entry l of the list section in question (wave_list.h), the per-row result is a reduction over the
+// lanes and a short scalar epilogue.  The solid-wall rows of the two boundary-condition passes go to the kernels of
+// sa_bounds.hip, which skip the open rows.  The physics is written from the equations (characteristic boundary condition of a
+// weakly compressible flow; area coordinates of a point in a triangle); results are held to the CPU oracle bit for bit where a
+// threshold decides what happens next (see wave_list.h on the order of sums).
 #include "sphx_internal.h"
 #include "neib_iter.h"
+#include "sa_args.h"
+#include "wave_list.h"
+#include "sa_wall_gamma.h"      // V3 and the corners of a boundary element from BUFFER_VERTPOS (wall_tri_setup)
 
-// Every launch of this file goes through one macro, so that tests/hostemu can run the kernels' SOURCE on the host, thread after
-// thread, against the oracle before a GPU is at hand (a test harness: the library has no CPU path and the macro below is what
-// hipcc sees).
+// tests/hostemu runs this file's SOURCE on the host (a test harness: the library has no CPU path; hipcc sees the definitions
+// below): row kernels as 64 lock-stepped fibres per wave, the element-wise ones thread after thread
 #ifndef SPHX_LAUNCH
 #define SPHX_LAUNCH(kernel, grid, block, stream, ...) kernel<<<(grid), (block), 0, (stream)>>>(__VA_ARGS__)
+#define SPHX_LAUNCH_WAVES(kernel, grid, block, stream, ...) kernel<<<(grid), (block), 0, (stream)>>>(__VA_ARGS__)
 #endif
 
-// particleinfo flags of open boundaries (src/particleinfo.h:153-156, 222-241)
-#define FG_INLET             (PART_FLAG_START << 2)
-#define FG_OUTLET            (PART_FLAG_START << 3)
-#define FG_VELOCITY_DRIVEN   (PART_FLAG_START << 4)
-#define FG_CORNER            (PART_FLAG_START << 5)
-#define IS_IO_BOUNDARY(f)    ((f).x & (FG_INLET | FG_OUTLET))
-#define IS_VEL_IO(f)         ((f).x & FG_VELOCITY_DRIVEN)
-#define IS_CORNER(f)         ((f).x & FG_CORNER)
-#define SA_IO_MAXNEIBVERTS 30       // boundary_conditions_kernel.cu:1977
+#define OPEN_MAX_RING 30          // other vertices of the open segments around a vertex that are remembered (_kernel.cu:1977)
+#define ROW_THREADS 256           // four rows per workgroup
+#ifndef ROW_GRID
+#define ROW_GRID 1024             // waves stride over the index: 4096 waves cover any open face in a few rounds
+#endif
 
-struct SaIoArgs {
-	const float4 *pos;             // the walker prefetches a position row per list entry
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	const uint4 *vertices;
-	const particleinfo *info;
-	uint32_t numParticles;
+// ---- (1) the index of a pass ---------------------------------------------------------------------------------------------------
+enum RowKind {
+	ROWS_OPEN_VERTICES,            // every vertex of an open face
+	ROWS_OPEN_INNER_VERTICES,      // ... that is not a corner (shared with a wall or another face)
+	ROWS_OPEN_SEGMENTS,
+	ROWS_DEPTH_GAUGES,             // active vertices of pressure-driven faces
+	ROWS_LEAVING_CANDIDATES        // active, unmarked fluid particles with boundary elements in reach
 };
 
-__device__ __forceinline__ bool io_has_vertex(const uint4 &v, uint32_t id) { return v.x == id || v.y == id || v.z == id; }
+struct RowSweep {
+	const particleinfo *info;
+	const float4 *pos;             // masses (activity): DEPTH_GAUGES, LEAVING_CANDIDATES
+	const uint4 *marks;            // BUFFER_VERTICES of the fluid rows: LEAVING_CANDIDATES
+	const neibdata *list;          // LEAVING_CANDIDATES
+	uint32_t first, end, stride, neibboundpos;
+	uint32_t *rows;                // [0] = how many, [1..] = which
+};
 
-__global__ void __launch_bounds__(128)
-sa_identify_corner_vertices_kernel(DevParams p, SaIoArgs a, particleinfo *infoOut)
+template<int KIND>
+__global__ void __launch_bounds__(256)
+open_rows_kernel(RowSweep a)
 {
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
-	particleinfo info = a.info[index];
-	if (!(PART_TYPE(info) == PT_VERTEX && IS_IO_BOUNDARY(info))) return;
-	const uint32_t obj = OBJECT_NUM(info), my_id = info_id(info);
-	const float4 pos = a.pos[index];
-	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-	bool corner = false;
-	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
-		const particleinfo ninfo = a.info[j];
-		// a segment that is not of this open boundary and holds this vertex
-		if (!(obj == OBJECT_NUM(ninfo) && IS_IO_BOUNDARY(ninfo)) && io_has_vertex(a.vertices[j], my_id)) corner = true;
-	});
-	if (corner) { info.x |= FG_CORNER; infoOut[index] = info; }
+	const uint32_t i = a.first + blockIdx.x*256 + threadIdx.x;
+	bool take = false;
+	if (i < a.end) {
+		const particleinfo f = a.info[i];
+		if (KIND == ROWS_OPEN_VERTICES) take = PART_TYPE(f) == PT_VERTEX && SA_IS_OPEN(f);
+		if (KIND == ROWS_OPEN_INNER_VERTICES) take = PART_TYPE(f) == PT_VERTEX && SA_IS_OPEN(f) && !SA_IS_CORNER(f);
+		if (KIND == ROWS_OPEN_SEGMENTS) take = PART_TYPE(f) == PT_BOUNDARY && SA_IS_OPEN(f);
+		if (KIND == ROWS_DEPTH_GAUGES) take = PART_TYPE(f) == PT_VERTEX && SA_IS_OPEN(f) && !SA_IS_VELOCITY_DRIVEN(f) && is_active_w(a.pos[i].w);
+		if (KIND == ROWS_LEAVING_CANDIDATES) {
+			take = PART_TYPE(f) == PT_FLUID && is_active_w(a.pos[i].w) && a.list[(size_t)a.neibboundpos*a.stride + i] != NEIBS_END;
+			if (take) { const uint4 m = a.marks[i]; take = (m.x | m.y) == 0u; }      // a marked one stays as it is (:1679-1686)
+		}
+	}
+	const unsigned long long m = wave_ballot(take);
+	if (!m) return;
+	const uint32_t lane = threadIdx.x & 63u;
+	const int leader = __builtin_ctzll(m);
+	uint32_t base = 0;
+	if ((int)lane == leader) base = atomicAdd(a.rows, (uint32_t)__builtin_popcountll(m));
+	base = (uint32_t)__shfl((int)base, leader);
+	if (take) a.rows[1u + base + wave_lanes_below(m, lane)] = i;
 }
 
-// the ids of the other vertices of the open-boundary segments vertex `index` belongs to, in list order (both kernels below)
-__device__ __forceinline__ uint32_t io_adjacent_vertex_ids(const DevParams &p, const SaIoArgs &a, uint32_t index, const float4 &pos,
-	const int3 &gridPos, uint32_t my_id, uint32_t *ids)
+// the rows of a launch, wave after wave
+#define FOR_MY_ROWS(rows, index) \
+	const uint32_t lane = threadIdx.x & 63u; \
+	const uint32_t waves_ = gridDim.x*(ROW_THREADS/64), count_ = (rows)[0]; \
+	for (uint32_t w_ = blockIdx.x*(ROW_THREADS/64) + (threadIdx.x >> 6), index; \
+	     w_ < count_ && ((index = __builtin_amdgcn_readfirstlane((rows)[1u + w_])), true); w_ += waves_)
+
+// ---- the list of a row, as the row kernels see it ---------------------------------------------------------------------------------
+struct RowLists {
+	const float4 *pos;
+	const uint32_t *hash, *cellStart;
+	const neibdata *list;
+};
+
+__device__ __forceinline__ bool tri_has(const uint4 &t, uint32_t id) { return t.x == id || t.y == id || t.z == id; }
+
+// ---- physics: the equation of state and the characteristics of the open-boundary condition ------------------------------------------
+// Tait: P = B((rho/rho0)^gamma - 1), c = c0 (rho/rho0)^((gamma-1)/2); densities are relative (rho/rho0 - 1).  The Riemann
+// invariants of the 1-D problem along the face normal are u_n +- psi(rho) with psi = 2 c /(gamma - 1).  (phys_core.cu:106-127)
+struct Tait {
+	float B, gamma, c0, rho0, halfGm1;
+	__device__ __forceinline__ Tait(const DevParams &p, uint32_t fl) : B(p.bcoeff[fl]), gamma(p.gammacoeff[fl]), c0(p.sscoeff[fl]), rho0(p.rho0[fl]),
+		halfGm1(p.sspowercoeff[fl]) {}
+	__device__ __forceinline__ float pressure(float rel) const { return B*(powf(rel + 1.0f, gamma) - 1.0f); }
+	__device__ __forceinline__ float density_of(float pres) const { return powf(pres/B + 1.0f, 1.0f/gamma) - 1.0f; }
+	__device__ __forceinline__ float celerity(float rel) const { return c0*powf(rel + 1.0f, halfGm1); }
+	__device__ __forceinline__ float psi(float rel) const { return 2.0f/(gamma - 1.0f)*c0*powf(rel + 1.0f, 0.5f*gamma - 0.5f); }
+	__device__ __forceinline__ float psi_inverse(float r) const
+	{ return (float)((double)powf((float)(((double)gamma - 1.)*(double)r/(2.*(double)c0)), (float)(2./((double)gamma - 1.))) - 1.0); }
+	__device__ __forceinline__ float absolute(float rel) const { return (rel + 1.0f)*rho0; }
+};
+
+// The state just inside the face (density `inside`, velocity u with normal part uIn) meets what the problem imposes outside.
+//   velocity-driven face: the normal velocity uOut is imposed, the density follows.  If the outside runs away from the interior
+//     (uOut <= uIn) an expansion fan connects the states and psi + u_n is conserved across it; otherwise a shock does, its strength
+//     from the jump conditions, unless the shock's characteristic is slower than the interior's (then nothing has arrived yet).
+//   pressure-driven face: the density `outside` is imposed, the normal velocity follows from the same two waves, tried in the
+//     order the density jump suggests and each kept only if its own characteristic says it is the wave that forms; the tangential
+//     velocity of the interior is kept on outflow and dropped on inflow.
+// (calculateIOboundaryCondition, _kernel.cu:111-200)
+__device__ __forceinline__ float4 open_face_state(const Tait &eos, bool velocityDriven, float4 imposed, float inside, float outside,
+	V3 u, float uIn, float uOut, V3 n)
 {
-	uint32_t count = 0;
-	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
-		if (!IS_IO_BOUNDARY(a.info[j])) return;
-		const uint4 nv = a.vertices[j];
-		if (!io_has_vertex(nv, my_id)) return;
-		if (my_id != nv.x && count < SA_IO_MAXNEIBVERTS) ids[count++] = nv.x;
-		if (my_id != nv.y && count < SA_IO_MAXNEIBVERTS) ids[count++] = nv.y;
-		if (my_id != nv.z && count < SA_IO_MAXNEIBVERTS) ids[count++] = nv.z;
-	});
-	return count;
+	const float psiIn = eos.psi(inside);
+	if (velocityDriven) {
+		float r;
+		if (uOut <= uIn)
+			r = psiIn + (uOut - uIn);
+		else {
+			const float behindShock = eos.density_of(eos.pressure(inside) + eos.absolute(inside)*uIn*(uIn - uOut));
+			r = eos.psi(behindShock);
+			if (uOut + eos.celerity(behindShock) <= uIn + eos.celerity(inside)) r = psiIn;
+		}
+		imposed.w = eos.psi_inverse(r);
+		return imposed;
+	}
+	const float cOut = eos.celerity(outside);
+	const float fastestIn = uIn + eos.celerity(inside);
+	const float fan = uIn + (eos.psi(outside) - psiIn);
+	float shock = (eos.pressure(inside) - eos.pressure(outside))/(eos.absolute(inside)*fmaxf(uIn, 1e-5f*eos.c0)) + uIn;
+	if (fabsf(shock) > eos.c0*0.1f) shock = uIn;
+	float un;
+	if (outside <= inside) {      // the fan first
+		un = fan;
+		if (un + cOut > fastestIn) { un = shock; if (un + cOut <= fastestIn) un = uIn; }
+	} else {                      // the shock first
+		un = shock;
+		if (un + cOut <= fastestIn) { un = fan; if (un + cOut > fastestIn) un = uIn; }
+	}
+	if (outside < 0.0f) un = fminf(un, 0.0f);
+	float4 s = make_float4(0.0f, 0.0f, 0.0f, outside);
+	if (un < 0.0f) {
+		const float along = u.x*n.x + u.y*n.y + u.z*n.z;
+		s.x = u.x - along*n.x; s.y = u.y - along*n.y; s.z = u.z - along*n.z;
+	}
+	s.x += n.x*un; s.y += n.y*un; s.z += n.z*un;
+	return s;
 }
 
-__global__ void __launch_bounds__(128)
-sa_init_io_mass_vertex_count_kernel(DevParams p, SaIoArgs a, float4 *forces)
+// ---- geometry: how a point's mass is shared among the three vertices of a segment ----------------------------------------------
+// q[k]: the point seen from vertex k.  The shares are the area coordinates of the point's projection onto the segment's plane:
+// share k = the (signed) area of the triangle the projection forms with the edge opposite vertex k, over the segment's area.
+// A projection outside the segment makes one or two of them negative; it is then moved to the nearest point of the outline: with
+// two negative the remaining vertex takes all, with one negative the projection slides along the line towards that vertex until
+// it meets the edge.  Areas in double where the reference's 0.5*dot() promotes them.  (getMassRepartitionFactor, :213-283)
+__device__ __forceinline__ float half_cross_along(V3 a, V3 b, V3 n) { return (float)(0.5*(double)dot(cross(a, b), n)); }
+__device__ __forceinline__ void vertex_shares(const V3 q[3], V3 n, float share[3])
 {
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
-	const particleinfo info = a.info[index];
-	if (!(PART_TYPE(info) == PT_VERTEX && IS_IO_BOUNDARY(info) && !IS_CORNER(info))) return;
-	const float4 pos = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-	uint32_t ids[SA_IO_MAXNEIBVERTS];
-	const uint32_t nids = io_adjacent_vertex_ids(p, a, index, pos, gridPos, info_id(info), ids);
-	uint32_t vertexCount = 0;
-	for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
-		const particleinfo ninfo = a.info[j];
-		const uint32_t nid = info_id(ninfo);
-		for (uint32_t k = 0; k < nids; ++k)
-			if (nid == ids[k] && !IS_CORNER(ninfo)) vertexCount += 1;
-	});
-	forces[index].w = (float)vertexCount;
+	// edge[k] is opposite vertex k and runs from vertex k+1 to vertex k+2; flat[k]: q[k] without its normal part
+	const V3 edge[3] = { q[2] - q[1], q[0] - q[2], -(q[0] - q[1]) };
+	V3 flat[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) flat[k] = q[k] - n*dot(q[k], n);
+	const float whole = half_cross_along(q[0] - q[1], q[0] - q[2], n);
+	float area[3];
+#pragma unroll
+	for (int k = 0; k < 3; ++k) area[k] = half_cross_along(flat[(k + 2)%3], edge[k], n);
+	const bool out0 = area[0] < 0.0f, out1 = area[1] < 0.0f, out2 = area[2] < 0.0f;
+	if ((int)out0 + (int)out1 + (int)out2 >= 2) {
+		const int keeper = out0 ? (out2 ? 1 : 2) : 0;
+#pragma unroll
+		for (int k = 0; k < 3; ++k) area[k] = (k == keeper) ? whole : 0.0f;
+	} else if (out0 | out1 | out2) {
+		const int k = out0 ? 0 : (out1 ? 1 : 2), k1 = (k + 1)%3, k2 = (k + 2)%3;
+		const float back = (float)((double)area[k]/(0.5*(double)dot(cross(flat[k], edge[k]), n)));
+		flat[k1] = flat[k1] - flat[k]*back;
+		flat[k] = flat[k]*(float)(1.0 - (double)back);
+		area[k] = 0.0f;
+		area[k1] = half_cross_along(flat[k], edge[k1], n);
+		area[k2] = half_cross_along(flat[k1], edge[k2], n);
+	}
+#pragma unroll
+	for (int k = 0; k < 3; ++k) share[k] = area[k]/whole;
 }
 
-__global__ void __launch_bounds__(128)
-sa_init_io_mass_kernel(DevParams p, SaIoArgs a, const float4 *forces, float4 *newPos, float deltap)
+// the vertices of segment j seen from its centre (scale: +1 towards them, -1 away), from BUFFER_VERTPOS
+struct SegmentCorners { const float2 *c0, *c1, *c2; };
+__device__ __forceinline__ void corners_of(const SegmentCorners &vp, uint32_t j, V3 n, float scale, V3 corner[3])
 {
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
-	const particleinfo info = a.info[index];
-	const float4 pos = a.pos[index];
-	newPos[index] = pos;
-	if (!(PART_TYPE(info) == PT_VERTEX && IS_IO_BOUNDARY(info) && !IS_CORNER(info))) return;
-	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-	const bool getMass = (info_id(info) % 2u) != 0u;      // odd ids take, even ids give
-	float massChange = 0.0f;
-	const float refMass = 0.5f*deltap*deltap*deltap*p.rho0[FLUID_NUM(info)];      // half a fluid particle
-	const float massDiff = refMass - pos.w;
-	const float vertexCount = forces[index].w;
-	uint32_t ids[SA_IO_MAXNEIBVERTS];
-	const uint32_t nids = io_adjacent_vertex_ids(p, a, index, pos, gridPos, info_id(info), ids);
-	for_each_neib<PT_VERTEX>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float, float, float) {
-		const particleinfo ninfo = a.info[j];
-		const uint32_t nid = info_id(ninfo);
-		for (uint32_t k = 0; k < nids; ++k) {
-			if (nid != ids[k]) continue;
-			const bool neibGetMass = (nid % 2u) != 0u;
-			if (getMass != neibGetMass && !IS_CORNER(ninfo)) {
-				if (getMass) {
-					if (massDiff > 0.0f) massChange += massDiff/vertexCount;
-				} else {
-					const float neibMassDiff = refMass - npos.w;
-					if (neibMassDiff > 0.0f) massChange -= neibMassDiff/forces[j].w;
+	V3 u, v;
+	wall_plane_basis(n, u, v);
+	const float2 c[3] = { vp.c0[j], vp.c1[j], vp.c2[j] };
+	const float inv = 1.0f/scale;
+#pragma unroll
+	for (int k = 0; k < 3; ++k) corner[k] = (-(u*c[k].x + v*c[k].y))*inv;
+}
+
+// ---- corner vertices: an open vertex that also belongs to a segment of something else ----------------------------------------------
+__global__ void __launch_bounds__(ROW_THREADS)
+open_corner_rows_kernel(DevParams p, RowLists a, const uint32_t *rows, const uint4 *triangles, const particleinfo *info, particleinfo *infoOut)
+{
+	FOR_MY_ROWS(rows, index) {
+		particleinfo mine = info[index];
+		const uint32_t face = OBJECT_NUM(mine), id = info_id(mine);
+		const float4 own = a.pos[index];
+		const int3 cell = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		unsigned long long foreign = 0ull;
+		int carry = 0; bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WaveEntry e = wave_entries<WAVE_SECTION_BOUNDARY>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+			bool hit = false;
+			if (e.live) {
+				const particleinfo f = info[e.j];
+				hit = !(OBJECT_NUM(f) == face && SA_IS_OPEN(f)) && tri_has(triangles[e.j], id);
+			}
+			foreign |= wave_ballot(hit);
+		}
+		if (foreign && lane == 0u) { mine.x |= SA_FG_CORNER; infoOut[index] = mine; }
+	}
+}
+
+// ---- the ring of an open vertex: the other vertices of the open segments it belongs to, in list order, each as often as it occurs ----
+// (one LDS row of OPEN_MAX_RING ids per wave; returns how many were kept)
+__device__ __forceinline__ uint32_t vertex_ring(const DevParams &p, const RowLists &a, const uint4 *triangles, const particleinfo *info,
+	uint32_t index, const float4 &own, const int3 &cell, uint32_t id, uint32_t lane, uint32_t *ring)
+{
+	uint32_t kept = 0;
+	int carry = 0; bool more = true;
+	for (int s0 = 0; more; s0 += 64) {
+		const WaveEntry e = wave_entries<WAVE_SECTION_BOUNDARY>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+		uint32_t other[3], n = 0;
+		if (e.live && SA_IS_OPEN(info[e.j])) {
+			const uint4 t = triangles[e.j];
+			if (tri_has(t, id)) {
+				if (t.x != id) other[n++] = t.x;
+				if (t.y != id) other[n++] = t.y;
+				if (t.z != id) other[n++] = t.z;
+			}
+		}
+		// exclusive prefix of n (0..3) over the lanes
+		const unsigned long long ge1 = wave_ballot(n >= 1u), ge2 = wave_ballot(n >= 2u), ge3 = wave_ballot(n >= 3u);
+		const uint32_t at = kept + wave_lanes_below(ge1, lane) + wave_lanes_below(ge2, lane) + wave_lanes_below(ge3, lane);
+		for (uint32_t k = 0; k < n; ++k)
+			if (at + k < OPEN_MAX_RING) ring[at + k] = other[k];
+		kept += (uint32_t)(__builtin_popcountll(ge1) + __builtin_popcountll(ge2) + __builtin_popcountll(ge3));
+	}
+	__builtin_amdgcn_wave_barrier();
+	return kept < OPEN_MAX_RING ? kept : OPEN_MAX_RING;
+}
+
+struct OpenMassArgs {
+	const uint4 *triangles;
+	const particleinfo *info;
+	float4 *forces;            // .w: the count (written by the first pass, read by the second)
+	float4 *newPos;
+	float deltap;
+};
+
+// first pass: how many non-corner ring vertices an open vertex has among its vertex neighbours (with multiplicity)
+// second pass: every open vertex is levelled towards half a fluid particle's mass; odd ids take what they lack from their even ring
+// neighbours in equal parts, even ids give what their odd ring neighbours lack (by those neighbours' counts)
+template<bool SECOND>
+__global__ void __launch_bounds__(ROW_THREADS)
+open_mass_rows_kernel(DevParams p, RowLists a, const uint32_t *rows, OpenMassArgs o)
+{
+	__shared__ uint32_t sRing[ROW_THREADS/64][OPEN_MAX_RING + 2];
+	uint32_t *ring = sRing[threadIdx.x >> 6];
+	FOR_MY_ROWS(rows, index) {
+		const particleinfo mine = o.info[index];
+		const uint32_t id = info_id(mine);
+		const float4 own = SECOND ? a.pos[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		const int3 cell = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		const uint32_t ringSize = vertex_ring(p, a, o.triangles, o.info, index, own, cell, id, lane, ring);
+		const bool taker = (id & 1u) != 0u;
+		const float target = 0.5f*o.deltap*o.deltap*o.deltap*p.rho0[FLUID_NUM(mine)];
+		const float lacking = target - own.w;
+		const float myCount = SECOND ? o.forces[index].w : 0.0f;
+		uint32_t total = 0;
+		float change = 0.0f;
+		int carry = 0; bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WaveEntry e = wave_entries<WAVE_SECTION_VERTEX>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+			uint32_t times = 0;
+			float part = 0.0f;
+			if (e.live) {
+				const particleinfo f = o.info[e.j];
+				const uint32_t nid = info_id(f);
+				for (uint32_t k = 0; k < ringSize; ++k) times += (ring[k] == nid) ? 1u : 0u;
+				if (SA_IS_CORNER(f)) times = 0;
+				if (SECOND) {
+					if (((nid & 1u) != 0u) == taker) times = 0;
+					if (taker) { part = lacking/myCount; if (!(lacking > 0.0f)) times = 0; }
+					else {
+						const float theirs = target - a.pos[e.j].w;
+						part = -(theirs/o.forces[e.j].w);
+						if (!(theirs > 0.0f)) times = 0;
+					}
+				}
+			}
+			if (!SECOND) total += times;
+			else {
+				unsigned long long any = wave_ballot(times != 0u);
+				while (any) {
+					const int l = __builtin_ctzll(any);
+					any &= any - 1ull;
+					const uint32_t c = wave_lane_u(times, l);
+					const float t = wave_lane_f(part, l);
+					for (uint32_t k = 0; k < c; ++k) change += t;
 				}
 			}
 		}
-	});
-	newPos[index].w = pos.w + massChange;
-}
-
-// ---- getMassRepartitionFactor (_kernel.cu:213-283) and calcVertexRelPos (src/cuda/gamma.cuh) for findOutgoingSegment ----
-struct IoV3 { float x, y, z; };
-__device__ __forceinline__ IoV3 iov(float x, float y, float z) { IoV3 r = { x, y, z }; return r; }
-__device__ __forceinline__ IoV3 io_sub(IoV3 a, IoV3 b) { return iov(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ IoV3 io_scale(IoV3 a, float s) { return iov(a.x*s, a.y*s, a.z*s); }
-__device__ __forceinline__ float io_dot(IoV3 a, IoV3 b) { return a.x*b.x + a.y*b.y + a.z*b.z; }
-__device__ __forceinline__ IoV3 io_cross(IoV3 a, IoV3 b) { return iov(a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x); }
-
-__device__ __forceinline__ void io_vertex_rel_pos(IoV3 q[3], IoV3 ns, float2 v0, float2 v1, float2 v2, float slength)
-{
-	unsigned j = 0;
-	if (fabsf(ns.x) > fabsf(ns.y)) j = 1;
-	if ((1 - j)*fabsf(ns.x) + j*fabsf(ns.y) > fabsf(ns.z)) j = 2;
-	IoV3 c1 = iov(-((j == 1)*ns.z) + (j == 2)*ns.y, (j == 0)*ns.z - ((j == 2)*ns.x), -((j == 0)*ns.y) + (j == 1)*ns.x);
-	c1 = io_scale(c1, 1.0f/sqrtf(io_dot(c1, c1)));
-	const IoV3 c2 = io_cross(ns, c1);
-	const float2 vp[3] = { v0, v1, v2 };
-	const float inv = 1.0f/slength;
-#pragma unroll
-	for (int k = 0; k < 3; ++k) {
-		const IoV3 s = iov(c1.x*vp[k].x + c2.x*vp[k].y, c1.y*vp[k].x + c2.y*vp[k].y, c1.z*vp[k].x + c2.z*vp[k].y);
-		q[k] = io_scale(iov(-s.x, -s.y, -s.z), inv);
+		__builtin_amdgcn_wave_barrier();      // the ring row is rewritten by the next row
+		if (!SECOND) { total = wave_sum_u(total); if (lane == 0u) o.forces[index].w = (float)total; }
+		else if (lane == 0u) o.newPos[index].w = own.w + change;
 	}
 }
 
-__device__ __forceinline__ void io_mass_repartition(const IoV3 q[3], IoV3 n, float beta[3])
-{
-	const IoV3 v01 = io_sub(q[0], q[1]), v02 = io_sub(q[0], q[2]);
-	IoV3 p0 = io_sub(q[0], io_scale(n, io_dot(q[0], n)));
-	IoV3 p1 = io_sub(q[1], io_scale(n, io_dot(q[1], n)));
-	IoV3 p2 = io_sub(q[2], io_scale(n, io_dot(q[2], n)));
-	const float refSurface = (float)(0.5*(double)io_dot(io_cross(v01, v02), n));
-	const IoV3 v21 = io_sub(q[2], q[1]);
-	float s0 = (float)(0.5*(double)io_dot(io_cross(p2, v21), n));
-	float s1 = (float)(0.5*(double)io_dot(io_cross(p0, v02), n));
-	float s2 = (float)(-0.5*(double)io_dot(io_cross(p1, v01), n));
-	if (s0 < 0.0f && s2 < 0.0f) { s0 = 0.0f; s1 = refSurface; s2 = 0.0f; }
-	else if (s0 < 0.0f && s1 < 0.0f) { s0 = 0.0f; s1 = 0.0f; s2 = refSurface; }
-	else if (s1 < 0.0f && s2 < 0.0f) { s0 = refSurface; s1 = 0.0f; s2 = 0.0f; }
-	else if (s0 < 0.0f) {
-		const float coef = (float)((double)s0/(0.5*(double)io_dot(io_cross(p0, v21), n)));
-		p1 = io_sub(p1, io_scale(p0, coef));
-		p0 = io_scale(p0, (float)(1.0 - (double)coef));
-		s0 = 0.0f;
-		s1 = (float)(0.5*(double)io_dot(io_cross(p0, v02), n));
-		s2 = (float)(-0.5*(double)io_dot(io_cross(p1, v01), n));
-	} else if (s1 < 0.0f) {
-		const float coef = (float)((double)s1/(0.5*(double)io_dot(io_cross(p1, v02), n)));
-		p2 = io_sub(p2, io_scale(p1, coef));
-		p1 = io_scale(p1, (float)(1.0 - (double)coef));
-		s0 = (float)(0.5*(double)io_dot(io_cross(p2, v21), n));
-		s1 = 0.0f;
-		s2 = (float)(-0.5*(double)io_dot(io_cross(p1, v01), n));
-	} else if (s2 < 0.0f) {
-		const float coef = (float)(-(double)s2/(0.5*(double)io_dot(io_cross(p2, v01), n)));
-		p0 = io_sub(p0, io_scale(p2, coef));
-		p2 = io_scale(p2, (float)(1.0 - (double)coef));
-		s0 = (float)(0.5*(double)io_dot(io_cross(p2, v21), n));
-		s1 = (float)(0.5*(double)io_dot(io_cross(p0, v02), n));
-		s2 = 0.0f;
-	}
-	beta[0] = s0/refSurface; beta[1] = s1/refSurface; beta[2] = s2/refSurface;
-}
-
-struct SaIoOutArgs {
+// ---- fluid particles about to leave: the nearest open segment they are behind and moving out of ------------------------------------
+struct LeavingArgs {
 	const float4 *vel, *boundElement;
-	const float2 *vertPos0, *vertPos1, *vertPos2;
-	uint4 *vertices;
-	float4 *gGam;
-	float influenceradius;
+	SegmentCorners corners;
+	const particleinfo *info;
+	uint4 *marks;              // BUFFER_VERTICES: a leaving particle's row takes the three vertex ids of its segment
+	float4 *shares;            // BUFFER_GRADGAMMA: ... and its row here the three shares and the particle's mass
+	float reach;
 };
 
-__global__ void __launch_bounds__(128)
-sa_find_outgoing_segment_kernel(DevParams p, SaIoArgs a, SaIoOutArgs o)
+__global__ void __launch_bounds__(ROW_THREADS)
+open_leaving_rows_kernel(DevParams p, RowLists a, const uint32_t *rows, LeavingArgs o)
 {
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
-	const particleinfo info = a.info[index];
-	if (PART_TYPE(info) != PT_FLUID) return;
-	const float4 pos = a.pos[index];
-	if (!is_active_w(pos.w)) return;
-	const uint4 mine = o.vertices[index];
-	if (mine.x | mine.y) return;           // already marked ("this shouldn't happen", :1679-1686)
-	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-	const float4 vel = o.vel[index];
-	float r2_min = o.influenceradius*o.influenceradius;
-	uint32_t index_min = 0xFFFFFFFFu;
-	IoV3 normal_min = iov(0.0f, 0.0f, 0.0f), relPos_min = normal_min;
-	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &, float rx, float ry, float rz) {
-		if (!IS_IO_BOUNDARY(a.info[j])) return;
-		const float4 nrm = o.boundElement[j];
-		const float4 nvel = o.vel[j];
-		const IoV3 relPos = iov(rx, ry, rz), normal = iov(nrm.x, nrm.y, nrm.z);
-		const IoV3 relVel = iov(vel.x - nvel.x, vel.y - nvel.y, vel.z - nvel.z);
-		const float r2 = io_dot(relPos, relPos);
-		// closer than the others, behind the element, moving out relative to it
-		if (r2 < r2_min && io_dot(normal, relPos) <= 0.0f && io_dot(normal, relVel) < 0.0f) {
-			r2_min = r2; index_min = j; normal_min = normal; relPos_min = relPos;
+	FOR_MY_ROWS(rows, index) {
+		const float4 own = a.pos[index];
+		const float4 u = o.vel[index];
+		const int3 cell = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		float best = o.reach*o.reach;
+		uint32_t bestSeg = 0xFFFFFFFFu;
+		V3 bestN = v3(0.0f, 0.0f, 0.0f), bestRel = bestN;
+		int carry = 0; bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WaveEntry e = wave_entries<WAVE_SECTION_BOUNDARY>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+			float d2 = __int_as_float(0x7f800000);
+			V3 n = v3(0.0f, 0.0f, 0.0f), rel = n;
+			if (e.live && SA_IS_OPEN(o.info[e.j])) {
+				const float4 np = a.pos[e.j], be = o.boundElement[e.j], nu = o.vel[e.j];
+				rel = v3(e.ox - np.x, e.oy - np.y, e.oz - np.z);
+				n = v3(be.x, be.y, be.z);
+				const V3 du = v3(u.x - nu.x, u.y - nu.y, u.z - nu.z);
+				// behind the element and moving out relative to it
+				if (dot(n, rel) <= 0.0f && dot(n, du) < 0.0f) d2 = dot(rel, rel);
+			}
+			const float least = wave_min_f(d2);
+			if (least < best) {      // strictly closer than anything before; among equals the earliest entry
+				const int l = __builtin_ctzll(wave_ballot(d2 == least));
+				best = least;
+				bestSeg = wave_lane_u(e.j, l);
+				bestN = v3(wave_lane_f(n.x, l), wave_lane_f(n.y, l), wave_lane_f(n.z, l));
+				bestRel = v3(wave_lane_f(rel.x, l), wave_lane_f(rel.y, l), wave_lane_f(rel.z, l));
+			}
 		}
-	});
-	if (index_min == 0xFFFFFFFFu) return;
-	IoV3 vx[3];
-	io_vertex_rel_pos(vx, normal_min, o.vertPos0[index_min], o.vertPos1[index_min], o.vertPos2[index_min], 1.0f);
-	for (int k = 0; k < 3; ++k) vx[k] = io_sub(relPos_min, vx[k]);
-	float beta[3];
-	io_mass_repartition(vx, normal_min, beta);
-	o.vertices[index] = o.vertices[index_min];
-	o.gGam[index] = make_float4(beta[0], beta[1], beta[2], pos.w);      // the shares and the mass travel where grad gamma was
+		if (bestSeg == 0xFFFFFFFFu) continue;
+		V3 corner[3], q[3];
+		corners_of(o.corners, bestSeg, bestN, 1.0f, corner);
+		for (int k = 0; k < 3; ++k) q[k] = bestRel - corner[k];
+		float share[3];
+		vertex_shares(q, bestN, share);
+		if (lane == 0u) {
+			o.marks[index] = o.marks[bestSeg];
+			o.shares[index] = make_float4(share[0], share[1], share[2], own.w);
+		}
+	}
 }
 
 __global__ void __launch_bounds__(256)
-sa_disable_outgoing_parts_kernel(float4 *pos, uint4 *vertices, const particleinfo *info, uint32_t numParticles)
+open_remove_marked_kernel(float4 *pos, uint4 *marks, const particleinfo *info, uint32_t numParticles)
 {
-	const uint32_t index = blockIdx.x*256 + threadIdx.x;
-	if (index >= numParticles) return;
-	if (PART_TYPE(info[index]) != PT_FLUID) return;
-	float4 ps = pos[index];
-	if (!is_active_w(ps.w)) return;
-	const uint4 v = vertices[index];
-	if ((v.x | v.y) != 0u) {
-		ps.w = __uint_as_float(0x7fc00000u);      // disable_particle
-		pos[index] = ps;
-		vertices[index] = make_uint4(0u, 0u, 0u, 0u);
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	if (i >= numParticles) return;
+	if (PART_TYPE(info[i]) != PT_FLUID) return;
+	float4 row = pos[i];
+	if (!is_active_w(row.w)) return;
+	const uint4 m = marks[i];
+	if ((m.x | m.y) == 0u) return;
+	row.w = __uint_as_float(0x7fc00000u);      // disable_particle: the mass becomes NaN
+	pos[i] = row;
+	marks[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+// ---- the boundary-condition passes on the open faces ---------------------------------------------------------------------------------
+struct OpenFaceArgs {
+	float4 *vel, *gGam, *eulerVel;          // in place
+	const float4 *boundElement;
+	const uint4 *triangles;
+	const particleinfo *info;
+	int step;
+	// vertex pass
+	float4 *newPos, *forces, *boundElementW;
+	uint4 *trianglesW;
+	particleinfo *infoW;
+	uint32_t *hashW, *nextIDs, *newNumParticles;
+	SegmentCorners corners;
+	uint32_t totParticles, numOpenVertices;
+	float deltap, dt;
+};
+
+// what a segment or a vertex takes from a fluid neighbour: its Shepard weight W V, its pressure, its velocity
+struct FluidSample { float weight, pressure; float4 vel; };
+__device__ __forceinline__ FluidSample sample_fluid(const DevParams &p, const float4 *vel, const particleinfo *info, uint32_t j, float dist, float mass)
+{
+	FluidSample s;
+	const uint32_t fl = FLUID_NUM(info[j]);
+	s.vel = vel[j];
+	s.weight = kernel_W<SPHX_WENDLAND>(p, dist)*mass/((s.vel.w + 1.0f)*p.rho0[fl]);
+	s.pressure = p.bcoeff[fl]*(powf(s.vel.w + 1.0f, p.gammacoeff[fl]) - 1.0f);
+	return s;
+}
+
+// Shepard means over the fluid in reach of an open element: { sum w (u + u_E), sum w max(P, 0), sum w } (io_fluid_contrib, :852-909)
+enum { SUM_UX, SUM_UY, SUM_UZ, SUM_P, SUM_W, SUM_RETURNED, FLUID_SUMS };
+
+// One open SEGMENT per wave.  Its Eulerian state is the Shepard mean of the fluid in front of it run through the characteristic
+// condition; gamma is re-derived from its three vertices when it has to be.  (impose_io_bc, :1362-1413)
+__global__ void __launch_bounds__(ROW_THREADS)
+open_segment_rows_kernel(DevParams p, RowLists a, const uint32_t *rows, OpenFaceArgs o)
+{
+	FOR_MY_ROWS(rows, index) {
+		const particleinfo mine = o.info[index];
+		const float4 own = a.pos[index], be = o.boundElement[index];
+		const uint4 tri = o.triangles[index];
+		const int3 cell = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		const V3 n = v3(be.x, be.y, be.z);
+		const bool bodies = (p.simflags & SPHX_ENABLE_MOVING_BODIES) != 0;
+		const bool velocityDriven = SA_IS_VELOCITY_DRIVEN(mine);
+		const bool carried = bodies && (mine.x & FG_MOVING_BOUNDARY);
+		float4 imposed = o.eulerVel[index];
+		if (velocityDriven) imposed.w = 0.0f;
+		float gammaStored = o.gGam[index].w;
+		const bool renewGamma = bodies || !is_active_w(gammaStored) || o.step == 0;
+		// the three vertices: mean gamma (and mean velocity of a segment that rides on a body)
+		float mean[7] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+		{
+			int carry = 0; bool more = true;
+			for (int s0 = 0; more; s0 += 64) {
+				const WaveEntry e = wave_entries<WAVE_SECTION_VERTEX>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+				bool corner = false;
+				float t[7] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+				if (e.live && is_active_w(a.pos[e.j].w) && tri_has(tri, info_id(o.info[e.j]))) {
+					corner = true;
+					const float4 g = o.gGam[e.j], v = o.vel[e.j];
+					t[0] = g.x; t[1] = g.y; t[2] = g.z; t[3] = g.w; t[4] = v.x; t[5] = v.y; t[6] = v.z;
+				}
+				ordered_sums(mean, t, wave_ballot(corner));
+			}
+		}
+		float gamma = gammaStored;
+		if (renewGamma) {
+			const float third = 1.0f/3;
+			const float4 g = make_float4(mean[0]*third, mean[1]*third, mean[2]*third, mean[3]*third);
+			if (lane == 0u) o.gGam[index] = g;
+			gamma = fmaxf(g.w, 1e-5f);
+		}
+		float4 result = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+		if (carried) { result.x = mean[4]/3; result.y = mean[5]/3; result.z = mean[6]/3; }
+		// the fluid in front of the segment
+		float sum[FLUID_SUMS] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+		{
+			int carry = 0; bool more = true;
+			for (int s0 = 0; more; s0 += 64) {
+				const WaveEntry e = wave_entries<WAVE_SECTION_FLUID>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+				bool seen = false;
+				float t[FLUID_SUMS] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+				if (e.live) {
+					const float4 np = a.pos[e.j];
+					const float rx = e.ox - np.x, ry = e.oy - np.y, rz = e.oz - np.z;
+					if (is_active_w(np.w)) {
+						const float dist = sqrtf(rx*rx + ry*ry + rz*rz);
+						const FluidSample f = sample_fluid(p, o.vel, o.info, e.j, dist, np.w);
+						if (dist < p.influenceradius && (n.x*rx + n.y*ry + n.z*rz) < 0.0f) {
+							seen = true;
+							const float4 ne = o.eulerVel[e.j];
+							t[SUM_UX] = f.weight*(f.vel.x + ne.x); t[SUM_UY] = f.weight*(f.vel.y + ne.y); t[SUM_UZ] = f.weight*(f.vel.z + ne.z);
+							t[SUM_P] = f.weight*fmaxf(0.0f, f.pressure);
+							t[SUM_W] = f.weight;
+						}
+					}
+				}
+				ordered_sums(sum, t, wave_ballot(seen));
+			}
+		}
+		const uint32_t fl = FLUID_NUM(mine);
+		const Tait eos(p, fl);
+		V3 u;
+		float inside;
+		if (sum[SUM_W] > 0.1f*gamma) {
+			u = v3(sum[SUM_UX]/sum[SUM_W], sum[SUM_UY]/sum[SUM_W], sum[SUM_UZ]/sum[SUM_W]);
+			inside = eos.density_of(sum[SUM_P]/sum[SUM_W]);
+		} else if (velocityDriven) {      // no fluid to speak of: the imposed velocity, at rest density
+			u = v3(imposed.x, imposed.y, imposed.z);
+			inside = 0.0f;
+		} else {                          // ... or the imposed density, at rest
+			u = v3(0.0f, 0.0f, 0.0f);
+			inside = imposed.w;
+		}
+		const float uIn = u.x*n.x + u.y*n.y + u.z*n.z;
+		const float uOut = imposed.x*n.x + imposed.y*n.y + imposed.z*n.z;
+		const float4 state = open_face_state(eos, velocityDriven, imposed, inside, imposed.w, u, uIn, uOut, n);
+		result.w = state.w;
+		if (lane == 0u) { o.eulerVel[index] = state; o.vel[index] = result; }
 	}
+}
+
+// One open non-corner VERTEX per wave: its Eulerian state as for a segment (without the half-space test), then its mass: it
+// gains what flows in through its share of the adjacent open segments, takes over the particles that left through them, and
+// releases a fluid particle when it has grown to half of one and the flow is inward.  (impose_vertex_io_bc :1168-1252,
+// io_boundary_contrib :937-988, generate_new_particles :1101-1159, createNewFluidParticle :73-104)
+__global__ void __launch_bounds__(ROW_THREADS)
+open_vertex_rows_kernel(DevParams p, RowLists a, const uint32_t *rows, OpenFaceArgs o)
+{
+	FOR_MY_ROWS(rows, index) {
+		const particleinfo mine = o.infoW[index];
+		const float4 own = a.pos[index], be = o.boundElementW[index];
+		const float gamma = o.gGam[index].w;
+		const uint32_t fl = FLUID_NUM(mine), id = info_id(mine);
+		const bool velocityDriven = SA_IS_VELOCITY_DRIVEN(mine);
+		const V3 n = v3(be.x, be.y, be.z);
+		const float fullMass = o.deltap*o.deltap*o.deltap*p.rho0[fl];
+		const int3 cell = grid_pos_from_hash(p, o.hashW[index] & CELLTYPE_BITMASK);
+		float sum[FLUID_SUMS] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+		{
+			int carry = 0; bool more = true;
+			for (int s0 = 0; more; s0 += 64) {
+				const WaveEntry e = wave_entries<WAVE_SECTION_FLUID>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+				bool seen = false;
+				float t[FLUID_SUMS] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+				if (e.live) {
+					const float4 np = a.pos[e.j];
+					const float rx = e.ox - np.x, ry = e.oy - np.y, rz = e.oz - np.z;
+					if (is_active_w(np.w)) {
+						const float dist = sqrtf(rx*rx + ry*ry + rz*rz);
+						const FluidSample f = sample_fluid(p, o.vel, o.infoW, e.j, dist, np.w);
+						if (dist < p.influenceradius) {
+							seen = true;
+							const float4 ne = o.eulerVel[e.j];
+							t[SUM_UX] = f.weight*(f.vel.x + ne.x); t[SUM_UY] = f.weight*(f.vel.y + ne.y); t[SUM_UZ] = f.weight*(f.vel.z + ne.z);
+							t[SUM_P] = f.weight*fmaxf(0.0f, f.pressure);
+							t[SUM_W] = f.weight;
+							if (o.step == 2) {      // a particle marked as leaving: its mass, by this vertex's share
+								const uint4 m = o.trianglesW[e.j];
+								if ((m.x | m.y) != 0u) {
+									const float4 s = o.gGam[e.j];
+									const float share = m.x == id ? s.x : m.y == id ? s.y : m.z == id ? s.z : 0.0f;
+									// adding +0 to a sum that is +0 or positive changes nothing: a lane without a share adds nothing
+									if (share > 0) t[SUM_RETURNED] = share*s.w;
+								}
+							}
+						}
+					}
+				}
+				ordered_sums(sum, t, wave_ballot(seen));
+			}
+		}
+		// the mass flux through the adjacent open segments, each by this vertex's share of a point at the segment's centre
+		float influx[1] = { 0.0f };
+		{
+			int carry = 0; bool more = true;
+			for (int s0 = 0; more; s0 += 64) {
+				const WaveEntry e = wave_entries<WAVE_SECTION_BOUNDARY>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+				bool mineToo = false;
+				float t[1] = { 0.0f };
+				if (e.live) {
+					const uint4 tri = o.trianglesW[e.j];
+					const particleinfo f = o.infoW[e.j];
+					if (tri_has(tri, id) && SA_IS_OPEN(f)) {
+						mineToo = true;
+						const float4 nb = o.boundElementW[e.j];
+						const V3 nn = v3(nb.x, nb.y, nb.z);
+						V3 q[3];
+						corners_of(o.corners, e.j, nn, -1.0f, q);
+						float share[3];
+						vertex_shares(q, nn, share);
+						const float w = tri.x == id ? share[0] : tri.y == id ? share[1] : tri.z == id ? share[2] : 0.0f;
+						const float4 ne = o.eulerVel[e.j];
+						t[0] = ((o.vel[e.j].w + 1.0f)*p.rho0[FLUID_NUM(f)])*nb.w*w*(ne.x*nn.x + ne.y*nn.y + ne.z*nn.z);
+					}
+				}
+				ordered_sums(influx, t, wave_ballot(mineToo));
+			}
+		}
+		const float massIn = influx[0];
+		const float shepard = fmaxf(sum[SUM_W], 0.1f*gamma);
+		const Tait eos(p, fl);
+		float4 state = o.eulerVel[index];
+		if (shepard > 0.1f*gamma) {
+			const V3 u = v3(sum[SUM_UX]/shepard, sum[SUM_UY]/shepard, sum[SUM_UZ]/shepard);
+			const float inside = eos.density_of(sum[SUM_P]/shepard);
+			const float uIn = u.x*n.x + u.y*n.y + u.z*n.z;
+			const float uOut = state.x*n.x + state.y*n.y + state.z*n.z;
+			state = open_face_state(eos, velocityDriven, state, inside, state.w, u, uIn, uOut, n);
+		} else if (velocityDriven)
+			state.w = 0.0f;
+		else
+			state.x = state.y = state.z = 0.0f;
+		float4 row = own;
+		const float un = n.x*state.x + n.y*state.y + n.z*state.z;
+		if (o.step != 0) {
+			row.w += o.dt*massIn;
+			if (shepard < 0.1f*gamma && massIn < 0.0f) row.w = 0.0f;
+			row.w = fmaxf(-2.0f*fullMass, fminf(2.0f*fullMass, row.w));
+			if (massIn < 0.0f || un < 1e-5f*p.sscoeff[fl]) {
+				const float bound = fullMass*be.w;      // be.w of a vertex is NaN: fminf / fmaxf hand back the other operand
+				row.w = fmaxf(-bound, fminf(bound, row.w));
+			}
+		}
+		float returned = sum[SUM_RETURNED];
+		const bool release = o.step == 2 && row.w > fullMass*0.5f && massIn > 0 && un > 1e-5f && (velocityDriven || state.w > 1e-5f);
+		if (lane == 0u) {
+			o.eulerVel[index] = state;
+			o.vel[index].w = state.w;
+			if (release) {
+				const uint32_t born = atomicAdd(o.newNumParticles, 1u);
+				if (born < o.totParticles) {
+					const uint32_t bornId = o.nextIDs[index];
+					o.nextIDs[index] = bornId + o.numOpenVertices;
+					particleinfo f;
+					f.x = PT_FLUID; f.y = (unsigned short)(fl << 12); f.z = (unsigned short)(bornId & 0xFFFFu); f.w = (unsigned short)(bornId >> 16);
+					float4 at = row;
+					at.w = fullMass;
+					returned -= at.w;
+					o.newPos[born] = at;
+					o.infoW[born] = f;
+					o.hashW[born] = o.hashW[index] & CELLTYPE_BITMASK;
+					o.vel[born] = state;
+					o.gGam[born] = o.gGam[index];
+					o.eulerVel[born] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					o.forces[born] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+					o.trianglesW[born] = make_uint4(0u, 0u, 0u, 0u);
+					o.nextIDs[born] = 0xFFFFFFFFu;
+					const float none = __uint_as_float(0xffc00000u);
+					o.boundElementW[born] = make_float4(none, none, none, none);
+				}
+			}
+			row.w += returned;
+			o.newPos[index] = row;
+		}
+	}
+}
+
+// ---- the water level at the pressure-driven faces: the highest fluid neighbour of their vertices, as a fixed-point height -------------
+__global__ void __launch_bounds__(ROW_THREADS)
+open_depth_rows_kernel(DevParams p, RowLists a, const uint32_t *rows, const particleinfo *info, uint32_t *level)
+{
+	FOR_MY_ROWS(rows, index) {
+		const float4 own = a.pos[index];
+		const int3 cell = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		uint32_t top = 0u;
+		int carry = 0; bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WaveEntry e = wave_entries<WAVE_SECTION_FLUID>(p, a.list, a.cellStart, index, own, cell, s0, lane, carry, more);
+			if (e.live) {
+				const float4 np = a.pos[e.j];
+				const float rx = e.ox - np.x, ry = e.oy - np.y, rz = e.oz - np.z;
+				const float dist = sqrtf(rx*rx + ry*ry + rz*rz);
+				if (is_active_w(np.w) && !(dist >= p.influenceradius) && !(rz < 0.0f)) {
+					float z = own.z - rz + cell.z*p.cs[2] + 0.5f*p.cs[2];
+					z *= ((float)UINT_MAX)/(p.gs[2]*p.cs[2]);
+					const uint32_t h = (uint32_t)z;
+					top = h > top ? h : top;
+				}
+			}
+		}
+		top = wave_max_u(top);
+		if (top && lane == 0u) atomicMax(level + OBJECT_NUM(info[index]), top);
+	}
+}
+
+// ---- FLUX_COMPUTATION: per open face the volume flux sum A_s (u_E . n_s) over its segments (the sums start from zero here; the
+// reference adds onto a freshly allocated array) ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+open_flux_kernel(const particleinfo *info, const float4 *eulerVel, const float4 *boundElement, float *flux, uint32_t faces, uint32_t numParticles)
+{
+	const uint32_t i = blockIdx.x*256 + threadIdx.x;
+	if (i >= numParticles) return;
+	const particleinfo f = info[i];
+	if (!(SA_IS_OPEN(f) && PART_TYPE(f) == PT_BOUNDARY)) return;
+	const uint32_t face = OBJECT_NUM(f);
+	if (face >= faces) return;
+	const float4 be = boundElement[i], e = eulerVel[i];
+	atomicAdd(flux + face, be.w*(e.x*be.x + e.y*be.y + e.z*be.z));
 }
 
 // ------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------
-static int sa_io_check(sphx_ctx *ctx, const char *who)
+static int open_check(sphx_ctx *ctx, const char *who)
 {
 	if (!ctx || !ctx->have_params) return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_io: constants not set");
 	if (ctx->params.boundarytype != SPHX_SA_BOUNDARY) return sphx_set_error(SPHX_ERR_INVALID, who);
 	return SPHX_OK;
 }
-
-extern "C" int sphx_sa_identify_corner_vertices(sphx_ctx *ctx, const void *pos, void *info, const uint32_t *hash, const void *vertices,
-	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+static int open_bc_check(sphx_ctx *ctx, const char *who)
 {
-	(void)numParticles;
-	int rc = sa_io_check(ctx, "saIdentifyCornerVertices called without SA_BOUNDARY");
-	if (rc != SPHX_OK) return rc;
-	SPHX_REQUIRE(pos && info && hash && vertices && cellStart && neibsList, "sphx_sa_identify_corner_vertices: missing buffer");
-	if (!particleRangeEnd) return SPHX_OK;
-	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
-	SPHX_LAUNCH(sa_identify_corner_vertices_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a, (particleinfo*)info);
-	SPHX_LAUNCH_CHECK("sa_identify_corner_vertices_kernel");
-	return SPHX_OK;
-}
-
-extern "C" int sphx_sa_init_io_mass_vertex_count(sphx_ctx *ctx, const void *vertices, const uint32_t *hash, const void *info,
-	const uint32_t *cellStart, const uint16_t *neibsList, void *forces, const void *pos,
-	uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
-{
-	(void)numParticles;
-	int rc = sa_io_check(ctx, "initIOmass_vertexCount called without SA_BOUNDARY");
-	if (rc != SPHX_OK) return rc;
-	SPHX_REQUIRE(vertices && hash && info && cellStart && neibsList && forces && pos, "sphx_sa_init_io_mass_vertex_count: missing buffer");
-	if (!particleRangeEnd) return SPHX_OK;
-	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
-	SPHX_LAUNCH(sa_init_io_mass_vertex_count_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a, (float4*)forces);
-	SPHX_LAUNCH_CHECK("sa_init_io_mass_vertex_count_kernel");
-	return SPHX_OK;
-}
-
-extern "C" int sphx_sa_init_io_mass(sphx_ctx *ctx, const void *oldPos, const void *forces, const void *vertices, const uint32_t *hash,
-	const void *info, const uint32_t *cellStart, const uint16_t *neibsList, void *newPos,
-	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, void *stream)
-{
-	(void)numParticles;
-	int rc = sa_io_check(ctx, "initIOmass called without SA_BOUNDARY");
-	if (rc != SPHX_OK) return rc;
-	SPHX_REQUIRE(oldPos && forces && vertices && hash && info && cellStart && neibsList && newPos && oldPos != newPos,
-		"sphx_sa_init_io_mass: missing buffer (newPos must not be oldPos)");
-	if (!particleRangeEnd) return SPHX_OK;
-	SaIoArgs a = { (const float4*)oldPos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
-	SPHX_LAUNCH(sa_init_io_mass_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a, (const float4*)forces,
-		(float4*)newPos, deltap);
-	SPHX_LAUNCH_CHECK("sa_init_io_mass_kernel");
-	return SPHX_OK;
-}
-
-extern "C" int sphx_sa_find_outgoing_segment(sphx_ctx *ctx, const void *pos, const void *vel, void *vertices, void *gGam,
-	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *boundElements, const void *info,
-	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
-	uint32_t numParticles, uint32_t particleRangeEnd, float influenceradius, void *stream)
-{
-	(void)numParticles;
-	int rc = sa_io_check(ctx, "findOutgoingSegment called without SA_BOUNDARY");
-	if (rc != SPHX_OK) return rc;
-	SPHX_REQUIRE(pos && vel && vertices && gGam && vertPos0 && vertPos1 && vertPos2 && boundElements && info && hash && cellStart && neibsList,
-		"sphx_sa_find_outgoing_segment: missing buffer");
-	if (!particleRangeEnd) return SPHX_OK;
-	SaIoArgs a = { (const float4*)pos, hash, cellStart, neibsList, (const uint4*)vertices, (const particleinfo*)info, particleRangeEnd };
-	SaIoOutArgs o = { (const float4*)vel, (const float4*)boundElements, (const float2*)vertPos0, (const float2*)vertPos1,
-		(const float2*)vertPos2, (uint4*)vertices, (float4*)gGam, influenceradius };
-	SPHX_LAUNCH(sa_find_outgoing_segment_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a, o);
-	SPHX_LAUNCH_CHECK("sa_find_outgoing_segment_kernel");
-	return SPHX_OK;
-}
-
-extern "C" int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *vertices, const void *info, uint32_t numParticles, void *stream)
-{
-	int rc = sa_io_check(ctx, "disableOutgoingParts called without SA_BOUNDARY");
-	if (rc != SPHX_OK) return rc;
-	SPHX_REQUIRE(pos && vertices && info, "sphx_sa_disable_outgoing_parts: missing buffer");
-	if (!numParticles) return SPHX_OK;
-	SPHX_LAUNCH(sa_disable_outgoing_parts_kernel, div_up_u(numParticles, 256), 256, (hipStream_t)stream, (float4*)pos, (uint4*)vertices,
-		(const particleinfo*)info, numParticles);
-	SPHX_LAUNCH_CHECK("sa_disable_outgoing_parts_kernel");
-	return SPHX_OK;
-}
-
-// ==========================================================================================
-// The boundary-condition passes with open boundaries (saSegmentBoundaryConditionsDevice / saVertexBoundaryConditionsDevice with
-// has_io, _kernel.cu:1427-1520, 2197-2252; laminar, not repacking, Wendland).  WRITTEN AT THE END OF ROUND 4 AND NOT YET RUN ON
-// A GPU: ports of the oracle's orc_sa_segment_bc_io / orc_sa_vertex_bc_io (which are held by known answers and by a whole
-// open-channel run on the CPU, tests/test_sa_io_oracle.py); their GPU parity test is in tests/test_gpu_sa_io.py behind
-// SPHX_TEST_SA_IO_BC=1 until it has passed once.  Nothing in the engines calls them yet.
-// ==========================================================================================
-__device__ __forceinline__ float io_eos_rho(const DevParams &p, float pres, uint32_t fl)      // RHO, phys_core.cu:106-112
-{ return powf(pres/p.bcoeff[fl] + 1.0f, 1.0f/p.gammacoeff[fl]) - 1.0f; }
-__device__ __forceinline__ float io_R(const DevParams &p, float rho_tilde, uint32_t fl)       // Riemann celerity, :114-120
-{ return 2.0f/(p.gammacoeff[fl] - 1.0f)*p.sscoeff[fl]*powf(rho_tilde + 1.0f, 0.5f*p.gammacoeff[fl] - 0.5f); }
-__device__ __forceinline__ float io_RHOR(const DevParams &p, float r, uint32_t fl)            // its inverse, :122-127 (double constants)
-{ return (float)((double)powf((float)(((double)p.gammacoeff[fl] - 1.)*(double)r/(2.*(double)p.sscoeff[fl])), (float)(2./((double)p.gammacoeff[fl] - 1.))) - 1.0); }
-
-// calculateIOboundaryCondition, _kernel.cu:111-200
-__device__ __forceinline__ void io_boundary_condition(const DevParams &p, float4 &eulerVel, bool velocity_driven, uint32_t a,
-	float rhoInt, float rhoExt, float ux, float uy, float uz, float unInt, float unExt, float nx, float ny, float nz)
-{
-	const float rInt = io_R(p, rhoInt, a);
-	if (velocity_driven) {
-		float riemannR = 0.0f;
-		if (unExt <= unInt)
-			riemannR = rInt + (unExt - unInt);
-		else {
-			const float riemannRho = io_eos_rho(p, sa_P(p, rhoInt, a) + ((rhoInt + 1.0f)*p.rho0[a])*unInt*(unInt - unExt), a);
-			riemannR = io_R(p, riemannRho, a);
-			const float lambda = unExt + sa_sound_speed(p, riemannRho, a);
-			const float lambdaInt = unInt + sa_sound_speed(p, rhoInt, a);
-			if (lambda <= lambdaInt) riemannR = rInt;
-		}
-		eulerVel.w = io_RHOR(p, riemannR, a);
-	} else {
-		float flux = 0.0f;
-		const float cExt = sa_sound_speed(p, rhoExt, a), cInt = sa_sound_speed(p, rhoInt, a);
-		const float lambdaInt = unInt + cInt;
-		const float rExt = io_R(p, rhoExt, a);
-		const float shock = (sa_P(p, rhoInt, a) - sa_P(p, rhoExt, a))/(((rhoInt + 1.0f)*p.rho0[a])*fmaxf(unInt, 1e-5f*p.sscoeff[a])) + unInt;
-		if (rhoExt <= rhoInt) {
-			flux = unInt + (rExt - rInt);
-			float lambda = flux + cExt;
-			if (lambda > lambdaInt) {
-				flux = shock;
-				if (fabsf(flux) > p.sscoeff[a]*0.1f) flux = unInt;
-				lambda = flux + cExt;
-				if (lambda <= lambdaInt) flux = unInt;
-			}
-		} else {
-			flux = shock;
-			if (fabsf(flux) > p.sscoeff[a]*0.1f) flux = unInt;
-			float lambda = flux + cExt;
-			if (lambda <= lambdaInt) {
-				flux = unInt + (rExt - rInt);
-				lambda = flux + cExt;
-				if (lambda > lambdaInt) flux = unInt;
-			}
-		}
-		eulerVel.x = eulerVel.y = eulerVel.z = 0.0f;
-		if (rhoExt < 0.0f) flux = fminf(flux, 0.0f);
-		if (flux < 0.0f) {
-			const float un = ux*nx + uy*ny + uz*nz;
-			eulerVel.x = ux - un*nx; eulerVel.y = uy - un*ny; eulerVel.z = uz - un*nz;
-		}
-		eulerVel.x += nx*flux; eulerVel.y += ny*flux; eulerVel.z += nz*flux;
-		eulerVel.w = rhoExt;
-	}
-}
-
-struct SaIoBcArgs {
-	float4 *vel, *gGam, *eulerVel;          // in place (boundary / vertex rows; the clones' rows in the last vertex pass)
-	const float4 *pos;                      // the walker's position rows
-	const float4 *boundElementRO;           // segment pass: read only
-	const uint4 *verticesRO;
-	const particleinfo *infoRO;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t numParticles;
-	int step;
-	// vertex pass
-	float4 *newPos, *forces, *boundElement;
-	uint4 *vertices;
-	particleinfo *info;
-	uint32_t *hashW, *nextIDs, *newNumParticles;
-	const float2 *vertPos0, *vertPos1, *vertPos2;
-	uint32_t totParticles, numOpenVertices;
-	float deltap, dt;
-	// what the walker reads
-	const uint32_t *hashRO;
-};
-
-struct IoNdata { float r, w, press; float4 vel; };
-__device__ __forceinline__ IoNdata io_fluid_ndata(const DevParams &p, const float4 *vel, const particleinfo *info, uint32_t j,
-	float rx, float ry, float rz, float mass)
-{
-	IoNdata n;
-	const uint32_t nfl = FLUID_NUM(info[j]);
-	n.vel = vel[j];
-	n.r = sqrtf(rx*rx + ry*ry + rz*rz);
-	n.w = kernel_W<SPHX_WENDLAND>(p, n.r)*mass/((n.vel.w + 1.0f)*p.rho0[nfl]);
-	n.press = p.bcoeff[nfl]*(powf(n.vel.w + 1.0f, p.gammacoeff[nfl]) - 1.0f);
-	return n;
-}
-
-struct IoWalk {       // what for_each_neib needs
-	const float4 *pos; const uint32_t *cellStart; const neibdata *neibsList;
-};
-
-__global__ void __launch_bounds__(128)
-sa_segment_bc_io_kernel(DevParams p, SaIoBcArgs a)
-{
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
-	const particleinfo info = a.infoRO[index];
-	if (!IS_BOUNDARY(info)) return;
-	const IoWalk wk = { a.pos, a.cellStart, a.neibsList };
-	const float4 pos = a.pos[index];
-	const float4 normal = a.boundElementRO[index];
-	const uint4 verts = a.verticesRO[index];
-	const int3 gridPos = grid_pos_from_hash(p, a.hashRO[index] & CELLTYPE_BITMASK);
-	const bool has_moving = (p.simflags & SPHX_ENABLE_MOVING_BODIES) != 0;
-	const bool io = IS_IO_BOUNDARY(info) != 0, vdriven = (info.x & FG_VELOCITY_DRIVEN) != 0;
-	float sumpWall = 0.0f, shepard_div = 0.0f, sump = 0.0f, svx = 0.0f, svy = 0.0f, svz = 0.0f;
-	float4 gGam = make_float4(0.0f, 0.0f, 0.0f, a.gGam[index].w);
-	float4 vel = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	const bool calcGam = has_moving || !is_active_w(gGam.w) || a.step == 0;
-	if (calcGam) gGam.w = 0.0f;
-	const bool moving = has_moving && (info.x & FG_MOVING_BOUNDARY);
-	float4 eulerVel = make_float4(0.0f, 0.0f, 0.0f, 0.0f);          // eulervel_pout, IO constructor (:488-505)
-	if (io) { eulerVel = a.eulerVel[index]; if (vdriven) eulerVel.w = 0.0f; }
-	for_each_neib<PT_VERTEX>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float, float, float) {
-		if (!is_active_w(npos.w)) return;
-		if (!io_has_vertex(verts, info_id(a.infoRO[j]))) return;
-		if (moving) { const float4 nv = a.vel[j]; vel.x += nv.x; vel.y += nv.y; vel.z += nv.z; }
-		if (calcGam) { const float4 g = a.gGam[j]; gGam.x += g.x; gGam.y += g.y; gGam.z += g.z; gGam.w += g.w; }
-	});
-	if (calcGam) {
-		const float inv = 1.0f/3;
-		gGam.x *= inv; gGam.y *= inv; gGam.z *= inv; gGam.w *= inv;
-		a.gGam[index] = gGam;
-		gGam.w = fmaxf(gGam.w, 1e-5f);
-	}
-	vel.x /= 3; vel.y /= 3; vel.z /= 3;
-	const uint32_t fl = FLUID_NUM(info);
-	for_each_neib<PT_FLUID>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
-		if (!is_active_w(npos.w)) return;
-		const IoNdata n = io_fluid_ndata(p, a.vel, a.infoRO, j, rx, ry, rz, npos.w);
-		if (!(n.r < p.influenceradius && (normal.x*rx + normal.y*ry + normal.z*rz) < 0.0f)) return;
-		const float gdot = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
-		sumpWall += fmaxf(n.press + ((n.vel.w + 1.0f)*p.rho0[fl])*gdot, 0.0f)*n.w;
-		if (io) {         // io_fluid_contrib, segments (:852-866)
-			const float4 ne = a.eulerVel[j];
-			svx += n.w*(n.vel.x + ne.x); svy += n.w*(n.vel.y + ne.y); svz += n.w*(n.vel.z + ne.z);
-			sump += n.w*fmaxf(0.0f, n.press);
-		}
-		shepard_div += n.w;
-	});
-	if (io) {             // impose_io_bc (:1362-1413)
-		if (shepard_div > 0.1f*gGam.w) {
-			svx /= shepard_div; svy /= shepard_div; svz /= shepard_div;
-			sump /= shepard_div;
-			vel.w = io_eos_rho(p, sump, fl);
-			if (!vdriven) a.eulerVel[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-		} else {
-			sump = 0.0f;
-			if (vdriven) { svx = eulerVel.x; svy = eulerVel.y; svz = eulerVel.z; vel.w = 0.0f; }
-			else { svx = svy = svz = 0.0f; vel.w = a.eulerVel[index].w; }
-		}
-		const float unInt = svx*normal.x + svy*normal.y + svz*normal.z;
-		const float unExt = eulerVel.x*normal.x + eulerVel.y*normal.y + eulerVel.z*normal.z;
-		float4 ev = eulerVel;
-		io_boundary_condition(p, ev, vdriven, fl, vel.w, eulerVel.w, svx, svy, svz, unInt, unExt, normal.x, normal.y, normal.z);
-		a.eulerVel[index] = ev;
-		vel.w = ev.w;
-	} else {              // impose_solid_bc<true>, impose_solid_eulerVel
-		shepard_div = fmaxf(shepard_div, 0.1f*gGam.w);
-		vel.w = io_eos_rho(p, sumpWall/shepard_div, fl);
-		a.eulerVel[index] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-	}
-	a.vel[index] = vel;
-}
-
-__global__ void __launch_bounds__(128)
-sa_vertex_bc_io_kernel(DevParams p, SaIoBcArgs a)
-{
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
-	const particleinfo info = a.info[index];
-	if (PART_TYPE(info) != PT_VERTEX) return;
-	const IoWalk wk = { a.pos, a.cellStart, a.neibsList };
-	const float4 pos = a.pos[index];
-	const float gam = a.gGam[index].w;
-	const uint32_t fl = FLUID_NUM(info), my_id = info_id(info);
-	const bool io = IS_IO_BOUNDARY(info) != 0, corner = IS_CORNER(info) != 0, vdriven = (info.x & FG_VELOCITY_DRIVEN) != 0;
-	const float4 normal = a.boundElement[index];
-	const float refMass = a.deltap*a.deltap*a.deltap*p.rho0[fl];
-	const int3 gridPos = grid_pos_from_hash(p, a.hashW[index] & CELLTYPE_BITMASK);
-	float sumpWall = 0.0f, shepard_div = 0.0f, sump = 0.0f, sumMdot = 0.0f, massFluid = 0.0f, svx = 0.0f, svy = 0.0f, svz = 0.0f;
-	for_each_neib<PT_FLUID>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
-		if (!is_active_w(npos.w)) return;
-		const IoNdata n = io_fluid_ndata(p, a.vel, a.info, j, rx, ry, rz, npos.w);
-		if (!(n.r < p.influenceradius)) return;
-		const float gdot = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
-		sumpWall += fmaxf(n.press + ((n.vel.w + 1.0f)*p.rho0[fl])*gdot, 0.0f)*n.w;
-		shepard_div += n.w;
-		if (!io) return;      // io_fluid_contrib, vertices (:868-909)
-		if (!corner) {
-			const float4 ne = a.eulerVel[j];
-			svx += n.w*(n.vel.x + ne.x); svy += n.w*(n.vel.y + ne.y); svz += n.w*(n.vel.z + ne.z);
-			sump += n.w*fmaxf(0.0f, n.press);
-		}
-		if (a.step == 2) {    // a particle marked by findOutgoingSegment: its mass, by this vertex's share
-			const uint4 nv = a.vertices[j];
-			if ((nv.x | nv.y) != 0u) {
-				const float4 w = a.gGam[j];
-				const float weight = nv.x == my_id ? w.x : nv.y == my_id ? w.y : nv.z == my_id ? w.z : 0.0f;
-				if (weight > 0) massFluid += weight*w.w;
-			}
-		}
-	});
-	if (io && !corner) {      // vertex_boundary_loop / io_boundary_contrib (:937-988): the mass flux through the adjacent open segments
-		for_each_neib<PT_BOUNDARY>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &, float, float, float) {
-			const uint4 nv = a.vertices[j];
-			if (!io_has_vertex(nv, my_id)) return;
-			const particleinfo ninfo = a.info[j];
-			if (!IS_IO_BOUNDARY(ninfo)) return;
-			const float4 nn = a.boundElement[j];
-			IoV3 vx[3];
-			io_vertex_rel_pos(vx, iov(nn.x, nn.y, nn.z), a.vertPos0[j], a.vertPos1[j], a.vertPos2[j], -1.0f);
-			float beta[3];
-			io_mass_repartition(vx, iov(nn.x, nn.y, nn.z), beta);
-			const float weight = nv.x == my_id ? beta[0] : nv.y == my_id ? beta[1] : nv.z == my_id ? beta[2] : 0.0f;
-			const float4 ne = a.eulerVel[j];
-			sumMdot += ((a.vel[j].w + 1.0f)*p.rho0[FLUID_NUM(ninfo)])*nn.w*weight*(ne.x*nn.x + ne.y*nn.y + ne.z*nn.z);
-		});
-	}
-	shepard_div = fmaxf(shepard_div, 0.1f*gam);
-	a.vel[index].w = io_eos_rho(p, sumpWall/shepard_div, fl);
-	if (!io || corner) return;
-	// impose_vertex_io_bc (:1168-1252)
-	float4 eulerVel = a.eulerVel[index];
-	if (shepard_div > 0.1f*gam) {
-		svx /= shepard_div; svy /= shepard_div; svz /= shepard_div;
-		sump /= shepard_div;
-		const float unInt = svx*normal.x + svy*normal.y + svz*normal.z;
-		const float unExt = eulerVel.x*normal.x + eulerVel.y*normal.y + eulerVel.z*normal.z;
-		const float rhoInt = io_eos_rho(p, sump, fl);
-		io_boundary_condition(p, eulerVel, vdriven, fl, rhoInt, eulerVel.w, svx, svy, svz, unInt, unExt, normal.x, normal.y, normal.z);
-	} else if (vdriven)
-		eulerVel.w = 0.0f;
-	else
-		eulerVel.x = eulerVel.y = eulerVel.z = 0.0f;
-	a.eulerVel[index] = eulerVel;
-	a.vel[index].w = eulerVel.w;
-	float4 np = pos;
-	const float un = normal.x*eulerVel.x + normal.y*eulerVel.y + normal.z*eulerVel.z;
-	if (a.step != 0) {
-		np.w += a.dt*sumMdot;
-		if (shepard_div < 0.1f*gam && sumMdot < 0.0f) np.w = 0.0f;
-		np.w = fmaxf(-2.0f*refMass, fminf(2.0f*refMass, np.w));
-		if (sumMdot < 0.0f || un < 1e-5f*p.sscoeff[fl]) {
-			const float weightedMass = refMass*normal.w;      // normal.w of a vertex is NaN: fminf / fmaxf return the other operand
-			np.w = fmaxf(-weightedMass, fminf(weightedMass, np.w));
-		}
-	}
-	// generate_new_particles (:1101-1159), createNewFluidParticle (:73-104)
-	if (a.step == 2 && np.w > refMass*0.5f && sumMdot > 0 && un > 1e-5f && (vdriven || eulerVel.w > 1e-5f)) {
-		const uint32_t clone = atomicAdd(a.newNumParticles, 1u);
-		if (clone < a.totParticles) {
-			const uint32_t new_id = a.nextIDs[index];
-			a.nextIDs[index] = new_id + a.numOpenVertices;
-			particleinfo ci;
-			ci.x = PT_FLUID; ci.y = (unsigned short)(fl << 12); ci.z = (unsigned short)(new_id & 0xFFFFu); ci.w = (unsigned short)(new_id >> 16);
-			float4 cp = np;
-			cp.w = refMass;
-			massFluid -= cp.w;
-			a.newPos[clone] = cp;
-			a.info[clone] = ci;
-			a.hashW[clone] = a.hashW[index] & CELLTYPE_BITMASK;
-			a.vel[clone] = eulerVel;
-			a.gGam[clone] = a.gGam[index];
-			a.eulerVel[clone] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-			a.forces[clone] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-			a.vertices[clone] = make_uint4(0u, 0u, 0u, 0u);
-			a.nextIDs[clone] = 0xFFFFFFFFu;
-			const float nanv = __uint_as_float(0xffc00000u);      // -NAN
-			a.boundElement[clone] = make_float4(nanv, nanv, nanv, nanv);
-		}
-	}
-	np.w += massFluid;
-	a.newPos[index] = np;
-}
-
-static int sa_io_bc_check(sphx_ctx *ctx, const char *who)
-{
-	int rc = sa_io_check(ctx, who);
+	int rc = open_check(ctx, who);
 	if (rc != SPHX_OK) return rc;
 	if (ctx->params.kerneltype != SPHX_WENDLAND)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_io: SA_BOUNDARY is built for the Wendland kernel");
@@ -648,22 +725,162 @@ static int sa_io_bc_check(sphx_ctx *ctx, const char *who)
 	return SPHX_OK;
 }
 
+// the index of a pass, in the context's scratch (one pass at a time per context, in stream order)
+template<int KIND>
+static int open_rows(sphx_ctx *ctx, RowSweep sw, hipStream_t st, uint32_t **rows)
+{
+	const uint32_t need = ctx->params.neiblist_stride + 1u;
+	if (ctx->open_rows_cap < need) {
+		if (ctx->open_rows) (void)hipFree(ctx->open_rows);
+		ctx->open_rows = nullptr; ctx->open_rows_cap = 0;
+		SPHX_HIP(hipMalloc((void**)&ctx->open_rows, sizeof(uint32_t)*(size_t)need));
+		ctx->open_rows_cap = need;
+	}
+	sw.rows = ctx->open_rows;
+	sw.stride = ctx->dev.stride; sw.neibboundpos = ctx->dev.neibboundpos;
+	SPHX_HIP(hipMemsetAsync(ctx->open_rows, 0, sizeof(uint32_t), st));
+	SPHX_LAUNCH_WAVES(open_rows_kernel<KIND>, div_up_u(sw.end - sw.first, 256), 256, st, sw);
+	SPHX_LAUNCH_CHECK("open_rows_kernel");
+	*rows = ctx->open_rows;
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_identify_corner_vertices(sphx_ctx *ctx, const void *pos, void *info, const uint32_t *hash, const void *vertices,
+	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+{
+	(void)numParticles;
+	int rc = open_check(ctx, "saIdentifyCornerVertices called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(pos && info && hash && vertices && cellStart && neibsList, "sphx_sa_identify_corner_vertices: missing buffer");
+	SPHX_REQUIRE(particleRangeEnd <= ctx->params.neiblist_stride, "sphx_sa_identify_corner_vertices: range exceeds the neighbour list stride");
+	if (!particleRangeEnd) return SPHX_OK;
+	hipStream_t st = (hipStream_t)stream;
+	RowSweep sw = {};
+	sw.info = (const particleinfo*)info; sw.end = particleRangeEnd;
+	uint32_t *rows;
+	rc = open_rows<ROWS_OPEN_VERTICES>(ctx, sw, st, &rows);
+	if (rc != SPHX_OK) return rc;
+	const RowLists l = { (const float4*)pos, hash, cellStart, neibsList };
+	// a row's flag is read by nobody in this launch: the test looks at segments, the flag sits on vertices
+	SPHX_LAUNCH_WAVES(open_corner_rows_kernel, ROW_GRID, ROW_THREADS, st, ctx->dev, l, rows, (const uint4*)vertices, (const particleinfo*)info, (particleinfo*)info);
+	SPHX_LAUNCH_CHECK("open_corner_rows_kernel");
+	return SPHX_OK;
+}
+
+static int open_mass_pass(sphx_ctx *ctx, bool second, const void *pos, const void *forces, const void *vertices, const uint32_t *hash,
+	const void *info, const uint32_t *cellStart, const uint16_t *neibsList, void *newPos, uint32_t particleRangeEnd, float deltap, hipStream_t st)
+{
+	SPHX_REQUIRE(particleRangeEnd <= ctx->params.neiblist_stride, "sphx_sa_init_io_mass: range exceeds the neighbour list stride");
+	RowSweep sw = {};
+	sw.info = (const particleinfo*)info; sw.end = particleRangeEnd;
+	uint32_t *rows;
+	int rc = open_rows<ROWS_OPEN_INNER_VERTICES>(ctx, sw, st, &rows);
+	if (rc != SPHX_OK) return rc;
+	const RowLists l = { (const float4*)pos, hash, cellStart, neibsList };
+	OpenMassArgs o = { (const uint4*)vertices, (const particleinfo*)info, (float4*)const_cast<void*>(forces), (float4*)newPos, deltap };
+	if (second) SPHX_LAUNCH_WAVES(open_mass_rows_kernel<true>, ROW_GRID, ROW_THREADS, st, ctx->dev, l, rows, o);
+	else SPHX_LAUNCH_WAVES(open_mass_rows_kernel<false>, ROW_GRID, ROW_THREADS, st, ctx->dev, l, rows, o);
+	SPHX_LAUNCH_CHECK("open_mass_rows_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_init_io_mass_vertex_count(sphx_ctx *ctx, const void *vertices, const uint32_t *hash, const void *info,
+	const uint32_t *cellStart, const uint16_t *neibsList, void *forces, const void *pos,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+{
+	(void)numParticles;
+	int rc = open_check(ctx, "initIOmass_vertexCount called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(vertices && hash && info && cellStart && neibsList && forces && pos, "sphx_sa_init_io_mass_vertex_count: missing buffer");
+	if (!particleRangeEnd) return SPHX_OK;
+	return open_mass_pass(ctx, false, pos, forces, vertices, hash, info, cellStart, neibsList, nullptr, particleRangeEnd, 0.0f, (hipStream_t)stream);
+}
+
+extern "C" int sphx_sa_init_io_mass(sphx_ctx *ctx, const void *oldPos, const void *forces, const void *vertices, const uint32_t *hash,
+	const void *info, const uint32_t *cellStart, const uint16_t *neibsList, void *newPos,
+	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, void *stream)
+{
+	(void)numParticles;
+	int rc = open_check(ctx, "initIOmass called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(oldPos && forces && vertices && hash && info && cellStart && neibsList && newPos && oldPos != newPos,
+		"sphx_sa_init_io_mass: missing buffer (newPos must not be oldPos)");
+	if (!particleRangeEnd) return SPHX_OK;
+	// every row is carried over; the open vertices then get their new masses
+	SPHX_HIP(hipMemcpyAsync(newPos, oldPos, sizeof(float4)*(size_t)particleRangeEnd, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+	return open_mass_pass(ctx, true, oldPos, forces, vertices, hash, info, cellStart, neibsList, newPos, particleRangeEnd, deltap, (hipStream_t)stream);
+}
+
+extern "C" int sphx_sa_find_outgoing_segment(sphx_ctx *ctx, const void *pos, const void *vel, void *vertices, void *gGam,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *boundElements, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float influenceradius, void *stream)
+{
+	(void)numParticles;
+	int rc = open_check(ctx, "findOutgoingSegment called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(pos && vel && vertices && gGam && vertPos0 && vertPos1 && vertPos2 && boundElements && info && hash && cellStart && neibsList,
+		"sphx_sa_find_outgoing_segment: missing buffer");
+	SPHX_REQUIRE(particleRangeEnd <= ctx->params.neiblist_stride, "sphx_sa_find_outgoing_segment: range exceeds the neighbour list stride");
+	if (!particleRangeEnd) return SPHX_OK;
+	hipStream_t st = (hipStream_t)stream;
+	RowSweep sw = {};
+	sw.info = (const particleinfo*)info; sw.pos = (const float4*)pos; sw.marks = (const uint4*)vertices; sw.list = neibsList; sw.end = particleRangeEnd;
+	uint32_t *rows;
+	rc = open_rows<ROWS_LEAVING_CANDIDATES>(ctx, sw, st, &rows);
+	if (rc != SPHX_OK) return rc;
+	const RowLists l = { (const float4*)pos, hash, cellStart, neibsList };
+	LeavingArgs o = { (const float4*)vel, (const float4*)boundElements, { (const float2*)vertPos0, (const float2*)vertPos1, (const float2*)vertPos2 },
+		(const particleinfo*)info, (uint4*)vertices, (float4*)gGam, influenceradius };
+	SPHX_LAUNCH_WAVES(open_leaving_rows_kernel, ROW_GRID, ROW_THREADS, st, ctx->dev, l, rows, o);
+	SPHX_LAUNCH_CHECK("open_leaving_rows_kernel");
+	return SPHX_OK;
+}
+
+extern "C" int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *vertices, const void *info, uint32_t numParticles, void *stream)
+{
+	int rc = open_check(ctx, "disableOutgoingParts called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(pos && vertices && info, "sphx_sa_disable_outgoing_parts: missing buffer");
+	if (!numParticles) return SPHX_OK;
+	SPHX_LAUNCH(open_remove_marked_kernel, div_up_u(numParticles, 256), 256, (hipStream_t)stream, (float4*)pos, (uint4*)vertices,
+		(const particleinfo*)info, numParticles);
+	SPHX_LAUNCH_CHECK("open_remove_marked_kernel");
+	return SPHX_OK;
+}
+
 extern "C" int sphx_sa_segment_bc_io(sphx_ctx *ctx, void *vel, void *gGam, void *eulerVel, const void *pos, const void *vertices,
 	const void *boundElements, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, int step, void *stream)
 {
 	(void)numParticles;
-	int rc = sa_io_bc_check(ctx, "saSegmentBoundaryConditions called without SA_BOUNDARY");
+	int rc = open_bc_check(ctx, "saSegmentBoundaryConditions called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	SPHX_REQUIRE(vel && gGam && eulerVel && pos && vertices && boundElements && info && hash && cellStart && neibsList,
 		"sphx_sa_segment_bc_io: missing buffer");
+	SPHX_REQUIRE(particleRangeEnd <= ctx->params.neiblist_stride, "sphx_sa_segment_bc_io: range exceeds the neighbour list stride");
 	if (!particleRangeEnd) return SPHX_OK;
-	SaIoBcArgs a = {};
-	a.vel = (float4*)vel; a.gGam = (float4*)gGam; a.eulerVel = (float4*)eulerVel; a.pos = (const float4*)pos;
-	a.boundElementRO = (const float4*)boundElements; a.verticesRO = (const uint4*)vertices; a.infoRO = (const particleinfo*)info;
-	a.hashRO = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd; a.step = step == -1 ? 0 : step;
-	SPHX_LAUNCH(sa_segment_bc_io_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a);
-	SPHX_LAUNCH_CHECK("sa_segment_bc_io_kernel");
+	hipStream_t st = (hipStream_t)stream;
+	const int s = step == -1 ? 0 : step;
+	// the walls: sa_bounds.hip's pass, which leaves the open segments alone and clears the walls' Eulerian velocity.  A segment
+	// reads vertex and fluid rows only, so the two launches do not see each other's writes
+	SaArgs w = {};
+	w.vel = (float4*)vel; w.gGam = (float4*)gGam; w.eulerVel = (float4*)eulerVel; w.pos = (const float4*)pos; w.vertices = (const uint4*)vertices;
+	w.boundElement = (float4*)const_cast<void*>(boundElements); w.info = (const particleinfo*)info; w.hash = hash; w.cellStart = cellStart;
+	w.neibsList = neibsList; w.numParticles = particleRangeEnd; w.step = s; w.openFaces = 1;
+	rc = sphx_sa_solid_rows_launch(ctx, w, false, st);
+	if (rc != SPHX_OK) return rc;
+	RowSweep sw = {};
+	sw.info = (const particleinfo*)info; sw.end = particleRangeEnd;
+	uint32_t *rows;
+	rc = open_rows<ROWS_OPEN_SEGMENTS>(ctx, sw, st, &rows);
+	if (rc != SPHX_OK) return rc;
+	const RowLists l = { (const float4*)pos, hash, cellStart, neibsList };
+	OpenFaceArgs o = {};
+	o.vel = (float4*)vel; o.gGam = (float4*)gGam; o.eulerVel = (float4*)eulerVel; o.boundElement = (const float4*)boundElements;
+	o.triangles = (const uint4*)vertices; o.info = (const particleinfo*)info; o.step = s;
+	SPHX_LAUNCH_WAVES(open_segment_rows_kernel, ROW_GRID, ROW_THREADS, st, ctx->dev, l, rows, o);
+	SPHX_LAUNCH_CHECK("open_segment_rows_kernel");
 	return SPHX_OK;
 }
 
@@ -674,487 +891,72 @@ extern "C" int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, v
 	uint32_t numOpenVertices, void *stream)
 {
 	(void)numParticles;
-	int rc = sa_io_bc_check(ctx, "saVertexBoundaryConditions called without SA_BOUNDARY");
+	int rc = open_bc_check(ctx, "saVertexBoundaryConditions called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	SPHX_REQUIRE(vel && pos && newPos && gGam && eulerVel && forces && vertices && boundElements && vertPos0 && vertPos1 &&
 		vertPos2 && info && hash && nextIDs && newNumParticles && cellStart && neibsList, "sphx_sa_vertex_bc_io: missing buffer");
+	SPHX_REQUIRE(particleRangeEnd <= ctx->params.neiblist_stride, "sphx_sa_vertex_bc_io: range exceeds the neighbour list stride");
 	if (!particleRangeEnd) return SPHX_OK;
-	// pos == newPos (the reference's call: the read and the write list hold the same array) is fine: a thread writes its own row,
-	// xyz unchanged, and reads the masses of fluid rows only, which the pass does not write
-	SaIoBcArgs a = {};
-	a.vel = (float4*)vel; a.gGam = (float4*)gGam; a.eulerVel = (float4*)eulerVel; a.pos = (const float4*)pos; a.newPos = (float4*)newPos;
-	a.forces = (float4*)forces; a.vertices = (uint4*)vertices; a.boundElement = (float4*)boundElements; a.info = (particleinfo*)info;
-	a.hashW = hash; a.nextIDs = nextIDs; a.newNumParticles = newNumParticles; a.cellStart = cellStart; a.neibsList = neibsList;
-	a.vertPos0 = (const float2*)vertPos0; a.vertPos1 = (const float2*)vertPos1; a.vertPos2 = (const float2*)vertPos2;
-	a.numParticles = particleRangeEnd; a.totParticles = totParticles; a.numOpenVertices = numOpenVertices;
-	a.deltap = deltap; a.dt = dt; a.step = step == -1 ? 0 : step;
-	SPHX_LAUNCH(sa_vertex_bc_io_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a);
-	SPHX_LAUNCH_CHECK("sa_vertex_bc_io_kernel");
-	return SPHX_OK;
-}
-
-// ==========================================================================================
-// Density summation and forces with open boundaries (density_sum_kernel.cu:119-140,206-250,374-420,606-655;
-// forces_kernel.def:1485-1497,2494-2507,2703-2708), one thread per particle over the list -- the list-walker kernels of
-// sa_bounds.hip (sa_density_sum_kernel, sa_forces_kernel without k-epsilon) with the open boundaries' terms, as the oracle's
-// orc_sa_density_sum_io / orc_forces_sa_io have them.  WRITTEN AT THE END OF ROUND 4, NOT YET RUN ON A GPU (see above); the
-// tiled fast paths do not know open boundaries, so these are the whole pass for such a run.
-// ==========================================================================================
-#include "sa_wall_gamma.h"
-#include "sa_args.h"
-
-struct SaIoDensitySumArgs {
-	float4 *newVel, *newGGam, *forces;
-	const float4 *oldPos, *pos, *oldVel, *oldEulerVel, *oldGGam, *boundElement;
-	const float2 *vertPos[3];
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t numParticles;
-	float dt;
-};
-
-__global__ void __launch_bounds__(128)
-sa_density_sum_io_kernel(DevParams p, SaIoDensitySumArgs a)
-{
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
-	const particleinfo info = a.info[index];
-	if (PART_TYPE(info) != PT_FLUID) {
-		if (PART_TYPE(info) == PT_VERTEX || PART_TYPE(info) == PT_BOUNDARY) a.newGGam[index] = a.oldGGam[index];
-		return;
-	}
-	const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
-	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-	const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
-	const IoWalk w = { a.oldPos, a.cellStart, a.neibsList };      // r_ab at step n: the walker reads the OLD positions
-	float sumPmwN = 0.0f, sumPmwNp1 = 0.0f, sumVmwDelta = 0.0f;
-	auto volumic = [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
-		if (!is_active_w(nN.w)) return;
-		const particleinfo ninfo = a.info[j];
-		const float4 nNp1 = a.pos[j];
-		const float rx = pcx - nN.x, ry = pcy - nN.y, rz = pcz - nN.z;
-		const float qx = (pcx - nNp1.x) + dx, qy = (pcy - nNp1.y) + dy, qz = (pcz - nNp1.z) + dz;
-		if (!IS_IO_BOUNDARY(ninfo)) {
-			const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
-			sumPmwN -= nN.w*kernel_W<SPHX_WENDLAND>(p, rN);
-		}
-		const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
-		if (rNp1 < p.influenceradius) sumPmwNp1 += nN.w*kernel_W<SPHX_WENDLAND>(p, rNp1);
-		if (IS_IO_BOUNDARY(ninfo)) {      // densitySumOpenBoundaryContribution: the neighbour displaced by its Eulerian velocity
-			const float4 e = a.oldEulerVel[j], v = a.oldVel[j];
-			const float ex = rx + a.dt*(e.x - v.x), ey = ry + a.dt*(e.y - v.y), ez = rz + a.dt*(e.z - v.z);
-			const float newDist = sqrtf(ex*ex + ey*ey + ez*ez);
-			if (newDist < p.influenceradius) sumVmwDelta -= nN.w*kernel_W<SPHX_WENDLAND>(p, newDist);
-		}
-	};
-	for_each_neib<PT_FLUID, true>(p, w, index, posN, gridPos, volumic);
-	for_each_neib<PT_VERTEX, true>(p, w, index, posN, gridPos, volumic);
-	const float fw = sumPmwNp1 + sumPmwN + sumVmwDelta;
-	a.forces[index].w = fw;
-	float gGamDotR = 0.0f, sumSgamDelta = 0.0f, sumSgamN = 0.0f;
-	V3 gGam = v3(0.0f, 0.0f, 0.0f);
-	for_each_neib<PT_BOUNDARY, true>(p, w, index, posN, gridPos, [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
-		if (!is_active_w(nN.w)) return;
-		const float4 nNp1 = a.pos[j];
-		const float inv = 1.0f/p.slength;
-		const V3 qN = v3((pcx - nN.x)*inv, (pcy - nN.y)*inv, (pcz - nN.z)*inv);
-		const V3 qNp1 = v3(((pcx - nNp1.x) + dx)*inv, ((pcy - nNp1.y) + dy)*inv, ((pcz - nNp1.z) + dz)*inv);
-		const float4 be = a.boundElement[j];
-		const V3 ns = v3(be.x, be.y, be.z);
-		WallTri tri;
-		wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-		const V3 gN = ns*(wall_grad_gamma(tri, qN)/p.slength);
-		const V3 gNp1 = ns*(wall_grad_gamma(tri, qNp1)/p.slength);
-		gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
-		gGam = gGam + gNp1;
-		if (IS_IO_BOUNDARY(a.info[j])) {      // io_gamma_contrib (:374-395)
-			const float4 e = a.oldEulerVel[j], v = a.oldVel[j];
-			const V3 deltaR = v3(a.dt*(e.x - v.x), a.dt*(e.y - v.y), a.dt*(e.z - v.z));
-			const V3 qDelta = qN + deltaR/p.slength;
-			const V3 gDelta = ns*(wall_grad_gamma(tri, qDelta)/p.slength);
-			sumSgamDelta += dot(deltaR, gDelta);
-			sumSgamN += dot(deltaR, gN);
-		}
-	});
-	gGamDotR *= p.slength;
-	const float4 gGamN = a.oldGGam[index];
-	float4 g = make_float4(gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR);
-	float imposedGam = gGamN.w + (sumSgamDelta + sumSgamN)/2.0f;      // compute_imposed_gamma (:404-417)
-	if (imposedGam > 1.0f) imposedGam = 1.0f;
-	else if (imposedGam < 0.1f) imposedGam = 0.1f;
-	const uint32_t fl = FLUID_NUM(info);
-	const float rho = (imposedGam*((a.oldVel[index].w + 1.0f)*p.rho0[fl]) + fw)/g.w;
-	if (g.w > 1.0f || sqrtf(g.x*g.x + g.y*g.y + g.z*g.z)*p.slength < 1e-10f) g.w = 1.0f;
-	else if (g.w < 0.1f) g.w = 0.1f;
-	a.newVel[index].w = rho/p.rho0[fl] - 1.0f;
-	a.newGGam[index] = g;
-}
-
-struct SaIoForcesArgs {
-	float4 *forces;
-	float *cfl, *cflGamma, *cflGammaBlocks;
-	const float4 *pos, *vel, *eulerVel, *gGam, *boundElement;
-	const float2 *vertPos[3];
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t fromParticle, toParticle, cflOffset;
-	float deltap;
-};
-
-__global__ void __launch_bounds__(SPHX_BLOCK_FORCES)
-sa_forces_io_kernel(DevParams p, SaIoForcesArgs a)
-{
-	__shared__ float sMax[SPHX_BLOCK_FORCES/64], sMaxG[SPHX_BLOCK_FORCES/64];
-	const uint32_t index = blockIdx.x*SPHX_BLOCK_FORCES + threadIdx.x + a.fromParticle;
-	float cflTerm = 0.0f, gammaCfl = 0.0f;
-	if (index < a.toParticle) {
-		const particleinfo info = a.info[index];
-		const float4 pos = a.pos[index];
-		if (is_active_w(pos.w)) {
-			float4 force = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-			const float4 vel = a.vel[index];
-			const uint32_t fl = FLUID_NUM(info);
-			if (PART_TYPE(info) == PT_FLUID) {
-				const IoWalk wk = { a.pos, a.cellStart, a.neibsList };
-				const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-				const float p_rho = (vel.w + 1.0f)*p.rho0[fl];
-				const float p_precalc = sa_P(p, vel.w, fl)/(p_rho*p_rho);
-				const float4 p_euler = a.eulerVel[index];
-				const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
-				const bool newtonian = p.rheology == SPHX_NEWTONIAN;
-				// fluid <- fluid (VERT false) and fluid <- vertex (VERT true: the viscous term sees relVel + relEulerVel, :2494-2507)
-				auto particle_pair = [&](bool VERT, uint32_t j, const float4 &npos, float rx, float ry, float rz) {
-					if (!is_active_w(npos.w)) return;
-					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
-					if (r >= p.influenceradius) return;
-					const float4 nvel = a.vel[j];
-					const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
-					const float vel_dot_pos = sa_dot3(vx, vy, vz, rx, ry, rz);
-					const float qm2 = r/p.slength - 2.0f;
-					const float f = qm2*qm2*qm2*p.fcoeff;
-					const uint32_t nfl = FLUID_NUM(a.info[j]);
-					const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
-					const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
-					const float nmass = npos.w;
-					if (!density_sum) force.w += nmass*vel_dot_pos*f;
-					const float s = (p_precalc + n_precalc)*nmass*f;
-					float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-					dx -= s*rx; dy -= s*ry; dz -= s*rz;
-					if (newtonian) {
-						float wx = vx, wy = vy, wz = vz;
-						if (VERT) { const float4 ne = a.eulerVel[j]; wx = vx + (p_euler.x - ne.x); wy = vy + (p_euler.y - ne.y); wz = vz + (p_euler.z - ne.z); }
-						const float vf = sa_visc_avg(p, p.visccoeff[fl], p.visccoeff[nfl], p_rho, n_rho, nmass)*f;
-						dx += vf*wx; dy += vf*wy; dz += vf*wz;
-					}
-					force.x += dx; force.y += dy; force.z += dz;
-				};
-				for_each_neib<PT_FLUID>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &np_, float rx, float ry, float rz) { particle_pair(false, j, np_, rx, ry, rz); });
-				for_each_neib<PT_VERTEX>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &np_, float rx, float ry, float rz) { particle_pair(true, j, np_, rx, ry, rz); });
-				for_each_neib<PT_BOUNDARY>(p, wk, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
-					if (!is_active_w(npos.w)) return;
-					const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
-					if (r >= p.influenceradius + a.deltap) return;
-					const particleinfo ninfo = a.info[j];
-					const float4 nvel = a.vel[j];
-					const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
-					const float4 ne = a.eulerVel[j];
-					const float wx = vx + (p_euler.x - ne.x), wy = vy + (p_euler.y - ne.y), wz = vz + (p_euler.z - ne.z);
-					const uint32_t nfl = FLUID_NUM(ninfo);
-					const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
-					const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
-					const float4 be = a.boundElement[j];
-					const V3 ns = v3(be.x, be.y, be.z);
-					const float inv_h = 1.0f/p.slength;
-					WallTri tri;
-					wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-					const float ggamAS = wall_grad_gamma(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
-					const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
-					if (a.cflGamma) {
-						const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
-						const float vs = sa_dot3(vel.x - vx, vel.y - vy, vel.z - vz, be.x, be.y, be.z);
-						gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
-						// compute_gamma_cfl_open_boundary (:1485-1497): n.(v_a + relEulerVel), n.(v_s - relEulerVel)
-						const float ex = wx - vx, ey = wy - vy, ez = wz - vz;
-						const float a1 = sa_dot3(vel.x + ex, vel.y + ey, vel.z + ez, be.x, be.y, be.z);
-						const float a2 = sa_dot3(-vx + vel.x - ex, -vy + vel.y - ey, -vz + vel.z - ez, be.x, be.y, be.z);
-						gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(a1), fabsf(a2)));
-					}
-					if (!density_sum) { float DrDt = 0.0f; DrDt -= p_rho*vn*ggamAS; force.w += DrDt; }
-					const float ps = (p_precalc + n_precalc)*n_rho*ggamAS;
-					float dx = 0.0f, dy = 0.0f, dz = 0.0f;
-					dx += ps*be.x; dy += ps*be.y; dz += ps*be.z;
-					if (newtonian) {      // compute_laminar_visc_contrib, boundary term (:2680-2718) with open boundaries
-						const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
-						const float wn = IS_IO_BOUNDARY(ninfo) ? 0.0f : sa_dot3(wx, wy, wz, be.x, be.y, be.z);
-						const float tx = wx - wn*be.x, ty = wy - wn*be.y, tz = wz - wn*be.z;
-						const float our_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl]*p_rho : p.visccoeff[fl];
-						const float neib_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl]*n_rho : p.visccoeff[nfl];
-						const float avg = (p.avgop == SPHX_ARITHMETIC) ? (our_mu + neib_mu)*0.5f :
-							(p.avgop == SPHX_HARMONIC) ? 2*our_mu*neib_mu/(our_mu + neib_mu) : sqrtf(our_mu*neib_mu);
-						const float c = ggamAS*2*avg/r_as;
-						const float inv_rho = 1.0f/p_rho;
-						dx -= (c*tx)*inv_rho; dy -= (c*ty)*inv_rho; dz -= (c*tz)*inv_rho;
-					}
-					force.x += dx; force.y += dy; force.z += dz;
-				});
-				const float gam = a.gGam[index].w;
-				force.x /= gam; force.y /= gam; force.z /= gam; force.w /= gam;
-				force.w /= p.rho0[fl];
-				force.x += p.gravity[0]; force.y += p.gravity[1]; force.z += p.gravity[2];
-				if (p.simflags & SPHX_ENABLE_DTADAPT) {
-					const float sspeed = sa_sound_speed(p, vel.w, fl);
-					const float acc = sqrtf(fmaf(force.z, force.z, fmaf(force.y, force.y, force.x*force.x)));
-					cflTerm = fmaxf(acc, sspeed*sspeed/p.slength);
-				}
-			}
-			a.forces[index] = force;
-		}
-		if (a.cflGamma) a.cflGamma[index] = gammaCfl;
-	}
-#pragma unroll
-	for (int d = 32; d > 0; d >>= 1) {
-		cflTerm = fmaxf(cflTerm, __shfl_down(cflTerm, d));
-		gammaCfl = fmaxf(gammaCfl, __shfl_down(gammaCfl, d));
-	}
-	if ((threadIdx.x & 63u) == 0u) { sMax[threadIdx.x >> 6] = cflTerm; sMaxG[threadIdx.x >> 6] = gammaCfl; }
-	__syncthreads();
-	if (threadIdx.x == 0 && a.cfl && (p.simflags & SPHX_ENABLE_DTADAPT)) {
-		float m = sMax[0], mg = sMaxG[0];
-		for (int w = 1; w < SPHX_BLOCK_FORCES/64; ++w) { m = fmaxf(m, sMax[w]); mg = fmaxf(mg, sMaxG[w]); }
-		a.cfl[a.cflOffset + blockIdx.x] = m;
-		if (a.cflGammaBlocks) a.cflGammaBlocks[a.cflOffset + blockIdx.x] = mg;
-	}
-}
-
-extern "C" int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces, const void *oldPos, const void *newPos,
-	const void *oldVel, const void *oldEulerVel, const void *oldGGam, const void *boundElements,
-	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
-	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
-	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream)
-{
-	(void)numParticles;
-	int rc = sa_io_bc_check(ctx, "density_sum called without SA_BOUNDARY");
+	hipStream_t st = (hipStream_t)stream;
+	const int s = step == -1 ? 0 : step;
+	// the walls' vertices (and the corners of the open faces) first, with sa_bounds.hip's pass.  A vertex reads fluid and segment
+	// rows and writes its own (pos == newPos, the reference's call, is fine: xyz unchanged, the masses read are fluid rows'); the
+	// rows of released particles lie behind particleRangeEnd
+	SaArgs w = {};
+	w.vel = (float4*)vel; w.gGam = (float4*)gGam; w.pos = (const float4*)pos; w.info = (const particleinfo*)info; w.hash = hash;
+	w.cellStart = cellStart; w.neibsList = neibsList; w.numParticles = particleRangeEnd; w.step = s; w.openFaces = 1;
+	rc = sphx_sa_solid_rows_launch(ctx, w, true, st);
 	if (rc != SPHX_OK) return rc;
-	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldEulerVel && oldGGam && boundElements && vertPos0 && vertPos1 &&
-		vertPos2 && info && hash && cellStart && neibsList, "sphx_sa_density_sum_io: missing buffer");
-	if (!particleRangeEnd) return SPHX_OK;
-	SaIoDensitySumArgs a = { (float4*)newVel, (float4*)newGGam, (float4*)forces, (const float4*)oldPos, (const float4*)newPos,
-		(const float4*)oldVel, (const float4*)oldEulerVel, (const float4*)oldGGam, (const float4*)boundElements,
-		{ (const float2*)vertPos0, (const float2*)vertPos1, (const float2*)vertPos2 }, (const particleinfo*)info, hash, cellStart,
-		neibsList, particleRangeEnd, dt };
-	SPHX_LAUNCH(sa_density_sum_io_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a);
-	SPHX_LAUNCH_CHECK("sa_density_sum_io_kernel");
-	return SPHX_OK;
-}
-
-extern "C" int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, const void *pos, const void *vel,
-	const void *eulerVel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
-	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
-	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, float deltap, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream)
-{
-	int rc = sa_io_bc_check(ctx, "forces called without SA_BOUNDARY");
+	RowSweep sw = {};
+	sw.info = (const particleinfo*)info; sw.end = particleRangeEnd;
+	uint32_t *rows;
+	rc = open_rows<ROWS_OPEN_INNER_VERTICES>(ctx, sw, st, &rows);
 	if (rc != SPHX_OK) return rc;
-	SPHX_REQUIRE(forces && pos && vel && eulerVel && info && hash && cellStart && neibsList && gGam && boundElements && vertPos0 && vertPos1 && vertPos2,
-		"sphx_forces_basicstep_sa_io: missing buffer");
-	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_forces_basicstep_sa_io: invalid particle range");
-	const uint32_t numBlocks = round_up_u(div_up_u(toParticle - fromParticle, SPHX_BLOCK_FORCES), 4u);
-	if (h_numBlocks) *h_numBlocks = numBlocks;
-	if (!numBlocks) return SPHX_OK;
-	const bool dtadapt = (ctx->dev.simflags & SPHX_ENABLE_DTADAPT) != 0;
-	if (dtadapt) SPHX_REQUIRE(cfl != nullptr, "sphx_forces_basicstep_sa_io: ENABLE_DTADAPT needs the CFL buffer");
-	const bool gcfl = cflGamma && dtadapt && !(ctx->dev.simflags & SPHX_ENABLE_GAMMA_QUADRATURE);
-	SaIoForcesArgs a = {};
-	a.forces = (float4*)forces; a.cfl = dtadapt ? cfl : nullptr;
-	a.cflGamma = gcfl ? cflGamma : nullptr; a.cflGammaBlocks = gcfl ? cflGamma + round_up_u(numParticles, 4u) : nullptr;
-	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.eulerVel = (const float4*)eulerVel; a.gGam = (const float4*)gGam;
-	a.boundElement = (const float4*)boundElements;
-	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
-	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
-	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
-	SPHX_LAUNCH(sa_forces_io_kernel, numBlocks, SPHX_BLOCK_FORCES, (hipStream_t)stream, ctx->dev, a);
-	SPHX_LAUNCH_CHECK("sa_forces_io_kernel");
-	return SPHX_OK;
-}
-
-// ==========================================================================================
-// The Brezzi diffusion with open boundaries and the water depth at the pressure-driven ones: computeDensityDiffusionDevice
-// with ENABLE_INLET_OUTLET (forces_kernel.def:4536-4582; the boundary term :1836-1852) and what forcesDevice<PT_VERTEX, PT_FLUID>
-// leaves behind with ENABLE_WATER_DEPTH (:192-205, 1375-1389, 3285-3303).  One thread per particle over the list; the checkers
-// are orc_sa_density_diffusion_io / orc_sa_io_water_depth.  WRITTEN AT THE END OF ROUND 4, NOT YET RUN ON A GPU (see above).
-// ==========================================================================================
-struct SaIoDiffusionArgs {
-	float4 *forces;
-	const float4 *pos, *vel, *gGam, *boundElement;
-	const float2 *vertPos[3];
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t numParticles;
-	float dt, deltap;
-};
-
-__global__ void __launch_bounds__(128)
-sa_density_diffusion_io_kernel(DevParams p, SaIoDiffusionArgs a)
-{
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
-	if (index >= a.numParticles) return;
-	const particleinfo info = a.info[index];
-	if (PART_TYPE(info) != PT_FLUID) return;
-	const float4 pos = a.pos[index];
-	if (!is_active_w(pos.w)) return;
-	const float4 vel = a.vel[index];
-	const uint32_t fl = FLUID_NUM(info);
-	const float rho = (vel.w + 1.0f)*p.rho0[fl];
-	const float pres = sa_P(p, vel.w, fl);
-	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-	float DrDt = 0.0f;
-	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
-		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
-		if (!is_active_w(npos.w)) return;
-		if (r >= p.influenceradius) return;
-		const float4 nvel = a.vel[j];
-		const uint32_t nfl = FLUID_NUM(a.info[j]);
-		const float neib_rho = (nvel.w + 1.0f)*p.rho0[nfl];
-		const float qm2 = r/p.slength - 2.0f;
-		const float f = qm2*qm2*qm2*p.fcoeff;
-		const float gdotr = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
-		float n = 0.0f;
-		n += p.densityDiffCoeff*((2.0f/(rho + neib_rho))*(pres - sa_P(p, nvel.w, nfl)) - gdotr)*npos.w/neib_rho*f*a.dt*2.0f*rho;
-		DrDt += n;
-	});
-	// the segments of PRESSURE-driven open boundaries: V_b grad W -> |grad gamma_as| / r_as, no diffusion coefficient, in double
-	// as the reference's literals make it (:1848)
-	for_each_neib<PT_BOUNDARY>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
-		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
-		if (!is_active_w(npos.w)) return;
-		if (r >= p.influenceradius + a.deltap) return;
-		const particleinfo ninfo = a.info[j];
-		if (!(IS_IO_BOUNDARY(ninfo) && !IS_VEL_IO(ninfo))) return;      // nout.DrDt stays 0: DrDt += 0 changes nothing
-		const float4 be = a.boundElement[j];
-		const V3 ns = v3(be.x, be.y, be.z);
-		const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
-		const float inv_h = 1.0f/p.slength;
-		WallTri tri;
-		wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-		const float ggamAS = wall_grad_gamma(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
-		const float nrt = a.vel[j].w;
-		const uint32_t nfl = FLUID_NUM(ninfo);
-		const float neib_rho = (nrt + 1.0f)*p.rho0[nfl];
-		const float gdotr = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
-		const double t = ((2.0/(rho + neib_rho))*(pres - sa_P(p, nrt, nfl)) - gdotr)*ggamAS/r_as*a.dt*2.0f*rho;
-		float n = 0.0f;
-		n = (float)(n - t);
-		DrDt += n;
-	});
-	DrDt /= a.gGam[index].w;
-	a.forces[index].w = DrDt/p.rho0[fl];
-}
-
-struct SaIoDepthArgs {
-	uint32_t *IOwaterdepth;
-	const float4 *pos;
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t fromParticle, toParticle;
-};
-
-__global__ void __launch_bounds__(128)
-sa_io_water_depth_kernel(DevParams p, SaIoDepthArgs a)
-{
-	const uint32_t index = blockIdx.x*128 + threadIdx.x + a.fromParticle;
-	if (index >= a.toParticle) return;
-	const particleinfo info = a.info[index];
-	if (PART_TYPE(info) != PT_VERTEX) return;
-	const float4 pos = a.pos[index];
-	if (!is_active_w(pos.w)) return;
-	if (!(IS_IO_BOUNDARY(info) && !IS_VEL_IO(info))) return;      // skip_neiblist (:1375-1389)
-	const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
-	uint32_t best = 0u;
-	for_each_neib<PT_FLUID>(p, a, index, pos, gridPos, [&](uint32_t j, const float4 &npos, float rx, float ry, float rz) {
-		(void)j;
-		const float r = sqrtf(rx*rx + ry*ry + rz*rz);
-		if (!is_active_w(npos.w)) return;
-		if (r >= p.influenceradius) return;
-		if (rz < 0.0f) return;
-		float nZpos = pos.z - rz + gridPos.z*p.cs[2] + 0.5f*p.cs[2];
-		nZpos *= ((float)UINT_MAX)/(p.gs[2]*p.cs[2]);
-		const uint32_t u = (uint32_t)nZpos;
-		best = u > best ? u : best;
-	});
-	if (best) atomicMax(a.IOwaterdepth + OBJECT_NUM(info), best);      // a maximum: one atomic per vertex gives the same number
-}
-
-extern "C" int sphx_sa_compute_density_diffusion_io(sphx_ctx *ctx, void *forces, const void *pos, const void *vel, const void *gGam,
-	const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
-	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
-	uint32_t numParticles, uint32_t particleRangeEnd, float deltap, float dt, void *stream)
-{
-	(void)numParticles;
-	int rc = sa_io_bc_check(ctx, "compute_density_diffusion called without SA_BOUNDARY");
-	if (rc != SPHX_OK) return rc;
-	if (ctx->params.densitydiffusiontype != SPHX_BREZZI || !(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) ||
-		ctx->params.sph_formulation == SPHX_SPH_HA)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_compute_density_diffusion_io: built for Brezzi diffusion with density summation");
-	SPHX_REQUIRE(forces && pos && vel && gGam && boundElements && vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList,
-		"sphx_sa_compute_density_diffusion_io: missing buffer");
-	if (!particleRangeEnd) return SPHX_OK;
-	SaIoDiffusionArgs a = { (float4*)forces, (const float4*)pos, (const float4*)vel, (const float4*)gGam, (const float4*)boundElements,
-		{ (const float2*)vertPos0, (const float2*)vertPos1, (const float2*)vertPos2 }, (const particleinfo*)info, hash, cellStart,
-		neibsList, particleRangeEnd, dt, deltap };
-	SPHX_LAUNCH(sa_density_diffusion_io_kernel, div_up_u(particleRangeEnd, 128), 128, (hipStream_t)stream, ctx->dev, a);
-	SPHX_LAUNCH_CHECK("sa_density_diffusion_io_kernel");
+	const RowLists l = { (const float4*)pos, hash, cellStart, neibsList };
+	OpenFaceArgs o = {};
+	o.vel = (float4*)vel; o.gGam = (float4*)gGam; o.eulerVel = (float4*)eulerVel; o.step = s;
+	o.newPos = (float4*)newPos; o.forces = (float4*)forces; o.boundElementW = (float4*)boundElements; o.trianglesW = (uint4*)vertices;
+	o.infoW = (particleinfo*)info; o.hashW = hash; o.nextIDs = nextIDs; o.newNumParticles = newNumParticles;
+	o.corners.c0 = (const float2*)vertPos0; o.corners.c1 = (const float2*)vertPos1; o.corners.c2 = (const float2*)vertPos2;
+	o.totParticles = totParticles; o.numOpenVertices = numOpenVertices; o.deltap = deltap; o.dt = dt;
+	SPHX_LAUNCH_WAVES(open_vertex_rows_kernel, ROW_GRID, ROW_THREADS, st, ctx->dev, l, rows, o);
+	SPHX_LAUNCH_CHECK("open_vertex_rows_kernel");
 	return SPHX_OK;
 }
 
 extern "C" int sphx_sa_io_water_depth(sphx_ctx *ctx, uint32_t *IOwaterdepth, const void *pos, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, void *stream)
 {
-	int rc = sa_io_bc_check(ctx, "the water depth is measured with SA_BOUNDARY only");
+	int rc = open_bc_check(ctx, "the water depth is measured with SA_BOUNDARY only");
 	if (rc != SPHX_OK) return rc;
 	SPHX_REQUIRE(IOwaterdepth && pos && info && hash && cellStart && neibsList, "sphx_sa_io_water_depth: missing buffer");
 	SPHX_REQUIRE(fromParticle <= toParticle && toParticle <= numParticles, "sphx_sa_io_water_depth: invalid particle range");
+	SPHX_REQUIRE(toParticle <= ctx->params.neiblist_stride, "sphx_sa_io_water_depth: range exceeds the neighbour list stride");
 	if (fromParticle == toParticle) return SPHX_OK;
-	SaIoDepthArgs a = { IOwaterdepth, (const float4*)pos, (const particleinfo*)info, hash, cellStart, neibsList, fromParticle, toParticle };
-	SPHX_LAUNCH(sa_io_water_depth_kernel, div_up_u(toParticle - fromParticle, 128), 128, (hipStream_t)stream, ctx->dev, a);
-	SPHX_LAUNCH_CHECK("sa_io_water_depth_kernel");
+	hipStream_t st = (hipStream_t)stream;
+	RowSweep sw = {};
+	sw.info = (const particleinfo*)info; sw.pos = (const float4*)pos; sw.first = fromParticle; sw.end = toParticle;
+	uint32_t *rows;
+	rc = open_rows<ROWS_DEPTH_GAUGES>(ctx, sw, st, &rows);
+	if (rc != SPHX_OK) return rc;
+	const RowLists l = { (const float4*)pos, hash, cellStart, neibsList };
+	SPHX_LAUNCH_WAVES(open_depth_rows_kernel, ROW_GRID, ROW_THREADS, st, ctx->dev, l, rows, (const particleinfo*)info, IOwaterdepth);
+	SPHX_LAUNCH_CHECK("open_depth_rows_kernel");
 	return SPHX_OK;
-}
-
-// ==========================================================================================
-// FLUX_COMPUTATION of the post-processing engine (src/cuda/post_process.cu:485-570, fluxComputationDevice
-// src/cuda/post_process_kernel.cu:822-840): per open boundary the volume flux sum A_s (u_E . n_s) over its segments.  The reference
-// adds onto a freshly allocated, uncleared device array; the sums start from zero here.  WRITTEN AT THE END OF ROUND 4, NOT YET RUN
-// ON A GPU (see above); the checker is orc_flux_computation.
-// ==========================================================================================
-__global__ void __launch_bounds__(256)
-sa_io_flux_kernel(const particleinfo *pinfo, const float4 *eulerVel, const float4 *boundElement, float *IOflux, uint32_t numOpenBoundaries,
-	uint32_t numParticles)
-{
-	const uint32_t index = blockIdx.x*256 + threadIdx.x;
-	if (index >= numParticles) return;
-	const particleinfo info = pinfo[index];
-	if (!(IS_IO_BOUNDARY(info) && PART_TYPE(info) == PT_BOUNDARY)) return;
-	const uint32_t ob = OBJECT_NUM(info);
-	if (ob >= numOpenBoundaries) return;      // (the reference would write out of bounds)
-	const float4 normal = boundElement[index], e = eulerVel[index];
-	atomicAdd(IOflux + ob, normal.w*(e.x*normal.x + e.y*normal.y + e.z*normal.z));
 }
 
 extern "C" int sphx_flux_computation(sphx_ctx *ctx, float *IOflux, const void *info, const void *eulerVel, const void *boundElements,
 	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t numOpenBoundaries, void *stream)
 {
 	(void)numParticles;
-	int rc = sa_io_bc_check(ctx, "the flux through open boundaries is computed with SA_BOUNDARY only");
+	int rc = open_bc_check(ctx, "the flux through open boundaries is computed with SA_BOUNDARY only");
 	if (rc != SPHX_OK) return rc;
 	SPHX_REQUIRE(IOflux && info && eulerVel && boundElements, "sphx_flux_computation: missing buffer");
 	if (!numOpenBoundaries) return SPHX_OK;
 	SPHX_HIP(hipMemsetAsync(IOflux, 0, numOpenBoundaries*sizeof(float), (hipStream_t)stream));
 	if (!particleRangeEnd) return SPHX_OK;
-	SPHX_LAUNCH(sa_io_flux_kernel, div_up_u(particleRangeEnd, 256), 256, (hipStream_t)stream, (const particleinfo*)info,
+	SPHX_LAUNCH(open_flux_kernel, div_up_u(particleRangeEnd, 256), 256, (hipStream_t)stream, (const particleinfo*)info,
 		(const float4*)eulerVel, (const float4*)boundElements, IOflux, numOpenBoundaries, particleRangeEnd);
-	SPHX_LAUNCH_CHECK("sa_io_flux_kernel");
+	SPHX_LAUNCH_CHECK("open_flux_kernel");
 	return SPHX_OK;
 }

@@ -55,13 +55,19 @@ struct WallTri {
 // BUFFER_VERTPOS holds the corners as 2-D coordinates in a basis of the element's plane that the neighbour-list build fixes
 // (sa_boundary_niC_vars, src/cuda/buildneibs_kernel.cu:147-190): first axis = n x e_j with e_j the coordinate axis along
 // which |n| is smallest (ties to the earlier axis), second axis = n x first.  The corners are MINUS those offsets.
-SPHX_WG_FN void wall_tri_setup(WallTri &w, V3 n, float2 c0, float2 c1, float2 c2, float h)
+SPHX_WG_FN void wall_plane_basis(V3 n, V3 &u, V3 &v)
 {
 	const float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
 	int j = (ax > ay) ? 1 : 0;
 	if (((j == 0) ? ax : ay) > az) j = 2;
 	const V3 ej = v3(j == 0 ? 1.0f : 0.0f, j == 1 ? 1.0f : 0.0f, j == 2 ? 1.0f : 0.0f);
-	const V3 u = normalize(cross(n, ej)), v = cross(n, u);
+	u = normalize(cross(n, ej));
+	v = cross(n, u);
+}
+SPHX_WG_FN void wall_tri_setup(WallTri &w, V3 n, float2 c0, float2 c1, float2 c2, float h)
+{
+	V3 u, v;
+	wall_plane_basis(n, u, v);
 	const float ih = 1.0f/h;
 	w.n = n;
 	w.corner[0] = (u*(-c0.x) + v*(-c0.y))*ih;

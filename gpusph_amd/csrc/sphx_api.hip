@@ -71,6 +71,7 @@ static void free_scratch(sphx_ctx *ctx)
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
 	ctx->tmp_info = nullptr;
 	ctx->eos_aux = nullptr; ctx->tau_pack = nullptr;
+	ctx->eos_tag_vel = nullptr; ctx->eos_tag_n = 0; ctx->eos_armed = false;
 	ctx->sa_wall = nullptr; ctx->sa_wall_neibslist = nullptr;
 	ctx->sa_wall_cache = nullptr; ctx->sa_wall_tag = nullptr; ctx->sa_wall_capacity = 0;
 	ctx->tile_list = nullptr; ctx->tile_runs = nullptr; ctx->tile_rows = nullptr; ctx->tile_lane_rec = nullptr; ctx->tile_lane_index = nullptr;
@@ -96,6 +97,7 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->ovf_host) { (void)hipHostFree(ctx->ovf_host); (void)hipEventDestroy(ctx->ovf_event); }
 	if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->side_fork); (void)hipEventDestroy(ctx->side_join); }
 	if (ctx->dem) (void)hipFree(ctx->dem);
+	if (ctx->open_rows) (void)hipFree(ctx->open_rows);
 	delete ctx->forces_events;
 	delete ctx;
 }

@@ -212,6 +212,16 @@ struct sphx_ctx {
 	float4     *sa_wall_tag;
 	uint32_t    sa_wall_capacity, sa_wall_gen;
 	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
+	// The EOS rows of the forces engine (eos_aux) written by the Euler step that writes the densities they are made of
+	// (sphx_eos_rows_follow_euler): eos_tag_* = the velocity buffer and the row count of that step; eos_armed = the caller has
+	// stated that this buffer is unchanged since (sphx_eos_rows_current), for the next sphx_forces_basicstep only
+	bool        eos_follow, eos_armed;
+	const void *eos_tag_vel;
+	uint32_t    eos_tag_n;
+	// open boundaries (sa_io.hip): the index of the pass in flight, [0] = how many rows, [1..] = which (one pass at a time per
+	// context, in stream order)
+	uint32_t   *open_rows;
+	uint32_t    open_rows_cap;
 };
 
 // ---- error plumbing ---------------------------------------------------------------------------

@@ -41,7 +41,8 @@ PT_FLUID, PT_BOUNDARY, PT_VERTEX, PT_TESTPOINT, PT_NONE = 0, 1, 2, 3, 4
 PART_FLAG_SHIFT = 3
 FG_COMPUTE_FORCE = 1 << 3
 FG_MOVING_BOUNDARY = 1 << 4
-# open boundaries of SA_BOUNDARY (src/particleinfo.h:153-156): data model only, no engine is built for them
+# open boundaries of SA_BOUNDARY (src/particleinfo.h:153-156); their passes: gpusph_amd/csrc/sa_io.hip + the open-boundary terms of
+# sa_bounds.hip, driven by MultiGpuEngine._sa_post_euler_io
 FG_INLET = 1 << 5
 FG_OUTLET = 1 << 6
 FG_VELOCITY_DRIVEN = 1 << 7

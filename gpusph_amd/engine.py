@@ -87,6 +87,7 @@ class TimestepEngine(MultiGpuEngine):
     def apply_filter(self, filtertype):
         """FILTER_CALL phase (src/integrators/PredictorCorrectorIntegrator.cc:831-859): read the unfiltered
         velocities, write the filtered ones, swap the two VEL buffers."""
+        self._rows_for = None      # the velocity buffer may be rewritten behind torch's back (multigpu.py, _rows_for)
         n = self.n_local
         self.k.filter(int(filtertype), self.vel2, self.pos, self.vel, self.info, self.hash, self.cellStart, self.neibslist, n, n)
         self.vel, self.vel2 = self.vel2, self.vel
@@ -97,6 +98,7 @@ class TimestepEngine(MultiGpuEngine):
         TESTPOINTS updates the velocity rows of test points in place, SURFACE_DETECTION updates FG_SURFACE (and
         INTERFACE_DETECTION also FG_INTERFACE) in INFO in place, and returns the normals when asked; FLUX_COMPUTATION returns the
         flux per open boundary, CALC_PRIVATE what the problem's calc_private makes of the state."""
+        self._rows_for = None      # the velocity buffer may be rewritten behind torch's back (multigpu.py, _rows_for)
         if pptype == D.FLUX_COMPUTATION:
             return self.open_boundary_flux()
         if pptype == D.CALC_PRIVATE:
@@ -118,6 +120,7 @@ class TimestepEngine(MultiGpuEngine):
     def repack_step(self):
         """one iteration of the repacking integrator (RepackingIntegrator::initializeRepackingSequence,
         src/integrators/RepackingIntegrator.cc:278-420): forces(REPACK) on step n, one full-dt Euler step."""
+        self._rows_for = None      # the velocity buffer may be rewritten behind torch's back (multigpu.py, _rows_for)
         if self.iterations % self.sp.buildneibsfreq == 0:
             self.build_neibs()
             if self.sa and self.iterations == 0:     # initialisation step of the boundary conditions, REPACK variants (:80-235)
@@ -247,6 +250,7 @@ class TimestepEngine(MultiGpuEngine):
         """HotFile::load + resume: particle buffers, iteration count, t and dt come from the file; the neighbour
         phase of the next step re-hashes and re-sorts them (calcHash, not the iteration-0 fixHash).  Body records restore
         the kinematic data of the moving bodies (readBody) and the centres of rotation of both engines."""
+        self._rows_for = None      # the velocity buffer may be rewritten behind torch's back (multigpu.py, _rows_for)
         from . import hotfile
         hf = hotfile.read_hotfile(path)
         a = hf["arrays"]

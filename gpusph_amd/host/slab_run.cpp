@@ -94,6 +94,7 @@ struct Worker {
 	double *d_t;
 	uint32_t cflElems;
 	uint64_t iterations;
+	const void *eulers;      // the velocity buffer the last Euler step wrote, untouched since (sphx_eos_rows_current), or NULL
 };
 
 // the neighbours of a slab; on a periodic split axis the first and the last slab are neighbours through the periodic face
@@ -167,6 +168,7 @@ static void build_neibs(Worker &w)
 {
 	const Case &c = *w.c;
 	const uint32_t n = w.n_local;
+	w.eulers = nullptr;      // the sort rewrites the buffers
 	if (w.iterations == 0) CALL(sphx_fix_hash(w.ctx, w.hash, w.partindex, w.info, w.devmap, n, nullptr));
 	else CALL(sphx_calc_hash(w.ctx, w.pos, w.hash, w.partindex, w.info, w.devmap, n, nullptr));
 	CALL(sphx_sort(w.ctx, w.hash, w.info, w.partindex, n, nullptr));
@@ -192,7 +194,10 @@ static void forces_pass(Worker &w, const void *pos, const void *vel, int combine
 	const sphx_params &P = w.c->params;
 	CALL(sphx_memset_async(w.cfl, 0, w.cflElems*sizeof(float), nullptr));
 	uint32_t nb1 = 0, nb2 = 0;
+	bool vouch = w.eulers == vel;      // nothing has touched the densities since the Euler step: its EOS rows stand
 	auto launch = [&](uint32_t from, uint32_t to, uint32_t off, uint32_t *nb) {
+		if (vouch) CALL(sphx_eos_rows_current(w.ctx, vel, w.n_local));
+		vouch = true;                  // the second stripe reads what the first one read
 		CALL(sphx_forces_basicstep(w.ctx, w.forces, w.cfl, nullptr, nullptr, pos, vel, w.info, w.hash, w.cellStart, w.neibslist,
 			nullptr, nullptr, nullptr, nullptr, w.n_local, from, to, P.deltap, P.slength, P.dtadaptfactor, P.influenceradius,
 			off, SPHX_SIMULATE, step, 0.0f, 0, nb, nullptr));
@@ -219,6 +224,7 @@ static void step(Worker &w)
 	auto euler = [&](float dt_scale, int stepnum) {
 		CALL(sphx_euler_basicstep(w.ctx, w.pos2, w.vel2, w.pos, w.vel, w.info, w.hash, w.forces, nullptr, n, n, 0.0f, w.d_dt, dt_scale,
 			stepnum, 0.0f, P.slength, P.influenceradius, SPHX_SIMULATE, nullptr));
+		w.eulers = w.vel2;
 	};
 	forces_pass(w, w.pos, w.vel, 0, 1);          // predictor: forces(n) -> n* = n + dt/2 f
 	euler(0.5f, 1);
@@ -247,6 +253,7 @@ static void worker(const Case *c, int rank, sphx_halo_group *group, const std::s
 	CALL(sphx_create(&w.ctx, 0));
 	CALL(sphx_set_constants(w.ctx, &c->params));
 	CALL(sphx_reserve(w.ctx, c->alloc));
+	CALL(sphx_eos_rows_follow_euler(w.ctx, 1));
 	if (w.world > 1) CALL(sphx_halo_create_threads(group, w.ctx, rank, &w.halo));
 	// the particles this slab starts with: its own planes plus one plane of each neighbour (they are sorted out by the first
 	// neighbour phase); the device map: CELLTYPE of every cell as seen from here (fillDeviceMapByAxis, src/ProblemCore.cc:1061-1116)

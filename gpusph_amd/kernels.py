@@ -274,6 +274,14 @@ class HipKernels:
                                                  p(forces), p(xsph), n, n, 0.0, p(d_dt), dt_scale, step, 0.0,
                                                  P.slength, P.influenceradius, run_mode, self._s()))
 
+    def eos_rows_follow_euler(self, on):
+        """the forces engine's EOS rows are written by the Euler step (include/sphx.h)"""
+        capi.check(self.lib.sphx_eos_rows_follow_euler(self.ctx.handle, 1 if on else 0))
+
+    def eos_rows_current(self, vel, n):
+        """the caller's statement that `vel` is unchanged since the rows were made for it; holds for the next forces call"""
+        capi.check(self.lib.sphx_eos_rows_current(self.ctx.handle, capi.ptr(vel), n))
+
     def time_advance(self, d_t, d_dt):
         capi.check(self.lib.sphx_time_advance(self.ctx.handle, capi.ptr(d_t), capi.ptr(d_dt), self._s()))
 

@@ -111,6 +111,15 @@ class MultiGpuEngine:
             from .kernels import HipKernels
             kernels = HipKernels(problem, self.alloc, self.device)
         self.k = kernels
+        # The EOS rows of the plain forces engine ride with the Euler step (include/sphx.h, sphx_eos_rows_follow_euler): this driver
+        # owns the sequence of a step, so it can vouch for the velocity buffer between an Euler step and the forces pass that reads
+        # it.  _rows_for = (the tensor the last Euler step wrote, its torch version counter): anything that rewrites it through
+        # torch bumps the counter, the library's own rewrites (sort, filters, halo import) go to the other buffer or clear this
+        self._rows_for = None
+        self._rows_follow = (not self.sa and not self.grenier and not self.effvisc_on and hasattr(kernels, "eos_rows_follow_euler")
+                             and problem.simparams.sph_formulation in (D.SPH_F1, D.SPH_F2))
+        if self._rows_follow:
+            kernels.eos_rows_follow_euler(True)
         # who moves the edge layers: torch.distributed by default, or a transport the caller built (halo.CapiTransport:
         # the library's own sphx_halo_* entry points; a callable gets the kernels of this rank and returns the transport)
         self.transport = None
@@ -261,6 +270,7 @@ class MultiGpuEngine:
     def build_neibs(self):
         K = self.k
         n = self.n_local
+        self._rows_for = None
         if self.iterations == 0:
             K.fix_hash(self.hash, self.partindex, self.info, self.devmap, n)
         else:
@@ -603,8 +613,13 @@ class MultiGpuEngine:
                 kw["xsph"] = self.xsph
             if run_mode != D.SIMULATE or step != 1:
                 kw.update(run_mode=run_mode, step=step)
+            vouch = [self._rows_follow and run_mode == D.SIMULATE and self._rows_for is not None and self._rows_for[0] is vel and
+                     vel._version == self._rows_for[1]]
 
             def launch(frm, to, off):
+                if vouch[0]:
+                    K.eos_rows_current(vel, self.n_local)
+                vouch[0] = self._rows_follow and run_mode == D.SIMULATE      # a second stripe of this pass reads the buffer the first one read
                 return K.forces(*args, frm, to, off, **kw)
         energy = self.energy_on and run_mode == D.SIMULATE      # the BUFFER_INTERNAL_ENERGY_UPD output of the pass travels with the forces
         if energy:
@@ -660,6 +675,7 @@ class MultiGpuEngine:
         if self.iterations > 0:      # FILTER phases: internal particles, then UPDATE_EXTERNAL of the velocity buffer
             for ftype, freq in self.filters:
                 if self.iterations % freq == 0:
+                    self._rows_for = None
                     K.filter(ftype, self.vel2, self.pos, self.vel, self.info, self.hash, self.cellStart, self.neibslist, n, self.n_int)
                     if self.world > 1:
                         self._exchange([self.vel2])
@@ -675,6 +691,7 @@ class MultiGpuEngine:
             K.euler_grenier(self.pos2, self.vel2, self.vol2, self.pos, self.vel, self.vol, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1)
         else:
             K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1, **ekw)
+            self._rows_for = (self.vel2, self.vel2._version)
         if self.energy_on:
             K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 0.5)
         if self.keps:
@@ -692,6 +709,7 @@ class MultiGpuEngine:
             self.vol, self.vol2 = self.vol2, self.vol
         else:
             K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2, **ekw)
+            self._rows_for = (self.vel2, self.vel2._version)
         if self.energy_on:
             K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 1.0)
             self.energy, self.energy2 = self.energy2, self.energy

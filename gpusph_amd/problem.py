@@ -1015,14 +1015,20 @@ class SABox(Problem):
 class SAChannelIO(SABox):
     """An open channel on the SABox mesh, the synthetic counterpart of src/problems/ChannelIO.cu (whose geometry is a set of
     Crixus HDF5 files): the x = 0 wall of the tank is a VELOCITY-driven open boundary (u_E = U ex, setVelocityDriven(inlet, 1),
-    :85-88), the x = l wall a PRESSURE-driven one (the hydrostatic pressure under the measured water level, :90-93), the fluid
-    starts as a stream at U.  Framework options of that problem (:38-47): Brezzi diffusion, density summation, ENABLE_INLET_OUTLET |
-    ENABLE_WATER_DEPTH, a neighbour-list rebuild in every iteration (:62).  Open boundaries are numbered 0 (inlet) and 1 (outlet):
-    the object number of their segments and vertices, the index into BUFFER IOwaterdepth.
+    :85-88), the x = l wall a PRESSURE-driven one, the fluid starts as a stream at U.  Framework options of that problem (:38-47):
+    Brezzi diffusion, density summation, ENABLE_INLET_OUTLET | ENABLE_WATER_DEPTH, a neighbour-list rebuild in every iteration
+    (:62).  Open boundaries are numbered 0 (inlet) and 1 (outlet): the object number of their segments and vertices, the index
+    into BUFFER IOwaterdepth.
 
-    STATUS: the driver sequence of gpusph_amd.multigpu runs this problem on the CPU over the oracle's kernels (tests); the HIP
-    kernels of the open-boundary passes have not run on a GPU yet and the library still refuses ENABLE_INLET_OUTLET in its SA entry
-    points."""
+    Where this mirror is NOT ChannelIO.cu: (1) the imposed values.  ChannelIO's callback (:142-230) reads IOwaterdepth for its
+    VELOCITY-driven boundary and holds the level of the pressure outlet at a constant 1.0, with U = 0.05; this mirror imposes the
+    hydrostatic pressure under the MEASURED level at the pressure-driven outlet -- the rule of src/problems/CompleteSaExample.cu:268
+    -- and a faster stream (U = 0.6 by default), so that the tests see particles enter and leave within tens of steps.  Nobody
+    should expect number-for-number parity with a run of the tree's ChannelIO; what is held to the reference is the option set
+    (test_channelio_framework_and_constants) and, pass by pass, the oracle's restatement of the kernels.  (2) the geometry (a box
+    mesh made here instead of Crixus files).
+
+    The passes run on the device (gpusph_amd/csrc/sa_io.hip, sa_bounds.hip; tests/test_gpu_sa_io.py)."""
 
     def __init__(self, deltap=0.05, *, U=0.6, l=1.0, w=0.4, h=0.4, H=0.25, water_depth=True, **kw):
         super().__init__(deltap, l=l, w=w, h=h, H=H, **kw)

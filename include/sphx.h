@@ -312,11 +312,9 @@ int sphx_sa_find_outgoing_segment(sphx_ctx *ctx, const void *pos, const void *ve
 /* disableOutgoingParts (src/cuda/boundary_conditions.cu:76-104): marked fluid particles are disabled (NaN mass), marks cleared */
 int sphx_sa_disable_outgoing_parts(sphx_ctx *ctx, void *pos, void *vertices, const void *info, uint32_t numParticles, void *stream);
 /* saSegmentBoundaryConditions / saVertexBoundaryConditions with open boundaries (src/cuda/boundary_conditions.cu:108-235,280-410
- * with has_io; laminar, SPHX_SIMULATE).  WRITTEN, NOT YET RUN ON A GPU (end of round 4): ports of the oracle's restatements, their
- * parity test waits behind SPHX_TEST_SA_IO_BC=1 in tests/test_gpu_sa_io.py.  Until it has passed, these and the other unverified
- * open-boundary passes (density_sum_io, forces_basicstep_sa_io, compute_density_diffusion_io, io_water_depth) answer
- * SPHX_ERR_UNSUPPORTED unless the environment holds SPHX_EXPERIMENTAL_SA_IO=1; the same word lets a context with
- * ENABLE_INLET_OUTLET past the refusal of the other SA entry points.  The driver that calls them: gpusph_amd/multigpu.py.
+ * with has_io; laminar, SPHX_SIMULATE).  The solid-wall rows go to the kernels of sphx_sa_segment_bc / sphx_sa_vertex_bc, the
+ * segments and the non-corner vertices of the open faces get a wave each (gpusph_amd/csrc/sa_io.hip).  Held against the oracle
+ * on an MI355X by tests/test_gpu_sa_io.py (round 5).  The driver that calls them: gpusph_amd/multigpu.py.
  * segment pass: vel, gGam, eulerVel in place (boundary rows): an open-boundary segment gets the Riemann-invariant condition from
  * the Shepard means of the fluid next to it and what IMPOSE_OPEN_BOUNDARY_CONDITION left in eulerVel, a solid one the wall density
  * and a cleared Eulerian velocity.
@@ -334,7 +332,8 @@ int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, void *newPos
 	uint32_t numOpenVertices, void *stream);
 /* density_sum and the forces of SA_BOUNDARY with open boundaries (src/cuda/density_sum.cu + density_sum_kernel.cu:119-140,206-250,
  * 374-420,606-655; src/cuda/forces.cu:751-795 + forces_kernel.def:1485-1497,2494-2507,2703-2708; laminar or inviscid, Wendland,
- * one thread per particle over the list).  WRITTEN, NOT YET RUN ON A GPU (see sphx_sa_segment_bc_io).
+ * one thread per particle over the list: the walkers of sphx_sa_density_sum / sphx_forces_basicstep_sa with their open-boundary
+ * terms; the tiled window does not know those terms and is not built for a context with ENABLE_INLET_OUTLET).
  * sphx_sa_density_sum_io: sphx_sa_density_sum with the open boundaries' terms; oldEulerVel = BUFFER_EULERVEL of step n; dt = the
  *   integration interval of the Euler step just taken.  forces.w receives the volumic sums, as in sphx_sa_density_sum.
  * sphx_forces_basicstep_sa_io: sphx_forces_basicstep_sa (SPHX_SIMULATE) with BUFFER_EULERVEL in the viscous terms and the gamma CFL;
@@ -348,8 +347,8 @@ int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *cfl, float *
 	const void *eulerVel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,
 	uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, float deltap, uint32_t cflOffset, uint32_t *h_numBlocks, void *stream);
-/* The Brezzi diffusion with open boundaries and the water depth at the pressure-driven ones.  WRITTEN, NOT YET RUN ON A GPU (see
- * sphx_sa_segment_bc_io); the checkers are orc_sa_density_diffusion_io / orc_sa_io_water_depth.
+/* The Brezzi diffusion with open boundaries and the water depth at the pressure-driven ones; the checkers are
+ * orc_sa_density_diffusion_io / orc_sa_io_water_depth (tests/test_gpu_sa_io.py).
  * sphx_sa_compute_density_diffusion_io: computeDensityDiffusionDevice with ENABLE_INLET_OUTLET (src/cuda/forces.cu
  *   compute_density_diffusion + forces_kernel.def:4536-4582): sphx_sa_compute_density_diffusion plus the boundary term of the
  *   segments of pressure-driven open boundaries (:1836-1852), which reads the elements and their vertices' positions.
@@ -366,8 +365,7 @@ int sphx_sa_io_water_depth(sphx_ctx *ctx, uint32_t *IOwaterdepth, const void *po
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t numParticles, uint32_t fromParticle, uint32_t toParticle, void *stream);
 /* FLUX_COMPUTATION of the post-processing engine (src/cuda/post_process.cu:485-570; fluxComputationDevice
  * src/cuda/post_process_kernel.cu:822-840): IOflux[numOpenBoundaries] (device) = per open boundary the volume flux
- * sum A_s (u_E . n_s) over its segments, from zero (the reference adds onto uncleared memory).  WRITTEN, NOT YET RUN ON A GPU:
- * refused like the other unverified open-boundary passes (see sphx_sa_segment_bc_io). */
+ * sum A_s (u_E . n_s) over its segments, from zero (the reference adds onto uncleared memory). */
 int sphx_flux_computation(sphx_ctx *ctx, float *IOflux, const void *info, const void *eulerVel, const void *boundElements,
 	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t numOpenBoundaries, void *stream);
 /* saInitGamma (src/cuda/boundary_conditions.cu:457-560): gamma and grad gamma of fluid and vertex particles at initialisation,
@@ -607,6 +605,18 @@ int sphx_euler_basicstep_grenier(sphx_ctx *ctx, void *newPos, void *newVel, void
  * disable (mass = NaN) the non-fluid particles flagged FG_SURFACE */
 int sphx_disable_free_surf_parts(sphx_ctx *ctx, void *pos, const void *info,
 	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
+
+/* The EOS rows of the forces engine ({P/rho^2, c, P, rho} per particle, a scratch array of the context) are made by a pre-pass of
+ * sphx_forces_basicstep over the velocity buffer it is given.  sphx_eos_rows_follow_euler(on != 0) makes sphx_euler_basicstep
+ * (SPHX_SIMULATE, DYN / LJ boundaries) write them next to the densities they are functions of; a caller that then hands that very
+ * buffer, unchanged, to sphx_forces_basicstep states so with sphx_eos_rows_current(vel, numParticles) right before the call, and
+ * the pre-pass is skipped for that call.  "Unchanged" is the caller's statement (no filter, boundary-condition pass, sort, halo
+ * import or upload since the Euler step, or since the previous forces call on the same buffer); a buffer / row count the rows
+ * were not made for is ignored.  Off by default: the engine adapters of host/hip_engines.h, which cannot see what the
+ * Integrator does between two commands, never make the statement; the native drivers (gpusph_amd/multigpu.py, slab_run.cpp) do.
+ * No reference counterpart (the reference recomputes the EOS of the neighbour in every pair). */
+int sphx_eos_rows_follow_euler(sphx_ctx *ctx, int on);
+int sphx_eos_rows_current(sphx_ctx *ctx, const void *vel, uint32_t numParticles);
 
 /* t += dt on the device (double += float, the sum GPUSPH::runSimulation keeps on the host, src/GPUSPH.cc:650-657): for
  * callers that keep dt device-resident (sphx_forces_dtreduce_device) and do not want a host round trip per step */

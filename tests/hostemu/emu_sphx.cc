@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
 #include "../../gpusph_amd/csrc/sphx_api.hip"
+#define ROW_GRID 2      // the row kernels stride over their index: two blocks of fibres do as well as a thousand
 #include "../../gpusph_amd/csrc/sa_io.hip"
 // sa_bounds.hip (the solid-wall SA passes: verified on the GPU, emulated for the regression value and because an open-boundary
 // run calls some of them) with its launches rewritten into _build/sa_bounds_emu.inc by tests/hostemu_lib.py.  The tiled window and

@@ -1,14 +1,20 @@
 // TEST HARNESS ONLY (tests/hostemu): a stand-in for <hip/hip_runtime.h> with which g++ compiles the SOURCE of some of this
-// repository's own HIP kernels for the host, so that kernels that have not yet run on a GPU can be held against the oracle on the
-// CPU: one "thread" after the other, blockIdx / threadIdx as globals.  It exists to find logic errors (indices, flags, signs,
-// operation order) early; it proves nothing about the device build, is never loaded by the package, and is no CPU fallback of
-// the library (libsphx.so has none).  Only what sphx_api.hip and sa_io.hip use is here.
+// repository's own HIP kernels for the host, so that their logic can be held against the oracle on the CPU, where there is no GPU:
+// element-wise kernels one "thread" after the other (SPHX_LAUNCH), wave-cooperative kernels (SPHX_LAUNCH_WAVES: ballots, shuffles,
+// readlane, LDS rows shared by the lanes of a wave) as 64 fibres per wave that meet at every wave operation, so that a lane sees
+// the values the other lanes hold at that instruction, as on the device.  It exists to find logic errors (indices, flags, signs,
+// operation order, lanes that miss a wave operation) early; it proves nothing about the device build, is never loaded by the
+// package, and is no CPU fallback of the library (libsphx.so has none).  Only what sphx_api.hip, sa_io.hip and sa_bounds.hip use is here.
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <climits>
+#include <functional>
+#include <vector>
+#include <ucontext.h>
 
 #define __HIPCC__ 1          // the repository's headers keep their device helpers behind it
 #define __global__
@@ -51,11 +57,79 @@ template<typename T> static inline T atomicMax(T *p, T v) { const T o = *p; if (
 template<typename T> static inline T atomicMin(T *p, T v) { const T o = *p; if (v < o) *p = v; return o; }
 template<typename T> static inline T atomicOr(T *p, T v) { const T o = *p; *p = o | v; return o; }
 template<typename T> static inline T atomicExch(T *p, T v) { const T o = *p; *p = v; return o; }
-template<typename T> static inline T __shfl_down(T v, unsigned) { return v; }
-template<typename T> static inline T __shfl_xor(T v, unsigned) { return v; }
-template<typename T> static inline T __shfl(T v, int) { return v; }
-static inline void __syncthreads() {}
 static inline void __threadfence() {}
+
+// ---- waves of fibres ---------------------------------------------------------------------------------------------------------------
+// A block of a SPHX_LAUNCH_WAVES launch is a team of fibres (ucontext), one per thread, run round-robin by a scheduler on the
+// calling OS thread.  A wave operation is a rendezvous of the 64 fibres of a wave: each deposits its operand, waits (yields) until
+// all 64 have, and then reads what it needs from the deposits; deposits are double-buffered by the parity of the rendezvous, so one
+// rendezvous per operation is enough.  A fibre that returns while its wave still waits for it, or a wave operation under a
+// lane-dependent condition, shows up as a round of the scheduler in which nothing moves: reported and aborted.  __syncthreads is
+// the same over the whole block.  Outside such a launch (serial SPHX_LAUNCH) a thread is a wave of its own lane.
+namespace emu {
+struct Fibre { ucontext_t ctx; bool done; };
+struct Wave { int arrived; unsigned gen; unsigned long long slot[2][64]; };
+struct Team {
+	std::vector<Fibre> fibre;
+	std::vector<Wave> wave;
+	ucontext_t scheduler;
+	unsigned current;
+	unsigned long moved;
+	int barArrived; unsigned barGen;
+	const std::function<void()> *body;
+};
+inline Team *team = nullptr;
+inline std::vector<char> stacks;
+static const size_t STACK = 512u*1024u;
+inline void yield() { Team *t = team; swapcontext(&t->fibre[t->current].ctx, &t->scheduler); }
+inline void fibre_main()
+{
+	Team *t = team;
+	(*t->body)();
+	t->fibre[t->current].done = true;
+	t->moved++;
+	swapcontext(&t->fibre[t->current].ctx, &t->scheduler);
+}
+// deposit v, meet the other lanes of the wave, hand back the deposits of this operation
+inline const unsigned long long *meet(unsigned long long v)
+{
+	Team *t = team;
+	const unsigned tid = t->current, lane = tid & 63u;
+	Wave &w = t->wave[tid >> 6];
+	const unsigned g = w.gen, par = g & 1u;
+	w.slot[par][lane] = v;
+	if (++w.arrived == 64) { w.arrived = 0; w.gen++; t->moved++; }
+	else while (w.gen == g) yield();
+	return w.slot[par];
+}
+inline void meet_block()
+{
+	Team *t = team;
+	const unsigned g = t->barGen;
+	if (++t->barArrived == (int)t->fibre.size()) { t->barArrived = 0; t->barGen++; t->moved++; }
+	else while (t->barGen == g) yield();
+}
+}
+template<typename T> static inline unsigned long long emu_bits(T v) { static_assert(sizeof(T) <= 8, "operand of a wave operation"); unsigned long long b = 0; memcpy(&b, &v, sizeof(T)); return b; }
+template<typename T> static inline T emu_value(unsigned long long b) { T v; memcpy(&v, &b, sizeof(T)); return v; }
+static inline unsigned emu_lane();
+template<typename T> static inline T __shfl(T v, int src) { if (!emu::team) return v; const unsigned long long *d = emu::meet(emu_bits(v)); return emu_value<T>(d[(unsigned)src & 63u]); }
+template<typename T> static inline T __shfl_xor(T v, int m) { if (!emu::team) return v; const unsigned l = emu_lane(); const unsigned long long *d = emu::meet(emu_bits(v)); return emu_value<T>(d[(l ^ (unsigned)m) & 63u]); }
+template<typename T> static inline T __shfl_down(T v, unsigned k) { if (!emu::team) return v; const unsigned l = emu_lane(); const unsigned long long *d = emu::meet(emu_bits(v)); return l + k < 64u ? emu_value<T>(d[l + k]) : v; }
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool b)
+{
+	if (!emu::team) return b ? (1ull << emu_lane()) : 0ull;
+	const unsigned long long *d = emu::meet(b ? 1ull : 0ull);
+	unsigned long long m = 0;
+	for (unsigned l = 0; l < 64u; ++l) m |= (d[l] & 1ull) << l;
+	return m;
+}
+static inline int __builtin_amdgcn_readlane(int v, int l) { if (!emu::team) return v; const unsigned long long *d = emu::meet(emu_bits(v)); return emu_value<int>(d[(unsigned)l & 63u]); }
+// every lane's value of v at once (wave_list.h's ordered_sums reads all lanes of a term: one meeting instead of sixty-four)
+static inline void emu_wave_gather(float v, float *out) { const unsigned long long *d = emu::meet(emu_bits(v)); for (unsigned l = 0; l < 64u; ++l) out[l] = emu_value<float>(d[l]); }
+#define SPHX_WAVE_GATHER(v, out) emu_wave_gather((v), (out))
+static inline void __builtin_amdgcn_wave_barrier() { if (emu::team) (void)emu::meet(0ull); }
+static inline void __syncthreads() { if (emu::team) emu::meet_block(); }
 #define __powf(a, b) powf((a), (b))
 #define __expf(a) expf(a)
 static inline int min(int a, int b) { return a < b ? a : b; }
@@ -67,7 +141,7 @@ static inline float max(float a, float b) { return fmaxf(a, b); }
 static inline float __fdividef(float a, float b) { return a/b; }
 static inline float rsqrtf(float a) { return 1.0f/sqrtf(a); }
 // (sphx_internal.h's LDS-DMA helpers are not used by the files built here; they only have to parse)
-static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { return v; }
+static inline unsigned __builtin_amdgcn_readfirstlane(unsigned v) { if (!emu::team) return v; const unsigned long long *d = emu::meet(emu_bits(v)); return emu_value<unsigned>(d[0]); }
 static inline void __builtin_amdgcn_global_load_lds(const void *src, void *dst, int bytes, int, int) { memcpy(dst, src, (size_t)bytes); }
 static inline float __int_as_float(int i) { float f; memcpy(&f, &i, 4); return f; }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
@@ -112,6 +186,55 @@ static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+
+static inline unsigned emu_lane() { return threadIdx.x & 63u; }
+
+// a launch of a wave-cooperative kernel: block after block, each as a team of fibres
+namespace emu {
+inline void run_grid(unsigned grid, unsigned block, const std::function<void()> &body)
+{
+	if (block % 64u) { fprintf(stderr, "hostemu: a wave launch needs whole waves (block of %u)\n", block); abort(); }
+	if (stacks.size() < (size_t)block*STACK) stacks.resize((size_t)block*STACK);
+	Team t;
+	t.body = &body;
+	gridDim = dim3(grid); blockDim = dim3(block);
+	for (unsigned bi = 0; bi < grid; ++bi) {
+		blockIdx = dim3(bi);
+		t.fibre.assign(block, Fibre());
+		t.wave.assign(block/64u, Wave());
+		t.moved = 0; t.barArrived = 0; t.barGen = 0;
+		team = &t;
+		for (unsigned i = 0; i < block; ++i) {
+			Fibre &f = t.fibre[i];
+			f.done = false;
+			getcontext(&f.ctx);
+			f.ctx.uc_stack.ss_sp = stacks.data() + (size_t)i*STACK;
+			f.ctx.uc_stack.ss_size = STACK;
+			f.ctx.uc_link = nullptr;
+			makecontext(&f.ctx, fibre_main, 0);
+		}
+		for (;;) {
+			bool alive = false;
+			const unsigned long before = t.moved;
+			for (unsigned i = 0; i < block; ++i) {
+				if (t.fibre[i].done) continue;
+				alive = true;
+				t.current = i;
+				threadIdx = dim3(i);
+				swapcontext(&t.scheduler, &t.fibre[i].ctx);
+			}
+			if (!alive) break;
+			if (t.moved == before) {
+				fprintf(stderr, "hostemu: block %u is stuck: a wave operation (or __syncthreads) was not reached by every lane\n", bi);
+				abort();
+			}
+		}
+		team = nullptr;
+	}
+}
+}
+#define SPHX_LAUNCH_WAVES(kernel, grid, block, stream, ...) do { (void)(stream); \
+	emu::run_grid((unsigned)(grid), (unsigned)(block), [&]() { kernel(__VA_ARGS__); }); } while (0)
 
 // a launch: every block, every thread, in order
 #define SPHX_LAUNCH(kernel, grid, block, stream, ...) do { \
