@@ -201,8 +201,15 @@ def test_sa_forces_gamma_integration_and_trajectory(kernels):
     scale = np.abs(f[fl, :3]).max()
     wall = wall_rows(sim.problem, sim.nl, sim.info, n)      # the gamma allowance is for particles next to a wall only
     assert 0.05 < wall[fl].mean() < 0.95
-    assert_close_but_for_gamma_spikes(gf[fl, :3], f[fl, :3], 1e-4, scale, what="SA forces", wall=wall[fl])
-    assert_close_but_for_gamma_spikes(gf[fl, 3], f[fl, 3], 1e-4, max(np.abs(f[fl, 3]).max(), 1e-3), what="SA continuity", wall=wall[fl])
+    # no fraction of outliers, no multiple of the tolerance: a row beyond 1e-4 of the scale must have boundary elements in reach and
+    # lie, like the oracle's value, within the room that the conditioning of |grad gamma_as| of THOSE elements leaves around the
+    # float64 value of the row's boundary terms (tests/sa_helpers.py assert_wall_rows_no_farther_from_float64)
+    from sa_helpers import assert_wall_rows_no_farther_from_float64
+    sw = max(np.abs(f[fl, 3]).max(), 1e-3)
+    errn = np.abs(gf[fl].astype(np.float64) - f[fl])/np.array([scale, scale, scale, sw])
+    assert errn[~wall[fl]].max() <= 1e-4, "a row with no boundary element in reach is %g of the scale off" % errn[~wall[fl]].max()
+    arbitrated, total = assert_wall_rows_no_farther_from_float64(sim, gf, f, fl, 1e-4, scale, sw, what="SA forces")
+    print("SA forces: %d of %d fluid rows beyond 1e-4 of the scale, each within the conditioning room of its own elements" % (arbitrated, total))
     assert not gf[t != D.PT_FLUID].any()
     assert_close_but_for_gamma_spikes(_np(eng.cfl)[:nb], cfl[:nb], 1e-4, what="SA CFL maxima")
     # gamma by quadrature at displaced positions
