@@ -78,6 +78,8 @@ SIGNATURES = {
     "sphx_sa_density_sum": (_i, [_vp] + [_vp] * 15 + [_u32, _u32, _f, _i, _f, _f, _f, _f, _f, _vp]),
     "sphx_sa_compute_density_diffusion": (_i, [_vp] + [_vp] * 8 + [_u32, _u32, _f, _f, _f, _f, _vp]),
     "sphx_apply_density_diffusion": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _f, _vp]),
+    "sphx_sa_update_normals": (_i, [_vp, _vp, _vp, _vp, _u32, _u32, _vp]),
+    "sphx_sa_density_sum_moving": (_i, [_vp] + [_vp] * 16 + [_u32, _u32, _vp]),
     "sphx_sa_integrate_gamma": (_i, [_vp] + [_vp] * 11 + [_u32, _u32, _f, _i, _f, _f, _f, _f, _i, _vp]),
     "sphx_sa_init_gamma": (_i, [_vp] + [_vp] * 11 + [_f, _f, _f, _f, _u32, _u32, _vp]),
     "sphx_sa_segment_bc": (_i, [_vp] + [_vp] * 9 + [_u32, _u32, _f, _f, _f, _i, _i, _vp]),

@@ -216,6 +216,45 @@ extern "C" int sphx_euler_basicstep_grenier(sphx_ctx *ctx, void *newPos, void *n
 		dt, d_dt, dt_scale, step, t, slength, influenceradius, run_mode, stream);
 }
 
+// update_normals (src/cuda/euler_kernel.def:237-254), the part of eulerDevice that exists with SA_BOUNDARY and ENABLE_MOVING_BODIES:
+// BUFFER_BOUNDELEMENTS of the new state = that of step n with the normals of the moving segments and vertices turned by the
+// body's rotation over the step (applyrot, euler_kernel.cu:67-74); everything else copied.  A launch of its own behind
+// sphx_euler_basicstep: the Euler entry point keeps the signature the other boundary models use.
+__global__ void __launch_bounds__(BLOCK_EULER)
+sa_update_normals_kernel(float4 *__restrict__ newBoundElem, const float4 *__restrict__ oldBoundElem, const particleinfo *__restrict__ info,
+	const RbParams *__restrict__ rb, uint32_t n)
+{
+	const uint32_t index = blockIdx.x*BLOCK_EULER + threadIdx.x;
+	if (index >= n) return;
+	const particleinfo pi = info[index];
+	float4 normal = oldBoundElem[index];
+	if (IS_MOVING(pi) && (PART_TYPE(pi) == PT_BOUNDARY || PART_TYPE(pi) == PT_VERTEX)) {
+		const float *rot = rb->steprot[OBJECT_NUM(pi)];
+		const float rx = normal.x, ry = normal.y, rz = normal.z;
+		normal.x += (rot[0] - 1.0f)*rx + rot[1]*ry + rot[2]*rz;
+		normal.y += rot[3]*rx + (rot[4] - 1.0f)*ry + rot[5]*rz;
+		normal.z += rot[6]*rx + rot[7]*ry + (rot[8] - 1.0f)*rz;
+	}
+	newBoundElem[index] = normal;
+}
+
+extern "C" int sphx_sa_update_normals(sphx_ctx *ctx, void *newBoundElements, const void *oldBoundElements, const void *info,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+{
+	(void)numParticles;
+	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_sa_update_normals: constants not set");
+	if (ctx->params.boundarytype != SPHX_SA_BOUNDARY || !(ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES))
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_update_normals: for SA_BOUNDARY with ENABLE_MOVING_BODIES");
+	SPHX_REQUIRE(newBoundElements && oldBoundElements && info && newBoundElements != oldBoundElements,
+		"sphx_sa_update_normals: BUFFER_BOUNDELEMENTS is double buffered with moving bodies");
+	if (!particleRangeEnd) return SPHX_OK;
+	{ const int rcf = sphx_rb_flush(ctx, (hipStream_t)stream); if (rcf != SPHX_OK) return rcf; }
+	sa_update_normals_kernel<<<div_up_u(particleRangeEnd, BLOCK_EULER), BLOCK_EULER, 0, (hipStream_t)stream>>>((float4*)newBoundElements,
+		(const float4*)oldBoundElements, (const particleinfo*)info, ctx->rb_dev, particleRangeEnd);
+	SPHX_LAUNCH_CHECK("sa_update_normals_kernel");
+	return SPHX_OK;
+}
+
 // disableFreeSurfPartsDevice (src/cuda/euler_kernel.cu:158-180)
 __global__ void __launch_bounds__(BLOCK_EULER)
 disable_free_surf_kernel(float4 *pos, const particleinfo *info, uint32_t n)

@@ -79,6 +79,7 @@ struct SaIntGammaArgs {
 	float epsilon;
 	int wallDone;      // the fluid particles with boundary elements in reach are done by sa_integrate_gamma_wall_kernel
 	SaWallCache wc;
+	int vertexRows;    // ENABLE_MOVING_BODIES: gamma of the vertex particles is integrated too
 };
 
 // density summation with dynamic gamma: see sa_density_sum_kernel (sa_bounds.hip)
@@ -96,6 +97,7 @@ struct SaDensitySumArgs {
 	SaWallCache wc;
 	const float4 *oldEulerVel;    // a run with open boundaries (sa_density_sum_kernel<true>)
 	float dt;
+	const float4 *boundElementNew; // ENABLE_MOVING_BODIES (sa_density_sum_kernel<.., true>): BUFFER_BOUNDELEMENTS of the new state
 };
 
 // sa_wall.hip: the boundary-element terms of the three engines for the particles of ctx->sa_wall

@@ -547,7 +547,8 @@ sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
 	if (index >= a.numParticles) return;
 	const particleinfo info = a.info[index];
 	const float4 og = a.oldGGam[index];
-	if (PART_TYPE(info) != PT_FLUID) {
+	const bool vertexRow = a.vertexRows && PART_TYPE(info) == PT_VERTEX;      // moving bodies: Gamma<PT_VERTEX> against the new elements
+	if (PART_TYPE(info) != PT_FLUID && !vertexRow) {
 		if (PART_TYPE(info) == PT_VERTEX || PART_TYPE(info) == PT_BOUNDARY) a.newGGam[index] = og;
 		return;
 	}
@@ -568,7 +569,7 @@ sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
 		wall_tri_setup(tri, normal, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
 		const float ggamAS = wall_grad_gamma(tri, q)/p.slength;
 		g.x += ggamAS*be.x; g.y += ggamAS*be.y; g.z += ggamAS*be.z;
-		g.w -= wall_gamma<false>(tri, q, oldg, p.slength, a.epsilon);
+		g.w -= vertexRow ? wall_gamma<true>(tri, q, oldg, p.slength, a.epsilon) : wall_gamma<false>(tri, q, oldg, p.slength, a.epsilon);
 	});
 	a.newGGam[index] = g;
 }
@@ -578,15 +579,20 @@ sa_integrate_gamma_kernel(DevParams p, SaIntGammaArgs a)
 // and replaced by the kernel at the distance it would have after moving with its Eulerian velocity instead of its own for dt
 // (densitySumOpenBoundaryContribution, density_sum_kernel.cu:119-140); the segments of an open face add to the gamma that
 // multiplies the old density the flux of gamma through them (io_gamma_contrib / compute_imposed_gamma, :374-417)
-template<bool OPEN>
+// MOVING: ENABLE_MOVING_BODIES.  The elements are where they were AND where they are: the normal of step n comes from
+// boundElement, that of the new state from boundElementNew (the Euler step turned it, sphx_sa_update_normals), the corners are
+// set up once per normal; gamma of the VERTEX rows is integrated by the same boundary terms instead of copied
+// (integrateGammaDevice<PT_VERTEX>, density_sum_impl src/cuda/euler.cu:112-160); boundary rows are left to the segment condition
+template<bool OPEN, bool MOVING = false>
 __global__ void __launch_bounds__(128)
 sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 {
 	const uint32_t index = blockIdx.x*128 + threadIdx.x;
 	if (index >= a.numParticles) return;
 	const particleinfo info = a.info[index];
-	if (PART_TYPE(info) != PT_FLUID) {
-		if (PART_TYPE(info) == PT_VERTEX || PART_TYPE(info) == PT_BOUNDARY) a.newGGam[index] = a.oldGGam[index];
+	const bool vertexRow = MOVING && PART_TYPE(info) == PT_VERTEX;
+	if (PART_TYPE(info) != PT_FLUID && !vertexRow) {
+		if (!MOVING && (PART_TYPE(info) == PT_VERTEX || PART_TYPE(info) == PT_BOUNDARY)) a.newGGam[index] = a.oldGGam[index];
 		return;
 	}
 	const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
@@ -616,8 +622,9 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 			if (moved < p.influenceradius) sumOpen -= nN.w*kernel_W<SPHX_WENDLAND>(p, moved);
 		}
 	};
-	float fw;
-	if (a.tiled && !(a.tileGuard && *a.tileGuard))
+	float fw = 0.0f;
+	if (vertexRow) { }      // a vertex has no density to sum
+	else if (a.tiled && !(a.tileGuard && *a.tileGuard))
 		fw = a.forces[index].w;
 	else {
 		for_each_neib<PT_FLUID, true>(p, w, index, posN, gridPos, volumic);
@@ -644,7 +651,13 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 		WallTri tri;       // one set-up, two positions
 		wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
 		const V3 gN = ns*(wall_grad_gamma(tri, qN)/p.slength);
-		const V3 gNp1 = ns*(wall_grad_gamma(tri, qNp1)/p.slength);
+		V3 nsNew = ns;
+		if (MOVING) {      // ... unless the element turned: its corners in the frame of the new normal
+			const float4 ben = a.boundElementNew[j];
+			nsNew = v3(ben.x, ben.y, ben.z);
+			wall_tri_setup(tri, nsNew, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+		}
+		const V3 gNp1 = nsNew*(wall_grad_gamma(tri, qNp1)/p.slength);
 		gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
 		gGam = gGam + gNp1;
 		if (OPEN && SA_IS_OPEN(a.info[j])) {
@@ -658,6 +671,7 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 	gGamDotR *= p.slength;
 	const float4 gGamN = a.oldGGam[index];
 	float4 g = make_float4(gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR);
+	if (vertexRow) { a.newGGam[index] = g; return; }      // integrateGammaDeviceFunc with dynamic gamma (:669-685): no clamp
 	const uint32_t fl = FLUID_NUM(info);
 	float gamOld = gGamN.w;
 	if (OPEN) {
@@ -949,8 +963,11 @@ static int sa_forces_check(sphx_ctx *ctx, const char *who)
 	const bool dsum = (q.simflags & SPHX_ENABLE_DENSITY_SUM) != 0, quad = (q.simflags & SPHX_ENABLE_GAMMA_QUADRATURE) != 0;
 	if (dsum == quad)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: built are ENABLE_DENSITY_SUM with dynamic gamma, and the continuity equation with ENABLE_GAMMA_QUADRATURE");
-	if (q.simflags & (SPHX_ENABLE_MOVING_BODIES | SPHX_ENABLE_XSPH | SPHX_ENABLE_PLANES))
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built without moving bodies, XSPH and planes");
+	// ENABLE_MOVING_BODIES: bodies with prescribed motion (segments and vertices flagged FG_MOVING_BOUNDARY); the pair terms read the
+	// elements' velocities from BUFFER_VEL as they do for walls at rest.  Bodies that FEEL the fluid (FG_COMPUTE_FORCE rows of
+	// BUFFER_RB_FORCES with SA_BOUNDARY) are not built.
+	if (q.simflags & (SPHX_ENABLE_XSPH | SPHX_ENABLE_PLANES))
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built without XSPH and planes");
 	if (q.sph_formulation != SPHX_SPH_F1)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built for SPH_F1");
 	if (!(q.densitydiffusiontype == SPHX_DENSITY_DIFFUSION_NONE || (dsum && q.densitydiffusiontype == SPHX_BREZZI)))
@@ -1022,7 +1039,11 @@ static int sa_forces_impl(sphx_ctx *ctx, void *forces, float *cfl, float *cflGam
 		a.tiled = used ? 1 : 0;
 		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
 			a.wallDone = 1;
-			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
+			// |grad gamma_as| kept from the density summation of this state: elements at rest only (a row is tagged with the
+			// particle's position, not with the elements')
+			if (!(ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES)) {
+				a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
+			}
 			rc = sphx_sa_wall_forces(ctx, a, st);
 			if (rc != SPHX_OK) return rc;
 		}
@@ -1172,8 +1193,9 @@ extern "C" int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void 
 	if (rc != SPHX_OK) return rc;
 	if (!(ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_integrate_gamma: dynamic gamma (transport equation) is not built; ENABLE_GAMMA_QUADRATURE is");
-	if (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_integrate_gamma: gamma of the vertices of moving bodies is not built");
+	// ENABLE_MOVING_BODIES: boundElements is BUFFER_BOUNDELEMENTS of the NEW state (quadrature_gamma_neib_data reads
+	// params.newBoundElement) and gamma of the vertex rows is integrated as well (integrate_gamma_impl, src/cuda/euler.cu:254-258)
+	const bool moving = (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES) != 0;
 	SPHX_REQUIRE(newGGam && oldGGam && newPos && boundElements && vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList,
 		"sphx_sa_integrate_gamma: missing buffer");
 	SPHX_REQUIRE(newGGam != oldGGam, "sphx_sa_integrate_gamma: in-place use is not supported");
@@ -1186,7 +1208,8 @@ extern "C" int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void 
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.numParticles = particleRangeEnd; a.epsilon = epsilon;
-	if (ctx->sa_wall && ctx->sa_wall_neibslist == neibsList && !ctx->disable_tiles) {
+	a.vertexRows = moving ? 1 : 0;
+	if (ctx->sa_wall && ctx->sa_wall_neibslist == neibsList && !ctx->disable_tiles && !moving) {
 		a.wallDone = 1;
 		a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
 		rc = sphx_sa_wall_integrate_gamma(ctx, a, (hipStream_t)stream);
@@ -1238,7 +1261,7 @@ extern "C" int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, v
 	if (!(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) || (ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_density_sum: needs ENABLE_DENSITY_SUM with dynamic gamma");
 	if (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_density_sum: moving bodies are not built");
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_density_sum: with ENABLE_MOVING_BODIES the boundary elements are double buffered: call sphx_sa_density_sum_moving");
 	if (ctx->params.sph_formulation != SPHX_SPH_F1 && ctx->params.sph_formulation != SPHX_SPH_F2)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_density_sum: SPH_HA is not built");
 	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldGGam && boundElements && vertPos0 && vertPos1 && vertPos2 &&
@@ -1268,6 +1291,41 @@ extern "C" int sphx_sa_density_sum(sphx_ctx *ctx, void *newVel, void *newGGam, v
 	}
 	sa_density_sum_kernel<false><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_kernel");
+	return SPHX_OK;
+}
+
+// density_sum with ENABLE_MOVING_BODIES (density_sum_impl<SA_BOUNDARY>, src/cuda/euler.cu:112-160): the old and the new
+// BUFFER_BOUNDELEMENTS (the read and the write list of the reference's call hold one each), fluid rows as sphx_sa_density_sum,
+// gamma of the vertex rows integrated, boundary rows untouched.  The list walker is the whole pass (the tiled window sums and
+// the wave-per-wall-particle kernels assume elements at rest).
+extern "C" int sphx_sa_density_sum_moving(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces,
+	const void *oldPos, const void *newPos, const void *oldVel, const void *oldGGam,
+	const void *oldBoundElements, const void *newBoundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_check(ctx, "density_sum called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	if (!(ctx->params.simflags & SPHX_ENABLE_DENSITY_SUM) || (ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_density_sum_moving: needs ENABLE_DENSITY_SUM with dynamic gamma");
+	if (!(ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES))
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_density_sum_moving: the uploaded option set has no ENABLE_MOVING_BODIES (call sphx_sa_density_sum)");
+	if (ctx->params.simflags & SPHX_ENABLE_INLET_OUTLET)
+		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_density_sum_moving: moving bodies together with open boundaries are not built");
+	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldGGam && oldBoundElements && newBoundElements &&
+		vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList, "sphx_sa_density_sum_moving: missing buffer");
+	SPHX_REQUIRE(newGGam != oldGGam && oldBoundElements != newBoundElements, "sphx_sa_density_sum_moving: gamma and the boundary elements are double buffered");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaDensitySumArgs a = {};
+	a.newVel = (float4*)newVel; a.newGGam = (float4*)newGGam; a.forces = (float4*)forces;
+	a.oldPos = (const float4*)oldPos; a.pos = (const float4*)newPos; a.oldVel = (const float4*)oldVel; a.oldGGam = (const float4*)oldGGam;
+	a.boundElement = (const float4*)oldBoundElements; a.boundElementNew = (const float4*)newBoundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
+	sa_density_sum_kernel<false, true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_density_sum_kernel<moving>");
 	return SPHX_OK;
 }
 

@@ -632,6 +632,16 @@ public:
 				bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, dt, NULL));
 			return;
 		}
+		if (m_c->params().simflags & ENABLE_MOVING_BODIES) {
+			// boundelements_density_sum_params (src/cuda/density_sum_params.h): with moving bodies BUFFER_BOUNDELEMENTS is a state
+			// buffer, the old one in the read list, the new one (read only) in the write list
+			sphx_throw(sphx_sa_density_sum_moving(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+				bufwrite.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_POS>(), newPos, bufread.getData<BUFFER_VEL>(),
+				bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), bufwrite.getConstData<BUFFER_BOUNDELEMENTS>(),
+				vertPos[0], vertPos[1], vertPos[2], bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+				bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, NULL));
+			return;
+		}
 		sphx_throw(sphx_sa_density_sum(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
 			bufwrite.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_POS>(), newPos, bufread.getData<BUFFER_VEL>(),
 			bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
@@ -648,8 +658,12 @@ public:
 		const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
 		if (!vertPos) throw std::invalid_argument("integrate_gamma: BUFFER_VERTPOS missing");
 		const float4 *newPos = bufreadUpdate.getConstData<BUFFER_POS>();
+		// with moving bodies the quadrature reads the elements of the NEW state (quadrature_gamma_neib_data,
+		// src/cuda/density_sum_kernel.cu:713-727) and the library integrates the vertex rows as well
+		const float4 *belem = (m_c->params().simflags & ENABLE_MOVING_BODIES) ? bufreadUpdate.getConstData<BUFFER_BOUNDELEMENTS>()
+			: bufread.getData<BUFFER_BOUNDELEMENTS>();
 		sphx_throw(sphx_sa_integrate_gamma(m_c->ctx(), bufreadUpdate.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_GRADGAMMA>(),
-			newPos, bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
+			newPos, belem, vertPos[0], vertPos[1], vertPos[2],
 			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
 			bufread.getData<BUFFER_NEIBSLIST>(), numParticles, particleRangeEnd, dt, step, t, epsilon, slength, influenceRadius,
 			run_mode == REPACK ? SPHX_REPACK : SPHX_SIMULATE, NULL));
@@ -691,6 +705,10 @@ public:
 			bufread.getData<BUFFER_POS>(), bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(),
 			bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_XSPH>(),
 			numParticles, particleRangeEnd, dt, NULL, 1.0f, step, t, slength, influenceRadius, (int)run_mode, NULL));
+		// update_normals (src/cuda/euler_kernel.def:237-254, sa_boundary_moving_euler_params): part of eulerDevice in the reference
+		if (m_c->params().boundarytype == SA_BOUNDARY && (m_c->params().simflags & ENABLE_MOVING_BODIES) && run_mode == SIMULATE)
+			sphx_throw(sphx_sa_update_normals(m_c->ctx(), bufwrite.getData<BUFFER_BOUNDELEMENTS>(), bufread.getData<BUFFER_BOUNDELEMENTS>(),
+				bufread.getData<BUFFER_INFO>(), numParticles, particleRangeEnd, NULL));
 	}
 
 	void disableFreeSurfParts(float4 *pos, const particleinfo *info, const uint numParticles, const uint particleRangeEnd)

@@ -192,6 +192,18 @@ class HipKernels:
                                                 p(cellStart), p(neibslist), n, range_end, float(dt), int(step), 0.0, 5e-5, P.deltap, P.slength,
                                                 P.influenceradius, self._s()))
 
+    # ---- SA_BOUNDARY with moving bodies (include/sphx.h)
+    def sa_update_normals(self, new_be, old_be, info, n, range_end):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_update_normals(self.ctx.handle, p(new_be), p(old_be), p(info), n, range_end, self._s()))
+
+    def sa_density_sum_moving(self, new_vel, new_ggam, forces, old_pos, new_pos, old_vel, old_ggam, old_be, new_be, vertpos, info, hash_,
+                              cellStart, neibslist, n, range_end):
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_density_sum_moving(self.ctx.handle, p(new_vel), p(new_ggam), p(forces), p(old_pos), p(new_pos), p(old_vel),
+                                                       p(old_ggam), p(old_be), p(new_be), p(vertpos[0]), p(vertpos[1]), p(vertpos[2]), p(info),
+                                                       p(hash_), p(cellStart), p(neibslist), n, range_end, self._s()))
+
     def sa_density_diffusion(self, forces, pos, vel, ggam, info, hash_, cellStart, neibslist, n, range_end, dt):
         """compute_density_diffusion (forces engine) + apply_density_diffusion (integration engine)"""
         p = capi.ptr

@@ -204,6 +204,11 @@ class MultiGpuEngine:
         # summation form, a rebuild in every iteration (the reference's open-boundary problems set buildneibsfreq = 1: a released
         # particle exists for the lists from the next rebuild on).  See _sa_post_euler_io.
         self.io = self.sa and bool(self.sp.simflags & D.ENABLE_INLET_OUTLET)
+        # SA bodies with prescribed motion: BUFFER_BOUNDELEMENTS is a state buffer (the Euler step turns the normals of the moving
+        # segments and vertices), boundelements2 holds it for the state n* / n+1 (PredictorCorrectorIntegrator.cc:408-418)
+        self.sa_moving = self.sa and bool(self.sp.simflags & D.ENABLE_MOVING_BODIES)
+        if self.sa_moving and (self.io or self.keps):
+            raise NotImplementedError("SA bodies with prescribed motion: not together with open boundaries or k-epsilon")
         if self.io:
             if not self.sa_density_sum or self.keps or self.sp.buildneibsfreq != 1:
                 raise NotImplementedError("open boundaries are built for the density summation form without k-epsilon, buildneibsfreq = 1")
@@ -328,11 +333,16 @@ class MultiGpuEngine:
         followed by the UPDATE_EXTERNAL of what it wrote"""
         K, n, ni = self.k, self.n_local, self.n_int
         ext = (lambda ts: self._exchange(ts)) if self.world > 1 else (lambda ts: None)
+        be_new = self.boundelements2 if self.sa_moving else self.boundelements      # the elements of the new state
         if self.sa_density_sum:
             # DENSITY_SUM [+ CALC_DENSITY_DIFFUSION + APPLY_DENSITY_DIFFUSION] (PredictorCorrectorIntegrator.cc:607-659): density and
             # gamma of the new state from the positions of step n and of the new state; BUFFER_FORCES is their scratch
-            K.sa_density_sum(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.gradgamma, self.boundelements,
-                             self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, ni)
+            if self.sa_moving:       # ... and from the elements where they were and where they are; gamma of the vertices too
+                K.sa_density_sum_moving(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.gradgamma,
+                                        self.boundelements, be_new, self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, ni)
+            else:
+                K.sa_density_sum(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.gradgamma, self.boundelements,
+                                 self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, ni)
             ext([self.vel2, self.gradgamma2])
             if self.sp.densitydiffusiontype == D.BREZZI:
                 dt = float(self.d_dt.item()) * (0.5 if step == 1 else 1.0)     # dt_op on the host, as the reference's command has it
@@ -340,7 +350,7 @@ class MultiGpuEngine:
                                        self.neibslist, n, ni, float(np.float32(dt)))
                 ext([self.vel2])
         else:
-            K.sa_integrate_gamma(self.gradgamma2, self.gradgamma, self.pos2, self.boundelements, self.vertpos, self.info, self.hash,
+            K.sa_integrate_gamma(self.gradgamma2, self.gradgamma, self.pos2, be_new, self.vertpos, self.info, self.hash,
                                  self.cellStart, self.neibslist, n, ni)
             ext([self.gradgamma2])
         if self.keps:
@@ -352,7 +362,7 @@ class MultiGpuEngine:
                                 self.cellStart, self.neibslist, n, ni, step)
             ext([self.vel2, ke["tke"], ke["eps"], ke["eulervel"]])
             return
-        K.sa_segment_bc(self.vel2, self.gradgamma2, self.pos2, self.vertices, self.boundelements, self.info, self.hash, self.cellStart,
+        K.sa_segment_bc(self.vel2, self.gradgamma2, self.pos2, self.vertices, be_new, self.info, self.hash, self.cellStart,
                         self.neibslist, n, ni, step, D.SIMULATE)
         ext([self.vel2, self.gradgamma2])
         K.sa_vertex_bc(self.vel2, self.gradgamma2, self.pos2, self.info, self.hash, self.cellStart, self.neibslist, n, ni, step, D.SIMULATE)
@@ -568,6 +578,7 @@ class MultiGpuEngine:
         # the forces entry of this option set, as a function of the particle range and the offset into the CFL array
         if self.sa:      # forces engine of SA_BOUNDARY: the state's gamma, the boundary elements, the vertex offsets of the segments
             ggam = self.gradgamma if pos is self.pos else self.gradgamma2
+            be = self.boundelements2 if (self.sa_moving and pos is not self.pos) else self.boundelements
 
             ke = (self.ke if pos is self.pos else self.ke2) if (self.keps and run_mode == D.SIMULATE) else None
             if ke is not None:
@@ -583,7 +594,7 @@ class MultiGpuEngine:
                     return K.forces_sa_io(self.forces, self.cfl, pos, vel, ev, self.info, self.hash, self.cellStart, self.neibslist, ggam,
                                           self.boundelements, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma)
                 return K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
-                                   self.boundelements, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma, run_mode=run_mode)
+                                   be, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma, run_mode=run_mode)
         elif self.effvisc_on and run_mode == D.SIMULATE:
             # CALC_VISC on the state the forces read (internal particles, then UPDATE_EXTERNAL); its largest kinematic viscosity
             # is the viscous limit of this pass's dt on this device (the dt of the step is the minimum over the devices)
@@ -692,6 +703,8 @@ class MultiGpuEngine:
         else:
             K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 0.5, 1, **ekw)
             self._rows_for = (self.vel2, self.vel2._version)
+        if self.sa_moving:           # update_normals of the Euler step: BUFFER_BOUNDELEMENTS of n* from that of n
+            K.sa_update_normals(self.boundelements2, self.boundelements, self.info, n, n)
         if self.energy_on:
             K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 0.5)
         if self.keps:
@@ -710,6 +723,8 @@ class MultiGpuEngine:
         else:
             K.euler(self.pos2, self.vel2, self.pos, self.vel, self.info, self.hash, self.forces, n, self.d_dt, 1.0, 2, **ekw)
             self._rows_for = (self.vel2, self.vel2._version)
+        if self.sa_moving:           # ... of n+1 from that of n (the full step's rotation)
+            K.sa_update_normals(self.boundelements2, self.boundelements, self.info, n, n)
         if self.energy_on:
             K.euler_internal_energy(self.energy2, self.energy, self.dedt, self.pos, self.info, n, self.d_dt, 1.0)
             self.energy, self.energy2 = self.energy2, self.energy
@@ -724,6 +739,8 @@ class MultiGpuEngine:
             if self.keps:
                 self.ke, self.ke2 = self.ke2, self.ke
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
+            if self.sa_moving:
+                self.boundelements, self.boundelements2 = self.boundelements2, self.boundelements
         if self.bodies is not None:                 # EULER_UPLOAD_OBJECTS_CG in the post-corrector phase (:331-332)
             K.set_body_cg_integration(m)
             self._last_motion = m

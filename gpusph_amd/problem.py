@@ -1012,6 +1012,53 @@ class SABox(Problem):
         return a
 
 
+class SAPaddleBox(SABox):
+    """SABox whose x = 0 wall is a MOVING body with prescribed motion (SA_BOUNDARY + ENABLE_MOVING_BODIES):
+    its segments and vertices carry FG_MOVING_BOUNDARY and object number 0, and turn about the hinge line x = 0, z = 0 (a flap
+    wave-maker, the SA counterpart of WaveTank's DYN paddle) while sliding along x -- rotation AND translation, so that the
+    normals (sphx_sa_update_normals), the old / new elements of the density summation and the velocities of the moving segments
+    all take part.  The reference has no ready-made problem of this kind without Crixus geometry files (CompleteSaExample.cu
+    builds its moving parts from HDF5 meshes); what this mirror pins is the option set and, pass by pass, the oracle's
+    restatement of the kernels.  A test geometry: the flap shares its edge vertices with the side walls and the floor, whose own
+    segments stay where they are (a real flap would be a separate plate); over the few steps of a parity run that gap is
+    1e-3 of deltap."""
+
+    def __init__(self, deltap=0.05, *, omega=3.0, slide=0.2, **kw):
+        super().__init__(deltap, **kw)
+        self.m_name = "SAPaddleBox"
+        sp = self.simparams
+        sp.simflags |= D.ENABLE_MOVING_BODIES
+        sp.numbodies = 1
+        sp.numforcesbodies = 0
+        self.flap_omega, self.flap_slide = float(omega), float(slide)
+        info, g = self.parts.info, self.parts.pos_global
+        t = info_type(info)
+        nrm = self.boundelements
+        flap = ((t == D.PT_VERTEX) & (np.abs(g[:, 0]) < 1e-9)) | ((t == D.PT_BOUNDARY) & (np.abs(g[:, 0]) < 1e-9) & (nrm[:, 0] > 0.5))
+        info[flap, 0] |= D.FG_MOVING_BOUNDARY
+        info[flap, 1] = (info[flap, 1] & 0xF000) | 0
+        self.flap = flap
+        self.num_obstacle = int(flap.sum())
+        self.rb_firstindex = np.zeros(1, dtype=np.int32)
+        cg = np.array([[0.0, 0.5*self.w, 0.0]])
+        self.rb_cg_global = cg.copy()
+        gcell = self.calc_grid_pos(cg)
+        self.rb_cg_gridpos = gcell.astype(np.int32)
+        self.rb_cg_pos = (cg - self.m_origin - (gcell + 0.5)*self.m_cellsize).astype(np.float32)
+        self.moving_bodies_callback = self._flap
+
+    def _flap(self, index, t0, t1, kd0, kd):
+        """constant angular velocity about y through the hinge + constant slide along x; the hinge travels with the slide"""
+        import math
+        w, u = self.flap_omega, self.flap_slide
+        kd.avel = np.array([0.0, w, 0.0]); kd.lvel = np.array([u, 0.0, 0.0])
+        a = w*(t1 - t0)
+        c, s = math.cos(a), math.sin(a)
+        dx = np.array([u*(t1 - t0), 0.0, 0.0])
+        kd.crot = kd.crot + dx
+        return dx, np.array([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]])
+
+
 class SAChannelIO(SABox):
     """An open channel on the SABox mesh, the synthetic counterpart of src/problems/ChannelIO.cu (whose geometry is a set of
     Crixus HDF5 files): the x = 0 wall of the tank is a VELOCITY-driven open boundary (u_E = U ex, setVelocityDriven(inlet, 1),

@@ -253,6 +253,27 @@ int sphx_forces_dtreduce_gamma_device(sphx_ctx *ctx, const float *cflGamma, uint
 	float *d_dt, void *stream);
 int sphx_forces_dtreduce_gamma(sphx_ctx *ctx, const float *cflGamma, uint32_t numParticles, uint32_t numBlocks,
 	float *h_dt_inout, void *stream);
+/* SA_BOUNDARY with ENABLE_MOVING_BODIES (bodies with prescribed motion; row f-2 of SURVEY.md 8).  What a caller does differently:
+ *   - BUFFER_BOUNDELEMENTS is double buffered; behind sphx_euler_basicstep, sphx_sa_update_normals writes that of the new state:
+ *     the normals of the moving segments and vertices turned by the body's step rotation (update_normals,
+ *     src/cuda/euler_kernel.def:237-254; the rotation is what sphx_set_rb_motion uploaded), the rest copied;
+ *   - density summation: sphx_sa_density_sum_moving with both boundary-element buffers (density_sum_impl, src/cuda/euler.cu:112-160;
+ *     the boundary terms take the elements where they were and where they are, src/cuda/density_sum_kernel.cu:455-470); gamma of
+ *     the VERTEX rows is integrated, not copied; the BOUNDARY rows of newGGam are not written (the segment condition re-derives
+ *     gamma in every step, boundary_conditions_kernel.cu:1467);
+ *   - gamma by quadrature: sphx_sa_integrate_gamma with the boundary elements of the NEW state; the vertex rows are integrated too
+ *     (integrate_gamma_impl, src/cuda/euler.cu:254-258);
+ *   - sphx_sa_segment_bc gives a moving segment the mean velocity of its vertices (moving_vertex_contrib,
+ *     boundary_conditions_kernel.cu:781-800); sphx_forces_basicstep_sa reads the elements' velocities from BUFFER_VEL as always.
+ * Not built: SA bodies that feel the fluid (object forces with SA_BOUNDARY), moving bodies together with open boundaries. */
+int sphx_sa_update_normals(sphx_ctx *ctx, void *newBoundElements, const void *oldBoundElements, const void *info,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
+int sphx_sa_density_sum_moving(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces,
+	const void *oldPos, const void *newPos, const void *oldVel, const void *oldGGam,
+	const void *oldBoundElements, const void *newBoundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
 /* AbstractIntegrationEngine::density_sum (src/cuda/euler.cu:112-200; densitySumVolumicDevice / densitySumBoundaryDevice,
  * src/cuda/density_sum_kernel.cu:523-655): density and (dynamic) gamma of the fluid from the old and the new positions;
  * newVel.w and newGGam are written, forces.w is scratch, gGam rows of vertex / boundary particles are copied */

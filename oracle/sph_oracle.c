@@ -3307,6 +3307,139 @@ void orc_sa_density_sum(const orc_params *p, orc_f4 *newVel, orc_f4 *newGGam, or
 	}
 }
 
+/* ---- SA_BOUNDARY with MOVING bodies (ENABLE_MOVING_BODIES; prescribed motion) -------------------------------------------------
+ * What changes against solid walls at rest (row f-2 of SURVEY.md 8):
+ *   - BUFFER_BOUNDELEMENTS is a state buffer: the Euler step rotates the normals of the moving segments and vertices
+ *     (update_normals, src/cuda/euler_kernel.def:237-254; applyrot euler_kernel.cu:67-74);
+ *   - the boundary terms of the density summation see the elements where they were and where they are: positions AND normals of
+ *     step n and of the new state (computeDensitySumBoundaryTerms, src/cuda/density_sum_kernel.cu:419-478: nsN from the old
+ *     BOUNDELEMENTS, nsNp1 from the new, the vertices' offsets re-derived with the new normal);
+ *   - gamma of the VERTEX particles is integrated like that of the fluid instead of copied (density_sum_impl /
+ *     integrate_gamma_impl, src/cuda/euler.cu:112-160,202-290): with dynamic gamma gamma^{n+1} = gamma^n + the boundary terms
+ *     (integrateGammaDeviceFunc :669-685), with ENABLE_GAMMA_QUADRATURE the quadrature of Gamma<PT_VERTEX> against the NEW
+ *     elements (:687-765; orc_sa_integrate_gamma_quadrature with cptype PT_VERTEX and the new BOUNDELEMENTS);
+ *   - the segment condition takes the velocity of a moving segment as the mean of its vertices' and re-derives gamma in every
+ *     step (moving_vertex_contrib boundary_conditions_kernel.cu:781-800, calcGam :1467; orc_sa_segment_bc has both). */
+void orc_sa_update_normals(const orc_params *p, orc_f4 *newBoundElem, const orc_f4 *oldBoundElem, const orc_info *infoArray,
+	uint32_t numParticles)
+{
+	for (uint32_t index = 0; index < numParticles; ++index) {
+		const orc_info info = infoArray[index];
+		orc_f4 normal = oldBoundElem[index];
+		if (MOVING(info) && (BOUNDARY(info) || VERTEX(info))) {
+			const float *rot = p->rbsteprot[OBJECT_NUM(info)];
+			const float rx = normal.x, ry = normal.y, rz = normal.z;      /* applyrot(rot, normal, normal) */
+			normal.x += (rot[0] - 1.0f)*rx + rot[1]*ry + rot[2]*rz;
+			normal.y += rot[3]*rx + (rot[4] - 1.0f)*ry + rot[5]*rz;
+			normal.z += rot[6]*rx + rot[7]*ry + (rot[8] - 1.0f)*rz;
+		}
+		newBoundElem[index] = normal;
+	}
+}
+
+/* the boundary terms of one particle between the old and the new state, elements old and new (:419-478) */
+static void density_sum_boundary_terms_moving(const orc_params *p, uint32_t index, const orc_f4 *oldPos, const orc_f4 *newPos,
+	const orc_f4 *boundelemOld, const orc_f4 *boundelemNew, const float *vertPos0, const float *vertPos1, const float *vertPos2,
+	const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList, v3 *gGamOut, float *gGamDotROut)
+{
+	const float slength = p->slength;
+	const orc_f4 posN = oldPos[index], posNp1 = newPos[index];
+	int gridPos[3];
+	orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+	const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
+	float gGamDotR = 0.0f;
+	v3 gGam = v3_make(0.0f, 0.0f, 0.0f);
+	neib_iter it;
+	uint32_t neib_index;
+	neib_iter_init(&it, p, PT_BOUNDARY, index, &posN, gridPos, cellStart, neibsList);
+	while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+		const orc_f4 nN = oldPos[neib_index];
+		if (INACTIVE(nN)) continue;
+		const orc_f4 nNp1 = newPos[neib_index];
+		const float inv = 1.0f/slength;
+		const v3 qN = v3_make((it.pos_corr[0] - nN.x)*inv, (it.pos_corr[1] - nN.y)*inv, (it.pos_corr[2] - nN.z)*inv);
+		const v3 qNp1 = v3_make(((it.pos_corr[0] - nNp1.x) + dx)*inv, ((it.pos_corr[1] - nNp1.y) + dy)*inv,
+			((it.pos_corr[2] - nNp1.z) + dz)*inv);
+		const orc_f4 beN = boundelemOld[neib_index], beNp1 = boundelemNew[neib_index];
+		const v3 nsN = v3_make(beN.x, beN.y, beN.z), nsNp1 = v3_make(beNp1.x, beNp1.y, beNp1.z);
+		v3 q_vb[3];
+		calc_vertex_rel_pos(q_vb, nsN, vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+			vertPos2 + 2*(size_t)neib_index, slength);
+		const v3 gN = v3_scale(nsN, grad_gamma_wendland(slength, qN, q_vb, nsN));
+		calc_vertex_rel_pos(q_vb, nsNp1, vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+			vertPos2 + 2*(size_t)neib_index, slength);
+		const v3 gNp1 = v3_scale(nsNp1, grad_gamma_wendland(slength, qNp1, q_vb, nsNp1));
+		gGamDotR += 0.5f*v3_dot(v3_add(gN, gNp1), v3_sub(qNp1, qN));
+		gGam = v3_add(gGam, gNp1);
+	}
+	*gGamOut = gGam;
+	*gGamDotROut = gGamDotR*slength;
+}
+
+/* density_sum_impl<SA_BOUNDARY> with ENABLE_MOVING_BODIES (src/cuda/euler.cu:112-160): the fluid rows as orc_sa_density_sum with
+ * the boundary terms above; the VERTEX rows' gamma by the same boundary terms (integrateGammaDevice<PT_VERTEX>, dynamic gamma);
+ * the BOUNDARY rows are not written by any of the three kernels (the segment condition re-derives them): they keep what the
+ * caller put into newGGam. */
+void orc_sa_density_sum_moving(const orc_params *p, orc_f4 *newVel, orc_f4 *newGGam, orc_f4 *forces,
+	const orc_f4 *oldPos, const orc_f4 *newPos, const orc_f4 *oldVel, const orc_f4 *oldGGam,
+	const orc_f4 *boundelemOld, const orc_f4 *boundelemNew,
+	const float *vertPos0, const float *vertPos1, const float *vertPos2, const orc_info *infoArray,
+	const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList, uint32_t particleRangeEnd)
+{
+	const float kr = 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const float slength = p->slength;
+#pragma omp parallel for schedule(dynamic, 256)
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (VERTEX(info)) {
+			v3 gGam; float gGamDotR;
+			density_sum_boundary_terms_moving(p, index, oldPos, newPos, boundelemOld, boundelemNew, vertPos0, vertPos1, vertPos2,
+				hashArray, cellStart, neibsList, &gGam, &gGamDotR);
+			const orc_f4 g = { gGam.x, gGam.y, gGam.z, oldGGam[index].w + gGamDotR };
+			newGGam[index] = g;
+			continue;
+		}
+		if (!FLUID(info)) continue;
+		const orc_f4 posN = oldPos[index], posNp1 = newPos[index];
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
+		float sumPmwN = 0.0f, sumPmwNp1 = 0.0f;
+		for (int nptype = PT_FLUID; nptype <= PT_VERTEX; nptype += 2) {
+			neib_iter it;
+			uint32_t neib_index;
+			neib_iter_init(&it, p, nptype, index, &posN, gridPos, cellStart, neibsList);
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 nN = oldPos[neib_index];
+				if (INACTIVE(nN)) continue;
+				const orc_f4 nNp1 = newPos[neib_index];
+				const float rx = it.pos_corr[0] - nN.x, ry = it.pos_corr[1] - nN.y, rz = it.pos_corr[2] - nN.z;
+				const float qx = (it.pos_corr[0] - nNp1.x) + dx, qy = (it.pos_corr[1] - nNp1.y) + dy, qz = (it.pos_corr[2] - nNp1.z) + dz;
+				const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+				sumPmwN -= nN.w*W_c(p->kerneltype, rN, slength, wcoeff, wsub);
+				const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
+				if (rNp1 < p->influenceradius)
+					sumPmwNp1 += nN.w*W_c(p->kerneltype, rNp1, slength, wcoeff, wsub);
+			}
+		}
+		forces[index].w = sumPmwNp1 + sumPmwN + 0.0f;
+		v3 gGam; float gGamDotR;
+		density_sum_boundary_terms_moving(p, index, oldPos, newPos, boundelemOld, boundelemNew, vertPos0, vertPos1, vertPos2,
+			hashArray, cellStart, neibsList, &gGam, &gGamDotR);
+		const orc_f4 gGamN = oldGGam[index];
+		orc_f4 g = { gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR };
+		const int fl = FLUID_NUM(info);
+		const float rho = (gGamN.w*physical_density(p, oldVel[index].w, fl) + forces[index].w)/g.w;
+		if (g.w > 1.0f || sqrtf(g.x*g.x + g.y*g.y + g.z*g.z)*slength < 1e-10f)
+			g.w = 1.0f;
+		else if (g.w < 0.1f)
+			g.w = 0.1f;
+		newVel[index].w = rho/p->rho0[fl] - 1.0f;
+		newGGam[index] = g;
+	}
+}
+
 /* computeDensityDiffusionDevice<.., BREZZI, SA_BOUNDARY, PT_FLUID> (src/cuda/forces_kernel.def:4515-4560): the Brezzi term over
  * the fluid neighbours (:1766-1783; boundary elements only contribute at pressure inlets), divided by gamma and rho0,
  * written to forces.w; updateDensityDevice (src/cuda/euler_kernel.cu:116-136) then adds forces.w dt to the density */

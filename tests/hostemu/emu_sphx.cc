@@ -9,6 +9,8 @@ thread_local dim3 blockIdx, threadIdx, blockDim, gridDim;
 // run calls some of them) with its launches rewritten into _build/sa_bounds_emu.inc by tests/hostemu_lib.py.  The tiled window and
 // the wall-particle kernels it can hand over to live in other files: absent here, so every pass is its list walker.
 #include "sa_bounds_emu.inc"
+// euler.hip (the Euler step and, with moving SA bodies, the normals of the new state), launches rewritten the same way
+#include "euler_emu.inc"
 int sphx_sa_tiles_run(sphx_ctx *, int, void *, const void *, const void *, const void *, const void *, const uint32_t *, const uint32_t *,
 	const uint16_t *, const void *, uint32_t, uint32_t, uint32_t, float, hipStream_t, bool *used, const uint32_t **guard)
 { if (used) *used = false; if (guard) *guard = nullptr; return SPHX_OK; }

@@ -36,7 +36,8 @@ struct alignas(8)  uint2  { unsigned x, y; };
 struct alignas(8)  ushort4 { unsigned short x, y, z, w; };
 struct alignas(8)  short4  { short x, y, z, w; };
 struct alignas(16) double2 { double x, y; };
-struct dim3 { unsigned x = 1, y = 1, z = 1; dim3() {} dim3(unsigned a, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct dim3 { unsigned x = 1, y = 1, z = 1; dim3() {} dim3(unsigned a, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+	explicit operator unsigned() const { return x; } };      // one-dimensional launches only
 static inline float2 make_float2(float x, float y) { return float2{x, y}; }
 static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }

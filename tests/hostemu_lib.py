@@ -15,8 +15,8 @@ _EMU = os.path.join(_HERE, "hostemu")
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_EMU, "_build", "libsphx_emu_asan.so" if os.environ.get("SPHX_HOSTEMU_ASAN") == "1" else "libsphx_emu.so")
 _SOURCES = [os.path.join(_EMU, "emu_sphx.cc"), os.path.join(_EMU, "hip", "hip_runtime.h")] + \
-    [os.path.join(_ROOT, "gpusph_amd", "csrc", f) for f in ("sphx_api.hip", "sa_io.hip", "sa_bounds.hip", "sphx_internal.h", "neib_iter.h",
-                                                              "sa_wall_gamma.h", "sa_args.h")] + \
+    [os.path.join(_ROOT, "gpusph_amd", "csrc", f) for f in ("sphx_api.hip", "sa_io.hip", "sa_bounds.hip", "euler.hip", "sphx_internal.h",
+                                                              "neib_iter.h", "wave_list.h", "sa_wall_gamma.h", "sa_args.h")] + \
     [os.path.join(_ROOT, "include", "sphx.h")]
 
 # the entry points of the two files
@@ -26,7 +26,10 @@ NAMES = ["sphx_create", "sphx_destroy", "sphx_set_constants", "sphx_last_error",
          "sphx_sa_density_sum_io", "sphx_forces_basicstep_sa_io", "sphx_sa_compute_density_diffusion_io", "sphx_sa_io_water_depth", "sphx_flux_computation",
          # sa_bounds.hip, list walkers only
          "sphx_sa_compute_vertex_normal", "sphx_sa_init_gamma", "sphx_sa_segment_bc", "sphx_sa_vertex_bc", "sphx_sa_density_sum",
-         "sphx_sa_compute_density_diffusion", "sphx_apply_density_diffusion", "sphx_sa_integrate_gamma", "sphx_forces_basicstep_sa"]
+         "sphx_sa_compute_density_diffusion", "sphx_apply_density_diffusion", "sphx_sa_integrate_gamma", "sphx_forces_basicstep_sa",
+         "sphx_sa_density_sum_moving",
+         # euler.hip
+         "sphx_sa_update_normals", "sphx_set_rb_motion"]
 
 
 def _rewrite_launches(src, dst):
@@ -45,6 +48,7 @@ def build():
     if os.path.exists(_SO) and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in _SOURCES):
         return _SO
     _rewrite_launches(os.path.join(_ROOT, "gpusph_amd", "csrc", "sa_bounds.hip"), os.path.join(_EMU, "_build", "sa_bounds_emu.inc"))
+    _rewrite_launches(os.path.join(_ROOT, "gpusph_amd", "csrc", "euler.hip"), os.path.join(_EMU, "_build", "euler_emu.inc"))
     # -ffp-contract=off as the library's own build of these files; -O1: compile time
     # SPHX_HOSTEMU_ASAN=1: an address-sanitised build, for a run under LD_PRELOAD=libasan.so (out-of-bounds reads and writes of the
     # kernels on the exact-size numpy buffers of these tests; see tests/hostemu/README)

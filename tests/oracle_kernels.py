@@ -263,9 +263,22 @@ class OracleKernels:
     def sa_integrate_gamma(self, new_ggam, old_ggam, new_pos, boundelements, vertpos, info, hash_, cellStart, neibslist, n, range_end,
                            epsilon=5e-5):
         new_ggam[:n] = old_ggam[:n]
-        self.L.orc_sa_integrate_gamma_quadrature(C.byref(self.op), _p(new_ggam), _p(old_ggam), _p(new_pos), _p(boundelements), _p(vertpos[0]),
-                                                 _p(vertpos[1]), _p(vertpos[2]), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
-                                                 C.c_uint32(range_end), C.c_int(0), C.c_float(epsilon))
+        from gpusph_amd import defs as D
+        moving = bool(int(self.op.simflags) & D.ENABLE_MOVING_BODIES)
+        for cptype in ((0, 2) if moving else (0,)):      # with moving bodies the vertex rows are integrated too
+            self.L.orc_sa_integrate_gamma_quadrature(C.byref(self.op), _p(new_ggam), _p(old_ggam), _p(new_pos), _p(boundelements), _p(vertpos[0]),
+                                                     _p(vertpos[1]), _p(vertpos[2]), _p(info), _p(hash_), _p(cellStart), _p(neibslist),
+                                                     C.c_uint32(range_end), C.c_int(cptype), C.c_float(epsilon))
+
+    # ---- SA_BOUNDARY with moving bodies
+    def sa_update_normals(self, new_be, old_be, info, n, range_end):
+        self.L.orc_sa_update_normals(C.byref(self.op), _p(new_be), _p(old_be), _p(info), C.c_uint32(range_end))
+
+    def sa_density_sum_moving(self, new_vel, new_ggam, forces, old_pos, new_pos, old_vel, old_ggam, old_be, new_be, vertpos, info, hash_,
+                              cellStart, neibslist, n, range_end):
+        self.L.orc_sa_density_sum_moving(C.byref(self.op), _p(new_vel), _p(new_ggam), _p(forces), _p(old_pos), _p(new_pos), _p(old_vel),
+                                         _p(old_ggam), _p(old_be), _p(new_be), _p(vertpos[0]), _p(vertpos[1]), _p(vertpos[2]), _p(info),
+                                         _p(hash_), _p(cellStart), _p(neibslist), C.c_uint32(range_end))
 
     # ---- SA open boundaries (ENABLE_INLET_OUTLET): the interface of HipKernels' *_io methods over the oracle's restatements
     def _vp(self, vertpos):

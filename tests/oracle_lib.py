@@ -335,6 +335,33 @@ class Oracle:
                                   P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n))
         return v, g
 
+    # ---- SA_BOUNDARY with moving bodies (oracle/sph_oracle.c "SA_BOUNDARY with MOVING bodies")
+    def sa_update_normals(self, boundelements, info, n):
+        """update_normals of the Euler step: the normals of moving segments and vertices turned by the body's step rotation"""
+        out = boundelements.copy()
+        self.L.orc_sa_update_normals(C.byref(self.p), P(out), P(boundelements), P(info), C.c_uint32(n))
+        return out
+
+    def sa_density_sum_moving(self, new_vel, old_pos, new_pos, old_vel, old_ggam, new_ggam_in, be_old, be_new, vertpos, info, hash_, cs, nl, n):
+        """density_sum with ENABLE_MOVING_BODIES: fluid rows (density, gamma) and vertex rows (gamma); the boundary rows keep
+        new_ggam_in's"""
+        v = new_vel.copy(); g = new_ggam_in.copy()
+        scratch = np.zeros((len(old_pos), 4), dtype=np.float32)
+        self.L.orc_sa_density_sum_moving(C.byref(self.p), P(v), P(g), P(scratch), P(old_pos), P(new_pos), P(old_vel), P(old_ggam),
+                                         P(be_old), P(be_new), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(info), P(hash_), P(cs), P(nl),
+                                         C.c_uint32(n))
+        return v, g
+
+    def sa_integrate_gamma_moving(self, old_ggam, new_pos, be_new, vertpos, info, hash_, cs, nl, n, epsilon=5e-5):
+        """integrate_gamma with ENABLE_GAMMA_QUADRATURE and ENABLE_MOVING_BODIES: fluid AND vertex rows by quadrature against the
+        new elements, boundary rows copied"""
+        g = old_ggam.copy()
+        for cptype in (0, 2):
+            self.L.orc_sa_integrate_gamma_quadrature(C.byref(self.p), P(g), P(old_ggam), P(new_pos), P(be_new), P(vertpos[0]),
+                                                     P(vertpos[1]), P(vertpos[2]), P(info), P(hash_), P(cs), P(nl), C.c_uint32(n),
+                                                     C.c_int(cptype), C.c_float(epsilon))
+        return g
+
     def sa_density_diffusion(self, pos, vel, ggam, info, hash_, cs, nl, n, dt):
         """compute_density_diffusion (Brezzi) + apply_density_diffusion: returns the updated velocity array"""
         f = np.zeros((len(pos), 4), dtype=np.float32)

@@ -208,10 +208,78 @@ class OracleSaSim:
         self.iterations += 1
         self.dt = dt1
 
+    # ---- SA bodies with prescribed motion (ENABLE_MOVING_BODIES): the command sequence of PredictorCorrectorIntegrator.cc:386-685
+    # with BUFFER_BOUNDELEMENTS as a state buffer (:408-418), restated independently of gpusph_amd.multigpu
+    def _move_bodies(self, step, dt):
+        m = self.bodies.timestep(step, dt, self.t)
+        p = self.o.p
+        for b in range(len(self.bodies)):
+            for a in range(3):
+                p.rbtrans[b][a] = float(m["trans"][b][a]); p.rblinearvel[b][a] = float(m["lvel"][b][a])
+                p.rbangularvel[b][a] = float(m["avel"][b][a])
+            for a in range(9):
+                p.rbsteprot[b][a] = float(m["rot"][b][a])
+        self._last_motion = m
+
+    def _post_euler_moving(self, ps, vs, be_new, hdt):
+        o, n = self.o, self.n
+        sp = self.problem.simparams
+        if sp.simflags & D.ENABLE_DENSITY_SUM:
+            vs, gs = o.sa_density_sum_moving(vs, self.pos, ps, self.vel, self.gg, self.gg, self.be, be_new, self.vertpos, self.info,
+                                             self.hash, self.cs, self.nl, n)
+            if sp.densitydiffusiontype == D.BREZZI:
+                vs, _ = o.sa_density_diffusion(ps, vs, gs, self.info, self.hash, self.cs, self.nl, n, hdt)
+        else:
+            gs = o.sa_integrate_gamma_moving(self.gg, ps, be_new, self.vertpos, self.info, self.hash, self.cs, self.nl, n)
+        return vs, gs
+
+    def _bc_moving(self, pos, vel, gg, be, step):
+        o, n = self.o, self.n
+        vel, gg = o.sa_segment_bc(pos, vel, gg, self.vertices, be, self.info, self.hash, self.cs, self.nl, n, step=step)
+        return o.sa_vertex_bc(pos, vel, gg, self.info, self.hash, self.cs, self.nl, n), gg
+
+    def step_moving(self):
+        from gpusph_amd.bodies import MovingBodies
+        o, n, p = self.o, self.n, self.problem
+        if getattr(self, "bodies", None) is None:
+            self.bodies = MovingBodies(p, p.rb_cg_global)
+            for b in range(len(self.bodies)):      # the centre of rotation the Euler step reads (uploaded at start and after every step)
+                for a in range(3):
+                    o.p.rbcgGridPosE[b][a] = int(p.rb_cg_gridpos[b][a]); o.p.rbcgPosE[b][a] = float(p.rb_cg_pos[b][a])
+        dp = p.m_deltap
+        dt = float(np.float32(self.dt))
+        hdt = float(np.float32(dt)/np.float32(2))
+        A = (self.info, self.hash, self.cs, self.nl)
+        f1, cfl, nb = o.forces_sa(self.pos, self.vel, *A, self.gg, self.be, self.vertpos, n, dp)
+        dt1 = self._dt(cfl, nb)
+        self._move_bodies(1, dt)
+        ps, vs = o.euler(self.pos, self.vel, self.info, self.hash, f1, n, hdt, 1)
+        bes = o.sa_update_normals(self.be, self.info, n)
+        vs, gs = self._post_euler_moving(ps, vs, bes, hdt)
+        vs, gs = self._bc_moving(ps, vs, gs, bes, 1)
+        f2, cfl, nb = o.forces_sa(ps, vs, *A, gs, bes, self.vertpos, n, dp)
+        dt2 = self._dt(cfl, nb)
+        self._move_bodies(2, dt)
+        pn, vn = o.euler(self.pos, self.vel, self.info, self.hash, f2, n, dt, 2)
+        ben = o.sa_update_normals(self.be, self.info, n)
+        vn, gn = self._post_euler_moving(pn, vn, ben, dt)
+        vn, gn = self._bc_moving(pn, vn, gn, ben, 2)
+        m = self._last_motion
+        for b in range(len(self.bodies)):
+            for a in range(3):
+                o.p.rbcgGridPosE[b][a] = int(m["cg_grid"][b][a]); o.p.rbcgPosE[b][a] = float(m["cg_pos"][b][a])
+        self.forces = f2
+        self.pos, self.vel, self.gg, self.be = pn, vn, gn, ben
+        self.t += dt
+        self.dt = min(dt1, dt2)
+        self.iterations += 1
+
     def step(self):
         """no neighbour rebuild here: the runs compared are shorter than buildneibsfreq"""
         if self.keps:
             return self.step_keps()
+        if self.problem.simparams.simflags & D.ENABLE_MOVING_BODIES:
+            return self.step_moving()
         o, n, p = self.o, self.n, self.problem
         dp = p.m_deltap
         dt = float(np.float32(self.dt))
