@@ -22,9 +22,11 @@ python scripts/time_sa.py 0.008 StillWaterSA 20 > $OUT/sa_4M_density_sum.txt 2>&
 python scripts/time_sa.py 0.008 StillWaterRepackSA 20 > $OUT/sa_4M_quadrature.txt 2>&1
 python scripts/time_sa.py 0.0045 StillWaterSA 20 > $OUT/sa_23M_density_sum.txt 2>&1
 SPHX_DISABLE_TILES=1 python scripts/time_sa.py 0.008 StillWaterSA 20 > $OUT/sa_4M_density_sum_list_walkers.txt 2>&1
+# both tiled kernels of an SPS step against the HBM roofline
+bash scripts/sps_roofline.sh 8e6 > $OUT/sps_roofline_8M.txt 2>&1
 # the neighbour phase alone
 python scripts/time_neibs.py 32e6 > $OUT/neibs_32M.txt 2>&1
-grep -h "ms/step\|rebuild ms" $OUT/*.txt
+grep -h "ms/step\|rebuild ms\|of the HBM roofline" $OUT/*.txt
 for f in $OUT/bench*.json; do python - "$f" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
