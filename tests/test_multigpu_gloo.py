@@ -44,6 +44,9 @@ def _worker(rank, world, port, steps, case, outdir, filters=()):
     elif which == "SABox":
         from gpusph_amd.problem import SABox
         prob = SABox(**case)
+    elif which == "SAPaddleBox":
+        from gpusph_amd.problem import SAPaddleBox
+        prob = SAPaddleBox(**case)
     elif which == "OpenChannel":
         from gpusph_amd.problem import OpenChannel
         prob = OpenChannel(**case)
@@ -318,6 +321,10 @@ FIDELITY_CASES = {
     # k-epsilon on SA walls: k, epsilon, eddy viscosity and Eulerian velocity travel with the halo, DKDE with the forces, the
     # boundary conditions export the wall rows they wrote
     "sa-keps": dict(problem="SABox", deltap=0.05, jitter=0.1, viscosity=dict(rheologytype=1, turbmodel=3)),
+    # SA bodies with prescribed motion: the flap straddles the cut; BUFFER_BOUNDELEMENTS is a state buffer whose halo copies are
+    # turned by the same body motion, the vertex rows' gamma travels with the density summation / gamma integration
+    "sa-moving-density-sum": dict(problem="SAPaddleBox", deltap=0.05, options="StillWaterSA", jitter=0.1),
+    "sa-moving-quadrature": dict(problem="SAPaddleBox", deltap=0.05, options="StillWaterRepackSA", jitter=0.1),
     # OpenChannel's options: slabs cut ACROSS the periodic stream, i.e. a ring of two devices (each is the other's left and right)
     "open-channel-ring": dict(problem="OpenChannel", deltap=0.05, linearization="yzx"),
 }
