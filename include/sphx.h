@@ -305,9 +305,11 @@ int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void *oldGGam, c
 int sphx_sa_compute_vertex_normal(sphx_ctx *ctx, void *boundElements, const void *vertices, const void *info,
 	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, void *stream);
-/* ---- the same engine, open boundaries (ENABLE_INLET_OUTLET): the initialisation kernels and the outgoing-particle kernels.
- * The boundary-condition passes, the density summation and the forces with open boundaries are NOT built: the entry points
- * above and sphx_forces_basicstep_sa / sphx_sa_density_sum still answer SPHX_ERR_UNSUPPORTED when the flag is set. ---- */
+/* ---- the same engine, open boundaries (ENABLE_INLET_OUTLET; gpusph_amd/csrc/sa_io.hip: one wave per open vertex / segment /
+ * leaving particle over an index of the pass): initialisation, outgoing particles, the two condition passes, the
+ * water depth, the flux; the passes over all fluid particles (density summation, forces, density diffusion) are the *_io entry
+ * points further down.  A context with the flag set calls THESE (the plain sphx_sa_segment_bc / _vertex_bc / _density_sum /
+ * sphx_forces_basicstep_sa do not know the open boundaries' terms). ---- */
 /* saIdentifyCornerVertices (src/cuda/boundary_conditions.cu:667-700): a vertex of an open boundary that also belongs to a
  * segment not of that open boundary gets FG_CORNER in info (in place) */
 int sphx_sa_identify_corner_vertices(sphx_ctx *ctx, const void *pos, void *info, const uint32_t *hash, const void *vertices,
