@@ -924,6 +924,17 @@ __device__ __forceinline__ void acc_load(const ListStream &ls, uint32_t firstBat
 	else if (REG == 12) SPHX_ACC_LOAD(12, 13); else SPHX_ACC_LOAD(14, 15);
 #undef SPHX_ACC_LOAD
 }
+// the ring's own loads inside the pair loop: a running scalar base (advanced once per ring cycle by the caller) and an immediate
+// offset per buffer -- no clamp, no index arithmetic per batch: past the end of a wave's share the loads read the next share (or the
+// allocation's slack behind the last one, sphx_ensure_tile_lists), rows that are gathered and never computed
+template<int REG, int OFF>
+__device__ __forceinline__ void acc_load_at(const char *base, uint32_t lane8)
+{
+	static_assert(REG >= 0 && REG < 8 && (REG & 1) == 0 && OFF >= 0 && OFF < 4096, "a register pair of the ring, a 12-bit offset");
+#define SPHX_ACC_LOAD_AT(R0, R1) asm volatile("global_load_dwordx2 a[" #R0 ":" #R1 "], %0, %1 offset:%2 ; ACCRING" :: "v"(lane8), "s"(base), "n"(OFF) : SPHX_ACC_CLOBBERS)
+	if (REG == 0) SPHX_ACC_LOAD_AT(0, 1); else if (REG == 2) SPHX_ACC_LOAD_AT(2, 3); else if (REG == 4) SPHX_ACC_LOAD_AT(4, 5); else SPHX_ACC_LOAD_AT(6, 7);
+#undef SPHX_ACC_LOAD_AT
+}
 // buffer REG/2 of the ring -> two ordinary registers (the batch has landed: acc_wait, or it was requested a tile ahead)
 template<int REG>
 __device__ __forceinline__ uint2 acc_read()
@@ -986,7 +997,7 @@ __device__ __forceinline__ WaveJob wave_job(uint32_t rt /* this lane's word of t
 	return j;
 }
 
-template<int KERNEL, int TURB, int COLAGROSSI, bool LJ>
+template<int KERNEL, int TURB, int COLAGROSSI, bool LJ, bool HIW>
 __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &a, const ListStream &ls, const WaveJob &wj, uint32_t rt,
 	uint32_t lane, float inv_h, const float4 *sPos, const float4 *sVel, const float4 *sAux, float4 *sPart, const uint32_t *sLaneRec,
 	float *sVal, ListWindow &lw /* batches 0..TILE_AHEAD-1 of the wave's stream, already requested */)
@@ -1093,7 +1104,7 @@ __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &
 	// also after the last batch (a clamped, in-bounds prefetch whose rows are never computed).
 	// The two waves of a SIMD (w and w + 4) take turns at being the one the issue arbiter prefers, batch by batch (priorities
 	// 3,3,0,0 against 2,1,2,1): left alone the older wave always wins and the younger one is starved while both have work
-	const bool hiw = (TILE_WAVES > 4) ? (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0) : (((blockIdx.x/256u) & 1u) != 0u);
+	constexpr bool hiw = HIW;      // which of the two waves of its SIMD this one is: a copy of the walk per value, no branch per batch
 #ifndef TILE_PRIO_VARIANT
 #define TILE_PRIO_VARIANT 0
 #endif
@@ -1119,16 +1130,18 @@ __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &
 	if (ASMR) {
 		// the ring lives in a0..a7 (AccRing above); `cur` is the batch being walked, in ordinary registers
 		acc_start_ring(lw);
+		const char *ringBase = reinterpret_cast<const char*>(ls.list + ((size_t)__builtin_amdgcn_readfirstlane(wj.firstBatch) + TILE_AHEAD)*64u);
 		uint2 cur = lw.q[0];
 		gather_half<TURB>(cur.x, sPos, sVel, sAux, p.rho0[0], A);
 #define SPHX_RING_STEP(J, JN) \
 		SPHX_RING_PRIO(J) \
 		gather_half<TURB>(cur.y, sPos, sVel, sAux, p.rho0[0], B); \
 		compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
-		acc_load<2*(J)>(ls, wj.firstBatch, next, last, lane8);      /* buffer J is free: its batch is in `cur` */ \
-		++next; \
-		/* the batch to gather next: requested a tile ahead if it is one of the first TILE_AHEAD, else TILE_AHEAD - 1 loads ago */ \
-		if (next >= 2*TILE_AHEAD) acc_wait(); \
+		acc_load_at<2*(J), (J)*512>(ringBase, lane8);      /* buffer J is free: its batch is in `cur` */ \
+		if ((J) == TILE_AHEAD - 1) ringBase += TILE_AHEAD*512; \
+		/* the batch to gather next: requested a tile ahead if it is one of the first TILE_AHEAD (then fewer than TILE_AHEAD loads \
+		 * are in flight and the wait is a no-op), else TILE_AHEAD - 1 loads ago */ \
+		acc_wait(); \
 		cur = acc_read<2*(JN)>(); \
 		gather_half<TURB>(cur.x, sPos, sVel, sAux, p.rho0[0], A); \
 		compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
@@ -1602,8 +1615,12 @@ forces_tile_kernel(DevParams p, ForcesArgs a, const uint32_t *__restrict__ tiles
 
 		SPHX_PROF(7);
 		// 4. the pair phase: this wave's share of the tile's list batches
-		if (inRange && pairs && wj.nRuns)
-			walk_runs<KERNEL, TURB, COLAGROSSI, LJ>(p, a, stream, wj, rtc, lane, inv_h, sPos, sVel, sAux, sPart, sLaneRec[par], sVal, ac.lw);
+		if (inRange && pairs && wj.nRuns) {
+			if ((TILE_WAVES > 4) ? (__builtin_amdgcn_readfirstlane(threadIdx.x >> 8) != 0) : (((blockIdx.x/256u) & 1u) != 0u))
+				walk_runs<KERNEL, TURB, COLAGROSSI, LJ, true>(p, a, stream, wj, rtc, lane, inv_h, sPos, sVel, sAux, sPart, sLaneRec[par], sVal, ac.lw);
+			else
+				walk_runs<KERNEL, TURB, COLAGROSSI, LJ, false>(p, a, stream, wj, rtc, lane, inv_h, sPos, sVel, sAux, sPart, sLaneRec[par], sVal, ac.lw);
+		}
 		havePrev = inRange;
 #ifdef SPHX_TILE_DEBUG_BUILD
 		if (prof) pacc[9] += 1;

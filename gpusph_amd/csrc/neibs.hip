@@ -625,6 +625,9 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 				const bool in = j0 < fluidEnd;
 				float4 cp[NEIB_MLP];
 				if (BUF) {
+					// (j0 < 2^28 with a position array below 4 GB: the row offsets j0*16 + 16 u cannot wrap, so they may ride in the
+					// instruction's immediate instead of costing a shift and an add per candidate)
+					__builtin_assume(j0 < (1u << 28) - 4u);
 #pragma unroll
 					for (int u = 0; u < NEIB_MLP; ++u) cp[u] = load_pos_row(posRsrc, j0*16u, u);
 				} else {
@@ -660,12 +663,12 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 				}
 #pragma unroll
 				for (int u = 0; u < NEIB_MLP; ++u) {
-					const uint32_t neib_index = j0 + (uint32_t)u;
-					const bool acc = (r2[u] < sqinfluenceradius) && ((uint32_t)u < rem) && (neib_index != index) &&
+					// (the candidate's index j0 + u is named nowhere: its row offset is an immediate of the load above)
+					const bool acc = (r2[u] < sqinfluenceradius) && ((uint32_t)u < rem) && (jrel + (uint32_t)u != selfrel) &&
 						is_active_w(cp[u].w);
 					nf += acc ? 1u : 0u;
 					const bool ok = acc && !too_many_neibs(p, nf, nb, nv, PT_FLUID);
-					ring.fring[ring.sf % (uint32_t)NEIB_FRING][lane] = (neibdata)((neib_index - bucketStart) + encv);
+					ring.fring[ring.sf % (uint32_t)NEIB_FRING][lane] = (neibdata)((jrel + (uint32_t)u) + encv);
 					ring.sf += ok ? 1u : 0u;
 					encv = ok ? 0u : encv;
 				}
