@@ -150,14 +150,18 @@ class MultiGpuEngine:
         self.cellEnd = torch.empty(self.ncells, dtype=i32, device=dev)
         self.neibslist = torch.empty(int(self.sp.neiblistsize) * A, dtype=i16, device=dev)
         self.forces = torch.zeros((A, 4), dtype=f32, device=dev)
-        self.cfl = torch.zeros(self.k.fmax_elements(A) + 8, dtype=f32, device=dev)
+        # what every forces pass starts from zero -- the CFL maxima and, with bodies, the RB_FORCES / RB_TORQUES rows -- lies in
+        # one allocation, so that it is one memset per pass (three fill kernels of a few microseconds each otherwise)
+        ncfl = (self.k.fmax_elements(A) + 8 + 3) // 4 * 4
+        nrb = max(getattr(problem, "num_obstacle", 0), 1)
+        self._zeroed = torch.zeros(ncfl + 8 * nrb, dtype=f32, device=dev)
+        self.cfl = self._zeroed[:ncfl]
         self.cfl_temp = torch.zeros(max(self.k.fmax_temp_elements(self.cfl.numel()), 4), dtype=f32, device=dev)
         self.new_num = torch.zeros(1, dtype=i32, device=dev)
         self.segment_start = torch.zeros(4, dtype=i32, device=dev)
-        nrb = max(getattr(problem, "num_obstacle", 0), 1)
         self.has_rb = bool(getattr(problem, "num_obstacle", 0))      # BUFFER_RB_FORCES / RB_TORQUES rows of body particles
-        self.rbforces = torch.zeros((nrb, 4), dtype=f32, device=dev)
-        self.rbtorques = torch.zeros((nrb, 4), dtype=f32, device=dev)
+        self.rbforces = self._zeroed[ncfl:ncfl + 4 * nrb].view(nrb, 4)
+        self.rbtorques = self._zeroed[ncfl + 4 * nrb:].view(nrb, 4)
         self.devmap = (torch.from_numpy(self.part.compact_device_map(rank).view(np.int32)).to(dev)
                        if world > 1 else None)
         dt0 = float(np.float32(self.sp.dt))
@@ -562,9 +566,8 @@ class MultiGpuEngine:
     # ------------------------------------------------------------------ forces / euler
     def _forces_pass(self, pos, vel, combine_min, run_mode=D.SIMULATE, step=1):
         K = self.k
-        K.memset(self.cfl, 0)
-        if self.has_rb:      # rows of body particles owned by other ranks must read zero in the reduction
-            K.memset(self.rbforces, 0); K.memset(self.rbtorques, 0)
+        # (with bodies: rows of body particles owned by other ranks must read zero in the reduction)
+        K.memset(self._zeroed if self.has_rb else self.cfl, 0)
         prof = self.profile_forces is not None and self.is_cuda
         if prof:
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
