@@ -592,7 +592,11 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 	const particleinfo info = a.info[index];
 	const bool vertexRow = MOVING && PART_TYPE(info) == PT_VERTEX;
 	if (PART_TYPE(info) != PT_FLUID && !vertexRow) {
-		if (!MOVING && (PART_TYPE(info) == PT_VERTEX || PART_TYPE(info) == PT_BOUNDARY)) a.newGGam[index] = a.oldGGam[index];
+		// MOVING: the reference leaves the BOUNDARY rows of the write buffer as they are (whatever an older step left there) and
+		// relies on the segment condition, which re-derives gamma of every segment in each step of such a run
+		// (sa_segment_bc_kernel, has_moving); here they are copied, as sa_integrate_gamma_kernel does, so that the rows between the
+		// two commands are a function of the inputs (tests/test_sa_moving.py holds both kernels to it)
+		if (PART_TYPE(info) == PT_BOUNDARY || (!MOVING && PART_TYPE(info) == PT_VERTEX)) a.newGGam[index] = a.oldGGam[index];
 		return;
 	}
 	const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
@@ -1188,14 +1192,16 @@ extern "C" int sphx_sa_integrate_gamma(sphx_ctx *ctx, void *newGGam, const void 
 	uint32_t numParticles, uint32_t particleRangeEnd, float dt, int step, float t,
 	float epsilon, float slength, float influenceradius, int run_mode, void *stream)
 {
-	(void)numParticles; (void)dt; (void)step; (void)t; (void)run_mode;
+	(void)numParticles; (void)dt; (void)step; (void)t;
 	int rc = sa_check(ctx, "integrate_gamma called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	if (!(ctx->params.simflags & SPHX_ENABLE_GAMMA_QUADRATURE))
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_integrate_gamma: dynamic gamma (transport equation) is not built; ENABLE_GAMMA_QUADRATURE is");
 	// ENABLE_MOVING_BODIES: boundElements is BUFFER_BOUNDELEMENTS of the NEW state (quadrature_gamma_neib_data reads
-	// params.newBoundElement) and gamma of the vertex rows is integrated as well (integrate_gamma_impl, src/cuda/euler.cu:254-258)
-	const bool moving = (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES) != 0;
+	// params.newBoundElement) and gamma of the vertex rows is integrated as well (integrate_gamma_impl, src/cuda/euler.cu:250-253).
+	// Not in the REPACK run mode: its branch (:222-239) integrates the fluid rows only and copies the vertex and boundary rows
+	// whatever the flags, against the elements of the state that is read (nothing moves while repacking)
+	const bool moving = (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES) != 0 && run_mode != SPHX_REPACK;
 	SPHX_REQUIRE(newGGam && oldGGam && newPos && boundElements && vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList,
 		"sphx_sa_integrate_gamma: missing buffer");
 	SPHX_REQUIRE(newGGam != oldGGam, "sphx_sa_integrate_gamma: in-place use is not supported");

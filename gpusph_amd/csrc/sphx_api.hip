@@ -153,10 +153,12 @@ int sphx_ensure_tile_lists(sphx_ctx *ctx)
 	if (ctx->disable_tiles || !ctx->reserved_particles) return SPHX_OK;
 	if (ctx->tile_list && ctx->tile_runs && ctx->tile_rows && ctx->tile_lane_rec && ctx->tile_lane_index) return SPHX_OK;
 	const size_t n = ctx->reserved_particles;
-	const size_t batches = n*5u/8u + 262144u;      // (the slack also holds the TILE_AHEAD batches the ring of the last share reads past its end)
+	const size_t batches = n*5u/8u + 262144u;
 	const size_t lanes = 2u*n + 262144u;
 	if (batches >= ((size_t)1 << 31) || lanes >= ((size_t)1 << 31)) return SPHX_OK;      // 32-bit cursors
-	bool ok = hipMalloc((void**)&ctx->tile_list, sizeof(uint2)*64u*batches) == hipSuccess;
+	// the ring of the walk reads TILE_AHEAD batches past the end of a wave's share without a clamp (acc_load_at, forces.hip): those
+	// batches are allocated behind the capacity the tiling may fill, so a stream filled to the last batch still reads its own memory
+	bool ok = hipMalloc((void**)&ctx->tile_list, sizeof(uint2)*64u*(batches + TILE_AHEAD)) == hipSuccess;
 	ok = ok && hipMalloc((void**)&ctx->tile_runs, sizeof(uint32_t)*TILE_RUNTAB*(size_t)ctx->tile_capacity) == hipSuccess;
 	ok = ok && hipMalloc((void**)&ctx->tile_rows, sizeof(uint32_t)*TILE_ROWDESC*(size_t)ctx->tile_capacity) == hipSuccess;
 	ok = ok && hipMalloc((void**)&ctx->tile_lane_rec, sizeof(uint32_t)*lanes) == hipSuccess;
@@ -365,6 +367,8 @@ extern "C" int sphx_set_constants(sphx_ctx *ctx, const sphx_params *sp)
 	d.mk_mask = (sp->boundarytype == SPHX_MK_BOUNDARY) ? 0xFFFFFFFFu : 0u;
 	if (sp->boundarytype == SPHX_MK_BOUNDARY) d.boundarytype = SPHX_LJ_BOUNDARY;
 	ctx->have_params = true;
+	// EOS rows left behind by an Euler step were made with the coefficients this call replaces: a vouch for them must not hold
+	ctx->eos_tag_vel = nullptr; ctx->eos_tag_n = 0; ctx->eos_armed = false;
 	return SPHX_OK;
 }
 

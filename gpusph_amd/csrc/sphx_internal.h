@@ -255,6 +255,10 @@ void sphx_fidelity_rows_launch(sphx_ctx *ctx, const void *vel, const void *info,
 int sphx_rb_flush(sphx_ctx *ctx, hipStream_t st);
 int sphx_xsph_launch(sphx_ctx *ctx, void *xsph, const void *pos, const void *vel, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint16_t *neibsList, uint32_t fromParticle, uint32_t toParticle, hipStream_t st);
+int sphx_neibs_list_launch(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint32_t *cellEnd, const void *vertices, const void *boundElements,
+	void *vertPos0, void *vertPos1, void *vertPos2, uint32_t numParticles, uint32_t particleRangeEnd,
+	float sqinfluenceradius, float boundNlSqInflRad, hipStream_t st);   // neibs_build.hip
 int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void *info, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st);
 // SA_BOUNDARY engines over the tiles (forces.hip): which sums the tiled kernel forms
 #define SPHX_SA_TILE_FORCES 0

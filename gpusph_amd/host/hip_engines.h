@@ -660,8 +660,10 @@ public:
 		const float4 *newPos = bufreadUpdate.getConstData<BUFFER_POS>();
 		// with moving bodies the quadrature reads the elements of the NEW state (quadrature_gamma_neib_data,
 		// src/cuda/density_sum_kernel.cu:713-727) and the library integrates the vertex rows as well
-		const float4 *belem = (m_c->params().simflags & ENABLE_MOVING_BODIES) ? bufreadUpdate.getConstData<BUFFER_BOUNDELEMENTS>()
-			: bufread.getData<BUFFER_BOUNDELEMENTS>();
+		// (not while repacking: that branch of integrate_gamma_impl, src/cuda/euler.cu:222-239, reads the state's own elements and
+		// nobody has written the new ones)
+		const float4 *belem = ((m_c->params().simflags & ENABLE_MOVING_BODIES) && run_mode != REPACK)
+			? bufreadUpdate.getConstData<BUFFER_BOUNDELEMENTS>() : bufread.getData<BUFFER_BOUNDELEMENTS>();
 		sphx_throw(sphx_sa_integrate_gamma(m_c->ctx(), bufreadUpdate.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_GRADGAMMA>(),
 			newPos, belem, vertPos[0], vertPos[1], vertPos[2],
 			bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),

@@ -195,3 +195,23 @@ def test_kernels_in_emulation_gamma_by_quadrature(emu_of):
     assert np.array_equal(_bits(got[:n][bd]), _bits(sim.gg[:n][bd]))          # copied
     moving = (sim.info[:n, 0] & D.FG_MOVING_BOUNDARY) != 0
     assert np.abs(want[:n][vt & ~moving, 3] - sim.gg[:n][vt & ~moving, 3]).max() > 1e-5      # a fixed vertex next to the flap sees it turn
+
+
+def test_kernels_in_emulation_gamma_while_repacking_leaves_the_body_alone(emu_of):
+    """REPACK with ENABLE_MOVING_BODIES in the flags: integrate_gamma_impl's repack branch (src/cuda/euler.cu:222-239) integrates
+    the fluid rows only, against the elements of the state that is read, and copies the vertex and boundary rows — it never takes
+    the moving-bodies branch.  (the entry point ignored run_mode and integrated the vertex rows.)"""
+    sim, ps, vs, be_new, rot = _moved_state("StillWaterRepackSA")
+    o, n = sim.o, sim.n
+    emu = emu_of(sim)
+    P = emu.params
+    want = o.sa_integrate_gamma(sim.gg, ps, sim.be, sim.vertpos, sim.info, sim.hash, sim.cs, sim.nl, n)    # fluid only, old elements
+    got = np.zeros_like(sim.gg)
+    vp = [np.ascontiguousarray(v) for v in sim.vertpos]
+    emu.call("sphx_sa_integrate_gamma", got, sim.gg, ps, sim.be, vp[0], vp[1], vp[2], sim.info, sim.hash, sim.cs, sim.nl, n, n,
+             0.0, 1, 0.0, 5e-5, float(P.slength), float(P.influenceradius), D.REPACK, None)
+    t = info_type(sim.info[:n])
+    fl, vt, bd = t == D.PT_FLUID, t == D.PT_VERTEX, t == D.PT_BOUNDARY
+    assert np.array_equal(_bits(got[:n][vt]), _bits(sim.gg[:n][vt]))          # copied, not integrated
+    assert np.array_equal(_bits(got[:n][bd]), _bits(sim.gg[:n][bd]))
+    assert np.abs(got[:n][fl, 3] - want[:n][fl, 3]).max() < 2e-6
