@@ -3,8 +3,13 @@
 // algorithm restated in oracle/sph_oracle.c.  Compiled with -ffp-contract=off like neibs.hip.
 #include "sphx_internal.h"
 #include <cstring>
+#include <cstdlib>
 
 #define BLOCK_NEIBS   256
+// (tests/hostemu compiles this file for the host and runs the kernel's waves as fibres: its stand-in header defines the macro)
+#ifndef SPHX_LAUNCH_WAVES
+#define SPHX_LAUNCH_WAVES(kernel, grid, block, stream, ...) kernel<<<(grid), (block), 0, (stream)>>>(__VA_ARGS__)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // buildNeibsList: src/cuda/buildneibs_kernel.cu:1019-1185, neibsInCell :536-644
@@ -141,9 +146,330 @@ struct SaNeibArgs {
 	float boundNlSqInflRad;         // search radius for boundary neighbours
 };
 
+
+// ------------------------------------------------------------------------------------------
+// The distance tests of the list build on the matrix cores (round 6).
+//
+// The walk below ("general walk") tests ~475 candidates per particle at ~17 vector instructions each, one lane per home
+// particle: 7.7 G vector instructions per build at 32 M particles, 13 ms.  The test itself -- |x_i - x_j|^2 < R^2 for every
+// home particle of a wave against every particle of the cells around them -- is a dense contraction: with the wave's 64 home
+// particles as columns and 32 candidates as rows, |c|^2 - 2 c.h + (|h|^2 - R^2) is a 32 x 64 product of inner dimension 4, two
+// v_mfma_f32_32x32x2_f32 per half of the wave, and what is left to the vector unit per pair is ONE instruction that shifts the
+// result's sign into a bit mask (v_alignbit) and a third of one that tracks the smallest |result| (v_min3_u32).  The 64 home
+// particles of a wave are consecutive in the sorted order, i.e. they sit in a few adjacent cells of one grid row (cells along
+// COORD1 are contiguous in memory), so the candidates of ALL of them are nine contiguous index ranges, one per neighbouring
+// row: cells [cmin - 1, cmax + 1] of that row.  A "group" is the lanes of a wave that share a grid row.
+//
+// What keeps the list bit-identical to the reference's: the matrix product does not reproduce the reference's roundings
+// (x_i - shift first, then the difference, then three fused multiply-adds), so its verdict is only trusted away from the
+// surface of the sphere: a result within `band` of zero (band = a bound of everything the two evaluations can differ by, from
+// the magnitudes of the operands, see nm_band) sends that home particle's 32 candidates of the tile through the reference's
+// own arithmetic.  That is ~1 tile in 50.  Order, encodings, overflow rules and the ring are the general walk's: per cell in
+// cell-code order, fluid segment then tail, the candidates of a cell in index order = the set bits of the mask in ascending
+// order.  Everything unusual stays with the general walk, lane by lane: COORD1 = z (the cells of a code triple are then not
+// one row), particles in the first / last cell of a periodic COORD1, rows whose candidate range exceeds NM_TMAX tiles even for
+// a single column of home cells, SA_BOUNDARY (vertex section, VERTPOS) -- a lane the prepass does not take is simply still
+// `walking` afterwards.
+// ------------------------------------------------------------------------------------------
+#define NM_TMAX 6                    // tiles of 32 candidates per row whose masks a lane keeps (192 candidates)
+#define NM_WORDS (NM_TMAX + 2)       // mask words per lane and row in LDS: the tiles + zeros for the 96-bit reads of the emission
+#define NM_MAXSPAN 40                // cells of one group along COORD1 (+ 2 neighbours: one lane each in the range look-up)
+typedef float nm_f16 __attribute__((ext_vector_type(16)));
+typedef uint32_t nm_u2 __attribute__((ext_vector_type(2)));
+
+// both halves of the wave see lanes 0..31 (x) / lanes 32..63 (y) of v: lane l gets v[l & 31] and v[32 + (l & 31)]
+__device__ __forceinline__ void nm_both_halves(uint32_t v, uint32_t &lo, uint32_t &hi)
+{
+	const nm_u2 r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+	lo = r[0]; hi = r[1];
+}
+__device__ __forceinline__ void nm_both_halves(float v, float &lo, float &hi)
+{
+	uint32_t a, b;
+	nm_both_halves(__float_as_uint(v), a, b);
+	lo = __uint_as_float(a); hi = __uint_as_float(b);
+}
+__device__ __forceinline__ unsigned long long nm_low_bits(uint32_t n)      // n <= 64 ones
+{
+	return n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+}
+
+// MC1: the axis of COORD1 (0 = x, 1 = y).  sMask: [3 rows of a slab][64 lanes][NM_WORDS], this wave's
+template<int MC1, int FR, int BR>
+__device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const float4 *__restrict__ posArray,
+	const particleinfo *__restrict__ infoArray, const uint32_t *__restrict__ particleHash,
+	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd, const uint32_t *__restrict__ cellFluidEnd,
+	float sqinfluenceradius, uint32_t lane, uint32_t index, const float4 &pos, const int3 &gridPos, const particleinfo &info,
+	bool fluidOnly, bool noBB, bool &walking, uint32_t &nf, uint32_t &nb, uint32_t &nv, NeibRing<FR, BR> &ring, neibdata *column,
+	uint32_t (*sMask)[64][NM_WORDS])
+{
+	constexpr int OA = 1 - MC1;      // the other horizontal axis; z is never COORD1 here
+	const int gs1 = p.gs[MC1], gsOA = p.gs[OA], gsZ = p.gs[2];
+	const float cs1 = p.cs[MC1], csOA = p.cs[OA], csZ = p.cs[2];
+	const bool per1 = (p.periodic & (1u << MC1)) != 0u, perOA = (p.periodic & (1u << OA)) != 0u, perZ = (p.periodic & 4u) != 0u;
+	const int c1 = MC1 == 0 ? gridPos.x : gridPos.y, oa = MC1 == 0 ? gridPos.y : gridPos.x, gz = gridPos.z;
+	const float pos1 = MC1 == 0 ? pos.x : pos.y, posOA = MC1 == 0 ? pos.y : pos.x;
+	const int rowKey = oa*p.hs[OA] + gz*p.hs[2];      // hash of the row's column 0 (hs[COORD1] = 1)
+	const bool boundary = IS_BOUNDARY(info);
+	const bool lowHalf = lane < 32u;
+	// candidate (row of the matrix) -> place in its tile of 32: the product leaves candidate rows 8a + 4h + b (a < 4, h < 2, b < 4)
+	// in register 4a + b of half h of the wave; numbered this way the sixteen bits a lane collects are sixteen CONSECUTIVE candidates
+	const uint32_t li = lane & 31u;
+	const uint32_t candPlace = 16u*((li >> 2) & 1u) + 4u*(li >> 3) + (li & 3u);
+
+	bool todo = walking && !(per1 && (c1 == 0 || c1 == gs1 - 1));
+	for (;;) {
+		const unsigned long long remaining = __builtin_amdgcn_ballot_w64(todo);
+		if (!remaining) break;
+		const int lead = __builtin_ctzll(remaining);
+		const int key = __builtin_amdgcn_readlane(rowKey, lead);
+		const unsigned long long gm0 = __builtin_amdgcn_ballot_w64(todo && rowKey == key);
+		const int cmin = __builtin_amdgcn_readlane(c1, __builtin_ctzll(gm0));
+		int cmax = __builtin_amdgcn_readlane(c1, 63 - __builtin_clzll(gm0));      // lanes are in hash order: c1 does not decrease
+		if (cmax - cmin > NM_MAXSPAN) cmax = cmin + NM_MAXSPAN;
+		const int oaG = __builtin_amdgcn_readlane(oa, lead), zG = __builtin_amdgcn_readlane(gz, lead);
+
+		// the nine rows: hash of their column 0 (or invalid), and the index range of their cells [cmin - 1, cmax + 1]
+		int rowBase[9];
+		uint32_t rowLo[9], rowHi[9];
+		bool fits = false;
+		for (;;) {
+			const int colLo = max(cmin - 1, 0), colHi = min(cmax + 1, gs1 - 1);
+			uint32_t longest = 0;
+#pragma unroll
+			for (int r9 = 0; r9 < 9; ++r9) {
+				int oar = oaG + (r9 % 3 - 1), zr = zG + (r9 / 3 - 1);
+				bool rv = true;
+				if (oar < 0) { if (perOA) oar = gsOA - 1; else rv = false; } else if (oar >= gsOA) { if (perOA) oar = 0; else rv = false; }
+				if (zr < 0) { if (perZ) zr = gsZ - 1; else rv = false; } else if (zr >= gsZ) { if (perZ) zr = 0; else rv = false; }
+				rowBase[r9] = rv ? oar*p.hs[OA] + zr*p.hs[2] : -1;
+				rowLo[r9] = 0u; rowHi[r9] = 0u;
+				if (!rv) continue;
+				const bool mine = (int)lane <= colHi - colLo;
+				const uint32_t h = (uint32_t)(rowBase[r9] + colLo + (mine ? (int)lane : 0));
+				const uint32_t cs = cellStart[h];
+				const bool nonEmpty = mine && cs != CELL_EMPTY;
+				const uint32_t ce = nonEmpty ? cellEnd[h] : 0u;
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(nonEmpty);
+				if (m) {
+					rowLo[r9] = (uint32_t)__builtin_amdgcn_readlane((int)cs, __builtin_ctzll(m));
+					rowHi[r9] = (uint32_t)__builtin_amdgcn_readlane((int)ce, 63 - __builtin_clzll(m));
+					longest = max(longest, rowHi[r9] - rowLo[r9]);
+				}
+			}
+			if (longest <= 32u*NM_TMAX) { fits = true; break; }
+			if (cmax == cmin) break;
+			cmax = cmin + (cmax - cmin)/2;
+		}
+		if (!fits) {      // one column of home cells whose neighbourhood does not fit: the general walk takes these lanes
+			todo = todo && !(rowKey == key && c1 == cmin);
+			continue;
+		}
+		const bool inG = todo && rowKey == key && c1 <= cmax;
+		todo = todo && !inG;
+		walking = walking && !inG;
+
+		// the group's frame along COORD1: column cref; the band inside which the product's verdict is not trusted
+		const int cref = (cmin + cmax) >> 1;
+		const float h1 = fmaf((float)(c1 - cref), cs1, pos1);
+		float band;
+		{
+			// |operands| <= m1 along COORD1 (half the span + the neighbour column + half a cell), 1.5 cells along the other two (the
+			// home particle shifted into the neighbouring row's frame); M bounds |c|^2 and |h|^2.  The product's value differs from
+			// the exact |x_i - x_j|^2 of the same inputs by at most the roundings of the frame conversion (2^-23 of a coordinate,
+			// times 2 r), of |c|^2, |h|^2 (3 x 2^-24 M each) and of four multiply-accumulate steps on magnitudes <= 4 M
+			// (2^-23 each if the unit rounds product and sum separately): < 2^-19 M + 2^-18 R^2; the reference's own value differs
+			// from the exact one by < 2^-21 R^2.  The band is twice that sum.
+			const float m1 = ((float)(cmax - cmin)*0.5f + 2.0f)*cs1;
+			const float M = fmaf(m1, m1, fmaf(1.5f*csOA, 1.5f*csOA, (1.5f*csZ)*(1.5f*csZ)));
+			band = fmaf(M, 1.0f/262144.0f, sqinfluenceradius*(1.0f/131072.0f));
+		}
+		const uint32_t ambBits = __float_as_uint(2.0f*band);      // 0 <= result + band < 2 band: inside the band
+		float h1s[2], hoas[2], hzs[2];
+		nm_both_halves(h1, h1s[0], h1s[1]);
+		nm_both_halves(posOA, hoas[0], hoas[1]);
+		nm_both_halves(pos.z, hzs[0], hzs[1]);
+
+#pragma unroll 1
+		for (int sl = 0; sl < 3; ++sl) {      // slab: dz = sl - 1
+			const float shZ = (float)(sl - 1)*csZ;
+			// this slab's three rows (static indices only: a run-time index would send the tables to scratch memory)
+			int curBase[3]; uint32_t curLo[3], curHi[3];
+#pragma unroll
+			for (int rs = 0; rs < 3; ++rs) {
+				curBase[rs] = sl == 0 ? rowBase[rs] : sl == 1 ? rowBase[3 + rs] : rowBase[6 + rs];
+				curLo[rs] = sl == 0 ? rowLo[rs] : sl == 1 ? rowLo[3 + rs] : rowLo[6 + rs];
+				curHi[rs] = sl == 0 ? rowHi[rs] : sl == 1 ? rowHi[3 + rs] : rowHi[6 + rs];
+			}
+			// ---- the masks of the slab's three rows
+#pragma unroll
+			for (int rs = 0; rs < 3; ++rs) {
+				uint32_t *myWords = sMask[rs][lane];
+#pragma unroll
+				for (int w = 0; w < NM_WORDS; ++w) myWords[w] = 0u;
+				const uint32_t lo = curLo[rs], hi = curHi[rs];
+				const int rbase = curBase[rs];
+				if (hi == lo) continue;
+				const float shOA = (float)(rs - 1)*csOA;
+				// the home particle in this row's frame (the reference shifts the home particle, not the candidate)
+				const float hOAr = posOA - shOA, hZr = pos.z - shZ;
+				const float nOwn = fmaf(hZr, hZr, fmaf(hOAr, hOAr, h1*h1));
+				float cinit[2];
+				nm_both_halves((nOwn - sqinfluenceradius) + band, cinit[0], cinit[1]);
+				float b1[2], b2[2];
+#pragma unroll
+				for (int s = 0; s < 2; ++s) {
+					b1[s] = lowHalf ? h1s[s] : hoas[s] - shOA;
+					b2[s] = lowHalf ? hzs[s] - shZ : 1.0f;
+				}
+				const uint32_t tiles = (hi - lo + 31u) >> 5;
+#pragma unroll 1
+				for (uint32_t t = 0; t < tiles; ++t) {
+					const uint32_t tileBase = lo + 32u*t;
+					const uint32_t j = tileBase + candPlace;
+					const bool inRow = j < hi;
+					const float4 cp = posArray[inRow ? j : lo];
+					const int col = (int)(particleHash[inRow ? j : lo] & CELLTYPE_BITMASK) - rbase;
+					const float c1f = fmaf((float)(col - cref), cs1, MC1 == 0 ? cp.x : cp.y);
+					const float cOA = MC1 == 0 ? cp.y : cp.x;
+					const float n = fmaf(cp.z, cp.z, fmaf(cOA, cOA, c1f*c1f));
+					const bool ok = inRow && is_active_w(cp.w) && n < __builtin_inff();
+					const float a1 = ok ? -2.0f*(lowHalf ? c1f : cOA) : 0.0f;
+					const float a2 = lowHalf ? (ok ? -2.0f*cp.z : 0.0f) : (ok ? n : __builtin_inff());
+					uint32_t q[2], amb[2];
+#pragma unroll
+					for (int s = 0; s < 2; ++s) {
+						nm_f16 acc;
+#pragma unroll
+						for (int r = 0; r < 16; ++r) acc[r] = cinit[s];
+						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[s], acc, 0, 0, 0);
+						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[s], acc, 0, 0, 0);
+						uint32_t bits = 0u, smallest = 0xFFFFFFFFu;
+#pragma unroll
+						for (int r = 15; r >= 0; --r) {
+							const uint32_t v = __float_as_uint(acc[r]);
+							bits = __builtin_amdgcn_alignbit(bits, v, 31);      // (bits << 1) | sign: negative = inside the sphere
+							smallest = min(smallest, v);                       // negative values are the largest unsigned ones
+						}
+						q[s] = bits; amb[s] = smallest < ambBits ? 1u : 0u;
+					}
+					// lane p < 32 holds home p: bits of candidates 0..15 in q[0], of 16..31 in lane p + 32's q[0]; lane p + 32 holds
+					// home p + 32: candidates 0..15 in lane p's q[1], 16..31 in its own q[1] -- one swap of the halves sorts that out
+					const nm_u2 sw = __builtin_amdgcn_permlane32_swap(q[0], q[1], false, false);
+					uint32_t mask = sw[0] | (sw[1] << 16);
+					const nm_u2 sa = __builtin_amdgcn_permlane32_swap(amb[0], amb[1], false, false);
+					const bool recheck = inG && (sa[0] | sa[1]) != 0u;
+					if (__builtin_amdgcn_ballot_w64(recheck)) {
+						// the reference's arithmetic for the 32 candidates of this tile (neibsInCell: the home particle shifted by the
+						// cell offset, then the difference, then the squared length) for the home particles that ask for it
+						uint32_t exact = 0u;
+						const float pOA = posOA - shOA, pZ = pos.z - shZ;      // = fmaf(-(float)offset, cell size, pos) of the reference
+#pragma unroll 1
+						for (uint32_t u = 0; u < 32u; ++u) {
+							const uint32_t ju = tileBase + u;
+							if (ju >= hi) break;
+							const float4 cu = posArray[ju];
+							const int d1 = (int)(particleHash[ju] & CELLTYPE_BITMASK) - rbase - c1;
+							const float p1 = fmaf(-(float)d1, cs1, pos1);
+							const float r1 = p1 - (MC1 == 0 ? cu.x : cu.y), rOA = pOA - (MC1 == 0 ? cu.y : cu.x), rz = pZ - cu.z;
+							const float rx = MC1 == 0 ? r1 : rOA, ry = MC1 == 0 ? rOA : r1;
+							const float r2 = fmaf(rz, rz, fmaf(ry, ry, rx*rx));
+							if (r2 < sqinfluenceradius && is_active_w(cu.w)) exact |= 1u << u;
+						}
+						mask = recheck ? exact : mask;
+					}
+					myWords[t] = mask;
+				}
+			}
+			// ---- emission: the nine cells of the slab in cell-code order
+			struct CellMeta { uint32_t start, fluidEnd, end; };
+			auto cell_meta = [&](int cc) {
+				const int dx = cc % 3 - 1, dy = cc/3 - 1;
+				const int d1 = MC1 == 0 ? dx : dy, rs = (MC1 == 0 ? dy : dx) + 1;
+				const int col = c1 + d1, base = rs == 0 ? curBase[0] : rs == 1 ? curBase[1] : curBase[2];
+				const bool valid = inG && base >= 0 && col >= 0 && col < gs1;
+				const uint32_t h = valid ? (uint32_t)(base + col) : 0u;
+				CellMeta m;
+				m.start = cellStart[h]; m.fluidEnd = cellFluidEnd[h]; m.end = cellEnd[h];
+				if (!valid) m.start = CELL_EMPTY;
+				return m;
+			};
+			CellMeta nextMeta = cell_meta(0);
+#pragma unroll 1
+			for (int cc = 0; cc < 9; ++cc) {
+				const CellMeta cur = nextMeta;
+				nextMeta = cell_meta(min(cc + 1, 8));
+				const int dx = cc % 3 - 1, dy = cc/3 - 1;
+				const int rs = (MC1 == 0 ? dy : dx) + 1;
+				const uint32_t cell = (uint32_t)(cc + 9*sl);
+				const uint32_t code = (cell + 1u) << CELLNUM_SHIFT;
+				const bool has = cur.start != CELL_EMPTY;
+				const uint32_t bucketEnd = fluidOnly ? cur.fluidEnd : cur.end;
+				const uint32_t len = has ? bucketEnd - cur.start : 0u, flen = has ? min(cur.fluidEnd - cur.start, len) : 0u;
+				const uint32_t off = has ? cur.start - (rs == 0 ? curLo[0] : rs == 1 ? curLo[1] : curLo[2]) : 0u;
+				const uint32_t selfrel = (cell == 13u) ? index - cur.start : 0xFFFFFFFFu;
+				uint32_t encv = code, neib_type = PT_FLUID;
+				const uint32_t *myWords = sMask[rs][lane];
+				for (uint32_t k0 = 0; __builtin_amdgcn_ballot_w64(k0 < len); k0 += 64u) {
+					unsigned long long bits = 0ull;
+					if (k0 < len) {
+						const uint32_t bo = off + k0, wi = bo >> 5, sh = bo & 31u;
+						const uint32_t w0 = myWords[wi], w1 = myWords[wi + 1u], w2 = myWords[wi + 2u];
+						const uint32_t lo32 = __builtin_amdgcn_alignbit(w1, w0, sh), hi32 = __builtin_amdgcn_alignbit(w2, w1, sh);
+						bits = ((unsigned long long)hi32 << 32) | lo32;
+						bits &= nm_low_bits(len - k0);
+						if (selfrel - k0 < 64u) bits &= ~(1ull << (selfrel - k0));
+					}
+					const unsigned long long fmask = nm_low_bits(flen > k0 ? flen - k0 : 0u);
+					unsigned long long fm = bits & fmask, tm = bits & ~fmask;
+					// fluid segment: the type is known from the index
+					while (__builtin_amdgcn_ballot_w64(fm != 0ull)) {
+						ring.room_f(1, 4);
+						if (fm) {
+							const uint32_t b = (uint32_t)__builtin_ctzll(fm);
+							fm &= fm - 1ull;
+							nf += 1u;
+							if (!too_many_neibs(p, nf, nb, nv, PT_FLUID)) {
+								ring.fring[ring.sf % (uint32_t)FR][lane] = (neibdata)(k0 + b + encv);
+								ring.sf += 1u;
+								encv = 0u;
+							}
+						}
+					}
+					// tail of the cell (boundary particles; test points are nobody's neighbours): the reference's steps for the
+					// candidates in reach, in index order
+					if (__builtin_amdgcn_ballot_w64(tm != 0ull)) {
+						ring.room_b(BR/2, 0);
+						while (tm) {
+							const uint32_t b = (uint32_t)__builtin_ctzll(tm);
+							tm &= tm - 1ull;
+							const uint32_t neib_index = cur.start + k0 + b;
+							const particleinfo neib_info = infoArray[neib_index];
+							if (IS_TESTPOINT(neib_info)) continue;
+							if (neib_type != PART_TYPE(neib_info)) encv = code;
+							neib_type = PART_TYPE(neib_info);
+							if (noBB && boundary && IS_BOUNDARY(neib_info)) continue;
+							const uint32_t num = (neib_type == PT_FLUID) ? nf : (neib_type == PT_BOUNDARY) ? nb : nv;
+							if (neib_type == PT_FLUID) nf++; else if (neib_type == PT_BOUNDARY) nb++; else nv++;
+							if (!too_many_neibs(p, nf, nb, nv, neib_type)) {
+								const uint32_t val = (k0 + b) + encv;
+								if (neib_type == PT_FLUID) ring.store_f(num, val);
+								else if (neib_type == PT_BOUNDARY) ring.store_b(num, val);
+								else column[(size_t)neib_list_offset(p, num, neib_type)*p.stride] = (neibdata)val;
+								encv = 0u;
+							}
+						}
+					}
+				}
+			}
+		}
+	}
+}
+
 // BUF: the position array is smaller than 4 GB and is read through a buffer descriptor
 // SA: semi-analytical boundaries (vertex section, wider boundary radius, VERTPOS of the segments)
-template<bool BUF, bool SA>
+// MC1: -1, or the axis of COORD1 (0 = x, 1 = y) for the prepass on the matrix cores above (never with SA)
+template<bool BUF, bool SA, int MC1 = -1>
 __global__ void __launch_bounds__(BLOCK_NEIBS)
 build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	const float4 *__restrict__ posArray, const particleinfo *__restrict__ infoArray,
@@ -155,6 +481,7 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	// (the partial counter sets lie behind *counters: NeibsSpread)
 {
 	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING][64];
+	__shared__ uint32_t sMask[MC1 >= 0 ? (BLOCK_NEIBS/64)*3*64*NM_WORDS : 1];      // [wave][row of a slab][lane][word]
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t index = blockIdx.x*BLOCK_NEIBS + threadIdx.x;
 	const bool inRange = index < particleRangeEnd;
@@ -202,6 +529,10 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 
 	const __amdgpu_buffer_rsrc_t posRsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(posArray), 0,
 		BUF ? (int)(posRows*16u) : 0, 0x00020000);
+	if constexpr (MC1 >= 0 && !SA)
+		neibs_mfma_prepass<MC1, NEIB_FRING, NEIB_BRING>(p, posArray, infoArray, particleHash, cellStart, cellEnd, cellFluidEnd,
+			sqinfluenceradius, lane, index, pos, gridPos, info, fluidOnly, noBB, walking, nf, nb, nv, ring, column,
+			reinterpret_cast<uint32_t (*)[64][NM_WORDS]>(sMask + (threadIdx.x >> 6)*(3*64*NM_WORDS)));
 	const unsigned long long wmask = __builtin_amdgcn_ballot_w64(walking);
 	// first particle, end of the fluid segment and end of neighbour cell `c` of every lane.  The three loads do not depend
 	// on each other and are issued one cell ahead of their use, so that a cell costs one memory round trip (its first batch
@@ -391,10 +722,18 @@ int sphx_neibs_list_launch(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, 
 	saArgs.vertices = (const uint4*)vertices; saArgs.boundElements = (const float4*)boundElements;
 	saArgs.vertPos[0] = (float2*)vertPos0; saArgs.vertPos[1] = (float2*)vertPos1; saArgs.vertPos[2] = (float2*)vertPos2;
 	saArgs.boundNlSqInflRad = boundNlSqInflRad;
-	(sa ? (posBuf ? build_neibs_kernel<true, true> : build_neibs_kernel<false, true>)
-	    : (posBuf ? build_neibs_kernel<true, false> : build_neibs_kernel<false, false>))<<<div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, 0, st>>>(ctx->dev,
-		saArgs, neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end,
-		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev, ctx->neib_counts);
+	// the prepass on the matrix cores: COORD1 = x or y, plain boundaries, positions behind a buffer descriptor
+	static const bool noMfma = getenv("SPHX_NEIBS_NO_MFMA") != nullptr;      // A/B switch: the general walk alone
+	const int mc1 = (!sa && posBuf && !noMfma && ctx->dev.c1 <= 1) ? ctx->dev.c1 : -1;
+#define SPHX_NB_LAUNCH(K) SPHX_LAUNCH_WAVES(K, div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, st, ctx->dev, \
+		saArgs, neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end, \
+		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev, ctx->neib_counts)
+	if (sa) { if (posBuf) SPHX_NB_LAUNCH((build_neibs_kernel<true, true>)); else SPHX_NB_LAUNCH((build_neibs_kernel<false, true>)); }
+	else if (mc1 == 0) SPHX_NB_LAUNCH((build_neibs_kernel<true, false, 0>));
+	else if (mc1 == 1) SPHX_NB_LAUNCH((build_neibs_kernel<true, false, 1>));
+	else if (posBuf) SPHX_NB_LAUNCH((build_neibs_kernel<true, false>));
+	else SPHX_NB_LAUNCH((build_neibs_kernel<false, false>));
+#undef SPHX_NB_LAUNCH
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	return SPHX_OK;
 }

@@ -149,6 +149,58 @@ static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; 
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }
 static inline float __uint_as_float(unsigned i) { float f; memcpy(&f, &i, 4); return f; }
 
+// ---- what neibs_build.hip uses on top of that (round 6: the list build with its distance tests on the matrix cores) ------------
+#define ext_vector_type(n) vector_size(4*(n))      // four-byte elements only (float x 16, uint32 x 2 / x 4); index with [], not .x
+#define __builtin_assume(x) ((void)0)
+template<typename T> static inline T atomicCAS(T *p, T cmp, T v) { const T o = *p; if (o == cmp) *p = v; return o; }
+typedef unsigned emu_u32x2 __attribute__((vector_size(8)));
+typedef unsigned emu_u32x4 __attribute__((vector_size(16)));
+typedef float emu_f32x16 __attribute__((vector_size(64)));
+// v_permlane32_swap_b32 vdst, vsrc: lanes 32..63 of vdst trade places with lanes 0..31 of vsrc; returns {vdst, vsrc}
+static inline emu_u32x2 __builtin_amdgcn_permlane32_swap(unsigned vdst, unsigned vsrc, bool, bool)
+{
+	const unsigned l = emu_lane();
+	const unsigned long long *d = emu::meet(((unsigned long long)vsrc << 32) | vdst);
+	emu_u32x2 r;
+	r[0] = l < 32u ? vdst : (unsigned)(d[l - 32u] >> 32);          // upper half of vdst <- lower half of vsrc
+	r[1] = l < 32u ? (unsigned)(d[l + 32u] & 0xFFFFFFFFu) : vsrc;  // lower half of vsrc <- upper half of vdst
+	return r;
+}
+// v_mfma_f32_32x32x2_f32: D = A (32 x 2) B (2 x 32) + C.  A[i][k] is lane i + 32 k's `a`, B[k][j] lane j + 32 k's `b`; lane l holds
+// D[8 (r / 4) + 4 (l / 32) + r % 4][l % 32] in element r (the layout of the CDNA3/4 ISA guides).  The rounding of the unit is not
+// modelled (one fused multiply-add per k here): the kernel's band logic must not depend on it, and does not
+static inline emu_f32x16 __builtin_amdgcn_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int)
+{
+	const unsigned l = emu_lane();
+	const unsigned long long *d = emu::meet(((unsigned long long)emu_bits(b) << 32) | emu_bits(a));
+	unsigned long long all[64];
+	for (unsigned k = 0; k < 64u; ++k) all[k] = d[k];
+	const unsigned j = l & 31u;
+	for (unsigned r = 0; r < 16u; ++r) {
+		const unsigned i = 8u*(r/4u) + 4u*(l/32u) + (r % 4u);
+		float acc = c[r];
+		for (unsigned k = 0; k < 2u; ++k) {
+			const float A = emu_value<float>(all[i + 32u*k] & 0xFFFFFFFFull), B = emu_value<float>(all[j + 32u*k] >> 32);
+			acc = fmaf(A, B, acc);
+		}
+		c[r] = acc;
+	}
+	return c;
+}
+static inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned s)
+{
+	return (unsigned)(((((unsigned long long)hi) << 32) | lo) >> (s & 31u));
+}
+struct __amdgpu_buffer_rsrc_t { const char *base; unsigned bytes; };
+static inline __amdgpu_buffer_rsrc_t __builtin_amdgcn_make_buffer_rsrc(void *p, int, int bytes, int) { return __amdgpu_buffer_rsrc_t{(const char*)p, (unsigned)bytes}; }
+static inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(__amdgpu_buffer_rsrc_t r, int voff, int soff, int)
+{
+	emu_u32x4 v = {0u, 0u, 0u, 0u};
+	const unsigned o = (unsigned)voff + (unsigned)soff;
+	if (r.bytes == 0u || o + 16u <= r.bytes) memcpy(&v, r.base + o, 16);      // rows past the array read as zeros
+	return v;
+}
+
 // ---- the runtime API the host side of the two files calls: memory is host memory, streams and events are nothing -------------
 typedef int hipError_t;
 typedef void *hipStream_t;
