@@ -7,6 +7,10 @@
 
 #define BLOCK_NEIBS   256
 // (tests/hostemu compiles this file for the host and runs the kernel's waves as fibres: its stand-in header defines the macro)
+#ifndef SPHX_EMU_MARK
+#define SPHX_EMU_MARK(n) ((void)0)
+#define SPHX_EMU_REFUSE(cond, what) ((void)0)
+#endif
 #ifndef SPHX_LAUNCH_WAVES
 #define SPHX_LAUNCH_WAVES(kernel, grid, block, stream, ...) kernel<<<(grid), (block), 0, (stream)>>>(__VA_ARGS__)
 #endif
@@ -135,7 +139,7 @@ typedef uint32_t neib_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load_pos_row(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, int u)
 {
 	const neib_u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + 16u*(uint32_t)u), 0, 0);
-	return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+	return make_float4(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[2]), __uint_as_float(r[3]));
 }
 
 // SA_BOUNDARY members of buildneibs_params (src/cuda/buildneibs_params.h:66-115)
@@ -219,6 +223,7 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 
 	bool todo = walking && !(per1 && (c1 == 0 || c1 == gs1 - 1));
 	for (;;) {
+		SPHX_EMU_MARK(1);
 		const unsigned long long remaining = __builtin_amdgcn_ballot_w64(todo);
 		if (!remaining) break;
 		const int lead = __builtin_ctzll(remaining);
@@ -234,6 +239,7 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 		uint32_t rowLo[9], rowHi[9];
 		bool fits = false;
 		for (;;) {
+			SPHX_EMU_MARK(2);
 			const int colLo = max(cmin - 1, 0), colHi = min(cmax + 1, gs1 - 1);
 			uint32_t longest = 0;
 #pragma unroll
@@ -261,6 +267,10 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 			if (cmax == cmin) break;
 			cmax = cmin + (cmax - cmin)/2;
 		}
+#ifdef SPHX_EMU_DEBUG
+		if (lane == (uint32_t)lead) { fprintf(stderr, "group key %d cmin %d cmax %d fits %d lead %d gm0 %llx oaG %d zG %d:", key, cmin, cmax, (int)fits, lead, gm0, oaG, zG);
+			for (int r9 = 0; r9 < 9; ++r9) fprintf(stderr, " [%d %u %u]", rowBase[r9], rowLo[r9], rowHi[r9]); fprintf(stderr, "\n"); }
+#endif
 		if (!fits) {      // one column of home cells whose neighbourhood does not fit: the general walk takes these lanes
 			todo = todo && !(rowKey == key && c1 == cmin);
 			continue;
@@ -325,6 +335,7 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 				const uint32_t tiles = (hi - lo + 31u) >> 5;
 #pragma unroll 1
 				for (uint32_t t = 0; t < tiles; ++t) {
+					SPHX_EMU_MARK(100 + 10*rs + (int)t);
 					const uint32_t tileBase = lo + 32u*t;
 					const uint32_t j = tileBase + candPlace;
 					const bool inRow = j < hi;
@@ -397,6 +408,7 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 			CellMeta nextMeta = cell_meta(0);
 #pragma unroll 1
 			for (int cc = 0; cc < 9; ++cc) {
+				SPHX_EMU_MARK(200 + cc);
 				const CellMeta cur = nextMeta;
 				nextMeta = cell_meta(min(cc + 1, 8));
 				const int dx = cc % 3 - 1, dy = cc/3 - 1;
@@ -533,7 +545,9 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 		neibs_mfma_prepass<MC1, NEIB_FRING, NEIB_BRING>(p, posArray, infoArray, particleHash, cellStart, cellEnd, cellFluidEnd,
 			sqinfluenceradius, lane, index, pos, gridPos, info, fluidOnly, noBB, walking, nf, nb, nv, ring, column,
 			reinterpret_cast<uint32_t (*)[64][NM_WORDS]>(sMask + (threadIdx.x >> 6)*(3*64*NM_WORDS)));
+	SPHX_EMU_MARK(300);
 	const unsigned long long wmask = __builtin_amdgcn_ballot_w64(walking);
+	SPHX_EMU_REFUSE(wmask != 0ull, "build_neibs_kernel: lanes are left to the general walk, whose ballots sit under lane-dependent conditions");
 	// first particle, end of the fluid segment and end of neighbour cell `c` of every lane.  The three loads do not depend
 	// on each other and are issued one cell ahead of their use, so that a cell costs one memory round trip (its first batch
 	// of positions) instead of two
@@ -687,6 +701,7 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 			}
 		}
 	}
+	SPHX_EMU_MARK(400);
 	ring.finish();
 	// the section lengths of this list, for the builder of the tile lists (forces.hip): it sizes the rows of a chunk of 64
 	// particles from them before it reads a single entry (second section: boundary particles, or the vertices with SA_BOUNDARY)

@@ -80,6 +80,7 @@ struct Team {
 	const std::function<void()> *body;
 };
 inline Team *team = nullptr;
+inline int marks[2048]; inline unsigned long meets[2048], meetsAtMark[2048];      // SPHX_EMU_MARK(n): where a fibre was last seen, printed when a block gets stuck
 inline std::vector<char> stacks;
 static const size_t STACK = 512u*1024u;
 inline void yield() { Team *t = team; swapcontext(&t->fibre[t->current].ctx, &t->scheduler); }
@@ -96,6 +97,7 @@ inline const unsigned long long *meet(unsigned long long v)
 {
 	Team *t = team;
 	const unsigned tid = t->current, lane = tid & 63u;
+	meets[tid]++;
 	Wave &w = t->wave[tid >> 6];
 	const unsigned g = w.gen, par = g & 1u;
 	w.slot[par][lane] = v;
@@ -251,11 +253,14 @@ inline void run_grid(unsigned grid, unsigned block, const std::function<void()> 
 	Team t;
 	t.body = &body;
 	gridDim = dim3(grid); blockDim = dim3(block);
+	static const bool trace = getenv("SPHX_EMU_TRACE") != nullptr;
 	for (unsigned bi = 0; bi < grid; ++bi) {
+		if (trace) fprintf(stderr, "hostemu: block %u of %u\n", bi, grid);
 		blockIdx = dim3(bi);
 		t.fibre.assign(block, Fibre());
 		t.wave.assign(block/64u, Wave());
 		t.moved = 0; t.barArrived = 0; t.barGen = 0;
+		for (unsigned i = 0; i < block && i < 2048u; ++i) { meets[i] = 0; marks[i] = 0; }
 		team = &t;
 		for (unsigned i = 0; i < block; ++i) {
 			Fibre &f = t.fibre[i];
@@ -279,6 +284,8 @@ inline void run_grid(unsigned grid, unsigned block, const std::function<void()> 
 			if (!alive) break;
 			if (t.moved == before) {
 				fprintf(stderr, "hostemu: block %u is stuck: a wave operation (or __syncthreads) was not reached by every lane\n", bi);
+				for (unsigned i = 0; i < block; ++i)
+					fprintf(stderr, "%s%d%s:%lu/%lu%s", (i & 63u) ? " " : "  wave marks: ", marks[i], t.fibre[i].done ? "d" : "", meetsAtMark[i], meets[i], (i & 63u) == 63u ? "\n" : "");
 				abort();
 			}
 		}
@@ -286,6 +293,9 @@ inline void run_grid(unsigned grid, unsigned block, const std::function<void()> 
 	}
 }
 }
+// a state the emulation cannot carry on from (fibres have no execution mask: ballots under lane-dependent conditions): say so and stop
+#define SPHX_EMU_REFUSE(cond, what) do { if (cond) { fprintf(stderr, "hostemu: %s\n", what); abort(); } } while (0)
+#define SPHX_EMU_MARK(n) (emu::marks[threadIdx.x] = (n), emu::meetsAtMark[threadIdx.x] = emu::meets[threadIdx.x])
 #define SPHX_LAUNCH_WAVES(kernel, grid, block, stream, ...) do { (void)(stream); \
 	emu::run_grid((unsigned)(grid), (unsigned)(block), [&]() { kernel(__VA_ARGS__); }); } while (0)
 

@@ -15,7 +15,7 @@ _EMU = os.path.join(_HERE, "hostemu")
 _ROOT = os.path.dirname(_HERE)
 _SO = os.path.join(_EMU, "_build", "libsphx_emu_asan.so" if os.environ.get("SPHX_HOSTEMU_ASAN") == "1" else "libsphx_emu.so")
 _SOURCES = [os.path.join(_EMU, "emu_sphx.cc"), os.path.join(_EMU, "hip", "hip_runtime.h")] + \
-    [os.path.join(_ROOT, "gpusph_amd", "csrc", f) for f in ("sphx_api.hip", "sa_io.hip", "sa_bounds.hip", "euler.hip", "sphx_internal.h",
+    [os.path.join(_ROOT, "gpusph_amd", "csrc", f) for f in ("sphx_api.hip", "sa_io.hip", "sa_bounds.hip", "euler.hip", "neibs_build.hip", "sphx_internal.h",
                                                               "neib_iter.h", "wave_list.h", "sa_wall_gamma.h", "sa_args.h")] + \
     [os.path.join(_ROOT, "include", "sphx.h")]
 
@@ -53,7 +53,7 @@ def build():
     # SPHX_HOSTEMU_ASAN=1: an address-sanitised build, for a run under LD_PRELOAD=libasan.so (out-of-bounds reads and writes of the
     # kernels on the exact-size numpy buffers of these tests; see tests/hostemu/README)
     san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"] if os.environ.get("SPHX_HOSTEMU_ASAN") == "1" else []
-    cmd = ["g++", "-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes"] + san + [
+    cmd = ["g++"] + (["-DSPHX_EMU_DEBUG"] if os.environ.get("SPHX_EMU_DEBUG") else []) + ["-O1", "-g0", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-attributes"] + san + [
            "-I" + _EMU, "-I" + os.path.join(_EMU, "_build"), "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.join(_ROOT, "gpusph_amd", "csrc"),
            "-o", _SO, os.path.join(_EMU, "emu_sphx.cc")]
     subprocess.run(cmd, check=True, capture_output=True)
