@@ -72,6 +72,7 @@ SIGNATURES = {
     "sphx_sa_compute_density_diffusion_io": (_i, [_vp] + [_vp] * 12 + [_u32, _u32, _f, _f, _vp]),
     "sphx_flux_computation": (_i, [_vp] + [_vp] * 4 + [_u32, _u32, _u32, _vp]),
     "sphx_sa_io_water_depth": (_i, [_vp] + [_vp] * 6 + [_u32, _u32, _u32, _vp]),
+    "sphx_sa_body_pressure_forces": (_i, [_vp] * 9 + [_u32, _u32, _vp]),
     "sphx_forces_basicstep_sa": (_i, [_vp] + [_vp] * 14 + [_u32, _u32, _u32, _f, _f, _f, _f, _u32, _i, _i, _f, _vp, _vp]),
     "sphx_forces_dtreduce_gamma_device": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),
     "sphx_forces_dtreduce_gamma": (_i, [_vp, _vp, _u32, _u32, _vp, _vp]),

@@ -174,6 +174,16 @@ struct SaNeibArgs {
 // one row), particles in the first / last cell of a periodic COORD1, rows whose candidate range exceeds NM_TMAX tiles even for
 // a single column of home cells, SA_BOUNDARY (vertex section, VERTPOS) -- a lane the prepass does not take is simply still
 // `walking` afterwards.
+//
+// MEASURED (round 6, MI355X, DamBreak3D 31.8 M particles, profiles/r06_neibs_mfma.txt): lists bit-identical to the oracle's up to
+// 32 M particles (tests/test_gpu_parity.py with SPHX_NEIBS_MFMA=1, tests/test_neibs_mfma_hostemu.py), and SLOWER than the general
+// walk: 18.8 - 19.8 ms per launch against 12.96.  Where it goes (variants of the same launch): masks alone 7.8 ms, the emission's
+// scaffolding with empty masks (27 x cell tables + mask words per lane, one memory round trip each at three waves per SIMD -- the
+// masks' LDS and the ring allow no more) 10.4 ms, the entries themselves ~4 ms.  And the premise was wrong by a factor: fp32 on the
+// matrix cores has the SAME rate as on the vector unit (256 flop/clk/CU either way; only the lower precisions are faster), so the
+// product buys issue slots, not throughput -- 45 tiles x 6 v_mfma x 64 cycles are 3.5 ms of every SIMD's matrix pipe per launch
+// before anything else.  It is therefore OFF unless SPHX_NEIBS_MFMA=1 (kept: it is a second, independent implementation of
+// the list build that the parity tests hold against the first).
 // ------------------------------------------------------------------------------------------
 #define NM_TMAX 6                    // tiles of 32 candidates per row whose masks a lane keeps (192 candidates)
 #define NM_WORDS (NM_TMAX + 2)       // mask words per lane and row in LDS: the tiles + zeros for the 96-bit reads of the emission
@@ -267,10 +277,6 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 			if (cmax == cmin) break;
 			cmax = cmin + (cmax - cmin)/2;
 		}
-#ifdef SPHX_EMU_DEBUG
-		if (lane == (uint32_t)lead) { fprintf(stderr, "group key %d cmin %d cmax %d fits %d lead %d gm0 %llx oaG %d zG %d:", key, cmin, cmax, (int)fits, lead, gm0, oaG, zG);
-			for (int r9 = 0; r9 < 9; ++r9) fprintf(stderr, " [%d %u %u]", rowBase[r9], rowLo[r9], rowHi[r9]); fprintf(stderr, "\n"); }
-#endif
 		if (!fits) {      // one column of home cells whose neighbourhood does not fit: the general walk takes these lanes
 			todo = todo && !(rowKey == key && c1 == cmin);
 			continue;
@@ -288,7 +294,7 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 			// home particle shifted into the neighbouring row's frame); M bounds |c|^2 and |h|^2.  The product's value differs from
 			// the exact |x_i - x_j|^2 of the same inputs by at most the roundings of the frame conversion (2^-23 of a coordinate,
 			// times 2 r), of |c|^2, |h|^2 (3 x 2^-24 M each) and of four multiply-accumulate steps on magnitudes <= 4 M
-			// (2^-23 each if the unit rounds product and sum separately): < 2^-19 M + 2^-18 R^2; the reference's own value differs
+			// (2^-23 each if the unit rounds product and sum separately; the constant term enters as a fifth, exact, product): < 2^-19 M + 2^-18 R^2; the reference's own value differs
 			// from the exact one by < 2^-21 R^2.  The band is twice that sum.
 			const float m1 = ((float)(cmax - cmin)*0.5f + 2.0f)*cs1;
 			const float M = fmaf(m1, m1, fmaf(1.5f*csOA, 1.5f*csOA, (1.5f*csZ)*(1.5f*csZ)));
@@ -311,36 +317,51 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 				curLo[rs] = sl == 0 ? rowLo[rs] : sl == 1 ? rowLo[3 + rs] : rowLo[6 + rs];
 				curHi[rs] = sl == 0 ? rowHi[rs] : sl == 1 ? rowHi[3 + rs] : rowHi[6 + rs];
 			}
-			// ---- the masks of the slab's three rows
+			// ---- the masks of the slab's three rows.  The candidates of a row (<= NM_TMAX tiles: a position row and a hash per lane
+			// and tile) are requested together, so that a row costs one memory round trip (round 6, first version: one exposed trip
+			// per TILE, ~40 per group at three waves per SIMD: the prepass lost to the walk it replaces, 18.8 against 13.0 ms at 32 M)
+			auto request_row = [&](uint32_t lo, uint32_t hi, float4 (&cp)[NM_TMAX], uint32_t (&ch)[NM_TMAX]) {
 #pragma unroll
-			for (int rs = 0; rs < 3; ++rs) {
+				for (int t = 0; t < NM_TMAX; ++t) {
+					const uint32_t j = lo + 32u*(uint32_t)t + candPlace;
+					if (lo + 32u*(uint32_t)t < hi) {      // (wave-uniform)
+						const uint32_t jj = j < hi ? j : lo;
+						cp[t] = posArray[jj]; ch[t] = particleHash[jj];
+					}
+				}
+			};
+			auto compute_row = [&](int rs, const float4 (&cpv)[NM_TMAX], const uint32_t (&chv)[NM_TMAX]) {
 				uint32_t *myWords = sMask[rs][lane];
 #pragma unroll
 				for (int w = 0; w < NM_WORDS; ++w) myWords[w] = 0u;
 				const uint32_t lo = curLo[rs], hi = curHi[rs];
 				const int rbase = curBase[rs];
-				if (hi == lo) continue;
+				if (hi == lo) return;
 				const float shOA = (float)(rs - 1)*csOA;
 				// the home particle in this row's frame (the reference shifts the home particle, not the candidate)
 				const float hOAr = posOA - shOA, hZr = pos.z - shZ;
 				const float nOwn = fmaf(hZr, hZr, fmaf(hOAr, hOAr, h1*h1));
+				// |h|^2 - R^2 + band, the term that depends on the home particle alone, rides as a fifth inner dimension (candidate
+				// side 1): the accumulator starts from the literal zero and needs no sixteen registers of copies per half
 				float cinit[2];
 				nm_both_halves((nOwn - sqinfluenceradius) + band, cinit[0], cinit[1]);
-				float b1[2], b2[2];
+				float b1[2], b2[2], b3[2];
 #pragma unroll
 				for (int s = 0; s < 2; ++s) {
 					b1[s] = lowHalf ? h1s[s] : hoas[s] - shOA;
 					b2[s] = lowHalf ? hzs[s] - shZ : 1.0f;
+					b3[s] = lowHalf ? cinit[s] : 0.0f;
 				}
-				const uint32_t tiles = (hi - lo + 31u) >> 5;
-#pragma unroll 1
-				for (uint32_t t = 0; t < tiles; ++t) {
-					SPHX_EMU_MARK(100 + 10*rs + (int)t);
-					const uint32_t tileBase = lo + 32u*t;
+				const float a3 = lowHalf ? 1.0f : 0.0f;
+#pragma unroll
+				for (int t = 0; t < NM_TMAX; ++t) {
+					const uint32_t tileBase = lo + 32u*(uint32_t)t;
+					if (tileBase >= hi) break;
+					SPHX_EMU_MARK(100 + 10*rs + t);
 					const uint32_t j = tileBase + candPlace;
 					const bool inRow = j < hi;
-					const float4 cp = posArray[inRow ? j : lo];
-					const int col = (int)(particleHash[inRow ? j : lo] & CELLTYPE_BITMASK) - rbase;
+					const float4 cp = cpv[t];
+					const int col = (int)(chv[t] & CELLTYPE_BITMASK) - rbase;
 					const float c1f = fmaf((float)(col - cref), cs1, MC1 == 0 ? cp.x : cp.y);
 					const float cOA = MC1 == 0 ? cp.y : cp.x;
 					const float n = fmaf(cp.z, cp.z, fmaf(cOA, cOA, c1f*c1f));
@@ -352,7 +373,8 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 					for (int s = 0; s < 2; ++s) {
 						nm_f16 acc;
 #pragma unroll
-						for (int r = 0; r < 16; ++r) acc[r] = cinit[s];
+						for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3[s], acc, 0, 0, 0);
 						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1[s], acc, 0, 0, 0);
 						acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2[s], acc, 0, 0, 0);
 						uint32_t bits = 0u, smallest = 0xFFFFFFFFu;
@@ -391,6 +413,14 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 					}
 					myWords[t] = mask;
 				}
+			};
+#pragma unroll
+			for (int rs = 0; rs < 3; ++rs) {
+				float4 cpv[NM_TMAX]; uint32_t chv[NM_TMAX];
+#pragma unroll
+				for (int t = 0; t < NM_TMAX; ++t) { cpv[t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); chv[t] = 0u; }
+				request_row(curLo[rs], curHi[rs], cpv, chv);
+				compute_row(rs, cpv, chv);
 			}
 			// ---- emission: the nine cells of the slab in cell-code order
 			struct CellMeta { uint32_t start, fluidEnd, end; };
@@ -482,7 +512,7 @@ __device__ __forceinline__ void neibs_mfma_prepass(const DevParams &p, const flo
 // SA: semi-analytical boundaries (vertex section, wider boundary radius, VERTPOS of the segments)
 // MC1: -1, or the axis of COORD1 (0 = x, 1 = y) for the prepass on the matrix cores above (never with SA)
 template<bool BUF, bool SA, int MC1 = -1>
-__global__ void __launch_bounds__(BLOCK_NEIBS)
+__global__ void __launch_bounds__(BLOCK_NEIBS, (MC1 >= 0 ? 3 : 1))      // (the prepass's LDS allows three workgroups per CU: registers for as many)
 build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	const float4 *__restrict__ posArray, const particleinfo *__restrict__ infoArray,
 	const uint32_t *__restrict__ particleHash,
@@ -737,9 +767,10 @@ int sphx_neibs_list_launch(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, 
 	saArgs.vertices = (const uint4*)vertices; saArgs.boundElements = (const float4*)boundElements;
 	saArgs.vertPos[0] = (float2*)vertPos0; saArgs.vertPos[1] = (float2*)vertPos1; saArgs.vertPos[2] = (float2*)vertPos2;
 	saArgs.boundNlSqInflRad = boundNlSqInflRad;
-	// the prepass on the matrix cores: COORD1 = x or y, plain boundaries, positions behind a buffer descriptor
-	static const bool noMfma = getenv("SPHX_NEIBS_NO_MFMA") != nullptr;      // A/B switch: the general walk alone
-	const int mc1 = (!sa && posBuf && !noMfma && ctx->dev.c1 <= 1) ? ctx->dev.c1 : -1;
+	// the prepass on the matrix cores (COORD1 = x or y, plain boundaries, positions behind a buffer descriptor): an experiment that
+	// is bit-identical and measured slower than the general walk (see the account above neibs_mfma_prepass): SPHX_NEIBS_MFMA=1 runs it
+	// (read when the context was created, like SPHX_DISABLE_TILES)
+	const int mc1 = (!sa && posBuf && ctx->neibs_mfma && ctx->dev.c1 <= 1) ? ctx->dev.c1 : -1;
 #define SPHX_NB_LAUNCH(K) SPHX_LAUNCH_WAVES(K, div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, st, ctx->dev, \
 		saArgs, neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end, \
 		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev, ctx->neib_counts)

@@ -969,7 +969,7 @@ static int sa_forces_check(sphx_ctx *ctx, const char *who)
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: built are ENABLE_DENSITY_SUM with dynamic gamma, and the continuity equation with ENABLE_GAMMA_QUADRATURE");
 	// ENABLE_MOVING_BODIES: bodies with prescribed motion (segments and vertices flagged FG_MOVING_BOUNDARY); the pair terms read the
 	// elements' velocities from BUFFER_VEL as they do for walls at rest.  Bodies that FEEL the fluid (FG_COMPUTE_FORCE rows of
-	// BUFFER_RB_FORCES with SA_BOUNDARY) are not built.
+	// BUFFER_RB_FORCES with SA_BOUNDARY): the pressure force on their elements is sphx_sa_body_pressure_forces, below.
 	if (q.simflags & (SPHX_ENABLE_XSPH | SPHX_ENABLE_PLANES))
 		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa: SA forces are built without XSPH and planes");
 	if (q.sph_formulation != SPHX_SPH_F1)
@@ -1069,6 +1069,63 @@ extern "C" int sphx_forces_basicstep_sa(sphx_ctx *ctx, void *forces, float *cfl,
 	return sa_forces_impl(ctx, forces, cfl, cflGamma, nullptr, pos, vel, info, hash, cellStart, neibsList, gGam, boundElements,
 		vertPos0, vertPos1, vertPos2, numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor, influenceradius,
 		cflOffset, run_mode, step, dt, h_numBlocks, stream);
+}
+
+// ---- the force of the fluid on the boundary elements of bodies that feel it (FG_COMPUTE_FORCE: floating bodies, force-feedback
+// bodies, fixed ones whose load is measured).  With SA_BOUNDARY the pair loops leave nothing on a segment; its force is the
+// pressure the boundary conditions gave it, acting on its area against its normal: F = -P(rho~) A n
+// (compute_boundary_pressure_force, src/cuda/forces_kernel.def:3258-3266), written to the body's rows of BUFFER_RB_FORCES /
+// BUFFER_RB_TORQUES (torque about the centre of gravity the forces engine holds) and to the segment's own row of
+// BUFFER_FORCES with w = 0, as finalizeforcesDevice does for these rows (:4115-4145; vertices write nothing).  The totals are
+// sphx_reduce_rb_forces' as for every other boundary model.
+struct SaBodyForceArgs {
+	float4 *forces, *rbforces, *rbtorques;
+	const float4 *pos, *vel, *boundElement;
+	const particleinfo *info; const uint32_t *hash;
+	const RbParams *rb;
+	uint32_t from, to;
+};
+
+__global__ void __launch_bounds__(256)
+sa_body_pressure_force_kernel(DevParams p, SaBodyForceArgs a)
+{
+	const uint32_t index = a.from + blockIdx.x*256 + threadIdx.x;
+	if (index >= a.to) return;
+	const particleinfo info = a.info[index];
+	if (PART_TYPE(info) != PT_BOUNDARY || !HAS_COMPUTE_FORCE(info)) return;
+	const float4 pos = a.pos[index];
+	if (!is_active_w(pos.w)) return;
+	const float4 be = a.boundElement[index];
+	const float scale = -sa_P(p, a.vel[index].w, FLUID_NUM(info))*be.w;
+	const float4 force = make_float4(scale*be.x, scale*be.y, scale*be.z, 0.0f);
+	const uint32_t obj = OBJECT_NUM(info);
+	const uint32_t rbindex = (uint32_t)((int)info_id(info) + a.rb->rbstart[obj]);
+	a.rbforces[rbindex] = force;
+	const int3 gp = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+	const float armx = (gp.x - a.rb->cgGridPos[obj][0])*p.cs[0] + (pos.x - a.rb->cgPos[obj][0]);
+	const float army = (gp.y - a.rb->cgGridPos[obj][1])*p.cs[1] + (pos.y - a.rb->cgPos[obj][1]);
+	const float armz = (gp.z - a.rb->cgGridPos[obj][2])*p.cs[2] + (pos.z - a.rb->cgPos[obj][2]);
+	a.rbtorques[rbindex] = make_float4(army*force.z - armz*force.y, armz*force.x - armx*force.z, armx*force.y - army*force.x, 0.0f);
+	a.forces[index] = force;
+}
+
+extern "C" int sphx_sa_body_pressure_forces(sphx_ctx *ctx, void *forces, void *rbforces, void *rbtorques,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash, const void *boundElements,
+	uint32_t fromParticle, uint32_t toParticle, void *stream)
+{
+	int rc = sa_check(ctx, "sphx_sa_body_pressure_forces called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	SPHX_REQUIRE(forces && rbforces && rbtorques && pos && vel && info && hash && boundElements, "sphx_sa_body_pressure_forces: missing buffer");
+	SPHX_REQUIRE(fromParticle <= toParticle, "sphx_sa_body_pressure_forces: empty range");
+	if (fromParticle == toParticle) return SPHX_OK;
+	{ const int rcf = sphx_rb_flush(ctx, (hipStream_t)stream); if (rcf != SPHX_OK) return rcf; }
+	SaBodyForceArgs a = {};
+	a.forces = (float4*)forces; a.rbforces = (float4*)rbforces; a.rbtorques = (float4*)rbtorques;
+	a.pos = (const float4*)pos; a.vel = (const float4*)vel; a.boundElement = (const float4*)boundElements;
+	a.info = (const particleinfo*)info; a.hash = hash; a.rb = ctx->rb_dev; a.from = fromParticle; a.to = toParticle;
+	sa_body_pressure_force_kernel<<<div_up_u(toParticle - fromParticle, 256), 256, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_body_pressure_force_kernel");
+	return SPHX_OK;
 }
 
 extern "C" int sphx_forces_basicstep_sa_keps(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, float *cflKeps, float *dkde,

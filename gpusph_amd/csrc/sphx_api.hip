@@ -45,6 +45,7 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	ctx->tile_grid = (uint32_t)(cus > 0 ? cus : 256)*TILE_WGS_PER_CU;   // persistent grid: one 512-thread workgroup per CU (LDS bound)
 	const char *dis = getenv("SPHX_DISABLE_TILES");
 	ctx->disable_tiles = dis && dis[0] == '1';
+	{ const char *mf = getenv("SPHX_NEIBS_MFMA"); ctx->neibs_mfma = mf && mf[0] == '1'; }
 	// SPHX_DISABLE_TILES=1: always the generic gather kernel (A/B runs, tests).
 	// SPHX_TILE_DEBUG (ForcesArgs::dbg: timing experiments, some of which skip work and give wrong results) only exists in a
 	// library built with -DSPHX_TILE_DEBUG_BUILD (make EXTRA=-DSPHX_TILE_DEBUG_BUILD); the product library ignores the variable

@@ -196,6 +196,7 @@ struct sphx_ctx {
 	hipEvent_t  side_fork, side_join;
 	bool        ovf_pending;
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
+	bool        neibs_mfma;    // SPHX_NEIBS_MFMA=1 in the environment when the context was created: the list build's prepass on the matrix cores (neibs_build.hip)
 	int         tile_debug;    // SPHX_TILE_DEBUG (timing experiments; only with -DSPHX_TILE_DEBUG_BUILD)
 	unsigned long long *tile_prof;   // ... & 16: phase timers of the tiled forces kernel
 	bool        time_forces;   // sphx_forces_timing: bracket the dominant forces kernel with HIP events

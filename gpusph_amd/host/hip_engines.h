@@ -437,6 +437,19 @@ public:
 			uint32_t nb = 0;
 			// BUFFER_CFL_GAMMA is there with dynamic gamma and adaptive dt (src/cuda/forces_params.h, dyndt + gamma)
 			const bool gcfl = !(P.simflags & ENABLE_GAMMA_QUADRATURE) && (P.simflags & ENABLE_DTADAPT);
+			// bodies that feel the fluid: with SA_BOUNDARY the force on a COMPUTE_FORCE element is the pressure on its area
+			// (compute_boundary_pressure_force in finalizeforcesDevice, src/cuda/forces_kernel.def:3258-3266,4115-4145), written to
+			// BUFFER_RB_FORCES / BUFFER_RB_TORQUES behind whichever SA forces entry ran on this range
+			struct BodyForces {
+				HIPForcesEngine *e; const BufferList &r; BufferList &w; float4 *forces; uint from, to; bool on;
+				~BodyForces() noexcept(false) {
+					if (!on || std::uncaught_exceptions()) return;
+					float4 *rbf = w.getData<BUFFER_RB_FORCES>(), *rbt = w.getData<BUFFER_RB_TORQUES>();
+					if (!rbf || !rbt) return;
+					sphx_throw(sphx_sa_body_pressure_forces(e->m_c->ctx(), forces, rbf, rbt, r.getData<BUFFER_POS>(), r.getData<BUFFER_VEL>(),
+						r.getData<BUFFER_INFO>(), r.getData<BUFFER_HASH>(), r.getData<BUFFER_BOUNDELEMENTS>(), from, to, NULL));
+				}
+			} bodyForces = { this, bufread, bufwrite, forces, fromParticle, toParticle, compute_object_forces && run_mode == SIMULATE };
 			if (P.turbmodel == KEPSILON && run_mode == SIMULATE) {
 				// keps_forces_params (src/cuda/forces_params.h:283-320): k, epsilon, eddy viscosity and Eulerian velocity of the
 				// state that is read; BUFFER_DKDE and BUFFER_CFL_KEPS written (BUFFER_TAU is not needed: one launch)

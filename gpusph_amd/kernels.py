@@ -142,6 +142,12 @@ class HipKernels:
                                                      run_mode, 1, 0.0, C.byref(nb), self._s()))
         return nb.value
 
+    def sa_body_pressure_forces(self, forces, rbforces, rbtorques, pos, vel, info, hash_, boundelements, frm, to):
+        """F = -P A n on the FG_COMPUTE_FORCE boundary elements of [frm, to) -> BUFFER_RB_FORCES / RB_TORQUES rows (+ their forces row)"""
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_body_pressure_forces(self.ctx.handle, p(forces), p(rbforces), p(rbtorques), p(pos), p(vel), p(info),
+                                                         p(hash_), p(boundelements), frm, to, self._s()))
+
     # ---- turbulence<KEPSILON> (SA_BOUNDARY, solid walls): ke = dict(tke, eps, turbvisc, eulervel) of the state
     def forces_sa_keps(self, forces, cfl, cfl_keps, dkde, pos, vel, info, hash_, cellStart, neibslist, ggam, boundelements, vertpos, ke,
                        n, frm, to, cfl_offset, cfl_gamma=None, epsilon=5e-5):

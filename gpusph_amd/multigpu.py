@@ -586,8 +586,17 @@ class MultiGpuEngine:
             ke = (self.ke if pos is self.pos else self.ke2) if (self.keps and run_mode == D.SIMULATE) else None
             if ke is not None:
                 K.memset(self.cfl_keps, 0)
+            # bodies that feel the fluid (FG_COMPUTE_FORCE segments): the pressure force on their elements rides with the pass
+            # (compute_boundary_pressure_force inside finalizeforcesDevice, src/cuda/forces_kernel.def:4115-4145)
+            body_forces = self.has_rb and self.sp.numforcesbodies > 0 and run_mode == D.SIMULATE
 
             def launch(frm, to, off):
+                nb = launch_sa(frm, to, off)
+                if body_forces:
+                    K.sa_body_pressure_forces(self.forces, self.rbforces, self.rbtorques, pos, vel, self.info, self.hash, be, frm, to)
+                return nb
+
+            def launch_sa(frm, to, off):
                 if ke is not None:
                     return K.forces_sa_keps(self.forces, self.cfl, self.cfl_keps, self.dkde, pos, vel, self.info, self.hash, self.cellStart,
                                             self.neibslist, ggam, self.boundelements, self.vertpos, ke, self.n_local, frm, to, off,

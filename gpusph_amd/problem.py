@@ -1012,6 +1012,38 @@ class SABox(Problem):
         return a
 
 
+class SALoadBox(SABox):
+    """SABox whose FLOOR is a body that feels the fluid: its segments carry FG_COMPUTE_FORCE and object number 0, so the forces
+    engine writes the pressure force -P A n of every such element to BUFFER_RB_FORCES / BUFFER_RB_TORQUES
+    (compute_boundary_pressure_force, src/cuda/forces_kernel.def:3258-3266,4115-4145) and REDUCE_BODIES_FORCES sums them -- the part
+    of CompleteSaExample.cu's option set (a GT_FLOATING_BODY under SA_BOUNDARY, :122-124) that concerns the forces engine.  The body
+    is fixed ("we might have fixed objects which still want to measure the force", the reference's comment at :3254): the known
+    answer is the weight of the water, rho g V, pressing on the floor.  Vertices write no object forces with SA_BOUNDARY (:4120)."""
+
+    def __init__(self, deltap=0.05, **kw):
+        super().__init__(deltap, **kw)
+        self.m_name = "SALoadBox"
+        sp = self.simparams
+        sp.numbodies = 1
+        sp.numforcesbodies = 1
+        info = self.parts.info
+        nf = self.num_fluid
+        nfloor = 2 * self.n_l * self.n_w                 # the floor is the first face meshed: its segments lead the PT_BOUNDARY rows
+        load = np.zeros(len(info), dtype=bool)
+        load[nf:nf + nfloor] = True
+        assert (np.abs(self.boundelements[load, 2] - 1.0) < 1e-6).all()
+        info[load, 0] |= D.FG_COMPUTE_FORCE
+        info[load, 1] = (info[load, 1] & 0xF000) | 0
+        self.load = load
+        self.num_obstacle = int(nfloor)
+        self.rb_firstindex = np.array([-nf], dtype=np.int32)      # row = id + rb_firstindex[object] (rb_particle_data, forces_kernel.def:526)
+        cg = np.array([[0.5*self.l, 0.5*self.w, 0.0]])
+        self.rb_cg_global = cg.copy()
+        gcell = self.calc_grid_pos(cg)
+        self.rb_cg_gridpos = gcell.astype(np.int32)
+        self.rb_cg_pos = (cg - self.m_origin - (gcell + 0.5)*self.m_cellsize).astype(np.float32)
+
+
 class SAPaddleBox(SABox):
     """SABox whose x = 0 wall is a MOVING body with prescribed motion (SA_BOUNDARY + ENABLE_MOVING_BODIES):
     its segments and vertices carry FG_MOVING_BOUNDARY and object number 0, and turn about the hinge line x = 0, z = 0 (a flap

@@ -235,6 +235,15 @@ int sphx_neibs_getinfo(sphx_ctx *ctx, sphx_neibs_info *h_out, void *stream);
  * beyond ~66 M particles with ~65 neighbours each; as a signed int beyond ~33 M); sync */
 int sphx_neibs_interactions64(sphx_ctx *ctx, uint64_t *h_out, void *stream);
 
+/* The part of finalizeforcesDevice that belongs to the boundary elements of bodies with FG_COMPUTE_FORCE under SA_BOUNDARY
+ * (compute_boundary_pressure_force, src/cuda/forces_kernel.def:3258-3266,4115-4145): F = -P(rho~) A n per element into
+ * rbforces / rbtorques (BUFFER_RB_FORCES / BUFFER_RB_TORQUES rows id + rbstart[object], torque about the forces engine's centre of
+ * gravity: sphx_set_rb_start, sphx_set_rb_cg_forces) and into the element's own row of `forces` (w = 0).  Call it after
+ * sphx_forces_basicstep_sa[_keps|_io] of the same range when compute_object_forces is asked; sphx_reduce_rb_forces sums the rows
+ * (reduceRbForces, src/cuda/forces.cu:966-1004).  CompleteSaExample's floating cube is the reference's user. */
+int sphx_sa_body_pressure_forces(sphx_ctx *ctx, void *forces, void *rbforces, void *rbtorques,
+	const void *pos, const void *vel, const void *info, const uint32_t *hash, const void *boundElements,
+	uint32_t fromParticle, uint32_t toParticle, void *stream);
 /* basicstep of the forces engine with SA_BOUNDARY (src/cuda/forces.cu:717-806 with the SA members of forces_params): fluid <-
  * fluid, fluid <- vertex, fluid <- boundary element (through |grad gamma_as|, src/cuda/gamma.cuh), sums divided by gamma,
  * gravity, CFL maxima.  Built for solid walls, SPH_F1, laminar Newtonian or inviscid flow, in two forms: the continuity

@@ -4297,3 +4297,36 @@ void orc_flux_computation(float *IOflux, const orc_info *infoArray, const orc_f4
 		IOflux[OBJECT_NUM(info)] += normal.w*(e.x*normal.x + e.y*normal.y + e.z*normal.z);
 	}
 }
+
+/* ---- SA_BOUNDARY: the fluid's force on the boundary elements of bodies that feel it ----------------------------------------
+ * compute_boundary_pressure_force (src/cuda/forces_kernel.def:3258-3266): pout.force = -P(vel.w, fluid_num) * belem.w * belem,
+ * force.w = 0, for BOUNDARY && COMPUTE_FORCE rows of finalizeforcesDevice (:4115-4120); then, as for every COMPUTE_FORCE row that
+ * is not a vertex (:4121-4142; no multiplication by the mass with SA_BOUNDARY), rbforces[rbindex] = force, rbtorques[rbindex] =
+ * arm x force with arm = globalDistance(particle, centre of gravity); params.forces[index] = force (:4144) */
+void orc_sa_body_pressure_forces(const orc_params *p, orc_f4 *forces, orc_f4 *rbforces, orc_f4 *rbtorques,
+	const orc_f4 *posArray, const orc_f4 *velArray, const orc_info *infoArray, const uint32_t *hashArray, const orc_f4 *boundElements,
+	uint32_t fromParticle, uint32_t toParticle)
+{
+	for (uint32_t index = fromParticle; index < toParticle; ++index) {
+		const orc_info info = infoArray[index];
+		if (!(BOUNDARY(info) && COMPUTE_FORCE(info))) continue;
+		const orc_f4 pos = posArray[index];
+		if (INACTIVE(pos)) continue;
+		const orc_f4 belem = boundElements[index];
+		const float s = -orc_P(p, velArray[index].w, FLUID_NUM(info))*belem.w;
+		orc_f4 force;
+		force.x = s*belem.x; force.y = s*belem.y; force.z = s*belem.z; force.w = 0.0f;
+		const int obj = OBJECT_NUM(info);
+		const uint32_t rbindex = (uint32_t)((int)orc_info_id(info) + p->rbstartindex[obj]);
+		rbforces[rbindex] = force;
+		int gp[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gp);
+		const float ax = (gp[0] - p->rbcgGridPos[obj][0])*p->cellSize[0] + (pos.x - p->rbcgPos[obj][0]);
+		const float ay = (gp[1] - p->rbcgGridPos[obj][1])*p->cellSize[1] + (pos.y - p->rbcgPos[obj][1]);
+		const float az = (gp[2] - p->rbcgGridPos[obj][2])*p->cellSize[2] + (pos.z - p->rbcgPos[obj][2]);
+		orc_f4 tq;
+		tq.x = ay*force.z - az*force.y; tq.y = az*force.x - ax*force.z; tq.z = ax*force.y - ay*force.x; tq.w = 0.0f;
+		rbtorques[rbindex] = tq;
+		forces[index] = force;
+	}
+}

@@ -205,6 +205,10 @@ class OracleKernels:
                                         _p(vertpos[2]), C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
                                         C.c_float(self.sp.deltap)))
 
+    def sa_body_pressure_forces(self, forces, rbforces, rbtorques, pos, vel, info, hash_, boundelements, frm, to):
+        self.L.orc_sa_body_pressure_forces(C.byref(self.op), _p(forces), _p(rbforces), _p(rbtorques), _p(pos), _p(vel), _p(info), _p(hash_),
+                                           _p(boundelements), C.c_uint32(frm), C.c_uint32(to))
+
     # ---- turbulence<KEPSILON>: the interface of HipKernels' *_keps methods
     def sa_segment_bc_keps(self, vel, ggam, ke, pos, vertices, boundelements, info, hash_, cellStart, neibslist, n, range_end, step):
         self.L.orc_sa_segment_bc_keps(C.byref(self.op), _p(vel), _p(ggam), _p(ke["tke"]), _p(ke["eps"]), _p(ke["eulervel"]), _p(pos),

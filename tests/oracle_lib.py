@@ -362,6 +362,14 @@ class Oracle:
                                                      C.c_int(cptype), C.c_float(epsilon))
         return g
 
+    def sa_body_pressure_forces(self, pos, vel, info, hash_, boundelements, n, rows):
+        """-P A n of the FG_COMPUTE_FORCE boundary elements: (forces rows, BUFFER_RB_FORCES, BUFFER_RB_TORQUES)"""
+        f = np.zeros((len(pos), 4), dtype=np.float32)
+        rbf, rbt = np.zeros((rows, 4), dtype=np.float32), np.zeros((rows, 4), dtype=np.float32)
+        self.L.orc_sa_body_pressure_forces(C.byref(self.p), P(f), P(rbf), P(rbt), P(pos), P(vel), P(info), P(hash_), P(boundelements),
+                                           C.c_uint32(0), C.c_uint32(n))
+        return f, rbf, rbt
+
     def sa_density_diffusion(self, pos, vel, ggam, info, hash_, cs, nl, n, dt):
         """compute_density_diffusion (Brezzi) + apply_density_diffusion: returns the updated velocity array"""
         f = np.zeros((len(pos), 4), dtype=np.float32)

@@ -63,6 +63,37 @@ def test_neibs_phase_bit_exact(case):
     assert info.hasTooManyNeibs == -1
 
 
+MFMA_CASES = {
+    "dambreak-xzy": lambda: DamBreak3D(0.02, obstacle=True, jitter=0.05, linearization="xzy"),
+    "dambreak-yzx": lambda: DamBreak3D(0.025, obstacle=True, jitter=0.1, linearization="yzx"),
+    "dambreak-zxy": lambda: DamBreak3D(0.04, obstacle=True, jitter=0.1, linearization="zxy"),          # COORD1 = z: every lane goes to the general walk
+    "lj-testpoints": lambda: DamBreak3D(0.03, boundary=D.LJ_BOUNDARY, jitter=0.1, linearization="yzx", testpoints=((0.5, 0.3, 0.1), (1.2, 0.33, 0.2))),
+    "gaussian": lambda: DamBreak3D(0.04, kerneltype=D.GAUSSIAN, jitter=0.1, linearization="xzy"),      # cells of ~60 particles: rows beyond six tiles
+    "periodic-xyz": lambda: __import__("gpusph_amd.problem", fromlist=["PeriodicBox"]).PeriodicBox(
+        n=(14, 12, 11), linearization="xzy", velocity=(0.4, 0.3, -0.2)),                   # first / last cell of a periodic COORD1
+    "dambreak-1M": lambda: DamBreak3D(DamBreak3D.deltap_for(1.0e6), obstacle=True, hydrostatic=False, jitter=0.05, linearization="xzy"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(MFMA_CASES))
+def test_list_build_on_the_matrix_cores_bit_exact(name, monkeypatch):
+    """SPHX_NEIBS_MFMA=1: the distance tests of the list build as v_mfma_f32_32x32x2_f32 products with the reference's arithmetic
+    inside the band where the product's verdict is not trusted (neibs_build.hip; off by default: measured slower than the general
+    walk).  Every list entry, the counters and the section lengths behind the tile lists (a tiled forces pass on them agrees with
+    the gather kernel) -- including the lanes the prepass hands to the general walk (COORD1 = z, periodic COORD1, long rows)."""
+    monkeypatch.setenv("SPHX_NEIBS_MFMA", "1")      # read when the context is created
+    prob = MFMA_CASES[name]()
+    eng = _engine(prob, clobber_neibslist=True)
+    sim = ol.OracleSim(prob)
+    sim.build_neibs(); eng.build_neibs()            # (the same inputs on both sides: the initial state, jittered)
+    n = eng.n
+    assert n == sim.n and np.array_equal(_np(eng.hash, np.uint32)[:n], sim.hash[:n])
+    assert np.array_equal(_np(eng.neibslist, np.uint16), sim.nl)
+    info = eng.neibs_info()
+    assert info.numInteractions == sim.neibs_info.numInteractions
+    assert info.maxFluidBoundaryNeibs == sim.neibs_info.maxFluidBoundaryNeibs and info.hasTooManyNeibs == -1
+
+
 def test_many_inactive_particles_sort_without_a_quadratic_bin():
     """1e5 disabled particles (outflow, disableFreeSurfParts at scale): they all share the CELL_HASH_MAX bin.  The
     active prefix is bit-identical to the oracle's (hash, info, permutation, cells, lists), the tail holds exactly the

@@ -465,3 +465,52 @@ def test_sa_tiled_kernels_agree_with_the_list_walkers(options, monkeypatch):
     assert_close_but_for_gamma_spikes(vel_t[:, 3], vel_w[:, 3], 2e-6, 1.0, spike=10.0, what="densities, tiled against list walkers")
     assert np.abs(gg_t[fl, 3] - gg_w[fl, 3]).max() < 2e-5
     assert abs(dt_t - dt_w) < 1e-4 * dt_w
+
+
+@pytest.mark.gpu
+def test_force_on_a_body_that_feels_the_fluid():
+    """sphx_sa_body_pressure_forces (compute_boundary_pressure_force + the BUFFER_RB_FORCES / RB_TORQUES rows of finalizeforcesDevice,
+    src/cuda/forces_kernel.def:3258-3266,4115-4145) for the floor of SALoadBox: rows, torques and the elements' own forces rows
+    against the oracle's restatement on identical inputs (the pressure goes through powf of two math libraries: 1 ulp of
+    (1 + rho~)^7 is 1e-5 of P at these densities), the totals through sphx_reduce_rb_forces against the weight of the water, and
+    the same rows left behind by the engine's own forces pass (the driver calls the entry point behind every SA forces pass when
+    the problem has force bodies)."""
+    from gpusph_amd.problem import SALoadBox
+    from sa_helpers import OracleSaSim
+    import torch
+    kw = dict(deltap=0.05, jitter=0.1)
+    sim = OracleSaSim(SALoadBox(**kw))
+    eng = _engine(SALoadBox(**kw), clobber_neibslist=True)
+    eng.build_neibs()
+    eng.sa_boundary_conditions(0)
+    n, o, k, p = sim.n, sim.o, eng.k, sim.problem
+    assert np.array_equal(_np(eng.info, np.uint16)[:n], sim.info[:n])
+    for name, arr in (("vel", sim.vel), ("boundelements", sim.be)):
+        getattr(eng, name)[:n] = torch.from_numpy(arr).to(eng.device)
+    f, rbf, rbt = o.sa_body_pressure_forces(sim.pos, sim.vel, sim.info, sim.hash, sim.be, n, p.num_obstacle)
+    eng.forces.zero_(); eng.rbforces.zero_(); eng.rbtorques.zero_()
+    k.sa_body_pressure_forces(eng.forces, eng.rbforces, eng.rbtorques, eng.pos, eng.vel, eng.info, eng.hash, eng.boundelements, 0, n)
+    grf, grt, gf = _np(eng.rbforces), _np(eng.rbtorques), _np(eng.forces)[:n]
+    scale = np.abs(rbf[:, 2]).max()
+    assert np.abs(grf - rbf).max() <= 3e-5 * scale
+    assert np.abs(grt - rbt).max() <= 3e-5 * scale * max(p.l, p.w)
+    assert np.abs(gf - f[:n]).max() <= 3e-5 * scale and (gf[:, 3] == 0).all()
+    load = (sim.info[:n, 0] & D.FG_COMPUTE_FORCE) != 0
+    assert not gf[~load].any()
+    # the totals: the weight of the water on the floor
+    weight = p.physparams.rho0[0] * 9.81 * p.l * p.w * p.water_level
+    tf, tt = eng.reduce_rb_forces()
+    assert abs(tf[2] + weight) < 0.01 * weight and abs(tf[2] - rbf[:, 2].astype(np.float64).sum()) < 1e-4 * weight
+    # a range launch touches its own rows only
+    eng.rbforces.zero_(); eng.rbtorques.zero_()
+    k.sa_body_pressure_forces(eng.forces, eng.rbforces, eng.rbtorques, eng.pos, eng.vel, eng.info, eng.hash, eng.boundelements, n // 2, n)
+    idx = np.where(load)[0]
+    rows = (sim.info[idx, 2].astype(np.int64) | (sim.info[idx, 3].astype(np.int64) << 16)) + int(p.rb_firstindex[0])
+    part = _np(eng.rbforces)
+    assert np.array_equal(part[rows[idx >= n // 2]].view(np.uint32), grf[rows[idx >= n // 2]].view(np.uint32))
+    assert not part[rows[idx < n // 2]].any()
+    # the engine's own step leaves the rows of its last forces pass
+    for _ in range(2):
+        eng.step()
+    tf2, _ = eng.reduce_rb_forces()
+    assert abs(tf2[2] + weight) < 0.02 * weight

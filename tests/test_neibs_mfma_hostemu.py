@@ -30,7 +30,11 @@ def _cell_fluid_end(sim):
 
 def _emulated_list(sim, env=None):
     p = sim.problem
-    emu = Emu(p.sphx_params(sim.alloc))
+    os.environ["SPHX_NEIBS_MFMA"] = "1"      # read when the context is created
+    try:
+        emu = Emu(p.sphx_params(sim.alloc))
+    finally:
+        del os.environ["SPHX_NEIBS_MFMA"]
     fn = emu.lib.emu_neibs_list
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p] * 8 + [C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -40,8 +44,9 @@ def _emulated_list(sim, env=None):
     fe = _cell_fluid_end(sim)
     sq = float(np.float32(p.simparams.nlSqInfluenceRadius))
     a = [np.ascontiguousarray(x) for x in (sim.pos, sim.info, sim.hash, sim.cs, sim.ce, fe)]
-    old = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})
+    env = dict(env or {})
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     try:
         rc = fn(emu.h, nl.ctypes.data, *[x.ctypes.data for x in a], sim.alloc, sim.n, sq, counts.ctypes.data, C.addressof(mx), C.addressof(tot))
     finally:

@@ -307,3 +307,34 @@ def test_sa_repacking_force_vanishes_in_a_filled_lattice_and_pushes_a_displaced_
         m = np.abs(s2.forces[:n, :3][calm]).mean()
         first = m if first is None else first
     assert np.isfinite(s2.pos[:n]).all() and m < first
+
+
+def test_floor_that_feels_the_fluid_carries_the_weight_of_the_water():
+    """compute_boundary_pressure_force (src/cuda/forces_kernel.def:3258-3266,4115-4145), the forces engine's part of
+    CompleteSaExample.cu's option set (a body with FG_COMPUTE_FORCE under SA_BOUNDARY): every COMPUTE_FORCE boundary element takes
+    F = -P A n.  Known answer: the floor of a hydrostatic tank carries the weight of the water above it, rho g (l w level); the
+    torque about the floor's centre vanishes by symmetry; the rows lie where id + rbstart[object] says; vertices and the segments of
+    the other walls write nothing."""
+    from gpusph_amd.problem import SALoadBox
+    from sa_helpers import OracleSaSim
+    p = SALoadBox(0.05)
+    sim = OracleSaSim(p)
+    o, n = sim.o, sim.n
+    f, rbf, rbt = o.sa_body_pressure_forces(sim.pos, sim.vel, sim.info, sim.hash, sim.be, n, p.num_obstacle)
+    tot, tq = rbf[:, :3].astype(np.float64).sum(0), rbt[:, :3].astype(np.float64).sum(0)
+    weight = p.physparams.rho0[0] * 9.81 * p.l * p.w * p.water_level
+    assert abs(tot[2] + weight) < 0.01 * weight and abs(tot[0]) < 1e-6 * weight and abs(tot[1]) < 1e-6 * weight
+    assert np.abs(tq).max() < 1e-5 * weight * p.l
+    load = (sim.info[:n, 0] & D.FG_COMPUTE_FORCE) != 0
+    t = info_type(sim.info[:n])
+    assert load.sum() == p.num_obstacle and (t[load] == D.PT_BOUNDARY).all()
+    # each element's row: id - first id of the body; its own forces row holds the same vector with w = 0
+    rows = info_id(sim.info[:n][load]).astype(np.int64) + int(p.rb_firstindex[0])
+    assert np.array_equal(np.sort(rows), np.arange(p.num_obstacle))
+    assert np.array_equal(rbf[rows], f[:n][load]) and (f[:n][load, 3] == 0).all() and (f[:n][load, 2] < 0).all()
+    assert not f[:n][~load].any()
+    # the force follows the pressure: after some steps of a tank at rest it is still the weight (the run does not drift)
+    for _ in range(4):
+        sim.step()
+    _, rbf2, _ = o.sa_body_pressure_forces(sim.pos, sim.vel, sim.info, sim.hash, sim.be, n, p.num_obstacle)
+    assert abs(rbf2[:, 2].astype(np.float64).sum() + weight) < 0.01 * weight
