@@ -68,6 +68,7 @@ SIGNATURES = {
     "sphx_sa_segment_bc_io": (_i, [_vp] + [_vp] * 10 + [_u32, _u32, _i, _vp]),
     "sphx_sa_vertex_bc_io": (_i, [_vp] + [_vp] * 17 + [_u32, _u32, _u32, _f, _f, _i, _u32, _vp]),
     "sphx_sa_density_sum_io": (_i, [_vp] + [_vp] * 16 + [_u32, _u32, _f, _vp]),
+    "sphx_sa_density_sum_io_moving": (_i, [_vp] + [_vp] * 17 + [_u32, _u32, _f, _vp]),
     "sphx_forces_basicstep_sa_io": (_i, [_vp] + [_vp] * 15 + [_u32, _u32, _u32, _f, _u32, _vp, _vp]),
     "sphx_sa_compute_density_diffusion_io": (_i, [_vp] + [_vp] * 12 + [_u32, _u32, _f, _f, _vp]),
     "sphx_flux_computation": (_i, [_vp] + [_vp] * 4 + [_u32, _u32, _u32, _vp]),

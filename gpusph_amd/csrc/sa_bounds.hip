@@ -655,6 +655,19 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 		WallTri tri;       // one set-up, two positions
 		wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
 		const V3 gN = ns*(wall_grad_gamma(tri, qN)/p.slength);
+		// the flux of gamma through an open segment (io_gamma_contrib, :374-397): the virtual displacement dt (u_E - u) at step n,
+		// against the element as it is at step n.  (With ENABLE_MOVING_BODIES as well -- CompleteSaExample.cu's option set -- the
+		// reference hands this term the corners set up for the NEW normal together with the OLD normal, and says so: "TODO check
+		// if we need the old or the new normal here, in case of moving open boundaries (for fixed open boundaries, it makes no
+		// difference)", :470-476.  Open faces that move are in none of its problems; for the fixed ones the two set-ups are the
+		// same numbers, and here the term is evaluated before the corners are set up again, i.e. wholly at step n.)
+		if (OPEN && SA_IS_OPEN(a.info[j])) {
+			const float4 e = a.oldEulerVel[j], v = a.oldVel[j];
+			const V3 drift = v3(a.dt*(e.x - v.x), a.dt*(e.y - v.y), a.dt*(e.z - v.z));
+			const V3 gMoved = ns*(wall_grad_gamma(tri, qN + drift/p.slength)/p.slength);
+			gamFluxMoved += dot(drift, gMoved);
+			gamFluxN += dot(drift, gN);
+		}
 		V3 nsNew = ns;
 		if (MOVING) {      // ... unless the element turned: its corners in the frame of the new normal
 			const float4 ben = a.boundElementNew[j];
@@ -664,13 +677,6 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 		const V3 gNp1 = nsNew*(wall_grad_gamma(tri, qNp1)/p.slength);
 		gGamDotR += 0.5f*dot(gN + gNp1, qNp1 - qN);
 		gGam = gGam + gNp1;
-		if (OPEN && SA_IS_OPEN(a.info[j])) {
-			const float4 e = a.oldEulerVel[j], v = a.oldVel[j];
-			const V3 drift = v3(a.dt*(e.x - v.x), a.dt*(e.y - v.y), a.dt*(e.z - v.z));
-			const V3 gMoved = ns*(wall_grad_gamma(tri, qN + drift/p.slength)/p.slength);
-			gamFluxMoved += dot(drift, gMoved);
-			gamFluxN += dot(drift, gN);
-		}
 	});
 	gGamDotR *= p.slength;
 	const float4 gGamN = a.oldGGam[index];
@@ -1376,7 +1382,7 @@ extern "C" int sphx_sa_density_sum_moving(sphx_ctx *ctx, void *newVel, void *new
 	if (!(ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES))
 		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_density_sum_moving: the uploaded option set has no ENABLE_MOVING_BODIES (call sphx_sa_density_sum)");
 	if (ctx->params.simflags & SPHX_ENABLE_INLET_OUTLET)
-		return sphx_set_error(SPHX_ERR_UNSUPPORTED, "sphx_sa_density_sum_moving: moving bodies together with open boundaries are not built");
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_density_sum_moving: with ENABLE_INLET_OUTLET as well the pass reads the Eulerian velocities: call sphx_sa_density_sum_io_moving");
 	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldGGam && oldBoundElements && newBoundElements &&
 		vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList, "sphx_sa_density_sum_moving: missing buffer");
 	SPHX_REQUIRE(newGGam != oldGGam && oldBoundElements != newBoundElements, "sphx_sa_density_sum_moving: gamma and the boundary elements are double buffered");
@@ -1387,6 +1393,16 @@ extern "C" int sphx_sa_density_sum_moving(sphx_ctx *ctx, void *newVel, void *new
 	a.boundElement = (const float4*)oldBoundElements; a.boundElementNew = (const float4*)newBoundElements;
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
+	{
+		// the particle <- particle sums (fluid and vertex neighbours, the moving vertices with their own displacement like any other
+		// particle) through the tiled window as for walls at rest (round 6); the boundary-element terms stay with the walker below:
+		// the wave-per-wall-particle kernels assume one normal per element
+		bool used = false;
+		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_DSUM, forces, oldPos, nullptr, newPos, info, hash, cellStart, neibsList, nullptr,
+			numParticles, 0u, particleRangeEnd, 0.0f, (hipStream_t)stream, &used, &a.tileGuard);
+		if (rc != SPHX_OK) return rc;
+		a.tiled = used ? 1 : 0;
+	}
 	sa_density_sum_kernel<false, true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_kernel<moving>");
 	return SPHX_OK;
@@ -1481,6 +1497,37 @@ extern "C" int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam
 	a.oldEulerVel = (const float4*)oldEulerVel; a.dt = dt;
 	sa_density_sum_kernel<true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_kernel<open>");
+	return SPHX_OK;
+}
+
+// ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES, the option set of CompleteSaExample.cu (:46): the open faces'
+// terms of sphx_sa_density_sum_io in the boundary loop of sphx_sa_density_sum_moving (io_gamma_contrib inside
+// computeDensitySumBoundaryTerms, src/cuda/density_sum_kernel.cu:422-484) -- elements where they were and where they are, gamma
+// of the VERTEX rows integrated, the virtual displacement of the open vertices and segments in the sums of the fluid
+extern "C" int sphx_sa_density_sum_io_moving(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces, const void *oldPos, const void *newPos,
+	const void *oldVel, const void *oldEulerVel, const void *oldGGam, const void *oldBoundElements, const void *newBoundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream)
+{
+	(void)numParticles;
+	int rc = sa_open_check(ctx, "density_sum called without SA_BOUNDARY");
+	if (rc != SPHX_OK) return rc;
+	if (!(ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES) || !(ctx->params.simflags & SPHX_ENABLE_INLET_OUTLET))
+		return sphx_set_error(SPHX_ERR_INVALID, "sphx_sa_density_sum_io_moving: the uploaded option set has not both ENABLE_INLET_OUTLET and ENABLE_MOVING_BODIES");
+	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldEulerVel && oldGGam && oldBoundElements && newBoundElements &&
+		vertPos0 && vertPos1 && vertPos2 && info && hash && cellStart && neibsList, "sphx_sa_density_sum_io_moving: missing buffer");
+	SPHX_REQUIRE(newGGam != oldGGam && oldBoundElements != newBoundElements, "sphx_sa_density_sum_io_moving: gamma and the boundary elements are double buffered");
+	if (!particleRangeEnd) return SPHX_OK;
+	SaDensitySumArgs a = {};
+	a.newVel = (float4*)newVel; a.newGGam = (float4*)newGGam; a.forces = (float4*)forces;
+	a.oldPos = (const float4*)oldPos; a.pos = (const float4*)newPos; a.oldVel = (const float4*)oldVel; a.oldGGam = (const float4*)oldGGam;
+	a.boundElement = (const float4*)oldBoundElements; a.boundElementNew = (const float4*)newBoundElements;
+	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
+	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
+	a.oldEulerVel = (const float4*)oldEulerVel; a.dt = dt;
+	sa_density_sum_kernel<true, true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
+	SPHX_LAUNCH_CHECK("sa_density_sum_kernel<open, moving>");
 	return SPHX_OK;
 }
 

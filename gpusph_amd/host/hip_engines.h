@@ -440,16 +440,14 @@ public:
 			// bodies that feel the fluid: with SA_BOUNDARY the force on a COMPUTE_FORCE element is the pressure on its area
 			// (compute_boundary_pressure_force in finalizeforcesDevice, src/cuda/forces_kernel.def:3258-3266,4115-4145), written to
 			// BUFFER_RB_FORCES / BUFFER_RB_TORQUES behind whichever SA forces entry ran on this range
-			struct BodyForces {
-				HIPForcesEngine *e; const BufferList &r; BufferList &w; float4 *forces; uint from, to; bool on;
-				~BodyForces() noexcept(false) {
-					if (!on || std::uncaught_exceptions()) return;
-					float4 *rbf = w.getData<BUFFER_RB_FORCES>(), *rbt = w.getData<BUFFER_RB_TORQUES>();
-					if (!rbf || !rbt) return;
-					sphx_throw(sphx_sa_body_pressure_forces(e->m_c->ctx(), forces, rbf, rbt, r.getData<BUFFER_POS>(), r.getData<BUFFER_VEL>(),
-						r.getData<BUFFER_INFO>(), r.getData<BUFFER_HASH>(), r.getData<BUFFER_BOUNDELEMENTS>(), from, to, NULL));
-				}
-			} bodyForces = { this, bufread, bufwrite, forces, fromParticle, toParticle, compute_object_forces && run_mode == SIMULATE };
+			auto bodyForces = [&]() {
+				if (!compute_object_forces || run_mode != SIMULATE) return;
+				float4 *rbf = bufwrite.getData<BUFFER_RB_FORCES>(), *rbt = bufwrite.getData<BUFFER_RB_TORQUES>();
+				if (!rbf || !rbt) return;
+				sphx_throw(sphx_sa_body_pressure_forces(m_c->ctx(), forces, rbf, rbt, bufread.getData<BUFFER_POS>(),
+					bufread.getData<BUFFER_VEL>(), bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(),
+					bufread.getData<BUFFER_BOUNDELEMENTS>(), fromParticle, toParticle, NULL));
+			};
 			if (P.turbmodel == KEPSILON && run_mode == SIMULATE) {
 				// keps_forces_params (src/cuda/forces_params.h:283-320): k, epsilon, eddy viscosity and Eulerian velocity of the
 				// state that is read; BUFFER_DKDE and BUFFER_CFL_KEPS written (BUFFER_TAU is not needed: one launch)
@@ -461,6 +459,7 @@ public:
 					bufread.getData<BUFFER_TKE>(), bufread.getData<BUFFER_EPSILON>(), bufread.getData<BUFFER_TURBVISC>(),
 					bufread.getData<BUFFER_EULERVEL>(), numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor,
 					influenceradius, epsilon, cflOffset, (int)run_mode, step, dt, &nb, NULL));
+				bodyForces();
 				return nb;
 			}
 			if ((P.simflags & ENABLE_INLET_OUTLET) && run_mode == SIMULATE) {
@@ -475,6 +474,7 @@ public:
 					sphx_throw(sphx_sa_io_water_depth(m_c->ctx(), IOwaterdepth, bufread.getData<BUFFER_POS>(),
 						bufread.getData<BUFFER_INFO>(), bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(),
 						bufread.getData<BUFFER_NEIBSLIST>(), numParticles, fromParticle, toParticle, NULL));
+				bodyForces();
 				return nb;
 			}
 			sphx_throw(sphx_forces_basicstep_sa(m_c->ctx(), forces, cfl, gcfl ? bufwrite.getData<BUFFER_CFL_GAMMA>() : NULL,
@@ -483,6 +483,7 @@ public:
 				bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2],
 				numParticles, fromParticle, toParticle, deltap, slength, dtadaptfactor, influenceradius,
 				cflOffset, (int)run_mode, step, dt, &nb, NULL));
+			bodyForces();
 			return nb;
 		}
 		if (NEEDS_EFFECTIVE_VISC(P.rheologytype) && run_mode == SIMULATE) {

@@ -142,6 +142,15 @@ class HipKernels:
                                                      run_mode, 1, 0.0, C.byref(nb), self._s()))
         return nb.value
 
+    def sa_density_sum_io_moving(self, new_vel, new_ggam, forces, old_pos, new_pos, old_vel, old_eulervel, old_ggam, be_old, be_new,
+                                 vertpos, info, hash_, cellStart, neibslist, n, range_end, dt):
+        """DENSITY_SUM with ENABLE_INLET_OUTLET | ENABLE_MOVING_BODIES (CompleteSaExample.cu's option set)"""
+        p = capi.ptr
+        capi.check(self.lib.sphx_sa_density_sum_io_moving(self.ctx.handle, p(new_vel), p(new_ggam), p(forces), p(old_pos), p(new_pos),
+                                                          p(old_vel), p(old_eulervel), p(old_ggam), p(be_old), p(be_new), p(vertpos[0]),
+                                                          p(vertpos[1]), p(vertpos[2]), p(info), p(hash_), p(cellStart), p(neibslist),
+                                                          n, range_end, float(np.float32(dt)), self._s()))
+
     def sa_body_pressure_forces(self, forces, rbforces, rbtorques, pos, vel, info, hash_, boundelements, frm, to):
         """F = -P A n on the FG_COMPUTE_FORCE boundary elements of [frm, to) -> BUFFER_RB_FORCES / RB_TORQUES rows (+ their forces row)"""
         p = capi.ptr

@@ -375,6 +375,14 @@ int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam, void *for
 	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
 	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream);
+/* ... and with ENABLE_MOVING_BODIES on top (CompleteSaExample.cu's option set, :46): the boundary elements of the state that is read
+ * and of the one that is written, as in sphx_sa_density_sum_moving; io_gamma_contrib in the moving boundary loop
+ * (src/cuda/density_sum_kernel.cu:422-484). */
+int sphx_sa_density_sum_io_moving(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces, const void *oldPos, const void *newPos,
+	const void *oldVel, const void *oldEulerVel, const void *oldGGam, const void *oldBoundElements, const void *newBoundElements,
+	const void *vertPos0, const void *vertPos1, const void *vertPos2, const void *info,
+	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream);
 int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *cfl, float *cflGamma, const void *pos, const void *vel,
 	const void *eulerVel, const void *info, const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	const void *gGam, const void *boundElements, const void *vertPos0, const void *vertPos1, const void *vertPos2,

@@ -4330,3 +4330,112 @@ void orc_sa_body_pressure_forces(const orc_params *p, orc_f4 *forces, orc_f4 *rb
 		forces[index] = force;
 	}
 }
+
+/* ---- ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES (CompleteSaExample.cu:46) -----------------------------------
+ * density_sum_impl (src/cuda/euler.cu:112-160) with both flags: densitySumVolumicDevice as with open boundaries alone,
+ * computeDensitySumBoundaryTerms (:422-484) with the corners set up for the old and then for the new normal, io_gamma_contrib
+ * called AFTER the second set-up with (qN, nsN, vertexRelPos, dt, gGamN) -- i.e. the corners of the new normal with the old
+ * normal, which the reference marks "TODO check if we need the old or the new normal here" (:470-476); restated as written.
+ * integrateGammaDevice<PT_VERTEX> for the vertex rows (its gamma_sum_terms carry the io sums too but only gGam and gGamDotR are
+ * used, :669-685); BOUNDARY rows are left as they are. */
+void orc_sa_density_sum_io_moving(const orc_params *p, orc_f4 *newVel, orc_f4 *newGGam, orc_f4 *forces,
+	const orc_f4 *oldPos, const orc_f4 *newPos, const orc_f4 *oldVel, const orc_f4 *oldEulerVel, const orc_f4 *oldGGam,
+	const orc_f4 *boundelemOld, const orc_f4 *boundelemNew, const float *vertPos0, const float *vertPos1, const float *vertPos2,
+	const orc_info *infoArray, const uint32_t *hashArray, const uint32_t *cellStart, const uint16_t *neibsList,
+	uint32_t particleRangeEnd, float dt)
+{
+	const float kr = 2.0f;
+	const float wcoeff = orc_wcoeff(p->kerneltype, p->slength, kr), wsub = expf(-kr*kr);
+	const float slength = p->slength;
+	for (uint32_t index = 0; index < particleRangeEnd; ++index) {
+		const orc_info info = infoArray[index];
+		if (!FLUID(info) && !VERTEX(info)) continue;
+		const orc_f4 posN = oldPos[index], posNp1 = newPos[index];
+		int gridPos[3];
+		orc_grid_pos_from_hash(p, hashArray[index] & CELLTYPE_BITMASK, gridPos);
+		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
+		float fw = 0.0f;
+		if (FLUID(info)) {
+			float sumPmwN = 0.0f, sumPmwNp1 = 0.0f, sumVmwDelta = 0.0f;
+			for (int nptype = PT_FLUID; nptype <= PT_VERTEX; nptype += 2) {
+				neib_iter it;
+				uint32_t neib_index;
+				neib_iter_init(&it, p, nptype, index, &posN, gridPos, cellStart, neibsList);
+				while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+					const orc_f4 nN = oldPos[neib_index];
+					if (INACTIVE(nN)) continue;
+					const orc_info ninfo = infoArray[neib_index];
+					const orc_f4 nNp1 = newPos[neib_index];
+					const float rx = it.pos_corr[0] - nN.x, ry = it.pos_corr[1] - nN.y, rz = it.pos_corr[2] - nN.z;
+					const float qx = (it.pos_corr[0] - nNp1.x) + dx, qy = (it.pos_corr[1] - nNp1.y) + dy, qz = (it.pos_corr[2] - nNp1.z) + dz;
+					if (!IO_BOUNDARY(ninfo)) {
+						const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+						sumPmwN -= nN.w*W_c(p->kerneltype, rN, slength, wcoeff, wsub);
+					}
+					const float rNp1 = sqrtf(qx*qx + qy*qy + qz*qz);
+					if (rNp1 < p->influenceradius)
+						sumPmwNp1 += nN.w*W_c(p->kerneltype, rNp1, slength, wcoeff, wsub);
+					if (IO_BOUNDARY(ninfo)) {
+						const orc_f4 e = oldEulerVel[neib_index], v = oldVel[neib_index];
+						const float ex = rx + dt*(e.x - v.x), ey = ry + dt*(e.y - v.y), ez = rz + dt*(e.z - v.z);
+						const float newDist = sqrtf(ex*ex + ey*ey + ez*ez);
+						if (newDist < p->influenceradius)
+							sumVmwDelta -= nN.w*W_c(p->kerneltype, newDist, slength, wcoeff, wsub);
+					}
+				}
+			}
+			fw = sumPmwNp1 + sumPmwN + sumVmwDelta;
+			forces[index].w = fw;
+		}
+		float gGamDotR = 0.0f, sumSgamDelta = 0.0f, sumSgamN = 0.0f;
+		v3 gGam = v3_make(0.0f, 0.0f, 0.0f);
+		{
+			neib_iter it;
+			uint32_t neib_index;
+			neib_iter_init(&it, p, PT_BOUNDARY, index, &posN, gridPos, cellStart, neibsList);
+			while ((neib_index = neib_iter_next(&it)) != UINT_MAX) {
+				const orc_f4 nN = oldPos[neib_index];
+				if (INACTIVE(nN)) continue;
+				const orc_f4 nNp1 = newPos[neib_index];
+				const float inv = 1.0f/slength;
+				const v3 qN = v3_make((it.pos_corr[0] - nN.x)*inv, (it.pos_corr[1] - nN.y)*inv, (it.pos_corr[2] - nN.z)*inv);
+				const v3 qNp1 = v3_make(((it.pos_corr[0] - nNp1.x) + dx)*inv, ((it.pos_corr[1] - nNp1.y) + dy)*inv,
+					((it.pos_corr[2] - nNp1.z) + dz)*inv);
+				const orc_f4 beN = boundelemOld[neib_index], beNp1 = boundelemNew[neib_index];
+				const v3 nsN = v3_make(beN.x, beN.y, beN.z), nsNp1 = v3_make(beNp1.x, beNp1.y, beNp1.z);
+				v3 q_vb[3];
+				calc_vertex_rel_pos(q_vb, nsN, vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+					vertPos2 + 2*(size_t)neib_index, slength);
+				const v3 gN = v3_scale(nsN, grad_gamma_wendland(slength, qN, q_vb, nsN));
+				calc_vertex_rel_pos(q_vb, nsNp1, vertPos0 + 2*(size_t)neib_index, vertPos1 + 2*(size_t)neib_index,
+					vertPos2 + 2*(size_t)neib_index, slength);
+				const v3 gNp1 = v3_scale(nsNp1, grad_gamma_wendland(slength, qNp1, q_vb, nsNp1));
+				gGamDotR += 0.5f*v3_dot(v3_add(gN, gNp1), v3_sub(qNp1, qN));
+				gGam = v3_add(gGam, gNp1);
+				if (IO_BOUNDARY(infoArray[neib_index])) {      /* io_gamma_contrib(sumGam, .., qN, nsN, vertexRelPos [of nsNp1], dt, gGamN) */
+					const orc_f4 e = oldEulerVel[neib_index], v = oldVel[neib_index];
+					const v3 deltaR = v3_make(dt*(e.x - v.x), dt*(e.y - v.y), dt*(e.z - v.z));
+					const v3 qDelta = v3_add(qN, v3_divs(deltaR, slength));
+					const v3 gDelta = v3_scale(nsN, grad_gamma_wendland(slength, qDelta, q_vb, nsN));
+					sumSgamDelta += v3_dot(deltaR, gDelta);
+					sumSgamN += v3_dot(deltaR, gN);
+				}
+			}
+			gGamDotR *= slength;
+		}
+		const orc_f4 gGamN = oldGGam[index];
+		orc_f4 g = { gGam.x, gGam.y, gGam.z, gGamN.w + gGamDotR };
+		if (VERTEX(info)) { newGGam[index] = g; continue; }
+		float imposedGam = gGamN.w + (sumSgamDelta + sumSgamN)/2.0f;
+		if (imposedGam > 1.0f) imposedGam = 1.0f;
+		else if (imposedGam < 0.1f) imposedGam = 0.1f;
+		const int fl = FLUID_NUM(info);
+		const float rho = (imposedGam*physical_density(p, oldVel[index].w, fl) + fw)/g.w;
+		if (g.w > 1.0f || sqrtf(g.x*g.x + g.y*g.y + g.z*g.z)*slength < 1e-10f)
+			g.w = 1.0f;
+		else if (g.w < 0.1f)
+			g.w = 0.1f;
+		newVel[index].w = rho/p->rho0[fl] - 1.0f;
+		newGGam[index] = g;
+	}
+}

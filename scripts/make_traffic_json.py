@@ -9,7 +9,7 @@ def kernel_source_sha():
     """hash of the kernel sources the profiled library was built from: bench.py reports the traffic of a profile only
     for the build it was taken on"""
     h = hashlib.sha256()
-    for name in ("forces.hip", "neibs.hip", "euler.hip", "sphx_internal.h"):
+    for name in ("forces.hip", "neibs.hip", "neibs_build.hip", "euler.hip", "sphx_internal.h"):
         h.update(open(os.path.join(ROOT, "gpusph_amd", "csrc", name), "rb").read())
     return h.hexdigest()
 

@@ -23,7 +23,7 @@ _SOURCES = [os.path.join(_EMU, "emu_sphx.cc"), os.path.join(_EMU, "hip", "hip_ru
 NAMES = ["sphx_create", "sphx_destroy", "sphx_set_constants", "sphx_last_error",
          "sphx_sa_identify_corner_vertices", "sphx_sa_init_io_mass_vertex_count", "sphx_sa_init_io_mass",
          "sphx_sa_find_outgoing_segment", "sphx_sa_disable_outgoing_parts", "sphx_sa_segment_bc_io", "sphx_sa_vertex_bc_io",
-         "sphx_sa_density_sum_io", "sphx_forces_basicstep_sa_io", "sphx_sa_compute_density_diffusion_io", "sphx_sa_io_water_depth", "sphx_flux_computation",
+         "sphx_sa_density_sum_io", "sphx_sa_density_sum_io_moving", "sphx_forces_basicstep_sa_io", "sphx_sa_compute_density_diffusion_io", "sphx_sa_io_water_depth", "sphx_flux_computation",
          # sa_bounds.hip, list walkers only
          "sphx_sa_compute_vertex_normal", "sphx_sa_init_gamma", "sphx_sa_segment_bc", "sphx_sa_vertex_bc", "sphx_sa_density_sum",
          "sphx_sa_compute_density_diffusion", "sphx_apply_density_diffusion", "sphx_sa_integrate_gamma", "sphx_forces_basicstep_sa",

@@ -484,6 +484,17 @@ class Oracle:
                                      P(cs), P(nl), C.c_uint32(n), C.c_float(dt))
         return v, g, scratch[:, 3].copy()
 
+    def sa_density_sum_io_moving(self, new_vel, old_pos, new_pos, old_vel, old_euler_vel, old_ggam, be_old, be_new, vertpos, info, hash_,
+                                 cs, nl, n, dt):
+        """density_sum with open boundaries AND moving bodies (CompleteSaExample's option set): (new_vel, gamma, the volumic sums);
+        the BOUNDARY rows of gamma keep the old values here (the kernels leave them to the segment condition)"""
+        v = new_vel.copy(); g = old_ggam.copy()
+        scratch = np.zeros((len(old_pos), 4), dtype=np.float32)
+        self.L.orc_sa_density_sum_io_moving(C.byref(self.p), P(v), P(g), P(scratch), P(old_pos), P(new_pos), P(old_vel), P(old_euler_vel),
+                                            P(old_ggam), P(be_old), P(be_new), P(vertpos[0]), P(vertpos[1]), P(vertpos[2]), P(info),
+                                            P(hash_), P(cs), P(nl), C.c_uint32(n), C.c_float(dt))
+        return v, g, scratch[:, 3].copy()
+
     def sa_density_diffusion_io(self, pos, vel, ggam, info, hash_, cs, nl, boundelements, vertpos, n, dt, deltap):
         """the Brezzi diffusion with open boundaries enabled: (updated velocity, forces with the diffusion in .w)"""
         f = np.zeros((len(pos), 4), dtype=np.float32)

@@ -352,3 +352,42 @@ def test_open_channel_on_the_device_follows_the_cpu_run():
     assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.15, spike=50.0,
                                       what="densities after 20 steps")
     assert np.array_equal(_np(eng.next_ids[:n], np.uint32)[a], ref.next_ids[:n].numpy().view(np.uint32)[b])
+
+
+@pytest.mark.gpu
+def test_density_summation_with_open_boundaries_and_moving_bodies():
+    """sphx_sa_density_sum_io_moving (sa_density_sum_kernel<OPEN, MOVING>): ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM |
+    ENABLE_MOVING_BODIES, the option set of CompleteSaExample.cu (:46), in the pass where the two features meet (io_gamma_contrib
+    inside the moving boundary loop, src/cuda/density_sum_kernel.cu:422-484), against the oracle's restatement -- which
+    tests/test_sa_io_moving.py pins to the open-boundary pass and to the moving-bodies pass bit for bit."""
+    import torch
+    from gpusph_amd.engine import TimestepEngine
+    from sa_helpers import assert_close_but_for_gamma_spikes, wall_rows
+    from test_sa_io_moving import io_moving_state
+    c = io_moving_state()
+    st, o, n, p = c["st"], c["o"], c["n"], c["p"]
+    from gpusph_amd.kernels import HipKernels
+    K = HipKernels(p, n, "cuda:0")
+    dev = torch.device("cuda:0")
+
+    def up(a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return t
+    d = {name: up(c[name]) for name in ("vel", "ev", "gg", "be", "be_new", "new_pos")}
+    d_pos, d_info, d_hash = up(st["pos"]), up(c["info"].view(np.int16)), up(st["hash"].view(np.int32))
+    d_cs, d_nl = up(st["cs"].view(np.int32)), up(np.asarray(st["nl"]).view(np.int16))
+    vp = [up(v) for v in st["vertpos"]]
+    want_v, want_g, want_s = o.sa_density_sum_io_moving(c["vel"], st["pos"], c["new_pos"], c["vel"], c["ev"], c["gg"], c["be"], c["be_new"],
+                                                        st["vertpos"], c["info"], st["hash"], st["cs"], st["nl"], n, c["dt"])
+    d_nv, d_ng, d_f = d["vel"].clone(), d["gg"].clone(), torch.zeros_like(d["vel"])
+    K.sa_density_sum_io_moving(d_nv, d_ng, d_f, d_pos, d["new_pos"], d["vel"], d["ev"], d["gg"], d["be"], d["be_new"], vp, d_info, d_hash,
+                               d_cs, d_nl, n, n, c["dt"])
+    torch.cuda.synchronize()
+    fl, vt, bd = c["fl"], c["vt"], c["bd"]
+    wall = wall_rows(p, st["nl"], c["info"], n)
+    gv, gg, gs = _np(d_nv)[:n], _np(d_ng)[:n], _np(d_f)[:n, 3]
+    assert np.abs(gs[fl] - want_s[fl]).max() < 2e-5 * np.abs(want_s[fl]).max() + 1e-3
+    assert_close_but_for_gamma_spikes(gv[fl, 3], want_v[fl, 3], 2e-6, 1.0, what="density after the summation", wall=wall[fl], frac=0.03)
+    assert_close_but_for_gamma_spikes(gg[fl], want_g[fl], 2e-5, np.abs(want_g[fl, :3]).max(), what="gamma of the fluid", wall=wall[fl], frac=0.03)
+    assert_close_but_for_gamma_spikes(gg[vt], want_g[vt], 2e-5, np.abs(want_g[vt, :3]).max(), what="gamma of the vertices", frac=0.05)
+    assert np.array_equal(gg[bd].view(np.uint32), c["gg"][bd].view(np.uint32))
