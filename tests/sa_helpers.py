@@ -15,11 +15,12 @@ def wall_rows(problem, nl, info, n):
     return (nl2[sp.neibboundpos] != 0xFFFF) | ~fluid
 
 
-def assert_close_but_for_gamma_spikes(got, want, tol, scale=None, frac=0.01, spike=200.0, what="", wall=None):
+def assert_close_but_for_gamma_spikes(got, want, tol, scale=None, frac=0.01, spike=200.0, what="", wall=None, away=1.0):
     """|got - want| <= tol * scale for all but a fraction `frac` of the entries, and <= spike * tol * scale for those.
     `wall` (one flag per row of got / want, see wall_rows): the allowance is for the rows that have a boundary element in
-    reach ONLY -- every other row must hold tol * scale, so that an indexing or ordering bug of the particle <- particle
-    sums cannot hide behind it.
+    reach ONLY -- every other row must hold away * tol * scale (away = 1 for a single pass; after some steps of a run the
+    difference of a wall row has reached its neighbours through the pair sums, diluted: the measured factor of each call site is
+    in its line), so that an indexing or ordering bug of the particle <- particle sums cannot hide behind it.
 
     The closed form of |grad gamma_as| (edge antiderivatives that cancel against each other and against the angle
     bookkeeping) is ill-conditioned for some positions of a particle relative to an element: two float evaluations of the
@@ -27,20 +28,32 @@ def assert_close_but_for_gamma_spikes(got, want, tol, scale=None, frac=0.01, spi
     evaluation is that far from the float64 value of its formula (tests/test_sa_wall_gamma.py measures both against the
     reference's numbers).  The kernels integrate the same expressions in their own order of operations (set-up of an element
     once, polynomial collected by powers of the distance), so the few particles that have such an element in reach carry a
-    difference the bulk does not; everything derived from gamma (SA forces, density summation, trajectories) inherits it."""
+    difference the bulk does not; everything derived from gamma (SA forces, density summation, trajectories) inherits it.
+
+    SPHX_TEST_REPORT=<file>: every call appends what it measured (share of the entries beyond the tolerance, worst entry, worst
+    row without an element in reach, in units of tol * scale) -- how the allowances of the call sites were set."""
+    import os
     got = np.asarray(got, dtype=np.float64); want = np.asarray(want, dtype=np.float64)
     s = float(np.abs(want).max() if scale is None else scale)
     err = np.abs(got - want)
     bad = float((err > tol * s).mean()) if err.size else 0.0
     worst = float(err.max()) if err.size else 0.0
+    report = os.environ.get("SPHX_TEST_REPORT")
+    if report:
+        w = np.asarray(wall, dtype=bool) if wall is not None else None
+        aw = float(err[~w].max()) if (w is not None and (~w).any()) else float("nan")
+        with open(report, "a") as f:
+            f.write("%-60s n=%d bad=%.4f (allowed %.4f) worst=%.2f tol (allowed %.1f) away_worst=%.2f tol (allowed %.1f) wall_share=%.3f\n" % (
+                what, err.size, bad, frac, worst / max(tol * s, 1e-300), spike, aw / max(tol * s, 1e-300), away,
+                float(w.mean()) if w is not None else float("nan")))
     assert bad <= frac and worst <= spike * tol * s, "%s: %.3g of the entries beyond %.1e of the scale %.3g (allowed %.3g), worst %.3g of the scale (allowed %.3g)" % (
         what, bad, tol, s, frac, worst / max(s, 1e-300), spike * tol)
     if wall is not None:
         wall = np.asarray(wall, dtype=bool)
         assert len(wall) == len(err), "%s: one wall flag per row" % what
-        away = err[~wall]
-        assert away.size == 0 or away.max() <= tol * s, "%s: a row with no boundary element in reach is %.3g of the scale off (allowed %.1e)" % (
-            what, away.max() / max(s, 1e-300), tol)
+        away_err = err[~wall]
+        assert away_err.size == 0 or away_err.max() <= away * tol * s, "%s: a row with no boundary element in reach is %.3g of the scale off (allowed %.1e)" % (
+            what, away_err.max() / max(s, 1e-300), away * tol)
 
 
 def analytic_vertex_gamma(problem, st):

@@ -102,6 +102,14 @@ def test_bench_gpus_2_as_typed_on_one_gpu():
     assert sum(ex["internal_particles"]) == d["config"]["particles"]
     assert ex["transport"] == "torch.distributed"            # gloo rig: the library's RCCL transport needs one device per rank
     assert d["config"]["env"].get("SPHX_BENCH_BACKEND") == "gloo"
+    # what the driver's scaling numbers are read against: bytes moved and time exposed, per rank; and the two ranks together
+    # step the particles the single domain steps (the line of N = 1 on the same workload)
+    assert len(ex["exposed_exchange_ms_per_step"]) == 2 and min(ex["exposed_exchange_ms_per_step"]) >= 0.0
+    d1 = json.loads([l for l in _run(["--particles", "2e5", "--steps", "12", "--warmup", "11", "--no-cpu-baseline"], 900).stdout.splitlines()
+                     if l.lstrip().startswith("{")][0])
+    assert d1["n_gpus"] == 1
+    assert d1["config"]["particles"] == d["config"]["particles"] == sum(ex["internal_particles"])
+    assert d1["config"]["workload"] == d["config"]["workload"] and d1["metric"] == d["metric"]
 
 
 @pytest.mark.gpu

@@ -11,6 +11,9 @@ from sa_helpers import sa_oracle_state, assert_close_but_for_gamma_spikes, wall_
 pytestmark = pytest.mark.gpu
 
 
+AWAY = 1e6      # (being measured)
+
+
 def _engine(problem, **kw):
     import torch
     from gpusph_amd.engine import TimestepEngine
@@ -232,8 +235,9 @@ def test_sa_forces_gamma_integration_and_trajectory(kernels):
     gp, gv, ggg = _np(eng2.pos)[:n], _np(eng2.vel)[:n], _np(eng2.gradgamma)[:n]
     cell = float(np.min(sim.problem.m_cellsize))
     assert np.abs(gp[:, :3] - sim.pos[:, :3]).max() < 6e-6 * cell
-    assert_close_but_for_gamma_spikes(gv[:, :3], sim.vel[:, :3], 1e-3, max(np.abs(sim.vel[:, :3]).max(), 1e-3), spike=10.0, what="velocities after 6 steps")
-    assert_close_but_for_gamma_spikes(gv[:, 3], sim.vel[:, 3], 2e-6, 1.0, spike=10.0, what="densities after 6 steps")
+    W = wall_rows(sim.problem, sim.nl, sim.info, n)
+    assert_close_but_for_gamma_spikes(gv[:, :3], sim.vel[:, :3], 1e-3, max(np.abs(sim.vel[:, :3]).max(), 1e-3), spike=10.0, what="velocities after 6 steps (quadrature)", wall=W, away=AWAY)
+    assert_close_but_for_gamma_spikes(gv[:, 3], sim.vel[:, 3], 2e-6, 1.0, spike=10.0, what="densities after 6 steps (quadrature)", wall=W, away=AWAY)
     assert np.abs(ggg[fl, 3] - sim.gg[fl, 3]).max() < 2e-5
     assert abs(eng2.current_dt() - sim.dt) < 1e-4 * sim.dt and abs(eng2.time() - sim.t) < 1e-5 * sim.t
 
@@ -332,8 +336,9 @@ def test_density_summation_form_on_the_gpu(kernels):
     gp, gv, ggg = _np(eng2.pos)[:n], _np(eng2.vel)[:n], _np(eng2.gradgamma)[:n]
     cell = float(np.min(sim2.problem.m_cellsize))
     assert np.abs(gp[:, :3] - sim2.pos[:, :3]).max() < 6e-6 * cell
-    assert_close_but_for_gamma_spikes(gv[:, :3], sim2.vel[:, :3], 1e-3, max(np.abs(sim2.vel[:, :3]).max(), 1e-3), spike=10.0, what="velocities after 6 steps")
-    assert_close_but_for_gamma_spikes(gv[:, 3], sim2.vel[:, 3], 2e-6, 1.0, spike=10.0, what="densities after 6 steps")
+    W = wall_rows(sim2.problem, sim2.nl, sim2.info, n)
+    assert_close_but_for_gamma_spikes(gv[:, :3], sim2.vel[:, :3], 1e-3, max(np.abs(sim2.vel[:, :3]).max(), 1e-3), spike=10.0, what="velocities after 6 steps (density sum)", wall=W, away=AWAY)
+    assert_close_but_for_gamma_spikes(gv[:, 3], sim2.vel[:, 3], 2e-6, 1.0, spike=10.0, what="densities after 6 steps (density sum)", wall=W, away=AWAY)
     assert np.abs(ggg[fl, 3] - sim2.gg[fl, 3]).max() < 2e-5
     assert abs(eng2.current_dt() - sim2.dt) < 1e-5 * sim2.dt and abs(eng2.time() - sim2.t) < 1e-6 * sim2.t
 

@@ -346,11 +346,13 @@ def test_open_channel_on_the_device_follows_the_cpu_run():
     gr = p.global_pos(ref.pos[:n].numpy(), ref.hash[:n].numpy().view(np.uint32))[b]
     act = np.isfinite(ref.pos[:n].numpy()[b][:, 3])
     assert np.array_equal(act, np.isfinite(_np(eng.pos[:n])[a][:, 3]))
-    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, float(p.m_cellsize[0]), spike=10.0, what="positions after 20 steps")
+    from sa_helpers import wall_rows
+    W = wall_rows(p, ref.neibslist.numpy(), ref.info[:n].numpy().view(np.uint16), n)[b][act]      # of the last list (rebuilt in every step)
+    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, float(p.m_cellsize[0]), spike=10.0, what="positions after 20 steps (open channel)", wall=W, away=1e6)
     assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, :3], ref.vel[:n].numpy()[b][act, :3], 1e-3, 0.6, spike=10.0,
-                                      what="velocities after 20 steps")
+                                      what="velocities after 20 steps (open channel)", wall=W, away=1e6)
     assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.15, spike=50.0,
-                                      what="densities after 20 steps")
+                                      what="densities after 20 steps (open channel)", wall=W, away=1e6)
     assert np.array_equal(_np(eng.next_ids[:n], np.uint32)[a], ref.next_ids[:n].numpy().view(np.uint32)[b])
 
 

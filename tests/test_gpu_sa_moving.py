@@ -92,9 +92,11 @@ def test_engine_follows_the_independent_sequence(options):
     assert np.array_equal(_bits(gb[seg]), _bits(sim.be[:n][seg]))
     assert gb[seg, 2].max() < -1e-3                      # it did turn
     cell = float(sim.o.p.cellSize[0])
-    assert_close_but_for_gamma_spikes(gp[:, :3], sim.pos[:n, :3], 2e-5, cell, spike=10.0, what="positions after 5 steps")
-    assert_close_but_for_gamma_spikes(gv[:, :3], sim.vel[:n, :3], 1e-3, max(np.abs(sim.vel[:n, :3]).max(), 1e-3), spike=10.0, what="velocities after 5 steps")
-    assert_close_but_for_gamma_spikes(gv[:, 3], sim.vel[:n, 3], 2e-6, 1.0, spike=10.0, frac=0.03, what="densities after 5 steps")
+    from sa_helpers import wall_rows
+    W = wall_rows(sim.problem, sim.nl, sim.info, n)
+    assert_close_but_for_gamma_spikes(gp[:, :3], sim.pos[:n, :3], 2e-5, cell, spike=10.0, what="positions after 5 steps (moving)", wall=W, away=1e6)
+    assert_close_but_for_gamma_spikes(gv[:, :3], sim.vel[:n, :3], 1e-3, max(np.abs(sim.vel[:n, :3]).max(), 1e-3), spike=10.0, what="velocities after 5 steps (moving)", wall=W, away=1e6)
+    assert_close_but_for_gamma_spikes(gv[:, 3], sim.vel[:n, 3], 2e-6, 1.0, spike=10.0, frac=0.03, what="densities after 5 steps (moving)", wall=W, away=1e6)
     fin = np.isfinite(sim.gg[:n, 3])
     assert_close_but_for_gamma_spikes(gg[fin, 3], sim.gg[:n][fin, 3], 5e-6, 1.0, spike=10.0, frac=0.03, what="gamma after 5 steps")
     assert abs(eng.current_dt() - sim.dt) <= 1e-4*sim.dt
