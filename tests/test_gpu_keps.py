@@ -178,8 +178,8 @@ def test_whole_steps_follow_the_oracle(options):
     # a 1e-7 difference of the relative position into a 1e-2 difference of that element's term for single particles; measured on the
     # same box with the laminar option set: the same spikes (per-step force difference up to 0.04 of 6, velocities to 1.2e-3 relative)
     from sa_helpers import wall_rows
-    assert_close_but_for_gamma_spikes(st["vel"][:n, :3], sim.vel[:n, :3], 3e-3, max(np.abs(sim.vel[:n, :3]).max(), 1e-3), spike=10.0, what="velocities after 5 steps (k-epsilon)",
-                                      wall=wall_rows(sim.problem, sim.nl, sim.info, n), away=1e6)
+    assert_close_but_for_gamma_spikes(st["vel"][:n, :3], sim.vel[:n, :3], 3e-3, max(np.abs(sim.vel[:n, :3]).max(), 1e-3), frac=0.002, spike=8.0, what="velocities after 5 steps (k-epsilon)",
+                                      wall=wall_rows(sim.problem, sim.nl, sim.info, n))      # measured: 4e-4 of the entries beyond, worst 4.0; away from the walls 0.08
     assert np.abs(st["vel"][:n, 3] - sim.vel[:n, 3]).max() < 2e-6
     for name in ("tke", "eps", "turbvisc"):
         got, want = _np(eng.ke[name])[:n], sim.ke[name]

@@ -11,7 +11,12 @@ from sa_helpers import sa_oracle_state, assert_close_but_for_gamma_spikes, wall_
 pytestmark = pytest.mark.gpu
 
 
-AWAY = 1e6      # (being measured)
+# The run comparisons below (several steps of an engine against the oracle's sequence): measured on an MI355X with
+# SPHX_TEST_REPORT (profiles/r06_sa_run_comparisons.txt), in units of the tolerance of each line: velocities after 6 steps worst
+# 0.25 - 0.81, densities 0.06 - 0.53, every row WITHOUT a boundary element in reach <= 0.23.  So: no spike allowance to speak of
+# (twice the tolerance for at most 2 per mille of the entries), and the plain tolerance for the rows away from the walls
+AWAY = 1.0
+RUN = dict(frac=0.002, spike=2.0)
 
 
 def _engine(problem, **kw):
@@ -236,8 +241,8 @@ def test_sa_forces_gamma_integration_and_trajectory(kernels):
     cell = float(np.min(sim.problem.m_cellsize))
     assert np.abs(gp[:, :3] - sim.pos[:, :3]).max() < 6e-6 * cell
     W = wall_rows(sim.problem, sim.nl, sim.info, n)
-    assert_close_but_for_gamma_spikes(gv[:, :3], sim.vel[:, :3], 1e-3, max(np.abs(sim.vel[:, :3]).max(), 1e-3), spike=10.0, what="velocities after 6 steps (quadrature)", wall=W, away=AWAY)
-    assert_close_but_for_gamma_spikes(gv[:, 3], sim.vel[:, 3], 2e-6, 1.0, spike=10.0, what="densities after 6 steps (quadrature)", wall=W, away=AWAY)
+    assert_close_but_for_gamma_spikes(gv[:, :3], sim.vel[:, :3], 1e-3, max(np.abs(sim.vel[:, :3]).max(), 1e-3), what="velocities after 6 steps (quadrature)", wall=W, away=AWAY, **RUN)
+    assert_close_but_for_gamma_spikes(gv[:, 3], sim.vel[:, 3], 2e-6, 1.0, what="densities after 6 steps (quadrature)", wall=W, away=AWAY, **RUN)
     assert np.abs(ggg[fl, 3] - sim.gg[fl, 3]).max() < 2e-5
     assert abs(eng2.current_dt() - sim.dt) < 1e-4 * sim.dt and abs(eng2.time() - sim.t) < 1e-5 * sim.t
 
@@ -337,8 +342,8 @@ def test_density_summation_form_on_the_gpu(kernels):
     cell = float(np.min(sim2.problem.m_cellsize))
     assert np.abs(gp[:, :3] - sim2.pos[:, :3]).max() < 6e-6 * cell
     W = wall_rows(sim2.problem, sim2.nl, sim2.info, n)
-    assert_close_but_for_gamma_spikes(gv[:, :3], sim2.vel[:, :3], 1e-3, max(np.abs(sim2.vel[:, :3]).max(), 1e-3), spike=10.0, what="velocities after 6 steps (density sum)", wall=W, away=AWAY)
-    assert_close_but_for_gamma_spikes(gv[:, 3], sim2.vel[:, 3], 2e-6, 1.0, spike=10.0, what="densities after 6 steps (density sum)", wall=W, away=AWAY)
+    assert_close_but_for_gamma_spikes(gv[:, :3], sim2.vel[:, :3], 1e-3, max(np.abs(sim2.vel[:, :3]).max(), 1e-3), what="velocities after 6 steps (density sum)", wall=W, away=AWAY, **RUN)
+    assert_close_but_for_gamma_spikes(gv[:, 3], sim2.vel[:, 3], 2e-6, 1.0, what="densities after 6 steps (density sum)", wall=W, away=AWAY, **RUN)
     assert np.abs(ggg[fl, 3] - sim2.gg[fl, 3]).max() < 2e-5
     assert abs(eng2.current_dt() - sim2.dt) < 1e-5 * sim2.dt and abs(eng2.time() - sim2.t) < 1e-6 * sim2.t
 
@@ -462,12 +467,12 @@ def test_sa_tiled_kernels_agree_with_the_list_walkers(options, monkeypatch):
     assert vmax > 0.2
     # (a particle with an ill-conditioned element among its neighbours is pushed a little differently by the two: see
     # assert_close_but_for_gamma_spikes)
-    assert_close_but_for_gamma_spikes(pos_t[:, :3], pos_w[:, :3], 2e-5, cell, spike=10.0, what="positions, tiled against list walkers")
+    assert_close_but_for_gamma_spikes(pos_t[:, :3], pos_w[:, :3], 2e-5, cell, frac=0.002, spike=2.0, what="positions, tiled against list walkers")      # measured worst 0.75
     # (velocities: the one or two worst particles end between 1.6e-3 and 2.1e-3 of max |v| after the twelve steps, depending on how
     # a build happens to group the partial sums of a tile -- the cut points of the waves' shares moved in round 4 --; the share
     # of the entries beyond the plain tolerance is 3e-4, held to 2e-3 here instead of the helper's 1e-2)
     assert_close_but_for_gamma_spikes(vel_t[:, :3], vel_w[:, :3], 2e-4, vmax, frac=2e-3, spike=15.0, what="velocities, tiled against list walkers")
-    assert_close_but_for_gamma_spikes(vel_t[:, 3], vel_w[:, 3], 2e-6, 1.0, spike=10.0, what="densities, tiled against list walkers")
+    assert_close_but_for_gamma_spikes(vel_t[:, 3], vel_w[:, 3], 2e-6, 1.0, frac=0.002, spike=4.0, what="densities, tiled against list walkers")      # measured 1e-4 of the entries, worst 1.6
     assert np.abs(gg_t[fl, 3] - gg_w[fl, 3]).max() < 2e-5
     assert abs(dt_t - dt_w) < 1e-4 * dt_w
 

@@ -348,11 +348,14 @@ def test_open_channel_on_the_device_follows_the_cpu_run():
     assert np.array_equal(act, np.isfinite(_np(eng.pos[:n])[a][:, 3]))
     from sa_helpers import wall_rows
     W = wall_rows(p, ref.neibslist.numpy(), ref.info[:n].numpy().view(np.uint16), n)[b][act]      # of the last list (rebuilt in every step)
-    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, float(p.m_cellsize[0]), spike=10.0, what="positions after 20 steps (open channel)", wall=W, away=1e6)
-    assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, :3], ref.vel[:n].numpy()[b][act, :3], 1e-3, 0.6, spike=10.0,
-                                      what="velocities after 20 steps (open channel)", wall=W, away=1e6)
-    assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.15, spike=50.0,
-                                      what="densities after 20 steps (open channel)", wall=W, away=1e6)
+    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, float(p.m_cellsize[0]), frac=0.002, spike=4.0, what="positions after 20 steps (open channel)", wall=W)      # measured 3e-4 beyond, worst 1.65
+    assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, :3], ref.vel[:n].numpy()[b][act, :3], 1e-3, 0.6, frac=0.002, spike=2.0,
+                                      what="velocities after 20 steps (open channel)", wall=W)      # worst 0.72
+    assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.12, spike=25.0,
+                                      what="densities after 20 steps (open channel)", wall=W)
+    # (measured: 8.3 % of the densities beyond 2e-6 after the twenty steps, worst 16 x; in this channel of 8 x 8 particles across,
+    # 99.4 % of the rows have a boundary element in reach, so the allowance is the statement -- the rows that have none hold the
+    # plain tolerance (worst 0.29 of it), which is what catches a wrong row of a released particle)
     assert np.array_equal(_np(eng.next_ids[:n], np.uint32)[a], ref.next_ids[:n].numpy().view(np.uint32)[b])
 
 

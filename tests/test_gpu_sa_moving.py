@@ -94,9 +94,9 @@ def test_engine_follows_the_independent_sequence(options):
     cell = float(sim.o.p.cellSize[0])
     from sa_helpers import wall_rows
     W = wall_rows(sim.problem, sim.nl, sim.info, n)
-    assert_close_but_for_gamma_spikes(gp[:, :3], sim.pos[:n, :3], 2e-5, cell, spike=10.0, what="positions after 5 steps (moving)", wall=W, away=1e6)
-    assert_close_but_for_gamma_spikes(gv[:, :3], sim.vel[:n, :3], 1e-3, max(np.abs(sim.vel[:n, :3]).max(), 1e-3), spike=10.0, what="velocities after 5 steps (moving)", wall=W, away=1e6)
-    assert_close_but_for_gamma_spikes(gv[:, 3], sim.vel[:n, 3], 2e-6, 1.0, spike=10.0, frac=0.03, what="densities after 5 steps (moving)", wall=W, away=1e6)
+    assert_close_but_for_gamma_spikes(gp[:, :3], sim.pos[:n, :3], 2e-5, cell, frac=0.002, spike=2.0, what="positions after 5 steps (moving)", wall=W)      # measured worst 0.12 of the tolerance
+    assert_close_but_for_gamma_spikes(gv[:, :3], sim.vel[:n, :3], 1e-3, max(np.abs(sim.vel[:n, :3]).max(), 1e-3), frac=0.002, spike=2.0, what="velocities after 5 steps (moving)", wall=W)      # 0.11
+    assert_close_but_for_gamma_spikes(gv[:, 3], sim.vel[:n, 3], 2e-6, 1.0, spike=10.0, frac=0.03, what="densities after 5 steps (moving)", wall=W)      # 1.4 % beyond, worst 7.4; rows away from the walls 0.23
     fin = np.isfinite(sim.gg[:n, 3])
     assert_close_but_for_gamma_spikes(gg[fin, 3], sim.gg[:n][fin, 3], 5e-6, 1.0, spike=10.0, frac=0.03, what="gamma after 5 steps")
     assert abs(eng.current_dt() - sim.dt) <= 1e-4*sim.dt

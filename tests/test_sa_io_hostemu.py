@@ -281,14 +281,14 @@ def test_the_open_channel_over_the_emulated_kernels_follows_the_oracle():
     act = np.isfinite(rpos[:, 3])
     assert np.array_equal(act, np.isfinite(spos[:, 3]))
     cell = float(sim.o.p.cellSize[0])
-    assert_close_but_for_gamma_spikes(spos[act, :3], rpos[act, :3], 2e-5, cell, spike=10.0, what="positions after 40 steps")
-    assert_close_but_for_gamma_spikes(svel[act, :3], rvel[act, :3], 1e-3, U, spike=10.0, what="velocities after 40 steps")
+    assert_close_but_for_gamma_spikes(spos[act, :3], rpos[act, :3], 2e-5, cell, spike=5.0, what="positions after 40 steps")      # measured (SPHX_TEST_REPORT): 0.26 % beyond, worst 2.5 tolerances
+    assert_close_but_for_gamma_spikes(svel[act, :3], rvel[act, :3], 1e-3, U, frac=0.002, spike=2.0, what="velocities after 40 steps")      # worst 0.34
     # densities: at the far end of an element's support the closed form of |grad gamma_as| cancels to ~4e-3 of the wall's own
     # gradient in EITHER formulation (both are that far from the float64 value there, tests/test_sa_wall_gamma.py), a fifth of
     # the local value for a particle 1.5 h from an open boundary; the density summation integrates it, and after 40 steps of a
     # stream that crosses two such zones a tenth of the particles carry more than 2e-6, none more than 1e-4 (hydrostatic
     # density of this tank: 4e-3)
-    assert_close_but_for_gamma_spikes(svel[act, 3], rvel[act, 3], 2e-6, 1.0, frac=0.15, spike=50.0, what="densities after 40 steps")
+    assert_close_but_for_gamma_spikes(svel[act, 3], rvel[act, 3], 2e-6, 1.0, frac=0.15, spike=15.0, what="densities after 40 steps")      # 12.8 % beyond, worst 6.6
     mref = float(p.physparams.rho0[0]) * p.m_deltap ** 3
     assert np.abs(spos[act, 3] - rpos[act, 3]).max() < 1e-3 * mref
     assert np.abs(np.array(sim.level_seen) - np.array(ref.level_seen)).max() < 1e-5
@@ -380,11 +380,11 @@ def test_the_engines_driver_over_the_bindings_and_the_emulated_kernels():
     gr = p.global_pos(ref.pos[:n].numpy(), ref.hash[:n].numpy().view(np.uint32))[b]
     act = np.isfinite(ref.pos[:n].numpy()[b][:, 3])
     cell = float(p.m_cellsize[0])
-    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, cell, spike=10.0, what="positions after 30 steps")
-    assert_close_but_for_gamma_spikes(eng.vel[:n].numpy()[a][act, :3], ref.vel[:n].numpy()[b][act, :3], 1e-3, 0.6, spike=10.0,
-                                      what="velocities after 30 steps")
-    assert_close_but_for_gamma_spikes(eng.vel[:n].numpy()[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.15, spike=50.0,
-                                      what="densities after 30 steps")
+    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, cell, spike=4.0, what="positions after 30 steps")      # measured: 0.12 % beyond, worst 1.7 tolerances
+    assert_close_but_for_gamma_spikes(eng.vel[:n].numpy()[a][act, :3], ref.vel[:n].numpy()[b][act, :3], 1e-3, 0.6, frac=0.002, spike=2.0,
+                                      what="velocities after 30 steps")      # worst 0.59
+    assert_close_but_for_gamma_spikes(eng.vel[:n].numpy()[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.15, spike=15.0,
+                                      what="densities after 30 steps")      # 13.4 % beyond, worst 7.7
     assert np.array_equal(eng.next_ids[:n].numpy()[a], ref.next_ids[:n].numpy()[b])
     ke.emu.close()
 
