@@ -637,6 +637,17 @@ public:
 		const float2 * const *vertPos = bufread.getRawPtr<BUFFER_VERTPOS>();
 		if (!vertPos) throw std::invalid_argument("density_sum: BUFFER_VERTPOS missing");
 		const float4 *newPos = bufwrite.getConstData<BUFFER_POS>();
+		if ((m_c->params().simflags & ENABLE_INLET_OUTLET) && (m_c->params().simflags & ENABLE_MOVING_BODIES)) {
+			// both (the option set of CompleteSaExample.cu:46): the Eulerian velocities of the state that is read AND the boundary
+			// elements of both states (io_density_sum_params + boundelements_density_sum_params, src/cuda/density_sum_params.h)
+			sphx_throw(sphx_sa_density_sum_io_moving(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),
+				bufwrite.getData<BUFFER_FORCES>(), bufread.getData<BUFFER_POS>(), newPos, bufread.getData<BUFFER_VEL>(),
+				bufread.getData<BUFFER_EULERVEL>(), bufread.getData<BUFFER_GRADGAMMA>(), bufread.getData<BUFFER_BOUNDELEMENTS>(),
+				bufwrite.getConstData<BUFFER_BOUNDELEMENTS>(), vertPos[0], vertPos[1], vertPos[2], bufread.getData<BUFFER_INFO>(),
+				bufread.getData<BUFFER_HASH>(), bufread.getData<BUFFER_CELLSTART>(), bufread.getData<BUFFER_NEIBSLIST>(), numParticles,
+				particleRangeEnd, dt, NULL));
+			return;
+		}
 		if (m_c->params().simflags & ENABLE_INLET_OUTLET) {
 			// io_density_sum_params (src/cuda/density_sum_params.h): BUFFER_EULERVEL of the state that is read
 			sphx_throw(sphx_sa_density_sum_io(m_c->ctx(), bufwrite.getData<BUFFER_VEL>(), bufwrite.getData<BUFFER_GRADGAMMA>(),

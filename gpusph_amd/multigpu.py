@@ -211,8 +211,8 @@ class MultiGpuEngine:
         # SA bodies with prescribed motion: BUFFER_BOUNDELEMENTS is a state buffer (the Euler step turns the normals of the moving
         # segments and vertices), boundelements2 holds it for the state n* / n+1 (PredictorCorrectorIntegrator.cc:408-418)
         self.sa_moving = self.sa and bool(self.sp.simflags & D.ENABLE_MOVING_BODIES)
-        if self.sa_moving and (self.io or self.keps):
-            raise NotImplementedError("SA bodies with prescribed motion: not together with open boundaries or k-epsilon")
+        if self.sa_moving and self.keps:
+            raise NotImplementedError("SA bodies with prescribed motion: not together with k-epsilon")
         if self.io:
             if not self.sa_density_sum or self.keps or self.sp.buildneibsfreq != 1:
                 raise NotImplementedError("open boundaries are built for the density summation form without k-epsilon, buildneibsfreq = 1")
@@ -382,23 +382,31 @@ class MultiGpuEngine:
         K, n, ni = self.k, self.n_local, self.n_int
         ext = (lambda ts: self._exchange(ts)) if self.world > 1 else (lambda ts: None)
         dt = float(np.float32(np.float32(self.d_dt.item()) * np.float32(0.5 if step == 1 else 1.0)))      # dt_op, on the host
-        K.sa_density_sum_io(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.eulervel, self.gradgamma,
-                            self.boundelements, self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, ni, dt)
+        # with bodies that move as well (the option set of CompleteSaExample.cu:46): the elements of step n and of the new state in
+        # the density summation, those of the new state in everything that follows (as without open boundaries, _sa_post_euler)
+        be_new = self.boundelements2 if self.sa_moving else self.boundelements
+        if self.sa_moving:
+            K.sa_density_sum_io_moving(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.eulervel, self.gradgamma,
+                                       self.boundelements, be_new, self.vertpos, self.info, self.hash, self.cellStart, self.neibslist,
+                                       n, ni, dt)
+        else:
+            K.sa_density_sum_io(self.vel2, self.gradgamma2, self.forces, self.pos, self.pos2, self.vel, self.eulervel, self.gradgamma,
+                                self.boundelements, self.vertpos, self.info, self.hash, self.cellStart, self.neibslist, n, ni, dt)
         ext([self.vel2, self.gradgamma2])
         if self.sp.densitydiffusiontype == D.BREZZI:
-            K.sa_density_diffusion_io(self.forces, self.pos2, self.vel2, self.gradgamma2, self.boundelements, self.vertpos, self.info,
+            K.sa_density_diffusion_io(self.forces, self.pos2, self.vel2, self.gradgamma2, be_new, self.vertpos, self.info,
                                       self.hash, self.cellStart, self.neibslist, n, ni, dt)
             ext([self.vel2])
         self.eulervel2[:n] = self.eulervel[:n]
         self._io_impose(self.pos2, self.vel2, self.eulervel2)
-        K.sa_segment_bc_io(self.vel2, self.gradgamma2, self.eulervel2, self.pos2, self.vertices, self.boundelements, self.info,
+        K.sa_segment_bc_io(self.vel2, self.gradgamma2, self.eulervel2, self.pos2, self.vertices, be_new, self.info,
                            self.hash, self.cellStart, self.neibslist, n, ni, step)
         ext([self.vel2, self.gradgamma2, self.eulervel2])
         if step == 2:
-            K.sa_find_outgoing_segment(self.pos2, self.vel2, self.vertices, self.gradgamma2, self.vertpos, self.boundelements,
+            K.sa_find_outgoing_segment(self.pos2, self.vel2, self.vertices, self.gradgamma2, self.vertpos, be_new,
                                        self.info, self.hash, self.cellStart, self.neibslist, n, ni)
             ext([self.vertices, self.gradgamma2])      # the marks: a vertex takes over from the halo's particles too
-        self._io_vertex_bc(self.pos2, self.vel2, self.gradgamma2, self.eulervel2, dt, step)
+        self._io_vertex_bc(self.pos2, self.vel2, self.gradgamma2, self.eulervel2, dt, step, be_new)
         if step == 2:
             K.sa_disable_outgoing_parts(self.pos2, self.vertices, self.info, self.n_local)
 
@@ -414,14 +422,15 @@ class MultiGpuEngine:
                                     torch.from_numpy(np.array(best, dtype=np.uint32).view(np.int32)).to(self.device))
         self.problem.impose_open_boundaries(pos, vel, eulervel, self.info, self.hash, self.iowaterdepth, self.time(), self.n_local)
 
-    def _io_vertex_bc(self, pos, vel, ggam, eulervel, dt, step):
+    def _io_vertex_bc(self, pos, vel, ggam, eulervel, dt, step, boundelements=None):
         """SA_CALC_VERTEX_BOUNDARY_CONDITIONS with open boundaries: the pass writes the vertex masses (and the rows of released
         particles) into `pos`, in place as the reference has it; the new particle count comes back in a device word.  Released
         particles are appended behind everything this device holds (its halo included); they belong to it (the hash of the vertex
         that released them) and are sorted in at the next rebuild"""
         K, n, ni = self.k, self.n_local, self.n_int
         self.io_count[0] = n
-        K.sa_vertex_bc_io(vel, pos, pos, ggam, eulervel, self.forces, self.vertices, self.boundelements, self.vertpos,
+        be = self.boundelements if boundelements is None else boundelements      # (the rows of released particles are written there)
+        K.sa_vertex_bc_io(vel, pos, pos, ggam, eulervel, self.forces, self.vertices, be, self.vertpos,
                           self.info, self.hash, self.next_ids, self.io_count, self.cellStart, self.neibslist, n, ni, self.alloc,
                           dt, step, self.num_open_vertices)
         n2 = int(self.io_count.item()) & 0xFFFFFFFF
@@ -604,7 +613,7 @@ class MultiGpuEngine:
                 if self.io:      # the Eulerian velocity of the open boundaries in the viscous terms and in the gamma CFL condition
                     ev = self.eulervel if pos is self.pos else self.eulervel2
                     return K.forces_sa_io(self.forces, self.cfl, pos, vel, ev, self.info, self.hash, self.cellStart, self.neibslist, ggam,
-                                          self.boundelements, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma)
+                                          be, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma)
                 return K.forces_sa(self.forces, self.cfl, pos, vel, self.info, self.hash, self.cellStart, self.neibslist, ggam,
                                    be, self.vertpos, self.n_local, frm, to, off, cfl_gamma=self.cfl_gamma, run_mode=run_mode)
         elif self.effvisc_on and run_mode == D.SIMULATE:
@@ -746,6 +755,8 @@ class MultiGpuEngine:
             self._sa_post_euler_io(2)        # (the particle count has grown by the released particles: n is stale from here on)
             self.gradgamma, self.gradgamma2 = self.gradgamma2, self.gradgamma
             self.eulervel, self.eulervel2 = self.eulervel2, self.eulervel
+            if self.sa_moving:
+                self.boundelements, self.boundelements2 = self.boundelements2, self.boundelements
         elif self.sa:
             self._sa_post_euler(2)
             if self.keps:

@@ -1193,6 +1193,58 @@ class SAChannelIO(SABox):
             iowaterdepth.zero_()
 
 
+
+class SAChannelIOFlap(SAChannelIO):
+    """SAChannelIO with a MOVING body on top: ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES, the option set of the
+    reference's src/problems/CompleteSaExample.cu (:46; there an inlet, an outlet and a floating cube from Crixus meshes).  The
+    y = w side wall of the channel is a flap with prescribed motion -- its segments and the vertices that are not part of an open
+    face carry FG_MOVING_BOUNDARY and object number 2 (objects 0 and 1 are the open boundaries: the object number is shared by
+    bodies and open boundaries as in the reference, so bodies 0 and 1 of the rigid-body tables are there and at rest) -- turning about
+    the hinge line y = w, z = 0 while sliding along y.  What this mirror exercises is the command sequence where the two features
+    meet: update_normals behind both Euler steps, the density summation between two states of the elements WITH the open faces'
+    terms (sphx_sa_density_sum_io_moving), the condition passes, the take-over and release of particles and the per-step rebuild
+    with BUFFER_BOUNDELEMENTS as state.  A test geometry, like SAPaddleBox (the flap shares its edge vertices with the floor)."""
+
+    def __init__(self, deltap=0.05, *, omega=2.0, slide=0.1, **kw):
+        super().__init__(deltap, **kw)
+        self.m_name = "SAChannelIOFlap"
+        sp = self.simparams
+        sp.simflags |= D.ENABLE_MOVING_BODIES
+        sp.numbodies = 3
+        sp.numforcesbodies = 0
+        self.flap_omega, self.flap_slide = float(omega), float(slide)
+        info, g = self.parts.info, self.parts.pos_global
+        t = info_type(info)
+        nrm = self.boundelements
+        opened = (info[:, 0] & (D.FG_INLET | D.FG_OUTLET)) != 0
+        onwall = np.abs(g[:, 1] - self.w) < 1e-9
+        flap = (((t == D.PT_VERTEX) & onwall) | ((t == D.PT_BOUNDARY) & onwall & (nrm[:, 1] < -0.5))) & ~opened
+        info[flap, 0] |= D.FG_MOVING_BOUNDARY
+        info[flap, 1] = (info[flap, 1] & 0xF000) | 2
+        self.flap = flap
+        self.num_obstacle = int(flap.sum())
+        self.rb_firstindex = np.zeros(3, dtype=np.int32)
+        cg = np.array([[0.0, 0.0, 0.0], [self.l, 0.0, 0.0], [0.5*self.l, self.w, 0.0]])
+        self.rb_cg_global = cg.copy()
+        gcell = self.calc_grid_pos(cg)
+        self.rb_cg_gridpos = gcell.astype(np.int32)
+        self.rb_cg_pos = (cg - self.m_origin - (gcell + 0.5)*self.m_cellsize).astype(np.float32)
+        self.moving_bodies_callback = self._flap
+
+    def _flap(self, index, t0, t1, kd0, kd):
+        """body 2: constant angular velocity about x through the hinge + constant slide along y (the hinge travels with the slide);
+        bodies 0 and 1 (the open boundaries' object numbers) do not move"""
+        import math
+        if index != 2:
+            return np.zeros(3), np.eye(3)
+        w, u = self.flap_omega, self.flap_slide
+        kd.avel = np.array([w, 0.0, 0.0]); kd.lvel = np.array([0.0, u, 0.0])
+        a = w*(t1 - t0)
+        c, s = math.cos(a), math.sin(a)
+        dx = np.array([0.0, u*(t1 - t0), 0.0])
+        kd.crot = kd.crot + dx
+        return dx, np.array([[1.0, 0.0, 0.0], [0.0, c, -s], [0.0, s, c]])
+
 class OpenChannel(Problem):
     """The option set and dimensions of src/problems/OpenChannel.cu: a channel inclined by 4.5 degrees whose flow is driven by
     gravity, periodic along the stream (and across it without side walls), DYN_BOUNDARY bottom (and side walls) of

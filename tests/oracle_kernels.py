@@ -205,6 +205,14 @@ class OracleKernels:
                                         _p(vertpos[2]), C.c_uint32(n), C.c_uint32(frm), C.c_uint32(to), C.c_uint32(cfl_offset),
                                         C.c_float(self.sp.deltap)))
 
+    def sa_density_sum_io_moving(self, new_vel, new_ggam, forces, old_pos, new_pos, old_vel, old_eulervel, old_ggam, be_old, be_new, vertpos,
+                                 info, hash_, cellStart, neibslist, n, range_end, dt):
+        new_ggam[:n] = old_ggam[:n]       # the BOUNDARY rows are copied, as the device kernel does (the segment condition re-derives them)
+        self.L.orc_sa_density_sum_io_moving(C.byref(self.op), _p(new_vel), _p(new_ggam), _p(forces), _p(old_pos), _p(new_pos), _p(old_vel),
+                                            _p(old_eulervel), _p(old_ggam), _p(be_old), _p(be_new), _p(vertpos[0]), _p(vertpos[1]),
+                                            _p(vertpos[2]), _p(info), _p(hash_), _p(cellStart), _p(neibslist), C.c_uint32(range_end),
+                                            C.c_float(dt))
+
     def sa_body_pressure_forces(self, forces, rbforces, rbtorques, pos, vel, info, hash_, boundelements, frm, to):
         self.L.orc_sa_body_pressure_forces(C.byref(self.op), _p(forces), _p(rbforces), _p(rbtorques), _p(pos), _p(vel), _p(info), _p(hash_),
                                            _p(boundelements), C.c_uint32(frm), C.c_uint32(to))

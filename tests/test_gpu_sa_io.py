@@ -396,3 +396,47 @@ def test_density_summation_with_open_boundaries_and_moving_bodies():
     assert_close_but_for_gamma_spikes(gg[fl], want_g[fl], 2e-5, np.abs(want_g[fl, :3]).max(), what="gamma of the fluid", wall=wall[fl], frac=0.03)
     assert_close_but_for_gamma_spikes(gg[vt], want_g[vt], 2e-5, np.abs(want_g[vt, :3]).max(), what="gamma of the vertices", frac=0.05)
     assert np.array_equal(gg[bd].view(np.uint32), c["gg"][bd].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_open_channel_with_a_moving_flap_on_the_device_follows_the_cpu_run():
+    """SAChannelIOFlap -- ENABLE_INLET_OUTLET | ENABLE_DENSITY_SUM | ENABLE_MOVING_BODIES, the option set of CompleteSaExample.cu (:46)
+    -- through the engine's sequence on the GPU against the same driver over the oracle's kernels on the CPU (which
+    tests/test_multigpu_gloo.py holds bit-equal between one and two devices): particle counts and ids, the flap's rows bit for bit
+    (prescribed motion: both sides apply the same float operations), positions / velocities / densities of the rest to the
+    allowances of the open channel without a flap."""
+    from gpusph_amd.engine import TimestepEngine
+    from gpusph_amd.multigpu import MultiGpuEngine
+    from gpusph_amd.problem import SAChannelIOFlap, info_id
+    from oracle_kernels import OracleKernels
+    from sa_helpers import assert_close_but_for_gamma_spikes, wall_rows
+    mk = lambda: SAChannelIOFlap(0.05, U=0.6)
+    alloc = int(mk().num_particles * 1.6)
+    ref = MultiGpuEngine(mk(), "cpu", 0, 1, kernels=OracleKernels(mk(), alloc), allocated=alloc)
+    eng = TimestepEngine(mk(), device="cuda:0", allocated=alloc)
+    for it in range(12):
+        ref.step(); eng.step()
+        assert eng.n_local == ref.n_local and eng.io_created == ref.io_created, it
+    n = eng.n_local
+    a = np.argsort(info_id(_np(eng.info[:n], np.uint16)), kind="stable")
+    b = np.argsort(info_id(ref.info[:n].numpy().view(np.uint16)), kind="stable")
+    ginfo = _np(eng.info[:n], np.uint16)[a]
+    assert np.array_equal(ginfo, ref.info[:n].numpy().view(np.uint16)[b])
+    p = eng.problem
+    gp = p.global_pos(_np(eng.pos[:n]), _np(eng.hash[:n], np.uint32))[a]
+    gr = p.global_pos(ref.pos[:n].numpy(), ref.hash[:n].numpy().view(np.uint32))[b]
+    act = np.isfinite(ref.pos[:n].numpy()[b][:, 3])
+    moving = (ginfo[:, 0] & D.FG_MOVING_BOUNDARY) != 0
+    assert moving.sum() == p.num_obstacle
+    # the flap: cell-local positions, velocities and normals bit for bit; it did turn
+    assert np.array_equal(_np(eng.pos[:n])[a][moving, :3].view(np.uint32), ref.pos[:n].numpy()[b][moving, :3].view(np.uint32))
+    gb, rb = _np(eng.boundelements[:n])[a], ref.boundelements[:n].numpy()[b]
+    seg = moving & ((ginfo[:, 0] & 7) == D.PT_BOUNDARY)
+    assert np.array_equal(gb[seg].view(np.uint32), rb[seg].view(np.uint32)) and np.abs(gb[seg, 2]).min() > 1e-3
+    W = wall_rows(p, ref.neibslist.numpy(), ref.info[:n].numpy().view(np.uint16), n)[b][act]
+    assert_close_but_for_gamma_spikes(gp[act], gr[act], 2e-5, float(p.m_cellsize[0]), frac=0.002, spike=4.0, what="positions after 12 steps (open channel + flap)", wall=W)
+    assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, :3], ref.vel[:n].numpy()[b][act, :3], 1e-3, 0.6, frac=0.002, spike=2.0,
+                                      what="velocities after 12 steps (open channel + flap)", wall=W)
+    assert_close_but_for_gamma_spikes(_np(eng.vel[:n])[a][act, 3], ref.vel[:n].numpy()[b][act, 3], 2e-6, 1.0, frac=0.12, spike=25.0,
+                                      what="densities after 12 steps (open channel + flap)", wall=W)
+    assert np.array_equal(_np(eng.next_ids[:n], np.uint32)[a], ref.next_ids[:n].numpy().view(np.uint32)[b])

@@ -53,6 +53,9 @@ def _worker(rank, world, port, steps, case, outdir, filters=()):
     elif which == "SAChannelIO":
         from gpusph_amd.problem import SAChannelIO
         prob = SAChannelIO(**case)
+    elif which == "SAChannelIOFlap":
+        from gpusph_amd.problem import SAChannelIOFlap
+        prob = SAChannelIOFlap(**case)
     elif which == "PeriodicBox":
         from gpusph_amd.problem import PeriodicBox
         prob = PeriodicBox(**case)
@@ -349,7 +352,8 @@ def test_slab_runs_of_the_fidelity_option_sets_equal_single_domain(tmp_path, nam
     assert all(p["n_local"] > 0 for p in p2) and float(p2[0]["dt"]) == float(p1[0]["dt"])
 
 
-@pytest.mark.parametrize("cut", ["across the stream", "along the stream", "along the stream, until particles leave"])
+@pytest.mark.parametrize("cut", ["across the stream", "along the stream", "along the stream, until particles leave",
+                                 "across the stream, with a moving flap"])
 def test_open_channel_over_two_slabs_equals_single_domain(tmp_path, cut):
     """SAChannelIO (open boundaries: inlet on the first slab, pressure outlet on the last, the water level the outlet's pressure
     follows measured on one device and used on both) cut across the stream: every pass of the open-boundary sequence over the
@@ -362,6 +366,11 @@ def test_open_channel_over_two_slabs_equals_single_domain(tmp_path, cut):
         # next to the cut, the outlet's water level measured on both
         case = dict(problem="SAChannelIO", deltap=0.05, U=0.6, l=0.6, w=0.8, linearization="xzy")
     steps = 14
+    if cut.endswith("flap"):
+        # CompleteSaExample.cu's option set (open boundaries + density summation + moving bodies): the y = w wall turns and slides,
+        # straddling the cut; BUFFER_BOUNDELEMENTS is state (re-sorted in every step, its halo copies turned by the same motion),
+        # the density summation takes the elements of both states and the open faces' terms
+        case = dict(problem="SAChannelIOFlap", deltap=0.05, U=0.6, linearization="yzx")
     if cut.endswith("leave"):
         # a fast stream in a short tank: the first layer crosses the outlet within the run -- the marks of FIND_OUTGOING_SEGMENT
         # travel to the halo, a vertex takes over the mass of a neighbour device's particle, both devices disable their copy
@@ -375,7 +384,7 @@ def test_open_channel_over_two_slabs_equals_single_domain(tmp_path, cut):
     if cut.endswith("leave"):
         assert len(ids1) < int(p1[0]["n0"]) + int(p1[0]["io_created"])       # somebody left
     assert int(p1[0]["io_created"]) > 0 and sum(int(p["io_created"]) for p in p2) == int(p1[0]["io_created"])
-    for k in ("pos", "vel", "gradgamma", "eulervel"):
+    for k in ("pos", "vel", "gradgamma", "eulervel") + (("boundelements",) if cut.endswith("flap") else ()):
         a, b = one[k], two[k]
         assert np.array_equal(np.isnan(a), np.isnan(b)), k
         assert np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32)), k
