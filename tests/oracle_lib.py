@@ -171,10 +171,11 @@ def orc_params_from(sphx_params, problem=None):
         problem._orc_dem = np.ascontiguousarray(problem.dem, dtype=np.float32)      # kept alive for the oracle's pointer
         lib().orc_set_dem(P(problem._orc_dem), C.c_int(problem._orc_dem.shape[1]), C.c_int(problem._orc_dem.shape[0]))
     if problem is not None and getattr(problem, "num_obstacle", 0):
-        for a in range(3):
-            o.rbcgGridPos[0][a] = o.rbcgGridPosE[0][a] = int(problem.rb_cg_gridpos[0][a])
-            o.rbcgPos[0][a] = o.rbcgPosE[0][a] = float(problem.rb_cg_pos[0][a])
-        o.rbstartindex[0] = int(problem.rb_firstindex[0])
+        for b in range(len(problem.rb_firstindex)):      # every body (SAChannelIOFlap: objects 0 and 1 are the open boundaries, 2 the flap)
+            for a in range(3):
+                o.rbcgGridPos[b][a] = o.rbcgGridPosE[b][a] = int(problem.rb_cg_gridpos[b][a])
+                o.rbcgPos[b][a] = o.rbcgPosE[b][a] = float(problem.rb_cg_pos[b][a])
+            o.rbstartindex[b] = int(problem.rb_firstindex[b])
     return o
 
 
