@@ -808,6 +808,9 @@ struct TilePk { static constexpr bool value = KERNEL == SPHX_WENDLAND && TURB ==
 #ifndef SPHX_ASMRING_ALL
 #define SPHX_ASMRING_ALL 0
 #endif
+#ifndef SPHX_RING_WARMUP
+#define SPHX_RING_WARMUP 1
+#endif
 // the instantiations whose list ring is hand-managed (load_list_b<true>): those that keep every value in registers.  The SPS
 // ones spill (their pair holds twelve more values per neighbour) and stay on compiler-managed loads
 template<int TURB>
@@ -1133,7 +1136,7 @@ __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &
 		const char *ringBase = reinterpret_cast<const char*>(ls.list + ((size_t)__builtin_amdgcn_readfirstlane(wj.firstBatch) + TILE_AHEAD)*64u);
 		uint2 cur = lw.q[0];
 		gather_half<TURB>(cur.x, sPos, sVel, sAux, p.rho0[0], A);
-#define SPHX_RING_STEP(J, JN) \
+#define SPHX_RING_STEP(J, JN, WAIT) \
 		SPHX_RING_PRIO(J) \
 		gather_half<TURB>(cur.y, sPos, sVel, sAux, p.rho0[0], B); \
 		compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, A, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
@@ -1141,16 +1144,28 @@ __device__ __forceinline__ void walk_runs(const DevParams &p, const ForcesArgs &
 		if ((J) == TILE_AHEAD - 1) ringBase += TILE_AHEAD*512; \
 		/* the batch to gather next: requested a tile ahead if it is one of the first TILE_AHEAD (then fewer than TILE_AHEAD loads \
 		 * are in flight and the wait is a no-op), else TILE_AHEAD - 1 loads ago */ \
-		acc_wait(); \
+		/* ... and the first TILE_AHEAD - 1 steps of a tile take buffers that acc_start_ring wrote from ordinary registers: with   \
+		 * RING_WARMUP they do not wait at all -- vmcnt(3) there waited for the requests made for the NEXT tile moments before     \
+		 * (four list batches, two lane-index rows: all older than the ring's first load), a memory latency per tile that nothing  \
+		 * needed: -0.9 % per launch at 32 M, -0.7 % at 8 M (profiles/r06_tile_chain_experiments.txt) */ \
+		if (WAIT) acc_wait(); \
 		cur = acc_read<2*(JN)>(); \
 		gather_half<TURB>(cur.x, sPos, sVel, sAux, p.rho0[0], A); \
 		compute_half<KERNEL, TURB, COLAGROSSI, LJ>(p, B, s, q, inv_h, take, momentum, diffuse, sec == 1, ljlane, force, fx); \
 		if (--leftSeg == 0) { if (!end_segment()) { __builtin_amdgcn_s_setprio(0); return; } }
+		// (not for the LJ_BOUNDARY instantiations: with a second copy of their pair code the compiler parks values in a0 inside the
+		// walk -- scripts/check_ring_isa.py finds it --, and they are not what a step of theirs waits for)
+		if (SPHX_RING_WARMUP && !LJ) {      // the tile's first ring cycle, peeled: nothing to wait for in its first TILE_AHEAD - 1 steps
+			SPHX_RING_STEP(0, 1, false)
+			SPHX_RING_STEP(1, 2, false)
+			SPHX_RING_STEP(2, 3, false)
+			SPHX_RING_STEP(3, 0, true)
+		}
 		for (;;) {
-			SPHX_RING_STEP(0, 1)
-			SPHX_RING_STEP(1, 2)
-			SPHX_RING_STEP(2, 3)
-			SPHX_RING_STEP(3, 0)
+			SPHX_RING_STEP(0, 1, true)
+			SPHX_RING_STEP(1, 2, true)
+			SPHX_RING_STEP(2, 3, true)
+			SPHX_RING_STEP(3, 0, true)
 		}
 #undef SPHX_RING_STEP
 	} else {
@@ -2003,6 +2018,13 @@ void sphx_part_sa_tile(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs
 	else SPHX_SA_TILE(SPHX_LAMINAR_FLOW | SPHX_TURB_SA);
 #undef SPHX_SA_TILE
 }
+#elif defined(SPHX_FORCES_PART) && defined(SPHX_PROBE_PLAIN)
+// one instantiation alone, for reading its ISA (scripts/probe_plain_isa.sh): the plain forces pass of the bench workload
+void sphx_probe_plain(const sphx_ctx *ctx, hipStream_t stream, const ForcesArgs &a)
+{
+	forces_tile_kernel<SPHX_WENDLAND, SPHX_ARTIFICIAL, DIFF_COLAGROSSI, false><<<ctx->tile_grid, TILE_THREADS, 0, stream>>>(ctx->dev, a,
+		ctx->tiles, ctx->tile_ctl, ctx->cell_end_copy);
+}
 #elif defined(SPHX_FORCES_PART)
 #define SPHX_PASTE2(a, b) a##b
 #define SPHX_PASTE(a, b) SPHX_PASTE2(a, b)
@@ -2099,7 +2121,8 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	uint32_t *__restrict__ tiles, uint32_t *tileCtl, uint32_t *__restrict__ tileRows, uint32_t *__restrict__ tileRuns,
 	uint2 *__restrict__ tileList, uint32_t listCapBatches, uint32_t *__restrict__ laneRec, uint32_t *__restrict__ laneIndex,
 	uint32_t laneCap, int saVertex /* SA_BOUNDARY lists: the second section is the VERTEX section */,
-	uint32_t shareLo /* tile_share_start */)
+	uint32_t shareLo /* tile_share_start */,
+	uint32_t homeFrom, uint32_t homeTo /* only the tiles whose last home particle lies in [homeFrom, homeTo): a build in parts */)
 {
 	__shared__ uint32_t sCellRel[TILE_WROWS*TILE_KW], sCellBase[TILE_WROWS*TILE_KW], sCellStart[TILE_WROWS*TILE_KW];
 	__shared__ uint32_t sRowTotal[TILE_WROWS], sRowStart[TILE_WROWS], sRowContig[TILE_WROWS], sRowBase[TILE_WROWS];
@@ -2140,6 +2163,17 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 		const int ca = __builtin_amdgcn_readlane((int)d, 2), dnc = __builtin_amdgcn_readlane((int)d, 3);
 		const uint32_t P = (uint32_t)(__builtin_amdgcn_readlane((int)d, 8) + __builtin_amdgcn_readlane((int)d, 9) +
 			__builtin_amdgcn_readlane((int)d, 10) + __builtin_amdgcn_readlane((int)d, 11));        // home particles (<= TILE_PMAX)
+		{	// a build in parts: the tile belongs to the part that holds its last home particle (its lists are all there then); every
+			// thread of the workgroup sees the same descriptor, so all of them skip or none
+			uint32_t homeEnd = 0u;
+#pragma unroll
+			for (int r = 0; r < TILE_HROWS; ++r) {
+				const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)d, 4 + r), cnt = (uint32_t)__builtin_amdgcn_readlane((int)d, 8 + r);
+				if (cnt) homeEnd = max(homeEnd, first + cnt);
+			}
+			const uint32_t last = homeEnd ? homeEnd - 1u : 0u;
+			if (last < homeFrom || last >= homeTo) continue;
+		}
 		const uint32_t C = (P + 63u)/64u;
 		for (uint32_t e = tid; e < TILE_CHUNKS*TL_BINS; e += TL_THREADS) (&sHist[0][0])[e] = 0;
 		if (tid < TILE_WROWS*TILE_KW) {
@@ -2427,7 +2461,8 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	}
 }
 
-int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void *info, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st)
+int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void *info, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st,
+	uint32_t homeFrom, uint32_t homeTo)
 {
 	if (!ctx->tile_list || !ctx->tile_runs || !ctx->tile_rows || !ctx->tile_lane_rec || !ctx->tile_lane_index || !ctx->neib_counts) {
 		ctx->tiles_built = false;
@@ -2438,7 +2473,7 @@ int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void 
 	const bool plain = !sa && ctx->dev.turbmodel == SPHX_ARTIFICIAL && ctx->dev.numfluids == 1 && ctx->dev.boundarytype == SPHX_DYN_BOUNDARY;
 	tile_lists_kernel<<<grid, TL_THREADS, 0, st>>>(ctx->dev, neibsList, ctx->neib_counts, (const particleinfo*)info, hash, cellStart, ctx->cell_end_copy,
 		ctx->tiles, ctx->tile_ctl, ctx->tile_rows, ctx->tile_runs, ctx->tile_list, ctx->tile_list_batches, ctx->tile_lane_rec, ctx->tile_lane_index,
-		ctx->tile_lane_cap, sa ? 1 : 0, plain ? TILE_SHARE_LO_PLAIN : 32u);
+		ctx->tile_lane_cap, sa ? 1 : 0, plain ? TILE_SHARE_LO_PLAIN : 32u, homeFrom, homeTo);
 	SPHX_LAUNCH_CHECK("tile_lists_kernel");
 	return SPHX_OK;
 }

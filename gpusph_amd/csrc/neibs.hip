@@ -759,7 +759,13 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		// tile lists.  Without the side stream (creation failed) the same launches go to the caller's stream
 		static const bool noSide = getenv("SPHX_TILING_INLINE") != nullptr;      // A/B switch: the tiling on the caller's stream
 		if (!ctx->side_stream && !noSide) {
-			if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->side_stream = nullptr; }
+			// SPHX_SIDE_PRIORITY=1 (experiment of round 6): the side stream at the highest priority, so that the dispatcher prefers
+			// its workgroups whenever room comes free on a CU
+			static const bool sidePrio = getenv("SPHX_SIDE_PRIORITY") != nullptr;
+			int prLeast = 0, prGreatest = 0;
+			if (sidePrio) (void)hipDeviceGetStreamPriorityRange(&prLeast, &prGreatest);
+			if ((sidePrio ? hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prGreatest)
+			              : hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking)) != hipSuccess) { (void)hipGetLastError(); ctx->side_stream = nullptr; }
 			else if (hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
 			         hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
 				(void)hipGetLastError(); (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr;
@@ -789,12 +795,45 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		ctx->tiles_cellstart = cellStart;
 		ctx->tiles_neibslist = neibsList;
 	}
-	rc = sphx_neibs_list_launch(ctx, neibsList, pos, info, hash, cellStart, cellEnd, vertices, boundElements, vertPos0, vertPos1, vertPos2,
-		numParticles, particleRangeEnd, sqinfluenceradius, boundNlSqInflRad, st);      // neibs_build.hip
-	if (rc != SPHX_OK) return rc;
+	// A tiled build in parts.  tile_lists_kernel is a chain of dependent round trips per tile at ten waves per CU (forces.hip): it
+	// needs little of the vector units and leaves most of the CU idle; build_neibs_kernel is bound by vector issue.  So the list is
+	// built in `list_parts` launches over consecutive particle ranges, and the tile lists of the tiles whose home particles are
+	// all listed go to the side stream behind each of them: they run beside the list build of the next part, and only the last
+	// part's tile lists are left over at the end.  Lists, counters and tile lists are what one launch each gives (the tiles get
+	// their room in the list stream in another order, which nothing reads).
+	int parts = 1;
+	if (ctx->tiles_built && tiling_on_side && ctx->list_parts > 1 && particleRangeEnd >= 65536u*(uint32_t)ctx->list_parts) {
+		if (!ctx->list_part_events) {
+			int made = 0;
+			for (; made < SPHX_LIST_PARTS_MAX; ++made)
+				if (hipEventCreateWithFlags(&ctx->list_part[made], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); break; }
+			if (made == SPHX_LIST_PARTS_MAX) ctx->list_part_events = true;
+			else for (int k = 0; k < made; ++k) (void)hipEventDestroy(ctx->list_part[k]);
+		}
+		if (ctx->list_part_events) parts = ctx->list_parts;
+	}
+	if (parts > 1) {
+		const uint32_t per = div_up_u(div_up_u(particleRangeEnd, (uint32_t)parts), 1024u)*1024u;      // whole workgroups of the list build
+		for (int k = 0; k < parts; ++k) {
+			const uint32_t from = (uint32_t)k*per, to = (k == parts - 1) ? particleRangeEnd : min(particleRangeEnd, from + per);
+			if (from >= particleRangeEnd) break;
+			rc = sphx_neibs_list_launch_part(ctx, neibsList, pos, info, hash, cellStart, cellEnd, vertices, boundElements, vertPos0, vertPos1, vertPos2,
+				numParticles, from, to, sqinfluenceradius, boundNlSqInflRad, st);      // neibs_build.hip
+			if (rc != SPHX_OK) return rc;
+			SPHX_HIP(hipEventRecord(ctx->list_part[k], st));
+			SPHX_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->list_part[k], 0));
+			rc = sphx_tile_lists_launch(ctx, neibsList, info, hash, cellStart, sa, ctx->side_stream, from, (k == parts - 1) ? 0xFFFFFFFFu : to);
+			if (rc != SPHX_OK) return rc;
+		}
+		SPHX_HIP(hipEventRecord(ctx->side_join, ctx->side_stream));
+	} else {
+		rc = sphx_neibs_list_launch(ctx, neibsList, pos, info, hash, cellStart, cellEnd, vertices, boundElements, vertPos0, vertPos1, vertPos2,
+			numParticles, particleRangeEnd, sqinfluenceradius, boundNlSqInflRad, st);      // neibs_build.hip
+		if (rc != SPHX_OK) return rc;
+	}
 	neibs_counters_fold_kernel<<<1, NEIBS_SPREAD, 0, st>>>(ctx->counters_dev);
 	SPHX_LAUNCH_CHECK("neibs_counters_fold_kernel");
-	if (tiling_on_side) {      // the tiling is there for everything queued from here on
+	if (tiling_on_side) {      // the tiling (and, of a build in parts, the tile lists) is there for everything queued from here on
 		SPHX_HIP(hipStreamWaitEvent(st, ctx->side_join, 0));
 		sideJoin.armed = false;
 	}
@@ -827,7 +866,7 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		}
 	}
 	if (ctx->tiles_built) {   // the lists of the tiled particles in the form the tiled forces kernel walks (forces.hip)
-		rc = sphx_tile_lists_launch(ctx, neibsList, info, hash, cellStart, sa, st);
+		if (parts == 1) rc = sphx_tile_lists_launch(ctx, neibsList, info, hash, cellStart, sa, st);
 		if (rc != SPHX_OK) return rc;
 		// the tiling's overflow flag travels to the host behind the build, without a synchronisation: the forces passes that
 		// find it arrived (sphx_tiles_overflow_poll) launch exactly one kernel, the others keep the guarded stand-by

@@ -519,13 +519,14 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 	const uint32_t *__restrict__ cellStart, const uint32_t *__restrict__ cellEnd,
 	const uint32_t *__restrict__ cellFluidEnd,
 	uint32_t particleRangeEnd, uint32_t posRows, float sqinfluenceradius, NeibsCounters *__restrict__ counters,
-	uint32_t *__restrict__ neibCounts /* [out] entries of the fluid section | of the second section << 16, for the tile lists */)
+	uint32_t *__restrict__ neibCounts /* [out] entries of the fluid section | of the second section << 16, for the tile lists */,
+	uint32_t firstParticle /* the launch builds the lists of [firstParticle, particleRangeEnd): a build in parts, sphx_build_neibs_sa */)
 	// (the partial counter sets lie behind *counters: NeibsSpread)
 {
 	__shared__ neibdata sRing[BLOCK_NEIBS/64][NEIB_FRING + NEIB_BRING][64];
 	__shared__ uint32_t sMask[MC1 >= 0 ? (BLOCK_NEIBS/64)*3*64*NM_WORDS : 1];      // [wave][row of a slab][lane][word]
 	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t index = blockIdx.x*BLOCK_NEIBS + threadIdx.x;
+	const uint32_t index = firstParticle + blockIdx.x*BLOCK_NEIBS + threadIdx.x;
 	const bool inRange = index < particleRangeEnd;
 	uint32_t nf = 0, nb = 0, nv = 0; // neibs_num[PT_FLUID, PT_BOUNDARY, PT_VERTEX]
 	neibdata *const column = neibsList + (inRange ? index : 0u);
@@ -755,12 +756,14 @@ build_neibs_kernel(DevParams p, SaNeibArgs sa, neibdata *__restrict__ neibsList,
 }
 
 
-// the launch behind sphx_build_neibs_sa (neibs.hip): the list of [0, particleRangeEnd), the counters, the section lengths
-int sphx_neibs_list_launch(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, const void *info, const uint32_t *hash,
+// the launch behind sphx_build_neibs_sa (neibs.hip): the list of [firstParticle, particleRangeEnd), the counters (added to what
+// earlier parts of the same build left), the section lengths
+int sphx_neibs_list_launch_part(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, const void *info, const uint32_t *hash,
 	const uint32_t *cellStart, const uint32_t *cellEnd, const void *vertices, const void *boundElements,
-	void *vertPos0, void *vertPos1, void *vertPos2, uint32_t numParticles, uint32_t particleRangeEnd,
+	void *vertPos0, void *vertPos1, void *vertPos2, uint32_t numParticles, uint32_t firstParticle, uint32_t particleRangeEnd,
 	float sqinfluenceradius, float boundNlSqInflRad, hipStream_t st)
 {
+	if (firstParticle >= particleRangeEnd) return SPHX_OK;
 	const bool sa = ctx->params.boundarytype == SPHX_SA_BOUNDARY;
 	const bool posBuf = (size_t)numParticles*16u < ((size_t)1 << 32);
 	SaNeibArgs saArgs;
@@ -771,9 +774,9 @@ int sphx_neibs_list_launch(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, 
 	// is bit-identical and measured slower than the general walk (see the account above neibs_mfma_prepass): SPHX_NEIBS_MFMA=1 runs it
 	// (read when the context was created, like SPHX_DISABLE_TILES)
 	const int mc1 = (!sa && posBuf && ctx->neibs_mfma && ctx->dev.c1 <= 1) ? ctx->dev.c1 : -1;
-#define SPHX_NB_LAUNCH(K) SPHX_LAUNCH_WAVES(K, div_up_u(particleRangeEnd, BLOCK_NEIBS), BLOCK_NEIBS, st, ctx->dev, \
+#define SPHX_NB_LAUNCH(K) SPHX_LAUNCH_WAVES(K, div_up_u(particleRangeEnd - firstParticle, BLOCK_NEIBS), BLOCK_NEIBS, st, ctx->dev, \
 		saArgs, neibsList, (const float4*)pos, (const particleinfo*)info, hash, cellStart, cellEnd, ctx->cell_fluid_end, \
-		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev, ctx->neib_counts)
+		particleRangeEnd, numParticles, sqinfluenceradius, ctx->counters_dev, ctx->neib_counts, firstParticle)
 	if (sa) { if (posBuf) SPHX_NB_LAUNCH((build_neibs_kernel<true, true>)); else SPHX_NB_LAUNCH((build_neibs_kernel<false, true>)); }
 	else if (mc1 == 0) SPHX_NB_LAUNCH((build_neibs_kernel<true, false, 0>));
 	else if (mc1 == 1) SPHX_NB_LAUNCH((build_neibs_kernel<true, false, 1>));
@@ -782,4 +785,13 @@ int sphx_neibs_list_launch(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, 
 #undef SPHX_NB_LAUNCH
 	SPHX_LAUNCH_CHECK("build_neibs_kernel");
 	return SPHX_OK;
+}
+
+int sphx_neibs_list_launch(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint32_t *cellEnd, const void *vertices, const void *boundElements,
+	void *vertPos0, void *vertPos1, void *vertPos2, uint32_t numParticles, uint32_t particleRangeEnd,
+	float sqinfluenceradius, float boundNlSqInflRad, hipStream_t st)
+{
+	return sphx_neibs_list_launch_part(ctx, neibsList, pos, info, hash, cellStart, cellEnd, vertices, boundElements, vertPos0, vertPos1, vertPos2,
+		numParticles, 0u, particleRangeEnd, sqinfluenceradius, boundNlSqInflRad, st);
 }

@@ -46,6 +46,9 @@ extern "C" int sphx_create(sphx_ctx **out, int device)
 	const char *dis = getenv("SPHX_DISABLE_TILES");
 	ctx->disable_tiles = dis && dis[0] == '1';
 	{ const char *mf = getenv("SPHX_NEIBS_MFMA"); ctx->neibs_mfma = mf && mf[0] == '1'; }
+	// a tiled list build in parts, the tile lists of a part beside the list build of the next one (sphx_build_neibs_sa); 1 = one launch each
+	{ const char *lp = getenv("SPHX_LIST_PARTS"); const int n = lp ? atoi(lp) : SPHX_LIST_PARTS_DEFAULT;
+	  ctx->list_parts = n < 1 ? 1 : n > SPHX_LIST_PARTS_MAX ? SPHX_LIST_PARTS_MAX : n; }
 	// SPHX_DISABLE_TILES=1: always the generic gather kernel (A/B runs, tests).
 	// SPHX_TILE_DEBUG (ForcesArgs::dbg: timing experiments, some of which skip work and give wrong results) only exists in a
 	// library built with -DSPHX_TILE_DEBUG_BUILD (make EXTRA=-DSPHX_TILE_DEBUG_BUILD); the product library ignores the variable
@@ -97,6 +100,7 @@ extern "C" void sphx_destroy(sphx_ctx *ctx)
 	if (ctx->tile_ctl) (void)hipFree(ctx->tile_ctl);
 	if (ctx->ovf_host) { (void)hipHostFree(ctx->ovf_host); (void)hipEventDestroy(ctx->ovf_event); }
 	if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); (void)hipEventDestroy(ctx->side_fork); (void)hipEventDestroy(ctx->side_join); }
+	if (ctx->list_part_events) for (int k = 0; k < SPHX_LIST_PARTS_MAX; ++k) (void)hipEventDestroy(ctx->list_part[k]);
 	if (ctx->dem) (void)hipFree(ctx->dem);
 	if (ctx->open_rows) (void)hipFree(ctx->open_rows);
 	delete ctx->forces_events;

@@ -138,6 +138,8 @@ struct NeibsCounters {   // device counters of cuneibs (src/cuda/buildneibs_kern
 #define NEIBS_SPREAD 256
 struct NeibsSpread { int maxFluidBoundaryNeibs, maxVertexNeibs; unsigned long long numInteractions; };
 
+#define SPHX_LIST_PARTS_MAX 16
+#define SPHX_LIST_PARTS_DEFAULT 1
 struct sphx_ctx {
 	int         device;
 	bool        have_params;
@@ -194,6 +196,10 @@ struct sphx_ctx {
 	// on a stream of the context's own next to build_neibs_kernel, forked from and joined to the caller's stream by events
 	hipStream_t side_stream;
 	hipEvent_t  side_fork, side_join;
+	// a tiled build in parts (sphx_build_neibs_sa): the lists of part k are there
+	hipEvent_t  list_part[SPHX_LIST_PARTS_MAX];
+	int         list_parts;    // parts of a tiled list build (SPHX_LIST_PARTS in the environment when the context was created)
+	bool        list_part_events;
 	bool        ovf_pending;
 	bool        disable_tiles; // SPHX_DISABLE_TILES=1 in the environment (A/B testing)
 	bool        neibs_mfma;    // SPHX_NEIBS_MFMA=1 in the environment when the context was created: the list build's prepass on the matrix cores (neibs_build.hip)
@@ -260,7 +266,13 @@ int sphx_neibs_list_launch(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, 
 	const uint32_t *cellStart, const uint32_t *cellEnd, const void *vertices, const void *boundElements,
 	void *vertPos0, void *vertPos1, void *vertPos2, uint32_t numParticles, uint32_t particleRangeEnd,
 	float sqinfluenceradius, float boundNlSqInflRad, hipStream_t st);   // neibs_build.hip
-int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void *info, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st);
+int sphx_neibs_list_launch_part(sphx_ctx *ctx, uint16_t *neibsList, const void *pos, const void *info, const uint32_t *hash,
+	const uint32_t *cellStart, const uint32_t *cellEnd, const void *vertices, const void *boundElements,
+	void *vertPos0, void *vertPos1, void *vertPos2, uint32_t numParticles, uint32_t firstParticle, uint32_t particleRangeEnd,
+	float sqinfluenceradius, float boundNlSqInflRad, hipStream_t st);   // ... of [firstParticle, particleRangeEnd)
+// the tile lists of the tiles whose LAST home particle lies in [homeFrom, homeTo) (the whole tiling: 0, 0xFFFFFFFF)
+int sphx_tile_lists_launch(sphx_ctx *ctx, const uint16_t *neibsList, const void *info, const uint32_t *hash, const uint32_t *cellStart, bool sa, hipStream_t st,
+	uint32_t homeFrom = 0u, uint32_t homeTo = 0xFFFFFFFFu);
 // SA_BOUNDARY engines over the tiles (forces.hip): which sums the tiled kernel forms
 #define SPHX_SA_TILE_FORCES 0
 #define SPHX_SA_TILE_DSUM 1

@@ -441,6 +441,38 @@ LJ_CASES = [dict(deltap=0.04, obstacle=True, jitter=0.2, hydrostatic=False, visc
                  density_diffusion=D.FERRARI)]
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(viscosity="SPSVISC"), dict(linearization="yzx", obstacle=False, jitter=0.1)])
+def test_list_build_in_parts_equals_one_launch(opts, monkeypatch):
+    """SPHX_LIST_PARTS (sphx_build_neibs_sa, round 6): the list of a tiled build is made in several launches over consecutive
+    particle ranges, the tile lists of the tiles whose home particles are all listed run on the context's side stream beside the
+    list build of the next part.  Every list entry, the counters and the tiled forces pass on the lists are those of one launch
+    each -- to the bit: a tile's room in the list stream is the only thing that depends on the order."""
+    import torch
+    prob = DamBreak3D(**dict(dict(deltap=DamBreak3D.deltap_for(3.4e5), obstacle=True, jitter=0.05), **opts))
+    outs = []
+    for parts in ("1", "4"):
+        monkeypatch.setenv("SPHX_LIST_PARTS", parts)      # read when the context is created
+        eng = _engine(prob, clobber_neibslist=True)
+        eng.build_neibs()
+        n = eng.n
+        assert n >= 4*65536, n      # below that a build is not split
+        rng = np.random.default_rng(5)
+        vel = _np(eng.vel).copy()
+        vel[:n, :3] += rng.uniform(-0.3, 0.3, size=(n, 3)).astype(np.float32)
+        vel[:n, 3] += rng.uniform(0, 2e-3, size=n).astype(np.float32)
+        eng.vel.copy_(torch.from_numpy(vel).to(eng.device))
+        eng._forces(eng.pos, eng.vel, 1, 0)
+        info = eng.neibs_info()
+        tau = np.concatenate([_np(t)[:n] for t in eng.tau], axis=1) if getattr(eng, "tau", None) else np.zeros((n, 6), np.float32)
+        outs.append((_np(eng.neibslist, np.uint16).copy(), (info.numInteractions, info.maxFluidBoundaryNeibs, info.hasTooManyNeibs),
+                     _np(eng.forces)[:n].copy(), float(eng.d_dt_next.item()), tau.copy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert outs[0][1] == outs[1][1]
+    assert np.array_equal(outs[0][2].view(np.uint32), outs[1][2].view(np.uint32))
+    assert outs[0][3] == outs[1][3]
+    assert np.array_equal(outs[0][4].view(np.uint32), outs[1][4].view(np.uint32))
+
+
 @pytest.mark.parametrize("case", CASES + LJ_CASES)
 def test_tiled_and_generic_kernels_agree(case, monkeypatch):
     """the LDS-tiled forces kernel and the generic gather kernel implement the same sum in the same order; the tiled one in
