@@ -125,6 +125,12 @@ static int euler_launch(sphx_ctx *ctx, void *newPos, void *newVel, void *newVol,
 	(void)t; (void)slength; (void)influenceradius; (void)numParticles;
 	SPHX_REQUIRE(ctx && ctx->have_params, "sphx_euler_basicstep: constants not set");
 	SPHX_REQUIRE(newPos && newVel && oldPos && oldVel && info && hash && forces, "sphx_euler_basicstep: missing buffer");
+	// SA_BOUNDARY with moving bodies: this step moves boundary elements, so what was kept of |grad gamma_as| per list entry
+	// (ctx->sa_wall_cache, sa_wall.hip) belongs to a state of the elements that is gone: a new generation of the rows
+	if (ctx->params.boundarytype == SPHX_SA_BOUNDARY && (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES)) {
+		++ctx->sa_wall_gen;
+		if (!ctx->sa_wall_gen) ctx->sa_wall_gen = 1u;
+	}
 	// SA_BOUNDARY: the fluid integrates like everywhere else, walls are copied; gamma follows in sphx_sa_integrate_gamma or,
 	// with density summation (FORCES.w is zero then), density and gamma in sphx_sa_density_sum
 	if ((ctx->dev.simflags & SPHX_ENABLE_XSPH) && run_mode == SPHX_SIMULATE)
@@ -249,6 +255,8 @@ extern "C" int sphx_sa_update_normals(sphx_ctx *ctx, void *newBoundElements, con
 		"sphx_sa_update_normals: BUFFER_BOUNDELEMENTS is double buffered with moving bodies");
 	if (!particleRangeEnd) return SPHX_OK;
 	{ const int rcf = sphx_rb_flush(ctx, (hipStream_t)stream); if (rcf != SPHX_OK) return rcf; }
+	++ctx->sa_wall_gen;      // the elements turn: rows of |grad gamma_as| kept before this call are of another state (sa_wall.hip)
+	if (!ctx->sa_wall_gen) ctx->sa_wall_gen = 1u;
 	sa_update_normals_kernel<<<div_up_u(particleRangeEnd, BLOCK_EULER), BLOCK_EULER, 0, (hipStream_t)stream>>>((float4*)newBoundElements,
 		(const float4*)oldBoundElements, (const particleinfo*)info, ctx->rb_dev, particleRangeEnd);
 	SPHX_LAUNCH_CHECK("sa_update_normals_kernel");

@@ -681,15 +681,16 @@ neibs_counters_fold_kernel(NeibsCounters *counters)
 	}
 }
 
-// SA_BOUNDARY: the active fluid particles whose boundary section is not empty, in no particular order (wave-aggregated append)
+// SA_BOUNDARY: the active particles of type `ptype` (fluid; vertex for moving bodies) whose boundary section is not empty, in no
+// particular order (wave-aggregated append)
 static __global__ void __launch_bounds__(256)
 sa_wall_list_kernel(const neibdata *__restrict__ list, const particleinfo *__restrict__ info, const float4 *__restrict__ pos,
-	uint32_t n, uint32_t stride, uint32_t neibboundpos, uint32_t *__restrict__ wall)
+	uint32_t n, uint32_t stride, uint32_t neibboundpos, uint32_t *__restrict__ wall, uint32_t ptype)
 {
 	const uint32_t i = blockIdx.x*256 + threadIdx.x;
 	bool has = false;
 	if (i < n)
-		has = PART_TYPE(info[i]) == PT_FLUID && is_active_w(pos[i].w) && list[(size_t)neibboundpos*stride + i] != NEIBS_END;
+		has = PART_TYPE(info[i]) == ptype && is_active_w(pos[i].w) && list[(size_t)neibboundpos*stride + i] != NEIBS_END;
 	const unsigned long long m = __builtin_amdgcn_ballot_w64(has);
 	if (!m) return;
 	const uint32_t lane = threadIdx.x & 63u;
@@ -860,8 +861,20 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 		if (ctx->sa_wall) {
 			SPHX_HIP(hipMemsetAsync(ctx->sa_wall, 0, sizeof(uint32_t), st));
 			sa_wall_list_kernel<<<div_up_u(particleRangeEnd, 256), 256, 0, st>>>(neibsList, (const particleinfo*)info, (const float4*)pos,
-				particleRangeEnd, ctx->dev.stride, ctx->dev.neibboundpos, ctx->sa_wall);
+				particleRangeEnd, ctx->dev.stride, ctx->dev.neibboundpos, ctx->sa_wall, (uint32_t)PT_FLUID);
 			SPHX_LAUNCH_CHECK("sa_wall_list_kernel");
+			if (ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES) {      // the vertex rows: their gamma is integrated by the density summation
+				if (!ctx->sa_wall_vert && hipMalloc((void**)&ctx->sa_wall_vert, sizeof(uint32_t)*((size_t)ctx->reserved_particles + 1)) != hipSuccess) {
+					(void)hipGetLastError();
+					ctx->sa_wall_vert = nullptr;      // one thread per vertex row then
+				}
+				if (ctx->sa_wall_vert) {
+					SPHX_HIP(hipMemsetAsync(ctx->sa_wall_vert, 0, sizeof(uint32_t), st));
+					sa_wall_list_kernel<<<div_up_u(particleRangeEnd, 256), 256, 0, st>>>(neibsList, (const particleinfo*)info, (const float4*)pos,
+						particleRangeEnd, ctx->dev.stride, ctx->dev.neibboundpos, ctx->sa_wall_vert, (uint32_t)PT_VERTEX);
+					SPHX_LAUNCH_CHECK("sa_wall_list_kernel<vertices>");
+				}
+			}
 			ctx->sa_wall_neibslist = neibsList;
 		}
 	}

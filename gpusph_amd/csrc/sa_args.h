@@ -103,4 +103,5 @@ struct SaDensitySumArgs {
 // sa_wall.hip: the boundary-element terms of the three engines for the particles of ctx->sa_wall
 int sphx_sa_wall_forces(sphx_ctx *ctx, const SaForcesArgs &a, hipStream_t st);
 int sphx_sa_wall_density_sum(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st);
+int sphx_sa_wall_density_sum_moving(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st);   // ... with ENABLE_MOVING_BODIES (fluid rows)
 int sphx_sa_wall_integrate_gamma(sphx_ctx *ctx, const SaIntGammaArgs &a, hipStream_t st);

@@ -638,7 +638,8 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 	}
 	float gGamDotR = 0.0f, gamFluxMoved = 0.0f, gamFluxN = 0.0f;
 	V3 gGam = v3(0.0f, 0.0f, 0.0f);
-	if (a.wallDone && a.tiled && !(a.tileGuard && *a.tileGuard)) {     // sa_density_sum_wall_kernel
+	// sa_density_sum_wall_kernel; with MOVING sa_density_sum_wall_moving_kernel: wallDone & 1 the fluid rows, & 2 the vertex rows
+	if ((vertexRow ? (a.wallDone & 2) : (a.wallDone & 1)) && a.tiled && !(a.tileGuard && *a.tileGuard)) {
 		if (a.neibsList[(size_t)p.neibboundpos*p.stride + index] != NEIBS_END && is_active_w(posN.w)) {
 			const float4 t = a.newGGam[index];
 			gGam = v3(t.x, t.y, t.z); gGamDotR = t.w;
@@ -1049,11 +1050,10 @@ static int sa_forces_impl(sphx_ctx *ctx, void *forces, float *cfl, float *cflGam
 		a.tiled = used ? 1 : 0;
 		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
 			a.wallDone = 1;
-			// |grad gamma_as| kept from the density summation of this state: elements at rest only (a row is tagged with the
-			// particle's position, not with the elements')
-			if (!(ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES)) {
-				a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
-			}
+			// |grad gamma_as| kept from the density summation of this state (a row is tagged with the particle's position and the
+			// generation of the rows; what moves elements -- a rebuild, the Euler step and the normals of a run with moving bodies --
+			// starts a new generation)
+			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
 			rc = sphx_sa_wall_forces(ctx, a, st);
 			if (rc != SPHX_OK) return rc;
 		}
@@ -1395,13 +1395,20 @@ extern "C" int sphx_sa_density_sum_moving(sphx_ctx *ctx, void *newVel, void *new
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
 	{
 		// the particle <- particle sums (fluid and vertex neighbours, the moving vertices with their own displacement like any other
-		// particle) through the tiled window as for walls at rest (round 6); the boundary-element terms stay with the walker below:
-		// the wave-per-wall-particle kernels assume one normal per element
+		// particle) through the tiled window as for walls at rest (round 6)
 		bool used = false;
 		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_DSUM, forces, oldPos, nullptr, newPos, info, hash, cellStart, neibsList, nullptr,
 			numParticles, 0u, particleRangeEnd, 0.0f, (hipStream_t)stream, &used, &a.tileGuard);
 		if (rc != SPHX_OK) return rc;
 		a.tiled = used ? 1 : 0;
+		// ... and the boundary-element terms of the fluid particles next to a wall with one element per lane, both states of
+		// every element (sa_density_sum_wall_moving_kernel); the vertex rows and a run without tiles stay with the walker below
+		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
+			a.wallDone = ctx->sa_wall_vert ? 3 : 1;
+			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
+			rc = sphx_sa_wall_density_sum_moving(ctx, a, (hipStream_t)stream);
+			if (rc != SPHX_OK) return rc;
+		}
 	}
 	sa_density_sum_kernel<false, true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_kernel<moving>");

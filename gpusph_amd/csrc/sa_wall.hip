@@ -251,6 +251,67 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 	}
 }
 
+// ... with ENABLE_MOVING_BODIES (sa_density_sum_kernel<., MOVING>, density_sum_kernel.cu:422-484): an element is where it was AND where
+// it is -- position and normal of both states --, so the step-n half of the second sum cannot be taken from the stored grad gamma:
+// two evaluations per element, the corners set up once per normal, as the one-thread kernel does.  The VERTEX rows, whose gamma
+// these terms integrate, come as a list of their own (ctx->sa_wall_vert; nothing is kept of them).  |grad gamma_as| of the NEW state is kept
+// for the forces pass that follows at that state, as for walls at rest: a row is tagged with the particle's position and the generation
+// of the rows, and every call that moves elements (the Euler step of such a run, sphx_sa_update_normals) starts a new generation.  (Round 6: the one-thread kernel was 61 % of a step of the
+// SAPaddleBox mirror at 4.3 M particles, profiles/r06_sa_moving_kernel_stats.txt)
+__global__ void __launch_bounds__(SA_WALL_THREADS)
+sa_density_sum_wall_moving_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__restrict__ wall)
+{
+	if (a.tileGuard && *a.tileGuard) return;
+	SA_WALL_LOOP(wall) {
+		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
+		if (index >= a.numParticles) continue;
+		const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
+		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
+		const float inv = 1.0f/p.slength;
+		float gx = 0.0f, gy = 0.0f, gz = 0.0f, dotSum = 0.0f;
+		const bool keep = wall_cache_row(a.wc, w);
+		bool complete = true;
+		int cellCarry = 0;
+		bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, posN, gridPos, s0, lane, cellCarry, more);
+			if (__builtin_amdgcn_ballot_w64(e.alive && (uint32_t)s0 + lane >= SA_WALL_CACHE_ENTRIES)) complete = false;
+			const uint32_t j = e.j;
+			const float4 nN = a.oldPos[j];
+			if (!e.alive || !is_active_w(nN.w)) continue;
+			const float4 nNp1 = a.pos[j];
+			const V3 qN = v3((e.pcx - nN.x)*inv, (e.pcy - nN.y)*inv, (e.pcz - nN.z)*inv);
+			const V3 qNp1 = v3(((e.pcx - nNp1.x) + dx)*inv, ((e.pcy - nNp1.y) + dy)*inv, ((e.pcz - nNp1.z) + dz)*inv);
+			const float4 be = a.boundElement[j], ben = a.boundElementNew[j];
+			const V3 ns = v3(be.x, be.y, be.z), nsNew = v3(ben.x, ben.y, ben.z);
+			// most elements of such a run do not move: the same bits in both states give the same corners, and seen from a particle
+			// that did not move either (a vertex of a wall at rest) the same |grad gamma_as| -- one evaluation instead of two, the
+			// same numbers (waves whose elements and particle all rest skip the second one altogether)
+			const bool sameEl = __float_as_uint(be.x) == __float_as_uint(ben.x) && __float_as_uint(be.y) == __float_as_uint(ben.y) &&
+				__float_as_uint(be.z) == __float_as_uint(ben.z) && __float_as_uint(nN.x) == __float_as_uint(nNp1.x) &&
+				__float_as_uint(nN.y) == __float_as_uint(nNp1.y) && __float_as_uint(nN.z) == __float_as_uint(nNp1.z);
+			const bool sameQ = sameEl && dx == 0.0f && dy == 0.0f && dz == 0.0f;
+			WallTri tri;
+			wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			const float ggamN = wall_grad_gamma_flat(tri, qN)/p.slength;
+			const V3 gN = ns*ggamN;
+			if (!sameEl) wall_tri_setup(tri, nsNew, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			float ggamNp1 = ggamN;
+			if (!sameQ) ggamNp1 = wall_grad_gamma_flat(tri, qNp1)/p.slength;
+			if (keep) wall_cache_put(a.wc, w, (uint32_t)s0 + lane, ggamNp1);      // for the forces pass at this state (fluid rows)
+			const V3 gNp1 = nsNew*ggamNp1;
+			dotSum += 0.5f*dot(gN + gNp1, qNp1 - qN);
+			gx += gNp1.x; gy += gNp1.y; gz += gNp1.z;
+		}
+		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); dotSum = wave_sum(dotSum);
+		if (lane == 0) {
+			a.newGGam[index] = make_float4(gx, gy, gz, dotSum);
+			if (keep) wall_cache_seal(a.wc, w, posNp1, complete);
+		}
+	}
+}
+
 // sa_integrate_gamma_kernel for the particles with boundary elements in reach
 __global__ void __launch_bounds__(SA_WALL_THREADS)
 sa_integrate_gamma_wall_kernel(DevParams p, SaIntGammaArgs a, const uint32_t *__restrict__ wall)
@@ -303,6 +364,18 @@ int sphx_sa_wall_density_sum(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream
 {
 	sa_density_sum_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
 	SPHX_LAUNCH_CHECK("sa_density_sum_wall_kernel");
+	return SPHX_OK;
+}
+int sphx_sa_wall_density_sum_moving(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st)
+{
+	sa_density_sum_wall_moving_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	SPHX_LAUNCH_CHECK("sa_density_sum_wall_moving_kernel");
+	if (a.wallDone & 2) {      // the vertex rows (row numbers of another list: nothing kept)
+		SaDensitySumArgs av = a;
+		av.wc.values = nullptr; av.wc.tag = nullptr; av.wc.capacity = 0; av.wc.gen = 0;
+		sa_density_sum_wall_moving_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, av, ctx->sa_wall_vert);
+		SPHX_LAUNCH_CHECK("sa_density_sum_wall_moving_kernel<vertices>");
+	}
 	return SPHX_OK;
 }
 int sphx_sa_wall_integrate_gamma(sphx_ctx *ctx, const SaIntGammaArgs &a, hipStream_t st)

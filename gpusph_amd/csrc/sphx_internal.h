@@ -212,6 +212,9 @@ struct sphx_ctx {
 	// the boundary-element terms are evaluated one element per lane for these, sa_bounds.hip); sa_wall_neibslist = that list
 	uint32_t   *sa_wall;
 	const void *sa_wall_neibslist;
+	// ... and, of a run with ENABLE_MOVING_BODIES, the VERTEX particles whose list has boundary elements (same layout, same list):
+	// the density summation integrates their gamma by the same boundary terms (sa_density_sum_wall_moving_kernel)
+	uint32_t   *sa_wall_vert;
 	// |grad gamma_as| of every (wall particle, entry of its boundary section) as the density summation / gamma quadrature of a
 	// step evaluates it at the new positions, kept for the forces pass that follows at those very positions (sa_wall.hip):
 	// [wall particle][SA_WALL_CACHE_ENTRIES] floats + a tag per wall particle {position bits, list generation}
