@@ -252,12 +252,12 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 }
 
 // ... with ENABLE_MOVING_BODIES (sa_density_sum_kernel<., MOVING>, density_sum_kernel.cu:422-484): an element is where it was AND where
-// it is -- position and normal of both states --, so the step-n half of the second sum cannot be taken from the stored grad gamma:
-// two evaluations per element, the corners set up once per normal, as the one-thread kernel does.  The VERTEX rows, whose gamma
-// these terms integrate, come as a list of their own (ctx->sa_wall_vert; nothing is kept of them).  |grad gamma_as| of the NEW state is kept
-// for the forces pass that follows at that state, as for walls at rest: a row is tagged with the particle's position and the generation
-// of the rows, and every call that moves elements (the Euler step of such a run, sphx_sa_update_normals) starts a new generation.  (Round 6: the one-thread kernel was 61 % of a step of the
-// SAPaddleBox mirror at 4.3 M particles, profiles/r06_sa_moving_kernel_stats.txt)
+// it is -- position and normal of both states.  The fluid particles next to a wall and, as a list of their own (ctx->sa_wall_vert;
+// nothing is kept of them), the VERTEX rows, whose gamma these terms integrate.  |grad gamma_as| of the NEW state is kept for the
+// forces pass that follows at that state, as for walls at rest: a row is tagged with the particle's position and the generation of
+// the rows, and every call that moves elements (the Euler step of such a run, sphx_sa_update_normals) starts a new generation.
+// (Round 6: the one-thread kernel was 61 % of a step of the SAPaddleBox mirror at 4.3 M particles,
+// profiles/r06_sa_moving_kernel_stats.txt)
 __global__ void __launch_bounds__(SA_WALL_THREADS)
 sa_density_sum_wall_moving_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__restrict__ wall)
 {
@@ -270,6 +270,31 @@ sa_density_sum_wall_moving_kernel(DevParams p, SaDensitySumArgs a, const uint32_
 		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
 		const float inv = 1.0f/p.slength;
 		float gx = 0.0f, gy = 0.0f, gz = 0.0f, dotSum = 0.0f;
+		float mx = 0.0f, my = 0.0f, mz = 0.0f;      // grad gamma_as(n) of the elements that moved
+		// a particle that did not move (a vertex of a wall at rest) none of whose elements moved: the sums are those of the previous
+		// step, to the bit -- the same elements seen from the same place by this same kernel (after a rebuild or the initialisation:
+		// the same numbers by another route) -- and are taken from there.  Most vertex rows of a run are of this kind
+		if (dx == 0.0f && dy == 0.0f && dz == 0.0f) {
+			bool moved = false;
+			int carry0 = 0;
+			bool more0 = true;
+			for (int s0 = 0; more0; s0 += 64) {
+				const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, posN, gridPos, s0, lane, carry0, more0);
+				const uint32_t j = e.j;
+				const float4 nN = a.oldPos[j], nNp1 = a.pos[j], be = a.boundElement[j], ben = a.boundElementNew[j];
+				const bool same = __float_as_uint(be.x) == __float_as_uint(ben.x) && __float_as_uint(be.y) == __float_as_uint(ben.y) &&
+					__float_as_uint(be.z) == __float_as_uint(ben.z) && __float_as_uint(nN.x) == __float_as_uint(nNp1.x) &&
+					__float_as_uint(nN.y) == __float_as_uint(nNp1.y) && __float_as_uint(nN.z) == __float_as_uint(nNp1.z);
+				if (__builtin_amdgcn_ballot_w64(e.alive && is_active_w(nN.w) && !same)) moved = true;
+			}
+			if (!moved) {
+				if (lane == 0) {
+					const float4 gGamN = a.oldGGam[index];
+					a.newGGam[index] = make_float4(gGamN.x, gGamN.y, gGamN.z, 0.0f);
+				}
+				continue;      // (nothing kept: the forces pass does not read rows of particles at rest -- fluid particles move)
+			}
+		}
 		const bool keep = wall_cache_row(a.wc, w);
 		bool complete = true;
 		int cellCarry = 0;
@@ -285,28 +310,35 @@ sa_density_sum_wall_moving_kernel(DevParams p, SaDensitySumArgs a, const uint32_
 			const V3 qNp1 = v3(((e.pcx - nNp1.x) + dx)*inv, ((e.pcy - nNp1.y) + dy)*inv, ((e.pcz - nNp1.z) + dz)*inv);
 			const float4 be = a.boundElement[j], ben = a.boundElementNew[j];
 			const V3 ns = v3(be.x, be.y, be.z), nsNew = v3(ben.x, ben.y, ben.z);
-			// most elements of such a run do not move: the same bits in both states give the same corners, and seen from a particle
-			// that did not move either (a vertex of a wall at rest) the same |grad gamma_as| -- one evaluation instead of two, the
-			// same numbers (waves whose elements and particle all rest skip the second one altogether)
+			// Most elements of such a run do not move (the same bits in both states).  For those q(n+1) - q(n) is the particle's own
+			// displacement, the same for all of them, so their step-n half of the second sum is 1/2 (sum grad gamma_as(n)) . dq with
+			// the sum taken from the particle's stored grad gamma of step n minus the moving elements' part of it (what
+			// sa_density_sum_wall_kernel does for walls at rest, see there for what it rests on): ONE evaluation per element at
+			// rest, two -- the corners set up once per normal -- only for the elements that moved
 			const bool sameEl = __float_as_uint(be.x) == __float_as_uint(ben.x) && __float_as_uint(be.y) == __float_as_uint(ben.y) &&
 				__float_as_uint(be.z) == __float_as_uint(ben.z) && __float_as_uint(nN.x) == __float_as_uint(nNp1.x) &&
 				__float_as_uint(nN.y) == __float_as_uint(nNp1.y) && __float_as_uint(nN.z) == __float_as_uint(nNp1.z);
-			const bool sameQ = sameEl && dx == 0.0f && dy == 0.0f && dz == 0.0f;
 			WallTri tri;
-			wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			const float ggamN = wall_grad_gamma_flat(tri, qN)/p.slength;
-			const V3 gN = ns*ggamN;
-			if (!sameEl) wall_tri_setup(tri, nsNew, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-			float ggamNp1 = ggamN;
-			if (!sameQ) ggamNp1 = wall_grad_gamma_flat(tri, qNp1)/p.slength;
+			V3 gN = v3(0.0f, 0.0f, 0.0f);
+			if (!sameEl) {
+				wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+				gN = ns*(wall_grad_gamma_flat(tri, qN)/p.slength);
+			}
+			wall_tri_setup(tri, nsNew, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			const float ggamNp1 = wall_grad_gamma_flat(tri, qNp1)/p.slength;
 			if (keep) wall_cache_put(a.wc, w, (uint32_t)s0 + lane, ggamNp1);      // for the forces pass at this state (fluid rows)
 			const V3 gNp1 = nsNew*ggamNp1;
-			dotSum += 0.5f*dot(gN + gNp1, qNp1 - qN);
+			// an element at rest: its step-(n+1) half here, its step-n half from the stored sum below; one that moved: both halves
+			dotSum += sameEl ? 0.5f*dot(gNp1, qNp1 - qN) : 0.5f*dot(gN + gNp1, qNp1 - qN);
+			mx += gN.x; my += gN.y; mz += gN.z;
 			gx += gNp1.x; gy += gNp1.y; gz += gNp1.z;
 		}
+		mx = wave_sum(mx); my = wave_sum(my); mz = wave_sum(mz);
 		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); dotSum = wave_sum(dotSum);
 		if (lane == 0) {
-			a.newGGam[index] = make_float4(gx, gy, gz, dotSum);
+			const float4 gGamN = a.oldGGam[index];
+			const float dotRest = ((gGamN.x - mx)*dx + (gGamN.y - my)*dy + (gGamN.z - mz)*dz)*inv;      // the elements at rest at step n
+			a.newGGam[index] = make_float4(gx, gy, gz, dotSum + 0.5f*dotRest);
 			if (keep) wall_cache_seal(a.wc, w, posNp1, complete);
 		}
 	}
