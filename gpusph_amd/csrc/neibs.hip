@@ -731,11 +731,10 @@ extern "C" int sphx_build_neibs_sa(sphx_ctx *ctx, uint16_t *neibsList, void *ver
 	// tiles serve sphx_forces_basicstep's pair loop only (SPH_F1, inviscid or Newtonian, DYN / LJ / MK boundaries) and sphx_calc_visc
 	// ... and, with SA_BOUNDARY, the particle <- particle sums of the SA forces, density summation and density diffusion
 	// (one fluid; with k-epsilon the density summation and the diffusion, which do not involve the model: sphx_sa_tiles_run, forces.hip)
-	// (a run with open boundaries goes through the list walkers: its passes carry terms the tiled window does not know, and it
-	// rebuilds the list in every step -- tiles nobody reads are not built)
+	// (a run with open boundaries rebuilds the list in every step; the fluid <- fluid sums of its passes are the solid-wall ones and go
+	// through the tiles since round 6: the tile lists of a rebuild cost a tenth of what its list walkers did per step)
 	const bool tiled_options = ctx->params.sph_formulation == SPHX_SPH_F1 && ctx->params.rheologytype <= SPHX_NEWTONIAN &&
-		(!sa || (ctx->dev.numfluids == 1 && (ctx->dev.turbmodel == SPHX_LAMINAR_FLOW || ctx->dev.turbmodel == SPHX_KEPSILON) &&
-		         !(ctx->params.simflags & SPHX_ENABLE_INLET_OUTLET)));
+		(!sa || (ctx->dev.numfluids == 1 && (ctx->dev.turbmodel == SPHX_LAMINAR_FLOW || ctx->dev.turbmodel == SPHX_KEPSILON)));
 	if (tiled_options && ctx->tiles && !ctx->disable_tiles && tile_cols_fit) {
 		rc = sphx_ensure_tile_lists(ctx);      // first tiled build: the tile lists are allocated now (or never: generic kernels)
 		if (rc != SPHX_OK) return rc;

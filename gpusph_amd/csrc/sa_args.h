@@ -100,8 +100,25 @@ struct SaDensitySumArgs {
 	const float4 *boundElementNew; // ENABLE_MOVING_BODIES (sa_density_sum_kernel<.., true>): BUFFER_BOUNDELEMENTS of the new state
 };
 
+// Brezzi density diffusion with SA_BOUNDARY: see sa_density_diffusion_kernel (sa_bounds.hip)
+struct SaDiffusionArgs {
+	float4 *forces;
+	const float4 *pos, *vel, *gGam;
+	const particleinfo *info;
+	const uint32_t *hash, *cellStart;
+	const neibdata *neibsList;
+	uint32_t numParticles;
+	float dt;
+	const uint32_t *tileGuard;    // stand-by launch behind the tiled kernel (SPHX_TURB_SA_DIFF): only if the tiling overflowed
+	// a run with open boundaries (sa_density_diffusion_kernel<true>): the segments of the pressure-driven faces take part
+	const float4 *boundElement;
+	const float2 *vertPos[3];
+	float deltap;
+};
+
 // sa_wall.hip: the boundary-element terms of the three engines for the particles of ctx->sa_wall
 int sphx_sa_wall_forces(sphx_ctx *ctx, const SaForcesArgs &a, hipStream_t st);
 int sphx_sa_wall_density_sum(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st);
 int sphx_sa_wall_density_sum_moving(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st);   // ... with ENABLE_MOVING_BODIES (fluid rows)
 int sphx_sa_wall_integrate_gamma(sphx_ctx *ctx, const SaIntGammaArgs &a, hipStream_t st);
+int sphx_sa_wall_density_diffusion_open(sphx_ctx *ctx, const SaDiffusionArgs &a, hipStream_t st);   // the open segments' part, added to FORCES.w

@@ -696,20 +696,6 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 	a.newGGam[index] = g;
 }
 
-struct SaDiffusionArgs {
-	float4 *forces;
-	const float4 *pos, *vel, *gGam;
-	const particleinfo *info;
-	const uint32_t *hash, *cellStart;
-	const neibdata *neibsList;
-	uint32_t numParticles;
-	float dt;
-	const uint32_t *tileGuard;    // stand-by launch behind the tiled kernel (SPHX_TURB_SA_DIFF): only if the tiling overflowed
-	// a run with open boundaries (sa_density_diffusion_kernel<true>): the segments of the pressure-driven faces take part
-	const float4 *boundElement;
-	const float2 *vertPos[3];
-	float deltap;
-};
 
 // computeDensityDiffusionDevice<.., BREZZI, SA_BOUNDARY, PT_FLUID> (forces_kernel.def:1766-1783, 4515-4560)
 // OPEN: with ENABLE_INLET_OUTLET the segments of PRESSURE-driven open faces exchange density with the fluid as a fluid neighbour
@@ -1587,6 +1573,22 @@ extern "C" int sphx_sa_compute_density_diffusion_io(sphx_ctx *ctx, void *forces,
 	a.numParticles = particleRangeEnd; a.dt = dt;
 	a.boundElement = (const float4*)boundElements;
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2; a.deltap = deltap;
+	{
+		// the fluid <- fluid sum is the solid-wall one: through the tiled window (SPHX_SA_TILE_DIFF finishes the row: / gamma / rho0);
+		// the segments of the pressure-driven open faces add theirs to it with one element per lane (sa_wall.hip).  Round 6: such a run
+		// rebuilds its lists in every step, and the tile lists of one rebuild cost a tenth of what the list walkers of one step did
+		// (profiles/r06_sa_io_kernel_stats.txt)
+		bool used = false;
+		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_DIFF, forces, pos, vel, nullptr, info, hash, cellStart, neibsList, gGam,
+			numParticles, 0u, particleRangeEnd, dt, (hipStream_t)stream, &used, &a.tileGuard);
+		if (rc != SPHX_OK) return rc;
+		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
+			rc = sphx_sa_wall_density_diffusion_open(ctx, a, (hipStream_t)stream);
+			if (rc != SPHX_OK) return rc;
+			if (!a.tileGuard) return SPHX_OK;      // the host has seen the tiling succeed: no stand-by launch
+		} else
+			a.tileGuard = nullptr;      // (no list of wall particles: the walker is the whole pass, whatever the tiles left in FORCES.w)
+	}
 	sa_density_diffusion_kernel<true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_diffusion_kernel<open>");
 	return SPHX_OK;

@@ -383,6 +383,54 @@ sa_integrate_gamma_wall_kernel(DevParams p, SaIntGammaArgs a, const uint32_t *__
 	}
 }
 
+// Brezzi diffusion in a run with open boundaries (sa_density_diffusion_kernel<true>): what the segments of the pressure-driven open
+// faces exchange with the fluid particles next to them, added to the rows the tiled kernel finished (fluid <- fluid, / gamma / rho0)
+__global__ void __launch_bounds__(SA_WALL_THREADS)
+sa_density_diffusion_open_wall_kernel(DevParams p, SaDiffusionArgs a, const uint32_t *__restrict__ wall)
+{
+	if (a.tileGuard && *a.tileGuard) return;      // no tiles after all: the stand-by launch of the walker is the whole pass
+	SA_WALL_LOOP(wall) {
+		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
+		if (index >= a.numParticles) continue;
+		const float4 pos = a.pos[index], vel = a.vel[index];
+		const uint32_t fl = FLUID_NUM(a.info[index]);
+		const float rho = (vel.w + 1.0f)*p.rho0[fl];
+		const float pres = sa_P(p, vel.w, fl);
+		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
+		float sum = 0.0f;
+		bool any = false;
+		int cellCarry = 0;
+		bool more = true;
+		for (int s0 = 0; more; s0 += 64) {
+			const WallEntry e = wall_chunk(p, a.neibsList, a.cellStart, index, pos, gridPos, s0, lane, cellCarry, more);
+			const uint32_t j = e.j;
+			const particleinfo ninfo = a.info[j];
+			const bool open = e.alive && SA_IS_OPEN(ninfo) && !SA_IS_VELOCITY_DRIVEN(ninfo);
+			if (!__builtin_amdgcn_ballot_w64(open)) continue;      // most particles next to a wall see no open face
+			const float4 npos = a.pos[j];
+			const float rx = e.pcx - npos.x, ry = e.pcy - npos.y, rz = e.pcz - npos.z;
+			const float r = sqrtf(rx*rx + ry*ry + rz*rz);
+			if (!open || !is_active_w(npos.w) || r >= p.influenceradius + a.deltap) continue;
+			any = true;
+			const float4 be = a.boundElement[j];
+			const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
+			const float inv_h = 1.0f/p.slength;
+			WallTri tri;
+			wall_tri_setup(tri, v3(be.x, be.y, be.z), a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
+			const float ggamAS = wall_grad_gamma_flat(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
+			const float nrt = a.vel[j].w;
+			const uint32_t nfl = FLUID_NUM(ninfo);
+			const float neib_rho = (nrt + 1.0f)*p.rho0[nfl];
+			const float gdotr = p.gravity[0]*rx + p.gravity[1]*ry + p.gravity[2]*rz;
+			const double t = ((2.0/(rho + neib_rho))*(pres - sa_P(p, nrt, nfl)) - gdotr)*ggamAS/r_as*a.dt*2.0f*rho;
+			sum -= (float)t;
+		}
+		if (!__builtin_amdgcn_ballot_w64(any)) continue;
+		sum = wave_sum(sum);
+		if (lane == 0) a.forces[index].w += (sum/a.gGam[index].w)/p.rho0[fl];
+	}
+}
+
 // a grid that fills the device with waves; each takes every (number of waves)-th wall particle
 static uint32_t sa_wall_grid(const sphx_ctx *ctx) { return ctx->tile_grid*8u; }
 
@@ -408,6 +456,12 @@ int sphx_sa_wall_density_sum_moving(sphx_ctx *ctx, const SaDensitySumArgs &a, hi
 		sa_density_sum_wall_moving_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, av, ctx->sa_wall_vert);
 		SPHX_LAUNCH_CHECK("sa_density_sum_wall_moving_kernel<vertices>");
 	}
+	return SPHX_OK;
+}
+int sphx_sa_wall_density_diffusion_open(sphx_ctx *ctx, const SaDiffusionArgs &a, hipStream_t st)
+{
+	sa_density_diffusion_open_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	SPHX_LAUNCH_CHECK("sa_density_diffusion_open_wall_kernel");
 	return SPHX_OK;
 }
 int sphx_sa_wall_integrate_gamma(sphx_ctx *ctx, const SaIntGammaArgs &a, hipStream_t st)

@@ -17,6 +17,7 @@ int sphx_sa_tiles_run(sphx_ctx *, int, void *, const void *, const void *, const
 int sphx_sa_wall_forces(sphx_ctx *, const SaForcesArgs &, hipStream_t) { return SPHX_OK; }
 int sphx_sa_wall_density_sum(sphx_ctx *, const SaDensitySumArgs &, hipStream_t) { return SPHX_OK; }
 int sphx_sa_wall_density_sum_moving(sphx_ctx *, const SaDensitySumArgs &, hipStream_t) { return SPHX_OK; }
+int sphx_sa_wall_density_diffusion_open(sphx_ctx *, const SaDiffusionArgs &, hipStream_t) { return SPHX_OK; }
 int sphx_sa_wall_integrate_gamma(sphx_ctx *, const SaIntGammaArgs &, hipStream_t) { return SPHX_OK; }
 
 // the list build (neibs_build.hip: build_neibs_kernel with the prepass on the matrix cores, the v_mfma / v_permlane32_swap /
