@@ -65,6 +65,7 @@ struct SaForcesArgs {
 	const uint32_t *tileGuard;
 	int wallDone;         // ... and sa_forces_wall_kernel has added the boundary elements (needs `tiled`)
 	SaWallCache wc;
+	int open;             // a run with open boundaries (sa_forces_kernel<., true>): sa_forces_wall_kernel adds the OPEN terms as well
 };
 
 // integrateGammaDevice, quadrature flavour: see sa_integrate_gamma_kernel (sa_bounds.hip)

@@ -1548,6 +1548,22 @@ extern "C" int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *c
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList;
 	a.fromParticle = fromParticle; a.toParticle = toParticle; a.cflOffset = cflOffset; a.deltap = deltap;
+	{
+		// round 6: the particle <- particle sums through the tiled window as for solid walls, the boundary elements with one element
+		// per lane; what an open boundary adds -- the Eulerian velocities in the viscous terms of vertices and elements, the second
+		// gamma CFL term -- rides with the latter (sa_forces_wall_kernel, a.open); this kernel then only finishes the rows
+		bool used = false;
+		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_FORCES, forces, pos, vel, nullptr, info, hash, cellStart, neibsList, gGam,
+			numParticles, fromParticle, toParticle, 0.0f, (hipStream_t)stream, &used, &a.tileGuard);
+		if (rc != SPHX_OK) return rc;
+		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
+			a.tiled = 1; a.wallDone = 1; a.open = 1;
+			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
+			rc = sphx_sa_wall_forces(ctx, a, (hipStream_t)stream);
+			if (rc != SPHX_OK) return rc;
+		} else
+			a.tileGuard = nullptr;      // (no list of wall particles: the walker is the whole pass)
+	}
 	sa_forces_kernel<false, true><<<numBlocks, SPHX_BLOCK_FORCES, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_forces_kernel<open>");
 	return SPHX_OK;

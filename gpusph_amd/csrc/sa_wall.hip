@@ -5,6 +5,7 @@
 #include "sphx_internal.h"
 #include "neib_iter.h"
 #include "sa_args.h"
+#include "wave_list.h"
 
 // atan2 for the edge integrals: quotient by reciprocal + one correction step, arctangent on [0, 1] as t + t s q(s), s = t^2, q
 // fitted here (minimax of the error of atan(t)/t, degree 9: 0.8 ulp on [0, 1]; the whole function stays within 1.8 ulp of the
@@ -133,6 +134,12 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 		const float p_precalc = sa_P(p, vel.w, fl)/(p_rho*p_rho);
 		const bool density_sum = (p.simflags & SPHX_ENABLE_DENSITY_SUM) != 0;
 		const bool newtonian = p.rheology == SPHX_NEWTONIAN;
+		// a.open: a run with open boundaries (sa_forces_kernel<false, true>, see there): the viscous term of a boundary element sees the
+		// relative velocity plus the relative Eulerian velocity (no normal part taken out for the segment of an open face), the gamma CFL
+		// term gains compute_gamma_cfl_open_boundary, and the fluid <- vertex pairs, whose sums the tiled kernel formed with the relative
+		// velocity alone, get the Eulerian part of their viscous term here (below)
+		const bool open = a.open != 0;
+		const float4 p_euler = open ? a.eulerVel[index] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 		float fx = 0.0f, fy = 0.0f, fz = 0.0f, fw = 0.0f, gammaCfl = 0.0f;
 		// |grad gamma_as| of this particle's elements as the previous pass left them, if they were evaluated at this very position
 		const bool kept = __builtin_amdgcn_readfirstlane((int)wall_cache_valid(a.wc, w, pos)) != 0;
@@ -161,17 +168,30 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 				ggamAS = wall_grad_gamma_flat(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
 			}
 			const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
+			float4 ne = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+			if (open) ne = a.eulerVel[j];
 			if (a.cflGamma) {
 				const float va = sa_dot3(vel.x, vel.y, vel.z, be.x, be.y, be.z);
 				const float vs = sa_dot3(vel.x - vx, vel.y - vy, vel.z - vz, be.x, be.y, be.z);
 				gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(vn), fmaxf(fabsf(va), fabsf(vs))));
+				if (open) {      // n.(v_a + relEulerVel), n.(v_s - relEulerVel)
+					const float ex = (vx + (p_euler.x - ne.x)) - vx, ey = (vy + (p_euler.y - ne.y)) - vy, ez = (vz + (p_euler.z - ne.z)) - vz;
+					const float a1 = sa_dot3(vel.x + ex, vel.y + ey, vel.z + ez, be.x, be.y, be.z);
+					const float a2 = sa_dot3(-vx + vel.x - ex, -vy + vel.y - ey, -vz + vel.z - ez, be.x, be.y, be.z);
+					gammaCfl = fmaxf(gammaCfl, ggamAS*fmaxf(fabsf(a1), fabsf(a2)));
+				}
 			}
 			if (!density_sum) fw -= p_rho*vn*ggamAS;
 			const float ps = (p_precalc + n_precalc)*n_rho*ggamAS;
 			float dx = ps*be.x, dy = ps*be.y, dz = ps*be.z;
 			if (newtonian) {
 				const float r_as = fmaxf(fabsf(sa_dot3(rx, ry, rz, be.x, be.y, be.z)), a.deltap);
-				const float tx = vx - vn*be.x, ty = vy - vn*be.y, tz = vz - vn*be.z;
+				float tx = vx - vn*be.x, ty = vy - vn*be.y, tz = vz - vn*be.z;
+				if (open) {
+					const float wx = vx + (p_euler.x - ne.x), wy = vy + (p_euler.y - ne.y), wz = vz + (p_euler.z - ne.z);
+					const float wn = SA_IS_OPEN(a.info[j]) ? 0.0f : sa_dot3(wx, wy, wz, be.x, be.y, be.z);
+					tx = wx - wn*be.x; ty = wy - wn*be.y; tz = wz - wn*be.z;
+				}
 				const float our_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[fl]*p_rho : p.visccoeff[fl];
 				const float neib_mu = (p.compvisc == SPHX_KINEMATIC) ? p.visccoeff[nfl]*n_rho : p.visccoeff[nfl];
 				const float avg = (p.avgop == SPHX_ARITHMETIC) ? (our_mu + neib_mu)*0.5f :
@@ -181,6 +201,29 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 				dx -= (c*tx)*inv_rho; dy -= (c*ty)*inv_rho; dz -= (c*tz)*inv_rho;
 			}
 			fx += dx; fy += dy; fz += dz;
+		}
+		if (open && newtonian) {      // fluid <- vertex: the Eulerian part of the laminar term, vf (u_a^E - u_b^E) (get_viscous_relVel)
+			int carry = 0;
+			bool moreV = true;
+			for (int s0 = 0; moreV; s0 += 64) {
+				const WaveEntry e = wave_entries<WAVE_SECTION_VERTEX>(p, a.neibsList, a.cellStart, index, pos, gridPos, s0, lane, carry, moreV);
+				const uint32_t j = e.j;
+				const float4 ne = a.eulerVel[j];
+				const float ex = p_euler.x - ne.x, ey = p_euler.y - ne.y, ez = p_euler.z - ne.z;
+				const bool has = e.live && (ex != 0.0f || ey != 0.0f || ez != 0.0f);
+				if (!__builtin_amdgcn_ballot_w64(has)) continue;      // vertices of walls: no Eulerian velocity on either side
+				const float4 npos = a.pos[j];
+				const float rx = e.ox - npos.x, ry = e.oy - npos.y, rz = e.oz - npos.z;
+				const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
+				if (!has || !is_active_w(npos.w) || r >= p.influenceradius) continue;
+				const float4 nvel = a.vel[j];
+				const uint32_t nfl = FLUID_NUM(a.info[j]);
+				const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+				const float qm2 = r/p.slength - 2.0f;
+				const float f = qm2*qm2*qm2*p.fcoeff;
+				const float vf = sa_visc_avg(p, p.visccoeff[fl], p.visccoeff[nfl], p_rho, n_rho, npos.w)*f;
+				fx += vf*ex; fy += vf*ey; fz += vf*ez;
+			}
 		}
 		fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz); fw = wave_sum(fw); gammaCfl = wave_max(gammaCfl);
 		if (lane == 0) {
