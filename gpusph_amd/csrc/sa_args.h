@@ -9,6 +9,9 @@ struct SaWallCache {
 	float *values;        // [wall particle][SA_WALL_CACHE_ENTRIES]
 	float4 *tag;          // per wall particle: position bits of the particle when its row was written, generation of the list
 	uint32_t capacity, gen;
+	// a run with open boundaries: sum_s grad gamma_as of the particle's elements as the forces pass of step n evaluated it, for the
+	// density summations of the step (both start from the positions of step n): [2 w] = {sum, generation}, [2 w + 1] = position bits
+	float4 *gsum;
 };
 
 // open boundaries of a run with ENABLE_INLET_OUTLET: flags of particleinfo.x (src/particleinfo.h:153-156, 222-241)

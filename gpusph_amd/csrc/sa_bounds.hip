@@ -643,6 +643,9 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 		if (a.neibsList[(size_t)p.neibboundpos*p.stride + index] != NEIBS_END && is_active_w(posN.w)) {
 			const float4 t = a.newGGam[index];
 			gGam = v3(t.x, t.y, t.z); gGamDotR = t.w;
+			// sa_density_sum_wall_kernel<true>: half the sum of the two fluxes of gamma through the open segments, left where the new
+			// density is about to be written
+			if (OPEN && !MOVING) gamFluxMoved = 2.0f*a.newVel[index].w;
 		}
 	} else
 	for_each_neib<PT_BOUNDARY, true>(p, w, index, posN, gridPos, [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
@@ -1475,7 +1478,6 @@ extern "C" int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam
 	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream)
 {
-	(void)numParticles;
 	int rc = sa_open_check(ctx, "density_sum called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	SPHX_REQUIRE(newVel && newGGam && forces && oldPos && newPos && oldVel && oldEulerVel && oldGGam && boundElements && vertPos0 && vertPos1 &&
@@ -1488,6 +1490,25 @@ extern "C" int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
 	a.oldEulerVel = (const float4*)oldEulerVel; a.dt = dt;
+	if (newVel != oldVel) {
+		// round 6: the particle <- particle sums through the tiled window as for solid walls (an open vertex summed like any vertex),
+		// the boundary elements with one element per lane; what the open faces change -- the flux of gamma through their segments,
+		// the virtual displacement of their vertices -- rides with the latter (sa_density_sum_wall_kernel<true>, sa_wall.hip), which
+		// hands the flux over in newVel.w (hence two buffers).  The one-thread kernel was 49 % of a step of the SAChannelIO mirror at
+		// 8.6 M particles (profiles/r06_sa_io_kernel_stats.txt)
+		bool used = false;
+		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_DSUM, forces, oldPos, nullptr, newPos, info, hash, cellStart, neibsList, nullptr,
+			numParticles, 0u, particleRangeEnd, 0.0f, (hipStream_t)stream, &used, &a.tileGuard);
+		if (rc != SPHX_OK) return rc;
+		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
+			a.tiled = 1; a.wallDone = 1;
+			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
+			a.wc.gsum = ctx->sa_wall_gsum;
+			rc = sphx_sa_wall_density_sum(ctx, a, (hipStream_t)stream);
+			if (rc != SPHX_OK) return rc;
+		} else
+			a.tileGuard = nullptr;      // (no list of wall particles: the walker is the whole pass, whatever the tiles left in FORCES.w)
+	}
 	sa_density_sum_kernel<true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_kernel<open>");
 	return SPHX_OK;
@@ -1559,6 +1580,19 @@ extern "C" int sphx_forces_basicstep_sa_io(sphx_ctx *ctx, void *forces, float *c
 		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
 			a.tiled = 1; a.wallDone = 1; a.open = 1;
 			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
+			// (the sum of grad gamma_as at step n for the density summations of this step -- not with moving bodies, whose elements are
+			// elsewhere when those run)
+			if (!(ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES)) {
+				if (!ctx->sa_wall_gsum && ctx->sa_wall_capacity) {      // two rows per wall particle that has rows of |grad gamma_as|
+					if (hipMalloc((void**)&ctx->sa_wall_gsum, sizeof(float4)*2u*ctx->sa_wall_capacity) == hipSuccess)
+						SPHX_HIP(hipMemsetAsync(ctx->sa_wall_gsum, 0, sizeof(float4)*2u*ctx->sa_wall_capacity, (hipStream_t)stream));
+					else {
+						(void)hipGetLastError();
+						ctx->sa_wall_gsum = nullptr;      // the density summations evaluate the elements at step n themselves
+					}
+				}
+				a.wc.gsum = ctx->sa_wall_gsum;
+			}
 			rc = sphx_sa_wall_forces(ctx, a, (hipStream_t)stream);
 			if (rc != SPHX_OK) return rc;
 		} else

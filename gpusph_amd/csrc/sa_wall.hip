@@ -119,6 +119,28 @@ __device__ __forceinline__ bool wall_cache_valid(const SaWallCache &wc, uint32_t
 		__float_as_uint(t.z) == __float_as_uint(pos.z) && __float_as_uint(t.w) == wc.gen;
 }
 
+// sum_s grad gamma_as of a wall particle's elements at step n (SaWallCache::gsum): left by the forces pass of a run with open
+// boundaries when it evaluates the elements afresh (the first pass of a step, right after the rebuild such a run does in every
+// step), taken by the two density summations of that step -- both integrate gamma from the positions of step n, so the step-n
+// half of their sum 1/2 (grad gamma_as(n) + grad gamma_as(n+1)) . dq is 1/2 (this sum) . dq for walls at rest, and the elements
+// are evaluated once per pass instead of twice.  sa_density_sum_wall_kernel<false> takes that sum from BUFFER_GRADGAMMA; with open
+// boundaries the rows of the particles an open vertex released in the previous step hold the VERTEX's gradient instead (the
+// reference copies it, vertex rows of sa_io.hip), so the stored row is not trusted there.  Tag: position bits and list generation,
+// as for the rows of |grad gamma_as|; no match (another list, the forces pass skipped or served from kept rows): two evaluations.
+__device__ __forceinline__ void wall_gsum_put(const SaWallCache &wc, uint32_t w, const float4 &pos, float gx, float gy, float gz)
+{
+	wc.gsum[2u*w] = make_float4(gx, gy, gz, __uint_as_float(wc.gen));
+	wc.gsum[2u*w + 1u] = make_float4(pos.x, pos.y, pos.z, 0.0f);
+}
+__device__ __forceinline__ bool wall_gsum_get(const SaWallCache &wc, uint32_t w, const float4 &pos, float4 &sum)
+{
+	if (wc.gsum == nullptr || w >= wc.capacity || !wc.gen) return false;
+	sum = wc.gsum[2u*w];
+	const float4 t = wc.gsum[2u*w + 1u];
+	return __float_as_uint(sum.w) == wc.gen && __float_as_uint(t.x) == __float_as_uint(pos.x) &&
+		__float_as_uint(t.y) == __float_as_uint(pos.y) && __float_as_uint(t.z) == __float_as_uint(pos.z);
+}
+
 // the fluid <- boundary-element part of sa_forces_kernel<false> (same terms, see there), added to the sums the tiled kernel left
 __global__ void __launch_bounds__(SA_WALL_THREADS)
 sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ wall)
@@ -143,6 +165,9 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 		float fx = 0.0f, fy = 0.0f, fz = 0.0f, fw = 0.0f, gammaCfl = 0.0f;
 		// |grad gamma_as| of this particle's elements as the previous pass left them, if they were evaluated at this very position
 		const bool kept = __builtin_amdgcn_readfirstlane((int)wall_cache_valid(a.wc, w, pos)) != 0;
+		// an open run, elements evaluated here: their sum for the density summations of this step (wall_gsum_put)
+		const bool leaveSum = open && !kept && a.wc.gsum != nullptr && w < a.wc.capacity;
+		float sgx = 0.0f, sgy = 0.0f, sgz = 0.0f;
 		int cellCarry = 0;
 		bool more = true;
 		for (int s0 = 0; more; s0 += 64) {
@@ -151,12 +176,10 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 			const float4 npos = a.pos[j];
 			const float rx = e.pcx - npos.x, ry = e.pcy - npos.y, rz = e.pcz - npos.z;
 			const float r = sqrtf(fmaf(rz, rz, fmaf(ry, ry, rx*rx)));
-			if (!e.alive || !is_active_w(npos.w) || r >= p.influenceradius + a.deltap) continue;
-			const float4 nvel = a.vel[j];
-			const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
-			const uint32_t nfl = FLUID_NUM(a.info[j]);
-			const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
-			const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
+			// (the density summation has no cut at this distance: an element behind it whose corners reach into the support all the
+			// same -- a wall meshed coarser than the particle spacing -- is in ITS sum, so it is in the sum left for it)
+			const bool inReach = r < p.influenceradius + a.deltap;
+			if (!e.alive || !is_active_w(npos.w) || (!inReach && !leaveSum)) continue;
 			const float4 be = a.boundElement[j];
 			float ggamAS;
 			if (kept)
@@ -167,6 +190,13 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 				wall_tri_setup(tri, v3(be.x, be.y, be.z), a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
 				ggamAS = wall_grad_gamma_flat(tri, v3(rx*inv_h, ry*inv_h, rz*inv_h))/p.slength;
 			}
+			if (leaveSum) { sgx = fmaf(ggamAS, be.x, sgx); sgy = fmaf(ggamAS, be.y, sgy); sgz = fmaf(ggamAS, be.z, sgz); }
+			if (!inReach) continue;
+			const float4 nvel = a.vel[j];
+			const float vx = vel.x - nvel.x, vy = vel.y - nvel.y, vz = vel.z - nvel.z;
+			const uint32_t nfl = FLUID_NUM(a.info[j]);
+			const float n_rho = (nvel.w + 1.0f)*p.rho0[nfl];
+			const float n_precalc = sa_P(p, nvel.w, nfl)/(n_rho*n_rho);
 			const float vn = sa_dot3(vx, vy, vz, be.x, be.y, be.z);
 			float4 ne = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 			if (open) ne = a.eulerVel[j];
@@ -226,6 +256,10 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 			}
 		}
 		fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz); fw = wave_sum(fw); gammaCfl = wave_max(gammaCfl);
+		if (leaveSum) {
+			sgx = wave_sum(sgx); sgy = wave_sum(sgy); sgz = wave_sum(sgz);
+			if (lane == 0) wall_gsum_put(a.wc, w, pos, sgx, sgy, sgz);
+		}
 		if (lane == 0) {
 			float4 f = a.forces[index];
 			f.x += fx; f.y += fy; f.z += fz; f.w += fw;
@@ -249,6 +283,16 @@ sa_forces_wall_kernel(DevParams p, SaForcesArgs a, const uint32_t *__restrict__ 
 // section is built out to boundNlSqInflRad >= the support).  So the assumption is the validity of the neighbour list itself,
 // which every sum of this engine already needs.  Held by tests/test_gpu_sa.py (this kernel against the one-thread kernel over
 // 12 sloshing steps across a rebuild) and by the two-rank run test_two_ranks_on_one_gpu_equal_single_domain[sa-walls-tiled] of tests/test_gpu_parity.py.
+// OPEN: a run with open boundaries (sa_density_sum_kernel<true>, density_sum_kernel.cu:119-140,374-417).  Three things on top:
+//  * the step-n sum is the one the forces pass of this step left (wall_gsum_get), not BUFFER_GRADGAMMA's; no such row: the elements
+//    are evaluated at step n as well, as the one-thread kernel does;
+//  * a segment of an open face adds the flux of gamma through it -- the virtual displacement dt (u_E - u) against grad gamma_as at
+//    step n and at the displaced point -- to the gamma that multiplies the old density: the half sum goes to the particle's row
+//    of newVel.w, where sa_density_sum_kernel<true> picks it up before it writes the new density there;
+//  * a vertex of an open face is not a reservoir of mass at rest: the tiled kernel has summed -m W(r_n) for it as for any
+//    neighbour; that term is taken back here and the kernel at the distance after the virtual displacement put in its place
+//    (FORCES.w, which holds the tiled sums).
+template<bool OPEN>
 __global__ void __launch_bounds__(SA_WALL_THREADS)
 sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__restrict__ wall)
 {
@@ -259,9 +303,13 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 		const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
 		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
-		const float4 gGamN = a.oldGGam[index];
+		float4 gGamN = a.oldGGam[index];
+		bool haveN = true;
+		if (OPEN) haveN = __builtin_amdgcn_readfirstlane((int)wall_gsum_get(a.wc, w, posN, gGamN)) != 0;
 		const float inv = 1.0f/p.slength;
 		float gx = 0.0f, gy = 0.0f, gz = 0.0f, dotNp1 = 0.0f;
+		float nx = 0.0f, ny = 0.0f, nz = 0.0f, flux = 0.0f;
+		bool anyOpen = false;
 		const bool keep = wall_cache_row(a.wc, w);
 		bool complete = true;
 		int cellCarry = 0;
@@ -284,12 +332,54 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 			const V3 gNp1 = ns*ggamAS;
 			dotNp1 += dot(gNp1, qNp1 - qN);
 			gx += gNp1.x; gy += gNp1.y; gz += gNp1.z;
+			if (OPEN) {
+				const bool openSeg = SA_IS_OPEN(a.info[j]);
+				if (!haveN || openSeg) {
+					const float ggamN = wall_grad_gamma_flat(tri, qN)/p.slength;
+					if (!haveN) { nx = fmaf(ggamN, ns.x, nx); ny = fmaf(ggamN, ns.y, ny); nz = fmaf(ggamN, ns.z, nz); }
+					if (openSeg) {
+						const float4 ev = a.oldEulerVel[j], v = a.oldVel[j];
+						const V3 drift = v3(a.dt*(ev.x - v.x), a.dt*(ev.y - v.y), a.dt*(ev.z - v.z));
+						const float ggamMoved = wall_grad_gamma_flat(tri, qN + drift*inv)/p.slength;
+						flux += 0.5f*dot(drift, ns)*(ggamMoved + ggamN);
+						anyOpen = true;
+					}
+				}
+			}
+		}
+		float corr = 0.0f;
+		if (OPEN) {      // the open vertices among the neighbours
+			int carry = 0;
+			bool moreV = true;
+			for (int s0 = 0; moreV; s0 += 64) {
+				const WaveEntry e = wave_entries<WAVE_SECTION_VERTEX>(p, a.neibsList, a.cellStart, index, posN, gridPos, s0, lane, carry, moreV);
+				const uint32_t j = e.j;
+				const bool openV = e.live && SA_IS_OPEN(a.info[j]);
+				if (!__builtin_amdgcn_ballot_w64(openV)) continue;
+				const float4 nN = a.oldPos[j];
+				if (!openV || !is_active_w(nN.w)) continue;
+				anyOpen = true;
+				const float rx = e.ox - nN.x, ry = e.oy - nN.y, rz = e.oz - nN.z;
+				const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+				corr += nN.w*kernel_W<SPHX_WENDLAND>(p, rN);
+				const float4 ev = a.oldEulerVel[j], v = a.oldVel[j];
+				const float ex = rx + a.dt*(ev.x - v.x), ey = ry + a.dt*(ev.y - v.y), ez = rz + a.dt*(ev.z - v.z);
+				const float moved = sqrtf(ex*ex + ey*ey + ez*ez);
+				if (moved < p.influenceradius) corr -= nN.w*kernel_W<SPHX_WENDLAND>(p, moved);
+			}
+			anyOpen = __builtin_amdgcn_ballot_w64(anyOpen) != 0;
 		}
 		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); dotNp1 = wave_sum(dotNp1);
+		if (OPEN && !haveN) { gGamN.x = wave_sum(nx); gGamN.y = wave_sum(ny); gGamN.z = wave_sum(nz); }
+		if (OPEN && anyOpen) { flux = wave_sum(flux); corr = wave_sum(corr); }
 		if (lane == 0) {
 			const float dotN = (gGamN.x*dx + gGamN.y*dy + gGamN.z*dz)*inv;
 			a.newGGam[index] = make_float4(gx, gy, gz, 0.5f*(dotN + dotNp1));
 			if (keep) wall_cache_seal(a.wc, w, posNp1, complete);
+			if (OPEN) {
+				a.newVel[index].w = anyOpen ? flux : 0.0f;
+				if (anyOpen) a.forces[index].w += corr;
+			}
 		}
 	}
 }
@@ -485,7 +575,8 @@ int sphx_sa_wall_forces(sphx_ctx *ctx, const SaForcesArgs &a, hipStream_t st)
 }
 int sphx_sa_wall_density_sum(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st)
 {
-	sa_density_sum_wall_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	if (a.oldEulerVel) sa_density_sum_wall_kernel<true><<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	else sa_density_sum_wall_kernel<false><<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
 	SPHX_LAUNCH_CHECK("sa_density_sum_wall_kernel");
 	return SPHX_OK;
 }

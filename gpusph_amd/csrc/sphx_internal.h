@@ -221,6 +221,9 @@ struct sphx_ctx {
 	float      *sa_wall_cache;
 	float4     *sa_wall_tag;
 	uint32_t    sa_wall_capacity, sa_wall_gen;
+	// a run with open boundaries: two rows per wall particle, {sum_s grad gamma_as at step n, list generation} and the position
+	// bits it was summed at -- from the forces pass of a step to its density summations (SaWallCache::gsum)
+	float4     *sa_wall_gsum;
 	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
 	// The EOS rows of the forces engine (eos_aux) written by the Euler step that writes the densities they are made of
 	// (sphx_eos_rows_follow_euler): eos_tag_* = the velocity buffer and the row count of that step; eos_armed = the caller has

@@ -241,7 +241,7 @@ def test_density_summation_and_forces_with_open_boundaries():
                                           P(eng.neibslist), n, n, float(np.float32(dt)), None))
     assert np.abs(_np(d_f)[:n][fl, 3] - want_s[fl]).max() < 2e-5 * np.abs(want_s[fl]).max() + 1e-3
     assert_close_but_for_gamma_spikes(_np(d_nv)[:n][fl, 3], want_v[fl, 3], 2e-6, 1.0, what="density after the summation", wall=wall[fl])
-    assert_close_but_for_gamma_spikes(_np(d_ng)[:n][fl], want_g[fl], 2e-5, np.abs(want_g[fl, :3]).max(), what="gamma after the summation", wall=wall[fl])
+    assert_close_but_for_gamma_spikes(_np(d_ng)[:n][fl], want_g[fl], 2e-5, np.abs(want_g[fl, :3]).max(), what="gamma after the summation", wall=wall[fl], frac=0.04)      # measured 0.027 (as with moving bodies, tests/test_gpu_sa_moving.py)
     # forces
     want_f, want_cfl, nb = o.forces_sa_io(st["pos"], vel, ev, info, st["hash"], st["cs"], st["nl"], gg, be, st["vertpos"], n, dp)
     d_forces = torch.zeros_like(eng.pos)
@@ -257,6 +257,18 @@ def test_density_summation_and_forces_with_open_boundaries():
     scale = np.abs(want_f[fl, :3]).max()
     assert_close_but_for_gamma_spikes(_np(d_forces)[:n][fl, :3], want_f[fl, :3], 1e-4, scale, what="forces with open boundaries", wall=wall[fl])
     assert np.abs(_np(d_cfl)[:nb] - want_cfl[:nb]).max() < 1e-4 * np.abs(want_cfl[:nb]).max()
+    # the density summation once more, now behind a forces pass at the positions of step n as in a step of a run: the step-n sum of
+    # grad gamma_as comes from that pass (one evaluation per element instead of two, sa_density_sum_wall_kernel<true>); same answer
+    first_v, first_g, first_s = _np(d_nv)[:n].copy(), _np(d_ng)[:n].copy(), _np(d_f)[:n].copy()
+    d_nv, d_ng, d_f = d_vel.clone(), torch.zeros_like(eng.gradgamma), torch.zeros_like(eng.pos)
+    capi.check(lib.sphx_sa_density_sum_io(h, P(d_nv), P(d_ng), P(d_f), P(eng.pos), P(d_new), P(d_vel), P(d_ev), P(d_gg), P(d_be),
+                                          P(eng.vertpos[0]), P(eng.vertpos[1]), P(eng.vertpos[2]), P(d_info), P(eng.hash), P(eng.cellStart),
+                                          P(eng.neibslist), n, n, float(np.float32(dt)), None))
+    assert np.abs(_np(d_f)[:n][fl, 3] - want_s[fl]).max() < 2e-5 * np.abs(want_s[fl]).max() + 1e-3
+    assert_close_but_for_gamma_spikes(_np(d_nv)[:n][fl, 3], want_v[fl, 3], 2e-6, 1.0, what="density after the summation (behind the forces)", wall=wall[fl])
+    assert_close_but_for_gamma_spikes(_np(d_ng)[:n][fl], want_g[fl], 2e-5, np.abs(want_g[fl, :3]).max(), what="gamma after the summation (behind the forces)", wall=wall[fl], frac=0.04)
+    assert np.array_equal(_np(d_f)[:n][fl, 3], first_s[fl, 3]) and np.array_equal(_np(d_ng)[:n][fl, :3], first_g[fl, :3])
+    assert np.abs(_np(d_ng)[:n][fl, 3] - first_g[fl, 3]).max() < 2e-6 and np.abs(_np(d_nv)[:n][fl, 3] - first_v[fl, 3]).max() < 2e-6
 
 
 def test_brezzi_diffusion_and_water_depth_with_open_boundaries():
