@@ -101,6 +101,7 @@ struct SaDensitySumArgs {
 	SaWallCache wc;
 	const float4 *oldEulerVel;    // a run with open boundaries (sa_density_sum_kernel<true>)
 	float dt;
+	uint32_t *openList;           // ... sa_density_sum_wall_kernel<true> appends the particles with an open segment in reach ([0] = count)
 	const float4 *boundElementNew; // ENABLE_MOVING_BODIES (sa_density_sum_kernel<.., true>): BUFFER_BOUNDELEMENTS of the new state
 };
 

@@ -1504,8 +1504,20 @@ extern "C" int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam
 			a.tiled = 1; a.wallDone = 1;
 			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
 			a.wc.gsum = ctx->sa_wall_gsum;
+			ctx->sa_wall_open_neibslist = nullptr;
+			if (!ctx->sa_wall_open && hipMalloc((void**)&ctx->sa_wall_open, sizeof(uint32_t)*((size_t)ctx->reserved_particles + 1)) != hipSuccess) {
+				(void)hipGetLastError();
+				ctx->sa_wall_open = nullptr;      // the diffusion goes through every wall particle then
+			}
+			if (ctx->sa_wall_open) {
+				SPHX_HIP(hipMemsetAsync(ctx->sa_wall_open, 0, sizeof(uint32_t), (hipStream_t)stream));
+				a.openList = ctx->sa_wall_open;
+			}
 			rc = sphx_sa_wall_density_sum(ctx, a, (hipStream_t)stream);
 			if (rc != SPHX_OK) return rc;
+			if (ctx->sa_wall_open && particleRangeEnd == numParticles) {      // (a pass over a part of the particles leaves a part of the list)
+				ctx->sa_wall_open_neibslist = neibsList; ctx->sa_wall_open_gen = ctx->sa_wall_gen;
+			}
 		} else
 			a.tileGuard = nullptr;      // (no list of wall particles: the walker is the whole pass, whatever the tiles left in FORCES.w)
 	}

@@ -224,6 +224,11 @@ struct sphx_ctx {
 	// a run with open boundaries: two rows per wall particle, {sum_s grad gamma_as at step n, list generation} and the position
 	// bits it was summed at -- from the forces pass of a step to its density summations (SaWallCache::gsum)
 	float4     *sa_wall_gsum;
+	// ... and the wall particles that have a segment of an OPEN face in reach ([0] = number of, [1..]; any order), left by the density
+	// summation of such a run for the Brezzi diffusion that follows it on the same list (only those exchange density with a face)
+	uint32_t   *sa_wall_open;
+	const void *sa_wall_open_neibslist;
+	uint32_t    sa_wall_open_gen;
 	uint32_t    tile_grid;     // persistent grid size: 2 workgroups per CU
 	// The EOS rows of the forces engine (eos_aux) written by the Euler step that writes the densities they are made of
 	// (sphx_eos_rows_follow_euler): eos_tag_* = the velocity buffer and the row count of that step; eos_armed = the caller has
