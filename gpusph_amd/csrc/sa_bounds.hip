@@ -645,7 +645,7 @@ sa_density_sum_kernel(DevParams p, SaDensitySumArgs a)
 			gGam = v3(t.x, t.y, t.z); gGamDotR = t.w;
 			// sa_density_sum_wall_kernel<true>: half the sum of the two fluxes of gamma through the open segments, left where the new
 			// density is about to be written
-			if (OPEN && !MOVING) gamFluxMoved = 2.0f*a.newVel[index].w;
+			if (OPEN && !vertexRow) gamFluxMoved = 2.0f*a.newVel[index].w;
 		}
 	} else
 	for_each_neib<PT_BOUNDARY, true>(p, w, index, posN, gridPos, [&](uint32_t j, const float4 &nN, float pcx, float pcy, float pcz) {
@@ -1536,7 +1536,6 @@ extern "C" int sphx_sa_density_sum_io_moving(sphx_ctx *ctx, void *newVel, void *
 	const uint32_t *hash, const uint32_t *cellStart, const uint16_t *neibsList,
 	uint32_t numParticles, uint32_t particleRangeEnd, float dt, void *stream)
 {
-	(void)numParticles;
 	int rc = sa_open_check(ctx, "density_sum called without SA_BOUNDARY");
 	if (rc != SPHX_OK) return rc;
 	if (!(ctx->params.simflags & SPHX_ENABLE_MOVING_BODIES) || !(ctx->params.simflags & SPHX_ENABLE_INLET_OUTLET))
@@ -1552,6 +1551,34 @@ extern "C" int sphx_sa_density_sum_io_moving(sphx_ctx *ctx, void *newVel, void *
 	a.vertPos[0] = (const float2*)vertPos0; a.vertPos[1] = (const float2*)vertPos1; a.vertPos[2] = (const float2*)vertPos2;
 	a.info = (const particleinfo*)info; a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
 	a.oldEulerVel = (const float4*)oldEulerVel; a.dt = dt;
+	if (newVel != oldVel) {
+		// round 6: as sphx_sa_density_sum_io and sphx_sa_density_sum_moving -- the particle <- particle sums through the tiled window, the
+		// boundary-element terms of the fluid rows (with the open faces' terms) and of the vertex rows with one element per lane
+		// (sa_density_sum_wall_moving_kernel<true>); the flux of gamma rides in newVel.w, hence two buffers
+		bool used = false;
+		rc = sphx_sa_tiles_run(ctx, SPHX_SA_TILE_DSUM, forces, oldPos, nullptr, newPos, info, hash, cellStart, neibsList, nullptr,
+			numParticles, 0u, particleRangeEnd, 0.0f, (hipStream_t)stream, &used, &a.tileGuard);
+		if (rc != SPHX_OK) return rc;
+		if (used && ctx->sa_wall && ctx->sa_wall_neibslist == neibsList) {
+			a.tiled = 1; a.wallDone = ctx->sa_wall_vert ? 3 : 1;
+			a.wc.values = ctx->sa_wall_cache; a.wc.tag = ctx->sa_wall_tag; a.wc.capacity = ctx->sa_wall_capacity; a.wc.gen = ctx->sa_wall_gen;
+			ctx->sa_wall_open_neibslist = nullptr;
+			if (!ctx->sa_wall_open && hipMalloc((void**)&ctx->sa_wall_open, sizeof(uint32_t)*((size_t)ctx->reserved_particles + 1)) != hipSuccess) {
+				(void)hipGetLastError();
+				ctx->sa_wall_open = nullptr;
+			}
+			if (ctx->sa_wall_open) {
+				SPHX_HIP(hipMemsetAsync(ctx->sa_wall_open, 0, sizeof(uint32_t), (hipStream_t)stream));
+				a.openList = ctx->sa_wall_open;
+			}
+			rc = sphx_sa_wall_density_sum_moving(ctx, a, (hipStream_t)stream);
+			if (rc != SPHX_OK) return rc;
+			if (ctx->sa_wall_open && particleRangeEnd == numParticles) {
+				ctx->sa_wall_open_neibslist = neibsList; ctx->sa_wall_open_gen = ctx->sa_wall_gen;
+			}
+		} else
+			a.tileGuard = nullptr;      // (no list of wall particles: the walker is the whole pass, whatever the tiles left in FORCES.w)
+	}
 	sa_density_sum_kernel<true, true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_density_sum_kernel<open, moving>");
 	return SPHX_OK;

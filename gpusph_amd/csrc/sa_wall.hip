@@ -395,6 +395,13 @@ sa_density_sum_wall_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__re
 // the rows, and every call that moves elements (the Euler step of such a run, sphx_sa_update_normals) starts a new generation.
 // (Round 6: the one-thread kernel was 61 % of a step of the SAPaddleBox mirror at 4.3 M particles,
 // profiles/r06_sa_moving_kernel_stats.txt)
+// OPEN: ... together with open boundaries (sa_density_sum_kernel<true, true>, the option set of CompleteSaExample.cu).  The FLUID rows get what
+// sa_density_sum_wall_kernel<true> adds -- the flux of gamma through the open segments (against the element as it is at step n, as the
+// one-thread kernel has it), the virtual displacement of the open vertices, the list for the Brezzi diffusion -- and take NOTHING from the
+// stored grad gamma of step n: the row of a particle an open vertex released holds the vertex's gradient, and the sum the forces pass leaves
+// for runs with walls at rest belongs to a generation of rows that ends when the elements move; every element is evaluated at both states.
+// The vertex rows are integrated as without open boundaries.
+template<bool OPEN>
 __global__ void __launch_bounds__(SA_WALL_THREADS)
 sa_density_sum_wall_moving_kernel(DevParams p, SaDensitySumArgs a, const uint32_t *__restrict__ wall)
 {
@@ -402,16 +409,19 @@ sa_density_sum_wall_moving_kernel(DevParams p, SaDensitySumArgs a, const uint32_
 	SA_WALL_LOOP(wall) {
 		const uint32_t index = __builtin_amdgcn_readfirstlane(wall[1u + w]);
 		if (index >= a.numParticles) continue;
+		const bool openFluid = OPEN && PART_TYPE(a.info[index]) == PT_FLUID;      // (wave-uniform)
 		const float4 posN = a.oldPos[index], posNp1 = a.pos[index];
 		const int3 gridPos = grid_pos_from_hash(p, a.hash[index] & CELLTYPE_BITMASK);
 		const float dx = posNp1.x - posN.x, dy = posNp1.y - posN.y, dz = posNp1.z - posN.z;
 		const float inv = 1.0f/p.slength;
 		float gx = 0.0f, gy = 0.0f, gz = 0.0f, dotSum = 0.0f;
 		float mx = 0.0f, my = 0.0f, mz = 0.0f;      // grad gamma_as(n) of the elements that moved
+		float flux = 0.0f;
+		bool seesOpen = false;
 		// a particle that did not move (a vertex of a wall at rest) none of whose elements moved: the sums are those of the previous
 		// step, to the bit -- the same elements seen from the same place by this same kernel (after a rebuild or the initialisation:
 		// the same numbers by another route) -- and are taken from there.  Most vertex rows of a run are of this kind
-		if (dx == 0.0f && dy == 0.0f && dz == 0.0f) {
+		if (dx == 0.0f && dy == 0.0f && dz == 0.0f && !openFluid) {
 			bool moved = false;
 			int carry0 = 0;
 			bool more0 = true;
@@ -457,26 +467,68 @@ sa_density_sum_wall_moving_kernel(DevParams p, SaDensitySumArgs a, const uint32_
 				__float_as_uint(nN.y) == __float_as_uint(nNp1.y) && __float_as_uint(nN.z) == __float_as_uint(nNp1.z);
 			WallTri tri;
 			V3 gN = v3(0.0f, 0.0f, 0.0f);
-			if (!sameEl) {
+			const bool both = !sameEl || openFluid;      // evaluated at step n as well
+			if (both) {
 				wall_tri_setup(tri, ns, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
-				gN = ns*(wall_grad_gamma_flat(tri, qN)/p.slength);
+				const float ggamN = wall_grad_gamma_flat(tri, qN)/p.slength;
+				gN = ns*ggamN;
+				if (OPEN && openFluid && SA_IS_OPEN(a.info[j])) {      // the flux of gamma through an open segment, wholly at step n
+					seesOpen = true;
+					const float4 ev = a.oldEulerVel[j], v = a.oldVel[j];
+					const V3 drift = v3(a.dt*(ev.x - v.x), a.dt*(ev.y - v.y), a.dt*(ev.z - v.z));
+					const float ggamMoved = wall_grad_gamma_flat(tri, qN + drift*inv)/p.slength;
+					flux += 0.5f*dot(drift, ns)*(ggamMoved + ggamN);
+				}
 			}
 			wall_tri_setup(tri, nsNew, a.vertPos[0][j], a.vertPos[1][j], a.vertPos[2][j], p.slength);
 			const float ggamNp1 = wall_grad_gamma_flat(tri, qNp1)/p.slength;
 			if (keep) wall_cache_put(a.wc, w, (uint32_t)s0 + lane, ggamNp1);      // for the forces pass at this state (fluid rows)
 			const V3 gNp1 = nsNew*ggamNp1;
-			// an element at rest: its step-(n+1) half here, its step-n half from the stored sum below; one that moved: both halves
-			dotSum += sameEl ? 0.5f*dot(gNp1, qNp1 - qN) : 0.5f*dot(gN + gNp1, qNp1 - qN);
+			// an element at rest: its step-(n+1) half here, its step-n half from the stored sum below; one evaluated at both states: both halves
+			dotSum += both ? 0.5f*dot(gN + gNp1, qNp1 - qN) : 0.5f*dot(gNp1, qNp1 - qN);
 			mx += gN.x; my += gN.y; mz += gN.z;
 			gx += gNp1.x; gy += gNp1.y; gz += gNp1.z;
+		}
+		float corr = 0.0f;
+		bool anyOpenV = false;
+		if (OPEN && openFluid) {      // the open vertices among the neighbours (see sa_density_sum_wall_kernel<true>)
+			int carry = 0;
+			bool moreV = true;
+			for (int s0 = 0; moreV; s0 += 64) {
+				const WaveEntry e = wave_entries<WAVE_SECTION_VERTEX>(p, a.neibsList, a.cellStart, index, posN, gridPos, s0, lane, carry, moreV);
+				const uint32_t j = e.j;
+				const bool openV = e.live && SA_IS_OPEN(a.info[j]);
+				if (!__builtin_amdgcn_ballot_w64(openV)) continue;
+				const float4 nN = a.oldPos[j];
+				if (!openV || !is_active_w(nN.w)) continue;
+				anyOpenV = true;
+				const float rx = e.ox - nN.x, ry = e.oy - nN.y, rz = e.oz - nN.z;
+				const float rN = sqrtf(rx*rx + ry*ry + rz*rz);
+				corr += nN.w*kernel_W<SPHX_WENDLAND>(p, rN);
+				const float4 ev = a.oldEulerVel[j], v = a.oldVel[j];
+				const float ex = rx + a.dt*(ev.x - v.x), ey = ry + a.dt*(ev.y - v.y), ez = rz + a.dt*(ev.z - v.z);
+				const float moved = sqrtf(ex*ex + ey*ey + ez*ez);
+				if (moved < p.influenceradius) corr -= nN.w*kernel_W<SPHX_WENDLAND>(p, moved);
+			}
+			anyOpenV = __builtin_amdgcn_ballot_w64(anyOpenV) != 0;
+			if (anyOpenV) corr = wave_sum(corr);
+			flux = wave_sum(flux);
 		}
 		mx = wave_sum(mx); my = wave_sum(my); mz = wave_sum(mz);
 		gx = wave_sum(gx); gy = wave_sum(gy); gz = wave_sum(gz); dotSum = wave_sum(dotSum);
 		if (lane == 0) {
 			const float4 gGamN = a.oldGGam[index];
-			const float dotRest = ((gGamN.x - mx)*dx + (gGamN.y - my)*dy + (gGamN.z - mz)*dz)*inv;      // the elements at rest at step n
+			// the elements at rest at step n (with open boundaries a fluid row has none of that kind: all were evaluated)
+			const float dotRest = openFluid ? 0.0f : ((gGamN.x - mx)*dx + (gGamN.y - my)*dy + (gGamN.z - mz)*dz)*inv;
 			a.newGGam[index] = make_float4(gx, gy, gz, dotSum + 0.5f*dotRest);
 			if (keep) wall_cache_seal(a.wc, w, posNp1, complete);
+			if (OPEN && openFluid) {
+				a.newVel[index].w = flux;
+				if (anyOpenV) a.forces[index].w += corr;
+			}
+		}
+		if (OPEN && openFluid && a.openList && __builtin_amdgcn_ballot_w64(seesOpen)) {
+			if (lane == 0) a.openList[1u + atomicAdd(&a.openList[0], 1u)] = index;
 		}
 	}
 }
@@ -586,12 +638,14 @@ int sphx_sa_wall_density_sum(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream
 }
 int sphx_sa_wall_density_sum_moving(sphx_ctx *ctx, const SaDensitySumArgs &a, hipStream_t st)
 {
-	sa_density_sum_wall_moving_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	if (a.oldEulerVel) sa_density_sum_wall_moving_kernel<true><<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
+	else sa_density_sum_wall_moving_kernel<false><<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, a, ctx->sa_wall);
 	SPHX_LAUNCH_CHECK("sa_density_sum_wall_moving_kernel");
-	if (a.wallDone & 2) {      // the vertex rows (row numbers of another list: nothing kept)
+	if (a.wallDone & 2) {      // the vertex rows (row numbers of another list: nothing kept; no open terms: they are the fluid rows')
 		SaDensitySumArgs av = a;
 		av.wc.values = nullptr; av.wc.tag = nullptr; av.wc.capacity = 0; av.wc.gen = 0;
-		sa_density_sum_wall_moving_kernel<<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, av, ctx->sa_wall_vert);
+		av.openList = nullptr;
+		sa_density_sum_wall_moving_kernel<false><<<sa_wall_grid(ctx), SA_WALL_THREADS, 0, st>>>(ctx->dev, av, ctx->sa_wall_vert);
 		SPHX_LAUNCH_CHECK("sa_density_sum_wall_moving_kernel<vertices>");
 	}
 	return SPHX_OK;
