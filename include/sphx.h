@@ -363,11 +363,14 @@ int sphx_sa_vertex_bc_io(sphx_ctx *ctx, void *vel, const void *pos, void *newPos
 	uint32_t numParticles, uint32_t particleRangeEnd, uint32_t totParticles, float deltap, float dt, int step,
 	uint32_t numOpenVertices, void *stream);
 /* density_sum and the forces of SA_BOUNDARY with open boundaries (src/cuda/density_sum.cu + density_sum_kernel.cu:119-140,206-250,
- * 374-420,606-655; src/cuda/forces.cu:751-795 + forces_kernel.def:1485-1497,2494-2507,2703-2708; laminar or inviscid, Wendland,
- * one thread per particle over the list: the walkers of sphx_sa_density_sum / sphx_forces_basicstep_sa with their open-boundary
- * terms; the tiled window does not know those terms and is not built for a context with ENABLE_INLET_OUTLET).
+ * 374-420,606-655; src/cuda/forces.cu:751-795 + forces_kernel.def:1485-1497,2494-2507,2703-2708; laminar or inviscid, Wendland).
+ * Since round 6 the particle <- particle sums go through the tiled window as for solid walls and the open faces' terms ride with the
+ * one-element-per-lane kernels of the boundary elements; the one-thread walkers of sphx_sa_density_sum /
+ * sphx_forces_basicstep_sa with their open-boundary terms stay as the stand-by (no tiling, no list of wall particles).
  * sphx_sa_density_sum_io: sphx_sa_density_sum with the open boundaries' terms; oldEulerVel = BUFFER_EULERVEL of step n; dt = the
- *   integration interval of the Euler step just taken.  forces.w receives the volumic sums, as in sphx_sa_density_sum.
+ *   integration interval of the Euler step just taken.  forces.w receives the volumic sums, as in sphx_sa_density_sum.  newVel and
+ *   oldVel are two buffers in the reference's call (write list / read list); if they are one, the stand-by walker is the whole pass
+ *   (the fast path hands the flux of gamma through the open segments over in newVel.w before the new density is written there).
  * sphx_forces_basicstep_sa_io: sphx_forces_basicstep_sa (SPHX_SIMULATE) with BUFFER_EULERVEL in the viscous terms and the gamma CFL;
  *   cfl / cflGamma as there (cflGamma: one value per particle, then one per block from round_up(numParticles, 4) on) */
 int sphx_sa_density_sum_io(sphx_ctx *ctx, void *newVel, void *newGGam, void *forces, const void *oldPos, const void *newPos,
