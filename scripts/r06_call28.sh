@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 6, GPU call 28: smoke and the whole GPU suite on the final tree, the default bench line (with the CPU baseline) and the SA mirrors
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+OUT=gpurun_out/r06_call28
+mkdir -p $OUT
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.txt 2>&1; echo "smoke rc=$?" >> $OUT/smoke.txt
+tail -2 $OUT/smoke.txt
+timeout 2700 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.txt 2>&1
+echo "pytest rc=$?" >> $OUT/pytest_gpu.txt
+grep -E "passed|failed" $OUT/pytest_gpu.txt | tail -2
+python bench.py > $OUT/bench32M.json 2> $OUT/bench32M.err; cat $OUT/bench32M.json
+for c in SABox SAPaddleBox SAChannelIO SAChannelIOFlap; do
+  steps=20; case $c in SAChannelIO*) steps=10;; esac
+  timeout 600 python scripts/time_sa_case_one.py $c 0.008 $steps 2>&1 | grep "ms/step"
+done | tee $OUT/sa_mirrors.txt
