@@ -40,6 +40,10 @@ struct SaArgs {
 	float4 *eulerVel;
 	float deltap;
 	int openFaces;                // a run with open boundaries: their segments and (non-corner) vertices are left to sa_io.hip
+	// [0] = number of, [1..] = the particles of the pass's type (sphx_ctx::sa_rows_bound / sa_rows_vert): thread t takes row t instead of
+	// particle t, so that the lanes of a wave all have a list to walk (boundary elements and vertices are a few per cent of the particles,
+	// a few lanes of every wave next to a wall); NULL: one thread per particle
+	const uint32_t *rows;
 };
 // the solid-wall rows of the two passes in a run with open boundaries (sa_io.hip launches its own kernels for the open faces)
 int sphx_sa_solid_rows_launch(sphx_ctx *ctx, const SaArgs &a, bool vertexPass, hipStream_t st);

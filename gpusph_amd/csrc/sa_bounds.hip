@@ -62,7 +62,11 @@ template<int KERNEL, bool KEPS>
 __global__ void __launch_bounds__(128)
 sa_segment_bc_kernel(DevParams p, SaArgs a)
 {
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (a.rows) {      // thread t: the t-th boundary element
+		if (index >= a.rows[0]) return;
+		index = a.rows[1u + index];
+	}
 	if (index >= a.numParticles) return;
 	const particleinfo info = a.info[index];
 	if (!IS_BOUNDARY(info)) return;
@@ -142,7 +146,11 @@ template<int KERNEL, bool KEPS>
 __global__ void __launch_bounds__(128)
 sa_vertex_bc_kernel(DevParams p, SaArgs a)
 {
-	const uint32_t index = blockIdx.x*128 + threadIdx.x;
+	uint32_t index = blockIdx.x*128 + threadIdx.x;
+	if (a.rows) {      // thread t: the t-th vertex particle
+		if (index >= a.rows[0]) return;
+		index = a.rows[1u + index];
+	}
 	if (index >= a.numParticles) return;
 	const particleinfo info = a.info[index];
 	if (PART_TYPE(info) != PT_VERTEX) return;
@@ -842,6 +850,7 @@ static int sa_segment_bc_impl(sphx_ctx *ctx, void *vel, void *gGam, float *tke, 
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
 	a.step = (step == -1) ? 0 : step;         // "step -1 is the same as step 0", boundary_conditions.cu:177-180
 	a.repack = (run_mode == SPHX_REPACK);
+	if (ctx->sa_wall_neibslist == neibsList && particleRangeEnd <= ctx->sa_rows_range) a.rows = ctx->sa_rows_bound;
 	if (tke) {
 		a.tke = tke; a.eps = eps; a.eulerVel = (float4*)eulerVel; a.deltap = deltap;
 		sa_segment_bc_kernel<SPHX_WENDLAND, true><<<div_up_u(particleRangeEnd, 128), 128, 0, (hipStream_t)stream>>>(ctx->dev, a);
@@ -891,6 +900,7 @@ static int sa_vertex_bc_impl(sphx_ctx *ctx, void *vel, const void *gGam, float *
 	SaArgs a = {};
 	a.vel = (float4*)vel; a.gGam = (float4*)const_cast<void*>(gGam); a.pos = (const float4*)pos; a.info = (const particleinfo*)info;
 	a.hash = hash; a.cellStart = cellStart; a.neibsList = neibsList; a.numParticles = particleRangeEnd;
+	if (ctx->sa_wall_neibslist == neibsList && particleRangeEnd <= ctx->sa_rows_range) a.rows = ctx->sa_rows_vert;
 	if (tke) {
 		a.tke = tke; a.eps = eps; a.eulerVel = (float4*)eulerVel;
 		a.vertices = (const uint4*)vertices; a.boundElement = (float4*)const_cast<void*>(boundElements);
@@ -1464,8 +1474,10 @@ static int sa_open_check(sphx_ctx *ctx, const char *who)
 	return SPHX_OK;
 }
 
-int sphx_sa_solid_rows_launch(sphx_ctx *ctx, const SaArgs &a, bool vertexPass, hipStream_t st)
+int sphx_sa_solid_rows_launch(sphx_ctx *ctx, const SaArgs &a_, bool vertexPass, hipStream_t st)
 {
+	SaArgs a = a_;
+	if (ctx->sa_wall_neibslist == a.neibsList && a.numParticles <= ctx->sa_rows_range) a.rows = vertexPass ? ctx->sa_rows_vert : ctx->sa_rows_bound;
 	if (vertexPass) sa_vertex_bc_kernel<SPHX_WENDLAND, false><<<div_up_u(a.numParticles, 128), 128, 0, st>>>(ctx->dev, a);
 	else sa_segment_bc_kernel<SPHX_WENDLAND, false><<<div_up_u(a.numParticles, 128), 128, 0, st>>>(ctx->dev, a);
 	SPHX_LAUNCH_CHECK("sa_segment_bc_kernel / sa_vertex_bc_kernel (solid rows of a run with open boundaries)");

@@ -69,7 +69,7 @@ static void free_scratch(sphx_ctx *ctx)
 	void *ptrs[] = { ctx->bin_count, ctx->bin_start, ctx->scan_partials, ctx->slot,
 		ctx->tmp_hash, ctx->tmp_index, ctx->tmp_info, ctx->eos_aux, ctx->tau_pack, ctx->tiles, ctx->cell_end_copy, ctx->cell_fluid_end, ctx->tile_cols,
 		ctx->tile_list, ctx->tile_runs, ctx->tile_rows, ctx->tile_lane_rec, ctx->tile_lane_index, ctx->neib_counts,
-		ctx->sa_wall, ctx->sa_wall_vert, ctx->sa_wall_cache, ctx->sa_wall_tag, ctx->sa_wall_gsum, ctx->sa_wall_open };
+		ctx->sa_wall, ctx->sa_wall_vert, ctx->sa_wall_cache, ctx->sa_wall_tag, ctx->sa_wall_gsum, ctx->sa_wall_open, ctx->sa_rows_bound, ctx->sa_rows_vert };
 	for (void *p : ptrs) if (p) (void)hipFree(p);
 	ctx->bin_count = ctx->bin_start = ctx->scan_partials = ctx->slot = nullptr;
 	ctx->tmp_hash = ctx->tmp_index = nullptr;
@@ -77,6 +77,7 @@ static void free_scratch(sphx_ctx *ctx)
 	ctx->eos_aux = nullptr; ctx->tau_pack = nullptr;
 	ctx->eos_tag_vel = nullptr; ctx->eos_tag_n = 0; ctx->eos_armed = false;
 	ctx->sa_wall = nullptr; ctx->sa_wall_vert = nullptr; ctx->sa_wall_neibslist = nullptr;
+	ctx->sa_rows_bound = nullptr; ctx->sa_rows_vert = nullptr; ctx->sa_rows_range = 0;
 	ctx->sa_wall_cache = nullptr; ctx->sa_wall_tag = nullptr; ctx->sa_wall_gsum = nullptr; ctx->sa_wall_open = nullptr; ctx->sa_wall_open_neibslist = nullptr; ctx->sa_wall_capacity = 0;
 	ctx->tile_list = nullptr; ctx->tile_runs = nullptr; ctx->tile_rows = nullptr; ctx->tile_lane_rec = nullptr; ctx->tile_lane_index = nullptr;
 	ctx->tile_list_batches = ctx->tile_lane_cap = 0; ctx->neib_counts = nullptr;

@@ -215,6 +215,10 @@ struct sphx_ctx {
 	// ... and, of a run with ENABLE_MOVING_BODIES, the VERTEX particles whose list has boundary elements (same layout, same list):
 	// the density summation integrates their gamma by the same boundary terms (sa_density_sum_wall_moving_kernel)
 	uint32_t   *sa_wall_vert;
+	// ... and ALL boundary elements / ALL vertex particles below the particleRangeEnd of that build (sa_rows_range), same layout: the two
+	// boundary-condition passes take one thread per ROW of these instead of one per particle (sa_segment_bc_kernel, sa_vertex_bc_kernel)
+	uint32_t   *sa_rows_bound, *sa_rows_vert;
+	uint32_t    sa_rows_range;
 	// |grad gamma_as| of every (wall particle, entry of its boundary section) as the density summation / gamma quadrature of a
 	// step evaluates it at the new positions, kept for the forces pass that follows at those very positions (sa_wall.hip):
 	// [wall particle][SA_WALL_CACHE_ENTRIES] floats + a tag per wall particle {position bits, list generation}
