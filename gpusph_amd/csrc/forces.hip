@@ -2156,9 +2156,37 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 	}
 	const int wr = (int)(tid/TILE_KW), wcol = (int)(tid - (tid/TILE_KW)*TILE_KW);   // my window cell (tid < 256)
 	const size_t stride = (size_t)p.stride;
+	// Everything a tile's setup reads from memory -- its descriptor, the window's cells (section 1), the list lengths / hash / info of the
+	// thread's home particle (sections 2 and 5) -- depends on the tile's number alone, and the setup is a chain of barriers with nothing to
+	// hide a round trip behind (~8 us per tile, half the kernel).  So it is asked for one tile ahead (the descriptor two ahead): while a
+	// tile's lists are translated the next tile's rows arrive.  (Round 6: 4.61 -> 4.28 ms at 32 M with the loads at the top of the same
+	// tile's setup, profiles/r06_tile_lists_prefetch_ab.txt.)
+	struct TilePre { uint32_t index, cnt, hash; particleinfo info; uint32_t wStart, wEnd; };
+	auto desc_of = [&](uint32_t t) -> uint32_t { return t < numTiles ? tiles[(size_t)TILE_DESC*t + (lane & (uint32_t)(TILE_DESC - 1))] : 0u; };
+	auto ask = [&](uint32_t dd, bool real, TilePre &q) {
+		q.index = 0u; q.cnt = 0u; q.hash = 0u; q.info = particleinfo{0, 0, 0, 0}; q.wStart = CELL_EMPTY; q.wEnd = 0u;
+		if (!real) return;
+		const uint32_t Pn = (uint32_t)(__builtin_amdgcn_readlane((int)dd, 8) + __builtin_amdgcn_readlane((int)dd, 9) +
+			__builtin_amdgcn_readlane((int)dd, 10) + __builtin_amdgcn_readlane((int)dd, 11));
+		q.index = tile_home(dd, tid < Pn ? tid : 0u).index;
+		q.cnt = neibCounts[q.index]; q.hash = hash[q.index]; q.info = info[q.index];
+		if (tid < TILE_WROWS*TILE_KW) {
+			const uint32_t h = window_cell_hash(p, __builtin_amdgcn_readlane((int)dd, 0), __builtin_amdgcn_readlane((int)dd, 1),
+				__builtin_amdgcn_readlane((int)dd, 2), __builtin_amdgcn_readlane((int)dd, 3), wr, wcol);
+			if (h != 0xFFFFFFFFu) { q.wStart = cellStart[h]; q.wEnd = cellEnd[h]; }
+		}
+	};
+	uint32_t dAhead = desc_of(blockIdx.x);
+	TilePre ahead;
+	ask(dAhead, blockIdx.x < numTiles, ahead);
+	uint32_t dAhead2 = desc_of(blockIdx.x + gridDim.x);
 	for (uint32_t tile = blockIdx.x; tile < numTiles; tile += gridDim.x) {
 		__syncthreads();   // the previous tile's tables are no longer read
-		const uint32_t d = tiles[(size_t)TILE_DESC*tile + (lane & (uint32_t)(TILE_DESC - 1))];      // the descriptor, a word per lane
+		const uint32_t d = dAhead;      // the descriptor, a word per lane
+		const TilePre pre = ahead;
+		dAhead = dAhead2;
+		ask(dAhead, tile + gridDim.x < numTiles, ahead);
+		dAhead2 = desc_of(tile + 2u*gridDim.x);
 		const int dg2 = __builtin_amdgcn_readlane((int)d, 0), dg3 = __builtin_amdgcn_readlane((int)d, 1);
 		const int ca = __builtin_amdgcn_readlane((int)d, 2), dnc = __builtin_amdgcn_readlane((int)d, 3);
 		const uint32_t P = (uint32_t)(__builtin_amdgcn_readlane((int)d, 8) + __builtin_amdgcn_readlane((int)d, 9) +
@@ -2175,10 +2203,12 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 			if (last < homeFrom || last >= homeTo) continue;
 		}
 		const uint32_t C = (P + 63u)/64u;
+		const uint32_t preCnt = pre.cnt, preHash = pre.hash;
+		const particleinfo preInfo = pre.info;
 		for (uint32_t e = tid; e < TILE_CHUNKS*TL_BINS; e += TL_THREADS) (&sHist[0][0])[e] = 0;
 		if (tid < TILE_WROWS*TILE_KW) {
-			uint32_t wStart = 0, wCnt = 0;
-			window_cell(p, cellStart, cellEnd, dg2, dg3, ca, dnc, wr, wcol, wStart, wCnt);
+			uint32_t wStart = 0, wCnt = 0;      // window_cell, asked for a tile ahead
+			if (pre.wStart != CELL_EMPTY) { wStart = pre.wStart; wCnt = pre.wEnd - pre.wStart; }
 			uint32_t incl = wCnt;
 			uint32_t lo = wCnt ? wStart : 0xFFFFFFFFu;
 			uint32_t hi = wCnt ? wStart + wCnt : 0u;
@@ -2236,7 +2266,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 		uint32_t F = 0, B = 0;
 		const bool inHome = tid < P;
 		if (inHome) {
-			const uint32_t cnt = neibCounts[tile_home(d, tid).index];
+			const uint32_t cnt = preCnt;
 			F = cnt & 0xFFFFu; B = cnt >> 16;
 			// A list that overflowed while it was built (build_neibs_kernel: nf >= neibboundpos, nf + nb >= neibboundpos, with
 			// SA_BOUNDARY nv >= neiblistsize - neibboundpos - 1) keeps COUNTING its entries but stops writing them: its counts
@@ -2387,7 +2417,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 		const uint32_t ch = min(myLane >> 6, (uint32_t)(TILE_CHUNKS - 1)), ln = myLane & 63u;
 		const TileHome h = tile_home(d, isHome ? tid : 0u);
 		const uint32_t index = h.index;
-		const int3 gp = grid_pos_from_hash(p, hash[index] & CELLTYPE_BITMASK);
+		const int3 gp = grid_pos_from_hash(p, preHash & CELLTYPE_BITMASK);
 		const int myG1 = (p.c1 == 0) ? gp.x : (p.c1 == 1) ? gp.y : gp.z;
 		const int myCol = min(max(myG1 - ca, 0), TILE_MAXCELLS - 1);
 		const uint16_t *myCB = sCB + (h.hrow*TILE_MAXCELLS + myCol)*27;
@@ -2398,7 +2428,7 @@ tile_lists_kernel(DevParams p, const neibdata *__restrict__ list, const uint32_t
 					const int wc = (5 + (h.hrow & 1) + 4*(h.hrow >> 1))*TILE_KW + myCol + 1;
 					const uint32_t slot = 1u + sCellBase[wc] + (index - sCellStart[wc]);
 					if (slot > 4095u) overflow = true;
-					const particleinfo pi = info[index];
+					const particleinfo pi = preInfo;
 					const uint32_t flags = PART_TYPE(pi) | (HAS_COMPUTE_FORCE(pi) ? LANE_COMPUTE_FORCE : 0u) | ((FLUID_NUM(pi) & 3u) << LANE_FLUID_SHIFT) | LANE_VALID;
 					rec = ((slot << 4) & 0xFFFFu) | (flags << 16);
 					idx = index;
